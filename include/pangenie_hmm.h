@@ -1,0 +1,170 @@
+/*
+ * pangenie_hmm.h — C ABI of the MI355X-native PanGenie genotyping hot path.
+ *
+ * This is the drop-in boundary: everything the reference does inside
+ *     HMM::HMM(...)                      (reference src/hmm.hpp:38, src/hmm.cpp:25-63)
+ * for run_genotyping=true — ColumnIndexer (src/columnindexer.cpp:8-33),
+ * EmissionProbabilityComputer (src/emissionprobabilitycomputer.cpp:9-53),
+ * TransitionProbabilityComputer (src/transitionprobabilitycomputer.cpp:8-19),
+ * forward/backward columns + posterior accumulation (src/hmm.cpp:76-110, 175-405) —
+ * happens behind pg_hmm_genotype_contig() / pg_job_run() on the GPU.
+ *
+ * Plain C: pointers + sizes, no STL, no exceptions, no torch types.  All host
+ * pointers are caller-owned and only read during the call (same ownership rule
+ * as the reference's borrowed unique_kmers / probabilities / only_paths
+ * pointers, src/hmm.cpp:25-31).  Error convention: 0 = ok, negative = error
+ * with a message in `err` (the C++ adapter rethrows std::runtime_error, which
+ * is what the reference throws, e.g. src/columnindexer.cpp:18-22).
+ *
+ * Numeric contract: the device computes in fp64 and returns every unnormalised
+ * genotype likelihood as  lik * 2^lik_exp ; the host rebuilds the reference's
+ * 80-bit `long double` value with ldexpl() and does normalisation / GT / GQ in
+ * long double (reference src/genotypingresult.cpp:118-210).
+ */
+#ifndef PANGENIE_HMM_H
+#define PANGENIE_HMM_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PG_OK 0
+#define PG_ERR_INVALID (-1)     /* bad argument / malformed batch            */
+#define PG_ERR_NO_PATHS (-2)    /* "column is not covered by any paths"      */
+#define PG_ERR_UNSUPPORTED (-3) /* feature not available on the device path  */
+#define PG_ERR_DEVICE (-4)      /* HIP runtime error / no GPU                */
+#define PG_ERR_NOMEM (-5)
+
+/* ------------------------------------------------------------------ *
+ *  Input: one (contig, path-subset) chain, flattened to SoA.
+ *  Replaces std::vector<std::shared_ptr<UniqueKmers>>* + only_paths
+ *  (reference src/uniquekmers.hpp:22-69, src/hmm.hpp:38).
+ * ------------------------------------------------------------------ */
+typedef struct pg_contig_batch {
+    uint32_t n_variants; /* V : unique_kmers->size()                                        */
+    uint32_t n_paths;    /* H : number of SELECTED paths (ColumnIndexer::nr_paths,          */
+                         /*     columnindexer.cpp:23,51-53); states per column = H*H        */
+    const uint64_t* variant_pos;  /* [V]   UniqueKmers::get_variant_position()              */
+    const uint16_t* coverage;     /* [V]   UniqueKmers::get_coverage() (float -> u16)       */
+    const uint32_t* kmer_off;     /* [V+1] prefix offsets into kmer_count                   */
+    const uint16_t* kmer_count;   /* [sumK] UniqueKmers::get_readcount_of(k)                */
+    const uint32_t* allele_off;   /* [V+1] prefix offsets into the allele_* arrays          */
+    const uint16_t* allele_id;    /* [sumA] get_allele_ids(): ALL alleles of the object,    */
+                                  /*        ascending (std::map order)                      */
+    const uint8_t*  allele_flags; /* [sumA] bit0 = is_undefined_allele(a)                   */
+    const uint16_t* allele_kmer_off;  /* [sumA] KmerPath::offset  (kmerpath.hpp:33)         */
+    const uint32_t* allele_kmer_mask; /* [sumA] KmerPath::kmers   (16-bit masks widened):   */
+                                  /* kmer k on allele a <=> 0<=k-off<32 && mask>>(k-off)&1  */
+                                  /* (kmerpath.cpp:33-48)                                   */
+    const uint16_t* path_allele;  /* [V*H] allele id carried by selected path p at variant  */
+                                  /* v: UniqueKmers::get_allele(paths[p])                   */
+} pg_contig_batch;
+
+/* HMM constructor arguments (reference src/hmm.hpp:38, call site src/commands.cpp:160). */
+typedef struct pg_hmm_params {
+    long double effective_N; /* default 25000.0L; production 1e-5 (pangenie-genotype.cpp:33-45) */
+    double recombrate;       /* default 1.26                                                     */
+    int32_t uniform;         /* uniform transition probabilities                                 */
+    int32_t run_genotyping;  /* forward-backward                                                 */
+    int32_t run_phasing;     /* Viterbi: not on the device path -> PG_ERR_UNSUPPORTED            */
+    int32_t reserved;
+} pg_hmm_params;
+
+/* ------------------------------------------------------------------ *
+ *  Output, caller-allocated.  Genotype bins of variant v live at
+ *  lik[geno_off[v] .. geno_off[v+1]) with geno_off from
+ *  pg_hmm_geno_offsets(): bin index of allele SLOTS (a<=b) of an A-allele
+ *  variant is  a*A - a*(a-1)/2 + (b-a)  (lexicographic (a,b), i.e. the
+ *  iteration order of the reference's std::map<pair<u16,u16>,long double>,
+ *  src/genotypingresult.hpp:84).  A bin is a key of the reference's map iff
+ *  kept[v] && allele_present[a] && allele_present[b] (src/hmm.cpp:368).
+ * ------------------------------------------------------------------ */
+typedef struct pg_contig_result {
+    double*   lik;            /* [geno_off[V]] unnormalised likelihood mantissa part          */
+    int32_t*  lik_exp;        /* [V] power-of-two exponent: L = lik * 2^lik_exp               */
+    uint8_t*  kept;           /* [V] 1 = variant is an HMM column (columnindexer.cpp:24-31)   */
+    uint8_t*  allele_present; /* [sumA] 1 = allele slot occurs on a selected path             */
+    uint16_t* n_kmers;        /* [V] GenotypingResult::set_unique_kmers (hmm.cpp:106-109)     */
+    uint16_t* coverage;       /* [V] GenotypingResult::set_coverage                           */
+    uint32_t  n_columns;      /* C = ColumnIndexer::size()                                    */
+    uint32_t  reserved;
+} pg_contig_result;
+
+/* geno_off[V+1] from allele_off: geno_off[v+1]-geno_off[v] = A_v*(A_v+1)/2. */
+int pg_hmm_geno_offsets(const pg_contig_batch* batch, uint64_t* geno_off);
+
+/* ------------------------------------------------------------------ *
+ *  ProbabilityTable (reference src/probabilitytable.hpp:13-29).  Built on the
+ *  host in long double exactly as the reference does before the HMM runs
+ *  (src/commands.cpp:846); the device receives it as (mantissa, exponent)
+ *  pairs.  Out-of-range (coverage,count) pairs are evaluated on the fly
+ *  (src/probabilitytable.cpp:47-53) — on the device in fp64.
+ * ------------------------------------------------------------------ */
+typedef struct pg_table pg_table;
+pg_table* pg_table_create(uint16_t cov_min, uint16_t cov_max, uint16_t count_max,
+                          long double regularization);            /* probabilitytable.cpp:28-45 */
+pg_table* pg_table_create_default(void);                           /* probabilitytable.cpp:21-26 */
+int  pg_table_modify(pg_table* t, uint16_t coverage, uint16_t count,
+                     long double p0, long double p1, long double p2); /* :67-73, test hook */
+int  pg_table_get(const pg_table* t, uint16_t coverage, uint16_t count,
+                  long double out3[3]);                             /* :47-53 */
+void pg_table_destroy(pg_table* t);
+
+/* ------------------------------------------------------------------ *
+ *  One-shot blocking call = the body of HMM::HMM for one (contig, subset).
+ *  Thread-safe; uses its own stream on `device`.
+ * ------------------------------------------------------------------ */
+int pg_hmm_device_count(void);
+const char* pg_hmm_version(void);
+int pg_hmm_genotype_contig(const pg_contig_batch* batch, const pg_table* table,
+                           const pg_hmm_params* params, int device,
+                           pg_contig_result* out, char* err, size_t errlen);
+
+/* ------------------------------------------------------------------ *
+ *  Resident job API: upload once, run many times (benchmarks, pipelines,
+ *  multi-contig batches that share one launch).  All contigs of a job run
+ *  concurrently (one persistent workgroup per chain direction).
+ * ------------------------------------------------------------------ */
+typedef struct pg_job pg_job;
+pg_job* pg_job_create(int device, uint32_t n_contigs, const pg_contig_batch* batches,
+                      const pg_table* table, const pg_hmm_params* params,
+                      char* err, size_t errlen);
+/* Runs the whole device path (prep -> forward/backward sweep -> bins) and
+ * synchronises.  `stream` = hipStream_t to launch on, NULL = the job's own. */
+int  pg_job_run(pg_job* job, void* stream, char* err, size_t errlen);
+/* Copies contig c's results to host buffers. */
+int  pg_job_fetch(pg_job* job, uint32_t contig, pg_contig_result* out, char* err, size_t errlen);
+/* Device-resident result buffers of contig c (for an RCCL gather without a host hop). */
+int  pg_job_device_results(pg_job* job, uint32_t contig, void** d_lik, uint64_t* n_lik,
+                           void** d_lik_exp, uint64_t* n_variants);
+/* Per-kernel-class elapsed milliseconds of the LAST pg_job_run, measured with
+ * hipEvents on the launch stream.  Order given by pg_job_kernel_name(). */
+#define PG_N_KERNEL_CLASSES 6
+int  pg_job_kernel_ms(const pg_job* job, double ms[PG_N_KERNEL_CLASSES]);
+const char* pg_job_kernel_name(int cls);
+/* Bytes of device memory held by the job. */
+uint64_t pg_job_device_bytes(const pg_job* job);
+void pg_job_destroy(pg_job* job);
+
+/* ------------------------------------------------------------------ *
+ *  Unit-level entry points (device), mirroring the reference classes the
+ *  reference's own unit tests exercise.
+ * ------------------------------------------------------------------ */
+/* EmissionProbabilityComputer (emissionprobabilitycomputer.cpp:9-34): A x A table over ALL
+ * allele slots of variant `v` (row-major, slot order), after the all_zeros rule. */
+int pg_emission_table(const pg_contig_batch* batch, const pg_table* table, uint32_t v,
+                      int device, long double* out_AxA, int32_t* all_zeros,
+                      char* err, size_t errlen);
+/* TransitionProbabilityComputer (transitionprobabilitycomputer.cpp:8-19):
+ * out3 = {no switch, one switch, two switches}. */
+int pg_transition_probs(uint64_t from_pos, uint64_t to_pos, double recombrate,
+                        uint32_t nr_paths, int uniform, long double effective_N,
+                        int device, double out3[3], char* err, size_t errlen);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PANGENIE_HMM_H */

@@ -1,0 +1,177 @@
+"""TEST INFRASTRUCTURE ONLY — ctypes wrapper of oracle/pg_oracle.c.
+
+Importable only from tests/, __graft_entry__.smoke() and bench.py's
+cpu_baseline leg.  Never imported by the pangenie_amd package.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import subprocess
+from pathlib import Path
+
+import numpy as np
+
+from pangenie_amd._lib import (PgContigBatch, PgHmmParams, i32p, ldp, u8p, u16p, u64p)
+
+HERE = Path(__file__).resolve().parent
+LIB_PATH = HERE / "_build" / "libpg_oracle.so"
+
+
+class PgoResult(C.Structure):
+    _fields_ = [
+        ("lik", ldp),
+        ("kept", u8p),
+        ("allele_present", u8p),
+        ("n_kmers", u16p),
+        ("coverage", u16p),
+        ("n_columns", C.c_uint32),
+        ("reserved", C.c_uint32),
+    ]
+
+
+_lib = None
+
+
+def build():
+    subprocess.run(["make", "-C", str(HERE)], check=True, capture_output=True)
+
+
+def load():
+    global _lib
+    if _lib is None:
+        if not LIB_PATH.exists():
+            build()
+        lib = C.CDLL(str(LIB_PATH))
+        ld = C.c_longdouble
+        lib.pgo_table_create.argtypes = [C.c_uint16, C.c_uint16, C.c_uint16, ld]
+        lib.pgo_table_create.restype = C.c_void_p
+        lib.pgo_table_create_default.argtypes = []
+        lib.pgo_table_create_default.restype = C.c_void_p
+        lib.pgo_table_modify.argtypes = [C.c_void_p, C.c_uint16, C.c_uint16, ld, ld, ld]
+        lib.pgo_table_modify.restype = C.c_int
+        lib.pgo_table_get.argtypes = [C.c_void_p, C.c_uint16, C.c_uint16, ldp]
+        lib.pgo_table_get.restype = None
+        lib.pgo_table_destroy.argtypes = [C.c_void_p]
+        lib.pgo_table_destroy.restype = None
+        lib.pgo_copynumber_regularized.argtypes = [ld, ld, ld, ld, ldp]
+        lib.pgo_copynumber_regularized.restype = None
+        lib.pgo_transition_probs.argtypes = [C.c_uint64, C.c_uint64, C.c_double, C.c_uint32,
+                                             C.c_int, ld, ldp]
+        lib.pgo_transition_probs.restype = None
+        lib.pgo_emission_table.argtypes = [C.POINTER(PgContigBatch), C.c_void_p, C.c_uint32,
+                                           ldp, i32p]
+        lib.pgo_emission_table.restype = C.c_int
+        lib.pgo_genotype_contig.argtypes = [C.POINTER(PgContigBatch), C.c_void_p,
+                                            C.POINTER(PgHmmParams), C.POINTER(PgoResult)]
+        lib.pgo_genotype_contig.restype = C.c_int
+        lib.pgo_geno_offsets.argtypes = [C.POINTER(PgContigBatch), u64p]
+        lib.pgo_geno_offsets.restype = None
+        _lib = lib
+    return _lib
+
+
+def _ld3():
+    return (C.c_longdouble * 3)()
+
+
+def _ld(x) -> C.c_longdouble:
+    """Python float / str / np.longdouble -> c_longdouble without a double round-trip."""
+    return C.c_longdouble(np.longdouble(x))
+
+
+class OracleTable:
+    """ProbabilityTable restatement (reference src/probabilitytable.cpp)."""
+
+    def __init__(self, cov_min=0, cov_max=0, count_max=0, regularization=0.0, default=False):
+        lib = load()
+        if default:
+            self.h = lib.pgo_table_create_default()
+        else:
+            self.h = lib.pgo_table_create(cov_min, cov_max, count_max, np.longdouble(regularization))
+        self.lib = lib
+
+    def modify(self, cov, count, p0, p1, p2):
+        rc = self.lib.pgo_table_modify(self.h, cov, count, np.longdouble(p0), np.longdouble(p1),
+                                       np.longdouble(p2))
+        if rc:
+            raise RuntimeError("ProbabilityTable::modify_probability: no precomputed values for these parameters.")
+
+    def get(self, cov, count) -> np.ndarray:
+        out = _ld3()
+        self.lib.pgo_table_get(self.h, cov, count, out)
+        return np.array([out[0], out[1], out[2]], dtype=np.longdouble)
+
+    def __del__(self):
+        try:
+            self.lib.pgo_table_destroy(self.h)
+        except Exception:
+            pass
+
+
+def copynumber_regularized(cn0, cn1, cn2, reg) -> np.ndarray:
+    out = _ld3()
+    load().pgo_copynumber_regularized(np.longdouble(cn0), np.longdouble(cn1), np.longdouble(cn2),
+                                      np.longdouble(reg), out)
+    return np.array([out[0], out[1], out[2]], dtype=np.longdouble)
+
+
+def transition_probs(from_pos, to_pos, recombrate, nr_paths, uniform, effective_N) -> np.ndarray:
+    out = _ld3()
+    load().pgo_transition_probs(from_pos, to_pos, recombrate, nr_paths, int(uniform),
+                                np.longdouble(effective_N), out)
+    return np.array([out[0], out[1], out[2]], dtype=np.longdouble)
+
+
+def emission_table(batch, table: OracleTable, v: int):
+    A = int(batch.allele_off[v + 1] - batch.allele_off[v])
+    out = np.zeros(A * A, dtype=np.longdouble)
+    az = C.c_int32(0)
+    rc = load().pgo_emission_table(C.byref(batch.as_c()), table.h, v,
+                                   out.ctypes.data_as(ldp), C.byref(az))
+    assert rc == 0
+    return out.reshape(A, A), bool(az.value)
+
+
+def make_params(recombrate=1.26, uniform=False, effective_N=25000.0, run_genotyping=True,
+                run_phasing=False) -> PgHmmParams:
+    p = PgHmmParams()
+    p.effective_N = np.longdouble(effective_N)
+    p.recombrate = float(recombrate)
+    p.uniform = int(uniform)
+    p.run_genotyping = int(run_genotyping)
+    p.run_phasing = int(run_phasing)
+    return p
+
+
+class OracleResult:
+    def __init__(self, batch):
+        V = batch.n_variants
+        self.geno_off = batch.geno_off
+        self.lik = np.zeros(int(self.geno_off[-1]), dtype=np.longdouble)
+        self.kept = np.zeros(V, np.uint8)
+        self.allele_present = np.zeros(int(batch.allele_off[-1]) if V else 0, np.uint8)
+        self.n_kmers = np.zeros(V, np.uint16)
+        self.coverage = np.zeros(V, np.uint16)
+        self.n_columns = 0
+
+
+def genotype_contig(batch, table: OracleTable, params: PgHmmParams) -> OracleResult:
+    """HMM::HMM(..., normalize=false) restated on the CPU in long double."""
+    r = OracleResult(batch)
+
+    def p(a, t):
+        if a.size == 0:
+            a = np.zeros(1, a.dtype)
+        return a, a.ctypes.data_as(t)
+    keep = []
+    c = PgoResult()
+    for name, typ in (("lik", ldp), ("kept", u8p), ("allele_present", u8p),
+                      ("n_kmers", u16p), ("coverage", u16p)):
+        arr, ptr = p(getattr(r, name), typ)
+        keep.append(arr)
+        setattr(c, name, ptr)
+    rc = load().pgo_genotype_contig(C.byref(batch.as_c()), table.h, C.byref(params), C.byref(c))
+    if rc:
+        raise RuntimeError(f"oracle error {rc}")
+    r.n_columns = int(c.n_columns)
+    return r
