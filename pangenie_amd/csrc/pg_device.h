@@ -1,0 +1,84 @@
+// pg_device.h — device-side data layout shared by the HIP kernels and the C-ABI shim.
+//
+// HBM layout per contig (one chain = one (contig, path-subset)):
+//   inputs        : the SoA of include/pangenie_hmm.h, uploaded verbatim
+//   vrec[V][RB]   : per-variant record written by k_prep (emission table, local allele
+//                   index of every selected path, emission exponent)
+//   colrec[C][RB] : the same records gathered in column order by k_records, with the
+//                   Li-Stephens constants of the gap (c-1 -> c) filled in.  This is the
+//                   ONE stream the chain kernels read besides the forward columns.
+//   fwd[C][HP*HP] : forward columns v_c = alpha_hat_c * fsum_c (fp64)  — written once by
+//                   k_forward, read once by k_backward: the 16*H^2 algorithmic bytes.
+//   part[C][AMAX][T] : per-thread posterior partials by row allele (reduced by k_bins)
+//   lik / lik_exp : outputs
+#pragma once
+#include <stdint.h>
+
+#define PG_AMAX 5                 // max distinct alleles on the selected paths of one column (fast path)
+#define PG_ESTRIDE (PG_AMAX + 1)  // row stride of the expanded emission table; row/col PG_AMAX = 0 (phantom paths)
+#define PG_ETAB (PG_ESTRIDE * PG_ESTRIDE)
+#define PG_MAX_ALLELES_PER_VARIANT 10  // all alleles of one UniqueKmers object handled by k_prep (pairs <= 64)
+#define PG_PHANTOM 255
+
+// byte offsets inside a record
+#define PG_REC_C0 0
+#define PG_REC_C1 8
+#define PG_REC_C2 16
+#define PG_REC_KAPPA 24
+#define PG_REC_VARIANT 32
+#define PG_REC_EXP 36
+#define PG_REC_NLOCAL 40
+#define PG_REC_FLAGS 41
+#define PG_REC_LOCAL_SLOT 48  // u16[PG_AMAX]
+#define PG_REC_E 64           // double[PG_ETAB]
+#define PG_REC_ALLELES (64 + 8 * PG_ETAB)  // u8[HP]
+#define PG_REC_FLAG_ALLZERO 1
+
+static inline uint32_t pg_rec_bytes(uint32_t hp) { return (PG_REC_ALLELES + hp + 63u) & ~63u; }
+
+// error bits raised by kernels in DevContig::err
+#define PG_DEVERR_ALLELE_NOT_FOUND 1u
+#define PG_DEVERR_TOO_MANY_ALLELES 2u
+#define PG_DEVERR_TOO_MANY_LOCAL 4u
+
+struct DevTable {
+    uint32_t cov_min, cov_max, count_max;  // dense box [cov_min,cov_max) x [0,count_max)
+    uint32_t pad;
+    double reg;           // regularization constant (on-the-fly path)
+    const double* mant;   // [cov-cov_min][count][3]
+    const int32_t* expo;  // [cov-cov_min][count][3]
+};
+
+struct DevContig {
+    uint32_t V, H, HP, RB;
+    uint32_t T;            // threads per chain workgroup = HP*HP/R
+    uint32_t pad0;
+    double dist_scale;     // 0.000004 * recombrate * effective_N
+    int32_t uniform;
+    int32_t pad1;
+    // inputs
+    const uint64_t* pos;
+    const uint16_t* cov;
+    const uint32_t* kmer_off;
+    const uint16_t* kmer_count;
+    const uint32_t* allele_off;
+    const uint16_t* allele_id;
+    const uint8_t*  allele_flags;
+    const uint16_t* allele_koff;
+    const uint32_t* allele_kmask;
+    const uint16_t* path_allele;
+    const uint64_t* geno_off;
+    // intermediates
+    uint8_t*  vrec;
+    uint8_t*  kept;
+    uint8_t*  allele_present;
+    uint32_t* n_cols;
+    uint32_t* col_variant;
+    uint8_t*  colrec;
+    double*   fwd;
+    double*   part;
+    uint32_t* err;
+    // outputs
+    double*   lik;
+    int32_t*  lik_exp;
+};

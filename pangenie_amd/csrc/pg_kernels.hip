@@ -1,0 +1,851 @@
+// pg_kernels.hip — hand-written CDNA4 (gfx950) kernels of the PanGenie genotyping hot path.
+//
+//   k_prep      EmissionProbabilityComputer + ColumnIndexer flags      (one wave / variant)
+//               reference src/emissionprobabilitycomputer.cpp:9-53, src/columnindexer.cpp:12-31,
+//               src/probabilitytable.cpp:47-85 (on-the-fly entries), src/copynumber.cpp:22-41
+//   k_compact   kept variants -> column list                           (one workgroup / contig)
+//   k_records   column records + Li-Stephens constants on device       (one wave / column)
+//               reference src/transitionprobabilitycomputer.cpp:8-19
+//   k_forward   forward recursion, persistent, one workgroup / chain   reference src/hmm.cpp:76-90,175-273
+//   k_backward  backward recursion + posterior partials                reference src/hmm.cpp:92-110,275-405
+//   k_bins      posterior partials -> genotype bins                    reference src/hmm.cpp:364-368
+//
+// No MFMA: the transition operator is rank-structured (A = r I + q 1 1^T), so a column
+// update is elementwise + row/column sums.  The recursion is bound by HBM (16 H^2 bytes
+// per column: one write + one read of the forward column) once enough chains run; a single
+// chain is bound by the per-column latency of one workgroup.
+//
+// Thread mapping of the chain kernels (HP = padded #paths, R rows per thread, T = HP*HP/R):
+//   j  = tid % HP            column (second path) owned by the thread
+//   rg = tid / HP            row group; the thread holds rows i = rg*R .. rg*R+R-1 of column j
+// For HP >= 64 a wave spans 64 columns of ONE row group, so everything indexed by the row
+// (allele of path i, u_i) is wave-uniform and lives in SGPRs; column sums are in-lane adds
+// plus one LDS exchange per column (one __syncthreads per column).  Forward columns are
+// symmetric, so row sums == column sums and only column sums are computed.
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <stdint.h>
+
+#include "pg_device.h"
+
+#define DEVI __device__ __forceinline__
+
+// ------------------------------------------------------------------------------------------
+//  wave-level helpers (wave = 64 lanes)
+// ------------------------------------------------------------------------------------------
+template <int CTRL, int ROW_MASK, bool BOUND>
+DEVI double dpp_f64(double v) {
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = __builtin_amdgcn_update_dpp(0, lo, CTRL, ROW_MASK, 0xF, BOUND);
+    hi = __builtin_amdgcn_update_dpp(0, hi, CTRL, ROW_MASK, 0xF, BOUND);
+    return __hiloint2double(hi, lo);
+}
+
+DEVI double readlane_f64(double v, int src_lane /*uniform*/) {
+    int lo = __builtin_amdgcn_readlane(__double2loint(v), src_lane);
+    int hi = __builtin_amdgcn_readlane(__double2hiint(v), src_lane);
+    return __hiloint2double(hi, lo);
+}
+
+// Sum over the 64 lanes, result broadcast to every lane.  4 row_shr steps inside the
+// 16-lane DPP rows, then row_bcast:15 / row_bcast:31 across rows (gfx9 DPP).
+DEVI double wave_sum(double v) {
+    v += dpp_f64<0x111, 0xF, true>(v);   // row_shr:1
+    v += dpp_f64<0x112, 0xF, true>(v);   // row_shr:2
+    v += dpp_f64<0x114, 0xF, true>(v);   // row_shr:4
+    v += dpp_f64<0x118, 0xF, true>(v);   // row_shr:8
+    v += dpp_f64<0x142, 0xA, false>(v);  // row_bcast:15 -> rows 1,3
+    v += dpp_f64<0x143, 0xC, false>(v);  // row_bcast:31 -> rows 2,3
+    return readlane_f64(v, 63);
+}
+
+DEVI void wave_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+}
+
+DEVI int wave_max_i32(int v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        int o = __shfl_xor(v, off);
+        v = o > v ? o : v;
+    }
+    return v;
+}
+
+DEVI uint32_t wave_or_u32(uint32_t v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v |= (uint32_t)__shfl_xor((int)v, off);
+    return v;
+}
+
+// ------------------------------------------------------------------------------------------
+//  ProbabilityTable lookups as (mantissa, exponent) pairs
+// ------------------------------------------------------------------------------------------
+DEVI void from_log2(double L, double& m, int& e) {
+    if (L == -INFINITY) { m = 0.0; e = 0; return; }
+    if (!(L == L) || L == INFINITY) { m = L; e = 0; return; }
+    double fl = floor(L);
+    e = (int)fl + 1;
+    m = exp2(L - fl - 1.0);  // [0.5, 1)
+}
+
+DEVI void split(double p, double& m, int& e) {
+    if (p == 0.0 || !(p == p) || isinf(p)) { m = p; e = 0; return; }
+    int ee;
+    m = frexp(p, &ee);
+    e = ee;
+}
+
+// compute_probability on the fly (reference src/probabilitytable.cpp:55-65,75-85) in fp64,
+// range-safe through log2-domain evaluation.
+__device__ __noinline__ void cn_on_the_fly(double reg, uint32_t cov, uint32_t count, double m[3], int e[3]) {
+    const double err = cov < 10 ? 0.99 : (cov < 20 ? 0.95 : (cov < 40 ? 0.9 : 0.8));
+    const double LOG2E = 1.4426950408889634074;
+    const double cnt = (double)count;
+    double L0 = cnt * log2(1.0 - err) + log2(err);  // geometric: (1-p)^count * p
+    double lg = lgamma(cnt + 1.0);                  // sum_{i<=count} log(i)
+    double mean1 = (double)cov * 0.5, mean2 = (double)cov;
+    double L1 = (-mean1 + cnt * log(mean1) - lg) * LOG2E;
+    double L2 = (-mean2 + cnt * log(mean2) - lg) * LOG2E;
+    from_log2(L0, m[0], e[0]);
+    from_log2(L1, m[1], e[1]);
+    from_log2(L2, m[2], e[2]);
+    if (reg > 0) {  // CopyNumber(cn0,cn1,cn2,reg), reference src/copynumber.cpp:22-41
+        double p0 = ldexp(m[0], e[0]), p1 = ldexp(m[1], e[1]), p2 = ldexp(m[2], e[2]);
+        double sum = p0 + p1 + p2 + 3.0 * reg;
+        double P0 = (p0 + reg) / sum, P1 = (p1 + reg) / sum;
+        double P2 = 1.0 - P0 - P1;
+        split(P0, m[0], e[0]);
+        split(P1, m[1], e[1]);
+        split(P2, m[2], e[2]);
+    }
+}
+
+DEVI void cn_lookup(const DevTable& t, uint32_t cov, uint32_t count, double m[3], int e[3]) {
+    if (cov >= t.cov_min && cov < t.cov_max && count < t.count_max) {
+        size_t idx = ((size_t)(cov - t.cov_min) * t.count_max + count) * 3;
+        m[0] = t.mant[idx]; m[1] = t.mant[idx + 1]; m[2] = t.mant[idx + 2];
+        e[0] = t.expo[idx]; e[1] = t.expo[idx + 1]; e[2] = t.expo[idx + 2];
+    } else {
+        cn_on_the_fly(t.reg, cov, count, m, e);
+    }
+}
+
+// scale * (a + b [+ c]) for (mantissa, exponent) operands, range-safe
+DEVI void mix2(double ma, int ea, double mb, int eb, double scale, double& m, int& e) {
+    int emax = ea > eb ? ea : eb;
+    if (ma == 0.0) emax = eb;
+    if (mb == 0.0) emax = ea;
+    double s = (ldexp(ma, ea - emax) + ldexp(mb, eb - emax)) * scale;
+    split(s, m, e);
+    e += emax;
+}
+DEVI void mix3(const double* mm, const int* ee, double scale, double& m, int& e) {
+    int emax = -(1 << 30);
+    bool any = false;
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+        if (mm[i] != 0.0) { emax = (any && emax > ee[i]) ? emax : ee[i]; any = true; }
+    if (!any) emax = 0;
+    double s = 0.0;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) s += ldexp(mm[i], ee[i] - emax);
+    s *= scale;
+    split(s, m, e);
+    e += emax;
+}
+
+// kmer k on allele slot <=> 0 <= k-off < 32 && mask>>(k-off)&1  (reference src/kmerpath.cpp:33-48)
+DEVI uint32_t kmer_on(uint32_t off, uint32_t mask, uint32_t k) {
+    uint32_t d = k - off;
+    return (k >= off && d < 32u) ? ((mask >> d) & 1u) : 0u;
+}
+
+// Product over all k-mers of variant v for allele-slot pair (s1,s2), one pair per lane.
+// Called by a full wave; lds_m/lds_e are this wave's staging buffers [64][3].
+// reference src/emissionprobabilitycomputer.cpp:36-53
+DEVI void emission_pair_products(const DevContig& dc, const DevTable& tab, uint32_t v, uint32_t lane,
+                                 bool active, uint32_t s1, uint32_t s2, double* lds_m, int* lds_e,
+                                 double& pm, int& pe) {
+    const uint32_t a0 = dc.allele_off[v];
+    const uint32_t k0 = dc.kmer_off[v], K = dc.kmer_off[v + 1] - k0;
+    const uint32_t cov = dc.cov[v];
+    uint32_t off1 = 0, mask1 = 0, off2 = 0, mask2 = 0;
+    bool u1 = false, u2 = false;
+    if (active) {
+        off1 = dc.allele_koff[a0 + s1]; mask1 = dc.allele_kmask[a0 + s1];
+        off2 = dc.allele_koff[a0 + s2]; mask2 = dc.allele_kmask[a0 + s2];
+        u1 = dc.allele_flags[a0 + s1] & 1; u2 = dc.allele_flags[a0 + s2] & 1;
+    }
+    pm = 1.0; pe = 0;
+    for (uint32_t kb = 0; kb < K; kb += 64) {
+        const uint32_t kk = kb + lane;
+        if (kk < K) {
+            double m[3]; int e[3];
+            cn_lookup(tab, cov, dc.kmer_count[k0 + kk], m, e);
+#pragma unroll
+            for (int i = 0; i < 3; ++i) { lds_m[lane * 3 + i] = m[i]; lds_e[lane * 3 + i] = e[i]; }
+        }
+        wave_sync();
+        const uint32_t n = (K - kb) < 64u ? (K - kb) : 64u;
+        if (active) {
+            for (uint32_t q = 0; q < n; ++q) {
+                const uint32_t k = kb + q;
+                const uint32_t c = kmer_on(off1, mask1, k) + kmer_on(off2, mask2, k);
+                double fm; int fe;
+                if (u1 && u2) {
+                    mix3(lds_m + q * 3, lds_e + q * 3, 1.0 / 3.0, fm, fe);
+                } else if (u1 || u2) {
+                    const uint32_t c2 = c + 1 > 2 ? 2 : c + 1;  // reference asserts c < 2 here
+                    mix2(lds_m[q * 3 + c], lds_e[q * 3 + c], lds_m[q * 3 + c2], lds_e[q * 3 + c2], 0.5, fm, fe);
+                } else {
+                    fm = lds_m[q * 3 + c]; fe = lds_e[q * 3 + c];
+                }
+                pm *= fm; pe += fe;
+            }
+            double mm; int ee;
+            split(pm, mm, ee);
+            pm = mm; pe += ee;
+        }
+        wave_sync();
+    }
+}
+
+DEVI void decode_pair(uint32_t idx, uint32_t A, uint32_t& s1, uint32_t& s2) {
+    uint32_t a = 0, rem = idx;
+    while (a < A && rem >= A - a) { rem -= A - a; ++a; }
+    s1 = a; s2 = a + rem;
+}
+
+// ------------------------------------------------------------------------------------------
+//  k_prep : one wave per variant
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_prep(const DevContig* __restrict__ contigs, DevTable tab) {
+    __shared__ double s_m[4][64 * 3];
+    __shared__ int s_e[4][64 * 3];
+    __shared__ double s_E[4][PG_ETAB];
+    const DevContig& dc = contigs[blockIdx.y];
+    const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const uint32_t v = blockIdx.x * 4 + wave;
+    if (v >= dc.V) return;  // whole wave leaves; the kernel only uses wave-level sync
+
+    const uint32_t a0 = dc.allele_off[v], A = dc.allele_off[v + 1] - a0;
+    const uint32_t H = dc.H, HP = dc.HP;
+    if (A > PG_MAX_ALLELES_PER_VARIANT || A == 0) {
+        if (lane == 0) { atomicOr(dc.err, PG_DEVERR_TOO_MANY_ALLELES); dc.kept[v] = 0; }
+        return;
+    }
+    // ---- ColumnIndexer rule: kept iff a selected path carries a defined non-ref allele
+    //      (reference src/columnindexer.cpp:24-31); also which allele slots are present.
+    uint32_t pmask = 0;
+    bool nonref = false, bad = false;
+    for (uint32_t p = lane; p < H; p += 64) {
+        const uint16_t a = dc.path_allele[(size_t)v * H + p];
+        int s = -1;
+        for (uint32_t q = 0; q < A; ++q)
+            if (dc.allele_id[a0 + q] == a) s = (int)q;
+        if (s < 0) bad = true;
+        else {
+            pmask |= 1u << s;
+            if (a != 0 && !(dc.allele_flags[a0 + s] & 1)) nonref = true;
+        }
+    }
+    pmask = wave_or_u32(pmask);
+    const bool kept = __any(nonref) != 0;
+    if (__any(bad) != 0) {
+        if (lane == 0) { atomicOr(dc.err, PG_DEVERR_ALLELE_NOT_FOUND); dc.kept[v] = 0; }
+        return;
+    }
+    const uint32_t n_local = __popc(pmask);
+    if (lane < A) dc.allele_present[a0 + lane] = (pmask >> lane) & 1u;
+    if (lane == 0) dc.kept[v] = kept ? 1 : 0;
+    if (!kept) return;
+    if (n_local > PG_AMAX) {
+        if (lane == 0) atomicOr(dc.err, PG_DEVERR_TOO_MANY_LOCAL);
+        return;
+    }
+
+    unsigned char* rec = dc.vrec + (size_t)v * dc.RB;
+    // local (dense) allele index of every selected path; phantom paths of the padding get 255
+    for (uint32_t p = lane; p < HP; p += 64) {
+        unsigned char val = PG_PHANTOM;
+        if (p < H) {
+            const uint16_t a = dc.path_allele[(size_t)v * H + p];
+            uint32_t s = 0;
+            for (uint32_t q = 0; q < A; ++q)
+                if (dc.allele_id[a0 + q] == a) s = q;
+            val = (unsigned char)__popc(pmask & ((1u << s) - 1u));
+        }
+        rec[PG_REC_ALLELES + p] = val;
+    }
+
+    // ---- emission products over ALL allele pairs of the object (a1<=a2; table is symmetric)
+    const uint32_t P = A * (A + 1) / 2;
+    const bool active = lane < P;
+    uint32_t s1 = 0, s2 = 0;
+    if (active) decode_pair(lane, A, s1, s2);
+    double pm; int pe;
+    emission_pair_products(dc, tab, v, lane, active, s1, s2, s_m[wave], s_e[wave], pm, pe);
+
+    const bool all_zeros = __any(active && pm > 0.0) == 0;  // emissionprobabilitycomputer.cpp:24
+    const bool both_present = active && ((pmask >> s1) & 1u) && ((pmask >> s2) & 1u);
+    int X = wave_max_i32((both_present && pm > 0.0) ? pe : -(1 << 30));
+    if (X == -(1 << 30) || all_zeros) X = 0;
+
+    if (lane < PG_ETAB) s_E[wave][lane] = 0.0;
+    wave_sync();
+    if (both_present) {
+        const uint32_t la = __popc(pmask & ((1u << s1) - 1u)), lb = __popc(pmask & ((1u << s2) - 1u));
+        double val;
+        if (all_zeros) val = 1.0;                           // emissionprobabilitycomputer.cpp:31-34
+        else val = (pm > 0.0) ? ldexp(pm, pe - X) : pm;     // 0 (or NaN) stays
+        s_E[wave][la * PG_ESTRIDE + lb] = val;
+        s_E[wave][lb * PG_ESTRIDE + la] = val;
+    }
+    wave_sync();
+    if (lane < PG_ETAB) ((double*)(rec + PG_REC_E))[lane] = s_E[wave][lane];
+    if (lane < 4) ((double*)rec)[lane] = 0.0;  // transition constants are filled by k_records
+    if (lane == 0) {
+        *(uint32_t*)(rec + PG_REC_VARIANT) = v;
+        *(int32_t*)(rec + PG_REC_EXP) = X;
+        rec[PG_REC_NLOCAL] = (unsigned char)n_local;
+        rec[PG_REC_FLAGS] = all_zeros ? PG_REC_FLAG_ALLZERO : 0;
+        rec[PG_REC_FLAGS + 1] = 0; rec[PG_REC_FLAGS + 2] = 0;
+        *(uint32_t*)(rec + 44) = 0;
+        uint16_t* ls = (uint16_t*)(rec + PG_REC_LOCAL_SLOT);
+        uint32_t l = 0;
+        for (uint32_t s = 0; s < A; ++s)
+            if ((pmask >> s) & 1u) ls[l++] = (uint16_t)s;
+        for (; l < 8; ++l) ls[l] = 0;
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+//  unit-level entry: full A x A emission products of one variant as (mantissa, exponent)
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void k_emission_single(const DevContig* __restrict__ contigs, DevTable tab,
+                                                        uint32_t v, double* out_m, int* out_e) {
+    __shared__ double s_m[64 * 3];
+    __shared__ int s_e[64 * 3];
+    const DevContig& dc = contigs[0];
+    const uint32_t lane = threadIdx.x;
+    const uint32_t A = dc.allele_off[v + 1] - dc.allele_off[v];
+    const uint32_t P = A * (A + 1) / 2;
+    for (uint32_t base = 0; base < P; base += 64) {
+        const bool active = base + lane < P;
+        uint32_t s1 = 0, s2 = 0;
+        if (active) decode_pair(base + lane, A, s1, s2);
+        double pm; int pe;
+        emission_pair_products(dc, tab, v, lane, active, s1, s2, s_m, s_e, pm, pe);
+        if (active) {
+            out_m[s1 * A + s2] = pm; out_e[s1 * A + s2] = pe;
+            out_m[s2 * A + s1] = pm; out_e[s2 * A + s1] = pe;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+//  k_compact : kept[] -> col_variant[], n_cols       (one 1024-thread workgroup per contig)
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(1024) void k_compact(const DevContig* __restrict__ contigs) {
+    __shared__ uint32_t s_cnt[1024];
+    const DevContig& dc = contigs[blockIdx.x];
+    const uint32_t tid = threadIdx.x, V = dc.V;
+    const uint32_t chunk = (V + 1023u) / 1024u;
+    const uint32_t lo = tid * chunk < V ? tid * chunk : V;
+    const uint32_t hi = lo + chunk < V ? lo + chunk : V;
+    uint32_t cnt = 0;
+    for (uint32_t v = lo; v < hi; ++v) cnt += dc.kept[v] ? 1u : 0u;
+    s_cnt[tid] = cnt;
+    __syncthreads();
+    // inclusive Hillis-Steele scan
+    for (uint32_t off = 1; off < 1024; off <<= 1) {
+        uint32_t add = tid >= off ? s_cnt[tid - off] : 0u;
+        __syncthreads();
+        s_cnt[tid] += add;
+        __syncthreads();
+    }
+    uint32_t pos = s_cnt[tid] - cnt;
+    for (uint32_t v = lo; v < hi; ++v)
+        if (dc.kept[v]) dc.col_variant[pos++] = v;
+    if (tid == 1023) *dc.n_cols = s_cnt[1023];
+}
+
+// ------------------------------------------------------------------------------------------
+//  Li-Stephens constants (reference src/transitionprobabilitycomputer.cpp:14-18).
+//  With r = exp(-d/H) and q = (1-exp(-d/H))/H = -expm1(-d/H)/H :
+//     t0 x + t1 (R_i+C_j-2x) + t2 (S-R_i-C_j+x) = r^2 x + q r (R_i+C_j) + q^2 S
+//  expm1 removes the 1-exp(-x) cancellation.
+// ------------------------------------------------------------------------------------------
+DEVI void transition_consts(double d, uint32_t H, int uniform, double& c0, double& c1, double& c2, double& kappa) {
+    if (uniform) { c0 = 0.0; c1 = 0.0; c2 = 1.0; }
+    else {
+        const double x = d / (double)H;
+        const double r = exp(-x);
+        const double q = -expm1(-x) / (double)H;
+        c0 = r * r; c1 = q * r; c2 = q * q;
+    }
+    const double h = (double)H;
+    kappa = c0 + 2.0 * h * c1 + h * h * c2;  // sum of one transition row-pair: sum(A w A^T) = kappa * sum(w)
+}
+
+__global__ __launch_bounds__(64) void k_transition_single(double d, uint32_t H, int uniform, double* out3) {
+    if (threadIdx.x == 0) {
+        if (uniform) { out3[0] = out3[1] = out3[2] = 1.0; return; }
+        const double x = d / (double)H;
+        const double q = -expm1(-x) / (double)H;
+        const double p = exp(-x) + q;
+        out3[0] = p * p; out3[1] = p * q; out3[2] = q * q;
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+//  k_records : gather variant records into column order, fill transition constants
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_records(const DevContig* __restrict__ contigs) {
+    const DevContig& dc = contigs[blockIdx.y];
+    const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const uint32_t c = blockIdx.x * 4 + wave;
+    const uint32_t C = *dc.n_cols;
+    if (c >= C) return;
+    const uint32_t v = dc.col_variant[c];
+    const uint64_t* src = (const uint64_t*)(dc.vrec + (size_t)v * dc.RB);
+    uint64_t* dst = (uint64_t*)(dc.colrec + (size_t)c * dc.RB);
+    const uint32_t words = dc.RB / 8;
+    double c0 = 0.0, c1 = 0.0, c2 = 0.0, kappa = 0.0;
+    if (c > 0) {
+        const uint32_t pv = dc.col_variant[c - 1];
+        const double d = (double)(dc.pos[v] - dc.pos[pv]) * dc.dist_scale;
+        transition_consts(d, dc.H, dc.uniform, c0, c1, c2, kappa);
+    }
+    for (uint32_t w = lane; w < words; w += 64) {
+        uint64_t val = src[w];
+        if (w < 4) {
+            const double cv = w == 0 ? c0 : (w == 1 ? c1 : (w == 2 ? c2 : kappa));
+            val = (uint64_t)__double_as_longlong(cv);
+        }
+        dst[w] = val;
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+//  chain kernels
+// ------------------------------------------------------------------------------------------
+template <int HP, int R>
+struct ChainCfg {
+    static constexpr int T = HP * HP / R;
+    static constexpr int NRG = HP / R;
+    static constexpr int NW = T / 64;
+    static constexpr bool UNI = HP >= 64;
+    static constexpr int RB = (PG_REC_ALLELES + HP + 63) & ~63;
+    static constexpr int WORDS = RB / 8;
+    static_assert(T % 64 == 0 && T <= 1024, "bad workgroup size");
+    static_assert(WORDS <= 64, "record must fit one wave-wide 8-byte load");
+};
+
+template <int HP, int R>
+struct ChainShared {
+    using Cfg = ChainCfg<HP, R>;
+    unsigned char rec[4][Cfg::RB] __attribute__((aligned(16)));
+    double psum[2][Cfg::NRG][HP];
+    double wsum[2][Cfg::NW];
+    double u[HP];
+};
+
+// emission of state (i, j) from a staged record: E[a_i][a_j]; phantom paths (255) hit the
+// zero row/column PG_AMAX of the expanded table.
+template <bool UNI>
+DEVI double emission_at(const unsigned char* rec, uint32_t i, uint32_t aj) {
+    uint32_t ai = rec[PG_REC_ALLELES + i];
+    ai = ai > PG_AMAX ? PG_AMAX : ai;
+    if (UNI) ai = __builtin_amdgcn_readfirstlane(ai);
+    return ((const double*)(rec + PG_REC_E))[ai * PG_ESTRIDE + aj];
+}
+DEVI uint32_t col_allele(const unsigned char* rec, uint32_t j) {
+    uint32_t aj = rec[PG_REC_ALLELES + j];
+    return aj > PG_AMAX ? PG_AMAX : aj;
+}
+
+// u_i of row i.  UNI: every wave holds the u vector of the 64-column block that contains its
+// rows (urow) and the row is wave-uniform -> v_readlane.  !UNI (single wave): via LDS.
+template <bool UNI>
+DEVI double row_value(const double* lds_u, double urow, uint32_t i) {
+    if (UNI) return readlane_f64(urow, __builtin_amdgcn_readfirstlane((int)(i & 63u)));
+    return lds_u[i];
+}
+
+template <int HP, int R>
+__global__ __launch_bounds__(HP * HP / R) void k_forward(const DevContig* __restrict__ contigs) {
+    using Cfg = ChainCfg<HP, R>;
+    __shared__ ChainShared<HP, R> sh;
+    const DevContig& dc = contigs[blockIdx.x];
+    if (dc.HP != (uint32_t)HP) return;
+    const uint32_t C = *dc.n_cols;
+    if (C == 0) return;
+    const uint32_t tid = threadIdx.x, lane = tid & 63u;
+    const uint32_t wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const uint32_t j = tid % HP, rg = tid / HP, i0 = rg * R;
+    const uint32_t H = dc.H;
+    const double unif = 1.0 / ((double)H * (double)H);
+    const unsigned char* colrec = dc.colrec;
+    double* fwd = dc.fwd;
+    const size_t colsz = (size_t)HP * HP;
+    const uint32_t rb = (i0 / 64u) * 64u;  // first column of the 64-block that contains my rows (UNI)
+
+    auto rec_load = [&](uint32_t c) -> uint64_t {
+        if (tid < (uint32_t)Cfg::WORDS && c < C) return ((const uint64_t*)(colrec + (size_t)c * Cfg::RB))[tid];
+        return 0ull;
+    };
+    auto rec_stage = [&](uint32_t c, uint64_t w) {
+        if (tid < (uint32_t)Cfg::WORDS) ((uint64_t*)sh.rec[c & 3u])[tid] = w;
+    };
+    auto store_col = [&](uint32_t c, const double (&x)[R]) {
+        double* dst = fwd + (size_t)c * colsz + (size_t)i0 * HP + j;
+#pragma unroll
+        for (int k = 0; k < R; ++k) dst[(size_t)k * HP] = x[k];
+    };
+
+    double x[R];
+    double Cj = 0.0, Crow = 0.0, S = 0.0;
+
+    // prologue: records 0 and 1 -> LDS, 2 and 3 in flight
+    rec_stage(0, rec_load(0));
+    rec_stage(1, rec_load(1));
+    uint64_t tE = rec_load(2), tO = rec_load(3);
+    __syncthreads();
+
+    // column 0: v_0 = e_0 (reference src/hmm.cpp:236-238, previous_cell = 1)
+    {
+        const uint32_t aj = col_allele(sh.rec[0], j);
+        double part = 0.0;
+#pragma unroll
+        for (int k = 0; k < R; ++k) { x[k] = emission_at<Cfg::UNI>(sh.rec[0], i0 + k, aj); part += x[k]; }
+        store_col(0, x);
+        sh.psum[0][rg][j] = part;
+        const double ws = wave_sum(part);
+        if (lane == 0) sh.wsum[0][wave] = ws;
+    }
+    __syncthreads();
+
+    // sums of column cprev; uniform fallback if the column summed to zero (hmm.cpp:253-267)
+    auto finalize = [&](uint32_t cprev) {
+        const uint32_t pb = cprev & 1u;
+        Cj = 0.0;
+#pragma unroll
+        for (int g = 0; g < Cfg::NRG; ++g) Cj += sh.psum[pb][g][j];
+        if (Cfg::UNI && HP > 64) {
+            Crow = 0.0;
+#pragma unroll
+            for (int g = 0; g < Cfg::NRG; ++g) Crow += sh.psum[pb][g][rb + lane];
+        } else {
+            Crow = Cj;
+        }
+        S = 0.0;
+#pragma unroll
+        for (int w = 0; w < Cfg::NW; ++w) S += sh.wsum[pb][w];
+        if (!(S > 0.0)) {
+#pragma unroll
+            for (int k = 0; k < R; ++k) x[k] = (j < H && i0 + k < H) ? unif : 0.0;
+            store_col(cprev, x);
+            Cj = j < H ? (double)H * unif : 0.0;
+            Crow = (rb + lane) < H ? (double)H * unif : 0.0;
+            S = 1.0;
+        }
+    };
+
+    auto step = [&](uint32_t c, uint64_t& tnext) {
+        finalize(c - 1);
+        const unsigned char* rec = sh.rec[c & 3u];
+        const double c0 = *(const double*)(rec + PG_REC_C0);
+        const double c1 = *(const double*)(rec + PG_REC_C1);
+        const double c2 = *(const double*)(rec + PG_REC_C2);
+        const double inv = 1.0 / S;
+        const double k0 = c0 * inv, k1 = c1 * inv, hk2 = 0.5 * c2;
+        const double uj = fma(k1, Cj, hk2);
+        const double urow = fma(k1, Crow, hk2);
+        if (!Cfg::UNI) {
+            if (rg == 0) sh.u[j] = uj;
+            __syncthreads();
+        }
+        const uint32_t aj = col_allele(rec, j);
+        double part = 0.0;
+#pragma unroll
+        for (int k = 0; k < R; ++k) {
+            const double ui = row_value<Cfg::UNI>(sh.u, urow, i0 + k);
+            const double t = fma(k0, x[k], ui + uj);
+            x[k] = t * emission_at<Cfg::UNI>(rec, i0 + k, aj);
+            part += x[k];
+        }
+        store_col(c, x);
+        sh.psum[c & 1u][rg][j] = part;
+        const double ws = wave_sum(part);
+        if (lane == 0) sh.wsum[c & 1u][wave] = ws;
+        rec_stage(c + 1, tnext);   // loaded two steps ago
+        tnext = rec_load(c + 3);
+        __syncthreads();
+    };
+
+    for (uint32_t c = 1; c < C; c += 2) {
+        step(c, tE);                    // stages column c+1 (even)
+        if (c + 1 < C) step(c + 1, tO); // stages column c+2 (odd)
+    }
+    finalize(C - 1);
+}
+
+// VBUF = number of forward-column register buffers (prefetch distance in columns)
+// KEEPW = keep w = beta_hat*e in registers across the column-sum exchange (else recompute it)
+template <int HP, int R, int VBUF, bool KEEPW>
+__global__ __launch_bounds__(HP * HP / R) void k_backward(const DevContig* __restrict__ contigs) {
+    using Cfg = ChainCfg<HP, R>;
+    __shared__ ChainShared<HP, R> sh;
+    const DevContig& dc = contigs[blockIdx.x];
+    if (dc.HP != (uint32_t)HP) return;
+    const uint32_t C = *dc.n_cols;
+    if (C == 0) return;
+    const uint32_t tid = threadIdx.x, lane = tid & 63u;
+    const uint32_t wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const uint32_t j = tid % HP, rg = tid / HP, i0 = rg * R;
+    const uint32_t H = dc.H;
+    const double unif = 1.0 / ((double)H * (double)H);
+    const unsigned char* colrec = dc.colrec;
+    const double* fwd = dc.fwd;
+    double* part_out = dc.part;
+    const size_t colsz = (size_t)HP * HP;
+    const uint32_t rb = (i0 / 64u) * 64u;
+
+    // records are consumed in DESCENDING column order
+    auto rec_load = [&](int64_t c) -> uint64_t {
+        if (tid < (uint32_t)Cfg::WORDS && c >= 0) return ((const uint64_t*)(colrec + (size_t)c * Cfg::RB))[tid];
+        return 0ull;
+    };
+    auto rec_stage = [&](int64_t c, uint64_t w) {
+        if (tid < (uint32_t)Cfg::WORDS && c >= 0) ((uint64_t*)sh.rec[(uint32_t)c & 3u])[tid] = w;
+    };
+    auto load_col = [&](int64_t c, double (&v)[R]) {
+        if (c < 0) return;
+        const double* src = fwd + (size_t)c * colsz + (size_t)i0 * HP + j;
+#pragma unroll
+        for (int k = 0; k < R; ++k) v[k] = src[(size_t)k * HP];
+    };
+
+    double y[R], vA[R], vB[VBUF == 2 ? R : 1];
+    double Sy = 0.0;
+    const int64_t last = (int64_t)C - 1;
+
+    rec_stage(last, rec_load(last));
+    rec_stage(last - 1, rec_load(last - 1));
+    uint64_t tA = rec_load(last - 2), tB = rec_load(last - 3);
+    load_col(last, vA);
+    if constexpr (VBUF == 2) load_col(last - 1, vB);
+    __syncthreads();
+
+    // posterior partials of column c: acc[a] = sum over my rows with allele a of v*beta
+    auto posterior = [&](uint32_t c, const double (&v)[R], const double (&beta)[R]) {
+        const unsigned char* rec0 = sh.rec[c & 3u];
+        const unsigned char* al = rec0 + PG_REC_ALLELES;
+        const uint32_t nl = rec0[PG_REC_NLOCAL];
+        double acc[PG_AMAX];
+#pragma unroll
+        for (int a = 0; a < PG_AMAX; ++a) acc[a] = 0.0;
+#pragma unroll
+        for (int k = 0; k < R; ++k) {
+            uint32_t ai = al[i0 + k];
+            if (Cfg::UNI) ai = __builtin_amdgcn_readfirstlane(ai);
+            const double p = v[k] * beta[k];
+#pragma unroll
+            for (int a = 0; a < PG_AMAX; ++a)
+                if (ai == (uint32_t)a) acc[a] += p;
+            if constexpr (R > 16) { if ((k & 7) == 7) __builtin_amdgcn_sched_barrier(0); }
+        }
+        double* dst = part_out + (size_t)c * PG_AMAX * Cfg::T + tid;
+#pragma unroll
+        for (int a = 0; a < PG_AMAX; ++a)
+            if ((uint32_t)a < nl) dst[(size_t)a * Cfg::T] = acc[a];
+    };
+
+    // column C-1: beta~ = 1 (reference src/hmm.cpp:356-358); sum = H^2
+    {
+        double beta[R];
+#pragma unroll
+        for (int k = 0; k < R; ++k) beta[k] = (j < H && i0 + k < H) ? 1.0 : 0.0;
+        posterior((uint32_t)last, vA, beta);
+#pragma unroll
+        for (int k = 0; k < R; ++k) y[k] = beta[k];
+        Sy = (double)H * (double)H;
+        load_col(last - VBUF, vA);
+    }
+
+    auto step = [&](int64_t c, double (&v)[R], uint64_t& tnext) {
+        // beta_hat_{c+1} = y / Sy, uniform if the sum is zero (hmm.cpp:374-380)
+        if (!(Sy > 0.0)) {
+#pragma unroll
+            for (int k = 0; k < R; ++k) y[k] = (j < H && i0 + k < H) ? unif : 0.0;
+            Sy = 1.0;
+        }
+        const unsigned char* rec1 = sh.rec[(uint32_t)(c + 1) & 3u];
+        const double c0 = *(const double*)(rec1 + PG_REC_C0);
+        const double c1 = *(const double*)(rec1 + PG_REC_C1);
+        const double c2 = *(const double*)(rec1 + PG_REC_C2);
+        const double kappa = *(const double*)(rec1 + PG_REC_KAPPA);
+        const uint32_t aj1 = col_allele(rec1, j);
+        double w[KEEPW ? R : 1];
+        double part = 0.0;
+#pragma unroll
+        for (int k = 0; k < R; ++k) {
+            const double wk = y[k] * emission_at<Cfg::UNI>(rec1, i0 + k, aj1);
+            if constexpr (KEEPW) w[k] = wk;
+            part += wk;
+            if constexpr (R > 16) { if ((k & 7) == 7) __builtin_amdgcn_sched_barrier(0); }
+        }
+        const uint32_t pb = (uint32_t)c & 1u;
+        sh.psum[pb][rg][j] = part;
+        const double ws = wave_sum(part);
+        if (lane == 0) sh.wsum[pb][wave] = ws;
+        rec_stage(c - 1, tnext);  // loaded two steps ago
+        tnext = rec_load(c - 3);
+        __syncthreads();
+        double Cj = 0.0, Crow, Sw = 0.0;
+#pragma unroll
+        for (int g = 0; g < Cfg::NRG; ++g) Cj += sh.psum[pb][g][j];
+        if (Cfg::UNI && HP > 64) {
+            Crow = 0.0;
+#pragma unroll
+            for (int g = 0; g < Cfg::NRG; ++g) Crow += sh.psum[pb][g][rb + lane];
+        } else {
+            Crow = Cj;
+        }
+#pragma unroll
+        for (int q = 0; q < Cfg::NW; ++q) Sw += sh.wsum[pb][q];
+        const double inv = 1.0 / Sy;
+        const double k0 = c0 * inv, k1 = c1 * inv, hk2 = 0.5 * c2 * Sw * inv;
+        const double uj = fma(k1, Cj, hk2);
+        const double urow = fma(k1, Crow, hk2);
+        if (!Cfg::UNI) {
+            if (rg == 0) sh.u[j] = uj;
+            __syncthreads();
+        }
+#pragma unroll
+        for (int k = 0; k < R; ++k) {
+            double wk;
+            if constexpr (KEEPW) wk = w[k];
+            else wk = y[k] * emission_at<Cfg::UNI>(rec1, i0 + k, aj1);
+            y[k] = fma(k0, wk, row_value<Cfg::UNI>(sh.u, urow, i0 + k) + uj);  // beta~_c
+            if constexpr (R > 16) { if ((k & 7) == 7) __builtin_amdgcn_sched_barrier(0); }
+        }
+        Sy = kappa * Sw * inv;                                        // = sum(beta~_c) over real states
+        posterior((uint32_t)c, v, y);
+        load_col(c - VBUF, v);
+        if (!Cfg::UNI) __syncthreads();  // sh.u is rewritten next step
+    };
+
+    for (int64_t c = last - 1; c >= 0; c -= 2) {
+        if constexpr (VBUF == 2) {
+            step(c, vB, tA);
+            if (c - 1 >= 0) step(c - 1, vA, tB);
+        } else {
+            step(c, vA, tA);
+            if (c - 1 >= 0) step(c - 1, vA, tB);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+//  k_bins : posterior partials -> genotype bins (one wave per column)
+//  L_v({a,b}) = sum over states (i,j) with alleles {a,b} of alpha_hat * beta~ * fsum
+//  (reference src/hmm.cpp:364-368); exponent = X_c + X_{c+1}.
+// ------------------------------------------------------------------------------------------
+DEVI uint32_t tri_local(uint32_t a, uint32_t b) {  // a <= b < PG_AMAX
+    return a * PG_AMAX - a * (a - 1) / 2 + (b - a);
+}
+
+__global__ __launch_bounds__(256) void k_bins(const DevContig* __restrict__ contigs) {
+    __shared__ double s_bins[4][PG_AMAX * (PG_AMAX + 1) / 2];
+    const DevContig& dc = contigs[blockIdx.y];
+    const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const uint32_t c = blockIdx.x * 4 + wave;
+    const uint32_t C = *dc.n_cols;
+    if (c >= C) return;
+    const unsigned char* rec = dc.colrec + (size_t)c * dc.RB;
+    const uint32_t v = *(const uint32_t*)(rec + PG_REC_VARIANT);
+    const uint32_t nl = rec[PG_REC_NLOCAL];
+    const uint32_t T = dc.T, HP = dc.HP;
+    const unsigned char* al = rec + PG_REC_ALLELES;
+    if (lane < PG_AMAX * (PG_AMAX + 1) / 2) s_bins[wave][lane] = 0.0;
+    wave_sync();
+    for (uint32_t a = 0; a < nl; ++a) {
+        const double* src = dc.part + ((size_t)c * PG_AMAX + a) * T;
+        for (uint32_t b = 0; b < nl; ++b) {
+            double s = 0.0;
+            for (uint32_t t = lane; t < T; t += 64)
+                if (al[t % HP] == b) s += src[t];
+            const double tot = wave_sum(s);
+            if (lane == 0) {
+                const uint32_t lo = a < b ? a : b, hi = a < b ? b : a;
+                s_bins[wave][tri_local(lo, hi)] += tot;
+            }
+        }
+    }
+    wave_sync();
+    const uint32_t a0 = dc.allele_off[v], A = dc.allele_off[v + 1] - a0;
+    const uint16_t* ls = (const uint16_t*)(rec + PG_REC_LOCAL_SLOT);
+    if (lane < nl * nl) {
+        const uint32_t la = lane / nl, lb = lane % nl;
+        if (la <= lb) {
+            const uint32_t sa = ls[la], sb = ls[lb];
+            const uint64_t idx = dc.geno_off[v] + (uint64_t)sa * A - (uint64_t)sa * (sa - 1) / 2 + (sb - sa);
+            dc.lik[idx] = s_bins[wave][tri_local(la, lb)];
+        }
+    }
+    if (lane == 0) {
+        int X = *(const int32_t*)(rec + PG_REC_EXP);
+        if (c + 1 < C) X += *(const int32_t*)(dc.colrec + (size_t)(c + 1) * dc.RB + PG_REC_EXP);
+        dc.lik_exp[v] = X;
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+//  host-callable launchers (defined here so that the shim needs no kernel templates)
+// ------------------------------------------------------------------------------------------
+extern "C" {
+
+void pgk_launch_prep(const DevContig* d_contigs, uint32_t n_contigs, uint32_t max_v, DevTable tab, hipStream_t s) {
+    dim3 grid((max_v + 3) / 4, n_contigs);
+    hipLaunchKernelGGL(k_prep, grid, dim3(256), 0, s, d_contigs, tab);
+}
+void pgk_launch_compact(const DevContig* d_contigs, uint32_t n_contigs, hipStream_t s) {
+    hipLaunchKernelGGL(k_compact, dim3(n_contigs), dim3(1024), 0, s, d_contigs);
+}
+void pgk_launch_records(const DevContig* d_contigs, uint32_t n_contigs, uint32_t max_v, hipStream_t s) {
+    dim3 grid((max_v + 3) / 4, n_contigs);
+    hipLaunchKernelGGL(k_records, grid, dim3(256), 0, s, d_contigs);
+}
+void pgk_launch_bins(const DevContig* d_contigs, uint32_t n_contigs, uint32_t max_v, hipStream_t s) {
+    dim3 grid((max_v + 3) / 4, n_contigs);
+    hipLaunchKernelGGL(k_bins, grid, dim3(256), 0, s, d_contigs);
+}
+// hp_mask: bit0 HP=16, bit1 HP=32, bit2 HP=64, bit3 HP=128
+void pgk_launch_forward(const DevContig* d_contigs, uint32_t n_contigs, uint32_t hp_mask, hipStream_t s) {
+    if (hp_mask & 1u) hipLaunchKernelGGL((k_forward<16, 4>), dim3(n_contigs), dim3(64), 0, s, d_contigs);
+    if (hp_mask & 2u) hipLaunchKernelGGL((k_forward<32, 16>), dim3(n_contigs), dim3(64), 0, s, d_contigs);
+    if (hp_mask & 4u) hipLaunchKernelGGL((k_forward<64, 16>), dim3(n_contigs), dim3(256), 0, s, d_contigs);
+    if (hp_mask & 8u) hipLaunchKernelGGL((k_forward<128, 32>), dim3(n_contigs), dim3(512), 0, s, d_contigs);
+}
+void pgk_launch_backward(const DevContig* d_contigs, uint32_t n_contigs, uint32_t hp_mask, hipStream_t s) {
+    if (hp_mask & 1u) hipLaunchKernelGGL((k_backward<16, 4, 2, true>), dim3(n_contigs), dim3(64), 0, s, d_contigs);
+    if (hp_mask & 2u) hipLaunchKernelGGL((k_backward<32, 16, 2, true>), dim3(n_contigs), dim3(64), 0, s, d_contigs);
+    if (hp_mask & 4u) hipLaunchKernelGGL((k_backward<64, 16, 2, true>), dim3(n_contigs), dim3(256), 0, s, d_contigs);
+    if (hp_mask & 8u) hipLaunchKernelGGL((k_backward<128, 32, 1, false>), dim3(n_contigs), dim3(512), 0, s, d_contigs);
+}
+void pgk_launch_emission_single(const DevContig* d_contig, DevTable tab, uint32_t v, double* out_m, int* out_e,
+                                hipStream_t s) {
+    hipLaunchKernelGGL(k_emission_single, dim3(1), dim3(64), 0, s, d_contig, tab, v, out_m, out_e);
+}
+void pgk_launch_transition_single(double d, uint32_t H, int uniform, double* out3, hipStream_t s) {
+    hipLaunchKernelGGL(k_transition_single, dim3(1), dim3(64), 0, s, d, H, uniform, out3);
+}
+uint32_t pgk_threads_for_hp(uint32_t hp) {
+    switch (hp) { case 16: return 64; case 32: return 64; case 64: return 256; case 128: return 512; default: return 0; }
+}
+
+}  // extern "C"

@@ -1,0 +1,209 @@
+"""Python face of the C ABI (include/pangenie_hmm.h): ProbabilityTable, HMM runs, resident jobs.
+
+All compute happens in libpangenie_hmm.so (HIP kernels, gfx950).  This module only
+marshals numpy arrays and rebuilds the reference's `long double` likelihoods from
+(lik, lik_exp) — `np.longdouble` is the x87 80-bit type on x86-64.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import List, Optional, Sequence
+
+import numpy as np
+
+from . import _lib
+from ._lib import (PG_N_KERNEL_CLASSES, PgContigBatch, PgContigResult, PgHmmParams, f64p, i32p,
+                   ldp, u8p, u16p, u64p)
+from .genotyping_result import GenotypingResult, results_from_flat
+from .panel import ContigBatch
+
+LD = np.longdouble
+_ERRLEN = 512
+
+
+class PanGenieError(RuntimeError):
+    def __init__(self, code: int, msg: str):
+        super().__init__(f"[{code}] {msg}")
+        self.code = code
+
+
+def make_params(recombrate: float = 1.26, uniform: bool = False, effective_N=25000.0,
+                run_genotyping: bool = True, run_phasing: bool = False) -> PgHmmParams:
+    """HMM constructor arguments (reference src/hmm.hpp:38)."""
+    p = PgHmmParams()
+    p.effective_N = LD(effective_N)
+    p.recombrate = float(recombrate)
+    p.uniform = int(bool(uniform))
+    p.run_genotyping = int(bool(run_genotyping))
+    p.run_phasing = int(bool(run_phasing))
+    return p
+
+
+class ProbabilityTable:
+    """Mirror of the reference ProbabilityTable (src/probabilitytable.hpp:13-29)."""
+
+    def __init__(self, cov_min: int = 0, cov_max: int = 0, count_max: int = 0,
+                 regularization=0.0, default: bool = False):
+        self._lib = _lib.load_hip()
+        if default:
+            self.h = self._lib.pg_table_create_default()
+        else:
+            self.h = self._lib.pg_table_create(cov_min, cov_max, count_max, LD(regularization))
+        if not self.h:
+            raise MemoryError("pg_table_create failed")
+
+    def modify(self, coverage: int, count: int, p0, p1, p2) -> None:
+        rc = self._lib.pg_table_modify(self.h, coverage, count, LD(p0), LD(p1), LD(p2))
+        if rc:
+            raise RuntimeError("ProbabilityTable::modify_probability: no precomputed values for these parameters.")
+
+    def get(self, coverage: int, count: int) -> np.ndarray:
+        out = (C.c_longdouble * 3)()
+        self._lib.pg_table_get(self.h, coverage, count, out)
+        return np.array([out[0], out[1], out[2]], dtype=LD)
+
+    def __del__(self):
+        try:
+            if self.h:
+                self._lib.pg_table_destroy(self.h)
+                self.h = None
+        except Exception:
+            pass
+
+
+class ContigResult:
+    """Host buffers of one pg_contig_result + long double reconstruction."""
+
+    def __init__(self, batch: ContigBatch):
+        V = batch.n_variants
+        self.batch = batch
+        self.geno_off = batch.geno_off
+        n = int(self.geno_off[-1])
+        self.lik = np.zeros(max(n, 1), np.float64)[:n]
+        self.lik_exp = np.zeros(max(V, 1), np.int32)[:V]
+        self.kept = np.zeros(max(V, 1), np.uint8)[:V]
+        nA = int(batch.allele_off[-1]) if V else 0
+        self.allele_present = np.zeros(max(nA, 1), np.uint8)[:nA]
+        self.n_kmers = np.zeros(max(V, 1), np.uint16)[:V]
+        self.coverage = np.zeros(max(V, 1), np.uint16)[:V]
+        self.n_columns = 0
+        self._c = PgContigResult()
+        self._c.lik = self.lik.ctypes.data_as(f64p)
+        self._c.lik_exp = self.lik_exp.ctypes.data_as(i32p)
+        self._c.kept = self.kept.ctypes.data_as(u8p)
+        self._c.allele_present = self.allele_present.ctypes.data_as(u8p)
+        self._c.n_kmers = self.n_kmers.ctypes.data_as(u16p)
+        self._c.coverage = self.coverage.ctypes.data_as(u16p)
+
+    def likelihoods_ld(self) -> np.ndarray:
+        """Unnormalised genotype likelihoods as 80-bit long double: lik * 2^lik_exp."""
+        G = np.diff(self.geno_off.astype(np.int64))
+        ex = np.repeat(self.lik_exp.astype(np.int64), G)
+        return np.ldexp(self.lik.astype(LD), ex)
+
+    def genotyping_results(self) -> List[GenotypingResult]:
+        return results_from_flat(self.batch, self.likelihoods_ld(), self.kept, self.allele_present,
+                                 self.n_kmers, self.coverage)
+
+
+def genotype_contig(batch: ContigBatch, table: ProbabilityTable, params: Optional[PgHmmParams] = None,
+                    device: int = 0) -> ContigResult:
+    """One blocking call = the body of HMM::HMM for one (contig, path subset)
+    (reference src/hmm.cpp:25-63 with normalize=false, as run_genotyping calls it,
+    src/commands.cpp:160)."""
+    lib = _lib.load_hip()
+    params = params or make_params()
+    res = ContigResult(batch)
+    err = C.create_string_buffer(_ERRLEN)
+    rc = lib.pg_hmm_genotype_contig(C.byref(batch.as_c()), table.h, C.byref(params), device,
+                                    C.byref(res._c), err, _ERRLEN)
+    if rc:
+        raise PanGenieError(rc, err.value.decode(errors="replace"))
+    res.n_columns = int(res._c.n_columns)
+    return res
+
+
+class Job:
+    """Resident multi-contig job: upload once, run many times (bench / pipelines)."""
+
+    def __init__(self, batches: Sequence[ContigBatch], table: ProbabilityTable,
+                 params: Optional[PgHmmParams] = None, device: int = 0):
+        self._lib = _lib.load_hip()
+        self.batches = list(batches)
+        self.table = table
+        self.params = params or make_params()
+        arr = (PgContigBatch * len(self.batches))(*[b.as_c() for b in self.batches])
+        err = C.create_string_buffer(_ERRLEN)
+        self.h = self._lib.pg_job_create(device, len(self.batches), arr, table.h, C.byref(self.params),
+                                         err, _ERRLEN)
+        if not self.h:
+            raise PanGenieError(_lib.PG_ERR_DEVICE, err.value.decode(errors="replace"))
+
+    def run(self, stream: int = 0) -> None:
+        err = C.create_string_buffer(_ERRLEN)
+        rc = self._lib.pg_job_run(self.h, C.c_void_p(stream) if stream else None, err, _ERRLEN)
+        if rc:
+            raise PanGenieError(rc, err.value.decode(errors="replace"))
+
+    def fetch(self, contig: int) -> ContigResult:
+        res = ContigResult(self.batches[contig])
+        err = C.create_string_buffer(_ERRLEN)
+        rc = self._lib.pg_job_fetch(self.h, contig, C.byref(res._c), err, _ERRLEN)
+        if rc:
+            raise PanGenieError(rc, err.value.decode(errors="replace"))
+        res.n_columns = int(res._c.n_columns)
+        return res
+
+    def device_results(self, contig: int):
+        """(lik_ptr, n_lik, lik_exp_ptr, n_variants): device pointers for an RCCL gather."""
+        d_lik, d_exp = C.c_void_p(), C.c_void_p()
+        n_lik, n_var = C.c_uint64(), C.c_uint64()
+        self._lib.pg_job_device_results(self.h, contig, C.byref(d_lik), C.byref(n_lik),
+                                        C.byref(d_exp), C.byref(n_var))
+        return d_lik.value, n_lik.value, d_exp.value, n_var.value
+
+    def kernel_ms(self) -> dict:
+        ms = (C.c_double * PG_N_KERNEL_CLASSES)()
+        self._lib.pg_job_kernel_ms(self.h, ms)
+        return {self._lib.pg_job_kernel_name(i).decode(): ms[i] for i in range(PG_N_KERNEL_CLASSES)}
+
+    def device_bytes(self) -> int:
+        return int(self._lib.pg_job_device_bytes(self.h))
+
+    def close(self):
+        if getattr(self, "h", None):
+            self._lib.pg_job_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def emission_table(batch: ContigBatch, table: ProbabilityTable, v: int, device: int = 0):
+    """EmissionProbabilityComputer of variant v on the device (A x A over all allele slots)."""
+    lib = _lib.load_hip()
+    A = int(batch.allele_off[v + 1] - batch.allele_off[v])
+    out = np.zeros(A * A, dtype=LD)
+    az = C.c_int32(0)
+    err = C.create_string_buffer(_ERRLEN)
+    rc = lib.pg_emission_table(C.byref(batch.as_c()), table.h, v, device, out.ctypes.data_as(ldp),
+                               C.byref(az), err, _ERRLEN)
+    if rc:
+        raise PanGenieError(rc, err.value.decode(errors="replace"))
+    return out.reshape(A, A), bool(az.value)
+
+
+def transition_probs(from_pos: int, to_pos: int, recombrate: float, nr_paths: int, uniform: bool,
+                     effective_N, device: int = 0) -> np.ndarray:
+    """TransitionProbabilityComputer on the device: {no switch, one switch, two switches}."""
+    lib = _lib.load_hip()
+    out = (C.c_double * 3)()
+    err = C.create_string_buffer(_ERRLEN)
+    rc = lib.pg_transition_probs(from_pos, to_pos, recombrate, nr_paths, int(uniform), LD(effective_N),
+                                 device, out, err, _ERRLEN)
+    if rc:
+        raise PanGenieError(rc, err.value.decode(errors="replace"))
+    return np.array([out[0], out[1], out[2]])

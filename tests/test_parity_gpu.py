@@ -1,0 +1,265 @@
+"""Parity tests proper (need a MI355X): HIP path through the C ABI vs
+  (1) the reference's own known-answer vectors (tests/golden/), tolerance 1e-7 absolute
+      like the reference's tests (reference tests/utils.cpp:9-11);
+  (2) the CPU oracle on seeded synthetic panels: <= 1e-6 relative on every unnormalised
+      genotype likelihood, identical genotype calls (BASELINE.json north_star);
+  (3) size-independent properties at BASELINE.json's full single-GPU size.
+"""
+import numpy as np
+import pytest
+
+from pangenie_amd import hmm
+from pangenie_amd.genotyping_result import normalized_bins
+from pangenie_amd.panel import default_table_args, flatten, synthetic_panel
+from tests.fixtures_util import build_batch, build_variant, fill_table, triple
+from tests.parity_util import assert_parity, calls, rel_errors
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-7
+
+
+@pytest.fixture(scope="module")
+def orc():
+    from oracle import pyoracle
+    return pyoracle
+
+
+def hip_table(spec, orc):
+    t = hmm.ProbabilityTable(default=True) if spec["default"] else hmm.ProbabilityTable(*spec["args"])
+    return fill_table(t, spec, orc.copynumber_regularized)
+
+
+def oracle_table(spec, orc):
+    t = orc.OracleTable(default=True) if spec["default"] else orc.OracleTable(*spec["args"])
+    return fill_table(t, spec, orc.copynumber_regularized)
+
+
+def run_case(case, orc):
+    batch = build_batch(case["variants"], case["hmm"]["only_paths"])
+    h = case["hmm"]
+    res = hmm.genotype_contig(batch, hip_table(case["table"], orc),
+                              hmm.make_params(h["recombrate"], h["uniform"], h["effective_N"]))
+    return batch, res
+
+
+def test_device_visible():
+    assert hmm._lib.load_hip().pg_hmm_device_count() >= 1
+
+
+def test_hmm_known_answers(golden, orc):
+    for case in golden["hmm"]:
+        batch, res = run_case(case, orc)
+        out = res.genotyping_results()
+        if case["hmm"]["normalize"]:
+            for g in out:
+                g.normalize()
+        got = [triple(g) for g in out]
+        assert np.allclose(got, case["expected_likelihoods"], rtol=0, atol=TOL), (case["name"], got)
+        if "expected_coverage" in case:
+            assert [g.coverage() for g in out] == case["expected_coverage"]
+            assert [g.nr_unique_kmers() for g in out] == case["expected_n_kmers"]
+        if "expected_specific" in case:
+            spec = [triple(g.get_specific_likelihoods(d)) for g, d in zip(out, case["defined_alleles"])]
+            assert np.allclose(spec, case["expected_specific"], rtol=0, atol=TOL), case["name"]
+        if "expected_gt" in case:
+            assert [list(g.get_likeliest_genotype()) for g in out] == case["expected_gt"]
+        if "expected_after_normalize" in case:
+            for g in out:
+                g.normalize()
+            assert np.allclose([triple(g) for g in out], case["expected_after_normalize"], rtol=0, atol=TOL)
+        # and bin-for-bin against the oracle
+        h = case["hmm"]
+        ref = orc.genotype_contig(batch, oracle_table(case["table"], orc),
+                                  orc.make_params(h["recombrate"], h["uniform"], h["effective_N"]))
+        assert_parity(batch, res, ref)
+
+
+def test_hmm_combine(golden, orc):
+    by_name = {c["name"]: c for c in golden["hmm"]}
+    a = run_case(by_name[golden["combine"]["first"]], orc)[1].genotyping_results()
+    b = run_case(by_name[golden["combine"]["second"]], orc)[1].genotyping_results()
+    for g in a + b:
+        g.normalize()
+    expect = [np.add(triple(x), triple(y)) for x, y in zip(a, b)]
+    for x, y in zip(a, b):
+        x.combine(y)
+    assert np.allclose([triple(x) for x in a], expect, rtol=0, atol=TOL)
+
+
+def test_emission_known_answers(golden, orc):
+    for case in golden["emission"]:
+        batch = flatten([build_variant(case["variant"])])
+        E, _ = hmm.emission_table(batch, hip_table(case["table"], orc), 0)
+        ids = list(batch.allele_id)
+        for key, val in case["expected"].items():
+            a, b = (int(x) for x in key.split(","))
+            assert abs(float(E[ids.index(a), ids.index(b)]) - val) < TOL, (case["name"], key)
+
+
+def test_transition_known_answers(golden):
+    for c in golden["transition"]:
+        t = hmm.transition_probs(c["from"], c["to"], c["recombrate"], c["nr_paths"], c["uniform"], c["effective_N"])
+        q = c["recomb_prob"]
+        p = q + c["no_recomb_minus_recomb"]
+        assert np.allclose(t, [p * p, p * q, q * q], rtol=0, atol=TOL)
+    assert list(hmm.transition_probs(1, 2, 1.26, 5, True, 0.25)) == [1.0, 1.0, 1.0]
+
+
+def test_emission_vs_oracle_on_the_fly_entries(orc):
+    # coverage / counts outside the precomputed box exercise the device's closed form
+    b = synthetic_panel(40, 6, 24, seed=11, multiallelic_frac=0.5, undefined_frac=0.3)
+    b.kmer_count[::7] = 300
+    b.kmer_count[3::11] = 2000
+    b.coverage[::5] = 3
+    b.coverage[1::9] = 400
+    args = default_table_args()
+    th, to = hmm.ProbabilityTable(*args), orc.OracleTable(*args)
+    for v in range(0, b.n_variants, 3):
+        Eh, zh = hmm.emission_table(b, th, v)
+        Eo, zo = orc.emission_table(b, to, v)
+        assert zh == zo
+        den = np.maximum(np.abs(Eh), np.abs(Eo))
+        rel = np.where(den > 0, np.abs(Eh - Eo) / np.where(den > 0, den, 1), 0)
+        assert float(rel.max()) < 1e-9, (v, float(rel.max()))
+
+
+PANELS = [
+    # V, H, K, multiallelic, kwargs
+    (3000, 16, 20, 0.0, {}),
+    (1500, 13, 20, 0.0, {}),
+    (64, 1, 20, 0.0, {}),
+    (700, 2, 12, 0.0, {}),
+    (800, 32, 20, 0.0, {}),
+    (500, 27, 30, 0.3, {}),
+    (600, 64, 20, 0.0, {}),
+    (400, 50, 24, 0.3, {}),
+    (150, 128, 20, 0.0, {}),
+    (120, 100, 20, 0.2, {}),
+    (1000, 16, 40, 0.4, {"undefined_frac": 0.2, "zero_kmer_frac": 0.2}),
+    (1, 16, 20, 0.0, {}), (2, 16, 20, 0.0, {}), (3, 64, 20, 0.0, {}), (4, 64, 20, 0.0, {}), (5, 128, 20, 0.0, {}),
+]
+
+
+@pytest.mark.parametrize("V,H,K,multi,kw", PANELS)
+def test_panels_vs_oracle(V, H, K, multi, kw, orc):
+    b = synthetic_panel(V, H, K, seed=1000 + V + H, multiallelic_frac=multi, **kw)
+    args = default_table_args()
+    res = hmm.genotype_contig(b, hmm.ProbabilityTable(*args), hmm.make_params(1.26, False, 1e-5))
+    ref = orc.genotype_contig(b, orc.OracleTable(*args), orc.make_params(1.26, False, 1e-5))
+    assert_parity(b, res, ref)
+
+
+@pytest.mark.parametrize("recomb,uniform,N", [(1.26, True, 1e-5), (0.0, False, 1e-5), (446.287102628, False, 0.25),
+                                              (1.26, False, 25000.0)])
+def test_transition_regimes_vs_oracle(recomb, uniform, N, orc):
+    b = synthetic_panel(400, 24, 16, seed=77, multiallelic_frac=0.2)
+    args = default_table_args()
+    res = hmm.genotype_contig(b, hmm.ProbabilityTable(*args), hmm.make_params(recomb, uniform, N))
+    ref = orc.genotype_contig(b, orc.OracleTable(*args), orc.make_params(recomb, uniform, N))
+    assert_parity(b, res, ref)
+
+
+def test_unregularized_table_zero_emissions_vs_oracle(orc):
+    # regularization 0: exact zeros appear, forward/backward uniform fallbacks and all_zeros fire
+    b = synthetic_panel(600, 16, 20, seed=5)
+    b.kmer_count[::3] = 0
+    b.kmer_count[1::17] = 60000
+    args = (6, 108, 54, 0.0)
+    res = hmm.genotype_contig(b, hmm.ProbabilityTable(*args), hmm.make_params(1.26, False, 1e-5))
+    ref = orc.genotype_contig(b, orc.OracleTable(*args), orc.make_params(1.26, False, 1e-5))
+    assert_parity(b, res, ref)
+
+
+def test_emission_dominated_corner_vs_oracle(orc):
+    # many k-mers per allele (K = 32 per allele, multiallelic): emission scale ~1e-150 per column
+    b = synthetic_panel(300, 16, 160, seed=9, multiallelic_frac=1.0)
+    args = default_table_args()
+    res = hmm.genotype_contig(b, hmm.ProbabilityTable(*args), hmm.make_params(1.26, False, 1e-5))
+    ref = orc.genotype_contig(b, orc.OracleTable(*args), orc.make_params(1.26, False, 1e-5))
+    assert_parity(b, res, ref)
+
+
+def test_no_columns_and_empty(orc):
+    b = synthetic_panel(50, 8, 10, seed=2)
+    b.path_allele[:] = 0  # every selected path carries the reference allele -> no columns
+    args = default_table_args()
+    res = hmm.genotype_contig(b, hmm.ProbabilityTable(*args), hmm.make_params())
+    ref = orc.genotype_contig(b, orc.OracleTable(*args), orc.make_params())
+    assert res.n_columns == 0 == ref.n_columns
+    assert_parity(b, res, ref)
+    assert not res.n_kmers.any() and not res.coverage.any()  # reference src/hmm.cpp:94
+
+
+def test_multi_contig_job_matches_single_calls(orc):
+    args = default_table_args()
+    t = hmm.ProbabilityTable(*args)
+    p = hmm.make_params(1.26, False, 1e-5)
+    batches = [synthetic_panel(300 + 50 * i, H, 20, seed=40 + i) for i, H in enumerate([16, 64, 64, 32, 16, 128])]
+    job = hmm.Job(batches, t, p)
+    job.run()
+    job.run()  # re-running a resident job must give the same answer
+    for i, b in enumerate(batches):
+        multi = job.fetch(i)
+        ref = orc.genotype_contig(b, orc.OracleTable(*args), orc.make_params(1.26, False, 1e-5))
+        assert_parity(b, multi, ref)
+        single = hmm.genotype_contig(b, t, p)
+        assert (single.lik == multi.lik).all() and (single.lik_exp == multi.lik_exp).all()  # deterministic
+    job.close()
+
+
+def test_limits_are_reported_not_silently_wrong():
+    b = synthetic_panel(20, 200, 10, seed=1)
+    with pytest.raises(hmm.PanGenieError) as e:
+        hmm.genotype_contig(b, hmm.ProbabilityTable(*default_table_args()), hmm.make_params())
+    assert e.value.code == hmm._lib.PG_ERR_UNSUPPORTED
+
+
+def test_full_size_properties():
+    """BASELINE.json configs[2] shape (200k variants x 64 haplotypes): size-independent checks.
+    (a) determinism; (b) normalised posteriors sum to 1; (c) reversibility: the Li-Stephens
+    chain with uniform start is time-reversible, so genotyping the mirrored contig must give
+    the same normalised posteriors for every variant."""
+    V, H = 200_000, 64
+    b = synthetic_panel(V, H, 20, seed=12345)
+    t = hmm.ProbabilityTable(*default_table_args())
+    p = hmm.make_params(1.26, False, 1e-5)
+    job = hmm.Job([b], t, p)
+    job.run()
+    r1 = job.fetch(0)
+    job.run()
+    r2 = job.fetch(0)
+    job.close()
+    assert (r1.lik == r2.lik).all() and (r1.lik_exp == r2.lik_exp).all()
+    n1 = normalized_bins(b, r1.likelihoods_ld())
+    G = np.diff(b.geno_off.astype(np.int64))
+    sums = np.add.reduceat(n1, b.geno_off[:-1].astype(np.int64))
+    kept = r1.kept.astype(bool)
+    assert np.allclose(sums[kept].astype(float), 1.0, atol=1e-12)
+    assert r1.n_columns == int(kept.sum()) > 0.9 * V
+
+    # mirrored contig
+    pos = b.variant_pos.astype(np.int64)
+    rev = synthetic_panel(1, H, 20, seed=1)  # container
+    idx = np.arange(V)[::-1]
+    K = np.diff(b.kmer_off.astype(np.int64)); A = np.diff(b.allele_off.astype(np.int64))
+    def regroup(arr, off, n):
+        parts = np.split(arr, off[1:-1].astype(np.int64))
+        return np.concatenate([parts[i] for i in idx]) if len(parts) else arr
+    from pangenie_amd.panel import ContigBatch
+    koff = np.zeros(V + 1, np.uint32); np.cumsum(K[idx], out=koff[1:])
+    aoff = np.zeros(V + 1, np.uint32); np.cumsum(A[idx], out=aoff[1:])
+    rb = ContigBatch(H, (pos.max() - pos[idx] + 10000).astype(np.uint64), b.coverage[idx], koff,
+                     regroup(b.kmer_count, b.kmer_off, V), aoff, regroup(b.allele_id, b.allele_off, V),
+                     regroup(b.allele_flags, b.allele_off, V), regroup(b.allele_kmer_off, b.allele_off, V),
+                     regroup(b.allele_kmer_mask, b.allele_off, V),
+                     b.path_allele.reshape(V, H)[idx].reshape(-1))
+    rr = hmm.genotype_contig(rb, t, p)
+    nr = normalized_bins(rb, rr.likelihoods_ld())
+    # map reversed bins back to forward order
+    goff_r = rb.geno_off.astype(np.int64)
+    parts = np.split(nr, goff_r[1:-1])
+    back = np.concatenate([parts[V - 1 - v] for v in range(V)])
+    rel = rel_errors(b, back, n1)
+    big = n1 > 1e-200
+    assert float(rel[big].max()) < 1e-6, float(rel[big].max())
+    assert (calls(b, back) == calls(b, n1)).all()
