@@ -77,6 +77,7 @@ struct DevContig {
     uint8_t*  colrec;
     double*   fwd;
     double*   part;
+    uint8_t*  fwd_fallback;  // [V] column c fell back to the uniform forward column (fsum := 1, no emission scale)
     uint32_t* err;
     // outputs
     double*   lik;

@@ -82,8 +82,13 @@ DEVI uint32_t wave_or_u32(uint32_t v) {
 // ------------------------------------------------------------------------------------------
 //  ProbabilityTable lookups as (mantissa, exponent) pairs
 // ------------------------------------------------------------------------------------------
+// Smallest exponent the reference's 80-bit long double can hold (denormal minimum 2^-16445):
+// anything below is an exact 0 there, and exact zeros matter (all_zeros rule, uniform
+// fallbacks), so the wider (mantissa, exponent) representation flushes at the same point.
+#define PG_LD_MIN_EXP (-16444)
+
 DEVI void from_log2(double L, double& m, int& e) {
-    if (L == -INFINITY) { m = 0.0; e = 0; return; }
+    if (L == -INFINITY || L < (double)(PG_LD_MIN_EXP - 1)) { m = 0.0; e = 0; return; }
     if (!(L == L) || L == INFINITY) { m = L; e = 0; return; }
     double fl = floor(L);
     e = (int)fl + 1;
@@ -207,6 +212,7 @@ DEVI void emission_pair_products(const DevContig& dc, const DevTable& tab, uint3
             double mm; int ee;
             split(pm, mm, ee);
             pm = mm; pe += ee;
+            if (pe < PG_LD_MIN_EXP) { pm = 0.0; pe = 0; }  // underflows to 0 in the reference too
         }
         wave_sync();
     }
@@ -548,6 +554,9 @@ __global__ __launch_bounds__(HP * HP / R) void k_forward(const DevContig* __rest
 #pragma unroll
             for (int k = 0; k < R; ++k) x[k] = (j < H && i0 + k < H) ? unif : 0.0;
             store_col(cprev, x);
+            // alpha_hat*fsum = 1/H^2 is an absolute value: it does not carry the emission
+            // exponent X_c of this column; k_bins drops X_c for flagged columns.
+            if (tid == 0) dc.fwd_fallback[cprev] = 1;
             Cj = j < H ? (double)H * unif : 0.0;
             Crow = (rb + lane) < H ? (double)H * unif : 0.0;
             S = 1.0;
@@ -798,7 +807,7 @@ __global__ __launch_bounds__(256) void k_bins(const DevContig* __restrict__ cont
         }
     }
     if (lane == 0) {
-        int X = *(const int32_t*)(rec + PG_REC_EXP);
+        int X = dc.fwd_fallback[c] ? 0 : *(const int32_t*)(rec + PG_REC_EXP);
         if (c + 1 < C) X += *(const int32_t*)(dc.colrec + (size_t)(c + 1) * dc.RB + PG_REC_EXP);
         dc.lik_exp[v] = X;
     }

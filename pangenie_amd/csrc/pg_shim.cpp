@@ -315,7 +315,7 @@ extern "C" pg_job* pg_job_create(int device, uint32_t n_contigs, const pg_contig
     job->contigs.resize(n_contigs);
     size_t off = 0;
     auto take = [&](size_t bytes) { size_t o = off; off = align_up(off + (bytes ? bytes : 8)); return o; };
-    struct Plan { size_t pos, cov, koff, kcnt, aoff, aid, aflag, akoff, akmask, pa, goff, vrec, cvar, colrec, fwd, part, kept, apres, lik, likexp; };
+    struct Plan { size_t fback, pos, cov, koff, kcnt, aoff, aid, aflag, akoff, akmask, pa, goff, vrec, cvar, colrec, fwd, part, kept, apres, lik, likexp; };
     std::vector<Plan> plan(n_contigs);
     const size_t o_contigs = take(sizeof(DevContig) * n_contigs);
     // zeroed-every-run block: n_cols, err, then per contig kept / allele_present / lik / lik_exp
@@ -332,6 +332,7 @@ extern "C" pg_job* pg_job_create(int device, uint32_t n_contigs, const pg_contig
         for (uint32_t v = 0; v < c.V; ++v) { uint64_t A = b.allele_off[v + 1] - b.allele_off[v]; nl += A * (A + 1) / 2; }
         c.n_lik = nl;
         plan[i].kept = take(c.V);
+        plan[i].fback = take(c.V);
         plan[i].apres = take(c.sumA);
         plan[i].lik = take(nl * sizeof(double));
         plan[i].likexp = take((size_t)c.V * sizeof(int32_t));
@@ -386,7 +387,7 @@ extern "C" pg_job* pg_job_create(int device, uint32_t n_contigs, const pg_contig
         d.geno_off = (const uint64_t*)(A + p.goff);
         d.vrec = A + p.vrec; d.kept = A + p.kept; d.allele_present = A + p.apres;
         d.n_cols = job->d_ncols + i; d.col_variant = (uint32_t*)(A + p.cvar); d.colrec = A + p.colrec;
-        d.fwd = (double*)(A + p.fwd); d.part = (double*)(A + p.part); d.err = job->d_err + i;
+        d.fwd = (double*)(A + p.fwd); d.part = (double*)(A + p.part); d.fwd_fallback = A + p.fback; d.err = job->d_err + i;
         d.lik = (double*)(A + p.lik); d.lik_exp = (int32_t*)(A + p.likexp);
         c.d = d;
         if (c.V == 0) continue;
