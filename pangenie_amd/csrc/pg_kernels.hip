@@ -437,16 +437,28 @@ __global__ __launch_bounds__(256) void k_records(const DevContig* __restrict__ c
 
 // ------------------------------------------------------------------------------------------
 //  chain kernels
+//
+//  Workgroup = T compute threads + one LOADER wave (the last wave).  VMEM counters are per
+//  wave, so the split keeps every wait off the recursion's critical path:
+//    * compute waves of k_forward only STORE (the forward column) and never wait on VMEM;
+//    * compute waves of k_backward only LOAD (the prefetched forward column);
+//    * the loader wave streams the column records HBM -> LDS two columns ahead and, in
+//      k_backward, drains the posterior partials LDS -> HBM.
+//  The per-column workgroup barrier orders LDS only (no vmcnt wait).
 // ------------------------------------------------------------------------------------------
 template <int HP, int R>
 struct ChainCfg {
-    static constexpr int T = HP * HP / R;
+    static constexpr int T = HP * HP / R;      // compute threads
+    // HP = 128 keeps its 8 compute waves at 2 waves/SIMD (256 VGPRs): a 9th wave would cut the
+    // register budget to 168 and spill, so there wave 0 does the loader's work inline.
+    static constexpr bool LOADER = HP < 128;
+    static constexpr int TT = T + (LOADER ? 64 : 0);
     static constexpr int NRG = HP / R;
-    static constexpr int NW = T / 64;
+    static constexpr int NW = T / 64;          // compute waves
     static constexpr bool UNI = HP >= 64;
     static constexpr int RB = (PG_REC_ALLELES + HP + 63) & ~63;
     static constexpr int WORDS = RB / 8;
-    static_assert(T % 64 == 0 && T <= 1024, "bad workgroup size");
+    static_assert(T % 64 == 0 && TT <= 1024, "bad workgroup size");
     static_assert(WORDS <= 64, "record must fit one wave-wide 8-byte load");
 };
 
@@ -458,6 +470,18 @@ struct ChainShared {
     double wsum[2][Cfg::NW];
     double u[HP];
 };
+
+// workgroup barrier that orders LDS traffic only (global stores/loads stay in flight)
+DEVI void lds_barrier() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+}
+DEVI void lds_wave_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+}
 
 // emission of state (i, j) from a staged record: E[a_i][a_j]; phantom paths (255) hit the
 // zero row/column PG_AMAX of the expanded table.
@@ -474,7 +498,7 @@ DEVI uint32_t col_allele(const unsigned char* rec, uint32_t j) {
 }
 
 // u_i of row i.  UNI: every wave holds the u vector of the 64-column block that contains its
-// rows (urow) and the row is wave-uniform -> v_readlane.  !UNI (single wave): via LDS.
+// rows (urow) and the row is wave-uniform -> v_readlane.  !UNI (single compute wave): via LDS.
 template <bool UNI>
 DEVI double row_value(const double* lds_u, double urow, uint32_t i) {
     if (UNI) return readlane_f64(urow, __builtin_amdgcn_readfirstlane((int)(i & 63u)));
@@ -482,7 +506,7 @@ DEVI double row_value(const double* lds_u, double urow, uint32_t i) {
 }
 
 template <int HP, int R>
-__global__ __launch_bounds__(HP * HP / R) void k_forward(const DevContig* __restrict__ contigs) {
+__global__ __launch_bounds__((ChainCfg<HP, R>::TT)) void k_forward(const DevContig* __restrict__ contigs) {
     using Cfg = ChainCfg<HP, R>;
     __shared__ ChainShared<HP, R> sh;
     const DevContig& dc = contigs[blockIdx.x];
@@ -491,21 +515,43 @@ __global__ __launch_bounds__(HP * HP / R) void k_forward(const DevContig* __rest
     if (C == 0) return;
     const uint32_t tid = threadIdx.x, lane = tid & 63u;
     const uint32_t wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const unsigned char* colrec = dc.colrec;
+
+    auto rec_load = [&](uint32_t c) -> uint64_t {
+        if (lane < (uint32_t)Cfg::WORDS && c < C) return ((const uint64_t*)(colrec + (size_t)c * Cfg::RB))[lane];
+        return 0ull;
+    };
+    auto rec_stage = [&](uint32_t c, uint64_t w) {
+        if (lane < (uint32_t)Cfg::WORDS) ((uint64_t*)sh.rec[c & 3u])[lane] = w;
+    };
+    if (Cfg::LOADER && wave == (uint32_t)Cfg::NW) {
+        // ------------------------------- loader wave ---------------------------------
+        rec_stage(0, rec_load(0));
+        rec_stage(1, rec_load(1));
+        uint64_t tE = rec_load(2), tO = rec_load(3);
+        lds_barrier();  // records 0,1 staged
+        lds_barrier();  // column 0 done
+        for (uint32_t c = 1; c < C; c += 2) {
+            rec_stage(c + 1, tE);  // loaded two columns ago
+            tE = rec_load(c + 3);
+            lds_barrier();
+            if (c + 1 < C) {
+                rec_stage(c + 2, tO);
+                tO = rec_load(c + 4);
+                lds_barrier();
+            }
+        }
+        return;
+    }
+
+    // --------------------------------- compute waves -------------------------------------
     const uint32_t j = tid % HP, rg = tid / HP, i0 = rg * R;
     const uint32_t H = dc.H;
     const double unif = 1.0 / ((double)H * (double)H);
-    const unsigned char* colrec = dc.colrec;
     double* fwd = dc.fwd;
     const size_t colsz = (size_t)HP * HP;
     const uint32_t rb = (i0 / 64u) * 64u;  // first column of the 64-block that contains my rows (UNI)
 
-    auto rec_load = [&](uint32_t c) -> uint64_t {
-        if (tid < (uint32_t)Cfg::WORDS && c < C) return ((const uint64_t*)(colrec + (size_t)c * Cfg::RB))[tid];
-        return 0ull;
-    };
-    auto rec_stage = [&](uint32_t c, uint64_t w) {
-        if (tid < (uint32_t)Cfg::WORDS) ((uint64_t*)sh.rec[c & 3u])[tid] = w;
-    };
     auto store_col = [&](uint32_t c, const double (&x)[R]) {
         double* dst = fwd + (size_t)c * colsz + (size_t)i0 * HP + j;
 #pragma unroll
@@ -514,12 +560,14 @@ __global__ __launch_bounds__(HP * HP / R) void k_forward(const DevContig* __rest
 
     double x[R];
     double Cj = 0.0, Crow = 0.0, S = 0.0;
+    uint64_t tq = 0;  // inline loader (no loader wave): record c+2 in flight
+    if (!Cfg::LOADER && wave == 0) {
+        rec_stage(0, rec_load(0));
+        rec_stage(1, rec_load(1));
+        tq = rec_load(2);
+    }
 
-    // prologue: records 0 and 1 -> LDS, 2 and 3 in flight
-    rec_stage(0, rec_load(0));
-    rec_stage(1, rec_load(1));
-    uint64_t tE = rec_load(2), tO = rec_load(3);
-    __syncthreads();
+    lds_barrier();  // records 0,1 staged by the loader
 
     // column 0: v_0 = e_0 (reference src/hmm.cpp:236-238, previous_cell = 1)
     {
@@ -532,7 +580,7 @@ __global__ __launch_bounds__(HP * HP / R) void k_forward(const DevContig* __rest
         const double ws = wave_sum(part);
         if (lane == 0) sh.wsum[0][wave] = ws;
     }
-    __syncthreads();
+    lds_barrier();
 
     // sums of column cprev; uniform fallback if the column summed to zero (hmm.cpp:253-267)
     auto finalize = [&](uint32_t cprev) {
@@ -563,7 +611,7 @@ __global__ __launch_bounds__(HP * HP / R) void k_forward(const DevContig* __rest
         }
     };
 
-    auto step = [&](uint32_t c, uint64_t& tnext) {
+    for (uint32_t c = 1; c < C; ++c) {
         finalize(c - 1);
         const unsigned char* rec = sh.rec[c & 3u];
         const double c0 = *(const double*)(rec + PG_REC_C0);
@@ -575,7 +623,7 @@ __global__ __launch_bounds__(HP * HP / R) void k_forward(const DevContig* __rest
         const double urow = fma(k1, Crow, hk2);
         if (!Cfg::UNI) {
             if (rg == 0) sh.u[j] = uj;
-            __syncthreads();
+            lds_wave_sync();
         }
         const uint32_t aj = col_allele(rec, j);
         double part = 0.0;
@@ -590,14 +638,11 @@ __global__ __launch_bounds__(HP * HP / R) void k_forward(const DevContig* __rest
         sh.psum[c & 1u][rg][j] = part;
         const double ws = wave_sum(part);
         if (lane == 0) sh.wsum[c & 1u][wave] = ws;
-        rec_stage(c + 1, tnext);   // loaded two steps ago
-        tnext = rec_load(c + 3);
-        __syncthreads();
-    };
-
-    for (uint32_t c = 1; c < C; c += 2) {
-        step(c, tE);                    // stages column c+1 (even)
-        if (c + 1 < C) step(c + 1, tO); // stages column c+2 (odd)
+        if (!Cfg::LOADER && wave == 0) {
+            rec_stage(c + 1, tq);  // loaded one column ago
+            tq = rec_load(c + 2);
+        }
+        lds_barrier();
     }
     finalize(C - 1);
 }
@@ -605,32 +650,69 @@ __global__ __launch_bounds__(HP * HP / R) void k_forward(const DevContig* __rest
 // VBUF = number of forward-column register buffers (prefetch distance in columns)
 // KEEPW = keep w = beta_hat*e in registers across the column-sum exchange (else recompute it)
 template <int HP, int R, int VBUF, bool KEEPW>
-__global__ __launch_bounds__(HP * HP / R) void k_backward(const DevContig* __restrict__ contigs) {
+__global__ __launch_bounds__((ChainCfg<HP, R>::TT)) void k_backward(const DevContig* __restrict__ contigs) {
     using Cfg = ChainCfg<HP, R>;
     __shared__ ChainShared<HP, R> sh;
+    __shared__ double s_pout[Cfg::LOADER ? 2 : 1][PG_AMAX][Cfg::LOADER ? Cfg::T : 1];  // posterior partials of the last two columns
     const DevContig& dc = contigs[blockIdx.x];
     if (dc.HP != (uint32_t)HP) return;
     const uint32_t C = *dc.n_cols;
     if (C == 0) return;
     const uint32_t tid = threadIdx.x, lane = tid & 63u;
     const uint32_t wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const uint32_t j = tid % HP, rg = tid / HP, i0 = rg * R;
-    const uint32_t H = dc.H;
-    const double unif = 1.0 / ((double)H * (double)H);
     const unsigned char* colrec = dc.colrec;
-    const double* fwd = dc.fwd;
-    double* part_out = dc.part;
-    const size_t colsz = (size_t)HP * HP;
-    const uint32_t rb = (i0 / 64u) * 64u;
+    const int64_t last = (int64_t)C - 1;
 
-    // records are consumed in DESCENDING column order
+    double* part_out = dc.part;
     auto rec_load = [&](int64_t c) -> uint64_t {
-        if (tid < (uint32_t)Cfg::WORDS && c >= 0) return ((const uint64_t*)(colrec + (size_t)c * Cfg::RB))[tid];
+        if (lane < (uint32_t)Cfg::WORDS && c >= 0) return ((const uint64_t*)(colrec + (size_t)c * Cfg::RB))[lane];
         return 0ull;
     };
     auto rec_stage = [&](int64_t c, uint64_t w) {
-        if (tid < (uint32_t)Cfg::WORDS && c >= 0) ((uint64_t*)sh.rec[(uint32_t)c & 3u])[tid] = w;
+        if (lane < (uint32_t)Cfg::WORDS && c >= 0) ((uint64_t*)sh.rec[(uint32_t)c & 3u])[lane] = w;
     };
+    if (Cfg::LOADER && wave == (uint32_t)Cfg::NW) {
+        // ------------------------------- loader wave ---------------------------------
+        // drain the posterior partials of column c (LDS -> HBM)
+        auto flush = [&](int64_t c) {
+            if (c < 0 || c > last) return;
+            const uint32_t nl = sh.rec[(uint32_t)c & 3u][PG_REC_NLOCAL];
+            double* dst = part_out + (size_t)c * PG_AMAX * Cfg::T;
+            for (uint32_t a = 0; a < nl; ++a)
+                for (uint32_t t = lane; t < (uint32_t)Cfg::T; t += 64)
+                    dst[(size_t)a * Cfg::T + t] = s_pout[(uint32_t)c & 1u][a][t];
+        };
+        rec_stage(last, rec_load(last));
+        rec_stage(last - 1, rec_load(last - 1));
+        uint64_t tA = rec_load(last - 2), tB = rec_load(last - 3);
+        lds_barrier();  // P0: records last, last-1 staged
+        for (int64_t c = last - 1; c >= 0; c -= 2) {
+            rec_stage(c - 1, tA);
+            tA = rec_load(c - 3);
+            flush(c + 2);
+            lds_barrier();  // B_c
+            if (c - 1 >= 0) {
+                rec_stage(c - 2, tB);
+                tB = rec_load(c - 4);
+                flush(c + 1);
+                lds_barrier();  // B_{c-1}
+            }
+        }
+        // columns 1 and 0 are still in LDS
+        flush(1);
+        lds_barrier();  // F
+        flush(0);
+        return;
+    }
+
+    // --------------------------------- compute waves -------------------------------------
+    const uint32_t j = tid % HP, rg = tid / HP, i0 = rg * R;
+    const uint32_t H = dc.H;
+    const double unif = 1.0 / ((double)H * (double)H);
+    const double* fwd = dc.fwd;
+    const size_t colsz = (size_t)HP * HP;
+    const uint32_t rb = (i0 / 64u) * 64u;
+
     auto load_col = [&](int64_t c, double (&v)[R]) {
         if (c < 0) return;
         const double* src = fwd + (size_t)c * colsz + (size_t)i0 * HP + j;
@@ -640,14 +722,16 @@ __global__ __launch_bounds__(HP * HP / R) void k_backward(const DevContig* __res
 
     double y[R], vA[R], vB[VBUF == 2 ? R : 1];
     double Sy = 0.0;
-    const int64_t last = (int64_t)C - 1;
+    uint64_t tq = 0;  // inline loader (no loader wave): record c-2 in flight
+    if (!Cfg::LOADER && wave == 0) {
+        rec_stage(last, rec_load(last));
+        rec_stage(last - 1, rec_load(last - 1));
+        tq = rec_load(last - 2);
+    }
 
-    rec_stage(last, rec_load(last));
-    rec_stage(last - 1, rec_load(last - 1));
-    uint64_t tA = rec_load(last - 2), tB = rec_load(last - 3);
     load_col(last, vA);
     if constexpr (VBUF == 2) load_col(last - 1, vB);
-    __syncthreads();
+    lds_barrier();  // P0
 
     // posterior partials of column c: acc[a] = sum over my rows with allele a of v*beta
     auto posterior = [&](uint32_t c, const double (&v)[R], const double (&beta)[R]) {
@@ -667,10 +751,16 @@ __global__ __launch_bounds__(HP * HP / R) void k_backward(const DevContig* __res
                 if (ai == (uint32_t)a) acc[a] += p;
             if constexpr (R > 16) { if ((k & 7) == 7) __builtin_amdgcn_sched_barrier(0); }
         }
-        double* dst = part_out + (size_t)c * PG_AMAX * Cfg::T + tid;
+        if constexpr (Cfg::LOADER) {
 #pragma unroll
-        for (int a = 0; a < PG_AMAX; ++a)
-            if ((uint32_t)a < nl) dst[(size_t)a * Cfg::T] = acc[a];
+            for (int a = 0; a < PG_AMAX; ++a)
+                if ((uint32_t)a < nl) s_pout[c & 1u][a][tid] = acc[a];
+        } else {
+            double* dst = part_out + (size_t)c * PG_AMAX * Cfg::T + tid;
+#pragma unroll
+            for (int a = 0; a < PG_AMAX; ++a)
+                if ((uint32_t)a < nl) dst[(size_t)a * Cfg::T] = acc[a];
+        }
     };
 
     // column C-1: beta~ = 1 (reference src/hmm.cpp:356-358); sum = H^2
@@ -685,7 +775,7 @@ __global__ __launch_bounds__(HP * HP / R) void k_backward(const DevContig* __res
         load_col(last - VBUF, vA);
     }
 
-    auto step = [&](int64_t c, double (&v)[R], uint64_t& tnext) {
+    auto step = [&](int64_t c, double (&v)[R]) {
         // beta_hat_{c+1} = y / Sy, uniform if the sum is zero (hmm.cpp:374-380)
         if (!(Sy > 0.0)) {
 #pragma unroll
@@ -711,9 +801,11 @@ __global__ __launch_bounds__(HP * HP / R) void k_backward(const DevContig* __res
         sh.psum[pb][rg][j] = part;
         const double ws = wave_sum(part);
         if (lane == 0) sh.wsum[pb][wave] = ws;
-        rec_stage(c - 1, tnext);  // loaded two steps ago
-        tnext = rec_load(c - 3);
-        __syncthreads();
+        if (!Cfg::LOADER && wave == 0) {
+            rec_stage(c - 1, tq);  // loaded one column ago
+            tq = rec_load(c - 2);
+        }
+        lds_barrier();  // B_c
         double Cj = 0.0, Crow, Sw = 0.0;
 #pragma unroll
         for (int g = 0; g < Cfg::NRG; ++g) Cj += sh.psum[pb][g][j];
@@ -731,8 +823,9 @@ __global__ __launch_bounds__(HP * HP / R) void k_backward(const DevContig* __res
         const double uj = fma(k1, Cj, hk2);
         const double urow = fma(k1, Crow, hk2);
         if (!Cfg::UNI) {
+            lds_wave_sync();  // previous step's reads of sh.u are done
             if (rg == 0) sh.u[j] = uj;
-            __syncthreads();
+            lds_wave_sync();
         }
 #pragma unroll
         for (int k = 0; k < R; ++k) {
@@ -742,21 +835,21 @@ __global__ __launch_bounds__(HP * HP / R) void k_backward(const DevContig* __res
             y[k] = fma(k0, wk, row_value<Cfg::UNI>(sh.u, urow, i0 + k) + uj);  // beta~_c
             if constexpr (R > 16) { if ((k & 7) == 7) __builtin_amdgcn_sched_barrier(0); }
         }
-        Sy = kappa * Sw * inv;                                        // = sum(beta~_c) over real states
+        Sy = kappa * Sw * inv;  // = sum(beta~_c) over real states
         posterior((uint32_t)c, v, y);
         load_col(c - VBUF, v);
-        if (!Cfg::UNI) __syncthreads();  // sh.u is rewritten next step
     };
 
     for (int64_t c = last - 1; c >= 0; c -= 2) {
         if constexpr (VBUF == 2) {
-            step(c, vB, tA);
-            if (c - 1 >= 0) step(c - 1, vA, tB);
+            step(c, vB);
+            if (c - 1 >= 0) step(c - 1, vA);
         } else {
-            step(c, vA, tA);
-            if (c - 1 >= 0) step(c - 1, vA, tB);
+            step(c, vA);
+            if (c - 1 >= 0) step(c - 1, vA);
         }
     }
+    lds_barrier();  // F: the last partials are in LDS
 }
 
 // ------------------------------------------------------------------------------------------
@@ -835,15 +928,15 @@ void pgk_launch_bins(const DevContig* d_contigs, uint32_t n_contigs, uint32_t ma
 }
 // hp_mask: bit0 HP=16, bit1 HP=32, bit2 HP=64, bit3 HP=128
 void pgk_launch_forward(const DevContig* d_contigs, uint32_t n_contigs, uint32_t hp_mask, hipStream_t s) {
-    if (hp_mask & 1u) hipLaunchKernelGGL((k_forward<16, 4>), dim3(n_contigs), dim3(64), 0, s, d_contigs);
-    if (hp_mask & 2u) hipLaunchKernelGGL((k_forward<32, 16>), dim3(n_contigs), dim3(64), 0, s, d_contigs);
-    if (hp_mask & 4u) hipLaunchKernelGGL((k_forward<64, 16>), dim3(n_contigs), dim3(256), 0, s, d_contigs);
+    if (hp_mask & 1u) hipLaunchKernelGGL((k_forward<16, 4>), dim3(n_contigs), dim3(128), 0, s, d_contigs);
+    if (hp_mask & 2u) hipLaunchKernelGGL((k_forward<32, 16>), dim3(n_contigs), dim3(128), 0, s, d_contigs);
+    if (hp_mask & 4u) hipLaunchKernelGGL((k_forward<64, 16>), dim3(n_contigs), dim3(320), 0, s, d_contigs);
     if (hp_mask & 8u) hipLaunchKernelGGL((k_forward<128, 32>), dim3(n_contigs), dim3(512), 0, s, d_contigs);
 }
 void pgk_launch_backward(const DevContig* d_contigs, uint32_t n_contigs, uint32_t hp_mask, hipStream_t s) {
-    if (hp_mask & 1u) hipLaunchKernelGGL((k_backward<16, 4, 2, true>), dim3(n_contigs), dim3(64), 0, s, d_contigs);
-    if (hp_mask & 2u) hipLaunchKernelGGL((k_backward<32, 16, 2, true>), dim3(n_contigs), dim3(64), 0, s, d_contigs);
-    if (hp_mask & 4u) hipLaunchKernelGGL((k_backward<64, 16, 2, true>), dim3(n_contigs), dim3(256), 0, s, d_contigs);
+    if (hp_mask & 1u) hipLaunchKernelGGL((k_backward<16, 4, 2, true>), dim3(n_contigs), dim3(128), 0, s, d_contigs);
+    if (hp_mask & 2u) hipLaunchKernelGGL((k_backward<32, 16, 2, true>), dim3(n_contigs), dim3(128), 0, s, d_contigs);
+    if (hp_mask & 4u) hipLaunchKernelGGL((k_backward<64, 16, 2, true>), dim3(n_contigs), dim3(320), 0, s, d_contigs);
     if (hp_mask & 8u) hipLaunchKernelGGL((k_backward<128, 32, 1, false>), dim3(n_contigs), dim3(512), 0, s, d_contigs);
 }
 void pgk_launch_emission_single(const DevContig* d_contig, DevTable tab, uint32_t v, double* out_m, int* out_e,
