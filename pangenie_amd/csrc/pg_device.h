@@ -29,9 +29,10 @@
 #define PG_REC_EXP 36
 #define PG_REC_NLOCAL 40
 #define PG_REC_FLAGS 41
-#define PG_REC_LOCAL_SLOT 48  // u16[PG_AMAX]
-#define PG_REC_E 64           // double[PG_ETAB]
-#define PG_REC_ALLELES (64 + 8 * PG_ETAB)  // u8[HP]
+#define PG_REC_LOCAL_SLOT 48  // u16[8] (PG_AMAX used)
+#define PG_REC_BITS1 64       // u64[2]: bit p = selected path p carries local allele 1 (biallelic fast path)
+#define PG_REC_E 80           // double[PG_ETAB]
+#define PG_REC_ALLELES (80 + 8 * PG_ETAB)  // u8[HP]
 #define PG_REC_FLAG_ALLZERO 1
 
 static inline uint32_t pg_rec_bytes(uint32_t hp) { return (PG_REC_ALLELES + hp + 63u) & ~63u; }
@@ -77,6 +78,8 @@ struct DevContig {
     uint8_t*  colrec;
     double*   fwd;
     double*   part;
+    double*   fscale;        // [V] mantissa m of the scale applied to forward column c (see chain kernels)
+    double*   bscale;        // [V] same for the backward column
     uint8_t*  fwd_fallback;  // [V] column c fell back to the uniform forward column (fsum := 1, no emission scale)
     uint32_t* err;
     // outputs

@@ -274,7 +274,8 @@ __global__ __launch_bounds__(256) void k_prep(const DevContig* __restrict__ cont
 
     unsigned char* rec = dc.vrec + (size_t)v * dc.RB;
     // local (dense) allele index of every selected path; phantom paths of the padding get 255
-    for (uint32_t p = lane; p < HP; p += 64) {
+    for (uint32_t p0 = 0; p0 < 128; p0 += 64) {
+        const uint32_t p = p0 + lane;
         unsigned char val = PG_PHANTOM;
         if (p < H) {
             const uint16_t a = dc.path_allele[(size_t)v * H + p];
@@ -283,7 +284,9 @@ __global__ __launch_bounds__(256) void k_prep(const DevContig* __restrict__ cont
                 if (dc.allele_id[a0 + q] == a) s = q;
             val = (unsigned char)__popc(pmask & ((1u << s) - 1u));
         }
-        rec[PG_REC_ALLELES + p] = val;
+        if (p < HP) rec[PG_REC_ALLELES + p] = val;
+        const unsigned long long b1 = __ballot(val == 1);
+        if (lane == 0) ((unsigned long long*)(rec + PG_REC_BITS1))[p0 >> 6] = b1;
     }
 
     // ---- emission products over ALL allele pairs of the object (a1<=a2; table is symmetric)
@@ -444,8 +447,23 @@ __global__ __launch_bounds__(256) void k_records(const DevContig* __restrict__ c
 //    * compute waves of k_backward only LOAD (the prefetched forward column);
 //    * the loader wave streams the column records HBM -> LDS two columns ahead and, in
 //      k_backward, drains the posterior partials LDS -> HBM.
-//  The per-column workgroup barrier orders LDS only (no vmcnt wait).
+//  The per-column workgroup barrier orders LDS only (no vmcnt wait).  All global pointers are
+//  address_space(1) so that stores/loads are global_* (FLAT ops would also tick lgkmcnt and
+//  put the HBM latency back on the LDS waits).
+//
+//  Scaling.  The reference normalises every column by its sum (a division on the critical
+//  path).  Here a column is rescaled by the exact power of two 2^-e, e = exponent(sum), and
+//  the mantissa m = sum * 2^-e in [0.5,1) goes to a side array; the true
+//  alpha_hat_c * fsum_c is the stored column divided by m_{c-1} (k_bins does that division,
+//  off the chain).  Same for the backward column.  Results are the reference's values up to
+//  fp64 rounding; no drift because every step renormalises to within a factor of 2.
 // ------------------------------------------------------------------------------------------
+#define GAS __attribute__((address_space(1)))
+typedef GAS double gdouble;
+typedef GAS const double gcdouble;
+typedef GAS const unsigned long long gcu64;
+typedef GAS unsigned char gu8;
+
 template <int HP, int R>
 struct ChainCfg {
     static constexpr int T = HP * HP / R;      // compute threads
@@ -460,6 +478,7 @@ struct ChainCfg {
     static constexpr int WORDS = RB / 8;
     static_assert(T % 64 == 0 && TT <= 1024, "bad workgroup size");
     static_assert(WORDS <= 64, "record must fit one wave-wide 8-byte load");
+    static_assert(64 % R == 0 || R % 64 == 0, "row groups must not straddle 64-column blocks");
 };
 
 template <int HP, int R>
@@ -483,13 +502,13 @@ DEVI void lds_wave_sync() {
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
 }
 
-// emission of state (i, j) from a staged record: E[a_i][a_j]; phantom paths (255) hit the
-// zero row/column PG_AMAX of the expanded table.
-template <bool UNI>
+// x = m * 2^e with m in [0.5,1)  (x > 0, finite)
+DEVI int exponent_of(double x) { return __builtin_amdgcn_frexp_exp(x); }
+
+// general emission lookup: E[a_i][a_j]; phantom paths (255) hit the zero row/column PG_AMAX
 DEVI double emission_at(const unsigned char* rec, uint32_t i, uint32_t aj) {
     uint32_t ai = rec[PG_REC_ALLELES + i];
     ai = ai > PG_AMAX ? PG_AMAX : ai;
-    if (UNI) ai = __builtin_amdgcn_readfirstlane(ai);
     return ((const double*)(rec + PG_REC_E))[ai * PG_ESTRIDE + aj];
 }
 DEVI uint32_t col_allele(const unsigned char* rec, uint32_t j) {
@@ -497,12 +516,39 @@ DEVI uint32_t col_allele(const unsigned char* rec, uint32_t j) {
     return aj > PG_AMAX ? PG_AMAX : aj;
 }
 
-// u_i of row i.  UNI: every wave holds the u vector of the 64-column block that contains its
-// rows (urow) and the row is wave-uniform -> v_readlane.  !UNI (single compute wave): via LDS.
+// biallelic fast path (<= 2 local alleles, no phantom paths): e(i,j) = bit_i ? eB : eA with
+// eA = E[0][a_j], eB = E[1][a_j] per lane and the row bits uniform per wave (UNI).
+struct FastE {
+    double eA, eB;
+    uint32_t rowbits;
+};
 template <bool UNI>
-DEVI double row_value(const double* lds_u, double urow, uint32_t i) {
-    if (UNI) return readlane_f64(urow, __builtin_amdgcn_readfirstlane((int)(i & 63u)));
-    return lds_u[i];
+DEVI FastE fast_setup(const unsigned char* rec, uint32_t j, uint32_t i0) {
+    const double* E = (const double*)(rec + PG_REC_E);
+    const double E00 = E[0], E01 = E[1], E11 = E[PG_ESTRIDE + 1];
+    const unsigned long long* bits = (const unsigned long long*)(rec + PG_REC_BITS1);
+    const uint32_t aj = (uint32_t)(bits[j >> 6] >> (j & 63u)) & 1u;
+    uint32_t rbits = (uint32_t)(bits[i0 >> 6] >> (i0 & 63u));
+    if (UNI) rbits = __builtin_amdgcn_readfirstlane(rbits);
+    FastE f;
+    f.eA = aj ? E01 : E00;
+    f.eB = aj ? E11 : E01;
+    f.rowbits = rbits;
+    return f;
+}
+
+// u_i for the thread's rows.  UNI: every wave holds the u vector of the 64-column block that
+// contains its rows (urow) and rows are wave-uniform -> v_readlane into SGPRs.
+template <int R, bool UNI>
+DEVI void row_values(const double* lds_u, double urow, uint32_t i0, double (&ui)[R]) {
+    if (UNI) {
+        const int base = __builtin_amdgcn_readfirstlane((int)(i0 & 63u));
+#pragma unroll
+        for (int k = 0; k < R; ++k) ui[k] = readlane_f64(urow, base + k);
+    } else {
+#pragma unroll
+        for (int k = 0; k < R; ++k) ui[k] = lds_u[i0 + k];
+    }
 }
 
 template <int HP, int R>
@@ -515,20 +561,20 @@ __global__ __launch_bounds__((ChainCfg<HP, R>::TT)) void k_forward(const DevCont
     if (C == 0) return;
     const uint32_t tid = threadIdx.x, lane = tid & 63u;
     const uint32_t wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const unsigned char* colrec = dc.colrec;
+    gcu64* colrec = (gcu64*)dc.colrec;
 
-    auto rec_load = [&](uint32_t c) -> uint64_t {
-        if (lane < (uint32_t)Cfg::WORDS && c < C) return ((const uint64_t*)(colrec + (size_t)c * Cfg::RB))[lane];
+    auto rec_load = [&](uint32_t c) -> unsigned long long {
+        if (lane < (uint32_t)Cfg::WORDS && c < C) return colrec[(size_t)c * Cfg::WORDS + lane];
         return 0ull;
     };
-    auto rec_stage = [&](uint32_t c, uint64_t w) {
-        if (lane < (uint32_t)Cfg::WORDS) ((uint64_t*)sh.rec[c & 3u])[lane] = w;
+    auto rec_stage = [&](uint32_t c, unsigned long long w) {
+        if (lane < (uint32_t)Cfg::WORDS) ((unsigned long long*)sh.rec[c & 3u])[lane] = w;
     };
     if (Cfg::LOADER && wave == (uint32_t)Cfg::NW) {
         // ------------------------------- loader wave ---------------------------------
         rec_stage(0, rec_load(0));
         rec_stage(1, rec_load(1));
-        uint64_t tE = rec_load(2), tO = rec_load(3);
+        unsigned long long tE = rec_load(2), tO = rec_load(3);
         lds_barrier();  // records 0,1 staged
         lds_barrier();  // column 0 done
         for (uint32_t c = 1; c < C; c += 2) {
@@ -547,20 +593,23 @@ __global__ __launch_bounds__((ChainCfg<HP, R>::TT)) void k_forward(const DevCont
     // --------------------------------- compute waves -------------------------------------
     const uint32_t j = tid % HP, rg = tid / HP, i0 = rg * R;
     const uint32_t H = dc.H;
+    const bool full = H == (uint32_t)HP;
     const double unif = 1.0 / ((double)H * (double)H);
-    double* fwd = dc.fwd;
+    gdouble* fwd = (gdouble*)dc.fwd;
+    gdouble* fscale = (gdouble*)dc.fscale;
+    gu8* fallback = (gu8*)dc.fwd_fallback;
     const size_t colsz = (size_t)HP * HP;
     const uint32_t rb = (i0 / 64u) * 64u;  // first column of the 64-block that contains my rows (UNI)
 
     auto store_col = [&](uint32_t c, const double (&x)[R]) {
-        double* dst = fwd + (size_t)c * colsz + (size_t)i0 * HP + j;
+        gdouble* dst = fwd + (size_t)c * colsz + (size_t)i0 * HP + j;
 #pragma unroll
         for (int k = 0; k < R; ++k) dst[(size_t)k * HP] = x[k];
     };
 
-    double x[R];
+    double x[R], ui[R];
     double Cj = 0.0, Crow = 0.0, S = 0.0;
-    uint64_t tq = 0;  // inline loader (no loader wave): record c+2 in flight
+    unsigned long long tq = 0;  // inline loader (no loader wave): record c+2 in flight
     if (!Cfg::LOADER && wave == 0) {
         rec_stage(0, rec_load(0));
         rec_stage(1, rec_load(1));
@@ -574,8 +623,9 @@ __global__ __launch_bounds__((ChainCfg<HP, R>::TT)) void k_forward(const DevCont
         const uint32_t aj = col_allele(sh.rec[0], j);
         double part = 0.0;
 #pragma unroll
-        for (int k = 0; k < R; ++k) { x[k] = emission_at<Cfg::UNI>(sh.rec[0], i0 + k, aj); part += x[k]; }
+        for (int k = 0; k < R; ++k) { x[k] = emission_at(sh.rec[0], i0 + k, aj); part += x[k]; }
         store_col(0, x);
+        if (tid == 0) fscale[0] = 1.0;
         sh.psum[0][rg][j] = part;
         const double ws = wave_sum(part);
         if (lane == 0) sh.wsum[0][wave] = ws;
@@ -598,13 +648,13 @@ __global__ __launch_bounds__((ChainCfg<HP, R>::TT)) void k_forward(const DevCont
         S = 0.0;
 #pragma unroll
         for (int w = 0; w < Cfg::NW; ++w) S += sh.wsum[pb][w];
-        if (!(S > 0.0)) {
+        if (!(S > 0.0) || !(S < INFINITY)) {
 #pragma unroll
             for (int k = 0; k < R; ++k) x[k] = (j < H && i0 + k < H) ? unif : 0.0;
             store_col(cprev, x);
-            // alpha_hat*fsum = 1/H^2 is an absolute value: it does not carry the emission
-            // exponent X_c of this column; k_bins drops X_c for flagged columns.
-            if (tid == 0) dc.fwd_fallback[cprev] = 1;
+            // alpha_hat*fsum = 1/H^2 is an absolute value: it carries neither the emission
+            // exponent X_c nor the column scale; k_bins treats flagged columns accordingly.
+            if (tid == 0) fallback[cprev] = 1;
             Cj = j < H ? (double)H * unif : 0.0;
             Crow = (rb + lane) < H ? (double)H * unif : 0.0;
             S = 1.0;
@@ -617,22 +667,35 @@ __global__ __launch_bounds__((ChainCfg<HP, R>::TT)) void k_forward(const DevCont
         const double c0 = *(const double*)(rec + PG_REC_C0);
         const double c1 = *(const double*)(rec + PG_REC_C1);
         const double c2 = *(const double*)(rec + PG_REC_C2);
-        const double inv = 1.0 / S;
-        const double k0 = c0 * inv, k1 = c1 * inv, hk2 = 0.5 * c2;
+        // alpha_hat_{c-1} = x / S.  Scale by 2^-es instead of dividing: the new column is
+        // (true v_c) * m with m = S * 2^-es in [0.5,1); m goes to the side array.
+        const int es = exponent_of(S);
+        const double m = ldexp(S, -es);
+        const double k0 = ldexp(c0, -es), k1 = ldexp(c1, -es), hk2 = 0.5 * c2 * m;
+        if (tid == 0) fscale[c] = m;
         const double uj = fma(k1, Cj, hk2);
         const double urow = fma(k1, Crow, hk2);
         if (!Cfg::UNI) {
             if (rg == 0) sh.u[j] = uj;
             lds_wave_sync();
         }
-        const uint32_t aj = col_allele(rec, j);
+        row_values<R, Cfg::UNI>(sh.u, urow, i0, ui);
         double part = 0.0;
+        if (full && rec[PG_REC_NLOCAL] <= 2) {
+            const FastE fe = fast_setup<Cfg::UNI>(rec, j, i0);
 #pragma unroll
-        for (int k = 0; k < R; ++k) {
-            const double ui = row_value<Cfg::UNI>(sh.u, urow, i0 + k);
-            const double t = fma(k0, x[k], ui + uj);
-            x[k] = t * emission_at<Cfg::UNI>(rec, i0 + k, aj);
-            part += x[k];
+            for (int k = 0; k < R; ++k) {
+                const double e = ((fe.rowbits >> k) & 1u) ? fe.eB : fe.eA;
+                x[k] = fma(k0, x[k], ui[k] + uj) * e;
+                part += x[k];
+            }
+        } else {
+            const uint32_t aj = col_allele(rec, j);
+#pragma unroll
+            for (int k = 0; k < R; ++k) {
+                x[k] = fma(k0, x[k], ui[k] + uj) * emission_at(rec, i0 + k, aj);
+                part += x[k];
+            }
         }
         store_col(c, x);
         sh.psum[c & 1u][rg][j] = part;
@@ -653,23 +716,23 @@ template <int HP, int R, int VBUF, bool KEEPW>
 __global__ __launch_bounds__((ChainCfg<HP, R>::TT)) void k_backward(const DevContig* __restrict__ contigs) {
     using Cfg = ChainCfg<HP, R>;
     __shared__ ChainShared<HP, R> sh;
-    __shared__ double s_pout[Cfg::LOADER ? 2 : 1][PG_AMAX][Cfg::LOADER ? Cfg::T : 1];  // posterior partials of the last two columns
+    __shared__ double s_pout[Cfg::LOADER ? 2 : 1][PG_AMAX][Cfg::LOADER ? Cfg::T : 1];  // partials of the last two columns
     const DevContig& dc = contigs[blockIdx.x];
     if (dc.HP != (uint32_t)HP) return;
     const uint32_t C = *dc.n_cols;
     if (C == 0) return;
     const uint32_t tid = threadIdx.x, lane = tid & 63u;
     const uint32_t wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const unsigned char* colrec = dc.colrec;
+    gcu64* colrec = (gcu64*)dc.colrec;
     const int64_t last = (int64_t)C - 1;
 
-    double* part_out = dc.part;
-    auto rec_load = [&](int64_t c) -> uint64_t {
-        if (lane < (uint32_t)Cfg::WORDS && c >= 0) return ((const uint64_t*)(colrec + (size_t)c * Cfg::RB))[lane];
+    gdouble* part_out = (gdouble*)dc.part;
+    auto rec_load = [&](int64_t c) -> unsigned long long {
+        if (lane < (uint32_t)Cfg::WORDS && c >= 0) return colrec[(size_t)c * Cfg::WORDS + lane];
         return 0ull;
     };
-    auto rec_stage = [&](int64_t c, uint64_t w) {
-        if (lane < (uint32_t)Cfg::WORDS && c >= 0) ((uint64_t*)sh.rec[(uint32_t)c & 3u])[lane] = w;
+    auto rec_stage = [&](int64_t c, unsigned long long w) {
+        if (lane < (uint32_t)Cfg::WORDS && c >= 0) ((unsigned long long*)sh.rec[(uint32_t)c & 3u])[lane] = w;
     };
     if (Cfg::LOADER && wave == (uint32_t)Cfg::NW) {
         // ------------------------------- loader wave ---------------------------------
@@ -677,14 +740,14 @@ __global__ __launch_bounds__((ChainCfg<HP, R>::TT)) void k_backward(const DevCon
         auto flush = [&](int64_t c) {
             if (c < 0 || c > last) return;
             const uint32_t nl = sh.rec[(uint32_t)c & 3u][PG_REC_NLOCAL];
-            double* dst = part_out + (size_t)c * PG_AMAX * Cfg::T;
+            gdouble* dst = part_out + (size_t)c * PG_AMAX * Cfg::T;
             for (uint32_t a = 0; a < nl; ++a)
                 for (uint32_t t = lane; t < (uint32_t)Cfg::T; t += 64)
                     dst[(size_t)a * Cfg::T + t] = s_pout[(uint32_t)c & 1u][a][t];
         };
         rec_stage(last, rec_load(last));
         rec_stage(last - 1, rec_load(last - 1));
-        uint64_t tA = rec_load(last - 2), tB = rec_load(last - 3);
+        unsigned long long tA = rec_load(last - 2), tB = rec_load(last - 3);
         lds_barrier();  // P0: records last, last-1 staged
         for (int64_t c = last - 1; c >= 0; c -= 2) {
             rec_stage(c - 1, tA);
@@ -708,21 +771,23 @@ __global__ __launch_bounds__((ChainCfg<HP, R>::TT)) void k_backward(const DevCon
     // --------------------------------- compute waves -------------------------------------
     const uint32_t j = tid % HP, rg = tid / HP, i0 = rg * R;
     const uint32_t H = dc.H;
+    const bool full = H == (uint32_t)HP;
     const double unif = 1.0 / ((double)H * (double)H);
-    const double* fwd = dc.fwd;
+    gcdouble* fwd = (gcdouble*)dc.fwd;
+    gdouble* bscale = (gdouble*)dc.bscale;
     const size_t colsz = (size_t)HP * HP;
     const uint32_t rb = (i0 / 64u) * 64u;
 
     auto load_col = [&](int64_t c, double (&v)[R]) {
         if (c < 0) return;
-        const double* src = fwd + (size_t)c * colsz + (size_t)i0 * HP + j;
+        gcdouble* src = fwd + (size_t)c * colsz + (size_t)i0 * HP + j;
 #pragma unroll
         for (int k = 0; k < R; ++k) v[k] = src[(size_t)k * HP];
     };
 
     double y[R], vA[R], vB[VBUF == 2 ? R : 1];
     double Sy = 0.0;
-    uint64_t tq = 0;  // inline loader (no loader wave): record c-2 in flight
+    unsigned long long tq = 0;  // inline loader (no loader wave): record c-2 in flight
     if (!Cfg::LOADER && wave == 0) {
         rec_stage(last, rec_load(last));
         rec_stage(last - 1, rec_load(last - 1));
@@ -736,27 +801,38 @@ __global__ __launch_bounds__((ChainCfg<HP, R>::TT)) void k_backward(const DevCon
     // posterior partials of column c: acc[a] = sum over my rows with allele a of v*beta
     auto posterior = [&](uint32_t c, const double (&v)[R], const double (&beta)[R]) {
         const unsigned char* rec0 = sh.rec[c & 3u];
-        const unsigned char* al = rec0 + PG_REC_ALLELES;
         const uint32_t nl = rec0[PG_REC_NLOCAL];
         double acc[PG_AMAX];
 #pragma unroll
         for (int a = 0; a < PG_AMAX; ++a) acc[a] = 0.0;
+        if (full && nl <= 2) {
+            const unsigned long long* bits = (const unsigned long long*)(rec0 + PG_REC_BITS1);
+            uint32_t rbits = (uint32_t)(bits[i0 >> 6] >> (i0 & 63u));
+            if (Cfg::UNI) rbits = __builtin_amdgcn_readfirstlane(rbits);
 #pragma unroll
-        for (int k = 0; k < R; ++k) {
-            uint32_t ai = al[i0 + k];
-            if (Cfg::UNI) ai = __builtin_amdgcn_readfirstlane(ai);
-            const double p = v[k] * beta[k];
+            for (int k = 0; k < R; ++k) {
+                const double p = v[k] * beta[k];
+                if ((rbits >> k) & 1u) acc[1] += p;
+                else acc[0] += p;
+            }
+        } else {
+            const unsigned char* al = rec0 + PG_REC_ALLELES;
 #pragma unroll
-            for (int a = 0; a < PG_AMAX; ++a)
-                if (ai == (uint32_t)a) acc[a] += p;
-            if constexpr (R > 16) { if ((k & 7) == 7) __builtin_amdgcn_sched_barrier(0); }
+            for (int k = 0; k < R; ++k) {
+                const uint32_t ai = al[i0 + k];
+                const double p = v[k] * beta[k];
+#pragma unroll
+                for (int a = 0; a < PG_AMAX; ++a)
+                    if (ai == (uint32_t)a) acc[a] += p;
+                if constexpr (R > 16) { if ((k & 7) == 7) __builtin_amdgcn_sched_barrier(0); }
+            }
         }
         if constexpr (Cfg::LOADER) {
 #pragma unroll
             for (int a = 0; a < PG_AMAX; ++a)
                 if ((uint32_t)a < nl) s_pout[c & 1u][a][tid] = acc[a];
         } else {
-            double* dst = part_out + (size_t)c * PG_AMAX * Cfg::T + tid;
+            gdouble* dst = part_out + (size_t)c * PG_AMAX * Cfg::T + tid;
 #pragma unroll
             for (int a = 0; a < PG_AMAX; ++a)
                 if ((uint32_t)a < nl) dst[(size_t)a * Cfg::T] = acc[a];
@@ -769,6 +845,7 @@ __global__ __launch_bounds__((ChainCfg<HP, R>::TT)) void k_backward(const DevCon
 #pragma unroll
         for (int k = 0; k < R; ++k) beta[k] = (j < H && i0 + k < H) ? 1.0 : 0.0;
         posterior((uint32_t)last, vA, beta);
+        if (tid == 0) bscale[last] = 1.0;
 #pragma unroll
         for (int k = 0; k < R; ++k) y[k] = beta[k];
         Sy = (double)H * (double)H;
@@ -777,7 +854,7 @@ __global__ __launch_bounds__((ChainCfg<HP, R>::TT)) void k_backward(const DevCon
 
     auto step = [&](int64_t c, double (&v)[R]) {
         // beta_hat_{c+1} = y / Sy, uniform if the sum is zero (hmm.cpp:374-380)
-        if (!(Sy > 0.0)) {
+        if (!(Sy > 0.0) || !(Sy < INFINITY)) {
 #pragma unroll
             for (int k = 0; k < R; ++k) y[k] = (j < H && i0 + k < H) ? unif : 0.0;
             Sy = 1.0;
@@ -787,15 +864,32 @@ __global__ __launch_bounds__((ChainCfg<HP, R>::TT)) void k_backward(const DevCon
         const double c1 = *(const double*)(rec1 + PG_REC_C1);
         const double c2 = *(const double*)(rec1 + PG_REC_C2);
         const double kappa = *(const double*)(rec1 + PG_REC_KAPPA);
-        const uint32_t aj1 = col_allele(rec1, j);
+        // beta~_c(true) = A (y/Sy . e) A^T; scaled by 2^-es: beta' = beta~ * m, m = Sy*2^-es
+        const int es = exponent_of(Sy);
+        const double m = ldexp(Sy, -es);
+        if (tid == 0) bscale[c] = m;
+        const bool fast = full && rec1[PG_REC_NLOCAL] <= 2;
+        FastE fe;
+        uint32_t aj1 = 0;
+        if (fast) fe = fast_setup<Cfg::UNI>(rec1, j, i0);
+        else aj1 = col_allele(rec1, j);
         double w[KEEPW ? R : 1];
         double part = 0.0;
+        if (fast) {
 #pragma unroll
-        for (int k = 0; k < R; ++k) {
-            const double wk = y[k] * emission_at<Cfg::UNI>(rec1, i0 + k, aj1);
-            if constexpr (KEEPW) w[k] = wk;
-            part += wk;
-            if constexpr (R > 16) { if ((k & 7) == 7) __builtin_amdgcn_sched_barrier(0); }
+            for (int k = 0; k < R; ++k) {
+                const double wk = y[k] * (((fe.rowbits >> k) & 1u) ? fe.eB : fe.eA);
+                if constexpr (KEEPW) w[k] = wk;
+                part += wk;
+            }
+        } else {
+#pragma unroll
+            for (int k = 0; k < R; ++k) {
+                const double wk = y[k] * emission_at(rec1, i0 + k, aj1);
+                if constexpr (KEEPW) w[k] = wk;
+                part += wk;
+                if constexpr (R > 16) { if ((k & 7) == 7) __builtin_amdgcn_sched_barrier(0); }
+            }
         }
         const uint32_t pb = (uint32_t)c & 1u;
         sh.psum[pb][rg][j] = part;
@@ -818,8 +912,7 @@ __global__ __launch_bounds__((ChainCfg<HP, R>::TT)) void k_backward(const DevCon
         }
 #pragma unroll
         for (int q = 0; q < Cfg::NW; ++q) Sw += sh.wsum[pb][q];
-        const double inv = 1.0 / Sy;
-        const double k0 = c0 * inv, k1 = c1 * inv, hk2 = 0.5 * c2 * Sw * inv;
+        const double k0 = ldexp(c0, -es), k1 = ldexp(c1, -es), hk2 = 0.5 * ldexp(c2 * Sw, -es);
         const double uj = fma(k1, Cj, hk2);
         const double urow = fma(k1, Crow, hk2);
         if (!Cfg::UNI) {
@@ -827,15 +920,20 @@ __global__ __launch_bounds__((ChainCfg<HP, R>::TT)) void k_backward(const DevCon
             if (rg == 0) sh.u[j] = uj;
             lds_wave_sync();
         }
+        double ui[R > 16 ? 1 : R];
+        if constexpr (R <= 16) row_values<R, Cfg::UNI>(sh.u, urow, i0, ui);
 #pragma unroll
         for (int k = 0; k < R; ++k) {
             double wk;
             if constexpr (KEEPW) wk = w[k];
-            else wk = y[k] * emission_at<Cfg::UNI>(rec1, i0 + k, aj1);
-            y[k] = fma(k0, wk, row_value<Cfg::UNI>(sh.u, urow, i0 + k) + uj);  // beta~_c
+            else wk = y[k] * (fast ? (((fe.rowbits >> k) & 1u) ? fe.eB : fe.eA) : emission_at(rec1, i0 + k, aj1));
+            double uik;
+            if constexpr (R <= 16) uik = ui[k];
+            else uik = readlane_f64(urow, __builtin_amdgcn_readfirstlane((int)((i0 + k) & 63u)));
+            y[k] = fma(k0, wk, uik + uj);  // beta'_c
             if constexpr (R > 16) { if ((k & 7) == 7) __builtin_amdgcn_sched_barrier(0); }
         }
-        Sy = kappa * Sw * inv;  // = sum(beta~_c) over real states
+        Sy = ldexp(kappa * Sw, -es);  // = sum(beta'_c) over real states
         posterior((uint32_t)c, v, y);
         load_col(c - VBUF, v);
     };
@@ -891,16 +989,20 @@ __global__ __launch_bounds__(256) void k_bins(const DevContig* __restrict__ cont
     wave_sync();
     const uint32_t a0 = dc.allele_off[v], A = dc.allele_off[v + 1] - a0;
     const uint16_t* ls = (const uint16_t*)(rec + PG_REC_LOCAL_SLOT);
+    // stored columns are (true value) * m: alpha_hat*fsum = fwd / fscale[c] (unless the forward
+    // column fell back to uniform), beta~ = bwd / bscale[c]
+    const bool fb = dc.fwd_fallback[c] != 0;
+    const double scale = 1.0 / ((fb ? 1.0 : dc.fscale[c]) * dc.bscale[c]);
     if (lane < nl * nl) {
         const uint32_t la = lane / nl, lb = lane % nl;
         if (la <= lb) {
             const uint32_t sa = ls[la], sb = ls[lb];
             const uint64_t idx = dc.geno_off[v] + (uint64_t)sa * A - (uint64_t)sa * (sa - 1) / 2 + (sb - sa);
-            dc.lik[idx] = s_bins[wave][tri_local(la, lb)];
+            dc.lik[idx] = s_bins[wave][tri_local(la, lb)] * scale;
         }
     }
     if (lane == 0) {
-        int X = dc.fwd_fallback[c] ? 0 : *(const int32_t*)(rec + PG_REC_EXP);
+        int X = fb ? 0 : *(const int32_t*)(rec + PG_REC_EXP);
         if (c + 1 < C) X += *(const int32_t*)(dc.colrec + (size_t)(c + 1) * dc.RB + PG_REC_EXP);
         dc.lik_exp[v] = X;
     }

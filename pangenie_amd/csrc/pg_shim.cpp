@@ -315,7 +315,7 @@ extern "C" pg_job* pg_job_create(int device, uint32_t n_contigs, const pg_contig
     job->contigs.resize(n_contigs);
     size_t off = 0;
     auto take = [&](size_t bytes) { size_t o = off; off = align_up(off + (bytes ? bytes : 8)); return o; };
-    struct Plan { size_t fback, pos, cov, koff, kcnt, aoff, aid, aflag, akoff, akmask, pa, goff, vrec, cvar, colrec, fwd, part, kept, apres, lik, likexp; };
+    struct Plan { size_t fback, fscale, bscale, pos, cov, koff, kcnt, aoff, aid, aflag, akoff, akmask, pa, goff, vrec, cvar, colrec, fwd, part, kept, apres, lik, likexp; };
     std::vector<Plan> plan(n_contigs);
     const size_t o_contigs = take(sizeof(DevContig) * n_contigs);
     // zeroed-every-run block: n_cols, err, then per contig kept / allele_present / lik / lik_exp
@@ -352,6 +352,8 @@ extern "C" pg_job* pg_job_create(int device, uint32_t n_contigs, const pg_contig
         p.colrec = take((size_t)c.V * c.RB);
         p.fwd = take((size_t)c.V * c.HP * c.HP * sizeof(double));
         p.part = take((size_t)c.V * PG_AMAX * c.T * sizeof(double));
+        p.fscale = take((size_t)c.V * sizeof(double));
+        p.bscale = take((size_t)c.V * sizeof(double));
         job->hp_mask |= c.HP == 16 ? 1u : c.HP == 32 ? 2u : c.HP == 64 ? 4u : 8u;
         if (c.V > job->max_v) job->max_v = c.V;
     }
@@ -387,7 +389,8 @@ extern "C" pg_job* pg_job_create(int device, uint32_t n_contigs, const pg_contig
         d.geno_off = (const uint64_t*)(A + p.goff);
         d.vrec = A + p.vrec; d.kept = A + p.kept; d.allele_present = A + p.apres;
         d.n_cols = job->d_ncols + i; d.col_variant = (uint32_t*)(A + p.cvar); d.colrec = A + p.colrec;
-        d.fwd = (double*)(A + p.fwd); d.part = (double*)(A + p.part); d.fwd_fallback = A + p.fback; d.err = job->d_err + i;
+        d.fwd = (double*)(A + p.fwd); d.part = (double*)(A + p.part); d.fwd_fallback = A + p.fback;
+        d.fscale = (double*)(A + p.fscale); d.bscale = (double*)(A + p.bscale); d.err = job->d_err + i;
         d.lik = (double*)(A + p.lik); d.lik_exp = (int32_t*)(A + p.likexp);
         c.d = d;
         if (c.V == 0) continue;
