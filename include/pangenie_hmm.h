@@ -145,6 +145,9 @@ int  pg_job_device_results(pg_job* job, uint32_t contig, void** d_lik, uint64_t*
 #define PG_N_KERNEL_CLASSES 6
 int  pg_job_kernel_ms(const pg_job* job, double ms[PG_N_KERNEL_CLASSES]);
 const char* pg_job_kernel_name(int cls);
+/* Profiling hook: 64 in-kernel cycle counters of contig c's chain kernels, filled when the
+ * environment variable PG_DEBUG has bit 3 set (layout documented in DESIGN.md); zeros otherwise. */
+int  pg_job_profile_counters(pg_job* job, uint32_t contig, uint64_t out64[64]);
 /* Bytes of device memory held by the job. */
 uint64_t pg_job_device_bytes(const pg_job* job);
 void pg_job_destroy(pg_job* job);

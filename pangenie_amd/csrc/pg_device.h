@@ -56,7 +56,7 @@ struct DevContig {
     uint32_t pad0;
     double dist_scale;     // 0.000004 * recombrate * effective_N
     int32_t uniform;
-    int32_t pad1;
+    uint32_t debug;        // PG_DEBUG env: ablation switches for profiling (0 in production)
     // inputs
     const uint64_t* pos;
     const uint16_t* cov;
@@ -82,6 +82,7 @@ struct DevContig {
     double*   bscale;        // [V] same for the backward column
     uint8_t*  fwd_fallback;  // [V] column c fell back to the uniform forward column (fsum := 1, no emission scale)
     uint32_t* err;
+    unsigned long long* prof;  // [64] in-kernel cycle counters (PG_DEBUG bit 3), profiling only
     // outputs
     double*   lik;
     int32_t*  lik_exp;

@@ -577,16 +577,22 @@ __global__ __launch_bounds__((ChainCfg<HP, R>::TT)) void k_forward(const DevCont
         unsigned long long tE = rec_load(2), tO = rec_load(3);
         lds_barrier();  // records 0,1 staged
         lds_barrier();  // column 0 done
+        unsigned long long t_stage = 0, t_bar = 0;
+        const bool prof = (dc.debug & 8u) != 0;
         for (uint32_t c = 1; c < C; c += 2) {
+            unsigned long long a0 = prof ? __builtin_amdgcn_s_memtime() : 0;
             rec_stage(c + 1, tE);  // loaded two columns ago
+            if (prof) { __builtin_amdgcn_s_waitcnt(0); unsigned long long a1 = __builtin_amdgcn_s_memtime(); t_stage += a1 - a0; a0 = a1; }
             tE = rec_load(c + 3);
             lds_barrier();
+            if (prof) { unsigned long long a1 = __builtin_amdgcn_s_memtime(); t_bar += a1 - a0; }
             if (c + 1 < C) {
                 rec_stage(c + 2, tO);
                 tO = rec_load(c + 4);
                 lds_barrier();
             }
         }
+        if (prof && lane == 0) { dc.prof[8] = t_stage; dc.prof[9] = t_bar; }
         return;
     }
 
@@ -601,7 +607,9 @@ __global__ __launch_bounds__((ChainCfg<HP, R>::TT)) void k_forward(const DevCont
     const size_t colsz = (size_t)HP * HP;
     const uint32_t rb = (i0 / 64u) * 64u;  // first column of the 64-block that contains my rows (UNI)
 
+    const uint32_t dbg = dc.debug;
     auto store_col = [&](uint32_t c, const double (&x)[R]) {
+        if (dbg & 1u) return;
         gdouble* dst = fwd + (size_t)c * colsz + (size_t)i0 * HP + j;
 #pragma unroll
         for (int k = 0; k < R; ++k) dst[(size_t)k * HP] = x[k];
@@ -661,7 +669,10 @@ __global__ __launch_bounds__((ChainCfg<HP, R>::TT)) void k_forward(const DevCont
         }
     };
 
+    unsigned long long t_pre = 0, t_main = 0, t_red = 0, t_bar = 0;
+    const bool prof = (dbg & 8u) != 0;
     for (uint32_t c = 1; c < C; ++c) {
+        unsigned long long q0 = prof ? __builtin_amdgcn_s_memtime() : 0;
         finalize(c - 1);
         const unsigned char* rec = sh.rec[c & 3u];
         const double c0 = *(const double*)(rec + PG_REC_C0);
@@ -680,6 +691,7 @@ __global__ __launch_bounds__((ChainCfg<HP, R>::TT)) void k_forward(const DevCont
             lds_wave_sync();
         }
         row_values<R, Cfg::UNI>(sh.u, urow, i0, ui);
+        if (prof) { __builtin_amdgcn_s_waitcnt(0xc07f); __builtin_amdgcn_sched_barrier(0); unsigned long long q1 = __builtin_amdgcn_s_memtime(); t_pre += q1 - q0; q0 = q1; }
         double part = 0.0;
         if (full && rec[PG_REC_NLOCAL] <= 2) {
             const FastE fe = fast_setup<Cfg::UNI>(rec, j, i0);
@@ -698,14 +710,21 @@ __global__ __launch_bounds__((ChainCfg<HP, R>::TT)) void k_forward(const DevCont
             }
         }
         store_col(c, x);
+        if (prof) { __builtin_amdgcn_sched_barrier(0); unsigned long long q1 = __builtin_amdgcn_s_memtime(); t_main += q1 - q0; q0 = q1; }
         sh.psum[c & 1u][rg][j] = part;
-        const double ws = wave_sum(part);
+        const double ws = (dbg & 2u) ? part * 64.0 : wave_sum(part);
         if (lane == 0) sh.wsum[c & 1u][wave] = ws;
         if (!Cfg::LOADER && wave == 0) {
             rec_stage(c + 1, tq);  // loaded one column ago
             tq = rec_load(c + 2);
         }
+        if (prof) { __builtin_amdgcn_s_waitcnt(0xc07f); __builtin_amdgcn_sched_barrier(0); unsigned long long q1 = __builtin_amdgcn_s_memtime(); t_red += q1 - q0; q0 = q1; }
         lds_barrier();
+        if (prof) { unsigned long long q1 = __builtin_amdgcn_s_memtime(); t_bar += q1 - q0; }
+    }
+    if (prof && lane == 0) {
+        unsigned long long* o = dc.prof + 16 + wave * 4;
+        o[0] = t_pre; o[1] = t_main; o[2] = t_red; o[3] = t_bar;
     }
     finalize(C - 1);
 }

@@ -10,6 +10,7 @@
 #include <math.h>
 #include <stdarg.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <mutex>
@@ -315,7 +316,7 @@ extern "C" pg_job* pg_job_create(int device, uint32_t n_contigs, const pg_contig
     job->contigs.resize(n_contigs);
     size_t off = 0;
     auto take = [&](size_t bytes) { size_t o = off; off = align_up(off + (bytes ? bytes : 8)); return o; };
-    struct Plan { size_t fback, fscale, bscale, pos, cov, koff, kcnt, aoff, aid, aflag, akoff, akmask, pa, goff, vrec, cvar, colrec, fwd, part, kept, apres, lik, likexp; };
+    struct Plan { size_t prof, fback, fscale, bscale, pos, cov, koff, kcnt, aoff, aid, aflag, akoff, akmask, pa, goff, vrec, cvar, colrec, fwd, part, kept, apres, lik, likexp; };
     std::vector<Plan> plan(n_contigs);
     const size_t o_contigs = take(sizeof(DevContig) * n_contigs);
     // zeroed-every-run block: n_cols, err, then per contig kept / allele_present / lik / lik_exp
@@ -333,6 +334,7 @@ extern "C" pg_job* pg_job_create(int device, uint32_t n_contigs, const pg_contig
         c.n_lik = nl;
         plan[i].kept = take(c.V);
         plan[i].fback = take(c.V);
+        plan[i].prof = take(64 * sizeof(unsigned long long));
         plan[i].apres = take(c.sumA);
         plan[i].lik = take(nl * sizeof(double));
         plan[i].likexp = take((size_t)c.V * sizeof(int32_t));
@@ -381,6 +383,7 @@ extern "C" pg_job* pg_job_create(int device, uint32_t n_contigs, const pg_contig
         memset(&d, 0, sizeof(d));
         d.V = c.V; d.H = c.H; d.HP = c.HP; d.RB = c.RB; d.T = c.T;
         d.dist_scale = (double)dist_scale; d.uniform = params->uniform ? 1 : 0;
+        { const char* dbg = getenv("PG_DEBUG"); d.debug = dbg ? (uint32_t)strtoul(dbg, nullptr, 0) : 0u; }
         d.pos = (const uint64_t*)(A + p.pos); d.cov = (const uint16_t*)(A + p.cov);
         d.kmer_off = (const uint32_t*)(A + p.koff); d.kmer_count = (const uint16_t*)(A + p.kcnt);
         d.allele_off = (const uint32_t*)(A + p.aoff); d.allele_id = (const uint16_t*)(A + p.aid);
@@ -389,7 +392,7 @@ extern "C" pg_job* pg_job_create(int device, uint32_t n_contigs, const pg_contig
         d.geno_off = (const uint64_t*)(A + p.goff);
         d.vrec = A + p.vrec; d.kept = A + p.kept; d.allele_present = A + p.apres;
         d.n_cols = job->d_ncols + i; d.col_variant = (uint32_t*)(A + p.cvar); d.colrec = A + p.colrec;
-        d.fwd = (double*)(A + p.fwd); d.part = (double*)(A + p.part); d.fwd_fallback = A + p.fback;
+        d.fwd = (double*)(A + p.fwd); d.part = (double*)(A + p.part); d.fwd_fallback = A + p.fback; d.prof = (unsigned long long*)(A + p.prof);
         d.fscale = (double*)(A + p.fscale); d.bscale = (double*)(A + p.bscale); d.err = job->d_err + i;
         d.lik = (double*)(A + p.lik); d.lik_exp = (int32_t*)(A + p.likexp);
         c.d = d;
@@ -509,6 +512,13 @@ extern "C" int pg_job_device_results(pg_job* job, uint32_t ci, void** d_lik, uin
     if (n_lik) *n_lik = c.n_lik;
     if (d_lik_exp) *d_lik_exp = c.d.lik_exp;
     if (n_variants) *n_variants = c.V;
+    return PG_OK;
+}
+
+extern "C" int pg_job_profile_counters(pg_job* job, uint32_t ci, uint64_t out64[64]) {
+    if (!job || !out64 || ci >= job->contigs.size()) return PG_ERR_INVALID;
+    if (hipSetDevice(job->device) != hipSuccess) return PG_ERR_DEVICE;
+    if (hipMemcpy(out64, job->contigs[ci].d.prof, 64 * sizeof(uint64_t), hipMemcpyDeviceToHost) != hipSuccess) return PG_ERR_DEVICE;
     return PG_OK;
 }
 

@@ -167,6 +167,11 @@ class Job:
         self._lib.pg_job_kernel_ms(self.h, ms)
         return {self._lib.pg_job_kernel_name(i).decode(): ms[i] for i in range(PG_N_KERNEL_CLASSES)}
 
+    def profile_counters(self, contig: int = 0) -> np.ndarray:
+        out = np.zeros(64, np.uint64)
+        self._lib.pg_job_profile_counters(self.h, contig, out.ctypes.data_as(u64p))
+        return out
+
     def device_bytes(self) -> int:
         return int(self._lib.pg_job_device_bytes(self.h))
 
