@@ -487,7 +487,7 @@ struct ChainShared {
     unsigned char rec[4][Cfg::RB] __attribute__((aligned(16)));
     double psum[2][Cfg::NRG][HP];
     double wsum[2][Cfg::NW];
-    double u[HP];
+    double u[Cfg::UNI ? Cfg::NW : 1][Cfg::UNI ? 64 : HP] __attribute__((aligned(16)));  // per-wave copy of the u vector
 };
 
 // workgroup barrier that orders LDS traffic only (global stores/loads stay in flight)
@@ -538,13 +538,17 @@ DEVI FastE fast_setup(const unsigned char* rec, uint32_t j, uint32_t i0) {
 }
 
 // u_i for the thread's rows.  UNI: every wave holds the u vector of the 64-column block that
-// contains its rows (urow) and rows are wave-uniform -> v_readlane into SGPRs.
+// contains its rows (urow, lane l = column rb+l); it parks it in a wave-private LDS row and reads
+// the R values back as broadcasts (one LDS round trip ~120 cycles; 2*R v_readlane cost ~20
+// cycles per value).  !UNI (single compute wave): the u vector of all HP columns is in LDS.
 template <int R, bool UNI>
-DEVI void row_values(const double* lds_u, double urow, uint32_t i0, double (&ui)[R]) {
+DEVI void row_values(double* lds_u /* this wave's row */, double urow, uint32_t lane, uint32_t i0, double (&ui)[R]) {
     if (UNI) {
-        const int base = __builtin_amdgcn_readfirstlane((int)(i0 & 63u));
+        lds_u[lane] = urow;
+        lds_wave_sync();
+        const uint32_t base = i0 & 63u;
 #pragma unroll
-        for (int k = 0; k < R; ++k) ui[k] = readlane_f64(urow, base + k);
+        for (int k = 0; k < R; ++k) ui[k] = lds_u[base + k];
     } else {
 #pragma unroll
         for (int k = 0; k < R; ++k) ui[k] = lds_u[i0 + k];
@@ -669,12 +673,22 @@ __global__ __launch_bounds__((ChainCfg<HP, R>::TT)) void k_forward(const DevCont
         }
     };
 
-    unsigned long long t_pre = 0, t_main = 0, t_red = 0, t_bar = 0;
+    unsigned long long t_pre = 0, t_main = 0, t_red = 0, t_bar = 0, t_f[3] = {0, 0, 0};
     const bool prof = (dbg & 8u) != 0;
     for (uint32_t c = 1; c < C; ++c) {
         unsigned long long q0 = prof ? __builtin_amdgcn_s_memtime() : 0;
-        finalize(c - 1);
+        // everything that depends only on the staged record is issued first so that its LDS
+        // latency overlaps the column-sum exchange
         const unsigned char* rec = sh.rec[c & 3u];
+        const bool fast = full && rec[PG_REC_NLOCAL] <= 2;
+        FastE fe;
+        uint32_t aj = 0;
+        if (fast) fe = fast_setup<Cfg::UNI>(rec, j, i0);
+        else aj = col_allele(rec, j);
+        unsigned long long f0 = 0, f1 = 0, f2 = 0;
+        if (prof) { __builtin_amdgcn_s_waitcnt(0xc07f); __builtin_amdgcn_sched_barrier(0); f0 = __builtin_amdgcn_s_memtime(); }
+        finalize(c - 1);
+        if (prof) { asm volatile("" : "+v"(S), "+v"(Cj)); __builtin_amdgcn_sched_barrier(0); f1 = __builtin_amdgcn_s_memtime(); }
         const double c0 = *(const double*)(rec + PG_REC_C0);
         const double c1 = *(const double*)(rec + PG_REC_C1);
         const double c2 = *(const double*)(rec + PG_REC_C2);
@@ -687,14 +701,14 @@ __global__ __launch_bounds__((ChainCfg<HP, R>::TT)) void k_forward(const DevCont
         const double uj = fma(k1, Cj, hk2);
         const double urow = fma(k1, Crow, hk2);
         if (!Cfg::UNI) {
-            if (rg == 0) sh.u[j] = uj;
+            if (rg == 0) sh.u[0][j] = uj;
             lds_wave_sync();
         }
-        row_values<R, Cfg::UNI>(sh.u, urow, i0, ui);
+        if (prof) { double tmp = uj; asm volatile("" : "+v"(tmp)); __builtin_amdgcn_sched_barrier(0); f2 = __builtin_amdgcn_s_memtime(); t_f[0] += f0 - q0; t_f[1] += f1 - f0; t_f[2] += f2 - f1; }
+        row_values<R, Cfg::UNI>(sh.u[Cfg::UNI ? wave : 0], urow, lane, i0, ui);
         if (prof) { __builtin_amdgcn_s_waitcnt(0xc07f); __builtin_amdgcn_sched_barrier(0); unsigned long long q1 = __builtin_amdgcn_s_memtime(); t_pre += q1 - q0; q0 = q1; }
         double part = 0.0;
-        if (full && rec[PG_REC_NLOCAL] <= 2) {
-            const FastE fe = fast_setup<Cfg::UNI>(rec, j, i0);
+        if (fast) {
 #pragma unroll
             for (int k = 0; k < R; ++k) {
                 const double e = ((fe.rowbits >> k) & 1u) ? fe.eB : fe.eA;
@@ -702,7 +716,6 @@ __global__ __launch_bounds__((ChainCfg<HP, R>::TT)) void k_forward(const DevCont
                 part += x[k];
             }
         } else {
-            const uint32_t aj = col_allele(rec, j);
 #pragma unroll
             for (int k = 0; k < R; ++k) {
                 x[k] = fma(k0, x[k], ui[k] + uj) * emission_at(rec, i0 + k, aj);
@@ -725,6 +738,7 @@ __global__ __launch_bounds__((ChainCfg<HP, R>::TT)) void k_forward(const DevCont
     if (prof && lane == 0) {
         unsigned long long* o = dc.prof + 16 + wave * 4;
         o[0] = t_pre; o[1] = t_main; o[2] = t_red; o[3] = t_bar;
+        if (wave == 0) { dc.prof[40] = t_f[0]; dc.prof[41] = t_f[1]; dc.prof[42] = t_f[2]; }
     }
     finalize(C - 1);
 }
@@ -936,11 +950,11 @@ __global__ __launch_bounds__((ChainCfg<HP, R>::TT)) void k_backward(const DevCon
         const double urow = fma(k1, Crow, hk2);
         if (!Cfg::UNI) {
             lds_wave_sync();  // previous step's reads of sh.u are done
-            if (rg == 0) sh.u[j] = uj;
+            if (rg == 0) sh.u[0][j] = uj;
             lds_wave_sync();
         }
         double ui[R > 16 ? 1 : R];
-        if constexpr (R <= 16) row_values<R, Cfg::UNI>(sh.u, urow, i0, ui);
+        if constexpr (R <= 16) row_values<R, Cfg::UNI>(sh.u[Cfg::UNI ? wave : 0], urow, lane, i0, ui);
 #pragma unroll
         for (int k = 0; k < R; ++k) {
             double wk;

@@ -15,3 +15,4 @@ print(" loader cycles/col: stage-wait %.0f  barrier %.0f"%(p[8]/(C/2), p[9]/(C/2
 for w in range(4):
     o=p[16+4*w:20+4*w]/C
     print(" wave",w,"cycles/col: pre %.0f main %.0f reduce %.0f barrier %.0f  total %.0f"%(o[0],o[1],o[2],o[3],o.sum()))
+print(" wave0 pre split cycles/col: setup(rec reads) %.0f  finalize(sums) %.0f  scale+u %.0f  -> rest = row_values" % tuple(p[40:43]/C))
