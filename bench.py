@@ -1,8 +1,8 @@
 #!/usr/bin/env python3
 """bench.py — throughput of the genotyping hot path (emissions + forward-backward HMM).
 
-A "step" = one full pass of the device path (k_prep -> k_compact -> k_records -> k_forward ->
-k_backward -> k_bins, plus the RCCL gather of the posteriors when N > 1) over one synthetic
+A "step" = one full pass of the device path (k_prep -> k_compact -> k_records -> k_sweep phase 1 ->
+k_sweep phase 2 -> k_bins, plus the RCCL gather of the posteriors when N > 1) over one synthetic
 contig batch that is already resident in HBM.  metric = genotyped variants/sec (whole job).
 
     python bench.py [--gpus N] [--steps K] [--warmup W] [--workload chr22_h64|contig_h16|...]
@@ -135,19 +135,19 @@ def main():
     if rank == 0:
         total_variants = V * world * args.steps
         value = total_variants / dt
-        # roofline of the dominant kernel (HBM-bound class).  Algorithmic bytes per launch
-        # (DESIGN.md §6): forward writes 8*H^2 per kept column, backward reads 8*H^2 per kept
-        # column; inputs/outputs (4K+2H+3A+16+8G+8 per variant) are charged to the backward launch.
+        # roofline of the dominant kernel (HBM-bound class), algorithmic bytes per launch
         kept = res.kept
         ncol = int(kept.sum())
         bytes_total = algorithmic_bytes(batch, kept)
-        fwd_bytes = 8.0 * H * H * ncol
-        bwd_bytes = bytes_total - fwd_bytes
-        dom = max(("k_forward", "k_backward"), key=lambda k: kms.get(k, 0.0))
-        dom_bytes = fwd_bytes if dom == "k_forward" else bwd_bytes
+        # sweep phase 1 writes every kept column once (8*H^2 B), phase 2 reads it once; the
+        # per-variant inputs/outputs (4K+2H+3A+16+8G+8 B) are charged to phase 2.
+        p1_bytes = 8.0 * H * H * ncol
+        p2_bytes = bytes_total - p1_bytes
+        dom = max(("k_sweep_phase1", "k_sweep_phase2"), key=lambda k: kms.get(k, 0.0))
+        dom_bytes = p1_bytes if dom == "k_sweep_phase1" else p2_bytes
         dom_ms = kms.get(dom, 0.0)
         achieved = dom_bytes / (dom_ms * 1e-3) / 1e9 if dom_ms > 0 else 0.0
-        sweep_ms = kms.get("k_forward", 0.0) + kms.get("k_backward", 0.0)
+        sweep_ms = kms.get("k_sweep_phase1", 0.0) + kms.get("k_sweep_phase2", 0.0)
         out = {
             "metric": "genotyped variants/sec (whole node) at H haplotypes; HBM GB/s vs roofline",
             "value": value, "unit": "variants/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -156,7 +156,7 @@ def main():
             "config": {"workload": f"{args.workload}: {w['cfg']}; {V} variants x {H} haplotypes x {K} k-mers/variant "
                                    f"per GPU, 1 contig (= 1 chain) per GPU, seed 12345+rank",
                        "variants_per_gpu": V, "haplotypes": H, "kmers_per_variant": K,
-                       "kept_columns": ncol, "chains_per_gpu": 1, "parallelism": f"contig-sharded x{world}"},
+                       "kept_columns": ncol, "chains_per_gpu": 1, "workgroups_per_chain": 2, "parallelism": f"contig-sharded x{world}"},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": None,
                          "algorithmic_bytes_per_launch": dom_bytes, "avg_launch_ms": dom_ms,

@@ -7,8 +7,9 @@
 //   colrec[C][RB] : the same records gathered in column order by k_records, with the
 //                   Li-Stephens constants of the gap (c-1 -> c) filled in.  This is the
 //                   ONE stream the chain kernels read besides the forward columns.
-//   fwd[C][HP*HP] : forward columns v_c = alpha_hat_c * fsum_c (fp64)  — written once by
-//                   k_forward, read once by k_backward: the 16*H^2 algorithmic bytes.
+//   fwd[C][HP*HP] : column slots (fp64): slot c holds the forward column of c < C/2 and the
+//                   backward column of c >= C/2 — written once in sweep phase 1, read once in
+//                   sweep phase 2: the 16*H^2 algorithmic bytes per column.
 //   part[C][AMAX][T] : per-thread posterior partials by row allele (reduced by k_bins)
 //   lik / lik_exp : outputs
 #pragma once
@@ -80,6 +81,7 @@ struct DevContig {
     double*   part;
     double*   fscale;        // [V] mantissa m of the scale applied to forward column c (see chain kernels)
     double*   bscale;        // [V] same for the backward column
+    double*   bsum;          // [V] sum of the stored backward column (hand-over between the phases)
     uint8_t*  fwd_fallback;  // [V] column c fell back to the uniform forward column (fsum := 1, no emission scale)
     uint32_t* err;
     unsigned long long* prof;  // [64] in-kernel cycle counters (PG_DEBUG bit 3), profiling only

@@ -439,24 +439,34 @@ __global__ __launch_bounds__(256) void k_records(const DevContig* __restrict__ c
 }
 
 // ------------------------------------------------------------------------------------------
-//  chain kernels
+//  chain kernels (meet in the middle)
+//
+//  One chain = one (contig, path subset).  The recursion is strictly sequential over its C
+//  columns, so the only exact parallelism inside a chain is the two directions: k_sweep runs
+//  the forward half-chain and the backward half-chain as two workgroups at once.
+//    phase 1 : forward  computes columns 0 .. mid-1   and stores v'_t   into slot t   (t <  mid)
+//              backward computes columns C-1 .. mid   and stores beta'_t into slot t  (t >= mid)
+//    phase 2 : forward  continues mid .. C-1, loads beta'_t from slot t, emits posterior partials
+//              backward continues mid-1 .. 0, loads v'_t    from slot t, emits posterior partials
+//  Every column is written once and read once (the 16*H^2 algorithmic bytes), by workgroups on
+//  different CUs, and the wall time of a chain is C/2 + C/2 column steps instead of 2C.  The
+//  hand-over at `mid` goes through the stored columns, i.e. through a kernel boundary — no
+//  inter-workgroup flags, nothing placement dependent.
 //
 //  Workgroup = T compute threads + one LOADER wave (the last wave).  VMEM counters are per
-//  wave, so the split keeps every wait off the recursion's critical path:
-//    * compute waves of k_forward only STORE (the forward column) and never wait on VMEM;
-//    * compute waves of k_backward only LOAD (the prefetched forward column);
-//    * the loader wave streams the column records HBM -> LDS two columns ahead and, in
-//      k_backward, drains the posterior partials LDS -> HBM.
-//  The per-column workgroup barrier orders LDS only (no vmcnt wait).  All global pointers are
-//  address_space(1) so that stores/loads are global_* (FLAT ops would also tick lgkmcnt and
-//  put the HBM latency back on the LDS waits).
+//  wave, so the split keeps every wait off the recursion's critical path: compute waves of a
+//  storing phase only STORE, compute waves of a posterior phase only LOAD (prefetched), and
+//  the loader wave streams the column records HBM -> LDS ahead of use and drains the posterior
+//  partials LDS -> HBM.  The per-column workgroup barrier orders LDS only (no vmcnt wait).
+//  All global pointers are address_space(1) so that accesses are global_* (FLAT ops would also
+//  tick lgkmcnt and put the HBM latency back on the LDS waits).
 //
 //  Scaling.  The reference normalises every column by its sum (a division on the critical
 //  path).  Here a column is rescaled by the exact power of two 2^-e, e = exponent(sum), and
 //  the mantissa m = sum * 2^-e in [0.5,1) goes to a side array; the true
-//  alpha_hat_c * fsum_c is the stored column divided by m_{c-1} (k_bins does that division,
-//  off the chain).  Same for the backward column.  Results are the reference's values up to
-//  fp64 rounding; no drift because every step renormalises to within a factor of 2.
+//  alpha_hat_c * fsum_c is the stored column divided by m (k_bins does that division, off the
+//  chain).  Same for the backward column.  Results are the reference's values up to fp64
+//  rounding; no drift because every step renormalises to within a factor of 2.
 // ------------------------------------------------------------------------------------------
 #define GAS __attribute__((address_space(1)))
 typedef GAS double gdouble;
@@ -488,6 +498,7 @@ struct ChainShared {
     double psum[2][Cfg::NRG][HP];
     double wsum[2][Cfg::NW];
     double u[Cfg::UNI ? Cfg::NW : 1][Cfg::UNI ? 64 : HP] __attribute__((aligned(16)));  // per-wave copy of the u vector
+    double pout[Cfg::LOADER ? 2 : 1][PG_AMAX][Cfg::LOADER ? Cfg::T : 1];                  // posterior partials of two columns
 };
 
 // workgroup barrier that orders LDS traffic only (global stores/loads stay in flight)
@@ -555,53 +566,144 @@ DEVI void row_values(double* lds_u /* this wave's row */, double urow, uint32_t 
     }
 }
 
+// per-thread coordinates of a compute thread
+struct ThreadPos {
+    uint32_t tid, lane, wave, j, rg, i0, rb;
+};
+
+// column sums of the previous column out of the LDS exchange buffers
 template <int HP, int R>
-__global__ __launch_bounds__((ChainCfg<HP, R>::TT)) void k_forward(const DevContig* __restrict__ contigs) {
+DEVI void read_sums(const ChainShared<HP, R>& sh, uint32_t pb, const ThreadPos& p, double& Cj, double& Crow, double& S) {
     using Cfg = ChainCfg<HP, R>;
-    __shared__ ChainShared<HP, R> sh;
-    const DevContig& dc = contigs[blockIdx.x];
-    if (dc.HP != (uint32_t)HP) return;
-    const uint32_t C = *dc.n_cols;
-    if (C == 0) return;
-    const uint32_t tid = threadIdx.x, lane = tid & 63u;
-    const uint32_t wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    Cj = 0.0;
+#pragma unroll
+    for (int g = 0; g < Cfg::NRG; ++g) Cj += sh.psum[pb][g][p.j];
+    if (Cfg::UNI && HP > 64) {
+        Crow = 0.0;
+#pragma unroll
+        for (int g = 0; g < Cfg::NRG; ++g) Crow += sh.psum[pb][g][p.rb + p.lane];
+    } else {
+        Crow = Cj;
+    }
+    S = 0.0;
+#pragma unroll
+    for (int w = 0; w < Cfg::NW; ++w) S += sh.wsum[pb][w];
+}
+template <int HP, int R>
+DEVI void write_sums(ChainShared<HP, R>& sh, uint32_t pb, const ThreadPos& p, double part) {
+    sh.psum[pb][p.rg][p.j] = part;
+    const double ws = wave_sum(part);
+    if (p.lane == 0) sh.wsum[pb][p.wave] = ws;
+}
+
+// posterior partials of column c: acc[a] = sum over my rows with local allele a of v*beta
+template <int HP, int R>
+DEVI void posterior(ChainShared<HP, R>& sh, gdouble* part_out, bool full, uint32_t c, const ThreadPos& p,
+                    const double (&v)[R], const double (&beta)[R]) {
+    using Cfg = ChainCfg<HP, R>;
+    const unsigned char* rec0 = sh.rec[c & 3u];
+    const uint32_t nl = rec0[PG_REC_NLOCAL];
+    double acc[PG_AMAX];
+#pragma unroll
+    for (int a = 0; a < PG_AMAX; ++a) acc[a] = 0.0;
+    if (full && nl <= 2) {
+        const unsigned long long* bits = (const unsigned long long*)(rec0 + PG_REC_BITS1);
+        uint32_t rbits = (uint32_t)(bits[p.i0 >> 6] >> (p.i0 & 63u));
+        if (Cfg::UNI) rbits = __builtin_amdgcn_readfirstlane(rbits);
+#pragma unroll
+        for (int k = 0; k < R; ++k) {
+            const double pr = v[k] * beta[k];
+            if ((rbits >> k) & 1u) acc[1] += pr;
+            else acc[0] += pr;
+        }
+    } else {
+        const unsigned char* al = rec0 + PG_REC_ALLELES;
+#pragma unroll
+        for (int k = 0; k < R; ++k) {
+            const uint32_t ai = al[p.i0 + k];
+            const double pr = v[k] * beta[k];
+#pragma unroll
+            for (int a = 0; a < PG_AMAX; ++a)
+                if (ai == (uint32_t)a) acc[a] += pr;
+            if constexpr (R > 16) { if ((k & 7) == 7) __builtin_amdgcn_sched_barrier(0); }
+        }
+    }
+    if constexpr (Cfg::LOADER) {
+#pragma unroll
+        for (int a = 0; a < PG_AMAX; ++a)
+            if ((uint32_t)a < nl) sh.pout[c & 1u][a][p.tid] = acc[a];
+    } else {
+        gdouble* dst = part_out + (size_t)c * PG_AMAX * Cfg::T + p.tid;
+#pragma unroll
+        for (int a = 0; a < PG_AMAX; ++a)
+            if ((uint32_t)a < nl) dst[(size_t)a * Cfg::T] = acc[a];
+    }
+}
+
+// loader: drain the posterior partials of column c (LDS -> HBM)
+template <int HP, int R>
+DEVI void flush_partials(const ChainShared<HP, R>& sh, gdouble* part_out, int64_t c, int64_t lo, int64_t hi, uint32_t lane) {
+    using Cfg = ChainCfg<HP, R>;
+    if (c < lo || c >= hi) return;
+    const uint32_t nl = sh.rec[(uint32_t)c & 3u][PG_REC_NLOCAL];
+    gdouble* dst = part_out + (size_t)c * PG_AMAX * Cfg::T;
+    for (uint32_t a = 0; a < nl; ++a)
+        for (uint32_t t = lane; t < (uint32_t)Cfg::T; t += 64)
+            dst[(size_t)a * Cfg::T + t] = sh.pout[Cfg::LOADER ? ((uint32_t)c & 1u) : 0][a][Cfg::LOADER ? t : 0];
+}
+
+// ------------------------------------------------------------------------------------------
+//  forward half-chain   (reference src/hmm.cpp:76-90, 175-273)
+// ------------------------------------------------------------------------------------------
+template <int HP, int R, int PHASE>
+DEVI void forward_body(const DevContig& dc, ChainShared<HP, R>& sh, uint32_t C) {
+    using Cfg = ChainCfg<HP, R>;
+    const uint32_t mid = C / 2;
+    const uint32_t lo = PHASE == 1 ? 0u : mid, hi = PHASE == 1 ? mid : C;
+    if (lo >= hi) return;
+    const uint32_t first = lo == 0 ? 1u : lo;  // first column produced by a recursion step
+    ThreadPos p;
+    p.tid = threadIdx.x; p.lane = p.tid & 63u;
+    p.wave = __builtin_amdgcn_readfirstlane(p.tid >> 6);
     gcu64* colrec = (gcu64*)dc.colrec;
+    gdouble* part_out = (gdouble*)dc.part;
 
     auto rec_load = [&](uint32_t c) -> unsigned long long {
-        if (lane < (uint32_t)Cfg::WORDS && c < C) return colrec[(size_t)c * Cfg::WORDS + lane];
+        if (p.lane < (uint32_t)Cfg::WORDS && c < C) return colrec[(size_t)c * Cfg::WORDS + p.lane];
         return 0ull;
     };
     auto rec_stage = [&](uint32_t c, unsigned long long w) {
-        if (lane < (uint32_t)Cfg::WORDS) ((unsigned long long*)sh.rec[c & 3u])[lane] = w;
+        if (p.lane < (uint32_t)Cfg::WORDS) ((unsigned long long*)sh.rec[c & 3u])[p.lane] = w;
     };
-    if (Cfg::LOADER && wave == (uint32_t)Cfg::NW) {
+    if (Cfg::LOADER && p.wave == (uint32_t)Cfg::NW) {
         // ------------------------------- loader wave ---------------------------------
-        rec_stage(0, rec_load(0));
-        rec_stage(1, rec_load(1));
-        unsigned long long tE = rec_load(2), tO = rec_load(3);
-        lds_barrier();  // records 0,1 staged
-        lds_barrier();  // column 0 done
-        unsigned long long t_stage = 0, t_bar = 0;
-        const bool prof = (dc.debug & 8u) != 0;
-        for (uint32_t c = 1; c < C; c += 2) {
-            unsigned long long a0 = prof ? __builtin_amdgcn_s_memtime() : 0;
-            rec_stage(c + 1, tE);  // loaded two columns ago
-            if (prof) { __builtin_amdgcn_s_waitcnt(0); unsigned long long a1 = __builtin_amdgcn_s_memtime(); t_stage += a1 - a0; a0 = a1; }
-            tE = rec_load(c + 3);
-            lds_barrier();
-            if (prof) { unsigned long long a1 = __builtin_amdgcn_s_memtime(); t_bar += a1 - a0; }
-            if (c + 1 < C) {
-                rec_stage(c + 2, tO);
-                tO = rec_load(c + 4);
-                lds_barrier();
+        if (lo == 0) rec_stage(0, rec_load(0));
+        rec_stage(first, rec_load(first));
+        unsigned long long ta = rec_load(first + 1), tb = rec_load(first + 2);
+        lds_barrier();  // P0: first records staged
+        lds_barrier();  // Bx: column lo initialised / resumed
+        for (uint32_t t = first; t < hi; t += 2) {
+            rec_stage(t + 1, ta);  // loaded two columns ago
+            ta = rec_load(t + 3);
+            if (PHASE == 2) flush_partials<HP, R>(sh, part_out, (int64_t)t - 2, mid, C, p.lane);
+            lds_barrier();  // B_t
+            if (t + 1 < hi) {
+                rec_stage(t + 2, tb);
+                tb = rec_load(t + 4);
+                if (PHASE == 2) flush_partials<HP, R>(sh, part_out, (int64_t)t - 1, mid, C, p.lane);
+                lds_barrier();  // B_{t+1}
             }
         }
-        if (prof && lane == 0) { dc.prof[8] = t_stage; dc.prof[9] = t_bar; }
+        if (PHASE == 2) {
+            flush_partials<HP, R>(sh, part_out, (int64_t)hi - 2, mid, C, p.lane);
+            lds_barrier();  // F
+            flush_partials<HP, R>(sh, part_out, (int64_t)hi - 1, mid, C, p.lane);
+        }
         return;
     }
 
     // --------------------------------- compute waves -------------------------------------
-    const uint32_t j = tid % HP, rg = tid / HP, i0 = rg * R;
+    p.j = p.tid % HP; p.rg = p.tid / HP; p.i0 = p.rg * R; p.rb = (p.i0 / 64u) * 64u;
     const uint32_t H = dc.H;
     const bool full = H == (uint32_t)HP;
     const double unif = 1.0 / ((double)H * (double)H);
@@ -609,303 +711,268 @@ __global__ __launch_bounds__((ChainCfg<HP, R>::TT)) void k_forward(const DevCont
     gdouble* fscale = (gdouble*)dc.fscale;
     gu8* fallback = (gu8*)dc.fwd_fallback;
     const size_t colsz = (size_t)HP * HP;
-    const uint32_t rb = (i0 / 64u) * 64u;  // first column of the 64-block that contains my rows (UNI)
-
     const uint32_t dbg = dc.debug;
+
     auto store_col = [&](uint32_t c, const double (&x)[R]) {
         if (dbg & 1u) return;
-        gdouble* dst = fwd + (size_t)c * colsz + (size_t)i0 * HP + j;
+        gdouble* dst = fwd + (size_t)c * colsz + (size_t)p.i0 * HP + p.j;
 #pragma unroll
         for (int k = 0; k < R; ++k) dst[(size_t)k * HP] = x[k];
     };
-
-    double x[R], ui[R];
-    double Cj = 0.0, Crow = 0.0, S = 0.0;
-    unsigned long long tq = 0;  // inline loader (no loader wave): record c+2 in flight
-    if (!Cfg::LOADER && wave == 0) {
-        rec_stage(0, rec_load(0));
-        rec_stage(1, rec_load(1));
-        tq = rec_load(2);
-    }
-
-    lds_barrier();  // records 0,1 staged by the loader
-
-    // column 0: v_0 = e_0 (reference src/hmm.cpp:236-238, previous_cell = 1)
-    {
-        const uint32_t aj = col_allele(sh.rec[0], j);
-        double part = 0.0;
-#pragma unroll
-        for (int k = 0; k < R; ++k) { x[k] = emission_at(sh.rec[0], i0 + k, aj); part += x[k]; }
-        store_col(0, x);
-        if (tid == 0) fscale[0] = 1.0;
-        sh.psum[0][rg][j] = part;
-        const double ws = wave_sum(part);
-        if (lane == 0) sh.wsum[0][wave] = ws;
-    }
-    lds_barrier();
-
-    // sums of column cprev; uniform fallback if the column summed to zero (hmm.cpp:253-267)
-    auto finalize = [&](uint32_t cprev) {
-        const uint32_t pb = cprev & 1u;
-        Cj = 0.0;
-#pragma unroll
-        for (int g = 0; g < Cfg::NRG; ++g) Cj += sh.psum[pb][g][j];
-        if (Cfg::UNI && HP > 64) {
-            Crow = 0.0;
-#pragma unroll
-            for (int g = 0; g < Cfg::NRG; ++g) Crow += sh.psum[pb][g][rb + lane];
-        } else {
-            Crow = Cj;
-        }
-        S = 0.0;
-#pragma unroll
-        for (int w = 0; w < Cfg::NW; ++w) S += sh.wsum[pb][w];
-        if (!(S > 0.0) || !(S < INFINITY)) {
-#pragma unroll
-            for (int k = 0; k < R; ++k) x[k] = (j < H && i0 + k < H) ? unif : 0.0;
-            store_col(cprev, x);
-            // alpha_hat*fsum = 1/H^2 is an absolute value: it carries neither the emission
-            // exponent X_c nor the column scale; k_bins treats flagged columns accordingly.
-            if (tid == 0) fallback[cprev] = 1;
-            Cj = j < H ? (double)H * unif : 0.0;
-            Crow = (rb + lane) < H ? (double)H * unif : 0.0;
-            S = 1.0;
-        }
-    };
-
-    unsigned long long t_pre = 0, t_main = 0, t_red = 0, t_bar = 0, t_f[3] = {0, 0, 0};
-    const bool prof = (dbg & 8u) != 0;
-    for (uint32_t c = 1; c < C; ++c) {
-        unsigned long long q0 = prof ? __builtin_amdgcn_s_memtime() : 0;
-        // everything that depends only on the staged record is issued first so that its LDS
-        // latency overlaps the column-sum exchange
-        const unsigned char* rec = sh.rec[c & 3u];
-        const bool fast = full && rec[PG_REC_NLOCAL] <= 2;
-        FastE fe;
-        uint32_t aj = 0;
-        if (fast) fe = fast_setup<Cfg::UNI>(rec, j, i0);
-        else aj = col_allele(rec, j);
-        unsigned long long f0 = 0, f1 = 0, f2 = 0;
-        if (prof) { __builtin_amdgcn_s_waitcnt(0xc07f); __builtin_amdgcn_sched_barrier(0); f0 = __builtin_amdgcn_s_memtime(); }
-        finalize(c - 1);
-        if (prof) { asm volatile("" : "+v"(S), "+v"(Cj)); __builtin_amdgcn_sched_barrier(0); f1 = __builtin_amdgcn_s_memtime(); }
-        const double c0 = *(const double*)(rec + PG_REC_C0);
-        const double c1 = *(const double*)(rec + PG_REC_C1);
-        const double c2 = *(const double*)(rec + PG_REC_C2);
-        // alpha_hat_{c-1} = x / S.  Scale by 2^-es instead of dividing: the new column is
-        // (true v_c) * m with m = S * 2^-es in [0.5,1); m goes to the side array.
-        const int es = exponent_of(S);
-        const double m = ldexp(S, -es);
-        const double k0 = ldexp(c0, -es), k1 = ldexp(c1, -es), hk2 = 0.5 * c2 * m;
-        if (tid == 0) fscale[c] = m;
-        const double uj = fma(k1, Cj, hk2);
-        const double urow = fma(k1, Crow, hk2);
-        if (!Cfg::UNI) {
-            if (rg == 0) sh.u[0][j] = uj;
-            lds_wave_sync();
-        }
-        if (prof) { double tmp = uj; asm volatile("" : "+v"(tmp)); __builtin_amdgcn_sched_barrier(0); f2 = __builtin_amdgcn_s_memtime(); t_f[0] += f0 - q0; t_f[1] += f1 - f0; t_f[2] += f2 - f1; }
-        row_values<R, Cfg::UNI>(sh.u[Cfg::UNI ? wave : 0], urow, lane, i0, ui);
-        if (prof) { __builtin_amdgcn_s_waitcnt(0xc07f); __builtin_amdgcn_sched_barrier(0); unsigned long long q1 = __builtin_amdgcn_s_memtime(); t_pre += q1 - q0; q0 = q1; }
-        double part = 0.0;
-        if (fast) {
-#pragma unroll
-            for (int k = 0; k < R; ++k) {
-                const double e = ((fe.rowbits >> k) & 1u) ? fe.eB : fe.eA;
-                x[k] = fma(k0, x[k], ui[k] + uj) * e;
-                part += x[k];
-            }
-        } else {
-#pragma unroll
-            for (int k = 0; k < R; ++k) {
-                x[k] = fma(k0, x[k], ui[k] + uj) * emission_at(rec, i0 + k, aj);
-                part += x[k];
-            }
-        }
-        store_col(c, x);
-        if (prof) { __builtin_amdgcn_sched_barrier(0); unsigned long long q1 = __builtin_amdgcn_s_memtime(); t_main += q1 - q0; q0 = q1; }
-        sh.psum[c & 1u][rg][j] = part;
-        const double ws = (dbg & 2u) ? part * 64.0 : wave_sum(part);
-        if (lane == 0) sh.wsum[c & 1u][wave] = ws;
-        if (!Cfg::LOADER && wave == 0) {
-            rec_stage(c + 1, tq);  // loaded one column ago
-            tq = rec_load(c + 2);
-        }
-        if (prof) { __builtin_amdgcn_s_waitcnt(0xc07f); __builtin_amdgcn_sched_barrier(0); unsigned long long q1 = __builtin_amdgcn_s_memtime(); t_red += q1 - q0; q0 = q1; }
-        lds_barrier();
-        if (prof) { unsigned long long q1 = __builtin_amdgcn_s_memtime(); t_bar += q1 - q0; }
-    }
-    if (prof && lane == 0) {
-        unsigned long long* o = dc.prof + 16 + wave * 4;
-        o[0] = t_pre; o[1] = t_main; o[2] = t_red; o[3] = t_bar;
-        if (wave == 0) { dc.prof[40] = t_f[0]; dc.prof[41] = t_f[1]; dc.prof[42] = t_f[2]; }
-    }
-    finalize(C - 1);
-}
-
-// VBUF = number of forward-column register buffers (prefetch distance in columns)
-// KEEPW = keep w = beta_hat*e in registers across the column-sum exchange (else recompute it)
-template <int HP, int R, int VBUF, bool KEEPW>
-__global__ __launch_bounds__((ChainCfg<HP, R>::TT)) void k_backward(const DevContig* __restrict__ contigs) {
-    using Cfg = ChainCfg<HP, R>;
-    __shared__ ChainShared<HP, R> sh;
-    __shared__ double s_pout[Cfg::LOADER ? 2 : 1][PG_AMAX][Cfg::LOADER ? Cfg::T : 1];  // partials of the last two columns
-    const DevContig& dc = contigs[blockIdx.x];
-    if (dc.HP != (uint32_t)HP) return;
-    const uint32_t C = *dc.n_cols;
-    if (C == 0) return;
-    const uint32_t tid = threadIdx.x, lane = tid & 63u;
-    const uint32_t wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    gcu64* colrec = (gcu64*)dc.colrec;
-    const int64_t last = (int64_t)C - 1;
-
-    gdouble* part_out = (gdouble*)dc.part;
-    auto rec_load = [&](int64_t c) -> unsigned long long {
-        if (lane < (uint32_t)Cfg::WORDS && c >= 0) return colrec[(size_t)c * Cfg::WORDS + lane];
-        return 0ull;
-    };
-    auto rec_stage = [&](int64_t c, unsigned long long w) {
-        if (lane < (uint32_t)Cfg::WORDS && c >= 0) ((unsigned long long*)sh.rec[(uint32_t)c & 3u])[lane] = w;
-    };
-    if (Cfg::LOADER && wave == (uint32_t)Cfg::NW) {
-        // ------------------------------- loader wave ---------------------------------
-        // drain the posterior partials of column c (LDS -> HBM)
-        auto flush = [&](int64_t c) {
-            if (c < 0 || c > last) return;
-            const uint32_t nl = sh.rec[(uint32_t)c & 3u][PG_REC_NLOCAL];
-            gdouble* dst = part_out + (size_t)c * PG_AMAX * Cfg::T;
-            for (uint32_t a = 0; a < nl; ++a)
-                for (uint32_t t = lane; t < (uint32_t)Cfg::T; t += 64)
-                    dst[(size_t)a * Cfg::T + t] = s_pout[(uint32_t)c & 1u][a][t];
-        };
-        rec_stage(last, rec_load(last));
-        rec_stage(last - 1, rec_load(last - 1));
-        unsigned long long tA = rec_load(last - 2), tB = rec_load(last - 3);
-        lds_barrier();  // P0: records last, last-1 staged
-        for (int64_t c = last - 1; c >= 0; c -= 2) {
-            rec_stage(c - 1, tA);
-            tA = rec_load(c - 3);
-            flush(c + 2);
-            lds_barrier();  // B_c
-            if (c - 1 >= 0) {
-                rec_stage(c - 2, tB);
-                tB = rec_load(c - 4);
-                flush(c + 1);
-                lds_barrier();  // B_{c-1}
-            }
-        }
-        // columns 1 and 0 are still in LDS
-        flush(1);
-        lds_barrier();  // F
-        flush(0);
-        return;
-    }
-
-    // --------------------------------- compute waves -------------------------------------
-    const uint32_t j = tid % HP, rg = tid / HP, i0 = rg * R;
-    const uint32_t H = dc.H;
-    const bool full = H == (uint32_t)HP;
-    const double unif = 1.0 / ((double)H * (double)H);
-    gcdouble* fwd = (gcdouble*)dc.fwd;
-    gdouble* bscale = (gdouble*)dc.bscale;
-    const size_t colsz = (size_t)HP * HP;
-    const uint32_t rb = (i0 / 64u) * 64u;
-
-    auto load_col = [&](int64_t c, double (&v)[R]) {
-        if (c < 0) return;
-        gcdouble* src = fwd + (size_t)c * colsz + (size_t)i0 * HP + j;
+    auto load_col = [&](uint32_t c, double (&v)[R]) {
+        if (c >= C) return;
+        gcdouble* src = (gcdouble*)fwd + (size_t)c * colsz + (size_t)p.i0 * HP + p.j;
 #pragma unroll
         for (int k = 0; k < R; ++k) v[k] = src[(size_t)k * HP];
     };
 
-    double y[R], vA[R], vB[VBUF == 2 ? R : 1];
-    double Sy = 0.0;
-    unsigned long long tq = 0;  // inline loader (no loader wave): record c-2 in flight
-    if (!Cfg::LOADER && wave == 0) {
-        rec_stage(last, rec_load(last));
-        rec_stage(last - 1, rec_load(last - 1));
-        tq = rec_load(last - 2);
+    constexpr int FB = R > 16 ? 1 : 2;  // beta' prefetch buffers (register budget at R = 32)
+    double x[R], ui[R > 16 ? 1 : R];
+    double vA[PHASE == 2 ? R : 1], vB[(PHASE == 2 && FB == 2) ? R : 1];  // prefetched beta' columns (phase 2)
+    double Cj = 0.0, Crow = 0.0, S = 0.0;
+    unsigned long long tq = 0;  // inline loader (no loader wave): next record in flight
+    if (!Cfg::LOADER && p.wave == 0) {
+        if (lo == 0) rec_stage(0, rec_load(0));
+        rec_stage(first, rec_load(first));
+        tq = rec_load(first + 1);
     }
-
-    load_col(last, vA);
-    if constexpr (VBUF == 2) load_col(last - 1, vB);
+    if constexpr (PHASE == 2) { load_col(mid, vA); if constexpr (FB == 2) load_col(mid + 1, vB); }
     lds_barrier();  // P0
 
-    // posterior partials of column c: acc[a] = sum over my rows with allele a of v*beta
-    auto posterior = [&](uint32_t c, const double (&v)[R], const double (&beta)[R]) {
-        const unsigned char* rec0 = sh.rec[c & 3u];
-        const uint32_t nl = rec0[PG_REC_NLOCAL];
-        double acc[PG_AMAX];
+    if (lo == 0) {
+        // column 0: v_0 = e_0 (reference src/hmm.cpp:236-238, previous_cell = 1)
+        const uint32_t aj = col_allele(sh.rec[0], p.j);
+        double part = 0.0;
 #pragma unroll
-        for (int a = 0; a < PG_AMAX; ++a) acc[a] = 0.0;
-        if (full && nl <= 2) {
-            const unsigned long long* bits = (const unsigned long long*)(rec0 + PG_REC_BITS1);
-            uint32_t rbits = (uint32_t)(bits[i0 >> 6] >> (i0 & 63u));
-            if (Cfg::UNI) rbits = __builtin_amdgcn_readfirstlane(rbits);
+        for (int k = 0; k < R; ++k) { x[k] = emission_at(sh.rec[0], p.i0 + k, aj); part += x[k]; }
+        if (PHASE == 1) store_col(0, x);
+        if (p.tid == 0) fscale[0] = 1.0;
+        write_sums<HP, R>(sh, 0, p, part);
+    } else {
+        // resume behind the column the other phase stored last
+        gcdouble* src = (gcdouble*)fwd + (size_t)(lo - 1) * colsz + (size_t)p.i0 * HP + p.j;
+        double part = 0.0;
 #pragma unroll
-            for (int k = 0; k < R; ++k) {
-                const double p = v[k] * beta[k];
-                if ((rbits >> k) & 1u) acc[1] += p;
-                else acc[0] += p;
-            }
-        } else {
-            const unsigned char* al = rec0 + PG_REC_ALLELES;
+        for (int k = 0; k < R; ++k) { x[k] = src[(size_t)k * HP]; part += x[k]; }
+        write_sums<HP, R>(sh, (lo - 1) & 1u, p, part);
+    }
+    lds_barrier();  // Bx
+
+    // sums of column cprev; uniform fallback if the column summed to zero (hmm.cpp:253-267)
+    auto finalize = [&](uint32_t cprev) {
+        read_sums<HP, R>(sh, cprev & 1u, p, Cj, Crow, S);
+        if (!(S > 0.0) || !(S < INFINITY)) {
 #pragma unroll
-            for (int k = 0; k < R; ++k) {
-                const uint32_t ai = al[i0 + k];
-                const double p = v[k] * beta[k];
-#pragma unroll
-                for (int a = 0; a < PG_AMAX; ++a)
-                    if (ai == (uint32_t)a) acc[a] += p;
-                if constexpr (R > 16) { if ((k & 7) == 7) __builtin_amdgcn_sched_barrier(0); }
-            }
-        }
-        if constexpr (Cfg::LOADER) {
-#pragma unroll
-            for (int a = 0; a < PG_AMAX; ++a)
-                if ((uint32_t)a < nl) s_pout[c & 1u][a][tid] = acc[a];
-        } else {
-            gdouble* dst = part_out + (size_t)c * PG_AMAX * Cfg::T + tid;
-#pragma unroll
-            for (int a = 0; a < PG_AMAX; ++a)
-                if ((uint32_t)a < nl) dst[(size_t)a * Cfg::T] = acc[a];
+            for (int k = 0; k < R; ++k) x[k] = (p.j < H && p.i0 + k < H) ? unif : 0.0;
+            if (PHASE == 1) store_col(cprev, x);
+            // alpha_hat*fsum = 1/H^2 is an absolute value: it carries neither the emission
+            // exponent X_c nor the column scale; k_bins treats flagged columns accordingly.
+            if (p.tid == 0) fallback[cprev] = 1;
+            Cj = p.j < H ? (double)H * unif : 0.0;
+            Crow = (p.rb + p.lane) < H ? (double)H * unif : 0.0;
+            S = 1.0;
         }
     };
 
-    // column C-1: beta~ = 1 (reference src/hmm.cpp:356-358); sum = H^2
-    {
-        double beta[R];
+    auto step = [&](uint32_t t, double (&vb)[PHASE == 2 ? R : 1]) {
+        // everything that depends only on the staged record is issued first so that its LDS
+        // latency overlaps the column-sum exchange
+        const unsigned char* rec = sh.rec[t & 3u];
+        const bool fast = full && rec[PG_REC_NLOCAL] <= 2;
+        FastE fe;
+        uint32_t aj = 0;
+        if (fast) fe = fast_setup<Cfg::UNI>(rec, p.j, p.i0);
+        else aj = col_allele(rec, p.j);
+        finalize(t - 1);
+        if constexpr (PHASE == 2) {
+            if (t - 1 >= mid) {
+                posterior<HP, R>(sh, part_out, full, t - 1, p, x, vb);
+                load_col(t - 1 + FB, vb);
+            }
+        }
+        const double c0 = *(const double*)(rec + PG_REC_C0);
+        const double c1 = *(const double*)(rec + PG_REC_C1);
+        const double c2 = *(const double*)(rec + PG_REC_C2);
+        // alpha_hat_{t-1} = x / S.  Scale by 2^-es instead of dividing: the new column is
+        // (true v_t) * m with m = S * 2^-es in [0.5,1); m goes to the side array.
+        const int es = exponent_of(S);
+        const double m = ldexp(S, -es);
+        const double k0 = ldexp(c0, -es), k1 = ldexp(c1, -es), hk2 = 0.5 * c2 * m;
+        if (p.tid == 0) fscale[t] = m;
+        const double uj = fma(k1, Cj, hk2);
+        const double urow = fma(k1, Crow, hk2);
+        if (!Cfg::UNI) {
+            if (p.rg == 0) sh.u[0][p.j] = uj;
+            lds_wave_sync();
+        }
+        if constexpr (R <= 16) row_values<R, Cfg::UNI>(sh.u[Cfg::UNI ? p.wave : 0], urow, p.lane, p.i0, ui);
+        double part = 0.0;
 #pragma unroll
-        for (int k = 0; k < R; ++k) beta[k] = (j < H && i0 + k < H) ? 1.0 : 0.0;
-        posterior((uint32_t)last, vA, beta);
-        if (tid == 0) bscale[last] = 1.0;
-#pragma unroll
-        for (int k = 0; k < R; ++k) y[k] = beta[k];
-        Sy = (double)H * (double)H;
-        load_col(last - VBUF, vA);
+        for (int k = 0; k < R; ++k) {
+            double uik;
+            if constexpr (R <= 16) uik = ui[k];
+            else uik = readlane_f64(urow, __builtin_amdgcn_readfirstlane((int)((p.i0 + k) & 63u)));
+            const double e = fast ? (((fe.rowbits >> k) & 1u) ? fe.eB : fe.eA) : emission_at(rec, p.i0 + k, aj);
+            x[k] = fma(k0, x[k], uik + uj) * e;
+            part += x[k];
+            if constexpr (R > 16) { if ((k & 7) == 7) __builtin_amdgcn_sched_barrier(0); }
+        }
+        if (PHASE == 1) store_col(t, x);
+        write_sums<HP, R>(sh, t & 1u, p, part);
+        if (!Cfg::LOADER && p.wave == 0) {
+            rec_stage(t + 1, tq);  // loaded one column ago
+            tq = rec_load(t + 2);
+        }
+        lds_barrier();  // B_t
+    };
+
+    // the posterior of column q uses buffer (q - mid) & 1; the first step handles q = first-1
+    if constexpr (PHASE == 2 && FB == 2) {
+        if (lo == 0) {  // first = 1, q = 0 = mid  -> vA first
+            for (uint32_t t = first; t < hi; t += 2) { step(t, vA); if (t + 1 < hi) step(t + 1, vB); }
+        } else {        // first = mid, q = mid-1 (not ours) -> vB is the dummy, then vA, vB, ...
+            for (uint32_t t = first; t < hi; t += 2) { step(t, vB); if (t + 1 < hi) step(t + 1, vA); }
+        }
+    } else {
+        for (uint32_t t = first; t < hi; ++t) step(t, vA);
+    }
+    finalize(hi - 1);
+    if constexpr (PHASE == 2) {
+        if constexpr (FB == 2) {
+            if (((hi - 1 - mid) & 1u) == 0) posterior<HP, R>(sh, part_out, full, hi - 1, p, x, vA);
+            else posterior<HP, R>(sh, part_out, full, hi - 1, p, x, vB);
+        } else {
+            posterior<HP, R>(sh, part_out, full, hi - 1, p, x, vA);
+        }
+        lds_barrier();  // F: the last partials are in LDS
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+//  backward half-chain   (reference src/hmm.cpp:92-110, 275-405)
+//  VBUF  = number of forward-column register buffers (prefetch distance in columns)
+//  KEEPW = keep w = beta_hat*e in registers across the column-sum exchange (else recompute it)
+// ------------------------------------------------------------------------------------------
+template <int HP, int R, int VBUF, bool KEEPW, int PHASE>
+DEVI void backward_body(const DevContig& dc, ChainShared<HP, R>& sh, uint32_t C) {
+    using Cfg = ChainCfg<HP, R>;
+    const int64_t mid = C / 2;
+    // phase 1 computes columns C-1 .. mid (stores beta'); phase 2 computes mid-1 .. 0 (posteriors)
+    const int64_t top = PHASE == 1 ? (int64_t)C - 1 : mid - 1;  // first column of this phase
+    const int64_t bot = PHASE == 1 ? mid : 0;                    // last column of this phase
+    if (top < bot) return;
+    ThreadPos p;
+    p.tid = threadIdx.x; p.lane = p.tid & 63u;
+    p.wave = __builtin_amdgcn_readfirstlane(p.tid >> 6);
+    gcu64* colrec = (gcu64*)dc.colrec;
+    gdouble* part_out = (gdouble*)dc.part;
+    // recursion steps run over t = t0 .. bot where t0 = top-1 in phase 1 (column top is the
+    // all-ones column) and t0 = top in phase 2 (resumed behind column mid)
+    const int64_t t0 = PHASE == 1 ? top - 1 : top;
+
+    auto rec_load = [&](int64_t c) -> unsigned long long {
+        if (p.lane < (uint32_t)Cfg::WORDS && c >= 0 && c < (int64_t)C) return colrec[(size_t)c * Cfg::WORDS + p.lane];
+        return 0ull;
+    };
+    auto rec_stage = [&](int64_t c, unsigned long long w) {
+        if (p.lane < (uint32_t)Cfg::WORDS && c >= 0) ((unsigned long long*)sh.rec[(uint32_t)c & 3u])[p.lane] = w;
+    };
+    if (Cfg::LOADER && p.wave == (uint32_t)Cfg::NW) {
+        // ------------------------------- loader wave ---------------------------------
+        // step t reads record t+1 (emission/transition of the column behind) and, in phase 2,
+        // record t (alleles for the posterior)
+        rec_stage(t0 + 1, rec_load(t0 + 1));
+        rec_stage(t0, rec_load(t0));
+        unsigned long long ta = rec_load(t0 - 1), tb = rec_load(t0 - 2);
+        lds_barrier();  // P0
+        for (int64_t t = t0; t >= bot; t -= 2) {
+            rec_stage(t - 1, ta);
+            ta = rec_load(t - 3);
+            if (PHASE == 2) flush_partials<HP, R>(sh, part_out, t + 2, 0, mid, p.lane);
+            lds_barrier();  // B_t
+            if (t - 1 >= bot) {
+                rec_stage(t - 2, tb);
+                tb = rec_load(t - 4);
+                if (PHASE == 2) flush_partials<HP, R>(sh, part_out, t + 1, 0, mid, p.lane);
+                lds_barrier();  // B_{t-1}
+            }
+        }
+        if (PHASE == 2) {
+            flush_partials<HP, R>(sh, part_out, 1, 0, mid, p.lane);
+            lds_barrier();  // F
+            flush_partials<HP, R>(sh, part_out, 0, 0, mid, p.lane);
+        }
+        return;
     }
 
-    auto step = [&](int64_t c, double (&v)[R]) {
-        // beta_hat_{c+1} = y / Sy, uniform if the sum is zero (hmm.cpp:374-380)
+    // --------------------------------- compute waves -------------------------------------
+    p.j = p.tid % HP; p.rg = p.tid / HP; p.i0 = p.rg * R; p.rb = (p.i0 / 64u) * 64u;
+    const uint32_t H = dc.H;
+    const bool full = H == (uint32_t)HP;
+    const double unif = 1.0 / ((double)H * (double)H);
+    gdouble* cols = (gdouble*)dc.fwd;
+    gdouble* bscale = (gdouble*)dc.bscale;
+    gdouble* bsum = (gdouble*)dc.bsum;
+    const size_t colsz = (size_t)HP * HP;
+
+    auto load_col = [&](int64_t c, double (&v)[R]) {
+        if (c < 0) return;
+        gcdouble* src = (gcdouble*)cols + (size_t)c * colsz + (size_t)p.i0 * HP + p.j;
+#pragma unroll
+        for (int k = 0; k < R; ++k) v[k] = src[(size_t)k * HP];
+    };
+    auto store_col = [&](int64_t c, const double (&y)[R]) {
+        gdouble* dst = cols + (size_t)c * colsz + (size_t)p.i0 * HP + p.j;
+#pragma unroll
+        for (int k = 0; k < R; ++k) dst[(size_t)k * HP] = y[k];
+    };
+
+    constexpr int NV = PHASE == 2 ? R : 1;
+    double y[R], vA[NV], vB[(PHASE == 2 && VBUF == 2) ? R : 1];
+    double Sy = 0.0;
+    unsigned long long tq = 0;  // inline loader (no loader wave): next record in flight
+    if (!Cfg::LOADER && p.wave == 0) {
+        rec_stage(t0 + 1, rec_load(t0 + 1));
+        rec_stage(t0, rec_load(t0));
+        tq = rec_load(t0 - 1);
+    }
+    if constexpr (PHASE == 1) {
+        // column C-1: beta~ = 1 (reference src/hmm.cpp:356-358); sum = H^2
+#pragma unroll
+        for (int k = 0; k < R; ++k) y[k] = (p.j < H && p.i0 + k < H) ? 1.0 : 0.0;
+        Sy = (double)H * (double)H;
+        store_col(top, y);
+        if (p.tid == 0) { bscale[top] = 1.0; bsum[top] = Sy; }
+    } else {
+        // resume behind column mid, stored by phase 1
+        load_col(mid, y);
+        Sy = bsum[mid];
+        load_col(top, vA);
+        if constexpr (VBUF == 2) load_col(top - 1, vB);
+    }
+    lds_barrier();  // P0
+
+    auto step = [&](int64_t t, double (&v)[NV]) {
+        // beta_hat_{t+1} = y / Sy, uniform if the sum is zero (hmm.cpp:374-380)
         if (!(Sy > 0.0) || !(Sy < INFINITY)) {
 #pragma unroll
-            for (int k = 0; k < R; ++k) y[k] = (j < H && i0 + k < H) ? unif : 0.0;
+            for (int k = 0; k < R; ++k) y[k] = (p.j < H && p.i0 + k < H) ? unif : 0.0;
             Sy = 1.0;
         }
-        const unsigned char* rec1 = sh.rec[(uint32_t)(c + 1) & 3u];
+        const unsigned char* rec1 = sh.rec[(uint32_t)(t + 1) & 3u];
         const double c0 = *(const double*)(rec1 + PG_REC_C0);
         const double c1 = *(const double*)(rec1 + PG_REC_C1);
         const double c2 = *(const double*)(rec1 + PG_REC_C2);
         const double kappa = *(const double*)(rec1 + PG_REC_KAPPA);
-        // beta~_c(true) = A (y/Sy . e) A^T; scaled by 2^-es: beta' = beta~ * m, m = Sy*2^-es
+        // beta~_t(true) = A (y/Sy . e) A^T; scaled by 2^-es: beta' = beta~ * m, m = Sy*2^-es
         const int es = exponent_of(Sy);
         const double m = ldexp(Sy, -es);
-        if (tid == 0) bscale[c] = m;
+        if (p.tid == 0) bscale[t] = m;
         const bool fast = full && rec1[PG_REC_NLOCAL] <= 2;
         FastE fe;
         uint32_t aj1 = 0;
-        if (fast) fe = fast_setup<Cfg::UNI>(rec1, j, i0);
-        else aj1 = col_allele(rec1, j);
+        if (fast) fe = fast_setup<Cfg::UNI>(rec1, p.j, p.i0);
+        else aj1 = col_allele(rec1, p.j);
         double w[KEEPW ? R : 1];
         double part = 0.0;
         if (fast) {
@@ -918,69 +985,74 @@ __global__ __launch_bounds__((ChainCfg<HP, R>::TT)) void k_backward(const DevCon
         } else {
 #pragma unroll
             for (int k = 0; k < R; ++k) {
-                const double wk = y[k] * emission_at(rec1, i0 + k, aj1);
+                const double wk = y[k] * emission_at(rec1, p.i0 + k, aj1);
                 if constexpr (KEEPW) w[k] = wk;
                 part += wk;
                 if constexpr (R > 16) { if ((k & 7) == 7) __builtin_amdgcn_sched_barrier(0); }
             }
         }
-        const uint32_t pb = (uint32_t)c & 1u;
-        sh.psum[pb][rg][j] = part;
-        const double ws = wave_sum(part);
-        if (lane == 0) sh.wsum[pb][wave] = ws;
-        if (!Cfg::LOADER && wave == 0) {
-            rec_stage(c - 1, tq);  // loaded one column ago
-            tq = rec_load(c - 2);
+        const uint32_t pb = (uint32_t)t & 1u;
+        write_sums<HP, R>(sh, pb, p, part);
+        if (!Cfg::LOADER && p.wave == 0) {
+            rec_stage(t - 1, tq);  // loaded one column ago
+            tq = rec_load(t - 2);
         }
-        lds_barrier();  // B_c
-        double Cj = 0.0, Crow, Sw = 0.0;
-#pragma unroll
-        for (int g = 0; g < Cfg::NRG; ++g) Cj += sh.psum[pb][g][j];
-        if (Cfg::UNI && HP > 64) {
-            Crow = 0.0;
-#pragma unroll
-            for (int g = 0; g < Cfg::NRG; ++g) Crow += sh.psum[pb][g][rb + lane];
-        } else {
-            Crow = Cj;
-        }
-#pragma unroll
-        for (int q = 0; q < Cfg::NW; ++q) Sw += sh.wsum[pb][q];
+        lds_barrier();  // B_t
+        double Cj, Crow, Sw;
+        read_sums<HP, R>(sh, pb, p, Cj, Crow, Sw);
         const double k0 = ldexp(c0, -es), k1 = ldexp(c1, -es), hk2 = 0.5 * ldexp(c2 * Sw, -es);
         const double uj = fma(k1, Cj, hk2);
         const double urow = fma(k1, Crow, hk2);
         if (!Cfg::UNI) {
             lds_wave_sync();  // previous step's reads of sh.u are done
-            if (rg == 0) sh.u[0][j] = uj;
+            if (p.rg == 0) sh.u[0][p.j] = uj;
             lds_wave_sync();
         }
         double ui[R > 16 ? 1 : R];
-        if constexpr (R <= 16) row_values<R, Cfg::UNI>(sh.u[Cfg::UNI ? wave : 0], urow, lane, i0, ui);
+        if constexpr (R <= 16) row_values<R, Cfg::UNI>(sh.u[Cfg::UNI ? p.wave : 0], urow, p.lane, p.i0, ui);
 #pragma unroll
         for (int k = 0; k < R; ++k) {
             double wk;
             if constexpr (KEEPW) wk = w[k];
-            else wk = y[k] * (fast ? (((fe.rowbits >> k) & 1u) ? fe.eB : fe.eA) : emission_at(rec1, i0 + k, aj1));
+            else wk = y[k] * (fast ? (((fe.rowbits >> k) & 1u) ? fe.eB : fe.eA) : emission_at(rec1, p.i0 + k, aj1));
             double uik;
             if constexpr (R <= 16) uik = ui[k];
-            else uik = readlane_f64(urow, __builtin_amdgcn_readfirstlane((int)((i0 + k) & 63u)));
-            y[k] = fma(k0, wk, uik + uj);  // beta'_c
+            else uik = readlane_f64(urow, __builtin_amdgcn_readfirstlane((int)((p.i0 + k) & 63u)));
+            y[k] = fma(k0, wk, uik + uj);  // beta'_t
             if constexpr (R > 16) { if ((k & 7) == 7) __builtin_amdgcn_sched_barrier(0); }
         }
-        Sy = ldexp(kappa * Sw, -es);  // = sum(beta'_c) over real states
-        posterior((uint32_t)c, v, y);
-        load_col(c - VBUF, v);
+        Sy = ldexp(kappa * Sw, -es);  // = sum(beta'_t) over real states
+        if constexpr (PHASE == 1) {
+            store_col(t, y);
+            if (p.tid == 0) bsum[t] = Sy;
+        } else {
+            posterior<HP, R>(sh, part_out, full, (uint32_t)t, p, v, y);
+            load_col(t - VBUF, v);
+        }
     };
 
-    for (int64_t c = last - 1; c >= 0; c -= 2) {
-        if constexpr (VBUF == 2) {
-            step(c, vB);
-            if (c - 1 >= 0) step(c - 1, vA);
+    for (int64_t t = t0; t >= bot; t -= 2) {
+        if constexpr (PHASE == 2 && VBUF == 2) {
+            step(t, vA);
+            if (t - 1 >= bot) step(t - 1, vB);
         } else {
-            step(c, vA);
-            if (c - 1 >= 0) step(c - 1, vA);
+            step(t, vA);
+            if (t - 1 >= bot) step(t - 1, vA);
         }
     }
-    lds_barrier();  // F: the last partials are in LDS
+    if constexpr (PHASE == 2) lds_barrier();  // F: the last partials are in LDS
+}
+
+// grid = (n_contigs, 2): blockIdx.y = 0 forward half-chain, 1 backward half-chain
+template <int HP, int R, int VBUF, bool KEEPW, int PHASE>
+__global__ __launch_bounds__((ChainCfg<HP, R>::TT)) void k_sweep(const DevContig* __restrict__ contigs) {
+    __shared__ ChainShared<HP, R> sh;
+    const DevContig& dc = contigs[blockIdx.x];
+    if (dc.HP != (uint32_t)HP) return;
+    const uint32_t C = *dc.n_cols;
+    if (C == 0) return;
+    if (blockIdx.y == 0) forward_body<HP, R, PHASE>(dc, sh, C);
+    else backward_body<HP, R, VBUF, KEEPW, PHASE>(dc, sh, C);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1044,6 +1116,16 @@ __global__ __launch_bounds__(256) void k_bins(const DevContig* __restrict__ cont
 // ------------------------------------------------------------------------------------------
 //  host-callable launchers (defined here so that the shim needs no kernel templates)
 // ------------------------------------------------------------------------------------------
+// hp_mask: bit0 HP=16, bit1 HP=32, bit2 HP=64, bit3 HP=128; phase 1 = store halves, 2 = posterior halves
+template <int PHASE>
+static void launch_sweep(const DevContig* d_contigs, uint32_t n_contigs, uint32_t hp_mask, hipStream_t s) {
+    const dim3 grid(n_contigs, 2);
+    if (hp_mask & 1u) hipLaunchKernelGGL((k_sweep<16, 4, 2, true, PHASE>), grid, dim3(ChainCfg<16, 4>::TT), 0, s, d_contigs);
+    if (hp_mask & 2u) hipLaunchKernelGGL((k_sweep<32, 16, 2, true, PHASE>), grid, dim3(ChainCfg<32, 16>::TT), 0, s, d_contigs);
+    if (hp_mask & 4u) hipLaunchKernelGGL((k_sweep<64, 16, 2, true, PHASE>), grid, dim3(ChainCfg<64, 16>::TT), 0, s, d_contigs);
+    if (hp_mask & 8u) hipLaunchKernelGGL((k_sweep<128, 32, 1, false, PHASE>), grid, dim3(ChainCfg<128, 32>::TT), 0, s, d_contigs);
+}
+
 extern "C" {
 
 void pgk_launch_prep(const DevContig* d_contigs, uint32_t n_contigs, uint32_t max_v, DevTable tab, hipStream_t s) {
@@ -1061,18 +1143,9 @@ void pgk_launch_bins(const DevContig* d_contigs, uint32_t n_contigs, uint32_t ma
     dim3 grid((max_v + 3) / 4, n_contigs);
     hipLaunchKernelGGL(k_bins, grid, dim3(256), 0, s, d_contigs);
 }
-// hp_mask: bit0 HP=16, bit1 HP=32, bit2 HP=64, bit3 HP=128
-void pgk_launch_forward(const DevContig* d_contigs, uint32_t n_contigs, uint32_t hp_mask, hipStream_t s) {
-    if (hp_mask & 1u) hipLaunchKernelGGL((k_forward<16, 4>), dim3(n_contigs), dim3(128), 0, s, d_contigs);
-    if (hp_mask & 2u) hipLaunchKernelGGL((k_forward<32, 16>), dim3(n_contigs), dim3(128), 0, s, d_contigs);
-    if (hp_mask & 4u) hipLaunchKernelGGL((k_forward<64, 16>), dim3(n_contigs), dim3(320), 0, s, d_contigs);
-    if (hp_mask & 8u) hipLaunchKernelGGL((k_forward<128, 32>), dim3(n_contigs), dim3(512), 0, s, d_contigs);
-}
-void pgk_launch_backward(const DevContig* d_contigs, uint32_t n_contigs, uint32_t hp_mask, hipStream_t s) {
-    if (hp_mask & 1u) hipLaunchKernelGGL((k_backward<16, 4, 2, true>), dim3(n_contigs), dim3(128), 0, s, d_contigs);
-    if (hp_mask & 2u) hipLaunchKernelGGL((k_backward<32, 16, 2, true>), dim3(n_contigs), dim3(128), 0, s, d_contigs);
-    if (hp_mask & 4u) hipLaunchKernelGGL((k_backward<64, 16, 2, true>), dim3(n_contigs), dim3(320), 0, s, d_contigs);
-    if (hp_mask & 8u) hipLaunchKernelGGL((k_backward<128, 32, 1, false>), dim3(n_contigs), dim3(512), 0, s, d_contigs);
+void pgk_launch_sweep(const DevContig* d_contigs, uint32_t n_contigs, uint32_t hp_mask, int phase, hipStream_t s) {
+    if (phase == 1) launch_sweep<1>(d_contigs, n_contigs, hp_mask, s);
+    else launch_sweep<2>(d_contigs, n_contigs, hp_mask, s);
 }
 void pgk_launch_emission_single(const DevContig* d_contig, DevTable tab, uint32_t v, double* out_m, int* out_e,
                                 hipStream_t s) {

@@ -25,8 +25,7 @@ void pgk_launch_prep(const DevContig*, uint32_t, uint32_t, DevTable, hipStream_t
 void pgk_launch_compact(const DevContig*, uint32_t, hipStream_t);
 void pgk_launch_records(const DevContig*, uint32_t, uint32_t, hipStream_t);
 void pgk_launch_bins(const DevContig*, uint32_t, uint32_t, hipStream_t);
-void pgk_launch_forward(const DevContig*, uint32_t, uint32_t, hipStream_t);
-void pgk_launch_backward(const DevContig*, uint32_t, uint32_t, hipStream_t);
+void pgk_launch_sweep(const DevContig*, uint32_t, uint32_t, int, hipStream_t);
 void pgk_launch_emission_single(const DevContig*, DevTable, uint32_t, double*, int*, hipStream_t);
 void pgk_launch_transition_single(double, uint32_t, int, double*, hipStream_t);
 uint32_t pgk_threads_for_hp(uint32_t);
@@ -207,7 +206,7 @@ extern "C" int pg_hmm_geno_offsets(const pg_contig_batch* b, uint64_t* geno_off)
 //  jobs
 // ---------------------------------------------------------------------------------------
 static const char* const kKernelNames[PG_N_KERNEL_CLASSES] = {"k_prep", "k_compact", "k_records",
-                                                              "k_forward", "k_backward", "k_bins"};
+                                                              "k_sweep_phase1", "k_sweep_phase2", "k_bins"};
 
 struct ContigHost {
     uint32_t V = 0, H = 0, HP = 0, T = 0, RB = 0;
@@ -316,7 +315,7 @@ extern "C" pg_job* pg_job_create(int device, uint32_t n_contigs, const pg_contig
     job->contigs.resize(n_contigs);
     size_t off = 0;
     auto take = [&](size_t bytes) { size_t o = off; off = align_up(off + (bytes ? bytes : 8)); return o; };
-    struct Plan { size_t prof, fback, fscale, bscale, pos, cov, koff, kcnt, aoff, aid, aflag, akoff, akmask, pa, goff, vrec, cvar, colrec, fwd, part, kept, apres, lik, likexp; };
+    struct Plan { size_t prof, fback, fscale, bscale, bsum, pos, cov, koff, kcnt, aoff, aid, aflag, akoff, akmask, pa, goff, vrec, cvar, colrec, fwd, part, kept, apres, lik, likexp; };
     std::vector<Plan> plan(n_contigs);
     const size_t o_contigs = take(sizeof(DevContig) * n_contigs);
     // zeroed-every-run block: n_cols, err, then per contig kept / allele_present / lik / lik_exp
@@ -356,6 +355,7 @@ extern "C" pg_job* pg_job_create(int device, uint32_t n_contigs, const pg_contig
         p.part = take((size_t)c.V * PG_AMAX * c.T * sizeof(double));
         p.fscale = take((size_t)c.V * sizeof(double));
         p.bscale = take((size_t)c.V * sizeof(double));
+        p.bsum = take((size_t)c.V * sizeof(double));
         job->hp_mask |= c.HP == 16 ? 1u : c.HP == 32 ? 2u : c.HP == 64 ? 4u : 8u;
         if (c.V > job->max_v) job->max_v = c.V;
     }
@@ -393,7 +393,7 @@ extern "C" pg_job* pg_job_create(int device, uint32_t n_contigs, const pg_contig
         d.vrec = A + p.vrec; d.kept = A + p.kept; d.allele_present = A + p.apres;
         d.n_cols = job->d_ncols + i; d.col_variant = (uint32_t*)(A + p.cvar); d.colrec = A + p.colrec;
         d.fwd = (double*)(A + p.fwd); d.part = (double*)(A + p.part); d.fwd_fallback = A + p.fback; d.prof = (unsigned long long*)(A + p.prof);
-        d.fscale = (double*)(A + p.fscale); d.bscale = (double*)(A + p.bscale); d.err = job->d_err + i;
+        d.fscale = (double*)(A + p.fscale); d.bscale = (double*)(A + p.bscale); d.bsum = (double*)(A + p.bsum); d.err = job->d_err + i;
         d.lik = (double*)(A + p.lik); d.lik_exp = (int32_t*)(A + p.likexp);
         c.d = d;
         if (c.V == 0) continue;
@@ -439,9 +439,9 @@ extern "C" int pg_job_run(pg_job* job, void* stream_, char* err, size_t errlen) 
         HIP_TRY(hipEventRecord(job->ev[2], s));
         pgk_launch_records(job->d_contigs, n, job->max_v, s);
         HIP_TRY(hipEventRecord(job->ev[3], s));
-        pgk_launch_forward(job->d_contigs, n, job->hp_mask, s);
+        pgk_launch_sweep(job->d_contigs, n, job->hp_mask, 1, s);
         HIP_TRY(hipEventRecord(job->ev[4], s));
-        pgk_launch_backward(job->d_contigs, n, job->hp_mask, s);
+        pgk_launch_sweep(job->d_contigs, n, job->hp_mask, 2, s);
         HIP_TRY(hipEventRecord(job->ev[5], s));
         pgk_launch_bins(job->d_contigs, n, job->max_v, s);
         HIP_TRY(hipEventRecord(job->ev[6], s));
