@@ -55,6 +55,21 @@ def cpu_baseline(batch, H, sample_variants):
                       f"{dt:.1f} s on {os.cpu_count()} host cores available, 1 used"}
 
 
+def profiled_traffic(workload, kernel_phase):
+    """HBM bytes per launch of the sweep phase from the committed rocprofv3 PMC summary
+    (profiles/rNN_<workload>_summary.json, made by tools/summarize_profile.py from separate
+    --pmc FETCH_SIZE / WRITE_SIZE passes).  None if no profile of this workload is committed."""
+    cands = sorted((ROOT / "profiles").glob(f"r*_{workload}_summary.json"))
+    if not cands:
+        return None, None
+    data = json.loads(cands[-1].read_text())
+    for name, v in data["kernels"].items():
+        if name.startswith("void k_sweep<") and name.rstrip().endswith(f", {kernel_phase}>(DevContig const*)"):
+            if "hbm_read_bytes_per_launch" in v:
+                return v["hbm_read_bytes_per_launch"] + v.get("hbm_write_bytes_per_launch", 0.0), cands[-1].name
+    return None, None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -148,6 +163,9 @@ def main():
         dom_ms = kms.get(dom, 0.0)
         achieved = dom_bytes / (dom_ms * 1e-3) / 1e9 if dom_ms > 0 else 0.0
         sweep_ms = kms.get("k_sweep_phase1", 0.0) + kms.get("k_sweep_phase2", 0.0)
+        traffic, traffic_src = (None, None)
+        if V == w["V"]:
+            traffic, traffic_src = profiled_traffic(args.workload, 1 if dom == "k_sweep_phase1" else 2)
         out = {
             "metric": "genotyped variants/sec (whole node) at H haplotypes; HBM GB/s vs roofline",
             "value": value, "unit": "variants/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -158,7 +176,7 @@ def main():
                        "variants_per_gpu": V, "haplotypes": H, "kmers_per_variant": K,
                        "kept_columns": ncol, "chains_per_gpu": 1, "workgroups_per_chain": 2, "parallelism": f"contig-sharded x{world}"},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
                          "algorithmic_bytes_per_launch": dom_bytes, "avg_launch_ms": dom_ms,
                          "sweep_GBs": (bytes_total / (sweep_ms * 1e-3) / 1e9) if sweep_ms > 0 else 0.0},
             "kernel_ms": kms,

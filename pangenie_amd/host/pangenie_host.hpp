@@ -1,0 +1,269 @@
+// pangenie_host.hpp — C++ host side of the boundary: the reference's interface for the
+// genotyping hot path (same class names, method names, argument meaning and error behaviour),
+// implemented over the C ABI of include/pangenie_hmm.h.
+//
+//   UniqueKmers / BiallelicUniqueKmers / MultiallelicUniqueKmers   reference src/uniquekmers.hpp:22-69,
+//                                                                  src/biallelicuniquekmers.hpp, src/multiallelicuniquekmers.hpp
+//   KmerPath (window 16 or 32)                                     reference src/kmerpath.hpp, src/kmerpath16.hpp
+//   CopyNumber, ProbabilityTable                                   reference src/copynumber.hpp, src/probabilitytable.hpp
+//   ColumnIndexer                                                  reference src/columnindexer.hpp
+//   EmissionProbabilityComputer, TransitionProbabilityComputer     reference src/emissionprobabilitycomputer.hpp,
+//                                                                  src/transitionprobabilitycomputer.hpp   (device)
+//   GenotypingResult                                               reference src/genotypingresult.hpp
+//   HMM                                                            reference src/hmm.hpp:26-47                (device)
+//
+// Everything that computes probabilities along the chain runs on the GPU through the C ABI;
+// there is no CPU implementation of the HMM in this library.  Containers, bookkeeping and the
+// long double post-processing (normalise, GT, GQ) stay on the host exactly where the reference
+// has them.
+#pragma once
+
+#include <cstddef>
+#include <cstdint>
+#include <map>
+#include <memory>
+#include <ostream>
+#include <string>
+#include <utility>
+#include <vector>
+
+#include "../../include/pangenie_hmm.h"
+
+namespace pangenie {
+
+/** Sequence of k-mer presence bits: (offset, mask) over a window of W k-mer indices. */
+class KmerPath {
+public:
+    explicit KmerPath(unsigned window = 32) : offset_(0), kmers_(0), window_(window) {}
+    void set_position(unsigned short index);
+    unsigned int get_position(unsigned short index) const;
+    size_t nr_kmers() const;
+    std::string convert_to_string() const;
+    unsigned short offset() const { return offset_; }
+    uint32_t mask() const { return kmers_; }
+
+private:
+    unsigned short offset_;
+    uint32_t kmers_;
+    unsigned window_;
+};
+std::ostream& operator<<(std::ostream& os, const KmerPath& p);
+
+/** Probabilities of a k-mer having copy number 0, 1, 2. */
+class CopyNumber {
+public:
+    CopyNumber();
+    CopyNumber(long double cn_0, long double cn_1, long double cn_2);
+    CopyNumber(long double cn_0, long double cn_1, long double cn_2, long double regularization_const);
+    long double get_probability_of(int cn) const;
+    bool operator==(const CopyNumber& other) const;
+    bool operator!=(const CopyNumber& other) const;
+
+private:
+    long double p_[3];
+};
+
+/** Pre-computed copy-number probabilities per (k-mer coverage, read k-mer count).
+ *  Owns a pg_table: the same object feeds the device. */
+class ProbabilityTable {
+public:
+    ProbabilityTable();
+    ProbabilityTable(unsigned short cov_min, unsigned short cov_max, unsigned short count_max,
+                     long double regularization_const);
+    ProbabilityTable(const ProbabilityTable&) = delete;
+    ProbabilityTable& operator=(const ProbabilityTable&) = delete;
+    ProbabilityTable(ProbabilityTable&& o) noexcept : t_(o.t_) { o.t_ = nullptr; }
+    ProbabilityTable& operator=(ProbabilityTable&& o) noexcept;
+    ~ProbabilityTable();
+    CopyNumber get_probability(unsigned short kmer_coverage, unsigned short read_kmer_count) const;
+    /** test hook, throws std::runtime_error outside the precomputed box */
+    void modify_probability(unsigned short kmer_coverage, unsigned short read_kmer_count, CopyNumber prob);
+    const pg_table* handle() const { return t_; }
+
+private:
+    pg_table* t_;
+};
+
+/** The set of unique k-mers of one variant position (abstract, as in the reference). */
+class UniqueKmers {
+public:
+    virtual ~UniqueKmers() = default;
+    virtual size_t get_variant_position() const = 0;
+    virtual void insert_kmer(unsigned short readcount, std::vector<unsigned short>& allele_ids) = 0;
+    virtual bool kmer_on_path(size_t kmer_index, size_t path_id) const = 0;
+    virtual bool kmer_on_allele(size_t kmer_index, size_t allele_id) const = 0;
+    virtual unsigned short get_readcount_of(size_t kmer_index) = 0;
+    virtual void update_readcount(size_t kmer_index, unsigned short new_count) = 0;
+    virtual size_t size() const = 0;
+    virtual unsigned short get_nr_paths() const = 0;
+    virtual void get_path_ids(std::vector<unsigned short>& paths, std::vector<unsigned short>& alleles,
+                              std::vector<unsigned short>* only_include = nullptr) = 0;
+    virtual void get_allele_ids(std::vector<unsigned short>& a) = 0;
+    virtual void get_defined_allele_ids(std::vector<unsigned short>& a) = 0;
+    virtual void set_coverage(unsigned short local_coverage) = 0;
+    virtual unsigned short get_coverage() const = 0;
+    virtual std::map<unsigned short, int> kmers_on_alleles() const = 0;
+    virtual unsigned short kmers_on_allele(unsigned short allele_id) const = 0;
+    virtual unsigned short present_kmers_on_allele(unsigned short allele_id) const = 0;
+    virtual float fraction_present_kmers_on_allele(unsigned short allele_id) const = 0;
+    virtual bool is_undefined_allele(unsigned short allele_id) const = 0;
+    virtual void set_undefined_allele(unsigned short allele_id) = 0;
+    virtual unsigned short get_allele(unsigned short path_id) const = 0;
+    virtual void update_paths(std::vector<unsigned short>& path_ids) = 0;
+    /** (offset, mask) of the allele's k-mer bits — what the flat batch carries (include/pangenie_hmm.h). */
+    virtual std::pair<unsigned short, uint32_t> kmer_bits(unsigned short allele_id) const = 0;
+};
+
+/** Shared implementation; BIALLELIC restricts alleles to {0,1} and uses the 16-k-mer window. */
+template <bool BIALLELIC>
+class UniqueKmersT : public UniqueKmers {
+public:
+    UniqueKmersT() : variant_pos_(0), local_coverage_(0) {}
+    UniqueKmersT(size_t variant_position, std::vector<unsigned short>& alleles);
+    size_t get_variant_position() const override { return variant_pos_; }
+    void insert_kmer(unsigned short readcount, std::vector<unsigned short>& allele_ids) override;
+    bool kmer_on_path(size_t kmer_index, size_t path_id) const override;
+    bool kmer_on_allele(size_t kmer_index, size_t allele_id) const override;
+    unsigned short get_readcount_of(size_t kmer_index) override;
+    void update_readcount(size_t kmer_index, unsigned short new_count) override;
+    size_t size() const override { return counts_.size(); }
+    unsigned short get_nr_paths() const override { return (unsigned short)path_to_allele_.size(); }
+    void get_path_ids(std::vector<unsigned short>& paths, std::vector<unsigned short>& alleles,
+                      std::vector<unsigned short>* only_include = nullptr) override;
+    void get_allele_ids(std::vector<unsigned short>& a) override;
+    void get_defined_allele_ids(std::vector<unsigned short>& a) override;
+    void set_coverage(unsigned short local_coverage) override { local_coverage_ = local_coverage; }
+    unsigned short get_coverage() const override { return (unsigned short)local_coverage_; }
+    std::map<unsigned short, int> kmers_on_alleles() const override;
+    unsigned short kmers_on_allele(unsigned short allele_id) const override;
+    unsigned short present_kmers_on_allele(unsigned short allele_id) const override;
+    float fraction_present_kmers_on_allele(unsigned short allele_id) const override;
+    bool is_undefined_allele(unsigned short allele_id) const override;
+    void set_undefined_allele(unsigned short allele_id) override;
+    unsigned short get_allele(unsigned short path_id) const override;
+    void update_paths(std::vector<unsigned short>& path_ids) override;
+    std::pair<unsigned short, uint32_t> kmer_bits(unsigned short allele_id) const override;
+
+private:
+    struct AlleleInfo {
+        KmerPath kmer_path{BIALLELIC ? 16u : 32u};
+        bool is_undefined = false;
+    };
+    void check_allele(unsigned short a, const char* where) const;
+    size_t variant_pos_;
+    float local_coverage_;
+    std::vector<unsigned short> counts_;
+    std::map<unsigned short, AlleleInfo> alleles_;
+    std::vector<unsigned short> path_to_allele_;
+};
+using BiallelicUniqueKmers = UniqueKmersT<true>;
+using MultiallelicUniqueKmers = UniqueKmersT<false>;
+
+/** Which variants become HMM columns, which paths are selected (host restatement; the device
+ *  applies the same rule in k_prep — this class serves callers and tests). */
+class ColumnIndexer {
+public:
+    ColumnIndexer(std::vector<std::shared_ptr<UniqueKmers>>* unique_kmers, std::vector<unsigned short>* only_paths);
+    size_t get_variant_id(size_t column_index) const;
+    size_t size() const { return columns_.size(); }
+    unsigned short nr_paths() const { return (unsigned short)paths_.size(); }
+    unsigned short get_path(unsigned short path_index) const;
+    unsigned short get_allele(unsigned short path_index, size_t column_index) const;
+    std::pair<unsigned short, unsigned short> get_path_ids_at(size_t position) const;
+    const std::vector<unsigned short>& paths() const { return paths_; }
+
+private:
+    std::vector<size_t> columns_;
+    std::vector<unsigned short> paths_;
+    std::vector<std::shared_ptr<UniqueKmers>>* unique_kmers_;
+};
+
+/** Genotyping / phasing result of one position. */
+class GenotypingResult {
+public:
+    GenotypingResult();
+    void add_to_likelihood(unsigned short allele1, unsigned short allele2, long double value);
+    void add_first_haplotype_allele(unsigned short allele) { haplotype_1_ = allele; }
+    void add_second_haplotype_allele(unsigned short allele) { haplotype_2_ = allele; }
+    long double get_genotype_likelihood(unsigned short allele1, unsigned short allele2) const;
+    std::vector<long double> get_all_likelihoods(size_t nr_alleles) const;
+    GenotypingResult get_specific_likelihoods(std::vector<unsigned short>& alleles) const;
+    size_t get_genotype_quality(unsigned short allele1, unsigned short allele2) const;
+    std::pair<unsigned short, unsigned short> get_haplotype() const { return {haplotype_1_, haplotype_2_}; }
+    void divide_likelihoods_by(long double value);
+    std::pair<int, int> get_likeliest_genotype() const;
+    void combine(GenotypingResult& likelihoods);
+    void normalize();
+    void set_unique_kmers(unsigned short nr_unique_kmers) { unique_kmers_ = nr_unique_kmers; }
+    void set_coverage(unsigned short coverage) { local_coverage_ = coverage; }
+    unsigned short nr_unique_kmers() const { return unique_kmers_; }
+    unsigned short coverage() const { return local_coverage_; }
+    bool contains_no_likelihoods() const { return genotype_to_likelihood_.empty(); }
+    const std::map<std::pair<unsigned short, unsigned short>, long double>& get_stored_likelihoods() const {
+        return genotype_to_likelihood_;
+    }
+    friend std::ostream& operator<<(std::ostream& os, const GenotypingResult& res);
+
+private:
+    std::map<std::pair<unsigned short, unsigned short>, long double> genotype_to_likelihood_;
+    unsigned short haplotype_1_, haplotype_2_, local_coverage_, unique_kmers_;
+};
+
+/** Li-Stephens transition probabilities between two variants — computed on the device. */
+class TransitionProbabilityComputer {
+public:
+    TransitionProbabilityComputer(size_t from_variant, size_t to_variant, double recomb_rate, unsigned short nr_paths,
+                                  bool uniform = false, long double effective_N = 25000.0L);
+    long double compute_transition_prob(unsigned short path_id1, unsigned short path_id2, unsigned short path_id3,
+                                        unsigned short path_id4);
+    long double compute_transition_prob(unsigned short nr_switches);
+
+private:
+    long double probabilities_[3];
+    bool uniform_;
+};
+
+/** Emission probabilities of one variant position — computed on the device. */
+class EmissionProbabilityComputer {
+public:
+    EmissionProbabilityComputer(std::shared_ptr<UniqueKmers> uniquekmers, ProbabilityTable* probabilities);
+    long double get_emission_probability(unsigned short allele_id1, unsigned short allele_id2) const;
+
+private:
+    std::vector<unsigned short> allele_ids_;
+    std::vector<long double> table_;  // A x A over allele slots, after the all_zeros rule
+};
+
+/** Flat view of a UniqueKmers vector (+ only_paths): owns the arrays a pg_contig_batch points to. */
+struct FlatContig {
+    std::vector<uint64_t> variant_pos;
+    std::vector<uint16_t> coverage, kmer_count, allele_id, allele_kmer_off, path_allele;
+    std::vector<uint32_t> kmer_off, allele_off, allele_kmer_mask;
+    std::vector<uint8_t> allele_flags;
+    std::vector<unsigned short> paths;  // selected path ids (ColumnIndexer::paths)
+    pg_contig_batch batch{};
+    void bind();
+};
+/** Throws std::runtime_error("HMM::index_columns: column N is not covered by any paths.") like ColumnIndexer. */
+void flatten(std::vector<std::shared_ptr<UniqueKmers>>* unique_kmers, std::vector<unsigned short>* only_paths, FlatContig& out);
+
+/** The genotyping HMM.  All work happens in the constructor, on the GPU. */
+class HMM {
+public:
+    HMM() = default;
+    HMM(std::vector<std::shared_ptr<UniqueKmers>>* unique_kmers, ProbabilityTable* probabilities, bool run_genotyping,
+        bool run_phasing, double recombrate = 1.26, bool uniform = false, long double effective_N = 25000.0L,
+        std::vector<unsigned short>* only_paths = nullptr, bool normalize = true);
+    void combine_likelihoods(HMM& other);
+    void normalize();
+    std::vector<GenotypingResult> get_genotyping_result() const { return genotyping_result_; }
+    std::vector<GenotypingResult> move_genotyping_result() { return std::move(genotyping_result_); }
+    /** device the calling thread's HMMs run on (default 0) */
+    static void set_device(int device);
+    static int device_count();
+
+private:
+    std::vector<GenotypingResult> genotyping_result_;
+};
+
+}  // namespace pangenie
