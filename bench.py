@@ -106,21 +106,27 @@ def main():
     job = hmm.Job([batch], table, params, device=local_rank)
     upload_s = time.perf_counter() - t_up
 
-    # gather plumbing: posteriors stay on the device, one RCCL gather to rank 0 per step
+    # gather plumbing: posteriors stay on the device; chain r lives on rank r (weak scaling),
+    # rank 0 collects the packed (lik, lik_exp) of every rank with ONE RCCL gather per step
     hip = C.CDLL("libamdhip64.so")
     d_lik, n_lik, d_exp, n_var = job.device_results(0)
     lik_t = torch.empty(n_lik, dtype=torch.float64, device="cuda")
     exp_t = torch.empty(n_var, dtype=torch.int32, device="cuda")
-    gather_lik = [torch.empty_like(lik_t) for _ in range(world)] if (world > 1 and rank == 0) else None
-    gather_exp = [torch.empty_like(exp_t) for _ in range(world)] if (world > 1 and rank == 0) else None
+    plan, all_lik, all_var = [[r] for r in range(world)], [n_lik], [n_var]
+    if world > 1:
+        from pangenie_amd.dist import gather_posteriors
+        sizes = torch.tensor([n_lik, n_var], dtype=torch.int64, device="cuda")
+        allsz = [torch.empty_like(sizes) for _ in range(world)]
+        dist.all_gather(allsz, sizes)
+        all_lik = [int(t[0]) for t in allsz]
+        all_var = [int(t[1]) for t in allsz]
 
     def step():
         job.run()
         if world > 1:
             hip.hipMemcpy(C.c_void_p(lik_t.data_ptr()), C.c_void_p(d_lik), C.c_size_t(n_lik * 8), 3)
             hip.hipMemcpy(C.c_void_p(exp_t.data_ptr()), C.c_void_p(d_exp), C.c_size_t(n_var * 4), 3)
-            dist.gather(lik_t, gather_lik, dst=0)
-            dist.gather(exp_t, gather_exp, dst=0)
+            gather_posteriors({rank: (lik_t, exp_t)}, all_lik, all_var, plan, dst=0)
 
     def fence():
         torch.cuda.synchronize()

@@ -49,3 +49,30 @@ def build_oracle(force: bool = False) -> Path:
         subprocess.run(["make", "-C", str(ROOT / "oracle"), "clean"], check=True, capture_output=True)
     subprocess.run(["make", "-C", str(ROOT / "oracle")], check=True, capture_output=True)
     return ROOT / "oracle" / "_build" / "libpg_oracle.so"
+
+
+HOST_DIR = ROOT / "pangenie_amd" / "host"
+HOST_LIB = HOST_DIR / "libpangenie_host.so"
+HOST_TEST = ROOT / "tests" / "cpp" / "test_host.bin"
+
+
+def build_host(force: bool = False) -> Path:
+    """g++ -> pangenie_amd/host/libpangenie_host.so (C++ mirror of the reference interface over
+    the C ABI) and tests/cpp/test_host.bin."""
+    build_hip()
+    cxx = shutil.which("g++") or "g++"
+    deps = [HOST_DIR / "pangenie_host.cpp", HOST_DIR / "pangenie_host.hpp", ROOT / "include" / "pangenie_hmm.h"]
+    if force or _stale(HOST_LIB, deps):
+        cmd = [cxx, "-O2", "-std=c++17", "-fPIC", "-shared", "-Wall", "-Wextra", str(HOST_DIR / "pangenie_host.cpp"),
+               "-o", str(HOST_LIB), f"-L{CSRC}", "-lpangenie_hmm", "-Wl,-rpath,$ORIGIN/../csrc"]
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        if r.returncode:
+            raise RuntimeError("g++ (host lib) failed:\n" + r.stderr)
+    tsrc = ROOT / "tests" / "cpp" / "test_host.cpp"
+    if force or _stale(HOST_TEST, [tsrc, HOST_LIB]):
+        cmd = [cxx, "-O1", "-std=c++17", "-Wall", str(tsrc), "-o", str(HOST_TEST), f"-L{HOST_DIR}", "-lpangenie_host",
+               f"-L{CSRC}", "-lpangenie_hmm", "-Wl,-rpath,$ORIGIN/../../pangenie_amd/host:$ORIGIN/../../pangenie_amd/csrc"]
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        if r.returncode:
+            raise RuntimeError("g++ (host tests) failed:\n" + r.stderr)
+    return HOST_LIB

@@ -92,11 +92,9 @@ UniqueKmersT<BI>::UniqueKmersT(size_t variant_position, std::vector<unsigned sho
 template <bool BI>
 void UniqueKmersT<BI>::insert_kmer(unsigned short readcount, std::vector<unsigned short>& allele_ids) {
     const size_t index = counts_.size();
+    for (unsigned short a : allele_ids) check_allele(a, "BiallelicUniqueKmers::insert_kmer");
     counts_.push_back(readcount);
-    for (unsigned short a : allele_ids) {
-        check_allele(a, "BiallelicUniqueKmers::insert_kmer");
-        alleles_[a].kmer_path.set_position((unsigned short)index);  // creates the allele if new
-    }
+    for (unsigned short a : allele_ids) alleles_[a].kmer_path.set_position((unsigned short)index);  // creates the allele if new
 }
 template <bool BI>
 bool UniqueKmersT<BI>::kmer_on_path(size_t kmer_index, size_t path_index) const {

@@ -1,0 +1,359 @@
+// test_host.cpp — C++ tests of the host interface (pangenie_amd/host/pangenie_host.hpp).
+//
+//   test_host cpu   host-only classes: KmerPath, UniqueKmers, CopyNumber, ProbabilityTable,
+//                   GenotypingResult, ColumnIndexer, flatten  (no device work)
+//   test_host gpu   HMM / EmissionProbabilityComputer / TransitionProbabilityComputer through
+//                   the C ABI on the GPU, against the reference's known answers
+//
+// The scenarios and expected numbers are those of the reference's unit tests
+// (tests/HMMTest.cpp, EmissionProbabilityComputerTest.cpp, TransitionProbabilityComputerTest.cpp,
+// UniqueKmersTest.cpp, GenotypingResultTest.cpp, CopyNumberTest.cpp, ColumnIndexerTest.cpp,
+// KmerPathTest.cpp); tolerance 1e-7 absolute as in reference tests/utils.cpp:9-11.
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <functional>
+#include <memory>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "../../pangenie_amd/host/pangenie_host.hpp"
+
+using namespace pangenie;
+using std::shared_ptr;
+using std::vector;
+typedef vector<unsigned short> us;
+
+static int g_failed = 0, g_checks = 0;
+#define CHECK(cond)                                                                       \
+    do {                                                                                  \
+        ++g_checks;                                                                       \
+        if (!(cond)) { ++g_failed; std::printf("  FAILED %s:%d: %s\n", __FILE__, __LINE__, #cond); } \
+    } while (0)
+#define CHECK_THROWS(expr)                                                                \
+    do {                                                                                  \
+        ++g_checks;                                                                       \
+        bool threw_ = false;                                                              \
+        try { (void)(expr); } catch (const std::exception&) { threw_ = true; }            \
+        if (!threw_) { ++g_failed; std::printf("  FAILED %s:%d: no throw: %s\n", __FILE__, __LINE__, #expr); } \
+    } while (0)
+static bool close(long double a, long double b) { return std::fabs((double)(a - b)) < 1e-7; }
+static bool close_all(const vector<double>& a, const vector<double>& b) {
+    if (a.size() != b.size()) return false;
+    for (size_t i = 0; i < a.size(); ++i)
+        if (!close(a[i], b[i])) { std::printf("    [%zu] got %.12g expected %.12g\n", i, a[i], b[i]); return false; }
+    return true;
+}
+static void run(const char* name, const std::function<void()>& f) {
+    const int before = g_failed;
+    try { f(); } catch (const std::exception& e) { ++g_failed; std::printf("  EXCEPTION in %s: %s\n", name, e.what()); }
+    std::printf("%s %s\n", g_failed == before ? "ok  " : "FAIL", name);
+}
+static shared_ptr<UniqueKmers> bi(size_t pos, us paths) { return shared_ptr<UniqueKmers>(new BiallelicUniqueKmers(pos, paths)); }
+static shared_ptr<UniqueKmers> multi(size_t pos, us paths) { return shared_ptr<UniqueKmers>(new MultiallelicUniqueKmers(pos, paths)); }
+static void kmer(shared_ptr<UniqueKmers>& u, unsigned short count, us alleles) { u->insert_kmer(count, alleles); }
+static vector<double> triples(const vector<GenotypingResult>& rs) {
+    vector<double> out;
+    for (auto& r : rs) {
+        out.push_back((double)r.get_genotype_likelihood(0, 0));
+        out.push_back((double)r.get_genotype_likelihood(0, 1));
+        out.push_back((double)r.get_genotype_likelihood(1, 1));
+    }
+    return out;
+}
+
+// ----------------------------------------------------------------------------------- CPU
+static void cpu_tests() {
+    run("KmerPath windows", [] {
+        KmerPath p32(32), p16(16);
+        p32.set_position(5); p32.set_position(36);
+        CHECK(p32.get_position(5) == 1 && p32.get_position(36) == 1 && p32.get_position(6) == 0 && p32.get_position(40) == 0);
+        CHECK(p32.nr_kmers() == 2 && p32.offset() == 5);
+        CHECK_THROWS(p32.set_position(37));
+        CHECK_THROWS(p32.set_position(4));
+        p16.set_position(3);
+        CHECK_THROWS(p16.set_position(19));
+        p16.set_position(18);
+        CHECK(p16.nr_kmers() == 2 && p16.mask() == ((1u << 0) | (1u << 15)));
+        CHECK(p16.convert_to_string().substr(0, 5) == "00010");
+    });
+    run("UniqueKmers biallelic basics", [] {
+        us paths = {0, 1, 1};
+        BiallelicUniqueKmers u(1000, paths);
+        CHECK(u.get_variant_position() == 1000 && u.get_nr_paths() == 3 && u.size() == 0);
+        us a0 = {0}, a1 = {1}, both = {0, 1}, bad = {2};
+        u.insert_kmer(4, a0); u.insert_kmer(6, a1); u.insert_kmer(8, both);
+        CHECK(u.size() == 3 && u.get_readcount_of(1) == 6);
+        CHECK(u.kmer_on_allele(0, 0) && !u.kmer_on_allele(0, 1) && u.kmer_on_allele(2, 0) && u.kmer_on_allele(2, 1));
+        CHECK(u.kmer_on_path(1, 1) && !u.kmer_on_path(1, 0));
+        CHECK_THROWS(u.insert_kmer(1, bad));
+        CHECK_THROWS(u.kmer_on_path(0, 3));
+        CHECK_THROWS(u.kmer_on_path(7, 0));
+        CHECK_THROWS(u.get_readcount_of(3));
+        u.update_readcount(0, 9);
+        CHECK(u.get_readcount_of(0) == 9);
+        CHECK_THROWS(u.update_readcount(5, 1));
+        u.set_coverage(27);
+        CHECK(u.get_coverage() == 27);
+        us p, a;
+        u.get_path_ids(p, a);
+        CHECK(p == us({0, 1, 2}) && a == us({0, 1, 1}));
+        us only = {2, 7}; p.clear(); a.clear();
+        u.get_path_ids(p, a, &only);
+        CHECK(p == us({2}) && a == us({1}));
+        CHECK(!u.is_undefined_allele(1));
+        u.set_undefined_allele(1);
+        CHECK(u.is_undefined_allele(1));
+        CHECK_THROWS(u.is_undefined_allele(2));
+        us ids, defined;
+        u.get_allele_ids(ids); u.get_defined_allele_ids(defined);
+        CHECK(ids == us({0, 1}) && defined == us({0}));
+        CHECK(u.kmers_on_allele(0) == 2 && u.present_kmers_on_allele(0) == 2 && u.kmers_on_alleles()[1] == 2);
+        CHECK(u.get_allele(2) == 1);
+        CHECK_THROWS(u.get_allele(3));
+        us wrong = {0, 3};
+        CHECK_THROWS(BiallelicUniqueKmers(5, wrong));
+    });
+    run("UniqueKmers multiallelic + update_paths", [] {
+        us paths = {0, 2, 1, 1};
+        MultiallelicUniqueKmers u(2000, paths);
+        us a0 = {0}, a1 = {1}, a2 = {2}, a3 = {3};
+        u.insert_kmer(10, a0); u.insert_kmer(11, a1); u.insert_kmer(12, a2); u.insert_kmer(2, a3);
+        us ids;
+        u.get_allele_ids(ids);
+        CHECK(ids == us({0, 1, 2, 3}));  // inserting a k-mer on an unseen allele creates it
+        CHECK(!u.is_undefined_allele(9));
+        CHECK_THROWS(u.set_undefined_allele(9));
+        u.set_undefined_allele(2);
+        CHECK(u.present_kmers_on_allele(3) == 0 && u.fraction_present_kmers_on_allele(3) == 0.0f);
+        us keep = {0, 1};
+        u.update_paths(keep);
+        CHECK(u.get_nr_paths() == 2 && u.get_allele(1) == 2 && u.size() == 2);
+        CHECK(u.get_readcount_of(0) == 10 && u.get_readcount_of(1) == 12 && u.is_undefined_allele(2));
+        ids.clear(); u.get_allele_ids(ids);
+        CHECK(ids == us({0, 2}));
+    });
+    run("CopyNumber", [] {
+        CHECK(close(CopyNumber(0.9, 0.1, 0.0).get_probability_of(0), 0.9));
+        CHECK(close(CopyNumber(0.0, 0.0, 1.0).get_probability_of(2), 1.0));
+        CopyNumber s(0.001, 0.6, 0.0004, 0.0);
+        CHECK(close(s.get_probability_of(0), 0.001 / 0.6014) && close(s.get_probability_of(1), 0.6 / 0.6014) && close(s.get_probability_of(2), 0.0004 / 0.6014));
+        CopyNumber r(0.2, 0.9, 1.1, 100.0);
+        CHECK(close(r.get_probability_of(0), 0.33156849768) && close(r.get_probability_of(1), 0.33388484447) && close(r.get_probability_of(2), 0.33454665784));
+        CHECK(CopyNumber(0.1, 0.2, 0.7) == CopyNumber(0.1, 0.2, 0.7) && CopyNumber(0.1, 0.2, 0.7) != CopyNumber(0.0, 1.0, 0.0));
+        CHECK_THROWS(r.get_probability_of(3));
+        CHECK(close(CopyNumber().get_probability_of(0), 1.0) && close(CopyNumber().get_probability_of(2), 0.0));
+    });
+    run("ProbabilityTable", [] {
+        ProbabilityTable p(4, 7, 2, 0.0L);
+        CHECK(close(p.get_probability(5, 0).get_probability_of(0), 0.99) && close(p.get_probability(5, 0).get_probability_of(1), 0.08208499862));
+        CHECK(close(p.get_probability(5, 1).get_probability_of(2), 0.03368973499) && close(p.get_probability(6, 1).get_probability_of(1), 0.149361205103));
+        CHECK(close(p.get_probability(6, 5).get_probability_of(0), 0.99 * std::pow(0.01, 5)));  // outside the box: on the fly
+        p.modify_probability(5, 1, CopyNumber(0.1, 0.2, 0.7));
+        CHECK(close(p.get_probability(5, 1).get_probability_of(2), 0.7));
+        CHECK_THROWS(p.modify_probability(9, 0, CopyNumber()));
+    });
+    run("GenotypingResult", [] {
+        GenotypingResult r;
+        CHECK(r.contains_no_likelihoods() && r.get_likeliest_genotype() == std::make_pair(-1, -1));
+        r.add_to_likelihood(0, 1, 0.1); r.add_to_likelihood(1, 0, 0.1); r.add_to_likelihood(0, 0, 0.05); r.add_to_likelihood(1, 1, 0.25);
+        CHECK(close(r.get_genotype_likelihood(1, 0), 0.2) && close(r.get_genotype_likelihood(2, 2), 0.0));
+        CHECK_THROWS(r.get_genotype_quality(1, 1));  // not normalised yet
+        r.normalize();
+        CHECK(close(r.get_genotype_likelihood(1, 1), 0.5) && r.get_likeliest_genotype() == std::make_pair(1, 1));
+        CHECK(r.get_genotype_quality(1, 1) == 3);
+        vector<long double> all = r.get_all_likelihoods(2);
+        CHECK(all.size() == 3 && close(all[0], 0.1) && close(all[1], 0.4) && close(all[2], 0.5));
+        CHECK_THROWS(r.get_all_likelihoods(1));
+        GenotypingResult tie;
+        tie.add_to_likelihood(0, 0, 0.5); tie.add_to_likelihood(0, 1, 0.5);
+        CHECK(tie.get_likeliest_genotype() == std::make_pair(-1, -1));
+        GenotypingResult sure;
+        sure.add_to_likelihood(0, 1, 1.0);
+        CHECK(sure.get_genotype_quality(0, 1) == 10000);
+        us only = {1};
+        GenotypingResult spec = r.get_specific_likelihoods(only);
+        CHECK(close(spec.get_genotype_likelihood(0, 0), 1.0));
+        GenotypingResult other;
+        other.add_to_likelihood(0, 2, 0.3);
+        r.combine(other);
+        CHECK(close(r.get_genotype_likelihood(0, 2), 0.3) && r.get_stored_likelihoods().size() == 4);
+        r.set_coverage(7); r.set_unique_kmers(9);
+        CHECK(r.coverage() == 7 && r.nr_unique_kmers() == 9);
+    });
+    run("ColumnIndexer + flatten", [] {
+        auto u1 = bi(2000, {0, 1, 0, 0, 0}); kmer(u1, 10, {0}); kmer(u1, 10, {1}); u1->set_coverage(5);
+        auto u2 = bi(2500, {0, 0, 1, 1, 1}); kmer(u2, 10, {0}); kmer(u2, 20, {1});
+        auto u3 = bi(3000, {0, 0, 1, 1, 1}); kmer(u3, 20, {0}); kmer(u3, 5, {1}); u3->set_coverage(5);
+        vector<shared_ptr<UniqueKmers>> uks = {u1, u2, u3};
+        us only = {2, 3};
+        ColumnIndexer ci(&uks, &only);
+        CHECK(ci.size() == 2 && ci.get_variant_id(0) == 1 && ci.get_variant_id(1) == 2 && ci.nr_paths() == 2);
+        CHECK(ci.get_path(0) == 2 && ci.get_path(1) == 3 && ci.get_allele(0, 0) == 1 && ci.get_allele(1, 1) == 1);
+        ColumnIndexer all(&uks, nullptr);
+        CHECK(all.size() == 3 && all.nr_paths() == 5 && all.get_allele(1, 0) == 1 && all.get_allele(4, 2) == 1 && all.get_allele(1, 2) == 0);
+        CHECK_THROWS(all.get_variant_id(3));
+        CHECK_THROWS(all.get_path(5));
+        CHECK_THROWS(all.get_allele(3, 3));
+        CHECK(all.get_path_ids_at(7) == std::make_pair((unsigned short)1, (unsigned short)2));
+        FlatContig f;
+        flatten(&uks, &only, f);
+        CHECK(f.batch.n_variants == 3 && f.batch.n_paths == 2 && f.path_allele == vector<uint16_t>({0, 0, 1, 1, 1, 1}));
+        CHECK(f.kmer_off == vector<uint32_t>({0, 2, 4, 6}) && f.allele_kmer_off[1] == 1 && f.allele_kmer_mask[1] == 1 && f.coverage[0] == 5);
+        us none = {8, 9};
+        CHECK_THROWS(flatten(&uks, &none, f));
+    });
+}
+
+// ----------------------------------------------------------------------------------- GPU
+static const double R01 = 446.287102628;  // recombination rate that gives recombination probability 0.1
+
+static void gpu_tests() {
+    run("device visible", [] { CHECK(HMM::device_count() >= 1); });
+    run("TransitionProbabilityComputer", [] {
+        TransitionProbabilityComputer t(1000000, 2000000, 1.26, 5, false, 0.25);
+        const double q = 0.04455105238, p = q + 0.77724473806;
+        CHECK(close(t.compute_transition_prob(0, 0, 0, 0), p * p) && close(t.compute_transition_prob(0, 0, 0, 1), p * q));
+        CHECK(close(t.compute_transition_prob(1, 2, 2, 1), q * q) && close(t.compute_transition_prob(1, 3, 1, 1), p * q));
+        CHECK(close(t.compute_transition_prob(0), p * p) && close(t.compute_transition_prob(2), q * q));
+        TransitionProbabilityComputer t10(1000000, 2000000, 1.26, 10, false, 0.25);
+        const double q10 = 0.01183851532, p10 = q10 + 0.88161484678;
+        CHECK(close(t10.compute_transition_prob(1), p10 * q10));
+        TransitionProbabilityComputer u(1, 2, 1.26, 5, true, 0.25);
+        CHECK(u.compute_transition_prob(2) == 1.0L);
+    });
+    run("EmissionProbabilityComputer", [] {
+        vector<us> alleles = {{0}, {0}, {1}, {1}, {1}};
+        us counts = {4, 6, 8, 2, 5};
+        vector<CopyNumber> cns = {CopyNumber(0.01, 0.2, 0.0), CopyNumber(0.001, 0.5, 0.001), CopyNumber(0.0, 0.3, 0.02), CopyNumber(0.05, 0.6, 0.0), CopyNumber(0.01, 0.2, 0.01)};
+        ProbabilityTable probs(0, 10, 10, 0.0);
+        auto u = multi(1000, {0, 1, 2});
+        u->set_undefined_allele(2);
+        for (size_t i = 0; i < counts.size(); ++i) { u->insert_kmer(counts[i], alleles[i]); probs.modify_probability(0, counts[i], cns[i]); }
+        EmissionProbabilityComputer e(u, &probs);
+        CHECK(close(e.get_emission_probability(0, 0), 0.0) && close(e.get_emission_probability(0, 1), 0.0036) && close(e.get_emission_probability(1, 0), 0.0036));
+        CHECK(close(e.get_emission_probability(1, 1), 0.0) && close(e.get_emission_probability(0, 2), 0.000128225) && close(e.get_emission_probability(2, 1), 0.000132565));
+        CHECK(close(e.get_emission_probability(2, 2), 0.000019852));
+    });
+    auto std_table = [] {
+        ProbabilityTable probs(5, 10, 30, 0.0L);
+        probs.modify_probability(5, 10, CopyNumber(0.1, 0.9, 0.1));
+        probs.modify_probability(5, 20, CopyNumber(0.01, 0.01, 0.9));
+        probs.modify_probability(5, 5, CopyNumber(0.9, 0.3, 0.1));
+        return probs;
+    };
+    run("HMM get_genotyping_result / skip_reference_position", [&] {
+        auto u1 = bi(2000, {0, 1}); kmer(u1, 10, {0}); kmer(u1, 10, {1}); u1->set_coverage(5);
+        auto ref_only = bi(2500, {0, 0}); kmer(ref_only, 10, {0}); kmer(ref_only, 20, {1}); ref_only->set_coverage(22);
+        auto u3 = bi(3000, {0, 1}); kmer(u3, 20, {0}); kmer(u3, 5, {1}); u3->set_coverage(5);
+        ProbabilityTable probs = std_table();
+        vector<shared_ptr<UniqueKmers>> two = {u1, u3}, three = {u1, ref_only, u3};
+        HMM a(&two, &probs, true, false, R01, false, 0.25);
+        CHECK(close_all(triples(a.get_genotyping_result()), {0.0509465435, 0.9483202731, 0.0007331832, 0.9678020017, 0.031003181, 0.0011948172}));
+        HMM b(&three, &probs, true, false, R01, false, 0.25);
+        auto res = b.get_genotyping_result();
+        CHECK(close_all(triples(res), {0.0509465435, 0.9483202731, 0.0007331832, 0.0, 0.0, 0.0, 0.9678020017, 0.031003181, 0.0011948172}));
+        CHECK(res[1].coverage() == 22 && res[0].coverage() == 5 && res[1].nr_unique_kmers() == 2 && res[1].contains_no_likelihoods());
+    });
+    run("HMM undefined alleles", [] {
+        auto u1 = bi(2000, {0, 1}); u1->set_undefined_allele(0); kmer(u1, 10, {0});
+        auto u2 = bi(3000, {1, 0}); kmer(u2, 20, {0}); kmer(u2, 1, {1});
+        ProbabilityTable probs(0, 1, 21, 0.0L);
+        probs.modify_probability(0, 10, CopyNumber(0.1, 0.9, 0.1));
+        probs.modify_probability(0, 20, CopyNumber(0.01, 0.01, 0.9));
+        probs.modify_probability(0, 1, CopyNumber(0.9, 0.3, 0.1));
+        vector<shared_ptr<UniqueKmers>> uks = {u1, u2};
+        HMM hmm(&uks, &probs, true, false, R01, false, 0.25);
+        auto res = hmm.get_genotyping_result();
+        CHECK(close_all(triples(res), {0.02396597038, 0.52185641164, 0.45417761795, 0.97855858361, 0.01875778106, 0.00268363531}));
+        us defined = {1};
+        CHECK(close(res[0].get_specific_likelihoods(defined).get_genotype_likelihood(0, 0), 1.0));
+    });
+    run("HMM no unique kmers / uniform / no alt allele", [] {
+        ProbabilityTable none;
+        auto a1 = bi(2000, {0, 0, 1}), a2 = bi(3000, {0, 1, 1});
+        vector<shared_ptr<UniqueKmers>> uks = {a1, a2};
+        HMM hmm(&uks, &none, true, false, 1070.02483182, false, 0.25);
+        CHECK(close_all(triples(hmm.get_genotyping_result()), {4.0 / 9, 4.0 / 9, 1.0 / 9, 1.0 / 9, 4.0 / 9, 4.0 / 9}));
+        auto b1 = bi(2000, {0, 1, 1}), b2 = bi(3000, {0, 0, 1});
+        vector<shared_ptr<UniqueKmers>> uks2 = {b1, b2};
+        HMM uni(&uks2, &none, true, false, 1.26, true, 0.25);
+        CHECK(close_all(triples(uni.get_genotyping_result()), {1 / 9.0, 4 / 9.0, 4 / 9.0, 4 / 9.0, 4 / 9.0, 1 / 9.0}));
+        auto c = bi(2000, {0, 0, 0}); kmer(c, 10, {0, 1}); kmer(c, 5, {});
+        ProbabilityTable probs(0, 1, 11, 0.0L);
+        probs.modify_probability(0, 10, CopyNumber(0.1, 0.2, 0.9));
+        probs.modify_probability(0, 5, CopyNumber(0.3, 0.4, 0.1));
+        vector<shared_ptr<UniqueKmers>> uks3 = {c};
+        HMM noalt(&uks3, &probs, true, false, 1.26, false, 0.25);
+        CHECK(noalt.get_genotyping_result()[0].get_likeliest_genotype() == std::make_pair(-1, -1));
+    });
+    run("HMM emissions_zero / underflow", [] {
+        auto u1 = bi(1000, {0, 1}); kmer(u1, 10, {0}); kmer(u1, 10, {1});
+        auto u2 = bi(2000, {1, 1}); kmer(u2, 0, {1}); kmer(u2, 0, {1});
+        auto u3 = bi(3000, {0, 1}); kmer(u3, 10, {0}); kmer(u3, 10, {1});
+        ProbabilityTable probs(0, 1, 11, 0.0L);
+        probs.modify_probability(0, 10, CopyNumber(0.0, 1.0, 0.0));
+        probs.modify_probability(0, 0, CopyNumber(1.0, 0.0, 0.0));
+        vector<shared_ptr<UniqueKmers>> uks = {u1, u2, u3};
+        HMM hmm(&uks, &probs, true, false, R01, false, 0.25);
+        CHECK(close_all(triples(hmm.get_genotyping_result()), {0.0, 1.0, 0.0, 0.0, 0.0, 1.0, 0.0, 1.0, 0.0}));
+        auto v2 = bi(2000, {0, 1}); kmer(v2, 20, {0}); kmer(v2, 0, {1});
+        ProbabilityTable p2(0, 1, 21, 0.0L);
+        p2.modify_probability(0, 10, CopyNumber(0.0, 1.0, 0.0));
+        p2.modify_probability(0, 20, CopyNumber(0.0, 0.0, 1.0));
+        p2.modify_probability(0, 0, CopyNumber(1.0, 0.0, 0.0));
+        vector<shared_ptr<UniqueKmers>> uks2 = {u1, v2, u3};
+        HMM under(&uks2, &p2, true, false, 0.0, false, 0.25);
+        CHECK(close_all(triples(under.get_genotyping_result()), {0.0, 0.0, 0.0, 0.0, 1.0, 0.0, 0.0, 1.0, 0.0}));
+    });
+    run("HMM only_paths / normalize / combine_likelihoods", [&] {
+        us only = {0, 3};
+        auto u1 = multi(2000, {0, 2, 1, 1}); kmer(u1, 10, {0}); kmer(u1, 10, {1});
+        auto u2 = multi(3000, {0, 0, 2, 1}); kmer(u2, 20, {0}); kmer(u2, 1, {1});
+        ProbabilityTable probs(0, 1, 21, 0.0L);
+        probs.modify_probability(0, 10, CopyNumber(0.1, 0.9, 0.1));
+        probs.modify_probability(0, 20, CopyNumber(0.01, 0.01, 0.9));
+        probs.modify_probability(0, 1, CopyNumber(0.9, 0.3, 0.1));
+        vector<shared_ptr<UniqueKmers>> uks = {u1, u2};
+        HMM hmm1(&uks, &probs, true, false, R01, false, 0.25, &only);
+        vector<double> first = triples(hmm1.get_genotyping_result());
+        CHECK(close_all(first, {0.0509465435, 0.9483202731, 0.0007331832, 0.9678020017, 0.031003181, 0.0011948172}));
+
+        us only01 = {0, 1};
+        auto w1 = multi(2000, {0, 1, 2}); kmer(w1, 12, {2});
+        auto w2 = multi(3000, {0, 1, 2}); kmer(w2, 12, {2});
+        ProbabilityTable p13(0, 1, 13, 0.0L);
+        p13.modify_probability(0, 12, CopyNumber(0.05, 0.8, 0.15));
+        vector<shared_ptr<UniqueKmers>> wks = {w1, w2};
+        HMM raw(&wks, &p13, true, false, R01, false, 0.25, &only01, false);
+        CHECK(close_all(triples(raw.get_genotyping_result()), {0.000625, 0.00125, 0.000625, 0.0125, 0.025, 0.0125}));
+        raw.normalize();
+        vector<double> second = triples(raw.get_genotyping_result());
+        CHECK(close_all(second, {0.25, 0.5, 0.25, 0.25, 0.5, 0.25}));
+        hmm1.combine_likelihoods(raw);
+        vector<double> expect;
+        for (size_t i = 0; i < 6; ++i) expect.push_back(first[i] + second[i]);
+        CHECK(close_all(triples(hmm1.get_genotyping_result()), expect));
+        vector<shared_ptr<UniqueKmers>> one = {w1};
+        HMM small(&one, &p13, true, false, R01, false, 0.25, &only01);
+        CHECK_THROWS(hmm1.combine_likelihoods(small));
+    });
+    run("HMM error behaviour", [] {
+        ProbabilityTable none;
+        auto u = bi(2000, {0, 1});
+        vector<shared_ptr<UniqueKmers>> uks = {u};
+        us nobody = {5, 6};
+        CHECK_THROWS(HMM(&uks, &none, true, false, 1.26, false, 0.25, &nobody));  // column not covered by any paths
+        CHECK_THROWS(HMM(&uks, &none, true, true));                                // Viterbi is not on the device path
+    });
+}
+
+int main(int argc, char** argv) {
+    const std::string mode = argc > 1 ? argv[1] : "cpu";
+    if (mode == "cpu") cpu_tests();
+    else if (mode == "gpu") gpu_tests();
+    else { std::printf("usage: test_host cpu|gpu\n"); return 2; }
+    std::printf("%d checks, %d failed\n", g_checks, g_failed);
+    return g_failed ? 1 : 0;
+}

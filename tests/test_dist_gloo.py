@@ -1,0 +1,69 @@
+"""N>1 path on CPU: chain sharding plan + the single gather of packed posteriors, run as two
+gloo processes (the same code runs over nccl = RCCL on GPUs)."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from pangenie_amd.dist import assign_chains, gather_posteriors, pack_sizes
+
+
+def test_lpt_plan_is_balanced_and_deterministic():
+    w = [248, 242, 198, 190, 181, 170, 159, 145, 138, 133, 135, 133, 114, 107, 102, 90, 83, 80, 58, 64, 46, 50, 156, 57]
+    plan = assign_chains(w, 8)
+    assert sorted(i for p in plan for i in p) == list(range(24))
+    loads = [sum(w[i] for i in p) for p in plan]
+    assert max(loads) <= 1.15 * (sum(w) / 8)
+    assert plan == assign_chains(w, 8)
+    assert assign_chains([5, 1], 4) == [[0], [1], [], []]
+    assert pack_sizes([3, 6], [1, 2], [[0], [1]]) == ([4, 8], 8)
+
+
+def _fake(i, n_lik, n_var):
+    rng = np.random.default_rng(100 + i)
+    return rng.random(n_lik[i]), rng.integers(-2000, 5, size=n_var[i]).astype(np.int32)
+
+
+def _worker(rank, world, port, n_lik, n_var, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    plan = assign_chains([a * 1.0 for a in n_var], world)
+    local = {}
+    for i in plan[rank]:
+        lik, ex = _fake(i, n_lik, n_var)
+        local[i] = (torch.from_numpy(lik), torch.from_numpy(ex))
+    got = gather_posteriors(local, n_lik, n_var, plan, dst=0)
+    ok = True
+    if rank == 0:
+        ok = sorted(got) == list(range(len(n_lik)))
+        for i in range(len(n_lik)):
+            lik, ex = _fake(i, n_lik, n_var)
+            ok = ok and np.array_equal(got[i][0], lik) and np.array_equal(got[i][1], ex)
+    else:
+        ok = got is None
+    q.put((rank, bool(ok)))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_gather_two_ranks_gloo():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    n_var = [50, 7, 31, 12, 1]
+    n_lik = [150, 21, 99, 40, 3]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, n_lik, n_var, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    results = dict(q.get(timeout=120) for _ in range(2))
+    for p in procs:
+        p.join(timeout=60)
+    assert results == {0: True, 1: True}
