@@ -36,7 +36,17 @@ WORKLOADS = {
     "contig_h16": dict(V=50_000, H=16, K=20, multi=0.0, cfg="configs[1]: 1 contig, 50k variants, 16 haplotypes, ~20 k-mers/var"),
     "chr22_h64": dict(V=200_000, H=64, K=20, multi=0.0, cfg="configs[2]: chr22-scale, 200k variants, 64 haplotypes"),
     "chr22_h128": dict(V=60_000, H=128, K=20, multi=0.2, cfg="configs[4] per-GPU slice: 128 haplotypes, 20% multiallelic"),
+    # many independent chains on one GPU (sample x contig shards): the regime
+    # in which the sweep is HBM-bound instead of per-column-latency-bound
+    "cohort_h64": dict(V=16_000, H=64, K=20, multi=0.0, chains=256, cfg="256 chains (sample x contig shards) of 16k variants, 64 haplotypes"),
+    "genome24_small": dict(V=40_000, H=64, K=20, multi=0.0, chains=24, cfg="configs[3] shape at 1/5 length, equal contigs: 24 contigs, 64 haplotypes, one GPU"),
+    # BASELINE.json configs[3]: whole genome, 24 contigs with human-like length proportions, 5M variants,
+    # 64 haplotypes.  164 GB of column slots: fits ONE 288 GB MI355X, so it is the single-GPU workload.
+    "genome24_h64": dict(V=5_000_000, H=64, K=20, multi=0.0, chains=24, genome=True,
+                         cfg="configs[3]: whole genome, 24 contigs (human chromosome length proportions), 5M variants, 64 haplotypes"),
 }
+# GRCh38 chromosome lengths (Mb) 1..22, X, Y: proportions of the 24 synthetic contigs
+CONTIG_MB = [248, 242, 198, 190, 181, 171, 159, 145, 138, 134, 135, 133, 114, 107, 102, 90, 83, 80, 59, 64, 47, 51, 156, 57]
 
 
 def cpu_baseline(batch, H, sample_variants):
@@ -75,7 +85,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--workload", default="chr22_h64", choices=sorted(WORKLOADS))
+    ap.add_argument("--workload", default="genome24_h64", choices=sorted(WORKLOADS))
     ap.add_argument("--variants", type=int, default=0, help="override the variant count (debug)")
     ap.add_argument("--cpu-sample", type=int, default=0, help="variants in the CPU-baseline sample (0 = auto ~10-20 s)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -99,11 +109,19 @@ def main():
     w = WORKLOADS[args.workload]
     V = args.variants or w["V"]
     H, K = w["H"], w["K"]
-    batch = synthetic_panel(V, H, K, seed=12345 + rank, multiallelic_frac=w["multi"])
+    n_chains = int(w.get("chains", 1))
+    if w.get("genome"):
+        tot = float(sum(CONTIG_MB))
+        sizes = [int(round(V * mb / tot)) for mb in CONTIG_MB]
+    else:
+        sizes = [V] * n_chains
+    batches = [synthetic_panel(sizes[i], H, K, seed=12345 + rank + 1000 * i, multiallelic_frac=w["multi"]) for i in range(n_chains)]
+    V_total = sum(sizes)
+    batch = batches[0]
     table = hmm.ProbabilityTable(*default_table_args())
     params = hmm.make_params(1.26, False, 1e-5)  # what run_genotyping passes (reference src/commands.cpp:160)
     t_up = time.perf_counter()
-    job = hmm.Job([batch], table, params, device=local_rank)
+    job = hmm.Job(batches, table, params, device=local_rank)
     upload_s = time.perf_counter() - t_up
 
     # gather plumbing: posteriors stay on the device; chain r lives on rank r (weak scaling),
@@ -154,12 +172,18 @@ def main():
     kms = {k: v / args.steps for k, v in kms.items()}
 
     if rank == 0:
-        total_variants = V * world * args.steps
+        total_variants = V_total * world * args.steps
         value = total_variants / dt
         # roofline of the dominant kernel (HBM-bound class), algorithmic bytes per launch
         kept = res.kept
         ncol = int(kept.sum())
         bytes_total = algorithmic_bytes(batch, kept)
+        if n_chains > 1:  # all chains of the job run in the same launch
+            ncol, bytes_total = 0, 0
+            for i, bt in enumerate(batches):
+                kp = job.fetch(i).kept
+                ncol += int(kp.sum())
+                bytes_total += algorithmic_bytes(bt, kp)
         # sweep phase 1 writes every kept column once (8*H^2 B), phase 2 reads it once; the
         # per-variant inputs/outputs (4K+2H+3A+16+8G+8 B) are charged to phase 2.
         p1_bytes = 8.0 * H * H * ncol
@@ -170,17 +194,17 @@ def main():
         achieved = dom_bytes / (dom_ms * 1e-3) / 1e9 if dom_ms > 0 else 0.0
         sweep_ms = kms.get("k_sweep_phase1", 0.0) + kms.get("k_sweep_phase2", 0.0)
         traffic, traffic_src = (None, None)
-        if V == w["V"]:
+        if V == w["V"] and n_chains == 1:
             traffic, traffic_src = profiled_traffic(args.workload, 1 if dom == "k_sweep_phase1" else 2)
         out = {
             "metric": "genotyped variants/sec (whole node) at H haplotypes; HBM GB/s vs roofline",
             "value": value, "unit": "variants/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-            "config": {"workload": f"{args.workload}: {w['cfg']}; {V} variants x {H} haplotypes x {K} k-mers/variant "
-                                   f"per GPU, 1 contig (= 1 chain) per GPU, seed 12345+rank",
-                       "variants_per_gpu": V, "haplotypes": H, "kmers_per_variant": K,
-                       "kept_columns": ncol, "chains_per_gpu": 1, "workgroups_per_chain": 2, "parallelism": f"contig-sharded x{world}"},
+            "config": {"workload": f"{args.workload}: {w['cfg']}; {V_total} variants x {H} haplotypes x {K} k-mers/variant "
+                                   f"per GPU in {n_chains} chain(s) (longest {max(sizes)}), seed 12345+rank",
+                       "variants_per_gpu": V_total, "haplotypes": H, "kmers_per_variant": K,
+                       "kept_columns": ncol, "chains_per_gpu": n_chains, "workgroups_per_chain": 2, "parallelism": f"contig-sharded x{world}"},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
                          "algorithmic_bytes_per_launch": dom_bytes, "avg_launch_ms": dom_ms,

@@ -10,7 +10,7 @@
 //   fwd[C][HP*HP] : column slots (fp64): slot c holds the forward column of c < C/2 and the
 //                   backward column of c >= C/2 — written once in sweep phase 1, read once in
 //                   sweep phase 2: the 16*H^2 algorithmic bytes per column.
-//   part[C][AMAX][T] : per-thread posterior partials by row allele (reduced by k_bins)
+//   part[C][part_slots][T] : per-thread posterior partials by row allele (reduced by k_bins)
 //   lik / lik_exp : outputs
 #pragma once
 #include <stdint.h>
@@ -58,6 +58,8 @@ struct DevContig {
     double dist_scale;     // 0.000004 * recombrate * effective_N
     int32_t uniform;
     uint32_t debug;        // PG_DEBUG env: ablation switches for profiling (0 in production)
+    uint32_t part_slots;   // allele slots per column in `part` = min(PG_AMAX, max alleles of a variant)
+    uint32_t pad2;
     // inputs
     const uint64_t* pos;
     const uint16_t* cov;

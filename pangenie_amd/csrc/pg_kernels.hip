@@ -473,6 +473,9 @@ typedef GAS double gdouble;
 typedef GAS const double gcdouble;
 typedef GAS const unsigned long long gcu64;
 typedef GAS unsigned char gu8;
+typedef double v2f64 __attribute__((ext_vector_type(2)));  // native vector type (address-space qualifiable)
+typedef GAS v2f64 gdouble2;
+typedef GAS const v2f64 gcdouble2;
 
 template <int HP, int R>
 struct ChainCfg {
@@ -598,7 +601,7 @@ DEVI void write_sums(ChainShared<HP, R>& sh, uint32_t pb, const ThreadPos& p, do
 
 // posterior partials of column c: acc[a] = sum over my rows with local allele a of v*beta
 template <int HP, int R>
-DEVI void posterior(ChainShared<HP, R>& sh, gdouble* part_out, bool full, uint32_t c, const ThreadPos& p,
+DEVI void posterior(ChainShared<HP, R>& sh, gdouble* part_out, uint32_t part_slots, bool full, uint32_t c, const ThreadPos& p,
                     const double (&v)[R], const double (&beta)[R]) {
     using Cfg = ChainCfg<HP, R>;
     const unsigned char* rec0 = sh.rec[c & 3u];
@@ -633,7 +636,7 @@ DEVI void posterior(ChainShared<HP, R>& sh, gdouble* part_out, bool full, uint32
         for (int a = 0; a < PG_AMAX; ++a)
             if ((uint32_t)a < nl) sh.pout[c & 1u][a][p.tid] = acc[a];
     } else {
-        gdouble* dst = part_out + (size_t)c * PG_AMAX * Cfg::T + p.tid;
+        gdouble* dst = part_out + (size_t)c * part_slots * Cfg::T + p.tid;
 #pragma unroll
         for (int a = 0; a < PG_AMAX; ++a)
             if ((uint32_t)a < nl) dst[(size_t)a * Cfg::T] = acc[a];
@@ -642,11 +645,11 @@ DEVI void posterior(ChainShared<HP, R>& sh, gdouble* part_out, bool full, uint32
 
 // loader: drain the posterior partials of column c (LDS -> HBM)
 template <int HP, int R>
-DEVI void flush_partials(const ChainShared<HP, R>& sh, gdouble* part_out, int64_t c, int64_t lo, int64_t hi, uint32_t lane) {
+DEVI void flush_partials(const ChainShared<HP, R>& sh, gdouble* part_out, uint32_t part_slots, int64_t c, int64_t lo, int64_t hi, uint32_t lane) {
     using Cfg = ChainCfg<HP, R>;
     if (c < lo || c >= hi) return;
     const uint32_t nl = sh.rec[(uint32_t)c & 3u][PG_REC_NLOCAL];
-    gdouble* dst = part_out + (size_t)c * PG_AMAX * Cfg::T;
+    gdouble* dst = part_out + (size_t)c * part_slots * Cfg::T;
     for (uint32_t a = 0; a < nl; ++a)
         for (uint32_t t = lane; t < (uint32_t)Cfg::T; t += 64)
             dst[(size_t)a * Cfg::T + t] = sh.pout[Cfg::LOADER ? ((uint32_t)c & 1u) : 0][a][Cfg::LOADER ? t : 0];
@@ -667,6 +670,7 @@ DEVI void forward_body(const DevContig& dc, ChainShared<HP, R>& sh, uint32_t C) 
     p.wave = __builtin_amdgcn_readfirstlane(p.tid >> 6);
     gcu64* colrec = (gcu64*)dc.colrec;
     gdouble* part_out = (gdouble*)dc.part;
+    const uint32_t part_slots = dc.part_slots;
 
     auto rec_load = [&](uint32_t c) -> unsigned long long {
         if (p.lane < (uint32_t)Cfg::WORDS && c < C) return colrec[(size_t)c * Cfg::WORDS + p.lane];
@@ -685,19 +689,19 @@ DEVI void forward_body(const DevContig& dc, ChainShared<HP, R>& sh, uint32_t C) 
         for (uint32_t t = first; t < hi; t += 2) {
             rec_stage(t + 1, ta);  // loaded two columns ago
             ta = rec_load(t + 3);
-            if (PHASE == 2) flush_partials<HP, R>(sh, part_out, (int64_t)t - 2, mid, C, p.lane);
+            if (PHASE == 2) flush_partials<HP, R>(sh, part_out, part_slots, (int64_t)t - 2, mid, C, p.lane);
             lds_barrier();  // B_t
             if (t + 1 < hi) {
                 rec_stage(t + 2, tb);
                 tb = rec_load(t + 4);
-                if (PHASE == 2) flush_partials<HP, R>(sh, part_out, (int64_t)t - 1, mid, C, p.lane);
+                if (PHASE == 2) flush_partials<HP, R>(sh, part_out, part_slots, (int64_t)t - 1, mid, C, p.lane);
                 lds_barrier();  // B_{t+1}
             }
         }
         if (PHASE == 2) {
-            flush_partials<HP, R>(sh, part_out, (int64_t)hi - 2, mid, C, p.lane);
+            flush_partials<HP, R>(sh, part_out, part_slots, (int64_t)hi - 2, mid, C, p.lane);
             lds_barrier();  // F
-            flush_partials<HP, R>(sh, part_out, (int64_t)hi - 1, mid, C, p.lane);
+            flush_partials<HP, R>(sh, part_out, part_slots, (int64_t)hi - 1, mid, C, p.lane);
         }
         return;
     }
@@ -715,15 +719,15 @@ DEVI void forward_body(const DevContig& dc, ChainShared<HP, R>& sh, uint32_t C) 
 
     auto store_col = [&](uint32_t c, const double (&x)[R]) {
         if (dbg & 1u) return;
-        gdouble* dst = fwd + (size_t)c * colsz + (size_t)p.i0 * HP + p.j;
+        gdouble2* dst = (gdouble2*)(fwd + (size_t)c * colsz) + (size_t)(p.i0 >> 1) * HP + p.j;
 #pragma unroll
-        for (int k = 0; k < R; ++k) dst[(size_t)k * HP] = x[k];
+        for (int k = 0; k < R; k += 2) dst[(size_t)(k >> 1) * HP] = v2f64{x[k], x[k + 1]};
     };
     auto load_col = [&](uint32_t c, double (&v)[R]) {
         if (c >= C) return;
-        gcdouble* src = (gcdouble*)fwd + (size_t)c * colsz + (size_t)p.i0 * HP + p.j;
+        gcdouble2* src = (gcdouble2*)(fwd + (size_t)c * colsz) + (size_t)(p.i0 >> 1) * HP + p.j;
 #pragma unroll
-        for (int k = 0; k < R; ++k) v[k] = src[(size_t)k * HP];
+        for (int k = 0; k < R; k += 2) { const v2f64 t = src[(size_t)(k >> 1) * HP]; v[k] = t.x; v[k + 1] = t.y; }
     };
 
     constexpr int FB = R > 16 ? 1 : 2;  // beta' prefetch buffers (register budget at R = 32)
@@ -750,10 +754,10 @@ DEVI void forward_body(const DevContig& dc, ChainShared<HP, R>& sh, uint32_t C) 
         write_sums<HP, R>(sh, 0, p, part);
     } else {
         // resume behind the column the other phase stored last
-        gcdouble* src = (gcdouble*)fwd + (size_t)(lo - 1) * colsz + (size_t)p.i0 * HP + p.j;
+        load_col(lo - 1, x);
         double part = 0.0;
 #pragma unroll
-        for (int k = 0; k < R; ++k) { x[k] = src[(size_t)k * HP]; part += x[k]; }
+        for (int k = 0; k < R; ++k) part += x[k];
         write_sums<HP, R>(sh, (lo - 1) & 1u, p, part);
     }
     lds_barrier();  // Bx
@@ -786,7 +790,7 @@ DEVI void forward_body(const DevContig& dc, ChainShared<HP, R>& sh, uint32_t C) 
         finalize(t - 1);
         if constexpr (PHASE == 2) {
             if (t - 1 >= mid) {
-                posterior<HP, R>(sh, part_out, full, t - 1, p, x, vb);
+                posterior<HP, R>(sh, part_out, part_slots, full, t - 1, p, x, vb);
                 load_col(t - 1 + FB, vb);
             }
         }
@@ -839,10 +843,10 @@ DEVI void forward_body(const DevContig& dc, ChainShared<HP, R>& sh, uint32_t C) 
     finalize(hi - 1);
     if constexpr (PHASE == 2) {
         if constexpr (FB == 2) {
-            if (((hi - 1 - mid) & 1u) == 0) posterior<HP, R>(sh, part_out, full, hi - 1, p, x, vA);
-            else posterior<HP, R>(sh, part_out, full, hi - 1, p, x, vB);
+            if (((hi - 1 - mid) & 1u) == 0) posterior<HP, R>(sh, part_out, part_slots, full, hi - 1, p, x, vA);
+            else posterior<HP, R>(sh, part_out, part_slots, full, hi - 1, p, x, vB);
         } else {
-            posterior<HP, R>(sh, part_out, full, hi - 1, p, x, vA);
+            posterior<HP, R>(sh, part_out, part_slots, full, hi - 1, p, x, vA);
         }
         lds_barrier();  // F: the last partials are in LDS
     }
@@ -866,6 +870,7 @@ DEVI void backward_body(const DevContig& dc, ChainShared<HP, R>& sh, uint32_t C)
     p.wave = __builtin_amdgcn_readfirstlane(p.tid >> 6);
     gcu64* colrec = (gcu64*)dc.colrec;
     gdouble* part_out = (gdouble*)dc.part;
+    const uint32_t part_slots = dc.part_slots;
     // recursion steps run over t = t0 .. bot where t0 = top-1 in phase 1 (column top is the
     // all-ones column) and t0 = top in phase 2 (resumed behind column mid)
     const int64_t t0 = PHASE == 1 ? top - 1 : top;
@@ -888,19 +893,19 @@ DEVI void backward_body(const DevContig& dc, ChainShared<HP, R>& sh, uint32_t C)
         for (int64_t t = t0; t >= bot; t -= 2) {
             rec_stage(t - 1, ta);
             ta = rec_load(t - 3);
-            if (PHASE == 2) flush_partials<HP, R>(sh, part_out, t + 2, 0, mid, p.lane);
+            if (PHASE == 2) flush_partials<HP, R>(sh, part_out, part_slots, t + 2, 0, mid, p.lane);
             lds_barrier();  // B_t
             if (t - 1 >= bot) {
                 rec_stage(t - 2, tb);
                 tb = rec_load(t - 4);
-                if (PHASE == 2) flush_partials<HP, R>(sh, part_out, t + 1, 0, mid, p.lane);
+                if (PHASE == 2) flush_partials<HP, R>(sh, part_out, part_slots, t + 1, 0, mid, p.lane);
                 lds_barrier();  // B_{t-1}
             }
         }
         if (PHASE == 2) {
-            flush_partials<HP, R>(sh, part_out, 1, 0, mid, p.lane);
+            flush_partials<HP, R>(sh, part_out, part_slots, 1, 0, mid, p.lane);
             lds_barrier();  // F
-            flush_partials<HP, R>(sh, part_out, 0, 0, mid, p.lane);
+            flush_partials<HP, R>(sh, part_out, part_slots, 0, 0, mid, p.lane);
         }
         return;
     }
@@ -917,14 +922,14 @@ DEVI void backward_body(const DevContig& dc, ChainShared<HP, R>& sh, uint32_t C)
 
     auto load_col = [&](int64_t c, double (&v)[R]) {
         if (c < 0) return;
-        gcdouble* src = (gcdouble*)cols + (size_t)c * colsz + (size_t)p.i0 * HP + p.j;
+        gcdouble2* src = (gcdouble2*)(cols + (size_t)c * colsz) + (size_t)(p.i0 >> 1) * HP + p.j;
 #pragma unroll
-        for (int k = 0; k < R; ++k) v[k] = src[(size_t)k * HP];
+        for (int k = 0; k < R; k += 2) { const v2f64 t = src[(size_t)(k >> 1) * HP]; v[k] = t.x; v[k + 1] = t.y; }
     };
     auto store_col = [&](int64_t c, const double (&y)[R]) {
-        gdouble* dst = cols + (size_t)c * colsz + (size_t)p.i0 * HP + p.j;
+        gdouble2* dst = (gdouble2*)(cols + (size_t)c * colsz) + (size_t)(p.i0 >> 1) * HP + p.j;
 #pragma unroll
-        for (int k = 0; k < R; ++k) dst[(size_t)k * HP] = y[k];
+        for (int k = 0; k < R; k += 2) dst[(size_t)(k >> 1) * HP] = v2f64{y[k], y[k + 1]};
     };
 
     constexpr int NV = PHASE == 2 ? R : 1;
@@ -1026,7 +1031,7 @@ DEVI void backward_body(const DevContig& dc, ChainShared<HP, R>& sh, uint32_t C)
             store_col(t, y);
             if (p.tid == 0) bsum[t] = Sy;
         } else {
-            posterior<HP, R>(sh, part_out, full, (uint32_t)t, p, v, y);
+            posterior<HP, R>(sh, part_out, part_slots, full, (uint32_t)t, p, v, y);
             load_col(t - VBUF, v);
         }
     };
@@ -1079,7 +1084,7 @@ __global__ __launch_bounds__(256) void k_bins(const DevContig* __restrict__ cont
     if (lane < PG_AMAX * (PG_AMAX + 1) / 2) s_bins[wave][lane] = 0.0;
     wave_sync();
     for (uint32_t a = 0; a < nl; ++a) {
-        const double* src = dc.part + ((size_t)c * PG_AMAX + a) * T;
+        const double* src = dc.part + ((size_t)c * dc.part_slots + a) * T;
         for (uint32_t b = 0; b < nl; ++b) {
             double s = 0.0;
             for (uint32_t t = lane; t < T; t += 64)

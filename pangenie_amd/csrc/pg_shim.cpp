@@ -209,7 +209,7 @@ static const char* const kKernelNames[PG_N_KERNEL_CLASSES] = {"k_prep", "k_compa
                                                               "k_sweep_phase1", "k_sweep_phase2", "k_bins"};
 
 struct ContigHost {
-    uint32_t V = 0, H = 0, HP = 0, T = 0, RB = 0;
+    uint32_t V = 0, H = 0, HP = 0, T = 0, RB = 0, part_slots = 1;
     uint32_t sumK = 0, sumA = 0;
     uint64_t n_lik = 0;
     std::vector<uint16_t> n_kmers, coverage;
@@ -328,8 +328,9 @@ extern "C" pg_job* pg_job_create(int device, uint32_t n_contigs, const pg_contig
         c.V = b.n_variants; c.H = b.n_paths; c.HP = pad_paths(c.H ? c.H : 1);
         c.T = pgk_threads_for_hp(c.HP); c.RB = pg_rec_bytes(c.HP);
         c.sumK = c.V ? b.kmer_off[c.V] : 0; c.sumA = c.V ? b.allele_off[c.V] : 0;
-        uint64_t nl = 0;
-        for (uint32_t v = 0; v < c.V; ++v) { uint64_t A = b.allele_off[v + 1] - b.allele_off[v]; nl += A * (A + 1) / 2; }
+        uint64_t nl = 0, maxA = 1;
+        for (uint32_t v = 0; v < c.V; ++v) { uint64_t A = b.allele_off[v + 1] - b.allele_off[v]; nl += A * (A + 1) / 2; if (A > maxA) maxA = A; }
+        c.part_slots = (uint32_t)(maxA < PG_AMAX ? maxA : PG_AMAX);
         c.n_lik = nl;
         plan[i].kept = take(c.V);
         plan[i].fback = take(c.V);
@@ -352,7 +353,7 @@ extern "C" pg_job* pg_job_create(int device, uint32_t n_contigs, const pg_contig
         p.cvar = take((size_t)c.V * 4);
         p.colrec = take((size_t)c.V * c.RB);
         p.fwd = take((size_t)c.V * c.HP * c.HP * sizeof(double));
-        p.part = take((size_t)c.V * PG_AMAX * c.T * sizeof(double));
+        p.part = take((size_t)c.V * c.part_slots * c.T * sizeof(double));
         p.fscale = take((size_t)c.V * sizeof(double));
         p.bscale = take((size_t)c.V * sizeof(double));
         p.bsum = take((size_t)c.V * sizeof(double));
@@ -381,7 +382,7 @@ extern "C" pg_job* pg_job_create(int device, uint32_t n_contigs, const pg_contig
         Plan& p = plan[i];
         DevContig& d = hd[i];
         memset(&d, 0, sizeof(d));
-        d.V = c.V; d.H = c.H; d.HP = c.HP; d.RB = c.RB; d.T = c.T;
+        d.V = c.V; d.H = c.H; d.HP = c.HP; d.RB = c.RB; d.T = c.T; d.part_slots = c.part_slots;
         d.dist_scale = (double)dist_scale; d.uniform = params->uniform ? 1 : 0;
         { const char* dbg = getenv("PG_DEBUG"); d.debug = dbg ? (uint32_t)strtoul(dbg, nullptr, 0) : 0u; }
         d.pos = (const uint64_t*)(A + p.pos); d.cov = (const uint16_t*)(A + p.cov);
