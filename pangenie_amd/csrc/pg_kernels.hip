@@ -26,6 +26,8 @@
 #include <math.h>
 #include <stdint.h>
 
+#include <type_traits>
+
 #include "pg_device.h"
 
 #define DEVI __device__ __forceinline__
@@ -501,7 +503,7 @@ struct ChainShared {
     double psum[2][Cfg::NRG][HP];
     double wsum[2][Cfg::NW];
     double u[Cfg::UNI ? Cfg::NW : 1][Cfg::UNI ? 64 : HP] __attribute__((aligned(16)));  // per-wave copy of the u vector
-    double pout[Cfg::LOADER ? 2 : 1][PG_AMAX][Cfg::LOADER ? Cfg::T : 1];                  // posterior partials of two columns
+    double pout[Cfg::LOADER ? 3 : 1][PG_AMAX][Cfg::LOADER ? Cfg::T : 1];                  // posterior partials, ring of three columns
 };
 
 // workgroup barrier that orders LDS traffic only (global stores/loads stay in flight)
@@ -549,6 +551,28 @@ DEVI FastE fast_setup(const unsigned char* rec, uint32_t j, uint32_t i0) {
     f.eB = aj ? E11 : E01;
     f.rowbits = rbits;
     return f;
+}
+
+// Everything a recursion step needs from a column record, decoded into registers one column
+// ahead of use so that the LDS latency of the record never sits on the chain.
+struct RecInfo {
+    double c0, c1, c2, kappa;
+    FastE fe;
+    uint32_t aj, nl;
+    bool fast;
+};
+template <bool UNI>
+DEVI RecInfo decode_record(const unsigned char* rec, uint32_t j, uint32_t i0, bool full) {
+    RecInfo r;
+    r.c0 = *(const double*)(rec + PG_REC_C0);
+    r.c1 = *(const double*)(rec + PG_REC_C1);
+    r.c2 = *(const double*)(rec + PG_REC_C2);
+    r.kappa = *(const double*)(rec + PG_REC_KAPPA);
+    r.nl = rec[PG_REC_NLOCAL];
+    r.fe = fast_setup<UNI>(rec, j, i0);
+    r.aj = col_allele(rec, j);
+    r.fast = full && r.nl <= 2;
+    return r;
 }
 
 // u_i for the thread's rows.  UNI: every wave holds the u vector of the 64-column block that
@@ -601,18 +625,16 @@ DEVI void write_sums(ChainShared<HP, R>& sh, uint32_t pb, const ThreadPos& p, do
 
 // posterior partials of column c: acc[a] = sum over my rows with local allele a of v*beta
 template <int HP, int R>
-DEVI void posterior(ChainShared<HP, R>& sh, gdouble* part_out, uint32_t part_slots, bool full, uint32_t c, const ThreadPos& p,
+DEVI void posterior(ChainShared<HP, R>& sh, gdouble* part_out, uint32_t part_slots, const RecInfo& ri, uint32_t c, const ThreadPos& p,
                     const double (&v)[R], const double (&beta)[R]) {
     using Cfg = ChainCfg<HP, R>;
-    const unsigned char* rec0 = sh.rec[c & 3u];
-    const uint32_t nl = rec0[PG_REC_NLOCAL];
+    const uint32_t nl = ri.nl;
     double acc[PG_AMAX];
 #pragma unroll
     for (int a = 0; a < PG_AMAX; ++a) acc[a] = 0.0;
-    if (full && nl <= 2) {
-        const unsigned long long* bits = (const unsigned long long*)(rec0 + PG_REC_BITS1);
-        uint32_t rbits = (uint32_t)(bits[p.i0 >> 6] >> (p.i0 & 63u));
-        if (Cfg::UNI) rbits = __builtin_amdgcn_readfirstlane(rbits);
+    if (ri.fast) {
+        // (re-assert wave-uniformity: the value may have travelled through loop-carried copies)
+        const uint32_t rbits = Cfg::UNI ? (uint32_t)__builtin_amdgcn_readfirstlane(ri.fe.rowbits) : ri.fe.rowbits;
 #pragma unroll
         for (int k = 0; k < R; ++k) {
             const double pr = v[k] * beta[k];
@@ -620,7 +642,7 @@ DEVI void posterior(ChainShared<HP, R>& sh, gdouble* part_out, uint32_t part_slo
             else acc[0] += pr;
         }
     } else {
-        const unsigned char* al = rec0 + PG_REC_ALLELES;
+        const unsigned char* al = sh.rec[c & 3u] + PG_REC_ALLELES;
 #pragma unroll
         for (int k = 0; k < R; ++k) {
             const uint32_t ai = al[p.i0 + k];
@@ -634,7 +656,7 @@ DEVI void posterior(ChainShared<HP, R>& sh, gdouble* part_out, uint32_t part_slo
     if constexpr (Cfg::LOADER) {
 #pragma unroll
         for (int a = 0; a < PG_AMAX; ++a)
-            if ((uint32_t)a < nl) sh.pout[c & 1u][a][p.tid] = acc[a];
+            if ((uint32_t)a < nl) sh.pout[c % 3u][a][p.tid] = acc[a];
     } else {
         gdouble* dst = part_out + (size_t)c * part_slots * Cfg::T + p.tid;
 #pragma unroll
@@ -652,7 +674,7 @@ DEVI void flush_partials(const ChainShared<HP, R>& sh, gdouble* part_out, uint32
     gdouble* dst = part_out + (size_t)c * part_slots * Cfg::T;
     for (uint32_t a = 0; a < nl; ++a)
         for (uint32_t t = lane; t < (uint32_t)Cfg::T; t += 64)
-            dst[(size_t)a * Cfg::T + t] = sh.pout[Cfg::LOADER ? ((uint32_t)c & 1u) : 0][a][Cfg::LOADER ? t : 0];
+            dst[(size_t)a * Cfg::T + t] = sh.pout[Cfg::LOADER ? ((uint32_t)c % 3u) : 0][a][Cfg::LOADER ? t : 0];
 }
 
 // ------------------------------------------------------------------------------------------
@@ -683,18 +705,20 @@ DEVI void forward_body(const DevContig& dc, ChainShared<HP, R>& sh, uint32_t C) 
         // ------------------------------- loader wave ---------------------------------
         if (lo == 0) rec_stage(0, rec_load(0));
         rec_stage(first, rec_load(first));
-        unsigned long long ta = rec_load(first + 1), tb = rec_load(first + 2);
+        rec_stage(first + 1, rec_load(first + 1));
+        unsigned long long ta = rec_load(first + 2), tb = rec_load(first + 3);
         lds_barrier();  // P0: first records staged
         lds_barrier();  // Bx: column lo initialised / resumed
         for (uint32_t t = first; t < hi; t += 2) {
-            rec_stage(t + 1, ta);  // loaded two columns ago
-            ta = rec_load(t + 3);
+            // (the partials of column t-2 live in the slot that record t+2 overwrites: flush first)
             if (PHASE == 2) flush_partials<HP, R>(sh, part_out, part_slots, (int64_t)t - 2, mid, C, p.lane);
+            rec_stage(t + 2, ta);  // loaded two columns ago, decoded by the compute waves at step t+1
+            ta = rec_load(t + 4);
             lds_barrier();  // B_t
             if (t + 1 < hi) {
-                rec_stage(t + 2, tb);
-                tb = rec_load(t + 4);
                 if (PHASE == 2) flush_partials<HP, R>(sh, part_out, part_slots, (int64_t)t - 1, mid, C, p.lane);
+                rec_stage(t + 3, tb);
+                tb = rec_load(t + 5);
                 lds_barrier();  // B_{t+1}
             }
         }
@@ -730,18 +754,27 @@ DEVI void forward_body(const DevContig& dc, ChainShared<HP, R>& sh, uint32_t C) 
         for (int k = 0; k < R; k += 2) { const v2f64 t = src[(size_t)(k >> 1) * HP]; v[k] = t.x; v[k + 1] = t.y; }
     };
 
-    constexpr int FB = R > 16 ? 1 : 2;  // beta' prefetch buffers (register budget at R = 32)
+    // beta' prefetch buffers: ONE column in flight is enough — the load is issued right after the
+    // posterior of step t and consumed by the posterior of step t+1, a whole step (> HBM latency)
+    // later; a second buffer costs 2R VGPRs and pushed the phase-2 kernel into scratch.
+    constexpr int FB = 1;
     double x[R], ui[R > 16 ? 1 : R];
-    double vA[PHASE == 2 ? R : 1], vB[(PHASE == 2 && FB == 2) ? R : 1];  // prefetched beta' columns (phase 2)
+    double vA[PHASE == 2 ? R : 1];  // prefetched beta' column (phase 2)
     double Cj = 0.0, Crow = 0.0, S = 0.0;
     unsigned long long tq = 0;  // inline loader (no loader wave): next record in flight
     if (!Cfg::LOADER && p.wave == 0) {
         if (lo == 0) rec_stage(0, rec_load(0));
         rec_stage(first, rec_load(first));
-        tq = rec_load(first + 1);
+        rec_stage(first + 1, rec_load(first + 1));
+        tq = rec_load(first + 2);
     }
-    if constexpr (PHASE == 2) { load_col(mid, vA); if constexpr (FB == 2) load_col(mid + 1, vB); }
+    if constexpr (PHASE == 2) load_col(mid, vA);
     lds_barrier();  // P0
+    // cur = record of the column the next step produces, prev = record of the column before it
+    RecInfo cur = decode_record<Cfg::UNI>(sh.rec[first & 3u], p.j, p.i0, full);
+    RecInfo prev = decode_record<Cfg::UNI>(sh.rec[(first - 1) & 3u], p.j, p.i0, full);
+    const bool prof = (dbg & 8u) != 0;
+    unsigned long long t_bar = 0, seg[5] = {0, 0, 0, 0, 0};
 
     if (lo == 0) {
         // column 0: v_0 = e_0 (reference src/hmm.cpp:236-238, previous_cell = 1)
@@ -752,6 +785,10 @@ DEVI void forward_body(const DevContig& dc, ChainShared<HP, R>& sh, uint32_t C) 
         if (PHASE == 1) store_col(0, x);
         if (p.tid == 0) fscale[0] = 1.0;
         write_sums<HP, R>(sh, 0, p, part);
+        if constexpr (PHASE == 2) {  // lo == 0 in phase 2 <=> mid == 0 <=> C == 1
+            posterior<HP, R>(sh, part_out, part_slots, prev, 0, p, x, vA);
+            load_col(1, vA);
+        }
     } else {
         // resume behind the column the other phase stored last
         load_col(lo - 1, x);
@@ -779,29 +816,19 @@ DEVI void forward_body(const DevContig& dc, ChainShared<HP, R>& sh, uint32_t C) 
     };
 
     auto step = [&](uint32_t t, double (&vb)[PHASE == 2 ? R : 1]) {
-        // everything that depends only on the staged record is issued first so that its LDS
-        // latency overlaps the column-sum exchange
+        // decode the NEXT column's record now; it is consumed one step later, so its LDS latency
+        // overlaps this step's work
+        unsigned long long g0 = prof ? __builtin_amdgcn_s_memtime() : 0, g1;
+        const RecInfo nxt = decode_record<Cfg::UNI>(sh.rec[(t + 1) & 3u], p.j, p.i0, full);
         const unsigned char* rec = sh.rec[t & 3u];
-        const bool fast = full && rec[PG_REC_NLOCAL] <= 2;
-        FastE fe;
-        uint32_t aj = 0;
-        if (fast) fe = fast_setup<Cfg::UNI>(rec, p.j, p.i0);
-        else aj = col_allele(rec, p.j);
         finalize(t - 1);
-        if constexpr (PHASE == 2) {
-            if (t - 1 >= mid) {
-                posterior<HP, R>(sh, part_out, part_slots, full, t - 1, p, x, vb);
-                load_col(t - 1 + FB, vb);
-            }
-        }
-        const double c0 = *(const double*)(rec + PG_REC_C0);
-        const double c1 = *(const double*)(rec + PG_REC_C1);
-        const double c2 = *(const double*)(rec + PG_REC_C2);
+        if (prof) { asm volatile("" : "+v"(S)); __builtin_amdgcn_sched_barrier(0); g1 = __builtin_amdgcn_s_memtime(); seg[0] += g1 - g0; g0 = g1; }
+
         // alpha_hat_{t-1} = x / S.  Scale by 2^-es instead of dividing: the new column is
         // (true v_t) * m with m = S * 2^-es in [0.5,1); m goes to the side array.
         const int es = exponent_of(S);
         const double m = ldexp(S, -es);
-        const double k0 = ldexp(c0, -es), k1 = ldexp(c1, -es), hk2 = 0.5 * c2 * m;
+        const double k0 = ldexp(cur.c0, -es), k1 = ldexp(cur.c1, -es), hk2 = 0.5 * cur.c2 * m;
         if (p.tid == 0) fscale[t] = m;
         const double uj = fma(k1, Cj, hk2);
         const double urow = fma(k1, Crow, hk2);
@@ -810,46 +837,69 @@ DEVI void forward_body(const DevContig& dc, ChainShared<HP, R>& sh, uint32_t C) 
             lds_wave_sync();
         }
         if constexpr (R <= 16) row_values<R, Cfg::UNI>(sh.u[Cfg::UNI ? p.wave : 0], urow, p.lane, p.i0, ui);
+        if (prof) { __builtin_amdgcn_s_waitcnt(0xc07f); __builtin_amdgcn_sched_barrier(0); g1 = __builtin_amdgcn_s_memtime(); seg[2] += g1 - g0; g0 = g1; }
         double part = 0.0;
+        const bool fast = cur.fast;
+        FastE fe = cur.fe;
+        if (Cfg::UNI) fe.rowbits = __builtin_amdgcn_readfirstlane(fe.rowbits);
+        const uint32_t aj = cur.aj;
+        // two straight-line loops (a per-state branch on `fast` would split the unrolled body into
+        // tiny basic blocks and serialise it)
+        if (fast) {
 #pragma unroll
-        for (int k = 0; k < R; ++k) {
-            double uik;
-            if constexpr (R <= 16) uik = ui[k];
-            else uik = readlane_f64(urow, __builtin_amdgcn_readfirstlane((int)((p.i0 + k) & 63u)));
-            const double e = fast ? (((fe.rowbits >> k) & 1u) ? fe.eB : fe.eA) : emission_at(rec, p.i0 + k, aj);
-            x[k] = fma(k0, x[k], uik + uj) * e;
-            part += x[k];
-            if constexpr (R > 16) { if ((k & 7) == 7) __builtin_amdgcn_sched_barrier(0); }
+            for (int k = 0; k < R; ++k) {
+                double uik;
+                if constexpr (R <= 16) uik = ui[k];
+                else uik = readlane_f64(urow, __builtin_amdgcn_readfirstlane((int)((p.i0 + k) & 63u)));
+                const double e = ((fe.rowbits >> k) & 1u) ? fe.eB : fe.eA;
+                x[k] = fma(k0, x[k], uik + uj) * e;
+                part += x[k];
+                if constexpr (R > 16) { if ((k & 7) == 7) __builtin_amdgcn_sched_barrier(0); }
+            }
+        } else {
+#pragma unroll
+            for (int k = 0; k < R; ++k) {
+                double uik;
+                if constexpr (R <= 16) uik = ui[k];
+                else uik = readlane_f64(urow, __builtin_amdgcn_readfirstlane((int)((p.i0 + k) & 63u)));
+                x[k] = fma(k0, x[k], uik + uj) * emission_at(rec, p.i0 + k, aj);
+                part += x[k];
+                if constexpr (R > 16) { if ((k & 7) == 7) __builtin_amdgcn_sched_barrier(0); }
+            }
         }
         if (PHASE == 1) store_col(t, x);
+        if (prof) { asm volatile("" : "+v"(part)); __builtin_amdgcn_sched_barrier(0); g1 = __builtin_amdgcn_s_memtime(); seg[3] += g1 - g0; g0 = g1; }
         write_sums<HP, R>(sh, t & 1u, p, part);
+        if (prof) { __builtin_amdgcn_s_waitcnt(0xc07f); __builtin_amdgcn_sched_barrier(0); g1 = __builtin_amdgcn_s_memtime(); seg[4] += g1 - g0; g0 = g1; }
+        if constexpr (PHASE == 2) {
+            // posterior of the column just formed (optimistic: if the column turns out to sum to
+            // zero, finalize() flags it one step later and k_bins re-forms its bins from the
+            // uniform column), then prefetch the next beta' column: a whole step ahead of its use
+            // and AFTER the last read of x, so no vmcnt wait lands inside the recursion
+            posterior<HP, R>(sh, part_out, part_slots, cur, t, p, x, vb);
+            load_col(t + 1, vb);
+            if (prof) { __builtin_amdgcn_s_waitcnt(0xc07f); __builtin_amdgcn_sched_barrier(0); g1 = __builtin_amdgcn_s_memtime(); seg[1] += g1 - g0; g0 = g1; }
+        }
         if (!Cfg::LOADER && p.wave == 0) {
-            rec_stage(t + 1, tq);  // loaded one column ago
-            tq = rec_load(t + 2);
+            rec_stage(t + 2, tq);  // loaded one column ago
+            tq = rec_load(t + 3);
         }
-        lds_barrier();  // B_t
+        prev = cur;
+        cur = nxt;
+        if (prof) { __builtin_amdgcn_s_waitcnt(0xc07f); const unsigned long long b0 = __builtin_amdgcn_s_memtime(); lds_barrier(); t_bar += __builtin_amdgcn_s_memtime() - b0; }
+        else lds_barrier();  // B_t
     };
+    const unsigned long long t_begin = prof ? __builtin_amdgcn_s_memtime() : 0;
 
-    // the posterior of column q uses buffer (q - mid) & 1; the first step handles q = first-1
-    if constexpr (PHASE == 2 && FB == 2) {
-        if (lo == 0) {  // first = 1, q = 0 = mid  -> vA first
-            for (uint32_t t = first; t < hi; t += 2) { step(t, vA); if (t + 1 < hi) step(t + 1, vB); }
-        } else {        // first = mid, q = mid-1 (not ours) -> vB is the dummy, then vA, vB, ...
-            for (uint32_t t = first; t < hi; t += 2) { step(t, vB); if (t + 1 < hi) step(t + 1, vA); }
-        }
-    } else {
-        for (uint32_t t = first; t < hi; ++t) step(t, vA);
+    for (uint32_t t = first; t < hi; ++t) step(t, vA);
+    if (prof && p.tid == 0) {
+        unsigned long long* o = dc.prof + (PHASE == 1 ? 0 : 8);
+        o[0] = __builtin_amdgcn_s_memtime() - t_begin; o[1] = t_bar; o[2] = hi - first;
+        unsigned long long* q = dc.prof + (PHASE == 1 ? 32 : 40);
+        for (int i = 0; i < 5; ++i) q[i] = seg[i];
     }
     finalize(hi - 1);
-    if constexpr (PHASE == 2) {
-        if constexpr (FB == 2) {
-            if (((hi - 1 - mid) & 1u) == 0) posterior<HP, R>(sh, part_out, part_slots, full, hi - 1, p, x, vA);
-            else posterior<HP, R>(sh, part_out, part_slots, full, hi - 1, p, x, vB);
-        } else {
-            posterior<HP, R>(sh, part_out, part_slots, full, hi - 1, p, x, vA);
-        }
-        lds_barrier();  // F: the last partials are in LDS
-    }
+    if constexpr (PHASE == 2) lds_barrier();  // F: the last partials are in LDS
 }
 
 // ------------------------------------------------------------------------------------------
@@ -888,17 +938,19 @@ DEVI void backward_body(const DevContig& dc, ChainShared<HP, R>& sh, uint32_t C)
         // record t (alleles for the posterior)
         rec_stage(t0 + 1, rec_load(t0 + 1));
         rec_stage(t0, rec_load(t0));
-        unsigned long long ta = rec_load(t0 - 1), tb = rec_load(t0 - 2);
+        rec_stage(t0 - 1, rec_load(t0 - 1));
+        unsigned long long ta = rec_load(t0 - 2), tb = rec_load(t0 - 3);
         lds_barrier();  // P0
         for (int64_t t = t0; t >= bot; t -= 2) {
-            rec_stage(t - 1, ta);
-            ta = rec_load(t - 3);
+            // (the partials of column t+2 live in the slot that record t-2 overwrites: flush first)
             if (PHASE == 2) flush_partials<HP, R>(sh, part_out, part_slots, t + 2, 0, mid, p.lane);
+            rec_stage(t - 2, ta);  // decoded by the compute waves at step t-2... staged two steps ahead
+            ta = rec_load(t - 4);
             lds_barrier();  // B_t
             if (t - 1 >= bot) {
-                rec_stage(t - 2, tb);
-                tb = rec_load(t - 4);
                 if (PHASE == 2) flush_partials<HP, R>(sh, part_out, part_slots, t + 1, 0, mid, p.lane);
+                rec_stage(t - 3, tb);
+                tb = rec_load(t - 5);
                 lds_barrier();  // B_{t-1}
             }
         }
@@ -939,7 +991,8 @@ DEVI void backward_body(const DevContig& dc, ChainShared<HP, R>& sh, uint32_t C)
     if (!Cfg::LOADER && p.wave == 0) {
         rec_stage(t0 + 1, rec_load(t0 + 1));
         rec_stage(t0, rec_load(t0));
-        tq = rec_load(t0 - 1);
+        rec_stage(t0 - 1, rec_load(t0 - 1));
+        tq = rec_load(t0 - 2);
     }
     if constexpr (PHASE == 1) {
         // column C-1: beta~ = 1 (reference src/hmm.cpp:356-358); sum = H^2
@@ -956,6 +1009,10 @@ DEVI void backward_body(const DevContig& dc, ChainShared<HP, R>& sh, uint32_t C)
         if constexpr (VBUF == 2) load_col(top - 1, vB);
     }
     lds_barrier();  // P0
+    RecInfo cur = decode_record<Cfg::UNI>(sh.rec[(uint32_t)(t0 + 1) & 3u], p.j, p.i0, full);
+    const bool prof = (dc.debug & 8u) != 0;
+    unsigned long long t_bar = 0;
+    const unsigned long long t_begin = prof ? __builtin_amdgcn_s_memtime() : 0;
 
     auto step = [&](int64_t t, double (&v)[NV]) {
         // beta_hat_{t+1} = y / Sy, uniform if the sum is zero (hmm.cpp:374-380)
@@ -964,20 +1021,19 @@ DEVI void backward_body(const DevContig& dc, ChainShared<HP, R>& sh, uint32_t C)
             for (int k = 0; k < R; ++k) y[k] = (p.j < H && p.i0 + k < H) ? unif : 0.0;
             Sy = 1.0;
         }
+        // decode record t now (posterior of this column, emission of the next step); the record of
+        // column t+1 was decoded one step ago
+        const RecInfo nxt = decode_record<Cfg::UNI>(sh.rec[(uint32_t)t & 3u], p.j, p.i0, full);
         const unsigned char* rec1 = sh.rec[(uint32_t)(t + 1) & 3u];
-        const double c0 = *(const double*)(rec1 + PG_REC_C0);
-        const double c1 = *(const double*)(rec1 + PG_REC_C1);
-        const double c2 = *(const double*)(rec1 + PG_REC_C2);
-        const double kappa = *(const double*)(rec1 + PG_REC_KAPPA);
+        const double c0 = cur.c0, c1 = cur.c1, c2 = cur.c2, kappa = cur.kappa;
         // beta~_t(true) = A (y/Sy . e) A^T; scaled by 2^-es: beta' = beta~ * m, m = Sy*2^-es
         const int es = exponent_of(Sy);
         const double m = ldexp(Sy, -es);
         if (p.tid == 0) bscale[t] = m;
-        const bool fast = full && rec1[PG_REC_NLOCAL] <= 2;
-        FastE fe;
-        uint32_t aj1 = 0;
-        if (fast) fe = fast_setup<Cfg::UNI>(rec1, p.j, p.i0);
-        else aj1 = col_allele(rec1, p.j);
+        const bool fast = cur.fast;
+        FastE fe = cur.fe;
+        if (Cfg::UNI) fe.rowbits = __builtin_amdgcn_readfirstlane(fe.rowbits);
+        const uint32_t aj1 = cur.aj;
         double w[KEEPW ? R : 1];
         double part = 0.0;
         if (fast) {
@@ -999,10 +1055,11 @@ DEVI void backward_body(const DevContig& dc, ChainShared<HP, R>& sh, uint32_t C)
         const uint32_t pb = (uint32_t)t & 1u;
         write_sums<HP, R>(sh, pb, p, part);
         if (!Cfg::LOADER && p.wave == 0) {
-            rec_stage(t - 1, tq);  // loaded one column ago
-            tq = rec_load(t - 2);
+            rec_stage(t - 2, tq);  // loaded one column ago
+            tq = rec_load(t - 3);
         }
-        lds_barrier();  // B_t
+        if (prof) { __builtin_amdgcn_s_waitcnt(0xc07f); const unsigned long long b0 = __builtin_amdgcn_s_memtime(); lds_barrier(); t_bar += __builtin_amdgcn_s_memtime() - b0; }
+        else lds_barrier();  // B_t
         double Cj, Crow, Sw;
         read_sums<HP, R>(sh, pb, p, Cj, Crow, Sw);
         const double k0 = ldexp(c0, -es), k1 = ldexp(c1, -es), hk2 = 0.5 * ldexp(c2 * Sw, -es);
@@ -1015,25 +1072,31 @@ DEVI void backward_body(const DevContig& dc, ChainShared<HP, R>& sh, uint32_t C)
         }
         double ui[R > 16 ? 1 : R];
         if constexpr (R <= 16) row_values<R, Cfg::UNI>(sh.u[Cfg::UNI ? p.wave : 0], urow, p.lane, p.i0, ui);
+        auto beta_loop = [&](auto fast_c) {
 #pragma unroll
-        for (int k = 0; k < R; ++k) {
-            double wk;
-            if constexpr (KEEPW) wk = w[k];
-            else wk = y[k] * (fast ? (((fe.rowbits >> k) & 1u) ? fe.eB : fe.eA) : emission_at(rec1, p.i0 + k, aj1));
-            double uik;
-            if constexpr (R <= 16) uik = ui[k];
-            else uik = readlane_f64(urow, __builtin_amdgcn_readfirstlane((int)((p.i0 + k) & 63u)));
-            y[k] = fma(k0, wk, uik + uj);  // beta'_t
-            if constexpr (R > 16) { if ((k & 7) == 7) __builtin_amdgcn_sched_barrier(0); }
-        }
+            for (int k = 0; k < R; ++k) {
+                double wk;
+                if constexpr (KEEPW) wk = w[k];
+                else if constexpr (decltype(fast_c)::value) wk = y[k] * (((fe.rowbits >> k) & 1u) ? fe.eB : fe.eA);
+                else wk = y[k] * emission_at(rec1, p.i0 + k, aj1);
+                double uik;
+                if constexpr (R <= 16) uik = ui[k];
+                else uik = readlane_f64(urow, __builtin_amdgcn_readfirstlane((int)((p.i0 + k) & 63u)));
+                y[k] = fma(k0, wk, uik + uj);  // beta'_t
+                if constexpr (R > 16) { if ((k & 7) == 7) __builtin_amdgcn_sched_barrier(0); }
+            }
+        };
+        if (KEEPW || fast) beta_loop(std::true_type{});
+        else beta_loop(std::false_type{});
         Sy = ldexp(kappa * Sw, -es);  // = sum(beta'_t) over real states
         if constexpr (PHASE == 1) {
             store_col(t, y);
             if (p.tid == 0) bsum[t] = Sy;
         } else {
-            posterior<HP, R>(sh, part_out, part_slots, full, (uint32_t)t, p, v, y);
+            posterior<HP, R>(sh, part_out, part_slots, nxt, (uint32_t)t, p, v, y);
             load_col(t - VBUF, v);
         }
+        cur = nxt;
     };
 
     for (int64_t t = t0; t >= bot; t -= 2) {
@@ -1044,6 +1107,10 @@ DEVI void backward_body(const DevContig& dc, ChainShared<HP, R>& sh, uint32_t C)
             step(t, vA);
             if (t - 1 >= bot) step(t - 1, vA);
         }
+    }
+    if (prof && p.tid == 0) {
+        unsigned long long* o = dc.prof + (PHASE == 1 ? 16 : 24);
+        o[0] = __builtin_amdgcn_s_memtime() - t_begin; o[1] = t_bar; o[2] = (unsigned long long)(t0 - bot + 1);
     }
     if constexpr (PHASE == 2) lds_barrier();  // F: the last partials are in LDS
 }
@@ -1083,6 +1150,29 @@ __global__ __launch_bounds__(256) void k_bins(const DevContig* __restrict__ cont
     const unsigned char* al = rec + PG_REC_ALLELES;
     if (lane < PG_AMAX * (PG_AMAX + 1) / 2) s_bins[wave][lane] = 0.0;
     wave_sync();
+    const bool fb = dc.fwd_fallback[c] != 0;
+    if (fb && c >= C / 2) {
+        // The forward column of c fell back to uniform (alpha_hat*fsum = 1/H^2 for every real
+        // state, reference src/hmm.cpp:259-266) AFTER the forward half-chain had already formed
+        // this column's partials from the all-zero column: re-form the bins from the stored
+        // backward column beta'_c (slot c, row-pair layout).  Rare path.
+        const uint32_t H = dc.H;
+        const double unif = 1.0 / ((double)H * (double)H);
+        const double* col = dc.fwd + (size_t)c * HP * HP;
+        for (uint32_t a = 0; a < nl; ++a)
+            for (uint32_t b = 0; b < nl; ++b) {
+                double s = 0.0;
+                for (uint32_t st = lane; st < H * H; st += 64) {
+                    const uint32_t i = st / H, jj = st % H;
+                    if (al[i] == a && al[jj] == b) s += col[((size_t)(i >> 1) * HP + jj) * 2 + (i & 1u)];
+                }
+                const double tot = wave_sum(s) * unif;
+                if (lane == 0) {
+                    const uint32_t lo2 = a < b ? a : b, hi2 = a < b ? b : a;
+                    s_bins[wave][tri_local(lo2, hi2)] += tot;
+                }
+            }
+    } else
     for (uint32_t a = 0; a < nl; ++a) {
         const double* src = dc.part + ((size_t)c * dc.part_slots + a) * T;
         for (uint32_t b = 0; b < nl; ++b) {
@@ -1101,7 +1191,6 @@ __global__ __launch_bounds__(256) void k_bins(const DevContig* __restrict__ cont
     const uint16_t* ls = (const uint16_t*)(rec + PG_REC_LOCAL_SLOT);
     // stored columns are (true value) * m: alpha_hat*fsum = fwd / fscale[c] (unless the forward
     // column fell back to uniform), beta~ = bwd / bscale[c]
-    const bool fb = dc.fwd_fallback[c] != 0;
     const double scale = 1.0 / ((fb ? 1.0 : dc.fscale[c]) * dc.bscale[c]);
     if (lane < nl * nl) {
         const uint32_t la = lane / nl, lb = lane % nl;
@@ -1125,9 +1214,9 @@ __global__ __launch_bounds__(256) void k_bins(const DevContig* __restrict__ cont
 template <int PHASE>
 static void launch_sweep(const DevContig* d_contigs, uint32_t n_contigs, uint32_t hp_mask, hipStream_t s) {
     const dim3 grid(n_contigs, 2);
-    if (hp_mask & 1u) hipLaunchKernelGGL((k_sweep<16, 4, 2, true, PHASE>), grid, dim3(ChainCfg<16, 4>::TT), 0, s, d_contigs);
-    if (hp_mask & 2u) hipLaunchKernelGGL((k_sweep<32, 16, 2, true, PHASE>), grid, dim3(ChainCfg<32, 16>::TT), 0, s, d_contigs);
-    if (hp_mask & 4u) hipLaunchKernelGGL((k_sweep<64, 16, 2, true, PHASE>), grid, dim3(ChainCfg<64, 16>::TT), 0, s, d_contigs);
+    if (hp_mask & 1u) hipLaunchKernelGGL((k_sweep<16, 4, 1, true, PHASE>), grid, dim3(ChainCfg<16, 4>::TT), 0, s, d_contigs);
+    if (hp_mask & 2u) hipLaunchKernelGGL((k_sweep<32, 16, 1, true, PHASE>), grid, dim3(ChainCfg<32, 16>::TT), 0, s, d_contigs);
+    if (hp_mask & 4u) hipLaunchKernelGGL((k_sweep<64, 16, 1, true, PHASE>), grid, dim3(ChainCfg<64, 16>::TT), 0, s, d_contigs);
     if (hp_mask & 8u) hipLaunchKernelGGL((k_sweep<128, 32, 1, false, PHASE>), grid, dim3(ChainCfg<128, 32>::TT), 0, s, d_contigs);
 }
 
