@@ -499,11 +499,10 @@ struct ChainCfg {
 template <int HP, int R>
 struct ChainShared {
     using Cfg = ChainCfg<HP, R>;
-    unsigned char rec[4][Cfg::RB] __attribute__((aligned(16)));
+    unsigned char rec[8][Cfg::RB] __attribute__((aligned(16)));  // ring of 8 column records
     double psum[2][Cfg::NRG][HP];
     double wsum[2][Cfg::NW];
     double u[Cfg::UNI ? Cfg::NW : 1][Cfg::UNI ? 64 : HP] __attribute__((aligned(16)));  // per-wave copy of the u vector
-    double pout[Cfg::LOADER ? 3 : 1][PG_AMAX][Cfg::LOADER ? Cfg::T : 1];                  // posterior partials, ring of three columns
 };
 
 // workgroup barrier that orders LDS traffic only (global stores/loads stay in flight)
@@ -593,6 +592,43 @@ DEVI void row_values(double* lds_u /* this wave's row */, double urow, uint32_t 
     }
 }
 
+// Phase-2 partner columns reach the compute waves through an LDS ring filled by the loader wave
+// with LDS-DMA (global_load_lds_dwordx4: HBM -> LDS, no VGPRs), two columns ahead of use.
+#define LAS __attribute__((address_space(3)))
+template <int HP>
+DEVI void dma_column(const gdouble* cols, int64_t c, int64_t C, LAS unsigned char* ring, uint32_t lane) {
+    if (c < 0 || c >= C) return;
+    constexpr uint32_t COLB = HP * HP * 8u;
+    const GAS char* g = (const GAS char*)(cols + (size_t)c * HP * HP) + lane * 16u;
+    LAS unsigned char* l = ring + (uint32_t)(c % 3) * COLB;  // wave-uniform base; lane l lands at +16*l
+#pragma unroll 4
+    for (uint32_t q = 0; q < COLB / 1024u; ++q)
+        __builtin_amdgcn_global_load_lds((const GAS void*)(g + q * 1024u), (LAS void*)(l + q * 1024u), 16, 0, 0);
+}
+// column record -> its LDS slot by DMA as well (lanes < RB/16 move 16 B each): the loader wave then
+// has no register-returning loads at all and every completion is an explicit counted vmcnt
+template <int RB>
+DEVI void dma_record(gcu64* colrec, int64_t c, int64_t C, LAS unsigned char* slots, uint32_t lane) {
+    if (c < 0 || c >= C) return;
+    if (lane < (uint32_t)(RB / 16)) {
+        const GAS char* g = (const GAS char*)colrec + (size_t)c * RB + lane * 16u;
+        __builtin_amdgcn_global_load_lds((const GAS void*)g, (LAS void*)(slots + (uint32_t)(c & 7) * RB), 16, 0, 0);
+    }
+}
+DEVI void wait_vmem_all() { __builtin_amdgcn_s_waitcnt(0x0F70); }  // vmcnt(0) only
+// wait until at most N vector-memory operations are outstanding (loads complete in order)
+template <int N>
+DEVI void wait_vmem_keep() {
+    static_assert(N >= 0 && N < 64, "vmcnt is 6 bits");
+    __builtin_amdgcn_s_waitcnt((N & 0xF) | ((N >> 4) << 14) | 0x0F70);
+}
+template <int HP, int R>
+DEVI void ring_read(const unsigned char* ring, int64_t c, const uint32_t i0, const uint32_t j, double (&v)[R]) {
+    const v2f64* slot = (const v2f64*)(ring + (size_t)(c % 3) * (HP * HP * 8u)) + (size_t)(i0 >> 1) * HP + j;
+#pragma unroll
+    for (int k = 0; k < R; k += 2) { const v2f64 t = slot[(size_t)(k >> 1) * HP]; v[k] = t.x; v[k + 1] = t.y; }
+}
+
 // per-thread coordinates of a compute thread
 struct ThreadPos {
     uint32_t tid, lane, wave, j, rg, i0, rb;
@@ -642,7 +678,7 @@ DEVI void posterior(ChainShared<HP, R>& sh, gdouble* part_out, uint32_t part_slo
             else acc[0] += pr;
         }
     } else {
-        const unsigned char* al = sh.rec[c & 3u] + PG_REC_ALLELES;
+        const unsigned char* al = sh.rec[c & 7u] + PG_REC_ALLELES;
 #pragma unroll
         for (int k = 0; k < R; ++k) {
             const uint32_t ai = al[p.i0 + k];
@@ -653,35 +689,20 @@ DEVI void posterior(ChainShared<HP, R>& sh, gdouble* part_out, uint32_t part_slo
             if constexpr (R > 16) { if ((k & 7) == 7) __builtin_amdgcn_sched_barrier(0); }
         }
     }
-    if constexpr (Cfg::LOADER) {
+    // phase-2 compute waves have no loads in flight (partner columns arrive through the LDS ring),
+    // so these stores never make them wait
+    gdouble* dst = part_out + (size_t)c * part_slots * Cfg::T + p.tid;
 #pragma unroll
-        for (int a = 0; a < PG_AMAX; ++a)
-            if ((uint32_t)a < nl) sh.pout[c % 3u][a][p.tid] = acc[a];
-    } else {
-        gdouble* dst = part_out + (size_t)c * part_slots * Cfg::T + p.tid;
-#pragma unroll
-        for (int a = 0; a < PG_AMAX; ++a)
-            if ((uint32_t)a < nl) dst[(size_t)a * Cfg::T] = acc[a];
-    }
-}
-
-// loader: drain the posterior partials of column c (LDS -> HBM)
-template <int HP, int R>
-DEVI void flush_partials(const ChainShared<HP, R>& sh, gdouble* part_out, uint32_t part_slots, int64_t c, int64_t lo, int64_t hi, uint32_t lane) {
-    using Cfg = ChainCfg<HP, R>;
-    if (c < lo || c >= hi) return;
-    const uint32_t nl = sh.rec[(uint32_t)c & 3u][PG_REC_NLOCAL];
-    gdouble* dst = part_out + (size_t)c * part_slots * Cfg::T;
-    for (uint32_t a = 0; a < nl; ++a)
-        for (uint32_t t = lane; t < (uint32_t)Cfg::T; t += 64)
-            dst[(size_t)a * Cfg::T + t] = sh.pout[Cfg::LOADER ? ((uint32_t)c % 3u) : 0][a][Cfg::LOADER ? t : 0];
+    for (int a = 0; a < PG_AMAX; ++a)
+        if ((uint32_t)a < nl) dst[(size_t)a * Cfg::T] = acc[a];
 }
 
 // ------------------------------------------------------------------------------------------
 //  forward half-chain   (reference src/hmm.cpp:76-90, 175-273)
 // ------------------------------------------------------------------------------------------
 template <int HP, int R, int PHASE>
-DEVI void forward_body(const DevContig& dc, ChainShared<HP, R>& sh, uint32_t C) {
+DEVI void forward_body(const DevContig& dc, ChainShared<HP, R>& sh, uint32_t C, unsigned char* ring) {
+    constexpr bool RING = ChainCfg<HP, R>::LOADER && PHASE == 2;  // partner columns via the LDS ring
     using Cfg = ChainCfg<HP, R>;
     const uint32_t mid = C / 2;
     const uint32_t lo = PHASE == 1 ? 0u : mid, hi = PHASE == 1 ? mid : C;
@@ -699,34 +720,39 @@ DEVI void forward_body(const DevContig& dc, ChainShared<HP, R>& sh, uint32_t C) 
         return 0ull;
     };
     auto rec_stage = [&](uint32_t c, unsigned long long w) {
-        if (p.lane < (uint32_t)Cfg::WORDS) ((unsigned long long*)sh.rec[c & 3u])[p.lane] = w;
+        if (p.lane < (uint32_t)Cfg::WORDS) ((unsigned long long*)sh.rec[c & 7u])[p.lane] = w;
     };
     if (Cfg::LOADER && p.wave == (uint32_t)Cfg::NW) {
         // ------------------------------- loader wave ---------------------------------
-        if (lo == 0) rec_stage(0, rec_load(0));
-        rec_stage(first, rec_load(first));
-        rec_stage(first + 1, rec_load(first + 1));
-        unsigned long long ta = rec_load(first + 2), tb = rec_load(first + 3);
+        LAS unsigned char* lring = (LAS unsigned char*)ring;
+        LAS unsigned char* lrec = (LAS unsigned char*)&sh.rec[0][0];
+        const gdouble* cols = (const gdouble*)dc.fwd;
+        // prologue: records of the first columns (+ beta' of the first two columns in phase 2)
+        if (lo == 0) dma_record<Cfg::RB>(colrec, 0, C, lrec, p.lane);
+        dma_record<Cfg::RB>(colrec, first, C, lrec, p.lane);
+        dma_record<Cfg::RB>(colrec, (int64_t)first + 1, C, lrec, p.lane);
+        dma_record<Cfg::RB>(colrec, (int64_t)first + 2, C, lrec, p.lane);
+        if (RING) {
+            dma_column<HP>(cols, (int64_t)lo, C, lring, p.lane);
+            dma_column<HP>(cols, (int64_t)lo + 1, C, lring, p.lane);
+        }
+        wait_vmem_all();
         lds_barrier();  // P0: first records staged
         lds_barrier();  // Bx: column lo initialised / resumed
-        for (uint32_t t = first; t < hi; t += 2) {
-            // (the partials of column t-2 live in the slot that record t+2 overwrites: flush first)
-            if (PHASE == 2) flush_partials<HP, R>(sh, part_out, part_slots, (int64_t)t - 2, mid, C, p.lane);
-            rec_stage(t + 2, ta);  // loaded two columns ago, decoded by the compute waves at step t+1
-            ta = rec_load(t + 4);
+        // One loader iteration per recursion step t.  It only ISSUES DMA (record t+3, decoded by the
+        // compute waves at step t+2; column t+2, consumed at the end of step t+2) and then waits
+        // for what the PREVIOUS iteration issued: loads complete in order, so "at most NISSUE
+        // outstanding" == "everything older than this iteration has landed".  Every transfer thus
+        // has a full step to complete before the barrier that publishes it.
+        constexpr int NISSUE = 1 + (RING ? (HP * HP * 8) / 1024 : 0);
+        for (uint32_t t = first; t < hi; ++t) {
+            dma_record<Cfg::RB>(colrec, (int64_t)t + 3, C, lrec, p.lane);
+            if (RING) dma_column<HP>(cols, (int64_t)t + 2, C, lring, p.lane);
+            if ((int64_t)t + 3 < (int64_t)C) wait_vmem_keep<NISSUE>();
+            else wait_vmem_all();  // tail: fewer transfers were issued, drain instead of counting
             lds_barrier();  // B_t
-            if (t + 1 < hi) {
-                if (PHASE == 2) flush_partials<HP, R>(sh, part_out, part_slots, (int64_t)t - 1, mid, C, p.lane);
-                rec_stage(t + 3, tb);
-                tb = rec_load(t + 5);
-                lds_barrier();  // B_{t+1}
-            }
         }
-        if (PHASE == 2) {
-            flush_partials<HP, R>(sh, part_out, part_slots, (int64_t)hi - 2, mid, C, p.lane);
-            lds_barrier();  // F
-            flush_partials<HP, R>(sh, part_out, part_slots, (int64_t)hi - 1, mid, C, p.lane);
-        }
+        if (PHASE == 2) lds_barrier();  // F
         return;
     }
 
@@ -759,7 +785,7 @@ DEVI void forward_body(const DevContig& dc, ChainShared<HP, R>& sh, uint32_t C) 
     // later; a second buffer costs 2R VGPRs and pushed the phase-2 kernel into scratch.
     constexpr int FB = 1;
     double x[R], ui[R > 16 ? 1 : R];
-    double vA[PHASE == 2 ? R : 1];  // prefetched beta' column (phase 2)
+    double vA[(PHASE == 2 && !RING) ? R : 1];  // register-prefetched beta' column (phase 2 without the LDS ring)
     double Cj = 0.0, Crow = 0.0, S = 0.0;
     unsigned long long tq = 0;  // inline loader (no loader wave): next record in flight
     if (!Cfg::LOADER && p.wave == 0) {
@@ -768,11 +794,11 @@ DEVI void forward_body(const DevContig& dc, ChainShared<HP, R>& sh, uint32_t C) 
         rec_stage(first + 1, rec_load(first + 1));
         tq = rec_load(first + 2);
     }
-    if constexpr (PHASE == 2) load_col(mid, vA);
+    if constexpr (PHASE == 2 && !RING) load_col(mid, vA);
     lds_barrier();  // P0
     // cur = record of the column the next step produces, prev = record of the column before it
-    RecInfo cur = decode_record<Cfg::UNI>(sh.rec[first & 3u], p.j, p.i0, full);
-    RecInfo prev = decode_record<Cfg::UNI>(sh.rec[(first - 1) & 3u], p.j, p.i0, full);
+    RecInfo cur = decode_record<Cfg::UNI>(sh.rec[first & 7u], p.j, p.i0, full);
+    RecInfo prev = decode_record<Cfg::UNI>(sh.rec[(first - 1) & 7u], p.j, p.i0, full);
     const bool prof = (dbg & 8u) != 0;
     unsigned long long t_bar = 0, seg[5] = {0, 0, 0, 0, 0};
 
@@ -786,8 +812,14 @@ DEVI void forward_body(const DevContig& dc, ChainShared<HP, R>& sh, uint32_t C) 
         if (p.tid == 0) fscale[0] = 1.0;
         write_sums<HP, R>(sh, 0, p, part);
         if constexpr (PHASE == 2) {  // lo == 0 in phase 2 <=> mid == 0 <=> C == 1
-            posterior<HP, R>(sh, part_out, part_slots, prev, 0, p, x, vA);
-            load_col(1, vA);
+            if constexpr (RING) {
+                double bt[R];
+                ring_read<HP, R>(ring, 0, p.i0, p.j, bt);
+                posterior<HP, R>(sh, part_out, part_slots, prev, 0, p, x, bt);
+            } else {
+                posterior<HP, R>(sh, part_out, part_slots, prev, 0, p, x, vA);
+                load_col(1, vA);
+            }
         }
     } else {
         // resume behind the column the other phase stored last
@@ -815,12 +847,12 @@ DEVI void forward_body(const DevContig& dc, ChainShared<HP, R>& sh, uint32_t C) 
         }
     };
 
-    auto step = [&](uint32_t t, double (&vb)[PHASE == 2 ? R : 1]) {
+    auto step = [&](uint32_t t, double (&vb)[(PHASE == 2 && !RING) ? R : 1]) {
         // decode the NEXT column's record now; it is consumed one step later, so its LDS latency
         // overlaps this step's work
         unsigned long long g0 = prof ? __builtin_amdgcn_s_memtime() : 0, g1;
-        const RecInfo nxt = decode_record<Cfg::UNI>(sh.rec[(t + 1) & 3u], p.j, p.i0, full);
-        const unsigned char* rec = sh.rec[t & 3u];
+        const RecInfo nxt = decode_record<Cfg::UNI>(sh.rec[(t + 1) & 7u], p.j, p.i0, full);
+        const unsigned char* rec = sh.rec[t & 7u];
         finalize(t - 1);
         if (prof) { asm volatile("" : "+v"(S)); __builtin_amdgcn_sched_barrier(0); g1 = __builtin_amdgcn_s_memtime(); seg[0] += g1 - g0; g0 = g1; }
 
@@ -829,7 +861,6 @@ DEVI void forward_body(const DevContig& dc, ChainShared<HP, R>& sh, uint32_t C) 
         const int es = exponent_of(S);
         const double m = ldexp(S, -es);
         const double k0 = ldexp(cur.c0, -es), k1 = ldexp(cur.c1, -es), hk2 = 0.5 * cur.c2 * m;
-        if (p.tid == 0) fscale[t] = m;
         const double uj = fma(k1, Cj, hk2);
         const double urow = fma(k1, Crow, hk2);
         if (!Cfg::UNI) {
@@ -867,7 +898,7 @@ DEVI void forward_body(const DevContig& dc, ChainShared<HP, R>& sh, uint32_t C) 
                 if constexpr (R > 16) { if ((k & 7) == 7) __builtin_amdgcn_sched_barrier(0); }
             }
         }
-        if (PHASE == 1) store_col(t, x);
+        if (PHASE == 1) { store_col(t, x); if (p.tid == 0) fscale[t] = m; }
         if (prof) { asm volatile("" : "+v"(part)); __builtin_amdgcn_sched_barrier(0); g1 = __builtin_amdgcn_s_memtime(); seg[3] += g1 - g0; g0 = g1; }
         write_sums<HP, R>(sh, t & 1u, p, part);
         if (prof) { __builtin_amdgcn_s_waitcnt(0xc07f); __builtin_amdgcn_sched_barrier(0); g1 = __builtin_amdgcn_s_memtime(); seg[4] += g1 - g0; g0 = g1; }
@@ -876,8 +907,15 @@ DEVI void forward_body(const DevContig& dc, ChainShared<HP, R>& sh, uint32_t C) 
             // zero, finalize() flags it one step later and k_bins re-forms its bins from the
             // uniform column), then prefetch the next beta' column: a whole step ahead of its use
             // and AFTER the last read of x, so no vmcnt wait lands inside the recursion
-            posterior<HP, R>(sh, part_out, part_slots, cur, t, p, x, vb);
-            load_col(t + 1, vb);
+            if constexpr (RING) {
+                double bt[R];
+                ring_read<HP, R>(ring, t, p.i0, p.j, bt);  // DMA'd by the loader two steps ago
+                posterior<HP, R>(sh, part_out, part_slots, cur, t, p, x, bt);
+            } else {
+                posterior<HP, R>(sh, part_out, part_slots, cur, t, p, x, vb);
+                load_col(t + 1, vb);
+            }
+            if (p.tid == 0) fscale[t] = m;
             if (prof) { __builtin_amdgcn_s_waitcnt(0xc07f); __builtin_amdgcn_sched_barrier(0); g1 = __builtin_amdgcn_s_memtime(); seg[1] += g1 - g0; g0 = g1; }
         }
         if (!Cfg::LOADER && p.wave == 0) {
@@ -899,7 +937,7 @@ DEVI void forward_body(const DevContig& dc, ChainShared<HP, R>& sh, uint32_t C) 
         for (int i = 0; i < 5; ++i) q[i] = seg[i];
     }
     finalize(hi - 1);
-    if constexpr (PHASE == 2) lds_barrier();  // F: the last partials are in LDS
+    if constexpr (PHASE == 2) lds_barrier();  // F (keeps the loader's barrier count)
 }
 
 // ------------------------------------------------------------------------------------------
@@ -908,8 +946,9 @@ DEVI void forward_body(const DevContig& dc, ChainShared<HP, R>& sh, uint32_t C) 
 //  KEEPW = keep w = beta_hat*e in registers across the column-sum exchange (else recompute it)
 // ------------------------------------------------------------------------------------------
 template <int HP, int R, int VBUF, bool KEEPW, int PHASE>
-DEVI void backward_body(const DevContig& dc, ChainShared<HP, R>& sh, uint32_t C) {
+DEVI void backward_body(const DevContig& dc, ChainShared<HP, R>& sh, uint32_t C, unsigned char* ring) {
     using Cfg = ChainCfg<HP, R>;
+    constexpr bool RING = Cfg::LOADER && PHASE == 2;  // partner columns via the LDS ring
     const int64_t mid = C / 2;
     // phase 1 computes columns C-1 .. mid (stores beta'); phase 2 computes mid-1 .. 0 (posteriors)
     const int64_t top = PHASE == 1 ? (int64_t)C - 1 : mid - 1;  // first column of this phase
@@ -930,35 +969,35 @@ DEVI void backward_body(const DevContig& dc, ChainShared<HP, R>& sh, uint32_t C)
         return 0ull;
     };
     auto rec_stage = [&](int64_t c, unsigned long long w) {
-        if (p.lane < (uint32_t)Cfg::WORDS && c >= 0) ((unsigned long long*)sh.rec[(uint32_t)c & 3u])[p.lane] = w;
+        if (p.lane < (uint32_t)Cfg::WORDS && c >= 0) ((unsigned long long*)sh.rec[(uint32_t)c & 7u])[p.lane] = w;
     };
     if (Cfg::LOADER && p.wave == (uint32_t)Cfg::NW) {
         // ------------------------------- loader wave ---------------------------------
         // step t reads record t+1 (emission/transition of the column behind) and, in phase 2,
         // record t (alleles for the posterior)
-        rec_stage(t0 + 1, rec_load(t0 + 1));
-        rec_stage(t0, rec_load(t0));
-        rec_stage(t0 - 1, rec_load(t0 - 1));
-        unsigned long long ta = rec_load(t0 - 2), tb = rec_load(t0 - 3);
+        LAS unsigned char* lring = (LAS unsigned char*)ring;
+        LAS unsigned char* lrec = (LAS unsigned char*)&sh.rec[0][0];
+        const gdouble* cols = (const gdouble*)dc.fwd;
+        dma_record<Cfg::RB>(colrec, t0 + 1, (int64_t)C, lrec, p.lane);
+        dma_record<Cfg::RB>(colrec, t0, (int64_t)C, lrec, p.lane);
+        dma_record<Cfg::RB>(colrec, t0 - 1, (int64_t)C, lrec, p.lane);
+        dma_record<Cfg::RB>(colrec, t0 - 2, (int64_t)C, lrec, p.lane);
+        if (RING) dma_column<HP>(cols, t0, (int64_t)C, lring, p.lane);  // v' of the first column of this phase
+        wait_vmem_all();
         lds_barrier();  // P0
-        for (int64_t t = t0; t >= bot; t -= 2) {
-            // (the partials of column t+2 live in the slot that record t-2 overwrites: flush first)
-            if (PHASE == 2) flush_partials<HP, R>(sh, part_out, part_slots, t + 2, 0, mid, p.lane);
-            rec_stage(t - 2, ta);  // decoded by the compute waves at step t-2... staged two steps ahead
-            ta = rec_load(t - 4);
+        // One iteration per recursion step t, i.e. per barrier interval (B_{t+1}, B_t).  The compute
+        // waves read column c in the interval after B_c (posterior of step c) and record c from the
+        // interval before B_c on, so: column t-1 is issued now and published by B_{t-1}; record t-3
+        // is issued now and decoded at step t-3... each waited for one iteration after its issue.
+        constexpr int NISSUE = 1 + (RING ? (HP * HP * 8) / 1024 : 0);
+        for (int64_t t = t0; t >= bot; --t) {
+            dma_record<Cfg::RB>(colrec, t - 3, (int64_t)C, lrec, p.lane);
+            if (RING) dma_column<HP>(cols, t - 1, (int64_t)C, lring, p.lane);
+            if (t - 3 >= 0) wait_vmem_keep<NISSUE>();
+            else wait_vmem_all();
             lds_barrier();  // B_t
-            if (t - 1 >= bot) {
-                if (PHASE == 2) flush_partials<HP, R>(sh, part_out, part_slots, t + 1, 0, mid, p.lane);
-                rec_stage(t - 3, tb);
-                tb = rec_load(t - 5);
-                lds_barrier();  // B_{t-1}
-            }
         }
-        if (PHASE == 2) {
-            flush_partials<HP, R>(sh, part_out, part_slots, 1, 0, mid, p.lane);
-            lds_barrier();  // F
-            flush_partials<HP, R>(sh, part_out, part_slots, 0, 0, mid, p.lane);
-        }
+        if (PHASE == 2) lds_barrier();  // F
         return;
     }
 
@@ -984,8 +1023,8 @@ DEVI void backward_body(const DevContig& dc, ChainShared<HP, R>& sh, uint32_t C)
         for (int k = 0; k < R; k += 2) dst[(size_t)(k >> 1) * HP] = v2f64{y[k], y[k + 1]};
     };
 
-    constexpr int NV = PHASE == 2 ? R : 1;
-    double y[R], vA[NV], vB[(PHASE == 2 && VBUF == 2) ? R : 1];
+    constexpr int NV = (PHASE == 2 && !RING) ? R : 1;
+    double y[R], vA[NV], vB[(PHASE == 2 && !RING && VBUF == 2) ? R : 1];
     double Sy = 0.0;
     unsigned long long tq = 0;  // inline loader (no loader wave): next record in flight
     if (!Cfg::LOADER && p.wave == 0) {
@@ -1005,11 +1044,13 @@ DEVI void backward_body(const DevContig& dc, ChainShared<HP, R>& sh, uint32_t C)
         // resume behind column mid, stored by phase 1
         load_col(mid, y);
         Sy = bsum[mid];
-        load_col(top, vA);
-        if constexpr (VBUF == 2) load_col(top - 1, vB);
+        if constexpr (!RING) {
+            load_col(top, vA);
+            if constexpr (VBUF == 2) load_col(top - 1, vB);
+        }
     }
     lds_barrier();  // P0
-    RecInfo cur = decode_record<Cfg::UNI>(sh.rec[(uint32_t)(t0 + 1) & 3u], p.j, p.i0, full);
+    RecInfo cur = decode_record<Cfg::UNI>(sh.rec[(uint32_t)(t0 + 1) & 7u], p.j, p.i0, full);
     const bool prof = (dc.debug & 8u) != 0;
     unsigned long long t_bar = 0;
     const unsigned long long t_begin = prof ? __builtin_amdgcn_s_memtime() : 0;
@@ -1023,8 +1064,8 @@ DEVI void backward_body(const DevContig& dc, ChainShared<HP, R>& sh, uint32_t C)
         }
         // decode record t now (posterior of this column, emission of the next step); the record of
         // column t+1 was decoded one step ago
-        const RecInfo nxt = decode_record<Cfg::UNI>(sh.rec[(uint32_t)t & 3u], p.j, p.i0, full);
-        const unsigned char* rec1 = sh.rec[(uint32_t)(t + 1) & 3u];
+        const RecInfo nxt = decode_record<Cfg::UNI>(sh.rec[(uint32_t)t & 7u], p.j, p.i0, full);
+        const unsigned char* rec1 = sh.rec[(uint32_t)(t + 1) & 7u];
         const double c0 = cur.c0, c1 = cur.c1, c2 = cur.c2, kappa = cur.kappa;
         // beta~_t(true) = A (y/Sy . e) A^T; scaled by 2^-es: beta' = beta~ * m, m = Sy*2^-es
         const int es = exponent_of(Sy);
@@ -1093,14 +1134,20 @@ DEVI void backward_body(const DevContig& dc, ChainShared<HP, R>& sh, uint32_t C)
             store_col(t, y);
             if (p.tid == 0) bsum[t] = Sy;
         } else {
-            posterior<HP, R>(sh, part_out, part_slots, nxt, (uint32_t)t, p, v, y);
-            load_col(t - VBUF, v);
+            if constexpr (RING) {
+                double vt[R];
+                ring_read<HP, R>(ring, t, p.i0, p.j, vt);  // DMA'd by the loader two steps ago
+                posterior<HP, R>(sh, part_out, part_slots, nxt, (uint32_t)t, p, vt, y);
+            } else {
+                posterior<HP, R>(sh, part_out, part_slots, nxt, (uint32_t)t, p, v, y);
+                load_col(t - VBUF, v);
+            }
         }
         cur = nxt;
     };
 
     for (int64_t t = t0; t >= bot; t -= 2) {
-        if constexpr (PHASE == 2 && VBUF == 2) {
+        if constexpr (PHASE == 2 && VBUF == 2 && !RING) {
             step(t, vA);
             if (t - 1 >= bot) step(t - 1, vB);
         } else {
@@ -1112,19 +1159,20 @@ DEVI void backward_body(const DevContig& dc, ChainShared<HP, R>& sh, uint32_t C)
         unsigned long long* o = dc.prof + (PHASE == 1 ? 16 : 24);
         o[0] = __builtin_amdgcn_s_memtime() - t_begin; o[1] = t_bar; o[2] = (unsigned long long)(t0 - bot + 1);
     }
-    if constexpr (PHASE == 2) lds_barrier();  // F: the last partials are in LDS
+    if constexpr (PHASE == 2) lds_barrier();  // F (keeps the loader's barrier count)
 }
 
 // grid = (n_contigs, 2): blockIdx.y = 0 forward half-chain, 1 backward half-chain
 template <int HP, int R, int VBUF, bool KEEPW, int PHASE>
 __global__ __launch_bounds__((ChainCfg<HP, R>::TT)) void k_sweep(const DevContig* __restrict__ contigs) {
     __shared__ ChainShared<HP, R> sh;
+    extern __shared__ __attribute__((aligned(16))) unsigned char dyn_ring[];  // phase 2: 3 column slots
     const DevContig& dc = contigs[blockIdx.x];
     if (dc.HP != (uint32_t)HP) return;
     const uint32_t C = *dc.n_cols;
     if (C == 0) return;
-    if (blockIdx.y == 0) forward_body<HP, R, PHASE>(dc, sh, C);
-    else backward_body<HP, R, VBUF, KEEPW, PHASE>(dc, sh, C);
+    if (blockIdx.y == 0) forward_body<HP, R, PHASE>(dc, sh, C, dyn_ring);
+    else backward_body<HP, R, VBUF, KEEPW, PHASE>(dc, sh, C, dyn_ring);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1211,15 +1259,25 @@ __global__ __launch_bounds__(256) void k_bins(const DevContig* __restrict__ cont
 //  host-callable launchers (defined here so that the shim needs no kernel templates)
 // ------------------------------------------------------------------------------------------
 // hp_mask: bit0 HP=16, bit1 HP=32, bit2 HP=64, bit3 HP=128; phase 1 = store halves, 2 = posterior halves
+template <int HP, int R, int VBUF, bool KEEPW, int PHASE>
+static void launch_one(const DevContig* d_contigs, uint32_t n_contigs, hipStream_t s) {
+    using Cfg = ChainCfg<HP, R>;
+    const size_t dyn = (Cfg::LOADER && PHASE == 2) ? (size_t)3 * HP * HP * 8 : 0;  // partner-column ring
+    auto kern = k_sweep<HP, R, VBUF, KEEPW, PHASE>;
+    static bool attr_set = false;
+    if (dyn > 0 && !attr_set) {  // more than the default 64 KiB of LDS per workgroup
+        (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn);
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(kern, dim3(n_contigs, 2), dim3(Cfg::TT), dyn, s, d_contigs);
+}
 template <int PHASE>
 static void launch_sweep(const DevContig* d_contigs, uint32_t n_contigs, uint32_t hp_mask, hipStream_t s) {
-    const dim3 grid(n_contigs, 2);
-    if (hp_mask & 1u) hipLaunchKernelGGL((k_sweep<16, 4, 1, true, PHASE>), grid, dim3(ChainCfg<16, 4>::TT), 0, s, d_contigs);
-    if (hp_mask & 2u) hipLaunchKernelGGL((k_sweep<32, 16, 1, true, PHASE>), grid, dim3(ChainCfg<32, 16>::TT), 0, s, d_contigs);
-    if (hp_mask & 4u) hipLaunchKernelGGL((k_sweep<64, 16, 1, true, PHASE>), grid, dim3(ChainCfg<64, 16>::TT), 0, s, d_contigs);
-    if (hp_mask & 8u) hipLaunchKernelGGL((k_sweep<128, 32, 1, false, PHASE>), grid, dim3(ChainCfg<128, 32>::TT), 0, s, d_contigs);
+    if (hp_mask & 1u) launch_one<16, 4, 1, true, PHASE>(d_contigs, n_contigs, s);
+    if (hp_mask & 2u) launch_one<32, 16, 1, true, PHASE>(d_contigs, n_contigs, s);
+    if (hp_mask & 4u) launch_one<64, 16, 1, true, PHASE>(d_contigs, n_contigs, s);
+    if (hp_mask & 8u) launch_one<128, 32, 1, false, PHASE>(d_contigs, n_contigs, s);
 }
-
 extern "C" {
 
 void pgk_launch_prep(const DevContig* d_contigs, uint32_t n_contigs, uint32_t max_v, DevTable tab, hipStream_t s) {
