@@ -668,24 +668,35 @@ DEVI void posterior(ChainShared<HP, R>& sh, gdouble* part_out, uint32_t part_slo
     double acc[PG_AMAX];
 #pragma unroll
     for (int a = 0; a < PG_AMAX; ++a) acc[a] = 0.0;
+    // Accumulate with 0/1 multipliers instead of predicated adds: acc[a] = fma(pr, [a_i == a], acc[a])
+    // rounds exactly like acc[a] += pr, needs no select chain through the accumulators, and for the
+    // wave-uniform row alleles (UNI) the multiplier is a scalar operand: one VALU op per (row, allele).
     if (ri.fast) {
         // (re-assert wave-uniformity: the value may have travelled through loop-carried copies)
         const uint32_t rbits = Cfg::UNI ? (uint32_t)__builtin_amdgcn_readfirstlane(ri.fe.rowbits) : ri.fe.rowbits;
 #pragma unroll
         for (int k = 0; k < R; ++k) {
             const double pr = v[k] * beta[k];
-            if ((rbits >> k) & 1u) acc[1] += pr;
-            else acc[0] += pr;
+            const bool bit = (rbits >> k) & 1u;
+            acc[1] = fma(pr, bit ? 1.0 : 0.0, acc[1]);
+            acc[0] = fma(pr, bit ? 0.0 : 1.0, acc[0]);
         }
     } else {
         const unsigned char* al = sh.rec[c & 7u] + PG_REC_ALLELES;
+        uint32_t aw[Cfg::UNI ? R / 4 : 1];
+        if constexpr (Cfg::UNI) {
+#pragma unroll
+            for (int q = 0; q < R / 4; ++q)
+                aw[q] = __builtin_amdgcn_readfirstlane(((const uint32_t*)(al + p.i0))[q]);
+        }
 #pragma unroll
         for (int k = 0; k < R; ++k) {
-            const uint32_t ai = al[p.i0 + k];
+            uint32_t ai;
+            if constexpr (Cfg::UNI) ai = (aw[k >> 2] >> (8 * (k & 3))) & 0xFFu;
+            else ai = al[p.i0 + k];
             const double pr = v[k] * beta[k];
 #pragma unroll
-            for (int a = 0; a < PG_AMAX; ++a)
-                if (ai == (uint32_t)a) acc[a] += pr;
+            for (int a = 0; a < PG_AMAX; ++a) acc[a] = fma(pr, ai == (uint32_t)a ? 1.0 : 0.0, acc[a]);
             if constexpr (R > 16) { if ((k & 7) == 7) __builtin_amdgcn_sched_barrier(0); }
         }
     }
