@@ -146,9 +146,10 @@ def load_hip():
     """Load the HIP product library; raises HipExtensionMissing if it was not built."""
     global _hip
     if _hip is None:
-        if not HIP_LIB_PATH.exists():
+        path = Path(os.environ.get("PANGENIE_HMM_LIB", HIP_LIB_PATH))  # override: instrumented builds (tools/)
+        if not path.exists():
             raise HipExtensionMissing(
-                f"{HIP_LIB_PATH} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                f"{path} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
                 "(hipcc --offload-arch=gfx950). There is no CPU fallback.")
-        _hip = _bind_hip(C.CDLL(str(HIP_LIB_PATH), mode=os.RTLD_GLOBAL if hasattr(os, "RTLD_GLOBAL") else 0))
+        _hip = _bind_hip(C.CDLL(str(path), mode=os.RTLD_GLOBAL if hasattr(os, "RTLD_GLOBAL") else 0))
     return _hip

@@ -28,19 +28,22 @@ def hipcc_path() -> str:
     raise RuntimeError("hipcc not found")
 
 
-def build_hip(force: bool = False, verbose: bool = False) -> Path:
-    """hipcc --offload-arch=gfx950 -> pangenie_amd/csrc/libpangenie_hmm.so (in-tree)."""
-    if force or _stale(HIP_LIB, HIP_DEPS):
+def build_hip(force: bool = False, verbose: bool = False, out: Path | None = None, defines=()) -> Path:
+    """hipcc --offload-arch=gfx950 -> pangenie_amd/csrc/libpangenie_hmm.so (in-tree).
+    `out`/`defines` build a variant elsewhere (tools/prof_chain.py: -DPG_CHAIN_PROF)."""
+    target = Path(out) if out else HIP_LIB
+    if force or _stale(target, HIP_DEPS):
+        target.parent.mkdir(parents=True, exist_ok=True)
         cmd = [hipcc_path(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
-               "-Wno-unused-value", "-Wno-unused-result",
-               *map(str, HIP_SOURCES), "-o", str(HIP_LIB)]
+               "-Wno-unused-value", "-Wno-unused-result", *[f"-D{d}" for d in defines],
+               *map(str, HIP_SOURCES), "-o", str(target)]
         r = subprocess.run(cmd, capture_output=True, text=True)
         if verbose or r.returncode:
             print(" ".join(cmd))
             print(r.stdout, r.stderr)
         if r.returncode:
             raise RuntimeError("hipcc failed:\n" + r.stderr)
-    return HIP_LIB
+    return target
 
 
 def build_oracle(force: bool = False) -> Path:

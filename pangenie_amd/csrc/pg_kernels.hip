@@ -470,6 +470,13 @@ __global__ __launch_bounds__(256) void k_records(const DevContig* __restrict__ c
 //  chain).  Same for the backward column.  Results are the reference's values up to fp64
 //  rounding; no drift because every step renormalises to within a factor of 2.
 // ------------------------------------------------------------------------------------------
+// In-kernel cycle profiling (tools/prof_chain.py) exists only in builds with -DPG_CHAIN_PROF; the
+// product library carries none of it.
+#ifdef PG_CHAIN_PROF
+static constexpr bool kChainProf = true;
+#else
+static constexpr bool kChainProf = false;
+#endif
 #define GAS __attribute__((address_space(1)))
 typedef GAS double gdouble;
 typedef GAS const double gcdouble;
@@ -758,7 +765,7 @@ DEVI void forward_body(const DevContig& dc, ChainShared<HP, R>& sh, uint32_t C, 
         constexpr int NISSUE = 1 + (RING ? (HP * HP * 8) / 1024 : 0);
         for (uint32_t t = first; t < hi; ++t) {
             dma_record<Cfg::RB>(colrec, (int64_t)t + 3, C, lrec, p.lane);
-            if (RING) dma_column<HP>(cols, (int64_t)t + 2, C, lring, p.lane);
+            if (RING && !(kChainProf && (dc.debug & 4u))) dma_column<HP>(cols, (int64_t)t + 2, C, lring, p.lane);
             if ((int64_t)t + 3 < (int64_t)C) wait_vmem_keep<NISSUE>();
             else wait_vmem_all();  // tail: fewer transfers were issued, drain instead of counting
             lds_barrier();  // B_t
@@ -779,10 +786,18 @@ DEVI void forward_body(const DevContig& dc, ChainShared<HP, R>& sh, uint32_t C, 
     const uint32_t dbg = dc.debug;
 
     auto store_col = [&](uint32_t c, const double (&x)[R]) {
-        if (dbg & 1u) return;
+        if (kChainProf && (dbg & 1u)) return;
         gdouble2* dst = (gdouble2*)(fwd + (size_t)c * colsz) + (size_t)(p.i0 >> 1) * HP + p.j;
 #pragma unroll
         for (int k = 0; k < R; k += 2) dst[(size_t)(k >> 1) * HP] = v2f64{x[k], x[k + 1]};
+    };
+    // store of one row pair, issued from inside the recursion loop: eight back-to-back 16-byte
+    // stores per wave queue behind each other in the texture-address unit (store-issue bound);
+    // spread between the arithmetic of the following rows they cost their issue slots only
+    auto store_pair = [&](uint32_t c, int k, double a, double b) {
+        if (kChainProf && (dbg & 1u)) return;
+        gdouble2* dst = (gdouble2*)(fwd + (size_t)c * colsz) + (size_t)(p.i0 >> 1) * HP + p.j;
+        dst[(size_t)(k >> 1) * HP] = v2f64{a, b};
     };
     auto load_col = [&](uint32_t c, double (&v)[R]) {
         if (c >= C) return;
@@ -810,7 +825,7 @@ DEVI void forward_body(const DevContig& dc, ChainShared<HP, R>& sh, uint32_t C, 
     // cur = record of the column the next step produces, prev = record of the column before it
     RecInfo cur = decode_record<Cfg::UNI>(sh.rec[first & 7u], p.j, p.i0, full);
     RecInfo prev = decode_record<Cfg::UNI>(sh.rec[(first - 1) & 7u], p.j, p.i0, full);
-    const bool prof = (dbg & 8u) != 0;
+    const bool prof = kChainProf && (dbg & 8u) != 0;
     unsigned long long t_bar = 0, seg[5] = {0, 0, 0, 0, 0};
 
     if (lo == 0) {
@@ -864,6 +879,10 @@ DEVI void forward_body(const DevContig& dc, ChainShared<HP, R>& sh, uint32_t C, 
         unsigned long long g0 = prof ? __builtin_amdgcn_s_memtime() : 0, g1;
         const RecInfo nxt = decode_record<Cfg::UNI>(sh.rec[(t + 1) & 7u], p.j, p.i0, full);
         const unsigned char* rec = sh.rec[t & 7u];
+        // partner column beta'_t out of the ring (landed before B_{t-1}); issued first so that the
+        // 32 KB of LDS reads overlap the sum exchange and the recursion instead of trailing them
+        double bt[RING ? R : 1];
+        if constexpr (RING) ring_read<HP, R>(ring, t, p.i0, p.j, bt);
         finalize(t - 1);
         if (prof) { asm volatile("" : "+v"(S)); __builtin_amdgcn_sched_barrier(0); g1 = __builtin_amdgcn_s_memtime(); seg[0] += g1 - g0; g0 = g1; }
 
@@ -896,7 +915,8 @@ DEVI void forward_body(const DevContig& dc, ChainShared<HP, R>& sh, uint32_t C, 
                 const double e = ((fe.rowbits >> k) & 1u) ? fe.eB : fe.eA;
                 x[k] = fma(k0, x[k], uik + uj) * e;
                 part += x[k];
-                if constexpr (R > 16) { if ((k & 7) == 7) __builtin_amdgcn_sched_barrier(0); }
+                if constexpr (PHASE == 1) { if (k & 1) { store_pair(t, k, x[k - 1], x[k]); __builtin_amdgcn_sched_barrier(0); } }
+                else if constexpr (R > 16) { if ((k & 7) == 7) __builtin_amdgcn_sched_barrier(0); }
             }
         } else {
 #pragma unroll
@@ -906,10 +926,11 @@ DEVI void forward_body(const DevContig& dc, ChainShared<HP, R>& sh, uint32_t C, 
                 else uik = readlane_f64(urow, __builtin_amdgcn_readfirstlane((int)((p.i0 + k) & 63u)));
                 x[k] = fma(k0, x[k], uik + uj) * emission_at(rec, p.i0 + k, aj);
                 part += x[k];
-                if constexpr (R > 16) { if ((k & 7) == 7) __builtin_amdgcn_sched_barrier(0); }
+                if constexpr (PHASE == 1) { if (k & 1) { store_pair(t, k, x[k - 1], x[k]); __builtin_amdgcn_sched_barrier(0); } }
+                else if constexpr (R > 16) { if ((k & 7) == 7) __builtin_amdgcn_sched_barrier(0); }
             }
         }
-        if (PHASE == 1) { store_col(t, x); if (p.tid == 0) fscale[t] = m; }
+        if (PHASE == 1) { if (p.tid == 0) fscale[t] = m; }
         if (prof) { asm volatile("" : "+v"(part)); __builtin_amdgcn_sched_barrier(0); g1 = __builtin_amdgcn_s_memtime(); seg[3] += g1 - g0; g0 = g1; }
         write_sums<HP, R>(sh, t & 1u, p, part);
         if (prof) { __builtin_amdgcn_s_waitcnt(0xc07f); __builtin_amdgcn_sched_barrier(0); g1 = __builtin_amdgcn_s_memtime(); seg[4] += g1 - g0; g0 = g1; }
@@ -919,8 +940,6 @@ DEVI void forward_body(const DevContig& dc, ChainShared<HP, R>& sh, uint32_t C, 
             // uniform column), then prefetch the next beta' column: a whole step ahead of its use
             // and AFTER the last read of x, so no vmcnt wait lands inside the recursion
             if constexpr (RING) {
-                double bt[R];
-                ring_read<HP, R>(ring, t, p.i0, p.j, bt);  // DMA'd by the loader two steps ago
                 posterior<HP, R>(sh, part_out, part_slots, cur, t, p, x, bt);
             } else {
                 posterior<HP, R>(sh, part_out, part_slots, cur, t, p, x, vb);
@@ -993,17 +1012,20 @@ DEVI void backward_body(const DevContig& dc, ChainShared<HP, R>& sh, uint32_t C,
         dma_record<Cfg::RB>(colrec, t0, (int64_t)C, lrec, p.lane);
         dma_record<Cfg::RB>(colrec, t0 - 1, (int64_t)C, lrec, p.lane);
         dma_record<Cfg::RB>(colrec, t0 - 2, (int64_t)C, lrec, p.lane);
-        if (RING) dma_column<HP>(cols, t0, (int64_t)C, lring, p.lane);  // v' of the first column of this phase
+        if (RING) {  // v' of the first two columns of this phase
+            dma_column<HP>(cols, t0, (int64_t)C, lring, p.lane);
+            dma_column<HP>(cols, t0 - 1, (int64_t)C, lring, p.lane);
+        }
         wait_vmem_all();
         lds_barrier();  // P0
-        // One iteration per recursion step t, i.e. per barrier interval (B_{t+1}, B_t).  The compute
-        // waves read column c in the interval after B_c (posterior of step c) and record c from the
-        // interval before B_c on, so: column t-1 is issued now and published by B_{t-1}; record t-3
-        // is issued now and decoded at step t-3... each waited for one iteration after its issue.
+        // One iteration per recursion step t, i.e. per barrier interval I_t = (B_{t+1}, B_t).  The
+        // compute waves read column t at the top of step t (inside I_t) and record c during
+        // I_c .. I_{c-2}.  Column t-2 issued now lands by the end of iteration t-1, i.e. before
+        // B_{t-1} opens I_{t-2}; its slot (t+1)%3 was last read in I_{t+1}.  Record t-3 likewise.
         constexpr int NISSUE = 1 + (RING ? (HP * HP * 8) / 1024 : 0);
         for (int64_t t = t0; t >= bot; --t) {
             dma_record<Cfg::RB>(colrec, t - 3, (int64_t)C, lrec, p.lane);
-            if (RING) dma_column<HP>(cols, t - 1, (int64_t)C, lring, p.lane);
+            if (RING && !(kChainProf && (dc.debug & 4u))) dma_column<HP>(cols, t - 2, (int64_t)C, lring, p.lane);
             if (t - 3 >= 0) wait_vmem_keep<NISSUE>();
             else wait_vmem_all();
             lds_barrier();  // B_t
@@ -1032,6 +1054,10 @@ DEVI void backward_body(const DevContig& dc, ChainShared<HP, R>& sh, uint32_t C,
         gdouble2* dst = (gdouble2*)(cols + (size_t)c * colsz) + (size_t)(p.i0 >> 1) * HP + p.j;
 #pragma unroll
         for (int k = 0; k < R; k += 2) dst[(size_t)(k >> 1) * HP] = v2f64{y[k], y[k + 1]};
+    };
+    auto store_pair = [&](int64_t c, int k, double a, double b) {  // see forward_body
+        gdouble2* dst = (gdouble2*)(cols + (size_t)c * colsz) + (size_t)(p.i0 >> 1) * HP + p.j;
+        dst[(size_t)(k >> 1) * HP] = v2f64{a, b};
     };
 
     constexpr int NV = (PHASE == 2 && !RING) ? R : 1;
@@ -1062,7 +1088,7 @@ DEVI void backward_body(const DevContig& dc, ChainShared<HP, R>& sh, uint32_t C,
     }
     lds_barrier();  // P0
     RecInfo cur = decode_record<Cfg::UNI>(sh.rec[(uint32_t)(t0 + 1) & 7u], p.j, p.i0, full);
-    const bool prof = (dc.debug & 8u) != 0;
+    const bool prof = kChainProf && (dc.debug & 8u) != 0;
     unsigned long long t_bar = 0;
     const unsigned long long t_begin = prof ? __builtin_amdgcn_s_memtime() : 0;
 
@@ -1077,6 +1103,9 @@ DEVI void backward_body(const DevContig& dc, ChainShared<HP, R>& sh, uint32_t C,
         // column t+1 was decoded one step ago
         const RecInfo nxt = decode_record<Cfg::UNI>(sh.rec[(uint32_t)t & 7u], p.j, p.i0, full);
         const unsigned char* rec1 = sh.rec[(uint32_t)(t + 1) & 7u];
+        // partner column v'_t out of the ring (landed before B_{t+1}), read ahead of its use
+        double vt[RING ? R : 1];
+        if constexpr (RING) ring_read<HP, R>(ring, t, p.i0, p.j, vt);
         const double c0 = cur.c0, c1 = cur.c1, c2 = cur.c2, kappa = cur.kappa;
         // beta~_t(true) = A (y/Sy . e) A^T; scaled by 2^-es: beta' = beta~ * m, m = Sy*2^-es
         const int es = exponent_of(Sy);
@@ -1135,19 +1164,17 @@ DEVI void backward_body(const DevContig& dc, ChainShared<HP, R>& sh, uint32_t C,
                 if constexpr (R <= 16) uik = ui[k];
                 else uik = readlane_f64(urow, __builtin_amdgcn_readfirstlane((int)((p.i0 + k) & 63u)));
                 y[k] = fma(k0, wk, uik + uj);  // beta'_t
-                if constexpr (R > 16) { if ((k & 7) == 7) __builtin_amdgcn_sched_barrier(0); }
+                if constexpr (PHASE == 1) { if (k & 1) { store_pair(t, k, y[k - 1], y[k]); __builtin_amdgcn_sched_barrier(0); } }
+                else if constexpr (R > 16) { if ((k & 7) == 7) __builtin_amdgcn_sched_barrier(0); }
             }
         };
         if (KEEPW || fast) beta_loop(std::true_type{});
         else beta_loop(std::false_type{});
         Sy = ldexp(kappa * Sw, -es);  // = sum(beta'_t) over real states
         if constexpr (PHASE == 1) {
-            store_col(t, y);
             if (p.tid == 0) bsum[t] = Sy;
         } else {
             if constexpr (RING) {
-                double vt[R];
-                ring_read<HP, R>(ring, t, p.i0, p.j, vt);  // DMA'd by the loader two steps ago
                 posterior<HP, R>(sh, part_out, part_slots, nxt, (uint32_t)t, p, vt, y);
             } else {
                 posterior<HP, R>(sh, part_out, part_slots, nxt, (uint32_t)t, p, v, y);

@@ -2,6 +2,12 @@ import os, sys
 sys.path.insert(0, os.getcwd())
 os.environ["PG_DEBUG"] = sys.argv[1] if len(sys.argv) > 1 else "8"
 H = int(sys.argv[2]) if len(sys.argv) > 2 else 64
+# instrumented variant of the product library (the product build has no profiling code)
+from pangenie_amd import build as _build
+_prof_lib = os.path.join(os.getcwd(), "tools", "_build", "libpangenie_hmm_prof.so")
+if not os.environ.get("PG_PROF_PREBUILT"):
+    _build.build_hip(out=_prof_lib, defines=("PG_CHAIN_PROF",))
+os.environ["PANGENIE_HMM_LIB"] = _prof_lib
 from pangenie_amd import hmm
 from pangenie_amd.panel import synthetic_panel, default_table_args
 V = 50000
