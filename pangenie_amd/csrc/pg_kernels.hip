@@ -472,10 +472,18 @@ __global__ __launch_bounds__(256) void k_records(const DevContig* __restrict__ c
 // ------------------------------------------------------------------------------------------
 // In-kernel cycle profiling (tools/prof_chain.py) exists only in builds with -DPG_CHAIN_PROF; the
 // product library carries none of it.
+// Timing experiments (tools/exp_chain.py): -DPG_EXP=<mask> builds a variant with one ingredient of
+// the recursion step removed (results are then WRONG; only the kernel time is of interest).
+#ifndef PG_EXP
+#define PG_EXP 0
+#endif
+static constexpr unsigned kExp = PG_EXP;
 #ifdef PG_CHAIN_PROF
 static constexpr bool kChainProf = true;
+static constexpr bool kChainProfSteps = (PG_CHAIN_PROF + 0) != 1;  // -DPG_CHAIN_PROF=1: per-role totals only
 #else
 static constexpr bool kChainProf = false;
+static constexpr bool kChainProfSteps = false;
 #endif
 #define GAS __attribute__((address_space(1)))
 typedef GAS double gdouble;
@@ -492,7 +500,10 @@ struct ChainCfg {
     // HP = 128 keeps its 8 compute waves at 2 waves/SIMD (256 VGPRs): a 9th wave would cut the
     // register budget to 168 and spill, so there wave 0 does the loader's work inline.
     static constexpr bool LOADER = HP < 128;
-    static constexpr int TT = T + (LOADER ? 64 : 0);
+    // loader waves: a wave can have at most 63 counted transfers in flight and a 32 KB column is 32
+    // of them, so two columns deep (what hides the ~1.1 us DMA latency) needs two waves at HP = 64
+    static constexpr int NLOAD = LOADER ? (HP >= 64 ? 2 : 1) : 0;
+    static constexpr int TT = T + 64 * NLOAD;
     static constexpr int NRG = HP / R;
     static constexpr int NW = T / 64;          // compute waves
     static constexpr bool UNI = HP >= 64;
@@ -507,8 +518,7 @@ template <int HP, int R>
 struct ChainShared {
     using Cfg = ChainCfg<HP, R>;
     unsigned char rec[8][Cfg::RB] __attribute__((aligned(16)));  // ring of 8 column records
-    double psum[2][Cfg::NRG][HP];
-    double wsum[2][Cfg::NW];
+    double psum[2][Cfg::NRG][HP];  // per row group partial column sums, double buffered by column parity
     double u[Cfg::UNI ? Cfg::NW : 1][Cfg::UNI ? 64 : HP] __attribute__((aligned(16)));  // per-wave copy of the u vector
 };
 
@@ -581,35 +591,19 @@ DEVI RecInfo decode_record(const unsigned char* rec, uint32_t j, uint32_t i0, bo
     return r;
 }
 
-// u_i for the thread's rows.  UNI: every wave holds the u vector of the 64-column block that
-// contains its rows (urow, lane l = column rb+l); it parks it in a wave-private LDS row and reads
-// the R values back as broadcasts (one LDS round trip ~120 cycles; 2*R v_readlane cost ~20
-// cycles per value).  !UNI (single compute wave): the u vector of all HP columns is in LDS.
-template <int R, bool UNI>
-DEVI void row_values(double* lds_u /* this wave's row */, double urow, uint32_t lane, uint32_t i0, double (&ui)[R]) {
-    if (UNI) {
-        lds_u[lane] = urow;
-        lds_wave_sync();
-        const uint32_t base = i0 & 63u;
-#pragma unroll
-        for (int k = 0; k < R; ++k) ui[k] = lds_u[base + k];
-    } else {
-#pragma unroll
-        for (int k = 0; k < R; ++k) ui[k] = lds_u[i0 + k];
-    }
-}
-
 // Phase-2 partner columns reach the compute waves through an LDS ring filled by the loader wave
 // with LDS-DMA (global_load_lds_dwordx4: HBM -> LDS, no VGPRs), two columns ahead of use.
 #define LAS __attribute__((address_space(3)))
-template <int HP>
-DEVI void dma_column(const gdouble* cols, int64_t c, int64_t C, LAS unsigned char* ring, uint32_t lane) {
+// loader wave `part` of NPARTS moves its share of the column (1 KB per wave-instruction)
+template <int HP, int NPARTS>
+DEVI void dma_column(const gdouble* cols, int64_t c, int64_t C, LAS unsigned char* ring, uint32_t lane, uint32_t part) {
     if (c < 0 || c >= C) return;
-    constexpr uint32_t COLB = HP * HP * 8u;
-    const GAS char* g = (const GAS char*)(cols + (size_t)c * HP * HP) + lane * 16u;
-    LAS unsigned char* l = ring + (uint32_t)(c % 3) * COLB;  // wave-uniform base; lane l lands at +16*l
+    constexpr uint32_t COLB = HP * HP * 8u, SHARE = COLB / (NPARTS > 0 ? NPARTS : 1);
+    static_assert(SHARE % 1024u == 0, "column share must be a whole number of wave transfers");
+    const GAS char* g = (const GAS char*)(cols + (size_t)c * HP * HP) + part * SHARE + lane * 16u;
+    LAS unsigned char* l = ring + (uint32_t)(c & 3) * COLB + part * SHARE;  // wave-uniform base; lane l lands at +16*l
 #pragma unroll 4
-    for (uint32_t q = 0; q < COLB / 1024u; ++q)
+    for (uint32_t q = 0; q < SHARE / 1024u; ++q)
         __builtin_amdgcn_global_load_lds((const GAS void*)(g + q * 1024u), (LAS void*)(l + q * 1024u), 16, 0, 0);
 }
 // column record -> its LDS slot by DMA as well (lanes < RB/16 move 16 B each): the loader wave then
@@ -631,7 +625,12 @@ DEVI void wait_vmem_keep() {
 }
 template <int HP, int R>
 DEVI void ring_read(const unsigned char* ring, int64_t c, const uint32_t i0, const uint32_t j, double (&v)[R]) {
-    const v2f64* slot = (const v2f64*)(ring + (size_t)(c % 3) * (HP * HP * 8u)) + (size_t)(i0 >> 1) * HP + j;
+    if (kExp & 32u) {
+#pragma unroll
+        for (int k = 0; k < R; ++k) v[k] = 1.0;
+        return;
+    }
+    const v2f64* slot = (const v2f64*)(ring + (size_t)(c & 3) * (HP * HP * 8u)) + (size_t)(i0 >> 1) * HP + j;
 #pragma unroll
     for (int k = 0; k < R; k += 2) { const v2f64 t = slot[(size_t)(k >> 1) * HP]; v[k] = t.x; v[k + 1] = t.y; }
 }
@@ -641,29 +640,67 @@ struct ThreadPos {
     uint32_t tid, lane, wave, j, rg, i0, rb;
 };
 
-// column sums of the previous column out of the LDS exchange buffers
+// Column-sum exchange.  Before the barrier every thread parks the sum of its R rows of its column;
+// after it every thread adds the NRG partials of its column.  By symmetry of the column (v_ij = v_ji)
+// the row sums equal the column sums, so the same vector serves u_i and u_j.  The TOTAL is reduced
+// after the barrier, redundantly in every wave, from the column sums (each wave holds all of them
+// across its lanes): that DPP reduction runs while the u vector makes its LDS round trip, instead
+// of sitting in front of the barrier behind the last arithmetic of the step.
+//   Cj   : sum of this thread's column
+//   Crow : sum of the column whose index is (row block of this wave) + lane  (== Cj for HP <= 64)
+//   Call : this lane's column sums added over all 64-column blocks (its wave sum is the total)
 template <int HP, int R>
-DEVI void read_sums(const ChainShared<HP, R>& sh, uint32_t pb, const ThreadPos& p, double& Cj, double& Crow, double& S) {
+DEVI void read_colsums(const ChainShared<HP, R>& sh, uint32_t pb, const ThreadPos& p, double& Cj, double& Crow, double& Call) {
     using Cfg = ChainCfg<HP, R>;
-    Cj = 0.0;
+    if (kExp & 64u) { Cj = Crow = Call = 1.0 / HP; return; }
+    if constexpr (HP <= 64) {
+        Cj = 0.0;
 #pragma unroll
-    for (int g = 0; g < Cfg::NRG; ++g) Cj += sh.psum[pb][g][p.j];
-    if (Cfg::UNI && HP > 64) {
-        Crow = 0.0;
-#pragma unroll
-        for (int g = 0; g < Cfg::NRG; ++g) Crow += sh.psum[pb][g][p.rb + p.lane];
+        for (int g = 0; g < Cfg::NRG; ++g) Cj += sh.psum[pb][g][p.j];
+        Crow = Call = Cj;
     } else {
-        Crow = Cj;
-    }
-    S = 0.0;
+        static_assert(HP == 128, "two 64-column blocks");
+        double ca = 0.0, cb = 0.0;
 #pragma unroll
-    for (int w = 0; w < Cfg::NW; ++w) S += sh.wsum[pb][w];
+        for (int g = 0; g < Cfg::NRG; ++g) { ca += sh.psum[pb][g][p.lane]; cb += sh.psum[pb][g][64 + p.lane]; }
+        Cj = p.j >= 64u ? cb : ca;  // wave-uniform choices
+        Crow = p.rb ? cb : ca;
+        Call = ca + cb;
+    }
+}
+template <int HP>
+DEVI double total_sum(double Call) {
+    if (kExp & 2u) return Call * 64.0;
+    const double s = wave_sum(Call);
+    return HP < 64 ? s * ((double)HP / 64.0) : s;  // HP < 64: every column sits in 64/HP lanes (exact power of two)
 }
 template <int HP, int R>
-DEVI void write_sums(ChainShared<HP, R>& sh, uint32_t pb, const ThreadPos& p, double part) {
+DEVI void write_colsums(ChainShared<HP, R>& sh, uint32_t pb, const ThreadPos& p, double part) {
     sh.psum[pb][p.rg][p.j] = part;
-    const double ws = wave_sum(part);
-    if (p.lane == 0) sh.wsum[pb][p.wave] = ws;
+}
+// u vector (c1 * column sums) for the thread's rows: UNI: each wave parks the vector of its row block
+// in a wave-private LDS row and reads its R values back as broadcasts (~120 cycles; 2R v_readlane
+// would cost ~20 cycles per value); !UNI (single compute wave): one shared row.
+template <int HP, int R>
+DEVI void publish_u(ChainShared<HP, R>& sh, const ThreadPos& p, double urow, double ucol) {
+    using Cfg = ChainCfg<HP, R>;
+    if (kExp & 4u) return;
+    if constexpr (Cfg::UNI) sh.u[p.wave][p.lane] = urow;
+    else { if (p.rg == 0) sh.u[0][p.j] = ucol; }
+}
+template <int HP, int R>
+DEVI void fetch_u(const ChainShared<HP, R>& sh, const ThreadPos& p, double urow, double (&ui)[R]) {
+    using Cfg = ChainCfg<HP, R>;
+    if (kExp & 4u) {
+#pragma unroll
+        for (int k = 0; k < R; ++k) ui[k] = urow;
+        return;
+    }
+    // no fence/wait between the write and these reads: the LDS executes one wave's instructions in
+    // order, and writer and readers are the same wave (the row is wave-private / the wave is alone)
+    const double* row = Cfg::UNI ? &sh.u[p.wave][p.i0 & 63u] : &sh.u[0][p.i0];
+#pragma unroll
+    for (int k = 0; k < R; ++k) ui[k] = row[k];
 }
 
 // posterior partials of column c: acc[a] = sum over my rows with local allele a of v*beta
@@ -671,10 +708,11 @@ template <int HP, int R>
 DEVI void posterior(ChainShared<HP, R>& sh, gdouble* part_out, uint32_t part_slots, const RecInfo& ri, uint32_t c, const ThreadPos& p,
                     const double (&v)[R], const double (&beta)[R]) {
     using Cfg = ChainCfg<HP, R>;
+    if (kExp & 8u) return;
     const uint32_t nl = ri.nl;
-    double acc[PG_AMAX];
+    double acc[PG_AMAX + 1];
 #pragma unroll
-    for (int a = 0; a < PG_AMAX; ++a) acc[a] = 0.0;
+    for (int a = 0; a <= PG_AMAX; ++a) acc[a] = 0.0;
     // Accumulate with 0/1 multipliers instead of predicated adds: acc[a] = fma(pr, [a_i == a], acc[a])
     // rounds exactly like acc[a] += pr, needs no select chain through the accumulators, and for the
     // wave-uniform row alleles (UNI) the multiplier is a scalar operand: one VALU op per (row, allele).
@@ -707,12 +745,14 @@ DEVI void posterior(ChainShared<HP, R>& sh, gdouble* part_out, uint32_t part_slo
             if constexpr (R > 16) { if ((k & 7) == 7) __builtin_amdgcn_sched_barrier(0); }
         }
     }
+    // Partials go out as 16-byte stores of allele PAIRS (slot pair q = alleles 2q, 2q+1): a
+    // wave-wide 16-byte store costs the texture-address unit a third of two 8-byte ones, and
     // phase-2 compute waves have no loads in flight (partner columns arrive through the LDS ring),
-    // so these stores never make them wait
-    gdouble* dst = part_out + (size_t)c * part_slots * Cfg::T + p.tid;
+    // so these stores never make them wait.  Layout: part[((c * part_slots/2 + q) * T + tid) * 2 + (a & 1)].
+    gdouble2* dst = (gdouble2*)part_out + (size_t)c * (part_slots >> 1) * Cfg::T + p.tid;
 #pragma unroll
-    for (int a = 0; a < PG_AMAX; ++a)
-        if ((uint32_t)a < nl) dst[(size_t)a * Cfg::T] = acc[a];
+    for (int q = 0; q < (PG_AMAX + 1) / 2; ++q)
+        if ((uint32_t)(2 * q) < nl) dst[(size_t)q * Cfg::T] = v2f64{acc[2 * q], acc[2 * q + 1]};
 }
 
 // ------------------------------------------------------------------------------------------
@@ -740,34 +780,40 @@ DEVI void forward_body(const DevContig& dc, ChainShared<HP, R>& sh, uint32_t C, 
     auto rec_stage = [&](uint32_t c, unsigned long long w) {
         if (p.lane < (uint32_t)Cfg::WORDS) ((unsigned long long*)sh.rec[c & 7u])[p.lane] = w;
     };
-    if (Cfg::LOADER && p.wave == (uint32_t)Cfg::NW) {
-        // ------------------------------- loader wave ---------------------------------
+    if (Cfg::LOADER && p.wave >= (uint32_t)Cfg::NW) {
+        // ------------------------------- loader waves --------------------------------
+        // They only ISSUE LDS-DMA (HBM -> LDS, no VGPRs) and count completions.  Loader 0 moves the
+        // column records (record t+6 at iteration t; a record is first read one step before its
+        // column) and, in phase 2, its share of the partner column t+3; loader 1 the other share.
+        // Column c is read during step c; its ring slot c&3 held column c-4.  Transfers complete
+        // in order, so "at most KEEP = k * (transfers per iteration) outstanding" means that
+        // everything issued k iterations ago has landed: k = 2 for the column stream (column t+1
+        // and record t+4 are in LDS before B_t publishes them), k = 4 for the record-only stream
+        // of phase 1.  Every transfer thus has >= 2 full steps (> the ~1.1 us DMA latency) to land.
+        // In the tail (iterations that issue less) the loaders drain instead of counting.
+        const uint32_t lw = p.wave - (uint32_t)Cfg::NW;
         LAS unsigned char* lring = (LAS unsigned char*)ring;
         LAS unsigned char* lrec = (LAS unsigned char*)&sh.rec[0][0];
         const gdouble* cols = (const gdouble*)dc.fwd;
-        // prologue: records of the first columns (+ beta' of the first two columns in phase 2)
-        if (lo == 0) dma_record<Cfg::RB>(colrec, 0, C, lrec, p.lane);
-        dma_record<Cfg::RB>(colrec, first, C, lrec, p.lane);
-        dma_record<Cfg::RB>(colrec, (int64_t)first + 1, C, lrec, p.lane);
-        dma_record<Cfg::RB>(colrec, (int64_t)first + 2, C, lrec, p.lane);
-        if (RING) {
-            dma_column<HP>(cols, (int64_t)lo, C, lring, p.lane);
-            dma_column<HP>(cols, (int64_t)lo + 1, C, lring, p.lane);
+        constexpr int QL = RING ? (HP * HP * 8) / 1024 / (Cfg::NLOAD > 0 ? Cfg::NLOAD : 1) : 0;  // column transfers per loader per iteration
+        constexpr int KEEP0 = RING ? 2 * (1 + QL) : 4, KEEP1 = 2 * QL;
+        static_assert(KEEP0 < 64 && KEEP1 < 64, "vmcnt is 6 bits");
+        if (lw == 0) {
+            if (lo == 0) dma_record<Cfg::RB>(colrec, 0, C, lrec, p.lane);
+            for (int q = 0; q < 6; ++q) dma_record<Cfg::RB>(colrec, (int64_t)first + q, C, lrec, p.lane);
         }
+        if (RING)
+            for (int q = 0; q < 3; ++q) dma_column<HP, Cfg::NLOAD>(cols, (int64_t)lo + q, C, lring, p.lane, lw);
         wait_vmem_all();
         lds_barrier();  // P0: first records staged
         lds_barrier();  // Bx: column lo initialised / resumed
-        // One loader iteration per recursion step t.  It only ISSUES DMA (record t+3, decoded by the
-        // compute waves at step t+2; column t+2, consumed at the end of step t+2) and then waits
-        // for what the PREVIOUS iteration issued: loads complete in order, so "at most NISSUE
-        // outstanding" == "everything older than this iteration has landed".  Every transfer thus
-        // has a full step to complete before the barrier that publishes it.
-        constexpr int NISSUE = 1 + (RING ? (HP * HP * 8) / 1024 : 0);
+        const bool nodma = (kExp & 128u) || (kChainProf && (dc.debug & 4u));
         for (uint32_t t = first; t < hi; ++t) {
-            dma_record<Cfg::RB>(colrec, (int64_t)t + 3, C, lrec, p.lane);
-            if (RING && !(kChainProf && (dc.debug & 4u))) dma_column<HP>(cols, (int64_t)t + 2, C, lring, p.lane);
-            if ((int64_t)t + 3 < (int64_t)C) wait_vmem_keep<NISSUE>();
-            else wait_vmem_all();  // tail: fewer transfers were issued, drain instead of counting
+            if (lw == 0) dma_record<Cfg::RB>(colrec, (int64_t)t + 6, C, lrec, p.lane);
+            if (RING && !nodma) dma_column<HP, Cfg::NLOAD>(cols, (int64_t)t + 3, C, lring, p.lane, lw);
+            if ((int64_t)t + 6 >= (int64_t)C) wait_vmem_all();  // tail
+            else if (lw == 0) wait_vmem_keep<KEEP0>();
+            else wait_vmem_keep<KEEP1>();
             lds_barrier();  // B_t
         }
         if (PHASE == 2) lds_barrier();  // F
@@ -795,7 +841,7 @@ DEVI void forward_body(const DevContig& dc, ChainShared<HP, R>& sh, uint32_t C, 
     // stores per wave queue behind each other in the texture-address unit (store-issue bound);
     // spread between the arithmetic of the following rows they cost their issue slots only
     auto store_pair = [&](uint32_t c, int k, double a, double b) {
-        if (kChainProf && (dbg & 1u)) return;
+        if ((kExp & 1u) || (kChainProf && (dbg & 1u))) return;
         gdouble2* dst = (gdouble2*)(fwd + (size_t)c * colsz) + (size_t)(p.i0 >> 1) * HP + p.j;
         dst[(size_t)(k >> 1) * HP] = v2f64{a, b};
     };
@@ -806,13 +852,8 @@ DEVI void forward_body(const DevContig& dc, ChainShared<HP, R>& sh, uint32_t C, 
         for (int k = 0; k < R; k += 2) { const v2f64 t = src[(size_t)(k >> 1) * HP]; v[k] = t.x; v[k + 1] = t.y; }
     };
 
-    // beta' prefetch buffers: ONE column in flight is enough — the load is issued right after the
-    // posterior of step t and consumed by the posterior of step t+1, a whole step (> HBM latency)
-    // later; a second buffer costs 2R VGPRs and pushed the phase-2 kernel into scratch.
-    constexpr int FB = 1;
     double x[R], ui[R > 16 ? 1 : R];
     double vA[(PHASE == 2 && !RING) ? R : 1];  // register-prefetched beta' column (phase 2 without the LDS ring)
-    double Cj = 0.0, Crow = 0.0, S = 0.0;
     unsigned long long tq = 0;  // inline loader (no loader wave): next record in flight
     if (!Cfg::LOADER && p.wave == 0) {
         if (lo == 0) rec_stage(0, rec_load(0));
@@ -826,7 +867,6 @@ DEVI void forward_body(const DevContig& dc, ChainShared<HP, R>& sh, uint32_t C, 
     RecInfo cur = decode_record<Cfg::UNI>(sh.rec[first & 7u], p.j, p.i0, full);
     RecInfo prev = decode_record<Cfg::UNI>(sh.rec[(first - 1) & 7u], p.j, p.i0, full);
     const bool prof = kChainProf && (dbg & 8u) != 0;
-    unsigned long long t_bar = 0, seg[5] = {0, 0, 0, 0, 0};
 
     if (lo == 0) {
         // column 0: v_0 = e_0 (reference src/hmm.cpp:236-238, previous_cell = 1)
@@ -836,7 +876,7 @@ DEVI void forward_body(const DevContig& dc, ChainShared<HP, R>& sh, uint32_t C, 
         for (int k = 0; k < R; ++k) { x[k] = emission_at(sh.rec[0], p.i0 + k, aj); part += x[k]; }
         if (PHASE == 1) store_col(0, x);
         if (p.tid == 0) fscale[0] = 1.0;
-        write_sums<HP, R>(sh, 0, p, part);
+        write_colsums<HP, R>(sh, 0, p, part);
         if constexpr (PHASE == 2) {  // lo == 0 in phase 2 <=> mid == 0 <=> C == 1
             if constexpr (RING) {
                 double bt[R];
@@ -853,57 +893,70 @@ DEVI void forward_body(const DevContig& dc, ChainShared<HP, R>& sh, uint32_t C, 
         double part = 0.0;
 #pragma unroll
         for (int k = 0; k < R; ++k) part += x[k];
-        write_sums<HP, R>(sh, (lo - 1) & 1u, p, part);
+        write_colsums<HP, R>(sh, (lo - 1) & 1u, p, part);
     }
     lds_barrier();  // Bx
 
-    // sums of column cprev; uniform fallback if the column summed to zero (hmm.cpp:253-267)
-    auto finalize = [&](uint32_t cprev) {
-        read_sums<HP, R>(sh, cprev & 1u, p, Cj, Crow, S);
-        if (!(S > 0.0) || !(S < INFINITY)) {
+    // column cprev summed to zero (or overflowed): the reference replaces it by the uniform column
+    // (hmm.cpp:253-267).  alpha_hat*fsum = 1/H^2 is then an absolute value: it carries neither the
+    // emission exponent X_c nor the column scale; k_bins treats flagged columns accordingly.
+    auto uniform_fallback = [&](uint32_t cprev, double& Cj, double& Crow, double& S) {
 #pragma unroll
-            for (int k = 0; k < R; ++k) x[k] = (p.j < H && p.i0 + k < H) ? unif : 0.0;
-            if (PHASE == 1) store_col(cprev, x);
-            // alpha_hat*fsum = 1/H^2 is an absolute value: it carries neither the emission
-            // exponent X_c nor the column scale; k_bins treats flagged columns accordingly.
-            if (p.tid == 0) fallback[cprev] = 1;
-            Cj = p.j < H ? (double)H * unif : 0.0;
-            Crow = (p.rb + p.lane) < H ? (double)H * unif : 0.0;
-            S = 1.0;
-        }
+        for (int k = 0; k < R; ++k) x[k] = (p.j < H && p.i0 + k < H) ? unif : 0.0;
+        if (PHASE == 1) store_col(cprev, x);
+        if (p.tid == 0) fallback[cprev] = 1;
+        Cj = p.j < H ? (double)H * unif : 0.0;
+        Crow = (p.rb + p.lane) < H ? (double)H * unif : 0.0;
+        S = 1.0;
     };
 
+    // One recursion step: column t from column t-1 (reference src/hmm.cpp:175-273).
+    //   v_t(i,j) = e_t(i,j) * (c0 x(i,j) + c1 (C_i + C_j) + c2 S),  x = stored column t-1, C/S its sums.
+    // alpha_hat_{t-1} = x / S.  Instead of dividing, the new column is scaled by 2^-es,
+    // es = exponent(S): it is (true v_t) * m with m = S * 2^-es in [0.5,1); m goes to the side
+    // array.  The power of two is folded into the emission factor, so nothing on the path from
+    // the barrier to the first multiply-add waits for the total S:
+    //   barrier -> column sums (4 LDS reads) -> c1*C parked in LDS (round trip, gives the u_i)
+    //           || S = DPP reduction of the column sums -> u_j = c1 C_j + c2 S, es, scaled e
+    //           -> R x { add, fma, select, mul, add }  -> partial column sums to LDS -> barrier
     auto step = [&](uint32_t t, double (&vb)[(PHASE == 2 && !RING) ? R : 1]) {
-        // decode the NEXT column's record now; it is consumed one step later, so its LDS latency
-        // overlaps this step's work
-        unsigned long long g0 = prof ? __builtin_amdgcn_s_memtime() : 0, g1;
-        const RecInfo nxt = decode_record<Cfg::UNI>(sh.rec[(t + 1) & 7u], p.j, p.i0, full);
         const unsigned char* rec = sh.rec[t & 7u];
-        // partner column beta'_t out of the ring (landed before B_{t-1}); issued first so that the
-        // 32 KB of LDS reads overlap the sum exchange and the recursion instead of trailing them
-        double bt[RING ? R : 1];
-        if constexpr (RING) ring_read<HP, R>(ring, t, p.i0, p.j, bt);
-        finalize(t - 1);
-        if (prof) { asm volatile("" : "+v"(S)); __builtin_amdgcn_sched_barrier(0); g1 = __builtin_amdgcn_s_memtime(); seg[0] += g1 - g0; g0 = g1; }
-
-        // alpha_hat_{t-1} = x / S.  Scale by 2^-es instead of dividing: the new column is
-        // (true v_t) * m with m = S * 2^-es in [0.5,1); m goes to the side array.
+        double Cj, Crow, Call;
+        read_colsums<HP, R>(sh, (t - 1) & 1u, p, Cj, Crow, Call);
+        double urow = cur.c1 * Crow, ucol = cur.c1 * Cj;
+        publish_u<HP, R>(sh, p, urow, ucol);
+        if constexpr (R <= 16) fetch_u<HP, R>(sh, p, urow, ui);
+        __builtin_amdgcn_sched_barrier(0);  // the LDS round trip must be in flight BEFORE the reduction starts
+        double S = total_sum<HP>(Call);
+        if (__builtin_expect(!(S > 0.0) || !(S < INFINITY), 0)) {
+            uniform_fallback(t - 1, Cj, Crow, S);
+            urow = cur.c1 * Crow; ucol = cur.c1 * Cj;
+            publish_u<HP, R>(sh, p, urow, ucol);
+            if constexpr (R <= 16) fetch_u<HP, R>(sh, p, urow, ui);
+        }
         const int es = exponent_of(S);
         const double m = ldexp(S, -es);
-        const double k0 = ldexp(cur.c0, -es), k1 = ldexp(cur.c1, -es), hk2 = 0.5 * cur.c2 * m;
-        const double uj = fma(k1, Cj, hk2);
-        const double urow = fma(k1, Crow, hk2);
-        if (!Cfg::UNI) {
-            if (p.rg == 0) sh.u[0][p.j] = uj;
-            lds_wave_sync();
-        }
-        if constexpr (R <= 16) row_values<R, Cfg::UNI>(sh.u[Cfg::UNI ? p.wave : 0], urow, p.lane, p.i0, ui);
-        if (prof) { __builtin_amdgcn_s_waitcnt(0xc07f); __builtin_amdgcn_sched_barrier(0); g1 = __builtin_amdgcn_s_memtime(); seg[2] += g1 - g0; g0 = g1; }
-        double part = 0.0;
+        const double uj = fma(cur.c2, S, ucol);
+        const double c0 = cur.c0;
         const bool fast = cur.fast;
         FastE fe = cur.fe;
         if (Cfg::UNI) fe.rowbits = __builtin_amdgcn_readfirstlane(fe.rowbits);
+        double eA = ldexp(fe.eA, -es), eB = ldexp(fe.eB, -es);
+        const double sc = ldexp(1.0, -es);
+        // opaque to the optimiser: it would otherwise sink the ldexp behind the per-row select
+        // (R scalings per step instead of two)
+        asm volatile("" : "+v"(eA), "+v"(eB));
         const uint32_t aj = cur.aj;
+        // LDS reads that nothing on the chain waits for are issued HERE, behind the sum exchange and
+        // the u round trip (LDS returns in order: issued earlier they would delay both) and ahead
+        // of the arithmetic that hides them: the partner column beta'_t out of the ring (32 KB per
+        // workgroup) and the NEXT column's record, which is consumed one step later.
+        __builtin_amdgcn_sched_barrier(0);
+        double bt[RING ? R : 1];
+        if constexpr (RING) ring_read<HP, R>(ring, t, p.i0, p.j, bt);
+        const RecInfo nxt = decode_record<Cfg::UNI>(sh.rec[(t + 1) & 7u], p.j, p.i0, full);
+        __builtin_amdgcn_sched_barrier(0);
+        double part = 0.0;
         // two straight-line loops (a per-state branch on `fast` would split the unrolled body into
         // tiny basic blocks and serialise it)
         if (fast) {
@@ -912,9 +965,9 @@ DEVI void forward_body(const DevContig& dc, ChainShared<HP, R>& sh, uint32_t C, 
                 double uik;
                 if constexpr (R <= 16) uik = ui[k];
                 else uik = readlane_f64(urow, __builtin_amdgcn_readfirstlane((int)((p.i0 + k) & 63u)));
-                const double e = ((fe.rowbits >> k) & 1u) ? fe.eB : fe.eA;
-                x[k] = fma(k0, x[k], uik + uj) * e;
-                part += x[k];
+                const double e = ((fe.rowbits >> k) & 1u) ? eB : eA;
+                if (!(kExp & 16u)) x[k] = fma(c0, x[k], uik + uj) * e;
+                part += (kExp & 16u) ? ((k == 0) ? x[0] * e + uik + uj : 0.0) : x[k];
                 if constexpr (PHASE == 1) { if (k & 1) { store_pair(t, k, x[k - 1], x[k]); __builtin_amdgcn_sched_barrier(0); } }
                 else if constexpr (R > 16) { if ((k & 7) == 7) __builtin_amdgcn_sched_barrier(0); }
             }
@@ -924,29 +977,25 @@ DEVI void forward_body(const DevContig& dc, ChainShared<HP, R>& sh, uint32_t C, 
                 double uik;
                 if constexpr (R <= 16) uik = ui[k];
                 else uik = readlane_f64(urow, __builtin_amdgcn_readfirstlane((int)((p.i0 + k) & 63u)));
-                x[k] = fma(k0, x[k], uik + uj) * emission_at(rec, p.i0 + k, aj);
+                x[k] = fma(c0, x[k], uik + uj) * (emission_at(rec, p.i0 + k, aj) * sc);
                 part += x[k];
                 if constexpr (PHASE == 1) { if (k & 1) { store_pair(t, k, x[k - 1], x[k]); __builtin_amdgcn_sched_barrier(0); } }
                 else if constexpr (R > 16) { if ((k & 7) == 7) __builtin_amdgcn_sched_barrier(0); }
             }
         }
-        if (PHASE == 1) { if (p.tid == 0) fscale[t] = m; }
-        if (prof) { asm volatile("" : "+v"(part)); __builtin_amdgcn_sched_barrier(0); g1 = __builtin_amdgcn_s_memtime(); seg[3] += g1 - g0; g0 = g1; }
-        write_sums<HP, R>(sh, t & 1u, p, part);
-        if (prof) { __builtin_amdgcn_s_waitcnt(0xc07f); __builtin_amdgcn_sched_barrier(0); g1 = __builtin_amdgcn_s_memtime(); seg[4] += g1 - g0; g0 = g1; }
+        write_colsums<HP, R>(sh, t & 1u, p, part);
+        if (p.tid == 0) fscale[t] = m;
         if constexpr (PHASE == 2) {
             // posterior of the column just formed (optimistic: if the column turns out to sum to
-            // zero, finalize() flags it one step later and k_bins re-forms its bins from the
-            // uniform column), then prefetch the next beta' column: a whole step ahead of its use
-            // and AFTER the last read of x, so no vmcnt wait lands inside the recursion
+            // zero, the next step flags it and k_bins re-forms its bins from the uniform column)
             if constexpr (RING) {
                 posterior<HP, R>(sh, part_out, part_slots, cur, t, p, x, bt);
             } else {
+                // register prefetch of the next beta' column: a whole step ahead of its use and
+                // AFTER the last read of x, so no vmcnt wait lands inside the recursion
                 posterior<HP, R>(sh, part_out, part_slots, cur, t, p, x, vb);
                 load_col(t + 1, vb);
             }
-            if (p.tid == 0) fscale[t] = m;
-            if (prof) { __builtin_amdgcn_s_waitcnt(0xc07f); __builtin_amdgcn_sched_barrier(0); g1 = __builtin_amdgcn_s_memtime(); seg[1] += g1 - g0; g0 = g1; }
         }
         if (!Cfg::LOADER && p.wave == 0) {
             rec_stage(t + 2, tq);  // loaded one column ago
@@ -954,19 +1003,21 @@ DEVI void forward_body(const DevContig& dc, ChainShared<HP, R>& sh, uint32_t C, 
         }
         prev = cur;
         cur = nxt;
-        if (prof) { __builtin_amdgcn_s_waitcnt(0xc07f); const unsigned long long b0 = __builtin_amdgcn_s_memtime(); lds_barrier(); t_bar += __builtin_amdgcn_s_memtime() - b0; }
-        else lds_barrier();  // B_t
+        lds_barrier();  // B_t
     };
     const unsigned long long t_begin = prof ? __builtin_amdgcn_s_memtime() : 0;
 
     for (uint32_t t = first; t < hi; ++t) step(t, vA);
     if (prof && p.tid == 0) {
         unsigned long long* o = dc.prof + (PHASE == 1 ? 0 : 8);
-        o[0] = __builtin_amdgcn_s_memtime() - t_begin; o[1] = t_bar; o[2] = hi - first;
-        unsigned long long* q = dc.prof + (PHASE == 1 ? 32 : 40);
-        for (int i = 0; i < 5; ++i) q[i] = seg[i];
+        o[0] = __builtin_amdgcn_s_memtime() - t_begin; o[1] = 0; o[2] = hi - first;
     }
-    finalize(hi - 1);
+    {   // the last column of this phase may itself have summed to zero
+        double Cj, Crow, Call;
+        read_colsums<HP, R>(sh, (hi - 1) & 1u, p, Cj, Crow, Call);
+        double S = total_sum<HP>(Call);
+        if (!(S > 0.0) || !(S < INFINITY)) uniform_fallback(hi - 1, Cj, Crow, S);
+    }
     if constexpr (PHASE == 2) lds_barrier();  // F (keeps the loader's barrier count)
 }
 
@@ -1001,33 +1052,34 @@ DEVI void backward_body(const DevContig& dc, ChainShared<HP, R>& sh, uint32_t C,
     auto rec_stage = [&](int64_t c, unsigned long long w) {
         if (p.lane < (uint32_t)Cfg::WORDS && c >= 0) ((unsigned long long*)sh.rec[(uint32_t)c & 7u])[p.lane] = w;
     };
-    if (Cfg::LOADER && p.wave == (uint32_t)Cfg::NW) {
-        // ------------------------------- loader wave ---------------------------------
-        // step t reads record t+1 (emission/transition of the column behind) and, in phase 2,
-        // record t (alleles for the posterior)
+    if (Cfg::LOADER && p.wave >= (uint32_t)Cfg::NW) {
+        // ------------------------------- loader waves --------------------------------
+        // (see forward_body)  One iteration per recursion step t, i.e. per barrier interval
+        // I_t = (B_{t+1}, B_t).  The compute waves read column t at the top of step t (inside I_t)
+        // and record c during I_c .. I_{c-2} (step t reads record t+1 for the emission/transition
+        // of the column behind and record t for the posterior).  Iteration t issues record t-5
+        // (its slot held record t+3, dead since I_{t+1}) and column t-3 (slot of column t+1, last
+        // read in I_{t+1}); KEEP guarantees column t-1 and record t-1 in LDS before B_t.
+        const uint32_t lw = p.wave - (uint32_t)Cfg::NW;
         LAS unsigned char* lring = (LAS unsigned char*)ring;
         LAS unsigned char* lrec = (LAS unsigned char*)&sh.rec[0][0];
         const gdouble* cols = (const gdouble*)dc.fwd;
-        dma_record<Cfg::RB>(colrec, t0 + 1, (int64_t)C, lrec, p.lane);
-        dma_record<Cfg::RB>(colrec, t0, (int64_t)C, lrec, p.lane);
-        dma_record<Cfg::RB>(colrec, t0 - 1, (int64_t)C, lrec, p.lane);
-        dma_record<Cfg::RB>(colrec, t0 - 2, (int64_t)C, lrec, p.lane);
-        if (RING) {  // v' of the first two columns of this phase
-            dma_column<HP>(cols, t0, (int64_t)C, lring, p.lane);
-            dma_column<HP>(cols, t0 - 1, (int64_t)C, lring, p.lane);
-        }
+        constexpr int QL = RING ? (HP * HP * 8) / 1024 / (Cfg::NLOAD > 0 ? Cfg::NLOAD : 1) : 0;
+        constexpr int KEEP0 = RING ? 2 * (1 + QL) : 4, KEEP1 = 2 * QL;
+        static_assert(KEEP0 < 64 && KEEP1 < 64, "vmcnt is 6 bits");
+        if (lw == 0)
+            for (int q = -1; q < 5; ++q) dma_record<Cfg::RB>(colrec, t0 - q, (int64_t)C, lrec, p.lane);  // t0+1 .. t0-4
+        if (RING)
+            for (int q = 0; q < 3; ++q) dma_column<HP, Cfg::NLOAD>(cols, t0 - q, (int64_t)C, lring, p.lane, lw);
         wait_vmem_all();
         lds_barrier();  // P0
-        // One iteration per recursion step t, i.e. per barrier interval I_t = (B_{t+1}, B_t).  The
-        // compute waves read column t at the top of step t (inside I_t) and record c during
-        // I_c .. I_{c-2}.  Column t-2 issued now lands by the end of iteration t-1, i.e. before
-        // B_{t-1} opens I_{t-2}; its slot (t+1)%3 was last read in I_{t+1}.  Record t-3 likewise.
-        constexpr int NISSUE = 1 + (RING ? (HP * HP * 8) / 1024 : 0);
+        const bool nodma = (kExp & 128u) || (kChainProf && (dc.debug & 4u));
         for (int64_t t = t0; t >= bot; --t) {
-            dma_record<Cfg::RB>(colrec, t - 3, (int64_t)C, lrec, p.lane);
-            if (RING && !(kChainProf && (dc.debug & 4u))) dma_column<HP>(cols, t - 2, (int64_t)C, lring, p.lane);
-            if (t - 3 >= 0) wait_vmem_keep<NISSUE>();
-            else wait_vmem_all();
+            if (lw == 0) dma_record<Cfg::RB>(colrec, t - 5, (int64_t)C, lrec, p.lane);
+            if (RING && !nodma) dma_column<HP, Cfg::NLOAD>(cols, t - 3, (int64_t)C, lring, p.lane, lw);
+            if (t - 5 < 0) wait_vmem_all();  // tail
+            else if (lw == 0) wait_vmem_keep<KEEP0>();
+            else wait_vmem_keep<KEEP1>();
             lds_barrier();  // B_t
         }
         if (PHASE == 2) lds_barrier();  // F
@@ -1056,6 +1108,7 @@ DEVI void backward_body(const DevContig& dc, ChainShared<HP, R>& sh, uint32_t C,
         for (int k = 0; k < R; k += 2) dst[(size_t)(k >> 1) * HP] = v2f64{y[k], y[k + 1]};
     };
     auto store_pair = [&](int64_t c, int k, double a, double b) {  // see forward_body
+        if ((kExp & 1u) || (kChainProf && (dc.debug & 1u))) return;
         gdouble2* dst = (gdouble2*)(cols + (size_t)c * colsz) + (size_t)(p.i0 >> 1) * HP + p.j;
         dst[(size_t)(k >> 1) * HP] = v2f64{a, b};
     };
@@ -1089,28 +1142,33 @@ DEVI void backward_body(const DevContig& dc, ChainShared<HP, R>& sh, uint32_t C,
     lds_barrier();  // P0
     RecInfo cur = decode_record<Cfg::UNI>(sh.rec[(uint32_t)(t0 + 1) & 7u], p.j, p.i0, full);
     const bool prof = kChainProf && (dc.debug & 8u) != 0;
-    unsigned long long t_bar = 0;
     const unsigned long long t_begin = prof ? __builtin_amdgcn_s_memtime() : 0;
 
+    // One recursion step: beta'_t from beta'_{t+1} (reference src/hmm.cpp:275-405).
+    //   w = beta_hat_{t+1} . e_{t+1};  beta~_t(i,j) = c0 w(i,j) + c1 (W_i + W_j) + c2 Sw,  W/Sw sums of w.
+    // The scale 2^-es (es = exponent of the previous column's sum Sy, known analytically through
+    // kappa) is folded into the transition constants before the barrier; behind it the path is
+    //   column sums of w -> c1'W parked in LDS (u_i)  ||  Sw = DPP reduction -> u_j  ->  R x { add, fma }
     auto step = [&](int64_t t, double (&v)[NV]) {
         // beta_hat_{t+1} = y / Sy, uniform if the sum is zero (hmm.cpp:374-380)
-        if (!(Sy > 0.0) || !(Sy < INFINITY)) {
+        if (__builtin_expect(!(Sy > 0.0) || !(Sy < INFINITY), 0)) {
 #pragma unroll
             for (int k = 0; k < R; ++k) y[k] = (p.j < H && p.i0 + k < H) ? unif : 0.0;
             Sy = 1.0;
         }
-        // decode record t now (posterior of this column, emission of the next step); the record of
-        // column t+1 was decoded one step ago
-        const RecInfo nxt = decode_record<Cfg::UNI>(sh.rec[(uint32_t)t & 7u], p.j, p.i0, full);
-        const unsigned char* rec1 = sh.rec[(uint32_t)(t + 1) & 7u];
-        // partner column v'_t out of the ring (landed before B_{t+1}), read ahead of its use
+        // partner column v'_t out of the ring (landed before B_{t+1}), read ahead of its use; then
+        // record t (posterior of this column, emission of the next step; the record of column
+        // t+1 was decoded one step ago)
         double vt[RING ? R : 1];
         if constexpr (RING) ring_read<HP, R>(ring, t, p.i0, p.j, vt);
-        const double c0 = cur.c0, c1 = cur.c1, c2 = cur.c2, kappa = cur.kappa;
+        const RecInfo nxt = decode_record<Cfg::UNI>(sh.rec[(uint32_t)t & 7u], p.j, p.i0, full);
+        const unsigned char* rec1 = sh.rec[(uint32_t)(t + 1) & 7u];
         // beta~_t(true) = A (y/Sy . e) A^T; scaled by 2^-es: beta' = beta~ * m, m = Sy*2^-es
         const int es = exponent_of(Sy);
         const double m = ldexp(Sy, -es);
         if (p.tid == 0) bscale[t] = m;
+        const double k0 = ldexp(cur.c0, -es), k1 = ldexp(cur.c1, -es), k2 = ldexp(cur.c2, -es);
+        const double kap = ldexp(cur.kappa, -es);
         const bool fast = cur.fast;
         FastE fe = cur.fe;
         if (Cfg::UNI) fe.rowbits = __builtin_amdgcn_readfirstlane(fe.rowbits);
@@ -1120,9 +1178,9 @@ DEVI void backward_body(const DevContig& dc, ChainShared<HP, R>& sh, uint32_t C,
         if (fast) {
 #pragma unroll
             for (int k = 0; k < R; ++k) {
-                const double wk = y[k] * (((fe.rowbits >> k) & 1u) ? fe.eB : fe.eA);
+                const double wk = (kExp & 16u) ? y[k] : y[k] * (((fe.rowbits >> k) & 1u) ? fe.eB : fe.eA);
                 if constexpr (KEEPW) w[k] = wk;
-                part += wk;
+                part += (kExp & 16u) ? (k == 0 ? wk : 0.0) : wk;
             }
         } else {
 #pragma unroll
@@ -1134,25 +1192,21 @@ DEVI void backward_body(const DevContig& dc, ChainShared<HP, R>& sh, uint32_t C,
             }
         }
         const uint32_t pb = (uint32_t)t & 1u;
-        write_sums<HP, R>(sh, pb, p, part);
+        write_colsums<HP, R>(sh, pb, p, part);
         if (!Cfg::LOADER && p.wave == 0) {
             rec_stage(t - 2, tq);  // loaded one column ago
             tq = rec_load(t - 3);
         }
-        if (prof) { __builtin_amdgcn_s_waitcnt(0xc07f); const unsigned long long b0 = __builtin_amdgcn_s_memtime(); lds_barrier(); t_bar += __builtin_amdgcn_s_memtime() - b0; }
-        else lds_barrier();  // B_t
-        double Cj, Crow, Sw;
-        read_sums<HP, R>(sh, pb, p, Cj, Crow, Sw);
-        const double k0 = ldexp(c0, -es), k1 = ldexp(c1, -es), hk2 = 0.5 * ldexp(c2 * Sw, -es);
-        const double uj = fma(k1, Cj, hk2);
-        const double urow = fma(k1, Crow, hk2);
-        if (!Cfg::UNI) {
-            lds_wave_sync();  // previous step's reads of sh.u are done
-            if (p.rg == 0) sh.u[0][p.j] = uj;
-            lds_wave_sync();
-        }
+        lds_barrier();  // B_t
+        double Cj, Crow, Call;
+        read_colsums<HP, R>(sh, pb, p, Cj, Crow, Call);
+        const double urow = k1 * Crow, ucol = k1 * Cj;
+        publish_u<HP, R>(sh, p, urow, ucol);
         double ui[R > 16 ? 1 : R];
-        if constexpr (R <= 16) row_values<R, Cfg::UNI>(sh.u[Cfg::UNI ? p.wave : 0], urow, p.lane, p.i0, ui);
+        if constexpr (R <= 16) fetch_u<HP, R>(sh, p, urow, ui);
+        __builtin_amdgcn_sched_barrier(0);  // the LDS round trip must be in flight BEFORE the reduction starts
+        const double Sw = total_sum<HP>(Call);
+        const double uj = fma(k2, Sw, ucol);
         auto beta_loop = [&](auto fast_c) {
 #pragma unroll
             for (int k = 0; k < R; ++k) {
@@ -1163,14 +1217,14 @@ DEVI void backward_body(const DevContig& dc, ChainShared<HP, R>& sh, uint32_t C,
                 double uik;
                 if constexpr (R <= 16) uik = ui[k];
                 else uik = readlane_f64(urow, __builtin_amdgcn_readfirstlane((int)((p.i0 + k) & 63u)));
-                y[k] = fma(k0, wk, uik + uj);  // beta'_t
+                y[k] = (kExp & 16u) ? (k == 0 ? wk + uik + uj : wk) : fma(k0, wk, uik + uj);  // beta'_t
                 if constexpr (PHASE == 1) { if (k & 1) { store_pair(t, k, y[k - 1], y[k]); __builtin_amdgcn_sched_barrier(0); } }
                 else if constexpr (R > 16) { if ((k & 7) == 7) __builtin_amdgcn_sched_barrier(0); }
             }
         };
         if (KEEPW || fast) beta_loop(std::true_type{});
         else beta_loop(std::false_type{});
-        Sy = ldexp(kappa * Sw, -es);  // = sum(beta'_t) over real states
+        Sy = kap * Sw;  // = sum(beta'_t) over real states
         if constexpr (PHASE == 1) {
             if (p.tid == 0) bsum[t] = Sy;
         } else {
@@ -1195,7 +1249,7 @@ DEVI void backward_body(const DevContig& dc, ChainShared<HP, R>& sh, uint32_t C,
     }
     if (prof && p.tid == 0) {
         unsigned long long* o = dc.prof + (PHASE == 1 ? 16 : 24);
-        o[0] = __builtin_amdgcn_s_memtime() - t_begin; o[1] = t_bar; o[2] = (unsigned long long)(t0 - bot + 1);
+        o[0] = __builtin_amdgcn_s_memtime() - t_begin; o[1] = 0; o[2] = (unsigned long long)(t0 - bot + 1);
     }
     if constexpr (PHASE == 2) lds_barrier();  // F (keeps the loader's barrier count)
 }
@@ -1260,11 +1314,11 @@ __global__ __launch_bounds__(256) void k_bins(const DevContig* __restrict__ cont
             }
     } else
     for (uint32_t a = 0; a < nl; ++a) {
-        const double* src = dc.part + ((size_t)c * dc.part_slots + a) * T;
+        const double* src = dc.part + (((size_t)c * (dc.part_slots >> 1) + (a >> 1)) * T) * 2 + (a & 1u);  // pair layout
         for (uint32_t b = 0; b < nl; ++b) {
             double s = 0.0;
             for (uint32_t t = lane; t < T; t += 64)
-                if (al[t % HP] == b) s += src[t];
+                if (al[t % HP] == b) s += src[(size_t)t * 2];
             const double tot = wave_sum(s);
             if (lane == 0) {
                 const uint32_t lo = a < b ? a : b, hi = a < b ? b : a;
@@ -1300,7 +1354,7 @@ __global__ __launch_bounds__(256) void k_bins(const DevContig* __restrict__ cont
 template <int HP, int R, int VBUF, bool KEEPW, int PHASE>
 static void launch_one(const DevContig* d_contigs, uint32_t n_contigs, hipStream_t s) {
     using Cfg = ChainCfg<HP, R>;
-    const size_t dyn = (Cfg::LOADER && PHASE == 2) ? (size_t)3 * HP * HP * 8 : 0;  // partner-column ring
+    const size_t dyn = (Cfg::LOADER && PHASE == 2) ? (size_t)4 * HP * HP * 8 : 0;  // partner-column ring (4 slots)
     auto kern = k_sweep<HP, R, VBUF, KEEPW, PHASE>;
     static bool attr_set = false;
     if (dyn > 0 && !attr_set) {  // more than the default 64 KiB of LDS per workgroup

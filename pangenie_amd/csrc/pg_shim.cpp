@@ -331,6 +331,8 @@ extern "C" pg_job* pg_job_create(int device, uint32_t n_contigs, const pg_contig
         uint64_t nl = 0, maxA = 1;
         for (uint32_t v = 0; v < c.V; ++v) { uint64_t A = b.allele_off[v + 1] - b.allele_off[v]; nl += A * (A + 1) / 2; if (A > maxA) maxA = A; }
         c.part_slots = (uint32_t)(maxA < PG_AMAX ? maxA : PG_AMAX);
+        c.part_slots = (c.part_slots + 1u) & ~1u;  // partials are stored as allele pairs (16-byte stores)
+        if (c.part_slots < 2) c.part_slots = 2;
         c.n_lik = nl;
         plan[i].kept = take(c.V);
         plan[i].fback = take(c.V);
