@@ -194,7 +194,7 @@ def main():
         achieved = dom_bytes / (dom_ms * 1e-3) / 1e9 if dom_ms > 0 else 0.0
         sweep_ms = kms.get("k_sweep_phase1", 0.0) + kms.get("k_sweep_phase2", 0.0)
         traffic, traffic_src = (None, None)
-        if V == w["V"] and n_chains == 1:
+        if V == w["V"]:  # the committed profile is of this very command (same seeds, same chains)
             traffic, traffic_src = profiled_traffic(args.workload, 1 if dom == "k_sweep_phase1" else 2)
         out = {
             "metric": "genotyped variants/sec (whole node) at H haplotypes; HBM GB/s vs roofline",

@@ -6,7 +6,7 @@ H = int(sys.argv[2]) if len(sys.argv) > 2 else 64
 from pangenie_amd import build as _build
 _prof_lib = os.path.join(os.getcwd(), "tools", "_build", "libpangenie_hmm_prof.so")
 if not os.environ.get("PG_PROF_PREBUILT"):
-    _build.build_hip(out=_prof_lib, defines=("PG_CHAIN_PROF",))
+    _build.build_hip(out=_prof_lib, defines=("PG_CHAIN_PROF=1",))
 os.environ["PANGENIE_HMM_LIB"] = _prof_lib
 from pangenie_amd import hmm
 from pangenie_amd.panel import synthetic_panel, default_table_args
@@ -19,6 +19,4 @@ p = job.profile_counters(0).astype(float)
 print("H", H, "dbg", os.environ["PG_DEBUG"], "phase1 ms", ms["k_sweep_phase1"], "phase2 ms", ms["k_sweep_phase2"], "cols", C)
 for name, o in (("forward  phase1", 0), ("forward  phase2", 8), ("backward phase1", 16), ("backward phase2", 24)):
     n = max(p[o + 2], 1)
-    print(" %s: %6.0f cycles/col total, %5.0f of them waiting at the barrier (%d steps)" % (name, p[o] / n, p[o + 1] / n, n))
-for name, o, n in (("forward phase1", 32, p[2]), ("forward phase2", 40, p[10])):
-    print(" %s segments cycles/col: sums %.0f | posterior %.0f | scale+rows %.0f | main(+store) %.0f | write_sums %.0f" % ((name,) + tuple(p[o:o + 5] / max(n, 1))))
+    print(" %s: %6.0f cycles/col (%d steps)" % (name, p[o] / n, n))
