@@ -470,8 +470,8 @@ __global__ __launch_bounds__(256) void k_records(const DevContig* __restrict__ c
 //  chain).  Same for the backward column.  Results are the reference's values up to fp64
 //  rounding; no drift because every step renormalises to within a factor of 2.
 // ------------------------------------------------------------------------------------------
-// In-kernel cycle profiling (tools/prof_chain.py) exists only in builds with -DPG_CHAIN_PROF; the
-// product library carries none of it.
+// In-kernel cycle counters per role (tools/prof_chain.py, tools/exp_chain.py; PG_DEBUG bit 8) exist
+// only in builds with -DPG_CHAIN_PROF; the product library carries none of it.
 // Timing experiments (tools/exp_chain.py): -DPG_EXP=<mask> builds a variant with one ingredient of
 // the recursion step removed (results are then WRONG; only the kernel time is of interest).
 #ifndef PG_EXP
@@ -480,10 +480,8 @@ __global__ __launch_bounds__(256) void k_records(const DevContig* __restrict__ c
 static constexpr unsigned kExp = PG_EXP;
 #ifdef PG_CHAIN_PROF
 static constexpr bool kChainProf = true;
-static constexpr bool kChainProfSteps = (PG_CHAIN_PROF + 0) != 1;  // -DPG_CHAIN_PROF=1: per-role totals only
 #else
 static constexpr bool kChainProf = false;
-static constexpr bool kChainProfSteps = false;
 #endif
 #define GAS __attribute__((address_space(1)))
 typedef GAS double gdouble;
@@ -807,7 +805,7 @@ DEVI void forward_body(const DevContig& dc, ChainShared<HP, R>& sh, uint32_t C, 
         wait_vmem_all();
         lds_barrier();  // P0: first records staged
         lds_barrier();  // Bx: column lo initialised / resumed
-        const bool nodma = (kExp & 128u) || (kChainProf && (dc.debug & 4u));
+        const bool nodma = (kExp & 128u) != 0;
         for (uint32_t t = first; t < hi; ++t) {
             if (lw == 0) dma_record<Cfg::RB>(colrec, (int64_t)t + 6, C, lrec, p.lane);
             if (RING && !nodma) dma_column<HP, Cfg::NLOAD>(cols, (int64_t)t + 3, C, lring, p.lane, lw);
@@ -832,7 +830,7 @@ DEVI void forward_body(const DevContig& dc, ChainShared<HP, R>& sh, uint32_t C, 
     const uint32_t dbg = dc.debug;
 
     auto store_col = [&](uint32_t c, const double (&x)[R]) {
-        if (kChainProf && (dbg & 1u)) return;
+        if (kExp & 1u) return;
         gdouble2* dst = (gdouble2*)(fwd + (size_t)c * colsz) + (size_t)(p.i0 >> 1) * HP + p.j;
 #pragma unroll
         for (int k = 0; k < R; k += 2) dst[(size_t)(k >> 1) * HP] = v2f64{x[k], x[k + 1]};
@@ -841,7 +839,7 @@ DEVI void forward_body(const DevContig& dc, ChainShared<HP, R>& sh, uint32_t C, 
     // stores per wave queue behind each other in the texture-address unit (store-issue bound);
     // spread between the arithmetic of the following rows they cost their issue slots only
     auto store_pair = [&](uint32_t c, int k, double a, double b) {
-        if ((kExp & 1u) || (kChainProf && (dbg & 1u))) return;
+        if (kExp & 1u) return;
         gdouble2* dst = (gdouble2*)(fwd + (size_t)c * colsz) + (size_t)(p.i0 >> 1) * HP + p.j;
         dst[(size_t)(k >> 1) * HP] = v2f64{a, b};
     };
@@ -1073,7 +1071,7 @@ DEVI void backward_body(const DevContig& dc, ChainShared<HP, R>& sh, uint32_t C,
             for (int q = 0; q < 3; ++q) dma_column<HP, Cfg::NLOAD>(cols, t0 - q, (int64_t)C, lring, p.lane, lw);
         wait_vmem_all();
         lds_barrier();  // P0
-        const bool nodma = (kExp & 128u) || (kChainProf && (dc.debug & 4u));
+        const bool nodma = (kExp & 128u) != 0;
         for (int64_t t = t0; t >= bot; --t) {
             if (lw == 0) dma_record<Cfg::RB>(colrec, t - 5, (int64_t)C, lrec, p.lane);
             if (RING && !nodma) dma_column<HP, Cfg::NLOAD>(cols, t - 3, (int64_t)C, lring, p.lane, lw);
@@ -1108,7 +1106,7 @@ DEVI void backward_body(const DevContig& dc, ChainShared<HP, R>& sh, uint32_t C,
         for (int k = 0; k < R; k += 2) dst[(size_t)(k >> 1) * HP] = v2f64{y[k], y[k + 1]};
     };
     auto store_pair = [&](int64_t c, int k, double a, double b) {  // see forward_body
-        if ((kExp & 1u) || (kChainProf && (dc.debug & 1u))) return;
+        if (kExp & 1u) return;
         gdouble2* dst = (gdouble2*)(cols + (size_t)c * colsz) + (size_t)(p.i0 >> 1) * HP + p.j;
         dst[(size_t)(k >> 1) * HP] = v2f64{a, b};
     };
