@@ -895,17 +895,19 @@ DEVI void forward_body(const DevContig& dc, ChainShared<HP, R>& sh, uint32_t C, 
     }
     lds_barrier();  // Bx
 
-    // column cprev summed to zero (or overflowed): the reference replaces it by the uniform column
-    // (hmm.cpp:253-267).  alpha_hat*fsum = 1/H^2 is then an absolute value: it carries neither the
-    // emission exponent X_c nor the column scale; k_bins treats flagged columns accordingly.
-    auto uniform_fallback = [&](uint32_t cprev, double& Cj, double& Crow, double& S) {
+    // Column cprev summed to zero: the reference replaces it by the uniform column (hmm.cpp:253-267).
+    // alpha_hat*fsum = 1/H^2 is then an absolute value: it carries neither the emission exponent
+    // X_c nor the column scale; k_bins treats flagged columns accordingly.  The register copy x of
+    // the column (all zeros) is left alone — the caller folds the uniform column into u_j — so the
+    // rare path changes no register array (no copies on the hot path).
+    auto flag_uniform = [&](uint32_t cprev) {
+        if (PHASE == 1) {
+            double xu[R];
 #pragma unroll
-        for (int k = 0; k < R; ++k) x[k] = (p.j < H && p.i0 + k < H) ? unif : 0.0;
-        if (PHASE == 1) store_col(cprev, x);
+            for (int k = 0; k < R; ++k) xu[k] = (p.j < H && p.i0 + k < H) ? unif : 0.0;
+            store_col(cprev, xu);
+        }
         if (p.tid == 0) fallback[cprev] = 1;
-        Cj = p.j < H ? (double)H * unif : 0.0;
-        Crow = (p.rb + p.lane) < H ? (double)H * unif : 0.0;
-        S = 1.0;
     };
 
     // One recursion step: column t from column t-1 (reference src/hmm.cpp:175-273).
@@ -926,16 +928,20 @@ DEVI void forward_body(const DevContig& dc, ChainShared<HP, R>& sh, uint32_t C, 
         if constexpr (R <= 16) fetch_u<HP, R>(sh, p, urow, ui);
         __builtin_amdgcn_sched_barrier(0);  // the LDS round trip must be in flight BEFORE the reduction starts
         double S = total_sum<HP>(Call);
-        if (__builtin_expect(!(S > 0.0) || !(S < INFINITY), 0)) {
-            uniform_fallback(t - 1, Cj, Crow, S);
-            urow = cur.c1 * Crow; ucol = cur.c1 * Cj;
-            publish_u<HP, R>(sh, p, urow, ucol);
-            if constexpr (R <= 16) fetch_u<HP, R>(sh, p, urow, ui);
+        double uj = fma(cur.c2, S, ucol);
+        double c0 = cur.c0;
+        if (__builtin_expect(!(S > 0.0), 0)) {
+            // uniform column: x = 1/H^2, C = 1/H, S = 1.  The old column and its sums are all zero
+            // (so are the u_i already fetched): everything goes into u_j, c0 * x drops out.
+            flag_uniform(t - 1);
+            const double Cu = (double)H * unif;
+            S = 1.0;
+            uj = fma(cur.c0, unif, fma(cur.c2, 1.0, 2.0 * cur.c1 * Cu));
+            urow = 0.0;  // (HP = 128 takes its u_i from urow by readlane: zero like the fetched u_i)
+            c0 = 0.0;
         }
         const int es = exponent_of(S);
         const double m = ldexp(S, -es);
-        const double uj = fma(cur.c2, S, ucol);
-        const double c0 = cur.c0;
         const bool fast = cur.fast;
         FastE fe = cur.fe;
         if (Cfg::UNI) fe.rowbits = __builtin_amdgcn_readfirstlane(fe.rowbits);
@@ -1013,8 +1019,7 @@ DEVI void forward_body(const DevContig& dc, ChainShared<HP, R>& sh, uint32_t C, 
     {   // the last column of this phase may itself have summed to zero
         double Cj, Crow, Call;
         read_colsums<HP, R>(sh, (hi - 1) & 1u, p, Cj, Crow, Call);
-        double S = total_sum<HP>(Call);
-        if (!(S > 0.0) || !(S < INFINITY)) uniform_fallback(hi - 1, Cj, Crow, S);
+        if (!(total_sum<HP>(Call) > 0.0)) flag_uniform(hi - 1);
     }
     if constexpr (PHASE == 2) lds_barrier();  // F (keeps the loader's barrier count)
 }
@@ -1236,6 +1241,97 @@ DEVI void backward_body(const DevContig& dc, ChainShared<HP, R>& sh, uint32_t C,
         cur = nxt;
     };
 
+    if constexpr (R <= 16) {
+        // -------------------------------------------------------------------------------------
+        // Fused formulation (all loader-wave configurations).  The emission multiply of the NEXT
+        // step (w = beta_hat . e) is done in the same loop that forms beta'_t, so a step is
+        //   barrier -> column sums of w -> u round trip || total -> R x { add, fma, select, mul, add }
+        //           -> partial column sums of the new w -> barrier
+        // exactly like the forward step: one dependent segment per column instead of two.
+        // -------------------------------------------------------------------------------------
+        static_assert(PHASE == 1 || RING, "loader configurations read partner columns from the LDS ring");
+        double w[R];
+        auto rowbits_of = [&](const RecInfo& ri) -> uint32_t {
+            return Cfg::UNI ? (uint32_t)__builtin_amdgcn_readfirstlane(ri.fe.rowbits) : ri.fe.rowbits;
+        };
+        {   // prologue: w = beta_hat_{t0+1} . e_{t0+1}
+            if (!(Sy > 0.0)) {  // (phase 2 resuming behind an all-zero column, hmm.cpp:374-380)
+#pragma unroll
+                for (int k = 0; k < R; ++k) y[k] = (p.j < H && p.i0 + k < H) ? unif : 0.0;
+                Sy = 1.0;
+            }
+            const unsigned char* rec1 = sh.rec[(uint32_t)(t0 + 1) & 7u];
+            const uint32_t rb1 = rowbits_of(cur);
+            double part = 0.0;
+            if (cur.fast) {
+#pragma unroll
+                for (int k = 0; k < R; ++k) { w[k] = y[k] * (((rb1 >> k) & 1u) ? cur.fe.eB : cur.fe.eA); part += w[k]; }
+            } else {
+#pragma unroll
+                for (int k = 0; k < R; ++k) { w[k] = y[k] * emission_at(rec1, p.i0 + k, cur.aj); part += w[k]; }
+            }
+            write_colsums<HP, R>(sh, (uint32_t)t0 & 1u, p, part);
+        }
+        for (int64_t t = t0; t >= bot; --t) {
+            // scale of this column: 2^-es, es = exponent of the previous column's sum (known
+            // analytically through kappa, so all of this sits in front of the barrier)
+            const int es = exponent_of(Sy);
+            const double m = ldexp(Sy, -es);
+            if (p.tid == 0) bscale[t] = m;
+            const double k0 = ldexp(cur.c0, -es), k1 = ldexp(cur.c1, -es), k2 = ldexp(cur.c2, -es);
+            const double kap = ldexp(cur.kappa, -es);
+            double vt[RING ? R : 1];
+            if constexpr (RING) ring_read<HP, R>(ring, t, p.i0, p.j, vt);  // landed before B_{t+1}
+            const RecInfo nxt = decode_record<Cfg::UNI>(sh.rec[(uint32_t)t & 7u], p.j, p.i0, full);
+            const unsigned char* rec0 = sh.rec[(uint32_t)t & 7u];
+            const uint32_t rb0 = rowbits_of(nxt);
+            lds_barrier();  // B_t
+            double Cj, Crow, Call;
+            read_colsums<HP, R>(sh, (uint32_t)t & 1u, p, Cj, Crow, Call);
+            const double urow = k1 * Crow, ucol = k1 * Cj;
+            publish_u<HP, R>(sh, p, urow, ucol);
+            double ui[R];
+            fetch_u<HP, R>(sh, p, urow, ui);
+            __builtin_amdgcn_sched_barrier(0);  // the LDS round trip must be in flight BEFORE the reduction starts
+            const double Sw = total_sum<HP>(Call);
+            const double uj = fma(k2, Sw, ucol);
+            const double Snew = kap * Sw;  // = sum(beta'_t) over real states
+            double part = 0.0;
+            if (__builtin_expect(!(Snew > 0.0), 0)) {
+                // beta~_t is all zero: its own posteriors are 0, the next step starts from the
+                // uniform column (hmm.cpp:374-380)
+#pragma unroll
+                for (int k = 0; k < R; ++k) {
+                    y[k] = 0.0;
+                    const double bu = (p.j < H && p.i0 + k < H) ? unif : 0.0;
+                    w[k] = bu * (nxt.fast ? (((rb0 >> k) & 1u) ? nxt.fe.eB : nxt.fe.eA) : emission_at(rec0, p.i0 + k, nxt.aj));
+                    part += w[k];
+                }
+                if constexpr (PHASE == 1) store_col(t, y);
+            } else if (nxt.fast) {
+#pragma unroll
+                for (int k = 0; k < R; ++k) {
+                    y[k] = (kExp & 16u) ? w[k] : fma(k0, w[k], ui[k] + uj);  // beta'_t
+                    if constexpr (PHASE == 1) { if (k & 1) { store_pair(t, k, y[k - 1], y[k]); __builtin_amdgcn_sched_barrier(0); } }
+                    w[k] = (kExp & 16u) ? y[k] : y[k] * (((rb0 >> k) & 1u) ? nxt.fe.eB : nxt.fe.eA);
+                    part += (kExp & 16u) ? (k == 0 ? w[0] + ui[k] + uj : 0.0) : w[k];
+                }
+            } else {
+#pragma unroll
+                for (int k = 0; k < R; ++k) {
+                    y[k] = fma(k0, w[k], ui[k] + uj);
+                    if constexpr (PHASE == 1) { if (k & 1) { store_pair(t, k, y[k - 1], y[k]); __builtin_amdgcn_sched_barrier(0); } }
+                    w[k] = y[k] * emission_at(rec0, p.i0 + k, nxt.aj);
+                    part += w[k];
+                }
+            }
+            write_colsums<HP, R>(sh, (uint32_t)(t - 1) & 1u, p, part);
+            if constexpr (PHASE == 1) { if (p.tid == 0) bsum[t] = Snew; }
+            else posterior<HP, R>(sh, part_out, part_slots, nxt, (uint32_t)t, p, vt, y);
+            Sy = Snew > 0.0 ? Snew : 1.0;
+            cur = nxt;
+        }
+    } else
     for (int64_t t = t0; t >= bot; t -= 2) {
         if constexpr (PHASE == 2 && VBUF == 2 && !RING) {
             step(t, vA);

@@ -98,7 +98,7 @@ __global__ void probe(double* out, uint64_t* t, double seed, double* gbuf) {
 int main() {
     double *out, *g; uint64_t* t;
     hipMalloc(&out, 4096 * 8); hipMalloc(&t, 64 * 8); hipMalloc(&g, 1 << 24);
-    for (int threads : {64, 256, 512}) {
+    for (int threads : {64, 256, 320, 384, 512}) {
         for (int rep = 0; rep < 2; ++rep) { hipLaunchKernelGGL(probe, dim3(1), dim3(threads), 0, 0, out, t, 1.0, g); hipDeviceSynchronize(); }
         uint64_t h[16]; hipMemcpy(h, t, sizeof(h), hipMemcpyDeviceToHost);
         printf("threads=%d: dep add %.1f cyc/op | dep fma %.1f | 8-indep fma %.1f cyc/op | wave_sum %.0f | lds rt %.0f | readlane dbl %.1f | barrier %.0f | store dwordx2 %.1f cyc/instr | frexp+ldexp+add %.0f | exch(barrier+4reads) %.0f\n",
