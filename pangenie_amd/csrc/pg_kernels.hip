@@ -582,7 +582,7 @@ DEVI RecInfo decode_record(const unsigned char* rec, uint32_t j, uint32_t i0, bo
     r.c1 = *(const double*)(rec + PG_REC_C1);
     r.c2 = *(const double*)(rec + PG_REC_C2);
     r.kappa = *(const double*)(rec + PG_REC_KAPPA);
-    r.nl = rec[PG_REC_NLOCAL];
+    r.nl = (uint32_t)__builtin_amdgcn_readfirstlane((int)rec[PG_REC_NLOCAL]);  // same record for every lane: keep it scalar
     r.fe = fast_setup<UNI>(rec, j, i0);
     r.aj = col_allele(rec, j);
     r.fast = full && r.nl <= 2;
@@ -652,15 +652,15 @@ DEVI void read_colsums(const ChainShared<HP, R>& sh, uint32_t pb, const ThreadPo
     using Cfg = ChainCfg<HP, R>;
     if (kExp & 64u) { Cj = Crow = Call = 1.0 / HP; return; }
     if constexpr (HP <= 64) {
-        Cj = 0.0;
+        Cj = sh.psum[pb][0][p.j];
 #pragma unroll
-        for (int g = 0; g < Cfg::NRG; ++g) Cj += sh.psum[pb][g][p.j];
+        for (int g = 1; g < Cfg::NRG; ++g) Cj += sh.psum[pb][g][p.j];
         Crow = Call = Cj;
     } else {
         static_assert(HP == 128, "two 64-column blocks");
-        double ca = 0.0, cb = 0.0;
+        double ca = sh.psum[pb][0][p.lane], cb = sh.psum[pb][0][64 + p.lane];
 #pragma unroll
-        for (int g = 0; g < Cfg::NRG; ++g) { ca += sh.psum[pb][g][p.lane]; cb += sh.psum[pb][g][64 + p.lane]; }
+        for (int g = 1; g < Cfg::NRG; ++g) { ca += sh.psum[pb][g][p.lane]; cb += sh.psum[pb][g][64 + p.lane]; }
         Cj = p.j >= 64u ? cb : ca;  // wave-uniform choices
         Crow = p.rb ? cb : ca;
         Call = ca + cb;
@@ -1355,7 +1355,9 @@ __global__ __launch_bounds__((ChainCfg<HP, R>::TT)) void k_sweep(const DevContig
     extern __shared__ __attribute__((aligned(16))) unsigned char dyn_ring[];  // phase 2: 3 column slots
     const DevContig& dc = contigs[blockIdx.x];
     if (dc.HP != (uint32_t)HP) return;
-    const uint32_t C = *dc.n_cols;
+    // (written by k_compact: a vector load as far as the compiler knows — make the trip count, and
+    // with it every column index, ring slot and address derived from it, wave-uniform again)
+    const uint32_t C = (uint32_t)__builtin_amdgcn_readfirstlane((int)*dc.n_cols);
     if (C == 0) return;
     if (blockIdx.y == 0) forward_body<HP, R, PHASE>(dc, sh, C, dyn_ring);
     else backward_body<HP, R, VBUF, KEEPW, PHASE>(dc, sh, C, dyn_ring);
