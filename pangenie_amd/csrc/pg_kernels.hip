@@ -592,6 +592,14 @@ DEVI RecInfo decode_record(const unsigned char* rec, uint32_t j, uint32_t i0, bo
 // Phase-2 partner columns reach the compute waves through an LDS ring filled by the loader wave
 // with LDS-DMA (global_load_lds_dwordx4: HBM -> LDS, no VGPRs), two columns ahead of use.
 #define LAS __attribute__((address_space(3)))
+// Partner-column ring: PG_RING_SLOTS column slots in dynamic LDS, prefetch distance SLOTS-1 columns.
+// 4 slots (128 KB at HP = 64) give every DMA two full steps to land — what a lone workgroup per CU
+// needs; 2 slots (64 KB) let two workgroups share a CU when hundreds of chains are resident.
+#ifndef PG_RING_SLOTS
+#define PG_RING_SLOTS 4
+#endif
+static constexpr int kRingSlots = PG_RING_SLOTS, kRingDist = PG_RING_SLOTS - 1;
+static_assert(kRingSlots == 2 || kRingSlots == 4, "ring slots: power of two");
 // loader wave `part` of NPARTS moves its share of the column (1 KB per wave-instruction)
 template <int HP, int NPARTS>
 DEVI void dma_column(const gdouble* cols, int64_t c, int64_t C, LAS unsigned char* ring, uint32_t lane, uint32_t part) {
@@ -599,7 +607,7 @@ DEVI void dma_column(const gdouble* cols, int64_t c, int64_t C, LAS unsigned cha
     constexpr uint32_t COLB = HP * HP * 8u, SHARE = COLB / (NPARTS > 0 ? NPARTS : 1);
     static_assert(SHARE % 1024u == 0, "column share must be a whole number of wave transfers");
     const GAS char* g = (const GAS char*)(cols + (size_t)c * HP * HP) + part * SHARE + lane * 16u;
-    LAS unsigned char* l = ring + (uint32_t)(c & 3) * COLB + part * SHARE;  // wave-uniform base; lane l lands at +16*l
+    LAS unsigned char* l = ring + (uint32_t)(c & (kRingSlots - 1)) * COLB + part * SHARE;  // wave-uniform base; lane l lands at +16*l
 #pragma unroll 4
     for (uint32_t q = 0; q < SHARE / 1024u; ++q)
         __builtin_amdgcn_global_load_lds((const GAS void*)(g + q * 1024u), (LAS void*)(l + q * 1024u), 16, 0, 0);
@@ -628,7 +636,7 @@ DEVI void ring_read(const unsigned char* ring, int64_t c, const uint32_t i0, con
         for (int k = 0; k < R; ++k) v[k] = 1.0;
         return;
     }
-    const v2f64* slot = (const v2f64*)(ring + (size_t)(c & 3) * (HP * HP * 8u)) + (size_t)(i0 >> 1) * HP + j;
+    const v2f64* slot = (const v2f64*)(ring + (size_t)(c & (kRingSlots - 1)) * (HP * HP * 8u)) + (size_t)(i0 >> 1) * HP + j;
 #pragma unroll
     for (int k = 0; k < R; k += 2) { const v2f64 t = slot[(size_t)(k >> 1) * HP]; v[k] = t.x; v[k + 1] = t.y; }
 }
@@ -794,21 +802,22 @@ DEVI void forward_body(const DevContig& dc, ChainShared<HP, R>& sh, uint32_t C, 
         LAS unsigned char* lrec = (LAS unsigned char*)&sh.rec[0][0];
         const gdouble* cols = (const gdouble*)dc.fwd;
         constexpr int QL = RING ? (HP * HP * 8) / 1024 / (Cfg::NLOAD > 0 ? Cfg::NLOAD : 1) : 0;  // column transfers per loader per iteration
-        constexpr int KEEP0 = RING ? 2 * (1 + QL) : 4, KEEP1 = 2 * QL;
+        constexpr int KSL = kRingDist - 1;  // iterations of slack a column transfer gets
+        constexpr int KEEP0 = RING ? KSL * (1 + QL) : 4, KEEP1 = KSL * QL;
         static_assert(KEEP0 < 64 && KEEP1 < 64, "vmcnt is 6 bits");
         if (lw == 0) {
             if (lo == 0) dma_record<Cfg::RB>(colrec, 0, C, lrec, p.lane);
             for (int q = 0; q < 6; ++q) dma_record<Cfg::RB>(colrec, (int64_t)first + q, C, lrec, p.lane);
         }
         if (RING)
-            for (int q = 0; q < 3; ++q) dma_column<HP, Cfg::NLOAD>(cols, (int64_t)lo + q, C, lring, p.lane, lw);
+            for (int q = 0; q < kRingDist; ++q) dma_column<HP, Cfg::NLOAD>(cols, (int64_t)lo + q, C, lring, p.lane, lw);
         wait_vmem_all();
         lds_barrier();  // P0: first records staged
         lds_barrier();  // Bx: column lo initialised / resumed
         const bool nodma = (kExp & 128u) != 0;
         for (uint32_t t = first; t < hi; ++t) {
             if (lw == 0) dma_record<Cfg::RB>(colrec, (int64_t)t + 6, C, lrec, p.lane);
-            if (RING && !nodma) dma_column<HP, Cfg::NLOAD>(cols, (int64_t)t + 3, C, lring, p.lane, lw);
+            if (RING && !nodma) dma_column<HP, Cfg::NLOAD>(cols, (int64_t)t + kRingDist, C, lring, p.lane, lw);
             if ((int64_t)t + 6 >= (int64_t)C) wait_vmem_all();  // tail
             else if (lw == 0) wait_vmem_keep<KEEP0>();
             else wait_vmem_keep<KEEP1>();
@@ -1068,18 +1077,19 @@ DEVI void backward_body(const DevContig& dc, ChainShared<HP, R>& sh, uint32_t C,
         LAS unsigned char* lrec = (LAS unsigned char*)&sh.rec[0][0];
         const gdouble* cols = (const gdouble*)dc.fwd;
         constexpr int QL = RING ? (HP * HP * 8) / 1024 / (Cfg::NLOAD > 0 ? Cfg::NLOAD : 1) : 0;
-        constexpr int KEEP0 = RING ? 2 * (1 + QL) : 4, KEEP1 = 2 * QL;
+        constexpr int KSL = kRingDist - 1;  // iterations of slack a column transfer gets
+        constexpr int KEEP0 = RING ? KSL * (1 + QL) : 4, KEEP1 = KSL * QL;
         static_assert(KEEP0 < 64 && KEEP1 < 64, "vmcnt is 6 bits");
         if (lw == 0)
             for (int q = -1; q < 5; ++q) dma_record<Cfg::RB>(colrec, t0 - q, (int64_t)C, lrec, p.lane);  // t0+1 .. t0-4
         if (RING)
-            for (int q = 0; q < 3; ++q) dma_column<HP, Cfg::NLOAD>(cols, t0 - q, (int64_t)C, lring, p.lane, lw);
+            for (int q = 0; q < kRingDist; ++q) dma_column<HP, Cfg::NLOAD>(cols, t0 - q, (int64_t)C, lring, p.lane, lw);
         wait_vmem_all();
         lds_barrier();  // P0
         const bool nodma = (kExp & 128u) != 0;
         for (int64_t t = t0; t >= bot; --t) {
             if (lw == 0) dma_record<Cfg::RB>(colrec, t - 5, (int64_t)C, lrec, p.lane);
-            if (RING && !nodma) dma_column<HP, Cfg::NLOAD>(cols, t - 3, (int64_t)C, lring, p.lane, lw);
+            if (RING && !nodma) dma_column<HP, Cfg::NLOAD>(cols, t - kRingDist, (int64_t)C, lring, p.lane, lw);
             if (t - 5 < 0) wait_vmem_all();  // tail
             else if (lw == 0) wait_vmem_keep<KEEP0>();
             else wait_vmem_keep<KEEP1>();
@@ -1352,7 +1362,7 @@ DEVI void backward_body(const DevContig& dc, ChainShared<HP, R>& sh, uint32_t C,
 template <int HP, int R, int VBUF, bool KEEPW, int PHASE>
 __global__ __launch_bounds__((ChainCfg<HP, R>::TT)) void k_sweep(const DevContig* __restrict__ contigs) {
     __shared__ ChainShared<HP, R> sh;
-    extern __shared__ __attribute__((aligned(16))) unsigned char dyn_ring[];  // phase 2: 3 column slots
+    extern __shared__ __attribute__((aligned(16))) unsigned char dyn_ring[];  // phase 2: kRingSlots column slots
     const DevContig& dc = contigs[blockIdx.x];
     if (dc.HP != (uint32_t)HP) return;
     // (written by k_compact: a vector load as far as the compiler knows — make the trip count, and
@@ -1450,7 +1460,7 @@ __global__ __launch_bounds__(256) void k_bins(const DevContig* __restrict__ cont
 template <int HP, int R, int VBUF, bool KEEPW, int PHASE>
 static void launch_one(const DevContig* d_contigs, uint32_t n_contigs, hipStream_t s) {
     using Cfg = ChainCfg<HP, R>;
-    const size_t dyn = (Cfg::LOADER && PHASE == 2) ? (size_t)4 * HP * HP * 8 : 0;  // partner-column ring (4 slots)
+    const size_t dyn = (Cfg::LOADER && PHASE == 2) ? (size_t)kRingSlots * HP * HP * 8 : 0;  // partner-column ring
     auto kern = k_sweep<HP, R, VBUF, KEEPW, PHASE>;
     static bool attr_set = false;
     if (dyn > 0 && !attr_set) {  // more than the default 64 KiB of LDS per workgroup
