@@ -1418,17 +1418,36 @@ __global__ __launch_bounds__(256) void k_bins(const DevContig* __restrict__ cont
                     s_bins[wave][tri_local(lo2, hi2)] += tot;
                 }
             }
-    } else
-    for (uint32_t a = 0; a < nl; ++a) {
-        const double* src = dc.part + (((size_t)c * (dc.part_slots >> 1) + (a >> 1)) * T) * 2 + (a & 1u);  // pair layout
-        for (uint32_t b = 0; b < nl; ++b) {
-            double s = 0.0;
-            for (uint32_t t = lane; t < T; t += 64)
-                if (al[t % HP] == b) s += src[(size_t)t * 2];
-            const double tot = wave_sum(s);
-            if (lane == 0) {
-                const uint32_t lo = a < b ? a : b, hi = a < b ? b : a;
-                s_bins[wave][tri_local(lo, hi)] += tot;
+    } else {
+        // partials of thread t for the row-allele pair q: part[((c * part_slots/2 + q) * T + t)] = {a = 2q, a = 2q+1};
+        // the column allele of thread t is al[t % HP].  All of a lane's 16-byte loads of a pair are
+        // issued together, then split by column allele with selects (no dynamic register indexing).
+        const v2f64* base = (const v2f64*)dc.part + (size_t)c * (dc.part_slots >> 1) * T;
+        const uint32_t nq = (nl + 1u) >> 1;
+        for (uint32_t q = 0; q < nq; ++q) {
+            double acc0[PG_AMAX], acc1[PG_AMAX];
+#pragma unroll
+            for (int bb = 0; bb < PG_AMAX; ++bb) { acc0[bb] = 0.0; acc1[bb] = 0.0; }
+            for (uint32_t t = lane; t < T; t += 64) {
+                const v2f64 pv = base[(size_t)q * T + t];
+                const uint32_t b = al[t % HP];
+#pragma unroll
+                for (int bb = 0; bb < PG_AMAX; ++bb) {
+                    acc0[bb] += b == (uint32_t)bb ? pv.x : 0.0;
+                    acc1[bb] += b == (uint32_t)bb ? pv.y : 0.0;
+                }
+            }
+            const uint32_t ra0 = 2u * q, ra1 = 2u * q + 1u;
+#pragma unroll
+            for (int bb = 0; bb < PG_AMAX; ++bb) {
+                if ((uint32_t)bb < nl) {
+                    const double t0 = wave_sum(acc0[bb]), t1 = wave_sum(acc1[bb]);
+                    if (lane == 0) {
+                        const uint32_t cb = (uint32_t)bb;
+                        s_bins[wave][tri_local(ra0 < cb ? ra0 : cb, ra0 < cb ? cb : ra0)] += t0;
+                        if (ra1 < nl) s_bins[wave][tri_local(ra1 < cb ? ra1 : cb, ra1 < cb ? cb : ra1)] += t1;
+                    }
+                }
             }
         }
     }
