@@ -85,6 +85,12 @@ struct DevContig {
     double*   bscale;        // [V] same for the backward column
     double*   bsum;          // [V] sum of the stored backward column (hand-over between the phases)
     uint8_t*  fwd_fallback;  // [V] column c fell back to the uniform forward column (fsum := 1, no emission scale)
+    // chunked mode (few chains, see pg_shim.cpp): phase 2 is run in chunks of chunk_cols columns per
+    // half-chain that only STORE their columns into this scratch ([2 buffers][2 roles][chunk_cols][HP*HP],
+    // forward role first); k_post forms the posteriors of a finished chunk on the idle CUs.
+    double*   scratch;
+    uint32_t  chunk_cols;
+    uint32_t  pad3;
     uint32_t* err;
     unsigned long long* prof;  // [64] in-kernel cycle counters (PG_DEBUG bit 3), profiling only
     // outputs

@@ -764,12 +764,22 @@ DEVI void posterior(ChainShared<HP, R>& sh, gdouble* part_out, uint32_t part_slo
 // ------------------------------------------------------------------------------------------
 //  forward half-chain   (reference src/hmm.cpp:76-90, 175-273)
 // ------------------------------------------------------------------------------------------
+// PHASE 1: columns [0, mid), stored.  PHASE 2 (fused): columns [mid, C), posterior partials inline.
+// PHASE 3 (chunked): columns [mid + chunk*K, +K), stored into the chunk scratch (posteriors by k_post).
 template <int HP, int R, int PHASE>
-DEVI void forward_body(const DevContig& dc, ChainShared<HP, R>& sh, uint32_t C, unsigned char* ring) {
+DEVI void forward_body(const DevContig& dc, ChainShared<HP, R>& sh, uint32_t C, unsigned char* ring, uint32_t chunk) {
     constexpr bool RING = ChainCfg<HP, R>::LOADER && PHASE == 2;  // partner columns via the LDS ring
+    constexpr bool STORE = PHASE != 2;
     using Cfg = ChainCfg<HP, R>;
     const uint32_t mid = C / 2;
-    const uint32_t lo = PHASE == 1 ? 0u : mid, hi = PHASE == 1 ? mid : C;
+    const uint32_t K = dc.chunk_cols;
+    uint32_t lo = PHASE == 1 ? 0u : mid, hi = PHASE == 1 ? mid : C;
+    if constexpr (PHASE == 3) {
+        const unsigned long long l = (unsigned long long)mid + (unsigned long long)chunk * K;
+        if (l >= C) return;
+        lo = (uint32_t)l;
+        hi = C - lo > K ? lo + K : C;
+    }
     if (lo >= hi) return;
     const uint32_t first = lo == 0 ? 1u : lo;  // first column produced by a recursion step
     ThreadPos p;
@@ -838,9 +848,17 @@ DEVI void forward_body(const DevContig& dc, ChainShared<HP, R>& sh, uint32_t C, 
     const size_t colsz = (size_t)HP * HP;
     const uint32_t dbg = dc.debug;
 
+    // where this phase stores column c (c in [lo,hi)) and where the column to resume from lives
+    gdouble* wr = fwd;
+    gcdouble* resume = (gcdouble*)(fwd + (size_t)(lo > 0 ? lo - 1 : 0) * colsz);
+    if constexpr (PHASE == 3) {
+        gdouble* scr = (gdouble*)dc.scratch;
+        wr = scr + (size_t)((chunk & 1u) * 2u) * K * colsz - (size_t)lo * colsz;
+        if (chunk > 0) resume = (gcdouble*)(scr + ((size_t)(((chunk - 1u) & 1u) * 2u) * K + (K - 1u)) * colsz);
+    }
     auto store_col = [&](uint32_t c, const double (&x)[R]) {
         if (kExp & 1u) return;
-        gdouble2* dst = (gdouble2*)(fwd + (size_t)c * colsz) + (size_t)(p.i0 >> 1) * HP + p.j;
+        gdouble2* dst = (gdouble2*)(wr + (size_t)c * colsz) + (size_t)(p.i0 >> 1) * HP + p.j;
 #pragma unroll
         for (int k = 0; k < R; k += 2) dst[(size_t)(k >> 1) * HP] = v2f64{x[k], x[k + 1]};
     };
@@ -849,12 +867,12 @@ DEVI void forward_body(const DevContig& dc, ChainShared<HP, R>& sh, uint32_t C, 
     // spread between the arithmetic of the following rows they cost their issue slots only
     auto store_pair = [&](uint32_t c, int k, double a, double b) {
         if (kExp & 1u) return;
-        gdouble2* dst = (gdouble2*)(fwd + (size_t)c * colsz) + (size_t)(p.i0 >> 1) * HP + p.j;
+        gdouble2* dst = (gdouble2*)(wr + (size_t)c * colsz) + (size_t)(p.i0 >> 1) * HP + p.j;
         dst[(size_t)(k >> 1) * HP] = v2f64{a, b};
     };
     auto load_col = [&](uint32_t c, double (&v)[R]) {
         if (c >= C) return;
-        gcdouble2* src = (gcdouble2*)(fwd + (size_t)c * colsz) + (size_t)(p.i0 >> 1) * HP + p.j;
+        gcdouble2* src = (gcdouble2*)(c + 1 == lo ? resume : (gcdouble*)(fwd + (size_t)c * colsz)) + (size_t)(p.i0 >> 1) * HP + p.j;
 #pragma unroll
         for (int k = 0; k < R; k += 2) { const v2f64 t = src[(size_t)(k >> 1) * HP]; v[k] = t.x; v[k + 1] = t.y; }
     };
@@ -881,7 +899,7 @@ DEVI void forward_body(const DevContig& dc, ChainShared<HP, R>& sh, uint32_t C, 
         double part = 0.0;
 #pragma unroll
         for (int k = 0; k < R; ++k) { x[k] = emission_at(sh.rec[0], p.i0 + k, aj); part += x[k]; }
-        if (PHASE == 1) store_col(0, x);
+        if (STORE) store_col(0, x);
         if (p.tid == 0) fscale[0] = 1.0;
         write_colsums<HP, R>(sh, 0, p, part);
         if constexpr (PHASE == 2) {  // lo == 0 in phase 2 <=> mid == 0 <=> C == 1
@@ -910,7 +928,7 @@ DEVI void forward_body(const DevContig& dc, ChainShared<HP, R>& sh, uint32_t C, 
     // the column (all zeros) is left alone — the caller folds the uniform column into u_j — so the
     // rare path changes no register array (no copies on the hot path).
     auto flag_uniform = [&](uint32_t cprev) {
-        if (PHASE == 1) {
+        if (STORE && cprev >= lo) {  // (cprev = lo-1 was flagged and stored by the launch that produced it)
             double xu[R];
 #pragma unroll
             for (int k = 0; k < R; ++k) xu[k] = (p.j < H && p.i0 + k < H) ? unif : 0.0;
@@ -981,7 +999,7 @@ DEVI void forward_body(const DevContig& dc, ChainShared<HP, R>& sh, uint32_t C, 
                 const double e = ((fe.rowbits >> k) & 1u) ? eB : eA;
                 if (!(kExp & 16u)) x[k] = fma(c0, x[k], uik + uj) * e;
                 part += (kExp & 16u) ? ((k == 0) ? x[0] * e + uik + uj : 0.0) : x[k];
-                if constexpr (PHASE == 1) { if (k & 1) { store_pair(t, k, x[k - 1], x[k]); __builtin_amdgcn_sched_barrier(0); } }
+                if constexpr (STORE) { if (k & 1) { store_pair(t, k, x[k - 1], x[k]); __builtin_amdgcn_sched_barrier(0); } }
                 else if constexpr (R > 16) { if ((k & 7) == 7) __builtin_amdgcn_sched_barrier(0); }
             }
         } else {
@@ -992,7 +1010,7 @@ DEVI void forward_body(const DevContig& dc, ChainShared<HP, R>& sh, uint32_t C, 
                 else uik = readlane_f64(urow, __builtin_amdgcn_readfirstlane((int)((p.i0 + k) & 63u)));
                 x[k] = fma(c0, x[k], uik + uj) * (emission_at(rec, p.i0 + k, aj) * sc);
                 part += x[k];
-                if constexpr (PHASE == 1) { if (k & 1) { store_pair(t, k, x[k - 1], x[k]); __builtin_amdgcn_sched_barrier(0); } }
+                if constexpr (STORE) { if (k & 1) { store_pair(t, k, x[k - 1], x[k]); __builtin_amdgcn_sched_barrier(0); } }
                 else if constexpr (R > 16) { if ((k & 7) == 7) __builtin_amdgcn_sched_barrier(0); }
             }
         }
@@ -1039,13 +1057,21 @@ DEVI void forward_body(const DevContig& dc, ChainShared<HP, R>& sh, uint32_t C, 
 //  KEEPW = keep w = beta_hat*e in registers across the column-sum exchange (else recompute it)
 // ------------------------------------------------------------------------------------------
 template <int HP, int R, int VBUF, bool KEEPW, int PHASE>
-DEVI void backward_body(const DevContig& dc, ChainShared<HP, R>& sh, uint32_t C, unsigned char* ring) {
+DEVI void backward_body(const DevContig& dc, ChainShared<HP, R>& sh, uint32_t C, unsigned char* ring, uint32_t chunk) {
     using Cfg = ChainCfg<HP, R>;
     constexpr bool RING = Cfg::LOADER && PHASE == 2;  // partner columns via the LDS ring
+    constexpr bool STORE = PHASE != 2;
     const int64_t mid = C / 2;
-    // phase 1 computes columns C-1 .. mid (stores beta'); phase 2 computes mid-1 .. 0 (posteriors)
-    const int64_t top = PHASE == 1 ? (int64_t)C - 1 : mid - 1;  // first column of this phase
-    const int64_t bot = PHASE == 1 ? mid : 0;                    // last column of this phase
+    const int64_t K = dc.chunk_cols;
+    // phase 1 computes columns C-1 .. mid (stores beta'); phase 2 computes mid-1 .. 0 (posteriors);
+    // phase 3 (chunked) computes mid-1-chunk*K .. K columns down and stores them into the scratch
+    int64_t top = PHASE == 1 ? (int64_t)C - 1 : mid - 1;  // first column of this phase
+    int64_t bot = PHASE == 1 ? mid : 0;                    // last column of this phase
+    if constexpr (PHASE == 3) {
+        top = mid - 1 - (int64_t)chunk * K;
+        if (top < 0) return;
+        bot = top - K + 1 > 0 ? top - K + 1 : 0;
+    }
     if (top < bot) return;
     ThreadPos p;
     p.tid = threadIdx.x; p.lane = p.tid & 63u;
@@ -1109,20 +1135,28 @@ DEVI void backward_body(const DevContig& dc, ChainShared<HP, R>& sh, uint32_t C,
     gdouble* bsum = (gdouble*)dc.bsum;
     const size_t colsz = (size_t)HP * HP;
 
+    // where this phase stores column c (c in [bot,top]) and where the column to resume from lives
+    gdouble* wr = cols;
+    gcdouble* resume = (gcdouble*)(cols + (size_t)(top + 1 < (int64_t)C ? top + 1 : top) * colsz);
+    if constexpr (PHASE == 3) {
+        gdouble* scr = (gdouble*)dc.scratch;
+        wr = scr + (size_t)((chunk & 1u) * 2u + 1u) * (size_t)K * colsz - (size_t)bot * colsz;
+        if (chunk > 0) resume = (gcdouble*)(scr + (size_t)(((chunk - 1u) & 1u) * 2u + 1u) * (size_t)K * colsz);  // its slot 0
+    }
     auto load_col = [&](int64_t c, double (&v)[R]) {
         if (c < 0) return;
-        gcdouble2* src = (gcdouble2*)(cols + (size_t)c * colsz) + (size_t)(p.i0 >> 1) * HP + p.j;
+        gcdouble2* src = (gcdouble2*)(c == top + 1 ? resume : (gcdouble*)(cols + (size_t)c * colsz)) + (size_t)(p.i0 >> 1) * HP + p.j;
 #pragma unroll
         for (int k = 0; k < R; k += 2) { const v2f64 t = src[(size_t)(k >> 1) * HP]; v[k] = t.x; v[k + 1] = t.y; }
     };
     auto store_col = [&](int64_t c, const double (&y)[R]) {
-        gdouble2* dst = (gdouble2*)(cols + (size_t)c * colsz) + (size_t)(p.i0 >> 1) * HP + p.j;
+        gdouble2* dst = (gdouble2*)(wr + (size_t)c * colsz) + (size_t)(p.i0 >> 1) * HP + p.j;
 #pragma unroll
         for (int k = 0; k < R; k += 2) dst[(size_t)(k >> 1) * HP] = v2f64{y[k], y[k + 1]};
     };
     auto store_pair = [&](int64_t c, int k, double a, double b) {  // see forward_body
         if (kExp & 1u) return;
-        gdouble2* dst = (gdouble2*)(cols + (size_t)c * colsz) + (size_t)(p.i0 >> 1) * HP + p.j;
+        gdouble2* dst = (gdouble2*)(wr + (size_t)c * colsz) + (size_t)(p.i0 >> 1) * HP + p.j;
         dst[(size_t)(k >> 1) * HP] = v2f64{a, b};
     };
 
@@ -1144,10 +1178,10 @@ DEVI void backward_body(const DevContig& dc, ChainShared<HP, R>& sh, uint32_t C,
         store_col(top, y);
         if (p.tid == 0) { bscale[top] = 1.0; bsum[top] = Sy; }
     } else {
-        // resume behind column mid, stored by phase 1
-        load_col(mid, y);
-        Sy = bsum[mid];
-        if constexpr (!RING) {
+        // resume behind the column stored last (by phase 1, or by the previous chunk)
+        load_col(top + 1, y);
+        Sy = bsum[top + 1];
+        if constexpr (PHASE == 2 && !RING) {
             load_col(top, vA);
             if constexpr (VBUF == 2) load_col(top - 1, vB);
         }
@@ -1231,14 +1265,14 @@ DEVI void backward_body(const DevContig& dc, ChainShared<HP, R>& sh, uint32_t C,
                 if constexpr (R <= 16) uik = ui[k];
                 else uik = readlane_f64(urow, __builtin_amdgcn_readfirstlane((int)((p.i0 + k) & 63u)));
                 y[k] = (kExp & 16u) ? (k == 0 ? wk + uik + uj : wk) : fma(k0, wk, uik + uj);  // beta'_t
-                if constexpr (PHASE == 1) { if (k & 1) { store_pair(t, k, y[k - 1], y[k]); __builtin_amdgcn_sched_barrier(0); } }
+                if constexpr (STORE) { if (k & 1) { store_pair(t, k, y[k - 1], y[k]); __builtin_amdgcn_sched_barrier(0); } }
                 else if constexpr (R > 16) { if ((k & 7) == 7) __builtin_amdgcn_sched_barrier(0); }
             }
         };
         if (KEEPW || fast) beta_loop(std::true_type{});
         else beta_loop(std::false_type{});
         Sy = kap * Sw;  // = sum(beta'_t) over real states
-        if constexpr (PHASE == 1) {
+        if constexpr (STORE) {
             if (p.tid == 0) bsum[t] = Sy;
         } else {
             if constexpr (RING) {
@@ -1259,7 +1293,7 @@ DEVI void backward_body(const DevContig& dc, ChainShared<HP, R>& sh, uint32_t C,
         //           -> partial column sums of the new w -> barrier
         // exactly like the forward step: one dependent segment per column instead of two.
         // -------------------------------------------------------------------------------------
-        static_assert(PHASE == 1 || RING, "loader configurations read partner columns from the LDS ring");
+        static_assert(PHASE != 2 || RING, "loader configurations read partner columns from the LDS ring");
         double w[R];
         auto rowbits_of = [&](const RecInfo& ri) -> uint32_t {
             return Cfg::UNI ? (uint32_t)__builtin_amdgcn_readfirstlane(ri.fe.rowbits) : ri.fe.rowbits;
@@ -1317,12 +1351,12 @@ DEVI void backward_body(const DevContig& dc, ChainShared<HP, R>& sh, uint32_t C,
                     w[k] = bu * (nxt.fast ? (((rb0 >> k) & 1u) ? nxt.fe.eB : nxt.fe.eA) : emission_at(rec0, p.i0 + k, nxt.aj));
                     part += w[k];
                 }
-                if constexpr (PHASE == 1) store_col(t, y);
+                if constexpr (STORE) store_col(t, y);
             } else if (nxt.fast) {
 #pragma unroll
                 for (int k = 0; k < R; ++k) {
                     y[k] = (kExp & 16u) ? w[k] : fma(k0, w[k], ui[k] + uj);  // beta'_t
-                    if constexpr (PHASE == 1) { if (k & 1) { store_pair(t, k, y[k - 1], y[k]); __builtin_amdgcn_sched_barrier(0); } }
+                    if constexpr (STORE) { if (k & 1) { store_pair(t, k, y[k - 1], y[k]); __builtin_amdgcn_sched_barrier(0); } }
                     w[k] = (kExp & 16u) ? y[k] : y[k] * (((rb0 >> k) & 1u) ? nxt.fe.eB : nxt.fe.eA);
                     part += (kExp & 16u) ? (k == 0 ? w[0] + ui[k] + uj : 0.0) : w[k];
                 }
@@ -1330,13 +1364,13 @@ DEVI void backward_body(const DevContig& dc, ChainShared<HP, R>& sh, uint32_t C,
 #pragma unroll
                 for (int k = 0; k < R; ++k) {
                     y[k] = fma(k0, w[k], ui[k] + uj);
-                    if constexpr (PHASE == 1) { if (k & 1) { store_pair(t, k, y[k - 1], y[k]); __builtin_amdgcn_sched_barrier(0); } }
+                    if constexpr (STORE) { if (k & 1) { store_pair(t, k, y[k - 1], y[k]); __builtin_amdgcn_sched_barrier(0); } }
                     w[k] = y[k] * emission_at(rec0, p.i0 + k, nxt.aj);
                     part += w[k];
                 }
             }
             write_colsums<HP, R>(sh, (uint32_t)(t - 1) & 1u, p, part);
-            if constexpr (PHASE == 1) { if (p.tid == 0) bsum[t] = Snew; }
+            if constexpr (STORE) { if (p.tid == 0) bsum[t] = Snew; }
             else posterior<HP, R>(sh, part_out, part_slots, nxt, (uint32_t)t, p, vt, y);
             Sy = Snew > 0.0 ? Snew : 1.0;
             cur = nxt;
@@ -1360,7 +1394,7 @@ DEVI void backward_body(const DevContig& dc, ChainShared<HP, R>& sh, uint32_t C,
 
 // grid = (n_contigs, 2): blockIdx.y = 0 forward half-chain, 1 backward half-chain
 template <int HP, int R, int VBUF, bool KEEPW, int PHASE>
-__global__ __launch_bounds__((ChainCfg<HP, R>::TT)) void k_sweep(const DevContig* __restrict__ contigs) {
+__global__ __launch_bounds__((ChainCfg<HP, R>::TT)) void k_sweep(const DevContig* __restrict__ contigs, uint32_t chunk) {
     __shared__ ChainShared<HP, R> sh;
     extern __shared__ __attribute__((aligned(16))) unsigned char dyn_ring[];  // phase 2: kRingSlots column slots
     const DevContig& dc = contigs[blockIdx.x];
@@ -1369,8 +1403,8 @@ __global__ __launch_bounds__((ChainCfg<HP, R>::TT)) void k_sweep(const DevContig
     // with it every column index, ring slot and address derived from it, wave-uniform again)
     const uint32_t C = (uint32_t)__builtin_amdgcn_readfirstlane((int)*dc.n_cols);
     if (C == 0) return;
-    if (blockIdx.y == 0) forward_body<HP, R, PHASE>(dc, sh, C, dyn_ring);
-    else backward_body<HP, R, VBUF, KEEPW, PHASE>(dc, sh, C, dyn_ring);
+    if (blockIdx.y == 0) forward_body<HP, R, PHASE>(dc, sh, C, dyn_ring, chunk);
+    else backward_body<HP, R, VBUF, KEEPW, PHASE>(dc, sh, C, dyn_ring, chunk);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1473,11 +1507,136 @@ __global__ __launch_bounds__(256) void k_bins(const DevContig* __restrict__ cont
 }
 
 // ------------------------------------------------------------------------------------------
+//  k_post : chunked mode.  Posteriors of the columns of one finished chunk straight from the two
+//  stored columns (one wave per column):  L_v({a,b}) = sum_(i,j) alpha'_c(i,j) * beta'_c(i,j) / (m_f m_b)
+//  (reference src/hmm.cpp:364-368).  For c >= mid alpha' is in the chunk scratch and beta' in the
+//  main slots, for c < mid the other way round.  Runs on the CUs the few chains leave idle: it is
+//  launched with PG_POST_PLACEMENT_LDS bytes of (unused) dynamic LDS, more than fits next to a sweep
+//  workgroup, so its 16-wave blocks never share a CU — and issue slots — with the latency-critical
+//  recursion (side by side the chunk sweeps ran 35 % slower).
+// ------------------------------------------------------------------------------------------
+#define PG_POST_WAVES 16
+#define PG_POST_PLACEMENT_LDS (152 * 1024)
+__global__ __launch_bounds__(64 * PG_POST_WAVES) void k_post(const DevContig* __restrict__ contigs, uint32_t chunk) {
+    __shared__ double s_bins[PG_POST_WAVES][PG_AMAX * (PG_AMAX + 1) / 2];
+    const DevContig& dc = contigs[blockIdx.y];
+    const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const uint32_t C = *dc.n_cols;
+    const uint32_t K = dc.chunk_cols, HP = dc.HP;
+    const uint32_t idx = blockIdx.x * PG_POST_WAVES + wave;
+    if (C == 0 || idx >= 2u * K) return;
+    const uint32_t mid = C / 2;
+    const size_t colsz = (size_t)HP * HP;
+    const double* scr = dc.scratch + (size_t)((chunk & 1u) * 2u) * K * colsz;
+    uint32_t c;
+    const double *A, *B;  // alpha', beta'
+    if (idx < K) {        // forward role: columns mid + chunk*K ...
+        const unsigned long long cc = (unsigned long long)mid + (unsigned long long)chunk * K + idx;
+        if (cc >= C) return;
+        c = (uint32_t)cc;
+        A = scr + (size_t)idx * colsz;
+        B = dc.fwd + (size_t)c * colsz;
+    } else {              // backward role: columns mid-1-chunk*K downwards; slot = column - bot
+        const long long top = (long long)mid - 1 - (long long)chunk * K;
+        if (top < 0) return;
+        const long long bot = top - (long long)K + 1 > 0 ? top - (long long)K + 1 : 0;
+        const long long cc = bot + (long long)(idx - K);
+        if (cc > top) return;
+        c = (uint32_t)cc;
+        B = scr + (size_t)K * colsz + (size_t)(idx - K) * colsz;
+        A = dc.fwd + (size_t)c * colsz;
+    }
+    const unsigned char* rec = dc.colrec + (size_t)c * dc.RB;
+    const uint32_t v = *(const uint32_t*)(rec + PG_REC_VARIANT);
+    const uint32_t nl = rec[PG_REC_NLOCAL];
+    const unsigned char* al = rec + PG_REC_ALLELES;
+    if (lane < PG_AMAX * (PG_AMAX + 1) / 2) s_bins[wave][lane] = 0.0;
+    wave_sync();
+
+    // element e of a column = row pair e / HP, column e % HP (16 bytes: rows 2*(e/HP), +1); lanes take
+    // consecutive elements, so every load is a coalesced 1 KB per wave.  Per lane the column is fixed
+    // when HP <= 64 (two columns for HP = 128: handled as two passes), so a lane accumulates by ROW
+    // allele only and the split by column allele happens once at the end.
+    const v2f64* A2 = (const v2f64*)A;
+    const v2f64* B2 = (const v2f64*)B;
+    const uint32_t npass = HP > 64 ? HP / 64 : 1;
+    for (uint32_t ps = 0; ps < npass; ++ps) {
+        double acc[PG_AMAX];
+#pragma unroll
+        for (int a = 0; a < PG_AMAX; ++a) acc[a] = 0.0;
+        uint32_t j, ip0, ipstep;
+        if (HP >= 64) { j = ps * 64 + lane; ip0 = 0; ipstep = 1; }
+        else { j = lane % HP; ip0 = lane / HP; ipstep = 64 / HP; }
+        // four row pairs (8 x 16-byte loads per lane) in flight at a time: this kernel has to stream
+        // 128 KB per column at HBM rate to keep up with the chunk sweeps
+        constexpr int UN = 4;
+        for (uint32_t ipb = ip0; ipb < HP / 2; ipb += ipstep * UN) {
+            v2f64 av[UN], bv[UN];
+#pragma unroll
+            for (int u = 0; u < UN; ++u) {
+                const uint32_t ip = ipb + u * ipstep;
+                const size_t e = (size_t)(ip < HP / 2 ? ip : ip0) * HP + j;
+                av[u] = A2[e]; bv[u] = B2[e];
+            }
+#pragma unroll
+            for (int u = 0; u < UN; ++u) {
+                const uint32_t ip = ipb + u * ipstep;
+                if (ip < HP / 2) {
+                    const double p0 = av[u].x * bv[u].x, p1 = av[u].y * bv[u].y;
+                    const uint32_t a0 = al[2 * ip], a1 = al[2 * ip + 1];
+#pragma unroll
+                    for (int a = 0; a < PG_AMAX; ++a) {
+                        acc[a] = fma(p0, a0 == (uint32_t)a ? 1.0 : 0.0, acc[a]);
+                        acc[a] = fma(p1, a1 == (uint32_t)a ? 1.0 : 0.0, acc[a]);
+                    }
+                }
+            }
+        }
+        const uint32_t b = al[j];
+#pragma unroll
+        for (int a = 0; a < PG_AMAX; ++a) {
+            if ((uint32_t)a < nl) {
+#pragma unroll
+                for (int bb = 0; bb < PG_AMAX; ++bb) {
+                    if ((uint32_t)bb < nl) {
+                        const double tot = wave_sum(b == (uint32_t)bb ? acc[a] : 0.0);
+                        if (lane == 0) {
+                            const uint32_t ra = (uint32_t)a, cb = (uint32_t)bb;
+                            s_bins[wave][tri_local(ra < cb ? ra : cb, ra < cb ? cb : ra)] += tot;
+                        }
+                    }
+                }
+            }
+        }
+    }
+    wave_sync();
+    const uint32_t a0v = dc.allele_off[v], Av = dc.allele_off[v + 1] - a0v;
+    const uint16_t* ls = (const uint16_t*)(rec + PG_REC_LOCAL_SLOT);
+    // stored columns are (true value) * m (see k_bins); a flagged forward column is the uniform
+    // column itself: absolute value, no emission exponent, no scale
+    const bool fb = dc.fwd_fallback[c] != 0;
+    const double scale = 1.0 / ((fb ? 1.0 : dc.fscale[c]) * dc.bscale[c]);
+    if (lane < nl * nl) {
+        const uint32_t la = lane / nl, lb = lane % nl;
+        if (la <= lb) {
+            const uint32_t sa = ls[la], sb = ls[lb];
+            const uint64_t gi = dc.geno_off[v] + (uint64_t)sa * Av - (uint64_t)sa * (sa - 1) / 2 + (sb - sa);
+            dc.lik[gi] = s_bins[wave][tri_local(la, lb)] * scale;
+        }
+    }
+    if (lane == 0) {
+        int X = fb ? 0 : *(const int32_t*)(rec + PG_REC_EXP);
+        if (c + 1 < C) X += *(const int32_t*)(dc.colrec + (size_t)(c + 1) * dc.RB + PG_REC_EXP);
+        dc.lik_exp[v] = X;
+    }
+}
+
+// ------------------------------------------------------------------------------------------
 //  host-callable launchers (defined here so that the shim needs no kernel templates)
 // ------------------------------------------------------------------------------------------
 // hp_mask: bit0 HP=16, bit1 HP=32, bit2 HP=64, bit3 HP=128; phase 1 = store halves, 2 = posterior halves
 template <int HP, int R, int VBUF, bool KEEPW, int PHASE>
-static void launch_one(const DevContig* d_contigs, uint32_t n_contigs, hipStream_t s) {
+static void launch_one(const DevContig* d_contigs, uint32_t n_contigs, uint32_t chunk, hipStream_t s) {
     using Cfg = ChainCfg<HP, R>;
     const size_t dyn = (Cfg::LOADER && PHASE == 2) ? (size_t)kRingSlots * HP * HP * 8 : 0;  // partner-column ring
     auto kern = k_sweep<HP, R, VBUF, KEEPW, PHASE>;
@@ -1486,14 +1645,14 @@ static void launch_one(const DevContig* d_contigs, uint32_t n_contigs, hipStream
         (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn);
         attr_set = true;
     }
-    hipLaunchKernelGGL(kern, dim3(n_contigs, 2), dim3(Cfg::TT), dyn, s, d_contigs);
+    hipLaunchKernelGGL(kern, dim3(n_contigs, 2), dim3(Cfg::TT), dyn, s, d_contigs, chunk);
 }
 template <int PHASE>
-static void launch_sweep(const DevContig* d_contigs, uint32_t n_contigs, uint32_t hp_mask, hipStream_t s) {
-    if (hp_mask & 1u) launch_one<16, 4, 1, true, PHASE>(d_contigs, n_contigs, s);
-    if (hp_mask & 2u) launch_one<32, 16, 1, true, PHASE>(d_contigs, n_contigs, s);
-    if (hp_mask & 4u) launch_one<64, 16, 1, true, PHASE>(d_contigs, n_contigs, s);
-    if (hp_mask & 8u) launch_one<128, 32, 1, false, PHASE>(d_contigs, n_contigs, s);
+static void launch_sweep(const DevContig* d_contigs, uint32_t n_contigs, uint32_t hp_mask, uint32_t chunk, hipStream_t s) {
+    if (hp_mask & 1u) launch_one<16, 4, 1, true, PHASE>(d_contigs, n_contigs, chunk, s);
+    if (hp_mask & 2u) launch_one<32, 16, 1, true, PHASE>(d_contigs, n_contigs, chunk, s);
+    if (hp_mask & 4u) launch_one<64, 16, 1, true, PHASE>(d_contigs, n_contigs, chunk, s);
+    if constexpr (PHASE != 3) { if (hp_mask & 8u) launch_one<128, 32, 1, false, PHASE>(d_contigs, n_contigs, chunk, s); }
 }
 extern "C" {
 
@@ -1513,8 +1672,21 @@ void pgk_launch_bins(const DevContig* d_contigs, uint32_t n_contigs, uint32_t ma
     hipLaunchKernelGGL(k_bins, grid, dim3(256), 0, s, d_contigs);
 }
 void pgk_launch_sweep(const DevContig* d_contigs, uint32_t n_contigs, uint32_t hp_mask, int phase, hipStream_t s) {
-    if (phase == 1) launch_sweep<1>(d_contigs, n_contigs, hp_mask, s);
-    else launch_sweep<2>(d_contigs, n_contigs, hp_mask, s);
+    if (phase == 1) launch_sweep<1>(d_contigs, n_contigs, hp_mask, 0, s);
+    else launch_sweep<2>(d_contigs, n_contigs, hp_mask, 0, s);
+}
+// chunked mode: chunk `chunk` of the second half of every half-chain (store-only sweep), then its posteriors
+void pgk_launch_sweep_chunk(const DevContig* d_contigs, uint32_t n_contigs, uint32_t hp_mask, uint32_t chunk, hipStream_t s) {
+    launch_sweep<3>(d_contigs, n_contigs, hp_mask, chunk, s);
+}
+void pgk_launch_post(const DevContig* d_contigs, uint32_t n_contigs, uint32_t chunk_cols, uint32_t chunk, hipStream_t s) {
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute((const void*)k_post, hipFuncAttributeMaxDynamicSharedMemorySize, PG_POST_PLACEMENT_LDS);
+        attr_set = true;
+    }
+    dim3 grid((2u * chunk_cols + PG_POST_WAVES - 1u) / PG_POST_WAVES, n_contigs);
+    hipLaunchKernelGGL(k_post, grid, dim3(64 * PG_POST_WAVES), PG_POST_PLACEMENT_LDS, s, d_contigs, chunk);
 }
 void pgk_launch_emission_single(const DevContig* d_contig, DevTable tab, uint32_t v, double* out_m, int* out_e,
                                 hipStream_t s) {

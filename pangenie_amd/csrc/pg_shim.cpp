@@ -26,6 +26,8 @@ void pgk_launch_compact(const DevContig*, uint32_t, hipStream_t);
 void pgk_launch_records(const DevContig*, uint32_t, uint32_t, hipStream_t);
 void pgk_launch_bins(const DevContig*, uint32_t, uint32_t, hipStream_t);
 void pgk_launch_sweep(const DevContig*, uint32_t, uint32_t, int, hipStream_t);
+void pgk_launch_sweep_chunk(const DevContig*, uint32_t, uint32_t, uint32_t, hipStream_t);
+void pgk_launch_post(const DevContig*, uint32_t, uint32_t, uint32_t, hipStream_t);
 void pgk_launch_emission_single(const DevContig*, DevTable, uint32_t, double*, int*, hipStream_t);
 void pgk_launch_transition_single(double, uint32_t, int, double*, hipStream_t);
 uint32_t pgk_threads_for_hp(uint32_t);
@@ -236,6 +238,16 @@ struct pg_job {
     double ms[PG_N_KERNEL_CLASSES] = {0, 0, 0, 0, 0, 0};
     pg_hmm_params params;
     bool ran = false;
+    // Sweep mode.  fused: phase 2 forms the posterior partials inline (k_bins reduces them) — least
+    // HBM traffic, the choice when hundreds of chains fill the chip.  chunked: with few chains the
+    // chip is idle and a chain's time is its per-column latency, so phase 2 runs as store-only
+    // chunks (as cheap per column as phase 1) and k_post forms the posteriors of each finished
+    // chunk on the idle CUs from a second stream.
+    bool chunked = false;
+    uint32_t chunk_cols = 0, n_chunks = 0;
+    hipStream_t stream2 = nullptr;
+    hipEvent_t ev_sweep[2], ev_post[2];
+    bool events2 = false;
 };
 
 namespace {
@@ -277,7 +289,10 @@ extern "C" void pg_job_destroy(pg_job* job) {
     hipSetDevice(job->device);
     if (job->events)
         for (auto& e : job->ev) hipEventDestroy(e);
+    if (job->events2)
+        for (int q = 0; q < 2; ++q) { hipEventDestroy(job->ev_sweep[q]); hipEventDestroy(job->ev_post[q]); }
     if (job->arena) hipFree(job->arena);
+    if (job->stream2) hipStreamDestroy(job->stream2);
     if (job->stream) hipStreamDestroy(job->stream);
     delete job;
 }
@@ -311,11 +326,46 @@ extern "C" pg_job* pg_job_create(int device, uint32_t n_contigs, const pg_contig
     job->events = true;
     if (table_on_device(const_cast<pg_table*>(table), device, &job->tab, err, errlen) != PG_OK) { pg_job_destroy(job); return nullptr; }
 
+    // ---- sweep mode ------------------------------------------------------------------
+    {
+        uint32_t max_hp = 0, max_v = 0;
+        size_t per_col = 0;  // scratch bytes per chunk column over all chains (2 buffers x 2 roles)
+        for (uint32_t i = 0; i < n_contigs; ++i) {
+            const uint32_t hp = pad_paths(batches[i].n_paths ? batches[i].n_paths : 1);
+            if (hp > max_hp) max_hp = hp;
+            if (batches[i].n_variants > max_v) max_v = batches[i].n_variants;
+            per_col += (size_t)4 * hp * hp * sizeof(double);
+        }
+        bool want = n_contigs * 2u < 128u;  // fewer workgroups than half the CUs
+        if (const char* m = getenv("PG_SWEEP_MODE")) {
+            if (!strcmp(m, "fused")) want = false;
+            else if (!strcmp(m, "chunked")) want = true;
+        }
+        job->chunked = want && max_hp <= 64 && max_v > 0 && params->run_genotyping;
+        if (job->chunked) {
+            size_t k = 4096;
+            const size_t budget = (size_t)12 << 30;
+            if (per_col * k > budget) k = budget / per_col;
+            if (const char* e = getenv("PG_CHUNK_COLS")) { const long v = strtol(e, nullptr, 0); if (v > 0) k = (size_t)v; }
+            const size_t half = (size_t)max_v / 2 + 1;
+            if (k > half) k = half;
+            if (k < 1) k = 1;
+            job->chunk_cols = (uint32_t)k;
+            job->n_chunks = (uint32_t)((half + k - 1) / k);
+            if ((he = hipStreamCreateWithFlags(&job->stream2, hipStreamNonBlocking)) != hipSuccess) return fail("hipStreamCreate", he);
+            for (int q = 0; q < 2; ++q) {
+                if ((he = hipEventCreateWithFlags(&job->ev_sweep[q], hipEventDisableTiming)) != hipSuccess) return fail("hipEventCreate", he);
+                if ((he = hipEventCreateWithFlags(&job->ev_post[q], hipEventDisableTiming)) != hipSuccess) return fail("hipEventCreate", he);
+            }
+            job->events2 = true;
+        }
+    }
+
     // ---- plan the arena -------------------------------------------------------------
     job->contigs.resize(n_contigs);
     size_t off = 0;
     auto take = [&](size_t bytes) { size_t o = off; off = align_up(off + (bytes ? bytes : 8)); return o; };
-    struct Plan { size_t prof, fback, fscale, bscale, bsum, pos, cov, koff, kcnt, aoff, aid, aflag, akoff, akmask, pa, goff, vrec, cvar, colrec, fwd, part, kept, apres, lik, likexp; };
+    struct Plan { size_t scratch, prof, fback, fscale, bscale, bsum, pos, cov, koff, kcnt, aoff, aid, aflag, akoff, akmask, pa, goff, vrec, cvar, colrec, fwd, part, kept, apres, lik, likexp; };
     std::vector<Plan> plan(n_contigs);
     const size_t o_contigs = take(sizeof(DevContig) * n_contigs);
     // zeroed-every-run block: n_cols, err, then per contig kept / allele_present / lik / lik_exp
@@ -355,7 +405,9 @@ extern "C" pg_job* pg_job_create(int device, uint32_t n_contigs, const pg_contig
         p.cvar = take((size_t)c.V * 4);
         p.colrec = take((size_t)c.V * c.RB);
         p.fwd = take((size_t)c.V * c.HP * c.HP * sizeof(double));
-        p.part = take((size_t)c.V * c.part_slots * c.T * sizeof(double));
+        // fused mode: posterior partials; chunked mode: the chunk scratch instead (k_post writes lik directly)
+        p.part = take(job->chunked ? 0 : (size_t)c.V * c.part_slots * c.T * sizeof(double));
+        p.scratch = take(job->chunked ? (size_t)4 * job->chunk_cols * c.HP * c.HP * sizeof(double) : 0);
         p.fscale = take((size_t)c.V * sizeof(double));
         p.bscale = take((size_t)c.V * sizeof(double));
         p.bsum = take((size_t)c.V * sizeof(double));
@@ -398,6 +450,7 @@ extern "C" pg_job* pg_job_create(int device, uint32_t n_contigs, const pg_contig
         d.fwd = (double*)(A + p.fwd); d.part = (double*)(A + p.part); d.fwd_fallback = A + p.fback; d.prof = (unsigned long long*)(A + p.prof);
         d.fscale = (double*)(A + p.fscale); d.bscale = (double*)(A + p.bscale); d.bsum = (double*)(A + p.bsum); d.err = job->d_err + i;
         d.lik = (double*)(A + p.lik); d.lik_exp = (int32_t*)(A + p.likexp);
+        d.scratch = (double*)(A + p.scratch); d.chunk_cols = job->chunk_cols;
         c.d = d;
         if (c.V == 0) continue;
         std::vector<uint64_t> goff((size_t)c.V + 1);
@@ -444,10 +497,29 @@ extern "C" int pg_job_run(pg_job* job, void* stream_, char* err, size_t errlen) 
         HIP_TRY(hipEventRecord(job->ev[3], s));
         pgk_launch_sweep(job->d_contigs, n, job->hp_mask, 1, s);
         HIP_TRY(hipEventRecord(job->ev[4], s));
-        pgk_launch_sweep(job->d_contigs, n, job->hp_mask, 2, s);
-        HIP_TRY(hipEventRecord(job->ev[5], s));
-        pgk_launch_bins(job->d_contigs, n, job->max_v, s);
-        HIP_TRY(hipEventRecord(job->ev[6], s));
+        if (!job->chunked) {
+            pgk_launch_sweep(job->d_contigs, n, job->hp_mask, 2, s);
+            HIP_TRY(hipEventRecord(job->ev[5], s));
+            pgk_launch_bins(job->d_contigs, n, job->max_v, s);
+            HIP_TRY(hipEventRecord(job->ev[6], s));
+        } else {
+            // chunk i: store-only sweep on s -> ev_sweep -> k_post on stream2 -> ev_post; the sweep of
+            // chunk i+2 reuses scratch buffer i&1 and therefore waits for the posteriors of chunk i
+            hipStream_t s2 = job->stream2;
+            for (uint32_t i = 0; i < job->n_chunks; ++i) {
+                const int b = (int)(i & 1u);
+                if (i >= 2) HIP_TRY(hipStreamWaitEvent(s, job->ev_post[b], 0));
+                pgk_launch_sweep_chunk(job->d_contigs, n, job->hp_mask, i, s);
+                HIP_TRY(hipEventRecord(job->ev_sweep[b], s));
+                HIP_TRY(hipStreamWaitEvent(s2, job->ev_sweep[b], 0));
+                pgk_launch_post(job->d_contigs, n, job->chunk_cols, i, s2);
+                HIP_TRY(hipEventRecord(job->ev_post[b], s2));
+            }
+            HIP_TRY(hipStreamWaitEvent(s, job->ev_post[0], 0));
+            if (job->n_chunks > 1) HIP_TRY(hipStreamWaitEvent(s, job->ev_post[1], 0));
+            HIP_TRY(hipEventRecord(job->ev[5], s));  // "k_sweep_phase2" = all chunks incl. their posteriors
+            HIP_TRY(hipEventRecord(job->ev[6], s));  // (no k_bins in this mode)
+        }
         HIP_TRY(hipGetLastError());
     } else if (job->max_v > 0) {
         // run_genotyping == false: only the ColumnIndexer part is meaningful (no likelihoods)

@@ -190,11 +190,17 @@ def test_no_columns_and_empty(orc):
     assert not res.n_kmers.any() and not res.coverage.any()  # reference src/hmm.cpp:94
 
 
-def test_multi_contig_job_matches_single_calls(orc):
+@pytest.mark.parametrize("mode,hs", [("fused", [16, 64, 64, 32, 16, 128]), ("chunked", [16, 64, 64, 32, 16]), ("fused", [16, 64, 32])])
+def test_multi_contig_job_matches_single_calls(orc, monkeypatch, mode, hs):
+    """One resident job over contigs of different length and haplotype count, in both sweep modes
+    (a job containing H = 128 always runs fused).  Bitwise comparisons are made within one mode:
+    the two modes sum in a different order and differ in the last bits."""
+    monkeypatch.setenv("PG_SWEEP_MODE", mode)
+    monkeypatch.setenv("PG_CHUNK_COLS", "64")  # several chunks even on these small panels
     args = default_table_args()
     t = hmm.ProbabilityTable(*args)
     p = hmm.make_params(1.26, False, 1e-5)
-    batches = [synthetic_panel(300 + 50 * i, H, 20, seed=40 + i) for i, H in enumerate([16, 64, 64, 32, 16, 128])]
+    batches = [synthetic_panel(300 + 50 * i, H, 20, seed=40 + i) for i, H in enumerate(hs)]
     job = hmm.Job(batches, t, p)
     job.run()
     job.run()  # re-running a resident job must give the same answer
