@@ -66,18 +66,28 @@ def cpu_baseline(batch, H, sample_variants):
 
 
 def profiled_traffic(workload, kernel_phase):
-    """HBM bytes per launch of the sweep phase from the committed rocprofv3 PMC summary
+    """HBM bytes per pass of one sweep phase from the committed rocprofv3 PMC summary
     (profiles/rNN_<workload>_summary.json, made by tools/summarize_profile.py from separate
-    --pmc FETCH_SIZE / WRITE_SIZE passes).  None if no profile of this workload is committed."""
+    --pmc FETCH_SIZE / WRITE_SIZE passes).  Phase 1 is one launch of k_sweep<..., 1>; phase 2 is one
+    launch of k_sweep<..., 2> (fused mode) or all chunk launches k_sweep<..., 3> plus their k_post
+    launches (chunked mode), summed and divided by the number of passes the profile ran.
+    None if no profile of this workload is committed."""
     cands = sorted((ROOT / "profiles").glob(f"r*_{workload}_summary.json"))
     if not cands:
         return None, None
     data = json.loads(cands[-1].read_text())
-    for name, v in data["kernels"].items():
-        if name.startswith("void k_sweep<") and name.rstrip().endswith(f", {kernel_phase}>(DevContig const*)"):
-            if "hbm_read_bytes_per_launch" in v:
-                return v["hbm_read_bytes_per_launch"] + v.get("hbm_write_bytes_per_launch", 0.0), cands[-1].name
-    return None, None
+    ks = data["kernels"]
+    passes = max([v.get("pmc_launches", 0) for n, v in ks.items() if n.startswith("void k_sweep<") and ", 1>(" in n] or [0])
+    if passes == 0:
+        return None, None
+    total = 0.0
+    for name, v in ks.items():
+        sweep = name.startswith("void k_sweep<")
+        mine = (sweep and f", {kernel_phase}>(" in name) or \
+               (kernel_phase == 2 and ((sweep and ", 3>(" in name) or name.startswith("k_post(")))
+        if mine:
+            total += v.get("hbm_read_bytes_total", 0.0) + v.get("hbm_write_bytes_total", 0.0)
+    return (total / passes if total > 0 else None), cands[-1].name
 
 
 def main():
@@ -204,7 +214,8 @@ def main():
             "config": {"workload": f"{args.workload}: {w['cfg']}; {V_total} variants x {H} haplotypes x {K} k-mers/variant "
                                    f"per GPU in {n_chains} chain(s) (longest {max(sizes)}), seed 12345+rank",
                        "variants_per_gpu": V_total, "haplotypes": H, "kmers_per_variant": K,
-                       "kept_columns": ncol, "chains_per_gpu": n_chains, "workgroups_per_chain": 2, "parallelism": f"contig-sharded x{world}"},
+                       "kept_columns": ncol, "chains_per_gpu": n_chains, "workgroups_per_chain": 2, "parallelism": f"contig-sharded x{world}",
+                       "sweep_mode": "%s (chunk_cols=%d)" % job.sweep_mode()},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
                          "algorithmic_bytes_per_launch": dom_bytes, "avg_launch_ms": dom_ms,

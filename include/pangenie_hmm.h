@@ -150,6 +150,11 @@ const char* pg_job_kernel_name(int cls);
 int  pg_job_profile_counters(pg_job* job, uint32_t contig, uint64_t out64[64]);
 /* Bytes of device memory held by the job. */
 uint64_t pg_job_device_bytes(const pg_job* job);
+/* How pg_job_run schedules the second half of every half-chain: 0 = fused (posterior partials formed
+ * inside the sweep, one launch; chosen when many chains fill the chip), 1 = chunked (store-only sweep
+ * chunks of *chunk_cols columns, posteriors of each finished chunk on the idle CUs; chosen for few
+ * chains).  Override with the environment variables PG_SWEEP_MODE=fused|chunked, PG_CHUNK_COLS=n. */
+int  pg_job_sweep_mode(const pg_job* job, uint32_t* chunk_cols);
 void pg_job_destroy(pg_job* job);
 
 /* ------------------------------------------------------------------ *

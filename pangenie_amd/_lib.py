@@ -121,6 +121,8 @@ def _bind_hip(lib):
     lib.pg_job_profile_counters.restype = C.c_int
     lib.pg_job_device_bytes.argtypes = [C.c_void_p]
     lib.pg_job_device_bytes.restype = C.c_uint64
+    lib.pg_job_sweep_mode.argtypes = [C.c_void_p, C.POINTER(C.c_uint32)]
+    lib.pg_job_sweep_mode.restype = C.c_int
     lib.pg_job_destroy.argtypes = [C.c_void_p]
     lib.pg_job_destroy.restype = None
     lib.pg_emission_table.argtypes = [C.POINTER(PgContigBatch), C.c_void_p, C.c_uint32, C.c_int,
@@ -137,7 +139,7 @@ HIP_ABI_SYMBOLS = [
     "pg_hmm_geno_offsets", "pg_table_create", "pg_table_create_default", "pg_table_modify",
     "pg_table_get", "pg_table_destroy", "pg_hmm_device_count", "pg_hmm_version",
     "pg_hmm_genotype_contig", "pg_job_create", "pg_job_run", "pg_job_fetch",
-    "pg_job_device_results", "pg_job_profile_counters", "pg_job_kernel_ms", "pg_job_kernel_name", "pg_job_device_bytes",
+    "pg_job_device_results", "pg_job_profile_counters", "pg_job_kernel_ms", "pg_job_kernel_name", "pg_job_device_bytes", "pg_job_sweep_mode",
     "pg_job_destroy", "pg_emission_table", "pg_transition_probs",
 ]
 

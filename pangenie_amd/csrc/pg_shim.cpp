@@ -604,6 +604,11 @@ extern "C" int pg_job_kernel_ms(const pg_job* job, double ms[PG_N_KERNEL_CLASSES
 }
 extern "C" const char* pg_job_kernel_name(int cls) { return (cls >= 0 && cls < PG_N_KERNEL_CLASSES) ? kKernelNames[cls] : ""; }
 extern "C" uint64_t pg_job_device_bytes(const pg_job* job) { return job ? job->arena_bytes : 0; }
+extern "C" int pg_job_sweep_mode(const pg_job* job, uint32_t* chunk_cols) {
+    if (!job) return PG_ERR_INVALID;
+    if (chunk_cols) *chunk_cols = job->chunk_cols;
+    return job->chunked ? 1 : 0;
+}
 
 extern "C" int pg_hmm_genotype_contig(const pg_contig_batch* batch, const pg_table* table, const pg_hmm_params* params,
                                       int device, pg_contig_result* out, char* err, size_t errlen) {

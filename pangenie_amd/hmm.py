@@ -175,6 +175,12 @@ class Job:
     def device_bytes(self) -> int:
         return int(self._lib.pg_job_device_bytes(self.h))
 
+    def sweep_mode(self):
+        """("fused" | "chunked", chunk_cols) — see include/pangenie_hmm.h:pg_job_sweep_mode."""
+        k = C.c_uint32(0)
+        m = self._lib.pg_job_sweep_mode(self.h, C.byref(k))
+        return ("chunked" if m == 1 else "fused"), int(k.value)
+
     def close(self):
         if getattr(self, "h", None):
             self._lib.pg_job_destroy(self.h)

@@ -31,7 +31,10 @@ for name, col in (("pmc_fetch", "FETCH_SIZE"), ("pmc_write", "WRITE_SIZE")):
         cnt[k] = cnt.get(k, 0) + 1
     for k in agg:
         per_launch = agg[k] / cnt[k] * 1024.0 * (2.0 if col == "FETCH_SIZE" else 1.0)
-        out["kernels"].setdefault(k, {})[("hbm_read_bytes" if col == "FETCH_SIZE" else "hbm_write_bytes") + "_per_launch"] = per_launch
+        key = "hbm_read_bytes" if col == "FETCH_SIZE" else "hbm_write_bytes"
+        out["kernels"].setdefault(k, {})[key + "_per_launch"] = per_launch
+        out["kernels"][k][key + "_total"] = per_launch * cnt[k]
+        out["kernels"][k]["pmc_launches"] = cnt[k]
 lines.append("")
 lines.append("HBM traffic per launch from PMC (bytes; reads = 2*FETCH_SIZE*1024, writes = WRITE_SIZE*1024):")
 for k, v in out["kernels"].items():
