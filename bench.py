@@ -134,27 +134,34 @@ def main():
     job = hmm.Job(batches, table, params, device=local_rank)
     upload_s = time.perf_counter() - t_up
 
-    # gather plumbing: posteriors stay on the device; chain r lives on rank r (weak scaling),
-    # rank 0 collects the packed (lik, lik_exp) of every rank with ONE RCCL gather per step
+    # gather plumbing: posteriors stay on the device; every rank owns its own n_chains chains (weak
+    # scaling), rank 0 collects the packed (lik, lik_exp) of ALL chains of every rank with ONE RCCL
+    # gather per step and keeps them in HBM (like the single-GPU run, the timed region ends with the
+    # posteriors resident on a device, not on the host)
     hip = C.CDLL("libamdhip64.so")
-    d_lik, n_lik, d_exp, n_var = job.device_results(0)
-    lik_t = torch.empty(n_lik, dtype=torch.float64, device="cuda")
-    exp_t = torch.empty(n_var, dtype=torch.int32, device="cuda")
-    plan, all_lik, all_var = [[r] for r in range(world)], [n_lik], [n_var]
+    dev_res = [job.device_results(i) for i in range(n_chains)]
+    plan = [[r * n_chains + i for i in range(n_chains)] for r in range(world)]
+    all_lik, all_var, local_t = [], [], {}
     if world > 1:
         from pangenie_amd.dist import gather_posteriors
-        sizes = torch.tensor([n_lik, n_var], dtype=torch.int64, device="cuda")
-        allsz = [torch.empty_like(sizes) for _ in range(world)]
-        dist.all_gather(allsz, sizes)
-        all_lik = [int(t[0]) for t in allsz]
-        all_var = [int(t[1]) for t in allsz]
+        mine = torch.tensor([[d[1], d[3]] for d in dev_res], dtype=torch.int64, device="cuda")
+        allsz = [torch.empty_like(mine) for _ in range(world)]
+        dist.all_gather(allsz, mine)
+        for t in allsz:  # chain ids are rank-major, same order as `plan`
+            all_lik += [int(x) for x in t[:, 0]]
+            all_var += [int(x) for x in t[:, 1]]
+        for i, (d_lik, n_lik, d_exp, n_var) in enumerate(dev_res):
+            local_t[rank * n_chains + i] = (torch.empty(n_lik, dtype=torch.float64, device="cuda"),
+                                            torch.empty(n_var, dtype=torch.int32, device="cuda"))
 
     def step():
         job.run()
         if world > 1:
-            hip.hipMemcpy(C.c_void_p(lik_t.data_ptr()), C.c_void_p(d_lik), C.c_size_t(n_lik * 8), 3)
-            hip.hipMemcpy(C.c_void_p(exp_t.data_ptr()), C.c_void_p(d_exp), C.c_size_t(n_var * 4), 3)
-            gather_posteriors({rank: (lik_t, exp_t)}, all_lik, all_var, plan, dst=0)
+            for i, (d_lik, n_lik, d_exp, n_var) in enumerate(dev_res):
+                lt, et = local_t[rank * n_chains + i]
+                hip.hipMemcpy(C.c_void_p(lt.data_ptr()), C.c_void_p(d_lik), C.c_size_t(n_lik * 8), 3)
+                hip.hipMemcpy(C.c_void_p(et.data_ptr()), C.c_void_p(d_exp), C.c_size_t(n_var * 4), 3)
+            gather_posteriors(local_t, all_lik, all_var, plan, dst=0, unpack=False)
 
     def fence():
         torch.cuda.synchronize()

@@ -36,8 +36,11 @@ def pack_sizes(n_lik: Sequence[int], n_var: Sequence[int], plan: List[List[int]]
 
 
 def gather_posteriors(local: Dict[int, Tuple["torch.Tensor", "torch.Tensor"]], n_lik: Sequence[int],
-                      n_var: Sequence[int], plan: List[List[int]], dst: int = 0):
+                      n_var: Sequence[int], plan: List[List[int]], dst: int = 0, unpack: bool = True):
     """One gather of every rank's packed posteriors to `dst`.
+
+    unpack=False leaves the gathered packed buffers on dst's device (list of world tensors) — what a
+    timed loop wants: like a single-GPU run it ends with the posteriors resident in HBM.
 
     local: {chain id: (lik f64 tensor [n_lik], lik_exp i32 tensor [n_var])} for this rank's chains,
     on the device the process group works with (cuda for nccl = RCCL, cpu for gloo).
@@ -61,6 +64,8 @@ def gather_posteriors(local: Dict[int, Tuple["torch.Tensor", "torch.Tensor"]], n
     dist.gather(buf, out, dst=dst)
     if rank != dst:
         return None
+    if not unpack:
+        return out
     res = {}
     for r in range(world):
         flat = out[r].cpu().numpy()
