@@ -1652,7 +1652,7 @@ static void launch_sweep(const DevContig* d_contigs, uint32_t n_contigs, uint32_
     if (hp_mask & 1u) launch_one<16, 4, 1, true, PHASE>(d_contigs, n_contigs, chunk, s);
     if (hp_mask & 2u) launch_one<32, 16, 1, true, PHASE>(d_contigs, n_contigs, chunk, s);
     if (hp_mask & 4u) launch_one<64, 16, 1, true, PHASE>(d_contigs, n_contigs, chunk, s);
-    if constexpr (PHASE != 3) { if (hp_mask & 8u) launch_one<128, 32, 1, false, PHASE>(d_contigs, n_contigs, chunk, s); }
+    if (hp_mask & 8u) launch_one<128, 32, 1, false, PHASE>(d_contigs, n_contigs, chunk, s);
 }
 extern "C" {
 

@@ -341,7 +341,7 @@ extern "C" pg_job* pg_job_create(int device, uint32_t n_contigs, const pg_contig
             if (!strcmp(m, "fused")) want = false;
             else if (!strcmp(m, "chunked")) want = true;
         }
-        job->chunked = want && max_hp <= 64 && max_v > 0 && params->run_genotyping;
+        job->chunked = want && max_v > 0 && params->run_genotyping;
         if (job->chunked) {
             size_t k = 4096;
             const size_t budget = (size_t)12 << 30;

@@ -190,11 +190,11 @@ def test_no_columns_and_empty(orc):
     assert not res.n_kmers.any() and not res.coverage.any()  # reference src/hmm.cpp:94
 
 
-@pytest.mark.parametrize("mode,hs", [("fused", [16, 64, 64, 32, 16, 128]), ("chunked", [16, 64, 64, 32, 16]), ("fused", [16, 64, 32])])
+@pytest.mark.parametrize("mode,hs", [("fused", [16, 64, 64, 32, 16, 128]), ("chunked", [16, 64, 64, 32, 16, 128])])
 def test_multi_contig_job_matches_single_calls(orc, monkeypatch, mode, hs):
-    """One resident job over contigs of different length and haplotype count, in both sweep modes
-    (a job containing H = 128 always runs fused).  Bitwise comparisons are made within one mode:
-    the two modes sum in a different order and differ in the last bits."""
+    """One resident job over contigs of different length and haplotype count, in both sweep modes.
+    Bitwise comparisons are made within one mode: the two modes sum in a different order and
+    differ in the last bits."""
     monkeypatch.setenv("PG_SWEEP_MODE", mode)
     monkeypatch.setenv("PG_CHUNK_COLS", "64")  # several chunks even on these small panels
     args = default_table_args()
