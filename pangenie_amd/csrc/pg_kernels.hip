@@ -1015,7 +1015,7 @@ DEVI void forward_body(const DevContig& dc, ChainShared<HP, R>& sh, uint32_t C, 
             }
         }
         write_colsums<HP, R>(sh, t & 1u, p, part);
-        if (p.tid == 0) fscale[t] = m;
+        if (Cfg::NW == 1 || p.tid == 0) fscale[t] = m;  // (single-wave configurations: all lanes, same address, no exec juggling)
         if constexpr (PHASE == 2) {
             // posterior of the column just formed (optimistic: if the column turns out to sum to
             // zero, the next step flags it and k_bins re-forms its bins from the uniform column)
@@ -1321,7 +1321,7 @@ DEVI void backward_body(const DevContig& dc, ChainShared<HP, R>& sh, uint32_t C,
             // analytically through kappa, so all of this sits in front of the barrier)
             const int es = exponent_of(Sy);
             const double m = ldexp(Sy, -es);
-            if (p.tid == 0) bscale[t] = m;
+            if (Cfg::NW == 1 || p.tid == 0) bscale[t] = m;
             const double k0 = ldexp(cur.c0, -es), k1 = ldexp(cur.c1, -es), k2 = ldexp(cur.c2, -es);
             const double kap = ldexp(cur.kappa, -es);
             double vt[RING ? R : 1];
@@ -1370,7 +1370,7 @@ DEVI void backward_body(const DevContig& dc, ChainShared<HP, R>& sh, uint32_t C,
                 }
             }
             write_colsums<HP, R>(sh, (uint32_t)(t - 1) & 1u, p, part);
-            if constexpr (STORE) { if (p.tid == 0) bsum[t] = Snew; }
+            if constexpr (STORE) { if (Cfg::NW == 1 || p.tid == 0) bsum[t] = Snew; }
             else posterior<HP, R>(sh, part_out, part_slots, nxt, (uint32_t)t, p, vt, y);
             Sy = Snew > 0.0 ? Snew : 1.0;
             cur = nxt;
