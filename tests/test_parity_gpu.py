@@ -170,6 +170,24 @@ def test_unregularized_table_zero_emissions_vs_oracle(orc):
     assert_parity(b, res, ref)
 
 
+@pytest.mark.parametrize("K", [1, 2, 5, 64])
+def test_chunk_boundaries_with_fallback_columns(K, orc, monkeypatch):
+    """Chunked sweep mode with tiny chunks: every few columns the recursion is resumed from a
+    stored column, on a panel whose unregularised table produces exact zeros (forward columns
+    that fall back to uniform, backward columns that are all zero) — so fallbacks land on, before
+    and behind chunk boundaries.  Same bar as everywhere: 1e-6 relative, identical calls."""
+    monkeypatch.setenv("PG_SWEEP_MODE", "chunked")
+    monkeypatch.setenv("PG_CHUNK_COLS", str(K))
+    args = (6, 108, 54, 0.0)
+    for seed, H, multi in ((5, 16, 0.0), (6, 64, 0.3), (7, 27, 0.2)):
+        b = synthetic_panel(160, H, 20, seed=seed, multiallelic_frac=multi)
+        b.kmer_count[::3] = 0
+        b.kmer_count[1::17] = 60000
+        res = hmm.genotype_contig(b, hmm.ProbabilityTable(*args), hmm.make_params(1.26, False, 1e-5))
+        ref = orc.genotype_contig(b, orc.OracleTable(*args), orc.make_params(1.26, False, 1e-5))
+        assert_parity(b, res, ref)
+
+
 def test_emission_dominated_corner_vs_oracle(orc):
     # many k-mers per allele (K = 32 per allele, multiallelic): emission scale ~1e-150 per column
     b = synthetic_panel(300, 16, 160, seed=9, multiallelic_frac=1.0)
