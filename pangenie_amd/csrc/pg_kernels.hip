@@ -61,6 +61,19 @@ DEVI double wave_sum(double v) {
     return readlane_f64(v, 63);
 }
 
+// Sum over the first N lanes only (N = 16: one DPP row; N = 32: two rows), broadcast to every lane.
+template <int N>
+DEVI double lanes_sum(double v) {
+    static_assert(N == 16 || N == 32 || N == 64, "DPP row multiples");
+    if constexpr (N == 64) return wave_sum(v);
+    v += dpp_f64<0x111, 0xF, true>(v);
+    v += dpp_f64<0x112, 0xF, true>(v);
+    v += dpp_f64<0x114, 0xF, true>(v);
+    v += dpp_f64<0x118, 0xF, true>(v);
+    if constexpr (N == 32) v += dpp_f64<0x142, 0xA, false>(v);
+    return readlane_f64(v, N - 1);
+}
+
 DEVI void wave_sync() {
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
     __builtin_amdgcn_wave_barrier();
@@ -677,8 +690,8 @@ DEVI void read_colsums(const ChainShared<HP, R>& sh, uint32_t pb, const ThreadPo
 template <int HP>
 DEVI double total_sum(double Call) {
     if (kExp & 2u) return Call * 64.0;
-    const double s = wave_sum(Call);
-    return HP < 64 ? s * ((double)HP / 64.0) : s;  // HP < 64: every column sits in 64/HP lanes (exact power of two)
+    // HP < 64: lanes 0..HP-1 hold every column once (the other lanes repeat them): reduce those only
+    return lanes_sum<(HP < 64 ? HP : 64)>(Call);
 }
 template <int HP, int R>
 DEVI void write_colsums(ChainShared<HP, R>& sh, uint32_t pb, const ThreadPos& p, double part) {
