@@ -18,7 +18,7 @@
 #define PG_AMAX 5                 // max distinct alleles on the selected paths of one column (fast path)
 #define PG_ESTRIDE (PG_AMAX + 1)  // row stride of the expanded emission table; row/col PG_AMAX = 0 (phantom paths)
 #define PG_ETAB (PG_ESTRIDE * PG_ESTRIDE)
-#define PG_MAX_ALLELES_PER_VARIANT 10  // all alleles of one UniqueKmers object handled by k_prep (pairs <= 64)
+#define PG_MAX_ALLELES_PER_VARIANT 32  // all alleles of one UniqueKmers object (k_prep keeps their presence in a 32-bit mask)
 #define PG_PHANTOM 255
 
 // byte offsets inside a record

@@ -233,6 +233,10 @@ DEVI void emission_pair_products(const DevContig& dc, const DevTable& tab, uint3
     }
 }
 
+DEVI uint32_t tri_local(uint32_t a, uint32_t b) {  // a <= b < PG_AMAX
+    return a * PG_AMAX - a * (a - 1) / 2 + (b - a);
+}
+
 DEVI void decode_pair(uint32_t idx, uint32_t A, uint32_t& s1, uint32_t& s2) {
     uint32_t a = 0, rem = idx;
     while (a < A && rem >= A - a) { rem -= A - a; ++a; }
@@ -246,6 +250,8 @@ __global__ __launch_bounds__(256) void k_prep(const DevContig* __restrict__ cont
     __shared__ double s_m[4][64 * 3];
     __shared__ int s_e[4][64 * 3];
     __shared__ double s_E[4][PG_ETAB];
+    __shared__ double s_pm[4][PG_AMAX * (PG_AMAX + 1) / 2];
+    __shared__ int s_pe[4][PG_AMAX * (PG_AMAX + 1) / 2];
     const DevContig& dc = contigs[blockIdx.y];
     const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const uint32_t v = blockIdx.x * 4 + wave;
@@ -304,23 +310,48 @@ __global__ __launch_bounds__(256) void k_prep(const DevContig* __restrict__ cont
         if (lane == 0) ((unsigned long long*)(rec + PG_REC_BITS1))[p0 >> 6] = b1;
     }
 
-    // ---- emission products over ALL allele pairs of the object (a1<=a2; table is symmetric)
+    // ---- emission products over ALL allele pairs of the object (a1<=a2; table is symmetric),
+    //      64 pairs (one per lane) at a time.  Only pairs of alleles present on the selected paths
+    //      enter the column's table, but the all_zeros rule looks at every pair of the object
+    //      (emissionprobabilitycomputer.cpp:24).
     const uint32_t P = A * (A + 1) / 2;
-    const bool active = lane < P;
-    uint32_t s1 = 0, s2 = 0;
-    if (active) decode_pair(lane, A, s1, s2);
-    double pm; int pe;
-    emission_pair_products(dc, tab, v, lane, active, s1, s2, s_m[wave], s_e[wave], pm, pe);
-
-    const bool all_zeros = __any(active && pm > 0.0) == 0;  // emissionprobabilitycomputer.cpp:24
-    const bool both_present = active && ((pmask >> s1) & 1u) && ((pmask >> s2) & 1u);
-    int X = wave_max_i32((both_present && pm > 0.0) ? pe : -(1 << 30));
+    constexpr int NLP = PG_AMAX * (PG_AMAX + 1) / 2;  // local pairs
+    if (lane < (uint32_t)NLP) { s_pm[wave][lane] = 0.0; s_pe[wave][lane] = 0; }
+    wave_sync();
+    bool any_nonzero = false;
+    for (uint32_t base = 0; base < P; base += 64) {
+        const uint32_t idx = base + lane;
+        const bool active = idx < P;
+        uint32_t s1 = 0, s2 = 0;
+        if (active) decode_pair(idx, A, s1, s2);
+        double pm; int pe;
+        emission_pair_products(dc, tab, v, lane, active, s1, s2, s_m[wave], s_e[wave], pm, pe);
+        any_nonzero = any_nonzero || (__any(active && pm > 0.0) != 0);
+        if (active && ((pmask >> s1) & 1u) && ((pmask >> s2) & 1u)) {
+            const uint32_t la = __popc(pmask & ((1u << s1) - 1u)), lb = __popc(pmask & ((1u << s2) - 1u));
+            s_pm[wave][tri_local(la, lb)] = pm;  // s1 <= s2  =>  la <= lb
+            s_pe[wave][tri_local(la, lb)] = pe;
+        }
+    }
+    wave_sync();
+    const bool all_zeros = !any_nonzero;
+    // this lane's local pair (la <= lb < n_local), if any
+    uint32_t la = 0, lb = 0;
+    bool mine = false;
+    if (lane < (uint32_t)NLP) {
+        uint32_t rem = lane;
+        while (la < PG_AMAX && rem >= PG_AMAX - la) { rem -= PG_AMAX - la; ++la; }
+        lb = la + rem;
+        mine = lb < n_local;
+    }
+    const double pm = mine ? s_pm[wave][lane] : 0.0;
+    const int pe = mine ? s_pe[wave][lane] : 0;
+    int X = wave_max_i32((mine && pm > 0.0) ? pe : -(1 << 30));
     if (X == -(1 << 30) || all_zeros) X = 0;
 
     if (lane < PG_ETAB) s_E[wave][lane] = 0.0;
     wave_sync();
-    if (both_present) {
-        const uint32_t la = __popc(pmask & ((1u << s1) - 1u)), lb = __popc(pmask & ((1u << s2) - 1u));
+    if (mine) {
         double val;
         if (all_zeros) val = 1.0;                           // emissionprobabilitycomputer.cpp:31-34
         else val = (pm > 0.0) ? ldexp(pm, pe - X) : pm;     // 0 (or NaN) stays
@@ -1425,9 +1456,6 @@ __global__ __launch_bounds__((ChainCfg<HP, R>::TT)) void k_sweep(const DevContig
 //  L_v({a,b}) = sum over states (i,j) with alleles {a,b} of alpha_hat * beta~ * fsum
 //  (reference src/hmm.cpp:364-368); exponent = X_c + X_{c+1}.
 // ------------------------------------------------------------------------------------------
-DEVI uint32_t tri_local(uint32_t a, uint32_t b) {  // a <= b < PG_AMAX
-    return a * PG_AMAX - a * (a - 1) / 2 + (b - a);
-}
 
 __global__ __launch_bounds__(256) void k_bins(const DevContig* __restrict__ contigs) {
     __shared__ double s_bins[4][PG_AMAX * (PG_AMAX + 1) / 2];

@@ -241,11 +241,11 @@ def default_table_args(peak: int = PEAK):
 def synthetic_panel(n_variants: int, n_paths: int, kmers_per_variant: int = 20, *,
                     seed: int = 12345, multiallelic_frac: float = 0.0,
                     undefined_frac: float = 0.01, zero_kmer_frac: float = 0.01,
-                    peak: int = PEAK) -> ContigBatch:
+                    peak: int = PEAK, max_alleles: int = 5) -> ContigBatch:
     """Deterministic synthetic contig of the shapes BASELINE.json names.
 
     Positions step by 50+U[0,1200) bp; allele frequency f~U(.05,.95); each path carries ALT
-    with probability f (multiallelic: uniform among 1..A-1, A~U{3,4,5}); the sample's true
+    with probability f (multiallelic: uniform among 1..A-1, A~U{3..max_alleles}); the sample's true
     genotype follows two panel paths; K k-mers per variant split evenly over the alleles,
     each k-mer on exactly one allele (as UniqueKmerComputer produces them, reference
     src/uniquekmercomputer.cpp:59-69); read counts ~ Poisson(cn*peak/2) for cn in {1,2},
@@ -259,10 +259,12 @@ def synthetic_panel(n_variants: int, n_paths: int, kmers_per_variant: int = 20, 
     n_all = np.full(V, 2, dtype=np.int64)
     if multiallelic_frac > 0:
         multi = rng.random(V) < multiallelic_frac
-        n_all[multi] = rng.integers(3, 6, size=int(multi.sum()))
+        n_all[multi] = rng.integers(3, max(6, max_alleles + 1), size=int(multi.sum()))
     f = rng.uniform(0.05, 0.95, size=V)
     carries_alt = rng.random((V, H)) < f[:, None]
-    alt_choice = 1 + (rng.integers(0, 1 << 30, size=(V, H)) % (n_all[:, None] - 1))
+    # (max_alleles > 5: bubbles with many alleles in the object of which the panel paths carry at
+    # most four ALTs — what a sampled panel looks like on a hypervariable site)
+    alt_choice = 1 + (rng.integers(0, 1 << 30, size=(V, H)) % np.minimum(n_all[:, None] - 1, 4 if max_alleles > 5 else 1 << 30))
     path_allele = np.where(carries_alt, alt_choice, 0).astype(np.uint16)
 
     # sample haplotypes: two panel paths with occasional switches

@@ -188,6 +188,22 @@ def test_chunk_boundaries_with_fallback_columns(K, orc, monkeypatch):
         assert_parity(b, res, ref)
 
 
+def test_many_alleles_per_variant_vs_oracle(orc):
+    """UniqueKmers objects with up to 32 alleles of which the selected paths carry <= 5: the
+    emission products (and the all_zeros rule) run over all A(A+1)/2 pairs, 64 at a time."""
+    b = synthetic_panel(300, 16, 128, seed=21, multiallelic_frac=0.6, max_alleles=32, undefined_frac=0.1)
+    assert int(np.diff(b.allele_off).max()) > 20
+    args = default_table_args()
+    res = hmm.genotype_contig(b, hmm.ProbabilityTable(*args), hmm.make_params(1.26, False, 1e-5))
+    ref = orc.genotype_contig(b, orc.OracleTable(*args), orc.make_params(1.26, False, 1e-5))
+    assert_parity(b, res, ref)
+    for v in (int(np.argmax(np.diff(b.allele_off))), 7):
+        Eh, zh = hmm.emission_table(b, hmm.ProbabilityTable(*args), v)
+        Eo, zo = orc.emission_table(b, orc.OracleTable(*args), v)
+        den = np.maximum(np.abs(Eh), np.abs(Eo))
+        assert zh == zo and float(np.where(den > 0, np.abs(Eh - Eo) / np.where(den > 0, den, 1), 0).max()) < 1e-9
+
+
 def test_emission_dominated_corner_vs_oracle(orc):
     # many k-mers per allele (K = 32 per allele, multiallelic): emission scale ~1e-150 per column
     b = synthetic_panel(300, 16, 160, seed=9, multiallelic_frac=1.0)
