@@ -254,6 +254,26 @@ def test_limits_are_reported_not_silently_wrong():
     assert e.value.code == hmm._lib.PG_ERR_UNSUPPORTED
 
 
+def test_allele_limits_are_reported(orc):
+    t, p = hmm.ProbabilityTable(*default_table_args()), hmm.make_params()
+    # more than 32 alleles in one UniqueKmers object
+    b = synthetic_panel(60, 16, 160, seed=3, multiallelic_frac=1.0, max_alleles=40)
+    assert int(np.diff(b.allele_off).max()) > 32
+    with pytest.raises(hmm.PanGenieError) as e:
+        hmm.genotype_contig(b, t, p)
+    assert e.value.code == hmm._lib.PG_ERR_UNSUPPORTED
+    # more than 5 distinct alleles on the selected paths of one column
+    b = synthetic_panel(60, 16, 128, seed=4, multiallelic_frac=1.0, max_alleles=12)
+    A = np.diff(b.allele_off)
+    v = int(np.argmax(A))
+    assert A[v] >= 8
+    pa = b.path_allele.reshape(b.n_variants, 16)
+    pa[v, :8] = np.arange(8, dtype=np.uint16)
+    with pytest.raises(hmm.PanGenieError) as e:
+        hmm.genotype_contig(b, t, p)
+    assert e.value.code == hmm._lib.PG_ERR_UNSUPPORTED
+
+
 def test_full_size_properties():
     """BASELINE.json configs[2] shape (200k variants x 64 haplotypes): size-independent checks.
     (a) determinism; (b) normalised posteriors sum to 1; (c) reversibility: the Li-Stephens
