@@ -15,7 +15,7 @@
 #pragma once
 #include <stdint.h>
 
-#define PG_AMAX 5                 // max distinct alleles on the selected paths of one column (fast path)
+#define PG_AMAX 5                 // max distinct alleles on the selected paths of a NARROW column (table inside the record)
 #define PG_ESTRIDE (PG_AMAX + 1)  // row stride of the expanded emission table; row/col PG_AMAX = 0 (phantom paths)
 #define PG_ETAB (PG_ESTRIDE * PG_ESTRIDE)
 #define PG_MAX_ALLELES_PER_VARIANT 32  // all alleles of one UniqueKmers object (k_prep keeps their presence in a 32-bit mask)
@@ -35,6 +35,19 @@
 #define PG_REC_E 80           // double[PG_ETAB]
 #define PG_REC_ALLELES (80 + 8 * PG_ETAB)  // u8[HP]
 #define PG_REC_FLAG_ALLZERO 1
+#define PG_REC_FLAG_WIDE 2    // more than PG_AMAX alleles on the selected paths: table in DevContig::wide
+#define PG_REC_WIDE_IDX 44    // u32: index of the variant's wide entry
+
+// Wide entries (columns with PG_AMAX < n_local <= PG_WIDE_MAX distinct alleles on the selected paths;
+// chunked sweep mode only): the emission table no longer fits the column record, so it lives in a
+// side buffer — double E[PG_WIDE_STRIDE][PG_WIDE_STRIDE] (symmetric, scaled by 2^-X like the narrow
+// one; row/column PG_WIDE_MAX is zero: phantom paths) followed by u16 local_slot[PG_WIDE_MAX] — one
+// entry per variant with more than PG_AMAX alleles.
+#define PG_WIDE_MAX 32
+#define PG_WIDE_STRIDE (PG_WIDE_MAX + 1)
+#define PG_WIDE_TABLE_BYTES (PG_WIDE_STRIDE * PG_WIDE_STRIDE * 8)
+#define PG_WIDE_ENTRY_BYTES (PG_WIDE_TABLE_BYTES + PG_WIDE_MAX * 2)  /* 8776: a multiple of 8 */
+#define PG_WIDE_NONE 0xFFFFFFFFu
 
 static inline uint32_t pg_rec_bytes(uint32_t hp) { return (PG_REC_ALLELES + hp + 63u) & ~63u; }
 
@@ -91,6 +104,8 @@ struct DevContig {
     double*   scratch;
     uint32_t  chunk_cols;
     uint32_t  pad3;
+    uint8_t*  wide;            // [n_wide][PG_WIDE_ENTRY_BYTES]
+    const uint32_t* wide_idx;  // [V]: entry of variant v, PG_WIDE_NONE if it has <= PG_AMAX alleles
     uint32_t* err;
     unsigned long long* prof;  // [64] in-kernel cycle counters (PG_DEBUG bit 3), profiling only
     // outputs

@@ -288,7 +288,12 @@ __global__ __launch_bounds__(256) void k_prep(const DevContig* __restrict__ cont
     if (lane < A) dc.allele_present[a0 + lane] = (pmask >> lane) & 1u;
     if (lane == 0) dc.kept[v] = kept ? 1 : 0;
     if (!kept) return;
-    if (n_local > PG_AMAX) {
+    // more than PG_AMAX alleles on the selected paths: a WIDE column, its table goes to the side
+    // buffer (chunked sweep mode only; pg_shim.cpp allocates an entry for every variant that could
+    // be wide and forces that mode)
+    const bool wide = n_local > PG_AMAX;
+    const uint32_t widx = wide && dc.wide_idx ? dc.wide_idx[v] : PG_WIDE_NONE;
+    if (wide && (widx == PG_WIDE_NONE || n_local > PG_WIDE_MAX)) {
         if (lane == 0) atomicOr(dc.err, PG_DEVERR_TOO_MANY_LOCAL);
         return;
     }
@@ -315,6 +320,57 @@ __global__ __launch_bounds__(256) void k_prep(const DevContig* __restrict__ cont
     //      enter the column's table, but the all_zeros rule looks at every pair of the object
     //      (emissionprobabilitycomputer.cpp:24).
     const uint32_t P = A * (A + 1) / 2;
+    if (wide) {
+        // two passes over the pairs: (1) all_zeros and the largest exponent X among the present pairs,
+        // (2) the products again, scaled by 2^-X, straight into the wide entry (rare columns: the
+        // recomputation is cheaper than staging up to 528 (mantissa, exponent) pairs)
+        double* Ew = (double*)(dc.wide + (size_t)widx * PG_WIDE_ENTRY_BYTES);
+        uint16_t* slots = (uint16_t*)(dc.wide + (size_t)widx * PG_WIDE_ENTRY_BYTES + PG_WIDE_TABLE_BYTES);
+        for (uint32_t q = lane; q < PG_WIDE_STRIDE * PG_WIDE_STRIDE; q += 64) Ew[q] = 0.0;  // incl. the phantom row/column
+        bool any_nz = false;
+        int Xw = -(1 << 30);
+        for (int pass = 0; pass < 2; ++pass) {
+            if (pass == 1 && (Xw == -(1 << 30) || !any_nz)) Xw = 0;
+            for (uint32_t base = 0; base < P; base += 64) {
+                const uint32_t idx = base + lane;
+                const bool active = idx < P;
+                uint32_t s1 = 0, s2 = 0;
+                if (active) decode_pair(idx, A, s1, s2);
+                double pm; int pe;
+                emission_pair_products(dc, tab, v, lane, active, s1, s2, s_m[wave], s_e[wave], pm, pe);
+                const bool both = active && ((pmask >> s1) & 1u) && ((pmask >> s2) & 1u);
+                if (pass == 0) {
+                    any_nz = any_nz || (__any(active && pm > 0.0) != 0);
+                    const int xm = wave_max_i32((both && pm > 0.0) ? pe : -(1 << 30));
+                    Xw = xm > Xw ? xm : Xw;
+                } else if (both) {
+                    const uint32_t la = __popc(pmask & ((1u << s1) - 1u)), lb = __popc(pmask & ((1u << s2) - 1u));
+                    double val;
+                    if (!any_nz) val = 1.0;                             // all_zeros: emissionprobabilitycomputer.cpp:31-34
+                    else val = (pm > 0.0) ? ldexp(pm, pe - Xw) : pm;
+                    Ew[la * PG_WIDE_STRIDE + lb] = val;
+                    Ew[lb * PG_WIDE_STRIDE + la] = val;
+                }
+            }
+        }
+        if (lane < PG_ETAB) ((double*)(rec + PG_REC_E))[lane] = 0.0;
+        if (lane < 4) ((double*)rec)[lane] = 0.0;
+        if (lane == 0) {
+            *(uint32_t*)(rec + PG_REC_VARIANT) = v;
+            *(int32_t*)(rec + PG_REC_EXP) = Xw;
+            rec[PG_REC_NLOCAL] = (unsigned char)n_local;
+            rec[PG_REC_FLAGS] = (unsigned char)((any_nz ? 0 : PG_REC_FLAG_ALLZERO) | PG_REC_FLAG_WIDE);
+            rec[PG_REC_FLAGS + 1] = 0; rec[PG_REC_FLAGS + 2] = 0;
+            *(uint32_t*)(rec + PG_REC_WIDE_IDX) = widx;
+            uint16_t* ls = (uint16_t*)(rec + PG_REC_LOCAL_SLOT);
+            for (uint32_t l = 0; l < 8; ++l) ls[l] = 0;
+            uint32_t l = 0;
+            for (uint32_t sl = 0; sl < A; ++sl)
+                if ((pmask >> sl) & 1u) slots[l++] = (uint16_t)sl;
+            for (; l < PG_WIDE_MAX; ++l) slots[l] = 0;
+        }
+        return;
+    }
     constexpr int NLP = PG_AMAX * (PG_AMAX + 1) / 2;  // local pairs
     if (lane < (uint32_t)NLP) { s_pm[wave][lane] = 0.0; s_pe[wave][lane] = 0; }
     wave_sync();
@@ -367,7 +423,7 @@ __global__ __launch_bounds__(256) void k_prep(const DevContig* __restrict__ cont
         rec[PG_REC_NLOCAL] = (unsigned char)n_local;
         rec[PG_REC_FLAGS] = all_zeros ? PG_REC_FLAG_ALLZERO : 0;
         rec[PG_REC_FLAGS + 1] = 0; rec[PG_REC_FLAGS + 2] = 0;
-        *(uint32_t*)(rec + 44) = 0;
+        *(uint32_t*)(rec + PG_REC_WIDE_IDX) = PG_WIDE_NONE;
         uint16_t* ls = (uint16_t*)(rec + PG_REC_LOCAL_SLOT);
         uint32_t l = 0;
         for (uint32_t s = 0; s < A; ++s)
@@ -579,11 +635,26 @@ DEVI void lds_wave_sync() {
 // x = m * 2^e with m in [0.5,1)  (x > 0, finite)
 DEVI int exponent_of(double x) { return __builtin_amdgcn_frexp_exp(x); }
 
-// general emission lookup: E[a_i][a_j]; phantom paths (255) hit the zero row/column PG_AMAX
-DEVI double emission_at(const unsigned char* rec, uint32_t i, uint32_t aj) {
-    uint32_t ai = rec[PG_REC_ALLELES + i];
-    ai = ai > PG_AMAX ? PG_AMAX : ai;
+// general emission lookup: E[a_i][a_j].  Narrow columns: the (PG_AMAX+1)^2 table inside the LDS
+// record, phantom paths (255) hit its zero row/column PG_AMAX.  Wide columns (more than PG_AMAX
+// alleles on the selected paths): the PG_WIDE_MAX^2 table of the variant's wide entry in global
+// memory (L2-resident for the duration of the column; rare, so no staging).
+struct EmSrc {
+    const double* wide;  // nullptr: narrow
+    uint32_t ajr;        // this thread's column allele, raw (PG_PHANTOM for padding paths)
+};
+DEVI double emission_narrow(const unsigned char* rec, uint32_t i, const EmSrc& es) {
+    const uint32_t air = rec[PG_REC_ALLELES + i];
+    const uint32_t ai = air > PG_AMAX ? PG_AMAX : air, aj = es.ajr > PG_AMAX ? PG_AMAX : es.ajr;
     return ((const double*)(rec + PG_REC_E))[ai * PG_ESTRIDE + aj];
+}
+DEVI double emission_wide(const unsigned char* rec, uint32_t i, const EmSrc& es) {
+    const uint32_t air = rec[PG_REC_ALLELES + i];
+    const uint32_t ai = air > PG_WIDE_MAX ? PG_WIDE_MAX : air, aj = es.ajr > PG_WIDE_MAX ? PG_WIDE_MAX : es.ajr;
+    return ((gcdouble*)es.wide)[ai * PG_WIDE_STRIDE + aj];
+}
+DEVI double emission_at(const unsigned char* rec, uint32_t i, const EmSrc& es) {
+    return es.wide ? emission_wide(rec, i, es) : emission_narrow(rec, i, es);
 }
 DEVI uint32_t col_allele(const unsigned char* rec, uint32_t j) {
     uint32_t aj = rec[PG_REC_ALLELES + j];
@@ -616,11 +687,12 @@ DEVI FastE fast_setup(const unsigned char* rec, uint32_t j, uint32_t i0) {
 struct RecInfo {
     double c0, c1, c2, kappa;
     FastE fe;
-    uint32_t aj, nl;
+    EmSrc em;
+    uint32_t nl;
     bool fast;
 };
 template <bool UNI>
-DEVI RecInfo decode_record(const unsigned char* rec, uint32_t j, uint32_t i0, bool full) {
+DEVI RecInfo decode_record(const unsigned char* rec, uint32_t j, uint32_t i0, bool full, const uint8_t* wide_base) {
     RecInfo r;
     r.c0 = *(const double*)(rec + PG_REC_C0);
     r.c1 = *(const double*)(rec + PG_REC_C1);
@@ -628,7 +700,12 @@ DEVI RecInfo decode_record(const unsigned char* rec, uint32_t j, uint32_t i0, bo
     r.kappa = *(const double*)(rec + PG_REC_KAPPA);
     r.nl = (uint32_t)__builtin_amdgcn_readfirstlane((int)rec[PG_REC_NLOCAL]);  // same record for every lane: keep it scalar
     r.fe = fast_setup<UNI>(rec, j, i0);
-    r.aj = col_allele(rec, j);
+    r.em.ajr = rec[PG_REC_ALLELES + j];
+    r.em.wide = nullptr;
+    if (r.nl > PG_AMAX) {  // wide column (scalar branch: nl is uniform)
+        const uint32_t widx = (uint32_t)__builtin_amdgcn_readfirstlane((int)*(const uint32_t*)(rec + PG_REC_WIDE_IDX));
+        r.em.wide = (const double*)(wide_base + (size_t)widx * PG_WIDE_ENTRY_BYTES);
+    }
     r.fast = full && r.nl <= 2;
     return r;
 }
@@ -933,16 +1010,15 @@ DEVI void forward_body(const DevContig& dc, ChainShared<HP, R>& sh, uint32_t C, 
     if constexpr (PHASE == 2 && !RING) load_col(mid, vA);
     lds_barrier();  // P0
     // cur = record of the column the next step produces, prev = record of the column before it
-    RecInfo cur = decode_record<Cfg::UNI>(sh.rec[first & 7u], p.j, p.i0, full);
-    RecInfo prev = decode_record<Cfg::UNI>(sh.rec[(first - 1) & 7u], p.j, p.i0, full);
+    RecInfo cur = decode_record<Cfg::UNI>(sh.rec[first & 7u], p.j, p.i0, full, dc.wide);
+    RecInfo prev = decode_record<Cfg::UNI>(sh.rec[(first - 1) & 7u], p.j, p.i0, full, dc.wide);
     const bool prof = kChainProf && (dbg & 8u) != 0;
 
     if (lo == 0) {
         // column 0: v_0 = e_0 (reference src/hmm.cpp:236-238, previous_cell = 1)
-        const uint32_t aj = col_allele(sh.rec[0], p.j);
         double part = 0.0;
 #pragma unroll
-        for (int k = 0; k < R; ++k) { x[k] = emission_at(sh.rec[0], p.i0 + k, aj); part += x[k]; }
+        for (int k = 0; k < R; ++k) { x[k] = emission_at(sh.rec[0], p.i0 + k, prev.em); part += x[k]; }
         if (STORE) store_col(0, x);
         if (p.tid == 0) fscale[0] = 1.0;
         write_colsums<HP, R>(sh, 0, p, part);
@@ -1021,7 +1097,6 @@ DEVI void forward_body(const DevContig& dc, ChainShared<HP, R>& sh, uint32_t C, 
         // opaque to the optimiser: it would otherwise sink the ldexp behind the per-row select
         // (R scalings per step instead of two)
         asm volatile("" : "+v"(eA), "+v"(eB));
-        const uint32_t aj = cur.aj;
         // LDS reads that nothing on the chain waits for are issued HERE, behind the sum exchange and
         // the u round trip (LDS returns in order: issued earlier they would delay both) and ahead
         // of the arithmetic that hides them: the partner column beta'_t out of the ring (32 KB per
@@ -1029,7 +1104,7 @@ DEVI void forward_body(const DevContig& dc, ChainShared<HP, R>& sh, uint32_t C, 
         __builtin_amdgcn_sched_barrier(0);
         double bt[RING ? R : 1];
         if constexpr (RING) ring_read<HP, R>(ring, t, p.i0, p.j, bt);
-        const RecInfo nxt = decode_record<Cfg::UNI>(sh.rec[(t + 1) & 7u], p.j, p.i0, full);
+        const RecInfo nxt = decode_record<Cfg::UNI>(sh.rec[(t + 1) & 7u], p.j, p.i0, full, dc.wide);
         __builtin_amdgcn_sched_barrier(0);
         double part = 0.0;
         // two straight-line loops (a per-state branch on `fast` would split the unrolled body into
@@ -1047,16 +1122,26 @@ DEVI void forward_body(const DevContig& dc, ChainShared<HP, R>& sh, uint32_t C, 
                 else if constexpr (R > 16) { if ((k & 7) == 7) __builtin_amdgcn_sched_barrier(0); }
             }
         } else {
+            // (R > 16: the wide lookups get their own loop — a per-state choice drags their live ranges
+            // through the 32-row loop and spills; R <= 16 measured faster with the choice per state)
+            auto general_loop = [&](auto kind_c) {
+                constexpr int KIND = decltype(kind_c)::value;  // 0 narrow, 1 wide, 2 per state
 #pragma unroll
-            for (int k = 0; k < R; ++k) {
-                double uik;
-                if constexpr (R <= 16) uik = ui[k];
-                else uik = readlane_f64(urow, __builtin_amdgcn_readfirstlane((int)((p.i0 + k) & 63u)));
-                x[k] = fma(c0, x[k], uik + uj) * (emission_at(rec, p.i0 + k, aj) * sc);
-                part += x[k];
-                if constexpr (STORE) { if (k & 1) { store_pair(t, k, x[k - 1], x[k]); __builtin_amdgcn_sched_barrier(0); } }
-                else if constexpr (R > 16) { if ((k & 7) == 7) __builtin_amdgcn_sched_barrier(0); }
-            }
+                for (int k = 0; k < R; ++k) {
+                    double uik;
+                    if constexpr (R <= 16) uik = ui[k];
+                    else uik = readlane_f64(urow, __builtin_amdgcn_readfirstlane((int)((p.i0 + k) & 63u)));
+                    const double e = KIND == 0 ? emission_narrow(rec, p.i0 + k, cur.em)
+                                   : KIND == 1 ? emission_wide(rec, p.i0 + k, cur.em) : emission_at(rec, p.i0 + k, cur.em);
+                    x[k] = fma(c0, x[k], uik + uj) * (e * sc);
+                    part += x[k];
+                    if constexpr (STORE) { if (k & 1) { store_pair(t, k, x[k - 1], x[k]); __builtin_amdgcn_sched_barrier(0); } }
+                    else if constexpr (R > 16) { if ((k & 7) == 7) __builtin_amdgcn_sched_barrier(0); }
+                }
+            };
+            if constexpr (R <= 16) general_loop(std::integral_constant<int, 2>{});
+            else if (cur.em.wide) general_loop(std::integral_constant<int, 1>{});
+            else general_loop(std::integral_constant<int, 0>{});
         }
         write_colsums<HP, R>(sh, t & 1u, p, part);
         if (Cfg::NW == 1 || p.tid == 0) fscale[t] = m;  // (single-wave configurations: all lanes, same address, no exec juggling)
@@ -1231,7 +1316,7 @@ DEVI void backward_body(const DevContig& dc, ChainShared<HP, R>& sh, uint32_t C,
         }
     }
     lds_barrier();  // P0
-    RecInfo cur = decode_record<Cfg::UNI>(sh.rec[(uint32_t)(t0 + 1) & 7u], p.j, p.i0, full);
+    RecInfo cur = decode_record<Cfg::UNI>(sh.rec[(uint32_t)(t0 + 1) & 7u], p.j, p.i0, full, dc.wide);
     const bool prof = kChainProf && (dc.debug & 8u) != 0;
     const unsigned long long t_begin = prof ? __builtin_amdgcn_s_memtime() : 0;
 
@@ -1252,7 +1337,7 @@ DEVI void backward_body(const DevContig& dc, ChainShared<HP, R>& sh, uint32_t C,
         // t+1 was decoded one step ago)
         double vt[RING ? R : 1];
         if constexpr (RING) ring_read<HP, R>(ring, t, p.i0, p.j, vt);
-        const RecInfo nxt = decode_record<Cfg::UNI>(sh.rec[(uint32_t)t & 7u], p.j, p.i0, full);
+        const RecInfo nxt = decode_record<Cfg::UNI>(sh.rec[(uint32_t)t & 7u], p.j, p.i0, full, dc.wide);
         const unsigned char* rec1 = sh.rec[(uint32_t)(t + 1) & 7u];
         // beta~_t(true) = A (y/Sy . e) A^T; scaled by 2^-es: beta' = beta~ * m, m = Sy*2^-es
         const int es = exponent_of(Sy);
@@ -1263,7 +1348,6 @@ DEVI void backward_body(const DevContig& dc, ChainShared<HP, R>& sh, uint32_t C,
         const bool fast = cur.fast;
         FastE fe = cur.fe;
         if (Cfg::UNI) fe.rowbits = __builtin_amdgcn_readfirstlane(fe.rowbits);
-        const uint32_t aj1 = cur.aj;
         double w[KEEPW ? R : 1];
         double part = 0.0;
         if (fast) {
@@ -1273,10 +1357,18 @@ DEVI void backward_body(const DevContig& dc, ChainShared<HP, R>& sh, uint32_t C,
                 if constexpr (KEEPW) w[k] = wk;
                 part += (kExp & 16u) ? (k == 0 ? wk : 0.0) : wk;
             }
+        } else if (cur.em.wide) {  // rare: branch at loop level, so the wide lookups stay out of the other loops' live ranges
+#pragma unroll
+            for (int k = 0; k < R; ++k) {
+                const double wk = y[k] * emission_wide(rec1, p.i0 + k, cur.em);
+                if constexpr (KEEPW) w[k] = wk;
+                part += wk;
+                if constexpr (R > 16) { if ((k & 7) == 7) __builtin_amdgcn_sched_barrier(0); }
+            }
         } else {
 #pragma unroll
             for (int k = 0; k < R; ++k) {
-                const double wk = y[k] * emission_at(rec1, p.i0 + k, aj1);
+                const double wk = y[k] * emission_narrow(rec1, p.i0 + k, cur.em);
                 if constexpr (KEEPW) w[k] = wk;
                 part += wk;
                 if constexpr (R > 16) { if ((k & 7) == 7) __builtin_amdgcn_sched_barrier(0); }
@@ -1298,13 +1390,15 @@ DEVI void backward_body(const DevContig& dc, ChainShared<HP, R>& sh, uint32_t C,
         __builtin_amdgcn_sched_barrier(0);  // the LDS round trip must be in flight BEFORE the reduction starts
         const double Sw = total_sum<HP>(Call);
         const double uj = fma(k2, Sw, ucol);
-        auto beta_loop = [&](auto fast_c) {
+        auto beta_loop = [&](auto kind_c) {  // 0 general narrow, 1 fast (or w kept), 2 general wide
+            constexpr int KIND = decltype(kind_c)::value;
 #pragma unroll
             for (int k = 0; k < R; ++k) {
                 double wk;
                 if constexpr (KEEPW) wk = w[k];
-                else if constexpr (decltype(fast_c)::value) wk = y[k] * (((fe.rowbits >> k) & 1u) ? fe.eB : fe.eA);
-                else wk = y[k] * emission_at(rec1, p.i0 + k, aj1);
+                else if constexpr (KIND == 1) wk = y[k] * (((fe.rowbits >> k) & 1u) ? fe.eB : fe.eA);
+                else if constexpr (KIND == 2) wk = y[k] * emission_wide(rec1, p.i0 + k, cur.em);
+                else wk = y[k] * emission_narrow(rec1, p.i0 + k, cur.em);
                 double uik;
                 if constexpr (R <= 16) uik = ui[k];
                 else uik = readlane_f64(urow, __builtin_amdgcn_readfirstlane((int)((p.i0 + k) & 63u)));
@@ -1313,8 +1407,9 @@ DEVI void backward_body(const DevContig& dc, ChainShared<HP, R>& sh, uint32_t C,
                 else if constexpr (R > 16) { if ((k & 7) == 7) __builtin_amdgcn_sched_barrier(0); }
             }
         };
-        if (KEEPW || fast) beta_loop(std::true_type{});
-        else beta_loop(std::false_type{});
+        if (KEEPW || fast) beta_loop(std::integral_constant<int, 1>{});
+        else if (cur.em.wide) beta_loop(std::integral_constant<int, 2>{});
+        else beta_loop(std::integral_constant<int, 0>{});
         Sy = kap * Sw;  // = sum(beta'_t) over real states
         if constexpr (STORE) {
             if (p.tid == 0) bsum[t] = Sy;
@@ -1356,7 +1451,7 @@ DEVI void backward_body(const DevContig& dc, ChainShared<HP, R>& sh, uint32_t C,
                 for (int k = 0; k < R; ++k) { w[k] = y[k] * (((rb1 >> k) & 1u) ? cur.fe.eB : cur.fe.eA); part += w[k]; }
             } else {
 #pragma unroll
-                for (int k = 0; k < R; ++k) { w[k] = y[k] * emission_at(rec1, p.i0 + k, cur.aj); part += w[k]; }
+                for (int k = 0; k < R; ++k) { w[k] = y[k] * emission_at(rec1, p.i0 + k, cur.em); part += w[k]; }
             }
             write_colsums<HP, R>(sh, (uint32_t)t0 & 1u, p, part);
         }
@@ -1370,7 +1465,7 @@ DEVI void backward_body(const DevContig& dc, ChainShared<HP, R>& sh, uint32_t C,
             const double kap = ldexp(cur.kappa, -es);
             double vt[RING ? R : 1];
             if constexpr (RING) ring_read<HP, R>(ring, t, p.i0, p.j, vt);  // landed before B_{t+1}
-            const RecInfo nxt = decode_record<Cfg::UNI>(sh.rec[(uint32_t)t & 7u], p.j, p.i0, full);
+            const RecInfo nxt = decode_record<Cfg::UNI>(sh.rec[(uint32_t)t & 7u], p.j, p.i0, full, dc.wide);
             const unsigned char* rec0 = sh.rec[(uint32_t)t & 7u];
             const uint32_t rb0 = rowbits_of(nxt);
             lds_barrier();  // B_t
@@ -1392,7 +1487,7 @@ DEVI void backward_body(const DevContig& dc, ChainShared<HP, R>& sh, uint32_t C,
                 for (int k = 0; k < R; ++k) {
                     y[k] = 0.0;
                     const double bu = (p.j < H && p.i0 + k < H) ? unif : 0.0;
-                    w[k] = bu * (nxt.fast ? (((rb0 >> k) & 1u) ? nxt.fe.eB : nxt.fe.eA) : emission_at(rec0, p.i0 + k, nxt.aj));
+                    w[k] = bu * (nxt.fast ? (((rb0 >> k) & 1u) ? nxt.fe.eB : nxt.fe.eA) : emission_at(rec0, p.i0 + k, nxt.em));
                     part += w[k];
                 }
                 if constexpr (STORE) store_col(t, y);
@@ -1409,7 +1504,7 @@ DEVI void backward_body(const DevContig& dc, ChainShared<HP, R>& sh, uint32_t C,
                 for (int k = 0; k < R; ++k) {
                     y[k] = fma(k0, w[k], ui[k] + uj);
                     if constexpr (STORE) { if (k & 1) { store_pair(t, k, y[k - 1], y[k]); __builtin_amdgcn_sched_barrier(0); } }
-                    w[k] = y[k] * emission_at(rec0, p.i0 + k, nxt.aj);
+                    w[k] = y[k] * emission_at(rec0, p.i0 + k, nxt.em);
                     part += w[k];
                 }
             }
@@ -1601,6 +1696,21 @@ __global__ __launch_bounds__(64 * PG_POST_WAVES) void k_post(const DevContig* __
     const v2f64* A2 = (const v2f64*)A;
     const v2f64* B2 = (const v2f64*)B;
     const uint32_t npass = HP > 64 ? HP / 64 : 1;
+    const uint32_t a0v = dc.allele_off[v], Av = dc.allele_off[v + 1] - a0v;
+    // stored columns are (true value) * m (see k_bins); a flagged forward column is the uniform
+    // column itself: absolute value, no emission exponent, no scale
+    const bool fb = dc.fwd_fallback[c] != 0;
+    const double scale = 1.0 / ((fb ? 1.0 : dc.fscale[c]) * dc.bscale[c]);
+    // Wide columns (more than PG_AMAX alleles on the selected paths) take one sweep over the two
+    // columns per block of PG_AMAX row alleles and add their bins straight into lik (zeroed at the
+    // start of the run; this wave is the only writer of the variant's bins).
+    const bool widec = nl > PG_AMAX;
+    const uint16_t* wslots = nullptr;
+    if (widec) {
+        const uint32_t widx = *(const uint32_t*)(rec + PG_REC_WIDE_IDX);
+        wslots = (const uint16_t*)(dc.wide + (size_t)widx * PG_WIDE_ENTRY_BYTES + PG_WIDE_TABLE_BYTES);
+    }
+    for (uint32_t abase = 0; abase < nl; abase += PG_AMAX)
     for (uint32_t ps = 0; ps < npass; ++ps) {
         double acc[PG_AMAX];
 #pragma unroll
@@ -1624,7 +1734,7 @@ __global__ __launch_bounds__(64 * PG_POST_WAVES) void k_post(const DevContig* __
                 const uint32_t ip = ipb + u * ipstep;
                 if (ip < HP / 2) {
                     const double p0 = av[u].x * bv[u].x, p1 = av[u].y * bv[u].y;
-                    const uint32_t a0 = al[2 * ip], a1 = al[2 * ip + 1];
+                    const uint32_t a0 = (uint32_t)al[2 * ip] - abase, a1 = (uint32_t)al[2 * ip + 1] - abase;
 #pragma unroll
                     for (int a = 0; a < PG_AMAX; ++a) {
                         acc[a] = fma(p0, a0 == (uint32_t)a ? 1.0 : 0.0, acc[a]);
@@ -1634,16 +1744,34 @@ __global__ __launch_bounds__(64 * PG_POST_WAVES) void k_post(const DevContig* __
             }
         }
         const uint32_t b = al[j];
+        if (!widec) {
 #pragma unroll
-        for (int a = 0; a < PG_AMAX; ++a) {
-            if ((uint32_t)a < nl) {
+            for (int a = 0; a < PG_AMAX; ++a) {
+                if ((uint32_t)a < nl) {
 #pragma unroll
-                for (int bb = 0; bb < PG_AMAX; ++bb) {
-                    if ((uint32_t)bb < nl) {
-                        const double tot = wave_sum(b == (uint32_t)bb ? acc[a] : 0.0);
-                        if (lane == 0) {
-                            const uint32_t ra = (uint32_t)a, cb = (uint32_t)bb;
-                            s_bins[wave][tri_local(ra < cb ? ra : cb, ra < cb ? cb : ra)] += tot;
+                    for (int bb = 0; bb < PG_AMAX; ++bb) {
+                        if ((uint32_t)bb < nl) {
+                            const double tot = wave_sum(b == (uint32_t)bb ? acc[a] : 0.0);
+                            if (lane == 0) {
+                                const uint32_t ra = (uint32_t)a, cb = (uint32_t)bb;
+                                s_bins[wave][tri_local(ra < cb ? ra : cb, ra < cb ? cb : ra)] += tot;
+                            }
+                        }
+                    }
+                }
+            }
+        } else {
+#pragma unroll
+            for (int a = 0; a < PG_AMAX; ++a) {
+                const uint32_t ra = abase + (uint32_t)a;
+                if (ra < nl) {
+                    for (uint32_t cb = 0; cb < nl; ++cb) {
+                        const double tot = wave_sum(b == cb ? acc[a] : 0.0);
+                        if (lane == 0 && tot != 0.0) {
+                            const uint32_t lo2 = ra < cb ? ra : cb, hi2 = ra < cb ? cb : ra;
+                            const uint32_t sa = wslots[lo2], sb = wslots[hi2];
+                            const uint64_t gi = dc.geno_off[v] + (uint64_t)sa * Av - (uint64_t)sa * (sa - 1) / 2 + (sb - sa);
+                            dc.lik[gi] += tot * scale;
                         }
                     }
                 }
@@ -1651,13 +1779,8 @@ __global__ __launch_bounds__(64 * PG_POST_WAVES) void k_post(const DevContig* __
         }
     }
     wave_sync();
-    const uint32_t a0v = dc.allele_off[v], Av = dc.allele_off[v + 1] - a0v;
-    const uint16_t* ls = (const uint16_t*)(rec + PG_REC_LOCAL_SLOT);
-    // stored columns are (true value) * m (see k_bins); a flagged forward column is the uniform
-    // column itself: absolute value, no emission exponent, no scale
-    const bool fb = dc.fwd_fallback[c] != 0;
-    const double scale = 1.0 / ((fb ? 1.0 : dc.fscale[c]) * dc.bscale[c]);
-    if (lane < nl * nl) {
+    if (!widec && lane < nl * nl) {
+        const uint16_t* ls = (const uint16_t*)(rec + PG_REC_LOCAL_SLOT);
         const uint32_t la = lane / nl, lb = lane % nl;
         if (la <= lb) {
             const uint32_t sa = ls[la], sb = ls[lb];

@@ -212,7 +212,7 @@ static const char* const kKernelNames[PG_N_KERNEL_CLASSES] = {"k_prep", "k_compa
 
 struct ContigHost {
     uint32_t V = 0, H = 0, HP = 0, T = 0, RB = 0, part_slots = 1;
-    uint32_t sumK = 0, sumA = 0;
+    uint32_t sumK = 0, sumA = 0, n_wide = 0;
     uint64_t n_lik = 0;
     std::vector<uint16_t> n_kmers, coverage;
     DevContig d;
@@ -336,11 +336,18 @@ extern "C" pg_job* pg_job_create(int device, uint32_t n_contigs, const pg_contig
             if (batches[i].n_variants > max_v) max_v = batches[i].n_variants;
             per_col += (size_t)4 * hp * hp * sizeof(double);
         }
+        // variants with more than PG_AMAX alleles may turn into WIDE columns, whose posteriors only
+        // k_post can form: such jobs always run chunked
+        bool wide_candidates = false;
+        for (uint32_t i = 0; i < n_contigs && !wide_candidates; ++i)
+            for (uint32_t v = 0; v < batches[i].n_variants; ++v)
+                if (batches[i].allele_off[v + 1] - batches[i].allele_off[v] > PG_AMAX) { wide_candidates = true; break; }
         bool want = n_contigs * 2u < 128u;  // fewer workgroups than half the CUs
         if (const char* m = getenv("PG_SWEEP_MODE")) {
             if (!strcmp(m, "fused")) want = false;
             else if (!strcmp(m, "chunked")) want = true;
         }
+        if (wide_candidates) want = true;
         job->chunked = want && max_v > 0 && params->run_genotyping;
         if (job->chunked) {
             size_t k = 4096;
@@ -365,7 +372,7 @@ extern "C" pg_job* pg_job_create(int device, uint32_t n_contigs, const pg_contig
     job->contigs.resize(n_contigs);
     size_t off = 0;
     auto take = [&](size_t bytes) { size_t o = off; off = align_up(off + (bytes ? bytes : 8)); return o; };
-    struct Plan { size_t scratch, prof, fback, fscale, bscale, bsum, pos, cov, koff, kcnt, aoff, aid, aflag, akoff, akmask, pa, goff, vrec, cvar, colrec, fwd, part, kept, apres, lik, likexp; };
+    struct Plan { size_t scratch, wide, widx, prof, fback, fscale, bscale, bsum, pos, cov, koff, kcnt, aoff, aid, aflag, akoff, akmask, pa, goff, vrec, cvar, colrec, fwd, part, kept, apres, lik, likexp; };
     std::vector<Plan> plan(n_contigs);
     const size_t o_contigs = take(sizeof(DevContig) * n_contigs);
     // zeroed-every-run block: n_cols, err, then per contig kept / allele_present / lik / lik_exp
@@ -408,6 +415,10 @@ extern "C" pg_job* pg_job_create(int device, uint32_t n_contigs, const pg_contig
         // fused mode: posterior partials; chunked mode: the chunk scratch instead (k_post writes lik directly)
         p.part = take(job->chunked ? 0 : (size_t)c.V * c.part_slots * c.T * sizeof(double));
         p.scratch = take(job->chunked ? (size_t)4 * job->chunk_cols * c.HP * c.HP * sizeof(double) : 0);
+        c.n_wide = 0;
+        for (uint32_t v = 0; v < c.V; ++v) c.n_wide += (batches[i].allele_off[v + 1] - batches[i].allele_off[v] > PG_AMAX) ? 1u : 0u;
+        p.wide = take((size_t)c.n_wide * PG_WIDE_ENTRY_BYTES);
+        p.widx = take(c.n_wide ? (size_t)c.V * sizeof(uint32_t) : 0);
         p.fscale = take((size_t)c.V * sizeof(double));
         p.bscale = take((size_t)c.V * sizeof(double));
         p.bsum = take((size_t)c.V * sizeof(double));
@@ -451,6 +462,7 @@ extern "C" pg_job* pg_job_create(int device, uint32_t n_contigs, const pg_contig
         d.fscale = (double*)(A + p.fscale); d.bscale = (double*)(A + p.bscale); d.bsum = (double*)(A + p.bsum); d.err = job->d_err + i;
         d.lik = (double*)(A + p.lik); d.lik_exp = (int32_t*)(A + p.likexp);
         d.scratch = (double*)(A + p.scratch); d.chunk_cols = job->chunk_cols;
+        d.wide = A + p.wide; d.wide_idx = c.n_wide ? (const uint32_t*)(A + p.widx) : nullptr;
         c.d = d;
         if (c.V == 0) continue;
         std::vector<uint64_t> goff((size_t)c.V + 1);
@@ -474,6 +486,13 @@ extern "C" pg_job* pg_job_create(int device, uint32_t n_contigs, const pg_contig
         UP(d.allele_kmask, b.allele_kmer_mask, (size_t)c.sumA * 4);
         UP(d.path_allele, b.path_allele, (size_t)c.V * c.H * 2);
         UP(d.geno_off, goff.data(), ((size_t)c.V + 1) * 8);
+        if (c.n_wide) {
+            std::vector<uint32_t> widx(c.V, PG_WIDE_NONE);
+            uint32_t k = 0;
+            for (uint32_t v = 0; v < c.V; ++v)
+                if (b.allele_off[v + 1] - b.allele_off[v] > PG_AMAX) widx[v] = k++;
+            UP(d.wide_idx, widx.data(), (size_t)c.V * 4);
+        }
 #undef UP
     }
     if ((he = hipMemcpy(job->d_contigs, hd.data(), sizeof(DevContig) * n_contigs, hipMemcpyHostToDevice)) != hipSuccess)
@@ -549,7 +568,7 @@ extern "C" int pg_job_run(pg_job* job, void* stream_, char* err, size_t errlen) 
             return PG_ERR_UNSUPPORTED;
         }
         if (errs[i] & PG_DEVERR_TOO_MANY_LOCAL) {
-            set_err(err, errlen, "contig %u: a column has more than %d distinct alleles on the selected paths (device limit this release)", i, PG_AMAX);
+            set_err(err, errlen, "contig %u: a column has more than %d distinct alleles on the selected paths (device limit this release)", i, PG_WIDE_MAX);
             return PG_ERR_UNSUPPORTED;
         }
     }

@@ -241,7 +241,7 @@ def default_table_args(peak: int = PEAK):
 def synthetic_panel(n_variants: int, n_paths: int, kmers_per_variant: int = 20, *,
                     seed: int = 12345, multiallelic_frac: float = 0.0,
                     undefined_frac: float = 0.01, zero_kmer_frac: float = 0.01,
-                    peak: int = PEAK, max_alleles: int = 5) -> ContigBatch:
+                    peak: int = PEAK, max_alleles: int = 5, local_alts: int = 4) -> ContigBatch:
     """Deterministic synthetic contig of the shapes BASELINE.json names.
 
     Positions step by 50+U[0,1200) bp; allele frequency f~U(.05,.95); each path carries ALT
@@ -263,8 +263,8 @@ def synthetic_panel(n_variants: int, n_paths: int, kmers_per_variant: int = 20, 
     f = rng.uniform(0.05, 0.95, size=V)
     carries_alt = rng.random((V, H)) < f[:, None]
     # (max_alleles > 5: bubbles with many alleles in the object of which the panel paths carry at
-    # most four ALTs — what a sampled panel looks like on a hypervariable site)
-    alt_choice = 1 + (rng.integers(0, 1 << 30, size=(V, H)) % np.minimum(n_all[:, None] - 1, 4 if max_alleles > 5 else 1 << 30))
+    # most `local_alts` ALTs — what a sampled panel looks like on a hypervariable site)
+    alt_choice = 1 + (rng.integers(0, 1 << 30, size=(V, H)) % np.minimum(n_all[:, None] - 1, local_alts if max_alleles > 5 else 1 << 30))
     path_allele = np.where(carries_alt, alt_choice, 0).astype(np.uint16)
 
     # sample haplotypes: two panel paths with occasional switches

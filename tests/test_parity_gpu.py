@@ -262,16 +262,20 @@ def test_allele_limits_are_reported(orc):
     with pytest.raises(hmm.PanGenieError) as e:
         hmm.genotype_contig(b, t, p)
     assert e.value.code == hmm._lib.PG_ERR_UNSUPPORTED
-    # more than 5 distinct alleles on the selected paths of one column
-    b = synthetic_panel(60, 16, 128, seed=4, multiallelic_frac=1.0, max_alleles=12)
-    A = np.diff(b.allele_off)
-    v = int(np.argmax(A))
-    assert A[v] >= 8
-    pa = b.path_allele.reshape(b.n_variants, 16)
-    pa[v, :8] = np.arange(8, dtype=np.uint16)
-    with pytest.raises(hmm.PanGenieError) as e:
-        hmm.genotype_contig(b, t, p)
-    assert e.value.code == hmm._lib.PG_ERR_UNSUPPORTED
+
+
+@pytest.mark.parametrize("H,V,local_alts", [(16, 300, 12), (64, 200, 20), (27, 150, 8), (128, 60, 31)])
+def test_wide_columns_vs_oracle(H, V, local_alts, orc):
+    """Columns with more than 5 (up to 32) distinct alleles on the selected paths: emission table in
+    the side buffer, posteriors by k_post in blocks of row alleles (always the chunked mode)."""
+    b = synthetic_panel(V, H, 128, seed=31 + H, multiallelic_frac=0.5, max_alleles=32, local_alts=local_alts,
+                        undefined_frac=0.05)
+    pa = b.path_allele.reshape(V, H)
+    assert max(len(set(r)) for r in pa) > 5
+    args = default_table_args()
+    res = hmm.genotype_contig(b, hmm.ProbabilityTable(*args), hmm.make_params(1.26, False, 1e-5))
+    ref = orc.genotype_contig(b, orc.OracleTable(*args), orc.make_params(1.26, False, 1e-5))
+    assert_parity(b, res, ref)
 
 
 def test_full_size_properties():
