@@ -34,7 +34,7 @@ extern "C" {
 #define PG_OK 0
 #define PG_ERR_INVALID (-1)     /* bad argument / malformed batch            */
 #define PG_ERR_NO_PATHS (-2)    /* "column is not covered by any paths"      */
-#define PG_ERR_UNSUPPORTED (-3) /* feature not available on the device path  */
+#define PG_ERR_UNSUPPORTED (-3) /* not on the device path: run_phasing, > 128 selected paths, > 32 alleles per variant */
 #define PG_ERR_DEVICE (-4)      /* HIP runtime error / no GPU                */
 #define PG_ERR_NOMEM (-5)
 
