@@ -1,0 +1,47 @@
+"""Randomised parity soak (GPU box): many seeded panels of mixed shape, both sweep modes, small chunk
+sizes, narrow and wide columns, regularised and unregularised tables — HIP path vs the oracle.
+usage: python tools/soak_parity.py [n_panels] [seed0]"""
+import os, sys, time
+sys.path.insert(0, os.getcwd())
+import numpy as np
+from oracle import pyoracle as orc
+from pangenie_amd import hmm
+from pangenie_amd.panel import default_table_args, synthetic_panel
+from tests.parity_util import assert_parity, rel_errors
+
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 40
+seed0 = int(sys.argv[2]) if len(sys.argv) > 2 else 1
+rng = np.random.default_rng(seed0)
+worst, t0 = 0.0, time.time()
+for it in range(n):
+    H = int(rng.choice([1, 2, 5, 13, 16, 17, 27, 32, 33, 50, 64, 65, 100, 128]))
+    V = int(rng.integers(1, 900 if H <= 64 else 250))
+    K = int(rng.choice([8, 20, 40, 128]))
+    multi = float(rng.choice([0.0, 0.2, 0.6]))
+    wide = bool(rng.random() < 0.3) and K >= 40
+    kw = dict(multiallelic_frac=multi, undefined_frac=float(rng.choice([0.0, 0.05, 0.3])), zero_kmer_frac=float(rng.choice([0.0, 0.05])))
+    if wide:
+        kw.update(max_alleles=int(rng.integers(6, 33)), local_alts=int(rng.integers(5, 32)), multiallelic_frac=max(multi, 0.2))
+    b = synthetic_panel(V, H, K, seed=int(rng.integers(1 << 30)), **kw)
+    reg = float(rng.choice([0.01, 0.01, 0.0, 0.001]))
+    if reg == 0.0:
+        b.kmer_count[::3] = 0
+        b.kmer_count[1::17] = 60000
+    args = (6, 108, 54, reg)
+    recomb, uniform, N = [(1.26, False, 1e-5), (1.26, True, 1e-5), (0.001, False, 1e-5), (446.287102628, False, 0.25), (1.26, False, 25000.0)][int(rng.integers(5))]
+    mode = str(rng.choice(["fused", "chunked", "chunked"]))
+    os.environ["PG_SWEEP_MODE"] = mode
+    os.environ["PG_CHUNK_COLS"] = str(int(rng.choice([1, 3, 16, 64, 4096])))
+    res = hmm.genotype_contig(b, hmm.ProbabilityTable(*args), hmm.make_params(recomb, uniform, N))
+    ref = orc.genotype_contig(b, orc.OracleTable(*args), orc.make_params(recomb, uniform, N))
+    try:
+        assert_parity(b, res, ref)
+    except AssertionError as e:
+        print("FAIL", it, dict(H=H, V=V, K=K, kw=kw, reg=reg, recomb=recomb, uniform=uniform, N=N, mode=mode, chunk=os.environ["PG_CHUNK_COLS"]), str(e)[:300])
+        sys.exit(1)
+    r = rel_errors(b, res.likelihoods_ld(), ref.lik)
+    rm = float(r.max()) if r.size else 0.0
+    if rm > 1e-8:
+        print("note", it, f"{rm:.2e}", dict(H=H, V=V, K=K, reg=reg, recomb=recomb, uniform=uniform, N=N, mode=mode, wide=wide))
+    worst = max(worst, rm)
+print(f"soak OK: {n} panels, worst relative error {worst:.3e}, {time.time() - t0:.0f} s")
