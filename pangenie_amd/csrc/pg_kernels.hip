@@ -6,9 +6,13 @@
 //   k_compact   kept variants -> column list                           (one workgroup / contig)
 //   k_records   column records + Li-Stephens constants on device       (one wave / column)
 //               reference src/transitionprobabilitycomputer.cpp:8-19
-//   k_forward   forward recursion, persistent, one workgroup / chain   reference src/hmm.cpp:76-90,175-273
-//   k_backward  backward recursion + posterior partials                reference src/hmm.cpp:92-110,275-405
-//   k_bins      posterior partials -> genotype bins                    reference src/hmm.cpp:364-368
+//   k_sweep     forward / backward half-chains, meet in the middle    (two workgroups / chain)
+//               reference src/hmm.cpp:76-110, 175-273, 275-405
+//               <..., 1> first halves, columns stored; <..., 2> second halves with the posterior
+//               partials formed in the sweep (fused mode); <..., 3> second halves as store-only
+//               chunks (chunked mode)
+//   k_bins      posterior partials -> genotype bins (fused mode)       reference src/hmm.cpp:364-368
+//   k_post      stored column pairs of a chunk -> genotype bins (chunked mode; idle CUs)
 //
 // No MFMA: the transition operator is rank-structured (A = r I + q 1 1^T), so a column
 // update is elementwise + row/column sums.  The recursion is bound by HBM (16 H^2 bytes
@@ -20,7 +24,7 @@
 //   rg = tid / HP            row group; the thread holds rows i = rg*R .. rg*R+R-1 of column j
 // For HP >= 64 a wave spans 64 columns of ONE row group, so everything indexed by the row
 // (allele of path i, u_i) is wave-uniform and lives in SGPRs; column sums are in-lane adds
-// plus one LDS exchange per column (one __syncthreads per column).  Forward columns are
+// plus one LDS exchange per column (one LDS-only workgroup barrier per column).  Columns are
 // symmetric, so row sums == column sums and only column sums are computed.
 #include <hip/hip_runtime.h>
 #include <math.h>
@@ -561,20 +565,22 @@ __global__ __launch_bounds__(256) void k_records(const DevContig* __restrict__ c
 //  the forward half-chain and the backward half-chain as two workgroups at once.
 //    phase 1 : forward  computes columns 0 .. mid-1   and stores v'_t   into slot t   (t <  mid)
 //              backward computes columns C-1 .. mid   and stores beta'_t into slot t  (t >= mid)
-//    phase 2 : forward  continues mid .. C-1, loads beta'_t from slot t, emits posterior partials
-//              backward continues mid-1 .. 0, loads v'_t    from slot t, emits posterior partials
-//  Every column is written once and read once (the 16*H^2 algorithmic bytes), by workgroups on
-//  different CUs, and the wall time of a chain is C/2 + C/2 column steps instead of 2C.  The
-//  hand-over at `mid` goes through the stored columns, i.e. through a kernel boundary — no
-//  inter-workgroup flags, nothing placement dependent.
+//    phase 2 : forward  continues mid .. C-1, gets beta'_t from slot t, emits posterior partials
+//              backward continues mid-1 .. 0, gets v'_t    from slot t, emits posterior partials
+//    phase 3 : (instead of 2, few chains) the same continuation in chunks that only store their
+//              columns into a scratch; k_post forms the posteriors of a finished chunk
+//  In the fused mode every column is written once and read once (the 16*H^2 algorithmic bytes), by
+//  workgroups on different CUs; the wall time of a chain is C/2 + C/2 column steps instead of 2C.
+//  Hand-overs (at `mid`, between chunks) go through stored columns, i.e. through kernel
+//  boundaries — no inter-workgroup flags, nothing placement dependent.
 //
-//  Workgroup = T compute threads + one LOADER wave (the last wave).  VMEM counters are per
-//  wave, so the split keeps every wait off the recursion's critical path: compute waves of a
-//  storing phase only STORE, compute waves of a posterior phase only LOAD (prefetched), and
-//  the loader wave streams the column records HBM -> LDS ahead of use and drains the posterior
-//  partials LDS -> HBM.  The per-column workgroup barrier orders LDS only (no vmcnt wait).
-//  All global pointers are address_space(1) so that accesses are global_* (FLAT ops would also
-//  tick lgkmcnt and put the HBM latency back on the LDS waits).
+//  Workgroup = T compute threads + LOADER waves (the last one or two waves; none at HP = 128).
+//  VMEM counters are per wave, so the split keeps every wait off the recursion's critical path:
+//  compute waves only STORE (columns, partials); the loader waves only issue LDS-DMA (column
+//  records, partner columns: HBM -> LDS without registers) and count its completion.  The
+//  per-column workgroup barrier orders LDS only (no vmcnt wait).  All global pointers are
+//  address_space(1) so that accesses are global_* (FLAT ops would also tick lgkmcnt and put the
+//  HBM latency back on the LDS waits).
 //
 //  Scaling.  The reference normalises every column by its sum (a division on the critical
 //  path).  Here a column is rescaled by the exact power of two 2^-e, e = exponent(sum), and
