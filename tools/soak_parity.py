@@ -1,6 +1,6 @@
 """Randomised parity soak (GPU box): many seeded panels of mixed shape, both sweep modes, small chunk
 sizes, narrow and wide columns, regularised and unregularised tables — HIP path vs the oracle.
-usage: python tools/soak_parity.py [n_panels] [seed0]"""
+usage: python tools/soak_parity.py [n_panels] [seed0]   (80 panels: about two minutes)"""
 import os, sys, time
 sys.path.insert(0, os.getcwd())
 import numpy as np
@@ -26,7 +26,10 @@ for it in range(n):
     reg = float(rng.choice([0.01, 0.01, 0.0, 0.001]))
     if reg == 0.0:
         b.kmer_count[::3] = 0
-        b.kmer_count[1::17] = 60000
+        # out-of-table counts: the oracle evaluates them like the reference, with a loop over the count
+        # per lookup — keep them small here (tests/ covers 60000 on a small panel); this tool runs on
+        # the GPU box and must not burn GPU-minutes on CPU work
+        b.kmer_count[1::17] = 300
     args = (6, 108, 54, reg)
     recomb, uniform, N = [(1.26, False, 1e-5), (1.26, True, 1e-5), (0.001, False, 1e-5), (446.287102628, False, 0.25), (1.26, False, 25000.0)][int(rng.integers(5))]
     mode = str(rng.choice(["fused", "chunked", "chunked"]))
