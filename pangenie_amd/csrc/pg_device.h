@@ -10,7 +10,10 @@
 //   fwd[C][HP*HP] : column slots (fp64): slot c holds the forward column of c < C/2 and the
 //                   backward column of c >= C/2 — written once in sweep phase 1, read once in
 //                   sweep phase 2: the 16*H^2 algorithmic bytes per column.
-//   part[C][part_slots][T] : per-thread posterior partials by row allele (reduced by k_bins)
+//   part[C][part_slots/2][T][2] : (fused mode) per-thread posterior partials by row-allele pair,
+//                   reduced by k_bins
+//   scratch / handoff-free chunk buffers : (chunked mode) see DevContig::scratch
+//   wide[n_wide][..] : emission tables of columns with more than PG_AMAX alleles on the selected paths
 //   lik / lik_exp : outputs
 #pragma once
 #include <stdint.h>
