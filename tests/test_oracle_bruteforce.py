@@ -1,0 +1,113 @@
+"""Second opinion on the CPU oracle: a dense-matrix restatement of the recursion in numpy long double,
+written from the maths (reference src/hmm.cpp:175-405,
+src/transitionprobabilitycomputer.cpp:14-18, src/columnindexer.cpp:24-31) and sharing no code with
+oracle/pg_oracle.c: columns are H x H matrices, the transition is the explicit matrix
+A = (p-q) I + q 11^T applied from both sides, genotype bins are filled by looping over states.
+Emission tables are taken from the oracle's own entry point (pinned separately on the reference's
+EmissionProbabilityComputer tests); everything downstream of them is independent.  Small panels
+only (pure-Python loops), including columns with more than five alleles on the paths and more than
+ten alleles per variant, which no golden vector of the reference covers."""
+import numpy as np
+import pytest
+
+from oracle import pyoracle as orc
+from pangenie_amd.panel import default_table_args, synthetic_panel
+
+LD = np.longdouble
+
+
+def brute_force(b, table, recombrate, uniform, effective_N):
+    V, H = b.n_variants, b.n_paths
+    pa = b.path_allele.reshape(V, H).astype(np.int64)
+    aoff = b.allele_off.astype(np.int64)
+    geno_off = b.geno_off.astype(np.int64)
+    lik = np.zeros(int(geno_off[-1]), dtype=LD)
+    # --- column selection: kept iff a selected path carries a defined non-reference allele
+    slot_of, kept = [], []
+    for v in range(V):
+        ids = [int(x) for x in b.allele_id[aoff[v]:aoff[v + 1]]]
+        flags = b.allele_flags[aoff[v]:aoff[v + 1]]
+        slots = np.array([ids.index(int(a)) for a in pa[v]])
+        slot_of.append(slots)
+        kept.append(any(ids[s] != 0 and not (flags[s] & 1) for s in slots))
+    cols = [v for v in range(V) if kept[v]]
+    if not cols:
+        return lik, np.array(kept, np.uint8)
+    # --- emissions per column as H x H matrices
+    em = []
+    for v in cols:
+        E, all_zeros = orc.emission_table(b, table, v)
+        s = slot_of[v]
+        em.append(np.ones((H, H), LD) if all_zeros else E[np.ix_(s, s)].astype(LD))
+    # --- transition matrices of the gaps
+    ones = np.ones((H, H), LD)
+    trans = [None]
+    for c in range(1, len(cols)):
+        if uniform:
+            trans.append(None)
+            continue
+        d = LD(int(b.variant_pos[cols[c]]) - int(b.variant_pos[cols[c - 1]])) * LD("0.000004") * LD(recombrate) * LD(effective_N)
+        q = (LD(1) - np.exp(-d / LD(H))) / LD(H)
+        p = np.exp(-d / LD(H)) + q
+        trans.append((p - q) * np.eye(H, dtype=LD) + q * ones)
+
+    def step(M, c):  # A M A^T for the gap c-1 -> c ; uniform: every entry = sum(M)
+        return ones * M.sum() if trans[c] is None else trans[c] @ M @ trans[c].T
+
+    C = len(cols)
+    unif = ones / LD(H * H)
+    # --- forward: alpha_hat (normalised) and fsum per column
+    alpha, fsum = [], []
+    for c in range(C):
+        v = em[c] if c == 0 else em[c] * step(alpha[c - 1], c)
+        s = v.sum()
+        if s > 0:
+            alpha.append(v / s); fsum.append(s)
+        else:
+            alpha.append(unif.copy()); fsum.append(LD(1))
+    # --- backward + posteriors
+    beta_hat_next = None
+    for c in range(C - 1, -1, -1):
+        bt = ones.copy() if c == C - 1 else step(beta_hat_next * em[c + 1], c + 1)
+        v = cols[c]
+        A = int(aoff[v + 1] - aoff[v])
+        post = alpha[c] * bt * fsum[c]
+        s = slot_of[v]
+        for i in range(H):
+            for j in range(H):
+                a, bb = (s[i], s[j]) if s[i] <= s[j] else (s[j], s[i])
+                lik[geno_off[v] + a * A - a * (a - 1) // 2 + (bb - a)] += post[i, j]
+        sb = bt.sum()
+        beta_hat_next = bt / sb if sb > 0 else unif.copy()
+    return lik, np.array(kept, np.uint8)
+
+
+CASES = [
+    # V, H, K, synthetic_panel kwargs, (recombrate, uniform, effective_N)
+    (25, 4, 20, dict(multiallelic_frac=0.3), (1.26, False, 1e-5)),
+    (30, 6, 24, dict(multiallelic_frac=0.5, undefined_frac=0.2, zero_kmer_frac=0.1), (1.26, False, 25000.0)),
+    (20, 5, 20, dict(multiallelic_frac=0.0), (1.26, True, 1e-5)),
+    (18, 9, 64, dict(multiallelic_frac=0.8, max_alleles=12, local_alts=8), (1.26, False, 1e-5)),        # wide columns
+    (14, 12, 96, dict(multiallelic_frac=1.0, max_alleles=24, local_alts=11, undefined_frac=0.1), (446.287102628, False, 0.25)),
+    (16, 3, 96, dict(multiallelic_frac=0.7, max_alleles=32), (0.001, False, 1e-5)),                       # many alleles, few on paths
+]
+
+
+@pytest.mark.parametrize("V,H,K,kw,par", CASES)
+def test_oracle_matches_dense_matrix_restatement(V, H, K, kw, par):
+    b = synthetic_panel(V, H, K, seed=900 + V + H, **kw)
+    if kw.get("local_alts", 0) > 5:  # these cases are meant to contain wide columns
+        assert max(len(set(r)) for r in b.path_allele.reshape(V, H)) > 5
+    for reg in (0.01, 0.0):
+        if reg == 0.0:
+            b.kmer_count[::3] = 0  # exact zeros: uniform fallbacks, all_zeros
+        args = default_table_args()[:3] + (reg,)
+        table = orc.OracleTable(*args)
+        ref = orc.genotype_contig(b, table, orc.make_params(*par))
+        lik, kept = brute_force(b, table, *par)
+        assert (kept == ref.kept).all()
+        den = np.maximum(np.abs(lik), np.abs(ref.lik))
+        rel = np.where(den > 0, np.abs(lik - ref.lik) / np.where(den > 0, den, 1), 0)
+        # different summation order, same 64-bit-mantissa arithmetic
+        assert float(rel.max()) < 1e-13, (reg, float(rel.max()))
+        assert ((lik == 0) == (ref.lik == 0)).all()
