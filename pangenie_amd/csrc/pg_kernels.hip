@@ -1818,16 +1818,25 @@ __global__ __launch_bounds__(64 * PG_POST_WAVES) void k_post(const DevContig* __
 //  host-callable launchers (defined here so that the shim needs no kernel templates)
 // ------------------------------------------------------------------------------------------
 // hp_mask: bit0 HP=16, bit1 HP=32, bit2 HP=64, bit3 HP=128; phase 1 = store halves, 2 = posterior halves
+// The opt-in to more than 64 KiB of dynamic LDS is a per-device attribute of a kernel: it is set once
+// per (kernel, device) — jobs on several devices can share a process (HMM::set_device()).  A racing
+// second thread at worst sets it twice.
+#define PG_MAX_DEVICES 64
+static bool lds_attr_pending(bool (&done)[PG_MAX_DEVICES]) {
+    int dev = -1;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= PG_MAX_DEVICES) return true;  // unknown: just set it again
+    if (done[dev]) return false;
+    done[dev] = true;
+    return true;
+}
 template <int HP, int R, int VBUF, bool KEEPW, int PHASE>
 static void launch_one(const DevContig* d_contigs, uint32_t n_contigs, uint32_t chunk, hipStream_t s) {
     using Cfg = ChainCfg<HP, R>;
     const size_t dyn = (Cfg::LOADER && PHASE == 2) ? (size_t)kRingSlots * HP * HP * 8 : 0;  // partner-column ring
     auto kern = k_sweep<HP, R, VBUF, KEEPW, PHASE>;
-    static bool attr_set = false;
-    if (dyn > 0 && !attr_set) {  // more than the default 64 KiB of LDS per workgroup
+    static bool attr_done[PG_MAX_DEVICES];
+    if (dyn > 0 && lds_attr_pending(attr_done))  // more than the default 64 KiB of LDS per workgroup
         (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn);
-        attr_set = true;
-    }
     hipLaunchKernelGGL(kern, dim3(n_contigs, 2), dim3(Cfg::TT), dyn, s, d_contigs, chunk);
 }
 template <int PHASE>
@@ -1863,11 +1872,9 @@ void pgk_launch_sweep_chunk(const DevContig* d_contigs, uint32_t n_contigs, uint
     launch_sweep<3>(d_contigs, n_contigs, hp_mask, chunk, s);
 }
 void pgk_launch_post(const DevContig* d_contigs, uint32_t n_contigs, uint32_t chunk_cols, uint32_t chunk, hipStream_t s) {
-    static bool attr_set = false;
-    if (!attr_set) {
+    static bool attr_done[PG_MAX_DEVICES];
+    if (lds_attr_pending(attr_done))
         (void)hipFuncSetAttribute((const void*)k_post, hipFuncAttributeMaxDynamicSharedMemorySize, PG_POST_PLACEMENT_LDS);
-        attr_set = true;
-    }
     dim3 grid((2u * chunk_cols + PG_POST_WAVES - 1u) / PG_POST_WAVES, n_contigs);
     hipLaunchKernelGGL(k_post, grid, dim3(64 * PG_POST_WAVES), PG_POST_PLACEMENT_LDS, s, d_contigs, chunk);
 }
