@@ -256,7 +256,7 @@ def main():
             "kernel_ms": kms,
             "device_bytes": job.device_bytes(), "upload_s": upload_s,
         }
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:  # reported baseline: rank 0 at N=1 only
             # ~10-20 s of single-thread CPU work: the port runs ~6k variants/s at H=64, ~60k at H=16
             auto = {16: 600_000, 64: 60_000, 128: 12_000}.get(H, 20_000)
             out["cpu_baseline"] = cpu_baseline(batches, H, args.cpu_sample or auto)
