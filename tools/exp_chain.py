@@ -1,7 +1,9 @@
 """Timing experiments on the chain kernels: builds variants of the product library with one
 ingredient of the recursion step compiled out (-DPG_EXP=<mask>, see pg_kernels.hip) and prints the
 sweep kernel times.  Results of the variants are wrong by construction; tooling only.
-usage: python tools/exp_chain.py build   (here, CPU)   |   python tools/exp_chain.py run [H]  (GPU box)"""
+usage: python tools/exp_chain.py build   (here, CPU)   |   python tools/exp_chain.py run [H]  (GPU box)
+A single chain runs the chunked mode by default (the phase-2 columns show the last chunk's store-only
+sweep); set PG_SWEEP_MODE=fused in the environment to time the fused phase 2."""
 import os, subprocess, sys
 sys.path.insert(0, os.getcwd())
 MASKS = {0: "baseline", 1: "no column stores", 2: "no wave_sum", 4: "no u_i round trip", 8: "no posterior",
