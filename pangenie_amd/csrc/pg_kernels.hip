@@ -1752,7 +1752,10 @@ __global__ __launch_bounds__(64 * PG_POST_WAVES) void k_post(const DevContig* __
             for (int u = 0; u < UN; ++u) {
                 const uint32_t ip = ipb + u * ipstep;
                 if (ip < HP / 2) {
-                    const double p0 = av[u].x * bv[u].x, p1 = av[u].y * bv[u].y;
+                    // 2^512 first: both factors are <= 1 and their product may lie far below DBL_MIN while
+                    // still mattering relative to the variant's largest bin (the factor comes off again
+                    // through lik_exp)
+                    const double p0 = (av[u].x * 0x1p512) * bv[u].x, p1 = (av[u].y * 0x1p512) * bv[u].y;
                     const uint32_t a0 = (uint32_t)al[2 * ip] - abase, a1 = (uint32_t)al[2 * ip + 1] - abase;
 #pragma unroll
                     for (int a = 0; a < PG_AMAX; ++a) {
@@ -1810,7 +1813,7 @@ __global__ __launch_bounds__(64 * PG_POST_WAVES) void k_post(const DevContig* __
     if (lane == 0) {
         int X = fb ? 0 : *(const int32_t*)(rec + PG_REC_EXP);
         if (c + 1 < C) X += *(const int32_t*)(dc.colrec + (size_t)(c + 1) * dc.RB + PG_REC_EXP);
-        dc.lik_exp[v] = X;
+        dc.lik_exp[v] = X - 512;  // the products were formed as (alpha' * 2^512) * beta'
     }
 }
 
