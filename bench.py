@@ -2,19 +2,29 @@
 """bench.py — throughput of the genotyping hot path (emissions + forward-backward HMM).
 
 A "step" = one full pass of the device path (k_prep -> k_compact -> k_records -> k_sweep phase 1 ->
-k_sweep phase 2 -> k_bins, plus the RCCL gather of the posteriors when N > 1) over one synthetic
-contig batch that is already resident in HBM.  metric = genotyped variants/sec (whole job).
+phase 2 -> bins, plus the exchange of the posteriors to rank 0 when N > 1) over synthetic contig
+batches that are already resident in HBM.  metric = genotyped variants/sec (whole job).
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload chr22_h64|contig_h16|...]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload genome24_h64|chr22_h64|...]
 
-N > 1 is launched by the driver with torch.distributed.run (one rank per GPU); contigs are
-independent chains, so every rank genotypes its own contig (weak scaling, no data-path
-collective) and rank 0 gathers the packed posteriors with one RCCL gather per step.
+One JSON line on rank 0:
+  value              resident rate of the main workload (inputs in HBM when the timed region starts)
+  value_end_to_end   the same workload timed from host buffers to host results: H2D of every input +
+                     run + D2H of every result, into the arena the job already holds
+  roofline           dominant kernel of the main workload against the HBM peak
+  cohort             second measurement in the same line: many (sample x contig) chains against ONE
+                     shared index (pg_cohort_new) — the regime in which the sweep
+                     is HBM-bound; per-rank work fixed (weak scaling), with its own roofline
+  cpu_baseline       the CPU port of the reference on a bounded sample (N = 1 only)
+
+N > 1 (launched by the driver with torch.distributed.run, one rank per GPU): the chains of the main
+workload are SHARDED over the ranks by longest-processing-time-first (pangenie_amd/dist.py), i.e.
+BASELINE.json configs[3] as written (strong scaling: the total work is fixed); rank 0 collects all
+posteriors with one batched group of point-to-point sends per step.
 """
 from __future__ import annotations
 
 import argparse
-import ctypes as C
 import json
 import os
 import sys
@@ -27,26 +37,31 @@ ROOT = Path(__file__).resolve().parent
 sys.path.insert(0, str(ROOT))
 
 from pangenie_amd import hmm  # noqa: E402
-from pangenie_amd.panel import algorithmic_bytes, default_table_args, synthetic_panel  # noqa: E402
+from pangenie_amd.panel import (algorithmic_bytes, default_table_args, synthetic_panel,  # noqa: E402
+                                synthetic_sample_counts)
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 GB/s achievable
 
-# BASELINE.json configs -> single-GPU shapes (variants, haplotypes, k-mers/variant, multiallelic)
+# BASELINE.json configs -> shapes (variants, haplotypes, k-mers/variant, multiallelic)
 WORKLOADS = {
     "contig_h16": dict(V=50_000, H=16, K=20, multi=0.0, cfg="configs[1]: 1 contig, 50k variants, 16 haplotypes, ~20 k-mers/var"),
     "chr22_h64": dict(V=200_000, H=64, K=20, multi=0.0, cfg="configs[2]: chr22-scale, 200k variants, 64 haplotypes"),
     "chr22_h128": dict(V=60_000, H=128, K=20, multi=0.2, cfg="configs[4] per-GPU slice: 128 haplotypes, 20% multiallelic"),
-    # many independent chains on one GPU (sample x contig shards): the regime
-    # in which the sweep is HBM-bound instead of per-column-latency-bound
-    "cohort_h64": dict(V=16_000, H=64, K=20, multi=0.0, chains=256, cfg="256 chains (sample x contig shards) of 16k variants, 64 haplotypes"),
     "genome24_small": dict(V=40_000, H=64, K=20, multi=0.0, chains=24, cfg="configs[3] shape at 1/5 length, equal contigs: 24 contigs, 64 haplotypes, one GPU"),
     # BASELINE.json configs[3]: whole genome, 24 contigs with human-like length proportions, 5M variants,
     # 64 haplotypes.  164 GB of column slots: fits ONE 288 GB MI355X, so it is the single-GPU workload.
     "genome24_h64": dict(V=5_000_000, H=64, K=20, multi=0.0, chains=24, genome=True,
                          cfg="configs[3]: whole genome, 24 contigs (human chromosome length proportions), 5M variants, 64 haplotypes"),
 }
+# the cohort measurement: samples x contigs over one shared index
+COHORT = dict(samples=32, contigs=8, V=16_000, H=64, K=20)
 # GRCh38 chromosome lengths (Mb) 1..22, X, Y: proportions of the 24 synthetic contigs
 CONTIG_MB = [248, 242, 198, 190, 181, 171, 159, 145, 138, 134, 135, 133, 114, 107, 102, 90, 83, 80, 59, 64, 47, 51, 156, 57]
+
+
+def genome_contig_sizes(total_variants: int):
+    tot = float(sum(CONTIG_MB))
+    return [int(round(total_variants * mb / tot)) for mb in CONTIG_MB]
 
 
 def cpu_baseline(batches, H, sample_variants):
@@ -55,7 +70,9 @@ def cpu_baseline(batches, H, sample_variants):
     (src/commands.cpp:949-953), so a multi-contig workload is timed with one thread per contig
     (up to the host's cores), each on the first `sample_variants` variants of its own contig.
     Plain Python threads: the oracle is a C library without global state and ctypes drops the GIL
-    for the duration of the call, so the threads run on separate cores."""
+    for the duration of the call, so the threads run on separate cores.  The port is a CONSERVATIVE
+    baseline: per thread it runs about 3x faster than the compiled reference measured in the survey
+    (flat arrays instead of shared_ptr / virtual calls / std::map; BASELINE.md §2)."""
     from concurrent.futures import ThreadPoolExecutor
     from oracle import pyoracle as orc  # checker / baseline leg only
     workers = max(1, min(len(batches), os.cpu_count() or 1))
@@ -80,7 +97,7 @@ def cpu_baseline(batches, H, sample_variants):
             "sample": f"first {subs[0].n_variants} variants of each of {workers} synthetic contig(s) (H={H}), one thread per contig "
                       f"(the reference's own parallelism), oracle/pg_oracle.c long double; {wall:.1f} s wall; "
                       f"{os.cpu_count()} host cores available, {workers} used; per-thread rate "
-                      f"{subs[0].n_variants / times[0]:.0f} variants/s"}
+                      f"{subs[0].n_variants / times[0]:.0f} variants/s (the compiled reference itself: ~1450/s per thread at H=64, BASELINE.md)"}
 
 
 def profiled_traffic(workload, kernel_phase):
@@ -108,6 +125,46 @@ def profiled_traffic(workload, kernel_phase):
     return (total / passes if total > 0 else None), cands[-1].name
 
 
+class _DevArray:
+    """Zero-copy torch view of a device range owned by the job (CUDA array interface)."""
+
+    def __init__(self, ptr, n, typestr):
+        self.__cuda_array_interface__ = {"shape": (int(n),), "typestr": typestr, "data": (int(ptr), False), "version": 2}
+
+
+def roofline_of(job, batches, kms, H, workload_name):
+    """Roofline of the dominant sweep launch: algorithmic bytes per launch / hipEvent time."""
+    ncol, bytes_total = 0, 0
+    for i, bt in enumerate(batches):
+        kp = job.fetch(i).kept
+        ncol += int(kp.sum())
+        bytes_total += algorithmic_bytes(bt, kp)
+    # sweep phase 1 writes every kept column once (8*H^2 B), phase 2 reads it once; the
+    # per-variant inputs/outputs (4K+2H+3A+16+8G+8 B) are charged to phase 2.
+    p1_bytes = 8.0 * H * H * ncol
+    p2_bytes = bytes_total - p1_bytes
+    mode, chunk_cols = job.sweep_mode()
+    if mode == "chunked":
+        # phase 2 is ~2*n_chunks short launches (store-only chunks + k_post); the dominant single
+        # kernel launch — the one rocprofv3 --stats lists once per pass — is the phase-1 sweep
+        dom = "k_sweep_phase1"
+    else:
+        dom = max(("k_sweep_phase1", "k_sweep_phase2"), key=lambda k: kms.get(k, 0.0))
+    dom_bytes = p1_bytes if dom == "k_sweep_phase1" else p2_bytes
+    dom_ms = kms.get(dom, 0.0)
+    achieved = dom_bytes / (dom_ms * 1e-3) / 1e9 if dom_ms > 0 else 0.0
+    sweep_ms = kms.get("k_sweep_phase1", 0.0) + kms.get("k_sweep_phase2", 0.0)
+    traffic, traffic_src = (None, None)
+    if workload_name:
+        traffic, traffic_src = profiled_traffic(workload_name, 1 if dom == "k_sweep_phase1" else 2)
+    return {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
+            "algorithmic_bytes_per_launch": dom_bytes, "avg_launch_ms": dom_ms,
+            "sweep_GBs": (bytes_total / (sweep_ms * 1e-3) / 1e9) if sweep_ms > 0 else 0.0,
+            "phase2_ms": kms.get("k_sweep_phase2", 0.0),
+            "phase2_traffic": (profiled_traffic(workload_name, 2)[0] if workload_name else None)}, ncol, (mode, chunk_cols)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -117,6 +174,9 @@ def main():
     ap.add_argument("--variants", type=int, default=0, help="override the variant count (debug)")
     ap.add_argument("--cpu-sample", type=int, default=0, help="variants in the CPU-baseline sample (0 = auto ~10-20 s)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-cohort", action="store_true", help="skip the cohort sub-measurement")
+    ap.add_argument("--cohort-only", action="store_true", help="profiling: only the cohort measurement")
+    ap.add_argument("--cohort-samples", type=int, default=COHORT["samples"])
     args = ap.parse_args()
 
     import torch
@@ -133,53 +193,7 @@ def main():
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", rank=rank, world_size=world)
-
-    w = WORKLOADS[args.workload]
-    V = args.variants or w["V"]
-    H, K = w["H"], w["K"]
-    n_chains = int(w.get("chains", 1))
-    if w.get("genome"):
-        tot = float(sum(CONTIG_MB))
-        sizes = [int(round(V * mb / tot)) for mb in CONTIG_MB]
-    else:
-        sizes = [V] * n_chains
-    batches = [synthetic_panel(sizes[i], H, K, seed=12345 + rank + 1000 * i, multiallelic_frac=w["multi"]) for i in range(n_chains)]
-    V_total = sum(sizes)
-    batch = batches[0]
-    table = hmm.ProbabilityTable(*default_table_args())
-    params = hmm.make_params(1.26, False, 1e-5)  # what run_genotyping passes (reference src/commands.cpp:160)
-    t_up = time.perf_counter()
-    job = hmm.Job(batches, table, params, device=local_rank)
-    upload_s = time.perf_counter() - t_up
-
-    # gather plumbing: posteriors stay on the device; every rank owns its own n_chains chains (weak
-    # scaling), rank 0 collects the packed (lik, lik_exp) of ALL chains of every rank with ONE RCCL
-    # gather per step and keeps them in HBM (like the single-GPU run, the timed region ends with the
-    # posteriors resident on a device, not on the host)
-    hip = C.CDLL("libamdhip64.so")
-    dev_res = [job.device_results(i) for i in range(n_chains)]
-    plan = [[r * n_chains + i for i in range(n_chains)] for r in range(world)]
-    all_lik, all_var, local_t = [], [], {}
-    if world > 1:
-        from pangenie_amd.dist import gather_posteriors
-        mine = torch.tensor([[d[1], d[3]] for d in dev_res], dtype=torch.int64, device="cuda")
-        allsz = [torch.empty_like(mine) for _ in range(world)]
-        dist.all_gather(allsz, mine)
-        for t in allsz:  # chain ids are rank-major, same order as `plan`
-            all_lik += [int(x) for x in t[:, 0]]
-            all_var += [int(x) for x in t[:, 1]]
-        for i, (d_lik, n_lik, d_exp, n_var) in enumerate(dev_res):
-            local_t[rank * n_chains + i] = (torch.empty(n_lik, dtype=torch.float64, device="cuda"),
-                                            torch.empty(n_var, dtype=torch.int32, device="cuda"))
-
-    def step():
-        job.run()
-        if world > 1:
-            for i, (d_lik, n_lik, d_exp, n_var) in enumerate(dev_res):
-                lt, et = local_t[rank * n_chains + i]
-                hip.hipMemcpy(C.c_void_p(lt.data_ptr()), C.c_void_p(d_lik), C.c_size_t(n_lik * 8), 3)
-                hip.hipMemcpy(C.c_void_p(et.data_ptr()), C.c_void_p(d_exp), C.c_size_t(n_var * 4), 3)
-            gather_posteriors(local_t, all_lik, all_var, plan, dst=0, unpack=False)
+    dev = torch.device("cuda", local_rank)
 
     def fence():
         torch.cuda.synchronize()
@@ -187,81 +201,163 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        step()
-    kms = {}
-    fence()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-        for k, v in job.kernel_ms().items():
-            kms[k] = kms.get(k, 0.0) + v
-    fence()
-    dt = time.perf_counter() - t0
-    if world > 1:
-        tt = torch.tensor([dt], dtype=torch.float64, device="cuda")
+    def max_over_ranks(x):
+        if world == 1:
+            return x
+        tt = torch.tensor([x], dtype=torch.float64, device=dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        dt = float(tt.item())
+        return float(tt.item())
 
-    res = job.fetch(0)
-    kms = {k: v / args.steps for k, v in kms.items()}
+    table = hmm.ProbabilityTable(*default_table_args())
+    params = hmm.make_params(1.26, False, 1e-5)  # what run_genotyping passes (reference src/commands.cpp:160)
+    out = {"metric": "genotyped variants/sec (whole node) at H haplotypes; HBM GB/s vs roofline", "unit": "variants/s",
+           "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "higher_is_better": True,
+           "vs_baseline": None, "dtype": "f64", "data": "synthetic"}
+
+    # ------------------------------------------------------------------ main workload
+    w = WORKLOADS[args.workload]
+    V = args.variants or w["V"]
+    H, K = w["H"], w["K"]
+    n_chains = int(w.get("chains", 1))
+    sizes = genome_contig_sizes(V) if w.get("genome") else [V] * n_chains
+    V_total = sum(sizes)
+    if not args.cohort_only:
+        from pangenie_amd.dist import assign_chains, gather_posteriors
+        # chains are sharded over the ranks (every rank computes the same plan); chain i is the same
+        # synthetic contig whatever the number of GPUs
+        plan = assign_chains([float(s) * H * H for s in sizes], world)
+        mine = plan[rank]
+        batches = [synthetic_panel(sizes[i], H, K, seed=12345 + 1000 * i, multiallelic_frac=w["multi"]) for i in mine]
+        job = hmm.Job(batches, table, params, device=local_rank) if mine else None
+        hs = job.host_seconds() if job else {"alloc_s": 0.0, "upload_s": 0.0}
+        n_lik = [0] * n_chains
+        local = {}
+        if job:
+            d_lik, d_exp, n_tot = job.packed_results()
+            for k, i in enumerate(mine):
+                n_lik[i] = job.device_results(k)[1]
+        if world > 1:
+            t = torch.tensor(n_lik, dtype=torch.int64, device=dev)
+            dist.all_reduce(t)
+            n_lik = [int(x) for x in t]
+            # zero-copy views of the job's packed result ranges, cut per chain for the exchange
+            if job:
+                lik_t = torch.as_tensor(_DevArray(d_lik, n_tot, "<f8"), device=dev)
+                exp_t = torch.as_tensor(_DevArray(d_exp, n_tot, "<i4"), device=dev)
+                off = 0
+                for i in mine:
+                    local[i] = (lik_t[off:off + n_lik[i]], exp_t[off:off + n_lik[i]])
+                    off += n_lik[i]
+
+        def step():
+            if job:
+                job.run()
+            if world > 1:
+                gather_posteriors(local, n_lik, plan, dst=0, unpack=False, device=dev)
+
+        for _ in range(args.warmup):
+            step()
+        kms = {}
+        fence()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            step()
+            if job:
+                for k, v in job.kernel_ms().items():
+                    kms[k] = kms.get(k, 0.0) + v
+        fence()
+        dt = max_over_ranks(time.perf_counter() - t0)
+        kms = {k: v / args.steps for k, v in kms.items()}
+
+        # end to end: host buffers -> H2D of every input -> run -> D2H of every result, into the resident arena
+        fence()
+        t0 = time.perf_counter()
+        if job:
+            job.upload()
+            job.run()
+            results = [job.fetch(k) for k in range(len(mine))]
+        if world > 1:
+            gather_posteriors(local, n_lik, plan, dst=0, unpack=False, device=dev)
+        fence()
+        dt_e2e = max_over_ranks(time.perf_counter() - t0)
+        hs2 = job.host_seconds() if job else {"upload_s": 0.0, "run_s": 0.0, "fetch_s": 0.0}
+
+        if rank == 0:
+            roof, ncol, (mode, chunk_cols) = roofline_of(job, batches, kms, H, args.workload if (V == w["V"] and world == 1) else None)
+            out.update({
+                "value": V_total * args.steps / dt, "ms_per_step": dt / args.steps * 1e3,
+                "scaling": "strong" if world > 1 else "weak",
+                "value_end_to_end": V_total / dt_e2e,
+                "end_to_end": {"ms": dt_e2e * 1e3, "h2d_ms": hs2["upload_s"] * 1e3, "run_ms": hs2["run_s"] * 1e3, "d2h_ms": hs2["fetch_s"] * 1e3,
+                               "h2d_bytes": sum(job.upload_bytes().values()),
+                               "note": "rank 0's share; arena resident (device allocation at job creation: alloc_s)"},
+                "config": {"workload": f"{args.workload}: {w['cfg']}; {V_total} variants x {H} haplotypes x {K} k-mers/variant in {n_chains} chain(s) "
+                                       f"(longest {max(sizes)}), seeds 12345+1000*chain; sharded over {world} GPU(s) by LPT",
+                           "variants": V_total, "haplotypes": H, "kmers_per_variant": K, "chains": n_chains,
+                           "chains_on_rank0": len(mine), "kept_columns_rank0": ncol, "workgroups_per_chain": 2,
+                           "parallelism": f"contig-sharded x{world}", "sweep_mode": "%s (chunk_cols=%d)" % (mode, chunk_cols)},
+                "roofline": roof, "kernel_ms": kms, "device_bytes": job.device_bytes(),
+                "alloc_s": hs["alloc_s"], "upload_s": hs["upload_s"],
+            })
+            if not args.no_cpu_baseline and world == 1:  # reported baseline: rank 0 at N=1 only
+                # ~10-20 s of single-thread CPU work: the port runs ~6k variants/s at H=64, ~60k at H=16
+                auto = {16: 600_000, 64: 60_000, 128: 12_000}.get(H, 20_000)
+                out["cpu_baseline"] = cpu_baseline(batches, H, args.cpu_sample or auto)
+        if job:
+            job.close()
+        del batches
+        hmm._lib.load_hip().pg_hmm_release_cache()
+
+    # ------------------------------------------------------------------ cohort sub-measurement
+    if not args.no_cohort:
+        c = COHORT
+        S, NC, Hc = args.cohort_samples, c["contigs"], c["H"]
+        index = [synthetic_panel(c["V"], Hc, c["K"], seed=777 + i) for i in range(NC)]
+        samples = []
+        for s in range(S):  # every rank genotypes its own samples (weak scaling)
+            kcs, covs = zip(*[synthetic_sample_counts(ix, seed=100_000 * (rank + 1) + 100 * s + i) for i, ix in enumerate(index)])
+            samples.append((list(kcs), list(covs)))
+        cjob = hmm.Job.cohort(index, samples, table, params, device=local_rank)
+        csteps, cwarm = max(2, min(args.steps, 3)), 1
+        for _ in range(cwarm):
+            cjob.run()
+        ckms = {}
+        fence()
+        t0 = time.perf_counter()
+        for _ in range(csteps):
+            cjob.run()
+            for k, v in cjob.kernel_ms().items():
+                ckms[k] = ckms.get(k, 0.0) + v
+        fence()
+        cdt = max_over_ranks(time.perf_counter() - t0)
+        ckms = {k: v / csteps for k, v in ckms.items()}
+        fence()
+        t0 = time.perf_counter()
+        cjob.upload()  # the next batch of samples: counts only, the index stays resident
+        cjob.run()
+        fence()
+        cdt_up = max_over_ranks(time.perf_counter() - t0)
+        if rank == 0:
+            cb = cjob.batches
+            croof, cncol, (cmode, _) = roofline_of(cjob, cb, ckms, Hc, "cohort_h64" if world == 1 and S == COHORT["samples"] else None)
+            cv = S * NC * c["V"]
+            ub = cjob.upload_bytes()
+            out["cohort"] = {
+                "workload": f"{S} samples x {NC} contigs of {c['V']} variants, {Hc} haplotypes, {c['K']} k-mers/variant per GPU: "
+                            f"{S * NC} chains over ONE shared index (pg_cohort_new)",
+                "value": cv * world * csteps / cdt, "unit": "variants/s", "scaling": "weak", "steps": csteps, "ms_per_step": cdt / csteps * 1e3,
+                "chains_per_gpu": S * NC, "sweep_mode": cmode, "kept_columns": cncol,
+                "value_with_sample_upload": cv * world / cdt_up,
+                "h2d_bytes_per_sample_variant": ub["samples"] / float(cv),
+                "roofline": croof, "kernel_ms": ckms, "device_bytes": cjob.device_bytes(),
+            }
+            if args.cohort_only:
+                out.update({"value": out["cohort"]["value"], "ms_per_step": out["cohort"]["ms_per_step"], "scaling": "weak",
+                            "config": {"workload": "cohort_h64 only: " + out["cohort"]["workload"]}, "roofline": croof})
+        cjob.close()
 
     if rank == 0:
-        total_variants = V_total * world * args.steps
-        value = total_variants / dt
-        # roofline of the dominant kernel (HBM-bound class), algorithmic bytes per launch
-        kept = res.kept
-        ncol = int(kept.sum())
-        bytes_total = algorithmic_bytes(batch, kept)
-        if n_chains > 1:  # all chains of the job run in the same launch
-            ncol, bytes_total = 0, 0
-            for i, bt in enumerate(batches):
-                kp = job.fetch(i).kept
-                ncol += int(kp.sum())
-                bytes_total += algorithmic_bytes(bt, kp)
-        # sweep phase 1 writes every kept column once (8*H^2 B), phase 2 reads it once; the
-        # per-variant inputs/outputs (4K+2H+3A+16+8G+8 B) are charged to phase 2.
-        p1_bytes = 8.0 * H * H * ncol
-        p2_bytes = bytes_total - p1_bytes
-        mode, chunk_cols = job.sweep_mode()
-        if mode == "chunked":
-            # phase 2 is ~2*n_chunks short launches (store-only chunks + k_post); the dominant single
-            # kernel launch — the one rocprofv3 --stats lists once per pass — is the phase-1 sweep
-            dom = "k_sweep_phase1"
-        else:
-            dom = max(("k_sweep_phase1", "k_sweep_phase2"), key=lambda k: kms.get(k, 0.0))
-        dom_bytes = p1_bytes if dom == "k_sweep_phase1" else p2_bytes
-        dom_ms = kms.get(dom, 0.0)
-        achieved = dom_bytes / (dom_ms * 1e-3) / 1e9 if dom_ms > 0 else 0.0
-        sweep_ms = kms.get("k_sweep_phase1", 0.0) + kms.get("k_sweep_phase2", 0.0)
-        traffic, traffic_src = (None, None)
-        if V == w["V"]:  # the committed profile is of this very command (same seeds, same chains)
-            traffic, traffic_src = profiled_traffic(args.workload, 1 if dom == "k_sweep_phase1" else 2)
-        out = {
-            "metric": "genotyped variants/sec (whole node) at H haplotypes; HBM GB/s vs roofline",
-            "value": value, "unit": "variants/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-            "config": {"workload": f"{args.workload}: {w['cfg']}; {V_total} variants x {H} haplotypes x {K} k-mers/variant "
-                                   f"per GPU in {n_chains} chain(s) (longest {max(sizes)}), seed 12345+rank",
-                       "variants_per_gpu": V_total, "haplotypes": H, "kmers_per_variant": K,
-                       "kept_columns": ncol, "chains_per_gpu": n_chains, "workgroups_per_chain": 2, "parallelism": f"contig-sharded x{world}",
-                       "sweep_mode": "%s (chunk_cols=%d)" % (mode, chunk_cols)},
-            "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
-                         "algorithmic_bytes_per_launch": dom_bytes, "avg_launch_ms": dom_ms,
-                         "sweep_GBs": (bytes_total / (sweep_ms * 1e-3) / 1e9) if sweep_ms > 0 else 0.0,
-                         "phase2_ms": kms.get("k_sweep_phase2", 0.0),
-                         "phase2_traffic": (profiled_traffic(args.workload, 2)[0] if V == w["V"] else None)},
-            "kernel_ms": kms,
-            "device_bytes": job.device_bytes(), "upload_s": upload_s,
-        }
-        if not args.no_cpu_baseline and world == 1:  # reported baseline: rank 0 at N=1 only
-            # ~10-20 s of single-thread CPU work: the port runs ~6k variants/s at H=64, ~60k at H=16
-            auto = {16: 600_000, 64: 60_000, 128: 12_000}.get(H, 20_000)
-            out["cpu_baseline"] = cpu_baseline(batches, H, args.cpu_sample or auto)
         print(json.dumps(out))
-    job.close()
     if world > 1:
         dist.destroy_process_group()
 

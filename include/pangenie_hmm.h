@@ -17,9 +17,19 @@
  * is what the reference throws, e.g. src/columnindexer.cpp:18-22).
  *
  * Numeric contract: the device computes in fp64 and returns every unnormalised
- * genotype likelihood as  lik * 2^lik_exp ; the host rebuilds the reference's
- * 80-bit `long double` value with ldexpl() and does normalisation / GT / GQ in
- * long double (reference src/genotypingresult.cpp:118-210).
+ * genotype likelihood as  lik[g] * 2^lik_exp[g]  — one fp64 mantissa in [0.5,1)
+ * (or 0) and one int32 exponent PER GENOTYPE BIN; the host rebuilds the
+ * reference's 80-bit `long double` value with ldexpl() and does normalisation /
+ * GT / GQ in long double (reference src/genotypingresult.cpp:118-210).
+ * Guaranteed range: every bin holds 1e-6 relative (observed 1e-13) down to the
+ * reference's own long double underflow (2^-16445), however many decades it lies
+ * below its variant's largest bin, for every chain whose transitions mix
+ * (recombination probability q > 0 between neighbouring columns: any gap of
+ * >= 1 bp at recombrate * effective_N >= 1e-12).  The emission of a bin is
+ * applied once, to the finished bin, as (mantissa, exponent); the stored columns
+ * carry a bounded dynamic range (>= q^2 of their sum).  Chains WITHOUT mixing
+ * (recombrate == 0 or effective_N == 0: every state evolves on its own) keep
+ * 2^-1400 relative to a column's sum in fp64 where the reference keeps 2^-16445.
  */
 #ifndef PANGENIE_HMM_H
 #define PANGENIE_HMM_H
@@ -34,7 +44,7 @@ extern "C" {
 #define PG_OK 0
 #define PG_ERR_INVALID (-1)     /* bad argument / malformed batch            */
 #define PG_ERR_NO_PATHS (-2)    /* "column is not covered by any paths"      */
-#define PG_ERR_UNSUPPORTED (-3) /* not on the device path: run_phasing, > 128 selected paths, > 32 alleles per variant */
+#define PG_ERR_UNSUPPORTED (-3) /* not on the device path: run_phasing, > 1024 selected paths, > 256 alleles per variant */
 #define PG_ERR_DEVICE (-4)      /* HIP runtime error / no GPU                */
 #define PG_ERR_NOMEM (-5)
 
@@ -83,8 +93,8 @@ typedef struct pg_hmm_params {
  *  kept[v] && allele_present[a] && allele_present[b] (src/hmm.cpp:368).
  * ------------------------------------------------------------------ */
 typedef struct pg_contig_result {
-    double*   lik;            /* [geno_off[V]] unnormalised likelihood mantissa part          */
-    int32_t*  lik_exp;        /* [V] power-of-two exponent: L = lik * 2^lik_exp               */
+    double*   lik;            /* [geno_off[V]] unnormalised likelihood, mantissa in [0.5,1) or 0 */
+    int32_t*  lik_exp;        /* [geno_off[V]] power-of-two exponent per bin: L = lik * 2^lik_exp */
     uint8_t*  kept;           /* [V] 1 = variant is an HMM column (columnindexer.cpp:24-31)   */
     uint8_t*  allele_present; /* [sumA] 1 = allele slot occurs on a selected path             */
     uint16_t* n_kmers;        /* [V] GenotypingResult::set_unique_kmers (hmm.cpp:106-109)     */
@@ -137,7 +147,7 @@ pg_job* pg_job_create(int device, uint32_t n_contigs, const pg_contig_batch* bat
 int  pg_job_run(pg_job* job, void* stream, char* err, size_t errlen);
 /* Copies contig c's results to host buffers. */
 int  pg_job_fetch(pg_job* job, uint32_t contig, pg_contig_result* out, char* err, size_t errlen);
-/* Device-resident result buffers of contig c (for an RCCL gather without a host hop). */
+/* Device-resident result buffers of contig c: lik f64 [n_lik], lik_exp i32 [n_lik]. */
 int  pg_job_device_results(pg_job* job, uint32_t contig, void** d_lik, uint64_t* n_lik,
                            void** d_lik_exp, uint64_t* n_variants);
 /* Per-kernel-class elapsed milliseconds of the LAST pg_job_run, measured with
@@ -156,6 +166,51 @@ uint64_t pg_job_device_bytes(const pg_job* job);
  * chains).  Override with the environment variables PG_SWEEP_MODE=fused|chunked, PG_CHUNK_COLS=n. */
 int  pg_job_sweep_mode(const pg_job* job, uint32_t* chunk_cols);
 void pg_job_destroy(pg_job* job);
+
+/* pg_job_create with an error code instead of a NULL: PG_ERR_INVALID (malformed batch),
+ * PG_ERR_UNSUPPORTED (limits above), PG_ERR_NOMEM (device allocation), PG_ERR_DEVICE. */
+int  pg_job_new(int device, uint32_t n_contigs, const pg_contig_batch* batches,
+                const pg_table* table, const pg_hmm_params* params,
+                pg_job** out, char* err, size_t errlen);
+/* Number of chains of a job (= n_contigs, or n_samples * n_contigs for a cohort job): the range of
+ * the `contig` argument of pg_job_fetch / pg_job_device_results / pg_job_profile_counters. */
+uint32_t pg_job_n_chains(const pg_job* job);
+
+/* ------------------------------------------------------------------ *
+ *  Cohort jobs: many samples against ONE index.
+ *  The index (`*_UniqueKmersMap.cereal`: positions, alleles, k-mer masks, path -> allele) is
+ *  shared by all samples; only the read k-mer counts and the local coverage differ per
+ *  sample (reference src/commands.cpp:118-138, README.md:128).  The index arrays are
+ *  uploaded once; every (sample, contig) pair is an independent chain of the job:
+ *      chain id = sample * n_contigs + contig.
+ *  `index[c].kmer_count` / `.coverage` are ignored (may be NULL).
+ * ------------------------------------------------------------------ */
+typedef struct pg_sample_counts {
+    const uint16_t* const* kmer_count; /* [n_contigs] -> [sumK of contig c]  UniqueKmers::update_readcount */
+    const uint16_t* const* coverage;   /* [n_contigs] -> [V of contig c]     UniqueKmers::set_coverage     */
+} pg_sample_counts;
+int  pg_cohort_new(int device, uint32_t n_contigs, const pg_contig_batch* index,
+                   uint32_t n_samples, const pg_sample_counts* samples,
+                   const pg_table* table, const pg_hmm_params* params,
+                   pg_job** out, char* err, size_t errlen);
+
+/* Re-uploads the inputs of a resident job (same shapes as at creation): what a pipeline does
+ * with the next set of read counts.  `samples` = NULL for a job made by pg_job_create/new (the
+ * batches carry their own counts), else the cohort's per-sample arrays (`batches` may then be
+ * NULL to keep the resident index and upload the counts only). */
+int  pg_job_upload(pg_job* job, const pg_contig_batch* batches, const pg_sample_counts* samples,
+                   char* err, size_t errlen);
+/* Host wall seconds: [0] device allocation at creation, [1] last input upload (H2D),
+ * [2] last pg_job_run, [3] last pg_job_fetch_all / sum of pg_job_fetch since the last run. */
+int  pg_job_host_seconds(const pg_job* job, double out4[4]);
+/* Input bytes moved H2D by the last upload: [0] index arrays, [1] per-sample arrays. */
+int  pg_job_upload_bytes(const pg_job* job, uint64_t out2[2]);
+/* All chains' posteriors as two packed device ranges, chain after chain (what a multi-GPU
+ * gather sends): lik f64 [n_lik_total], lik_exp i32 [n_lik_total]. */
+int  pg_job_packed_results(pg_job* job, void** d_lik, void** d_lik_exp, uint64_t* n_lik_total);
+/* The one-shot call keeps the device arena of its last job for the next call on that device;
+ * this releases it. */
+void pg_hmm_release_cache(void);
 
 /* ------------------------------------------------------------------ *
  *  Unit-level entry points (device), mirroring the reference classes the

@@ -72,6 +72,13 @@ class PgContigResult(C.Structure):
     ]
 
 
+class PgSampleCounts(C.Structure):
+    _fields_ = [
+        ("kmer_count", C.POINTER(u16p)),
+        ("coverage", C.POINTER(u16p)),
+    ]
+
+
 class HipExtensionMissing(RuntimeError):
     pass
 
@@ -125,6 +132,24 @@ def _bind_hip(lib):
     lib.pg_job_sweep_mode.restype = C.c_int
     lib.pg_job_destroy.argtypes = [C.c_void_p]
     lib.pg_job_destroy.restype = None
+    lib.pg_job_new.argtypes = [C.c_int, C.c_uint32, C.POINTER(PgContigBatch), C.c_void_p, C.POINTER(PgHmmParams),
+                               C.POINTER(C.c_void_p), C.c_char_p, C.c_size_t]
+    lib.pg_job_new.restype = C.c_int
+    lib.pg_cohort_new.argtypes = [C.c_int, C.c_uint32, C.POINTER(PgContigBatch), C.c_uint32, C.POINTER(PgSampleCounts),
+                                  C.c_void_p, C.POINTER(PgHmmParams), C.POINTER(C.c_void_p), C.c_char_p, C.c_size_t]
+    lib.pg_cohort_new.restype = C.c_int
+    lib.pg_job_n_chains.argtypes = [C.c_void_p]
+    lib.pg_job_n_chains.restype = C.c_uint32
+    lib.pg_job_upload.argtypes = [C.c_void_p, C.POINTER(PgContigBatch), C.POINTER(PgSampleCounts), C.c_char_p, C.c_size_t]
+    lib.pg_job_upload.restype = C.c_int
+    lib.pg_job_host_seconds.argtypes = [C.c_void_p, f64p]
+    lib.pg_job_host_seconds.restype = C.c_int
+    lib.pg_job_upload_bytes.argtypes = [C.c_void_p, u64p]
+    lib.pg_job_upload_bytes.restype = C.c_int
+    lib.pg_job_packed_results.argtypes = [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), u64p]
+    lib.pg_job_packed_results.restype = C.c_int
+    lib.pg_hmm_release_cache.argtypes = []
+    lib.pg_hmm_release_cache.restype = None
     lib.pg_emission_table.argtypes = [C.POINTER(PgContigBatch), C.c_void_p, C.c_uint32, C.c_int,
                                       ldp, i32p, C.c_char_p, C.c_size_t]
     lib.pg_emission_table.restype = C.c_int
@@ -141,6 +166,8 @@ HIP_ABI_SYMBOLS = [
     "pg_hmm_genotype_contig", "pg_job_create", "pg_job_run", "pg_job_fetch",
     "pg_job_device_results", "pg_job_profile_counters", "pg_job_kernel_ms", "pg_job_kernel_name", "pg_job_device_bytes", "pg_job_sweep_mode",
     "pg_job_destroy", "pg_emission_table", "pg_transition_probs",
+    "pg_job_new", "pg_cohort_new", "pg_job_n_chains", "pg_job_upload", "pg_job_host_seconds", "pg_job_upload_bytes",
+    "pg_job_packed_results", "pg_hmm_release_cache",
 ]
 
 

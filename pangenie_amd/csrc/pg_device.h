@@ -13,15 +13,20 @@
 //   part[C][part_slots/2][T][2] : (fused mode) per-thread posterior partials by row-allele pair,
 //                   reduced by k_bins
 //   scratch / handoff-free chunk buffers : (chunked mode) see DevContig::scratch
-//   wide[n_wide][..] : emission tables of columns with more than PG_AMAX alleles on the selected paths
-//   lik / lik_exp : outputs
+//   vpair[V][..]  : (mantissa, exponent) of the emission product of every local allele pair of a
+//                   variant — applied ONCE to a finished posterior bin (k_bins / k_post), so a bin keeps
+//                   full relative precision however small its emission is
+//   wide[..]      : emission tables of columns with more than PG_AMAX alleles on the selected paths
+//   xbuf[2][HP*HP]: generic sweep kernel only (HP >= 256): the column after the emission multiply
+//   lik / lik_exp : outputs, one (mantissa, exponent) pair per genotype bin
 #pragma once
 #include <stdint.h>
 
 #define PG_AMAX 5                 // max distinct alleles on the selected paths of a NARROW column (table inside the record)
 #define PG_ESTRIDE (PG_AMAX + 1)  // row stride of the expanded emission table; row/col PG_AMAX = 0 (phantom paths)
 #define PG_ETAB (PG_ESTRIDE * PG_ESTRIDE)
-#define PG_MAX_ALLELES_PER_VARIANT 32  // all alleles of one UniqueKmers object (k_prep keeps their presence in a 32-bit mask)
+#define PG_MAX_ALLELES_PER_VARIANT 256  // all alleles of one UniqueKmers object (k_prep keeps their presence in a 256-bit LDS bitmap)
+#define PG_MAX_PATHS 1024               // selected paths per chain (HP = 16..128: register-resident kernels; 256..1024: generic kernel)
 #define PG_PHANTOM 255
 
 // byte offsets inside a record
@@ -39,18 +44,35 @@
 #define PG_REC_ALLELES (80 + 8 * PG_ETAB)  // u8[HP]
 #define PG_REC_FLAG_ALLZERO 1
 #define PG_REC_FLAG_WIDE 2    // more than PG_AMAX alleles on the selected paths: table in DevContig::wide
-#define PG_REC_WIDE_IDX 44    // u32: index of the variant's wide entry
+#define PG_REC_WIDE_IDX 44    // u32: byte offset / 16 of the variant's wide entry inside DevContig::wide
 
 // Wide entries (columns with PG_AMAX < n_local <= PG_WIDE_MAX distinct alleles on the selected paths;
 // chunked sweep mode only): the emission table no longer fits the column record, so it lives in a
-// side buffer — double E[PG_WIDE_STRIDE][PG_WIDE_STRIDE] (symmetric, scaled by 2^-X like the narrow
-// one; row/column PG_WIDE_MAX is zero: phantom paths) followed by u16 local_slot[PG_WIDE_MAX] — one
-// entry per variant with more than PG_AMAX alleles.
-#define PG_WIDE_MAX 32
-#define PG_WIDE_STRIDE (PG_WIDE_MAX + 1)
-#define PG_WIDE_TABLE_BYTES (PG_WIDE_STRIDE * PG_WIDE_STRIDE * 8)
-#define PG_WIDE_ENTRY_BYTES (PG_WIDE_TABLE_BYTES + PG_WIDE_MAX * 2)  /* 8776: a multiple of 8 */
+// side buffer.  With S = n_local + 1 (row/column n_local is zero: phantom paths) an entry holds
+//   double  E [S][S]   emission products scaled by 2^-X (symmetric), read by the recursion
+//   double  Pm[S][S]   mantissa in [0.5,1) (or 0) of the unscaled product of the local pair
+//   int32   Pe[S][S]   its exponent                      (Pm, Pe: applied to finished bins)
+//   u16     slot[n_local]  local allele -> allele slot of the variant
+// The host reserves room for S = min(A, H) + 1 per variant with more than PG_AMAX alleles.
+#define PG_WIDE_MAX 254
 #define PG_WIDE_NONE 0xFFFFFFFFu
+static inline uint64_t pg_wide_entry_bytes(uint32_t n_local) {
+    const uint64_t s = (uint64_t)n_local + 1;
+    return (s * s * 20 + (uint64_t)n_local * 2 + 15) & ~(uint64_t)15;
+}
+#define PG_WIDE_OFF_PM(S) ((size_t)(S) * (S) * 8)
+#define PG_WIDE_OFF_PE(S) ((size_t)(S) * (S) * 16)
+#define PG_WIDE_OFF_SLOT(S) ((size_t)(S) * (S) * 20)
+
+// Column biases: stored forward columns (before the emission multiply) sum to about
+// 2^PG_BIAS_F, stored backward columns to about 2^PG_BIAS_B times their emission-weighted mass.
+#define PG_BIAS_F 400
+#define PG_BIAS_B 400
+
+// (mantissa, exponent) pair tables of narrow variants: vpair[v] = double m[NP] then int32 e[NP],
+// NP = pair_n (pair_n + 1) / 2 padded to even, index la * pair_n - la (la - 1) / 2 + (lb - la)
+static inline uint32_t pg_pair_count(uint32_t pair_n) { return ((pair_n * (pair_n + 1) / 2) + 1u) & ~1u; }
+static inline uint32_t pg_pair_bytes(uint32_t pair_n) { return pg_pair_count(pair_n) * 12u; }
 
 static inline uint32_t pg_rec_bytes(uint32_t hp) { return (PG_REC_ALLELES + hp + 63u) & ~63u; }
 
@@ -75,7 +97,7 @@ struct DevContig {
     int32_t uniform;
     uint32_t debug;        // PG_DEBUG env: ablation switches for profiling (0 in production)
     uint32_t part_slots;   // allele slots per column in `part` = min(PG_AMAX, max alleles of a variant)
-    uint32_t pad2;
+    uint32_t pair_n;       // local alleles the vpair tables are laid out for = min(PG_AMAX, max alleles of a variant)
     // inputs
     const uint64_t* pos;
     const uint16_t* cov;
@@ -107,11 +129,13 @@ struct DevContig {
     double*   scratch;
     uint32_t  chunk_cols;
     uint32_t  pad3;
-    uint8_t*  wide;            // [n_wide][PG_WIDE_ENTRY_BYTES]
-    const uint32_t* wide_idx;  // [V]: entry of variant v, PG_WIDE_NONE if it has <= PG_AMAX alleles
+    uint8_t*  wide;            // wide entries (see above)
+    const uint32_t* wide_idx;  // [V]: byte offset / 16 of the entry of variant v, PG_WIDE_NONE if it has <= PG_AMAX alleles
+    uint8_t*  vpair;           // [V][pg_pair_bytes(pair_n)]
+    double*   xbuf;            // [2][HP*HP] generic kernel scratch (forward role first)
     uint32_t* err;
     unsigned long long* prof;  // [64] in-kernel cycle counters (PG_DEBUG bit 3), profiling only
     // outputs
-    double*   lik;
-    int32_t*  lik_exp;
+    double*   lik;             // [n_lik] mantissa in [0.5,1) or 0
+    int32_t*  lik_exp;         // [n_lik] exponent: L = lik * 2^lik_exp
 };

@@ -240,6 +240,9 @@ DEVI void emission_pair_products(const DevContig& dc, const DevTable& tab, uint3
 DEVI uint32_t tri_local(uint32_t a, uint32_t b) {  // a <= b < PG_AMAX
     return a * PG_AMAX - a * (a - 1) / 2 + (b - a);
 }
+DEVI uint32_t tri_n(uint32_t a, uint32_t b, uint32_t n) {  // a <= b < n
+    return a * n - a * (a - 1) / 2 + (b - a);
+}
 
 DEVI void decode_pair(uint32_t idx, uint32_t A, uint32_t& s1, uint32_t& s2) {
     uint32_t a = 0, rem = idx;
@@ -247,15 +250,32 @@ DEVI void decode_pair(uint32_t idx, uint32_t A, uint32_t& s1, uint32_t& s2) {
     s1 = a; s2 = a + rem;
 }
 
+// presence bitmap of the allele slots of one variant (256 bits, one per wave, in LDS)
+DEVI bool slot_present(const uint32_t* pres, uint32_t s) { return (pres[s >> 5] >> (s & 31u)) & 1u; }
+DEVI uint32_t local_index(const uint32_t* pres, uint32_t s) {  // number of present slots below s
+    uint32_t n = 0;
+    const uint32_t w = s >> 5;
+    for (uint32_t q = 0; q < w; ++q) n += __popc(pres[q]);
+    return n + __popc(pres[w] & ((1u << (s & 31u)) - 1u));
+}
+DEVI int slot_of(const DevContig& dc, uint32_t a0, uint32_t A, uint16_t a) {
+    int s = -1;
+    for (uint32_t q = 0; q < A; ++q)
+        if (dc.allele_id[a0 + q] == a) s = (int)q;
+    return s;
+}
+
 // ------------------------------------------------------------------------------------------
 //  k_prep : one wave per variant
 // ------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_prep(const DevContig* __restrict__ contigs, DevTable tab) {
+    constexpr int NLP = PG_AMAX * (PG_AMAX + 1) / 2;  // local pairs of a narrow column
     __shared__ double s_m[4][64 * 3];
     __shared__ int s_e[4][64 * 3];
     __shared__ double s_E[4][PG_ETAB];
-    __shared__ double s_pm[4][PG_AMAX * (PG_AMAX + 1) / 2];
-    __shared__ int s_pe[4][PG_AMAX * (PG_AMAX + 1) / 2];
+    __shared__ double s_pm[4][NLP];
+    __shared__ int s_pe[4][NLP];
+    __shared__ uint32_t s_pres[4][8];
     const DevContig& dc = contigs[blockIdx.y];
     const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const uint32_t v = blockIdx.x * 4 + wave;
@@ -269,54 +289,54 @@ __global__ __launch_bounds__(256) void k_prep(const DevContig* __restrict__ cont
     }
     // ---- ColumnIndexer rule: kept iff a selected path carries a defined non-ref allele
     //      (reference src/columnindexer.cpp:24-31); also which allele slots are present.
-    uint32_t pmask = 0;
+    uint32_t* pres = s_pres[wave];
+    if (lane < 8) pres[lane] = 0;
+    wave_sync();
     bool nonref = false, bad = false;
     for (uint32_t p = lane; p < H; p += 64) {
         const uint16_t a = dc.path_allele[(size_t)v * H + p];
-        int s = -1;
-        for (uint32_t q = 0; q < A; ++q)
-            if (dc.allele_id[a0 + q] == a) s = (int)q;
+        const int s = slot_of(dc, a0, A, a);
         if (s < 0) bad = true;
         else {
-            pmask |= 1u << s;
+            atomicOr(&pres[(uint32_t)s >> 5], 1u << ((uint32_t)s & 31u));
             if (a != 0 && !(dc.allele_flags[a0 + s] & 1)) nonref = true;
         }
     }
-    pmask = wave_or_u32(pmask);
+    wave_sync();
     const bool kept = __any(nonref) != 0;
     if (__any(bad) != 0) {
         if (lane == 0) { atomicOr(dc.err, PG_DEVERR_ALLELE_NOT_FOUND); dc.kept[v] = 0; }
         return;
     }
-    const uint32_t n_local = __popc(pmask);
-    if (lane < A) dc.allele_present[a0 + lane] = (pmask >> lane) & 1u;
+    uint32_t n_local = 0;
+#pragma unroll
+    for (int q = 0; q < 8; ++q) n_local += __popc(pres[q]);
+    for (uint32_t q = lane; q < A; q += 64) dc.allele_present[a0 + q] = slot_present(pres, q) ? 1 : 0;
     if (lane == 0) dc.kept[v] = kept ? 1 : 0;
     if (!kept) return;
-    // more than PG_AMAX alleles on the selected paths: a WIDE column, its table goes to the side
-    // buffer (chunked sweep mode only; pg_shim.cpp allocates an entry for every variant that could
+    // more than PG_AMAX alleles on the selected paths: a WIDE column, its tables go to the side
+    // buffer (chunked sweep mode only; pg_shim.cpp reserves an entry for every variant that could
     // be wide and forces that mode)
     const bool wide = n_local > PG_AMAX;
-    const uint32_t widx = wide && dc.wide_idx ? dc.wide_idx[v] : PG_WIDE_NONE;
-    if (wide && (widx == PG_WIDE_NONE || n_local > PG_WIDE_MAX)) {
+    const uint32_t woff = wide && dc.wide_idx ? dc.wide_idx[v] : PG_WIDE_NONE;
+    if (wide && (woff == PG_WIDE_NONE || n_local > PG_WIDE_MAX)) {
         if (lane == 0) atomicOr(dc.err, PG_DEVERR_TOO_MANY_LOCAL);
         return;
     }
 
     unsigned char* rec = dc.vrec + (size_t)v * dc.RB;
     // local (dense) allele index of every selected path; phantom paths of the padding get 255
-    for (uint32_t p0 = 0; p0 < 128; p0 += 64) {
+    const uint32_t pspan = HP < 128u ? 128u : HP;
+    for (uint32_t p0 = 0; p0 < pspan; p0 += 64) {
         const uint32_t p = p0 + lane;
         unsigned char val = PG_PHANTOM;
         if (p < H) {
-            const uint16_t a = dc.path_allele[(size_t)v * H + p];
-            uint32_t s = 0;
-            for (uint32_t q = 0; q < A; ++q)
-                if (dc.allele_id[a0 + q] == a) s = q;
-            val = (unsigned char)__popc(pmask & ((1u << s) - 1u));
+            const int s = slot_of(dc, a0, A, dc.path_allele[(size_t)v * H + p]);
+            val = (unsigned char)local_index(pres, (uint32_t)s);
         }
         if (p < HP) rec[PG_REC_ALLELES + p] = val;
         const unsigned long long b1 = __ballot(val == 1);
-        if (lane == 0) ((unsigned long long*)(rec + PG_REC_BITS1))[p0 >> 6] = b1;
+        if (lane == 0 && p0 < 128u) ((unsigned long long*)(rec + PG_REC_BITS1))[p0 >> 6] = b1;
     }
 
     // ---- emission products over ALL allele pairs of the object (a1<=a2; table is symmetric),
@@ -326,11 +346,16 @@ __global__ __launch_bounds__(256) void k_prep(const DevContig* __restrict__ cont
     const uint32_t P = A * (A + 1) / 2;
     if (wide) {
         // two passes over the pairs: (1) all_zeros and the largest exponent X among the present pairs,
-        // (2) the products again, scaled by 2^-X, straight into the wide entry (rare columns: the
-        // recomputation is cheaper than staging up to 528 (mantissa, exponent) pairs)
-        double* Ew = (double*)(dc.wide + (size_t)widx * PG_WIDE_ENTRY_BYTES);
-        uint16_t* slots = (uint16_t*)(dc.wide + (size_t)widx * PG_WIDE_ENTRY_BYTES + PG_WIDE_TABLE_BYTES);
-        for (uint32_t q = lane; q < PG_WIDE_STRIDE * PG_WIDE_STRIDE; q += 64) Ew[q] = 0.0;  // incl. the phantom row/column
+        // (2) the products again, straight into the wide entry — scaled by 2^-X for the recursion and as
+        // (mantissa, exponent) for the bins (rare columns: the recomputation is cheaper than staging
+        // thousands of pairs)
+        const uint32_t S = n_local + 1u;
+        unsigned char* ent = dc.wide + (size_t)woff * 16u;
+        double* Ew = (double*)ent;
+        double* Pm = (double*)(ent + PG_WIDE_OFF_PM(S));
+        int* Pe = (int*)(ent + PG_WIDE_OFF_PE(S));
+        uint16_t* slots = (uint16_t*)(ent + PG_WIDE_OFF_SLOT(S));
+        for (uint32_t q = lane; q < S * S; q += 64) { Ew[q] = 0.0; Pm[q] = 0.0; Pe[q] = 0; }  // incl. the phantom row/column
         bool any_nz = false;
         int Xw = -(1 << 30);
         for (int pass = 0; pass < 2; ++pass) {
@@ -342,18 +367,20 @@ __global__ __launch_bounds__(256) void k_prep(const DevContig* __restrict__ cont
                 if (active) decode_pair(idx, A, s1, s2);
                 double pm; int pe;
                 emission_pair_products(dc, tab, v, lane, active, s1, s2, s_m[wave], s_e[wave], pm, pe);
-                const bool both = active && ((pmask >> s1) & 1u) && ((pmask >> s2) & 1u);
+                const bool both = active && slot_present(pres, s1) && slot_present(pres, s2);
                 if (pass == 0) {
                     any_nz = any_nz || (__any(active && pm > 0.0) != 0);
                     const int xm = wave_max_i32((both && pm > 0.0) ? pe : -(1 << 30));
                     Xw = xm > Xw ? xm : Xw;
                 } else if (both) {
-                    const uint32_t la = __popc(pmask & ((1u << s1) - 1u)), lb = __popc(pmask & ((1u << s2) - 1u));
-                    double val;
-                    if (!any_nz) val = 1.0;                             // all_zeros: emissionprobabilitycomputer.cpp:31-34
+                    const uint32_t la = local_index(pres, s1), lb = local_index(pres, s2);
+                    double val, mv = pm;
+                    int ev = pe;
+                    if (!any_nz) { val = 1.0; mv = 0.5; ev = 1; }       // all_zeros: emissionprobabilitycomputer.cpp:31-34
                     else val = (pm > 0.0) ? ldexp(pm, pe - Xw) : pm;
-                    Ew[la * PG_WIDE_STRIDE + lb] = val;
-                    Ew[lb * PG_WIDE_STRIDE + la] = val;
+                    Ew[la * S + lb] = val; Ew[lb * S + la] = val;
+                    Pm[la * S + lb] = mv; Pm[lb * S + la] = mv;
+                    Pe[la * S + lb] = ev; Pe[lb * S + la] = ev;
                 }
             }
         }
@@ -365,17 +392,15 @@ __global__ __launch_bounds__(256) void k_prep(const DevContig* __restrict__ cont
             rec[PG_REC_NLOCAL] = (unsigned char)n_local;
             rec[PG_REC_FLAGS] = (unsigned char)((any_nz ? 0 : PG_REC_FLAG_ALLZERO) | PG_REC_FLAG_WIDE);
             rec[PG_REC_FLAGS + 1] = 0; rec[PG_REC_FLAGS + 2] = 0;
-            *(uint32_t*)(rec + PG_REC_WIDE_IDX) = widx;
+            *(uint32_t*)(rec + PG_REC_WIDE_IDX) = woff;
             uint16_t* ls = (uint16_t*)(rec + PG_REC_LOCAL_SLOT);
             for (uint32_t l = 0; l < 8; ++l) ls[l] = 0;
             uint32_t l = 0;
             for (uint32_t sl = 0; sl < A; ++sl)
-                if ((pmask >> sl) & 1u) slots[l++] = (uint16_t)sl;
-            for (; l < PG_WIDE_MAX; ++l) slots[l] = 0;
+                if (slot_present(pres, sl)) slots[l++] = (uint16_t)sl;
         }
         return;
     }
-    constexpr int NLP = PG_AMAX * (PG_AMAX + 1) / 2;  // local pairs
     if (lane < (uint32_t)NLP) { s_pm[wave][lane] = 0.0; s_pe[wave][lane] = 0; }
     wave_sync();
     bool any_nonzero = false;
@@ -387,8 +412,8 @@ __global__ __launch_bounds__(256) void k_prep(const DevContig* __restrict__ cont
         double pm; int pe;
         emission_pair_products(dc, tab, v, lane, active, s1, s2, s_m[wave], s_e[wave], pm, pe);
         any_nonzero = any_nonzero || (__any(active && pm > 0.0) != 0);
-        if (active && ((pmask >> s1) & 1u) && ((pmask >> s2) & 1u)) {
-            const uint32_t la = __popc(pmask & ((1u << s1) - 1u)), lb = __popc(pmask & ((1u << s2) - 1u));
+        if (active && slot_present(pres, s1) && slot_present(pres, s2)) {
+            const uint32_t la = local_index(pres, s1), lb = local_index(pres, s2);
             s_pm[wave][tri_local(la, lb)] = pm;  // s1 <= s2  =>  la <= lb
             s_pe[wave][tri_local(la, lb)] = pe;
         }
@@ -417,6 +442,12 @@ __global__ __launch_bounds__(256) void k_prep(const DevContig* __restrict__ cont
         else val = (pm > 0.0) ? ldexp(pm, pe - X) : pm;     // 0 (or NaN) stays
         s_E[wave][la * PG_ESTRIDE + lb] = val;
         s_E[wave][lb * PG_ESTRIDE + la] = val;
+        // the unscaled product as (mantissa, exponent): what a finished posterior bin is multiplied with
+        const uint32_t pn = dc.pair_n, NP = (pn * (pn + 1) / 2 + 1u) & ~1u;
+        unsigned char* vp = dc.vpair + (size_t)v * (NP * 12u);
+        const uint32_t pi = tri_n(la, lb, pn);  // la <= lb < n_local <= pair_n
+        ((double*)vp)[pi] = all_zeros ? 0.5 : pm;
+        ((int*)(vp + (size_t)NP * 8u))[pi] = all_zeros ? 1 : pe;
     }
     wave_sync();
     if (lane < PG_ETAB) ((double*)(rec + PG_REC_E))[lane] = s_E[wave][lane];
@@ -430,8 +461,8 @@ __global__ __launch_bounds__(256) void k_prep(const DevContig* __restrict__ cont
         *(uint32_t*)(rec + PG_REC_WIDE_IDX) = PG_WIDE_NONE;
         uint16_t* ls = (uint16_t*)(rec + PG_REC_LOCAL_SLOT);
         uint32_t l = 0;
-        for (uint32_t s = 0; s < A; ++s)
-            if ((pmask >> s) & 1u) ls[l++] = (uint16_t)s;
+        for (uint32_t s = 0; s < A && l < 8; ++s)
+            if (slot_present(pres, s)) ls[l++] = (uint16_t)s;
         for (; l < 8; ++l) ls[l] = 0;
     }
 }
@@ -661,6 +692,7 @@ DEVI int exponent_of(double x) { return __builtin_amdgcn_frexp_exp(x); }
 struct EmSrc {
     const double* wide;  // nullptr: narrow
     uint32_t ajr;        // this thread's column allele, raw (PG_PHANTOM for padding paths)
+    uint32_t wn;         // wide: n_local (row/column n_local of the table is zero; row stride n_local + 1)
 };
 DEVI double emission_narrow(const unsigned char* rec, uint32_t i, const EmSrc& es) {
     const uint32_t air = rec[PG_REC_ALLELES + i];
@@ -669,8 +701,8 @@ DEVI double emission_narrow(const unsigned char* rec, uint32_t i, const EmSrc& e
 }
 DEVI double emission_wide(const unsigned char* rec, uint32_t i, const EmSrc& es) {
     const uint32_t air = rec[PG_REC_ALLELES + i];
-    const uint32_t ai = air > PG_WIDE_MAX ? PG_WIDE_MAX : air, aj = es.ajr > PG_WIDE_MAX ? PG_WIDE_MAX : es.ajr;
-    return ((gcdouble*)es.wide)[ai * PG_WIDE_STRIDE + aj];
+    const uint32_t ai = air > es.wn ? es.wn : air, aj = es.ajr > es.wn ? es.wn : es.ajr;
+    return ((gcdouble*)es.wide)[ai * (es.wn + 1u) + aj];
 }
 DEVI double emission_at(const unsigned char* rec, uint32_t i, const EmSrc& es) {
     return es.wide ? emission_wide(rec, i, es) : emission_narrow(rec, i, es);
@@ -721,9 +753,10 @@ DEVI RecInfo decode_record(const unsigned char* rec, uint32_t j, uint32_t i0, bo
     r.fe = fast_setup<UNI>(rec, j, i0);
     r.em.ajr = rec[PG_REC_ALLELES + j];
     r.em.wide = nullptr;
+    r.em.wn = r.nl;
     if (r.nl > PG_AMAX) {  // wide column (scalar branch: nl is uniform)
-        const uint32_t widx = (uint32_t)__builtin_amdgcn_readfirstlane((int)*(const uint32_t*)(rec + PG_REC_WIDE_IDX));
-        r.em.wide = (const double*)(wide_base + (size_t)widx * PG_WIDE_ENTRY_BYTES);
+        const uint32_t woff = (uint32_t)__builtin_amdgcn_readfirstlane((int)*(const uint32_t*)(rec + PG_REC_WIDE_IDX));
+        r.em.wide = (const double*)(wide_base + (size_t)woff * 16u);
     }
     r.fast = full && r.nl <= 2;
     return r;
@@ -849,10 +882,12 @@ DEVI void fetch_u(const ChainShared<HP, R>& sh, const ThreadPos& p, double urow,
     for (int k = 0; k < R; ++k) ui[k] = row[k];
 }
 
-// posterior partials of column c: acc[a] = sum over my rows with local allele a of v*beta
+// posterior partials of column c: acc[a] = sum over my rows with local allele a of pr = P' * beta'
+// (P' = forward column BEFORE its emission multiply: the emission of a bin is applied once, to the
+// finished bin, by k_bins — DESIGN.md §5)
 template <int HP, int R>
 DEVI void posterior(ChainShared<HP, R>& sh, gdouble* part_out, uint32_t part_slots, const RecInfo& ri, uint32_t c, const ThreadPos& p,
-                    const double (&v)[R], const double (&beta)[R]) {
+                    const double (&prod)[R]) {
     using Cfg = ChainCfg<HP, R>;
     if (kExp & 8u) return;
     const uint32_t nl = ri.nl;
@@ -867,7 +902,7 @@ DEVI void posterior(ChainShared<HP, R>& sh, gdouble* part_out, uint32_t part_slo
         const uint32_t rbits = Cfg::UNI ? (uint32_t)__builtin_amdgcn_readfirstlane(ri.fe.rowbits) : ri.fe.rowbits;
 #pragma unroll
         for (int k = 0; k < R; ++k) {
-            const double pr = v[k] * beta[k];
+            const double pr = prod[k];
             const bool bit = (rbits >> k) & 1u;
             acc[1] = fma(pr, bit ? 1.0 : 0.0, acc[1]);
             acc[0] = fma(pr, bit ? 0.0 : 1.0, acc[0]);
@@ -885,7 +920,7 @@ DEVI void posterior(ChainShared<HP, R>& sh, gdouble* part_out, uint32_t part_slo
             uint32_t ai;
             if constexpr (Cfg::UNI) ai = (aw[k >> 2] >> (8 * (k & 3))) & 0xFFu;
             else ai = al[p.i0 + k];
-            const double pr = v[k] * beta[k];
+            const double pr = prod[k];
 #pragma unroll
             for (int a = 0; a < PG_AMAX; ++a) acc[a] = fma(pr, ai == (uint32_t)a ? 1.0 : 0.0, acc[a]);
             if constexpr (R > 16) { if ((k & 7) == 7) __builtin_amdgcn_sched_barrier(0); }
@@ -955,10 +990,8 @@ DEVI void forward_body(const DevContig& dc, ChainShared<HP, R>& sh, uint32_t C, 
         constexpr int KSL = kRingDist - 1;  // iterations of slack a column transfer gets
         constexpr int KEEP0 = RING ? KSL * (1 + QL) : 4, KEEP1 = KSL * QL;
         static_assert(KEEP0 < 64 && KEEP1 < 64, "vmcnt is 6 bits");
-        if (lw == 0) {
-            if (lo == 0) dma_record<Cfg::RB>(colrec, 0, C, lrec, p.lane);
-            for (int q = 0; q < 6; ++q) dma_record<Cfg::RB>(colrec, (int64_t)first + q, C, lrec, p.lane);
-        }
+        if (lw == 0)  // records first-1 (column 0, or the column resumed from) .. first+5
+            for (int q = -1; q < 6; ++q) dma_record<Cfg::RB>(colrec, (int64_t)first + q, C, lrec, p.lane);
         if (RING)
             for (int q = 0; q < kRingDist; ++q) dma_column<HP, Cfg::NLOAD>(cols, (int64_t)lo + q, C, lring, p.lane, lw);
         wait_vmem_all();
@@ -1021,7 +1054,7 @@ DEVI void forward_body(const DevContig& dc, ChainShared<HP, R>& sh, uint32_t C, 
     double vA[(PHASE == 2 && !RING) ? R : 1];  // register-prefetched beta' column (phase 2 without the LDS ring)
     unsigned long long tq = 0;  // inline loader (no loader wave): next record in flight
     if (!Cfg::LOADER && p.wave == 0) {
-        if (lo == 0) rec_stage(0, rec_load(0));
+        rec_stage(first - 1, rec_load(first - 1));
         rec_stage(first, rec_load(first));
         rec_stage(first + 1, rec_load(first + 1));
         tq = rec_load(first + 2);
@@ -1034,27 +1067,40 @@ DEVI void forward_body(const DevContig& dc, ChainShared<HP, R>& sh, uint32_t C, 
     const bool prof = kChainProf && (dbg & 8u) != 0;
 
     if (lo == 0) {
-        // column 0: v_0 = e_0 (reference src/hmm.cpp:236-238, previous_cell = 1)
-        double part = 0.0;
+        // column 0: v_0 = e_0 (reference src/hmm.cpp:236-238, previous_cell = 1).  Stored: P'_0 = 2^BIAS_F
+        // (the column before its emission multiply, at the forward bias), fscale = 1.
+        const double P0 = ldexp(1.0, PG_BIAS_F);
+        double part = 0.0, pz[R];
 #pragma unroll
-        for (int k = 0; k < R; ++k) { x[k] = emission_at(sh.rec[0], p.i0 + k, prev.em); part += x[k]; }
-        if (STORE) store_col(0, x);
+        for (int k = 0; k < R; ++k) { pz[k] = P0; x[k] = emission_at(sh.rec[0], p.i0 + k, prev.em) * P0; part += x[k]; }
+        if (STORE) store_col(0, pz);
         if (p.tid == 0) fscale[0] = 1.0;
         write_colsums<HP, R>(sh, 0, p, part);
         if constexpr (PHASE == 2) {  // lo == 0 in phase 2 <=> mid == 0 <=> C == 1
             if constexpr (RING) {
                 double bt[R];
                 ring_read<HP, R>(ring, 0, p.i0, p.j, bt);
-                posterior<HP, R>(sh, part_out, part_slots, prev, 0, p, x, bt);
+#pragma unroll
+                for (int k = 0; k < R; ++k) bt[k] *= P0;
+                posterior<HP, R>(sh, part_out, part_slots, prev, 0, p, bt);
             } else {
-                posterior<HP, R>(sh, part_out, part_slots, prev, 0, p, x, vA);
+#pragma unroll
+                for (int k = 0; k < R; ++k) vA[k] *= P0;
+                posterior<HP, R>(sh, part_out, part_slots, prev, 0, p, vA);
                 load_col(1, vA);
             }
         }
     } else {
-        // resume behind the column the other phase stored last
+        // resume behind the column the other phase (or the previous chunk) stored last: P'_{lo-1}, the
+        // column before its emission multiply — or the uniform column itself if it was flagged
         load_col(lo - 1, x);
+        const bool was_uniform = fallback[lo - 1] != 0;
         double part = 0.0;
+        if (!was_uniform) {
+            const unsigned char* recp = sh.rec[(lo - 1) & 7u];
+#pragma unroll
+            for (int k = 0; k < R; ++k) x[k] *= emission_at(recp, p.i0 + k, prev.em);
+        }
 #pragma unroll
         for (int k = 0; k < R; ++k) part += x[k];
         write_colsums<HP, R>(sh, (lo - 1) & 1u, p, part);
@@ -1077,14 +1123,17 @@ DEVI void forward_body(const DevContig& dc, ChainShared<HP, R>& sh, uint32_t C, 
     };
 
     // One recursion step: column t from column t-1 (reference src/hmm.cpp:175-273).
-    //   v_t(i,j) = e_t(i,j) * (c0 x(i,j) + c1 (C_i + C_j) + c2 S),  x = stored column t-1, C/S its sums.
-    // alpha_hat_{t-1} = x / S.  Instead of dividing, the new column is scaled by 2^-es,
-    // es = exponent(S): it is (true v_t) * m with m = S * 2^-es in [0.5,1); m goes to the side
-    // array.  The power of two is folded into the emission factor, so nothing on the path from
-    // the barrier to the first multiply-add waits for the total S:
+    //   P_t(i,j) = c0 x(i,j) + c1 (C_i + C_j) + c2 S,   v_t = e_t . P_t,   x = v_{t-1} (registers), C/S its sums.
+    // alpha_hat_{t-1} = x / S.  Instead of dividing, P_t is scaled by 2^-es, es = exponent(S) - BIAS_F:
+    // P'_t = (true P_t) * m * 2^BIAS_F with m = S * 2^-exponent(S) in [0.5,1); m goes to the side array.
+    // P'_t — NOT v_t — is what gets stored: its entries are bounded below by q^2 times its sum, so the
+    // stored column has a bounded dynamic range whatever the emissions are, and the emission of a genotype
+    // bin is applied once, to the finished bin, as (mantissa, exponent) (k_bins / k_post).
+    // The power of two rides on c0, u_j and the fma that adds u_i, so nothing on the path from the barrier
+    // to the first multiply-add waits for the total S:
     //   barrier -> column sums (4 LDS reads) -> c1*C parked in LDS (round trip, gives the u_i)
-    //           || S = DPP reduction of the column sums -> u_j = c1 C_j + c2 S, es, scaled e
-    //           -> R x { add, fma, select, mul, add }  -> partial column sums to LDS -> barrier
+    //           || S = DPP reduction of the column sums -> u_j = c1 C_j + c2 S, es, scaled constants
+    //           -> R x { fma, fma, select, mul, add }  -> partial column sums to LDS -> barrier
     auto step = [&](uint32_t t, double (&vb)[(PHASE == 2 && !RING) ? R : 1]) {
         const unsigned char* rec = sh.rec[t & 7u];
         double Cj, Crow, Call;
@@ -1106,16 +1155,17 @@ DEVI void forward_body(const DevContig& dc, ChainShared<HP, R>& sh, uint32_t C, 
             urow = 0.0;  // (HP = 128 takes its u_i from urow by readlane: zero like the fetched u_i)
             c0 = 0.0;
         }
-        const int es = exponent_of(S);
-        const double m = ldexp(S, -es);
+        // P'_t = (c0 x + c1 (C_i + C_j) + c2 S) * 2^-es with es = exponent(S) - BIAS_F: the stored column, BEFORE
+        // its emission multiply, sums to (about) m * 2^BIAS_F; the power of two is folded into c0, u_j and
+        // (as an fma multiplier) the u_i, so it costs no instruction per state.  (es is bounded below so
+        // that 2^-es stays finite when S is far down the range — chains without mixing)
+        int es = exponent_of(S) - PG_BIAS_F;
+        es = es < -900 ? -900 : es;
+        const double m = ldexp(S, -es - PG_BIAS_F);
         const bool fast = cur.fast;
         FastE fe = cur.fe;
         if (Cfg::UNI) fe.rowbits = __builtin_amdgcn_readfirstlane(fe.rowbits);
-        double eA = ldexp(fe.eA, -es), eB = ldexp(fe.eB, -es);
-        const double sc = ldexp(1.0, -es);
-        // opaque to the optimiser: it would otherwise sink the ldexp behind the per-row select
-        // (R scalings per step instead of two)
-        asm volatile("" : "+v"(eA), "+v"(eB));
+        const double sc = ldexp(1.0, -es), c0s = ldexp(c0, -es), ujs = ldexp(uj, -es);
         // LDS reads that nothing on the chain waits for are issued HERE, behind the sum exchange and
         // the u round trip (LDS returns in order: issued earlier they would delay both) and ahead
         // of the arithmetic that hides them: the partner column beta'_t out of the ring (32 KB per
@@ -1126,25 +1176,38 @@ DEVI void forward_body(const DevContig& dc, ChainShared<HP, R>& sh, uint32_t C, 
         const RecInfo nxt = decode_record<Cfg::UNI>(sh.rec[(t + 1) & 7u], p.j, p.i0, full, dc.wide);
         __builtin_amdgcn_sched_barrier(0);
         double part = 0.0;
+        // one state: P' = fma(c0s, x, fma(u_i, sc, ujs)); the recursion continues with x = P' * e; the
+        // posterior (phase 2) takes P' * beta'
+        auto state = [&](int k, double uik, double e, double& pprev) __attribute__((always_inline)) {
+            const double pk = fma(c0s, x[k], fma(uik, sc, ujs));
+            x[k] = pk * e;
+            part += x[k];
+            if constexpr (PHASE == 2) {
+                if constexpr (RING) bt[k] *= pk;
+                else vb[k] *= pk;
+            }
+            if constexpr (STORE) {
+                if (k & 1) { store_pair(t, k, pprev, pk); __builtin_amdgcn_sched_barrier(0); }
+                else pprev = pk;
+            } else if constexpr (R > 16) { if ((k & 7) == 7) __builtin_amdgcn_sched_barrier(0); }
+        };
         // two straight-line loops (a per-state branch on `fast` would split the unrolled body into
         // tiny basic blocks and serialise it)
         if (fast) {
+            double pprev = 0.0;
 #pragma unroll
             for (int k = 0; k < R; ++k) {
                 double uik;
                 if constexpr (R <= 16) uik = ui[k];
                 else uik = readlane_f64(urow, __builtin_amdgcn_readfirstlane((int)((p.i0 + k) & 63u)));
-                const double e = ((fe.rowbits >> k) & 1u) ? eB : eA;
-                if (!(kExp & 16u)) x[k] = fma(c0, x[k], uik + uj) * e;
-                part += (kExp & 16u) ? ((k == 0) ? x[0] * e + uik + uj : 0.0) : x[k];
-                if constexpr (STORE) { if (k & 1) { store_pair(t, k, x[k - 1], x[k]); __builtin_amdgcn_sched_barrier(0); } }
-                else if constexpr (R > 16) { if ((k & 7) == 7) __builtin_amdgcn_sched_barrier(0); }
+                state(k, uik, ((fe.rowbits >> k) & 1u) ? fe.eB : fe.eA, pprev);
             }
         } else {
             // (R > 16: the wide lookups get their own loop — a per-state choice drags their live ranges
             // through the 32-row loop and spills; R <= 16 measured faster with the choice per state)
             auto general_loop = [&](auto kind_c) {
                 constexpr int KIND = decltype(kind_c)::value;  // 0 narrow, 1 wide, 2 per state
+                double pprev = 0.0;
 #pragma unroll
                 for (int k = 0; k < R; ++k) {
                     double uik;
@@ -1152,10 +1215,7 @@ DEVI void forward_body(const DevContig& dc, ChainShared<HP, R>& sh, uint32_t C, 
                     else uik = readlane_f64(urow, __builtin_amdgcn_readfirstlane((int)((p.i0 + k) & 63u)));
                     const double e = KIND == 0 ? emission_narrow(rec, p.i0 + k, cur.em)
                                    : KIND == 1 ? emission_wide(rec, p.i0 + k, cur.em) : emission_at(rec, p.i0 + k, cur.em);
-                    x[k] = fma(c0, x[k], uik + uj) * (e * sc);
-                    part += x[k];
-                    if constexpr (STORE) { if (k & 1) { store_pair(t, k, x[k - 1], x[k]); __builtin_amdgcn_sched_barrier(0); } }
-                    else if constexpr (R > 16) { if ((k & 7) == 7) __builtin_amdgcn_sched_barrier(0); }
+                    state(k, uik, e, pprev);
                 }
             };
             if constexpr (R <= 16) general_loop(std::integral_constant<int, 2>{});
@@ -1168,11 +1228,11 @@ DEVI void forward_body(const DevContig& dc, ChainShared<HP, R>& sh, uint32_t C, 
             // posterior of the column just formed (optimistic: if the column turns out to sum to
             // zero, the next step flags it and k_bins re-forms its bins from the uniform column)
             if constexpr (RING) {
-                posterior<HP, R>(sh, part_out, part_slots, cur, t, p, x, bt);
+                posterior<HP, R>(sh, part_out, part_slots, cur, t, p, bt);
             } else {
                 // register prefetch of the next beta' column: a whole step ahead of its use and
-                // AFTER the last read of x, so no vmcnt wait lands inside the recursion
-                posterior<HP, R>(sh, part_out, part_slots, cur, t, p, x, vb);
+                // AFTER the last read of the old one, so no vmcnt wait lands inside the recursion
+                posterior<HP, R>(sh, part_out, part_slots, cur, t, p, vb);
                 load_col(t + 1, vb);
             }
         }
@@ -1319,10 +1379,11 @@ DEVI void backward_body(const DevContig& dc, ChainShared<HP, R>& sh, uint32_t C,
         tq = rec_load(t0 - 2);
     }
     if constexpr (PHASE == 1) {
-        // column C-1: beta~ = 1 (reference src/hmm.cpp:356-358); sum = H^2
+        // column C-1: beta~ = 1 (reference src/hmm.cpp:356-358), stored at the backward bias: sum = H^2 2^BIAS_B
+        const double B0 = ldexp(1.0, PG_BIAS_B);
 #pragma unroll
-        for (int k = 0; k < R; ++k) y[k] = (p.j < H && p.i0 + k < H) ? 1.0 : 0.0;
-        Sy = (double)H * (double)H;
+        for (int k = 0; k < R; ++k) y[k] = (p.j < H && p.i0 + k < H) ? B0 : 0.0;
+        Sy = (double)H * (double)H * B0;
         store_col(top, y);
         if (p.tid == 0) { bscale[top] = 1.0; bsum[top] = Sy; }
     } else {
@@ -1359,8 +1420,9 @@ DEVI void backward_body(const DevContig& dc, ChainShared<HP, R>& sh, uint32_t C,
         const RecInfo nxt = decode_record<Cfg::UNI>(sh.rec[(uint32_t)t & 7u], p.j, p.i0, full, dc.wide);
         const unsigned char* rec1 = sh.rec[(uint32_t)(t + 1) & 7u];
         // beta~_t(true) = A (y/Sy . e) A^T; scaled by 2^-es: beta' = beta~ * m, m = Sy*2^-es
-        const int es = exponent_of(Sy);
-        const double m = ldexp(Sy, -es);
+        int es = exponent_of(Sy) - PG_BIAS_B;  // stored backward columns carry 2^BIAS_B (see forward_body)
+        es = es < -900 ? -900 : es;
+        const double m = ldexp(Sy, -es - PG_BIAS_B);
         if (p.tid == 0) bscale[t] = m;
         const double k0 = ldexp(cur.c0, -es), k1 = ldexp(cur.c1, -es), k2 = ldexp(cur.c2, -es);
         const double kap = ldexp(cur.kappa, -es);
@@ -1434,9 +1496,13 @@ DEVI void backward_body(const DevContig& dc, ChainShared<HP, R>& sh, uint32_t C,
             if (p.tid == 0) bsum[t] = Sy;
         } else {
             if constexpr (RING) {
-                posterior<HP, R>(sh, part_out, part_slots, nxt, (uint32_t)t, p, vt, y);
+#pragma unroll
+                for (int k = 0; k < R; ++k) vt[k] *= y[k];
+                posterior<HP, R>(sh, part_out, part_slots, nxt, (uint32_t)t, p, vt);
             } else {
-                posterior<HP, R>(sh, part_out, part_slots, nxt, (uint32_t)t, p, v, y);
+#pragma unroll
+                for (int k = 0; k < R; ++k) v[k] *= y[k];
+                posterior<HP, R>(sh, part_out, part_slots, nxt, (uint32_t)t, p, v);
                 load_col(t - VBUF, v);
             }
         }
@@ -1477,8 +1543,9 @@ DEVI void backward_body(const DevContig& dc, ChainShared<HP, R>& sh, uint32_t C,
         for (int64_t t = t0; t >= bot; --t) {
             // scale of this column: 2^-es, es = exponent of the previous column's sum (known
             // analytically through kappa, so all of this sits in front of the barrier)
-            const int es = exponent_of(Sy);
-            const double m = ldexp(Sy, -es);
+            int es = exponent_of(Sy) - PG_BIAS_B;  // stored backward columns carry 2^BIAS_B
+            es = es < -900 ? -900 : es;
+            const double m = ldexp(Sy, -es - PG_BIAS_B);
             if (Cfg::NW == 1 || p.tid == 0) bscale[t] = m;
             const double k0 = ldexp(cur.c0, -es), k1 = ldexp(cur.c1, -es), k2 = ldexp(cur.c2, -es);
             const double kap = ldexp(cur.kappa, -es);
@@ -1529,7 +1596,11 @@ DEVI void backward_body(const DevContig& dc, ChainShared<HP, R>& sh, uint32_t C,
             }
             write_colsums<HP, R>(sh, (uint32_t)(t - 1) & 1u, p, part);
             if constexpr (STORE) { if (Cfg::NW == 1 || p.tid == 0) bsum[t] = Snew; }
-            else posterior<HP, R>(sh, part_out, part_slots, nxt, (uint32_t)t, p, vt, y);
+            else {
+#pragma unroll
+                for (int k = 0; k < R; ++k) vt[k] *= y[k];  // P'_t * beta'_t
+                posterior<HP, R>(sh, part_out, part_slots, nxt, (uint32_t)t, p, vt);
+            }
             Sy = Snew > 0.0 ? Snew : 1.0;
             cur = nxt;
         }
@@ -1566,10 +1637,329 @@ __global__ __launch_bounds__((ChainCfg<HP, R>::TT)) void k_sweep(const DevContig
 }
 
 // ------------------------------------------------------------------------------------------
+//  k_sweep_generic : the same half-chains for any HP = 64 .. 1024 (power of two), store-only phases
+//  (1 and 3; the posteriors come from k_post).  Used for HP >= 256 — more states per column than a
+//  workgroup's registers hold (reference README.md:260 allows up to 65534 paths; its own integration
+//  fixture runs 215 in one subset, tests/CommandsTest.cpp:31) — and on request (PG_SWEEP_KERNEL=generic)
+//  for HP = 64 / 128 as an independently written cross-check of the register-resident kernels.
+//
+//  1024 threads; thread -> column j = tid % HP and the row pairs ip = g + NG n (g = tid / HP, NG = 1024 / HP):
+//  the same elements every column, so the column after its emission multiply (x forward, w backward)
+//  lives in an element-private global scratch (xbuf: each thread re-reads only what it wrote itself).
+//  Per column: partial column sums -> LDS -> barrier -> column sums -> LDS -> barrier -> total (every
+//  wave, fixed order: deterministic) -> one pass over the thread's elements.  Same stored columns, side
+//  arrays, fall-back rules and resume conventions as forward_body / backward_body.
+// ------------------------------------------------------------------------------------------
+#define PG_GEN_THREADS 1024
+#define PG_GEN_RB (PG_REC_ALLELES + PG_MAX_PATHS + 64)
+struct GenShared {
+    unsigned char rec[2][PG_GEN_RB] __attribute__((aligned(16)));
+    double psum[PG_GEN_THREADS];
+    double colsum[PG_MAX_PATHS];
+};
+struct GenPos {
+    uint32_t tid, lane, j, g, HP, NG, N, H;
+};
+DEVI void gen_stage_record(GenShared& sh, const DevContig& dc, int64_t c, uint32_t C, uint32_t tid) {
+    if (c < 0 || c >= (int64_t)C) return;
+    const uint32_t words = dc.RB / 8u;
+    if (tid < words) ((unsigned long long*)sh.rec[(uint32_t)c & 1u])[tid] = ((const unsigned long long*)(dc.colrec + (size_t)c * dc.RB))[tid];
+}
+struct GenRec {
+    double c0, c1, c2, kappa;
+    const unsigned char* al;
+    const double* E;      // narrow table (LDS)
+    const double* wide;   // wide table (global) or nullptr
+    uint32_t wn;
+};
+DEVI GenRec gen_decode(const GenShared& sh, const DevContig& dc, uint32_t c) {
+    const unsigned char* rec = sh.rec[c & 1u];
+    GenRec r;
+    r.c0 = *(const double*)(rec + PG_REC_C0); r.c1 = *(const double*)(rec + PG_REC_C1);
+    r.c2 = *(const double*)(rec + PG_REC_C2); r.kappa = *(const double*)(rec + PG_REC_KAPPA);
+    r.al = rec + PG_REC_ALLELES;
+    r.E = (const double*)(rec + PG_REC_E);
+    r.wn = rec[PG_REC_NLOCAL];
+    r.wide = nullptr;
+    if (r.wn > PG_AMAX) r.wide = (const double*)(dc.wide + (size_t)(*(const uint32_t*)(rec + PG_REC_WIDE_IDX)) * 16u);
+    return r;
+}
+DEVI double gen_emission(const GenRec& r, uint32_t i, uint32_t j) {
+    const uint32_t air = r.al[i], ajr = r.al[j];
+    if (r.wide) {
+        const uint32_t ai = air > r.wn ? r.wn : air, aj = ajr > r.wn ? r.wn : ajr;
+        return r.wide[ai * (r.wn + 1u) + aj];
+    }
+    const uint32_t ai = air > PG_AMAX ? PG_AMAX : air, aj = ajr > PG_AMAX ? PG_AMAX : ajr;
+    return r.E[ai * PG_ESTRIDE + aj];
+}
+// column sums from the per-thread partials (call between two barriers); returns this thread's C_j
+DEVI double gen_colsums(GenShared& sh, const GenPos& p) {
+    double cj = 0.0;
+    for (uint32_t g = 0; g < p.NG; ++g) cj += sh.psum[g * p.HP + p.j];
+    if (p.g == 0) sh.colsum[p.j] = cj;
+    return cj;
+}
+DEVI double gen_total(const GenShared& sh, const GenPos& p) {  // after the barrier behind gen_colsums
+    double t = 0.0;
+    for (uint32_t k = p.lane; k < p.HP; k += 64) t += sh.colsum[k];
+    return wave_sum(t);
+}
+
+template <int PHASE>
+DEVI void gen_forward(const DevContig& dc, GenShared& sh, uint32_t C, uint32_t chunk, const GenPos& p) {
+    const uint32_t mid = C / 2, K = dc.chunk_cols, HP = p.HP, H = p.H;
+    uint32_t lo = PHASE == 1 ? 0u : mid, hi = PHASE == 1 ? mid : C;
+    if constexpr (PHASE == 3) {
+        const unsigned long long l = (unsigned long long)mid + (unsigned long long)chunk * K;
+        if (l >= C) return;
+        lo = (uint32_t)l;
+        hi = C - lo > K ? lo + K : C;
+    }
+    if (lo >= hi) return;
+    const uint32_t first = lo == 0 ? 1u : lo;
+    const size_t colsz = (size_t)HP * HP;
+    const double unif = 1.0 / ((double)H * (double)H);
+    double* fwd = dc.fwd;
+    double* wr = fwd;
+    const double* resume = fwd + (size_t)(lo > 0 ? lo - 1 : 0) * colsz;
+    if constexpr (PHASE == 3) {
+        wr = dc.scratch + (size_t)((chunk & 1u) * 2u) * K * colsz - (size_t)lo * colsz;
+        if (chunk > 0) resume = dc.scratch + ((size_t)(((chunk - 1u) & 1u) * 2u) * K + (K - 1u)) * colsz;
+    }
+    v2f64* xb = (v2f64*)dc.xbuf;  // forward role: first half of xbuf
+    auto real = [&](uint32_t i) { return (i < H && p.j < H); };
+
+    gen_stage_record(sh, dc, (int64_t)first - 1, C, p.tid);
+    gen_stage_record(sh, dc, (int64_t)first, C, p.tid);
+    __syncthreads();
+    {
+        const GenRec r0 = gen_decode(sh, dc, first - 1);
+        double part = 0.0;
+        if (lo == 0) {
+            const double P0 = ldexp(1.0, PG_BIAS_F);
+            v2f64* dst = (v2f64*)wr;
+            for (uint32_t n = 0; n < p.N; ++n) {
+                const uint32_t ip = p.g + p.NG * n;
+                const size_t e = (size_t)ip * HP + p.j;
+                dst[e] = v2f64{P0, P0};
+                const v2f64 xv = {gen_emission(r0, 2 * ip, p.j) * P0, gen_emission(r0, 2 * ip + 1, p.j) * P0};
+                xb[e] = xv;
+                part += xv.x + xv.y;
+            }
+            if (p.tid == 0) dc.fscale[0] = 1.0;
+        } else {
+            const bool was_uniform = dc.fwd_fallback[lo - 1] != 0;
+            const v2f64* src = (const v2f64*)resume;
+            for (uint32_t n = 0; n < p.N; ++n) {
+                const uint32_t ip = p.g + p.NG * n;
+                const size_t e = (size_t)ip * HP + p.j;
+                v2f64 xv = src[e];
+                if (!was_uniform) { xv.x *= gen_emission(r0, 2 * ip, p.j); xv.y *= gen_emission(r0, 2 * ip + 1, p.j); }
+                xb[e] = xv;
+                part += xv.x + xv.y;
+            }
+        }
+        sh.psum[p.tid] = part;
+    }
+    auto flag_uniform = [&](uint32_t cprev) {
+        if (cprev >= lo) {
+            v2f64* dst = (v2f64*)(wr + (size_t)cprev * colsz);
+            for (uint32_t n = 0; n < p.N; ++n) {
+                const uint32_t ip = p.g + p.NG * n;
+                dst[(size_t)ip * HP + p.j] = v2f64{real(2 * ip) ? unif : 0.0, real(2 * ip + 1) ? unif : 0.0};
+            }
+        }
+        if (p.tid == 0) dc.fwd_fallback[cprev] = 1;
+    };
+    for (uint32_t t = first; t < hi; ++t) {
+        __syncthreads();  // partial sums of column t-1, record t staged
+        double Cj = gen_colsums(sh, p);
+        gen_stage_record(sh, dc, (int64_t)t + 1, C, p.tid);
+        __syncthreads();
+        double S = gen_total(sh, p);
+        const GenRec r = gen_decode(sh, dc, t);
+        const bool fbk = !(S > 0.0);
+        const double Cu = (double)H * unif;
+        if (fbk) { flag_uniform(t - 1); S = 1.0; Cj = p.j < H ? Cu : 0.0; }
+        int es = exponent_of(S) - PG_BIAS_F;
+        es = es < -900 ? -900 : es;
+        const double m = ldexp(S, -es - PG_BIAS_F);
+        const double sc = ldexp(1.0, -es), c0s = ldexp(r.c0, -es), ujs = ldexp(fma(r.c2, S, r.c1 * Cj), -es);
+        v2f64* dst = (v2f64*)(wr + (size_t)t * colsz);
+        double part = 0.0;
+        for (uint32_t n = 0; n < p.N; ++n) {
+            const uint32_t ip = p.g + p.NG * n, i0 = 2 * ip, i1 = 2 * ip + 1;
+            const size_t e = (size_t)ip * HP + p.j;
+            v2f64 xv;
+            double u0, u1;
+            if (fbk) {
+                xv = v2f64{real(i0) ? unif : 0.0, real(i1) ? unif : 0.0};
+                u0 = i0 < H ? r.c1 * Cu : 0.0; u1 = i1 < H ? r.c1 * Cu : 0.0;
+            } else {
+                xv = xb[e];
+                u0 = r.c1 * sh.colsum[i0]; u1 = r.c1 * sh.colsum[i1];
+            }
+            const double p0 = fma(c0s, xv.x, fma(u0, sc, ujs)), p1 = fma(c0s, xv.y, fma(u1, sc, ujs));
+            dst[e] = v2f64{p0, p1};
+            xv.x = p0 * gen_emission(r, i0, p.j);
+            xv.y = p1 * gen_emission(r, i1, p.j);
+            xb[e] = xv;
+            part += xv.x + xv.y;
+        }
+        if (p.tid == 0) dc.fscale[t] = m;
+        __syncthreads();  // every thread is done with colsum / psum of the previous column
+        sh.psum[p.tid] = part;
+    }
+    __syncthreads();
+    gen_colsums(sh, p);
+    __syncthreads();
+    if (!(gen_total(sh, p) > 0.0)) flag_uniform(hi - 1);  // the last column of this phase may itself have summed to zero
+}
+
+template <int PHASE>
+DEVI void gen_backward(const DevContig& dc, GenShared& sh, uint32_t C, uint32_t chunk, const GenPos& p) {
+    const int64_t mid = C / 2, K = dc.chunk_cols;
+    const uint32_t HP = p.HP, H = p.H;
+    int64_t top = PHASE == 1 ? (int64_t)C - 1 : mid - 1;
+    int64_t bot = PHASE == 1 ? mid : 0;
+    if constexpr (PHASE == 3) {
+        top = mid - 1 - (int64_t)chunk * K;
+        if (top < 0) return;
+        bot = top - K + 1 > 0 ? top - K + 1 : 0;
+    }
+    if (top < bot) return;
+    const int64_t t0 = PHASE == 1 ? top - 1 : top;
+    const size_t colsz = (size_t)HP * HP;
+    const double unif = 1.0 / ((double)H * (double)H);
+    double* cols = dc.fwd;
+    double* wr = cols;
+    const double* resume = cols + (size_t)(top + 1 < (int64_t)C ? top + 1 : top) * colsz;
+    if constexpr (PHASE == 3) {
+        wr = dc.scratch + (size_t)((chunk & 1u) * 2u + 1u) * (size_t)K * colsz - (size_t)bot * colsz;
+        if (chunk > 0) resume = dc.scratch + (size_t)(((chunk - 1u) & 1u) * 2u + 1u) * (size_t)K * colsz;
+    }
+    v2f64* wb = (v2f64*)(dc.xbuf + colsz);  // backward role: second half of xbuf
+    auto real = [&](uint32_t i) { return (i < H && p.j < H); };
+
+    gen_stage_record(sh, dc, t0 + 1, C, p.tid);
+    gen_stage_record(sh, dc, t0, C, p.tid);
+    __syncthreads();
+    double Sy;
+    {
+        // w = beta'_{t0+1} . e_{t0+1}: the all-ones last column (phase 1) or the column stored last
+        const GenRec r1 = gen_decode(sh, dc, (uint32_t)(t0 + 1));
+        double part = 0.0;
+        if constexpr (PHASE == 1) {
+            const double B0 = ldexp(1.0, PG_BIAS_B);
+            v2f64* dst = (v2f64*)(wr + (size_t)top * colsz);
+            for (uint32_t n = 0; n < p.N; ++n) {
+                const uint32_t ip = p.g + p.NG * n;
+                const size_t e = (size_t)ip * HP + p.j;
+                const v2f64 yv = {real(2 * ip) ? B0 : 0.0, real(2 * ip + 1) ? B0 : 0.0};
+                dst[e] = yv;
+                const v2f64 wv = {yv.x * gen_emission(r1, 2 * ip, p.j), yv.y * gen_emission(r1, 2 * ip + 1, p.j)};
+                wb[e] = wv;
+                part += wv.x + wv.y;
+            }
+            Sy = (double)H * (double)H * B0;
+            if (p.tid == 0) { dc.bscale[top] = 1.0; dc.bsum[top] = Sy; }
+        } else {
+            Sy = dc.bsum[top + 1];
+            const bool zero = !(Sy > 0.0);  // resuming behind an all-zero column: uniform (hmm.cpp:374-380)
+            if (zero) Sy = 1.0;
+            const v2f64* src = (const v2f64*)resume;
+            for (uint32_t n = 0; n < p.N; ++n) {
+                const uint32_t ip = p.g + p.NG * n;
+                const size_t e = (size_t)ip * HP + p.j;
+                v2f64 yv = src[e];
+                if (zero) yv = v2f64{real(2 * ip) ? unif : 0.0, real(2 * ip + 1) ? unif : 0.0};
+                const v2f64 wv = {yv.x * gen_emission(r1, 2 * ip, p.j), yv.y * gen_emission(r1, 2 * ip + 1, p.j)};
+                wb[e] = wv;
+                part += wv.x + wv.y;
+            }
+        }
+        sh.psum[p.tid] = part;
+    }
+    for (int64_t t = t0; t >= bot; --t) {
+        const GenRec r1 = gen_decode(sh, dc, (uint32_t)(t + 1));  // constants of the gap t -> t+1
+        int es = exponent_of(Sy) - PG_BIAS_B;
+        es = es < -900 ? -900 : es;
+        const double m = ldexp(Sy, -es - PG_BIAS_B);
+        const double k0 = ldexp(r1.c0, -es), k1 = ldexp(r1.c1, -es), k2 = ldexp(r1.c2, -es), kap = ldexp(r1.kappa, -es);
+        __syncthreads();  // partial sums of w, record t staged, constants of record t+1 read by everyone
+        const double Cj = gen_colsums(sh, p);
+        gen_stage_record(sh, dc, t - 1, C, p.tid);  // into the buffer of record t+1
+        __syncthreads();
+        const double Sw = gen_total(sh, p);
+        const GenRec r0 = gen_decode(sh, dc, (uint32_t)t);
+        const double uj = fma(k2, Sw, k1 * Cj);
+        const double Snew = kap * Sw;
+        const bool zero = !(Snew > 0.0);
+        v2f64* dst = (v2f64*)(wr + (size_t)t * colsz);
+        double part = 0.0;
+        for (uint32_t n = 0; n < p.N; ++n) {
+            const uint32_t ip = p.g + p.NG * n, i0 = 2 * ip, i1 = 2 * ip + 1;
+            const size_t e = (size_t)ip * HP + p.j;
+            v2f64 yv, wv;
+            if (zero) {
+                // beta~_t is all zero: its own posteriors are 0, the next step starts from the uniform column
+                yv = v2f64{0.0, 0.0};
+                wv = v2f64{real(i0) ? unif : 0.0, real(i1) ? unif : 0.0};
+            } else {
+                const v2f64 wo = wb[e];
+                yv.x = fma(k0, wo.x, k1 * sh.colsum[i0] + uj);
+                yv.y = fma(k0, wo.y, k1 * sh.colsum[i1] + uj);
+                wv = yv;
+            }
+            dst[e] = yv;
+            wv.x *= gen_emission(r0, i0, p.j);
+            wv.y *= gen_emission(r0, i1, p.j);
+            wb[e] = wv;
+            part += wv.x + wv.y;
+        }
+        if (p.tid == 0) { dc.bscale[t] = m; dc.bsum[t] = Snew; }
+        Sy = zero ? 1.0 : Snew;
+        __syncthreads();
+        sh.psum[p.tid] = part;
+    }
+}
+
+template <int PHASE>
+__global__ __launch_bounds__(PG_GEN_THREADS) void k_sweep_generic(const DevContig* __restrict__ contigs, uint32_t chunk, uint32_t min_hp) {
+    __shared__ GenShared sh;
+    const DevContig& dc = contigs[blockIdx.x];
+    if (dc.HP < min_hp || dc.HP < 64u) return;
+    const uint32_t C = (uint32_t)__builtin_amdgcn_readfirstlane((int)*dc.n_cols);
+    if (C == 0) return;
+    GenPos p;
+    p.tid = threadIdx.x; p.lane = p.tid & 63u; p.HP = dc.HP; p.H = dc.H;
+    p.j = p.tid % p.HP; p.g = p.tid / p.HP; p.NG = PG_GEN_THREADS / p.HP; p.N = p.HP / (2u * p.NG);
+    if (blockIdx.y == 0) gen_forward<PHASE>(dc, sh, C, chunk, p);
+    else gen_backward<PHASE>(dc, sh, C, chunk, p);
+}
+
+// ------------------------------------------------------------------------------------------
 //  k_bins : posterior partials -> genotype bins (one wave per column)
 //  L_v({a,b}) = sum over states (i,j) with alleles {a,b} of alpha_hat * beta~ * fsum
 //  (reference src/hmm.cpp:364-368); exponent = X_c + X_{c+1}.
 // ------------------------------------------------------------------------------------------
+
+// A finished posterior bin: sum * (pm * 2^pe) * 2^xexp  ->  mantissa in [0.5,1) (or 0) and exponent.
+// `sum` is the fp64 sum of P' * beta' over the states of the bin divided by the column scales, (pm, pe)
+// the emission product of the bin's allele pair (full range: pe is an int), xexp the exponents the
+// sweeps carried outside the columns (emission exponent of the next column, column biases).
+DEVI void store_bin(double* lik, int32_t* lik_exp, uint64_t idx, double sum, double pm, int pe, int xexp) {
+    const double val = sum * pm;
+    double mm = val;
+    int ee = 0;
+    if (val != 0.0 && val == val && !isinf(val)) {
+        mm = frexp(val, &ee);
+        ee += pe + xexp;
+    }
+    lik[idx] = mm;
+    lik_exp[idx] = ee;
+}
 
 __global__ __launch_bounds__(256) void k_bins(const DevContig* __restrict__ contigs) {
     __shared__ double s_bins[4][PG_AMAX * (PG_AMAX + 1) / 2];
@@ -1643,21 +2033,24 @@ __global__ __launch_bounds__(256) void k_bins(const DevContig* __restrict__ cont
     wave_sync();
     const uint32_t a0 = dc.allele_off[v], A = dc.allele_off[v + 1] - a0;
     const uint16_t* ls = (const uint16_t*)(rec + PG_REC_LOCAL_SLOT);
-    // stored columns are (true value) * m: alpha_hat*fsum = fwd / fscale[c] (unless the forward
-    // column fell back to uniform), beta~ = bwd / bscale[c]
+    // L_v({a,b}) = e(a,b) * sum over the bin of P'_c beta'_c / (m_f m_b) * 2^(X_{c+1} - BIAS_F - BIAS_B):
+    // stored columns are (true value) * m * 2^bias (see forward_body).  A flagged forward column is the
+    // uniform column itself: absolute value, no emission, no scale, no bias.
     const double scale = 1.0 / ((fb ? 1.0 : dc.fscale[c]) * dc.bscale[c]);
+    int xexp = -((fb ? 0 : PG_BIAS_F) + PG_BIAS_B);
+    if (c + 1 < C) xexp += *(const int32_t*)(dc.colrec + (size_t)(c + 1) * dc.RB + PG_REC_EXP);
+    const uint32_t pn = dc.pair_n, NP = (pn * (pn + 1) / 2 + 1u) & ~1u;
+    const unsigned char* vp = dc.vpair + (size_t)v * (NP * 12u);
     if (lane < nl * nl) {
         const uint32_t la = lane / nl, lb = lane % nl;
         if (la <= lb) {
             const uint32_t sa = ls[la], sb = ls[lb];
             const uint64_t idx = dc.geno_off[v] + (uint64_t)sa * A - (uint64_t)sa * (sa - 1) / 2 + (sb - sa);
-            dc.lik[idx] = s_bins[wave][tri_local(la, lb)] * scale;
+            const uint32_t pi = tri_n(la, lb, pn);
+            const double pm = fb ? 0.5 : ((const double*)vp)[pi];
+            const int pe = fb ? 1 : ((const int*)(vp + (size_t)NP * 8u))[pi];
+            store_bin(dc.lik, dc.lik_exp, idx, s_bins[wave][tri_local(la, lb)] * scale, pm, pe, xexp);
         }
-    }
-    if (lane == 0) {
-        int X = fb ? 0 : *(const int32_t*)(rec + PG_REC_EXP);
-        if (c + 1 < C) X += *(const int32_t*)(dc.colrec + (size_t)(c + 1) * dc.RB + PG_REC_EXP);
-        dc.lik_exp[v] = X;
     }
 }
 
@@ -1716,18 +2109,22 @@ __global__ __launch_bounds__(64 * PG_POST_WAVES) void k_post(const DevContig* __
     const v2f64* B2 = (const v2f64*)B;
     const uint32_t npass = HP > 64 ? HP / 64 : 1;
     const uint32_t a0v = dc.allele_off[v], Av = dc.allele_off[v + 1] - a0v;
-    // stored columns are (true value) * m (see k_bins); a flagged forward column is the uniform
-    // column itself: absolute value, no emission exponent, no scale
+    // stored columns are (true value) * m * 2^bias (see k_bins); a flagged forward column is the uniform
+    // column itself: absolute value, no emission, no scale, no bias
     const bool fb = dc.fwd_fallback[c] != 0;
     const double scale = 1.0 / ((fb ? 1.0 : dc.fscale[c]) * dc.bscale[c]);
+    int xexp = -((fb ? 0 : PG_BIAS_F) + PG_BIAS_B);
+    if (c + 1 < C) xexp += *(const int32_t*)(dc.colrec + (size_t)(c + 1) * dc.RB + PG_REC_EXP);
     // Wide columns (more than PG_AMAX alleles on the selected paths) take one sweep over the two
     // columns per block of PG_AMAX row alleles and add their bins straight into lik (zeroed at the
     // start of the run; this wave is the only writer of the variant's bins).
     const bool widec = nl > PG_AMAX;
     const uint16_t* wslots = nullptr;
+    const unsigned char* went = nullptr;
+    const uint32_t WS = nl + 1u;  // row stride of a wide entry's tables
     if (widec) {
-        const uint32_t widx = *(const uint32_t*)(rec + PG_REC_WIDE_IDX);
-        wslots = (const uint16_t*)(dc.wide + (size_t)widx * PG_WIDE_ENTRY_BYTES + PG_WIDE_TABLE_BYTES);
+        went = dc.wide + (size_t)(*(const uint32_t*)(rec + PG_REC_WIDE_IDX)) * 16u;
+        wslots = (const uint16_t*)(went + PG_WIDE_OFF_SLOT(WS));
     }
     for (uint32_t abase = 0; abase < nl; abase += PG_AMAX)
     for (uint32_t ps = 0; ps < npass; ++ps) {
@@ -1752,10 +2149,9 @@ __global__ __launch_bounds__(64 * PG_POST_WAVES) void k_post(const DevContig* __
             for (int u = 0; u < UN; ++u) {
                 const uint32_t ip = ipb + u * ipstep;
                 if (ip < HP / 2) {
-                    // 2^512 first: both factors are <= 1 and their product may lie far below DBL_MIN while
-                    // still mattering relative to the variant's largest bin (the factor comes off again
-                    // through lik_exp)
-                    const double p0 = (av[u].x * 0x1p512) * bv[u].x, p1 = (av[u].y * 0x1p512) * bv[u].y;
+                    // P' * beta': both factors are bounded below relative to their column sums (>= q^2) and
+                    // carry their biases, so the products are normal fp64 numbers
+                    const double p0 = av[u].x * bv[u].x, p1 = av[u].y * bv[u].y;
                     const uint32_t a0 = (uint32_t)al[2 * ip] - abase, a1 = (uint32_t)al[2 * ip + 1] - abase;
 #pragma unroll
                     for (int a = 0; a < PG_AMAX; ++a) {
@@ -1793,7 +2189,7 @@ __global__ __launch_bounds__(64 * PG_POST_WAVES) void k_post(const DevContig* __
                             const uint32_t lo2 = ra < cb ? ra : cb, hi2 = ra < cb ? cb : ra;
                             const uint32_t sa = wslots[lo2], sb = wslots[hi2];
                             const uint64_t gi = dc.geno_off[v] + (uint64_t)sa * Av - (uint64_t)sa * (sa - 1) / 2 + (sb - sa);
-                            dc.lik[gi] += tot * scale;
+                            dc.lik[gi] += tot;  // raw sum; finished below
                         }
                     }
                 }
@@ -1801,19 +2197,38 @@ __global__ __launch_bounds__(64 * PG_POST_WAVES) void k_post(const DevContig* __
         }
     }
     wave_sync();
-    if (!widec && lane < nl * nl) {
-        const uint16_t* ls = (const uint16_t*)(rec + PG_REC_LOCAL_SLOT);
-        const uint32_t la = lane / nl, lb = lane % nl;
-        if (la <= lb) {
-            const uint32_t sa = ls[la], sb = ls[lb];
-            const uint64_t gi = dc.geno_off[v] + (uint64_t)sa * Av - (uint64_t)sa * (sa - 1) / 2 + (sb - sa);
-            dc.lik[gi] = s_bins[wave][tri_local(la, lb)] * scale;
+    if (!widec) {
+        const uint32_t pn = dc.pair_n, NP = (pn * (pn + 1) / 2 + 1u) & ~1u;
+        const unsigned char* vp = dc.vpair + (size_t)v * (NP * 12u);
+        if (lane < nl * nl) {
+            const uint16_t* ls = (const uint16_t*)(rec + PG_REC_LOCAL_SLOT);
+            const uint32_t la = lane / nl, lb = lane % nl;
+            if (la <= lb) {
+                const uint32_t sa = ls[la], sb = ls[lb];
+                const uint64_t gi = dc.geno_off[v] + (uint64_t)sa * Av - (uint64_t)sa * (sa - 1) / 2 + (sb - sa);
+                const uint32_t pi = tri_n(la, lb, pn);
+                const double pm = fb ? 0.5 : ((const double*)vp)[pi];
+                const int pe = fb ? 1 : ((const int*)(vp + (size_t)NP * 8u))[pi];
+                store_bin(dc.lik, dc.lik_exp, gi, s_bins[wave][tri_local(la, lb)] * scale, pm, pe, xexp);
+            }
         }
-    }
-    if (lane == 0) {
-        int X = fb ? 0 : *(const int32_t*)(rec + PG_REC_EXP);
-        if (c + 1 < C) X += *(const int32_t*)(dc.colrec + (size_t)(c + 1) * dc.RB + PG_REC_EXP);
-        dc.lik_exp[v] = X - 512;  // the products were formed as (alpha' * 2^512) * beta'
+    } else {
+        // wide column: the raw sums of its bins sit in lik (lane 0 added them up above); finish every
+        // local pair la <= lb, one per lane
+        __threadfence();
+        wave_sync();
+        const double* Pm = (const double*)(went + PG_WIDE_OFF_PM(WS));
+        const int* Pe = (const int*)(went + PG_WIDE_OFF_PE(WS));
+        const uint32_t npairs = nl * (nl + 1u) / 2u;
+        for (uint32_t q = lane; q < npairs; q += 64) {
+            uint32_t la, lb;
+            decode_pair(q, nl, la, lb);
+            const uint32_t sa = wslots[la], sb = wslots[lb];  // ascending with the local index
+            const uint64_t gi = dc.geno_off[v] + (uint64_t)sa * Av - (uint64_t)sa * (sa - 1) / 2 + (sb - sa);
+            const double pm = fb ? 0.5 : Pm[la * WS + lb];
+            const int pe = fb ? 1 : Pe[la * WS + lb];
+            store_bin(dc.lik, dc.lik_exp, gi, dc.lik[gi] * scale, pm, pe, xexp);
+        }
     }
 }
 
@@ -1848,6 +2263,12 @@ static void launch_sweep(const DevContig* d_contigs, uint32_t n_contigs, uint32_
     if (hp_mask & 2u) launch_one<32, 16, 1, true, PHASE>(d_contigs, n_contigs, chunk, s);
     if (hp_mask & 4u) launch_one<64, 16, 1, true, PHASE>(d_contigs, n_contigs, chunk, s);
     if (hp_mask & 8u) launch_one<128, 32, 1, false, PHASE>(d_contigs, n_contigs, chunk, s);
+    if constexpr (PHASE != 2) {
+        // bit 4: contigs with HP >= 256; bit 5: (forced) the generic kernel for every HP >= 64
+        if (hp_mask & 48u)
+            hipLaunchKernelGGL(k_sweep_generic<PHASE>, dim3(n_contigs, 2), dim3(PG_GEN_THREADS), 0, s, d_contigs, chunk,
+                               (hp_mask & 32u) ? 64u : 256u);
+    }
 }
 extern "C" {
 
@@ -1889,7 +2310,7 @@ void pgk_launch_transition_single(double d, uint32_t H, int uniform, double* out
     hipLaunchKernelGGL(k_transition_single, dim3(1), dim3(64), 0, s, d, H, uniform, out3);
 }
 uint32_t pgk_threads_for_hp(uint32_t hp) {
-    switch (hp) { case 16: return 64; case 32: return 64; case 64: return 256; case 128: return 512; default: return 0; }
+    switch (hp) { case 16: return 64; case 32: return 64; case 64: return 256; case 128: return 512; default: return hp >= 256 ? 1024 : 0; }
 }
 
 }  // extern "C"

@@ -5,6 +5,12 @@
 // ProbabilityTable, which the reference also builds on the host in long double before any
 // HMM runs (reference src/commands.cpp:846, src/probabilitytable.cpp:28-45).
 // There is NO CPU fallback: without a HIP device every entry point returns PG_ERR_DEVICE.
+//
+// A job = a set of CHAINS (one per (contig, path subset) — or per (sample, contig) in a cohort
+// job) over a set of INDEX contigs.  Index arrays (positions, alleles, k-mer masks, path ->
+// allele) are uploaded once per index contig; chains of a cohort job share them and own only
+// their read counts, coverage, intermediates and results (reference src/commands.cpp:118-138:
+// the index is sample-independent, update_readcount / set_coverage are the per-sample part).
 #include <hip/hip_runtime_api.h>
 
 #include <math.h>
@@ -13,6 +19,7 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <chrono>
 #include <mutex>
 #include <string>
 #include <vector>
@@ -54,6 +61,10 @@ void set_err(char* err, size_t errlen, const char* fmt, ...) {
 
 inline size_t align_up(size_t x, size_t a = 256) { return (x + a - 1) / a * a; }
 
+double now_s() {
+    return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
+
 }  // namespace
 
 // ---------------------------------------------------------------------------------------
@@ -63,10 +74,6 @@ struct pg_table {
     uint16_t cov_min = 0, cov_max = 0, count_max = 0;
     long double reg = 0.0L;
     std::vector<long double> p;  // [count][cov - cov_min][3], as the reference indexes it
-    uint64_t version = 1;
-    // device copies, one per device, rebuilt when `version` changes
-    struct DevCopy { int device; uint64_t version; double* mant; int32_t* expo; };
-    std::vector<DevCopy> dev;
     std::mutex mu;
 };
 
@@ -109,17 +116,17 @@ bool in_table(const pg_table* t, uint16_t cov, uint16_t count) {
     return cov >= t->cov_min && cov < t->cov_max && count < t->count_max;
 }
 
-// (mantissa, exponent) view of the dense table on `device`, layout [cov][count][3]
-int table_on_device(pg_table* t, int device, DevTable* out, char* err, size_t errlen) {
+// (mantissa, exponent) view of the dense table, layout [cov][count][3].  Every job gets its OWN device
+// copy inside its arena: a later pg_table_modify / pg_table_destroy cannot pull it away from under a
+// resident job.
+void table_snapshot(pg_table* t, std::vector<double>& m, std::vector<int32_t>& e, DevTable* meta) {
     std::lock_guard<std::mutex> lock(t->mu);
     const uint32_t ncov = t->cov_max > t->cov_min ? t->cov_max - t->cov_min : 0;
-    out->cov_min = t->cov_min; out->cov_max = t->cov_max; out->count_max = t->count_max; out->pad = 0;
-    out->reg = (double)t->reg;
-    for (auto& d : t->dev)
-        if (d.device == device && d.version == t->version) { out->mant = d.mant; out->expo = d.expo; return PG_OK; }
+    meta->cov_min = t->cov_min; meta->cov_max = t->cov_max; meta->count_max = t->count_max; meta->pad = 0;
+    meta->reg = (double)t->reg;
     const size_t n = (size_t)ncov * t->count_max * 3;
-    std::vector<double> m(n ? n : 1);
-    std::vector<int32_t> e(n ? n : 1);
+    m.assign(n ? n : 1, 0.0);
+    e.assign(n ? n : 1, 0);
     for (uint32_t c = 0; c < ncov; ++c)
         for (uint32_t k = 0; k < t->count_max; ++k)
             for (int i = 0; i < 3; ++i) {
@@ -129,17 +136,6 @@ int table_on_device(pg_table* t, int device, DevTable* out, char* err, size_t er
                 m[((size_t)c * t->count_max + k) * 3 + i] = (double)mant;
                 e[((size_t)c * t->count_max + k) * 3 + i] = ex;
             }
-    double* dm = nullptr; int32_t* de = nullptr;
-    HIP_TRY(hipMalloc((void**)&dm, m.size() * sizeof(double)));
-    HIP_TRY(hipMalloc((void**)&de, e.size() * sizeof(int32_t)));
-    HIP_TRY(hipMemcpy(dm, m.data(), m.size() * sizeof(double), hipMemcpyHostToDevice));
-    HIP_TRY(hipMemcpy(de, e.data(), e.size() * sizeof(int32_t), hipMemcpyHostToDevice));
-    bool replaced = false;
-    for (auto& d : t->dev)
-        if (d.device == device) { hipFree(d.mant); hipFree(d.expo); d = {device, t->version, dm, de}; replaced = true; }
-    if (!replaced) t->dev.push_back({device, t->version, dm, de});
-    out->mant = dm; out->expo = de;
-    return PG_OK;
 }
 
 }  // namespace
@@ -162,7 +158,6 @@ extern "C" int pg_table_modify(pg_table* t, uint16_t cov, uint16_t count, long d
     const size_t ncov = (size_t)(t->cov_max - t->cov_min);
     long double* e = &t->p[((size_t)count * ncov + (cov - t->cov_min)) * 3];
     e[0] = p0; e[1] = p1; e[2] = p2;
-    t->version++;
     return PG_OK;
 }
 extern "C" int pg_table_get(const pg_table* t, uint16_t cov, uint16_t count, long double out3[3]) {
@@ -176,13 +171,7 @@ extern "C" int pg_table_get(const pg_table* t, uint16_t cov, uint16_t count, lon
     }
     return PG_OK;
 }
-extern "C" void pg_table_destroy(pg_table* t) {
-    if (!t) return;
-    for (auto& d : t->dev) {
-        if (hipSetDevice(d.device) == hipSuccess) { hipFree(d.mant); hipFree(d.expo); }
-    }
-    delete t;
-}
+extern "C" void pg_table_destroy(pg_table* t) { delete t; }
 
 // ---------------------------------------------------------------------------------------
 //  misc
@@ -192,7 +181,7 @@ extern "C" int pg_hmm_device_count(void) {
     if (hipGetDeviceCount(&n) != hipSuccess) return 0;
     return n;
 }
-extern "C" const char* pg_hmm_version(void) { return "pangenie-hmm-mi355x 0.1 (gfx950, fp64)"; }
+extern "C" const char* pg_hmm_version(void) { return "pangenie-hmm-mi355x 0.2 (gfx950, fp64)"; }
 
 extern "C" int pg_hmm_geno_offsets(const pg_contig_batch* b, uint64_t* geno_off) {
     if (!b || !geno_off) return PG_ERR_INVALID;
@@ -210,32 +199,105 @@ extern "C" int pg_hmm_geno_offsets(const pg_contig_batch* b, uint64_t* geno_off)
 static const char* const kKernelNames[PG_N_KERNEL_CLASSES] = {"k_prep", "k_compact", "k_records",
                                                               "k_sweep_phase1", "k_sweep_phase2", "k_bins"};
 
-struct ContigHost {
-    uint32_t V = 0, H = 0, HP = 0, T = 0, RB = 0, part_slots = 1;
-    uint32_t sumK = 0, sumA = 0, n_wide = 0;
-    uint64_t n_lik = 0;
-    std::vector<uint16_t> n_kmers, coverage;
+namespace {
+
+struct IndexHost {   // one index contig
+    uint32_t V = 0, H = 0, HP = 0, T = 0, RB = 0, part_slots = 2, pair_n = 1;
+    uint32_t sumK = 0, sumA = 0;
+    uint64_t n_lik = 0, wide_bytes = 0;
+    std::vector<uint16_t> n_kmers;   // [V] K of every variant
+    std::vector<uint32_t> widx;      // [V] wide entry offset / 16 (only if wide_bytes)
+    std::vector<uint64_t> goff;      // [V+1]
+    // device
+    size_t o_pos = 0, o_koff = 0, o_aoff = 0, o_aid = 0, o_aflag = 0, o_akoff = 0, o_akmask = 0, o_pa = 0, o_goff = 0, o_widx = 0;
+};
+
+struct ChainHost {
+    uint32_t index = 0;
+    std::vector<uint16_t> coverage;  // [V] host copy (GenotypingResult::set_coverage)
+    size_t o_cov = 0, o_kcnt = 0;
+    uint64_t lik_first = 0;          // offset of this chain's bins inside the packed lik / lik_exp regions
     DevContig d;
     uint32_t n_cols_host = 0;
 };
 
+uint32_t pad_paths(uint32_t H) {
+    for (uint32_t hp = 16; hp <= PG_MAX_PATHS; hp <<= 1)
+        if (H <= hp) return hp;
+    return 0;
+}
+
+int check_batch(const pg_contig_batch* b, bool need_counts, char* err, size_t errlen) {
+    if (!b) { set_err(err, errlen, "null batch"); return PG_ERR_INVALID; }
+    const uint32_t V = b->n_variants;
+    if (V > 0) {
+        if (b->n_paths == 0) {  // reference src/columnindexer.cpp:18-22
+            set_err(err, errlen, "HMM::index_columns: column 0 is not covered by any paths.");
+            return PG_ERR_NO_PATHS;
+        }
+        if (!b->variant_pos || !b->kmer_off || !b->allele_off || !b->allele_id ||
+            !b->allele_flags || !b->allele_kmer_off || !b->allele_kmer_mask || !b->path_allele || (need_counts && !b->coverage)) {
+            set_err(err, errlen, "batch has null arrays");
+            return PG_ERR_INVALID;
+        }
+        if (b->kmer_off[0] != 0 || b->allele_off[0] != 0) { set_err(err, errlen, "offset arrays must start at 0"); return PG_ERR_INVALID; }
+        uint32_t maxA = 0;
+        for (uint32_t v = 0; v < V; ++v) {
+            if (b->kmer_off[v + 1] < b->kmer_off[v]) { set_err(err, errlen, "kmer_off is not monotonic at variant %u", v); return PG_ERR_INVALID; }
+            if (b->allele_off[v + 1] <= b->allele_off[v]) {
+                set_err(err, errlen, "variant %u has no alleles (allele_off must be strictly increasing)", v);
+                return PG_ERR_INVALID;
+            }
+            const uint32_t A = b->allele_off[v + 1] - b->allele_off[v];
+            if (A > maxA) maxA = A;
+        }
+        if (maxA > PG_MAX_ALLELES_PER_VARIANT) {
+            set_err(err, errlen, "a variant has %u alleles; the device path supports at most %d per UniqueKmers object", maxA, PG_MAX_ALLELES_PER_VARIANT);
+            return PG_ERR_UNSUPPORTED;
+        }
+        if (need_counts && b->kmer_off[V] > 0 && !b->kmer_count) { set_err(err, errlen, "kmer_count is null"); return PG_ERR_INVALID; }
+    }
+    if (b->n_paths > PG_MAX_PATHS) {
+        set_err(err, errlen, "device path supports at most %d selected paths per chain (got %u); use path subsets (-a)", PG_MAX_PATHS, b->n_paths);
+        return PG_ERR_UNSUPPORTED;
+    }
+    return PG_OK;
+}
+
+// one cached device arena per process (the one-shot call creates and destroys a job per call)
+struct ArenaCache { std::mutex mu; int device = -1; unsigned char* ptr = nullptr; size_t bytes = 0; } g_cache;
+
+}  // namespace
+
 struct pg_job {
     int device = 0;
     hipStream_t stream = nullptr;
-    std::vector<ContigHost> contigs;
+    std::vector<IndexHost> index;
+    std::vector<ChainHost> chains;
+    uint32_t n_contigs = 0, n_samples = 1;  // chains = n_samples * n_contigs (sample-major)
+    bool cohort = false;
     DevContig* d_contigs = nullptr;
     unsigned char* arena = nullptr;
     size_t arena_bytes = 0;
+    bool cache_arena = false;  // hand the arena to the process cache on destroy (one-shot call)
     // regions zeroed at the start of every run
     unsigned char* zero_base = nullptr;
     size_t zero_bytes = 0;
-    uint32_t* d_ncols = nullptr;  // [n]
-    uint32_t* d_err = nullptr;    // [n]
+    uint32_t* d_ncols = nullptr;  // [n_chains]
+    uint32_t* d_err = nullptr;    // [n_chains]
+    double* d_lik = nullptr;      // packed, chain after chain
+    int32_t* d_likexp = nullptr;
+    uint64_t n_lik_total = 0;
+    size_t o_tab_m = 0, o_tab_e = 0;
+    std::vector<double> tab_m;
+    std::vector<int32_t> tab_e;
     DevTable tab;
     uint32_t hp_mask = 0, max_v = 0;
     hipEvent_t ev[PG_N_KERNEL_CLASSES + 1];
     bool events = false;
     double ms[PG_N_KERNEL_CLASSES] = {0, 0, 0, 0, 0, 0};
+    double host_s[4] = {0, 0, 0, 0};
+    uint64_t up_bytes[2] = {0, 0};
     pg_hmm_params params;
     bool ran = false;
     // Sweep mode.  fused: phase 2 forms the posterior partials inline (k_bins reduces them) — least
@@ -250,104 +312,192 @@ struct pg_job {
     bool events2 = false;
 };
 
-namespace {
-
-uint32_t pad_paths(uint32_t H) {
-    if (H <= 16) return 16;
-    if (H <= 32) return 32;
-    if (H <= 64) return 64;
-    if (H <= 128) return 128;
-    return 0;
-}
-
-int check_batch(const pg_contig_batch* b, char* err, size_t errlen) {
-    if (!b) { set_err(err, errlen, "null batch"); return PG_ERR_INVALID; }
-    if (b->n_variants > 0) {
-        if (b->n_paths == 0) {  // reference src/columnindexer.cpp:18-22
-            set_err(err, errlen, "HMM::index_columns: column 0 is not covered by any paths.");
-            return PG_ERR_NO_PATHS;
-        }
-        if (!b->variant_pos || !b->coverage || !b->kmer_off || !b->allele_off || !b->allele_id ||
-            !b->allele_flags || !b->allele_kmer_off || !b->allele_kmer_mask || !b->path_allele) {
-            set_err(err, errlen, "batch has null arrays");
-            return PG_ERR_INVALID;
-        }
-        if (b->kmer_off[0] != 0 || b->allele_off[0] != 0) { set_err(err, errlen, "offset arrays must start at 0"); return PG_ERR_INVALID; }
-        if (b->kmer_off[b->n_variants] > 0 && !b->kmer_count) { set_err(err, errlen, "kmer_count is null"); return PG_ERR_INVALID; }
-    }
-    if (b->n_paths > 128) {
-        set_err(err, errlen, "device path supports at most 128 selected paths per chain (got %u); use path subsets (-a)", b->n_paths);
-        return PG_ERR_UNSUPPORTED;
-    }
-    return PG_OK;
-}
-
-}  // namespace
-
 extern "C" void pg_job_destroy(pg_job* job) {
     if (!job) return;
     hipSetDevice(job->device);
+    if (job->stream) hipStreamSynchronize(job->stream);
+    if (job->stream2) hipStreamSynchronize(job->stream2);
     if (job->events)
         for (auto& e : job->ev) hipEventDestroy(e);
     if (job->events2)
         for (int q = 0; q < 2; ++q) { hipEventDestroy(job->ev_sweep[q]); hipEventDestroy(job->ev_post[q]); }
-    if (job->arena) hipFree(job->arena);
+    if (job->arena) {
+        bool kept = false;
+        if (job->cache_arena) {
+            std::lock_guard<std::mutex> lock(g_cache.mu);
+            if (!g_cache.ptr) { g_cache.ptr = job->arena; g_cache.bytes = job->arena_bytes; g_cache.device = job->device; kept = true; }
+        }
+        if (!kept) hipFree(job->arena);
+    }
     if (job->stream2) hipStreamDestroy(job->stream2);
     if (job->stream) hipStreamDestroy(job->stream);
     delete job;
 }
 
-extern "C" pg_job* pg_job_create(int device, uint32_t n_contigs, const pg_contig_batch* batches,
-                                 const pg_table* table, const pg_hmm_params* params, char* err, size_t errlen) {
-    if (!batches || !table || !params || n_contigs == 0) { set_err(err, errlen, "null argument"); return nullptr; }
+extern "C" void pg_hmm_release_cache(void) {
+    std::lock_guard<std::mutex> lock(g_cache.mu);
+    if (g_cache.ptr) {
+        if (hipSetDevice(g_cache.device) == hipSuccess) hipFree(g_cache.ptr);
+        g_cache.ptr = nullptr; g_cache.bytes = 0; g_cache.device = -1;
+    }
+}
+
+namespace {
+
+struct ChainSpec { uint32_t index; const uint16_t* kmer_count; const uint16_t* coverage; };
+
+// H2D of the inputs into a planned job.  Copies are queued on the job's stream; pageable sources are
+// staged by the runtime, so every call returns when its source has been read.
+int upload_inputs(pg_job* job, const pg_contig_batch* batches, const std::vector<ChainSpec>& specs, bool with_index,
+                  char* err, size_t errlen) {
+    const double t0 = now_s();
+    unsigned char* A = job->arena;
+    hipStream_t s = job->stream;
+    uint64_t bi = 0, bs = 0;
+#define UP(off, src, bytes, acc)                                                                              \
+    do {                                                                                                      \
+        if ((bytes) > 0) {                                                                                    \
+            HIP_TRY(hipMemcpyAsync((void*)(A + (off)), (src), (bytes), hipMemcpyHostToDevice, s));            \
+            acc += (uint64_t)(bytes);                                                                         \
+        }                                                                                                     \
+    } while (0)
+    if (with_index) {
+        for (size_t i = 0; i < job->index.size(); ++i) {
+            const pg_contig_batch& b = batches[i];
+            IndexHost& x = job->index[i];
+            if (x.V == 0) continue;
+            UP(x.o_pos, b.variant_pos, (size_t)x.V * 8, bi);
+            UP(x.o_koff, b.kmer_off, ((size_t)x.V + 1) * 4, bi);
+            UP(x.o_aoff, b.allele_off, ((size_t)x.V + 1) * 4, bi);
+            UP(x.o_aid, b.allele_id, (size_t)x.sumA * 2, bi);
+            UP(x.o_aflag, b.allele_flags, (size_t)x.sumA, bi);
+            UP(x.o_akoff, b.allele_kmer_off, (size_t)x.sumA * 2, bi);
+            UP(x.o_akmask, b.allele_kmer_mask, (size_t)x.sumA * 4, bi);
+            UP(x.o_pa, b.path_allele, (size_t)x.V * x.H * 2, bi);
+            UP(x.o_goff, x.goff.data(), ((size_t)x.V + 1) * 8, bi);
+            if (x.wide_bytes) UP(x.o_widx, x.widx.data(), (size_t)x.V * 4, bi);
+        }
+        UP(job->o_tab_m, job->tab_m.data(), job->tab_m.size() * sizeof(double), bi);
+        UP(job->o_tab_e, job->tab_e.data(), job->tab_e.size() * sizeof(int32_t), bi);
+    }
+    for (size_t c = 0; c < job->chains.size(); ++c) {
+        ChainHost& ch = job->chains[c];
+        const IndexHost& x = job->index[ch.index];
+        if (x.V == 0) continue;
+        UP(ch.o_cov, specs[c].coverage, (size_t)x.V * 2, bs);
+        UP(ch.o_kcnt, specs[c].kmer_count, (size_t)x.sumK * 2, bs);
+        ch.coverage.assign(specs[c].coverage, specs[c].coverage + x.V);
+    }
+#undef UP
+    HIP_TRY(hipStreamSynchronize(s));
+    job->up_bytes[0] = bi; job->up_bytes[1] = bs;
+    job->host_s[1] = now_s() - t0;
+    return PG_OK;
+}
+
+int job_build(int device, uint32_t n_index, const pg_contig_batch* batches, const std::vector<ChainSpec>& specs,
+              uint32_t n_samples, bool cohort, const pg_table* table, const pg_hmm_params* params, bool cache_arena,
+              pg_job** out, char* err, size_t errlen) {
+    *out = nullptr;
+    if (!batches || !table || !params || n_index == 0 || specs.empty()) { set_err(err, errlen, "null argument"); return PG_ERR_INVALID; }
     if (params->run_phasing) {
         set_err(err, errlen, "run_phasing (Viterbi, reference src/hmm.cpp:112-173) is not on the device path");
-        return nullptr;
+        return PG_ERR_UNSUPPORTED;
+    }
+    for (uint32_t i = 0; i < n_index; ++i) {
+        const int rc = check_batch(&batches[i], !cohort, err, errlen);
+        if (rc != PG_OK) return rc;
+    }
+    for (const ChainSpec& sp : specs) {
+        const pg_contig_batch& b = batches[sp.index];
+        if (b.n_variants > 0 && (!sp.coverage || (b.kmer_off[b.n_variants] > 0 && !sp.kmer_count))) {
+            set_err(err, errlen, "a chain has null kmer_count / coverage arrays");
+            return PG_ERR_INVALID;
+        }
     }
     int ndev = 0;
-    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) { set_err(err, errlen, "no HIP device available (no CPU fallback)"); return nullptr; }
-    if (device < 0 || device >= ndev) { set_err(err, errlen, "bad device %d", device); return nullptr; }
-    for (uint32_t i = 0; i < n_contigs; ++i)
-        if (check_batch(&batches[i], err, errlen) != PG_OK) return nullptr;
-    if (hipSetDevice(device) != hipSuccess) { set_err(err, errlen, "hipSetDevice failed"); return nullptr; }
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) { set_err(err, errlen, "no HIP device available (no CPU fallback)"); return PG_ERR_DEVICE; }
+    if (device < 0 || device >= ndev) { set_err(err, errlen, "bad device %d", device); return PG_ERR_INVALID; }
+    if (hipSetDevice(device) != hipSuccess) { set_err(err, errlen, "hipSetDevice failed"); return PG_ERR_DEVICE; }
 
+    const uint32_t n_chains = (uint32_t)specs.size();
     pg_job* job = new pg_job();
     job->device = device;
     job->params = *params;
-    auto fail = [&](const char* what, hipError_t e) -> pg_job* {
+    job->cache_arena = cache_arena;
+    job->cohort = cohort;
+    job->n_samples = n_samples;
+    job->n_contigs = n_index;
+    auto fail = [&](int rc, const char* what, hipError_t e) -> int {
         set_err(err, errlen, "%s: %s", what, hipGetErrorString(e));
         pg_job_destroy(job);
-        return nullptr;
+        return rc;
     };
     hipError_t he;
-    if ((he = hipStreamCreate(&job->stream)) != hipSuccess) return fail("hipStreamCreate", he);
+    if ((he = hipStreamCreate(&job->stream)) != hipSuccess) return fail(PG_ERR_DEVICE, "hipStreamCreate", he);
     for (auto& e : job->ev)
-        if ((he = hipEventCreate(&e)) != hipSuccess) return fail("hipEventCreate", he);
+        if ((he = hipEventCreate(&e)) != hipSuccess) return fail(PG_ERR_DEVICE, "hipEventCreate", he);
     job->events = true;
-    if (table_on_device(const_cast<pg_table*>(table), device, &job->tab, err, errlen) != PG_OK) { pg_job_destroy(job); return nullptr; }
+    table_snapshot(const_cast<pg_table*>(table), job->tab_m, job->tab_e, &job->tab);
 
-    // ---- sweep mode ------------------------------------------------------------------
-    {
-        uint32_t max_hp = 0, max_v = 0;
-        size_t per_col = 0;  // scratch bytes per chunk column over all chains (2 buffers x 2 roles)
-        for (uint32_t i = 0; i < n_contigs; ++i) {
-            const uint32_t hp = pad_paths(batches[i].n_paths ? batches[i].n_paths : 1);
-            if (hp > max_hp) max_hp = hp;
-            if (batches[i].n_variants > max_v) max_v = batches[i].n_variants;
-            per_col += (size_t)4 * hp * hp * sizeof(double);
+    // ---- index contigs -------------------------------------------------------------------
+    job->index.resize(n_index);
+    bool wide_candidates = false, generic_needed = false;
+    uint32_t max_v = 0;
+    for (uint32_t i = 0; i < n_index; ++i) {
+        const pg_contig_batch& b = batches[i];
+        IndexHost& x = job->index[i];
+        x.V = b.n_variants; x.H = b.n_paths; x.HP = pad_paths(x.H ? x.H : 1);
+        x.T = pgk_threads_for_hp(x.HP); x.RB = pg_rec_bytes(x.HP);
+        x.sumK = x.V ? b.kmer_off[x.V] : 0; x.sumA = x.V ? b.allele_off[x.V] : 0;
+        x.goff.assign((size_t)x.V + 1, 0);
+        x.n_kmers.resize(x.V);
+        uint64_t maxA = 1, woff = 0;
+        for (uint32_t v = 0; v < x.V; ++v) {
+            const uint64_t A = b.allele_off[v + 1] - b.allele_off[v];
+            x.goff[v + 1] = x.goff[v] + A * (A + 1) / 2;
+            if (A > maxA) maxA = A;
+            x.n_kmers[v] = (uint16_t)(b.kmer_off[v + 1] - b.kmer_off[v]);
         }
-        // variants with more than PG_AMAX alleles may turn into WIDE columns, whose posteriors only
-        // k_post can form: such jobs always run chunked
-        bool wide_candidates = false;
-        for (uint32_t i = 0; i < n_contigs && !wide_candidates; ++i)
-            for (uint32_t v = 0; v < batches[i].n_variants; ++v)
-                if (batches[i].allele_off[v + 1] - batches[i].allele_off[v] > PG_AMAX) { wide_candidates = true; break; }
-        bool want = n_contigs * 2u < 128u;  // fewer workgroups than half the CUs
+        x.n_lik = x.goff[x.V];
+        x.pair_n = (uint32_t)(maxA < PG_AMAX ? maxA : PG_AMAX);
+        x.part_slots = (x.pair_n + 1u) & ~1u;  // partials are stored as allele pairs (16-byte stores)
+        if (x.part_slots < 2) x.part_slots = 2;
+        if (maxA > PG_AMAX) {
+            // variants with more than PG_AMAX alleles may turn into WIDE columns (as many distinct alleles
+            // on the selected paths): room for min(A, H) local alleles each
+            x.widx.assign(x.V, PG_WIDE_NONE);
+            for (uint32_t v = 0; v < x.V; ++v) {
+                const uint64_t A = b.allele_off[v + 1] - b.allele_off[v];
+                if (A > PG_AMAX) {
+                    uint64_t nl = A < x.H ? A : x.H;
+                    if (nl > PG_WIDE_MAX) nl = PG_WIDE_MAX;
+                    x.widx[v] = (uint32_t)(woff / 16);
+                    woff += pg_wide_entry_bytes((uint32_t)nl);
+                    if (woff / 16 >= 0xFFFFFFF0ull) { pg_job_destroy(job); set_err(err, errlen, "wide-column tables exceed 64 GB"); return PG_ERR_UNSUPPORTED; }
+                }
+            }
+            x.wide_bytes = woff;
+            wide_candidates = true;
+        }
+        if (x.HP >= 256) generic_needed = true;
+        if (x.V > max_v) max_v = x.V;
+    }
+    job->max_v = max_v;
+
+    // ---- sweep mode ------------------------------------------------------------------------
+    bool force_generic = false;
+    if (const char* k = getenv("PG_SWEEP_KERNEL")) force_generic = !strcmp(k, "generic");
+    {
+        size_t per_col = 0;  // scratch bytes per chunk column over all chains (2 buffers x 2 roles)
+        for (const ChainSpec& sp : specs) { const IndexHost& x = job->index[sp.index]; per_col += (size_t)4 * x.HP * x.HP * sizeof(double); }
+        // wide columns and HP >= 256 have their posteriors formed by k_post only: such jobs always run chunked
+        bool want = n_chains * 2u < 128u;  // fewer workgroups than half the CUs
         if (const char* m = getenv("PG_SWEEP_MODE")) {
             if (!strcmp(m, "fused")) want = false;
             else if (!strcmp(m, "chunked")) want = true;
         }
-        if (wide_candidates) want = true;
+        if (wide_candidates || generic_needed || force_generic) want = true;
         job->chunked = want && max_v > 0 && params->run_genotyping;
         if (job->chunked) {
             size_t k = 4096;
@@ -359,167 +509,239 @@ extern "C" pg_job* pg_job_create(int device, uint32_t n_contigs, const pg_contig
             if (k < 1) k = 1;
             job->chunk_cols = (uint32_t)k;
             job->n_chunks = (uint32_t)((half + k - 1) / k);
-            if ((he = hipStreamCreateWithFlags(&job->stream2, hipStreamNonBlocking)) != hipSuccess) return fail("hipStreamCreate", he);
+            if ((he = hipStreamCreateWithFlags(&job->stream2, hipStreamNonBlocking)) != hipSuccess) return fail(PG_ERR_DEVICE, "hipStreamCreate", he);
             for (int q = 0; q < 2; ++q) {
-                if ((he = hipEventCreateWithFlags(&job->ev_sweep[q], hipEventDisableTiming)) != hipSuccess) return fail("hipEventCreate", he);
-                if ((he = hipEventCreateWithFlags(&job->ev_post[q], hipEventDisableTiming)) != hipSuccess) return fail("hipEventCreate", he);
+                if ((he = hipEventCreateWithFlags(&job->ev_sweep[q], hipEventDisableTiming)) != hipSuccess) return fail(PG_ERR_DEVICE, "hipEventCreate", he);
+                if ((he = hipEventCreateWithFlags(&job->ev_post[q], hipEventDisableTiming)) != hipSuccess) return fail(PG_ERR_DEVICE, "hipEventCreate", he);
             }
             job->events2 = true;
         }
     }
 
-    // ---- plan the arena -------------------------------------------------------------
-    job->contigs.resize(n_contigs);
+    // ---- plan the arena -----------------------------------------------------------------------
+    job->chains.resize(n_chains);
     size_t off = 0;
-    auto take = [&](size_t bytes) { size_t o = off; off = align_up(off + (bytes ? bytes : 8)); return o; };
-    struct Plan { size_t scratch, wide, widx, prof, fback, fscale, bscale, bsum, pos, cov, koff, kcnt, aoff, aid, aflag, akoff, akmask, pa, goff, vrec, cvar, colrec, fwd, part, kept, apres, lik, likexp; };
-    std::vector<Plan> plan(n_contigs);
-    const size_t o_contigs = take(sizeof(DevContig) * n_contigs);
-    // zeroed-every-run block: n_cols, err, then per contig kept / allele_present / lik / lik_exp
-    const size_t zero_lo = off;
-    const size_t o_ncols = take(sizeof(uint32_t) * n_contigs);
-    const size_t o_err = take(sizeof(uint32_t) * n_contigs);
-    for (uint32_t i = 0; i < n_contigs; ++i) {
-        const pg_contig_batch& b = batches[i];
-        ContigHost& c = job->contigs[i];
-        c.V = b.n_variants; c.H = b.n_paths; c.HP = pad_paths(c.H ? c.H : 1);
-        c.T = pgk_threads_for_hp(c.HP); c.RB = pg_rec_bytes(c.HP);
-        c.sumK = c.V ? b.kmer_off[c.V] : 0; c.sumA = c.V ? b.allele_off[c.V] : 0;
-        uint64_t nl = 0, maxA = 1;
-        for (uint32_t v = 0; v < c.V; ++v) { uint64_t A = b.allele_off[v + 1] - b.allele_off[v]; nl += A * (A + 1) / 2; if (A > maxA) maxA = A; }
-        c.part_slots = (uint32_t)(maxA < PG_AMAX ? maxA : PG_AMAX);
-        c.part_slots = (c.part_slots + 1u) & ~1u;  // partials are stored as allele pairs (16-byte stores)
-        if (c.part_slots < 2) c.part_slots = 2;
-        c.n_lik = nl;
-        plan[i].kept = take(c.V);
-        plan[i].fback = take(c.V);
-        plan[i].prof = take(64 * sizeof(unsigned long long));
-        plan[i].apres = take(c.sumA);
-        plan[i].lik = take(nl * sizeof(double));
-        plan[i].likexp = take((size_t)c.V * sizeof(int32_t));
+    auto take = [&](size_t bytes, size_t al = 256) { off = align_up(off, al); size_t o = off; off += (bytes ? bytes : 8); return o; };
+    struct Plan { size_t scratch, wide, vpair, xbuf, prof, fback, fscale, bscale, bsum, vrec, cvar, colrec, fwd, part, kept, apres; };
+    std::vector<Plan> plan(n_chains);
+    const size_t o_contigs = take(sizeof(DevContig) * n_chains);
+    // zeroed-every-run block: n_cols, err, per chain kept / fallback flags / profile counters / allele_present,
+    // then the packed lik and lik_exp regions (chain after chain, no gaps: one range each for a gather)
+    const size_t zero_lo = align_up(off);
+    const size_t o_ncols = take(sizeof(uint32_t) * n_chains);
+    const size_t o_err = take(sizeof(uint32_t) * n_chains);
+    uint64_t lik_total = 0;
+    for (uint32_t c = 0; c < n_chains; ++c) {
+        ChainHost& ch = job->chains[c];
+        ch.index = specs[c].index;
+        const IndexHost& x = job->index[ch.index];
+        plan[c].kept = take(x.V);
+        plan[c].fback = take(x.V);
+        plan[c].prof = take(64 * sizeof(unsigned long long));
+        plan[c].apres = take(x.sumA);
+        ch.lik_first = lik_total;
+        lik_total += x.n_lik;
     }
+    job->n_lik_total = lik_total;
+    const size_t o_lik = take(lik_total * sizeof(double));
+    const size_t o_likexp = take(lik_total * sizeof(int32_t));
     const size_t zero_hi = off;
-    for (uint32_t i = 0; i < n_contigs; ++i) {
-        ContigHost& c = job->contigs[i];
-        Plan& p = plan[i];
-        p.pos = take((size_t)c.V * 8); p.cov = take((size_t)c.V * 2);
-        p.koff = take(((size_t)c.V + 1) * 4); p.kcnt = take((size_t)c.sumK * 2);
-        p.aoff = take(((size_t)c.V + 1) * 4); p.aid = take((size_t)c.sumA * 2);
-        p.aflag = take(c.sumA); p.akoff = take((size_t)c.sumA * 2); p.akmask = take((size_t)c.sumA * 4);
-        p.pa = take((size_t)c.V * c.H * 2);
-        p.goff = take(((size_t)c.V + 1) * 8);
-        p.vrec = take((size_t)c.V * c.RB);
-        p.cvar = take((size_t)c.V * 4);
-        p.colrec = take((size_t)c.V * c.RB);
-        p.fwd = take((size_t)c.V * c.HP * c.HP * sizeof(double));
+    job->o_tab_m = take(job->tab_m.size() * sizeof(double));
+    job->o_tab_e = take(job->tab_e.size() * sizeof(int32_t));
+    for (uint32_t i = 0; i < n_index; ++i) {
+        IndexHost& x = job->index[i];
+        x.o_pos = take((size_t)x.V * 8);
+        x.o_koff = take(((size_t)x.V + 1) * 4);
+        x.o_aoff = take(((size_t)x.V + 1) * 4); x.o_aid = take((size_t)x.sumA * 2);
+        x.o_aflag = take(x.sumA); x.o_akoff = take((size_t)x.sumA * 2); x.o_akmask = take((size_t)x.sumA * 4);
+        x.o_pa = take((size_t)x.V * x.H * 2);
+        x.o_goff = take(((size_t)x.V + 1) * 8);
+        x.o_widx = take(x.wide_bytes ? (size_t)x.V * 4 : 0);
+    }
+    for (uint32_t c = 0; c < n_chains; ++c) {
+        ChainHost& ch = job->chains[c];
+        const IndexHost& x = job->index[ch.index];
+        Plan& p = plan[c];
+        ch.o_cov = take((size_t)x.V * 2); ch.o_kcnt = take((size_t)x.sumK * 2);
+        p.vrec = take((size_t)x.V * x.RB);
+        p.cvar = take((size_t)x.V * 4);
+        p.colrec = take((size_t)x.V * x.RB);
+        p.fwd = take((size_t)x.V * x.HP * x.HP * sizeof(double));
         // fused mode: posterior partials; chunked mode: the chunk scratch instead (k_post writes lik directly)
-        p.part = take(job->chunked ? 0 : (size_t)c.V * c.part_slots * c.T * sizeof(double));
-        p.scratch = take(job->chunked ? (size_t)4 * job->chunk_cols * c.HP * c.HP * sizeof(double) : 0);
-        c.n_wide = 0;
-        for (uint32_t v = 0; v < c.V; ++v) c.n_wide += (batches[i].allele_off[v + 1] - batches[i].allele_off[v] > PG_AMAX) ? 1u : 0u;
-        p.wide = take((size_t)c.n_wide * PG_WIDE_ENTRY_BYTES);
-        p.widx = take(c.n_wide ? (size_t)c.V * sizeof(uint32_t) : 0);
-        p.fscale = take((size_t)c.V * sizeof(double));
-        p.bscale = take((size_t)c.V * sizeof(double));
-        p.bsum = take((size_t)c.V * sizeof(double));
-        job->hp_mask |= c.HP == 16 ? 1u : c.HP == 32 ? 2u : c.HP == 64 ? 4u : 8u;
-        if (c.V > job->max_v) job->max_v = c.V;
+        p.part = take(job->chunked ? 0 : (size_t)x.V * x.part_slots * x.T * sizeof(double));
+        p.scratch = take(job->chunked ? (size_t)4 * job->chunk_cols * x.HP * x.HP * sizeof(double) : 0);
+        p.wide = take(x.wide_bytes);
+        p.vpair = take((size_t)x.V * pg_pair_bytes(x.pair_n));
+        p.xbuf = take((x.HP >= 256 || (force_generic && x.HP >= 64)) ? (size_t)2 * x.HP * x.HP * sizeof(double) : 0);
+        p.fscale = take((size_t)x.V * sizeof(double));
+        p.bscale = take((size_t)x.V * sizeof(double));
+        p.bsum = take((size_t)x.V * sizeof(double));
+        if (x.HP >= 256) job->hp_mask |= 16u;
+        else if (force_generic && x.HP >= 64) job->hp_mask |= 32u;
+        else job->hp_mask |= x.HP == 16 ? 1u : x.HP == 32 ? 2u : x.HP == 64 ? 4u : 8u;
     }
-    job->arena_bytes = off;
-    if ((he = hipMalloc((void**)&job->arena, job->arena_bytes)) != hipSuccess) {
-        set_err(err, errlen, "hipMalloc(%zu bytes) failed: %s", job->arena_bytes, hipGetErrorString(he));
-        pg_job_destroy(job);
-        return nullptr;
+    if (job->hp_mask & 32u) job->hp_mask |= 16u;  // one generic launch covers both
+    job->arena_bytes = align_up(off);
+    const double t_alloc = now_s();
+    {
+        std::lock_guard<std::mutex> lock(g_cache.mu);
+        if (g_cache.ptr && g_cache.device == device && g_cache.bytes >= job->arena_bytes) {
+            job->arena = g_cache.ptr;
+            job->arena_bytes = g_cache.bytes;
+            g_cache.ptr = nullptr; g_cache.bytes = 0; g_cache.device = -1;
+        }
     }
+    if (!job->arena) {
+        he = hipMalloc((void**)&job->arena, job->arena_bytes);
+        if (he != hipSuccess) {
+            pg_hmm_release_cache();  // a cached arena may be what stands in the way
+            he = hipMalloc((void**)&job->arena, job->arena_bytes);
+        }
+        if (he != hipSuccess) {
+            job->arena = nullptr;
+            set_err(err, errlen, "hipMalloc(%zu bytes) failed: %s", job->arena_bytes, hipGetErrorString(he));
+            pg_job_destroy(job);
+            return PG_ERR_NOMEM;
+        }
+    }
+    job->host_s[0] = now_s() - t_alloc;
     unsigned char* A = job->arena;
     job->d_contigs = (DevContig*)(A + o_contigs);
     job->d_ncols = (uint32_t*)(A + o_ncols);
     job->d_err = (uint32_t*)(A + o_err);
+    job->d_lik = (double*)(A + o_lik);
+    job->d_likexp = (int32_t*)(A + o_likexp);
     job->zero_base = A + zero_lo;
     job->zero_bytes = zero_hi - zero_lo;
+    job->tab.mant = (const double*)(A + job->o_tab_m);
+    job->tab.expo = (const int32_t*)(A + job->o_tab_e);
 
-    // ---- upload -----------------------------------------------------------------------
-    std::vector<DevContig> hd(n_contigs);
+    // ---- chain descriptors ----------------------------------------------------------------------
+    std::vector<DevContig> hd(n_chains);
     const long double dist_scale = 0.000004L * ((long double)params->recombrate) * params->effective_N;
-    for (uint32_t i = 0; i < n_contigs; ++i) {
-        const pg_contig_batch& b = batches[i];
-        ContigHost& c = job->contigs[i];
-        Plan& p = plan[i];
-        DevContig& d = hd[i];
+    const char* dbg = getenv("PG_DEBUG");
+    for (uint32_t c = 0; c < n_chains; ++c) {
+        ChainHost& ch = job->chains[c];
+        const IndexHost& x = job->index[ch.index];
+        const Plan& p = plan[c];
+        DevContig& d = hd[c];
         memset(&d, 0, sizeof(d));
-        d.V = c.V; d.H = c.H; d.HP = c.HP; d.RB = c.RB; d.T = c.T; d.part_slots = c.part_slots;
+        d.V = x.V; d.H = x.H; d.HP = x.HP; d.RB = x.RB; d.T = x.T; d.part_slots = x.part_slots; d.pair_n = x.pair_n;
         d.dist_scale = (double)dist_scale; d.uniform = params->uniform ? 1 : 0;
-        { const char* dbg = getenv("PG_DEBUG"); d.debug = dbg ? (uint32_t)strtoul(dbg, nullptr, 0) : 0u; }
-        d.pos = (const uint64_t*)(A + p.pos); d.cov = (const uint16_t*)(A + p.cov);
-        d.kmer_off = (const uint32_t*)(A + p.koff); d.kmer_count = (const uint16_t*)(A + p.kcnt);
-        d.allele_off = (const uint32_t*)(A + p.aoff); d.allele_id = (const uint16_t*)(A + p.aid);
-        d.allele_flags = (const uint8_t*)(A + p.aflag); d.allele_koff = (const uint16_t*)(A + p.akoff);
-        d.allele_kmask = (const uint32_t*)(A + p.akmask); d.path_allele = (const uint16_t*)(A + p.pa);
-        d.geno_off = (const uint64_t*)(A + p.goff);
+        d.debug = dbg ? (uint32_t)strtoul(dbg, nullptr, 0) : 0u;
+        d.pos = (const uint64_t*)(A + x.o_pos); d.cov = (const uint16_t*)(A + ch.o_cov);
+        d.kmer_off = (const uint32_t*)(A + x.o_koff); d.kmer_count = (const uint16_t*)(A + ch.o_kcnt);
+        d.allele_off = (const uint32_t*)(A + x.o_aoff); d.allele_id = (const uint16_t*)(A + x.o_aid);
+        d.allele_flags = (const uint8_t*)(A + x.o_aflag); d.allele_koff = (const uint16_t*)(A + x.o_akoff);
+        d.allele_kmask = (const uint32_t*)(A + x.o_akmask); d.path_allele = (const uint16_t*)(A + x.o_pa);
+        d.geno_off = (const uint64_t*)(A + x.o_goff);
         d.vrec = A + p.vrec; d.kept = A + p.kept; d.allele_present = A + p.apres;
-        d.n_cols = job->d_ncols + i; d.col_variant = (uint32_t*)(A + p.cvar); d.colrec = A + p.colrec;
+        d.n_cols = job->d_ncols + c; d.col_variant = (uint32_t*)(A + p.cvar); d.colrec = A + p.colrec;
         d.fwd = (double*)(A + p.fwd); d.part = (double*)(A + p.part); d.fwd_fallback = A + p.fback; d.prof = (unsigned long long*)(A + p.prof);
-        d.fscale = (double*)(A + p.fscale); d.bscale = (double*)(A + p.bscale); d.bsum = (double*)(A + p.bsum); d.err = job->d_err + i;
-        d.lik = (double*)(A + p.lik); d.lik_exp = (int32_t*)(A + p.likexp);
+        d.fscale = (double*)(A + p.fscale); d.bscale = (double*)(A + p.bscale); d.bsum = (double*)(A + p.bsum); d.err = job->d_err + c;
+        d.lik = job->d_lik + ch.lik_first; d.lik_exp = job->d_likexp + ch.lik_first;
         d.scratch = (double*)(A + p.scratch); d.chunk_cols = job->chunk_cols;
-        d.wide = A + p.wide; d.wide_idx = c.n_wide ? (const uint32_t*)(A + p.widx) : nullptr;
-        c.d = d;
-        if (c.V == 0) continue;
-        std::vector<uint64_t> goff((size_t)c.V + 1);
-        pg_hmm_geno_offsets(&b, goff.data());
-        c.n_kmers.resize(c.V); c.coverage.resize(c.V);
-        for (uint32_t v = 0; v < c.V; ++v) {
-            c.n_kmers[v] = (uint16_t)(b.kmer_off[v + 1] - b.kmer_off[v]);
-            c.coverage[v] = b.coverage[v];
-        }
-#define UP(dst, src, bytes)                                                                         \
-    if ((bytes) > 0 && (he = hipMemcpy((void*)(dst), (src), (bytes), hipMemcpyHostToDevice)) != hipSuccess) \
-        return fail("hipMemcpy H2D", he);
-        UP(d.pos, b.variant_pos, (size_t)c.V * 8);
-        UP(d.cov, b.coverage, (size_t)c.V * 2);
-        UP(d.kmer_off, b.kmer_off, ((size_t)c.V + 1) * 4);
-        UP(d.kmer_count, b.kmer_count, (size_t)c.sumK * 2);
-        UP(d.allele_off, b.allele_off, ((size_t)c.V + 1) * 4);
-        UP(d.allele_id, b.allele_id, (size_t)c.sumA * 2);
-        UP(d.allele_flags, b.allele_flags, (size_t)c.sumA);
-        UP(d.allele_koff, b.allele_kmer_off, (size_t)c.sumA * 2);
-        UP(d.allele_kmask, b.allele_kmer_mask, (size_t)c.sumA * 4);
-        UP(d.path_allele, b.path_allele, (size_t)c.V * c.H * 2);
-        UP(d.geno_off, goff.data(), ((size_t)c.V + 1) * 8);
-        if (c.n_wide) {
-            std::vector<uint32_t> widx(c.V, PG_WIDE_NONE);
-            uint32_t k = 0;
-            for (uint32_t v = 0; v < c.V; ++v)
-                if (b.allele_off[v + 1] - b.allele_off[v] > PG_AMAX) widx[v] = k++;
-            UP(d.wide_idx, widx.data(), (size_t)c.V * 4);
-        }
-#undef UP
+        d.wide = A + p.wide; d.wide_idx = x.wide_bytes ? (const uint32_t*)(A + x.o_widx) : nullptr;
+        d.vpair = A + p.vpair; d.xbuf = (double*)(A + p.xbuf);
+        ch.d = d;
     }
-    if ((he = hipMemcpy(job->d_contigs, hd.data(), sizeof(DevContig) * n_contigs, hipMemcpyHostToDevice)) != hipSuccess)
-        return fail("hipMemcpy contigs", he);
+    if ((he = hipMemcpyAsync(job->d_contigs, hd.data(), sizeof(DevContig) * n_chains, hipMemcpyHostToDevice, job->stream)) != hipSuccess ||
+        (he = hipStreamSynchronize(job->stream)) != hipSuccess)
+        return fail(PG_ERR_DEVICE, "hipMemcpy contigs", he);
+    const int rc = upload_inputs(job, batches, specs, true, err, errlen);
+    if (rc != PG_OK) { pg_job_destroy(job); return rc; }
+    *out = job;
+    return PG_OK;
+}
+
+}  // namespace
+
+extern "C" int pg_job_new(int device, uint32_t n_contigs, const pg_contig_batch* batches, const pg_table* table,
+                          const pg_hmm_params* params, pg_job** out, char* err, size_t errlen) {
+    if (!out) { set_err(err, errlen, "null argument"); return PG_ERR_INVALID; }
+    *out = nullptr;
+    if (!batches || n_contigs == 0) { set_err(err, errlen, "null argument"); return PG_ERR_INVALID; }
+    std::vector<ChainSpec> specs(n_contigs);
+    for (uint32_t i = 0; i < n_contigs; ++i) specs[i] = {i, batches[i].kmer_count, batches[i].coverage};
+    return job_build(device, n_contigs, batches, specs, 1, false, table, params, false, out, err, errlen);
+}
+
+extern "C" pg_job* pg_job_create(int device, uint32_t n_contigs, const pg_contig_batch* batches,
+                                 const pg_table* table, const pg_hmm_params* params, char* err, size_t errlen) {
+    pg_job* job = nullptr;
+    pg_job_new(device, n_contigs, batches, table, params, &job, err, errlen);
     return job;
+}
+
+extern "C" int pg_cohort_new(int device, uint32_t n_contigs, const pg_contig_batch* index, uint32_t n_samples,
+                             const pg_sample_counts* samples, const pg_table* table, const pg_hmm_params* params,
+                             pg_job** out, char* err, size_t errlen) {
+    if (!out) { set_err(err, errlen, "null argument"); return PG_ERR_INVALID; }
+    *out = nullptr;
+    if (!index || !samples || n_contigs == 0 || n_samples == 0) { set_err(err, errlen, "null argument"); return PG_ERR_INVALID; }
+    std::vector<ChainSpec> specs((size_t)n_samples * n_contigs);
+    for (uint32_t s = 0; s < n_samples; ++s) {
+        if (!samples[s].kmer_count || !samples[s].coverage) { set_err(err, errlen, "sample %u has null arrays", s); return PG_ERR_INVALID; }
+        for (uint32_t c = 0; c < n_contigs; ++c)
+            specs[(size_t)s * n_contigs + c] = {c, samples[s].kmer_count[c], samples[s].coverage[c]};
+    }
+    return job_build(device, n_contigs, index, specs, n_samples, true, table, params, false, out, err, errlen);
+}
+
+extern "C" int pg_job_upload(pg_job* job, const pg_contig_batch* batches, const pg_sample_counts* samples, char* err, size_t errlen) {
+    if (!job) { set_err(err, errlen, "null job"); return PG_ERR_INVALID; }
+    HIP_TRY(hipSetDevice(job->device));
+    const uint32_t n = (uint32_t)job->chains.size();
+    std::vector<ChainSpec> specs(n);
+    if (job->cohort) {
+        if (!samples) { set_err(err, errlen, "cohort job: samples must be given"); return PG_ERR_INVALID; }
+        for (uint32_t s = 0; s < job->n_samples; ++s)
+            for (uint32_t c = 0; c < job->n_contigs; ++c)
+                specs[(size_t)s * job->n_contigs + c] = {c, samples[s].kmer_count[c], samples[s].coverage[c]};
+    } else {
+        if (!batches) { set_err(err, errlen, "batches must be given"); return PG_ERR_INVALID; }
+        for (uint32_t i = 0; i < n; ++i) specs[i] = {i, batches[i].kmer_count, batches[i].coverage};
+    }
+    if (batches)  // shapes must be the ones the arena was planned for
+        for (uint32_t i = 0; i < job->n_contigs; ++i) {
+            const IndexHost& x = job->index[i];
+            if (batches[i].n_variants != x.V || batches[i].n_paths != x.H ||
+                (x.V && (batches[i].kmer_off[x.V] != x.sumK || batches[i].allele_off[x.V] != x.sumA))) {
+                set_err(err, errlen, "contig %u: shape differs from the resident job", i);
+                return PG_ERR_INVALID;
+            }
+        }
+    return upload_inputs(job, batches, specs, batches != nullptr, err, errlen);
 }
 
 extern "C" int pg_job_run(pg_job* job, void* stream_, char* err, size_t errlen) {
     if (!job) { set_err(err, errlen, "null job"); return PG_ERR_INVALID; }
+    const double t_run = now_s();
     HIP_TRY(hipSetDevice(job->device));
     hipStream_t s = stream_ ? (hipStream_t)stream_ : job->stream;
-    const uint32_t n = (uint32_t)job->contigs.size();
+    const uint32_t n = (uint32_t)job->chains.size();
+    job->host_s[3] = 0.0;
     HIP_TRY(hipMemsetAsync(job->zero_base, 0, job->zero_bytes, s));
     if (job->max_v > 0 && job->params.run_genotyping) {
         HIP_TRY(hipEventRecord(job->ev[0], s));
         pgk_launch_prep(job->d_contigs, n, job->max_v, job->tab, s);
+        HIP_TRY(hipGetLastError());
         HIP_TRY(hipEventRecord(job->ev[1], s));
         pgk_launch_compact(job->d_contigs, n, s);
+        HIP_TRY(hipGetLastError());
         HIP_TRY(hipEventRecord(job->ev[2], s));
         pgk_launch_records(job->d_contigs, n, job->max_v, s);
+        HIP_TRY(hipGetLastError());
         HIP_TRY(hipEventRecord(job->ev[3], s));
         pgk_launch_sweep(job->d_contigs, n, job->hp_mask, 1, s);
+        HIP_TRY(hipGetLastError());
         HIP_TRY(hipEventRecord(job->ev[4], s));
         if (!job->chunked) {
             pgk_launch_sweep(job->d_contigs, n, job->hp_mask, 2, s);
+            HIP_TRY(hipGetLastError());
             HIP_TRY(hipEventRecord(job->ev[5], s));
             pgk_launch_bins(job->d_contigs, n, job->max_v, s);
+            HIP_TRY(hipGetLastError());
             HIP_TRY(hipEventRecord(job->ev[6], s));
         } else {
             // chunk i: store-only sweep on s -> ev_sweep -> k_post on stream2 -> ev_post; the sweep of
@@ -529,9 +751,11 @@ extern "C" int pg_job_run(pg_job* job, void* stream_, char* err, size_t errlen) 
                 const int b = (int)(i & 1u);
                 if (i >= 2) HIP_TRY(hipStreamWaitEvent(s, job->ev_post[b], 0));
                 pgk_launch_sweep_chunk(job->d_contigs, n, job->hp_mask, i, s);
+                HIP_TRY(hipGetLastError());
                 HIP_TRY(hipEventRecord(job->ev_sweep[b], s));
                 HIP_TRY(hipStreamWaitEvent(s2, job->ev_sweep[b], 0));
                 pgk_launch_post(job->d_contigs, n, job->chunk_cols, i, s2);
+                HIP_TRY(hipGetLastError());
                 HIP_TRY(hipEventRecord(job->ev_post[b], s2));
             }
             HIP_TRY(hipStreamWaitEvent(s, job->ev_post[0], 0));
@@ -539,13 +763,14 @@ extern "C" int pg_job_run(pg_job* job, void* stream_, char* err, size_t errlen) 
             HIP_TRY(hipEventRecord(job->ev[5], s));  // "k_sweep_phase2" = all chunks incl. their posteriors
             HIP_TRY(hipEventRecord(job->ev[6], s));  // (no k_bins in this mode)
         }
-        HIP_TRY(hipGetLastError());
     } else if (job->max_v > 0) {
         // run_genotyping == false: only the ColumnIndexer part is meaningful (no likelihoods)
         pgk_launch_prep(job->d_contigs, n, job->max_v, job->tab, s);
         pgk_launch_compact(job->d_contigs, n, s);
+        HIP_TRY(hipGetLastError());
     }
     HIP_TRY(hipStreamSynchronize(s));
+    if (job->stream2) HIP_TRY(hipStreamSynchronize(job->stream2));
     if (job->max_v > 0 && job->params.run_genotyping) {
         for (int i = 0; i < PG_N_KERNEL_CLASSES; ++i) {
             float ms = 0.f;
@@ -557,18 +782,19 @@ extern "C" int pg_job_run(pg_job* job, void* stream_, char* err, size_t errlen) 
     HIP_TRY(hipMemcpy(ncols.data(), job->d_ncols, sizeof(uint32_t) * n, hipMemcpyDeviceToHost));
     HIP_TRY(hipMemcpy(errs.data(), job->d_err, sizeof(uint32_t) * n, hipMemcpyDeviceToHost));
     job->ran = true;
+    job->host_s[2] = now_s() - t_run;
     for (uint32_t i = 0; i < n; ++i) {
-        job->contigs[i].n_cols_host = ncols[i];
+        job->chains[i].n_cols_host = ncols[i];
         if (errs[i] & PG_DEVERR_ALLELE_NOT_FOUND) {
-            set_err(err, errlen, "contig %u: a path_allele value is not in the variant's allele list", i);
+            set_err(err, errlen, "chain %u: a path_allele value is not in the variant's allele list", i);
             return PG_ERR_INVALID;
         }
         if (errs[i] & PG_DEVERR_TOO_MANY_ALLELES) {
-            set_err(err, errlen, "contig %u: a variant has more than %d alleles (device limit this release)", i, PG_MAX_ALLELES_PER_VARIANT);
+            set_err(err, errlen, "chain %u: a variant has more than %d alleles (device limit)", i, PG_MAX_ALLELES_PER_VARIANT);
             return PG_ERR_UNSUPPORTED;
         }
         if (errs[i] & PG_DEVERR_TOO_MANY_LOCAL) {
-            set_err(err, errlen, "contig %u: a column has more than %d distinct alleles on the selected paths (device limit this release)", i, PG_WIDE_MAX);
+            set_err(err, errlen, "chain %u: a column has more than %d distinct alleles on the selected paths (device limit)", i, PG_WIDE_MAX);
             return PG_ERR_UNSUPPORTED;
         }
     }
@@ -576,43 +802,68 @@ extern "C" int pg_job_run(pg_job* job, void* stream_, char* err, size_t errlen) 
 }
 
 extern "C" int pg_job_fetch(pg_job* job, uint32_t ci, pg_contig_result* out, char* err, size_t errlen) {
-    if (!job || !out || ci >= job->contigs.size()) { set_err(err, errlen, "bad argument"); return PG_ERR_INVALID; }
+    if (!job || !out || ci >= job->chains.size()) { set_err(err, errlen, "bad argument"); return PG_ERR_INVALID; }
     if (!job->ran) { set_err(err, errlen, "pg_job_run has not been called"); return PG_ERR_INVALID; }
+    const double t0 = now_s();
     HIP_TRY(hipSetDevice(job->device));
-    const ContigHost& c = job->contigs[ci];
+    const ChainHost& c = job->chains[ci];
+    const IndexHost& x = job->index[c.index];
     out->n_columns = c.n_cols_host;
-    if (c.V == 0) return PG_OK;
-    if (out->lik && c.n_lik) HIP_TRY(hipMemcpy(out->lik, c.d.lik, c.n_lik * sizeof(double), hipMemcpyDeviceToHost));
-    if (out->lik_exp) HIP_TRY(hipMemcpy(out->lik_exp, c.d.lik_exp, (size_t)c.V * sizeof(int32_t), hipMemcpyDeviceToHost));
-    if (out->kept) HIP_TRY(hipMemcpy(out->kept, c.d.kept, c.V, hipMemcpyDeviceToHost));
-    if (out->allele_present && c.sumA) HIP_TRY(hipMemcpy(out->allele_present, c.d.allele_present, c.sumA, hipMemcpyDeviceToHost));
+    if (x.V == 0) return PG_OK;
+    if (out->lik && x.n_lik) HIP_TRY(hipMemcpy(out->lik, c.d.lik, x.n_lik * sizeof(double), hipMemcpyDeviceToHost));
+    if (out->lik_exp && x.n_lik) HIP_TRY(hipMemcpy(out->lik_exp, c.d.lik_exp, x.n_lik * sizeof(int32_t), hipMemcpyDeviceToHost));
+    if (out->kept) HIP_TRY(hipMemcpy(out->kept, c.d.kept, x.V, hipMemcpyDeviceToHost));
+    if (out->allele_present && x.sumA) HIP_TRY(hipMemcpy(out->allele_present, c.d.allele_present, x.sumA, hipMemcpyDeviceToHost));
     // reference src/hmm.cpp:94,106-109: set only when there is at least one column
     const bool fill = job->params.run_genotyping && c.n_cols_host > 0;
     if (out->n_kmers) {
-        if (fill) memcpy(out->n_kmers, c.n_kmers.data(), (size_t)c.V * 2);
-        else memset(out->n_kmers, 0, (size_t)c.V * 2);
+        if (fill) memcpy(out->n_kmers, x.n_kmers.data(), (size_t)x.V * 2);
+        else memset(out->n_kmers, 0, (size_t)x.V * 2);
     }
     if (out->coverage) {
-        if (fill) memcpy(out->coverage, c.coverage.data(), (size_t)c.V * 2);
-        else memset(out->coverage, 0, (size_t)c.V * 2);
+        if (fill) memcpy(out->coverage, c.coverage.data(), (size_t)x.V * 2);
+        else memset(out->coverage, 0, (size_t)x.V * 2);
     }
+    job->host_s[3] += now_s() - t0;
     return PG_OK;
 }
 
 extern "C" int pg_job_device_results(pg_job* job, uint32_t ci, void** d_lik, uint64_t* n_lik, void** d_lik_exp, uint64_t* n_variants) {
-    if (!job || ci >= job->contigs.size()) return PG_ERR_INVALID;
-    const ContigHost& c = job->contigs[ci];
+    if (!job || ci >= job->chains.size()) return PG_ERR_INVALID;
+    const ChainHost& c = job->chains[ci];
+    const IndexHost& x = job->index[c.index];
     if (d_lik) *d_lik = c.d.lik;
-    if (n_lik) *n_lik = c.n_lik;
+    if (n_lik) *n_lik = x.n_lik;
     if (d_lik_exp) *d_lik_exp = c.d.lik_exp;
-    if (n_variants) *n_variants = c.V;
+    if (n_variants) *n_variants = x.V;
+    return PG_OK;
+}
+
+extern "C" int pg_job_packed_results(pg_job* job, void** d_lik, void** d_lik_exp, uint64_t* n_lik_total) {
+    if (!job) return PG_ERR_INVALID;
+    if (d_lik) *d_lik = job->d_lik;
+    if (d_lik_exp) *d_lik_exp = job->d_likexp;
+    if (n_lik_total) *n_lik_total = job->n_lik_total;
+    return PG_OK;
+}
+
+extern "C" uint32_t pg_job_n_chains(const pg_job* job) { return job ? (uint32_t)job->chains.size() : 0; }
+
+extern "C" int pg_job_host_seconds(const pg_job* job, double out4[4]) {
+    if (!job || !out4) return PG_ERR_INVALID;
+    for (int i = 0; i < 4; ++i) out4[i] = job->host_s[i];
+    return PG_OK;
+}
+extern "C" int pg_job_upload_bytes(const pg_job* job, uint64_t out2[2]) {
+    if (!job || !out2) return PG_ERR_INVALID;
+    out2[0] = job->up_bytes[0]; out2[1] = job->up_bytes[1];
     return PG_OK;
 }
 
 extern "C" int pg_job_profile_counters(pg_job* job, uint32_t ci, uint64_t out64[64]) {
-    if (!job || !out64 || ci >= job->contigs.size()) return PG_ERR_INVALID;
+    if (!job || !out64 || ci >= job->chains.size()) return PG_ERR_INVALID;
     if (hipSetDevice(job->device) != hipSuccess) return PG_ERR_DEVICE;
-    if (hipMemcpy(out64, job->contigs[ci].d.prof, 64 * sizeof(uint64_t), hipMemcpyDeviceToHost) != hipSuccess) return PG_ERR_DEVICE;
+    if (hipMemcpy(out64, job->chains[ci].d.prof, 64 * sizeof(uint64_t), hipMemcpyDeviceToHost) != hipSuccess) return PG_ERR_DEVICE;
     return PG_OK;
 }
 
@@ -632,14 +883,13 @@ extern "C" int pg_job_sweep_mode(const pg_job* job, uint32_t* chunk_cols) {
 extern "C" int pg_hmm_genotype_contig(const pg_contig_batch* batch, const pg_table* table, const pg_hmm_params* params,
                                       int device, pg_contig_result* out, char* err, size_t errlen) {
     if (!batch || !table || !params || !out) { set_err(err, errlen, "null argument"); return PG_ERR_INVALID; }
-    int rc = check_batch(batch, err, errlen);
+    std::vector<ChainSpec> specs(1);
+    specs[0] = {0, batch->kmer_count, batch->coverage};
+    pg_job* job = nullptr;
+    // (the arena of this job goes to the process cache when the job is destroyed: the next call on
+    // this device reuses it instead of paying for a device allocation again)
+    int rc = job_build(device, 1, batch, specs, 1, false, table, params, true, &job, err, errlen);
     if (rc != PG_OK) return rc;
-    if (params->run_phasing) {
-        set_err(err, errlen, "run_phasing (Viterbi, reference src/hmm.cpp:112-173) is not on the device path");
-        return PG_ERR_UNSUPPORTED;
-    }
-    pg_job* job = pg_job_create(device, 1, batch, table, params, err, errlen);
-    if (!job) return PG_ERR_DEVICE;
     rc = pg_job_run(job, nullptr, err, errlen);
     if (rc == PG_OK) rc = pg_job_fetch(job, 0, out, err, errlen);
     pg_job_destroy(job);
@@ -655,11 +905,11 @@ extern "C" int pg_emission_table(const pg_contig_batch* batch, const pg_table* t
     pg_hmm_params p;
     memset(&p, 0, sizeof(p));
     p.effective_N = 25000.0L; p.recombrate = 1.26; p.run_genotyping = 1;
-    pg_job* job = pg_job_create(device, 1, batch, table, &p, err, errlen);
-    if (!job) return PG_ERR_DEVICE;
+    pg_job* job = nullptr;
+    int rc = pg_job_new(device, 1, batch, table, &p, &job, err, errlen);
+    if (rc != PG_OK) return rc;
     const uint32_t A = batch->allele_off[v + 1] - batch->allele_off[v];
     double* dm = nullptr; int* de = nullptr;
-    int rc = PG_OK;
     std::vector<double> m((size_t)A * A);
     std::vector<int> e((size_t)A * A);
     if (hipMalloc((void**)&dm, m.size() * 8 + 8) != hipSuccess || hipMalloc((void**)&de, e.size() * 4 + 8) != hipSuccess) {

@@ -3,9 +3,10 @@
 Chains (contig x path-subset) are independent — the reference already runs them as
 independent thread-pool jobs (src/commands.cpp:955-978) — so they shard across ranks with
 NO data-path collective.  The only exchange is the final collection of the packed posteriors
-on rank 0: ONE gather (RCCL over xGMI on GPUs; gloo in the CPU tests).  Payload per variant is
-8*G + 4 bytes (28 B biallelic), i.e. tens of MB per peer for a whole genome, each peer on its
-own direct xGMI link to rank 0.
+on rank 0: ONE batched group of point-to-point sends (RCCL over xGMI on GPUs; gloo in the CPU
+tests).  Payload per genotype bin is 8 + 4 bytes (36 B per biallelic variant), i.e. tens of MB
+per peer for a whole genome, each peer on its own direct xGMI link to rank 0.  The same exchange
+exists behind the C ABI for hosts without torch (include/pangenie_hmm.h: pg_hmm_gather).
 """
 from __future__ import annotations
 
@@ -29,51 +30,62 @@ def assign_chains(weights: Sequence[float], world: int) -> List[List[int]]:
     return plan
 
 
-def pack_sizes(n_lik: Sequence[int], n_var: Sequence[int], plan: List[List[int]]) -> Tuple[List[int], int]:
-    """Per-rank packed length (f64 words: all lik of its chains, then all lik_exp) and the max."""
-    per_rank = [int(sum(n_lik[i] + n_var[i] for i in chains)) for chains in plan]
+def pack_sizes(n_lik: Sequence[int], plan: List[List[int]]) -> Tuple[List[int], int]:
+    """Genotype bins per rank (lik f64 + lik_exp i32 each) and the maximum over ranks."""
+    per_rank = [int(sum(n_lik[i] for i in chains)) for chains in plan]
     return per_rank, max(per_rank) if per_rank else 0
 
 
 def gather_posteriors(local: Dict[int, Tuple["torch.Tensor", "torch.Tensor"]], n_lik: Sequence[int],
-                      n_var: Sequence[int], plan: List[List[int]], dst: int = 0, unpack: bool = True):
-    """One gather of every rank's packed posteriors to `dst`.
+                      plan: List[List[int]], dst: int = 0, unpack: bool = True, device=None):
+    """ONE exchange of every rank's posteriors to `dst`: per peer one send of its lik (f64) and one of
+    its lik_exp (i32), exactly as long as that rank's data (no widening, no padding to the longest
+    rank), batched into a single group of point-to-point operations — on GPUs each peer uses its own
+    xGMI link to dst.
 
-    unpack=False leaves the gathered packed buffers on dst's device (list of world tensors) — what a
-    timed loop wants: like a single-GPU run it ends with the posteriors resident in HBM.
-
-    local: {chain id: (lik f64 tensor [n_lik], lik_exp i32 tensor [n_var])} for this rank's chains,
-    on the device the process group works with (cuda for nccl = RCCL, cpu for gloo).
+    local: {chain id: (lik f64 tensor [n_lik], lik_exp i32 tensor [n_lik])} for this rank's chains.
+    device: where the buffers of the collective live (cuda for nccl = RCCL, cpu for gloo); needed
+            explicitly because a rank may own no chain at all.
+    unpack=False leaves the gathered buffers on dst's device ({rank: (lik, lik_exp)}) — what a timed
+    loop wants: like a single-GPU run it ends with the posteriors resident in HBM.
     Returns on dst: {chain id: (lik float64 ndarray, lik_exp int32 ndarray)} for ALL chains; None elsewhere.
     """
     import torch
     import torch.distributed as dist
     rank, world = dist.get_rank(), dist.get_world_size()
-    per_rank, width = pack_sizes(n_lik, n_var, plan)
+    per_rank, _ = pack_sizes(n_lik, plan)
+    if device is None:
+        device = next(iter(local.values()))[0].device if local else torch.device("cpu")
     mine = plan[rank]
-    dev = next(iter(local.values()))[0].device if local else torch.device("cpu")
-    buf = torch.zeros(max(width, 1), dtype=torch.float64, device=dev)
-    off = 0
-    for i in mine:  # lik blocks, then exponent blocks (int32 is exact in float64)
-        buf[off:off + n_lik[i]] = local[i][0]
-        off += n_lik[i]
-    for i in mine:
-        buf[off:off + n_var[i]] = local[i][1].to(torch.float64)
-        off += n_var[i]
-    out = [torch.empty_like(buf) for _ in range(world)] if rank == dst else None
-    dist.gather(buf, out, dst=dst)
+    if mine:
+        lik = torch.cat([local[i][0].reshape(-1).to(torch.float64) for i in mine]) if len(mine) > 1 else local[mine[0]][0].reshape(-1)
+        ex = torch.cat([local[i][1].reshape(-1).to(torch.int32) for i in mine]) if len(mine) > 1 else local[mine[0]][1].reshape(-1)
+    else:
+        lik = torch.empty(0, dtype=torch.float64, device=device)
+        ex = torch.empty(0, dtype=torch.int32, device=device)
+    got = None
+    if rank == dst:
+        got = {r: (torch.empty(per_rank[r], dtype=torch.float64, device=device),
+                   torch.empty(per_rank[r], dtype=torch.int32, device=device)) for r in range(world) if r != dst}
+        ops = []
+        for r, (gl, ge) in got.items():
+            if per_rank[r]:
+                ops += [dist.P2POp(dist.irecv, gl, r), dist.P2POp(dist.irecv, ge, r)]
+        got[dst] = (lik, ex)
+    else:
+        ops = [dist.P2POp(dist.isend, lik, dst), dist.P2POp(dist.isend, ex, dst)] if per_rank[rank] else []
+    if ops:
+        for w in dist.batch_isend_irecv(ops):
+            w.wait()
     if rank != dst:
         return None
     if not unpack:
-        return out
+        return got
     res = {}
     for r in range(world):
-        flat = out[r].cpu().numpy()
+        fl, fe = got[r][0].cpu().numpy(), got[r][1].cpu().numpy()
         off = 0
         for i in plan[r]:
-            res[i] = [flat[off:off + n_lik[i]].copy(), None]
+            res[i] = (fl[off:off + n_lik[i]].copy(), fe[off:off + n_lik[i]].copy())
             off += n_lik[i]
-        for i in plan[r]:
-            res[i][1] = np.rint(flat[off:off + n_var[i]]).astype(np.int32)
-            off += n_var[i]
-    return {i: (v[0], v[1]) for i, v in res.items()}
+    return res

@@ -12,7 +12,7 @@ from typing import List, Optional, Sequence
 import numpy as np
 
 from . import _lib
-from ._lib import (PG_N_KERNEL_CLASSES, PgContigBatch, PgContigResult, PgHmmParams, f64p, i32p,
+from ._lib import (PG_N_KERNEL_CLASSES, PgContigBatch, PgContigResult, PgHmmParams, PgSampleCounts, f64p, i32p,
                    ldp, u8p, u16p, u64p)
 from .genotyping_result import GenotypingResult, results_from_flat
 from .panel import ContigBatch
@@ -80,7 +80,7 @@ class ContigResult:
         self.geno_off = batch.geno_off
         n = int(self.geno_off[-1])
         self.lik = np.zeros(max(n, 1), np.float64)[:n]
-        self.lik_exp = np.zeros(max(V, 1), np.int32)[:V]
+        self.lik_exp = np.zeros(max(n, 1), np.int32)[:n]  # one exponent per genotype bin
         self.kept = np.zeros(max(V, 1), np.uint8)[:V]
         nA = int(batch.allele_off[-1]) if V else 0
         self.allele_present = np.zeros(max(nA, 1), np.uint8)[:nA]
@@ -96,10 +96,8 @@ class ContigResult:
         self._c.coverage = self.coverage.ctypes.data_as(u16p)
 
     def likelihoods_ld(self) -> np.ndarray:
-        """Unnormalised genotype likelihoods as 80-bit long double: lik * 2^lik_exp."""
-        G = np.diff(self.geno_off.astype(np.int64))
-        ex = np.repeat(self.lik_exp.astype(np.int64), G)
-        return np.ldexp(self.lik.astype(LD), ex)
+        """Unnormalised genotype likelihoods as 80-bit long double: lik[g] * 2^lik_exp[g]."""
+        return np.ldexp(self.lik.astype(LD), self.lik_exp.astype(np.int64))
 
     def genotyping_results(self) -> List[GenotypingResult]:
         return results_from_flat(self.batch, self.likelihoods_ld(), self.kept, self.allele_present,
@@ -124,20 +122,91 @@ def genotype_contig(batch: ContigBatch, table: ProbabilityTable, params: Optiona
 
 
 class Job:
-    """Resident multi-contig job: upload once, run many times (bench / pipelines)."""
+    """Resident multi-chain job: upload once, run many times (bench / pipelines).
+
+    Job(batches, ...)                      one chain per batch (contig x path subset)
+    Job.cohort(index, samples, ...)        chains = samples x contigs over ONE shared index
+                                           (include/pangenie_hmm.h: pg_cohort_new); chain id =
+                                           sample * n_contigs + contig
+    """
 
     def __init__(self, batches: Sequence[ContigBatch], table: ProbabilityTable,
-                 params: Optional[PgHmmParams] = None, device: int = 0):
+                 params: Optional[PgHmmParams] = None, device: int = 0, _cohort=None):
         self._lib = _lib.load_hip()
-        self.batches = list(batches)
         self.table = table
         self.params = params or make_params()
-        arr = (PgContigBatch * len(self.batches))(*[b.as_c() for b in self.batches])
+        self.index = list(batches)
+        self._arr = (PgContigBatch * len(self.index))(*[b.as_c() for b in self.index])
         err = C.create_string_buffer(_ERRLEN)
-        self.h = self._lib.pg_job_create(device, len(self.batches), arr, table.h, C.byref(self.params),
-                                         err, _ERRLEN)
-        if not self.h:
-            raise PanGenieError(_lib.PG_ERR_DEVICE, err.value.decode(errors="replace"))
+        h = C.c_void_p()
+        if _cohort is None:
+            self.batches = self.index
+            self._samples = None
+            rc = self._lib.pg_job_new(device, len(self.index), self._arr, table.h, C.byref(self.params),
+                                      C.byref(h), err, _ERRLEN)
+        else:
+            self._samples, self._keep = self._marshal_samples(_cohort)
+            self.batches = [b.with_counts(kc, cov) for (kcs, covs) in _cohort for b, kc, cov in zip(self.index, kcs, covs)]
+            rc = self._lib.pg_cohort_new(device, len(self.index), self._arr, len(_cohort), self._samples, table.h,
+                                         C.byref(self.params), C.byref(h), err, _ERRLEN)
+        if rc:
+            raise PanGenieError(rc, err.value.decode(errors="replace"))
+        self.h = h.value
+
+    @classmethod
+    def cohort(cls, index: Sequence[ContigBatch], samples, table: ProbabilityTable,
+               params: Optional[PgHmmParams] = None, device: int = 0) -> "Job":
+        """samples: list (one entry per sample) of (kmer_counts, coverages), each a list with one uint16
+        array per index contig."""
+        return cls(index, table, params, device, _cohort=list(samples))
+
+    def _marshal_samples(self, samples):
+        n, nc = len(samples), len(self.index)
+        arr = (PgSampleCounts * n)()
+        keep = []
+        for s, (kcs, covs) in enumerate(samples):
+            assert len(kcs) == nc and len(covs) == nc
+            kc = [np.ascontiguousarray(a, np.uint16) if len(a) else np.zeros(1, np.uint16) for a in kcs]
+            cv = [np.ascontiguousarray(a, np.uint16) if len(a) else np.zeros(1, np.uint16) for a in covs]
+            pk = (u16p * nc)(*[a.ctypes.data_as(u16p) for a in kc])
+            pc = (u16p * nc)(*[a.ctypes.data_as(u16p) for a in cv])
+            arr[s].kmer_count = pk
+            arr[s].coverage = pc
+            keep += [kc, cv, pk, pc]
+        return arr, keep
+
+    @property
+    def n_chains(self) -> int:
+        return int(self._lib.pg_job_n_chains(self.h))
+
+    def upload(self, samples=None) -> None:
+        """Re-upload the inputs (same shapes): all arrays of a plain job; for a cohort job the given
+        per-sample counts (index stays resident)."""
+        err = C.create_string_buffer(_ERRLEN)
+        if self._samples is None:
+            rc = self._lib.pg_job_upload(self.h, self._arr, None, err, _ERRLEN)
+        else:
+            if samples is not None:
+                self._samples, self._keep = self._marshal_samples(list(samples))
+            rc = self._lib.pg_job_upload(self.h, None, self._samples, err, _ERRLEN)
+        if rc:
+            raise PanGenieError(rc, err.value.decode(errors="replace"))
+
+    def host_seconds(self) -> dict:
+        out = (C.c_double * 4)()
+        self._lib.pg_job_host_seconds(self.h, out)
+        return {"alloc_s": out[0], "upload_s": out[1], "run_s": out[2], "fetch_s": out[3]}
+
+    def upload_bytes(self) -> dict:
+        out = (C.c_uint64 * 2)()
+        self._lib.pg_job_upload_bytes(self.h, out)
+        return {"index": int(out[0]), "samples": int(out[1])}
+
+    def packed_results(self):
+        """(lik_ptr, lik_exp_ptr, n_lik_total): the posteriors of all chains as two packed device ranges."""
+        d_lik, d_exp, n = C.c_void_p(), C.c_void_p(), C.c_uint64()
+        self._lib.pg_job_packed_results(self.h, C.byref(d_lik), C.byref(d_exp), C.byref(n))
+        return d_lik.value, d_exp.value, int(n.value)
 
     def run(self, stream: int = 0) -> None:
         err = C.create_string_buffer(_ERRLEN)

@@ -423,7 +423,7 @@ HMM::HMM(std::vector<std::shared_ptr<UniqueKmers>>* unique_kmers, ProbabilityTab
     std::vector<uint64_t> geno_off(V + 1, 0);
     pg_hmm_geno_offsets(&f.batch, geno_off.data());
     std::vector<double> lik(geno_off[V] ? geno_off[V] : 1);
-    std::vector<int32_t> lik_exp(V ? V : 1);
+    std::vector<int32_t> lik_exp(geno_off[V] ? geno_off[V] : 1);  // one exponent per genotype bin
     std::vector<uint8_t> kept(V ? V : 1), present(f.allele_id.size() ? f.allele_id.size() : 1);
     std::vector<uint16_t> n_kmers(V ? V : 1), cov(V ? V : 1);
     pg_contig_result r{};
@@ -444,8 +444,8 @@ HMM::HMM(std::vector<std::shared_ptr<UniqueKmers>>* unique_kmers, ProbabilityTab
                 for (uint32_t b = a; b < A; ++b) {
                     if (!present[a0 + b]) continue;
                     const uint64_t idx = geno_off[v] + (uint64_t)a * A - (uint64_t)a * (a - 1) / 2 + (b - a);
-                    // the device returns lik * 2^lik_exp; rebuild the reference's long double
-                    g.add_to_likelihood(f.allele_id[a0 + a], f.allele_id[a0 + b], ldexpl((long double)lik[idx], lik_exp[v]));
+                    // the device returns lik[g] * 2^lik_exp[g]; rebuild the reference's long double
+                    g.add_to_likelihood(f.allele_id[a0 + a], f.allele_id[a0 + b], ldexpl((long double)lik[idx], lik_exp[idx]));
                 }
             }
         }

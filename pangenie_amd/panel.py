@@ -109,6 +109,16 @@ class ContigBatch:
             path_allele=self.path_allele[lo * H:hi * H].copy(),
         )
 
+    def with_counts(self, kmer_count: np.ndarray, coverage: np.ndarray) -> "ContigBatch":
+        """The same index with another sample's read k-mer counts / local coverage (what
+        fill_read_kmercounts changes per sample, reference src/commands.cpp:118-138).  Index arrays
+        are shared, not copied."""
+        kc = np.ascontiguousarray(kmer_count, np.uint16)
+        cv = np.ascontiguousarray(coverage, np.uint16)
+        assert kc.shape == self.kmer_count.shape and cv.shape == self.coverage.shape
+        return ContigBatch(self.n_paths, self.variant_pos, cv, self.kmer_off, kc, self.allele_off, self.allele_id,
+                           self.allele_flags, self.allele_kmer_off, self.allele_kmer_mask, self.path_allele)
+
     def nbytes(self) -> int:
         return sum(getattr(self, f).nbytes for f in (
             "variant_pos", "coverage", "kmer_off", "kmer_count", "allele_off", "allele_id",
@@ -314,6 +324,41 @@ def synthetic_panel(n_variants: int, n_paths: int, kmers_per_variant: int = 20, 
 
     return ContigBatch(H, pos, cov, kmer_off, counts, allele_off, allele_id, allele_flags,
                        allele_kmer_off, allele_kmer_mask, path_allele.reshape(-1))
+
+
+def synthetic_sample_counts(index: ContigBatch, *, seed: int, peak: int = PEAK):
+    """Read k-mer counts + local coverage of ANOTHER sample against the same index: a new true
+    genotype (two mosaic panel paths), counts ~ Poisson(cn * peak / 2) as in synthetic_panel.
+    Returns (kmer_count u16 [sumK], coverage u16 [V])."""
+    rng = np.random.Generator(np.random.PCG64(seed))
+    V, H = index.n_variants, index.n_paths
+    pa = index.path_allele.reshape(V, H)
+
+    def mosaic():
+        sw = rng.random(V) < 0.002
+        seg = np.cumsum(sw)
+        starts = rng.integers(0, H, size=int(seg.max()) + 1 if V else 1)
+        return starts[seg]
+    rows = np.arange(V)
+    g1, g2 = pa[rows, mosaic()].astype(np.int64), pa[rows, mosaic()].astype(np.int64)
+    Kv = np.diff(index.kmer_off.astype(np.int64))
+    sumK = int(index.kmer_off[-1]) if V else 0
+    kv = np.repeat(np.arange(V), Kv)
+    kidx = np.arange(sumK) - np.repeat(index.kmer_off[:-1].astype(np.int64), Kv)
+    # allele (id) that owns k-mer kidx of its variant: the one whose (offset, mask) window holds it
+    A = np.diff(index.allele_off.astype(np.int64))
+    av = np.repeat(np.arange(V), A)
+    mask = index.allele_kmer_mask.astype(np.float64)
+    alen = np.where(mask > 0, np.floor(np.log2(np.maximum(mask, 1.0))) + 1, 0).astype(np.int64)  # k-mers per allele block
+    per = np.zeros(V, np.int64)
+    np.maximum.at(per, av, alen)
+    kallele = kidx // np.maximum(per[kv], 1)
+    cn = (kallele == g1[kv]).astype(np.int64) + (kallele == g2[kv]).astype(np.int64)
+    counts = rng.poisson(cn * (peak / 2.0)).astype(np.int64)
+    noise = (rng.random(sumK) < 0.1).astype(np.int64)
+    counts = np.clip(np.where(cn == 0, noise, counts), 0, 65535).astype(np.uint16)
+    cov = (peak - 3 + rng.integers(0, 7, size=V)).astype(np.uint16)
+    return counts, cov
 
 
 # algorithmic HBM bytes per variant, SURVEY.md §8(d):

@@ -85,3 +85,30 @@ def test_argument_errors_without_device(lib):
         # no CPU fallback: without a GPU the product path must fail loudly
         with pytest.raises(hmm.PanGenieError):
             hmm.genotype_contig(b, t, hmm.make_params())
+
+
+def test_malformed_batches_are_rejected_on_the_host(lib):
+    """offsets are validated (O(V)) before anything reaches the device, with specific codes."""
+    from pangenie_amd import hmm
+    t = hmm.ProbabilityTable(6, 108, 54, 0.01)
+
+    def code(b):
+        b._c = None
+        with pytest.raises(hmm.PanGenieError) as e:
+            hmm.genotype_contig(b, t, hmm.make_params())
+        return e.value.code
+
+    b = synthetic_panel(12, 4, 6, seed=1)
+    b.kmer_off[5] = b.kmer_off[7] + 3          # not monotonic: a huge K after unsigned wrap on the device
+    assert code(b) == _lib.PG_ERR_INVALID
+    b = synthetic_panel(12, 4, 6, seed=1)
+    b.allele_off[4] = b.allele_off[3]          # a variant without alleles
+    assert code(b) == _lib.PG_ERR_INVALID
+    b = synthetic_panel(12, 4, 6, seed=1)
+    b.allele_off[0] = 1
+    assert code(b) == _lib.PG_ERR_INVALID
+    # limits: more than 256 alleles in one object, more than 1024 selected paths
+    b = synthetic_panel(8, 4, 6, seed=1, multiallelic_frac=1.0, max_alleles=400)
+    if int(np.diff(b.allele_off).max()) > 256:
+        assert code(b) == _lib.PG_ERR_UNSUPPORTED
+    assert code(synthetic_panel(3, 1100, 4, seed=1)) == _lib.PG_ERR_UNSUPPORTED

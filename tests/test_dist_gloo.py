@@ -20,29 +20,29 @@ def test_lpt_plan_is_balanced_and_deterministic():
     assert max(loads) <= 1.15 * (sum(w) / 8)
     assert plan == assign_chains(w, 8)
     assert assign_chains([5, 1], 4) == [[0], [1], [], []]
-    assert pack_sizes([3, 6], [1, 2], [[0], [1]]) == ([4, 8], 8)
+    assert pack_sizes([3, 6], [[0], [1]]) == ([3, 6], 6)
 
 
-def _fake(i, n_lik, n_var):
+def _fake(i, n_lik):
     rng = np.random.default_rng(100 + i)
-    return rng.random(n_lik[i]), rng.integers(-2000, 5, size=n_var[i]).astype(np.int32)
+    return rng.random(n_lik[i]), rng.integers(-17000, 5, size=n_lik[i]).astype(np.int32)
 
 
-def _worker(rank, world, port, n_lik, n_var, q):
+def _worker(rank, world, port, n_lik, q):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
-    plan = assign_chains([a * 1.0 for a in n_var], world)
+    plan = assign_chains([a * 1.0 for a in n_lik], world)
     local = {}
     for i in plan[rank]:
-        lik, ex = _fake(i, n_lik, n_var)
+        lik, ex = _fake(i, n_lik)
         local[i] = (torch.from_numpy(lik), torch.from_numpy(ex))
-    got = gather_posteriors(local, n_lik, n_var, plan, dst=0)
+    got = gather_posteriors(local, n_lik, plan, dst=0, device=torch.device("cpu"))
     ok = True
     if rank == 0:
         ok = sorted(got) == list(range(len(n_lik)))
         for i in range(len(n_lik)):
-            lik, ex = _fake(i, n_lik, n_var)
+            lik, ex = _fake(i, n_lik)
             ok = ok and np.array_equal(got[i][0], lik) and np.array_equal(got[i][1], ex)
     else:
         ok = got is None
@@ -51,19 +51,28 @@ def _worker(rank, world, port, n_lik, n_var, q):
     dist.destroy_process_group()
 
 
-def test_gather_two_ranks_gloo():
+def _run(world, n_lik):
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
     port = s.getsockname()[1]
     s.close()
-    n_var = [50, 7, 31, 12, 1]
-    n_lik = [150, 21, 99, 40, 3]
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, n_lik, n_var, q)) for r in range(2)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, n_lik, q)) for r in range(world)]
     for p in procs:
         p.start()
-    results = dict(q.get(timeout=120) for _ in range(2))
+    results = dict(q.get(timeout=180) for _ in range(world))
     for p in procs:
         p.join(timeout=60)
-    assert results == {0: True, 1: True}
+    return results
+
+
+def test_gather_two_ranks_gloo():
+    assert _run(2, [150, 21, 99, 40, 3]) == {0: True, 1: True}
+
+
+def test_gather_with_an_empty_rank_gloo():
+    # more ranks than chains: rank 1 owns nothing and must still take part with a buffer on the
+    # collective's device
+    assert assign_chains([7.0], 2) == [[0], []]
+    assert _run(2, [7]) == {0: True, 1: True}

@@ -149,14 +149,34 @@ def test_panels_vs_oracle(V, H, K, multi, kw, orc):
     assert_parity(b, res, ref)
 
 
-@pytest.mark.parametrize("recomb,uniform,N", [(1.26, True, 1e-5), (0.0, False, 1e-5), (446.287102628, False, 0.25),
-                                              (1.26, False, 25000.0)])
+@pytest.mark.parametrize("recomb,uniform,N", [(1.26, True, 1e-5), (0.001, False, 1e-5), (1e-9, False, 1e-5),
+                                              (446.287102628, False, 0.25), (1.26, False, 25000.0)])
 def test_transition_regimes_vs_oracle(recomb, uniform, N, orc):
     b = synthetic_panel(400, 24, 16, seed=77, multiallelic_frac=0.2)
     args = default_table_args()
     res = hmm.genotype_contig(b, hmm.ProbabilityTable(*args), hmm.make_params(recomb, uniform, N))
     ref = orc.genotype_contig(b, orc.OracleTable(*args), orc.make_params(recomb, uniform, N))
     assert_parity(b, res, ref)
+
+
+def test_zero_recombination_documented_range(orc):
+    """recombrate == 0: no mixing at all, every state evolves on its own (a setting the reference's CLI
+    never produces: recombrate is fixed at 1.26, src/pangenie-genotype.cpp:33-45).  The stored fp64
+    columns then keep 2^-1400 of a column's sum where the reference's long double keeps 2^-16445
+    (include/pangenie_hmm.h, numeric contract): bins within 350 decades of their variant's largest bin
+    are held to the usual 1e-6 relative, calls are identical; deeper bins may flush to 0."""
+    b = synthetic_panel(400, 24, 16, seed=77, multiallelic_frac=0.2)
+    args = default_table_args()
+    res = hmm.genotype_contig(b, hmm.ProbabilityTable(*args), hmm.make_params(0.0, False, 1e-5))
+    ref = orc.genotype_contig(b, orc.OracleTable(*args), orc.make_params(0.0, False, 1e-5))
+    got = res.likelihoods_ld()
+    rel = rel_errors(b, got, ref.lik)
+    go = b.geno_off.astype(np.int64)
+    mx = np.repeat(np.maximum.reduceat(np.concatenate([ref.lik, np.zeros(1, ref.lik.dtype)]), go[:-1])[:b.n_variants],
+                   np.diff(go))
+    near = ref.lik > mx * np.longdouble(10.0) ** -350
+    assert float(rel[near].max()) < 1e-6
+    assert (calls(b, got) == calls(b, ref.lik)).all()
 
 
 def test_unregularized_table_zero_emissions_vs_oracle(orc):
@@ -247,21 +267,151 @@ def test_multi_contig_job_matches_single_calls(orc, monkeypatch, mode, hs):
     job.close()
 
 
+@pytest.mark.parametrize("H,V", [(215, 60), (200, 40), (300, 24), (700, 10)])
+def test_many_paths_generic_kernel_vs_oracle(H, V, orc):
+    """More than 128 selected paths (HP = 256 / 512 / 1024: the generic sweep kernel).  H = 215 is the
+    reference's own integration fixture (all paths in one subset, tests/CommandsTest.cpp:31)."""
+    b = synthetic_panel(V, H, 20, seed=500 + H, multiallelic_frac=0.2)
+    args = default_table_args()
+    res = hmm.genotype_contig(b, hmm.ProbabilityTable(*args), hmm.make_params(1.26, False, 1e-5))
+    ref = orc.genotype_contig(b, orc.OracleTable(*args), orc.make_params(1.26, False, 1e-5))
+    assert_parity(b, res, ref)
+
+
+def test_fixture_shape_215_paths_44_alleles_vs_oracle(orc):
+    """The shape of the reference's region fixture (215 paths, first record 62
+    k-mers and 44 alleles, most of them undefined and carried by single paths): wide columns with up to 44
+    distinct alleles on the selected paths, on the generic kernel."""
+    b = synthetic_panel(40, 215, 62, seed=44, multiallelic_frac=0.5, max_alleles=44, local_alts=43, undefined_frac=0.3)
+    pa = b.path_allele.reshape(40, 215)
+    assert int(np.diff(b.allele_off).max()) >= 40 and max(len(set(r)) for r in pa) > 32
+    for reg in (0.01, 0.0):
+        args = (6, 108, 54, reg)
+        res = hmm.genotype_contig(b, hmm.ProbabilityTable(*args), hmm.make_params(1.26, False, 1e-5))
+        ref = orc.genotype_contig(b, orc.OracleTable(*args), orc.make_params(1.26, False, 1e-5))
+        assert_parity(b, res, ref)
+
+
+@pytest.mark.parametrize("H", [64, 100, 128])
+def test_generic_kernel_cross_checks_register_kernels(H, orc, monkeypatch):
+    """PG_SWEEP_KERNEL=generic runs HP = 64 / 128 on the independently written generic kernel: both must
+    match the oracle, and each other to fp64 rounding."""
+    b = synthetic_panel(260, H, 24, seed=70 + H, multiallelic_frac=0.3)
+    args = (6, 108, 54, 0.0)
+    b.kmer_count[::3] = 0
+    t, p = hmm.ProbabilityTable(*args), hmm.make_params(1.26, False, 1e-5)
+    monkeypatch.setenv("PG_SWEEP_MODE", "chunked")
+    monkeypatch.setenv("PG_CHUNK_COLS", "37")
+    reg = hmm.genotype_contig(b, t, p)
+    monkeypatch.setenv("PG_SWEEP_KERNEL", "generic")
+    gen = hmm.genotype_contig(b, t, p)
+    ref = orc.genotype_contig(b, orc.OracleTable(*args), orc.make_params(1.26, False, 1e-5))
+    assert_parity(b, reg, ref)
+    assert_parity(b, gen, ref)
+    a, c = reg.likelihoods_ld(), gen.likelihoods_ld()
+    den = np.maximum(np.abs(a), np.abs(c))
+    assert float(np.where(den > 0, np.abs(a - c) / np.where(den > 0, den, 1), 0).max()) < 1e-11
+
+
 def test_limits_are_reported_not_silently_wrong():
-    b = synthetic_panel(20, 200, 10, seed=1)
+    b = synthetic_panel(4, 1100, 10, seed=1)
     with pytest.raises(hmm.PanGenieError) as e:
         hmm.genotype_contig(b, hmm.ProbabilityTable(*default_table_args()), hmm.make_params())
     assert e.value.code == hmm._lib.PG_ERR_UNSUPPORTED
 
 
-def test_allele_limits_are_reported(orc):
-    t, p = hmm.ProbabilityTable(*default_table_args()), hmm.make_params()
-    # more than 32 alleles in one UniqueKmers object
-    b = synthetic_panel(60, 16, 160, seed=3, multiallelic_frac=1.0, max_alleles=40)
-    assert int(np.diff(b.allele_off).max()) > 32
-    with pytest.raises(hmm.PanGenieError) as e:
-        hmm.genotype_contig(b, t, p)
-    assert e.value.code == hmm._lib.PG_ERR_UNSUPPORTED
+def test_many_alleles_per_object_vs_oracle(orc):
+    """More than 32 (up to 256) alleles in one UniqueKmers object: presence bitmap of 256 slots."""
+    b = synthetic_panel(60, 16, 160, seed=3, multiallelic_frac=1.0, max_alleles=90)
+    assert int(np.diff(b.allele_off).max()) > 64
+    args = default_table_args()
+    res = hmm.genotype_contig(b, hmm.ProbabilityTable(*args), hmm.make_params(1.26, False, 1e-5))
+    ref = orc.genotype_contig(b, orc.OracleTable(*args), orc.make_params(1.26, False, 1e-5))
+    assert_parity(b, res, ref)
+
+
+def test_deep_bins_keep_relative_precision(orc, monkeypatch):
+    """The round-1 soak failure, now a test: 16-allele columns, H = 65, K = 128, unregularised table —
+    genotype bins hundreds to thousands of decades below their variant's largest bin.  Every bin holds
+    1e-6 relative, in the chunked and in the fused mode (narrow panel for the latter), and the two modes
+    agree with each other."""
+    args = (6, 108, 54, 0.0)
+    wide = synthetic_panel(150, 65, 128, seed=99, multiallelic_frac=0.6, max_alleles=17, local_alts=15, undefined_frac=0.05)
+    narrow = synthetic_panel(300, 65, 128, seed=98, multiallelic_frac=0.6, max_alleles=5)
+    for b in (wide, narrow):
+        b.kmer_count[::3] = 0
+        b.kmer_count[1::17] = 300
+    ref = orc.genotype_contig(wide, orc.OracleTable(*args), orc.make_params(1.26, False, 1e-5))
+    nz = ref.lik[ref.lik > 0]
+    assert float(np.log10(nz.max() / nz.min())) > 1000  # the panel really reaches that deep
+    res = hmm.genotype_contig(wide, hmm.ProbabilityTable(*args), hmm.make_params(1.26, False, 1e-5))
+    assert_parity(wide, res, ref)
+    refn = orc.genotype_contig(narrow, orc.OracleTable(*args), orc.make_params(1.26, False, 1e-5))
+    out = {}
+    for mode in ("fused", "chunked"):
+        monkeypatch.setenv("PG_SWEEP_MODE", mode)
+        monkeypatch.setenv("PG_CHUNK_COLS", "64")
+        out[mode] = hmm.genotype_contig(narrow, hmm.ProbabilityTable(*args), hmm.make_params(1.26, False, 1e-5))
+        assert_parity(narrow, out[mode], refn)
+    a, c = out["fused"].likelihoods_ld(), out["chunked"].likelihoods_ld()
+    den = np.maximum(np.abs(a), np.abs(c))
+    assert float(np.where(den > 0, np.abs(a - c) / np.where(den > 0, den, 1), 0).max()) < 1e-10
+
+
+def test_resident_job_survives_table_modify_and_destroy(orc):
+    """a job keeps its own device copy of the ProbabilityTable."""
+    args = default_table_args()
+    b = synthetic_panel(200, 16, 20, seed=4)
+    t = hmm.ProbabilityTable(*args)
+    p = hmm.make_params(1.26, False, 1e-5)
+    job_a = hmm.Job([b], t, p)
+    t.modify(27, 13, 0.3, 0.3, 0.4)
+    job_b = hmm.Job([b], t, p)
+    job_b.run()
+    del t
+    job_a.run()
+    ref = orc.genotype_contig(b, orc.OracleTable(*args), orc.make_params(1.26, False, 1e-5))
+    assert_parity(b, job_a.fetch(0), ref)
+    to = orc.OracleTable(*args)
+    to.modify(27, 13, 0.3, 0.3, 0.4)
+    assert_parity(b, job_b.fetch(0), orc.genotype_contig(b, to, orc.make_params(1.26, False, 1e-5)))
+    job_a.close(); job_b.close()
+
+
+@pytest.mark.parametrize("mode", ["fused", "chunked"])
+def test_cohort_job_vs_oracle(mode, orc, monkeypatch):
+    """8 samples x 3 contigs against ONE index uploaded once (pg_cohort_new); every
+    (sample, contig) chain against the oracle run on that sample's counts; per-sample upload moves
+    2 K + 2 bytes per variant."""
+    from pangenie_amd.panel import synthetic_sample_counts
+    monkeypatch.setenv("PG_SWEEP_MODE", mode)
+    monkeypatch.setenv("PG_CHUNK_COLS", "128")
+    args = default_table_args()
+    index = [synthetic_panel(350, 64, 20, seed=60), synthetic_panel(240, 16, 20, seed=61, multiallelic_frac=0.3),
+             synthetic_panel(300, 32, 24, seed=62, multiallelic_frac=0.2)]
+    n_samples = 8
+    samples = []
+    for s in range(n_samples):
+        kcs, covs = zip(*[synthetic_sample_counts(ix, seed=900 + 10 * s + c) for c, ix in enumerate(index)])
+        samples.append((list(kcs), list(covs)))
+    job = hmm.Job.cohort(index, samples, hmm.ProbabilityTable(*args), hmm.make_params(1.26, False, 1e-5))
+    assert job.n_chains == n_samples * len(index)
+    up = job.upload_bytes()
+    per_sample = sum(2 * int(ix.kmer_off[-1]) + 2 * ix.n_variants for ix in index)
+    assert up["samples"] == n_samples * per_sample and up["index"] < 2 * sum(ix.nbytes() for ix in index)
+    job.run()
+    for s in range(n_samples):
+        for c, ix in enumerate(index):
+            b = ix.with_counts(samples[s][0][c], samples[s][1][c])
+            ref = orc.genotype_contig(b, orc.OracleTable(*args), orc.make_params(1.26, False, 1e-5))
+            assert_parity(b, job.fetch(s * len(index) + c), ref)
+    # the next batch of samples: counts only, the index stays resident
+    job.upload(samples[::-1])
+    assert job.upload_bytes() == {"index": 0, "samples": n_samples * per_sample}
+    job.run()
+    b = index[1].with_counts(samples[-1][0][1], samples[-1][1][1])
+    assert_parity(b, job.fetch(1), orc.genotype_contig(b, orc.OracleTable(*args), orc.make_params(1.26, False, 1e-5)))
+    job.close()
 
 
 @pytest.mark.parametrize("H,V,local_alts", [(16, 300, 12), (64, 200, 20), (27, 150, 8), (128, 60, 31)])
@@ -276,6 +426,63 @@ def test_wide_columns_vs_oracle(H, V, local_alts, orc):
     res = hmm.genotype_contig(b, hmm.ProbabilityTable(*args), hmm.make_params(1.26, False, 1e-5))
     ref = orc.genotype_contig(b, orc.OracleTable(*args), orc.make_params(1.26, False, 1e-5))
     assert_parity(b, res, ref)
+
+
+def _check_normalised(b, r):
+    n = normalized_bins(b, r.likelihoods_ld())
+    sums = np.add.reduceat(np.concatenate([n, np.zeros(1, n.dtype)]), b.geno_off[:-1].astype(np.int64))[:b.n_variants]
+    kept = r.kept.astype(bool)
+    assert np.allclose(sums[kept].astype(float), 1.0, atol=1e-12)
+    assert not np.isnan(n.astype(float)).any()
+    return n
+
+
+def test_config3_whole_genome_full_size(orc):
+    """BASELINE.json configs[3] at full size on ONE GPU: 24 contigs (human chromosome proportions), 5 M
+    variants, 64 haplotypes.  Size-independent properties on the full job (determinism, normalised
+    posteriors sum to 1, every variant accounted for) and oracle parity of the same device path on the
+    first 2 000 variants of three of its contigs."""
+    from bench import genome_contig_sizes
+    sizes = genome_contig_sizes(5_000_000)
+    batches = [synthetic_panel(sizes[i], 64, 20, seed=12345 + 1000 * i) for i in range(24)]
+    t = hmm.ProbabilityTable(*default_table_args())
+    p = hmm.make_params(1.26, False, 1e-5)
+    job = hmm.Job(batches, t, p)
+    job.run()
+    first = [job.fetch(i) for i in (0, 11, 23)]
+    job.run()
+    for k, i in enumerate((0, 11, 23)):
+        r2 = job.fetch(i)
+        assert (first[k].lik == r2.lik).all() and (first[k].lik_exp == r2.lik_exp).all()
+        assert r2.n_columns == int(r2.kept.sum()) > 0.9 * sizes[i]
+        _check_normalised(batches[i], r2)
+    job.close()
+    hmm._lib.load_hip().pg_hmm_release_cache()
+    args = default_table_args()
+    for i in (0, 11, 23):
+        sl = batches[i].slice(0, 2000)
+        res = hmm.genotype_contig(sl, t, p)
+        ref = orc.genotype_contig(sl, orc.OracleTable(*args), orc.make_params(1.26, False, 1e-5))
+        assert_parity(sl, res, ref)
+
+
+def test_config4_shape_h128_multiallelic(orc):
+    """BASELINE.json configs[4] shape, one GPU's slice: 60 k variants x 128 haplotypes, 20 % multiallelic.
+    Properties at full slice size + oracle parity on a 300-variant piece."""
+    b = synthetic_panel(60_000, 128, 20, seed=4242, multiallelic_frac=0.2)
+    t = hmm.ProbabilityTable(*default_table_args())
+    p = hmm.make_params(1.26, False, 1e-5)
+    job = hmm.Job([b], t, p)
+    job.run()
+    r1 = job.fetch(0)
+    job.run()
+    r2 = job.fetch(0)
+    job.close()
+    assert (r1.lik == r2.lik).all() and (r1.lik_exp == r2.lik_exp).all()
+    _check_normalised(b, r1)
+    sl = b.slice(30_000, 30_300)
+    args = default_table_args()
+    assert_parity(sl, hmm.genotype_contig(sl, t, p), orc.genotype_contig(sl, orc.OracleTable(*args), orc.make_params(1.26, False, 1e-5)))
 
 
 def test_full_size_properties():

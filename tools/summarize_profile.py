@@ -35,6 +35,25 @@ for name, col in (("pmc_fetch", "FETCH_SIZE"), ("pmc_write", "WRITE_SIZE")):
         out["kernels"].setdefault(k, {})[key + "_per_launch"] = per_launch
         out["kernels"][k][key + "_total"] = per_launch * cnt[k]
         out["kernels"][k]["pmc_launches"] = cnt[k]
+# optional SQ passes (tools/profile_workload.sh with SQ=1): per-launch averages of the raw counters
+sq = {}
+for f in sorted(src.glob("pmc_sq*/pmc_counter_collection.csv")):
+    agg, cnt = {}, {}
+    for r in csv.DictReader(open(f)):
+        key = (r["Kernel_Name"], r["Counter_Name"])
+        agg[key] = agg.get(key, 0.0) + float(r["Counter_Value"])
+        cnt[key] = cnt.get(key, 0) + 1
+    for (k, c), v in agg.items():
+        sq.setdefault(k, {})[c] = v / cnt[(k, c)]
+for k, d in sq.items():
+    out["kernels"].setdefault(k, {})["sq_per_launch"] = d
+if sq:
+    lines.append("")
+    lines.append("SQ counters per launch (rocprofv3 --pmc, four separate passes):")
+    for k, d in sq.items():
+        if "k_sweep" in k or "k_post" in k:
+            lines.append("  " + k[:70])
+            lines.append("    " + "  ".join("%s=%.4g" % (c, v) for c, v in sorted(d.items())))
 lines.append("")
 lines.append("HBM traffic per launch from PMC (bytes; reads = 2*FETCH_SIZE*1024, writes = WRITE_SIZE*1024):")
 for k, v in out["kernels"].items():
