@@ -11,6 +11,7 @@
 // KmerPathTest.cpp); tolerance 1e-7 absolute as in reference tests/utils.cpp:9-11.
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <functional>
 #include <memory>
@@ -209,6 +210,61 @@ static void cpu_tests() {
 // ----------------------------------------------------------------------------------- GPU
 static const double R01 = 446.287102628;  // recombination rate that gives recombination probability 0.1
 
+static void viterbi_cpu_tests() {
+    // Viterbi alone needs no device (run_genotyping = false): host long double, reference src/hmm.cpp:112-173, 408-511
+    run("HMM phasing only (Viterbi on the host)", [] {
+        auto u1 = bi(2000, {0, 1}); kmer(u1, 10, {0}); kmer(u1, 10, {1});
+        auto u2 = bi(3000, {0, 1});
+        auto u3 = bi(4000, {0, 1}); kmer(u3, 10, {0}); kmer(u3, 9, {1});
+        ProbabilityTable probs(0, 1, 21, 0.0L);
+        probs.modify_probability(0, 10, CopyNumber(0.1, 0.9, 0.1));
+        probs.modify_probability(0, 9, CopyNumber(0.1, 0.8, 0.1));
+        vector<shared_ptr<UniqueKmers>> uks = {u1, u2, u3};
+        HMM hmm(&uks, &probs, false, true, 446.287102628, false, 0.25);
+        auto res = hmm.get_genotyping_result();
+        us h1, h2;
+        for (auto& r : res) { h1.push_back(r.get_haplotype().first); h2.push_back(r.get_haplotype().second); CHECK(r.contains_no_likelihoods()); }
+        CHECK((h1 == us{0, 0, 0} && h2 == us{1, 1, 1}) || (h1 == us{1, 1, 1} && h2 == us{0, 0, 0}));
+        CHECK(res[0].nr_unique_kmers() == 2 && res[1].nr_unique_kmers() == 0 && res[2].nr_unique_kmers() == 2);
+    });
+    run("HMM Viterbi: O(H^2) form == the reference's O(H^4) loop, checkpointed backtrace", [] {
+        // 45 paths: above the switch the max over previous states is taken from row / column / global maxima
+        // (exact, same tie rule); PG_VITERBI_NAIVE_MAX=100 runs the reference's loop on the same panel.
+        // 300 columns exercise several checkpoint blocks; many equal paths exercise the tie rule.
+        const size_t V = 300, H = 45;
+        unsigned long long x = 88172645463325252ull;
+        auto rnd = [&]() { x ^= x << 13; x ^= x >> 7; x ^= x << 17; return x; };
+        vector<shared_ptr<UniqueKmers>> a;
+        ProbabilityTable probs(6, 108, 54, 0.01L);
+        for (size_t v = 0; v < V; ++v) {
+            us p1;
+            for (size_t p = 0; p < H; ++p) p1.push_back((unsigned short)(rnd() % 3 == 0));
+            p1[v % H] = 1;
+            for (size_t p = 38; p < H; ++p) p1[p] = p1[p - 38];  // duplicated paths: exact ties
+            auto ua = bi(1000 + 700 * v, p1);
+            for (int q = 0; q < 4; ++q) {
+                kmer(ua, (unsigned short)(rnd() % 30), {0});
+                kmer(ua, (unsigned short)(rnd() % 30), {1});
+            }
+            ua->set_coverage(27);
+            a.push_back(ua);
+        }
+        for (int regime = 0; regime < 2; ++regime) {
+            const double rec = regime ? 446.287102628 : 1.26;
+            const long double N = regime ? 0.25L : 25000.0L;
+            unsetenv("PG_VITERBI_NAIVE_MAX");
+            HMM fast(&a, &probs, false, true, rec, false, N);
+            setenv("PG_VITERBI_NAIVE_MAX", "100", 1);
+            HMM naive(&a, &probs, false, true, rec, false, N);
+            unsetenv("PG_VITERBI_NAIVE_MAX");
+            auto ra = fast.get_genotyping_result(), rb = naive.get_genotyping_result();
+            size_t same = 0;
+            for (size_t v = 0; v < V; ++v) same += ra[v].get_haplotype() == rb[v].get_haplotype();
+            CHECK(same == V);
+        }
+    });
+}
+
 static void gpu_tests() {
     run("device visible", [] { CHECK(HMM::device_count() >= 1); });
     run("TransitionProbabilityComputer", [] {
@@ -345,13 +401,29 @@ static void gpu_tests() {
         vector<shared_ptr<UniqueKmers>> uks = {u};
         us nobody = {5, 6};
         CHECK_THROWS(HMM(&uks, &none, true, false, 1.26, false, 0.25, &nobody));  // column not covered by any paths
-        CHECK_THROWS(HMM(&uks, &none, true, true));                                // Viterbi is not on the device path
+    });
+    run("HMM genotyping + phasing in one constructor (no_unique_kmers3)", [] {
+        // reference tests/HMMTest.cpp:392-438: likelihoods AND the Viterbi haplotypes
+        auto u1 = bi(2000, {0, 1}); kmer(u1, 10, {0}); kmer(u1, 10, {1});
+        auto u2 = bi(3000, {0, 1});
+        auto u3 = bi(4000, {0, 1}); kmer(u3, 10, {0}); kmer(u3, 9, {1});
+        ProbabilityTable probs(0, 1, 21, 0.0L);
+        probs.modify_probability(0, 10, CopyNumber(0.1, 0.9, 0.1));
+        probs.modify_probability(0, 9, CopyNumber(0.1, 0.8, 0.1));
+        vector<shared_ptr<UniqueKmers>> uks = {u1, u2, u3};
+        HMM hmm(&uks, &probs, true, true, R01, false, 0.25);
+        auto res = hmm.get_genotyping_result();
+        CHECK(close_all(triples(res), {0.00264169937, 0.99471660125, 0.00264169937, 0.02552917716, 0.94894164567, 0.02552917716,
+                                       0.002961313333, 0.99407737333, 0.002961313333}));
+        us h1, h2;
+        for (auto& r : res) { h1.push_back(r.get_haplotype().first); h2.push_back(r.get_haplotype().second); }
+        CHECK((h1 == us{0, 0, 0} && h2 == us{1, 1, 1}) || (h1 == us{1, 1, 1} && h2 == us{0, 0, 0}));
     });
 }
 
 int main(int argc, char** argv) {
     const std::string mode = argc > 1 ? argv[1] : "cpu";
-    if (mode == "cpu") cpu_tests();
+    if (mode == "cpu") { cpu_tests(); viterbi_cpu_tests(); }
     else if (mode == "gpu") gpu_tests();
     else { std::printf("usage: test_host cpu|gpu\n"); return 2; }
     std::printf("%d checks, %d failed\n", g_checks, g_failed);
