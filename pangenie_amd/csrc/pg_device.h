@@ -132,6 +132,11 @@ struct DevContig {
     uint8_t*  wide;            // wide entries (see above)
     const uint32_t* wide_idx;  // [V]: byte offset / 16 of the entry of variant v, PG_WIDE_NONE if it has <= PG_AMAX alleles
     uint8_t*  vpair;           // [V][pg_pair_bytes(pair_n)]
+    // lean sweep (k_sweep_lean: HP = H = 64, every object biallelic): compact column records
+    // {c0, c1, c2, kappa, E'00, E'01, E'11, bits1} (64 B, read with scalar loads) and the flag
+    double*   frec;            // [V][8]
+    uint32_t  lean;            // 1: the store-only phases of this chain run on k_sweep_lean
+    uint32_t  pad4;
     double*   xbuf;            // [2][HP*HP] generic kernel scratch (forward role first)
     uint32_t* err;
     unsigned long long* prof;  // [64] in-kernel cycle counters (PG_DEBUG bit 3), profiling only

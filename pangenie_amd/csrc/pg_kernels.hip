@@ -29,6 +29,7 @@
 #include <hip/hip_runtime.h>
 #include <math.h>
 #include <stdint.h>
+#include <stdlib.h>
 
 #include <type_traits>
 
@@ -585,6 +586,17 @@ __global__ __launch_bounds__(256) void k_records(const DevContig* __restrict__ c
             val = (uint64_t)__double_as_longlong(cv);
         }
         dst[w] = val;
+    }
+    if (dc.lean && lane < 8) {
+        // compact record of the lean sweep: {c0, c1, c2, kappa, E'00, E'01, E'11, bits1}
+        const uint64_t* E = src + PG_REC_E / 8;
+        uint64_t val;
+        if (lane < 4) { const double cv = lane == 0 ? c0 : (lane == 1 ? c1 : (lane == 2 ? c2 : kappa)); val = (uint64_t)__double_as_longlong(cv); }
+        else if (lane == 4) val = E[0];
+        else if (lane == 5) val = E[1];
+        else if (lane == 6) val = E[PG_ESTRIDE + 1];
+        else val = src[PG_REC_BITS1 / 8];
+        ((uint64_t*)dc.frec)[(size_t)c * 8 + lane] = val;
     }
 }
 
@@ -1628,12 +1640,451 @@ __global__ __launch_bounds__((ChainCfg<HP, R>::TT)) void k_sweep(const DevContig
     extern __shared__ __attribute__((aligned(16))) unsigned char dyn_ring[];  // phase 2: kRingSlots column slots
     const DevContig& dc = contigs[blockIdx.x];
     if (dc.HP != (uint32_t)HP) return;
+    if (PHASE != 2 && dc.lean) return;  // store-only phases of all-biallelic H = 64 chains: k_sweep_lean
     // (written by k_compact: a vector load as far as the compiler knows — make the trip count, and
     // with it every column index, ring slot and address derived from it, wave-uniform again)
     const uint32_t C = (uint32_t)__builtin_amdgcn_readfirstlane((int)*dc.n_cols);
     if (C == 0) return;
     if (blockIdx.y == 0) forward_body<HP, R, PHASE>(dc, sh, C, dyn_ring, chunk);
     else backward_body<HP, R, VBUF, KEEPW, PHASE>(dc, sh, C, dyn_ring, chunk);
+}
+
+// ------------------------------------------------------------------------------------------
+//  k_sweep_lean : the store-only half-chains (phases 1 and 3) of chains whose every column is
+//  biallelic with H = HP = 64 (BASELINE.json configs[2], [3]) — the lone-chain regime, where the time of
+//  a chain is (columns) x (instructions per column) x (4 cycles: one wave per SIMD issues one
+//  instruction of ANY type every fourth cycle).  Same arithmetic and stored data as forward_body /
+//  backward_body; what is gone is instruction count:
+//    * no loader waves, no LDS record ring, no per-lane record decode: a column's constants
+//      {c0, c1, c2, kappa, E'00, E'01, E'11, bits1} are a 64-byte compact record (k_records) fetched with
+//      ONE scalar load a column ahead; everything wave-uniform stays in SGPRs and enters the VALU as
+//      a scalar operand.  Four waves on four SIMDs: the per-column barrier costs ~10 cycles instead of ~115.
+//    * the total S = sum over the 64 lanes: two fp64 MFMAs against a ones matrix (+ 3 adds) instead of
+//      six DPP steps (~26 instructions).  D = A x 1 sums the four 16-lane groups; the second product
+//      sums the sixteen rows (C/D layout of v_mfma_f64_16x16x4: row = (lane >> 4) + 4 reg, col = lane & 15).
+//      This is a reduction, not a contraction of the model: the recursion itself stays rank-structured.
+//    * row-allele selects by scalar-built lane masks (s_bfe_i64 of the row bits), stores with immediate
+//      offsets off two per-thread bases.
+// ------------------------------------------------------------------------------------------
+// timing experiments (tools/exp_lean.py): -DPG_LEANX=<mask> compiles one ingredient of the lean step out
+// (results are then WRONG; only the kernel time is of interest).  0 in the product.
+#ifndef PG_LEANX
+#define PG_LEANX 0
+#endif
+static constexpr unsigned kLX = PG_LEANX;
+// -DPG_LEANPROF: time stamps (s_memtime, forward role, every wave; wave 0 reports) at the seams of the lean
+// step, accumulated per segment into DevContig::prof[32..47] — tooling only (tools/prof_lean.py); each stamp
+// drains the LDS queue, so overlapping segments are measured serialised.
+#ifdef PG_LEANPROF
+#define LEAN_STAMP(i) do { const unsigned long long now_ = __builtin_amdgcn_s_memtime(); acc_[i] += now_ - last_; last_ = now_; } while (0)
+#define LEAN_DEP(v) asm volatile("" :: "v"(v))
+#else
+#define LEAN_STAMP(i) do { } while (0)
+#define LEAN_DEP(v) do { } while (0)
+#endif
+#define PG_LEAN_BLOCK 64  // column records per LDS block (one 16-byte piece per thread: 64 x 64 B = 256 x 16 B)
+template <int R>
+struct LeanShared {
+    static constexpr int NW = 64 / R;  // waves = row groups
+    double psum[2][NW][64];
+    double u[NW][64] __attribute__((aligned(16)));
+    double rec[2][PG_LEAN_BLOCK][8] __attribute__((aligned(16)));  // two blocks of compact records
+};
+struct FRec {  // compact column record (64 B)
+    double c0, c1, c2, kappa, E00, E01, E11;
+    unsigned long long bits1;
+};
+typedef double v4f64 __attribute__((ext_vector_type(4)));
+// Records reach the waves in BLOCKS of 64 columns: every thread fetches one 16-byte piece of the block
+// after next into a register (one global load per thread per 64 columns) and parks it in LDS a few
+// columns before the block is needed; a column's record is then four broadcast LDS reads, issued one
+// step ahead of use.  `rel` = distance of the record from the first one of this launch (ascending
+// columns forward, descending backward).
+// (Measured alternatives: scalar loads of the record — every LDS wait of the step then also waits out the
+// scalar load's memory latency, lgkmcnt being shared: 2300 cycles per column; records and the u_i kept
+// in registers and pulled out with v_readlane — ~17 cycles per v_readlane_b32: 2230 cycles per column.)
+struct LeanRecs {
+    const GAS char* base;   // frec
+    int64_t origin, C;      // column of rel 0, number of columns
+    int dir;                // +1 forward, -1 backward
+    uint32_t tid;
+    DEVI v2f64 fetch(uint32_t block) const {  // this thread's piece of block `block` (threads 0..255)
+        int64_t c = origin + (int64_t)dir * ((int64_t)block * PG_LEAN_BLOCK + ((tid & 255u) >> 2));
+        c = c < 0 ? 0 : (c >= C ? C - 1 : c);
+        return *(const GAS v2f64*)(base + (size_t)c * 64u + (tid & 3u) * 16u);
+    }
+    template <class SH>
+    DEVI void park(SH& sh, uint32_t block, v2f64 piece) const {
+        if (tid < 256u) ((v2f64*)&sh.rec[block & 1u][0][0])[tid] = piece;
+    }
+};
+template <class SH>
+DEVI FRec read_frec(const SH& sh, uint32_t rel /*uniform*/) {
+    const double* q = sh.rec[(rel / PG_LEAN_BLOCK) & 1u][rel % PG_LEAN_BLOCK];
+    FRec r;
+    r.c0 = q[0]; r.c1 = q[1]; r.c2 = q[2]; r.kappa = q[3]; r.E00 = q[4]; r.E01 = q[5]; r.E11 = q[6];
+    r.bits1 = (unsigned long long)__double_as_longlong(q[7]);
+    return r;
+}
+
+DEVI double wave_total_mfma(double v) {
+    const v4f64 z = {0.0, 0.0, 0.0, 0.0};
+    const v4f64 a = __builtin_amdgcn_mfma_f64_16x16x4f64(v, 1.0, z, 0, 0, 0);   // rows: sums over the four 16-lane groups
+    const double u = (a[0] + a[1]) + (a[2] + a[3]);                              // four of the sixteen rows per lane group
+    const v4f64 b = __builtin_amdgcn_mfma_f64_16x16x4f64(u, 1.0, z, 0, 0, 0);   // + over the four lane groups: the total, in every lane
+    return b[0];
+}
+// all-ones / all-zeros lane mask from bit k of a wave-uniform word, as a double-typed select
+DEVI double sel_by_bit(uint32_t bits /*uniform*/, int k, double if0, double if1) {
+    // 0 / ~0 from bit k on the scalar unit (one s_bfe_i32), then one bit-field insert per register half
+    const uint32_t m = (uint32_t)(((int32_t)(bits << (31 - k))) >> 31);
+    const uint32_t lo = ((uint32_t)__double2loint(if1) & m) | ((uint32_t)__double2loint(if0) & ~m);
+    const uint32_t hi = ((uint32_t)__double2hiint(if1) & m) | ((uint32_t)__double2hiint(if0) & ~m);
+    return __hiloint2double((int)hi, (int)lo);
+}
+
+// Per-column scalars (column scale mantissas, hand-over sums) of the lean kernel: one 8-byte store per
+// column measured ~200 cycles on the chain, so wave 0 collects the value of column t in lane t & 63 (one
+// compare + two selects) and writes 64 columns with ONE coalesced store.
+struct ColScalars {
+    double buf = 0.0;
+    unsigned long long valid = 0ull;  // uniform: lanes holding a value not yet written
+    DEVI void put(uint32_t lane, uint64_t t /*uniform*/, double v) {
+        if (lane == (uint32_t)(t & 63u)) buf = v;
+        valid |= 1ull << (t & 63u);
+    }
+    DEVI void flush(gdouble* arr, uint32_t lane, uint64_t t_any /*uniform: any column of the 64-block held*/) {
+        if ((valid >> lane) & 1ull) arr[(t_any & ~(uint64_t)63u) + lane] = buf;
+        valid = 0ull;
+    }
+};
+
+template <int R>
+DEVI double lean_colsum(const LeanShared<R>& sh, uint32_t pb, uint32_t lane) {
+    if constexpr (R == 16)
+        return (sh.psum[pb][0][lane] + sh.psum[pb][1][lane]) + (sh.psum[pb][2][lane] + sh.psum[pb][3][lane]);
+    else
+        return ((sh.psum[pb][0][lane] + sh.psum[pb][1][lane]) + (sh.psum[pb][2][lane] + sh.psum[pb][3][lane])) +
+               ((sh.psum[pb][4][lane] + sh.psum[pb][5][lane]) + (sh.psum[pb][6][lane] + sh.psum[pb][7][lane]));
+}
+
+template <int PHASE, int R>
+DEVI void lean_forward(const DevContig& dc, LeanShared<R>& sh, uint32_t C, uint32_t chunk) {
+    constexpr int HP = 64;
+    constexpr uint32_t RMASK = (1u << R) - 1u;
+    const uint32_t mid = C / 2, K = dc.chunk_cols;
+    uint32_t lo = PHASE == 1 ? 0u : mid, hi = PHASE == 1 ? mid : C;
+    if constexpr (PHASE == 3) {
+        const unsigned long long l = (unsigned long long)mid + (unsigned long long)chunk * K;
+        if (l >= C) return;
+        lo = (uint32_t)l;
+        hi = C - lo > K ? lo + K : C;
+    }
+    if (lo >= hi) return;
+    const uint32_t first = lo == 0 ? 1u : lo;
+    const uint32_t tid = threadIdx.x, lane = tid & 63u;
+    const uint32_t wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const uint32_t i0 = wave * R;
+    const size_t colsz = (size_t)HP * HP;
+    const double unif = 1.0 / 4096.0;
+    LeanRecs recs{(const GAS char*)dc.frec, (int64_t)first - 1, (int64_t)C, +1, tid};
+    recs.park(sh, 0, recs.fetch(0));
+    v2f64 piece = recs.fetch(1);
+    lds_barrier();
+    gdouble* fwd = (gdouble*)dc.fwd;
+    gdouble* fscale = (gdouble*)dc.fscale;
+    gu8* fallback = (gu8*)dc.fwd_fallback;
+    gdouble* wr = fwd;
+    gcdouble* resume = (gcdouble*)(fwd + (size_t)(lo > 0 ? lo - 1 : 0) * colsz);
+    if constexpr (PHASE == 3) {
+        gdouble* scr = (gdouble*)dc.scratch;
+        wr = scr + (size_t)((chunk & 1u) * 2u) * K * colsz - (size_t)lo * colsz;
+        if (chunk > 0) resume = (gcdouble*)(scr + ((size_t)(((chunk - 1u) & 1u) * 2u) * K + (K - 1u)) * colsz);
+    }
+    const size_t toff = (size_t)(i0 >> 1) * HP + lane;  // this thread's first row pair inside a column (in 16-byte units)
+    auto emis = [&](const FRec& r, double& eA, double& eB) {  // e(i, j) = row bit ? eB : eA for this lane's column allele
+        const bool aj = (r.bits1 >> lane) & 1ull;
+        eA = aj ? r.E01 : r.E00;
+        eB = aj ? r.E11 : r.E01;
+    };
+    auto store_col = [&](uint32_t c, const double (&v)[R]) {
+        gdouble2* dst = (gdouble2*)(wr + (size_t)c * colsz) + toff;
+#pragma unroll
+        for (int k = 0; k < R; k += 2) dst[(size_t)(k >> 1) * HP] = v2f64{v[k], v[k + 1]};
+    };
+    auto flag_uniform = [&](uint32_t cprev) {
+        if (cprev >= lo) {
+            double xu[R];
+#pragma unroll
+            for (int k = 0; k < R; ++k) xu[k] = unif;
+            store_col(cprev, xu);
+        }
+        if (wave == 0) fallback[cprev] = 1;
+    };
+
+    ColScalars fsc;
+    double x[R];
+    {
+        const FRec r0 = read_frec(sh, 0);
+        double eA, eB;
+        emis(r0, eA, eB);
+        const uint32_t rb = (uint32_t)__builtin_amdgcn_readfirstlane((int)((uint32_t)(r0.bits1 >> i0) & RMASK));
+        double part = 0.0;
+        if (lo == 0) {
+            const double P0 = ldexp(1.0, PG_BIAS_F);
+            double pz[R];
+#pragma unroll
+            for (int k = 0; k < R; ++k) { pz[k] = P0; x[k] = sel_by_bit(rb, k, eA, eB) * P0; part += x[k]; }
+            store_col(0, pz);
+            if (wave == 0) fscale[0] = 1.0;
+        } else {
+            gcdouble2* src = (gcdouble2*)resume + toff;
+#pragma unroll
+            for (int k = 0; k < R; k += 2) { const v2f64 t = src[(size_t)(k >> 1) * HP]; x[k] = t.x; x[k + 1] = t.y; }
+            if (!fallback[lo - 1]) {
+#pragma unroll
+                for (int k = 0; k < R; ++k) x[k] *= sel_by_bit(rb, k, eA, eB);
+            }
+#pragma unroll
+            for (int k = 0; k < R; ++k) part += x[k];
+        }
+        sh.psum[(first - 1) & 1u][wave][lane] = part;
+    }
+    FRec cur = read_frec(sh, 1);
+    lds_barrier();
+#ifdef PG_LEANPROF
+    unsigned long long acc_[8] = {0, 0, 0, 0, 0, 0, 0, 0}, last_ = __builtin_amdgcn_s_memtime();
+#endif
+    for (uint32_t t = first; t < hi; ++t) {
+        const uint32_t n = t - first;                 // step number: reads the record with rel = n + 2
+        const FRec nxt = (kLX & 64u) ? cur : read_frec(sh, n + 2u);  // four broadcast LDS reads, a whole step ahead of use
+        if (((n + 4u) % PG_LEAN_BLOCK) == 0u) {       // (uniform) a few columns before the next block is needed
+            const uint32_t blk = (n + 4u) / PG_LEAN_BLOCK;
+            recs.park(sh, blk, piece);
+            piece = recs.fetch(blk + 1u);
+        }
+        const uint32_t pb = (t - 1) & 1u;
+        const double Cj = (kLX & 8u) ? x[0] * 64.0 : lean_colsum<R>(sh, pb, lane);
+        LEAN_DEP(Cj); LEAN_STAMP(0);   // 0: record reads issued, column sums read and added
+        const double ucol = cur.c1 * Cj;
+        double ui[R];
+        if (kLX & 4u) {
+#pragma unroll
+            for (int k = 0; k < R; ++k) ui[k] = ucol;
+        } else {
+            sh.u[wave][lane] = ucol;   // wave-private row: the u_i of this wave's rows come back as broadcasts
+            const double* row = &sh.u[wave][i0];
+#pragma unroll
+            for (int k = 0; k < R; ++k) ui[k] = row[k];
+        }
+        __builtin_amdgcn_sched_barrier(0);  // the LDS round trip is in flight before the reduction starts
+        LEAN_DEP(ui[R - 1]); LEAN_STAMP(1);   // 1: u round trip (serialised by the stamp)
+        double S = (kLX & 2u) ? Cj * 64.0 : wave_total_mfma(Cj);
+        LEAN_DEP(S); LEAN_STAMP(2);   // 2: MFMA total
+        double uj = fma(cur.c2, S, ucol);
+        double c0 = cur.c0;
+        if (__builtin_expect(!(S > 0.0), 0)) {
+            // column t-1 summed to zero: the uniform column takes its place (hmm.cpp:253-267), see forward_body
+            flag_uniform(t - 1);
+            const double Cu = 64.0 * unif;
+            S = 1.0;
+            uj = fma(cur.c0, unif, fma(cur.c2, 1.0, 2.0 * cur.c1 * Cu));
+            c0 = 0.0;
+        }
+        int es = exponent_of(S) - PG_BIAS_F;
+        es = es < -900 ? -900 : es;
+        const double m = ldexp(S, -es - PG_BIAS_F);
+        const double sc = ldexp(1.0, -es), c0s = ldexp(c0, -es), ujs = ldexp(uj, -es);
+        double eA, eB;
+        emis(cur, eA, eB);
+        const uint32_t rb = (uint32_t)__builtin_amdgcn_readfirstlane((int)((uint32_t)(cur.bits1 >> i0) & RMASK));
+        gdouble2* dst = (gdouble2*)(wr + (size_t)t * colsz) + toff;
+        double part = 0.0, pprev = 0.0;
+        LEAN_DEP(ujs); LEAN_DEP(eA); LEAN_STAMP(3);   // 3: scale, constants, emission pair
+#pragma unroll
+        for (int k = 0; k < R; ++k) {
+            const double pk = (kLX & 16u) ? x[k] + ujs : fma(c0s, x[k], fma(ui[k], sc, ujs));
+            x[k] = (kLX & 16u) ? pk : pk * sel_by_bit(rb, k, eA, eB);
+            part += (kLX & 16u) ? (k == 0 ? x[0] + ui[k] : 0.0) : x[k];
+            if (k & 1) { if (!(kLX & 1u)) dst[(size_t)(k >> 1) * HP] = v2f64{pprev, pk}; __builtin_amdgcn_sched_barrier(0); }
+            else pprev = pk;
+        }
+        LEAN_DEP(part); LEAN_STAMP(4);   // 4: the 16 states + their stores
+        sh.psum[t & 1u][wave][lane] = part;
+        if (!(kLX & 128u)) {
+            if (wave == 0) {  // (scalar branch)
+                fsc.put(lane, t, m);
+                if ((t & 63u) == 63u) fsc.flush(fscale, lane, t);
+            }
+        }
+        cur = nxt;
+        LEAN_STAMP(5);   // 5: partial sums parked, scalars collected
+        if (!(kLX & 32u)) lds_barrier();
+        LEAN_STAMP(6);   // 6: barrier
+    }
+#ifdef PG_LEANPROF
+    if (tid == 0) { for (int q = 0; q < 7; ++q) dc.prof[32 + q] = acc_[q]; dc.prof[39] = hi - first; }
+#endif
+    if (wave == 0 && fsc.valid) fsc.flush(fscale, lane, hi - 1);
+    {   // the last column of this phase may itself have summed to zero
+        const uint32_t pb = (hi - 1) & 1u;
+        const double Cj = lean_colsum<R>(sh, pb, lane);
+        if (!(wave_total_mfma(Cj) > 0.0)) flag_uniform(hi - 1);
+    }
+}
+
+template <int PHASE, int R>
+DEVI void lean_backward(const DevContig& dc, LeanShared<R>& sh, uint32_t C, uint32_t chunk) {
+    constexpr int HP = 64;
+    constexpr uint32_t RMASK = (1u << R) - 1u;
+    const int64_t mid = C / 2, K = dc.chunk_cols;
+    int64_t top = PHASE == 1 ? (int64_t)C - 1 : mid - 1;
+    int64_t bot = PHASE == 1 ? mid : 0;
+    if constexpr (PHASE == 3) {
+        top = mid - 1 - (int64_t)chunk * K;
+        if (top < 0) return;
+        bot = top - K + 1 > 0 ? top - K + 1 : 0;
+    }
+    if (top < bot) return;
+    const int64_t t0 = PHASE == 1 ? top - 1 : top;
+    const uint32_t tid = threadIdx.x, lane = tid & 63u;
+    const uint32_t wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const uint32_t i0 = wave * R;
+    const size_t colsz = (size_t)HP * HP;
+    const double unif = 1.0 / 4096.0;
+    LeanRecs recs{(const GAS char*)dc.frec, t0 + 1, (int64_t)C, -1, tid};
+    recs.park(sh, 0, recs.fetch(0));
+    v2f64 piece = recs.fetch(1);
+    lds_barrier();
+    gdouble* cols = (gdouble*)dc.fwd;
+    gdouble* bscale = (gdouble*)dc.bscale;
+    gdouble* bsum = (gdouble*)dc.bsum;
+    gdouble* wr = cols;
+    gcdouble* resume = (gcdouble*)(cols + (size_t)(top + 1 < (int64_t)C ? top + 1 : top) * colsz);
+    if constexpr (PHASE == 3) {
+        gdouble* scr = (gdouble*)dc.scratch;
+        wr = scr + (size_t)((chunk & 1u) * 2u + 1u) * (size_t)K * colsz - (size_t)bot * colsz;
+        if (chunk > 0) resume = (gcdouble*)(scr + (size_t)(((chunk - 1u) & 1u) * 2u + 1u) * (size_t)K * colsz);
+    }
+    const size_t toff = (size_t)(i0 >> 1) * HP + lane;
+    auto emis = [&](const FRec& r, double& eA, double& eB) {
+        const bool aj = (r.bits1 >> lane) & 1ull;
+        eA = aj ? r.E01 : r.E00;
+        eB = aj ? r.E11 : r.E01;
+    };
+    auto store_col = [&](int64_t c, const double (&v)[R]) {
+        gdouble2* dst = (gdouble2*)(wr + (size_t)c * colsz) + toff;
+#pragma unroll
+        for (int k = 0; k < R; k += 2) dst[(size_t)(k >> 1) * HP] = v2f64{v[k], v[k + 1]};
+    };
+
+    ColScalars bsc, bsm;
+    double w[R], Sy;
+    FRec cur = read_frec(sh, 0);  // record t0+1: constants of the gap t0 -> t0+1, emission of column t0+1
+    {
+        double y[R];
+        if constexpr (PHASE == 1) {
+            // column C-1: beta~ = 1 (hmm.cpp:356-358), stored at the backward bias
+            const double B0 = ldexp(1.0, PG_BIAS_B);
+#pragma unroll
+            for (int k = 0; k < R; ++k) y[k] = B0;
+            Sy = 4096.0 * B0;
+            store_col(top, y);
+            if (wave == 0) { bscale[top] = 1.0; bsum[top] = Sy; }
+        } else {
+            gcdouble2* src = (gcdouble2*)resume + toff;
+#pragma unroll
+            for (int k = 0; k < R; k += 2) { const v2f64 t = src[(size_t)(k >> 1) * HP]; y[k] = t.x; y[k + 1] = t.y; }
+            Sy = bsum[top + 1];
+            if (!(Sy > 0.0)) {  // resuming behind an all-zero column: uniform (hmm.cpp:374-380)
+#pragma unroll
+                for (int k = 0; k < R; ++k) y[k] = unif;
+                Sy = 1.0;
+            }
+        }
+        double eA, eB;
+        emis(cur, eA, eB);
+        const uint32_t rb = (uint32_t)__builtin_amdgcn_readfirstlane((int)((uint32_t)(cur.bits1 >> i0) & RMASK));
+        double part = 0.0;
+#pragma unroll
+        for (int k = 0; k < R; ++k) { w[k] = y[k] * sel_by_bit(rb, k, eA, eB); part += w[k]; }
+        sh.psum[(uint32_t)t0 & 1u][wave][lane] = part;
+    }
+    for (int64_t t = t0; t >= bot; --t) {
+        const uint32_t n = (uint32_t)(t0 - t);        // step number: reads the record with rel = n + 1 (column t)
+        const FRec nxt = (kLX & 64u) ? cur : read_frec(sh, n + 1u);  // emission of column t (this step's w), constants of the next step
+        if (((n + 4u) % PG_LEAN_BLOCK) == 0u) {
+            const uint32_t blk = (n + 4u) / PG_LEAN_BLOCK;
+            recs.park(sh, blk, piece);
+            piece = recs.fetch(blk + 1u);
+        }
+        int es = exponent_of(Sy) - PG_BIAS_B;
+        es = es < -900 ? -900 : es;
+        const double m = ldexp(Sy, -es - PG_BIAS_B);
+        if (!(kLX & 128u)) { if (wave == 0) bsc.put(lane, (uint64_t)t, m); }
+        const double k0 = ldexp(cur.c0, -es), k1 = ldexp(cur.c1, -es), k2 = ldexp(cur.c2, -es), kap = ldexp(cur.kappa, -es);
+        if (!(kLX & 32u)) lds_barrier();
+        const uint32_t pb = (uint32_t)t & 1u;
+        const double Cj = (kLX & 8u) ? w[0] * 64.0 : lean_colsum<R>(sh, pb, lane);
+        const double ucol = k1 * Cj;
+        double ui[R];
+        if (kLX & 4u) {
+#pragma unroll
+            for (int k = 0; k < R; ++k) ui[k] = ucol;
+        } else {
+            sh.u[wave][lane] = ucol;
+            const double* row = &sh.u[wave][i0];
+#pragma unroll
+            for (int k = 0; k < R; ++k) ui[k] = row[k];
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        const double Sw = (kLX & 2u) ? Cj * 64.0 : wave_total_mfma(Cj);
+        const double uj = fma(k2, Sw, ucol);
+        const double Snew = kap * Sw;  // = sum(beta'_t)
+        double eA, eB;
+        emis(nxt, eA, eB);
+        const uint32_t rb = (uint32_t)__builtin_amdgcn_readfirstlane((int)((uint32_t)(nxt.bits1 >> i0) & RMASK));
+        gdouble2* dst = (gdouble2*)(wr + (size_t)t * colsz) + toff;
+        double part = 0.0;
+        if (__builtin_expect(!(Snew > 0.0), 0)) {
+            // beta~_t is all zero: its own posteriors are 0, the next step starts from the uniform column
+            double y[R];
+#pragma unroll
+            for (int k = 0; k < R; ++k) { y[k] = 0.0; w[k] = unif * sel_by_bit(rb, k, eA, eB); part += w[k]; }
+            store_col(t, y);
+        } else {
+            double yprev = 0.0;
+#pragma unroll
+            for (int k = 0; k < R; ++k) {
+                const double yk = (kLX & 16u) ? w[k] + uj : fma(k0, w[k], ui[k] + uj);  // beta'_t
+                w[k] = (kLX & 16u) ? yk : yk * sel_by_bit(rb, k, eA, eB);
+                part += (kLX & 16u) ? (k == 0 ? w[0] + ui[k] : 0.0) : w[k];
+                if (k & 1) { if (!(kLX & 1u)) dst[(size_t)(k >> 1) * HP] = v2f64{yprev, yk}; __builtin_amdgcn_sched_barrier(0); }
+                else yprev = yk;
+            }
+        }
+        sh.psum[(uint32_t)(t - 1) & 1u][wave][lane] = part;
+        if (!(kLX & 128u)) {
+            if (wave == 0) {
+                bsm.put(lane, (uint64_t)t, Snew);
+                if (((uint64_t)t & 63u) == 0u) { bsc.flush(bscale, lane, (uint64_t)t); bsm.flush(bsum, lane, (uint64_t)t); }
+            }
+        }
+        Sy = Snew > 0.0 ? Snew : 1.0;
+        cur = nxt;
+    }
+    if (wave == 0 && bsc.valid) { bsc.flush(bscale, lane, (uint64_t)bot); bsm.flush(bsum, lane, (uint64_t)bot); }
+}
+
+template <int PHASE, int R>
+__global__ __launch_bounds__((64 * 64 / R)) void k_sweep_lean(const DevContig* __restrict__ contigs, uint32_t chunk) {
+    __shared__ LeanShared<R> sh;
+    const DevContig& dc = contigs[blockIdx.x];
+    if (!dc.lean) return;
+    const uint32_t C = (uint32_t)__builtin_amdgcn_readfirstlane((int)*dc.n_cols);
+    if (C == 0) return;
+    if (blockIdx.y == 0) lean_forward<PHASE, R>(dc, sh, C, chunk);
+    else lean_backward<PHASE, R>(dc, sh, C, chunk);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -2264,6 +2715,11 @@ static void launch_sweep(const DevContig* d_contigs, uint32_t n_contigs, uint32_
     if (hp_mask & 4u) launch_one<64, 16, 1, true, PHASE>(d_contigs, n_contigs, chunk, s);
     if (hp_mask & 8u) launch_one<128, 32, 1, false, PHASE>(d_contigs, n_contigs, chunk, s);
     if constexpr (PHASE != 2) {
+        if (hp_mask & 64u) {  // bit 6: the job has lean chains (all-biallelic, H = HP = 64)
+            static const int lean_r = [] { const char* e = getenv("PG_LEAN_R"); return e ? atoi(e) : 16; }();
+            if (lean_r == 8) hipLaunchKernelGGL((k_sweep_lean<PHASE, 8>), dim3(n_contigs, 2), dim3(512), 0, s, d_contigs, chunk);
+            else hipLaunchKernelGGL((k_sweep_lean<PHASE, 16>), dim3(n_contigs, 2), dim3(256), 0, s, d_contigs, chunk);
+        }
         // bit 4: contigs with HP >= 256; bit 5: (forced) the generic kernel for every HP >= 64
         if (hp_mask & 48u)
             hipLaunchKernelGGL(k_sweep_generic<PHASE>, dim3(n_contigs, 2), dim3(PG_GEN_THREADS), 0, s, d_contigs, chunk,

@@ -203,6 +203,7 @@ namespace {
 
 struct IndexHost {   // one index contig
     uint32_t V = 0, H = 0, HP = 0, T = 0, RB = 0, part_slots = 2, pair_n = 1;
+    bool lean = false;  // every object biallelic and H = HP = 64: the store-only phases run on k_sweep_lean
     uint32_t sumK = 0, sumA = 0;
     uint64_t n_lik = 0, wide_bytes = 0;
     std::vector<uint16_t> n_kmers;   // [V] K of every variant
@@ -444,6 +445,8 @@ int job_build(int device, uint32_t n_index, const pg_contig_batch* batches, cons
     job->index.resize(n_index);
     bool wide_candidates = false, generic_needed = false;
     uint32_t max_v = 0;
+    bool lean_ok = true, force_generic = false;
+    if (const char* k = getenv("PG_SWEEP_KERNEL")) { force_generic = !strcmp(k, "generic"); lean_ok = strcmp(k, "general") != 0 && !force_generic; }
     for (uint32_t i = 0; i < n_index; ++i) {
         const pg_contig_batch& b = batches[i];
         IndexHost& x = job->index[i];
@@ -481,13 +484,12 @@ int job_build(int device, uint32_t n_index, const pg_contig_batch* batches, cons
             wide_candidates = true;
         }
         if (x.HP >= 256) generic_needed = true;
+        x.lean = lean_ok && x.HP == 64 && x.H == 64 && maxA == 2 && x.V > 0;
         if (x.V > max_v) max_v = x.V;
     }
     job->max_v = max_v;
 
     // ---- sweep mode ------------------------------------------------------------------------
-    bool force_generic = false;
-    if (const char* k = getenv("PG_SWEEP_KERNEL")) force_generic = !strcmp(k, "generic");
     {
         size_t per_col = 0;  // scratch bytes per chunk column over all chains (2 buffers x 2 roles)
         for (const ChainSpec& sp : specs) { const IndexHost& x = job->index[sp.index]; per_col += (size_t)4 * x.HP * x.HP * sizeof(double); }
@@ -522,7 +524,7 @@ int job_build(int device, uint32_t n_index, const pg_contig_batch* batches, cons
     job->chains.resize(n_chains);
     size_t off = 0;
     auto take = [&](size_t bytes, size_t al = 256) { off = align_up(off, al); size_t o = off; off += (bytes ? bytes : 8); return o; };
-    struct Plan { size_t scratch, wide, vpair, xbuf, prof, fback, fscale, bscale, bsum, vrec, cvar, colrec, fwd, part, kept, apres; };
+    struct Plan { size_t frec, scratch, wide, vpair, xbuf, prof, fback, fscale, bscale, bsum, vrec, cvar, colrec, fwd, part, kept, apres; };
     std::vector<Plan> plan(n_chains);
     const size_t o_contigs = take(sizeof(DevContig) * n_chains);
     // zeroed-every-run block: n_cols, err, per chain kept / fallback flags / profile counters / allele_present,
@@ -573,6 +575,8 @@ int job_build(int device, uint32_t n_index, const pg_contig_batch* batches, cons
         p.wide = take(x.wide_bytes);
         p.vpair = take((size_t)x.V * pg_pair_bytes(x.pair_n));
         p.xbuf = take((x.HP >= 256 || (force_generic && x.HP >= 64)) ? (size_t)2 * x.HP * x.HP * sizeof(double) : 0);
+        p.frec = take(x.lean ? (size_t)x.V * 64 : 0);
+        if (x.lean) job->hp_mask |= 64u;
         p.fscale = take((size_t)x.V * sizeof(double));
         p.bscale = take((size_t)x.V * sizeof(double));
         p.bsum = take((size_t)x.V * sizeof(double));
@@ -643,6 +647,7 @@ int job_build(int device, uint32_t n_index, const pg_contig_batch* batches, cons
         d.scratch = (double*)(A + p.scratch); d.chunk_cols = job->chunk_cols;
         d.wide = A + p.wide; d.wide_idx = x.wide_bytes ? (const uint32_t*)(A + x.o_widx) : nullptr;
         d.vpair = A + p.vpair; d.xbuf = (double*)(A + p.xbuf);
+        d.frec = (double*)(A + p.frec); d.lean = x.lean ? 1u : 0u;
         ch.d = d;
     }
     if ((he = hipMemcpyAsync(job->d_contigs, hd.data(), sizeof(DevContig) * n_chains, hipMemcpyHostToDevice, job->stream)) != hipSuccess ||

@@ -313,6 +313,34 @@ def test_generic_kernel_cross_checks_register_kernels(H, orc, monkeypatch):
     assert float(np.where(den > 0, np.abs(a - c) / np.where(den > 0, den, 1), 0).max()) < 1e-11
 
 
+@pytest.mark.parametrize("K", [1, 2, 7, 64, 4096])
+def test_lean_kernel_biallelic_h64_vs_oracle_and_general(K, orc, monkeypatch):
+    """All-biallelic H = 64 chains run their store-only phases on k_sweep_lean (scalar-loaded compact
+    records, MFMA totals).  Unregularised table: forward columns that fall back to uniform and all-zero
+    backward columns, on, before and behind chunk boundaries.  The lean and the general kernel must both
+    match the oracle and agree with each other to fp64 rounding."""
+    monkeypatch.setenv("PG_SWEEP_MODE", "chunked")
+    monkeypatch.setenv("PG_CHUNK_COLS", str(K))
+    for seed, reg in ((5, 0.0), (6, 0.01)):
+        args = (6, 108, 54, reg)
+        b = synthetic_panel(330, 64, 20, seed=seed)
+        if reg == 0.0:
+            b.kmer_count[::3] = 0
+            b.kmer_count[1::17] = 60000
+        t, p = hmm.ProbabilityTable(*args), hmm.make_params(1.26, False, 1e-5)
+        monkeypatch.delenv("PG_SWEEP_KERNEL", raising=False)
+        lean = hmm.genotype_contig(b, t, p)
+        monkeypatch.setenv("PG_SWEEP_KERNEL", "general")
+        gen = hmm.genotype_contig(b, t, p)
+        monkeypatch.delenv("PG_SWEEP_KERNEL", raising=False)
+        ref = orc.genotype_contig(b, orc.OracleTable(*args), orc.make_params(1.26, False, 1e-5))
+        assert_parity(b, lean, ref)
+        assert_parity(b, gen, ref)
+        a, c = lean.likelihoods_ld(), gen.likelihoods_ld()
+        den = np.maximum(np.abs(a), np.abs(c))
+        assert float(np.where(den > 0, np.abs(a - c) / np.where(den > 0, den, 1), 0).max()) < 1e-11
+
+
 def test_limits_are_reported_not_silently_wrong():
     b = synthetic_panel(4, 1100, 10, seed=1)
     with pytest.raises(hmm.PanGenieError) as e:
