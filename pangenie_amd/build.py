@@ -28,14 +28,17 @@ def hipcc_path() -> str:
     raise RuntimeError("hipcc not found")
 
 
-def build_hip(force: bool = False, verbose: bool = False, out: Path | None = None, defines=()) -> Path:
+def build_hip(force: bool = False, verbose: bool = False, out: Path | None = None, defines=(), extra=()) -> Path:
     """hipcc --offload-arch=gfx950 -> pangenie_amd/csrc/libpangenie_hmm.so (in-tree).
     `out`/`defines` build a variant elsewhere (tools/prof_chain.py: -DPG_CHAIN_PROF)."""
     target = Path(out) if out else HIP_LIB
     if force or _stale(target, HIP_DEPS):
         target.parent.mkdir(parents=True, exist_ok=True)
         cmd = [hipcc_path(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
-               "-Wno-unused-value", "-Wno-unused-result", *[f"-D{d}" for d in defines],
+               "-Wno-unused-value", "-Wno-unused-result",
+               # fp64 MFMA results straight into VGPRs (the wave totals of the lean sweep): no v_accvgpr_read round trip
+               "-mllvm", "-amdgpu-mfma-vgpr-form",
+               *[f"-D{d}" for d in defines], *extra,
                *map(str, HIP_SOURCES), "-o", str(target)]
         r = subprocess.run(cmd, capture_output=True, text=True)
         if verbose or r.returncode:

@@ -1672,6 +1672,10 @@ __global__ __launch_bounds__((ChainCfg<HP, R>::TT)) void k_sweep(const DevContig
 #define PG_LEANX 0
 #endif
 static constexpr unsigned kLX = PG_LEANX;
+#ifndef PG_LEANV
+#define PG_LEANV 0
+#endif
+static constexpr unsigned kLV = PG_LEANV;  // codegen variants under test (tools/exp_lean.py)
 // -DPG_LEANPROF: time stamps (s_memtime, forward role, every wave; wave 0 reports) at the seams of the lean
 // step, accumulated per segment into DevContig::prof[32..47] — tooling only (tools/prof_lean.py); each stamp
 // drains the LDS queue, so overlapping segments are measured serialised.
@@ -1883,7 +1887,8 @@ DEVI void lean_forward(const DevContig& dc, LeanShared<R>& sh, uint32_t C, uint3
         LEAN_DEP(S); LEAN_STAMP(2);   // 2: MFMA total
         double uj = fma(cur.c2, S, ucol);
         double c0 = cur.c0;
-        if (__builtin_expect(!(S > 0.0), 0)) {
+        const bool s_zero = (kLV & 1u) ? (__builtin_amdgcn_readfirstlane(S > 0.0 ? 1 : 0) == 0) : !(S > 0.0);
+        if (__builtin_expect(s_zero, 0)) {
             // column t-1 summed to zero: the uniform column takes its place (hmm.cpp:253-267), see forward_body
             flag_uniform(t - 1);
             const double Cu = 64.0 * unif;
@@ -1912,7 +1917,10 @@ DEVI void lean_forward(const DevContig& dc, LeanShared<R>& sh, uint32_t C, uint3
         LEAN_DEP(part); LEAN_STAMP(4);   // 4: the 16 states + their stores
         sh.psum[t & 1u][wave][lane] = part;
         if (!(kLX & 128u)) {
-            if (wave == 0) {  // (scalar branch)
+            if (kLV & 2u) {
+                fsc.put(lane, t, m);
+                if ((t & 63u) == 63u) { if (wave == 0) fsc.flush(fscale, lane, t); else fsc.valid = 0ull; }
+            } else if (wave == 0) {  // (scalar branch)
                 fsc.put(lane, t, m);
                 if ((t & 63u) == 63u) fsc.flush(fscale, lane, t);
             }
@@ -2021,7 +2029,7 @@ DEVI void lean_backward(const DevContig& dc, LeanShared<R>& sh, uint32_t C, uint
         int es = exponent_of(Sy) - PG_BIAS_B;
         es = es < -900 ? -900 : es;
         const double m = ldexp(Sy, -es - PG_BIAS_B);
-        if (!(kLX & 128u)) { if (wave == 0) bsc.put(lane, (uint64_t)t, m); }
+        if (!(kLX & 128u)) { if ((kLV & 2u) || wave == 0) bsc.put(lane, (uint64_t)t, m); }
         const double k0 = ldexp(cur.c0, -es), k1 = ldexp(cur.c1, -es), k2 = ldexp(cur.c2, -es), kap = ldexp(cur.kappa, -es);
         if (!(kLX & 32u)) lds_barrier();
         const uint32_t pb = (uint32_t)t & 1u;
@@ -2046,7 +2054,8 @@ DEVI void lean_backward(const DevContig& dc, LeanShared<R>& sh, uint32_t C, uint
         const uint32_t rb = (uint32_t)__builtin_amdgcn_readfirstlane((int)((uint32_t)(nxt.bits1 >> i0) & RMASK));
         gdouble2* dst = (gdouble2*)(wr + (size_t)t * colsz) + toff;
         double part = 0.0;
-        if (__builtin_expect(!(Snew > 0.0), 0)) {
+        const bool b_zero = (kLV & 1u) ? (__builtin_amdgcn_readfirstlane(Snew > 0.0 ? 1 : 0) == 0) : !(Snew > 0.0);
+        if (__builtin_expect(b_zero, 0)) {
             // beta~_t is all zero: its own posteriors are 0, the next step starts from the uniform column
             double y[R];
 #pragma unroll
@@ -2065,9 +2074,12 @@ DEVI void lean_backward(const DevContig& dc, LeanShared<R>& sh, uint32_t C, uint
         }
         sh.psum[(uint32_t)(t - 1) & 1u][wave][lane] = part;
         if (!(kLX & 128u)) {
-            if (wave == 0) {
+            if ((kLV & 2u) || wave == 0) {
                 bsm.put(lane, (uint64_t)t, Snew);
-                if (((uint64_t)t & 63u) == 0u) { bsc.flush(bscale, lane, (uint64_t)t); bsm.flush(bsum, lane, (uint64_t)t); }
+                if (((uint64_t)t & 63u) == 0u) {
+                    if (wave == 0) { bsc.flush(bscale, lane, (uint64_t)t); bsm.flush(bsum, lane, (uint64_t)t); }
+                    else { bsc.valid = 0ull; bsm.valid = 0ull; }
+                }
             }
         }
         Sy = Snew > 0.0 ? Snew : 1.0;
@@ -2083,8 +2095,13 @@ __global__ __launch_bounds__((64 * 64 / R)) void k_sweep_lean(const DevContig* _
     if (!dc.lean) return;
     const uint32_t C = (uint32_t)__builtin_amdgcn_readfirstlane((int)*dc.n_cols);
     if (C == 0) return;
+    const unsigned long long t_begin = kChainProf ? __builtin_amdgcn_s_memtime() : 0ull;
     if (blockIdx.y == 0) lean_forward<PHASE, R>(dc, sh, C, chunk);
     else lean_backward<PHASE, R>(dc, sh, C, chunk);
+    if (kChainProf && threadIdx.x == 0) {  // -DPG_CHAIN_PROF builds only: cycles of this role's launch (last chunk wins)
+        unsigned long long* o = dc.prof + (blockIdx.y == 0 ? 0 : 16) + (PHASE == 1 ? 0 : 8);
+        o[0] = __builtin_amdgcn_s_memtime() - t_begin;
+    }
 }
 
 // ------------------------------------------------------------------------------------------
@@ -2516,13 +2533,11 @@ __global__ __launch_bounds__(256) void k_bins(const DevContig* __restrict__ cont
 // ------------------------------------------------------------------------------------------
 #define PG_POST_WAVES 16
 #define PG_POST_PLACEMENT_LDS (152 * 1024)
-__global__ __launch_bounds__(64 * PG_POST_WAVES) void k_post(const DevContig* __restrict__ contigs, uint32_t chunk) {
-    __shared__ double s_bins[PG_POST_WAVES][PG_AMAX * (PG_AMAX + 1) / 2];
-    const DevContig& dc = contigs[blockIdx.y];
-    const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+// one column (index idx inside the chunk: forward role first) by one wave
+DEVI void post_column(const DevContig& dc, uint32_t chunk, uint32_t idx, uint32_t wave, uint32_t lane,
+                      double (&s_bins)[PG_POST_WAVES][PG_AMAX * (PG_AMAX + 1) / 2]) {
     const uint32_t C = *dc.n_cols;
     const uint32_t K = dc.chunk_cols, HP = dc.HP;
-    const uint32_t idx = blockIdx.x * PG_POST_WAVES + wave;
     if (C == 0 || idx >= 2u * K) return;
     const uint32_t mid = C / 2;
     const size_t colsz = (size_t)HP * HP;
@@ -2591,18 +2606,27 @@ __global__ __launch_bounds__(64 * PG_POST_WAVES) void k_post(const DevContig* __
         for (uint32_t ipb = ip0; ipb < HP / 2; ipb += ipstep * UN) {
             v2f64 av[UN], bv[UN];
 #pragma unroll
+            // Columns are symmetric (to rounding), and a genotype bin takes (i,j) and (j,i) alike: only the
+            // upper triangle j >= i is read — a lane skips the row pairs below its column — and off-diagonal
+            // states count twice.  Halves what this kernel pulls out of HBM next to the running chains.
             for (int u = 0; u < UN; ++u) {
                 const uint32_t ip = ipb + u * ipstep;
-                const size_t e = (size_t)(ip < HP / 2 ? ip : ip0) * HP + j;
-                av[u] = A2[e]; bv[u] = B2[e];
+                av[u] = v2f64{0.0, 0.0}; bv[u] = v2f64{0.0, 0.0};
+                if (ip < HP / 2 && j >= 2u * ip) {
+                    const size_t e = (size_t)ip * HP + j;
+                    av[u] = A2[e]; bv[u] = B2[e];
+                }
             }
 #pragma unroll
             for (int u = 0; u < UN; ++u) {
                 const uint32_t ip = ipb + u * ipstep;
                 if (ip < HP / 2) {
                     // P' * beta': both factors are bounded below relative to their column sums (>= q^2) and
-                    // carry their biases, so the products are normal fp64 numbers
-                    const double p0 = av[u].x * bv[u].x, p1 = av[u].y * bv[u].y;
+                    // carry their biases, so the products are normal fp64 numbers.  Weights: 2 above the
+                    // diagonal, 1 on it, 0 below (those lanes loaded nothing).
+                    const double w0 = j > 2u * ip ? 2.0 : (j == 2u * ip ? 1.0 : 0.0);
+                    const double w1 = j > 2u * ip + 1u ? 2.0 : (j == 2u * ip + 1u ? 1.0 : 0.0);
+                    const double p0 = av[u].x * bv[u].x * w0, p1 = av[u].y * bv[u].y * w1;
                     const uint32_t a0 = (uint32_t)al[2 * ip] - abase, a1 = (uint32_t)al[2 * ip + 1] - abase;
 #pragma unroll
                     for (int a = 0; a < PG_AMAX; ++a) {
@@ -2683,6 +2707,18 @@ __global__ __launch_bounds__(64 * PG_POST_WAVES) void k_post(const DevContig* __
     }
 }
 
+__global__ __launch_bounds__(64 * PG_POST_WAVES) void k_post(const DevContig* __restrict__ contigs, uint32_t chunk) {
+    __shared__ double s_bins[PG_POST_WAVES][PG_AMAX * (PG_AMAX + 1) / 2];
+    const DevContig& dc = contigs[blockIdx.y];
+    const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    // grid-stride over the columns of the chunk: the launcher may cap the number of blocks per chain so that
+    // this kernel trickles along next to the chains instead of bursting
+    for (uint32_t idx = blockIdx.x * PG_POST_WAVES + wave; idx < 2u * dc.chunk_cols; idx += gridDim.x * PG_POST_WAVES) {
+        post_column(dc, chunk, idx, wave, lane, s_bins);
+        wave_sync();
+    }
+}
+
 // ------------------------------------------------------------------------------------------
 //  host-callable launchers (defined here so that the shim needs no kernel templates)
 // ------------------------------------------------------------------------------------------
@@ -2755,7 +2791,27 @@ void pgk_launch_post(const DevContig* d_contigs, uint32_t n_contigs, uint32_t ch
     static bool attr_done[PG_MAX_DEVICES];
     if (lds_attr_pending(attr_done))
         (void)hipFuncSetAttribute((const void*)k_post, hipFuncAttributeMaxDynamicSharedMemorySize, PG_POST_PLACEMENT_LDS);
-    dim3 grid((2u * chunk_cols + PG_POST_WAVES - 1u) / PG_POST_WAVES, n_contigs);
+    // Blocks per chain: k_post blocks fill the CUs the chains leave idle and no more.  A block in excess would
+    // sit in the queue and take the CU of a chain workgroup the moment a chunk sweep ends — the next chunk's
+    // workgroup (which cannot share a CU with it, by LDS size) then waits for it: measured on the 24-contig
+    // genome, 8 blocks per chain (= (256 - 48) / 24) 144 ms for phase 2, 6 blocks 164 ms, 10 blocks 173 ms,
+    // uncapped 172 ms.  PG_POST_BLOCKS overrides.
+    static const uint32_t env_cap = [] { const char* e = getenv("PG_POST_BLOCKS"); return e ? (uint32_t)strtoul(e, nullptr, 0) : 0u; }();
+    uint32_t cap = env_cap;
+    if (!cap) {
+        static int cus[PG_MAX_DEVICES];
+        int dev = 0;
+        if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= PG_MAX_DEVICES) dev = 0;
+        if (cus[dev] == 0) {
+            hipDeviceProp_t prop;
+            cus[dev] = (hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0) ? prop.multiProcessorCount : 256;
+        }
+        const int idle = cus[dev] - 2 * (int)n_contigs;
+        cap = idle > (int)n_contigs ? (uint32_t)(idle / (int)n_contigs) : 1u;
+    }
+    uint32_t bx = (2u * chunk_cols + PG_POST_WAVES - 1u) / PG_POST_WAVES;
+    if (bx > cap) bx = cap;
+    dim3 grid(bx, n_contigs);
     hipLaunchKernelGGL(k_post, grid, dim3(64 * PG_POST_WAVES), PG_POST_PLACEMENT_LDS, s, d_contigs, chunk);
 }
 void pgk_launch_emission_single(const DevContig* d_contig, DevTable tab, uint32_t v, double* out_m, int* out_e,
