@@ -100,11 +100,20 @@ def cpu_baseline(batches, H, sample_variants):
                       f"{subs[0].n_variants / times[0]:.0f} variants/s (the compiled reference itself: ~1450/s per thread at H=64, BASELINE.md)"}
 
 
+def _sweep_phase(name: str):
+    """Phase (1, 2, 3) of a sweep kernel from its demangled name, None for other kernels:
+    k_sweep<HP, R, VBUF, KEEPW, PHASE>, k_sweep_lean<PHASE, R>, k_sweep_generic<PHASE>."""
+    import re
+    m = re.match(r"void k_sweep_lean<(\d), ", name) or re.match(r"void k_sweep_generic<(\d)>", name) or \
+        re.match(r"void k_sweep<\d+, \d+, \d+, \w+, (\d)>", name)
+    return int(m.group(1)) if m else None
+
+
 def profiled_traffic(workload, kernel_phase):
     """HBM bytes per pass of one sweep phase from the committed rocprofv3 PMC summary
     (profiles/rNN_<workload>_summary.json, made by tools/summarize_profile.py from separate
-    --pmc FETCH_SIZE / WRITE_SIZE passes).  Phase 1 is one launch of k_sweep<..., 1>; phase 2 is one
-    launch of k_sweep<..., 2> (fused mode) or all chunk launches k_sweep<..., 3> plus their k_post
+    --pmc FETCH_SIZE / WRITE_SIZE passes).  Phase 1 is one launch of the phase-1 sweep kernel(s); phase 2 is
+    one launch of the fused phase-2 sweep, or all store-only chunk launches (phase 3) plus their k_post
     launches (chunked mode), summed and divided by the number of passes the profile ran.
     None if no profile of this workload is committed."""
     cands = sorted((ROOT / "profiles").glob(f"r*_{workload}_summary.json"))
@@ -112,14 +121,13 @@ def profiled_traffic(workload, kernel_phase):
         return None, None
     data = json.loads(cands[-1].read_text())
     ks = data["kernels"]
-    passes = max([v.get("pmc_launches", 0) for n, v in ks.items() if n.startswith("void k_sweep<") and ", 1>(" in n] or [0])
+    passes = max([v.get("pmc_launches", 0) for n, v in ks.items() if _sweep_phase(n) == 1] or [0])
     if passes == 0:
         return None, None
     total = 0.0
     for name, v in ks.items():
-        sweep = name.startswith("void k_sweep<")
-        mine = (sweep and f", {kernel_phase}>(" in name) or \
-               (kernel_phase == 2 and ((sweep and ", 3>(" in name) or name.startswith("k_post(")))
+        ph = _sweep_phase(name)
+        mine = (ph == kernel_phase) or (kernel_phase == 2 and (ph == 3 or name.startswith("k_post(")))
         if mine:
             total += v.get("hbm_read_bytes_total", 0.0) + v.get("hbm_write_bytes_total", 0.0)
     return (total / passes if total > 0 else None), cands[-1].name

@@ -213,6 +213,39 @@ int  pg_job_packed_results(pg_job* job, void** d_lik, void** d_lik_exp, uint64_t
 void pg_hmm_release_cache(void);
 
 /* ------------------------------------------------------------------ *
+ *  Multi-GPU: contigs (x subsets x samples) shard across the GPUs of a node with no data-path
+ *  collective — the reference already runs them as independent jobs and only merges results
+ *  (src/commands.cpp:955-978, 163-177).  The ONE exchange is the collection of every rank's
+ *  packed posteriors on the root: grouped RCCL point-to-point sends over xGMI, each block exactly
+ *  as long as that rank's data (lik f64 + lik_exp i32 per genotype bin).  RCCL is loaded at run
+ *  time, only when a communicator is made.
+ * ------------------------------------------------------------------ */
+typedef struct pg_comm pg_comm;
+/* process-per-GPU: rank 0 makes the id, the host hands it to the other ranks (file, MPI, ...) */
+int  pg_comm_unique_id(uint8_t id128[128], char* err, size_t errlen);
+int  pg_comm_init(const uint8_t id128[128], int world, int rank, int device,
+                  pg_comm** out, char* err, size_t errlen);
+/* one process, several GPUs: out_comms[i] = rank i on devices[i] */
+int  pg_comm_init_all(int n_devices, const int* devices, pg_comm** out_comms, char* err, size_t errlen);
+int  pg_comm_rank(const pg_comm* comm);
+int  pg_comm_world(const pg_comm* comm);
+void pg_comm_destroy(pg_comm* comm);
+/* Every rank calls this once per run with its job (NULL on a rank without chains) and the plan
+ * n_lik_per_rank[world] (genotype bins each rank holds; known to every host up front).  On `root`,
+ * d_lik_all (f64) / d_exp_all (i32) are device buffers of sum(n_lik_per_rank) elements: rank r's
+ * block lands at offset sum_{q<r} n_lik_per_rank[q], in that rank's chain order.  Blocking. */
+int  pg_hmm_gather(pg_comm* comm, pg_job* job, int root, const uint64_t* n_lik_per_rank,
+                   void* d_lik_all, void* d_exp_all, char* err, size_t errlen);
+/* the same for the n_local communicators one process holds (pg_comm_init_all) */
+int  pg_hmm_gather_all(int n_local, pg_comm* const* comms, pg_job* const* jobs, int root,
+                       const uint64_t* n_lik_per_rank, void* d_lik_all, void* d_exp_all,
+                       char* err, size_t errlen);
+/* the same into HOST buffers of the root's process (temporary device buffers inside) */
+int  pg_hmm_gather_to_host(int n_local, pg_comm* const* comms, pg_job* const* jobs, int root,
+                           const uint64_t* n_lik_per_rank, double* h_lik_all, int32_t* h_exp_all,
+                           char* err, size_t errlen);
+
+/* ------------------------------------------------------------------ *
  *  Unit-level entry points (device), mirroring the reference classes the
  *  reference's own unit tests exercise.
  * ------------------------------------------------------------------ */

@@ -150,6 +150,23 @@ def _bind_hip(lib):
     lib.pg_job_packed_results.restype = C.c_int
     lib.pg_hmm_release_cache.argtypes = []
     lib.pg_hmm_release_cache.restype = None
+    lib.pg_comm_unique_id.argtypes = [u8p, C.c_char_p, C.c_size_t]
+    lib.pg_comm_unique_id.restype = C.c_int
+    lib.pg_comm_init.argtypes = [u8p, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_void_p), C.c_char_p, C.c_size_t]
+    lib.pg_comm_init.restype = C.c_int
+    lib.pg_comm_init_all.argtypes = [C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_void_p), C.c_char_p, C.c_size_t]
+    lib.pg_comm_init_all.restype = C.c_int
+    lib.pg_comm_rank.argtypes = [C.c_void_p]
+    lib.pg_comm_rank.restype = C.c_int
+    lib.pg_comm_world.argtypes = [C.c_void_p]
+    lib.pg_comm_world.restype = C.c_int
+    lib.pg_comm_destroy.argtypes = [C.c_void_p]
+    lib.pg_comm_destroy.restype = None
+    lib.pg_hmm_gather.argtypes = [C.c_void_p, C.c_void_p, C.c_int, u64p, C.c_void_p, C.c_void_p, C.c_char_p, C.c_size_t]
+    lib.pg_hmm_gather.restype = C.c_int
+    lib.pg_hmm_gather_all.argtypes = [C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.c_int, u64p, C.c_void_p, C.c_void_p,
+                                      C.c_char_p, C.c_size_t]
+    lib.pg_hmm_gather_all.restype = C.c_int
     lib.pg_emission_table.argtypes = [C.POINTER(PgContigBatch), C.c_void_p, C.c_uint32, C.c_int,
                                       ldp, i32p, C.c_char_p, C.c_size_t]
     lib.pg_emission_table.restype = C.c_int
@@ -168,6 +185,8 @@ HIP_ABI_SYMBOLS = [
     "pg_job_destroy", "pg_emission_table", "pg_transition_probs",
     "pg_job_new", "pg_cohort_new", "pg_job_n_chains", "pg_job_upload", "pg_job_host_seconds", "pg_job_upload_bytes",
     "pg_job_packed_results", "pg_hmm_release_cache",
+    "pg_comm_unique_id", "pg_comm_init", "pg_comm_init_all", "pg_comm_rank", "pg_comm_world", "pg_comm_destroy",
+    "pg_hmm_gather", "pg_hmm_gather_all", "pg_hmm_gather_to_host",
 ]
 
 

@@ -10,7 +10,7 @@ from pathlib import Path
 ROOT = Path(__file__).resolve().parent.parent
 CSRC = ROOT / "pangenie_amd" / "csrc"
 HIP_LIB = CSRC / "libpangenie_hmm.so"
-HIP_SOURCES = [CSRC / "pg_kernels.hip", CSRC / "pg_shim.cpp"]
+HIP_SOURCES = [CSRC / "pg_kernels.hip", CSRC / "pg_shim.cpp", CSRC / "pg_gather.cpp"]
 HIP_DEPS = HIP_SOURCES + [CSRC / "pg_device.h", ROOT / "include" / "pangenie_hmm.h"]
 
 
@@ -39,7 +39,7 @@ def build_hip(force: bool = False, verbose: bool = False, out: Path | None = Non
                # fp64 MFMA results straight into VGPRs (the wave totals of the lean sweep): no v_accvgpr_read round trip
                "-mllvm", "-amdgpu-mfma-vgpr-form",
                *[f"-D{d}" for d in defines], *extra,
-               *map(str, HIP_SOURCES), "-o", str(target)]
+               *map(str, HIP_SOURCES), "-ldl", "-o", str(target)]
         r = subprocess.run(cmd, capture_output=True, text=True)
         if verbose or r.returncode:
             print(" ".join(cmd))
@@ -70,7 +70,7 @@ def build_host(force: bool = False) -> Path:
     deps = [HOST_DIR / "pangenie_host.cpp", HOST_DIR / "pangenie_host.hpp", ROOT / "include" / "pangenie_hmm.h"]
     if force or _stale(HOST_LIB, deps):
         cmd = [cxx, "-O2", "-std=c++17", "-fPIC", "-shared", "-Wall", "-Wextra", str(HOST_DIR / "pangenie_host.cpp"),
-               "-o", str(HOST_LIB), f"-L{CSRC}", "-lpangenie_hmm", "-Wl,-rpath,$ORIGIN/../csrc"]
+               "-o", str(HOST_LIB), f"-L{CSRC}", "-lpangenie_hmm", "-lpthread", "-Wl,-rpath,$ORIGIN/../csrc"]
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode:
             raise RuntimeError("g++ (host lib) failed:\n" + r.stderr)

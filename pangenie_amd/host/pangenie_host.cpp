@@ -6,6 +6,7 @@
 #include <cstdlib>
 #include <sstream>
 #include <stdexcept>
+#include <thread>
 #include <unordered_set>
 
 namespace pangenie {
@@ -633,6 +634,124 @@ HMM::HMM(std::vector<std::shared_ptr<UniqueKmers>>* unique_kmers, ProbabilityTab
     }
     if (run_phasing) viterbi_phasing(f, probabilities->handle(), recombrate, uniform, effective_N, genotyping_result_);  // :47-49
 }
+// ------------------------------------------------------------------ multi-GPU job loop
+std::vector<std::vector<GenotypingResult>> run_contigs_multi_gpu(std::vector<ContigTask>& tasks, ProbabilityTable* probabilities,
+                                                                 double recombrate, bool uniform, long double effective_N,
+                                                                 const std::vector<int>& devices) {
+    if (devices.empty()) fail("run_contigs_multi_gpu: no devices");
+    const size_t T = tasks.size(), D = devices.size();
+    std::vector<FlatContig> flat(T);
+    std::vector<std::vector<uint64_t>> goff(T);
+    std::vector<double> weight(T);
+    for (size_t t = 0; t < T; ++t) {
+        flatten(tasks[t].unique_kmers, tasks[t].only_paths, flat[t]);
+        const size_t V = flat[t].variant_pos.size();
+        goff[t].assign(V + 1, 0);
+        pg_hmm_geno_offsets(&flat[t].batch, goff[t].data());
+        weight[t] = (double)V * (double)flat[t].paths.size() * (double)flat[t].paths.size();
+    }
+    // longest processing time first; ties by index: every host computes the same plan
+    std::vector<size_t> order(T);
+    for (size_t t = 0; t < T; ++t) order[t] = t;
+    std::stable_sort(order.begin(), order.end(), [&](size_t a, size_t b) { return weight[a] > weight[b]; });
+    std::vector<std::vector<size_t>> plan(D);
+    std::vector<double> load(D, 0.0);
+    for (size_t t : order) {
+        size_t best = 0;
+        for (size_t d = 1; d < D; ++d) if (load[d] < load[best]) best = d;
+        plan[best].push_back(t);
+        load[best] += weight[t];
+    }
+    for (auto& p : plan) std::sort(p.begin(), p.end());
+
+    pg_hmm_params prm{};
+    prm.effective_N = effective_N; prm.recombrate = recombrate; prm.uniform = uniform ? 1 : 0; prm.run_genotyping = 1;
+    std::vector<pg_job*> jobs(D, nullptr);
+    std::vector<std::string> errors(D);
+    std::vector<std::thread> threads;
+    for (size_t d = 0; d < D; ++d)
+        threads.emplace_back([&, d] {
+            if (plan[d].empty()) return;
+            std::vector<pg_contig_batch> b;
+            for (size_t t : plan[d]) b.push_back(flat[t].batch);
+            char err[512] = {0};
+            int rc = pg_job_new(devices[d], (uint32_t)b.size(), b.data(), probabilities->handle(), &prm, &jobs[d], err, sizeof(err));
+            if (rc == PG_OK) rc = pg_job_run(jobs[d], nullptr, err, sizeof(err));
+            if (rc != PG_OK) errors[d] = err[0] ? err : "pangenie_hmm error";
+        });
+    for (auto& th : threads) th.join();
+    auto cleanup = [&] { for (pg_job* j : jobs) if (j) pg_job_destroy(j); };
+    for (size_t d = 0; d < D; ++d)
+        if (!errors[d].empty()) { cleanup(); fail(errors[d]); }
+
+    // ONE exchange: every device's packed posteriors to devices[0], then to the host
+    std::vector<uint64_t> n_lik(D, 0);
+    uint64_t total = 0;
+    for (size_t d = 0; d < D; ++d) { for (size_t t : plan[d]) n_lik[d] += goff[t].back(); total += n_lik[d]; }
+    std::vector<double> lik(total ? total : 1);
+    std::vector<int32_t> lexp(total ? total : 1);
+    char err[512] = {0};
+    if (D == 1) {
+        uint64_t off = 0;
+        for (size_t k = 0; k < plan[0].size(); ++k) {
+            pg_contig_result r{};
+            r.lik = lik.data() + off; r.lik_exp = lexp.data() + off;
+            const int rc = pg_job_fetch(jobs[0], (uint32_t)k, &r, err, sizeof(err));
+            if (rc != PG_OK) { cleanup(); check_rc(rc, err); }
+            off += goff[plan[0][k]].back();
+        }
+    } else {
+        std::vector<pg_comm*> comms(D, nullptr);
+        int rc = pg_comm_init_all((int)D, devices.data(), comms.data(), err, sizeof(err));
+        if (rc == PG_OK) rc = pg_hmm_gather_to_host((int)D, comms.data(), jobs.data(), 0, n_lik.data(), lik.data(), lexp.data(), err, sizeof(err));
+        for (pg_comm* c : comms) if (c) pg_comm_destroy(c);
+        if (rc != PG_OK) { cleanup(); check_rc(rc, err); }
+    }
+    cleanup();
+
+    // rebuild the GenotypingResults (reference src/hmm.cpp:364-368, 106-109); kept columns and allele presence by
+    // the ColumnIndexer rule on the host (src/columnindexer.cpp:24-31)
+    std::vector<std::vector<GenotypingResult>> out(T);
+    uint64_t base = 0;
+    for (size_t d = 0; d < D; ++d)
+        for (size_t t : plan[d]) {
+            const FlatContig& f = flat[t];
+            const size_t V = f.variant_pos.size(), H = f.paths.size();
+            out[t].assign(V, GenotypingResult());
+            size_t columns = 0;
+            std::vector<uint8_t> kept(V, 0), present(f.allele_id.size(), 0);
+            for (size_t v = 0; v < V; ++v) {
+                const uint32_t a0 = f.allele_off[v], A = f.allele_off[v + 1] - a0;
+                for (size_t p = 0; p < H; ++p) {
+                    const uint16_t a = f.path_allele[v * H + p];
+                    for (uint32_t q = 0; q < A; ++q)
+                        if (f.allele_id[a0 + q] == a) { present[a0 + q] = 1; if (a != 0 && !(f.allele_flags[a0 + q] & 1)) kept[v] = 1; }
+                }
+                columns += kept[v];
+            }
+            for (size_t v = 0; v < V; ++v) {
+                GenotypingResult& g = out[t][v];
+                if (kept[v]) {
+                    const uint32_t a0 = f.allele_off[v], A = f.allele_off[v + 1] - a0;
+                    for (uint32_t a = 0; a < A; ++a) {
+                        if (!present[a0 + a]) continue;
+                        for (uint32_t b = a; b < A; ++b) {
+                            if (!present[a0 + b]) continue;
+                            const uint64_t idx = base + goff[t][v] + (uint64_t)a * A - (uint64_t)a * (a - 1) / 2 + (b - a);
+                            g.add_to_likelihood(f.allele_id[a0 + a], f.allele_id[a0 + b], ldexpl((long double)lik[idx], lexp[idx]));
+                        }
+                    }
+                }
+                if (columns > 0) {  // reference src/hmm.cpp:94,106-109
+                    g.set_unique_kmers((unsigned short)(f.kmer_off[v + 1] - f.kmer_off[v]));
+                    g.set_coverage(f.coverage[v]);
+                }
+            }
+            base += goff[t].back();
+        }
+    return out;
+}
+
 void HMM::combine_likelihoods(HMM& other) {
     if (genotyping_result_.size() != other.genotyping_result_.size())
         fail("HMM::combine_likelihoods: HMMs to be combined must be of the same size.");

@@ -266,4 +266,20 @@ private:
     std::vector<GenotypingResult> genotyping_result_;
 };
 
+/** One (contig, path subset) to genotype: what run_genotyping receives (reference src/commands.cpp:155-160). */
+struct ContigTask {
+    std::vector<std::shared_ptr<UniqueKmers>>* unique_kmers = nullptr;
+    std::vector<unsigned short>* only_paths = nullptr;
+};
+
+/** The reference's job loop (src/commands.cpp:955-978: one HMM per contig x subset on a thread pool) across the
+ *  GPUs of one node: tasks are assigned to `devices` by longest-processing-time-first (weight = variants x H^2),
+ *  every device runs ONE resident job over its tasks (all its chains concurrently, driven by its own host
+ *  thread), and the posteriors of all devices are collected with ONE RCCL exchange over xGMI
+ *  (pg_hmm_gather_to_host); with a single device there is no exchange at all.  Returns, per task, what
+ *  HMM(...).get_genotyping_result() returns for it (unnormalised: normalize = false, as run_genotyping calls it). */
+std::vector<std::vector<GenotypingResult>> run_contigs_multi_gpu(std::vector<ContigTask>& tasks, ProbabilityTable* probabilities,
+                                                                 double recombrate, bool uniform, long double effective_N,
+                                                                 const std::vector<int>& devices);
+
 }  // namespace pangenie

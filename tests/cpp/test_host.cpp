@@ -402,6 +402,30 @@ static void gpu_tests() {
         us nobody = {5, 6};
         CHECK_THROWS(HMM(&uks, &none, true, false, 1.26, false, 0.25, &nobody));  // column not covered by any paths
     });
+    run("run_contigs_multi_gpu == one HMM per task", [&] {
+        // three tasks (two contigs, one of them with a path subset) through the multi-GPU job loop on the
+        // devices present; results must equal those of the one-shot HMM constructor, bin for bin
+        auto mk = [](size_t pos, us paths, unsigned short c0, unsigned short c1) {
+            auto u = bi(pos, paths); kmer(u, c0, {0}); kmer(u, c1, {1}); u->set_coverage(5); return u; };
+        vector<shared_ptr<UniqueKmers>> c1 = {mk(2000, {0, 1, 1, 0}, 10, 10), mk(3000, {0, 1, 0, 0}, 20, 5), mk(4100, {1, 1, 0, 0}, 5, 20)};
+        vector<shared_ptr<UniqueKmers>> c2 = {mk(500, {0, 1, 1, 0}, 5, 5), mk(900, {1, 0, 1, 0}, 20, 10)};
+        us sub = {0, 1, 3};
+        ProbabilityTable probs = std_table();
+        vector<ContigTask> tasks = {{&c1, nullptr}, {&c2, nullptr}, {&c1, &sub}};
+        vector<int> devs;
+        for (int d = 0; d < HMM::device_count(); ++d) devs.push_back(d);
+        auto res = run_contigs_multi_gpu(tasks, &probs, R01, false, 0.25, devs);
+        CHECK(res.size() == 3);
+        for (size_t t = 0; t < tasks.size(); ++t) {
+            HMM one(tasks[t].unique_kmers, &probs, true, false, R01, false, 0.25, tasks[t].only_paths, false);
+            auto ref = one.get_genotyping_result();
+            CHECK(ref.size() == res[t].size());
+            for (size_t v = 0; v < ref.size() && v < res[t].size(); ++v) {
+                CHECK(ref[v].get_stored_likelihoods() == res[t][v].get_stored_likelihoods());
+                CHECK(ref[v].coverage() == res[t][v].coverage() && ref[v].nr_unique_kmers() == res[t][v].nr_unique_kmers());
+            }
+        }
+    });
     run("HMM genotyping + phasing in one constructor (no_unique_kmers3)", [] {
         // reference tests/HMMTest.cpp:392-438: likelihoods AND the Viterbi haplotypes
         auto u1 = bi(2000, {0, 1}); kmer(u1, 10, {0}); kmer(u1, 10, {1});

@@ -458,6 +458,40 @@ def test_wide_columns_vs_oracle(H, V, local_alts, orc):
     assert_parity(b, res, ref)
 
 
+def test_c_abi_gather_single_rank_rccl_loopback(monkeypatch):
+    """The multi-GPU exchange behind the C ABI (pg_comm_* / pg_hmm_gather) on ONE GPU: a world-size-1 RCCL
+    communicator, the rank's packed posteriors sent to itself through ncclSend / ncclRecv
+    (PG_GATHER_LOOPBACK), compared with what pg_job_fetch returns — and the plain world-1 path, which
+    is a device-to-device copy."""
+    import ctypes as C
+    import torch
+    lib = hmm._lib.load_hip()
+    batches = [synthetic_panel(300, 16, 20, seed=81), synthetic_panel(200, 64, 20, seed=82, multiallelic_frac=0.3)]
+    job = hmm.Job(batches, hmm.ProbabilityTable(*default_table_args()), hmm.make_params(1.26, False, 1e-5))
+    job.run()
+    _, _, n = job.packed_results()
+    want_l = np.concatenate([job.fetch(i).lik for i in range(2)])
+    want_e = np.concatenate([job.fetch(i).lik_exp for i in range(2)])
+    assert n == want_l.size
+    err = C.create_string_buffer(512)
+    uid = (C.c_uint8 * 128)()
+    assert lib.pg_comm_unique_id(uid, err, 512) == 0, err.value
+    comm = C.c_void_p()
+    assert lib.pg_comm_init(uid, 1, 0, 0, C.byref(comm), err, 512) == 0, err.value
+    assert lib.pg_comm_rank(comm) == 0 and lib.pg_comm_world(comm) == 1
+    plan = (C.c_uint64 * 1)(n)
+    for loop in (False, True):
+        if loop:
+            monkeypatch.setenv("PG_GATHER_LOOPBACK", "1")
+        got_l = torch.zeros(n, dtype=torch.float64, device="cuda")
+        got_e = torch.zeros(n, dtype=torch.int32, device="cuda")
+        rc = lib.pg_hmm_gather(comm, job.h, 0, plan, C.c_void_p(got_l.data_ptr()), C.c_void_p(got_e.data_ptr()), err, 512)
+        assert rc == 0, err.value
+        assert np.array_equal(got_l.cpu().numpy(), want_l) and np.array_equal(got_e.cpu().numpy(), want_e)
+    lib.pg_comm_destroy(comm)
+    job.close()
+
+
 def _check_normalised(b, r):
     n = normalized_bins(b, r.likelihoods_ld())
     sums = np.add.reduceat(np.concatenate([n, np.zeros(1, n.dtype)]), b.geno_off[:-1].astype(np.int64))[:b.n_variants]
