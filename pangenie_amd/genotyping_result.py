@@ -119,6 +119,32 @@ class GenotypingResult:
         return self.local_coverage
 
 
+def vcf_sample_field(result: "GenotypingResult", defined_alleles: Sequence[int], nr_alleles: int, ignore_imputed: bool = False) -> str:
+    """`GT:GQ:GL:KC` of one record as Graph::write_genotypes prints it (reference src/graph.cpp:217-273);
+    mirror of pangenie::genotype_field (pangenie_amd/host/pangenie_host.hpp).  `result` must be normalised."""
+    tmp = GenotypingResult()
+    tmp.genotype_to_likelihood = dict(result.genotype_to_likelihood)
+    tmp.local_coverage, tmp.unique_kmers = result.local_coverage, result.unique_kmers
+    if tmp.contains_no_likelihoods():
+        tmp.add_to_likelihood(0, 0, 1.0)
+    nr_missing = nr_alleles - len(defined_alleles)
+    gl = tmp.get_specific_likelihoods(defined_alleles) if nr_missing > 0 else tmp
+    n = len(defined_alleles)
+    g = gl.get_likeliest_genotype()
+    if ignore_imputed and result.nr_unique_kmers() == 0:
+        g = (-1, -1)
+    out = f"{g[0]}/{g[1]}:{gl.get_genotype_quality(g[0], g[1])}:" if g[0] != -1 and g[1] != -1 else ".:.:"
+    liks = gl.get_all_likelihoods(n)
+    if len(liks) < 3:
+        raise RuntimeError(f"Graph::write_genotypes_of: too few likelihoods ({len(liks)}) computed")
+
+    def fmt(x):  # ostream << setprecision(4) << log10(long double)
+        with np.errstate(divide="ignore"):
+            v = float(np.log10(LD(x)))
+        return "%.4g" % v if v == v and abs(v) != float("inf") else ("-inf" if v < 0 else ("inf" if v > 0 else "nan"))
+    return out + ",".join(fmt(x) for x in liks) + f":{result.coverage()}"
+
+
 def results_from_flat(batch, lik_ld: np.ndarray, kept: np.ndarray, allele_present: np.ndarray,
                       n_kmers: np.ndarray, coverage: np.ndarray) -> List[GenotypingResult]:
     """Rebuild vector<GenotypingResult> from the flat bins (include/pangenie_hmm.h layout):

@@ -3,6 +3,7 @@
 
 #include <algorithm>
 #include <cmath>
+#include <iomanip>
 #include <cstdlib>
 #include <sstream>
 #include <stdexcept>
@@ -323,6 +324,54 @@ std::ostream& operator<<(std::ostream& os, const GenotypingResult& r) {
        << "\nlocal coverage: " << r.local_coverage_ << "\nnr of unique kmers: " << r.unique_kmers_ << "\n";
     for (auto& kv : r.genotype_to_likelihood_) os << kv.first.first << "/" << kv.first.second << ": " << (double)kv.second << "\n";
     return os;
+}
+
+template <bool B>
+UniqueKmersT<B>::UniqueKmersT(const Raw& raw)
+    : variant_pos_(raw.variant_pos), local_coverage_(raw.local_coverage), counts_(raw.counts), path_to_allele_(raw.path_to_allele) {
+    for (auto& kv : raw.alleles) {
+        AlleleInfo info;
+        info.kmer_path = KmerPath(B ? 16u : 32u, kv.second.offset, kv.second.mask);
+        info.is_undefined = kv.second.is_undefined;
+        alleles_[kv.first] = info;
+    }
+}
+template <bool B>
+typename UniqueKmersT<B>::Raw UniqueKmersT<B>::raw() const {
+    Raw r;
+    r.variant_pos = variant_pos_; r.local_coverage = local_coverage_; r.counts = counts_; r.path_to_allele = path_to_allele_;
+    for (auto& kv : alleles_) {
+        RawAllele a;
+        a.offset = kv.second.kmer_path.offset(); a.mask = kv.second.kmer_path.mask(); a.is_undefined = kv.second.is_undefined;
+        r.alleles[kv.first] = a;
+    }
+    return r;
+}
+template UniqueKmersT<true>::UniqueKmersT(const Raw&);
+template UniqueKmersT<false>::UniqueKmersT(const Raw&);
+template UniqueKmersT<true>::Raw UniqueKmersT<true>::raw() const;
+template UniqueKmersT<false>::Raw UniqueKmersT<false>::raw() const;
+
+// ------------------------------------------------------------------ VCF sample column
+std::string genotype_field(const GenotypingResult& result, std::vector<unsigned short>& defined_alleles, size_t nr_alleles, bool ignore_imputed) {
+    GenotypingResult tmp = result;
+    if (tmp.contains_no_likelihoods()) tmp.add_to_likelihood(0, 0, 1.0);   // reference src/graph.cpp:225-227
+    const size_t nr_missing = nr_alleles - defined_alleles.size();
+    GenotypingResult gl = nr_missing > 0 ? tmp.get_specific_likelihoods(defined_alleles) : tmp;   // :229-233
+    nr_alleles = defined_alleles.size();
+    std::ostringstream out;
+    std::pair<int, int> genotype = gl.get_likeliest_genotype();
+    if (ignore_imputed && result.nr_unique_kmers() == 0) genotype = {-1, -1};
+    if (genotype.first != -1 && genotype.second != -1)
+        out << genotype.first << "/" << genotype.second << ":" << gl.get_genotype_quality((unsigned short)genotype.first, (unsigned short)genotype.second) << ":";
+    else
+        out << ".:.:";
+    std::vector<long double> likelihoods = gl.get_all_likelihoods(nr_alleles);
+    if (likelihoods.size() < 3) fail("Graph::write_genotypes_of: too few likelihoods (" + std::to_string(likelihoods.size()) + ") computed");
+    out << std::setprecision(4) << log10(likelihoods[0]);
+    for (size_t j = 1; j < likelihoods.size(); ++j) out << "," << std::setprecision(4) << log10(likelihoods[j]);
+    out << ":" << result.coverage();
+    return out.str();
 }
 
 // ------------------------------------------------------------------ flatten

@@ -23,6 +23,7 @@
 #include <map>
 #include <memory>
 #include <ostream>
+#include <sstream>
 #include <string>
 #include <utility>
 #include <vector>
@@ -35,6 +36,7 @@ namespace pangenie {
 class KmerPath {
 public:
     explicit KmerPath(unsigned window = 32) : offset_(0), kmers_(0), window_(window) {}
+    KmerPath(unsigned window, unsigned short offset, uint32_t mask) : offset_(offset), kmers_(mask), window_(window) {}  // from an archive
     void set_position(unsigned short index);
     unsigned int get_position(unsigned short index) const;
     size_t nr_kmers() const;
@@ -144,6 +146,18 @@ public:
     void update_paths(std::vector<unsigned short>& path_ids) override;
     std::pair<unsigned short, uint32_t> kmer_bits(unsigned short allele_id) const override;
 
+    /** The stored fields as plain data (archive I/O, cereal_io.hpp). */
+    struct RawAllele { unsigned short offset = 0; uint32_t mask = 0; bool is_undefined = false; };
+    struct Raw {
+        size_t variant_pos = 0;
+        float local_coverage = 0.f;
+        std::vector<unsigned short> counts;
+        std::map<unsigned short, RawAllele> alleles;
+        std::vector<unsigned short> path_to_allele;
+    };
+    explicit UniqueKmersT(const Raw& raw);
+    Raw raw() const;
+
 private:
     struct AlleleInfo {
         KmerPath kmer_path{BIALLELIC ? 16u : 32u};
@@ -208,6 +222,14 @@ private:
     std::map<std::pair<unsigned short, unsigned short>, long double> genotype_to_likelihood_;
     unsigned short haplotype_1_, haplotype_2_, local_coverage_, unique_kmers_;
 };
+
+/** The sample column of a genotyped VCF record, `GT:GQ:GL:KC`, as Graph::write_genotypes prints it (reference
+ *  src/graph.cpp:217-273): an empty result becomes L(0/0) = 1 (:225-227), genotypes with undefined alleles are
+ *  dropped and the rest renormalised (:229-233), GT = likeliest genotype or `.` when there is no unique maximum
+ *  (:246-258), GQ (genotypingresult.cpp:118-137), GL = log10 with 4 significant digits in VCF order (:268-273),
+ *  KC = local k-mer coverage.  `result` must be normalised; `nr_alleles` = all alleles of the record. */
+std::string genotype_field(const GenotypingResult& result, std::vector<unsigned short>& defined_alleles, size_t nr_alleles,
+                           bool ignore_imputed = false);
 
 /** Li-Stephens transition probabilities between two variants — computed on the device. */
 class TransitionProbabilityComputer {

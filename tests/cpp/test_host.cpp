@@ -19,6 +19,7 @@
 #include <string>
 #include <vector>
 
+#include "../../pangenie_amd/host/cereal_io.hpp"
 #include "../../pangenie_amd/host/pangenie_host.hpp"
 
 using namespace pangenie;
@@ -209,6 +210,70 @@ static void cpu_tests() {
 
 // ----------------------------------------------------------------------------------- GPU
 static const double R01 = 446.287102628;  // recombination rate that gives recombination probability 0.1
+
+static std::string g_golden_dir = "tests/golden";
+static void archive_cpu_tests() {
+    run("cereal binary archive: the reference's own fixtures parse and re-serialise byte for byte", [] {
+        for (const char* name : {"region_UniqueKmersList.cereal", "region2_UniqueKmersList.cereal"}) {
+            const std::string path = g_golden_dir + "/" + name;
+            FILE* f = std::fopen(path.c_str(), "rb");
+            CHECK(f != nullptr);
+            if (!f) continue;
+            std::vector<unsigned char> bytes;
+            unsigned char buf[4096];
+            size_t n;
+            while ((n = std::fread(buf, 1, sizeof(buf), f)) > 0) bytes.insert(bytes.end(), buf, buf + n);
+            std::fclose(f);
+            UniqueKmersMap m = parse_unique_kmers_map(bytes);
+            CHECK(m.kmersize == 31 && m.unique_kmers.size() == 1 && m.unique_kmers.count("chr1") == 1 && m.add_reference);
+            CHECK(m.unique_kmers["chr1"].size() == 2);
+            CHECK(serialize_unique_kmers_map(m) == bytes);
+        }
+        // first record of the region fixture: position 138, coverage 30, 62 k-mers, 44 alleles, 215 paths
+        UniqueKmersMap m = load_unique_kmers_map(g_golden_dir + "/region_UniqueKmersList.cereal");
+        auto& u = *m.unique_kmers["chr1"][0];
+        us ids;
+        u.get_allele_ids(ids);
+        CHECK(u.get_variant_position() == 138 && u.get_coverage() == 30 && u.size() == 62 && ids.size() == 44 && u.get_nr_paths() == 215);
+        CHECK(u.kmers_on_allele(0) == 31 && u.kmers_on_allele(1) == 31 && u.kmers_on_allele(2) == 0 && u.is_undefined_allele(2) && !u.is_undefined_allele(1));
+    });
+    run("cereal binary archive: written objects read back identically", [] {
+        UniqueKmersMap m;
+        m.kmersize = 31; m.add_reference = true; m.runtimes["chrA"] = 0.25; m.sampling_runtimes["chrA"] = 0.5;
+        auto a = bi(1000, {0, 1, 1}); kmer(a, 7, {0}); kmer(a, 9, {1}); a->set_coverage(21);
+        auto b = multi(2000, {0, 2, 1, 1}); kmer(b, 3, {0}); kmer(b, 4, {1, 2}); kmer(b, 5, {2}); b->set_undefined_allele(2); b->set_coverage(18);
+        m.unique_kmers["chrA"] = {a, b};
+        m.unique_kmers["chrB"] = {a};   // the same object twice: a back reference in the archive
+        const std::vector<unsigned char> bytes = serialize_unique_kmers_map(m);
+        UniqueKmersMap r = parse_unique_kmers_map(bytes);
+        CHECK(serialize_unique_kmers_map(r) == bytes);
+        CHECK(r.unique_kmers["chrB"][0].get() == r.unique_kmers["chrA"][0].get());
+        auto& rb = *r.unique_kmers["chrA"][1];
+        CHECK(rb.get_variant_position() == 2000 && rb.get_coverage() == 18 && rb.size() == 3 && rb.is_undefined_allele(2));
+        CHECK(rb.kmer_on_allele(1, 2) && rb.kmer_on_allele(1, 1) && !rb.kmer_on_allele(1, 0) && rb.get_allele(1) == 2);
+        CHECK(r.runtimes["chrA"] == 0.25 && r.sampling_runtimes["chrA"] == 0.5);
+    });
+    run("VCF sample column (GT:GQ:GL:KC)", [] {
+        GenotypingResult g;
+        g.add_to_likelihood(0, 0, 0.1L); g.add_to_likelihood(0, 1, 0.8L); g.add_to_likelihood(1, 1, 0.1L);
+        g.set_coverage(27);
+        us defined = {0, 1};
+        CHECK(genotype_field(g, defined, 2) == "0/1:6:-1,-0.09691,-1:27");   // GQ = (size_t)(-10 log10(0.2)) = 6
+        GenotypingResult sure;
+        sure.add_to_likelihood(1, 1, 1.0L); sure.add_to_likelihood(0, 0, 0.0L); sure.add_to_likelihood(0, 1, 0.0L);
+        CHECK(genotype_field(sure, defined, 2) == "1/1:10000:-inf,-inf,0:0");
+        GenotypingResult empty;   // no likelihoods: 0/0 with certainty (reference src/graph.cpp:225-227)
+        CHECK(genotype_field(empty, defined, 2) == "0/0:10000:0,-inf,-inf:0");
+        GenotypingResult tie;
+        tie.add_to_likelihood(0, 0, 0.5L); tie.add_to_likelihood(0, 1, 0.5L);
+        CHECK(genotype_field(tie, defined, 2).substr(0, 4) == ".:.:");
+        // an undefined allele (2) is dropped and the rest renormalised
+        GenotypingResult three;
+        three.add_to_likelihood(0, 0, 0.2L); three.add_to_likelihood(0, 1, 0.2L); three.add_to_likelihood(1, 1, 0.1L);
+        three.add_to_likelihood(0, 2, 0.25L); three.add_to_likelihood(1, 2, 0.25L);
+        CHECK(genotype_field(three, defined, 3) == ".:.:-0.3979,-0.3979,-0.699:0");
+    });
+}
 
 static void viterbi_cpu_tests() {
     // Viterbi alone needs no device (run_genotyping = false): host long double, reference src/hmm.cpp:112-173, 408-511
@@ -402,6 +467,29 @@ static void gpu_tests() {
         us nobody = {5, 6};
         CHECK_THROWS(HMM(&uks, &none, true, false, 1.26, false, 0.25, &nobody));  // column not covered by any paths
     });
+    run("index archive -> HMM -> VCF sample column (the reference's region fixtures)", [] {
+        // tests/CommandsTest.cpp:59-93 builds these strings from a directly constructed HMM over the archive; the
+        // expected values here are the CPU oracle's for the same fixture and parameters (tests/test_cereal_io.py)
+        ProbabilityTable probs(18 / 4, 18 * 4, 2 * 18, 0.01L);
+        struct Case { const char* file; vector<us> defined; vector<std::string> expect; };
+        vector<Case> cases = {
+            {"region_UniqueKmersList.cereal", {{0, 1}, {0, 1, 2}}, {"0/1:10000:-55.77,0,-56.61:30", "0/1:10000:-30.56,0,-40.21,-85.2,-77.92,-103.2:34"}},
+            {"region2_UniqueKmersList.cereal", {{0, 1}, {0, 1}}, {"0/1:10000:-55.72,0,-56.66:30", "0/1:10000:-29.55,0,-41.23:34"}}};
+        for (auto& c : cases) {
+            UniqueKmersMap m = load_unique_kmers_map(g_golden_dir + "/" + c.file);
+            HMM hmm(&m.unique_kmers["chr1"], &probs, true, false, 1.26, false, 0.00001L);
+            auto res = hmm.get_genotyping_result();
+            CHECK(res.size() == 2);
+            for (size_t i = 0; i < res.size() && i < 2; ++i) {
+                res[i].normalize();
+                us ids;
+                m.unique_kmers["chr1"][i]->get_allele_ids(ids);
+                const std::string got = genotype_field(res[i], c.defined[i], ids.size());
+                if (got != c.expect[i]) std::printf("    got %s expected %s\n", got.c_str(), c.expect[i].c_str());
+                CHECK(got == c.expect[i]);
+            }
+        }
+    });
     run("run_contigs_multi_gpu == one HMM per task", [&] {
         // three tasks (two contigs, one of them with a path subset) through the multi-GPU job loop on the
         // devices present; results must equal those of the one-shot HMM constructor, bin for bin
@@ -447,7 +535,8 @@ static void gpu_tests() {
 
 int main(int argc, char** argv) {
     const std::string mode = argc > 1 ? argv[1] : "cpu";
-    if (mode == "cpu") { cpu_tests(); viterbi_cpu_tests(); }
+    if (argc > 2) g_golden_dir = argv[2];
+    if (mode == "cpu") { cpu_tests(); viterbi_cpu_tests(); archive_cpu_tests(); }
     else if (mode == "gpu") gpu_tests();
     else { std::printf("usage: test_host cpu|gpu\n"); return 2; }
     std::printf("%d checks, %d failed\n", g_checks, g_failed);

@@ -1,0 +1,75 @@
+"""The reference's cereal-binary UniqueKmers archives without cereal (pangenie_amd/cereal_io.py; the C++ host
+reader is exercised by tests/cpp/test_host.cpp): the reference's own fixtures tests/data/region*_UniqueKmersList.cereal
+(kept as data under tests/golden/) parse, re-serialise byte for byte, flatten into batches the oracle
+accepts, and — on a GPU — give HIP results identical to the oracle's down to the VCF sample column
+(`GT:GQ:GL:KC`, reference src/graph.cpp:217-273; tests/CommandsTest.cpp:59-93 builds the same strings from a
+directly constructed HMM)."""
+from pathlib import Path
+
+import numpy as np
+import pytest
+
+from pangenie_amd import cereal_io
+from pangenie_amd.genotyping_result import results_from_flat, vcf_sample_field
+from pangenie_amd.panel import flatten
+
+GOLDEN = Path(__file__).resolve().parent / "golden"
+# tests/CommandsTest.cpp:20-35,59-60: k-mer abundance peak 18, regularization 0.01, effective_N 1e-5, recombrate 1.26
+TABLE = (18 // 4, 18 * 4, 2 * 18, 0.01)
+PARAMS = (1.26, False, 1e-5)
+
+
+def oracle_fields(batch, uks, defined):
+    from oracle import pyoracle as orc
+    ref = orc.genotype_contig(batch, orc.OracleTable(*TABLE), orc.make_params(*PARAMS))
+    res = results_from_flat(batch, ref.lik, ref.kept, ref.allele_present, ref.n_kmers, ref.coverage)
+    out = []
+    for g, d, u in zip(res, defined, uks):
+        g.normalize()
+        out.append(vcf_sample_field(g, d, len(u.alleles)))
+    return ref, out
+
+
+def test_reference_fixtures_parse_and_roundtrip():
+    for name, paths, alleles in (("region_UniqueKmersList.cereal", 215, (44, 45)), ("region2_UniqueKmersList.cereal", 6, (2, 2))):
+        raw = (GOLDEN / name).read_bytes()
+        m = cereal_io.loads(raw)
+        assert m.kmersize == 31 and list(m.unique_kmers) == ["chr1"] and m.add_reference
+        uks = m.unique_kmers["chr1"]
+        assert [u.variant_pos for u in uks] == [138, 207] and [len(u.path_to_allele) for u in uks] == [paths, paths]
+        assert tuple(len(u.alleles) for u in uks) == alleles and not any(u.biallelic for u in uks)
+        assert cereal_io.dumps(m) == raw
+    u = cereal_io.load(GOLDEN / "region_UniqueKmersList.cereal").unique_kmers["chr1"][0]
+    # coverage 30, 62 k-mers, alleles 0 and 1 carry 31 k-mers each, alleles 2..43 none and undefined
+    assert u.local_coverage == 30.0 and len(u.kmer_to_count) == 62
+    assert bin(u.alleles[0][1]).count("1") == 31 and bin(u.alleles[1][1]).count("1") == 31 and u.alleles[1][0] == 31
+    assert all(u.alleles[a][1] == 0 and u.alleles[a][2] for a in range(2, 44))
+
+
+def test_fixtures_through_the_oracle_give_wellformed_records():
+    for name, defined in (("region_UniqueKmersList.cereal", [[0, 1], [0, 1, 2]]), ("region2_UniqueKmersList.cereal", [[0, 1], [0, 1]])):
+        uks = cereal_io.load(GOLDEN / name).unique_kmers["chr1"]
+        batch = flatten(uks)
+        ref, fields = oracle_fields(batch, uks, defined)
+        assert ref.n_columns == 2
+        for f, d in zip(fields, defined):
+            gt, gq, gl, kc = f.split(":")
+            assert len(gl.split(",")) == len(d) * (len(d) + 1) // 2 and kc in ("30", "34")
+            assert gt == "." or (int(gq) >= 0 and all(int(a) < len(d) for a in gt.split("/")))
+
+
+@pytest.mark.gpu
+def test_fixtures_hip_vs_oracle_down_to_the_vcf_column():
+    from pangenie_amd import hmm
+    from tests.parity_util import assert_parity
+    for name, defined in (("region_UniqueKmersList.cereal", [[0, 1], [0, 1, 2]]), ("region2_UniqueKmersList.cereal", [[0, 1], [0, 1]])):
+        uks = cereal_io.load(GOLDEN / name).unique_kmers["chr1"]
+        batch = flatten(uks)
+        ref, want = oracle_fields(batch, uks, defined)
+        res = hmm.genotype_contig(batch, hmm.ProbabilityTable(*TABLE), hmm.make_params(*PARAMS))
+        assert_parity(batch, res, ref)
+        got = []
+        for g, d, u in zip(res.genotyping_results(), defined, uks):
+            g.normalize()
+            got.append(vcf_sample_field(g, d, len(u.alleles)))
+        assert got == want, (got, want)

@@ -14,11 +14,11 @@ def binary():
 
 
 def test_host_classes_cpu(binary):
-    r = subprocess.run([binary, "cpu"], capture_output=True, text=True, timeout=120)
+    r = subprocess.run([binary, "cpu", str(build.ROOT / "tests" / "golden")], capture_output=True, text=True, timeout=120)
     assert r.returncode == 0, r.stdout + r.stderr
 
 
 @pytest.mark.gpu
 def test_hmm_through_cpp_adapter_gpu(binary):
-    r = subprocess.run([binary, "gpu"], capture_output=True, text=True, timeout=300)
+    r = subprocess.run([binary, "gpu", str(build.ROOT / "tests" / "golden")], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stdout + r.stderr
