@@ -14,14 +14,14 @@ seed0 = int(sys.argv[2]) if len(sys.argv) > 2 else 1
 rng = np.random.default_rng(seed0)
 worst, t0 = 0.0, time.time()
 for it in range(n):
-    H = int(rng.choice([1, 2, 5, 13, 16, 17, 27, 32, 33, 50, 64, 65, 100, 128]))
-    V = int(rng.integers(1, 900 if H <= 64 else 250))
+    H = int(rng.choice([1, 2, 5, 13, 16, 17, 27, 32, 33, 50, 64, 64, 64, 65, 100, 128, 129, 200, 300]))
+    V = int(rng.integers(1, 900 if H <= 64 else (250 if H <= 128 else 60)))
     K = int(rng.choice([8, 20, 40, 128]))
     multi = float(rng.choice([0.0, 0.2, 0.6]))
     wide = bool(rng.random() < 0.3) and K >= 40
     kw = dict(multiallelic_frac=multi, undefined_frac=float(rng.choice([0.0, 0.05, 0.3])), zero_kmer_frac=float(rng.choice([0.0, 0.05])))
     if wide:
-        kw.update(max_alleles=int(rng.integers(6, 33)), local_alts=int(rng.integers(5, 32)), multiallelic_frac=max(multi, 0.2))
+        kw.update(max_alleles=int(rng.integers(6, 70)), local_alts=int(rng.integers(5, 60)), multiallelic_frac=max(multi, 0.2))
     b = synthetic_panel(V, H, K, seed=int(rng.integers(1 << 30)), **kw)
     reg = float(rng.choice([0.01, 0.01, 0.0, 0.001]))
     if reg == 0.0:
@@ -34,13 +34,18 @@ for it in range(n):
     recomb, uniform, N = [(1.26, False, 1e-5), (1.26, True, 1e-5), (0.001, False, 1e-5), (446.287102628, False, 0.25), (1.26, False, 25000.0)][int(rng.integers(5))]
     mode = str(rng.choice(["fused", "chunked", "chunked"]))
     os.environ["PG_SWEEP_MODE"] = mode
+    kern = str(rng.choice(["", "", "general", "generic"]))
+    if kern:
+        os.environ["PG_SWEEP_KERNEL"] = kern
+    else:
+        os.environ.pop("PG_SWEEP_KERNEL", None)
     os.environ["PG_CHUNK_COLS"] = str(int(rng.choice([1, 3, 16, 64, 4096])))
     res = hmm.genotype_contig(b, hmm.ProbabilityTable(*args), hmm.make_params(recomb, uniform, N))
     ref = orc.genotype_contig(b, orc.OracleTable(*args), orc.make_params(recomb, uniform, N))
     try:
         assert_parity(b, res, ref)
     except AssertionError as e:
-        print("FAIL", it, dict(H=H, V=V, K=K, kw=kw, reg=reg, recomb=recomb, uniform=uniform, N=N, mode=mode, chunk=os.environ["PG_CHUNK_COLS"]), str(e)[:300])
+        print("FAIL", it, dict(H=H, V=V, K=K, kw=kw, reg=reg, recomb=recomb, uniform=uniform, N=N, mode=mode, kern=kern, chunk=os.environ["PG_CHUNK_COLS"]), str(e)[:300])
         sys.exit(1)
     r = rel_errors(b, res.likelihoods_ld(), ref.lik)
     rm = float(r.max()) if r.size else 0.0
