@@ -73,6 +73,15 @@ typedef struct pgo_result {
 int pgo_genotype_contig(const pg_contig_batch* b, const pgo_table* t,
                         const pg_hmm_params* p, pgo_result* out);
 
+/* HaplotypeSampler restatement (pg_sampler_oracle.c; reference src/haplotypesampler.cpp,
+ * src/samplingemissions.cpp, src/samplingtransitions.cpp): same flat batch, over all panel paths. */
+void pgo_sampler_emission_costs(const pg_contig_batch* b, uint16_t* cost_sumA);
+uint32_t pgo_sampler_transition_cost(uint64_t from_pos, uint64_t to_pos, double recombrate, uint32_t nr_paths,
+                                     long double effective_N);
+void pgo_sampler_column_minima(const uint32_t* column, const uint8_t* mask, uint32_t n, uint32_t out4[4]);
+int pgo_sampler_run(const pg_contig_batch* b, uint32_t size, double recombrate, long double effective_N,
+                    uint16_t allele_penalty, uint32_t* sampled_paths, uint32_t* best_scores);
+
 /* geno_off helper (same rule as pg_hmm_geno_offsets). */
 void pgo_geno_offsets(const pg_contig_batch* b, uint64_t* geno_off);
 

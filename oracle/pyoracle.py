@@ -11,7 +11,7 @@ from pathlib import Path
 
 import numpy as np
 
-from pangenie_amd._lib import (PgContigBatch, PgHmmParams, i32p, ldp, u8p, u16p, u64p)
+from pangenie_amd._lib import (PgContigBatch, PgHmmParams, i32p, ldp, u8p, u16p, u32p, u64p)
 
 HERE = Path(__file__).resolve().parent
 LIB_PATH = HERE / "_build" / "libpg_oracle.so"
@@ -66,6 +66,14 @@ def load():
         lib.pgo_genotype_contig.restype = C.c_int
         lib.pgo_geno_offsets.argtypes = [C.POINTER(PgContigBatch), u64p]
         lib.pgo_geno_offsets.restype = None
+        lib.pgo_sampler_emission_costs.argtypes = [C.POINTER(PgContigBatch), u16p]
+        lib.pgo_sampler_emission_costs.restype = None
+        lib.pgo_sampler_transition_cost.argtypes = [C.c_uint64, C.c_uint64, C.c_double, C.c_uint32, ld]
+        lib.pgo_sampler_transition_cost.restype = C.c_uint32
+        lib.pgo_sampler_column_minima.argtypes = [u32p, u8p, C.c_uint32, u32p]
+        lib.pgo_sampler_column_minima.restype = None
+        lib.pgo_sampler_run.argtypes = [C.POINTER(PgContigBatch), C.c_uint32, C.c_double, ld, C.c_uint16, u32p, u32p]
+        lib.pgo_sampler_run.restype = C.c_int
         _lib = lib
     return _lib
 
@@ -175,3 +183,55 @@ def genotype_contig(batch, table: OracleTable, params: PgHmmParams) -> OracleRes
         raise RuntimeError(f"oracle error {rc}")
     r.n_columns = int(c.n_columns)
     return r
+
+
+# --------------------------------------------------------------------------- #
+#  HaplotypeSampler restatement (pg_sampler_oracle.c)
+# --------------------------------------------------------------------------- #
+def sampler_emission_costs(batch) -> np.ndarray:
+    n = int(batch.allele_off[-1])
+    out = np.zeros(max(1, n), np.uint16)
+    load().pgo_sampler_emission_costs(C.byref(batch.as_c()), out.ctypes.data_as(u16p))
+    return out[:n]
+
+
+def sampler_transition_cost(from_pos, to_pos, recombrate, nr_paths, effective_N=25000.0) -> int:
+    return int(load().pgo_sampler_transition_cost(int(from_pos), int(to_pos), float(recombrate), int(nr_paths), np.longdouble(effective_N)))
+
+
+def sampler_column_minima(column, mask):
+    col = np.ascontiguousarray(column, np.uint32)
+    m = np.ascontiguousarray(mask, np.uint8)
+    out = np.zeros(4, np.uint32)
+    load().pgo_sampler_column_minima(col.ctypes.data_as(u32p), m.ctypes.data_as(u8p), col.size, out.ctypes.data_as(u32p))
+    return tuple(int(x) for x in out)
+
+
+def sampler_run(batch, size, recombrate=1.26, effective_N=25000.0, allele_penalty=10):
+    """-> (sampled_paths [size, V] u32, best_scores [size] u32)"""
+    V = batch.n_variants
+    sampled = np.zeros((size, max(V, 1)), np.uint32)
+    best = np.zeros(max(size, 1), np.uint32)
+    rc = load().pgo_sampler_run(C.byref(batch.as_c()), size, float(recombrate), np.longdouble(effective_N), int(allele_penalty),
+                                sampled.ctypes.data_as(u32p), best.ctypes.data_as(u32p))
+    if rc:
+        raise RuntimeError(f"oracle sampler error {rc}")
+    return sampled[:, :V], best[:size]
+
+
+_ref_transitions = None
+
+
+def ref_transition_cost(from_pos, to_pos, recombrate, nr_paths, effective_N=25000.0):
+    """The reference's OWN SamplingTransitions translation unit (oracle/_ref/libref_transitions.so, built by
+    `make ref` where /root/reference exists).  Returns None when the library is not there."""
+    global _ref_transitions
+    path = HERE / "_ref" / "libref_transitions.so"
+    if _ref_transitions is None:
+        if not path.exists():
+            return None
+        lib = C.CDLL(str(path))
+        lib.ref_sampling_transition_cost.argtypes = [C.c_ulonglong, C.c_ulonglong, C.c_double, C.c_ushort, C.c_longdouble]
+        lib.ref_sampling_transition_cost.restype = C.c_uint
+        _ref_transitions = lib
+    return int(_ref_transitions.ref_sampling_transition_cost(int(from_pos), int(to_pos), float(recombrate), int(nr_paths), np.longdouble(effective_N)))

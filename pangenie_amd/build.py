@@ -10,8 +10,8 @@ from pathlib import Path
 ROOT = Path(__file__).resolve().parent.parent
 CSRC = ROOT / "pangenie_amd" / "csrc"
 HIP_LIB = CSRC / "libpangenie_hmm.so"
-HIP_SOURCES = [CSRC / "pg_kernels.hip", CSRC / "pg_shim.cpp", CSRC / "pg_gather.cpp"]
-HIP_DEPS = HIP_SOURCES + [CSRC / "pg_device.h", ROOT / "include" / "pangenie_hmm.h"]
+HIP_SOURCES = [CSRC / "pg_kernels.hip", CSRC / "pg_shim.cpp", CSRC / "pg_gather.cpp", CSRC / "pg_sampler.hip"]
+HIP_DEPS = HIP_SOURCES + [CSRC / "pg_device.h", ROOT / "include" / "pangenie_hmm.h", ROOT / "include" / "pangenie_sampler.h"]
 
 
 def _stale(target: Path, deps) -> bool:
@@ -54,6 +54,9 @@ def build_oracle(force: bool = False) -> Path:
     if force:
         subprocess.run(["make", "-C", str(ROOT / "oracle"), "clean"], check=True, capture_output=True)
     subprocess.run(["make", "-C", str(ROOT / "oracle")], check=True, capture_output=True)
+    if Path("/root/reference/src/samplingtransitions.cpp").exists():
+        # oracle/_ref: the one reference translation unit of the path that compiles here (see oracle/Makefile)
+        subprocess.run(["make", "-C", str(ROOT / "oracle"), "ref"], check=True, capture_output=True)
     return ROOT / "oracle" / "_build" / "libpg_oracle.so"
 
 

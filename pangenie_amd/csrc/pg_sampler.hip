@@ -1,0 +1,749 @@
+// pg_sampler.hip — MI355X-native HaplotypeSampler (include/pangenie_sampler.h).
+//
+// The reference (src/haplotypesampler.cpp) runs `size` passes of an integer min-plus Viterbi over the H
+// panel paths, each pass masking the paths earlier passes picked at a column and penalising the alleles
+// they covered.  Per column the update is
+//     cell_i = min( prev_i            (same path, if prev_i is unmasked; cost 0),
+//                   min_{j != i} prev_j + cost(recombination) )  + emission(allele of path i)
+// i.e. elementwise work on H values plus ONE reduction: the smallest and second smallest entry of the
+// previous column (the minimum "over all j but i" is the first unless i holds it).  Integer work with a
+// sequential dependency over the columns AND over the passes: the only parallelism is over the paths of a
+// column (one workgroup) and over contigs (one workgroup each), so the design goal is the shortest
+// possible dependent chain per column.  No MFMA, no GEMM shape.
+//
+// Fast path (every realistic input; the host checks the two bounds that make it exact):
+//   ks_expand         all CUs, per pass: emission cost of every (column, path) cell as ONE byte (0xFF =
+//                     masked by an earlier pass / beyond H), stored thread-major so that the sequential
+//                     kernel reads one coalesced dword per lane and column
+//   ks_forward_fast   one workgroup per contig, 4 paths per lane.  Values are kept RELATIVE to the
+//                     previous column's minimum (all unmasked cells lie within recombination cost + 50 of
+//                     it), so (value, index) packs into one u32 key and "smaller value, then smaller index"
+//                     (the reference's tie rule, src/haplotypesampler.cpp:79-107) is v_min_u32: the two
+//                     reductions per column are 6 DPP steps each, one LDS exchange + one barrier when the
+//                     workgroup has more than one wave.  The cost bytes are prefetched 16 columns ahead.
+//                     The backtrace is 1 bit per cell ("stayed on the path") + the two minima ids per column.
+//   ks_backtrack_fast one wave per contig, 64 columns at a time: a ballot finds the next column at which
+//                     the traced path switched; writes the sampled path and applies
+//                     SamplingEmissions::penalize to the alleles on it
+// General path (saturating arithmetic, any cost range, H up to 65534; PG_SAMPLER_KERNEL=general forces
+// it): ks_forward / ks_backtrack with u64 keys and u16 backtrace ids.
+// Costs are formed on the HOST exactly as the reference forms them (float / long double + truncation).
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <stdarg.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include <vector>
+
+#include "../../include/pangenie_sampler.h"
+
+#define KS_UMAX 0xFFFFFFFFu
+#define KS_KMAX 0xFFFFFFFFFFFFFFFFull
+#define KS_MAXPPT 64    // paths per thread of the general kernel (H <= 65536 at 1024 threads)
+#define KS_MAXPASS 64   // passes whose picks are kept in LDS for the masks
+#define KS_BT_BLOCK 32  // columns per backtrack block of the general kernel
+#define KS_INF 0x40000000u  // relative value of a masked cell (fast path)
+#define KS_DEPTH 16     // columns of cost bytes in flight per lane (fast path)
+
+namespace {
+
+void set_err(char* err, size_t errlen, const char* fmt, ...) {
+    if (!err || errlen == 0) return;
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(err, errlen, fmt, ap);
+    va_end(ap);
+}
+
+struct SamplerDev {
+    uint32_t V, P, T, penalty;    // T = threads of the fast forward kernel (4 paths each)
+    const uint32_t* allele_off;   // [V+1]
+    const uint16_t* allele_id;    // [sumA]
+    const uint16_t* path_allele;  // [V*P]
+    const uint32_t* tcost;        // [V+48] cost of a recombination between columns c-1 and c
+    uint16_t* ecost;              // [sumA] emission costs, penalised pass by pass
+    uint32_t* paths;              // [size*V] sampled paths
+    uint32_t* best;               // [size]
+    // general path
+    uint16_t* bt;                 // [V*P] backtrace ids of the pass in flight (0xFFFF = none)
+    uint32_t* last_col;           // [P] last column of the pass in flight
+    // fast path
+    uint32_t* ecell;              // [(V+32)*T] byte k of word (c, t) = cost of path k*T + t at column c
+    uint32_t* stay;               // [ceil((V-1)/16)*2*T] "cell continued its own path" bits, 16 columns per half word
+    uint32_t* minima;             // [V] first | second << 16: ids of the two smallest entries of column c-1
+    uint32_t* last;               // [1] best path of the last column
+};
+
+// ------------------------------------------------------------------------------------------------
+//  general path
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ unsigned long long shfl_xor_u64(unsigned long long v, int m) {
+    const int lo = __shfl_xor((int)(uint32_t)v, m), hi = __shfl_xor((int)(uint32_t)(v >> 32), m);
+    return ((unsigned long long)(uint32_t)hi << 32) | (uint32_t)lo;
+}
+// merge two sorted pairs of distinct keys into the two smallest
+__device__ __forceinline__ void top2_merge(unsigned long long& a1, unsigned long long& a2, unsigned long long b1, unsigned long long b2) {
+    const unsigned long long f = a1 < b1 ? a1 : b1;
+    const unsigned long long s = a1 < b1 ? (a2 < b1 ? a2 : b1) : (a1 < b2 ? a1 : b2);
+    a1 = f; a2 = s;
+}
+
+// one pass of the Viterbi: grid = contigs, block = T threads
+template <int T, int PPT>
+__global__ __launch_bounds__(T) void ks_forward(const SamplerDev* devs, uint32_t pass) {
+    __shared__ unsigned long long s_k1[T / 64], s_k2[T / 64];
+    __shared__ uint16_t s_aid[2][256];
+    __shared__ uint16_t s_ec[2][256];
+    __shared__ uint32_t s_pick[2][KS_MAXPASS];
+    const SamplerDev d = devs[blockIdx.x];
+    const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+    const uint32_t V = d.V, P = d.P;
+    uint32_t prev[PPT];  // the column, in registers: path tid + k*T in prev[k]
+    unsigned long long prev_ok = 0ull;  // bit k: path tid + k*T was unmasked in the previous column
+    // stage column c's alleles / emission costs / earlier picks into LDS buffer c & 1
+    auto stage = [&](uint32_t c) {
+        if (c >= V) return;
+        const uint32_t a0 = d.allele_off[c], A = d.allele_off[c + 1] - a0;
+        for (uint32_t q = tid; q < A && q < 256u; q += T) { s_aid[c & 1u][q] = d.allele_id[a0 + q]; s_ec[c & 1u][q] = d.ecost[a0 + q]; }
+        for (uint32_t q = tid; q < pass && q < KS_MAXPASS; q += T) s_pick[c & 1u][q] = d.paths[(size_t)q * V + c];
+    };
+    stage(0);
+    __syncthreads();
+    for (uint32_t c = 0; c < V; ++c) {
+        const uint32_t b = c & 1u;
+        const uint32_t a0 = d.allele_off[c], A = d.allele_off[c + 1] - a0;
+        // ---- smallest and second smallest unmasked entry of the previous column
+        unsigned long long k1 = KS_KMAX, k2 = KS_KMAX;
+        if (c > 0) {
+#pragma unroll
+            for (int k = 0; k < PPT; ++k) {
+                const uint32_t i = tid + k * T;
+                if (i < P && ((prev_ok >> k) & 1ull) && prev[k] != KS_UMAX) {  // a saturated entry is never a minimum (strict <)
+                    const unsigned long long key = ((unsigned long long)prev[k] << 32) | i;
+                    if (key < k1) { k2 = k1; k1 = key; }
+                    else if (key < k2) k2 = key;
+                }
+            }
+#pragma unroll
+            for (int m = 1; m < 64; m <<= 1) {
+                const unsigned long long o1 = shfl_xor_u64(k1, m), o2 = shfl_xor_u64(k2, m);
+                top2_merge(k1, k2, o1, o2);
+            }
+            if (lane == 0) { s_k1[wave] = k1; s_k2[wave] = k2; }
+        }
+        stage(c + 1);  // next column's tables into the other buffer (read after the next barrier)
+        __syncthreads();
+        uint32_t first_val = KS_UMAX, first_id = KS_UMAX, second_val = KS_UMAX, second_id = KS_UMAX, tcost = 0;
+        if (c > 0) {
+            k1 = s_k1[0]; k2 = s_k2[0];
+            for (int w = 1; w < T / 64; ++w) top2_merge(k1, k2, s_k1[w], s_k2[w]);
+            if (k1 != KS_KMAX) { first_val = (uint32_t)(k1 >> 32); first_id = (uint32_t)k1; }
+            if (k2 != KS_KMAX) { second_val = (uint32_t)(k2 >> 32); second_id = (uint32_t)k2; }
+            tcost = d.tcost[c];
+        }
+        // ---- the column (reference src/haplotypesampler.cpp:242-283)
+        unsigned long long cur_ok = 0ull;
+#pragma unroll
+        for (int k = 0; k < PPT; ++k) {
+            const uint32_t i = tid + k * T;
+            if (i >= P) continue;
+            bool ok = true;  // SampledPaths::mask_indexes: false if an earlier pass picked path i here
+            for (uint32_t q = 0; q < pass && q < KS_MAXPASS; ++q) ok = ok && (s_pick[b][q] != i);
+            for (uint32_t q = KS_MAXPASS; q < pass; ++q) ok = ok && (d.paths[(size_t)q * V + c] != i);
+            uint32_t cell = KS_UMAX;
+            uint16_t back = 0xFFFFu;
+            if (ok) {
+                uint32_t previous_cell = 0;
+                if (c > 0) {
+                    const uint32_t hv = (i == first_id) ? second_val : first_val;
+                    const uint32_t hid = (i == first_id) ? second_id : first_id;
+                    previous_cell = hv + tcost;
+                    if (previous_cell < hv) previous_cell = KS_UMAX;
+                    back = (uint16_t)hid;  // (0xFFFFFFFF -> 0xFFFF: none)
+                    if ((prev_ok >> k) & 1ull) {
+                        const uint32_t same = prev[k];
+                        if (same < previous_cell) { previous_cell = same; back = (uint16_t)i; }
+                    }
+                }
+                const uint16_t allele = d.path_allele[(size_t)c * P + i];
+                uint32_t e = 0;
+                if (A <= 256u) {
+                    for (uint32_t q = 0; q < A; ++q) if (s_aid[b][q] == allele) { e = s_ec[b][q]; break; }
+                } else {
+                    for (uint32_t q = 0; q < A; ++q) if (d.allele_id[a0 + q] == allele) { e = d.ecost[a0 + q]; break; }
+                }
+                cell = previous_cell + e;
+                if (cell < previous_cell) cell = KS_UMAX;
+                cur_ok |= 1ull << k;
+            }
+            prev[k] = cell;
+            d.bt[(size_t)c * P + i] = back;
+        }
+        prev_ok = cur_ok;
+        // (the barrier of the next iteration separates this column's reads of buffer b from the staging
+        // of column c+2 into it; s_k1/s_k2 are rewritten only after that barrier too)
+        __syncthreads();
+    }
+#pragma unroll
+    for (int k = 0; k < PPT; ++k) {
+        const uint32_t i = tid + k * T;
+        if (i < P) d.last_col[i] = prev[k];
+    }
+}
+
+// SamplingEmissions::penalize on the allele the picked path carries (src/samplingemissions.cpp:39-45)
+__device__ __forceinline__ void penalize(const SamplerDev& d, uint32_t c, uint32_t path) {
+    const uint32_t a0 = d.allele_off[c], A = d.allele_off[c + 1] - a0;
+    const uint16_t allele = d.path_allele[(size_t)c * d.P + path];
+    for (uint32_t q = 0; q < A; ++q)
+        if (d.allele_id[a0 + q] == allele) {
+            uint16_t e = (uint16_t)(d.ecost[a0 + q] + d.penalty);  // unsigned short arithmetic, as in the reference
+            if (e > 25u) e = 25u;
+            d.ecost[a0 + q] = e;
+            break;
+        }
+}
+
+// backtrace of one pass: grid = contigs, block = 256 threads
+__global__ __launch_bounds__(256) void ks_backtrack(const SamplerDev* devs, uint32_t pass, uint32_t lds_cols) {
+    extern __shared__ uint16_t s_bt[];  // [lds_cols][P] when a block fits, else unused
+    __shared__ uint32_t s_best;
+    const SamplerDev d = devs[blockIdx.x];
+    const uint32_t tid = threadIdx.x, V = d.V, P = d.P;
+    if (tid == 0) {
+        // best value in the last column: the FIRST minimum, masked entries included (they hold UINT_MAX)
+        uint32_t bi = 0, bv = d.last_col[0];
+        for (uint32_t i = 1; i < P; ++i) if (d.last_col[i] < bv) { bv = d.last_col[i]; bi = i; }
+        d.best[pass] = bv;
+        s_best = bi;
+    }
+    __syncthreads();
+    uint32_t best = s_best;
+    const bool lds = lds_cols > 0 && (size_t)lds_cols * P * 2 <= 64u * 1024u;
+    int64_t hi = (int64_t)V - 1;
+    while (hi >= 0) {
+        const int64_t lo = (lds && hi + 1 > (int64_t)lds_cols) ? hi + 1 - lds_cols : 0;
+        if (lds) {  // stage columns lo..hi (coalesced), then chase through LDS
+            const size_t n = (size_t)(hi - lo + 1) * P;
+            const uint16_t* src = d.bt + (size_t)lo * P;
+            for (size_t q = tid; q < n; q += 256) s_bt[q] = src[q];
+            __syncthreads();
+        }
+        if (tid == 0) {
+            for (int64_t c = hi; c >= lo; --c) {
+                d.paths[(size_t)pass * V + c] = best;
+                penalize(d, (uint32_t)c, best);
+                if (c > 0) best = lds ? s_bt[(size_t)(c - lo) * P + best] : d.bt[(size_t)c * P + best];
+            }
+            s_best = best;
+        }
+        __syncthreads();
+        best = s_best;
+        hi = lo - 1;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+//  fast path
+// ------------------------------------------------------------------------------------------------
+// cost byte of every cell of this pass: grid = (column blocks, contigs), block = 256
+__global__ __launch_bounds__(256) void ks_expand(const SamplerDev* devs, uint32_t pass) {
+    const SamplerDev d = devs[blockIdx.y];
+    const uint32_t V = d.V, P = d.P, T = d.T;
+    for (uint32_t c = blockIdx.x; c < V; c += gridDim.x) {
+        const uint32_t a0 = d.allele_off[c], A = d.allele_off[c + 1] - a0;
+        for (uint32_t t = threadIdx.x; t < T; t += 256) {
+            uint32_t word = 0;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const uint32_t i = (uint32_t)k * T + t;
+                uint32_t e = 0xFFu;
+                if (i < P) {
+                    bool ok = true;  // SampledPaths::mask_indexes
+                    for (uint32_t q = 0; q < pass; ++q) ok = ok && (d.paths[(size_t)q * V + c] != i);
+                    if (ok) {
+                        const uint16_t allele = d.path_allele[(size_t)c * P + i];
+                        e = 0;
+                        for (uint32_t q = 0; q < A; ++q) if (d.allele_id[a0 + q] == allele) { e = d.ecost[a0 + q]; break; }
+                    }
+                }
+                word |= e << (8 * k);
+            }
+            d.ecell[(size_t)c * T + t] = word;
+        }
+    }
+}
+
+template <int CTRL, int ROWMASK>
+__device__ __forceinline__ uint32_t dpp_min(uint32_t v) {
+    const uint32_t o = (uint32_t)__builtin_amdgcn_update_dpp((int)KS_UMAX, (int)v, CTRL, ROWMASK, 0xF, false);
+    return o < v ? o : v;
+}
+// minimum over the wave, uniform: row_shr 1/2/4/8 gather each row of 16 into its last lane, row_bcast15 /
+// row_bcast31 carry the row results to lane 63
+__device__ __forceinline__ uint32_t wave_min(uint32_t v) {
+    v = dpp_min<0x111, 0xF>(v);
+    v = dpp_min<0x112, 0xF>(v);
+    v = dpp_min<0x114, 0xF>(v);
+    v = dpp_min<0x118, 0xF>(v);
+    v = dpp_min<0x142, 0xA>(v);
+    v = dpp_min<0x143, 0xC>(v);
+    return (uint32_t)__builtin_amdgcn_readlane((int)v, 63);
+}
+// the same over one row of 16 lanes (for values every row holds alike)
+__device__ __forceinline__ uint32_t row_min(uint32_t v) {
+    v = dpp_min<0x111, 0xF>(v);
+    v = dpp_min<0x112, 0xF>(v);
+    v = dpp_min<0x114, 0xF>(v);
+    v = dpp_min<0x118, 0xF>(v);
+    return (uint32_t)__builtin_amdgcn_readlane((int)v, 15);
+}
+
+// smallest and second smallest key of the workgroup's 4 * NW * 64 keys
+template <int NW>
+__device__ __forceinline__ void block_top2(const uint32_t (&k)[4], uint32_t (*s_x)[2], uint32_t wave, uint32_t lane, uint32_t& F, uint32_t& S) {
+    const uint32_t m01 = min(k[0], k[1]), m23 = min(k[2], k[3]);
+    const uint32_t fw = wave_min(min(m01, m23));
+    uint32_t cand = KS_UMAX;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) cand = min(cand, k[j] == fw ? KS_UMAX : k[j]);
+    const uint32_t sw = wave_min(cand);
+    if (NW == 1) { F = fw; S = sw; return; }
+    if (lane == 0) { s_x[wave][0] = fw; s_x[wave][1] = sw; }
+    __syncthreads();
+    const uint32_t a = s_x[lane & (NW - 1)][0], b = s_x[lane & (NW - 1)][1];
+    F = row_min(a);  // NW <= 16: every row of 16 lanes holds all the waves' pairs
+    S = row_min(a == F ? b : a);
+}
+
+#define KS_AS1 __attribute__((address_space(1)))  // loads / stores through these compile to global_* (vmcnt only), not flat_*
+
+// one column of the relative-value DP (reference src/haplotypesampler.cpp:223-284).  r[] = the previous
+// column relative to `base`, w = the four cost bytes of this column, t = recombination cost.  Returns the
+// stay bits in st[], the packed ids (first | second << 16) of the previous column's minima in `mins`.
+template <int NW>
+__device__ __forceinline__ void fast_column(uint32_t (&r)[4], uint32_t& base, uint32_t w, uint32_t t, uint32_t (*s_x)[2], uint32_t tid,
+                                            uint32_t wave, uint32_t lane, bool (&st)[4], uint32_t& mins) {
+    constexpr uint32_t T = NW * 64;
+    uint32_t k[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) k[q] = r[q] >= KS_INF ? KS_UMAX : ((r[q] << 16) | ((uint32_t)q * T + tid));
+    uint32_t F, S;
+    block_top2<NW>(k, s_x, wave, lane, F, S);
+    const uint32_t m = F >> 16, first_id = F & 0xFFFFu;
+    const uint32_t h_first = S == KS_UMAX ? KS_INF : (S >> 16) - m + t;  // helper of the minimum itself: the second
+    base += m;
+    mins = first_id | (S << 16);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const uint32_t i = (uint32_t)q * T + tid;
+        const uint32_t e = (w >> (8 * q)) & 0xFFu;
+        const uint32_t same = r[q] - m;  // stays huge when the cell was masked
+        const uint32_t h = i == first_id ? h_first : t;
+        st[q] = same < h;  // strict: a tie goes to the recombination (src/haplotypesampler.cpp:272)
+        const uint32_t v = (st[q] ? same : h) + e;
+        r[q] = e == 0xFFu ? KS_INF : v;
+    }
+}
+
+// Backtrace layout of the fast path: columns 1.. are grouped in blocks of 16 (column c -> block (c-1)/16,
+// bit (c-1)%16); per block and thread two dwords hold the stay bits of its four paths
+// (q0 | q1 << 16, q2 | q3 << 16); minima[c] = first_id | second_id << 16 of column c-1.
+template <int NW>
+__global__ __launch_bounds__(NW * 64) void ks_forward_fast(const SamplerDev* devs, uint32_t pass) {
+    constexpr uint32_t T = NW * 64;
+    __shared__ uint32_t s_x[2][NW][2];
+    const SamplerDev d = devs[blockIdx.x];
+    const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+    const uint32_t V = d.V;
+    const uint32_t KS_AS1* ecell = (const uint32_t KS_AS1*)d.ecell + tid;
+    const uint32_t KS_AS1* tcost = (const uint32_t KS_AS1*)d.tcost;
+    uint32_t KS_AS1* stay = (uint32_t KS_AS1*)d.stay + tid;
+    uint32_t KS_AS1* minima = (uint32_t KS_AS1*)d.minima;
+    uint32_t r[4];  // values relative to `base`; KS_INF when masked
+    uint32_t base = 0;
+    {
+        const uint32_t w = ecell[0];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) { const uint32_t e = (w >> (8 * q)) & 0xFFu; r[q] = e == 0xFFu ? KS_INF : e; }
+    }
+    const uint32_t nfull = (V - 1) / 16;  // blocks of 16 columns after column 0
+    // cost words of the block in flight and of the next one: the loads of block b+1 are issued before block b
+    // is processed, a whole block (16 dependent columns) ahead of their use.  ecell / tcost are padded by 32
+    // columns, so the prefetch never needs a bounds check.
+    uint32_t cur[16], nxt[16];
+#pragma unroll
+    for (int j = 0; j < 16; ++j) cur[j] = ecell[(size_t)(1u + j) * T];
+    uint32_t tc_cur = tcost[1u + (lane & 15u)], tc_next;
+    uint32_t par = 0;
+    for (uint32_t blk = 0; blk < nfull; ++blk) {
+        const uint32_t c0 = 1u + 16u * blk;
+#pragma unroll
+        for (int j = 0; j < 16; ++j) nxt[j] = ecell[(size_t)(c0 + 16u + j) * T];
+        tc_next = tcost[c0 + 16u + (lane & 15u)];
+        uint32_t hist[4] = {0u, 0u, 0u, 0u}, mins_v = 0;
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            const uint32_t t = (uint32_t)__builtin_amdgcn_readlane((int)tc_cur, j);
+            bool st[4];
+            uint32_t mins;
+            fast_column<NW>(r, base, cur[j], t, s_x[par], tid, wave, lane, st, mins);
+            par ^= 1u;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) hist[q] |= st[q] ? (1u << j) : 0u;
+            mins_v = lane == (uint32_t)j ? mins : mins_v;
+        }
+        stay[(size_t)(blk * 2u) * T] = hist[0] | (hist[1] << 16);
+        stay[(size_t)(blk * 2u + 1u) * T] = hist[2] | (hist[3] << 16);
+        if (tid < 16u) minima[c0 + tid] = mins_v;
+#pragma unroll
+        for (int j = 0; j < 16; ++j) cur[j] = nxt[j];
+        tc_cur = tc_next;
+    }
+    {   // the last, partial block
+        const uint32_t c0 = 1u + 16u * nfull;
+        uint32_t hist[4] = {0u, 0u, 0u, 0u};
+        for (uint32_t c = c0; c < V; ++c) {
+            const uint32_t j = c - c0;
+            bool st[4];
+            uint32_t mins;
+            fast_column<NW>(r, base, ecell[(size_t)c * T], tcost[c], s_x[par], tid, wave, lane, st, mins);
+            par ^= 1u;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) hist[q] |= st[q] ? (1u << j) : 0u;
+            if (tid == 0) minima[c] = mins;
+        }
+        if (c0 < V) {
+            stay[(size_t)(nfull * 2u) * T] = hist[0] | (hist[1] << 16);
+            stay[(size_t)(nfull * 2u + 1u) * T] = hist[2] | (hist[3] << 16);
+        }
+    }
+    // best value in the last column = its first minimum (at least one cell is unmasked and finite)
+    uint32_t k[4], F, S;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) k[q] = r[q] >= KS_INF ? KS_UMAX : ((r[q] << 16) | ((uint32_t)q * T + tid));
+    block_top2<NW>(k, s_x[par], wave, lane, F, S);
+    if (tid == 0) { d.best[pass] = base + (F >> 16); d.last[0] = F & 0xFFFFu; }
+}
+
+// grid = contigs, block = one wave.  The traced path stays on `b` until a column whose stay bit is 0; each
+// lane inspects one block of 16 columns, so one step covers 1024 columns.
+__global__ __launch_bounds__(64) void ks_backtrack_fast(const SamplerDev* devs, uint32_t pass) {
+    const SamplerDev d = devs[blockIdx.x];
+    const uint32_t lane = threadIdx.x, V = d.V, T = d.T;
+    auto assign = [&](uint32_t lo, uint32_t hi, uint32_t path) {  // columns lo..hi carry `path`
+        for (uint32_t c = lo + lane; c <= hi; c += 64u) {
+            d.paths[(size_t)pass * V + c] = path;
+            penalize(d, c, path);
+        }
+    };
+    uint32_t b = d.last[0], cur = V - 1;  // the state at column cur is b
+    while (cur >= 1u) {
+        const uint32_t blk_cur = (cur - 1u) / 16u, j_cur = (cur - 1u) % 16u;
+        const bool valid = lane <= blk_cur;
+        const uint32_t q = b / T, t = b % T;
+        uint32_t word = 0xFFFFu;
+        if (valid) {
+            const uint32_t dw = d.stay[((size_t)(blk_cur - lane) * 2u + (q >> 1)) * T + t];
+            word = (q & 1u) ? dw >> 16 : dw & 0xFFFFu;
+        }
+        if (lane == 0) word |= ~((2u << j_cur) - 1u);  // columns above cur are behind us
+        const uint32_t zero = ~word & 0xFFFFu;
+        const unsigned long long sw = __ballot(valid && zero != 0u);
+        if (sw == 0ull) {
+            const uint32_t lo = blk_cur >= 63u ? (blk_cur - 63u) * 16u + 1u : 1u;
+            assign(lo, cur, b);
+            cur = lo - 1u;
+            continue;
+        }
+        const uint32_t ls = (uint32_t)__ffsll((long long)sw) - 1u;
+        const uint32_t wz = (uint32_t)__builtin_amdgcn_readlane((int)zero, ls);
+        const uint32_t cs = (blk_cur - ls) * 16u + 1u + (31u - (uint32_t)__clz((int)wz));  // the highest column at which the path switched
+        assign(cs, cur, b);
+        const uint32_t mm = d.minima[cs], fid = mm & 0xFFFFu, sid = mm >> 16;
+        b = b == fid ? sid : fid;
+        cur = cs - 1u;
+    }
+    assign(0u, 0u, b);
+}
+
+__global__ void ks_minima(const uint32_t* column, const uint8_t* mask, uint32_t n, uint32_t* out4) {
+    __shared__ unsigned long long s_k1[4], s_k2[4];
+    const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+    unsigned long long k1 = KS_KMAX, k2 = KS_KMAX;
+    for (uint32_t i = tid; i < n; i += 256)
+        if (mask[i] && column[i] != KS_UMAX) {
+            const unsigned long long key = ((unsigned long long)column[i] << 32) | i;
+            if (key < k1) { k2 = k1; k1 = key; }
+            else if (key < k2) k2 = key;
+        }
+    for (int m = 1; m < 64; m <<= 1) {
+        const unsigned long long o1 = shfl_xor_u64(k1, m), o2 = shfl_xor_u64(k2, m);
+        top2_merge(k1, k2, o1, o2);
+    }
+    if (lane == 0) { s_k1[wave] = k1; s_k2[wave] = k2; }
+    __syncthreads();
+    if (tid == 0) {
+        k1 = s_k1[0]; k2 = s_k2[0];
+        for (int w = 1; w < 4; ++w) top2_merge(k1, k2, s_k1[w], s_k2[w]);
+        out4[0] = k1 == KS_KMAX ? KS_UMAX : (uint32_t)k1;
+        out4[1] = k2 == KS_KMAX ? KS_UMAX : (uint32_t)k2;
+        out4[2] = k1 == KS_KMAX ? KS_UMAX : (uint32_t)(k1 >> 32);
+        out4[3] = k2 == KS_KMAX ? KS_UMAX : (uint32_t)(k2 >> 32);
+    }
+}
+
+thread_local double g_last_ms[3] = {0.0, 0.0, 0.0};
+thread_local int g_last_kernel = 0;
+
+unsigned on_slot(const pg_contig_batch* b, uint32_t slot, uint32_t k) {
+    const uint32_t off = b->allele_kmer_off[slot];
+    if (k < off || k >= off + 32u) return 0;
+    return (b->allele_kmer_mask[slot] >> (k - off)) & 1u;
+}
+
+int check_panel(const pg_contig_batch* b, uint32_t size, char* err, size_t errlen) {
+    const uint32_t V = b->n_variants, P = b->n_paths;
+    if (P < 2) { set_err(err, errlen, "HaplotypeSampler needs at least two paths"); return PG_ERR_INVALID; }
+    if (P > 65534u) { set_err(err, errlen, "at most 65534 paths (reference README.md:260)"); return PG_ERR_UNSUPPORTED; }
+    if (size >= P) { set_err(err, errlen, "more passes than paths"); return PG_ERR_INVALID; }
+    if (!b->variant_pos || !b->kmer_off || !b->allele_off || !b->allele_id || !b->allele_flags || !b->allele_kmer_off ||
+        !b->allele_kmer_mask || !b->path_allele || (b->kmer_off[V] > 0 && !b->kmer_count)) {
+        set_err(err, errlen, "batch has null arrays");
+        return PG_ERR_INVALID;
+    }
+    for (uint32_t v = 0; v < V; ++v)
+        if (b->allele_off[v + 1] <= b->allele_off[v] || b->kmer_off[v + 1] < b->kmer_off[v]) { set_err(err, errlen, "malformed offsets at variant %u", v); return PG_ERR_INVALID; }
+    return PG_OK;
+}
+
+}  // namespace
+
+extern "C" int pg_sampler_emission_costs(const pg_contig_batch* b, uint16_t* cost) {
+    if (!b || !cost) return PG_ERR_INVALID;
+    for (uint32_t v = 0; v < b->n_variants; ++v) {
+        const uint32_t k0 = b->kmer_off[v], K = b->kmer_off[v + 1] - k0;
+        for (uint32_t s = b->allele_off[v]; s < b->allele_off[v + 1]; ++s) {
+            if (b->allele_flags[s] & 1) { cost[s] = 50; continue; }  // undefined allele (src/samplingemissions.cpp:18-21)
+            /* total = KmerPath::nr_kmers (popcount of the window, src/kmerpath.cpp:50-55); present = k-mers of the
+             * variant with a read count >= 3 that lie on the allele (src/multiallelicuniquekmers.cpp:155-162) */
+            unsigned short total = (unsigned short)__builtin_popcount(b->allele_kmer_mask[s]), present = 0;
+            for (uint32_t k = 0; k < K; ++k)
+                if (b->kmer_count[k0 + k] >= 3 && on_slot(b, s, k)) present += 1;
+            const float fraction = total > 0 ? present / (float)total : 1.0f;
+            // the reference's `log10(fraction)` is the FLOAT overload (<cmath>, using namespace std): log10f
+            if (fraction > 0.0) cost[s] = (unsigned short)(-10.0 * log10f(fraction));
+            else cost[s] = 25;
+        }
+    }
+    return PG_OK;
+}
+
+extern "C" uint32_t pg_sampler_transition_cost(uint64_t from_pos, uint64_t to_pos, double recombrate, uint32_t nr_paths,
+                                               long double effective_N) {
+    const long double distance = (to_pos - from_pos) * 0.000004L * ((long double)recombrate) * effective_N;
+    // the reference's exp()/log10() here are the C double functions (no `using namespace std` in
+    // src/samplingtransitions.cpp), the products around them long double
+    const long double recomb_prob = (1.0L - exp((double)(-distance / (long double)nr_paths))) * (1.0L / (long double)nr_paths);
+    const double cost = -10.0 * log10((double)recomb_prob);
+    if (!(cost < 4294967295.0)) return KS_UMAX;  // coincident positions: undefined in the reference, saturates here
+    if (cost < 0.0) return 0;
+    return (unsigned int)cost;
+}
+
+#define HIP_TRY(call)                                                                     \
+    do {                                                                                  \
+        hipError_t e_ = (call);                                                           \
+        if (e_ != hipSuccess) {                                                           \
+            set_err(err, errlen, "%s failed: %s", #call, hipGetErrorString(e_));          \
+            rc = PG_ERR_DEVICE;                                                           \
+            goto done;                                                                    \
+        }                                                                                 \
+    } while (0)
+
+extern "C" int pg_sampler_column_minima(const uint32_t* column, const uint8_t* mask, uint32_t n, int device, uint32_t out4[4],
+                                        char* err, size_t errlen) {
+    if (!column || !mask || !out4 || n == 0) { set_err(err, errlen, "bad argument"); return PG_ERR_INVALID; }
+    int ndev = 0, rc = PG_OK;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) { set_err(err, errlen, "no HIP device available (no CPU fallback)"); return PG_ERR_DEVICE; }
+    uint32_t *d_col = nullptr, *d_out = nullptr;
+    uint8_t* d_mask = nullptr;
+    HIP_TRY(hipSetDevice(device));
+    HIP_TRY(hipMalloc((void**)&d_col, (size_t)n * 4));
+    HIP_TRY(hipMalloc((void**)&d_mask, n));
+    HIP_TRY(hipMalloc((void**)&d_out, 16));
+    HIP_TRY(hipMemcpy(d_col, column, (size_t)n * 4, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(d_mask, mask, n, hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(ks_minima, dim3(1), dim3(256), 0, nullptr, d_col, d_mask, n, d_out);
+    HIP_TRY(hipMemcpy(out4, d_out, 16, hipMemcpyDeviceToHost));
+done:
+    if (d_col) hipFree(d_col);
+    if (d_mask) hipFree(d_mask);
+    if (d_out) hipFree(d_out);
+    return rc;
+}
+
+extern "C" int pg_sampler_run_batch(const pg_contig_batch* panels, uint32_t n_contigs, uint32_t size, double recombrate,
+                                    long double effective_N, uint16_t allele_penalty, int device, uint32_t* const* sampled_paths,
+                                    uint32_t* const* best_scores, char* err, size_t errlen) {
+    if (!panels || !sampled_paths) { set_err(err, errlen, "null argument"); return PG_ERR_INVALID; }
+    if (size < 1 || n_contigs == 0) return PG_OK;  // reference src/haplotypesampler.cpp:28
+    // contigs without variants have nothing to sample
+    std::vector<uint32_t> live;
+    for (uint32_t g = 0; g < n_contigs; ++g) {
+        if (panels[g].n_variants == 0) continue;
+        if (!sampled_paths[g]) { set_err(err, errlen, "null output for contig %u", g); return PG_ERR_INVALID; }
+        const int rc0 = check_panel(&panels[g], size, err, errlen);
+        if (rc0 != PG_OK) return rc0;
+        live.push_back(g);
+    }
+    if (live.empty()) return PG_OK;
+    int ndev = 0, rc = PG_OK;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) { set_err(err, errlen, "no HIP device available (no CPU fallback)"); return PG_ERR_DEVICE; }
+    if (device < 0 || device >= ndev) { set_err(err, errlen, "bad device %d", device); return PG_ERR_INVALID; }
+    const uint32_t n = (uint32_t)live.size();
+    // host-side costs, and the two bounds under which the relative-value kernel is exact:
+    //   every recombination cost + 51 fits 16 bits (keys), 50 (V + 1) + the largest cost fits 32 bits (no saturation)
+    std::vector<std::vector<uint16_t>> ecost(n);
+    std::vector<std::vector<uint32_t>> tcost(n);
+    uint32_t maxP = 0, maxV = 0;
+    bool fast = true;
+    for (uint32_t j = 0; j < n; ++j) {
+        const pg_contig_batch* b = &panels[live[j]];
+        const uint32_t V = b->n_variants, P = b->n_paths;
+        ecost[j].resize(b->allele_off[V]);
+        pg_sampler_emission_costs(b, ecost[j].data());
+        tcost[j].assign(V, 0);
+        uint32_t tmax = 0;
+        for (uint32_t c = 1; c < V; ++c) {
+            tcost[j][c] = pg_sampler_transition_cost(b->variant_pos[c - 1], b->variant_pos[c], recombrate, P, effective_N);
+            if (tcost[j][c] > tmax) tmax = tcost[j][c];
+        }
+        if (tmax > 65000u || 50.0 * ((double)V + 1.0) + tmax >= 4294967295.0 || P > 4096u) fast = false;
+        if (P > maxP) maxP = P;
+        if (V > maxV) maxV = V;
+    }
+    if (const char* e = getenv("PG_SAMPLER_KERNEL")) {
+        if (!strcmp(e, "general")) fast = false;
+        else if (!strcmp(e, "fast") && !fast) { set_err(err, errlen, "PG_SAMPLER_KERNEL=fast: the panel is outside the fast kernel's bounds"); return PG_ERR_UNSUPPORTED; }
+    }
+    uint32_t NW = 1;
+    while (NW * 256u < maxP) NW *= 2;  // 4 paths per lane
+    const uint32_t T = NW * 64u;
+
+    std::vector<SamplerDev> devs(n);
+    unsigned char* arena = nullptr;
+    hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
+    size_t off = 0;
+    auto take = [&](size_t bytes) { off = (off + 255) / 256 * 256; size_t o = off; off += bytes ? bytes : 8; return o; };
+    struct Offs { size_t aoff, aid, pa, tc, ec, paths, best, bt, last_col, ecell, stay, minima, last; };
+    std::vector<Offs> offs(n);
+    for (uint32_t j = 0; j < n; ++j) {
+        const pg_contig_batch* b = &panels[live[j]];
+        const size_t V = b->n_variants, P = b->n_paths, sumA = b->allele_off[V];
+        Offs& o = offs[j];
+        o.aoff = take((V + 1) * 4); o.aid = take(sumA * 2); o.pa = take(V * P * 2); o.tc = take((V + 48) * 4); o.ec = take(sumA * 2);
+        o.paths = take((size_t)size * V * 4); o.best = take((size_t)size * 4);
+        if (fast) { o.ecell = take((V + 32) * T * 4); o.stay = take(((V + 14) / 16 + 1) * 2 * T * 4); o.minima = take(V * 4); o.last = take(4); o.bt = o.last_col = 0; }
+        else { o.bt = take(V * P * 2); o.last_col = take(P * 4); o.ecell = o.stay = o.minima = o.last = 0; }
+    }
+    const size_t o_devs = take(sizeof(SamplerDev) * n);
+    double ms[3] = {0.0, 0.0, 0.0};
+    HIP_TRY(hipSetDevice(device));
+    {
+        hipError_t he = hipMalloc((void**)&arena, off);
+        if (he != hipSuccess) { set_err(err, errlen, "hipMalloc(%zu bytes) failed: %s", off, hipGetErrorString(he)); rc = PG_ERR_NOMEM; goto done; }
+    }
+    for (auto& e : ev) HIP_TRY(hipEventCreate(&e));
+    for (uint32_t j = 0; j < n; ++j) {
+        const pg_contig_batch* b = &panels[live[j]];
+        const size_t V = b->n_variants, P = b->n_paths, sumA = b->allele_off[V];
+        const Offs& o = offs[j];
+        SamplerDev& d = devs[j];
+        memset(&d, 0, sizeof(d));
+        d.V = (uint32_t)V; d.P = (uint32_t)P; d.T = T; d.penalty = allele_penalty;
+        d.allele_off = (const uint32_t*)(arena + o.aoff); d.allele_id = (const uint16_t*)(arena + o.aid);
+        d.path_allele = (const uint16_t*)(arena + o.pa); d.tcost = (const uint32_t*)(arena + o.tc);
+        d.ecost = (uint16_t*)(arena + o.ec); d.paths = (uint32_t*)(arena + o.paths); d.best = (uint32_t*)(arena + o.best);
+        if (fast) {
+            d.ecell = (uint32_t*)(arena + o.ecell); d.stay = (uint32_t*)(arena + o.stay);
+            d.minima = (uint32_t*)(arena + o.minima); d.last = (uint32_t*)(arena + o.last);
+        } else {
+            d.bt = (uint16_t*)(arena + o.bt); d.last_col = (uint32_t*)(arena + o.last_col);
+        }
+        HIP_TRY(hipMemcpy(arena + o.aoff, b->allele_off, (V + 1) * 4, hipMemcpyHostToDevice));
+        HIP_TRY(hipMemcpy(arena + o.aid, b->allele_id, sumA * 2, hipMemcpyHostToDevice));
+        HIP_TRY(hipMemcpy(arena + o.pa, b->path_allele, V * P * 2, hipMemcpyHostToDevice));
+        HIP_TRY(hipMemcpy(arena + o.tc, tcost[j].data(), V * 4, hipMemcpyHostToDevice));
+        HIP_TRY(hipMemcpy(arena + o.ec, ecost[j].data(), sumA * 2, hipMemcpyHostToDevice));
+    }
+    HIP_TRY(hipMemcpy(arena + o_devs, devs.data(), sizeof(SamplerDev) * n, hipMemcpyHostToDevice));
+    {
+        const SamplerDev* dd = (const SamplerDev*)(arena + o_devs);
+        // general path: backtrack blocks through LDS when KS_BT_BLOCK columns of u16 ids fit into 64 KB
+        const uint32_t lds_cols = ((size_t)KS_BT_BLOCK * maxP * 2 <= 64u * 1024u) ? KS_BT_BLOCK : 0u;
+        const size_t lds_bytes = (size_t)lds_cols * maxP * 2;
+        const uint32_t ex_blocks = maxV < 4096u ? (maxV ? maxV : 1u) : 4096u;
+        for (uint32_t pass = 0; pass < size; ++pass) {
+            HIP_TRY(hipEventRecord(ev[0], nullptr));
+            if (fast) hipLaunchKernelGGL(ks_expand, dim3(ex_blocks, n), dim3(256), 0, nullptr, dd, pass);
+            HIP_TRY(hipGetLastError());
+            HIP_TRY(hipEventRecord(ev[1], nullptr));
+            if (fast) {
+                switch (NW) {
+                    case 1: hipLaunchKernelGGL(ks_forward_fast<1>, dim3(n), dim3(64), 0, nullptr, dd, pass); break;
+                    case 2: hipLaunchKernelGGL(ks_forward_fast<2>, dim3(n), dim3(128), 0, nullptr, dd, pass); break;
+                    case 4: hipLaunchKernelGGL(ks_forward_fast<4>, dim3(n), dim3(256), 0, nullptr, dd, pass); break;
+                    case 8: hipLaunchKernelGGL(ks_forward_fast<8>, dim3(n), dim3(512), 0, nullptr, dd, pass); break;
+                    default: hipLaunchKernelGGL(ks_forward_fast<16>, dim3(n), dim3(1024), 0, nullptr, dd, pass); break;
+                }
+            } else if (maxP <= 256u) hipLaunchKernelGGL((ks_forward<256, 1>), dim3(n), dim3(256), 0, nullptr, dd, pass);
+            else if (maxP <= 1024u) hipLaunchKernelGGL((ks_forward<1024, 1>), dim3(n), dim3(1024), 0, nullptr, dd, pass);
+            else if (maxP <= 4096u) hipLaunchKernelGGL((ks_forward<1024, 4>), dim3(n), dim3(1024), 0, nullptr, dd, pass);
+            else if (maxP <= 16384u) hipLaunchKernelGGL((ks_forward<1024, 16>), dim3(n), dim3(1024), 0, nullptr, dd, pass);
+            else hipLaunchKernelGGL((ks_forward<1024, KS_MAXPPT>), dim3(n), dim3(1024), 0, nullptr, dd, pass);
+            HIP_TRY(hipGetLastError());
+            HIP_TRY(hipEventRecord(ev[2], nullptr));
+            if (fast) hipLaunchKernelGGL(ks_backtrack_fast, dim3(n), dim3(64), 0, nullptr, dd, pass);
+            else hipLaunchKernelGGL(ks_backtrack, dim3(n), dim3(256), lds_bytes, nullptr, dd, pass, lds_cols);
+            HIP_TRY(hipGetLastError());
+            HIP_TRY(hipEventRecord(ev[3], nullptr));
+            HIP_TRY(hipEventSynchronize(ev[3]));
+            float a = 0.f, f = 0.f, k = 0.f;
+            HIP_TRY(hipEventElapsedTime(&a, ev[0], ev[1]));
+            HIP_TRY(hipEventElapsedTime(&f, ev[1], ev[2]));
+            HIP_TRY(hipEventElapsedTime(&k, ev[2], ev[3]));
+            ms[0] += a; ms[1] += f; ms[2] += k;
+        }
+    }
+    for (uint32_t j = 0; j < n; ++j) {
+        const size_t V = panels[live[j]].n_variants;
+        HIP_TRY(hipMemcpy(sampled_paths[live[j]], arena + offs[j].paths, (size_t)size * V * 4, hipMemcpyDeviceToHost));
+        if (best_scores && best_scores[live[j]]) HIP_TRY(hipMemcpy(best_scores[live[j]], arena + offs[j].best, (size_t)size * 4, hipMemcpyDeviceToHost));
+    }
+    g_last_ms[0] = ms[0]; g_last_ms[1] = ms[1]; g_last_ms[2] = ms[2];
+    g_last_kernel = fast ? (int)NW : 0;
+done:
+    for (auto& e : ev) if (e) hipEventDestroy(e);
+    if (arena) hipFree(arena);
+    return rc;
+}
+
+extern "C" int pg_sampler_run(const pg_contig_batch* b, uint32_t size, double recombrate, long double effective_N,
+                              uint16_t allele_penalty, int device, uint32_t* sampled_paths, uint32_t* best_scores,
+                              char* err, size_t errlen) {
+    if (!b || !sampled_paths) { set_err(err, errlen, "null argument"); return PG_ERR_INVALID; }
+    uint32_t* sp[1] = {sampled_paths};
+    uint32_t* bs[1] = {best_scores};
+    return pg_sampler_run_batch(b, 1, size, recombrate, effective_N, allele_penalty, device, sp, bs, err, errlen);
+}
+
+extern "C" int pg_sampler_last_ms(double out3[3], int* kernel) {
+    if (!out3) return PG_ERR_INVALID;
+    out3[0] = g_last_ms[0]; out3[1] = g_last_ms[1]; out3[2] = g_last_ms[2];
+    if (kernel) *kernel = g_last_kernel;
+    return PG_OK;
+}

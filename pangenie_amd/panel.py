@@ -119,6 +119,43 @@ class ContigBatch:
         return ContigBatch(self.n_paths, self.variant_pos, cv, self.kmer_off, kc, self.allele_off, self.allele_id,
                            self.allele_flags, self.allele_kmer_off, self.allele_kmer_mask, self.path_allele)
 
+    def update_paths(self, sampled_paths: np.ndarray) -> "ContigBatch":
+        """UniqueKmers::update_paths on every variant at once (reference
+        src/haplotypesampler.cpp:296-309, src/multiallelicuniquekmers.cpp:195-232): the panel keeps
+        path j = sampled_paths[j][v] at variant v, the alleles those paths carry and the k-mers that lie on
+        at least one kept allele (re-indexed in their old order).  sampled_paths: [S, V] path ids."""
+        sp = np.ascontiguousarray(sampled_paths, dtype=np.int64)
+        V, H = self.n_variants, self.n_paths
+        S = sp.shape[0]
+        assert sp.shape == (S, V) and (V == 0 or (sp.min() >= 0 and sp.max() < H))
+        pa = self.path_allele.reshape(V, H)
+        new_pa = pa[np.arange(V)[None, :], sp].T.copy()  # [V, S]
+        A = np.diff(self.allele_off.astype(np.int64))
+        K = np.diff(self.kmer_off.astype(np.int64))
+        slot_v = np.repeat(np.arange(V), A)
+        keep_slot = (new_pa[slot_v] == self.allele_id[:, None]).any(axis=1)
+        bits = ((self.allele_kmer_mask[:, None] >> np.arange(32, dtype=np.uint32)[None, :]) & 1).astype(bool)
+        local = self.allele_kmer_off.astype(np.int64)[:, None] + np.arange(32)[None, :]
+        bits &= local < K[slot_v][:, None]  # bits beyond the variant's k-mers do not exist
+        gidx = self.kmer_off.astype(np.int64)[slot_v][:, None] + local
+        keep_kmer = np.zeros(int(self.kmer_off[-1]), bool)
+        sel = bits & keep_slot[:, None]
+        keep_kmer[gidx[sel]] = True
+        csum = np.concatenate([[0], np.cumsum(keep_kmer)])
+        new_koff = csum[self.kmer_off.astype(np.int64)]
+        new_local = np.where(sel, csum[np.minimum(gidx, keep_kmer.size - 1 if keep_kmer.size else 0)] - new_koff[slot_v][:, None], 1 << 30) if keep_kmer.size else np.full(sel.shape, 1 << 30)
+        first = new_local.min(axis=1)  # KmerPath offset = first index set (src/kmerpath.cpp:13-17)
+        has = first < (1 << 30)
+        first = np.where(has, first, 0)
+        shift = np.where(sel, new_local - first[:, None], 0)
+        assert shift.max(initial=0) < 32
+        new_mask = (np.where(sel, np.uint64(1) << shift.astype(np.uint64), np.uint64(0))).sum(axis=1).astype(np.uint32)
+        ks = keep_slot
+        new_aoff = np.concatenate([[0], np.cumsum(np.bincount(slot_v[ks], minlength=V))]).astype(np.uint32)
+        return ContigBatch(S, self.variant_pos.copy(), self.coverage.copy(), new_koff.astype(np.uint32), self.kmer_count[keep_kmer],
+                           new_aoff, self.allele_id[ks], self.allele_flags[ks], first[ks].astype(np.uint16), new_mask[ks],
+                           new_pa.reshape(-1))
+
     def nbytes(self) -> int:
         return sum(getattr(self, f).nbytes for f in (
             "variant_pos", "coverage", "kmer_off", "kmer_count", "allele_off", "allele_id",
@@ -188,6 +225,42 @@ class UniqueKmers:
         if path_id >= len(self.path_to_allele):
             raise RuntimeError("UniqueKmers:get_allele: index out of bounds.")
         return self.path_to_allele[path_id]
+
+    def get_readcount_of(self, kmer_index: int) -> int:
+        if kmer_index >= len(self.kmer_to_count):
+            raise RuntimeError(f"get_readcount_of: requested kmer index: {kmer_index} does not exist.")
+        return self.kmer_to_count[kmer_index]
+
+    def kmer_on_allele(self, kmer_index: int, allele: int) -> bool:
+        off, mask, _ = self.alleles[allele]
+        return off <= kmer_index < off + self.window and bool((mask >> (kmer_index - off)) & 1)
+
+    def kmer_on_path(self, kmer_index: int, path_index: int) -> bool:
+        if path_index >= len(self.path_to_allele):
+            raise RuntimeError(f"kmer_on_path: path_index {path_index} does not exist.")
+        if kmer_index >= len(self.kmer_to_count):
+            raise RuntimeError(f"kmer_on_path: requested kmer index: {kmer_index} does not exist.")
+        return self.kmer_on_allele(kmer_index, self.path_to_allele[path_index])
+
+    def update_paths(self, path_ids: Sequence[int]):
+        """Keep only the given paths (in that order), the alleles they carry and the k-mers on those
+        alleles (reference src/multiallelicuniquekmers.cpp:195-232, src/biallelicuniquekmers.cpp:223-260)."""
+        new_p2a = [self.get_allele(int(p)) for p in path_ids]
+        kept = {a: self.alleles[a] for a in sorted(set(new_p2a))}
+        kmer_to_alleles: dict[int, list[int]] = {}
+        for a in kept:
+            for k in range(len(self.kmer_to_count)):
+                if self.kmer_on_allele(k, a):
+                    kmer_to_alleles.setdefault(k, []).append(a)
+        undefined = [a for a, info in kept.items() if info[2]]
+        old_counts = self.kmer_to_count
+        self.path_to_allele = new_p2a
+        self.alleles = {a: [0, 0, False] for a in kept}
+        self.kmer_to_count = []
+        for a in undefined:
+            self.set_undefined_allele(a)
+        for k in sorted(kmer_to_alleles):
+            self.insert_kmer(old_counts[k], kmer_to_alleles[k])
 
 
 def BiallelicUniqueKmers(pos, path_to_allele):

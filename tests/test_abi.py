@@ -29,6 +29,29 @@ def test_every_declared_symbol_is_exported(lib):
         assert hasattr(lib, sym), sym
 
 
+def test_sampler_symbols_are_exported_and_host_costs(lib):
+    """include/pangenie_sampler.h: every declared symbol is exported; the two host-side cost functions
+    (no device involved) agree bit for bit with the oracle."""
+    from oracle import pyoracle as orc
+    from pangenie_amd import sampler as smp
+    header = (ROOT / "include" / "pangenie_sampler.h").read_text()
+    declared = set(re.findall(r"\b(pg_sampler_[a-z_]+)\s*\(", header))
+    assert declared == set(smp.SAMPLER_ABI_SYMBOLS)
+    for sym in declared:
+        assert hasattr(lib, sym), sym
+    b = synthetic_panel(200, 12, 20, seed=9, multiallelic_frac=0.4)
+    b.kmer_count[::2] = 1
+    assert np.array_equal(smp.emission_costs(b), orc.sampler_emission_costs(b))
+    rng = np.random.default_rng(1)
+    for _ in range(2000):
+        a, d = int(rng.integers(0, 2 ** 28)), int(rng.integers(1, 10 ** 6))
+        H = int(rng.integers(2, 3000))
+        assert smp.SamplingTransitions(a, a + d, 1.26, H).cost == orc.sampler_transition_cost(a, a + d, 1.26, H)
+    # argument errors are raised before any device work
+    with pytest.raises(RuntimeError):
+        smp.HaplotypeSampler(synthetic_panel(5, 1, 4, seed=1), 1)
+
+
 def test_struct_layout_matches_header(lib):
     # sizes the C compiler gives the header's structs (x86-64 SysV)
     assert C.sizeof(_lib.PgContigBatch) == 8 + 10 * 8

@@ -1,9 +1,14 @@
 """Per-kernel register / scratch / LDS usage of the product kernels (hipcc remarks; runs without a GPU).
-usage: python tools/kernel_resources.py [extra hipcc flags]"""
+usage: python tools/kernel_resources.py [--file pg_sampler.hip] [extra hipcc flags]"""
 import re, subprocess, sys
 from pathlib import Path
 ROOT = Path(__file__).resolve().parent.parent
-cmd = ["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-c", str(ROOT / "pangenie_amd/csrc/pg_kernels.hip"),
+SRC = "pg_kernels.hip"
+if "--file" in sys.argv:
+    i = sys.argv.index("--file")
+    SRC = sys.argv[i + 1]
+    del sys.argv[i:i + 2]
+cmd = ["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-c", str(ROOT / "pangenie_amd/csrc" / SRC),
        "-o", "/tmp/pg_kernels_res.o", "-Wno-unused-value", "-Rpass-analysis=kernel-resource-usage", *sys.argv[1:]]
 out = subprocess.run(cmd, capture_output=True, text=True).stderr
 rows, cur = [], None
