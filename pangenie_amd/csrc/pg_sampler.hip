@@ -45,8 +45,6 @@
 #define KS_MAXPPT 64    // paths per thread of the general kernel (H <= 65536 at 1024 threads)
 #define KS_MAXPASS 64   // passes whose picks are kept in LDS for the masks
 #define KS_BT_BLOCK 32  // columns per backtrack block of the general kernel
-#define KS_INF 0x40000000u  // relative value of a masked cell (fast path)
-#define KS_DEPTH 16     // columns of cost bytes in flight per lane (fast path)
 
 namespace {
 
@@ -71,9 +69,10 @@ struct SamplerDev {
     uint16_t* bt;                 // [V*P] backtrace ids of the pass in flight (0xFFFF = none)
     uint32_t* last_col;           // [P] last column of the pass in flight
     // fast path
-    uint32_t* ecell;              // [(V+32)*T] byte k of word (c, t) = cost of path k*T + t at column c
+    uint8_t* slot;                // [V*P] index of the cell's allele in its column's allele list (0xFF = not listed, 0xFE = masked)
+    unsigned long long* ecell;    // [(V+32)*T] half word k of (c, t) = KS_BIAS + cost of path k*T + t at column c
     uint32_t* stay;               // [ceil((V-1)/16)*2*T] "cell continued its own path" bits, 16 columns per half word
-    uint32_t* minima;             // [V] first | second << 16: ids of the two smallest entries of column c-1
+    uint32_t* minima;             // [V] id of the smallest entry of column c-1
     uint32_t* last;               // [1] best path of the last column
 };
 
@@ -249,31 +248,67 @@ __global__ __launch_bounds__(256) void ks_backtrack(const SamplerDev* devs, uint
 // ------------------------------------------------------------------------------------------------
 //  fast path
 // ------------------------------------------------------------------------------------------------
-// cost byte of every cell of this pass: grid = (column blocks, contigs), block = 256
-__global__ __launch_bounds__(256) void ks_expand(const SamplerDev* devs, uint32_t pass) {
+#define KS_AS1 __attribute__((address_space(1)))  // loads / stores through these compile to global_* (vmcnt only), not flat_*
+#define KS_BIAS 0x2000u    // added to every cost word: keeps the relative values positive
+#define KS_MASKED 0x8000u  // cost word (before the bias) of a masked cell: above every live value
+#define KS_TMAX 8191u      // largest recombination cost the fast path takes (KS_BIAS - 1)
+
+// slot (index into the column's allele list) of every cell, once per run: grid-stride over (column, path)
+__global__ __launch_bounds__(256) void ks_slots(const SamplerDev* devs) {
+    const SamplerDev d = devs[blockIdx.y];
+    const uint32_t V = d.V, P = d.P;
+    const size_t n = (size_t)V * P;
+    for (size_t g = (size_t)blockIdx.x * 256 + threadIdx.x; g < n; g += (size_t)gridDim.x * 256) {
+        const uint32_t c = (uint32_t)(g / P);
+        const uint32_t a0 = d.allele_off[c], A = d.allele_off[c + 1] - a0;
+        const uint16_t allele = d.path_allele[g];
+        uint32_t slot = 0xFFu;  // not listed (malformed input): cost 0, nothing to penalise
+        for (uint32_t q = 0; q < A && q < 254u; ++q) if (d.allele_id[a0 + q] == allele) { slot = q; break; }
+        d.slot[g] = (uint8_t)slot;
+    }
+}
+
+// after a pass: SamplingEmissions::penalize on the allele the picked path carries (reference
+// src/haplotypesampler.cpp:162-164, src/samplingemissions.cpp:39-45), and the picked cell is masked for
+// all later passes (SampledPaths::mask_indexes) by overwriting its slot byte.  One thread per column.
+__global__ __launch_bounds__(256) void ks_apply(const SamplerDev* devs, uint32_t pass) {
+    const SamplerDev d = devs[blockIdx.y];
+    const uint32_t V = d.V, P = d.P;
+    for (uint32_t c = blockIdx.x * 256u + threadIdx.x; c < V; c += gridDim.x * 256u) {
+        const uint32_t path = d.paths[(size_t)pass * V + c];
+        const size_t cell = (size_t)c * P + path;
+        const uint32_t slot = d.slot[cell];
+        if (slot < 0xFEu) {
+            const uint32_t a = d.allele_off[c] + slot;
+            uint16_t e = (uint16_t)(d.ecost[a] + d.penalty);  // unsigned short arithmetic, as in the reference
+            if (e > 25u) e = 25u;
+            d.ecost[a] = e;
+        }
+        d.slot[cell] = 0xFEu;
+    }
+}
+
+// cost word of every cell of this pass: grid-stride over (column, thread of the forward kernel)
+__global__ __launch_bounds__(256) void ks_expand(const SamplerDev* devs) {
     const SamplerDev d = devs[blockIdx.y];
     const uint32_t V = d.V, P = d.P, T = d.T;
-    for (uint32_t c = blockIdx.x; c < V; c += gridDim.x) {
-        const uint32_t a0 = d.allele_off[c], A = d.allele_off[c + 1] - a0;
-        for (uint32_t t = threadIdx.x; t < T; t += 256) {
-            uint32_t word = 0;
+    const size_t n = (size_t)V * T;
+    for (size_t g = (size_t)blockIdx.x * 256 + threadIdx.x; g < n; g += (size_t)gridDim.x * 256) {
+        const uint32_t c = (uint32_t)(g / T), t = (uint32_t)(g % T);
+        const uint32_t a0 = d.allele_off[c];
+        uint32_t w[4];
 #pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                const uint32_t i = (uint32_t)k * T + t;
-                uint32_t e = 0xFFu;
-                if (i < P) {
-                    bool ok = true;  // SampledPaths::mask_indexes
-                    for (uint32_t q = 0; q < pass; ++q) ok = ok && (d.paths[(size_t)q * V + c] != i);
-                    if (ok) {
-                        const uint16_t allele = d.path_allele[(size_t)c * P + i];
-                        e = 0;
-                        for (uint32_t q = 0; q < A; ++q) if (d.allele_id[a0 + q] == allele) { e = d.ecost[a0 + q]; break; }
-                    }
-                }
-                word |= e << (8 * k);
+        for (int k = 0; k < 4; ++k) {
+            const uint32_t i = (uint32_t)k * T + t;
+            uint32_t e = KS_MASKED;  // beyond H, or picked by an earlier pass
+            if (i < P) {
+                const uint32_t slot = d.slot[(size_t)c * P + i];
+                if (slot < 0xFEu) e = d.ecost[a0 + slot];
+                else if (slot == 0xFFu) e = 0u;
             }
-            d.ecell[(size_t)c * T + t] = word;
+            w[k] = e + KS_BIAS;
         }
+        d.ecell[g] = (unsigned long long)(w[0] | (w[1] << 16)) | ((unsigned long long)(w[2] | (w[3] << 16)) << 32);
     }
 }
 
@@ -301,144 +336,139 @@ __device__ __forceinline__ uint32_t row_min(uint32_t v) {
     v = dpp_min<0x118, 0xF>(v);
     return (uint32_t)__builtin_amdgcn_readlane((int)v, 15);
 }
-
-// smallest and second smallest key of the workgroup's 4 * NW * 64 keys
 template <int NW>
-__device__ __forceinline__ void block_top2(const uint32_t (&k)[4], uint32_t (*s_x)[2], uint32_t wave, uint32_t lane, uint32_t& F, uint32_t& S) {
-    const uint32_t m01 = min(k[0], k[1]), m23 = min(k[2], k[3]);
-    const uint32_t fw = wave_min(min(m01, m23));
-    uint32_t cand = KS_UMAX;
-#pragma unroll
-    for (int j = 0; j < 4; ++j) cand = min(cand, k[j] == fw ? KS_UMAX : k[j]);
-    const uint32_t sw = wave_min(cand);
-    if (NW == 1) { F = fw; S = sw; return; }
-    if (lane == 0) { s_x[wave][0] = fw; s_x[wave][1] = sw; }
+__device__ __forceinline__ uint32_t block_min(uint32_t v, uint32_t* s_x, uint32_t wave, uint32_t lane) {
+    const uint32_t fw = wave_min(v);
+    if (NW == 1) return fw;
+    if (lane == 0) s_x[wave] = fw;
     __syncthreads();
-    const uint32_t a = s_x[lane & (NW - 1)][0], b = s_x[lane & (NW - 1)][1];
-    F = row_min(a);  // NW <= 16: every row of 16 lanes holds all the waves' pairs
-    S = row_min(a == F ? b : a);
+    return row_min(s_x[lane & (NW - 1)]);  // NW <= 16: every row of 16 lanes holds all the waves' minima
 }
 
-#define KS_AS1 __attribute__((address_space(1)))  // loads / stores through these compile to global_* (vmcnt only), not flat_*
-
-// one column of the relative-value DP (reference src/haplotypesampler.cpp:223-284).  r[] = the previous
-// column relative to `base`, w = the four cost bytes of this column, t = recombination cost.  Returns the
-// stay bits in st[], the packed ids (first | second << 16) of the previous column's minima in `mins`.
-template <int NW>
-__device__ __forceinline__ void fast_column(uint32_t (&r)[4], uint32_t& base, uint32_t w, uint32_t t, uint32_t (*s_x)[2], uint32_t tid,
-                                            uint32_t wave, uint32_t lane, bool (&st)[4], uint32_t& mins) {
-    constexpr uint32_t T = NW * 64;
-    uint32_t k[4];
+// One column of the relative-value DP (reference src/haplotypesampler.cpp:223-284).
+//   rho[q] = value of path q*T + tid at the previous column, relative to THAT column's predecessor minimum,
+//            minus the previous recombination cost, plus KS_BIAS (what the cost words carry); a masked cell
+//            holds >= 0x8001.  All live values of a column lie within (recombination cost + 50) of its
+//            minimum, so (rho << 16 | path id) is a u32 key whose minimum is the reference's "smallest value,
+//            then smallest index".
+//   With a recombination cost t >= 1 the minimum itself always continues its own path (same = min < second +
+//   t), so the second smallest entry of the reference's helper never decides anything: ONE reduction.
+//   d = same - t < 0  <=>  the cell continues its own path (strict, src/haplotypesampler.cpp:272).
+template <int NW, int PPL>
+__device__ __forceinline__ void fast_column(uint32_t (&rho)[4], const uint32_t (&idx)[4], uint32_t& acc, uint32_t& t_prev, unsigned long long w, uint32_t t,
+                                            uint32_t* s_x, uint32_t wave, uint32_t lane, uint32_t (&hist)[4], uint32_t& first_id) {
+    uint32_t kmin = KS_UMAX;
 #pragma unroll
-    for (int q = 0; q < 4; ++q) k[q] = r[q] >= KS_INF ? KS_UMAX : ((r[q] << 16) | ((uint32_t)q * T + tid));
-    uint32_t F, S;
-    block_top2<NW>(k, s_x, wave, lane, F, S);
-    const uint32_t m = F >> 16, first_id = F & 0xFFFFu;
-    const uint32_t h_first = S == KS_UMAX ? KS_INF : (S >> 16) - m + t;  // helper of the minimum itself: the second
-    base += m;
-    mins = first_id | (S << 16);
+    for (int q = 0; q < PPL; ++q) kmin = min(kmin, (rho[q] << 16) | idx[q]);
+    const uint32_t F = block_min<NW>(kmin, s_x, wave, lane);
+    const uint32_t rmin = F >> 16;
+    first_id = F & 0xFFFFu;
+    acc += rmin + t_prev - KS_BIAS;  // absolute minimum of the previous column
+    t_prev = t;
+    const uint32_t mt = rmin + t;
+    const uint32_t wx = (uint32_t)w, wy = (uint32_t)(w >> 32);
+    const uint32_t e[4] = {wx & 0xFFFFu, wx >> 16, wy & 0xFFFFu, wy >> 16};
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
-        const uint32_t i = (uint32_t)q * T + tid;
-        const uint32_t e = (w >> (8 * q)) & 0xFFu;
-        const uint32_t same = r[q] - m;  // stays huge when the cell was masked
-        const uint32_t h = i == first_id ? h_first : t;
-        st[q] = same < h;  // strict: a tie goes to the recombination (src/haplotypesampler.cpp:272)
-        const uint32_t v = (st[q] ? same : h) + e;
-        r[q] = e == 0xFFu ? KS_INF : v;
+    for (int q = 0; q < PPL; ++q) {
+        const int32_t dd = (int32_t)(rho[q] - mt);
+        hist[q] = (hist[q] << 1) | ((uint32_t)dd >> 31);
+        rho[q] = (uint32_t)min(dd, 0) + e[q];
     }
 }
 
 // Backtrace layout of the fast path: columns 1.. are grouped in blocks of 16 (column c -> block (c-1)/16,
-// bit (c-1)%16); per block and thread two dwords hold the stay bits of its four paths
-// (q0 | q1 << 16, q2 | q3 << 16); minima[c] = first_id | second_id << 16 of column c-1.
-template <int NW>
+// bit 15 - (c-1)%16); per block and thread two dwords hold the stay bits of its four paths
+// (q0 | q1 << 16, q2 | q3 << 16); minima[c] = id of the smallest entry of column c-1.
+// PPL = paths per lane (1, 2 or 4; fewer than 4 only with one wave): the cost words always carry four.
+template <int NW, int PPL>
 __global__ __launch_bounds__(NW * 64) void ks_forward_fast(const SamplerDev* devs, uint32_t pass) {
     constexpr uint32_t T = NW * 64;
-    __shared__ uint32_t s_x[2][NW][2];
+    __shared__ uint32_t s_x[2][NW];
     const SamplerDev d = devs[blockIdx.x];
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
     const uint32_t V = d.V;
-    const uint32_t KS_AS1* ecell = (const uint32_t KS_AS1*)d.ecell + tid;
+    const unsigned long long KS_AS1* ecell = (const unsigned long long KS_AS1*)d.ecell + tid;
     const uint32_t KS_AS1* tcost = (const uint32_t KS_AS1*)d.tcost;
     uint32_t KS_AS1* stay = (uint32_t KS_AS1*)d.stay + tid;
     uint32_t KS_AS1* minima = (uint32_t KS_AS1*)d.minima;
-    uint32_t r[4];  // values relative to `base`; KS_INF when masked
-    uint32_t base = 0;
+    const uint32_t idx[4] = {tid, T + tid, 2 * T + tid, 3 * T + tid};
+    uint32_t rho[4];
+    uint32_t acc = 0, t_prev = 0;
     {
-        const uint32_t w = ecell[0];
-#pragma unroll
-        for (int q = 0; q < 4; ++q) { const uint32_t e = (w >> (8 * q)) & 0xFFu; r[q] = e == 0xFFu ? KS_INF : e; }
+        const unsigned long long w = ecell[0];  // column 0: the emission cost alone
+        const uint32_t wx = (uint32_t)w, wy = (uint32_t)(w >> 32);
+        rho[0] = wx & 0xFFFFu; rho[1] = wx >> 16; rho[2] = wy & 0xFFFFu; rho[3] = wy >> 16;
     }
     const uint32_t nfull = (V - 1) / 16;  // blocks of 16 columns after column 0
-    // cost words of the block in flight and of the next one: the loads of block b+1 are issued before block b
-    // is processed, a whole block (16 dependent columns) ahead of their use.  ecell / tcost are padded by 32
-    // columns, so the prefetch never needs a bounds check.
-    uint32_t cur[16], nxt[16];
+    // cost words of the block in flight and of the next one, in two register buffers that swap roles (no
+    // copies): the loads of block b+1 are issued before block b is processed, a whole block (16 dependent
+    // columns) ahead of their use.  ecell / tcost are padded by 32 columns, so the prefetch never needs a
+    // bounds check.
+    unsigned long long bufA[16], bufB[16];
 #pragma unroll
-    for (int j = 0; j < 16; ++j) cur[j] = ecell[(size_t)(1u + j) * T];
-    uint32_t tc_cur = tcost[1u + (lane & 15u)], tc_next;
+    for (int j = 0; j < 16; ++j) bufA[j] = ecell[(size_t)(1u + j) * T];
+    uint32_t tcA = tcost[1u + (lane & 15u)], tcB = 0;
     uint32_t par = 0;
-    for (uint32_t blk = 0; blk < nfull; ++blk) {
+    uint32_t hist[4] = {0u, 0u, 0u, 0u};
+    auto do_block = [&](const unsigned long long (&use)[16], unsigned long long (&load)[16], const uint32_t& tc_use, uint32_t& tc_load, uint32_t blk) {
         const uint32_t c0 = 1u + 16u * blk;
 #pragma unroll
-        for (int j = 0; j < 16; ++j) nxt[j] = ecell[(size_t)(c0 + 16u + j) * T];
-        tc_next = tcost[c0 + 16u + (lane & 15u)];
-        uint32_t hist[4] = {0u, 0u, 0u, 0u}, mins_v = 0;
+        for (int j = 0; j < 16; ++j) load[j] = ecell[(size_t)(c0 + 16u + j) * T];
+        tc_load = tcost[c0 + 16u + (lane & 15u)];
+        // nothing of this block before its prefetches are in flight: the first use of `use` / tc_use then waits
+        // with these 17 loads behind it instead of draining the previous block's stores
+        __builtin_amdgcn_sched_barrier(0);
+        uint32_t mins_v = 0;
 #pragma unroll
         for (int j = 0; j < 16; ++j) {
-            const uint32_t t = (uint32_t)__builtin_amdgcn_readlane((int)tc_cur, j);
-            bool st[4];
-            uint32_t mins;
-            fast_column<NW>(r, base, cur[j], t, s_x[par], tid, wave, lane, st, mins);
+            const uint32_t t = (uint32_t)__builtin_amdgcn_readlane((int)tc_use, j);
+            uint32_t first_id;
+            fast_column<NW, PPL>(rho, idx, acc, t_prev, use[j], t, s_x[par], wave, lane, hist, first_id);
             par ^= 1u;
-#pragma unroll
-            for (int q = 0; q < 4; ++q) hist[q] |= st[q] ? (1u << j) : 0u;
-            mins_v = lane == (uint32_t)j ? mins : mins_v;
+            mins_v = lane == (uint32_t)j ? first_id : mins_v;
         }
-        stay[(size_t)(blk * 2u) * T] = hist[0] | (hist[1] << 16);
-        stay[(size_t)(blk * 2u + 1u) * T] = hist[2] | (hist[3] << 16);
+        stay[(size_t)(blk * 2u) * T] = (hist[0] & 0xFFFFu) | (hist[1] << 16);
+        stay[(size_t)(blk * 2u + 1u) * T] = (hist[2] & 0xFFFFu) | (hist[3] << 16);
         if (tid < 16u) minima[c0 + tid] = mins_v;
-#pragma unroll
-        for (int j = 0; j < 16; ++j) cur[j] = nxt[j];
-        tc_cur = tc_next;
+    };
+    {
+        uint32_t blk = 0;
+        for (; blk + 2u <= nfull; blk += 2u) {
+            do_block(bufA, bufB, tcA, tcB, blk);
+            do_block(bufB, bufA, tcB, tcA, blk + 1u);
+        }
+        if (blk < nfull) do_block(bufA, bufB, tcA, tcB, blk);
     }
     {   // the last, partial block
         const uint32_t c0 = 1u + 16u * nfull;
-        uint32_t hist[4] = {0u, 0u, 0u, 0u};
         for (uint32_t c = c0; c < V; ++c) {
-            const uint32_t j = c - c0;
-            bool st[4];
-            uint32_t mins;
-            fast_column<NW>(r, base, ecell[(size_t)c * T], tcost[c], s_x[par], tid, wave, lane, st, mins);
+            uint32_t first_id;
+            fast_column<NW, PPL>(rho, idx, acc, t_prev, ecell[(size_t)c * T], tcost[c], s_x[par], wave, lane, hist, first_id);
             par ^= 1u;
-#pragma unroll
-            for (int q = 0; q < 4; ++q) hist[q] |= st[q] ? (1u << j) : 0u;
-            if (tid == 0) minima[c] = mins;
+            if (tid == 0) minima[c] = first_id;
         }
         if (c0 < V) {
-            stay[(size_t)(nfull * 2u) * T] = hist[0] | (hist[1] << 16);
-            stay[(size_t)(nfull * 2u + 1u) * T] = hist[2] | (hist[3] << 16);
+            const uint32_t sh = 16u - (V - c0);  // column c0 + j at bit 15 - j, as in a full block
+            stay[(size_t)(nfull * 2u) * T] = ((hist[0] << sh) & 0xFFFFu) | ((hist[1] << sh) << 16);
+            stay[(size_t)(nfull * 2u + 1u) * T] = ((hist[2] << sh) & 0xFFFFu) | ((hist[3] << sh) << 16);
         }
     }
-    // best value in the last column = its first minimum (at least one cell is unmasked and finite)
-    uint32_t k[4], F, S;
+    // best value in the last column = its first minimum (at least one cell is unmasked)
+    uint32_t kmin = KS_UMAX;
 #pragma unroll
-    for (int q = 0; q < 4; ++q) k[q] = r[q] >= KS_INF ? KS_UMAX : ((r[q] << 16) | ((uint32_t)q * T + tid));
-    block_top2<NW>(k, s_x[par], wave, lane, F, S);
-    if (tid == 0) { d.best[pass] = base + (F >> 16); d.last[0] = F & 0xFFFFu; }
+    for (int q = 0; q < PPL; ++q) kmin = min(kmin, (rho[q] << 16) | idx[q]);
+    const uint32_t F = block_min<NW>(kmin, s_x[par], wave, lane);
+    if (tid == 0) { d.best[pass] = acc + (F >> 16) + t_prev - KS_BIAS; d.last[0] = F & 0xFFFFu; }
 }
 
-// grid = contigs, block = one wave.  The traced path stays on `b` until a column whose stay bit is 0; each
-// lane inspects one block of 16 columns, so one step covers 1024 columns.
+// grid = contigs, block = one wave.  The traced path stays on `b` until a column whose stay bit is 0 (there
+// it came from the minimum of the column before); each lane inspects one block of 16 columns, so one step
+// covers 1024 columns.
 __global__ __launch_bounds__(64) void ks_backtrack_fast(const SamplerDev* devs, uint32_t pass) {
     const SamplerDev d = devs[blockIdx.x];
     const uint32_t lane = threadIdx.x, V = d.V, T = d.T;
-    auto assign = [&](uint32_t lo, uint32_t hi, uint32_t path) {  // columns lo..hi carry `path`
-        for (uint32_t c = lo + lane; c <= hi; c += 64u) {
-            d.paths[(size_t)pass * V + c] = path;
-            penalize(d, c, path);
-        }
+    auto assign = [&](uint32_t lo, uint32_t hi, uint32_t path) {  // columns lo..hi carry `path` (penalties: ks_apply)
+        for (uint32_t c = lo + lane; c <= hi; c += 64u) d.paths[(size_t)pass * V + c] = path;
     };
     uint32_t b = d.last[0], cur = V - 1;  // the state at column cur is b
     while (cur >= 1u) {
@@ -450,7 +480,7 @@ __global__ __launch_bounds__(64) void ks_backtrack_fast(const SamplerDev* devs, 
             const uint32_t dw = d.stay[((size_t)(blk_cur - lane) * 2u + (q >> 1)) * T + t];
             word = (q & 1u) ? dw >> 16 : dw & 0xFFFFu;
         }
-        if (lane == 0) word |= ~((2u << j_cur) - 1u);  // columns above cur are behind us
+        if (lane == 0) word |= (1u << (15u - j_cur)) - 1u;  // columns above cur are behind us
         const uint32_t zero = ~word & 0xFFFFu;
         const unsigned long long sw = __ballot(valid && zero != 0u);
         if (sw == 0ull) {
@@ -461,10 +491,9 @@ __global__ __launch_bounds__(64) void ks_backtrack_fast(const SamplerDev* devs, 
         }
         const uint32_t ls = (uint32_t)__ffsll((long long)sw) - 1u;
         const uint32_t wz = (uint32_t)__builtin_amdgcn_readlane((int)zero, ls);
-        const uint32_t cs = (blk_cur - ls) * 16u + 1u + (31u - (uint32_t)__clz((int)wz));  // the highest column at which the path switched
+        const uint32_t cs = (blk_cur - ls) * 16u + 1u + (15u - ((uint32_t)__ffs((int)wz) - 1u));  // the highest column at which the path switched
         assign(cs, cur, b);
-        const uint32_t mm = d.minima[cs], fid = mm & 0xFFFFu, sid = mm >> 16;
-        b = b == fid ? sid : fid;
+        b = d.minima[cs];
         cur = cs - 1u;
     }
     assign(0u, 0u, b);
@@ -605,8 +634,10 @@ extern "C" int pg_sampler_run_batch(const pg_contig_batch* panels, uint32_t n_co
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) { set_err(err, errlen, "no HIP device available (no CPU fallback)"); return PG_ERR_DEVICE; }
     if (device < 0 || device >= ndev) { set_err(err, errlen, "bad device %d", device); return PG_ERR_INVALID; }
     const uint32_t n = (uint32_t)live.size();
-    // host-side costs, and the two bounds under which the relative-value kernel is exact:
-    //   every recombination cost + 51 fits 16 bits (keys), 50 (V + 1) + the largest cost fits 32 bits (no saturation)
+    // host-side costs, and the bounds under which the relative-value kernel is exact: every recombination
+    // cost in 1..KS_TMAX (with two or more paths the reference's formula gives >= 3; the largest real ones are
+    // a few hundred), 50 (V + 1) + the largest cost fits 32 bits (no saturation anywhere), <= 4096 paths,
+    // <= 254 alleles per column
     std::vector<std::vector<uint16_t>> ecost(n);
     std::vector<std::vector<uint32_t>> tcost(n);
     uint32_t maxP = 0, maxV = 0;
@@ -617,12 +648,15 @@ extern "C" int pg_sampler_run_batch(const pg_contig_batch* panels, uint32_t n_co
         ecost[j].resize(b->allele_off[V]);
         pg_sampler_emission_costs(b, ecost[j].data());
         tcost[j].assign(V, 0);
-        uint32_t tmax = 0;
+        uint32_t tmax = 0, tmin = 1;
         for (uint32_t c = 1; c < V; ++c) {
             tcost[j][c] = pg_sampler_transition_cost(b->variant_pos[c - 1], b->variant_pos[c], recombrate, P, effective_N);
             if (tcost[j][c] > tmax) tmax = tcost[j][c];
+            if (tcost[j][c] < tmin) tmin = tcost[j][c];
         }
-        if (tmax > 65000u || 50.0 * ((double)V + 1.0) + tmax >= 4294967295.0 || P > 4096u) fast = false;
+        uint32_t maxA = 0;
+        for (uint32_t v = 0; v < V; ++v) if (b->allele_off[v + 1] - b->allele_off[v] > maxA) maxA = b->allele_off[v + 1] - b->allele_off[v];
+        if (tmin < 1u || tmax > KS_TMAX || 50.0 * ((double)V + 1.0) + tmax >= 4294967295.0 || P > 4096u || maxA > 254u) fast = false;
         if (P > maxP) maxP = P;
         if (V > maxV) maxV = V;
     }
@@ -639,7 +673,7 @@ extern "C" int pg_sampler_run_batch(const pg_contig_batch* panels, uint32_t n_co
     hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
     size_t off = 0;
     auto take = [&](size_t bytes) { off = (off + 255) / 256 * 256; size_t o = off; off += bytes ? bytes : 8; return o; };
-    struct Offs { size_t aoff, aid, pa, tc, ec, paths, best, bt, last_col, ecell, stay, minima, last; };
+    struct Offs { size_t aoff, aid, pa, tc, ec, paths, best, bt, last_col, ecell, stay, minima, last, slot; };
     std::vector<Offs> offs(n);
     for (uint32_t j = 0; j < n; ++j) {
         const pg_contig_batch* b = &panels[live[j]];
@@ -647,8 +681,8 @@ extern "C" int pg_sampler_run_batch(const pg_contig_batch* panels, uint32_t n_co
         Offs& o = offs[j];
         o.aoff = take((V + 1) * 4); o.aid = take(sumA * 2); o.pa = take(V * P * 2); o.tc = take((V + 48) * 4); o.ec = take(sumA * 2);
         o.paths = take((size_t)size * V * 4); o.best = take((size_t)size * 4);
-        if (fast) { o.ecell = take((V + 32) * T * 4); o.stay = take(((V + 14) / 16 + 1) * 2 * T * 4); o.minima = take(V * 4); o.last = take(4); o.bt = o.last_col = 0; }
-        else { o.bt = take(V * P * 2); o.last_col = take(P * 4); o.ecell = o.stay = o.minima = o.last = 0; }
+        if (fast) { o.slot = take(V * P); o.ecell = take((V + 32) * T * 8); o.stay = take(((V + 14) / 16 + 1) * 2 * T * 4); o.minima = take(V * 4); o.last = take(4); o.bt = o.last_col = 0; }
+        else { o.bt = take(V * P * 2); o.last_col = take(P * 4); o.ecell = o.stay = o.minima = o.last = o.slot = 0; }
     }
     const size_t o_devs = take(sizeof(SamplerDev) * n);
     double ms[3] = {0.0, 0.0, 0.0};
@@ -669,7 +703,7 @@ extern "C" int pg_sampler_run_batch(const pg_contig_batch* panels, uint32_t n_co
         d.path_allele = (const uint16_t*)(arena + o.pa); d.tcost = (const uint32_t*)(arena + o.tc);
         d.ecost = (uint16_t*)(arena + o.ec); d.paths = (uint32_t*)(arena + o.paths); d.best = (uint32_t*)(arena + o.best);
         if (fast) {
-            d.ecell = (uint32_t*)(arena + o.ecell); d.stay = (uint32_t*)(arena + o.stay);
+            d.slot = (uint8_t*)(arena + o.slot); d.ecell = (unsigned long long*)(arena + o.ecell); d.stay = (uint32_t*)(arena + o.stay);
             d.minima = (uint32_t*)(arena + o.minima); d.last = (uint32_t*)(arena + o.last);
         } else {
             d.bt = (uint16_t*)(arena + o.bt); d.last_col = (uint32_t*)(arena + o.last_col);
@@ -686,19 +720,22 @@ extern "C" int pg_sampler_run_batch(const pg_contig_batch* panels, uint32_t n_co
         // general path: backtrack blocks through LDS when KS_BT_BLOCK columns of u16 ids fit into 64 KB
         const uint32_t lds_cols = ((size_t)KS_BT_BLOCK * maxP * 2 <= 64u * 1024u) ? KS_BT_BLOCK : 0u;
         const size_t lds_bytes = (size_t)lds_cols * maxP * 2;
-        const uint32_t ex_blocks = maxV < 4096u ? (maxV ? maxV : 1u) : 4096u;
+        const uint32_t ex_blocks = 2048u;
         for (uint32_t pass = 0; pass < size; ++pass) {
             HIP_TRY(hipEventRecord(ev[0], nullptr));
-            if (fast) hipLaunchKernelGGL(ks_expand, dim3(ex_blocks, n), dim3(256), 0, nullptr, dd, pass);
+            if (fast && pass == 0) hipLaunchKernelGGL(ks_slots, dim3(ex_blocks, n), dim3(256), 0, nullptr, dd);
+            if (fast) hipLaunchKernelGGL(ks_expand, dim3(ex_blocks, n), dim3(256), 0, nullptr, dd);
             HIP_TRY(hipGetLastError());
             HIP_TRY(hipEventRecord(ev[1], nullptr));
             if (fast) {
-                switch (NW) {
-                    case 1: hipLaunchKernelGGL(ks_forward_fast<1>, dim3(n), dim3(64), 0, nullptr, dd, pass); break;
-                    case 2: hipLaunchKernelGGL(ks_forward_fast<2>, dim3(n), dim3(128), 0, nullptr, dd, pass); break;
-                    case 4: hipLaunchKernelGGL(ks_forward_fast<4>, dim3(n), dim3(256), 0, nullptr, dd, pass); break;
-                    case 8: hipLaunchKernelGGL(ks_forward_fast<8>, dim3(n), dim3(512), 0, nullptr, dd, pass); break;
-                    default: hipLaunchKernelGGL(ks_forward_fast<16>, dim3(n), dim3(1024), 0, nullptr, dd, pass); break;
+                if (maxP <= 64u) hipLaunchKernelGGL((ks_forward_fast<1, 1>), dim3(n), dim3(64), 0, nullptr, dd, pass);
+                else if (maxP <= 128u) hipLaunchKernelGGL((ks_forward_fast<1, 2>), dim3(n), dim3(64), 0, nullptr, dd, pass);
+                else switch (NW) {
+                    case 1: hipLaunchKernelGGL((ks_forward_fast<1, 4>), dim3(n), dim3(64), 0, nullptr, dd, pass); break;
+                    case 2: hipLaunchKernelGGL((ks_forward_fast<2, 4>), dim3(n), dim3(128), 0, nullptr, dd, pass); break;
+                    case 4: hipLaunchKernelGGL((ks_forward_fast<4, 4>), dim3(n), dim3(256), 0, nullptr, dd, pass); break;
+                    case 8: hipLaunchKernelGGL((ks_forward_fast<8, 4>), dim3(n), dim3(512), 0, nullptr, dd, pass); break;
+                    default: hipLaunchKernelGGL((ks_forward_fast<16, 4>), dim3(n), dim3(1024), 0, nullptr, dd, pass); break;
                 }
             } else if (maxP <= 256u) hipLaunchKernelGGL((ks_forward<256, 1>), dim3(n), dim3(256), 0, nullptr, dd, pass);
             else if (maxP <= 1024u) hipLaunchKernelGGL((ks_forward<1024, 1>), dim3(n), dim3(1024), 0, nullptr, dd, pass);
@@ -707,8 +744,10 @@ extern "C" int pg_sampler_run_batch(const pg_contig_batch* panels, uint32_t n_co
             else hipLaunchKernelGGL((ks_forward<1024, KS_MAXPPT>), dim3(n), dim3(1024), 0, nullptr, dd, pass);
             HIP_TRY(hipGetLastError());
             HIP_TRY(hipEventRecord(ev[2], nullptr));
-            if (fast) hipLaunchKernelGGL(ks_backtrack_fast, dim3(n), dim3(64), 0, nullptr, dd, pass);
-            else hipLaunchKernelGGL(ks_backtrack, dim3(n), dim3(256), lds_bytes, nullptr, dd, pass, lds_cols);
+            if (fast) {
+                hipLaunchKernelGGL(ks_backtrack_fast, dim3(n), dim3(64), 0, nullptr, dd, pass);
+                hipLaunchKernelGGL(ks_apply, dim3(256, n), dim3(256), 0, nullptr, dd, pass);
+            } else hipLaunchKernelGGL(ks_backtrack, dim3(n), dim3(256), lds_bytes, nullptr, dd, pass, lds_cols);
             HIP_TRY(hipGetLastError());
             HIP_TRY(hipEventRecord(ev[3], nullptr));
             HIP_TRY(hipEventSynchronize(ev[3]));
