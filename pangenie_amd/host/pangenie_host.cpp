@@ -2,7 +2,10 @@
 #include "pangenie_host.hpp"
 
 #include <algorithm>
+#include <chrono>
 #include <cmath>
+#include <fstream>
+#include <limits>
 #include <iomanip>
 #include <cstdlib>
 #include <sstream>
@@ -808,6 +811,116 @@ void HMM::combine_likelihoods(HMM& other) {
 }
 void HMM::normalize() {
     for (auto& g : genotyping_result_) g.normalize();
+}
+
+// ------------------------------------------------------------------ haplotype sampling
+std::vector<bool> SampledPaths::mask_indexes(size_t column_index, size_t max_index) {
+    std::vector<bool> masked(max_index + 1, true);
+    for (size_t i = 0; i < sampled_paths.size(); ++i) {
+        if (column_index >= sampled_paths[i].size())
+            throw std::runtime_error("HaplotypeSampler::SampledPaths::mask_indexes: column_index exceeds number of columns.");
+        const size_t index = sampled_paths[i][column_index];
+        if (index > max_index) throw std::runtime_error("HaplotypeSampler::SampledPaths::mask_indexes: observed index exceeds max_index.");
+        masked[index] = false;
+    }
+    return masked;
+}
+
+bool SampledPaths::recombination(size_t column_index, size_t path_id) {
+    if (path_id >= sampled_paths.size()) throw std::runtime_error("HaplotypeSampler::SampledPaths::recombination: path_id does not exist.");
+    if (column_index >= sampled_paths[path_id].size())
+        throw std::runtime_error("HaplotypeSampler::SampledPaths::recombination: column_id does not exist.");
+    if (column_index > 0) return sampled_paths[path_id][column_index - 1] != sampled_paths[path_id][column_index];
+    return false;
+}
+
+SamplingEmissions::SamplingEmissions(std::shared_ptr<UniqueKmers> uk) : default_penalty(25) {
+    std::vector<std::shared_ptr<UniqueKmers>> one{uk};
+    FlatContig f;
+    std::vector<unsigned short> all;  // every path: the costs do not depend on the selection, but flatten needs one
+    flatten(&one, nullptr, f);
+    std::vector<uint16_t> cost(f.allele_id.size());
+    if (pg_sampler_emission_costs(&f.batch, cost.data()) != PG_OK) throw std::runtime_error("SamplingEmissions: pg_sampler_emission_costs failed");
+    unsigned short max_allele = 0;
+    for (uint16_t a : f.allele_id) max_allele = std::max<unsigned short>(max_allele, a);
+    allele_penalties.assign((size_t)max_allele + 1, 0);
+    for (size_t s = 0; s < f.allele_id.size(); ++s) allele_penalties[f.allele_id[s]] = cost[s];
+}
+
+unsigned int SamplingEmissions::get_emission_cost(unsigned short allele_id) const { return allele_penalties.at(allele_id); }
+
+void SamplingEmissions::penalize(unsigned short allele_id, unsigned short penalty) {
+    allele_penalties.at(allele_id) += penalty;
+    if (allele_penalties[allele_id] > default_penalty) allele_penalties[allele_id] = (unsigned short)default_penalty;
+}
+
+SamplingTransitions::SamplingTransitions(size_t from_variant, size_t to_variant, double recomb_rate, unsigned short nr_paths, long double effective_N)
+    : cost(pg_sampler_transition_cost(from_variant, to_variant, recomb_rate, nr_paths, effective_N)) {}
+
+unsigned int SamplingTransitions::compute_transition_cost(bool recombination) { return recombination ? cost : 0u; }
+
+namespace {
+thread_local int g_sampler_device = 0;
+}
+void HaplotypeSampler::set_device(int device) { g_sampler_device = device; }
+
+HaplotypeSampler::HaplotypeSampler(std::vector<std::shared_ptr<UniqueKmers>>* uks, size_t size, double recombrate, long double effective_N,
+                                   std::vector<unsigned int>* best_scores, bool add_reference, std::string path_output,
+                                   std::string chromosome, unsigned short allele_penalty, double* time)
+    : unique_kmers(uks) {
+    const auto t0 = std::chrono::steady_clock::now();
+    if (size < 1) return;
+    const size_t V = uks->size();
+    if (V > 0) {
+        FlatContig f;
+        flatten(uks, nullptr, f);  // ALL paths of the panel
+        std::vector<uint32_t> sampled(size * V), best(size);
+        char err[512] = {0};
+        const int rc = pg_sampler_run(&f.batch, (uint32_t)size, recombrate, effective_N, allele_penalty, g_sampler_device, sampled.data(),
+                                      best.data(), err, sizeof(err));
+        if (rc != PG_OK) throw std::runtime_error(std::string("HaplotypeSampler: ") + err);
+        for (size_t i = 0; i < size; ++i) {
+            sampled_paths.sampled_paths.emplace_back(sampled.begin() + i * V, sampled.begin() + (i + 1) * V);
+            if (best_scores != nullptr) best_scores->push_back(best[i]);
+        }
+    } else {
+        for (size_t i = 0; i < size; ++i) sampled_paths.sampled_paths.emplace_back();
+    }
+    if (add_reference) sampled_paths.sampled_paths.push_back(std::vector<size_t>(V, 0));
+    if (path_output != "") {  // reference src/haplotypesampler.cpp:46-66
+        std::ofstream out(path_output);
+        out << "#chromosome\tposition";
+        for (size_t p = 0; p < sampled_paths.sampled_paths.size(); ++p) out << "\tHaplotypeID_path" << p << "\tRecombination_path" << p;
+        out << std::endl;
+        for (size_t c = 0; c < V; ++c) {
+            out << chromosome << "\t" << uks->at(c)->get_variant_position();
+            for (size_t p = 0; p < sampled_paths.sampled_paths.size(); ++p)
+                out << "\t" << sampled_paths.sampled_paths[p][c] << "\t" << sampled_paths.recombination(c, p);
+            out << std::endl;
+        }
+    }
+    update_unique_kmers();
+    if (time != nullptr) *time = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+}
+
+void HaplotypeSampler::get_column_minima(std::vector<unsigned int>& column, std::vector<bool>& mask, size_t& first_id, size_t& second_id,
+                                         unsigned int& first_val, unsigned int& second_val) const {
+    std::vector<uint8_t> m(mask.begin(), mask.end());
+    uint32_t out4[4];
+    char err[256] = {0};
+    if (pg_sampler_column_minima(column.data(), m.data(), (uint32_t)column.size(), g_sampler_device, out4, err, sizeof(err)) != PG_OK)
+        throw std::runtime_error(std::string("HaplotypeSampler::get_column_minima: ") + err);
+    // absent entries: numeric_limits<unsigned int>::max() widened to size_t, as in the reference
+    first_id = out4[0]; second_id = out4[1]; first_val = out4[2]; second_val = out4[3];
+}
+
+void HaplotypeSampler::update_unique_kmers() {
+    const size_t nr_paths = sampled_paths.sampled_paths.size();
+    for (size_t i = 0; i < unique_kmers->size(); ++i) {
+        std::vector<unsigned short> p(nr_paths);
+        for (size_t j = 0; j < nr_paths; ++j) p[j] = (unsigned short)sampled_paths.sampled_paths[j][i];
+        (*unique_kmers)[i]->update_paths(p);
+    }
 }
 
 }  // namespace pangenie

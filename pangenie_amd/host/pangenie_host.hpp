@@ -29,6 +29,7 @@
 #include <vector>
 
 #include "../../include/pangenie_hmm.h"
+#include "../../include/pangenie_sampler.h"
 
 namespace pangenie {
 
@@ -303,5 +304,56 @@ struct ContigTask {
 std::vector<std::vector<GenotypingResult>> run_contigs_multi_gpu(std::vector<ContigTask>& tasks, ProbabilityTable* probabilities,
                                                                  double recombrate, bool uniform, long double effective_N,
                                                                  const std::vector<int>& devices);
+
+// ------------------------------------------------------------------ haplotype sampling (include/pangenie_sampler.h)
+/** reference src/haplotypesampler.hpp:16-59 */
+struct SampledPaths {
+    std::vector<std::vector<size_t>> sampled_paths;
+    std::vector<bool> mask_indexes(size_t column_index, size_t max_index);
+    bool recombination(size_t column_index, size_t path_id);
+};
+
+/** reference src/samplingemissions.hpp / .cpp:9-45 (costs formed by pg_sampler_emission_costs) */
+class SamplingEmissions {
+public:
+    SamplingEmissions(std::shared_ptr<UniqueKmers> uniquekmers);
+    unsigned int get_emission_cost(unsigned short allele_id) const;
+    void penalize(unsigned short allele_id, unsigned short penalty);
+
+private:
+    std::vector<unsigned short> allele_penalties;
+    unsigned int default_penalty;
+};
+
+/** reference src/samplingtransitions.hpp / .cpp:5-23 */
+class SamplingTransitions {
+public:
+    SamplingTransitions(size_t from_variant, size_t to_variant, double recomb_rate, unsigned short nr_paths, long double effective_N = 25000.0L);
+    unsigned int compute_transition_cost(bool recombination);
+
+private:
+    unsigned int cost;
+};
+
+/** reference src/haplotypesampler.hpp:62-96.  The `size` Viterbi passes run on the GPU (pg_sampler_run); the
+ *  constructor then reduces the UniqueKmers objects to the sampled paths exactly as the reference does
+ *  (update_unique_kmers).  path_output / chromosome: the per-position table of sampled path ids the reference
+ *  writes when asked to. */
+class HaplotypeSampler {
+public:
+    HaplotypeSampler(std::vector<std::shared_ptr<UniqueKmers>>* unique_kmers, size_t size, double recombrate = 1.26,
+                     long double effective_N = 25000.0L, std::vector<unsigned int>* best_scores = nullptr, bool add_reference = false,
+                     std::string path_output = "", std::string chromosome = "None", unsigned short allele_penalty = 10,
+                     double* time = nullptr);
+    void get_column_minima(std::vector<unsigned int>& column, std::vector<bool>& mask, size_t& first_id, size_t& second_id,
+                           unsigned int& first_val, unsigned int& second_val) const;
+    SampledPaths get_sampled_paths() const { return sampled_paths; }
+    static void set_device(int device);
+
+private:
+    void update_unique_kmers();
+    std::vector<std::shared_ptr<UniqueKmers>>* unique_kmers;
+    SampledPaths sampled_paths;
+};
 
 }  // namespace pangenie

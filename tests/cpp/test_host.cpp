@@ -17,6 +17,7 @@
 #include <memory>
 #include <stdexcept>
 #include <string>
+#include <unordered_set>
 #include <vector>
 
 #include "../../pangenie_amd/host/cereal_io.hpp"
@@ -330,6 +331,179 @@ static void viterbi_cpu_tests() {
     });
 }
 
+
+// ----------------------------------------------------------------------------------- sampler (CPU: host-side costs)
+static void sampler_cpu_tests() {
+    run("SampledPaths::mask_indexes / recombination", [] {
+        SampledPaths s;
+        s.sampled_paths = {{0, 0, 1, 1}, {1, 1, 2, 0}};
+        CHECK((s.mask_indexes(1, 2) == vector<bool>{false, false, true}));
+        CHECK((s.mask_indexes(2, 2) == vector<bool>{true, false, false}));
+        CHECK_THROWS(s.mask_indexes(4, 2));
+        CHECK_THROWS(s.mask_indexes(2, 1));
+        CHECK(!s.recombination(0, 0) && !s.recombination(1, 0) && s.recombination(2, 0) && !s.recombination(3, 0));
+        CHECK(!s.recombination(0, 1) && !s.recombination(1, 1) && s.recombination(2, 1) && s.recombination(3, 1));
+    });
+    run("SamplingEmissions get_emission_cost", [] {
+        auto u1 = bi(2000, {0, 0});
+        auto u2 = bi(3000, {1, 0});
+        u2->set_undefined_allele(0);
+        kmer(u2, 20, {1}); kmer(u2, 1, {1});
+        SamplingEmissions s1(u1), s2(u2);
+        CHECK(s1.get_emission_cost(0) == 0);
+        CHECK(s2.get_emission_cost(0) == 50 && s2.get_emission_cost(1) == 3);
+        auto v1 = bi(2000, {0, 1});
+        kmer(v1, 20, {0}); kmer(v1, 10, {0}); kmer(v1, 1, {0}); kmer(v1, 3, {1});
+        auto v2 = bi(3000, {0, 1});
+        v2->set_undefined_allele(0);
+        kmer(v2, 1, {0}); kmer(v2, 1, {0}); kmer(v2, 20, {1}); kmer(v2, 2, {1}); kmer(v2, 0, {1});
+        SamplingEmissions t1(v1), t2(v2);
+        CHECK(t1.get_emission_cost(0) == 1 && t1.get_emission_cost(1) == 0);
+        CHECK(t2.get_emission_cost(0) == 50 && t2.get_emission_cost(1) == 4);
+        auto w = bi(2000, {0, 1});
+        kmer(w, 20, {0}); kmer(w, 1, {1});
+        SamplingEmissions t3(w);
+        CHECK(t3.get_emission_cost(0) == 0 && t3.get_emission_cost(1) == 25);
+        auto m = multi(2000, {0, 1, 2});
+        m->set_undefined_allele(1);
+        kmer(m, 20, {0}); kmer(m, 2, {2});
+        SamplingEmissions t4(m);
+        CHECK(t4.get_emission_cost(0) == 0 && t4.get_emission_cost(1) == 50 && t4.get_emission_cost(2) == 25);
+        t1.penalize(0, 10); CHECK(t1.get_emission_cost(0) == 11);
+        t1.penalize(0, 10); t1.penalize(0, 10); CHECK(t1.get_emission_cost(0) == 25);
+    });
+    run("SamplingTransitions compute_transition_cost", [] {
+        SamplingTransitions s(1000000, 2000000, 1.26, 5, 0.25);
+        const double recomb_prob = 0.04455105238;
+        const unsigned int expected_cost = -10.0 * log10(recomb_prob);
+        CHECK(s.compute_transition_cost(false) == 0);
+        CHECK(s.compute_transition_cost(true) == expected_cost);
+    });
+}
+
+// ----------------------------------------------------------------------------------- sampler (GPU)
+static vector<shared_ptr<UniqueKmers>> sampler_panel3(size_t pos2, bool extra_kmer) {
+    auto u1 = multi(1000000, {0, 1, 2});
+    kmer(u1, 10, {0}); kmer(u1, 10, {0}); kmer(u1, 7, {0});
+    kmer(u1, 1, {1}); kmer(u1, 2, {1});
+    if (extra_kmer) kmer(u1, 1, {1});
+    kmer(u1, 20, {1});
+    kmer(u1, 11, {2}); kmer(u1, 10, {2}); kmer(u1, 1, {2});
+    u1->set_coverage(5);
+    auto u2 = bi(pos2, {0, 1, 1});
+    kmer(u2, 1, {0}); kmer(u2, 1, {0}); kmer(u2, 20, {1}); kmer(u2, 22, {1});
+    u2->set_coverage(5);
+    return {u1, u2};
+}
+
+static void sampler_gpu_tests() {
+    run("HaplotypeSampler get_column_minima", [] {
+        HaplotypeSampler h(nullptr, 0);
+        size_t f, s2; unsigned int fv, sv;
+        vector<unsigned int> col = {10, 2, 14, 1};
+        vector<bool> mask = {true, true, true, true};
+        h.get_column_minima(col, mask, f, s2, fv, sv);
+        CHECK(f == 3 && s2 == 1 && fv == 1 && sv == 2);
+        col = {10, 2, 14, 2};
+        h.get_column_minima(col, mask, f, s2, fv, sv);
+        CHECK(f == 1 && s2 == 3 && fv == 2 && sv == 2);
+        col = {10, 10, 10, 10};
+        h.get_column_minima(col, mask, f, s2, fv, sv);
+        CHECK(f == 0 && s2 == 1 && fv == 10 && sv == 10);
+        col = {10, 20, 30}; mask = {true, false, true};
+        h.get_column_minima(col, mask, f, s2, fv, sv);
+        CHECK(f == 0 && s2 == 2 && fv == 10 && sv == 30);
+        mask = {false, true, true};
+        h.get_column_minima(col, mask, f, s2, fv, sv);
+        CHECK(f == 1 && s2 == 2 && fv == 20 && sv == 30);
+    });
+    run("HaplotypeSampler size 0 leaves the panel alone", [] {
+        auto u1 = bi(2000, {0, 0});
+        auto u2 = bi(3000, {1, 0});
+        vector<shared_ptr<UniqueKmers>> uks = {u1, u2};
+        HaplotypeSampler h(&uks, 0);
+        CHECK(h.get_sampled_paths().sampled_paths.empty() && u2->get_nr_paths() == 2);
+    });
+    run("HaplotypeSampler Viterbi", [] {
+        auto u1 = bi(1000000, {0, 1});
+        kmer(u1, 10, {0}); kmer(u1, 1, {1}); u1->set_coverage(5);
+        auto u2 = bi(2000000, {1, 0});
+        kmer(u2, 10, {0}); kmer(u2, 1, {0}); kmer(u2, 2, {1}); u2->set_coverage(5);
+        vector<shared_ptr<UniqueKmers>> uks = {u1, u2};
+        vector<unsigned int> best;
+        HaplotypeSampler h(&uks, 1, 1.26, 25000.0L, &best);
+        CHECK(best.size() == 1 && best[0] == 6);
+        auto sp = h.get_sampled_paths();
+        CHECK(sp.sampled_paths.size() == 1 && (sp.sampled_paths[0] == vector<size_t>{0, 1}));
+    });
+    run("HaplotypeSampler Viterbi2 / Viterbi3", [] {
+        auto uks = sampler_panel3(1000010, false);
+        vector<unsigned int> best;
+        HaplotypeSampler h(&uks, 2, 1.26, 25000.0L, &best);
+        CHECK(best.size() == 2 && best[0] == 1 && best[1] == 14);
+        auto sp = h.get_sampled_paths();
+        CHECK((sp.sampled_paths[0] == vector<size_t>{2, 2}) && (sp.sampled_paths[1] == vector<size_t>{1, 1}));
+        auto uks3 = sampler_panel3(2000000, true);
+        best.clear();
+        HaplotypeSampler h3(&uks3, 2, 1.26, 25000.0L, &best);
+        CHECK(best[0] == 1 && best[1] == 14);
+        sp = h3.get_sampled_paths();
+        CHECK((sp.sampled_paths[0] == vector<size_t>{2, 2}) && (sp.sampled_paths[1] == vector<size_t>{0, 1}));
+    });
+    run("HaplotypeSampler update_unique_kmers (+ reference path)", [] {
+        auto uks = sampler_panel3(2000000, true);
+        HaplotypeSampler h(&uks, 2, 1.26, 25000.0L, nullptr);
+        auto u1 = uks[0], u2 = uks[1];
+        CHECK(u1->size() == 6);
+        const us c1 = {10, 10, 7, 11, 10, 1};
+        for (size_t i = 0; i < c1.size(); ++i) CHECK(u1->get_readcount_of(i) == c1[i]);
+        for (size_t i = 0; i < 3; ++i) CHECK(u1->kmer_on_path(i + 3, 0) && u1->kmer_on_path(i, 1));
+        CHECK(u2->size() == 2 && u2->get_readcount_of(0) == 20 && u2->get_readcount_of(1) == 22);
+        for (size_t i = 0; i < 2; ++i) CHECK(u2->kmer_on_path(i, 0) && u2->kmer_on_path(i, 1));
+        auto uksr = sampler_panel3(2000000, true);
+        HaplotypeSampler hr(&uksr, 2, 1.26, 25000.0L, nullptr, true);
+        auto sp = hr.get_sampled_paths();
+        CHECK(sp.sampled_paths.size() == 3 && (sp.sampled_paths[2] == vector<size_t>{0, 0}));
+        u1 = uksr[0]; u2 = uksr[1];
+        CHECK(u1->size() == 6 && u2->size() == 4);
+        for (size_t i = 0; i < 3; ++i) CHECK(u1->kmer_on_path(i + 3, 0) && u1->kmer_on_path(i, 1) && u1->kmer_on_path(i, 2));
+        const us c2 = {1, 1, 20, 22};
+        for (size_t i = 0; i < c2.size(); ++i) CHECK(u2->get_readcount_of(i) == c2[i]);
+        for (size_t i = 0; i < 2; ++i) CHECK(u2->kmer_on_path(i + 2, 0) && u2->kmer_on_path(i + 2, 1) && u2->kmer_on_path(i, 2));
+    });
+    run("HaplotypeSampler then HMM on the sampled panel", [] {
+        // 40 paths over 30 variants: sample 6 (+ reference), then genotype on what is left, as the reference's
+        // prepare_unique_kmers + run_genotyping do (src/commands.cpp:148-151, :155-175)
+        vector<shared_ptr<UniqueKmers>> uks;
+        unsigned x = 12345;
+        auto rnd = [&x]() { x = x * 1664525u + 1013904223u; return x >> 8; };
+        for (size_t v = 0; v < 30; ++v) {
+            us p2a(40);
+            for (auto& a : p2a) a = rnd() % 2;
+            p2a[0] = 0;
+            auto u = bi(1000 + 700 * v, p2a);
+            for (int k = 0; k < 4; ++k) kmer(u, rnd() % 30, {(unsigned short)(k % 2)});
+            u->set_coverage(20);
+            uks.push_back(u);
+        }
+        HaplotypeSampler h(&uks, 6, 1.26, 25000.0L, nullptr, true);
+        for (auto& u : uks) CHECK(u->get_nr_paths() == 7);
+        for (size_t v = 0; v < 30; ++v) {
+            std::unordered_set<size_t> seen;
+            for (size_t j = 0; j < 6; ++j) seen.insert(h.get_sampled_paths().sampled_paths[j][v]);
+            CHECK(seen.size() == 6);  // a pass never re-picks a path an earlier pass holds at that column
+        }
+        ProbabilityTable probs(5, 41, 61, 0.0L);
+        HMM hmm(&uks, &probs, true, false, 1.26, false, 25000.0L);
+        auto res = hmm.get_genotyping_result();
+        CHECK(res.size() == 30);
+        for (auto& r : res) {
+            const long double sum = r.get_genotype_likelihood(0, 0) + r.get_genotype_likelihood(0, 1) + r.get_genotype_likelihood(1, 1);
+            CHECK(std::fabs((double)(sum - 1.0L)) < 1e-9);
+        }
+    });
+}
+
 static void gpu_tests() {
     run("device visible", [] { CHECK(HMM::device_count() >= 1); });
     run("TransitionProbabilityComputer", [] {
@@ -536,8 +710,8 @@ static void gpu_tests() {
 int main(int argc, char** argv) {
     const std::string mode = argc > 1 ? argv[1] : "cpu";
     if (argc > 2) g_golden_dir = argv[2];
-    if (mode == "cpu") { cpu_tests(); viterbi_cpu_tests(); archive_cpu_tests(); }
-    else if (mode == "gpu") gpu_tests();
+    if (mode == "cpu") { cpu_tests(); viterbi_cpu_tests(); archive_cpu_tests(); sampler_cpu_tests(); }
+    else if (mode == "gpu") { gpu_tests(); sampler_gpu_tests(); }
     else { std::printf("usage: test_host cpu|gpu\n"); return 2; }
     std::printf("%d checks, %d failed\n", g_checks, g_failed);
     return g_failed ? 1 : 0;
