@@ -53,6 +53,8 @@ WORKLOADS = {
     "genome24_h64": dict(V=5_000_000, H=64, K=20, multi=0.0, chains=24, genome=True,
                          cfg="configs[3]: whole genome, 24 contigs (human chromosome length proportions), 5M variants, 64 haplotypes"),
 }
+# the sampler measurement: contigs x variants x panel paths, 15 passes (the reference's default panel size)
+SAMPLER = {"contigs": 8, "V": 40_000, "H": 215, "size": 15}
 # the cohort measurement: samples x contigs over one shared index
 COHORT = dict(samples=32, contigs=8, V=16_000, H=64, K=20)
 # GRCh38 chromosome lengths (Mb) 1..22, X, Y: proportions of the 24 synthetic contigs
@@ -184,6 +186,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-cohort", action="store_true", help="skip the cohort sub-measurement")
     ap.add_argument("--cohort-only", action="store_true", help="profiling: only the cohort measurement")
+    ap.add_argument("--no-sampler", action="store_true", help="skip the HaplotypeSampler sub-measurement")
     ap.add_argument("--cohort-samples", type=int, default=COHORT["samples"])
     args = ap.parse_args()
 
@@ -363,6 +366,43 @@ def main():
                 out.update({"value": out["cohort"]["value"], "ms_per_step": out["cohort"]["ms_per_step"], "scaling": "weak",
                             "config": {"workload": "cohort_h64 only: " + out["cohort"]["workload"]}, "roofline": croof})
         cjob.close()
+
+    # ------------------------------------------------------------------ HaplotypeSampler sub-measurement
+    if not args.no_sampler and not args.cohort_only:
+        from pangenie_amd import sampler as smp
+        sp = SAMPLER
+        panels = [synthetic_panel(sp["V"], sp["H"], 20, seed=4242 + 100 * rank + i, multiallelic_frac=0.2) for i in range(sp["contigs"])]
+        for b in panels:
+            b.kmer_count[::3] = 1  # spread the fractions of present k-mers (the emission costs) over their range
+        smp.sample_contigs(panels[:1], 2, device=local_rank)  # warm-up: module load
+        fence()
+        t0 = time.perf_counter()
+        sampled, _ = smp.sample_contigs(panels, sp["size"], device=local_rank)  # H2D + 15 passes + D2H
+        fence()
+        sdt = max_over_ranks(time.perf_counter() - t0)
+        sms, skern = smp.last_ms()
+        if rank == 0:
+            cells = sp["contigs"] * sp["V"] * sp["H"] * sp["size"]
+            sres = {"workload": f"{sp['contigs']} contigs x {sp['V']} variants, {sp['H']} panel paths, {sp['size']} Viterbi passes (pg_sampler_run_batch), per GPU",
+                    "value": cells * world / (1e-3 * sum(sms)), "unit": "cells/s (paths x variants x passes, kernel time)", "scaling": "weak",
+                    "value_end_to_end": cells * world / sdt, "ms_expand": sms[0], "ms_forward": sms[1], "ms_backtrack": sms[2],
+                    "ns_per_column_pass": 1e6 * sms[1] / (sp["V"] * sp["size"]), "kernel_waves": skern,
+                    "bound": "latency: one workgroup per contig and pass, dependent chain per column (DESIGN.md 4b)"}
+            if not args.no_cpu_baseline:
+                from oracle import pyoracle as orc  # checker / CPU baseline only
+                sub = panels[0].slice(0, min(20_000, sp["V"]))
+                t0 = time.perf_counter()
+                want, _ = orc.sampler_run(sub, sp["size"])
+                cdt_s = time.perf_counter() - t0
+                sres["cpu_baseline"] = {"value": sub.n_variants * sp["H"] * sp["size"] / cdt_s, "unit": "cells/s", "cores": 1, "kind": "port",
+                                        "sample": f"first {sub.n_variants} variants of contig 0, {sp['size']} passes", "ns_per_column_pass": 1e9 * cdt_s / (sub.n_variants * sp["size"])}
+                # the first pass of a prefix equals the prefix of... nothing in general (Viterbi looks ahead), so the
+                # check is a separate full comparison on a small contig
+                small = panels[0].slice(0, 3000)
+                got, _ = smp.sample_contigs([small], sp["size"], device=local_rank)
+                ref, _ = orc.sampler_run(small, sp["size"])
+                sres["matches_oracle"] = bool((got[0] == ref).all())
+            out["sampler"] = sres
 
     if rank == 0:
         print(json.dumps(out))

@@ -13,9 +13,9 @@ mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 cd $R
 if [ "$W" = "cohort_h64" ]; then
-  CMD="python bench.py --steps 3 --warmup 1 --cohort-only --no-cpu-baseline"
+  CMD="python bench.py --steps 3 --warmup 1 --cohort-only --no-cpu-baseline --no-sampler"
 else
-  CMD="python bench.py --steps 3 --warmup 1 --workload $W --no-cpu-baseline --no-cohort"
+  CMD="python bench.py --steps 3 --warmup 1 --workload $W --no-cpu-baseline --no-cohort --no-sampler"
 fi
 timeout 900 rocprofv3 --kernel-trace --stats -d $OUT/kt -o kt --output-format csv -- $CMD > $OUT/kt.log 2>&1
 tail -1 $OUT/kt.log | cut -c1-400

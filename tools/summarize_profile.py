@@ -51,7 +51,7 @@ if sq:
     lines.append("")
     lines.append("SQ counters per launch (rocprofv3 --pmc, four separate passes):")
     for k, d in sq.items():
-        if "k_sweep" in k or "k_post" in k:
+        if "k_sweep" in k or "k_post" in k or "ks_" in k:
             lines.append("  " + k[:70])
             lines.append("    " + "  ".join("%s=%.4g" % (c, v) for c, v in sorted(d.items())))
 lines.append("")
