@@ -2088,7 +2088,506 @@ DEVI void lean_backward(const DevContig& dc, LeanShared<R>& sh, uint32_t C, uint
     if (wave == 0 && bsc.valid) { bsc.flush(bscale, lane, (uint64_t)bot); bsm.flush(bsum, lane, (uint64_t)bot); }
 }
 
+// ------------------------------------------------------------------------------------------
+//  The PIPELINED lean step (round 2b; opt-in with PG_LEAN_PIPE=1 — correct, but measured slower than the plain
+//  step on MI355X, see the end of this comment).  The plain lean step above waits, every column, for the exchange of the
+//  column sums: partial sums -> LDS -> barrier -> LDS reads -> c1 C -> LDS -> 16 broadcast reads, plus the MFMA
+//  total — ~670 exposed wait cycles of 1580.  But the column sums of the NEXT product column follow in closed form
+//  from sums that are already known one step earlier:
+//      w_t = e_t (.) P'_t ,  P'_t = c0 w_{t-1} + u_i + u_j      (u_i = c1 C_i(w_{t-1}),  u_j = u_j + c2 S)
+//      C_j(w_t) = sum_i e_t(a_i, a_j) P'_t(i, j)
+//               = c0 G_j + (eA U0 + eB U1) + u_j (eA N0 + eB N1)
+//  with  G_j = sum_i e_t(a_i, a_j) w_{t-1}(i, j)   (the e_t-WEIGHTED column sums of the previous product column:
+//  accumulated by the fma that used to add up the plain sum — the emission factor of the next column is selected
+//  one step early and kept in registers, so no instruction is added per state),  (eA, eB) = e_t(0, a_j), e_t(1, a_j),
+//  U0/U1 = sums of u_i over the rows with allele 0/1 at column t,  N0/N1 = their numbers.  So the exchange of step
+//  t-1 (now of G) is consumed by step t only to prepare step t+1: the LDS round trips, the barrier skew and the two
+//  MFMA totals run in the shadow of the 16 states of step t, which need nothing but constants prepared a step
+//  earlier.  Exact zeros stay exact (every term carries the emission factor or an empty class sum), so the
+//  zero-column fall-back rules (hmm.cpp:253-267, :374-380) trigger on the same columns.
+//  MEASURED (tools/exp_lean.py, profiles/r02_lean_pipe.txt): 252 instructions per column instead of 215, waitcnt
+//  stalls down (563 -> 396 cycles) but instruction-issue stalls up (110 -> 593): the two extra fp64 MFMA totals
+//  cost ~77 cycles each during which the wave issues nothing (fp64 MFMA and fp64 VALU do not overlap), the 32
+//  broadcast LDS reads of four lock-stepped waves queue behind one LDS pipe (~256 cycles until the last wave has
+//  its 16 u_i), and the wait before the barrier now collects them.  855 ns per column against 655 ns.
+// ------------------------------------------------------------------------------------------
+struct LeanStep {       // what a step's 16 states need, prepared one step ahead (scaled by the column's 2^-es)
+    double c0s, ujs;    // c0 2^-es; (c2 S + c1 C_j) 2^-es, this lane's column
+    double U0s, U1s;    // class sums of the u_i (rows with allele 0 / 1 at the column these constants build)
+    double N0, N1;      // class sizes
+    double m;           // mantissa of the column sum: fscale / bscale
+    double Snew;        // backward: sum of beta'_t
+    bool zero;          // the column summed to zero: fall-back
+};
+DEVI void class_totals(double v, bool bit, double& t0, double& t1) {
+    t1 = wave_total_mfma(bit ? v : 0.0);
+    t0 = wave_total_mfma(bit ? 0.0 : v);
+}
+
 template <int PHASE, int R>
+DEVI void lean_forward_pipe(const DevContig& dc, LeanShared<R>& sh, uint32_t C, uint32_t chunk) {
+    constexpr int HP = 64;
+    constexpr uint32_t RMASK = (1u << R) - 1u;
+    const uint32_t mid = C / 2, K = dc.chunk_cols;
+    uint32_t lo = PHASE == 1 ? 0u : mid, hi = PHASE == 1 ? mid : C;
+    if constexpr (PHASE == 3) {
+        const unsigned long long l = (unsigned long long)mid + (unsigned long long)chunk * K;
+        if (l >= C) return;
+        lo = (uint32_t)l;
+        hi = C - lo > K ? lo + K : C;
+    }
+    if (lo >= hi) return;
+    const uint32_t first = lo == 0 ? 1u : lo;
+    const uint32_t tid = threadIdx.x, lane = tid & 63u;
+    const uint32_t wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const uint32_t i0 = wave * R;
+    const size_t colsz = (size_t)HP * HP;
+    const double unif = 1.0 / 4096.0;
+    LeanRecs recs{(const GAS char*)dc.frec, (int64_t)first - 1, (int64_t)C, +1, tid};
+    recs.park(sh, 0, recs.fetch(0));
+    v2f64 piece = recs.fetch(1);
+    lds_barrier();
+    gdouble* fwd = (gdouble*)dc.fwd;
+    gdouble* fscale = (gdouble*)dc.fscale;
+    gu8* fallback = (gu8*)dc.fwd_fallback;
+    gdouble* wr = fwd;
+    gcdouble* resume = (gcdouble*)(fwd + (size_t)(lo > 0 ? lo - 1 : 0) * colsz);
+    if constexpr (PHASE == 3) {
+        gdouble* scr = (gdouble*)dc.scratch;
+        wr = scr + (size_t)((chunk & 1u) * 2u) * K * colsz - (size_t)lo * colsz;
+        if (chunk > 0) resume = (gcdouble*)(scr + ((size_t)(((chunk - 1u) & 1u) * 2u) * K + (K - 1u)) * colsz);
+    }
+    const size_t toff = (size_t)(i0 >> 1) * HP + lane;
+    auto emis = [&](const FRec& r, double& eA, double& eB) {  // e(i, j) = row bit ? eB : eA for this lane's column allele
+        const bool aj = (r.bits1 >> lane) & 1ull;
+        eA = aj ? r.E01 : r.E00;
+        eB = aj ? r.E11 : r.E01;
+    };
+    auto rowbits = [&](const FRec& r) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)((uint32_t)(r.bits1 >> i0) & RMASK)); };
+    auto store_col = [&](uint32_t c, const double (&v)[R]) {
+        gdouble2* dst = (gdouble2*)(wr + (size_t)c * colsz) + toff;
+#pragma unroll
+        for (int k = 0; k < R; k += 2) dst[(size_t)(k >> 1) * HP] = v2f64{v[k], v[k + 1]};
+    };
+    auto flag_uniform = [&](uint32_t cprev) {
+        if (cprev >= lo) {
+            double xu[R];
+#pragma unroll
+            for (int k = 0; k < R; ++k) xu[k] = unif;
+            store_col(cprev, xu);
+        }
+        if (wave == 0) fallback[cprev] = 1;
+    };
+    // constants of the step that builds column c+1, from the column sums Cn of w_c (this lane's column) and the
+    // record of column c+1 (gap c -> c+1, alleles of column c+1); the u_i of this wave's rows go through its LDS row
+    auto prepare = [&](const FRec& r, double Cn, double (&uo)[R], LeanStep& k) {
+        const bool bj = (r.bits1 >> lane) & 1ull;
+        double UC0, UC1;
+        class_totals(Cn, bj, UC0, UC1);
+        double S = UC0 + UC1;
+        k.zero = !(S > 0.0);
+        double c0 = r.c0;
+        if (__builtin_expect(k.zero, 0)) { S = 1.0; c0 = 0.0; }  // the uniform column takes its place (hmm.cpp:253-267)
+        int es = exponent_of(S) - PG_BIAS_F;
+        es = es < -900 ? -900 : es;
+        k.m = ldexp(S, -es - PG_BIAS_F);
+        k.c0s = ldexp(c0, -es);
+        const double c1s = ldexp(r.c1, -es), c2s = ldexp(r.c2, -es);
+        const double ucol = c1s * Cn;
+        sh.u[wave][lane] = ucol;  // wave-private row: the u_i of this wave's rows come back as broadcasts
+        const double* row = &sh.u[wave][i0];
+#pragma unroll
+        for (int q = 0; q < R; ++q) uo[q] = row[q];
+        k.ujs = fma(c2s, S, ucol);
+        if (__builtin_expect(k.zero, 0)) k.ujs = ldexp(fma(r.c0, unif, fma(r.c2, 1.0, 2.0 * r.c1 * (64.0 * unif))), -es);
+        k.U0s = c1s * UC0;
+        k.U1s = c1s * UC1;
+        k.N1 = (double)__popcll(r.bits1);
+        k.N0 = 64.0 - k.N1;
+        k.Snew = 0.0;
+    };
+
+    ColScalars fsc;
+    double x[R], ecur[R], uis[R];
+    LeanStep ks;
+    FRec cur = read_frec(sh, 1);  // record of column `first`
+    FRec nxt = read_frec(sh, 2);  // record of column first+1 (records are read two steps ahead of their first use)
+    double eA, eB;                // this lane's emission pair at column `cur`
+    {
+        const FRec r0 = read_frec(sh, 0);
+        double e0A, e0B;
+        emis(r0, e0A, e0B);
+        const uint32_t rb0 = rowbits(r0);
+        if (lo == 0) {
+            const double P0 = ldexp(1.0, PG_BIAS_F);
+            double pz[R];
+#pragma unroll
+            for (int k = 0; k < R; ++k) { pz[k] = P0; x[k] = sel_by_bit(rb0, k, e0A, e0B) * P0; }
+            store_col(0, pz);
+            if (wave == 0) fscale[0] = 1.0;
+        } else {
+            gcdouble2* src = (gcdouble2*)resume + toff;
+#pragma unroll
+            for (int k = 0; k < R; k += 2) { const v2f64 t = src[(size_t)(k >> 1) * HP]; x[k] = t.x; x[k + 1] = t.y; }
+            if (!fallback[lo - 1]) {
+#pragma unroll
+                for (int k = 0; k < R; ++k) x[k] *= sel_by_bit(rb0, k, e0A, e0B);
+            }
+        }
+        emis(cur, eA, eB);
+        const uint32_t rbc = rowbits(cur);
+        double part = 0.0, G = 0.0;
+#pragma unroll
+        for (int k = 0; k < R; ++k) { ecur[k] = sel_by_bit(rbc, k, eA, eB); part += x[k]; G = fma(x[k], ecur[k], G); }
+        sh.psum[first & 1u][wave][lane] = part;       // plain sums of w_{first-1}: this launch's only direct exchange
+        sh.psum[(first - 1) & 1u][wave][lane] = G;    // e_first-weighted sums of w_{first-1}
+        lds_barrier();
+        const double Cj = lean_colsum<R>(sh, first & 1u, lane);
+        lds_barrier();  // the slot is rewritten at the end of step `first`
+        prepare(cur, Cj, uis, ks);
+    }
+#ifdef PG_LEANPROF
+    unsigned long long acc_[8] = {0, 0, 0, 0, 0, 0, 0, 0}, last_ = __builtin_amdgcn_s_memtime();
+#endif
+    for (uint32_t t = first; t < hi; ++t) {
+        const uint32_t n = t - first;
+        const FRec nx2 = (kLX & 64u) ? nxt : read_frec(sh, n + 3u);  // record of column t+2: first used a step from now
+        if (((n + 4u) % PG_LEAN_BLOCK) == 0u) {
+            const uint32_t blk = (n + 4u) / PG_LEAN_BLOCK;
+            recs.park(sh, blk, piece);
+            piece = recs.fetch(blk + 1u);
+        }
+        if (__builtin_expect(ks.zero, 0)) flag_uniform(t - 1);
+        // Two independent strands, interleaved by hand (the scheduler keeps them apart otherwise and every
+        // LDS / MFMA latency of strand A is then exposed):
+        //   A: column sums of w_t in closed form (from the exchange of the previous step) -> constants of step t+1
+        //   B: the 16 states of column t, which need nothing younger than a step
+        double eAn, eBn;
+        emis(nxt, eAn, eBn);
+        const uint32_t rbn = rowbits(nxt);
+        gdouble2* dst = (gdouble2*)(wr + (size_t)t * colsz) + toff;
+        double Gq[4] = {0.0, 0.0, 0.0, 0.0}, pprev = 0.0;
+        // (the empty asm pins the whole chunk — products, selects, its partial sum — in front of the next piece of
+        // strand A: left alone, everything not feeding a store sinks to the end of the step)
+#define PG_LEAN_STATES_F(K0)                                                          \
+        _Pragma("unroll") for (int k = (K0); k < (K0) + 4; ++k) {                     \
+            const double pk = fma(ks.c0s, x[k], uis[k] + ks.ujs);                     \
+            x[k] = pk * ecur[k];                                                      \
+            ecur[k] = sel_by_bit(rbn, k, eAn, eBn);                                   \
+            Gq[(K0) / 4] = fma(x[k], ecur[k], Gq[(K0) / 4]);                          \
+            if (k & 1) { dst[(size_t)(k >> 1) * HP] = v2f64{pprev, pk}; }             \
+            else pprev = pk;                                                          \
+        }                                                                             \
+        asm volatile("" :: "v"(Gq[(K0) / 4]));
+        const uint32_t pb = (t - 1) & 1u;
+        double g0 = sh.psum[pb][0][lane], g1 = sh.psum[pb][1][lane], g2 = sh.psum[pb][2][lane], g3 = sh.psum[pb][3][lane];
+        if (kLX & 8u) { g0 = x[0]; g1 = x[1]; g2 = x[2]; g3 = x[3]; }
+        __builtin_amdgcn_sched_barrier(0);
+        LEAN_STAMP(0);
+        PG_LEAN_STATES_F(0)
+        LEAN_DEP(x[3]); LEAN_STAMP(1);
+        __builtin_amdgcn_sched_barrier(0);
+        const double Gj = (g0 + g1) + (g2 + g3);
+        const double Cn = fma(ks.c0s, Gj, fma(ks.ujs, fma(eA, ks.N0, eB * ks.N1), fma(eA, ks.U0s, eB * ks.U1s)));
+        const bool bj = (nxt.bits1 >> lane) & 1ull;
+        const v4f64 zz = {0.0, 0.0, 0.0, 0.0};
+        const double cm1 = bj ? Cn : 0.0, cm0 = bj ? 0.0 : Cn;
+        const v4f64 a1 = (kLX & 2u) ? v4f64{cm1, cm1, cm1, cm1} : __builtin_amdgcn_mfma_f64_16x16x4f64(cm1, 1.0, zz, 0, 0, 0);
+        const v4f64 a0 = (kLX & (2u | 256u)) ? v4f64{cm0, cm0, cm0, cm0} : __builtin_amdgcn_mfma_f64_16x16x4f64(cm0, 1.0, zz, 0, 0, 0);
+        LEAN_STAMP(2);
+        __builtin_amdgcn_sched_barrier(0);
+        PG_LEAN_STATES_F(4)
+        LEAN_DEP(x[7]); LEAN_STAMP(3);
+        __builtin_amdgcn_sched_barrier(0);
+        const double s1_ = (a1[0] + a1[1]) + (a1[2] + a1[3]), s0_ = (a0[0] + a0[1]) + (a0[2] + a0[3]);
+        const v4f64 b1 = (kLX & 2u) ? v4f64{s1_, s1_, s1_, s1_} : __builtin_amdgcn_mfma_f64_16x16x4f64(s1_, 1.0, zz, 0, 0, 0);
+        const v4f64 b0 = (kLX & (2u | 256u)) ? v4f64{s0_, s0_, s0_, s0_} : __builtin_amdgcn_mfma_f64_16x16x4f64(s0_, 1.0, zz, 0, 0, 0);
+        LEAN_STAMP(4);
+        __builtin_amdgcn_sched_barrier(0);
+        PG_LEAN_STATES_F(8)
+        LEAN_DEP(x[11]); LEAN_STAMP(5);
+        __builtin_amdgcn_sched_barrier(0);
+        double uin[R];
+        LeanStep kn;
+        {
+            const double UC1 = b1[0], UC0 = b0[0];
+            double S = UC0 + UC1;
+            kn.zero = !(S > 0.0);
+            double c0 = nxt.c0;
+            if (__builtin_expect(kn.zero, 0)) { S = 1.0; c0 = 0.0; }  // the uniform column takes its place (hmm.cpp:253-267)
+            int es = exponent_of(S) - PG_BIAS_F;
+            es = es < -900 ? -900 : es;
+            kn.m = ldexp(S, -es - PG_BIAS_F);
+            kn.c0s = ldexp(c0, -es);
+            const double c1s = ldexp(nxt.c1, -es), c2s = ldexp(nxt.c2, -es);
+            const double ucol = c1s * Cn;
+            sh.u[wave][lane] = ucol;  // wave-private row: the u_i of this wave's rows come back as broadcasts
+            const double* row = &sh.u[wave][i0];
+#pragma unroll
+            for (int q = 0; q < R; ++q) uin[q] = (kLX & 4u) ? ucol : row[q];
+            kn.ujs = fma(c2s, S, ucol);
+            if (__builtin_expect(kn.zero, 0)) kn.ujs = ldexp(fma(nxt.c0, unif, fma(nxt.c2, 1.0, 2.0 * nxt.c1 * (64.0 * unif))), -es);
+            kn.U0s = c1s * UC0;
+            kn.U1s = c1s * UC1;
+            kn.N1 = (double)__popcll(nxt.bits1);
+            kn.N0 = 64.0 - kn.N1;
+            kn.Snew = 0.0;
+        }
+        LEAN_DEP(kn.ujs); LEAN_STAMP(6);
+        __builtin_amdgcn_sched_barrier(0);
+        PG_LEAN_STATES_F(12)
+        __builtin_amdgcn_sched_barrier(0);
+#undef PG_LEAN_STATES_F
+        sh.psum[t & 1u][wave][lane] = (Gq[0] + Gq[1]) + (Gq[2] + Gq[3]);
+        if (wave == 0) {  // (scalar branch)
+            fsc.put(lane, t, ks.m);
+            if ((t & 63u) == 63u) fsc.flush(fscale, lane, t);
+        }
+#pragma unroll
+        for (int k = 0; k < R; ++k) uis[k] = uin[k];
+        ks = kn;
+        eA = eAn; eB = eBn;
+        cur = nxt;
+        nxt = nx2;
+        if (!(kLX & 32u)) lds_barrier();
+        LEAN_STAMP(7);
+    }
+#ifdef PG_LEANPROF
+    if (tid == 0) { for (int q = 0; q < 8; ++q) dc.prof[32 + q] = acc_[q]; dc.prof[40] = hi - first; }
+#endif
+    if (wave == 0 && fsc.valid) fsc.flush(fscale, lane, hi - 1);
+    if (ks.zero) flag_uniform(hi - 1);  // the last column of this phase may itself have summed to zero
+}
+
+template <int PHASE, int R>
+DEVI void lean_backward_pipe(const DevContig& dc, LeanShared<R>& sh, uint32_t C, uint32_t chunk) {
+    constexpr int HP = 64;
+    constexpr uint32_t RMASK = (1u << R) - 1u;
+    const int64_t mid = C / 2, K = dc.chunk_cols;
+    int64_t top = PHASE == 1 ? (int64_t)C - 1 : mid - 1;
+    int64_t bot = PHASE == 1 ? mid : 0;
+    if constexpr (PHASE == 3) {
+        top = mid - 1 - (int64_t)chunk * K;
+        if (top < 0) return;
+        bot = top - K + 1 > 0 ? top - K + 1 : 0;
+    }
+    if (top < bot) return;
+    const int64_t t0 = PHASE == 1 ? top - 1 : top;
+    const uint32_t tid = threadIdx.x, lane = tid & 63u;
+    const uint32_t wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const uint32_t i0 = wave * R;
+    const size_t colsz = (size_t)HP * HP;
+    const double unif = 1.0 / 4096.0;
+    LeanRecs recs{(const GAS char*)dc.frec, t0 + 1, (int64_t)C, -1, tid};
+    recs.park(sh, 0, recs.fetch(0));
+    v2f64 piece = recs.fetch(1);
+    lds_barrier();
+    gdouble* cols = (gdouble*)dc.fwd;
+    gdouble* bscale = (gdouble*)dc.bscale;
+    gdouble* bsum = (gdouble*)dc.bsum;
+    gdouble* wr = cols;
+    gcdouble* resume = (gcdouble*)(cols + (size_t)(top + 1 < (int64_t)C ? top + 1 : top) * colsz);
+    if constexpr (PHASE == 3) {
+        gdouble* scr = (gdouble*)dc.scratch;
+        wr = scr + (size_t)((chunk & 1u) * 2u + 1u) * (size_t)K * colsz - (size_t)bot * colsz;
+        if (chunk > 0) resume = (gcdouble*)(scr + (size_t)(((chunk - 1u) & 1u) * 2u + 1u) * (size_t)K * colsz);
+    }
+    const size_t toff = (size_t)(i0 >> 1) * HP + lane;
+    auto emis = [&](const FRec& r, double& eA, double& eB) {
+        const bool aj = (r.bits1 >> lane) & 1ull;
+        eA = aj ? r.E01 : r.E00;
+        eB = aj ? r.E11 : r.E01;
+    };
+    auto rowbits = [&](const FRec& r) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)((uint32_t)(r.bits1 >> i0) & RMASK)); };
+    auto store_col = [&](int64_t c, const double (&v)[R]) {
+        gdouble2* dst = (gdouble2*)(wr + (size_t)c * colsz) + toff;
+#pragma unroll
+        for (int k = 0; k < R; k += 2) dst[(size_t)(k >> 1) * HP] = v2f64{v[k], v[k + 1]};
+    };
+    // constants of the step that builds beta'_t: gap record r (column t+1), Sy = sum of beta'_{t+1} (1 behind a zero
+    // column), Cn = column sums of the entering product column w = e_{t+1} (.) beta'_{t+1}, class bits = alleles of
+    // column t (the emission the new product column is weighted with)
+    auto prepare = [&](const FRec& r, double Sy, double Cn, unsigned long long cbits, double (&uo)[R], LeanStep& k) {
+        int es = exponent_of(Sy) - PG_BIAS_B;
+        es = es < -900 ? -900 : es;
+        k.m = ldexp(Sy, -es - PG_BIAS_B);
+        const double k1 = ldexp(r.c1, -es), k2 = ldexp(r.c2, -es), kap = ldexp(r.kappa, -es);
+        k.c0s = ldexp(r.c0, -es);
+        const double ucol = k1 * Cn;
+        sh.u[wave][lane] = ucol;
+        const double* row = &sh.u[wave][i0];
+#pragma unroll
+        for (int q = 0; q < R; ++q) uo[q] = row[q];
+        const bool bj = (cbits >> lane) & 1ull;
+        double UC0, UC1;
+        class_totals(Cn, bj, UC0, UC1);
+        const double Sw = UC0 + UC1;
+        k.ujs = fma(k2, Sw, ucol);
+        k.Snew = kap * Sw;  // = sum(beta'_t)
+        k.zero = !(k.Snew > 0.0);
+        k.U0s = k1 * UC0;
+        k.U1s = k1 * UC1;
+        k.N1 = (double)__popcll(cbits);
+        k.N0 = 64.0 - k.N1;
+        if (__builtin_expect(k.zero, 0)) {
+            // beta~_t is all zero: its own posteriors are 0, the next step starts from the uniform column (hmm.cpp:374-380)
+            k.c0s = 0.0; k.ujs = unif; k.U0s = 0.0; k.U1s = 0.0;
+#pragma unroll
+            for (int q = 0; q < R; ++q) uo[q] = 0.0;
+        }
+    };
+
+    ColScalars bsc, bsm;
+    double w[R], ecur[R], uis[R];
+    LeanStep ks;
+    FRec cur = read_frec(sh, 1);  // record of column t0: emission of column t0, constants of the gap t0-1 -> t0
+    FRec nxt = read_frec(sh, 2);  // record of column t0-1 (records are read two steps ahead of their first use)
+    double eA, eB;
+    {
+        const FRec r1 = read_frec(sh, 0);  // record t0+1: constants of the gap t0 -> t0+1, emission of column t0+1
+        double y[R], Sy;
+        if constexpr (PHASE == 1) {
+            const double B0 = ldexp(1.0, PG_BIAS_B);  // column C-1: beta~ = 1 (hmm.cpp:356-358), stored at the backward bias
+#pragma unroll
+            for (int k = 0; k < R; ++k) y[k] = B0;
+            Sy = 4096.0 * B0;
+            store_col(top, y);
+            if (wave == 0) { bscale[top] = 1.0; bsum[top] = Sy; }
+        } else {
+            gcdouble2* src = (gcdouble2*)resume + toff;
+#pragma unroll
+            for (int k = 0; k < R; k += 2) { const v2f64 t = src[(size_t)(k >> 1) * HP]; y[k] = t.x; y[k + 1] = t.y; }
+            Sy = bsum[top + 1];
+            if (!(Sy > 0.0)) {  // resuming behind an all-zero column: uniform (hmm.cpp:374-380)
+#pragma unroll
+                for (int k = 0; k < R; ++k) y[k] = unif;
+                Sy = 1.0;
+            }
+        }
+        double e1A, e1B;
+        emis(r1, e1A, e1B);
+        const uint32_t rb1 = rowbits(r1);
+        emis(cur, eA, eB);
+        const uint32_t rbc = rowbits(cur);
+        double part = 0.0, G = 0.0;
+#pragma unroll
+        for (int k = 0; k < R; ++k) {
+            w[k] = y[k] * sel_by_bit(rb1, k, e1A, e1B);
+            ecur[k] = sel_by_bit(rbc, k, eA, eB);
+            part += w[k];
+            G = fma(w[k], ecur[k], G);
+        }
+        sh.psum[(uint32_t)(t0 - 1) & 1u][wave][lane] = part;  // plain sums of the entering product column
+        sh.psum[(uint32_t)t0 & 1u][wave][lane] = G;            // e_t0-weighted sums
+        lds_barrier();
+        const double Cj = lean_colsum<R>(sh, (uint32_t)(t0 - 1) & 1u, lane);
+        lds_barrier();
+        prepare(r1, Sy, Cj, cur.bits1, uis, ks);
+    }
+    for (int64_t t = t0; t >= bot; --t) {
+        const uint32_t n = (uint32_t)(t0 - t);
+        const FRec nx2 = (kLX & 64u) ? nxt : read_frec(sh, n + 3u);  // record of column t-2: first used a step from now
+        if (((n + 4u) % PG_LEAN_BLOCK) == 0u) {
+            const uint32_t blk = (n + 4u) / PG_LEAN_BLOCK;
+            recs.park(sh, blk, piece);
+            piece = recs.fetch(blk + 1u);
+        }
+        // strands A (closed-form column sums of w_t = e_t (.) beta'_t -> constants of step t-1) and B (the 16 states of
+        // column t), interleaved by hand as in lean_forward_pipe
+        double eAn, eBn;
+        emis(nxt, eAn, eBn);
+        const uint32_t rbn = rowbits(nxt);
+        gdouble2* dst = (gdouble2*)(wr + (size_t)t * colsz) + toff;
+        double Gq[4] = {0.0, 0.0, 0.0, 0.0}, yprev = 0.0;
+#define PG_LEAN_STATES_B(K0)                                                          \
+        _Pragma("unroll") for (int k = (K0); k < (K0) + 4; ++k) {                     \
+            const double yk = fma(ks.c0s, w[k], uis[k] + ks.ujs);                     \
+            w[k] = yk * ecur[k];                                                      \
+            ecur[k] = sel_by_bit(rbn, k, eAn, eBn);                                   \
+            Gq[(K0) / 4] = fma(w[k], ecur[k], Gq[(K0) / 4]);                          \
+            if (k & 1) { dst[(size_t)(k >> 1) * HP] = v2f64{yprev, yk}; }             \
+            else yprev = yk;                                                          \
+        }                                                                             \
+        asm volatile("" :: "v"(Gq[(K0) / 4]));
+        const uint32_t pb = (uint32_t)t & 1u;
+        double g0 = sh.psum[pb][0][lane], g1 = sh.psum[pb][1][lane], g2 = sh.psum[pb][2][lane], g3 = sh.psum[pb][3][lane];
+        if (kLX & 8u) { g0 = w[0]; g1 = w[1]; g2 = w[2]; g3 = w[3]; }
+        __builtin_amdgcn_sched_barrier(0);
+        PG_LEAN_STATES_B(0)
+        __builtin_amdgcn_sched_barrier(0);
+        const double Gj = (g0 + g1) + (g2 + g3);
+        const double Cn = fma(ks.c0s, Gj, fma(ks.ujs, fma(eA, ks.N0, eB * ks.N1), fma(eA, ks.U0s, eB * ks.U1s)));
+        const bool bj = (nxt.bits1 >> lane) & 1ull;
+        const v4f64 zz = {0.0, 0.0, 0.0, 0.0};
+        const double cm1 = bj ? Cn : 0.0, cm0 = bj ? 0.0 : Cn;
+        const v4f64 a1 = (kLX & 2u) ? v4f64{cm1, cm1, cm1, cm1} : __builtin_amdgcn_mfma_f64_16x16x4f64(cm1, 1.0, zz, 0, 0, 0);
+        const v4f64 a0 = (kLX & (2u | 256u)) ? v4f64{cm0, cm0, cm0, cm0} : __builtin_amdgcn_mfma_f64_16x16x4f64(cm0, 1.0, zz, 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        PG_LEAN_STATES_B(4)
+        __builtin_amdgcn_sched_barrier(0);
+        const double s1_ = (a1[0] + a1[1]) + (a1[2] + a1[3]), s0_ = (a0[0] + a0[1]) + (a0[2] + a0[3]);
+        const v4f64 b1 = (kLX & 2u) ? v4f64{s1_, s1_, s1_, s1_} : __builtin_amdgcn_mfma_f64_16x16x4f64(s1_, 1.0, zz, 0, 0, 0);
+        const v4f64 b0 = (kLX & (2u | 256u)) ? v4f64{s0_, s0_, s0_, s0_} : __builtin_amdgcn_mfma_f64_16x16x4f64(s0_, 1.0, zz, 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        PG_LEAN_STATES_B(8)
+        __builtin_amdgcn_sched_barrier(0);
+        double uin[R];
+        LeanStep kn;
+        {
+            const double Sy = ks.Snew > 0.0 ? ks.Snew : 1.0;
+            int es = exponent_of(Sy) - PG_BIAS_B;
+            es = es < -900 ? -900 : es;
+            kn.m = ldexp(Sy, -es - PG_BIAS_B);
+            const double k1 = ldexp(cur.c1, -es), k2 = ldexp(cur.c2, -es), kap = ldexp(cur.kappa, -es);
+            kn.c0s = ldexp(cur.c0, -es);
+            const double ucol = k1 * Cn;
+            sh.u[wave][lane] = ucol;
+            const double* row = &sh.u[wave][i0];
+#pragma unroll
+            for (int q = 0; q < R; ++q) uin[q] = (kLX & 4u) ? ucol : row[q];
+            const double UC1 = b1[0], UC0 = b0[0];
+            const double Sw = UC0 + UC1;
+            kn.ujs = fma(k2, Sw, ucol);
+            kn.Snew = kap * Sw;  // = sum(beta'_{t-1})
+            kn.zero = !(kn.Snew > 0.0);
+            kn.U0s = k1 * UC0;
+            kn.U1s = k1 * UC1;
+            kn.N1 = (double)__popcll(nxt.bits1);
+            kn.N0 = 64.0 - kn.N1;
+            if (__builtin_expect(kn.zero, 0)) {
+                kn.c0s = 0.0; kn.ujs = unif; kn.U0s = 0.0; kn.U1s = 0.0;
+#pragma unroll
+                for (int q = 0; q < R; ++q) uin[q] = 0.0;
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        PG_LEAN_STATES_B(12)
+        __builtin_amdgcn_sched_barrier(0);
+#undef PG_LEAN_STATES_B
+        if (__builtin_expect(ks.zero, 0)) {  // an all-zero beta~_t is stored as zeros (same thread, same addresses, later in program order)
+            double yz[R];
+#pragma unroll
+            for (int k = 0; k < R; ++k) yz[k] = 0.0;
+            store_col(t, yz);
+        }
+        sh.psum[(uint32_t)(t - 1) & 1u][wave][lane] = (Gq[0] + Gq[1]) + (Gq[2] + Gq[3]);
+        if (wave == 0) {
+            bsc.put(lane, (uint64_t)t, ks.m);
+            bsm.put(lane, (uint64_t)t, ks.Snew);
+            if (((uint64_t)t & 63u) == 0u) { bsc.flush(bscale, lane, (uint64_t)t); bsm.flush(bsum, lane, (uint64_t)t); }
+        }
+#pragma unroll
+        for (int k = 0; k < R; ++k) uis[k] = uin[k];
+        ks = kn;
+        eA = eAn; eB = eBn;
+        cur = nxt;
+        nxt = nx2;
+        if (!(kLX & 32u)) lds_barrier();
+    }
+    if (wave == 0 && bsc.valid) { bsc.flush(bscale, lane, (uint64_t)bot); bsm.flush(bsum, lane, (uint64_t)bot); }
+}
+
+template <int PHASE, int R, bool PIPE>
 __global__ __launch_bounds__((64 * 64 / R)) void k_sweep_lean(const DevContig* __restrict__ contigs, uint32_t chunk) {
     __shared__ LeanShared<R> sh;
     const DevContig& dc = contigs[blockIdx.x];
@@ -2096,8 +2595,13 @@ __global__ __launch_bounds__((64 * 64 / R)) void k_sweep_lean(const DevContig* _
     const uint32_t C = (uint32_t)__builtin_amdgcn_readfirstlane((int)*dc.n_cols);
     if (C == 0) return;
     const unsigned long long t_begin = kChainProf ? __builtin_amdgcn_s_memtime() : 0ull;
-    if (blockIdx.y == 0) lean_forward<PHASE, R>(dc, sh, C, chunk);
-    else lean_backward<PHASE, R>(dc, sh, C, chunk);
+    if constexpr (PIPE) {
+        if (blockIdx.y == 0) lean_forward_pipe<PHASE, R>(dc, sh, C, chunk);
+        else lean_backward_pipe<PHASE, R>(dc, sh, C, chunk);
+    } else {
+        if (blockIdx.y == 0) lean_forward<PHASE, R>(dc, sh, C, chunk);
+        else lean_backward<PHASE, R>(dc, sh, C, chunk);
+    }
     if (kChainProf && threadIdx.x == 0) {  // -DPG_CHAIN_PROF builds only: cycles of this role's launch (last chunk wins)
         unsigned long long* o = dc.prof + (blockIdx.y == 0 ? 0 : 16) + (PHASE == 1 ? 0 : 8);
         o[0] = __builtin_amdgcn_s_memtime() - t_begin;
@@ -2753,8 +3257,12 @@ static void launch_sweep(const DevContig* d_contigs, uint32_t n_contigs, uint32_
     if constexpr (PHASE != 2) {
         if (hp_mask & 64u) {  // bit 6: the job has lean chains (all-biallelic, H = HP = 64)
             static const int lean_r = [] { const char* e = getenv("PG_LEAN_R"); return e ? atoi(e) : 16; }();
-            if (lean_r == 8) hipLaunchKernelGGL((k_sweep_lean<PHASE, 8>), dim3(n_contigs, 2), dim3(512), 0, s, d_contigs, chunk);
-            else hipLaunchKernelGGL((k_sweep_lean<PHASE, 16>), dim3(n_contigs, 2), dim3(256), 0, s, d_contigs, chunk);
+            // PG_LEAN_PIPE=1: the pipelined lean step (closed-form column sums; measured SLOWER than the plain step,
+            // 855 vs 655 ns per column — DESIGN.md 4 — and kept as an independently derived cross-check)
+            static const int lean_pipe = [] { const char* e = getenv("PG_LEAN_PIPE"); return e ? atoi(e) : 0; }();
+            if (lean_r == 8) hipLaunchKernelGGL((k_sweep_lean<PHASE, 8, false>), dim3(n_contigs, 2), dim3(512), 0, s, d_contigs, chunk);
+            else if (lean_pipe) hipLaunchKernelGGL((k_sweep_lean<PHASE, 16, true>), dim3(n_contigs, 2), dim3(256), 0, s, d_contigs, chunk);
+            else hipLaunchKernelGGL((k_sweep_lean<PHASE, 16, false>), dim3(n_contigs, 2), dim3(256), 0, s, d_contigs, chunk);
         }
         // bit 4: contigs with HP >= 256; bit 5: (forced) the generic kernel for every HP >= 64
         if (hp_mask & 48u)

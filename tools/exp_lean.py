@@ -6,7 +6,7 @@ import os, subprocess, sys
 sys.path.insert(0, os.getcwd())
 NAMES = {0: "baseline", 1: "no column stores", 2: "no MFMA total", 4: "no u_i round trip", 8: "no column-sum reads", 16: "no per-state arithmetic",
          32: "no barrier", 64: "no record reads", 128: "no scale stores", 129: "no stores at all", 255: "none of them",
-         17: "no arithmetic, no stores", 6: "no MFMA, no u", 14: "no sums at all", 46: "no sums, no barrier"}
+         17: "no arithmetic, no stores", 256: "one MFMA total instead of two", 258: "no MFMA at all (2|256)", 6: "no MFMA, no u", 14: "no sums at all", 46: "no sums, no barrier"}
 # a mask may carry a codegen-variant suffix: "0v3" = PG_LEANX=0, PG_LEANV=3; "0f" adds -mllvm -amdgpu-mfma-vgpr-form
 args_ = sys.argv[2:] or [str(k) for k in NAMES]
 def parse(a):

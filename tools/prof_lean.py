@@ -17,8 +17,13 @@ else:
     job.run(); job.run()
     ms = job.kernel_ms(); C = job.fetch(0).n_columns
     p = job.profile_counters(0).astype(float)
-    n = max(p[39], 1)
-    names = ["record reads + column sums", "u round trip", "MFMA total", "scale / constants / emission pair", "16 states + stores",
+    pipe = os.environ.get("PG_LEAN_PIPE", "1") != "0"
+    n = max(p[40] if pipe else p[39], 1)
+    if pipe:
+        names = ["top: records, park, issue G reads", "states 0-3", "Gj, Cn, first MFMAs issued", "states 4-7", "adds, second MFMAs issued",
+                 "states 8-11", "constants, u round trip", "states 12-15, tail, barrier"]
+    else:
+      names = ["record reads + column sums", "u round trip", "MFMA total", "scale / constants / emission pair", "16 states + stores",
              "park sums, collect scalars", "barrier"]
     print("phase1 %.2f ms, %d columns; last forward launch: %d steps (s_memtime ticks; 100 MHz constant clock if the counter is REFCLK)" % (ms["k_sweep_phase1"], C, n))
     tot = 0
