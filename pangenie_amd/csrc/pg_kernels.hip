@@ -83,6 +83,12 @@ DEVI void wave_sync() {
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
     __builtin_amdgcn_wave_barrier();
 }
+// wave-level sync for data exchanged through LDS only: waits for the LDS queue, not for outstanding global loads and
+// stores (wave_sync() drains vmcnt too — in k_prep that put every global round trip of a variant in series)
+DEVI void wave_sync_lds() {
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup", "local");
+    __builtin_amdgcn_wave_barrier();
+}
 
 DEVI int wave_max_i32(int v) {
 #pragma unroll
@@ -212,7 +218,7 @@ DEVI void emission_pair_products(const DevContig& dc, const DevTable& tab, uint3
 #pragma unroll
             for (int i = 0; i < 3; ++i) { lds_m[lane * 3 + i] = m[i]; lds_e[lane * 3 + i] = e[i]; }
         }
-        wave_sync();
+        wave_sync_lds();
         const uint32_t n = (K - kb) < 64u ? (K - kb) : 64u;
         if (active) {
             for (uint32_t q = 0; q < n; ++q) {
@@ -234,7 +240,7 @@ DEVI void emission_pair_products(const DevContig& dc, const DevTable& tab, uint3
             pm = mm; pe += ee;
             if (pe < PG_LD_MIN_EXP) { pm = 0.0; pe = 0; }  // underflows to 0 in the reference too
         }
-        wave_sync();
+        wave_sync_lds();
     }
 }
 
@@ -277,6 +283,8 @@ __global__ __launch_bounds__(256) void k_prep(const DevContig* __restrict__ cont
     __shared__ double s_pm[4][NLP];
     __shared__ int s_pe[4][NLP];
     __shared__ uint32_t s_pres[4][8];
+    __shared__ uint16_t s_aid[4][64];   // the variant's allele ids / flags (objects with <= 64 alleles: every real one)
+    __shared__ uint8_t s_afl[4][64];
     const DevContig& dc = contigs[blockIdx.y];
     const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const uint32_t v = blockIdx.x * 4 + wave;
@@ -292,18 +300,30 @@ __global__ __launch_bounds__(256) void k_prep(const DevContig* __restrict__ cont
     //      (reference src/columnindexer.cpp:24-31); also which allele slots are present.
     uint32_t* pres = s_pres[wave];
     if (lane < 8) pres[lane] = 0;
-    wave_sync();
+    const bool staged = A <= 64u;  // allele list in LDS: one coalesced load instead of A dependent loads per path
+    if (staged && lane < A) { s_aid[wave][lane] = dc.allele_id[a0 + lane]; s_afl[wave][lane] = dc.allele_flags[a0 + lane]; }
+    wave_sync_lds();
+    auto slot_lookup = [&](uint16_t a) -> int {
+        if (staged) {
+            int s = -1;
+            for (uint32_t q = 0; q < A; ++q)
+                if (s_aid[wave][q] == a) s = (int)q;
+            return s;
+        }
+        return slot_of(dc, a0, A, a);
+    };
     bool nonref = false, bad = false;
     for (uint32_t p = lane; p < H; p += 64) {
         const uint16_t a = dc.path_allele[(size_t)v * H + p];
-        const int s = slot_of(dc, a0, A, a);
+        const int s = slot_lookup(a);
         if (s < 0) bad = true;
         else {
             atomicOr(&pres[(uint32_t)s >> 5], 1u << ((uint32_t)s & 31u));
-            if (a != 0 && !(dc.allele_flags[a0 + s] & 1)) nonref = true;
+            const uint8_t fl = staged ? s_afl[wave][s] : dc.allele_flags[a0 + s];
+            if (a != 0 && !(fl & 1)) nonref = true;
         }
     }
-    wave_sync();
+    wave_sync_lds();
     const bool kept = __any(nonref) != 0;
     if (__any(bad) != 0) {
         if (lane == 0) { atomicOr(dc.err, PG_DEVERR_ALLELE_NOT_FOUND); dc.kept[v] = 0; }
@@ -332,7 +352,7 @@ __global__ __launch_bounds__(256) void k_prep(const DevContig* __restrict__ cont
         const uint32_t p = p0 + lane;
         unsigned char val = PG_PHANTOM;
         if (p < H) {
-            const int s = slot_of(dc, a0, A, dc.path_allele[(size_t)v * H + p]);
+            const int s = slot_lookup(dc.path_allele[(size_t)v * H + p]);
             val = (unsigned char)local_index(pres, (uint32_t)s);
         }
         if (p < HP) rec[PG_REC_ALLELES + p] = val;
@@ -403,8 +423,79 @@ __global__ __launch_bounds__(256) void k_prep(const DevContig* __restrict__ cont
         return;
     }
     if (lane < (uint32_t)NLP) { s_pm[wave][lane] = 0.0; s_pe[wave][lane] = 0; }
-    wave_sync();
+    wave_sync_lds();
     bool any_nonzero = false;
+    if (P <= 32u) {
+        // Few pairs (<= 7 alleles: every BASELINE shape): G lanes per pair share its k-mers (lane g takes k-mers
+        // g, g + G, ...) and the partial products are folded by xor shuffles — K / G sequential factors instead of K
+        // on 3 of 64 lanes.  Same factors as emission_pair_products (emissionprobabilitycomputer.cpp:36-53); only the
+        // order of the multiplications differs.
+        const uint32_t G = P <= 4u ? 16u : (P <= 8u ? 8u : (P <= 16u ? 4u : 2u));
+        const uint32_t idx = lane / G, g = lane % G;
+        const bool active = idx < P;
+        uint32_t s1 = 0, s2 = 0;
+        if (active) decode_pair(idx, A, s1, s2);
+        const uint32_t k0 = dc.kmer_off[v], K = dc.kmer_off[v + 1] - k0;
+        const uint32_t cov = dc.cov[v];
+        uint32_t off1 = 0, mask1 = 0, off2 = 0, mask2 = 0;
+        bool u1 = false, u2 = false;
+        if (active) {
+            off1 = dc.allele_koff[a0 + s1]; mask1 = dc.allele_kmask[a0 + s1];
+            off2 = dc.allele_koff[a0 + s2]; mask2 = dc.allele_kmask[a0 + s2];
+            u1 = s_afl[wave][s1] & 1; u2 = s_afl[wave][s2] & 1;  // (P <= 32 implies A <= 7: staged)
+        }
+        double pm = 1.0;
+        int pe = 0;
+        double* lds_m = s_m[wave];
+        int* lds_e = s_e[wave];
+        for (uint32_t kb = 0; kb < K; kb += 64) {
+            const uint32_t kk = kb + lane;
+            if (kk < K) {
+                double m[3]; int e[3];
+                cn_lookup(tab, cov, dc.kmer_count[k0 + kk], m, e);
+#pragma unroll
+                for (int i = 0; i < 3; ++i) { lds_m[lane * 3 + i] = m[i]; lds_e[lane * 3 + i] = e[i]; }
+            }
+            wave_sync_lds();
+            const uint32_t n = (K - kb) < 64u ? (K - kb) : 64u;
+            if (active) {
+                for (uint32_t q = g; q < n; q += G) {
+                    const uint32_t k = kb + q;
+                    const uint32_t c = kmer_on(off1, mask1, k) + kmer_on(off2, mask2, k);
+                    double fm; int fe;
+                    if (u1 && u2) {
+                        mix3(lds_m + q * 3, lds_e + q * 3, 1.0 / 3.0, fm, fe);
+                    } else if (u1 || u2) {
+                        const uint32_t c2 = c + 1 > 2 ? 2 : c + 1;  // reference asserts c < 2 here
+                        mix2(lds_m[q * 3 + c], lds_e[q * 3 + c], lds_m[q * 3 + c2], lds_e[q * 3 + c2], 0.5, fm, fe);
+                    } else {
+                        fm = lds_m[q * 3 + c]; fe = lds_e[q * 3 + c];
+                    }
+                    pm *= fm; pe += fe;
+                }
+                double mm; int ee;
+                split(pm, mm, ee);
+                pm = mm; pe += ee;
+            }
+            wave_sync_lds();
+        }
+        for (uint32_t m = 1; m < G; m <<= 1) {  // fold the G partial products of every pair
+            pm *= __shfl_xor(pm, (int)m);
+            pe += __shfl_xor(pe, (int)m);
+        }
+        {
+            double mm; int ee;
+            split(pm, mm, ee);
+            pm = mm; pe += ee;
+            if (pe < PG_LD_MIN_EXP) { pm = 0.0; pe = 0; }  // underflows to 0 in the reference too
+        }
+        any_nonzero = __any(active && pm > 0.0) != 0;
+        if (active && g == 0 && slot_present(pres, s1) && slot_present(pres, s2)) {
+            const uint32_t la = local_index(pres, s1), lb = local_index(pres, s2);
+            s_pm[wave][tri_local(la, lb)] = pm;  // s1 <= s2  =>  la <= lb
+            s_pe[wave][tri_local(la, lb)] = pe;
+        }
+    } else
     for (uint32_t base = 0; base < P; base += 64) {
         const uint32_t idx = base + lane;
         const bool active = idx < P;
@@ -419,7 +510,7 @@ __global__ __launch_bounds__(256) void k_prep(const DevContig* __restrict__ cont
             s_pe[wave][tri_local(la, lb)] = pe;
         }
     }
-    wave_sync();
+    wave_sync_lds();
     const bool all_zeros = !any_nonzero;
     // this lane's local pair (la <= lb < n_local), if any
     uint32_t la = 0, lb = 0;
@@ -436,7 +527,7 @@ __global__ __launch_bounds__(256) void k_prep(const DevContig* __restrict__ cont
     if (X == -(1 << 30) || all_zeros) X = 0;
 
     if (lane < PG_ETAB) s_E[wave][lane] = 0.0;
-    wave_sync();
+    wave_sync_lds();
     if (mine) {
         double val;
         if (all_zeros) val = 1.0;                           // emissionprobabilitycomputer.cpp:31-34
@@ -450,7 +541,7 @@ __global__ __launch_bounds__(256) void k_prep(const DevContig* __restrict__ cont
         ((double*)vp)[pi] = all_zeros ? 0.5 : pm;
         ((int*)(vp + (size_t)NP * 8u))[pi] = all_zeros ? 1 : pe;
     }
-    wave_sync();
+    wave_sync_lds();
     if (lane < PG_ETAB) ((double*)(rec + PG_REC_E))[lane] = s_E[wave][lane];
     if (lane < 4) ((double*)rec)[lane] = 0.0;  // transition constants are filled by k_records
     if (lane == 0) {
