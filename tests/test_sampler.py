@@ -299,3 +299,62 @@ def test_sampler_then_genotyping_matches_oracle():
     res = hmm.genotype_contig(sub, hmm.ProbabilityTable(*args), hmm.make_params(1.26, False, 25000.0))
     want = orc.genotype_contig(sub, orc.OracleTable(*args), orc.make_params(1.26, False, 25000.0))
     assert_parity(sub, res, want)
+
+
+# --------------------------------------------------------------------------- #
+#  the reference's own 215-path fixture (tests/data/region_UniqueKmersList.cereal, kept as data under tests/golden)
+# --------------------------------------------------------------------------- #
+def _fixture_panel():
+    from pangenie_amd import cereal_io
+    return cereal_io.load(Path(__file__).parent / "golden" / "region_UniqueKmersList.cereal").unique_kmers["chr1"]
+
+
+def test_oracle_sampler_on_the_reference_fixture():
+    """215 paths, 44 / 45 alleles per record, most of them undefined (cost 50): the sampler's real input shape
+    (the reference enables sampling above 100 paths, src/commands.cpp:283-287)."""
+    uks = _fixture_panel()
+    b = pn.flatten(uks)
+    assert b.n_paths == 215 and b.n_variants == 2
+    cost = orc.sampler_emission_costs(b)
+    assert set(np.unique(cost).tolist()) <= {0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 25, 50} and (cost == 50).sum() >= 80
+    sampled, best = orc.sampler_run(b, 15)
+    for v in range(2):
+        assert len(set(sampled[:, v].tolist())) == 15
+    assert (np.diff(best.astype(np.int64)) >= 0).all()  # every pass is at best as good as the one before
+    # the object mirror and the flat restatement of update_paths agree on the reduced panel
+    flat = b.update_paths(np.vstack([sampled, np.zeros((1, 2), np.uint32)]))
+    for v, uk in enumerate(uks):
+        uk.update_paths(sampled[:, v].tolist() + [0])
+    want = pn.flatten(uks)
+    for f in ("kmer_off", "kmer_count", "allele_off", "allele_id", "allele_flags", "allele_kmer_off", "allele_kmer_mask", "path_allele"):
+        assert np.array_equal(getattr(flat, f), getattr(want, f)), f
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kernel", ["fast", "general"])
+def test_hip_sampler_and_hmm_on_the_reference_fixture(kernel, monkeypatch):
+    """Index archive -> sampler (15 paths + reference) -> HMM -> VCF sample column, HIP against oracle, on
+    reference-held data."""
+    from pangenie_amd import hmm
+    from pangenie_amd.genotyping_result import results_from_flat, vcf_sample_field
+    from tests.parity_util import assert_parity
+    if kernel == "general":
+        monkeypatch.setenv("PG_SAMPLER_KERNEL", "general")
+    uks = _fixture_panel()
+    b = pn.flatten(uks)
+    want_paths, want_best = orc.sampler_run(b, 15)
+    h = smp.HaplotypeSampler(b, 15, add_reference=True)
+    assert h.kernel == (0 if kernel == "general" else 1)
+    assert h.best_scores == want_best.tolist()
+    assert np.array_equal(h.sampled[:15], want_paths) and (h.sampled[15] == 0).all()
+    sub = h.panel
+    assert sub.n_paths == 16
+    table, params = (18 // 4, 18 * 4, 2 * 18, 0.01), (1.26, False, 1e-5)  # tests/CommandsTest.cpp:20-35
+    res = hmm.genotype_contig(sub, hmm.ProbabilityTable(*table), hmm.make_params(*params))
+    ref = orc.genotype_contig(sub, orc.OracleTable(*table), orc.make_params(*params))
+    assert_parity(sub, res, ref)
+    got = res.genotyping_results()
+    want = results_from_flat(sub, ref.lik, ref.kept, ref.allele_present, ref.n_kmers, ref.coverage)
+    for g, w, d, na in zip(got, want, ([0, 1], [0, 1, 2]), (44, 45)):
+        g.normalize(); w.normalize()
+        assert vcf_sample_field(g, d, na) == vcf_sample_field(w, d, na)
