@@ -877,13 +877,24 @@ DEVI RecInfo decode_record(const unsigned char* rec, uint32_t j, uint32_t i0, bo
 static constexpr int kRingSlots = PG_RING_SLOTS, kRingDist = PG_RING_SLOTS - 1;
 static_assert(kRingSlots == 2 || kRingSlots == 4, "ring slots: power of two");
 // loader wave `part` of NPARTS moves its share of the column (1 KB per wave-instruction)
+// tri (HP = 64 only: one wave transfer = one row pair): the partner column was stored as its upper triangle
+// (DevContig::tri) — lanes below the diagonal of the row pair stay off, their ring bytes keep the zeros the ring
+// was initialised with.  Every transfer still issues (at least lanes 62, 63 are on), so the counted waits hold.
 template <int HP, int NPARTS>
-DEVI void dma_column(const gdouble* cols, int64_t c, int64_t C, LAS unsigned char* ring, uint32_t lane, uint32_t part) {
+DEVI void dma_column(const gdouble* cols, int64_t c, int64_t C, LAS unsigned char* ring, uint32_t lane, uint32_t part, bool tri = false) {
     if (c < 0 || c >= C) return;
     constexpr uint32_t COLB = HP * HP * 8u, SHARE = COLB / (NPARTS > 0 ? NPARTS : 1);
     static_assert(SHARE % 1024u == 0, "column share must be a whole number of wave transfers");
     const GAS char* g = (const GAS char*)(cols + (size_t)c * HP * HP) + part * SHARE + lane * 16u;
     LAS unsigned char* l = ring + (uint32_t)(c & (kRingSlots - 1)) * COLB + part * SHARE;  // wave-uniform base; lane l lands at +16*l
+    if (HP == 64 && tri) {
+#pragma unroll 4
+        for (uint32_t q = 0; q < SHARE / 1024u; ++q) {
+            const uint32_t r0 = 2u * (part * (SHARE / 1024u) + q);  // first row of this row pair
+            if (lane >= (r0 & ~7u)) __builtin_amdgcn_global_load_lds((const GAS void*)(g + q * 1024u), (LAS void*)(l + q * 1024u), 16, 0, 0);  // whole 128-byte lines
+        }
+        return;
+    }
 #pragma unroll 4
     for (uint32_t q = 0; q < SHARE / 1024u; ++q)
         __builtin_amdgcn_global_load_lds((const GAS void*)(g + q * 1024u), (LAS void*)(l + q * 1024u), 16, 0, 0);
@@ -1066,6 +1077,7 @@ DEVI void forward_body(const DevContig& dc, ChainShared<HP, R>& sh, uint32_t C, 
     gcu64* colrec = (gcu64*)dc.colrec;
     gdouble* part_out = (gdouble*)dc.part;
     const uint32_t part_slots = dc.part_slots;
+    const bool tri = PHASE == 2 && HP == 64 && __builtin_amdgcn_readfirstlane((int)dc.tri) != 0;  // stored columns are upper triangles
 
     auto rec_load = [&](uint32_t c) -> unsigned long long {
         if (p.lane < (uint32_t)Cfg::WORDS && c < C) return colrec[(size_t)c * Cfg::WORDS + p.lane];
@@ -1096,14 +1108,14 @@ DEVI void forward_body(const DevContig& dc, ChainShared<HP, R>& sh, uint32_t C, 
         if (lw == 0)  // records first-1 (column 0, or the column resumed from) .. first+5
             for (int q = -1; q < 6; ++q) dma_record<Cfg::RB>(colrec, (int64_t)first + q, C, lrec, p.lane);
         if (RING)
-            for (int q = 0; q < kRingDist; ++q) dma_column<HP, Cfg::NLOAD>(cols, (int64_t)lo + q, C, lring, p.lane, lw);
+            for (int q = 0; q < kRingDist; ++q) dma_column<HP, Cfg::NLOAD>(cols, (int64_t)lo + q, C, lring, p.lane, lw, tri);
         wait_vmem_all();
         lds_barrier();  // P0: first records staged
         lds_barrier();  // Bx: column lo initialised / resumed
         const bool nodma = (kExp & 128u) != 0;
         for (uint32_t t = first; t < hi; ++t) {
             if (lw == 0) dma_record<Cfg::RB>(colrec, (int64_t)t + 6, C, lrec, p.lane);
-            if (RING && !nodma) dma_column<HP, Cfg::NLOAD>(cols, (int64_t)t + kRingDist, C, lring, p.lane, lw);
+            if (RING && !nodma) dma_column<HP, Cfg::NLOAD>(cols, (int64_t)t + kRingDist, C, lring, p.lane, lw, tri);
             if ((int64_t)t + 6 >= (int64_t)C) wait_vmem_all();  // tail
             else if (lw == 0) wait_vmem_keep<KEEP0>();
             else wait_vmem_keep<KEEP1>();
@@ -1152,6 +1164,16 @@ DEVI void forward_body(const DevContig& dc, ChainShared<HP, R>& sh, uint32_t C, 
 #pragma unroll
         for (int k = 0; k < R; k += 2) { const v2f64 t = src[(size_t)(k >> 1) * HP]; v[k] = t.x; v[k + 1] = t.y; }
     };
+    // a column stored as its upper triangle (DevContig::tri: diagonal halved, nothing below it): element (i, j)
+    // of the full column = the stored (min, max), the diagonal doubled.  Once per launch (the resume column).
+    auto load_col_tri = [&](gcdouble* col, double (&v)[R]) {
+#pragma unroll
+        for (int k = 0; k < R; ++k) {
+            const uint32_t i = p.i0 + (uint32_t)k, a = i <= p.j ? i : p.j, b = i <= p.j ? p.j : i;
+            const double val = col[((size_t)(a >> 1) * HP + b) * 2 + (a & 1u)];
+            v[k] = a == b ? 2.0 * val : val;
+        }
+    };
 
     double x[R], ui[R > 16 ? 1 : R];
     double vA[(PHASE == 2 && !RING) ? R : 1];  // register-prefetched beta' column (phase 2 without the LDS ring)
@@ -1196,7 +1218,8 @@ DEVI void forward_body(const DevContig& dc, ChainShared<HP, R>& sh, uint32_t C, 
     } else {
         // resume behind the column the other phase (or the previous chunk) stored last: P'_{lo-1}, the
         // column before its emission multiply — or the uniform column itself if it was flagged
-        load_col(lo - 1, x);
+        if (tri) load_col_tri(resume, x);
+        else load_col(lo - 1, x);
         const bool was_uniform = fallback[lo - 1] != 0;
         double part = 0.0;
         if (!was_uniform) {
@@ -1393,6 +1416,7 @@ DEVI void backward_body(const DevContig& dc, ChainShared<HP, R>& sh, uint32_t C,
     // recursion steps run over t = t0 .. bot where t0 = top-1 in phase 1 (column top is the
     // all-ones column) and t0 = top in phase 2 (resumed behind column mid)
     const int64_t t0 = PHASE == 1 ? top - 1 : top;
+    const bool tri = PHASE == 2 && HP == 64 && __builtin_amdgcn_readfirstlane((int)dc.tri) != 0;  // stored columns are upper triangles
 
     auto rec_load = [&](int64_t c) -> unsigned long long {
         if (p.lane < (uint32_t)Cfg::WORDS && c >= 0 && c < (int64_t)C) return colrec[(size_t)c * Cfg::WORDS + p.lane];
@@ -1420,13 +1444,13 @@ DEVI void backward_body(const DevContig& dc, ChainShared<HP, R>& sh, uint32_t C,
         if (lw == 0)
             for (int q = -1; q < 5; ++q) dma_record<Cfg::RB>(colrec, t0 - q, (int64_t)C, lrec, p.lane);  // t0+1 .. t0-4
         if (RING)
-            for (int q = 0; q < kRingDist; ++q) dma_column<HP, Cfg::NLOAD>(cols, t0 - q, (int64_t)C, lring, p.lane, lw);
+            for (int q = 0; q < kRingDist; ++q) dma_column<HP, Cfg::NLOAD>(cols, t0 - q, (int64_t)C, lring, p.lane, lw, tri);
         wait_vmem_all();
         lds_barrier();  // P0
         const bool nodma = (kExp & 128u) != 0;
         for (int64_t t = t0; t >= bot; --t) {
             if (lw == 0) dma_record<Cfg::RB>(colrec, t - 5, (int64_t)C, lrec, p.lane);
-            if (RING && !nodma) dma_column<HP, Cfg::NLOAD>(cols, t - kRingDist, (int64_t)C, lring, p.lane, lw);
+            if (RING && !nodma) dma_column<HP, Cfg::NLOAD>(cols, t - kRingDist, (int64_t)C, lring, p.lane, lw, tri);
             if (t - 5 < 0) wait_vmem_all();  // tail
             else if (lw == 0) wait_vmem_keep<KEEP0>();
             else wait_vmem_keep<KEEP1>();
@@ -1460,6 +1484,14 @@ DEVI void backward_body(const DevContig& dc, ChainShared<HP, R>& sh, uint32_t C,
 #pragma unroll
         for (int k = 0; k < R; k += 2) { const v2f64 t = src[(size_t)(k >> 1) * HP]; v[k] = t.x; v[k + 1] = t.y; }
     };
+    auto load_col_tri = [&](gcdouble* col, double (&v)[R]) {  // see forward_body
+#pragma unroll
+        for (int k = 0; k < R; ++k) {
+            const uint32_t i = p.i0 + (uint32_t)k, a = i <= p.j ? i : p.j, b = i <= p.j ? p.j : i;
+            const double val = col[((size_t)(a >> 1) * HP + b) * 2 + (a & 1u)];
+            v[k] = a == b ? 2.0 * val : val;
+        }
+    };
     auto store_col = [&](int64_t c, const double (&y)[R]) {
         gdouble2* dst = (gdouble2*)(wr + (size_t)c * colsz) + (size_t)(p.i0 >> 1) * HP + p.j;
 #pragma unroll
@@ -1491,7 +1523,8 @@ DEVI void backward_body(const DevContig& dc, ChainShared<HP, R>& sh, uint32_t C,
         if (p.tid == 0) { bscale[top] = 1.0; bsum[top] = Sy; }
     } else {
         // resume behind the column stored last (by phase 1, or by the previous chunk)
-        load_col(top + 1, y);
+        if (tri) load_col_tri(resume, y);
+        else load_col(top + 1, y);
         Sy = bsum[top + 1];
         if constexpr (PHASE == 2 && !RING) {
             load_col(top, vA);
@@ -1736,6 +1769,15 @@ __global__ __launch_bounds__((ChainCfg<HP, R>::TT)) void k_sweep(const DevContig
     // with it every column index, ring slot and address derived from it, wave-uniform again)
     const uint32_t C = (uint32_t)__builtin_amdgcn_readfirstlane((int)*dc.n_cols);
     if (C == 0) return;
+    if constexpr (PHASE == 2 && HP == 64 && ChainCfg<HP, R>::LOADER) {
+        if (__builtin_amdgcn_readfirstlane((int)dc.tri) != 0) {
+            // partner columns arrive as upper triangles (DevContig::tri): the ring bytes the masked LDS-DMA lanes
+            // never write must read as zero for the whole launch
+            v2f64* r16 = (v2f64*)dyn_ring;
+            for (uint32_t q = threadIdx.x; q < (uint32_t)kRingSlots * HP * HP / 2u; q += ChainCfg<HP, R>::TT) r16[q] = v2f64{0.0, 0.0};
+            lds_barrier();
+        }
+    }
     if (blockIdx.y == 0) forward_body<HP, R, PHASE>(dc, sh, C, dyn_ring, chunk);
     else backward_body<HP, R, VBUF, KEEPW, PHASE>(dc, sh, C, dyn_ring, chunk);
 }
@@ -1863,7 +1905,7 @@ DEVI double lean_colsum(const LeanShared<R>& sh, uint32_t pb, uint32_t lane) {
                ((sh.psum[pb][4][lane] + sh.psum[pb][5][lane]) + (sh.psum[pb][6][lane] + sh.psum[pb][7][lane]));
 }
 
-template <int PHASE, int R>
+template <int PHASE, int R, bool TRI>
 DEVI void lean_forward(const DevContig& dc, LeanShared<R>& sh, uint32_t C, uint32_t chunk) {
     constexpr int HP = 64;
     constexpr uint32_t RMASK = (1u << R) - 1u;
@@ -1902,10 +1944,31 @@ DEVI void lean_forward(const DevContig& dc, LeanShared<R>& sh, uint32_t C, uint3
         eA = aj ? r.E01 : r.E00;
         eB = aj ? r.E11 : r.E01;
     };
+    // TRI (lean chains of fused jobs, DevContig::tri): only the upper triangle is stored, the diagonal halved, the
+    // element below the diagonal inside a straddling 16-byte unit as 0.  The per-pair factors / skip bits are
+    // fixed per thread (row pair i0 + 2q, column = lane).
+    double tfa[TRI ? R / 2 : 1], tfb[TRI ? R / 2 : 1];
+    uint32_t tskip = 0;
+    if constexpr (TRI) {
+#pragma unroll
+        for (int q = 0; q < R / 2; ++q) {
+            const uint32_t r0 = i0 + 2u * (uint32_t)q;
+            tfa[q] = lane < r0 ? 0.0 : (lane == r0 ? 0.5 : 1.0);
+            tfb[q] = lane <= r0 ? 0.0 : (lane == r0 + 1u ? 0.5 : 1.0);
+            tskip |= (lane < (r0 & ~7u) ? 1u : 0u) << q;  // whole 128-byte lines only: the lanes between are written as zeros
+        }
+    }
+    auto put_pair = [&](gdouble2* dst, int q, double a, double b) __attribute__((always_inline)) {
+        if constexpr (TRI) {
+            if (!((tskip >> q) & 1u)) dst[(size_t)q * HP] = v2f64{a * tfa[q], b * tfb[q]};
+        } else {
+            dst[(size_t)q * HP] = v2f64{a, b};
+        }
+    };
     auto store_col = [&](uint32_t c, const double (&v)[R]) {
         gdouble2* dst = (gdouble2*)(wr + (size_t)c * colsz) + toff;
 #pragma unroll
-        for (int k = 0; k < R; k += 2) dst[(size_t)(k >> 1) * HP] = v2f64{v[k], v[k + 1]};
+        for (int k = 0; k < R; k += 2) put_pair(dst, k >> 1, v[k], v[k + 1]);
     };
     auto flag_uniform = [&](uint32_t cprev) {
         if (cprev >= lo) {
@@ -2002,7 +2065,7 @@ DEVI void lean_forward(const DevContig& dc, LeanShared<R>& sh, uint32_t C, uint3
             const double pk = (kLX & 16u) ? x[k] + ujs : fma(c0s, x[k], fma(ui[k], sc, ujs));
             x[k] = (kLX & 16u) ? pk : pk * sel_by_bit(rb, k, eA, eB);
             part += (kLX & 16u) ? (k == 0 ? x[0] + ui[k] : 0.0) : x[k];
-            if (k & 1) { if (!(kLX & 1u)) dst[(size_t)(k >> 1) * HP] = v2f64{pprev, pk}; __builtin_amdgcn_sched_barrier(0); }
+            if (k & 1) { if (!(kLX & 1u)) put_pair(dst, k >> 1, pprev, pk); __builtin_amdgcn_sched_barrier(0); }
             else pprev = pk;
         }
         LEAN_DEP(part); LEAN_STAMP(4);   // 4: the 16 states + their stores
@@ -2032,7 +2095,7 @@ DEVI void lean_forward(const DevContig& dc, LeanShared<R>& sh, uint32_t C, uint3
     }
 }
 
-template <int PHASE, int R>
+template <int PHASE, int R, bool TRI>
 DEVI void lean_backward(const DevContig& dc, LeanShared<R>& sh, uint32_t C, uint32_t chunk) {
     constexpr int HP = 64;
     constexpr uint32_t RMASK = (1u << R) - 1u;
@@ -2071,10 +2134,28 @@ DEVI void lean_backward(const DevContig& dc, LeanShared<R>& sh, uint32_t C, uint
         eA = aj ? r.E01 : r.E00;
         eB = aj ? r.E11 : r.E01;
     };
+    double tfa[TRI ? R / 2 : 1], tfb[TRI ? R / 2 : 1];  // see lean_forward
+    uint32_t tskip = 0;
+    if constexpr (TRI) {
+#pragma unroll
+        for (int q = 0; q < R / 2; ++q) {
+            const uint32_t r0 = i0 + 2u * (uint32_t)q;
+            tfa[q] = lane < r0 ? 0.0 : (lane == r0 ? 0.5 : 1.0);
+            tfb[q] = lane <= r0 ? 0.0 : (lane == r0 + 1u ? 0.5 : 1.0);
+            tskip |= (lane < (r0 & ~7u) ? 1u : 0u) << q;  // whole 128-byte lines only: the lanes between are written as zeros
+        }
+    }
+    auto put_pair = [&](gdouble2* dst, int q, double a, double b) __attribute__((always_inline)) {
+        if constexpr (TRI) {
+            if (!((tskip >> q) & 1u)) dst[(size_t)q * HP] = v2f64{a * tfa[q], b * tfb[q]};
+        } else {
+            dst[(size_t)q * HP] = v2f64{a, b};
+        }
+    };
     auto store_col = [&](int64_t c, const double (&v)[R]) {
         gdouble2* dst = (gdouble2*)(wr + (size_t)c * colsz) + toff;
 #pragma unroll
-        for (int k = 0; k < R; k += 2) dst[(size_t)(k >> 1) * HP] = v2f64{v[k], v[k + 1]};
+        for (int k = 0; k < R; k += 2) put_pair(dst, k >> 1, v[k], v[k + 1]);
     };
 
     ColScalars bsc, bsm;
@@ -2159,7 +2240,7 @@ DEVI void lean_backward(const DevContig& dc, LeanShared<R>& sh, uint32_t C, uint
                 const double yk = (kLX & 16u) ? w[k] + uj : fma(k0, w[k], ui[k] + uj);  // beta'_t
                 w[k] = (kLX & 16u) ? yk : yk * sel_by_bit(rb, k, eA, eB);
                 part += (kLX & 16u) ? (k == 0 ? w[0] + ui[k] : 0.0) : w[k];
-                if (k & 1) { if (!(kLX & 1u)) dst[(size_t)(k >> 1) * HP] = v2f64{yprev, yk}; __builtin_amdgcn_sched_barrier(0); }
+                if (k & 1) { if (!(kLX & 1u)) put_pair(dst, k >> 1, yprev, yk); __builtin_amdgcn_sched_barrier(0); }
                 else yprev = yk;
             }
         }
@@ -2678,11 +2759,12 @@ DEVI void lean_backward_pipe(const DevContig& dc, LeanShared<R>& sh, uint32_t C,
     if (wave == 0 && bsc.valid) { bsc.flush(bscale, lane, (uint64_t)bot); bsm.flush(bsum, lane, (uint64_t)bot); }
 }
 
-template <int PHASE, int R, bool PIPE>
+template <int PHASE, int R, bool PIPE, bool TRI = false>
 __global__ __launch_bounds__((64 * 64 / R)) void k_sweep_lean(const DevContig* __restrict__ contigs, uint32_t chunk) {
     __shared__ LeanShared<R> sh;
     const DevContig& dc = contigs[blockIdx.x];
     if (!dc.lean) return;
+    if ((dc.tri != 0u) != TRI) return;
     const uint32_t C = (uint32_t)__builtin_amdgcn_readfirstlane((int)*dc.n_cols);
     if (C == 0) return;
     const unsigned long long t_begin = kChainProf ? __builtin_amdgcn_s_memtime() : 0ull;
@@ -2690,8 +2772,8 @@ __global__ __launch_bounds__((64 * 64 / R)) void k_sweep_lean(const DevContig* _
         if (blockIdx.y == 0) lean_forward_pipe<PHASE, R>(dc, sh, C, chunk);
         else lean_backward_pipe<PHASE, R>(dc, sh, C, chunk);
     } else {
-        if (blockIdx.y == 0) lean_forward<PHASE, R>(dc, sh, C, chunk);
-        else lean_backward<PHASE, R>(dc, sh, C, chunk);
+        if (blockIdx.y == 0) lean_forward<PHASE, R, TRI>(dc, sh, C, chunk);
+        else lean_backward<PHASE, R, TRI>(dc, sh, C, chunk);
     }
     if (kChainProf && threadIdx.x == 0) {  // -DPG_CHAIN_PROF builds only: cycles of this role's launch (last chunk wins)
         unsigned long long* o = dc.prof + (blockIdx.y == 0 ? 0 : 16) + (PHASE == 1 ? 0 : 8);
@@ -3052,7 +3134,15 @@ __global__ __launch_bounds__(256) void k_bins(const DevContig* __restrict__ cont
                 double s = 0.0;
                 for (uint32_t st = lane; st < H * H; st += 64) {
                     const uint32_t i = st / H, jj = st % H;
-                    if (al[i] == a && al[jj] == b) s += col[((size_t)(i >> 1) * HP + jj) * 2 + (i & 1u)];
+                    if (al[i] == a && al[jj] == b) {
+                        if (dc.tri) {  // the column was stored as its upper triangle, the diagonal halved
+                            const uint32_t lo3 = i < jj ? i : jj, hi3 = i < jj ? jj : i;
+                            const double val = col[((size_t)(lo3 >> 1) * HP + hi3) * 2 + (lo3 & 1u)];
+                            s += lo3 == hi3 ? 2.0 * val : val;
+                        } else {
+                            s += col[((size_t)(i >> 1) * HP + jj) * 2 + (i & 1u)];
+                        }
+                    }
                 }
                 const double tot = wave_sum(s) * unif;
                 if (lane == 0) {
@@ -3102,6 +3192,8 @@ __global__ __launch_bounds__(256) void k_bins(const DevContig* __restrict__ cont
     const double scale = 1.0 / ((fb ? 1.0 : dc.fscale[c]) * dc.bscale[c]);
     int xexp = -((fb ? 0 : PG_BIAS_F) + PG_BIAS_B);
     if (c + 1 < C) xexp += *(const int32_t*)(dc.colrec + (size_t)(c + 1) * dc.RB + PG_REC_EXP);
+    // triangle storage: the partials are sums over the upper triangle with the diagonal halved = half of the bin
+    if (dc.tri && !(fb && c >= C / 2)) xexp += 1;
     const uint32_t pn = dc.pair_n, NP = (pn * (pn + 1) / 2 + 1u) & ~1u;
     const unsigned char* vp = dc.vpair + (size_t)v * (NP * 12u);
     if (lane < nl * nl) {
@@ -3353,6 +3445,8 @@ static void launch_sweep(const DevContig* d_contigs, uint32_t n_contigs, uint32_
             static const int lean_pipe = [] { const char* e = getenv("PG_LEAN_PIPE"); return e ? atoi(e) : 0; }();
             if (lean_r == 8) hipLaunchKernelGGL((k_sweep_lean<PHASE, 8, false>), dim3(n_contigs, 2), dim3(512), 0, s, d_contigs, chunk);
             else if (lean_pipe) hipLaunchKernelGGL((k_sweep_lean<PHASE, 16, true>), dim3(n_contigs, 2), dim3(256), 0, s, d_contigs, chunk);
+            else if (PHASE == 1 && (hp_mask & 128u))  // bit 7: fused job whose lean chains store triangles (DevContig::tri)
+                hipLaunchKernelGGL((k_sweep_lean<PHASE, 16, false, true>), dim3(n_contigs, 2), dim3(256), 0, s, d_contigs, chunk);
             else hipLaunchKernelGGL((k_sweep_lean<PHASE, 16, false>), dim3(n_contigs, 2), dim3(256), 0, s, d_contigs, chunk);
         }
         // bit 4: contigs with HP >= 256; bit 5: (forced) the generic kernel for every HP >= 64

@@ -648,6 +648,12 @@ int job_build(int device, uint32_t n_index, const pg_contig_batch* batches, cons
         d.wide = A + p.wide; d.wide_idx = x.wide_bytes ? (const uint32_t*)(A + x.o_widx) : nullptr;
         d.vpair = A + p.vpair; d.xbuf = (double*)(A + p.xbuf);
         d.frec = (double*)(A + p.frec); d.lean = x.lean ? 1u : 0u;
+        // fused jobs: lean chains store / read their columns as upper triangles (half the sweep's HBM bytes);
+        // PG_TRI=0 keeps full columns (cross-check)
+        const char* tri_env = getenv("PG_TRI");
+        const bool tri_ok = !(tri_env && !strcmp(tri_env, "0"));
+        d.tri = (x.lean && !job->chunked && tri_ok) ? 1u : 0u;
+        if (d.tri) job->hp_mask |= 128u;
         ch.d = d;
     }
     if ((he = hipMemcpyAsync(job->d_contigs, hd.data(), sizeof(DevContig) * n_chains, hipMemcpyHostToDevice, job->stream)) != hipSuccess ||

@@ -341,6 +341,37 @@ def test_lean_kernel_biallelic_h64_vs_oracle_and_general(K, orc, monkeypatch):
         assert float(np.where(den > 0, np.abs(a - c) / np.where(den > 0, den, 1), 0).max()) < 1e-11
 
 
+@pytest.mark.parametrize("C_odd", [False, True])
+def test_triangle_storage_fused_lean_vs_oracle_and_full_columns(C_odd, orc, monkeypatch):
+    """Fused jobs store the (symmetric) columns of lean chains as upper triangles — diagonal halved, nothing
+    below it — and phase 2 sums the stored half (k_bins doubles).  Unregularised table: forward fall-backs in
+    both halves (the stored uniform column, the re-formed bins of k_bins) and all-zero backward columns go
+    through the triangle path; PG_TRI=0 (full columns) must give the same bins to fp64 rounding."""
+    monkeypatch.setenv("PG_SWEEP_MODE", "fused")
+    for seed, reg in ((15, 0.0), (16, 0.01), (17, 0.0)):
+        args = (6, 108, 54, reg)
+        b = synthetic_panel(331 if C_odd else 330, 64, 20, seed=seed)
+        if reg == 0.0:
+            b.kmer_count[::3] = 0
+            b.kmer_count[1::17] = 60000
+        t, p = hmm.ProbabilityTable(*args), hmm.make_params(1.26, False, 1e-5)
+        monkeypatch.delenv("PG_TRI", raising=False)
+        job = hmm.Job([b], t, p)
+        job.run()
+        assert job.sweep_mode()[0] == "fused"
+        tri = job.fetch(0)
+        job.close()
+        monkeypatch.setenv("PG_TRI", "0")
+        full = hmm.genotype_contig(b, t, p)
+        monkeypatch.delenv("PG_TRI", raising=False)
+        ref = orc.genotype_contig(b, orc.OracleTable(*args), orc.make_params(1.26, False, 1e-5))
+        assert_parity(b, tri, ref)
+        assert_parity(b, full, ref)
+        a, c = tri.likelihoods_ld(), full.likelihoods_ld()
+        den = np.maximum(np.abs(a), np.abs(c))
+        assert float(np.where(den > 0, np.abs(a - c) / np.where(den > 0, den, 1), 0).max()) < 1e-11
+
+
 def test_limits_are_reported_not_silently_wrong():
     b = synthetic_panel(4, 1100, 10, seed=1)
     with pytest.raises(hmm.PanGenieError) as e:
