@@ -877,24 +877,13 @@ DEVI RecInfo decode_record(const unsigned char* rec, uint32_t j, uint32_t i0, bo
 static constexpr int kRingSlots = PG_RING_SLOTS, kRingDist = PG_RING_SLOTS - 1;
 static_assert(kRingSlots == 2 || kRingSlots == 4, "ring slots: power of two");
 // loader wave `part` of NPARTS moves its share of the column (1 KB per wave-instruction)
-// tri (HP = 64 only: one wave transfer = one row pair): the partner column was stored as its upper triangle
-// (DevContig::tri) — lanes below the diagonal of the row pair stay off, their ring bytes keep the zeros the ring
-// was initialised with.  Every transfer still issues (at least lanes 62, 63 are on), so the counted waits hold.
 template <int HP, int NPARTS>
-DEVI void dma_column(const gdouble* cols, int64_t c, int64_t C, LAS unsigned char* ring, uint32_t lane, uint32_t part, bool tri = false) {
+DEVI void dma_column(const gdouble* cols, int64_t c, int64_t C, LAS unsigned char* ring, uint32_t lane, uint32_t part) {
     if (c < 0 || c >= C) return;
     constexpr uint32_t COLB = HP * HP * 8u, SHARE = COLB / (NPARTS > 0 ? NPARTS : 1);
     static_assert(SHARE % 1024u == 0, "column share must be a whole number of wave transfers");
     const GAS char* g = (const GAS char*)(cols + (size_t)c * HP * HP) + part * SHARE + lane * 16u;
     LAS unsigned char* l = ring + (uint32_t)(c & (kRingSlots - 1)) * COLB + part * SHARE;  // wave-uniform base; lane l lands at +16*l
-    if (HP == 64 && tri) {
-#pragma unroll 4
-        for (uint32_t q = 0; q < SHARE / 1024u; ++q) {
-            const uint32_t r0 = 2u * (part * (SHARE / 1024u) + q);  // first row of this row pair
-            if (lane >= (r0 & ~7u)) __builtin_amdgcn_global_load_lds((const GAS void*)(g + q * 1024u), (LAS void*)(l + q * 1024u), 16, 0, 0);  // whole 128-byte lines
-        }
-        return;
-    }
 #pragma unroll 4
     for (uint32_t q = 0; q < SHARE / 1024u; ++q)
         __builtin_amdgcn_global_load_lds((const GAS void*)(g + q * 1024u), (LAS void*)(l + q * 1024u), 16, 0, 0);
@@ -926,6 +915,61 @@ DEVI void ring_read(const unsigned char* ring, int64_t c, const uint32_t i0, con
     const v2f64* slot = (const v2f64*)(ring + (size_t)(c & (kRingSlots - 1)) * (HP * HP * 8u)) + (size_t)(i0 >> 1) * HP + j;
 #pragma unroll
     for (int k = 0; k < R; k += 2) { const v2f64 t = slot[(size_t)(k >> 1) * HP]; v[k] = t.x; v[k + 1] = t.y; }
+}
+
+// ---- triangle ring (DevContig::tri, HP = 64): the stored half of a column is 1152 16-byte units (row pair q holds
+// lanes 8 (q >> 2) .. 63: whole 128-byte lines, see k_sweep_lean's put_pair), enumerated row pair by row pair.  The
+// ring keeps them COMPACT — 18 KB per column instead of 32 — so 8 slots fit where 4 did and every LDS-DMA transfer
+// is a full 1 KB (lane l of transfer n fetches unit 64 n + l from wherever it lies in the stored column): 9
+// transfers per loader and column instead of 16, seven columns in flight instead of three.  Phase 2 of many
+// resident chains is bound by the bytes a CU has in flight, not by HBM bandwidth.
+static constexpr int kTriSlots = 8, kTriDist = 7;
+static constexpr uint32_t kTriUnits = 1152u, kTriSlotB = kTriUnits * 16u;  // 18432
+static constexpr uint32_t kTriRingB = (uint32_t)kTriSlots * kTriSlotB + 16u;  // + one unit of zeros (what lies below the diagonal)
+DEVI uint32_t tri_unit_of(uint32_t q /*row pair*/, uint32_t lane /* >= 8 (q >> 2) */) {
+    const uint32_t g = q >> 2;
+    return 256u * g - 16u * g * (g - 1u) + (q & 3u) * (64u - 8u * g) + (lane - 8u * g);
+}
+DEVI uint32_t tri_unit_goff(uint32_t u) {  // byte offset of unit u inside the stored (full-layout) column
+    uint32_t g = 0, base = 0;
+    for (; g < 7u; ++g) {
+        const uint32_t n = 4u * (64u - 8u * g);
+        if (u < base + n) break;
+        base += n;
+    }
+    const uint32_t w = 64u - 8u * g, r = (u - base) / w, l = (u - base) % w + 8u * g;
+    return (4u * g + r) * 1024u + l * 16u;
+}
+// loader `part` (of 2) moves transfers 9 part .. 9 part + 8; goff[n] = this lane's byte offset for its n-th transfer
+DEVI void dma_column_tri(const gdouble* cols, int64_t c, int64_t C, LAS unsigned char* ring, uint32_t part, const uint32_t (&goff)[9]) {
+    if (c < 0 || c >= C) return;
+    const GAS char* g = (const GAS char*)(cols + (size_t)c * 64u * 64u);
+    LAS unsigned char* l = ring + (uint32_t)(c & (kTriSlots - 1)) * kTriSlotB + part * 9u * 1024u;
+#pragma unroll
+    for (uint32_t n = 0; n < 9u; ++n)
+        __builtin_amdgcn_global_load_lds((const GAS void*)(g + goff[n]), (LAS void*)(l + n * 1024u), 16, 0, 0);
+}
+// this thread's eight units of a column: LDS byte offsets inside a slot; units below the diagonal read the zero unit
+template <int R>
+DEVI void tri_read_setup(uint32_t i0, uint32_t j, uint32_t (&loff)[R / 2], uint32_t& valid) {
+    valid = 0;
+#pragma unroll
+    for (int q = 0; q < R / 2; ++q) {
+        const uint32_t rp = (i0 >> 1) + (uint32_t)q;
+        const bool ok = j >= 8u * (rp >> 2);
+        loff[q] = ok ? tri_unit_of(rp, j) * 16u : 0u;
+        valid |= (ok ? 1u : 0u) << q;
+    }
+}
+template <int R>
+DEVI void ring_read_tri(const unsigned char* ring, int64_t c, const uint32_t (&loff)[R / 2], uint32_t valid, double (&v)[R]) {
+    const uint32_t slot = (uint32_t)(c & (kTriSlots - 1)) * kTriSlotB;
+#pragma unroll
+    for (int q = 0; q < R / 2; ++q) {
+        const uint32_t off = ((valid >> q) & 1u) ? slot + loff[q] : (uint32_t)kTriSlots * kTriSlotB;
+        const v2f64 t = *(const v2f64*)(ring + off);
+        v[2 * q] = t.x; v[2 * q + 1] = t.y;
+    }
 }
 
 // per-thread coordinates of a compute thread
@@ -1105,17 +1149,44 @@ DEVI void forward_body(const DevContig& dc, ChainShared<HP, R>& sh, uint32_t C, 
         constexpr int KSL = kRingDist - 1;  // iterations of slack a column transfer gets
         constexpr int KEEP0 = RING ? KSL * (1 + QL) : 4, KEEP1 = KSL * QL;
         static_assert(KEEP0 < 64 && KEEP1 < 64, "vmcnt is 6 bits");
+        if constexpr (RING && HP == 64) {
+            if (tri) {
+                // triangle ring: 9 full transfers per loader and column, 7 columns ahead.  Loader 0 also moves the
+                // records, whose 8-slot ring fixes its slack at 2 iterations (record t+4 landed before B_t, as in the
+                // full-column schedule); loader 1 keeps 6 iterations of its half in flight (column t+1 landed before
+                // B_t).  A slot is rewritten by the issue of iteration c+1, after B_c closed the step that read it.
+                uint32_t goff[9];
+#pragma unroll
+                for (uint32_t n = 0; n < 9u; ++n) goff[n] = tri_unit_goff((lw * 9u + n) * 64u + p.lane);
+                if (lw == 0)
+                    for (int q = -1; q < 6; ++q) dma_record<Cfg::RB>(colrec, (int64_t)first + q, C, lrec, p.lane);
+                for (int q = 0; q < kTriDist; ++q) dma_column_tri(cols, (int64_t)lo + q, C, lring, lw, goff);
+                wait_vmem_all();
+                lds_barrier();  // P0
+                lds_barrier();  // Bx
+                for (uint32_t t = first; t < hi; ++t) {
+                    if (lw == 0) dma_record<Cfg::RB>(colrec, (int64_t)t + 6, C, lrec, p.lane);
+                    dma_column_tri(cols, (int64_t)t + kTriDist, C, lring, lw, goff);
+                    if ((int64_t)t + kTriDist >= (int64_t)C) wait_vmem_all();  // tail
+                    else if (lw == 0) wait_vmem_keep<2 * (1 + 9)>();
+                    else wait_vmem_keep<6 * 9>();
+                    lds_barrier();  // B_t
+                }
+                lds_barrier();  // F
+                return;
+            }
+        }
         if (lw == 0)  // records first-1 (column 0, or the column resumed from) .. first+5
             for (int q = -1; q < 6; ++q) dma_record<Cfg::RB>(colrec, (int64_t)first + q, C, lrec, p.lane);
         if (RING)
-            for (int q = 0; q < kRingDist; ++q) dma_column<HP, Cfg::NLOAD>(cols, (int64_t)lo + q, C, lring, p.lane, lw, tri);
+            for (int q = 0; q < kRingDist; ++q) dma_column<HP, Cfg::NLOAD>(cols, (int64_t)lo + q, C, lring, p.lane, lw);
         wait_vmem_all();
         lds_barrier();  // P0: first records staged
         lds_barrier();  // Bx: column lo initialised / resumed
         const bool nodma = (kExp & 128u) != 0;
         for (uint32_t t = first; t < hi; ++t) {
             if (lw == 0) dma_record<Cfg::RB>(colrec, (int64_t)t + 6, C, lrec, p.lane);
-            if (RING && !nodma) dma_column<HP, Cfg::NLOAD>(cols, (int64_t)t + kRingDist, C, lring, p.lane, lw, tri);
+            if (RING && !nodma) dma_column<HP, Cfg::NLOAD>(cols, (int64_t)t + kRingDist, C, lring, p.lane, lw);
             if ((int64_t)t + 6 >= (int64_t)C) wait_vmem_all();  // tail
             else if (lw == 0) wait_vmem_keep<KEEP0>();
             else wait_vmem_keep<KEEP1>();
@@ -1175,6 +1246,12 @@ DEVI void forward_body(const DevContig& dc, ChainShared<HP, R>& sh, uint32_t C, 
         }
     };
 
+    uint32_t tloff[R / 2], tvalid = 0;  // triangle ring: this thread's units inside a slot
+    if constexpr (RING && HP == 64) { if (tri) tri_read_setup<R>(p.i0, p.j, tloff, tvalid); }
+    auto ring_get = [&](int64_t c, double (&v)[R]) __attribute__((always_inline)) {
+        if constexpr (HP == 64) { if (tri) { ring_read_tri<R>(ring, c, tloff, tvalid, v); return; } }
+        ring_read<HP, R>(ring, c, p.i0, p.j, v);
+    };
     double x[R], ui[R > 16 ? 1 : R];
     double vA[(PHASE == 2 && !RING) ? R : 1];  // register-prefetched beta' column (phase 2 without the LDS ring)
     unsigned long long tq = 0;  // inline loader (no loader wave): next record in flight
@@ -1204,7 +1281,7 @@ DEVI void forward_body(const DevContig& dc, ChainShared<HP, R>& sh, uint32_t C, 
         if constexpr (PHASE == 2) {  // lo == 0 in phase 2 <=> mid == 0 <=> C == 1
             if constexpr (RING) {
                 double bt[R];
-                ring_read<HP, R>(ring, 0, p.i0, p.j, bt);
+                ring_get(0, bt);
 #pragma unroll
                 for (int k = 0; k < R; ++k) bt[k] *= P0;
                 posterior<HP, R>(sh, part_out, part_slots, prev, 0, p, bt);
@@ -1298,7 +1375,7 @@ DEVI void forward_body(const DevContig& dc, ChainShared<HP, R>& sh, uint32_t C, 
         // workgroup) and the NEXT column's record, which is consumed one step later.
         __builtin_amdgcn_sched_barrier(0);
         double bt[RING ? R : 1];
-        if constexpr (RING) ring_read<HP, R>(ring, t, p.i0, p.j, bt);
+        if constexpr (RING) ring_get(t, bt);
         const RecInfo nxt = decode_record<Cfg::UNI>(sh.rec[(t + 1) & 7u], p.j, p.i0, full, dc.wide);
         __builtin_amdgcn_sched_barrier(0);
         double part = 0.0;
@@ -1441,16 +1518,38 @@ DEVI void backward_body(const DevContig& dc, ChainShared<HP, R>& sh, uint32_t C,
         constexpr int KSL = kRingDist - 1;  // iterations of slack a column transfer gets
         constexpr int KEEP0 = RING ? KSL * (1 + QL) : 4, KEEP1 = KSL * QL;
         static_assert(KEEP0 < 64 && KEEP1 < 64, "vmcnt is 6 bits");
+        if constexpr (RING && HP == 64) {
+            if (tri) {  // triangle ring: see forward_body
+                uint32_t goff[9];
+#pragma unroll
+                for (uint32_t n = 0; n < 9u; ++n) goff[n] = tri_unit_goff((lw * 9u + n) * 64u + p.lane);
+                if (lw == 0)
+                    for (int q = -1; q < 5; ++q) dma_record<Cfg::RB>(colrec, t0 - q, (int64_t)C, lrec, p.lane);  // t0+1 .. t0-4
+                for (int q = 0; q < kTriDist; ++q) dma_column_tri(cols, t0 - q, (int64_t)C, lring, lw, goff);
+                wait_vmem_all();
+                lds_barrier();  // P0
+                for (int64_t t = t0; t >= bot; --t) {
+                    if (lw == 0) dma_record<Cfg::RB>(colrec, t - 5, (int64_t)C, lrec, p.lane);
+                    dma_column_tri(cols, t - kTriDist, (int64_t)C, lring, lw, goff);
+                    if (t - kTriDist < 0) wait_vmem_all();  // tail
+                    else if (lw == 0) wait_vmem_keep<2 * (1 + 9)>();
+                    else wait_vmem_keep<6 * 9>();
+                    lds_barrier();  // B_t
+                }
+                lds_barrier();  // F
+                return;
+            }
+        }
         if (lw == 0)
             for (int q = -1; q < 5; ++q) dma_record<Cfg::RB>(colrec, t0 - q, (int64_t)C, lrec, p.lane);  // t0+1 .. t0-4
         if (RING)
-            for (int q = 0; q < kRingDist; ++q) dma_column<HP, Cfg::NLOAD>(cols, t0 - q, (int64_t)C, lring, p.lane, lw, tri);
+            for (int q = 0; q < kRingDist; ++q) dma_column<HP, Cfg::NLOAD>(cols, t0 - q, (int64_t)C, lring, p.lane, lw);
         wait_vmem_all();
         lds_barrier();  // P0
         const bool nodma = (kExp & 128u) != 0;
         for (int64_t t = t0; t >= bot; --t) {
             if (lw == 0) dma_record<Cfg::RB>(colrec, t - 5, (int64_t)C, lrec, p.lane);
-            if (RING && !nodma) dma_column<HP, Cfg::NLOAD>(cols, t - kRingDist, (int64_t)C, lring, p.lane, lw, tri);
+            if (RING && !nodma) dma_column<HP, Cfg::NLOAD>(cols, t - kRingDist, (int64_t)C, lring, p.lane, lw);
             if (t - 5 < 0) wait_vmem_all();  // tail
             else if (lw == 0) wait_vmem_keep<KEEP0>();
             else wait_vmem_keep<KEEP1>();
@@ -1503,6 +1602,12 @@ DEVI void backward_body(const DevContig& dc, ChainShared<HP, R>& sh, uint32_t C,
         dst[(size_t)(k >> 1) * HP] = v2f64{a, b};
     };
 
+    uint32_t tloff[R / 2], tvalid = 0;  // triangle ring: this thread's units inside a slot
+    if constexpr (RING && HP == 64) { if (tri) tri_read_setup<R>(p.i0, p.j, tloff, tvalid); }
+    auto ring_get = [&](int64_t c, double (&v)[R]) __attribute__((always_inline)) {
+        if constexpr (HP == 64) { if (tri) { ring_read_tri<R>(ring, c, tloff, tvalid, v); return; } }
+        ring_read<HP, R>(ring, c, p.i0, p.j, v);
+    };
     constexpr int NV = (PHASE == 2 && !RING) ? R : 1;
     double y[R], vA[NV], vB[(PHASE == 2 && !RING && VBUF == 2) ? R : 1];
     double Sy = 0.0;
@@ -1552,7 +1657,7 @@ DEVI void backward_body(const DevContig& dc, ChainShared<HP, R>& sh, uint32_t C,
         // record t (posterior of this column, emission of the next step; the record of column
         // t+1 was decoded one step ago)
         double vt[RING ? R : 1];
-        if constexpr (RING) ring_read<HP, R>(ring, t, p.i0, p.j, vt);
+        if constexpr (RING) ring_get(t, vt);
         const RecInfo nxt = decode_record<Cfg::UNI>(sh.rec[(uint32_t)t & 7u], p.j, p.i0, full, dc.wide);
         const unsigned char* rec1 = sh.rec[(uint32_t)(t + 1) & 7u];
         // beta~_t(true) = A (y/Sy . e) A^T; scaled by 2^-es: beta' = beta~ * m, m = Sy*2^-es
@@ -1686,7 +1791,7 @@ DEVI void backward_body(const DevContig& dc, ChainShared<HP, R>& sh, uint32_t C,
             const double k0 = ldexp(cur.c0, -es), k1 = ldexp(cur.c1, -es), k2 = ldexp(cur.c2, -es);
             const double kap = ldexp(cur.kappa, -es);
             double vt[RING ? R : 1];
-            if constexpr (RING) ring_read<HP, R>(ring, t, p.i0, p.j, vt);  // landed before B_{t+1}
+            if constexpr (RING) ring_get(t, vt);  // landed before B_{t+1}
             const RecInfo nxt = decode_record<Cfg::UNI>(sh.rec[(uint32_t)t & 7u], p.j, p.i0, full, dc.wide);
             const unsigned char* rec0 = sh.rec[(uint32_t)t & 7u];
             const uint32_t rb0 = rowbits_of(nxt);
@@ -1770,13 +1875,9 @@ __global__ __launch_bounds__((ChainCfg<HP, R>::TT)) void k_sweep(const DevContig
     const uint32_t C = (uint32_t)__builtin_amdgcn_readfirstlane((int)*dc.n_cols);
     if (C == 0) return;
     if constexpr (PHASE == 2 && HP == 64 && ChainCfg<HP, R>::LOADER) {
-        if (__builtin_amdgcn_readfirstlane((int)dc.tri) != 0) {
-            // partner columns arrive as upper triangles (DevContig::tri): the ring bytes the masked LDS-DMA lanes
-            // never write must read as zero for the whole launch
-            v2f64* r16 = (v2f64*)dyn_ring;
-            for (uint32_t q = threadIdx.x; q < (uint32_t)kRingSlots * HP * HP / 2u; q += ChainCfg<HP, R>::TT) r16[q] = v2f64{0.0, 0.0};
-            lds_barrier();
-        }
+        // triangle ring (DevContig::tri): the unit of zeros that stands for everything below the diagonal; first read
+        // behind the P0 barrier of the bodies
+        if (threadIdx.x == 0) *(v2f64*)(dyn_ring + (uint32_t)kTriSlots * kTriSlotB) = v2f64{0.0, 0.0};
     }
     if (blockIdx.y == 0) forward_body<HP, R, PHASE>(dc, sh, C, dyn_ring, chunk);
     else backward_body<HP, R, VBUF, KEEPW, PHASE>(dc, sh, C, dyn_ring, chunk);
@@ -3424,7 +3525,8 @@ static bool lds_attr_pending(bool (&done)[PG_MAX_DEVICES]) {
 template <int HP, int R, int VBUF, bool KEEPW, int PHASE>
 static void launch_one(const DevContig* d_contigs, uint32_t n_contigs, uint32_t chunk, hipStream_t s) {
     using Cfg = ChainCfg<HP, R>;
-    const size_t dyn = (Cfg::LOADER && PHASE == 2) ? (size_t)kRingSlots * HP * HP * 8 : 0;  // partner-column ring
+    size_t dyn = (Cfg::LOADER && PHASE == 2) ? (size_t)kRingSlots * HP * HP * 8 : 0;  // partner-column ring
+    if (HP == 64 && dyn > 0 && dyn < kTriRingB) dyn = kTriRingB;  // the triangle ring of lean chains (8 compact slots + the zero unit)
     auto kern = k_sweep<HP, R, VBUF, KEEPW, PHASE>;
     static bool attr_done[PG_MAX_DEVICES];
     if (dyn > 0 && lds_attr_pending(attr_done))  // more than the default 64 KiB of LDS per workgroup
