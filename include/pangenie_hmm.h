@@ -165,6 +165,10 @@ uint64_t pg_job_device_bytes(const pg_job* job);
  * chunks of *chunk_cols columns, posteriors of each finished chunk on the idle CUs; chosen for few
  * chains).  Override with the environment variables PG_SWEEP_MODE=fused|chunked, PG_CHUNK_COLS=n. */
 int  pg_job_sweep_mode(const pg_job* job, uint32_t* chunk_cols);
+/* Number of chains of the job whose columns are kept as upper triangles (fused mode, every object biallelic,
+ * H = 64: the columns are symmetric, so phase 1 writes and phase 2 reads only the stored half — half of the
+ * 16 H^2 bytes per variant of the full formulation; PG_TRI=0 turns it off).  For traffic accounting. */
+uint32_t pg_job_triangle_chains(const pg_job* job);
 void pg_job_destroy(pg_job* job);
 
 /* pg_job_create with an error code instead of a NULL: PG_ERR_INVALID (malformed batch),

@@ -891,6 +891,13 @@ extern "C" int pg_job_sweep_mode(const pg_job* job, uint32_t* chunk_cols) {
     return job->chunked ? 1 : 0;
 }
 
+extern "C" uint32_t pg_job_triangle_chains(const pg_job* job) {
+    if (!job) return 0;
+    uint32_t n = 0;
+    for (const auto& ch : job->chains) n += ch.d.tri ? 1u : 0u;
+    return n;
+}
+
 extern "C" int pg_hmm_genotype_contig(const pg_contig_batch* batch, const pg_table* table, const pg_hmm_params* params,
                                       int device, pg_contig_result* out, char* err, size_t errlen) {
     if (!batch || !table || !params || !out) { set_err(err, errlen, "null argument"); return PG_ERR_INVALID; }

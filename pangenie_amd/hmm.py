@@ -250,6 +250,10 @@ class Job:
         m = self._lib.pg_job_sweep_mode(self.h, C.byref(k))
         return ("chunked" if m == 1 else "fused"), int(k.value)
 
+    def triangle_chains(self) -> int:
+        """chains whose columns are stored as upper triangles (fused jobs, lean chains)"""
+        return int(self._lib.pg_job_triangle_chains(self.h))
+
     def close(self):
         if getattr(self, "h", None):
             self._lib.pg_job_destroy(self.h)
