@@ -136,10 +136,11 @@ struct DevContig {
     // {c0, c1, c2, kappa, E'00, E'01, E'11, bits1} (64 B, read with scalar loads) and the flag
     double*   frec;            // [V][8]
     uint32_t  lean;            // 1: the store-only phases of this chain run on k_sweep_lean
-    // 1 (lean chains of FUSED jobs): phase 1 stores only the upper triangle of its (symmetric) columns — elements
-    // below the diagonal are never written (inside a 16-byte unit that straddles it: written as 0), the diagonal
-    // is stored HALVED — so that phase 2 can take the posterior sums over the stored half alone and k_bins doubles
-    // them: half the HBM bytes written by phase 1 and read by phase 2
+    // 1 (lean chains of FUSED jobs): phase 1 stores only the upper triangle of its (symmetric) columns, COMPACT at the
+    // start of the column's slot (1152 16-byte units: row pair q, lanes 8 (q >> 2) .. 63, see tri_unit_of); elements
+    // below the diagonal inside those units are written as 0, the diagonal is stored HALVED — so that phase 2 can
+    // take the posterior sums over the stored half alone and k_bins doubles them: half the HBM bytes written by
+    // phase 1 and read by phase 2
     uint32_t  tri;
     double*   xbuf;            // [2][HP*HP] generic kernel scratch (forward role first)
     uint32_t* err;

@@ -919,35 +919,30 @@ DEVI void ring_read(const unsigned char* ring, int64_t c, const uint32_t i0, con
 
 // ---- triangle ring (DevContig::tri, HP = 64): the stored half of a column is 1152 16-byte units (row pair q holds
 // lanes 8 (q >> 2) .. 63: whole 128-byte lines, see k_sweep_lean's put_pair), enumerated row pair by row pair.  The
-// ring keeps them COMPACT — 18 KB per column instead of 32 — so 8 slots fit where 4 did and every LDS-DMA transfer
-// is a full 1 KB (lane l of transfer n fetches unit 64 n + l from wherever it lies in the stored column): 9
+// stored column and the ring keep them COMPACT — one contiguous 18 KB run instead of 32 KB — so 8 ring slots fit
+// where 4 did and every LDS-DMA transfer is a full 1 KB: 9
 // transfers per loader and column instead of 16, seven columns in flight instead of three.  Phase 2 of many
 // resident chains is bound by the bytes a CU has in flight, not by HBM bandwidth.
-static constexpr int kTriSlots = 8, kTriDist = 7;
+#ifndef PG_TRI_SLOTS
+#define PG_TRI_SLOTS 8
+#endif
+static constexpr int kTriSlots = PG_TRI_SLOTS, kTriDist = PG_TRI_SLOTS - 1;  // (3 slots: two workgroups share a CU's LDS)
+static constexpr int kTriKeep0 = (kTriDist - 1 < 2 ? kTriDist - 1 : 2) * (1 + 9), kTriKeep1 = (kTriDist - 1) * 9;
+static_assert(kTriKeep0 < 64 && kTriKeep1 < 64 && kTriSlots >= 2, "vmcnt is 6 bits");
 static constexpr uint32_t kTriUnits = 1152u, kTriSlotB = kTriUnits * 16u;  // 18432
 static constexpr uint32_t kTriRingB = (uint32_t)kTriSlots * kTriSlotB + 16u;  // + one unit of zeros (what lies below the diagonal)
 DEVI uint32_t tri_unit_of(uint32_t q /*row pair*/, uint32_t lane /* >= 8 (q >> 2) */) {
     const uint32_t g = q >> 2;
     return 256u * g - 16u * g * (g - 1u) + (q & 3u) * (64u - 8u * g) + (lane - 8u * g);
 }
-DEVI uint32_t tri_unit_goff(uint32_t u) {  // byte offset of unit u inside the stored (full-layout) column
-    uint32_t g = 0, base = 0;
-    for (; g < 7u; ++g) {
-        const uint32_t n = 4u * (64u - 8u * g);
-        if (u < base + n) break;
-        base += n;
-    }
-    const uint32_t w = 64u - 8u * g, r = (u - base) / w, l = (u - base) % w + 8u * g;
-    return (4u * g + r) * 1024u + l * 16u;
-}
-// loader `part` (of 2) moves transfers 9 part .. 9 part + 8; goff[n] = this lane's byte offset for its n-th transfer
-DEVI void dma_column_tri(const gdouble* cols, int64_t c, int64_t C, LAS unsigned char* ring, uint32_t part, const uint32_t (&goff)[9]) {
+// loader `part` (of 2) moves transfers 9 part .. 9 part + 8 of the column's 18
+DEVI void dma_column_tri(const gdouble* cols, int64_t c, int64_t C, LAS unsigned char* ring, uint32_t part, uint32_t lane) {
     if (c < 0 || c >= C) return;
-    const GAS char* g = (const GAS char*)(cols + (size_t)c * 64u * 64u);
-    LAS unsigned char* l = ring + (uint32_t)(c & (kTriSlots - 1)) * kTriSlotB + part * 9u * 1024u;
+    const GAS char* g = (const GAS char*)(cols + (size_t)c * 64u * 64u) + part * 9u * 1024u + lane * 16u;  // the stored half is compact
+    LAS unsigned char* l = ring + (uint32_t)((uint64_t)c % (uint32_t)kTriSlots) * kTriSlotB + part * 9u * 1024u;
 #pragma unroll
     for (uint32_t n = 0; n < 9u; ++n)
-        __builtin_amdgcn_global_load_lds((const GAS void*)(g + goff[n]), (LAS void*)(l + n * 1024u), 16, 0, 0);
+        __builtin_amdgcn_global_load_lds((const GAS void*)(g + n * 1024u), (LAS void*)(l + n * 1024u), 16, 0, 0);
 }
 // this thread's eight units of a column: LDS byte offsets inside a slot; units below the diagonal read the zero unit
 template <int R>
@@ -963,7 +958,7 @@ DEVI void tri_read_setup(uint32_t i0, uint32_t j, uint32_t (&loff)[R / 2], uint3
 }
 template <int R>
 DEVI void ring_read_tri(const unsigned char* ring, int64_t c, const uint32_t (&loff)[R / 2], uint32_t valid, double (&v)[R]) {
-    const uint32_t slot = (uint32_t)(c & (kTriSlots - 1)) * kTriSlotB;
+    const uint32_t slot = (uint32_t)((uint64_t)c % (uint32_t)kTriSlots) * kTriSlotB;
 #pragma unroll
     for (int q = 0; q < R / 2; ++q) {
         const uint32_t off = ((valid >> q) & 1u) ? slot + loff[q] : (uint32_t)kTriSlots * kTriSlotB;
@@ -1155,21 +1150,18 @@ DEVI void forward_body(const DevContig& dc, ChainShared<HP, R>& sh, uint32_t C, 
                 // records, whose 8-slot ring fixes its slack at 2 iterations (record t+4 landed before B_t, as in the
                 // full-column schedule); loader 1 keeps 6 iterations of its half in flight (column t+1 landed before
                 // B_t).  A slot is rewritten by the issue of iteration c+1, after B_c closed the step that read it.
-                uint32_t goff[9];
-#pragma unroll
-                for (uint32_t n = 0; n < 9u; ++n) goff[n] = tri_unit_goff((lw * 9u + n) * 64u + p.lane);
                 if (lw == 0)
                     for (int q = -1; q < 6; ++q) dma_record<Cfg::RB>(colrec, (int64_t)first + q, C, lrec, p.lane);
-                for (int q = 0; q < kTriDist; ++q) dma_column_tri(cols, (int64_t)lo + q, C, lring, lw, goff);
+                for (int q = 0; q < kTriDist; ++q) dma_column_tri(cols, (int64_t)lo + q, C, lring, lw, p.lane);
                 wait_vmem_all();
                 lds_barrier();  // P0
                 lds_barrier();  // Bx
                 for (uint32_t t = first; t < hi; ++t) {
                     if (lw == 0) dma_record<Cfg::RB>(colrec, (int64_t)t + 6, C, lrec, p.lane);
-                    dma_column_tri(cols, (int64_t)t + kTriDist, C, lring, lw, goff);
+                    dma_column_tri(cols, (int64_t)t + kTriDist, C, lring, lw, p.lane);
                     if ((int64_t)t + kTriDist >= (int64_t)C) wait_vmem_all();  // tail
-                    else if (lw == 0) wait_vmem_keep<2 * (1 + 9)>();
-                    else wait_vmem_keep<6 * 9>();
+                    else if (lw == 0) wait_vmem_keep<kTriKeep0>();
+                    else wait_vmem_keep<kTriKeep1>();
                     lds_barrier();  // B_t
                 }
                 lds_barrier();  // F
@@ -1241,7 +1233,7 @@ DEVI void forward_body(const DevContig& dc, ChainShared<HP, R>& sh, uint32_t C, 
 #pragma unroll
         for (int k = 0; k < R; ++k) {
             const uint32_t i = p.i0 + (uint32_t)k, a = i <= p.j ? i : p.j, b = i <= p.j ? p.j : i;
-            const double val = col[((size_t)(a >> 1) * HP + b) * 2 + (a & 1u)];
+            const double val = col[(size_t)tri_unit_of(a >> 1, b) * 2 + (a & 1u)];
             v[k] = a == b ? 2.0 * val : val;
         }
     };
@@ -1520,20 +1512,17 @@ DEVI void backward_body(const DevContig& dc, ChainShared<HP, R>& sh, uint32_t C,
         static_assert(KEEP0 < 64 && KEEP1 < 64, "vmcnt is 6 bits");
         if constexpr (RING && HP == 64) {
             if (tri) {  // triangle ring: see forward_body
-                uint32_t goff[9];
-#pragma unroll
-                for (uint32_t n = 0; n < 9u; ++n) goff[n] = tri_unit_goff((lw * 9u + n) * 64u + p.lane);
                 if (lw == 0)
                     for (int q = -1; q < 5; ++q) dma_record<Cfg::RB>(colrec, t0 - q, (int64_t)C, lrec, p.lane);  // t0+1 .. t0-4
-                for (int q = 0; q < kTriDist; ++q) dma_column_tri(cols, t0 - q, (int64_t)C, lring, lw, goff);
+                for (int q = 0; q < kTriDist; ++q) dma_column_tri(cols, t0 - q, (int64_t)C, lring, lw, p.lane);
                 wait_vmem_all();
                 lds_barrier();  // P0
                 for (int64_t t = t0; t >= bot; --t) {
                     if (lw == 0) dma_record<Cfg::RB>(colrec, t - 5, (int64_t)C, lrec, p.lane);
-                    dma_column_tri(cols, t - kTriDist, (int64_t)C, lring, lw, goff);
+                    dma_column_tri(cols, t - kTriDist, (int64_t)C, lring, lw, p.lane);
                     if (t - kTriDist < 0) wait_vmem_all();  // tail
-                    else if (lw == 0) wait_vmem_keep<2 * (1 + 9)>();
-                    else wait_vmem_keep<6 * 9>();
+                    else if (lw == 0) wait_vmem_keep<kTriKeep0>();
+                    else wait_vmem_keep<kTriKeep1>();
                     lds_barrier();  // B_t
                 }
                 lds_barrier();  // F
@@ -1587,7 +1576,7 @@ DEVI void backward_body(const DevContig& dc, ChainShared<HP, R>& sh, uint32_t C,
 #pragma unroll
         for (int k = 0; k < R; ++k) {
             const uint32_t i = p.i0 + (uint32_t)k, a = i <= p.j ? i : p.j, b = i <= p.j ? p.j : i;
-            const double val = col[((size_t)(a >> 1) * HP + b) * 2 + (a & 1u)];
+            const double val = col[(size_t)tri_unit_of(a >> 1, b) * 2 + (a & 1u)];
             v[k] = a == b ? 2.0 * val : val;
         }
     };
@@ -2049,19 +2038,21 @@ DEVI void lean_forward(const DevContig& dc, LeanShared<R>& sh, uint32_t C, uint3
     // element below the diagonal inside a straddling 16-byte unit as 0.  The per-pair factors / skip bits are
     // fixed per thread (row pair i0 + 2q, column = lane).
     double tfa[TRI ? R / 2 : 1], tfb[TRI ? R / 2 : 1];
-    uint32_t tskip = 0;
+    uint32_t tskip = 0, tunit[TRI ? R / 2 : 1];
     if constexpr (TRI) {
 #pragma unroll
         for (int q = 0; q < R / 2; ++q) {
             const uint32_t r0 = i0 + 2u * (uint32_t)q;
             tfa[q] = lane < r0 ? 0.0 : (lane == r0 ? 0.5 : 1.0);
             tfb[q] = lane <= r0 ? 0.0 : (lane == r0 + 1u ? 0.5 : 1.0);
-            tskip |= (lane < (r0 & ~7u) ? 1u : 0u) << q;  // whole 128-byte lines only: the lanes between are written as zeros
+            const bool off_q = lane < (r0 & ~7u);  // whole 128-byte lines only: the lanes between are written as zeros
+            tskip |= (off_q ? 1u : 0u) << q;
+            tunit[q] = off_q ? 0u : tri_unit_of(r0 >> 1, lane);  // compact: the stored half is one contiguous 18 KB run
         }
     }
     auto put_pair = [&](gdouble2* dst, int q, double a, double b) __attribute__((always_inline)) {
         if constexpr (TRI) {
-            if (!((tskip >> q) & 1u)) dst[(size_t)q * HP] = v2f64{a * tfa[q], b * tfb[q]};
+            if (!((tskip >> q) & 1u)) (dst - toff)[tunit[q]] = v2f64{a * tfa[q], b * tfb[q]};
         } else {
             dst[(size_t)q * HP] = v2f64{a, b};
         }
@@ -2236,19 +2227,21 @@ DEVI void lean_backward(const DevContig& dc, LeanShared<R>& sh, uint32_t C, uint
         eB = aj ? r.E11 : r.E01;
     };
     double tfa[TRI ? R / 2 : 1], tfb[TRI ? R / 2 : 1];  // see lean_forward
-    uint32_t tskip = 0;
+    uint32_t tskip = 0, tunit[TRI ? R / 2 : 1];
     if constexpr (TRI) {
 #pragma unroll
         for (int q = 0; q < R / 2; ++q) {
             const uint32_t r0 = i0 + 2u * (uint32_t)q;
             tfa[q] = lane < r0 ? 0.0 : (lane == r0 ? 0.5 : 1.0);
             tfb[q] = lane <= r0 ? 0.0 : (lane == r0 + 1u ? 0.5 : 1.0);
-            tskip |= (lane < (r0 & ~7u) ? 1u : 0u) << q;  // whole 128-byte lines only: the lanes between are written as zeros
+            const bool off_q = lane < (r0 & ~7u);  // whole 128-byte lines only: the lanes between are written as zeros
+            tskip |= (off_q ? 1u : 0u) << q;
+            tunit[q] = off_q ? 0u : tri_unit_of(r0 >> 1, lane);  // compact: the stored half is one contiguous 18 KB run
         }
     }
     auto put_pair = [&](gdouble2* dst, int q, double a, double b) __attribute__((always_inline)) {
         if constexpr (TRI) {
-            if (!((tskip >> q) & 1u)) dst[(size_t)q * HP] = v2f64{a * tfa[q], b * tfb[q]};
+            if (!((tskip >> q) & 1u)) (dst - toff)[tunit[q]] = v2f64{a * tfa[q], b * tfb[q]};
         } else {
             dst[(size_t)q * HP] = v2f64{a, b};
         }
@@ -3238,7 +3231,7 @@ __global__ __launch_bounds__(256) void k_bins(const DevContig* __restrict__ cont
                     if (al[i] == a && al[jj] == b) {
                         if (dc.tri) {  // the column was stored as its upper triangle, the diagonal halved
                             const uint32_t lo3 = i < jj ? i : jj, hi3 = i < jj ? jj : i;
-                            const double val = col[((size_t)(lo3 >> 1) * HP + hi3) * 2 + (lo3 & 1u)];
+                            const double val = col[(size_t)tri_unit_of(lo3 >> 1, hi3) * 2 + (lo3 & 1u)];
                             s += lo3 == hi3 ? 2.0 * val : val;
                         } else {
                             s += col[((size_t)(i >> 1) * HP + jj) * 2 + (i & 1u)];
@@ -3526,7 +3519,13 @@ template <int HP, int R, int VBUF, bool KEEPW, int PHASE>
 static void launch_one(const DevContig* d_contigs, uint32_t n_contigs, uint32_t chunk, hipStream_t s) {
     using Cfg = ChainCfg<HP, R>;
     size_t dyn = (Cfg::LOADER && PHASE == 2) ? (size_t)kRingSlots * HP * HP * 8 : 0;  // partner-column ring
-    if (HP == 64 && dyn > 0 && dyn < kTriRingB) dyn = kTriRingB;  // the triangle ring of lean chains (8 compact slots + the zero unit)
+    if (HP == 64 && dyn > 0) {  // the triangle ring of lean chains (compact slots + the zero unit)
+#if PG_TRI_SLOTS >= 8
+        if (dyn < kTriRingB) dyn = kTriRingB;
+#else
+        if (const char* e = getenv("PG_TRI_ONLY")) { if (e[0] == '1') dyn = kTriRingB; }  // experiment: every HP = 64 chain of the job is a triangle chain
+#endif
+    }
     auto kern = k_sweep<HP, R, VBUF, KEEPW, PHASE>;
     static bool attr_done[PG_MAX_DEVICES];
     if (dyn > 0 && lds_attr_pending(attr_done))  // more than the default 64 KiB of LDS per workgroup
