@@ -871,6 +871,10 @@ DEVI RecInfo decode_record(const unsigned char* rec, uint32_t j, uint32_t i0, bo
 // Partner-column ring: PG_RING_SLOTS column slots in dynamic LDS, prefetch distance SLOTS-1 columns.
 // 4 slots (128 KB at HP = 64) give every DMA two full steps to land — what a lone workgroup per CU
 // needs; 2 slots (64 KB) let two workgroups share a CU when hundreds of chains are resident.
+#ifndef PG_LEAN2
+#define PG_LEAN2 1
+#endif
+static constexpr bool kLean2 = PG_LEAN2 != 0;  // phase 2 of triangle chains on k_sweep_lean2 (0: on the general kernel's triangle ring)
 #ifndef PG_RING_SLOTS
 #define PG_RING_SLOTS 4
 #endif
@@ -1863,6 +1867,7 @@ __global__ __launch_bounds__((ChainCfg<HP, R>::TT)) void k_sweep(const DevContig
     // with it every column index, ring slot and address derived from it, wave-uniform again)
     const uint32_t C = (uint32_t)__builtin_amdgcn_readfirstlane((int)*dc.n_cols);
     if (C == 0) return;
+    if (PHASE == 2 && kLean2 && dc.tri && C >= 2) return;  // triangle chains: k_sweep_lean2
     if constexpr (PHASE == 2 && HP == 64 && ChainCfg<HP, R>::LOADER) {
         // triangle ring (DevContig::tri): the unit of zeros that stands for everything below the diagonal; first read
         // behind the P0 barrier of the bodies
@@ -2352,6 +2357,308 @@ DEVI void lean_backward(const DevContig& dc, LeanShared<R>& sh, uint32_t C, uint
         cur = nxt;
     }
     if (wave == 0 && bsc.valid) { bsc.flush(bscale, lane, (uint64_t)bot); bsm.flush(bsum, lane, (uint64_t)bot); }
+}
+
+// ------------------------------------------------------------------------------------------
+//  Lean PHASE 2 (fused jobs, triangle chains — DevContig::tri, C >= 2): the second half of a half-chain with the
+//  posterior partials formed inline.  Same step as lean_forward / lean_backward; instead of storing the column the
+//  thread multiplies it with the partner column (beta' for the forward role, P' for the backward role — stored by
+//  phase 1 as a compact upper triangle) and adds the products up by the row allele.  No loader waves and no LDS
+//  ring: every thread fetches its own (at most 8) 16-byte units of the partner column two columns ahead into
+//  registers, so a workgroup is 4 waves with ~200 VGPRs and TWO of them share a CU (the general phase-2 kernel:
+//  6 waves of 241 VGPRs, one workgroup per CU).  The partials of the four waves are added up through LDS (riding on
+//  the step's barrier) before they leave: 1 KB per column instead of 4 (k_bins reads 64 entries per column).
+// ------------------------------------------------------------------------------------------
+template <int R>
+struct LeanShared2 {
+    LeanShared<R> a;
+    v2f64 ppart[2][64 / R][64];  // posterior partials {row allele 0, row allele 1} per wave and lane, by step parity
+};
+template <int R>
+struct LeanTri {  // this thread's units of a compact triangle column
+    uint32_t unit[R / 2];
+    uint32_t valid;
+    DEVI void setup(uint32_t i0, uint32_t lane) {
+        valid = 0;
+#pragma unroll
+        for (int q = 0; q < R / 2; ++q) {
+            const uint32_t rp = (i0 >> 1) + (uint32_t)q;
+            const bool ok = lane >= 8u * (rp >> 2);
+            unit[q] = ok ? tri_unit_of(rp, lane) : 0u;
+            valid |= (ok ? 1u : 0u) << q;
+        }
+    }
+    // units below the stored half keep the zeros the buffer was initialised with
+    DEVI void load(gcdouble* col, double (&v)[R]) const {
+        gcdouble2* c2 = (gcdouble2*)col;
+#pragma unroll
+        for (int q = 0; q < R / 2; ++q)
+            if ((valid >> q) & 1u) { const v2f64 t = c2[unit[q]]; v[2 * q] = t.x; v[2 * q + 1] = t.y; }
+    }
+};
+// full element (i0 + k, lane) of a compact triangle column: the stored (min, max), the diagonal doubled (once per launch)
+template <int R>
+DEVI void lean_load_mirrored(gcdouble* col, uint32_t i0, uint32_t lane, double (&v)[R]) {
+#pragma unroll
+    for (int k = 0; k < R; ++k) {
+        const uint32_t i = i0 + (uint32_t)k, a = i <= lane ? i : lane, b = i <= lane ? lane : i;
+        const double val = col[(size_t)tri_unit_of(a >> 1, b) * 2 + (a & 1u)];
+        v[k] = a == b ? 2.0 * val : val;
+    }
+}
+// partials of column c: the four waves' {acc0, acc1} of step parity pb, added by wave 0, one 1 KB store
+template <int R>
+DEVI void lean2_flush_partials(const LeanShared2<R>& sh, uint32_t pb, gdouble* part, size_t c, uint32_t wave, uint32_t lane) {
+    if (wave != 0) return;  // (scalar branch)
+    v2f64 t = sh.ppart[pb][0][lane];
+#pragma unroll
+    for (int w = 1; w < 64 / R; ++w) { const v2f64 o = sh.ppart[pb][w][lane]; t.x += o.x; t.y += o.y; }
+    ((gdouble2*)part)[c * 64u + lane] = t;
+}
+
+template <int R>
+DEVI void lean2_forward(const DevContig& dc, LeanShared2<R>& sh2, uint32_t C) {
+    constexpr int HP = 64;
+    constexpr uint32_t RMASK = (1u << R) - 1u;
+    LeanShared<R>& sh = sh2.a;
+    const uint32_t mid = C / 2, lo = mid, hi = C, first = lo;  // C >= 2: lo >= 1
+    const uint32_t tid = threadIdx.x, lane = tid & 63u;
+    const uint32_t wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const uint32_t i0 = wave * R;
+    const size_t colsz = (size_t)HP * HP;
+    const double unif = 1.0 / 4096.0;
+    LeanRecs recs{(const GAS char*)dc.frec, (int64_t)first - 1, (int64_t)C, +1, tid};
+    recs.park(sh, 0, recs.fetch(0));
+    v2f64 piece = recs.fetch(1);
+    lds_barrier();
+    gcdouble* cols = (gcdouble*)dc.fwd;
+    gdouble* fscale = (gdouble*)dc.fscale;
+    gu8* fallback = (gu8*)dc.fwd_fallback;
+    gdouble* part = (gdouble*)dc.part;
+    auto emis = [&](const FRec& r, double& eA, double& eB) {
+        const bool aj = (r.bits1 >> lane) & 1ull;
+        eA = aj ? r.E01 : r.E00;
+        eB = aj ? r.E11 : r.E01;
+    };
+    LeanTri<R> tri;
+    tri.setup(i0, lane);
+    // partner columns beta'_t, two ahead of their use
+    double b0[R], b1[R], b2[R];
+#pragma unroll
+    for (int k = 0; k < R; ++k) { b0[k] = 0.0; b1[k] = 0.0; b2[k] = 0.0; }
+    tri.load(cols + (size_t)lo * colsz, b0);
+    if (lo + 1 < C) tri.load(cols + (size_t)(lo + 1) * colsz, b1);
+
+    ColScalars fsc;
+    double x[R];
+    {
+        const FRec r0 = read_frec(sh, 0);
+        double eA, eB;
+        emis(r0, eA, eB);
+        const uint32_t rb = (uint32_t)__builtin_amdgcn_readfirstlane((int)((uint32_t)(r0.bits1 >> i0) & RMASK));
+        lean_load_mirrored<R>(cols + (size_t)(lo - 1) * colsz, i0, lane, x);  // P'_{lo-1}, stored by phase 1 of this role
+        if (!fallback[lo - 1]) {
+#pragma unroll
+            for (int k = 0; k < R; ++k) x[k] *= sel_by_bit(rb, k, eA, eB);
+        }
+        double part0 = 0.0;
+#pragma unroll
+        for (int k = 0; k < R; ++k) part0 += x[k];
+        sh.psum[(first - 1) & 1u][wave][lane] = part0;
+    }
+    FRec cur = read_frec(sh, 1);
+    lds_barrier();
+    for (uint32_t t = first; t < hi; ++t) {
+        const uint32_t n = t - first;
+        const FRec nxt = read_frec(sh, n + 2u);
+        if (((n + 4u) % PG_LEAN_BLOCK) == 0u) {
+            const uint32_t blk = (n + 4u) / PG_LEAN_BLOCK;
+            recs.park(sh, blk, piece);
+            piece = recs.fetch(blk + 1u);
+        }
+        if (t + 2 < C) tri.load(cols + (size_t)(t + 2) * colsz, b2);  // two columns ahead (b2 was last read a step ago)
+        if (t > first) lean2_flush_partials<R>(sh2, (t - 1) & 1u, part, (size_t)(t - 1), wave, lane);
+        const uint32_t pb = (t - 1) & 1u;
+        const double Cj = lean_colsum<R>(sh, pb, lane);
+        const double ucol = cur.c1 * Cj;
+        double ui[R];
+        sh.u[wave][lane] = ucol;
+        const double* row = &sh.u[wave][i0];
+#pragma unroll
+        for (int k = 0; k < R; ++k) ui[k] = row[k];
+        __builtin_amdgcn_sched_barrier(0);
+        double S = wave_total_mfma(Cj);
+        double uj = fma(cur.c2, S, ucol);
+        double c0 = cur.c0;
+        if (__builtin_expect(!(S > 0.0), 0)) {
+            // column t-1 summed to zero: the uniform column takes its place (hmm.cpp:253-267); its own partials were
+            // formed from the all-zero column — k_bins re-forms those bins from the flag
+            if (wave == 0) fallback[t - 1] = 1;
+            const double Cu = 64.0 * unif;
+            S = 1.0;
+            uj = fma(cur.c0, unif, fma(cur.c2, 1.0, 2.0 * cur.c1 * Cu));
+            c0 = 0.0;
+        }
+        int es = exponent_of(S) - PG_BIAS_F;
+        es = es < -900 ? -900 : es;
+        const double m = ldexp(S, -es - PG_BIAS_F);
+        const double sc = ldexp(1.0, -es), c0s = ldexp(c0, -es), ujs = ldexp(uj, -es);
+        double eA, eB;
+        emis(cur, eA, eB);
+        const uint32_t rb = (uint32_t)__builtin_amdgcn_readfirstlane((int)((uint32_t)(cur.bits1 >> i0) & RMASK));
+        double part0 = 0.0, acc0 = 0.0, acc1 = 0.0;
+#pragma unroll
+        for (int k = 0; k < R; ++k) {
+            const double pk = fma(c0s, x[k], fma(ui[k], sc, ujs));
+            x[k] = pk * sel_by_bit(rb, k, eA, eB);
+            part0 += x[k];
+            const double pr = pk * b0[k];  // P'_t beta'_t (0 below the stored half)
+            const bool bit = (rb >> k) & 1u;
+            acc1 = fma(pr, bit ? 1.0 : 0.0, acc1);  // exact 0/1 multipliers: rounds like a predicated add
+            acc0 = fma(pr, bit ? 0.0 : 1.0, acc0);
+        }
+        sh.psum[t & 1u][wave][lane] = part0;
+        sh2.ppart[t & 1u][wave][lane] = v2f64{acc0, acc1};
+        if (wave == 0) {
+            fsc.put(lane, t, m);
+            if ((t & 63u) == 63u) fsc.flush(fscale, lane, t);
+        }
+#pragma unroll
+        for (int k = 0; k < R; ++k) { b0[k] = b1[k]; b1[k] = b2[k]; }
+        cur = nxt;
+        lds_barrier();
+    }
+    lean2_flush_partials<R>(sh2, (hi - 1) & 1u, part, (size_t)(hi - 1), wave, lane);
+    if (wave == 0 && fsc.valid) fsc.flush(fscale, lane, hi - 1);
+    {   // the last column may itself have summed to zero
+        const double Cj = lean_colsum<R>(sh, (hi - 1) & 1u, lane);
+        if (!(wave_total_mfma(Cj) > 0.0) && wave == 0) fallback[hi - 1] = 1;
+    }
+}
+
+template <int R>
+DEVI void lean2_backward(const DevContig& dc, LeanShared2<R>& sh2, uint32_t C) {
+    constexpr int HP = 64;
+    constexpr uint32_t RMASK = (1u << R) - 1u;
+    LeanShared<R>& sh = sh2.a;
+    const int64_t mid = C / 2, top = mid - 1, bot = 0, t0 = top;  // C >= 2: top >= 0, column mid exists
+    const uint32_t tid = threadIdx.x, lane = tid & 63u;
+    const uint32_t wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const uint32_t i0 = wave * R;
+    const size_t colsz = (size_t)HP * HP;
+    const double unif = 1.0 / 4096.0;
+    LeanRecs recs{(const GAS char*)dc.frec, t0 + 1, (int64_t)C, -1, tid};
+    recs.park(sh, 0, recs.fetch(0));
+    v2f64 piece = recs.fetch(1);
+    lds_barrier();
+    gcdouble* cols = (gcdouble*)dc.fwd;
+    gdouble* bscale = (gdouble*)dc.bscale;
+    gcdouble* bsum = (gcdouble*)dc.bsum;
+    gdouble* part = (gdouble*)dc.part;
+    auto emis = [&](const FRec& r, double& eA, double& eB) {
+        const bool aj = (r.bits1 >> lane) & 1ull;
+        eA = aj ? r.E01 : r.E00;
+        eB = aj ? r.E11 : r.E01;
+    };
+    LeanTri<R> tri;
+    tri.setup(i0, lane);
+    // partner columns P'_t (forward, stored by phase 1), two ahead of their use
+    double b0[R], b1[R], b2[R];
+#pragma unroll
+    for (int k = 0; k < R; ++k) { b0[k] = 0.0; b1[k] = 0.0; b2[k] = 0.0; }
+    tri.load(cols + (size_t)t0 * colsz, b0);
+    if (t0 - 1 >= 0) tri.load(cols + (size_t)(t0 - 1) * colsz, b1);
+
+    ColScalars bsc;
+    double w[R], Sy;
+    FRec cur = read_frec(sh, 0);  // record t0+1: constants of the gap t0 -> t0+1, emission of column t0+1
+    {
+        double y[R];
+        lean_load_mirrored<R>(cols + (size_t)(top + 1) * colsz, i0, lane, y);  // beta'_{mid}, stored by phase 1 of this role
+        Sy = bsum[top + 1];
+        if (!(Sy > 0.0)) {  // resuming behind an all-zero column: uniform (hmm.cpp:374-380)
+#pragma unroll
+            for (int k = 0; k < R; ++k) y[k] = unif;
+            Sy = 1.0;
+        }
+        double eA, eB;
+        emis(cur, eA, eB);
+        const uint32_t rb = (uint32_t)__builtin_amdgcn_readfirstlane((int)((uint32_t)(cur.bits1 >> i0) & RMASK));
+        double part0 = 0.0;
+#pragma unroll
+        for (int k = 0; k < R; ++k) { w[k] = y[k] * sel_by_bit(rb, k, eA, eB); part0 += w[k]; }
+        sh.psum[(uint32_t)t0 & 1u][wave][lane] = part0;
+    }
+    for (int64_t t = t0; t >= bot; --t) {
+        const uint32_t n = (uint32_t)(t0 - t);
+        const FRec nxt = read_frec(sh, n + 1u);  // record t: emission of column t (this step's w), row alleles of the posterior
+        if (((n + 4u) % PG_LEAN_BLOCK) == 0u) {
+            const uint32_t blk = (n + 4u) / PG_LEAN_BLOCK;
+            recs.park(sh, blk, piece);
+            piece = recs.fetch(blk + 1u);
+        }
+        if (t - 2 >= 0) tri.load(cols + (size_t)(t - 2) * colsz, b2);
+        int es = exponent_of(Sy) - PG_BIAS_B;
+        es = es < -900 ? -900 : es;
+        const double m = ldexp(Sy, -es - PG_BIAS_B);
+        if (wave == 0) bsc.put(lane, (uint64_t)t, m);
+        const double k0 = ldexp(cur.c0, -es), k1 = ldexp(cur.c1, -es), k2 = ldexp(cur.c2, -es), kap = ldexp(cur.kappa, -es);
+        lds_barrier();
+        if (t < t0) lean2_flush_partials<R>(sh2, (uint32_t)(t + 1) & 1u, part, (size_t)(t + 1), wave, lane);
+        const double Cj = lean_colsum<R>(sh, (uint32_t)t & 1u, lane);
+        const double ucol = k1 * Cj;
+        double ui[R];
+        sh.u[wave][lane] = ucol;
+        const double* row = &sh.u[wave][i0];
+#pragma unroll
+        for (int k = 0; k < R; ++k) ui[k] = row[k];
+        __builtin_amdgcn_sched_barrier(0);
+        const double Sw = wave_total_mfma(Cj);
+        const double uj = fma(k2, Sw, ucol);
+        const double Snew = kap * Sw;  // = sum(beta'_t)
+        double eA, eB;
+        emis(nxt, eA, eB);
+        const uint32_t rb = (uint32_t)__builtin_amdgcn_readfirstlane((int)((uint32_t)(nxt.bits1 >> i0) & RMASK));
+        double part0 = 0.0, acc0 = 0.0, acc1 = 0.0;
+        if (__builtin_expect(!(Snew > 0.0), 0)) {
+            // beta~_t is all zero: its own posteriors are 0, the next step starts from the uniform column
+#pragma unroll
+            for (int k = 0; k < R; ++k) { w[k] = unif * sel_by_bit(rb, k, eA, eB); part0 += w[k]; }
+        } else {
+#pragma unroll
+            for (int k = 0; k < R; ++k) {
+                const double yk = fma(k0, w[k], ui[k] + uj);  // beta'_t
+                w[k] = yk * sel_by_bit(rb, k, eA, eB);
+                part0 += w[k];
+                const double pr = b0[k] * yk;  // P'_t beta'_t
+                const bool bit = (rb >> k) & 1u;
+                acc1 = fma(pr, bit ? 1.0 : 0.0, acc1);
+                acc0 = fma(pr, bit ? 0.0 : 1.0, acc0);
+            }
+        }
+        sh.psum[(uint32_t)(t - 1) & 1u][wave][lane] = part0;
+        sh2.ppart[(uint32_t)t & 1u][wave][lane] = v2f64{acc0, acc1};
+        if (wave == 0 && ((uint64_t)t & 63u) == 0u) bsc.flush(bscale, lane, (uint64_t)t);
+        Sy = Snew > 0.0 ? Snew : 1.0;
+#pragma unroll
+        for (int k = 0; k < R; ++k) { b0[k] = b1[k]; b1[k] = b2[k]; }
+        cur = nxt;
+    }
+    lds_barrier();
+    lean2_flush_partials<R>(sh2, (uint32_t)bot & 1u, part, (size_t)bot, wave, lane);
+    if (wave == 0 && bsc.valid) bsc.flush(bscale, lane, (uint64_t)bot);
+}
+
+template <int R>
+__global__ __launch_bounds__((64 * 64 / R)) __attribute__((amdgpu_waves_per_eu(2, 2)))  // two workgroups per CU: <= 256 registers per lane
+void k_sweep_lean2(const DevContig* __restrict__ contigs) {
+    __shared__ LeanShared2<R> sh;
+    const DevContig& dc = contigs[blockIdx.x];
+    if (!dc.lean || !dc.tri) return;
+    const uint32_t C = (uint32_t)__builtin_amdgcn_readfirstlane((int)*dc.n_cols);
+    if (C < 2) return;  // (a single column: the general kernel)
+    if (blockIdx.y == 0) lean2_forward<R>(dc, sh, C);
+    else lean2_backward<R>(dc, sh, C);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -3248,14 +3555,17 @@ __global__ __launch_bounds__(256) void k_bins(const DevContig* __restrict__ cont
         // partials of thread t for the row-allele pair q: part[((c * part_slots/2 + q) * T + t)] = {a = 2q, a = 2q+1};
         // the column allele of thread t is al[t % HP].  All of a lane's 16-byte loads of a pair are
         // issued together, then split by column allele with selects (no dynamic register indexing).
-        const v2f64* base = (const v2f64*)dc.part + (size_t)c * (dc.part_slots >> 1) * T;
+        // triangle chains with >= 2 columns (k_sweep_lean2): the four waves' partials arrive added up, 64 per column
+        const bool l2 = kLean2 && dc.tri && C >= 2;
+        const uint32_t Tn = l2 ? 64u : T;
+        const v2f64* base = l2 ? (const v2f64*)dc.part + (size_t)c * 64u : (const v2f64*)dc.part + (size_t)c * (dc.part_slots >> 1) * T;
         const uint32_t nq = (nl + 1u) >> 1;
         for (uint32_t q = 0; q < nq; ++q) {
             double acc0[PG_AMAX], acc1[PG_AMAX];
 #pragma unroll
             for (int bb = 0; bb < PG_AMAX; ++bb) { acc0[bb] = 0.0; acc1[bb] = 0.0; }
-            for (uint32_t t = lane; t < T; t += 64) {
-                const v2f64 pv = base[(size_t)q * T + t];
+            for (uint32_t t = lane; t < Tn; t += 64) {
+                const v2f64 pv = base[(size_t)q * Tn + t];
                 const uint32_t b = al[t % HP];
 #pragma unroll
                 for (int bb = 0; bb < PG_AMAX; ++bb) {
@@ -3538,6 +3848,9 @@ static void launch_sweep(const DevContig* d_contigs, uint32_t n_contigs, uint32_
     if (hp_mask & 2u) launch_one<32, 16, 1, true, PHASE>(d_contigs, n_contigs, chunk, s);
     if (hp_mask & 4u) launch_one<64, 16, 1, true, PHASE>(d_contigs, n_contigs, chunk, s);
     if (hp_mask & 8u) launch_one<128, 32, 1, false, PHASE>(d_contigs, n_contigs, chunk, s);
+    if constexpr (PHASE == 2) {
+        if (kLean2 && (hp_mask & 128u)) hipLaunchKernelGGL((k_sweep_lean2<16>), dim3(n_contigs, 2), dim3(256), 0, s, d_contigs);
+    }
     if constexpr (PHASE != 2) {
         if (hp_mask & 64u) {  // bit 6: the job has lean chains (all-biallelic, H = HP = 64)
             static const int lean_r = [] { const char* e = getenv("PG_LEAN_R"); return e ? atoi(e) : 16; }();
