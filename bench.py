@@ -106,6 +106,8 @@ def _sweep_phase(name: str):
     """Phase (1, 2, 3) of a sweep kernel from its demangled name, None for other kernels:
     k_sweep<HP, R, VBUF, KEEPW, PHASE>, k_sweep_lean<PHASE, R>, k_sweep_generic<PHASE>."""
     import re
+    if name.startswith("void k_sweep_lean2<"):  # phase 2 of triangle chains
+        return 2
     m = re.match(r"void k_sweep_lean<(\d), ", name) or re.match(r"void k_sweep_generic<(\d)>", name) or \
         re.match(r"void k_sweep<\d+, \d+, \d+, \w+, (\d)>", name)
     return int(m.group(1)) if m else None
@@ -169,13 +171,18 @@ def roofline_of(job, batches, kms, H, workload_name):
         traffic, traffic_src = profiled_traffic(workload_name, 1 if dom == "k_sweep_phase1" else 2)
     extra = {}
     if job.triangle_chains() == job.n_chains and H == 64:
-        # every chain keeps its (symmetric) columns as upper triangles: 1152 16-byte units per column instead of 2048.
-        # `achieved` stays on SURVEY 8(d)'s figure (a full column written once and read once); these are the bytes the
-        # launch really has to move, and the rate on them
-        moved = dom_bytes - 8.0 * H * H * ncol + 1152 * 16.0 * ncol
-        extra = {"triangle_storage": True, "stored_bytes_per_launch": moved,
-                 "moved_GBs": moved / (dom_ms * 1e-3) / 1e9 if dom_ms > 0 else 0.0,
-                 "note": "columns are symmetric and stored as upper triangles: PMC traffic is below the algorithmic bytes (SURVEY 8(d))"}
+        # Every chain keeps its (symmetric) columns as upper triangles: 1152 16-byte units per column instead of 2048
+        # (DESIGN.md 4/6).  The algorithmic bytes of THIS formulation are what `achieved` is taken on — the figure of
+        # the full formulation (a whole column written once and read once) would put the rate above the
+        # HBM peak; it is reported beside it.
+        full_bytes = dom_bytes
+        dom_bytes = dom_bytes - 8.0 * H * H * ncol + 1152 * 16.0 * ncol
+        bytes_total = bytes_total - 2 * 8.0 * H * H * ncol + 2 * 1152 * 16.0 * ncol
+        achieved = dom_bytes / (dom_ms * 1e-3) / 1e9 if dom_ms > 0 else 0.0
+        extra = {"triangle_storage": True, "full_formulation_bytes_per_launch": full_bytes,
+                 "full_formulation_GBs": full_bytes / (dom_ms * 1e-3) / 1e9 if dom_ms > 0 else 0.0,
+                 "note": "columns are symmetric and stored as upper triangles (18 KB of 32 KB per column): algorithmic bytes and "
+                         "PMC traffic are those of the triangle formulation"}
     return {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
             "algorithmic_bytes_per_launch": dom_bytes, "avg_launch_ms": dom_ms, **extra,

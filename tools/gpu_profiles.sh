@@ -21,6 +21,6 @@ mkdir -p gpurun_out/${TAG}_sampler
   timeout 600 rocprofv3 --pmc SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR --kernel-trace -d gpurun_out/${TAG}_sampler/pmc_sq2 -o pmc --output-format csv -- $SCMD > gpurun_out/${TAG}_sampler/pmc_sq2.log 2>&1
   rm -f gpurun_out/${TAG}_sampler/*/*kernel_trace.csv gpurun_out/${TAG}_sampler/*/*agent_info.csv )
 cp gpurun_out/${TAG}_sampler/kt/kt_kernel_stats.csv gpurun_out/profiles/${TAG}_sampler_kernel_stats.csv 2>/dev/null
-tail -1 gpurun_out/${TAG}_sampler/kt.log > gpurun_out/profiles/${TAG}_sampler_bench.json 2>/dev/null
+grep "^{" gpurun_out/${TAG}_sampler/kt.log | tail -1 > gpurun_out/profiles/${TAG}_sampler_bench.json 2>/dev/null
 python tools/summarize_profile.py gpurun_out/${TAG}_sampler gpurun_out/profiles/${TAG}_sampler "sampler 8 contigs x 40000 x 215 paths x 15 passes" > /dev/null 2>&1
 ls -la gpurun_out/profiles
