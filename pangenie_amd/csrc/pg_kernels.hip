@@ -3856,7 +3856,8 @@ static void launch_sweep(const DevContig* d_contigs, uint32_t n_contigs, uint32_
             static const int lean_r = [] { const char* e = getenv("PG_LEAN_R"); return e ? atoi(e) : 16; }();
             // PG_LEAN_PIPE=1: the pipelined lean step (closed-form column sums; measured SLOWER than the plain step,
             // 855 vs 655 ns per column — DESIGN.md 4 — and kept as an independently derived cross-check)
-            static const int lean_pipe = [] { const char* e = getenv("PG_LEAN_PIPE"); return e ? atoi(e) : 0; }();
+            const char* pipe_env = getenv("PG_LEAN_PIPE");  // (read per launch: tests switch it inside one process)
+            const int lean_pipe = pipe_env ? atoi(pipe_env) : 0;
             if (lean_r == 8) hipLaunchKernelGGL((k_sweep_lean<PHASE, 8, false>), dim3(n_contigs, 2), dim3(512), 0, s, d_contigs, chunk);
             else if (lean_pipe) hipLaunchKernelGGL((k_sweep_lean<PHASE, 16, true>), dim3(n_contigs, 2), dim3(256), 0, s, d_contigs, chunk);
             else if (PHASE == 1 && (hp_mask & 128u))  // bit 7: fused job whose lean chains store triangles (DevContig::tri)

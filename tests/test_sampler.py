@@ -273,6 +273,22 @@ def test_hip_sampler_saturation():
 
 
 @pytest.mark.gpu
+def test_hip_sampler_batch_of_contigs():
+    """pg_sampler_run_batch: contigs of different lengths (and one without variants) in one call — one workgroup per
+    contig and pass — give what the oracle gives for each of them alone."""
+    batches = [pn.flatten(sampler_panel(v, 90, 40 + i)) for i, v in enumerate((130, 17, 400, 1, 64))]
+    empty = pn.flatten(sampler_panel(3, 90, 99)).slice(0, 0)
+    batches.insert(2, empty)
+    sampled, best = smp.sample_contigs(batches, 7)
+    for b, s, bs in zip(batches, sampled, best):
+        if b.n_variants == 0:
+            assert s.shape == (7, 0)
+            continue
+        want_paths, want_best = orc.sampler_run(b, 7)
+        assert np.array_equal(s, want_paths) and bs.tolist() == want_best.tolist()
+
+
+@pytest.mark.gpu
 def test_hip_sampler_errors():
     b = pn.flatten(sampler_panel(10, 5, 1))
     with pytest.raises(RuntimeError):
