@@ -1991,6 +1991,24 @@ struct ColScalars {
     }
 };
 
+// The u_i of a wave's R = 16 rows without an LDS round trip: every lane also adds up the column sum of index
+// i0 + (lane & 15) (each 16-lane DPP row then holds the wave's sixteen row values) and one v_mov_b64_dpp
+// row_newbcast:k per row pulls value k into all lanes of every row (gfx90a+: the only DPP form 64-bit moves have).
+// Before: c1 C parked in a wave-private LDS row and read back as 8 broadcast ds_read_b128 — 8 KB of LDS reads per
+// wave and column for 128 bytes of information, and the four lock-stepped waves queue behind one LDS pipe.
+template <int K>
+DEVI double row_bcast_f64(double v) {
+    // (old = the source itself: every lane has a valid source under row_newbcast, so no separate `old` register is set up)
+    return __longlong_as_double(__builtin_amdgcn_update_dpp(__double_as_longlong(v), __double_as_longlong(v), 0x150 + K, 0xF, 0xF, true));
+}
+template <int R>
+DEVI void lean_u_rows(double urep, double (&ui)[R]) {
+    static_assert(R == 16, "one DPP row of 16 lanes = the wave's 16 rows");
+    ui[0] = row_bcast_f64<0>(urep);   ui[1] = row_bcast_f64<1>(urep);   ui[2] = row_bcast_f64<2>(urep);   ui[3] = row_bcast_f64<3>(urep);
+    ui[4] = row_bcast_f64<4>(urep);   ui[5] = row_bcast_f64<5>(urep);   ui[6] = row_bcast_f64<6>(urep);   ui[7] = row_bcast_f64<7>(urep);
+    ui[8] = row_bcast_f64<8>(urep);   ui[9] = row_bcast_f64<9>(urep);   ui[10] = row_bcast_f64<10>(urep); ui[11] = row_bcast_f64<11>(urep);
+    ui[12] = row_bcast_f64<12>(urep); ui[13] = row_bcast_f64<13>(urep); ui[14] = row_bcast_f64<14>(urep); ui[15] = row_bcast_f64<15>(urep);
+}
 template <int R>
 DEVI double lean_colsum(const LeanShared<R>& sh, uint32_t pb, uint32_t lane) {
     if constexpr (R == 16)
@@ -2123,18 +2141,34 @@ DEVI void lean_forward(const DevContig& dc, LeanShared<R>& sh, uint32_t C, uint3
         LEAN_DEP(Cj); LEAN_STAMP(0);   // 0: record reads issued, column sums read and added
         const double ucol = cur.c1 * Cj;
         double ui[R];
+        v4f64 mfma_a = {0.0, 0.0, 0.0, 0.0};
+        bool mfma_split = false;  // (compile-time known on every path)
         if (kLX & 4u) {
 #pragma unroll
             for (int k = 0; k < R; ++k) ui[k] = ucol;
+        } else if constexpr (R == 16) {
+            // (the sixteen broadcasts fill the latency of the first MFMA of the total)
+            const double urep = cur.c1 * lean_colsum<R>(sh, pb, i0 + (lane & 15u));
+            const v4f64 zz = {0.0, 0.0, 0.0, 0.0};
+            mfma_a = __builtin_amdgcn_mfma_f64_16x16x4f64(Cj, 1.0, zz, 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            lean_u_rows<R>(urep, ui);
+            __builtin_amdgcn_sched_barrier(0);
+            mfma_split = true;
         } else {
             sh.u[wave][lane] = ucol;   // wave-private row: the u_i of this wave's rows come back as broadcasts
             const double* row = &sh.u[wave][i0];
 #pragma unroll
             for (int k = 0; k < R; ++k) ui[k] = row[k];
         }
-        __builtin_amdgcn_sched_barrier(0);  // the LDS round trip is in flight before the reduction starts
+        __builtin_amdgcn_sched_barrier(0);
         LEAN_DEP(ui[R - 1]); LEAN_STAMP(1);   // 1: u round trip (serialised by the stamp)
-        double S = (kLX & 2u) ? Cj * 64.0 : wave_total_mfma(Cj);
+        double S;
+        if (mfma_split) {
+            const v4f64 zz = {0.0, 0.0, 0.0, 0.0};
+            const v4f64 b = __builtin_amdgcn_mfma_f64_16x16x4f64((mfma_a[0] + mfma_a[1]) + (mfma_a[2] + mfma_a[3]), 1.0, zz, 0, 0, 0);
+            S = b[0];
+        } else S = (kLX & 2u) ? Cj * 64.0 : wave_total_mfma(Cj);
         LEAN_DEP(S); LEAN_STAMP(2);   // 2: MFMA total
         double uj = fma(cur.c2, S, ucol);
         double c0 = cur.c0;
@@ -2307,9 +2341,19 @@ DEVI void lean_backward(const DevContig& dc, LeanShared<R>& sh, uint32_t C, uint
         const double Cj = (kLX & 8u) ? w[0] * 64.0 : lean_colsum<R>(sh, pb, lane);
         const double ucol = k1 * Cj;
         double ui[R];
+        v4f64 mfma_a = {0.0, 0.0, 0.0, 0.0};
+        bool mfma_split = false;
         if (kLX & 4u) {
 #pragma unroll
             for (int k = 0; k < R; ++k) ui[k] = ucol;
+        } else if constexpr (R == 16) {
+            const double urep = k1 * lean_colsum<R>(sh, pb, i0 + (lane & 15u));
+            const v4f64 zz = {0.0, 0.0, 0.0, 0.0};
+            mfma_a = __builtin_amdgcn_mfma_f64_16x16x4f64(Cj, 1.0, zz, 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            lean_u_rows<R>(urep, ui);
+            __builtin_amdgcn_sched_barrier(0);
+            mfma_split = true;
         } else {
             sh.u[wave][lane] = ucol;
             const double* row = &sh.u[wave][i0];
@@ -2317,7 +2361,12 @@ DEVI void lean_backward(const DevContig& dc, LeanShared<R>& sh, uint32_t C, uint
             for (int k = 0; k < R; ++k) ui[k] = row[k];
         }
         __builtin_amdgcn_sched_barrier(0);
-        const double Sw = (kLX & 2u) ? Cj * 64.0 : wave_total_mfma(Cj);
+        double Sw;
+        if (mfma_split) {
+            const v4f64 zz = {0.0, 0.0, 0.0, 0.0};
+            const v4f64 b = __builtin_amdgcn_mfma_f64_16x16x4f64((mfma_a[0] + mfma_a[1]) + (mfma_a[2] + mfma_a[3]), 1.0, zz, 0, 0, 0);
+            Sw = b[0];
+        } else Sw = (kLX & 2u) ? Cj * 64.0 : wave_total_mfma(Cj);
         const double uj = fma(k2, Sw, ucol);
         const double Snew = kap * Sw;  // = sum(beta'_t)
         double eA, eB;
@@ -2482,12 +2531,13 @@ DEVI void lean2_forward(const DevContig& dc, LeanShared2<R>& sh2, uint32_t C) {
         const double Cj = lean_colsum<R>(sh, pb, lane);
         const double ucol = cur.c1 * Cj;
         double ui[R];
-        sh.u[wave][lane] = ucol;
-        const double* row = &sh.u[wave][i0];
-#pragma unroll
-        for (int k = 0; k < R; ++k) ui[k] = row[k];
+        const double urep = cur.c1 * lean_colsum<R>(sh, pb, i0 + (lane & 15u));
+        const v4f64 zz = {0.0, 0.0, 0.0, 0.0};
+        const v4f64 ma = __builtin_amdgcn_mfma_f64_16x16x4f64(Cj, 1.0, zz, 0, 0, 0);
         __builtin_amdgcn_sched_barrier(0);
-        double S = wave_total_mfma(Cj);
+        lean_u_rows<R>(urep, ui);  // (fills the latency of the first MFMA of the total)
+        __builtin_amdgcn_sched_barrier(0);
+        double S = __builtin_amdgcn_mfma_f64_16x16x4f64((ma[0] + ma[1]) + (ma[2] + ma[3]), 1.0, zz, 0, 0, 0)[0];
         double uj = fma(cur.c2, S, ucol);
         double c0 = cur.c0;
         if (__builtin_expect(!(S > 0.0), 0)) {
@@ -2608,12 +2658,13 @@ DEVI void lean2_backward(const DevContig& dc, LeanShared2<R>& sh2, uint32_t C) {
         const double Cj = lean_colsum<R>(sh, (uint32_t)t & 1u, lane);
         const double ucol = k1 * Cj;
         double ui[R];
-        sh.u[wave][lane] = ucol;
-        const double* row = &sh.u[wave][i0];
-#pragma unroll
-        for (int k = 0; k < R; ++k) ui[k] = row[k];
+        const double urep = k1 * lean_colsum<R>(sh, (uint32_t)t & 1u, i0 + (lane & 15u));
+        const v4f64 zz = {0.0, 0.0, 0.0, 0.0};
+        const v4f64 ma = __builtin_amdgcn_mfma_f64_16x16x4f64(Cj, 1.0, zz, 0, 0, 0);
         __builtin_amdgcn_sched_barrier(0);
-        const double Sw = wave_total_mfma(Cj);
+        lean_u_rows<R>(urep, ui);
+        __builtin_amdgcn_sched_barrier(0);
+        const double Sw = __builtin_amdgcn_mfma_f64_16x16x4f64((ma[0] + ma[1]) + (ma[2] + ma[3]), 1.0, zz, 0, 0, 0)[0];
         const double uj = fma(k2, Sw, ucol);
         const double Snew = kap * Sw;  // = sum(beta'_t)
         double eA, eB;
