@@ -1,6 +1,7 @@
 """Randomised parity soak (GPU box): many seeded panels of mixed shape, both sweep modes, small chunk
 sizes, narrow and wide columns, regularised and unregularised tables — HIP path vs the oracle.
-usage: python tools/soak_parity.py [n_panels] [seed0]   (80 panels: about two minutes)"""
+usage: python tools/soak_parity.py [n_panels] [seed0]   (80 panels: about two minutes)
+SOAK_TRI=1: only all-biallelic H = 64 panels in fused mode (triangle storage, k_sweep_lean2), from 1 variant up."""
 import os, sys, time
 sys.path.insert(0, os.getcwd())
 import numpy as np
@@ -22,6 +23,10 @@ for it in range(n):
     kw = dict(multiallelic_frac=multi, undefined_frac=float(rng.choice([0.0, 0.05, 0.3])), zero_kmer_frac=float(rng.choice([0.0, 0.05])))
     if wide:
         kw.update(max_alleles=int(rng.integers(6, 70)), local_alts=int(rng.integers(5, 60)), multiallelic_frac=max(multi, 0.2))
+    if os.environ.get("SOAK_TRI") == "1":
+        H, wide = 64, False
+        V = int(rng.choice([1, 2, 3, 4, 5, 7, 64, 65, 129, int(rng.integers(6, 900))]))
+        kw.update(multiallelic_frac=0.0)
     b = synthetic_panel(V, H, K, seed=int(rng.integers(1 << 30)), **kw)
     reg = float(rng.choice([0.01, 0.01, 0.0, 0.001]))
     if reg == 0.0:
@@ -33,8 +38,12 @@ for it in range(n):
     args = (6, 108, 54, reg)
     recomb, uniform, N = [(1.26, False, 1e-5), (1.26, True, 1e-5), (0.001, False, 1e-5), (446.287102628, False, 0.25), (1.26, False, 25000.0)][int(rng.integers(5))]
     mode = str(rng.choice(["fused", "chunked", "chunked"]))
+    if os.environ.get("SOAK_TRI") == "1":
+        mode = "fused"
     os.environ["PG_SWEEP_MODE"] = mode
     kern = str(rng.choice(["", "", "general", "generic"]))
+    if os.environ.get("SOAK_TRI") == "1":
+        kern = ""
     if kern:
         os.environ["PG_SWEEP_KERNEL"] = kern
     else:
