@@ -56,7 +56,7 @@ WORKLOADS = {
 # the sampler measurement: contigs x variants x panel paths, 15 passes (the reference's default panel size)
 SAMPLER = {"contigs": 8, "V": 40_000, "H": 215, "size": 15}
 # the cohort measurement: samples x contigs over one shared index
-COHORT = dict(samples=32, contigs=8, V=16_000, H=64, K=20)
+COHORT = dict(samples=64, contigs=8, V=16_000, H=64, K=20)  # 512 chains, 194 GB of the 288 (columns as compact triangles)
 # GRCh38 chromosome lengths (Mb) 1..22, X, Y: proportions of the 24 synthetic contigs
 CONTIG_MB = [248, 242, 198, 190, 181, 171, 159, 145, 138, 134, 135, 133, 114, 107, 102, 90, 83, 80, 59, 64, 47, 51, 156, 57]
 

@@ -128,7 +128,7 @@ struct DevContig {
     // forward role first); k_post forms the posteriors of a finished chunk on the idle CUs.
     double*   scratch;
     uint32_t  chunk_cols;
-    uint32_t  pad3;
+    uint32_t  col_stride;      // doubles between consecutive columns of `fwd`: HP*HP, or 2304 (the 18 KB of a compact triangle) when tri
     uint8_t*  wide;            // wide entries (see above)
     const uint32_t* wide_idx;  // [V]: byte offset / 16 of the entry of variant v, PG_WIDE_NONE if it has <= PG_AMAX alleles
     uint8_t*  vpair;           // [V][pg_pair_bytes(pair_n)]

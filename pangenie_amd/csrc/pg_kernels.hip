@@ -940,9 +940,9 @@ DEVI uint32_t tri_unit_of(uint32_t q /*row pair*/, uint32_t lane /* >= 8 (q >> 2
     return 256u * g - 16u * g * (g - 1u) + (q & 3u) * (64u - 8u * g) + (lane - 8u * g);
 }
 // loader `part` (of 2) moves transfers 9 part .. 9 part + 8 of the column's 18
-DEVI void dma_column_tri(const gdouble* cols, int64_t c, int64_t C, LAS unsigned char* ring, uint32_t part, uint32_t lane) {
+DEVI void dma_column_tri(const gdouble* cols, size_t stride, int64_t c, int64_t C, LAS unsigned char* ring, uint32_t part, uint32_t lane) {
     if (c < 0 || c >= C) return;
-    const GAS char* g = (const GAS char*)(cols + (size_t)c * 64u * 64u) + part * 9u * 1024u + lane * 16u;  // the stored half is compact
+    const GAS char* g = (const GAS char*)(cols + (size_t)c * stride) + part * 9u * 1024u + lane * 16u;  // the stored half is compact
     LAS unsigned char* l = ring + (uint32_t)((uint64_t)c % (uint32_t)kTriSlots) * kTriSlotB + part * 9u * 1024u;
 #pragma unroll
     for (uint32_t n = 0; n < 9u; ++n)
@@ -1156,13 +1156,13 @@ DEVI void forward_body(const DevContig& dc, ChainShared<HP, R>& sh, uint32_t C, 
                 // B_t).  A slot is rewritten by the issue of iteration c+1, after B_c closed the step that read it.
                 if (lw == 0)
                     for (int q = -1; q < 6; ++q) dma_record<Cfg::RB>(colrec, (int64_t)first + q, C, lrec, p.lane);
-                for (int q = 0; q < kTriDist; ++q) dma_column_tri(cols, (int64_t)lo + q, C, lring, lw, p.lane);
+                for (int q = 0; q < kTriDist; ++q) dma_column_tri(cols, dc.col_stride, (int64_t)lo + q, C, lring, lw, p.lane);
                 wait_vmem_all();
                 lds_barrier();  // P0
                 lds_barrier();  // Bx
                 for (uint32_t t = first; t < hi; ++t) {
                     if (lw == 0) dma_record<Cfg::RB>(colrec, (int64_t)t + 6, C, lrec, p.lane);
-                    dma_column_tri(cols, (int64_t)t + kTriDist, C, lring, lw, p.lane);
+                    dma_column_tri(cols, dc.col_stride, (int64_t)t + kTriDist, C, lring, lw, p.lane);
                     if ((int64_t)t + kTriDist >= (int64_t)C) wait_vmem_all();  // tail
                     else if (lw == 0) wait_vmem_keep<kTriKeep0>();
                     else wait_vmem_keep<kTriKeep1>();
@@ -1200,7 +1200,7 @@ DEVI void forward_body(const DevContig& dc, ChainShared<HP, R>& sh, uint32_t C, 
     gdouble* fwd = (gdouble*)dc.fwd;
     gdouble* fscale = (gdouble*)dc.fscale;
     gu8* fallback = (gu8*)dc.fwd_fallback;
-    const size_t colsz = (size_t)HP * HP;
+    const size_t colsz = tri ? (size_t)dc.col_stride : (size_t)HP * HP;
     const uint32_t dbg = dc.debug;
 
     // where this phase stores column c (c in [lo,hi)) and where the column to resume from lives
@@ -1518,12 +1518,12 @@ DEVI void backward_body(const DevContig& dc, ChainShared<HP, R>& sh, uint32_t C,
             if (tri) {  // triangle ring: see forward_body
                 if (lw == 0)
                     for (int q = -1; q < 5; ++q) dma_record<Cfg::RB>(colrec, t0 - q, (int64_t)C, lrec, p.lane);  // t0+1 .. t0-4
-                for (int q = 0; q < kTriDist; ++q) dma_column_tri(cols, t0 - q, (int64_t)C, lring, lw, p.lane);
+                for (int q = 0; q < kTriDist; ++q) dma_column_tri(cols, dc.col_stride, t0 - q, (int64_t)C, lring, lw, p.lane);
                 wait_vmem_all();
                 lds_barrier();  // P0
                 for (int64_t t = t0; t >= bot; --t) {
                     if (lw == 0) dma_record<Cfg::RB>(colrec, t - 5, (int64_t)C, lrec, p.lane);
-                    dma_column_tri(cols, t - kTriDist, (int64_t)C, lring, lw, p.lane);
+                    dma_column_tri(cols, dc.col_stride, t - kTriDist, (int64_t)C, lring, lw, p.lane);
                     if (t - kTriDist < 0) wait_vmem_all();  // tail
                     else if (lw == 0) wait_vmem_keep<kTriKeep0>();
                     else wait_vmem_keep<kTriKeep1>();
@@ -1560,7 +1560,7 @@ DEVI void backward_body(const DevContig& dc, ChainShared<HP, R>& sh, uint32_t C,
     gdouble* cols = (gdouble*)dc.fwd;
     gdouble* bscale = (gdouble*)dc.bscale;
     gdouble* bsum = (gdouble*)dc.bsum;
-    const size_t colsz = (size_t)HP * HP;
+    const size_t colsz = tri ? (size_t)dc.col_stride : (size_t)HP * HP;
 
     // where this phase stores column c (c in [bot,top]) and where the column to resume from lives
     gdouble* wr = cols;
@@ -2035,7 +2035,7 @@ DEVI void lean_forward(const DevContig& dc, LeanShared<R>& sh, uint32_t C, uint3
     const uint32_t tid = threadIdx.x, lane = tid & 63u;
     const uint32_t wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const uint32_t i0 = wave * R;
-    const size_t colsz = (size_t)HP * HP;
+    const size_t colsz = TRI ? (size_t)dc.col_stride : (size_t)HP * HP;
     const double unif = 1.0 / 4096.0;
     LeanRecs recs{(const GAS char*)dc.frec, (int64_t)first - 1, (int64_t)C, +1, tid};
     recs.park(sh, 0, recs.fetch(0));
@@ -2243,7 +2243,7 @@ DEVI void lean_backward(const DevContig& dc, LeanShared<R>& sh, uint32_t C, uint
     const uint32_t tid = threadIdx.x, lane = tid & 63u;
     const uint32_t wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const uint32_t i0 = wave * R;
-    const size_t colsz = (size_t)HP * HP;
+    const size_t colsz = TRI ? (size_t)dc.col_stride : (size_t)HP * HP;
     const double unif = 1.0 / 4096.0;
     LeanRecs recs{(const GAS char*)dc.frec, t0 + 1, (int64_t)C, -1, tid};
     recs.park(sh, 0, recs.fetch(0));
@@ -2474,7 +2474,7 @@ DEVI void lean2_forward(const DevContig& dc, LeanShared2<R>& sh2, uint32_t C) {
     const uint32_t tid = threadIdx.x, lane = tid & 63u;
     const uint32_t wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const uint32_t i0 = wave * R;
-    const size_t colsz = (size_t)HP * HP;
+    const size_t colsz = dc.col_stride;  // compact triangles
     const double unif = 1.0 / 4096.0;
     LeanRecs recs{(const GAS char*)dc.frec, (int64_t)first - 1, (int64_t)C, +1, tid};
     recs.park(sh, 0, recs.fetch(0));
@@ -2595,7 +2595,7 @@ DEVI void lean2_backward(const DevContig& dc, LeanShared2<R>& sh2, uint32_t C) {
     const uint32_t tid = threadIdx.x, lane = tid & 63u;
     const uint32_t wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const uint32_t i0 = wave * R;
-    const size_t colsz = (size_t)HP * HP;
+    const size_t colsz = dc.col_stride;  // compact triangles
     const double unif = 1.0 / 4096.0;
     LeanRecs recs{(const GAS char*)dc.frec, t0 + 1, (int64_t)C, -1, tid};
     recs.park(sh, 0, recs.fetch(0));
@@ -3580,7 +3580,7 @@ __global__ __launch_bounds__(256) void k_bins(const DevContig* __restrict__ cont
         // backward column beta'_c (slot c, row-pair layout).  Rare path.
         const uint32_t H = dc.H;
         const double unif = 1.0 / ((double)H * (double)H);
-        const double* col = dc.fwd + (size_t)c * HP * HP;
+        const double* col = dc.fwd + (size_t)c * dc.col_stride;
         for (uint32_t a = 0; a < nl; ++a)
             for (uint32_t b = 0; b < nl; ++b) {
                 double s = 0.0;

@@ -560,6 +560,7 @@ int job_build(int device, uint32_t n_index, const pg_contig_batch* batches, cons
         x.o_goff = take(((size_t)x.V + 1) * 8);
         x.o_widx = take(x.wide_bytes ? (size_t)x.V * 4 : 0);
     }
+    std::vector<char> tri_of_chain(n_chains, 0);
     for (uint32_t c = 0; c < n_chains; ++c) {
         ChainHost& ch = job->chains[c];
         const IndexHost& x = job->index[ch.index];
@@ -568,7 +569,12 @@ int job_build(int device, uint32_t n_index, const pg_contig_batch* batches, cons
         p.vrec = take((size_t)x.V * x.RB);
         p.cvar = take((size_t)x.V * 4);
         p.colrec = take((size_t)x.V * x.RB);
-        p.fwd = take((size_t)x.V * x.HP * x.HP * sizeof(double));
+        // fused jobs: lean chains store / read their columns as compact upper triangles (18 KB instead of 32 KB per
+        // column: half the sweep's HBM bytes and of the arena); PG_TRI=0 keeps full columns (cross-check)
+        const char* tri_env = getenv("PG_TRI");
+        const bool tri = x.lean && !job->chunked && !(tri_env && !strcmp(tri_env, "0"));
+        tri_of_chain[c] = tri;
+        p.fwd = take((size_t)x.V * (tri ? 2304u : (size_t)x.HP * x.HP) * sizeof(double));
         // fused mode: posterior partials; chunked mode: the chunk scratch instead (k_post writes lik directly)
         p.part = take(job->chunked ? 0 : (size_t)x.V * x.part_slots * x.T * sizeof(double));
         p.scratch = take(job->chunked ? (size_t)4 * job->chunk_cols * x.HP * x.HP * sizeof(double) : 0);
@@ -648,11 +654,8 @@ int job_build(int device, uint32_t n_index, const pg_contig_batch* batches, cons
         d.wide = A + p.wide; d.wide_idx = x.wide_bytes ? (const uint32_t*)(A + x.o_widx) : nullptr;
         d.vpair = A + p.vpair; d.xbuf = (double*)(A + p.xbuf);
         d.frec = (double*)(A + p.frec); d.lean = x.lean ? 1u : 0u;
-        // fused jobs: lean chains store / read their columns as upper triangles (half the sweep's HBM bytes);
-        // PG_TRI=0 keeps full columns (cross-check)
-        const char* tri_env = getenv("PG_TRI");
-        const bool tri_ok = !(tri_env && !strcmp(tri_env, "0"));
-        d.tri = (x.lean && !job->chunked && tri_ok) ? 1u : 0u;
+        d.tri = tri_of_chain[c] ? 1u : 0u;
+        d.col_stride = d.tri ? 2304u : x.HP * x.HP;
         if (d.tri) job->hp_mask |= 128u;
         ch.d = d;
     }
