@@ -136,7 +136,7 @@ struct DevContig {
     // {c0, c1, c2, kappa, E'00, E'01, E'11, bits1} (64 B, read with scalar loads) and the flag
     double*   frec;            // [V][8]
     uint32_t  lean;            // 1: the store-only phases of this chain run on k_sweep_lean
-    // 1 (lean chains of FUSED jobs): phase 1 stores only the upper triangle of its (symmetric) columns, COMPACT at the
+    // 1 or 2 (lean chains of FUSED jobs; 2: phase 2 on k_sweep_lean2, 1: on the general kernel's triangle ring): phase 1 stores only the upper triangle of its (symmetric) columns, COMPACT at the
     // start of the column's slot (1152 16-byte units: row pair q, lanes 8 (q >> 2) .. 63, see tri_unit_of); elements
     // below the diagonal inside those units are written as 0, the diagonal is stored HALVED — so that phase 2 can
     // take the posterior sums over the stored half alone and k_bins doubles them: half the HBM bytes written by

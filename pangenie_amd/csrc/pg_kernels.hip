@@ -871,10 +871,8 @@ DEVI RecInfo decode_record(const unsigned char* rec, uint32_t j, uint32_t i0, bo
 // Partner-column ring: PG_RING_SLOTS column slots in dynamic LDS, prefetch distance SLOTS-1 columns.
 // 4 slots (128 KB at HP = 64) give every DMA two full steps to land — what a lone workgroup per CU
 // needs; 2 slots (64 KB) let two workgroups share a CU when hundreds of chains are resident.
-#ifndef PG_LEAN2
-#define PG_LEAN2 1
-#endif
-static constexpr bool kLean2 = PG_LEAN2 != 0;  // phase 2 of triangle chains on k_sweep_lean2 (0: on the general kernel's triangle ring)
+// DevContig::tri == 2: phase 2 of the chain runs on k_sweep_lean2 (the default for triangle chains); == 1 (PG_LEAN2=0):
+// on the general kernel's triangle ring (cross-check of the two phase-2 implementations)
 #ifndef PG_RING_SLOTS
 #define PG_RING_SLOTS 4
 #endif
@@ -1867,7 +1865,7 @@ __global__ __launch_bounds__((ChainCfg<HP, R>::TT)) void k_sweep(const DevContig
     // with it every column index, ring slot and address derived from it, wave-uniform again)
     const uint32_t C = (uint32_t)__builtin_amdgcn_readfirstlane((int)*dc.n_cols);
     if (C == 0) return;
-    if (PHASE == 2 && kLean2 && dc.tri && C >= 2) return;  // triangle chains: k_sweep_lean2
+    if (PHASE == 2 && dc.tri == 2u && C >= 2) return;  // triangle chains: k_sweep_lean2
     if constexpr (PHASE == 2 && HP == 64 && ChainCfg<HP, R>::LOADER) {
         // triangle ring (DevContig::tri): the unit of zeros that stands for everything below the diagonal; first read
         // behind the P0 barrier of the bodies
@@ -2705,7 +2703,7 @@ __global__ __launch_bounds__((64 * 64 / R)) __attribute__((amdgpu_waves_per_eu(2
 void k_sweep_lean2(const DevContig* __restrict__ contigs) {
     __shared__ LeanShared2<R> sh;
     const DevContig& dc = contigs[blockIdx.x];
-    if (!dc.lean || !dc.tri) return;
+    if (!dc.lean || dc.tri != 2u) return;
     const uint32_t C = (uint32_t)__builtin_amdgcn_readfirstlane((int)*dc.n_cols);
     if (C < 2) return;  // (a single column: the general kernel)
     if (blockIdx.y == 0) lean2_forward<R>(dc, sh, C);
@@ -3607,7 +3605,7 @@ __global__ __launch_bounds__(256) void k_bins(const DevContig* __restrict__ cont
         // the column allele of thread t is al[t % HP].  All of a lane's 16-byte loads of a pair are
         // issued together, then split by column allele with selects (no dynamic register indexing).
         // triangle chains with >= 2 columns (k_sweep_lean2): the four waves' partials arrive added up, 64 per column
-        const bool l2 = kLean2 && dc.tri && C >= 2;
+        const bool l2 = dc.tri == 2u && C >= 2;
         const uint32_t Tn = l2 ? 64u : T;
         const v2f64* base = l2 ? (const v2f64*)dc.part + (size_t)c * 64u : (const v2f64*)dc.part + (size_t)c * (dc.part_slots >> 1) * T;
         const uint32_t nq = (nl + 1u) >> 1;
@@ -3900,7 +3898,7 @@ static void launch_sweep(const DevContig* d_contigs, uint32_t n_contigs, uint32_
     if (hp_mask & 4u) launch_one<64, 16, 1, true, PHASE>(d_contigs, n_contigs, chunk, s);
     if (hp_mask & 8u) launch_one<128, 32, 1, false, PHASE>(d_contigs, n_contigs, chunk, s);
     if constexpr (PHASE == 2) {
-        if (kLean2 && (hp_mask & 128u)) hipLaunchKernelGGL((k_sweep_lean2<16>), dim3(n_contigs, 2), dim3(256), 0, s, d_contigs);
+        if (hp_mask & 256u) hipLaunchKernelGGL((k_sweep_lean2<16>), dim3(n_contigs, 2), dim3(256), 0, s, d_contigs);  // bit 8: chains with tri == 2
     }
     if constexpr (PHASE != 2) {
         if (hp_mask & 64u) {  // bit 6: the job has lean chains (all-biallelic, H = HP = 64)

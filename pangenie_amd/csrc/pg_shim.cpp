@@ -654,9 +654,11 @@ int job_build(int device, uint32_t n_index, const pg_contig_batch* batches, cons
         d.wide = A + p.wide; d.wide_idx = x.wide_bytes ? (const uint32_t*)(A + x.o_widx) : nullptr;
         d.vpair = A + p.vpair; d.xbuf = (double*)(A + p.xbuf);
         d.frec = (double*)(A + p.frec); d.lean = x.lean ? 1u : 0u;
-        d.tri = tri_of_chain[c] ? 1u : 0u;
+        const char* l2_env = getenv("PG_LEAN2");  // 0: phase 2 of triangle chains on the general kernel's triangle ring
+        d.tri = tri_of_chain[c] ? ((l2_env && !strcmp(l2_env, "0")) ? 1u : 2u) : 0u;
         d.col_stride = d.tri ? 2304u : x.HP * x.HP;
         if (d.tri) job->hp_mask |= 128u;
+        if (d.tri == 2u) job->hp_mask |= 256u;
         ch.d = d;
     }
     if ((he = hipMemcpyAsync(job->d_contigs, hd.data(), sizeof(DevContig) * n_chains, hipMemcpyHostToDevice, job->stream)) != hipSuccess ||

@@ -367,13 +367,15 @@ def test_pipelined_lean_step_vs_oracle_and_plain(K, orc, monkeypatch):
         assert float(np.where(den > 0, np.abs(a - c) / np.where(den > 0, den, 1), 0).max()) < 1e-11
 
 
+@pytest.mark.parametrize("lean2", ["1", "0"])
 @pytest.mark.parametrize("C_odd", [False, True])
-def test_triangle_storage_fused_lean_vs_oracle_and_full_columns(C_odd, orc, monkeypatch):
+def test_triangle_storage_fused_lean_vs_oracle_and_full_columns(C_odd, lean2, orc, monkeypatch):
     """Fused jobs store the (symmetric) columns of lean chains as upper triangles — diagonal halved, nothing
     below it — and phase 2 sums the stored half (k_bins doubles).  Unregularised table: forward fall-backs in
     both halves (the stored uniform column, the re-formed bins of k_bins) and all-zero backward columns go
     through the triangle path; PG_TRI=0 (full columns) must give the same bins to fp64 rounding."""
     monkeypatch.setenv("PG_SWEEP_MODE", "fused")
+    monkeypatch.setenv("PG_LEAN2", lean2)  # phase 2 on k_sweep_lean2 (default) or on the general kernel's triangle ring
     for seed, reg in ((15, 0.0), (16, 0.01), (17, 0.0)):
         args = (6, 108, 54, reg)
         b = synthetic_panel(331 if C_odd else 330, 64, 20, seed=seed)
