@@ -484,3 +484,142 @@ done:
     free(x.col_variant); free(x.slot_of_path); free(x.geno_off);
     return rc;
 }
+
+/* ------------------------------------------------------------------ */
+/*  Viterbi (phasing)                                                  */
+/* ------------------------------------------------------------------ */
+
+/* HMM::compute_viterbi_path / compute_viterbi_column, reference src/hmm.cpp:112-173, :408-511.
+ * Max-product over ordered path pairs; a column is divided by its sum (uniform if the sum is 0, :484-491); ties are
+ * resolved by `>=` while scanning the previous states in index order, so the LAST maximum wins (:468, :139).
+ *   form 0: the reference's loop itself — every state scans all H^2 previous states (O(H^4) per column)
+ *   form 1: the same maximum from the row / column / global maxima of the previous column (t0 >= t1 >= t2, so
+ *           max_j prev[j] t(j -> i) = max(t0 prev[i], t1 rowmax, t1 colmax, t2 gmax)); among equal values the largest
+ *           index, and the last index of all when every product is 0 — what the scan ends on.  O(H^2) per column.
+ * The reference keeps sqrt(C) columns and recomputes the rest while backtracking (:118-128, :152-158); recomputed
+ * columns are the same values, so all backtrace columns are simply kept here.
+ * hap1/hap2[v]: alleles of the two haplotypes at kept variants (GenotypingResult::add_first/second_haplotype_allele),
+ * 0 elsewhere.  n_kmers / coverage: set at index c (the COLUMN index, sic: reference :164-165) for c < C. */
+int pgo_viterbi_contig(const pg_contig_batch* b, const pgo_table* t, const pg_hmm_params* p, int form,
+                       uint16_t* hap1, uint16_t* hap2, uint8_t* kept, uint32_t* n_columns,
+                       uint16_t* n_kmers, uint16_t* coverage) {
+    const uint32_t V = b->n_variants, H = b->n_paths;
+    if (V > 0 && H == 0) return PG_ERR_NO_PATHS;
+    memset(hap1, 0, sizeof(uint16_t) * V);
+    memset(hap2, 0, sizeof(uint16_t) * V);
+    memset(kept, 0, V);
+    memset(n_kmers, 0, sizeof(uint16_t) * V);
+    memset(coverage, 0, sizeof(uint16_t) * V);
+    uint32_t* col_variant = (uint32_t*)malloc(sizeof(uint32_t) * ((size_t)V + 1));
+    uint16_t* slot_of_path = (uint16_t*)malloc(sizeof(uint16_t) * ((size_t)V * H + 1));
+    uint32_t C = 0, maxA = 1;
+    int rc = PG_OK;
+    long double *emis = NULL, *prev = NULL, *cur = NULL, *rowmax = NULL, *colmax = NULL;
+    uint32_t *back = NULL, *rowidx = NULL, *colidx = NULL;
+    for (uint32_t v = 0; v < V; ++v) { /* ColumnIndexer, src/columnindexer.cpp:8-33 */
+        uint32_t A = b->allele_off[v + 1] - b->allele_off[v];
+        if (A > maxA) maxA = A;
+        int all_absent = 1;
+        for (uint32_t pth = 0; pth < H; ++pth) {
+            uint16_t a = b->path_allele[(size_t)v * H + pth];
+            int s = slot_of_allele(b, v, a);
+            if (s < 0) { rc = PG_ERR_INVALID; goto done; }
+            slot_of_path[(size_t)v * H + pth] = (uint16_t)s;
+            if (a != 0 && !(b->allele_flags[b->allele_off[v] + s] & 1)) all_absent = 0;
+        }
+        if (!all_absent) { col_variant[C++] = v; kept[v] = 1; }
+    }
+    *n_columns = C;
+    if (C == 0) goto done; /* :114 */
+    {
+        const size_t n = (size_t)H * H;
+        emis = (long double*)malloc(sizeof(long double) * (size_t)maxA * maxA);
+        prev = (long double*)malloc(sizeof(long double) * n);
+        cur = (long double*)malloc(sizeof(long double) * n);
+        rowmax = (long double*)malloc(sizeof(long double) * H);
+        colmax = (long double*)malloc(sizeof(long double) * H);
+        rowidx = (uint32_t*)malloc(sizeof(uint32_t) * H);
+        colidx = (uint32_t*)malloc(sizeof(uint32_t) * H);
+        back = (uint32_t*)malloc(sizeof(uint32_t) * n * C);
+        if (!emis || !prev || !cur || !rowmax || !colmax || !rowidx || !colidx || !back) { rc = PG_ERR_NOMEM; goto done; }
+        for (uint32_t c = 0; c < C; ++c) { /* compute_viterbi_column, :408-511 */
+            const uint32_t v = col_variant[c];
+            const uint32_t A = b->allele_off[v + 1] - b->allele_off[v];
+            long double tp[3] = {1.0L, 1.0L, 1.0L};
+            if (c > 0)
+                pgo_transition_probs(b->variant_pos[col_variant[c - 1]], b->variant_pos[v], p->recombrate, H, p->uniform,
+                                     p->effective_N, tp); /* :420-428 */
+            pgo_emission_table(b, t, v, emis, NULL); /* :434 */
+            long double gmax = 0.0L;
+            uint32_t gidx = 0;
+            if (c > 0 && form == 1) {
+                for (uint32_t a = 0; a < H; ++a) { rowmax[a] = colmax[a] = 0.0L; rowidx[a] = colidx[a] = 0; }
+                for (size_t j = 0; j < n; ++j) {
+                    const uint32_t q1 = (uint32_t)(j / H), q2 = (uint32_t)(j % H);
+                    if (prev[j] >= rowmax[q1]) { rowmax[q1] = prev[j]; rowidx[q1] = (uint32_t)j; }
+                    if (prev[j] >= colmax[q2]) { colmax[q2] = prev[j]; colidx[q2] = (uint32_t)j; }
+                    if (prev[j] >= gmax) { gmax = prev[j]; gidx = (uint32_t)j; }
+                }
+            }
+            const uint16_t* slots = slot_of_path + (size_t)v * H;
+            long double normalization_sum = 0.0L;
+            size_t i = 0;
+            for (uint32_t p1 = 0; p1 < H; ++p1) {
+                for (uint32_t p2 = 0; p2 < H; ++p2) {
+                    long double previous_cell = 1.0L;
+                    if (c > 0) {
+                        long double max_value = 0.0L;
+                        size_t max_index = 0;
+                        if (form == 0) { /* :446-473 */
+                            size_t j = 0;
+                            for (uint32_t q1 = 0; q1 < H; ++q1)
+                                for (uint32_t q2 = 0; q2 < H; ++q2) {
+                                    long double prev_prob = prev[j];
+                                    prev_prob *= tp[(q1 != p1) + (q2 != p2)]; /* compute_transition_prob, transitionprobabilitycomputer.cpp:21-31 */
+                                    if (prev_prob >= max_value) { max_value = prev_prob; max_index = j; }
+                                    j += 1;
+                                }
+                        } else {
+                            const long double cv[4] = {prev[i] * tp[0], rowmax[p1] * tp[1], colmax[p2] * tp[1], gmax * tp[2]};
+                            const size_t ci[4] = {i, rowidx[p1], colidx[p2], gidx};
+                            for (int q = 0; q < 4; ++q)
+                                if (cv[q] > max_value || (cv[q] == max_value && ci[q] >= max_index)) { max_value = cv[q]; max_index = ci[q]; }
+                            if (max_value == 0.0L) max_index = n - 1; /* every product is 0: the scan ends on the last state */
+                        }
+                        previous_cell = max_value;
+                        back[(size_t)c * n + i] = (uint32_t)max_index;
+                    }
+                    long double emission_prob = emis[(size_t)slots[p1] * A + slots[p2]];
+                    long double current_cell = previous_cell * emission_prob;
+                    cur[i] = current_cell;
+                    normalization_sum += current_cell;
+                    i += 1;
+                }
+            }
+            if (normalization_sum > 0.0L) { /* :484-491 */
+                for (size_t s = 0; s < n; ++s) cur[s] = cur[s] / normalization_sum;
+            } else {
+                long double uniform = 1.0L / (long double)n;
+                for (size_t s = 0; s < n; ++s) cur[s] = uniform;
+            }
+            long double* tmp = prev; prev = cur; cur = tmp;
+        }
+        /* best state of the last column (:131-141), backtracking (:144-172) */
+        size_t best_index = 0;
+        long double best_value = 0.0L;
+        for (size_t s = 0; s < n; ++s)
+            if (prev[s] >= best_value) { best_value = prev[s]; best_index = s; }
+        for (uint32_t c = C; c-- > 0;) {
+            const uint32_t v = col_variant[c];
+            hap1[v] = b->path_allele[(size_t)v * H + best_index / H];
+            hap2[v] = b->path_allele[(size_t)v * H + best_index % H];
+            n_kmers[c] = (uint16_t)(b->kmer_off[c + 1] - b->kmer_off[c]); /* sic: by column index, :164-165 */
+            coverage[c] = b->coverage[c];
+            if (c > 0) best_index = back[(size_t)c * n + best_index];
+        }
+    }
+done:
+    free(emis); free(prev); free(cur); free(rowmax); free(colmax); free(rowidx); free(colidx); free(back);
+    free(col_variant); free(slot_of_path);
+    return rc;
+}

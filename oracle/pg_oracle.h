@@ -73,6 +73,13 @@ typedef struct pgo_result {
 int pgo_genotype_contig(const pg_contig_batch* b, const pgo_table* t,
                         const pg_hmm_params* p, pgo_result* out);
 
+/* HMM with run_phasing: Viterbi path over ordered path pairs (reference src/hmm.cpp:112-173, :408-511).
+ * form 0 = the reference's O(H^4) loop, form 1 = the same maxima in O(H^2) (see pg_oracle.c).
+ * hap1/hap2 [V]: haplotype alleles at kept variants; n_kmers / coverage [V]: set at the COLUMN index (sic). */
+int pgo_viterbi_contig(const pg_contig_batch* b, const pgo_table* t, const pg_hmm_params* p, int form,
+                       uint16_t* hap1, uint16_t* hap2, uint8_t* kept, uint32_t* n_columns,
+                       uint16_t* n_kmers, uint16_t* coverage);
+
 /* HaplotypeSampler restatement (pg_sampler_oracle.c; reference src/haplotypesampler.cpp,
  * src/samplingemissions.cpp, src/samplingtransitions.cpp): same flat batch, over all panel paths. */
 void pgo_sampler_emission_costs(const pg_contig_batch* b, uint16_t* cost_sumA);

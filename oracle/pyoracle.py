@@ -64,6 +64,9 @@ def load():
         lib.pgo_genotype_contig.argtypes = [C.POINTER(PgContigBatch), C.c_void_p,
                                             C.POINTER(PgHmmParams), C.POINTER(PgoResult)]
         lib.pgo_genotype_contig.restype = C.c_int
+        lib.pgo_viterbi_contig.argtypes = [C.POINTER(PgContigBatch), C.c_void_p, C.POINTER(PgHmmParams), C.c_int,
+                                           u16p, u16p, u8p, u32p, u16p, u16p]
+        lib.pgo_viterbi_contig.restype = C.c_int
         lib.pgo_geno_offsets.argtypes = [C.POINTER(PgContigBatch), u64p]
         lib.pgo_geno_offsets.restype = None
         lib.pgo_sampler_emission_costs.argtypes = [C.POINTER(PgContigBatch), u16p]
@@ -182,6 +185,36 @@ def genotype_contig(batch, table: OracleTable, params: PgHmmParams) -> OracleRes
     if rc:
         raise RuntimeError(f"oracle error {rc}")
     r.n_columns = int(c.n_columns)
+    return r
+
+
+class OraclePhasing:
+    """hap1 / hap2 [V]: Viterbi haplotype alleles at kept variants (0 elsewhere)."""
+
+    def __init__(self, V):
+        n = max(V, 1)
+        self.hap1 = np.zeros(n, np.uint16)
+        self.hap2 = np.zeros(n, np.uint16)
+        self.kept = np.zeros(n, np.uint8)
+        self.n_kmers = np.zeros(n, np.uint16)
+        self.coverage = np.zeros(n, np.uint16)
+        self.n_columns = 0
+
+
+def viterbi_contig(batch, table: OracleTable, params: PgHmmParams, form: int = 0) -> OraclePhasing:
+    """HMM::compute_viterbi_path restated in long double (reference src/hmm.cpp:112-173, :408-511);
+    form 0 = the reference's O(H^4) loop, form 1 = the same maxima in O(H^2)."""
+    V = batch.n_variants
+    r = OraclePhasing(V)
+    nc = np.zeros(1, np.uint32)
+    rc = load().pgo_viterbi_contig(C.byref(batch.as_c()), table.h, C.byref(params), int(form),
+                                   r.hap1.ctypes.data_as(u16p), r.hap2.ctypes.data_as(u16p), r.kept.ctypes.data_as(u8p),
+                                   nc.ctypes.data_as(u32p), r.n_kmers.ctypes.data_as(u16p), r.coverage.ctypes.data_as(u16p))
+    if rc:
+        raise RuntimeError(f"oracle error {rc}")
+    r.n_columns = int(nc[0])
+    for name in ("hap1", "hap2", "kept", "n_kmers", "coverage"):
+        setattr(r, name, getattr(r, name)[:V])
     return r
 
 

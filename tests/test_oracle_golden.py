@@ -53,6 +53,35 @@ def test_hmm_known_answers(golden):
             assert np.allclose([triple(g) for g in res], case["expected_after_normalize"], rtol=0, atol=TOL)
 
 
+def test_viterbi_known_answer_and_forms(golden):
+    """HMM(run_phasing=true): the reference's own haplotype pin (tests/HMMTest.cpp:393-439) on both forms of the oracle's
+    Viterbi, then form 1 (O(H^2)) == form 0 (the reference's O(H^4) loop) on every HMM fixture and on seeded panels."""
+    for case in golden["hmm"]:
+        batch = build_batch(case["variants"], case["hmm"]["only_paths"])
+        table = make_table(case["table"])
+        h = case["hmm"]
+        params = orc.make_params(h["recombrate"], h["uniform"], h["effective_N"], run_genotyping=False, run_phasing=True)
+        a = orc.viterbi_contig(batch, table, params, form=0)
+        b = orc.viterbi_contig(batch, table, params, form=1)
+        for name in ("hap1", "hap2", "kept", "n_kmers", "coverage"):
+            assert np.array_equal(getattr(a, name), getattr(b, name)), (case["name"], name)
+        assert a.n_columns == b.n_columns
+        if "expected_haplotype1" in case:
+            e1, e2 = case["expected_haplotype1"], case["expected_haplotype2"]
+            got1, got2 = a.hap1.tolist(), a.hap2.tolist()
+            assert (got1 == e1 and got2 == e2) or (got1 == e2 and got2 == e1), case["name"]
+    from pangenie_amd.panel import synthetic_panel
+    table = orc.OracleTable(6, 108, 54, 0.01)
+    for seed, (V, H, multi) in enumerate([(60, 5, 0.0), (80, 12, 0.3), (50, 20, 0.2), (40, 7, 0.5)]):
+        batch = synthetic_panel(V, H, seed=400 + seed, multiallelic_frac=multi)
+        for recomb, effn, uni in ((1.26, 25000.0, False), (1.26, 1e-5, False), (0.0, 25000.0, False), (1.26, 25000.0, True)):
+            params = orc.make_params(recomb, uni, effn, run_genotyping=False, run_phasing=True)
+            a = orc.viterbi_contig(batch, table, params, form=0)
+            b = orc.viterbi_contig(batch, table, params, form=1)
+            assert np.array_equal(a.hap1, b.hap1) and np.array_equal(a.hap2, b.hap2), (seed, recomb, effn, uni)
+            assert a.n_columns == b.n_columns > 0
+
+
 def test_hmm_combine(golden):
     by_name = {c["name"]: c for c in golden["hmm"]}
     a = run_case(by_name[golden["combine"]["first"]])[2]
