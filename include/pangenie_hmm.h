@@ -3,7 +3,8 @@
  *
  * This is the drop-in boundary: everything the reference does inside
  *     HMM::HMM(...)                      (reference src/hmm.hpp:38, src/hmm.cpp:25-63)
- * for run_genotyping=true — ColumnIndexer (src/columnindexer.cpp:8-33),
+ * for run_genotyping=true (and run_phasing=true: the Viterbi path, src/hmm.cpp:112-173, 408-511,
+ * pangenie_amd/csrc/pg_viterbi.hip) — ColumnIndexer (src/columnindexer.cpp:8-33),
  * EmissionProbabilityComputer (src/emissionprobabilitycomputer.cpp:9-53),
  * TransitionProbabilityComputer (src/transitionprobabilitycomputer.cpp:8-19),
  * forward/backward columns + posterior accumulation (src/hmm.cpp:76-110, 175-405) —
@@ -44,7 +45,7 @@ extern "C" {
 #define PG_OK 0
 #define PG_ERR_INVALID (-1)     /* bad argument / malformed batch            */
 #define PG_ERR_NO_PATHS (-2)    /* "column is not covered by any paths"      */
-#define PG_ERR_UNSUPPORTED (-3) /* not on the device path: run_phasing, > 1024 selected paths, > 256 alleles per variant */
+#define PG_ERR_UNSUPPORTED (-3) /* device limits: > 1024 selected paths (> 64 with run_phasing), > 256 alleles per variant */
 #define PG_ERR_DEVICE (-4)      /* HIP runtime error / no GPU                */
 #define PG_ERR_NOMEM (-5)
 
@@ -79,7 +80,8 @@ typedef struct pg_hmm_params {
     double recombrate;       /* default 1.26                                                     */
     int32_t uniform;         /* uniform transition probabilities                                 */
     int32_t run_genotyping;  /* forward-backward                                                 */
-    int32_t run_phasing;     /* Viterbi: not on the device path -> PG_ERR_UNSUPPORTED            */
+    int32_t run_phasing;     /* Viterbi path over ordered path pairs (src/hmm.cpp:112-173, 408-511): */
+                             /* fills haplotype_1 / haplotype_2; at most 64 selected paths          */
     int32_t reserved;
 } pg_hmm_params;
 
@@ -101,6 +103,12 @@ typedef struct pg_contig_result {
     uint16_t* coverage;       /* [V] GenotypingResult::set_coverage                           */
     uint32_t  n_columns;      /* C = ColumnIndexer::size()                                    */
     uint32_t  reserved;
+    /* run_phasing only (may be NULL): alleles of the Viterbi path's two haplotypes at kept variants  */
+    /* (GenotypingResult::add_first/second_haplotype_allele, src/hmm.cpp:146-162), 0 elsewhere.  With */
+    /* run_phasing the reference also sets unique_kmers / coverage of results[c] for every COLUMN     */
+    /* index c < C from variant c (sic, src/hmm.cpp:164-165): n_kmers / coverage above follow that.   */
+    uint16_t* haplotype_1;    /* [V] */
+    uint16_t* haplotype_2;    /* [V] */
 } pg_contig_result;
 
 /* geno_off[V+1] from allele_off: geno_off[v+1]-geno_off[v] = A_v*(A_v+1)/2. */
@@ -169,6 +177,8 @@ int  pg_job_sweep_mode(const pg_job* job, uint32_t* chunk_cols);
  * H = 64: the columns are symmetric, so phase 1 writes and phase 2 reads only the stored half — half of the
  * 16 H^2 bytes per variant of the full formulation; PG_TRI=0 turns it off).  For traffic accounting. */
 uint32_t pg_job_triangle_chains(const pg_job* job);
+/* Elapsed milliseconds of the Viterbi kernels (run_phasing) of the LAST pg_job_run, hipEvents on the launch stream. */
+double pg_job_viterbi_ms(const pg_job* job);
 void pg_job_destroy(pg_job* job);
 
 /* pg_job_create with an error code instead of a NULL: PG_ERR_INVALID (malformed batch),

@@ -69,6 +69,8 @@ class PgContigResult(C.Structure):
         ("coverage", u16p),
         ("n_columns", C.c_uint32),
         ("reserved", C.c_uint32),
+        ("haplotype_1", u16p),
+        ("haplotype_2", u16p),
     ]
 
 
@@ -126,6 +128,8 @@ def _bind_hip(lib):
     lib.pg_job_kernel_name.restype = C.c_char_p
     lib.pg_job_profile_counters.argtypes = [C.c_void_p, C.c_uint32, u64p]
     lib.pg_job_profile_counters.restype = C.c_int
+    lib.pg_job_viterbi_ms.argtypes = [C.c_void_p]
+    lib.pg_job_viterbi_ms.restype = C.c_double
     lib.pg_job_device_bytes.argtypes = [C.c_void_p]
     lib.pg_job_device_bytes.restype = C.c_uint64
     lib.pg_job_sweep_mode.argtypes = [C.c_void_p, C.POINTER(C.c_uint32)]
@@ -186,7 +190,7 @@ HIP_ABI_SYMBOLS = [
     "pg_job_device_results", "pg_job_profile_counters", "pg_job_kernel_ms", "pg_job_kernel_name", "pg_job_device_bytes", "pg_job_sweep_mode",
     "pg_job_destroy", "pg_emission_table", "pg_transition_probs",
     "pg_job_new", "pg_cohort_new", "pg_job_n_chains", "pg_job_upload", "pg_job_host_seconds", "pg_job_upload_bytes",
-    "pg_job_packed_results", "pg_hmm_release_cache", "pg_job_triangle_chains",
+    "pg_job_packed_results", "pg_hmm_release_cache", "pg_job_triangle_chains", "pg_job_viterbi_ms",
     "pg_comm_unique_id", "pg_comm_init", "pg_comm_init_all", "pg_comm_rank", "pg_comm_world", "pg_comm_destroy",
     "pg_hmm_gather", "pg_hmm_gather_all", "pg_hmm_gather_to_host",
 ]

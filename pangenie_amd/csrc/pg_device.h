@@ -19,6 +19,7 @@
 //   wide[..]      : emission tables of columns with more than PG_AMAX alleles on the selected paths
 //   xbuf[2][HP*HP]: generic sweep kernel only (HP >= 256): the column after the emission multiply
 //   lik / lik_exp : outputs, one (mantissa, exponent) pair per genotype bin
+//   vit_*         : (run_phasing) Viterbi backtrace and haplotypes, see DevContig
 #pragma once
 #include <stdint.h>
 
@@ -145,6 +146,14 @@ struct DevContig {
     double*   xbuf;            // [2][HP*HP] generic kernel scratch (forward role first)
     uint32_t* err;
     unsigned long long* prof;  // [64] in-kernel cycle counters (PG_DEBUG bit 3), profiling only
+    // Viterbi phasing (run_phasing, pg_viterbi.hip): transition probabilities {p^2, pq, q^2} of every column,
+    // the backtrace (index of the best previous state of every state, H*H per column), the best state of
+    // the last column, and the haplotype alleles per variant
+    double*   vit_tq;          // [V][8]: {t0, t1, t2} as exact (hi, lo) pairs of the long double values, formed on the host
+    uint16_t* vit_back;        // [V][H*H]
+    uint32_t* vit_best;        // [1]
+    uint16_t* hap1;            // [V] allele of the first / second haplotype at kept variants, 0 elsewhere
+    uint16_t* hap2;
     // outputs
     double*   lik;             // [n_lik] mantissa in [0.5,1) or 0
     int32_t*  lik_exp;         // [n_lik] exponent: L = lik * 2^lik_exp

@@ -34,6 +34,7 @@
 #include <type_traits>
 
 #include "pg_device.h"
+#include "pg_devmath.h"
 
 #define DEVI __device__ __forceinline__
 
@@ -614,21 +615,8 @@ __global__ __launch_bounds__(1024) void k_compact(const DevContig* __restrict__ 
 //  Li-Stephens constants (reference src/transitionprobabilitycomputer.cpp:14-18).
 //  With r = exp(-d/H) and q = (1-exp(-d/H))/H = -expm1(-d/H)/H :
 //     t0 x + t1 (R_i+C_j-2x) + t2 (S-R_i-C_j+x) = r^2 x + q r (R_i+C_j) + q^2 S
-//  expm1 removes the 1-exp(-x) cancellation that plain fp64 would suffer.
-//  The reference forms 1 - expl(-x) in 80-bit arithmetic, i.e. with e^-x rounded to a multiple of
-//  2^-64 (for e^-x in [1/2,1)): its result is the exact difference rounded to a multiple of 2^-64.
-//  That rounding is its dominant error once x is tiny (relative 5.4e-20/x: 1e-10 at the default
-//  parameters, 1e-7..1e-6 at recombrate 1e-3), so it is reproduced here — the bar is parity with the
-//  reference, not with the exact value — including q == 0 once x < 2^-65.
+//  (1 - exp(-x) as the reference's 80-bit arithmetic rounds it: pg_devmath.h)
 // ------------------------------------------------------------------------------------------
-DEVI double one_minus_exp_neg_like_reference(double x) {
-    double t = -expm1(-x);
-    if (x < 0.6931471805599453) {
-        const double s = t * 0x1p64;
-        if (s < 0x1p52) t = rint(s) * 0x1p-64;
-    }
-    return t;
-}
 DEVI void transition_consts(double d, uint32_t H, int uniform, double& c0, double& c1, double& c2, double& kappa) {
     if (uniform) { c0 = 0.0; c1 = 0.0; c2 = 1.0; }
     else {
@@ -643,11 +631,7 @@ DEVI void transition_consts(double d, uint32_t H, int uniform, double& c0, doubl
 
 __global__ __launch_bounds__(64) void k_transition_single(double d, uint32_t H, int uniform, double* out3) {
     if (threadIdx.x == 0) {
-        if (uniform) { out3[0] = out3[1] = out3[2] = 1.0; return; }
-        const double x = d / (double)H;
-        const double q = one_minus_exp_neg_like_reference(x) / (double)H;
-        const double p = exp(-x) + q;
-        out3[0] = p * p; out3[1] = p * q; out3[2] = q * q;
+        transition_probs_f64(d, H, uniform, out3[0], out3[1], out3[2]);
     }
 }
 

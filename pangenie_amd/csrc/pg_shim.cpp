@@ -38,6 +38,7 @@ void pgk_launch_post(const DevContig*, uint32_t, uint32_t, uint32_t, hipStream_t
 void pgk_launch_emission_single(const DevContig*, DevTable, uint32_t, double*, int*, hipStream_t);
 void pgk_launch_transition_single(double, uint32_t, int, double*, hipStream_t);
 uint32_t pgk_threads_for_hp(uint32_t);
+void pgk_launch_viterbi(const DevContig*, uint32_t, uint32_t, uint32_t, hipStream_t);  // pg_viterbi.hip
 }
 
 namespace {
@@ -209,6 +210,7 @@ struct IndexHost {   // one index contig
     std::vector<uint16_t> n_kmers;   // [V] K of every variant
     std::vector<uint32_t> widx;      // [V] wide entry offset / 16 (only if wide_bytes)
     std::vector<uint64_t> goff;      // [V+1]
+    std::vector<uint64_t> pos;       // [V] host copy of the positions (run_phasing: the Viterbi's transition probabilities)
     // device
     size_t o_pos = 0, o_koff = 0, o_aoff = 0, o_aid = 0, o_aflag = 0, o_akoff = 0, o_akmask = 0, o_pa = 0, o_goff = 0, o_widx = 0;
 };
@@ -294,6 +296,10 @@ struct pg_job {
     std::vector<int32_t> tab_e;
     DevTable tab;
     uint32_t hp_mask = 0, max_v = 0;
+    uint32_t vit_bits = 0;     // run_phasing: 1 / 2 / 4 = chains with 16 / 32 / 64 padded paths
+    hipEvent_t ev_vit[2];
+    double vit_ms = 0.0;
+    bool vit_tq_ready = false;  // the transition probabilities of the kept columns are on the device (they depend on the index only)
     hipEvent_t ev[PG_N_KERNEL_CLASSES + 1];
     bool events = false;
     double ms[PG_N_KERNEL_CLASSES] = {0, 0, 0, 0, 0, 0};
@@ -318,8 +324,10 @@ extern "C" void pg_job_destroy(pg_job* job) {
     hipSetDevice(job->device);
     if (job->stream) hipStreamSynchronize(job->stream);
     if (job->stream2) hipStreamSynchronize(job->stream2);
-    if (job->events)
+    if (job->events) {
         for (auto& e : job->ev) hipEventDestroy(e);
+        for (auto& e : job->ev_vit) hipEventDestroy(e);
+    }
     if (job->events2)
         for (int q = 0; q < 2; ++q) { hipEventDestroy(job->ev_sweep[q]); hipEventDestroy(job->ev_post[q]); }
     if (job->arena) {
@@ -368,6 +376,7 @@ int upload_inputs(pg_job* job, const pg_contig_batch* batches, const std::vector
             IndexHost& x = job->index[i];
             if (x.V == 0) continue;
             UP(x.o_pos, b.variant_pos, (size_t)x.V * 8, bi);
+            if (job->params.run_phasing) { x.pos.assign(b.variant_pos, b.variant_pos + x.V); job->vit_tq_ready = false; }
             UP(x.o_koff, b.kmer_off, ((size_t)x.V + 1) * 4, bi);
             UP(x.o_aoff, b.allele_off, ((size_t)x.V + 1) * 4, bi);
             UP(x.o_aid, b.allele_id, (size_t)x.sumA * 2, bi);
@@ -402,8 +411,13 @@ int job_build(int device, uint32_t n_index, const pg_contig_batch* batches, cons
     *out = nullptr;
     if (!batches || !table || !params || n_index == 0 || specs.empty()) { set_err(err, errlen, "null argument"); return PG_ERR_INVALID; }
     if (params->run_phasing) {
-        set_err(err, errlen, "run_phasing (Viterbi, reference src/hmm.cpp:112-173) is not on the device path");
-        return PG_ERR_UNSUPPORTED;
+        // Viterbi (pg_viterbi.hip): a row of states is one wave's lanes, so at most 64 selected paths (the reference's
+        // own callers pass at most 30, src/commands.cpp:939)
+        for (const ChainSpec& sp : specs)
+            if (batches[sp.index].n_paths > 64u) {
+                set_err(err, errlen, "run_phasing: %u selected paths, the device Viterbi takes at most 64", batches[sp.index].n_paths);
+                return PG_ERR_UNSUPPORTED;
+            }
     }
     for (uint32_t i = 0; i < n_index; ++i) {
         const int rc = check_batch(&batches[i], !cohort, err, errlen);
@@ -437,6 +451,8 @@ int job_build(int device, uint32_t n_index, const pg_contig_batch* batches, cons
     hipError_t he;
     if ((he = hipStreamCreate(&job->stream)) != hipSuccess) return fail(PG_ERR_DEVICE, "hipStreamCreate", he);
     for (auto& e : job->ev)
+        if ((he = hipEventCreate(&e)) != hipSuccess) return fail(PG_ERR_DEVICE, "hipEventCreate", he);
+    for (auto& e : job->ev_vit)
         if ((he = hipEventCreate(&e)) != hipSuccess) return fail(PG_ERR_DEVICE, "hipEventCreate", he);
     job->events = true;
     table_snapshot(const_cast<pg_table*>(table), job->tab_m, job->tab_e, &job->tab);
@@ -524,7 +540,8 @@ int job_build(int device, uint32_t n_index, const pg_contig_batch* batches, cons
     job->chains.resize(n_chains);
     size_t off = 0;
     auto take = [&](size_t bytes, size_t al = 256) { off = align_up(off, al); size_t o = off; off += (bytes ? bytes : 8); return o; };
-    struct Plan { size_t frec, scratch, wide, vpair, xbuf, prof, fback, fscale, bscale, bsum, vrec, cvar, colrec, fwd, part, kept, apres; };
+    struct Plan { size_t frec, scratch, wide, vpair, xbuf, prof, fback, fscale, bscale, bsum, vrec, cvar, colrec, fwd, part, kept, apres,
+                  vtq, vback, vbest, hap1, hap2; };
     std::vector<Plan> plan(n_chains);
     const size_t o_contigs = take(sizeof(DevContig) * n_chains);
     // zeroed-every-run block: n_cols, err, per chain kept / fallback flags / profile counters / allele_present,
@@ -541,6 +558,10 @@ int job_build(int device, uint32_t n_index, const pg_contig_batch* batches, cons
         plan[c].fback = take(x.V);
         plan[c].prof = take(64 * sizeof(unsigned long long));
         plan[c].apres = take(x.sumA);
+        const bool vit = params->run_phasing != 0;
+        plan[c].vbest = take(vit ? 4 : 0);
+        plan[c].hap1 = take(vit ? (size_t)x.V * 2 : 0);
+        plan[c].hap2 = take(vit ? (size_t)x.V * 2 : 0);
         ch.lik_first = lik_total;
         lik_total += x.n_lik;
     }
@@ -574,9 +595,14 @@ int job_build(int device, uint32_t n_index, const pg_contig_batch* batches, cons
         const char* tri_env = getenv("PG_TRI");
         const bool tri = x.lean && !job->chunked && !(tri_env && !strcmp(tri_env, "0"));
         tri_of_chain[c] = tri;
-        p.fwd = take((size_t)x.V * (tri ? 2304u : (size_t)x.HP * x.HP) * sizeof(double));
+        const bool geno = params->run_genotyping != 0;  // (a phasing-only job has no sweep: no columns, no partials)
+        p.fwd = take(geno ? (size_t)x.V * (tri ? 2304u : (size_t)x.HP * x.HP) * sizeof(double) : 0);
         // fused mode: posterior partials; chunked mode: the chunk scratch instead (k_post writes lik directly)
-        p.part = take(job->chunked ? 0 : (size_t)x.V * x.part_slots * x.T * sizeof(double));
+        p.part = take(job->chunked || !geno ? 0 : (size_t)x.V * x.part_slots * x.T * sizeof(double));
+        // Viterbi: transition probabilities and one 2-byte backpointer per state and column
+        p.vtq = take(params->run_phasing ? (size_t)x.V * 8 * sizeof(double) : 0);
+        p.vback = take(params->run_phasing ? (size_t)x.V * x.H * x.H * sizeof(uint16_t) : 0);
+        if (params->run_phasing) job->vit_bits |= x.HP == 16 ? 1u : (x.HP == 32 ? 2u : 4u);
         p.scratch = take(job->chunked ? (size_t)4 * job->chunk_cols * x.HP * x.HP * sizeof(double) : 0);
         p.wide = take(x.wide_bytes);
         p.vpair = take((size_t)x.V * pg_pair_bytes(x.pair_n));
@@ -654,6 +680,10 @@ int job_build(int device, uint32_t n_index, const pg_contig_batch* batches, cons
         d.wide = A + p.wide; d.wide_idx = x.wide_bytes ? (const uint32_t*)(A + x.o_widx) : nullptr;
         d.vpair = A + p.vpair; d.xbuf = (double*)(A + p.xbuf);
         d.frec = (double*)(A + p.frec); d.lean = x.lean ? 1u : 0u;
+        if (params->run_phasing) {
+            d.vit_tq = (double*)(A + p.vtq); d.vit_back = (uint16_t*)(A + p.vback); d.vit_best = (uint32_t*)(A + p.vbest);
+            d.hap1 = (uint16_t*)(A + p.hap1); d.hap2 = (uint16_t*)(A + p.hap2);
+        }
         const char* l2_env = getenv("PG_LEAN2");  // 0: phase 2 of triangle chains on the general kernel's triangle ring
         d.tri = tri_of_chain[c] ? ((l2_env && !strcmp(l2_env, "0")) ? 1u : 2u) : 0u;
         d.col_stride = d.tri ? 2304u : x.HP * x.HP;
@@ -730,6 +760,52 @@ extern "C" int pg_job_upload(pg_job* job, const pg_contig_batch* batches, const 
     return upload_inputs(job, batches, specs, batches != nullptr, err, errlen);
 }
 
+namespace {
+// Transition probabilities of the Viterbi, per kept column, formed on the host in long double exactly as the
+// reference forms them (TransitionProbabilityComputer, src/transitionprobabilitycomputer.cpp:8-19, :33-39) and split
+// into exact (hi, lo) double pairs: {t0, t1, t2} = {p^2, pq, q^2}.  The reference's decisions hang on p/q - 1, which
+// drops below fp64's resolution once distance / H > 37 (pg_viterbi.hip).  Column 0 has no predecessor.
+int viterbi_transitions(pg_job* job, hipStream_t s, char* err, size_t errlen) {
+    const uint32_t n = (uint32_t)job->chains.size();
+    std::vector<std::vector<double>> tq_of_index(job->index.size());
+    std::vector<char> done(job->index.size(), 0);
+    std::vector<uint32_t> colv;
+    for (uint32_t c = 0; c < n; ++c) {
+        const ChainHost& ch = job->chains[c];
+        const IndexHost& x = job->index[ch.index];
+        if (x.V == 0) continue;
+        std::vector<double>& tq = tq_of_index[ch.index];
+        if (!done[ch.index]) {  // (the kept columns depend on the index alone: once per index contig)
+            done[ch.index] = 1;
+            uint32_t C = 0;
+            HIP_TRY(hipMemcpy(&C, ch.d.n_cols, sizeof(uint32_t), hipMemcpyDeviceToHost));
+            if (C > x.V) { set_err(err, errlen, "chain %u: bad column count", c); return PG_ERR_DEVICE; }
+            colv.resize(C ? C : 1);
+            if (C) HIP_TRY(hipMemcpy(colv.data(), ch.d.col_variant, (size_t)C * sizeof(uint32_t), hipMemcpyDeviceToHost));
+            tq.assign((size_t)C * 8, 0.0);
+            const long double H = (long double)x.H;
+            for (uint32_t k = 0; k < C; ++k) {
+                long double t[3] = {1.0L, 1.0L, 1.0L};
+                if (k > 0 && !job->params.uniform) {
+                    const long double distance = (x.pos[colv[k]] - x.pos[colv[k - 1]]) * 0.000004L * ((long double)job->params.recombrate) * job->params.effective_N;
+                    const long double recomb_prob = (1.0L - expl(-distance / H)) * (1.0L / H);
+                    const long double no_recomb_prob = expl(-distance / H) + recomb_prob;
+                    t[0] = no_recomb_prob * no_recomb_prob; t[1] = no_recomb_prob * recomb_prob; t[2] = recomb_prob * recomb_prob;
+                }
+                for (int q = 0; q < 3; ++q) {
+                    const double hi = (double)t[q];
+                    tq[(size_t)k * 8 + 2 * q] = hi;
+                    tq[(size_t)k * 8 + 2 * q + 1] = (double)(t[q] - (long double)hi);  // exact: 64 - 53 bits are left
+                }
+            }
+        }
+        if (!tq.empty()) HIP_TRY(hipMemcpyAsync(ch.d.vit_tq, tq.data(), tq.size() * sizeof(double), hipMemcpyHostToDevice, s));
+    }
+    HIP_TRY(hipStreamSynchronize(s));  // (tq_of_index goes out of scope)
+    return PG_OK;
+}
+}  // namespace
+
 extern "C" int pg_job_run(pg_job* job, void* stream_, char* err, size_t errlen) {
     if (!job) { set_err(err, errlen, "null job"); return PG_ERR_INVALID; }
     const double t_run = now_s();
@@ -780,10 +856,24 @@ extern "C" int pg_job_run(pg_job* job, void* stream_, char* err, size_t errlen) 
             HIP_TRY(hipEventRecord(job->ev[6], s));  // (no k_bins in this mode)
         }
     } else if (job->max_v > 0) {
-        // run_genotyping == false: only the ColumnIndexer part is meaningful (no likelihoods)
+        // run_genotyping == false: the ColumnIndexer part and the column records (what the Viterbi reads)
         pgk_launch_prep(job->d_contigs, n, job->max_v, job->tab, s);
         pgk_launch_compact(job->d_contigs, n, s);
         HIP_TRY(hipGetLastError());
+    }
+    if (job->max_v > 0 && job->params.run_phasing) {
+        // Viterbi phasing (reference src/hmm.cpp:47-49): reads k_prep's records, independent of the sweep
+        if (!job->vit_tq_ready) {  // first run with this index: the transition probabilities of the kept columns
+            HIP_TRY(hipStreamSynchronize(s));
+            if (job->stream2) HIP_TRY(hipStreamSynchronize(job->stream2));
+            const int rc = viterbi_transitions(job, s, err, errlen);
+            if (rc != PG_OK) return rc;
+            job->vit_tq_ready = true;
+        }
+        HIP_TRY(hipEventRecord(job->ev_vit[0], s));
+        pgk_launch_viterbi(job->d_contigs, n, job->max_v, job->vit_bits, s);
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipEventRecord(job->ev_vit[1], s));
     }
     HIP_TRY(hipStreamSynchronize(s));
     if (job->stream2) HIP_TRY(hipStreamSynchronize(job->stream2));
@@ -793,6 +883,11 @@ extern "C" int pg_job_run(pg_job* job, void* stream_, char* err, size_t errlen) 
             HIP_TRY(hipEventElapsedTime(&ms, job->ev[i], job->ev[i + 1]));
             job->ms[i] = ms;
         }
+    }
+    if (job->max_v > 0 && job->params.run_phasing) {
+        float ms = 0.f;
+        HIP_TRY(hipEventElapsedTime(&ms, job->ev_vit[0], job->ev_vit[1]));
+        job->vit_ms = ms;
     }
     std::vector<uint32_t> ncols(n), errs(n);
     HIP_TRY(hipMemcpy(ncols.data(), job->d_ncols, sizeof(uint32_t) * n, hipMemcpyDeviceToHost));
@@ -832,13 +927,19 @@ extern "C" int pg_job_fetch(pg_job* job, uint32_t ci, pg_contig_result* out, cha
     if (out->allele_present && x.sumA) HIP_TRY(hipMemcpy(out->allele_present, c.d.allele_present, x.sumA, hipMemcpyDeviceToHost));
     // reference src/hmm.cpp:94,106-109: set only when there is at least one column
     const bool fill = job->params.run_genotyping && c.n_cols_host > 0;
+    // the Viterbi backtrace sets both at the COLUMN index (sic, reference src/hmm.cpp:164-165): entries [0, C)
+    const size_t nvit = job->params.run_phasing ? c.n_cols_host : 0;
     if (out->n_kmers) {
         if (fill) memcpy(out->n_kmers, x.n_kmers.data(), (size_t)x.V * 2);
-        else memset(out->n_kmers, 0, (size_t)x.V * 2);
+        else { memset(out->n_kmers, 0, (size_t)x.V * 2); memcpy(out->n_kmers, x.n_kmers.data(), nvit * 2); }
     }
     if (out->coverage) {
         if (fill) memcpy(out->coverage, c.coverage.data(), (size_t)x.V * 2);
-        else memset(out->coverage, 0, (size_t)x.V * 2);
+        else { memset(out->coverage, 0, (size_t)x.V * 2); memcpy(out->coverage, c.coverage.data(), nvit * 2); }
+    }
+    if (job->params.run_phasing) {
+        if (out->haplotype_1) HIP_TRY(hipMemcpy(out->haplotype_1, c.d.hap1, (size_t)x.V * 2, hipMemcpyDeviceToHost));
+        if (out->haplotype_2) HIP_TRY(hipMemcpy(out->haplotype_2, c.d.hap2, (size_t)x.V * 2, hipMemcpyDeviceToHost));
     }
     job->host_s[3] += now_s() - t0;
     return PG_OK;
@@ -895,6 +996,8 @@ extern "C" int pg_job_sweep_mode(const pg_job* job, uint32_t* chunk_cols) {
     if (chunk_cols) *chunk_cols = job->chunk_cols;
     return job->chunked ? 1 : 0;
 }
+
+extern "C" double pg_job_viterbi_ms(const pg_job* job) { return job ? job->vit_ms : 0.0; }
 
 extern "C" uint32_t pg_job_triangle_chains(const pg_job* job) {
     if (!job) return 0;

@@ -146,7 +146,8 @@ def vcf_sample_field(result: "GenotypingResult", defined_alleles: Sequence[int],
 
 
 def results_from_flat(batch, lik_ld: np.ndarray, kept: np.ndarray, allele_present: np.ndarray,
-                      n_kmers: np.ndarray, coverage: np.ndarray) -> List[GenotypingResult]:
+                      n_kmers: np.ndarray, coverage: np.ndarray, haplotype_1=None, haplotype_2=None,
+                      with_likelihoods: bool = True) -> List[GenotypingResult]:
     """Rebuild vector<GenotypingResult> from the flat bins (include/pangenie_hmm.h layout):
     a bin becomes a map key iff the variant is a kept column and both allele
     slots occur on a selected path (reference src/hmm.cpp:368)."""
@@ -156,7 +157,10 @@ def results_from_flat(batch, lik_ld: np.ndarray, kept: np.ndarray, allele_presen
         r = GenotypingResult()
         r.unique_kmers = int(n_kmers[v])
         r.local_coverage = int(coverage[v])
-        if kept[v]:
+        if haplotype_1 is not None and kept[v]:  # Viterbi path (reference src/hmm.cpp:161-162)
+            r.haplotype_1 = int(haplotype_1[v])
+            r.haplotype_2 = int(haplotype_2[v])
+        if kept[v] and with_likelihoods:
             a0, a1 = int(batch.allele_off[v]), int(batch.allele_off[v + 1])
             A = a1 - a0
             ids = batch.allele_id[a0:a1]

@@ -87,6 +87,10 @@ class ContigResult:
         self.n_kmers = np.zeros(max(V, 1), np.uint16)[:V]
         self.coverage = np.zeros(max(V, 1), np.uint16)[:V]
         self.n_columns = 0
+        # run_phasing: alleles of the Viterbi path's two haplotypes at kept variants
+        self.haplotype_1 = np.zeros(max(V, 1), np.uint16)[:V]
+        self.haplotype_2 = np.zeros(max(V, 1), np.uint16)[:V]
+        self.run_genotyping = True
         self._c = PgContigResult()
         self._c.lik = self.lik.ctypes.data_as(f64p)
         self._c.lik_exp = self.lik_exp.ctypes.data_as(i32p)
@@ -94,6 +98,8 @@ class ContigResult:
         self._c.allele_present = self.allele_present.ctypes.data_as(u8p)
         self._c.n_kmers = self.n_kmers.ctypes.data_as(u16p)
         self._c.coverage = self.coverage.ctypes.data_as(u16p)
+        self._c.haplotype_1 = self.haplotype_1.ctypes.data_as(u16p)
+        self._c.haplotype_2 = self.haplotype_2.ctypes.data_as(u16p)
 
     def likelihoods_ld(self) -> np.ndarray:
         """Unnormalised genotype likelihoods as 80-bit long double: lik[g] * 2^lik_exp[g]."""
@@ -101,7 +107,8 @@ class ContigResult:
 
     def genotyping_results(self) -> List[GenotypingResult]:
         return results_from_flat(self.batch, self.likelihoods_ld(), self.kept, self.allele_present,
-                                 self.n_kmers, self.coverage)
+                                 self.n_kmers, self.coverage, self.haplotype_1, self.haplotype_2,
+                                 with_likelihoods=self.run_genotyping)
 
 
 def genotype_contig(batch: ContigBatch, table: ProbabilityTable, params: Optional[PgHmmParams] = None,
@@ -118,6 +125,7 @@ def genotype_contig(batch: ContigBatch, table: ProbabilityTable, params: Optiona
     if rc:
         raise PanGenieError(rc, err.value.decode(errors="replace"))
     res.n_columns = int(res._c.n_columns)
+    res.run_genotyping = bool(params.run_genotyping)
     return res
 
 
@@ -221,7 +229,12 @@ class Job:
         if rc:
             raise PanGenieError(rc, err.value.decode(errors="replace"))
         res.n_columns = int(res._c.n_columns)
+        res.run_genotyping = bool(self.params.run_genotyping)
         return res
+
+    def viterbi_ms(self) -> float:
+        """elapsed ms of the Viterbi kernels (run_phasing) of the last run"""
+        return float(self._lib.pg_job_viterbi_ms(self.h))
 
     def device_results(self, contig: int):
         """(lik_ptr, n_lik, lik_exp_ptr, n_variants): device pointers for an RCCL gather."""

@@ -8,6 +8,7 @@
 #include <limits>
 #include <iomanip>
 #include <cstdlib>
+#include <cstring>
 #include <sstream>
 #include <stdexcept>
 #include <thread>
@@ -463,12 +464,12 @@ long double EmissionProbabilityComputer::get_emission_probability(unsigned short
 
 // ------------------------------------------------------------------ Viterbi (phasing), host, long double
 // The reference's experimental phasing mode (`-p`, src/pangenie-genotype.cpp:60; at most 30 paths,
-// src/commands.cpp:939): most likely pair of haplotype paths through the columns.  Not part of the
-// device path (BASELINE.json north_star is the forward-backward genotyping); it stays on the host in
+// src/commands.cpp:939): most likely pair of haplotype paths through the columns.  The HMM constructor
+// runs it on the GPU (pangenie_amd/csrc/pg_viterbi.hip, up to 64 selected paths); this host version in
 // the reference's own arithmetic — same operation order, same tie rule (`>=`: the LAST maximum wins,
 // reference src/hmm.cpp:468, :139), same uniform fall-back (:484-491), same sqrt(C) checkpointing
-// idea (:118-128, :152-158; here per block) — so that `HMM(..., run_phasing = true)` behaves like
-// the reference's constructor.
+// idea (:118-128, :152-158; here per block) — is what the constructor uses above 64 paths or when the
+// environment variable PG_VITERBI=host asks for it (cross-check).
 namespace {
 
 // EmissionProbabilityComputer in long double on the host (reference src/emissionprobabilitycomputer.cpp:9-53)
@@ -563,6 +564,7 @@ struct ViterbiColumns {
                         const size_t ci[4] = {i, rowidx[p1], colidx[p2], gidx};
                         for (int q = 0; q < 4; ++q)
                             if (cv[q] > max_value || (cv[q] == max_value && ci[q] >= max_index)) { max_value = cv[q]; max_index = ci[q]; }
+                        if (max_value == 0.0L) max_index = n - 1;  // every product is 0: the scan ends on the last state
                     }
                     previous_cell = max_value;
                     if (back) (*back)[i] = (uint32_t)max_index;
@@ -655,16 +657,21 @@ HMM::HMM(std::vector<std::shared_ptr<UniqueKmers>>* unique_kmers, ProbabilityTab
     std::vector<double> lik(geno_off[V] ? geno_off[V] : 1);
     std::vector<int32_t> lik_exp(geno_off[V] ? geno_off[V] : 1);  // one exponent per genotype bin
     std::vector<uint8_t> kept(V ? V : 1), present(f.allele_id.size() ? f.allele_id.size() : 1);
-    std::vector<uint16_t> n_kmers(V ? V : 1), cov(V ? V : 1);
+    std::vector<uint16_t> n_kmers(V ? V : 1), cov(V ? V : 1), hap1(V ? V : 1), hap2(V ? V : 1);
+    // Viterbi on the device (pg_viterbi.hip) up to 64 selected paths; on the host above that / with PG_VITERBI=host
+    const char* vit_env = getenv("PG_VITERBI");
+    const bool phase_on_device = run_phasing && f.paths.size() <= 64 && !(vit_env && !strcmp(vit_env, "host"));
     pg_contig_result r{};
     r.lik = lik.data(); r.lik_exp = lik_exp.data(); r.kept = kept.data(); r.allele_present = present.data();
     r.n_kmers = n_kmers.data(); r.coverage = cov.data();
+    r.haplotype_1 = hap1.data(); r.haplotype_2 = hap2.data();
     pg_hmm_params prm{};
     prm.effective_N = effective_N; prm.recombrate = recombrate; prm.uniform = uniform ? 1 : 0;
-    prm.run_genotyping = run_genotyping ? 1 : 0; prm.run_phasing = 0;  // phasing: host, below
+    prm.run_genotyping = run_genotyping ? 1 : 0; prm.run_phasing = phase_on_device ? 1 : 0;
     char err[512] = {0};
-    if (run_genotyping) {
+    if (run_genotyping || phase_on_device)
         check_rc(pg_hmm_genotype_contig(&f.batch, probabilities->handle(), &prm, g_device, &r, err, sizeof(err)), err);
+    if (run_genotyping) {
         for (size_t v = 0; v < V; ++v) {
             GenotypingResult& g = genotyping_result_[v];
             if (kept[v]) {
@@ -684,7 +691,20 @@ HMM::HMM(std::vector<std::shared_ptr<UniqueKmers>>* unique_kmers, ProbabilityTab
         }
         if (normalize_results) normalize();  // reference src/hmm.cpp:36-45
     }
-    if (run_phasing) viterbi_phasing(f, probabilities->handle(), recombrate, uniform, effective_N, genotyping_result_);  // :47-49
+    if (phase_on_device) {  // reference src/hmm.cpp:47-49, :144-172
+        for (size_t v = 0; v < V; ++v)
+            if (kept[v]) {
+                genotyping_result_[v].add_first_haplotype_allele(hap1[v]);
+                genotyping_result_[v].add_second_haplotype_allele(hap2[v]);
+            }
+        // (sic: the reference sets these two by COLUMN index, not by variant — src/hmm.cpp:164-165)
+        for (size_t c = 0; c < r.n_columns; ++c) {
+            genotyping_result_[c].set_unique_kmers((unsigned short)(f.kmer_off[c + 1] - f.kmer_off[c]));
+            genotyping_result_[c].set_coverage(f.coverage[c]);
+        }
+    } else if (run_phasing) {
+        viterbi_phasing(f, probabilities->handle(), recombrate, uniform, effective_N, genotyping_result_);
+    }
 }
 // ------------------------------------------------------------------ multi-GPU job loop
 std::vector<std::vector<GenotypingResult>> run_contigs_multi_gpu(std::vector<ContigTask>& tasks, ProbabilityTable* probabilities,

@@ -270,7 +270,9 @@ struct FlatContig {
 /** Throws std::runtime_error("HMM::index_columns: column N is not covered by any paths.") like ColumnIndexer. */
 void flatten(std::vector<std::shared_ptr<UniqueKmers>>* unique_kmers, std::vector<unsigned short>* only_paths, FlatContig& out);
 
-/** The genotyping HMM.  All work happens in the constructor, on the GPU. */
+/** The genotyping HMM.  All work happens in the constructor, on the GPU: forward-backward genotyping and, with
+ *  run_phasing, the Viterbi path (get_haplotype(); pangenie_amd/csrc/pg_viterbi.hip, up to 64 selected paths — above
+ *  that, or with PG_VITERBI=host, the long double host Viterbi of pangenie_host.cpp). */
 class HMM {
 public:
     HMM() = default;

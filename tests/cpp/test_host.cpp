@@ -276,8 +276,36 @@ static void archive_cpu_tests() {
     });
 }
 
+// a panel with duplicated paths (exact ties), 300 columns (several checkpoint blocks of the host Viterbi).  The gaps
+// between the variants differ: with EQUAL neighbouring gaps "switch here" and "switch one column later" are the same
+// product taken in a different order, and which one wins is decided by the rounding of the last bit — in the
+// reference as anywhere else.
+static vector<shared_ptr<UniqueKmers>> viterbi_panel(size_t V, size_t H, size_t dup_from) {
+    unsigned long long x = 88172645463325252ull;
+    auto rnd = [&]() { x ^= x << 13; x ^= x >> 7; x ^= x << 17; return x; };
+    vector<shared_ptr<UniqueKmers>> a;
+    size_t position = 1000;
+    for (size_t v = 0; v < V; ++v) {
+        position += 60 + (size_t)(rnd() % 1300);
+        us p1;
+        for (size_t p = 0; p < H; ++p) p1.push_back((unsigned short)(rnd() % 3 == 0));
+        p1[v % H] = 1;
+        for (size_t p = dup_from; p < H; ++p) p1[p] = p1[p - dup_from];  // duplicated paths: exact ties
+        auto ua = bi(position, p1);
+        for (int q = 0; q < 4; ++q) {
+            kmer(ua, (unsigned short)(rnd() % 30), {0});
+            kmer(ua, (unsigned short)(rnd() % 30), {1});
+        }
+        ua->set_coverage(27);
+        a.push_back(ua);
+    }
+    return a;
+}
+
 static void viterbi_cpu_tests() {
-    // Viterbi alone needs no device (run_genotyping = false): host long double, reference src/hmm.cpp:112-173, 408-511
+    // The host Viterbi needs no device (run_genotyping = false, PG_VITERBI=host): long double, reference
+    // src/hmm.cpp:112-173, 408-511
+    setenv("PG_VITERBI", "host", 1);
     run("HMM phasing only (Viterbi on the host)", [] {
         auto u1 = bi(2000, {0, 1}); kmer(u1, 10, {0}); kmer(u1, 10, {1});
         auto u2 = bi(3000, {0, 1});
@@ -298,26 +326,11 @@ static void viterbi_cpu_tests() {
         // (exact, same tie rule); PG_VITERBI_NAIVE_MAX=100 runs the reference's loop on the same panel.
         // 300 columns exercise several checkpoint blocks; many equal paths exercise the tie rule.
         const size_t V = 300, H = 45;
-        unsigned long long x = 88172645463325252ull;
-        auto rnd = [&]() { x ^= x << 13; x ^= x >> 7; x ^= x << 17; return x; };
-        vector<shared_ptr<UniqueKmers>> a;
         ProbabilityTable probs(6, 108, 54, 0.01L);
-        for (size_t v = 0; v < V; ++v) {
-            us p1;
-            for (size_t p = 0; p < H; ++p) p1.push_back((unsigned short)(rnd() % 3 == 0));
-            p1[v % H] = 1;
-            for (size_t p = 38; p < H; ++p) p1[p] = p1[p - 38];  // duplicated paths: exact ties
-            auto ua = bi(1000 + 700 * v, p1);
-            for (int q = 0; q < 4; ++q) {
-                kmer(ua, (unsigned short)(rnd() % 30), {0});
-                kmer(ua, (unsigned short)(rnd() % 30), {1});
-            }
-            ua->set_coverage(27);
-            a.push_back(ua);
-        }
-        for (int regime = 0; regime < 2; ++regime) {
-            const double rec = regime ? 446.287102628 : 1.26;
-            const long double N = regime ? 0.25L : 25000.0L;
+        auto a = viterbi_panel(V, H, 38);
+        for (int regime = 0; regime < 3; ++regime) {  // (regime 2: no recombination at all, q == 0)
+            const double rec = regime == 1 ? 446.287102628 : (regime == 2 ? 0.0 : 1.26);
+            const long double N = regime == 1 ? 0.25L : 25000.0L;
             unsetenv("PG_VITERBI_NAIVE_MAX");
             HMM fast(&a, &probs, false, true, rec, false, N);
             setenv("PG_VITERBI_NAIVE_MAX", "100", 1);
@@ -329,6 +342,7 @@ static void viterbi_cpu_tests() {
             CHECK(same == V);
         }
     });
+    unsetenv("PG_VITERBI");
 }
 
 
@@ -705,6 +719,37 @@ static void gpu_tests() {
         for (auto& r : res) { h1.push_back(r.get_haplotype().first); h2.push_back(r.get_haplotype().second); }
         CHECK((h1 == us{0, 0, 0} && h2 == us{1, 1, 1}) || (h1 == us{1, 1, 1} && h2 == us{0, 0, 0}));
     });
+    run("HMM Viterbi on the device (pg_viterbi.hip) == host long double Viterbi", [] {
+        // 30 / 45 / 64 paths (lanes per row of states 32 / 64 / 64), duplicated paths for exact ties, three transition
+        // regimes (default, strong recombination, none); phasing alone and together with genotyping
+        ProbabilityTable probs(6, 108, 54, 0.01L);
+        const size_t shapes[4][2] = {{300, 45}, {500, 30}, {200, 64}, {260, 12}};
+        for (auto& sh : shapes) {
+            const size_t V = sh[0], H = sh[1];
+            auto a = viterbi_panel(V, H, H - H / 6);
+            for (int regime = 0; regime < 3; ++regime) {
+                const double rec = regime == 1 ? 446.287102628 : (regime == 2 ? 0.0 : 1.26);
+                const long double N = regime == 1 ? 0.25L : 25000.0L;
+                setenv("PG_VITERBI", "host", 1);
+                HMM host(&a, &probs, false, true, rec, false, N);
+                unsetenv("PG_VITERBI");
+                HMM dev(&a, &probs, false, true, rec, false, N);
+                HMM both(&a, &probs, true, true, rec, false, N);
+                auto ra = host.get_genotyping_result(), rb = dev.get_genotyping_result(), rc = both.get_genotyping_result();
+                size_t same = 0, same2 = 0, meta = 0;
+                for (size_t v = 0; v < V; ++v) {
+                    same += ra[v].get_haplotype() == rb[v].get_haplotype();
+                    same2 += ra[v].get_haplotype() == rc[v].get_haplotype();
+                    meta += ra[v].nr_unique_kmers() == rb[v].nr_unique_kmers() && ra[v].coverage() == rb[v].coverage() &&
+                            rb[v].contains_no_likelihoods();
+                }
+                if (same != V || same2 != V) std::printf("  viterbi device/host: V=%zu H=%zu regime=%d same=%zu same2=%zu\n", V, H, regime, same, same2);
+                CHECK(same == V);
+                CHECK(same2 == V);
+                CHECK(meta == V);
+            }
+        }
+    });
 }
 
 int main(int argc, char** argv) {
@@ -712,6 +757,19 @@ int main(int argc, char** argv) {
     if (argc > 2) g_golden_dir = argv[2];
     if (mode == "cpu") { cpu_tests(); viterbi_cpu_tests(); archive_cpu_tests(); sampler_cpu_tests(); }
     else if (mode == "gpu") { gpu_tests(); sampler_gpu_tests(); }
+    else if (mode == "dump-viterbi" && argc >= 5) {
+        // haplotypes of the host Viterbi on viterbi_panel(V, H) in a regime: "h1 h2" per variant (debugging aid)
+        const size_t V = (size_t)atol(argv[2]), H = (size_t)atol(argv[3]);
+        const int regime = atoi(argv[4]);
+        ProbabilityTable probs(6, 108, 54, 0.01L);
+        auto a = viterbi_panel(V, H, H - H / 6);
+        const double rec = regime == 1 ? 446.287102628 : (regime == 2 ? 0.0 : 1.26);
+        const long double N = regime == 1 ? 0.25L : 25000.0L;
+        if (argc < 6) setenv("PG_VITERBI", "host", 1);
+        HMM hmm(&a, &probs, false, true, rec, false, N);
+        for (auto& r : hmm.get_genotyping_result()) std::printf("%u %u\n", r.get_haplotype().first, r.get_haplotype().second);
+        return 0;
+    }
     else { std::printf("usage: test_host cpu|gpu\n"); return 2; }
     std::printf("%d checks, %d failed\n", g_checks, g_failed);
     return g_failed ? 1 : 0;

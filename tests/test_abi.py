@@ -56,7 +56,7 @@ def test_struct_layout_matches_header(lib):
     # sizes the C compiler gives the header's structs (x86-64 SysV)
     assert C.sizeof(_lib.PgContigBatch) == 8 + 10 * 8
     assert C.sizeof(_lib.PgHmmParams) == 16 + 8 + 4 * 4 + 8  # long double, double, 4 ints, tail pad to 16
-    assert C.sizeof(_lib.PgContigResult) == 6 * 8 + 8
+    assert C.sizeof(_lib.PgContigResult) == 6 * 8 + 8 + 2 * 8  # 6 pointers, 2 u32, haplotype_1 / haplotype_2
 
 
 def test_probability_table_known_answers(lib, golden):
@@ -92,9 +92,10 @@ def test_argument_errors_without_device(lib):
     from pangenie_amd import hmm
     b = synthetic_panel(10, 4, 6, seed=1)
     t = hmm.ProbabilityTable(6, 108, 54, 0.01)
-    # Viterbi is not on the device path: refused before any device work
+    # the device Viterbi takes at most 64 selected paths: refused before any device work
+    b65 = synthetic_panel(10, 65, 6, seed=1)
     with pytest.raises(hmm.PanGenieError) as e:
-        hmm.genotype_contig(b, t, hmm.make_params(run_phasing=True))
+        hmm.genotype_contig(b65, t, hmm.make_params(run_phasing=True))
     assert e.value.code == _lib.PG_ERR_UNSUPPORTED
     # no selected paths -> the reference's ColumnIndexer error
     b0 = synthetic_panel(10, 4, 6, seed=1)
