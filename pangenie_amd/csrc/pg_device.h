@@ -150,7 +150,7 @@ struct DevContig {
     // the backtrace (index of the best previous state of every state, H*H per column), the best state of
     // the last column, and the haplotype alleles per variant
     double*   vit_tq;          // [V][8]: {t0, t1, t2} as exact (hi, lo) pairs of the long double values, formed on the host
-    uint16_t* vit_back;        // [V][H*H]
+    uint16_t* vit_back;        // [V][H][HP]: state index (p1 * H + p2) of the best previous state of state (p1, p2)
     uint32_t* vit_best;        // [1]
     uint16_t* hap1;            // [V] allele of the first / second haplotype at kept variants, 0 elsewhere
     uint16_t* hap2;

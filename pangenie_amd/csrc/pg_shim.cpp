@@ -601,7 +601,7 @@ int job_build(int device, uint32_t n_index, const pg_contig_batch* batches, cons
         p.part = take(job->chunked || !geno ? 0 : (size_t)x.V * x.part_slots * x.T * sizeof(double));
         // Viterbi: transition probabilities and one 2-byte backpointer per state and column
         p.vtq = take(params->run_phasing ? (size_t)x.V * 8 * sizeof(double) : 0);
-        p.vback = take(params->run_phasing ? (size_t)x.V * x.H * x.H * sizeof(uint16_t) : 0);
+        p.vback = take(params->run_phasing ? (size_t)x.V * x.H * x.HP * sizeof(uint16_t) : 0);
         if (params->run_phasing) job->vit_bits |= x.HP == 16 ? 1u : (x.HP == 32 ? 2u : 4u);
         p.scratch = take(job->chunked ? (size_t)4 * job->chunk_cols * x.HP * x.HP * sizeof(double) : 0);
         p.wide = take(x.wide_bytes);

@@ -44,20 +44,62 @@ typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));  // (HIP's uint4 has
 
 namespace {
 
-template <int CTRL, int ROWMASK>
+DEVI uint32_t last_bit64(unsigned long long m) { return 63u - (uint32_t)__builtin_clzll(m | 1ull); }
+constexpr double kNone = -1.7976931348623157e308;  // below every lo part: a lane that does not take part in a reduction
+
+// ---- DPP steps of the reductions (gfx9 DPP: row_shr inside rows of 16 lanes, row_bcast15 / row_bcast31 across rows)
+// x = max(x, the lane's DPP source); lanes without a source keep x.  ZERO: such lanes are fed 0 instead of a copy of
+// themselves (two moves less) — only for values >= 0.
+template <int CTRL, int ROWMASK, bool ZERO>
 DEVI double dpp_max(double x) {
     const int lo = __double2loint(x), hi = __double2hiint(x);
-    // lanes without a source (row edges, rows outside ROWMASK) keep their own value
-    const int olo = __builtin_amdgcn_update_dpp(lo, lo, CTRL, ROWMASK, 0xF, false);
-    const int ohi = __builtin_amdgcn_update_dpp(hi, hi, CTRL, ROWMASK, 0xF, false);
+    const int olo = ZERO ? __builtin_amdgcn_update_dpp(0, lo, CTRL, ROWMASK, 0xF, true) : __builtin_amdgcn_update_dpp(lo, lo, CTRL, ROWMASK, 0xF, false);
+    const int ohi = ZERO ? __builtin_amdgcn_update_dpp(0, hi, CTRL, ROWMASK, 0xF, true) : __builtin_amdgcn_update_dpp(hi, hi, CTRL, ROWMASK, 0xF, false);
     return fmax(x, __hiloint2double(ohi, olo));
 }
-template <int LANE>
-DEVI double readlane_f64(double x) {
-    return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(x), LANE), __builtin_amdgcn_readlane(__double2loint(x), LANE));
+template <int CTRL>
+DEVI uint32_t dpp_max_u32(uint32_t x) {
+    const uint32_t o = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, CTRL, 0xF, 0xF, true);
+    return o > x ? o : x;
 }
-DEVI uint32_t last_bit32(uint32_t m) { return 31u - (uint32_t)__builtin_clz(m | 1u); }
-DEVI uint32_t last_bit64(unsigned long long m) { return 63u - (uint32_t)__builtin_clzll(m | 1ull); }
+// lane 15 of every row of 16 to all lanes of the row (one v_mov_b64_dpp row_newbcast)
+DEVI double row_bcast15_f64(double v) {
+    return __longlong_as_double(__builtin_amdgcn_update_dpp(__double_as_longlong(v), __double_as_longlong(v), 0x15F, 0xF, 0xF, true));
+}
+DEVI uint32_t row_bcast15_u32(uint32_t v) { return (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x15F, 0xF, 0xF, true); }
+DEVI double readlane63_f64(double x) {
+    return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(x), 63), __builtin_amdgcn_readlane(__double2loint(x), 63));
+}
+// maximum over every row of 16 lanes, in all lanes of the row
+template <bool ZERO>
+DEVI double row16_max(double x) {
+    double r = x;
+    r = dpp_max<0x111, 0xF, ZERO>(r);  // row_shr:1,2,4,8: lane 15 holds the row's maximum
+    r = dpp_max<0x112, 0xF, ZERO>(r);
+    r = dpp_max<0x114, 0xF, ZERO>(r);
+    r = dpp_max<0x118, 0xF, ZERO>(r);
+    return row_bcast15_f64(r);
+}
+DEVI uint32_t row16_max_u32(uint32_t x) {
+    uint32_t r = x;
+    r = dpp_max_u32<0x111>(r);
+    r = dpp_max_u32<0x112>(r);
+    r = dpp_max_u32<0x114>(r);
+    r = dpp_max_u32<0x118>(r);
+    return row_bcast15_u32(r);
+}
+// maximum over the wave, uniform
+template <bool ZERO>
+DEVI double wave_max(double x) {
+    double r = x;
+    r = dpp_max<0x111, 0xF, ZERO>(r);
+    r = dpp_max<0x112, 0xF, ZERO>(r);
+    r = dpp_max<0x114, 0xF, ZERO>(r);
+    r = dpp_max<0x118, 0xF, ZERO>(r);
+    r = dpp_max<0x142, 0xA, false>(r);  // row_bcast15: lanes 31 / 63 hold the maxima of the two halves
+    r = dpp_max<0x143, 0xC, false>(r);  // row_bcast31: lane 63 holds the wave's
+    return readlane63_f64(r);
+}
 
 // ---- double-double: value = hi + lo, |lo| <= ulp(hi) / 2 (so the order of two values is the order of (hi, lo))
 struct dd { double hi, lo; };
@@ -76,90 +118,65 @@ DEVI dd dd_mul_d(dd a, double b) {
     const double s = p + e;
     return {s, e - (s - p)};
 }
-DEVI bool dd_gt(dd a, dd b) { return a.hi > b.hi || (a.hi == b.hi && a.lo > b.lo); }
-DEVI bool dd_eq(dd a, dd b) { return a.hi == b.hi && a.lo == b.lo; }
-
-// maximum of x over every group of L neighbouring lanes (values are >= 0, or -1 / -inf on lanes that do not take part)
-template <int L>
-DEVI double group_max(double x, uint32_t grp) {
-    double r = x;
-    r = dpp_max<0x111, 0xF>(r);  // row_shr:1,2,4,8: lane 15 of every row of 16 holds the row's maximum
-    r = dpp_max<0x112, 0xF>(r);
-    r = dpp_max<0x114, 0xF>(r);
-    r = dpp_max<0x118, 0xF>(r);
-    if (L >= 32) r = dpp_max<0x142, 0xA>(r);  // row_bcast15: lanes 31 / 63 hold the maxima of the two halves
-    if (L == 64) r = dpp_max<0x143, 0xC>(r);  // row_bcast31: lane 63 holds the wave's
-    if (L == 64) return readlane_f64<63>(r);
-    if (L == 32) {
-        const double m0 = readlane_f64<31>(r), m1 = readlane_f64<63>(r);
-        return grp ? m1 : m0;
-    }
-    const double m0 = readlane_f64<15>(r), m1 = readlane_f64<31>(r), m2 = readlane_f64<47>(r), m3 = readlane_f64<63>(r);
-    return grp == 0 ? m0 : (grp == 1 ? m1 : (grp == 2 ? m2 : m3));
-}
-DEVI double wave_max(double x) { return group_max<64>(x, 0u); }
-// the LAST lane of this lane's group for which `hit` holds
-template <int L>
-DEVI uint32_t group_last(bool hit, uint32_t grp) {
-    const unsigned long long b = __ballot(hit);
-    if (L == 64) return last_bit64(b);
-    if (L == 32) {
-        const uint32_t l0 = last_bit32((uint32_t)b), l1 = last_bit32((uint32_t)(b >> 32));
-        return grp ? l1 : l0;
-    }
-    const uint32_t l0 = last_bit32((uint32_t)b & 0xFFFFu), l1 = last_bit32((uint32_t)(b >> 16) & 0xFFFFu),
-                   l2 = last_bit32((uint32_t)(b >> 32) & 0xFFFFu), l3 = last_bit32((uint32_t)(b >> 48) & 0xFFFFu);
-    return grp == 0 ? l0 : (grp == 1 ? l1 : (grp == 2 ? l2 : l3));
-}
-// maximum of the double-double x over every group of L lanes and the last lane that holds it: the largest hi, then
-// the largest lo among the lanes with that hi
-template <int L>
-DEVI void group_max_last(dd x, uint32_t grp, dd& m, uint32_t& last) {
-    m.hi = group_max<L>(x.hi, grp);
-    m.lo = group_max<L>(x.hi == m.hi ? x.lo : -__builtin_inf(), grp);
-    last = group_last<L>(x.hi == m.hi && x.lo == m.lo, grp);
+// (bitwise, not short-circuit: selects, no branches)
+DEVI bool dd_gt(dd a, dd b) { return (a.hi > b.hi) | ((a.hi == b.hi) & (a.lo > b.lo)); }
+DEVI bool dd_ge(dd a, dd b) { return (a.hi > b.hi) | ((a.hi == b.hi) & (a.lo >= b.lo)); }
+DEVI bool dd_eq(dd a, dd b) { return (a.hi == b.hi) & (a.lo == b.lo); }
+// the larger of two (value, state index) candidates; of equal values the larger index — what the reference's
+// scan with `>=` ends on
+struct Cand { dd v; uint32_t i; };
+DEVI Cand better(Cand a, Cand b) {
+    const bool t = dd_gt(b.v, a.v) | (dd_eq(b.v, a.v) & (b.i >= a.i));
+    return {{t ? b.v.hi : a.v.hi, t ? b.v.lo : a.v.lo}, t ? b.i : a.i};
 }
 
 // ------------------------------------------------------------------------------------------
-//  k_viterbi<L> : the forward recursion of one chain with HP = L padded paths
+//  k_viterbi<K> : the forward recursion of one chain with HP = 16 K padded paths.
+//  A row of the state matrix (first path fixed) lies in one DPP row of 16 lanes, K neighbouring second paths per lane;
+//  a wave holds 4 rows, the workgroup 16 (K = 1) or 32 rows per pass, R passes cover the matrix.
 // ------------------------------------------------------------------------------------------
-template <int L>
+template <int K>
 struct VitCfg {
-    static constexpr int NW = L == 16 ? 4 : 8;          // waves
+    static constexpr int HP = 16 * K;
+    static constexpr int NW = K == 1 ? 4 : 8;           // waves
     static constexpr int T = 64 * NW;
-    static constexpr int G = 64 / L;                    // rows of states per wave and pass
-    static constexpr int RPP = NW * G;                  // rows per pass of the workgroup
-    static constexpr int SPL = (L + RPP - 1) / RPP;     // states per lane (1 / 2 / 8)
-    static constexpr int RB = (PG_REC_ALLELES + L + 63) & ~63;  // = pg_rec_bytes(L)
+    static constexpr int RPP = NW * 4;                  // rows per pass of the workgroup
+    static constexpr int R = HP / RPP;                  // passes: 1 / 1 / 2
+    static constexpr int RB = (PG_REC_ALLELES + HP + 63) & ~63;  // = pg_rec_bytes(HP)
     static constexpr int BC = 32;                       // columns per staged block
     static constexpr int UNITS = BC * RB / 16;          // 16-byte units of a block of column records
     static constexpr int UPT = (UNITS + T - 1) / T;
+    static_assert(R * RPP == HP, "rows");
 };
-template <int L>
+template <int K>
 struct VitShared {
-    alignas(16) unsigned char rec[2][VitCfg<L>::BC * VitCfg<L>::RB];  // column records, BC columns per block, two blocks
-    alignas(16) double tq[2][VitCfg<L>::BC * 8];                      // their transition probabilities {t0, t1, t2} as (hi, lo)
-    double rmh[2][64], rml[2][64];                         // row maxima of the previous column (by step parity)
-    uint32_t rl[2][64];                                    // ... and the last second-path index that holds them
+    alignas(16) unsigned char rec[2][VitCfg<K>::BC * VitCfg<K>::RB];  // column records, BC columns per block, two blocks
+    alignas(16) double tq[2][VitCfg<K>::BC * 8];                      // their transition probabilities {t0, t1, t2} as (hi, lo)
+    alignas(16) double rmh[2][64], rml[2][64];                        // row maxima of the previous column (by step parity)
+    alignas(16) uint32_t rl[2][64];                                   // ... and the last second-path index that holds them
 };
 
-template <int L>
-__global__ __launch_bounds__((VitCfg<L>::T)) void k_viterbi(const DevContig* __restrict__ contigs) {
-    using Cfg = VitCfg<L>;
-    constexpr int SPL = Cfg::SPL, RB = Cfg::RB, T = Cfg::T, UPT = Cfg::UPT, UNITS = Cfg::UNITS;
+template <int K>
+__global__ __launch_bounds__((VitCfg<K>::T)) void k_viterbi(const DevContig* __restrict__ contigs) {
+    using Cfg = VitCfg<K>;
+    constexpr int R = Cfg::R, RB = Cfg::RB, T = Cfg::T, UPT = Cfg::UPT, UNITS = Cfg::UNITS, HP = Cfg::HP;
     constexpr uint32_t BC = Cfg::BC, BSH = 5;  // block of column c: c >> BSH
     static_assert((1u << BSH) == BC, "block size");
     const DevContig& dc = contigs[blockIdx.x];
-    if (!dc.vit_back || dc.HP != (uint32_t)L) return;  // chains of another width: their own launch
+    if (!dc.vit_back || dc.HP != (uint32_t)HP) return;  // chains of another width: their own launch
     const uint32_t C = *dc.n_cols, H = dc.H;
     if (C == 0) return;  // reference src/hmm.cpp:114
-    __shared__ VitShared<L> sh;
+    __shared__ VitShared<K> sh;
     const uint32_t tid = threadIdx.x, wave = tid >> 6, lane = tid & 63u;
-    const uint32_t grp = lane / L, p2 = lane % L, n = H * H;
-    uint32_t row[SPL];
-    bool real[SPL];
+    const uint32_t grp = lane >> 4, col0 = (lane & 15u) * K, n = H * H;
+    uint32_t row[R];
+    bool real[R][K];
 #pragma unroll
-    for (int s = 0; s < SPL; ++s) { row[s] = (uint32_t)s * Cfg::RPP + wave * Cfg::G + grp; real[s] = row[s] < H && p2 < H; }
+    for (int r = 0; r < R; ++r) {
+        row[r] = (uint32_t)r * Cfg::RPP + wave * 4u + grp;
+#pragma unroll
+        for (int k = 0; k < K; ++k) real[r][k] = row[r] < H && col0 + k < H;
+    }
     const GAS unsigned char* vrec = (const GAS unsigned char*)dc.vrec;
     const GAS uint32_t* colv = (const GAS uint32_t*)dc.col_variant;
     const GAS double* tqg = (const GAS double*)dc.vit_tq;
@@ -167,7 +184,7 @@ __global__ __launch_bounds__((VitCfg<L>::T)) void k_viterbi(const DevContig* __r
     GAS uint16_t* back = (GAS uint16_t*)dc.vit_back;
 
     // ---- block staging: the records of columns [BC b, BC b + BC) are loaded into registers while block b - 1 is
-    //      being worked on, and written to LDS at the block boundary
+    //      being worked on, and written to LDS one column before the block starts
     u32x4 pre[UPT];
     u32x4 pretq = {0u, 0u, 0u, 0u};
 #pragma unroll
@@ -192,33 +209,53 @@ __global__ __launch_bounds__((VitCfg<L>::T)) void k_viterbi(const DevContig* __r
         }
         if (tid < BC * 4u) *(u32x4*)((unsigned char*)sh.tq[blk & 1u] + tid * 16u) = pretq;
     };
-    // emission probability of this lane's states at column c (EmissionProbabilityComputer::get_emission_probability,
-    // reference src/emissionprobabilitycomputer.cpp:31-34): table of the column's record, indexed by the local
-    // alleles of the two paths; lanes outside the matrix hit the table's zero row
-    auto fetch_e = [&](uint32_t c, double (&e)[SPL]) {
+    // Emission probability of this lane's states at column c (EmissionProbabilityComputer::get_emission_probability,
+    // reference src/emissionprobabilitycomputer.cpp:31-34): table of the column's record, indexed by the local alleles
+    // of the two paths; lanes outside the matrix hit the table's zero row.  Two rounds of LDS reads, issued one column
+    // ahead and far apart in the step, so that neither is waited for: (1) the alleles, (2) the table entries.
+    struct Alleles { uint32_t la[R], lb[K]; };
+    struct WideInfo { uint32_t flags, nlocal, widx; };
+    auto fetch_alleles = [&](uint32_t c, Alleles& a) {
         const unsigned char* rec = sh.rec[(c >> BSH) & 1u] + (c & (BC - 1u)) * RB;
-        const uint32_t flags = rec[PG_REC_FLAGS];
-        uint32_t lb = rec[PG_REC_ALLELES + p2];
-        if (!(flags & PG_REC_FLAG_WIDE)) {
-            lb = lb < (uint32_t)PG_AMAX ? lb : (uint32_t)PG_AMAX;
-            const double* E = (const double*)(rec + PG_REC_E);
 #pragma unroll
-            for (int s = 0; s < SPL; ++s) {
-                uint32_t la = rec[PG_REC_ALLELES + row[s]];
-                la = la < (uint32_t)PG_AMAX ? la : (uint32_t)PG_AMAX;
-                e[s] = E[la * PG_ESTRIDE + lb];
-            }
-        } else {  // more than PG_AMAX alleles on the selected paths: the table lives in the side buffer (rare)
-            const uint32_t S = (uint32_t)rec[PG_REC_NLOCAL] + 1u;
-            const GAS double* Ew = (const GAS double*)(wide + (size_t)(*(const uint32_t*)(rec + PG_REC_WIDE_IDX)) * 16u);
-            lb = lb < S - 1u ? lb : S - 1u;
+        for (int r = 0; r < R; ++r) a.la[r] = rec[PG_REC_ALLELES + row[r]];
 #pragma unroll
-            for (int s = 0; s < SPL; ++s) {
-                uint32_t la = rec[PG_REC_ALLELES + row[s]];
-                la = la < S - 1u ? la : S - 1u;
-                e[s] = Ew[la * S + lb];
+        for (int k = 0; k < K; ++k) a.lb[k] = rec[PG_REC_ALLELES + col0 + k];
+    };
+    auto fetch_e = [&](uint32_t c, const Alleles& a, double (&e)[R][K], WideInfo& w) {
+        const unsigned char* rec = sh.rec[(c >> BSH) & 1u] + (c & (BC - 1u)) * RB;
+        const double* E = (const double*)(rec + PG_REC_E);
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            const uint32_t la = a.la[r] < (uint32_t)PG_AMAX ? a.la[r] : (uint32_t)PG_AMAX;
+#pragma unroll
+            for (int k = 0; k < K; ++k) {
+                const uint32_t lb = a.lb[k] < (uint32_t)PG_AMAX ? a.lb[k] : (uint32_t)PG_AMAX;
+                e[r][k] = E[la * PG_ESTRIDE + lb];
             }
         }
+        w.flags = rec[PG_REC_FLAGS];
+        w.nlocal = rec[PG_REC_NLOCAL];
+        w.widx = *(const uint32_t*)(rec + PG_REC_WIDE_IDX);
+    };
+    // more than PG_AMAX alleles on the selected paths: the table lives in the side buffer (rare).  The loads are
+    // waited for right here, so that the common path carries no pending load to its next wait.
+    auto fetch_e_wide = [&](const Alleles& a, const WideInfo& w, double (&e)[R][K]) {
+        const uint32_t S = w.nlocal + 1u;
+        const GAS double* Ew = (const GAS double*)(wide + (size_t)w.widx * 16u);
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            const uint32_t la = a.la[r] < S - 1u ? a.la[r] : S - 1u;
+#pragma unroll
+            for (int k = 0; k < K; ++k) {
+                const uint32_t lb = a.lb[k] < S - 1u ? a.lb[k] : S - 1u;
+                e[r][k] = Ew[la * S + lb];
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < R; ++r)
+#pragma unroll
+            for (int k = 0; k < K; ++k) asm volatile("" : "+v"(e[r][k]));
     };
 
     issue(0);
@@ -226,79 +263,132 @@ __global__ __launch_bounds__((VitCfg<L>::T)) void k_viterbi(const DevContig* __r
     __syncthreads();
     if (C > BC) issue(1);
 
-    dd cur[SPL];  // the previous column (scaled); hi = -1 outside the matrix
+    dd cur[R][K];       // the previous column (scaled); hi = -1 outside the matrix
+    double e[R][K];     // emission probabilities of the column in work
     {
-        double e[SPL];
-        fetch_e(0, e);  // first column: previous_cell = 1 (reference src/hmm.cpp:475-477)
+        Alleles a;
+        WideInfo w;
+        fetch_alleles(0, a);
+        fetch_e(0, a, e, w);  // first column: previous_cell = 1 (reference src/hmm.cpp:475-477)
+        if (w.flags & PG_REC_FLAG_WIDE) fetch_e_wide(a, w, e);
 #pragma unroll
-        for (int s = 0; s < SPL; ++s) cur[s] = {real[s] ? e[s] : -1.0, 0.0};
+        for (int r = 0; r < R; ++r)
+#pragma unroll
+            for (int k = 0; k < K; ++k) cur[r][k] = {real[r][k] ? e[r][k] : -1.0, 0.0};
+        if (C > 1u) {
+            fetch_alleles(1, a);
+            fetch_e(1, a, e, w);
+            if (w.flags & PG_REC_FLAG_WIDE) fetch_e_wide(a, w, e);
+        }
     }
     for (uint32_t c = 1; c <= C; ++c) {
-        if ((c & (BC - 1u)) == 0u && c < C) {
-            commit(c >> BSH);
+        const uint32_t cn = c + 1u;  // the column whose emissions are fetched during this step
+        if ((cn & (BC - 1u)) == 0u && cn < C) {
+            commit(cn >> BSH);
             __syncthreads();
-            if (((c >> BSH) + 1u) * BC < C) issue((c >> BSH) + 1u);
+            if (((cn >> BSH) + 1u) * BC < C) issue((cn >> BSH) + 1u);
         }
-        double e[SPL];
-        if (c < C) fetch_e(c, e);
+        Alleles an;
+        fetch_alleles(cn, an);  // (beyond the last column: stale bytes of the LDS block, never used)
+        // this step's transition probabilities: read now, used after the exchange
+        const double* tq = sh.tq[(c >> BSH) & 1u] + (c & (BC - 1u)) * 8u;
+        const dd t0 = {tq[0], tq[1]}, t1 = {tq[2], tq[3]}, t2 = {tq[4], tq[5]};
+        __builtin_amdgcn_sched_barrier(0);  // (the reads above are consumed far below: nothing waits for them here)
         const uint32_t par = c & 1u;
-        // ---- maxima of the previous column: rows inside the wave, the rest through LDS
-        dd m[SPL];
-        uint32_t ml[SPL];
+        // ---- maxima of the previous column: inside the lane, inside the row of 16 lanes, the rest through LDS
+        dd m[R];
+        uint32_t ml[R];
 #pragma unroll
-        for (int s = 0; s < SPL; ++s) {
-            group_max_last<L>(cur[s], grp, m[s], ml[s]);
-            if (p2 == 0u && row[s] < H) { sh.rmh[par][row[s]] = m[s].hi; sh.rml[par][row[s]] = m[s].lo; sh.rl[par][row[s]] = ml[s]; }
+        for (int r = 0; r < R; ++r) {
+            dd lm = cur[r][0];
+            uint32_t lk = 0;
+#pragma unroll
+            for (int k = 1; k < K; ++k) {
+                const bool t = dd_ge(cur[r][k], lm);  // >=: the last one wins
+                lm.hi = t ? cur[r][k].hi : lm.hi;
+                lm.lo = t ? cur[r][k].lo : lm.lo;
+                lk = t ? (uint32_t)k : lk;
+            }
+            m[r].hi = row16_max<true>(lm.hi);   // (an all-phantom row gives 0 instead of -1: never read)
+            m[r].lo = row16_max<false>(lm.hi == m[r].hi ? lm.lo : kNone);
+            ml[r] = row16_max_u32(((lm.hi == m[r].hi) & (lm.lo == m[r].lo)) ? col0 + lk : 0u);
+            if (((lane & 15u) == 0u) & (row[r] < H)) { sh.rmh[par][row[r]] = m[r].hi; sh.rml[par][row[r]] = m[r].lo; sh.rl[par][row[r]] = ml[r]; }
         }
         __syncthreads();
-        const uint32_t pc = p2 < H ? p2 : 0u, pl = lane < H ? lane : 0u;
-        dd colm = {p2 < H ? sh.rmh[par][pc] : -1.0, sh.rml[par][pc]};  // column p2 of a symmetric matrix = row p2
-        uint32_t coll = sh.rl[par][pc];                                // ... its last maximum sits in row rl[p2]
+        dd colm[K];      // column j of a symmetric matrix = row j
+        uint32_t coll[K];  // ... its last maximum sits in row rl[j]
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+            const uint32_t j = col0 + k < H ? col0 + k : 0u;
+            colm[k] = {col0 + k < H ? sh.rmh[par][j] : -1.0, sh.rml[par][j]};
+            coll[k] = sh.rl[par][j];
+        }
+        const uint32_t pl = lane < H ? lane : 0u;
         const dd x = {lane < H ? sh.rmh[par][pl] : -1.0, sh.rml[par][pl]};
         const uint32_t xl = sh.rl[par][pl];
+        double en[R][K];
+        WideInfo wn;
+        fetch_e(cn, an, en, wn);  // (second round of the emission prefetch, in the shadow of the reads above)
         dd gmax;
-        gmax.hi = wave_max(x.hi);
-        gmax.lo = wave_max(x.hi == gmax.hi ? x.lo : -__builtin_inf());
-        const uint32_t ga = last_bit64(__ballot(x.hi == gmax.hi && x.lo == gmax.lo));  // last row that holds the column's maximum
+        gmax.hi = wave_max<true>(x.hi);
+        gmax.lo = wave_max<false>(x.hi == gmax.hi ? x.lo : kNone);
+        const uint32_t ga = last_bit64(__ballot((x.hi == gmax.hi) & (x.lo == gmax.lo)));  // last row that holds the column's maximum
         uint32_t gidx = ga * H + (uint32_t)__builtin_amdgcn_readlane((int)xl, (int)__builtin_amdgcn_readfirstlane((int)ga));
         if (!(gmax.hi > 0.0)) {
             // the previous column was all 0: the reference sets it to the constant 1/n (src/hmm.cpp:484-491)
 #pragma unroll
-            for (int s = 0; s < SPL; ++s) { cur[s] = {real[s] ? 1.0 : -1.0, 0.0}; m[s] = {1.0, 0.0}; ml[s] = H - 1u; }
-            colm = {p2 < H ? 1.0 : -1.0, 0.0}; coll = H - 1u;
+            for (int r = 0; r < R; ++r) {
+#pragma unroll
+                for (int k = 0; k < K; ++k) cur[r][k] = {real[r][k] ? 1.0 : -1.0, 0.0};
+                m[r] = {1.0, 0.0}; ml[r] = H - 1u;
+            }
+#pragma unroll
+            for (int k = 0; k < K; ++k) { colm[k] = {col0 + k < H ? 1.0 : -1.0, 0.0}; coll[k] = H - 1u; }
             gmax = {1.0, 0.0}; gidx = n - 1u;
         }
         if (c == C) {  // best state of the last column: the last maximum (reference src/hmm.cpp:131-141)
             if (tid == 0) *dc.vit_best = gidx;
             break;
         }
-        const double* tq = sh.tq[(c >> BSH) & 1u] + (c & (BC - 1u)) * 8u;
-        const dd t0 = {tq[0], tq[1]}, t1 = {tq[2], tq[3]}, t2 = {tq[4], tq[5]};
         int ex;
         (void)frexp(gmax.hi, &ex);
         const double scale = ldexp(1.0, -ex);  // exact: the new column's largest entry lands below 1
-        const dd gv = dd_mul(gmax, t2), cv = dd_mul(colm, t1);
-        const uint32_t ci = coll * H + p2;
-        GAS uint16_t* bk = back + (size_t)c * n;
+        const Cand g = {dd_mul(gmax, t2), gidx};
+        Cand cc[K];
 #pragma unroll
-        for (int s = 0; s < SPL; ++s) {
-            const uint32_t i = row[s] * H + p2;
-            dd v = dd_mul(cur[s], t0);
-            uint32_t idx = i;
-            auto take = [&](dd w, uint32_t wi) {
-                const bool b = dd_gt(w, v) || (dd_eq(w, v) && wi >= idx);
-                v.hi = b ? w.hi : v.hi;
-                v.lo = b ? w.lo : v.lo;
-                idx = b ? wi : idx;
-            };
-            take(dd_mul(m[s], t1), row[s] * H + ml[s]);
-            take(cv, ci);
-            take(gv, gidx);
-            if (v.hi == 0.0) idx = n - 1u;  // every product is 0: the reference's scan ends on the last state
-            if (real[s]) bk[i] = (uint16_t)idx;
-            const dd nv = dd_mul_d(v, e[s]);
-            cur[s] = {real[s] ? nv.hi * scale : -1.0, real[s] ? nv.lo * scale : 0.0};
+        for (int k = 0; k < K; ++k) cc[k] = {dd_mul(colm[k], t1), coll[k] * H + col0 + k};
+        GAS uint16_t* bk = back + (size_t)c * H * HP;
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            const Cand rg = better({dd_mul(m[r], t1), row[r] * H + ml[r]}, g);  // row or anywhere: the same for the whole row
+            uint32_t idx[K];
+#pragma unroll
+            for (int k = 0; k < K; ++k) {
+                Cand b = {dd_mul(cur[r][k], t0), row[r] * H + col0 + k};
+                b = better(b, rg);
+                b = better(b, cc[k]);
+                if (b.v.hi == 0.0) b.i = n - 1u;  // every product is 0: the reference's scan ends on the last state
+                idx[k] = b.i;
+                const dd nv = dd_mul_d(b.v, e[r][k]);
+                cur[r][k] = {real[r][k] ? nv.hi * scale : -1.0, real[r][k] ? nv.lo * scale : 0.0};
+            }
+            // K backpointers of one row, neighbouring second paths: one aligned store (row stride HP)
+            if (row[r] < H && col0 < H) {
+                GAS uint16_t* o = bk + row[r] * HP + col0;
+                if (K == 1) o[0] = (uint16_t)idx[0];
+                else if (K == 2) *(GAS uint32_t*)o = idx[0] | (idx[K > 1 ? 1 : 0] << 16);
+                else {
+                    typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+                    const u32x2 w = {idx[0] | (idx[K > 1 ? 1 : 0] << 16), idx[K > 2 ? 2 : 0] | (idx[K > 3 ? 3 : 0] << 16)};
+                    *(GAS u32x2*)o = w;
+                }
+            }
         }
+        if ((wn.flags & PG_REC_FLAG_WIDE) && cn < C) fetch_e_wide(an, wn, en);
+#pragma unroll
+        for (int r = 0; r < R; ++r)
+#pragma unroll
+            for (int k = 0; k < K; ++k) e[r][k] = en[r][k];
     }
 }
 
@@ -308,7 +398,7 @@ __global__ __launch_bounds__((VitCfg<L>::T)) void k_viterbi(const DevContig* __r
 __global__ __launch_bounds__(64) void k_vit_backtrack(const DevContig* __restrict__ contigs) {
     const DevContig& dc = contigs[blockIdx.x];
     if (!dc.vit_back) return;
-    const uint32_t C = *dc.n_cols, H = dc.H, n = H * H;
+    const uint32_t C = *dc.n_cols, H = dc.H, HP = dc.HP, n = H * H;
     if (C == 0) return;
     const uint32_t lane = threadIdx.x;
     const GAS uint16_t* back = (const GAS uint16_t*)dc.vit_back;
@@ -320,7 +410,7 @@ __global__ __launch_bounds__(64) void k_vit_backtrack(const DevContig* __restric
         const int cc = c - (int)lane;
         const bool valid = cc >= 1;
         uint32_t b = 0xFFFFFFFFu;
-        if (valid) b = back[(size_t)cc * n + s];
+        if (valid) b = back[((size_t)cc * H + s / H) * HP + s % H];  // (rows of the backtrace are HP entries apart)
         const unsigned long long stay = __ballot(valid && b == s);
         const uint32_t r = stay == ~0ull ? 64u : (uint32_t)__builtin_ctzll(~stay);
         // columns c, c-1, ..., c-r are in state s
@@ -343,8 +433,8 @@ __global__ __launch_bounds__(64) void k_vit_backtrack(const DevContig* __restric
 // hp_bits: 1 / 2 / 4 = the job has phasing chains with 16 / 32 / 64 padded paths
 extern "C" void pgk_launch_viterbi(const DevContig* d_contigs, uint32_t n, uint32_t max_v, uint32_t hp_bits, hipStream_t s) {
     if (n == 0 || max_v == 0) return;
-    if (hp_bits & 1u) k_viterbi<16><<<n, VitCfg<16>::T, 0, s>>>(d_contigs);
-    if (hp_bits & 2u) k_viterbi<32><<<n, VitCfg<32>::T, 0, s>>>(d_contigs);
-    if (hp_bits & 4u) k_viterbi<64><<<n, VitCfg<64>::T, 0, s>>>(d_contigs);
+    if (hp_bits & 1u) k_viterbi<1><<<n, VitCfg<1>::T, 0, s>>>(d_contigs);
+    if (hp_bits & 2u) k_viterbi<2><<<n, VitCfg<2>::T, 0, s>>>(d_contigs);
+    if (hp_bits & 4u) k_viterbi<4><<<n, VitCfg<4>::T, 0, s>>>(d_contigs);
     k_vit_backtrack<<<n, 64, 0, s>>>(d_contigs);
 }
