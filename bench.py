@@ -55,6 +55,8 @@ WORKLOADS = {
 }
 # the sampler measurement: contigs x variants x panel paths, 15 passes (the reference's default panel size)
 SAMPLER = {"contigs": 8, "V": 40_000, "H": 215, "size": 15}
+# the phasing (Viterbi) measurement: contigs x variants x selected paths (the reference's callers pass 30, src/commands.cpp:939)
+VITERBI = {"contigs": 8, "V": 100_000, "H": 30}
 # the cohort measurement: samples x contigs over one shared index
 COHORT = dict(samples=64, contigs=8, V=16_000, H=64, K=20)  # 512 chains, 194 GB of the 288 (columns as compact triangles)
 # GRCh38 chromosome lengths (Mb) 1..22, X, Y: proportions of the 24 synthetic contigs
@@ -203,6 +205,7 @@ def main():
     ap.add_argument("--no-cohort", action="store_true", help="skip the cohort sub-measurement")
     ap.add_argument("--cohort-only", action="store_true", help="profiling: only the cohort measurement")
     ap.add_argument("--no-sampler", action="store_true", help="skip the HaplotypeSampler sub-measurement")
+    ap.add_argument("--no-viterbi", action="store_true", help="skip the Viterbi phasing sub-measurement")
     ap.add_argument("--cohort-samples", type=int, default=COHORT["samples"])
     args = ap.parse_args()
 
@@ -419,6 +422,45 @@ def main():
                 ref, _ = orc.sampler_run(small, sp["size"])
                 sres["matches_oracle"] = bool((got[0] == ref).all())
             out["sampler"] = sres
+
+    # ------------------------------------------------------------------ Viterbi phasing sub-measurement (run_phasing)
+    if not args.no_viterbi and not args.cohort_only:
+        vp = VITERBI
+        vpanels = [synthetic_panel(vp["V"], vp["H"], 20, seed=777 + 100 * rank + i) for i in range(vp["contigs"])]
+        vprm = hmm.make_params(1.26, False, 1e-5, run_genotyping=False, run_phasing=True)
+        vjob = hmm.Job(vpanels, table, vprm, device=local_rank)
+        vjob.run()  # warm-up: module load, the transition constants of the kept columns (host, long double, once per index)
+        fence()
+        t0 = time.perf_counter()
+        vjob.run()
+        fence()
+        vdt = max_over_ranks(time.perf_counter() - t0)
+        vms = vjob.viterbi_ms()
+        if rank == 0:
+            vcols = [int(vjob.fetch(i).n_columns) for i in range(vp["contigs"])]
+            vres = {"workload": f"{vp['contigs']} contigs x {vp['V']} variants, {vp['H']} selected paths, phasing only (run_phasing), per GPU",
+                    "value": sum(vcols) * world / (1e-3 * vms), "unit": "columns/s (Viterbi kernels)", "scaling": "weak",
+                    "value_end_to_end": sum(vcols) * world / vdt, "viterbi_ms": vms, "ns_per_column_of_a_chain": 1e6 * vms / max(vcols),
+                    "bound": "latency: one workgroup per chain, dependent chain per column (DESIGN.md 4c)", "device_bytes": vjob.device_bytes()}
+            if not args.no_cpu_baseline:
+                from oracle import pyoracle as orc  # checker / CPU baseline only
+                otab = orc.OracleTable(*default_table_args())
+                oprm = orc.make_params(1.26, False, 1e-5, run_genotyping=False, run_phasing=True)
+                sub = vpanels[0].slice(0, 300)
+                t0 = time.perf_counter()
+                orc.viterbi_contig(sub, otab, oprm, form=0)  # the reference's own O(H^4) loop
+                cdt_v = time.perf_counter() - t0
+                small = vpanels[0].slice(0, 5000)
+                t0 = time.perf_counter()
+                ref = orc.viterbi_contig(small, otab, oprm, form=1)  # the same maxima in O(H^2)
+                cdt_f = time.perf_counter() - t0
+                vres["cpu_baseline"] = {"value": sub.n_variants / cdt_v, "unit": "columns/s", "cores": 1, "kind": "port",
+                                        "sample": f"first {sub.n_variants} variants of contig 0, the reference's O(H^4) scan (oracle form 0)",
+                                        "o_h2_form_columns_per_s": small.n_variants / cdt_f}
+                got = hmm.genotype_contig(small, table, vprm, device=local_rank)
+                vres["matches_oracle"] = bool((got.haplotype_1 == ref.hap1).all() and (got.haplotype_2 == ref.hap2).all())
+            out["viterbi"] = vres
+        vjob.close()
 
     if rank == 0:
         print(json.dumps(out))

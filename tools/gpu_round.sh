@@ -27,4 +27,12 @@ if [ "${2:-}" != "quick" ]; then
   run bench_h16 600 python bench.py --workload contig_h16 --no-cohort --steps 3 --warmup 1
   run bench_h128 600 python bench.py --workload chr22_h128 --no-cohort --steps 3 --warmup 1
 fi
+if [ "${2:-}" != "quick" ]; then
+  # kernel trace of the Viterbi timing script (profiles/<tag>_viterbi_kernel_stats.csv)
+  ( cd /tmp && export TMPDIR=/tmp && cd $R && mkdir -p gpurun_out/profiles &&
+    timeout 600 rocprofv3 --kernel-trace --stats -d $O/viterbi_kt -o kt --output-format csv -- python tools/bench_viterbi.py > $O/viterbi_kt.log 2>&1
+    rm -f $O/viterbi_kt/*kernel_trace.csv $O/viterbi_kt/*agent_info.csv
+    cp $O/viterbi_kt/kt_kernel_stats.csv gpurun_out/profiles/${TAG}_viterbi_kernel_stats.csv 2>/dev/null
+    grep "^{" $O/viterbi_kt.log > gpurun_out/profiles/${TAG}_viterbi_bench.jsonl 2>/dev/null )
+fi
 echo "total $(( $(date +%s) - T0 )) s" | tee -a $O/summary.txt
