@@ -178,3 +178,68 @@ def dumps(m: UniqueKmersMap) -> bytes:
 def dump(m: UniqueKmersMap, path) -> None:
     with open(path, "wb") as f:
         f.write(dumps(m))
+
+
+# --------------------------------------------------------------------------- #
+#  Results: what PanGenie serializes with `-w` to <out>_genotyping.cereal (reference
+#  src/commands.cpp:59-72, :511-516, :1012-1017) and PanGenie-vcf reads back (:1099-1104).
+#  map<string, vector<GenotypingResult>> + runtimes map<string, f64>; a GenotypingResult is
+#  genotype_to_likelihood (u64 n; per entry u16 a1, u16 a2, long double = its 16 bytes in memory: the
+#  80-bit value + 6 padding bytes) · haplotype_1 · haplotype_2 · local_coverage · unique_kmers (u16 each)
+#  (src/genotypingresult.hpp:13-29, :77-80).  Same layout as pangenie_amd/host/cereal_io.hpp.
+# --------------------------------------------------------------------------- #
+@dataclass
+class Results:
+    result: Dict[str, list] = field(default_factory=dict)   # chromosome -> [GenotypingResult]
+    runtimes: Dict[str, float] = field(default_factory=dict)
+
+
+def loads_results(data: bytes) -> Results:
+    import numpy as np
+    from .genotyping_result import GenotypingResult
+    r = _Reader(data)
+    out = Results()
+    for _ in range(r.take("Q")):
+        name = r.string()
+        lst = []
+        for _ in range(r.take("Q")):
+            g = GenotypingResult()
+            for _ in range(r.take("Q")):
+                a1, a2 = r.take("HH")
+                lik = np.frombuffer(r.d[r.o:r.o + 16], dtype=np.longdouble)[0]
+                r.o += 16
+                g.genotype_to_likelihood[(a1, a2)] = lik
+            g.haplotype_1, g.haplotype_2, g.local_coverage, g.unique_kmers = r.take("HHHH")
+            lst.append(g)
+        out.result[name] = lst
+    out.runtimes = _read_str_double_map(r)
+    if r.o != len(data):
+        raise ValueError("Results archive: trailing bytes")
+    return out
+
+
+def dumps_results(res: Results) -> bytes:
+    import numpy as np
+    out = bytearray()
+    w = lambda fmt, *v: out.extend(struct.pack("<" + fmt, *v))
+
+    def string(s: str):
+        b = s.encode()
+        w("Q", len(b))
+        out.extend(b)
+    w("Q", len(res.result))
+    for name in sorted(res.result):  # std::map order
+        string(name)
+        w("Q", len(res.result[name]))
+        for g in res.result[name]:
+            w("Q", len(g.genotype_to_likelihood))
+            for (a1, a2) in sorted(g.genotype_to_likelihood):
+                w("HH", a1, a2)
+                raw = np.array([g.genotype_to_likelihood[(a1, a2)]], dtype=np.longdouble).tobytes()
+                out.extend(raw[:10] + b"\x00" * 6)
+            w("HHHH", g.haplotype_1, g.haplotype_2, g.local_coverage, g.unique_kmers)
+    w("Q", len(res.runtimes))
+    for k in sorted(res.runtimes):
+        string(k)
+        w("d", res.runtimes[k])
+    return bytes(out)

@@ -186,4 +186,79 @@ void save_unique_kmers_map(const UniqueKmersMap& m, const std::string& path) {
     f.write((const char*)b.data(), (std::streamsize)b.size());
 }
 
+// ------------------------------------------------------------------ Results (`-w`: <out>_genotyping.cereal)
+Results parse_results(const std::vector<unsigned char>& bytes) {
+    Reader r{bytes.data(), bytes.size()};
+    Results out;
+    const uint64_t nc = r.take<uint64_t>();
+    for (uint64_t c = 0; c < nc; ++c) {
+        const std::string name = r.str();
+        const uint64_t nv = r.take<uint64_t>();
+        if (nv > bytes.size()) throw std::runtime_error("Results archive: implausible vector size");
+        std::vector<GenotypingResult>& vec = out.result[name];
+        vec.resize((size_t)nv);
+        for (uint64_t v = 0; v < nv; ++v) {
+            GenotypingResult& g = vec[(size_t)v];
+            const uint64_t nl = r.take<uint64_t>();
+            for (uint64_t l = 0; l < nl; ++l) {
+                const unsigned short a1 = r.take<uint16_t>(), a2 = r.take<uint16_t>();
+                if (r.o + 16 > r.n) throw std::runtime_error("Results archive: truncated");
+                long double lik = 0.0L;
+                std::memcpy(&lik, r.p + r.o, 10);  // the 80-bit value; 6 bytes of padding follow
+                r.o += 16;
+                g.add_to_likelihood(a1, a2, lik);
+            }
+            g.add_first_haplotype_allele(r.take<uint16_t>());
+            g.add_second_haplotype_allele(r.take<uint16_t>());
+            g.set_coverage(r.take<uint16_t>());
+            g.set_unique_kmers(r.take<uint16_t>());
+        }
+    }
+    out.runtimes = read_str_double(r);
+    if (r.o != r.n) throw std::runtime_error("Results archive: trailing bytes");
+    return out;
+}
+
+std::vector<unsigned char> serialize_results(const Results& res) {
+    static_assert(sizeof(long double) == 16, "x86-64 long double");
+    Writer w;
+    w.put<uint64_t>(res.result.size());
+    for (const auto& kv : res.result) {
+        w.str(kv.first);
+        w.put<uint64_t>(kv.second.size());
+        for (const GenotypingResult& g : kv.second) {
+            const auto& m = g.get_stored_likelihoods();
+            w.put<uint64_t>(m.size());
+            for (const auto& e : m) {
+                w.put<uint16_t>(e.first.first);
+                w.put<uint16_t>(e.first.second);
+                unsigned char b[16] = {0};
+                std::memcpy(b, &e.second, 10);
+                w.out.insert(w.out.end(), b, b + 16);
+            }
+            w.put<uint16_t>(g.get_haplotype().first);
+            w.put<uint16_t>(g.get_haplotype().second);
+            w.put<uint16_t>(g.coverage());
+            w.put<uint16_t>(g.nr_unique_kmers());
+        }
+    }
+    w.put<uint64_t>(res.runtimes.size());
+    for (const auto& kv : res.runtimes) { w.str(kv.first); w.put<double>(kv.second); }
+    return w.out;
+}
+
+Results load_results(const std::string& path) {
+    std::ifstream is(path, std::ios::binary);
+    if (!is) throw std::runtime_error("cannot open " + path);
+    std::vector<unsigned char> bytes((std::istreambuf_iterator<char>(is)), std::istreambuf_iterator<char>());
+    return parse_results(bytes);
+}
+
+void save_results(const Results& r, const std::string& path) {
+    std::ofstream os(path, std::ios::binary);
+    if (!os) throw std::runtime_error("cannot open " + path);
+    const std::vector<unsigned char> bytes = serialize_results(r);
+    os.write((const char*)bytes.data(), (std::streamsize)bytes.size());
+}
+
 }  // namespace pangenie

@@ -1,6 +1,6 @@
-// cereal_io.hpp — reader / writer of the reference's cereal *binary* archives of UniqueKmers tables
-// (`<prefix>_UniqueKmersMap.cereal`, the index PanGenie-index writes and PanGenie reads: reference
-// src/commands.hpp:11-28, src/commands.cpp:653-705, :771-777) — without cereal.
+// cereal_io.hpp — reader / writer of the reference's cereal *binary* archives either side of the path — without
+// cereal: the UniqueKmers tables (`<prefix>_UniqueKmersMap.cereal`, the index PanGenie-index writes and PanGenie reads:
+// reference src/commands.hpp:11-28, src/commands.cpp:653-705, :771-777) and the genotyping Results (`-w`, below).
 //
 // Layout (little endian, no framing; member order from the reference's serialize functions
 // src/commands.hpp:19-22, src/biallelicuniquekmers.hpp:101-104 and :32-41,
@@ -38,5 +38,21 @@ UniqueKmersMap load_unique_kmers_map(const std::string& path);
 UniqueKmersMap parse_unique_kmers_map(const std::vector<unsigned char>& bytes);
 std::vector<unsigned char> serialize_unique_kmers_map(const UniqueKmersMap& m);
 void save_unique_kmers_map(const UniqueKmersMap& m, const std::string& path);
+
+/** reference src/commands.cpp:59-72 (without the mutex): the object PanGenie serializes with `-w` to
+ *  `<out>_genotyping.cereal` (src/commands.cpp:511-516, :1012-1017) and PanGenie-vcf reads back (:1099-1104) to write
+ *  the VCFs.  Layout: map<string, vector<GenotypingResult>> (u64 n; per entry string, u64 n, per element:
+ *  genotype_to_likelihood — u64 n; per entry u16 a1, u16 a2 (the reference's own pair serializer,
+ *  src/genotypingresult.hpp:13-29), long double as its 16 bytes in memory (x86-64: 80-bit value + 6 padding bytes,
+ *  written as 0 here) — · haplotype_1 u16 · haplotype_2 u16 · local_coverage u16 · unique_kmers u16
+ *  (src/genotypingresult.hpp:77-80)) · runtimes map<string, f64>. */
+struct Results {
+    std::map<std::string, std::vector<GenotypingResult>> result;
+    std::map<std::string, double> runtimes;
+};
+Results load_results(const std::string& path);
+Results parse_results(const std::vector<unsigned char>& bytes);
+std::vector<unsigned char> serialize_results(const Results& r);
+void save_results(const Results& r, const std::string& path);
 
 }  // namespace pangenie

@@ -213,7 +213,57 @@ static void cpu_tests() {
 static const double R01 = 446.287102628;  // recombination rate that gives recombination probability 0.1
 
 static std::string g_golden_dir = "tests/golden";
+// the Results object of the archive tests: two chromosomes, likelihood maps, haplotypes, meta data
+static Results sample_results() {
+    Results r;
+    GenotypingResult a;
+    a.add_to_likelihood(0, 0, 0.5L); a.add_to_likelihood(0, 1, 0.25L); a.add_to_likelihood(1, 1, 1.0L / 3.0L);
+    a.add_first_haplotype_allele(1); a.add_second_haplotype_allele(0); a.set_coverage(27); a.set_unique_kmers(20);
+    GenotypingResult b;  // no likelihoods (a skipped variant)
+    b.set_coverage(3);
+    GenotypingResult c;
+    c.add_to_likelihood(2, 5, 1e-4000L);  // below the double range: the archive keeps the long double
+    c.add_first_haplotype_allele(5); c.add_second_haplotype_allele(2); c.set_unique_kmers(301);
+    r.result["chr1"] = {a, b};
+    r.result["chr10"] = {c};
+    r.runtimes["chr1"] = 1.5; r.runtimes["chr10"] = 0.125;
+    return r;
+}
+
 static void archive_cpu_tests() {
+    run("cereal binary archive: Results (`-w`, what PanGenie-vcf reads) layout and round trip", [] {
+        // the smallest case byte by byte: one chromosome "c", one result with one likelihood 0.5 of genotype (0, 1)
+        Results one;
+        GenotypingResult g;
+        g.add_to_likelihood(0, 1, 0.5L); g.add_first_haplotype_allele(1); g.add_second_haplotype_allele(0); g.set_coverage(7); g.set_unique_kmers(9);
+        one.result["c"] = {g};
+        one.runtimes["c"] = 2.0;
+        const std::vector<unsigned char> want = {
+            1, 0, 0, 0, 0, 0, 0, 0,                                   // map size
+            1, 0, 0, 0, 0, 0, 0, 0, 'c',                              // key
+            1, 0, 0, 0, 0, 0, 0, 0,                                   // vector size
+            1, 0, 0, 0, 0, 0, 0, 0,                                   // genotype_to_likelihood size
+            0, 0, 1, 0,                                               // pair (0, 1)
+            0, 0, 0, 0, 0, 0, 0, 0x80, 0xFE, 0x3F, 0, 0, 0, 0, 0, 0,  // 0.5L: mantissa 2^63, exponent 0x3FFE, 6 padding bytes
+            1, 0, 0, 0, 7, 0, 9, 0,                                   // haplotype_1, haplotype_2, local_coverage, unique_kmers
+            1, 0, 0, 0, 0, 0, 0, 0,                                   // runtimes size
+            1, 0, 0, 0, 0, 0, 0, 0, 'c', 0, 0, 0, 0, 0, 0, 0, 0x40};  // "c" -> 2.0
+        CHECK(serialize_results(one) == want);
+        const Results r = sample_results();
+        const std::vector<unsigned char> bytes = serialize_results(r);
+        Results back = parse_results(bytes);
+        CHECK(serialize_results(back) == bytes);
+        CHECK(back.result.size() == 2 && back.result["chr1"].size() == 2 && back.result["chr10"].size() == 1);
+        CHECK(back.result["chr1"][0].get_stored_likelihoods() == r.result.at("chr1")[0].get_stored_likelihoods());
+        CHECK(back.result["chr1"][0].get_haplotype() == std::make_pair((unsigned short)1, (unsigned short)0));
+        CHECK(back.result["chr1"][0].coverage() == 27 && back.result["chr1"][0].nr_unique_kmers() == 20);
+        CHECK(back.result["chr1"][1].contains_no_likelihoods() && back.result["chr1"][1].coverage() == 3);
+        CHECK(back.result["chr10"][0].get_genotype_likelihood(5, 2) == 1e-4000L && back.result["chr10"][0].nr_unique_kmers() == 301);
+        CHECK(back.runtimes["chr10"] == 0.125);
+        bool threw = false;
+        try { std::vector<unsigned char> cut(bytes.begin(), bytes.end() - 3); parse_results(cut); } catch (const std::runtime_error&) { threw = true; }
+        CHECK(threw);
+    });
     run("cereal binary archive: the reference's own fixtures parse and re-serialise byte for byte", [] {
         for (const char* name : {"region_UniqueKmersList.cereal", "region2_UniqueKmersList.cereal"}) {
             const std::string path = g_golden_dir + "/" + name;
@@ -757,6 +807,10 @@ int main(int argc, char** argv) {
     if (argc > 2) g_golden_dir = argv[2];
     if (mode == "cpu") { cpu_tests(); viterbi_cpu_tests(); archive_cpu_tests(); sampler_cpu_tests(); }
     else if (mode == "gpu") { gpu_tests(); sampler_gpu_tests(); }
+    else if (mode == "dump-results" && argc >= 3) {  // the archive of sample_results() for the Python reader (tests/test_cereal_io.py)
+        save_results(sample_results(), argv[2]);
+        return 0;
+    }
     else if (mode == "dump-viterbi" && argc >= 5) {
         // haplotypes of the host Viterbi on viterbi_panel(V, H) in a regime: "h1 h2" per variant (debugging aid)
         const size_t V = (size_t)atol(argv[2]), H = (size_t)atol(argv[3]);

@@ -73,3 +73,27 @@ def test_fixtures_hip_vs_oracle_down_to_the_vcf_column():
             g.normalize()
             got.append(vcf_sample_field(g, d, len(u.alleles)))
         assert got == want, (got, want)
+
+
+def test_results_archive_cpp_writer_python_reader(tmp_path):
+    """`-w` Results archive (<out>_genotyping.cereal, reference src/commands.cpp:59-72, :511-516): the C++ writer
+    (pangenie_amd/host/cereal_io.cpp) and the independent Python reader / writer agree byte for byte, and the values
+    come back as 80-bit long doubles (one of them below the double range)."""
+    import subprocess
+    from pangenie_amd.build import build_host, HOST_TEST
+    build_host()
+    path = tmp_path / "x_genotyping.cereal"
+    subprocess.run([str(HOST_TEST), "dump-results", str(path)], check=True)
+    raw = path.read_bytes()
+    res = cereal_io.loads_results(raw)
+    assert sorted(res.result) == ["chr1", "chr10"] and [len(res.result[c]) for c in ("chr1", "chr10")] == [2, 1]
+    a, b = res.result["chr1"]
+    LD = np.longdouble
+    assert a.genotype_to_likelihood == {(0, 0): LD(0.5), (0, 1): LD(0.25), (1, 1): LD(1) / LD(3)}
+    assert (a.haplotype_1, a.haplotype_2, a.local_coverage, a.unique_kmers) == (1, 0, 27, 20)
+    assert b.contains_no_likelihoods() and b.local_coverage == 3
+    c = res.result["chr10"][0]
+    assert c.genotype_to_likelihood[(2, 5)] == LD("1e-4000") and c.genotype_to_likelihood[(2, 5)] > 0
+    assert (c.haplotype_1, c.haplotype_2, c.unique_kmers) == (5, 2, 301)
+    assert res.runtimes == {"chr1": 1.5, "chr10": 0.125}
+    assert cereal_io.dumps_results(res) == raw
