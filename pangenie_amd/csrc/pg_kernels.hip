@@ -638,11 +638,36 @@ __global__ __launch_bounds__(64) void k_transition_single(double d, uint32_t H, 
 // ------------------------------------------------------------------------------------------
 //  k_records : gather variant records into column order, fill transition constants
 // ------------------------------------------------------------------------------------------
+// Chains whose sweeps read only the compact records (triangle chains on k_sweep_lean / k_sweep_lean2, at least two
+// columns) get nothing else: one THREAD per column forms the transition constants and gathers the 64-byte record;
+// k_bins reads the variant record itself.  (The column-order copy of the full 448-byte records, one wave per column
+// with 64 lanes computing the same exp(), was 4.6 ms of the cohort's 80.)
+DEVI bool compact_records_only(const DevContig& dc, uint32_t C) { return dc.tri == 2u && C >= 2u; }
+
 __global__ __launch_bounds__(256) void k_records(const DevContig* __restrict__ contigs) {
     const DevContig& dc = contigs[blockIdx.y];
     const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const uint32_t c = blockIdx.x * 4 + wave;
     const uint32_t C = *dc.n_cols;
+    if (compact_records_only(dc, C)) {
+        const uint32_t c = blockIdx.x * 256u + threadIdx.x;
+        if (c >= C) return;
+        const uint32_t v = dc.col_variant[c];
+        const uint64_t* src = (const uint64_t*)(dc.vrec + (size_t)v * dc.RB);
+        double c0 = 0.0, c1 = 0.0, c2 = 0.0, kappa = 0.0;
+        if (c > 0) {
+            const double d = (double)(dc.pos[v] - dc.pos[dc.col_variant[c - 1]]) * dc.dist_scale;
+            transition_consts(d, dc.H, dc.uniform, c0, c1, c2, kappa);
+        }
+        const uint64_t* E = src + PG_REC_E / 8;
+        typedef double f64x2 __attribute__((ext_vector_type(2)));
+        f64x2* out = (f64x2*)(dc.frec + (size_t)c * 8);
+        out[0] = f64x2{c0, c1};
+        out[1] = f64x2{c2, kappa};
+        out[2] = f64x2{__longlong_as_double((long long)E[0]), __longlong_as_double((long long)E[1])};
+        out[3] = f64x2{__longlong_as_double((long long)E[PG_ESTRIDE + 1]), __longlong_as_double((long long)src[PG_REC_BITS1 / 8])};
+        return;
+    }
+    const uint32_t c = blockIdx.x * 4 + wave;
     if (c >= C) return;
     const uint32_t v = dc.col_variant[c];
     const uint64_t* src = (const uint64_t*)(dc.vrec + (size_t)v * dc.RB);
@@ -3547,7 +3572,9 @@ __global__ __launch_bounds__(256) void k_bins(const DevContig* __restrict__ cont
     const uint32_t c = blockIdx.x * 4 + wave;
     const uint32_t C = *dc.n_cols;
     if (c >= C) return;
-    const unsigned char* rec = dc.colrec + (size_t)c * dc.RB;
+    // (chains with compact records only have no column-order copy of the records: the variant's own record)
+    const bool direct = compact_records_only(dc, C);
+    const unsigned char* rec = direct ? dc.vrec + (size_t)dc.col_variant[c] * dc.RB : dc.colrec + (size_t)c * dc.RB;
     const uint32_t v = *(const uint32_t*)(rec + PG_REC_VARIANT);
     const uint32_t nl = rec[PG_REC_NLOCAL];
     const uint32_t T = dc.T, HP = dc.HP;
@@ -3628,7 +3655,8 @@ __global__ __launch_bounds__(256) void k_bins(const DevContig* __restrict__ cont
     // uniform column itself: absolute value, no emission, no scale, no bias.
     const double scale = 1.0 / ((fb ? 1.0 : dc.fscale[c]) * dc.bscale[c]);
     int xexp = -((fb ? 0 : PG_BIAS_F) + PG_BIAS_B);
-    if (c + 1 < C) xexp += *(const int32_t*)(dc.colrec + (size_t)(c + 1) * dc.RB + PG_REC_EXP);
+    if (c + 1 < C)
+        xexp += *(const int32_t*)((direct ? dc.vrec + (size_t)dc.col_variant[c + 1] * dc.RB : dc.colrec + (size_t)(c + 1) * dc.RB) + PG_REC_EXP);
     // triangle storage: the partials are sums over the upper triangle with the diagonal halved = half of the bin
     if (dc.tri && !(fb && c >= C / 2)) xexp += 1;
     const uint32_t pn = dc.pair_n, NP = (pn * (pn + 1) / 2 + 1u) & ~1u;
