@@ -287,6 +287,7 @@ __global__ __launch_bounds__(256) void k_prep(const DevContig* __restrict__ cont
     __shared__ uint16_t s_aid[4][64];   // the variant's allele ids / flags (objects with <= 64 alleles: every real one)
     __shared__ uint8_t s_afl[4][64];
     const DevContig& dc = contigs[blockIdx.y];
+    if (dc.prep_fast) return;  // k_prep_bi's chain
     const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const uint32_t v = blockIdx.x * 4 + wave;
     if (v >= dc.V) return;  // whole wave leaves; the kernel only uses wave-level sync
@@ -560,6 +561,170 @@ __global__ __launch_bounds__(256) void k_prep(const DevContig* __restrict__ cont
     }
 }
 
+
+// ------------------------------------------------------------------------------------------
+//  k_prep_bi : the same for chains of biallelic objects with <= 32 k-mers and <= 64 selected paths (every BASELINE
+//  shape but the multiallelic one) — FOUR variants per wave, one per DPP row of 16 lanes.  k_prep spends a whole wave,
+//  its LDS staging and half a dozen wave syncs on 3 allele pairs x 20 k-mers; here a lane takes 4 paths and 2 k-mers,
+//  the three pair products are folded by DPP row shifts, nothing goes through LDS.  Same factors as k_prep
+//  (emissionprobabilitycomputer.cpp:36-53), multiplied in a different order: the (mantissa, exponent) products can
+//  differ in the last bit.
+// ------------------------------------------------------------------------------------------
+template <int CTRL>
+DEVI void dpp_mul_step(double& m, int& e) {
+    // lanes without a source multiply by 1 * 2^0
+    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(m), CTRL, 0xF, 0xF, false);
+    const int hi = __builtin_amdgcn_update_dpp(0x3FF00000, __double2hiint(m), CTRL, 0xF, 0xF, false);
+    const int oe = __builtin_amdgcn_update_dpp(0, e, CTRL, 0xF, 0xF, false);
+    m *= __hiloint2double(hi, lo);
+    e += oe;
+}
+DEVI double row_last_f64(double v) {  // lane 15 of the row of 16 to all its lanes
+    return __longlong_as_double(__builtin_amdgcn_update_dpp(__double_as_longlong(v), __double_as_longlong(v), 0x15F, 0xF, 0xF, true));
+}
+DEVI int row_last_i32(int v) { return __builtin_amdgcn_update_dpp(v, v, 0x15F, 0xF, 0xF, true); }
+
+__global__ __launch_bounds__(256) void k_prep_bi(const DevContig* __restrict__ contigs, DevTable tab) {
+    const DevContig& dc = contigs[blockIdx.y];
+    if (!dc.prep_fast) return;
+    const uint32_t lane = threadIdx.x & 63u, grp = lane >> 4, l = lane & 15u;
+    const uint32_t v = blockIdx.x * 16u + (threadIdx.x >> 6) * 4u + grp;
+    if (blockIdx.x * 16u + (threadIdx.x >> 6) * 4u >= dc.V) return;  // the whole wave is beyond the contig
+    const bool live = v < dc.V;   // (a row beyond the contig idles along: the ballots below are wave-wide)
+    const uint32_t vv = live ? v : dc.V - 1u;
+    const uint32_t H = dc.H, HP = dc.HP;
+    const uint32_t a0 = dc.allele_off[vv];  // two alleles
+    const uint16_t id0 = dc.allele_id[a0], id1 = dc.allele_id[a0 + 1];
+    const bool u0 = dc.allele_flags[a0] & 1, u1 = dc.allele_flags[a0 + 1] & 1;
+    // ---- ColumnIndexer rule and the allele of every selected path (reference src/columnindexer.cpp:24-31): lane l
+    //      takes paths l, 16 + l, 32 + l, 48 + l
+    uint32_t slot[4];
+    bool bad = false, nonref = false, has0 = false, has1 = false;
+    unsigned long long ones = 0;  // bit p: selected path p carries allele slot 1
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const uint32_t p = 16u * (uint32_t)i + l;
+        const bool inb = live && p < H;
+        const uint16_t a = inb ? dc.path_allele[(size_t)vv * H + p] : (uint16_t)0;
+        const bool s1 = inb && a == id1, s0 = inb && !s1 && a == id0;  // (the last matching slot, as slot_of)
+        slot[i] = s1 ? 1u : 0u;
+        bad = bad || (inb && !s1 && !s0);
+        has0 = has0 || s0;
+        has1 = has1 || s1;
+        nonref = nonref || ((s1 || s0) && a != 0 && !(s1 ? u1 : u0));
+        const unsigned long long b = __ballot(s1);
+        ones |= ((b >> (16u * grp)) & 0xFFFFull) << (16u * (uint32_t)i);
+    }
+    const uint32_t sh16 = 16u * grp;
+    const bool any_bad = ((__ballot(bad) >> sh16) & 0xFFFFull) != 0, kept = ((__ballot(nonref) >> sh16) & 0xFFFFull) != 0;
+    has0 = ((__ballot(has0) >> sh16) & 0xFFFFull) != 0;
+    has1 = ((__ballot(has1) >> sh16) & 0xFFFFull) != 0;
+    if (!live) return;
+    if (any_bad) {
+        if (l == 0) { atomicOr(dc.err, PG_DEVERR_ALLELE_NOT_FOUND); dc.kept[v] = 0; }
+        return;
+    }
+    if (l == 0) { dc.allele_present[a0] = has0 ? 1 : 0; dc.kept[v] = kept ? 1 : 0; }
+    if (l == 1) dc.allele_present[a0 + 1] = has1 ? 1 : 0;
+    if (!kept) return;
+    const uint32_t n_local = (has0 ? 1u : 0u) + (has1 ? 1u : 0u);
+    const uint32_t loc1 = has0 ? 1u : 0u;  // local (dense) index of slot 1; slot 0 is local 0
+    unsigned char* rec = dc.vrec + (size_t)v * dc.RB;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const uint32_t p = 16u * (uint32_t)i + l;
+        if (p < HP) rec[PG_REC_ALLELES + p] = (unsigned char)(p < H ? (slot[i] ? loc1 : 0u) : (uint32_t)PG_PHANTOM);
+    }
+    // ---- emission products of the three allele pairs (0,0), (0,1), (1,1): lane l takes k-mers l and 16 + l
+    const uint32_t k0 = dc.kmer_off[v], K = dc.kmer_off[v + 1] - k0, cov = dc.cov[v];
+    const uint32_t off0 = dc.allele_koff[a0], mask0 = dc.allele_kmask[a0], off1 = dc.allele_koff[a0 + 1], mask1 = dc.allele_kmask[a0 + 1];
+    double pm[3] = {1.0, 1.0, 1.0};
+    int pe[3] = {0, 0, 0};
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const uint32_t k = 16u * (uint32_t)j + l;
+        if (k < K) {
+            double m[3]; int e[3];
+            cn_lookup(tab, cov, dc.kmer_count[k0 + k], m, e);
+            const uint32_t on0 = kmer_on(off0, mask0, k), on1 = kmer_on(off1, mask1, k);
+            auto factor = [&](uint32_t c, bool ua, bool ub, double& fm, int& fe) {
+                const double mc = c == 0 ? m[0] : (c == 1 ? m[1] : m[2]);
+                const int ec = c == 0 ? e[0] : (c == 1 ? e[1] : e[2]);
+                if (ua && ub) mix3(m, e, 1.0 / 3.0, fm, fe);
+                else if (ua || ub) {
+                    const double m2 = c == 0 ? m[1] : m[2];   // c + 1, capped at 2 (the reference asserts c < 2 here)
+                    const int e2 = c == 0 ? e[1] : e[2];
+                    mix2(mc, ec, m2, e2, 0.5, fm, fe);
+                } else { fm = mc; fe = ec; }
+            };
+            double fm; int fe;
+            factor(2u * on0, u0, u0, fm, fe); pm[0] *= fm; pe[0] += fe;
+            factor(on0 + on1, u0, u1, fm, fe); pm[1] *= fm; pe[1] += fe;
+            factor(2u * on1, u1, u1, fm, fe); pm[2] *= fm; pe[2] += fe;
+        }
+    }
+#pragma unroll
+    for (int q = 0; q < 3; ++q) {
+        dpp_mul_step<0x111>(pm[q], pe[q]);  // row_shr:1,2,4,8: lane 15 holds the product over the row
+        dpp_mul_step<0x112>(pm[q], pe[q]);
+        dpp_mul_step<0x114>(pm[q], pe[q]);
+        dpp_mul_step<0x118>(pm[q], pe[q]);
+        pm[q] = row_last_f64(pm[q]);
+        pe[q] = row_last_i32(pe[q]);
+        double mm; int ee;
+        split(pm[q], mm, ee);
+        pm[q] = mm; pe[q] += ee;
+        if (pe[q] < PG_LD_MIN_EXP) { pm[q] = 0.0; pe[q] = 0; }  // underflows to 0 in the reference too
+    }
+    const bool all_zeros = !(pm[0] > 0.0 || pm[1] > 0.0 || pm[2] > 0.0);  // over ALL pairs of the object (emissionprobabilitycomputer.cpp:24)
+    // local pairs (la <= lb < n_local) -> object pairs: both alleles present: the three pairs; one: its own pair
+    const int q00 = has0 ? 0 : 2;
+    const double m00 = pm[q00], m01 = pm[1], m11 = pm[2];
+    const int e00 = pe[q00], e01 = pe[1], e11 = pe[2];
+    const bool two = n_local == 2u;
+    int X = -(1 << 30);
+    if (m00 > 0.0) X = e00;
+    if (two && m01 > 0.0 && e01 > X) X = e01;
+    if (two && m11 > 0.0 && e11 > X) X = e11;
+    if (X == -(1 << 30) || all_zeros) X = 0;
+    auto scaled = [&](double m, int e) { return all_zeros ? 1.0 : (m > 0.0 ? ldexp(m, e - X) : m); };  // (0 or NaN stays)
+    const double E00 = scaled(m00, e00), E01 = two ? scaled(m01, e01) : 0.0, E11 = two ? scaled(m11, e11) : 0.0;
+    // the 6 x 6 table of the record: entries l, 16 + l, 32 + l
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        const uint32_t t = 16u * (uint32_t)i + l;
+        if (t < (uint32_t)PG_ETAB) {
+            const double val = t == 0 ? E00 : ((t == 1 || t == (uint32_t)PG_ESTRIDE) ? E01 : (t == (uint32_t)PG_ESTRIDE + 1u ? E11 : 0.0));
+            ((double*)(rec + PG_REC_E))[t] = val;
+        }
+    }
+    // the unscaled products as (mantissa, exponent): what a finished posterior bin is multiplied with
+    const uint32_t pn = dc.pair_n, NP = (pn * (pn + 1) / 2 + 1u) & ~1u;
+    unsigned char* vp = dc.vpair + (size_t)v * (NP * 12u);
+    if (l < 3u && (l == 0u || two)) {
+        const uint32_t la = l == 2u ? 1u : 0u, lb = l == 0u ? 0u : 1u;
+        const uint32_t pi = tri_n(la, lb, pn);
+        const double mv = l == 0u ? m00 : (l == 1u ? m01 : m11);
+        const int ev = l == 0u ? e00 : (l == 1u ? e01 : e11);
+        ((double*)vp)[pi] = all_zeros ? 0.5 : mv;
+        ((int*)(vp + (size_t)NP * 8u))[pi] = all_zeros ? 1 : ev;
+    }
+    if (l < 4u) ((double*)rec)[l] = 0.0;  // transition constants are filled by k_records
+    if (l < 8u) ((uint16_t*)(rec + PG_REC_LOCAL_SLOT))[l] = (uint16_t)((l == 0u && !has0) || (l == 1u && two) ? 1u : 0u);
+    if (l == 8u) {
+        *(uint32_t*)(rec + PG_REC_VARIANT) = v;
+        *(int32_t*)(rec + PG_REC_EXP) = X;
+        rec[PG_REC_NLOCAL] = (unsigned char)n_local;
+        rec[PG_REC_FLAGS] = all_zeros ? PG_REC_FLAG_ALLZERO : 0;
+        rec[PG_REC_FLAGS + 1] = 0; rec[PG_REC_FLAGS + 2] = 0;
+        *(uint32_t*)(rec + PG_REC_WIDE_IDX) = PG_WIDE_NONE;
+    }
+    if (l == 9u) {
+        ((unsigned long long*)(rec + PG_REC_BITS1))[0] = has0 ? ones : 0ull;  // bit p: path p carries LOCAL allele 1
+        ((unsigned long long*)(rec + PG_REC_BITS1))[1] = 0ull;
+    }
+}
+
 // ------------------------------------------------------------------------------------------
 //  unit-level entry: full A x A emission products of one variant as (mantissa, exponent)
 // ------------------------------------------------------------------------------------------
@@ -642,7 +807,8 @@ __global__ __launch_bounds__(64) void k_transition_single(double d, uint32_t H, 
 // columns) get nothing else: one THREAD per column forms the transition constants and gathers the 64-byte record;
 // k_bins reads the variant record itself.  (The column-order copy of the full 448-byte records, one wave per column
 // with 64 lanes computing the same exp(), was 4.6 ms of the cohort's 80.)
-DEVI bool compact_records_only(const DevContig& dc, uint32_t C) { return dc.tri == 2u && C >= 2u; }
+// The same for lean chains of chunked jobs: their sweeps run on k_sweep_lean and k_post reads the variant record.
+DEVI bool compact_records_only(const DevContig& dc, uint32_t C) { return (dc.tri == 2u && C >= 2u) || (dc.lean && dc.tri == 0u && dc.chunk_cols > 0u); }
 
 __global__ __launch_bounds__(256) void k_records(const DevContig* __restrict__ contigs) {
     const DevContig& dc = contigs[blockIdx.y];
@@ -3712,7 +3878,8 @@ DEVI void post_column(const DevContig& dc, uint32_t chunk, uint32_t idx, uint32_
         B = scr + (size_t)K * colsz + (size_t)(idx - K) * colsz;
         A = dc.fwd + (size_t)c * colsz;
     }
-    const unsigned char* rec = dc.colrec + (size_t)c * dc.RB;
+    const bool direct = compact_records_only(dc, C);  // (no column-order copy of the records: the variant's own)
+    const unsigned char* rec = direct ? dc.vrec + (size_t)dc.col_variant[c] * dc.RB : dc.colrec + (size_t)c * dc.RB;
     const uint32_t v = *(const uint32_t*)(rec + PG_REC_VARIANT);
     const uint32_t nl = rec[PG_REC_NLOCAL];
     const unsigned char* al = rec + PG_REC_ALLELES;
@@ -3732,7 +3899,8 @@ DEVI void post_column(const DevContig& dc, uint32_t chunk, uint32_t idx, uint32_
     const bool fb = dc.fwd_fallback[c] != 0;
     const double scale = 1.0 / ((fb ? 1.0 : dc.fscale[c]) * dc.bscale[c]);
     int xexp = -((fb ? 0 : PG_BIAS_F) + PG_BIAS_B);
-    if (c + 1 < C) xexp += *(const int32_t*)(dc.colrec + (size_t)(c + 1) * dc.RB + PG_REC_EXP);
+    if (c + 1 < C)
+        xexp += *(const int32_t*)((direct ? dc.vrec + (size_t)dc.col_variant[c + 1] * dc.RB : dc.colrec + (size_t)(c + 1) * dc.RB) + PG_REC_EXP);
     // Wide columns (more than PG_AMAX alleles on the selected paths) take one sweep over the two
     // columns per block of PG_AMAX row alleles and add their bins straight into lik (zeroed at the
     // start of the run; this wave is the only writer of the variant's bins).
@@ -3936,6 +4104,8 @@ extern "C" {
 void pgk_launch_prep(const DevContig* d_contigs, uint32_t n_contigs, uint32_t max_v, DevTable tab, hipStream_t s) {
     dim3 grid((max_v + 3) / 4, n_contigs);
     hipLaunchKernelGGL(k_prep, grid, dim3(256), 0, s, d_contigs, tab);
+    dim3 grid16((max_v + 15) / 16, n_contigs);
+    hipLaunchKernelGGL(k_prep_bi, grid16, dim3(256), 0, s, d_contigs, tab);  // (chains of biallelic objects; each kernel skips the other's)
 }
 void pgk_launch_compact(const DevContig* d_contigs, uint32_t n_contigs, hipStream_t s) {
     hipLaunchKernelGGL(k_compact, dim3(n_contigs), dim3(1024), 0, s, d_contigs);

@@ -205,6 +205,7 @@ namespace {
 struct IndexHost {   // one index contig
     uint32_t V = 0, H = 0, HP = 0, T = 0, RB = 0, part_slots = 2, pair_n = 1;
     bool lean = false;  // every object biallelic and H = HP = 64: the store-only phases run on k_sweep_lean
+    bool prep_fast = false;  // every object has exactly two alleles and <= 32 k-mers, H <= 64: k_prep_bi
     uint32_t sumK = 0, sumA = 0;
     uint64_t n_lik = 0, wide_bytes = 0;
     std::vector<uint16_t> n_kmers;   // [V] K of every variant
@@ -472,11 +473,19 @@ int job_build(int device, uint32_t n_index, const pg_contig_batch* batches, cons
         x.goff.assign((size_t)x.V + 1, 0);
         x.n_kmers.resize(x.V);
         uint64_t maxA = 1, woff = 0;
+        bool two_alleles = true;
+        uint32_t maxK = 0;
         for (uint32_t v = 0; v < x.V; ++v) {
             const uint64_t A = b.allele_off[v + 1] - b.allele_off[v];
             x.goff[v + 1] = x.goff[v] + A * (A + 1) / 2;
             if (A > maxA) maxA = A;
+            if (A != 2) two_alleles = false;
             x.n_kmers[v] = (uint16_t)(b.kmer_off[v + 1] - b.kmer_off[v]);
+            if (b.kmer_off[v + 1] - b.kmer_off[v] > maxK) maxK = b.kmer_off[v + 1] - b.kmer_off[v];
+        }
+        {
+            const char* pe = getenv("PG_PREP");  // PG_PREP=wave: k_prep for every chain (cross-check of k_prep_bi)
+            x.prep_fast = two_alleles && maxK <= 32u && x.H <= 64u && x.V > 0 && !(pe && !strcmp(pe, "wave"));
         }
         x.n_lik = x.goff[x.V];
         x.pair_n = (uint32_t)(maxA < PG_AMAX ? maxA : PG_AMAX);
@@ -680,6 +689,7 @@ int job_build(int device, uint32_t n_index, const pg_contig_batch* batches, cons
         d.wide = A + p.wide; d.wide_idx = x.wide_bytes ? (const uint32_t*)(A + x.o_widx) : nullptr;
         d.vpair = A + p.vpair; d.xbuf = (double*)(A + p.xbuf);
         d.frec = (double*)(A + p.frec); d.lean = x.lean ? 1u : 0u;
+        d.prep_fast = x.prep_fast ? 1u : 0u;
         if (params->run_phasing) {
             d.vit_tq = (double*)(A + p.vtq); d.vit_back = (uint16_t*)(A + p.vback); d.vit_best = (uint32_t*)(A + p.vbest);
             d.hap1 = (uint16_t*)(A + p.hap1); d.hap2 = (uint16_t*)(A + p.hap2);

@@ -657,3 +657,31 @@ def test_full_size_properties():
     big = n1 > 1e-200
     assert float(rel[big].max()) < 1e-6, float(rel[big].max())
     assert (calls(b, back) == calls(b, n1)).all()
+
+
+@pytest.mark.parametrize("shape", [(700, 5, 20), (600, 16, 12), (500, 30, 32), (400, 64, 20), (300, 33, 7)], ids=lambda s: "V%d_H%d_K%d" % s)
+def test_prep_four_variants_per_wave_vs_one(shape, orc, monkeypatch):
+    """k_prep_bi (chains of biallelic objects: four variants per wave, DPP folds) against k_prep (PG_PREP=wave: one
+    variant per wave) and against the oracle: same kept columns and present alleles, likelihoods equal to rounding
+    (the products are taken in a different order).  Undefined alleles, k-mer-less variants, zero counts, and a table
+    without regularisation (exact zeros: the all_zeros rule, uniform columns) are in."""
+    V, H, K = shape
+    batch = synthetic_panel(V, H, K, seed=31 + V, undefined_frac=0.05, zero_kmer_frac=0.05)
+    batch.path_allele.reshape(V, H)[V // 2] = 1          # a variant whose selected paths all carry the ALT allele
+    batch.path_allele.reshape(V, H)[V // 2 + 1, :] = 0   # and one that is not a column at all
+    batch._c = None
+    for targs in (default_table_args(), (6, 108, 54, 0.0)):
+        table, otab = hmm.ProbabilityTable(*targs), orc.OracleTable(*targs)
+        prm = hmm.make_params(1.26, False, 1e-5)
+        monkeypatch.delenv("PG_PREP", raising=False)
+        four = hmm.genotype_contig(batch, table, prm)
+        monkeypatch.setenv("PG_PREP", "wave")
+        one = hmm.genotype_contig(batch, table, prm)
+        monkeypatch.delenv("PG_PREP", raising=False)
+        assert four.n_columns == one.n_columns and np.array_equal(four.kept, one.kept)
+        assert np.array_equal(four.allele_present, one.allele_present)
+        a, b = four.likelihoods_ld(), one.likelihoods_ld()
+        denom = np.maximum(np.abs(a), np.abs(b))
+        rel = np.where(denom > 0, np.abs(a - b) / np.where(denom > 0, denom, 1), 0)
+        assert float(rel.max()) < 1e-12, float(rel.max())
+        assert_parity(batch, four, orc.genotype_contig(batch, otab, orc.make_params(1.26, False, 1e-5)))
