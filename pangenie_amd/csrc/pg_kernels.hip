@@ -2628,14 +2628,21 @@ DEVI void lean_load_mirrored(gcdouble* col, uint32_t i0, uint32_t lane, double (
         v[k] = a == b ? 2.0 * val : val;
     }
 }
-// partials of column c: the four waves' {acc0, acc1} of step parity pb, added by wave 0, one 1 KB store
+// Partials of column c -> its four bin sums.  The four waves' {acc0, acc1} (row allele 0 / 1, per column j = lane) of
+// step parity pb are added per lane; wave w then sums ONE of the four (row allele, column allele) classes over the 64
+// lanes and stores one double: part[c][w], w = 2 * (row allele) + (column allele) — 32 bytes per column instead of the
+// 1 KB of per-lane partials that k_bins used to read back and reduce (same additions in the same order as before).
 template <int R>
-DEVI void lean2_flush_partials(const LeanShared2<R>& sh, uint32_t pb, gdouble* part, size_t c, uint32_t wave, uint32_t lane) {
-    if (wave != 0) return;  // (scalar branch)
+DEVI void lean2_flush_partials(const LeanShared2<R>& sh, uint32_t pb, gdouble* part, size_t c, uint32_t wave, uint32_t lane,
+                               unsigned long long bits1 /* of column c */) {
+    static_assert(64 / R == 4, "one class per wave");
     v2f64 t = sh.ppart[pb][0][lane];
 #pragma unroll
     for (int w = 1; w < 64 / R; ++w) { const v2f64 o = sh.ppart[pb][w][lane]; t.x += o.x; t.y += o.y; }
-    ((gdouble2*)part)[c * 64u + lane] = t;
+    const bool aj = (bits1 >> lane) & 1ull;
+    const double mine = (wave & 2u) ? t.y : t.x;  // (scalar select)
+    const double s = wave_sum(aj == ((wave & 1u) != 0u) ? mine : 0.0);
+    if (lane == 0) part[c * 4u + wave] = s;
 }
 
 template <int R>
@@ -2689,6 +2696,7 @@ DEVI void lean2_forward(const DevContig& dc, LeanShared2<R>& sh2, uint32_t C) {
         sh.psum[(first - 1) & 1u][wave][lane] = part0;
     }
     FRec cur = read_frec(sh, 1);
+    unsigned long long pbits = 0;  // column alleles of the column whose partials are pending
     lds_barrier();
     for (uint32_t t = first; t < hi; ++t) {
         const uint32_t n = t - first;
@@ -2699,7 +2707,7 @@ DEVI void lean2_forward(const DevContig& dc, LeanShared2<R>& sh2, uint32_t C) {
             piece = recs.fetch(blk + 1u);
         }
         if (t + 2 < C) tri.load(cols + (size_t)(t + 2) * colsz, b2);  // two columns ahead (b2 was last read a step ago)
-        if (t > first) lean2_flush_partials<R>(sh2, (t - 1) & 1u, part, (size_t)(t - 1), wave, lane);
+        if (t > first) lean2_flush_partials<R>(sh2, (t - 1) & 1u, part, (size_t)(t - 1), wave, lane, pbits);
         const uint32_t pb = (t - 1) & 1u;
         const double Cj = lean_colsum<R>(sh, pb, lane);
         const double ucol = cur.c1 * Cj;
@@ -2748,10 +2756,11 @@ DEVI void lean2_forward(const DevContig& dc, LeanShared2<R>& sh2, uint32_t C) {
         }
 #pragma unroll
         for (int k = 0; k < R; ++k) { b0[k] = b1[k]; b1[k] = b2[k]; }
+        pbits = cur.bits1;
         cur = nxt;
         lds_barrier();
     }
-    lean2_flush_partials<R>(sh2, (hi - 1) & 1u, part, (size_t)(hi - 1), wave, lane);
+    lean2_flush_partials<R>(sh2, (hi - 1) & 1u, part, (size_t)(hi - 1), wave, lane, pbits);
     if (wave == 0 && fsc.valid) fsc.flush(fscale, lane, hi - 1);
     {   // the last column may itself have summed to zero
         const double Cj = lean_colsum<R>(sh, (hi - 1) & 1u, lane);
@@ -2827,7 +2836,7 @@ DEVI void lean2_backward(const DevContig& dc, LeanShared2<R>& sh2, uint32_t C) {
         if (wave == 0) bsc.put(lane, (uint64_t)t, m);
         const double k0 = ldexp(cur.c0, -es), k1 = ldexp(cur.c1, -es), k2 = ldexp(cur.c2, -es), kap = ldexp(cur.kappa, -es);
         lds_barrier();
-        if (t < t0) lean2_flush_partials<R>(sh2, (uint32_t)(t + 1) & 1u, part, (size_t)(t + 1), wave, lane);
+        if (t < t0) lean2_flush_partials<R>(sh2, (uint32_t)(t + 1) & 1u, part, (size_t)(t + 1), wave, lane, cur.bits1);
         const double Cj = lean_colsum<R>(sh, (uint32_t)t & 1u, lane);
         const double ucol = k1 * Cj;
         double ui[R];
@@ -2869,7 +2878,7 @@ DEVI void lean2_backward(const DevContig& dc, LeanShared2<R>& sh2, uint32_t C) {
         cur = nxt;
     }
     lds_barrier();
-    lean2_flush_partials<R>(sh2, (uint32_t)bot & 1u, part, (size_t)bot, wave, lane);
+    lean2_flush_partials<R>(sh2, (uint32_t)bot & 1u, part, (size_t)bot, wave, lane, cur.bits1);
     if (wave == 0 && bsc.valid) bsc.flush(bscale, lane, (uint64_t)bot);
 }
 
@@ -3748,6 +3757,7 @@ __global__ __launch_bounds__(256) void k_bins(const DevContig* __restrict__ cont
     if (lane < PG_AMAX * (PG_AMAX + 1) / 2) s_bins[wave][lane] = 0.0;
     wave_sync();
     const bool fb = dc.fwd_fallback[c] != 0;
+    if (direct && !(fb && c >= C / 2) && dc.tri == 2u) return;  // k_bins_lean2's column (one THREAD per column)
     if (fb && c >= C / 2) {
         // The forward column of c fell back to uniform (alpha_hat*fsum = 1/H^2 for every real
         // state, reference src/hmm.cpp:259-266) AFTER the forward half-chain had already formed
@@ -3781,10 +3791,9 @@ __global__ __launch_bounds__(256) void k_bins(const DevContig* __restrict__ cont
         // partials of thread t for the row-allele pair q: part[((c * part_slots/2 + q) * T + t)] = {a = 2q, a = 2q+1};
         // the column allele of thread t is al[t % HP].  All of a lane's 16-byte loads of a pair are
         // issued together, then split by column allele with selects (no dynamic register indexing).
-        // triangle chains with >= 2 columns (k_sweep_lean2): the four waves' partials arrive added up, 64 per column
-        const bool l2 = dc.tri == 2u && C >= 2;
-        const uint32_t Tn = l2 ? 64u : T;
-        const v2f64* base = l2 ? (const v2f64*)dc.part + (size_t)c * 64u : (const v2f64*)dc.part + (size_t)c * (dc.part_slots >> 1) * T;
+        // (chains on k_sweep_lean2 never get here: their class sums arrive finished and k_bins_lean2 turns them into bins)
+        const uint32_t Tn = T;
+        const v2f64* base = (const v2f64*)dc.part + (size_t)c * (dc.part_slots >> 1) * T;
         const uint32_t nq = (nl + 1u) >> 1;
         for (uint32_t q = 0; q < nq; ++q) {
             double acc0[PG_AMAX], acc1[PG_AMAX];
@@ -3838,6 +3847,46 @@ __global__ __launch_bounds__(256) void k_bins(const DevContig* __restrict__ cont
             store_bin(dc.lik, dc.lik_exp, idx, s_bins[wave][tri_local(la, lb)] * scale, pm, pe, xexp);
         }
     }
+}
+
+
+// ------------------------------------------------------------------------------------------
+//  k_bins_lean2 : the bins of chains on k_sweep_lean2 (two local alleles at most; the four class sums of a column
+//  arrive finished, part[c][2 * (row allele) + (column allele)]) — one THREAD per column.  Columns whose bins have to
+//  be re-formed from the stored backward column (forward fall-back, see k_bins) stay with k_bins.
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_bins_lean2(const DevContig* __restrict__ contigs) {
+    const DevContig& dc = contigs[blockIdx.y];
+    const uint32_t C = *dc.n_cols;
+    if (!(dc.tri == 2u && C >= 2u)) return;
+    const uint32_t c = blockIdx.x * 256u + threadIdx.x;
+    if (c >= C) return;
+    const bool fb = dc.fwd_fallback[c] != 0;
+    if (fb && c >= C / 2) return;
+    const unsigned char* rec = dc.vrec + (size_t)dc.col_variant[c] * dc.RB;
+    const uint32_t v = *(const uint32_t*)(rec + PG_REC_VARIANT);
+    const uint32_t nl = rec[PG_REC_NLOCAL];
+    const uint16_t* ls = (const uint16_t*)(rec + PG_REC_LOCAL_SLOT);
+    const double* p4 = dc.part + (size_t)c * 4u;
+    const double b00 = 0.0 + p4[0];
+    double b01 = 0.0, b11 = 0.0;
+    if (nl > 1u) { b01 = (0.0 + p4[1]) + p4[2]; b11 = 0.0 + p4[3]; }
+    const double scale = 1.0 / ((fb ? 1.0 : dc.fscale[c]) * dc.bscale[c]);
+    int xexp = -((fb ? 0 : PG_BIAS_F) + PG_BIAS_B) + 1;  // (+1: the partials are sums over the stored half, see k_bins)
+    if (c + 1 < C) xexp += *(const int32_t*)(dc.vrec + (size_t)dc.col_variant[c + 1] * dc.RB + PG_REC_EXP);
+    const uint32_t a0 = dc.allele_off[v], A = dc.allele_off[v + 1] - a0;
+    const uint32_t pn = dc.pair_n, NP = (pn * (pn + 1) / 2 + 1u) & ~1u;
+    const unsigned char* vp = dc.vpair + (size_t)v * (NP * 12u);
+    for (uint32_t la = 0; la < nl; ++la)
+        for (uint32_t lb = la; lb < nl; ++lb) {
+            const uint32_t sa = ls[la], sb = ls[lb];
+            const uint64_t idx = dc.geno_off[v] + (uint64_t)sa * A - (uint64_t)sa * (sa - 1) / 2 + (sb - sa);
+            const uint32_t pi = tri_n(la, lb, pn);
+            const double pm = fb ? 0.5 : ((const double*)vp)[pi];
+            const int pe = fb ? 1 : ((const int*)(vp + (size_t)NP * 8u))[pi];
+            const double bin = la == lb ? (la == 0 ? b00 : b11) : b01;
+            store_bin(dc.lik, dc.lik_exp, idx, bin * scale, pm, pe, xexp);
+        }
 }
 
 // ------------------------------------------------------------------------------------------
@@ -4117,6 +4166,8 @@ void pgk_launch_records(const DevContig* d_contigs, uint32_t n_contigs, uint32_t
 void pgk_launch_bins(const DevContig* d_contigs, uint32_t n_contigs, uint32_t max_v, hipStream_t s) {
     dim3 grid((max_v + 3) / 4, n_contigs);
     hipLaunchKernelGGL(k_bins, grid, dim3(256), 0, s, d_contigs);
+    dim3 grid256((max_v + 255) / 256, n_contigs);
+    hipLaunchKernelGGL(k_bins_lean2, grid256, dim3(256), 0, s, d_contigs);  // (chains on k_sweep_lean2; each kernel skips the other's columns)
 }
 void pgk_launch_sweep(const DevContig* d_contigs, uint32_t n_contigs, uint32_t hp_mask, int phase, hipStream_t s) {
     if (phase == 1) launch_sweep<1>(d_contigs, n_contigs, hp_mask, 0, s);
