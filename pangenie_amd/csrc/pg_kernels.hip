@@ -3747,6 +3747,7 @@ __global__ __launch_bounds__(256) void k_bins(const DevContig* __restrict__ cont
     const uint32_t c = blockIdx.x * 4 + wave;
     const uint32_t C = *dc.n_cols;
     if (c >= C) return;
+    if (dc.tri == 2u && C >= 2u) return;  // chains on k_sweep_lean2: k_bins_lean2
     // (chains with compact records only have no column-order copy of the records: the variant's own record)
     const bool direct = compact_records_only(dc, C);
     const unsigned char* rec = direct ? dc.vrec + (size_t)dc.col_variant[c] * dc.RB : dc.colrec + (size_t)c * dc.RB;
@@ -3757,7 +3758,6 @@ __global__ __launch_bounds__(256) void k_bins(const DevContig* __restrict__ cont
     if (lane < PG_AMAX * (PG_AMAX + 1) / 2) s_bins[wave][lane] = 0.0;
     wave_sync();
     const bool fb = dc.fwd_fallback[c] != 0;
-    if (direct && !(fb && c >= C / 2) && dc.tri == 2u) return;  // k_bins_lean2's column (one THREAD per column)
     if (fb && c >= C / 2) {
         // The forward column of c fell back to uniform (alpha_hat*fsum = 1/H^2 for every real
         // state, reference src/hmm.cpp:259-266) AFTER the forward half-chain had already formed
@@ -3852,8 +3852,8 @@ __global__ __launch_bounds__(256) void k_bins(const DevContig* __restrict__ cont
 
 // ------------------------------------------------------------------------------------------
 //  k_bins_lean2 : the bins of chains on k_sweep_lean2 (two local alleles at most; the four class sums of a column
-//  arrive finished, part[c][2 * (row allele) + (column allele)]) — one THREAD per column.  Columns whose bins have to
-//  be re-formed from the stored backward column (forward fall-back, see k_bins) stay with k_bins.
+//  arrive finished, part[c][2 * (row allele) + (column allele)]) — one THREAD per column.  The rare column whose bins
+//  have to be re-formed from the stored backward column (forward fall-back, see k_bins) is walked by its thread alone.
 // ------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_bins_lean2(const DevContig* __restrict__ contigs) {
     const DevContig& dc = contigs[blockIdx.y];
@@ -3862,17 +3862,36 @@ __global__ __launch_bounds__(256) void k_bins_lean2(const DevContig* __restrict_
     const uint32_t c = blockIdx.x * 256u + threadIdx.x;
     if (c >= C) return;
     const bool fb = dc.fwd_fallback[c] != 0;
-    if (fb && c >= C / 2) return;
+    const bool reform = fb && c >= C / 2;
     const unsigned char* rec = dc.vrec + (size_t)dc.col_variant[c] * dc.RB;
     const uint32_t v = *(const uint32_t*)(rec + PG_REC_VARIANT);
     const uint32_t nl = rec[PG_REC_NLOCAL];
     const uint16_t* ls = (const uint16_t*)(rec + PG_REC_LOCAL_SLOT);
-    const double* p4 = dc.part + (size_t)c * 4u;
-    const double b00 = 0.0 + p4[0];
-    double b01 = 0.0, b11 = 0.0;
-    if (nl > 1u) { b01 = (0.0 + p4[1]) + p4[2]; b11 = 0.0 + p4[3]; }
+    double b00 = 0.0, b01 = 0.0, b11 = 0.0;
+    if (!reform) {
+        const double* p4 = dc.part + (size_t)c * 4u;
+        b00 = 0.0 + p4[0];
+        if (nl > 1u) { b01 = (0.0 + p4[1]) + p4[2]; b11 = 0.0 + p4[3]; }
+    } else {
+        // the forward column fell back to uniform after this column's partials had been formed from the all-zero
+        // column: alpha_hat * fsum = 1 / H^2 for every state, times the stored backward column (upper triangle, the
+        // diagonal halved)
+        const uint32_t H = dc.H;
+        const unsigned char* al = rec + PG_REC_ALLELES;
+        const double* col = dc.fwd + (size_t)c * dc.col_stride;
+        for (uint32_t i = 0; i < H; ++i)
+            for (uint32_t j = i; j < H; ++j) {
+                const double val = col[(size_t)tri_unit_of(i >> 1, j) * 2 + (i & 1u)];
+                const double both = 2.0 * val;  // (i, j) and (j, i); the halved diagonal once, doubled
+                const uint32_t a = al[i], b = al[j];
+                if (a == b) { if (a == 0u) b00 += both; else b11 += both; }
+                else b01 += both;
+            }
+        const double unif = 1.0 / ((double)H * (double)H);
+        b00 *= unif; b01 *= unif; b11 *= unif;
+    }
     const double scale = 1.0 / ((fb ? 1.0 : dc.fscale[c]) * dc.bscale[c]);
-    int xexp = -((fb ? 0 : PG_BIAS_F) + PG_BIAS_B) + 1;  // (+1: the partials are sums over the stored half, see k_bins)
+    int xexp = -((fb ? 0 : PG_BIAS_F) + PG_BIAS_B) + (reform ? 0 : 1);  // (+1: the partials are sums over the stored half, see k_bins)
     if (c + 1 < C) xexp += *(const int32_t*)(dc.vrec + (size_t)dc.col_variant[c + 1] * dc.RB + PG_REC_EXP);
     const uint32_t a0 = dc.allele_off[v], A = dc.allele_off[v + 1] - a0;
     const uint32_t pn = dc.pair_n, NP = (pn * (pn + 1) / 2 + 1u) & ~1u;
