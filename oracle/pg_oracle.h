@@ -11,10 +11,13 @@
  * link, load or call anything in this directory — as the checker, never as the
  * product.  The product (pangenie_amd/csrc) has no CPU fallback.
  *
- * Parity pin: the reference itself cannot be compiled in this image (its
- * hot-path translation units include <cereal/...>, which is not installed, and
- * no stand-in headers may be written), so there is no oracle/_ref.  The oracle
- * is pinned on the reference's own known-answer unit tests instead
+ * Parity pin: the reference's HMM cannot be compiled in this image (its
+ * translation units include <cereal/...>, which is not installed, and no
+ * stand-in headers may be written).  What does compile from its own sources is
+ * built by `make ref` into oracle/_ref/ and used as the pin where it reaches:
+ * src/probabilitytable.cpp + src/copynumber.cpp (the table: bit for bit) and
+ * src/samplingtransitions.cpp (the sampler's recombination cost).  The rest of
+ * the oracle is pinned on the reference's own known-answer unit tests
  * (tests/HMMTest.cpp, EmissionProbabilityComputerTest.cpp,
  * TransitionProbabilityComputerTest.cpp, ProbabilityTableTest.cpp,
  * CopyNumberTest.cpp, ColumnIndexerTest.cpp), transcribed as data in

@@ -268,3 +268,59 @@ def ref_transition_cost(from_pos, to_pos, recombrate, nr_paths, effective_N=2500
         lib.ref_sampling_transition_cost.restype = C.c_uint
         _ref_transitions = lib
     return int(_ref_transitions.ref_sampling_transition_cost(int(from_pos), int(to_pos), float(recombrate), int(nr_paths), np.longdouble(effective_N)))
+
+
+# --------------------------------------------------------------------------- #
+#  oracle/_ref/libref_table.so: the reference's OWN ProbabilityTable + CopyNumber translation units
+#  (built by `make -C oracle ref` from /root/reference/src where they lie); None where it was never built
+# --------------------------------------------------------------------------- #
+_ref_table = None
+
+
+def ref_table_lib():
+    global _ref_table
+    path = HERE / "_ref" / "libref_table.so"
+    if _ref_table is None:
+        if not path.exists():
+            return None
+        lib = C.CDLL(str(path))
+        ld = C.c_longdouble
+        lib.ref_table_create.argtypes = [C.c_uint16, C.c_uint16, C.c_uint16, ld]
+        lib.ref_table_create.restype = C.c_void_p
+        lib.ref_table_create_default.argtypes = []
+        lib.ref_table_create_default.restype = C.c_void_p
+        lib.ref_table_destroy.argtypes = [C.c_void_p]
+        lib.ref_table_destroy.restype = None
+        lib.ref_table_get.argtypes = [C.c_void_p, C.c_uint16, C.c_uint16, ldp]
+        lib.ref_table_get.restype = None
+        lib.ref_copynumber_regularized.argtypes = [ld, ld, ld, ld, ldp]
+        lib.ref_copynumber_regularized.restype = None
+        _ref_table = lib
+    return _ref_table
+
+
+class RefTable:
+    """ProbabilityTable of the reference's own compiled code (reference src/probabilitytable.cpp)."""
+
+    def __init__(self, cov_min=0, cov_max=0, count_max=0, regularization=0.0, default=False):
+        self.lib = ref_table_lib()
+        self.h = self.lib.ref_table_create_default() if default else self.lib.ref_table_create(cov_min, cov_max, count_max, _ld(regularization))
+
+    def get(self, cov, count) -> np.ndarray:
+        out = _ld3()
+        self.lib.ref_table_get(self.h, cov, count, out)
+        return np.array([out[0], out[1], out[2]], dtype=np.longdouble)
+
+    def __del__(self):
+        try:
+            if self.h:
+                self.lib.ref_table_destroy(self.h)
+                self.h = None
+        except Exception:
+            pass
+
+
+def ref_copynumber_regularized(cn0, cn1, cn2, reg) -> np.ndarray:
+    out = _ld3()
+    ref_table_lib().ref_copynumber_regularized(_ld(cn0), _ld(cn1), _ld(cn2), _ld(reg), out)
+    return np.array([out[0], out[1], out[2]], dtype=np.longdouble)

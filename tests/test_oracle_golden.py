@@ -145,3 +145,33 @@ def test_column_indexer(golden):
     assert (batch.n_paths, r.n_columns, list(np.nonzero(r.kept)[0])) == (a["nr_paths"], a["n_columns"], a["column_variants"])
     with pytest.raises(RuntimeError):
         flatten(uks, [7, 9])  # no paths -> "column ... is not covered by any paths"
+
+
+def test_probability_table_bit_for_bit_against_the_reference_translation_units():
+    """oracle/_ref/libref_table.so is the reference's OWN src/probabilitytable.cpp + src/copynumber.cpp (no cereal
+    includes: they compile where they lie, `make -C oracle ref`).  The oracle's table — and the product's host-side
+    table behind pg_table_get, which feeds the device its (mantissa, exponent) pairs — must give the very same long
+    doubles: inside the precomputed box, on the fly outside it, with and without regularisation, default-constructed."""
+    if orc.ref_table_lib() is None:
+        pytest.skip("oracle/_ref not built (no /root/reference)")
+    from pangenie_amd import hmm
+
+    def same(a, b):
+        return all((x == y) or (np.isnan(x) and np.isnan(y)) for x, y in zip(a, b))
+    for args in ((6, 108, 54, 0.01), (4, 72, 36, 0.01), (0, 1, 21, 0.0), (5, 40, 30, 0.0), (0, 300, 10, 0.001)):
+        ref, o, t = orc.RefTable(*args), orc.OracleTable(*args), hmm.ProbabilityTable(*args)
+        covs = list(range(0, 130, 1)) + [200, 299, 300, 1000, 65535]
+        counts = list(range(0, 70)) + [100, 255, 1000, 65535]
+        for cov in covs:
+            for count in counts[::3] if cov % 7 else counts:
+                r = ref.get(cov, count)
+                assert same(o.get(cov, count), r), (args, cov, count)
+                assert same(t.get(cov, count), r), (args, cov, count)
+    ref, o, t = orc.RefTable(default=True), orc.OracleTable(default=True), hmm.ProbabilityTable(default=True)
+    for cov, count in ((0, 0), (1, 0), (10, 3), (27, 27), (40, 0), (500, 499)):
+        assert same(o.get(cov, count), ref.get(cov, count)) and same(t.get(cov, count), ref.get(cov, count)), (cov, count)
+    rng = np.random.default_rng(5)
+    for _ in range(500):
+        cn = rng.random(3) * 10.0 ** rng.integers(-30, 1, size=3)
+        reg = float(10.0 ** rng.integers(-6, 0))
+        assert same(orc.copynumber_regularized(cn[0], cn[1], cn[2], reg), orc.ref_copynumber_regularized(cn[0], cn[1], cn[2], reg))
