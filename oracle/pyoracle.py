@@ -82,12 +82,16 @@ def load():
 
 
 def _ld3():
-    return (C.c_longdouble * 3)()
+    """(array, pointer) for a `long double out3[3]` argument — the numpy array keeps all 64 mantissa bits (an element
+    of a ctypes long double array reads back as a Python float, i.e. a double)."""
+    a = np.zeros(3, dtype=np.longdouble)
+    return a, a.ctypes.data_as(ldp)
 
 
 def _ld(x) -> C.c_longdouble:
-    """Python float / str / np.longdouble -> c_longdouble without a double round-trip."""
-    return C.c_longdouble(np.longdouble(x))
+    """Python float / str / np.longdouble -> c_longdouble without a double round-trip (ctypes' own conversion of a
+    np.longdouble goes through a Python float)."""
+    return C.c_longdouble.from_buffer_copy(np.array([np.longdouble(x)], dtype=np.longdouble).tobytes())
 
 
 class OracleTable:
@@ -98,19 +102,18 @@ class OracleTable:
         if default:
             self.h = lib.pgo_table_create_default()
         else:
-            self.h = lib.pgo_table_create(cov_min, cov_max, count_max, np.longdouble(regularization))
+            self.h = lib.pgo_table_create(cov_min, cov_max, count_max, _ld(regularization))
         self.lib = lib
 
     def modify(self, cov, count, p0, p1, p2):
-        rc = self.lib.pgo_table_modify(self.h, cov, count, np.longdouble(p0), np.longdouble(p1),
-                                       np.longdouble(p2))
+        rc = self.lib.pgo_table_modify(self.h, cov, count, _ld(p0), _ld(p1), _ld(p2))
         if rc:
             raise RuntimeError("ProbabilityTable::modify_probability: no precomputed values for these parameters.")
 
     def get(self, cov, count) -> np.ndarray:
-        out = _ld3()
-        self.lib.pgo_table_get(self.h, cov, count, out)
-        return np.array([out[0], out[1], out[2]], dtype=np.longdouble)
+        out, ptr = _ld3()
+        self.lib.pgo_table_get(self.h, cov, count, ptr)
+        return out
 
     def __del__(self):
         try:
@@ -120,17 +123,15 @@ class OracleTable:
 
 
 def copynumber_regularized(cn0, cn1, cn2, reg) -> np.ndarray:
-    out = _ld3()
-    load().pgo_copynumber_regularized(np.longdouble(cn0), np.longdouble(cn1), np.longdouble(cn2),
-                                      np.longdouble(reg), out)
-    return np.array([out[0], out[1], out[2]], dtype=np.longdouble)
+    out, ptr = _ld3()
+    load().pgo_copynumber_regularized(_ld(cn0), _ld(cn1), _ld(cn2), _ld(reg), ptr)
+    return out
 
 
 def transition_probs(from_pos, to_pos, recombrate, nr_paths, uniform, effective_N) -> np.ndarray:
-    out = _ld3()
-    load().pgo_transition_probs(from_pos, to_pos, recombrate, nr_paths, int(uniform),
-                                np.longdouble(effective_N), out)
-    return np.array([out[0], out[1], out[2]], dtype=np.longdouble)
+    out, ptr = _ld3()
+    load().pgo_transition_probs(from_pos, to_pos, recombrate, nr_paths, int(uniform), _ld(effective_N), ptr)
+    return out
 
 
 def emission_table(batch, table: OracleTable, v: int):
@@ -146,7 +147,7 @@ def emission_table(batch, table: OracleTable, v: int):
 def make_params(recombrate=1.26, uniform=False, effective_N=25000.0, run_genotyping=True,
                 run_phasing=False) -> PgHmmParams:
     p = PgHmmParams()
-    p.effective_N = np.longdouble(effective_N)
+    p.effective_N = _ld(effective_N)
     p.recombrate = float(recombrate)
     p.uniform = int(uniform)
     p.run_genotyping = int(run_genotyping)
@@ -229,7 +230,7 @@ def sampler_emission_costs(batch) -> np.ndarray:
 
 
 def sampler_transition_cost(from_pos, to_pos, recombrate, nr_paths, effective_N=25000.0) -> int:
-    return int(load().pgo_sampler_transition_cost(int(from_pos), int(to_pos), float(recombrate), int(nr_paths), np.longdouble(effective_N)))
+    return int(load().pgo_sampler_transition_cost(int(from_pos), int(to_pos), float(recombrate), int(nr_paths), _ld(effective_N)))
 
 
 def sampler_column_minima(column, mask):
@@ -245,7 +246,7 @@ def sampler_run(batch, size, recombrate=1.26, effective_N=25000.0, allele_penalt
     V = batch.n_variants
     sampled = np.zeros((size, max(V, 1)), np.uint32)
     best = np.zeros(max(size, 1), np.uint32)
-    rc = load().pgo_sampler_run(C.byref(batch.as_c()), size, float(recombrate), np.longdouble(effective_N), int(allele_penalty),
+    rc = load().pgo_sampler_run(C.byref(batch.as_c()), size, float(recombrate), _ld(effective_N), int(allele_penalty),
                                 sampled.ctypes.data_as(u32p), best.ctypes.data_as(u32p))
     if rc:
         raise RuntimeError(f"oracle sampler error {rc}")
@@ -267,7 +268,7 @@ def ref_transition_cost(from_pos, to_pos, recombrate, nr_paths, effective_N=2500
         lib.ref_sampling_transition_cost.argtypes = [C.c_ulonglong, C.c_ulonglong, C.c_double, C.c_ushort, C.c_longdouble]
         lib.ref_sampling_transition_cost.restype = C.c_uint
         _ref_transitions = lib
-    return int(_ref_transitions.ref_sampling_transition_cost(int(from_pos), int(to_pos), float(recombrate), int(nr_paths), np.longdouble(effective_N)))
+    return int(_ref_transitions.ref_sampling_transition_cost(int(from_pos), int(to_pos), float(recombrate), int(nr_paths), _ld(effective_N)))
 
 
 # --------------------------------------------------------------------------- #
@@ -307,9 +308,9 @@ class RefTable:
         self.h = self.lib.ref_table_create_default() if default else self.lib.ref_table_create(cov_min, cov_max, count_max, _ld(regularization))
 
     def get(self, cov, count) -> np.ndarray:
-        out = _ld3()
-        self.lib.ref_table_get(self.h, cov, count, out)
-        return np.array([out[0], out[1], out[2]], dtype=np.longdouble)
+        out, ptr = _ld3()
+        self.lib.ref_table_get(self.h, cov, count, ptr)
+        return out
 
     def __del__(self):
         try:
@@ -321,6 +322,6 @@ class RefTable:
 
 
 def ref_copynumber_regularized(cn0, cn1, cn2, reg) -> np.ndarray:
-    out = _ld3()
-    ref_table_lib().ref_copynumber_regularized(_ld(cn0), _ld(cn1), _ld(cn2), _ld(reg), out)
-    return np.array([out[0], out[1], out[2]], dtype=np.longdouble)
+    out, ptr = _ld3()
+    ref_table_lib().ref_copynumber_regularized(_ld(cn0), _ld(cn1), _ld(cn2), _ld(reg), ptr)
+    return out

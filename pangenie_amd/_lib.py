@@ -8,6 +8,8 @@ never imported from here).
 from __future__ import annotations
 
 import ctypes as C
+
+import numpy as np
 import os
 from pathlib import Path
 
@@ -29,6 +31,18 @@ u64p = C.POINTER(C.c_uint64)
 i32p = C.POINTER(C.c_int32)
 f64p = C.POINTER(C.c_double)
 ldp = C.POINTER(C.c_longdouble)
+
+
+def c_ld(x) -> C.c_longdouble:
+    """np.longdouble / float -> c_longdouble with all 64 mantissa bits (ctypes' own conversion goes through a Python
+    float, i.e. a double)."""
+    return C.c_longdouble.from_buffer_copy(np.array([x], dtype=np.longdouble).tobytes())
+
+
+def ld_out(n: int):
+    """(array, pointer) for `long double out[n]` arguments: read the array, not a ctypes element (which is a float)."""
+    a = np.zeros(n, dtype=np.longdouble)
+    return a, a.ctypes.data_as(ldp)
 
 
 class PgContigBatch(C.Structure):

@@ -31,7 +31,7 @@ def make_params(recombrate: float = 1.26, uniform: bool = False, effective_N=250
                 run_genotyping: bool = True, run_phasing: bool = False) -> PgHmmParams:
     """HMM constructor arguments (reference src/hmm.hpp:38)."""
     p = PgHmmParams()
-    p.effective_N = LD(effective_N)
+    p.effective_N = _lib.c_ld(effective_N)
     p.recombrate = float(recombrate)
     p.uniform = int(bool(uniform))
     p.run_genotyping = int(bool(run_genotyping))
@@ -48,19 +48,19 @@ class ProbabilityTable:
         if default:
             self.h = self._lib.pg_table_create_default()
         else:
-            self.h = self._lib.pg_table_create(cov_min, cov_max, count_max, LD(regularization))
+            self.h = self._lib.pg_table_create(cov_min, cov_max, count_max, _lib.c_ld(regularization))
         if not self.h:
             raise MemoryError("pg_table_create failed")
 
     def modify(self, coverage: int, count: int, p0, p1, p2) -> None:
-        rc = self._lib.pg_table_modify(self.h, coverage, count, LD(p0), LD(p1), LD(p2))
+        rc = self._lib.pg_table_modify(self.h, coverage, count, _lib.c_ld(p0), _lib.c_ld(p1), _lib.c_ld(p2))
         if rc:
             raise RuntimeError("ProbabilityTable::modify_probability: no precomputed values for these parameters.")
 
     def get(self, coverage: int, count: int) -> np.ndarray:
-        out = (C.c_longdouble * 3)()
-        self._lib.pg_table_get(self.h, coverage, count, out)
-        return np.array([out[0], out[1], out[2]], dtype=LD)
+        out, ptr = _lib.ld_out(3)
+        self._lib.pg_table_get(self.h, coverage, count, ptr)
+        return out
 
     def __del__(self):
         try:
@@ -299,7 +299,7 @@ def transition_probs(from_pos: int, to_pos: int, recombrate: float, nr_paths: in
     lib = _lib.load_hip()
     out = (C.c_double * 3)()
     err = C.create_string_buffer(_ERRLEN)
-    rc = lib.pg_transition_probs(from_pos, to_pos, recombrate, nr_paths, int(uniform), LD(effective_N),
+    rc = lib.pg_transition_probs(from_pos, to_pos, recombrate, nr_paths, int(uniform), _lib.c_ld(effective_N),
                                  device, out, err, _ERRLEN)
     if rc:
         raise PanGenieError(rc, err.value.decode(errors="replace"))
