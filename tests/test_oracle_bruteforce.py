@@ -111,3 +111,52 @@ def test_oracle_matches_dense_matrix_restatement(V, H, K, kw, par):
         # different summation order, same 64-bit-mantissa arithmetic
         assert float(rel.max()) < 1e-13, (reg, float(rel.max()))
         assert ((lik == 0) == (ref.lik == 0)).all()
+
+
+def test_oracle_viterbi_path_is_the_most_probable_one():
+    """The oracle's Viterbi (the reference's loop, src/hmm.cpp:408-511, and its four-candidate form) against an
+    ENUMERATION of all (H^2)^C sequences of path pairs on tiny panels, in exact rational arithmetic: the probability of
+    the reported path (product of transition and emission probabilities along it) is the maximum over all sequences.
+    Ties between sequences are common (the two orders of a pair), so probabilities are compared, not the paths."""
+    from fractions import Fraction
+    from itertools import product
+
+    def frac(x):
+        n, d = np.longdouble(x).as_integer_ratio()
+        return Fraction(int(n), int(d))
+    table = orc.OracleTable(*default_table_args())
+    checked = 0
+    for (V, H, seed, recomb, effn) in ((6, 2, 1, 1.26, 25000.0), (5, 3, 2, 446.287102628, 0.25), (6, 2, 3, 1.26, 1e-5), (4, 4, 4, 446.287102628, 0.25)):
+        b = synthetic_panel(V, H, 6, seed=900 + seed, undefined_frac=0.0)
+        pa = b.path_allele.reshape(V, H)
+        for v in range(V):
+            pa[v, v % H] = 1  # every variant is a column
+        b._c = None
+        prm = orc.make_params(recomb, False, effn, run_genotyping=False, run_phasing=True)
+        for form in (0, 1):
+            r = orc.viterbi_contig(b, table, prm, form=form)
+            cols = [v for v in range(V) if r.kept[v]]
+            assert len(cols) == V
+            n = H * H
+            em = []
+            for v in cols:
+                E, _ = orc.emission_table(b, table, v)
+                ids = [int(x) for x in b.allele_id[b.allele_off[v]:b.allele_off[v + 1]]]
+                s = [ids.index(int(a)) for a in pa[v]]
+                em.append([frac(E[s[i], s[j]]) for i in range(H) for j in range(H)])
+            tr = [None] + [[frac(x) for x in orc.transition_probs(int(b.variant_pos[cols[c - 1]]), int(b.variant_pos[cols[c]]), recomb, H, False, effn)] for c in range(1, len(cols))]
+
+            def prob(seq):
+                p = em[0][seq[0]]
+                for c in range(1, len(seq)):
+                    a, bb = seq[c - 1], seq[c]
+                    p *= tr[c][(a // H != bb // H) + (a % H != bb % H)] * em[c][bb]
+                return p
+            best = max(prob(seq) for seq in product(range(n), repeat=len(cols)))
+            # the reported path: any state sequence that spells the reported alleles AND is a path of maximal probability
+            # need not be unique, so take the best sequence among those that spell the oracle's haplotype alleles
+            spelled = [[s for s in range(n) if pa[v, s // H] == r.hap1[v] and pa[v, s % H] == r.hap2[v]] for v in cols]
+            got = max(prob(seq) for seq in product(*spelled))
+            assert got == best and best > 0, (V, H, form, float(got), float(best))
+            checked += 1
+    assert checked == 8
