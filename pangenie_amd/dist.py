@@ -89,3 +89,49 @@ def gather_posteriors(local: Dict[int, Tuple["torch.Tensor", "torch.Tensor"]], n
             res[i] = (fl[off:off + n_lik[i]].copy(), fe[off:off + n_lik[i]].copy())
             off += n_lik[i]
     return res
+
+
+def gather_haplotypes(local: Dict[int, Tuple["np.ndarray", "np.ndarray"]], n_variants: Sequence[int],
+                      plan: List[List[int]], dst: int = 0, device=None):
+    """The phasing results (run_phasing: `haplotype_1` / `haplotype_2` of every chain, u16 per variant) of a sharded
+    run on `dst` — the same single group of point-to-point sends as gather_posteriors, one i32 per variant
+    (haplotype_1 | haplotype_2 << 16: a dtype every backend carries).
+
+    local: {chain id: (haplotype_1 uint16 [V], haplotype_2 uint16 [V])} for this rank's chains (numpy or tensors).
+    Returns on dst: {chain id: (haplotype_1 uint16 ndarray, haplotype_2 uint16 ndarray)} for ALL chains; None elsewhere."""
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+    rank, world = dist.get_rank(), dist.get_world_size()
+    per_rank = [int(sum(n_variants[i] for i in chains)) for chains in plan]
+    if device is None:
+        device = torch.device("cpu")
+
+    def packed(i):
+        h1 = np.asarray(local[i][0]).astype(np.int64).reshape(-1)
+        h2 = np.asarray(local[i][1]).astype(np.int64).reshape(-1)
+        assert h1.size == n_variants[i] and h2.size == n_variants[i]
+        return torch.from_numpy(((h1 & 0xFFFF) | ((h2 & 0xFFFF) << 16)).astype(np.uint32).view(np.int32))
+    mine = plan[rank]
+    buf = torch.cat([packed(i) for i in mine]).to(device) if mine else torch.empty(0, dtype=torch.int32, device=device)
+    got = None
+    if rank == dst:
+        got = {r: torch.empty(per_rank[r], dtype=torch.int32, device=device) for r in range(world) if r != dst}
+        ops = [dist.P2POp(dist.irecv, g, r) for r, g in got.items() if per_rank[r]]
+        got[dst] = buf
+    else:
+        ops = [dist.P2POp(dist.isend, buf, dst)] if per_rank[rank] else []
+    if ops:
+        for w in dist.batch_isend_irecv(ops):
+            w.wait()
+    if rank != dst:
+        return None
+    res = {}
+    for r in range(world):
+        flat = got[r].cpu().numpy().view(np.uint32)
+        off = 0
+        for i in plan[r]:
+            seg = flat[off:off + n_variants[i]]
+            res[i] = ((seg & 0xFFFF).astype(np.uint16), (seg >> 16).astype(np.uint16))
+            off += n_variants[i]
+    return res

@@ -9,7 +9,7 @@ import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
 
-from pangenie_amd.dist import assign_chains, gather_posteriors, pack_sizes
+from pangenie_amd.dist import assign_chains, gather_haplotypes, gather_posteriors, pack_sizes
 
 
 def test_lpt_plan_is_balanced_and_deterministic():
@@ -28,6 +28,11 @@ def _fake(i, n_lik):
     return rng.random(n_lik[i]), rng.integers(-17000, 5, size=n_lik[i]).astype(np.int32)
 
 
+def _fake_haps(i, n_lik):
+    rng = np.random.default_rng(500 + i)
+    return rng.integers(0, 65536, size=n_lik[i]).astype(np.uint16), rng.integers(0, 65536, size=n_lik[i]).astype(np.uint16)
+
+
 def _worker(rank, world, port, n_lik, q):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
@@ -38,14 +43,18 @@ def _worker(rank, world, port, n_lik, q):
         lik, ex = _fake(i, n_lik)
         local[i] = (torch.from_numpy(lik), torch.from_numpy(ex))
     got = gather_posteriors(local, n_lik, plan, dst=0, device=torch.device("cpu"))
+    # the phasing results of the same plan (n_lik doubles as the variant counts of the fake chains)
+    haps = gather_haplotypes({i: _fake_haps(i, n_lik) for i in plan[rank]}, n_lik, plan, dst=0, device=torch.device("cpu"))
     ok = True
     if rank == 0:
-        ok = sorted(got) == list(range(len(n_lik)))
+        ok = sorted(got) == list(range(len(n_lik))) and sorted(haps) == list(range(len(n_lik)))
         for i in range(len(n_lik)):
             lik, ex = _fake(i, n_lik)
             ok = ok and np.array_equal(got[i][0], lik) and np.array_equal(got[i][1], ex)
+            h1, h2 = _fake_haps(i, n_lik)
+            ok = ok and np.array_equal(haps[i][0], h1) and np.array_equal(haps[i][1], h2) and haps[i][0].dtype == np.uint16
     else:
-        ok = got is None
+        ok = got is None and haps is None
     q.put((rank, bool(ok)))
     dist.barrier()
     dist.destroy_process_group()
