@@ -21,6 +21,7 @@
 #include <vector>
 
 #include "../../pangenie_amd/host/cereal_io.hpp"
+#include "../../pangenie_amd/host/kmer_counts.hpp"
 #include "../../pangenie_amd/host/pangenie_host.hpp"
 
 using namespace pangenie;
@@ -228,6 +229,67 @@ static Results sample_results() {
     r.result["chr10"] = {c};
     r.runtimes["chr1"] = 1.5; r.runtimes["chr10"] = 0.125;
     return r;
+}
+
+static std::vector<unsigned char> read_file(const std::string& path) {
+    std::vector<unsigned char> bytes;
+    FILE* f = std::fopen(path.c_str(), "rb");
+    if (!f) return bytes;
+    unsigned char buf[4096];
+    size_t n;
+    while ((n = std::fread(buf, 1, sizeof(buf), f)) > 0) bytes.insert(bytes.end(), buf, buf + n);
+    std::fclose(f);
+    return bytes;
+}
+
+static void kmer_count_cpu_tests() {
+    run("fill_read_kmercounts: the reference's index + k-mer table + reads give the reference's counted archive", [] {
+        // tests/data/index_UniqueKmersMap.cereal (PanGenie-index output), index_chr1_kmers.tsv.gz, region-reads.fa ->
+        // tests/data/region_UniqueKmersList.cereal, the archive tests/CommandsTest.cpp:59-93 feeds its HMM
+        // (k-mer abundance peak 18, tests/CommandsTest.cpp:56).  Byte for byte, once the run times the reference
+        // measured are copied over.
+        UniqueKmersMap m = load_unique_kmers_map(g_golden_dir + "/index_UniqueKmersMap.cereal");
+        const UniqueKmersMap want = load_unique_kmers_map(g_golden_dir + "/region_UniqueKmersList.cereal");
+        CHECK(m.kmersize == 31 && m.unique_kmers["chr1"].size() == 2);
+        CHECK(m.unique_kmers["chr1"][0]->get_readcount_of(0) == 0);  // the index carries no counts
+        ExactKmerCounter counts(g_golden_dir + "/region-reads.fa", m.kmersize);
+        CHECK(counts.distinct_kmers() > 1000);
+        fill_read_kmercounts("chr1", &m, counts, g_golden_dir + "/index_chr1_kmers.tsv.gz", 18);
+        for (size_t v = 0; v < 2; ++v) {
+            UniqueKmers& got = *m.unique_kmers["chr1"][v];
+            UniqueKmers& exp = *want.unique_kmers.at("chr1")[v];
+            CHECK(got.size() == exp.size() && got.get_coverage() == exp.get_coverage());
+            size_t same = 0;
+            for (size_t k = 0; k < got.size() && k < exp.size(); ++k) same += got.get_readcount_of(k) == exp.get_readcount_of(k);
+            CHECK(same == exp.size());
+        }
+        CHECK(m.unique_kmers["chr1"][0]->get_coverage() == 30 && m.unique_kmers["chr1"][1]->get_coverage() == 34);
+        m.runtimes = want.runtimes;
+        m.sampling_runtimes = want.sampling_runtimes;
+        CHECK(serialize_unique_kmers_map(m) == read_file(g_golden_dir + "/region_UniqueKmersList.cereal"));
+    });
+    run("ExactKmerCounter: canonical counts, FASTA and FASTQ, letters outside ACGT", [] {
+        const std::string fa = "/tmp/pg_test_reads.fa", fq = "/tmp/pg_test_reads.fq";
+        { FILE* f = std::fopen(fa.c_str(), "w"); std::fputs(">r1\nACGTAC\nGT\n>r2\nACGNACGTA\n", f); std::fclose(f); }
+        { FILE* f = std::fopen(fq.c_str(), "w"); std::fputs("@r1\nACGTACGT\n+\n@@@@@@@@\n@r2\nACGNACGTA\n+r2\n>>>>>>>>>\n", f); std::fclose(f); }
+        for (const std::string& path : {fa, fq}) {
+            ExactKmerCounter c(path, 4);
+            // r1 = ACGTACGT: ACGT (its own reverse complement) x2, CGTA / TACG (one canonical class) x2, GTAC (palindrome) x1;
+            // r2 = ACG N ACGTA: ACGT x1, CGTA x1
+            CHECK(c.getKmerAbundance("ACGT") == 3);
+            CHECK(c.getKmerAbundance("CGTA") == 3 && c.getKmerAbundance("TACG") == 3);
+            CHECK(c.getKmerAbundance("GTAC") == 1);
+            CHECK(c.getKmerAbundance("AAAA") == 0 && c.getKmerAbundance("ACGN") == 0);
+            bool threw = false;
+            try { c.getKmerAbundance("ACG"); } catch (const std::runtime_error&) { threw = true; }
+            CHECK(threw);
+        }
+        std::vector<std::string> fl = {"ACGT", "CGTA", "GTAC", "AAAA"};
+        ExactKmerCounter c(fa, 4);
+        CHECK(compute_local_coverage(fl, c, 3) == 1);   // counts 3, 3, 1, 0 within [0, 12]: (3 + 3 + 1 + 0) / 4 in integers
+        CHECK(compute_local_coverage(fl, c, 8) == 3);   // [2, 32]: (3 + 3) / 2
+        CHECK(compute_local_coverage(fl, c, 100) == 100);  // none within [25, 400]: the given coverage
+    });
 }
 
 static void archive_cpu_tests() {
@@ -805,7 +867,7 @@ static void gpu_tests() {
 int main(int argc, char** argv) {
     const std::string mode = argc > 1 ? argv[1] : "cpu";
     if (argc > 2) g_golden_dir = argv[2];
-    if (mode == "cpu") { cpu_tests(); viterbi_cpu_tests(); archive_cpu_tests(); sampler_cpu_tests(); }
+    if (mode == "cpu") { cpu_tests(); viterbi_cpu_tests(); archive_cpu_tests(); kmer_count_cpu_tests(); sampler_cpu_tests(); }
     else if (mode == "gpu") { gpu_tests(); sampler_gpu_tests(); }
     else if (mode == "dump-results" && argc >= 3) {  // the archive of sample_results() for the Python reader (tests/test_cereal_io.py)
         save_results(sample_results(), argv[2]);
