@@ -100,6 +100,67 @@ size_t ExactKmerCounter::getKmerAbundance(std::string kmer) {
     return it == counts_.end() ? 0 : (size_t)it->second;
 }
 
+size_t ExactKmerCounter::computeHistogram(size_t max_count, bool largest_peak) const {
+    Histogram histogram(max_count);
+    for (const auto& kv : counts_)
+        if (kv.second > 0) histogram.add_value((size_t)kv.second);
+    histogram.smooth_histogram();
+    std::vector<size_t> peak_ids, peak_values;
+    histogram.find_peaks(peak_ids, peak_values);
+    return compute_kmer_coverage(peak_ids, peak_values, largest_peak);
+}
+
+// ------------------------------------------------------------------ Histogram (reference src/histogram.cpp)
+Histogram::Histogram(size_t max_value) : histogram_(max_value + 1, 0) {}
+
+Histogram::Histogram(const std::string& filename, size_t max_value) : histogram_(max_value + 1, 0) {
+    gzFile file = gzopen(filename.c_str(), "rb");  // (reads plain files as well)
+    if (!file) throw std::runtime_error("Histogram: cannot open " + filename);
+    char buffer[256];
+    while (gzgets(file, buffer, sizeof(buffer)) != nullptr) {
+        std::istringstream iss(buffer);
+        size_t count, value;
+        if (!(iss >> count >> value)) break;  // (the reference's `while (histfile >> count >> value)` stops at the first line that is not two numbers)
+        if (count <= max_value) histogram_[count] = value;
+    }
+    gzclose(file);
+}
+
+void Histogram::add_value(size_t value) {
+    if (value < histogram_.size()) histogram_[value] += 1;
+}
+
+void Histogram::smooth_histogram() {  // in place: entry i - 1 is already smoothed when entry i is formed (src/histogram.cpp:43-47)
+    for (size_t i = 1; i + 1 < histogram_.size(); ++i) histogram_[i] = (histogram_[i - 1] + histogram_[i] + histogram_[i + 1]) / 3;
+}
+
+void Histogram::find_peaks(std::vector<size_t>& peak_ids, std::vector<size_t>& peak_values) const {
+    bool direction = 0;
+    size_t prev_val = 0;
+    for (size_t i = 0; i < histogram_.size(); ++i) {
+        const size_t value = histogram_[i];
+        if (prev_val < value) direction = 0;
+        else if (prev_val > value) {
+            if (direction != 1) { peak_ids.push_back(i - 1); peak_values.push_back(prev_val); }
+            direction = 1;
+        }
+        prev_val = value;
+    }
+}
+
+size_t compute_kmer_coverage(std::vector<size_t>& peak_ids, std::vector<size_t>& peak_values, bool largest_peak) {
+    if (peak_ids.size() == 0) throw std::runtime_error("sequenceutils::computeHistogram: no peak found in kmer-count histogram.");
+    if (peak_ids.size() < 2) return peak_ids[0];
+    size_t largest, second, largest_id, second_id;
+    if (peak_values[0] < peak_values[1]) { largest = peak_values[1]; largest_id = peak_ids[1]; second = peak_values[0]; second_id = peak_ids[0]; }
+    else { largest = peak_values[0]; largest_id = peak_ids[0]; second = peak_values[1]; second_id = peak_ids[1]; }
+    for (size_t i = 0; i < peak_values.size(); ++i) {
+        if (peak_values[i] > largest) { second = largest; second_id = largest_id; largest = peak_values[i]; largest_id = peak_ids[i]; }
+        else if ((peak_values[i] > second) && (peak_values[i] != largest)) { second = peak_values[i]; second_id = peak_ids[i]; }
+    }
+    return largest_peak ? largest_id : second_id;
+}
+
 // ------------------------------------------------------------------ kmerparser
 void parse_kmer_line(std::string line, std::string& chrom, size_t& start, std::vector<std::string>& kmers,
                      std::vector<std::string>& flanking_kmers, bool& is_header) {

@@ -34,6 +34,9 @@ public:
     ExactKmerCounter(const std::string& readfile, size_t kmer_size);
     size_t getKmerAbundance(std::string kmer) override;
     size_t distinct_kmers() const { return counts_.size(); }
+    /** reference JellyfishCounter::computeHistogram (src/jellyfishcounter.cpp:119-153) over the counted k-mers:
+     *  histogram of the abundances, smoothed, its largest / second largest peak */
+    size_t computeHistogram(size_t max_count, bool largest_peak) const;
 
 private:
     void add_sequence(const std::string& seq);
@@ -41,6 +44,24 @@ private:
     size_t k_;
     std::unordered_map<uint64_t, uint64_t> counts_;
 };
+
+/** reference src/histogram.hpp:7-20, src/histogram.cpp: k-mer abundance histogram (count -> number of k-mers) */
+class Histogram {
+public:
+    explicit Histogram(size_t max_value);
+    /** "count <tab> value" lines (plain or gzipped); counts above max_value are dropped (src/histogram.cpp:12-24) */
+    Histogram(const std::string& filename, size_t max_value);
+    void add_value(size_t value);
+    void smooth_histogram();
+    void find_peaks(std::vector<size_t>& peak_ids, std::vector<size_t>& peak_values) const;
+    const std::vector<size_t>& values() const { return histogram_; }
+
+private:
+    std::vector<size_t> histogram_;
+};
+/** reference src/sequenceutils.cpp:42-83: the largest (or second largest) peak of the smoothed histogram = the k-mer
+ *  abundance peak the ProbabilityTable is built from (src/commands.cpp:840-846) */
+size_t compute_kmer_coverage(std::vector<size_t>& peak_ids, std::vector<size_t>& peak_values, bool largest_peak);
 
 /** reference src/kmerparser.cpp:16-30: one line of `<prefix>_<chromosome>_kmers.tsv(.gz)` */
 void parse_kmer_line(std::string line, std::string& chrom, size_t& start, std::vector<std::string>& kmers,
