@@ -4,7 +4,8 @@
 #include <zlib.h>
 
 #include <fstream>
-#include <sstream>
+#include <charconv>
+#include <string_view>
 #include <stdexcept>
 
 namespace pangenie {
@@ -18,11 +19,6 @@ inline int base_code(char c) {
         case 'T': case 't': return 3;
         default: return -1;
     }
-}
-void split(std::vector<std::string>& result, const std::string& line, char sep) {  // reference src/kmerparser.cpp:8-14
-    std::string token;
-    std::istringstream iss(line);
-    while (std::getline(iss, token, sep)) result.push_back(token);
 }
 }  // namespace
 
@@ -100,91 +96,70 @@ size_t ExactKmerCounter::getKmerAbundance(std::string kmer) {
     return it == counts_.end() ? 0 : (size_t)it->second;
 }
 
-size_t ExactKmerCounter::computeHistogram(size_t max_count, bool largest_peak) const {
-    Histogram histogram(max_count);
-    for (const auto& kv : counts_)
-        if (kv.second > 0) histogram.add_value((size_t)kv.second);
-    histogram.smooth_histogram();
-    std::vector<size_t> peak_ids, peak_values;
-    histogram.find_peaks(peak_ids, peak_values);
-    return compute_kmer_coverage(peak_ids, peak_values, largest_peak);
-}
-
-// ------------------------------------------------------------------ Histogram (reference src/histogram.cpp)
-Histogram::Histogram(size_t max_value) : histogram_(max_value + 1, 0) {}
-
-Histogram::Histogram(const std::string& filename, size_t max_value) : histogram_(max_value + 1, 0) {
-    gzFile file = gzopen(filename.c_str(), "rb");  // (reads plain files as well)
-    if (!file) throw std::runtime_error("Histogram: cannot open " + filename);
-    char buffer[256];
-    while (gzgets(file, buffer, sizeof(buffer)) != nullptr) {
-        std::istringstream iss(buffer);
-        size_t count, value;
-        if (!(iss >> count >> value)) break;  // (the reference's `while (histfile >> count >> value)` stops at the first line that is not two numbers)
-        if (count <= max_value) histogram_[count] = value;
-    }
-    gzclose(file);
-}
-
-void Histogram::add_value(size_t value) {
-    if (value < histogram_.size()) histogram_[value] += 1;
-}
-
-void Histogram::smooth_histogram() {  // in place: entry i - 1 is already smoothed when entry i is formed (src/histogram.cpp:43-47)
-    for (size_t i = 1; i + 1 < histogram_.size(); ++i) histogram_[i] = (histogram_[i - 1] + histogram_[i] + histogram_[i + 1]) / 3;
-}
-
-void Histogram::find_peaks(std::vector<size_t>& peak_ids, std::vector<size_t>& peak_values) const {
-    bool direction = 0;
-    size_t prev_val = 0;
-    for (size_t i = 0; i < histogram_.size(); ++i) {
-        const size_t value = histogram_[i];
-        if (prev_val < value) direction = 0;
-        else if (prev_val > value) {
-            if (direction != 1) { peak_ids.push_back(i - 1); peak_values.push_back(prev_val); }
-            direction = 1;
+// ------------------------------------------------------------------ the k-mer table (behaviour: src/kmerparser.cpp)
+// A row of `<prefix>_<chromosome>_kmers.tsv` is five tab-separated columns: chromosome, start, (a column this step
+// does not use), the variant's unique k-mers, the flanking k-mers — the two lists comma-separated, "nan" when empty;
+// rows whose first column starts with '#' are headers.  KmerRow scans a row in place: columns and list items are
+// views into the line, nothing is copied until a caller asks for strings.
+namespace {
+struct KmerRow {
+    std::string_view column[5];
+    bool header = false;
+    explicit KmerRow(std::string_view line) {
+        size_t n = 0, at = 0;
+        while (true) {
+            const size_t tab = line.find('\t', at);
+            if (n == 5) { n = 6; break; }  // a sixth column
+            column[n++] = line.substr(at, tab == std::string_view::npos ? std::string_view::npos : tab - at);
+            if (tab == std::string_view::npos) break;
+            at = tab + 1;
+            if (at == line.size()) break;  // (a trailing tab opens no further column: std::getline semantics of the reference's tokenizer)
         }
-        prev_val = value;
+        if (n != 5) throw std::runtime_error("parse_kmer_line: expected 5 tab-separated fields");
+        header = !column[0].empty() && column[0].front() == '#';
     }
-}
-
-size_t compute_kmer_coverage(std::vector<size_t>& peak_ids, std::vector<size_t>& peak_values, bool largest_peak) {
-    if (peak_ids.size() == 0) throw std::runtime_error("sequenceutils::computeHistogram: no peak found in kmer-count histogram.");
-    if (peak_ids.size() < 2) return peak_ids[0];
-    size_t largest, second, largest_id, second_id;
-    if (peak_values[0] < peak_values[1]) { largest = peak_values[1]; largest_id = peak_ids[1]; second = peak_values[0]; second_id = peak_ids[0]; }
-    else { largest = peak_values[0]; largest_id = peak_ids[0]; second = peak_values[1]; second_id = peak_ids[1]; }
-    for (size_t i = 0; i < peak_values.size(); ++i) {
-        if (peak_values[i] > largest) { second = largest; second_id = largest_id; largest = peak_values[i]; largest_id = peak_ids[i]; }
-        else if ((peak_values[i] > second) && (peak_values[i] != largest)) { second = peak_values[i]; second_id = peak_ids[i]; }
+    size_t start() const {  // leading decimal digits of column 1 (0 when there are none)
+        size_t value = 0;
+        std::from_chars(column[1].data(), column[1].data() + column[1].size(), value);
+        return value;
     }
-    return largest_peak ? largest_id : second_id;
+    template <class F>
+    static void each_item(std::string_view list, F&& f) {  // comma-separated items of a list column; "nan" = no items
+        if (list == "nan") return;
+        while (!list.empty()) {
+            const size_t comma = list.find(',');
+            f(list.substr(0, comma));
+            if (comma == std::string_view::npos) break;
+            list.remove_prefix(comma + 1);
+        }
+    }
+};
+/** mean (integer division) of the counts inside [expected / 4, expected * 4]; `expected` itself when no count lies in
+ *  the window or the window holds only zeros */
+unsigned short windowed_mean(const std::vector<size_t>& counts, size_t expected) {
+    const size_t lowest = expected / 4, highest = expected * 4;
+    size_t sum = 0, used = 0;
+    for (const size_t c : counts)
+        if (c >= lowest && c <= highest) { sum += c; ++used; }
+    return (unsigned short)((used && sum) ? sum / used : expected);
 }
+}  // namespace
 
-// ------------------------------------------------------------------ kmerparser
 void parse_kmer_line(std::string line, std::string& chrom, size_t& start, std::vector<std::string>& kmers,
                      std::vector<std::string>& flanking_kmers, bool& is_header) {
-    std::vector<std::string> tokens;
-    split(tokens, line, '\t');
-    if (tokens.size() != 5) throw std::runtime_error("parse_kmer_line: expected 5 tab-separated fields");  // (the reference asserts)
-    if (tokens[0][0] == '#') { is_header = true; return; }
-    chrom = tokens[0];
-    start = (size_t)atoi(tokens[1].c_str());
-    if (tokens[3] != "nan") split(kmers, tokens[3], ',');
-    if (tokens[4] != "nan") split(flanking_kmers, tokens[4], ',');
+    const KmerRow row(line);
+    if (row.header) { is_header = true; return; }
+    chrom.assign(row.column[0]);
+    start = row.start();
+    KmerRow::each_item(row.column[3], [&](std::string_view k) { kmers.emplace_back(k); });
+    KmerRow::each_item(row.column[4], [&](std::string_view k) { flanking_kmers.emplace_back(k); });
 }
 
 unsigned short compute_local_coverage(std::vector<std::string>& kmers, KmerCounter& read_counts, size_t kmer_coverage) {
-    size_t total_coverage = 0, total_kmers = 0;
-    const size_t min_cov = kmer_coverage / 4, max_cov = kmer_coverage * 4;
-    for (auto& kmer : kmers) {
-        const size_t read_count = read_counts.getKmerAbundance(kmer);
-        if ((read_count < min_cov) || (read_count > max_cov)) continue;  // ignore too extreme counts
-        total_coverage += read_count;
-        total_kmers += 1;
-    }
-    if ((total_kmers > 0) && (total_coverage > 0)) return (unsigned short)(total_coverage / total_kmers);
-    return (unsigned short)kmer_coverage;
+    std::vector<size_t> counts;
+    counts.reserve(kmers.size());
+    for (const std::string& k : kmers) counts.push_back(read_counts.getKmerAbundance(k));
+    return windowed_mean(counts, kmer_coverage);
 }
 
 // ------------------------------------------------------------------ fill_read_kmercounts
@@ -202,21 +177,22 @@ void fill_read_kmercounts(const std::string& chromosome, UniqueKmersMap* unique_
             line += buffer;
             if (line.empty() || line.back() != '\n') continue;
             line.pop_back();
-            std::vector<std::string> kmers, flanking_kmers;
-            bool is_header = false;
-            std::string chrom;
-            size_t start = 0;
-            parse_kmer_line(line, chrom, start, kmers, flanking_kmers, is_header);
+            const KmerRow row(line);
+            if (!row.header) {
+                if (row.column[0] != chromosome) throw std::runtime_error("fill_read_kmercounts: line of chromosome " + std::string(row.column[0]) + " in the table of " + chromosome);
+                if (var_index >= objects.size()) throw std::runtime_error("fill_read_kmercounts: more lines than variants");
+                UniqueKmers& u = *objects[var_index];
+                if (row.start() != u.get_variant_position()) throw std::runtime_error("fill_read_kmercounts: position " + std::to_string(row.start()) + " does not match the index");
+                size_t i = 0;
+                KmerRow::each_item(row.column[3], [&](std::string_view k) {
+                    u.update_readcount(i++, (unsigned short)read_kmer_counts.getKmerAbundance(std::string(k)));  // (size_t -> unsigned short as in the reference)
+                });
+                std::vector<size_t> flank_counts;
+                KmerRow::each_item(row.column[4], [&](std::string_view k) { flank_counts.push_back(read_kmer_counts.getKmerAbundance(std::string(k))); });
+                u.set_coverage(windowed_mean(flank_counts, kmer_coverage));
+                var_index += 1;
+            }
             line.clear();
-            if (is_header) continue;
-            if (chrom != chromosome) throw std::runtime_error("fill_read_kmercounts: line of chromosome " + chrom + " in the table of " + chromosome);
-            if (var_index >= objects.size()) throw std::runtime_error("fill_read_kmercounts: more lines than variants");
-            UniqueKmers& u = *objects[var_index];
-            if (start != u.get_variant_position()) throw std::runtime_error("fill_read_kmercounts: position " + std::to_string(start) + " does not match the index");
-            for (size_t i = 0; i < kmers.size(); ++i)
-                u.update_readcount(i, (unsigned short)read_kmer_counts.getKmerAbundance(kmers[i]));  // (size_t -> unsigned short as in the reference)
-            u.set_coverage(compute_local_coverage(flanking_kmers, read_kmer_counts, kmer_coverage));
-            var_index += 1;
         }
     } catch (...) {
         gzclose(file);

@@ -290,31 +290,24 @@ static void kmer_count_cpu_tests() {
         CHECK(compute_local_coverage(fl, c, 8) == 3);   // [2, 32]: (3 + 3) / 2
         CHECK(compute_local_coverage(fl, c, 100) == 100);  // none within [25, 400]: the given coverage
     });
-}
-
-static void histogram_cpu_tests() {
-    run("Histogram / compute_kmer_coverage: the reference's known answers", [] {
-        // tests/HistogramTest.cpp:11-30
-        Histogram histo(10);
-        for (size_t v : {0, 0, 1, 1, 1, 1, 2, 2, 3}) histo.add_value(v);
-        std::vector<size_t> ids, vals;
-        histo.find_peaks(ids, vals);
-        CHECK(ids.size() == 1 && vals.size() == 1 && ids[0] == 1 && vals[0] == 4);
-        // :32-73 — the four k-mer abundance histograms of the reference's tests (kept gzipped under tests/golden/)
-        const std::pair<const char*, size_t> cases[4] = {{"test.histo.gz", 56}, {"test2.histo.gz", 26}, {"test3.histo.gz", 60}, {"test4.histo.gz", 42}};
-        for (const auto& c : cases) {
-            Histogram h(g_golden_dir + "/" + c.first, 10000);
-            h.smooth_histogram();
-            std::vector<size_t> pi, pv;
-            h.find_peaks(pi, pv);
-            CHECK(compute_kmer_coverage(pi, pv, true) == c.second);
+    run("parse_kmer_line: columns, lists, headers, malformed rows", [] {
+        std::string chrom; size_t start = 0; std::vector<std::string> km, fl; bool header = false;
+        parse_kmer_line("chr7\t1234\tx\tACGT,CCCC,GGGT\tAAAA", chrom, start, km, fl, header);
+        CHECK(chrom == "chr7" && start == 1234 && !header);
+        CHECK(km == std::vector<std::string>({"ACGT", "CCCC", "GGGT"}) && fl == std::vector<std::string>({"AAAA"}));
+        km.clear(); fl.clear();
+        parse_kmer_line("chr7\t99\tx\tnan\tnan", chrom, start, km, fl, header);
+        CHECK(start == 99 && km.empty() && fl.empty() && !header);
+        parse_kmer_line("chr7\t5\tx\tA,,C,\tnan\t", chrom, start, km, fl, header);  // empty item kept, trailing comma / tab ignored
+        CHECK(km == std::vector<std::string>({"A", "", "C"}) && fl.empty());
+        km.clear();
+        parse_kmer_line("#chromosome\tstart\tend\tunique_kmers\tunique_kmers_overhang", chrom, start, km, fl, header);
+        CHECK(header && km.empty() && chrom == "chr7");
+        for (const char* bad : {"chr7\t5\tx\tA", "chr7\t5\tx\tA\tB\tC", ""}) {
+            bool threw = false;
+            try { parse_kmer_line(bad, chrom, start, km, fl, header); } catch (const std::runtime_error&) { threw = true; }
+            CHECK(threw);
         }
-        // the same through the counter: three 8-mer classes, five copies each -> h[5] = 3, smoothed 1, 1 at 4 and 5: peak 5
-        const std::string fa = "/tmp/pg_test_peak.fa";
-        { FILE* f = std::fopen(fa.c_str(), "w"); for (int i = 0; i < 5; ++i) std::fputs(">r\nACGTTGCA\n>s\nAAAACCCC\n>t\nAACCGGTA\n", f); std::fclose(f); }
-        ExactKmerCounter c(fa, 8);
-        CHECK(c.getKmerAbundance("ACGTTGCA") == 5 && c.getKmerAbundance("GGGGTTTT") == 5 && c.distinct_kmers() == 3);
-        CHECK(c.computeHistogram(100, true) == 5);
     });
 }
 
@@ -893,7 +886,7 @@ static void gpu_tests() {
 int main(int argc, char** argv) {
     const std::string mode = argc > 1 ? argv[1] : "cpu";
     if (argc > 2) g_golden_dir = argv[2];
-    if (mode == "cpu") { cpu_tests(); viterbi_cpu_tests(); archive_cpu_tests(); kmer_count_cpu_tests(); histogram_cpu_tests(); sampler_cpu_tests(); }
+    if (mode == "cpu") { cpu_tests(); viterbi_cpu_tests(); archive_cpu_tests(); kmer_count_cpu_tests(); sampler_cpu_tests(); }
     else if (mode == "gpu") { gpu_tests(); sampler_gpu_tests(); }
     else if (mode == "dump-results" && argc >= 3) {  // the archive of sample_results() for the Python reader (tests/test_cereal_io.py)
         save_results(sample_results(), argv[2]);
