@@ -34,9 +34,11 @@ ldp = C.POINTER(C.c_longdouble)
 
 
 def c_ld(x) -> C.c_longdouble:
-    """np.longdouble / float -> c_longdouble with all 64 mantissa bits (ctypes' own conversion goes through a Python
-    float, i.e. a double)."""
-    return C.c_longdouble.from_buffer_copy(np.array([x], dtype=np.longdouble).tobytes())
+    """np.longdouble / float / decimal string -> c_longdouble with all 64 mantissa bits (ctypes' own conversion goes
+    through a Python float, i.e. a double).  A string is parsed AS a long double: c_ld("0.01") is the reference's
+    0.01L (its default sampling_effective_N), which no double holds."""
+    v = np.longdouble(x) if isinstance(x, str) else x
+    return C.c_longdouble.from_buffer_copy(np.array([v], dtype=np.longdouble).tobytes())
 
 
 def ld_out(n: int):

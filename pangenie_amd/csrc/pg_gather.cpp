@@ -160,8 +160,14 @@ extern "C" int pg_hmm_gather_all(int n_local, pg_comm* const* comms, pg_job* con
                                  const uint64_t* n_lik_per_rank, void* d_lik_all, void* d_exp_all,
                                  char* err, size_t errlen) {
     if (n_local < 1 || !comms || !jobs || !n_lik_per_rank) { set_err(err, errlen, "bad argument"); return PG_ERR_INVALID; }
+    for (int i = 0; i < n_local; ++i)
+        if (!comms[i]) { set_err(err, errlen, "communicator %d is null", i); return PG_ERR_INVALID; }
     const int world = comms[0]->world;
     if (root < 0 || root >= world) { set_err(err, errlen, "bad root"); return PG_ERR_INVALID; }
+    // NOTE: the checks up to the group are LOCAL: a rank that fails one returns before the exchange while its peers
+    // enter it and wait for this rank's block.  The plan (n_lik_per_rank) is known to every host up front, so a
+    // mismatch is a programming error of the caller; a caller that cannot rule it out agrees on the return codes of a
+    // dry call (comm = the same, jobs checked with pg_job_packed_results) before the exchange, or aborts the peers.
     std::vector<uint64_t> off((size_t)world + 1, 0);
     for (int r = 0; r < world; ++r) off[r + 1] = off[r] + n_lik_per_rank[r];
     // loop-back self test (tests on a single GPU): the root's own block also goes through ncclSend / ncclRecv
@@ -183,22 +189,32 @@ extern "C" int pg_hmm_gather_all(int n_local, pg_comm* const* comms, pg_job* con
     if (world > 1 || loopback) {
         if (!load_rccl(err, errlen)) return PG_ERR_DEVICE;
         NCCL_TRY(g_rccl.GroupStart());
-        for (int i = 0; i < n_local; ++i) {
+        // inside the group nothing returns: a failure is remembered, the group is always closed (an open group would
+        // swallow every later RCCL call of this thread), and the first error is reported afterwards
+        int rc_in = PG_OK;
+        auto note_nccl = [&](ncclResult_t r, const char* what) {
+            if (r != ncclSuccess && rc_in == PG_OK) { set_err(err, errlen, "%s failed: %s", what, g_rccl.GetErrorString(r)); rc_in = PG_ERR_DEVICE; }
+        };
+        for (int i = 0; i < n_local && rc_in == PG_OK; ++i) {
             const pg_comm* c = comms[i];
-            HIP_TRY(hipSetDevice(c->device));
+            const hipError_t he = hipSetDevice(c->device);
+            if (he != hipSuccess) { set_err(err, errlen, "hipSetDevice(%d) failed: %s", c->device, hipGetErrorString(he)); rc_in = PG_ERR_DEVICE; break; }
             if (c->rank == root) {
-                for (int q = 0; q < world; ++q) {
+                for (int q = 0; q < world && rc_in == PG_OK; ++q) {
                     if ((q == root && !loopback) || n_lik_per_rank[q] == 0) continue;
-                    NCCL_TRY(g_rccl.Recv((double*)d_lik_all + off[q], n_lik_per_rank[q], ncclDouble, q, c->comm, nullptr));
-                    NCCL_TRY(g_rccl.Recv((int32_t*)d_exp_all + off[q], n_lik_per_rank[q], ncclInt32, q, c->comm, nullptr));
+                    note_nccl(g_rccl.Recv((double*)d_lik_all + off[q], n_lik_per_rank[q], ncclDouble, q, c->comm, nullptr), "ncclRecv(lik)");
+                    note_nccl(g_rccl.Recv((int32_t*)d_exp_all + off[q], n_lik_per_rank[q], ncclInt32, q, c->comm, nullptr), "ncclRecv(lik_exp)");
                 }
             }
-            if ((c->rank != root || loopback) && loc[i].n > 0) {
-                NCCL_TRY(g_rccl.Send(loc[i].d_lik, loc[i].n, ncclDouble, root, c->comm, nullptr));
-                NCCL_TRY(g_rccl.Send(loc[i].d_exp, loc[i].n, ncclInt32, root, c->comm, nullptr));
+            if ((c->rank != root || loopback) && loc[i].n > 0 && rc_in == PG_OK) {
+                note_nccl(g_rccl.Send(loc[i].d_lik, loc[i].n, ncclDouble, root, c->comm, nullptr), "ncclSend(lik)");
+                note_nccl(g_rccl.Send(loc[i].d_exp, loc[i].n, ncclInt32, root, c->comm, nullptr), "ncclSend(lik_exp)");
             }
         }
-        NCCL_TRY(g_rccl.GroupEnd());
+        const ncclResult_t r_end = g_rccl.GroupEnd();
+        if (rc_in != PG_OK) return rc_in;
+        note_nccl(r_end, "ncclGroupEnd");
+        if (rc_in != PG_OK) return rc_in;
     }
     for (int i = 0; i < n_local; ++i) {
         const pg_comm* c = comms[i];
@@ -226,6 +242,8 @@ extern "C" int pg_hmm_gather_to_host(int n_local, pg_comm* const* comms, pg_job*
                                      const uint64_t* n_lik_per_rank, double* h_lik_all, int32_t* h_exp_all,
                                      char* err, size_t errlen) {
     if (n_local < 1 || !comms || !n_lik_per_rank) { set_err(err, errlen, "bad argument"); return PG_ERR_INVALID; }
+    for (int i = 0; i < n_local; ++i)
+        if (!comms[i]) { set_err(err, errlen, "communicator %d is null", i); return PG_ERR_INVALID; }
     const int world = comms[0]->world;
     uint64_t total = 0;
     for (int r = 0; r < world; ++r) total += n_lik_per_rank[r];

@@ -212,6 +212,7 @@ struct IndexHost {   // one index contig
     std::vector<uint32_t> widx;      // [V] wide entry offset / 16 (only if wide_bytes)
     std::vector<uint64_t> goff;      // [V+1]
     std::vector<uint64_t> pos;       // [V] host copy of the positions (run_phasing: the Viterbi's transition probabilities)
+    std::vector<uint32_t> koff, aoff;  // [V+1] the per-variant layout the arena, goff / widx and the kernel choice were planned for
     // device
     size_t o_pos = 0, o_koff = 0, o_aoff = 0, o_aid = 0, o_aflag = 0, o_akoff = 0, o_akmask = 0, o_pa = 0, o_goff = 0, o_widx = 0;
 };
@@ -472,6 +473,7 @@ int job_build(int device, uint32_t n_index, const pg_contig_batch* batches, cons
         x.sumK = x.V ? b.kmer_off[x.V] : 0; x.sumA = x.V ? b.allele_off[x.V] : 0;
         x.goff.assign((size_t)x.V + 1, 0);
         x.n_kmers.resize(x.V);
+        if (x.V) { x.koff.assign(b.kmer_off, b.kmer_off + x.V + 1); x.aoff.assign(b.allele_off, b.allele_off + x.V + 1); }
         uint64_t maxA = 1, woff = 0;
         bool two_alleles = true;
         uint32_t maxK = 0;
@@ -749,24 +751,36 @@ extern "C" int pg_job_upload(pg_job* job, const pg_contig_batch* batches, const 
     HIP_TRY(hipSetDevice(job->device));
     const uint32_t n = (uint32_t)job->chains.size();
     std::vector<ChainSpec> specs(n);
+    if (batches)  // the layout must be the one the arena, the genotype / wide offsets and the kernel choice were planned for:
+        for (uint32_t i = 0; i < job->n_contigs; ++i) {  // per-variant K and A, not just their totals
+            const IndexHost& x = job->index[i];
+            const int rc = check_batch(&batches[i], !job->cohort, err, errlen);
+            if (rc != PG_OK) return rc;
+            if (batches[i].n_variants != x.V || batches[i].n_paths != x.H ||
+                (x.V && (memcmp(batches[i].kmer_off, x.koff.data(), ((size_t)x.V + 1) * 4) != 0 ||
+                         memcmp(batches[i].allele_off, x.aoff.data(), ((size_t)x.V + 1) * 4) != 0))) {
+                set_err(err, errlen, "contig %u: shape (variants, paths, k-mers or alleles per variant) differs from the resident job", i);
+                return PG_ERR_INVALID;
+            }
+        }
     if (job->cohort) {
         if (!samples) { set_err(err, errlen, "cohort job: samples must be given"); return PG_ERR_INVALID; }
-        for (uint32_t s = 0; s < job->n_samples; ++s)
+        for (uint32_t s = 0; s < job->n_samples; ++s) {
+            if (!samples[s].kmer_count || !samples[s].coverage) { set_err(err, errlen, "sample %u has null arrays", s); return PG_ERR_INVALID; }
             for (uint32_t c = 0; c < job->n_contigs; ++c)
                 specs[(size_t)s * job->n_contigs + c] = {c, samples[s].kmer_count[c], samples[s].coverage[c]};
+        }
     } else {
         if (!batches) { set_err(err, errlen, "batches must be given"); return PG_ERR_INVALID; }
         for (uint32_t i = 0; i < n; ++i) specs[i] = {i, batches[i].kmer_count, batches[i].coverage};
     }
-    if (batches)  // shapes must be the ones the arena was planned for
-        for (uint32_t i = 0; i < job->n_contigs; ++i) {
-            const IndexHost& x = job->index[i];
-            if (batches[i].n_variants != x.V || batches[i].n_paths != x.H ||
-                (x.V && (batches[i].kmer_off[x.V] != x.sumK || batches[i].allele_off[x.V] != x.sumA))) {
-                set_err(err, errlen, "contig %u: shape differs from the resident job", i);
-                return PG_ERR_INVALID;
-            }
+    for (uint32_t c = 0; c < n; ++c) {
+        const IndexHost& x = job->index[job->chains[c].index];
+        if (x.V > 0 && (!specs[c].coverage || (x.sumK > 0 && !specs[c].kmer_count))) {
+            set_err(err, errlen, "chain %u has null kmer_count / coverage arrays", c);
+            return PG_ERR_INVALID;
         }
+    }
     return upload_inputs(job, batches, specs, batches != nullptr, err, errlen);
 }
 

@@ -17,7 +17,7 @@ struct Reader {
     size_t n, o = 0;
     template <class T>
     T take() {
-        if (o + sizeof(T) > n) throw std::runtime_error("UniqueKmersMap archive: truncated");
+        if (sizeof(T) > n - o) throw std::runtime_error("UniqueKmersMap archive: truncated");  // (o <= n always)
         T v;
         std::memcpy(&v, p + o, sizeof(T));
         o += sizeof(T);
@@ -25,10 +25,16 @@ struct Reader {
     }
     std::string str() {
         const uint64_t len = take<uint64_t>();
-        if (o + len > n) throw std::runtime_error("UniqueKmersMap archive: truncated string");
+        if (len > n - o) throw std::runtime_error("UniqueKmersMap archive: truncated string");  // (no wrap for lengths near 2^64)
         std::string s((const char*)p + o, (size_t)len);
         o += (size_t)len;
         return s;
+    }
+    /** an element count read from the archive: at most what the remaining bytes can hold at `min_bytes` each */
+    uint64_t count(size_t min_bytes) {
+        const uint64_t c = take<uint64_t>();
+        if (c > (n - o) / (min_bytes ? min_bytes : 1)) throw std::runtime_error("UniqueKmersMap archive: element count exceeds the data");
+        return c;
     }
 };
 
@@ -51,9 +57,9 @@ std::shared_ptr<UniqueKmers> read_object(Reader& r) {
     raw.variant_pos = (size_t)r.take<uint64_t>();
     raw.local_coverage = r.take<float>();
     (void)r.take<uint64_t>();  // current_index: number of k-mers inserted so far
-    const uint64_t nk = r.take<uint64_t>();
+    const uint64_t nk = r.count(2);
     for (uint64_t i = 0; i < nk; ++i) raw.counts.push_back(r.take<uint16_t>());
-    const uint64_t na = r.take<uint64_t>();
+    const uint64_t na = r.count(BI ? 6 : 9);
     for (uint64_t i = 0; i < na; ++i) {
         const unsigned short key = BI ? (unsigned short)r.take<uint8_t>() : r.take<uint16_t>();
         typename UniqueKmersT<BI>::RawAllele a;
@@ -62,7 +68,7 @@ std::shared_ptr<UniqueKmers> read_object(Reader& r) {
         a.is_undefined = r.take<uint8_t>() != 0;
         raw.alleles[key] = a;
     }
-    const uint64_t np = r.take<uint64_t>();
+    const uint64_t np = r.count(BI ? 1 : 2);
     for (uint64_t i = 0; i < np; ++i) raw.path_to_allele.push_back(BI ? (unsigned short)r.take<uint8_t>() : r.take<uint16_t>());
     return std::shared_ptr<UniqueKmers>(new UniqueKmersT<BI>(raw));
 }
@@ -88,7 +94,7 @@ void write_object(Writer& w, const UniqueKmersT<BI>& u) {
 
 std::map<std::string, double> read_str_double(Reader& r) {
     std::map<std::string, double> m;
-    const uint64_t n = r.take<uint64_t>();
+    const uint64_t n = r.count(16);
     for (uint64_t i = 0; i < n; ++i) { std::string k = r.str(); m[k] = r.take<double>(); }
     return m;
 }
@@ -100,11 +106,11 @@ UniqueKmersMap parse_unique_kmers_map(const std::vector<unsigned char>& bytes) {
     m.kmersize = (size_t)r.take<uint64_t>();
     std::map<uint32_t, bool> type_is_bi;                         // polymorphic id -> biallelic?
     std::map<uint32_t, std::shared_ptr<UniqueKmers>> objects;    // shared-pointer id -> object
-    const uint64_t nmap = r.take<uint64_t>();
+    const uint64_t nmap = r.count(16);
     for (uint64_t e = 0; e < nmap; ++e) {
         const std::string name = r.str();
         std::vector<std::shared_ptr<UniqueKmers>>& list = m.unique_kmers[name];
-        const uint64_t nv = r.take<uint64_t>();
+        const uint64_t nv = r.count(4);
         for (uint64_t i = 0; i < nv; ++i) {
             uint32_t tid = r.take<uint32_t>();
             if (tid & MSB) {
@@ -190,19 +196,18 @@ void save_unique_kmers_map(const UniqueKmersMap& m, const std::string& path) {
 Results parse_results(const std::vector<unsigned char>& bytes) {
     Reader r{bytes.data(), bytes.size()};
     Results out;
-    const uint64_t nc = r.take<uint64_t>();
+    const uint64_t nc = r.count(16);
     for (uint64_t c = 0; c < nc; ++c) {
         const std::string name = r.str();
-        const uint64_t nv = r.take<uint64_t>();
-        if (nv > bytes.size()) throw std::runtime_error("Results archive: implausible vector size");
+        const uint64_t nv = r.count(16);
         std::vector<GenotypingResult>& vec = out.result[name];
         vec.resize((size_t)nv);
         for (uint64_t v = 0; v < nv; ++v) {
             GenotypingResult& g = vec[(size_t)v];
-            const uint64_t nl = r.take<uint64_t>();
+            const uint64_t nl = r.count(20);
             for (uint64_t l = 0; l < nl; ++l) {
                 const unsigned short a1 = r.take<uint16_t>(), a2 = r.take<uint16_t>();
-                if (r.o + 16 > r.n) throw std::runtime_error("Results archive: truncated");
+                if (16 > r.n - r.o) throw std::runtime_error("Results archive: truncated");
                 long double lik = 0.0L;
                 std::memcpy(&lik, r.p + r.o, 10);  // the 80-bit value; 6 bytes of padding follow
                 r.o += 16;

@@ -462,183 +462,6 @@ long double EmissionProbabilityComputer::get_emission_probability(unsigned short
     return table_[s1 * A + s2];
 }
 
-// ------------------------------------------------------------------ Viterbi (phasing), host, long double
-// The reference's experimental phasing mode (`-p`, src/pangenie-genotype.cpp:60; at most 30 paths,
-// src/commands.cpp:939): most likely pair of haplotype paths through the columns.  The HMM constructor
-// runs it on the GPU (pangenie_amd/csrc/pg_viterbi.hip, up to 64 selected paths); this host version in
-// the reference's own arithmetic — same operation order, same tie rule (`>=`: the LAST maximum wins,
-// reference src/hmm.cpp:468, :139), same uniform fall-back (:484-491), same sqrt(C) checkpointing
-// idea (:118-128, :152-158; here per block) — is what the constructor uses above 64 paths or when the
-// environment variable PG_VITERBI=host asks for it (cross-check).
-namespace {
-
-// EmissionProbabilityComputer in long double on the host (reference src/emissionprobabilitycomputer.cpp:9-53)
-void host_emission_table(const FlatContig& f, const pg_table* table, size_t v, std::vector<long double>& E) {
-    const uint32_t a0 = f.allele_off[v], A = f.allele_off[v + 1] - a0;
-    const uint32_t k0 = f.kmer_off[v], K = f.kmer_off[v + 1] - k0;
-    E.assign((size_t)A * A, 0.0L);
-    auto on = [&](uint32_t slot, uint32_t k) -> unsigned {
-        const uint32_t off = f.allele_kmer_off[a0 + slot];
-        if (k < off || k >= off + 32u) return 0u;
-        return (f.allele_kmer_mask[a0 + slot] >> (k - off)) & 1u;
-    };
-    bool all_zeros = true;
-    for (uint32_t s1 = 0; s1 < A; ++s1)
-        for (uint32_t s2 = 0; s2 < A; ++s2) {
-            const bool u1 = f.allele_flags[a0 + s1] & 1, u2 = f.allele_flags[a0 + s2] & 1;
-            long double result = 1.0L;
-            for (uint32_t k = 0; k < K; ++k) {
-                long double p[3];
-                pg_table_get(table, f.coverage[v], f.kmer_count[k0 + k], p);
-                const unsigned expected = on(s1, k) + on(s2, k);
-                if (u1 && u2) result *= (1.0L / 3.0L) * (p[0] + p[1] + p[2]);
-                else if (u1 || u2) result *= 0.5L * (p[expected] + p[expected + 1 > 2 ? 2 : expected + 1]);
-                else result *= p[expected];
-            }
-            E[(size_t)s1 * A + s2] = result;
-            if (result > 0) all_zeros = false;
-        }
-    if (all_zeros) std::fill(E.begin(), E.end(), 1.0L);
-}
-
-struct ViterbiColumns {
-    const FlatContig& f;
-    const pg_table* table;
-    std::vector<size_t> cols;          // kept variants (ColumnIndexer rule)
-    std::vector<uint16_t> slot;        // [V*H] allele slot of every selected path
-    size_t H;
-    double recombrate; bool uniform; long double eff_N;
-
-    // column c from the previous one (prev empty for c == 0); fills cur and, for c > 0, back
-    void column(size_t c, const std::vector<long double>& prev, std::vector<long double>& cur, std::vector<uint32_t>* back) const {
-        const size_t v = cols[c], n = H * H;
-        std::vector<long double> E;
-        host_emission_table(f, table, v, E);
-        const uint32_t A = f.allele_off[v + 1] - f.allele_off[v];
-        long double t[3] = {1.0L, 1.0L, 1.0L};
-        if (c > 0 && !uniform) {  // reference src/transitionprobabilitycomputer.cpp:14-18
-            const long double distance = (f.variant_pos[v] - f.variant_pos[cols[c - 1]]) * 0.000004L * ((long double)recombrate) * eff_N;
-            const long double recomb = (1.0L - expl(-distance / (long double)H)) * (1.0L / (long double)H);
-            const long double no_recomb = expl(-distance / (long double)H) + recomb;
-            t[0] = no_recomb * no_recomb; t[1] = no_recomb * recomb; t[2] = recomb * recomb;
-        }
-        cur.assign(n, 0.0L);
-        if (back) back->assign(c > 0 ? n : 0, 0);
-        // helpers for the O(H^2) form: last index of the row / column / global maximum of prev
-        std::vector<long double> rowmax, colmax;
-        std::vector<size_t> rowidx, colidx;
-        long double gmax = 0.0L; size_t gidx = 0;
-        // H <= 40 (the reference caps phasing at 30 paths): the reference's own O(H^4) loop; above, the exact
-        // O(H^2) form below.  PG_VITERBI_NAIVE_MAX moves the switch (tests compare the two forms).
-        size_t naive_max = 40;
-        if (const char* e = getenv("PG_VITERBI_NAIVE_MAX")) naive_max = (size_t)strtoul(e, nullptr, 0);
-        const bool naive = H <= naive_max;
-        if (c > 0 && !naive) {
-            rowmax.assign(H, 0.0L); colmax.assign(H, 0.0L); rowidx.assign(H, 0); colidx.assign(H, 0);
-            for (size_t j = 0; j < n; ++j) {
-                const size_t a = j / H, b = j % H;
-                if (prev[j] >= rowmax[a]) { rowmax[a] = prev[j]; rowidx[a] = j; }
-                if (prev[j] >= colmax[b]) { colmax[b] = prev[j]; colidx[b] = j; }
-                if (prev[j] >= gmax) { gmax = prev[j]; gidx = j; }
-            }
-        }
-        long double sum = 0.0L;
-        for (size_t p1 = 0; p1 < H; ++p1)
-            for (size_t p2 = 0; p2 < H; ++p2) {
-                const size_t i = p1 * H + p2;
-                long double previous_cell = 1.0L;
-                if (c > 0) {
-                    long double max_value = 0.0L; size_t max_index = 0;
-                    if (naive) {  // the reference's loop itself (src/hmm.cpp:446-473)
-                        size_t j = 0;
-                        for (size_t q1 = 0; q1 < H; ++q1)
-                            for (size_t q2 = 0; q2 < H; ++q2) {
-                                const long double pp = prev[j] * t[(q1 != p1) + (q2 != p2)];
-                                if (pp >= max_value) { max_value = pp; max_index = j; }
-                                j += 1;
-                            }
-                    } else {
-                        // t0 >= t1 >= t2, so max_j prev[j] * t(j -> i) = max(t0 prev[i], t1 rowmax, t1 colmax, t2 gmax);
-                        // among equal values the largest index (what the scan with `>=` ends on)
-                        const long double cv[4] = {prev[i] * t[0], rowmax[p1] * t[1], colmax[p2] * t[1], gmax * t[2]};
-                        const size_t ci[4] = {i, rowidx[p1], colidx[p2], gidx};
-                        for (int q = 0; q < 4; ++q)
-                            if (cv[q] > max_value || (cv[q] == max_value && ci[q] >= max_index)) { max_value = cv[q]; max_index = ci[q]; }
-                        if (max_value == 0.0L) max_index = n - 1;  // every product is 0: the scan ends on the last state
-                    }
-                    previous_cell = max_value;
-                    if (back) (*back)[i] = (uint32_t)max_index;
-                }
-                const long double e = E[(size_t)slot[v * H + p1] * A + slot[v * H + p2]];
-                cur[i] = previous_cell * e;
-                sum += cur[i];
-            }
-        if (sum > 0.0L) { for (auto& x : cur) x = x / sum; }
-        else { const long double u = 1.0L / (long double)n; for (auto& x : cur) x = u; }
-    }
-};
-
-void viterbi_phasing(const FlatContig& f, const pg_table* table, double recombrate, bool uniform, long double eff_N,
-                     std::vector<GenotypingResult>& results) {
-    const size_t V = f.variant_pos.size(), H = f.paths.size();
-    ViterbiColumns vc{f, table, {}, {}, H, recombrate, uniform, eff_N};
-    vc.slot.assign(V * H, 0);
-    for (size_t v = 0; v < V; ++v) {  // ColumnIndexer rule, reference src/columnindexer.cpp:24-31
-        const uint32_t a0 = f.allele_off[v], A = f.allele_off[v + 1] - a0;
-        bool keep = false;
-        for (size_t p = 0; p < H; ++p) {
-            const uint16_t a = f.path_allele[v * H + p];
-            uint32_t s = 0;
-            for (uint32_t q = 0; q < A; ++q) if (f.allele_id[a0 + q] == a) s = q;
-            vc.slot[v * H + p] = (uint16_t)s;
-            if (a != 0 && !(f.allele_flags[a0 + s] & 1)) keep = true;
-        }
-        if (keep) vc.cols.push_back(v);
-    }
-    const size_t C = vc.cols.size();
-    if (C == 0) return;  // reference src/hmm.cpp:114
-    size_t k = (size_t)sqrt((double)C);
-    if (k < 1) k = 1;
-    // forward: keep the columns at multiples of k
-    std::vector<std::vector<long double>> checkpoint((C + k - 1) / k);
-    std::vector<long double> prev, cur;
-    for (size_t c = 0; c < C; ++c) {
-        vc.column(c, prev, cur, nullptr);
-        if (c % k == 0) checkpoint[c / k] = cur;
-        prev.swap(cur);
-    }
-    // best state of the last column: the LAST maximum (reference src/hmm.cpp:133-141)
-    size_t best_index = 0;
-    long double best_value = 0.0L;
-    for (size_t i = 0; i < prev.size(); ++i)
-        if (prev[i] >= best_value) { best_value = prev[i]; best_index = i; }
-    // backtracking, block by block: the backtrace columns lo+1 .. lo+k are recomputed from checkpoint lo
-    auto record = [&](size_t c) {
-        const size_t v = vc.cols[c];
-        const size_t p1 = best_index / H, p2 = best_index % H;  // ColumnIndexer::get_path_ids_at
-        results[v].add_first_haplotype_allele(f.path_allele[v * H + p1]);
-        results[v].add_second_haplotype_allele(f.path_allele[v * H + p2]);
-        // (sic: the reference indexes these two by COLUMN, not by variant — src/hmm.cpp:164-165)
-        results[c].set_unique_kmers((unsigned short)(f.kmer_off[c + 1] - f.kmer_off[c]));
-        results[c].set_coverage(f.coverage[c]);
-    };
-    size_t c = C - 1;
-    for (size_t blk = (C - 1) / k + 1; blk-- > 0;) {
-        const size_t lo = blk * k, top = std::min(C - 1, lo + k);
-        std::vector<std::vector<uint32_t>> back(top - lo);
-        prev = checkpoint[blk];
-        for (size_t cc = lo + 1; cc <= top; ++cc) { vc.column(cc, prev, cur, &back[cc - lo - 1]); prev.swap(cur); }
-        while (c > lo) {
-            record(c);
-            best_index = back[c - lo - 1][best_index];
-            c -= 1;
-        }
-    }
-    record(0);
-}
-
-}  // namespace
-
 // ------------------------------------------------------------------ HMM
 void HMM::set_device(int device) { g_device = device; }
 int HMM::device_count() { return pg_hmm_device_count(); }
@@ -658,9 +481,10 @@ HMM::HMM(std::vector<std::shared_ptr<UniqueKmers>>* unique_kmers, ProbabilityTab
     std::vector<int32_t> lik_exp(geno_off[V] ? geno_off[V] : 1);  // one exponent per genotype bin
     std::vector<uint8_t> kept(V ? V : 1), present(f.allele_id.size() ? f.allele_id.size() : 1);
     std::vector<uint16_t> n_kmers(V ? V : 1), cov(V ? V : 1), hap1(V ? V : 1), hap2(V ? V : 1);
-    // Viterbi on the device (pg_viterbi.hip) up to 64 selected paths; on the host above that / with PG_VITERBI=host
-    const char* vit_env = getenv("PG_VITERBI");
-    const bool phase_on_device = run_phasing && f.paths.size() <= 64 && !(vit_env && !strcmp(vit_env, "host"));
+    // Viterbi on the device (pg_viterbi.hip): at most 64 selected paths (the reference's callers pass at most 30,
+    // src/commands.cpp:939); above that the C ABI refuses (PG_ERR_UNSUPPORTED -> std::runtime_error).  There is no host
+    // compute path behind this constructor.
+    const bool phase_on_device = run_phasing;
     pg_contig_result r{};
     r.lik = lik.data(); r.lik_exp = lik_exp.data(); r.kept = kept.data(); r.allele_present = present.data();
     r.n_kmers = n_kmers.data(); r.coverage = cov.data();
@@ -702,8 +526,6 @@ HMM::HMM(std::vector<std::shared_ptr<UniqueKmers>>* unique_kmers, ProbabilityTab
             genotyping_result_[c].set_unique_kmers((unsigned short)(f.kmer_off[c + 1] - f.kmer_off[c]));
             genotyping_result_[c].set_coverage(f.coverage[c]);
         }
-    } else if (run_phasing) {
-        viterbi_phasing(f, probabilities->handle(), recombrate, uniform, effective_N, genotyping_result_);
     }
 }
 // ------------------------------------------------------------------ multi-GPU job loop

@@ -271,8 +271,8 @@ struct FlatContig {
 void flatten(std::vector<std::shared_ptr<UniqueKmers>>* unique_kmers, std::vector<unsigned short>* only_paths, FlatContig& out);
 
 /** The genotyping HMM.  All work happens in the constructor, on the GPU: forward-backward genotyping and, with
- *  run_phasing, the Viterbi path (get_haplotype(); pangenie_amd/csrc/pg_viterbi.hip, up to 64 selected paths — above
- *  that, or with PG_VITERBI=host, the long double host Viterbi of pangenie_host.cpp). */
+ *  run_phasing, the Viterbi path (get_haplotype(); pangenie_amd/csrc/pg_viterbi.hip, up to 64 selected paths — more are
+ *  refused with std::runtime_error; the reference's callers pass at most 30, src/commands.cpp:939). */
 class HMM {
 public:
     HMM() = default;

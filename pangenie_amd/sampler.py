@@ -13,7 +13,7 @@ from typing import Sequence
 import numpy as np
 
 from . import _lib
-from ._lib import PgContigBatch, u8p, u16p, u32p, f64p
+from ._lib import PgContigBatch, u8p, u16p, u32p, f64p, c_ld as _c_ld
 from .panel import ContigBatch
 
 _bound = False
@@ -79,7 +79,7 @@ class SamplingTransitions:
     def __init__(self, from_variant: int, to_variant: int, recomb_rate: float, nr_paths: int, effective_N=25000.0):
         assert from_variant <= to_variant
         self.cost = int(_hip().pg_sampler_transition_cost(int(from_variant), int(to_variant), float(recomb_rate), int(nr_paths),
-                                                          np.longdouble(effective_N)))
+                                                          _c_ld(effective_N)))
 
     def compute_transition_cost(self, recombination: bool) -> int:
         return self.cost if recombination else 0
@@ -146,7 +146,7 @@ def sample_contigs(batches: Sequence[ContigBatch], size: int, recombrate: float 
     sp = (u32p * n)(*[a.ctypes.data_as(u32p) for a in sampled])
     bp = (u32p * n)(*[a.ctypes.data_as(u32p) for a in best])
     err = C.create_string_buffer(512)
-    rc = _hip().pg_sampler_run_batch(arr, n, size, float(recombrate), np.longdouble(effective_N), int(allele_penalty), device, sp, bp, err, 512)
+    rc = _hip().pg_sampler_run_batch(arr, n, size, float(recombrate), _c_ld(effective_N), int(allele_penalty), device, sp, bp, err, 512)
     if rc:
         raise RuntimeError(f"pg_sampler_run_batch: {err.value.decode()} (error {rc})")
     return [s[:, : b.n_variants] for s, b in zip(sampled, batches)], [x[:size] for x in best]
@@ -172,7 +172,7 @@ class HaplotypeSampler:
         best = np.zeros(size, np.uint32)
         err = C.create_string_buffer(512)
         lib = _hip()
-        rc = lib.pg_sampler_run(C.byref(batch.as_c()), size, float(recombrate), np.longdouble(effective_N), int(allele_penalty),
+        rc = lib.pg_sampler_run(C.byref(batch.as_c()), size, float(recombrate), _c_ld(effective_N), int(allele_penalty),
                                 device, sampled.ctypes.data_as(u32p), best.ctypes.data_as(u32p), err, 512)
         if rc:
             raise RuntimeError(f"pg_sampler_run: {err.value.decode()} (error {rc})")

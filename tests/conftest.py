@@ -16,3 +16,16 @@ def pytest_configure(config):
 def golden():
     import json
     return json.loads((ROOT / "tests" / "golden" / "reference_known_answers.json").read_text())
+
+
+def pytest_collection_modifyitems(config, items):
+    """`-m gpu` on a machine without any AMD GPU driver (no /dev/kfd: e.g. the build container) skips the GPU tests
+    instead of failing 100+ of them one by one.  A machine that HAS the driver but shows no device is a broken GPU box:
+    there the tests run and fail loudly (the product has no CPU fallback)."""
+    import os
+    if os.path.exists("/dev/kfd"):
+        return
+    skip = pytest.mark.skip(reason="no AMD GPU driver on this machine (/dev/kfd missing)")
+    for item in items:
+        if "gpu" in item.keywords:
+            item.add_marker(skip)
