@@ -25,6 +25,12 @@ def pytest_collection_modifyitems(config, items):
     import os
     if os.path.exists("/dev/kfd"):
         return
+    try:  # (belt and braces: a device that is visible some other way is used)
+        from pangenie_amd import _lib
+        if _lib.load_hip().pg_hmm_device_count() > 0:
+            return
+    except Exception:
+        pass
     skip = pytest.mark.skip(reason="no AMD GPU driver on this machine (/dev/kfd missing)")
     for item in items:
         if "gpu" in item.keywords:
