@@ -82,8 +82,9 @@ typedef struct pg_hmm_params {
     int32_t run_genotyping;  /* forward-backward                                                 */
     int32_t run_phasing;     /* Viterbi path over ordered path pairs (src/hmm.cpp:112-173, 408-511): */
                              /* fills haplotype_1 / haplotype_2; at most 64 selected paths          */
-    int32_t reserved;
+    int32_t reserved;        /* call flags of the one-shot entry point: PG_CALL_ANNOUNCED; else 0                */
 } pg_hmm_params;
+#define PG_CALL_ANNOUNCED 1  /* this pg_hmm_genotype_contig call was announced with pg_hmm_announce(device) */
 
 /* ------------------------------------------------------------------ *
  *  Output, caller-allocated.  Genotype bins of variant v live at
@@ -133,13 +134,29 @@ void pg_table_destroy(pg_table* t);
 
 /* ------------------------------------------------------------------ *
  *  One-shot blocking call = the body of HMM::HMM for one (contig, subset).
- *  Thread-safe; uses its own stream on `device`.
+ *  Thread-safe and re-entrant, the way the reference calls its constructor: N thread-pool workers at
+ *  a time, one call per (contig x subset), sharing the table read-only (src/commands.cpp:949-978,
+ *  :155-185).  Calls that are in flight together on one device with the same table and parameters are
+ *  MERGED into one multi-chain device job by the first of them (the others sleep until their results
+ *  are in their buffers); chains of a job are independent, so each caller gets exactly what it would
+ *  have got alone, and an error of one caller's batch is that caller's alone (the merged job is then
+ *  re-run call by call).  Environment: PG_COALESCE=0 (off), PG_COALESCE_WINDOW_US (300),
+ *  PG_COALESCE_WAIT_MS (250), PG_COALESCE_INFLIGHT (2 merged jobs per device at a time).
+ *  Device arenas of finished calls are pooled for the next ones (pg_hmm_release_cache frees them).
  * ------------------------------------------------------------------ */
 int pg_hmm_device_count(void);
 const char* pg_hmm_version(void);
 int pg_hmm_genotype_contig(const pg_contig_batch* batch, const pg_table* table,
                            const pg_hmm_params* params, int device,
                            pg_contig_result* out, char* err, size_t errlen);
+/* Optional: a worker that WILL call pg_hmm_genotype_contig on `device` shortly (it is still
+ * flattening its UniqueKmers) says so; a leader about to launch waits for announced calls (bounded by
+ * PG_COALESCE_WAIT_MS).  The call itself then carries PG_CALL_ANNOUNCED in params->reserved; a worker
+ * that gives up before calling retracts. */
+void pg_hmm_announce(int device);
+void pg_hmm_retract(int device);
+/* {merged jobs launched, calls served, largest merge} since the process started */
+int  pg_hmm_coalesce_stats(uint64_t out3[3]);
 
 /* ------------------------------------------------------------------ *
  *  Resident job API: upload once, run many times (benchmarks, pipelines,
@@ -155,6 +172,8 @@ pg_job* pg_job_create(int device, uint32_t n_contigs, const pg_contig_batch* bat
 int  pg_job_run(pg_job* job, void* stream, char* err, size_t errlen);
 /* Copies contig c's results to host buffers. */
 int  pg_job_fetch(pg_job* job, uint32_t contig, pg_contig_result* out, char* err, size_t errlen);
+/* The same for all chains with one synchronisation: outs[n_chains], chain order. */
+int  pg_job_fetch_all(pg_job* job, pg_contig_result* outs, char* err, size_t errlen);
 /* Device-resident result buffers of contig c: lik f64 [n_lik], lik_exp i32 [n_lik]. */
 int  pg_job_device_results(pg_job* job, uint32_t contig, void** d_lik, uint64_t* n_lik,
                            void** d_lik_exp, uint64_t* n_variants);
@@ -222,8 +241,8 @@ int  pg_job_upload_bytes(const pg_job* job, uint64_t out2[2]);
 /* All chains' posteriors as two packed device ranges, chain after chain (what a multi-GPU
  * gather sends): lik f64 [n_lik_total], lik_exp i32 [n_lik_total]. */
 int  pg_job_packed_results(pg_job* job, void** d_lik, void** d_lik_exp, uint64_t* n_lik_total);
-/* The one-shot call keeps the device arena of its last job for the next call on that device;
- * this releases it. */
+/* The one-shot call keeps the device arenas of its finished jobs in a pool for the next calls
+ * (at most PG_ARENA_POOL_GB, default 200); this releases them. */
 void pg_hmm_release_cache(void);
 
 /* ------------------------------------------------------------------ *

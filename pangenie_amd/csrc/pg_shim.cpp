@@ -20,6 +20,8 @@
 #include <string.h>
 
 #include <chrono>
+#include <condition_variable>
+#include <memory>
 #include <mutex>
 #include <string>
 #include <vector>
@@ -60,6 +62,7 @@ void set_err(char* err, size_t errlen, const char* fmt, ...) {
         }                                                                                 \
     } while (0)
 
+constexpr int PG_MAX_DEVICES_HOST = 64;
 inline size_t align_up(size_t x, size_t a = 256) { return (x + a - 1) / a * a; }
 
 double now_s() {
@@ -269,8 +272,56 @@ int check_batch(const pg_contig_batch* b, bool need_counts, char* err, size_t er
     return PG_OK;
 }
 
-// one cached device arena per process (the one-shot call creates and destroys a job per call)
-struct ArenaCache { std::mutex mu; int device = -1; unsigned char* ptr = nullptr; size_t bytes = 0; } g_cache;
+// Device arenas of finished one-shot jobs, kept for the next calls (the one-shot call creates and destroys a job per call,
+// and a device allocation of tens of GB costs more than the job: the pages are mapped on first touch).  A POOL: the
+// reference runs N constructors at a time on thread-pool workers (src/commands.cpp:949-978), so several arenas of
+// different sizes are in use at once.  take(): the smallest cached arena of the device that is large enough.
+// put(): keeps the arena unless the pool would then hold more than PG_ARENA_POOL_GB (default 200) — the smallest
+// entries go first.  pg_hmm_release_cache() empties it; an allocation failure empties it and retries.
+struct ArenaPool {
+    struct Entry { int device; unsigned char* ptr; size_t bytes; };
+    std::mutex mu;
+    std::vector<Entry> free_list;
+    size_t limit() {
+        static const size_t lim = [] { const char* e = getenv("PG_ARENA_POOL_GB"); return (size_t)((e ? strtod(e, nullptr) : 200.0) * 1073741824.0); }();
+        return lim;
+    }
+    bool take(int device, size_t need, unsigned char** ptr, size_t* bytes) {
+        std::lock_guard<std::mutex> lock(mu);
+        int best = -1;
+        for (size_t i = 0; i < free_list.size(); ++i)
+            if (free_list[i].device == device && free_list[i].bytes >= need && (best < 0 || free_list[i].bytes < free_list[(size_t)best].bytes)) best = (int)i;
+        if (best < 0) return false;
+        *ptr = free_list[(size_t)best].ptr; *bytes = free_list[(size_t)best].bytes;
+        free_list.erase(free_list.begin() + best);
+        return true;
+    }
+    void put(int device, unsigned char* ptr, size_t bytes) {  // (the caller has made `device` current)
+        std::vector<Entry> drop;
+        {
+            std::lock_guard<std::mutex> lock(mu);
+            free_list.push_back({device, ptr, bytes});
+            size_t total = 0;
+            for (const Entry& e : free_list) total += e.bytes;
+            while (total > limit() && !free_list.empty()) {
+                size_t k = 0;
+                for (size_t i = 1; i < free_list.size(); ++i) if (free_list[i].bytes < free_list[k].bytes) k = i;
+                total -= free_list[k].bytes;
+                drop.push_back(free_list[k]);
+                free_list.erase(free_list.begin() + (long)k);
+            }
+        }
+        for (const Entry& e : drop)
+            if (hipSetDevice(e.device) == hipSuccess) hipFree(e.ptr);
+        if (!drop.empty()) hipSetDevice(device);
+    }
+    void clear() {
+        std::vector<Entry> all;
+        { std::lock_guard<std::mutex> lock(mu); all.swap(free_list); }
+        for (const Entry& e : all)
+            if (hipSetDevice(e.device) == hipSuccess) hipFree(e.ptr);
+    }
+} g_pool;
 
 }  // namespace
 
@@ -333,12 +384,8 @@ extern "C" void pg_job_destroy(pg_job* job) {
     if (job->events2)
         for (int q = 0; q < 2; ++q) { hipEventDestroy(job->ev_sweep[q]); hipEventDestroy(job->ev_post[q]); }
     if (job->arena) {
-        bool kept = false;
-        if (job->cache_arena) {
-            std::lock_guard<std::mutex> lock(g_cache.mu);
-            if (!g_cache.ptr) { g_cache.ptr = job->arena; g_cache.bytes = job->arena_bytes; g_cache.device = job->device; kept = true; }
-        }
-        if (!kept) hipFree(job->arena);
+        if (job->cache_arena) g_pool.put(job->device, job->arena, job->arena_bytes);
+        else hipFree(job->arena);
     }
     if (job->stream2) hipStreamDestroy(job->stream2);
     if (job->stream) hipStreamDestroy(job->stream);
@@ -346,11 +393,10 @@ extern "C" void pg_job_destroy(pg_job* job) {
 }
 
 extern "C" void pg_hmm_release_cache(void) {
-    std::lock_guard<std::mutex> lock(g_cache.mu);
-    if (g_cache.ptr) {
-        if (hipSetDevice(g_cache.device) == hipSuccess) hipFree(g_cache.ptr);
-        g_cache.ptr = nullptr; g_cache.bytes = 0; g_cache.device = -1;
-    }
+    int cur = -1;
+    const bool have = hipGetDevice(&cur) == hipSuccess;
+    g_pool.clear();
+    if (have) hipSetDevice(cur);
 }
 
 namespace {
@@ -630,18 +676,13 @@ int job_build(int device, uint32_t n_index, const pg_contig_batch* batches, cons
     if (job->hp_mask & 32u) job->hp_mask |= 16u;  // one generic launch covers both
     job->arena_bytes = align_up(off);
     const double t_alloc = now_s();
-    {
-        std::lock_guard<std::mutex> lock(g_cache.mu);
-        if (g_cache.ptr && g_cache.device == device && g_cache.bytes >= job->arena_bytes) {
-            job->arena = g_cache.ptr;
-            job->arena_bytes = g_cache.bytes;
-            g_cache.ptr = nullptr; g_cache.bytes = 0; g_cache.device = -1;
-        }
-    }
+    if (cache_arena) g_pool.take(device, job->arena_bytes, &job->arena, &job->arena_bytes);
     if (!job->arena) {
         he = hipMalloc((void**)&job->arena, job->arena_bytes);
         if (he != hipSuccess) {
-            pg_hmm_release_cache();  // a cached arena may be what stands in the way
+            (void)hipGetLastError();
+            pg_hmm_release_cache();  // cached arenas may be what stands in the way
+            hipSetDevice(device);
             he = hipMalloc((void**)&job->arena, job->arena_bytes);
         }
         if (he != hipSuccess) {
@@ -969,6 +1010,45 @@ extern "C" int pg_job_fetch(pg_job* job, uint32_t ci, pg_contig_result* out, cha
     return PG_OK;
 }
 
+// All chains at once: the copies are queued on the job's stream and waited for once (24 chains x 6 blocking copies
+// were 13 ms of the whole-genome job's 360 ms end-to-end time).
+extern "C" int pg_job_fetch_all(pg_job* job, pg_contig_result* outs, char* err, size_t errlen) {
+    if (!job || !outs) { set_err(err, errlen, "bad argument"); return PG_ERR_INVALID; }
+    if (!job->ran) { set_err(err, errlen, "pg_job_run has not been called"); return PG_ERR_INVALID; }
+    const double t0 = now_s();
+    HIP_TRY(hipSetDevice(job->device));
+    hipStream_t s = job->stream;
+    for (size_t ci = 0; ci < job->chains.size(); ++ci) {
+        const ChainHost& c = job->chains[ci];
+        const IndexHost& x = job->index[c.index];
+        pg_contig_result* out = &outs[ci];
+        out->n_columns = c.n_cols_host;
+        if (x.V == 0) continue;
+        if (out->lik && x.n_lik) HIP_TRY(hipMemcpyAsync(out->lik, c.d.lik, x.n_lik * sizeof(double), hipMemcpyDeviceToHost, s));
+        if (out->lik_exp && x.n_lik) HIP_TRY(hipMemcpyAsync(out->lik_exp, c.d.lik_exp, x.n_lik * sizeof(int32_t), hipMemcpyDeviceToHost, s));
+        if (out->kept) HIP_TRY(hipMemcpyAsync(out->kept, c.d.kept, x.V, hipMemcpyDeviceToHost, s));
+        if (out->allele_present && x.sumA) HIP_TRY(hipMemcpyAsync(out->allele_present, c.d.allele_present, x.sumA, hipMemcpyDeviceToHost, s));
+        if (job->params.run_phasing) {
+            if (out->haplotype_1) HIP_TRY(hipMemcpyAsync(out->haplotype_1, c.d.hap1, (size_t)x.V * 2, hipMemcpyDeviceToHost, s));
+            if (out->haplotype_2) HIP_TRY(hipMemcpyAsync(out->haplotype_2, c.d.hap2, (size_t)x.V * 2, hipMemcpyDeviceToHost, s));
+        }
+        // host-side meta data while the copies run (rules: pg_job_fetch)
+        const bool fill = job->params.run_genotyping && c.n_cols_host > 0;
+        const size_t nvit = job->params.run_phasing ? c.n_cols_host : 0;
+        if (out->n_kmers) {
+            if (fill) memcpy(out->n_kmers, x.n_kmers.data(), (size_t)x.V * 2);
+            else { memset(out->n_kmers, 0, (size_t)x.V * 2); memcpy(out->n_kmers, x.n_kmers.data(), nvit * 2); }
+        }
+        if (out->coverage) {
+            if (fill) memcpy(out->coverage, c.coverage.data(), (size_t)x.V * 2);
+            else { memset(out->coverage, 0, (size_t)x.V * 2); memcpy(out->coverage, c.coverage.data(), nvit * 2); }
+        }
+    }
+    HIP_TRY(hipStreamSynchronize(s));
+    job->host_s[3] += now_s() - t0;
+    return PG_OK;
+}
+
 extern "C" int pg_job_device_results(pg_job* job, uint32_t ci, void** d_lik, uint64_t* n_lik, void** d_lik_exp, uint64_t* n_variants) {
     if (!job || ci >= job->chains.size()) return PG_ERR_INVALID;
     const ChainHost& c = job->chains[ci];
@@ -1030,20 +1110,179 @@ extern "C" uint32_t pg_job_triangle_chains(const pg_job* job) {
     return n;
 }
 
-extern "C" int pg_hmm_genotype_contig(const pg_contig_batch* batch, const pg_table* table, const pg_hmm_params* params,
-                                      int device, pg_contig_result* out, char* err, size_t errlen) {
-    if (!batch || !table || !params || !out) { set_err(err, errlen, "null argument"); return PG_ERR_INVALID; }
+namespace {
+
+// the body of the one-shot call for ONE chain: a job of its own (arena from / to the pool)
+int genotype_single(const pg_contig_batch* batch, const pg_table* table, const pg_hmm_params* params, int device,
+                    pg_contig_result* out, char* err, size_t errlen) {
     std::vector<ChainSpec> specs(1);
     specs[0] = {0, batch->kmer_count, batch->coverage};
     pg_job* job = nullptr;
-    // (the arena of this job goes to the process cache when the job is destroyed: the next call on
-    // this device reuses it instead of paying for a device allocation again)
     int rc = job_build(device, 1, batch, specs, 1, false, table, params, true, &job, err, errlen);
     if (rc != PG_OK) return rc;
     rc = pg_job_run(job, nullptr, err, errlen);
     if (rc == PG_OK) rc = pg_job_fetch(job, 0, out, err, errlen);
     pg_job_destroy(job);
     return rc;
+}
+
+// ---------------------------------------------------------------------------------------
+//  Coalescing of concurrent one-shot calls.
+//
+//  The reference constructs one HMM per (contig x subset) on N thread-pool workers at a time
+//  (src/commands.cpp:949-978, run_genotyping :155-185).  N one-shot jobs side by side would each bring their own
+//  two streams (more streams than hardware queues: kernels of different jobs then queue behind each other's
+//  half-chain kernels, which run for the whole phase), ~100 launches per job, and a k_post grid sized as if the job
+//  had the chip to itself.  So calls that are in flight at the same time on the same device with the same table and
+//  parameters are merged into ONE job — exactly the resident multi-chain job of pg_job_new — by whichever caller
+//  arrives first (the leader); the others sleep until their results are in their buffers.  Chains of a job are
+//  independent, so every caller gets bit for bit what it would have got alone.
+//    * a leader launches when a job slot of the device is free (at most PG_COALESCE_INFLIGHT = 2 merged jobs at a
+//      time per device), every ANNOUNCED call has arrived (pg_hmm_announce: the C++ adapter announces at the top of
+//      the HMM constructor, before it flattens its UniqueKmers — the leader then knows who is still coming; bounded by
+//      PG_COALESCE_WAIT_MS = 250), and nobody new has joined for PG_COALESCE_WINDOW_US = 300 (only when other
+//      callers have been seen at all: a single-threaded host never waits);
+//    * if the merged job fails (one malformed batch, a device limit, no memory for the sum) the leader runs the
+//      requests one by one, so every caller gets its own error code and message;
+//    * PG_COALESCE=0 turns it off.
+// ---------------------------------------------------------------------------------------
+struct CoRequest {
+    const pg_contig_batch* batch; pg_contig_result* out; char* err; size_t errlen;
+    int rc = PG_OK; bool done = false;
+};
+struct CoBatch {
+    int device; const pg_table* table; pg_hmm_params params;
+    std::vector<CoRequest*> reqs;
+    std::chrono::steady_clock::time_point last_arrival;
+};
+struct Coalescer {
+    std::mutex mu;
+    std::condition_variable cv;
+    std::vector<std::shared_ptr<CoBatch>> open;
+    int callers_inside = 0;
+    int announced[PG_MAX_DEVICES_HOST] = {0};
+    int inflight[PG_MAX_DEVICES_HOST] = {0};
+    std::chrono::steady_clock::time_point last_concurrency = std::chrono::steady_clock::time_point::min();
+    uint64_t stat_batches = 0, stat_requests = 0, stat_largest = 0;
+} g_co;
+
+long env_long(const char* name, long dflt) { const char* e = getenv(name); return e ? strtol(e, nullptr, 0) : dflt; }
+
+bool same_params(const pg_hmm_params& a, const pg_hmm_params& b) {
+    return a.effective_N == b.effective_N && a.recombrate == b.recombrate && (a.uniform != 0) == (b.uniform != 0) &&
+           (a.run_genotyping != 0) == (b.run_genotyping != 0) && (a.run_phasing != 0) == (b.run_phasing != 0);
+}
+
+void run_merged(CoBatch& b) {
+    const size_t n = b.reqs.size();
+    pg_hmm_params prm = b.params;
+    prm.reserved = 0;
+    if (n > 1) {
+        std::vector<pg_contig_batch> bs(n);
+        std::vector<ChainSpec> specs(n);
+        for (size_t i = 0; i < n; ++i) { bs[i] = *b.reqs[i]->batch; specs[i] = {(uint32_t)i, bs[i].kmer_count, bs[i].coverage}; }
+        char err[512] = {0};
+        pg_job* job = nullptr;
+        int rc = job_build(b.device, (uint32_t)n, bs.data(), specs, 1, false, b.table, &prm, true, &job, err, sizeof(err));
+        if (rc == PG_OK) rc = pg_job_run(job, nullptr, err, sizeof(err));
+        if (rc == PG_OK) {
+            std::vector<pg_contig_result> outs(n);
+            for (size_t i = 0; i < n; ++i) outs[i] = *b.reqs[i]->out;
+            rc = pg_job_fetch_all(job, outs.data(), err, sizeof(err));
+            for (size_t i = 0; i < n; ++i) b.reqs[i]->out->n_columns = outs[i].n_columns;
+        }
+        if (job) pg_job_destroy(job);
+        if (rc == PG_OK) { for (CoRequest* r : b.reqs) r->rc = PG_OK; return; }
+        // fall through: one by one, every caller its own verdict
+    }
+    for (CoRequest* r : b.reqs) r->rc = genotype_single(r->batch, b.table, &prm, b.device, r->out, r->err, r->errlen);
+}
+
+}  // namespace
+
+extern "C" void pg_hmm_announce(int device) {
+    if (device < 0 || device >= PG_MAX_DEVICES_HOST) return;
+    std::lock_guard<std::mutex> lock(g_co.mu);
+    g_co.announced[device] += 1;
+}
+extern "C" void pg_hmm_retract(int device) {
+    if (device < 0 || device >= PG_MAX_DEVICES_HOST) return;
+    std::lock_guard<std::mutex> lock(g_co.mu);
+    if (g_co.announced[device] > 0) g_co.announced[device] -= 1;
+    g_co.cv.notify_all();
+}
+extern "C" int pg_hmm_coalesce_stats(uint64_t out3[3]) {
+    if (!out3) return PG_ERR_INVALID;
+    std::lock_guard<std::mutex> lock(g_co.mu);
+    out3[0] = g_co.stat_batches; out3[1] = g_co.stat_requests; out3[2] = g_co.stat_largest;
+    return PG_OK;
+}
+
+extern "C" int pg_hmm_genotype_contig(const pg_contig_batch* batch, const pg_table* table, const pg_hmm_params* params,
+                                      int device, pg_contig_result* out, char* err, size_t errlen) {
+    if (!batch || !table || !params || !out) { set_err(err, errlen, "null argument"); return PG_ERR_INVALID; }
+    using clock = std::chrono::steady_clock;
+    static const bool enabled = env_long("PG_COALESCE", 1) != 0;
+    static const long window_us = env_long("PG_COALESCE_WINDOW_US", 300), wait_ms = env_long("PG_COALESCE_WAIT_MS", 250);
+    static const long max_inflight = env_long("PG_COALESCE_INFLIGHT", 2), max_batch = env_long("PG_COALESCE_MAX", 256);
+    const bool announced = (params->reserved & PG_CALL_ANNOUNCED) != 0;
+    if (!enabled || device < 0 || device >= PG_MAX_DEVICES_HOST) {
+        if (announced) pg_hmm_retract(device);
+        return genotype_single(batch, table, params, device, out, err, errlen);
+    }
+    CoRequest req{batch, out, err, errlen};
+    std::shared_ptr<CoBatch> mine;
+    {
+        std::unique_lock<std::mutex> lk(g_co.mu);
+        if (announced && g_co.announced[device] > 0) g_co.announced[device] -= 1;
+        g_co.callers_inside += 1;
+        if (g_co.callers_inside > 1) g_co.last_concurrency = clock::now();
+        for (auto& ob : g_co.open)
+            if (ob->device == device && ob->table == table && same_params(ob->params, *params) && (long)ob->reqs.size() < max_batch) {
+                ob->reqs.push_back(&req);
+                ob->last_arrival = clock::now();
+                g_co.cv.notify_all();
+                g_co.cv.wait(lk, [&] { return req.done; });
+                g_co.callers_inside -= 1;
+                return req.rc;
+            }
+        // leader of a new batch
+        mine = std::make_shared<CoBatch>();
+        mine->device = device; mine->table = table; mine->params = *params;
+        mine->reqs.push_back(&req);
+        mine->last_arrival = clock::now();
+        g_co.open.push_back(mine);
+        g_co.cv.notify_all();
+        const clock::time_point hard = clock::now() + std::chrono::milliseconds(wait_ms);
+        for (;;) {
+            const clock::time_point now = clock::now();
+            const bool concurrent = g_co.callers_inside > 1 || (g_co.last_concurrency != clock::time_point::min() &&
+                                                                now - g_co.last_concurrency < std::chrono::seconds(2));
+            const clock::time_point quiet_until = mine->last_arrival + std::chrono::microseconds(concurrent ? window_us : 0);
+            const bool slot = g_co.inflight[device] < max_inflight;
+            const bool coming = g_co.announced[device] > 0 && now < hard;
+            const bool full = (long)mine->reqs.size() >= max_batch;
+            if (slot && (full || (!coming && now >= quiet_until))) break;
+            clock::time_point until = now + std::chrono::milliseconds(50);
+            if (slot && !coming && quiet_until < until) until = quiet_until;
+            if (coming && hard < until) until = hard;
+            g_co.cv.wait_until(lk, until);
+        }
+        for (size_t i = 0; i < g_co.open.size(); ++i)
+            if (g_co.open[i] == mine) { g_co.open.erase(g_co.open.begin() + (long)i); break; }
+        g_co.inflight[device] += 1;
+        g_co.stat_batches += 1; g_co.stat_requests += mine->reqs.size();
+        if (mine->reqs.size() > g_co.stat_largest) g_co.stat_largest = mine->reqs.size();
+    }
+    run_merged(*mine);
+    {
+        std::lock_guard<std::mutex> lk(g_co.mu);
+        g_co.inflight[device] -= 1;
+        g_co.callers_inside -= 1;
+        for (CoRequest* r : mine->reqs) r->done = true;
+        g_co.cv.notify_all();
+    }
+    return req.rc;
 }
 
 // ---------------------------------------------------------------------------------------

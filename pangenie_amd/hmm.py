@@ -112,13 +112,20 @@ class ContigResult:
 
 
 def genotype_contig(batch: ContigBatch, table: ProbabilityTable, params: Optional[PgHmmParams] = None,
-                    device: int = 0) -> ContigResult:
+                    device: int = 0, announced: bool = False, into: Optional[ContigResult] = None) -> ContigResult:
     """One blocking call = the body of HMM::HMM for one (contig, path subset)
     (reference src/hmm.cpp:25-63 with normalize=false, as run_genotyping calls it,
-    src/commands.cpp:160)."""
+    src/commands.cpp:160).  Thread-safe (ctypes drops the GIL for the call); calls in flight together are merged
+    into one device job.  `announced`: the caller has called announce(device) for this call (what the C++ adapter's
+    constructor does before it flattens).  `into`: result buffers to reuse."""
     lib = _lib.load_hip()
     params = params or make_params()
-    res = ContigResult(batch)
+    if announced:
+        q = PgHmmParams()
+        C.memmove(C.byref(q), C.byref(params), C.sizeof(PgHmmParams))
+        q.reserved = _lib.PG_CALL_ANNOUNCED
+        params = q
+    res = into if into is not None else ContigResult(batch)
     err = C.create_string_buffer(_ERRLEN)
     rc = lib.pg_hmm_genotype_contig(C.byref(batch.as_c()), table.h, C.byref(params), device,
                                     C.byref(res._c), err, _ERRLEN)
@@ -127,6 +134,51 @@ def genotype_contig(batch: ContigBatch, table: ProbabilityTable, params: Optiona
     res.n_columns = int(res._c.n_columns)
     res.run_genotyping = bool(params.run_genotyping)
     return res
+
+
+def announce(device: int = 0) -> None:
+    """pg_hmm_announce: a genotype_contig(..., announced=True) call on `device` will follow shortly."""
+    _lib.load_hip().pg_hmm_announce(device)
+
+
+def coalesce_stats() -> dict:
+    out = (C.c_uint64 * 3)()
+    _lib.load_hip().pg_hmm_coalesce_stats(out)
+    return {"merged_jobs": int(out[0]), "calls": int(out[1]), "largest_merge": int(out[2])}
+
+
+def genotype_contigs_threaded(batches: Sequence[ContigBatch], table: ProbabilityTable, params=None, device: int = 0,
+                              n_threads: Optional[int] = None, into: Optional[Sequence[ContigResult]] = None):
+    """The reference's calling pattern (src/commands.cpp:949-978): one one-shot call per contig from `n_threads`
+    worker threads (default: one per batch).  `params` may be a list (one per batch).  Returns the list of
+    ContigResult / raised exceptions, in batch order."""
+    import threading
+    n = len(batches)
+    n_threads = n_threads or n
+    plist = list(params) if isinstance(params, (list, tuple)) else [params] * n
+    out: list = [None] * n
+    nxt = [0]
+    lock = threading.Lock()
+
+    def worker():
+        while True:
+            with lock:
+                i = nxt[0]
+                nxt[0] += 1
+            if i >= n:
+                return
+            announce(device)
+            try:
+                out[i] = genotype_contig(batches[i], table, plist[i], device, announced=True, into=into[i] if into else None)
+            except Exception as e:  # noqa: BLE001 - handed to the caller
+                out[i] = e
+
+    ts = [threading.Thread(target=worker) for _ in range(min(n_threads, n))]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join()
+    return out
 
 
 class Job:
@@ -230,6 +282,19 @@ class Job:
             raise PanGenieError(rc, err.value.decode(errors="replace"))
         res.n_columns = int(res._c.n_columns)
         res.run_genotyping = bool(self.params.run_genotyping)
+        return res
+
+    def fetch_all(self, into: Optional[Sequence[ContigResult]] = None) -> List[ContigResult]:
+        """pg_job_fetch_all: every chain's results with one synchronisation; `into` = buffers to reuse."""
+        res = list(into) if into is not None else [ContigResult(b) for b in self.batches]
+        arr = (PgContigResult * len(res))(*[r._c for r in res])
+        err = C.create_string_buffer(_ERRLEN)
+        rc = self._lib.pg_job_fetch_all(self.h, arr, err, _ERRLEN)
+        if rc:
+            raise PanGenieError(rc, err.value.decode(errors="replace"))
+        for r, c in zip(res, arr):
+            r.n_columns = int(c.n_columns)
+            r.run_genotyping = bool(self.params.run_genotyping)
         return res
 
     def viterbi_ms(self) -> float:

@@ -400,17 +400,21 @@ void flatten(std::vector<std::shared_ptr<UniqueKmers>>* unique_kmers, std::vecto
     f = FlatContig();
     f.kmer_off.assign(1, 0);
     f.allele_off.assign(1, 0);
+    f.variant_pos.reserve(V); f.coverage.reserve(V); f.kmer_off.reserve(V + 1); f.allele_off.reserve(V + 1);
+    std::vector<unsigned short> p, a, ids;
     for (size_t v = 0; v < V; ++v) {
         UniqueKmers& uk = *unique_kmers->at(v);
-        std::vector<unsigned short> p, a;
+        p.clear(); a.clear(); ids.clear();
         uk.get_path_ids(p, a, only_paths);
         if (p.empty()) fail("HMM::index_columns: column " + std::to_string(v) + " is not covered by any paths.");
-        if (v == 0) f.paths = p;  // the selected paths are those of the first variant (ColumnIndexer)
+        if (v == 0) {  // the selected paths are those of the first variant (ColumnIndexer)
+            f.paths = p;
+            f.path_allele.reserve(V * p.size()); f.kmer_count.reserve(V * (uk.size() + 4)); f.allele_id.reserve(V * 2);
+        }
         f.variant_pos.push_back(uk.get_variant_position());
         f.coverage.push_back(uk.get_coverage());
         for (size_t k = 0; k < uk.size(); ++k) f.kmer_count.push_back(uk.get_readcount_of(k));
         f.kmer_off.push_back((uint32_t)f.kmer_count.size());
-        std::vector<unsigned short> ids;
         uk.get_allele_ids(ids);
         for (unsigned short id : ids) {
             f.allele_id.push_back(id);
@@ -420,7 +424,8 @@ void flatten(std::vector<std::shared_ptr<UniqueKmers>>* unique_kmers, std::vecto
             f.allele_kmer_mask.push_back(bits.second);
         }
         f.allele_off.push_back((uint32_t)f.allele_id.size());
-        for (unsigned short path : f.paths) f.path_allele.push_back(uk.get_allele(path));
+        if (p == f.paths) f.path_allele.insert(f.path_allele.end(), a.begin(), a.end());  // (get_path_ids already gave the alleles)
+        else for (unsigned short path : f.paths) f.path_allele.push_back(uk.get_allele(path));
     }
     f.bind();
 }
@@ -472,6 +477,14 @@ HMM::HMM(std::vector<std::shared_ptr<UniqueKmers>>* unique_kmers, ProbabilityTab
          bool run_phasing, double recombrate, bool uniform, long double effective_N, std::vector<unsigned short>* only_paths,
          bool normalize_results)
     : genotyping_result_(unique_kmers->size()) {
+    // N of these constructors run at a time on the reference's thread-pool workers (src/commands.cpp:949-978): tell the
+    // library a call is coming BEFORE the (host-side, size-dependent) flattening, so that whichever worker reaches the
+    // device first knows whom to wait for and all of them end up as chains of ONE device job (pg_hmm_announce).
+    struct Announcement {
+        int device; bool open;
+        explicit Announcement(int d) : device(d), open(true) { pg_hmm_announce(d); }
+        ~Announcement() { if (open) pg_hmm_retract(device); }
+    } announcement(g_device);
     FlatContig f;
     flatten(unique_kmers, only_paths, f);
     const size_t V = f.variant_pos.size();
@@ -493,8 +506,11 @@ HMM::HMM(std::vector<std::shared_ptr<UniqueKmers>>* unique_kmers, ProbabilityTab
     prm.effective_N = effective_N; prm.recombrate = recombrate; prm.uniform = uniform ? 1 : 0;
     prm.run_genotyping = run_genotyping ? 1 : 0; prm.run_phasing = phase_on_device ? 1 : 0;
     char err[512] = {0};
-    if (run_genotyping || phase_on_device)
-        check_rc(pg_hmm_genotype_contig(&f.batch, probabilities->handle(), &prm, g_device, &r, err, sizeof(err)), err);
+    if (run_genotyping || phase_on_device) {
+        prm.reserved = PG_CALL_ANNOUNCED;
+        announcement.open = false;  // (the call retires the announcement itself)
+        check_rc(pg_hmm_genotype_contig(&f.batch, probabilities->handle(), &prm, announcement.device, &r, err, sizeof(err)), err);
+    }
     if (run_genotyping) {
         for (size_t v = 0; v < V; ++v) {
             GenotypingResult& g = genotyping_result_[v];

@@ -17,6 +17,7 @@
 #include <memory>
 #include <stdexcept>
 #include <string>
+#include <thread>
 #include <unordered_set>
 #include <vector>
 
@@ -805,6 +806,47 @@ static void gpu_tests() {
         us h1, h2;
         for (auto& r : res) { h1.push_back(r.get_haplotype().first); h2.push_back(r.get_haplotype().second); }
         CHECK((h1 == us{0, 0, 0} && h2 == us{1, 1, 1}) || (h1 == us{1, 1, 1} && h2 == us{0, 0, 0}));
+    });
+    run("24 HMM constructors at once on worker threads (src/commands.cpp:949-978) == one after the other", [] {
+        // the reference's calling pattern: one constructor per (contig x subset) on thread-pool workers, all sharing the
+        // ProbabilityTable; mixed shapes; every worker must get exactly what it gets alone (stored likelihoods are
+        // compared as long doubles, bit for bit), one worker's failure must stay its own
+        ProbabilityTable probs(6, 108, 54, 0.01L);
+        const size_t shapes[24][2] = {{900, 64}, {400, 16}, {300, 128}, {700, 64}, {250, 30}, {1200, 16}, {500, 64}, {350, 64},
+                                      {150, 128}, {800, 16}, {450, 64}, {200, 5}, {650, 64}, {300, 32}, {1000, 64}, {120, 128},
+                                      {550, 16}, {380, 64}, {270, 64}, {600, 48}, {330, 64}, {90, 2}, {1, 64}, {40, 64}};
+        vector<vector<shared_ptr<UniqueKmers>>> panels;
+        for (auto& sh : shapes) panels.push_back(viterbi_panel(sh[0], sh[1], sh[1] > 4 ? sh[1] - sh[1] / 6 : sh[1]));
+        vector<vector<GenotypingResult>> alone(24), together(24);
+        for (size_t t = 0; t < 24; ++t) alone[t] = HMM(&panels[t], &probs, true, false, 1.26, false, 1e-5L, nullptr, false).get_genotyping_result();
+        vector<std::string> errors(25);
+        vector<shared_ptr<UniqueKmers>> broken = viterbi_panel(50, 16, 16);
+        broken.push_back(bi(999999, {0, 1}));  // its paths {0, 1} restricted to an only_paths set without them: "not covered by any paths"
+        vector<std::thread> workers;
+        for (size_t t = 0; t < 24; ++t)
+            workers.emplace_back([&, t] {
+                try { together[t] = HMM(&panels[t], &probs, true, false, 1.26, false, 1e-5L, nullptr, false).get_genotyping_result(); }
+                catch (const std::exception& e) { errors[t] = e.what(); }
+            });
+        workers.emplace_back([&] {
+            vector<unsigned short> only = {2, 3, 4};
+            try { HMM h(&broken, &probs, true, false, 1.26, false, 1e-5L, &only, false); }
+            catch (const std::exception& e) { errors[24] = e.what(); }
+        });
+        for (auto& w : workers) w.join();
+        for (size_t t = 0; t < 24; ++t) {
+            CHECK(errors[t].empty());
+            CHECK(alone[t].size() == together[t].size());
+            size_t same = 0;
+            for (size_t v = 0; v < alone[t].size() && v < together[t].size(); ++v)
+                same += alone[t][v].get_stored_likelihoods() == together[t][v].get_stored_likelihoods() &&
+                        alone[t][v].coverage() == together[t][v].coverage() && alone[t][v].nr_unique_kmers() == together[t][v].nr_unique_kmers();
+            CHECK(same == alone[t].size());
+        }
+        CHECK(!errors[24].empty());
+        uint64_t st[3] = {0, 0, 0};
+        pg_hmm_coalesce_stats(st);
+        CHECK(st[2] >= 2);  // calls were merged
     });
     run("HMM phasing only (tests/HMMTest.cpp:392-438 without the likelihoods)", [] {
         auto u1 = bi(2000, {0, 1}); kmer(u1, 10, {0}); kmer(u1, 10, {1});
