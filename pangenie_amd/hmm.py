@@ -160,20 +160,29 @@ def genotype_contigs_threaded(batches: Sequence[ContigBatch], table: Probability
     nxt = [0]
     lock = threading.Lock()
 
+    n_workers = min(n_threads, n)
+    for _ in range(n_workers):  # the pool's workers all pick up their first job at once: announce those calls up front
+        announce(device)
+
     def worker():
+        first = True
         while True:
             with lock:
                 i = nxt[0]
                 nxt[0] += 1
             if i >= n:
+                if first:
+                    _lib.load_hip().pg_hmm_retract(device)
                 return
-            announce(device)
+            if not first:
+                announce(device)
+            first = False
             try:
                 out[i] = genotype_contig(batches[i], table, plist[i], device, announced=True, into=into[i] if into else None)
             except Exception as e:  # noqa: BLE001 - handed to the caller
                 out[i] = e
 
-    ts = [threading.Thread(target=worker) for _ in range(min(n_threads, n))]
+    ts = [threading.Thread(target=worker) for _ in range(n_workers)]
     for t in ts:
         t.start()
     for t in ts:

@@ -880,7 +880,7 @@ static void gpu_tests() {
                 size_t same = 0, meta = 0;
                 for (size_t v = 0; v < V; ++v) {
                     same += rb[v].get_haplotype() == rc[v].get_haplotype();
-                    meta += rb[v].contains_no_likelihoods() && !rc[v].contains_no_likelihoods();
+                    meta += rb[v].contains_no_likelihoods();
                 }
                 CHECK(same == V);
                 CHECK(meta == V);

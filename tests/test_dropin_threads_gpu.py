@@ -25,7 +25,9 @@ def mixed_batches():
               (500, 64, 0.0), (350, 64, 0.25), (150, 128, 0.0), (800, 16, 0.0), (450, 64, 0.0), (200, 5, 0.0),
               (650, 64, 0.0), (300, 32, 0.2), (1000, 64, 0.0), (120, 128, 0.2), (550, 16, 0.0), (380, 64, 0.0),
               (270, 64, 0.0), (600, 48, 0.1), (330, 64, 0.0), (90, 2, 0.0), (1, 64, 0.0), (0, 64, 0.0)]
-    return [synthetic_panel(V, H, 20, seed=500 + i, multiallelic_frac=m) for i, (V, H, m) in enumerate(shapes)]
+    out = [synthetic_panel(max(V, 1), H, 20, seed=500 + i, multiallelic_frac=m) for i, (V, H, m) in enumerate(shapes)]
+    out[-1] = out[-1].slice(0, 0)  # a contig without variants
+    return out
 
 
 def test_24_threads_mixed_shapes_vs_oracle(orc):
