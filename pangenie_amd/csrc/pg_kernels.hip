@@ -2067,26 +2067,11 @@ __global__ __launch_bounds__((ChainCfg<HP, R>::TT)) void k_sweep(const DevContig
 //    * row-allele selects by scalar-built lane masks (s_bfe_i64 of the row bits), stores with immediate
 //      offsets off two per-thread bases.
 // ------------------------------------------------------------------------------------------
-// timing experiments (tools/exp_lean.py): -DPG_LEANX=<mask> compiles one ingredient of the lean step out
-// (results are then WRONG; only the kernel time is of interest).  0 in the product.
-#ifndef PG_LEANX
-#define PG_LEANX 0
+// how many of a step's sixteen product-column multiplies are deferred into the next step (behind its second MFMA)
+#ifndef PG_LEAN_DEFER
+#define PG_LEAN_DEFER 8
 #endif
-static constexpr unsigned kLX = PG_LEANX;
-#ifndef PG_LEANV
-#define PG_LEANV 0
-#endif
-static constexpr unsigned kLV = PG_LEANV;  // codegen variants under test (tools/exp_lean.py)
-// -DPG_LEANPROF: time stamps (s_memtime, forward role, every wave; wave 0 reports) at the seams of the lean
-// step, accumulated per segment into DevContig::prof[32..47] — tooling only (tools/prof_lean.py); each stamp
-// drains the LDS queue, so overlapping segments are measured serialised.
-#ifdef PG_LEANPROF
-#define LEAN_STAMP(i) do { const unsigned long long now_ = __builtin_amdgcn_s_memtime(); acc_[i] += now_ - last_; last_ = now_; } while (0)
-#define LEAN_DEP(v) asm volatile("" :: "v"(v))
-#else
-#define LEAN_STAMP(i) do { } while (0)
-#define LEAN_DEP(v) do { } while (0)
-#endif
+static constexpr int kLeanDefer = PG_LEAN_DEFER;
 #define PG_LEAN_BLOCK 64  // column records per LDS block (one 16-byte piece per thread: 64 x 64 B = 256 x 16 B)
 template <int R>
 struct LeanShared {
@@ -2165,10 +2150,9 @@ struct ColScalars {
 };
 
 // The u_i of a wave's R = 16 rows without an LDS round trip: every lane also adds up the column sum of index
-// i0 + (lane & 15) (each 16-lane DPP row then holds the wave's sixteen row values) and one v_mov_b64_dpp
-// row_newbcast:k per row pulls value k into all lanes of every row (gfx90a+: the only DPP form 64-bit moves have).
-// Before: c1 C parked in a wave-private LDS row and read back as 8 broadcast ds_read_b128 — 8 KB of LDS reads per
-// wave and column for 128 bytes of information, and the four lock-stepped waves queue behind one LDS pipe.
+// i0 + (lane & 15) (each 16-lane DPP row then holds the wave's sixteen row values).  Round 2 pulled value k into all
+// lanes with one v_mov_b64_dpp row_newbcast:k per row and added it with a second instruction; DP-ALU DPP (gfx90a+:
+// row_newbcast is the one DPP control the 64-bit ALU operations take) does both in ONE: t = u[row lane k] + c.
 template <int K>
 DEVI double row_bcast_f64(double v) {
     // (old = the source itself: every lane has a valid source under row_newbcast, so no separate `old` register is set up)
@@ -2181,6 +2165,42 @@ DEVI void lean_u_rows(double urep, double (&ui)[R]) {
     ui[4] = row_bcast_f64<4>(urep);   ui[5] = row_bcast_f64<5>(urep);   ui[6] = row_bcast_f64<6>(urep);   ui[7] = row_bcast_f64<7>(urep);
     ui[8] = row_bcast_f64<8>(urep);   ui[9] = row_bcast_f64<9>(urep);   ui[10] = row_bcast_f64<10>(urep); ui[11] = row_bcast_f64<11>(urep);
     ui[12] = row_bcast_f64<12>(urep); ui[13] = row_bcast_f64<13>(urep); ui[14] = row_bcast_f64<14>(urep); ui[15] = row_bcast_f64<15>(urep);
+}
+// acc += u[lane (l & ~15) + K] * s.  DP-ALU DPP: of the 64-bit ALU operations only the VOP2 ones (v_fmac_f64) have a
+// DPP form, with row_newbcast as the one control.  The value `u` must come out of dpp_source() (a VALU result needs two
+// wait states before a DPP instruction may read it, and the compiler does not look inside an asm statement).
+template <int K>
+DEVI double fmac_row_bcast(double acc, double u, double s) {
+    asm("v_fmac_f64_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(u), "v"(s), "n"(K));
+    return acc;
+}
+// keeps the instruction that forms `v` where the source puts it (the compiler otherwise sinks work whose result is only
+// needed behind a branch into that branch's fall-through block — out of the MFMA shadow it was written to fill)
+DEVI void pin_here(double& v) { asm volatile("" : "+v"(v)); }
+DEVI void lean_fence() { __builtin_amdgcn_sched_barrier(0); }
+DEVI double dpp_source(double v) {
+    double r;
+    asm("v_mov_b64 %0, %1\n\ts_nop 1" : "=v"(r) : "v"(v));
+    return r;
+}
+// Row-allele selects of the lean step: bit K of the wave-uniform row bits as an all-lanes mask (ONE scalar instruction,
+// s_bfe_i64 with width 1 sign-extends the bit over the pair), consumed by v_cndmask_b32 as its mask operand — three
+// instructions per 64-bit select where bit test + mask + two selects took four.
+template <int K>
+DEVI unsigned long long row_mask64(unsigned long long bits /*uniform*/) {
+    unsigned long long m;
+    asm("s_bfe_i64 %0, %1, %2" : "=s"(m) : "s"(bits), "n"((1 << 16) | K) : "scc");
+    return m;
+}
+DEVI double sel_by_mask(double if0, double if1, unsigned long long m /*uniform: 0 or ~0*/) {
+    uint32_t lo, hi;
+    asm("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(lo) : "v"(__double2loint(if0)), "v"(__double2loint(if1)), "s"(m));
+    asm("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(hi) : "v"(__double2hiint(if0)), "v"(__double2hiint(if1)), "s"(m));
+    return __hiloint2double((int)hi, (int)lo);
+}
+template <int K, int N, class F>
+DEVI void static_for(F&& f) {
+    if constexpr (K < N) { f(std::integral_constant<int, K>{}); static_for<K + 1, N>(f); }
 }
 template <int R>
 DEVI double lean_colsum(const LeanShared<R>& sh, uint32_t pb, uint32_t lane) {
@@ -2296,58 +2316,51 @@ DEVI void lean_forward(const DevContig& dc, LeanShared<R>& sh, uint32_t C, uint3
         }
         sh.psum[(first - 1) & 1u][wave][lane] = part;
     }
-    FRec cur = read_frec(sh, 1);
-    lds_barrier();
-#ifdef PG_LEANPROF
-    unsigned long long acc_[8] = {0, 0, 0, 0, 0, 0, 0, 0}, last_ = __builtin_amdgcn_s_memtime();
-#endif
-    for (uint32_t t = first; t < hi; ++t) {
+    double ee[R], pp[R];  // emission factor and column entry of the last step: x = ee pp
+#pragma unroll
+    for (int k = 0; k < R; ++k) { ee[k] = 1.0; pp[k] = x[k]; }
+    // One column step.  `cur` = record of this step (constants of the gap t-1 -> t, emission of column t), `nxt` takes
+    // the record of the next step (four broadcast LDS reads, a whole step ahead of use); the loop calls the step twice
+    // with the two record variables in swapped roles, so no record is ever moved.
+    auto step = [&](uint32_t t, const FRec& cur, FRec& nxt) __attribute__((always_inline)) {
         const uint32_t n = t - first;                 // step number: reads the record with rel = n + 2
-        const FRec nxt = (kLX & 64u) ? cur : read_frec(sh, n + 2u);  // four broadcast LDS reads, a whole step ahead of use
+        nxt = read_frec(sh, n + 2u);
         if (((n + 4u) % PG_LEAN_BLOCK) == 0u) {       // (uniform) a few columns before the next block is needed
             const uint32_t blk = (n + 4u) / PG_LEAN_BLOCK;
             recs.park(sh, blk, piece);
             piece = recs.fetch(blk + 1u);
         }
         const uint32_t pb = (t - 1) & 1u;
-        const double Cj = (kLX & 8u) ? x[0] * 64.0 : lean_colsum<R>(sh, pb, lane);
-        LEAN_DEP(Cj); LEAN_STAMP(0);   // 0: record reads issued, column sums read and added
+        // both column sums' partials are fetched up front (this lane's column; the column of index i0 + (lane & 15):
+        // the DPP source of the wave's sixteen u_i); everything that does not need the total S — the second sum, the
+        // emission pair, the row bits — is issued between the two MFMAs of the total and fills their latency
+        double pc[64 / R], pr[64 / R];
+#pragma unroll
+        for (int q = 0; q < 64 / R; ++q) { pc[q] = sh.psum[pb][q][lane]; pr[q] = sh.psum[pb][q][i0 + (lane & 15u)]; }
+        const double Cj = (pc[0] + pc[1]) + (pc[2] + pc[3]);
+        const v4f64 zz = {0.0, 0.0, 0.0, 0.0};
+        const v4f64 ma = __builtin_amdgcn_mfma_f64_16x16x4f64(Cj, 1.0, zz, 0, 0, 0);
+        lean_fence();
         const double ucol = cur.c1 * Cj;
-        double ui[R];
-        v4f64 mfma_a = {0.0, 0.0, 0.0, 0.0};
-        bool mfma_split = false;  // (compile-time known on every path)
-        if (kLX & 4u) {
-#pragma unroll
-            for (int k = 0; k < R; ++k) ui[k] = ucol;
-        } else if constexpr (R == 16) {
-            // (the sixteen broadcasts fill the latency of the first MFMA of the total)
-            const double urep = cur.c1 * lean_colsum<R>(sh, pb, i0 + (lane & 15u));
-            const v4f64 zz = {0.0, 0.0, 0.0, 0.0};
-            mfma_a = __builtin_amdgcn_mfma_f64_16x16x4f64(Cj, 1.0, zz, 0, 0, 0);
-            __builtin_amdgcn_sched_barrier(0);
-            lean_u_rows<R>(urep, ui);
-            __builtin_amdgcn_sched_barrier(0);
-            mfma_split = true;
-        } else {
-            sh.u[wave][lane] = ucol;   // wave-private row: the u_i of this wave's rows come back as broadcasts
-            const double* row = &sh.u[wave][i0];
-#pragma unroll
-            for (int k = 0; k < R; ++k) ui[k] = row[k];
-        }
-        __builtin_amdgcn_sched_barrier(0);
-        LEAN_DEP(ui[R - 1]); LEAN_STAMP(1);   // 1: u round trip (serialised by the stamp)
-        double S;
-        if (mfma_split) {
-            const v4f64 zz = {0.0, 0.0, 0.0, 0.0};
-            const v4f64 b = __builtin_amdgcn_mfma_f64_16x16x4f64((mfma_a[0] + mfma_a[1]) + (mfma_a[2] + mfma_a[3]), 1.0, zz, 0, 0, 0);
-            S = b[0];
-        } else S = (kLX & 2u) ? Cj * 64.0 : wave_total_mfma(Cj);
-        LEAN_DEP(S); LEAN_STAMP(2);   // 2: MFMA total
+        const double urep = dpp_source(cur.c1 * ((pr[0] + pr[1]) + (pr[2] + pr[3])));
+        double eA, eB;
+        emis(cur, eA, eB);
+        const unsigned long long rbits = (unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(cur.bits1 >> i0));
+        const double msum = (ma[0] + ma[1]) + (ma[2] + ma[3]);
+        lean_fence();
+        const v4f64 mb = __builtin_amdgcn_mfma_f64_16x16x4f64(msum, 1.0, zz, 0, 0, 0);
+        // the product column of the PREVIOUS step is formed here, behind the second MFMA (kLeanDefer of the sixteen
+        // multiplies; the rest ran before the step's barrier, behind the LDS write of the partial sums)
+        lean_fence();
+        static_for<R - kLeanDefer, R>([&](auto kc) __attribute__((always_inline)) { constexpr int k = decltype(kc)::value; x[k] = ee[k] * pp[k]; pin_here(x[k]); });
+        pin_here(eA); pin_here(eB);
+        lean_fence();
+        double S = mb[0];
         double uj = fma(cur.c2, S, ucol);
         double c0 = cur.c0;
-        const bool s_zero = (kLV & 1u) ? (__builtin_amdgcn_readfirstlane(S > 0.0 ? 1 : 0) == 0) : !(S > 0.0);
-        if (__builtin_expect(s_zero, 0)) {
+        if (__builtin_expect(!(S > 0.0), 0)) {
             // column t-1 summed to zero: the uniform column takes its place (hmm.cpp:253-267), see forward_body
+            // (every x and with it every column sum is 0: the whole uniform step rides on u_j)
             flag_uniform(t - 1);
             const double Cu = 64.0 * unif;
             S = 1.0;
@@ -2358,39 +2371,35 @@ DEVI void lean_forward(const DevContig& dc, LeanShared<R>& sh, uint32_t C, uint3
         es = es < -900 ? -900 : es;
         const double m = ldexp(S, -es - PG_BIAS_F);
         const double sc = ldexp(1.0, -es), c0s = ldexp(c0, -es), ujs = ldexp(uj, -es);
-        double eA, eB;
-        emis(cur, eA, eB);
-        const uint32_t rb = (uint32_t)__builtin_amdgcn_readfirstlane((int)((uint32_t)(cur.bits1 >> i0) & RMASK));
         gdouble2* dst = (gdouble2*)(wr + (size_t)t * colsz) + toff;
         double part = 0.0, pprev = 0.0;
-        LEAN_DEP(ujs); LEAN_DEP(eA); LEAN_STAMP(3);   // 3: scale, constants, emission pair
-#pragma unroll
-        for (int k = 0; k < R; ++k) {
-            const double pk = (kLX & 16u) ? x[k] + ujs : fma(c0s, x[k], fma(ui[k], sc, ujs));
-            x[k] = (kLX & 16u) ? pk : pk * sel_by_bit(rb, k, eA, eB);
-            part += (kLX & 16u) ? (k == 0 ? x[0] + ui[k] : 0.0) : x[k];
-            if (k & 1) { if (!(kLX & 1u)) put_pair(dst, k >> 1, pprev, pk); __builtin_amdgcn_sched_barrier(0); }
+        static_for<0, R>([&](auto kc) __attribute__((always_inline)) {
+            constexpr int k = decltype(kc)::value;
+            const double pk = fmac_row_bcast<k>(fma(c0s, x[k], ujs), urep, sc);   // P'_t(i0 + k, lane) 2^-es = c0 x + u_j + u_i
+            const double ek = sel_by_mask(eA, eB, row_mask64<k>(rbits));
+            part = fma(ek, pk, part);
+            ee[k] = ek; pp[k] = pk;   // x = ek pk: formed below / in the next step
+            // (the fence keeps every pair's store where it is: eight 1 KB stores issued back to back stall the wave
+            // on the memory pipeline's queue — 787 instead of ~650 ns per column)
+            if constexpr (k & 1) { put_pair(dst, k >> 1, pprev, pk); __builtin_amdgcn_sched_barrier(0); }
             else pprev = pk;
-        }
-        LEAN_DEP(part); LEAN_STAMP(4);   // 4: the 16 states + their stores
+        });
         sh.psum[t & 1u][wave][lane] = part;
-        if (!(kLX & 128u)) {
-            if (kLV & 2u) {
-                fsc.put(lane, t, m);
-                if ((t & 63u) == 63u) { if (wave == 0) fsc.flush(fscale, lane, t); else fsc.valid = 0ull; }
-            } else if (wave == 0) {  // (scalar branch)
-                fsc.put(lane, t, m);
-                if ((t & 63u) == 63u) fsc.flush(fscale, lane, t);
-            }
+        if (wave == 0) {  // (scalar branch)
+            fsc.put(lane, t, m);
+            if ((t & 63u) == 63u) fsc.flush(fscale, lane, t);
         }
-        cur = nxt;
-        LEAN_STAMP(5);   // 5: partial sums parked, scalars collected
-        if (!(kLX & 32u)) lds_barrier();
-        LEAN_STAMP(6);   // 6: barrier
+        static_for<0, R - kLeanDefer>([&](auto kc) __attribute__((always_inline)) { constexpr int k = decltype(kc)::value; x[k] = ee[k] * pp[k]; });
+        lds_barrier();
+    };
+    FRec ra = read_frec(sh, 1), rb2;
+    lds_barrier();
+    uint32_t t = first;
+    for (; t + 1 < hi; t += 2) {
+        step(t, ra, rb2);
+        step(t + 1, rb2, ra);
     }
-#ifdef PG_LEANPROF
-    if (tid == 0) { for (int q = 0; q < 7; ++q) dc.prof[32 + q] = acc_[q]; dc.prof[39] = hi - first; }
-#endif
+    if (t < hi) step(t, ra, rb2);
     if (wave == 0 && fsc.valid) fsc.flush(fscale, lane, hi - 1);
     {   // the last column of this phase may itself have summed to zero
         const uint32_t pb = (hi - 1) & 1u;
@@ -2496,9 +2505,14 @@ DEVI void lean_backward(const DevContig& dc, LeanShared<R>& sh, uint32_t C, uint
         for (int k = 0; k < R; ++k) { w[k] = y[k] * sel_by_bit(rb, k, eA, eB); part += w[k]; }
         sh.psum[(uint32_t)t0 & 1u][wave][lane] = part;
     }
-    for (int64_t t = t0; t >= bot; --t) {
+    double ee[R], pp[R];  // (see lean_forward)
+#pragma unroll
+    for (int k = 0; k < R; ++k) { ee[k] = 1.0; pp[k] = w[k]; }
+    // One column step (see lean_forward): `cur` = record t+1 (constants of the gap t -> t+1), `nxt` takes record t
+    // (emission of column t: this step's w; constants of the next step).
+    auto step = [&](int64_t t, const FRec& cur, FRec& nxt) __attribute__((always_inline)) {
         const uint32_t n = (uint32_t)(t0 - t);        // step number: reads the record with rel = n + 1 (column t)
-        const FRec nxt = (kLX & 64u) ? cur : read_frec(sh, n + 1u);  // emission of column t (this step's w), constants of the next step
+        nxt = read_frec(sh, n + 1u);
         if (((n + 4u) % PG_LEAN_BLOCK) == 0u) {
             const uint32_t blk = (n + 4u) / PG_LEAN_BLOCK;
             recs.park(sh, blk, piece);
@@ -2507,78 +2521,71 @@ DEVI void lean_backward(const DevContig& dc, LeanShared<R>& sh, uint32_t C, uint
         int es = exponent_of(Sy) - PG_BIAS_B;
         es = es < -900 ? -900 : es;
         const double m = ldexp(Sy, -es - PG_BIAS_B);
-        if (!(kLX & 128u)) { if ((kLV & 2u) || wave == 0) bsc.put(lane, (uint64_t)t, m); }
-        const double k0 = ldexp(cur.c0, -es), k1 = ldexp(cur.c1, -es), k2 = ldexp(cur.c2, -es), kap = ldexp(cur.kappa, -es);
-        if (!(kLX & 32u)) lds_barrier();
+        if (wave == 1) bsc.put(lane, (uint64_t)t, m);   // (the per-column scalars are collected by two DIFFERENT waves: the waves meet
+                                                        // at a barrier every column, one wave's extra instructions are everybody's wait)
+        double k0 = ldexp(cur.c0, -es), k1 = ldexp(cur.c1, -es), k2 = ldexp(cur.c2, -es), kap = ldexp(cur.kappa, -es);
+        pin_here(k0); pin_here(k1); pin_here(k2); pin_here(kap);   // (in front of the barrier, not behind it)
+        lds_barrier();
         const uint32_t pb = (uint32_t)t & 1u;
-        const double Cj = (kLX & 8u) ? w[0] * 64.0 : lean_colsum<R>(sh, pb, lane);
+        double pc[64 / R], pr[64 / R];  // (see lean_forward)
+#pragma unroll
+        for (int q = 0; q < 64 / R; ++q) { pc[q] = sh.psum[pb][q][lane]; pr[q] = sh.psum[pb][q][i0 + (lane & 15u)]; }
+        const double Cj = (pc[0] + pc[1]) + (pc[2] + pc[3]);
+        const v4f64 zz = {0.0, 0.0, 0.0, 0.0};
+        const v4f64 ma = __builtin_amdgcn_mfma_f64_16x16x4f64(Cj, 1.0, zz, 0, 0, 0);
+        lean_fence();
         const double ucol = k1 * Cj;
-        double ui[R];
-        v4f64 mfma_a = {0.0, 0.0, 0.0, 0.0};
-        bool mfma_split = false;
-        if (kLX & 4u) {
-#pragma unroll
-            for (int k = 0; k < R; ++k) ui[k] = ucol;
-        } else if constexpr (R == 16) {
-            const double urep = k1 * lean_colsum<R>(sh, pb, i0 + (lane & 15u));
-            const v4f64 zz = {0.0, 0.0, 0.0, 0.0};
-            mfma_a = __builtin_amdgcn_mfma_f64_16x16x4f64(Cj, 1.0, zz, 0, 0, 0);
-            __builtin_amdgcn_sched_barrier(0);
-            lean_u_rows<R>(urep, ui);
-            __builtin_amdgcn_sched_barrier(0);
-            mfma_split = true;
-        } else {
-            sh.u[wave][lane] = ucol;
-            const double* row = &sh.u[wave][i0];
-#pragma unroll
-            for (int k = 0; k < R; ++k) ui[k] = row[k];
-        }
-        __builtin_amdgcn_sched_barrier(0);
-        double Sw;
-        if (mfma_split) {
-            const v4f64 zz = {0.0, 0.0, 0.0, 0.0};
-            const v4f64 b = __builtin_amdgcn_mfma_f64_16x16x4f64((mfma_a[0] + mfma_a[1]) + (mfma_a[2] + mfma_a[3]), 1.0, zz, 0, 0, 0);
-            Sw = b[0];
-        } else Sw = (kLX & 2u) ? Cj * 64.0 : wave_total_mfma(Cj);
+        const double urep = dpp_source(k1 * ((pr[0] + pr[1]) + (pr[2] + pr[3])));  // u_i of row i0 + (lane & 15)
+        double eA, eB, one;
+        emis(nxt, eA, eB);
+        asm("v_mov_b64 %0, 1.0" : "=v"(one));  // (a register: the DPP form takes no constant)
+        const unsigned long long rbits = (unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(nxt.bits1 >> i0));
+        const double msum = (ma[0] + ma[1]) + (ma[2] + ma[3]);
+        lean_fence();
+        const v4f64 mb = __builtin_amdgcn_mfma_f64_16x16x4f64(msum, 1.0, zz, 0, 0, 0);
+        lean_fence();
+        static_for<R - kLeanDefer, R>([&](auto kc) __attribute__((always_inline)) { constexpr int k = decltype(kc)::value; w[k] = ee[k] * pp[k]; pin_here(w[k]); });
+        pin_here(eA); pin_here(eB);
+        lean_fence();
+        const double Sw = mb[0];
         const double uj = fma(k2, Sw, ucol);
         const double Snew = kap * Sw;  // = sum(beta'_t)
-        double eA, eB;
-        emis(nxt, eA, eB);
-        const uint32_t rb = (uint32_t)__builtin_amdgcn_readfirstlane((int)((uint32_t)(nxt.bits1 >> i0) & RMASK));
         gdouble2* dst = (gdouble2*)(wr + (size_t)t * colsz) + toff;
-        double part = 0.0;
-        const bool b_zero = (kLV & 1u) ? (__builtin_amdgcn_readfirstlane(Snew > 0.0 ? 1 : 0) == 0) : !(Snew > 0.0);
-        if (__builtin_expect(b_zero, 0)) {
-            // beta~_t is all zero: its own posteriors are 0, the next step starts from the uniform column
-            double y[R];
+        double part = 0.0, yprev = 0.0;
+        static_for<0, R>([&](auto kc) __attribute__((always_inline)) {
+            constexpr int k = decltype(kc)::value;
+            const double yk = fmac_row_bcast<k>(fma(k0, w[k], uj), urep, one);  // beta'_t = k0 w + u_j + u_i
+            const double ek = sel_by_mask(eA, eB, row_mask64<k>(rbits));
+            part = fma(ek, yk, part);
+            ee[k] = ek; pp[k] = yk;   // w = ek yk: formed below / in the next step
+            if constexpr (k & 1) { put_pair(dst, k >> 1, yprev, yk); __builtin_amdgcn_sched_barrier(0); }
+            else yprev = yk;
+        });
+        if (__builtin_expect(!(Snew > 0.0), 0)) {
+            // beta~_t is all zero (a sum of non-negative terms: every y_k above IS 0, and so is what was stored): its own
+            // posteriors are 0, the next step starts from the uniform column (hmm.cpp:374-380)
+            part = 0.0;
 #pragma unroll
-            for (int k = 0; k < R; ++k) { y[k] = 0.0; w[k] = unif * sel_by_bit(rb, k, eA, eB); part += w[k]; }
-            store_col(t, y);
-        } else {
-            double yprev = 0.0;
-#pragma unroll
-            for (int k = 0; k < R; ++k) {
-                const double yk = (kLX & 16u) ? w[k] + uj : fma(k0, w[k], ui[k] + uj);  // beta'_t
-                w[k] = (kLX & 16u) ? yk : yk * sel_by_bit(rb, k, eA, eB);
-                part += (kLX & 16u) ? (k == 0 ? w[0] + ui[k] : 0.0) : w[k];
-                if (k & 1) { if (!(kLX & 1u)) put_pair(dst, k >> 1, yprev, yk); __builtin_amdgcn_sched_barrier(0); }
-                else yprev = yk;
-            }
+            for (int k = 0; k < R; ++k) { pp[k] = unif; part += unif * ee[k]; }
         }
         sh.psum[(uint32_t)(t - 1) & 1u][wave][lane] = part;
-        if (!(kLX & 128u)) {
-            if ((kLV & 2u) || wave == 0) {
-                bsm.put(lane, (uint64_t)t, Snew);
-                if (((uint64_t)t & 63u) == 0u) {
-                    if (wave == 0) { bsc.flush(bscale, lane, (uint64_t)t); bsm.flush(bsum, lane, (uint64_t)t); }
-                    else { bsc.valid = 0ull; bsm.valid = 0ull; }
-                }
-            }
+        if (wave == 2) bsm.put(lane, (uint64_t)t, Snew);
+        if (((uint64_t)t & 63u) == 0u) {
+            if (wave == 1) bsc.flush(bscale, lane, (uint64_t)t);
+            if (wave == 2) bsm.flush(bsum, lane, (uint64_t)t);
         }
         Sy = Snew > 0.0 ? Snew : 1.0;
-        cur = nxt;
+        static_for<0, R - kLeanDefer>([&](auto kc) __attribute__((always_inline)) { constexpr int k = decltype(kc)::value; w[k] = ee[k] * pp[k]; });
+    };
+    FRec rb2;
+    int64_t t = t0;
+    for (; t - 1 >= bot; t -= 2) {
+        step(t, cur, rb2);
+        step(t - 1, rb2, cur);
     }
-    if (wave == 0 && bsc.valid) { bsc.flush(bscale, lane, (uint64_t)bot); bsm.flush(bsum, lane, (uint64_t)bot); }
+    if (t >= bot) step(t, cur, rb2);
+    if (wave == 1 && bsc.valid) bsc.flush(bscale, lane, (uint64_t)bot);
+    if (wave == 2 && bsm.valid) bsm.flush(bsum, lane, (uint64_t)bot);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -2894,506 +2901,7 @@ void k_sweep_lean2(const DevContig* __restrict__ contigs) {
     else lean2_backward<R>(dc, sh, C);
 }
 
-// ------------------------------------------------------------------------------------------
-//  The PIPELINED lean step (round 2b; opt-in with PG_LEAN_PIPE=1 — correct, but measured slower than the plain
-//  step on MI355X, see the end of this comment).  The plain lean step above waits, every column, for the exchange of the
-//  column sums: partial sums -> LDS -> barrier -> LDS reads -> c1 C -> LDS -> 16 broadcast reads, plus the MFMA
-//  total — ~670 exposed wait cycles of 1580.  But the column sums of the NEXT product column follow in closed form
-//  from sums that are already known one step earlier:
-//      w_t = e_t (.) P'_t ,  P'_t = c0 w_{t-1} + u_i + u_j      (u_i = c1 C_i(w_{t-1}),  u_j = u_j + c2 S)
-//      C_j(w_t) = sum_i e_t(a_i, a_j) P'_t(i, j)
-//               = c0 G_j + (eA U0 + eB U1) + u_j (eA N0 + eB N1)
-//  with  G_j = sum_i e_t(a_i, a_j) w_{t-1}(i, j)   (the e_t-WEIGHTED column sums of the previous product column:
-//  accumulated by the fma that used to add up the plain sum — the emission factor of the next column is selected
-//  one step early and kept in registers, so no instruction is added per state),  (eA, eB) = e_t(0, a_j), e_t(1, a_j),
-//  U0/U1 = sums of u_i over the rows with allele 0/1 at column t,  N0/N1 = their numbers.  So the exchange of step
-//  t-1 (now of G) is consumed by step t only to prepare step t+1: the LDS round trips, the barrier skew and the two
-//  MFMA totals run in the shadow of the 16 states of step t, which need nothing but constants prepared a step
-//  earlier.  Exact zeros stay exact (every term carries the emission factor or an empty class sum), so the
-//  zero-column fall-back rules (hmm.cpp:253-267, :374-380) trigger on the same columns.
-//  MEASURED (tools/exp_lean.py, profiles/r02_lean_pipe.txt): 252 instructions per column instead of 215, waitcnt
-//  stalls down (563 -> 396 cycles) but instruction-issue stalls up (110 -> 593): the two extra fp64 MFMA totals
-//  cost ~77 cycles each during which the wave issues nothing (fp64 MFMA and fp64 VALU do not overlap), the 32
-//  broadcast LDS reads of four lock-stepped waves queue behind one LDS pipe (~256 cycles until the last wave has
-//  its 16 u_i), and the wait before the barrier now collects them.  855 ns per column against 655 ns.
-// ------------------------------------------------------------------------------------------
-struct LeanStep {       // what a step's 16 states need, prepared one step ahead (scaled by the column's 2^-es)
-    double c0s, ujs;    // c0 2^-es; (c2 S + c1 C_j) 2^-es, this lane's column
-    double U0s, U1s;    // class sums of the u_i (rows with allele 0 / 1 at the column these constants build)
-    double N0, N1;      // class sizes
-    double m;           // mantissa of the column sum: fscale / bscale
-    double Snew;        // backward: sum of beta'_t
-    bool zero;          // the column summed to zero: fall-back
-};
-DEVI void class_totals(double v, bool bit, double& t0, double& t1) {
-    t1 = wave_total_mfma(bit ? v : 0.0);
-    t0 = wave_total_mfma(bit ? 0.0 : v);
-}
-
-template <int PHASE, int R>
-DEVI void lean_forward_pipe(const DevContig& dc, LeanShared<R>& sh, uint32_t C, uint32_t chunk) {
-    constexpr int HP = 64;
-    constexpr uint32_t RMASK = (1u << R) - 1u;
-    const uint32_t mid = C / 2, K = dc.chunk_cols;
-    uint32_t lo = PHASE == 1 ? 0u : mid, hi = PHASE == 1 ? mid : C;
-    if constexpr (PHASE == 3) {
-        const unsigned long long l = (unsigned long long)mid + (unsigned long long)chunk * K;
-        if (l >= C) return;
-        lo = (uint32_t)l;
-        hi = C - lo > K ? lo + K : C;
-    }
-    if (lo >= hi) return;
-    const uint32_t first = lo == 0 ? 1u : lo;
-    const uint32_t tid = threadIdx.x, lane = tid & 63u;
-    const uint32_t wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const uint32_t i0 = wave * R;
-    const size_t colsz = (size_t)HP * HP;
-    const double unif = 1.0 / 4096.0;
-    LeanRecs recs{(const GAS char*)dc.frec, (int64_t)first - 1, (int64_t)C, +1, tid};
-    recs.park(sh, 0, recs.fetch(0));
-    v2f64 piece = recs.fetch(1);
-    lds_barrier();
-    gdouble* fwd = (gdouble*)dc.fwd;
-    gdouble* fscale = (gdouble*)dc.fscale;
-    gu8* fallback = (gu8*)dc.fwd_fallback;
-    gdouble* wr = fwd;
-    gcdouble* resume = (gcdouble*)(fwd + (size_t)(lo > 0 ? lo - 1 : 0) * colsz);
-    if constexpr (PHASE == 3) {
-        gdouble* scr = (gdouble*)dc.scratch;
-        wr = scr + (size_t)((chunk & 1u) * 2u) * K * colsz - (size_t)lo * colsz;
-        if (chunk > 0) resume = (gcdouble*)(scr + ((size_t)(((chunk - 1u) & 1u) * 2u) * K + (K - 1u)) * colsz);
-    }
-    const size_t toff = (size_t)(i0 >> 1) * HP + lane;
-    auto emis = [&](const FRec& r, double& eA, double& eB) {  // e(i, j) = row bit ? eB : eA for this lane's column allele
-        const bool aj = (r.bits1 >> lane) & 1ull;
-        eA = aj ? r.E01 : r.E00;
-        eB = aj ? r.E11 : r.E01;
-    };
-    auto rowbits = [&](const FRec& r) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)((uint32_t)(r.bits1 >> i0) & RMASK)); };
-    auto store_col = [&](uint32_t c, const double (&v)[R]) {
-        gdouble2* dst = (gdouble2*)(wr + (size_t)c * colsz) + toff;
-#pragma unroll
-        for (int k = 0; k < R; k += 2) dst[(size_t)(k >> 1) * HP] = v2f64{v[k], v[k + 1]};
-    };
-    auto flag_uniform = [&](uint32_t cprev) {
-        if (cprev >= lo) {
-            double xu[R];
-#pragma unroll
-            for (int k = 0; k < R; ++k) xu[k] = unif;
-            store_col(cprev, xu);
-        }
-        if (wave == 0) fallback[cprev] = 1;
-    };
-    // constants of the step that builds column c+1, from the column sums Cn of w_c (this lane's column) and the
-    // record of column c+1 (gap c -> c+1, alleles of column c+1); the u_i of this wave's rows go through its LDS row
-    auto prepare = [&](const FRec& r, double Cn, double (&uo)[R], LeanStep& k) {
-        const bool bj = (r.bits1 >> lane) & 1ull;
-        double UC0, UC1;
-        class_totals(Cn, bj, UC0, UC1);
-        double S = UC0 + UC1;
-        k.zero = !(S > 0.0);
-        double c0 = r.c0;
-        if (__builtin_expect(k.zero, 0)) { S = 1.0; c0 = 0.0; }  // the uniform column takes its place (hmm.cpp:253-267)
-        int es = exponent_of(S) - PG_BIAS_F;
-        es = es < -900 ? -900 : es;
-        k.m = ldexp(S, -es - PG_BIAS_F);
-        k.c0s = ldexp(c0, -es);
-        const double c1s = ldexp(r.c1, -es), c2s = ldexp(r.c2, -es);
-        const double ucol = c1s * Cn;
-        sh.u[wave][lane] = ucol;  // wave-private row: the u_i of this wave's rows come back as broadcasts
-        const double* row = &sh.u[wave][i0];
-#pragma unroll
-        for (int q = 0; q < R; ++q) uo[q] = row[q];
-        k.ujs = fma(c2s, S, ucol);
-        if (__builtin_expect(k.zero, 0)) k.ujs = ldexp(fma(r.c0, unif, fma(r.c2, 1.0, 2.0 * r.c1 * (64.0 * unif))), -es);
-        k.U0s = c1s * UC0;
-        k.U1s = c1s * UC1;
-        k.N1 = (double)__popcll(r.bits1);
-        k.N0 = 64.0 - k.N1;
-        k.Snew = 0.0;
-    };
-
-    ColScalars fsc;
-    double x[R], ecur[R], uis[R];
-    LeanStep ks;
-    FRec cur = read_frec(sh, 1);  // record of column `first`
-    FRec nxt = read_frec(sh, 2);  // record of column first+1 (records are read two steps ahead of their first use)
-    double eA, eB;                // this lane's emission pair at column `cur`
-    {
-        const FRec r0 = read_frec(sh, 0);
-        double e0A, e0B;
-        emis(r0, e0A, e0B);
-        const uint32_t rb0 = rowbits(r0);
-        if (lo == 0) {
-            const double P0 = ldexp(1.0, PG_BIAS_F);
-            double pz[R];
-#pragma unroll
-            for (int k = 0; k < R; ++k) { pz[k] = P0; x[k] = sel_by_bit(rb0, k, e0A, e0B) * P0; }
-            store_col(0, pz);
-            if (wave == 0) fscale[0] = 1.0;
-        } else {
-            gcdouble2* src = (gcdouble2*)resume + toff;
-#pragma unroll
-            for (int k = 0; k < R; k += 2) { const v2f64 t = src[(size_t)(k >> 1) * HP]; x[k] = t.x; x[k + 1] = t.y; }
-            if (!fallback[lo - 1]) {
-#pragma unroll
-                for (int k = 0; k < R; ++k) x[k] *= sel_by_bit(rb0, k, e0A, e0B);
-            }
-        }
-        emis(cur, eA, eB);
-        const uint32_t rbc = rowbits(cur);
-        double part = 0.0, G = 0.0;
-#pragma unroll
-        for (int k = 0; k < R; ++k) { ecur[k] = sel_by_bit(rbc, k, eA, eB); part += x[k]; G = fma(x[k], ecur[k], G); }
-        sh.psum[first & 1u][wave][lane] = part;       // plain sums of w_{first-1}: this launch's only direct exchange
-        sh.psum[(first - 1) & 1u][wave][lane] = G;    // e_first-weighted sums of w_{first-1}
-        lds_barrier();
-        const double Cj = lean_colsum<R>(sh, first & 1u, lane);
-        lds_barrier();  // the slot is rewritten at the end of step `first`
-        prepare(cur, Cj, uis, ks);
-    }
-#ifdef PG_LEANPROF
-    unsigned long long acc_[8] = {0, 0, 0, 0, 0, 0, 0, 0}, last_ = __builtin_amdgcn_s_memtime();
-#endif
-    for (uint32_t t = first; t < hi; ++t) {
-        const uint32_t n = t - first;
-        const FRec nx2 = (kLX & 64u) ? nxt : read_frec(sh, n + 3u);  // record of column t+2: first used a step from now
-        if (((n + 4u) % PG_LEAN_BLOCK) == 0u) {
-            const uint32_t blk = (n + 4u) / PG_LEAN_BLOCK;
-            recs.park(sh, blk, piece);
-            piece = recs.fetch(blk + 1u);
-        }
-        if (__builtin_expect(ks.zero, 0)) flag_uniform(t - 1);
-        // Two independent strands, interleaved by hand (the scheduler keeps them apart otherwise and every
-        // LDS / MFMA latency of strand A is then exposed):
-        //   A: column sums of w_t in closed form (from the exchange of the previous step) -> constants of step t+1
-        //   B: the 16 states of column t, which need nothing younger than a step
-        double eAn, eBn;
-        emis(nxt, eAn, eBn);
-        const uint32_t rbn = rowbits(nxt);
-        gdouble2* dst = (gdouble2*)(wr + (size_t)t * colsz) + toff;
-        double Gq[4] = {0.0, 0.0, 0.0, 0.0}, pprev = 0.0;
-        // (the empty asm pins the whole chunk — products, selects, its partial sum — in front of the next piece of
-        // strand A: left alone, everything not feeding a store sinks to the end of the step)
-#define PG_LEAN_STATES_F(K0)                                                          \
-        _Pragma("unroll") for (int k = (K0); k < (K0) + 4; ++k) {                     \
-            const double pk = fma(ks.c0s, x[k], uis[k] + ks.ujs);                     \
-            x[k] = pk * ecur[k];                                                      \
-            ecur[k] = sel_by_bit(rbn, k, eAn, eBn);                                   \
-            Gq[(K0) / 4] = fma(x[k], ecur[k], Gq[(K0) / 4]);                          \
-            if (k & 1) { dst[(size_t)(k >> 1) * HP] = v2f64{pprev, pk}; }             \
-            else pprev = pk;                                                          \
-        }                                                                             \
-        asm volatile("" :: "v"(Gq[(K0) / 4]));
-        const uint32_t pb = (t - 1) & 1u;
-        double g0 = sh.psum[pb][0][lane], g1 = sh.psum[pb][1][lane], g2 = sh.psum[pb][2][lane], g3 = sh.psum[pb][3][lane];
-        if (kLX & 8u) { g0 = x[0]; g1 = x[1]; g2 = x[2]; g3 = x[3]; }
-        __builtin_amdgcn_sched_barrier(0);
-        LEAN_STAMP(0);
-        PG_LEAN_STATES_F(0)
-        LEAN_DEP(x[3]); LEAN_STAMP(1);
-        __builtin_amdgcn_sched_barrier(0);
-        const double Gj = (g0 + g1) + (g2 + g3);
-        const double Cn = fma(ks.c0s, Gj, fma(ks.ujs, fma(eA, ks.N0, eB * ks.N1), fma(eA, ks.U0s, eB * ks.U1s)));
-        const bool bj = (nxt.bits1 >> lane) & 1ull;
-        const v4f64 zz = {0.0, 0.0, 0.0, 0.0};
-        const double cm1 = bj ? Cn : 0.0, cm0 = bj ? 0.0 : Cn;
-        const v4f64 a1 = (kLX & 2u) ? v4f64{cm1, cm1, cm1, cm1} : __builtin_amdgcn_mfma_f64_16x16x4f64(cm1, 1.0, zz, 0, 0, 0);
-        const v4f64 a0 = (kLX & (2u | 256u)) ? v4f64{cm0, cm0, cm0, cm0} : __builtin_amdgcn_mfma_f64_16x16x4f64(cm0, 1.0, zz, 0, 0, 0);
-        LEAN_STAMP(2);
-        __builtin_amdgcn_sched_barrier(0);
-        PG_LEAN_STATES_F(4)
-        LEAN_DEP(x[7]); LEAN_STAMP(3);
-        __builtin_amdgcn_sched_barrier(0);
-        const double s1_ = (a1[0] + a1[1]) + (a1[2] + a1[3]), s0_ = (a0[0] + a0[1]) + (a0[2] + a0[3]);
-        const v4f64 b1 = (kLX & 2u) ? v4f64{s1_, s1_, s1_, s1_} : __builtin_amdgcn_mfma_f64_16x16x4f64(s1_, 1.0, zz, 0, 0, 0);
-        const v4f64 b0 = (kLX & (2u | 256u)) ? v4f64{s0_, s0_, s0_, s0_} : __builtin_amdgcn_mfma_f64_16x16x4f64(s0_, 1.0, zz, 0, 0, 0);
-        LEAN_STAMP(4);
-        __builtin_amdgcn_sched_barrier(0);
-        PG_LEAN_STATES_F(8)
-        LEAN_DEP(x[11]); LEAN_STAMP(5);
-        __builtin_amdgcn_sched_barrier(0);
-        double uin[R];
-        LeanStep kn;
-        {
-            const double UC1 = b1[0], UC0 = b0[0];
-            double S = UC0 + UC1;
-            kn.zero = !(S > 0.0);
-            double c0 = nxt.c0;
-            if (__builtin_expect(kn.zero, 0)) { S = 1.0; c0 = 0.0; }  // the uniform column takes its place (hmm.cpp:253-267)
-            int es = exponent_of(S) - PG_BIAS_F;
-            es = es < -900 ? -900 : es;
-            kn.m = ldexp(S, -es - PG_BIAS_F);
-            kn.c0s = ldexp(c0, -es);
-            const double c1s = ldexp(nxt.c1, -es), c2s = ldexp(nxt.c2, -es);
-            const double ucol = c1s * Cn;
-            sh.u[wave][lane] = ucol;  // wave-private row: the u_i of this wave's rows come back as broadcasts
-            const double* row = &sh.u[wave][i0];
-#pragma unroll
-            for (int q = 0; q < R; ++q) uin[q] = (kLX & 4u) ? ucol : row[q];
-            kn.ujs = fma(c2s, S, ucol);
-            if (__builtin_expect(kn.zero, 0)) kn.ujs = ldexp(fma(nxt.c0, unif, fma(nxt.c2, 1.0, 2.0 * nxt.c1 * (64.0 * unif))), -es);
-            kn.U0s = c1s * UC0;
-            kn.U1s = c1s * UC1;
-            kn.N1 = (double)__popcll(nxt.bits1);
-            kn.N0 = 64.0 - kn.N1;
-            kn.Snew = 0.0;
-        }
-        LEAN_DEP(kn.ujs); LEAN_STAMP(6);
-        __builtin_amdgcn_sched_barrier(0);
-        PG_LEAN_STATES_F(12)
-        __builtin_amdgcn_sched_barrier(0);
-#undef PG_LEAN_STATES_F
-        sh.psum[t & 1u][wave][lane] = (Gq[0] + Gq[1]) + (Gq[2] + Gq[3]);
-        if (wave == 0) {  // (scalar branch)
-            fsc.put(lane, t, ks.m);
-            if ((t & 63u) == 63u) fsc.flush(fscale, lane, t);
-        }
-#pragma unroll
-        for (int k = 0; k < R; ++k) uis[k] = uin[k];
-        ks = kn;
-        eA = eAn; eB = eBn;
-        cur = nxt;
-        nxt = nx2;
-        if (!(kLX & 32u)) lds_barrier();
-        LEAN_STAMP(7);
-    }
-#ifdef PG_LEANPROF
-    if (tid == 0) { for (int q = 0; q < 8; ++q) dc.prof[32 + q] = acc_[q]; dc.prof[40] = hi - first; }
-#endif
-    if (wave == 0 && fsc.valid) fsc.flush(fscale, lane, hi - 1);
-    if (ks.zero) flag_uniform(hi - 1);  // the last column of this phase may itself have summed to zero
-}
-
-template <int PHASE, int R>
-DEVI void lean_backward_pipe(const DevContig& dc, LeanShared<R>& sh, uint32_t C, uint32_t chunk) {
-    constexpr int HP = 64;
-    constexpr uint32_t RMASK = (1u << R) - 1u;
-    const int64_t mid = C / 2, K = dc.chunk_cols;
-    int64_t top = PHASE == 1 ? (int64_t)C - 1 : mid - 1;
-    int64_t bot = PHASE == 1 ? mid : 0;
-    if constexpr (PHASE == 3) {
-        top = mid - 1 - (int64_t)chunk * K;
-        if (top < 0) return;
-        bot = top - K + 1 > 0 ? top - K + 1 : 0;
-    }
-    if (top < bot) return;
-    const int64_t t0 = PHASE == 1 ? top - 1 : top;
-    const uint32_t tid = threadIdx.x, lane = tid & 63u;
-    const uint32_t wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const uint32_t i0 = wave * R;
-    const size_t colsz = (size_t)HP * HP;
-    const double unif = 1.0 / 4096.0;
-    LeanRecs recs{(const GAS char*)dc.frec, t0 + 1, (int64_t)C, -1, tid};
-    recs.park(sh, 0, recs.fetch(0));
-    v2f64 piece = recs.fetch(1);
-    lds_barrier();
-    gdouble* cols = (gdouble*)dc.fwd;
-    gdouble* bscale = (gdouble*)dc.bscale;
-    gdouble* bsum = (gdouble*)dc.bsum;
-    gdouble* wr = cols;
-    gcdouble* resume = (gcdouble*)(cols + (size_t)(top + 1 < (int64_t)C ? top + 1 : top) * colsz);
-    if constexpr (PHASE == 3) {
-        gdouble* scr = (gdouble*)dc.scratch;
-        wr = scr + (size_t)((chunk & 1u) * 2u + 1u) * (size_t)K * colsz - (size_t)bot * colsz;
-        if (chunk > 0) resume = (gcdouble*)(scr + (size_t)(((chunk - 1u) & 1u) * 2u + 1u) * (size_t)K * colsz);
-    }
-    const size_t toff = (size_t)(i0 >> 1) * HP + lane;
-    auto emis = [&](const FRec& r, double& eA, double& eB) {
-        const bool aj = (r.bits1 >> lane) & 1ull;
-        eA = aj ? r.E01 : r.E00;
-        eB = aj ? r.E11 : r.E01;
-    };
-    auto rowbits = [&](const FRec& r) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)((uint32_t)(r.bits1 >> i0) & RMASK)); };
-    auto store_col = [&](int64_t c, const double (&v)[R]) {
-        gdouble2* dst = (gdouble2*)(wr + (size_t)c * colsz) + toff;
-#pragma unroll
-        for (int k = 0; k < R; k += 2) dst[(size_t)(k >> 1) * HP] = v2f64{v[k], v[k + 1]};
-    };
-    // constants of the step that builds beta'_t: gap record r (column t+1), Sy = sum of beta'_{t+1} (1 behind a zero
-    // column), Cn = column sums of the entering product column w = e_{t+1} (.) beta'_{t+1}, class bits = alleles of
-    // column t (the emission the new product column is weighted with)
-    auto prepare = [&](const FRec& r, double Sy, double Cn, unsigned long long cbits, double (&uo)[R], LeanStep& k) {
-        int es = exponent_of(Sy) - PG_BIAS_B;
-        es = es < -900 ? -900 : es;
-        k.m = ldexp(Sy, -es - PG_BIAS_B);
-        const double k1 = ldexp(r.c1, -es), k2 = ldexp(r.c2, -es), kap = ldexp(r.kappa, -es);
-        k.c0s = ldexp(r.c0, -es);
-        const double ucol = k1 * Cn;
-        sh.u[wave][lane] = ucol;
-        const double* row = &sh.u[wave][i0];
-#pragma unroll
-        for (int q = 0; q < R; ++q) uo[q] = row[q];
-        const bool bj = (cbits >> lane) & 1ull;
-        double UC0, UC1;
-        class_totals(Cn, bj, UC0, UC1);
-        const double Sw = UC0 + UC1;
-        k.ujs = fma(k2, Sw, ucol);
-        k.Snew = kap * Sw;  // = sum(beta'_t)
-        k.zero = !(k.Snew > 0.0);
-        k.U0s = k1 * UC0;
-        k.U1s = k1 * UC1;
-        k.N1 = (double)__popcll(cbits);
-        k.N0 = 64.0 - k.N1;
-        if (__builtin_expect(k.zero, 0)) {
-            // beta~_t is all zero: its own posteriors are 0, the next step starts from the uniform column (hmm.cpp:374-380)
-            k.c0s = 0.0; k.ujs = unif; k.U0s = 0.0; k.U1s = 0.0;
-#pragma unroll
-            for (int q = 0; q < R; ++q) uo[q] = 0.0;
-        }
-    };
-
-    ColScalars bsc, bsm;
-    double w[R], ecur[R], uis[R];
-    LeanStep ks;
-    FRec cur = read_frec(sh, 1);  // record of column t0: emission of column t0, constants of the gap t0-1 -> t0
-    FRec nxt = read_frec(sh, 2);  // record of column t0-1 (records are read two steps ahead of their first use)
-    double eA, eB;
-    {
-        const FRec r1 = read_frec(sh, 0);  // record t0+1: constants of the gap t0 -> t0+1, emission of column t0+1
-        double y[R], Sy;
-        if constexpr (PHASE == 1) {
-            const double B0 = ldexp(1.0, PG_BIAS_B);  // column C-1: beta~ = 1 (hmm.cpp:356-358), stored at the backward bias
-#pragma unroll
-            for (int k = 0; k < R; ++k) y[k] = B0;
-            Sy = 4096.0 * B0;
-            store_col(top, y);
-            if (wave == 0) { bscale[top] = 1.0; bsum[top] = Sy; }
-        } else {
-            gcdouble2* src = (gcdouble2*)resume + toff;
-#pragma unroll
-            for (int k = 0; k < R; k += 2) { const v2f64 t = src[(size_t)(k >> 1) * HP]; y[k] = t.x; y[k + 1] = t.y; }
-            Sy = bsum[top + 1];
-            if (!(Sy > 0.0)) {  // resuming behind an all-zero column: uniform (hmm.cpp:374-380)
-#pragma unroll
-                for (int k = 0; k < R; ++k) y[k] = unif;
-                Sy = 1.0;
-            }
-        }
-        double e1A, e1B;
-        emis(r1, e1A, e1B);
-        const uint32_t rb1 = rowbits(r1);
-        emis(cur, eA, eB);
-        const uint32_t rbc = rowbits(cur);
-        double part = 0.0, G = 0.0;
-#pragma unroll
-        for (int k = 0; k < R; ++k) {
-            w[k] = y[k] * sel_by_bit(rb1, k, e1A, e1B);
-            ecur[k] = sel_by_bit(rbc, k, eA, eB);
-            part += w[k];
-            G = fma(w[k], ecur[k], G);
-        }
-        sh.psum[(uint32_t)(t0 - 1) & 1u][wave][lane] = part;  // plain sums of the entering product column
-        sh.psum[(uint32_t)t0 & 1u][wave][lane] = G;            // e_t0-weighted sums
-        lds_barrier();
-        const double Cj = lean_colsum<R>(sh, (uint32_t)(t0 - 1) & 1u, lane);
-        lds_barrier();
-        prepare(r1, Sy, Cj, cur.bits1, uis, ks);
-    }
-    for (int64_t t = t0; t >= bot; --t) {
-        const uint32_t n = (uint32_t)(t0 - t);
-        const FRec nx2 = (kLX & 64u) ? nxt : read_frec(sh, n + 3u);  // record of column t-2: first used a step from now
-        if (((n + 4u) % PG_LEAN_BLOCK) == 0u) {
-            const uint32_t blk = (n + 4u) / PG_LEAN_BLOCK;
-            recs.park(sh, blk, piece);
-            piece = recs.fetch(blk + 1u);
-        }
-        // strands A (closed-form column sums of w_t = e_t (.) beta'_t -> constants of step t-1) and B (the 16 states of
-        // column t), interleaved by hand as in lean_forward_pipe
-        double eAn, eBn;
-        emis(nxt, eAn, eBn);
-        const uint32_t rbn = rowbits(nxt);
-        gdouble2* dst = (gdouble2*)(wr + (size_t)t * colsz) + toff;
-        double Gq[4] = {0.0, 0.0, 0.0, 0.0}, yprev = 0.0;
-#define PG_LEAN_STATES_B(K0)                                                          \
-        _Pragma("unroll") for (int k = (K0); k < (K0) + 4; ++k) {                     \
-            const double yk = fma(ks.c0s, w[k], uis[k] + ks.ujs);                     \
-            w[k] = yk * ecur[k];                                                      \
-            ecur[k] = sel_by_bit(rbn, k, eAn, eBn);                                   \
-            Gq[(K0) / 4] = fma(w[k], ecur[k], Gq[(K0) / 4]);                          \
-            if (k & 1) { dst[(size_t)(k >> 1) * HP] = v2f64{yprev, yk}; }             \
-            else yprev = yk;                                                          \
-        }                                                                             \
-        asm volatile("" :: "v"(Gq[(K0) / 4]));
-        const uint32_t pb = (uint32_t)t & 1u;
-        double g0 = sh.psum[pb][0][lane], g1 = sh.psum[pb][1][lane], g2 = sh.psum[pb][2][lane], g3 = sh.psum[pb][3][lane];
-        if (kLX & 8u) { g0 = w[0]; g1 = w[1]; g2 = w[2]; g3 = w[3]; }
-        __builtin_amdgcn_sched_barrier(0);
-        PG_LEAN_STATES_B(0)
-        __builtin_amdgcn_sched_barrier(0);
-        const double Gj = (g0 + g1) + (g2 + g3);
-        const double Cn = fma(ks.c0s, Gj, fma(ks.ujs, fma(eA, ks.N0, eB * ks.N1), fma(eA, ks.U0s, eB * ks.U1s)));
-        const bool bj = (nxt.bits1 >> lane) & 1ull;
-        const v4f64 zz = {0.0, 0.0, 0.0, 0.0};
-        const double cm1 = bj ? Cn : 0.0, cm0 = bj ? 0.0 : Cn;
-        const v4f64 a1 = (kLX & 2u) ? v4f64{cm1, cm1, cm1, cm1} : __builtin_amdgcn_mfma_f64_16x16x4f64(cm1, 1.0, zz, 0, 0, 0);
-        const v4f64 a0 = (kLX & (2u | 256u)) ? v4f64{cm0, cm0, cm0, cm0} : __builtin_amdgcn_mfma_f64_16x16x4f64(cm0, 1.0, zz, 0, 0, 0);
-        __builtin_amdgcn_sched_barrier(0);
-        PG_LEAN_STATES_B(4)
-        __builtin_amdgcn_sched_barrier(0);
-        const double s1_ = (a1[0] + a1[1]) + (a1[2] + a1[3]), s0_ = (a0[0] + a0[1]) + (a0[2] + a0[3]);
-        const v4f64 b1 = (kLX & 2u) ? v4f64{s1_, s1_, s1_, s1_} : __builtin_amdgcn_mfma_f64_16x16x4f64(s1_, 1.0, zz, 0, 0, 0);
-        const v4f64 b0 = (kLX & (2u | 256u)) ? v4f64{s0_, s0_, s0_, s0_} : __builtin_amdgcn_mfma_f64_16x16x4f64(s0_, 1.0, zz, 0, 0, 0);
-        __builtin_amdgcn_sched_barrier(0);
-        PG_LEAN_STATES_B(8)
-        __builtin_amdgcn_sched_barrier(0);
-        double uin[R];
-        LeanStep kn;
-        {
-            const double Sy = ks.Snew > 0.0 ? ks.Snew : 1.0;
-            int es = exponent_of(Sy) - PG_BIAS_B;
-            es = es < -900 ? -900 : es;
-            kn.m = ldexp(Sy, -es - PG_BIAS_B);
-            const double k1 = ldexp(cur.c1, -es), k2 = ldexp(cur.c2, -es), kap = ldexp(cur.kappa, -es);
-            kn.c0s = ldexp(cur.c0, -es);
-            const double ucol = k1 * Cn;
-            sh.u[wave][lane] = ucol;
-            const double* row = &sh.u[wave][i0];
-#pragma unroll
-            for (int q = 0; q < R; ++q) uin[q] = (kLX & 4u) ? ucol : row[q];
-            const double UC1 = b1[0], UC0 = b0[0];
-            const double Sw = UC0 + UC1;
-            kn.ujs = fma(k2, Sw, ucol);
-            kn.Snew = kap * Sw;  // = sum(beta'_{t-1})
-            kn.zero = !(kn.Snew > 0.0);
-            kn.U0s = k1 * UC0;
-            kn.U1s = k1 * UC1;
-            kn.N1 = (double)__popcll(nxt.bits1);
-            kn.N0 = 64.0 - kn.N1;
-            if (__builtin_expect(kn.zero, 0)) {
-                kn.c0s = 0.0; kn.ujs = unif; kn.U0s = 0.0; kn.U1s = 0.0;
-#pragma unroll
-                for (int q = 0; q < R; ++q) uin[q] = 0.0;
-            }
-        }
-        __builtin_amdgcn_sched_barrier(0);
-        PG_LEAN_STATES_B(12)
-        __builtin_amdgcn_sched_barrier(0);
-#undef PG_LEAN_STATES_B
-        if (__builtin_expect(ks.zero, 0)) {  // an all-zero beta~_t is stored as zeros (same thread, same addresses, later in program order)
-            double yz[R];
-#pragma unroll
-            for (int k = 0; k < R; ++k) yz[k] = 0.0;
-            store_col(t, yz);
-        }
-        sh.psum[(uint32_t)(t - 1) & 1u][wave][lane] = (Gq[0] + Gq[1]) + (Gq[2] + Gq[3]);
-        if (wave == 0) {
-            bsc.put(lane, (uint64_t)t, ks.m);
-            bsm.put(lane, (uint64_t)t, ks.Snew);
-            if (((uint64_t)t & 63u) == 0u) { bsc.flush(bscale, lane, (uint64_t)t); bsm.flush(bsum, lane, (uint64_t)t); }
-        }
-#pragma unroll
-        for (int k = 0; k < R; ++k) uis[k] = uin[k];
-        ks = kn;
-        eA = eAn; eB = eBn;
-        cur = nxt;
-        nxt = nx2;
-        if (!(kLX & 32u)) lds_barrier();
-    }
-    if (wave == 0 && bsc.valid) { bsc.flush(bscale, lane, (uint64_t)bot); bsm.flush(bsum, lane, (uint64_t)bot); }
-}
-
-template <int PHASE, int R, bool PIPE, bool TRI = false>
+template <int PHASE, int R, bool TRI = false>
 __global__ __launch_bounds__((64 * 64 / R)) void k_sweep_lean(const DevContig* __restrict__ contigs, uint32_t chunk) {
     __shared__ LeanShared<R> sh;
     const DevContig& dc = contigs[blockIdx.x];
@@ -3402,13 +2910,8 @@ __global__ __launch_bounds__((64 * 64 / R)) void k_sweep_lean(const DevContig* _
     const uint32_t C = (uint32_t)__builtin_amdgcn_readfirstlane((int)*dc.n_cols);
     if (C == 0) return;
     const unsigned long long t_begin = kChainProf ? __builtin_amdgcn_s_memtime() : 0ull;
-    if constexpr (PIPE) {
-        if (blockIdx.y == 0) lean_forward_pipe<PHASE, R>(dc, sh, C, chunk);
-        else lean_backward_pipe<PHASE, R>(dc, sh, C, chunk);
-    } else {
-        if (blockIdx.y == 0) lean_forward<PHASE, R, TRI>(dc, sh, C, chunk);
-        else lean_backward<PHASE, R, TRI>(dc, sh, C, chunk);
-    }
+    if (blockIdx.y == 0) lean_forward<PHASE, R, TRI>(dc, sh, C, chunk);
+    else lean_backward<PHASE, R, TRI>(dc, sh, C, chunk);
     if (kChainProf && threadIdx.x == 0) {  // -DPG_CHAIN_PROF builds only: cycles of this role's launch (last chunk wins)
         unsigned long long* o = dc.prof + (blockIdx.y == 0 ? 0 : 16) + (PHASE == 1 ? 0 : 8);
         o[0] = __builtin_amdgcn_s_memtime() - t_begin;
@@ -4150,15 +3653,8 @@ static void launch_sweep(const DevContig* d_contigs, uint32_t n_contigs, uint32_
     }
     if constexpr (PHASE != 2) {
         if (hp_mask & 64u) {  // bit 6: the job has lean chains (all-biallelic, H = HP = 64)
-            static const int lean_r = [] { const char* e = getenv("PG_LEAN_R"); return e ? atoi(e) : 16; }();
-            // PG_LEAN_PIPE=1: the pipelined lean step (closed-form column sums; measured SLOWER than the plain step,
-            // 855 vs 655 ns per column — DESIGN.md 4 — and kept as an independently derived cross-check)
-            const char* pipe_env = getenv("PG_LEAN_PIPE");  // (read per launch: tests switch it inside one process)
-            const int lean_pipe = pipe_env ? atoi(pipe_env) : 0;
-            if (lean_r == 8) hipLaunchKernelGGL((k_sweep_lean<PHASE, 8, false>), dim3(n_contigs, 2), dim3(512), 0, s, d_contigs, chunk);
-            else if (lean_pipe) hipLaunchKernelGGL((k_sweep_lean<PHASE, 16, true>), dim3(n_contigs, 2), dim3(256), 0, s, d_contigs, chunk);
-            else if (PHASE == 1 && (hp_mask & 128u))  // bit 7: fused job whose lean chains store triangles (DevContig::tri)
-                hipLaunchKernelGGL((k_sweep_lean<PHASE, 16, false, true>), dim3(n_contigs, 2), dim3(256), 0, s, d_contigs, chunk);
+            if (PHASE == 1 && (hp_mask & 128u))  // bit 7: fused job whose lean chains store triangles (DevContig::tri)
+                hipLaunchKernelGGL((k_sweep_lean<PHASE, 16, true>), dim3(n_contigs, 2), dim3(256), 0, s, d_contigs, chunk);
             else hipLaunchKernelGGL((k_sweep_lean<PHASE, 16, false>), dim3(n_contigs, 2), dim3(256), 0, s, d_contigs, chunk);
         }
         // bit 4: contigs with HP >= 256; bit 5: (forced) the generic kernel for every HP >= 64

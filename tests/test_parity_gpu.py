@@ -341,32 +341,6 @@ def test_lean_kernel_biallelic_h64_vs_oracle_and_general(K, orc, monkeypatch):
         assert float(np.where(den > 0, np.abs(a - c) / np.where(den > 0, den, 1), 0).max()) < 1e-11
 
 
-@pytest.mark.parametrize("K", [64, 997])
-def test_pipelined_lean_step_vs_oracle_and_plain(K, orc, monkeypatch):
-    """PG_LEAN_PIPE=1: the lean step with the column sums in closed form (the exchange off the critical path) — an
-    independently derived second implementation of the lean sweep (measured slower, kept as a cross-check).
-    Zero-sum columns on, before and behind chunk boundaries must take the same fall-backs."""
-    monkeypatch.setenv("PG_SWEEP_MODE", "chunked")
-    monkeypatch.setenv("PG_CHUNK_COLS", str(K))
-    for seed, reg in ((25, 0.0), (26, 0.01)):
-        args = (6, 108, 54, reg)
-        b = synthetic_panel(330, 64, 20, seed=seed)
-        if reg == 0.0:
-            b.kmer_count[::3] = 0
-            b.kmer_count[1::17] = 60000
-        t, p = hmm.ProbabilityTable(*args), hmm.make_params(1.26, False, 1e-5)
-        monkeypatch.setenv("PG_LEAN_PIPE", "1")
-        pipe = hmm.genotype_contig(b, t, p)
-        monkeypatch.delenv("PG_LEAN_PIPE", raising=False)
-        plain = hmm.genotype_contig(b, t, p)
-        ref = orc.genotype_contig(b, orc.OracleTable(*args), orc.make_params(1.26, False, 1e-5))
-        assert_parity(b, pipe, ref)
-        assert_parity(b, plain, ref)
-        a, c = pipe.likelihoods_ld(), plain.likelihoods_ld()
-        den = np.maximum(np.abs(a), np.abs(c))
-        assert float(np.where(den > 0, np.abs(a - c) / np.where(den > 0, den, 1), 0).max()) < 1e-11
-
-
 @pytest.mark.parametrize("lean2", ["1", "0"])
 @pytest.mark.parametrize("C_odd", [False, True])
 def test_triangle_storage_fused_lean_vs_oracle_and_full_columns(C_odd, lean2, orc, monkeypatch):
