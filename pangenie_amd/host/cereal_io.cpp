@@ -1,5 +1,6 @@
 // cereal_io.cpp — see cereal_io.hpp.
 #include "cereal_io.hpp"
+#include "archive_bytes.hpp"
 
 #include <cstring>
 #include <fstream>
@@ -8,48 +9,12 @@
 namespace pangenie {
 
 namespace {
-constexpr uint32_t MSB = 0x80000000u;
+constexpr uint32_t MSB = archive_bytes::MSB;
 const char* const kBi = "BiallelicUniqueKmers";
 const char* const kMulti = "MultiallelicUniqueKmers";
 
-struct Reader {
-    const unsigned char* p;
-    size_t n, o = 0;
-    template <class T>
-    T take() {
-        if (sizeof(T) > n - o) throw std::runtime_error("UniqueKmersMap archive: truncated");  // (o <= n always)
-        T v;
-        std::memcpy(&v, p + o, sizeof(T));
-        o += sizeof(T);
-        return v;
-    }
-    std::string str() {
-        const uint64_t len = take<uint64_t>();
-        if (len > n - o) throw std::runtime_error("UniqueKmersMap archive: truncated string");  // (no wrap for lengths near 2^64)
-        std::string s((const char*)p + o, (size_t)len);
-        o += (size_t)len;
-        return s;
-    }
-    /** an element count read from the archive: at most what the remaining bytes can hold at `min_bytes` each */
-    uint64_t count(size_t min_bytes) {
-        const uint64_t c = take<uint64_t>();
-        if (c > (n - o) / (min_bytes ? min_bytes : 1)) throw std::runtime_error("UniqueKmersMap archive: element count exceeds the data");
-        return c;
-    }
-};
-
-struct Writer {
-    std::vector<unsigned char> out;
-    template <class T>
-    void put(T v) {
-        const unsigned char* q = (const unsigned char*)&v;
-        out.insert(out.end(), q, q + sizeof(T));
-    }
-    void str(const std::string& s) {
-        put<uint64_t>(s.size());
-        out.insert(out.end(), s.begin(), s.end());
-    }
-};
+using archive_bytes::Reader;
+using archive_bytes::Writer;
 
 template <bool BI>
 std::shared_ptr<UniqueKmers> read_object(Reader& r) {

@@ -14,6 +14,8 @@
 #include <cstdlib>
 #include <cstring>
 #include <functional>
+#include <iomanip>
+#include <sstream>
 #include <memory>
 #include <stdexcept>
 #include <string>
@@ -22,6 +24,7 @@
 #include <vector>
 
 #include "../../pangenie_amd/host/cereal_io.hpp"
+#include "../../pangenie_amd/host/graph_io.hpp"
 #include "../../pangenie_amd/host/kmer_counts.hpp"
 #include "../../pangenie_amd/host/pangenie_host.hpp"
 
@@ -309,6 +312,114 @@ static void kmer_count_cpu_tests() {
             try { parse_kmer_line(bad, chrom, start, km, fl, header); } catch (const std::runtime_error&) { threw = true; }
             CHECK(threw);
         }
+    });
+}
+
+// What the reference's run_genotype_command does with a PanGenie-index prefix (src/commands.cpp:738-1050), on its own
+// fixture tests/data/index_* + region-reads.fa (tests/CommandsTest.cpp:18-37): index + graph archives, read k-mer counts
+// into the index, the HMM of every chromosome (on the device), normalised results, VCF lines.
+static std::vector<std::string> genotype_index_fixture(std::vector<GenotypingResult>* results_out = nullptr) {
+    UniqueKmersMap m = load_unique_kmers_map(g_golden_dir + "/index_UniqueKmersMap.cereal");
+    Graph graph = Graph::load(g_golden_dir + "/index_chr1_Graph.cereal");
+    ExactKmerCounter counts(g_golden_dir + "/region-reads.fa", m.kmersize);
+    const size_t kmer_abundance_peak = 18;   // tests/CommandsTest.cpp:56
+    fill_read_kmercounts("chr1", &m, counts, g_golden_dir + "/index_chr1_kmers.tsv.gz", kmer_abundance_peak);
+    ProbabilityTable probs(kmer_abundance_peak / 4, kmer_abundance_peak * 4, 2 * kmer_abundance_peak, 0.01L);
+    HMM hmm(&m.unique_kmers["chr1"], &probs, true, false, 1.26, false, 0.00001L, nullptr, false);   // src/commands.cpp:160
+    std::vector<GenotypingResult> results = hmm.move_genotyping_result();
+    for (auto& r : results) r.normalize();                                                           // :981-987
+    if (results_out) *results_out = results;
+    std::vector<std::string> lines = Graph::genotypes_header("sample");
+    for (const std::string& l : graph.genotypes_records(results)) lines.push_back(l);
+    return lines;
+}
+
+static void graph_cpu_tests() {
+    run("Graph archive: the reference's fixture parses and re-serialises byte for byte", [] {
+        // tests/data/index_chr1_Graph.cereal: what PanGenie-index wrote for tests/data/region.vcf + region.fa (k = 31, the
+        // reference added as a path) and run_genotype_command reads back (tests/CommandsTest.cpp:18-37)
+        const std::vector<unsigned char> raw = read_file(g_golden_dir + "/index_chr1_Graph.cereal");
+        CHECK(raw.size() == 3399);
+        Graph g = Graph::parse(raw);
+        CHECK(g.get_chromosome() == "chr1" && g.get_kmer_size() == 31 && g.reference_added() && g.size() == 2);
+        CHECK(g.serialize() == raw);
+        const Variant& a = g.get_variant(0);
+        const Variant& b = g.get_variant(1);
+        CHECK(a.get_start_position() == 138 && b.get_start_position() == 207 && a.get_end_position() == 139 && b.get_end_position() == 209);
+        CHECK(a.nr_of_alleles() == 44 && b.nr_of_alleles() == 45 && a.nr_of_paths() == 215 && !a.is_combined() && !b.is_combined());
+        // tests/data/region.vcf: chr1 139 T C and chr1 208 TG CG,CA; the bubble alleles carry 30 bases of flank either side
+        const std::string ref = g.reference("chr1");
+        CHECK(ref.size() == 301);
+        CHECK(a.get_allele_string(0) == ref.substr(138 - 30, 30 + 1 + 30));
+        CHECK(a.get_allele_string(0).substr(30, 1) == "T" && a.get_allele_string(1).substr(30, 1) == "C");
+        CHECK(b.get_allele_string(0).substr(30, 2) == "TG" && b.get_allele_string(1).substr(30, 2) == "CG" && b.get_allele_string(2).substr(30, 2) == "CA");
+        CHECK(!a.is_undefined_allele(0) && !a.is_undefined_allele(1) && a.is_undefined_allele(2) && a.is_undefined_allele(43));
+        CHECK(g.variant_ids().size() == 2 && g.variant_ids()[0].size() == 1 && g.variant_ids()[1].size() == 2);
+        bool threw = false;
+        try { std::vector<unsigned char> cut(raw.begin(), raw.begin() + 2000); Graph::parse(cut); } catch (const std::runtime_error&) { threw = true; }
+        CHECK(threw);
+    });
+    run("Variant: a combined bubble back into its records (tests/VariantTest.cpp:170-241)", [] {
+        // three records of chr2 merged into one bubble: A>T at 4, GAG>ACC at 7, G>GTC at 13; paths (0,0,0) (0,0,0) (1,1,1) (1,1,0)
+        Variant v = Variant::from_parts("chr2", 4, "ATGA", "GGAA", {{"A", "T"}, {"GAG", "ACC"}, {"G", "GTC"}}, {"CT", "ACT"},
+                                        {{0, 0, 0}, {1, 1, 0}, {1, 1, 1}}, {0, 0, 2, 1}, false);
+        CHECK(v.is_combined() && v.nr_of_alleles() == 3 && v.get_end_position() == 14);
+        CHECK(v.get_allele_string(0) == "ACTGAGACTG" && v.get_allele_string(2) == "TCTACCACTGTC");
+        GenotypingResult g;
+        g.add_to_likelihood(0, 0, 0.05); g.add_to_likelihood(0, 1, 0.05); g.add_to_likelihood(1, 1, 0.0);
+        g.add_to_likelihood(0, 2, 0.3); g.add_to_likelihood(1, 2, 0.5); g.add_to_likelihood(2, 2, 0.1);
+        g.add_first_haplotype_allele(0); g.add_second_haplotype_allele(2);
+        g.set_coverage(7); g.set_unique_kmers(14);
+        std::vector<VcfSite> sites = v.records(&g);
+        CHECK(sites.size() == 3);
+        const size_t starts[3] = {4, 7, 13};
+        const std::vector<std::vector<std::string>> alleles = {{"A", "T"}, {"GAG", "ACC"}, {"G", "GTC"}};
+        const std::vector<std::vector<unsigned short>> paths = {{0, 0, 1, 1}, {0, 0, 1, 1}, {0, 0, 1, 0}};
+        const double expected[3][3] = {{0.05, 0.35, 0.6}, {0.05, 0.35, 0.6}, {0.1, 0.8, 0.1}};
+        for (size_t i = 0; i < 3 && i < sites.size(); ++i) {
+            CHECK(sites[i].chromosome == "chr2" && sites[i].start == starts[i] && sites[i].alleles == alleles[i] && sites[i].paths == paths[i]);
+            std::vector<long double> got = sites[i].likelihoods.get_all_likelihoods(2);
+            CHECK(got.size() == 3 && close_all({(double)got[0], (double)got[1], (double)got[2]}, {expected[i][0], expected[i][1], expected[i][2]}));
+            CHECK(sites[i].likelihoods.get_haplotype() == std::make_pair((unsigned short)0, (unsigned short)1));
+            CHECK(sites[i].likelihoods.coverage() == 7 && sites[i].likelihoods.nr_unique_kmers() == 14);
+        }
+        CHECK(v.records(nullptr).size() == 3 && v.records(nullptr)[1].likelihoods.contains_no_likelihoods());
+    });
+    run("Graph::genotypes_records: the text of the records (src/graph.cpp:165-277)", [] {
+        Variant merged = Variant::from_parts("chr2", 4, "ATGA", "GGAA", {{"A", "T"}, {"GAG", "ACC"}, {"G", "GTC"}}, {"CT", "ACT"},
+                                             {{0, 0, 0}, {1, 1, 0}, {1, 1, 1}}, {0, 0, 2, 1}, true);
+        // a single record with an allele no path carries and an undefined one: dropped from ALT, counted in MA
+        Variant single = Variant::from_parts("chr2", 99, "AAAA", "CCCC", {{"C", "G", "CNN", "T"}}, {}, {{0}, {1}, {2}, {3}}, {0, 1, 1, 3}, true);
+        Graph graph = Graph::from_parts("chr2", 4, false, {merged, single}, {{"id-T"}, {}, {"id-GTC"}, {"id-G", "id-T2"}});
+        GenotypingResult g;
+        g.add_to_likelihood(0, 0, 0.05L); g.add_to_likelihood(0, 1, 0.05L); g.add_to_likelihood(1, 1, 0.0L);
+        g.add_to_likelihood(0, 2, 0.3L); g.add_to_likelihood(1, 2, 0.5L); g.add_to_likelihood(2, 2, 0.1L);
+        g.set_coverage(7); g.set_unique_kmers(14);
+        GenotypingResult empty;   // no likelihoods: 0/0 with probability 1 (src/graph.cpp:225-227)
+        empty.set_coverage(3);
+        std::vector<std::string> lines = graph.genotypes_records({g, empty});
+        CHECK(lines.size() == 4);
+        auto fields = [](const std::string& l) { std::vector<std::string> f; std::string t; std::istringstream is(l); while (std::getline(is, t, '\t')) f.push_back(t); return f; };
+        const std::vector<std::vector<std::string>> want = {
+            {"chr2", "5", ".", "A", "T", ".", "PASS", "AF=0.5;UK=14;MA=0;ID=id-T", "GT:GQ:GL:KC"},
+            {"chr2", "8", ".", "GAG", "ACC", ".", "PASS", "AF=0.5;UK=14;MA=0", "GT:GQ:GL:KC"},
+            {"chr2", "14", ".", "G", "GTC", ".", "PASS", "AF=0.25;UK=14;MA=0;ID=id-GTC", "GT:GQ:GL:KC"},
+            {"chr2", "100", ".", "C", "G,T", ".", "PASS", "AF=0.5,0.25;UK=0;MA=1;ID=id-G,id-T2", "GT:GQ:GL:KC"}};
+        for (size_t i = 0; i < 4 && i < lines.size(); ++i) {
+            std::vector<std::string> f = fields(lines[i]);
+            CHECK(f.size() == 10);
+            for (size_t k = 0; k < 9 && k < f.size(); ++k) { if (f[k] != want[i][k]) std::printf("  record %zu column %zu: %s\n", i, k, f[k].c_str()); CHECK(f[k] == want[i][k]); }
+        }
+        // the sample columns: record 0 = likelihoods (0.05, 0.35, 0.6) -> 1/1; the empty result -> 0/0 with GL 0,-inf,...
+        CHECK(fields(lines[0])[9] == "1/1:3:-1.301,-0.4559,-0.2218:7");
+        CHECK(fields(lines[2])[9] == "0/1:6:-1,-0.09691,-1:7");
+        CHECK(fields(lines[3])[9] == "0/0:10000:0,-inf,-inf,-inf,-inf,-inf:3");
+        std::vector<std::string> header = Graph::genotypes_header("HG0", "20250226");
+        CHECK(header.size() == 12 && header[0] == "##fileformat=VCFv4.2" && header[1] == "##fileDate=20250226");
+        CHECK(header[11] == "#CHROM\tPOS\tID\tREF\tALT\tQUAL\tFILTER\tINFO\tFORMAT\tHG0");
+        bool threw = false;
+        try { graph.genotypes_records({g}); } catch (const std::runtime_error&) { threw = true; }
+        CHECK(threw);
     });
 }
 
@@ -848,6 +959,37 @@ static void gpu_tests() {
         pg_hmm_coalesce_stats(st);
         CHECK(st[2] >= 2);  // calls were merged
     });
+    run("run_genotype_command on the reference's index fixture: the genotyped VCF (tests/CommandsTest.cpp:18-93)", [] {
+        std::vector<GenotypingResult> results;
+        const std::vector<std::string> lines = genotype_index_fixture(&results);
+        CHECK(lines.size() == 12 + 2 && results.size() == 2);
+        auto fields = [](const std::string& l) { std::vector<std::string> f; std::string t; std::istringstream is(l); while (std::getline(is, t, '\t')) f.push_back(t); return f; };
+        // the records of tests/data/region.vcf: chr1 139 T C and chr1 208 TG CG,CA with their ids; 42 of the 44 / 45 bubble
+        // alleles are undefined sequence (MA); allele frequencies over the 214 panel paths
+        Graph graph = Graph::load(g_golden_dir + "/index_chr1_Graph.cereal");
+        auto af = [&](size_t variant, unsigned short allele) {
+            float n = 0.0f;
+            for (size_t p = 0; p < 215; ++p) n += graph.get_variant(variant).get_allele_on_path(p) == allele ? 1.0f : 0.0f;
+            std::ostringstream os; os << std::setprecision(6) << n / 214u; return os.str();
+        };
+        const std::vector<std::string> a = fields(lines[12]), b = fields(lines[13]);
+        CHECK(a.size() == 10 && b.size() == 10);
+        const std::vector<std::string> want_a = {"chr1", "139", ".", "T", "C", ".", "PASS",
+            "AF=" + af(0, 1) + ";UK=62;MA=42;ID=chr1-49638-SNV->50027902>50027904>50027905-1", "GT:GQ:GL:KC"};
+        const std::vector<std::string> want_b = {"chr1", "208", ".", "TG", "CG,CA", ".", "PASS",
+            "AF=" + af(1, 1) + "," + af(1, 2) + ";UK=" + std::to_string(results[1].nr_unique_kmers()) +
+            ";MA=42;ID=chr1-49707-SNV->50027911>50027913>50027914-1,chr1-49707-COMPLEX->50027911>50027913>50027915>50027916-2", "GT:GQ:GL:KC"};
+        for (size_t k = 0; k < 9 && a.size() == 10 && b.size() == 10; ++k) {
+            if (a[k] != want_a[k]) std::printf("  record 0 column %zu: %s\n", k, a[k].c_str());
+            if (b[k] != want_b[k]) std::printf("  record 1 column %zu: %s\n", k, b[k].c_str());
+            CHECK(a[k] == want_a[k] && b[k] == want_b[k]);
+        }
+        // the sample columns as tests/CommandsTest.cpp:59-93 forms them from a directly constructed HMM
+        std::vector<std::vector<unsigned short>> defined = {{0, 1}, {0, 1, 2}};
+        CHECK(a.size() == 10 && a[9] == genotype_field(results[0], defined[0], 44));
+        CHECK(b.size() == 10 && b[9] == genotype_field(results[1], defined[1], 45));
+        CHECK(results[0].coverage() == 30 && results[1].coverage() == 34);
+    });
     run("HMM phasing only (tests/HMMTest.cpp:392-438 without the likelihoods)", [] {
         auto u1 = bi(2000, {0, 1}); kmer(u1, 10, {0}); kmer(u1, 10, {1});
         auto u2 = bi(3000, {0, 1});
@@ -896,10 +1038,17 @@ static void gpu_tests() {
 int main(int argc, char** argv) {
     const std::string mode = argc > 1 ? argv[1] : "cpu";
     if (argc > 2) g_golden_dir = argv[2];
-    if (mode == "cpu") { cpu_tests(); archive_cpu_tests(); kmer_count_cpu_tests(); sampler_cpu_tests(); }
+    if (mode == "cpu") { cpu_tests(); archive_cpu_tests(); graph_cpu_tests(); kmer_count_cpu_tests(); sampler_cpu_tests(); }
     else if (mode == "gpu") { gpu_tests(); sampler_gpu_tests(); }
     else if (mode == "dump-results" && argc >= 3) {  // the archive of sample_results() for the Python reader (tests/test_cereal_io.py)
         save_results(sample_results(), argv[2]);
+        return 0;
+    }
+    else if (mode == "write-vcf" && argc >= 4) {   // the genotyped VCF of the index fixture (tests/test_cereal_io.py compares it with the oracle)
+        std::FILE* f = std::fopen(argv[3], "w");
+        if (!f) return 2;
+        for (const std::string& l : genotype_index_fixture()) std::fprintf(f, "%s\n", l.c_str());
+        std::fclose(f);
         return 0;
     }
     else { std::printf("usage: test_host cpu|gpu\n"); return 2; }

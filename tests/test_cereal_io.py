@@ -97,3 +97,35 @@ def test_results_archive_cpp_writer_python_reader(tmp_path):
     assert (c.haplotype_1, c.haplotype_2, c.unique_kmers) == (5, 2, 301)
     assert res.runtimes == {"chr1": 1.5, "chr10": 0.125}
     assert cereal_io.dumps_results(res) == raw
+
+
+@pytest.mark.gpu
+def test_genotyped_vcf_of_the_index_fixture_vs_oracle(tmp_path):
+    """run_genotype_command on the reference's own index fixture (tests/CommandsTest.cpp:18-93), by the C++ host over
+    the device: index + Graph archives -> read k-mer counts -> HMM on the GPU -> Graph::genotypes_records.  The fixed
+    columns come from tests/data/region.vcf (what the graph was built from), the sample columns must be the ones the
+    CPU oracle gives on the reference's counted archive."""
+    import subprocess
+    from pangenie_amd.build import build_host, HOST_TEST
+    build_host()
+    out = tmp_path / "fixture_genotyping.vcf"
+    subprocess.run([str(HOST_TEST), "write-vcf", str(GOLDEN), str(out)], check=True)
+    lines = out.read_text().splitlines()
+    header, records = [l for l in lines if l.startswith("#")], [l.split("\t") for l in lines if not l.startswith("#")]
+    assert header[0] == "##fileformat=VCFv4.2" and header[1].startswith("##fileDate=20") and len(header) == 12
+    assert header[-1] == "#CHROM\tPOS\tID\tREF\tALT\tQUAL\tFILTER\tINFO\tFORMAT\tsample"
+    assert [r[:7] for r in records] == [["chr1", "139", ".", "T", "C", ".", "PASS"], ["chr1", "208", ".", "TG", "CG,CA", ".", "PASS"]]
+    assert all(r[8] == "GT:GQ:GL:KC" for r in records)
+    info = [dict(kv.split("=", 1) for kv in r[7].split(";")) for r in records]
+    assert [i["MA"] for i in info] == ["42", "42"] and info[0]["UK"] == "62"
+    assert info[0]["ID"] == "chr1-49638-SNV->50027902>50027904>50027905-1"
+    assert info[1]["ID"] == "chr1-49707-SNV->50027911>50027913>50027914-1,chr1-49707-COMPLEX->50027911>50027913>50027915>50027916-2"
+    uks = cereal_io.load(GOLDEN / "region_UniqueKmersList.cereal").unique_kmers["chr1"]
+    batch = flatten(uks)
+    # allele frequencies over the 214 panel paths (the reference path, index 0 of 215, left out)
+    pa = batch.path_allele.reshape(2, 215)
+    want_af = [["%.6g" % np.float32(np.float32((pa[0] == 1).sum()) / np.float32(214))],
+               ["%.6g" % np.float32(np.float32((pa[1] == a).sum()) / np.float32(214)) for a in (1, 2)]]
+    assert [i["AF"].split(",") for i in info] == want_af
+    _, want = oracle_fields(batch, uks, [[0, 1], [0, 1, 2]])
+    assert [r[9] for r in records] == want
