@@ -287,10 +287,33 @@ def main():
                     local[i] = (lik_t[off:off + n_lik[i]], exp_t[off:off + n_lik[i]])
                     off += n_lik[i]
 
+        # the ONE exchange of a sharded run: every rank's packed posteriors to rank 0.  Through the C ABI
+        # (pg_comm_init + pg_hmm_gather: grouped RCCL sends, the path a host without torch takes); if that cannot be
+        # set up on this node the torch.distributed form of the same exchange runs instead and the line says so.
+        per_rank = [int(sum(n_lik[i] for i in chains)) for chains in plan]
+        abi, gather_kind = None, "none (one GPU)"
+        if world > 1 or os.environ.get("PG_BENCH_FORCE_GATHER"):
+            from pangenie_amd.dist import AbiGather
+            try:
+                abi = AbiGather(rank, world, local_rank)
+                abi.gather(job, per_rank)
+                ok = 1.0
+            except Exception as e:  # noqa: BLE001
+                print(f"[rank {rank}] pg_hmm_gather unavailable ({e}); using the torch.distributed exchange", file=sys.stderr)
+                abi, ok = None, 0.0
+            if world > 1:  # every rank must take the same path
+                tt = torch.tensor([ok], dtype=torch.float64, device=dev)
+                dist.all_reduce(tt, op=dist.ReduceOp.MIN)
+                if float(tt.item()) < 1.0:
+                    abi = None
+            gather_kind = "pg_hmm_gather (C ABI: grouped ncclSend / ncclRecv)" if abi else "torch.distributed batch_isend_irecv"
+
         def step():
             if job:
                 job.run()
-            if world > 1:
+            if abi:
+                abi.gather(job, per_rank)
+            elif world > 1:
                 gather_posteriors(local, n_lik, plan, dst=0, unpack=False, device=dev)
 
         for _ in range(args.warmup):
@@ -322,7 +345,9 @@ def main():
                 job.upload()
                 job.run()
                 job.fetch_all(results)
-            if world > 1:
+            if abi:
+                abi.gather(job, per_rank)
+            elif world > 1:
                 gather_posteriors(local, n_lik, plan, dst=0, unpack=False, device=dev)
             fence()
             dt_e2e += max_over_ranks(time.perf_counter() - t0) / e2e_rounds
@@ -374,7 +399,8 @@ def main():
                                        f"(longest {max(sizes)}), seeds 12345+1000*chain; sharded over {world} GPU(s) by LPT",
                            "variants": V_total, "haplotypes": H, "kmers_per_variant": K, "chains": n_chains,
                            "chains_on_rank0": len(mine), "kept_columns_rank0": ncol, "workgroups_per_chain": 2,
-                           "parallelism": f"contig-sharded x{world}", "sweep_mode": "%s (chunk_cols=%d)" % (mode, chunk_cols)},
+                           "parallelism": f"contig-sharded x{world}", "sweep_mode": "%s (chunk_cols=%d)" % (mode, chunk_cols),
+                           "gather": gather_kind},
                 "roofline": roof, "kernel_ms": kms, "device_bytes": job_info["device_bytes"],
                 "alloc_s": hs["alloc_s"], "upload_s": hs["upload_s"],
             })

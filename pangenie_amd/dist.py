@@ -135,3 +135,61 @@ def gather_haplotypes(local: Dict[int, Tuple["np.ndarray", "np.ndarray"]], n_var
             res[i] = ((seg & 0xFFFF).astype(np.uint16), (seg >> 16).astype(np.uint16))
             off += n_variants[i]
     return res
+
+
+class AbiGather:
+    """The exchange behind the C ABI (include/pangenie_hmm.h: pg_comm_init + pg_hmm_gather — grouped RCCL point-to-point
+    sends, what a host without torch uses): rank 0 makes the RCCL id, the existing process group hands it round, every
+    rank opens its own communicator.  `world == 1`: a single-rank communicator (with PG_GATHER_LOOPBACK set the block still
+    travels through ncclSend / ncclRecv).
+
+        g = AbiGather(rank, world, device_index)      # collective: every rank
+        g.gather(job, n_lik_per_rank)                 # collective; rank 0 ends with g.lik_all / g.exp_all (torch, on device)
+    """
+
+    def __init__(self, rank: int, world: int, device: int):
+        import ctypes as C
+        import torch
+        from . import _lib
+        self._C, self._lib, self.rank, self.world, self.device = C, _lib.load_hip(), rank, world, device
+        ident = torch.zeros(128, dtype=torch.uint8)
+        err = C.create_string_buffer(512)
+        if rank == 0:
+            buf = (C.c_uint8 * 128)()
+            rc = self._lib.pg_comm_unique_id(buf, err, 512)
+            if rc:
+                raise RuntimeError(f"pg_comm_unique_id: {err.value.decode()} ({rc})")
+            ident = torch.tensor(list(buf), dtype=torch.uint8)
+        if world > 1:
+            import torch.distributed as dist
+            dev_ident = ident.to(torch.device("cuda", device))
+            dist.broadcast(dev_ident, src=0)
+            ident = dev_ident.cpu()
+        buf = (C.c_uint8 * 128)(*[int(x) for x in ident.tolist()])
+        h = C.c_void_p()
+        rc = self._lib.pg_comm_init(buf, world, rank, device, C.byref(h), err, 512)
+        if rc:
+            raise RuntimeError(f"pg_comm_init: {err.value.decode()} ({rc})")
+        self.h = h
+        self.lik_all = self.exp_all = None
+
+    def gather(self, job, n_lik_per_rank: Sequence[int], root: int = 0) -> None:
+        import torch
+        C = self._C
+        total = int(sum(n_lik_per_rank))
+        if self.rank == root and (self.lik_all is None or self.lik_all.numel() != total):
+            dev = torch.device("cuda", self.device)
+            self.lik_all = torch.empty(max(total, 1), dtype=torch.float64, device=dev)
+            self.exp_all = torch.empty(max(total, 1), dtype=torch.int32, device=dev)
+        plan = (C.c_uint64 * self.world)(*[int(x) for x in n_lik_per_rank])
+        err = C.create_string_buffer(512)
+        rc = self._lib.pg_hmm_gather(self.h, job.h if job is not None else None, root, plan,
+                                     C.c_void_p(self.lik_all.data_ptr()) if self.rank == root else None,
+                                     C.c_void_p(self.exp_all.data_ptr()) if self.rank == root else None, err, 512)
+        if rc:
+            raise RuntimeError(f"pg_hmm_gather: {err.value.decode()} ({rc})")
+
+    def close(self) -> None:
+        if getattr(self, "h", None):
+            self._lib.pg_comm_destroy(self.h)
+            self.h = None

@@ -525,6 +525,28 @@ def test_c_abi_gather_single_rank_rccl_loopback(monkeypatch):
     job.close()
 
 
+def test_abi_gather_helper_as_bench_uses_it(monkeypatch):
+    """pangenie_amd.dist.AbiGather (what `bench.py --gpus N` gathers with): a world-size-1 communicator made from an id,
+    the job's packed posteriors through ncclSend / ncclRecv into the root's buffers — with torch (and its own RCCL) in
+    the process."""
+    import torch
+    from pangenie_amd.dist import AbiGather
+    monkeypatch.setenv("PG_GATHER_LOOPBACK", "1")
+    batches = [synthetic_panel(250, 64, 20, seed=91), synthetic_panel(180, 16, 20, seed=92)]
+    job = hmm.Job(batches, hmm.ProbabilityTable(*default_table_args()), hmm.make_params(1.26, False, 1e-5))
+    job.run()
+    _, _, n = job.packed_results()
+    g = AbiGather(0, 1, 0)
+    g.gather(job, [n])
+    torch.cuda.synchronize()
+    want_l = np.concatenate([job.fetch(i).lik for i in range(2)])
+    want_e = np.concatenate([job.fetch(i).lik_exp for i in range(2)])
+    assert np.array_equal(g.lik_all.cpu().numpy()[:n], want_l) and np.array_equal(g.exp_all.cpu().numpy()[:n], want_e)
+    g.gather(job, [n])  # (buffers are reused)
+    g.close()
+    job.close()
+
+
 def _check_normalised(b, r):
     n = normalized_bins(b, r.likelihoods_ld())
     sums = np.add.reduceat(np.concatenate([n, np.zeros(1, n.dtype)]), b.geno_off[:-1].astype(np.int64))[:b.n_variants]
