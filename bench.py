@@ -52,6 +52,11 @@ WORKLOADS = {
     # 64 haplotypes.  164 GB of column slots: fits ONE 288 GB MI355X, so it is the single-GPU workload.
     "genome24_h64": dict(V=5_000_000, H=64, K=20, multi=0.0, chains=24, genome=True,
                          cfg="configs[3]: whole genome, 24 contigs (human chromosome length proportions), 5M variants, 64 haplotypes"),
+    # BASELINE.json configs[4]: the HPRC-style panel — 5M variants, 128 haplotypes, 20 % multiallelic — is an 8-GPU
+    # workload (656 GB of columns); on ONE GPU the bench runs the share rank 0 gets under `--gpus 8` (LPT over 8 ranks:
+    # ~625k variants, ~82 GB of columns), with --gpus N > 1 the whole panel sharded over the N ranks.
+    "hprc_h128": dict(V=5_000_000, H=128, K=20, multi=0.2, chains=24, genome=True, share_of=8,
+                      cfg="configs[4]: HPRC-style panel, 24 contigs, 5M variants, 128 haplotypes, 20% multiallelic"),
 }
 # the sampler measurement: contigs x variants x panel paths, 15 passes (the reference's default panel size)
 SAMPLER = {"contigs": 8, "V": 40_000, "H": 215, "size": 15}
@@ -264,6 +269,9 @@ def main():
         # chains are sharded over the ranks (every rank computes the same plan); chain i is the same
         # synthetic contig whatever the number of GPUs
         plan = assign_chains([float(s) * H * H for s in sizes], world)
+        if world == 1 and w.get("share_of"):  # one GPU's share of a workload that needs several: rank 0's chains of the share_of-rank plan
+            plan = [assign_chains([float(s) * H * H for s in sizes], int(w["share_of"]))[0]]
+            V_total = sum(sizes[i] for i in plan[0])
         mine = plan[rank]
         batches = [synthetic_panel(sizes[i], H, K, seed=12345 + 1000 * i, multiallelic_frac=w["multi"]) for i in mine]
         job = hmm.Job(batches, table, params, device=local_rank) if mine else None
@@ -395,8 +403,9 @@ def main():
                 "end_to_end": {"ms": dt_e2e * 1e3, "h2d_ms": hs2["upload_s"] * 1e3, "run_ms": hs2["run_s"] * 1e3, "d2h_ms": hs2["fetch_s"] * 1e3,
                                "h2d_bytes": sum(job_info["upload_bytes"].values()),
                                "note": "rank 0's share; arena resident (device allocation at job creation: alloc_s)"},
-                "config": {"workload": f"{args.workload}: {w['cfg']}; {V_total} variants x {H} haplotypes x {K} k-mers/variant in {n_chains} chain(s) "
-                                       f"(longest {max(sizes)}), seeds 12345+1000*chain; sharded over {world} GPU(s) by LPT",
+                "config": {"workload": f"{args.workload}: {w['cfg']}; {V_total} variants x {H} haplotypes x {K} k-mers/variant in {len(mine) if w.get('share_of') and world == 1 else n_chains} chain(s) "
+                                       f"(longest {max(sizes)}), seeds 12345+1000*chain; " +
+                                       (f"rank 0's share of the {w['share_of']}-GPU plan (LPT)" if w.get("share_of") and world == 1 else f"sharded over {world} GPU(s) by LPT"),
                            "variants": V_total, "haplotypes": H, "kmers_per_variant": K, "chains": n_chains,
                            "chains_on_rank0": len(mine), "kept_columns_rank0": ncol, "workgroups_per_chain": 2,
                            "parallelism": f"contig-sharded x{world}", "sweep_mode": "%s (chunk_cols=%d)" % (mode, chunk_cols),

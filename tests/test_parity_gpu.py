@@ -604,6 +604,41 @@ def test_config4_shape_h128_multiallelic(orc):
     assert_parity(sl, hmm.genotype_contig(sl, t, p), orc.genotype_contig(sl, orc.OracleTable(*args), orc.make_params(1.26, False, 1e-5)))
 
 
+def test_config4_one_gpu_share_full_size(orc):
+    """BASELINE.json configs[4] at ONE GPU's real size: the share rank 0 gets when the 24 contigs of the 5 M-variant,
+    128-haplotype, 20 %-multiallelic panel are spread over 8 GPUs by longest-processing-time-first (what
+    `bench.py --gpus 8 --workload hprc_h128` gives each rank): ~625 k variants, ~82 GB of columns, the large-arena
+    multi-chunk path at HP = 128 with wide and narrow multiallelic columns.  Size-independent properties on the full
+    job (determinism, normalised posteriors, every variant accounted for) + oracle parity of the same device path on
+    slices from the start, the middle and the end of its longest chain."""
+    from bench import genome_contig_sizes
+    from pangenie_amd.dist import assign_chains
+    sizes = genome_contig_sizes(5_000_000)
+    mine = assign_chains([float(v) * 128 * 128 for v in sizes], 8)[0]
+    assert 550_000 < sum(sizes[i] for i in mine) < 700_000
+    batches = [synthetic_panel(sizes[i], 128, 20, seed=12345 + 1000 * i, multiallelic_frac=0.2) for i in mine]
+    t = hmm.ProbabilityTable(*default_table_args())
+    p = hmm.make_params(1.26, False, 1e-5)
+    job = hmm.Job(batches, t, p)
+    assert job.device_bytes() > 80e9
+    job.run()
+    first = job.fetch_all()
+    job.run()
+    again = job.fetch_all()
+    job.close()
+    hmm._lib.load_hip().pg_hmm_release_cache()
+    for b, r1, r2 in zip(batches, first, again):
+        assert (r1.lik == r2.lik).all() and (r1.lik_exp == r2.lik_exp).all()
+        assert r2.n_columns == int(r2.kept.sum()) > 0.9 * b.n_variants
+        _check_normalised(b, r2)
+    args = default_table_args()
+    big = batches[0]
+    V = big.n_variants
+    for lo in (0, V // 2 - 150, V - 300):
+        sl = big.slice(lo, lo + 300)
+        assert_parity(sl, hmm.genotype_contig(sl, t, p), orc.genotype_contig(sl, orc.OracleTable(*args), orc.make_params(1.26, False, 1e-5)))
+
+
 def test_full_size_properties():
     """BASELINE.json configs[2] shape (200k variants x 64 haplotypes): size-independent checks.
     (a) determinism; (b) normalised posteriors sum to 1; (c) reversibility: the Li-Stephens
