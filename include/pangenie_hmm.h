@@ -164,6 +164,8 @@ int  pg_hmm_coalesce_stats(uint64_t out3[3]);
  *  concurrently (one persistent workgroup per chain direction).
  * ------------------------------------------------------------------ */
 typedef struct pg_job pg_job;
+/* (The six big arrays of a batch — kmer_count, allele_id, allele_flags, allele_kmer_off, allele_kmer_mask,
+ * path_allele — may also be DEVICE pointers of `device`; the offset arrays, positions and coverage are read on the host.) */
 pg_job* pg_job_create(int device, uint32_t n_contigs, const pg_contig_batch* batches,
                       const pg_table* table, const pg_hmm_params* params,
                       char* err, size_t errlen);
@@ -199,6 +201,16 @@ uint32_t pg_job_triangle_chains(const pg_job* job);
 /* Elapsed milliseconds of the Viterbi kernels (run_phasing) of the LAST pg_job_run, hipEvents on the launch stream. */
 double pg_job_viterbi_ms(const pg_job* job);
 void pg_job_destroy(pg_job* job);
+
+/* The inputs a job holds on the device: sizes of chain `contig`'s panel, and the arrays themselves back on the host
+ * (caller-allocated by those sizes; any pointer may be NULL).  For jobs whose panel was formed on the device
+ * (include/pangenie_sampler.h: pg_sampler_then_job) this is the only way to see it. */
+int  pg_job_panel_sizes(const pg_job* job, uint32_t contig, uint32_t* n_variants, uint32_t* n_paths,
+                        uint64_t* sum_kmers, uint64_t* sum_alleles);
+int  pg_job_fetch_panel(pg_job* job, uint32_t contig, uint32_t* kmer_off, uint16_t* kmer_count,
+                        uint32_t* allele_off, uint16_t* allele_id, uint8_t* allele_flags,
+                        uint16_t* allele_kmer_off, uint32_t* allele_kmer_mask, uint16_t* path_allele,
+                        char* err, size_t errlen);
 
 /* pg_job_create with an error code instead of a NULL: PG_ERR_INVALID (malformed batch),
  * PG_ERR_UNSUPPORTED (limits above), PG_ERR_NOMEM (device allocation), PG_ERR_DEVICE. */

@@ -49,6 +49,20 @@ int pg_sampler_run(const pg_contig_batch* panel, uint32_t size, double recombrat
 int pg_sampler_run_batch(const pg_contig_batch* panels, uint32_t n_contigs, uint32_t size, double recombrate,
                          long double effective_N, uint16_t allele_penalty, int device,
                          uint32_t* const* sampled_paths, uint32_t* const* best_scores, char* err, size_t errlen);
+/* Sampler -> UniqueKmers::update_paths -> genotyping job with the panel staying on the device (the reference's
+ * constructor tail, src/haplotypesampler.cpp:44, :296-309; src/biallelicuniquekmers.cpp:223-260,
+ * src/multiallelicuniquekmers.cpp:195-232, followed by run_genotyping on the sampled panel, src/commands.cpp:138-152):
+ * `size` passes over every contig of `panels`, then the panel reduced — on the GPU — to the sampled paths (+ the
+ * reference path 0 when add_reference), the alleles they carry and the k-mers on those alleles, and a resident job
+ * (include/pangenie_hmm.h: pg_job_run / pg_job_fetch) over the reduced panel: chain g = contig g, size (+ 1) paths.
+ * Only two counts per variant travel to the host (the job's memory is planned from them).  sampled_paths /
+ * best_scores as in pg_sampler_run_batch, or NULL.  The reduced panel (its allele ids give the genotype bins their
+ * meaning) is read back with pg_job_fetch_panel.  At most 1024 kept paths, 1024 alleles and 2048 k-mers per variant. */
+int pg_sampler_then_job(const pg_contig_batch* panels, uint32_t n_contigs, uint32_t size, int add_reference,
+                        double sampling_recombrate, long double sampling_effective_N, uint16_t allele_penalty,
+                        const pg_table* table, const pg_hmm_params* params, int device,
+                        uint32_t* const* sampled_paths, uint32_t* const* best_scores,
+                        pg_job** out_job, char* err, size_t errlen);
 /* Kernel milliseconds of the last pg_sampler_run[_batch] of the calling thread, summed over the passes:
  * [0] cost expansion, [1] forward passes, [2] backtraces; *kernel (may be NULL) = waves per workgroup of
  * the relative-value kernel, 0 when the general (saturating) kernel ran. */

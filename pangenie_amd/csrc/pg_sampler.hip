@@ -615,16 +615,36 @@ done:
     return rc;
 }
 
+namespace {
+// what pg_sampler_then_job keeps of a sampler run: the arena stays allocated (the caller frees it), and for every
+// contig with variants the device arrays the panel update reads
+struct SamplerKeep {
+    unsigned char* arena = nullptr;
+    struct Contig { uint32_t g; const uint32_t* allele_off; const uint16_t* allele_id; const uint16_t* path_allele; const uint32_t* paths; };
+    std::vector<Contig> contigs;
+};
+int sampler_run_core(const pg_contig_batch* panels, uint32_t n_contigs, uint32_t size, double recombrate,
+                     long double effective_N, uint16_t allele_penalty, int device, uint32_t* const* sampled_paths,
+                     uint32_t* const* best_scores, SamplerKeep* keep, char* err, size_t errlen);
+}  // namespace
+
 extern "C" int pg_sampler_run_batch(const pg_contig_batch* panels, uint32_t n_contigs, uint32_t size, double recombrate,
                                     long double effective_N, uint16_t allele_penalty, int device, uint32_t* const* sampled_paths,
                                     uint32_t* const* best_scores, char* err, size_t errlen) {
     if (!panels || !sampled_paths) { set_err(err, errlen, "null argument"); return PG_ERR_INVALID; }
+    return sampler_run_core(panels, n_contigs, size, recombrate, effective_N, allele_penalty, device, sampled_paths, best_scores, nullptr, err, errlen);
+}
+
+namespace {
+int sampler_run_core(const pg_contig_batch* panels, uint32_t n_contigs, uint32_t size, double recombrate,
+                     long double effective_N, uint16_t allele_penalty, int device, uint32_t* const* sampled_paths,
+                     uint32_t* const* best_scores, SamplerKeep* keep, char* err, size_t errlen) {
     if (size < 1 || n_contigs == 0) return PG_OK;  // reference src/haplotypesampler.cpp:28
     // contigs without variants have nothing to sample
     std::vector<uint32_t> live;
     for (uint32_t g = 0; g < n_contigs; ++g) {
         if (panels[g].n_variants == 0) continue;
-        if (!sampled_paths[g]) { set_err(err, errlen, "null output for contig %u", g); return PG_ERR_INVALID; }
+        if (!keep && !sampled_paths[g]) { set_err(err, errlen, "null output for contig %u", g); return PG_ERR_INVALID; }
         const int rc0 = check_panel(&panels[g], size, err, errlen);
         if (rc0 != PG_OK) return rc0;
         live.push_back(g);
@@ -760,16 +780,19 @@ extern "C" int pg_sampler_run_batch(const pg_contig_batch* panels, uint32_t n_co
     }
     for (uint32_t j = 0; j < n; ++j) {
         const size_t V = panels[live[j]].n_variants;
-        HIP_TRY(hipMemcpy(sampled_paths[live[j]], arena + offs[j].paths, (size_t)size * V * 4, hipMemcpyDeviceToHost));
+        if (sampled_paths && sampled_paths[live[j]]) HIP_TRY(hipMemcpy(sampled_paths[live[j]], arena + offs[j].paths, (size_t)size * V * 4, hipMemcpyDeviceToHost));
         if (best_scores && best_scores[live[j]]) HIP_TRY(hipMemcpy(best_scores[live[j]], arena + offs[j].best, (size_t)size * 4, hipMemcpyDeviceToHost));
+        if (keep) keep->contigs.push_back({live[j], devs[j].allele_off, devs[j].allele_id, devs[j].path_allele, devs[j].paths});
     }
     g_last_ms[0] = ms[0]; g_last_ms[1] = ms[1]; g_last_ms[2] = ms[2];
     g_last_kernel = fast ? (int)NW : 0;
+    if (keep) { keep->arena = arena; arena = nullptr; }
 done:
     for (auto& e : ev) if (e) hipEventDestroy(e);
     if (arena) hipFree(arena);
     return rc;
 }
+}  // namespace
 
 extern "C" int pg_sampler_run(const pg_contig_batch* b, uint32_t size, double recombrate, long double effective_N,
                               uint16_t allele_penalty, int device, uint32_t* sampled_paths, uint32_t* best_scores,
@@ -778,6 +801,247 @@ extern "C" int pg_sampler_run(const pg_contig_batch* b, uint32_t size, double re
     uint32_t* sp[1] = {sampled_paths};
     uint32_t* bs[1] = {best_scores};
     return pg_sampler_run_batch(b, 1, size, recombrate, effective_N, allele_penalty, device, sp, bs, err, errlen);
+}
+
+// ------------------------------------------------------------------------------------------------
+//  Sampler -> panel update -> genotyping job, the panel staying on the device.
+//
+//  The reference's constructor ends with UniqueKmers::update_paths on every variant (src/haplotypesampler.cpp:44,
+//  :296-309; src/biallelicuniquekmers.cpp:223-260, src/multiallelicuniquekmers.cpp:195-232): the panel keeps, at
+//  variant v, path j = sampled_paths[j][v] (+ the reference path 0 when add_reference), the alleles those paths carry,
+//  and the k-mers that lie on at least one kept allele — re-indexed in their old order, every allele's window starting
+//  at its first k-mer (src/kmerpath.cpp:13-17).  Here two kernels do that on the flat arrays, one wave per variant:
+//    ku_count  new path -> allele row (written at once: its place needs no scan), kept alleles / k-mers counted
+//    ku_write  compacted allele and k-mer arrays at the offsets the host formed from the counts
+//  Only the two counts per variant travel to the host (it plans the job's arena from them) and the offsets back.
+// ------------------------------------------------------------------------------------------------
+namespace {
+
+struct UpdateDev {
+    uint32_t V, P, S, size;            // S = kept paths = size (+ 1 with the reference path)
+    // old panel (device)
+    const uint32_t* kmer_off; const uint16_t* kmer_count; const uint32_t* allele_off; const uint16_t* allele_id;
+    const uint8_t* allele_flags; const uint16_t* allele_koff; const uint32_t* allele_kmask; const uint16_t* path_allele;
+    const uint32_t* paths;             // [size * V] sampled path of pass s at variant v
+    // new panel (device)
+    uint32_t* counts;                  // [2 V] kept alleles, kept k-mers of every variant
+    const uint32_t* new_koff; const uint32_t* new_aoff;   // [V + 1] (ku_write)
+    uint16_t* new_kcount; uint16_t* new_aid; uint8_t* new_aflags; uint16_t* new_akoff; uint32_t* new_akmask; uint16_t* new_pa;
+    uint32_t* err;
+};
+#define KU_MAX_PATHS 1024u   // kept paths staged in LDS per variant
+#define KU_MAX_KMERS 2048u   // k-mers of a variant whose new index is staged in LDS
+#define KU_MAX_ALLELES 1024u
+
+// which alleles / k-mers of variant v stay (shared by both kernels): kept alleles as a bitmap in LDS, kept k-mers as
+// flags; returns through LDS: row[S] new path alleles, aKeep[A] / kKeep[K] 0 / 1
+__device__ void ku_mark(const UpdateDev& d, uint32_t v, uint32_t lane, uint16_t* row, uint8_t* aKeep, uint8_t* kKeep) {
+    const uint32_t a0 = d.allele_off[v], A = d.allele_off[v + 1] - a0, k0 = d.kmer_off[v], K = d.kmer_off[v + 1] - k0;
+    for (uint32_t j = lane; j < d.S; j += 64u) {
+        const uint32_t path = j < d.size ? d.paths[(size_t)j * d.V + v] : 0u;   // (the reference path, src/haplotypesampler.cpp:44)
+        row[j] = d.path_allele[(size_t)v * d.P + path];
+    }
+    __builtin_amdgcn_wave_barrier();
+    for (uint32_t a = lane; a < A; a += 64u) {
+        const uint16_t id = d.allele_id[a0 + a];
+        uint8_t keep = 0;
+        for (uint32_t j = 0; j < d.S; ++j) keep |= row[j] == id ? 1 : 0;
+        aKeep[a] = keep;
+    }
+    __builtin_amdgcn_wave_barrier();
+    for (uint32_t k = lane; k < K; k += 64u) {
+        uint8_t keep = 0;
+        for (uint32_t a = 0; a < A; ++a) {
+            if (!aKeep[a]) continue;
+            const uint32_t off = d.allele_koff[a0 + a];
+            if (k >= off && k < off + 32u && ((d.allele_kmask[a0 + a] >> (k - off)) & 1u)) keep = 1;
+        }
+        kKeep[k] = keep;
+    }
+    __builtin_amdgcn_wave_barrier();
+}
+
+struct KuShared {
+    uint16_t row[4][KU_MAX_PATHS];
+    uint8_t aKeep[4][KU_MAX_ALLELES];
+    uint8_t kKeep[4][KU_MAX_KMERS];
+    uint16_t kNew[4][KU_MAX_KMERS];
+};
+
+__global__ __launch_bounds__(256) void ku_count(UpdateDev d) {
+    __shared__ KuShared sh;
+    const uint32_t w = threadIdx.x >> 6, lane = threadIdx.x & 63u, v = blockIdx.x * 4u + w;
+    if (v >= d.V) return;
+    const uint32_t A = d.allele_off[v + 1] - d.allele_off[v], K = d.kmer_off[v + 1] - d.kmer_off[v];
+    if (A > KU_MAX_ALLELES || K > KU_MAX_KMERS) { if (lane == 0) atomicOr(d.err, 1u); return; }
+    ku_mark(d, v, lane, sh.row[w], sh.aKeep[w], sh.kKeep[w]);
+    for (uint32_t j = lane; j < d.S; j += 64u) d.new_pa[(size_t)v * d.S + j] = sh.row[w][j];
+    uint32_t na = 0, nk = 0;
+    for (uint32_t a = lane; a < A; a += 64u) na += sh.aKeep[w][a];
+    for (uint32_t k = lane; k < K; k += 64u) nk += sh.kKeep[w][k];
+    for (int m = 32; m >= 1; m >>= 1) { na += __shfl_xor((int)na, m); nk += __shfl_xor((int)nk, m); }
+    if (lane == 0) { d.counts[2 * v] = na; d.counts[2 * v + 1] = nk; }
+}
+
+__global__ __launch_bounds__(256) void ku_write(UpdateDev d) {
+    __shared__ KuShared sh;
+    const uint32_t w = threadIdx.x >> 6, lane = threadIdx.x & 63u, v = blockIdx.x * 4u + w;
+    if (v >= d.V) return;
+    const uint32_t a0 = d.allele_off[v], A = d.allele_off[v + 1] - a0, k0 = d.kmer_off[v], K = d.kmer_off[v + 1] - k0;
+    if (A > KU_MAX_ALLELES || K > KU_MAX_KMERS) return;
+    ku_mark(d, v, lane, sh.row[w], sh.aKeep[w], sh.kKeep[w]);
+    // new index of every kept k-mer = its rank among the kept ones (old order), and the compacted counts
+    const uint32_t nk0 = d.new_koff[v];
+    uint32_t base = 0;
+    for (uint32_t kb = 0; kb < K; kb += 64u) {
+        const uint32_t k = kb + lane;
+        const bool keep = k < K && sh.kKeep[w][k];
+        const unsigned long long m = __ballot(keep);
+        const uint32_t rank = base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+        if (keep) { sh.kNew[w][k] = (uint16_t)rank; d.new_kcount[nk0 + rank] = d.kmer_count[k0 + k]; }
+        base += (uint32_t)__popcll(m);
+    }
+    __builtin_amdgcn_wave_barrier();
+    // kept alleles, in their old (= ascending id) order
+    const uint32_t na0 = d.new_aoff[v];
+    base = 0;
+    for (uint32_t ab = 0; ab < A; ab += 64u) {
+        const uint32_t a = ab + lane;
+        const bool keep = a < A && sh.aKeep[w][a];
+        const unsigned long long m = __ballot(keep);
+        const uint32_t rank = base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+        if (keep) {
+            const uint32_t off = d.allele_koff[a0 + a], mask = d.allele_kmask[a0 + a];
+            uint32_t first = 0xFFFFFFFFu, bits = 0;
+            for (uint32_t b = 0; b < 32u; ++b)   // (bits beyond the variant's k-mers do not exist)
+                if (((mask >> b) & 1u) && off + b < K) { const uint32_t n = sh.kNew[w][off + b]; first = n < first ? n : first; }
+            if (first != 0xFFFFFFFFu)
+                for (uint32_t b = 0; b < 32u; ++b)
+                    if (((mask >> b) & 1u) && off + b < K) {
+                        const uint32_t sft = sh.kNew[w][off + b] - first;
+                        if (sft >= 32u) atomicOr(d.err, 2u); else bits |= 1u << sft;
+                    }
+            d.new_aid[na0 + rank] = d.allele_id[a0 + a];
+            d.new_aflags[na0 + rank] = d.allele_flags[a0 + a];
+            d.new_akoff[na0 + rank] = (uint16_t)(first == 0xFFFFFFFFu ? 0u : first);
+            d.new_akmask[na0 + rank] = bits;
+        }
+        base += (uint32_t)__popcll(m);
+    }
+}
+
+}  // namespace
+
+extern "C" int pg_sampler_then_job(const pg_contig_batch* panels, uint32_t n_contigs, uint32_t size, int add_reference,
+                                   double sampling_recombrate, long double sampling_effective_N, uint16_t allele_penalty,
+                                   const pg_table* table, const pg_hmm_params* params, int device,
+                                   uint32_t* const* sampled_paths, uint32_t* const* best_scores,
+                                   pg_job** out_job, char* err, size_t errlen) {
+    if (!panels || !table || !params || !out_job || n_contigs == 0) { set_err(err, errlen, "null argument"); return PG_ERR_INVALID; }
+    *out_job = nullptr;
+    if (size < 1) { set_err(err, errlen, "pg_sampler_then_job: at least one pass"); return PG_ERR_INVALID; }
+    const uint32_t S = size + (add_reference ? 1u : 0u);
+    if (S > KU_MAX_PATHS) { set_err(err, errlen, "pg_sampler_then_job: at most %u kept paths", KU_MAX_PATHS); return PG_ERR_UNSUPPORTED; }
+    SamplerKeep keep;
+    int rc = sampler_run_core(panels, n_contigs, size, sampling_recombrate, sampling_effective_N, allele_penalty, device,
+                              sampled_paths, best_scores, &keep, err, errlen);
+    if (rc != PG_OK) return rc;
+    // the rest of the old panel (what the sampler itself did not need on the device) and room for the new one
+    struct Stage { size_t koff, kcnt, aflag, akoff, akmask, counts, nkoff, naoff, nkcnt, naid, naflag, nakoff, nakmask, npa; };
+    std::vector<Stage> st(n_contigs);
+    std::vector<int> keep_of(n_contigs, -1);
+    for (size_t j = 0; j < keep.contigs.size(); ++j) keep_of[keep.contigs[j].g] = (int)j;
+    size_t off = 0;
+    auto take = [&](size_t bytes) { off = (off + 255) / 256 * 256; size_t o = off; off += bytes ? bytes : 8; return o; };
+    for (uint32_t g = 0; g < n_contigs; ++g) {
+        const size_t V = panels[g].n_variants;
+        if (V == 0) continue;
+        const size_t sumK = panels[g].kmer_off[V], sumA = panels[g].allele_off[V];
+        Stage& t = st[g];
+        t.koff = take((V + 1) * 4); t.kcnt = take(sumK * 2); t.aflag = take(sumA); t.akoff = take(sumA * 2); t.akmask = take(sumA * 4);
+        t.counts = take(V * 8); t.nkoff = take((V + 1) * 4); t.naoff = take((V + 1) * 4);
+        t.nkcnt = take(sumK * 2); t.naid = take(sumA * 2); t.naflag = take(sumA); t.nakoff = take(sumA * 2); t.nakmask = take(sumA * 4);
+        t.npa = take(V * S * 2);
+    }
+    const size_t o_err = take(4);
+    unsigned char* stage = nullptr;
+    std::vector<std::vector<uint32_t>> nkoff(n_contigs), naoff(n_contigs);
+    std::vector<pg_contig_batch> nb(n_contigs);
+    uint32_t dev_err = 0;
+    HIP_TRY(hipSetDevice(device));
+    {
+        hipError_t he = hipMalloc((void**)&stage, off);
+        if (he != hipSuccess) { set_err(err, errlen, "hipMalloc(%zu bytes) failed: %s", off, hipGetErrorString(he)); rc = PG_ERR_NOMEM; goto done; }
+    }
+    HIP_TRY(hipMemset(stage + o_err, 0, 4));
+    for (int phase = 0; phase < 2; ++phase) {
+        for (uint32_t g = 0; g < n_contigs; ++g) {
+            const pg_contig_batch& b = panels[g];
+            const size_t V = b.n_variants;
+            if (V == 0) continue;
+            const size_t sumK = b.kmer_off[V], sumA = b.allele_off[V];
+            const Stage& t = st[g];
+            const SamplerKeep::Contig& kc = keep.contigs[(size_t)keep_of[g]];
+            UpdateDev d;
+            memset(&d, 0, sizeof(d));
+            d.V = (uint32_t)V; d.P = b.n_paths; d.S = S; d.size = size;
+            d.kmer_off = (const uint32_t*)(stage + t.koff); d.kmer_count = (const uint16_t*)(stage + t.kcnt);
+            d.allele_off = kc.allele_off; d.allele_id = kc.allele_id; d.path_allele = kc.path_allele; d.paths = kc.paths;
+            d.allele_flags = stage + t.aflag; d.allele_koff = (const uint16_t*)(stage + t.akoff); d.allele_kmask = (const uint32_t*)(stage + t.akmask);
+            d.counts = (uint32_t*)(stage + t.counts); d.new_koff = (const uint32_t*)(stage + t.nkoff); d.new_aoff = (const uint32_t*)(stage + t.naoff);
+            d.new_kcount = (uint16_t*)(stage + t.nkcnt); d.new_aid = (uint16_t*)(stage + t.naid); d.new_aflags = stage + t.naflag;
+            d.new_akoff = (uint16_t*)(stage + t.nakoff); d.new_akmask = (uint32_t*)(stage + t.nakmask); d.new_pa = (uint16_t*)(stage + t.npa);
+            d.err = (uint32_t*)(stage + o_err);
+            if (phase == 0) {
+                HIP_TRY(hipMemcpyAsync(stage + t.koff, b.kmer_off, (V + 1) * 4, hipMemcpyHostToDevice, nullptr));
+                if (sumK) HIP_TRY(hipMemcpyAsync(stage + t.kcnt, b.kmer_count, sumK * 2, hipMemcpyHostToDevice, nullptr));
+                HIP_TRY(hipMemcpyAsync(stage + t.aflag, b.allele_flags, sumA, hipMemcpyHostToDevice, nullptr));
+                HIP_TRY(hipMemcpyAsync(stage + t.akoff, b.allele_kmer_off, sumA * 2, hipMemcpyHostToDevice, nullptr));
+                HIP_TRY(hipMemcpyAsync(stage + t.akmask, b.allele_kmer_mask, sumA * 4, hipMemcpyHostToDevice, nullptr));
+                hipLaunchKernelGGL(ku_count, dim3((uint32_t)((V + 3) / 4)), dim3(256), 0, nullptr, d);
+                HIP_TRY(hipGetLastError());
+            } else {
+                hipLaunchKernelGGL(ku_write, dim3((uint32_t)((V + 3) / 4)), dim3(256), 0, nullptr, d);
+                HIP_TRY(hipGetLastError());
+            }
+        }
+        HIP_TRY(hipStreamSynchronize(nullptr));
+        if (phase == 0) {
+            HIP_TRY(hipMemcpy(&dev_err, stage + o_err, 4, hipMemcpyDeviceToHost));
+            if (dev_err & 1u) { set_err(err, errlen, "pg_sampler_then_job: a variant has more than %u alleles or %u k-mers", KU_MAX_ALLELES, KU_MAX_KMERS); rc = PG_ERR_UNSUPPORTED; goto done; }
+            // the counts -> offsets (host: the job's arena is planned from them), and back
+            for (uint32_t g = 0; g < n_contigs; ++g) {
+                const size_t V = panels[g].n_variants;
+                nkoff[g].assign(V + 1, 0); naoff[g].assign(V + 1, 0);
+                if (V == 0) continue;
+                std::vector<uint32_t> counts(2 * V);
+                HIP_TRY(hipMemcpy(counts.data(), stage + st[g].counts, V * 8, hipMemcpyDeviceToHost));
+                for (size_t v = 0; v < V; ++v) { naoff[g][v + 1] = naoff[g][v] + counts[2 * v]; nkoff[g][v + 1] = nkoff[g][v] + counts[2 * v + 1]; }
+                HIP_TRY(hipMemcpy(stage + st[g].nkoff, nkoff[g].data(), (V + 1) * 4, hipMemcpyHostToDevice));
+                HIP_TRY(hipMemcpy(stage + st[g].naoff, naoff[g].data(), (V + 1) * 4, hipMemcpyHostToDevice));
+            }
+        }
+    }
+    HIP_TRY(hipMemcpy(&dev_err, stage + o_err, 4, hipMemcpyDeviceToHost));
+    if (dev_err & 2u) { set_err(err, errlen, "pg_sampler_then_job: an allele's k-mers span more than 32 positions after the update"); rc = PG_ERR_INVALID; goto done; }
+    // the job over the updated panel: offsets, positions and coverage from the host, the six big arrays from the device
+    for (uint32_t g = 0; g < n_contigs; ++g) {
+        const pg_contig_batch& b = panels[g];
+        pg_contig_batch& q = nb[g];
+        q = b;
+        if (b.n_variants == 0) continue;
+        const Stage& t = st[g];
+        q.n_paths = S;
+        q.kmer_off = nkoff[g].data(); q.allele_off = naoff[g].data();
+        q.kmer_count = (const uint16_t*)(stage + t.nkcnt); q.allele_id = (const uint16_t*)(stage + t.naid); q.allele_flags = stage + t.naflag;
+        q.allele_kmer_off = (const uint16_t*)(stage + t.nakoff); q.allele_kmer_mask = (const uint32_t*)(stage + t.nakmask);
+        q.path_allele = (const uint16_t*)(stage + t.npa);
+    }
+    rc = pg_job_new(device, n_contigs, nb.data(), table, params, out_job, err, errlen);
+done:
+    if (stage) hipFree(stage);
+    if (keep.arena) hipFree(keep.arena);
+    return rc;
 }
 
 extern "C" int pg_sampler_last_ms(double out3[3], int* kernel) {

@@ -414,7 +414,7 @@ int upload_inputs(pg_job* job, const pg_contig_batch* batches, const std::vector
 #define UP(off, src, bytes, acc)                                                                              \
     do {                                                                                                      \
         if ((bytes) > 0) {                                                                                    \
-            HIP_TRY(hipMemcpyAsync((void*)(A + (off)), (src), (bytes), hipMemcpyHostToDevice, s));            \
+            HIP_TRY(hipMemcpyAsync((void*)(A + (off)), (src), (bytes), hipMemcpyDefault, s));  /* (host or device source) */ \
             acc += (uint64_t)(bytes);                                                                         \
         }                                                                                                     \
     } while (0)
@@ -1046,6 +1046,36 @@ extern "C" int pg_job_fetch_all(pg_job* job, pg_contig_result* outs, char* err, 
     }
     HIP_TRY(hipStreamSynchronize(s));
     job->host_s[3] += now_s() - t0;
+    return PG_OK;
+}
+
+// The inputs a job holds on the device, back on the host (the panel of a job made by pg_sampler_then_job never was there).
+extern "C" int pg_job_panel_sizes(const pg_job* job, uint32_t ci, uint32_t* n_variants, uint32_t* n_paths, uint64_t* sum_kmers, uint64_t* sum_alleles) {
+    if (!job || ci >= job->chains.size()) return PG_ERR_INVALID;
+    const IndexHost& x = job->index[job->chains[ci].index];
+    if (n_variants) *n_variants = x.V;
+    if (n_paths) *n_paths = x.H;
+    if (sum_kmers) *sum_kmers = x.sumK;
+    if (sum_alleles) *sum_alleles = x.sumA;
+    return PG_OK;
+}
+extern "C" int pg_job_fetch_panel(pg_job* job, uint32_t ci, uint32_t* kmer_off, uint16_t* kmer_count, uint32_t* allele_off, uint16_t* allele_id,
+                                  uint8_t* allele_flags, uint16_t* allele_kmer_off, uint32_t* allele_kmer_mask, uint16_t* path_allele,
+                                  char* err, size_t errlen) {
+    if (!job || ci >= job->chains.size()) { set_err(err, errlen, "bad argument"); return PG_ERR_INVALID; }
+    HIP_TRY(hipSetDevice(job->device));
+    const ChainHost& c = job->chains[ci];
+    const IndexHost& x = job->index[c.index];
+    if (x.V == 0) return PG_OK;
+    const unsigned char* A = job->arena;
+    if (kmer_off) HIP_TRY(hipMemcpy(kmer_off, A + x.o_koff, ((size_t)x.V + 1) * 4, hipMemcpyDeviceToHost));
+    if (kmer_count && x.sumK) HIP_TRY(hipMemcpy(kmer_count, A + c.o_kcnt, (size_t)x.sumK * 2, hipMemcpyDeviceToHost));
+    if (allele_off) HIP_TRY(hipMemcpy(allele_off, A + x.o_aoff, ((size_t)x.V + 1) * 4, hipMemcpyDeviceToHost));
+    if (allele_id) HIP_TRY(hipMemcpy(allele_id, A + x.o_aid, (size_t)x.sumA * 2, hipMemcpyDeviceToHost));
+    if (allele_flags) HIP_TRY(hipMemcpy(allele_flags, A + x.o_aflag, (size_t)x.sumA, hipMemcpyDeviceToHost));
+    if (allele_kmer_off) HIP_TRY(hipMemcpy(allele_kmer_off, A + x.o_akoff, (size_t)x.sumA * 2, hipMemcpyDeviceToHost));
+    if (allele_kmer_mask) HIP_TRY(hipMemcpy(allele_kmer_mask, A + x.o_akmask, (size_t)x.sumA * 4, hipMemcpyDeviceToHost));
+    if (path_allele) HIP_TRY(hipMemcpy(path_allele, A + x.o_pa, (size_t)x.V * x.H * 2, hipMemcpyDeviceToHost));
     return PG_OK;
 }
 
