@@ -200,6 +200,10 @@ def _bind_hip(lib):
     lib.pg_transition_probs.restype = C.c_int
     lib.pg_job_fetch_all.argtypes = [C.c_void_p, C.POINTER(PgContigResult), C.c_char_p, C.c_size_t]
     lib.pg_job_fetch_all.restype = C.c_int
+    lib.pg_job_panel_sizes.argtypes = [C.c_void_p, C.c_uint32, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), u64p, u64p]
+    lib.pg_job_panel_sizes.restype = C.c_int
+    lib.pg_job_fetch_panel.argtypes = [C.c_void_p, C.c_uint32, u32p, u16p, u32p, u16p, u8p, u16p, u32p, u16p, C.c_char_p, C.c_size_t]
+    lib.pg_job_fetch_panel.restype = C.c_int
     lib.pg_hmm_announce.argtypes = [C.c_int]
     lib.pg_hmm_announce.restype = None
     lib.pg_hmm_retract.argtypes = [C.c_int]
@@ -220,7 +224,7 @@ HIP_ABI_SYMBOLS = [
     "pg_job_packed_results", "pg_hmm_release_cache", "pg_job_triangle_chains", "pg_job_viterbi_ms",
     "pg_comm_unique_id", "pg_comm_init", "pg_comm_init_all", "pg_comm_rank", "pg_comm_world", "pg_comm_destroy",
     "pg_hmm_gather", "pg_hmm_gather_all", "pg_hmm_gather_to_host",
-    "pg_hmm_announce", "pg_hmm_retract", "pg_hmm_coalesce_stats", "pg_job_fetch_all",
+    "pg_hmm_announce", "pg_hmm_retract", "pg_hmm_coalesce_stats", "pg_job_fetch_all", "pg_job_panel_sizes", "pg_job_fetch_panel",
 ]
 
 

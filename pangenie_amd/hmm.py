@@ -223,6 +223,37 @@ class Job:
         self.h = h.value
 
     @classmethod
+    def from_handle(cls, handle: int, table: ProbabilityTable, params: PgHmmParams, positions: Optional[Sequence[np.ndarray]] = None) -> "Job":
+        """A job made elsewhere behind the C ABI (pg_sampler_then_job): its panels are read back from the device
+        (pg_job_fetch_panel) so that results can be fetched and interpreted like any other job's."""
+        self = cls.__new__(cls)
+        self._lib = _lib.load_hip()
+        self.table, self.params, self.h = table, params, handle
+        self._samples = None
+        self.batches = [self.fetch_panel(c) for c in range(self.n_chains)]
+        self.index = self.batches
+        return self
+
+    def fetch_panel(self, contig: int) -> ContigBatch:
+        """pg_job_fetch_panel: the inputs chain `contig` holds on the device as a ContigBatch (positions and coverage are
+        not part of what the C ABI returns here: zeros)."""
+        V, H, sK, sA = C.c_uint32(), C.c_uint32(), C.c_uint64(), C.c_uint64()
+        if self._lib.pg_job_panel_sizes(self.h, contig, C.byref(V), C.byref(H), C.byref(sK), C.byref(sA)):
+            raise PanGenieError(-1, "pg_job_panel_sizes")
+        V, H, sK, sA = V.value, H.value, sK.value, sA.value
+        z = lambda n, dt: np.zeros(max(int(n), 1), dt)
+        koff, aoff = z(V + 1, np.uint32), z(V + 1, np.uint32)
+        kc, aid, afl, ako, akm, pa = z(sK, np.uint16), z(sA, np.uint16), z(sA, np.uint8), z(sA, np.uint16), z(sA, np.uint32), z(V * H, np.uint16)
+        err = C.create_string_buffer(_ERRLEN)
+        p = lambda a, t: a.ctypes.data_as(t)
+        rc = self._lib.pg_job_fetch_panel(self.h, contig, p(koff, _lib.u32p), p(kc, u16p), p(aoff, _lib.u32p), p(aid, u16p), p(afl, u8p),
+                                          p(ako, u16p), p(akm, _lib.u32p), p(pa, u16p), err, _ERRLEN)
+        if rc:
+            raise PanGenieError(rc, err.value.decode(errors="replace"))
+        return ContigBatch(H, np.zeros(V, np.uint64), np.zeros(V, np.uint16), koff[:V + 1], kc[:sK], aoff[:V + 1], aid[:sA], afl[:sA],
+                           ako[:sA], akm[:sA], pa[:V * H])
+
+    @classmethod
     def cohort(cls, index: Sequence[ContigBatch], samples, table: ProbabilityTable,
                params: Optional[PgHmmParams] = None, device: int = 0) -> "Job":
         """samples: list (one entry per sample) of (kmer_counts, coverages), each a list with one uint16

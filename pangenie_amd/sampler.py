@@ -36,6 +36,10 @@ def _hip():
         lib.pg_sampler_run_batch.argtypes = [C.POINTER(PgContigBatch), C.c_uint32, C.c_uint32, C.c_double, ld, C.c_uint16, C.c_int,
                                              C.POINTER(u32p), C.POINTER(u32p), C.c_char_p, C.c_size_t]
         lib.pg_sampler_run_batch.restype = C.c_int
+        lib.pg_sampler_then_job.argtypes = [C.POINTER(PgContigBatch), C.c_uint32, C.c_uint32, C.c_int, C.c_double, ld, C.c_uint16,
+                                            C.c_void_p, C.c_void_p, C.c_int, C.POINTER(u32p), C.POINTER(u32p),
+                                            C.POINTER(C.c_void_p), C.c_char_p, C.c_size_t]
+        lib.pg_sampler_then_job.restype = C.c_int
         lib.pg_sampler_last_ms.argtypes = [f64p, C.POINTER(C.c_int)]
         lib.pg_sampler_last_ms.restype = C.c_int
         _bound = True
@@ -43,7 +47,7 @@ def _hip():
 
 
 SAMPLER_ABI_SYMBOLS = ["pg_sampler_emission_costs", "pg_sampler_transition_cost", "pg_sampler_column_minima",
-                       "pg_sampler_run", "pg_sampler_run_batch", "pg_sampler_last_ms"]
+                       "pg_sampler_run", "pg_sampler_run_batch", "pg_sampler_last_ms", "pg_sampler_then_job"]
 NO_ID = 0xFFFFFFFF
 
 
@@ -150,6 +154,31 @@ def sample_contigs(batches: Sequence[ContigBatch], size: int, recombrate: float 
     if rc:
         raise RuntimeError(f"pg_sampler_run_batch: {err.value.decode()} (error {rc})")
     return [s[:, : b.n_variants] for s, b in zip(sampled, batches)], [x[:size] for x in best]
+
+
+def sample_then_job(batches: Sequence[ContigBatch], size: int, table, params=None, add_reference: bool = False,
+                    recombrate: float = 1.26, effective_N=25000.0, allele_penalty: int = 10, device: int = 0, want_paths: bool = True):
+    """pg_sampler_then_job: the sampler, UniqueKmers::update_paths and the genotyping job's upload without the panel
+    leaving the device.  -> (hmm.Job over the reduced panels — job.batches are read back from the device —,
+    sampled paths per contig [size, V] or None, best scores per contig [size] or None)."""
+    from . import hmm
+    n = len(batches)
+    arr = (PgContigBatch * n)(*[b.as_c() for b in batches])
+    sampled = [np.zeros((size, max(1, b.n_variants)), np.uint32) for b in batches] if want_paths else None
+    best = [np.zeros(max(1, size), np.uint32) for _ in batches] if want_paths else None
+    sp = (u32p * n)(*[a.ctypes.data_as(u32p) for a in sampled]) if want_paths else None
+    bp = (u32p * n)(*[a.ctypes.data_as(u32p) for a in best]) if want_paths else None
+    params = params or hmm.make_params()
+    err = C.create_string_buffer(512)
+    h = C.c_void_p()
+    rc = _hip().pg_sampler_then_job(arr, n, size, int(bool(add_reference)), float(recombrate), _c_ld(effective_N), int(allele_penalty),
+                                    table.h, C.byref(params), device, sp, bp, C.byref(h), err, 512)
+    if rc:
+        raise hmm.PanGenieError(rc, err.value.decode(errors="replace"))
+    job = hmm.Job.from_handle(h.value, table, params)
+    if want_paths:
+        return job, [s[:, : b.n_variants] for s, b in zip(sampled, batches)], [x[:size] for x in best]
+    return job, None, None
 
 
 class HaplotypeSampler:

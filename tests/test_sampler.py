@@ -374,3 +374,66 @@ def test_hip_sampler_and_hmm_on_the_reference_fixture(kernel, monkeypatch):
     for g, w, d, na in zip(got, want, ([0, 1], [0, 1, 2]), (44, 45)):
         g.normalize(); w.normalize()
         assert vcf_sample_field(g, d, na) == vcf_sample_field(w, d, na)
+
+
+# --------------------------------------------------------------------------- #
+#  sampler -> update_paths -> job with the panel staying on the device (pg_sampler_then_job)
+# --------------------------------------------------------------------------- #
+PANEL_FIELDS = ("kmer_off", "kmer_count", "allele_off", "allele_id", "allele_flags", "allele_kmer_off", "allele_kmer_mask", "path_allele")
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("add_reference", [False, True])
+def test_sampler_then_job_panel_is_the_hosts_update_paths_bit_for_bit(add_reference):
+    """The reduced panel the device forms (ku_count / ku_write) must be, array for array, what update_paths gives on the
+    host (pangenie_amd.panel.ContigBatch.update_paths, itself checked against the object mirror of the reference's
+    update_paths above) — on the reference's 215-path fixture and on seeded multiallelic panels, several contigs in one
+    call (one of them without variants); the job's posteriors are then those of a job made from the host's panel, bit
+    for bit, and match the oracle's sampler -> HMM."""
+    from pangenie_amd import hmm
+    from tests.parity_util import assert_parity
+    fixture = pn.flatten(_fixture_panel())
+    panels = [fixture, pn.flatten(sampler_panel(150, 120, 5, max_alleles=4)), pn.flatten(sampler_panel(90, 64, 6, max_alleles=2)),
+              pn.flatten(sampler_panel(40, 33, 7, max_alleles=6)).slice(0, 0), pn.flatten(sampler_panel(300, 215, 8, max_alleles=3))]
+    for b in panels[1:]:
+        b.kmer_count[::3] = 1
+    size = 12
+    table, params = (18 // 4, 18 * 4, 2 * 18, 0.01), (1.26, False, 1e-5)
+    t, p = hmm.ProbabilityTable(*table), hmm.make_params(*params)
+    job, sampled, best = smp.sample_then_job(panels, size, t, p, add_reference=add_reference)
+    job.run()
+    got = job.fetch_all()
+    for g, b in enumerate(panels):
+        if b.n_variants == 0:
+            assert job.batches[g].n_variants == 0
+            continue
+        want_paths, want_best = orc.sampler_run(b, size)
+        assert np.array_equal(sampled[g], want_paths) and best[g].tolist() == want_best.tolist()
+        rows = np.vstack([want_paths, np.zeros((1, b.n_variants), np.uint32)]) if add_reference else want_paths
+        host = b.update_paths(rows)
+        dev = job.batches[g]
+        assert dev.n_paths == host.n_paths == size + int(add_reference)
+        for f in PANEL_FIELDS:
+            assert np.array_equal(getattr(dev, f), getattr(host, f)), (g, f)
+        alone = hmm.genotype_contig(host, t, p)
+        assert np.array_equal(got[g].lik, alone.lik) and np.array_equal(got[g].lik_exp, alone.lik_exp)
+        assert np.array_equal(got[g].kept, alone.kept) and got[g].n_columns == alone.n_columns
+        assert np.array_equal(got[g].coverage, alone.coverage) and np.array_equal(got[g].n_kmers, alone.n_kmers)
+        ref = orc.genotype_contig(host, orc.OracleTable(*table), orc.make_params(*params))
+        assert_parity(host, alone, ref)
+    job.close()
+
+
+@pytest.mark.gpu
+def test_sampler_then_job_limits_and_errors():
+    from pangenie_amd import hmm
+    t = hmm.ProbabilityTable(6, 108, 54, 0.01)
+    b = pn.flatten(sampler_panel(30, 20, 3, max_alleles=2))
+    with pytest.raises(hmm.PanGenieError):
+        smp.sample_then_job([b], 20, t)          # more passes than paths
+    with pytest.raises(hmm.PanGenieError):
+        smp.sample_then_job([b], 0, t)           # no pass at all
+    job, _, _ = smp.sample_then_job([b], 5, t, want_paths=False)
+    job.run()
+    assert job.fetch(0).n_columns > 0
+    job.close()
