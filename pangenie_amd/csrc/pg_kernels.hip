@@ -2393,6 +2393,9 @@ DEVI void lean_forward(const DevContig& dc, LeanShared<R>& sh, uint32_t C, uint3
         lds_barrier();
     };
     FRec ra = read_frec(sh, 1), rb2;
+    // every load of the prologue has landed before the loop is entered: a register still "waiting for a load" at the loop
+    // head would make the compiler put a vmcnt wait — a cap on the stores in flight — into every step
+    __builtin_amdgcn_s_waitcnt(0x0F70);
     lds_barrier();
     uint32_t t = first;
     for (; t + 1 < hi; t += 2) {
@@ -2508,6 +2511,8 @@ DEVI void lean_backward(const DevContig& dc, LeanShared<R>& sh, uint32_t C, uint
     double ee[R], pp[R];  // (see lean_forward)
 #pragma unroll
     for (int k = 0; k < R; ++k) { ee[k] = 1.0; pp[k] = w[k]; }
+    double one = 1.0;   // (in a register for the whole sweep: the DPP form of v_fmac_f64 takes no constant)
+    asm volatile("" : "+v"(one));
     // One column step (see lean_forward): `cur` = record t+1 (constants of the gap t -> t+1), `nxt` takes record t
     // (emission of column t: this step's w; constants of the next step).
     auto step = [&](int64_t t, const FRec& cur, FRec& nxt) __attribute__((always_inline)) {
@@ -2521,7 +2526,7 @@ DEVI void lean_backward(const DevContig& dc, LeanShared<R>& sh, uint32_t C, uint
         int es = exponent_of(Sy) - PG_BIAS_B;
         es = es < -900 ? -900 : es;
         const double m = ldexp(Sy, -es - PG_BIAS_B);
-        if (wave == 1) bsc.put(lane, (uint64_t)t, m);   // (the per-column scalars are collected by two DIFFERENT waves: the waves meet
+        if (wave == 1) { asm volatile("" ::: "memory"); bsc.put(lane, (uint64_t)t, m); }   // (the per-column scalars are collected by two DIFFERENT waves: the waves meet
                                                         // at a barrier every column, one wave's extra instructions are everybody's wait)
         double k0 = ldexp(cur.c0, -es), k1 = ldexp(cur.c1, -es), k2 = ldexp(cur.c2, -es), kap = ldexp(cur.kappa, -es);
         pin_here(k0); pin_here(k1); pin_here(k2); pin_here(kap);   // (in front of the barrier, not behind it)
@@ -2536,9 +2541,8 @@ DEVI void lean_backward(const DevContig& dc, LeanShared<R>& sh, uint32_t C, uint
         lean_fence();
         const double ucol = k1 * Cj;
         const double urep = dpp_source(k1 * ((pr[0] + pr[1]) + (pr[2] + pr[3])));  // u_i of row i0 + (lane & 15)
-        double eA, eB, one;
+        double eA, eB;
         emis(nxt, eA, eB);
-        asm("v_mov_b64 %0, 1.0" : "=v"(one));  // (a register: the DPP form takes no constant)
         const unsigned long long rbits = (unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(nxt.bits1 >> i0));
         const double msum = (ma[0] + ma[1]) + (ma[2] + ma[3]);
         lean_fence();
@@ -2550,6 +2554,7 @@ DEVI void lean_backward(const DevContig& dc, LeanShared<R>& sh, uint32_t C, uint
         const double Sw = mb[0];
         const double uj = fma(k2, Sw, ucol);
         const double Snew = kap * Sw;  // = sum(beta'_t)
+        Sy = Snew;                     // (1 behind an all-zero column, below)
         gdouble2* dst = (gdouble2*)(wr + (size_t)t * colsz) + toff;
         double part = 0.0, yprev = 0.0;
         static_for<0, R>([&](auto kc) __attribute__((always_inline)) {
@@ -2567,18 +2572,19 @@ DEVI void lean_backward(const DevContig& dc, LeanShared<R>& sh, uint32_t C, uint
             part = 0.0;
 #pragma unroll
             for (int k = 0; k < R; ++k) { pp[k] = unif; part += unif * ee[k]; }
+            Sy = 1.0;
         }
         sh.psum[(uint32_t)(t - 1) & 1u][wave][lane] = part;
-        if (wave == 2) bsm.put(lane, (uint64_t)t, Snew);
+        if (wave == 2) { asm volatile("" ::: "memory"); bsm.put(lane, (uint64_t)t, Snew); }   // (a branch, not predication: three of the four waves skip it)
         if (((uint64_t)t & 63u) == 0u) {
             if (wave == 1) bsc.flush(bscale, lane, (uint64_t)t);
             if (wave == 2) bsm.flush(bsum, lane, (uint64_t)t);
         }
-        Sy = Snew > 0.0 ? Snew : 1.0;
         static_for<0, R - kLeanDefer>([&](auto kc) __attribute__((always_inline)) { constexpr int k = decltype(kc)::value; w[k] = ee[k] * pp[k]; });
     };
     FRec rb2;
     int64_t t = t0;
+    __builtin_amdgcn_s_waitcnt(0x0F70);   // (see lean_forward: no load of the prologue is still in flight inside the loop)
     for (; t - 1 >= bot; t -= 2) {
         step(t, cur, rb2);
         step(t - 1, rb2, cur);

@@ -1,6 +1,6 @@
 #!/bin/bash
 # rocprofv3 captures of the three bench measurements + summaries into profiles/ (GPU box).  usage: bash tools/gpu_profiles.sh <tag>
-TAG=${1:-r02}
+TAG=${1:-r03}
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 cd $R
 mkdir -p gpurun_out/profiles

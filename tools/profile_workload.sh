@@ -6,7 +6,7 @@
 #   pass 4 (optional, SQ=1): four --pmc passes of SQ counters (issue / wait picture of the sweep)
 # usage: tools/profile_workload.sh <workload|cohort_h64> <round-tag>      output: gpurun_out/<tag>_<workload>/
 set -u
-W=${1:-genome24_h64}; TAG=${2:-r02}
+W=${1:-genome24_h64}; TAG=${2:-r03}
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$R/gpurun_out/${TAG}_$W
 mkdir -p $OUT
@@ -15,7 +15,7 @@ cd $R
 if [ "$W" = "cohort_h64" ]; then
   CMD="python bench.py --steps 3 --warmup 1 --cohort-only --no-cpu-baseline --no-sampler"
 else
-  CMD="python bench.py --steps 3 --warmup 1 --workload $W --no-cpu-baseline --no-cohort --no-sampler"
+  CMD="python bench.py --steps 3 --warmup 1 --workload $W --no-cpu-baseline --no-cohort --no-sampler --no-viterbi --no-dropin"
 fi
 timeout 900 rocprofv3 --kernel-trace --stats -d $OUT/kt -o kt --output-format csv -- $CMD > $OUT/kt.log 2>&1
 tail -1 $OUT/kt.log | cut -c1-400
