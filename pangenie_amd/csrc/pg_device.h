@@ -146,6 +146,9 @@ struct DevContig {
     // take the posterior sums over the stored half alone and k_bins doubles them: half the HBM bytes written by
     // phase 1 and read by phase 2
     uint32_t  tri;
+    // 1: every object of the chain is biallelic and H = HP = 16: the store-only phases run on k_sweep_small16 (four
+    // half-chains per wave); the chain keeps its compact records (frec) next to the full ones
+    uint32_t  small;
     double*   xbuf;            // [2][HP*HP] generic kernel scratch (forward role first)
     uint32_t* err;
     unsigned long long* prof;  // [64] in-kernel cycle counters (PG_DEBUG bit 3), profiling only

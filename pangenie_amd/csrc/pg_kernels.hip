@@ -853,7 +853,7 @@ __global__ __launch_bounds__(256) void k_records(const DevContig* __restrict__ c
         }
         dst[w] = val;
     }
-    if (dc.lean && lane < 8) {
+    if ((dc.lean || dc.small) && lane < 8) {
         // compact record of the lean sweep: {c0, c1, c2, kappa, E'00, E'01, E'11, bits1}
         const uint64_t* E = src + PG_REC_E / 8;
         uint64_t val;
@@ -2035,7 +2035,7 @@ __global__ __launch_bounds__((ChainCfg<HP, R>::TT)) void k_sweep(const DevContig
     extern __shared__ __attribute__((aligned(16))) unsigned char dyn_ring[];  // phase 2: kRingSlots column slots
     const DevContig& dc = contigs[blockIdx.x];
     if (dc.HP != (uint32_t)HP) return;
-    if (PHASE != 2 && dc.lean) return;  // store-only phases of all-biallelic H = 64 chains: k_sweep_lean
+    if (PHASE != 2 && (dc.lean || dc.small)) return;  // store-only phases of all-biallelic H = 64 / H = 16 chains: k_sweep_lean / k_sweep_small16
     // (written by k_compact: a vector load as far as the compiler knows — make the trip count, and
     // with it every column index, ring slot and address derived from it, wave-uniform again)
     const uint32_t C = (uint32_t)__builtin_amdgcn_readfirstlane((int)*dc.n_cols);
@@ -2925,6 +2925,348 @@ __global__ __launch_bounds__((64 * 64 / R)) void k_sweep_lean(const DevContig* _
 }
 
 // ------------------------------------------------------------------------------------------
+//  k_sweep_small16 : the store-only phases (1, 3) of all-biallelic chains with H = HP = 16 — BASELINE configs[1], and the
+//  shape of many-sample runs over small (sampled) panels.  A 16 x 16 column is 256 states: FOUR half-chains share one
+//  wave, each in its own 16-lane DPP row.  lane -> (half-chain r = lane >> 4, column j = lane & 15); the sixteen rows
+//  of the column live in the lane's registers.  Everything a column step exchanges stays inside the DPP row:
+//    * column sums C_j are in-lane sums (all rows of a column are in one lane);
+//    * the row terms u_i = c1 C_i are the SAME numbers (the column is symmetric): lane i of the row holds u_i, and
+//      v_fmac_f64_dpp row_newbcast:i adds it in the lanes of the row — no LDS, no barrier, no MFMA;
+//    * the total S is four rotate-and-add steps inside the row (every lane of a row ends with the same bits).
+//  Nothing is wave-uniform (four different chains): column records are read per lane (three in flight: the loop runs
+//  three steps per iteration with the record variables in rotated roles), row-allele selects are per-lane bit-field
+//  inserts, the trip count is the longest of the four half-chains and finished rows run on masked out.
+//  Same stored columns, scales, fall-back rules and resume conventions as lean_forward / lean_backward (k_post and the
+//  general phase-2 kernel read what this kernel writes).  One wave per workgroup; grid = (ceil(chains / 4), 2 roles).
+// ------------------------------------------------------------------------------------------
+DEVI double row16_sum(double v) {   // sum over the 16 lanes of the DPP row, in every lane of the row (bitwise the same)
+    v += dpp_f64<0x128, 0xF, true>(v);   // row_ror:8
+    v += dpp_f64<0x124, 0xF, true>(v);   // row_ror:4
+    v += dpp_f64<0x122, 0xF, true>(v);   // row_ror:2
+    v += dpp_f64<0x121, 0xF, true>(v);   // row_ror:1
+    return v;
+}
+DEVI FRec load_frec(gcdouble* frec, int64_t c, int64_t C) {   // record of column c (clamped: records past the end are never used)
+    c = c < 0 ? 0 : (c >= C ? C - 1 : c);
+    gcdouble2* q = (gcdouble2*)(frec + (size_t)c * 8);
+    const v2f64 a = q[0], b = q[1], e = q[2], f = q[3];
+    FRec r;
+    r.c0 = a.x; r.c1 = a.y; r.c2 = b.x; r.kappa = b.y; r.E00 = e.x; r.E01 = e.y; r.E11 = f.x;
+    r.bits1 = (unsigned long long)__double_as_longlong(f.y);
+    return r;
+}
+// e(i, j) of row k for this lane: bit k of the lane's row bits picks between the two values of its column
+template <int K>
+DEVI double sel_row_bit(uint32_t rbits /*per lane*/, double if0, double if1) {
+    uint32_t m, lo, hi;   // v_bfe_i32: bit K as 0 / ~0, then one bit-field insert per register half
+    asm("v_bfe_i32 %0, %1, %2, 1" : "=v"(m) : "v"(rbits), "n"(K));
+    asm("v_bfi_b32 %0, %1, %2, %3" : "=v"(lo) : "v"(m), "v"(__double2loint(if1)), "v"(__double2loint(if0)));
+    asm("v_bfi_b32 %0, %1, %2, %3" : "=v"(hi) : "v"(m), "v"(__double2hiint(if1)), "v"(__double2hiint(if0)));
+    return __hiloint2double((int)hi, (int)lo);
+}
+struct SmallCtx {      // per lane: the half-chain of its DPP row
+    bool live;         // the row has a half-chain with columns to do in this launch
+    gcdouble* frec; gdouble* wr; gcdouble* resume; gdouble* sc_a; gdouble* sc_b; gu8* fallback;
+    int64_t C, lo, hi;   // forward: columns [lo, hi) ascending; backward: [bot = lo, top = hi] descending
+};
+
+template <int PHASE>
+DEVI void small16_forward(const DevContig* contigs, const uint32_t* ids, uint32_t n_ids, uint32_t chunk, double* dump) {
+    constexpr int HP = 16, R = 16;
+    const uint32_t lane = threadIdx.x & 63u, j = lane & 15u;
+    const uint32_t slot = blockIdx.x * 4u + (lane >> 4);
+    const size_t colsz = (size_t)HP * HP;
+    const double unif = 1.0 / 256.0;
+    SmallCtx cx{};
+    uint32_t first = 1;
+    if (slot < n_ids) {
+        const DevContig& dc = contigs[ids[slot]];
+        const uint32_t C = *dc.n_cols, mid = C / 2, K = dc.chunk_cols;
+        uint32_t lo = PHASE == 1 ? 0u : mid, hi = PHASE == 1 ? mid : C;
+        bool ok = C > 0;
+        if constexpr (PHASE == 3) {
+            const unsigned long long l = (unsigned long long)mid + (unsigned long long)chunk * K;
+            ok = ok && l < C;
+            lo = ok ? (uint32_t)l : 0u;
+            hi = ok ? (C - lo > K ? lo + K : C) : 0u;
+        }
+        ok = ok && lo < hi;
+        if (ok) {
+            cx.live = true; cx.C = C; cx.lo = lo; cx.hi = hi;
+            cx.frec = (gcdouble*)dc.frec; cx.sc_a = (gdouble*)dc.fscale; cx.fallback = (gu8*)dc.fwd_fallback;
+            gdouble* fwd = (gdouble*)dc.fwd;
+            cx.wr = fwd;
+            cx.resume = (gcdouble*)(fwd + (size_t)(lo > 0 ? lo - 1 : 0) * colsz);
+            if constexpr (PHASE == 3) {
+                gdouble* scr = (gdouble*)dc.scratch;
+                cx.wr = scr + (size_t)((chunk & 1u) * 2u) * K * colsz - (size_t)lo * colsz;
+                if (chunk > 0) cx.resume = (gcdouble*)(scr + ((size_t)(((chunk - 1u) & 1u) * 2u) * K + (K - 1u)) * colsz);
+            }
+            first = lo == 0 ? 1u : lo;
+        }
+    }
+    const int n_steps = __builtin_amdgcn_readfirstlane(wave_max_i32(cx.live ? (int)(cx.hi - (int64_t)first) : 0));   // (uniform) the longest of the four
+    if (__builtin_amdgcn_readfirstlane(wave_max_i32(cx.live ? 1 : 0)) == 0) return;
+    auto emis = [&](const FRec& r, double& eA, double& eB) {
+        const bool aj = (r.bits1 >> j) & 1ull;
+        eA = aj ? r.E01 : r.E00;
+        eB = aj ? r.E11 : r.E01;
+    };
+    auto store_col = [&](int64_t c, const double (&v)[R]) {
+        gdouble2* dst = (gdouble2*)(cx.wr + (size_t)c * colsz) + j;
+#pragma unroll
+        for (int k = 0; k < R; k += 2) dst[(size_t)(k >> 1) * HP] = v2f64{v[k], v[k + 1]};
+    };
+    auto flag_uniform = [&](int64_t cprev) {   // (lanes of rows whose column cprev summed to zero)
+        if (cprev >= cx.lo) {
+            double xu[R];
+#pragma unroll
+            for (int k = 0; k < R; ++k) xu[k] = unif;
+            store_col(cprev, xu);
+        }
+        if (j == 0) cx.fallback[cprev] = 1;
+    };
+    // the column before the first step: x = e (.) P'
+    double x[R], buf = 0.0;
+#pragma unroll
+    for (int k = 0; k < R; ++k) x[k] = 0.0;
+    if (cx.live) {
+        const FRec r0 = load_frec(cx.frec, (int64_t)first - 1, cx.C);
+        double eA, eB;
+        emis(r0, eA, eB);
+        const uint32_t rb = (uint32_t)(r0.bits1 & 0xFFFFull);
+        if (cx.lo == 0) {
+            const double P0 = ldexp(1.0, PG_BIAS_F);
+            double pz[R];
+#pragma unroll
+            for (int k = 0; k < R; ++k) { pz[k] = P0; x[k] = (((rb >> k) & 1u) ? eB : eA) * P0; }
+            store_col(0, pz);
+            if (j == 0) cx.sc_a[0] = 1.0;
+        } else {
+            gcdouble2* src = (gcdouble2*)cx.resume + j;
+#pragma unroll
+            for (int k = 0; k < R; k += 2) { const v2f64 t = src[(size_t)(k >> 1) * HP]; x[k] = t.x; x[k + 1] = t.y; }
+            if (!cx.fallback[cx.lo - 1]) {
+#pragma unroll
+                for (int k = 0; k < R; ++k) x[k] *= ((rb >> k) & 1u) ? eB : eA;
+            }
+        }
+    }
+    double ee[R], pp[R];   // x = ee pp (formed at the start of the next step, see lean_forward)
+#pragma unroll
+    for (int k = 0; k < R; ++k) { ee[k] = 1.0; pp[k] = x[k]; }
+    // One column step of the (up to) four half-chains; `cur` = record of column first + n, `far` takes the record three
+    // steps on.  Rows whose half-chain is done (or absent) compute on whatever their registers hold and store nothing.
+    auto step = [&](int n, FRec& slot_rec) __attribute__((always_inline)) {
+        const int64_t t = (int64_t)first + n;
+        const bool act = cx.live && t < cx.hi;
+        const FRec cur = slot_rec;                                   // (its fields move on; the variable takes the far record)
+        if (cx.live) slot_rec = load_frec(cx.frec, t + 3, cx.C);
+        double Cj = 0.0;
+        static_for<0, R>([&](auto kc) __attribute__((always_inline)) { constexpr int k = decltype(kc)::value; x[k] = ee[k] * pp[k]; Cj += x[k]; });
+        double S = row16_sum(Cj);
+        // a row that did its last column a step ago: that column may itself have summed to zero (rows of longer
+        // half-chains keep the wave going; a finished row computes on, its registers no longer mean anything)
+        if (cx.live && t == cx.hi && !(S > 0.0)) flag_uniform(t - 1);
+        const double ucol = dpp_source(cur.c1 * Cj);   // u_i of row i = this lane's column (the column is symmetric)
+        double uj = fma(cur.c2, S, ucol);
+        double c0 = cur.c0;
+        if (act && !(S > 0.0)) {
+            // column t-1 summed to zero: the uniform column takes its place (hmm.cpp:253-267), see lean_forward
+            flag_uniform(t - 1);
+            const double Cu = 16.0 * unif;
+            S = 1.0;
+            uj = fma(cur.c0, unif, fma(cur.c2, 1.0, 2.0 * cur.c1 * Cu));
+            c0 = 0.0;
+        }
+        int es = exponent_of(S) - PG_BIAS_F;
+        es = es < -900 ? -900 : es;
+        const double m = ldexp(S, -es - PG_BIAS_F);
+        const double sc = ldexp(1.0, -es), c0s = ldexp(c0, -es), ujs = ldexp(uj, -es);
+        double eA, eB;
+        emis(cur, eA, eB);
+        const uint32_t rb = (uint32_t)(cur.bits1 & 0xFFFFull);
+        // (rows that are done keep computing: their stores go to a scrap column instead of under a mask)
+        gdouble2* dst = act ? (gdouble2*)(cx.wr + (size_t)t * colsz) + j : (gdouble2*)dump + lane;
+        double pprev = 0.0;
+        static_for<0, R>([&](auto kc) __attribute__((always_inline)) {
+            constexpr int k = decltype(kc)::value;
+            const double pk = fmac_row_bcast<k>(fma(c0s, x[k], ujs), ucol, sc);   // P'_t(k, j) 2^-es = c0 x + u_j + u_k
+            ee[k] = sel_row_bit<k>(rb, eA, eB);
+            pp[k] = pk;
+            if constexpr (k & 1) dst[(size_t)(k >> 1) * HP] = v2f64{pprev, pk};
+            else pprev = pk;
+        });
+        if (act) {   // the column's scale mantissa: sixteen columns collected in the row's lanes, one store per sixteen
+            if (j == ((uint32_t)t & 15u)) buf = m;
+            if (((uint32_t)t & 15u) == 15u || t + 1 == cx.hi) { if (j <= ((uint32_t)t & 15u) && (int64_t)((t & ~15ll) + j) >= (int64_t)first) cx.sc_a[(t & ~15ll) + j] = buf; }
+        }
+    };
+    FRec ra = cx.live ? load_frec(cx.frec, (int64_t)first, cx.C) : FRec{};
+    FRec rb_ = cx.live ? load_frec(cx.frec, (int64_t)first + 1, cx.C) : FRec{};
+    FRec rc_ = cx.live ? load_frec(cx.frec, (int64_t)first + 2, cx.C) : FRec{};
+    __builtin_amdgcn_s_waitcnt(0x0F70);   // (no load of the prologue in flight inside the loop: see lean_forward)
+    int n = 0;
+    for (; n + 2 < n_steps; n += 3) {
+        step(n, ra);
+        step(n + 1, rb_);
+        step(n + 2, rc_);
+    }
+    if (n < n_steps) { step(n, ra); ++n; }
+    if (n < n_steps) { step(n, rb_); ++n; }
+    {   // the last column of the rows that ran to the wave's last step may itself have summed to zero
+        double Cj = 0.0;
+#pragma unroll
+        for (int k = 0; k < R; ++k) Cj += ee[k] * pp[k];
+        const double Sl = row16_sum(Cj);
+        if (cx.live && (int64_t)first + n_steps == cx.hi && !(Sl > 0.0)) flag_uniform(cx.hi - 1);
+    }
+}
+
+template <int PHASE>
+DEVI void small16_backward(const DevContig* contigs, const uint32_t* ids, uint32_t n_ids, uint32_t chunk, double* dump) {
+    constexpr int HP = 16, R = 16;
+    const uint32_t lane = threadIdx.x & 63u, j = lane & 15u;
+    const uint32_t slot = blockIdx.x * 4u + (lane >> 4);
+    const size_t colsz = (size_t)HP * HP;
+    const double unif = 1.0 / 256.0;
+    SmallCtx cx{};   // lo = bot, hi = top
+    int64_t t0 = -1;
+    double Sy = 1.0;
+    double ee[R], pp[R];
+#pragma unroll
+    for (int k = 0; k < R; ++k) { ee[k] = 1.0; pp[k] = 0.0; }
+    if (slot < n_ids) {
+        const DevContig& dc = contigs[ids[slot]];
+        const int64_t C = *dc.n_cols, mid = C / 2, K = dc.chunk_cols;
+        int64_t top = PHASE == 1 ? C - 1 : mid - 1, bot = PHASE == 1 ? mid : 0;
+        bool ok = C > 0;
+        if constexpr (PHASE == 3) {
+            top = mid - 1 - (int64_t)chunk * K;
+            ok = ok && top >= 0;
+            bot = top - K + 1 > 0 ? top - K + 1 : 0;
+        }
+        ok = ok && top >= bot;
+        if (ok) {
+            cx.live = true; cx.C = C; cx.lo = bot; cx.hi = top;
+            cx.frec = (gcdouble*)dc.frec; cx.sc_a = (gdouble*)dc.bscale; cx.sc_b = (gdouble*)dc.bsum;
+            gdouble* cols = (gdouble*)dc.fwd;
+            cx.wr = cols;
+            cx.resume = (gcdouble*)(cols + (size_t)(top + 1 < C ? top + 1 : top) * colsz);
+            if constexpr (PHASE == 3) {
+                gdouble* scr = (gdouble*)dc.scratch;
+                cx.wr = scr + (size_t)((chunk & 1u) * 2u + 1u) * (size_t)K * colsz - (size_t)bot * colsz;
+                if (chunk > 0) cx.resume = (gcdouble*)(scr + (size_t)(((chunk - 1u) & 1u) * 2u + 1u) * (size_t)K * colsz);
+            }
+            t0 = PHASE == 1 ? top - 1 : top;
+        }
+    }
+    const int n_steps = __builtin_amdgcn_readfirstlane(wave_max_i32(cx.live ? (int)(t0 - cx.lo + 1) : 0));
+    if (__builtin_amdgcn_readfirstlane(wave_max_i32(cx.live ? 1 : 0)) == 0) return;
+    auto emis = [&](const FRec& r, double& eA, double& eB) {
+        const bool aj = (r.bits1 >> j) & 1ull;
+        eA = aj ? r.E01 : r.E00;
+        eB = aj ? r.E11 : r.E01;
+    };
+    if (cx.live) {
+        double y[R];
+        if constexpr (PHASE == 1) {
+            // column C-1: beta~ = 1 (hmm.cpp:356-358), stored at the backward bias
+            const double B0 = ldexp(1.0, PG_BIAS_B);
+#pragma unroll
+            for (int k = 0; k < R; ++k) y[k] = B0;
+            Sy = 256.0 * B0;
+            gdouble2* dst = (gdouble2*)(cx.wr + (size_t)cx.hi * colsz) + j;
+#pragma unroll
+            for (int k = 0; k < R; k += 2) dst[(size_t)(k >> 1) * HP] = v2f64{y[k], y[k + 1]};
+            if (j == 0) { cx.sc_a[cx.hi] = 1.0; cx.sc_b[cx.hi] = Sy; }
+        } else {
+            gcdouble2* src = (gcdouble2*)cx.resume + j;
+#pragma unroll
+            for (int k = 0; k < R; k += 2) { const v2f64 t = src[(size_t)(k >> 1) * HP]; y[k] = t.x; y[k + 1] = t.y; }
+            Sy = cx.sc_b[cx.hi + 1];
+            if (!(Sy > 0.0)) {  // resuming behind an all-zero column: uniform (hmm.cpp:374-380)
+#pragma unroll
+                for (int k = 0; k < R; ++k) y[k] = unif;
+                Sy = 1.0;
+            }
+        }
+        const FRec r0 = load_frec(cx.frec, t0 + 1, cx.C);   // record t0+1: emission of column t0+1
+        double eA, eB;
+        emis(r0, eA, eB);
+        const uint32_t rb = (uint32_t)(r0.bits1 & 0xFFFFull);
+#pragma unroll
+        for (int k = 0; k < R; ++k) { ee[k] = ((rb >> k) & 1u) ? eB : eA; pp[k] = y[k]; }
+    }
+    double one = 1.0, bufA = 0.0, bufB = 0.0;
+    asm volatile("" : "+v"(one));
+    // step n: column t = t0 - n.  `cur_rec` = record t+1 (constants of the gap t -> t+1; its variable then takes the
+    // record three steps on), `nxt` = record t (emission of column t).
+    auto step = [&](int n, FRec& cur_rec, const FRec& nxt) __attribute__((always_inline)) {
+        const int64_t t = t0 - n;
+        const bool act = cx.live && t >= cx.lo;
+        const FRec cur = cur_rec;
+        if (cx.live) cur_rec = load_frec(cx.frec, t - 2, cx.C);
+        int es = exponent_of(Sy) - PG_BIAS_B;
+        es = es < -900 ? -900 : es;
+        const double m = ldexp(Sy, -es - PG_BIAS_B);
+        const double k0 = ldexp(cur.c0, -es), k1 = ldexp(cur.c1, -es), k2 = ldexp(cur.c2, -es), kap = ldexp(cur.kappa, -es);
+        double w[R], Cj = 0.0;
+        static_for<0, R>([&](auto kc) __attribute__((always_inline)) { constexpr int k = decltype(kc)::value; w[k] = ee[k] * pp[k]; Cj += w[k]; });
+        const double Sw = row16_sum(Cj);
+        const double ucol = dpp_source(k1 * Cj);
+        const double uj = fma(k2, Sw, ucol);
+        const double Snew = kap * Sw;  // = sum(beta'_t)
+        double eA, eB;
+        emis(nxt, eA, eB);
+        const uint32_t rb = (uint32_t)(nxt.bits1 & 0xFFFFull);
+        gdouble2* dst = act ? (gdouble2*)(cx.wr + (size_t)t * colsz) + j : (gdouble2*)dump + lane;
+        double yprev = 0.0;
+        static_for<0, R>([&](auto kc) __attribute__((always_inline)) {
+            constexpr int k = decltype(kc)::value;
+            const double yk = fmac_row_bcast<k>(fma(k0, w[k], uj), ucol, one);  // beta'_t = k0 w + u_j + u_k
+            ee[k] = sel_row_bit<k>(rb, eA, eB);
+            pp[k] = yk;
+            if constexpr (k & 1) dst[(size_t)(k >> 1) * HP] = v2f64{yprev, yk};
+            else yprev = yk;
+        });
+        Sy = Snew;
+        if (act && !(Snew > 0.0)) {
+            // beta~_t is all zero (what was stored IS zero): the next step starts from the uniform column (hmm.cpp:374-380)
+#pragma unroll
+            for (int k = 0; k < R; ++k) pp[k] = unif;
+            Sy = 1.0;
+        }
+        if (act) {   // scale mantissa and sum of the column: sixteen columns collected in the row's lanes (descending)
+            const uint32_t q = (uint32_t)t & 15u;
+            if (j == q) { bufA = m; bufB = Snew; }
+            if (q == 0u || t == cx.lo) {
+                const int64_t c = (t & ~15ll) + j;
+                if (j >= q && c <= t0) { cx.sc_a[c] = bufA; cx.sc_b[c] = bufB; }
+            }
+        }
+    };
+    FRec ra = cx.live ? load_frec(cx.frec, t0 + 1, cx.C) : FRec{};
+    FRec rb_ = cx.live ? load_frec(cx.frec, t0, cx.C) : FRec{};
+    FRec rc_ = cx.live ? load_frec(cx.frec, t0 - 1, cx.C) : FRec{};
+    __builtin_amdgcn_s_waitcnt(0x0F70);
+    int n = 0;
+    for (; n + 2 < n_steps; n += 3) {
+        step(n, ra, rb_);
+        step(n + 1, rb_, rc_);
+        step(n + 2, rc_, ra);
+    }
+    if (n < n_steps) { step(n, ra, rb_); ++n; }
+    if (n < n_steps) { step(n, rb_, rc_); ++n; }
+}
+
+template <int PHASE>
+__global__ __launch_bounds__(64) void k_sweep_small16(const DevContig* __restrict__ contigs, const uint32_t* __restrict__ ids, uint32_t n_ids, uint32_t chunk,
+                                                      double* dump) {
+    if (blockIdx.y == 0) small16_forward<PHASE>(contigs, ids, n_ids, chunk, dump);
+    else small16_backward<PHASE>(contigs, ids, n_ids, chunk, dump);
+}
+// ------------------------------------------------------------------------------------------
 //  k_sweep_generic : the same half-chains for any HP = 64 .. 1024 (power of two), store-only phases
 //  (1 and 3; the posteriors come from k_post).  Used for HP >= 256 — more states per column than a
 //  workgroup's registers hold (reference README.md:260 allows up to 65534 paths; its own integration
@@ -3697,6 +4039,13 @@ void pgk_launch_sweep(const DevContig* d_contigs, uint32_t n_contigs, uint32_t h
 // chunked mode: chunk `chunk` of the second half of every half-chain (store-only sweep), then its posteriors
 void pgk_launch_sweep_chunk(const DevContig* d_contigs, uint32_t n_contigs, uint32_t hp_mask, uint32_t chunk, hipStream_t s) {
     launch_sweep<3>(d_contigs, n_contigs, hp_mask, chunk, s);
+}
+// the store-only phases of the H = 16 chains (DevContig::small): four half-chains per wave, phase 1 or chunk `chunk` of phase 3
+void pgk_launch_sweep_small(const DevContig* d_contigs, const uint32_t* d_ids, uint32_t n_ids, int phase, uint32_t chunk, double* d_dump, hipStream_t s) {
+    if (n_ids == 0) return;
+    const dim3 grid((n_ids + 3u) / 4u, 2);
+    if (phase == 1) hipLaunchKernelGGL(k_sweep_small16<1>, grid, dim3(64), 0, s, d_contigs, d_ids, n_ids, chunk, d_dump);
+    else hipLaunchKernelGGL(k_sweep_small16<3>, grid, dim3(64), 0, s, d_contigs, d_ids, n_ids, chunk, d_dump);
 }
 void pgk_launch_post(const DevContig* d_contigs, uint32_t n_contigs, uint32_t chunk_cols, uint32_t chunk, hipStream_t s) {
     static bool attr_done[PG_MAX_DEVICES];

@@ -37,6 +37,7 @@ void pgk_launch_bins(const DevContig*, uint32_t, uint32_t, hipStream_t);
 void pgk_launch_sweep(const DevContig*, uint32_t, uint32_t, int, hipStream_t);
 void pgk_launch_sweep_chunk(const DevContig*, uint32_t, uint32_t, uint32_t, hipStream_t);
 void pgk_launch_post(const DevContig*, uint32_t, uint32_t, uint32_t, hipStream_t);
+void pgk_launch_sweep_small(const DevContig*, const uint32_t*, uint32_t, int, uint32_t, double*, hipStream_t);
 void pgk_launch_emission_single(const DevContig*, DevTable, uint32_t, double*, int*, hipStream_t);
 void pgk_launch_transition_single(double, uint32_t, int, double*, hipStream_t);
 uint32_t pgk_threads_for_hp(uint32_t);
@@ -208,6 +209,7 @@ namespace {
 struct IndexHost {   // one index contig
     uint32_t V = 0, H = 0, HP = 0, T = 0, RB = 0, part_slots = 2, pair_n = 1;
     bool lean = false;  // every object biallelic and H = HP = 64: the store-only phases run on k_sweep_lean
+    bool small = false; // every object biallelic and H = HP = 16: the store-only phases run on k_sweep_small16
     bool prep_fast = false;  // every object has exactly two alleles and <= 32 k-mers, H <= 64: k_prep_bi
     uint32_t sumK = 0, sumA = 0;
     uint64_t n_lik = 0, wide_bytes = 0;
@@ -339,6 +341,9 @@ struct pg_job {
     // regions zeroed at the start of every run
     unsigned char* zero_base = nullptr;
     size_t zero_bytes = 0;
+    uint32_t* d_small = nullptr;  // [n_small] chain ids of the H = 16 chains
+    uint32_t n_small = 0;
+    double* d_dump = nullptr;
     uint32_t* d_ncols = nullptr;  // [n_chains]
     uint32_t* d_err = nullptr;    // [n_chains]
     double* d_lik = nullptr;      // packed, chain after chain
@@ -558,9 +563,19 @@ int job_build(int device, uint32_t n_index, const pg_contig_batch* batches, cons
         }
         if (x.HP >= 256) generic_needed = true;
         x.lean = lean_ok && x.HP == 64 && x.H == 64 && maxA == 2 && x.V > 0;
+        x.small = lean_ok && x.HP == 16 && x.H == 16 && maxA == 2 && x.V > 0;   // (and enough of them: below)
         if (x.V > max_v) max_v = x.V;
     }
     job->max_v = max_v;
+    {
+        // k_sweep_small16 packs four H = 16 half-chains into a wave: a throughput kernel.  A single chain is faster on the
+        // general kernel (four states per lane instead of sixteen: 375 vs 470 ns per column); PG_SMALL=1 / 0 forces.
+        size_t n_small_chains = 0;
+        for (const ChainSpec& sp : specs) n_small_chains += job->index[sp.index].small ? 1 : 0;
+        const char* e = getenv("PG_SMALL");
+        const bool use = e ? !strcmp(e, "1") : n_small_chains >= 512;
+        if (!use) for (auto& x : job->index) x.small = false;
+    }
 
     // ---- sweep mode ------------------------------------------------------------------------
     {
@@ -601,6 +616,8 @@ int job_build(int device, uint32_t n_index, const pg_contig_batch* batches, cons
                   vtq, vback, vbest, hap1, hap2; };
     std::vector<Plan> plan(n_chains);
     const size_t o_contigs = take(sizeof(DevContig) * n_chains);
+    const size_t o_small = take(sizeof(uint32_t) * n_chains);   // chain ids of the H = 16 chains (k_sweep_small16)
+    const size_t o_dump = take(64 * 8 * 16 + 8 * 16 * 16 * 16);  // scrap column for the stores of its rows that are done
     // zeroed-every-run block: n_cols, err, per chain kept / fallback flags / profile counters / allele_present,
     // then the packed lik and lik_exp regions (chain after chain, no gaps: one range each for a gather)
     const size_t zero_lo = align_up(off);
@@ -664,7 +681,7 @@ int job_build(int device, uint32_t n_index, const pg_contig_batch* batches, cons
         p.wide = take(x.wide_bytes);
         p.vpair = take((size_t)x.V * pg_pair_bytes(x.pair_n));
         p.xbuf = take((x.HP >= 256 || (force_generic && x.HP >= 64)) ? (size_t)2 * x.HP * x.HP * sizeof(double) : 0);
-        p.frec = take(x.lean ? (size_t)x.V * 64 : 0);
+        p.frec = take((x.lean || x.small) ? (size_t)x.V * 64 : 0);
         if (x.lean) job->hp_mask |= 64u;
         p.fscale = take((size_t)x.V * sizeof(double));
         p.bscale = take((size_t)x.V * sizeof(double));
@@ -731,7 +748,7 @@ int job_build(int device, uint32_t n_index, const pg_contig_batch* batches, cons
         d.scratch = (double*)(A + p.scratch); d.chunk_cols = job->chunk_cols;
         d.wide = A + p.wide; d.wide_idx = x.wide_bytes ? (const uint32_t*)(A + x.o_widx) : nullptr;
         d.vpair = A + p.vpair; d.xbuf = (double*)(A + p.xbuf);
-        d.frec = (double*)(A + p.frec); d.lean = x.lean ? 1u : 0u;
+        d.frec = (double*)(A + p.frec); d.lean = x.lean ? 1u : 0u; d.small = x.small ? 1u : 0u;
         d.prep_fast = x.prep_fast ? 1u : 0u;
         if (params->run_phasing) {
             d.vit_tq = (double*)(A + p.vtq); d.vit_back = (uint16_t*)(A + p.vback); d.vit_best = (uint32_t*)(A + p.vbest);
@@ -743,6 +760,16 @@ int job_build(int device, uint32_t n_index, const pg_contig_batch* batches, cons
         if (d.tri) job->hp_mask |= 128u;
         if (d.tri == 2u) job->hp_mask |= 256u;
         ch.d = d;
+    }
+    {
+        std::vector<uint32_t> small_ids;
+        for (uint32_t c = 0; c < n_chains; ++c) if (hd[c].small) small_ids.push_back(c);
+        job->n_small = (uint32_t)small_ids.size();
+        job->d_small = (uint32_t*)(A + o_small);
+        job->d_dump = (double*)(A + o_dump);
+        if (job->n_small && (he = hipMemcpyAsync(job->d_small, small_ids.data(), sizeof(uint32_t) * job->n_small, hipMemcpyHostToDevice, job->stream)) != hipSuccess)
+            return fail(PG_ERR_DEVICE, "hipMemcpy small ids", he);
+        if (job->n_small && (he = hipStreamSynchronize(job->stream)) != hipSuccess) return fail(PG_ERR_DEVICE, "hipMemcpy small ids", he);
     }
     if ((he = hipMemcpyAsync(job->d_contigs, hd.data(), sizeof(DevContig) * n_chains, hipMemcpyHostToDevice, job->stream)) != hipSuccess ||
         (he = hipStreamSynchronize(job->stream)) != hipSuccess)
@@ -891,6 +918,7 @@ extern "C" int pg_job_run(pg_job* job, void* stream_, char* err, size_t errlen) 
         HIP_TRY(hipGetLastError());
         HIP_TRY(hipEventRecord(job->ev[3], s));
         pgk_launch_sweep(job->d_contigs, n, job->hp_mask, 1, s);
+        pgk_launch_sweep_small(job->d_contigs, job->d_small, job->n_small, 1, 0, job->d_dump, s);
         HIP_TRY(hipGetLastError());
         HIP_TRY(hipEventRecord(job->ev[4], s));
         if (!job->chunked) {
@@ -908,6 +936,7 @@ extern "C" int pg_job_run(pg_job* job, void* stream_, char* err, size_t errlen) 
                 const int b = (int)(i & 1u);
                 if (i >= 2) HIP_TRY(hipStreamWaitEvent(s, job->ev_post[b], 0));
                 pgk_launch_sweep_chunk(job->d_contigs, n, job->hp_mask, i, s);
+                pgk_launch_sweep_small(job->d_contigs, job->d_small, job->n_small, 3, i, job->d_dump, s);
                 HIP_TRY(hipGetLastError());
                 HIP_TRY(hipEventRecord(job->ev_sweep[b], s));
                 HIP_TRY(hipStreamWaitEvent(s2, job->ev_sweep[b], 0));

@@ -341,6 +341,64 @@ def test_lean_kernel_biallelic_h64_vs_oracle_and_general(K, orc, monkeypatch):
         assert float(np.where(den > 0, np.abs(a - c) / np.where(den > 0, den, 1), 0).max()) < 1e-11
 
 
+@pytest.mark.parametrize("K", [1, 2, 7, 64, 4096])
+def test_small16_kernel_biallelic_h16_vs_oracle_and_general(K, orc, monkeypatch):
+    """All-biallelic H = 16 chains (BASELINE configs[1]) run their store-only phases on k_sweep_small16: four half-chains
+    per wave, one per DPP row, nothing exchanged outside the row.  Unregularised table: forward columns that fall back to
+    uniform and all-zero backward columns, on, before and behind chunk boundaries.  The small and the general kernel
+    must both match the oracle and agree with each other to fp64 rounding."""
+    monkeypatch.setenv("PG_SWEEP_MODE", "chunked")
+    monkeypatch.setenv("PG_CHUNK_COLS", str(K))
+    for seed, reg in ((15, 0.0), (16, 0.01)):
+        args = (6, 108, 54, reg)
+        b = synthetic_panel(330, 16, 20, seed=seed)
+        if reg == 0.0:
+            b.kmer_count[::3] = 0
+            b.kmer_count[1::17] = 60000
+        t, p = hmm.ProbabilityTable(*args), hmm.make_params(1.26, False, 1e-5)
+        monkeypatch.setenv("PG_SMALL", "1")   # (by default only jobs with hundreds of such chains take this kernel)
+        small = hmm.genotype_contig(b, t, p)
+        monkeypatch.setenv("PG_SMALL", "0")
+        gen = hmm.genotype_contig(b, t, p)
+        monkeypatch.delenv("PG_SMALL", raising=False)
+        ref = orc.genotype_contig(b, orc.OracleTable(*args), orc.make_params(1.26, False, 1e-5))
+        assert_parity(b, small, ref)
+        assert_parity(b, gen, ref)
+        a, c = small.likelihoods_ld(), gen.likelihoods_ld()
+        den = np.maximum(np.abs(a), np.abs(c))
+        assert float(np.where(den > 0, np.abs(a - c) / np.where(den > 0, den, 1), 0).max()) < 1e-11
+
+
+@pytest.mark.parametrize("mode", ["chunked", "fused"])
+def test_small16_kernel_many_chains_of_different_lengths(mode, orc, monkeypatch):
+    """Chains of very different lengths share waves (the trip count is the longest row's; finished rows run on with
+    their stores parked): 11 chains — a partial last wave — incl. chains of one and two columns, next to H = 64 and
+    multiallelic H = 16 chains that take other kernels; every chain equals its single-call result bit for bit and
+    matches the oracle."""
+    monkeypatch.setenv("PG_SWEEP_MODE", mode)
+    monkeypatch.setenv("PG_CHUNK_COLS", "97")
+    monkeypatch.setenv("PG_SMALL", "1")
+    sizes = [700, 3, 260, 1, 2, 510, 64, 65, 33, 400, 129]
+    batches = [synthetic_panel(v, 16, 20, seed=300 + i) for i, v in enumerate(sizes)]
+    batches.insert(4, synthetic_panel(150, 64, 20, seed=350))
+    batches.insert(8, synthetic_panel(200, 16, 20, seed=351, multiallelic_frac=0.3))
+    args = default_table_args()
+    t, p = hmm.ProbabilityTable(*args), hmm.make_params(1.26, False, 1e-5)
+    job = hmm.Job(batches, t, p)
+    job.run()
+    got = job.fetch_all()
+    job.run()
+    again = job.fetch_all()
+    job.close()
+    for b, r, r2 in zip(batches, got, again):
+        assert np.array_equal(r.lik, r2.lik) and np.array_equal(r.lik_exp, r2.lik_exp)
+        ref = orc.genotype_contig(b, orc.OracleTable(*args), orc.make_params(1.26, False, 1e-5))
+        assert_parity(b, r, ref)
+        alone = hmm.genotype_contig(b, t, p)
+        if mode == "chunked":   # (a lone call runs chunked: the same kernels — PG_SMALL is still set —, the same bits)
+            assert np.array_equal(r.lik, alone.lik) and np.array_equal(r.lik_exp, alone.lik_exp)
+
+
 @pytest.mark.parametrize("lean2", ["1", "0"])
 @pytest.mark.parametrize("C_odd", [False, True])
 def test_triangle_storage_fused_lean_vs_oracle_and_full_columns(C_odd, lean2, orc, monkeypatch):
