@@ -64,6 +64,10 @@ SAMPLER = {"contigs": 8, "V": 40_000, "H": 215, "size": 15}
 VITERBI = {"contigs": 8, "V": 100_000, "H": 30}
 # the cohort measurement: samples x contigs over one shared index
 COHORT = dict(samples=64, contigs=8, V=16_000, H=64, K=20)  # 512 chains, 194 GB of the 288 (columns as compact triangles)
+COHORTS_MORE = {
+    "cohort_h16": dict(samples=512, contigs=8, V=8_000, H=16, K=20, distinct=16),              # 4096 chains, 32.8 M variants
+    "cohort_h128": dict(samples=16, contigs=8, V=3_000, H=128, K=20, multi=0.2, distinct=16),  # 128 chains, 50 GB of columns
+}
 # GRCh38 chromosome lengths (Mb) 1..22, X, Y: proportions of the 24 synthetic contigs
 CONTIG_MB = [248, 242, 198, 190, 181, 171, 159, 145, 138, 134, 135, 133, 114, 107, 102, 90, 83, 80, 59, 64, 47, 51, 156, 57]
 
@@ -424,15 +428,18 @@ def main():
         del batches
         hmm._lib.load_hip().pg_hmm_release_cache()
 
-    # ------------------------------------------------------------------ cohort sub-measurement
-    if not args.no_cohort:
-        c = COHORT
-        S, NC, Hc = args.cohort_samples, c["contigs"], c["H"]
-        index = [synthetic_panel(c["V"], Hc, c["K"], seed=777 + i) for i in range(NC)]
-        samples = []
-        for s in range(S):  # every rank genotypes its own samples (weak scaling)
+    # ------------------------------------------------------------------ cohort sub-measurements
+    def cohort_measure(c, S, key, profile_name):
+        """many (sample x contig) chains over ONE shared index (pg_cohort_new): the regime in which the sweeps are
+        bound by the memory system.  c: dict(contigs, V, H, K, multi, distinct)."""
+        NC, Hc = c["contigs"], c["H"]
+        index = [synthetic_panel(c["V"], Hc, c["K"], seed=777 + i, multiallelic_frac=c.get("multi", 0.0)) for i in range(NC)]
+        distinct = min(S, c.get("distinct", S))   # count sets formed; samples beyond reuse them in turn
+        pool = []
+        for s in range(distinct):  # every rank genotypes its own samples (weak scaling)
             kcs, covs = zip(*[synthetic_sample_counts(ix, seed=100_000 * (rank + 1) + 100 * s + i) for i, ix in enumerate(index)])
-            samples.append((list(kcs), list(covs)))
+            pool.append((list(kcs), list(covs)))
+        samples = [pool[s % distinct] for s in range(S)]
         cjob = hmm.Job.cohort(index, samples, table, params, device=local_rank)
         csteps, cwarm = max(2, min(args.steps, 3)), 1
         for _ in range(cwarm):
@@ -453,24 +460,41 @@ def main():
         cjob.run()
         fence()
         cdt_up = max_over_ranks(time.perf_counter() - t0)
+        res = None
         if rank == 0:
             cb = cjob.batches
-            croof, cncol, (cmode, _) = roofline_of(cjob.fetch_all(), cb, ckms, Hc, "cohort_h64" if world == 1 and S == COHORT["samples"] else None, job_info_of(cjob))
+            croof, cncol, (cmode, _) = roofline_of(cjob.fetch_all(), cb, ckms, Hc, profile_name, job_info_of(cjob))
             cv = S * NC * c["V"]
             ub = cjob.upload_bytes()
-            out["cohort"] = {
-                "workload": f"{S} samples x {NC} contigs of {c['V']} variants, {Hc} haplotypes, {c['K']} k-mers/variant per GPU: "
-                            f"{S * NC} chains over ONE shared index (pg_cohort_new)",
+            res = {
+                "workload": f"{S} samples x {NC} contigs of {c['V']} variants, {Hc} haplotypes, {c['K']} k-mers/variant" +
+                            (f", {int(100 * c['multi'])} % multiallelic" if c.get("multi") else "") + f" per GPU: "
+                            f"{S * NC} chains over ONE shared index (pg_cohort_new)" +
+                            (f"; {distinct} distinct count sets, reused in turn" if distinct < S else ""),
                 "value": cv * world * csteps / cdt, "unit": "variants/s", "scaling": "weak", "steps": csteps, "ms_per_step": cdt / csteps * 1e3,
                 "chains_per_gpu": S * NC, "sweep_mode": cmode, "kept_columns": cncol,
                 "value_with_sample_upload": cv * world / cdt_up,
                 "h2d_bytes_per_sample_variant": ub["samples"] / float(cv),
                 "roofline": croof, "kernel_ms": ckms, "device_bytes": cjob.device_bytes(),
             }
-            if args.cohort_only:
-                out.update({"value": out["cohort"]["value"], "ms_per_step": out["cohort"]["ms_per_step"], "scaling": "weak",
-                            "config": {"workload": "cohort_h64 only: " + out["cohort"]["workload"]}, "roofline": croof})
         cjob.close()
+        hmm._lib.load_hip().pg_hmm_release_cache()
+        return res
+
+    if not args.no_cohort:
+        r = cohort_measure(COHORT, args.cohort_samples, "cohort", "cohort_h64" if world == 1 and args.cohort_samples == COHORT["samples"] else None)
+        if rank == 0:
+            out["cohort"] = r
+            if args.cohort_only:
+                out.update({"value": r["value"], "ms_per_step": r["ms_per_step"], "scaling": "weak",
+                            "config": {"workload": "cohort_h64 only: " + r["workload"]}, "roofline": r["roofline"]})
+        if not args.cohort_only:
+            # the other panel widths of BASELINE.json in the same regime: 16 haplotypes (configs[1]; k_sweep_small16 in
+            # phase 1) and 128 haplotypes with 20 % multiallelic objects (configs[4]; the general kernel)
+            for key, spec in COHORTS_MORE.items():
+                r = cohort_measure(spec, spec["samples"], key, None)
+                if rank == 0:
+                    out[key] = r
 
     # ------------------------------------------------------------------ HaplotypeSampler sub-measurement
     if not args.no_sampler and not args.cohort_only:
