@@ -2214,6 +2214,7 @@ DEVI double lean_colsum(const LeanShared<R>& sh, uint32_t pb, uint32_t lane) {
 template <int PHASE, int R, bool TRI>
 DEVI void lean_forward(const DevContig& dc, LeanShared<R>& sh, uint32_t C, uint32_t chunk) {
     constexpr int HP = 64;
+    constexpr int DEFER = TRI ? 0 : kLeanDefer;   // (triangle chains run two workgroups per CU: registers before shadows)
     constexpr uint32_t RMASK = (1u << R) - 1u;
     const uint32_t mid = C / 2, K = dc.chunk_cols;
     uint32_t lo = PHASE == 1 ? 0u : mid, hi = PHASE == 1 ? mid : C;
@@ -2349,10 +2350,10 @@ DEVI void lean_forward(const DevContig& dc, LeanShared<R>& sh, uint32_t C, uint3
         const double msum = (ma[0] + ma[1]) + (ma[2] + ma[3]);
         lean_fence();
         const v4f64 mb = __builtin_amdgcn_mfma_f64_16x16x4f64(msum, 1.0, zz, 0, 0, 0);
-        // the product column of the PREVIOUS step is formed here, behind the second MFMA (kLeanDefer of the sixteen
+        // the product column of the PREVIOUS step is formed here, behind the second MFMA (DEFER of the sixteen
         // multiplies; the rest ran before the step's barrier, behind the LDS write of the partial sums)
         lean_fence();
-        static_for<R - kLeanDefer, R>([&](auto kc) __attribute__((always_inline)) { constexpr int k = decltype(kc)::value; x[k] = ee[k] * pp[k]; pin_here(x[k]); });
+        static_for<R - DEFER, R>([&](auto kc) __attribute__((always_inline)) { constexpr int k = decltype(kc)::value; x[k] = ee[k] * pp[k]; pin_here(x[k]); });
         pin_here(eA); pin_here(eB);
         lean_fence();
         double S = mb[0];
@@ -2389,7 +2390,7 @@ DEVI void lean_forward(const DevContig& dc, LeanShared<R>& sh, uint32_t C, uint3
             fsc.put(lane, t, m);
             if ((t & 63u) == 63u) fsc.flush(fscale, lane, t);
         }
-        static_for<0, R - kLeanDefer>([&](auto kc) __attribute__((always_inline)) { constexpr int k = decltype(kc)::value; x[k] = ee[k] * pp[k]; });
+        static_for<0, R - DEFER>([&](auto kc) __attribute__((always_inline)) { constexpr int k = decltype(kc)::value; x[k] = ee[k] * pp[k]; });
         lds_barrier();
     };
     FRec ra = read_frec(sh, 1), rb2;
@@ -2414,6 +2415,7 @@ DEVI void lean_forward(const DevContig& dc, LeanShared<R>& sh, uint32_t C, uint3
 template <int PHASE, int R, bool TRI>
 DEVI void lean_backward(const DevContig& dc, LeanShared<R>& sh, uint32_t C, uint32_t chunk) {
     constexpr int HP = 64;
+    constexpr int DEFER = TRI ? 0 : kLeanDefer;
     constexpr uint32_t RMASK = (1u << R) - 1u;
     const int64_t mid = C / 2, K = dc.chunk_cols;
     int64_t top = PHASE == 1 ? (int64_t)C - 1 : mid - 1;
@@ -2548,7 +2550,7 @@ DEVI void lean_backward(const DevContig& dc, LeanShared<R>& sh, uint32_t C, uint
         lean_fence();
         const v4f64 mb = __builtin_amdgcn_mfma_f64_16x16x4f64(msum, 1.0, zz, 0, 0, 0);
         lean_fence();
-        static_for<R - kLeanDefer, R>([&](auto kc) __attribute__((always_inline)) { constexpr int k = decltype(kc)::value; w[k] = ee[k] * pp[k]; pin_here(w[k]); });
+        static_for<R - DEFER, R>([&](auto kc) __attribute__((always_inline)) { constexpr int k = decltype(kc)::value; w[k] = ee[k] * pp[k]; pin_here(w[k]); });
         pin_here(eA); pin_here(eB);
         lean_fence();
         const double Sw = mb[0];
@@ -2580,7 +2582,7 @@ DEVI void lean_backward(const DevContig& dc, LeanShared<R>& sh, uint32_t C, uint
             if (wave == 1) bsc.flush(bscale, lane, (uint64_t)t);
             if (wave == 2) bsm.flush(bsum, lane, (uint64_t)t);
         }
-        static_for<0, R - kLeanDefer>([&](auto kc) __attribute__((always_inline)) { constexpr int k = decltype(kc)::value; w[k] = ee[k] * pp[k]; });
+        static_for<0, R - DEFER>([&](auto kc) __attribute__((always_inline)) { constexpr int k = decltype(kc)::value; w[k] = ee[k] * pp[k]; });
     };
     FRec rb2;
     int64_t t = t0;
@@ -2724,13 +2726,9 @@ DEVI void lean2_forward(const DevContig& dc, LeanShared2<R>& sh2, uint32_t C) {
         const uint32_t pb = (t - 1) & 1u;
         const double Cj = lean_colsum<R>(sh, pb, lane);
         const double ucol = cur.c1 * Cj;
-        double ui[R];
-        const double urep = cur.c1 * lean_colsum<R>(sh, pb, i0 + (lane & 15u));
+        const double urep = dpp_source(cur.c1 * lean_colsum<R>(sh, pb, i0 + (lane & 15u)));   // u_i of row i0 + (lane & 15): the DPP source
         const v4f64 zz = {0.0, 0.0, 0.0, 0.0};
         const v4f64 ma = __builtin_amdgcn_mfma_f64_16x16x4f64(Cj, 1.0, zz, 0, 0, 0);
-        __builtin_amdgcn_sched_barrier(0);
-        lean_u_rows<R>(urep, ui);  // (fills the latency of the first MFMA of the total)
-        __builtin_amdgcn_sched_barrier(0);
         double S = __builtin_amdgcn_mfma_f64_16x16x4f64((ma[0] + ma[1]) + (ma[2] + ma[3]), 1.0, zz, 0, 0, 0)[0];
         double uj = fma(cur.c2, S, ucol);
         double c0 = cur.c0;
@@ -2750,17 +2748,18 @@ DEVI void lean2_forward(const DevContig& dc, LeanShared2<R>& sh2, uint32_t C) {
         double eA, eB;
         emis(cur, eA, eB);
         const uint32_t rb = (uint32_t)__builtin_amdgcn_readfirstlane((int)((uint32_t)(cur.bits1 >> i0) & RMASK));
+        const unsigned long long rbits = (unsigned long long)rb;
         double part0 = 0.0, acc0 = 0.0, acc1 = 0.0;
-#pragma unroll
-        for (int k = 0; k < R; ++k) {
-            const double pk = fma(c0s, x[k], fma(ui[k], sc, ujs));
-            x[k] = pk * sel_by_bit(rb, k, eA, eB);
+        static_for<0, R>([&](auto kc) __attribute__((always_inline)) {
+            constexpr int k = decltype(kc)::value;
+            const double pk = fmac_row_bcast<k>(fma(c0s, x[k], ujs), urep, sc);   // P'_t = c0 x + u_j + u_i (lean_forward)
+            x[k] = pk * sel_by_mask(eA, eB, row_mask64<k>(rbits));
             part0 += x[k];
             const double pr = pk * b0[k];  // P'_t beta'_t (0 below the stored half)
             const bool bit = (rb >> k) & 1u;
             acc1 = fma(pr, bit ? 1.0 : 0.0, acc1);  // exact 0/1 multipliers: rounds like a predicated add
             acc0 = fma(pr, bit ? 0.0 : 1.0, acc0);
-        }
+        });
         sh.psum[t & 1u][wave][lane] = part0;
         sh2.ppart[t & 1u][wave][lane] = v2f64{acc0, acc1};
         if (wave == 0) {
@@ -2834,6 +2833,8 @@ DEVI void lean2_backward(const DevContig& dc, LeanShared2<R>& sh2, uint32_t C) {
         for (int k = 0; k < R; ++k) { w[k] = y[k] * sel_by_bit(rb, k, eA, eB); part0 += w[k]; }
         sh.psum[(uint32_t)t0 & 1u][wave][lane] = part0;
     }
+    double one = 1.0;   // (in a register: the DPP form of v_fmac_f64 takes no constant)
+    asm volatile("" : "+v"(one));
     for (int64_t t = t0; t >= bot; --t) {
         const uint32_t n = (uint32_t)(t0 - t);
         const FRec nxt = read_frec(sh, n + 1u);  // record t: emission of column t (this step's w), row alleles of the posterior
@@ -2852,35 +2853,32 @@ DEVI void lean2_backward(const DevContig& dc, LeanShared2<R>& sh2, uint32_t C) {
         if (t < t0) lean2_flush_partials<R>(sh2, (uint32_t)(t + 1) & 1u, part, (size_t)(t + 1), wave, lane, cur.bits1);
         const double Cj = lean_colsum<R>(sh, (uint32_t)t & 1u, lane);
         const double ucol = k1 * Cj;
-        double ui[R];
-        const double urep = k1 * lean_colsum<R>(sh, (uint32_t)t & 1u, i0 + (lane & 15u));
+        const double urep = dpp_source(k1 * lean_colsum<R>(sh, (uint32_t)t & 1u, i0 + (lane & 15u)));
         const v4f64 zz = {0.0, 0.0, 0.0, 0.0};
         const v4f64 ma = __builtin_amdgcn_mfma_f64_16x16x4f64(Cj, 1.0, zz, 0, 0, 0);
-        __builtin_amdgcn_sched_barrier(0);
-        lean_u_rows<R>(urep, ui);
-        __builtin_amdgcn_sched_barrier(0);
         const double Sw = __builtin_amdgcn_mfma_f64_16x16x4f64((ma[0] + ma[1]) + (ma[2] + ma[3]), 1.0, zz, 0, 0, 0)[0];
         const double uj = fma(k2, Sw, ucol);
         const double Snew = kap * Sw;  // = sum(beta'_t)
         double eA, eB;
         emis(nxt, eA, eB);
         const uint32_t rb = (uint32_t)__builtin_amdgcn_readfirstlane((int)((uint32_t)(nxt.bits1 >> i0) & RMASK));
+        const unsigned long long rbits = (unsigned long long)rb;
         double part0 = 0.0, acc0 = 0.0, acc1 = 0.0;
         if (__builtin_expect(!(Snew > 0.0), 0)) {
             // beta~_t is all zero: its own posteriors are 0, the next step starts from the uniform column
 #pragma unroll
             for (int k = 0; k < R; ++k) { w[k] = unif * sel_by_bit(rb, k, eA, eB); part0 += w[k]; }
         } else {
-#pragma unroll
-            for (int k = 0; k < R; ++k) {
-                const double yk = fma(k0, w[k], ui[k] + uj);  // beta'_t
-                w[k] = yk * sel_by_bit(rb, k, eA, eB);
+            static_for<0, R>([&](auto kc) __attribute__((always_inline)) {
+                constexpr int k = decltype(kc)::value;
+                const double yk = fmac_row_bcast<k>(fma(k0, w[k], uj), urep, one);  // beta'_t = k0 w + u_j + u_i (lean_backward)
+                w[k] = yk * sel_by_mask(eA, eB, row_mask64<k>(rbits));
                 part0 += w[k];
                 const double pr = b0[k] * yk;  // P'_t beta'_t
                 const bool bit = (rb >> k) & 1u;
                 acc1 = fma(pr, bit ? 1.0 : 0.0, acc1);
                 acc0 = fma(pr, bit ? 0.0 : 1.0, acc0);
-            }
+            });
         }
         sh.psum[(uint32_t)(t - 1) & 1u][wave][lane] = part0;
         sh2.ppart[(uint32_t)t & 1u][wave][lane] = v2f64{acc0, acc1};
@@ -2907,9 +2905,26 @@ void k_sweep_lean2(const DevContig* __restrict__ contigs) {
     else lean2_backward<R>(dc, sh, C);
 }
 
+// (shared by the two kernels below)
+template <int PHASE, int R, bool TRI>
+DEVI void sweep_lean_body(const DevContig* __restrict__ contigs, uint32_t chunk, LeanShared<R>& sh);
+
+// phase 1 of fused jobs (triangle stores): hundreds of chains, two workgroups per CU — at most 256 registers per lane
+template <int PHASE, int R>
+__global__ __launch_bounds__((64 * 64 / R)) __attribute__((amdgpu_waves_per_eu(2, 2)))
+void k_sweep_lean_tri(const DevContig* __restrict__ contigs, uint32_t chunk) {
+    __shared__ LeanShared<R> sh;
+    sweep_lean_body<PHASE, R, true>(contigs, chunk, sh);
+}
+
 template <int PHASE, int R, bool TRI = false>
 __global__ __launch_bounds__((64 * 64 / R)) void k_sweep_lean(const DevContig* __restrict__ contigs, uint32_t chunk) {
     __shared__ LeanShared<R> sh;
+    sweep_lean_body<PHASE, R, TRI>(contigs, chunk, sh);
+}
+
+template <int PHASE, int R, bool TRI>
+DEVI void sweep_lean_body(const DevContig* __restrict__ contigs, uint32_t chunk, LeanShared<R>& sh) {
     const DevContig& dc = contigs[blockIdx.x];
     if (!dc.lean) return;
     if ((dc.tri != 0u) != TRI) return;
@@ -4002,7 +4017,7 @@ static void launch_sweep(const DevContig* d_contigs, uint32_t n_contigs, uint32_
     if constexpr (PHASE != 2) {
         if (hp_mask & 64u) {  // bit 6: the job has lean chains (all-biallelic, H = HP = 64)
             if (PHASE == 1 && (hp_mask & 128u))  // bit 7: fused job whose lean chains store triangles (DevContig::tri)
-                hipLaunchKernelGGL((k_sweep_lean<PHASE, 16, true>), dim3(n_contigs, 2), dim3(256), 0, s, d_contigs, chunk);
+                hipLaunchKernelGGL((k_sweep_lean_tri<PHASE, 16>), dim3(n_contigs, 2), dim3(256), 0, s, d_contigs, chunk);
             else hipLaunchKernelGGL((k_sweep_lean<PHASE, 16, false>), dim3(n_contigs, 2), dim3(256), 0, s, d_contigs, chunk);
         }
         // bit 4: contigs with HP >= 256; bit 5: (forced) the generic kernel for every HP >= 64
