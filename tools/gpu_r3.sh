@@ -25,6 +25,7 @@ for step in "$@"; do
       run bench_chr22 600 python bench.py --workload chr22_h64 --no-cohort --no-sampler --no-viterbi --steps 3 --warmup 1
       run bench_h16 600 python bench.py --workload contig_h16 --no-cohort --no-sampler --no-viterbi --steps 3 --warmup 1
       run bench_h128 600 python bench.py --workload chr22_h128 --no-cohort --no-sampler --no-viterbi --steps 3 --warmup 1 ;;
+    profiles) run profiles 2400 bash tools/gpu_profiles.sh r03 ;;
     *.sh) run $(basename $step .sh) 1500 bash tools/$step $O ;;
     *) echo "unknown step $step" | tee -a $O/summary.txt ;;
   esac
