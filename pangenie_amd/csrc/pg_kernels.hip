@@ -2035,7 +2035,7 @@ __global__ __launch_bounds__((ChainCfg<HP, R>::TT)) void k_sweep(const DevContig
     extern __shared__ __attribute__((aligned(16))) unsigned char dyn_ring[];  // phase 2: kRingSlots column slots
     const DevContig& dc = contigs[blockIdx.x];
     if (dc.HP != (uint32_t)HP) return;
-    if (PHASE != 2 && (dc.lean || dc.small)) return;  // store-only phases of all-biallelic H = 64 / H = 16 chains: k_sweep_lean / k_sweep_small16
+    if (PHASE != 2 && (dc.lean || dc.small || dc.leanx)) return;  // store-only phases of all-biallelic H = 64 / H = 16 chains: k_sweep_lean / k_sweep_small16
     // (written by k_compact: a vector load as far as the compiler knows — make the trip count, and
     // with it every column index, ring slot and address derived from it, wave-uniform again)
     const uint32_t C = (uint32_t)__builtin_amdgcn_readfirstlane((int)*dc.n_cols);
@@ -2934,6 +2934,455 @@ DEVI void sweep_lean_body(const DevContig* __restrict__ contigs, uint32_t chunk,
     if (blockIdx.y == 0) lean_forward<PHASE, R, TRI>(dc, sh, C, chunk);
     else lean_backward<PHASE, R, TRI>(dc, sh, C, chunk);
     if (kChainProf && threadIdx.x == 0) {  // -DPG_CHAIN_PROF builds only: cycles of this role's launch (last chunk wins)
+        unsigned long long* o = dc.prof + (blockIdx.y == 0 ? 0 : 16) + (PHASE == 1 ? 0 : 8);
+        o[0] = __builtin_amdgcn_s_memtime() - t_begin;
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+//  k_sweep_leanx : the store-only phases (1, 3) of chains at HP = 128 whose objects all have at most PG_AMAX alleles
+//  (every column NARROW: its emission table is the 6 x 6 one inside the column record) — BASELINE configs[4], the
+//  HPRC-style panel with multiallelic objects, H <= 128.  The lean step (k_sweep_lean: column sums through LDS, wave
+//  totals by two fp64 MFMAs, u_i by v_fmac_f64_dpp row_newbcast, scale folded into the constants, one dependent segment
+//  per column in BOTH directions — the general kernel's backward role at R = 32 runs two) with the emission of a state
+//  taken from the column's table instead of a two-way select:
+//    * the FULL column records travel through LDS in blocks of 16 (every thread fetches one 16-byte piece of the block
+//      after next: one global load per thread per 16 columns); when a block is parked its allele bytes are rewritten in
+//      place as table row offsets min(a, 5) * 48 (phantom paths, allele 255, hit the zero row / column);
+//    * a state's emission is E[a_i][a_j] = one LDS read at (lane's table column) + (row offset, a scalar bit-field
+//      extract of the wave-uniform row alleles): three issue slots, what the biallelic select costs — so there is ONE
+//      path for biallelic and multiallelic columns alike;
+//    * row alleles, the lane's column allele and the transition constants of a column are read one step ahead.
+//  Layout as the general kernel's at HP = 128: 8 waves, wave -> (row group of 32 rows, 64-column block), lane =
+//  column, 32 states per lane; two waves per SIMD.  Same stored columns, scales, fall-back rules and resume
+//  conventions as the general kernel (k_post and the fused phase 2 read what this kernel writes).
+// ------------------------------------------------------------------------------------------
+template <int HP>
+struct LxCfg {
+    static constexpr int R = HP / 4;            // rows per wave: four row groups
+    static constexpr int NCH = HP / 64;         // 64-column blocks
+    static constexpr int NW = 4 * NCH;          // waves
+    static constexpr int T = 64 * NW;
+    static constexpr int NS = R / 16;           // DPP rows' worth of u_i per wave
+    static constexpr int RB = (PG_REC_ALLELES + HP + 63) & ~63;
+    static constexpr int BLK = 16;              // records per LDS block
+    static constexpr int PIECES = BLK * RB / 16;
+    static constexpr int PPT = (PIECES + T - 1) / T;   // 16-byte pieces per thread and block
+    static_assert(R % 16 == 0 && (BLK * HP / 4) % T == 0, "bad lean-x geometry");
+};
+template <int HP>
+struct LxShared {
+    using Cfg = LxCfg<HP>;
+    double psum[2][4][HP];
+    unsigned char rec[2][Cfg::BLK][Cfg::RB] __attribute__((aligned(16)));
+};
+template <int HP>
+struct LxRecs {
+    using Cfg = LxCfg<HP>;
+    const GAS char* base;   // colrec
+    int64_t origin, C;      // column of rel 0, number of columns
+    int dir;                // +1 forward, -1 backward
+    uint32_t tid;
+    DEVI v2f64 fetch(uint32_t block, int p) const {
+        const uint32_t piece = tid + (uint32_t)p * Cfg::T;
+        if (piece >= (uint32_t)Cfg::PIECES) return v2f64{0.0, 0.0};
+        const uint32_t q = piece / (uint32_t)(Cfg::RB / 16), w = piece % (uint32_t)(Cfg::RB / 16);
+        int64_t c = origin + (int64_t)dir * ((int64_t)block * Cfg::BLK + q);
+        c = c < 0 ? 0 : (c >= C ? C - 1 : c);
+        return *(const GAS v2f64*)(base + (size_t)c * Cfg::RB + w * 16u);
+    }
+    DEVI void park(LxShared<HP>& sh, uint32_t block, int p, v2f64 v) const {
+        const uint32_t piece = tid + (uint32_t)p * Cfg::T;
+        if (piece < (uint32_t)Cfg::PIECES) ((v2f64*)&sh.rec[block & 1u][0][0])[piece] = v;
+    }
+};
+// allele bytes of a freshly parked block -> table row offsets min(a, 5) * 48 (in place)
+template <int HP>
+DEVI void lx_transform(LxShared<HP>& sh, uint32_t block, uint32_t tid) {
+    using Cfg = LxCfg<HP>;
+    auto f = [](uint32_t v) {  // two bytes in the 16-bit halves
+        uint32_t a = v & 0xFFFFu, b = v >> 16;
+        a = a > (uint32_t)PG_AMAX ? (uint32_t)PG_AMAX : a;
+        b = b > (uint32_t)PG_AMAX ? (uint32_t)PG_AMAX : b;
+        return (a * (uint32_t)(PG_ESTRIDE * 8)) | ((b * (uint32_t)(PG_ESTRIDE * 8)) << 16);
+    };
+#pragma unroll
+    for (uint32_t d = tid; d < (uint32_t)(Cfg::BLK * HP / 4); d += (uint32_t)Cfg::T) {
+        uint32_t* ptr = (uint32_t*)(&sh.rec[block & 1u][d / (uint32_t)(HP / 4)][PG_REC_ALLELES]) + d % (uint32_t)(HP / 4);
+        const uint32_t v = *ptr;
+        *ptr = f(v & 0x00FF00FFu) | (f((v >> 8) & 0x00FF00FFu) << 8);
+    }
+}
+template <int HP>
+DEVI const unsigned char* lx_rec(const LxShared<HP>& sh, uint32_t rel /*uniform*/) {
+    return sh.rec[(rel / (uint32_t)LxCfg<HP>::BLK) & 1u][rel % (uint32_t)LxCfg<HP>::BLK];
+}
+struct LxConsts { double c0, c1, c2, kappa; };
+template <int HP>
+DEVI LxConsts lx_consts(const LxShared<HP>& sh, uint32_t rel) {
+    const double* q = (const double*)lx_rec(sh, rel);
+    return LxConsts{q[0], q[1], q[2], q[3]};
+}
+// what a step needs of a column's alleles: the lane's table column (byte offset a_j * 8 inside a table row) and the
+// row offsets of the wave's R rows (R bytes, wave-uniform: kept in scalar registers)
+template <int R>
+struct LxAlleles { uint32_t col8; uint32_t rows[R / 4]; };
+template <int HP>
+DEVI LxAlleles<LxCfg<HP>::R> lx_alleles(const LxShared<HP>& sh, uint32_t rel, uint32_t j, uint32_t i0) {
+    constexpr int R = LxCfg<HP>::R;
+    const unsigned char* al = lx_rec(sh, rel) + PG_REC_ALLELES;
+    LxAlleles<R> a;
+    a.col8 = ((uint32_t)al[j] * 171u) >> 10;   // (row offset a * 48) / 6 = a * 8, a <= 5
+#pragma unroll
+    for (int q = 0; q < R / 4; ++q) a.rows[q] = (uint32_t)__builtin_amdgcn_readfirstlane((int)((const uint32_t*)(al + i0))[q]);
+    return a;
+}
+template <int HP, int K>
+DEVI double lx_emission(const unsigned char* ecol /*record + PG_REC_E + col8, per lane*/, const LxAlleles<LxCfg<HP>::R>& a) {
+    const uint32_t off = (a.rows[K >> 2] >> (8 * (K & 3))) & 0xFFu;   // scalar: s_bfe_u32
+    return *(const double*)(ecol + off);
+}
+
+template <int PHASE, int HP>
+DEVI void leanx_forward(const DevContig& dc, LxShared<HP>& sh, uint32_t C, uint32_t chunk) {
+    using Cfg = LxCfg<HP>;
+    constexpr int R = Cfg::R, NS = Cfg::NS, BLK = Cfg::BLK, PPT = Cfg::PPT;
+    const uint32_t mid = C / 2, K = dc.chunk_cols;
+    uint32_t lo = PHASE == 1 ? 0u : mid, hi = PHASE == 1 ? mid : C;
+    if constexpr (PHASE == 3) {
+        const unsigned long long l = (unsigned long long)mid + (unsigned long long)chunk * K;
+        if (l >= C) return;
+        lo = (uint32_t)l;
+        hi = C - lo > K ? lo + K : C;
+    }
+    if (lo >= hi) return;
+    const uint32_t first = lo == 0 ? 1u : lo;
+    const uint32_t tid = threadIdx.x, lane = tid & 63u;
+    const uint32_t wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const uint32_t rg = wave / (uint32_t)Cfg::NCH, i0 = rg * R, j = (wave % (uint32_t)Cfg::NCH) * 64u + lane;
+    const uint32_t H = dc.H;
+    const size_t colsz = (size_t)HP * HP;
+    const double unif = 1.0 / ((double)H * (double)H);
+    LxRecs<HP> recs{(const GAS char*)dc.colrec, (int64_t)first - 1, (int64_t)C, +1, tid};
+    v2f64 piece[PPT];
+#pragma unroll
+    for (int p = 0; p < PPT; ++p) recs.park(sh, 0, p, recs.fetch(0, p));
+#pragma unroll
+    for (int p = 0; p < PPT; ++p) piece[p] = recs.fetch(1, p);
+    lds_barrier();
+    lx_transform<HP>(sh, 0, tid);
+    lds_barrier();
+    gdouble* fwd = (gdouble*)dc.fwd;
+    gdouble* fscale = (gdouble*)dc.fscale;
+    gu8* fallback = (gu8*)dc.fwd_fallback;
+    gdouble* wr = fwd;
+    gcdouble* resume = (gcdouble*)(fwd + (size_t)(lo > 0 ? lo - 1 : 0) * colsz);
+    if constexpr (PHASE == 3) {
+        gdouble* scr = (gdouble*)dc.scratch;
+        wr = scr + (size_t)((chunk & 1u) * 2u) * K * colsz - (size_t)lo * colsz;
+        if (chunk > 0) resume = (gcdouble*)(scr + ((size_t)(((chunk - 1u) & 1u) * 2u) * K + (K - 1u)) * colsz);
+    }
+    const size_t toff = (size_t)(i0 >> 1) * HP + j;  // this thread's first row pair inside a column (in 16-byte units)
+    auto store_col = [&](uint32_t c, const double (&v)[R]) {
+        gdouble2* dst = (gdouble2*)(wr + (size_t)c * colsz) + toff;
+#pragma unroll
+        for (int k = 0; k < R; k += 2) dst[(size_t)(k >> 1) * HP] = v2f64{v[k], v[k + 1]};
+    };
+    auto flag_uniform = [&](uint32_t cprev) {
+        if (cprev >= lo) {
+            double xu[R];
+#pragma unroll
+            for (int k = 0; k < R; ++k) xu[k] = (j < H && i0 + (uint32_t)k < H) ? unif : 0.0;
+            store_col(cprev, xu);
+        }
+        if (tid == 0) fallback[cprev] = 1;
+    };
+    auto gather = [&](uint32_t rel, const LxAlleles<R>& al, double (&e)[R]) __attribute__((always_inline)) {
+        const unsigned char* ecol = lx_rec(sh, rel) + PG_REC_E + al.col8;
+        static_for<0, R>([&](auto kc) __attribute__((always_inline)) { constexpr int k = decltype(kc)::value; e[k] = lx_emission<HP, k>(ecol, al); });
+    };
+
+    ColScalars fsc;
+    double x[R], e[R];
+    {
+        const LxAlleles<R> a0 = lx_alleles<HP>(sh, 0, j, i0);
+        gather(0, a0, e);
+        double part = 0.0;
+        if (lo == 0) {
+            const double P0 = ldexp(1.0, PG_BIAS_F);
+            double pz[R];
+#pragma unroll
+            for (int k = 0; k < R; ++k) { pz[k] = P0; x[k] = e[k] * P0; part += x[k]; }
+            store_col(0, pz);
+            if (tid == 0) fscale[0] = 1.0;
+        } else {
+            gcdouble2* src = (gcdouble2*)resume + toff;
+#pragma unroll
+            for (int k = 0; k < R; k += 2) { const v2f64 t = src[(size_t)(k >> 1) * HP]; x[k] = t.x; x[k + 1] = t.y; }
+            if (!fallback[lo - 1]) {
+#pragma unroll
+                for (int k = 0; k < R; ++k) x[k] *= e[k];
+            }
+#pragma unroll
+            for (int k = 0; k < R; ++k) part += x[k];
+        }
+        sh.psum[(first - 1) & 1u][rg][j] = part;
+    }
+    LxConsts cur = lx_consts<HP>(sh, 1);            // column `first`: constants of the gap first-1 -> first
+    LxAlleles<R> al = lx_alleles<HP>(sh, 1, j, i0);  // and its alleles
+    double one = 1.0;
+    asm volatile("" : "+v"(one));
+    auto step = [&](uint32_t t) __attribute__((always_inline)) {
+        const uint32_t n = t - first;                 // step number: column t is the record with rel = n + 1
+        if (((n + 4u) % (uint32_t)BLK) == 0u) {       // (uniform) a few columns before the next block is needed
+            const uint32_t blk = (n + 4u) / (uint32_t)BLK;
+#pragma unroll
+            for (int p = 0; p < PPT; ++p) { recs.park(sh, blk, p, piece[p]); piece[p] = recs.fetch(blk + 1u, p); }
+        } else if (((n + 3u) % (uint32_t)BLK) == 0u) {
+            lx_transform<HP>(sh, (n + 3u) / (uint32_t)BLK, tid);   // the block parked a step ago (a barrier lies between)
+        }
+        const uint32_t pb = (t - 1) & 1u;
+        double pc[4], po[4], pr[NS][4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            pc[q] = sh.psum[pb][q][j];
+            po[q] = Cfg::NCH == 2 ? sh.psum[pb][q][j ^ 64u] : 0.0;
+#pragma unroll
+            for (int s = 0; s < NS; ++s) pr[s][q] = sh.psum[pb][q][i0 + 16u * (uint32_t)s + (lane & 15u)];
+        }
+        lean_fence();
+        gather(n + 1u, al, e);                          // e_t(i0 + k, j): lands while the total is formed
+        const LxConsts cnx = lx_consts<HP>(sh, n + 2u);
+        const LxAlleles<R> anx = lx_alleles<HP>(sh, n + 2u, j, i0);
+        lean_fence();
+        const double Cj = (pc[0] + pc[1]) + (pc[2] + pc[3]);
+        const double Call = Cfg::NCH == 2 ? Cj + ((po[0] + po[1]) + (po[2] + po[3])) : Cj;
+        const v4f64 zz = {0.0, 0.0, 0.0, 0.0};
+        const v4f64 ma = __builtin_amdgcn_mfma_f64_16x16x4f64(Call, 1.0, zz, 0, 0, 0);
+        const double ucol = cur.c1 * Cj;
+        double urep[NS];
+#pragma unroll
+        for (int s = 0; s < NS; ++s) urep[s] = dpp_source(cur.c1 * ((pr[s][0] + pr[s][1]) + (pr[s][2] + pr[s][3])));
+        const double msum = (ma[0] + ma[1]) + (ma[2] + ma[3]);
+        const v4f64 mb = __builtin_amdgcn_mfma_f64_16x16x4f64(msum, 1.0, zz, 0, 0, 0);
+        double S = mb[0];
+        double uj = fma(cur.c2, S, ucol);
+        double c0 = cur.c0;
+        if (__builtin_expect(!(S > 0.0), 0)) {
+            // column t-1 summed to zero: the uniform column takes its place (hmm.cpp:253-267), see forward_body
+            flag_uniform(t - 1);
+            const double Cu = (double)H * unif;
+            S = 1.0;
+            uj = fma(cur.c0, unif, fma(cur.c2, 1.0, 2.0 * cur.c1 * Cu));
+            c0 = 0.0;
+        }
+        int es = exponent_of(S) - PG_BIAS_F;
+        es = es < -900 ? -900 : es;
+        const double m = ldexp(S, -es - PG_BIAS_F);
+        const double sc = ldexp(1.0, -es), c0s = ldexp(c0, -es), ujs = ldexp(uj, -es);
+        gdouble2* dst = (gdouble2*)(wr + (size_t)t * colsz) + toff;
+        double part = 0.0, pprev = 0.0;
+        static_for<0, R>([&](auto kc) __attribute__((always_inline)) {
+            constexpr int k = decltype(kc)::value;
+            const double pk = fmac_row_bcast<(k & 15)>(fma(c0s, x[k], ujs), urep[k >> 4], sc);   // P'_t(i0 + k, j) 2^-es
+            part = fma(e[k], pk, part);
+            x[k] = e[k] * pk;
+            if constexpr (k & 1) { dst[(size_t)(k >> 1) * HP] = v2f64{pprev, pk}; __builtin_amdgcn_sched_barrier(0); }
+            else pprev = pk;
+        });
+        sh.psum[t & 1u][rg][j] = part;
+        if (wave == 0) {  // (scalar branch)
+            fsc.put(lane, t, m);
+            if ((t & 63u) == 63u) fsc.flush(fscale, lane, t);
+        }
+        cur = cnx; al = anx;
+        lds_barrier();
+    };
+    __builtin_amdgcn_s_waitcnt(0x0F70);   // (no load of the prologue in flight inside the loop: see lean_forward)
+    lds_barrier();
+    for (uint32_t t = first; t < hi; ++t) step(t);
+    if (wave == 0 && fsc.valid) fsc.flush(fscale, lane, hi - 1);
+    {   // the last column of this phase may itself have summed to zero
+        const uint32_t pb = (hi - 1) & 1u;
+        double Call = 0.0;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) Call += sh.psum[pb][q][j] + (Cfg::NCH == 2 ? sh.psum[pb][q][j ^ 64u] : 0.0);
+        if (!(wave_total_mfma(Call) > 0.0)) flag_uniform(hi - 1);
+    }
+}
+
+template <int PHASE, int HP>
+DEVI void leanx_backward(const DevContig& dc, LxShared<HP>& sh, uint32_t C, uint32_t chunk) {
+    using Cfg = LxCfg<HP>;
+    constexpr int R = Cfg::R, NS = Cfg::NS, BLK = Cfg::BLK, PPT = Cfg::PPT;
+    const int64_t mid = C / 2, K = dc.chunk_cols;
+    int64_t top = PHASE == 1 ? (int64_t)C - 1 : mid - 1;
+    int64_t bot = PHASE == 1 ? mid : 0;
+    if constexpr (PHASE == 3) {
+        top = mid - 1 - (int64_t)chunk * K;
+        if (top < 0) return;
+        bot = top - K + 1 > 0 ? top - K + 1 : 0;
+    }
+    if (top < bot) return;
+    const int64_t t0 = PHASE == 1 ? top - 1 : top;
+    const uint32_t tid = threadIdx.x, lane = tid & 63u;
+    const uint32_t wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const uint32_t rg = wave / (uint32_t)Cfg::NCH, i0 = rg * R, j = (wave % (uint32_t)Cfg::NCH) * 64u + lane;
+    const uint32_t H = dc.H;
+    const size_t colsz = (size_t)HP * HP;
+    const double unif = 1.0 / ((double)H * (double)H);
+    LxRecs<HP> recs{(const GAS char*)dc.colrec, t0 + 1, (int64_t)C, -1, tid};   // rel r = column t0 + 1 - r
+    v2f64 piece[PPT];
+#pragma unroll
+    for (int p = 0; p < PPT; ++p) recs.park(sh, 0, p, recs.fetch(0, p));
+#pragma unroll
+    for (int p = 0; p < PPT; ++p) piece[p] = recs.fetch(1, p);
+    lds_barrier();
+    lx_transform<HP>(sh, 0, tid);
+    lds_barrier();
+    gdouble* cols = (gdouble*)dc.fwd;
+    gdouble* bscale = (gdouble*)dc.bscale;
+    gdouble* bsum = (gdouble*)dc.bsum;
+    gdouble* wr = cols;
+    gcdouble* resume = (gcdouble*)(cols + (size_t)(top + 1 < (int64_t)C ? top + 1 : top) * colsz);
+    if constexpr (PHASE == 3) {
+        gdouble* scr = (gdouble*)dc.scratch;
+        wr = scr + (size_t)((chunk & 1u) * 2u + 1u) * (size_t)K * colsz - (size_t)bot * colsz;
+        if (chunk > 0) resume = (gcdouble*)(scr + (size_t)(((chunk - 1u) & 1u) * 2u + 1u) * (size_t)K * colsz);
+    }
+    const size_t toff = (size_t)(i0 >> 1) * HP + j;
+    auto store_col = [&](int64_t c, const double (&v)[R]) {
+        gdouble2* dst = (gdouble2*)(wr + (size_t)c * colsz) + toff;
+#pragma unroll
+        for (int k = 0; k < R; k += 2) dst[(size_t)(k >> 1) * HP] = v2f64{v[k], v[k + 1]};
+    };
+    auto gather = [&](uint32_t rel, const LxAlleles<R>& al, double (&e)[R]) __attribute__((always_inline)) {
+        const unsigned char* ecol = lx_rec(sh, rel) + PG_REC_E + al.col8;
+        static_for<0, R>([&](auto kc) __attribute__((always_inline)) { constexpr int k = decltype(kc)::value; e[k] = lx_emission<HP, k>(ecol, al); });
+    };
+
+    ColScalars bsc, bsm;
+    double w[R], e[R], Sy;
+    {
+        double y[R];
+        if constexpr (PHASE == 1) {
+            // column C-1: beta~ = 1 (hmm.cpp:356-358), stored at the backward bias
+            const double B0 = ldexp(1.0, PG_BIAS_B);
+#pragma unroll
+            for (int k = 0; k < R; ++k) y[k] = (j < H && i0 + (uint32_t)k < H) ? B0 : 0.0;
+            Sy = (double)H * (double)H * B0;
+            store_col(top, y);
+            if (tid == 0) { bscale[top] = 1.0; bsum[top] = Sy; }
+        } else {
+            gcdouble2* src = (gcdouble2*)resume + toff;
+#pragma unroll
+            for (int k = 0; k < R; k += 2) { const v2f64 t = src[(size_t)(k >> 1) * HP]; y[k] = t.x; y[k + 1] = t.y; }
+            Sy = bsum[top + 1];
+            if (!(Sy > 0.0)) {  // resuming behind an all-zero column: uniform (hmm.cpp:374-380)
+#pragma unroll
+                for (int k = 0; k < R; ++k) y[k] = (j < H && i0 + (uint32_t)k < H) ? unif : 0.0;
+                Sy = 1.0;
+            }
+        }
+        const LxAlleles<R> a0 = lx_alleles<HP>(sh, 0, j, i0);   // column t0+1: its emission goes into the first w
+        gather(0, a0, e);
+        double part = 0.0;
+#pragma unroll
+        for (int k = 0; k < R; ++k) { w[k] = y[k] * e[k]; part += w[k]; }
+        sh.psum[(uint32_t)t0 & 1u][rg][j] = part;
+    }
+    LxConsts cur = lx_consts<HP>(sh, 0);             // constants of the gap t0 -> t0+1
+    LxAlleles<R> al = lx_alleles<HP>(sh, 1, j, i0);   // alleles of column t0 (its emission: the first step's w)
+    double one = 1.0;   // (in a register for the whole sweep: the DPP form of v_fmac_f64 takes no constant)
+    asm volatile("" : "+v"(one));
+    // One column step: beta'_t from w = e_{t+1} beta'_{t+1} (see lean_backward); `cur` = constants of the gap t -> t+1
+    // (record t+1, rel n), `al` = alleles of column t (rel n + 1).
+    auto step = [&](int64_t t) __attribute__((always_inline)) {
+        const uint32_t n = (uint32_t)(t0 - t);
+        if (((n + 4u) % (uint32_t)BLK) == 0u) {
+            const uint32_t blk = (n + 4u) / (uint32_t)BLK;
+#pragma unroll
+            for (int p = 0; p < PPT; ++p) { recs.park(sh, blk, p, piece[p]); piece[p] = recs.fetch(blk + 1u, p); }
+        } else if (((n + 3u) % (uint32_t)BLK) == 0u) {
+            lx_transform<HP>(sh, (n + 3u) / (uint32_t)BLK, tid);
+        }
+        int es = exponent_of(Sy) - PG_BIAS_B;
+        es = es < -900 ? -900 : es;
+        const double m = ldexp(Sy, -es - PG_BIAS_B);
+        if (wave == 1) { asm volatile("" ::: "memory"); bsc.put(lane, (uint64_t)t, m); }
+        const double k0 = ldexp(cur.c0, -es), k1 = ldexp(cur.c1, -es), k2 = ldexp(cur.c2, -es), kap = ldexp(cur.kappa, -es);
+        lds_barrier();
+        const uint32_t pb = (uint32_t)t & 1u;
+        double pc[4], po[4], pr[NS][4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            pc[q] = sh.psum[pb][q][j];
+            po[q] = Cfg::NCH == 2 ? sh.psum[pb][q][j ^ 64u] : 0.0;
+#pragma unroll
+            for (int s = 0; s < NS; ++s) pr[s][q] = sh.psum[pb][q][i0 + 16u * (uint32_t)s + (lane & 15u)];
+        }
+        lean_fence();
+        gather(n + 1u, al, e);                          // e_t(i0 + k, j)
+        const LxConsts cnx = lx_consts<HP>(sh, n + 1u);  // next step: gap t-1 -> t = record t
+        const LxAlleles<R> anx = lx_alleles<HP>(sh, n + 2u, j, i0);
+        lean_fence();
+        const double Cj = (pc[0] + pc[1]) + (pc[2] + pc[3]);
+        const double Call = Cfg::NCH == 2 ? Cj + ((po[0] + po[1]) + (po[2] + po[3])) : Cj;
+        const v4f64 zz = {0.0, 0.0, 0.0, 0.0};
+        const v4f64 ma = __builtin_amdgcn_mfma_f64_16x16x4f64(Call, 1.0, zz, 0, 0, 0);
+        const double ucol = k1 * Cj;
+        double urep[NS];
+#pragma unroll
+        for (int s = 0; s < NS; ++s) urep[s] = dpp_source(k1 * ((pr[s][0] + pr[s][1]) + (pr[s][2] + pr[s][3])));
+        const double msum = (ma[0] + ma[1]) + (ma[2] + ma[3]);
+        const v4f64 mb = __builtin_amdgcn_mfma_f64_16x16x4f64(msum, 1.0, zz, 0, 0, 0);
+        const double Sw = mb[0];
+        const double uj = fma(k2, Sw, ucol);
+        const double Snew = kap * Sw;  // = sum(beta'_t)
+        Sy = Snew;                     // (1 behind an all-zero column, below)
+        gdouble2* dst = (gdouble2*)(wr + (size_t)t * colsz) + toff;
+        double part = 0.0, yprev = 0.0;
+        static_for<0, R>([&](auto kc) __attribute__((always_inline)) {
+            constexpr int k = decltype(kc)::value;
+            const double yk = fmac_row_bcast<(k & 15)>(fma(k0, w[k], uj), urep[k >> 4], one);  // beta'_t = k0 w + u_j + u_i
+            part = fma(e[k], yk, part);
+            w[k] = e[k] * yk;
+            if constexpr (k & 1) { dst[(size_t)(k >> 1) * HP] = v2f64{yprev, yk}; __builtin_amdgcn_sched_barrier(0); }
+            else yprev = yk;
+        });
+        if (__builtin_expect(!(Snew > 0.0), 0)) {
+            // beta~_t is all zero (every y_k above IS 0, and so is what was stored): its own posteriors are 0, the next
+            // step starts from the uniform column (hmm.cpp:374-380); phantom paths have zero emission
+            part = 0.0;
+#pragma unroll
+            for (int k = 0; k < R; ++k) { w[k] = unif * e[k]; part += w[k]; }
+            Sy = 1.0;
+        }
+        sh.psum[(uint32_t)(t - 1) & 1u][rg][j] = part;
+        if (wave == 2) { asm volatile("" ::: "memory"); bsm.put(lane, (uint64_t)t, Snew); }
+        if (((uint64_t)t & 63u) == 0u) {
+            if (wave == 1) bsc.flush(bscale, lane, (uint64_t)t);
+            if (wave == 2) bsm.flush(bsum, lane, (uint64_t)t);
+        }
+        cur = cnx; al = anx;
+    };
+    __builtin_amdgcn_s_waitcnt(0x0F70);
+    for (int64_t t = t0; t >= bot; --t) step(t);
+    if (wave == 1 && bsc.valid) bsc.flush(bscale, lane, (uint64_t)bot);
+    if (wave == 2 && bsm.valid) bsm.flush(bsum, lane, (uint64_t)bot);
+}
+
+template <int PHASE, int HP>
+__global__ __launch_bounds__((LxCfg<HP>::T)) void k_sweep_leanx(const DevContig* __restrict__ contigs, uint32_t chunk) {
+    __shared__ LxShared<HP> sh;
+    const DevContig& dc = contigs[blockIdx.x];
+    if (!dc.leanx || dc.HP != (uint32_t)HP) return;
+    const uint32_t C = (uint32_t)__builtin_amdgcn_readfirstlane((int)*dc.n_cols);
+    if (C == 0) return;
+    const unsigned long long t_begin = kChainProf ? __builtin_amdgcn_s_memtime() : 0ull;
+    if (blockIdx.y == 0) leanx_forward<PHASE, HP>(dc, sh, C, chunk);
+    else leanx_backward<PHASE, HP>(dc, sh, C, chunk);
+    if (kChainProf && threadIdx.x == 0) {
         unsigned long long* o = dc.prof + (blockIdx.y == 0 ? 0 : 16) + (PHASE == 1 ? 0 : 8);
         o[0] = __builtin_amdgcn_s_memtime() - t_begin;
     }
@@ -4020,6 +4469,8 @@ static void launch_sweep(const DevContig* d_contigs, uint32_t n_contigs, uint32_
                 hipLaunchKernelGGL((k_sweep_lean_tri<PHASE, 16>), dim3(n_contigs, 2), dim3(256), 0, s, d_contigs, chunk);
             else hipLaunchKernelGGL((k_sweep_lean<PHASE, 16, false>), dim3(n_contigs, 2), dim3(256), 0, s, d_contigs, chunk);
         }
+        if (hp_mask & 512u)   // bit 9: the job has lean-x chains (HP = 128, narrow columns only)
+            hipLaunchKernelGGL((k_sweep_leanx<PHASE, 128>), dim3(n_contigs, 2), dim3(LxCfg<128>::T), 0, s, d_contigs, chunk);
         // bit 4: contigs with HP >= 256; bit 5: (forced) the generic kernel for every HP >= 64
         if (hp_mask & 48u)
             hipLaunchKernelGGL(k_sweep_generic<PHASE>, dim3(n_contigs, 2), dim3(PG_GEN_THREADS), 0, s, d_contigs, chunk,

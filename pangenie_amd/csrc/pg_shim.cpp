@@ -209,6 +209,7 @@ namespace {
 struct IndexHost {   // one index contig
     uint32_t V = 0, H = 0, HP = 0, T = 0, RB = 0, part_slots = 2, pair_n = 1;
     bool lean = false;  // every object biallelic and H = HP = 64: the store-only phases run on k_sweep_lean
+    bool leanx = false; // HP = 128 and every object has at most PG_AMAX alleles: the store-only phases run on k_sweep_leanx
     bool small = false; // every object biallelic and H = HP = 16: the store-only phases run on k_sweep_small16
     bool prep_fast = false;  // every object has exactly two alleles and <= 32 k-mers, H <= 64: k_prep_bi
     uint32_t sumK = 0, sumA = 0;
@@ -564,6 +565,10 @@ int job_build(int device, uint32_t n_index, const pg_contig_batch* batches, cons
         if (x.HP >= 256) generic_needed = true;
         x.lean = lean_ok && x.HP == 64 && x.H == 64 && maxA == 2 && x.V > 0;
         x.small = lean_ok && x.HP == 16 && x.H == 16 && maxA == 2 && x.V > 0;   // (and enough of them: below)
+        {
+            const char* e = getenv("PG_LEANX");   // PG_LEANX=0: the general kernel (cross-check)
+            x.leanx = lean_ok && x.HP == 128 && maxA >= 1 && maxA <= PG_AMAX && x.V > 0 && !(e && !strcmp(e, "0"));
+        }
         if (x.V > max_v) max_v = x.V;
     }
     job->max_v = max_v;
@@ -683,6 +688,7 @@ int job_build(int device, uint32_t n_index, const pg_contig_batch* batches, cons
         p.xbuf = take((x.HP >= 256 || (force_generic && x.HP >= 64)) ? (size_t)2 * x.HP * x.HP * sizeof(double) : 0);
         p.frec = take((x.lean || x.small) ? (size_t)x.V * 64 : 0);
         if (x.lean) job->hp_mask |= 64u;
+        if (x.leanx) job->hp_mask |= 512u;
         p.fscale = take((size_t)x.V * sizeof(double));
         p.bscale = take((size_t)x.V * sizeof(double));
         p.bsum = take((size_t)x.V * sizeof(double));
@@ -748,7 +754,7 @@ int job_build(int device, uint32_t n_index, const pg_contig_batch* batches, cons
         d.scratch = (double*)(A + p.scratch); d.chunk_cols = job->chunk_cols;
         d.wide = A + p.wide; d.wide_idx = x.wide_bytes ? (const uint32_t*)(A + x.o_widx) : nullptr;
         d.vpair = A + p.vpair; d.xbuf = (double*)(A + p.xbuf);
-        d.frec = (double*)(A + p.frec); d.lean = x.lean ? 1u : 0u; d.small = x.small ? 1u : 0u;
+        d.frec = (double*)(A + p.frec); d.lean = x.lean ? 1u : 0u; d.small = x.small ? 1u : 0u; d.leanx = x.leanx ? 1u : 0u;
         d.prep_fast = x.prep_fast ? 1u : 0u;
         if (params->run_phasing) {
             d.vit_tq = (double*)(A + p.vtq); d.vit_back = (uint16_t*)(A + p.vback); d.vit_best = (uint32_t*)(A + p.vbest);

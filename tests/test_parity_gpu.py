@@ -341,6 +341,36 @@ def test_lean_kernel_biallelic_h64_vs_oracle_and_general(K, orc, monkeypatch):
         assert float(np.where(den > 0, np.abs(a - c) / np.where(den > 0, den, 1), 0).max()) < 1e-11
 
 
+@pytest.mark.parametrize("mode,K", [("chunked", 1), ("chunked", 2), ("chunked", 7), ("chunked", 19), ("chunked", 4096), ("fused", 0)])
+def test_leanx_kernel_h128_narrow_columns_vs_oracle_and_general(mode, K, orc, monkeypatch):
+    """HP = 128 chains whose objects have at most five alleles run their store-only phases on k_sweep_leanx (full
+    records through LDS in blocks of 16, emissions by table lookup, biallelic and multiallelic columns on one path).
+    128 paths and 100 paths (phantom rows / columns), 30 % multiallelic, regularised and unregularised table (uniform
+    fall-backs and all-zero backward columns on, before and behind chunk and record-block boundaries).  Both kernels
+    must match the oracle and agree with each other to fp64 rounding."""
+    monkeypatch.setenv("PG_SWEEP_MODE", mode)
+    if K:
+        monkeypatch.setenv("PG_CHUNK_COLS", str(K))
+    for seed, H, reg, V in ((5, 128, 0.0, 150), (6, 128, 0.01, 131), (7, 100, 0.0, 90), (8, 100, 0.01, 77)):
+        args = (6, 108, 54, reg)
+        b = synthetic_panel(V, H, 20, seed=seed, multiallelic_frac=0.3)
+        if reg == 0.0:
+            b.kmer_count[::3] = 0
+            b.kmer_count[1::17] = 60000
+        t, p = hmm.ProbabilityTable(*args), hmm.make_params(1.26, False, 1e-5)
+        monkeypatch.delenv("PG_LEANX", raising=False)
+        lx = hmm.genotype_contig(b, t, p)
+        monkeypatch.setenv("PG_LEANX", "0")
+        gen = hmm.genotype_contig(b, t, p)
+        monkeypatch.delenv("PG_LEANX", raising=False)
+        ref = orc.genotype_contig(b, orc.OracleTable(*args), orc.make_params(1.26, False, 1e-5))
+        assert_parity(b, lx, ref)
+        assert_parity(b, gen, ref)
+        a, c = lx.likelihoods_ld(), gen.likelihoods_ld()
+        den = np.maximum(np.abs(a), np.abs(c))
+        assert float(np.where(den > 0, np.abs(a - c) / np.where(den > 0, den, 1), 0).max()) < 1e-11
+
+
 @pytest.mark.parametrize("K", [1, 2, 7, 64, 4096])
 def test_small16_kernel_biallelic_h16_vs_oracle_and_general(K, orc, monkeypatch):
     """All-biallelic H = 16 chains (BASELINE configs[1]) run their store-only phases on k_sweep_small16: four half-chains
