@@ -2983,9 +2983,11 @@ struct LxRecs {
     int64_t origin, C;      // column of rel 0, number of columns
     int dir;                // +1 forward, -1 backward
     uint32_t tid;
+    // (threads past the last piece — only when PIECES is not a multiple of T — fetch the last one again and park nothing:
+    // no branch around the load, so nothing waits for it where it is issued)
     DEVI v2f64 fetch(uint32_t block, int p) const {
-        const uint32_t piece = tid + (uint32_t)p * Cfg::T;
-        if (piece >= (uint32_t)Cfg::PIECES) return v2f64{0.0, 0.0};
+        uint32_t piece = tid + (uint32_t)p * Cfg::T;
+        if constexpr (Cfg::PIECES % Cfg::T != 0) piece = piece < (uint32_t)Cfg::PIECES ? piece : (uint32_t)Cfg::PIECES - 1u;
         const uint32_t q = piece / (uint32_t)(Cfg::RB / 16), w = piece % (uint32_t)(Cfg::RB / 16);
         int64_t c = origin + (int64_t)dir * ((int64_t)block * Cfg::BLK + q);
         c = c < 0 ? 0 : (c >= C ? C - 1 : c);
@@ -2993,7 +2995,7 @@ struct LxRecs {
     }
     DEVI void park(LxShared<HP>& sh, uint32_t block, int p, v2f64 v) const {
         const uint32_t piece = tid + (uint32_t)p * Cfg::T;
-        if (piece < (uint32_t)Cfg::PIECES) ((v2f64*)&sh.rec[block & 1u][0][0])[piece] = v;
+        if (Cfg::PIECES % Cfg::T == 0 || piece < (uint32_t)Cfg::PIECES) ((v2f64*)&sh.rec[block & 1u][0][0])[piece] = v;
     }
 };
 // allele bytes of a freshly parked block -> table row offsets min(a, 5) * 48 (in place)
@@ -3024,9 +3026,19 @@ DEVI LxConsts lx_consts(const LxShared<HP>& sh, uint32_t rel) {
     return LxConsts{q[0], q[1], q[2], q[3]};
 }
 // what a step needs of a column's alleles: the lane's table column (byte offset a_j * 8 inside a table row) and the
-// row offsets of the wave's R rows (R bytes, wave-uniform: kept in scalar registers)
+// row offsets of the wave's R rows (R bytes, the same in every lane: broadcast LDS reads)
 template <int R>
 struct LxAlleles { uint32_t col8; uint32_t rows[R / 4]; };
+// base + byte SEL of `bytes` in ONE instruction (SDWA source select): the LDS address of a state's emission
+template <int SEL>
+DEVI uint32_t add_byte(uint32_t bytes, uint32_t base) {
+    uint32_t r;
+    if constexpr (SEL == 0) asm("v_add_u32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_0 src1_sel:DWORD" : "=v"(r) : "v"(bytes), "v"(base));
+    else if constexpr (SEL == 1) asm("v_add_u32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_1 src1_sel:DWORD" : "=v"(r) : "v"(bytes), "v"(base));
+    else if constexpr (SEL == 2) asm("v_add_u32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_2 src1_sel:DWORD" : "=v"(r) : "v"(bytes), "v"(base));
+    else asm("v_add_u32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_3 src1_sel:DWORD" : "=v"(r) : "v"(bytes), "v"(base));
+    return r;
+}
 template <int HP>
 DEVI LxAlleles<LxCfg<HP>::R> lx_alleles(const LxShared<HP>& sh, uint32_t rel, uint32_t j, uint32_t i0) {
     constexpr int R = LxCfg<HP>::R;
@@ -3034,13 +3046,17 @@ DEVI LxAlleles<LxCfg<HP>::R> lx_alleles(const LxShared<HP>& sh, uint32_t rel, ui
     LxAlleles<R> a;
     a.col8 = ((uint32_t)al[j] * 171u) >> 10;   // (row offset a * 48) / 6 = a * 8, a <= 5
 #pragma unroll
-    for (int q = 0; q < R / 4; ++q) a.rows[q] = (uint32_t)__builtin_amdgcn_readfirstlane((int)((const uint32_t*)(al + i0))[q]);
+    for (int q = 0; q < R / 4; ++q) a.rows[q] = ((const uint32_t*)(al + i0))[q];
     return a;
 }
+// LDS address of the lane's table column inside record `rel`
+template <int HP>
+DEVI uint32_t lx_ecol(const LxShared<HP>& sh, uint32_t rel, uint32_t col8) {
+    return (uint32_t)(uintptr_t)(LAS const unsigned char*)(lx_rec(sh, rel) + PG_REC_E) + col8;
+}
 template <int HP, int K>
-DEVI double lx_emission(const unsigned char* ecol /*record + PG_REC_E + col8, per lane*/, const LxAlleles<LxCfg<HP>::R>& a) {
-    const uint32_t off = (a.rows[K >> 2] >> (8 * (K & 3))) & 0xFFu;   // scalar: s_bfe_u32
-    return *(const double*)(ecol + off);
+DEVI double lx_emission(uint32_t ecol, const LxAlleles<LxCfg<HP>::R>& a) {
+    return *(LAS const double*)(uintptr_t)add_byte<(K & 3)>(a.rows[K >> 2], ecol);
 }
 
 template <int PHASE, int HP>
@@ -3083,6 +3099,11 @@ DEVI void leanx_forward(const DevContig& dc, LxShared<HP>& sh, uint32_t C, uint3
         if (chunk > 0) resume = (gcdouble*)(scr + ((size_t)(((chunk - 1u) & 1u) * 2u) * K + (K - 1u)) * colsz);
     }
     const size_t toff = (size_t)(i0 >> 1) * HP + j;  // this thread's first row pair inside a column (in 16-byte units)
+    // the stores of a step: R/8 per-thread pointers (four row pairs each, reached by immediates), advanced by one column
+    // per step — one 64-bit add each instead of an address computation per store
+    GAS char* sp[R / 8];
+#pragma unroll
+    for (int g = 0; g < R / 8; ++g) sp[g] = (GAS char*)(wr + (size_t)first * colsz) + toff * 16u + (size_t)(4 * g + 2) * (size_t)(HP * 16);
     auto store_col = [&](uint32_t c, const double (&v)[R]) {
         gdouble2* dst = (gdouble2*)(wr + (size_t)c * colsz) + toff;
 #pragma unroll
@@ -3097,16 +3118,16 @@ DEVI void leanx_forward(const DevContig& dc, LxShared<HP>& sh, uint32_t C, uint3
         }
         if (tid == 0) fallback[cprev] = 1;
     };
-    auto gather = [&](uint32_t rel, const LxAlleles<R>& al, double (&e)[R]) __attribute__((always_inline)) {
-        const unsigned char* ecol = lx_rec(sh, rel) + PG_REC_E + al.col8;
-        static_for<0, R>([&](auto kc) __attribute__((always_inline)) { constexpr int k = decltype(kc)::value; e[k] = lx_emission<HP, k>(ecol, al); });
+    auto gather = [&](auto lo_c, auto hi_c, uint32_t ecol, const LxAlleles<R>& al, double (&e)[R]) __attribute__((always_inline)) {
+        static_for<decltype(lo_c)::value, decltype(hi_c)::value>([&](auto kc) __attribute__((always_inline)) { constexpr int k = decltype(kc)::value; e[k] = lx_emission<HP, k>(ecol, al); });
     };
+    using I0 = std::integral_constant<int, 0>; using IH = std::integral_constant<int, R / 2>; using IR = std::integral_constant<int, R>;
 
     ColScalars fsc;
     double x[R], e[R];
     {
         const LxAlleles<R> a0 = lx_alleles<HP>(sh, 0, j, i0);
-        gather(0, a0, e);
+        gather(I0{}, IR{}, lx_ecol<HP>(sh, 0, a0.col8), a0, e);
         double part = 0.0;
         if (lo == 0) {
             const double P0 = ldexp(1.0, PG_BIAS_F);
@@ -3129,7 +3150,10 @@ DEVI void leanx_forward(const DevContig& dc, LxShared<HP>& sh, uint32_t C, uint3
         sh.psum[(first - 1) & 1u][rg][j] = part;
     }
     LxConsts cur = lx_consts<HP>(sh, 1);            // column `first`: constants of the gap first-1 -> first
-    LxAlleles<R> al = lx_alleles<HP>(sh, 1, j, i0);  // and its alleles
+    {
+        const LxAlleles<R> a1 = lx_alleles<HP>(sh, 1, j, i0);   // and its emissions (every step fetches those of the next)
+        gather(I0{}, IR{}, lx_ecol<HP>(sh, 1, a1.col8), a1, e);
+    }
     double one = 1.0;
     asm volatile("" : "+v"(one));
     auto step = [&](uint32_t t) __attribute__((always_inline)) {
@@ -3151,20 +3175,23 @@ DEVI void leanx_forward(const DevContig& dc, LxShared<HP>& sh, uint32_t C, uint3
             for (int s = 0; s < NS; ++s) pr[s][q] = sh.psum[pb][q][i0 + 16u * (uint32_t)s + (lane & 15u)];
         }
         lean_fence();
-        gather(n + 1u, al, e);                          // e_t(i0 + k, j): lands while the total is formed
-        const LxConsts cnx = lx_consts<HP>(sh, n + 2u);
-        const LxAlleles<R> anx = lx_alleles<HP>(sh, n + 2u, j, i0);
-        lean_fence();
         const double Cj = (pc[0] + pc[1]) + (pc[2] + pc[3]);
         const double Call = Cfg::NCH == 2 ? Cj + ((po[0] + po[1]) + (po[2] + po[3])) : Cj;
         const v4f64 zz = {0.0, 0.0, 0.0, 0.0};
         const v4f64 ma = __builtin_amdgcn_mfma_f64_16x16x4f64(Call, 1.0, zz, 0, 0, 0);
+        // (in the shadows of the two MFMAs of the total: the u terms, the next column's constants and alleles)
         const double ucol = cur.c1 * Cj;
         double urep[NS];
 #pragma unroll
         for (int s = 0; s < NS; ++s) urep[s] = dpp_source(cur.c1 * ((pr[s][0] + pr[s][1]) + (pr[s][2] + pr[s][3])));
+        const LxConsts cnx = lx_consts<HP>(sh, n + 2u);
+        const LxAlleles<R> anx = lx_alleles<HP>(sh, n + 2u, j, i0);
+        lean_fence();
         const double msum = (ma[0] + ma[1]) + (ma[2] + ma[3]);
         const v4f64 mb = __builtin_amdgcn_mfma_f64_16x16x4f64(msum, 1.0, zz, 0, 0, 0);
+        const uint32_t ecoln = lx_ecol<HP>(sh, n + 2u, anx.col8);   // the lane's table column of the NEXT column
+        asm volatile("" :: "v"(mb));   // (the whole result stays allocated: a temporary in one of its registers would wait out the MFMA)
+        lean_fence();
         double S = mb[0];
         double uj = fma(cur.c2, S, ucol);
         double c0 = cur.c0;
@@ -3180,14 +3207,18 @@ DEVI void leanx_forward(const DevContig& dc, LxShared<HP>& sh, uint32_t C, uint3
         es = es < -900 ? -900 : es;
         const double m = ldexp(S, -es - PG_BIAS_F);
         const double sc = ldexp(1.0, -es), c0s = ldexp(c0, -es), ujs = ldexp(uj, -es);
-        gdouble2* dst = (gdouble2*)(wr + (size_t)t * colsz) + toff;
         double part = 0.0, pprev = 0.0;
         static_for<0, R>([&](auto kc) __attribute__((always_inline)) {
             constexpr int k = decltype(kc)::value;
             const double pk = fmac_row_bcast<(k & 15)>(fma(c0s, x[k], ujs), urep[k >> 4], sc);   // P'_t(i0 + k, j) 2^-es
             part = fma(e[k], pk, part);
             x[k] = e[k] * pk;
-            if constexpr (k & 1) { dst[(size_t)(k >> 1) * HP] = v2f64{pprev, pk}; __builtin_amdgcn_sched_barrier(0); }
+            pin_here(x[k]);
+            e[k] = lx_emission<HP, k>(ecoln, anx);   // e_{t+1}(i0 + k, j): the LDS reads of the next step ride under this step's arithmetic
+            if constexpr (k & 1) {
+                *(gdouble2*)(sp[k >> 3] + (((k >> 1) & 3) - 2) * (HP * 16)) = v2f64{pprev, pk};
+                __builtin_amdgcn_sched_barrier(0);
+            }
             else pprev = pk;
         });
         sh.psum[t & 1u][rg][j] = part;
@@ -3195,7 +3226,9 @@ DEVI void leanx_forward(const DevContig& dc, LxShared<HP>& sh, uint32_t C, uint3
             fsc.put(lane, t, m);
             if ((t & 63u) == 63u) fsc.flush(fscale, lane, t);
         }
-        cur = cnx; al = anx;
+        cur = cnx;
+#pragma unroll
+        for (int g = 0; g < R / 8; ++g) { sp[g] += colsz * 8u; asm("" : "+v"(sp[g])); }   // (opaque: kept as R/8 separate induction pointers)
         lds_barrier();
     };
     __builtin_amdgcn_s_waitcnt(0x0F70);   // (no load of the prologue in flight inside the loop: see lean_forward)
@@ -3251,15 +3284,16 @@ DEVI void leanx_backward(const DevContig& dc, LxShared<HP>& sh, uint32_t C, uint
         if (chunk > 0) resume = (gcdouble*)(scr + (size_t)(((chunk - 1u) & 1u) * 2u + 1u) * (size_t)K * colsz);
     }
     const size_t toff = (size_t)(i0 >> 1) * HP + j;
+    GAS char* sp[R / 8];   // (see leanx_forward; filled in below, once `wr` is known)
     auto store_col = [&](int64_t c, const double (&v)[R]) {
         gdouble2* dst = (gdouble2*)(wr + (size_t)c * colsz) + toff;
 #pragma unroll
         for (int k = 0; k < R; k += 2) dst[(size_t)(k >> 1) * HP] = v2f64{v[k], v[k + 1]};
     };
-    auto gather = [&](uint32_t rel, const LxAlleles<R>& al, double (&e)[R]) __attribute__((always_inline)) {
-        const unsigned char* ecol = lx_rec(sh, rel) + PG_REC_E + al.col8;
-        static_for<0, R>([&](auto kc) __attribute__((always_inline)) { constexpr int k = decltype(kc)::value; e[k] = lx_emission<HP, k>(ecol, al); });
+    auto gather = [&](auto lo_c, auto hi_c, uint32_t ecol, const LxAlleles<R>& al, double (&e)[R]) __attribute__((always_inline)) {
+        static_for<decltype(lo_c)::value, decltype(hi_c)::value>([&](auto kc) __attribute__((always_inline)) { constexpr int k = decltype(kc)::value; e[k] = lx_emission<HP, k>(ecol, al); });
     };
+    using I0 = std::integral_constant<int, 0>; using IH = std::integral_constant<int, R / 2>; using IR = std::integral_constant<int, R>;
 
     ColScalars bsc, bsm;
     double w[R], e[R], Sy;
@@ -3285,14 +3319,17 @@ DEVI void leanx_backward(const DevContig& dc, LxShared<HP>& sh, uint32_t C, uint
             }
         }
         const LxAlleles<R> a0 = lx_alleles<HP>(sh, 0, j, i0);   // column t0+1: its emission goes into the first w
-        gather(0, a0, e);
+        gather(I0{}, IR{}, lx_ecol<HP>(sh, 0, a0.col8), a0, e);
         double part = 0.0;
 #pragma unroll
         for (int k = 0; k < R; ++k) { w[k] = y[k] * e[k]; part += w[k]; }
         sh.psum[(uint32_t)t0 & 1u][rg][j] = part;
     }
     LxConsts cur = lx_consts<HP>(sh, 0);             // constants of the gap t0 -> t0+1
-    LxAlleles<R> al = lx_alleles<HP>(sh, 1, j, i0);   // alleles of column t0 (its emission: the first step's w)
+    {
+        const LxAlleles<R> a1 = lx_alleles<HP>(sh, 1, j, i0);   // emissions of column t0 (the first step's w); every step fetches the next
+        gather(I0{}, IR{}, lx_ecol<HP>(sh, 1, a1.col8), a1, e);
+    }
     double one = 1.0;   // (in a register for the whole sweep: the DPP form of v_fmac_f64 takes no constant)
     asm volatile("" : "+v"(one));
     // One column step: beta'_t from w = e_{t+1} beta'_{t+1} (see lean_backward); `cur` = constants of the gap t -> t+1
@@ -3322,10 +3359,6 @@ DEVI void leanx_backward(const DevContig& dc, LxShared<HP>& sh, uint32_t C, uint
             for (int s = 0; s < NS; ++s) pr[s][q] = sh.psum[pb][q][i0 + 16u * (uint32_t)s + (lane & 15u)];
         }
         lean_fence();
-        gather(n + 1u, al, e);                          // e_t(i0 + k, j)
-        const LxConsts cnx = lx_consts<HP>(sh, n + 1u);  // next step: gap t-1 -> t = record t
-        const LxAlleles<R> anx = lx_alleles<HP>(sh, n + 2u, j, i0);
-        lean_fence();
         const double Cj = (pc[0] + pc[1]) + (pc[2] + pc[3]);
         const double Call = Cfg::NCH == 2 ? Cj + ((po[0] + po[1]) + (po[2] + po[3])) : Cj;
         const v4f64 zz = {0.0, 0.0, 0.0, 0.0};
@@ -3334,28 +3367,42 @@ DEVI void leanx_backward(const DevContig& dc, LxShared<HP>& sh, uint32_t C, uint
         double urep[NS];
 #pragma unroll
         for (int s = 0; s < NS; ++s) urep[s] = dpp_source(k1 * ((pr[s][0] + pr[s][1]) + (pr[s][2] + pr[s][3])));
+        const LxConsts cnx = lx_consts<HP>(sh, n + 1u);  // next step: gap t-1 -> t = record t
+        const LxAlleles<R> anx = lx_alleles<HP>(sh, n + 2u, j, i0);   // and the emission of column t-1
+        lean_fence();
         const double msum = (ma[0] + ma[1]) + (ma[2] + ma[3]);
         const v4f64 mb = __builtin_amdgcn_mfma_f64_16x16x4f64(msum, 1.0, zz, 0, 0, 0);
+        const uint32_t ecoln = lx_ecol<HP>(sh, n + 2u, anx.col8);
+        asm volatile("" :: "v"(mb));
+        lean_fence();
         const double Sw = mb[0];
         const double uj = fma(k2, Sw, ucol);
         const double Snew = kap * Sw;  // = sum(beta'_t)
         Sy = Snew;                     // (1 behind an all-zero column, below)
-        gdouble2* dst = (gdouble2*)(wr + (size_t)t * colsz) + toff;
         double part = 0.0, yprev = 0.0;
         static_for<0, R>([&](auto kc) __attribute__((always_inline)) {
             constexpr int k = decltype(kc)::value;
             const double yk = fmac_row_bcast<(k & 15)>(fma(k0, w[k], uj), urep[k >> 4], one);  // beta'_t = k0 w + u_j + u_i
             part = fma(e[k], yk, part);
             w[k] = e[k] * yk;
-            if constexpr (k & 1) { dst[(size_t)(k >> 1) * HP] = v2f64{yprev, yk}; __builtin_amdgcn_sched_barrier(0); }
+            pin_here(w[k]);
+            e[k] = lx_emission<HP, k>(ecoln, anx);   // e_{t-1}(i0 + k, j) for the next step
+            if constexpr (k & 1) {
+                *(gdouble2*)(sp[k >> 3] + (((k >> 1) & 3) - 2) * (HP * 16)) = v2f64{yprev, yk};
+                __builtin_amdgcn_sched_barrier(0);
+            }
             else yprev = yk;
         });
         if (__builtin_expect(!(Snew > 0.0), 0)) {
             // beta~_t is all zero (every y_k above IS 0, and so is what was stored): its own posteriors are 0, the next
             // step starts from the uniform column (hmm.cpp:374-380); phantom paths have zero emission
+            // (e[] holds the next column's emissions by now: this column's are fetched again)
+            const LxAlleles<R> at = lx_alleles<HP>(sh, n + 1u, j, i0);
+            double et[R];
+            gather(I0{}, IR{}, lx_ecol<HP>(sh, n + 1u, at.col8), at, et);
             part = 0.0;
 #pragma unroll
-            for (int k = 0; k < R; ++k) { w[k] = unif * e[k]; part += w[k]; }
+            for (int k = 0; k < R; ++k) { w[k] = unif * et[k]; part += w[k]; }
             Sy = 1.0;
         }
         sh.psum[(uint32_t)(t - 1) & 1u][rg][j] = part;
@@ -3364,8 +3411,12 @@ DEVI void leanx_backward(const DevContig& dc, LxShared<HP>& sh, uint32_t C, uint
             if (wave == 1) bsc.flush(bscale, lane, (uint64_t)t);
             if (wave == 2) bsm.flush(bsum, lane, (uint64_t)t);
         }
-        cur = cnx; al = anx;
+        cur = cnx;
+#pragma unroll
+        for (int g = 0; g < R / 8; ++g) { sp[g] -= colsz * 8u; asm("" : "+v"(sp[g])); }
     };
+#pragma unroll
+    for (int g = 0; g < R / 8; ++g) sp[g] = (GAS char*)(wr + (size_t)t0 * colsz) + toff * 16u + (size_t)(4 * g + 2) * (size_t)(HP * 16);
     __builtin_amdgcn_s_waitcnt(0x0F70);
     for (int64_t t = t0; t >= bot; --t) step(t);
     if (wave == 1 && bsc.valid) bsc.flush(bscale, lane, (uint64_t)bot);
