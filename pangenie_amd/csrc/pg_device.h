@@ -149,8 +149,8 @@ struct DevContig {
     // 1: every object of the chain is biallelic and H = HP = 16: the store-only phases run on k_sweep_small16 (four
     // half-chains per wave); the chain keeps its compact records (frec) next to the full ones
     uint32_t  small;
-    // 1: HP = 128 and every object has at most PG_AMAX alleles (all columns narrow): the store-only phases run on
-    // k_sweep_leanx (the lean step with table emissions)
+    // 1: HP = 128 or 64, every object has at most PG_AMAX alleles (all columns narrow) and the chain is not `lean`: the
+    // store-only phases run on k_sweep_leanx (the lean step with table emissions)
     uint32_t  leanx;
     double*   xbuf;            // [2][HP*HP] generic kernel scratch (forward role first)
     uint32_t* err;

@@ -3059,6 +3059,10 @@ DEVI double lx_emission(uint32_t ecol, const LxAlleles<LxCfg<HP>::R>& a) {
     return *(LAS const double*)(uintptr_t)add_byte<(K & 3)>(a.rows[K >> 2], ecol);
 }
 
+#ifndef PG_LX_EXP
+#define PG_LX_EXP 0
+#endif
+static constexpr unsigned kLxExp = PG_LX_EXP;   // timing experiments (tools/exp_leanx.py): 1 no column stores, 2 no emission fetches — results WRONG
 template <int PHASE, int HP>
 DEVI void leanx_forward(const DevContig& dc, LxShared<HP>& sh, uint32_t C, uint32_t chunk) {
     using Cfg = LxCfg<HP>;
@@ -3214,9 +3218,9 @@ DEVI void leanx_forward(const DevContig& dc, LxShared<HP>& sh, uint32_t C, uint3
             part = fma(e[k], pk, part);
             x[k] = e[k] * pk;
             pin_here(x[k]);
-            e[k] = lx_emission<HP, k>(ecoln, anx);   // e_{t+1}(i0 + k, j): the LDS reads of the next step ride under this step's arithmetic
+            if (!(kLxExp & 2)) e[k] = lx_emission<HP, k>(ecoln, anx);   // e_{t+1}(i0 + k, j): the LDS reads of the next step ride under this step's arithmetic
             if constexpr (k & 1) {
-                *(gdouble2*)(sp[k >> 3] + (((k >> 1) & 3) - 2) * (HP * 16)) = v2f64{pprev, pk};
+                if (!(kLxExp & 1)) *(gdouble2*)(sp[k >> 3] + (((k >> 1) & 3) - 2) * (HP * 16)) = v2f64{pprev, pk};
                 __builtin_amdgcn_sched_barrier(0);
             }
             else pprev = pk;
@@ -3386,9 +3390,9 @@ DEVI void leanx_backward(const DevContig& dc, LxShared<HP>& sh, uint32_t C, uint
             part = fma(e[k], yk, part);
             w[k] = e[k] * yk;
             pin_here(w[k]);
-            e[k] = lx_emission<HP, k>(ecoln, anx);   // e_{t-1}(i0 + k, j) for the next step
+            if (!(kLxExp & 2)) e[k] = lx_emission<HP, k>(ecoln, anx);   // e_{t-1}(i0 + k, j) for the next step
             if constexpr (k & 1) {
-                *(gdouble2*)(sp[k >> 3] + (((k >> 1) & 3) - 2) * (HP * 16)) = v2f64{yprev, yk};
+                if (!(kLxExp & 1)) *(gdouble2*)(sp[k >> 3] + (((k >> 1) & 3) - 2) * (HP * 16)) = v2f64{yprev, yk};
                 __builtin_amdgcn_sched_barrier(0);
             }
             else yprev = yk;
@@ -4520,8 +4524,10 @@ static void launch_sweep(const DevContig* d_contigs, uint32_t n_contigs, uint32_
                 hipLaunchKernelGGL((k_sweep_lean_tri<PHASE, 16>), dim3(n_contigs, 2), dim3(256), 0, s, d_contigs, chunk);
             else hipLaunchKernelGGL((k_sweep_lean<PHASE, 16, false>), dim3(n_contigs, 2), dim3(256), 0, s, d_contigs, chunk);
         }
-        if (hp_mask & 512u)   // bit 9: the job has lean-x chains (HP = 128, narrow columns only)
+        if (hp_mask & 512u)   // bit 9: the job has lean-x chains at HP = 128 (narrow columns only)
             hipLaunchKernelGGL((k_sweep_leanx<PHASE, 128>), dim3(n_contigs, 2), dim3(LxCfg<128>::T), 0, s, d_contigs, chunk);
+        if (hp_mask & 1024u)  // bit 10: ... at HP = 64 (chains with multiallelic objects; all-biallelic H = 64 chains are bit 6)
+            hipLaunchKernelGGL((k_sweep_leanx<PHASE, 64>), dim3(n_contigs, 2), dim3(LxCfg<64>::T), 0, s, d_contigs, chunk);
         // bit 4: contigs with HP >= 256; bit 5: (forced) the generic kernel for every HP >= 64
         if (hp_mask & 48u)
             hipLaunchKernelGGL(k_sweep_generic<PHASE>, dim3(n_contigs, 2), dim3(PG_GEN_THREADS), 0, s, d_contigs, chunk,

@@ -209,7 +209,7 @@ namespace {
 struct IndexHost {   // one index contig
     uint32_t V = 0, H = 0, HP = 0, T = 0, RB = 0, part_slots = 2, pair_n = 1;
     bool lean = false;  // every object biallelic and H = HP = 64: the store-only phases run on k_sweep_lean
-    bool leanx = false; // HP = 128 and every object has at most PG_AMAX alleles: the store-only phases run on k_sweep_leanx
+    bool leanx = false; // HP = 128 / 64 and every object has at most PG_AMAX alleles (not `lean`): the store-only phases run on k_sweep_leanx
     bool small = false; // every object biallelic and H = HP = 16: the store-only phases run on k_sweep_small16
     bool prep_fast = false;  // every object has exactly two alleles and <= 32 k-mers, H <= 64: k_prep_bi
     uint32_t sumK = 0, sumA = 0;
@@ -567,7 +567,7 @@ int job_build(int device, uint32_t n_index, const pg_contig_batch* batches, cons
         x.small = lean_ok && x.HP == 16 && x.H == 16 && maxA == 2 && x.V > 0;   // (and enough of them: below)
         {
             const char* e = getenv("PG_LEANX");   // PG_LEANX=0: the general kernel (cross-check)
-            x.leanx = lean_ok && x.HP == 128 && maxA >= 1 && maxA <= PG_AMAX && x.V > 0 && !(e && !strcmp(e, "0"));
+            x.leanx = lean_ok && (x.HP == 128 || x.HP == 64) && !x.lean && maxA >= 1 && maxA <= PG_AMAX && x.V > 0 && !(e && !strcmp(e, "0"));
         }
         if (x.V > max_v) max_v = x.V;
     }
@@ -688,7 +688,7 @@ int job_build(int device, uint32_t n_index, const pg_contig_batch* batches, cons
         p.xbuf = take((x.HP >= 256 || (force_generic && x.HP >= 64)) ? (size_t)2 * x.HP * x.HP * sizeof(double) : 0);
         p.frec = take((x.lean || x.small) ? (size_t)x.V * 64 : 0);
         if (x.lean) job->hp_mask |= 64u;
-        if (x.leanx) job->hp_mask |= 512u;
+        if (x.leanx) job->hp_mask |= x.HP == 128 ? 512u : 1024u;
         p.fscale = take((size_t)x.V * sizeof(double));
         p.bscale = take((size_t)x.V * sizeof(double));
         p.bsum = take((size_t)x.V * sizeof(double));

@@ -342,16 +342,16 @@ def test_lean_kernel_biallelic_h64_vs_oracle_and_general(K, orc, monkeypatch):
 
 
 @pytest.mark.parametrize("mode,K", [("chunked", 1), ("chunked", 2), ("chunked", 7), ("chunked", 19), ("chunked", 4096), ("fused", 0)])
-def test_leanx_kernel_h128_narrow_columns_vs_oracle_and_general(mode, K, orc, monkeypatch):
-    """HP = 128 chains whose objects have at most five alleles run their store-only phases on k_sweep_leanx (full
-    records through LDS in blocks of 16, emissions by table lookup, biallelic and multiallelic columns on one path).
-    128 paths and 100 paths (phantom rows / columns), 30 % multiallelic, regularised and unregularised table (uniform
+def test_leanx_kernel_narrow_columns_vs_oracle_and_general(mode, K, orc, monkeypatch):
+    """HP = 128 chains — and HP = 64 chains with multiallelic objects — whose objects have at most five alleles run their
+    store-only phases on k_sweep_leanx (full records through LDS in blocks of 16, emissions by table lookup, biallelic and
+    multiallelic columns on one path).  128 / 100 paths and 64 / 50 paths (phantom rows / columns), 30 % multiallelic, regularised and unregularised table (uniform
     fall-backs and all-zero backward columns on, before and behind chunk and record-block boundaries).  Both kernels
     must match the oracle and agree with each other to fp64 rounding."""
     monkeypatch.setenv("PG_SWEEP_MODE", mode)
     if K:
         monkeypatch.setenv("PG_CHUNK_COLS", str(K))
-    for seed, H, reg, V in ((5, 128, 0.0, 150), (6, 128, 0.01, 131), (7, 100, 0.0, 90), (8, 100, 0.01, 77)):
+    for seed, H, reg, V in ((5, 128, 0.0, 150), (6, 128, 0.01, 131), (7, 100, 0.0, 90), (8, 100, 0.01, 77), (9, 64, 0.0, 140), (10, 50, 0.01, 117)):
         args = (6, 108, 54, reg)
         b = synthetic_panel(V, H, 20, seed=seed, multiallelic_frac=0.3)
         if reg == 0.0:

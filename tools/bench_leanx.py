@@ -12,8 +12,8 @@ from pangenie_amd.panel import default_table_args, synthetic_panel  # noqa: E402
 V = int(sys.argv[1]) if len(sys.argv) > 1 else 20000
 table = hmm.ProbabilityTable(*default_table_args())
 params = hmm.make_params(1.26, False, 1e-5)
-for H in (128, 100):
-    for multi in (0.0, 0.2, 1.0):
+for H in (128, 64, 50):
+    for multi in ((0.2, 1.0) if H != 128 else (0.0, 0.2)):
         b = synthetic_panel(V, H, 20, seed=77, multiallelic_frac=multi)
         out = {}
         for lx in ("1", "0"):
