@@ -2064,14 +2064,9 @@ __global__ __launch_bounds__((ChainCfg<HP, R>::TT)) void k_sweep(const DevContig
 //      six DPP steps (~26 instructions).  D = A x 1 sums the four 16-lane groups; the second product
 //      sums the sixteen rows (C/D layout of v_mfma_f64_16x16x4: row = (lane >> 4) + 4 reg, col = lane & 15).
 //      This is a reduction, not a contraction of the model: the recursion itself stays rank-structured.
-//    * row-allele selects by scalar-built lane masks (s_bfe_i64 of the row bits), stores with immediate
-//      offsets off two per-thread bases.
+//    * emissions by row pairs: one SDWA add + one 16-byte LDS read per pair out of a table built when the block of
+//      records is parked (lean_expand), fetched a step ahead; stores with immediate offsets off two per-thread bases.
 // ------------------------------------------------------------------------------------------
-// how many of a step's sixteen product-column multiplies are deferred into the next step (behind its second MFMA)
-#ifndef PG_LEAN_DEFER
-#define PG_LEAN_DEFER 8
-#endif
-static constexpr int kLeanDefer = PG_LEAN_DEFER;
 #define PG_LEAN_BLOCK 64  // column records per LDS block (one 16-byte piece per thread: 64 x 64 B = 256 x 16 B)
 template <int R>
 struct LeanShared {
@@ -2079,6 +2074,10 @@ struct LeanShared {
     double psum[2][NW][64];
     double u[NW][64] __attribute__((aligned(16)));
     double rec[2][PG_LEAN_BLOCK][8] __attribute__((aligned(16)));  // two blocks of compact records
+    // emissions by ROW PAIRS (lean_expand): tab[b][r][c][a] = {e(row 2p, column allele a), e(row 2p+1, a)} for the row
+    // pair's allele combination c = bit(2p) + 2 bit(2p+1); comb[b][r][w][p] = 32 c of pair p of wave w's rows
+    v2f64 tab[2][PG_LEAN_BLOCK][4][2];
+    unsigned char comb[2][PG_LEAN_BLOCK][NW][R / 2] __attribute__((aligned(8)));
 };
 struct FRec {  // compact column record (64 B)
     double c0, c1, c2, kappa, E00, E01, E11;
@@ -2202,6 +2201,63 @@ template <int K, int N, class F>
 DEVI void static_for(F&& f) {
     if constexpr (K < N) { f(std::integral_constant<int, K>{}); static_for<K + 1, N>(f); }
 }
+// base + byte SEL of `bytes` in ONE instruction (SDWA source select): the LDS address of a state's emission
+template <int SEL>
+DEVI uint32_t add_byte(uint32_t bytes, uint32_t base) {
+    uint32_t r;
+    if constexpr (SEL == 0) asm("v_add_u32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_0 src1_sel:DWORD" : "=v"(r) : "v"(bytes), "v"(base));
+    else if constexpr (SEL == 1) asm("v_add_u32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_1 src1_sel:DWORD" : "=v"(r) : "v"(bytes), "v"(base));
+    else if constexpr (SEL == 2) asm("v_add_u32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_2 src1_sel:DWORD" : "=v"(r) : "v"(bytes), "v"(base));
+    else asm("v_add_u32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_3 src1_sel:DWORD" : "=v"(r) : "v"(bytes), "v"(base));
+    return r;
+}
+// The lean step takes the emissions of a column by row PAIRS: a pair of rows has one of four allele combinations, a lane
+// (column) one of two alleles, so the eight possible {e(row 2p, j), e(row 2p+1, j)} of a column record are laid out as a
+// 128-byte table when its block is parked, next to one byte per row pair (32 x combination: the offset into the table).
+// A pair's two emissions are then ONE SDWA add (lane's table column + the pair's byte) and ONE 16-byte LDS read —
+// where bit test, mask and two selects per row took six instructions per pair.
+template <class SH>
+DEVI void lean_expand(SH& sh, uint32_t block /*uniform*/, uint32_t tid) {
+    static_assert(sizeof(sh.comb[0][0]) == 32, "four waves of eight row pairs");
+    if (tid >= 256u) return;
+    const uint32_t b = block & 1u;
+    {
+        const uint32_t r = tid >> 2, c = tid & 3u;   // two of the block's 512 table entries per thread: (r, c, column allele 0 / 1)
+        const double* rc = sh.rec[b][r];
+        const double E00 = rc[4], E01 = rc[5], E11 = rc[6];
+        sh.tab[b][r][c][0] = v2f64{(c & 1u) ? E01 : E00, (c & 2u) ? E01 : E00};
+        sh.tab[b][r][c][1] = v2f64{(c & 1u) ? E11 : E01, (c & 2u) ? E11 : E01};
+    }
+    {
+        const uint32_t r = tid >> 2, w = tid & 3u;   // the eight pair bytes of wave w's rows of record r
+        const unsigned long long bits = (unsigned long long)__double_as_longlong(sh.rec[b][r][7]);
+        const uint32_t b16 = (uint32_t)(bits >> (16u * w)) & 0xFFFFu;
+        auto spread = [](uint32_t v8) { return ((v8 & 3u) | (((v8 >> 2) & 3u) << 8) | (((v8 >> 4) & 3u) << 16) | (((v8 >> 6) & 3u) << 24)) << 5; };
+        typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+        *(u32x2*)&sh.comb[b][r][w][0] = u32x2{spread(b16 & 0xFFu), spread(b16 >> 8)};
+    }
+}
+// what a step needs to fetch the emissions of column `rel`: the lane's table column and the wave's pair bytes
+struct LeanPairs { uint32_t tbase, cd0, cd1; };
+typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+template <class SH>
+DEVI u32x2 lean_pair_bytes(const SH& sh, uint32_t rel /*uniform*/, uint32_t wave /*uniform*/) {   // (one broadcast LDS read: issue it early)
+    return *(const u32x2*)&sh.comb[(rel / PG_LEAN_BLOCK) & 1u][rel % PG_LEAN_BLOCK][wave][0];
+}
+template <class SH>
+DEVI LeanPairs lean_pairs(const SH& sh, uint32_t rel /*uniform*/, u32x2 cd, uint32_t aj /*0 / 1: the lane's column allele*/) {
+    return LeanPairs{(uint32_t)(uintptr_t)(LAS const unsigned char*)&sh.tab[(rel / PG_LEAN_BLOCK) & 1u][rel % PG_LEAN_BLOCK][0][0] + aj * 16u, cd.x, cd.y};
+}
+template <class SH>
+DEVI LeanPairs lean_pairs(const SH& sh, uint32_t rel, uint32_t wave, uint32_t aj) { return lean_pairs(sh, rel, lean_pair_bytes(sh, rel, wave), aj); }
+template <int P>
+DEVI v2f64 lean_pair(const LeanPairs& lp) {
+    return *(LAS const v2f64*)(uintptr_t)add_byte<(P & 3)>(P < 4 ? lp.cd0 : lp.cd1, lp.tbase);
+}
+template <int R>
+DEVI void lean_pairs_all(const LeanPairs& lp, double (&e)[R]) {
+    static_for<0, R / 2>([&](auto pc) __attribute__((always_inline)) { constexpr int q = decltype(pc)::value; const v2f64 t = lean_pair<q>(lp); e[2 * q] = t.x; e[2 * q + 1] = t.y; });
+}
 template <int R>
 DEVI double lean_colsum(const LeanShared<R>& sh, uint32_t pb, uint32_t lane) {
     if constexpr (R == 16)
@@ -2211,10 +2267,13 @@ DEVI double lean_colsum(const LeanShared<R>& sh, uint32_t pb, uint32_t lane) {
                ((sh.psum[pb][4][lane] + sh.psum[pb][5][lane]) + (sh.psum[pb][6][lane] + sh.psum[pb][7][lane]));
 }
 
+#ifndef PG_LEAN_EXP
+#define PG_LEAN_EXP 0
+#endif
+static constexpr unsigned kLeanExp = PG_LEAN_EXP;   // timing experiments (tools/exp_lean.py): 1 no column stores, 2 no emission fetches, 4 no MFMA total — results WRONG
 template <int PHASE, int R, bool TRI>
 DEVI void lean_forward(const DevContig& dc, LeanShared<R>& sh, uint32_t C, uint32_t chunk) {
     constexpr int HP = 64;
-    constexpr int DEFER = TRI ? 0 : kLeanDefer;   // (triangle chains run two workgroups per CU: registers before shadows)
     constexpr uint32_t RMASK = (1u << R) - 1u;
     const uint32_t mid = C / 2, K = dc.chunk_cols;
     uint32_t lo = PHASE == 1 ? 0u : mid, hi = PHASE == 1 ? mid : C;
@@ -2234,6 +2293,8 @@ DEVI void lean_forward(const DevContig& dc, LeanShared<R>& sh, uint32_t C, uint3
     LeanRecs recs{(const GAS char*)dc.frec, (int64_t)first - 1, (int64_t)C, +1, tid};
     recs.park(sh, 0, recs.fetch(0));
     v2f64 piece = recs.fetch(1);
+    lds_barrier();
+    lean_expand(sh, 0, tid);
     lds_barrier();
     gdouble* fwd = (gdouble*)dc.fwd;
     gdouble* fscale = (gdouble*)dc.fscale;
@@ -2317,24 +2378,33 @@ DEVI void lean_forward(const DevContig& dc, LeanShared<R>& sh, uint32_t C, uint3
         }
         sh.psum[(first - 1) & 1u][wave][lane] = part;
     }
-    double ee[R], pp[R];  // emission factor and column entry of the last step: x = ee pp
-#pragma unroll
-    for (int k = 0; k < R; ++k) { ee[k] = 1.0; pp[k] = x[k]; }
-    // One column step.  `cur` = record of this step (constants of the gap t-1 -> t, emission of column t), `nxt` takes
-    // the record of the next step (four broadcast LDS reads, a whole step ahead of use); the loop calls the step twice
-    // with the two record variables in swapped roles, so no record is ever moved.
+    // Emissions of a column are fetched by row pairs (lean_pairs) DURING the previous step: a pair's next emissions are
+    // read right after its two states used the current ones, so the LDS reads ride under the following pairs' arithmetic.
+    // (Measured alternatives: all eight reads in the shadow of the second MFMA into a second array: 696 instead of 604 ns
+    // per column — they sit in front of the total's consumer; product-column multiplies deferred into that shadow: 656.)
+    double ec[R];
+    {
+        const FRec r1 = read_frec(sh, 1);
+        lean_pairs_all<R>(lean_pairs(sh, 1, wave, (uint32_t)((r1.bits1 >> lane) & 1ull)), ec);   // column `first`
+    }
+    // One column step.  `cur` = record of this step (constants of the gap t-1 -> t), `nxt` takes the record of the next
+    // step (four broadcast LDS reads, a whole step ahead of use); the loop calls the step twice with the two record
+    // variables and the two emission arrays in swapped roles, so nothing is ever moved.
     auto step = [&](uint32_t t, const FRec& cur, FRec& nxt) __attribute__((always_inline)) {
         const uint32_t n = t - first;                 // step number: reads the record with rel = n + 2
         nxt = read_frec(sh, n + 2u);
+        const u32x2 cdn = lean_pair_bytes(sh, n + 2u, wave);
         if (((n + 4u) % PG_LEAN_BLOCK) == 0u) {       // (uniform) a few columns before the next block is needed
             const uint32_t blk = (n + 4u) / PG_LEAN_BLOCK;
             recs.park(sh, blk, piece);
             piece = recs.fetch(blk + 1u);
+        } else if (((n + 3u) % PG_LEAN_BLOCK) == 0u) {
+            lean_expand(sh, (n + 3u) / PG_LEAN_BLOCK, tid);   // the block parked a step ago (a barrier lies between)
         }
         const uint32_t pb = (t - 1) & 1u;
         // both column sums' partials are fetched up front (this lane's column; the column of index i0 + (lane & 15):
         // the DPP source of the wave's sixteen u_i); everything that does not need the total S — the second sum, the
-        // emission pair, the row bits — is issued between the two MFMAs of the total and fills their latency
+        // next column's table address and pair bytes — is issued between the two MFMAs of the total and fills their latency
         double pc[64 / R], pr[64 / R];
 #pragma unroll
         for (int q = 0; q < 64 / R; ++q) { pc[q] = sh.psum[pb][q][lane]; pr[q] = sh.psum[pb][q][i0 + (lane & 15u)]; }
@@ -2344,19 +2414,13 @@ DEVI void lean_forward(const DevContig& dc, LeanShared<R>& sh, uint32_t C, uint3
         lean_fence();
         const double ucol = cur.c1 * Cj;
         const double urep = dpp_source(cur.c1 * ((pr[0] + pr[1]) + (pr[2] + pr[3])));
-        double eA, eB;
-        emis(cur, eA, eB);
-        const unsigned long long rbits = (unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(cur.bits1 >> i0));
+        const LeanPairs lp = lean_pairs(sh, n + 2u, cdn, (uint32_t)((nxt.bits1 >> lane) & 1ull));   // column t+1
         const double msum = (ma[0] + ma[1]) + (ma[2] + ma[3]);
         lean_fence();
         const v4f64 mb = __builtin_amdgcn_mfma_f64_16x16x4f64(msum, 1.0, zz, 0, 0, 0);
-        // the product column of the PREVIOUS step is formed here, behind the second MFMA (DEFER of the sixteen
-        // multiplies; the rest ran before the step's barrier, behind the LDS write of the partial sums)
+        asm volatile("" :: "v"(mb));   // (the whole result stays allocated: a temporary in one of its registers would wait out the MFMA)
         lean_fence();
-        static_for<R - DEFER, R>([&](auto kc) __attribute__((always_inline)) { constexpr int k = decltype(kc)::value; x[k] = ee[k] * pp[k]; pin_here(x[k]); });
-        pin_here(eA); pin_here(eB);
-        lean_fence();
-        double S = mb[0];
+        double S = (kLeanExp & 4) ? 64.0 * Cj : mb[0];
         double uj = fma(cur.c2, S, ucol);
         double c0 = cur.c0;
         if (__builtin_expect(!(S > 0.0), 0)) {
@@ -2377,20 +2441,23 @@ DEVI void lean_forward(const DevContig& dc, LeanShared<R>& sh, uint32_t C, uint3
         static_for<0, R>([&](auto kc) __attribute__((always_inline)) {
             constexpr int k = decltype(kc)::value;
             const double pk = fmac_row_bcast<k>(fma(c0s, x[k], ujs), urep, sc);   // P'_t(i0 + k, lane) 2^-es = c0 x + u_j + u_i
-            const double ek = sel_by_mask(eA, eB, row_mask64<k>(rbits));
-            part = fma(ek, pk, part);
-            ee[k] = ek; pp[k] = pk;   // x = ek pk: formed below / in the next step
+            part = fma(ec[k], pk, part);
+            x[k] = ec[k] * pk;
+            pin_here(x[k]);
             // (the fence keeps every pair's store where it is: eight 1 KB stores issued back to back stall the wave
             // on the memory pipeline's queue — 787 instead of ~650 ns per column)
-            if constexpr (k & 1) { put_pair(dst, k >> 1, pprev, pk); __builtin_amdgcn_sched_barrier(0); }
-            else pprev = pk;
+            if constexpr (k & 1) {
+                if (!(kLeanExp & 1)) put_pair(dst, k >> 1, pprev, pk);
+                const v2f64 t2 = (kLeanExp & 2) ? v2f64{0.5, 0.5} : lean_pair<(k >> 1)>(lp);   // e_{t+1} of this row pair
+                ec[k - 1] = t2.x; ec[k] = t2.y;
+                __builtin_amdgcn_sched_barrier(0);
+            } else pprev = pk;
         });
         sh.psum[t & 1u][wave][lane] = part;
         if (wave == 0) {  // (scalar branch)
             fsc.put(lane, t, m);
             if ((t & 63u) == 63u) fsc.flush(fscale, lane, t);
         }
-        static_for<0, R - DEFER>([&](auto kc) __attribute__((always_inline)) { constexpr int k = decltype(kc)::value; x[k] = ee[k] * pp[k]; });
         lds_barrier();
     };
     FRec ra = read_frec(sh, 1), rb2;
@@ -2415,7 +2482,6 @@ DEVI void lean_forward(const DevContig& dc, LeanShared<R>& sh, uint32_t C, uint3
 template <int PHASE, int R, bool TRI>
 DEVI void lean_backward(const DevContig& dc, LeanShared<R>& sh, uint32_t C, uint32_t chunk) {
     constexpr int HP = 64;
-    constexpr int DEFER = TRI ? 0 : kLeanDefer;
     constexpr uint32_t RMASK = (1u << R) - 1u;
     const int64_t mid = C / 2, K = dc.chunk_cols;
     int64_t top = PHASE == 1 ? (int64_t)C - 1 : mid - 1;
@@ -2435,6 +2501,8 @@ DEVI void lean_backward(const DevContig& dc, LeanShared<R>& sh, uint32_t C, uint
     LeanRecs recs{(const GAS char*)dc.frec, t0 + 1, (int64_t)C, -1, tid};
     recs.park(sh, 0, recs.fetch(0));
     v2f64 piece = recs.fetch(1);
+    lds_barrier();
+    lean_expand(sh, 0, tid);
     lds_barrier();
     gdouble* cols = (gdouble*)dc.fwd;
     gdouble* bscale = (gdouble*)dc.bscale;
@@ -2510,20 +2578,26 @@ DEVI void lean_backward(const DevContig& dc, LeanShared<R>& sh, uint32_t C, uint
         for (int k = 0; k < R; ++k) { w[k] = y[k] * sel_by_bit(rb, k, eA, eB); part += w[k]; }
         sh.psum[(uint32_t)t0 & 1u][wave][lane] = part;
     }
-    double ee[R], pp[R];  // (see lean_forward)
-#pragma unroll
-    for (int k = 0; k < R; ++k) { ee[k] = 1.0; pp[k] = w[k]; }
+    double ec[R];   // (see lean_forward)
+    {
+        const FRec r1 = read_frec(sh, 1);   // column t0: its emission goes into the first step's w
+        lean_pairs_all<R>(lean_pairs(sh, 1, wave, (uint32_t)((r1.bits1 >> lane) & 1ull)), ec);
+    }
     double one = 1.0;   // (in a register for the whole sweep: the DPP form of v_fmac_f64 takes no constant)
     asm volatile("" : "+v"(one));
     // One column step (see lean_forward): `cur` = record t+1 (constants of the gap t -> t+1), `nxt` takes record t
-    // (emission of column t: this step's w; constants of the next step).
+    // (constants of the next step); `ec` = emissions of column t (this step's w), `en` takes those of column t-1.
     auto step = [&](int64_t t, const FRec& cur, FRec& nxt) __attribute__((always_inline)) {
-        const uint32_t n = (uint32_t)(t0 - t);        // step number: reads the record with rel = n + 1 (column t)
+        const uint32_t n = (uint32_t)(t0 - t);        // step number: column t is the record with rel = n + 1
         nxt = read_frec(sh, n + 1u);
+        const unsigned long long bits_n = (unsigned long long)__double_as_longlong(sh.rec[((n + 2u) / PG_LEAN_BLOCK) & 1u][(n + 2u) % PG_LEAN_BLOCK][7]);  // column t-1
+        const u32x2 cdn = lean_pair_bytes(sh, n + 2u, wave);
         if (((n + 4u) % PG_LEAN_BLOCK) == 0u) {
             const uint32_t blk = (n + 4u) / PG_LEAN_BLOCK;
             recs.park(sh, blk, piece);
             piece = recs.fetch(blk + 1u);
+        } else if (((n + 3u) % PG_LEAN_BLOCK) == 0u) {
+            lean_expand(sh, (n + 3u) / PG_LEAN_BLOCK, tid);
         }
         int es = exponent_of(Sy) - PG_BIAS_B;
         es = es < -900 ? -900 : es;
@@ -2543,37 +2617,40 @@ DEVI void lean_backward(const DevContig& dc, LeanShared<R>& sh, uint32_t C, uint
         lean_fence();
         const double ucol = k1 * Cj;
         const double urep = dpp_source(k1 * ((pr[0] + pr[1]) + (pr[2] + pr[3])));  // u_i of row i0 + (lane & 15)
-        double eA, eB;
-        emis(nxt, eA, eB);
-        const unsigned long long rbits = (unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(nxt.bits1 >> i0));
+        const LeanPairs lp = lean_pairs(sh, n + 2u, cdn, (uint32_t)((bits_n >> lane) & 1ull));   // column t-1
         const double msum = (ma[0] + ma[1]) + (ma[2] + ma[3]);
         lean_fence();
         const v4f64 mb = __builtin_amdgcn_mfma_f64_16x16x4f64(msum, 1.0, zz, 0, 0, 0);
+        asm volatile("" :: "v"(mb));
         lean_fence();
-        static_for<R - DEFER, R>([&](auto kc) __attribute__((always_inline)) { constexpr int k = decltype(kc)::value; w[k] = ee[k] * pp[k]; pin_here(w[k]); });
-        pin_here(eA); pin_here(eB);
-        lean_fence();
-        const double Sw = mb[0];
+        const double Sw = (kLeanExp & 4) ? 64.0 * Cj : mb[0];
         const double uj = fma(k2, Sw, ucol);
         const double Snew = kap * Sw;  // = sum(beta'_t)
         Sy = Snew;                     // (1 behind an all-zero column, below)
         gdouble2* dst = (gdouble2*)(wr + (size_t)t * colsz) + toff;
         double part = 0.0, yprev = 0.0;
+        const bool zero = !(Snew > 0.0);   // beta~_t is all zero (below)
         static_for<0, R>([&](auto kc) __attribute__((always_inline)) {
             constexpr int k = decltype(kc)::value;
             const double yk = fmac_row_bcast<k>(fma(k0, w[k], uj), urep, one);  // beta'_t = k0 w + u_j + u_i
-            const double ek = sel_by_mask(eA, eB, row_mask64<k>(rbits));
-            part = fma(ek, yk, part);
-            ee[k] = ek; pp[k] = yk;   // w = ek yk: formed below / in the next step
-            if constexpr (k & 1) { put_pair(dst, k >> 1, yprev, yk); __builtin_amdgcn_sched_barrier(0); }
-            else yprev = yk;
+            part = fma(ec[k], yk, part);
+            w[k] = ec[k] * yk;
+            pin_here(w[k]);
+            if constexpr (k & 1) {
+                if (!(kLeanExp & 1)) put_pair(dst, k >> 1, yprev, yk);
+                const v2f64 t2 = (kLeanExp & 2) ? v2f64{0.5, 0.5} : lean_pair<(k >> 1)>(lp);   // e_{t-1} of this row pair
+                ec[k - 1] = t2.x; ec[k] = t2.y;
+                __builtin_amdgcn_sched_barrier(0);
+            } else yprev = yk;
         });
-        if (__builtin_expect(!(Snew > 0.0), 0)) {
+        if (__builtin_expect(zero, 0)) {
             // beta~_t is all zero (a sum of non-negative terms: every y_k above IS 0, and so is what was stored): its own
             // posteriors are 0, the next step starts from the uniform column (hmm.cpp:374-380)
+            double et[R];   // (ec holds the next column's emissions by now: this column's are fetched again)
+            lean_pairs_all<R>(lean_pairs(sh, n + 1u, wave, (uint32_t)((nxt.bits1 >> lane) & 1ull)), et);
             part = 0.0;
 #pragma unroll
-            for (int k = 0; k < R; ++k) { pp[k] = unif; part += unif * ee[k]; }
+            for (int k = 0; k < R; ++k) { w[k] = unif * et[k]; part += w[k]; }
             Sy = 1.0;
         }
         sh.psum[(uint32_t)(t - 1) & 1u][wave][lane] = part;
@@ -2582,7 +2659,6 @@ DEVI void lean_backward(const DevContig& dc, LeanShared<R>& sh, uint32_t C, uint
             if (wave == 1) bsc.flush(bscale, lane, (uint64_t)t);
             if (wave == 2) bsm.flush(bsum, lane, (uint64_t)t);
         }
-        static_for<0, R - DEFER>([&](auto kc) __attribute__((always_inline)) { constexpr int k = decltype(kc)::value; w[k] = ee[k] * pp[k]; });
     };
     FRec rb2;
     int64_t t = t0;
@@ -3029,16 +3105,6 @@ DEVI LxConsts lx_consts(const LxShared<HP>& sh, uint32_t rel) {
 // row offsets of the wave's R rows (R bytes, the same in every lane: broadcast LDS reads)
 template <int R>
 struct LxAlleles { uint32_t col8; uint32_t rows[R / 4]; };
-// base + byte SEL of `bytes` in ONE instruction (SDWA source select): the LDS address of a state's emission
-template <int SEL>
-DEVI uint32_t add_byte(uint32_t bytes, uint32_t base) {
-    uint32_t r;
-    if constexpr (SEL == 0) asm("v_add_u32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_0 src1_sel:DWORD" : "=v"(r) : "v"(bytes), "v"(base));
-    else if constexpr (SEL == 1) asm("v_add_u32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_1 src1_sel:DWORD" : "=v"(r) : "v"(bytes), "v"(base));
-    else if constexpr (SEL == 2) asm("v_add_u32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_2 src1_sel:DWORD" : "=v"(r) : "v"(bytes), "v"(base));
-    else asm("v_add_u32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_3 src1_sel:DWORD" : "=v"(r) : "v"(bytes), "v"(base));
-    return r;
-}
 template <int HP>
 DEVI LxAlleles<LxCfg<HP>::R> lx_alleles(const LxShared<HP>& sh, uint32_t rel, uint32_t j, uint32_t i0) {
     constexpr int R = LxCfg<HP>::R;

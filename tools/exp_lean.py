@@ -1,5 +1,5 @@
 """Timing experiments on the lean sweep kernel (k_sweep_lean): builds variants of the product library with compile-time
-knobs of the lean step (-DNAME=value, e.g. PG_LEAN_DEFER=8) and prints the phase-1 / phase-2 sweep time per column of a
+knobs of the lean step (-DNAME=value, e.g. PG_LEAN_EXP=1: no column stores) and prints the phase-1 / phase-2 sweep time per column of a
 50 000-variant, 64-path chain; every variant is also checked against the default library's results (bit for bit unless
 the knob changes the arithmetic).  Tooling only.
 usage: python tools/exp_lean.py build NAME=V[,NAME=V...] ...   (here, CPU)
