@@ -2689,24 +2689,29 @@ struct LeanShared2 {
 };
 template <int R>
 struct LeanTri {  // this thread's units of a compact triangle column
-    uint32_t unit[R / 2];
-    uint32_t valid;
-    DEVI void setup(uint32_t i0, uint32_t lane) {
+    // unit of (row pair rp, lane) = (a number that depends on the row pair only) + lane: the row pairs of a wave are
+    // uniform, so the per-pair part lives in scalar registers and ONE vector register (16 * lane) serves all pairs
+    uint32_t sbase[R / 2];   // (uniform) byte offset of the pair's lane-0 unit (may be "negative": wraps, lanes below 8 g are not loaded)
+    uint32_t lane16, valid;
+    DEVI void setup(uint32_t i0 /*uniform*/, uint32_t lane) {
         valid = 0;
+        lane16 = lane * 16u;
 #pragma unroll
         for (int q = 0; q < R / 2; ++q) {
-            const uint32_t rp = (i0 >> 1) + (uint32_t)q;
-            const bool ok = lane >= 8u * (rp >> 2);
-            unit[q] = ok ? tri_unit_of(rp, lane) : 0u;
-            valid |= (ok ? 1u : 0u) << q;
+            const uint32_t rp = (i0 >> 1) + (uint32_t)q, g = rp >> 2;
+            sbase[q] = (uint32_t)__builtin_amdgcn_readfirstlane((int)((256u * g - 16u * g * (g - 1u) + (rp & 3u) * (64u - 8u * g) - 8u * g) * 16u));
+            valid |= (lane >= 8u * g ? 1u : 0u) << q;
         }
     }
     // units below the stored half keep the zeros the buffer was initialised with
-    DEVI void load(gcdouble* col, double (&v)[R]) const {
-        gcdouble2* c2 = (gcdouble2*)col;
+    DEVI void load(gcdouble* col /*uniform*/, double (&v)[R]) const {
 #pragma unroll
         for (int q = 0; q < R / 2; ++q)
-            if ((valid >> q) & 1u) { const v2f64 t = c2[unit[q]]; v[2 * q] = t.x; v[2 * q + 1] = t.y; }
+            if ((valid >> q) & 1u) {
+                const GAS char* cb = (const GAS char*)col + (int32_t)sbase[q];   // (uniform: scalar base of the load)
+                const v2f64 t = *(const GAS v2f64*)(cb + lane16);
+                v[2 * q] = t.x; v[2 * q + 1] = t.y;
+            }
     }
 };
 // full element (i0 + k, lane) of a compact triangle column: the stored (min, max), the diagonal doubled (once per launch)
@@ -2751,6 +2756,7 @@ DEVI void lean2_forward(const DevContig& dc, LeanShared2<R>& sh2, uint32_t C) {
     recs.park(sh, 0, recs.fetch(0));
     v2f64 piece = recs.fetch(1);
     lds_barrier();
+    lean_expand(sh, 0, tid);
     gcdouble* cols = (gcdouble*)dc.fwd;
     gdouble* fscale = (gdouble*)dc.fscale;
     gu8* fallback = (gu8*)dc.fwd_fallback;
@@ -2786,55 +2792,71 @@ DEVI void lean2_forward(const DevContig& dc, LeanShared2<R>& sh2, uint32_t C) {
         for (int k = 0; k < R; ++k) part0 += x[k];
         sh.psum[(first - 1) & 1u][wave][lane] = part0;
     }
-    FRec cur = read_frec(sh, 1);
     unsigned long long pbits = 0;  // column alleles of the column whose partials are pending
     lds_barrier();
-    for (uint32_t t = first; t < hi; ++t) {
+    // column alleles and row-pair bytes of the column a step produces: read a step ahead and carried
+    unsigned long long cbits = read_frec(sh, 1).bits1;
+    u32x2 ccd = lean_pair_bytes(sh, 1, wave);
+    // One column step.  `ba` = the partner column beta'_t, `bc` takes beta'_{t+2} (two columns ahead of its use; the three
+    // buffers rotate through the loop's three calls, so no column is ever copied).  Emissions and class multipliers
+    // of the sixteen states come pair by pair out of LDS tables (lean_expand), fetched one pair ahead.
+    auto step = [&](uint32_t t, const double (&ba)[R], double (&bc)[R]) __attribute__((always_inline)) {
         const uint32_t n = t - first;
-        const FRec nxt = read_frec(sh, n + 2u);
+        const double* rq = sh.rec[((n + 1u) / PG_LEAN_BLOCK) & 1u][(n + 1u) % PG_LEAN_BLOCK];   // record t: constants of the gap t-1 -> t
+        const double rc0 = rq[0], rc1 = rq[1], rc2 = rq[2];
+        const unsigned long long nbits = (unsigned long long)__double_as_longlong(sh.rec[((n + 2u) / PG_LEAN_BLOCK) & 1u][(n + 2u) % PG_LEAN_BLOCK][7]);
+        const u32x2 ncd = lean_pair_bytes(sh, n + 2u, wave);
         if (((n + 4u) % PG_LEAN_BLOCK) == 0u) {
             const uint32_t blk = (n + 4u) / PG_LEAN_BLOCK;
             recs.park(sh, blk, piece);
             piece = recs.fetch(blk + 1u);
+        } else if (((n + 3u) % PG_LEAN_BLOCK) == 0u) {
+            lean_expand(sh, (n + 3u) / PG_LEAN_BLOCK, tid);   // the block parked a step ago (a barrier lies between)
         }
-        if (t + 2 < C) tri.load(cols + (size_t)(t + 2) * colsz, b2);  // two columns ahead (b2 was last read a step ago)
+        if (t + 2 < C) tri.load(cols + (size_t)(t + 2) * colsz, bc);  // two columns ahead (bc was last read a step ago)
         if (t > first) lean2_flush_partials<R>(sh2, (t - 1) & 1u, part, (size_t)(t - 1), wave, lane, pbits);
         const uint32_t pb = (t - 1) & 1u;
         const double Cj = lean_colsum<R>(sh, pb, lane);
-        const double ucol = cur.c1 * Cj;
-        const double urep = dpp_source(cur.c1 * lean_colsum<R>(sh, pb, i0 + (lane & 15u)));   // u_i of row i0 + (lane & 15): the DPP source
+        const double ucol = rc1 * Cj;
+        const double urep = dpp_source(rc1 * lean_colsum<R>(sh, pb, i0 + (lane & 15u)));   // u_i of row i0 + (lane & 15): the DPP source
+        const LeanPairs lp = lean_pairs(sh, n + 1u, ccd, (uint32_t)((cbits >> lane) & 1ull));
         const v4f64 zz = {0.0, 0.0, 0.0, 0.0};
         const v4f64 ma = __builtin_amdgcn_mfma_f64_16x16x4f64(Cj, 1.0, zz, 0, 0, 0);
         double S = __builtin_amdgcn_mfma_f64_16x16x4f64((ma[0] + ma[1]) + (ma[2] + ma[3]), 1.0, zz, 0, 0, 0)[0];
-        double uj = fma(cur.c2, S, ucol);
-        double c0 = cur.c0;
+        double uj = fma(rc2, S, ucol);
+        double c0 = rc0;
         if (__builtin_expect(!(S > 0.0), 0)) {
             // column t-1 summed to zero: the uniform column takes its place (hmm.cpp:253-267); its own partials were
             // formed from the all-zero column — k_bins re-forms those bins from the flag
             if (wave == 0) fallback[t - 1] = 1;
             const double Cu = 64.0 * unif;
             S = 1.0;
-            uj = fma(cur.c0, unif, fma(cur.c2, 1.0, 2.0 * cur.c1 * Cu));
+            uj = fma(rc0, unif, fma(rc2, 1.0, 2.0 * rc1 * Cu));
             c0 = 0.0;
         }
         int es = exponent_of(S) - PG_BIAS_F;
         es = es < -900 ? -900 : es;
         const double m = ldexp(S, -es - PG_BIAS_F);
         const double sc = ldexp(1.0, -es), c0s = ldexp(c0, -es), ujs = ldexp(uj, -es);
-        double eA, eB;
-        emis(cur, eA, eB);
-        const uint32_t rb = (uint32_t)__builtin_amdgcn_readfirstlane((int)((uint32_t)(cur.bits1 >> i0) & RMASK));
-        const unsigned long long rbits = (unsigned long long)rb;
         double part0 = 0.0, acc0 = 0.0, acc1 = 0.0;
-        static_for<0, R>([&](auto kc) __attribute__((always_inline)) {
-            constexpr int k = decltype(kc)::value;
-            const double pk = fmac_row_bcast<k>(fma(c0s, x[k], ujs), urep, sc);   // P'_t = c0 x + u_j + u_i (lean_forward)
-            x[k] = pk * sel_by_mask(eA, eB, row_mask64<k>(rbits));
+        const uint32_t rb = (uint32_t)__builtin_amdgcn_readfirstlane((int)((uint32_t)(cbits >> i0) & RMASK));   // row alleles: uniform
+        v2f64 en = lean_pair<0>(lp);
+        static_for<0, R / 2>([&](auto pc) __attribute__((always_inline)) {
+            constexpr int q = decltype(pc)::value, k = 2 * q;
+            const v2f64 e = en;
+            if constexpr (q + 1 < R / 2) en = lean_pair<q + 1>(lp);
+            const double pa = fmac_row_bcast<k>(fma(c0s, x[k], ujs), urep, sc);           // P'_t = c0 x + u_j + u_i (lean_forward)
+            const double pb2 = fmac_row_bcast<k + 1>(fma(c0s, x[k + 1], ujs), urep, sc);
+            x[k] = pa * e.x;
             part0 += x[k];
-            const double pr = pk * b0[k];  // P'_t beta'_t (0 below the stored half)
-            const bool bit = (rb >> k) & 1u;
-            acc1 = fma(pr, bit ? 1.0 : 0.0, acc1);  // exact 0/1 multipliers: rounds like a predicated add
-            acc0 = fma(pr, bit ? 0.0 : 1.0, acc0);
+            x[k + 1] = pb2 * e.y;
+            part0 += x[k + 1];
+            const double pra = pa * ba[k], prb = pb2 * ba[k + 1];  // P'_t beta'_t (0 below the stored half)
+            const bool bita = (rb >> k) & 1u, bitb = (rb >> (k + 1)) & 1u;
+            acc1 = fma(pra, bita ? 1.0 : 0.0, acc1);  // exact 0/1 multipliers (scalar operands): rounds like a predicated add
+            acc0 = fma(pra, bita ? 0.0 : 1.0, acc0);
+            acc1 = fma(prb, bitb ? 1.0 : 0.0, acc1);
+            acc0 = fma(prb, bitb ? 0.0 : 1.0, acc0);
         });
         sh.psum[t & 1u][wave][lane] = part0;
         sh2.ppart[t & 1u][wave][lane] = v2f64{acc0, acc1};
@@ -2842,11 +2864,18 @@ DEVI void lean2_forward(const DevContig& dc, LeanShared2<R>& sh2, uint32_t C) {
             fsc.put(lane, t, m);
             if ((t & 63u) == 63u) fsc.flush(fscale, lane, t);
         }
-#pragma unroll
-        for (int k = 0; k < R; ++k) { b0[k] = b1[k]; b1[k] = b2[k]; }
-        pbits = cur.bits1;
-        cur = nxt;
+        pbits = cbits; cbits = nbits; ccd = ncd;
         lds_barrier();
+    };
+    {
+        uint32_t t = first;
+        for (; t + 2 < hi; t += 3) {
+            step(t, b0, b2);
+            step(t + 1, b1, b0);
+            step(t + 2, b2, b1);
+        }
+        if (t < hi) step(t, b0, b2);
+        if (t + 1 < hi) step(t + 1, b1, b0);
     }
     lean2_flush_partials<R>(sh2, (hi - 1) & 1u, part, (size_t)(hi - 1), wave, lane, pbits);
     if (wave == 0 && fsc.valid) fsc.flush(fscale, lane, hi - 1);
@@ -2871,6 +2900,7 @@ DEVI void lean2_backward(const DevContig& dc, LeanShared2<R>& sh2, uint32_t C) {
     recs.park(sh, 0, recs.fetch(0));
     v2f64 piece = recs.fetch(1);
     lds_barrier();
+    lean_expand(sh, 0, tid);
     gcdouble* cols = (gcdouble*)dc.fwd;
     gdouble* bscale = (gdouble*)dc.bscale;
     gcdouble* bsum = (gcdouble*)dc.bsum;
@@ -2911,61 +2941,91 @@ DEVI void lean2_backward(const DevContig& dc, LeanShared2<R>& sh2, uint32_t C) {
     }
     double one = 1.0;   // (in a register: the DPP form of v_fmac_f64 takes no constant)
     asm volatile("" : "+v"(one));
-    for (int64_t t = t0; t >= bot; --t) {
-        const uint32_t n = (uint32_t)(t0 - t);
-        const FRec nxt = read_frec(sh, n + 1u);  // record t: emission of column t (this step's w), row alleles of the posterior
+    lds_barrier();   // (the tables of block 0 are complete)
+    // carried from step to step (see lean2_forward): the constants of the gap t -> t+1, the column alleles and row-pair
+    // bytes of column t, the column alleles of column t+1 (whose partials are pending)
+    double kc0 = cur.c0, kc1 = cur.c1, kc2 = cur.c2, kck = cur.kappa;
+    unsigned long long pbits = cur.bits1;
+    unsigned long long cbits = read_frec(sh, 1).bits1;
+    u32x2 ccd = lean_pair_bytes(sh, 1, wave);
+    auto step = [&](int64_t t, const double (&ba)[R], double (&bc)[R]) __attribute__((always_inline)) {
+        const uint32_t n = (uint32_t)(t0 - t);   // column t is the record with rel = n + 1
         if (((n + 4u) % PG_LEAN_BLOCK) == 0u) {
             const uint32_t blk = (n + 4u) / PG_LEAN_BLOCK;
             recs.park(sh, blk, piece);
             piece = recs.fetch(blk + 1u);
+        } else if (((n + 3u) % PG_LEAN_BLOCK) == 0u) {
+            lean_expand(sh, (n + 3u) / PG_LEAN_BLOCK, tid);
         }
-        if (t - 2 >= 0) tri.load(cols + (size_t)(t - 2) * colsz, b2);
+        if (t - 2 >= 0) tri.load(cols + (size_t)(t - 2) * colsz, bc);
         int es = exponent_of(Sy) - PG_BIAS_B;
         es = es < -900 ? -900 : es;
         const double m = ldexp(Sy, -es - PG_BIAS_B);
         if (wave == 0) bsc.put(lane, (uint64_t)t, m);
-        const double k0 = ldexp(cur.c0, -es), k1 = ldexp(cur.c1, -es), k2 = ldexp(cur.c2, -es), kap = ldexp(cur.kappa, -es);
+        const double k0 = ldexp(kc0, -es), k1 = ldexp(kc1, -es), k2 = ldexp(kc2, -es), kap = ldexp(kck, -es);
         lds_barrier();
-        if (t < t0) lean2_flush_partials<R>(sh2, (uint32_t)(t + 1) & 1u, part, (size_t)(t + 1), wave, lane, cur.bits1);
+        // the next step's constants (record t: gap t-1 -> t), column alleles and pair bytes (column t-1)
+        const double* rq = sh.rec[((n + 1u) / PG_LEAN_BLOCK) & 1u][(n + 1u) % PG_LEAN_BLOCK];
+        const double nc0 = rq[0], nc1 = rq[1], nc2 = rq[2], nck = rq[3];
+        const unsigned long long nbits = (unsigned long long)__double_as_longlong(sh.rec[((n + 2u) / PG_LEAN_BLOCK) & 1u][(n + 2u) % PG_LEAN_BLOCK][7]);
+        const u32x2 ncd = lean_pair_bytes(sh, n + 2u, wave);
+        if (t < t0) lean2_flush_partials<R>(sh2, (uint32_t)(t + 1) & 1u, part, (size_t)(t + 1), wave, lane, pbits);
         const double Cj = lean_colsum<R>(sh, (uint32_t)t & 1u, lane);
         const double ucol = k1 * Cj;
         const double urep = dpp_source(k1 * lean_colsum<R>(sh, (uint32_t)t & 1u, i0 + (lane & 15u)));
+        const LeanPairs lp = lean_pairs(sh, n + 1u, ccd, (uint32_t)((cbits >> lane) & 1ull));   // emission of column t: this step's w
         const v4f64 zz = {0.0, 0.0, 0.0, 0.0};
         const v4f64 ma = __builtin_amdgcn_mfma_f64_16x16x4f64(Cj, 1.0, zz, 0, 0, 0);
         const double Sw = __builtin_amdgcn_mfma_f64_16x16x4f64((ma[0] + ma[1]) + (ma[2] + ma[3]), 1.0, zz, 0, 0, 0)[0];
         const double uj = fma(k2, Sw, ucol);
         const double Snew = kap * Sw;  // = sum(beta'_t)
-        double eA, eB;
-        emis(nxt, eA, eB);
-        const uint32_t rb = (uint32_t)__builtin_amdgcn_readfirstlane((int)((uint32_t)(nxt.bits1 >> i0) & RMASK));
-        const unsigned long long rbits = (unsigned long long)rb;
         double part0 = 0.0, acc0 = 0.0, acc1 = 0.0;
         if (__builtin_expect(!(Snew > 0.0), 0)) {
             // beta~_t is all zero: its own posteriors are 0, the next step starts from the uniform column
+            double et[R];
+            lean_pairs_all<R>(lp, et);
 #pragma unroll
-            for (int k = 0; k < R; ++k) { w[k] = unif * sel_by_bit(rb, k, eA, eB); part0 += w[k]; }
+            for (int k = 0; k < R; ++k) { w[k] = unif * et[k]; part0 += w[k]; }
         } else {
-            static_for<0, R>([&](auto kc) __attribute__((always_inline)) {
-                constexpr int k = decltype(kc)::value;
-                const double yk = fmac_row_bcast<k>(fma(k0, w[k], uj), urep, one);  // beta'_t = k0 w + u_j + u_i (lean_backward)
-                w[k] = yk * sel_by_mask(eA, eB, row_mask64<k>(rbits));
+            const uint32_t rb = (uint32_t)__builtin_amdgcn_readfirstlane((int)((uint32_t)(cbits >> i0) & RMASK));
+            v2f64 en = lean_pair<0>(lp);
+            static_for<0, R / 2>([&](auto pc) __attribute__((always_inline)) {
+                constexpr int q = decltype(pc)::value, k = 2 * q;
+                const v2f64 e = en;
+                if constexpr (q + 1 < R / 2) en = lean_pair<q + 1>(lp);
+                const double ya = fmac_row_bcast<k>(fma(k0, w[k], uj), urep, one);           // beta'_t = k0 w + u_j + u_i (lean_backward)
+                const double yb = fmac_row_bcast<k + 1>(fma(k0, w[k + 1], uj), urep, one);
+                w[k] = ya * e.x;
                 part0 += w[k];
-                const double pr = b0[k] * yk;  // P'_t beta'_t
-                const bool bit = (rb >> k) & 1u;
-                acc1 = fma(pr, bit ? 1.0 : 0.0, acc1);
-                acc0 = fma(pr, bit ? 0.0 : 1.0, acc0);
+                w[k + 1] = yb * e.y;
+                part0 += w[k + 1];
+                const double pra = ba[k] * ya, prb = ba[k + 1] * yb;  // P'_t beta'_t
+                const bool bita = (rb >> k) & 1u, bitb = (rb >> (k + 1)) & 1u;
+                acc1 = fma(pra, bita ? 1.0 : 0.0, acc1);
+                acc0 = fma(pra, bita ? 0.0 : 1.0, acc0);
+                acc1 = fma(prb, bitb ? 1.0 : 0.0, acc1);
+                acc0 = fma(prb, bitb ? 0.0 : 1.0, acc0);
             });
         }
         sh.psum[(uint32_t)(t - 1) & 1u][wave][lane] = part0;
         sh2.ppart[(uint32_t)t & 1u][wave][lane] = v2f64{acc0, acc1};
         if (wave == 0 && ((uint64_t)t & 63u) == 0u) bsc.flush(bscale, lane, (uint64_t)t);
         Sy = Snew > 0.0 ? Snew : 1.0;
-#pragma unroll
-        for (int k = 0; k < R; ++k) { b0[k] = b1[k]; b1[k] = b2[k]; }
-        cur = nxt;
+        kc0 = nc0; kc1 = nc1; kc2 = nc2; kck = nck;
+        pbits = cbits; cbits = nbits; ccd = ncd;
+    };
+    {
+        int64_t t = t0;
+        for (; t - 2 >= bot; t -= 3) {
+            step(t, b0, b2);
+            step(t - 1, b1, b0);
+            step(t - 2, b2, b1);
+        }
+        if (t >= bot) step(t, b0, b2);
+        if (t - 1 >= bot) step(t - 1, b1, b0);
     }
     lds_barrier();
-    lean2_flush_partials<R>(sh2, (uint32_t)bot & 1u, part, (size_t)bot, wave, lane, cur.bits1);
+    lean2_flush_partials<R>(sh2, (uint32_t)bot & 1u, part, (size_t)bot, wave, lane, pbits);
     if (wave == 0 && bsc.valid) bsc.flush(bscale, lane, (uint64_t)bot);
 }
 
