@@ -594,6 +594,13 @@ int job_build(int device, uint32_t n_index, const pg_contig_batch* batches, cons
         }
         if (wide_candidates || generic_needed || force_generic) want = true;
         job->chunked = want && max_v > 0 && params->run_genotyping;
+        // k_sweep_leanx is a latency kernel (lone chains: 1470 vs 2645 ns per column at 128 paths); phase 1 of a fused job
+        // with hundreds of chains is bound by HBM writes, where the general kernel measured faster (7.8 vs 8.9 ms on 128 chains
+        // of 128 paths).  PG_LEANX=1 forces it there too.
+        if (!job->chunked) {
+            const char* e = getenv("PG_LEANX");
+            if (!(e && !strcmp(e, "1"))) for (auto& x : job->index) x.leanx = false;
+        }
         if (job->chunked) {
             size_t k = 4096;
             const size_t budget = (size_t)12 << 30;
