@@ -12,6 +12,10 @@ done
 SQ=1 bash tools/profile_workload.sh chr22_h64 $TAG > gpurun_out/${TAG}_chr22_h64.log 2>&1
 python tools/summarize_profile.py gpurun_out/${TAG}_chr22_h64 gpurun_out/profiles/${TAG}_chr22_h64 chr22_h64 > /dev/null 2>&1
 cp gpurun_out/${TAG}_chr22_h64/kt/kt_kernel_stats.csv gpurun_out/profiles/${TAG}_chr22_h64_kernel_stats.csv 2>/dev/null
+# the 128-path chain with multiallelic objects (k_sweep_leanx), SQ counters included
+SQ=1 bash tools/profile_workload.sh chr22_h128 $TAG > gpurun_out/${TAG}_chr22_h128.log 2>&1
+python tools/summarize_profile.py gpurun_out/${TAG}_chr22_h128 gpurun_out/profiles/${TAG}_chr22_h128 chr22_h128 > /dev/null 2>&1
+cp gpurun_out/${TAG}_chr22_h128/kt/kt_kernel_stats.csv gpurun_out/profiles/${TAG}_chr22_h128_kernel_stats.csv 2>/dev/null
 # the sampler: kernel trace + SQ instruction counters of the bench's sampler shape
 mkdir -p gpurun_out/${TAG}_sampler
 ( cd /tmp && export TMPDIR=/tmp && cd $R
