@@ -276,7 +276,11 @@ DEVI int slot_of(const DevContig& dc, uint32_t a0, uint32_t A, uint16_t a) {
 // ------------------------------------------------------------------------------------------
 //  k_prep : one wave per variant
 // ------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_prep(const DevContig* __restrict__ contigs, DevTable tab) {
+#ifndef PG_VREP
+#define PG_VREP 8   // units (what one block of the one-variant-per-wave grid did) a block of k_prep / k_prep_bi walks: fewer, longer blocks
+                    // (measured on 4096 chains of 8000 variants: 15.1 -> 13.2 ms; k_records and k_bins lose with the same change)
+#endif
+DEVI void prep_unit(const DevContig& dc, const DevTable& tab, uint32_t unit) {
     constexpr int NLP = PG_AMAX * (PG_AMAX + 1) / 2;  // local pairs of a narrow column
     __shared__ double s_m[4][64 * 3];
     __shared__ int s_e[4][64 * 3];
@@ -286,10 +290,8 @@ __global__ __launch_bounds__(256) void k_prep(const DevContig* __restrict__ cont
     __shared__ uint32_t s_pres[4][8];
     __shared__ uint16_t s_aid[4][64];   // the variant's allele ids / flags (objects with <= 64 alleles: every real one)
     __shared__ uint8_t s_afl[4][64];
-    const DevContig& dc = contigs[blockIdx.y];
-    if (dc.prep_fast) return;  // k_prep_bi's chain
     const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const uint32_t v = blockIdx.x * 4 + wave;
+    const uint32_t v = unit * 4 + wave;
     if (v >= dc.V) return;  // whole wave leaves; the kernel only uses wave-level sync
 
     const uint32_t a0 = dc.allele_off[v], A = dc.allele_off[v + 1] - a0;
@@ -560,6 +562,17 @@ __global__ __launch_bounds__(256) void k_prep(const DevContig* __restrict__ cont
         for (; l < 8; ++l) ls[l] = 0;
     }
 }
+__global__ __launch_bounds__(256) void k_prep(const DevContig* __restrict__ contigs, DevTable tab) {
+    const DevContig& dc = contigs[blockIdx.y];
+    if (dc.prep_fast) return;  // k_prep_bi's chain
+#pragma unroll 1
+    for (uint32_t r = 0; r < (uint32_t)PG_VREP; ++r) {
+        prep_unit(dc, tab, blockIdx.x * (uint32_t)PG_VREP + r);
+        wave_sync_lds();   // (a wave's LDS slices are its own: the next unit's writes stay behind this unit's reads)
+    }
+}
+
+
 
 
 // ------------------------------------------------------------------------------------------
@@ -584,12 +597,10 @@ DEVI double row_last_f64(double v) {  // lane 15 of the row of 16 to all its lan
 }
 DEVI int row_last_i32(int v) { return __builtin_amdgcn_update_dpp(v, v, 0x15F, 0xF, 0xF, true); }
 
-__global__ __launch_bounds__(256) void k_prep_bi(const DevContig* __restrict__ contigs, DevTable tab) {
-    const DevContig& dc = contigs[blockIdx.y];
-    if (!dc.prep_fast) return;
+DEVI void prep_bi_unit(const DevContig& dc, const DevTable& tab, uint32_t unit) {
     const uint32_t lane = threadIdx.x & 63u, grp = lane >> 4, l = lane & 15u;
-    const uint32_t v = blockIdx.x * 16u + (threadIdx.x >> 6) * 4u + grp;
-    if (blockIdx.x * 16u + (threadIdx.x >> 6) * 4u >= dc.V) return;  // the whole wave is beyond the contig
+    const uint32_t v = unit * 16u + (threadIdx.x >> 6) * 4u + grp;
+    if (unit * 16u + (threadIdx.x >> 6) * 4u >= dc.V) return;  // the whole wave is beyond the contig
     const bool live = v < dc.V;   // (a row beyond the contig idles along: the ballots below are wave-wide)
     const uint32_t vv = live ? v : dc.V - 1u;
     const uint32_t H = dc.H, HP = dc.HP;
@@ -724,6 +735,13 @@ __global__ __launch_bounds__(256) void k_prep_bi(const DevContig* __restrict__ c
         ((unsigned long long*)(rec + PG_REC_BITS1))[1] = 0ull;
     }
 }
+__global__ __launch_bounds__(256) void k_prep_bi(const DevContig* __restrict__ contigs, DevTable tab) {
+    const DevContig& dc = contigs[blockIdx.y];
+    if (!dc.prep_fast) return;
+#pragma unroll 1
+    for (uint32_t r = 0; r < (uint32_t)PG_VREP; ++r) prep_bi_unit(dc, tab, blockIdx.x * (uint32_t)PG_VREP + r);
+}
+
 
 // ------------------------------------------------------------------------------------------
 //  unit-level entry: full A x A emission products of one variant as (mantissa, exponent)
@@ -810,12 +828,11 @@ __global__ __launch_bounds__(64) void k_transition_single(double d, uint32_t H, 
 // The same for lean chains of chunked jobs: their sweeps run on k_sweep_lean and k_post reads the variant record.
 DEVI bool compact_records_only(const DevContig& dc, uint32_t C) { return (dc.tri == 2u && C >= 2u) || (dc.lean && dc.tri == 0u && dc.chunk_cols > 0u); }
 
-__global__ __launch_bounds__(256) void k_records(const DevContig* __restrict__ contigs) {
-    const DevContig& dc = contigs[blockIdx.y];
+DEVI void records_unit(const DevContig& dc, uint32_t unit) {
     const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const uint32_t C = *dc.n_cols;
     if (compact_records_only(dc, C)) {
-        const uint32_t c = blockIdx.x * 256u + threadIdx.x;
+        const uint32_t c = unit * 256u + threadIdx.x;
         if (c >= C) return;
         const uint32_t v = dc.col_variant[c];
         const uint64_t* src = (const uint64_t*)(dc.vrec + (size_t)v * dc.RB);
@@ -833,7 +850,7 @@ __global__ __launch_bounds__(256) void k_records(const DevContig* __restrict__ c
         out[3] = f64x2{__longlong_as_double((long long)E[PG_ESTRIDE + 1]), __longlong_as_double((long long)src[PG_REC_BITS1 / 8])};
         return;
     }
-    const uint32_t c = blockIdx.x * 4 + wave;
+    const uint32_t c = unit * 4 + wave;
     if (c >= C) return;
     const uint32_t v = dc.col_variant[c];
     const uint64_t* src = (const uint64_t*)(dc.vrec + (size_t)v * dc.RB);
@@ -864,6 +881,11 @@ __global__ __launch_bounds__(256) void k_records(const DevContig* __restrict__ c
         else val = src[PG_REC_BITS1 / 8];
         ((uint64_t*)dc.frec)[(size_t)c * 8 + lane] = val;
     }
+}
+
+__global__ __launch_bounds__(256) void k_records(const DevContig* __restrict__ contigs) {
+    const DevContig& dc = contigs[blockIdx.y];
+    records_unit(dc, blockIdx.x);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -4236,11 +4258,9 @@ DEVI void store_bin(double* lik, int32_t* lik_exp, uint64_t idx, double sum, dou
     lik_exp[idx] = ee;
 }
 
-__global__ __launch_bounds__(256) void k_bins(const DevContig* __restrict__ contigs) {
-    __shared__ double s_bins[4][PG_AMAX * (PG_AMAX + 1) / 2];
-    const DevContig& dc = contigs[blockIdx.y];
+DEVI void bins_unit(const DevContig& dc, uint32_t unit, double (&s_bins)[4][PG_AMAX * (PG_AMAX + 1) / 2]) {
     const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const uint32_t c = blockIdx.x * 4 + wave;
+    const uint32_t c = unit * 4 + wave;
     const uint32_t C = *dc.n_cols;
     if (c >= C) return;
     if (dc.tri == 2u && C >= 2u) return;  // chains on k_sweep_lean2: k_bins_lean2
@@ -4343,6 +4363,11 @@ __global__ __launch_bounds__(256) void k_bins(const DevContig* __restrict__ cont
             store_bin(dc.lik, dc.lik_exp, idx, s_bins[wave][tri_local(la, lb)] * scale, pm, pe, xexp);
         }
     }
+}
+__global__ __launch_bounds__(256) void k_bins(const DevContig* __restrict__ contigs) {
+    __shared__ double s_bins[4][PG_AMAX * (PG_AMAX + 1) / 2];
+    const DevContig& dc = contigs[blockIdx.y];
+    bins_unit(dc, blockIdx.x, s_bins);
 }
 
 
@@ -4663,9 +4688,9 @@ static void launch_sweep(const DevContig* d_contigs, uint32_t n_contigs, uint32_
 extern "C" {
 
 void pgk_launch_prep(const DevContig* d_contigs, uint32_t n_contigs, uint32_t max_v, DevTable tab, hipStream_t s) {
-    dim3 grid((max_v + 3) / 4, n_contigs);
+    dim3 grid((max_v + 4 * PG_VREP - 1) / (4 * PG_VREP), n_contigs);
     hipLaunchKernelGGL(k_prep, grid, dim3(256), 0, s, d_contigs, tab);
-    dim3 grid16((max_v + 15) / 16, n_contigs);
+    dim3 grid16((max_v + 16 * PG_VREP - 1) / (16 * PG_VREP), n_contigs);
     hipLaunchKernelGGL(k_prep_bi, grid16, dim3(256), 0, s, d_contigs, tab);  // (chains of biallelic objects; each kernel skips the other's)
 }
 void pgk_launch_compact(const DevContig* d_contigs, uint32_t n_contigs, hipStream_t s) {
@@ -4675,11 +4700,13 @@ void pgk_launch_records(const DevContig* d_contigs, uint32_t n_contigs, uint32_t
     dim3 grid((max_v + 3) / 4, n_contigs);
     hipLaunchKernelGGL(k_records, grid, dim3(256), 0, s, d_contigs);
 }
-void pgk_launch_bins(const DevContig* d_contigs, uint32_t n_contigs, uint32_t max_v, hipStream_t s) {
-    dim3 grid((max_v + 3) / 4, n_contigs);
+// which: bit 0 = the job has chains whose bins k_bins forms, bit 1 = chains on k_sweep_lean2 (k_bins_lean2)
+void pgk_launch_bins(const DevContig* d_contigs, uint32_t n_contigs, uint32_t max_v, uint32_t which, hipStream_t s) {
+    // (a chain on k_sweep_lean2 that ends up with a single column is k_bins' too: one block per chain covers that)
+    dim3 grid((which & 1u) ? (max_v + 3) / 4 : 1u, n_contigs);
     hipLaunchKernelGGL(k_bins, grid, dim3(256), 0, s, d_contigs);
     dim3 grid256((max_v + 255) / 256, n_contigs);
-    hipLaunchKernelGGL(k_bins_lean2, grid256, dim3(256), 0, s, d_contigs);  // (chains on k_sweep_lean2; each kernel skips the other's columns)
+    if (which & 2u) hipLaunchKernelGGL(k_bins_lean2, grid256, dim3(256), 0, s, d_contigs);  // (each kernel skips the other's columns)
 }
 void pgk_launch_sweep(const DevContig* d_contigs, uint32_t n_contigs, uint32_t hp_mask, int phase, hipStream_t s) {
     if (phase == 1) launch_sweep<1>(d_contigs, n_contigs, hp_mask, 0, s);

@@ -33,7 +33,7 @@ extern "C" {
 void pgk_launch_prep(const DevContig*, uint32_t, uint32_t, DevTable, hipStream_t);
 void pgk_launch_compact(const DevContig*, uint32_t, hipStream_t);
 void pgk_launch_records(const DevContig*, uint32_t, uint32_t, hipStream_t);
-void pgk_launch_bins(const DevContig*, uint32_t, uint32_t, hipStream_t);
+void pgk_launch_bins(const DevContig*, uint32_t, uint32_t, uint32_t, hipStream_t);
 void pgk_launch_sweep(const DevContig*, uint32_t, uint32_t, int, hipStream_t);
 void pgk_launch_sweep_chunk(const DevContig*, uint32_t, uint32_t, uint32_t, hipStream_t);
 void pgk_launch_post(const DevContig*, uint32_t, uint32_t, uint32_t, hipStream_t);
@@ -355,6 +355,7 @@ struct pg_job {
     std::vector<int32_t> tab_e;
     DevTable tab;
     uint32_t hp_mask = 0, max_v = 0;
+    uint32_t bins_which = 0;   // bit 0: chains whose bins k_bins forms, bit 1: chains on k_sweep_lean2 (k_bins_lean2)
     uint32_t vit_bits = 0;     // run_phasing: 1 / 2 / 4 = chains with 16 / 32 / 64 padded paths
     hipEvent_t ev_vit[2];
     double vit_ms = 0.0;
@@ -772,6 +773,7 @@ int job_build(int device, uint32_t n_index, const pg_contig_batch* batches, cons
         d.col_stride = d.tri ? 2304u : x.HP * x.HP;
         if (d.tri) job->hp_mask |= 128u;
         if (d.tri == 2u) job->hp_mask |= 256u;
+        job->bins_which |= (d.tri == 2u) ? 2u : 1u;
         ch.d = d;
     }
     {
@@ -938,7 +940,7 @@ extern "C" int pg_job_run(pg_job* job, void* stream_, char* err, size_t errlen) 
             pgk_launch_sweep(job->d_contigs, n, job->hp_mask, 2, s);
             HIP_TRY(hipGetLastError());
             HIP_TRY(hipEventRecord(job->ev[5], s));
-            pgk_launch_bins(job->d_contigs, n, job->max_v, s);
+            pgk_launch_bins(job->d_contigs, n, job->max_v, job->bins_which, s);
             HIP_TRY(hipGetLastError());
             HIP_TRY(hipEventRecord(job->ev[6], s));
         } else {
