@@ -850,36 +850,54 @@ DEVI void records_unit(const DevContig& dc, uint32_t unit) {
         out[3] = f64x2{__longlong_as_double((long long)E[PG_ESTRIDE + 1]), __longlong_as_double((long long)src[PG_REC_BITS1 / 8])};
         return;
     }
-    const uint32_t c = unit * 4 + wave;
-    if (c >= C) return;
-    const uint32_t v = dc.col_variant[c];
-    const uint64_t* src = (const uint64_t*)(dc.vrec + (size_t)v * dc.RB);
-    uint64_t* dst = (uint64_t*)(dc.colrec + (size_t)c * dc.RB);
-    const uint32_t words = dc.RB / 8;
-    double c0 = 0.0, c1 = 0.0, c2 = 0.0, kappa = 0.0;
-    if (c > 0) {
-        const uint32_t pv = dc.col_variant[c - 1];
-        const double d = (double)(dc.pos[v] - dc.pos[pv]) * dc.dist_scale;
-        transition_consts(d, dc.H, dc.uniform, c0, c1, c2, kappa);
-    }
-    for (uint32_t w = lane; w < words; w += 64) {
-        uint64_t val = src[w];
-        if (w < 4) {
-            const double cv = w == 0 ? c0 : (w == 1 ? c1 : (w == 2 ? c2 : kappa));
-            val = (uint64_t)__double_as_longlong(cv);
+    // Full records: a wave takes 64 consecutive columns.  First every LANE forms the transition constants of ONE of them
+    // (one wave per column had all 64 lanes evaluate the same exp(): 17.7 ms for 31.5 M columns of 16-path chains), then
+    // the wave copies the 64 records into column order, the four constants of a column coming out of its LDS slice.
+    __shared__ double s_c[4][64][4];
+    __shared__ uint32_t s_v[4][64];
+    const uint32_t cbase = (unit * 4u + wave) * 64u;
+    if (cbase >= C) return;
+    {
+        const uint32_t c = cbase + lane;
+        double c0 = 0.0, c1 = 0.0, c2 = 0.0, kappa = 0.0;
+        uint32_t v = 0;
+        if (c < C) {
+            v = dc.col_variant[c];
+            if (c > 0) {
+                const double d = (double)(dc.pos[v] - dc.pos[dc.col_variant[c - 1]]) * dc.dist_scale;
+                transition_consts(d, dc.H, dc.uniform, c0, c1, c2, kappa);
+            }
         }
-        dst[w] = val;
+        s_c[wave][lane][0] = c0; s_c[wave][lane][1] = c1; s_c[wave][lane][2] = c2; s_c[wave][lane][3] = kappa;
+        s_v[wave][lane] = v;
     }
-    if ((dc.lean || dc.small) && lane < 8) {
-        // compact record of the lean sweep: {c0, c1, c2, kappa, E'00, E'01, E'11, bits1}
-        const uint64_t* E = src + PG_REC_E / 8;
-        uint64_t val;
-        if (lane < 4) { const double cv = lane == 0 ? c0 : (lane == 1 ? c1 : (lane == 2 ? c2 : kappa)); val = (uint64_t)__double_as_longlong(cv); }
-        else if (lane == 4) val = E[0];
-        else if (lane == 5) val = E[1];
-        else if (lane == 6) val = E[PG_ESTRIDE + 1];
-        else val = src[PG_REC_BITS1 / 8];
-        ((uint64_t*)dc.frec)[(size_t)c * 8 + lane] = val;
+    wave_sync_lds();
+    // the copy: the wave's n records are n * RB/16 16-byte pieces, contiguous on the destination side (1 KB per wave
+    // instruction); piece p belongs to column p / (RB/16) (exact by a 32-bit reciprocal: p < 5632, 24 <= RB/16 <= 88)
+    const uint32_t n = C - cbase < 64u ? C - cbase : 64u;
+    const uint32_t ppr = dc.RB / 16u, inv = (uint32_t)((0x100000000ull + ppr - 1u) / ppr);
+    typedef double f64x2 __attribute__((ext_vector_type(2)));
+    f64x2* dst = (f64x2*)(dc.colrec + (size_t)cbase * dc.RB);
+    for (uint32_t p = lane; p < n * ppr; p += 64u) {
+        const uint32_t q = __umulhi(p, inv), w = p - q * ppr;
+        const uint32_t v = s_v[wave][q];
+        f64x2 val = ((const f64x2*)(dc.vrec + (size_t)v * dc.RB))[w];
+        if (w < 2u) val = f64x2{s_c[wave][q][2u * w], s_c[wave][q][2u * w + 1u]};
+        dst[p] = val;
+    }
+    if (dc.lean || dc.small) {
+        // compact records of the lean sweeps: {c0, c1, c2, kappa, E'00, E'01, E'11, bits1}, eight columns per wave instruction
+        for (uint32_t p = lane; p < n * 8u; p += 64u) {
+            const uint32_t q = p >> 3, f = p & 7u;
+            const uint64_t* src = (const uint64_t*)(dc.vrec + (size_t)s_v[wave][q] * dc.RB);
+            uint64_t val;
+            if (f < 4u) val = (uint64_t)__double_as_longlong(s_c[wave][q][f]);
+            else if (f == 4u) val = src[PG_REC_E / 8];
+            else if (f == 5u) val = src[PG_REC_E / 8 + 1];
+            else if (f == 6u) val = src[PG_REC_E / 8 + PG_ESTRIDE + 1];
+            else val = src[PG_REC_BITS1 / 8];
+            ((uint64_t*)dc.frec)[(size_t)cbase * 8 + p] = val;
+        }
     }
 }
 
@@ -4697,7 +4715,7 @@ void pgk_launch_compact(const DevContig* d_contigs, uint32_t n_contigs, hipStrea
     hipLaunchKernelGGL(k_compact, dim3(n_contigs), dim3(1024), 0, s, d_contigs);
 }
 void pgk_launch_records(const DevContig* d_contigs, uint32_t n_contigs, uint32_t max_v, hipStream_t s) {
-    dim3 grid((max_v + 3) / 4, n_contigs);
+    dim3 grid((max_v + 255) / 256, n_contigs);   // 256 columns per block either way (a thread or a quarter of a wave's 64 each)
     hipLaunchKernelGGL(k_records, grid, dim3(256), 0, s, d_contigs);
 }
 // which: bit 0 = the job has chains whose bins k_bins forms, bit 1 = chains on k_sweep_lean2 (k_bins_lean2)
