@@ -152,6 +152,10 @@ struct DevContig {
     // 1: HP = 128 or 64, every object has at most PG_AMAX alleles (all columns narrow) and the chain is not `lean`: the
     // store-only phases run on k_sweep_leanx (the lean step with table emissions)
     uint32_t  leanx;
+    // 1 (fused jobs): HP = 16 or 32, H = HP, every object biallelic: phase 2 (general kernel, one compute wave per
+    // half-chain) writes the four class sums of a column, part[4 c + 2 (row allele) + (column allele)], and
+    // k_bins_lean2 turns them into bins — instead of per-thread partials reduced by k_bins
+    uint32_t  cls4;
     double*   xbuf;            // [2][HP*HP] generic kernel scratch (forward role first)
     uint32_t* err;
     unsigned long long* prof;  // [64] in-kernel cycle counters (PG_DEBUG bit 3), profiling only

@@ -1277,6 +1277,23 @@ DEVI void posterior(ChainShared<HP, R>& sh, gdouble* part_out, uint32_t part_slo
             acc[1] = fma(pr, bit ? 1.0 : 0.0, acc[1]);
             acc[0] = fma(pr, bit ? 0.0 : 1.0, acc[0]);
         }
+        if constexpr (Cfg::NW == 1) {
+            if (part_slots == 0u) {
+                // DevContig::cls4 (single-wave configurations, every object biallelic, no phantom paths): the wave IS the
+                // column, so the four (row allele, column allele) class sums are formed here — four 64-lane sums — and
+                // leave as 32 bytes, part[4 c + 2 (row allele) + (column allele)] (what k_sweep_lean2 writes; k_bins_lean2
+                // turns them into bins, one thread per column), instead of 1 KB of per-thread partials for k_bins to reduce
+                const bool aj1 = ri.em.ajr == 1u;
+                const double s00 = wave_sum(aj1 ? 0.0 : acc[0]), s01 = wave_sum(aj1 ? acc[0] : 0.0);
+                const double s10 = wave_sum(aj1 ? 0.0 : acc[1]), s11 = wave_sum(aj1 ? acc[1] : 0.0);
+                if (p.tid == 0) {
+                    gdouble2* o = (gdouble2*)part_out + (size_t)c * 2u;
+                    o[0] = v2f64{s00, s01};
+                    o[1] = v2f64{s10, s11};
+                }
+                return;
+            }
+        }
     } else {
         const unsigned char* al = sh.rec[c & 7u] + PG_REC_ALLELES;
         uint32_t aw[Cfg::UNI ? R / 4 : 1];
@@ -1332,7 +1349,7 @@ DEVI void forward_body(const DevContig& dc, ChainShared<HP, R>& sh, uint32_t C, 
     p.wave = __builtin_amdgcn_readfirstlane(p.tid >> 6);
     gcu64* colrec = (gcu64*)dc.colrec;
     gdouble* part_out = (gdouble*)dc.part;
-    const uint32_t part_slots = dc.part_slots;
+    const uint32_t part_slots = dc.cls4 ? 0u : dc.part_slots;   // (0: the four class sums of a column instead of per-thread partials, see posterior)
     const bool tri = PHASE == 2 && HP == 64 && __builtin_amdgcn_readfirstlane((int)dc.tri) != 0;  // stored columns are upper triangles
 
     auto rec_load = [&](uint32_t c) -> unsigned long long {
@@ -1698,7 +1715,7 @@ DEVI void backward_body(const DevContig& dc, ChainShared<HP, R>& sh, uint32_t C,
     p.wave = __builtin_amdgcn_readfirstlane(p.tid >> 6);
     gcu64* colrec = (gcu64*)dc.colrec;
     gdouble* part_out = (gdouble*)dc.part;
-    const uint32_t part_slots = dc.part_slots;
+    const uint32_t part_slots = dc.cls4 ? 0u : dc.part_slots;   // (0: the four class sums of a column instead of per-thread partials, see posterior)
     // recursion steps run over t = t0 .. bot where t0 = top-1 in phase 1 (column top is the
     // all-ones column) and t0 = top in phase 2 (resumed behind column mid)
     const int64_t t0 = PHASE == 1 ? top - 1 : top;
@@ -4281,7 +4298,7 @@ DEVI void bins_unit(const DevContig& dc, uint32_t unit, double (&s_bins)[4][PG_A
     const uint32_t c = unit * 4 + wave;
     const uint32_t C = *dc.n_cols;
     if (c >= C) return;
-    if (dc.tri == 2u && C >= 2u) return;  // chains on k_sweep_lean2: k_bins_lean2
+    if ((dc.tri == 2u && C >= 2u) || dc.cls4) return;  // chains whose class sums arrive finished (k_sweep_lean2, DevContig::cls4): k_bins_lean2
     // (chains with compact records only have no column-order copy of the records: the variant's own record)
     const bool direct = compact_records_only(dc, C);
     const unsigned char* rec = direct ? dc.vrec + (size_t)dc.col_variant[c] * dc.RB : dc.colrec + (size_t)c * dc.RB;
@@ -4397,7 +4414,8 @@ __global__ __launch_bounds__(256) void k_bins(const DevContig* __restrict__ cont
 __global__ __launch_bounds__(256) void k_bins_lean2(const DevContig* __restrict__ contigs) {
     const DevContig& dc = contigs[blockIdx.y];
     const uint32_t C = *dc.n_cols;
-    if (!(dc.tri == 2u && C >= 2u)) return;
+    const bool cls = dc.cls4 != 0u;   // class sums from the general kernel's single-wave configurations: full columns, no halving
+    if (!((dc.tri == 2u && C >= 2u) || cls)) return;
     const uint32_t c = blockIdx.x * 256u + threadIdx.x;
     if (c >= C) return;
     const bool fb = dc.fwd_fallback[c] != 0;
@@ -4414,23 +4432,33 @@ __global__ __launch_bounds__(256) void k_bins_lean2(const DevContig* __restrict_
     } else {
         // the forward column fell back to uniform after this column's partials had been formed from the all-zero
         // column: alpha_hat * fsum = 1 / H^2 for every state, times the stored backward column (upper triangle, the
-        // diagonal halved)
-        const uint32_t H = dc.H;
+        // diagonal halved — or, for class-sum chains of the general kernel, the full column in row-pair layout)
+        const uint32_t H = dc.H, HP = dc.HP;
         const unsigned char* al = rec + PG_REC_ALLELES;
         const double* col = dc.fwd + (size_t)c * dc.col_stride;
-        for (uint32_t i = 0; i < H; ++i)
-            for (uint32_t j = i; j < H; ++j) {
-                const double val = col[(size_t)tri_unit_of(i >> 1, j) * 2 + (i & 1u)];
-                const double both = 2.0 * val;  // (i, j) and (j, i); the halved diagonal once, doubled
-                const uint32_t a = al[i], b = al[j];
-                if (a == b) { if (a == 0u) b00 += both; else b11 += both; }
-                else b01 += both;
-            }
+        if (cls) {
+            for (uint32_t i = 0; i < H; ++i)
+                for (uint32_t j = 0; j < H; ++j) {
+                    const double val = col[((size_t)(i >> 1) * HP + j) * 2 + (i & 1u)];
+                    const uint32_t a = al[i], b = al[j];
+                    if (a == b) { if (a == 0u) b00 += val; else b11 += val; }
+                    else b01 += val;
+                }
+        } else {
+            for (uint32_t i = 0; i < H; ++i)
+                for (uint32_t j = i; j < H; ++j) {
+                    const double val = col[(size_t)tri_unit_of(i >> 1, j) * 2 + (i & 1u)];
+                    const double both = 2.0 * val;  // (i, j) and (j, i); the halved diagonal once, doubled
+                    const uint32_t a = al[i], b = al[j];
+                    if (a == b) { if (a == 0u) b00 += both; else b11 += both; }
+                    else b01 += both;
+                }
+        }
         const double unif = 1.0 / ((double)H * (double)H);
         b00 *= unif; b01 *= unif; b11 *= unif;
     }
     const double scale = 1.0 / ((fb ? 1.0 : dc.fscale[c]) * dc.bscale[c]);
-    int xexp = -((fb ? 0 : PG_BIAS_F) + PG_BIAS_B) + (reform ? 0 : 1);  // (+1: the partials are sums over the stored half, see k_bins)
+    int xexp = -((fb ? 0 : PG_BIAS_F) + PG_BIAS_B) + ((reform || cls) ? 0 : 1);  // (+1: the partials of triangle chains are sums over the stored half, see k_bins)
     if (c + 1 < C) xexp += *(const int32_t*)(dc.vrec + (size_t)dc.col_variant[c + 1] * dc.RB + PG_REC_EXP);
     const uint32_t a0 = dc.allele_off[v], A = dc.allele_off[v + 1] - a0;
     const uint32_t pn = dc.pair_n, NP = (pn * (pn + 1) / 2 + 1u) & ~1u;

@@ -209,6 +209,7 @@ namespace {
 struct IndexHost {   // one index contig
     uint32_t V = 0, H = 0, HP = 0, T = 0, RB = 0, part_slots = 2, pair_n = 1;
     bool lean = false;  // every object biallelic and H = HP = 64: the store-only phases run on k_sweep_lean
+    bool cls4 = false;  // HP = 16 / 32, H = HP, every object biallelic, fused job: class sums instead of per-thread partials (DevContig::cls4)
     bool leanx = false; // HP = 128 / 64 and every object has at most PG_AMAX alleles (not `lean`): the store-only phases run on k_sweep_leanx
     bool small = false; // every object biallelic and H = HP = 16: the store-only phases run on k_sweep_small16
     bool prep_fast = false;  // every object has exactly two alleles and <= 32 k-mers, H <= 64: k_prep_bi
@@ -567,6 +568,10 @@ int job_build(int device, uint32_t n_index, const pg_contig_batch* batches, cons
         x.lean = lean_ok && x.HP == 64 && x.H == 64 && maxA == 2 && x.V > 0;
         x.small = lean_ok && x.HP == 16 && x.H == 16 && maxA == 2 && x.V > 0;   // (and enough of them: below)
         {
+            const char* e = getenv("PG_CLS4");    // PG_CLS4=0: per-thread partials + k_bins (cross-check)
+            x.cls4 = (x.HP == 16 || x.HP == 32) && x.H == x.HP && maxA == 2 && x.V > 0 && !(e && !strcmp(e, "0"));
+        }
+        {
             const char* e = getenv("PG_LEANX");   // PG_LEANX=0: the general kernel (cross-check)
             x.leanx = lean_ok && (x.HP == 128 || x.HP == 64) && !x.lean && maxA >= 1 && maxA <= PG_AMAX && x.V > 0 && !(e && !strcmp(e, "0"));
         }
@@ -598,6 +603,7 @@ int job_build(int device, uint32_t n_index, const pg_contig_batch* batches, cons
         // k_sweep_leanx is a latency kernel (lone chains: 1470 vs 2645 ns per column at 128 paths); phase 1 of a fused job
         // with hundreds of chains is bound by HBM writes, where the general kernel measured faster (7.8 vs 8.9 ms on 128 chains
         // of 128 paths).  PG_LEANX=1 forces it there too.
+        if (job->chunked) for (auto& x : job->index) x.cls4 = false;   // (chunked jobs form their posteriors in k_post)
         if (!job->chunked) {
             const char* e = getenv("PG_LEANX");
             if (!(e && !strcmp(e, "1"))) for (auto& x : job->index) x.leanx = false;
@@ -762,7 +768,7 @@ int job_build(int device, uint32_t n_index, const pg_contig_batch* batches, cons
         d.scratch = (double*)(A + p.scratch); d.chunk_cols = job->chunk_cols;
         d.wide = A + p.wide; d.wide_idx = x.wide_bytes ? (const uint32_t*)(A + x.o_widx) : nullptr;
         d.vpair = A + p.vpair; d.xbuf = (double*)(A + p.xbuf);
-        d.frec = (double*)(A + p.frec); d.lean = x.lean ? 1u : 0u; d.small = x.small ? 1u : 0u; d.leanx = x.leanx ? 1u : 0u;
+        d.frec = (double*)(A + p.frec); d.lean = x.lean ? 1u : 0u; d.small = x.small ? 1u : 0u; d.leanx = x.leanx ? 1u : 0u; d.cls4 = x.cls4 ? 1u : 0u;
         d.prep_fast = x.prep_fast ? 1u : 0u;
         if (params->run_phasing) {
             d.vit_tq = (double*)(A + p.vtq); d.vit_back = (uint16_t*)(A + p.vback); d.vit_best = (uint32_t*)(A + p.vbest);
@@ -773,7 +779,7 @@ int job_build(int device, uint32_t n_index, const pg_contig_batch* batches, cons
         d.col_stride = d.tri ? 2304u : x.HP * x.HP;
         if (d.tri) job->hp_mask |= 128u;
         if (d.tri == 2u) job->hp_mask |= 256u;
-        job->bins_which |= (d.tri == 2u) ? 2u : 1u;
+        job->bins_which |= (d.tri == 2u || d.cls4) ? 2u : 1u;
         ch.d = d;
     }
     {

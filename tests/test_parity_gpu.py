@@ -399,6 +399,33 @@ def test_small16_kernel_biallelic_h16_vs_oracle_and_general(K, orc, monkeypatch)
         assert float(np.where(den > 0, np.abs(a - c) / np.where(den > 0, den, 1), 0).max()) < 1e-11
 
 
+@pytest.mark.parametrize("H", [16, 32])
+def test_class_sums_in_the_single_wave_sweeps_vs_oracle_and_partials(H, orc, monkeypatch):
+    """Fused jobs, 16 / 32 paths, every object biallelic (DevContig::cls4): phase 2 writes the four class sums of a column
+    and k_bins_lean2 forms the bins (one thread per column), instead of 1 KB of per-thread partials reduced by k_bins.
+    Regularised and unregularised table (forward fall-backs whose bins are re-formed from the stored backward column),
+    chains of 1 ... 300 variants; both forms must match the oracle and agree with each other to fp64 rounding."""
+    monkeypatch.setenv("PG_SWEEP_MODE", "fused")
+    for seed, reg, V in ((5, 0.0, 300), (6, 0.01, 257), (7, 0.0, 1), (8, 0.01, 2), (9, 0.0, 3)):
+        args = (6, 108, 54, reg)
+        b = synthetic_panel(V, H, 20, seed=seed)
+        if reg == 0.0 and V > 3:
+            b.kmer_count[::3] = 0
+            b.kmer_count[1::17] = 60000
+        t, p = hmm.ProbabilityTable(*args), hmm.make_params(1.26, False, 1e-5)
+        monkeypatch.delenv("PG_CLS4", raising=False)
+        cls = hmm.genotype_contig(b, t, p)
+        monkeypatch.setenv("PG_CLS4", "0")
+        old = hmm.genotype_contig(b, t, p)
+        monkeypatch.delenv("PG_CLS4", raising=False)
+        ref = orc.genotype_contig(b, orc.OracleTable(*args), orc.make_params(1.26, False, 1e-5))
+        assert_parity(b, cls, ref)
+        assert_parity(b, old, ref)
+        a, c = cls.likelihoods_ld(), old.likelihoods_ld()
+        den = np.maximum(np.abs(a), np.abs(c))
+        assert float(np.where(den > 0, np.abs(a - c) / np.where(den > 0, den, 1), 0).max()) < 1e-11
+
+
 @pytest.mark.parametrize("mode", ["chunked", "fused"])
 def test_small16_kernel_many_chains_of_different_lengths(mode, orc, monkeypatch):
     """Chains of very different lengths share waves (the trip count is the longest row's; finished rows run on with

@@ -1,6 +1,6 @@
 #!/bin/bash
 cd ${GRAFT_REPO_ROOT:-.}
-timeout 900 python -m pytest tests/test_parity_gpu.py -m gpu -q --no-header -x -k "panels or known_answers or many_alleles or wide or cohort or small16 or no_columns or fixture_shape or transition or multi_contig or lean_kernel" 2>&1 | tail -3
+timeout 900 python -m pytest tests/test_parity_gpu.py -m gpu -q --no-header -x -k "class_sums or panels or known_answers or many_alleles or wide or cohort or small16 or no_columns or fixture_shape or transition or multi_contig or lean_kernel" 2>&1 | tail -3
 python bench.py --workload genome24_small --steps 2 --warmup 1 --no-cpu-baseline --no-sampler --no-viterbi --no-dropin 2>&1 | tail -1 | python -c "
 import sys, json
 d = json.loads(sys.stdin.readline())
