@@ -2131,6 +2131,7 @@ struct LeanShared {
     double psum[2][NW][64];
     double u[NW][64] __attribute__((aligned(16)));
     double rec[2][PG_LEAN_BLOCK][8] __attribute__((aligned(16)));  // two blocks of compact records
+    double scal[2][64];   // per-column scalars on their way out (ColScalars)
     // emissions by ROW PAIRS (lean_expand): tab[b][r][c][a] = {e(row 2p, column allele a), e(row 2p+1, a)} for the row
     // pair's allele combination c = bit(2p) + 2 bit(2p+1); comb[b][r][w][p] = 32 c of pair p of wave w's rows
     v2f64 tab[2][PG_LEAN_BLOCK][4][2];
@@ -2190,17 +2191,17 @@ DEVI double sel_by_bit(uint32_t bits /*uniform*/, int k, double if0, double if1)
 }
 
 // Per-column scalars (column scale mantissas, hand-over sums) of the lean kernel: one 8-byte store per
-// column measured ~200 cycles on the chain, so wave 0 collects the value of column t in lane t & 63 (one
-// compare + two selects) and writes 64 columns with ONE coalesced store.
+// column measured ~200 cycles on the chain, so the collecting wave parks the value of column t in entry t & 63 of an
+// LDS row (one LDS write per column) and writes 64 columns with ONE coalesced store.
 struct ColScalars {
-    double buf = 0.0;
-    unsigned long long valid = 0ull;  // uniform: lanes holding a value not yet written
-    DEVI void put(uint32_t lane, uint64_t t /*uniform*/, double v) {
-        if (lane == (uint32_t)(t & 63u)) buf = v;
+    double* row;                      // 64 doubles of LDS, this wave's own
+    unsigned long long valid = 0ull;  // uniform: entries holding a value not yet written
+    DEVI void put(uint32_t /*lane*/, uint64_t t /*uniform*/, double v /*the same in every lane*/) {
+        row[t & 63u] = v;             // (every lane the same address and value: one LDS instruction, no selects)
         valid |= 1ull << (t & 63u);
     }
     DEVI void flush(gdouble* arr, uint32_t lane, uint64_t t_any /*uniform: any column of the 64-block held*/) {
-        if ((valid >> lane) & 1ull) arr[(t_any & ~(uint64_t)63u) + lane] = buf;
+        if ((valid >> lane) & 1ull) arr[(t_any & ~(uint64_t)63u) + lane] = row[lane];
         valid = 0ull;
     }
 };
@@ -2407,7 +2408,7 @@ DEVI void lean_forward(const DevContig& dc, LeanShared<R>& sh, uint32_t C, uint3
         if (wave == 0) fallback[cprev] = 1;
     };
 
-    ColScalars fsc;
+    ColScalars fsc{&sh.scal[0][0]};
     double x[R];
     {
         const FRec r0 = read_frec(sh, 0);
@@ -2603,7 +2604,7 @@ DEVI void lean_backward(const DevContig& dc, LeanShared<R>& sh, uint32_t C, uint
         for (int k = 0; k < R; k += 2) put_pair(dst, k >> 1, v[k], v[k + 1]);
     };
 
-    ColScalars bsc, bsm;
+    ColScalars bsc{&sh.scal[0][0]}, bsm{&sh.scal[1][0]};
     double w[R], Sy;
     FRec cur = read_frec(sh, 0);  // record t0+1: constants of the gap t0 -> t0+1, emission of column t0+1
     {
@@ -2646,9 +2647,6 @@ DEVI void lean_backward(const DevContig& dc, LeanShared<R>& sh, uint32_t C, uint
     // (constants of the next step); `ec` = emissions of column t (this step's w), `en` takes those of column t-1.
     auto step = [&](int64_t t, const FRec& cur, FRec& nxt) __attribute__((always_inline)) {
         const uint32_t n = (uint32_t)(t0 - t);        // step number: column t is the record with rel = n + 1
-        nxt = read_frec(sh, n + 1u);
-        const unsigned long long bits_n = (unsigned long long)__double_as_longlong(sh.rec[((n + 2u) / PG_LEAN_BLOCK) & 1u][(n + 2u) % PG_LEAN_BLOCK][7]);  // column t-1
-        const u32x2 cdn = lean_pair_bytes(sh, n + 2u, wave);
         if (((n + 4u) % PG_LEAN_BLOCK) == 0u) {
             const uint32_t blk = (n + 4u) / PG_LEAN_BLOCK;
             recs.park(sh, blk, piece);
@@ -2668,6 +2666,13 @@ DEVI void lean_backward(const DevContig& dc, LeanShared<R>& sh, uint32_t C, uint
         double pc[64 / R], pr[64 / R];  // (see lean_forward)
 #pragma unroll
         for (int q = 0; q < 64 / R; ++q) { pc[q] = sh.psum[pb][q][lane]; pr[q] = sh.psum[pb][q][i0 + (lane & 15u)]; }
+        // the records of the next step are read HERE, behind the barrier and behind the column sums (in front of the barrier
+        // the wave would wait out their LDS latency: the barrier's release waits for every outstanding LDS operation)
+        lean_fence();
+        nxt = read_frec(sh, n + 1u);
+        const unsigned long long bits_n = (unsigned long long)__double_as_longlong(sh.rec[((n + 2u) / PG_LEAN_BLOCK) & 1u][(n + 2u) % PG_LEAN_BLOCK][7]);  // column t-1
+        const u32x2 cdn = lean_pair_bytes(sh, n + 2u, wave);
+        lean_fence();
         const double Cj = (pc[0] + pc[1]) + (pc[2] + pc[3]);
         const v4f64 zz = {0.0, 0.0, 0.0, 0.0};
         const v4f64 ma = __builtin_amdgcn_mfma_f64_16x16x4f64(Cj, 1.0, zz, 0, 0, 0);
@@ -2832,7 +2837,7 @@ DEVI void lean2_forward(const DevContig& dc, LeanShared2<R>& sh2, uint32_t C) {
     tri.load(cols + (size_t)lo * colsz, b0);
     if (lo + 1 < C) tri.load(cols + (size_t)(lo + 1) * colsz, b1);
 
-    ColScalars fsc;
+    ColScalars fsc{&sh.scal[0][0]};
     double x[R];
     {
         const FRec r0 = read_frec(sh, 0);
@@ -2976,7 +2981,7 @@ DEVI void lean2_backward(const DevContig& dc, LeanShared2<R>& sh2, uint32_t C) {
     tri.load(cols + (size_t)t0 * colsz, b0);
     if (t0 - 1 >= 0) tri.load(cols + (size_t)(t0 - 1) * colsz, b1);
 
-    ColScalars bsc;
+    ColScalars bsc{&sh.scal[0][0]};
     double w[R], Sy;
     FRec cur = read_frec(sh, 0);  // record t0+1: constants of the gap t0 -> t0+1, emission of column t0+1
     {
@@ -3167,6 +3172,7 @@ template <int HP>
 struct LxShared {
     using Cfg = LxCfg<HP>;
     double psum[2][4][HP];
+    double scal[2][64];   // per-column scalars on their way out (ColScalars)
     unsigned char rec[2][Cfg::BLK][Cfg::RB] __attribute__((aligned(16)));
 };
 template <int HP>
@@ -3310,7 +3316,7 @@ DEVI void leanx_forward(const DevContig& dc, LxShared<HP>& sh, uint32_t C, uint3
     };
     using I0 = std::integral_constant<int, 0>; using IH = std::integral_constant<int, R / 2>; using IR = std::integral_constant<int, R>;
 
-    ColScalars fsc;
+    ColScalars fsc{&sh.scal[0][0]};
     double x[R], e[R];
     {
         const LxAlleles<R> a0 = lx_alleles<HP>(sh, 0, j, i0);
@@ -3482,7 +3488,7 @@ DEVI void leanx_backward(const DevContig& dc, LxShared<HP>& sh, uint32_t C, uint
     };
     using I0 = std::integral_constant<int, 0>; using IH = std::integral_constant<int, R / 2>; using IR = std::integral_constant<int, R>;
 
-    ColScalars bsc, bsm;
+    ColScalars bsc{&sh.scal[0][0]}, bsm{&sh.scal[1][0]};
     double w[R], e[R], Sy;
     {
         double y[R];
