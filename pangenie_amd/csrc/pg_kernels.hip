@@ -1252,6 +1252,36 @@ DEVI void fetch_u(const ChainShared<HP, R>& sh, const ThreadPos& p, double urow,
     for (int k = 0; k < R; ++k) ui[k] = row[k];
 }
 
+template <int K>
+DEVI double row_bcast_f64(double v) {
+    // (old = the source itself: every lane has a valid source under row_newbcast, so no separate `old` register is set up)
+    return __longlong_as_double(__builtin_amdgcn_update_dpp(__double_as_longlong(v), __double_as_longlong(v), 0x150 + K, 0xF, 0xF, true));
+}
+// R = 32 rows per wave (HP = 128): the u_i come out of two DPP-row registers — lane (l & 15) of urep[s] holds c1 * C of row
+// i0 + 16 s + (l & 15) — by one v_mov_b64_dpp row_newbcast each (round 2 pulled them out of a lane-indexed register with
+// two v_readlane_b32, ~17 cycles apiece, per state).  `k` is a constant once the caller's loop is unrolled.
+template <int HP, int R>
+DEVI void u_rows_setup(const ChainShared<HP, R>& sh, uint32_t pb, const ThreadPos& p, double c1, double (&urep)[2]) {
+    using Cfg = ChainCfg<HP, R>;
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+        const uint32_t col = p.i0 + 16u * (uint32_t)s + (p.lane & 15u);
+        double c = sh.psum[pb][0][col];
+#pragma unroll
+        for (int g = 1; g < Cfg::NRG; ++g) c += sh.psum[pb][g][col];
+        urep[s] = c1 * c;
+    }
+}
+DEVI double u_of_row(const double (&urep)[2], int k) {
+    const double src = urep[(k >> 4) & 1];
+    switch (k & 15) {
+        case 0: return row_bcast_f64<0>(src);   case 1: return row_bcast_f64<1>(src);   case 2: return row_bcast_f64<2>(src);   case 3: return row_bcast_f64<3>(src);
+        case 4: return row_bcast_f64<4>(src);   case 5: return row_bcast_f64<5>(src);   case 6: return row_bcast_f64<6>(src);   case 7: return row_bcast_f64<7>(src);
+        case 8: return row_bcast_f64<8>(src);   case 9: return row_bcast_f64<9>(src);   case 10: return row_bcast_f64<10>(src); case 11: return row_bcast_f64<11>(src);
+        case 12: return row_bcast_f64<12>(src); case 13: return row_bcast_f64<13>(src); case 14: return row_bcast_f64<14>(src); default: return row_bcast_f64<15>(src);
+    }
+}
+
 // posterior partials of column c: acc[a] = sum over my rows with local allele a of pr = P' * beta'
 // (P' = forward column BEFORE its emission multiply: the emission of a bin is applied once, to the
 // finished bin, by k_bins — DESIGN.md §5)
@@ -1568,8 +1598,12 @@ DEVI void forward_body(const DevContig& dc, ChainShared<HP, R>& sh, uint32_t C, 
         double Cj, Crow, Call;
         read_colsums<HP, R>(sh, (t - 1) & 1u, p, Cj, Crow, Call);
         double urow = cur.c1 * Crow, ucol = cur.c1 * Cj;
-        publish_u<HP, R>(sh, p, urow, ucol);
-        if constexpr (R <= 16) fetch_u<HP, R>(sh, p, urow, ui);
+        // (R = 32, HP = 128: the store-only phases take the u_i from DPP-row registers; phase 2 — instruction-bound with its
+        // posterior, and measured 5 % slower with them on 128 resident chains — keeps the lane-indexed register)
+        constexpr bool UDPP = R > 16 && PHASE != 2;
+        if constexpr (R <= 16) { publish_u<HP, R>(sh, p, urow, ucol); fetch_u<HP, R>(sh, p, urow, ui); }
+        double urep[2] = {0.0, 0.0};
+        if constexpr (UDPP) u_rows_setup<HP, R>(sh, (t - 1) & 1u, p, cur.c1, urep);
         __builtin_amdgcn_sched_barrier(0);  // the LDS round trip must be in flight BEFORE the reduction starts
         double S = total_sum<HP>(Call);
         double uj = fma(cur.c2, S, ucol);
@@ -1581,7 +1615,7 @@ DEVI void forward_body(const DevContig& dc, ChainShared<HP, R>& sh, uint32_t C, 
             const double Cu = (double)H * unif;
             S = 1.0;
             uj = fma(cur.c0, unif, fma(cur.c2, 1.0, 2.0 * cur.c1 * Cu));
-            urow = 0.0;  // (HP = 128 takes its u_i from urow by readlane: zero like the fetched u_i)
+            urow = 0.0;  // (the lane-indexed form of the u_i: zero like the fetched / DPP-row ones)
             c0 = 0.0;
         }
         // P'_t = (c0 x + c1 (C_i + C_j) + c2 S) * 2^-es with es = exponent(S) - BIAS_F: the stored column, BEFORE
@@ -1628,6 +1662,7 @@ DEVI void forward_body(const DevContig& dc, ChainShared<HP, R>& sh, uint32_t C, 
             for (int k = 0; k < R; ++k) {
                 double uik;
                 if constexpr (R <= 16) uik = ui[k];
+                else if constexpr (UDPP) uik = u_of_row(urep, k);
                 else uik = readlane_f64(urow, __builtin_amdgcn_readfirstlane((int)((p.i0 + k) & 63u)));
                 state(k, uik, ((fe.rowbits >> k) & 1u) ? fe.eB : fe.eA, pprev);
             }
@@ -1641,6 +1676,7 @@ DEVI void forward_body(const DevContig& dc, ChainShared<HP, R>& sh, uint32_t C, 
                 for (int k = 0; k < R; ++k) {
                     double uik;
                     if constexpr (R <= 16) uik = ui[k];
+                    else if constexpr (UDPP) uik = u_of_row(urep, k);
                     else uik = readlane_f64(urow, __builtin_amdgcn_readfirstlane((int)((p.i0 + k) & 63u)));
                     const double e = KIND == 0 ? emission_narrow(rec, p.i0 + k, cur.em)
                                    : KIND == 1 ? emission_wide(rec, p.i0 + k, cur.em) : emission_at(rec, p.i0 + k, cur.em);
@@ -1929,9 +1965,11 @@ DEVI void backward_body(const DevContig& dc, ChainShared<HP, R>& sh, uint32_t C,
         double Cj, Crow, Call;
         read_colsums<HP, R>(sh, pb, p, Cj, Crow, Call);
         const double urow = k1 * Crow, ucol = k1 * Cj;
-        publish_u<HP, R>(sh, p, urow, ucol);
         double ui[R > 16 ? 1 : R];
-        if constexpr (R <= 16) fetch_u<HP, R>(sh, p, urow, ui);
+        if constexpr (R <= 16) { publish_u<HP, R>(sh, p, urow, ucol); fetch_u<HP, R>(sh, p, urow, ui); }
+        constexpr bool UDPP = R > 16 && PHASE != 2;   // (see forward_body)
+        double urep[2] = {0.0, 0.0};
+        if constexpr (UDPP) u_rows_setup<HP, R>(sh, pb, p, k1, urep);
         __builtin_amdgcn_sched_barrier(0);  // the LDS round trip must be in flight BEFORE the reduction starts
         const double Sw = total_sum<HP>(Call);
         const double uj = fma(k2, Sw, ucol);
@@ -1946,6 +1984,7 @@ DEVI void backward_body(const DevContig& dc, ChainShared<HP, R>& sh, uint32_t C,
                 else wk = y[k] * emission_narrow(rec1, p.i0 + k, cur.em);
                 double uik;
                 if constexpr (R <= 16) uik = ui[k];
+                else if constexpr (UDPP) uik = u_of_row(urep, k);
                 else uik = readlane_f64(urow, __builtin_amdgcn_readfirstlane((int)((p.i0 + k) & 63u)));
                 y[k] = (kExp & 16u) ? (k == 0 ? wk + uik + uj : wk) : fma(k0, wk, uik + uj);  // beta'_t
                 if constexpr (STORE) { if (k & 1) { store_pair(t, k, y[k - 1], y[k]); __builtin_amdgcn_sched_barrier(0); } }
@@ -2210,11 +2249,6 @@ struct ColScalars {
 // i0 + (lane & 15) (each 16-lane DPP row then holds the wave's sixteen row values).  Round 2 pulled value k into all
 // lanes with one v_mov_b64_dpp row_newbcast:k per row and added it with a second instruction; DP-ALU DPP (gfx90a+:
 // row_newbcast is the one DPP control the 64-bit ALU operations take) does both in ONE: t = u[row lane k] + c.
-template <int K>
-DEVI double row_bcast_f64(double v) {
-    // (old = the source itself: every lane has a valid source under row_newbcast, so no separate `old` register is set up)
-    return __longlong_as_double(__builtin_amdgcn_update_dpp(__double_as_longlong(v), __double_as_longlong(v), 0x150 + K, 0xF, 0xF, true));
-}
 template <int R>
 DEVI void lean_u_rows(double urep, double (&ui)[R]) {
     static_assert(R == 16, "one DPP row of 16 lanes = the wave's 16 rows");
