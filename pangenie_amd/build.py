@@ -82,7 +82,7 @@ def build_host(force: bool = False) -> Path:
     tsrc = ROOT / "tests" / "cpp" / "test_host.cpp"
     if force or _stale(HOST_TEST, [tsrc, HOST_LIB]):
         cmd = [cxx, "-O1", "-std=c++17", "-Wall", str(tsrc), "-o", str(HOST_TEST), f"-L{HOST_DIR}", "-lpangenie_host",
-               f"-L{CSRC}", "-lpangenie_hmm", "-Wl,-rpath,$ORIGIN/../../pangenie_amd/host:$ORIGIN/../../pangenie_amd/csrc"]
+               f"-L{CSRC}", "-lpangenie_hmm", "-lz", "-lpthread", "-Wl,-rpath,$ORIGIN/../../pangenie_amd/host:$ORIGIN/../../pangenie_amd/csrc"]
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode:
             raise RuntimeError("g++ (host tests) failed:\n" + r.stderr)

@@ -3,10 +3,17 @@
 
 #include <zlib.h>
 
-#include <fstream>
+#include <algorithm>
+#include <atomic>
 #include <charconv>
-#include <string_view>
+#include <condition_variable>
+#include <cstring>
+#include <deque>
+#include <fstream>
+#include <mutex>
 #include <stdexcept>
+#include <string_view>
+#include <thread>
 
 namespace pangenie {
 
@@ -94,6 +101,249 @@ size_t ExactKmerCounter::getKmerAbundance(std::string kmer) {
     if (!encode_canonical(kmer.data(), code)) return 0;
     const auto it = counts_.find(code);
     return it == counts_.end() ? 0 : (size_t)it->second;
+}
+
+// ------------------------------------------------------------------ TargetedKmerCounter
+namespace {
+// Sequences of a FASTA / FASTQ file, plain or gzipped (zlib reads both), handed to `sink` one record at a time — the same
+// record grammar as ExactKmerCounter's constructor, over a line reader that never holds more than one record.
+template <class Sink>
+void stream_sequences(const std::string& path, Sink&& sink) {
+    gzFile in = gzopen(path.c_str(), "rb");
+    if (!in) throw std::runtime_error("TargetedKmerCounter: cannot open " + path);
+    gzbuffer(in, 1u << 20);
+    std::string seq;
+    enum { NONE, FASTA, FQ_SEQ, FQ_QUAL } state = NONE;
+    size_t qual_left = 0;
+    auto handle = [&](std::string_view l) {
+        if (!l.empty() && l.back() == '\r') l.remove_suffix(1);
+        if (state == FQ_QUAL) {
+            qual_left = l.size() >= qual_left ? 0 : qual_left - l.size();
+            if (qual_left == 0) state = NONE;
+            return;
+        }
+        if (state == FQ_SEQ && !l.empty() && l[0] == '+') {
+            sink(seq);
+            qual_left = seq.size();
+            seq.clear();
+            state = qual_left ? FQ_QUAL : NONE;
+            return;
+        }
+        if (!l.empty() && l[0] == '>' && state != FQ_SEQ) {
+            if (state == FASTA) sink(seq);
+            seq.clear();
+            state = FASTA;
+            return;
+        }
+        if (!l.empty() && l[0] == '@' && (state == NONE || state == FASTA)) {
+            if (state == FASTA) sink(seq);
+            seq.clear();
+            state = FQ_SEQ;
+            return;
+        }
+        if (state == FASTA || state == FQ_SEQ) seq.append(l.data(), l.size());
+    };
+    // blocks of 4 MB, lines split in place; the unfinished tail of a block moves to the front of the next one
+    std::vector<char> buf(4u << 20);
+    size_t have = 0;
+    try {
+        while (true) {
+            if (have == buf.size()) buf.resize(buf.size() * 2);   // a single line longer than the block
+            const int got = gzread(in, buf.data() + have, (unsigned)(buf.size() - have));
+            if (got < 0) throw std::runtime_error("TargetedKmerCounter: read error in " + path);
+            const size_t end = have + (size_t)got;
+            size_t at = 0;
+            while (true) {
+                const char* nl = (const char*)std::memchr(buf.data() + at, '\n', end - at);
+                if (!nl) break;
+                handle(std::string_view(buf.data() + at, (size_t)(nl - (buf.data() + at))));
+                at = (size_t)(nl - buf.data()) + 1;
+            }
+            have = end - at;
+            if (have && at) std::memmove(buf.data(), buf.data() + at, have);
+            if (got == 0) break;
+        }
+        if (have) handle(std::string_view(buf.data(), have));   // last line without a newline
+        if (state == FASTA || state == FQ_SEQ) sink(seq);
+    } catch (...) {
+        gzclose(in);
+        throw;
+    }
+    gzclose(in);
+}
+inline uint64_t mix64(uint64_t x) {   // (splitmix64 finaliser: 2-bit codes of similar k-mers differ in few bits)
+    x ^= x >> 30; x *= 0xbf58476d1ce4e5b9ull; x ^= x >> 27; x *= 0x94d049bb133111ebull; x ^= x >> 31;
+    return x;
+}
+}  // namespace
+
+TargetedKmerCounter::TargetedKmerCounter(size_t kmer_size) : k_(kmer_size) {
+    if (k_ == 0 || k_ > 32) throw std::runtime_error("TargetedKmerCounter: k-mer size must be 1..32");
+}
+
+bool TargetedKmerCounter::encode_canonical(const char* s, uint64_t& code) const {
+    uint64_t fwd = 0, rev = 0;
+    for (size_t i = 0; i < k_; ++i) {
+        const int b = base_code(s[i]);
+        if (b < 0) return false;
+        fwd = (fwd << 2) | (uint64_t)b;
+        rev = (rev >> 2) | ((uint64_t)(3 - b) << (2 * (k_ - 1)));
+    }
+    code = fwd < rev ? fwd : rev;
+    return true;
+}
+
+void TargetedKmerCounter::add_target(std::string_view kmer) {
+    if (frozen_) throw std::runtime_error("TargetedKmerCounter: targets must be registered before the reads are counted");
+    if (kmer.size() != k_) throw std::runtime_error("TargetedKmerCounter::add_target: k-mer of length " + std::to_string(kmer.size()) + ", counter holds " + std::to_string(k_) + "-mers");
+    uint64_t code;
+    if (encode_canonical(kmer.data(), code)) pending_.push_back(code);
+}
+
+size_t TargetedKmerCounter::add_targets_from_table(const std::string& kmers_tsv_gz) {
+    gzFile file = gzopen(kmers_tsv_gz.c_str(), "rb");
+    if (!file) throw std::runtime_error("TargetedKmerCounter: kmer file cannot be opened.");
+    std::vector<char> buf(1u << 16);
+    std::string line;
+    size_t rows = 0;
+    try {
+        while (gzgets(file, buf.data(), (int)buf.size()) != nullptr) {
+            line += buf.data();
+            if (line.empty() || line.back() != '\n') continue;
+            line.pop_back();
+            std::string chrom; size_t start = 0; std::vector<std::string> kmers, flanking; bool header = false;
+            parse_kmer_line(line, chrom, start, kmers, flanking, header);
+            if (!header) {
+                for (const std::string& k : kmers) add_target(k);
+                for (const std::string& k : flanking) add_target(k);
+                rows += 1;
+            }
+            line.clear();
+        }
+    } catch (...) {
+        gzclose(file);
+        throw;
+    }
+    gzclose(file);
+    return rows;
+}
+
+void TargetedKmerCounter::freeze() {
+    if (frozen_) return;
+    std::sort(pending_.begin(), pending_.end());
+    pending_.erase(std::unique(pending_.begin(), pending_.end()), pending_.end());
+    n_targets_ = pending_.size();
+    size_t cap = 16;
+    while (cap < 2 * n_targets_ + 1) cap <<= 1;
+    keys_.assign(cap, kEmpty);
+    counts_.assign(cap, 0);
+    for (const uint64_t code : pending_) {
+        size_t at = (size_t)mix64(code) & (cap - 1);
+        while (keys_[at] != kEmpty) at = (at + 1) & (cap - 1);
+        keys_[at] = code;
+    }
+    std::vector<uint64_t>().swap(pending_);
+    frozen_ = true;
+}
+
+size_t TargetedKmerCounter::find(uint64_t code) const {
+    const size_t cap = keys_.size();
+    size_t at = (size_t)mix64(code) & (cap - 1);
+    while (true) {
+        const uint64_t key = keys_[at];
+        if (key == code) return at;
+        if (key == kEmpty) return (size_t)-1;
+        at = (at + 1) & (cap - 1);
+    }
+}
+
+void TargetedKmerCounter::count_sequence(const char* s, size_t n, uint64_t* counts, uint64_t& windows) const {
+    // (a prefetch ring — slot prefetched when the code is formed, probed twelve windows later — measured no better)
+    const uint64_t mask = k_ == 32 ? ~0ull : ((1ull << (2 * k_)) - 1ull);
+    uint64_t fwd = 0, rev = 0;
+    size_t filled = 0;
+    for (size_t i = 0; i < n; ++i) {
+        const int b = base_code(s[i]);
+        if (b < 0) { filled = 0; fwd = rev = 0; continue; }
+        fwd = ((fwd << 2) | (uint64_t)b) & mask;
+        rev = (rev >> 2) | ((uint64_t)(3 - b) << (2 * (k_ - 1)));
+        if (++filled >= k_) {
+            windows += 1;
+            const size_t at = find(fwd < rev ? fwd : rev);
+            if (at != (size_t)-1) __atomic_fetch_add(&counts[at], 1ull, __ATOMIC_RELAXED);   // (workers share the table)
+        }
+    }
+}
+
+void TargetedKmerCounter::count(const std::string& readfile, unsigned threads) {
+    freeze();
+    if (threads == 0) threads = 1;
+    // one reader (decompression and record parsing), `threads` workers on batches of sequences; hits are relaxed atomic
+    // increments on the shared table
+    struct Batch { std::vector<std::string> seqs; size_t bytes = 0; };
+    std::mutex mu;
+    std::condition_variable cv_work, cv_room;
+    std::deque<Batch> queue;
+    bool done = false;
+    std::exception_ptr failure;
+    uint64_t windows_total = 0;
+    auto worker = [&]() {
+        while (true) {
+            Batch b;
+            {
+                std::unique_lock<std::mutex> lk(mu);
+                cv_work.wait(lk, [&] { return done || !queue.empty(); });
+                if (queue.empty()) return;
+                b = std::move(queue.front());
+                queue.pop_front();
+            }
+            cv_room.notify_one();
+            uint64_t windows = 0;
+            for (const std::string& s : b.seqs) count_sequence(s.data(), s.size(), counts_.data(), windows);
+            std::lock_guard<std::mutex> lk(mu);
+            windows_total += windows;
+        }
+    };
+    std::vector<std::thread> pool;
+    for (unsigned t = 0; t < threads; ++t) pool.emplace_back(worker);
+    try {
+        Batch cur;
+        auto flush = [&]() {
+            if (cur.seqs.empty()) return;
+            std::unique_lock<std::mutex> lk(mu);
+            cv_room.wait(lk, [&] { return queue.size() < 4u * threads; });
+            queue.push_back(std::move(cur));
+            cur = Batch{};
+            lk.unlock();
+            cv_work.notify_one();
+        };
+        stream_sequences(readfile, [&](const std::string& seq) {
+            cur.bytes += seq.size();
+            cur.seqs.push_back(seq);
+            if (cur.bytes >= (4u << 20)) flush();
+        });
+        flush();
+    } catch (...) {
+        failure = std::current_exception();
+    }
+    {
+        std::lock_guard<std::mutex> lk(mu);
+        done = true;
+    }
+    cv_work.notify_all();
+    for (std::thread& t : pool) t.join();
+    if (failure) std::rethrow_exception(failure);
+    windows_ += windows_total;
+}
+
+size_t TargetedKmerCounter::getKmerAbundance(std::string kmer) {
+    if (kmer.size() != k_) throw std::runtime_error("TargetedKmerCounter::getKmerAbundance: k-mer of length " + std::to_string(kmer.size()) + ", counter holds " + std::to_string(k_) + "-mers");
+    freeze();
+    uint64_t code;
+    if (!encode_canonical(kmer.data(), code)) return 0;   // (letters outside ACGT: no window of a read can be this k-mer)
+    const size_t at = find(code);
+    if (at == (size_t)-1) throw std::runtime_error("TargetedKmerCounter::getKmerAbundance: " + kmer + " was not registered before the reads were counted");
+    return (size_t)counts_[at];
 }
 
 // ------------------------------------------------------------------ the k-mer table (behaviour: src/kmerparser.cpp)

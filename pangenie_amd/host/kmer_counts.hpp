@@ -6,7 +6,9 @@
 // image): JellyfishCounter runs `mer_counter` over the read file with canonical = true (src/jellyfishcounter.cpp:26-49),
 // i.e. every window of k letters over {A,C,G,T} of every read is counted under the lexicographically smaller of the
 // k-mer and its reverse complement; windows containing any other letter are skipped.  ExactKmerCounter restates that
-// with an exact hash map — for small inputs (tests, regions); k <= 32.
+// with an exact hash map of EVERY k-mer of the reads — for small inputs (tests, regions); TargetedKmerCounter counts only
+// the k-mers the index asks about (memory proportional to the index, not to the reads; plain or gzipped reads, worker
+// threads) — the same numbers for those k-mers, for read sets of any size; k <= 32.
 // The k-mer abundance peak (`kmer_coverage`) is an ARGUMENT here: finding it (the reference's Histogram /
 // compute_kmer_coverage over Jellyfish's histogram) is upstream of this path and out of scope.
 // Pinned on the reference's own fixtures: tests/data/index_UniqueKmersMap.cereal + index_chr1_kmers.tsv.gz +
@@ -15,6 +17,7 @@
 
 #include <cstdint>
 #include <string>
+#include <string_view>
 #include <unordered_map>
 #include <vector>
 
@@ -42,6 +45,40 @@ private:
     bool encode_canonical(const char* s, uint64_t& code) const;
     size_t k_;
     std::unordered_map<uint64_t, uint64_t> counts_;
+};
+
+/** Counts of a GIVEN set of k-mers in read files of any size.  fill_read_kmercounts only ever asks for the unique and
+ *  the flanking k-mers listed in the `_kmers.tsv.gz` tables of the index, so those are registered first
+ *  (add_targets_from_table for every chromosome), then the reads are streamed once (count(): FASTA / FASTQ, plain or
+ *  gzipped; one reader, `threads` counting workers) and every window that is a registered k-mer is counted under its
+ *  canonical code in an open-addressing table.  getKmerAbundance of a k-mer that was never registered throws (a silent 0
+ *  would be a wrong count).  Same counts as ExactKmerCounter / the reference's Jellyfish pass for registered k-mers. */
+class TargetedKmerCounter : public KmerCounter {
+public:
+    explicit TargetedKmerCounter(size_t kmer_size);
+    /** register a k-mer (any orientation); k-mers with letters outside ACGT can never be counted and are ignored */
+    void add_target(std::string_view kmer);
+    /** register every unique and flanking k-mer of a `<prefix>_<chromosome>_kmers.tsv(.gz)` table; returns how many rows */
+    size_t add_targets_from_table(const std::string& kmers_tsv_gz);
+    /** stream a read file and count; may be called for several files (counts add up).  No targets may be added afterwards. */
+    void count(const std::string& readfile, unsigned threads = 1);
+    size_t getKmerAbundance(std::string kmer) override;
+    size_t targets() const { return n_targets_; }
+    size_t kmers_seen() const { return windows_; }   // windows over ACGT of all reads streamed so far
+
+private:
+    bool encode_canonical(const char* s, uint64_t& code) const;
+    void freeze();
+    size_t find(uint64_t code) const;   // slot, or npos
+    void count_sequence(const char* s, size_t n, uint64_t* counts, uint64_t& windows) const;
+    static constexpr uint64_t kEmpty = ~0ull;   // (never a canonical code: the reverse complement of all-T is all-A = 0)
+    size_t k_;
+    std::vector<uint64_t> pending_;     // codes registered before the table is built
+    std::vector<uint64_t> keys_;        // open addressing, power-of-two size, linear probing
+    std::vector<uint64_t> counts_;
+    size_t n_targets_ = 0;
+    uint64_t windows_ = 0;
+    bool frozen_ = false;
 };
 
 /** one row of `<prefix>_<chromosome>_kmers.tsv(.gz)` — the reference's interface (src/kmerparser.hpp); implemented

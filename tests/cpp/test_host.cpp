@@ -20,6 +20,7 @@
 #include <stdexcept>
 #include <string>
 #include <thread>
+#include <zlib.h>
 #include <unordered_set>
 #include <vector>
 
@@ -293,6 +294,93 @@ static void kmer_count_cpu_tests() {
         CHECK(compute_local_coverage(fl, c, 3) == 1);   // counts 3, 3, 1, 0 within [0, 12]: (3 + 3 + 1 + 0) / 4 in integers
         CHECK(compute_local_coverage(fl, c, 8) == 3);   // [2, 32]: (3 + 3) / 2
         CHECK(compute_local_coverage(fl, c, 100) == 100);  // none within [25, 400]: the given coverage
+    });
+    run("TargetedKmerCounter: the index's k-mers only, any read set size; same counts as the exact counter", [] {
+        // the reference's fixture again: every unique and flanking k-mer of the table registered, the reads streamed
+        UniqueKmersMap m = load_unique_kmers_map(g_golden_dir + "/index_UniqueKmersMap.cereal");
+        const std::string table = g_golden_dir + "/index_chr1_kmers.tsv.gz", reads = g_golden_dir + "/region-reads.fa";
+        ExactKmerCounter exact(reads, m.kmersize);
+        // a gzipped copy of the reads and a FASTA rendering of them (the counter reads all three forms)
+        const std::string gz = "/tmp/pg_test_region_reads.fq.gz", fq = "/tmp/pg_test_region_reads_as.fa";
+        {
+            const std::vector<unsigned char> raw = read_file(reads);
+            gzFile out = gzopen(gz.c_str(), "wb");
+            CHECK(out != nullptr);
+            gzwrite(out, raw.data(), (unsigned)raw.size());
+            gzclose(out);
+            // the fixture is FASTQ (four lines per read): a FASTA rendering of it, every sequence broken over two lines
+            std::FILE* f = std::fopen(fq.c_str(), "w");
+            std::string text(raw.begin(), raw.end());
+            size_t at = 0, lineno = 0;
+            while (at < text.size()) {
+                const size_t nl = text.find('\n', at);
+                const std::string line = text.substr(at, nl == std::string::npos ? std::string::npos : nl - at);
+                if (lineno % 4 == 1) std::fprintf(f, ">r%zu\n%s\n%s\n", lineno / 4, line.substr(0, line.size() / 2).c_str(), line.substr(line.size() / 2).c_str());
+                lineno += 1;
+                if (nl == std::string::npos) break;
+                at = nl + 1;
+            }
+            std::fclose(f);
+        }
+        std::vector<std::string> all;   // the table's k-mers
+        {
+            gzFile t = gzopen(table.c_str(), "rb");
+            char buf[1 << 16]; std::string line;
+            while (gzgets(t, buf, sizeof buf)) {
+                line += buf;
+                if (line.empty() || line.back() != '\n') continue;
+                line.pop_back();
+                std::string chrom; size_t start = 0; std::vector<std::string> km, fl; bool header = false;
+                parse_kmer_line(line, chrom, start, km, fl, header);
+                all.insert(all.end(), km.begin(), km.end());
+                all.insert(all.end(), fl.begin(), fl.end());
+                line.clear();
+            }
+            gzclose(t);
+        }
+        CHECK(all.size() > 100);
+        for (const std::string& path : {reads, gz, fq}) {
+            for (unsigned threads : {1u, 4u}) {
+                TargetedKmerCounter c(m.kmersize);
+                CHECK(c.add_targets_from_table(table) == 2);
+                c.count(path, threads);
+                CHECK(c.targets() > 100 && c.targets() <= all.size() && c.kmers_seen() > 1000);
+                size_t same = 0, nonzero = 0;
+                for (const std::string& k : all) { const size_t n = c.getKmerAbundance(k); same += n == exact.getKmerAbundance(k); nonzero += n > 0; }
+                CHECK(same == all.size() && nonzero > 50);
+            }
+        }
+        // the pinned fixture through the targeted counter: the reference's counted archive byte for byte
+        {
+            const UniqueKmersMap want = load_unique_kmers_map(g_golden_dir + "/region_UniqueKmersList.cereal");
+            TargetedKmerCounter c(m.kmersize);
+            c.add_targets_from_table(table);
+            c.count(gz, 3);
+            fill_read_kmercounts("chr1", &m, c, table, 18);
+            m.runtimes = want.runtimes;
+            m.sampling_runtimes = want.sampling_runtimes;
+            CHECK(serialize_unique_kmers_map(m) == read_file(g_golden_dir + "/region_UniqueKmersList.cereal"));
+        }
+        // counts of two files add up; a k-mer that was not registered is refused, not answered with 0; no targets after counting
+        {
+            TargetedKmerCounter c(4);
+            c.add_target("ACGT"); c.add_target("TACG"); c.add_target("ACGN");
+            const std::string fa = "/tmp/pg_test_reads_t.fa";
+            { FILE* f = std::fopen(fa.c_str(), "w"); std::fputs(">r1\nACGTAC\nGT\n>r2\nACGNACGTA", f); std::fclose(f); }   // (no final newline)
+            c.count(fa);
+            CHECK(c.getKmerAbundance("ACGT") == 3 && c.getKmerAbundance("CGTA") == 3 && c.getKmerAbundance("ACGN") == 0);
+            c.count(fa, 2);
+            CHECK(c.getKmerAbundance("ACGT") == 6 && c.kmers_seen() == 2 * 7);
+            bool threw = false;
+            try { c.getKmerAbundance("GTAC"); } catch (const std::runtime_error&) { threw = true; }
+            CHECK(threw);
+            threw = false;
+            try { c.add_target("GTAC"); } catch (const std::runtime_error&) { threw = true; }
+            CHECK(threw);
+            threw = false;
+            try { c.count("/tmp/pg_no_such_reads.fa"); } catch (const std::runtime_error&) { threw = true; }
+            CHECK(threw);
+        }
     });
     run("parse_kmer_line: columns, lists, headers, malformed rows", [] {
         std::string chrom; size_t start = 0; std::vector<std::string> km, fl; bool header = false;
