@@ -115,12 +115,14 @@ def cpu_baseline(batches, H, sample_variants):
 
 def _sweep_phase(name: str):
     """Phase (1, 2, 3) of a sweep kernel from its demangled name, None for other kernels:
-    k_sweep<HP, R, VBUF, KEEPW, PHASE>, k_sweep_lean<PHASE, R>, k_sweep_generic<PHASE>."""
+    k_sweep<HP, R, VBUF, KEEPW, PHASE>, k_sweep_lean[_tri]<PHASE, R>, k_sweep_leanx<PHASE, HP>, k_sweep_small16<PHASE>,
+    k_sweep_generic<PHASE>."""
     import re
     if name.startswith("void k_sweep_lean2<"):  # phase 2 of triangle chains
         return 2
-    m = re.match(r"void k_sweep_lean<(\d), ", name) or re.match(r"void k_sweep_generic<(\d)>", name) or \
-        re.match(r"void k_sweep<\d+, \d+, \d+, \w+, (\d)>", name)
+    m = re.match(r"void k_sweep_lean<(\d), ", name) or re.match(r"void k_sweep_lean_tri<(\d), ", name) or \
+        re.match(r"void k_sweep_leanx<(\d), ", name) or re.match(r"void k_sweep_small16<(\d)>", name) or \
+        re.match(r"void k_sweep_generic<(\d)>", name) or re.match(r"void k_sweep<\d+, \d+, \d+, \w+, (\d)>", name)
     return int(m.group(1)) if m else None
 
 
@@ -220,6 +222,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-cohort", action="store_true", help="skip the cohort sub-measurement")
     ap.add_argument("--cohort-only", action="store_true", help="profiling: only the cohort measurement")
+    ap.add_argument("--cohort-key", default="cohort", choices=["cohort"] + sorted(COHORTS_MORE), help="with --cohort-only: which cohort (profiling)")
     ap.add_argument("--no-sampler", action="store_true", help="skip the HaplotypeSampler sub-measurement")
     ap.add_argument("--no-viterbi", action="store_true", help="skip the Viterbi phasing sub-measurement")
     ap.add_argument("--no-dropin", action="store_true", help="skip the threaded one-shot (drop-in) sub-measurement")
@@ -482,19 +485,27 @@ def main():
         return res
 
     if not args.no_cohort:
-        r = cohort_measure(COHORT, args.cohort_samples, "cohort", "cohort_h64" if world == 1 and args.cohort_samples == COHORT["samples"] else None)
-        if rank == 0:
-            out["cohort"] = r
-            if args.cohort_only:
+        if args.cohort_only and args.cohort_key != "cohort":   # profiling: one of the other cohorts alone
+            spec = COHORTS_MORE[args.cohort_key]
+            r = cohort_measure(spec, spec["samples"], args.cohort_key, args.cohort_key if world == 1 else None)
+            if rank == 0:
+                out[args.cohort_key] = r
                 out.update({"value": r["value"], "ms_per_step": r["ms_per_step"], "scaling": "weak",
-                            "config": {"workload": "cohort_h64 only: " + r["workload"]}, "roofline": r["roofline"]})
-        if not args.cohort_only:
-            # the other panel widths of BASELINE.json in the same regime: 16 haplotypes (configs[1]; k_sweep_small16 in
-            # phase 1) and 128 haplotypes with 20 % multiallelic objects (configs[4]; the general kernel)
-            for key, spec in COHORTS_MORE.items():
-                r = cohort_measure(spec, spec["samples"], key, None)
-                if rank == 0:
-                    out[key] = r
+                            "config": {"workload": args.cohort_key + " only: " + r["workload"]}, "roofline": r["roofline"]})
+        else:
+            r = cohort_measure(COHORT, args.cohort_samples, "cohort", "cohort_h64" if world == 1 and args.cohort_samples == COHORT["samples"] else None)
+            if rank == 0:
+                out["cohort"] = r
+                if args.cohort_only:
+                    out.update({"value": r["value"], "ms_per_step": r["ms_per_step"], "scaling": "weak",
+                                "config": {"workload": "cohort_h64 only: " + r["workload"]}, "roofline": r["roofline"]})
+            if not args.cohort_only:
+                # the other panel widths of BASELINE.json in the same regime: 16 haplotypes (configs[1]; k_sweep_small16 in
+                # phase 1, class sums in phase 2) and 128 haplotypes with 20 % multiallelic objects (configs[4]; the general kernel)
+                for key, spec in COHORTS_MORE.items():
+                    r = cohort_measure(spec, spec["samples"], key, key if world == 1 else None)
+                    if rank == 0:
+                        out[key] = r
 
     # ------------------------------------------------------------------ HaplotypeSampler sub-measurement
     if not args.no_sampler and not args.cohort_only:

@@ -640,12 +640,16 @@ DEVI void prep_bi_unit(const DevContig& dc, const DevTable& tab, uint32_t unit) 
     if (!kept) return;
     const uint32_t n_local = (has0 ? 1u : 0u) + (has1 ? 1u : 0u);
     const uint32_t loc1 = has0 ? 1u : 0u;  // local (dense) index of slot 1; slot 0 is local 0
-    unsigned char* rec = dc.vrec + (size_t)v * dc.RB;
+    // The record is put together in LDS and leaves as whole 16-byte pieces (below): written field by field straight to
+    // global memory, a record's lines reached HBM several times over (PMC: 1040 bytes written per 384-byte record).
+    __shared__ unsigned char s_rec[4][4][448] __attribute__((aligned(16)));   // [wave][variant of the wave][RB <= 448: H <= 64]
+    unsigned char* rec = s_rec[threadIdx.x >> 6][grp];
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const uint32_t p = 16u * (uint32_t)i + l;
         if (p < HP) rec[PG_REC_ALLELES + p] = (unsigned char)(p < H ? (slot[i] ? loc1 : 0u) : (uint32_t)PG_PHANTOM);
     }
+    for (uint32_t pad = PG_REC_ALLELES + HP + l; pad < dc.RB; pad += 16u) rec[pad] = 0;   // (the record's tail up to RB)
     // ---- emission products of the three allele pairs (0,0), (0,1), (1,1): lane l takes k-mers l and 16 + l
     const uint32_t k0 = dc.kmer_off[v], K = dc.kmer_off[v + 1] - k0, cov = dc.cov[v];
     const uint32_t off0 = dc.allele_koff[a0], mask0 = dc.allele_kmask[a0], off1 = dc.allele_koff[a0 + 1], mask1 = dc.allele_kmask[a0 + 1];
@@ -734,6 +738,14 @@ DEVI void prep_bi_unit(const DevContig& dc, const DevTable& tab, uint32_t unit) 
         ((unsigned long long*)(rec + PG_REC_BITS1))[0] = has0 ? ones : 0ull;  // bit p: path p carries LOCAL allele 1
         ((unsigned long long*)(rec + PG_REC_BITS1))[1] = 0ull;
     }
+    wave_sync_lds();
+    {   // copy-out: the variant's 16 lanes move RB / 16 pieces of 16 bytes, consecutive lanes consecutive pieces
+        typedef double f64x2 __attribute__((ext_vector_type(2)));
+        const f64x2* src = (const f64x2*)rec;
+        f64x2* dst = (f64x2*)(dc.vrec + (size_t)v * dc.RB);
+        for (uint32_t p = l; p < dc.RB / 16u; p += 16u) dst[p] = src[p];
+    }
+    wave_sync_lds();   // (the slot is rewritten by the wave's next unit)
 }
 __global__ __launch_bounds__(256) void k_prep_bi(const DevContig* __restrict__ contigs, DevTable tab) {
     const DevContig& dc = contigs[blockIdx.y];

@@ -4,7 +4,7 @@ TAG=${1:-r03}
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 cd $R
 mkdir -p gpurun_out/profiles
-for W in genome24_h64 cohort_h64; do
+for W in genome24_h64 cohort_h64 cohort_h16 cohort_h128; do
   bash tools/profile_workload.sh $W $TAG > gpurun_out/${TAG}_$W.log 2>&1
   python tools/summarize_profile.py gpurun_out/${TAG}_$W gpurun_out/profiles/${TAG}_$W $W > /dev/null 2>&1
   cp gpurun_out/${TAG}_$W/kt/kt_kernel_stats.csv gpurun_out/profiles/${TAG}_${W}_kernel_stats.csv 2>/dev/null

@@ -4,7 +4,7 @@
 #   pass 2: --pmc FETCH_SIZE  (own pass)     -> HBM read  KiB per launch
 #   pass 3: --pmc WRITE_SIZE  (own pass)     -> HBM write KiB per launch
 #   pass 4 (optional, SQ=1): four --pmc passes of SQ counters (issue / wait picture of the sweep)
-# usage: tools/profile_workload.sh <workload|cohort_h64> <round-tag>      output: gpurun_out/<tag>_<workload>/
+# usage: tools/profile_workload.sh <workload|cohort_h64|cohort_h16|cohort_h128> <round-tag>      output: gpurun_out/<tag>_<workload>/
 set -u
 W=${1:-genome24_h64}; TAG=${2:-r03}
 R=${GRAFT_REPO_ROOT:-$(pwd)}
@@ -14,6 +14,8 @@ cd /tmp && export TMPDIR=/tmp
 cd $R
 if [ "$W" = "cohort_h64" ]; then
   CMD="python bench.py --steps 3 --warmup 1 --cohort-only --no-cpu-baseline --no-sampler"
+elif [ "$W" = "cohort_h16" ] || [ "$W" = "cohort_h128" ]; then
+  CMD="python bench.py --steps 3 --warmup 1 --cohort-only --cohort-key $W --no-cpu-baseline --no-sampler"
 else
   CMD="python bench.py --steps 3 --warmup 1 --workload $W --no-cpu-baseline --no-cohort --no-sampler --no-viterbi --no-dropin"
 fi
