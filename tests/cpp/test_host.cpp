@@ -512,6 +512,43 @@ static void graph_cpu_tests() {
 }
 
 static void archive_cpu_tests() {
+    run("archives: every truncation and byte corruption parses or throws std::runtime_error (never crashes)", [] {
+        // the three readers (index map, `-w` results, graph) on the reference's fixtures and our own archive: cut at every
+        // length (step 1 near the ends, coarser in the middle), and with single bytes overwritten — a length field turned
+        // into 2^64-ish, a shared-pointer id into nonsense.  What counts is that nothing but runtime_error comes out
+        // (bad_alloc / length_error / out-of-range reads would be the bug); the sanitizer build of this test checks the rest.
+        struct Kind { const char* name; std::vector<unsigned char> bytes; std::function<void(const std::vector<unsigned char>&)> parse; };
+        std::vector<Kind> kinds;
+        kinds.push_back({"index", read_file(g_golden_dir + "/index_UniqueKmersMap.cereal"), [](const std::vector<unsigned char>& b) { (void)parse_unique_kmers_map(b); }});
+        kinds.push_back({"results", serialize_results(sample_results()), [](const std::vector<unsigned char>& b) { (void)parse_results(b); }});
+        kinds.push_back({"graph", read_file(g_golden_dir + "/index_chr1_Graph.cereal"), [](const std::vector<unsigned char>& b) { (void)Graph::parse(b); }});
+        for (Kind& k : kinds) {
+            size_t other = 0, threw = 0, parsed = 0;
+            auto attempt = [&](const std::vector<unsigned char>& b) {
+                try { k.parse(b); parsed += 1; }
+                catch (const std::runtime_error&) { threw += 1; }
+                catch (...) { other += 1; }
+            };
+            const size_t n = k.bytes.size();
+            CHECK(n > 64);
+            for (size_t cut = 0; cut < n; cut += (cut < 256 || cut + 256 > n) ? 1 : 97) attempt(std::vector<unsigned char>(k.bytes.begin(), k.bytes.begin() + (long)cut));
+            const size_t truncations_parsed = parsed;
+            uint64_t x = 88172645463325252ull;   // xorshift: positions and values of the corruptions
+            for (int it = 0; it < 600; ++it) {
+                x ^= x << 13; x ^= x >> 7; x ^= x << 17;
+                std::vector<unsigned char> b = k.bytes;
+                const size_t at = (size_t)(x % n);
+                const unsigned char vals[4] = {0xFF, 0x00, 0x80, (unsigned char)(x >> 40)};
+                b[at] = vals[(x >> 33) & 3];
+                if ((x >> 36) & 1) for (size_t q = at; q < at + 8 && q < n; ++q) b[q] = 0xFF;   // a whole 64-bit field
+                attempt(b);
+            }
+            CHECK(other == 0);
+            CHECK(threw > 100);                   // (cuts almost always fail; corruptions of payload bytes parse fine)
+            CHECK(truncations_parsed <= 2);       // only (nearly) complete prefixes can parse
+            (void)k.name;
+        }
+    });
     run("cereal binary archive: Results (`-w`, what PanGenie-vcf reads) layout and round trip", [] {
         // the smallest case byte by byte: one chromosome "c", one result with one likelihood 0.5 of genotype (0, 1)
         Results one;
