@@ -72,10 +72,10 @@ def build_host(force: bool = False) -> Path:
     cxx = shutil.which("g++") or "g++"
     deps = [HOST_DIR / "pangenie_host.cpp", HOST_DIR / "pangenie_host.hpp", HOST_DIR / "cereal_io.cpp", HOST_DIR / "cereal_io.hpp",
             HOST_DIR / "kmer_counts.cpp", HOST_DIR / "kmer_counts.hpp", HOST_DIR / "graph_io.cpp", HOST_DIR / "graph_io.hpp",
-            HOST_DIR / "archive_bytes.hpp", ROOT / "include" / "pangenie_hmm.h"]
+            HOST_DIR / "index_builder.cpp", HOST_DIR / "index_builder.hpp", HOST_DIR / "archive_bytes.hpp", ROOT / "include" / "pangenie_hmm.h"]
     if force or _stale(HOST_LIB, deps):
         cmd = [cxx, "-O2", "-std=c++17", "-fPIC", "-shared", "-Wall", "-Wextra", str(HOST_DIR / "pangenie_host.cpp"), str(HOST_DIR / "cereal_io.cpp"),
-               str(HOST_DIR / "kmer_counts.cpp"), str(HOST_DIR / "graph_io.cpp"), "-o", str(HOST_LIB), f"-L{CSRC}", "-lpangenie_hmm", "-lpthread", "-lz", "-Wl,-rpath,$ORIGIN/../csrc"]
+               str(HOST_DIR / "kmer_counts.cpp"), str(HOST_DIR / "graph_io.cpp"), str(HOST_DIR / "index_builder.cpp"), "-o", str(HOST_LIB), f"-L{CSRC}", "-lpangenie_hmm", "-lpthread", "-lz", "-Wl,-rpath,$ORIGIN/../csrc"]
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode:
             raise RuntimeError("g++ (host lib) failed:\n" + r.stderr)

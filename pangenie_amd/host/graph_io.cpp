@@ -350,6 +350,13 @@ Graph Graph::from_parts(const std::string& chromosome, size_t kmer_size, bool re
     return g;
 }
 
+Graph Graph::from_parts(const std::string& chromosome, size_t kmer_size, bool reference_added, const std::vector<Variant>& variants,
+                        const std::vector<std::vector<std::string>>& variant_ids, const std::string& reference_bases) {
+    Graph g = from_parts(chromosome, kmer_size, reference_added, variants, variant_ids);
+    g.fasta_.emplace_back(chromosome, std::make_shared<DnaSequence>(reference_bases));
+    return g;
+}
+
 const Variant& Graph::get_variant(size_t index) const {
     if (index >= variants_.size()) throw std::runtime_error("Graph::get_variant: index out of bounds.");
     if (!variants_[index]) throw std::runtime_error("Graph::get_variant: variant was previously destroyed by delete_variant function.");

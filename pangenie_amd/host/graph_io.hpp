@@ -116,6 +116,9 @@ public:
      *  (what the archive stores), or empty */
     static Graph from_parts(const std::string& chromosome, size_t kmer_size, bool reference_added, const std::vector<Variant>& variants,
                             const std::vector<std::vector<std::string>>& variant_ids);
+    /** the same with the chromosome's reference sequence (what PanGenie-index keeps in the graph: index_builder.hpp) */
+    static Graph from_parts(const std::string& chromosome, size_t kmer_size, bool reference_added, const std::vector<Variant>& variants,
+                            const std::vector<std::vector<std::string>>& variant_ids, const std::string& reference_bases);
 
     size_t get_kmer_size() const { return kmer_size_; }
     const std::string& get_chromosome() const { return chromosome_; }

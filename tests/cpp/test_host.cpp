@@ -26,6 +26,7 @@
 
 #include "../../pangenie_amd/host/cereal_io.hpp"
 #include "../../pangenie_amd/host/graph_io.hpp"
+#include "../../pangenie_amd/host/index_builder.hpp"
 #include "../../pangenie_amd/host/kmer_counts.hpp"
 #include "../../pangenie_amd/host/pangenie_host.hpp"
 
@@ -245,6 +246,101 @@ static std::vector<unsigned char> read_file(const std::string& path) {
     while ((n = std::fread(buf, 1, sizeof(buf), f)) > 0) bytes.insert(bytes.end(), buf, buf + n);
     std::fclose(f);
     return bytes;
+}
+
+static std::string gunzip_text(const std::string& path) {
+    gzFile z = gzopen(path.c_str(), "rb");
+    std::string text;
+    char buf[1 << 14];
+    int got;
+    while (z && (got = gzread(z, buf, sizeof buf)) > 0) text.append(buf, (size_t)got);
+    if (z) gzclose(z);
+    return text;
+}
+
+static void index_builder_cpu_tests() {
+    run("build_index: the reference's region.fa + region.vcf give its index_* fixtures (PanGenie-index)", [] {
+        // tests/data/region.{fa,vcf} at k = 31 with the reference path added -> tests/data/index_path_segments.fasta,
+        // index_chr1_Graph.cereal, index_chr1_kmers.tsv.gz, index_UniqueKmersMap.cereal: the files tests/CommandsTest.cpp runs
+        // PanGenie-genotype on.  Segment file and k-mer table text for text; the archives byte for byte (the measured run time
+        // the index archive carries is copied over).
+        const std::string prefix = "/tmp/pg_test_index";
+        const std::vector<std::string> chromosomes = build_index(g_golden_dir + "/region.fa", g_golden_dir + "/region.vcf", prefix, 31, true);
+        CHECK(chromosomes == std::vector<std::string>({"chr1"}));
+        const std::vector<unsigned char> seg = read_file(prefix + "_path_segments.fasta"), seg_want = read_file(g_golden_dir + "/index_path_segments.fasta");
+        CHECK(seg == seg_want);
+        CHECK(read_file(prefix + "_chr1_Graph.cereal") == read_file(g_golden_dir + "/index_chr1_Graph.cereal"));
+        CHECK(gunzip_text(prefix + "_chr1_kmers.tsv.gz") == gunzip_text(g_golden_dir + "/index_chr1_kmers.tsv.gz"));
+        UniqueKmersMap got = load_unique_kmers_map(prefix + "_UniqueKmersMap.cereal");
+        const UniqueKmersMap want = load_unique_kmers_map(g_golden_dir + "/index_UniqueKmersMap.cereal");
+        CHECK(got.kmersize == 31 && got.add_reference && got.unique_kmers["chr1"].size() == 2);
+        got.runtimes = want.runtimes;
+        got.sampling_runtimes = want.sampling_runtimes;
+        CHECK(serialize_unique_kmers_map(got) == read_file(g_golden_dir + "/index_UniqueKmersMap.cereal"));
+    });
+    run("build_graphs: records closer than k - 1 merge into one bubble; what the reference refuses is refused", [] {
+        // a 400-base reference without repeats of length >= 5 would be ideal; a fixed pseudo-random one serves
+        std::string ref;
+        uint64_t x = 0x9E3779B97F4A7C15ull;
+        for (int i = 0; i < 400; ++i) { x ^= x << 13; x ^= x >> 7; x ^= x << 17; ref += "ACGT"[x & 3]; }
+        const std::string fa = "/tmp/pg_test_ib.fa", vcf = "/tmp/pg_test_ib.vcf";
+        { std::FILE* f = std::fopen(fa.c_str(), "w"); std::fprintf(f, ">c1 some description\n%s\n>c2\n%s\n", ref.c_str(), ref.substr(0, 120).c_str()); std::fclose(f); }
+        auto alt_of = [&](size_t pos) { return std::string(1, ref[pos] == 'A' ? 'C' : 'A'); };
+        auto write_vcf = [&](const std::string& body) {
+            std::FILE* f = std::fopen(vcf.c_str(), "w");
+            std::fprintf(f, "##fileformat=VCFv4.2\n#CHROM\tPOS\tID\tREF\tALT\tQUAL\tFILTER\tINFO\tFORMAT\ts1\ts2\n%s", body.c_str());
+            std::fclose(f);
+        };
+        auto rec = [&](size_t pos0, const std::string& alt, const std::string& gts, const std::string& info = ".") {
+            return "c1\t" + std::to_string(pos0 + 1) + "\t.\t" + std::string(1, ref[pos0]) + "\t" + alt + "\t.\t.\t" + info + "\tGT\t" + gts + "\n";
+        };
+        const size_t k = 11;
+        // records at 100, 105 (5 apart: same bubble), 130 (own bubble), 140 with a missing haplotype; one too close to the start
+        write_vcf(rec(5, alt_of(5), "0|1\t1|1") + rec(100, alt_of(100), "0|1\t1|0", "ID=a1") + rec(105, alt_of(105), "1|1\t0|0", "ID=b1") +
+                  rec(130, alt_of(130) + ",G" + std::string(ref[130] == 'G' ? "T" : ""), "2|0\t1|0", "AC=1;ID=x,y") + rec(160, alt_of(160), ".|1\t0|0"));
+        const ReferenceSequences reference(fa);
+        CHECK(reference.names() == std::vector<std::string>({"c1", "c2"}) && reference.of("c1") == ref);
+        const BuiltGraphs b = build_graphs(vcf, reference, k, true);
+        CHECK(b.nr_paths == 5 && b.skipped == 1 && b.chromosomes == std::vector<std::string>({"c1"}));
+        const Graph& g = b.graphs.at("c1");
+        CHECK(g.size() == 3);
+        const Variant& merged = g.get_variant(0);
+        CHECK(merged.is_combined() && merged.nr_of_records() == 2 && merged.get_start_position() == 100 && merged.get_end_position() == 106);
+        // paths: reference 0|0; s1 = (0,1), (1,1); s2 = (1,0), (0,0): combinations sorted (0,0) (0,1) (1,0) (1,1)
+        CHECK(merged.nr_of_alleles() == 4 && merged.nr_of_paths() == 5);
+        CHECK(merged.get_allele_on_path(0) == 0 && merged.get_allele_on_path(1) == 1 && merged.get_allele_on_path(2) == 3 && merged.get_allele_on_path(3) == 2 && merged.get_allele_on_path(4) == 0);
+        CHECK(merged.get_allele_string(0) == ref.substr(90, 26));   // k - 1 flanking bases on both sides
+        CHECK(merged.get_allele_string(3) == ref.substr(90, 10) + alt_of(100) + ref.substr(101, 4) + alt_of(105) + ref.substr(106, 10));
+        CHECK(g.get_variant(1).nr_of_alleles() == 3 && !g.get_variant(1).is_combined());
+        CHECK(g.variant_ids().size() == 4 && g.variant_ids()[0] == std::vector<std::string>({"a1"}) && g.variant_ids()[2].size() == 2);
+        CHECK(g.get_variant(2).nr_of_alleles() == 3 && g.get_variant(2).is_undefined_allele(2));   // REF, ALT, the missing haplotype's own allele
+        // the segment file: reference up to the first bubble, its alleles, ..., the rest; then the chromosome without variants
+        const std::string seg = path_segments_fasta(b, reference);
+        CHECK(seg.find(">c1_reference_100\n" + ref.substr(0, 100) + "\n>c1_100_0\n" + ref.substr(90, 26) + "\n") == 0);
+        CHECK(seg.find(">c1_reference_end\n" + ref.substr(161) + "\n>c2_reference_end\n" + ref.substr(0, 120) + "\n") != std::string::npos);
+        // unique k-mers of the bubbles against the graph's own k-mer counts
+        { std::FILE* f = std::fopen("/tmp/pg_test_ib_segments.fa", "w"); std::fputs(seg.c_str(), f); std::fclose(f); }
+        ExactKmerCounter graph_kmers("/tmp/pg_test_ib_segments.fa", k);
+        const ChromosomeKmers ck = unique_kmers_of(g, graph_kmers);
+        CHECK(ck.rows.size() == 3 && ck.objects.size() == 3);
+        CHECK(ck.rows[0].rfind("c1\t100\t106\t", 0) == 0 && ck.objects[0]->get_nr_paths() == 5 && ck.objects[0]->size() > 0);
+        CHECK(ck.objects[2]->is_undefined_allele(2) && !ck.objects[2]->is_undefined_allele(1));
+        // refusals
+        auto refused = [&](const std::string& body) {
+            write_vcf(body);
+            try { (void)build_graphs(vcf, reference, k, true); } catch (const std::runtime_error&) { return true; }
+            return false;
+        };
+        CHECK(refused(rec(100, alt_of(100), "0/1\t1|0")));                                   // unphased
+        CHECK(refused(rec(100, alt_of(100), "0|1|1\t1|0")));                                 // not diploid
+        CHECK(refused(rec(100, alt_of(100), "0|2\t1|0")));                                   // allele that does not exist
+        CHECK(refused(rec(100, alt_of(100), "0|1\t1|0") + rec(100, alt_of(100), "0|1\t1|0")));   // overlapping records
+        CHECK(refused("c1\t101\t.\t" + alt_of(100) + "\t" + std::string(1, ref[100]) + "\t.\t.\t.\tGT\t0|1\t1|0\n"));   // REF does not match
+        CHECK(refused("c9\t101\t.\tA\tC\t.\t.\t.\tGT\t0|1\t1|0\n"));                    // unknown chromosome
+        write_vcf(rec(100, "<DEL>", "0|1\t1|0") + rec(200, alt_of(200) + "N", "0|1\t1|0"));   // symbolic / undefined ALT: skipped, not refused
+        const BuiltGraphs none = build_graphs(vcf, reference, k, true);
+        CHECK(none.skipped == 2 && none.graphs.empty());
+    });
 }
 
 static void kmer_count_cpu_tests() {
@@ -1163,7 +1259,7 @@ static void gpu_tests() {
 int main(int argc, char** argv) {
     const std::string mode = argc > 1 ? argv[1] : "cpu";
     if (argc > 2) g_golden_dir = argv[2];
-    if (mode == "cpu") { cpu_tests(); archive_cpu_tests(); graph_cpu_tests(); kmer_count_cpu_tests(); sampler_cpu_tests(); }
+    if (mode == "cpu") { cpu_tests(); archive_cpu_tests(); graph_cpu_tests(); index_builder_cpu_tests(); kmer_count_cpu_tests(); sampler_cpu_tests(); }
     else if (mode == "gpu") { gpu_tests(); sampler_gpu_tests(); }
     else if (mode == "dump-results" && argc >= 3) {  // the archive of sample_results() for the Python reader (tests/test_cereal_io.py)
         save_results(sample_results(), argv[2]);

@@ -30,7 +30,7 @@ def test_host_classes_cpu_under_sanitizers(binary, tmp_path):
     exe = tmp_path / "test_host_san"
     cmd = [cxx, "-O1", "-g", "-std=c++17", "-fsanitize=address,undefined", "-fno-omit-frame-pointer", "-fno-sanitize-recover=undefined",
            str(build.ROOT / "tests" / "cpp" / "test_host.cpp"), str(host / "pangenie_host.cpp"), str(host / "cereal_io.cpp"),
-           str(host / "kmer_counts.cpp"), str(host / "graph_io.cpp"), "-o", str(exe),
+           str(host / "kmer_counts.cpp"), str(host / "graph_io.cpp"), str(host / "index_builder.cpp"), "-o", str(exe),
            f"-L{build.ROOT / 'pangenie_amd' / 'csrc'}", "-lpangenie_hmm", "-lz", "-lpthread", f"-Wl,-rpath,{build.ROOT / 'pangenie_amd' / 'csrc'}"]
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
     if r.returncode != 0 and "sanitize" in r.stderr:
