@@ -228,6 +228,36 @@ size_t TargetedKmerCounter::add_targets_from_table(const std::string& kmers_tsv_
     return rows;
 }
 
+size_t TargetedKmerCounter::add_targets_from_sequences(const std::string& fasta) {
+    if (frozen_) throw std::runtime_error("TargetedKmerCounter: targets must be registered before the reads are counted");
+    const uint64_t mask = k_ == 32 ? ~0ull : ((1ull << (2 * k_)) - 1ull);
+    size_t registered = 0;
+    stream_sequences(fasta, [&](const std::string& seq) {
+        uint64_t fwd = 0, rev = 0;
+        size_t filled = 0;
+        for (const char c : seq) {
+            const int b = base_code(c);
+            if (b < 0) { filled = 0; fwd = rev = 0; continue; }
+            fwd = ((fwd << 2) | (uint64_t)b) & mask;
+            rev = (rev >> 2) | ((uint64_t)(3 - b) << (2 * (k_ - 1)));
+            if (++filled >= k_) { pending_.push_back(fwd < rev ? fwd : rev); registered += 1; }
+        }
+        if (pending_.size() > (64u << 20)) {   // (long graphs: drop repeats now and then)
+            std::sort(pending_.begin(), pending_.end());
+            pending_.erase(std::unique(pending_.begin(), pending_.end()), pending_.end());
+        }
+    });
+    return registered;
+}
+
+std::vector<size_t> TargetedKmerCounter::abundance_histogram(size_t max_count) {
+    freeze();
+    std::vector<size_t> seen(max_count + 1, 0);
+    for (size_t at = 0; at < keys_.size(); ++at)
+        if (keys_[at] != kEmpty && counts_[at] > 0 && counts_[at] <= max_count) seen[(size_t)counts_[at]] += 1;
+    return seen;
+}
+
 void TargetedKmerCounter::freeze() {
     if (frozen_) return;
     std::sort(pending_.begin(), pending_.end());

@@ -60,10 +60,18 @@ public:
     void add_target(std::string_view kmer);
     /** register every unique and flanking k-mer of a `<prefix>_<chromosome>_kmers.tsv(.gz)` table; returns how many rows */
     size_t add_targets_from_table(const std::string& kmers_tsv_gz);
+    /** register every window of a FASTA / FASTQ file — `<prefix>_path_segments.fasta` makes this counter the reference's
+     *  default count source (JellyfishCounter(readfile, {segment_file}, ...), src/jellyfishcounter.cpp:51-84: only k-mers of
+     *  the graph are counted); returns how many windows were registered (with repeats) */
+    size_t add_targets_from_sequences(const std::string& fasta);
     /** stream a read file and count; may be called for several files (counts add up).  No targets may be added afterwards. */
     void count(const std::string& readfile, unsigned threads = 1);
     size_t getKmerAbundance(std::string kmer) override;
     size_t targets() const { return n_targets_; }
+    /** how many registered k-mers were seen c times, c = 1..max_count (index 0 stays 0, larger counts are left out) — the
+     *  numbers the reference's JellyfishCounter::computeHistogram collects (src/jellyfishcounter.cpp:119-126) before it
+     *  looks for the abundance peak; the peak rule itself is not part of this build (see above) */
+    std::vector<size_t> abundance_histogram(size_t max_count);
     size_t kmers_seen() const { return windows_; }   // windows over ACGT of all reads streamed so far
 
 private:

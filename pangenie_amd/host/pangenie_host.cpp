@@ -372,8 +372,8 @@ std::string genotype_field(const GenotypingResult& result, std::vector<unsigned 
         out << ".:.:";
     std::vector<long double> likelihoods = gl.get_all_likelihoods(nr_alleles);
     if (likelihoods.size() < 3) fail("Graph::write_genotypes_of: too few likelihoods (" + std::to_string(likelihoods.size()) + ") computed");
-    out << std::setprecision(4) << log10(likelihoods[0]);
-    for (size_t j = 1; j < likelihoods.size(); ++j) out << "," << std::setprecision(4) << log10(likelihoods[j]);
+    out << std::setprecision(4) << std::log10(likelihoods[0]);
+    for (size_t j = 1; j < likelihoods.size(); ++j) out << "," << std::setprecision(4) << std::log10(likelihoods[j]);
     out << ":" << result.coverage();
     return out.str();
 }

@@ -1256,6 +1256,83 @@ static void gpu_tests() {
     });
 }
 
+// ------------------------------------------------------------------ the reference's demo (BASELINE.json configs[0]; README "Demo"):
+//   PanGenie-index -r test-reference.fa -v test-variants.vcf -o preprocessing ; PanGenie -f preprocessing -i test-reads.fa -o test
+// composed from the host pieces.  Kept on the test side: it is the reference's command layer (run_index_command +
+// run_genotype_command, src/commands.cpp:592-1052), which this build does not ship; what it shows is that the pieces either side
+// of the device path reproduce demo/test_genotyping.vcf.
+//
+// The k-mer abundance peak of the default run (only graph k-mers counted => the LARGEST peak, src/commands.cpp:840): the
+// histogram is averaged in place over windows of three, left to right, so every mean already sees the mean before it; a peak
+// is the last position of a rise before a fall; the highest one wins, the earlier one on ties.  (Test-side on purpose: the
+// product takes the peak as an argument, kmer_counts.hpp.)
+static size_t demo_abundance_peak(std::vector<size_t> seen) {
+    for (size_t c = 1; c + 1 < seen.size(); ++c) seen[c] = (seen[c - 1] + seen[c] + seen[c + 1]) / 3;
+    size_t best = 0, best_height = 0, before = 0;
+    bool found = false, falling = false;
+    for (size_t c = 0; c < seen.size(); before = seen[c], ++c) {
+        if (seen[c] > before) falling = false;
+        else if (seen[c] < before) {
+            if (!falling && (!found || before > best_height)) { best = c - 1; best_height = before; found = true; }
+            falling = true;
+        }
+    }
+    if (!found) throw std::runtime_error("no peak in the k-mer abundance histogram");
+    return best;
+}
+
+struct DemoSample {
+    std::vector<std::string> chromosomes;   // in the order run_genotype_command visits them (the archive's map order)
+    UniqueKmersMap counted;
+    size_t peak = 0;
+};
+
+// PanGenie-index, then steps 1-3 of run_genotype_command (src/commands.cpp:812-876): counts of the graph's k-mers in the reads,
+// the abundance peak, counts and local coverage into the index
+static DemoSample demo_prepare(const std::string& demo_dir, const std::string& prefix, unsigned threads) {
+    build_index(demo_dir + "/test-reference.fa", demo_dir + "/test-variants.vcf", prefix, 31, true);
+    DemoSample d;
+    d.counted = load_unique_kmers_map(prefix + "_UniqueKmersMap.cereal");
+    TargetedKmerCounter reads(d.counted.kmersize);
+    reads.add_targets_from_sequences(prefix + "_path_segments.fasta");
+    reads.count(demo_dir + "/test-reads.fa", threads);
+    d.peak = demo_abundance_peak(reads.abundance_histogram(10000));
+    for (auto& kv : d.counted.unique_kmers) {
+        d.chromosomes.push_back(kv.first);
+        fill_read_kmercounts(kv.first, &d.counted, reads, prefix + "_" + kv.first + "_kmers.tsv.gz", d.peak);
+    }
+    return d;
+}
+
+// the writing part of run_genotype_command / run_vcf_command (src/commands.cpp:1019-1044, :1106-1135)
+static void demo_write_vcf(const std::string& prefix, const std::map<std::string, std::vector<GenotypingResult>>& results,
+                           const std::vector<std::string>& chromosomes, const std::string& out, const std::string& sample) {
+    std::remove(out.c_str());
+    bool header = true;
+    for (const std::string& c : chromosomes) {
+        Graph::load(prefix + "_" + c + "_Graph.cereal").write_genotypes(out, results.at(c), header, sample, false);
+        header = false;
+    }
+}
+
+// the whole default run with the HMM on the device: one subset of all paths (<= 100 paths: no sampling; src/commands.cpp:799-803,
+// :906-915), likelihoods unnormalised out of the HMM, normalised afterwards (:160, :981-987)
+static void demo_genotype_on_device(const std::string& demo_dir, const std::string& prefix, const std::string& out) {
+    DemoSample d = demo_prepare(demo_dir, prefix, 2);
+    ProbabilityTable probs(d.peak / 4, d.peak * 4, 2 * d.peak, 0.01L);
+    std::map<std::string, std::vector<GenotypingResult>> results;
+    for (const std::string& c : d.chromosomes) {
+        std::vector<std::shared_ptr<UniqueKmers>>& uks = d.counted.unique_kmers[c];
+        if (uks.empty()) { results[c] = {}; continue; }
+        std::vector<unsigned short> all_paths(uks[0]->get_nr_paths());
+        for (size_t p = 0; p < all_paths.size(); ++p) all_paths[p] = (unsigned short)p;
+        HMM hmm(&uks, &probs, true, false, 1.26, false, 0.00001L, &all_paths, false);
+        results[c] = hmm.move_genotyping_result();
+        for (GenotypingResult& r : results[c]) r.normalize();
+    }
+    demo_write_vcf(prefix, results, d.chromosomes, out, "sample");
+}
+
 int main(int argc, char** argv) {
     const std::string mode = argc > 1 ? argv[1] : "cpu";
     if (argc > 2) g_golden_dir = argv[2];
@@ -1270,6 +1347,23 @@ int main(int argc, char** argv) {
         if (!f) return 2;
         for (const std::string& l : genotype_index_fixture()) std::fprintf(f, "%s\n", l.c_str());
         std::fclose(f);
+        return 0;
+    }
+    else if (mode == "demo-counts" && argc >= 4) {   // CPU: index + counted archive of the demo, peak on stdout (tests/test_demo.py)
+        DemoSample d = demo_prepare(argv[2], argv[3], argc > 4 ? (unsigned)std::atoi(argv[4]) : 2u);
+        save_unique_kmers_map(d.counted, std::string(argv[3]) + "_counted_UniqueKmersMap.cereal");
+        std::printf("peak=%zu\n", d.peak);
+        return 0;
+    }
+    else if (mode == "vcf" && argc >= 5) {   // CPU: PanGenie-vcf — a Results archive + the Graph archives of <prefix> -> genotyped VCF
+        Results r = load_results(argv[3]);
+        std::vector<std::string> chromosomes;
+        for (const auto& kv : r.result) chromosomes.push_back(kv.first);
+        demo_write_vcf(argv[2], r.result, chromosomes, argv[4], "sample");
+        return 0;
+    }
+    else if (mode == "demo" && argc >= 5) {   // GPU: the demo end to end
+        demo_genotype_on_device(argv[2], argv[3], argv[4]);
         return 0;
     }
     else { std::printf("usage: test_host cpu|gpu\n"); return 2; }
