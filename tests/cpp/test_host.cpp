@@ -737,6 +737,13 @@ static void archive_cpu_tests() {
         three.add_to_likelihood(0, 0, 0.2L); three.add_to_likelihood(0, 1, 0.2L); three.add_to_likelihood(1, 1, 0.1L);
         three.add_to_likelihood(0, 2, 0.25L); three.add_to_likelihood(1, 2, 0.25L);
         CHECK(genotype_field(three, defined, 3) == ".:.:-0.3979,-0.3979,-0.699:0");
+        // a likelihood sixteen long double steps below 1 keeps its logarithm (the last record of demo/test_genotyping.vcf:
+        // 1/1:180:-55.05,-18.08,-3.767e-19) — the log10 is taken in long double
+        GenotypingResult close;
+        close.add_to_likelihood(0, 0, 8.959757403193811914e-56L); close.add_to_likelihood(0, 1, 8.3995489827273644067e-19L);
+        close.add_to_likelihood(1, 1, 1.0L - 16.0L * 0x1p-64L);
+        close.set_coverage(3);
+        CHECK(genotype_field(close, defined, 2) == "1/1:180:-55.05,-18.08,-3.767e-19:3");
     });
 }
 
