@@ -395,14 +395,40 @@ std::vector<std::string> Graph::genotypes_header(const std::string& sample, cons
 }
 
 std::vector<std::string> Graph::genotypes_records(const std::vector<GenotypingResult>& genotyping_result, bool ignore_imputed) const {
-    if (variants_deleted_) throw std::runtime_error("Graph::write_genotypes_of: variants have been deleted by delete_variant funtion. Re-build object.");
-    if (genotyping_result.size() != size()) throw std::runtime_error("Graph::write_genotypes_of: number of variants and number of computed genotypes differ.");
+    return sample_records(genotyping_result, ignore_imputed, false);
+}
+
+std::vector<std::string> Graph::phasing_records(const std::vector<GenotypingResult>& genotyping_result, bool ignore_imputed) const {
+    return sample_records(genotyping_result, ignore_imputed, true);
+}
+
+// the haplotype pair of a record as `a|b` (reference src/graph.cpp:388-407): an allele of undefined sequence is written as
+// `.`, the others as their index among the defined alleles
+static std::string phased_field(const VcfSite& site, const std::vector<unsigned short>& defined_in, bool ignore_imputed) {
+    std::ostringstream out;
+    if (ignore_imputed && site.likelihoods.nr_unique_kmers() == 0) out << "./.";
+    else {
+        std::vector<unsigned short> defined = defined_in;
+        const std::pair<unsigned short, unsigned short> in_record = site.likelihoods.get_haplotype();
+        const std::pair<unsigned short, unsigned short> among_defined =
+            defined.size() < site.alleles.size() ? site.likelihoods.get_specific_likelihoods(defined).get_haplotype() : in_record;
+        if (site.undefined.at(in_record.first)) out << ".|"; else out << (unsigned int)among_defined.first << "|";
+        if (site.undefined.at(in_record.second)) out << "."; else out << (unsigned int)among_defined.second;
+    }
+    out << ":" << site.likelihoods.coverage();
+    return out.str();
+}
+
+std::vector<std::string> Graph::sample_records(const std::vector<GenotypingResult>& genotyping_result, bool ignore_imputed, bool phasing) const {
+    const char* who = phasing ? "Graph::write_phasing_of" : "Graph::write_genotypes_of";
+    if (variants_deleted_) throw std::runtime_error(std::string(who) + ": variants have been deleted by delete_variant funtion. Re-build object.");
+    if (genotyping_result.size() != size()) throw std::runtime_error(std::string(who) + ": number of variants and number of computed " + (phasing ? "phasings" : "genotypes") + " differ.");
     std::vector<std::string> lines;
     size_t record_index = 0;   // over single records: the row of variant_ids
     for (size_t i = 0; i < size(); ++i) {
         for (const VcfSite& site : get_variant(i).records(&genotyping_result[i])) {
             const size_t n_all = site.alleles.size();
-            if (n_all < 2) throw std::runtime_error("Graph::write_genotypes_of: less than 2 alleles given for variant at position " + std::to_string(site.start));
+            if (n_all < 2) throw std::runtime_error(std::string(who) + ": less than 2 alleles given for variant at position " + std::to_string(site.start));
             // ALT = the defined alternative alleles; genotypes over undefined alleles are dropped below
             std::vector<unsigned short> defined = {0};
             std::vector<std::string> alts;
@@ -422,7 +448,7 @@ std::vector<std::string> Graph::genotypes_records(const std::vector<GenotypingRe
             const std::vector<std::string>& ids = variant_ids_.at(record_index);
             if (!ids.empty()) {
                 // the ids are kept in the lexicographic order of their ALT alleles: back into ALT order
-                if (ids.size() != alts.size()) throw std::runtime_error("Graph::write_genotypes_of: number of variant ids and of ALT alleles differ");
+                if (ids.size() != alts.size()) throw std::runtime_error(std::string(who) + ": number of variant ids and of ALT alleles differ");
                 std::vector<size_t> by_sequence(alts.size());
                 std::iota(by_sequence.begin(), by_sequence.end(), (size_t)0);
                 std::sort(by_sequence.begin(), by_sequence.end(), [&](size_t x, size_t y) { return alts[x] < alts[y]; });
@@ -431,7 +457,8 @@ std::vector<std::string> Graph::genotypes_records(const std::vector<GenotypingRe
                 line << ";ID=";
                 for (size_t k = 0; k < in_alt_order.size(); ++k) line << (k ? "," : "") << *in_alt_order[k];
             }
-            line << "\tGT:GQ:GL:KC\t" << genotype_field(site.likelihoods, defined, n_all, ignore_imputed);
+            if (phasing) line << "\tGT:KC\t" << phased_field(site, defined, ignore_imputed);
+            else line << "\tGT:GQ:GL:KC\t" << genotype_field(site.likelihoods, defined, n_all, ignore_imputed);
             lines.push_back(line.str());
             record_index += 1;
         }
@@ -446,6 +473,27 @@ void Graph::write_genotypes(const std::string& filename, const std::vector<Genot
     if (!out.is_open()) throw std::runtime_error("Graph::write_genotypes_of: genotyping output file cannot be opened. Note that the filename must not contain non-existing directories.");
     if (write_header)
         for (const std::string& h : genotypes_header(sample)) out << h << '\n';
+    for (const std::string& l : records) out << l << '\n';
+}
+
+std::vector<std::string> Graph::phasing_header(const std::string& sample, const std::string& date) {
+    // the genotyping header without the GQ / GL lines (reference src/graph.cpp:296-308; its AK description ends with a full stop here)
+    std::vector<std::string> lines;
+    for (const std::string& l : genotypes_header(sample, date)) {
+        if (l.rfind("##FORMAT=<ID=GQ", 0) == 0 || l.rfind("##FORMAT=<ID=GL", 0) == 0) continue;
+        if (l.rfind("##INFO=<ID=AK", 0) == 0) { lines.push_back(l.substr(0, l.size() - 2) + ".\">"); continue; }
+        lines.push_back(l);
+    }
+    return lines;
+}
+
+void Graph::write_phasing(const std::string& filename, const std::vector<GenotypingResult>& genotyping_result, bool write_header,
+                          const std::string& sample, bool ignore_imputed) const {
+    const std::vector<std::string> records = phasing_records(genotyping_result, ignore_imputed);
+    std::ofstream out(filename, write_header ? std::ios::out : std::ios::app);
+    if (!out.is_open()) throw std::runtime_error("Graph::write_phasing_of: phasing output file cannot be opened. Note that the filename must not contain non-existing directories.");
+    if (write_header)
+        for (const std::string& h : phasing_header(sample)) out << h << '\n';
     for (const std::string& l : records) out << l << '\n';
 }
 

@@ -139,7 +139,15 @@ public:
     void write_genotypes(const std::string& filename, const std::vector<GenotypingResult>& genotyping_result, bool write_header,
                          const std::string& sample, bool ignore_imputed = false) const;
 
+    /** the phasing VCF of a `-p` run (reference Graph::write_phasing, src/graph.cpp:280-412): the same fixed columns, `GT:KC`
+     *  with the Viterbi haplotypes `a|b` (HMM with run_phasing; `.` for an allele of undefined sequence) */
+    static std::vector<std::string> phasing_header(const std::string& sample, const std::string& date = "");
+    std::vector<std::string> phasing_records(const std::vector<GenotypingResult>& genotyping_result, bool ignore_imputed = false) const;
+    void write_phasing(const std::string& filename, const std::vector<GenotypingResult>& genotyping_result, bool write_header,
+                       const std::string& sample, bool ignore_imputed = false) const;
+
 private:
+    std::vector<std::string> sample_records(const std::vector<GenotypingResult>& genotyping_result, bool ignore_imputed, bool phasing) const;
     std::vector<std::pair<std::string, std::shared_ptr<DnaSequence>>> fasta_;   // name -> sequence, archive (= sorted) order
     std::string chromosome_;
     size_t kmer_size_ = 0;

@@ -543,6 +543,31 @@ static void graph_cpu_tests() {
         try { std::vector<unsigned char> cut(raw.begin(), raw.begin() + 2000); Graph::parse(cut); } catch (const std::runtime_error&) { threw = true; }
         CHECK(threw);
     });
+    run("Graph::phasing_records: GT:KC of the Viterbi haplotypes (src/graph.cpp:280-412)", [] {
+        Graph g = Graph::load(g_golden_dir + "/index_chr1_Graph.cereal");   // chr1 139 T C; chr1 208 TG CG,CA; bubble alleles 2.. / 3.. undefined
+        std::vector<GenotypingResult> ph(2);
+        ph[0].add_first_haplotype_allele(1); ph[0].add_second_haplotype_allele(0); ph[0].set_coverage(30); ph[0].set_unique_kmers(62);
+        ph[1].add_first_haplotype_allele(2); ph[1].add_second_haplotype_allele(7); ph[1].set_coverage(34); ph[1].set_unique_kmers(0);
+        const std::vector<std::string> lines = g.phasing_records(ph);
+        CHECK(lines.size() == 2);
+        auto last = [](const std::string& l) { return l.substr(l.rfind('\t') + 1); };
+        auto format = [](const std::string& l) { const size_t e = l.rfind('\t'), b = l.rfind('\t', e - 1); return l.substr(b + 1, e - b - 1); };
+        CHECK(format(lines[0]) == "GT:KC" && format(lines[1]) == "GT:KC");
+        CHECK(lines[0].rfind("chr1\t139\t.\tT\tC\t.\tPASS\tAF=", 0) == 0 && lines[0].find(";UK=62;MA=42;ID=") != std::string::npos);
+        // a phasing-only result holds no likelihoods: among the DEFINED alleles the haplotypes come out as 0 (the reference
+        // maps them inside get_specific_likelihoods' loop over the stored genotypes, src/genotypingresult.cpp:83-91)
+        CHECK(last(lines[0]) == "0|0:30");
+        CHECK(last(lines[1]) == "0|.:34");              // allele 7 of the second record is undefined sequence
+        CHECK(last(g.phasing_records(ph, true)[1]) == "./.:34");   // ignore_imputed and no unique k-mers
+        // with likelihoods stored (a run with genotyping and phasing) the haplotypes are mapped onto the defined alleles
+        ph[0].add_to_likelihood(0, 1, 0.75L); ph[0].add_to_likelihood(1, 1, 0.25L);
+        CHECK(last(g.phasing_records(ph)[0]) == "1|0:30");
+        const std::vector<std::string> head = Graph::phasing_header("sample", "20230821");
+        CHECK(head.size() == 10 && head[1] == "##fileDate=20230821" && head[8] == "##FORMAT=<ID=KC,Number=1,Type=Float,Description=\"Local kmer coverage.\">");
+        bool threw = false;
+        try { ph.pop_back(); g.phasing_records(ph); } catch (const std::runtime_error&) { threw = true; }
+        CHECK(threw);
+    });
     run("Variant: a combined bubble back into its records (tests/VariantTest.cpp:170-241)", [] {
         // three records of chr2 merged into one bubble: A>T at 4, GAG>ACC at 7, G>GTC at 13; paths (0,0,0) (0,0,0) (1,1,1) (1,1,0)
         Variant v = Variant::from_parts("chr2", 4, "ATGA", "GGAA", {{"A", "T"}, {"GAG", "ACC"}, {"G", "GTC"}}, {"CT", "ACT"},
@@ -1313,31 +1338,41 @@ static DemoSample demo_prepare(const std::string& demo_dir, const std::string& p
 
 // the writing part of run_genotype_command / run_vcf_command (src/commands.cpp:1019-1044, :1106-1135)
 static void demo_write_vcf(const std::string& prefix, const std::map<std::string, std::vector<GenotypingResult>>& results,
-                           const std::vector<std::string>& chromosomes, const std::string& out, const std::string& sample) {
+                           const std::vector<std::string>& chromosomes, const std::string& out, const std::string& sample, bool phasing = false) {
     std::remove(out.c_str());
     bool header = true;
     for (const std::string& c : chromosomes) {
-        Graph::load(prefix + "_" + c + "_Graph.cereal").write_genotypes(out, results.at(c), header, sample, false);
+        const Graph graph = Graph::load(prefix + "_" + c + "_Graph.cereal");
+        if (phasing) graph.write_phasing(out, results.at(c), header, sample, false);
+        else graph.write_genotypes(out, results.at(c), header, sample, false);
         header = false;
     }
 }
 
 // the whole default run with the HMM on the device: one subset of all paths (<= 100 paths: no sampling; src/commands.cpp:799-803,
 // :906-915), likelihoods unnormalised out of the HMM, normalised afterwards (:160, :981-987)
-static void demo_genotype_on_device(const std::string& demo_dir, const std::string& prefix, const std::string& out) {
+// With `phasing_out` also the phasing job of a `-p` run (:961-966: the Viterbi path over min(paths, 30) paths — PathSampler's
+// single subset of ALL paths is all of them, whatever its random numbers) and its VCF.
+static void demo_genotype_on_device(const std::string& demo_dir, const std::string& prefix, const std::string& out, const std::string& phasing_out) {
     DemoSample d = demo_prepare(demo_dir, prefix, 2);
     ProbabilityTable probs(d.peak / 4, d.peak * 4, 2 * d.peak, 0.01L);
-    std::map<std::string, std::vector<GenotypingResult>> results;
+    std::map<std::string, std::vector<GenotypingResult>> results, phasings;
     for (const std::string& c : d.chromosomes) {
         std::vector<std::shared_ptr<UniqueKmers>>& uks = d.counted.unique_kmers[c];
-        if (uks.empty()) { results[c] = {}; continue; }
+        if (uks.empty()) { results[c] = {}; phasings[c] = {}; continue; }
         std::vector<unsigned short> all_paths(uks[0]->get_nr_paths());
         for (size_t p = 0; p < all_paths.size(); ++p) all_paths[p] = (unsigned short)p;
         HMM hmm(&uks, &probs, true, false, 1.26, false, 0.00001L, &all_paths, false);
         results[c] = hmm.move_genotyping_result();
         for (GenotypingResult& r : results[c]) r.normalize();
+        if (!phasing_out.empty()) {
+            if (all_paths.size() > 30) throw std::runtime_error("demo: more than 30 paths (the reference would sample 30 for phasing)");
+            HMM viterbi(&uks, &probs, false, true, 1.26, false, 0.00001L, &all_paths, false);
+            phasings[c] = viterbi.move_genotyping_result();
+        }
     }
     demo_write_vcf(prefix, results, d.chromosomes, out, "sample");
+    if (!phasing_out.empty()) demo_write_vcf(prefix, phasings, d.chromosomes, phasing_out, "sample", true);
 }
 
 int main(int argc, char** argv) {
@@ -1366,11 +1401,11 @@ int main(int argc, char** argv) {
         Results r = load_results(argv[3]);
         std::vector<std::string> chromosomes;
         for (const auto& kv : r.result) chromosomes.push_back(kv.first);
-        demo_write_vcf(argv[2], r.result, chromosomes, argv[4], "sample");
+        demo_write_vcf(argv[2], r.result, chromosomes, argv[4], "sample", argc > 5 && std::string(argv[5]) == "phasing");
         return 0;
     }
     else if (mode == "demo" && argc >= 5) {   // GPU: the demo end to end
-        demo_genotype_on_device(argv[2], argv[3], argv[4]);
+        demo_genotype_on_device(argv[2], argv[3], argv[4], argc > 5 ? argv[5] : "");
         return 0;
     }
     else { std::printf("usage: test_host cpu|gpu\n"); return 2; }

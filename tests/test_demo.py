@@ -30,6 +30,22 @@ def expected():
     return without_date((DEMO / "test_genotyping.vcf").read_text())
 
 
+def check_phasing(text):
+    """demo/test_phasing.vcf was written by an earlier release (2023: other unique k-mer rules, hence other UK / KC values),
+    so it pins what did not change: the header, the fixed columns, AF / MA and — the Viterbi path over the same panel and
+    the same reads — the phased genotypes."""
+    got, want = without_date(text), without_date((DEMO / "test_phasing.vcf").read_text())
+    assert got[:9] == want[:9] and len(got) == len(want) == 13
+    for g, w in zip(got[9:], want[9:]):
+        g, w = g.split("\t"), w.split("\t")
+        assert g[:7] == w[:7] and g[8] == w[8] == "GT:KC"
+        gi, wi = (dict(kv.split("=") for kv in x[7].split(";")) for x in (g, w))
+        assert gi["AF"] == wi["AF"] and gi["MA"] == wi["MA"] and sorted(gi) == sorted(wi)
+        assert g[9].split(":")[0] == w[9].split(":")[0]
+    assert [g.split("\t")[9] for g in got[9:]] == ["1|0:3", "0|1:3", "1|2:1", "1|1:3"]
+    assert [g.split("\t")[7].split(";")[1] for g in got[9:]] == ["UK=32", "UK=32", "UK=48", "UK=32"]
+
+
 def test_demo_index_counts_oracle_vcf(tmp_path):
     from oracle import pyoracle as orc
     build_host()
@@ -65,11 +81,26 @@ def test_demo_index_counts_oracle_vcf(tmp_path):
     assert r.returncode == 0, r.stdout + r.stderr
     assert without_date(out.read_text()) == expected()
 
+    # the phasing job of a `-p` run (src/commands.cpp:961-966): Viterbi over all 25 paths, by the oracle
+    ph = cereal_io.Results()
+    for chrom, objects in counted.unique_kmers.items():
+        batch = flatten(objects)
+        vit = orc.viterbi_contig(batch, orc.OracleTable(peak // 4, peak * 4, 2 * peak, 0.01),
+                                 orc.make_params(1.26, False, 1e-5, run_genotyping=False, run_phasing=True))
+        ph.result[chrom] = results_from_flat(batch, None, vit.kept, None, vit.n_kmers, vit.coverage, vit.hap1, vit.hap2, with_likelihoods=False)
+        ph.runtimes[chrom] = 0.0
+    archive.write_bytes(cereal_io.dumps_results(ph))
+    out = tmp_path / "test_phasing.vcf"
+    r = subprocess.run([str(HOST_TEST), "vcf", str(prefix), str(archive), str(out), "phasing"], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stdout + r.stderr
+    check_phasing(out.read_text())
+
 
 @pytest.mark.gpu
 def test_demo_end_to_end_on_the_device(tmp_path):
     build_host()
-    out = tmp_path / "test_genotyping.vcf"
-    r = subprocess.run([str(HOST_TEST), "demo", str(DEMO), str(tmp_path / "preprocessing"), str(out)], capture_output=True, text=True, timeout=300)
+    out, phasing = tmp_path / "test_genotyping.vcf", tmp_path / "test_phasing.vcf"
+    r = subprocess.run([str(HOST_TEST), "demo", str(DEMO), str(tmp_path / "preprocessing"), str(out), str(phasing)], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stdout + r.stderr
     assert without_date(out.read_text()) == expected()
+    check_phasing(phasing.read_text())
