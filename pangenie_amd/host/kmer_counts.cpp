@@ -177,7 +177,7 @@ inline uint64_t mix64(uint64_t x) {   // (splitmix64 finaliser: 2-bit codes of s
 }
 }  // namespace
 
-TargetedKmerCounter::TargetedKmerCounter(size_t kmer_size) : k_(kmer_size) {
+TargetedKmerCounter::TargetedKmerCounter(size_t kmer_size, bool unregistered_counts_zero) : k_(kmer_size), lenient_(unregistered_counts_zero) {
     if (k_ == 0 || k_ > 32) throw std::runtime_error("TargetedKmerCounter: k-mer size must be 1..32");
 }
 
@@ -372,7 +372,10 @@ size_t TargetedKmerCounter::getKmerAbundance(std::string kmer) {
     uint64_t code;
     if (!encode_canonical(kmer.data(), code)) return 0;   // (letters outside ACGT: no window of a read can be this k-mer)
     const size_t at = find(code);
-    if (at == (size_t)-1) throw std::runtime_error("TargetedKmerCounter::getKmerAbundance: " + kmer + " was not registered before the reads were counted");
+    if (at == (size_t)-1) {
+        if (lenient_) return 0;
+        throw std::runtime_error("TargetedKmerCounter::getKmerAbundance: " + kmer + " was not registered before the reads were counted");
+    }
     return (size_t)counts_[at];
 }
 

@@ -55,7 +55,9 @@ private:
  *  would be a wrong count).  Same counts as ExactKmerCounter / the reference's Jellyfish pass for registered k-mers. */
 class TargetedKmerCounter : public KmerCounter {
 public:
-    explicit TargetedKmerCounter(size_t kmer_size);
+    /** `unregistered_counts_zero`: what getKmerAbundance does for a k-mer that was never registered — false (default): throw;
+     *  true: return 0, which is what the reference's graph-only JellyfishCounter answers (tests/KmerCounterTest.cpp:21-32) */
+    explicit TargetedKmerCounter(size_t kmer_size, bool unregistered_counts_zero = false);
     /** register a k-mer (any orientation); k-mers with letters outside ACGT can never be counted and are ignored */
     void add_target(std::string_view kmer);
     /** register every unique and flanking k-mer of a `<prefix>_<chromosome>_kmers.tsv(.gz)` table; returns how many rows */
@@ -87,6 +89,7 @@ private:
     size_t n_targets_ = 0;
     uint64_t windows_ = 0;
     bool frozen_ = false;
+    bool lenient_ = false;
 };
 
 /** one row of `<prefix>_<chromosome>_kmers.tsv(.gz)` — the reference's interface (src/kmerparser.hpp); implemented

@@ -278,6 +278,139 @@ static void index_builder_cpu_tests() {
         got.sampling_runtimes = want.sampling_runtimes;
         CHECK(serialize_unique_kmers_map(got) == read_file(g_golden_dir + "/index_UniqueKmersMap.cereal"));
     });
+    run("build_graphs on the reference's small VCFs (tests/GraphBuilderTest.cpp:18-74, :103-199, :259-318, :397-405, :432-438)", [] {
+        const std::string dir = g_golden_dir + "/graphbuilder/";
+        const ReferenceSequences reference(dir + "small1.fa");
+        {   // get_allele_string: small1.vcf at k = 10 with the reference path
+            const BuiltGraphs b = build_graphs(dir + "small1.vcf", reference, 10, true);
+            CHECK(b.chromosomes == std::vector<std::string>({"chrA", "chrB"}) && b.nr_paths == 5 && b.graphs.size() == 2);
+            const Graph& a = b.graphs.at("chrA");
+            const Graph& bb = b.graphs.at("chrB");
+            CHECK(a.get_kmer_size() == 10 && bb.get_kmer_size() == 10 && a.get_chromosome() == "chrA" && bb.get_chromosome() == "chrB");
+            CHECK(a.size() == 7 && bb.size() == 2 && a.get_variant(2).nr_of_alleles() == 3 && a.get_variant(2).nr_of_paths() == 5);
+            const std::vector<std::vector<std::string>> want = {
+                {"GGAATTCCGACATAAGTTA", "GGAATTCCGTCATAAGTTA"}, {"CCTTAGCTACGAAGCCAGT", "CCTTAGCTAGGGGGAAGCCAGT"},
+                {"GAAGCCAGTGCCCCGAGACGGCCAAA", "GAAGCCAGTTCCCCGAGACGGCCAAA", "GAAGCCAGTTCCCCTACGGCCAAA"},
+                {"ACGTCCGTTCAGCCTTAGC", "ACGTCCGTTTAGCCTTAGC"}, {"CCGATTTTCTTGTGCTATA", "CCGATTTTCCTGTGCTATA"},
+                {"GGAGGGTATGAAGCCATCAC", "GGAGGGTATTCAGCCATCAC"}, {"TGTGGACTTATTTGGCTAA", "TGTGGACTTGTTTGGCTAA"}};
+            for (size_t v = 0; v < want.size() && a.size() == 7; ++v)
+                for (size_t al = 0; al < want[v].size(); ++al) CHECK(a.get_variant(v).get_allele_string(al) == want[v][al]);
+            CHECK(bb.get_variant(0).get_allele_string(0) == "CCACTTCATCAAGACACAA" && bb.get_variant(1).get_allele_string(0) == "GAGTATTTTGATCATAAAT");
+        }
+        auto lines_of = [](const std::string& text) { std::vector<std::string> l; std::istringstream is(text); std::string t; while (std::getline(is, t)) l.push_back(t); return l; };
+        auto file_text = [](const std::string& path) { const std::vector<unsigned char> raw = read_file(path); return std::string(raw.begin(), raw.end()); };
+        auto trimmed = [](std::string t) { const size_t b = t.find_first_not_of(" \t\r\n"), e = t.find_last_not_of(" \t\r\n"); return b == std::string::npos ? std::string() : t.substr(b, e - b + 1); };
+        const BuiltGraphs plain = build_graphs(dir + "small1.vcf", reference, 10, false);
+        CHECK(plain.nr_paths == 4);
+        {   // write_path_segments: the stretches of reference between the bubbles (small1-expected-ref-segments.fa)
+            std::vector<std::string> got, want;
+            for (const std::string& l : lines_of(file_text(dir + "small1-expected-ref-segments.fa"))) want.push_back(trimmed(l));
+            bool take = false;
+            for (const std::string& l : lines_of(path_segments_fasta(plain, reference))) {
+                if (l.empty()) continue;
+                if (l[0] == '>') { take = l.find("reference") != std::string::npos; continue; }
+                if (take) got.push_back(trimmed(l));
+            }
+            CHECK(got == want);
+        }
+        {   // no variants at all: the segment file is the reference (empty.vcf)
+            const BuiltGraphs none = build_graphs(dir + "empty.vcf", reference, 10, false);
+            std::vector<std::string> got, want;
+            for (const std::string& l : lines_of(path_segments_fasta(none, reference))) if (!l.empty() && l[0] != '>') got.push_back(trimmed(l));
+            for (const std::string& n : reference.names()) want.push_back(reference.of(n));
+            std::sort(got.begin(), got.end()); std::sort(want.begin(), want.end());
+            CHECK(got == want && got.size() >= 2);
+        }
+        {   // write_genotypes_of / write_phasing_of with the likelihoods of the reference's test: small1-genotypes.vcf and
+            // small1-phasing.vcf are what an early release wrote for them (AK / KC still in INFO, the first GL with six digits),
+            // so the columns both layouts share are compared: CHROM .. FILTER, AF, GT, GQ, GL to four digits, the phased GT
+            std::vector<GenotypingResult> ga(7), gb(2);
+            for (size_t i = 0; i < 7; ++i) {
+                if (i == 2) continue;
+                ga[i].add_to_likelihood(0, 0, 0.2L); ga[i].add_to_likelihood(0, 1, 0.7L); ga[i].add_to_likelihood(1, 1, 0.1L);
+            }
+            ga[2].add_to_likelihood(0, 0, 0.2L); ga[2].add_to_likelihood(0, 1, 0.0L); ga[2].add_to_likelihood(0, 2, 0.2L);
+            ga[2].add_to_likelihood(1, 1, 0.0L); ga[2].add_to_likelihood(1, 2, 0.5L); ga[2].add_to_likelihood(2, 2, 0.1L);
+            ga[2].add_first_haplotype_allele(2); ga[2].add_second_haplotype_allele(1);
+            for (auto& r : gb) { r.add_to_likelihood(0, 0, 0.1L); r.add_to_likelihood(0, 1, 0.1L); r.add_to_likelihood(1, 1, 0.8L); }
+            auto cols = [](const std::string& l) { std::vector<std::string> f; std::string t; std::istringstream is(l); while (std::getline(is, t, '\t')) f.push_back(t); return f; };
+            auto records_of = [&](const std::string& path) { std::vector<std::vector<std::string>> r; for (const std::string& l : lines_of(file_text(path))) if (!l.empty() && l[0] != '#') r.push_back(cols(l)); return r; };
+            auto split = [](const std::string& t, char sep) { std::vector<std::string> f; std::string x; std::istringstream is(t); while (std::getline(is, x, sep)) f.push_back(x); return f; };
+            std::vector<std::string> got = plain.graphs.at("chrA").genotypes_records(ga), got_b = plain.graphs.at("chrB").genotypes_records(gb);
+            got.insert(got.end(), got_b.begin(), got_b.end());
+            const auto want = records_of(dir + "small1-genotypes.vcf");
+            CHECK(got.size() == 10 && want.size() == 10);
+            for (size_t i = 0; i < got.size() && i < want.size(); ++i) {
+                const std::vector<std::string> g = cols(got[i]), &w = want[i];
+                bool same = g.size() == 10 && w.size() == 10;
+                for (size_t c = 0; same && c < 7; ++c) same = g[c] == w[c];
+                same = same && split(g[7], ';')[0] == split(w[7], ';')[0] && g[8] == "GT:GQ:GL:KC";
+                if (same) {
+                    const std::vector<std::string> gs = split(g[9], ':'), ws = split(w[9], ':');
+                    same = gs.size() == 4 && ws.size() == 3 && gs[0] == ws[0] && gs[1] == ws[1];
+                    const std::vector<std::string> gl = split(gs[2], ','), wl = split(ws[2], ',');
+                    same = same && gl.size() == wl.size();
+                    for (size_t j = 0; same && j < gl.size(); ++j) same = std::fabs(std::stod(gl[j]) - std::stod(wl[j])) <= 5e-4 * std::fabs(std::stod(wl[j]));
+                }
+                if (!same) std::printf("  record %zu: %s\n", i, got[i].c_str());
+                CHECK(same);
+            }
+            std::vector<std::string> ph = plain.graphs.at("chrA").phasing_records(ga), ph_b = plain.graphs.at("chrB").phasing_records(gb);
+            ph.insert(ph.end(), ph_b.begin(), ph_b.end());
+            const auto want_ph = records_of(dir + "small1-phasing.vcf");
+            CHECK(ph.size() == 10 && want_ph.size() == 10);
+            for (size_t i = 0; i < ph.size() && i < want_ph.size(); ++i) {
+                const std::vector<std::string> g = cols(ph[i]), &w = want_ph[i];
+                bool same = g.size() == 10 && w.size() == 10;
+                for (size_t c = 0; same && c < 7; ++c) same = g[c] == w[c];
+                same = same && split(g[7], ';')[0] == split(w[7], ';')[0] && split(g[9], ':')[0] == w[9];
+                if (!same) std::printf("  phasing record %zu: %s\n", i, ph[i].c_str());
+                CHECK(same);
+            }
+        }
+        auto refused = [&](const std::string& vcf) { try { (void)build_graphs(dir + vcf, reference, 10, false); } catch (const std::runtime_error&) { return true; } return false; };
+        CHECK(refused("no-paths.vcf") && refused("malformatted-vcf1.vcf") && refused("overlapping-variants.vcf"));
+        CHECK(build_graphs(dir + "no-alt-alleles.vcf", reference, 10, false).graphs.at("chrA").size() == 1);   // symbolic ALT alleles are skipped
+        CHECK(build_graphs(dir + "small2.vcf", reference, 10, false).chromosomes == std::vector<std::string>({"chrB", "chrC", "chrA"}));   // by number of bubbles
+        CHECK(!refused("small3.vcf"));   // `.` alleles in the panel
+        {   // variant_ids2: ids of a multi-ALT record and of two ids on one allele (small1-ids.vcf)
+            const BuiltGraphs ids = build_graphs(dir + "small1-ids.vcf", reference, 10, true);
+            CHECK(ids.graphs.size() == 1 && ids.graphs.at("chrA").size() == 2);
+            const std::vector<std::string> lines = ids.graphs.at("chrA").genotypes_records(std::vector<GenotypingResult>(2));
+            CHECK(lines.size() == 2 && lines[0].find("\tGGGG,A,T\t") != std::string::npos && lines[0].find(";ID=var1:var2,var3,var4\t") != std::string::npos);
+            CHECK(lines.size() == 2 && lines[1].find(";ID=var5:var6\t") != std::string::npos);
+        }
+        {   // close_to_start: a record closer than 2 k to the chromosome start is left out (close.vcf, k = 31)
+            const ReferenceSequences close_ref(dir + "close.fa");
+            const BuiltGraphs close = build_graphs(dir + "close.vcf", close_ref, 31, true);
+            CHECK(close.graphs.at("chr10").size() == 1 && close.skipped == 1);
+            const std::vector<std::string> lines = close.graphs.at("chr10").genotypes_records(std::vector<GenotypingResult>(1));
+            CHECK(lines.size() == 1 && lines[0].rfind("chr10\t79\t.\tT\tC,A\t.\tPASS\tAF=0.5,0;UK=0;MA=0;ID=testvar2,testvar3\tGT:GQ:GL:KC\t", 0) == 0);
+        }
+    });
+    run("unique_kmers_of on the reference's small VCFs (tests/UniqueKmerComputerTest.cpp:85-150)", [] {
+        const std::string dir = g_golden_dir + "/graphbuilder/";
+        const ReferenceSequences reference(dir + "small1.fa");
+        auto unique_kmers = [&](const std::string& vcf, const std::string& chromosome) {
+            const BuiltGraphs b = build_graphs(dir + vcf, reference, 31, true);
+            const std::string segments = "/tmp/pg_test_uk_segments.fa";
+            { std::FILE* f = std::fopen(segments.c_str(), "w"); std::fputs(path_segments_fasta(b, reference).c_str(), f); std::fclose(f); }
+            ExactKmerCounter graph_kmers(segments, 31);
+            return unique_kmers_of(b.graphs.at(chromosome), graph_kmers);
+        };
+        // every k-mer lies on exactly one allele: the per-allele numbers add up to the total
+        auto adds_up = [](const std::shared_ptr<UniqueKmers>& u) {
+            size_t summed = 0;
+            for (const auto& kv : u->kmers_on_alleles()) if (kv.second > 0) summed += (size_t)kv.second;
+            return summed == u->size();
+        };
+        const ChromosomeKmers a = unique_kmers("small1.vcf", "chrA");   // 8 records, three of them within 30 bases: 6 bubbles
+        CHECK(a.objects.size() == 6 && a.rows.size() == 6);
+        for (const auto& u : a.objects) CHECK(adds_up(u));
+        const ChromosomeKmers b = unique_kmers("small5.vcf", "chrB");   // one record with many long alleles
+        CHECK(b.objects.size() == 1);
+        for (const auto& u : b.objects) CHECK(adds_up(u) && u->size() <= 301 && u->size() > 0);
+    });
     run("build_graphs: records closer than k - 1 merge into one bubble; what the reference refuses is refused", [] {
         // a 400-base reference without repeats of length >= 5 would be ideal; a fixed pseudo-random one serves
         std::string ref;
@@ -368,6 +501,27 @@ static void kmer_count_cpu_tests() {
         m.runtimes = want.runtimes;
         m.sampling_runtimes = want.sampling_runtimes;
         CHECK(serialize_unique_kmers_map(m) == read_file(g_golden_dir + "/region_UniqueKmersList.cereal"));
+    });
+    run("k-mer counters on the reference's known answers (tests/KmerCounterTest.cpp:10-32)", [] {
+        const std::string reads = "/tmp/pg_kc_reads.fa", kmerfile = "/tmp/pg_kc_kmerfile.fa";   // tests/data/reads.fa, kmerfile.fa
+        { FILE* f = std::fopen(reads.c_str(), "w"); std::fputs(">read1\nATGCTGTAAAAAAACGGC\n", f); std::fclose(f); }
+        { FILE* f = std::fopen(kmerfile.c_str(), "w"); std::fputs(">kmers\nATGCTGTAAAA\n", f); std::fclose(f); }
+        const std::string read = "ATGCTGTAAAAAAACGGC";
+        ExactKmerCounter all(reads, 10);
+        for (size_t i = 0; i + 10 <= read.size(); ++i) CHECK(all.getKmerAbundance(read.substr(i, 10)) == 1);
+        // only the k-mers of kmerfile.fa are counted; the others answer 0 when the counter is asked to behave like Jellyfish's
+        TargetedKmerCounter graph_only(10, true);
+        CHECK(graph_only.add_targets_from_sequences(kmerfile) == 2);
+        graph_only.count(reads, 1);
+        CHECK(graph_only.getKmerAbundance("ATGCTGTAAA") == 1 && graph_only.getKmerAbundance("TGCTGTAAAA") == 1 && graph_only.targets() == 2);
+        const std::string others = "GCTGTAAAAAAACGGC";
+        for (size_t i = 0; i + 10 <= others.size(); ++i) CHECK(graph_only.getKmerAbundance(others.substr(i, 10)) == 0);
+        CHECK(graph_only.abundance_histogram(5) == std::vector<size_t>({0, 2, 0, 0, 0, 0}));
+        TargetedKmerCounter strict(10);
+        strict.add_targets_from_sequences(kmerfile);
+        strict.count(reads, 1);
+        CHECK(strict.getKmerAbundance("TTTACAGCAT") == 1);   // (the reverse complement of the first one)
+        CHECK_THROWS(strict.getKmerAbundance("GCTGTAAAAA"));
     });
     run("ExactKmerCounter: canonical counts, FASTA and FASTQ, letters outside ACGT", [] {
         const std::string fa = "/tmp/pg_test_reads.fa", fq = "/tmp/pg_test_reads.fq";
