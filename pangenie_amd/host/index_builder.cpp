@@ -4,6 +4,12 @@
 #include <zlib.h>
 
 #include <algorithm>
+#include <atomic>
+#include <mutex>
+#include <thread>
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
 #include <fstream>
 #include <set>
 #include <sstream>
@@ -279,10 +285,12 @@ std::string path_segments_fasta(const BuiltGraphs& built, const ReferenceSequenc
 }
 
 // ------------------------------------------------------------------ unique k-mers of a chromosome
-ChromosomeKmers unique_kmers_of(const Graph& graph, KmerCounter& graph_kmers) {
+ChromosomeKmers unique_kmers_of(const Graph& graph, KmerCounter& graph_kmers, unsigned threads) {
     const size_t k = graph.get_kmer_size();
     const std::string reference = graph.reference(graph.get_chromosome());
     ChromosomeKmers out;
+    out.rows.resize(graph.size());
+    out.objects.resize(graph.size());
     // up to 12 k-mers of a reference stretch that occur once in it and once in the whole graph, smallest first
     auto single_copy = [&](const std::string& stretch, std::vector<std::string>& into) {
         size_t taken = 0;
@@ -293,7 +301,8 @@ ChromosomeKmers unique_kmers_of(const Graph& graph, KmerCounter& graph_kmers) {
             if (graph_kmers.getKmerAbundance(kmer) == 1) { into.push_back(kmer); taken += 1; }
         }
     };
-    for (size_t v = 0; v < graph.size(); ++v) {
+    // one bubble: independent of every other (the counter is only read), so bubbles are dealt to `threads` workers
+    auto one_bubble = [&](size_t v) {
         const Variant& bubble = graph.get_variant(v);
         std::vector<unsigned short> path_alleles(bubble.nr_of_paths());
         bool two_alleles_only = true;
@@ -353,24 +362,96 @@ ChromosomeKmers unique_kmers_of(const Graph& graph, KmerCounter& graph_kmers) {
         single_copy(reference.substr(end, right_to - end), flanking);
         std::string flank_column;
         for (const std::string& f : flanking) { if (!flank_column.empty()) flank_column += ','; flank_column += f; }
-        out.rows.push_back(bubble.get_chromosome() + '\t' + std::to_string(start) + '\t' + std::to_string(end) + '\t' +
-                           (unique_column.empty() ? "nan" : unique_column) + '\t' + (flank_column.empty() ? "nan" : flank_column));
-        out.objects.push_back(object);
+        out.rows[v] = bubble.get_chromosome() + '\t' + std::to_string(start) + '\t' + std::to_string(end) + '\t' +
+                      (unique_column.empty() ? "nan" : unique_column) + '\t' + (flank_column.empty() ? "nan" : flank_column);
+        out.objects[v] = object;
+    };
+    if (threads <= 1 || graph.size() < 64) {
+        for (size_t v = 0; v < graph.size(); ++v) one_bubble(v);
+        return out;
     }
+    std::atomic<size_t> next{0};
+    std::exception_ptr failure;
+    std::mutex failure_lock;
+    std::vector<std::thread> workers;
+    for (unsigned t = 0; t < threads; ++t)
+        workers.emplace_back([&] {
+            try {
+                for (size_t from = next.fetch_add(64); from < graph.size(); from = next.fetch_add(64))
+                    for (size_t v = from; v < std::min(from + 64, graph.size()); ++v) one_bubble(v);
+            } catch (...) {
+                std::lock_guard<std::mutex> hold(failure_lock);
+                if (!failure) failure = std::current_exception();
+                next.store(graph.size());
+            }
+        });
+    for (std::thread& w : workers) w.join();
+    if (failure) std::rethrow_exception(failure);
     return out;
 }
 
+// the k-mer table as gzip: the rows are cut into pieces of a few MB, every piece becomes a gzip member of its own (deflated by
+// one of `threads` workers), the members follow each other in the file — which gzread / zcat read as one stream
+static void write_gz_members(const std::string& path, const std::string& header, const std::vector<std::string>& rows, unsigned threads) {
+    std::vector<std::string> pieces(1, header);
+    for (const std::string& row : rows) {
+        if (pieces.back().size() > (4u << 20)) pieces.emplace_back();
+        pieces.back() += row;
+        pieces.back() += '\n';
+    }
+    std::vector<std::vector<unsigned char>> members(pieces.size());
+    std::atomic<size_t> next{0};
+    std::atomic<bool> failed{false};
+    auto work = [&] {
+        for (size_t i = next.fetch_add(1); i < pieces.size(); i = next.fetch_add(1)) {
+            z_stream z{};
+            if (deflateInit2(&z, Z_DEFAULT_COMPRESSION, Z_DEFLATED, 15 + 16, 8, Z_DEFAULT_STRATEGY) != Z_OK) { failed = true; return; }
+            members[i].resize(deflateBound(&z, (uLong)pieces[i].size()) + 64);
+            z.next_in = (Bytef*)pieces[i].data(); z.avail_in = (uInt)pieces[i].size();
+            z.next_out = members[i].data(); z.avail_out = (uInt)members[i].size();
+            const int rc = deflate(&z, Z_FINISH);
+            members[i].resize(z.total_out);
+            deflateEnd(&z);
+            if (rc != Z_STREAM_END) { failed = true; return; }
+            std::string().swap(pieces[i]);
+        }
+    };
+    if (threads <= 1 || pieces.size() == 1) work();
+    else {
+        std::vector<std::thread> workers;
+        for (unsigned t = 0; t < std::min<size_t>(threads, pieces.size()); ++t) workers.emplace_back(work);
+        for (std::thread& w : workers) w.join();
+    }
+    std::ofstream f(path, std::ios::binary);
+    if (failed || !f.good()) throw std::runtime_error("build_index: File " + path + " cannot be created. Note that the filename must not contain non-existing directories.");
+    for (const auto& m : members) f.write((const char*)m.data(), (std::streamsize)m.size());
+    if (!f.good()) throw std::runtime_error("build_index: File " + path + " cannot be written.");
+}
+
 // ------------------------------------------------------------------ everything
-std::vector<std::string> build_index(const std::string& reference_fasta, const std::string& vcf, const std::string& prefix, size_t k, bool add_reference) {
+std::vector<std::string> build_index(const std::string& reference_fasta, const std::string& vcf, const std::string& prefix, size_t k, bool add_reference,
+                                     unsigned threads) {
+    if (threads == 0) threads = std::max(1u, std::thread::hardware_concurrency());
+    const bool verbose = std::getenv("PG_INDEX_VERBOSE") != nullptr;   // stage times on stderr
+    auto clock = std::chrono::steady_clock::now();
+    auto stage = [&](const char* what) {
+        const auto now = std::chrono::steady_clock::now();
+        if (verbose) std::fprintf(stderr, "build_index: %-28s %8.3f s\n", what, std::chrono::duration<double>(now - clock).count());
+        clock = now;
+    };
     const ReferenceSequences reference(reference_fasta);
+    stage("reference read");
     const BuiltGraphs built = build_graphs(vcf, reference, k, add_reference);
+    stage("graphs built");
     const std::string segments = prefix + "_path_segments.fasta";
     {
         std::ofstream f(segments);
         if (!f.good()) throw std::runtime_error("build_index: File " + segments + " cannot be created. Note that the filename must not contain non-existing directories.");
         f << path_segments_fasta(built, reference);
     }
+    stage("segment file written");
     ExactKmerCounter graph_kmers(segments, k);
+    stage("graph k-mers counted");
     UniqueKmersMap map;
     map.kmersize = k;
     map.add_reference = add_reference;
@@ -382,18 +463,16 @@ std::vector<std::string> build_index(const std::string& reference_fasta, const s
             if (!f.good()) throw std::runtime_error("build_index: cannot write the graph of " + name);
             f.write((const char*)bytes.data(), (std::streamsize)bytes.size());
         }
-        ChromosomeKmers kmers = unique_kmers_of(graph, graph_kmers);
-        const std::string table = prefix + "_" + name + "_kmers.tsv.gz";
-        gzFile z = gzopen(table.c_str(), "wb");
-        if (!z) throw std::runtime_error("build_index: File " + table + " cannot be created. Note that the filename must not contain non-existing directories.");
-        std::string text = "#chromosome\tstart\tend\tunique_kmers\tunique_kmers_overhang\n";
-        for (const std::string& row : kmers.rows) { text += row; text += '\n'; }
-        gzwrite(z, text.data(), (unsigned)text.size());
-        gzclose(z);
+        stage("graph archive written");
+        ChromosomeKmers kmers = unique_kmers_of(graph, graph_kmers, threads);
+        stage("unique k-mers selected");
+        write_gz_members(prefix + "_" + name + "_kmers.tsv.gz", "#chromosome\tstart\tend\tunique_kmers\tunique_kmers_overhang\n", kmers.rows, threads);
         map.unique_kmers[name] = std::move(kmers.objects);
         map.runtimes[name] = 0.0;
+        stage("k-mer table written");
     }
     save_unique_kmers_map(map, prefix + "_UniqueKmersMap.cereal");
+    stage("index archive written");
     return built.chromosomes;
 }
 

@@ -56,10 +56,12 @@ struct ChromosomeKmers {
     std::vector<std::string> rows;
     std::vector<std::shared_ptr<UniqueKmers>> objects;
 };
-ChromosomeKmers unique_kmers_of(const Graph& graph, KmerCounter& graph_kmers);
+/** `threads` workers share the bubbles; the counter is only read (getKmerAbundance must be safe to call concurrently:
+ *  ExactKmerCounter is) */
+ChromosomeKmers unique_kmers_of(const Graph& graph, KmerCounter& graph_kmers, unsigned threads = 1);
 
 /** Everything at once, written under `prefix`; returns the chromosomes in the reference's order. */
 std::vector<std::string> build_index(const std::string& reference_fasta, const std::string& vcf, const std::string& prefix,
-                                     size_t kmer_size = 31, bool add_reference = true);
+                                     size_t kmer_size = 31, bool add_reference = true, unsigned threads = 1);   // threads 0 = all cores
 
 }  // namespace pangenie

@@ -27,6 +27,10 @@ inline int base_code(char c) {
         default: return -1;
     }
 }
+inline uint64_t mix64(uint64_t x) {   // (splitmix64 finaliser: 2-bit codes of similar k-mers differ in few bits)
+    x ^= x >> 30; x *= 0xbf58476d1ce4e5b9ull; x ^= x >> 27; x *= 0x94d049bb133111ebull; x ^= x >> 31;
+    return x;
+}
 }  // namespace
 
 // ------------------------------------------------------------------ ExactKmerCounter
@@ -34,6 +38,15 @@ ExactKmerCounter::ExactKmerCounter(const std::string& readfile, size_t kmer_size
     if (k_ == 0 || k_ > 32) throw std::runtime_error("ExactKmerCounter: k-mer size must be 1..32");
     std::ifstream in(readfile);
     if (!in.good()) throw std::runtime_error("ExactKmerCounter: cannot open " + readfile);
+    {   // a file of n letters holds fewer than n windows: start with room for them (up to 2^27 slots; growth goes on from there)
+        in.seekg(0, std::ios::end);
+        const std::streamoff letters = in.tellg();
+        in.seekg(0, std::ios::beg);
+        size_t cap = (size_t)1 << 16;
+        while (cap < ((size_t)1 << 27) && letters > 0 && (double)cap * 0.6 < (double)letters) cap <<= 1;
+        keys_.assign(cap, kFree);
+        seen_.assign(cap, 0);
+    }
     // FASTA (">" header, sequence on one or more lines) or FASTQ ("@" header, sequence, "+", qualities)
     std::string line, seq;
     enum { NONE, FASTA, FQ_SEQ, FQ_PLUS, FQ_QUAL } state = NONE;
@@ -70,17 +83,55 @@ ExactKmerCounter::ExactKmerCounter(const std::string& readfile, size_t kmer_size
 }
 
 void ExactKmerCounter::add_sequence(const std::string& seq) {
-    // rolling 2-bit codes of the window and of its reverse complement; a letter outside {A,C,G,T} restarts the window
+    // rolling 2-bit codes of the window and of its reverse complement; a letter outside {A,C,G,T} restarts the window.
+    // The codes are counted a batch behind: the slot of each is touched when the code is formed, so the table's cache misses
+    // of one batch overlap instead of following each other.
     const uint64_t mask = k_ == 32 ? ~0ull : ((1ull << (2 * k_)) - 1ull);
+    constexpr size_t kBatch = 32;
+    uint64_t batch[kBatch];
+    size_t waiting = 0;
     uint64_t fwd = 0, rev = 0;
     size_t filled = 0;
+    if (keys_.empty()) grow();
     for (char c : seq) {
         const int b = base_code(c);
         if (b < 0) { filled = 0; fwd = rev = 0; continue; }
         fwd = ((fwd << 2) | (uint64_t)b) & mask;
         rev = (rev >> 2) | ((uint64_t)(3 - b) << (2 * (k_ - 1)));
-        if (++filled >= k_) counts_[fwd < rev ? fwd : rev] += 1;  // (2-bit codes order like the letters: A < C < G < T)
+        if (++filled >= k_) {
+            const uint64_t code = fwd < rev ? fwd : rev;   // (2-bit codes order like the letters: A < C < G < T)
+            __builtin_prefetch(&keys_[(size_t)mix64(code) & (keys_.size() - 1)]);
+            batch[waiting++] = code;
+            if (waiting == kBatch) { for (size_t i = 0; i < kBatch; ++i) bump(batch[i]); waiting = 0; }
+        }
     }
+    for (size_t i = 0; i < waiting; ++i) bump(batch[i]);
+}
+
+void ExactKmerCounter::grow() {
+    const size_t cap = keys_.empty() ? (size_t)1 << 16 : keys_.size() * 2;
+    std::vector<uint64_t> keys(cap, kFree);
+    std::vector<uint32_t> seen(cap, 0);
+    for (size_t at = 0; at < keys_.size(); ++at) {
+        if (keys_[at] == kFree) continue;
+        size_t to = (size_t)mix64(keys_[at]) & (cap - 1);
+        while (keys[to] != kFree) to = (to + 1) & (cap - 1);
+        keys[to] = keys_[at];
+        seen[to] = seen_[at];
+    }
+    keys_.swap(keys);
+    seen_.swap(seen);
+}
+
+void ExactKmerCounter::bump(uint64_t code) {
+    if ((filled_ + 1) * 5 > keys_.size() * 3) grow();
+    const size_t cap = keys_.size();
+    size_t at = (size_t)mix64(code) & (cap - 1);
+    while (keys_[at] != code) {
+        if (keys_[at] == kFree) { keys_[at] = code; filled_ += 1; break; }
+        at = (at + 1) & (cap - 1);
+    }
+    if (seen_[at] != ~0u) seen_[at] += 1;
 }
 
 bool ExactKmerCounter::encode_canonical(const char* s, uint64_t& code) const {
@@ -99,8 +150,11 @@ size_t ExactKmerCounter::getKmerAbundance(std::string kmer) {
     if (kmer.size() != k_) throw std::runtime_error("ExactKmerCounter::getKmerAbundance: k-mer of length " + std::to_string(kmer.size()) + ", counter holds " + std::to_string(k_) + "-mers");
     uint64_t code;
     if (!encode_canonical(kmer.data(), code)) return 0;
-    const auto it = counts_.find(code);
-    return it == counts_.end() ? 0 : (size_t)it->second;
+    if (keys_.empty()) return 0;
+    const size_t cap = keys_.size();
+    for (size_t at = (size_t)mix64(code) & (cap - 1); keys_[at] != kFree; at = (at + 1) & (cap - 1))
+        if (keys_[at] == code) return (size_t)seen_[at];
+    return 0;
 }
 
 // ------------------------------------------------------------------ TargetedKmerCounter
@@ -170,10 +224,6 @@ void stream_sequences(const std::string& path, Sink&& sink) {
         throw;
     }
     gzclose(in);
-}
-inline uint64_t mix64(uint64_t x) {   // (splitmix64 finaliser: 2-bit codes of similar k-mers differ in few bits)
-    x ^= x >> 30; x *= 0xbf58476d1ce4e5b9ull; x ^= x >> 27; x *= 0x94d049bb133111ebull; x ^= x >> 31;
-    return x;
 }
 }  // namespace
 

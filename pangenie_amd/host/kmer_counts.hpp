@@ -18,7 +18,6 @@
 #include <cstdint>
 #include <string>
 #include <string_view>
-#include <unordered_map>
 #include <vector>
 
 #include "cereal_io.hpp"
@@ -38,13 +37,20 @@ class ExactKmerCounter : public KmerCounter {
 public:
     ExactKmerCounter(const std::string& readfile, size_t kmer_size);
     size_t getKmerAbundance(std::string kmer) override;
-    size_t distinct_kmers() const { return counts_.size(); }
+    size_t distinct_kmers() const { return filled_; }
 
 private:
     void add_sequence(const std::string& seq);
     bool encode_canonical(const char* s, uint64_t& code) const;
+    void bump(uint64_t code);
+    void grow();
+    // canonical code -> count: open addressing with linear probing, 12 bytes a slot, doubled at 60 % load (a graph's or a
+    // region's worth of k-mers: tens of millions of entries, where a node-based map spends its time in the allocator)
+    static constexpr uint64_t kFree = ~0ull;   // (never a canonical code: the reverse complement of all-T is all-A = 0)
     size_t k_;
-    std::unordered_map<uint64_t, uint64_t> counts_;
+    std::vector<uint64_t> keys_;
+    std::vector<uint32_t> seen_;     // saturates at 2^32 - 1
+    size_t filled_ = 0;
 };
 
 /** Counts of a GIVEN set of k-mers in read files of any size.  fill_read_kmercounts only ever asks for the unique and

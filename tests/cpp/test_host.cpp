@@ -411,6 +411,54 @@ static void index_builder_cpu_tests() {
         CHECK(b.objects.size() == 1);
         for (const auto& u : b.objects) CHECK(adds_up(u) && u->size() <= 301 && u->size() > 0);
     });
+    run("build_index with worker threads: the same files as with one", [] {
+        // 60 kb of pseudo-random reference, 300 records (SNPs, a deletion and a two-ALT insertion now and then), 6 haplotypes
+        std::string ref;
+        uint64_t x = 0x2545F4914F6CDD1Dull;
+        auto rnd = [&]() { x ^= x << 13; x ^= x >> 7; x ^= x << 17; return x; };
+        for (int i = 0; i < 60000; ++i) ref += "ACGT"[rnd() & 3];
+        const std::string fa = "/tmp/pg_test_mt.fa", vcf = "/tmp/pg_test_mt.vcf";
+        { std::FILE* f = std::fopen(fa.c_str(), "w"); std::fprintf(f, ">chrT\n%s\n", ref.c_str()); std::fclose(f); }
+        {
+            std::FILE* f = std::fopen(vcf.c_str(), "w");
+            std::fprintf(f, "##fileformat=VCFv4.2\n#CHROM\tPOS\tID\tREF\tALT\tQUAL\tFILTER\tINFO\tFORMAT\ts1\ts2\ts3\n");
+            for (size_t i = 0, pos = 150; i < 300; ++i, pos += 60 + rnd() % 250) {
+                const char r = ref[pos];
+                const std::string other(1, r == 'A' ? 'C' : 'A');
+                std::string refa(1, r), alt = other;
+                int n_alt = 1;
+                if (i % 17 == 3) refa = ref.substr(pos, 6), alt = std::string(1, r);
+                if (i % 23 == 5) { alt = refa + "GATTACA," + refa + "TT"; n_alt = 2; }
+                std::string gts;
+                bool used[3] = {false, false, false};
+                for (int h = 0; h < 6; ++h) {
+                    const int a = (int)(rnd() % (size_t)(n_alt + 1));
+                    used[a] = true;
+                    gts += (h % 2 ? "|" : "\t") + std::to_string(a);
+                }
+                if (!used[1] || (n_alt == 2 && !used[2])) gts = n_alt == 2 ? "\t1|2\t0|0\t0|1" : "\t1|0\t0|0\t0|1";
+                std::fprintf(f, "chrT\t%zu\t.\t%s\t%s\t.\tPASS\t.\tGT%s\n", pos + 1, refa.c_str(), alt.c_str(), gts.c_str());
+            }
+            std::fclose(f);
+        }
+        const std::string one = "/tmp/pg_test_mt1", four = "/tmp/pg_test_mt4";
+        CHECK(build_index(fa, vcf, one, 31, true, 1) == std::vector<std::string>({"chrT"}));
+        CHECK(build_index(fa, vcf, four, 31, true, 4) == std::vector<std::string>({"chrT"}));
+        CHECK(read_file(one + "_path_segments.fasta") == read_file(four + "_path_segments.fasta"));
+        CHECK(read_file(one + "_chrT_Graph.cereal") == read_file(four + "_chrT_Graph.cereal"));
+        CHECK(read_file(one + "_UniqueKmersMap.cereal") == read_file(four + "_UniqueKmersMap.cereal"));
+        const std::string table = gunzip_text(one + "_chrT_kmers.tsv.gz");
+        CHECK(table == gunzip_text(four + "_chrT_kmers.tsv.gz") && std::count(table.begin(), table.end(), '\n') > 200);
+        const UniqueKmersMap m = load_unique_kmers_map(four + "_UniqueKmersMap.cereal");
+        CHECK(m.unique_kmers.at("chrT").size() + 1 == (size_t)std::count(table.begin(), table.end(), '\n'));
+        // and the table is what the count filling reads back: every row's k-mers are the object's
+        UniqueKmersMap filled = m;
+        ExactKmerCounter reads(one + "_path_segments.fasta", 31);   // (the graph itself as "reads": every unique k-mer is seen once)
+        fill_read_kmercounts("chrT", &filled, reads, four + "_chrT_kmers.tsv.gz", 1);
+        size_t ones = 0, kmers = 0;
+        for (const auto& u : filled.unique_kmers.at("chrT")) for (size_t i = 0; i < u->size(); ++i) { kmers += 1; ones += u->get_readcount_of(i) == 1; }
+        CHECK(kmers > 1000 && ones == kmers);
+    });
     run("build_graphs: records closer than k - 1 merge into one bubble; what the reference refuses is refused", [] {
         // a 400-base reference without repeats of length >= 5 would be ideal; a fixed pseudo-random one serves
         std::string ref;
@@ -1543,6 +1591,11 @@ int main(int argc, char** argv) {
         if (!f) return 2;
         for (const std::string& l : genotype_index_fixture()) std::fprintf(f, "%s\n", l.c_str());
         std::fclose(f);
+        return 0;
+    }
+    else if (mode == "index" && argc >= 5) {   // PanGenie-index on any input (scale checks)
+        const std::vector<std::string> chromosomes = build_index(argv[2], argv[3], argv[4], argc > 5 ? (size_t)std::atoi(argv[5]) : 31u, true, argc > 6 ? (unsigned)std::atoi(argv[6]) : 1u);
+        std::printf("%zu chromosomes\n", chromosomes.size());
         return 0;
     }
     else if (mode == "demo-counts" && argc >= 4) {   // CPU: index + counted archive of the demo, peak on stdout (tests/test_demo.py)
