@@ -204,7 +204,13 @@ BuiltGraphs build_graphs(const std::string& vcf, const ReferenceSequences& refer
         if (col.size() < 10) throw std::runtime_error("build_graphs: malformed VCF-file, or no haplotype paths given in VCF.");
         const std::string name(col[0]);
         Record rec;
-        rec.start = (size_t)std::strtoull(std::string(col[1]).c_str(), nullptr, 10) - 1;   // VCF positions are 1-based
+        {   // VCF positions are 1-based decimal numbers
+            unsigned long long pos = 0;
+            bool digits = !col[1].empty() && col[1].size() <= 18;
+            for (const char c : col[1]) { digits = digits && c >= '0' && c <= '9'; pos = pos * 10 + (unsigned long long)(c - '0'); }
+            if (!digits || pos == 0) throw std::runtime_error("build_graphs: malformed VCF-file: position '" + std::string(col[1]) + "'");
+            rec.start = (size_t)pos - 1;
+        }
         if (name == chrom && rec.start < previous_end)
             throw std::runtime_error("build_graphs: variant at " + name + ":" + std::to_string(rec.start) + " overlaps previous one. VCF does not represent a pangenome graph.");
         const std::string& ref_bases = reference.of(name);

@@ -459,6 +459,36 @@ static void index_builder_cpu_tests() {
         for (const auto& u : filled.unique_kmers.at("chrT")) for (size_t i = 0; i < u->size(); ++i) { kmers += 1; ones += u->get_readcount_of(i) == 1; }
         CHECK(kmers > 1000 && ones == kmers);
     });
+    run("build_graphs on damaged VCFs: a graph or a runtime_error, nothing else", [] {
+        const std::string dir = g_golden_dir + "/graphbuilder/";
+        const ReferenceSequences reference(dir + "small1.fa");
+        const std::vector<unsigned char> raw = read_file(dir + "small1.vcf");
+        const std::string tmp = "/tmp/pg_test_damaged.vcf";
+        uint64_t x = 0x9E3779B97F4A7C15ull;
+        auto rnd = [&]() { x ^= x << 13; x ^= x >> 7; x ^= x << 17; return x; };
+        size_t built = 0, refused = 0, other = 0;
+        for (int round = 0; round < 400; ++round) {
+            std::string text(raw.begin(), raw.end());
+            const int edits = 1 + (int)(rnd() % 3);
+            for (int e = 0; e < edits; ++e) {
+                const size_t at = rnd() % text.size();
+                switch (rnd() % 5) {
+                    case 0: text.erase(at, 1 + rnd() % 12); break;                        // a hole
+                    case 1: text[at] = "\t\n|/.,0123ACGTN;:"[rnd() % 18]; break;          // a wrong character
+                    case 2: text.insert(at, 1, "\t\n|/.,9"[rnd() % 8]); break;            // an extra one
+                    case 3: text.resize(at); break;                                       // cut short
+                    default: text.insert(at, text.substr(at, std::min<size_t>(40, text.size() - at))); break;   // a repeat
+                }
+                if (text.empty()) text = "#";
+            }
+            { std::FILE* f = std::fopen(tmp.c_str(), "w"); std::fwrite(text.data(), 1, text.size(), f); std::fclose(f); }
+            try { const BuiltGraphs b = build_graphs(tmp, reference, 10, round % 2 == 0); (void)path_segments_fasta(b, reference); built += 1; }
+            catch (const std::runtime_error&) { refused += 1; }
+            catch (const std::exception& e) { other += 1; if (other < 4) std::printf("  round %d: %s\n", round, e.what()); }
+            catch (...) { other += 1; }
+        }
+        CHECK(other == 0 && built > 0 && refused > 0);
+    });
     run("build_graphs: records closer than k - 1 merge into one bubble; what the reference refuses is refused", [] {
         // a 400-base reference without repeats of length >= 5 would be ideal; a fixed pseudo-random one serves
         std::string ref;
