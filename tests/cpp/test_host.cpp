@@ -9,6 +9,7 @@
 // (tests/HMMTest.cpp, EmissionProbabilityComputerTest.cpp, TransitionProbabilityComputerTest.cpp,
 // UniqueKmersTest.cpp, GenotypingResultTest.cpp, CopyNumberTest.cpp, ColumnIndexerTest.cpp,
 // KmerPathTest.cpp); tolerance 1e-7 absolute as in reference tests/utils.cpp:9-11.
+#include <chrono>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -1553,13 +1554,17 @@ struct DemoSample {
 
 // PanGenie-index, then steps 1-3 of run_genotype_command (src/commands.cpp:812-876): counts of the graph's k-mers in the reads,
 // the abundance peak, counts and local coverage into the index
+static DemoSample sample_prepare(const std::string& prefix, const std::string& readfile, unsigned threads);
 static DemoSample demo_prepare(const std::string& demo_dir, const std::string& prefix, unsigned threads) {
     build_index(demo_dir + "/test-reference.fa", demo_dir + "/test-variants.vcf", prefix, 31, true);
+    return sample_prepare(prefix, demo_dir + "/test-reads.fa", threads);
+}
+static DemoSample sample_prepare(const std::string& prefix, const std::string& readfile, unsigned threads) {
     DemoSample d;
     d.counted = load_unique_kmers_map(prefix + "_UniqueKmersMap.cereal");
     TargetedKmerCounter reads(d.counted.kmersize);
     reads.add_targets_from_sequences(prefix + "_path_segments.fasta");
-    reads.count(demo_dir + "/test-reads.fa", threads);
+    reads.count(readfile, threads);
     d.peak = demo_abundance_peak(reads.abundance_histogram(10000));
     for (auto& kv : d.counted.unique_kmers) {
         d.chromosomes.push_back(kv.first);
@@ -1585,8 +1590,12 @@ static void demo_write_vcf(const std::string& prefix, const std::map<std::string
 // :906-915), likelihoods unnormalised out of the HMM, normalised afterwards (:160, :981-987)
 // With `phasing_out` also the phasing job of a `-p` run (:961-966: the Viterbi path over min(paths, 30) paths — PathSampler's
 // single subset of ALL paths is all of them, whatever its random numbers) and its VCF.
+static void sample_genotype_on_device(DemoSample& d, const std::string& prefix, const std::string& out, const std::string& phasing_out);
 static void demo_genotype_on_device(const std::string& demo_dir, const std::string& prefix, const std::string& out, const std::string& phasing_out) {
     DemoSample d = demo_prepare(demo_dir, prefix, 2);
+    sample_genotype_on_device(d, prefix, out, phasing_out);
+}
+static void sample_genotype_on_device(DemoSample& d, const std::string& prefix, const std::string& out, const std::string& phasing_out) {
     ProbabilityTable probs(d.peak / 4, d.peak * 4, 2 * d.peak, 0.01L);
     std::map<std::string, std::vector<GenotypingResult>> results, phasings;
     for (const std::string& c : d.chromosomes) {
@@ -1639,6 +1648,22 @@ int main(int argc, char** argv) {
         std::vector<std::string> chromosomes;
         for (const auto& kv : r.result) chromosomes.push_back(kv.first);
         demo_write_vcf(argv[2], r.result, chromosomes, argv[4], "sample", argc > 5 && std::string(argv[5]) == "phasing");
+        return 0;
+    }
+    else if (mode == "counts" && argc >= 4) {   // CPU: the counted archive of any index + reads, peak on stdout
+        DemoSample d = sample_prepare(argv[2], argv[3], argc > 4 ? (unsigned)std::atoi(argv[4]) : 8u);
+        save_unique_kmers_map(d.counted, std::string(argv[2]) + "_counted_UniqueKmersMap.cereal");
+        std::printf("peak=%zu\n", d.peak);
+        return 0;
+    }
+    else if (mode == "genotype" && argc >= 5) {   // GPU: PanGenie -f <prefix> -i <reads> on any index (tools/pipeline_check.sh); stage times on stderr
+        auto t0 = std::chrono::steady_clock::now();
+        auto lap = [&](const char* what) { const auto t = std::chrono::steady_clock::now(); std::fprintf(stderr, "genotype: %-36s %8.3f s\n", what, std::chrono::duration<double>(t - t0).count()); t0 = t; };
+        DemoSample d = sample_prepare(argv[2], argv[3], argc > 5 ? (unsigned)std::atoi(argv[5]) : 8u);
+        std::fprintf(stderr, "genotype: k-mer abundance peak %zu\n", d.peak);
+        lap("reads counted, counts into the index");
+        sample_genotype_on_device(d, argv[2], argv[4], "");
+        lap("HMM on the device, VCF written");
         return 0;
     }
     else if (mode == "demo" && argc >= 5) {   // GPU: the demo end to end
