@@ -281,7 +281,7 @@ size_t TargetedKmerCounter::add_targets_from_table(const std::string& kmers_tsv_
 size_t TargetedKmerCounter::add_targets_from_sequences(const std::string& fasta) {
     if (frozen_) throw std::runtime_error("TargetedKmerCounter: targets must be registered before the reads are counted");
     const uint64_t mask = k_ == 32 ? ~0ull : ((1ull << (2 * k_)) - 1ull);
-    size_t registered = 0;
+    size_t registered = 0, dedup_at = (size_t)64 << 20;
     stream_sequences(fasta, [&](const std::string& seq) {
         uint64_t fwd = 0, rev = 0;
         size_t filled = 0;
@@ -292,9 +292,10 @@ size_t TargetedKmerCounter::add_targets_from_sequences(const std::string& fasta)
             rev = (rev >> 2) | ((uint64_t)(3 - b) << (2 * (k_ - 1)));
             if (++filled >= k_) { pending_.push_back(fwd < rev ? fwd : rev); registered += 1; }
         }
-        if (pending_.size() > (64u << 20)) {   // (long graphs: drop repeats now and then)
+        if (pending_.size() > dedup_at) {   // (long graphs: drop repeats now and then — each time at twice what was left)
             std::sort(pending_.begin(), pending_.end());
             pending_.erase(std::unique(pending_.begin(), pending_.end()), pending_.end());
+            dedup_at = std::max<size_t>(dedup_at, 2 * pending_.size());
         }
     });
     return registered;
@@ -303,43 +304,92 @@ size_t TargetedKmerCounter::add_targets_from_sequences(const std::string& fasta)
 std::vector<size_t> TargetedKmerCounter::abundance_histogram(size_t max_count) {
     freeze();
     std::vector<size_t> seen(max_count + 1, 0);
-    for (size_t at = 0; at < keys_.size(); ++at)
-        if (keys_[at] != kEmpty && counts_[at] > 0 && counts_[at] <= max_count) seen[(size_t)counts_[at]] += 1;
+    for (const Slot& slot : slots_)
+        if (slot.key != kEmpty && slot.count > 0 && slot.count <= max_count) seen[(size_t)slot.count] += 1;
     return seen;
 }
 
-void TargetedKmerCounter::freeze() {
+void TargetedKmerCounter::freeze(unsigned threads) {
     if (frozen_) return;
-    std::sort(pending_.begin(), pending_.end());
-    pending_.erase(std::unique(pending_.begin(), pending_.end()), pending_.end());
-    n_targets_ = pending_.size();
+    // the table has room for every registered code (repeats included: the distinct ones are not known yet) at <= 50 % load;
+    // the codes go in with compare-and-swap on the key — insert-only linear probing needs nothing more —, a batch of
+    // prefetched slots at a time, from `threads` workers
     size_t cap = 16;
-    while (cap < 2 * n_targets_ + 1) cap <<= 1;
-    keys_.assign(cap, kEmpty);
-    counts_.assign(cap, 0);
-    for (const uint64_t code : pending_) {
-        size_t at = (size_t)mix64(code) & (cap - 1);
-        while (keys_[at] != kEmpty) at = (at + 1) & (cap - 1);
-        keys_[at] = code;
+    while (cap < 2 * pending_.size() + 1) cap <<= 1;
+    slots_.resize(cap);
+    std::atomic<size_t> distinct{0}, next{0}, next_clear{0};
+    auto clear = [&] {
+        constexpr size_t kPiece = 1u << 18;
+        for (size_t from = next_clear.fetch_add(kPiece); from < cap; from = next_clear.fetch_add(kPiece))
+            std::fill(slots_.begin() + (std::ptrdiff_t)from, slots_.begin() + (std::ptrdiff_t)std::min(from + kPiece, cap), Slot{kEmpty, 0});
+    };
+    if (threads <= 1 || cap < (1u << 20)) clear();
+    else {
+        std::vector<std::thread> workers;
+        for (unsigned t = 0; t < threads; ++t) workers.emplace_back(clear);
+        for (std::thread& w : workers) w.join();
     }
+    auto work = [&] {
+        constexpr size_t kChunk = 1u << 16, kBatch = 16;
+        size_t mine = 0;
+        for (size_t from = next.fetch_add(kChunk); from < pending_.size(); from = next.fetch_add(kChunk)) {
+            const size_t to = std::min(from + kChunk, pending_.size());
+            for (size_t b = from; b < to; b += kBatch) {
+                const size_t e = std::min(b + kBatch, to);
+                for (size_t i = b; i < e; ++i) __builtin_prefetch(&slots_[(size_t)mix64(pending_[i]) & (cap - 1)], 1);
+                for (size_t i = b; i < e; ++i) {
+                    const uint64_t code = pending_[i];
+                    size_t at = (size_t)mix64(code) & (cap - 1);
+                    while (true) {
+                        uint64_t seen = __atomic_load_n(&slots_[at].key, __ATOMIC_RELAXED);
+                        if (seen == code) break;
+                        if (seen == kEmpty) {
+                            if (__atomic_compare_exchange_n(&slots_[at].key, &seen, code, false, __ATOMIC_RELAXED, __ATOMIC_RELAXED)) { mine += 1; break; }
+                            if (seen == code) break;   // (another worker put the same code here first)
+                        }
+                        at = (at + 1) & (cap - 1);
+                    }
+                }
+            }
+        }
+        distinct += mine;
+    };
+    if (threads <= 1 || pending_.size() < (1u << 18)) work();
+    else {
+        std::vector<std::thread> workers;
+        for (unsigned t = 0; t < threads; ++t) workers.emplace_back(work);
+        for (std::thread& w : workers) w.join();
+    }
+    n_targets_ = distinct;
     std::vector<uint64_t>().swap(pending_);
     frozen_ = true;
 }
 
 size_t TargetedKmerCounter::find(uint64_t code) const {
-    const size_t cap = keys_.size();
+    const size_t cap = slots_.size();
     size_t at = (size_t)mix64(code) & (cap - 1);
     while (true) {
-        const uint64_t key = keys_[at];
+        const uint64_t key = slots_[at].key;
         if (key == code) return at;
         if (key == kEmpty) return (size_t)-1;
         at = (at + 1) & (cap - 1);
     }
 }
 
-void TargetedKmerCounter::count_sequence(const char* s, size_t n, uint64_t* counts, uint64_t& windows) const {
-    // (a prefetch ring — slot prefetched when the code is formed, probed twelve windows later — measured no better)
+void TargetedKmerCounter::count_sequence(const char* s, size_t n, uint64_t& windows) {
+    // Key and count of a k-mer share a 16-byte slot (one cache line per hit), and the windows are looked up a batch behind:
+    // the slot of each is touched when its code is formed, so the misses of a batch overlap.
     const uint64_t mask = k_ == 32 ? ~0ull : ((1ull << (2 * k_)) - 1ull);
+    constexpr size_t kBatch = 16;
+    uint64_t batch[kBatch];
+    size_t waiting = 0;
+    const size_t cap_mask = slots_.size() - 1;
+    auto settle = [&](size_t upto) {
+        for (size_t i = 0; i < upto; ++i) {
+            const size_t at = find(batch[i]);
+            if (at != (size_t)-1) __atomic_fetch_add(&slots_[at].count, 1ull, __ATOMIC_RELAXED);   // (workers share the table)
+        }
+    };
     uint64_t fwd = 0, rev = 0;
     size_t filled = 0;
     for (size_t i = 0; i < n; ++i) {
@@ -349,18 +399,23 @@ void TargetedKmerCounter::count_sequence(const char* s, size_t n, uint64_t* coun
         rev = (rev >> 2) | ((uint64_t)(3 - b) << (2 * (k_ - 1)));
         if (++filled >= k_) {
             windows += 1;
-            const size_t at = find(fwd < rev ? fwd : rev);
-            if (at != (size_t)-1) __atomic_fetch_add(&counts[at], 1ull, __ATOMIC_RELAXED);   // (workers share the table)
+            const uint64_t code = fwd < rev ? fwd : rev;
+            __builtin_prefetch(&slots_[(size_t)mix64(code) & cap_mask]);
+            batch[waiting++] = code;
+            if (waiting == kBatch) { settle(kBatch); waiting = 0; }
         }
     }
+    settle(waiting);
 }
 
 void TargetedKmerCounter::count(const std::string& readfile, unsigned threads) {
-    freeze();
     if (threads == 0) threads = 1;
+    freeze(threads);
     // one reader (decompression and record parsing), `threads` workers on batches of sequences; hits are relaxed atomic
     // increments on the shared table
-    struct Batch { std::vector<std::string> seqs; size_t bytes = 0; };
+    // (a batch is the sequences of a few MB of reads back to back, a newline after each: the rolling window starts over at
+    // every letter outside ACGT, so the newline is all the separation the counting needs)
+    struct Batch { std::string text; };
     std::mutex mu;
     std::condition_variable cv_work, cv_room;
     std::deque<Batch> queue;
@@ -379,7 +434,7 @@ void TargetedKmerCounter::count(const std::string& readfile, unsigned threads) {
             }
             cv_room.notify_one();
             uint64_t windows = 0;
-            for (const std::string& s : b.seqs) count_sequence(s.data(), s.size(), counts_.data(), windows);
+            count_sequence(b.text.data(), b.text.size(), windows);
             std::lock_guard<std::mutex> lk(mu);
             windows_total += windows;
         }
@@ -388,19 +443,21 @@ void TargetedKmerCounter::count(const std::string& readfile, unsigned threads) {
     for (unsigned t = 0; t < threads; ++t) pool.emplace_back(worker);
     try {
         Batch cur;
+        cur.text.reserve((4u << 20) + (1u << 16));
         auto flush = [&]() {
-            if (cur.seqs.empty()) return;
+            if (cur.text.empty()) return;
             std::unique_lock<std::mutex> lk(mu);
             cv_room.wait(lk, [&] { return queue.size() < 4u * threads; });
             queue.push_back(std::move(cur));
             cur = Batch{};
+            cur.text.reserve((4u << 20) + (1u << 16));
             lk.unlock();
             cv_work.notify_one();
         };
         stream_sequences(readfile, [&](const std::string& seq) {
-            cur.bytes += seq.size();
-            cur.seqs.push_back(seq);
-            if (cur.bytes >= (4u << 20)) flush();
+            cur.text.append(seq);
+            cur.text.push_back('\n');
+            if (cur.text.size() >= (4u << 20)) flush();
         });
         flush();
     } catch (...) {
@@ -426,7 +483,7 @@ size_t TargetedKmerCounter::getKmerAbundance(std::string kmer) {
         if (lenient_) return 0;
         throw std::runtime_error("TargetedKmerCounter::getKmerAbundance: " + kmer + " was not registered before the reads were counted");
     }
-    return (size_t)counts_[at];
+    return (size_t)slots_[at].count;
 }
 
 // ------------------------------------------------------------------ the k-mer table (behaviour: src/kmerparser.cpp)

@@ -16,6 +16,7 @@
 #pragma once
 
 #include <cstdint>
+#include <memory>
 #include <string>
 #include <string_view>
 #include <vector>
@@ -84,14 +85,22 @@ public:
 
 private:
     bool encode_canonical(const char* s, uint64_t& code) const;
-    void freeze();
+    void freeze(unsigned threads = 1);
     size_t find(uint64_t code) const;   // slot, or npos
-    void count_sequence(const char* s, size_t n, uint64_t* counts, uint64_t& windows) const;
+    void count_sequence(const char* s, size_t n, uint64_t& windows);
     static constexpr uint64_t kEmpty = ~0ull;   // (never a canonical code: the reverse complement of all-T is all-A = 0)
     size_t k_;
     std::vector<uint64_t> pending_;     // codes registered before the table is built
-    std::vector<uint64_t> keys_;        // open addressing, power-of-two size, linear probing
-    std::vector<uint64_t> counts_;
+    struct Slot { uint64_t key, count; };
+    // (resize() of this vector leaves new slots untouched — freeze() fills them from its workers, so that the pages of a
+    // table of gigabytes are first touched in parallel)
+    template <class T> struct RawAllocator : std::allocator<T> {
+        template <class U> struct rebind { using other = RawAllocator<U>; };
+        template <class U, class... A> void construct(U* p, A&&... a) {
+            if constexpr (sizeof...(A) == 0) ::new ((void*)p) U; else ::new ((void*)p) U(std::forward<A>(a)...);
+        }
+    };
+    std::vector<Slot, RawAllocator<Slot>> slots_;   // open addressing, power-of-two size, linear probing
     size_t n_targets_ = 0;
     uint64_t windows_ = 0;
     bool frozen_ = false;

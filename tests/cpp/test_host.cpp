@@ -602,6 +602,42 @@ static void kmer_count_cpu_tests() {
         CHECK(strict.getKmerAbundance("TTTACAGCAT") == 1);   // (the reverse complement of the first one)
         CHECK_THROWS(strict.getKmerAbundance("GCTGTAAAAA"));
     });
+    run("TargetedKmerCounter with a large target set: table built and filled by worker threads = the exact counts", [] {
+        // 400 k windows of a pseudo-random sequence registered (more than the 2^18 at which the table is built in parallel),
+        // reads = 6000 pieces of it, either strand, a few wrong letters and an N now and then
+        std::string graph;
+        uint64_t x = 0xD1B54A32D192ED03ull;
+        auto rnd = [&]() { x ^= x << 13; x ^= x >> 7; x ^= x << 17; return x; };
+        for (int i = 0; i < 400030; ++i) graph += "ACGT"[rnd() & 3];
+        const std::string fa = "/tmp/pg_test_big_graph.fa", reads = "/tmp/pg_test_big_reads.fa";
+        { std::FILE* f = std::fopen(fa.c_str(), "w"); std::fprintf(f, ">g\n%s\n", graph.c_str()); std::fclose(f); }
+        {
+            std::FILE* f = std::fopen(reads.c_str(), "w");
+            for (int r = 0; r < 6000; ++r) {
+                std::string piece = graph.substr(rnd() % (graph.size() - 200), 100 + rnd() % 100);
+                if (r % 2) { std::reverse(piece.begin(), piece.end()); for (char& c : piece) c = c == 'A' ? 'T' : c == 'C' ? 'G' : c == 'G' ? 'C' : 'A'; }
+                if (r % 7 == 0) piece[rnd() % piece.size()] = "ACGT"[rnd() & 3];
+                if (r % 31 == 0) piece[rnd() % piece.size()] = 'N';
+                std::fprintf(f, ">r%d\n%s\n", r, piece.c_str());
+            }
+            std::fclose(f);
+        }
+        ExactKmerCounter exact(reads, 31);
+        TargetedKmerCounter one(31), four(31);
+        CHECK(one.add_targets_from_sequences(fa) == 400000 && four.add_targets_from_sequences(fa) == 400000);
+        one.count(reads, 1);
+        four.count(reads, 4);
+        CHECK(one.targets() == four.targets() && one.targets() > 399000 && one.kmers_seen() == four.kmers_seen());
+        size_t differ = 0, seen = 0;
+        for (size_t i = 0; i + 31 <= graph.size(); i += 3) {
+            const std::string kmer = graph.substr(i, 31);
+            const size_t want = exact.getKmerAbundance(kmer);
+            differ += one.getKmerAbundance(kmer) != want || four.getKmerAbundance(kmer) != want;
+            seen += want > 0;
+        }
+        CHECK(differ == 0 && seen > 50000);
+        CHECK(one.abundance_histogram(100) == four.abundance_histogram(100));
+    });
     run("ExactKmerCounter: canonical counts, FASTA and FASTQ, letters outside ACGT", [] {
         const std::string fa = "/tmp/pg_test_reads.fa", fq = "/tmp/pg_test_reads.fq";
         { FILE* f = std::fopen(fa.c_str(), "w"); std::fputs(">r1\nACGTAC\nGT\n>r2\nACGNACGTA\n", f); std::fclose(f); }
