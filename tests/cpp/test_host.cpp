@@ -1637,6 +1637,10 @@ static void sample_genotype_on_device(DemoSample& d, const std::string& prefix, 
     for (const std::string& c : d.chromosomes) {
         std::vector<std::shared_ptr<UniqueKmers>>& uks = d.counted.unique_kmers[c];
         if (uks.empty()) { results[c] = {}; phasings[c] = {}; continue; }
+        // more than 100 paths: 15 haplotypes are sampled first (src/commands.cpp:799-803; the sampler at the end of the
+        // reference's fill_read_kmercounts, :148-151, with the command line's defaults: sampling effective N 0.01, allele
+        // penalty 5) and the panel shrinks to them (+ the reference path)
+        if (uks[0]->get_nr_paths() > 100) HaplotypeSampler(&uks, 15, 1.26, 0.01L, nullptr, d.counted.add_reference, "", c, 5);
         std::vector<unsigned short> all_paths(uks[0]->get_nr_paths());
         for (size_t p = 0; p < all_paths.size(); ++p) all_paths[p] = (unsigned short)p;
         HMM hmm(&uks, &probs, true, false, 1.26, false, 0.00001L, &all_paths, false);

@@ -28,6 +28,12 @@ def main(prefix, reads, out):
     t = time.time()
     for chrom, objects in counted.unique_kmers.items():
         batch = flatten(objects)
+        if batch.n_paths > 100:   # the reference's default: 15 sampled haplotypes (+ the reference path) — oracle sampler
+            import numpy as np
+            sampled, _ = orc.sampler_run(batch, 15, 1.26, np.longdouble("0.01"), 5)
+            if counted.add_reference:
+                sampled = np.vstack([sampled, np.zeros((1, batch.n_variants), np.uint32)])
+            batch = batch.update_paths(sampled)
         ref = orc.genotype_contig(batch, orc.OracleTable(peak // 4, peak * 4, 2 * peak, 0.01), orc.make_params(1.26, False, 1e-5))
         results = results_from_flat(batch, ref.lik, ref.kept, ref.allele_present, ref.n_kmers, ref.coverage)
         for g in results:
