@@ -1,0 +1,51 @@
+"""The pieces either side of the device path strung together on a small synthetic pangenome (tools/simulate_pangenome.py:
+SNPs, deletions, multi-allelic insertions; the sample is a mosaic of panel haplotypes, 25x reads with wrong letters):
+index builder -> graph-only k-mer counts -> abundance peak -> counts into the index -> [haplotype sampling when the panel has
+more than 100 paths] -> HMM -> VCF.  On the CPU the HMM (and the sampler) are the oracle's and the genotypes are scored
+against the truth; on the GPU the device's VCF must be the oracle twin's, text for text (GT, GQ, four-digit GL, KC of every
+record).  The full-size runs of the same scripts are in profiles/r03_pipeline_check*.txt."""
+import subprocess
+import sys
+from pathlib import Path
+
+import pytest
+
+ROOT = Path(__file__).resolve().parent.parent
+sys.path.insert(0, str(ROOT / "tools"))
+
+import pipeline_cpu_check   # noqa: E402
+import simulate_pangenome   # noqa: E402
+from pangenie_amd.build import build_host, HOST_TEST   # noqa: E402
+
+
+def prepared(tmp_path, samples, seed):
+    build_host()
+    p = str(tmp_path / "sim")
+    simulate_pangenome.panel(300000, 600, samples, seed, p)
+    simulate_pangenome.sample(p, 25, seed + 1)
+    subprocess.run([str(HOST_TEST), "index", p + ".fa", p + ".vcf", p + "_idx", "31", "2"], check=True, capture_output=True, timeout=300)
+    return p
+
+
+def without_date(path):
+    return [l for l in Path(path).read_text().splitlines() if not l.startswith("##fileDate")]
+
+
+@pytest.mark.parametrize("samples", [8, 54])
+def test_pipeline_with_the_oracle_scores_against_the_truth(tmp_path, samples):
+    p = prepared(tmp_path, samples, 100 + samples)
+    peak = pipeline_cpu_check.main(p + "_idx", p + "_reads.fa", p + "_cpu.vcf")
+    assert 12 <= peak <= 26   # 25x reads of 150 bases, k = 31: about 20 windows over an error-free k-mer
+    r = simulate_pangenome.score(p + "_truth.tsv", p + "_cpu.vcf")
+    assert r["records"] == r["truth"] > 550 and r["untyped"] <= 2
+    assert r["concordance"] >= 0.99 and r["nonref_concordance"] >= 0.99
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("samples", [8, 54])
+def test_pipeline_on_the_device_writes_the_oracle_twins_vcf(tmp_path, samples):
+    p = prepared(tmp_path, samples, 100 + samples)
+    pipeline_cpu_check.main(p + "_idx", p + "_reads.fa", p + "_cpu.vcf")
+    r = subprocess.run([str(HOST_TEST), "genotype", p + "_idx", p + "_reads.fa", p + "_gpu.vcf", "4"], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert without_date(p + "_gpu.vcf") == without_date(p + "_cpu.vcf")

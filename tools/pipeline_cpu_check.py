@@ -23,6 +23,7 @@ def main(prefix, reads, out):
     r = subprocess.run([str(HOST_TEST), "counts", prefix, reads, "8"], capture_output=True, text=True, check=True)
     peak = int(r.stdout.strip().split("=")[1])
     print(f"peak {peak}; counts {time.time() - t:.1f} s")
+    return_peak = peak
     counted = cereal_io.load(prefix + "_counted_UniqueKmersMap.cereal")
     res = cereal_io.Results()
     t = time.time()
@@ -44,6 +45,7 @@ def main(prefix, reads, out):
     archive = out + ".results.cereal"
     Path(archive).write_bytes(cereal_io.dumps_results(res))
     subprocess.run([str(HOST_TEST), "vcf", prefix, archive, out], check=True)
+    return return_peak
 
 
 if __name__ == "__main__":

@@ -133,8 +133,8 @@ def score(truth_tsv, vcf):
         if want != (0, 0):
             nonref += 1
             nonref_same += got == want
-    print(f"records {total} of {len(truth)} in the truth; genotype concordance {same / max(total, 1):.4f} "
-          f"(non-reference genotypes {nonref_same / max(nonref, 1):.4f} of {nonref}); untyped {untyped}")
+    return {"records": total, "truth": len(truth), "concordance": same / max(total, 1), "nonref": nonref,
+            "nonref_concordance": nonref_same / max(nonref, 1), "untyped": untyped}
 
 
 if __name__ == "__main__":
@@ -144,6 +144,8 @@ if __name__ == "__main__":
     elif cmd == "sample":
         sample(sys.argv[2], float(sys.argv[3]), int(sys.argv[4]))
     elif cmd == "score":
-        score(sys.argv[2], sys.argv[3])
+        r = score(sys.argv[2], sys.argv[3])
+        print(f"records {r['records']} of {r['truth']} in the truth; genotype concordance {r['concordance']:.4f} "
+              f"(non-reference genotypes {r['nonref_concordance']:.4f} of {r['nonref']}); untyped {r['untyped']}")
     else:
         sys.exit(__doc__)
