@@ -142,7 +142,7 @@ bool Variant::is_undefined_allele(size_t index) const {
     return false;
 }
 
-std::vector<VcfSite> Variant::records(const GenotypingResult* result) const {
+std::vector<VcfSite> Variant::records(const GenotypingResult* result, const SampledPanel* sampled) const {
     const size_t n_records = allele_sequences_.size();
     std::vector<VcfSite> out(n_records);
     size_t position = start_position_;
@@ -162,6 +162,8 @@ std::vector<VcfSite> Variant::records(const GenotypingResult* result) const {
         }
         site.paths.reserve(paths_.size());
         for (unsigned short bubble_allele : paths_) site.paths.push_back(own.at(bubble_allele));
+        if (sampled)
+            for (unsigned short bubble_allele : sampled->path_to_allele) site.sampled.push_back(own.at(bubble_allele));
         if (result) {
             for (const auto& entry : result->get_stored_likelihoods())
                 site.likelihoods.add_to_likelihood(own.at(entry.first.first), own.at(entry.first.second), entry.second);
@@ -419,14 +421,16 @@ static std::string phased_field(const VcfSite& site, const std::vector<unsigned 
     return out.str();
 }
 
-std::vector<std::string> Graph::sample_records(const std::vector<GenotypingResult>& genotyping_result, bool ignore_imputed, bool phasing) const {
-    const char* who = phasing ? "Graph::write_phasing_of" : "Graph::write_genotypes_of";
+std::vector<std::string> Graph::sample_records(const std::vector<GenotypingResult>& genotyping_result, bool ignore_imputed, bool phasing,
+                                               const std::vector<SampledPanel>* sampled_paths) const {
+    const char* who = sampled_paths ? "Graph::write_sampled_panel" : phasing ? "Graph::write_phasing_of" : "Graph::write_genotypes_of";
     if (variants_deleted_) throw std::runtime_error(std::string(who) + ": variants have been deleted by delete_variant funtion. Re-build object.");
-    if (genotyping_result.size() != size()) throw std::runtime_error(std::string(who) + ": number of variants and number of computed " + (phasing ? "phasings" : "genotypes") + " differ.");
+    if ((sampled_paths ? sampled_paths->size() : genotyping_result.size()) != size())
+        throw std::runtime_error(std::string(who) + ": number of variants and number of computed " + (phasing || sampled_paths ? "phasings" : "genotypes") + " differ.");
     std::vector<std::string> lines;
     size_t record_index = 0;   // over single records: the row of variant_ids
     for (size_t i = 0; i < size(); ++i) {
-        for (const VcfSite& site : get_variant(i).records(&genotyping_result[i])) {
+        for (const VcfSite& site : sampled_paths ? get_variant(i).records(nullptr, &(*sampled_paths)[i]) : get_variant(i).records(&genotyping_result[i])) {
             const size_t n_all = site.alleles.size();
             if (n_all < 2) throw std::runtime_error(std::string(who) + ": less than 2 alleles given for variant at position " + std::to_string(site.start));
             // ALT = the defined alternative alleles; genotypes over undefined alleles are dropped below
@@ -444,7 +448,7 @@ std::vector<std::string> Graph::sample_records(const std::vector<GenotypingResul
             for (size_t k = 0; k < alts.size(); ++k) line << (k ? "," : "") << alts[k];
             line << "\t.\tPASS\tAF=";
             for (size_t k = 1; k < defined.size(); ++k) line << (k > 1 ? "," : "") << std::setprecision(6) << freq[defined[k]] / n_paths;
-            line << ";UK=" << site.likelihoods.nr_unique_kmers() << ";MA=" << (n_all - defined.size());
+            line << ";UK=" << (sampled_paths ? (*sampled_paths)[i].unique_kmers : (size_t)site.likelihoods.nr_unique_kmers()) << ";MA=" << (n_all - defined.size());
             const std::vector<std::string>& ids = variant_ids_.at(record_index);
             if (!ids.empty()) {
                 // the ids are kept in the lexicographic order of their ALT alleles: back into ALT order
@@ -457,7 +461,16 @@ std::vector<std::string> Graph::sample_records(const std::vector<GenotypingResul
                 line << ";ID=";
                 for (size_t k = 0; k < in_alt_order.size(); ++k) line << (k ? "," : "") << *in_alt_order[k];
             }
-            if (phasing) line << "\tGT:KC\t" << phased_field(site, defined, ignore_imputed);
+            if (sampled_paths) {
+                // every sampled haplotype's allele as its index among the defined ones
+                std::vector<int> among_defined(n_all, -1);
+                for (size_t k = 0; k < defined.size(); ++k) among_defined[defined[k]] = (int)k;
+                line << "\tGT";
+                for (const unsigned short a : site.sampled) {
+                    if (among_defined.at(a) < 0) line << "\t."; else line << '\t' << among_defined[a];
+                }
+            }
+            else if (phasing) line << "\tGT:KC\t" << phased_field(site, defined, ignore_imputed);
             else line << "\tGT:GQ:GL:KC\t" << genotype_field(site.likelihoods, defined, n_all, ignore_imputed);
             lines.push_back(line.str());
             record_index += 1;
@@ -473,6 +486,32 @@ void Graph::write_genotypes(const std::string& filename, const std::vector<Genot
     if (!out.is_open()) throw std::runtime_error("Graph::write_genotypes_of: genotyping output file cannot be opened. Note that the filename must not contain non-existing directories.");
     if (write_header)
         for (const std::string& h : genotypes_header(sample)) out << h << '\n';
+    for (const std::string& l : records) out << l << '\n';
+}
+
+std::vector<std::string> Graph::sampled_panel_header(size_t nr_paths, const std::string& date) {
+    // the genotyping header without AK and the per-sample FORMAT lines other than GT; one column per sampled haplotype
+    std::string columns;
+    for (size_t i = 0; i < nr_paths; ++i) columns += (i ? "\tsampledHT" : "sampledHT") + std::to_string(i);
+    std::vector<std::string> lines;
+    for (const std::string& l : genotypes_header(columns, date)) {
+        if (l.rfind("##INFO=<ID=AK", 0) == 0) continue;
+        if (l.rfind("##FORMAT=", 0) == 0 && l.rfind("##FORMAT=<ID=GT,", 0) != 0) continue;
+        lines.push_back(l);
+    }
+    return lines;
+}
+
+std::vector<std::string> Graph::sampled_panel_records(const std::vector<SampledPanel>& sampled_paths) const {
+    return sample_records({}, false, false, &sampled_paths);
+}
+
+void Graph::write_sampled_panel(const std::string& filename, const std::vector<SampledPanel>& sampled_paths, bool write_header) const {
+    const std::vector<std::string> records = sampled_panel_records(sampled_paths);
+    std::ofstream out(filename, write_header ? std::ios::out : std::ios::app);
+    if (!out.is_open()) throw std::runtime_error("Graph::write_sampled_panel: panel output file cannot be opened. Note that the filename must not contain non-existing directories.");
+    if (write_header)
+        for (const std::string& h : sampled_panel_header(sampled_paths.empty() ? 0 : sampled_paths[0].path_to_allele.size())) out << h << '\n';
     for (const std::string& l : records) out << l << '\n';
 }
 

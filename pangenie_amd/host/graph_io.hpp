@@ -61,6 +61,14 @@ struct VcfSite {
     std::vector<bool> undefined;              // allele contains a base outside ACGT
     std::vector<unsigned short> paths;        // allele of every panel path
     GenotypingResult likelihoods;             // over this record's alleles
+    std::vector<unsigned short> sampled;      // allele of every sampled haplotype (records() with a sampled panel)
+};
+
+/** what the HaplotypeSampler left of a bubble: the bubble allele of every sampled haplotype and the number of unique k-mers
+ *  still counted (reference src/sampledpanel.hpp; filled from UniqueKmers::get_path_ids + size(), src/commands.cpp:994-1005) */
+struct SampledPanel {
+    std::vector<unsigned short> path_to_allele;
+    size_t unique_kmers = 0;
 };
 
 /** A variant bubble of the graph: one or several VCF records closer than the k-mer size, merged
@@ -90,7 +98,7 @@ public:
     /** the bubble as its single records (positions, alleles, path alleles), and `result` — likelihoods over bubble
      *  alleles — folded onto each record's own alleles (genotypes that agree on a record's alleles add up);
      *  coverage / unique k-mer count are the bubble's.  `result` may be null. */
-    std::vector<VcfSite> records(const GenotypingResult* result) const;
+    std::vector<VcfSite> records(const GenotypingResult* result, const SampledPanel* sampled = nullptr) const;
 
 private:
     friend class Graph;
@@ -146,8 +154,15 @@ public:
     void write_phasing(const std::string& filename, const std::vector<GenotypingResult>& genotyping_result, bool write_header,
                        const std::string& sample, bool ignore_imputed = false) const;
 
+    /** the sampled panel as a VCF (`-d`; reference Graph::write_sampled_panel, src/graph.cpp:414-547): one column per sampled
+     *  haplotype (`sampledHT<i>`), its allele among the record's defined ones, `.` where it carries undefined sequence */
+    static std::vector<std::string> sampled_panel_header(size_t nr_paths, const std::string& date = "");
+    std::vector<std::string> sampled_panel_records(const std::vector<SampledPanel>& sampled_paths) const;
+    void write_sampled_panel(const std::string& filename, const std::vector<SampledPanel>& sampled_paths, bool write_header) const;
+
 private:
-    std::vector<std::string> sample_records(const std::vector<GenotypingResult>& genotyping_result, bool ignore_imputed, bool phasing) const;
+    std::vector<std::string> sample_records(const std::vector<GenotypingResult>& genotyping_result, bool ignore_imputed, bool phasing,
+                                            const std::vector<SampledPanel>* sampled_paths = nullptr) const;
     std::vector<std::pair<std::string, std::shared_ptr<DnaSequence>>> fasta_;   // name -> sequence, archive (= sorted) order
     std::string chromosome_;
     size_t kmer_size_ = 0;

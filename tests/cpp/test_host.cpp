@@ -381,6 +381,22 @@ static void index_builder_cpu_tests() {
             CHECK(lines.size() == 2 && lines[0].find("\tGGGG,A,T\t") != std::string::npos && lines[0].find(";ID=var1:var2,var3,var4\t") != std::string::npos);
             CHECK(lines.size() == 2 && lines[1].find(";ID=var5:var6\t") != std::string::npos);
         }
+        {   // write_sampled_panel (tests/GraphBuilderTest.cpp:453-504): small4.vcf, two records in one bubble, `.` haplotypes
+            const BuiltGraphs four = build_graphs(dir + "small4.vcf", reference, 10, false);
+            CHECK(four.chromosomes == std::vector<std::string>({"chrA"}) && four.graphs.at("chrA").size() == 1);
+            const Variant& bubble = four.graphs.at("chrA").get_variant(0);
+            SampledPanel panel;
+            panel.unique_kmers = 14;
+            for (size_t p = 0; p < bubble.nr_of_paths(); ++p) panel.path_to_allele.push_back(bubble.get_allele_on_path(p));
+            const std::vector<std::string> lines = four.graphs.at("chrA").sampled_panel_records({panel});
+            const std::string want1 = "chrA\t161\t.\tG\tTA,TAAA\t.\tPASS\tAF=0.375,0.416667;UK=14;MA=2\tGT\t0\t1\t1\t1\t2\t1\t2\t2\t2\t1\t1\t0\t2\t2\t.\t.\t1\t2\t2\t1\t2\t2\t1\t0";
+            const std::string want2 = "chrA\t166\t.\tG\tT\t.\tPASS\tAF=0.666667;UK=14;MA=6\tGT\t.\t1\t.\t.\t.\t1\t1\t1\t1\t1\t1\t0\t1\t1\t.\t.\t1\t1\t1\t1\t1\t1\t1\t0";
+            CHECK(lines.size() == 2 && lines[0] == want1 && lines[1] == want2);
+            if (lines.size() == 2 && (lines[0] != want1 || lines[1] != want2)) std::printf("  %s\n  %s\n", lines[0].c_str(), lines[1].c_str());
+            const std::vector<std::string> head = Graph::sampled_panel_header(3, "20240101");
+            CHECK(head.size() == 8 && head.back() == "#CHROM\tPOS\tID\tREF\tALT\tQUAL\tFILTER\tINFO\tFORMAT\tsampledHT0\tsampledHT1\tsampledHT2");
+            CHECK_THROWS(four.graphs.at("chrA").sampled_panel_records({}));
+        }
         {   // close_to_start: a record closer than 2 k to the chromosome start is left out (close.vcf, k = 31)
             const ReferenceSequences close_ref(dir + "close.fa");
             const BuiltGraphs close = build_graphs(dir + "close.vcf", close_ref, 31, true);
