@@ -476,6 +476,33 @@ static void index_builder_cpu_tests() {
         for (const auto& u : filled.unique_kmers.at("chrT")) for (size_t i = 0; i < u->size(); ++i) { kmers += 1; ones += u->get_readcount_of(i) == 1; }
         CHECK(kmers > 1000 && ones == kmers);
     });
+    run("an ALT allele no path carries, inside a merged bubble (tests/VariantTest.cpp:559-627 through VCF and writer)", [] {
+        // chr2 ...ATGA A CTG A CTG...: A>T at 4 (paths 0, 1) and G>C,T at 7 (paths 0, 2: C is on no path), k = 5
+        std::string pad;
+        uint64_t x = 0x853C49E6748FEA9Bull;
+        for (int i = 0; i < 30; ++i) { x ^= x << 13; x ^= x >> 7; x ^= x << 17; pad += "ACGT"[x & 3]; }
+        const std::string fa = "/tmp/pg_test_unc.fa", vcf = "/tmp/pg_test_unc.vcf";
+        { std::FILE* f = std::fopen(fa.c_str(), "w"); std::fprintf(f, ">chr2\n%sATGAACTGACTG%s\n", pad.c_str(), pad.c_str()); std::fclose(f); }
+        { std::FILE* f = std::fopen(vcf.c_str(), "w");
+          std::fprintf(f, "##fileformat=VCFv4.2\n#CHROM\tPOS\tID\tREF\tALT\tQUAL\tFILTER\tINFO\tFORMAT\ts\nchr2\t35\t.\tA\tT\t.\t.\t.\tGT\t0|1\nchr2\t38\t.\tG\tC,T\t.\t.\t.\tGT\t0|2\n");
+          std::fclose(f); }
+        const ReferenceSequences reference(fa);
+        const BuiltGraphs b = build_graphs(vcf, reference, 5, false);
+        const Graph& g = b.graphs.at("chr2");
+        CHECK(g.size() == 1 && g.get_variant(0).is_combined() && g.get_variant(0).nr_of_alleles() == 2 && g.get_variant(0).nr_of_records() == 2);
+        GenotypingResult r;
+        r.add_to_likelihood(0, 0, 0.05L); r.add_to_likelihood(0, 1, 0.05L); r.add_to_likelihood(1, 1, 0.9L);
+        r.add_first_haplotype_allele(0); r.add_second_haplotype_allele(0);
+        r.set_unique_kmers(12);
+        const std::vector<std::string> lines = g.genotypes_records({r});
+        CHECK(lines.size() == 2);
+        // the likelihoods land on the record's own alleles: (0,0) (0,T) (T,T) = bins 0, 3 and 5 of G / C / T
+        CHECK(lines.size() == 2 && lines[0] == "chr2\t35\t.\tA\tT\t.\tPASS\tAF=0.5;UK=12;MA=0\tGT:GQ:GL:KC\t1/1:9:-1.301,-1.301,-0.04576:0");
+        CHECK(lines.size() == 2 && lines[1] == "chr2\t38\t.\tG\tC,T\t.\tPASS\tAF=0,0.5;UK=12;MA=0\tGT:GQ:GL:KC\t2/2:9:-1.301,-inf,-inf,-1.301,-inf,-0.04576:0");
+        if (g_failed) for (const std::string& l : lines) std::printf("  %s\n", l.c_str());
+        const std::vector<std::string> ph = g.phasing_records({r});
+        CHECK(ph.size() == 2 && ph[0].substr(ph[0].rfind('\t') + 1) == "0|0:0" && ph[1].substr(ph[1].rfind('\t') + 1) == "0|0:0");
+    });
     run("build_graphs on damaged VCFs: a graph or a runtime_error, nothing else", [] {
         const std::string dir = g_golden_dir + "/graphbuilder/";
         const ReferenceSequences reference(dir + "small1.fa");
