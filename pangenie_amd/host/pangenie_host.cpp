@@ -544,6 +544,46 @@ HMM::HMM(std::vector<std::shared_ptr<UniqueKmers>>* unique_kmers, ProbabilityTab
         }
     }
 }
+// ------------------------------------------------------------------ results of one chain of a job
+// vector<GenotypingResult> of one chain from its packed posteriors (reference src/hmm.cpp:364-368, 106-109); kept columns
+// and allele presence by the ColumnIndexer rule on the host (src/columnindexer.cpp:24-31).  `coverage` = the chain's own
+// local coverages (a cohort's chains share the index, not these).
+static std::vector<GenotypingResult> results_of_chain(const FlatContig& f, const uint16_t* coverage, const std::vector<uint64_t>& goff,
+                                                      const double* lik, const int32_t* lexp) {
+    const size_t V = f.variant_pos.size(), H = f.paths.size();
+    std::vector<GenotypingResult> out(V);
+    size_t columns = 0;
+    std::vector<uint8_t> kept(V, 0), present(f.allele_id.size(), 0);
+    for (size_t v = 0; v < V; ++v) {
+        const uint32_t a0 = f.allele_off[v], A = f.allele_off[v + 1] - a0;
+        for (size_t p = 0; p < H; ++p) {
+            const uint16_t a = f.path_allele[v * H + p];
+            for (uint32_t q = 0; q < A; ++q)
+                if (f.allele_id[a0 + q] == a) { present[a0 + q] = 1; if (a != 0 && !(f.allele_flags[a0 + q] & 1)) kept[v] = 1; }
+        }
+        columns += kept[v];
+    }
+    for (size_t v = 0; v < V; ++v) {
+        GenotypingResult& g = out[v];
+        if (kept[v]) {
+            const uint32_t a0 = f.allele_off[v], A = f.allele_off[v + 1] - a0;
+            for (uint32_t a = 0; a < A; ++a) {
+                if (!present[a0 + a]) continue;
+                for (uint32_t b = a; b < A; ++b) {
+                    if (!present[a0 + b]) continue;
+                    const uint64_t idx = goff[v] + (uint64_t)a * A - (uint64_t)a * (a - 1) / 2 + (b - a);
+                    g.add_to_likelihood(f.allele_id[a0 + a], f.allele_id[a0 + b], ldexpl((long double)lik[idx], lexp[idx]));
+                }
+            }
+        }
+        if (columns > 0) {  // reference src/hmm.cpp:94,106-109
+            g.set_unique_kmers((unsigned short)(f.kmer_off[v + 1] - f.kmer_off[v]));
+            g.set_coverage(coverage[v]);
+        }
+    }
+    return out;
+}
+
 // ------------------------------------------------------------------ multi-GPU job loop
 std::vector<std::vector<GenotypingResult>> run_contigs_multi_gpu(std::vector<ContigTask>& tasks, ProbabilityTable* probabilities,
                                                                  double recombrate, bool uniform, long double effective_N,
@@ -619,46 +659,85 @@ std::vector<std::vector<GenotypingResult>> run_contigs_multi_gpu(std::vector<Con
     }
     cleanup();
 
-    // rebuild the GenotypingResults (reference src/hmm.cpp:364-368, 106-109); kept columns and allele presence by
-    // the ColumnIndexer rule on the host (src/columnindexer.cpp:24-31)
+    // rebuild the GenotypingResults
     std::vector<std::vector<GenotypingResult>> out(T);
     uint64_t base = 0;
     for (size_t d = 0; d < D; ++d)
         for (size_t t : plan[d]) {
-            const FlatContig& f = flat[t];
-            const size_t V = f.variant_pos.size(), H = f.paths.size();
-            out[t].assign(V, GenotypingResult());
-            size_t columns = 0;
-            std::vector<uint8_t> kept(V, 0), present(f.allele_id.size(), 0);
-            for (size_t v = 0; v < V; ++v) {
-                const uint32_t a0 = f.allele_off[v], A = f.allele_off[v + 1] - a0;
-                for (size_t p = 0; p < H; ++p) {
-                    const uint16_t a = f.path_allele[v * H + p];
-                    for (uint32_t q = 0; q < A; ++q)
-                        if (f.allele_id[a0 + q] == a) { present[a0 + q] = 1; if (a != 0 && !(f.allele_flags[a0 + q] & 1)) kept[v] = 1; }
-                }
-                columns += kept[v];
-            }
-            for (size_t v = 0; v < V; ++v) {
-                GenotypingResult& g = out[t][v];
-                if (kept[v]) {
-                    const uint32_t a0 = f.allele_off[v], A = f.allele_off[v + 1] - a0;
-                    for (uint32_t a = 0; a < A; ++a) {
-                        if (!present[a0 + a]) continue;
-                        for (uint32_t b = a; b < A; ++b) {
-                            if (!present[a0 + b]) continue;
-                            const uint64_t idx = base + goff[t][v] + (uint64_t)a * A - (uint64_t)a * (a - 1) / 2 + (b - a);
-                            g.add_to_likelihood(f.allele_id[a0 + a], f.allele_id[a0 + b], ldexpl((long double)lik[idx], lexp[idx]));
-                        }
-                    }
-                }
-                if (columns > 0) {  // reference src/hmm.cpp:94,106-109
-                    g.set_unique_kmers((unsigned short)(f.kmer_off[v + 1] - f.kmer_off[v]));
-                    g.set_coverage(f.coverage[v]);
-                }
-            }
+            out[t] = results_of_chain(flat[t], flat[t].coverage.data(), goff[t], lik.data() + base, lexp.data() + base);
             base += goff[t].back();
         }
+    return out;
+}
+
+// ------------------------------------------------------------------ cohort job
+SampleCounts SampleCounts::of(const std::map<std::string, std::vector<std::shared_ptr<UniqueKmers>>>& chromosomes) {
+    SampleCounts s;
+    for (const auto& kv : chromosomes) {
+        std::vector<uint16_t>& counts = s.kmer_count[kv.first];
+        std::vector<uint16_t>& cov = s.coverage[kv.first];
+        for (const std::shared_ptr<UniqueKmers>& u : kv.second) {
+            for (size_t i = 0; i < u->size(); ++i) counts.push_back(u->get_readcount_of(i));
+            cov.push_back(u->get_coverage());
+        }
+    }
+    return s;
+}
+
+std::vector<std::map<std::string, std::vector<GenotypingResult>>> genotype_cohort(
+    std::map<std::string, std::vector<std::shared_ptr<UniqueKmers>>>& chromosomes, const std::vector<SampleCounts>& samples,
+    ProbabilityTable* probabilities, double recombrate, bool uniform, long double effective_N, int device) {
+    const size_t C = chromosomes.size(), S = samples.size();
+    std::vector<std::map<std::string, std::vector<GenotypingResult>>> out(S);
+    if (C == 0 || S == 0) return out;
+    std::vector<std::string> names;
+    std::vector<FlatContig> flat(C);
+    std::vector<std::vector<uint64_t>> goff(C);
+    std::vector<pg_contig_batch> index(C);
+    size_t c = 0;
+    for (auto& kv : chromosomes) {
+        names.push_back(kv.first);
+        flatten(&kv.second, nullptr, flat[c]);
+        goff[c].assign(flat[c].variant_pos.size() + 1, 0);
+        pg_hmm_geno_offsets(&flat[c].batch, goff[c].data());
+        index[c] = flat[c].batch;
+        c += 1;
+    }
+    // per sample the two pointer rows of pg_sample_counts; sizes checked against the index
+    static const uint16_t none = 0;
+    std::vector<std::vector<const uint16_t*>> count_rows(S, std::vector<const uint16_t*>(C)), cov_rows(S, std::vector<const uint16_t*>(C));
+    std::vector<pg_sample_counts> rows(S);
+    for (size_t s = 0; s < S; ++s) {
+        for (c = 0; c < C; ++c) {
+            const auto k = samples[s].kmer_count.find(names[c]), v = samples[s].coverage.find(names[c]);
+            if (k == samples[s].kmer_count.end() || v == samples[s].coverage.end() || k->second.size() != flat[c].kmer_count.size() ||
+                v->second.size() != flat[c].variant_pos.size())
+                fail("genotype_cohort: sample " + std::to_string(s) + " does not fit the index on " + names[c]);
+            count_rows[s][c] = k->second.empty() ? &none : k->second.data();
+            cov_rows[s][c] = v->second.empty() ? &none : v->second.data();
+        }
+        rows[s].kmer_count = count_rows[s].data();
+        rows[s].coverage = cov_rows[s].data();
+    }
+    pg_hmm_params prm{};
+    prm.effective_N = effective_N; prm.recombrate = recombrate; prm.uniform = uniform ? 1 : 0; prm.run_genotyping = 1;
+    char err[512] = {0};
+    pg_job* job = nullptr;
+    int rc = pg_cohort_new(device, (uint32_t)C, index.data(), (uint32_t)S, rows.data(), probabilities->handle(), &prm, &job, err, sizeof(err));
+    if (rc == PG_OK) rc = pg_job_run(job, nullptr, err, sizeof(err));
+    if (rc != PG_OK) { if (job) pg_job_destroy(job); check_rc(rc, err); }
+    for (size_t s = 0; s < S && rc == PG_OK; ++s)
+        for (c = 0; c < C && rc == PG_OK; ++c) {
+            const uint64_t n = goff[c].back();
+            std::vector<double> lik(n ? n : 1);
+            std::vector<int32_t> lexp(n ? n : 1);
+            pg_contig_result r{};
+            r.lik = lik.data(); r.lik_exp = lexp.data();
+            rc = pg_job_fetch(job, (uint32_t)(s * C + c), &r, err, sizeof(err));   // chain id = sample * n_contigs + contig
+            if (rc == PG_OK) out[s][names[c]] = results_of_chain(flat[c], cov_rows[s][c], goff[c], lik.data(), lexp.data());
+        }
+    pg_job_destroy(job);
+    check_rc(rc, err);
     return out;
 }
 

@@ -307,6 +307,26 @@ std::vector<std::vector<GenotypingResult>> run_contigs_multi_gpu(std::vector<Con
                                                                  double recombrate, bool uniform, long double effective_N,
                                                                  const std::vector<int>& devices);
 
+/** One sample's numbers against a shared index: per chromosome the read count of every unique k-mer (variant after
+ *  variant, k-mer after k-mer) and the local coverage of every variant — all that differs between the samples of a cohort
+ *  (reference src/commands.cpp:118-138: update_readcount / set_coverage). */
+struct SampleCounts {
+    std::map<std::string, std::vector<uint16_t>> kmer_count, coverage;
+    /** the numbers the objects of `chromosomes` hold right now (after fill_read_kmercounts for this sample) */
+    static SampleCounts of(const std::map<std::string, std::vector<std::shared_ptr<UniqueKmers>>>& chromosomes);
+};
+
+/** Many samples against ONE index in one device job (C ABI pg_cohort_new): the index arrays of
+ *  `chromosomes` go to the device once, every (sample, chromosome) pair is an independent chain over ALL paths of the index,
+ *  and what comes back is, per sample and chromosome, what HMM(...).get_genotyping_result() returns for that sample alone
+ *  (unnormalised, as run_genotyping asks for it, src/commands.cpp:160).  `probabilities` serves every sample: a table
+ *  entry depends on (coverage, count) only, so one table whose box spans the samples' peaks (min peak / 4 .. max peak * 4,
+ *  counts up to 2 * max peak) gives each sample the values of its own table.  Throws std::runtime_error on samples whose
+ *  arrays do not fit the index. */
+std::vector<std::map<std::string, std::vector<GenotypingResult>>> genotype_cohort(
+    std::map<std::string, std::vector<std::shared_ptr<UniqueKmers>>>& chromosomes, const std::vector<SampleCounts>& samples,
+    ProbabilityTable* probabilities, double recombrate = 1.26, bool uniform = false, long double effective_N = 25000.0L, int device = 0);
+
 // ------------------------------------------------------------------ haplotype sampling (include/pangenie_sampler.h)
 /** reference src/haplotypesampler.hpp:16-59 */
 struct SampledPaths {

@@ -1749,6 +1749,32 @@ int main(int argc, char** argv) {
         lap("HMM on the device, VCF written");
         return 0;
     }
+    else if (mode == "cohort" && argc >= 6) {   // GPU: several samples against one index in ONE device job: cohort <prefix> <out prefix> <threads> <reads>...
+        const std::string prefix = argv[2], out_prefix = argv[3];
+        const unsigned threads = (unsigned)std::atoi(argv[4]);
+        UniqueKmersMap index = load_unique_kmers_map(prefix + "_UniqueKmersMap.cereal");
+        std::vector<std::string> chromosomes;
+        for (const auto& kv : index.unique_kmers) chromosomes.push_back(kv.first);
+        std::vector<SampleCounts> samples;
+        size_t low = ~(size_t)0, high = 0;
+        for (int i = 5; i < argc; ++i) {   // per sample: graph-only counts, abundance peak, counts into the (shared) objects, copied out
+            TargetedKmerCounter reads(index.kmersize);
+            reads.add_targets_from_sequences(prefix + "_path_segments.fasta");
+            reads.count(argv[i], threads);
+            const size_t peak = demo_abundance_peak(reads.abundance_histogram(10000));
+            for (const std::string& c : chromosomes) fill_read_kmercounts(c, &index, reads, prefix + "_" + c + "_kmers.tsv.gz", peak);
+            samples.push_back(SampleCounts::of(index.unique_kmers));
+            low = std::min(low, peak); high = std::max(high, peak);
+            std::fprintf(stderr, "cohort: sample %d peak %zu\n", i - 5, peak);
+        }
+        ProbabilityTable probs(low / 4, high * 4, 2 * high, 0.01L);   // one table whose box spans every sample's
+        auto results = genotype_cohort(index.unique_kmers, samples, &probs, 1.26, false, 0.00001L, 0);
+        for (size_t s = 0; s < results.size(); ++s) {
+            for (auto& kv : results[s]) for (GenotypingResult& r : kv.second) r.normalize();
+            demo_write_vcf(prefix, results[s], chromosomes, out_prefix + "_" + std::to_string(s) + ".vcf", "sample");
+        }
+        return 0;
+    }
     else if (mode == "demo" && argc >= 5) {   // GPU: the demo end to end
         demo_genotype_on_device(argv[2], argv[3], argv[4], argc > 5 ? argv[5] : "");
         return 0;

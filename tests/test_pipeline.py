@@ -49,3 +49,23 @@ def test_pipeline_on_the_device_writes_the_oracle_twins_vcf(tmp_path, samples):
     r = subprocess.run([str(HOST_TEST), "genotype", p + "_idx", p + "_reads.fa", p + "_gpu.vcf", "4"], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stdout + r.stderr
     assert without_date(p + "_gpu.vcf") == without_date(p + "_cpu.vcf")
+
+
+@pytest.mark.gpu
+def test_cohort_of_three_samples_in_one_job_writes_each_samples_own_vcf(tmp_path):
+    """pangenie::genotype_cohort (pg_cohort_new: the index on the device once, every (sample, chromosome) a chain of one
+    job, one probability table whose box spans the samples' peaks): three samples of different depth against the same
+    index must each get the VCF the oracle twin writes for that sample alone with its own table."""
+    p = prepared(tmp_path, 10, 77)                      # (leaves a 25x sample in <p>_reads.fa)
+    reads = [p + "_reads_a.fa"]
+    Path(p + "_reads.fa").rename(reads[0])
+    for name, coverage, seed in (("b", 14, 500), ("c", 36, 501)):
+        simulate_pangenome.sample(p, coverage, seed)   # (writes <p>_reads.fa)
+        reads.append(p + f"_reads_{name}.fa")
+        Path(p + "_reads.fa").rename(reads[-1])
+    peaks = [pipeline_cpu_check.main(p + "_idx", r, p + f"_cpu{i}.vcf") for i, r in enumerate(reads)]
+    assert len(set(peaks)) == 3
+    r = subprocess.run([str(HOST_TEST), "cohort", p + "_idx", p + "_cohort", "4"] + reads, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    for i in range(3):
+        assert without_date(p + f"_cohort_{i}.vcf") == without_date(p + f"_cpu{i}.vcf")
