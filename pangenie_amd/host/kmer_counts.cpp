@@ -591,4 +591,33 @@ void fill_read_kmercounts(const std::string& chromosome, UniqueKmersMap* unique_
     gzclose(file);
 }
 
+void fill_read_kmercounts_all(UniqueKmersMap* unique_kmers_map, KmerCounter& read_kmer_counts, const std::string& prefix,
+                              size_t kmer_coverage, unsigned threads) {
+    std::vector<std::string> chromosomes;
+    for (const auto& kv : unique_kmers_map->unique_kmers) chromosomes.push_back(kv.first);
+    std::atomic<size_t> next{0};
+    std::mutex failure_lock;
+    std::exception_ptr failure;
+    auto work = [&] {
+        for (size_t i = next.fetch_add(1); i < chromosomes.size(); i = next.fetch_add(1)) {
+            try {
+                fill_read_kmercounts(chromosomes[i], unique_kmers_map, read_kmer_counts, prefix + "_" + chromosomes[i] + "_kmers.tsv.gz", kmer_coverage);
+            } catch (...) {
+                std::lock_guard<std::mutex> hold(failure_lock);
+                if (!failure) failure = std::current_exception();
+                next.store(chromosomes.size());
+            }
+        }
+    };
+    if (threads <= 1 || chromosomes.size() <= 1) work();
+    else {
+        // (a counter that finishes its table lazily does so here, on one thread; a strict one may refuse the k-mer itself)
+        try { (void)read_kmer_counts.getKmerAbundance(std::string(unique_kmers_map->kmersize, 'A')); } catch (const std::runtime_error&) {}
+        std::vector<std::thread> workers;
+        for (unsigned t = 0; t < std::min<size_t>(threads, chromosomes.size()); ++t) workers.emplace_back(work);
+        for (std::thread& w : workers) w.join();
+    }
+    if (failure) std::rethrow_exception(failure);
+}
+
 }  // namespace pangenie

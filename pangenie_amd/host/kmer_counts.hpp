@@ -123,4 +123,10 @@ unsigned short compute_local_coverage(std::vector<std::string>& kmers, KmerCount
 void fill_read_kmercounts(const std::string& chromosome, UniqueKmersMap* unique_kmers_map, KmerCounter& read_kmer_counts,
                           const std::string& kmers_tsv_gz, size_t kmer_coverage);
 
+/** fill_read_kmercounts for every chromosome of the index, `threads` chromosomes at a time (the reference's thread pool
+ *  around it, src/commands.cpp:857-868), tables at `<prefix>_<chromosome>_kmers.tsv.gz`.  The counter is only read; the
+ *  first exception of a worker is rethrown after all have stopped. */
+void fill_read_kmercounts_all(UniqueKmersMap* unique_kmers_map, KmerCounter& read_kmer_counts, const std::string& prefix,
+                              size_t kmer_coverage, unsigned threads = 1);
+
 }  // namespace pangenie

@@ -428,6 +428,23 @@ static void index_builder_cpu_tests() {
         CHECK(b.objects.size() == 1);
         for (const auto& u : b.objects) CHECK(adds_up(u) && u->size() <= 301 && u->size() > 0);
     });
+    run("fill_read_kmercounts_all: chromosomes on worker threads = one after the other", [] {
+        // the reference's small2.vcf: bubbles on chrA, chrB and chrC; the graph itself serves as reads
+        const std::string dir = g_golden_dir + "/graphbuilder/", prefix = "/tmp/pg_test_fill_all";
+        CHECK(build_index(dir + "small1.fa", dir + "small2.vcf", prefix, 10, true).size() == 3);
+        TargetedKmerCounter reads(10);
+        reads.add_targets_from_sequences(prefix + "_path_segments.fasta");
+        reads.count(prefix + "_path_segments.fasta", 2);
+        UniqueKmersMap serial = load_unique_kmers_map(prefix + "_UniqueKmersMap.cereal"), threaded = load_unique_kmers_map(prefix + "_UniqueKmersMap.cereal");
+        for (const auto& kv : serial.unique_kmers) fill_read_kmercounts(kv.first, &serial, reads, prefix + "_" + kv.first + "_kmers.tsv.gz", 2);
+        fill_read_kmercounts_all(&threaded, reads, prefix, 2, 3);
+        CHECK(serialize_unique_kmers_map(serial) == serialize_unique_kmers_map(threaded));
+        size_t counted = 0;
+        for (const auto& kv : threaded.unique_kmers) for (const auto& u : kv.second) for (size_t i = 0; i < u->size(); ++i) counted += u->get_readcount_of(i);
+        CHECK(counted > 0);
+        UniqueKmersMap broken = load_unique_kmers_map(prefix + "_UniqueKmersMap.cereal");
+        CHECK_THROWS(fill_read_kmercounts_all(&broken, reads, "/tmp/pg_no_such_prefix", 2, 3));
+    });
     run("build_index with worker threads: the same files as with one", [] {
         // 60 kb of pseudo-random reference, 300 records (SNPs, a deletion and a two-ALT insertion now and then), 6 haplotypes
         std::string ref;
