@@ -291,6 +291,31 @@ std::string path_segments_fasta(const BuiltGraphs& built, const ReferenceSequenc
 }
 
 // ------------------------------------------------------------------ unique k-mers of a chromosome
+namespace {
+// the reference on either side of bubble v: up to 2 k bases, not into the neighbouring bubbles
+struct Flanks { size_t left_from, start, end, right_to; };
+Flanks flanks_of(const Graph& graph, size_t v, size_t k, size_t reference_size) {
+    const Variant& bubble = graph.get_variant(v);
+    const size_t start = bubble.get_start_position(), end = bubble.get_end_position();
+    const size_t left_limit = v > 0 ? graph.get_variant(v - 1).get_end_position() : 0;
+    const size_t right_limit = v + 1 < graph.size() ? graph.get_variant(v + 1).get_start_position() : reference_size;
+    return {std::max(left_limit, start >= 2 * k ? start - 2 * k : 0), start, end, std::min(right_limit, end + 2 * k)};
+}
+}  // namespace
+
+void register_candidate_kmers(const Graph& graph, TargetedKmerCounter& counter) {
+    const size_t k = graph.get_kmer_size();
+    const std::string reference = graph.reference(graph.get_chromosome());
+    for (size_t v = 0; v < graph.size(); ++v) {
+        const Variant& bubble = graph.get_variant(v);
+        for (size_t a = 0; a < bubble.nr_of_alleles(); ++a)
+            if (!bubble.is_undefined_allele(a)) counter.add_targets_of(bubble.get_allele_string(a));
+        const Flanks f = flanks_of(graph, v, k, reference.size());
+        counter.add_targets_of(std::string_view(reference).substr(f.left_from, f.start - f.left_from));
+        counter.add_targets_of(std::string_view(reference).substr(f.end, f.right_to - f.end));
+    }
+}
+
 ChromosomeKmers unique_kmers_of(const Graph& graph, KmerCounter& graph_kmers, unsigned threads) {
     const size_t k = graph.get_kmer_size();
     const std::string reference = graph.reference(graph.get_chromosome());
@@ -358,14 +383,11 @@ ChromosomeKmers unique_kmers_of(const Graph& graph, KmerCounter& graph_kmers, un
                 if (!unique_column.empty()) unique_column += ',';
                 unique_column += code_to_kmer(code, k);
             }
-        // the reference on either side: up to 2 k bases, not into the neighbouring bubbles
-        const size_t start = bubble.get_start_position(), end = bubble.get_end_position();
-        const size_t left_limit = v > 0 ? graph.get_variant(v - 1).get_end_position() : 0;
-        const size_t right_limit = v + 1 < graph.size() ? graph.get_variant(v + 1).get_start_position() : reference.size();
-        const size_t left_from = std::max(left_limit, start >= 2 * k ? start - 2 * k : 0), right_to = std::min(right_limit, end + 2 * k);
+        const Flanks f = flanks_of(graph, v, k, reference.size());
+        const size_t start = f.start, end = f.end;
         std::vector<std::string> flanking;
-        single_copy(reference.substr(left_from, start - left_from), flanking);
-        single_copy(reference.substr(end, right_to - end), flanking);
+        single_copy(reference.substr(f.left_from, f.start - f.left_from), flanking);
+        single_copy(reference.substr(f.end, f.right_to - f.end), flanking);
         std::string flank_column;
         for (const std::string& f : flanking) { if (!flank_column.empty()) flank_column += ','; flank_column += f; }
         out.rows[v] = bubble.get_chromosome() + '\t' + std::to_string(start) + '\t' + std::to_string(end) + '\t' +
@@ -436,7 +458,7 @@ static void write_gz_members(const std::string& path, const std::string& header,
 
 // ------------------------------------------------------------------ everything
 std::vector<std::string> build_index(const std::string& reference_fasta, const std::string& vcf, const std::string& prefix, size_t k, bool add_reference,
-                                     unsigned threads) {
+                                     unsigned threads, bool whole_graph_counts) {
     if (threads == 0) threads = std::max(1u, std::thread::hardware_concurrency());
     const bool verbose = std::getenv("PG_INDEX_VERBOSE") != nullptr;   // stage times on stderr
     auto clock = std::chrono::steady_clock::now();
@@ -456,8 +478,11 @@ std::vector<std::string> build_index(const std::string& reference_fasta, const s
         f << path_segments_fasta(built, reference);
     }
     stage("segment file written");
-    ExactKmerCounter graph_kmers(segments, k);
-    stage("graph k-mers counted");
+    std::unique_ptr<ExactKmerCounter> whole_graph;
+    if (whole_graph_counts) {
+        whole_graph.reset(new ExactKmerCounter(segments, k));
+        stage("graph k-mers counted");
+    }
     UniqueKmersMap map;
     map.kmersize = k;
     map.add_reference = add_reference;
@@ -470,6 +495,14 @@ std::vector<std::string> build_index(const std::string& reference_fasta, const s
             f.write((const char*)bytes.data(), (std::streamsize)bytes.size());
         }
         stage("graph archive written");
+        std::unique_ptr<TargetedKmerCounter> asked;
+        if (!whole_graph_counts) {
+            asked.reset(new TargetedKmerCounter(k));
+            register_candidate_kmers(graph, *asked);
+            asked->count(segments, threads);
+            stage("candidate k-mers counted");
+        }
+        KmerCounter& graph_kmers = whole_graph_counts ? static_cast<KmerCounter&>(*whole_graph) : static_cast<KmerCounter&>(*asked);
         ChromosomeKmers kmers = unique_kmers_of(graph, graph_kmers, threads);
         stage("unique k-mers selected");
         write_gz_members(prefix + "_" + name + "_kmers.tsv.gz", "#chromosome\tstart\tend\tunique_kmers\tunique_kmers_overhang\n", kmers.rows, threads);

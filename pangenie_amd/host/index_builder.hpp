@@ -60,8 +60,17 @@ struct ChromosomeKmers {
  *  ExactKmerCounter is) */
 ChromosomeKmers unique_kmers_of(const Graph& graph, KmerCounter& graph_kmers, unsigned threads = 1);
 
-/** Everything at once, written under `prefix`; returns the chromosomes in the reference's order. */
+/** Every k-mer unique_kmers_of(graph, ...) can ask its counter about — the windows of the bubbles' alleles and of the
+ *  reference stretches either side of them — registered with `counter`: a TargetedKmerCounter that then streams the
+ *  segment file holds the graph's counts for ONE chromosome's questions instead of every k-mer of the graph. */
+void register_candidate_kmers(const Graph& graph, TargetedKmerCounter& counter);
+
+/** Everything at once, written under `prefix`; returns the chromosomes in the reference's order.  The graph's k-mer counts
+ *  are taken chromosome by chromosome (register_candidate_kmers + one pass over the segment file each, `threads` counting
+ *  workers): memory follows one chromosome's bubbles, not the whole graph; `whole_graph_counts` = true keeps every k-mer
+ *  of the graph in one table instead (one pass; the reference's way, with Jellyfish). */
 std::vector<std::string> build_index(const std::string& reference_fasta, const std::string& vcf, const std::string& prefix,
-                                     size_t kmer_size = 31, bool add_reference = true, unsigned threads = 1);   // threads 0 = all cores
+                                     size_t kmer_size = 31, bool add_reference = true, unsigned threads = 1,   // threads 0 = all cores
+                                     bool whole_graph_counts = false);
 
 }  // namespace pangenie

@@ -278,6 +278,20 @@ size_t TargetedKmerCounter::add_targets_from_table(const std::string& kmers_tsv_
     return rows;
 }
 
+void TargetedKmerCounter::add_targets_of(std::string_view sequence) {
+    if (frozen_) throw std::runtime_error("TargetedKmerCounter: targets must be registered before the reads are counted");
+    const uint64_t mask = k_ == 32 ? ~0ull : ((1ull << (2 * k_)) - 1ull);
+    uint64_t fwd = 0, rev = 0;
+    size_t filled = 0;
+    for (const char c : sequence) {
+        const int b = base_code(c);
+        if (b < 0) { filled = 0; fwd = rev = 0; continue; }
+        fwd = ((fwd << 2) | (uint64_t)b) & mask;
+        rev = (rev >> 2) | ((uint64_t)(3 - b) << (2 * (k_ - 1)));
+        if (++filled >= k_) pending_.push_back(fwd < rev ? fwd : rev);
+    }
+}
+
 size_t TargetedKmerCounter::add_targets_from_sequences(const std::string& fasta) {
     if (frozen_) throw std::runtime_error("TargetedKmerCounter: targets must be registered before the reads are counted");
     const uint64_t mask = k_ == 32 ? ~0ull : ((1ull << (2 * k_)) - 1ull);

@@ -73,6 +73,8 @@ public:
      *  default count source (JellyfishCounter(readfile, {segment_file}, ...), src/jellyfishcounter.cpp:51-84: only k-mers of
      *  the graph are counted); returns how many windows were registered (with repeats) */
     size_t add_targets_from_sequences(const std::string& fasta);
+    /** register every window of a sequence held in memory */
+    void add_targets_of(std::string_view sequence);
     /** stream a read file and count; may be called for several files (counts add up).  No targets may be added afterwards. */
     void count(const std::string& readfile, unsigned threads = 1);
     size_t getKmerAbundance(std::string kmer) override;

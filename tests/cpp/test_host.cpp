@@ -481,6 +481,12 @@ static void index_builder_cpu_tests() {
         CHECK(read_file(one + "_path_segments.fasta") == read_file(four + "_path_segments.fasta"));
         CHECK(read_file(one + "_chrT_Graph.cereal") == read_file(four + "_chrT_Graph.cereal"));
         CHECK(read_file(one + "_UniqueKmersMap.cereal") == read_file(four + "_UniqueKmersMap.cereal"));
+        // ... and as with every k-mer of the graph counted in one table (the default counts, per chromosome, only the k-mers
+        // the selection can ask about)
+        const std::string whole = "/tmp/pg_test_mtw";
+        CHECK(build_index(fa, vcf, whole, 31, true, 2, true) == std::vector<std::string>({"chrT"}));
+        CHECK(read_file(one + "_UniqueKmersMap.cereal") == read_file(whole + "_UniqueKmersMap.cereal"));
+        CHECK(gunzip_text(one + "_chrT_kmers.tsv.gz") == gunzip_text(whole + "_chrT_kmers.tsv.gz"));
         const std::string table = gunzip_text(one + "_chrT_kmers.tsv.gz");
         CHECK(table == gunzip_text(four + "_chrT_kmers.tsv.gz") && std::count(table.begin(), table.end(), '\n') > 200);
         const UniqueKmersMap m = load_unique_kmers_map(four + "_UniqueKmersMap.cereal");
