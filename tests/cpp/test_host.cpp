@@ -526,6 +526,17 @@ static void index_builder_cpu_tests() {
         const std::vector<std::string> ph = g.phasing_records({r});
         CHECK(ph.size() == 2 && ph[0].substr(ph[0].rfind('\t') + 1) == "0|0:0" && ph[1].substr(ph[1].rfind('\t') + 1) == "0|0:0");
     });
+    run("ReferenceSequences on the reference's FASTA known answers (tests/FastaReaderTest.cpp:9-48)", [] {
+        const std::string dir = g_golden_dir + "/graphbuilder/";
+        const ReferenceSequences f(dir + "simple-fasta.fa");
+        CHECK(f.contains("chr01") && f.contains("chr02") && !f.contains("chr03"));
+        CHECK(f.of("chr01").size() == 1688 && f.of("chr02").size() == 2135 && f.names() == std::vector<std::string>({"chr01", "chr02"}));
+        CHECK_THROWS(f.of("chrNone"));
+        CHECK(f.of("chr01").substr(0, 10) == "CATTTTAAAG" && f.of("chr01").substr(21, 19) == "CCCAGAGCAGGCAAAACCC");
+        CHECK(f.of("chr02").substr(1, 11) == "CCAACAATTTA" && f.of("chr02").substr(71, 10) == "TCAAATCACA");
+        CHECK_THROWS(ReferenceSequences(dir + "broken-fasta.fa"));   // sequence before the first header
+        CHECK_THROWS(ReferenceSequences("/tmp/pg_no_such.fa"));
+    });
     run("build_graphs on damaged VCFs: a graph or a runtime_error, nothing else", [] {
         const std::string dir = g_golden_dir + "/graphbuilder/";
         const ReferenceSequences reference(dir + "small1.fa");
@@ -818,6 +829,18 @@ static void kmer_count_cpu_tests() {
         parse_kmer_line("chr7\t1234\tx\tACGT,CCCC,GGGT\tAAAA", chrom, start, km, fl, header);
         CHECK(chrom == "chr7" && start == 1234 && !header);
         CHECK(km == std::vector<std::string>({"ACGT", "CCCC", "GGGT"}) && fl == std::vector<std::string>({"AAAA"}));
+        km.clear(); fl.clear();
+        // tests/KmerParser.cpp:9-94 (the lists are appended to, as the reference's are: fresh ones per row)
+        parse_kmer_line("chr1\t1\t2\tnan\tnan", chrom, start, km, fl, header);
+        CHECK(!header && km.empty() && fl.empty() && chrom == "chr1" && start == 1);
+        parse_kmer_line("chr1\t1\t2\tnan\tAAAT,TGGG", chrom, start, km, fl, header);
+        CHECK(km.empty() && fl == std::vector<std::string>({"AAAT", "TGGG"}) && chrom == "chr1" && start == 1);
+        km.clear(); fl.clear();
+        parse_kmer_line("chr1\t1\t2\tTGTG,ATGT\tnan", chrom, start, km, fl, header);
+        CHECK(km == std::vector<std::string>({"TGTG", "ATGT"}) && fl.empty());
+        km.clear(); fl.clear();
+        parse_kmer_line("chr1\t1\t2\tTGTG,ATGT\tTTTT,GGGG", chrom, start, km, fl, header);
+        CHECK(km == std::vector<std::string>({"TGTG", "ATGT"}) && fl == std::vector<std::string>({"TTTT", "GGGG"}) && chrom == "chr1" && start == 1);
         km.clear(); fl.clear();
         parse_kmer_line("chr7\t99\tx\tnan\tnan", chrom, start, km, fl, header);
         CHECK(start == 99 && km.empty() && fl.empty() && !header);
