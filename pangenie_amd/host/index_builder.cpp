@@ -57,7 +57,13 @@ struct Record {
     std::vector<std::string> ids;                 // INFO ID=, one per ALT allele (may be empty)
 };
 
-/** Forward (not canonical) 2-bit code of every window of k letters over ACGT in `seq`, with how often it occurs there. */
+/** Forward (not canonical) 2-bit code of every window of k letters over ACGT in `seq`, with how often it occurs there.
+ *  A sequence SHORTER than k gives one entry all the same: the reference's enumeration (stepwise_unique_kmers,
+ *  src/stepwiseuniquekmercomputer.cpp:11-35) shifts the letters into a k-mer register that starts as k A's and counts the
+ *  register once more after its loop, so what it sees of n < k letters is (k - n) A's followed by them.  That happens to the
+ *  reference stretch between two bubbles exactly k - 1 apart (closer ones are merged), and the k-mer is a real one of the
+ *  graph whenever the bubble before ends in A's.  (With a letter outside ACGT among the n the register's content is
+ *  Jellyfish's business; no entry then.) */
 std::map<uint64_t, size_t> window_counts(const std::string& seq, size_t k) {
     std::map<uint64_t, size_t> counts;
     const uint64_t mask = k == 32 ? ~0ull : ((1ull << (2 * k)) - 1ull);
@@ -68,6 +74,7 @@ std::map<uint64_t, size_t> window_counts(const std::string& seq, size_t k) {
         code = ((code << 2) | (uint64_t)(c == 'A' ? 0 : c == 'C' ? 1 : c == 'G' ? 2 : 3)) & mask;
         if (++valid >= k) counts[code] += 1;
     }
+    if (seq.size() < k && valid == seq.size()) counts[code] += 1;   // (A = 0: the padded register is the code so far)
     return counts;
 }
 
@@ -311,8 +318,11 @@ void register_candidate_kmers(const Graph& graph, TargetedKmerCounter& counter) 
         for (size_t a = 0; a < bubble.nr_of_alleles(); ++a)
             if (!bubble.is_undefined_allele(a)) counter.add_targets_of(bubble.get_allele_string(a));
         const Flanks f = flanks_of(graph, v, k, reference.size());
-        counter.add_targets_of(std::string_view(reference).substr(f.left_from, f.start - f.left_from));
-        counter.add_targets_of(std::string_view(reference).substr(f.end, f.right_to - f.end));
+        for (const std::string_view stretch : {std::string_view(reference).substr(f.left_from, f.start - f.left_from),
+                                               std::string_view(reference).substr(f.end, f.right_to - f.end)}) {
+            counter.add_targets_of(stretch);
+            if (stretch.size() < k) counter.add_target(std::string(k - stretch.size(), 'A') + std::string(stretch));   // (window_counts: the padded register)
+        }
     }
 }
 

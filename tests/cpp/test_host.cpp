@@ -537,6 +537,34 @@ static void index_builder_cpu_tests() {
         CHECK_THROWS(ReferenceSequences(dir + "broken-fasta.fa"));   // sequence before the first header
         CHECK_THROWS(ReferenceSequences("/tmp/pg_no_such.fa"));
     });
+    run("two bubbles exactly k - 1 apart: the stretch between them is shorter than k (src/stepwiseuniquekmercomputer.cpp:11-35)", [] {
+        // k = 11, SNPs at 100 and 111: ten reference bases between them, not merged (src/graphbuilder.cpp:186).  The reference's
+        // k-mer register, started as A's, turns those ten bases into the 11-mer 'A' + bases; one allele of the first SNP is an
+        // A here, so that 11-mer exists once in the graph and becomes a flanking k-mer of BOTH bubbles
+        std::string ref;
+        uint64_t x = 0xA0761D6478BD642Full;
+        for (int i = 0; i < 400; ++i) { x ^= x << 13; x ^= x >> 7; x ^= x << 17; ref += "ACGT"[x & 3]; }
+        const std::string fa = "/tmp/pg_test_k1.fa", vcf = "/tmp/pg_test_k1.vcf";
+        { std::FILE* f = std::fopen(fa.c_str(), "w"); std::fprintf(f, ">c\n%s\n", ref.c_str()); std::fclose(f); }
+        auto alt_of = [&](size_t pos) { return ref[pos] == 'A' ? 'C' : 'A'; };
+        { std::FILE* f = std::fopen(vcf.c_str(), "w");
+          std::fprintf(f, "##fileformat=VCFv4.2\n#CHROM\tPOS\tID\tREF\tALT\tQUAL\tFILTER\tINFO\tFORMAT\ts\nc\t101\t.\t%c\t%c\t.\t.\t.\tGT\t0|1\nc\t112\t.\t%c\t%c\t.\t.\t.\tGT\t1|0\n",
+                       ref[100], alt_of(100), ref[111], alt_of(111));
+          std::fclose(f); }
+        const std::string prefix = "/tmp/pg_test_k1_idx";
+        for (const bool whole : {false, true}) {
+            CHECK(build_index(fa, vcf, prefix, 11, true, 1, whole).size() == 1);
+            CHECK(Graph::load(prefix + "_c_Graph.cereal").size() == 2);
+            std::vector<std::string> rows;
+            { std::istringstream is(gunzip_text(prefix + "_c_kmers.tsv.gz")); std::string l; while (std::getline(is, l)) if (l[0] != '#') rows.push_back(l); }
+            CHECK(rows.size() == 2);
+            const std::string padded = "A" + ref.substr(101, 10);
+            for (const std::string& row : rows) {
+                const std::string flanking = row.substr(row.rfind('\t') + 1);
+                CHECK(("," + flanking + ",").find("," + padded + ",") != std::string::npos);
+            }
+        }
+    });
     run("build_graphs on damaged VCFs: a graph or a runtime_error, nothing else", [] {
         const std::string dir = g_golden_dir + "/graphbuilder/";
         const ReferenceSequences reference(dir + "small1.fa");
