@@ -220,6 +220,10 @@ BuiltGraphs build_graphs(const std::string& vcf, const ReferenceSequences& refer
         }
         if (name == chrom && rec.start < previous_end)
             throw std::runtime_error("build_graphs: variant at " + name + ":" + std::to_string(rec.start) + " overlaps previous one. VCF does not represent a pangenome graph.");
+        // (the reference hands a chromosome's sequence over to its Graph when the first bubble is seen; records of that
+        // chromosome after another one's no longer find it: src/graphbuilder.cpp:142-146, src/fastareader.cpp:86-92)
+        if (name != chrom && done.count(name))
+            throw std::runtime_error("build_graphs: chromosome " + name + " is not present in FASTA-file. (its records are not in one block of the VCF)");
         const std::string& ref_bases = reference.of(name);
         const std::string ref_allele = normalised(col[3]);
         rec.end = rec.start + ref_allele.size();

@@ -648,6 +648,8 @@ static void index_builder_cpu_tests() {
             try { (void)build_graphs(vcf, reference, k, true); } catch (const std::runtime_error&) { return true; }
             return false;
         };
+        CHECK(refused(rec(100, alt_of(100), "0|1\t1|0") + "c2\t51\t.\t" + std::string(1, ref[50]) + "\t" + alt_of(50) + "\t.\t.\t.\tGT\t0|1\t1|0\n" +
+                      rec(200, alt_of(200), "0|1\t1|0")));                                  // c1 again after c2
         CHECK(refused(rec(100, alt_of(100), "0/1\t1|0")));                                   // unphased
         CHECK(refused(rec(100, alt_of(100), "0|1|1\t1|0")));                                 // not diploid
         CHECK(refused(rec(100, alt_of(100), "0|2\t1|0")));                                   // allele that does not exist
