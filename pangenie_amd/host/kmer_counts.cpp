@@ -7,6 +7,7 @@
 #include <atomic>
 #include <charconv>
 #include <condition_variable>
+#include <cstdlib>
 #include <cstring>
 #include <deque>
 #include <fstream>
@@ -159,17 +160,14 @@ size_t ExactKmerCounter::getKmerAbundance(std::string kmer) {
 
 // ------------------------------------------------------------------ TargetedKmerCounter
 namespace {
-// Sequences of a FASTA / FASTQ file, plain or gzipped (zlib reads both), handed to `sink` one record at a time — the same
-// record grammar as ExactKmerCounter's constructor, over a line reader that never holds more than one record.
-template <class Sink>
-void stream_sequences(const std::string& path, Sink&& sink) {
-    gzFile in = gzopen(path.c_str(), "rb");
-    if (!in) throw std::runtime_error("TargetedKmerCounter: cannot open " + path);
-    gzbuffer(in, 1u << 20);
+// The record grammar of FASTA / FASTQ as a machine fed line by line — the same as ExactKmerCounter's constructor: `sink` gets
+// the letters of one record at a time.
+struct RecordLines {
     std::string seq;
     enum { NONE, FASTA, FQ_SEQ, FQ_QUAL } state = NONE;
     size_t qual_left = 0;
-    auto handle = [&](std::string_view l) {
+    template <class Sink>
+    void line(std::string_view l, Sink&& sink) {
         if (!l.empty() && l.back() == '\r') l.remove_suffix(1);
         if (state == FQ_QUAL) {
             qual_left = l.size() >= qual_left ? 0 : qual_left - l.size();
@@ -196,7 +194,24 @@ void stream_sequences(const std::string& path, Sink&& sink) {
             return;
         }
         if (state == FASTA || state == FQ_SEQ) seq.append(l.data(), l.size());
-    };
+    }
+    template <class Sink>
+    void finish(Sink&& sink) {
+        if (state == FASTA || state == FQ_SEQ) sink(seq);
+        seq.clear();
+        state = NONE;
+    }
+};
+
+// Sequences of a FASTA / FASTQ file, plain or gzipped (zlib reads both), handed to `sink` one record at a time, over a line
+// reader that never holds more than one record.
+template <class Sink>
+void stream_sequences(const std::string& path, Sink&& sink) {
+    gzFile in = gzopen(path.c_str(), "rb");
+    if (!in) throw std::runtime_error("TargetedKmerCounter: cannot open " + path);
+    gzbuffer(in, 1u << 20);
+    RecordLines records;
+    auto handle = [&](std::string_view l) { records.line(l, sink); };
     // blocks of 4 MB, lines split in place; the unfinished tail of a block moves to the front of the next one
     std::vector<char> buf(4u << 20);
     size_t have = 0;
@@ -218,13 +233,14 @@ void stream_sequences(const std::string& path, Sink&& sink) {
             if (got == 0) break;
         }
         if (have) handle(std::string_view(buf.data(), have));   // last line without a newline
-        if (state == FASTA || state == FQ_SEQ) sink(seq);
+        records.finish(sink);
     } catch (...) {
         gzclose(in);
         throw;
     }
     gzclose(in);
 }
+
 }  // namespace
 
 TargetedKmerCounter::TargetedKmerCounter(size_t kmer_size, bool unregistered_counts_zero) : k_(kmer_size), lenient_(unregistered_counts_zero) {
@@ -426,7 +442,8 @@ void TargetedKmerCounter::count(const std::string& readfile, unsigned threads) {
     if (threads == 0) threads = 1;
     freeze(threads);
     // one reader (decompression and record parsing), `threads` workers on batches of sequences; hits are relaxed atomic
-    // increments on the shared table
+    // increments on the shared table.  (Workers that parse byte ranges of the mapped file themselves — no single reader —
+    // measured no better: 3.7-4.1 s against 3.1-3.3 s for 589 MB on the 256 cores of the MI355X box, 3.7-4.9 against 3.5 on 8.)
     // (a batch is the sequences of a few MB of reads back to back, a newline after each: the rolling window starts over at
     // every letter outside ACGT, so the newline is all the separation the counting needs)
     struct Batch { std::string text; };

@@ -744,6 +744,39 @@ static void kmer_count_cpu_tests() {
         }
         CHECK(differ == 0 && seen > 50000);
         CHECK(one.abundance_histogram(100) == four.abundance_histogram(100));
+        // the same reads as FASTA with the sequence over several lines, and as FASTQ whose quality lines begin with '@', '+' and
+        // '>' now and then: the same counts
+        const std::string fa_lines = "/tmp/pg_test_big_reads_lines.fa", fq = "/tmp/pg_test_big_reads.fq";
+        {
+            std::FILE* in = std::fopen(reads.c_str(), "r");
+            std::FILE* a = std::fopen(fa_lines.c_str(), "w");
+            std::FILE* q = std::fopen(fq.c_str(), "w");
+            char line[512];
+            int r = 0;
+            while (std::fgets(line, sizeof line, in)) {
+                if (line[0] == '>') continue;
+                std::string seq(line);
+                while (!seq.empty() && (seq.back() == '\n' || seq.back() == '\r')) seq.pop_back();
+                std::fprintf(a, ">read%d some text\n", r);
+                for (size_t i = 0; i < seq.size(); i += 37 + r % 5) std::fprintf(a, "%s\n", seq.substr(i, 37 + r % 5).c_str());
+                std::string quality(seq.size(), 'I');
+                if (r % 3 == 0) quality[0] = '@';
+                if (r % 3 == 1) quality[0] = '+';
+                if (r % 7 == 2) quality[0] = '>';
+                std::fprintf(q, "@read%d/1\n%s\n+%s\n%s\n", r, seq.c_str(), r % 2 ? "read" : "", quality.c_str());
+                r += 1;
+            }
+            std::fclose(in); std::fclose(a); std::fclose(q);
+        }
+        for (const std::string& path : {fa_lines, fq}) {
+            TargetedKmerCounter other(31);
+            other.add_targets_from_sequences(fa);
+            other.count(path, 3);
+            CHECK(other.kmers_seen() == one.kmers_seen());
+            size_t wrong = 0;
+            for (size_t i = 0; i + 31 <= graph.size(); i += 3) wrong += other.getKmerAbundance(graph.substr(i, 31)) != one.getKmerAbundance(graph.substr(i, 31));
+            CHECK(wrong == 0);
+        }
     });
     run("ExactKmerCounter: canonical counts, FASTA and FASTQ, letters outside ACGT", [] {
         const std::string fa = "/tmp/pg_test_reads.fa", fq = "/tmp/pg_test_reads.fq";
