@@ -1825,7 +1825,8 @@ int main(int argc, char** argv) {
         return 0;
     }
     else if (mode == "index" && argc >= 5) {   // PanGenie-index on any input (scale checks)
-        const std::vector<std::string> chromosomes = build_index(argv[2], argv[3], argv[4], argc > 5 ? (size_t)std::atoi(argv[5]) : 31u, true, argc > 6 ? (unsigned)std::atoi(argv[6]) : 1u);
+        const std::vector<std::string> chromosomes = build_index(argv[2], argv[3], argv[4], argc > 5 ? (size_t)std::atoi(argv[5]) : 31u, true, argc > 6 ? (unsigned)std::atoi(argv[6]) : 1u,
+                                                                  argc > 7 && std::string(argv[7]) == "whole");
         std::printf("%zu chromosomes\n", chromosomes.size());
         return 0;
     }
