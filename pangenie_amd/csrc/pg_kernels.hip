@@ -2375,6 +2375,40 @@ DEVI double lean_colsum(const LeanShared<R>& sh, uint32_t pb, uint32_t lane) {
 #define PG_LEAN_EXP 0
 #endif
 static constexpr unsigned kLeanExp = PG_LEAN_EXP;   // timing experiments (tools/exp_lean.py): 1 no column stores, 2 no emission fetches, 4 no MFMA total — results WRONG
+
+// -DPG_LEAN_TIMELINE builds only (tools/exp_pipe.py, profiles/r04_lean_chain.txt): s_memtime stamps at the segment
+// boundaries of one column step of wave 0, each issued behind a use of the value that ends the segment; the stamps are
+// only read behind the step's barrier (reading one earlier would drain the LDS queue with it).  Sums per segment over
+// the launch go to DevContig::prof[32 + segment] (forward role) / [48 + segment] (backward role), [.. + 15] = steps.
+#ifdef PG_LEAN_TIMELINE
+static constexpr bool kLeanTimeline = true;
+#else
+static constexpr bool kLeanTimeline = false;
+#endif
+struct LeanTimeline {
+    unsigned long long t[10], acc[10];
+    DEVI void init() { if constexpr (kLeanTimeline) { for (int i = 0; i < 10; ++i) { t[i] = 0; acc[i] = 0; } } }
+    template <int I>
+    DEVI void mark(double dep) {
+        if constexpr (kLeanTimeline) {
+            __builtin_amdgcn_sched_barrier(0);
+            asm volatile("" :: "v"(dep));
+            t[I] = __builtin_amdgcn_s_memtime();
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+    template <int N>
+    DEVI void fold() {   // behind the barrier: t[0] .. t[N] are this step's stamps
+        if constexpr (kLeanTimeline) {
+#pragma unroll
+            for (int i = 0; i < N; ++i) acc[i] += t[i + 1] - t[i];
+            acc[9] += 1;
+        }
+    }
+    DEVI void write(unsigned long long* o) const {
+        if constexpr (kLeanTimeline) { for (int i = 0; i < 9; ++i) o[i] = acc[i]; o[15] = acc[9]; }
+    }
+};
 template <int PHASE, int R, bool TRI>
 DEVI void lean_forward(const DevContig& dc, LeanShared<R>& sh, uint32_t C, uint32_t chunk) {
     constexpr int HP = 64;
@@ -2494,8 +2528,11 @@ DEVI void lean_forward(const DevContig& dc, LeanShared<R>& sh, uint32_t C, uint3
     // One column step.  `cur` = record of this step (constants of the gap t-1 -> t), `nxt` takes the record of the next
     // step (four broadcast LDS reads, a whole step ahead of use); the loop calls the step twice with the two record
     // variables and the two emission arrays in swapped roles, so nothing is ever moved.
+    LeanTimeline tl;
+    tl.init();
     auto step = [&](uint32_t t, const FRec& cur, FRec& nxt) __attribute__((always_inline)) {
         const uint32_t n = t - first;                 // step number: reads the record with rel = n + 2
+        tl.template mark<0>(0.0);                     // (behind the barrier of the step before)
         nxt = read_frec(sh, n + 2u);
         const u32x2 cdn = lean_pair_bytes(sh, n + 2u, wave);
         if (((n + 4u) % PG_LEAN_BLOCK) == 0u) {       // (uniform) a few columns before the next block is needed
@@ -2513,6 +2550,7 @@ DEVI void lean_forward(const DevContig& dc, LeanShared<R>& sh, uint32_t C, uint3
 #pragma unroll
         for (int q = 0; q < 64 / R; ++q) { pc[q] = sh.psum[pb][q][lane]; pr[q] = sh.psum[pb][q][i0 + (lane & 15u)]; }
         const double Cj = (pc[0] + pc[1]) + (pc[2] + pc[3]);
+        tl.template mark<1>(Cj);                      // the column sums are back from LDS
         const v4f64 zz = {0.0, 0.0, 0.0, 0.0};
         const v4f64 ma = __builtin_amdgcn_mfma_f64_16x16x4f64(Cj, 1.0, zz, 0, 0, 0);
         lean_fence();
@@ -2520,11 +2558,13 @@ DEVI void lean_forward(const DevContig& dc, LeanShared<R>& sh, uint32_t C, uint3
         const double urep = dpp_source(cur.c1 * ((pr[0] + pr[1]) + (pr[2] + pr[3])));
         const LeanPairs lp = lean_pairs(sh, n + 2u, cdn, (uint32_t)((nxt.bits1 >> lane) & 1ull));   // column t+1
         const double msum = (ma[0] + ma[1]) + (ma[2] + ma[3]);
+        tl.template mark<2>(msum);                    // first MFMA + three adds
         lean_fence();
         const v4f64 mb = __builtin_amdgcn_mfma_f64_16x16x4f64(msum, 1.0, zz, 0, 0, 0);
         asm volatile("" :: "v"(mb));   // (the whole result stays allocated: a temporary in one of its registers would wait out the MFMA)
         lean_fence();
         double S = (kLeanExp & 4) ? 64.0 * Cj : mb[0];
+        tl.template mark<3>(S);                       // second MFMA: the total
         double uj = fma(cur.c2, S, ucol);
         double c0 = cur.c0;
         if (__builtin_expect(!(S > 0.0), 0)) {
@@ -2540,6 +2580,7 @@ DEVI void lean_forward(const DevContig& dc, LeanShared<R>& sh, uint32_t C, uint3
         es = es < -900 ? -900 : es;
         const double m = ldexp(S, -es - PG_BIAS_F);
         const double sc = ldexp(1.0, -es), c0s = ldexp(c0, -es), ujs = ldexp(uj, -es);
+        tl.template mark<4>(c0s + ujs + sc);          // zero test, exponent, scaled constants
         gdouble2* dst = (gdouble2*)(wr + (size_t)t * colsz) + toff;
         double part = 0.0, pprev = 0.0;
         static_for<0, R>([&](auto kc) __attribute__((always_inline)) {
@@ -2548,6 +2589,7 @@ DEVI void lean_forward(const DevContig& dc, LeanShared<R>& sh, uint32_t C, uint3
             part = fma(ec[k], pk, part);
             x[k] = ec[k] * pk;
             pin_here(x[k]);
+            if constexpr (k == 1) tl.template mark<5>(x[1]);    // the first row pair's states
             // (the fence keeps every pair's store where it is: eight 1 KB stores issued back to back stall the wave
             // on the memory pipeline's queue — 787 instead of ~650 ns per column)
             if constexpr (k & 1) {
@@ -2557,12 +2599,16 @@ DEVI void lean_forward(const DevContig& dc, LeanShared<R>& sh, uint32_t C, uint3
                 __builtin_amdgcn_sched_barrier(0);
             } else pprev = pk;
         });
+        tl.template mark<6>(part);                    // the other seven row pairs: states, stores, next emissions
         sh.psum[t & 1u][wave][lane] = part;
         if (wave == 0) {  // (scalar branch)
             fsc.put(lane, t, m);
             if ((t & 63u) == 63u) fsc.flush(fscale, lane, t);
         }
+        tl.template mark<7>(0.0);                     // partial sum parked, per-column scalar
         lds_barrier();
+        tl.template mark<8>(0.0);                     // the barrier
+        tl.template fold<8>();
     };
     FRec ra = read_frec(sh, 1), rb2;
     // every load of the prologue has landed before the loop is entered: a register still "waiting for a load" at the loop
@@ -2576,6 +2622,7 @@ DEVI void lean_forward(const DevContig& dc, LeanShared<R>& sh, uint32_t C, uint3
     }
     if (t < hi) step(t, ra, rb2);
     if (wave == 0 && fsc.valid) fsc.flush(fscale, lane, hi - 1);
+    if (kLeanTimeline && tid == 0) tl.write(dc.prof + 32);
     {   // the last column of this phase may itself have summed to zero
         const uint32_t pb = (hi - 1) & 1u;
         const double Cj = lean_colsum<R>(sh, pb, lane);
@@ -2691,8 +2738,11 @@ DEVI void lean_backward(const DevContig& dc, LeanShared<R>& sh, uint32_t C, uint
     asm volatile("" : "+v"(one));
     // One column step (see lean_forward): `cur` = record t+1 (constants of the gap t -> t+1), `nxt` takes record t
     // (constants of the next step); `ec` = emissions of column t (this step's w), `en` takes those of column t-1.
+    LeanTimeline tl;
+    tl.init();
     auto step = [&](int64_t t, const FRec& cur, FRec& nxt) __attribute__((always_inline)) {
         const uint32_t n = (uint32_t)(t0 - t);        // step number: column t is the record with rel = n + 1
+        tl.template mark<0>(0.0);
         if (((n + 4u) % PG_LEAN_BLOCK) == 0u) {
             const uint32_t blk = (n + 4u) / PG_LEAN_BLOCK;
             recs.park(sh, blk, piece);
@@ -2707,7 +2757,9 @@ DEVI void lean_backward(const DevContig& dc, LeanShared<R>& sh, uint32_t C, uint
                                                         // at a barrier every column, one wave's extra instructions are everybody's wait)
         double k0 = ldexp(cur.c0, -es), k1 = ldexp(cur.c1, -es), k2 = ldexp(cur.c2, -es), kap = ldexp(cur.kappa, -es);
         pin_here(k0); pin_here(k1); pin_here(k2); pin_here(kap);   // (in front of the barrier, not behind it)
+        tl.template mark<1>(k0 + kap);                // exponent, scaled constants, scale mantissa parked
         lds_barrier();
+        tl.template mark<2>(0.0);                     // the barrier
         const uint32_t pb = (uint32_t)t & 1u;
         double pc[64 / R], pr[64 / R];  // (see lean_forward)
 #pragma unroll
@@ -2720,6 +2772,7 @@ DEVI void lean_backward(const DevContig& dc, LeanShared<R>& sh, uint32_t C, uint
         const u32x2 cdn = lean_pair_bytes(sh, n + 2u, wave);
         lean_fence();
         const double Cj = (pc[0] + pc[1]) + (pc[2] + pc[3]);
+        tl.template mark<3>(Cj);                      // the column sums are back from LDS (the next records read behind them)
         const v4f64 zz = {0.0, 0.0, 0.0, 0.0};
         const v4f64 ma = __builtin_amdgcn_mfma_f64_16x16x4f64(Cj, 1.0, zz, 0, 0, 0);
         lean_fence();
@@ -2727,11 +2780,13 @@ DEVI void lean_backward(const DevContig& dc, LeanShared<R>& sh, uint32_t C, uint
         const double urep = dpp_source(k1 * ((pr[0] + pr[1]) + (pr[2] + pr[3])));  // u_i of row i0 + (lane & 15)
         const LeanPairs lp = lean_pairs(sh, n + 2u, cdn, (uint32_t)((bits_n >> lane) & 1ull));   // column t-1
         const double msum = (ma[0] + ma[1]) + (ma[2] + ma[3]);
+        tl.template mark<4>(msum);                    // first MFMA + three adds
         lean_fence();
         const v4f64 mb = __builtin_amdgcn_mfma_f64_16x16x4f64(msum, 1.0, zz, 0, 0, 0);
         asm volatile("" :: "v"(mb));
         lean_fence();
         const double Sw = (kLeanExp & 4) ? 64.0 * Cj : mb[0];
+        tl.template mark<5>(Sw);                      // second MFMA: the total
         const double uj = fma(k2, Sw, ucol);
         const double Snew = kap * Sw;  // = sum(beta'_t)
         Sy = Snew;                     // (1 behind an all-zero column, below)
@@ -2744,6 +2799,7 @@ DEVI void lean_backward(const DevContig& dc, LeanShared<R>& sh, uint32_t C, uint
             part = fma(ec[k], yk, part);
             w[k] = ec[k] * yk;
             pin_here(w[k]);
+            if constexpr (k == 1) tl.template mark<6>(w[1]);    // u_j, the first row pair's states
             if constexpr (k & 1) {
                 if (!(kLeanExp & 1)) put_pair(dst, k >> 1, yprev, yk);
                 const v2f64 t2 = (kLeanExp & 2) ? v2f64{0.5, 0.5} : lean_pair<(k >> 1)>(lp);   // e_{t-1} of this row pair
@@ -2761,12 +2817,15 @@ DEVI void lean_backward(const DevContig& dc, LeanShared<R>& sh, uint32_t C, uint
             for (int k = 0; k < R; ++k) { w[k] = unif * et[k]; part += w[k]; }
             Sy = 1.0;
         }
+        tl.template mark<7>(part);                    // the other seven row pairs: states, stores, next emissions
         sh.psum[(uint32_t)(t - 1) & 1u][wave][lane] = part;
         if (wave == 2) { asm volatile("" ::: "memory"); bsm.put(lane, (uint64_t)t, Snew); }   // (a branch, not predication: three of the four waves skip it)
         if (((uint64_t)t & 63u) == 0u) {
             if (wave == 1) bsc.flush(bscale, lane, (uint64_t)t);
             if (wave == 2) bsm.flush(bsum, lane, (uint64_t)t);
         }
+        tl.template mark<8>(0.0);                     // partial sum parked, per-column scalars
+        tl.template fold<8>();
     };
     FRec rb2;
     int64_t t = t0;
@@ -2778,6 +2837,7 @@ DEVI void lean_backward(const DevContig& dc, LeanShared<R>& sh, uint32_t C, uint
     if (t >= bot) step(t, cur, rb2);
     if (wave == 1 && bsc.valid) bsc.flush(bscale, lane, (uint64_t)bot);
     if (wave == 2 && bsm.valid) bsm.flush(bsum, lane, (uint64_t)bot);
+    if (kLeanTimeline && tid == 0) tl.write(dc.prof + 48);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -3170,7 +3230,7 @@ __global__ __launch_bounds__((64 * 64 / R)) void k_sweep_lean(const DevContig* _
 template <int PHASE, int R, bool TRI>
 DEVI void sweep_lean_body(const DevContig* __restrict__ contigs, uint32_t chunk, LeanShared<R>& sh) {
     const DevContig& dc = contigs[blockIdx.x];
-    if (!dc.lean) return;
+    if (dc.lean != 1u) return;   // (2: the pipelined step, k_sweep_leanp)
     if ((dc.tri != 0u) != TRI) return;
     const uint32_t C = (uint32_t)__builtin_amdgcn_readfirstlane((int)*dc.n_cols);
     if (C == 0) return;
@@ -3182,6 +3242,8 @@ DEVI void sweep_lean_body(const DevContig* __restrict__ contigs, uint32_t chunk,
         o[0] = __builtin_amdgcn_s_memtime() - t_begin;
     }
 }
+
+#include "pg_lean_pipe.h"   // k_sweep_leanp: the pipelined lean step (lone chains)
 
 // ------------------------------------------------------------------------------------------
 //  k_sweep_leanx : the store-only phases (1, 3) of chains at HP = 128 whose objects all have at most PG_AMAX alleles
@@ -4773,6 +4835,8 @@ static void launch_sweep(const DevContig* d_contigs, uint32_t n_contigs, uint32_
                 hipLaunchKernelGGL((k_sweep_lean_tri<PHASE, 16>), dim3(n_contigs, 2), dim3(256), 0, s, d_contigs, chunk);
             else hipLaunchKernelGGL((k_sweep_lean<PHASE, 16, false>), dim3(n_contigs, 2), dim3(256), 0, s, d_contigs, chunk);
         }
+        if (hp_mask & 2048u)  // bit 11: lean chains on the pipelined step (DevContig::lean == 2: lone chains of chunked jobs)
+            hipLaunchKernelGGL((k_sweep_leanp<PHASE>), dim3(n_contigs, 2), dim3(256), 0, s, d_contigs, chunk);
         if (hp_mask & 512u)   // bit 9: the job has lean-x chains at HP = 128 (narrow columns only)
             hipLaunchKernelGGL((k_sweep_leanx<PHASE, 128>), dim3(n_contigs, 2), dim3(LxCfg<128>::T), 0, s, d_contigs, chunk);
         if (hp_mask & 1024u)  // bit 10: ... at HP = 64 (chains with multiallelic objects; all-biallelic H = 64 chains are bit 6)

@@ -209,6 +209,7 @@ namespace {
 struct IndexHost {   // one index contig
     uint32_t V = 0, H = 0, HP = 0, T = 0, RB = 0, part_slots = 2, pair_n = 1;
     bool lean = false;  // every object biallelic and H = HP = 64: the store-only phases run on k_sweep_lean
+    bool lean_pipe = false;  // ... of a chunked job (lone chains): on the pipelined step k_sweep_leanp (DevContig::lean == 2)
     bool cls4 = false;  // HP = 16 / 32, H = HP, every object biallelic, fused job: class sums instead of per-thread partials (DevContig::cls4)
     bool leanx = false; // HP = 128 / 64 and every object has at most PG_AMAX alleles (not `lean`): the store-only phases run on k_sweep_leanx
     bool small = false; // every object biallelic and H = HP = 16: the store-only phases run on k_sweep_small16
@@ -568,6 +569,10 @@ int job_build(int device, uint32_t n_index, const pg_contig_batch* batches, cons
         x.lean = lean_ok && x.HP == 64 && x.H == 64 && maxA == 2 && x.V > 0;
         x.small = lean_ok && x.HP == 16 && x.H == 16 && maxA == 2 && x.V > 0;   // (and enough of them: below)
         {
+            const char* e = getenv("PG_LEAN_PIPE");   // PG_LEAN_PIPE=0: the plain lean step (cross-check)
+            x.lean_pipe = x.lean && !(e && !strcmp(e, "0"));
+        }
+        {
             const char* e = getenv("PG_CLS4");    // PG_CLS4=0: per-thread partials + k_bins (cross-check)
             x.cls4 = (x.HP == 16 || x.HP == 32) && x.H == x.HP && maxA == 2 && x.V > 0 && !(e && !strcmp(e, "0"));
         }
@@ -701,7 +706,7 @@ int job_build(int device, uint32_t n_index, const pg_contig_batch* batches, cons
         p.vpair = take((size_t)x.V * pg_pair_bytes(x.pair_n));
         p.xbuf = take((x.HP >= 256 || (force_generic && x.HP >= 64)) ? (size_t)2 * x.HP * x.HP * sizeof(double) : 0);
         p.frec = take((x.lean || x.small) ? (size_t)x.V * 64 : 0);
-        if (x.lean) job->hp_mask |= 64u;
+        if (x.lean) job->hp_mask |= (x.lean_pipe && job->chunked) ? 2048u : 64u;
         if (x.leanx) job->hp_mask |= x.HP == 128 ? 512u : 1024u;
         p.fscale = take((size_t)x.V * sizeof(double));
         p.bscale = take((size_t)x.V * sizeof(double));
@@ -768,7 +773,7 @@ int job_build(int device, uint32_t n_index, const pg_contig_batch* batches, cons
         d.scratch = (double*)(A + p.scratch); d.chunk_cols = job->chunk_cols;
         d.wide = A + p.wide; d.wide_idx = x.wide_bytes ? (const uint32_t*)(A + x.o_widx) : nullptr;
         d.vpair = A + p.vpair; d.xbuf = (double*)(A + p.xbuf);
-        d.frec = (double*)(A + p.frec); d.lean = x.lean ? 1u : 0u; d.small = x.small ? 1u : 0u; d.leanx = x.leanx ? 1u : 0u; d.cls4 = x.cls4 ? 1u : 0u;
+        d.frec = (double*)(A + p.frec); d.lean = x.lean ? ((x.lean_pipe && job->chunked) ? 2u : 1u) : 0u; d.small = x.small ? 1u : 0u; d.leanx = x.leanx ? 1u : 0u; d.cls4 = x.cls4 ? 1u : 0u;
         d.prep_fast = x.prep_fast ? 1u : 0u;
         if (params->run_phasing) {
             d.vit_tq = (double*)(A + p.vtq); d.vit_back = (uint16_t*)(A + p.vback); d.vit_best = (uint32_t*)(A + p.vbest);

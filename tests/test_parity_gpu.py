@@ -313,23 +313,28 @@ def test_generic_kernel_cross_checks_register_kernels(H, orc, monkeypatch):
     assert float(np.where(den > 0, np.abs(a - c) / np.where(den > 0, den, 1), 0).max()) < 1e-11
 
 
+@pytest.mark.parametrize("pipe", ["1", "0"])
 @pytest.mark.parametrize("K", [1, 2, 7, 64, 4096])
-def test_lean_kernel_biallelic_h64_vs_oracle_and_general(K, orc, monkeypatch):
-    """All-biallelic H = 64 chains run their store-only phases on k_sweep_lean (scalar-loaded compact
-    records, MFMA totals).  Unregularised table: forward columns that fall back to uniform and all-zero
-    backward columns, on, before and behind chunk boundaries.  The lean and the general kernel must both
-    match the oracle and agree with each other to fp64 rounding."""
+def test_lean_kernel_biallelic_h64_vs_oracle_and_general(K, pipe, orc, monkeypatch):
+    """All-biallelic H = 64 chains of chunked jobs run their store-only phases on k_sweep_leanp — the pipelined lean step:
+    column sums in closed form, the LDS exchange beside the state block — or, with PG_LEAN_PIPE=0, on k_sweep_lean (the
+    plain step: MFMA totals behind the exchange).  Unregularised table: forward columns that fall back to uniform and
+    all-zero backward columns, on, before and behind chunk and record-block boundaries (330 and 131 columns: blocks of
+    64 records).  Either lean kernel and the general kernel must match the oracle and agree with each other to fp64
+    rounding."""
     monkeypatch.setenv("PG_SWEEP_MODE", "chunked")
     monkeypatch.setenv("PG_CHUNK_COLS", str(K))
-    for seed, reg in ((5, 0.0), (6, 0.01)):
+    for seed, reg, V in ((5, 0.0, 330), (6, 0.01, 330), (7, 0.0, 131), (8, 0.01, 3)):
         args = (6, 108, 54, reg)
-        b = synthetic_panel(330, 64, 20, seed=seed)
+        b = synthetic_panel(V, 64, 20, seed=seed)
         if reg == 0.0:
             b.kmer_count[::3] = 0
             b.kmer_count[1::17] = 60000
         t, p = hmm.ProbabilityTable(*args), hmm.make_params(1.26, False, 1e-5)
         monkeypatch.delenv("PG_SWEEP_KERNEL", raising=False)
+        monkeypatch.setenv("PG_LEAN_PIPE", pipe)
         lean = hmm.genotype_contig(b, t, p)
+        monkeypatch.delenv("PG_LEAN_PIPE", raising=False)
         monkeypatch.setenv("PG_SWEEP_KERNEL", "general")
         gen = hmm.genotype_contig(b, t, p)
         monkeypatch.delenv("PG_SWEEP_KERNEL", raising=False)
