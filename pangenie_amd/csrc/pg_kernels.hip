@@ -2374,7 +2374,12 @@ DEVI double lean_colsum(const LeanShared<R>& sh, uint32_t pb, uint32_t lane) {
 #ifndef PG_LEAN_EXP
 #define PG_LEAN_EXP 0
 #endif
-static constexpr unsigned kLeanExp = PG_LEAN_EXP;   // timing experiments (tools/exp_lean.py): 1 no column stores, 2 no emission fetches, 4 no MFMA total — results WRONG
+static constexpr unsigned kLeanExp = PG_LEAN_EXP;
+#ifdef PG_LEAN_DPPSUM   // experiment: the wave total by six DPP steps (wave_sum) instead of the two fp64 MFMAs
+static constexpr bool kLeanDppSum = true;
+#else
+static constexpr bool kLeanDppSum = false;
+#endif   // timing experiments (tools/exp_lean.py): 1 no column stores, 2 no emission fetches, 4 no MFMA total — results WRONG
 
 // -DPG_LEAN_TIMELINE builds only (tools/exp_pipe.py, profiles/r04_lean_chain.txt): s_memtime stamps at the segment
 // boundaries of one column step of wave 0, each issued behind a use of the value that ends the segment; the stamps are
@@ -2552,7 +2557,7 @@ DEVI void lean_forward(const DevContig& dc, LeanShared<R>& sh, uint32_t C, uint3
         const double Cj = (pc[0] + pc[1]) + (pc[2] + pc[3]);
         tl.template mark<1>(Cj);                      // the column sums are back from LDS
         const v4f64 zz = {0.0, 0.0, 0.0, 0.0};
-        const v4f64 ma = __builtin_amdgcn_mfma_f64_16x16x4f64(Cj, 1.0, zz, 0, 0, 0);
+        const v4f64 ma = kLeanDppSum ? zz : __builtin_amdgcn_mfma_f64_16x16x4f64(Cj, 1.0, zz, 0, 0, 0);
         lean_fence();
         const double ucol = cur.c1 * Cj;
         const double urep = dpp_source(cur.c1 * ((pr[0] + pr[1]) + (pr[2] + pr[3])));
@@ -2560,10 +2565,10 @@ DEVI void lean_forward(const DevContig& dc, LeanShared<R>& sh, uint32_t C, uint3
         const double msum = (ma[0] + ma[1]) + (ma[2] + ma[3]);
         tl.template mark<2>(msum);                    // first MFMA + three adds
         lean_fence();
-        const v4f64 mb = __builtin_amdgcn_mfma_f64_16x16x4f64(msum, 1.0, zz, 0, 0, 0);
+        const v4f64 mb = kLeanDppSum ? zz : __builtin_amdgcn_mfma_f64_16x16x4f64(msum, 1.0, zz, 0, 0, 0);
         asm volatile("" :: "v"(mb));   // (the whole result stays allocated: a temporary in one of its registers would wait out the MFMA)
         lean_fence();
-        double S = (kLeanExp & 4) ? 64.0 * Cj : mb[0];
+        double S = (kLeanExp & 4) ? 64.0 * Cj : (kLeanDppSum ? wave_sum(Cj) : mb[0]);
         tl.template mark<3>(S);                       // second MFMA: the total
         double uj = fma(cur.c2, S, ucol);
         double c0 = cur.c0;
@@ -2774,7 +2779,7 @@ DEVI void lean_backward(const DevContig& dc, LeanShared<R>& sh, uint32_t C, uint
         const double Cj = (pc[0] + pc[1]) + (pc[2] + pc[3]);
         tl.template mark<3>(Cj);                      // the column sums are back from LDS (the next records read behind them)
         const v4f64 zz = {0.0, 0.0, 0.0, 0.0};
-        const v4f64 ma = __builtin_amdgcn_mfma_f64_16x16x4f64(Cj, 1.0, zz, 0, 0, 0);
+        const v4f64 ma = kLeanDppSum ? zz : __builtin_amdgcn_mfma_f64_16x16x4f64(Cj, 1.0, zz, 0, 0, 0);
         lean_fence();
         const double ucol = k1 * Cj;
         const double urep = dpp_source(k1 * ((pr[0] + pr[1]) + (pr[2] + pr[3])));  // u_i of row i0 + (lane & 15)
@@ -2782,10 +2787,10 @@ DEVI void lean_backward(const DevContig& dc, LeanShared<R>& sh, uint32_t C, uint
         const double msum = (ma[0] + ma[1]) + (ma[2] + ma[3]);
         tl.template mark<4>(msum);                    // first MFMA + three adds
         lean_fence();
-        const v4f64 mb = __builtin_amdgcn_mfma_f64_16x16x4f64(msum, 1.0, zz, 0, 0, 0);
+        const v4f64 mb = kLeanDppSum ? zz : __builtin_amdgcn_mfma_f64_16x16x4f64(msum, 1.0, zz, 0, 0, 0);
         asm volatile("" :: "v"(mb));
         lean_fence();
-        const double Sw = (kLeanExp & 4) ? 64.0 * Cj : mb[0];
+        const double Sw = (kLeanExp & 4) ? 64.0 * Cj : (kLeanDppSum ? wave_sum(Cj) : mb[0]);
         tl.template mark<5>(Sw);                      // second MFMA: the total
         const double uj = fma(k2, Sw, ucol);
         const double Snew = kap * Sw;  // = sum(beta'_t)

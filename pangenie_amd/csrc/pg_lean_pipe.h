@@ -48,17 +48,27 @@ struct PipeCol {
     uint32_t tbase, nbase, cd0, cd1;
     double ajf;
 };
-DEVI PipeCol leanp_col(const LeanSharedP& sh, uint32_t rel /*uniform*/, uint32_t wave /*uniform*/, uint32_t lane) {
-    const uint32_t b = (rel / PG_LEAN_BLOCK) & 1u, r = rel % PG_LEAN_BLOCK;
-    const unsigned long long bits = (unsigned long long)__double_as_longlong(sh.rec[b][r][7]);
-    const uint32_t aj = (uint32_t)((bits >> lane) & 1ull);
-    const u32x2 cd = *(const u32x2*)&sh.comb[b][r][wave][0];
+// (the two blocks of every per-record array are contiguous: record `rel` lies at entry rel & 127)
+struct PipeRaw { unsigned long long bits; u32x2 cd; };   // what a column's descriptor is made of: two LDS reads, issued a step early
+DEVI PipeRaw leanp_raw(const LeanSharedP& sh, uint32_t rel /*uniform*/, uint32_t wave /*uniform*/) {
+    const uint32_t r = rel & (2u * PG_LEAN_BLOCK - 1u);
+    PipeRaw w;
+    w.bits = (unsigned long long)__double_as_longlong((&sh.rec[0][0][0])[r * 8u + 7u]);
+    w.cd = *(const u32x2*)((&sh.comb[0][0][0][0]) + r * 32u + wave * 8u);
+    return w;
+}
+DEVI PipeCol leanp_col_of(const LeanSharedP& sh, const PipeRaw& w, uint32_t rel /*uniform*/, uint32_t lane) {
+    const uint32_t r = rel & (2u * PG_LEAN_BLOCK - 1u);
+    const uint32_t aj = (uint32_t)((w.bits >> lane) & 1ull);
     PipeCol pc;
-    pc.tbase = (uint32_t)(uintptr_t)(LAS const unsigned char*)&sh.tab[b][r][0][0] + aj * 16u;
-    pc.nbase = (uint32_t)(uintptr_t)(LAS const unsigned char*)&sh.nn[b][r][0] + aj * 8u;
-    pc.cd0 = cd.x; pc.cd1 = cd.y;
+    pc.tbase = (uint32_t)(uintptr_t)(LAS const unsigned char*)&sh.tab[0][0][0][0] + r * 128u + aj * 16u;
+    pc.nbase = (uint32_t)(uintptr_t)(LAS const unsigned char*)&sh.nn[0][0][0] + r * 16u + aj * 8u;
+    pc.cd0 = w.cd.x; pc.cd1 = w.cd.y;
     pc.ajf = (double)aj;
     return pc;
+}
+DEVI PipeCol leanp_col(const LeanSharedP& sh, uint32_t rel /*uniform*/, uint32_t wave /*uniform*/, uint32_t lane) {
+    return leanp_col_of(sh, leanp_raw(sh, rel, wave), rel, lane);
 }
 template <int P>
 DEVI v2f64 leanp_pair(const PipeCol& pc) {   // {e(row 2P, lane), e(row 2P + 1, lane)} of the column
@@ -71,10 +81,10 @@ DEVI v2f64 leanp_T(const PipeCol& pc) { return *(LAS const v2f64*)(uintptr_t)(pc
 DEVI double leanp_N(const PipeCol& pc) { return *(LAS const double*)(uintptr_t)pc.nbase; }
 
 template <int CTRL, int ROW_MASK>
-DEVI double dpp_keep_f64(double v) {
+DEVI double dpp_keep_f64(double v) {   // (rows outside the row mask: whatever the destination held — never read)
     int lo = __double2loint(v), hi = __double2hiint(v);
-    lo = __builtin_amdgcn_update_dpp(lo, lo, CTRL, ROW_MASK, 0xF, false);
-    hi = __builtin_amdgcn_update_dpp(hi, hi, CTRL, ROW_MASK, 0xF, false);
+    lo = __builtin_amdgcn_mov_dpp(lo, CTRL, ROW_MASK, 0xF, false);
+    hi = __builtin_amdgcn_mov_dpp(hi, CTRL, ROW_MASK, 0xF, false);
     return __hiloint2double(hi, lo);
 }
 // one level of the two wave totals (row_shr 1, 2, 4, 8 inside the DPP rows, then row_bcast 15 / 31 across them: the
@@ -116,10 +126,34 @@ DEVI PipeCarry leanp_prime(LeanSharedP& sh, const double (&v)[16], const double 
     return c;
 }
 
+// One state in ONE asm statement: P' = acc + u[row lane K] * sc (DP-ALU DPP fmac, see fmac_row_bcast), the Y term of
+// the state before (independent: it sits in the slot behind the DPP operation), x = e * P'.  hipcc pads every inline asm
+// whose result the next VALU instruction reads with an s_nop (it cannot see that the asm holds no SDWA destination
+// select): three instructions in one statement leave nothing to pad — 33 s_nop per step otherwise.
+template <int K>
+DEVI void leanp_state(double& acc /*in: c0 x + u_j, out: P'*/, double u, double sc, double& yacc, double ya, double yb, double& xn, double e) {
+    asm("v_fmac_f64_dpp %0, %3, %4 row_newbcast:%8 row_mask:0xf bank_mask:0xf\n\t"
+        "v_fmac_f64_e32 %1, %5, %6\n\t"
+        "v_mul_f64 %2, %7, %0"
+        : "+v"(acc), "+v"(yacc), "=v"(xn) : "v"(u), "v"(sc), "v"(ya), "v"(yb), "v"(e), "n"(K));
+}
+template <int K>
+DEVI void leanp_state0(double& acc, double u, double sc, double& xn, double e) {   // (the first state: no Y term yet)
+    asm("v_fmac_f64_dpp %0, %2, %3 row_newbcast:%5 row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 0\n\t"
+        "v_mul_f64 %1, %4, %0"
+        : "+v"(acc), "=v"(xn) : "v"(u), "v"(sc), "v"(e), "n"(K));
+}
 #ifndef PG_LEANP_EXP
 #define PG_LEANP_EXP 0
 #endif
 static constexpr unsigned kLeanpExp = PG_LEANP_EXP;   // timing experiments (results WRONG): 1 no column stores, 2 no wave totals
+
+// the per-record arrays hold two blocks: block b is parked PARK_AHEAD steps before its first record is read
+// (a step reads up to record n + 4: the raw descriptor of the column three steps on) and expanded a step later
+#define PG_LEANP_PARK 6u
+
+struct PipeFwdK { double c0s, c1s, ujs, sc, urep; };   // constants of a forward step
 
 template <int PHASE>
 DEVI void leanp_forward(const DevContig& dc, LeanSharedP& sh, uint32_t C, uint32_t chunk) {
@@ -140,7 +174,7 @@ DEVI void leanp_forward(const DevContig& dc, LeanSharedP& sh, uint32_t C, uint32
     const uint32_t i0 = wave * R;
     const size_t colsz = (size_t)HP * HP;
     const double unif = 1.0 / 4096.0;
-    LeanRecs recs{(const GAS char*)dc.frec, (int64_t)first - 1, (int64_t)C, +1, tid};
+    LeanRecs recs{(const GAS char*)dc.frec, (int64_t)first - 1, (int64_t)C, +1, tid};   // rel k = column first - 1 + k
     recs.park(sh, 0, recs.fetch(0));
     v2f64 piece = recs.fetch(1);
     lds_barrier();
@@ -200,100 +234,117 @@ DEVI void leanp_forward(const DevContig& dc, LeanSharedP& sh, uint32_t C, uint32
     // the Y partials; a pair of eC is overwritten with the column after next's right after its two states used it.
     double ea[R], eb[R];
     PipeCol pa = leanp_col(sh, 1, wave, lane), pb_ = leanp_col(sh, 2, wave, lane);   // columns first, first + 1
+    PipeRaw raw = leanp_raw(sh, 3, wave);                                             // column first + 2: what the first step makes its p2 of
     leanp_pairs_all(pa, ea);
     leanp_pairs_all(pb_, eb);
     PipeCarry cy = leanp_prime(sh, x, ea, pa.ajf, (first - 1) & 1u, wave, lane);
-    // constants of a step, formed at the end of the step before (S = total of the column the step starts from)
-    double c0s, c1s, ujs, sc, urep;
-    auto prepare = [&](uint32_t tn, double c0, double c1, double c2) __attribute__((always_inline)) {
-        double S = cy.Q0 + cy.Q1;
-        double uj = fma(c2, S, c1 * cy.Cj);
-        if (__builtin_expect(!(S > 0.0), 0)) {
-            // column tn - 1 summed to zero: the uniform column takes its place (hmm.cpp:253-267), see lean_forward — every x,
-            // every column sum and both class totals are 0, the whole uniform step rides on u_j
-            flag_uniform(tn - 1);
+    // Constants of step tn from the totals of column tn - 1 (S = 0: that column summed to zero — the uniform column takes
+    // its place, hmm.cpp:253-267: every x, every column sum and both class totals are 0, the whole uniform step rides on
+    // u_j; the caller stores the uniform column and raises the flag once the column's own stores are out).
+    auto constants = [&](uint32_t tn, double c0, double c1, double c2, const PipeCarry& c, bool& fb, double& m) __attribute__((always_inline)) {
+        double S = c.Q0 + c.Q1;
+        double uj = fma(c2, S, c1 * c.Cj);
+        fb = !(S > 0.0);
+        if (__builtin_expect(fb, 0)) {
             S = 1.0;
             uj = fma(c0, unif, fma(c2, 1.0, 2.0 * c1 * (64.0 * unif)));
             c0 = 0.0;
         }
-        if (tn < hi) {
-            int es = exponent_of(S) - PG_BIAS_F;
-            es = es < -900 ? -900 : es;
-            const double m = ldexp(S, -es - PG_BIAS_F);
-            sc = ldexp(1.0, -es); c0s = ldexp(c0, -es); c1s = ldexp(c1, -es); ujs = ldexp(uj, -es);
-            urep = dpp_source(c1 * cy.Crep);
-            if (wave == 0) {  // (scalar branch)
-                fsc.put(lane, tn, m);
-                if ((tn & 63u) == 63u) fsc.flush(fscale, lane, tn);
-            }
+        int es = exponent_of(S) - PG_BIAS_F;
+        es = es < -900 ? -900 : es;
+        m = ldexp(S, -es - PG_BIAS_F);
+        PipeFwdK k;
+        k.sc = ldexp(1.0, -es); k.c0s = ldexp(c0, -es); k.c1s = ldexp(c1, -es); k.ujs = ldexp(uj, -es);
+        k.urep = dpp_source(c1 * c.Crep);
+        return k;
+    };
+    auto put_scale = [&](uint32_t tn, double m) __attribute__((always_inline)) {
+        if (wave == 0) {  // (scalar branch)
+            fsc.put(lane, tn, m);
+            if ((tn & 63u) == 63u) fsc.flush(fscale, lane, tn);
         }
     };
+    PipeFwdK kc;
     {
         const FRec r1 = read_frec(sh, 1);
-        prepare(first, r1.c0, r1.c1, r1.c2);
+        bool fb; double m;
+        kc = constants(first, r1.c0, r1.c1, r1.c2, cy, fb, m);
+        if (fb) flag_uniform(first - 1);
+        if (first < hi) put_scale(first, m);
     }
-    // One column step: eC / pC = emissions / table of column t, eN / pN = of column t + 1; pC ends up as column t + 2's.
+    // One column step: eC / pC = emissions / descriptor of column t, eN / pN = of column t + 1; pC ends up as column
+    // t + 2's.  The chain of the column sums of THIS column is sliced between the sixteen states (static `slot`).
     auto step = [&](uint32_t t, double (&eC)[R], double (&eN)[R], PipeCol& pC, const PipeCol& pN) __attribute__((always_inline)) {
         const uint32_t n = t - first;                 // column t = rel n + 1
         const uint32_t pbuf = (t - 1) & 1u;
+        const PipeFwdK k = kc;
         double yq[4];
 #pragma unroll
         for (int q = 0; q < 4; ++q) yq[q] = sh.psum[pbuf][q][lane];
         const v2f64 Tj = leanp_T(pC);
         const double Nj = leanp_N(pC);
-        const double* rn = sh.rec[((n + 2u) / PG_LEAN_BLOCK) & 1u][(n + 2u) % PG_LEAN_BLOCK];   // record t + 1: the next step's constants
+        const double* rn = (&sh.rec[0][0][0]) + ((n + 2u) & (2u * PG_LEAN_BLOCK - 1u)) * 8u;   // record t + 1: the next step's constants
         const v2f64 n01 = *(const v2f64*)rn;
         const double n2 = rn[2];
-        if (((n + 5u) % PG_LEAN_BLOCK) == 0u) {       // (uniform) a few columns before the next block is needed
-            const uint32_t blk = (n + 5u) / PG_LEAN_BLOCK;
+        const PipeCol p2 = leanp_col_of(sh, raw, n + 3u, lane);   // column t + 2 (its two LDS reads were issued a step ago)
+        if (((n + PG_LEANP_PARK) % PG_LEAN_BLOCK) == 0u) {        // (uniform) a few columns before the next block is needed
+            const uint32_t blk = (n + PG_LEANP_PARK) / PG_LEAN_BLOCK;
             recs.park(sh, blk, piece);
             piece = recs.fetch(blk + 1u);
-        } else if (((n + 4u) % PG_LEAN_BLOCK) == 0u) {
-            leanp_expand(sh, (n + 4u) / PG_LEAN_BLOCK, tid);   // the block parked a step ago (a barrier lies between)
+        } else if (((n + PG_LEANP_PARK - 1u) % PG_LEAN_BLOCK) == 0u) {
+            leanp_expand(sh, (n + PG_LEANP_PARK - 1u) / PG_LEAN_BLOCK, tid);   // the block parked a step ago (a barrier lies between)
         }
-        const PipeCol p2 = leanp_col(sh, n + 3u, wave, lane);   // column t + 2
         gdouble2* dst = (gdouble2*)(wr + (size_t)t * colsz) + toff;
-        double yp = 0.0, yp2 = 0.0;
-        double Y = 0.0, Cn = 0.0, m0 = 0.0, m1 = 0.0, Crn = 0.0;
+        double yp = 0.0, yp2 = 0.0, pprev = 0.0, sprev0 = 0.0, sprev1 = 0.0;
+        double Y = 0.0, m0 = 0.0, m1 = 0.0, mn = 0.0;
+        PipeCarry cn{0.0, 0.0, 0.0, 0.0};
+        PipeFwdK kn = k;
+        bool fb = false;
         lean_fence();
-        static_for<0, R / 2>([&](auto qc) __attribute__((always_inline)) {
-            constexpr int q = decltype(qc)::value, k = 2 * q;
-            const double pa_ = fmac_row_bcast<k>(fma(c0s, x[k], ujs), urep, sc);          // P'_t(i0 + k, lane) 2^-es = c0 x + u_j + u_i
-            const double pb2 = fmac_row_bcast<k + 1>(fma(c0s, x[k + 1], ujs), urep, sc);
-            if constexpr (q > 0) {   // (the Y terms of the pair before: they fill the wait states behind the two DPP operations)
-                yp = fma(eN[k - 2], x[k - 2], yp); yp2 = fma(eN[k - 1], x[k - 1], yp2);
-                pin_here(yp); pin_here(yp2);
-            }
-            x[k] = eC[k] * pa_; x[k + 1] = eC[k + 1] * pb2;
-            pin_here(x[k]); pin_here(x[k + 1]);
-            // ---- a slice of the column-sum chain of THIS column (independent of the state block) ----
-            if constexpr (q == 0) {
-                Y = (yq[0] + yq[1]) + (yq[2] + yq[3]);
-            } else if constexpr (q == 1) {
-                const double W = fma(Tj.y, cy.Q1, Tj.x * cy.Q0);
-                Cn = fma(c0s, Y, fma(c1s, W, ujs * Nj));
-                sh.u[wave][lane] = Cn;
-                m1 = Cn * pN.ajf; m0 = Cn - m1;
-            } else if constexpr (q == 2) {
-                if (!(kLeanpExp & 2)) leanp_level<0>(m0, m1);
-                Crn = sh.u[wave][i0 + (lane & 15u)];
-            } else if constexpr (q == 3) { if (!(kLeanpExp & 2)) leanp_level<1>(m0, m1); }
-            else if constexpr (q == 4) { if (!(kLeanpExp & 2)) leanp_level<2>(m0, m1); }
-            else if constexpr (q == 5) { if (!(kLeanpExp & 2)) leanp_level<3>(m0, m1); }
-            else if constexpr (q == 6) { if (!(kLeanpExp & 2)) leanp_level<4>(m0, m1); }
-            else { if (!(kLeanpExp & 2)) leanp_level<5>(m0, m1); }
-            if (!(kLeanpExp & 1)) dst[(size_t)q * HP] = v2f64{pa_, pb2};
-            const v2f64 t2 = leanp_pair<q>(p2);   // e_{t+2} of this row pair
-            eC[k] = t2.x; eC[k + 1] = t2.y;
+        static_for<0, R>([&](auto kcst) __attribute__((always_inline)) {
+            constexpr int s = decltype(kcst)::value;
+            double pk = fma(k.c0s, x[s], k.ujs);       // P'_t(i0 + s, lane) 2^-es = c0 x + u_j + u_i
+            if constexpr (s == 0) leanp_state0<s>(pk, k.urep, k.sc, x[s], eC[s]);
+            else if constexpr (s & 1) leanp_state<s>(pk, k.urep, k.sc, yp, eN[s - 1], x[s - 1], x[s], eC[s]);
+            else leanp_state<s>(pk, k.urep, k.sc, yp2, eN[s - 1], x[s - 1], x[s], eC[s]);
+            if constexpr (s & 1) {
+                constexpr int q = s >> 1;
+                // (a pair's store goes out one pair late: its registers are then not the ones the next states are formed in —
+                // a store's data registers must not be rewritten within two wait states)
+                if constexpr (q > 0) { if (!(kLeanpExp & 1)) dst[(size_t)(q - 1) * HP] = v2f64{sprev0, sprev1}; }
+                sprev0 = pprev; sprev1 = pk;
+                const v2f64 t2 = leanp_pair<q>(p2);   // e_{t+2} of this row pair
+                eC[s - 1] = t2.x; eC[s] = t2.y;
+            } else pprev = pk;
             lean_fence();
+            // ---- slot s of the column-sum chain of THIS column (independent of the state block) ----
+            if constexpr (s == 2) {
+                Y = (yq[0] + yq[1]) + (yq[2] + yq[3]);
+            } else if constexpr (s == 3) {
+                const double W = fma(Tj.y, cy.Q1, Tj.x * cy.Q0);
+                cn.Cj = fma(k.c0s, Y, fma(k.c1s, W, k.ujs * Nj));
+                sh.u[wave][lane] = cn.Cj;
+                m1 = cn.Cj * pN.ajf; m0 = cn.Cj - m1;
+            } else if constexpr (s >= 4 && s <= 9) {
+                if (!(kLeanpExp & 2)) leanp_level<s - 4>(m0, m1);
+                if constexpr (s == 7) cn.Crep = sh.u[wave][i0 + (lane & 15u)];
+            } else if constexpr (s == 10) {
+                cn.Q0 = readlane_f64(m0, 63); cn.Q1 = readlane_f64(m1, 63);
+            } else if constexpr (s == 11) {
+                kn = constants(t + 1u, n01.x, n01.y, n2, cn, fb, mn);
+                pin_here(kn.sc); pin_here(kn.c0s); pin_here(kn.c1s); pin_here(kn.ujs); pin_here(kn.urep); pin_here(mn);   // (here, not sunk behind the branches below)
+            } else if constexpr (s == 13) {
+                raw = leanp_raw(sh, n + 4u, wave);   // column t + 3: next step's p2
+            }
+            if constexpr (s >= 2 && s <= 13) lean_fence();
         });
-        yp = fma(eN[R - 2], x[R - 2], yp); yp2 = fma(eN[R - 1], x[R - 1], yp2);
-        yp += yp2;
-        sh.psum[t & 1u][wave][lane] = yp;
-        cy.Cj = Cn; cy.Crep = Crn;
-        cy.Q0 = readlane_f64(m0, 63); cy.Q1 = readlane_f64(m1, 63);
+        yp = fma(eN[R - 1], x[R - 1], yp);
+        if (!(kLeanpExp & 1)) dst[(size_t)(R / 2 - 1) * HP] = v2f64{sprev0, sprev1};
+        sh.psum[t & 1u][wave][lane] = yp + yp2;
+        if (__builtin_expect(fb, 0)) flag_uniform(t);   // (behind the column's own stores)
+        if (t + 1u < hi) put_scale(t + 1u, mn);
+        cy = cn; kc = kn;
         pC = p2;
-        prepare(t + 1u, n01.x, n01.y, n2);
         lds_barrier();
     };
     __builtin_amdgcn_s_waitcnt(0x0F70);   // (see lean_forward: no load of the prologue is still in flight inside the loop)
@@ -305,6 +356,8 @@ DEVI void leanp_forward(const DevContig& dc, LeanSharedP& sh, uint32_t C, uint32
     if (t < hi) step(t, ea, eb, pa, pb_);
     if (wave == 0 && fsc.valid) fsc.flush(fscale, lane, hi - 1);
 }
+
+struct PipeBwdK { double k0, k1, uj, urep, Snew; };   // constants of a backward step; Snew = sum of the column it stores
 
 template <int PHASE>
 DEVI void leanp_backward(const DevContig& dc, LeanSharedP& sh, uint32_t C, uint32_t chunk) {
@@ -379,28 +432,28 @@ DEVI void leanp_backward(const DevContig& dc, LeanSharedP& sh, uint32_t C, uint3
     }
     double ea[R], eb[R];
     PipeCol pa = leanp_col(sh, 1, wave, lane), pb_ = leanp_col(sh, 2, wave, lane);   // columns t0, t0 - 1
+    PipeRaw raw = leanp_raw(sh, 3, wave);                                             // column t0 - 2
     leanp_pairs_all(pa, ea);
     leanp_pairs_all(pb_, eb);
     PipeCarry cy = leanp_prime(sh, w, ea, pa.ajf, (uint32_t)t0 & 1u, wave, lane);
     double one = 1.0;   // (in a register for the whole sweep: the DPP form of v_fmac_f64 takes no constant)
     asm volatile("" : "+v"(one));
-    // constants of step t (record t + 1: the gap t -> t + 1), formed at the end of the step before: the scale from
-    // Sy = sum(beta'_{t+1}), the sum of the column this step stores, the zero rule
-    double k0, k1, uj, urep;
-    bool zero = false;
-    auto prepare = [&](int64_t tn, double c0, double c1, double c2, double kappa) __attribute__((always_inline)) {
-        if (tn < bot) return;
-        const double Sw = cy.Q0 + cy.Q1;
-        int es = exponent_of(Sy) - PG_BIAS_B;
+    // Constants of step tn (record tn + 1: the gap tn -> tn + 1) from the totals of w = beta'_{tn+1} . e_{tn+1}: the scale
+    // from sy = sum(beta'_{tn+1}), the sum of the column the step stores (Snew == 0: the zero rule, in the step itself)
+    auto constants = [&](double c0, double c1, double c2, double kappa, const PipeCarry& c, double sy, double& m) __attribute__((always_inline)) {
+        const double Sw = c.Q0 + c.Q1;
+        int es = exponent_of(sy) - PG_BIAS_B;
         es = es < -900 ? -900 : es;
-        const double m = ldexp(Sy, -es - PG_BIAS_B);
-        k0 = ldexp(c0, -es); k1 = ldexp(c1, -es);
+        m = ldexp(sy, -es - PG_BIAS_B);
+        PipeBwdK k;
+        k.k0 = ldexp(c0, -es); k.k1 = ldexp(c1, -es);
         const double k2 = ldexp(c2, -es), kap = ldexp(kappa, -es);
-        uj = fma(k2, Sw, k1 * cy.Cj);
-        urep = dpp_source(k1 * cy.Crep);
-        const double Snew = kap * Sw;   // = sum(beta'_tn)
-        Sy = Snew;
-        zero = !(Snew > 0.0);
+        k.uj = fma(k2, Sw, k.k1 * c.Cj);
+        k.urep = dpp_source(k.k1 * c.Crep);
+        k.Snew = kap * Sw;   // = sum(beta'_tn)
+        return k;
+    };
+    auto put_scalars = [&](int64_t tn, double m, double Snew) __attribute__((always_inline)) {
         if (wave == 1) { asm volatile("" ::: "memory"); bsc.put(lane, (uint64_t)tn, m); }
         if (wave == 2) { asm volatile("" ::: "memory"); bsm.put(lane, (uint64_t)tn, Snew); }
         if (((uint64_t)tn & 63u) == 0u) {
@@ -408,83 +461,92 @@ DEVI void leanp_backward(const DevContig& dc, LeanSharedP& sh, uint32_t C, uint3
             if (wave == 2) bsm.flush(bsum, lane, (uint64_t)tn);
         }
     };
-    {
+    PipeBwdK kc{0.0, 0.0, 0.0, 0.0, 0.0};
+    if (t0 >= bot) {
         const FRec cur = read_frec(sh, 0);
-        prepare(t0, cur.c0, cur.c1, cur.c2, cur.kappa);
+        double m;
+        kc = constants(cur.c0, cur.c1, cur.c2, cur.kappa, cy, Sy, m);
+        put_scalars(t0, m, kc.Snew);
     }
-    // One column step: eC / pC = emissions / table of column t, eN / pN = of column t - 1; pC ends up as column t - 2's.
+    // One column step: eC / pC = emissions / descriptor of column t, eN / pN = of column t - 1; pC ends up as column t - 2's.
     auto step = [&](int64_t t, double (&eC)[R], double (&eN)[R], PipeCol& pC, const PipeCol& pN) __attribute__((always_inline)) {
         const uint32_t n = (uint32_t)(t0 - t);        // column t = rel n + 1
         const uint32_t pbuf = (uint32_t)t & 1u;
+        const PipeBwdK k = kc;
+        const bool zero_t = !(k.Snew > 0.0);          // beta~_t is all zero (below)
         double yq[4];
 #pragma unroll
         for (int q = 0; q < 4; ++q) yq[q] = sh.psum[pbuf][q][lane];
         const v2f64 Tj = leanp_T(pC);
         const double Nj = leanp_N(pC);
-        const double* rn = sh.rec[((n + 1u) / PG_LEAN_BLOCK) & 1u][(n + 1u) % PG_LEAN_BLOCK];   // record t: the next step's constants
+        const double* rn = (&sh.rec[0][0][0]) + ((n + 1u) & (2u * PG_LEAN_BLOCK - 1u)) * 8u;   // record t: the next step's constants
         const v2f64 n01 = *(const v2f64*)rn, n23 = *(const v2f64*)(rn + 2);
-        if (((n + 5u) % PG_LEAN_BLOCK) == 0u) {
-            const uint32_t blk = (n + 5u) / PG_LEAN_BLOCK;
+        const PipeCol p2 = leanp_col_of(sh, raw, n + 3u, lane);   // column t - 2
+        if (((n + PG_LEANP_PARK) % PG_LEAN_BLOCK) == 0u) {
+            const uint32_t blk = (n + PG_LEANP_PARK) / PG_LEAN_BLOCK;
             recs.park(sh, blk, piece);
             piece = recs.fetch(blk + 1u);
-        } else if (((n + 4u) % PG_LEAN_BLOCK) == 0u) {
-            leanp_expand(sh, (n + 4u) / PG_LEAN_BLOCK, tid);
+        } else if (((n + PG_LEANP_PARK - 1u) % PG_LEAN_BLOCK) == 0u) {
+            leanp_expand(sh, (n + PG_LEANP_PARK - 1u) / PG_LEAN_BLOCK, tid);
         }
-        const PipeCol p2 = leanp_col(sh, n + 3u, wave, lane);   // column t - 2
         gdouble2* dst = (gdouble2*)(wr + (size_t)t * colsz) + toff;
-        const bool zero_t = zero;
-        double yp = 0.0, yp2 = 0.0;
-        double Y = 0.0, Cn = 0.0, m0 = 0.0, m1 = 0.0, Crn = 0.0;
+        double yp = 0.0, yp2 = 0.0, yprev = 0.0, sprev0 = 0.0, sprev1 = 0.0;
+        double Y = 0.0, m0 = 0.0, m1 = 0.0, mn = 0.0;
+        PipeCarry cn{0.0, 0.0, 0.0, 0.0};
+        PipeBwdK kn = k;
         lean_fence();
-        static_for<0, R / 2>([&](auto qc) __attribute__((always_inline)) {
-            constexpr int q = decltype(qc)::value, k = 2 * q;
-            const double ya = fmac_row_bcast<k>(fma(k0, w[k], uj), urep, one);          // beta'_t = k0 w + u_j + u_i
-            const double yb = fmac_row_bcast<k + 1>(fma(k0, w[k + 1], uj), urep, one);
-            if constexpr (q > 0) {
-                yp = fma(eN[k - 2], w[k - 2], yp); yp2 = fma(eN[k - 1], w[k - 1], yp2);
-                pin_here(yp); pin_here(yp2);
-            }
-            w[k] = eC[k] * ya; w[k + 1] = eC[k + 1] * yb;
-            pin_here(w[k]); pin_here(w[k + 1]);
-            if constexpr (q == 0) {
-                Y = (yq[0] + yq[1]) + (yq[2] + yq[3]);
-            } else if constexpr (q == 1) {
-                const double W = fma(Tj.y, cy.Q1, Tj.x * cy.Q0);
-                Cn = fma(k0, Y, fma(k1, W, uj * Nj));
-                sh.u[wave][lane] = Cn;
-                m1 = Cn * pN.ajf; m0 = Cn - m1;
-            } else if constexpr (q == 2) {
-                if (!(kLeanpExp & 2)) leanp_level<0>(m0, m1);
-                Crn = sh.u[wave][i0 + (lane & 15u)];
-            } else if constexpr (q == 3) { if (!(kLeanpExp & 2)) leanp_level<1>(m0, m1); }
-            else if constexpr (q == 4) { if (!(kLeanpExp & 2)) leanp_level<2>(m0, m1); }
-            else if constexpr (q == 5) { if (!(kLeanpExp & 2)) leanp_level<3>(m0, m1); }
-            else if constexpr (q == 6) { if (!(kLeanpExp & 2)) leanp_level<4>(m0, m1); }
-            else { if (!(kLeanpExp & 2)) leanp_level<5>(m0, m1); }
-            if (!(kLeanpExp & 1)) dst[(size_t)q * HP] = v2f64{ya, yb};
-            const v2f64 t2 = leanp_pair<q>(p2);   // e_{t-2} of this row pair
-            eC[k] = t2.x; eC[k + 1] = t2.y;
+        static_for<0, R>([&](auto kcst) __attribute__((always_inline)) {
+            constexpr int s = decltype(kcst)::value;
+            double yk = fma(k.k0, w[s], k.uj);           // beta'_t = k0 w + u_j + u_i
+            if constexpr (s == 0) leanp_state0<s>(yk, k.urep, one, w[s], eC[s]);
+            else if constexpr (s & 1) leanp_state<s>(yk, k.urep, one, yp, eN[s - 1], w[s - 1], w[s], eC[s]);
+            else leanp_state<s>(yk, k.urep, one, yp2, eN[s - 1], w[s - 1], w[s], eC[s]);
+            if constexpr (s & 1) {
+                constexpr int q = s >> 1;
+                if constexpr (q > 0) { if (!(kLeanpExp & 1)) dst[(size_t)(q - 1) * HP] = v2f64{sprev0, sprev1}; }
+                sprev0 = yprev; sprev1 = yk;
+                const v2f64 t2 = leanp_pair<q>(p2);   // e_{t-2} of this row pair
+                eC[s - 1] = t2.x; eC[s] = t2.y;
+            } else yprev = yk;
             lean_fence();
+            if constexpr (s == 2) {
+                Y = (yq[0] + yq[1]) + (yq[2] + yq[3]);
+            } else if constexpr (s == 3) {
+                const double W = fma(Tj.y, cy.Q1, Tj.x * cy.Q0);
+                cn.Cj = fma(k.k0, Y, fma(k.k1, W, k.uj * Nj));
+                sh.u[wave][lane] = cn.Cj;
+                m1 = cn.Cj * pN.ajf; m0 = cn.Cj - m1;
+            } else if constexpr (s >= 4 && s <= 9) {
+                if (!(kLeanpExp & 2)) leanp_level<s - 4>(m0, m1);
+                if constexpr (s == 7) cn.Crep = sh.u[wave][i0 + (lane & 15u)];
+            } else if constexpr (s == 10) {
+                cn.Q0 = readlane_f64(m0, 63); cn.Q1 = readlane_f64(m1, 63);
+            } else if constexpr (s == 11) {
+                kn = constants(n01.x, n01.y, n23.x, n23.y, cn, k.Snew, mn);
+                pin_here(kn.k0); pin_here(kn.k1); pin_here(kn.uj); pin_here(kn.urep); pin_here(kn.Snew); pin_here(mn);
+            } else if constexpr (s == 13) {
+                raw = leanp_raw(sh, n + 4u, wave);   // column t - 3: next step's p2
+            }
+            if constexpr (s >= 2 && s <= 13) lean_fence();
         });
-        yp = fma(eN[R - 2], w[R - 2], yp); yp2 = fma(eN[R - 1], w[R - 1], yp2);
-        yp += yp2;
+        yp = fma(eN[R - 1], w[R - 1], yp);
+        if (!(kLeanpExp & 1)) dst[(size_t)(R / 2 - 1) * HP] = v2f64{sprev0, sprev1};
         if (__builtin_expect(zero_t, 0)) {
             // beta~_t is all zero (a sum of non-negative terms: every y_k above IS 0, and so is what was stored): its own
             // posteriors are 0, the next step starts from the uniform column (hmm.cpp:374-380) — w = unif . e_t, primed again
             double et[R];   // (eC holds the column after next's emissions by now: this column's are fetched again)
             leanp_pairs_all(leanp_col(sh, n + 1u, wave, lane), et);
 #pragma unroll
-            for (int k = 0; k < R; ++k) w[k] = unif * et[k];
+            for (int q = 0; q < R; ++q) w[q] = unif * et[q];
             lds_barrier();   // (every wave is done with the Y partials of this step: the buffer takes the plain partials)
-            cy = leanp_prime(sh, w, eN, pN.ajf, (uint32_t)(t - 1) & 1u, wave, lane);
-            Sy = 1.0;
+            cn = leanp_prime(sh, w, eN, pN.ajf, (uint32_t)(t - 1) & 1u, wave, lane);
+            kn = constants(n01.x, n01.y, n23.x, n23.y, cn, 1.0, mn);
         } else {
-            sh.psum[(uint32_t)(t - 1) & 1u][wave][lane] = yp;
-            cy.Cj = Cn; cy.Crep = Crn;
-            cy.Q0 = readlane_f64(m0, 63); cy.Q1 = readlane_f64(m1, 63);
+            sh.psum[(uint32_t)(t - 1) & 1u][wave][lane] = yp + yp2;
         }
+        if (t - 1 >= bot) put_scalars(t - 1, mn, kn.Snew);
+        cy = cn; kc = kn;
         pC = p2;
-        prepare(t - 1, n01.x, n01.y, n23.x, n23.y);
         lds_barrier();
     };
     __builtin_amdgcn_s_waitcnt(0x0F70);

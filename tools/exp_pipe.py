@@ -96,8 +96,10 @@ if __name__ == "__main__":
         timeit("pipelined (product)")
         timeit("plain (PG_LEAN_PIPE=0)", PG_LEAN_PIPE=0)
     if "variants" in args:
-        for v in args[args.index("variants") + 1:]:
-            timeit(v, lib=variant_lib(v))
-            if v == "prof":
-                timeit(v + " plain", lib=variant_lib(v), PG_LEAN_PIPE=0)
+        for v in args[args.index("variants") + 1:]:   # NAME or NAME@plain (the plain lean step of that build)
+            name, _, how = v.partition("@")
+            if how == "plain":
+                timeit(name + " plain", lib=variant_lib(name), PG_LEAN_PIPE=0)
+            else:
+                timeit(name, lib=variant_lib(name))
     sys.exit(1 if rc else 0)
