@@ -272,12 +272,15 @@ DEVI void leanp_forward(const DevContig& dc, LeanSharedP& sh, uint32_t C, uint32
         if (fb) flag_uniform(first - 1);
         if (first < hi) put_scale(first, m);
     }
+    LeanTimeline tl;
+    tl.init();
     // One column step: eC / pC = emissions / descriptor of column t, eN / pN = of column t + 1; pC ends up as column
     // t + 2's.  The chain of the column sums of THIS column is sliced between the sixteen states (static `slot`).
     auto step = [&](uint32_t t, double (&eC)[R], double (&eN)[R], PipeCol& pC, const PipeCol& pN) __attribute__((always_inline)) {
         const uint32_t n = t - first;                 // column t = rel n + 1
         const uint32_t pbuf = (t - 1) & 1u;
         const PipeFwdK k = kc;
+        tl.template mark<0>(0.0);                     // (behind the barrier of the step before)
         double yq[4];
 #pragma unroll
         for (int q = 0; q < 4; ++q) yq[q] = sh.psum[pbuf][q][lane];
@@ -300,7 +303,10 @@ DEVI void leanp_forward(const DevContig& dc, LeanSharedP& sh, uint32_t C, uint32
         PipeCarry cn{0.0, 0.0, 0.0, 0.0};
         PipeFwdK kn = k;
         bool fb = false;
+        double nS = 0.0, nuj = 0.0, nc0 = 0.0;
+        int nes = 0;
         lean_fence();
+        tl.template mark<1>(0.0);                     // top: LDS reads issued, descriptor of column t + 2
         static_for<0, R>([&](auto kcst) __attribute__((always_inline)) {
             constexpr int s = decltype(kcst)::value;
             double pk = fma(k.c0s, x[s], k.ujs);       // P'_t(i0 + s, lane) 2^-es = c0 x + u_j + u_i
@@ -318,34 +324,59 @@ DEVI void leanp_forward(const DevContig& dc, LeanSharedP& sh, uint32_t C, uint32
             } else pprev = pk;
             lean_fence();
             // ---- slot s of the column-sum chain of THIS column (independent of the state block) ----
-            if constexpr (s == 2) {
+            if constexpr (s == 1) tl.template mark<2>(x[1]);    // states 0, 1
+            // (the Y partials are ~200 cycles away behind the barrier — the four waves' reads queue in one LDS pipe: first use at slot 4)
+            if constexpr (s == 4) {
                 Y = (yq[0] + yq[1]) + (yq[2] + yq[3]);
-            } else if constexpr (s == 3) {
+            } else if constexpr (s == 5) {
                 const double W = fma(Tj.y, cy.Q1, Tj.x * cy.Q0);
                 cn.Cj = fma(k.c0s, Y, fma(k.c1s, W, k.ujs * Nj));
                 sh.u[wave][lane] = cn.Cj;
                 m1 = cn.Cj * pN.ajf; m0 = cn.Cj - m1;
-            } else if constexpr (s >= 4 && s <= 9) {
-                if (!(kLeanpExp & 2)) leanp_level<s - 4>(m0, m1);
-                if constexpr (s == 7) cn.Crep = sh.u[wave][i0 + (lane & 15u)];
-            } else if constexpr (s == 10) {
+                tl.template mark<3>(m0);              // states 2 .. 5 + the Y partials back from LDS, closed form
+            } else if constexpr (s >= 6 && s <= 11) {
+                if (!(kLeanpExp & 2)) leanp_level<s - 6>(m0, m1);
+                if constexpr (s == 9) cn.Crep = sh.u[wave][i0 + (lane & 15u)];
+            } else if constexpr (s == 12) {
+                // the next step's constants in three slices (a dependent chain: a state's worth of issue between its links)
+                tl.template mark<4>(m0 + m1);         // states 6 .. 12 + six DPP levels of the two totals
                 cn.Q0 = readlane_f64(m0, 63); cn.Q1 = readlane_f64(m1, 63);
-            } else if constexpr (s == 11) {
-                kn = constants(t + 1u, n01.x, n01.y, n2, cn, fb, mn);
-                pin_here(kn.sc); pin_here(kn.c0s); pin_here(kn.c1s); pin_here(kn.ujs); pin_here(kn.urep); pin_here(mn);   // (here, not sunk behind the branches below)
+                nS = cn.Q0 + cn.Q1;
+                nuj = fma(n2, nS, n01.y * cn.Cj);
+                nc0 = n01.x;
+                fb = !(nS > 0.0);
+                if (__builtin_expect(fb, 0)) {   // column t summed to zero: see `constants`
+                    nS = 1.0;
+                    nuj = fma(n01.x, unif, fma(n2, 1.0, 2.0 * n01.y * (64.0 * unif)));
+                    nc0 = 0.0;
+                }
+                nes = exponent_of(nS) - PG_BIAS_F;
+                nes = nes < -900 ? -900 : nes;
             } else if constexpr (s == 13) {
-                raw = leanp_raw(sh, n + 4u, wave);   // column t + 3: next step's p2
+                mn = ldexp(nS, -nes - PG_BIAS_F);
+                kn.sc = ldexp(1.0, -nes); kn.c0s = ldexp(nc0, -nes);
+                pin_here(mn); pin_here(kn.sc); pin_here(kn.c0s);
+            } else if constexpr (s == 14) {
+                kn.c1s = ldexp(n01.y, -nes); kn.ujs = ldexp(nuj, -nes);
+                kn.urep = dpp_source(n01.y * cn.Crep);
+                pin_here(kn.c1s); pin_here(kn.ujs); pin_here(kn.urep);
+                tl.template mark<5>(kn.ujs);          // states 13, 14 + readlanes, zero test, the next step's constants
             }
-            if constexpr (s >= 2 && s <= 13) lean_fence();
+            if constexpr (s == 8) raw = leanp_raw(sh, n + 4u, wave);   // column t + 3: next step's p2 (two LDS reads, long before the barrier)
+            if constexpr (s >= 4) lean_fence();
         });
         yp = fma(eN[R - 1], x[R - 1], yp);
+        tl.template mark<6>(yp);                      // states 12 .. 15, the next descriptor's reads
         if (!(kLeanpExp & 1)) dst[(size_t)(R / 2 - 1) * HP] = v2f64{sprev0, sprev1};
         sh.psum[t & 1u][wave][lane] = yp + yp2;
         if (__builtin_expect(fb, 0)) flag_uniform(t);   // (behind the column's own stores)
         if (t + 1u < hi) put_scale(t + 1u, mn);
         cy = cn; kc = kn;
         pC = p2;
+        tl.template mark<7>(0.0);                     // Y partial parked, per-column scalar
         lds_barrier();
+        tl.template mark<8>(0.0);                     // the barrier
+        tl.template fold<8>();
     };
     __builtin_amdgcn_s_waitcnt(0x0F70);   // (see lean_forward: no load of the prologue is still in flight inside the loop)
     uint32_t t = first;
@@ -355,6 +386,7 @@ DEVI void leanp_forward(const DevContig& dc, LeanSharedP& sh, uint32_t C, uint32
     }
     if (t < hi) step(t, ea, eb, pa, pb_);
     if (wave == 0 && fsc.valid) fsc.flush(fscale, lane, hi - 1);
+    if (kLeanTimeline && tid == 0) tl.write(dc.prof + 32);
 }
 
 struct PipeBwdK { double k0, k1, uj, urep, Snew; };   // constants of a backward step; Snew = sum of the column it stores
@@ -468,11 +500,14 @@ DEVI void leanp_backward(const DevContig& dc, LeanSharedP& sh, uint32_t C, uint3
         kc = constants(cur.c0, cur.c1, cur.c2, cur.kappa, cy, Sy, m);
         put_scalars(t0, m, kc.Snew);
     }
+    LeanTimeline tl;
+    tl.init();
     // One column step: eC / pC = emissions / descriptor of column t, eN / pN = of column t - 1; pC ends up as column t - 2's.
     auto step = [&](int64_t t, double (&eC)[R], double (&eN)[R], PipeCol& pC, const PipeCol& pN) __attribute__((always_inline)) {
         const uint32_t n = (uint32_t)(t0 - t);        // column t = rel n + 1
         const uint32_t pbuf = (uint32_t)t & 1u;
         const PipeBwdK k = kc;
+        tl.template mark<0>(0.0);
         const bool zero_t = !(k.Snew > 0.0);          // beta~_t is all zero (below)
         double yq[4];
 #pragma unroll
@@ -494,7 +529,10 @@ DEVI void leanp_backward(const DevContig& dc, LeanSharedP& sh, uint32_t C, uint3
         double Y = 0.0, m0 = 0.0, m1 = 0.0, mn = 0.0;
         PipeCarry cn{0.0, 0.0, 0.0, 0.0};
         PipeBwdK kn = k;
+        double nk2 = 0.0, nkap = 0.0;
+        int nes = 0;
         lean_fence();
+        tl.template mark<1>(0.0);
         static_for<0, R>([&](auto kcst) __attribute__((always_inline)) {
             constexpr int s = decltype(kcst)::value;
             double yk = fma(k.k0, w[s], k.uj);           // beta'_t = k0 w + u_j + u_i
@@ -509,27 +547,44 @@ DEVI void leanp_backward(const DevContig& dc, LeanSharedP& sh, uint32_t C, uint3
                 eC[s - 1] = t2.x; eC[s] = t2.y;
             } else yprev = yk;
             lean_fence();
-            if constexpr (s == 2) {
+            if constexpr (s == 1) tl.template mark<2>(w[1]);
+            if constexpr (s == 1) {
+                // the part of the next step's constants that hangs on this step's Snew alone (known since the step before)
+                nes = exponent_of(k.Snew) - PG_BIAS_B;
+                nes = nes < -900 ? -900 : nes;
+                mn = ldexp(k.Snew, -nes - PG_BIAS_B);
+                kn.k0 = ldexp(n01.x, -nes); kn.k1 = ldexp(n01.y, -nes);
+                pin_here(mn); pin_here(kn.k0); pin_here(kn.k1);
+            } else if constexpr (s == 2) {
+                nk2 = ldexp(n23.x, -nes); nkap = ldexp(n23.y, -nes);
+                pin_here(nk2); pin_here(nkap);
+            } else if constexpr (s == 4) {
                 Y = (yq[0] + yq[1]) + (yq[2] + yq[3]);
-            } else if constexpr (s == 3) {
+            } else if constexpr (s == 5) {
                 const double W = fma(Tj.y, cy.Q1, Tj.x * cy.Q0);
                 cn.Cj = fma(k.k0, Y, fma(k.k1, W, k.uj * Nj));
                 sh.u[wave][lane] = cn.Cj;
                 m1 = cn.Cj * pN.ajf; m0 = cn.Cj - m1;
-            } else if constexpr (s >= 4 && s <= 9) {
-                if (!(kLeanpExp & 2)) leanp_level<s - 4>(m0, m1);
-                if constexpr (s == 7) cn.Crep = sh.u[wave][i0 + (lane & 15u)];
-            } else if constexpr (s == 10) {
+                tl.template mark<3>(m0);
+            } else if constexpr (s >= 6 && s <= 11) {
+                if (!(kLeanpExp & 2)) leanp_level<s - 6>(m0, m1);
+                if constexpr (s == 9) cn.Crep = sh.u[wave][i0 + (lane & 15u)];
+            } else if constexpr (s == 12) {
+                tl.template mark<4>(m0 + m1);
                 cn.Q0 = readlane_f64(m0, 63); cn.Q1 = readlane_f64(m1, 63);
-            } else if constexpr (s == 11) {
-                kn = constants(n01.x, n01.y, n23.x, n23.y, cn, k.Snew, mn);
-                pin_here(kn.k0); pin_here(kn.k1); pin_here(kn.uj); pin_here(kn.urep); pin_here(kn.Snew); pin_here(mn);
             } else if constexpr (s == 13) {
-                raw = leanp_raw(sh, n + 4u, wave);   // column t - 3: next step's p2
+                const double Sw = cn.Q0 + cn.Q1;
+                kn.uj = fma(nk2, Sw, kn.k1 * cn.Cj);
+                kn.Snew = nkap * Sw;   // = sum(beta'_{t-1})
+                kn.urep = dpp_source(kn.k1 * cn.Crep);
+                pin_here(kn.uj); pin_here(kn.urep); pin_here(kn.Snew);
+                tl.template mark<5>(kn.uj);
             }
-            if constexpr (s >= 2 && s <= 13) lean_fence();
+            if constexpr (s == 8) raw = leanp_raw(sh, n + 4u, wave);   // column t - 3: next step's p2
+            if constexpr (s >= 1) lean_fence();
         });
         yp = fma(eN[R - 1], w[R - 1], yp);
+        tl.template mark<6>(yp);
         if (!(kLeanpExp & 1)) dst[(size_t)(R / 2 - 1) * HP] = v2f64{sprev0, sprev1};
         if (__builtin_expect(zero_t, 0)) {
             // beta~_t is all zero (a sum of non-negative terms: every y_k above IS 0, and so is what was stored): its own
@@ -547,7 +602,10 @@ DEVI void leanp_backward(const DevContig& dc, LeanSharedP& sh, uint32_t C, uint3
         if (t - 1 >= bot) put_scalars(t - 1, mn, kn.Snew);
         cy = cn; kc = kn;
         pC = p2;
+        tl.template mark<7>(0.0);
         lds_barrier();
+        tl.template mark<8>(0.0);
+        tl.template fold<8>();
     };
     __builtin_amdgcn_s_waitcnt(0x0F70);
     int64_t t = t0;
@@ -558,6 +616,7 @@ DEVI void leanp_backward(const DevContig& dc, LeanSharedP& sh, uint32_t C, uint3
     if (t >= bot) step(t, ea, eb, pa, pb_);
     if (wave == 1 && bsc.valid) bsc.flush(bscale, lane, (uint64_t)bot);
     if (wave == 2 && bsm.valid) bsm.flush(bsum, lane, (uint64_t)bot);
+    if (kLeanTimeline && tid == 0) tl.write(dc.prof + 48);
 }
 
 template <int PHASE>

@@ -569,8 +569,8 @@ int job_build(int device, uint32_t n_index, const pg_contig_batch* batches, cons
         x.lean = lean_ok && x.HP == 64 && x.H == 64 && maxA == 2 && x.V > 0;
         x.small = lean_ok && x.HP == 16 && x.H == 16 && maxA == 2 && x.V > 0;   // (and enough of them: below)
         {
-            const char* e = getenv("PG_LEAN_PIPE");   // PG_LEAN_PIPE=0: the plain lean step (cross-check)
-            x.lean_pipe = x.lean && !(e && !strcmp(e, "0"));
+            const char* e = getenv("PG_LEAN_PIPE");   // PG_LEAN_PIPE=1: the pipelined lean step (measured at par with the plain one: DESIGN 4)
+            x.lean_pipe = x.lean && e && !strcmp(e, "1");
         }
         {
             const char* e = getenv("PG_CLS4");    // PG_CLS4=0: per-thread partials + k_bins (cross-check)

@@ -93,13 +93,15 @@ if __name__ == "__main__":
     if "check" in args:
         rc = check()
     if "time" in args:
-        timeit("pipelined (product)")
-        timeit("plain (PG_LEAN_PIPE=0)", PG_LEAN_PIPE=0)
+        timeit("plain (product)")
+        timeit("pipelined (PG_LEAN_PIPE=1)", PG_LEAN_PIPE=1)
+        timeit("fused mode (triangle stores)", PG_SWEEP_MODE="fused")
+        timeit("fused, full columns (PG_TRI=0)", PG_SWEEP_MODE="fused", PG_TRI=0)
     if "variants" in args:
-        for v in args[args.index("variants") + 1:]:   # NAME or NAME@plain (the plain lean step of that build)
+        for v in args[args.index("variants") + 1:]:   # NAME or NAME@pipe (the pipelined lean step of that build)
             name, _, how = v.partition("@")
-            if how == "plain":
-                timeit(name + " plain", lib=variant_lib(name), PG_LEAN_PIPE=0)
+            if how == "pipe":
+                timeit(name + " pipelined", lib=variant_lib(name), PG_LEAN_PIPE=1)
             else:
                 timeit(name, lib=variant_lib(name))
     sys.exit(1 if rc else 0)

@@ -12,7 +12,8 @@ if len(sys.argv) > 1 and sys.argv[1] == "build":
     print("built", LIB)
     sys.exit(0)
 os.environ["PANGENIE_HMM_LIB"] = LIB
-os.environ["PG_LEAN_PIPE"] = "0"
+PIPE = len(sys.argv) > 1 and sys.argv[1] == "pipe"
+os.environ["PG_LEAN_PIPE"] = "1" if PIPE else "0"
 from pangenie_amd import hmm  # noqa: E402
 from pangenie_amd.panel import default_table_args, synthetic_panel  # noqa: E402
 
@@ -21,13 +22,18 @@ job = hmm.Job([b], hmm.ProbabilityTable(*default_table_args()), hmm.make_params(
 job.run(); job.run()
 ms = job.kernel_ms(); C = job.fetch(0).n_columns
 p = job.profile_counters(0).astype(float)
-print("plain lean step, timeline build (stamps perturb the step: compare the sum with the unstamped cycles per column)")
+print(("pipelined" if PIPE else "plain") + " lean step, timeline build (stamps perturb the step: compare the sum with the unstamped cycles per column)")
 print("phase 1 %.2f ms = %.0f ns per column (%d columns)" % (ms["k_sweep_phase1"], ms["k_sweep_phase1"] * 1e6 / (C / 2), C))
 FWD = ["barrier release -> column sums back from LDS (4 + 4 reads, 3 adds)", "first MFMA + 3 adds", "second MFMA (total S)",
        "zero test, exponent, scaled constants", "u_j, first row pair's states", "other seven row pairs (states, stores, emission reads)",
        "partial sum to LDS, per-column scalar", "barrier"]
 BWD = ["exponent, scaled constants, scalar parked", "barrier", "column sums back from LDS + next records", "first MFMA + 3 adds",
        "second MFMA (total)", "u_j, first row pair's states", "other seven row pairs", "partial sum to LDS, scalars, zero test"]
+PSEG = ["top of the step: LDS reads issued, descriptor of the column after next", "states 0, 1", "states 2, 3 + Y partials back from LDS, closed form of the column sums",
+        "states 4 .. 10 + six DPP levels of the two class totals", "state 11 + readlanes, zero test, next step's constants", "states 12 .. 15 + next descriptor's reads",
+        "Y partial to LDS, last store, per-column scalars", "barrier"]
+if PIPE:
+    FWD = BWD = PSEG
 for name, o, segs in (("forward role (last chunk of phase 2)", 32, FWD), ("backward role", 48, BWD)):
     n = max(p[o + 15], 1.0)
     print("%s: %d steps" % (name, n))
