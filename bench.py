@@ -459,10 +459,25 @@ def main():
         ckms = {k: v / csteps for k, v in ckms.items()}
         fence()
         t0 = time.perf_counter()
-        cjob.upload()  # the next batch of samples: counts only, the index stays resident
+        cjob.upload()  # the next batch of samples, one after the other: counts only, the index stays resident
         cjob.run()
         fence()
-        cdt_up = max_over_ranks(time.perf_counter() - t0)
+        cdt_serial = max_over_ranks(time.perf_counter() - t0)
+        # ... and as a pipeline (pg_job_upload_begin / _end): batch n + 1 is packed into pinned staging and copied into the
+        # job's second set of per-sample arrays WHILE batch n is genotyped; steady state over `csteps` batches
+        cjob.upload_begin()
+        cjob.run()
+        cjob.upload_end()
+        fence()
+        t0 = time.perf_counter()
+        wait_s = 0.0
+        for _ in range(csteps):
+            cjob.upload_begin()
+            cjob.run()
+            cjob.upload_end()
+            wait_s += cjob.host_seconds()["upload_s"]
+        fence()
+        cdt_up = max_over_ranks(time.perf_counter() - t0) / csteps
         res = None
         if rank == 0:
             cb = cjob.batches
@@ -476,7 +491,11 @@ def main():
                             (f"; {distinct} distinct count sets, reused in turn" if distinct < S else ""),
                 "value": cv * world * csteps / cdt, "unit": "variants/s", "scaling": "weak", "steps": csteps, "ms_per_step": cdt / csteps * 1e3,
                 "chains_per_gpu": S * NC, "sweep_mode": cmode, "kept_columns": cncol,
-                "value_with_sample_upload": cv * world / cdt_up,
+                "value_with_sample_upload": cv * world / cdt_up,   # every step with the NEXT batch's counts uploaded beside it
+                "sample_upload": {"pipelined_ms_per_step": cdt_up * 1e3, "waited_for_upload_ms_per_step": wait_s / csteps * 1e3,
+                                  "serial_upload_then_run_ms": cdt_serial * 1e3, "value_serial": cv * world / cdt_serial,
+                                  "note": "pipelined = pg_job_upload_begin(next batch); pg_job_run(this batch); pg_job_upload_end: pinned staging, "
+                                          "<= chains/64 H2D copies, second set of per-sample arrays on the device"},
                 "h2d_bytes_per_sample_variant": ub["samples"] / float(cv),
                 "roofline": croof, "kernel_ms": ckms, "device_bytes": cjob.device_bytes(),
             }

@@ -245,7 +245,17 @@ int  pg_cohort_new(int device, uint32_t n_contigs, const pg_contig_batch* index,
  * NULL to keep the resident index and upload the counts only). */
 int  pg_job_upload(pg_job* job, const pg_contig_batch* batches, const pg_sample_counts* samples,
                    char* err, size_t errlen);
-/* Host wall seconds: [0] device allocation at creation, [1] last input upload (H2D),
+/* The same for a cohort job WITHOUT stalling the device: pg_job_upload_begin starts copying the next batch of samples
+ * (reference: one PanGenie run per sample re-reads its counts, src/commands.cpp:118-138) into the job's second set of
+ * per-sample arrays — host threads pack the counts into a pinned staging buffer, a few large H2D copies on a copy stream of
+ * the job's own — and returns at once; pg_job_run keeps genotyping the current batch meanwhile.  pg_job_upload_end waits
+ * for the copy and makes the new batch the one the next pg_job_run reads.  Call order of a pipeline:
+ *     upload_begin(n+1); run(n); fetch(n); upload_end(n+1); upload_begin(n+2); run(n+1); ...
+ * The arrays behind `samples` must stay valid and unchanged until pg_job_upload_end returns; results of the previous run
+ * must be fetched BEFORE pg_job_upload_end (it invalidates them: fetch then returns PG_ERR_INVALID until the next run). */
+int  pg_job_upload_begin(pg_job* job, const pg_sample_counts* samples, char* err, size_t errlen);
+int  pg_job_upload_end(pg_job* job, char* err, size_t errlen);
+/* Host wall seconds: [0] device allocation at creation, [1] last input upload (H2D; after pg_job_upload_end: what it waited),
  * [2] last pg_job_run, [3] last pg_job_fetch_all / sum of pg_job_fetch since the last run. */
 int  pg_job_host_seconds(const pg_job* job, double out4[4]);
 /* Input bytes moved H2D by the last upload: [0] index arrays, [1] per-sample arrays. */

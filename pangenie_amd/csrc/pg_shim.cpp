@@ -24,6 +24,7 @@
 #include <memory>
 #include <mutex>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "../../include/pangenie_hmm.h"
@@ -379,11 +380,33 @@ struct pg_job {
     hipStream_t stream2 = nullptr;
     hipEvent_t ev_sweep[2], ev_post[2];
     bool events2 = false;
+    // Per-sample inputs (read k-mer counts, local coverage) of all chains lie in ONE contiguous run of the arena,
+    // [sample_lo, sample_lo + sample_bytes): a cohort's next batch of samples is packed by host threads into a pinned
+    // staging buffer of the same layout and moved with a handful of large copies (sample_upload) — and, through
+    // pg_job_upload_begin / _end, into a SECOND set of arrays while the current one is being genotyped.
+    size_t sample_lo = 0, sample_bytes = 0;
+    unsigned char* staging = nullptr;         // pinned, sample_bytes (allocated on first use)
+    unsigned char* alt_samples = nullptr;     // device: the other set of per-sample arrays (allocated on first pg_job_upload_begin)
+    DevContig* d_contigs_alt = nullptr;       // chain descriptors pointing into the other set (the spare of the two descriptor arrays)
+    DevContig* d_contigs_owned = nullptr;     // the descriptor array that is not part of the arena (to free)
+    std::vector<DevContig> h_contigs;         // host copy of the descriptors of the set in use
+    unsigned char* cur_samples = nullptr;     // base of the set in use (arena + sample_lo, or alt_samples)
+    hipStream_t copy_stream = nullptr;
+    std::thread uploader;                     // pg_job_upload_begin's worker
+    bool upload_pending = false;
+    int upload_rc = PG_OK;
+    std::string upload_err;
+    std::vector<std::vector<uint16_t>> next_coverage;   // host copies of the pending batch's coverage arrays
 };
 
 extern "C" void pg_job_destroy(pg_job* job) {
     if (!job) return;
     hipSetDevice(job->device);
+    if (job->uploader.joinable()) job->uploader.join();
+    if (job->copy_stream) { hipStreamSynchronize(job->copy_stream); hipStreamDestroy(job->copy_stream); }
+    if (job->staging) hipHostFree(job->staging);
+    if (job->alt_samples) hipFree(job->alt_samples);
+    if (job->d_contigs_owned) hipFree(job->d_contigs_owned);
     if (job->stream) hipStreamSynchronize(job->stream);
     if (job->stream2) hipStreamSynchronize(job->stream2);
     if (job->events) {
@@ -411,6 +434,55 @@ extern "C" void pg_hmm_release_cache(void) {
 namespace {
 
 struct ChainSpec { uint32_t index; const uint16_t* kmer_count; const uint16_t* coverage; };
+
+// The per-sample arrays of a COHORT job (host memory by contract, one pair of small arrays per chain: 8192 pageable copies
+// for 4096 chains cost more than the kernels they feed) go through ONE pinned staging buffer laid out like the arena's
+// sample run: `pieces` host threads pack a contiguous range of chains each and queue one large H2D copy for it.  The
+// reference re-reads the counts per sample (src/commands.cpp:118-138); this is that step for a batch of samples.
+// `dev_base` = device address of the sample run to fill; `cov_out[c]` takes the host copy of chain c's coverage.
+int sample_upload(pg_job* job, const std::vector<ChainSpec>& specs, unsigned char* dev_base, hipStream_t stream,
+                  std::vector<std::vector<uint16_t>>* cov_out, uint64_t* bytes, char* err, size_t errlen) {
+    const size_t n = job->chains.size();
+    if (!job->staging) {
+        hipError_t he = hipHostMalloc((void**)&job->staging, job->sample_bytes ? job->sample_bytes : 8, hipHostMallocDefault);
+        if (he != hipSuccess) { job->staging = nullptr; set_err(err, errlen, "hipHostMalloc(%zu bytes) failed: %s", job->sample_bytes, hipGetErrorString(he)); return PG_ERR_NOMEM; }
+    }
+    size_t pieces = n / 64;   // (at most one copy per 64 chains)
+    const unsigned hw = std::thread::hardware_concurrency();
+    const size_t cap = hw ? (hw > 32 ? 16 : (hw + 1) / 2) : 4;
+    if (pieces > cap) pieces = cap;
+    if (pieces < 1) pieces = 1;
+    std::vector<int> rcs(pieces, (int)hipSuccess);
+    std::vector<uint64_t> moved(pieces, 0);
+    const size_t lo0 = job->sample_lo;
+    auto work = [&](size_t k) {
+        if (hipSetDevice(job->device) != hipSuccess) { rcs[k] = (int)hipErrorInvalidDevice; return; }
+        const size_t c0 = n * k / pieces, c1 = n * (k + 1) / pieces;
+        if (c0 >= c1) return;
+        for (size_t c = c0; c < c1; ++c) {
+            ChainHost& ch = job->chains[c];
+            const IndexHost& x = job->index[ch.index];
+            if (x.V == 0) continue;
+            memcpy(job->staging + (ch.o_cov - lo0), specs[c].coverage, (size_t)x.V * 2);
+            if (x.sumK) memcpy(job->staging + (ch.o_kcnt - lo0), specs[c].kmer_count, (size_t)x.sumK * 2);
+            moved[k] += (uint64_t)x.V * 2 + (uint64_t)x.sumK * 2;
+            if (cov_out) (*cov_out)[c].assign(specs[c].coverage, specs[c].coverage + x.V);
+        }
+        const size_t b0 = job->chains[c0].o_cov - lo0;
+        const size_t b1 = c1 < n ? job->chains[c1].o_cov - lo0 : job->sample_bytes;
+        rcs[k] = (int)hipMemcpyAsync(dev_base + b0, job->staging + b0, b1 - b0, hipMemcpyHostToDevice, stream);
+    };
+    std::vector<std::thread> th;
+    for (size_t k = 1; k < pieces; ++k) th.emplace_back(work, k);
+    work(0);
+    for (auto& t : th) t.join();
+    for (size_t k = 0; k < pieces; ++k) {
+        if (rcs[k] != (int)hipSuccess) { set_err(err, errlen, "sample upload: %s", hipGetErrorString((hipError_t)rcs[k])); return PG_ERR_DEVICE; }
+        if (bytes) *bytes += moved[k];
+    }
+    HIP_TRY(hipStreamSynchronize(stream));   // (the staging buffer is free again, the set is complete)
+    return PG_OK;
+}
 
 // H2D of the inputs into a planned job.  Copies are queued on the job's stream; pageable sources are
 // staged by the runtime, so every call returns when its source has been read.
@@ -447,13 +519,21 @@ int upload_inputs(pg_job* job, const pg_contig_batch* batches, const std::vector
         UP(job->o_tab_m, job->tab_m.data(), job->tab_m.size() * sizeof(double), bi);
         UP(job->o_tab_e, job->tab_e.data(), job->tab_e.size() * sizeof(int32_t), bi);
     }
-    for (size_t c = 0; c < job->chains.size(); ++c) {
-        ChainHost& ch = job->chains[c];
-        const IndexHost& x = job->index[ch.index];
-        if (x.V == 0) continue;
-        UP(ch.o_cov, specs[c].coverage, (size_t)x.V * 2, bs);
-        UP(ch.o_kcnt, specs[c].kmer_count, (size_t)x.sumK * 2, bs);
-        ch.coverage.assign(specs[c].coverage, specs[c].coverage + x.V);
+    if (job->cohort) {   // (host arrays by contract: packed into pinned staging, a few large copies)
+        std::vector<std::vector<uint16_t>> cov(job->chains.size());
+        const int rc = sample_upload(job, specs, job->cur_samples, s, &cov, &bs, err, errlen);
+        if (rc != PG_OK) return rc;
+        for (size_t c = 0; c < job->chains.size(); ++c) job->chains[c].coverage.swap(cov[c]);
+    } else {
+        const size_t rebase = (size_t)(job->cur_samples - (A + job->sample_lo));   // (0: jobs with device-resident counts never switch sets)
+        for (size_t c = 0; c < job->chains.size(); ++c) {
+            ChainHost& ch = job->chains[c];
+            const IndexHost& x = job->index[ch.index];
+            if (x.V == 0) continue;
+            UP(ch.o_cov + rebase, specs[c].coverage, (size_t)x.V * 2, bs);
+            UP(ch.o_kcnt + rebase, specs[c].kmer_count, (size_t)x.sumK * 2, bs);
+            ch.coverage.assign(specs[c].coverage, specs[c].coverage + x.V);
+        }
     }
 #undef UP
     HIP_TRY(hipStreamSynchronize(s));
@@ -679,12 +759,18 @@ int job_build(int device, uint32_t n_index, const pg_contig_batch* batches, cons
         x.o_goff = take(((size_t)x.V + 1) * 8);
         x.o_widx = take(x.wide_bytes ? (size_t)x.V * 4 : 0);
     }
+    job->sample_lo = align_up(off);   // the per-sample arrays of all chains, one contiguous run (pg_job::sample_lo)
+    for (uint32_t c = 0; c < n_chains; ++c) {
+        ChainHost& ch = job->chains[c];
+        const IndexHost& x = job->index[ch.index];
+        ch.o_cov = take((size_t)x.V * 2); ch.o_kcnt = take((size_t)x.sumK * 2);
+    }
+    job->sample_bytes = align_up(off) - job->sample_lo;
     std::vector<char> tri_of_chain(n_chains, 0);
     for (uint32_t c = 0; c < n_chains; ++c) {
         ChainHost& ch = job->chains[c];
         const IndexHost& x = job->index[ch.index];
         Plan& p = plan[c];
-        ch.o_cov = take((size_t)x.V * 2); ch.o_kcnt = take((size_t)x.sumK * 2);
         p.vrec = take((size_t)x.V * x.RB);
         p.cvar = take((size_t)x.V * 4);
         p.colrec = take((size_t)x.V * x.RB);
@@ -797,6 +883,8 @@ int job_build(int device, uint32_t n_index, const pg_contig_batch* batches, cons
             return fail(PG_ERR_DEVICE, "hipMemcpy small ids", he);
         if (job->n_small && (he = hipStreamSynchronize(job->stream)) != hipSuccess) return fail(PG_ERR_DEVICE, "hipMemcpy small ids", he);
     }
+    job->h_contigs = hd;
+    job->cur_samples = A + job->sample_lo;
     if ((he = hipMemcpyAsync(job->d_contigs, hd.data(), sizeof(DevContig) * n_chains, hipMemcpyHostToDevice, job->stream)) != hipSuccess ||
         (he = hipStreamSynchronize(job->stream)) != hipSuccess)
         return fail(PG_ERR_DEVICE, "hipMemcpy contigs", he);
@@ -842,6 +930,7 @@ extern "C" int pg_cohort_new(int device, uint32_t n_contigs, const pg_contig_bat
 
 extern "C" int pg_job_upload(pg_job* job, const pg_contig_batch* batches, const pg_sample_counts* samples, char* err, size_t errlen) {
     if (!job) { set_err(err, errlen, "null job"); return PG_ERR_INVALID; }
+    if (job->upload_pending) { set_err(err, errlen, "an asynchronous upload is in flight: call pg_job_upload_end first"); return PG_ERR_INVALID; }
     HIP_TRY(hipSetDevice(job->device));
     const uint32_t n = (uint32_t)job->chains.size();
     std::vector<ChainSpec> specs(n);
@@ -876,6 +965,99 @@ extern "C" int pg_job_upload(pg_job* job, const pg_contig_batch* batches, const 
         }
     }
     return upload_inputs(job, batches, specs, batches != nullptr, err, errlen);
+}
+
+namespace {
+int cohort_specs(pg_job* job, const pg_sample_counts* samples, std::vector<ChainSpec>& specs, char* err, size_t errlen) {
+    if (!job->cohort) { set_err(err, errlen, "not a cohort job"); return PG_ERR_INVALID; }
+    if (!samples) { set_err(err, errlen, "cohort job: samples must be given"); return PG_ERR_INVALID; }
+    specs.resize(job->chains.size());
+    for (uint32_t s = 0; s < job->n_samples; ++s) {
+        if (!samples[s].kmer_count || !samples[s].coverage) { set_err(err, errlen, "sample %u has null arrays", s); return PG_ERR_INVALID; }
+        for (uint32_t c = 0; c < job->n_contigs; ++c)
+            specs[(size_t)s * job->n_contigs + c] = {c, samples[s].kmer_count[c], samples[s].coverage[c]};
+    }
+    for (size_t c = 0; c < specs.size(); ++c) {
+        const IndexHost& x = job->index[job->chains[c].index];
+        if (x.V > 0 && (!specs[c].coverage || (x.sumK > 0 && !specs[c].kmer_count))) {
+            set_err(err, errlen, "chain %zu has null kmer_count / coverage arrays", c);
+            return PG_ERR_INVALID;
+        }
+    }
+    return PG_OK;
+}
+}  // namespace
+
+// The next batch of samples of a cohort job, uploaded WHILE the current one is being genotyped: a worker thread packs
+// the counts into the pinned staging buffer and copies them into the job's second set of per-sample arrays on a copy
+// stream of its own; pg_job_upload_end waits for it and makes that set the one pg_job_run reads.  The caller's arrays
+// must stay valid (and unchanged) until pg_job_upload_end returns.
+extern "C" int pg_job_upload_begin(pg_job* job, const pg_sample_counts* samples, char* err, size_t errlen) {
+    if (!job) { set_err(err, errlen, "null job"); return PG_ERR_INVALID; }
+    if (job->upload_pending) { set_err(err, errlen, "an upload is already in flight: call pg_job_upload_end first"); return PG_ERR_INVALID; }
+    HIP_TRY(hipSetDevice(job->device));
+    auto specs = std::make_shared<std::vector<ChainSpec>>();
+    const int rc = cohort_specs(job, samples, *specs, err, errlen);
+    if (rc != PG_OK) return rc;
+    const size_t n = job->chains.size();
+    if (!job->copy_stream) HIP_TRY(hipStreamCreateWithFlags(&job->copy_stream, hipStreamNonBlocking));
+    if (!job->alt_samples) {   // the second set + descriptors that point into it
+        hipError_t he = hipMalloc((void**)&job->alt_samples, job->sample_bytes ? job->sample_bytes : 8);
+        if (he == hipSuccess) he = hipMalloc((void**)&job->d_contigs_owned, sizeof(DevContig) * n);
+        job->d_contigs_alt = job->d_contigs_owned;
+        if (he != hipSuccess) {
+            if (job->alt_samples) { hipFree(job->alt_samples); job->alt_samples = nullptr; }
+            job->d_contigs_alt = job->d_contigs_owned = nullptr;
+            set_err(err, errlen, "hipMalloc (second sample set, %zu bytes) failed: %s", job->sample_bytes, hipGetErrorString(he));
+            return PG_ERR_NOMEM;
+        }
+    }
+    unsigned char* other = job->cur_samples == job->alt_samples ? job->arena + job->sample_lo : job->alt_samples;
+    DevContig* d_other = job->d_contigs_alt;   // (the spare descriptor array: pg_job_upload_end swaps the two)
+    job->next_coverage.assign(n, {});
+    job->upload_pending = true;
+    job->upload_rc = PG_OK;
+    job->upload_err.clear();
+    if (job->uploader.joinable()) job->uploader.join();
+    job->uploader = std::thread([job, specs, other, d_other, n]() {
+        char e[256] = {0};
+        uint64_t bytes = 0;
+        int r = hipSetDevice(job->device) == hipSuccess ? PG_OK : PG_ERR_DEVICE;
+        if (r == PG_OK) r = sample_upload(job, *specs, other, job->copy_stream, &job->next_coverage, &bytes, e, sizeof(e));
+        if (r == PG_OK) {   // the descriptors of that set (cov / kmer_count rebased), next to it on the device
+            std::vector<DevContig> hd = job->h_contigs;
+            for (size_t c = 0; c < n; ++c) {
+                hd[c].cov = (const uint16_t*)(other + (job->chains[c].o_cov - job->sample_lo));
+                hd[c].kmer_count = (const uint16_t*)(other + (job->chains[c].o_kcnt - job->sample_lo));
+            }
+            if (hipMemcpyAsync(d_other, hd.data(), sizeof(DevContig) * n, hipMemcpyHostToDevice, job->copy_stream) != hipSuccess ||
+                hipStreamSynchronize(job->copy_stream) != hipSuccess) { r = PG_ERR_DEVICE; snprintf(e, sizeof(e), "descriptor upload failed"); }
+            else job->h_contigs.swap(hd);
+        }
+        job->up_bytes[0] = 0; job->up_bytes[1] = bytes;
+        job->upload_rc = r;
+        job->upload_err = e;
+    });
+    return PG_OK;
+}
+
+extern "C" int pg_job_upload_end(pg_job* job, char* err, size_t errlen) {
+    if (!job) { set_err(err, errlen, "null job"); return PG_ERR_INVALID; }
+    if (!job->upload_pending) { set_err(err, errlen, "no upload in flight"); return PG_ERR_INVALID; }
+    const double t0 = now_s();
+    if (job->uploader.joinable()) job->uploader.join();
+    job->upload_pending = false;
+    job->host_s[1] = now_s() - t0;   // (what the caller waited: 0 when the upload hid behind the run)
+    if (job->upload_rc != PG_OK) { set_err(err, errlen, "%s", job->upload_err.c_str()); return job->upload_rc; }
+    // the freshly filled set becomes the current one: its descriptors sit in d_contigs_alt — swap the two descriptor arrays
+    std::swap(job->d_contigs, job->d_contigs_alt);
+    job->cur_samples = job->cur_samples == job->alt_samples ? job->arena + job->sample_lo : job->alt_samples;
+    for (size_t c = 0; c < job->chains.size(); ++c) {
+        job->chains[c].coverage.swap(job->next_coverage[c]);
+        job->chains[c].d = job->h_contigs[c];
+    }
+    job->ran = false;
+    return PG_OK;
 }
 
 namespace {
@@ -1124,7 +1306,7 @@ extern "C" int pg_job_fetch_panel(pg_job* job, uint32_t ci, uint32_t* kmer_off, 
     if (x.V == 0) return PG_OK;
     const unsigned char* A = job->arena;
     if (kmer_off) HIP_TRY(hipMemcpy(kmer_off, A + x.o_koff, ((size_t)x.V + 1) * 4, hipMemcpyDeviceToHost));
-    if (kmer_count && x.sumK) HIP_TRY(hipMemcpy(kmer_count, A + c.o_kcnt, (size_t)x.sumK * 2, hipMemcpyDeviceToHost));
+    if (kmer_count && x.sumK) HIP_TRY(hipMemcpy(kmer_count, job->cur_samples + (c.o_kcnt - job->sample_lo), (size_t)x.sumK * 2, hipMemcpyDeviceToHost));
     if (allele_off) HIP_TRY(hipMemcpy(allele_off, A + x.o_aoff, ((size_t)x.V + 1) * 4, hipMemcpyDeviceToHost));
     if (allele_id) HIP_TRY(hipMemcpy(allele_id, A + x.o_aid, (size_t)x.sumA * 2, hipMemcpyDeviceToHost));
     if (allele_flags) HIP_TRY(hipMemcpy(allele_flags, A + x.o_aflag, (size_t)x.sumA, hipMemcpyDeviceToHost));

@@ -292,6 +292,28 @@ class Job:
         if rc:
             raise PanGenieError(rc, err.value.decode(errors="replace"))
 
+    def upload_begin(self, samples=None) -> None:
+        """pg_job_upload_begin: start copying the next batch of samples of a cohort job into the job's second set of
+        per-sample arrays while the current batch is genotyped (run()); upload_end() makes it the current one.  Fetch
+        the previous run's results before upload_end()."""
+        if self._samples is None:
+            raise PanGenieError(-2, "upload_begin: not a cohort job")
+        if samples is not None:
+            self._next_samples, self._next_keep = self._marshal_samples(list(samples))
+        else:
+            self._next_samples, self._next_keep = self._samples, self._keep
+        err = C.create_string_buffer(_ERRLEN)
+        rc = self._lib.pg_job_upload_begin(self.h, self._next_samples, err, _ERRLEN)
+        if rc:
+            raise PanGenieError(rc, err.value.decode(errors="replace"))
+
+    def upload_end(self) -> None:
+        err = C.create_string_buffer(_ERRLEN)
+        rc = self._lib.pg_job_upload_end(self.h, err, _ERRLEN)
+        if rc:
+            raise PanGenieError(rc, err.value.decode(errors="replace"))
+        self._samples, self._keep = self._next_samples, self._next_keep
+
     def host_seconds(self) -> dict:
         out = (C.c_double * 4)()
         self._lib.pg_job_host_seconds(self.h, out)

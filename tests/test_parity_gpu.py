@@ -597,6 +597,55 @@ def test_cohort_job_vs_oracle(mode, orc, monkeypatch):
     job.close()
 
 
+def test_cohort_upload_overlapped_with_the_run(orc):
+    """pg_job_upload_begin / _end: the next batch of samples is copied into the job's second set of per-sample arrays
+    while the current batch is genotyped.  Three batches through the pipeline (both sets used twice): every batch's
+    results are bit for bit those of a fresh cohort job on that batch, and match the oracle; misuse is an error."""
+    from pangenie_amd.panel import synthetic_sample_counts
+    args = default_table_args()
+    t, p = hmm.ProbabilityTable(*args), hmm.make_params(1.26, False, 1e-5)
+    index = [synthetic_panel(260, 64, 20, seed=70), synthetic_panel(180, 16, 20, seed=71, multiallelic_frac=0.3)]
+    n_samples = 70   # (140 chains: more than one staging piece)
+
+    def batch(k):
+        out = []
+        for s in range(n_samples):
+            kcs, covs = zip(*[synthetic_sample_counts(ix, seed=5000 * k + 10 * s + c) for c, ix in enumerate(index)])
+            out.append((list(kcs), list(covs)))
+        return out
+
+    batches = [batch(k) for k in range(4)]
+    fresh = []
+    for k in range(4):
+        j = hmm.Job.cohort(index, batches[k], t, p)
+        j.run()
+        fresh.append([j.fetch(c) for c in range(j.n_chains)])
+        j.close()
+    job = hmm.Job.cohort(index, batches[0], t, p)
+    with pytest.raises(hmm.PanGenieError):
+        job.upload_end()                       # nothing in flight
+    for k in range(4):
+        if k + 1 < 4:
+            job.upload_begin(batches[k + 1])   # copies while batch k runs
+            with pytest.raises(hmm.PanGenieError):
+                job.upload_begin(batches[k + 1])   # one at a time
+        job.run()
+        got = [job.fetch(c) for c in range(job.n_chains)]
+        for c in range(job.n_chains):
+            assert np.array_equal(got[c].lik, fresh[k][c].lik) and np.array_equal(got[c].lik_exp, fresh[k][c].lik_exp)
+            assert np.array_equal(got[c].coverage, fresh[k][c].coverage) and np.array_equal(got[c].kept, fresh[k][c].kept)
+        if k + 1 < 4:
+            job.upload_end()
+            with pytest.raises(hmm.PanGenieError):
+                job.fetch(0)                   # the previous results are gone once the new batch is current
+    for c in (0, 1, job.n_chains - 1):
+        s_, ci = divmod(c, len(index))
+        b = index[ci].with_counts(batches[3][s_][0][ci], batches[3][s_][1][ci])
+        assert_parity(b, got[c], orc.genotype_contig(b, orc.OracleTable(*args), orc.make_params(1.26, False, 1e-5)))
+    assert job.upload_bytes()["samples"] == n_samples * sum(2 * int(ix.kmer_off[-1]) + 2 * ix.n_variants for ix in index)
+    job.close()
+
+
 @pytest.mark.parametrize("H,V,local_alts", [(16, 300, 12), (64, 200, 20), (27, 150, 8), (128, 60, 31)])
 def test_wide_columns_vs_oracle(H, V, local_alts, orc):
     """Columns with more than 5 (up to 32) distinct alleles on the selected paths: emission table in
