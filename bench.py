@@ -323,13 +323,22 @@ def main():
                     abi = None
             gather_kind = "pg_hmm_gather (C ABI: grouped ncclSend / ncclRecv)" if abi else "torch.distributed batch_isend_irecv"
 
-        def step():
+        rank_ms = {"run": 0.0, "gather": 0.0}   # this rank's own wall time per step (run = its chains; gather = the ONE exchange)
+
+        def step(timed=False):
+            t_a = time.perf_counter()
             if job:
                 job.run()
+            t_b = time.perf_counter()
             if abi:
                 abi.gather(job, per_rank)
             elif world > 1:
                 gather_posteriors(local, n_lik, plan, dst=0, unpack=False, device=dev)
+            if timed:
+                if world > 1:
+                    torch.cuda.synchronize()
+                rank_ms["run"] += (t_b - t_a) * 1e3
+                rank_ms["gather"] += (time.perf_counter() - t_b) * 1e3
 
         for _ in range(args.warmup):
             step()
@@ -337,13 +346,21 @@ def main():
         fence()
         t0 = time.perf_counter()
         for _ in range(args.steps):
-            step()
+            step(timed=True)
             if job:
                 for k, v in job.kernel_ms().items():
                     kms[k] = kms.get(k, 0.0) + v
         fence()
         dt = max_over_ranks(time.perf_counter() - t0)
         kms = {k: v / args.steps for k, v in kms.items()}
+        # per rank: its chains, its variants, its own run time and the time it spent in the exchange (the scaling curve's anatomy)
+        mine_row = {"rank": rank, "chains": len(mine), "variants": int(sum(sizes[i] for i in mine)), "longest_chain": int(max([sizes[i] for i in mine] or [0])),
+                    "run_ms_per_step": rank_ms["run"] / max(args.steps, 1), "gather_ms_per_step": rank_ms["gather"] / max(args.steps, 1)}
+        if world > 1:
+            rows = [None] * world
+            dist.all_gather_object(rows, mine_row)
+        else:
+            rows = [mine_row]
 
         # end to end: host buffers -> H2D of every input -> run -> D2H of every result, into the resident arena and into
         # result buffers the host already holds (allocated — and touched — once, outside the timed region)
@@ -417,6 +434,7 @@ def main():
                            "chains_on_rank0": len(mine), "kept_columns_rank0": ncol, "workgroups_per_chain": 2,
                            "parallelism": f"contig-sharded x{world}", "sweep_mode": "%s (chunk_cols=%d)" % (mode, chunk_cols),
                            "gather": gather_kind},
+                "per_rank": rows,
                 "roofline": roof, "kernel_ms": kms, "device_bytes": job_info["device_bytes"],
                 "alloc_s": hs["alloc_s"], "upload_s": hs["upload_s"],
             })
@@ -478,6 +496,7 @@ def main():
             wait_s += cjob.host_seconds()["upload_s"]
         fence()
         cdt_up = max_over_ranks(time.perf_counter() - t0) / csteps
+        cjob.run()   # (pg_job_upload_end invalidated the last results: the ones fetched below)
         res = None
         if rank == 0:
             cb = cjob.batches

@@ -264,7 +264,7 @@ int  pg_job_upload_bytes(const pg_job* job, uint64_t out2[2]);
  * gather sends): lik f64 [n_lik_total], lik_exp i32 [n_lik_total]. */
 int  pg_job_packed_results(pg_job* job, void** d_lik, void** d_lik_exp, uint64_t* n_lik_total);
 /* The one-shot call keeps the device arenas of its finished jobs in a pool for the next calls
- * (at most PG_ARENA_POOL_GB, default 200); this releases them. */
+ * (per device at most PG_ARENA_POOL_GB, default 70 % of the device's memory); this releases them. */
 void pg_hmm_release_cache(void);
 
 /* ------------------------------------------------------------------ *

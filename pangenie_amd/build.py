@@ -63,6 +63,7 @@ def build_oracle(force: bool = False) -> Path:
 HOST_DIR = ROOT / "pangenie_amd" / "host"
 HOST_LIB = HOST_DIR / "libpangenie_host.so"
 HOST_TEST = ROOT / "tests" / "cpp" / "test_host.bin"
+HOST_MOCK_TEST = ROOT / "tests" / "cpp" / "test_multi_gpu_mock.bin"
 
 
 def build_host(force: bool = False) -> Path:
@@ -86,4 +87,12 @@ def build_host(force: bool = False) -> Path:
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode:
             raise RuntimeError("g++ (host tests) failed:\n" + r.stderr)
+    msrc = ROOT / "tests" / "cpp" / "test_multi_gpu_mock.cpp"
+    if msrc.exists() and (force or _stale(HOST_MOCK_TEST, [msrc, HOST_LIB])):
+        # the multi-GPU job loop with the device calls replaced at the C-ABI seam (definitions in the executable, -rdynamic)
+        cmd = [cxx, "-O1", "-std=c++17", "-Wall", "-rdynamic", str(msrc), "-o", str(HOST_MOCK_TEST), f"-L{HOST_DIR}", "-lpangenie_host",
+               f"-L{CSRC}", "-lpangenie_hmm", "-lz", "-lpthread", "-Wl,-rpath,$ORIGIN/../../pangenie_amd/host:$ORIGIN/../../pangenie_amd/csrc"]
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        if r.returncode:
+            raise RuntimeError("g++ (multi-GPU mock test) failed:\n" + r.stderr)
     return HOST_LIB

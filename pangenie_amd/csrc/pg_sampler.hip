@@ -709,6 +709,11 @@ int sampler_run_core(const pg_contig_batch* panels, uint32_t n_contigs, uint32_t
     HIP_TRY(hipSetDevice(device));
     {
         hipError_t he = hipMalloc((void**)&arena, off);
+        if (he != hipSuccess) {   // cached arenas of the one-shot call may be what stands in the way
+            pg_hmm_release_cache();
+            hipSetDevice(device);
+            he = hipMalloc((void**)&arena, off);
+        }
         if (he != hipSuccess) { set_err(err, errlen, "hipMalloc(%zu bytes) failed: %s", off, hipGetErrorString(he)); rc = PG_ERR_NOMEM; goto done; }
     }
     for (auto& e : ev) HIP_TRY(hipEventCreate(&e));
@@ -971,6 +976,11 @@ extern "C" int pg_sampler_then_job(const pg_contig_batch* panels, uint32_t n_con
     HIP_TRY(hipSetDevice(device));
     {
         hipError_t he = hipMalloc((void**)&stage, off);
+        if (he != hipSuccess) {   // cached arenas of the one-shot call may be what stands in the way
+            pg_hmm_release_cache();
+            hipSetDevice(device);
+            he = hipMalloc((void**)&stage, off);
+        }
         if (he != hipSuccess) { set_err(err, errlen, "hipMalloc(%zu bytes) failed: %s", off, hipGetErrorString(he)); rc = PG_ERR_NOMEM; goto done; }
     }
     HIP_TRY(hipMemset(stage + o_err, 0, 4));

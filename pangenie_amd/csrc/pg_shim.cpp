@@ -288,9 +288,17 @@ struct ArenaPool {
     struct Entry { int device; unsigned char* ptr; size_t bytes; };
     std::mutex mu;
     std::vector<Entry> free_list;
-    size_t limit() {
-        static const size_t lim = [] { const char* e = getenv("PG_ARENA_POOL_GB"); return (size_t)((e ? strtod(e, nullptr) : 200.0) * 1073741824.0); }();
-        return lim;
+    // per device: PG_ARENA_POOL_GB, else 70 % of that device's memory (hipMemGetInfo; the caller has made `device` current)
+    size_t limit(int device) {
+        static const double env_gb = [] { const char* e = getenv("PG_ARENA_POOL_GB"); return e ? strtod(e, nullptr) : -1.0; }();
+        if (env_gb >= 0.0) return (size_t)(env_gb * 1073741824.0);
+        static size_t of_device[64] = {0};
+        if (device < 0 || device >= 64) return (size_t)200 << 30;
+        if (of_device[device] == 0) {
+            size_t free_b = 0, total_b = 0;
+            of_device[device] = (hipMemGetInfo(&free_b, &total_b) == hipSuccess && total_b > 0) ? (size_t)(0.7 * (double)total_b) : ((size_t)200 << 30);
+        }
+        return of_device[device];
     }
     bool take(int device, size_t need, unsigned char** ptr, size_t* bytes) {
         std::lock_guard<std::mutex> lock(mu);
@@ -308,13 +316,16 @@ struct ArenaPool {
             std::lock_guard<std::mutex> lock(mu);
             free_list.push_back({device, ptr, bytes});
             size_t total = 0;
-            for (const Entry& e : free_list) total += e.bytes;
-            while (total > limit() && !free_list.empty()) {
-                size_t k = 0;
-                for (size_t i = 1; i < free_list.size(); ++i) if (free_list[i].bytes < free_list[k].bytes) k = i;
-                total -= free_list[k].bytes;
-                drop.push_back(free_list[k]);
-                free_list.erase(free_list.begin() + (long)k);
+            for (const Entry& e : free_list) if (e.device == device) total += e.bytes;
+            const size_t lim = limit(device);
+            while (total > lim) {   // (this device's smallest entries go first)
+                long k = -1;
+                for (size_t i = 0; i < free_list.size(); ++i)
+                    if (free_list[i].device == device && (k < 0 || free_list[i].bytes < free_list[(size_t)k].bytes)) k = (long)i;
+                if (k < 0) break;
+                total -= free_list[(size_t)k].bytes;
+                drop.push_back(free_list[(size_t)k]);
+                free_list.erase(free_list.begin() + k);
             }
         }
         for (const Entry& e : drop)
@@ -679,6 +690,9 @@ int job_build(int device, uint32_t n_index, const pg_contig_batch* batches, cons
         for (const ChainSpec& sp : specs) { const IndexHost& x = job->index[sp.index]; per_col += (size_t)4 * x.HP * x.HP * sizeof(double); }
         // wide columns and HP >= 256 have their posteriors formed by k_post only: such jobs always run chunked
         bool want = n_chains * 2u < 128u;  // fewer workgroups than half the CUs
+        // merged one-shot calls (cache_arena): always the mode — and with it the kernels — every one of them runs alone, so
+        // that a caller's result does not depend on who else happened to be in flight (bit for bit, by construction)
+        if (cache_arena) want = true;
         if (const char* m = getenv("PG_SWEEP_MODE")) {
             if (!strcmp(m, "fused")) want = false;
             else if (!strcmp(m, "chunked")) want = true;
@@ -1541,7 +1555,14 @@ extern "C" int pg_hmm_genotype_contig(const pg_contig_batch* batch, const pg_tab
         g_co.stat_batches += 1; g_co.stat_requests += mine->reqs.size();
         if (mine->reqs.size() > g_co.stat_largest) g_co.stat_largest = mine->reqs.size();
     }
-    run_merged(*mine);
+    try {
+        run_merged(*mine);
+    } catch (...) {   // (std::bad_alloc of the host-side vectors, ...): every caller of the batch gets an error — and is woken up below
+        for (CoRequest* r : mine->reqs) {
+            r->rc = PG_ERR_DEVICE;
+            set_err(r->err, r->errlen, "merged one-shot job failed with a host exception");
+        }
+    }
     {
         std::lock_guard<std::mutex> lk(g_co.mu);
         g_co.inflight[device] -= 1;

@@ -125,10 +125,15 @@ def genotype_contig(batch: ContigBatch, table: ProbabilityTable, params: Optiona
         C.memmove(C.byref(q), C.byref(params), C.sizeof(PgHmmParams))
         q.reserved = _lib.PG_CALL_ANNOUNCED
         params = q
-    res = into if into is not None else ContigResult(batch)
-    err = C.create_string_buffer(_ERRLEN)
-    rc = lib.pg_hmm_genotype_contig(C.byref(batch.as_c()), table.h, C.byref(params), device,
-                                    C.byref(res._c), err, _ERRLEN)
+    try:
+        res = into if into is not None else ContigResult(batch)
+        err = C.create_string_buffer(_ERRLEN)
+        cb, th = batch.as_c(), table.h
+    except Exception:
+        if announced:   # the C call that would have consumed the announcement is never made: take it back (a leader would
+            lib.pg_hmm_retract(device)   # otherwise wait PG_COALESCE_WAIT_MS for a caller that is not coming)
+        raise
+    rc = lib.pg_hmm_genotype_contig(C.byref(cb), th, C.byref(params), device, C.byref(res._c), err, _ERRLEN)
     if rc:
         raise PanGenieError(rc, err.value.decode(errors="replace"))
     res.n_columns = int(res._c.n_columns)

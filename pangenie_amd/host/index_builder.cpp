@@ -132,6 +132,18 @@ namespace {
  *  the left with an ordered map arrives at. */
 Variant bubble_of(const std::string& chromosome, const std::vector<Record>& run, const std::string& reference, size_t k) {
     const size_t n_paths = run.front().paths.size();
+    if (run.size() == 1) {
+        // a record on its own keeps EVERY allele of the VCF line, carried by a path or not, bubble allele = VCF allele
+        // (Variant's constructor, src/variant.cpp:52-77; Graph::add_variant_cluster prunes nothing): the sequences of
+        // uncovered alleles stay in the graph (segment file, k-mer counts, exclusion of shared k-mers), a record whose paths
+        // carry alleles 0 and 2 stays a three-allele object.  Only MERGING reduces to the combinations the paths carry.
+        const Record& rec = run.front();
+        if (rec.alleles.size() > 65535) throw std::runtime_error("build_graphs: more than 65535 alleles in one bubble");
+        std::vector<std::vector<unsigned short>> combinations;
+        for (size_t a = 0; a < rec.alleles.size(); ++a) combinations.push_back({(unsigned short)a});
+        return Variant::from_parts(chromosome, rec.start, reference.substr(rec.start - (k - 1), k - 1), reference.substr(rec.end, k - 1),
+                                   {rec.alleles}, {}, combinations, rec.paths, /*flanks_added=*/true);
+    }
     std::set<std::vector<unsigned short>> distinct;
     distinct.insert(std::vector<unsigned short>(run.size(), 0));
     std::vector<std::vector<unsigned short>> of_path(n_paths, std::vector<unsigned short>(run.size()));

@@ -16,6 +16,7 @@
 #include <cstring>
 #include <functional>
 #include <iomanip>
+#include <fstream>
 #include <sstream>
 #include <memory>
 #include <stdexcept>
@@ -297,6 +298,31 @@ static void index_builder_cpu_tests() {
             for (size_t v = 0; v < want.size() && a.size() == 7; ++v)
                 for (size_t al = 0; al < want[v].size(); ++al) CHECK(a.get_variant(v).get_allele_string(al) == want[v][al]);
             CHECK(bb.get_variant(0).get_allele_string(0) == "CCACTTCATCAAGACACAA" && bb.get_variant(1).get_allele_string(0) == "GAGTATTTTGATCATAAAT");
+        }
+        {   // a record on its own keeps every VCF allele, carried or not, bubble allele = VCF allele (the reference's Variant
+            // constructor; tests/VariantTest.cpp:384-390 "uncovered_single": {A, G, T} with paths {0,0,1,0} stays three alleles);
+            // merged records keep the combinations their paths carry (+ all-REF)
+            const std::string dir2 = "/tmp/pg_test_uncovered";
+            { std::ofstream f(dir2 + ".fa"); f << ">chrU\n" << std::string(30, 'A') + "CAGTCAGTCAGGTTTACCATGACCATGGCAT" + std::string(30, 'C') << "\n"; }
+            {
+                std::ofstream f(dir2 + ".vcf");
+                f << "##fileformat=VCFv4.2\n#CHROM\tPOS\tID\tREF\tALT\tQUAL\tFILTER\tINFO\tFORMAT\ts1\ts2\n";
+                f << "chrU\t35\t.\tC\tT,G\t.\tPASS\t.\tGT\t1|0\t0|1\n";      // ALT G carried by nobody
+                f << "chrU\t55\t.\tA\tG,C\t.\tPASS\t.\tGT\t0|2\t2|0\n";      // ALT G carried by nobody, paths carry 0 and 2
+            }
+            const ReferenceSequences ref2(dir2 + ".fa");
+            const BuiltGraphs b = build_graphs(dir2 + ".vcf", ref2, 10, false);
+            const Graph& g = b.graphs.at("chrU");
+            CHECK(g.size() == 2);
+            if (g.size() == 2) {
+                const Variant& v0 = g.get_variant(0);
+                const Variant& v1 = g.get_variant(1);
+                CHECK(v0.nr_of_alleles() == 3 && v1.nr_of_alleles() == 3);
+                CHECK(v0.get_allele_on_path(0) == 1 && v0.get_allele_on_path(1) == 0 && v0.get_allele_on_path(2) == 0 && v0.get_allele_on_path(3) == 1);
+                CHECK(v1.get_allele_on_path(0) == 0 && v1.get_allele_on_path(1) == 2 && v1.get_allele_on_path(2) == 2 && v1.get_allele_on_path(3) == 0);
+                const std::string a2 = v0.get_allele_string(2);
+                CHECK(a2.size() == 19 && a2[9] == 'G');   // the uncovered allele's sequence is in the graph
+            }
         }
         auto lines_of = [](const std::string& text) { std::vector<std::string> l; std::istringstream is(text); std::string t; while (std::getline(is, t)) l.push_back(t); return l; };
         auto file_text = [](const std::string& path) { const std::vector<unsigned char> raw = read_file(path); return std::string(raw.begin(), raw.end()); };

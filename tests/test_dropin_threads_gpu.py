@@ -103,3 +103,46 @@ def test_fewer_workers_than_contigs(orc):
     for b, r in zip(batches, got):
         assert not isinstance(r, Exception), r
         assert_parity(b, r, orc.genotype_contig(b, otable, orc.make_params(1.26, False, 1e-5)))
+
+
+def test_an_announced_call_that_never_arrives_costs_the_wait_bound_once(orc):
+    """pg_hmm_announce promises a call; a worker that announces and then never calls (it threw while flattening its
+    UniqueKmers, or an external caller forgot) makes the first leader wait for it — bounded by PG_COALESCE_WAIT_MS (250
+    ms), after which the batch runs without it.  Results are unaffected; the cost is measured and printed.  Un-announced
+    callers next to announced ones (fewer announcements than callers) simply join the batch in flight."""
+    import threading
+    import time
+    lib = hmm._lib.load_hip()
+    batches = mixed_batches()[:6]
+    args = default_table_args()
+    table, prm = hmm.ProbabilityTable(*args), hmm.make_params(1.26, False, 1e-5)
+    solo = [hmm.genotype_contig(b, table, prm) for b in batches]
+
+    def round_of_calls(n_announced):
+        out = [None] * len(batches)
+        for _ in range(n_announced):
+            hmm.announce(0)
+
+        def work(i):
+            out[i] = hmm.genotype_contig(batches[i], table, prm, announced=i < n_announced)
+        ts = [threading.Thread(target=work, args=(i,)) for i in range(len(batches))]
+        t0 = time.perf_counter()
+        for t in ts:
+            t.start()
+        for t in ts:
+            t.join()
+        return out, time.perf_counter() - t0
+
+    round_of_calls(len(batches))                       # (warm: arenas into the pool)
+    ok, t_all = round_of_calls(len(batches))           # every caller announced
+    half, t_half = round_of_calls(len(batches) // 2)   # fewer announcements than callers
+    hmm.announce(0)                                    # one announcement nobody honours ...
+    late, t_late = round_of_calls(len(batches))
+    lib.pg_hmm_retract(0)                              # (... taken back, whatever the leader did with it)
+    for got in (ok, half, late):
+        for g, s in zip(got, solo):
+            assert np.array_equal(g.lik, s.lik) and np.array_equal(g.lik_exp, s.lik_exp) and g.n_columns == s.n_columns
+    print("one-shot round of %d calls: all announced %.1f ms, half announced %.1f ms, with a call announced but never made %.1f ms"
+          % (len(batches), t_all * 1e3, t_half * 1e3, t_late * 1e3))
+    assert t_late < t_all + 0.6      # bounded: the 250 ms wait once, not per caller
+    assert t_half < t_all + 0.2      # un-announced callers cost nothing extra

@@ -18,6 +18,15 @@ def test_host_classes_cpu(binary):
     assert r.returncode == 0, r.stdout + r.stderr
 
 
+def test_multi_gpu_job_loop_with_the_device_mocked_at_the_c_abi(binary):
+    """pangenie::run_contigs_multi_gpu on 1 / 2 / 3 / 8 / 12 'devices' without a GPU: pg_job_* / pg_comm_* /
+    pg_hmm_gather_to_host are replaced at the C-ABI seam (tests/cpp/test_multi_gpu_mock.cpp), so the plan (longest
+    processing time first), one job per device, the ONE exchange with its block sizes, and the reassembly of every
+    task's GenotypingResults run for real; what is left untested without hardware is RCCL itself."""
+    r = subprocess.run([str(build.HOST_MOCK_TEST)], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0 and " 0 failed" in r.stdout, r.stdout + r.stderr
+
+
 def test_host_classes_cpu_under_sanitizers(binary, tmp_path):
     """The same CPU scenarios with the host sources compiled under AddressSanitizer + UndefinedBehaviorSanitizer (archive
     readers on malformed input, the k-mer counters' threads and tables): no report, same checks."""

@@ -808,6 +808,43 @@ def test_config4_one_gpu_share_full_size(orc):
         assert_parity(sl, hmm.genotype_contig(sl, t, p), orc.genotype_contig(sl, orc.OracleTable(*args), orc.make_params(1.26, False, 1e-5)))
 
 
+def test_config1_full_size_50k_variants_16_paths(orc):
+    """BASELINE.json configs[1] at its stated size: one contig, 50 000 variants x 16 haplotypes, ~20 unique k-mers per
+    variant.  Size-independent checks on the whole chain (determinism, normalised posteriors sum to 1 at every kept
+    variant, kept-column count), the oracle on three 400-variant windows of it run as contigs of their own (the same
+    kernels, prologue and resume code at a size the oracle finishes in seconds), and the chunked and the fused mode of
+    the whole chain agreeing to fp64 rounding with identical calls."""
+    V, H = 50_000, 16
+    b = synthetic_panel(V, H, 20, seed=12345)
+    args = default_table_args()
+    t, p = hmm.ProbabilityTable(*args), hmm.make_params(1.26, False, 1e-5)
+    job = hmm.Job([b], t, p)
+    job.run()
+    r1 = job.fetch(0)
+    job.run()
+    r2 = job.fetch(0)
+    job.close()
+    assert (r1.lik == r2.lik).all() and (r1.lik_exp == r2.lik_exp).all()
+    n1 = normalized_bins(b, r1.likelihoods_ld())
+    sums = np.add.reduceat(n1, b.geno_off[:-1].astype(np.int64))
+    kept = r1.kept.astype(bool)
+    assert np.allclose(sums[kept].astype(float), 1.0, atol=1e-12)
+    assert r1.n_columns == int(kept.sum()) > 0.9 * V
+    for lo in (0, 24_800, V - 400):
+        sl = b.slice(lo, lo + 400)
+        assert_parity(sl, hmm.genotype_contig(sl, t, p), orc.genotype_contig(sl, orc.OracleTable(*args), orc.make_params(1.26, False, 1e-5)))
+    import os
+    os.environ["PG_SWEEP_MODE"] = "fused"
+    try:
+        rf = hmm.genotype_contig(b, t, p)
+    finally:
+        os.environ.pop("PG_SWEEP_MODE", None)
+    nf = normalized_bins(b, rf.likelihoods_ld())
+    rel = rel_errors(b, nf, n1)
+    assert float(rel[n1 > 1e-200].max()) < 1e-9
+    assert (calls(b, nf) == calls(b, n1)).all()
+
+
 def test_full_size_properties():
     """BASELINE.json configs[2] shape (200k variants x 64 haplotypes): size-independent checks.
     (a) determinism; (b) normalised posteriors sum to 1; (c) reversibility: the Li-Stephens

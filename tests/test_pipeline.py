@@ -36,9 +36,10 @@ def assert_same_vcf(got_path, want_path):
     device's are fp64 values normalised in long double — a likelihood within a few long double steps of 1 (log10 of the order of
     1e-19) can come out as exactly 1 on one side, and the genotype quality, -10 log10 of what is missing to 1, then reads
     10000 instead of something above 150.  So: GT and KC identical, every GL equal to the four printed digits or both below
-    1e-15 in magnitude, GQ identical or both at least 150."""
+    1e-15 in magnitude, GQ identical or both at least 150 — and no more than 1 record in 200 (at least 2) may need an allowance."""
     got, want = without_date(got_path), without_date(want_path)
     assert len(got) == len(want)
+    allowed = 0
     for g, w in zip(got, want):
         if g == w:
             continue
@@ -48,7 +49,9 @@ def assert_same_vcf(got_path, want_path):
         assert ggt == wgt and gkc == wkc, (g, w)
         assert ggq == wgq or (min(int(ggq), int(wgq)) >= 150), (g, w)
         for a, b in zip(ggl.split(","), wgl.split(",")):
-            assert a == b or (abs(float(a)) < 1e-15 and abs(float(b)) < 1e-15) or abs(float(a) - float(b)) <= 2e-3 * abs(float(b)), (g, w)
+            assert a == b or (abs(float(a)) < 1e-15 and abs(float(b)) < 1e-15), (g, w)
+        allowed += 1
+    assert allowed <= max(2, len(want) // 200), allowed
 
 
 @pytest.mark.parametrize("samples", [8, 54])
