@@ -67,6 +67,9 @@ COHORT = dict(samples=64, contigs=8, V=16_000, H=64, K=20)  # 512 chains, 194 GB
 COHORTS_MORE = {
     "cohort_h16": dict(samples=512, contigs=8, V=8_000, H=16, K=20, distinct=16),              # 4096 chains, 32.8 M variants
     "cohort_h128": dict(samples=16, contigs=8, V=3_000, H=128, K=20, multi=0.2, distinct=16),  # 128 chains, 50 GB of columns
+    # the production shape behind haplotype sampling: 15 sampled paths + the reference path (src/commands.cpp:799-803), a fifth
+    # of the objects multiallelic; 17 paths pad to 32: 8 KB per column
+    "cohort_h17": dict(samples=128, contigs=8, V=8_000, H=17, K=20, multi=0.2, distinct=16),    # 1024 chains, 8.2 M variants, 67 GB of columns
 }
 # GRCh38 chromosome lengths (Mb) 1..22, X, Y: proportions of the 24 synthetic contigs
 CONTIG_MB = [248, 242, 198, 190, 181, 171, 159, 145, 138, 134, 135, 133, 114, 107, 102, 90, 83, 80, 59, 64, 47, 51, 156, 57]

@@ -137,7 +137,8 @@ struct DevContig {
     // {c0, c1, c2, kappa, E'00, E'01, E'11, bits1} (64 B, read with scalar loads) and the flag
     double*   frec;            // [V][8]
     // 1: every object of the chain is biallelic with at most 32 k-mers and H <= 64: k_prep_bi prepares four variants
-    // per wave (a DPP row of 16 lanes each) instead of k_prep's one (PG_PREP=wave keeps k_prep: cross-check)
+    // per wave (a DPP row of 16 lanes each) instead of k_prep's one (PG_PREP=wave keeps k_prep: cross-check); 2: at least
+    // half of the objects are such: k_prep_bi takes those, k_prep the others (each kernel skips the other's objects)
     uint32_t  prep_fast;
     uint32_t  lean;            // 1: the store-only phases of this chain run on k_sweep_lean
     // 1 or 2 (lean chains of FUSED jobs; 2: phase 2 on k_sweep_lean2, 1: on the general kernel's triangle ring): phase 1 stores only the upper triangle of its (symmetric) columns, COMPACT at the

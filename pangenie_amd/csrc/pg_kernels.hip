@@ -296,6 +296,7 @@ DEVI void prep_unit(const DevContig& dc, const DevTable& tab, uint32_t unit) {
 
     const uint32_t a0 = dc.allele_off[v], A = dc.allele_off[v + 1] - a0;
     const uint32_t H = dc.H, HP = dc.HP;
+    if (dc.prep_fast == 2u && A == 2u && dc.kmer_off[v + 1] - dc.kmer_off[v] <= 32u) return;   // k_prep_bi's object
     if (A > PG_MAX_ALLELES_PER_VARIANT || A == 0) {
         if (lane == 0) { atomicOr(dc.err, PG_DEVERR_TOO_MANY_ALLELES); dc.kept[v] = 0; }
         return;
@@ -564,7 +565,7 @@ DEVI void prep_unit(const DevContig& dc, const DevTable& tab, uint32_t unit) {
 }
 __global__ __launch_bounds__(256) void k_prep(const DevContig* __restrict__ contigs, DevTable tab) {
     const DevContig& dc = contigs[blockIdx.y];
-    if (dc.prep_fast) return;  // k_prep_bi's chain
+    if (dc.prep_fast == 1u) return;  // k_prep_bi's chain (2: its two-allele objects only, see prep_unit)
 #pragma unroll 1
     for (uint32_t r = 0; r < (uint32_t)PG_VREP; ++r) {
         prep_unit(dc, tab, blockIdx.x * (uint32_t)PG_VREP + r);
@@ -601,12 +602,17 @@ DEVI void prep_bi_unit(const DevContig& dc, const DevTable& tab, uint32_t unit) 
     const uint32_t lane = threadIdx.x & 63u, grp = lane >> 4, l = lane & 15u;
     const uint32_t v = unit * 16u + (threadIdx.x >> 6) * 4u + grp;
     if (unit * 16u + (threadIdx.x >> 6) * 4u >= dc.V) return;  // the whole wave is beyond the contig
-    const bool live = v < dc.V;   // (a row beyond the contig idles along: the ballots below are wave-wide)
+    bool live = v < dc.V;   // (a row beyond the contig idles along: the ballots below are wave-wide)
     const uint32_t vv = live ? v : dc.V - 1u;
     const uint32_t H = dc.H, HP = dc.HP;
     const uint32_t a0 = dc.allele_off[vv];  // two alleles
-    const uint16_t id0 = dc.allele_id[a0], id1 = dc.allele_id[a0 + 1];
-    const bool u0 = dc.allele_flags[a0] & 1, u1 = dc.allele_flags[a0 + 1] & 1;
+    // DevContig::prep_fast == 2: a chain with other objects too — this kernel takes its two-allele objects with <= 32
+    // k-mers, k_prep the rest (a row whose object is not this kernel's idles along like one beyond the contig)
+    const bool mine = dc.prep_fast != 2u || (dc.allele_off[vv + 1] - a0 == 2u && dc.kmer_off[vv + 1] - dc.kmer_off[vv] <= 32u);
+    live = live && mine;
+    const uint32_t a1 = mine ? a0 + 1u : a0;
+    const uint16_t id0 = dc.allele_id[a0], id1 = dc.allele_id[a1];
+    const bool u0 = dc.allele_flags[a0] & 1, u1 = dc.allele_flags[a1] & 1;
     // ---- ColumnIndexer rule and the allele of every selected path (reference src/columnindexer.cpp:24-31): lane l
     //      takes paths l, 16 + l, 32 + l, 48 + l
     uint32_t slot[4];

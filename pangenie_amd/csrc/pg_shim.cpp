@@ -214,7 +214,7 @@ struct IndexHost {   // one index contig
     bool cls4 = false;  // HP = 16 / 32, H = HP, every object biallelic, fused job: class sums instead of per-thread partials (DevContig::cls4)
     bool leanx = false; // HP = 128 / 64 and every object has at most PG_AMAX alleles (not `lean`): the store-only phases run on k_sweep_leanx
     bool small = false; // every object biallelic and H = HP = 16: the store-only phases run on k_sweep_small16
-    bool prep_fast = false;  // every object has exactly two alleles and <= 32 k-mers, H <= 64: k_prep_bi
+    uint32_t prep_fast = 0;  // 1: every object has exactly two alleles and <= 32 k-mers, H <= 64: k_prep_bi; 2: at least half of them (k_prep the rest)
     uint32_t sumK = 0, sumA = 0;
     uint64_t n_lik = 0, wide_bytes = 0;
     std::vector<uint16_t> n_kmers;   // [V] K of every variant
@@ -622,7 +622,7 @@ int job_build(int device, uint32_t n_index, const pg_contig_batch* batches, cons
         if (x.V) { x.koff.assign(b.kmer_off, b.kmer_off + x.V + 1); x.aoff.assign(b.allele_off, b.allele_off + x.V + 1); }
         uint64_t maxA = 1, woff = 0;
         bool two_alleles = true;
-        uint32_t maxK = 0;
+        uint32_t maxK = 0, n_bi = 0;
         for (uint32_t v = 0; v < x.V; ++v) {
             const uint64_t A = b.allele_off[v + 1] - b.allele_off[v];
             x.goff[v + 1] = x.goff[v] + A * (A + 1) / 2;
@@ -630,10 +630,15 @@ int job_build(int device, uint32_t n_index, const pg_contig_batch* batches, cons
             if (A != 2) two_alleles = false;
             x.n_kmers[v] = (uint16_t)(b.kmer_off[v + 1] - b.kmer_off[v]);
             if (b.kmer_off[v + 1] - b.kmer_off[v] > maxK) maxK = b.kmer_off[v + 1] - b.kmer_off[v];
+            if (A == 2 && b.kmer_off[v + 1] - b.kmer_off[v] <= 32u) n_bi += 1;
         }
         {
-            const char* pe = getenv("PG_PREP");  // PG_PREP=wave: k_prep for every chain (cross-check of k_prep_bi)
-            x.prep_fast = two_alleles && maxK <= 32u && x.H <= 64u && x.V > 0 && !(pe && !strcmp(pe, "wave"));
+            // k_prep_bi (four variants per wave) takes the two-allele objects with <= 32 k-mers of chains with <= 64 paths:
+            // 1 = the whole chain is such objects, 2 = at least half of it (k_prep takes the rest: HPRC-style panels and the
+            // 15 + 1 sampled paths have a fifth of their objects multiallelic); PG_PREP=wave: k_prep for everything (cross-check)
+            const char* pe = getenv("PG_PREP");
+            const bool ok = x.H <= 64u && x.V > 0 && !(pe && !strcmp(pe, "wave"));
+            x.prep_fast = !ok ? 0u : ((two_alleles && maxK <= 32u) ? 1u : (2u * n_bi >= x.V ? 2u : 0u));
         }
         x.n_lik = x.goff[x.V];
         x.pair_n = (uint32_t)(maxA < PG_AMAX ? maxA : PG_AMAX);
@@ -874,7 +879,7 @@ int job_build(int device, uint32_t n_index, const pg_contig_batch* batches, cons
         d.wide = A + p.wide; d.wide_idx = x.wide_bytes ? (const uint32_t*)(A + x.o_widx) : nullptr;
         d.vpair = A + p.vpair; d.xbuf = (double*)(A + p.xbuf);
         d.frec = (double*)(A + p.frec); d.lean = x.lean ? ((x.lean_pipe && job->chunked) ? 2u : 1u) : 0u; d.small = x.small ? 1u : 0u; d.leanx = x.leanx ? 1u : 0u; d.cls4 = x.cls4 ? 1u : 0u;
-        d.prep_fast = x.prep_fast ? 1u : 0u;
+        d.prep_fast = x.prep_fast;
         if (params->run_phasing) {
             d.vit_tq = (double*)(A + p.vtq); d.vit_back = (uint16_t*)(A + p.vback); d.vit_best = (uint32_t*)(A + p.vbest);
             d.hap1 = (uint16_t*)(A + p.hap1); d.hap2 = (uint16_t*)(A + p.hap2);

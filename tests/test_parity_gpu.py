@@ -922,3 +922,27 @@ def test_prep_four_variants_per_wave_vs_one(shape, orc, monkeypatch):
         rel = np.where(denom > 0, np.abs(a - b) / np.where(denom > 0, denom, 1), 0)
         assert float(rel.max()) < 1e-12, float(rel.max())
         assert_parity(batch, four, orc.genotype_contig(batch, otab, orc.make_params(1.26, False, 1e-5)))
+
+
+@pytest.mark.parametrize("shape", [(600, 17, 20, 0.2), (500, 64, 20, 0.3), (400, 30, 12, 0.45), (300, 16, 40, 0.2)], ids=lambda s: "V%d_H%d_K%d_m%g" % s)
+def test_prep_mixed_chains_two_allele_objects_on_the_fast_kernel(shape, orc, monkeypatch):
+    """Chains with multiallelic objects (HPRC-style panels, the 15 + 1 sampled paths): k_prep_bi takes the two-allele
+    objects with at most 32 k-mers, k_prep the others (DevContig::prep_fast == 2) — against k_prep alone (PG_PREP=wave)
+    and the oracle; K = 40 puts two-allele objects with more than 32 k-mers on k_prep as well."""
+    V, H, K, multi = shape
+    batch = synthetic_panel(V, H, K, seed=77 + V, multiallelic_frac=multi, undefined_frac=0.05, zero_kmer_frac=0.05)
+    for targs in (default_table_args(), (6, 108, 54, 0.0)):
+        table, otab = hmm.ProbabilityTable(*targs), orc.OracleTable(*targs)
+        prm = hmm.make_params(1.26, False, 1e-5)
+        monkeypatch.delenv("PG_PREP", raising=False)
+        mixed = hmm.genotype_contig(batch, table, prm)
+        monkeypatch.setenv("PG_PREP", "wave")
+        one = hmm.genotype_contig(batch, table, prm)
+        monkeypatch.delenv("PG_PREP", raising=False)
+        assert mixed.n_columns == one.n_columns and np.array_equal(mixed.kept, one.kept)
+        assert np.array_equal(mixed.allele_present, one.allele_present)
+        a, b = mixed.likelihoods_ld(), one.likelihoods_ld()
+        denom = np.maximum(np.abs(a), np.abs(b))
+        rel = np.where(denom > 0, np.abs(a - b) / np.where(denom > 0, denom, 1), 0)
+        assert float(rel.max()) < 1e-11, float(rel.max())
+        assert_parity(batch, mixed, orc.genotype_contig(batch, otab, orc.make_params(1.26, False, 1e-5)))

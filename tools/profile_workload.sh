@@ -14,7 +14,7 @@ cd /tmp && export TMPDIR=/tmp
 cd $R
 if [ "$W" = "cohort_h64" ]; then
   CMD="python bench.py --steps 3 --warmup 1 --cohort-only --no-cpu-baseline --no-sampler"
-elif [ "$W" = "cohort_h16" ] || [ "$W" = "cohort_h128" ]; then
+elif [ "$W" = "cohort_h16" ] || [ "$W" = "cohort_h128" ] || [ "$W" = "cohort_h17" ]; then
   CMD="python bench.py --steps 3 --warmup 1 --cohort-only --cohort-key $W --no-cpu-baseline --no-sampler"
 else
   CMD="python bench.py --steps 3 --warmup 1 --workload $W --no-cpu-baseline --no-cohort --no-sampler --no-viterbi --no-dropin"
