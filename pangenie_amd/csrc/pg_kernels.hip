@@ -1003,7 +1003,7 @@ struct ChainShared {
     using Cfg = ChainCfg<HP, R>;
     unsigned char rec[8][Cfg::RB] __attribute__((aligned(16)));  // ring of 8 column records
     double psum[2][Cfg::NRG][HP];  // per row group partial column sums, double buffered by column parity
-    double u[Cfg::UNI ? Cfg::NW : 1][Cfg::UNI ? 64 : HP] __attribute__((aligned(16)));  // per-wave copy of the u vector
+    double u[Cfg::NW][Cfg::UNI ? 64 : HP] __attribute__((aligned(16)));  // per-wave copy of the u vector
 };
 
 // workgroup barrier that orders LDS traffic only (global stores/loads stay in flight)
@@ -1247,13 +1247,13 @@ DEVI void write_colsums(ChainShared<HP, R>& sh, uint32_t pb, const ThreadPos& p,
 }
 // u vector (c1 * column sums) for the thread's rows: UNI: each wave parks the vector of its row block
 // in a wave-private LDS row and reads its R values back as broadcasts (~120 cycles; 2R v_readlane
-// would cost ~20 cycles per value); !UNI (single compute wave): one shared row.
+// would cost ~20 cycles per value); !UNI (HP < 64): the same with the column sums themselves (lanes 0 .. HP-1 hold them all).
 template <int HP, int R>
 DEVI void publish_u(ChainShared<HP, R>& sh, const ThreadPos& p, double urow, double ucol) {
     using Cfg = ChainCfg<HP, R>;
     if (kExp & 4u) return;
     if constexpr (Cfg::UNI) sh.u[p.wave][p.lane] = urow;
-    else { if (p.rg == 0) sh.u[0][p.j] = ucol; }
+    else { if (p.lane < (uint32_t)HP) sh.u[p.wave][p.j] = ucol; }   // (every wave its own copy: lanes 0 .. HP-1 hold every column once)
 }
 template <int HP, int R>
 DEVI void fetch_u(const ChainShared<HP, R>& sh, const ThreadPos& p, double urow, double (&ui)[R]) {
@@ -1265,7 +1265,7 @@ DEVI void fetch_u(const ChainShared<HP, R>& sh, const ThreadPos& p, double urow,
     }
     // no fence/wait between the write and these reads: the LDS executes one wave's instructions in
     // order, and writer and readers are the same wave (the row is wave-private / the wave is alone)
-    const double* row = Cfg::UNI ? &sh.u[p.wave][p.i0 & 63u] : &sh.u[0][p.i0];
+    const double* row = Cfg::UNI ? &sh.u[p.wave][p.i0 & 63u] : &sh.u[p.wave][p.i0];
 #pragma unroll
     for (int k = 0; k < R; ++k) ui[k] = row[k];
 }
@@ -2144,7 +2144,14 @@ DEVI void backward_body(const DevContig& dc, ChainShared<HP, R>& sh, uint32_t C,
 
 // grid = (n_contigs, 2): blockIdx.y = 0 forward half-chain, 1 backward half-chain
 template <int HP, int R, int VBUF, bool KEEPW, int PHASE>
-__global__ __launch_bounds__((ChainCfg<HP, R>::TT)) void k_sweep(const DevContig* __restrict__ contigs, uint32_t chunk) {
+// HP = 32 (17 .. 32 paths: the 15 + 1 paths behind haplotype sampling): 8 rows per lane = two compute waves + the loader per
+// half-chain, held to 128 registers (a few spills) so that a SIMD takes four waves.  With 16 rows per lane (one compute
+// wave of 209 - 240 registers) a CU ran four half-chains at a time and two thirds of a 1024-chain cohort's time was
+// waiting: 72 -> 59 ms per step on `cohort_h17` (PG_HP32_ROWS=16 PG_HP32_WAVES=1 builds the old configuration).
+#ifndef PG_HP32_WAVES
+#define PG_HP32_WAVES 4
+#endif
+__global__ __launch_bounds__((ChainCfg<HP, R>::TT), (HP == 32 ? PG_HP32_WAVES : 1)) void k_sweep(const DevContig* __restrict__ contigs, uint32_t chunk) {
     __shared__ ChainShared<HP, R> sh;
     extern __shared__ __attribute__((aligned(16))) unsigned char dyn_ring[];  // phase 2: kRingSlots column slots
     const DevContig& dc = contigs[blockIdx.x];
@@ -4834,7 +4841,10 @@ static void launch_one(const DevContig* d_contigs, uint32_t n_contigs, uint32_t 
 template <int PHASE>
 static void launch_sweep(const DevContig* d_contigs, uint32_t n_contigs, uint32_t hp_mask, uint32_t chunk, hipStream_t s) {
     if (hp_mask & 1u) launch_one<16, 4, 1, true, PHASE>(d_contigs, n_contigs, chunk, s);
-    if (hp_mask & 2u) launch_one<32, 16, 1, true, PHASE>(d_contigs, n_contigs, chunk, s);
+#ifndef PG_HP32_ROWS
+#define PG_HP32_ROWS 8
+#endif
+    if (hp_mask & 2u) launch_one<32, PG_HP32_ROWS, 1, true, PHASE>(d_contigs, n_contigs, chunk, s);
     if (hp_mask & 4u) launch_one<64, 16, 1, true, PHASE>(d_contigs, n_contigs, chunk, s);
     if (hp_mask & 8u) launch_one<128, 32, 1, false, PHASE>(d_contigs, n_contigs, chunk, s);
     if constexpr (PHASE == 2) {
@@ -4931,7 +4941,7 @@ void pgk_launch_transition_single(double d, uint32_t H, int uniform, double* out
     hipLaunchKernelGGL(k_transition_single, dim3(1), dim3(64), 0, s, d, H, uniform, out3);
 }
 uint32_t pgk_threads_for_hp(uint32_t hp) {
-    switch (hp) { case 16: return 64; case 32: return 64; case 64: return 256; case 128: return 512; default: return hp >= 256 ? 1024 : 0; }
+    switch (hp) { case 16: return 64; case 32: return 32 * 32 / PG_HP32_ROWS; case 64: return 256; case 128: return 512; default: return hp >= 256 ? 1024 : 0; }
 }
 
 }  // extern "C"

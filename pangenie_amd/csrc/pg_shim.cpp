@@ -670,7 +670,8 @@ int job_build(int device, uint32_t n_index, const pg_contig_batch* batches, cons
         }
         {
             const char* e = getenv("PG_CLS4");    // PG_CLS4=0: per-thread partials + k_bins (cross-check)
-            x.cls4 = (x.HP == 16 || x.HP == 32) && x.H == x.HP && maxA == 2 && x.V > 0 && !(e && !strcmp(e, "0"));
+            // (the class sums are formed by a half-chain's ONE compute wave: 16 paths, and 32 when the kernel is built with 16 rows per lane)
+            x.cls4 = (x.HP == 16 || (x.HP == 32 && pgk_threads_for_hp(32) == 64u)) && x.H == x.HP && maxA == 2 && x.V > 0 && !(e && !strcmp(e, "0"));
         }
         {
             const char* e = getenv("PG_LEANX");   // PG_LEANX=0: the general kernel (cross-check)
