@@ -185,7 +185,7 @@ int  pg_job_device_results(pg_job* job, uint32_t contig, void** d_lik, uint64_t*
 int  pg_job_kernel_ms(const pg_job* job, double ms[PG_N_KERNEL_CLASSES]);
 const char* pg_job_kernel_name(int cls);
 /* Profiling hook: 64 in-kernel cycle counters of contig c's chain kernels, filled when the
- * environment variable PG_DEBUG has bit 3 set (layout documented in DESIGN.md); zeros otherwise. */
+ * library was built with -DPG_CHAIN_PROF (a measurement build; layout documented in DESIGN.md); zeros otherwise. */
 int  pg_job_profile_counters(pg_job* job, uint32_t contig, uint64_t out64[64]);
 /* Bytes of device memory held by the job. */
 uint64_t pg_job_device_bytes(const pg_job* job);
@@ -196,7 +196,7 @@ uint64_t pg_job_device_bytes(const pg_job* job);
 int  pg_job_sweep_mode(const pg_job* job, uint32_t* chunk_cols);
 /* Number of chains of the job whose columns are kept as upper triangles (fused mode, every object biallelic,
  * H = 64: the columns are symmetric, so phase 1 writes and phase 2 reads only the stored half — half of the
- * 16 H^2 bytes per variant of the full formulation; PG_TRI=0 turns it off).  For traffic accounting. */
+ * 16 H^2 bytes per variant of the full formulation; PG_KERNELS=notri turns it off).  For traffic accounting. */
 uint32_t pg_job_triangle_chains(const pg_job* job);
 /* Elapsed milliseconds of the Viterbi kernels (run_phasing) of the LAST pg_job_run, hipEvents on the launch stream. */
 double pg_job_viterbi_ms(const pg_job* job);

@@ -11,7 +11,7 @@ ROOT = Path(__file__).resolve().parent.parent
 CSRC = ROOT / "pangenie_amd" / "csrc"
 HIP_LIB = CSRC / "libpangenie_hmm.so"
 HIP_SOURCES = [CSRC / "pg_kernels.hip", CSRC / "pg_shim.cpp", CSRC / "pg_gather.cpp", CSRC / "pg_sampler.hip", CSRC / "pg_viterbi.hip"]
-HIP_DEPS = HIP_SOURCES + [CSRC / "pg_device.h", CSRC / "pg_devmath.h", CSRC / "pg_lean_pipe.h", ROOT / "include" / "pangenie_hmm.h", ROOT / "include" / "pangenie_sampler.h"]
+HIP_DEPS = HIP_SOURCES + [CSRC / "pg_device.h", CSRC / "pg_devmath.h", CSRC / "pg_lean_pipe.h", CSRC / "pg_experiments.h", ROOT / "include" / "pangenie_hmm.h", ROOT / "include" / "pangenie_sampler.h"]
 
 
 def _stale(target: Path, deps) -> bool:
@@ -30,7 +30,7 @@ def hipcc_path() -> str:
 
 def build_hip(force: bool = False, verbose: bool = False, out: Path | None = None, defines=(), extra=()) -> Path:
     """hipcc --offload-arch=gfx950 -> pangenie_amd/csrc/libpangenie_hmm.so (in-tree).
-    `out`/`defines` build a variant elsewhere (tools/prof_chain.py: -DPG_CHAIN_PROF)."""
+    `out`/`defines` build a variant elsewhere (tools/exp_pipe.py build ...: -DPG_CHAIN_PROF and the masks of pg_experiments.h)."""
     target = Path(out) if out else HIP_LIB
     if force or _stale(target, HIP_DEPS):
         target.parent.mkdir(parents=True, exist_ok=True)

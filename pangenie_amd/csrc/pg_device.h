@@ -96,7 +96,7 @@ struct DevContig {
     uint32_t pad0;
     double dist_scale;     // 0.000004 * recombrate * effective_N
     int32_t uniform;
-    uint32_t debug;        // PG_DEBUG env: ablation switches for profiling (0 in production)
+    uint32_t debug;        // bit 3: in-kernel cycle counters (-DPG_CHAIN_PROF builds only; no effect in the product build)
     uint32_t part_slots;   // allele slots per column in `part` = min(PG_AMAX, max alleles of a variant)
     uint32_t pair_n;       // local alleles the vpair tables are laid out for = min(PG_AMAX, max alleles of a variant)
     // inputs
@@ -137,7 +137,7 @@ struct DevContig {
     // {c0, c1, c2, kappa, E'00, E'01, E'11, bits1} (64 B, read with scalar loads) and the flag
     double*   frec;            // [V][8]
     // 1: every object of the chain is biallelic with at most 32 k-mers and H <= 64: k_prep_bi prepares four variants
-    // per wave (a DPP row of 16 lanes each) instead of k_prep's one (PG_PREP=wave keeps k_prep: cross-check); 2: at least
+    // per wave (a DPP row of 16 lanes each) instead of k_prep's one (PG_KERNELS=prepwave keeps k_prep: cross-check); 2: at least
     // half of the objects are such: k_prep_bi takes those, k_prep the others (each kernel skips the other's objects)
     uint32_t  prep_fast;
     uint32_t  lean;            // 1: the store-only phases of this chain run on k_sweep_lean
@@ -159,7 +159,7 @@ struct DevContig {
     uint32_t  cls4;
     double*   xbuf;            // [2][HP*HP] generic kernel scratch (forward role first)
     uint32_t* err;
-    unsigned long long* prof;  // [64] in-kernel cycle counters (PG_DEBUG bit 3), profiling only
+    unsigned long long* prof;  // [64] in-kernel cycle counters (-DPG_CHAIN_PROF / -DPG_LEAN_TIMELINE builds), profiling only
     // Viterbi phasing (run_phasing, pg_viterbi.hip): transition probabilities {p^2, pq, q^2} of every column,
     // the backtrace (index of the best previous state of every state, H*H per column), the best state of
     // the last column, and the haplotype alleles per variant

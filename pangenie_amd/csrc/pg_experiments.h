@@ -1,0 +1,76 @@
+// pg_experiments.h — compile-time knobs of the TIMING EXPERIMENTS and in-kernel profilers (tools/exp_pipe.py,
+// tools/exp_timeline.py, tools/bench_leanx.py).  The product library is built with none of them defined: every mask below
+// is 0 / false and the code it guards folds away.  Builds with a *_EXP mask set produce WRONG results by design (a part of
+// the step is compiled out so that its share of the time can be read): only their timing is of interest, and their results
+// are recorded under profiles/ (r03_lean_ablation.txt, r04_lean_chain.txt).  Included by pg_kernels.hip only.
+#pragma once
+
+// general kernel (k_sweep): 1 no column stores, 2 total := 64 C_j, 4 no u round trip, 8 no posterior, 16 no emission
+// multiply, 32 / 64 / 128: see the sites.  PG_CHAIN_PROF: cycle counters of a role's launch in DevContig::prof.
+#ifndef PG_EXP
+#define PG_EXP 0
+#endif
+static constexpr unsigned kExp = PG_EXP;
+#ifdef PG_CHAIN_PROF
+static constexpr bool kChainProf = true;
+#else
+static constexpr bool kChainProf = false;
+#endif
+
+// lean step (k_sweep_lean): 1 no column stores, 2 no emission fetches, 4 no MFMA total; PG_LEAN_DPPSUM: the wave total by
+// six DPP steps (wave_sum) instead of the two fp64 MFMAs
+#ifndef PG_LEAN_EXP
+#define PG_LEAN_EXP 0
+#endif
+static constexpr unsigned kLeanExp = PG_LEAN_EXP;
+#ifdef PG_LEAN_DPPSUM   // experiment: the wave total by six DPP steps (wave_sum) instead of the two fp64 MFMAs
+static constexpr bool kLeanDppSum = true;
+#else
+static constexpr bool kLeanDppSum = false;
+#endif
+
+// lean-x step (k_sweep_leanx): 1 no column stores, 2 no emission fetches
+#ifndef PG_LX_EXP
+#define PG_LX_EXP 0
+#endif
+static constexpr unsigned kLxExp = PG_LX_EXP;   // timing experiments: 1 no column stores, 2 no emission fetches — results WRONG
+
+// pipelined lean step (k_sweep_leanp, pg_lean_pipe.h): 1 no column stores, 2 no class totals
+#ifndef PG_LEANP_EXP
+#define PG_LEANP_EXP 0
+#endif
+static constexpr unsigned kLeanpExp = PG_LEANP_EXP;
+
+// -DPG_LEAN_TIMELINE builds only (tools/exp_pipe.py, profiles/r04_lean_chain.txt): s_memtime stamps at the segment
+// boundaries of one column step of wave 0, each issued behind a use of the value that ends the segment; the stamps are
+// only read behind the step's barrier (reading one earlier would drain the LDS queue with it).  Sums per segment over
+// the launch go to DevContig::prof[32 + segment] (forward role) / [48 + segment] (backward role), [.. + 15] = steps.
+#ifdef PG_LEAN_TIMELINE
+static constexpr bool kLeanTimeline = true;
+#else
+static constexpr bool kLeanTimeline = false;
+#endif
+struct LeanTimeline {
+    unsigned long long t[10], acc[10];
+    DEVI void init() { if constexpr (kLeanTimeline) { for (int i = 0; i < 10; ++i) { t[i] = 0; acc[i] = 0; } } }
+    template <int I>
+    DEVI void mark(double dep) {
+        if constexpr (kLeanTimeline) {
+            __builtin_amdgcn_sched_barrier(0);
+            asm volatile("" :: "v"(dep));
+            t[I] = __builtin_amdgcn_s_memtime();
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+    template <int N>
+    DEVI void fold() {   // behind the barrier: t[0] .. t[N] are this step's stamps
+        if constexpr (kLeanTimeline) {
+#pragma unroll
+            for (int i = 0; i < N; ++i) acc[i] += t[i + 1] - t[i];
+            acc[9] += 1;
+        }
+    }
+    DEVI void write(unsigned long long* o) const {
+        if constexpr (kLeanTimeline) { for (int i = 0; i < 9; ++i) o[i] = acc[i]; o[15] = acc[9]; }
+    }
+};

@@ -37,6 +37,7 @@
 #include "pg_devmath.h"
 
 #define DEVI __device__ __forceinline__
+#include "pg_experiments.h"   // masks of the timing experiments: all zero in the product build
 
 // ------------------------------------------------------------------------------------------
 //  wave-level helpers (wave = 64 lanes)
@@ -956,19 +957,8 @@ __global__ __launch_bounds__(256) void k_records(const DevContig* __restrict__ c
 //  chain).  Same for the backward column.  Results are the reference's values up to fp64
 //  rounding; no drift because every step renormalises to within a factor of 2.
 // ------------------------------------------------------------------------------------------
-// In-kernel cycle counters per role (tools/prof_chain.py, tools/exp_chain.py; PG_DEBUG bit 8) exist
-// only in builds with -DPG_CHAIN_PROF; the product library carries none of it.
-// Timing experiments (tools/exp_chain.py): -DPG_EXP=<mask> builds a variant with one ingredient of
-// the recursion step removed (results are then WRONG; only the kernel time is of interest).
-#ifndef PG_EXP
-#define PG_EXP 0
-#endif
-static constexpr unsigned kExp = PG_EXP;
-#ifdef PG_CHAIN_PROF
-static constexpr bool kChainProf = true;
-#else
-static constexpr bool kChainProf = false;
-#endif
+// (In-kernel cycle counters and the masks of the timing experiments — kExp, kLeanExp, ... — live in pg_experiments.h: all
+// zero / false in the product build.)
 #define GAS __attribute__((address_space(1)))
 typedef GAS double gdouble;
 typedef GAS const double gcdouble;
@@ -2384,49 +2374,8 @@ DEVI double lean_colsum(const LeanShared<R>& sh, uint32_t pb, uint32_t lane) {
                ((sh.psum[pb][4][lane] + sh.psum[pb][5][lane]) + (sh.psum[pb][6][lane] + sh.psum[pb][7][lane]));
 }
 
-#ifndef PG_LEAN_EXP
-#define PG_LEAN_EXP 0
-#endif
-static constexpr unsigned kLeanExp = PG_LEAN_EXP;
-#ifdef PG_LEAN_DPPSUM   // experiment: the wave total by six DPP steps (wave_sum) instead of the two fp64 MFMAs
-static constexpr bool kLeanDppSum = true;
-#else
-static constexpr bool kLeanDppSum = false;
-#endif   // timing experiments (tools/exp_lean.py): 1 no column stores, 2 no emission fetches, 4 no MFMA total — results WRONG
 
-// -DPG_LEAN_TIMELINE builds only (tools/exp_pipe.py, profiles/r04_lean_chain.txt): s_memtime stamps at the segment
-// boundaries of one column step of wave 0, each issued behind a use of the value that ends the segment; the stamps are
-// only read behind the step's barrier (reading one earlier would drain the LDS queue with it).  Sums per segment over
-// the launch go to DevContig::prof[32 + segment] (forward role) / [48 + segment] (backward role), [.. + 15] = steps.
-#ifdef PG_LEAN_TIMELINE
-static constexpr bool kLeanTimeline = true;
-#else
-static constexpr bool kLeanTimeline = false;
-#endif
-struct LeanTimeline {
-    unsigned long long t[10], acc[10];
-    DEVI void init() { if constexpr (kLeanTimeline) { for (int i = 0; i < 10; ++i) { t[i] = 0; acc[i] = 0; } } }
-    template <int I>
-    DEVI void mark(double dep) {
-        if constexpr (kLeanTimeline) {
-            __builtin_amdgcn_sched_barrier(0);
-            asm volatile("" :: "v"(dep));
-            t[I] = __builtin_amdgcn_s_memtime();
-            __builtin_amdgcn_sched_barrier(0);
-        }
-    }
-    template <int N>
-    DEVI void fold() {   // behind the barrier: t[0] .. t[N] are this step's stamps
-        if constexpr (kLeanTimeline) {
-#pragma unroll
-            for (int i = 0; i < N; ++i) acc[i] += t[i + 1] - t[i];
-            acc[9] += 1;
-        }
-    }
-    DEVI void write(unsigned long long* o) const {
-        if constexpr (kLeanTimeline) { for (int i = 0; i < 9; ++i) o[i] = acc[i]; o[15] = acc[9]; }
-    }
-};
+
 template <int PHASE, int R, bool TRI>
 DEVI void lean_forward(const DevContig& dc, LeanShared<R>& sh, uint32_t C, uint32_t chunk) {
     constexpr int HP = 64;
@@ -3374,10 +3323,6 @@ DEVI double lx_emission(uint32_t ecol, const LxAlleles<LxCfg<HP>::R>& a) {
     return *(LAS const double*)(uintptr_t)add_byte<(K & 3)>(a.rows[K >> 2], ecol);
 }
 
-#ifndef PG_LX_EXP
-#define PG_LX_EXP 0
-#endif
-static constexpr unsigned kLxExp = PG_LX_EXP;   // timing experiments (tools/exp_leanx.py): 1 no column stores, 2 no emission fetches — results WRONG
 template <int PHASE, int HP>
 DEVI void leanx_forward(const DevContig& dc, LxShared<HP>& sh, uint32_t C, uint32_t chunk) {
     using Cfg = LxCfg<HP>;
@@ -4826,11 +4771,7 @@ static void launch_one(const DevContig* d_contigs, uint32_t n_contigs, uint32_t 
     using Cfg = ChainCfg<HP, R>;
     size_t dyn = (Cfg::LOADER && PHASE == 2) ? (size_t)kRingSlots * HP * HP * 8 : 0;  // partner-column ring
     if (HP == 64 && dyn > 0) {  // the triangle ring of lean chains (compact slots + the zero unit)
-#if PG_TRI_SLOTS >= 8
         if (dyn < kTriRingB) dyn = kTriRingB;
-#else
-        if (const char* e = getenv("PG_TRI_ONLY")) { if (e[0] == '1') dyn = kTriRingB; }  // experiment: every HP = 64 chain of the job is a triangle chain
-#endif
     }
     auto kern = k_sweep<HP, R, VBUF, KEEPW, PHASE>;
     static bool attr_done[PG_MAX_DEVICES];
@@ -4914,9 +4855,8 @@ void pgk_launch_post(const DevContig* d_contigs, uint32_t n_contigs, uint32_t ch
     // sit in the queue and take the CU of a chain workgroup the moment a chunk sweep ends — the next chunk's
     // workgroup (which cannot share a CU with it, by LDS size) then waits for it: measured on the 24-contig
     // genome, 8 blocks per chain (= (256 - 48) / 24) 144 ms for phase 2, 6 blocks 164 ms, 10 blocks 173 ms,
-    // uncapped 172 ms.  PG_POST_BLOCKS overrides.
-    static const uint32_t env_cap = [] { const char* e = getenv("PG_POST_BLOCKS"); return e ? (uint32_t)strtoul(e, nullptr, 0) : 0u; }();
-    uint32_t cap = env_cap;
+    // uncapped 172 ms.
+    uint32_t cap = 0;
     if (!cap) {
         static int cus[PG_MAX_DEVICES];
         int dev = 0;

@@ -144,10 +144,6 @@ DEVI void leanp_state0(double& acc, double u, double sc, double& xn, double e) {
         "v_mul_f64 %1, %4, %0"
         : "+v"(acc), "=v"(xn) : "v"(u), "v"(sc), "v"(e), "n"(K));
 }
-#ifndef PG_LEANP_EXP
-#define PG_LEANP_EXP 0
-#endif
-static constexpr unsigned kLeanpExp = PG_LEANP_EXP;   // timing experiments (results WRONG): 1 no column stores, 2 no wave totals
 
 // the per-record arrays hold two blocks: block b is parked PARK_AHEAD steps before its first record is read
 // (a step reads up to record n + 4: the raw descriptor of the column three steps on) and expanded a step later

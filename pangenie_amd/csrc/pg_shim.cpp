@@ -553,6 +553,38 @@ int upload_inputs(pg_job* job, const pg_contig_batch* batches, const std::vector
     return PG_OK;
 }
 
+// PG_KERNELS: the ONE override of the kernel choice — a comma-separated list of tokens that put a second implementation
+// of a step beside the default one (cross-checks in tests/, measurements in tools/).  Nothing here is needed
+// in production: the library takes every decision from the job (chain count, panel width, allele structure).
+//   general | generic   no lean / lean-x / small kernels | the generic kernel for every HP >= 64
+//   leanx | noleanx     k_sweep_leanx also in phase 1 of fused jobs | never
+//   small | nosmall     k_sweep_small16 whatever the chain count | never
+//   nolean2 notri nocls4 prepwave   phase 2 of triangle chains on the general kernel's ring | full columns | per-thread
+//                       partials instead of class sums | k_prep for every object
+//   leanpipe            the pipelined lean step k_sweep_leanp for lone 64-path chains (measured at par: profiles/r04_lean_chain.txt)
+struct KernelChoice {
+    bool general = false, generic = false, nolean2 = false, notri = false, nocls4 = false, prepwave = false, leanpipe = false;
+    int leanx = -1, small = -1;   // -1: by the job, 0 / 1: forced
+};
+KernelChoice kernel_choice() {
+    KernelChoice k;
+    const char* e = getenv("PG_KERNELS");
+    if (!e) return k;
+    std::string tok;
+    auto take = [&]() {
+        if (tok == "general") k.general = true; else if (tok == "generic") k.generic = true;
+        else if (tok == "leanx") k.leanx = 1; else if (tok == "noleanx") k.leanx = 0;
+        else if (tok == "small") k.small = 1; else if (tok == "nosmall") k.small = 0;
+        else if (tok == "nolean2") k.nolean2 = true; else if (tok == "notri") k.notri = true;
+        else if (tok == "nocls4") k.nocls4 = true; else if (tok == "prepwave") k.prepwave = true;
+        else if (tok == "leanpipe") k.leanpipe = true;
+        tok.clear();
+    };
+    for (const char* c = e; *c; ++c) { if (*c == ',' || *c == ' ') take(); else tok.push_back(*c); }
+    take();
+    return k;
+}
+
 int job_build(int device, uint32_t n_index, const pg_contig_batch* batches, const std::vector<ChainSpec>& specs,
               uint32_t n_samples, bool cohort, const pg_table* table, const pg_hmm_params* params, bool cache_arena,
               pg_job** out, char* err, size_t errlen) {
@@ -610,7 +642,8 @@ int job_build(int device, uint32_t n_index, const pg_contig_batch* batches, cons
     bool wide_candidates = false, generic_needed = false;
     uint32_t max_v = 0;
     bool lean_ok = true, force_generic = false;
-    if (const char* k = getenv("PG_SWEEP_KERNEL")) { force_generic = !strcmp(k, "generic"); lean_ok = strcmp(k, "general") != 0 && !force_generic; }
+    const KernelChoice kc = kernel_choice();
+    force_generic = kc.generic; lean_ok = !kc.general && !kc.generic;
     for (uint32_t i = 0; i < n_index; ++i) {
         const pg_contig_batch& b = batches[i];
         IndexHost& x = job->index[i];
@@ -635,9 +668,8 @@ int job_build(int device, uint32_t n_index, const pg_contig_batch* batches, cons
         {
             // k_prep_bi (four variants per wave) takes the two-allele objects with <= 32 k-mers of chains with <= 64 paths:
             // 1 = the whole chain is such objects, 2 = at least half of it (k_prep takes the rest: HPRC-style panels and the
-            // 15 + 1 sampled paths have a fifth of their objects multiallelic); PG_PREP=wave: k_prep for everything (cross-check)
-            const char* pe = getenv("PG_PREP");
-            const bool ok = x.H <= 64u && x.V > 0 && !(pe && !strcmp(pe, "wave"));
+            // 15 + 1 sampled paths have a fifth of their objects multiallelic); PG_KERNELS=prepwave: k_prep for everything (cross-check)
+            const bool ok = x.H <= 64u && x.V > 0 && !kc.prepwave;
             x.prep_fast = !ok ? 0u : ((two_alleles && maxK <= 32u) ? 1u : (2u * n_bi >= x.V ? 2u : 0u));
         }
         x.n_lik = x.goff[x.V];
@@ -665,28 +697,26 @@ int job_build(int device, uint32_t n_index, const pg_contig_batch* batches, cons
         x.lean = lean_ok && x.HP == 64 && x.H == 64 && maxA == 2 && x.V > 0;
         x.small = lean_ok && x.HP == 16 && x.H == 16 && maxA == 2 && x.V > 0;   // (and enough of them: below)
         {
-            const char* e = getenv("PG_LEAN_PIPE");   // PG_LEAN_PIPE=1: the pipelined lean step (measured at par with the plain one: DESIGN 4)
-            x.lean_pipe = x.lean && e && !strcmp(e, "1");
+            x.lean_pipe = x.lean && kc.leanpipe;   // PG_KERNELS=leanpipe: the pipelined lean step (measured at par with the plain one: DESIGN 4)
         }
         {
-            const char* e = getenv("PG_CLS4");    // PG_CLS4=0: per-thread partials + k_bins (cross-check)
+            // PG_KERNELS=nocls4: per-thread partials + k_bins (cross-check)
             // (the class sums are formed by a half-chain's ONE compute wave: 16 paths, and 32 when the kernel is built with 16 rows per lane)
-            x.cls4 = (x.HP == 16 || (x.HP == 32 && pgk_threads_for_hp(32) == 64u)) && x.H == x.HP && maxA == 2 && x.V > 0 && !(e && !strcmp(e, "0"));
+            x.cls4 = (x.HP == 16 || (x.HP == 32 && pgk_threads_for_hp(32) == 64u)) && x.H == x.HP && maxA == 2 && x.V > 0 && !kc.nocls4;
         }
         {
-            const char* e = getenv("PG_LEANX");   // PG_LEANX=0: the general kernel (cross-check)
-            x.leanx = lean_ok && (x.HP == 128 || x.HP == 64) && !x.lean && maxA >= 1 && maxA <= PG_AMAX && x.V > 0 && !(e && !strcmp(e, "0"));
+            // PG_KERNELS=noleanx: the general kernel (cross-check)
+            x.leanx = lean_ok && (x.HP == 128 || x.HP == 64) && !x.lean && maxA >= 1 && maxA <= PG_AMAX && x.V > 0 && kc.leanx != 0;
         }
         if (x.V > max_v) max_v = x.V;
     }
     job->max_v = max_v;
     {
         // k_sweep_small16 packs four H = 16 half-chains into a wave: a throughput kernel.  A single chain is faster on the
-        // general kernel (four states per lane instead of sixteen: 375 vs 470 ns per column); PG_SMALL=1 / 0 forces.
+        // general kernel (four states per lane instead of sixteen: 375 vs 470 ns per column); PG_KERNELS=small / nosmall forces.
         size_t n_small_chains = 0;
         for (const ChainSpec& sp : specs) n_small_chains += job->index[sp.index].small ? 1 : 0;
-        const char* e = getenv("PG_SMALL");
-        const bool use = e ? !strcmp(e, "1") : n_small_chains >= 512;
+        const bool use = kc.small >= 0 ? kc.small == 1 : n_small_chains >= 512;
         if (!use) for (auto& x : job->index) x.small = false;
     }
 
@@ -707,11 +737,10 @@ int job_build(int device, uint32_t n_index, const pg_contig_batch* batches, cons
         job->chunked = want && max_v > 0 && params->run_genotyping;
         // k_sweep_leanx is a latency kernel (lone chains: 1470 vs 2645 ns per column at 128 paths); phase 1 of a fused job
         // with hundreds of chains is bound by HBM writes, where the general kernel measured faster (7.8 vs 8.9 ms on 128 chains
-        // of 128 paths).  PG_LEANX=1 forces it there too.
+        // of 128 paths).  PG_KERNELS=leanx forces it there too.
         if (job->chunked) for (auto& x : job->index) x.cls4 = false;   // (chunked jobs form their posteriors in k_post)
         if (!job->chunked) {
-            const char* e = getenv("PG_LEANX");
-            if (!(e && !strcmp(e, "1"))) for (auto& x : job->index) x.leanx = false;
+            if (kc.leanx != 1) for (auto& x : job->index) x.leanx = false;
         }
         if (job->chunked) {
             size_t k = 4096;
@@ -795,9 +824,8 @@ int job_build(int device, uint32_t n_index, const pg_contig_batch* batches, cons
         p.cvar = take((size_t)x.V * 4);
         p.colrec = take((size_t)x.V * x.RB);
         // fused jobs: lean chains store / read their columns as compact upper triangles (18 KB instead of 32 KB per
-        // column: half the sweep's HBM bytes and of the arena); PG_TRI=0 keeps full columns (cross-check)
-        const char* tri_env = getenv("PG_TRI");
-        const bool tri = x.lean && !job->chunked && !(tri_env && !strcmp(tri_env, "0"));
+        // column: half the sweep's HBM bytes and of the arena); PG_KERNELS=notri keeps full columns (cross-check)
+        const bool tri = x.lean && !job->chunked && !kc.notri;
         tri_of_chain[c] = tri;
         const bool geno = params->run_genotyping != 0;  // (a phasing-only job has no sweep: no columns, no partials)
         p.fwd = take(geno ? (size_t)x.V * (tri ? 2304u : (size_t)x.HP * x.HP) * sizeof(double) : 0);
@@ -855,7 +883,6 @@ int job_build(int device, uint32_t n_index, const pg_contig_batch* batches, cons
     // ---- chain descriptors ----------------------------------------------------------------------
     std::vector<DevContig> hd(n_chains);
     const long double dist_scale = 0.000004L * ((long double)params->recombrate) * params->effective_N;
-    const char* dbg = getenv("PG_DEBUG");
     for (uint32_t c = 0; c < n_chains; ++c) {
         ChainHost& ch = job->chains[c];
         const IndexHost& x = job->index[ch.index];
@@ -864,7 +891,7 @@ int job_build(int device, uint32_t n_index, const pg_contig_batch* batches, cons
         memset(&d, 0, sizeof(d));
         d.V = x.V; d.H = x.H; d.HP = x.HP; d.RB = x.RB; d.T = x.T; d.part_slots = x.part_slots; d.pair_n = x.pair_n;
         d.dist_scale = (double)dist_scale; d.uniform = params->uniform ? 1 : 0;
-        d.debug = dbg ? (uint32_t)strtoul(dbg, nullptr, 0) : 0u;
+        d.debug = 8u;   // (bit 3: the in-kernel cycle counters of -DPG_CHAIN_PROF builds; the product build has none)
         d.pos = (const uint64_t*)(A + x.o_pos); d.cov = (const uint16_t*)(A + ch.o_cov);
         d.kmer_off = (const uint32_t*)(A + x.o_koff); d.kmer_count = (const uint16_t*)(A + ch.o_kcnt);
         d.allele_off = (const uint32_t*)(A + x.o_aoff); d.allele_id = (const uint16_t*)(A + x.o_aid);
@@ -885,8 +912,7 @@ int job_build(int device, uint32_t n_index, const pg_contig_batch* batches, cons
             d.vit_tq = (double*)(A + p.vtq); d.vit_back = (uint16_t*)(A + p.vback); d.vit_best = (uint32_t*)(A + p.vbest);
             d.hap1 = (uint16_t*)(A + p.hap1); d.hap2 = (uint16_t*)(A + p.hap2);
         }
-        const char* l2_env = getenv("PG_LEAN2");  // 0: phase 2 of triangle chains on the general kernel's triangle ring
-        d.tri = tri_of_chain[c] ? ((l2_env && !strcmp(l2_env, "0")) ? 1u : 2u) : 0u;
+        d.tri = tri_of_chain[c] ? (kc.nolean2 ? 1u : 2u) : 0u;   // (PG_KERNELS=nolean2: phase 2 of triangle chains on the general kernel's triangle ring)
         d.col_stride = d.tri ? 2304u : x.HP * x.HP;
         if (d.tri) job->hp_mask |= 128u;
         if (d.tri == 2u) job->hp_mask |= 256u;
@@ -1424,10 +1450,10 @@ int genotype_single(const pg_contig_batch* batch, const pg_table* table, const p
 //  parameters are merged into ONE job — exactly the resident multi-chain job of pg_job_new — by whichever caller
 //  arrives first (the leader); the others sleep until their results are in their buffers.  Chains of a job are
 //  independent, so every caller gets bit for bit what it would have got alone.
-//    * a leader launches when a job slot of the device is free (at most PG_COALESCE_INFLIGHT = 2 merged jobs at a
+//    * a leader launches when a job slot of the device is free (at most 2 merged jobs at a
 //      time per device), every ANNOUNCED call has arrived (pg_hmm_announce: the C++ adapter announces at the top of
 //      the HMM constructor, before it flattens its UniqueKmers — the leader then knows who is still coming; bounded by
-//      PG_COALESCE_WAIT_MS = 250), and nobody new has joined for PG_COALESCE_WINDOW_US = 300 (only when other
+//      PG_COALESCE_WAIT_MS = 250), and nobody new has joined for 300 us (only when other
 //      callers have been seen at all: a single-threaded host never waits);
 //    * if the merged job fails (one malformed batch, a device limit, no memory for the sum) the leader runs the
 //      requests one by one, so every caller gets its own error code and message;
@@ -1510,8 +1536,8 @@ extern "C" int pg_hmm_genotype_contig(const pg_contig_batch* batch, const pg_tab
     if (!batch || !table || !params || !out) { set_err(err, errlen, "null argument"); return PG_ERR_INVALID; }
     using clock = std::chrono::steady_clock;
     static const bool enabled = env_long("PG_COALESCE", 1) != 0;
-    static const long window_us = env_long("PG_COALESCE_WINDOW_US", 300), wait_ms = env_long("PG_COALESCE_WAIT_MS", 250);
-    static const long max_inflight = env_long("PG_COALESCE_INFLIGHT", 2), max_batch = env_long("PG_COALESCE_MAX", 256);
+    static const long wait_ms = env_long("PG_COALESCE_WAIT_MS", 250);
+    const long window_us = 300, max_inflight = 2, max_batch = 256;   // (measured settings)
     const bool announced = (params->reserved & PG_CALL_ANNOUNCED) != 0;
     if (!enabled || device < 0 || device >= PG_MAX_DEVICES_HOST) {
         if (announced) pg_hmm_retract(device);

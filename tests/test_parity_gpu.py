@@ -294,7 +294,7 @@ def test_fixture_shape_215_paths_44_alleles_vs_oracle(orc):
 
 @pytest.mark.parametrize("H", [64, 100, 128])
 def test_generic_kernel_cross_checks_register_kernels(H, orc, monkeypatch):
-    """PG_SWEEP_KERNEL=generic runs HP = 64 / 128 on the independently written generic kernel: both must
+    """PG_KERNELS=generic runs HP = 64 / 128 on the independently written generic kernel: both must
     match the oracle, and each other to fp64 rounding."""
     b = synthetic_panel(260, H, 24, seed=70 + H, multiallelic_frac=0.3)
     args = (6, 108, 54, 0.0)
@@ -303,7 +303,7 @@ def test_generic_kernel_cross_checks_register_kernels(H, orc, monkeypatch):
     monkeypatch.setenv("PG_SWEEP_MODE", "chunked")
     monkeypatch.setenv("PG_CHUNK_COLS", "37")
     reg = hmm.genotype_contig(b, t, p)
-    monkeypatch.setenv("PG_SWEEP_KERNEL", "generic")
+    monkeypatch.setenv("PG_KERNELS", "generic")
     gen = hmm.genotype_contig(b, t, p)
     ref = orc.genotype_contig(b, orc.OracleTable(*args), orc.make_params(1.26, False, 1e-5))
     assert_parity(b, reg, ref)
@@ -316,8 +316,8 @@ def test_generic_kernel_cross_checks_register_kernels(H, orc, monkeypatch):
 @pytest.mark.parametrize("pipe", ["1", "0"])
 @pytest.mark.parametrize("K", [1, 2, 7, 64, 4096])
 def test_lean_kernel_biallelic_h64_vs_oracle_and_general(K, pipe, orc, monkeypatch):
-    """All-biallelic H = 64 chains of chunked jobs run their store-only phases on k_sweep_leanp — the pipelined lean step:
-    column sums in closed form, the LDS exchange beside the state block — or, with PG_LEAN_PIPE=0, on k_sweep_lean (the
+    """All-biallelic H = 64 chains of chunked jobs run their store-only phases (PG_KERNELS=leanpipe) on k_sweep_leanp — the pipelined lean step:
+    column sums in closed form, the LDS exchange beside the state block — or, by default, on k_sweep_lean (the
     plain step: MFMA totals behind the exchange).  Unregularised table: forward columns that fall back to uniform and
     all-zero backward columns, on, before and behind chunk and record-block boundaries (330 and 131 columns: blocks of
     64 records).  Either lean kernel and the general kernel must match the oracle and agree with each other to fp64
@@ -331,13 +331,13 @@ def test_lean_kernel_biallelic_h64_vs_oracle_and_general(K, pipe, orc, monkeypat
             b.kmer_count[::3] = 0
             b.kmer_count[1::17] = 60000
         t, p = hmm.ProbabilityTable(*args), hmm.make_params(1.26, False, 1e-5)
-        monkeypatch.delenv("PG_SWEEP_KERNEL", raising=False)
-        monkeypatch.setenv("PG_LEAN_PIPE", pipe)
+        monkeypatch.delenv("PG_KERNELS", raising=False)
+        if pipe == "1":
+            monkeypatch.setenv("PG_KERNELS", "leanpipe")
         lean = hmm.genotype_contig(b, t, p)
-        monkeypatch.delenv("PG_LEAN_PIPE", raising=False)
-        monkeypatch.setenv("PG_SWEEP_KERNEL", "general")
+        monkeypatch.setenv("PG_KERNELS", "general")
         gen = hmm.genotype_contig(b, t, p)
-        monkeypatch.delenv("PG_SWEEP_KERNEL", raising=False)
+        monkeypatch.delenv("PG_KERNELS", raising=False)
         ref = orc.genotype_contig(b, orc.OracleTable(*args), orc.make_params(1.26, False, 1e-5))
         assert_parity(b, lean, ref)
         assert_parity(b, gen, ref)
@@ -363,11 +363,11 @@ def test_leanx_kernel_narrow_columns_vs_oracle_and_general(mode, K, orc, monkeyp
             b.kmer_count[::3] = 0
             b.kmer_count[1::17] = 60000
         t, p = hmm.ProbabilityTable(*args), hmm.make_params(1.26, False, 1e-5)
-        monkeypatch.setenv("PG_LEANX", "1")   # (also in phase 1 of the fused mode, where the general kernel is the default)
+        monkeypatch.setenv("PG_KERNELS", "leanx")   # (also in phase 1 of the fused mode, where the general kernel is the default)
         lx = hmm.genotype_contig(b, t, p)
-        monkeypatch.setenv("PG_LEANX", "0")
+        monkeypatch.setenv("PG_KERNELS", "noleanx")
         gen = hmm.genotype_contig(b, t, p)
-        monkeypatch.delenv("PG_LEANX", raising=False)
+        monkeypatch.delenv("PG_KERNELS", raising=False)
         ref = orc.genotype_contig(b, orc.OracleTable(*args), orc.make_params(1.26, False, 1e-5))
         assert_parity(b, lx, ref)
         assert_parity(b, gen, ref)
@@ -391,11 +391,11 @@ def test_small16_kernel_biallelic_h16_vs_oracle_and_general(K, orc, monkeypatch)
             b.kmer_count[::3] = 0
             b.kmer_count[1::17] = 60000
         t, p = hmm.ProbabilityTable(*args), hmm.make_params(1.26, False, 1e-5)
-        monkeypatch.setenv("PG_SMALL", "1")   # (by default only jobs with hundreds of such chains take this kernel)
+        monkeypatch.setenv("PG_KERNELS", "small")   # (by default only jobs with hundreds of such chains take this kernel)
         small = hmm.genotype_contig(b, t, p)
-        monkeypatch.setenv("PG_SMALL", "0")
+        monkeypatch.setenv("PG_KERNELS", "nosmall")
         gen = hmm.genotype_contig(b, t, p)
-        monkeypatch.delenv("PG_SMALL", raising=False)
+        monkeypatch.delenv("PG_KERNELS", raising=False)
         ref = orc.genotype_contig(b, orc.OracleTable(*args), orc.make_params(1.26, False, 1e-5))
         assert_parity(b, small, ref)
         assert_parity(b, gen, ref)
@@ -418,11 +418,11 @@ def test_class_sums_in_the_single_wave_sweeps_vs_oracle_and_partials(H, orc, mon
             b.kmer_count[::3] = 0
             b.kmer_count[1::17] = 60000
         t, p = hmm.ProbabilityTable(*args), hmm.make_params(1.26, False, 1e-5)
-        monkeypatch.delenv("PG_CLS4", raising=False)
+        monkeypatch.delenv("PG_KERNELS", raising=False)
         cls = hmm.genotype_contig(b, t, p)
-        monkeypatch.setenv("PG_CLS4", "0")
+        monkeypatch.setenv("PG_KERNELS", "nocls4")
         old = hmm.genotype_contig(b, t, p)
-        monkeypatch.delenv("PG_CLS4", raising=False)
+        monkeypatch.delenv("PG_KERNELS", raising=False)
         ref = orc.genotype_contig(b, orc.OracleTable(*args), orc.make_params(1.26, False, 1e-5))
         assert_parity(b, cls, ref)
         assert_parity(b, old, ref)
@@ -439,7 +439,7 @@ def test_small16_kernel_many_chains_of_different_lengths(mode, orc, monkeypatch)
     matches the oracle."""
     monkeypatch.setenv("PG_SWEEP_MODE", mode)
     monkeypatch.setenv("PG_CHUNK_COLS", "97")
-    monkeypatch.setenv("PG_SMALL", "1")
+    monkeypatch.setenv("PG_KERNELS", "small")
     sizes = [700, 3, 260, 1, 2, 510, 64, 65, 33, 400, 129]
     batches = [synthetic_panel(v, 16, 20, seed=300 + i) for i, v in enumerate(sizes)]
     batches.insert(4, synthetic_panel(150, 64, 20, seed=350))
@@ -457,7 +457,7 @@ def test_small16_kernel_many_chains_of_different_lengths(mode, orc, monkeypatch)
         ref = orc.genotype_contig(b, orc.OracleTable(*args), orc.make_params(1.26, False, 1e-5))
         assert_parity(b, r, ref)
         alone = hmm.genotype_contig(b, t, p)
-        if mode == "chunked":   # (a lone call runs chunked: the same kernels — PG_SMALL is still set —, the same bits)
+        if mode == "chunked":   # (a lone call runs chunked: the same kernels — PG_KERNELS=small is still set —, the same bits)
             assert np.array_equal(r.lik, alone.lik) and np.array_equal(r.lik_exp, alone.lik_exp)
 
 
@@ -467,9 +467,15 @@ def test_triangle_storage_fused_lean_vs_oracle_and_full_columns(C_odd, lean2, or
     """Fused jobs store the (symmetric) columns of lean chains as upper triangles — diagonal halved, nothing
     below it — and phase 2 sums the stored half (k_bins doubles).  Unregularised table: forward fall-backs in
     both halves (the stored uniform column, the re-formed bins of k_bins) and all-zero backward columns go
-    through the triangle path; PG_TRI=0 (full columns) must give the same bins to fp64 rounding."""
+    through the triangle path; PG_KERNELS=notri (full columns) must give the same bins to fp64 rounding."""
     monkeypatch.setenv("PG_SWEEP_MODE", "fused")
-    monkeypatch.setenv("PG_LEAN2", lean2)  # phase 2 on k_sweep_lean2 (default) or on the general kernel's triangle ring
+    l2 = [] if lean2 == "1" else ["nolean2"]   # phase 2 on k_sweep_lean2 (default) or on the general kernel's triangle ring
+    def kernels(*more):
+        toks = l2 + list(more)
+        if toks:
+            monkeypatch.setenv("PG_KERNELS", ",".join(toks))
+        else:
+            monkeypatch.delenv("PG_KERNELS", raising=False)
     for seed, reg in ((15, 0.0), (16, 0.01), (17, 0.0)):
         args = (6, 108, 54, reg)
         b = synthetic_panel(331 if C_odd else 330, 64, 20, seed=seed)
@@ -477,15 +483,15 @@ def test_triangle_storage_fused_lean_vs_oracle_and_full_columns(C_odd, lean2, or
             b.kmer_count[::3] = 0
             b.kmer_count[1::17] = 60000
         t, p = hmm.ProbabilityTable(*args), hmm.make_params(1.26, False, 1e-5)
-        monkeypatch.delenv("PG_TRI", raising=False)
+        kernels()
         job = hmm.Job([b], t, p)
         job.run()
         assert job.sweep_mode()[0] == "fused"
         tri = job.fetch(0)
         job.close()
-        monkeypatch.setenv("PG_TRI", "0")
+        kernels("notri")
         full = hmm.genotype_contig(b, t, p)
-        monkeypatch.delenv("PG_TRI", raising=False)
+        kernels()
         ref = orc.genotype_contig(b, orc.OracleTable(*args), orc.make_params(1.26, False, 1e-5))
         assert_parity(b, tri, ref)
         assert_parity(b, full, ref)
@@ -898,7 +904,7 @@ def test_full_size_properties():
 
 @pytest.mark.parametrize("shape", [(700, 5, 20), (600, 16, 12), (500, 30, 32), (400, 64, 20), (300, 33, 7)], ids=lambda s: "V%d_H%d_K%d" % s)
 def test_prep_four_variants_per_wave_vs_one(shape, orc, monkeypatch):
-    """k_prep_bi (chains of biallelic objects: four variants per wave, DPP folds) against k_prep (PG_PREP=wave: one
+    """k_prep_bi (chains of biallelic objects: four variants per wave, DPP folds) against k_prep (PG_KERNELS=prepwave: one
     variant per wave) and against the oracle: same kept columns and present alleles, likelihoods equal to rounding
     (the products are taken in a different order).  Undefined alleles, k-mer-less variants, zero counts, and a table
     without regularisation (exact zeros: the all_zeros rule, uniform columns) are in."""
@@ -910,11 +916,11 @@ def test_prep_four_variants_per_wave_vs_one(shape, orc, monkeypatch):
     for targs in (default_table_args(), (6, 108, 54, 0.0)):
         table, otab = hmm.ProbabilityTable(*targs), orc.OracleTable(*targs)
         prm = hmm.make_params(1.26, False, 1e-5)
-        monkeypatch.delenv("PG_PREP", raising=False)
+        monkeypatch.delenv("PG_KERNELS", raising=False)
         four = hmm.genotype_contig(batch, table, prm)
-        monkeypatch.setenv("PG_PREP", "wave")
+        monkeypatch.setenv("PG_KERNELS", "prepwave")
         one = hmm.genotype_contig(batch, table, prm)
-        monkeypatch.delenv("PG_PREP", raising=False)
+        monkeypatch.delenv("PG_KERNELS", raising=False)
         assert four.n_columns == one.n_columns and np.array_equal(four.kept, one.kept)
         assert np.array_equal(four.allele_present, one.allele_present)
         a, b = four.likelihoods_ld(), one.likelihoods_ld()
@@ -927,18 +933,18 @@ def test_prep_four_variants_per_wave_vs_one(shape, orc, monkeypatch):
 @pytest.mark.parametrize("shape", [(600, 17, 20, 0.2), (500, 64, 20, 0.3), (400, 30, 12, 0.45), (300, 16, 40, 0.2)], ids=lambda s: "V%d_H%d_K%d_m%g" % s)
 def test_prep_mixed_chains_two_allele_objects_on_the_fast_kernel(shape, orc, monkeypatch):
     """Chains with multiallelic objects (HPRC-style panels, the 15 + 1 sampled paths): k_prep_bi takes the two-allele
-    objects with at most 32 k-mers, k_prep the others (DevContig::prep_fast == 2) — against k_prep alone (PG_PREP=wave)
+    objects with at most 32 k-mers, k_prep the others (DevContig::prep_fast == 2) — against k_prep alone (PG_KERNELS=prepwave)
     and the oracle; K = 40 puts two-allele objects with more than 32 k-mers on k_prep as well."""
     V, H, K, multi = shape
     batch = synthetic_panel(V, H, K, seed=77 + V, multiallelic_frac=multi, undefined_frac=0.05, zero_kmer_frac=0.05)
     for targs in (default_table_args(), (6, 108, 54, 0.0)):
         table, otab = hmm.ProbabilityTable(*targs), orc.OracleTable(*targs)
         prm = hmm.make_params(1.26, False, 1e-5)
-        monkeypatch.delenv("PG_PREP", raising=False)
+        monkeypatch.delenv("PG_KERNELS", raising=False)
         mixed = hmm.genotype_contig(batch, table, prm)
-        monkeypatch.setenv("PG_PREP", "wave")
+        monkeypatch.setenv("PG_KERNELS", "prepwave")
         one = hmm.genotype_contig(batch, table, prm)
-        monkeypatch.delenv("PG_PREP", raising=False)
+        monkeypatch.delenv("PG_KERNELS", raising=False)
         assert mixed.n_columns == one.n_columns and np.array_equal(mixed.kept, one.kept)
         assert np.array_equal(mixed.allele_present, one.allele_present)
         a, b = mixed.likelihoods_ld(), one.likelihoods_ld()

@@ -17,7 +17,7 @@ for H in (128, 64, 50):
         b = synthetic_panel(V, H, 20, seed=77, multiallelic_frac=multi)
         out = {}
         for lx in ("1", "0"):
-            os.environ["PG_LEANX"] = lx
+            os.environ["PG_KERNELS"] = "leanx" if lx == "1" else "noleanx"
             job = hmm.Job([b], table, params)
             job.run()
             job.run()
@@ -25,7 +25,7 @@ for H in (128, 64, 50):
             r = job.fetch(0)
             C = r.n_columns
             out[lx] = r
-            print("H %3d multi %.1f PG_LEANX=%s %-8s phase1 %8.2f ms = %5.0f ns/column  phase2 %8.2f ms = %5.0f ns/column  %.3f M variants/s" % (
+            print("H %3d multi %.1f leanx=%s %-8s phase1 %8.2f ms = %5.0f ns/column  phase2 %8.2f ms = %5.0f ns/column  %.3f M variants/s" % (
                 H, multi, lx, job.sweep_mode()[0], ms["k_sweep_phase1"], ms["k_sweep_phase1"] * 1e6 / (C / 2), ms["k_sweep_phase2"],
                 ms["k_sweep_phase2"] * 1e6 / (C / 2), V / (sum(ms.values()) * 1e-3) / 1e6), flush=True)
             job.close()

@@ -21,7 +21,7 @@ for n_chains in [int(a) for a in sys.argv[1:]] or [24, 512, 4096]:
         kcs, covs = zip(*[synthetic_sample_counts(ix, seed=1000 * s + i) for i, ix in enumerate(index)])
         samples.append((list(kcs), list(covs)))
     for small in ("0", "1"):
-        os.environ["PG_SMALL"] = small
+        os.environ["PG_KERNELS"] = "small" if small == "1" else "nosmall"
         job = hmm.Job.cohort(index, samples, table, params)
         job.run()
         t0 = time.perf_counter()
@@ -30,6 +30,6 @@ for n_chains in [int(a) for a in sys.argv[1:]] or [24, 512, 4096]:
         ms = job.kernel_ms()
         mode = job.sweep_mode()[0]
         r = job.fetch(S * 8 - 1)
-        print("chains %5d PG_SMALL=%s %-8s run %8.2f ms  phase1 %8.2f phase2 %8.2f  %.1f M variants/s  (check %.6e)" % (
+        print("chains %5d small=%s %-8s run %8.2f ms  phase1 %8.2f phase2 %8.2f  %.1f M variants/s  (check %.6e)" % (
             S * 8, small, mode, dt * 1e3, ms["k_sweep_phase1"], ms["k_sweep_phase2"], S * 8 * V / dt / 1e6, float(np.abs(r.lik).sum())), flush=True)
         job.close()

@@ -1,4 +1,4 @@
-"""The pipelined lean step (k_sweep_leanp) against the plain one (PG_LEAN_PIPE=0) on lone 64-path chains: agreement of
+"""The pipelined lean step (k_sweep_leanp) against the plain one (the default) on lone 64-path chains: agreement of
 the likelihoods over chain lengths and chunk sizes that cross every boundary of the kernel (record blocks of 64, chunk
 resume, a chain shorter than a block), then ns per column of both on a 50 000-variant chain.  Tooling only.
 usage (GPU box): python tools/exp_pipe.py [check] [time] [variants NAME=V ...]"""
@@ -14,7 +14,7 @@ from pangenie_amd.panel import default_table_args, synthetic_panel  # noqa: E402
 
 
 def run(batch, pipe, table_args=None, **env):
-    os.environ["PG_LEAN_PIPE"] = "1" if pipe else "0"
+    (os.environ.__setitem__("PG_KERNELS", "leanpipe") if pipe else os.environ.pop("PG_KERNELS", None))
     for k, v in env.items():
         os.environ[k] = str(v)
     try:
@@ -25,7 +25,7 @@ def run(batch, pipe, table_args=None, **env):
     finally:
         for k in env:
             os.environ.pop(k, None)
-        os.environ.pop("PG_LEAN_PIPE", None)
+        os.environ.pop("PG_KERNELS", None)
 
 
 def rel(a, b):
@@ -94,14 +94,14 @@ if __name__ == "__main__":
         rc = check()
     if "time" in args:
         timeit("plain (product)")
-        timeit("pipelined (PG_LEAN_PIPE=1)", PG_LEAN_PIPE=1)
+        timeit("pipelined (PG_KERNELS=leanpipe)", PG_KERNELS="leanpipe")
         timeit("fused mode (triangle stores)", PG_SWEEP_MODE="fused")
-        timeit("fused, full columns (PG_TRI=0)", PG_SWEEP_MODE="fused", PG_TRI=0)
+        timeit("fused, full columns (PG_KERNELS=notri)", PG_SWEEP_MODE="fused", PG_KERNELS="notri")
     if "variants" in args:
         for v in args[args.index("variants") + 1:]:   # NAME or NAME@pipe (the pipelined lean step of that build)
             name, _, how = v.partition("@")
             if how == "pipe":
-                timeit(name + " pipelined", lib=variant_lib(name), PG_LEAN_PIPE=1)
+                timeit(name + " pipelined", lib=variant_lib(name), PG_KERNELS="leanpipe")
             else:
                 timeit(name, lib=variant_lib(name))
     sys.exit(1 if rc else 0)

@@ -13,7 +13,8 @@ if len(sys.argv) > 1 and sys.argv[1] == "build":
     sys.exit(0)
 os.environ["PANGENIE_HMM_LIB"] = LIB
 PIPE = len(sys.argv) > 1 and sys.argv[1] == "pipe"
-os.environ["PG_LEAN_PIPE"] = "1" if PIPE else "0"
+if PIPE:
+    os.environ["PG_KERNELS"] = "leanpipe"
 from pangenie_amd import hmm  # noqa: E402
 from pangenie_amd.panel import default_table_args, synthetic_panel  # noqa: E402
 

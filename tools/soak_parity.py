@@ -45,9 +45,9 @@ for it in range(n):
     if os.environ.get("SOAK_TRI") == "1":
         kern = ""
     if kern:
-        os.environ["PG_SWEEP_KERNEL"] = kern
+        os.environ["PG_KERNELS"] = kern
     else:
-        os.environ.pop("PG_SWEEP_KERNEL", None)
+        os.environ.pop("PG_KERNELS", None)
     os.environ["PG_CHUNK_COLS"] = str(int(rng.choice([1, 3, 16, 64, 4096])))
     res = hmm.genotype_contig(b, hmm.ProbabilityTable(*args), hmm.make_params(recomb, uniform, N))
     ref = orc.genotype_contig(b, orc.OracleTable(*args), orc.make_params(recomb, uniform, N))
