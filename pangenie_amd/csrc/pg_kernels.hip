@@ -4596,7 +4596,7 @@ DEVI void post_column(const DevContig& dc, uint32_t chunk, uint32_t idx, uint32_
     const uint32_t nl = rec[PG_REC_NLOCAL];
     const unsigned char* al = rec + PG_REC_ALLELES;
     if (lane < PG_AMAX * (PG_AMAX + 1) / 2) s_bins[wave][lane] = 0.0;
-    wave_sync();
+    wave_sync_lds();   // (LDS only: the header loads above stay in flight under the first column loads below)
 
     // element e of a column = row pair e / HP, column e % HP (16 bytes: rows 2*(e/HP), +1); lanes take
     // consecutive elements, so every load is a coalesced 1 KB per wave.  Per lane the column is fixed
@@ -4703,7 +4703,7 @@ DEVI void post_column(const DevContig& dc, uint32_t chunk, uint32_t idx, uint32_
             }
         }
     }
-    wave_sync();
+    wave_sync_lds();
     if (!widec) {
         const uint32_t pn = dc.pair_n, NP = (pn * (pn + 1) / 2 + 1u) & ~1u;
         const unsigned char* vp = dc.vpair + (size_t)v * (NP * 12u);
@@ -4747,7 +4747,7 @@ __global__ __launch_bounds__(64 * PG_POST_WAVES) void k_post(const DevContig* __
     // this kernel trickles along next to the chains instead of bursting
     for (uint32_t idx = blockIdx.x * PG_POST_WAVES + wave; idx < 2u * dc.chunk_cols; idx += gridDim.x * PG_POST_WAVES) {
         post_column(dc, chunk, idx, wave, lane, s_bins);
-        wave_sync();
+        wave_sync_lds();   // (the wave's s_bins row is reused by its next column; its global stores need no wait)
     }
 }
 

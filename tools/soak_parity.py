@@ -15,7 +15,7 @@ seed0 = int(sys.argv[2]) if len(sys.argv) > 2 else 1
 rng = np.random.default_rng(seed0)
 worst, t0 = 0.0, time.time()
 for it in range(n):
-    H = int(rng.choice([1, 2, 5, 13, 16, 17, 27, 32, 33, 50, 64, 64, 64, 65, 100, 128, 129, 200, 300]))
+    H = int(rng.choice([1, 2, 5, 13, 16, 17, 17, 20, 24, 27, 30, 32, 33, 50, 64, 64, 64, 65, 100, 128, 129, 200, 300]))
     V = int(rng.integers(1, 900 if H <= 64 else (250 if H <= 128 else 60)))
     K = int(rng.choice([8, 20, 40, 128]))
     multi = float(rng.choice([0.0, 0.2, 0.6]))
@@ -41,7 +41,7 @@ for it in range(n):
     if os.environ.get("SOAK_TRI") == "1":
         mode = "fused"
     os.environ["PG_SWEEP_MODE"] = mode
-    kern = str(rng.choice(["", "", "general", "generic"]))
+    kern = str(rng.choice(["", "", "", "general", "generic", "leanpipe", "prepwave"]))
     if os.environ.get("SOAK_TRI") == "1":
         kern = ""
     if kern:
