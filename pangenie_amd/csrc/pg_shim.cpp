@@ -19,6 +19,7 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <atomic>
 #include <chrono>
 #include <condition_variable>
 #include <memory>
@@ -585,11 +586,35 @@ KernelChoice kernel_choice() {
     return k;
 }
 
+// f(i) for every index contig: on worker threads when the contigs together hold enough variants to pay for them
+template <class F>
+void parallel_contigs(uint32_t n, const pg_contig_batch* batches, F&& f) {
+    uint64_t total = 0;
+    for (uint32_t i = 0; i < n; ++i) total += batches[i].n_variants;
+    unsigned nt = std::thread::hardware_concurrency();
+    nt = nt ? (nt > 16 ? 16 : nt) : 4;
+    if (nt > n) nt = n;
+    if (n < 2 || total < 200000 || nt < 2) { for (uint32_t i = 0; i < n; ++i) f(i); return; }
+    std::atomic<uint32_t> next{0};
+    std::vector<std::thread> th;
+    auto work = [&]() { for (uint32_t i = next.fetch_add(1); i < n; i = next.fetch_add(1)) f(i); };
+    for (unsigned t = 1; t < nt; ++t) th.emplace_back(work);
+    work();
+    for (auto& t : th) t.join();
+}
+
 int job_build(int device, uint32_t n_index, const pg_contig_batch* batches, const std::vector<ChainSpec>& specs,
               uint32_t n_samples, bool cohort, const pg_table* table, const pg_hmm_params* params, bool cache_arena,
               pg_job** out, char* err, size_t errlen) {
     *out = nullptr;
     if (!batches || !table || !params || n_index == 0 || specs.empty()) { set_err(err, errlen, "null argument"); return PG_ERR_INVALID; }
+#ifdef PG_HOST_TIMING   // (measurement builds: where the host time of a job's construction goes)
+    const double tb0 = now_s();
+    double tb_last = tb0;
+    auto lap = [&](const char* what) { const double t = now_s(); fprintf(stderr, "[job_build] %-28s %8.3f ms\n", what, (t - tb_last) * 1e3); tb_last = t; };
+#else
+    auto lap = [](const char*) {};
+#endif
     if (params->run_phasing) {
         // Viterbi (pg_viterbi.hip): a row of states is one wave's lanes, so at most 64 selected paths (the reference's
         // own callers pass at most 30, src/commands.cpp:939)
@@ -599,9 +624,17 @@ int job_build(int device, uint32_t n_index, const pg_contig_batch* batches, cons
                 return PG_ERR_UNSUPPORTED;
             }
     }
-    for (uint32_t i = 0; i < n_index; ++i) {
-        const int rc = check_batch(&batches[i], !cohort, err, errlen);
-        if (rc != PG_OK) return rc;
+    {   // (per-variant validation: contigs on worker threads when there is enough of it — a merged one-shot job of a whole
+        //  genome spent 3 + 22 ms here and in the planning loop below, single-threaded, per round)
+        std::vector<int> rcs(n_index, PG_OK);
+        std::vector<std::string> msgs(n_index);
+        parallel_contigs(n_index, batches, [&](uint32_t i) {
+            char e[256] = {0};
+            rcs[i] = check_batch(&batches[i], !cohort, e, sizeof(e));
+            if (rcs[i] != PG_OK) msgs[i] = e;
+        });
+        for (uint32_t i = 0; i < n_index; ++i)
+            if (rcs[i] != PG_OK) { set_err(err, errlen, "%s", msgs[i].c_str()); return rcs[i]; }
     }
     for (const ChainSpec& sp : specs) {
         const pg_contig_batch& b = batches[sp.index];
@@ -610,6 +643,7 @@ int job_build(int device, uint32_t n_index, const pg_contig_batch* batches, cons
             return PG_ERR_INVALID;
         }
     }
+    lap("batch checks");
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) { set_err(err, errlen, "no HIP device available (no CPU fallback)"); return PG_ERR_DEVICE; }
     if (device < 0 || device >= ndev) { set_err(err, errlen, "bad device %d", device); return PG_ERR_INVALID; }
@@ -637,6 +671,7 @@ int job_build(int device, uint32_t n_index, const pg_contig_batch* batches, cons
     job->events = true;
     table_snapshot(const_cast<pg_table*>(table), job->tab_m, job->tab_e, &job->tab);
 
+    lap("streams, events, table");
     // ---- index contigs -------------------------------------------------------------------
     job->index.resize(n_index);
     bool wide_candidates = false, generic_needed = false;
@@ -644,7 +679,8 @@ int job_build(int device, uint32_t n_index, const pg_contig_batch* batches, cons
     bool lean_ok = true, force_generic = false;
     const KernelChoice kc = kernel_choice();
     force_generic = kc.generic; lean_ok = !kc.general && !kc.generic;
-    for (uint32_t i = 0; i < n_index; ++i) {
+    std::vector<char> wide_overflow(n_index, 0);
+    parallel_contigs(n_index, batches, [&](uint32_t i) {
         const pg_contig_batch& b = batches[i];
         IndexHost& x = job->index[i];
         x.V = b.n_variants; x.H = b.n_paths; x.HP = pad_paths(x.H ? x.H : 1);
@@ -687,13 +723,11 @@ int job_build(int device, uint32_t n_index, const pg_contig_batch* batches, cons
                     if (nl > PG_WIDE_MAX) nl = PG_WIDE_MAX;
                     x.widx[v] = (uint32_t)(woff / 16);
                     woff += pg_wide_entry_bytes((uint32_t)nl);
-                    if (woff / 16 >= 0xFFFFFFF0ull) { pg_job_destroy(job); set_err(err, errlen, "wide-column tables exceed 64 GB"); return PG_ERR_UNSUPPORTED; }
+                    if (woff / 16 >= 0xFFFFFFF0ull) { wide_overflow[i] = 1; return; }
                 }
             }
             x.wide_bytes = woff;
-            wide_candidates = true;
         }
-        if (x.HP >= 256) generic_needed = true;
         x.lean = lean_ok && x.HP == 64 && x.H == 64 && maxA == 2 && x.V > 0;
         x.small = lean_ok && x.HP == 16 && x.H == 16 && maxA == 2 && x.V > 0;   // (and enough of them: below)
         {
@@ -708,9 +742,16 @@ int job_build(int device, uint32_t n_index, const pg_contig_batch* batches, cons
             // PG_KERNELS=noleanx: the general kernel (cross-check)
             x.leanx = lean_ok && (x.HP == 128 || x.HP == 64) && !x.lean && maxA >= 1 && maxA <= PG_AMAX && x.V > 0 && kc.leanx != 0;
         }
+    });
+    for (uint32_t i = 0; i < n_index; ++i) {
+        const IndexHost& x = job->index[i];
+        if (wide_overflow[i]) { pg_job_destroy(job); set_err(err, errlen, "wide-column tables exceed 64 GB"); return PG_ERR_UNSUPPORTED; }
+        if (x.wide_bytes) wide_candidates = true;
+        if (x.HP >= 256) generic_needed = true;
         if (x.V > max_v) max_v = x.V;
     }
     job->max_v = max_v;
+    lap("index planning");
     {
         // k_sweep_small16 packs four H = 16 half-chains into a wave: a throughput kernel.  A single chain is faster on the
         // general kernel (four states per lane instead of sixteen: 375 vs 470 ns per column); PG_KERNELS=small / nosmall forces.
@@ -869,6 +910,7 @@ int job_build(int device, uint32_t n_index, const pg_contig_batch* batches, cons
         }
     }
     job->host_s[0] = now_s() - t_alloc;
+    lap("arena plan + allocation");
     unsigned char* A = job->arena;
     job->d_contigs = (DevContig*)(A + o_contigs);
     job->d_ncols = (uint32_t*)(A + o_ncols);
@@ -934,8 +976,10 @@ int job_build(int device, uint32_t n_index, const pg_contig_batch* batches, cons
     if ((he = hipMemcpyAsync(job->d_contigs, hd.data(), sizeof(DevContig) * n_chains, hipMemcpyHostToDevice, job->stream)) != hipSuccess ||
         (he = hipStreamSynchronize(job->stream)) != hipSuccess)
         return fail(PG_ERR_DEVICE, "hipMemcpy contigs", he);
+    lap("descriptors");
     const int rc = upload_inputs(job, batches, specs, true, err, errlen);
     if (rc != PG_OK) { pg_job_destroy(job); return rc; }
+    lap("upload of the inputs");
     *out = job;
     return PG_OK;
 }
