@@ -19,6 +19,7 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <algorithm>
 #include <atomic>
 #include <chrono>
 #include <condition_variable>
@@ -504,10 +505,15 @@ int upload_inputs(pg_job* job, const pg_contig_batch* batches, const std::vector
     unsigned char* A = job->arena;
     hipStream_t s = job->stream;
     uint64_t bi = 0, bs = 0;
+    // the copies are collected first: a large upload from pageable buffers (a whole genome through the one-shot call: 264
+    // arrays, 1.06 GB) is then issued from several host threads on streams of their own — the runtime stages a pageable
+    // source through its bounce buffers on the calling thread, one copy after the other: 24 ms on one thread
+    struct Copy { void* dst; const void* src; size_t bytes; };
+    std::vector<Copy> copies;
 #define UP(off, src, bytes, acc)                                                                              \
     do {                                                                                                      \
         if ((bytes) > 0) {                                                                                    \
-            HIP_TRY(hipMemcpyAsync((void*)(A + (off)), (src), (bytes), hipMemcpyDefault, s));  /* (host or device source) */ \
+            copies.push_back({(void*)(A + (off)), (const void*)(src), (size_t)(bytes)});  /* (host or device source) */ \
             acc += (uint64_t)(bytes);                                                                         \
         }                                                                                                     \
     } while (0)
@@ -548,6 +554,40 @@ int upload_inputs(pg_job* job, const pg_contig_batch* batches, const std::vector
         }
     }
 #undef UP
+    {
+        size_t total = 0;
+        for (const Copy& c : copies) total += c.bytes;
+        unsigned nt = (total >= ((size_t)64 << 20) && copies.size() >= 8) ? 4u : 1u;
+        if (nt > 1) {
+            std::vector<std::vector<size_t>> share(nt);   // largest first onto the least loaded thread
+            std::vector<size_t> load(nt, 0), order(copies.size());
+            for (size_t i = 0; i < order.size(); ++i) order[i] = i;
+            std::sort(order.begin(), order.end(), [&](size_t x, size_t y) { return copies[x].bytes > copies[y].bytes; });
+            for (size_t i : order) {
+                unsigned best = 0;
+                for (unsigned t = 1; t < nt; ++t) if (load[t] < load[best]) best = t;
+                share[best].push_back(i); load[best] += copies[i].bytes;
+            }
+            std::vector<int> rcs(nt, (int)hipSuccess);
+            auto work = [&](unsigned t) {
+                hipStream_t st = nullptr;
+                hipError_t e = hipSetDevice(job->device);
+                if (e == hipSuccess) e = hipStreamCreateWithFlags(&st, hipStreamNonBlocking);
+                for (size_t i : share[t]) { if (e != hipSuccess) break; e = hipMemcpyAsync(copies[i].dst, copies[i].src, copies[i].bytes, hipMemcpyDefault, st); }
+                if (e == hipSuccess) e = hipStreamSynchronize(st);
+                if (st) hipStreamDestroy(st);
+                rcs[t] = (int)e;
+            };
+            std::vector<std::thread> th;
+            for (unsigned t = 1; t < nt; ++t) th.emplace_back(work, t);
+            work(0);
+            for (auto& t : th) t.join();
+            for (unsigned t = 0; t < nt; ++t)
+                if (rcs[t] != (int)hipSuccess) { set_err(err, errlen, "input upload: %s", hipGetErrorString((hipError_t)rcs[t])); return PG_ERR_DEVICE; }
+        } else {
+            for (const Copy& c : copies) HIP_TRY(hipMemcpyAsync(c.dst, c.src, c.bytes, hipMemcpyDefault, s));
+        }
+    }
     HIP_TRY(hipStreamSynchronize(s));
     job->up_bytes[0] = bi; job->up_bytes[1] = bs;
     job->host_s[1] = now_s() - t0;
