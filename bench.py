@@ -359,11 +359,17 @@ def main():
         # per rank: its chains, its variants, its own run time and the time it spent in the exchange (the scaling curve's anatomy)
         mine_row = {"rank": rank, "chains": len(mine), "variants": int(sum(sizes[i] for i in mine)), "longest_chain": int(max([sizes[i] for i in mine] or [0])),
                     "run_ms_per_step": rank_ms["run"] / max(args.steps, 1), "gather_ms_per_step": rank_ms["gather"] / max(args.steps, 1)}
+        rows = [mine_row]
         if world > 1:
-            rows = [None] * world
-            dist.all_gather_object(rows, mine_row)
-        else:
-            rows = [mine_row]
+            keys = ["chains", "variants", "longest_chain", "run_ms_per_step", "gather_ms_per_step"]
+            mine_t = torch.tensor([float(mine_row[k]) for k in keys], dtype=torch.float64, device=dev)
+            got = [torch.zeros_like(mine_t) for _ in range(world)]
+            dist.all_gather(got, mine_t)   # (five numbers per rank, the same collective path as the timing reductions)
+            rows = []
+            for r, t_r in enumerate(got):
+                vals = t_r.tolist()
+                rows.append({"rank": r, "chains": int(vals[0]), "variants": int(vals[1]), "longest_chain": int(vals[2]),
+                             "run_ms_per_step": vals[3], "gather_ms_per_step": vals[4]})
 
         # end to end: host buffers -> H2D of every input -> run -> D2H of every result, into the resident arena and into
         # result buffers the host already holds (allocated — and touched — once, outside the timed region)
