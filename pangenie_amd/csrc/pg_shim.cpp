@@ -483,7 +483,7 @@ int sample_upload(pg_job* job, const std::vector<ChainSpec>& specs, unsigned cha
         }
         const size_t b0 = job->chains[c0].o_cov - lo0;
         const size_t b1 = c1 < n ? job->chains[c1].o_cov - lo0 : job->sample_bytes;
-        rcs[k] = (int)hipMemcpyAsync(dev_base + b0, job->staging + b0, b1 - b0, hipMemcpyHostToDevice, stream);
+        if (b1 > b0) rcs[k] = (int)hipMemcpyAsync(dev_base + b0, job->staging + b0, b1 - b0, hipMemcpyHostToDevice, stream);
     };
     std::vector<std::thread> th;
     for (size_t k = 1; k < pieces; ++k) th.emplace_back(work, k);
