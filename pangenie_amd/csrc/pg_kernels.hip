@@ -968,6 +968,9 @@ typedef double v2f64 __attribute__((ext_vector_type(2)));  // native vector type
 typedef GAS v2f64 gdouble2;
 typedef GAS const v2f64 gcdouble2;
 
+#ifndef PG_PARK_ROWS
+#define PG_PARK_ROWS 16
+#endif
 template <int HP, int R>
 struct ChainCfg {
     static constexpr int T = HP * HP / R;      // compute threads
@@ -983,6 +986,12 @@ struct ChainCfg {
     static constexpr bool UNI = HP >= 64;
     static constexpr int RB = (PG_REC_ALLELES + HP + 63) & ~63;
     static constexpr int WORDS = RB / 8;
+    // phase 2 without the LDS ring (HP = 128): a thread holds 32 rows of its own column AND of the prefetched partner
+    // column; with the rest of the step that is ~22 doubles more than the 256 registers two waves per SIMD leave, and
+    // the compiler spilled them to scratch inside the state loop (43 KB each way per 128 KB column, and every reload a
+    // trip to memory).  The last PARK rows of the thread's OWN column live in LDS instead (read and rewritten by the
+    // thread itself: no barrier involved), PARK/2 16-byte slots per thread in dynamic LDS.
+    static constexpr int PARK = (!LOADER && R > 16) ? PG_PARK_ROWS : 0;
     static_assert(T % 64 == 0 && TT <= 1024, "bad workgroup size");
     static_assert(WORDS <= 64, "record must fit one wave-wide 8-byte load");
     static_assert(64 % R == 0 || R % 64 == 0, "row groups must not straddle 64-column blocks");
@@ -1518,6 +1527,9 @@ DEVI void forward_body(const DevContig& dc, ChainShared<HP, R>& sh, uint32_t C, 
     };
     double x[R], ui[R > 16 ? 1 : R];
     double vA[(PHASE == 2 && !RING) ? R : 1];  // register-prefetched beta' column (phase 2 without the LDS ring)
+    // rows KP .. R-1 of the thread's own column live in LDS between steps (ChainCfg::PARK): slot q = rows KP + 2q, + 1
+    constexpr int KP = (PHASE == 2 && !RING) ? R - Cfg::PARK : R;
+    v2f64* const park = (v2f64*)ring + p.tid;
     unsigned long long tq = 0;  // inline loader (no loader wave): next record in flight
     if (!Cfg::LOADER && p.wave == 0) {
         rec_stage(first - 1, rec_load(first - 1));
@@ -1571,6 +1583,10 @@ DEVI void forward_body(const DevContig& dc, ChainShared<HP, R>& sh, uint32_t C, 
 #pragma unroll
         for (int k = 0; k < R; ++k) part += x[k];
         write_colsums<HP, R>(sh, (lo - 1) & 1u, p, part);
+    }
+    if constexpr (KP < R) {
+#pragma unroll
+        for (int k = KP; k < R; k += 2) park[(size_t)((k - KP) >> 1) * Cfg::T] = v2f64{x[k], x[k + 1]};
     }
     lds_barrier();  // Bx
 
@@ -1649,10 +1665,20 @@ DEVI void forward_body(const DevContig& dc, ChainShared<HP, R>& sh, uint32_t C, 
         double part = 0.0;
         // one state: P' = fma(c0s, x, fma(u_i, sc, ujs)); the recursion continues with x = P' * e; the
         // posterior (phase 2) takes P' * beta'
+        v2f64 xq = v2f64{0.0, 0.0};  // the parked row pair in hand
         auto state = [&](int k, double uik, double e, double& pprev) __attribute__((always_inline)) {
-            const double pk = fma(c0s, x[k], fma(uik, sc, ujs));
-            x[k] = pk * e;
-            part += x[k];
+            double xk;
+            if (k < KP) xk = x[k < KP ? k : 0];
+            else {
+                if (!(k & 1)) xq = park[(size_t)((k - KP) >> 1) * Cfg::T];
+                xk = (k & 1) ? xq.y : xq.x;
+            }
+            const double pk = fma(c0s, xk, fma(uik, sc, ujs));
+            const double xn = pk * e;
+            part += xn;
+            if (k < KP) x[k < KP ? k : 0] = xn;
+            else if (k & 1) { xq.y = xn; park[(size_t)((k - KP) >> 1) * Cfg::T] = xq; }
+            else xq.x = xn;
             if constexpr (PHASE == 2) {
                 if constexpr (RING) bt[k] *= pk;
                 else vb[k] *= pk;
@@ -1877,6 +1903,19 @@ DEVI void backward_body(const DevContig& dc, ChainShared<HP, R>& sh, uint32_t C,
     };
     constexpr int NV = (PHASE == 2 && !RING) ? R : 1;
     double y[R], vA[NV], vB[(PHASE == 2 && !RING && VBUF == 2) ? R : 1];
+    // rows KP .. R-1 of the thread's own column live in LDS between steps (ChainCfg::PARK, see forward_body)
+    constexpr int KP = (PHASE == 2 && !RING) ? R - Cfg::PARK : R;
+    v2f64* const park = (v2f64*)ring + p.tid;
+    auto y_get = [&](int k, v2f64& q) __attribute__((always_inline)) -> double {
+        if (k < KP) return y[k < KP ? k : 0];
+        if (!(k & 1)) q = park[(size_t)((k - KP) >> 1) * Cfg::T];
+        return (k & 1) ? q.y : q.x;
+    };
+    auto y_put = [&](int k, v2f64& q, double val) __attribute__((always_inline)) {
+        if (k < KP) y[k < KP ? k : 0] = val;
+        else if (k & 1) { q.y = val; park[(size_t)((k - KP) >> 1) * Cfg::T] = q; }
+        else q.x = val;
+    };
     double Sy = 0.0;
     unsigned long long tq = 0;  // inline loader (no loader wave): next record in flight
     if (!Cfg::LOADER && p.wave == 0) {
@@ -1903,6 +1942,10 @@ DEVI void backward_body(const DevContig& dc, ChainShared<HP, R>& sh, uint32_t C,
             if constexpr (VBUF == 2) load_col(top - 1, vB);
         }
     }
+    if constexpr (KP < R) {
+#pragma unroll
+        for (int k = KP; k < R; k += 2) park[(size_t)((k - KP) >> 1) * Cfg::T] = v2f64{y[k], y[k + 1]};
+    }
     lds_barrier();  // P0
     RecInfo cur = decode_record<Cfg::UNI>(sh.rec[(uint32_t)(t0 + 1) & 7u], p.j, p.i0, full, dc.wide);
     const bool prof = kChainProf && (dc.debug & 8u) != 0;
@@ -1916,8 +1959,9 @@ DEVI void backward_body(const DevContig& dc, ChainShared<HP, R>& sh, uint32_t C,
     auto step = [&](int64_t t, double (&v)[NV]) {
         // beta_hat_{t+1} = y / Sy, uniform if the sum is zero (hmm.cpp:374-380)
         if (__builtin_expect(!(Sy > 0.0) || !(Sy < INFINITY), 0)) {
+            v2f64 uq = v2f64{0.0, 0.0};
 #pragma unroll
-            for (int k = 0; k < R; ++k) y[k] = (p.j < H && p.i0 + k < H) ? unif : 0.0;
+            for (int k = 0; k < R; ++k) y_put(k, uq, (p.j < H && p.i0 + k < H) ? unif : 0.0);
             Sy = 1.0;
         }
         // partner column v'_t out of the ring (landed before B_{t+1}), read ahead of its use; then
@@ -1937,19 +1981,24 @@ DEVI void backward_body(const DevContig& dc, ChainShared<HP, R>& sh, uint32_t C,
         const bool fast = cur.fast;
         FastE fe = cur.fe;
         if (Cfg::UNI) fe.rowbits = __builtin_amdgcn_readfirstlane(fe.rowbits);
+        // (values, not fields: "bit ? fe.eB : fe.eA" is a conditional LVALUE — a select between two addresses inside the struct —
+        // and where the struct then stayed in memory the 32 selects of a loop became 32 loads from SCRATCH, indexed by the bit)
+        const double feA = fe.eA, feB = fe.eB;
         double w[KEEPW ? R : 1];
         double part = 0.0;
+        v2f64 yq = v2f64{0.0, 0.0};  // the parked row pair in hand
         if (fast) {
 #pragma unroll
             for (int k = 0; k < R; ++k) {
-                const double wk = (kExp & 16u) ? y[k] : y[k] * (((fe.rowbits >> k) & 1u) ? fe.eB : fe.eA);
+                const double yk = y_get(k, yq);
+                const double wk = (kExp & 16u) ? yk : yk * (((fe.rowbits >> k) & 1u) ? +feB : +feA);
                 if constexpr (KEEPW) w[k] = wk;
                 part += (kExp & 16u) ? (k == 0 ? wk : 0.0) : wk;
             }
         } else if (cur.em.wide) {  // rare: branch at loop level, so the wide lookups stay out of the other loops' live ranges
 #pragma unroll
             for (int k = 0; k < R; ++k) {
-                const double wk = y[k] * emission_wide(rec1, p.i0 + k, cur.em);
+                const double wk = y_get(k, yq) * emission_wide(rec1, p.i0 + k, cur.em);
                 if constexpr (KEEPW) w[k] = wk;
                 part += wk;
                 if constexpr (R > 16) { if ((k & 7) == 7) __builtin_amdgcn_sched_barrier(0); }
@@ -1957,7 +2006,7 @@ DEVI void backward_body(const DevContig& dc, ChainShared<HP, R>& sh, uint32_t C,
         } else {
 #pragma unroll
             for (int k = 0; k < R; ++k) {
-                const double wk = y[k] * emission_narrow(rec1, p.i0 + k, cur.em);
+                const double wk = y_get(k, yq) * emission_narrow(rec1, p.i0 + k, cur.em);
                 if constexpr (KEEPW) w[k] = wk;
                 part += wk;
                 if constexpr (R > 16) { if ((k & 7) == 7) __builtin_amdgcn_sched_barrier(0); }
@@ -1987,14 +2036,19 @@ DEVI void backward_body(const DevContig& dc, ChainShared<HP, R>& sh, uint32_t C,
             for (int k = 0; k < R; ++k) {
                 double wk;
                 if constexpr (KEEPW) wk = w[k];
-                else if constexpr (KIND == 1) wk = y[k] * (((fe.rowbits >> k) & 1u) ? fe.eB : fe.eA);
-                else if constexpr (KIND == 2) wk = y[k] * emission_wide(rec1, p.i0 + k, cur.em);
-                else wk = y[k] * emission_narrow(rec1, p.i0 + k, cur.em);
+                else {
+                    const double yk = y_get(k, yq);
+                    if constexpr (KIND == 1) wk = yk * (((fe.rowbits >> k) & 1u) ? +feB : +feA);
+                    else if constexpr (KIND == 2) wk = yk * emission_wide(rec1, p.i0 + k, cur.em);
+                    else wk = yk * emission_narrow(rec1, p.i0 + k, cur.em);
+                }
                 double uik;
                 if constexpr (R <= 16) uik = ui[k];
                 else if constexpr (UDPP) uik = u_of_row(urep, k);
                 else uik = readlane_f64(urow, __builtin_amdgcn_readfirstlane((int)((p.i0 + k) & 63u)));
-                y[k] = (kExp & 16u) ? (k == 0 ? wk + uik + uj : wk) : fma(k0, wk, uik + uj);  // beta'_t
+                const double yn = (kExp & 16u) ? (k == 0 ? wk + uik + uj : wk) : fma(k0, wk, uik + uj);  // beta'_t
+                y_put(k, yq, yn);
+                if constexpr (PHASE == 2 && !RING) v[k] *= yn;  // P'_t * beta'_t (posterior below)
                 if constexpr (STORE) { if (k & 1) { store_pair(t, k, y[k - 1], y[k]); __builtin_amdgcn_sched_barrier(0); } }
                 else if constexpr (R > 16) { if ((k & 7) == 7) __builtin_amdgcn_sched_barrier(0); }
             }
@@ -2010,9 +2064,7 @@ DEVI void backward_body(const DevContig& dc, ChainShared<HP, R>& sh, uint32_t C,
 #pragma unroll
                 for (int k = 0; k < R; ++k) vt[k] *= y[k];
                 posterior<HP, R>(sh, part_out, part_slots, nxt, (uint32_t)t, p, vt);
-            } else {
-#pragma unroll
-                for (int k = 0; k < R; ++k) v[k] *= y[k];
+            } else {  // (the products were formed in beta_loop)
                 posterior<HP, R>(sh, part_out, part_slots, nxt, (uint32_t)t, p, v);
                 load_col(t - VBUF, v);
             }
@@ -4770,6 +4822,7 @@ template <int HP, int R, int VBUF, bool KEEPW, int PHASE>
 static void launch_one(const DevContig* d_contigs, uint32_t n_contigs, uint32_t chunk, hipStream_t s) {
     using Cfg = ChainCfg<HP, R>;
     size_t dyn = (Cfg::LOADER && PHASE == 2) ? (size_t)kRingSlots * HP * HP * 8 : 0;  // partner-column ring
+    if (!Cfg::LOADER && PHASE == 2) dyn = (size_t)(Cfg::PARK / 2) * 16 * Cfg::T;       // parked rows (ChainCfg::PARK)
     if (HP == 64 && dyn > 0) {  // the triangle ring of lean chains (compact slots + the zero unit)
         if (dyn < kTriRingB) dyn = kTriRingB;
     }
