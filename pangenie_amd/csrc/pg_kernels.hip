@@ -2190,10 +2190,14 @@ template <int HP, int R, int VBUF, bool KEEPW, int PHASE>
 // half-chain, held to 128 registers (a few spills) so that a SIMD takes four waves.  With 16 rows per lane (one compute
 // wave of 209 - 240 registers) a CU ran four half-chains at a time and two thirds of a 1024-chain cohort's time was
 // waiting: 72 -> 59 ms per step on `cohort_h17` (PG_HP32_ROWS=16 PG_HP32_WAVES=1 builds the old configuration).
+// Phase 2 (posterior inline) is better off with three waves per SIMD and 168 registers: 22.5 -> 20.5 ms there.
 #ifndef PG_HP32_WAVES
 #define PG_HP32_WAVES 4
 #endif
-__global__ __launch_bounds__((ChainCfg<HP, R>::TT), (HP == 32 ? PG_HP32_WAVES : 1)) void k_sweep(const DevContig* __restrict__ contigs, uint32_t chunk) {
+#ifndef PG_HP32_WAVES_P2
+#define PG_HP32_WAVES_P2 3
+#endif
+__global__ __launch_bounds__((ChainCfg<HP, R>::TT), (HP == 32 ? (PHASE == 2 ? PG_HP32_WAVES_P2 : PG_HP32_WAVES) : 1)) void k_sweep(const DevContig* __restrict__ contigs, uint32_t chunk) {
     __shared__ ChainShared<HP, R> sh;
     extern __shared__ __attribute__((aligned(16))) unsigned char dyn_ring[];  // phase 2: kRingSlots column slots
     const DevContig& dc = contigs[blockIdx.x];
