@@ -92,7 +92,7 @@ struct DevTable {
 
 struct DevContig {
     uint32_t V, H, HP, RB;
-    uint32_t T;            // threads per chain workgroup = HP*HP/R
+    uint32_t T;            // entries of posterior partials per column and slot pair: threads per chain workgroup = HP*HP/R (half of them at HP = 32)
     uint32_t pad0;
     double dist_scale;     // 0.000004 * recombrate * effective_N
     int32_t uniform;
@@ -157,6 +157,11 @@ struct DevContig {
     // half-chain) writes the four class sums of a column, part[4 c + 2 (row allele) + (column allele)], and
     // k_bins_lean2 turns them into bins — instead of per-thread partials reduced by k_bins
     uint32_t  cls4;
+    // rows and lanes of a stored column that carry data: H rounded up to a multiple of 4 (fused jobs at HP = 32, where
+    // 17 paths — the 15 + 1 behind haplotype sampling — would otherwise move 32 x 32 states per column for 17 x 17 real ones), else HP.
+    // Phase 1 stores only rows and lanes below `live` (whole 64-byte sectors), the loader of phase 2 fetches only those,
+    // and the rest of the LDS ring is zeroed once.  Nothing else reads the columns of a fused job.
+    uint32_t  live;
     double*   xbuf;            // [2][HP*HP] generic kernel scratch (forward role first)
     uint32_t* err;
     unsigned long long* prof;  // [64] in-kernel cycle counters (-DPG_CHAIN_PROF / -DPG_LEAN_TIMELINE builds), profiling only

@@ -992,6 +992,8 @@ struct ChainCfg {
     // trip to memory).  The last PARK rows of the thread's OWN column live in LDS instead (read and rewritten by the
     // thread itself: no barrier involved), PARK/2 16-byte slots per thread in dynamic LDS.
     static constexpr int PARK = (!LOADER && R > 16) ? PG_PARK_ROWS : 0;
+    // columns of fused jobs carry data in their first DevContig::live rows and lanes only (see there)
+    static constexpr bool SHORT = HP == 32;
     static_assert(T % 64 == 0 && TT <= 1024, "bad workgroup size");
     static_assert(WORDS <= 64, "record must fit one wave-wide 8-byte load");
     static_assert(64 % R == 0 || R % 64 == 0, "row groups must not straddle 64-column blocks");
@@ -1122,6 +1124,21 @@ DEVI void dma_column(const gdouble* cols, int64_t c, int64_t C, LAS unsigned cha
     for (uint32_t q = 0; q < SHARE / 1024u; ++q)
         __builtin_amdgcn_global_load_lds((const GAS void*)(g + q * 1024u), (LAS void*)(l + q * 1024u), 16, 0, 0);
 }
+// ... its first NT transfers only, and of those the lanes whose column lies below `live` (ChainCfg::SHORT: rows and lanes
+// from `live` on are neither stored nor fetched; their part of the ring is zeroed once by the compute waves)
+template <int HP, int NPARTS, int NT>
+DEVI void dma_column_live(const gdouble* cols, int64_t c, int64_t C, LAS unsigned char* ring, uint32_t lane, uint32_t part, uint32_t live) {
+    if (c < 0 || c >= C) return;
+    constexpr uint32_t COLB = HP * HP * 8u, SHARE = COLB / (NPARTS > 0 ? NPARTS : 1);
+    static_assert((uint32_t)NT <= SHARE / 1024u && HP <= 64, "a transfer is 64 lanes: whole rows of pairs");
+    const GAS char* g = (const GAS char*)(cols + (size_t)c * HP * HP) + part * SHARE + lane * 16u;
+    LAS unsigned char* l = ring + (uint32_t)(c & (kRingSlots - 1)) * COLB + part * SHARE;
+    if ((lane % (uint32_t)HP) < live) {
+#pragma unroll
+        for (uint32_t q = 0; q < (uint32_t)NT; ++q)
+            __builtin_amdgcn_global_load_lds((const GAS void*)(g + q * 1024u), (LAS void*)(l + q * 1024u), 16, 0, 0);
+    }
+}
 // column record -> its LDS slot by DMA as well (lanes < RB/16 move 16 B each): the loader wave then
 // has no register-returning loads at all and every completion is an explicit counted vmcnt
 template <int RB>
@@ -1204,7 +1221,18 @@ DEVI void ring_read_tri(const unsigned char* ring, int64_t c, const uint32_t (&l
 // per-thread coordinates of a compute thread
 struct ThreadPos {
     uint32_t tid, lane, wave, j, rg, i0, rb;
+    uint32_t pe, pT;   // posterior partials: this thread's entry (PG_NO_ENTRY: none) and the entries per column and slot pair
 };
+#define PG_NO_ENTRY 0xFFFFFFFFu
+// HP = 32: lanes l and l + 32 of a wave hold rows of the SAME column — their partials are added in registers (sum of the two
+// halves in every lane) and only the lower half's lanes below DevContig::live write one: T / 2 entries per slot pair, of
+// which k_bins fetches the real paths' only (2 KB -> 544 B per column and slot pair at 17 paths)
+DEVI double fold32(double v) {
+    const int lo = __double2loint(v), hi = __double2hiint(v);
+    const auto a = __builtin_amdgcn_permlane32_swap(lo, lo, false, false);
+    const auto b = __builtin_amdgcn_permlane32_swap(hi, hi, false, false);
+    return __hiloint2double(b[0], a[0]) + __hiloint2double(b[1], a[1]);
+}
 
 // Column-sum exchange.  Before the barrier every thread parks the sum of its R rows of its column;
 // after it every thread adds the NRG partials of its column.  By symmetry of the column (v_ij = v_ji)
@@ -1364,10 +1392,16 @@ DEVI void posterior(ChainShared<HP, R>& sh, gdouble* part_out, uint32_t part_slo
     // wave-wide 16-byte store costs the texture-address unit a third of two 8-byte ones, and
     // phase-2 compute waves have no loads in flight (partner columns arrive through the LDS ring),
     // so these stores never make them wait.  Layout: part[((c * part_slots/2 + q) * T + tid) * 2 + (a & 1)].
-    gdouble2* dst = (gdouble2*)part_out + (size_t)c * (part_slots >> 1) * Cfg::T + p.tid;
+    if constexpr (HP == 32) {
+#pragma unroll
+        for (int q = 0; q < (PG_AMAX + 1) / 2; ++q)
+            if ((uint32_t)(2 * q) < nl) { acc[2 * q] = fold32(acc[2 * q]); acc[2 * q + 1] = fold32(acc[2 * q + 1]); }
+    }
+    if (p.pe == PG_NO_ENTRY) return;
+    gdouble2* dst = (gdouble2*)part_out + (size_t)c * (part_slots >> 1) * p.pT + p.pe;
 #pragma unroll
     for (int q = 0; q < (PG_AMAX + 1) / 2; ++q)
-        if ((uint32_t)(2 * q) < nl) dst[(size_t)q * Cfg::T] = v2f64{acc[2 * q], acc[2 * q + 1]};
+        if ((uint32_t)(2 * q) < nl) dst[(size_t)q * p.pT] = v2f64{acc[2 * q], acc[2 * q + 1]};
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1449,6 +1483,38 @@ DEVI void forward_body(const DevContig& dc, ChainShared<HP, R>& sh, uint32_t C, 
                 return;
             }
         }
+        if constexpr (RING && Cfg::SHORT) {
+            // short columns (DevContig::live < HP): live / 4 transfers per column instead of HP / 4, the others' lanes never fetched
+            const uint32_t live = (uint32_t)__builtin_amdgcn_readfirstlane((int)dc.live);
+            if (live < (uint32_t)HP) {
+                auto run = [&](auto nt_c) {
+                    constexpr int NT = decltype(nt_c)::value;
+                    constexpr int KP0 = KSL * (1 + NT);
+                    static_assert(KP0 < 64 && Cfg::NLOAD == 1, "vmcnt is 6 bits");
+                    for (int q = -1; q < 6; ++q) dma_record<Cfg::RB>(colrec, (int64_t)first + q, C, lrec, p.lane);
+                    for (int q = 0; q < kRingDist; ++q) dma_column_live<HP, 1, NT>(cols, (int64_t)lo + q, C, lring, p.lane, 0, live);
+                    wait_vmem_all();
+                    lds_barrier();  // P0
+                    lds_barrier();  // Bx
+                    for (uint32_t t = first; t < hi; ++t) {
+                        dma_record<Cfg::RB>(colrec, (int64_t)t + 6, C, lrec, p.lane);
+                        dma_column_live<HP, 1, NT>(cols, (int64_t)t + kRingDist, C, lring, p.lane, 0, live);
+                        if ((int64_t)t + 6 >= (int64_t)C) wait_vmem_all();  // tail
+                        else wait_vmem_keep<KP0>();
+                        lds_barrier();  // B_t
+                    }
+                    lds_barrier();  // F
+                };
+                constexpr int FULL = HP / 4;   // = HP * HP * 8 / 1024 at HP = 32
+                static_assert(HP * HP * 8 / 1024 == FULL, "short columns: two row pairs per transfer");
+                switch (live / 4u) {
+                    case FULL - 3: run(std::integral_constant<int, FULL - 3>{}); break;
+                    case FULL - 2: run(std::integral_constant<int, FULL - 2>{}); break;
+                    default: run(std::integral_constant<int, FULL - 1>{}); break;   // (live / 4 == FULL - 1; fewer paths run at HP = 16)
+                }
+                return;
+            }
+        }
         if (lw == 0)  // records first-1 (column 0, or the column resumed from) .. first+5
             for (int q = -1; q < 6; ++q) dma_record<Cfg::RB>(colrec, (int64_t)first + q, C, lrec, p.lane);
         if (RING)
@@ -1479,6 +1545,19 @@ DEVI void forward_body(const DevContig& dc, ChainShared<HP, R>& sh, uint32_t C, 
     gu8* fallback = (gu8*)dc.fwd_fallback;
     const size_t colsz = tri ? (size_t)dc.col_stride : (size_t)HP * HP;
     const uint32_t dbg = dc.debug;
+    // short columns (ChainCfg::SHORT): this thread stores / resumes from its rows k < kl only
+    const uint32_t live = Cfg::SHORT ? (uint32_t)__builtin_amdgcn_readfirstlane((int)dc.live) : (uint32_t)HP;
+    const int kl = Cfg::SHORT ? (p.j < live ? (int)live - (int)p.i0 : 0) : R;
+    p.pe = p.tid; p.pT = (uint32_t)Cfg::T;
+    if constexpr (HP == 32) { p.pT = (uint32_t)Cfg::T / 2u; p.pe = (p.lane < 32u && p.j < live) ? p.wave * 32u + p.j : PG_NO_ENTRY; }
+    if constexpr (RING && Cfg::SHORT) {
+        if (live < (uint32_t)HP) {   // the part of the ring that no transfer writes: zero, once (read as beta' = 0 by every step)
+            for (uint32_t u = p.tid; u < (uint32_t)kRingSlots * HP * HP / 2u; u += (uint32_t)Cfg::T) {
+                const uint32_t us = u % (uint32_t)(HP * HP / 2), q = us / (uint32_t)HP, j = us % (uint32_t)HP;
+                if (j >= live || 2u * q >= live) ((v2f64*)ring)[u] = v2f64{0.0, 0.0};
+            }
+        }
+    }
 
     // where this phase stores column c (c in [lo,hi)) and where the column to resume from lives
     gdouble* wr = fwd;
@@ -1492,13 +1571,15 @@ DEVI void forward_body(const DevContig& dc, ChainShared<HP, R>& sh, uint32_t C, 
         if (kExp & 1u) return;
         gdouble2* dst = (gdouble2*)(wr + (size_t)c * colsz) + (size_t)(p.i0 >> 1) * HP + p.j;
 #pragma unroll
-        for (int k = 0; k < R; k += 2) dst[(size_t)(k >> 1) * HP] = v2f64{x[k], x[k + 1]};
+        for (int k = 0; k < R; k += 2)
+            if (!Cfg::SHORT || k < kl) dst[(size_t)(k >> 1) * HP] = v2f64{x[k], x[k + 1]};
     };
     // store of one row pair, issued from inside the recursion loop: eight back-to-back 16-byte
     // stores per wave queue behind each other in the texture-address unit (store-issue bound);
     // spread between the arithmetic of the following rows they cost their issue slots only
     auto store_pair = [&](uint32_t c, int k, double a, double b) {
         if (kExp & 1u) return;
+        if (Cfg::SHORT && !(k < kl)) return;
         gdouble2* dst = (gdouble2*)(wr + (size_t)c * colsz) + (size_t)(p.i0 >> 1) * HP + p.j;
         dst[(size_t)(k >> 1) * HP] = v2f64{a, b};
     };
@@ -1506,7 +1587,11 @@ DEVI void forward_body(const DevContig& dc, ChainShared<HP, R>& sh, uint32_t C, 
         if (c >= C) return;
         gcdouble2* src = (gcdouble2*)(c + 1 == lo ? resume : (gcdouble*)(fwd + (size_t)c * colsz)) + (size_t)(p.i0 >> 1) * HP + p.j;
 #pragma unroll
-        for (int k = 0; k < R; k += 2) { const v2f64 t = src[(size_t)(k >> 1) * HP]; v[k] = t.x; v[k + 1] = t.y; }
+        for (int k = 0; k < R; k += 2) {
+            v2f64 t = v2f64{0.0, 0.0};
+            if (!Cfg::SHORT || k < kl) t = src[(size_t)(k >> 1) * HP];
+            v[k] = t.x; v[k + 1] = t.y;
+        }
     };
     // a column stored as its upper triangle (DevContig::tri: diagonal halved, nothing below it): element (i, j)
     // of the full column = the stored (min, max), the diagonal doubled.  Once per launch (the resume column).
@@ -1833,6 +1918,35 @@ DEVI void backward_body(const DevContig& dc, ChainShared<HP, R>& sh, uint32_t C,
                 return;
             }
         }
+        if constexpr (RING && Cfg::SHORT) {
+            const uint32_t live = (uint32_t)__builtin_amdgcn_readfirstlane((int)dc.live);   // (see forward_body)
+            if (live < (uint32_t)HP) {
+                auto run = [&](auto nt_c) {
+                    constexpr int NT = decltype(nt_c)::value;
+                    constexpr int KP0 = KSL * (1 + NT);
+                    static_assert(KP0 < 64 && Cfg::NLOAD == 1, "vmcnt is 6 bits");
+                    for (int q = -1; q < 5; ++q) dma_record<Cfg::RB>(colrec, t0 - q, (int64_t)C, lrec, p.lane);
+                    for (int q = 0; q < kRingDist; ++q) dma_column_live<HP, 1, NT>(cols, t0 - q, (int64_t)C, lring, p.lane, 0, live);
+                    wait_vmem_all();
+                    lds_barrier();  // P0
+                    for (int64_t t = t0; t >= bot; --t) {
+                        dma_record<Cfg::RB>(colrec, t - 5, (int64_t)C, lrec, p.lane);
+                        dma_column_live<HP, 1, NT>(cols, t - kRingDist, (int64_t)C, lring, p.lane, 0, live);
+                        if (t - 5 < 0) wait_vmem_all();  // tail
+                        else wait_vmem_keep<KP0>();
+                        lds_barrier();  // B_t
+                    }
+                    lds_barrier();  // F
+                };
+                constexpr int FULL = HP / 4;
+                switch (live / 4u) {
+                    case FULL - 3: run(std::integral_constant<int, FULL - 3>{}); break;
+                    case FULL - 2: run(std::integral_constant<int, FULL - 2>{}); break;
+                    default: run(std::integral_constant<int, FULL - 1>{}); break;
+                }
+                return;
+            }
+        }
         if (lw == 0)
             for (int q = -1; q < 5; ++q) dma_record<Cfg::RB>(colrec, t0 - q, (int64_t)C, lrec, p.lane);  // t0+1 .. t0-4
         if (RING)
@@ -1861,6 +1975,19 @@ DEVI void backward_body(const DevContig& dc, ChainShared<HP, R>& sh, uint32_t C,
     gdouble* bscale = (gdouble*)dc.bscale;
     gdouble* bsum = (gdouble*)dc.bsum;
     const size_t colsz = tri ? (size_t)dc.col_stride : (size_t)HP * HP;
+    // short columns (ChainCfg::SHORT, see forward_body): this thread stores / resumes from its rows k < kl only
+    const uint32_t live = Cfg::SHORT ? (uint32_t)__builtin_amdgcn_readfirstlane((int)dc.live) : (uint32_t)HP;
+    const int kl = Cfg::SHORT ? (p.j < live ? (int)live - (int)p.i0 : 0) : R;
+    p.pe = p.tid; p.pT = (uint32_t)Cfg::T;
+    if constexpr (HP == 32) { p.pT = (uint32_t)Cfg::T / 2u; p.pe = (p.lane < 32u && p.j < live) ? p.wave * 32u + p.j : PG_NO_ENTRY; }
+    if constexpr (RING && Cfg::SHORT) {
+        if (live < (uint32_t)HP) {
+            for (uint32_t u = p.tid; u < (uint32_t)kRingSlots * HP * HP / 2u; u += (uint32_t)Cfg::T) {
+                const uint32_t us = u % (uint32_t)(HP * HP / 2), q = us / (uint32_t)HP, j = us % (uint32_t)HP;
+                if (j >= live || 2u * q >= live) ((v2f64*)ring)[u] = v2f64{0.0, 0.0};
+            }
+        }
+    }
 
     // where this phase stores column c (c in [bot,top]) and where the column to resume from lives
     gdouble* wr = cols;
@@ -1874,7 +2001,11 @@ DEVI void backward_body(const DevContig& dc, ChainShared<HP, R>& sh, uint32_t C,
         if (c < 0) return;
         gcdouble2* src = (gcdouble2*)(c == top + 1 ? resume : (gcdouble*)(cols + (size_t)c * colsz)) + (size_t)(p.i0 >> 1) * HP + p.j;
 #pragma unroll
-        for (int k = 0; k < R; k += 2) { const v2f64 t = src[(size_t)(k >> 1) * HP]; v[k] = t.x; v[k + 1] = t.y; }
+        for (int k = 0; k < R; k += 2) {
+            v2f64 t = v2f64{0.0, 0.0};
+            if (!Cfg::SHORT || k < kl) t = src[(size_t)(k >> 1) * HP];
+            v[k] = t.x; v[k + 1] = t.y;
+        }
     };
     auto load_col_tri = [&](gcdouble* col, double (&v)[R]) {  // see forward_body
 #pragma unroll
@@ -1887,10 +2018,12 @@ DEVI void backward_body(const DevContig& dc, ChainShared<HP, R>& sh, uint32_t C,
     auto store_col = [&](int64_t c, const double (&y)[R]) {
         gdouble2* dst = (gdouble2*)(wr + (size_t)c * colsz) + (size_t)(p.i0 >> 1) * HP + p.j;
 #pragma unroll
-        for (int k = 0; k < R; k += 2) dst[(size_t)(k >> 1) * HP] = v2f64{y[k], y[k + 1]};
+        for (int k = 0; k < R; k += 2)
+            if (!Cfg::SHORT || k < kl) dst[(size_t)(k >> 1) * HP] = v2f64{y[k], y[k + 1]};
     };
     auto store_pair = [&](int64_t c, int k, double a, double b) {  // see forward_body
         if (kExp & 1u) return;
+        if (Cfg::SHORT && !(k < kl)) return;
         gdouble2* dst = (gdouble2*)(wr + (size_t)c * colsz) + (size_t)(p.i0 >> 1) * HP + p.j;
         dst[(size_t)(k >> 1) * HP] = v2f64{a, b};
     };
@@ -4484,8 +4617,9 @@ DEVI void bins_unit(const DevContig& dc, uint32_t unit, double (&s_bins)[4][PG_A
 #pragma unroll
             for (int bb = 0; bb < PG_AMAX; ++bb) { acc0[bb] = 0.0; acc1[bb] = 0.0; }
             for (uint32_t t = lane; t < Tn; t += 64) {
-                const v2f64 pv = base[(size_t)q * Tn + t];
                 const uint32_t b = al[t % HP];
+                v2f64 pv = v2f64{0.0, 0.0};
+                if (b != PG_PHANTOM) pv = base[(size_t)q * Tn + t];   // (phantom paths' entries: zero, or — DevContig::live — never written)
 #pragma unroll
                 for (int bb = 0; bb < PG_AMAX; ++bb) {
                     acc0[bb] += b == (uint32_t)bb ? pv.x : 0.0;

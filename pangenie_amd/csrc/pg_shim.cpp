@@ -603,8 +603,9 @@ int upload_inputs(pg_job* job, const pg_contig_batch* batches, const std::vector
 //   nolean2 notri nocls4 prepwave   phase 2 of triangle chains on the general kernel's ring | full columns | per-thread
 //                       partials instead of class sums | k_prep for every object
 //   leanpipe            the pipelined lean step k_sweep_leanp for lone 64-path chains (measured at par: profiles/r04_lean_chain.txt)
+//   fullcols            fused jobs at HP = 32 store and fetch whole 32 x 32 columns (DevContig::live = HP)
 struct KernelChoice {
-    bool general = false, generic = false, nolean2 = false, notri = false, nocls4 = false, prepwave = false, leanpipe = false;
+    bool general = false, generic = false, nolean2 = false, notri = false, nocls4 = false, prepwave = false, leanpipe = false, fullcols = false;
     int leanx = -1, small = -1;   // -1: by the job, 0 / 1: forced
 };
 KernelChoice kernel_choice() {
@@ -618,7 +619,7 @@ KernelChoice kernel_choice() {
         else if (tok == "small") k.small = 1; else if (tok == "nosmall") k.small = 0;
         else if (tok == "nolean2") k.nolean2 = true; else if (tok == "notri") k.notri = true;
         else if (tok == "nocls4") k.nocls4 = true; else if (tok == "prepwave") k.prepwave = true;
-        else if (tok == "leanpipe") k.leanpipe = true;
+        else if (tok == "leanpipe") k.leanpipe = true; else if (tok == "fullcols") k.fullcols = true;
         tok.clear();
     };
     for (const char* c = e; *c; ++c) { if (*c == ',' || *c == ' ') take(); else tok.push_back(*c); }
@@ -971,7 +972,7 @@ int job_build(int device, uint32_t n_index, const pg_contig_batch* batches, cons
         const Plan& p = plan[c];
         DevContig& d = hd[c];
         memset(&d, 0, sizeof(d));
-        d.V = x.V; d.H = x.H; d.HP = x.HP; d.RB = x.RB; d.T = x.T; d.part_slots = x.part_slots; d.pair_n = x.pair_n;
+        d.V = x.V; d.H = x.H; d.HP = x.HP; d.RB = x.RB; d.T = x.HP == 32u ? x.T / 2u : x.T /* entries of posterior partials per column and slot pair: see fold32 */; d.part_slots = x.part_slots; d.pair_n = x.pair_n;
         d.dist_scale = (double)dist_scale; d.uniform = params->uniform ? 1 : 0;
         d.debug = 8u;   // (bit 3: the in-kernel cycle counters of -DPG_CHAIN_PROF builds; the product build has none)
         d.pos = (const uint64_t*)(A + x.o_pos); d.cov = (const uint16_t*)(A + ch.o_cov);
@@ -989,6 +990,7 @@ int job_build(int device, uint32_t n_index, const pg_contig_batch* batches, cons
         d.wide = A + p.wide; d.wide_idx = x.wide_bytes ? (const uint32_t*)(A + x.o_widx) : nullptr;
         d.vpair = A + p.vpair; d.xbuf = (double*)(A + p.xbuf);
         d.frec = (double*)(A + p.frec); d.lean = x.lean ? ((x.lean_pipe && job->chunked) ? 2u : 1u) : 0u; d.small = x.small ? 1u : 0u; d.leanx = x.leanx ? 1u : 0u; d.cls4 = x.cls4 ? 1u : 0u;
+        d.live = (!job->chunked && x.HP == 32u && !kc.fullcols) ? std::min<uint32_t>(x.HP, (x.H + 3u) & ~3u) : x.HP;
         d.prep_fast = x.prep_fast;
         if (params->run_phasing) {
             d.vit_tq = (double*)(A + p.vtq); d.vit_back = (uint16_t*)(A + p.vback); d.vit_best = (uint32_t*)(A + p.vbest);

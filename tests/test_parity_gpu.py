@@ -431,6 +431,32 @@ def test_class_sums_in_the_single_wave_sweeps_vs_oracle_and_partials(H, orc, mon
         assert float(np.where(den > 0, np.abs(a - c) / np.where(den > 0, den, 1), 0).max()) < 1e-11
 
 
+@pytest.mark.parametrize("H", [17, 20, 21, 24, 25, 29, 32])
+def test_short_columns_of_fused_jobs_vs_oracle_and_full_columns(H, orc, monkeypatch):
+    """Fused jobs at 17 ... 32 paths (HP = 32; 17 = the 15 + 1 paths behind haplotype sampling): phase 1 stores, and the loader of
+    phase 2 fetches, only the first DevContig::live = H rounded up to 4 rows and lanes of a column (the rest of the LDS ring is
+    zeroed once); the posterior partials of a wave's two halves are added in registers and only real paths' entries are
+    written / read.  Regularised and unregularised table (fall-back columns re-formed from the stored backward column, which
+    is read below H only), 1 ... 260 variants, multiallelic objects: must match the oracle, and PG_KERNELS=fullcols (whole
+    32 x 32 columns) bit for bit — rows and lanes at or above H only ever contribute exact zeros."""
+    monkeypatch.setenv("PG_SWEEP_MODE", "fused")
+    for seed, reg, V in ((5, 0.0, 260), (6, 0.01, 257), (7, 0.0, 1), (8, 0.01, 2), (9, 0.0, 3), (10, 0.01, 9)):
+        args = (6, 108, 54, reg)
+        b = synthetic_panel(V, H, 20, seed=seed, multiallelic_frac=0.3, undefined_frac=0.05)
+        if reg == 0.0 and V > 3:
+            b.kmer_count[::3] = 0
+        t, p = hmm.ProbabilityTable(*args), hmm.make_params(1.26, False, 1e-5)
+        monkeypatch.delenv("PG_KERNELS", raising=False)
+        short = hmm.genotype_contig(b, t, p)
+        monkeypatch.setenv("PG_KERNELS", "fullcols")
+        full = hmm.genotype_contig(b, t, p)
+        monkeypatch.delenv("PG_KERNELS", raising=False)
+        ref = orc.genotype_contig(b, orc.OracleTable(*args), orc.make_params(1.26, False, 1e-5))
+        assert_parity(b, short, ref)
+        assert_parity(b, full, ref)
+        assert np.array_equal(short.likelihoods_ld(), full.likelihoods_ld())
+
+
 @pytest.mark.parametrize("mode", ["chunked", "fused"])
 def test_small16_kernel_many_chains_of_different_lengths(mode, orc, monkeypatch):
     """Chains of very different lengths share waves (the trip count is the longest row's; finished rows run on with
