@@ -149,6 +149,8 @@ struct DevContig {
     uint32_t  tri;
     // 1: every object of the chain is biallelic and H = HP = 16: the store-only phases run on k_sweep_small16 (four
     // half-chains per wave); the chain keeps its compact records (frec) next to the full ones
+    // 2 (fused jobs, with cls4): phase 2 runs there too — partner columns prefetched into registers three steps ahead, the four
+    // class sums of a column formed inside the 16-lane row
     uint32_t  small;
     // 1: HP = 128 or 64, every object has at most PG_AMAX alleles (all columns narrow) and the chain is not `lean`: the
     // store-only phases run on k_sweep_leanx (the lean step with table emissions)

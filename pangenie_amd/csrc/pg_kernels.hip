@@ -845,7 +845,10 @@ __global__ __launch_bounds__(64) void k_transition_single(double d, uint32_t H, 
 // k_bins reads the variant record itself.  (The column-order copy of the full 448-byte records, one wave per column
 // with 64 lanes computing the same exp(), was 4.6 ms of the cohort's 80.)
 // The same for lean chains of chunked jobs: their sweeps run on k_sweep_lean and k_post reads the variant record.
-DEVI bool compact_records_only(const DevContig& dc, uint32_t C) { return (dc.tri == 2u && C >= 2u) || (dc.lean && dc.tri == 0u && dc.chunk_cols > 0u); }
+// And for the 16-path chains whose two phases both run on k_sweep_small16 (DevContig::small == 2).
+DEVI bool compact_records_only(const DevContig& dc, uint32_t C) {
+    return ((dc.tri == 2u || dc.small == 2u) && C >= 2u) || (dc.lean && dc.tri == 0u && dc.chunk_cols > 0u);
+}
 
 DEVI void records_unit(const DevContig& dc, uint32_t unit) {
     const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -2341,6 +2344,7 @@ __global__ __launch_bounds__((ChainCfg<HP, R>::TT), (HP == 32 ? (PHASE == 2 ? PG
     const uint32_t C = (uint32_t)__builtin_amdgcn_readfirstlane((int)*dc.n_cols);
     if (C == 0) return;
     if (PHASE == 2 && dc.tri == 2u && C >= 2) return;  // triangle chains: k_sweep_lean2
+    if (PHASE == 2 && dc.small == 2u && C >= 2) return;  // all-biallelic 16-path chains of fused jobs: k_sweep_small16<2>
     if constexpr (PHASE == 2 && HP == 64 && ChainCfg<HP, R>::LOADER) {
         // triangle ring (DevContig::tri): the unit of zeros that stands for everything below the diagonal; first read
         // behind the P0 barrier of the bodies
@@ -3923,11 +3927,13 @@ DEVI FRec load_frec(gcdouble* frec, int64_t c, int64_t C) {   // record of colum
     r.bits1 = (unsigned long long)__double_as_longlong(f.y);
     return r;
 }
-// e(i, j) of row k for this lane: bit k of the lane's row bits picks between the two values of its column
+// bit K of the lane's row bits as 0 / ~0 (v_bfe_i32), the select through it — e(i, j) of row k: the bit picks between the two values of the
+// lane's column, one bit-field insert per register half — and (phase 2) the bit as the doubles (1 - bit, bit): exact 0 / 1 multipliers
+// for the posterior sums by row allele
 template <int K>
-DEVI double sel_row_bit(uint32_t rbits /*per lane*/, double if0, double if1) {
-    uint32_t m, lo, hi;   // v_bfe_i32: bit K as 0 / ~0, then one bit-field insert per register half
-    asm("v_bfe_i32 %0, %1, %2, 1" : "=v"(m) : "v"(rbits), "n"(K));
+DEVI uint32_t row_bit_mask(uint32_t rbits) { uint32_t m; asm("v_bfe_i32 %0, %1, %2, 1" : "=v"(m) : "v"(rbits), "n"(K)); return m; }
+DEVI double sel_by_mask(uint32_t m, double if0, double if1) {
+    uint32_t lo, hi;
     asm("v_bfi_b32 %0, %1, %2, %3" : "=v"(lo) : "v"(m), "v"(__double2loint(if1)), "v"(__double2loint(if0)));
     asm("v_bfi_b32 %0, %1, %2, %3" : "=v"(hi) : "v"(m), "v"(__double2hiint(if1)), "v"(__double2hiint(if0)));
     return __hiloint2double((int)hi, (int)lo);
@@ -3935,6 +3941,7 @@ DEVI double sel_row_bit(uint32_t rbits /*per lane*/, double if0, double if1) {
 struct SmallCtx {      // per lane: the half-chain of its DPP row
     bool live;         // the row has a half-chain with columns to do in this launch
     gcdouble* frec; gdouble* wr; gcdouble* resume; gdouble* sc_a; gdouble* sc_b; gu8* fallback;
+    gcdouble* partner; gdouble* part;   // phase 2: the columns the other role stored, the class sums of the posterior (DevContig::cls4 layout)
     int64_t C, lo, hi;   // forward: columns [lo, hi) ascending; backward: [bot = lo, top = hi] descending
 };
 
@@ -3952,6 +3959,7 @@ DEVI void small16_forward(const DevContig* contigs, const uint32_t* ids, uint32_
         const uint32_t C = *dc.n_cols, mid = C / 2, K = dc.chunk_cols;
         uint32_t lo = PHASE == 1 ? 0u : mid, hi = PHASE == 1 ? mid : C;
         bool ok = C > 0;
+        if constexpr (PHASE == 2) ok = dc.small == 2u && C >= 2u;   // (a chain left with a single column: the general kernel, like k_sweep_lean2's)
         if constexpr (PHASE == 3) {
             const unsigned long long l = (unsigned long long)mid + (unsigned long long)chunk * K;
             ok = ok && l < C;
@@ -3963,7 +3971,7 @@ DEVI void small16_forward(const DevContig* contigs, const uint32_t* ids, uint32_
             cx.live = true; cx.C = C; cx.lo = lo; cx.hi = hi;
             cx.frec = (gcdouble*)dc.frec; cx.sc_a = (gdouble*)dc.fscale; cx.fallback = (gu8*)dc.fwd_fallback;
             gdouble* fwd = (gdouble*)dc.fwd;
-            cx.wr = fwd;
+            cx.wr = fwd; cx.partner = (gcdouble*)fwd; cx.part = (gdouble*)dc.part;
             cx.resume = (gcdouble*)(fwd + (size_t)(lo > 0 ? lo - 1 : 0) * colsz);
             if constexpr (PHASE == 3) {
                 gdouble* scr = (gdouble*)dc.scratch;
@@ -3985,8 +3993,16 @@ DEVI void small16_forward(const DevContig* contigs, const uint32_t* ids, uint32_
 #pragma unroll
         for (int k = 0; k < R; k += 2) dst[(size_t)(k >> 1) * HP] = v2f64{v[k], v[k + 1]};
     };
+    // phase 2: the partner column beta'_t of this lane's column, fetched three steps ahead (clamped: a column past the end is never used)
+    auto load_partner = [&](int64_t c, double (&v)[R]) {
+        if (!cx.live) return;
+        c = c < cx.lo ? cx.lo : (c >= cx.hi ? cx.hi - 1 : c);
+        gcdouble2* src = (gcdouble2*)(cx.partner + (size_t)c * colsz) + j;
+#pragma unroll
+        for (int k = 0; k < R; k += 2) { const v2f64 t = src[(size_t)(k >> 1) * HP]; v[k] = t.x; v[k + 1] = t.y; }
+    };
     auto flag_uniform = [&](int64_t cprev) {   // (lanes of rows whose column cprev summed to zero)
-        if (cprev >= cx.lo) {
+        if (PHASE != 2 && cprev >= cx.lo) {
             double xu[R];
 #pragma unroll
             for (int k = 0; k < R; ++k) xu[k] = unif;
@@ -4025,7 +4041,7 @@ DEVI void small16_forward(const DevContig* contigs, const uint32_t* ids, uint32_
     for (int k = 0; k < R; ++k) { ee[k] = 1.0; pp[k] = x[k]; }
     // One column step of the (up to) four half-chains; `cur` = record of column first + n, `far` takes the record three
     // steps on.  Rows whose half-chain is done (or absent) compute on whatever their registers hold and store nothing.
-    auto step = [&](int n, FRec& slot_rec) __attribute__((always_inline)) {
+    auto step = [&](int n, FRec& slot_rec, double (&vp)[PHASE == 2 ? R : 1]) __attribute__((always_inline)) {
         const int64_t t = (int64_t)first + n;
         const bool act = cx.live && t < cx.hi;
         const FRec cur = slot_rec;                                   // (its fields move on; the variable takes the far record)
@@ -4056,15 +4072,35 @@ DEVI void small16_forward(const DevContig* contigs, const uint32_t* ids, uint32_
         const uint32_t rb = (uint32_t)(cur.bits1 & 0xFFFFull);
         // (rows that are done keep computing: their stores go to a scrap column instead of under a mask)
         gdouble2* dst = act ? (gdouble2*)(cx.wr + (size_t)t * colsz) + j : (gdouble2*)dump + lane;
-        double pprev = 0.0;
+        double pprev = 0.0, acc0 = 0.0, acc1 = 0.0;
         static_for<0, R>([&](auto kc) __attribute__((always_inline)) {
             constexpr int k = decltype(kc)::value;
             const double pk = fmac_row_bcast<k>(fma(c0s, x[k], ujs), ucol, sc);   // P'_t(k, j) 2^-es = c0 x + u_j + u_k
-            ee[k] = sel_row_bit<k>(rb, eA, eB);
+            const uint32_t mk = row_bit_mask<k>(rb);
+            ee[k] = sel_by_mask(mk, eA, eB);
             pp[k] = pk;
-            if constexpr (k & 1) dst[(size_t)(k >> 1) * HP] = v2f64{pprev, pk};
-            else pprev = pk;
+            if constexpr (PHASE == 2) {
+                // posterior: P'_t beta'_t added by row allele (exact 0 / 1 multipliers, as in the general kernel)
+                const double pr = vp[k] * pk;
+                acc1 = fma(pr, __hiloint2double((int)(mk & 0x3FF00000u), 0), acc1);
+                acc0 = fma(pr, __hiloint2double((int)(~mk & 0x3FF00000u), 0), acc0);
+            } else {
+                if constexpr (k & 1) dst[(size_t)(k >> 1) * HP] = v2f64{pprev, pk};
+                else pprev = pk;
+            }
         });
+        if constexpr (PHASE == 2) {
+            // ... and by column allele over the sixteen lanes of the row: the four class sums of the column (DevContig::cls4 layout)
+            const bool aj = (cur.bits1 >> j) & 1ull;
+            const double s00 = row16_sum(aj ? 0.0 : acc0), s01 = row16_sum(aj ? acc0 : 0.0);
+            const double s10 = row16_sum(aj ? 0.0 : acc1), s11 = row16_sum(aj ? acc1 : 0.0);
+            if (act && j == 0) {
+                gdouble2* o = (gdouble2*)cx.part + (size_t)t * 2u;
+                o[0] = v2f64{s00, s01};
+                o[1] = v2f64{s10, s11};
+            }
+            load_partner(t + 3, vp);
+        }
         if (act) {   // the column's scale mantissa: sixteen columns collected in the row's lanes, one store per sixteen
             if (j == ((uint32_t)t & 15u)) buf = m;
             if (((uint32_t)t & 15u) == 15u || t + 1 == cx.hi) { if (j <= ((uint32_t)t & 15u) && (int64_t)((t & ~15ll) + j) >= (int64_t)first) cx.sc_a[(t & ~15ll) + j] = buf; }
@@ -4073,15 +4109,17 @@ DEVI void small16_forward(const DevContig* contigs, const uint32_t* ids, uint32_
     FRec ra = cx.live ? load_frec(cx.frec, (int64_t)first, cx.C) : FRec{};
     FRec rb_ = cx.live ? load_frec(cx.frec, (int64_t)first + 1, cx.C) : FRec{};
     FRec rc_ = cx.live ? load_frec(cx.frec, (int64_t)first + 2, cx.C) : FRec{};
+    double va[PHASE == 2 ? R : 1], vb[PHASE == 2 ? R : 1], vc[PHASE == 2 ? R : 1];
+    if constexpr (PHASE == 2) { load_partner((int64_t)first, va); load_partner((int64_t)first + 1, vb); load_partner((int64_t)first + 2, vc); }
     __builtin_amdgcn_s_waitcnt(0x0F70);   // (no load of the prologue in flight inside the loop: see lean_forward)
     int n = 0;
     for (; n + 2 < n_steps; n += 3) {
-        step(n, ra);
-        step(n + 1, rb_);
-        step(n + 2, rc_);
+        step(n, ra, va);
+        step(n + 1, rb_, vb);
+        step(n + 2, rc_, vc);
     }
-    if (n < n_steps) { step(n, ra); ++n; }
-    if (n < n_steps) { step(n, rb_); ++n; }
+    if (n < n_steps) { step(n, ra, va); ++n; }
+    if (n < n_steps) { step(n, rb_, vb); ++n; }
     {   // the last column of the rows that ran to the wave's last step may itself have summed to zero
         double Cj = 0.0;
 #pragma unroll
@@ -4109,6 +4147,7 @@ DEVI void small16_backward(const DevContig* contigs, const uint32_t* ids, uint32
         const int64_t C = *dc.n_cols, mid = C / 2, K = dc.chunk_cols;
         int64_t top = PHASE == 1 ? C - 1 : mid - 1, bot = PHASE == 1 ? mid : 0;
         bool ok = C > 0;
+        if constexpr (PHASE == 2) ok = dc.small == 2u && C >= 2;
         if constexpr (PHASE == 3) {
             top = mid - 1 - (int64_t)chunk * K;
             ok = ok && top >= 0;
@@ -4119,7 +4158,7 @@ DEVI void small16_backward(const DevContig* contigs, const uint32_t* ids, uint32
             cx.live = true; cx.C = C; cx.lo = bot; cx.hi = top;
             cx.frec = (gcdouble*)dc.frec; cx.sc_a = (gdouble*)dc.bscale; cx.sc_b = (gdouble*)dc.bsum;
             gdouble* cols = (gdouble*)dc.fwd;
-            cx.wr = cols;
+            cx.wr = cols; cx.partner = (gcdouble*)cols; cx.part = (gdouble*)dc.part;
             cx.resume = (gcdouble*)(cols + (size_t)(top + 1 < C ? top + 1 : top) * colsz);
             if constexpr (PHASE == 3) {
                 gdouble* scr = (gdouble*)dc.scratch;
@@ -4170,7 +4209,15 @@ DEVI void small16_backward(const DevContig* contigs, const uint32_t* ids, uint32
     asm volatile("" : "+v"(one));
     // step n: column t = t0 - n.  `cur_rec` = record t+1 (constants of the gap t -> t+1; its variable then takes the
     // record three steps on), `nxt` = record t (emission of column t).
-    auto step = [&](int n, FRec& cur_rec, const FRec& nxt) __attribute__((always_inline)) {
+    // phase 2: the partner column P'_t of this lane's column, fetched three steps ahead (clamped: see small16_forward)
+    auto load_partner = [&](int64_t c, double (&v)[R]) {
+        if (!cx.live) return;
+        c = c < cx.lo ? cx.lo : (c > cx.hi ? cx.hi : c);
+        gcdouble2* src = (gcdouble2*)(cx.partner + (size_t)c * colsz) + j;
+#pragma unroll
+        for (int k = 0; k < R; k += 2) { const v2f64 t = src[(size_t)(k >> 1) * HP]; v[k] = t.x; v[k + 1] = t.y; }
+    };
+    auto step = [&](int n, FRec& cur_rec, const FRec& nxt, double (&vp)[PHASE == 2 ? R : 1]) __attribute__((always_inline)) {
         const int64_t t = t0 - n;
         const bool act = cx.live && t >= cx.lo;
         const FRec cur = cur_rec;
@@ -4189,15 +4236,33 @@ DEVI void small16_backward(const DevContig* contigs, const uint32_t* ids, uint32
         emis(nxt, eA, eB);
         const uint32_t rb = (uint32_t)(nxt.bits1 & 0xFFFFull);
         gdouble2* dst = act ? (gdouble2*)(cx.wr + (size_t)t * colsz) + j : (gdouble2*)dump + lane;
-        double yprev = 0.0;
+        double yprev = 0.0, acc0 = 0.0, acc1 = 0.0;
         static_for<0, R>([&](auto kc) __attribute__((always_inline)) {
             constexpr int k = decltype(kc)::value;
             const double yk = fmac_row_bcast<k>(fma(k0, w[k], uj), ucol, one);  // beta'_t = k0 w + u_j + u_k
-            ee[k] = sel_row_bit<k>(rb, eA, eB);
+            const uint32_t mk = row_bit_mask<k>(rb);
+            ee[k] = sel_by_mask(mk, eA, eB);
             pp[k] = yk;
-            if constexpr (k & 1) dst[(size_t)(k >> 1) * HP] = v2f64{yprev, yk};
-            else yprev = yk;
+            if constexpr (PHASE == 2) {   // (see small16_forward)
+                const double pr = vp[k] * yk;
+                acc1 = fma(pr, __hiloint2double((int)(mk & 0x3FF00000u), 0), acc1);
+                acc0 = fma(pr, __hiloint2double((int)(~mk & 0x3FF00000u), 0), acc0);
+            } else {
+                if constexpr (k & 1) dst[(size_t)(k >> 1) * HP] = v2f64{yprev, yk};
+                else yprev = yk;
+            }
         });
+        if constexpr (PHASE == 2) {
+            const bool aj = (nxt.bits1 >> j) & 1ull;
+            const double s00 = row16_sum(aj ? 0.0 : acc0), s01 = row16_sum(aj ? acc0 : 0.0);
+            const double s10 = row16_sum(aj ? 0.0 : acc1), s11 = row16_sum(aj ? acc1 : 0.0);
+            if (act && j == 0) {
+                gdouble2* o = (gdouble2*)cx.part + (size_t)t * 2u;
+                o[0] = v2f64{s00, s01};
+                o[1] = v2f64{s10, s11};
+            }
+            load_partner(t - 3, vp);
+        }
         Sy = Snew;
         if (act && !(Snew > 0.0)) {
             // beta~_t is all zero (what was stored IS zero): the next step starts from the uniform column (hmm.cpp:374-380)
@@ -4217,15 +4282,17 @@ DEVI void small16_backward(const DevContig* contigs, const uint32_t* ids, uint32
     FRec ra = cx.live ? load_frec(cx.frec, t0 + 1, cx.C) : FRec{};
     FRec rb_ = cx.live ? load_frec(cx.frec, t0, cx.C) : FRec{};
     FRec rc_ = cx.live ? load_frec(cx.frec, t0 - 1, cx.C) : FRec{};
+    double va[PHASE == 2 ? R : 1], vb[PHASE == 2 ? R : 1], vc[PHASE == 2 ? R : 1];
+    if constexpr (PHASE == 2) { load_partner(t0, va); load_partner(t0 - 1, vb); load_partner(t0 - 2, vc); }
     __builtin_amdgcn_s_waitcnt(0x0F70);
     int n = 0;
     for (; n + 2 < n_steps; n += 3) {
-        step(n, ra, rb_);
-        step(n + 1, rb_, rc_);
-        step(n + 2, rc_, ra);
+        step(n, ra, rb_, va);
+        step(n + 1, rb_, rc_, vb);
+        step(n + 2, rc_, ra, vc);
     }
-    if (n < n_steps) { step(n, ra, rb_); ++n; }
-    if (n < n_steps) { step(n, rb_, rc_); ++n; }
+    if (n < n_steps) { step(n, ra, rb_, va); ++n; }
+    if (n < n_steps) { step(n, rb_, rc_, vb); ++n; }
 }
 
 template <int PHASE>
@@ -5036,6 +5103,7 @@ void pgk_launch_sweep_small(const DevContig* d_contigs, const uint32_t* d_ids, u
     if (n_ids == 0) return;
     const dim3 grid((n_ids + 3u) / 4u, 2);
     if (phase == 1) hipLaunchKernelGGL(k_sweep_small16<1>, grid, dim3(64), 0, s, d_contigs, d_ids, n_ids, chunk, d_dump);
+    else if (phase == 2) hipLaunchKernelGGL(k_sweep_small16<2>, grid, dim3(64), 0, s, d_contigs, d_ids, n_ids, chunk, d_dump);
     else hipLaunchKernelGGL(k_sweep_small16<3>, grid, dim3(64), 0, s, d_contigs, d_ids, n_ids, chunk, d_dump);
 }
 void pgk_launch_post(const DevContig* d_contigs, uint32_t n_contigs, uint32_t chunk_cols, uint32_t chunk, hipStream_t s) {

@@ -360,6 +360,7 @@ struct pg_job {
     size_t zero_bytes = 0;
     uint32_t* d_small = nullptr;  // [n_small] chain ids of the H = 16 chains
     uint32_t n_small = 0;
+    bool small_phase2 = false;    // some of them (fused jobs, class sums: DevContig::small == 2) also run their phase 2 on k_sweep_small16
     double* d_dump = nullptr;
     uint32_t* d_ncols = nullptr;  // [n_chains]
     uint32_t* d_err = nullptr;    // [n_chains]
@@ -604,8 +605,9 @@ int upload_inputs(pg_job* job, const pg_contig_batch* batches, const std::vector
 //                       partials instead of class sums | k_prep for every object
 //   leanpipe            the pipelined lean step k_sweep_leanp for lone 64-path chains (measured at par: profiles/r04_lean_chain.txt)
 //   fullcols            fused jobs at HP = 32 store and fetch whole 32 x 32 columns (DevContig::live = HP)
+//   nosmall2            phase 2 of the 16-path chains of fused jobs on the general kernel (k_sweep_small16 for phase 1 only)
 struct KernelChoice {
-    bool general = false, generic = false, nolean2 = false, notri = false, nocls4 = false, prepwave = false, leanpipe = false, fullcols = false;
+    bool general = false, generic = false, nolean2 = false, notri = false, nocls4 = false, prepwave = false, leanpipe = false, fullcols = false, nosmall2 = false;
     int leanx = -1, small = -1;   // -1: by the job, 0 / 1: forced
 };
 KernelChoice kernel_choice() {
@@ -619,7 +621,7 @@ KernelChoice kernel_choice() {
         else if (tok == "small") k.small = 1; else if (tok == "nosmall") k.small = 0;
         else if (tok == "nolean2") k.nolean2 = true; else if (tok == "notri") k.notri = true;
         else if (tok == "nocls4") k.nocls4 = true; else if (tok == "prepwave") k.prepwave = true;
-        else if (tok == "leanpipe") k.leanpipe = true; else if (tok == "fullcols") k.fullcols = true;
+        else if (tok == "leanpipe") k.leanpipe = true; else if (tok == "fullcols") k.fullcols = true; else if (tok == "nosmall2") k.nosmall2 = true;
         tok.clear();
     };
     for (const char* c = e; *c; ++c) { if (*c == ',' || *c == ' ') take(); else tok.push_back(*c); }
@@ -989,7 +991,7 @@ int job_build(int device, uint32_t n_index, const pg_contig_batch* batches, cons
         d.scratch = (double*)(A + p.scratch); d.chunk_cols = job->chunk_cols;
         d.wide = A + p.wide; d.wide_idx = x.wide_bytes ? (const uint32_t*)(A + x.o_widx) : nullptr;
         d.vpair = A + p.vpair; d.xbuf = (double*)(A + p.xbuf);
-        d.frec = (double*)(A + p.frec); d.lean = x.lean ? ((x.lean_pipe && job->chunked) ? 2u : 1u) : 0u; d.small = x.small ? 1u : 0u; d.leanx = x.leanx ? 1u : 0u; d.cls4 = x.cls4 ? 1u : 0u;
+        d.frec = (double*)(A + p.frec); d.lean = x.lean ? ((x.lean_pipe && job->chunked) ? 2u : 1u) : 0u; d.small = x.small ? ((!job->chunked && x.cls4 && !kc.nosmall2) ? 2u : 1u) : 0u; d.leanx = x.leanx ? 1u : 0u; d.cls4 = x.cls4 ? 1u : 0u;
         d.live = (!job->chunked && x.HP == 32u && !kc.fullcols) ? std::min<uint32_t>(x.HP, (x.H + 3u) & ~3u) : x.HP;
         d.prep_fast = x.prep_fast;
         if (params->run_phasing) {
@@ -1005,7 +1007,7 @@ int job_build(int device, uint32_t n_index, const pg_contig_batch* batches, cons
     }
     {
         std::vector<uint32_t> small_ids;
-        for (uint32_t c = 0; c < n_chains; ++c) if (hd[c].small) small_ids.push_back(c);
+        for (uint32_t c = 0; c < n_chains; ++c) if (hd[c].small) { small_ids.push_back(c); if (hd[c].small == 2u) job->small_phase2 = true; }
         job->n_small = (uint32_t)small_ids.size();
         job->d_small = (uint32_t*)(A + o_small);
         job->d_dump = (double*)(A + o_dump);
@@ -1263,6 +1265,7 @@ extern "C" int pg_job_run(pg_job* job, void* stream_, char* err, size_t errlen) 
         HIP_TRY(hipEventRecord(job->ev[4], s));
         if (!job->chunked) {
             pgk_launch_sweep(job->d_contigs, n, job->hp_mask, 2, s);
+            if (job->small_phase2) pgk_launch_sweep_small(job->d_contigs, job->d_small, job->n_small, 2, 0, job->d_dump, s);
             HIP_TRY(hipGetLastError());
             HIP_TRY(hipEventRecord(job->ev[5], s));
             pgk_launch_bins(job->d_contigs, n, job->max_v, job->bins_which, s);

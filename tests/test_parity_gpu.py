@@ -487,6 +487,40 @@ def test_small16_kernel_many_chains_of_different_lengths(mode, orc, monkeypatch)
             assert np.array_equal(r.lik, alone.lik) and np.array_equal(r.lik_exp, alone.lik_exp)
 
 
+@pytest.mark.parametrize("reg", [0.01, 0.0])
+def test_small16_kernel_phase2_of_fused_jobs_vs_oracle_and_general(reg, orc, monkeypatch):
+    """Fused jobs of all-biallelic 16-path chains (DevContig::small == 2): phase 2 runs on k_sweep_small16 as well — partner
+    columns prefetched into registers three steps ahead, the posterior added by row allele with exact 0 / 1 multipliers and
+    by column allele inside the 16-lane row, four class sums per column for k_bins_lean2 — and k_records writes the compact
+    records only.  Thirteen chains of 1 ... 640 columns in one job (a partial last wave; the one-column chain stays on the
+    general kernel), regularised and unregularised table (fall-back columns re-formed from the stored backward column):
+    every chain matches the oracle, and PG_KERNELS=small,nosmall2 (phase 2 on the general kernel) to fp64 rounding."""
+    monkeypatch.setenv("PG_SWEEP_MODE", "fused")
+    sizes = [640, 3, 260, 1, 2, 511, 64, 65, 33, 400, 129, 7, 300]
+    batches = [synthetic_panel(v, 16, 20, seed=700 + i, undefined_frac=0.05) for i, v in enumerate(sizes)]
+    if reg == 0.0:
+        for b in batches:
+            if b.n_variants > 3:
+                b.kmer_count[::3] = 0
+    args = (6, 108, 54, reg)
+    t, p = hmm.ProbabilityTable(*args), hmm.make_params(1.26, False, 1e-5)
+    out = {}
+    for kern in ("small", "small,nosmall2"):
+        monkeypatch.setenv("PG_KERNELS", kern)
+        job = hmm.Job(batches, t, p)
+        job.run()
+        out[kern] = job.fetch_all()
+        job.close()
+    monkeypatch.delenv("PG_KERNELS", raising=False)
+    for b, r, g in zip(batches, out["small"], out["small,nosmall2"]):
+        ref = orc.genotype_contig(b, orc.OracleTable(*args), orc.make_params(1.26, False, 1e-5))
+        assert_parity(b, r, ref)
+        assert_parity(b, g, ref)
+        a, c = r.likelihoods_ld(), g.likelihoods_ld()
+        den = np.maximum(np.abs(a), np.abs(c))
+        assert float(np.where(den > 0, np.abs(a - c) / np.where(den > 0, den, 1), 0).max()) < 1e-11
+
+
 @pytest.mark.parametrize("lean2", ["1", "0"])
 @pytest.mark.parametrize("C_odd", [False, True])
 def test_triangle_storage_fused_lean_vs_oracle_and_full_columns(C_odd, lean2, orc, monkeypatch):
