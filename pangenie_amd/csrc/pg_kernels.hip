@@ -564,7 +564,10 @@ DEVI void prep_unit(const DevContig& dc, const DevTable& tab, uint32_t unit) {
         for (; l < 8; ++l) ls[l] = 0;
     }
 }
-__global__ __launch_bounds__(256) void k_prep(const DevContig* __restrict__ contigs, DevTable tab) {
+#ifndef PG_PREP_WAVES
+#define PG_PREP_WAVES 1
+#endif
+__global__ __launch_bounds__(256, PG_PREP_WAVES) void k_prep(const DevContig* __restrict__ contigs, DevTable tab) {
     const DevContig& dc = contigs[blockIdx.y];
     if (dc.prep_fast == 1u) return;  // k_prep_bi's chain (2: its two-allele objects only, see prep_unit)
 #pragma unroll 1
@@ -754,7 +757,10 @@ DEVI void prep_bi_unit(const DevContig& dc, const DevTable& tab, uint32_t unit) 
     }
     wave_sync_lds();   // (the slot is rewritten by the wave's next unit)
 }
-__global__ __launch_bounds__(256) void k_prep_bi(const DevContig* __restrict__ contigs, DevTable tab) {
+#ifndef PG_PREPBI_WAVES
+#define PG_PREPBI_WAVES 1
+#endif
+__global__ __launch_bounds__(256, PG_PREPBI_WAVES) void k_prep_bi(const DevContig* __restrict__ contigs, DevTable tab) {
     const DevContig& dc = contigs[blockIdx.y];
     if (!dc.prep_fast) return;
 #pragma unroll 1
@@ -4626,12 +4632,18 @@ DEVI void store_bin(double* lik, int32_t* lik_exp, uint64_t idx, double sum, dou
     lik_exp[idx] = ee;
 }
 
+// chains of up to 32 paths (at most 64 partial entries per column and slot pair): one THREAD per column (k_bins_thin) —
+// a wave per column spent ~460 vector instructions on each (eight 64-lane sums, the index arithmetic and a division, all
+// wave-wide for one column), 7 ms for the 8.2 M columns of `cohort_h17`
+DEVI bool bins_thin(const DevContig& dc) { return dc.T <= 64u && dc.HP <= 32u && !dc.cls4 && dc.chunk_cols == 0u; }
+
 DEVI void bins_unit(const DevContig& dc, uint32_t unit, double (&s_bins)[4][PG_AMAX * (PG_AMAX + 1) / 2]) {
     const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const uint32_t c = unit * 4 + wave;
     const uint32_t C = *dc.n_cols;
     if (c >= C) return;
     if ((dc.tri == 2u && C >= 2u) || dc.cls4) return;  // chains whose class sums arrive finished (k_sweep_lean2, DevContig::cls4): k_bins_lean2
+    if (bins_thin(dc)) return;                           // few partial entries per column: k_bins_thin
     // (chains with compact records only have no column-order copy of the records: the variant's own record)
     const bool direct = compact_records_only(dc, C);
     const unsigned char* rec = direct ? dc.vrec + (size_t)dc.col_variant[c] * dc.RB : dc.colrec + (size_t)c * dc.RB;
@@ -4739,6 +4751,101 @@ __global__ __launch_bounds__(256) void k_bins(const DevContig* __restrict__ cont
     bins_unit(dc, blockIdx.x, s_bins);
 }
 
+// ------------------------------------------------------------------------------------------
+//  k_bins_thin : the same bins for chains with at most 64 partial entries per column and slot pair (bins_thin) — one
+//  THREAD per column.  The thread walks the real paths' entries of its column (entry t belongs to column allele
+//  al[t % HP]) and adds each pair of row-allele sums to its bins, kept in a private LDS row (the bin index is data).
+//  Same factors, exponents and fall-back rule as bins_unit; the sums are taken in entry order.
+// ------------------------------------------------------------------------------------------
+#define PG_NBINS (PG_AMAX * (PG_AMAX + 1) / 2)
+__global__ __launch_bounds__(256) void k_bins_thin(const DevContig* __restrict__ contigs) {
+    __shared__ double s_acc[256][PG_NBINS + 2];   // (17 doubles: an odd row stride spreads the threads' rows over the banks)
+    const DevContig& dc = contigs[blockIdx.y];
+    if (!bins_thin(dc)) return;
+    const uint32_t C = *dc.n_cols;
+    if (blockIdx.x * 256u >= C) return;
+    // (threads beyond the last column run along on its data — the wave takes its loop bounds together — and store nothing)
+    const bool active = blockIdx.x * 256u + threadIdx.x < C;
+    const uint32_t c = active ? blockIdx.x * 256u + threadIdx.x : C - 1u;
+    const bool direct = compact_records_only(dc, C);
+    const unsigned char* rec = direct ? dc.vrec + (size_t)dc.col_variant[c] * dc.RB : dc.colrec + (size_t)c * dc.RB;
+    const uint32_t v = *(const uint32_t*)(rec + PG_REC_VARIANT);
+    const uint32_t nl = rec[PG_REC_NLOCAL];
+    const uint32_t T = dc.T, HP = dc.HP, H = dc.H;
+    const unsigned char* al = rec + PG_REC_ALLELES;
+    double* acc = s_acc[threadIdx.x];
+#pragma unroll
+    for (int i = 0; i < PG_NBINS; ++i) acc[i] = 0.0;
+    auto add = [&](uint32_t a, uint32_t b, double val) { acc[tri_local(a < b ? a : b, a < b ? b : a)] += val; };
+    const bool fb = dc.fwd_fallback[c] != 0;
+    const bool reform = fb && c >= C / 2;
+    if (reform) {
+        // (see bins_unit) re-formed from the stored backward column, which carries data in rows and lanes below H
+        const double unif = 1.0 / ((double)H * (double)H);
+        const double* col = dc.fwd + (size_t)c * dc.col_stride;
+        for (uint32_t i = 0; i < H; ++i) {
+            const uint32_t a = al[i];
+            for (uint32_t jj = 0; jj < H; ++jj) {
+                const uint32_t b = al[jj];
+                if (a < nl && b < nl) add(a, b, col[((size_t)(i >> 1) * HP + jj) * 2 + (i & 1u)] * unif);
+            }
+        }
+    }
+    {
+        // The column alleles of the (up to 32) paths: two 16-byte loads, then bytes out of registers.  Entries are fetched eight
+        // at a time whatever the alleles say — indices clamped to what was written (entries at and above DevContig::live never
+        // were), loop bounds wave-uniform — so that the loads of a run are in flight together; a thread alone with its
+        // column's forty-odd entries, one load at a time, spent nine tenths of its cycles waiting.
+        const uint32_t nq = reform ? 0u : (nl + 1u) >> 1;
+        const uint32_t nq_w = (uint32_t)__builtin_amdgcn_readfirstlane(wave_max_i32((int)nq));
+        const v2f64* base = (const v2f64*)dc.part + (size_t)c * (dc.part_slots >> 1) * T;
+        const uint4 aw0 = ((const uint4*)al)[0], aw1 = HP > 16u ? ((const uint4*)al)[1] : uint4{0, 0, 0, 0};
+        const uint32_t alw[8] = {aw0.x, aw0.y, aw0.z, aw0.w, aw1.x, aw1.y, aw1.z, aw1.w};
+        const uint32_t jn = HP == 32u ? dc.live : HP;
+        for (uint32_t q = 0; q < nq_w; ++q) {
+            const bool mine = q < nq;
+            const uint32_t ra0 = 2u * q, ra1 = 2u * q + 1u;
+            for (uint32_t w = 0; w * HP < T; ++w) {
+                const v2f64* bw = base + (size_t)(mine ? q : 0u) * T + (size_t)w * HP;
+                static_for<0, 4>([&](auto jb) __attribute__((always_inline)) {
+                    constexpr int j0 = decltype(jb)::value * 8;
+                    if ((uint32_t)j0 < jn) {
+                        v2f64 pv[8];
+#pragma unroll
+                        for (int k = 0; k < 8; ++k) pv[k] = bw[(uint32_t)(j0 + k) < jn ? (uint32_t)(j0 + k) : jn - 1u];
+#pragma unroll
+                        for (int k = 0; k < 8; ++k) {
+                            const uint32_t bcol = (alw[(j0 + k) >> 2] >> (8 * ((j0 + k) & 3))) & 0xFFu;
+                            if (mine && (uint32_t)(j0 + k) < jn && bcol < nl) {   // (not a phantom path)
+                                add(ra0, bcol, pv[k].x);
+                                if (ra1 < nl) add(ra1, bcol, pv[k].y);
+                            }
+                        }
+                    }
+                });
+            }
+        }
+    }
+    if (!active) return;
+    const double scale = 1.0 / ((fb ? 1.0 : dc.fscale[c]) * dc.bscale[c]);
+    int xexp = -((fb ? 0 : PG_BIAS_F) + PG_BIAS_B);
+    if (c + 1 < C)
+        xexp += *(const int32_t*)((direct ? dc.vrec + (size_t)dc.col_variant[c + 1] * dc.RB : dc.colrec + (size_t)(c + 1) * dc.RB) + PG_REC_EXP);
+    if (dc.tri && !reform) xexp += 1;
+    const uint16_t* ls = (const uint16_t*)(rec + PG_REC_LOCAL_SLOT);
+    const uint32_t a0 = dc.allele_off[v], A = dc.allele_off[v + 1] - a0;
+    const uint32_t pn = dc.pair_n, NP = (pn * (pn + 1) / 2 + 1u) & ~1u;
+    const unsigned char* vp = dc.vpair + (size_t)v * (NP * 12u);
+    for (uint32_t la = 0; la < nl; ++la)
+        for (uint32_t lb = la; lb < nl; ++lb) {
+            const uint32_t sa = ls[la], sb = ls[lb];
+            const uint64_t idx = dc.geno_off[v] + (uint64_t)sa * A - (uint64_t)sa * (sa - 1) / 2 + (sb - sa);
+            const uint32_t pi = tri_n(la, lb, pn);
+            const double pm = fb ? 0.5 : ((const double*)vp)[pi];
+            const int pe = fb ? 1 : ((const int*)(vp + (size_t)NP * 8u))[pi];
+            store_bin(dc.lik, dc.lik_exp, idx, acc[tri_local(la, lb)] * scale, pm, pe, xexp);
+        }
+}
 
 // ------------------------------------------------------------------------------------------
 //  k_bins_lean2 : the bins of chains on k_sweep_lean2 (two local alleles at most; the four class sums of a column
@@ -5082,13 +5189,14 @@ void pgk_launch_records(const DevContig* d_contigs, uint32_t n_contigs, uint32_t
     dim3 grid((max_v + 255) / 256, n_contigs);   // 256 columns per block either way (a thread or a quarter of a wave's 64 each)
     hipLaunchKernelGGL(k_records, grid, dim3(256), 0, s, d_contigs);
 }
-// which: bit 0 = the job has chains whose bins k_bins forms, bit 1 = chains on k_sweep_lean2 (k_bins_lean2)
+// which: bit 0 = the job has chains whose bins k_bins forms, bit 1 = chains on k_sweep_lean2 (k_bins_lean2), bit 2 = chains of k_bins_thin
 void pgk_launch_bins(const DevContig* d_contigs, uint32_t n_contigs, uint32_t max_v, uint32_t which, hipStream_t s) {
     // (a chain on k_sweep_lean2 that ends up with a single column is k_bins' too: one block per chain covers that)
     dim3 grid((which & 1u) ? (max_v + 3) / 4 : 1u, n_contigs);
     hipLaunchKernelGGL(k_bins, grid, dim3(256), 0, s, d_contigs);
     dim3 grid256((max_v + 255) / 256, n_contigs);
     if (which & 2u) hipLaunchKernelGGL(k_bins_lean2, grid256, dim3(256), 0, s, d_contigs);  // (each kernel skips the other's columns)
+    if (which & 4u) hipLaunchKernelGGL(k_bins_thin, grid256, dim3(256), 0, s, d_contigs);
 }
 void pgk_launch_sweep(const DevContig* d_contigs, uint32_t n_contigs, uint32_t hp_mask, int phase, hipStream_t s) {
     if (phase == 1) launch_sweep<1>(d_contigs, n_contigs, hp_mask, 0, s);

@@ -372,7 +372,7 @@ struct pg_job {
     std::vector<int32_t> tab_e;
     DevTable tab;
     uint32_t hp_mask = 0, max_v = 0;
-    uint32_t bins_which = 0;   // bit 0: chains whose bins k_bins forms, bit 1: chains on k_sweep_lean2 (k_bins_lean2)
+    uint32_t bins_which = 0;   // bit 0: chains whose bins k_bins forms, bit 1: chains on k_sweep_lean2 (k_bins_lean2), bit 2: k_bins_thin
     uint32_t vit_bits = 0;     // run_phasing: 1 / 2 / 4 = chains with 16 / 32 / 64 padded paths
     hipEvent_t ev_vit[2];
     double vit_ms = 0.0;
@@ -1002,7 +1002,8 @@ int job_build(int device, uint32_t n_index, const pg_contig_batch* batches, cons
         d.col_stride = d.tri ? 2304u : x.HP * x.HP;
         if (d.tri) job->hp_mask |= 128u;
         if (d.tri == 2u) job->hp_mask |= 256u;
-        job->bins_which |= (d.tri == 2u || d.cls4) ? 2u : 1u;
+        // (k_bins_thin: what bins_thin() in pg_kernels.hip says — at most 64 partial entries per column, fused job)
+        job->bins_which |= (d.tri == 2u || d.cls4) ? 2u : ((d.T <= 64u && d.HP <= 32u && !job->chunked) ? 4u : 1u);
         ch.d = d;
     }
     {
