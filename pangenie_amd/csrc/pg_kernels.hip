@@ -1386,16 +1386,24 @@ DEVI void posterior(ChainShared<HP, R>& sh, gdouble* part_out, uint32_t part_slo
             for (int q = 0; q < R / 4; ++q)
                 aw[q] = __builtin_amdgcn_readfirstlane(((const uint32_t*)(al + p.i0))[q]);
         }
+        // (the local alleles of a column are 0 .. nl - 1, nl the same for every lane: a column with at most two — four out of
+        // five in a chain that takes this path only because it has fewer paths than lanes — adds for two alleles, not five;
+        // the others' sums stay exactly 0 either way)
+        auto rows = [&](auto na_c) __attribute__((always_inline)) {
+            constexpr int NA = decltype(na_c)::value;
 #pragma unroll
-        for (int k = 0; k < R; ++k) {
-            uint32_t ai;
-            if constexpr (Cfg::UNI) ai = (aw[k >> 2] >> (8 * (k & 3))) & 0xFFu;
-            else ai = al[p.i0 + k];
-            const double pr = prod[k];
+            for (int k = 0; k < R; ++k) {
+                uint32_t ai;
+                if constexpr (Cfg::UNI) ai = (aw[k >> 2] >> (8 * (k & 3))) & 0xFFu;
+                else ai = al[p.i0 + k];
+                const double pr = prod[k];
 #pragma unroll
-            for (int a = 0; a < PG_AMAX; ++a) acc[a] = fma(pr, ai == (uint32_t)a ? 1.0 : 0.0, acc[a]);
-            if constexpr (R > 16) { if ((k & 7) == 7) __builtin_amdgcn_sched_barrier(0); }
-        }
+                for (int a = 0; a < NA; ++a) acc[a] = fma(pr, ai == (uint32_t)a ? 1.0 : 0.0, acc[a]);
+                if constexpr (R > 16) { if ((k & 7) == 7) __builtin_amdgcn_sched_barrier(0); }
+            }
+        };
+        if (nl <= 2u) rows(std::integral_constant<int, 2>{});
+        else rows(std::integral_constant<int, PG_AMAX>{});
     }
     // Partials go out as 16-byte stores of allele PAIRS (slot pair q = alleles 2q, 2q+1): a
     // wave-wide 16-byte store costs the texture-address unit a third of two 8-byte ones, and
