@@ -980,12 +980,14 @@ typedef GAS const v2f64 gcdouble2;
 #ifndef PG_PARK_ROWS
 #define PG_PARK_ROWS 16
 #endif
-template <int HP, int R>
+template <int HP, int R, bool LD = (HP < 128)>
 struct ChainCfg {
     static constexpr int T = HP * HP / R;      // compute threads
     // HP = 128 keeps its 8 compute waves at 2 waves/SIMD (256 VGPRs): a 9th wave would cut the
-    // register budget to 168 and spill, so there wave 0 does the loader's work inline.
-    static constexpr bool LOADER = HP < 128;
+    // register budget to 168 and spill, so there wave 0 does the loader's work inline.  So do the store-only phases at
+    // HP = 32 (sweep_has_loader): their loader wave moved nothing but the column records, and without it a half-chain is two
+    // waves instead of three — eight half-chains per CU instead of five, in a kernel whose waves wait three quarters of their cycles.
+    static constexpr bool LOADER = LD;
     // loader waves: a wave can have at most 63 counted transfers in flight and a 32 KB column is 32
     // of them, so two columns deep (what hides the ~1.1 us DMA latency) needs two waves at HP = 64
     static constexpr int NLOAD = LOADER ? (HP >= 64 ? 2 : 1) : 0;
@@ -1007,6 +1009,9 @@ struct ChainCfg {
     static_assert(WORDS <= 64, "record must fit one wave-wide 8-byte load");
     static_assert(64 % R == 0 || R % 64 == 0, "row groups must not straddle 64-column blocks");
 };
+
+template <int HP, int PHASE>
+constexpr bool sweep_has_loader() { return HP < 128 && !(HP == 32 && PHASE != 2); }
 
 template <int HP, int R>
 struct ChainShared {
@@ -1428,9 +1433,9 @@ DEVI void posterior(ChainShared<HP, R>& sh, gdouble* part_out, uint32_t part_slo
 // PHASE 3 (chunked): columns [mid + chunk*K, +K), stored into the chunk scratch (posteriors by k_post).
 template <int HP, int R, int PHASE>
 DEVI void forward_body(const DevContig& dc, ChainShared<HP, R>& sh, uint32_t C, unsigned char* ring, uint32_t chunk) {
-    constexpr bool RING = ChainCfg<HP, R>::LOADER && PHASE == 2;  // partner columns via the LDS ring
+    using Cfg = ChainCfg<HP, R, sweep_has_loader<HP, PHASE>()>;
+    constexpr bool RING = Cfg::LOADER && PHASE == 2;  // partner columns via the LDS ring
     constexpr bool STORE = PHASE != 2;
-    using Cfg = ChainCfg<HP, R>;
     const uint32_t mid = C / 2;
     const uint32_t K = dc.chunk_cols;
     uint32_t lo = PHASE == 1 ? 0u : mid, hi = PHASE == 1 ? mid : C;
@@ -1867,7 +1872,7 @@ DEVI void forward_body(const DevContig& dc, ChainShared<HP, R>& sh, uint32_t C, 
 // ------------------------------------------------------------------------------------------
 template <int HP, int R, int VBUF, bool KEEPW, int PHASE>
 DEVI void backward_body(const DevContig& dc, ChainShared<HP, R>& sh, uint32_t C, unsigned char* ring, uint32_t chunk) {
-    using Cfg = ChainCfg<HP, R>;
+    using Cfg = ChainCfg<HP, R, sweep_has_loader<HP, PHASE>()>;
     constexpr bool RING = Cfg::LOADER && PHASE == 2;  // partner columns via the LDS ring
     constexpr bool STORE = PHASE != 2;
     const int64_t mid = C / 2;
@@ -2267,6 +2272,10 @@ DEVI void backward_body(const DevContig& dc, ChainShared<HP, R>& sh, uint32_t C,
             const RecInfo nxt = decode_record<Cfg::UNI>(sh.rec[(uint32_t)t & 7u], p.j, p.i0, full, dc.wide);
             const unsigned char* rec0 = sh.rec[(uint32_t)t & 7u];
             const uint32_t rb0 = rowbits_of(nxt);
+            if (!Cfg::LOADER && p.wave == 0) {   // (no loader wave: see the 32-row step)
+                rec_stage(t - 2, tq);  // loaded one column ago
+                tq = rec_load(t - 3);
+            }
             lds_barrier();  // B_t
             double Cj, Crow, Call;
             read_colsums<HP, R>(sh, (uint32_t)t & 1u, p, Cj, Crow, Call);
@@ -2347,7 +2356,7 @@ template <int HP, int R, int VBUF, bool KEEPW, int PHASE>
 #ifndef PG_HP32_WAVES_P2
 #define PG_HP32_WAVES_P2 3
 #endif
-__global__ __launch_bounds__((ChainCfg<HP, R>::TT), (HP == 32 ? (PHASE == 2 ? PG_HP32_WAVES_P2 : PG_HP32_WAVES) : 1)) void k_sweep(const DevContig* __restrict__ contigs, uint32_t chunk) {
+__global__ __launch_bounds__((ChainCfg<HP, R, sweep_has_loader<HP, PHASE>()>::TT), (HP == 32 ? (PHASE == 2 ? PG_HP32_WAVES_P2 : PG_HP32_WAVES) : 1)) void k_sweep(const DevContig* __restrict__ contigs, uint32_t chunk) {
     __shared__ ChainShared<HP, R> sh;
     extern __shared__ __attribute__((aligned(16))) unsigned char dyn_ring[];  // phase 2: kRingSlots column slots
     const DevContig& dc = contigs[blockIdx.x];
@@ -5142,7 +5151,7 @@ static bool lds_attr_pending(bool (&done)[PG_MAX_DEVICES]) {
 }
 template <int HP, int R, int VBUF, bool KEEPW, int PHASE>
 static void launch_one(const DevContig* d_contigs, uint32_t n_contigs, uint32_t chunk, hipStream_t s) {
-    using Cfg = ChainCfg<HP, R>;
+    using Cfg = ChainCfg<HP, R, sweep_has_loader<HP, PHASE>()>;
     size_t dyn = (Cfg::LOADER && PHASE == 2) ? (size_t)kRingSlots * HP * HP * 8 : 0;  // partner-column ring
     if (!Cfg::LOADER && PHASE == 2) dyn = (size_t)(Cfg::PARK / 2) * 16 * Cfg::T;       // parked rows (ChainCfg::PARK)
     if (HP == 64 && dyn > 0) {  // the triangle ring of lean chains (compact slots + the zero unit)
