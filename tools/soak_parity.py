@@ -41,7 +41,7 @@ for it in range(n):
     if os.environ.get("SOAK_TRI") == "1":
         mode = "fused"
     os.environ["PG_SWEEP_MODE"] = mode
-    kern = str(rng.choice(["", "", "", "general", "generic", "leanpipe", "prepwave"]))
+    kern = str(rng.choice(["", "", "", "general", "generic", "leanpipe", "prepwave", "small", "small,nosmall2", "fullcols", "nocls4"]))
     if os.environ.get("SOAK_TRI") == "1":
         kern = ""
     if kern:
