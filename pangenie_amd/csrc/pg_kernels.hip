@@ -1413,7 +1413,8 @@ DEVI void posterior(ChainShared<HP, R>& sh, gdouble* part_out, uint32_t part_slo
     // Partials go out as 16-byte stores of allele PAIRS (slot pair q = alleles 2q, 2q+1): a
     // wave-wide 16-byte store costs the texture-address unit a third of two 8-byte ones, and
     // phase-2 compute waves have no loads in flight (partner columns arrive through the LDS ring),
-    // so these stores never make them wait.  Layout: part[((c * part_slots/2 + q) * T + tid) * 2 + (a & 1)].
+    // so these stores never make them wait.  Layout: part[((c * part_slots/2 + q) * pT + pe) * 2 + (a & 1)], entry pe = tid of
+    // pT = T entries — at HP = 32: lane j of the wave's lower half, wave * 32 + j of pT = T / 2, after the two halves were added.
     if constexpr (HP == 32) {
 #pragma unroll
         for (int q = 0; q < (PG_AMAX + 1) / 2; ++q)
@@ -2345,8 +2346,8 @@ DEVI void backward_body(const DevContig& dc, ChainShared<HP, R>& sh, uint32_t C,
 
 // grid = (n_contigs, 2): blockIdx.y = 0 forward half-chain, 1 backward half-chain
 template <int HP, int R, int VBUF, bool KEEPW, int PHASE>
-// HP = 32 (17 .. 32 paths: the 15 + 1 paths behind haplotype sampling): 8 rows per lane = two compute waves + the loader per
-// half-chain, held to 128 registers (a few spills) so that a SIMD takes four waves.  With 16 rows per lane (one compute
+// HP = 32 (17 .. 32 paths: the 15 + 1 paths behind haplotype sampling): 8 rows per lane = two compute waves (+ the loader in
+// phase 2 only: sweep_has_loader) per half-chain, held to 128 registers (a few spills) so that a SIMD takes four waves.  With 16 rows per lane (one compute
 // wave of 209 - 240 registers) a CU ran four half-chains at a time and two thirds of a 1024-chain cohort's time was
 // waiting: 72 -> 59 ms per step on `cohort_h17` (PG_HP32_ROWS=16 PG_HP32_WAVES=1 builds the old configuration).
 // Phase 2 (posterior inline) is better off with three waves per SIMD and 168 registers: 22.5 -> 20.5 ms there.
@@ -3920,7 +3921,8 @@ __global__ __launch_bounds__((LxCfg<HP>::T)) void k_sweep_leanx(const DevContig*
 }
 
 // ------------------------------------------------------------------------------------------
-//  k_sweep_small16 : the store-only phases (1, 3) of all-biallelic chains with H = HP = 16 — BASELINE configs[1], and the
+//  k_sweep_small16 : all-biallelic chains with H = HP = 16 — the store-only phases (1, 3) and, for fused jobs (DevContig::small == 2),
+//  phase 2 with the posterior's four class sums per column formed inside the row — BASELINE configs[1], and the
 //  shape of many-sample runs over small (sampled) panels.  A 16 x 16 column is 256 states: FOUR half-chains share one
 //  wave, each in its own 16-lane DPP row.  lane -> (half-chain r = lane >> 4, column j = lane & 15); the sixteen rows
 //  of the column live in the lane's registers.  Everything a column step exchanges stays inside the DPP row:
