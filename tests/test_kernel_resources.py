@@ -33,9 +33,9 @@ def asm(tmp_path_factory):
     out = tmp_path_factory.mktemp("isa") / "pg_kernels.s"
     cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-S", "--cuda-device-only",
            "-Wno-unused-value", "-Wno-unused-result", "-mllvm", "-amdgpu-mfma-vgpr-form", str(SRC), "-o", str(out)]
-    r = subprocess.run(cmd, capture_output=True, text=True)
+    r = subprocess.run(cmd + ["-Rpass-analysis=kernel-resource-usage"], capture_output=True, text=True)
     assert r.returncode == 0, r.stderr[-2000:]
-    return out.read_text()
+    return out.read_text(), r.stderr
 
 
 def blocks_of(text, name):
@@ -59,7 +59,7 @@ def blocks_of(text, name):
 @pytest.mark.parametrize("kernel", sorted(KERNELS))
 def test_hot_loops_have_no_scratch_traffic(asm, kernel):
     min_instr, spills_elsewhere_ok = KERNELS[kernel]
-    blocks = blocks_of(asm, kernel)
+    blocks = blocks_of(asm[0], kernel)
     assert blocks, kernel
     hot = [b for b in blocks if b[1] >= min_instr]
     assert hot, "no large basic block found: the kernel's shape changed, adjust the threshold"
@@ -71,3 +71,31 @@ def test_hot_loops_have_no_scratch_traffic(asm, kernel):
         assert sum(1 for b in hot if not b[2]) >= 3, "the unrolled state loops must be scratch-free"
     else:
         assert not dirty, dirty
+
+
+# waves per SIMD the measured configurations rely on: a register more and the occupancy — and with it the
+# number of half-chains a CU holds — drops a step
+OCCUPANCY = {
+    "_Z7k_sweepILi32ELi8ELi1ELb1ELi1EEvPK9DevContigj": 4,     # 17 ... 32 paths, store-only phases: two waves per half-chain, eight half-chains per CU
+    "_Z7k_sweepILi32ELi8ELi1ELb1ELi2EEvPK9DevContigj": 3,     # ... fused phase 2
+    "_Z7k_sweepILi64ELi16ELi1ELb1ELi2EEvPK9DevContigj": 2,
+    "_Z7k_sweepILi128ELi32ELi1ELb0ELi2EEvPK9DevContigj": 2,   # eight waves per workgroup: two per SIMD
+    "_Z16k_sweep_lean_triILi1ELi16EEvPK9DevContigj": 2,       # two workgroups per CU
+    "_Z13k_sweep_lean2ILi16EEvPK9DevContig": 2,
+    "_Z15k_sweep_small16ILi1EEvPK9DevContigPKjjjPd": 2,
+    "_Z15k_sweep_small16ILi2EEvPK9DevContigPKjjjPd": 1,       # three partner-column buffers: one wave per SIMD, 2048 waves per launch
+    "_Z12k_bins_lean2PK9DevContig": 8,
+}
+
+
+def test_occupancy_of_the_measured_configurations(asm):
+    remarks = asm[1]
+    got = {}
+    for blk in remarks.split("Function Name: ")[1:]:
+        name = blk.split()[0]
+        m = re.search(r"Occupancy \[waves/SIMD\]: (\d+)", blk)
+        if m:
+            got[name] = int(m.group(1))
+    for name, want in OCCUPANCY.items():
+        assert name in got, name
+        assert got[name] >= want, (name, got[name], want)
