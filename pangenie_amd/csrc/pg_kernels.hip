@@ -564,10 +564,7 @@ DEVI void prep_unit(const DevContig& dc, const DevTable& tab, uint32_t unit) {
         for (; l < 8; ++l) ls[l] = 0;
     }
 }
-#ifndef PG_PREP_WAVES
-#define PG_PREP_WAVES 1
-#endif
-__global__ __launch_bounds__(256, PG_PREP_WAVES) void k_prep(const DevContig* __restrict__ contigs, DevTable tab) {
+__global__ __launch_bounds__(256) void k_prep(const DevContig* __restrict__ contigs, DevTable tab) {
     const DevContig& dc = contigs[blockIdx.y];
     if (dc.prep_fast == 1u) return;  // k_prep_bi's chain (2: its two-allele objects only, see prep_unit)
 #pragma unroll 1
@@ -757,10 +754,7 @@ DEVI void prep_bi_unit(const DevContig& dc, const DevTable& tab, uint32_t unit) 
     }
     wave_sync_lds();   // (the slot is rewritten by the wave's next unit)
 }
-#ifndef PG_PREPBI_WAVES
-#define PG_PREPBI_WAVES 1
-#endif
-__global__ __launch_bounds__(256, PG_PREPBI_WAVES) void k_prep_bi(const DevContig* __restrict__ contigs, DevTable tab) {
+__global__ __launch_bounds__(256) void k_prep_bi(const DevContig* __restrict__ contigs, DevTable tab) {
     const DevContig& dc = contigs[blockIdx.y];
     if (!dc.prep_fast) return;
 #pragma unroll 1
