@@ -67,8 +67,16 @@ COHORT = dict(samples=64, contigs=8, V=16_000, H=64, K=20)  # 512 chains, 194 GB
 COHORTS_MORE = {
     "cohort_h16": dict(samples=512, contigs=8, V=8_000, H=16, K=20, distinct=16),              # 4096 chains, 32.8 M variants
     "cohort_h128": dict(samples=16, contigs=8, V=3_000, H=128, K=20, multi=0.2, distinct=16),  # 128 chains, 50 GB of columns
-    # the production shape behind haplotype sampling: 15 sampled paths + the reference path (src/commands.cpp:799-803), a fifth
-    # of the objects multiallelic; 17 paths pad to 32: 8 KB per column
+    # THE DEFAULT PRODUCTION SHAPE of every panel with more than 100 haplotypes: 15 sampled paths + the reference path = 16
+    # paths (src/commands.cpp:799-803, src/haplotypesampler.cpp:43) whose bubbles keep every allele those paths carry
+    # (src/multiallelicuniquekmers.cpp:195-232): a fifth of the objects with 3-5 alleles ...
+    "cohort_h16m": dict(samples=512, contigs=8, V=8_000, H=16, K=20, multi=0.2, distinct=16),
+    # ... and 2 % of them bubbles of 6-12 alleles, of which the 16 paths carry up to nine (wide columns)
+    "cohort_h16w": dict(samples=512, contigs=8, V=8_000, H=16, K=20, multi=0.2, wide=0.02, distinct=16),
+    # an unsampled <= 100-haplotype panel (src/commands.cpp:799) with its multiallelic bubbles: full columns (no triangle
+    # storage yet for chains with multiallelic objects): 32 samples = 256 chains, 134 GB of columns
+    "cohort_h64m": dict(samples=32, contigs=8, V=16_000, H=64, K=20, multi=0.2, distinct=16),
+    # a user-chosen panel size (`-x 16` + the reference path = 17 ... 31 paths; NOT the default, which is 15 + 1 = 16): pads to 32
     "cohort_h17": dict(samples=128, contigs=8, V=8_000, H=17, K=20, multi=0.2, distinct=16),    # 1024 chains, 8.2 M variants, 67 GB of columns
 }
 # GRCh38 chromosome lengths (Mb) 1..22, X, Y: proportions of the 24 synthetic contigs
@@ -431,7 +439,7 @@ def main():
             roof, ncol, (mode, chunk_cols) = roofline_of(results, batches, kms, H, args.workload if (V == w["V"] and world == 1) else None, job_info)
             out.update({
                 "value": V_total * args.steps / dt, "ms_per_step": dt / args.steps * 1e3,
-                "scaling": "strong" if world > 1 else "weak",
+                "scaling": "strong",   # BASELINE configs[3] as written: the total work is fixed, the chains are sharded over the ranks
                 "value_end_to_end": V_total / dt_e2e,
                 "end_to_end": {"ms": dt_e2e * 1e3, "h2d_ms": hs2["upload_s"] * 1e3, "run_ms": hs2["run_s"] * 1e3, "d2h_ms": hs2["fetch_s"] * 1e3,
                                "h2d_bytes": sum(job_info["upload_bytes"].values()),
@@ -463,7 +471,7 @@ def main():
         """many (sample x contig) chains over ONE shared index (pg_cohort_new): the regime in which the sweeps are
         bound by the memory system.  c: dict(contigs, V, H, K, multi, distinct)."""
         NC, Hc = c["contigs"], c["H"]
-        index = [synthetic_panel(c["V"], Hc, c["K"], seed=777 + i, multiallelic_frac=c.get("multi", 0.0)) for i in range(NC)]
+        index = [synthetic_panel(c["V"], Hc, c["K"], seed=777 + i, multiallelic_frac=c.get("multi", 0.0), wide_frac=c.get("wide", 0.0)) for i in range(NC)]
         distinct = min(S, c.get("distinct", S))   # count sets formed; samples beyond reuse them in turn
         pool = []
         for s in range(distinct):  # every rank genotypes its own samples (weak scaling)
@@ -514,7 +522,8 @@ def main():
             ub = cjob.upload_bytes()
             res = {
                 "workload": f"{S} samples x {NC} contigs of {c['V']} variants, {Hc} haplotypes, {c['K']} k-mers/variant" +
-                            (f", {int(100 * c['multi'])} % multiallelic" if c.get("multi") else "") + f" per GPU: "
+                            (f", {int(100 * c['multi'])} % multiallelic" if c.get("multi") else "") +
+                            (f", {int(100 * c['wide'])} % of the objects with 6-12 alleles (wide columns)" if c.get("wide") else "") + f" per GPU: "
                             f"{S * NC} chains over ONE shared index (pg_cohort_new)" +
                             (f"; {distinct} distinct count sets, reused in turn" if distinct < S else ""),
                 "value": cv * world * csteps / cdt, "unit": "variants/s", "scaling": "weak", "steps": csteps, "ms_per_step": cdt / csteps * 1e3,
@@ -528,6 +537,106 @@ def main():
                 "roofline": croof, "kernel_ms": ckms, "device_bytes": cjob.device_bytes(),
             }
         cjob.close()
+        hmm._lib.load_hip().pg_hmm_release_cache()
+        return res
+
+    def cohort_strong_measure(key, like):
+        """The cohort as a STRONG-scaling line (where north_star's >= 6x 1 -> 8 GPUs can land): a FIXED set
+        of samples — COHORTS_MORE[key]'s, whatever N — sharded by sample over the ranks, every rank one resident cohort job
+        over the shared index, ONE gather of the packed posteriors to rank 0 per step (pg_hmm_gather; torch.distributed if
+        the C-ABI communicator cannot be made).  At N = 1 it IS the weak line `key` (`like`: no second run)."""
+        c = COHORTS_MORE[key]
+        S_total, NC, Hc = c["samples"], c["contigs"], c["H"]
+        if world == 1:
+            if like is None or rank != 0:
+                return None
+            return {"workload": like["workload"] + f"; the same {S_total} samples at every N, sharded by sample", "value": like["value"], "unit": "variants/s",
+                    "scaling": "strong", "steps": like["steps"], "ms_per_step": like["ms_per_step"], "n_gpus": 1, "gather": "none (one GPU)",
+                    "per_rank": [{"rank": 0, "samples": S_total, "chains": S_total * NC, "run_ms_per_step": like["ms_per_step"], "gather_ms_per_step": 0.0}],
+                    "note": f"N = 1: the `{key}` measurement of this line (same job)"}
+        S_mine = S_total // world + (1 if rank < S_total % world else 0)
+        index = [synthetic_panel(c["V"], Hc, c["K"], seed=777 + i, multiallelic_frac=c.get("multi", 0.0), wide_frac=c.get("wide", 0.0)) for i in range(NC)]
+        distinct = min(max(S_mine, 1), c.get("distinct", S_total))
+        pool = []
+        for sidx in range(distinct):
+            kcs, covs = zip(*[synthetic_sample_counts(ix, seed=100_000 * (rank + 1) + 100 * sidx + i) for i, ix in enumerate(index)])
+            pool.append((list(kcs), list(covs)))
+        cjob = hmm.Job.cohort(index, [pool[i % distinct] for i in range(S_mine)], table, params, device=local_rank) if S_mine else None
+        n_mine = cjob.packed_results()[2] if cjob else 0
+        tt = torch.zeros(world, dtype=torch.int64, device=dev)
+        tt[rank] = n_mine
+        dist.all_reduce(tt)
+        per_rank_lik = [int(x) for x in tt]
+        from pangenie_amd.dist import AbiGather
+        try:
+            abi = AbiGather(rank, world, local_rank)
+            abi.gather(cjob, per_rank_lik)
+            ok = 1.0
+        except Exception as e:  # noqa: BLE001
+            print(f"[rank {rank}] pg_hmm_gather unavailable ({e}); torch.distributed exchange", file=sys.stderr)
+            abi, ok = None, 0.0
+        t_ok = torch.tensor([ok], dtype=torch.float64, device=dev)
+        dist.all_reduce(t_ok, op=dist.ReduceOp.MIN)
+        if float(t_ok.item()) < 1.0:
+            abi = None
+        lik_t = exp_t = recv = None
+        if abi is None:   # the same exchange through torch: every rank's two packed ranges to rank 0
+            if cjob:
+                d_lik, d_exp, n_tot = cjob.packed_results()
+                lik_t = torch.as_tensor(_DevArray(d_lik, n_tot, "<f8"), device=dev)
+                exp_t = torch.as_tensor(_DevArray(d_exp, n_tot, "<i4"), device=dev)
+            if rank == 0:
+                recv = {r: (torch.empty(per_rank_lik[r], dtype=torch.float64, device=dev), torch.empty(per_rank_lik[r], dtype=torch.int32, device=dev))
+                        for r in range(1, world) if per_rank_lik[r]}
+
+        def exchange():
+            if abi:
+                abi.gather(cjob, per_rank_lik)
+                return
+            ops = []
+            if rank == 0:
+                for r, (a, b) in recv.items():
+                    ops += [dist.P2POp(dist.irecv, a, r), dist.P2POp(dist.irecv, b, r)]
+            elif n_mine:
+                ops = [dist.P2POp(dist.isend, lik_t, 0), dist.P2POp(dist.isend, exp_t, 0)]
+            if ops:
+                for wk in dist.batch_isend_irecv(ops):
+                    wk.wait()
+
+        csteps = max(2, min(args.steps, 3))
+        if cjob:
+            cjob.run()
+        exchange()
+        ms = {"run": 0.0, "gather": 0.0}
+        fence()
+        t0 = time.perf_counter()
+        for _ in range(csteps):
+            t_a = time.perf_counter()
+            if cjob:
+                cjob.run()
+            t_b = time.perf_counter()
+            exchange()
+            torch.cuda.synchronize()
+            ms["run"] += (t_b - t_a) * 1e3
+            ms["gather"] += (time.perf_counter() - t_b) * 1e3
+        fence()
+        cdt = max_over_ranks(time.perf_counter() - t0)
+        mine_t = torch.tensor([float(S_mine), ms["run"] / csteps, ms["gather"] / csteps], dtype=torch.float64, device=dev)
+        got = [torch.zeros_like(mine_t) for _ in range(world)]
+        dist.all_gather(got, mine_t)
+        res = None
+        if rank == 0:
+            rows = [{"rank": r, "samples": int(g[0].item()), "chains": int(g[0].item()) * NC, "run_ms_per_step": float(g[1].item()), "gather_ms_per_step": float(g[2].item())}
+                    for r, g in enumerate(got)]
+            res = {"workload": f"{S_total} samples x {NC} contigs of {c['V']} variants, {Hc} haplotypes — the SAME {S_total} samples at every N, sharded by sample "
+                               f"({S_total * NC} chains in all), one gather of the packed posteriors to rank 0 per step",
+                   "value": S_total * NC * c["V"] * csteps / cdt, "unit": "variants/s", "scaling": "strong", "steps": csteps, "ms_per_step": cdt / csteps * 1e3,
+                   "n_gpus": world, "gather": "pg_hmm_gather (C ABI: grouped ncclSend / ncclRecv)" if abi else "torch.distributed batch_isend_irecv",
+                   "gathered_bytes_per_step": 12 * int(sum(per_rank_lik[1:])), "per_rank": rows}
+        if abi:
+            abi.close()
+        if cjob:
+            cjob.close()
         hmm._lib.load_hip().pg_hmm_release_cache()
         return res
 
@@ -553,6 +662,10 @@ def main():
                     r = cohort_measure(spec, spec["samples"], key, key if world == 1 else None)
                     if rank == 0:
                         out[key] = r
+                # the strong-scaling cohort: the default production shape, a fixed set of samples sharded over the ranks
+                r = cohort_strong_measure("cohort_h16m", out.get("cohort_h16m") if rank == 0 else None)
+                if rank == 0 and r:
+                    out["cohort_strong"] = r
 
     # ------------------------------------------------------------------ HaplotypeSampler sub-measurement
     if not args.no_sampler and not args.cohort_only:

@@ -140,8 +140,9 @@ void pg_table_destroy(pg_table* t);
  *  MERGED into one multi-chain device job by the first of them (the others sleep until their results
  *  are in their buffers); chains of a job are independent, so each caller gets exactly what it would
  *  have got alone, and an error of one caller's batch is that caller's alone (the merged job is then
- *  re-run call by call).  Environment: PG_COALESCE=0 (off), PG_COALESCE_WINDOW_US (300),
- *  PG_COALESCE_WAIT_MS (250), PG_COALESCE_INFLIGHT (2 merged jobs per device at a time).
+ *  re-run call by call).  Environment: PG_COALESCE=0 (off), PG_COALESCE_WAIT_MS (250: the bound on waiting
+ *  for an announced call); the join window (300 us), the merged jobs in flight per device (2) and the batch
+ *  size (256 calls) are constants.
  *  Device arenas of finished calls are pooled for the next ones (pg_hmm_release_cache frees them).
  * ------------------------------------------------------------------ */
 int pg_hmm_device_count(void);

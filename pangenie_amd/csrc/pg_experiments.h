@@ -35,7 +35,7 @@ static constexpr bool kLeanDppSum = false;
 #endif
 static constexpr unsigned kLxExp = PG_LX_EXP;   // timing experiments: 1 no column stores, 2 no emission fetches — results WRONG
 
-// pipelined lean step (k_sweep_leanp, pg_lean_pipe.h): 1 no column stores, 2 no class totals
+// pipelined lean step (k_sweep_leanp — tools/lean_pipe/pg_lean_pipe.h, outside the product since round 5): 1 no column stores, 2 no class totals
 #ifndef PG_LEANP_EXP
 #define PG_LEANP_EXP 0
 #endif

@@ -3408,7 +3408,7 @@ __global__ __launch_bounds__((64 * 64 / R)) void k_sweep_lean(const DevContig* _
 template <int PHASE, int R, bool TRI>
 DEVI void sweep_lean_body(const DevContig* __restrict__ contigs, uint32_t chunk, LeanShared<R>& sh) {
     const DevContig& dc = contigs[blockIdx.x];
-    if (dc.lean != 1u) return;   // (2: the pipelined step, k_sweep_leanp)
+    if (dc.lean != 1u) return;
     if ((dc.tri != 0u) != TRI) return;
     const uint32_t C = (uint32_t)__builtin_amdgcn_readfirstlane((int)*dc.n_cols);
     if (C == 0) return;
@@ -3421,7 +3421,6 @@ DEVI void sweep_lean_body(const DevContig* __restrict__ contigs, uint32_t chunk,
     }
 }
 
-#include "pg_lean_pipe.h"   // k_sweep_leanp: the pipelined lean step (lone chains)
 
 // ------------------------------------------------------------------------------------------
 //  k_sweep_leanx : the store-only phases (1, 3) of chains at HP = 128 whose objects all have at most PG_AMAX alleles
@@ -5177,8 +5176,6 @@ static void launch_sweep(const DevContig* d_contigs, uint32_t n_contigs, uint32_
                 hipLaunchKernelGGL((k_sweep_lean_tri<PHASE, 16>), dim3(n_contigs, 2), dim3(256), 0, s, d_contigs, chunk);
             else hipLaunchKernelGGL((k_sweep_lean<PHASE, 16, false>), dim3(n_contigs, 2), dim3(256), 0, s, d_contigs, chunk);
         }
-        if (hp_mask & 2048u)  // bit 11: lean chains on the pipelined step (DevContig::lean == 2: lone chains of chunked jobs)
-            hipLaunchKernelGGL((k_sweep_leanp<PHASE>), dim3(n_contigs, 2), dim3(256), 0, s, d_contigs, chunk);
         if (hp_mask & 512u)   // bit 9: the job has lean-x chains at HP = 128 (narrow columns only)
             hipLaunchKernelGGL((k_sweep_leanx<PHASE, 128>), dim3(n_contigs, 2), dim3(LxCfg<128>::T), 0, s, d_contigs, chunk);
         if (hp_mask & 1024u)  // bit 10: ... at HP = 64 (chains with multiallelic objects; all-biallelic H = 64 chains are bit 6)

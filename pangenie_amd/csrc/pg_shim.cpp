@@ -212,7 +212,6 @@ namespace {
 struct IndexHost {   // one index contig
     uint32_t V = 0, H = 0, HP = 0, T = 0, RB = 0, part_slots = 2, pair_n = 1;
     bool lean = false;  // every object biallelic and H = HP = 64: the store-only phases run on k_sweep_lean
-    bool lean_pipe = false;  // ... of a chunked job (lone chains): on the pipelined step k_sweep_leanp (DevContig::lean == 2)
     bool cls4 = false;  // HP = 16 / 32, H = HP, every object biallelic, fused job: class sums instead of per-thread partials (DevContig::cls4)
     bool leanx = false; // HP = 128 / 64 and every object has at most PG_AMAX alleles (not `lean`): the store-only phases run on k_sweep_leanx
     bool small = false; // every object biallelic and H = HP = 16: the store-only phases run on k_sweep_small16
@@ -236,6 +235,10 @@ struct ChainHost {
     DevContig d;
     uint32_t n_cols_host = 0;
 };
+
+// entries of posterior partials per column and slot pair (DevContig::T), the ONE place the arena plan and the chain
+// descriptors take it from: threads per chain workgroup, half of them at HP = 32 (lanes l and l + 32 are folded: fold32)
+uint32_t part_entries(const IndexHost& x) { return x.HP == 32u ? x.T / 2u : x.T; }
 
 uint32_t pad_paths(uint32_t H) {
     for (uint32_t hp = 16; hp <= PG_MAX_PATHS; hp <<= 1)
@@ -400,6 +403,7 @@ struct pg_job {
     // pg_job_upload_begin / _end, into a SECOND set of arrays while the current one is being genotyped.
     size_t sample_lo = 0, sample_bytes = 0;
     unsigned char* staging = nullptr;         // pinned, sample_bytes (allocated on first use)
+    bool staging_refused = false;             // hipHostMalloc failed once: sample uploads copy chain by chain from pageable memory
     unsigned char* alt_samples = nullptr;     // device: the other set of per-sample arrays (allocated on first pg_job_upload_begin)
     DevContig* d_contigs_alt = nullptr;       // chain descriptors pointing into the other set (the spare of the two descriptor arrays)
     DevContig* d_contigs_owned = nullptr;     // the descriptor array that is not part of the arena (to free)
@@ -457,9 +461,25 @@ struct ChainSpec { uint32_t index; const uint16_t* kmer_count; const uint16_t* c
 int sample_upload(pg_job* job, const std::vector<ChainSpec>& specs, unsigned char* dev_base, hipStream_t stream,
                   std::vector<std::vector<uint16_t>>* cov_out, uint64_t* bytes, char* err, size_t errlen) {
     const size_t n = job->chains.size();
-    if (!job->staging) {
+    if (!job->staging && !job->staging_refused) {
         hipError_t he = hipHostMalloc((void**)&job->staging, job->sample_bytes ? job->sample_bytes : 8, hipHostMallocDefault);
-        if (he != hipSuccess) { job->staging = nullptr; set_err(err, errlen, "hipHostMalloc(%zu bytes) failed: %s", job->sample_bytes, hipGetErrorString(he)); return PG_ERR_NOMEM; }
+        if (he != hipSuccess) { (void)hipGetLastError(); job->staging = nullptr; job->staging_refused = true; }
+    }
+    if (!job->staging) {
+        // The host would not pin sample_bytes (tens of GB for a large cohort): the chains' arrays go straight from the
+        // caller's pageable buffers, one pair of copies per chain — slower (the runtime stages every copy), never a failure.
+        const size_t lo0 = job->sample_lo;
+        for (size_t c = 0; c < n; ++c) {
+            ChainHost& ch = job->chains[c];
+            const IndexHost& x = job->index[ch.index];
+            if (x.V == 0) continue;
+            HIP_TRY(hipMemcpyAsync(dev_base + (ch.o_cov - lo0), specs[c].coverage, (size_t)x.V * 2, hipMemcpyHostToDevice, stream));
+            if (x.sumK) HIP_TRY(hipMemcpyAsync(dev_base + (ch.o_kcnt - lo0), specs[c].kmer_count, (size_t)x.sumK * 2, hipMemcpyHostToDevice, stream));
+            if (bytes) *bytes += (uint64_t)x.V * 2 + (uint64_t)x.sumK * 2;
+            if (cov_out) (*cov_out)[c].assign(specs[c].coverage, specs[c].coverage + x.V);
+        }
+        HIP_TRY(hipStreamSynchronize(stream));
+        return PG_OK;
     }
     size_t pieces = n / 64;   // (at most one copy per 64 chains)
     const unsigned hw = std::thread::hardware_concurrency();
@@ -603,12 +623,12 @@ int upload_inputs(pg_job* job, const pg_contig_batch* batches, const std::vector
 //   small | nosmall     k_sweep_small16 whatever the chain count | never
 //   nolean2 notri nocls4 prepwave   phase 2 of triangle chains on the general kernel's ring | full columns | per-thread
 //                       partials instead of class sums | k_prep for every object
-//   leanpipe            the pipelined lean step k_sweep_leanp for lone 64-path chains (measured at par: profiles/r04_lean_chain.txt)
 //   fullcols            fused jobs at HP = 32 store and fetch whole 32 x 32 columns (DevContig::live = HP)
 //   nosmall2            phase 2 of the 16-path chains of fused jobs on the general kernel (k_sweep_small16 for phase 1 only)
 struct KernelChoice {
-    bool general = false, generic = false, nolean2 = false, notri = false, nocls4 = false, prepwave = false, leanpipe = false, fullcols = false, nosmall2 = false;
+    bool general = false, generic = false, nolean2 = false, notri = false, nocls4 = false, prepwave = false, fullcols = false, nosmall2 = false;
     int leanx = -1, small = -1;   // -1: by the job, 0 / 1: forced
+    std::string unknown;          // a token this list does not know
 };
 KernelChoice kernel_choice() {
     KernelChoice k;
@@ -621,7 +641,8 @@ KernelChoice kernel_choice() {
         else if (tok == "small") k.small = 1; else if (tok == "nosmall") k.small = 0;
         else if (tok == "nolean2") k.nolean2 = true; else if (tok == "notri") k.notri = true;
         else if (tok == "nocls4") k.nocls4 = true; else if (tok == "prepwave") k.prepwave = true;
-        else if (tok == "leanpipe") k.leanpipe = true; else if (tok == "fullcols") k.fullcols = true; else if (tok == "nosmall2") k.nosmall2 = true;
+        else if (tok == "fullcols") k.fullcols = true; else if (tok == "nosmall2") k.nosmall2 = true;
+        else if (!tok.empty()) k.unknown = tok;   // (a typo would quietly test the default path against itself: job creation fails)
         tok.clear();
     };
     for (const char* c = e; *c; ++c) { if (*c == ',' || *c == ' ') take(); else tok.push_back(*c); }
@@ -721,6 +742,11 @@ int job_build(int device, uint32_t n_index, const pg_contig_batch* batches, cons
     uint32_t max_v = 0;
     bool lean_ok = true, force_generic = false;
     const KernelChoice kc = kernel_choice();
+    if (!kc.unknown.empty()) {
+        set_err(err, errlen, "PG_KERNELS: unknown token '%s'", kc.unknown.c_str());
+        pg_job_destroy(job);
+        return PG_ERR_INVALID;
+    }
     force_generic = kc.generic; lean_ok = !kc.general && !kc.generic;
     std::vector<char> wide_overflow(n_index, 0);
     parallel_contigs(n_index, batches, [&](uint32_t i) {
@@ -773,9 +799,6 @@ int job_build(int device, uint32_t n_index, const pg_contig_batch* batches, cons
         }
         x.lean = lean_ok && x.HP == 64 && x.H == 64 && maxA == 2 && x.V > 0;
         x.small = lean_ok && x.HP == 16 && x.H == 16 && maxA == 2 && x.V > 0;   // (and enough of them: below)
-        {
-            x.lean_pipe = x.lean && kc.leanpipe;   // PG_KERNELS=leanpipe: the pipelined lean step (measured at par with the plain one: DESIGN 4)
-        }
         {
             // PG_KERNELS=nocls4: per-thread partials + k_bins (cross-check)
             // (the class sums are formed by a half-chain's ONE compute wave: 16 paths, and 32 when the kernel is built with 16 rows per lane)
@@ -914,7 +937,7 @@ int job_build(int device, uint32_t n_index, const pg_contig_batch* batches, cons
         const bool geno = params->run_genotyping != 0;  // (a phasing-only job has no sweep: no columns, no partials)
         p.fwd = take(geno ? (size_t)x.V * (tri ? 2304u : (size_t)x.HP * x.HP) * sizeof(double) : 0);
         // fused mode: posterior partials; chunked mode: the chunk scratch instead (k_post writes lik directly)
-        p.part = take(job->chunked || !geno ? 0 : (size_t)x.V * x.part_slots * x.T * sizeof(double));
+        p.part = take(job->chunked || !geno ? 0 : (size_t)x.V * x.part_slots * part_entries(x) * sizeof(double));
         // Viterbi: transition probabilities and one 2-byte backpointer per state and column
         p.vtq = take(params->run_phasing ? (size_t)x.V * 8 * sizeof(double) : 0);
         p.vback = take(params->run_phasing ? (size_t)x.V * x.H * x.HP * sizeof(uint16_t) : 0);
@@ -924,7 +947,7 @@ int job_build(int device, uint32_t n_index, const pg_contig_batch* batches, cons
         p.vpair = take((size_t)x.V * pg_pair_bytes(x.pair_n));
         p.xbuf = take((x.HP >= 256 || (force_generic && x.HP >= 64)) ? (size_t)2 * x.HP * x.HP * sizeof(double) : 0);
         p.frec = take((x.lean || x.small) ? (size_t)x.V * 64 : 0);
-        if (x.lean) job->hp_mask |= (x.lean_pipe && job->chunked) ? 2048u : 64u;
+        if (x.lean) job->hp_mask |= 64u;
         if (x.leanx) job->hp_mask |= x.HP == 128 ? 512u : 1024u;
         p.fscale = take((size_t)x.V * sizeof(double));
         p.bscale = take((size_t)x.V * sizeof(double));
@@ -974,7 +997,7 @@ int job_build(int device, uint32_t n_index, const pg_contig_batch* batches, cons
         const Plan& p = plan[c];
         DevContig& d = hd[c];
         memset(&d, 0, sizeof(d));
-        d.V = x.V; d.H = x.H; d.HP = x.HP; d.RB = x.RB; d.T = x.HP == 32u ? x.T / 2u : x.T /* entries of posterior partials per column and slot pair: see fold32 */; d.part_slots = x.part_slots; d.pair_n = x.pair_n;
+        d.V = x.V; d.H = x.H; d.HP = x.HP; d.RB = x.RB; d.T = part_entries(x); d.part_slots = x.part_slots; d.pair_n = x.pair_n;
         d.dist_scale = (double)dist_scale; d.uniform = params->uniform ? 1 : 0;
         d.debug = 8u;   // (bit 3: the in-kernel cycle counters of -DPG_CHAIN_PROF builds; the product build has none)
         d.pos = (const uint64_t*)(A + x.o_pos); d.cov = (const uint16_t*)(A + ch.o_cov);
@@ -991,7 +1014,7 @@ int job_build(int device, uint32_t n_index, const pg_contig_batch* batches, cons
         d.scratch = (double*)(A + p.scratch); d.chunk_cols = job->chunk_cols;
         d.wide = A + p.wide; d.wide_idx = x.wide_bytes ? (const uint32_t*)(A + x.o_widx) : nullptr;
         d.vpair = A + p.vpair; d.xbuf = (double*)(A + p.xbuf);
-        d.frec = (double*)(A + p.frec); d.lean = x.lean ? ((x.lean_pipe && job->chunked) ? 2u : 1u) : 0u; d.small = x.small ? ((!job->chunked && x.cls4 && !kc.nosmall2) ? 2u : 1u) : 0u; d.leanx = x.leanx ? 1u : 0u; d.cls4 = x.cls4 ? 1u : 0u;
+        d.frec = (double*)(A + p.frec); d.lean = x.lean ? 1u : 0u; d.small = x.small ? ((!job->chunked && x.cls4 && !kc.nosmall2) ? 2u : 1u) : 0u; d.leanx = x.leanx ? 1u : 0u; d.cls4 = x.cls4 ? 1u : 0u;
         d.live = (!job->chunked && x.HP == 32u && !kc.fullcols) ? std::min<uint32_t>(x.HP, (x.H + 3u) & ~3u) : x.HP;
         d.prep_fast = x.prep_fast;
         if (params->run_phasing) {
@@ -1138,6 +1161,13 @@ extern "C" int pg_job_upload_begin(pg_job* job, const pg_sample_counts* samples,
     if (!job->copy_stream) HIP_TRY(hipStreamCreateWithFlags(&job->copy_stream, hipStreamNonBlocking));
     if (!job->alt_samples) {   // the second set + descriptors that point into it
         hipError_t he = hipMalloc((void**)&job->alt_samples, job->sample_bytes ? job->sample_bytes : 8);
+        if (he != hipSuccess) {   // cached arenas of finished one-shot calls may be what stands in the way (as in job_build)
+            (void)hipGetLastError();
+            job->alt_samples = nullptr;
+            pg_hmm_release_cache();
+            hipSetDevice(job->device);
+            he = hipMalloc((void**)&job->alt_samples, job->sample_bytes ? job->sample_bytes : 8);
+        }
         if (he == hipSuccess) he = hipMalloc((void**)&job->d_contigs_owned, sizeof(DevContig) * n);
         job->d_contigs_alt = job->d_contigs_owned;
         if (he != hipSuccess) {

@@ -303,14 +303,17 @@ class Job:
         the previous run's results before upload_end()."""
         if self._samples is None:
             raise PanGenieError(-2, "upload_begin: not a cohort job")
+        # marshalled into locals: when an upload is already in flight the C side refuses this call, and the uploader thread
+        # is still reading the FIRST call's arrays — which only self._next_* keep alive (ADVICE r4)
         if samples is not None:
-            self._next_samples, self._next_keep = self._marshal_samples(list(samples))
+            nxt, keep = self._marshal_samples(list(samples))
         else:
-            self._next_samples, self._next_keep = self._samples, self._keep
+            nxt, keep = self._samples, self._keep
         err = C.create_string_buffer(_ERRLEN)
-        rc = self._lib.pg_job_upload_begin(self.h, self._next_samples, err, _ERRLEN)
+        rc = self._lib.pg_job_upload_begin(self.h, nxt, err, _ERRLEN)
         if rc:
             raise PanGenieError(rc, err.value.decode(errors="replace"))
+        self._next_samples, self._next_keep = nxt, keep
 
     def upload_end(self) -> None:
         err = C.create_string_buffer(_ERRLEN)

@@ -64,3 +64,14 @@ def assert_parity(batch, res, ref, tol=REL_TOL, check_calls=True):
         a, b = calls(batch, got), calls(batch, ref.lik)
         assert (a == b).all(), f"{int((a != b).sum())} genotype calls differ"
     return worst
+
+
+def log_parity(line: str) -> None:
+    """Worst-error lines of the whole-chain parity tests: printed (pytest -s) and, when PG_PARITY_LOG names a file,
+    appended to it (how profiles/r05_whole_chain_parity.txt was made on the GPU box)."""
+    import os
+    print(line)
+    path = os.environ.get("PG_PARITY_LOG")
+    if path:
+        with open(path, "a") as f:
+            f.write(line + "\n")

@@ -12,7 +12,7 @@ from pangenie_amd import hmm
 from pangenie_amd.genotyping_result import normalized_bins
 from pangenie_amd.panel import default_table_args, flatten, synthetic_panel
 from tests.fixtures_util import build_batch, build_variant, fill_table, triple
-from tests.parity_util import assert_parity, calls, rel_errors
+from tests.parity_util import assert_parity, calls, log_parity, rel_errors
 
 pytestmark = pytest.mark.gpu
 TOL = 1e-7
@@ -313,14 +313,12 @@ def test_generic_kernel_cross_checks_register_kernels(H, orc, monkeypatch):
     assert float(np.where(den > 0, np.abs(a - c) / np.where(den > 0, den, 1), 0).max()) < 1e-11
 
 
-@pytest.mark.parametrize("pipe", ["1", "0"])
 @pytest.mark.parametrize("K", [1, 2, 7, 64, 4096])
-def test_lean_kernel_biallelic_h64_vs_oracle_and_general(K, pipe, orc, monkeypatch):
-    """All-biallelic H = 64 chains of chunked jobs run their store-only phases (PG_KERNELS=leanpipe) on k_sweep_leanp — the pipelined lean step:
-    column sums in closed form, the LDS exchange beside the state block — or, by default, on k_sweep_lean (the
-    plain step: MFMA totals behind the exchange).  Unregularised table: forward columns that fall back to uniform and
+def test_lean_kernel_biallelic_h64_vs_oracle_and_general(K, orc, monkeypatch):
+    """All-biallelic H = 64 chains of chunked jobs run their store-only phases on k_sweep_lean (MFMA totals behind the
+    LDS exchange; the pipelined formulation measured at par in round 4 lives under tools/lean_pipe/, outside the product).  Unregularised table: forward columns that fall back to uniform and
     all-zero backward columns, on, before and behind chunk and record-block boundaries (330 and 131 columns: blocks of
-    64 records).  Either lean kernel and the general kernel must match the oracle and agree with each other to fp64
+    64 records).  The lean kernel and the general kernel must match the oracle and agree with each other to fp64
     rounding."""
     monkeypatch.setenv("PG_SWEEP_MODE", "chunked")
     monkeypatch.setenv("PG_CHUNK_COLS", str(K))
@@ -332,8 +330,6 @@ def test_lean_kernel_biallelic_h64_vs_oracle_and_general(K, pipe, orc, monkeypat
             b.kmer_count[1::17] = 60000
         t, p = hmm.ProbabilityTable(*args), hmm.make_params(1.26, False, 1e-5)
         monkeypatch.delenv("PG_KERNELS", raising=False)
-        if pipe == "1":
-            monkeypatch.setenv("PG_KERNELS", "leanpipe")
         lean = hmm.genotype_contig(b, t, p)
         monkeypatch.setenv("PG_KERNELS", "general")
         gen = hmm.genotype_contig(b, t, p)
@@ -810,9 +806,16 @@ def test_config3_whole_genome_full_size(orc):
         assert (first[k].lik == r2.lik).all() and (first[k].lik_exp == r2.lik_exp).all()
         assert r2.n_columns == int(r2.kept.sum()) > 0.9 * sizes[i]
         _check_normalised(batches[i], r2)
+    whole = job.fetch(20)   # the shortest contig (chr21's share: ~76 k variants) — a WHOLE chain of the 24-chain job, below
     job.close()
     hmm._lib.load_hip().pg_hmm_release_cache()
     args = default_table_args()
+    # every bin of that chain against the oracle: ~38 k columns per half-chain, ten chunks of 4096 handed over, the
+    # two directions meeting in the middle — as it ran INSIDE the 24-chain job, not re-run alone (parity gap 1)
+    assert sizes[20] > 70_000
+    ref = orc.genotype_contig(batches[20], orc.OracleTable(*args), orc.make_params(1.26, False, 1e-5))
+    worst = assert_parity(batches[20], whole, ref)
+    log_parity(f"whole chain 20 of genome24_h64 ({sizes[20]} variants x 64 paths, {whole.n_columns} columns) vs oracle: worst relative error {worst:.3e}")
     for i in (0, 11, 23):
         sl = batches[i].slice(0, 2000)
         res = hmm.genotype_contig(sl, t, p)
@@ -905,21 +908,29 @@ def test_config1_full_size_50k_variants_16_paths(orc):
         rf = hmm.genotype_contig(b, t, p)
     finally:
         os.environ.pop("PG_SWEEP_MODE", None)
+    # the WHOLE chain against the oracle, every bin, in both sweep modes (the oracle needs ~1 s for it)
+    ref = orc.genotype_contig(b, orc.OracleTable(*args), orc.make_params(1.26, False, 1e-5))
+    w_chunked, w_fused = assert_parity(b, r1, ref), assert_parity(b, rf, ref)
+    log_parity(f"configs[1] whole chain (50 000 x 16) vs oracle: worst relative error chunked {w_chunked:.3e}, fused {w_fused:.3e}")
     nf = normalized_bins(b, rf.likelihoods_ld())
     rel = rel_errors(b, nf, n1)
     assert float(rel[n1 > 1e-200].max()) < 1e-9
     assert (calls(b, nf) == calls(b, n1)).all()
 
 
-def test_full_size_properties():
+def test_full_size_properties(orc):
     """BASELINE.json configs[2] shape (200k variants x 64 haplotypes): size-independent checks.
     (a) determinism; (b) normalised posteriors sum to 1; (c) reversibility: the Li-Stephens
     chain with uniform start is time-reversible, so genotyping the mirrored contig must give
-    the same normalised posteriors for every variant."""
+    the same normalised posteriors for every variant; (d) the WHOLE chain against the oracle, every bin
+    (~45 s of oracle on a worker thread while the device does (c))."""
+    from concurrent.futures import ThreadPoolExecutor
     V, H = 200_000, 64
     b = synthetic_panel(V, H, 20, seed=12345)
     t = hmm.ProbabilityTable(*default_table_args())
     p = hmm.make_params(1.26, False, 1e-5)
+    pool = ThreadPoolExecutor(1)   # (ctypes drops the GIL for the duration of the oracle call)
+    ref_future = pool.submit(orc.genotype_contig, b, orc.OracleTable(*default_table_args()), orc.make_params(1.26, False, 1e-5))
     job = hmm.Job([b], t, p)
     job.run()
     r1 = job.fetch(0)
@@ -960,6 +971,33 @@ def test_full_size_properties():
     big = n1 > 1e-200
     assert float(rel[big].max()) < 1e-6, float(rel[big].max())
     assert (calls(b, back) == calls(b, n1)).all()
+    worst = assert_parity(b, r1, ref_future.result())
+    pool.shutdown()
+    log_parity(f"configs[2] whole chain (200 000 x 64, {r1.n_columns} columns) vs oracle: worst relative error {worst:.3e}")
+
+
+def test_whole_chain_h128_multiallelic_vs_oracle(orc):
+    """One whole 20 000-variant chain at 128 paths, a fifth of the objects multiallelic (BASELINE configs[4]'s shape) — every
+    bin against the oracle, chunked (k_sweep_leanx + k_post, three chunks per half-chain) and fused (the general kernel's
+    phase 2): column 10 000 of a 20 000-column chain, not a 300-variant window re-run alone."""
+    b = synthetic_panel(20_000, 128, 20, seed=20128, multiallelic_frac=0.2)
+    args = default_table_args()
+    t, p = hmm.ProbabilityTable(*args), hmm.make_params(1.26, False, 1e-5)
+    from concurrent.futures import ThreadPoolExecutor
+    pool = ThreadPoolExecutor(1)
+    ref_future = pool.submit(orc.genotype_contig, b, orc.OracleTable(*args), orc.make_params(1.26, False, 1e-5))
+    import os
+    got = {}
+    for mode in ("chunked", "fused"):
+        os.environ["PG_SWEEP_MODE"] = mode
+        try:
+            got[mode] = hmm.genotype_contig(b, t, p)
+        finally:
+            os.environ.pop("PG_SWEEP_MODE", None)
+    ref = ref_future.result()
+    pool.shutdown()
+    worst = {m: assert_parity(b, r, ref) for m, r in got.items()}
+    log_parity(f"whole chain 20 000 x 128, 20 % multiallelic ({ref.n_columns} columns) vs oracle: worst relative error chunked {worst['chunked']:.3e}, fused {worst['fused']:.3e}")
 
 
 @pytest.mark.parametrize("shape", [(700, 5, 20), (600, 16, 12), (500, 30, 32), (400, 64, 20), (300, 33, 7)], ids=lambda s: "V%d_H%d_K%d" % s)
