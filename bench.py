@@ -126,13 +126,13 @@ def cpu_baseline(batches, H, sample_variants):
 
 def _sweep_phase(name: str):
     """Phase (1, 2, 3) of a sweep kernel from its demangled name, None for other kernels:
-    k_sweep<HP, R, VBUF, KEEPW, PHASE>, k_sweep_lean[_tri]<PHASE, R>, k_sweep_leanx<PHASE, HP>, k_sweep_small16<PHASE>,
+    k_sweep<HP, R, VBUF, KEEPW, PHASE>, k_sweep_lean[_tri]<PHASE, R>, k_sweep_leanx<PHASE, HP>, k_sweep_small16[x]<PHASE>,
     k_sweep_generic<PHASE>."""
     import re
     if name.startswith("void k_sweep_lean2<"):  # phase 2 of triangle chains
         return 2
     m = re.match(r"void k_sweep_lean<(\d), ", name) or re.match(r"void k_sweep_lean_tri<(\d), ", name) or \
-        re.match(r"void k_sweep_leanx<(\d), ", name) or re.match(r"void k_sweep_small16<(\d)>", name) or \
+        re.match(r"void k_sweep_leanx<(\d), ", name) or re.match(r"void k_sweep_small16x?<(\d)>", name) or \
         re.match(r"void k_sweep_generic<(\d)>", name) or re.match(r"void k_sweep<\d+, \d+, \d+, \w+, (\d)>", name)
     return int(m.group(1)) if m else None
 

@@ -46,6 +46,7 @@
 #define PG_REC_FLAG_ALLZERO 1
 #define PG_REC_FLAG_WIDE 2    // more than PG_AMAX alleles on the selected paths: table in DevContig::wide
 #define PG_REC_WIDE_IDX 44    // u32: byte offset / 16 of the variant's wide entry inside DevContig::wide
+#define PG_REC_AUX 60         // u32: byte offset / 16 of the variant's slot inside DevContig::aux (PG_WIDE_NONE: none); the last two of the eight local-slot entries
 
 // Wide entries (columns with PG_AMAX < n_local <= PG_WIDE_MAX distinct alleles on the selected paths;
 // chunked sweep mode only): the emission table no longer fits the column record, so it lives in a
@@ -81,6 +82,7 @@ static inline uint32_t pg_rec_bytes(uint32_t hp) { return (PG_REC_ALLELES + hp +
 #define PG_DEVERR_ALLELE_NOT_FOUND 1u
 #define PG_DEVERR_TOO_MANY_ALLELES 2u
 #define PG_DEVERR_TOO_MANY_LOCAL 4u
+#define PG_DEVERR_WIDE_FUSED 8u   // a wide column reached a fused bins kernel that has no path for it (a single-column chain of k_sweep_small16x's job)
 
 struct DevTable {
     uint32_t cov_min, cov_max, count_max;  // dense box [cov_min,cov_max) x [0,count_max)
@@ -159,6 +161,14 @@ struct DevContig {
     // half-chain) writes the four class sums of a column, part[4 c + 2 (row allele) + (column allele)], and
     // k_bins_lean2 turns them into bins — instead of per-thread partials reduced by k_bins
     uint32_t  cls4;
+    // 1 / 2: HP = H = 16 and NOT every object biallelic: the store-only phases (1) / both phases (2: fused jobs) run on
+    // k_sweep_small16x (pg_small16x.h): 320-byte column records in `frec`, class sums of columns with at most two local
+    // alleles in `part` ([C][4]), the accumulators of columns with three to five and the phase-2 column of WIDE columns in
+    // the variant's `aux` slot (k_bins_x, k_bins_wide)
+    uint32_t  smallx;
+    uint32_t  pad1;
+    unsigned char* aux;        // per chain: slots of the variants with more than two alleles (768 B) / more than PG_AMAX (max(768, 8 HP^2) B)
+    const uint32_t* aux_idx;   // [V] per index contig: byte offset / 16 of the variant's slot, PG_WIDE_NONE if it has two alleles
     // rows and lanes of a stored column that carry data: H rounded up to a multiple of 4 (fused jobs at HP = 32, where
     // 17 paths — the 15 + 1 behind haplotype sampling — would otherwise move 32 x 32 states per column for 17 x 17 real ones), else HP.
     // Phase 1 stores only rows and lanes below `live` (whole 64-byte sectors), the loader of phase 2 fetches only those,

@@ -425,6 +425,7 @@ DEVI void prep_unit(const DevContig& dc, const DevTable& tab, uint32_t unit) {
             uint32_t l = 0;
             for (uint32_t sl = 0; sl < A; ++sl)
                 if (slot_present(pres, sl)) slots[l++] = (uint16_t)sl;
+            *(uint32_t*)(rec + PG_REC_AUX) = dc.aux_idx ? dc.aux_idx[v] : PG_WIDE_NONE;
         }
         return;
     }
@@ -562,6 +563,7 @@ DEVI void prep_unit(const DevContig& dc, const DevTable& tab, uint32_t unit) {
         for (uint32_t s = 0; s < A && l < 8; ++s)
             if (slot_present(pres, s)) ls[l++] = (uint16_t)s;
         for (; l < 8; ++l) ls[l] = 0;
+        *(uint32_t*)(rec + PG_REC_AUX) = dc.aux_idx ? dc.aux_idx[v] : PG_WIDE_NONE;   // (the last two of the eight slots: PG_AMAX = 5 are used)
     }
 }
 __global__ __launch_bounds__(256) void k_prep(const DevContig* __restrict__ contigs, DevTable tab) {
@@ -847,13 +849,13 @@ __global__ __launch_bounds__(64) void k_transition_single(double d, uint32_t H, 
 // The same for lean chains of chunked jobs: their sweeps run on k_sweep_lean and k_post reads the variant record.
 // And for the 16-path chains whose two phases both run on k_sweep_small16 (DevContig::small == 2).
 DEVI bool compact_records_only(const DevContig& dc, uint32_t C) {
-    return ((dc.tri == 2u || dc.small == 2u) && C >= 2u) || (dc.lean && dc.tri == 0u && dc.chunk_cols > 0u);
+    return ((dc.tri == 2u || dc.small == 2u || dc.smallx == 2u) && C >= 2u) || (dc.lean && dc.tri == 0u && dc.chunk_cols > 0u);
 }
 
 DEVI void records_unit(const DevContig& dc, uint32_t unit) {
     const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const uint32_t C = *dc.n_cols;
-    if (compact_records_only(dc, C)) {
+    if (compact_records_only(dc, C) && !dc.smallx) {
         const uint32_t c = unit * 256u + threadIdx.x;
         if (c >= C) return;
         const uint32_t v = dc.col_variant[c];
@@ -900,12 +902,49 @@ DEVI void records_unit(const DevContig& dc, uint32_t unit) {
     const uint32_t ppr = dc.RB / 16u, inv = (uint32_t)((0x100000000ull + ppr - 1u) / ppr);
     typedef double f64x2 __attribute__((ext_vector_type(2)));
     f64x2* dst = (f64x2*)(dc.colrec + (size_t)cbase * dc.RB);
+    if (!compact_records_only(dc, C))   // (x chains of fused jobs: only the 320-byte records below)
     for (uint32_t p = lane; p < n * ppr; p += 64u) {
         const uint32_t q = __umulhi(p, inv), w = p - q * ppr;
         const uint32_t v = s_v[wave][q];
         f64x2 val = ((const f64x2*)(dc.vrec + (size_t)v * dc.RB))[w];
         if (w < 2u) val = f64x2{s_c[wave][q][2u * w], s_c[wave][q][2u * w + 1u]};
         dst[p] = val;
+    }
+    if (dc.smallx) {
+        // the 320-byte records of k_sweep_small16x (pg_small16x.h): pieces 0..14 = rows 0..4 of the 6 x 6 table, 15 = header,
+        // 16-17 = constants, 18 = table-row offset (a + 1) * 48 of every path's allele (0: phantom, and every path of a wide
+        // column), 19 = the raw local alleles; the wave's n records are n * 20 pieces, contiguous on the destination side
+        f64x2* xd = (f64x2*)((unsigned char*)dc.frec + (size_t)cbase * 320u);
+        for (uint32_t p = lane; p < n * 20u; p += 64u) {
+            const uint32_t q = p / 20u, w = p - q * 20u;
+            const unsigned char* src = dc.vrec + (size_t)s_v[wave][q] * dc.RB;
+            f64x2 val;
+            if (w < 15u) val = ((const f64x2*)(src + PG_REC_E))[w];
+            else if (w == 16u) val = f64x2{s_c[wave][q][0], s_c[wave][q][1]};
+            else if (w == 17u) val = f64x2{s_c[wave][q][2], s_c[wave][q][3]};
+            else {
+                const uint32_t nlf = (uint32_t)src[PG_REC_NLOCAL] | ((uint32_t)src[PG_REC_FLAGS] << 8);
+                uint4 u;
+                if (w == 15u) u = uint4{*(const uint32_t*)(src + PG_REC_VARIANT), nlf, *(const uint32_t*)(src + PG_REC_WIDE_IDX), *(const uint32_t*)(src + PG_REC_AUX)};
+                else {
+                    u = *(const uint4*)(src + PG_REC_ALLELES);
+                    if (w == 18u) {
+                        auto f = [&](uint32_t x) {   // four allele bytes -> four row offsets
+                            uint32_t r = 0;
+#pragma unroll
+                            for (int b = 0; b < 4; ++b) {
+                                const uint32_t a = (x >> (8 * b)) & 0xFFu;
+                                r |= ((a < (uint32_t)PG_AMAX && !(nlf & 0x200u)) ? (a + 1u) * (uint32_t)(PG_ESTRIDE * 8) : 0u) << (8 * b);
+                            }
+                            return r;
+                        };
+                        u = uint4{f(u.x), f(u.y), f(u.z), f(u.w)};
+                    }
+                }
+                val = *(const f64x2*)&u;
+            }
+            xd[p] = val;
+        }
     }
     if (dc.lean || dc.small) {
         // compact records of the lean sweeps: {c0, c1, c2, kappa, E'00, E'01, E'11, bits1}, eight columns per wave instruction
@@ -2356,13 +2395,13 @@ __global__ __launch_bounds__((ChainCfg<HP, R, sweep_has_loader<HP, PHASE>()>::TT
     extern __shared__ __attribute__((aligned(16))) unsigned char dyn_ring[];  // phase 2: kRingSlots column slots
     const DevContig& dc = contigs[blockIdx.x];
     if (dc.HP != (uint32_t)HP) return;
-    if (PHASE != 2 && (dc.lean || dc.small || dc.leanx)) return;  // store-only phases of all-biallelic H = 64 / H = 16 chains: k_sweep_lean / k_sweep_small16
+    if (PHASE != 2 && (dc.lean || dc.small || dc.smallx || dc.leanx)) return;  // store-only phases of all-biallelic H = 64 / H = 16 chains: k_sweep_lean / k_sweep_small16[x]
     // (written by k_compact: a vector load as far as the compiler knows — make the trip count, and
     // with it every column index, ring slot and address derived from it, wave-uniform again)
     const uint32_t C = (uint32_t)__builtin_amdgcn_readfirstlane((int)*dc.n_cols);
     if (C == 0) return;
     if (PHASE == 2 && dc.tri == 2u && C >= 2) return;  // triangle chains: k_sweep_lean2
-    if (PHASE == 2 && dc.small == 2u && C >= 2) return;  // all-biallelic 16-path chains of fused jobs: k_sweep_small16<2>
+    if (PHASE == 2 && (dc.small == 2u || dc.smallx == 2u) && C >= 2) return;  // 16-path chains of fused jobs: k_sweep_small16<2> / k_sweep_small16x<2>
     if constexpr (PHASE == 2 && HP == 64 && ChainCfg<HP, R>::LOADER) {
         // triangle ring (DevContig::tri): the unit of zeros that stands for everything below the diagonal; first read
         // behind the P0 barrier of the bodies
@@ -4319,6 +4358,8 @@ __global__ __launch_bounds__(64) void k_sweep_small16(const DevContig* __restric
     if (blockIdx.y == 0) small16_forward<PHASE>(contigs, ids, n_ids, chunk, dump);
     else small16_backward<PHASE>(contigs, ids, n_ids, chunk, dump);
 }
+#include "pg_small16x.h"   // k_sweep_small16x: the same step with table emissions — 16-path chains with multiallelic objects, wide columns per column
+
 // ------------------------------------------------------------------------------------------
 //  k_sweep_generic : the same half-chains for any HP = 64 .. 1024 (power of two), store-only phases
 //  (1 and 3; the posteriors come from k_post).  Used for HP >= 256 — more states per column than a
@@ -4647,7 +4688,8 @@ DEVI void store_bin(double* lik, int32_t* lik_exp, uint64_t idx, double sum, dou
 // chains of up to 32 paths (at most 64 partial entries per column and slot pair): one THREAD per column (k_bins_thin) —
 // a wave per column spent ~460 vector instructions on each (eight 64-lane sums, the index arithmetic and a division, all
 // wave-wide for one column), 7 ms for the 8.2 M columns of `cohort_h17`
-DEVI bool bins_thin(const DevContig& dc) { return dc.T <= 64u && dc.HP <= 32u && !dc.cls4 && dc.chunk_cols == 0u; }
+DEVI bool bins_x(const DevContig& dc, uint32_t C) { return dc.smallx == 2u && C >= 2u; }   // k_bins_x / k_bins_wide (chains on k_sweep_small16x<2>)
+DEVI bool bins_thin(const DevContig& dc) { return dc.T <= 64u && dc.HP <= 32u && !dc.cls4 && dc.chunk_cols == 0u && !bins_x(dc, *dc.n_cols); }
 
 DEVI void bins_unit(const DevContig& dc, uint32_t unit, double (&s_bins)[4][PG_AMAX * (PG_AMAX + 1) / 2]) {
     const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -4655,6 +4697,7 @@ DEVI void bins_unit(const DevContig& dc, uint32_t unit, double (&s_bins)[4][PG_A
     const uint32_t C = *dc.n_cols;
     if (c >= C) return;
     if ((dc.tri == 2u && C >= 2u) || dc.cls4) return;  // chains whose class sums arrive finished (k_sweep_lean2, DevContig::cls4): k_bins_lean2
+    if (bins_x(dc, C)) return;                           // chains on k_sweep_small16x<2>: k_bins_x, k_bins_wide
     if (bins_thin(dc)) return;                           // few partial entries per column: k_bins_thin
     // (chains with compact records only have no column-order copy of the records: the variant's own record)
     const bool direct = compact_records_only(dc, C);
@@ -4784,6 +4827,7 @@ __global__ __launch_bounds__(256) void k_bins_thin(const DevContig* __restrict__
     const uint32_t v = *(const uint32_t*)(rec + PG_REC_VARIANT);
     const uint32_t nl = rec[PG_REC_NLOCAL];
     const uint32_t T = dc.T, HP = dc.HP, H = dc.H;
+    if (active && nl > (uint32_t)PG_AMAX) atomicOr(dc.err, PG_DEVERR_WIDE_FUSED);   // (fused jobs take wide columns on k_sweep_small16x only; this is that job's single-column chain)
     const unsigned char* al = rec + PG_REC_ALLELES;
     double* acc = s_acc[threadIdx.x];
 #pragma unroll
@@ -4941,6 +4985,10 @@ __global__ __launch_bounds__(256) void k_bins_lean2(const DevContig* __restrict_
 // ------------------------------------------------------------------------------------------
 #define PG_POST_WAVES 16
 #define PG_POST_PLACEMENT_LDS (152 * 1024)
+// the bins of column c from its two stored columns A = alpha', B = beta' (full columns, row-pair layout) by one wave;
+// s_bins = the wave's row of narrow bins
+DEVI void post_ab(const DevContig& dc, uint32_t C, uint32_t c, const double* A, const double* B, uint32_t lane,
+                  double (&s_bins_row)[PG_AMAX * (PG_AMAX + 1) / 2]);
 // one column (index idx inside the chunk: forward role first) by one wave
 DEVI void post_column(const DevContig& dc, uint32_t chunk, uint32_t idx, uint32_t wave, uint32_t lane,
                       double (&s_bins)[PG_POST_WAVES][PG_AMAX * (PG_AMAX + 1) / 2]) {
@@ -4968,12 +5016,17 @@ DEVI void post_column(const DevContig& dc, uint32_t chunk, uint32_t idx, uint32_
         B = scr + (size_t)K * colsz + (size_t)(idx - K) * colsz;
         A = dc.fwd + (size_t)c * colsz;
     }
+    post_ab(dc, C, c, A, B, lane, s_bins[wave]);
+}
+DEVI void post_ab(const DevContig& dc, uint32_t C, uint32_t c, const double* A, const double* B, uint32_t lane,
+                  double (&s_bins_row)[PG_AMAX * (PG_AMAX + 1) / 2]) {
+    const uint32_t HP = dc.HP;
     const bool direct = compact_records_only(dc, C);  // (no column-order copy of the records: the variant's own)
     const unsigned char* rec = direct ? dc.vrec + (size_t)dc.col_variant[c] * dc.RB : dc.colrec + (size_t)c * dc.RB;
     const uint32_t v = *(const uint32_t*)(rec + PG_REC_VARIANT);
     const uint32_t nl = rec[PG_REC_NLOCAL];
     const unsigned char* al = rec + PG_REC_ALLELES;
-    if (lane < PG_AMAX * (PG_AMAX + 1) / 2) s_bins[wave][lane] = 0.0;
+    if (lane < PG_AMAX * (PG_AMAX + 1) / 2) s_bins_row[lane] = 0.0;
     wave_sync_lds();   // (LDS only: the header loads above stay in flight under the first column loads below)
 
     // element e of a column = row pair e / HP, column e % HP (16 bytes: rows 2*(e/HP), +1); lanes take
@@ -5057,7 +5110,7 @@ DEVI void post_column(const DevContig& dc, uint32_t chunk, uint32_t idx, uint32_
                             const double tot = wave_sum(b == (uint32_t)bb ? acc[a] : 0.0);
                             if (lane == 0) {
                                 const uint32_t ra = (uint32_t)a, cb = (uint32_t)bb;
-                                s_bins[wave][tri_local(ra < cb ? ra : cb, ra < cb ? cb : ra)] += tot;
+                                s_bins_row[tri_local(ra < cb ? ra : cb, ra < cb ? cb : ra)] += tot;
                             }
                         }
                     }
@@ -5094,7 +5147,7 @@ DEVI void post_column(const DevContig& dc, uint32_t chunk, uint32_t idx, uint32_
                 const uint32_t pi = tri_n(la, lb, pn);
                 const double pm = fb ? 0.5 : ((const double*)vp)[pi];
                 const int pe = fb ? 1 : ((const int*)(vp + (size_t)NP * 8u))[pi];
-                store_bin(dc.lik, dc.lik_exp, gi, s_bins[wave][tri_local(la, lb)] * scale, pm, pe, xexp);
+                store_bin(dc.lik, dc.lik_exp, gi, s_bins_row[tri_local(la, lb)] * scale, pm, pe, xexp);
             }
         }
     } else {
@@ -5126,6 +5179,122 @@ __global__ __launch_bounds__(64 * PG_POST_WAVES) void k_post(const DevContig* __
     for (uint32_t idx = blockIdx.x * PG_POST_WAVES + wave; idx < 2u * dc.chunk_cols; idx += gridDim.x * PG_POST_WAVES) {
         post_column(dc, chunk, idx, wave, lane, s_bins);
         wave_sync_lds();   // (the wave's s_bins row is reused by its next column; its global stores need no wait)
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+//  k_bins_x / k_bins_wide : the bins of chains whose phase 2 ran on k_sweep_small16x (DevContig::smallx == 2).
+//  k_bins_x — one THREAD per column: a column with at most two local alleles has its four class sums in part[c][4]
+//  (DevContig::cls4's layout); one with three to five has the sixteen lanes' row-allele accumulators in its aux slot
+//  ([lane j][6 doubles]; the column allele of lane j is the allele of path j); the rare column whose bins are re-formed
+//  from the stored backward column (forward fall-back, see k_bins) is walked by its thread alone.  Same factors,
+//  exponents and fall-back rule as bins_unit.  WIDE columns are left to k_bins_wide — one WAVE per wide column: the
+//  column this role's phase 2 put into the aux slot times the stored partner column, as k_post does it (post_ab).
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_bins_x(const DevContig* __restrict__ contigs) {
+    __shared__ double s_acc[256][PG_NBINS + 2];   // (17 doubles: an odd row stride spreads the threads' rows over the banks)
+    const DevContig& dc = contigs[blockIdx.y];
+    const uint32_t C = *dc.n_cols;
+    if (!bins_x(dc, C)) return;
+    if (blockIdx.x * 256u >= C) return;
+    const uint32_t c = blockIdx.x * 256u + threadIdx.x;
+    if (c >= C) return;
+    const unsigned char* rec = dc.vrec + (size_t)dc.col_variant[c] * dc.RB;
+    if (rec[PG_REC_FLAGS] & PG_REC_FLAG_WIDE) return;   // k_bins_wide
+    const uint32_t v = *(const uint32_t*)(rec + PG_REC_VARIANT);
+    const uint32_t nl = rec[PG_REC_NLOCAL];
+    const uint32_t H = dc.H, HP = dc.HP;
+    const unsigned char* al = rec + PG_REC_ALLELES;
+    double* acc = s_acc[threadIdx.x];
+#pragma unroll
+    for (int i = 0; i < PG_NBINS; ++i) acc[i] = 0.0;
+    auto add = [&](uint32_t a, uint32_t b, double val) { acc[tri_local(a < b ? a : b, a < b ? b : a)] += val; };
+    const bool fb = dc.fwd_fallback[c] != 0;
+    const bool reform = fb && c >= C / 2;
+    if (reform) {
+        // (see bins_unit) alpha_hat * fsum = 1 / H^2 for every state, times the stored backward column
+        const double unif = 1.0 / ((double)H * (double)H);
+        const double* col = dc.fwd + (size_t)c * dc.col_stride;
+        for (uint32_t i = 0; i < H; ++i) {
+            const uint32_t a = al[i];
+            for (uint32_t jj = 0; jj < H; ++jj) {
+                const uint32_t b = al[jj];
+                if (a < nl && b < nl) add(a, b, col[((size_t)(i >> 1) * HP + jj) * 2 + (i & 1u)] * unif);
+            }
+        }
+    } else if (nl <= 2u) {
+        const double* p4 = dc.part + (size_t)c * 4u;
+        acc[tri_local(0, 0)] = 0.0 + p4[0];
+        if (nl > 1u) { acc[tri_local(0, 1)] = (0.0 + p4[1]) + p4[2]; acc[tri_local(1, 1)] = 0.0 + p4[3]; }
+    } else {
+        // sixteen lanes x {acc0 .. acc4, 0}: eight lanes' entries (24 16-byte loads) in flight at a time
+        const v2f64* e = (const v2f64*)(dc.aux + (size_t)(*(const uint32_t*)(rec + PG_REC_AUX)) * 16u);
+        const uint4 aw = ((const uint4*)al)[0];
+        const uint32_t alw[4] = {aw.x, aw.y, aw.z, aw.w};
+        static_for<0, 2>([&](auto hb) __attribute__((always_inline)) {
+            constexpr int j0 = decltype(hb)::value * 8;
+            v2f64 pv[8][3];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) { pv[k][0] = e[3 * (j0 + k)]; pv[k][1] = e[3 * (j0 + k) + 1]; pv[k][2] = e[3 * (j0 + k) + 2]; }
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const uint32_t b = (alw[(j0 + k) >> 2] >> (8 * ((j0 + k) & 3))) & 0xFFu;
+                if (b < nl) {
+                    add(0, b, pv[k][0].x); add(1, b, pv[k][0].y);
+                    add(2, b, pv[k][1].x);
+                    if (nl > 3u) add(3, b, pv[k][1].y);
+                    if (nl > 4u) add(4, b, pv[k][2].x);
+                }
+            }
+        });
+    }
+    const double scale = 1.0 / ((fb ? 1.0 : dc.fscale[c]) * dc.bscale[c]);
+    int xexp = -((fb ? 0 : PG_BIAS_F) + PG_BIAS_B);
+    if (c + 1 < C) xexp += *(const int32_t*)(dc.vrec + (size_t)dc.col_variant[c + 1] * dc.RB + PG_REC_EXP);
+    const uint16_t* ls = (const uint16_t*)(rec + PG_REC_LOCAL_SLOT);
+    const uint32_t a0 = dc.allele_off[v], A = dc.allele_off[v + 1] - a0;
+    const uint32_t pn = dc.pair_n, NP = (pn * (pn + 1) / 2 + 1u) & ~1u;
+    const unsigned char* vp = dc.vpair + (size_t)v * (NP * 12u);
+    for (uint32_t la = 0; la < nl; ++la)
+        for (uint32_t lb = la; lb < nl; ++lb) {
+            const uint32_t sa = ls[la], sb = ls[lb];
+            const uint64_t idx = dc.geno_off[v] + (uint64_t)sa * A - (uint64_t)sa * (sa - 1) / 2 + (sb - sa);
+            const uint32_t pi = tri_n(la, lb, pn);
+            const double pm = fb ? 0.5 : ((const double*)vp)[pi];
+            const int pe = fb ? 1 : ((const int*)(vp + (size_t)NP * 8u))[pi];
+            store_bin(dc.lik, dc.lik_exp, idx, acc[tri_local(la, lb)] * scale, pm, pe, xexp);
+        }
+}
+
+__global__ __launch_bounds__(256) void k_bins_wide(const DevContig* __restrict__ contigs) {
+    __shared__ double s_bins[4][PG_AMAX * (PG_AMAX + 1) / 2];
+    const DevContig& dc = contigs[blockIdx.y];
+    const uint32_t C = *dc.n_cols;
+    if (!bins_x(dc, C) || !dc.wide_idx) return;   // (no object of this chain's index has more than PG_AMAX alleles)
+    const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
+    const uint32_t cbase = (blockIdx.x * 4u + wave) * 64u;
+    if (cbase >= C) return;
+    // the wave's 64 columns: which of them are wide (rare), then one after the other by the whole wave
+    bool wide = false;
+    uint32_t aux = 0;
+    if (cbase + lane < C) {
+        const unsigned char* rec = dc.vrec + (size_t)dc.col_variant[cbase + lane] * dc.RB;
+        wide = (rec[PG_REC_FLAGS] & PG_REC_FLAG_WIDE) != 0;
+        aux = *(const uint32_t*)(rec + PG_REC_AUX);
+    }
+    unsigned long long todo = __ballot(wide);
+    const size_t colsz = (size_t)dc.HP * dc.HP;
+    while (todo) {
+        const int i = __builtin_ctzll(todo);
+        todo &= todo - 1ull;
+        const uint32_t c = cbase + (uint32_t)i;
+        const uint32_t ax = (uint32_t)__builtin_amdgcn_readlane((int)aux, i);
+        const double* mine = (const double*)(dc.aux + (size_t)ax * 16u);   // what this column's phase-2 role stored
+        const double* stored = dc.fwd + (size_t)c * colsz;                 // its partner, from phase 1
+        // c >= mid: the forward role ran phase 2 (alpha' = its column, beta' = the stored one); below: the backward role
+        if (c >= C / 2) post_ab(dc, C, c, mine, stored, lane, s_bins[wave]);
+        else post_ab(dc, C, c, stored, mine, lane, s_bins[wave]);
+        wave_sync_lds();
     }
 }
 
@@ -5209,6 +5378,8 @@ void pgk_launch_bins(const DevContig* d_contigs, uint32_t n_contigs, uint32_t ma
     dim3 grid256((max_v + 255) / 256, n_contigs);
     if (which & 2u) hipLaunchKernelGGL(k_bins_lean2, grid256, dim3(256), 0, s, d_contigs);  // (each kernel skips the other's columns)
     if (which & 4u) hipLaunchKernelGGL(k_bins_thin, grid256, dim3(256), 0, s, d_contigs);
+    if (which & 8u) hipLaunchKernelGGL(k_bins_x, grid256, dim3(256), 0, s, d_contigs);      // bit 3: chains on k_sweep_small16x<2>
+    if (which & 16u) hipLaunchKernelGGL(k_bins_wide, grid256, dim3(256), 0, s, d_contigs);  // bit 4: ... with objects of more than PG_AMAX alleles
 }
 void pgk_launch_sweep(const DevContig* d_contigs, uint32_t n_contigs, uint32_t hp_mask, int phase, hipStream_t s) {
     if (phase == 1) launch_sweep<1>(d_contigs, n_contigs, hp_mask, 0, s);
@@ -5225,6 +5396,14 @@ void pgk_launch_sweep_small(const DevContig* d_contigs, const uint32_t* d_ids, u
     if (phase == 1) hipLaunchKernelGGL(k_sweep_small16<1>, grid, dim3(64), 0, s, d_contigs, d_ids, n_ids, chunk, d_dump);
     else if (phase == 2) hipLaunchKernelGGL(k_sweep_small16<2>, grid, dim3(64), 0, s, d_contigs, d_ids, n_ids, chunk, d_dump);
     else hipLaunchKernelGGL(k_sweep_small16<3>, grid, dim3(64), 0, s, d_contigs, d_ids, n_ids, chunk, d_dump);
+}
+// ... and of the H = 16 chains with multiallelic objects (DevContig::smallx): k_sweep_small16x
+void pgk_launch_sweep_smallx(const DevContig* d_contigs, const uint32_t* d_ids, uint32_t n_ids, int phase, uint32_t chunk, double* d_dump, hipStream_t s) {
+    if (n_ids == 0) return;
+    const dim3 grid((n_ids + 3u) / 4u, 2);
+    if (phase == 1) hipLaunchKernelGGL(k_sweep_small16x<1>, grid, dim3(64), 0, s, d_contigs, d_ids, n_ids, chunk, d_dump);
+    else if (phase == 2) hipLaunchKernelGGL(k_sweep_small16x<2>, grid, dim3(64), 0, s, d_contigs, d_ids, n_ids, chunk, d_dump);
+    else hipLaunchKernelGGL(k_sweep_small16x<3>, grid, dim3(64), 0, s, d_contigs, d_ids, n_ids, chunk, d_dump);
 }
 void pgk_launch_post(const DevContig* d_contigs, uint32_t n_contigs, uint32_t chunk_cols, uint32_t chunk, hipStream_t s) {
     static bool attr_done[PG_MAX_DEVICES];

@@ -41,6 +41,7 @@ void pgk_launch_sweep(const DevContig*, uint32_t, uint32_t, int, hipStream_t);
 void pgk_launch_sweep_chunk(const DevContig*, uint32_t, uint32_t, uint32_t, hipStream_t);
 void pgk_launch_post(const DevContig*, uint32_t, uint32_t, uint32_t, hipStream_t);
 void pgk_launch_sweep_small(const DevContig*, const uint32_t*, uint32_t, int, uint32_t, double*, hipStream_t);
+void pgk_launch_sweep_smallx(const DevContig*, const uint32_t*, uint32_t, int, uint32_t, double*, hipStream_t);
 void pgk_launch_emission_single(const DevContig*, DevTable, uint32_t, double*, int*, hipStream_t);
 void pgk_launch_transition_single(double, uint32_t, int, double*, hipStream_t);
 uint32_t pgk_threads_for_hp(uint32_t);
@@ -215,6 +216,10 @@ struct IndexHost {   // one index contig
     bool cls4 = false;  // HP = 16 / 32, H = HP, every object biallelic, fused job: class sums instead of per-thread partials (DevContig::cls4)
     bool leanx = false; // HP = 128 / 64 and every object has at most PG_AMAX alleles (not `lean`): the store-only phases run on k_sweep_leanx
     bool small = false; // every object biallelic and H = HP = 16: the store-only phases run on k_sweep_small16
+    bool smallx = false; // H = HP = 16 with multiallelic objects (the 15 + 1 sampled paths): k_sweep_small16x (pg_small16x.h)
+    std::vector<uint32_t> auxidx;    // [V] aux slot offset / 16 of every variant with more than two alleles (smallx), PG_WIDE_NONE otherwise
+    uint64_t aux_bytes = 0;
+    size_t o_auxidx = 0;
     uint32_t prep_fast = 0;  // 1: every object has exactly two alleles and <= 32 k-mers, H <= 64: k_prep_bi; 2: at least half of them (k_prep the rest)
     uint32_t sumK = 0, sumA = 0;
     uint64_t n_lik = 0, wide_bytes = 0;
@@ -363,6 +368,9 @@ struct pg_job {
     size_t zero_bytes = 0;
     uint32_t* d_small = nullptr;  // [n_small] chain ids of the H = 16 chains
     uint32_t n_small = 0;
+    uint32_t* d_smallx = nullptr; // [n_smallx] ... of those with multiallelic objects (k_sweep_small16x), behind d_small's
+    uint32_t n_smallx = 0;
+    bool smallx_phase2 = false;
     bool small_phase2 = false;    // some of them (fused jobs, class sums: DevContig::small == 2) also run their phase 2 on k_sweep_small16
     double* d_dump = nullptr;
     uint32_t* d_ncols = nullptr;  // [n_chains]
@@ -554,6 +562,7 @@ int upload_inputs(pg_job* job, const pg_contig_batch* batches, const std::vector
             UP(x.o_pa, b.path_allele, (size_t)x.V * x.H * 2, bi);
             UP(x.o_goff, x.goff.data(), ((size_t)x.V + 1) * 8, bi);
             if (x.wide_bytes) UP(x.o_widx, x.widx.data(), (size_t)x.V * 4, bi);
+            if (x.aux_bytes) UP(x.o_auxidx, x.auxidx.data(), (size_t)x.V * 4, bi);
         }
         UP(job->o_tab_m, job->tab_m.data(), job->tab_m.size() * sizeof(double), bi);
         UP(job->o_tab_e, job->tab_e.data(), job->tab_e.size() * sizeof(int32_t), bi);
@@ -799,6 +808,25 @@ int job_build(int device, uint32_t n_index, const pg_contig_batch* batches, cons
         }
         x.lean = lean_ok && x.HP == 64 && x.H == 64 && maxA == 2 && x.V > 0;
         x.small = lean_ok && x.HP == 16 && x.H == 16 && maxA == 2 && x.V > 0;   // (and enough of them: below)
+        // the same shape with multiallelic objects — 15 sampled paths + the reference path, bubbles keeping every allele those
+        // paths carry (src/commands.cpp:799-803, src/multiallelicuniquekmers.cpp:195-232): k_sweep_small16x, any allele count
+        // per object (narrow columns from the record's table, wide ones from the side table: per COLUMN)
+        x.smallx = lean_ok && x.HP == 16 && x.H == 16 && maxA > 2 && x.V > 0;
+        if (x.smallx) {
+            // aux slots: a variant with 3 .. PG_AMAX alleles may leave phase 2 as sixteen lanes' accumulators (HP x 48 bytes),
+            // one with more as a whole column (a wide column) — or as accumulators, if its paths carry at most PG_AMAX of them
+            x.auxidx.assign(x.V, PG_WIDE_NONE);
+            uint64_t ao = 0;
+            for (uint32_t v = 0; v < x.V; ++v) {
+                const uint64_t A = b.allele_off[v + 1] - b.allele_off[v];
+                if (A <= 2) continue;
+                const uint64_t small_slot = (uint64_t)x.HP * 48u, col_slot = (uint64_t)x.HP * x.HP * 8u;
+                x.auxidx[v] = (uint32_t)(ao / 16);
+                ao += A > PG_AMAX ? (col_slot > small_slot ? col_slot : small_slot) : small_slot;
+            }
+            if (ao / 16 >= 0xFFFFFFF0ull) x.smallx = false;   // (the general kernel then)
+            else x.aux_bytes = ao;
+        }
         {
             // PG_KERNELS=nocls4: per-thread partials + k_bins (cross-check)
             // (the class sums are formed by a half-chain's ONE compute wave: 16 paths, and 32 when the kernel is built with 16 rows per lane)
@@ -822,10 +850,15 @@ int job_build(int device, uint32_t n_index, const pg_contig_batch* batches, cons
         // k_sweep_small16 packs four H = 16 half-chains into a wave: a throughput kernel.  A single chain is faster on the
         // general kernel (four states per lane instead of sixteen: 375 vs 470 ns per column); PG_KERNELS=small / nosmall forces.
         size_t n_small_chains = 0;
-        for (const ChainSpec& sp : specs) n_small_chains += job->index[sp.index].small ? 1 : 0;
+        for (const ChainSpec& sp : specs) n_small_chains += (job->index[sp.index].small || job->index[sp.index].smallx) ? 1 : 0;
         const bool use = kc.small >= 0 ? kc.small == 1 : n_small_chains >= 512;
-        if (!use) for (auto& x : job->index) x.small = false;
+        if (!use) for (auto& x : job->index) { x.small = false; x.smallx = false; x.aux_bytes = 0; }
     }
+    // A WIDE column (more than PG_AMAX alleles on the selected paths) costs that column, not the job, on the kernels that
+    // take it inside a fused phase 2 — k_sweep_small16x (its column goes to the aux slot, k_bins_wide forms the bins); a
+    // chain of any other kernel with such an object still makes the job chunked (k_post is their only wide path)
+    wide_candidates = false;
+    for (const IndexHost& x : job->index) if (x.wide_bytes && !(x.smallx && !kc.nosmall2)) wide_candidates = true;
 
     // ---- sweep mode ------------------------------------------------------------------------
     {
@@ -845,7 +878,8 @@ int job_build(int device, uint32_t n_index, const pg_contig_batch* batches, cons
         // k_sweep_leanx is a latency kernel (lone chains: 1470 vs 2645 ns per column at 128 paths); phase 1 of a fused job
         // with hundreds of chains is bound by HBM writes, where the general kernel measured faster (7.8 vs 8.9 ms on 128 chains
         // of 128 paths).  PG_KERNELS=leanx forces it there too.
-        if (job->chunked) for (auto& x : job->index) x.cls4 = false;   // (chunked jobs form their posteriors in k_post)
+        if (job->chunked) for (auto& x : job->index) { x.cls4 = false; x.aux_bytes = 0; }   // (chunked jobs form their posteriors in k_post)
+        if (kc.nosmall2) for (auto& x : job->index) x.aux_bytes = 0;
         if (!job->chunked) {
             if (kc.leanx != 1) for (auto& x : job->index) x.leanx = false;
         }
@@ -872,7 +906,7 @@ int job_build(int device, uint32_t n_index, const pg_contig_batch* batches, cons
     job->chains.resize(n_chains);
     size_t off = 0;
     auto take = [&](size_t bytes, size_t al = 256) { off = align_up(off, al); size_t o = off; off += (bytes ? bytes : 8); return o; };
-    struct Plan { size_t frec, scratch, wide, vpair, xbuf, prof, fback, fscale, bscale, bsum, vrec, cvar, colrec, fwd, part, kept, apres,
+    struct Plan { size_t aux, frec, scratch, wide, vpair, xbuf, prof, fback, fscale, bscale, bsum, vrec, cvar, colrec, fwd, part, kept, apres,
                   vtq, vback, vbest, hap1, hap2; };
     std::vector<Plan> plan(n_chains);
     const size_t o_contigs = take(sizeof(DevContig) * n_chains);
@@ -914,6 +948,7 @@ int job_build(int device, uint32_t n_index, const pg_contig_batch* batches, cons
         x.o_pa = take((size_t)x.V * x.H * 2);
         x.o_goff = take(((size_t)x.V + 1) * 8);
         x.o_widx = take(x.wide_bytes ? (size_t)x.V * 4 : 0);
+        x.o_auxidx = take(x.aux_bytes ? (size_t)x.V * 4 : 0);
     }
     job->sample_lo = align_up(off);   // the per-sample arrays of all chains, one contiguous run (pg_job::sample_lo)
     for (uint32_t c = 0; c < n_chains; ++c) {
@@ -937,7 +972,12 @@ int job_build(int device, uint32_t n_index, const pg_contig_batch* batches, cons
         const bool geno = params->run_genotyping != 0;  // (a phasing-only job has no sweep: no columns, no partials)
         p.fwd = take(geno ? (size_t)x.V * (tri ? 2304u : (size_t)x.HP * x.HP) * sizeof(double) : 0);
         // fused mode: posterior partials; chunked mode: the chunk scratch instead (k_post writes lik directly)
-        p.part = take(job->chunked || !geno ? 0 : (size_t)x.V * x.part_slots * part_entries(x) * sizeof(double));
+        // (x chains of fused jobs: four class sums per column — plus the per-thread partials of ONE column, should the chain
+        //  be left with a single column and run its phase 2 on the general kernel)
+        const bool x2 = x.smallx && !job->chunked && !kc.nosmall2;
+        p.part = take(job->chunked || !geno ? 0 : (x2 ? (size_t)x.V * 32u + (size_t)x.part_slots * part_entries(x) * sizeof(double)
+                                                      : (size_t)x.V * x.part_slots * part_entries(x) * sizeof(double)));
+        p.aux = take(x2 && geno ? x.aux_bytes : 0);
         // Viterbi: transition probabilities and one 2-byte backpointer per state and column
         p.vtq = take(params->run_phasing ? (size_t)x.V * 8 * sizeof(double) : 0);
         p.vback = take(params->run_phasing ? (size_t)x.V * x.H * x.HP * sizeof(uint16_t) : 0);
@@ -946,7 +986,7 @@ int job_build(int device, uint32_t n_index, const pg_contig_batch* batches, cons
         p.wide = take(x.wide_bytes);
         p.vpair = take((size_t)x.V * pg_pair_bytes(x.pair_n));
         p.xbuf = take((x.HP >= 256 || (force_generic && x.HP >= 64)) ? (size_t)2 * x.HP * x.HP * sizeof(double) : 0);
-        p.frec = take((x.lean || x.small) ? (size_t)x.V * 64 : 0);
+        p.frec = take((x.lean || x.small) ? (size_t)x.V * 64 : (x.smallx ? (size_t)x.V * 320 : 0));
         if (x.lean) job->hp_mask |= 64u;
         if (x.leanx) job->hp_mask |= x.HP == 128 ? 512u : 1024u;
         p.fscale = take((size_t)x.V * sizeof(double));
@@ -1015,6 +1055,8 @@ int job_build(int device, uint32_t n_index, const pg_contig_batch* batches, cons
         d.wide = A + p.wide; d.wide_idx = x.wide_bytes ? (const uint32_t*)(A + x.o_widx) : nullptr;
         d.vpair = A + p.vpair; d.xbuf = (double*)(A + p.xbuf);
         d.frec = (double*)(A + p.frec); d.lean = x.lean ? 1u : 0u; d.small = x.small ? ((!job->chunked && x.cls4 && !kc.nosmall2) ? 2u : 1u) : 0u; d.leanx = x.leanx ? 1u : 0u; d.cls4 = x.cls4 ? 1u : 0u;
+        d.smallx = x.smallx ? ((!job->chunked && !kc.nosmall2) ? 2u : 1u) : 0u;
+        d.aux = A + p.aux; d.aux_idx = (d.smallx == 2u && x.aux_bytes) ? (const uint32_t*)(A + x.o_auxidx) : nullptr;
         d.live = (!job->chunked && x.HP == 32u && !kc.fullcols) ? std::min<uint32_t>(x.HP, (x.H + 3u) & ~3u) : x.HP;
         d.prep_fast = x.prep_fast;
         if (params->run_phasing) {
@@ -1027,17 +1069,30 @@ int job_build(int device, uint32_t n_index, const pg_contig_batch* batches, cons
         if (d.tri == 2u) job->hp_mask |= 256u;
         // (k_bins_thin: what bins_thin() in pg_kernels.hip says — at most 64 partial entries per column, fused job)
         job->bins_which |= (d.tri == 2u || d.cls4) ? 2u : ((d.T <= 64u && d.HP <= 32u && !job->chunked) ? 4u : 1u);
+        if (d.smallx == 2u) job->bins_which |= 8u | (x.wide_bytes ? 16u : 0u);   // k_bins_x, k_bins_wide (a chain left with one column: k_bins_thin, above)
         ch.d = d;
     }
     {
-        std::vector<uint32_t> small_ids;
-        for (uint32_t c = 0; c < n_chains; ++c) if (hd[c].small) { small_ids.push_back(c); if (hd[c].small == 2u) job->small_phase2 = true; }
+        // chain ids of the four-half-chains-per-wave kernels: the all-biallelic chains first, then the x chains; each list in the
+        // order of the index contigs (stable), so that the four rows of a wave are — in a cohort — samples of ONE contig: the same
+        // columns are multiallelic / wide in all four (the wide branch of k_sweep_small16x is wave-uniform)
+        std::vector<uint32_t> small_ids, x_ids;
+        for (uint32_t c = 0; c < n_chains; ++c) {
+            if (hd[c].small) { small_ids.push_back(c); if (hd[c].small == 2u) job->small_phase2 = true; }
+            if (hd[c].smallx) { x_ids.push_back(c); if (hd[c].smallx == 2u) job->smallx_phase2 = true; }
+        }
+        auto by_index = [&](uint32_t a, uint32_t b) { return job->chains[a].index < job->chains[b].index; };
+        std::stable_sort(small_ids.begin(), small_ids.end(), by_index);
+        std::stable_sort(x_ids.begin(), x_ids.end(), by_index);
         job->n_small = (uint32_t)small_ids.size();
+        job->n_smallx = (uint32_t)x_ids.size();
         job->d_small = (uint32_t*)(A + o_small);
+        job->d_smallx = job->d_small + job->n_small;
         job->d_dump = (double*)(A + o_dump);
-        if (job->n_small && (he = hipMemcpyAsync(job->d_small, small_ids.data(), sizeof(uint32_t) * job->n_small, hipMemcpyHostToDevice, job->stream)) != hipSuccess)
+        small_ids.insert(small_ids.end(), x_ids.begin(), x_ids.end());
+        if (!small_ids.empty() && (he = hipMemcpyAsync(job->d_small, small_ids.data(), sizeof(uint32_t) * small_ids.size(), hipMemcpyHostToDevice, job->stream)) != hipSuccess)
             return fail(PG_ERR_DEVICE, "hipMemcpy small ids", he);
-        if (job->n_small && (he = hipStreamSynchronize(job->stream)) != hipSuccess) return fail(PG_ERR_DEVICE, "hipMemcpy small ids", he);
+        if (!small_ids.empty() && (he = hipStreamSynchronize(job->stream)) != hipSuccess) return fail(PG_ERR_DEVICE, "hipMemcpy small ids", he);
     }
     job->h_contigs = hd;
     job->cur_samples = A + job->sample_lo;
@@ -1292,11 +1347,13 @@ extern "C" int pg_job_run(pg_job* job, void* stream_, char* err, size_t errlen) 
         HIP_TRY(hipEventRecord(job->ev[3], s));
         pgk_launch_sweep(job->d_contigs, n, job->hp_mask, 1, s);
         pgk_launch_sweep_small(job->d_contigs, job->d_small, job->n_small, 1, 0, job->d_dump, s);
+        pgk_launch_sweep_smallx(job->d_contigs, job->d_smallx, job->n_smallx, 1, 0, job->d_dump, s);
         HIP_TRY(hipGetLastError());
         HIP_TRY(hipEventRecord(job->ev[4], s));
         if (!job->chunked) {
             pgk_launch_sweep(job->d_contigs, n, job->hp_mask, 2, s);
             if (job->small_phase2) pgk_launch_sweep_small(job->d_contigs, job->d_small, job->n_small, 2, 0, job->d_dump, s);
+            if (job->smallx_phase2) pgk_launch_sweep_smallx(job->d_contigs, job->d_smallx, job->n_smallx, 2, 0, job->d_dump, s);
             HIP_TRY(hipGetLastError());
             HIP_TRY(hipEventRecord(job->ev[5], s));
             pgk_launch_bins(job->d_contigs, n, job->max_v, job->bins_which, s);
@@ -1311,6 +1368,7 @@ extern "C" int pg_job_run(pg_job* job, void* stream_, char* err, size_t errlen) 
                 if (i >= 2) HIP_TRY(hipStreamWaitEvent(s, job->ev_post[b], 0));
                 pgk_launch_sweep_chunk(job->d_contigs, n, job->hp_mask, i, s);
                 pgk_launch_sweep_small(job->d_contigs, job->d_small, job->n_small, 3, i, job->d_dump, s);
+                pgk_launch_sweep_smallx(job->d_contigs, job->d_smallx, job->n_smallx, 3, i, job->d_dump, s);
                 HIP_TRY(hipGetLastError());
                 HIP_TRY(hipEventRecord(job->ev_sweep[b], s));
                 HIP_TRY(hipStreamWaitEvent(s2, job->ev_sweep[b], 0));
@@ -1370,6 +1428,10 @@ extern "C" int pg_job_run(pg_job* job, void* stream_, char* err, size_t errlen) 
         }
         if (errs[i] & PG_DEVERR_TOO_MANY_ALLELES) {
             set_err(err, errlen, "chain %u: a variant has more than %d alleles (device limit)", i, PG_MAX_ALLELES_PER_VARIANT);
+            return PG_ERR_UNSUPPORTED;
+        }
+        if (errs[i] & PG_DEVERR_WIDE_FUSED) {
+            set_err(err, errlen, "chain %u: its only column carries more than %d alleles on the selected paths, which a fused job cannot genotype (PG_SWEEP_MODE=chunked)", i, PG_AMAX);
             return PG_ERR_UNSUPPORTED;
         }
         if (errs[i] & PG_DEVERR_TOO_MANY_LOCAL) {

@@ -325,7 +325,7 @@ def synthetic_panel(n_variants: int, n_paths: int, kmers_per_variant: int = 20, 
                     seed: int = 12345, multiallelic_frac: float = 0.0,
                     undefined_frac: float = 0.01, zero_kmer_frac: float = 0.01,
                     peak: int = PEAK, max_alleles: int = 5, local_alts: int = 4,
-                    wide_frac: float = 0.0, wide_alleles: tuple = (6, 12)) -> ContigBatch:
+                    wide_frac: float = 0.0, wide_alleles: tuple = (6, 12), wide_at: Sequence[int] = ()) -> ContigBatch:
     """Deterministic synthetic contig of the shapes BASELINE.json names.
 
     Positions step by 50+U[0,1200) bp; allele frequency f~U(.05,.95); each path carries ALT
@@ -336,7 +336,8 @@ def synthetic_panel(n_variants: int, n_paths: int, kmers_per_variant: int = 20, 
     and 0 (90%) / 1 (10%) for cn=0; local coverage = peak-3+U{0..6}.
     `wide_frac` of the objects (drawn from a generator of their own: the other draws are the same with and without
     them) get A ~ U{wide_alleles[0]..wide_alleles[1]} alleles with every path's ALT uniform among all of them — bubbles
-    whose columns carry more than five distinct alleles on the selected paths (the device's "wide" columns).
+    whose columns carry more than five distinct alleles on the selected paths (the device's "wide" columns); `wide_at`
+    names variants that are such objects whatever the draw says.
     """
     rng = np.random.Generator(np.random.PCG64(seed))
     V, H, K = int(n_variants), int(n_paths), int(kmers_per_variant)
@@ -347,9 +348,10 @@ def synthetic_panel(n_variants: int, n_paths: int, kmers_per_variant: int = 20, 
     if multiallelic_frac > 0:
         multi = rng.random(V) < multiallelic_frac
         n_all[multi] = rng.integers(3, max(6, max_alleles + 1), size=int(multi.sum()))
-    if wide_frac > 0:
+    if wide_frac > 0 or len(wide_at):
         rng_w = np.random.Generator(np.random.PCG64(int(seed) * 7919 + 17))
         wide = rng_w.random(V) < wide_frac
+        wide[[int(i) for i in wide_at if 0 <= int(i) < V]] = True   # (tests: wide objects at chosen places — first, last, the meeting point)
         n_all[wide] = rng_w.integers(int(wide_alleles[0]), int(wide_alleles[1]) + 1, size=int(wide.sum()))
     f = rng.uniform(0.05, 0.95, size=V)
     carries_alt = rng.random((V, H)) < f[:, None]
