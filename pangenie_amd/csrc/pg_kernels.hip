@@ -292,7 +292,13 @@ DEVI void prep_unit(const DevContig& dc, const DevTable& tab, uint32_t unit) {
     __shared__ uint16_t s_aid[4][64];   // the variant's allele ids / flags (objects with <= 64 alleles: every real one)
     __shared__ uint8_t s_afl[4][64];
     const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const uint32_t v = unit * 4 + wave;
+    uint32_t v = unit * 4 + wave;
+    // mixed chains (DevContig::prep_fast == 2): this kernel walks the LIST of the objects that are neither k_prep_bi's nor
+    // k_prep_m4's — a grid over all variants whose waves mostly leave at once cost more than the objects it is here for
+    if (dc.prep_w) {
+        if (v >= dc.n_prep_w) return;
+        v = dc.prep_w[v];
+    }
     if (v >= dc.V) return;  // whole wave leaves; the kernel only uses wave-level sync
 
     const uint32_t a0 = dc.allele_off[v], A = dc.allele_off[v + 1] - a0;
@@ -767,6 +773,190 @@ __global__ __launch_bounds__(256) void k_prep_bi(const DevContig* __restrict__ c
 // ------------------------------------------------------------------------------------------
 //  unit-level entry: full A x A emission products of one variant as (mantissa, exponent)
 // ------------------------------------------------------------------------------------------
+// ------------------------------------------------------------------------------------------
+//  k_prep_m4 : FOUR multiallelic objects per wave (a DPP row of 16 lanes each) — the objects with 3 .. PG_AMAX alleles and at
+//  most 64 k-mers of mixed chains with at most 64 paths (DevContig::prep_fast == 2), taken from the chain's list prep_m4
+//  (HPRC-style panels and the 15 + 1 sampled paths have a fifth of their objects such: one wave per object — k_prep — spent
+//  ~1100 instructions on each, 19 of the 31 ms of `cohort_h16m`'s preparation).  Lane l of the row takes paths l, 16 + l,
+//  32 + l, 48 + l, the k-mers l, 16 + l, ... (their three copy-number factors go to LDS once) and the allele PAIR l (at most
+//  15): its product over the k-mers is a sequential loop in the lane — no cross-lane fold.  Same factors, rules (all_zeros
+//  over every pair of the object, the largest exponent over the present pairs) and record layout as prep_unit; only the
+//  order of the multiplications differs.  reference src/emissionprobabilitycomputer.cpp:9-53, src/columnindexer.cpp:24-31
+// ------------------------------------------------------------------------------------------
+DEVI uint32_t row16_ballot(bool p, uint32_t grp) { return (uint32_t)((__ballot(p) >> (16u * grp)) & 0xFFFFull); }
+DEVI void prep_m4_unit(const DevContig& dc, const DevTable& tab, uint32_t unit) {
+    __shared__ double s_m[4][4][64 * 3];
+    __shared__ int s_e[4][4][64 * 3];
+    __shared__ unsigned char s_rec[4][4][448] __attribute__((aligned(16)));   // [wave][object of the wave][RB <= 448: H <= 64]
+    const uint32_t wv = threadIdx.x >> 6, lane = threadIdx.x & 63u, grp = lane >> 4, l = lane & 15u;
+    const uint32_t base = unit * 16u + wv * 4u;
+    if (base >= dc.n_prep_m4) return;   // the whole wave is beyond the list
+    bool live = base + grp < dc.n_prep_m4;   // (a row beyond the list idles along: the ballots below are wave-wide)
+    const uint32_t v = dc.prep_m4[live ? base + grp : dc.n_prep_m4 - 1u];
+    const uint32_t H = dc.H, HP = dc.HP;
+    const uint32_t a0 = dc.allele_off[v], A = dc.allele_off[v + 1] - a0;   // 3 .. PG_AMAX
+    uint32_t ids[PG_AMAX];
+    bool und[PG_AMAX];
+#pragma unroll
+    for (int q = 0; q < PG_AMAX; ++q) {
+        const bool in = (uint32_t)q < A;
+        ids[q] = in ? (uint32_t)dc.allele_id[a0 + q] : 0xFFFFFFFFu;
+        und[q] = in && (dc.allele_flags[a0 + q] & 1);
+    }
+    // ---- ColumnIndexer rule and the allele slot of every selected path
+    int slot[4];
+    uint32_t mine = 0;   // slots this lane's paths carry
+    bool bad = false, nonref = false;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const uint32_t p = 16u * (uint32_t)i + l;
+        const bool inb = live && p < H;
+        const uint32_t a = inb ? (uint32_t)dc.path_allele[(size_t)v * H + p] : 0u;
+        int sl = -1;
+#pragma unroll
+        for (int q = 0; q < PG_AMAX; ++q) if (ids[q] == a) sl = q;   // (the last matching slot, as slot_of)
+        slot[i] = sl;
+        bad = bad || (inb && sl < 0);
+        if (inb && sl >= 0) {
+            mine |= 1u << sl;
+            bool u = false;
+#pragma unroll
+            for (int q = 0; q < PG_AMAX; ++q) u = u || (sl == q && und[q]);
+            nonref = nonref || (a != 0u && !u);
+        }
+    }
+    const bool any_bad = row16_ballot(bad, grp) != 0u, kept = row16_ballot(nonref, grp) != 0u;
+    uint32_t pres = 0;
+#pragma unroll
+    for (int q = 0; q < PG_AMAX; ++q) pres |= (row16_ballot((mine >> q) & 1u, grp) != 0u ? 1u : 0u) << q;
+    if (!live) return;
+    if (any_bad) {
+        if (l == 0) { atomicOr(dc.err, PG_DEVERR_ALLELE_NOT_FOUND); dc.kept[v] = 0; }
+        return;
+    }
+    if (l < A) dc.allele_present[a0 + l] = (pres >> l) & 1u;
+    if (l == 0) dc.kept[v] = kept ? 1 : 0;
+    if (!kept) return;
+    const uint32_t n_local = __popc(pres);
+    auto local_of = [&](uint32_t sl) { return (uint32_t)__popc(pres & ((1u << sl) - 1u)); };
+    unsigned char* rec = s_rec[wv][grp];
+    unsigned long long ones = 0;   // bit p: selected path p carries LOCAL allele 1
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const uint32_t p = 16u * (uint32_t)i + l;
+        const uint32_t loc = (p < H && slot[i] >= 0) ? local_of((uint32_t)slot[i]) : (uint32_t)PG_PHANTOM;
+        if (p < HP) rec[PG_REC_ALLELES + p] = (unsigned char)loc;
+        ones |= (unsigned long long)row16_ballot(loc == 1u, grp) << (16u * (uint32_t)i);
+    }
+    for (uint32_t pad = PG_REC_ALLELES + HP + l; pad < dc.RB; pad += 16u) rec[pad] = 0;   // (the record's tail up to RB)
+    // ---- the copy-number factors of the object's k-mers -> LDS (lane l: k-mers l, 16 + l, 32 + l, 48 + l)
+    const uint32_t k0 = dc.kmer_off[v], K = dc.kmer_off[v + 1] - k0, cov = dc.cov[v];
+    double* lm = s_m[wv][grp];
+    int* le = s_e[wv][grp];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const uint32_t k = 16u * (uint32_t)i + l;
+        if (k < K) {
+            double m[3]; int e[3];
+            cn_lookup(tab, cov, dc.kmer_count[k0 + k], m, e);
+#pragma unroll
+            for (int c = 0; c < 3; ++c) { lm[k * 3 + c] = m[c]; le[k * 3 + c] = e[c]; }
+        }
+    }
+    if (l < 4u) ((double*)rec)[l] = 0.0;  // transition constants are filled by k_records
+    for (uint32_t t = l; t < (uint32_t)PG_ETAB; t += 16u) ((double*)(rec + PG_REC_E))[t] = 0.0;
+    wave_sync_lds();
+    // ---- the product of allele pair l over the k-mers
+    const uint32_t P = A * (A + 1u) / 2u;
+    const bool active = l < P;
+    uint32_t s1 = 0, s2 = 0;
+    if (active) decode_pair(l, A, s1, s2);
+    uint32_t off1 = 0, mask1 = 0, off2 = 0, mask2 = 0;
+    bool u1 = false, u2 = false;
+    if (active) {
+        off1 = dc.allele_koff[a0 + s1]; mask1 = dc.allele_kmask[a0 + s1];
+        off2 = dc.allele_koff[a0 + s2]; mask2 = dc.allele_kmask[a0 + s2];
+        u1 = dc.allele_flags[a0 + s1] & 1; u2 = dc.allele_flags[a0 + s2] & 1;
+    }
+    double pm = 1.0;
+    int pe = 0;
+    if (active) {
+        for (uint32_t k = 0; k < K; ++k) {
+            const uint32_t c = kmer_on(off1, mask1, k) + kmer_on(off2, mask2, k);
+            double fm; int fe;
+            if (u1 && u2) mix3(lm + k * 3, le + k * 3, 1.0 / 3.0, fm, fe);
+            else if (u1 || u2) {
+                const uint32_t c2 = c + 1 > 2 ? 2 : c + 1;  // reference asserts c < 2 here
+                mix2(lm[k * 3 + c], le[k * 3 + c], lm[k * 3 + c2], le[k * 3 + c2], 0.5, fm, fe);
+            } else { fm = lm[k * 3 + c]; fe = le[k * 3 + c]; }
+            pm *= fm; pe += fe;
+        }
+        double mm; int ee;
+        split(pm, mm, ee);
+        pm = mm; pe += ee;
+        if (pe < PG_LD_MIN_EXP) { pm = 0.0; pe = 0; }  // underflows to 0 in the reference too
+    }
+    const bool all_zeros = row16_ballot(active && pm > 0.0, grp) == 0u;  // over ALL pairs of the object (emissionprobabilitycomputer.cpp:24)
+    const bool both = active && ((pres >> s1) & 1u) && ((pres >> s2) & 1u);
+    // X = the largest exponent among the present pairs with a non-zero product (a max over the row's 16 lanes)
+    int X = (both && pm > 0.0) ? pe : -(1 << 30);
+    {
+        int o;
+        o = __builtin_amdgcn_update_dpp(X, X, 0x128, 0xF, 0xF, false); X = o > X ? o : X;   // row_ror:8
+        o = __builtin_amdgcn_update_dpp(X, X, 0x124, 0xF, 0xF, false); X = o > X ? o : X;   // row_ror:4
+        o = __builtin_amdgcn_update_dpp(X, X, 0x122, 0xF, 0xF, false); X = o > X ? o : X;   // row_ror:2
+        o = __builtin_amdgcn_update_dpp(X, X, 0x121, 0xF, 0xF, false); X = o > X ? o : X;   // row_ror:1
+    }
+    if (X == -(1 << 30) || all_zeros) X = 0;
+    if (both) {
+        const uint32_t la = local_of(s1), lb = local_of(s2);   // s1 <= s2  =>  la <= lb
+        double val;
+        if (all_zeros) val = 1.0;                           // emissionprobabilitycomputer.cpp:31-34
+        else val = (pm > 0.0) ? ldexp(pm, pe - X) : pm;     // 0 (or NaN) stays
+        ((double*)(rec + PG_REC_E))[la * PG_ESTRIDE + lb] = val;
+        ((double*)(rec + PG_REC_E))[lb * PG_ESTRIDE + la] = val;
+        // the unscaled product as (mantissa, exponent): what a finished posterior bin is multiplied with
+        const uint32_t pn = dc.pair_n, NP = (pn * (pn + 1) / 2 + 1u) & ~1u;
+        unsigned char* vp = dc.vpair + (size_t)v * (NP * 12u);
+        const uint32_t pi = tri_n(la, lb, pn);
+        ((double*)vp)[pi] = all_zeros ? 0.5 : pm;
+        ((int*)(vp + (size_t)NP * 8u))[pi] = all_zeros ? 1 : pe;
+    }
+    if (l < 8u) {   // local allele l -> allele slot: the l-th present slot
+        uint32_t sl = 0, seen = 0;
+#pragma unroll
+        for (int q = 0; q < PG_AMAX; ++q) { if (((pres >> q) & 1u) && seen == l) sl = (uint32_t)q; seen += (pres >> q) & 1u; }
+        if (l < 6u) ((uint16_t*)(rec + PG_REC_LOCAL_SLOT))[l] = (uint16_t)(l < n_local ? sl : 0u);
+    }
+    if (l == 8u) {
+        *(uint32_t*)(rec + PG_REC_VARIANT) = v;
+        *(int32_t*)(rec + PG_REC_EXP) = X;
+        rec[PG_REC_NLOCAL] = (unsigned char)n_local;
+        rec[PG_REC_FLAGS] = all_zeros ? PG_REC_FLAG_ALLZERO : 0;
+        rec[PG_REC_FLAGS + 1] = 0; rec[PG_REC_FLAGS + 2] = 0;
+        *(uint32_t*)(rec + PG_REC_WIDE_IDX) = PG_WIDE_NONE;
+        *(uint32_t*)(rec + PG_REC_AUX) = dc.aux_idx ? dc.aux_idx[v] : PG_WIDE_NONE;
+    }
+    if (l == 9u) {
+        ((unsigned long long*)(rec + PG_REC_BITS1))[0] = ones;
+        ((unsigned long long*)(rec + PG_REC_BITS1))[1] = 0ull;
+    }
+    wave_sync_lds();
+    {   // copy-out: the object's 16 lanes move RB / 16 pieces of 16 bytes, consecutive lanes consecutive pieces
+        typedef double f64x2 __attribute__((ext_vector_type(2)));
+        const f64x2* src = (const f64x2*)rec;
+        f64x2* dst = (f64x2*)(dc.vrec + (size_t)v * dc.RB);
+        for (uint32_t p = l; p < dc.RB / 16u; p += 16u) dst[p] = src[p];
+    }
+    wave_sync_lds();   // (the slots are rewritten by the wave's next unit)
+}
+__global__ __launch_bounds__(256) void k_prep_m4(const DevContig* __restrict__ contigs, DevTable tab) {
+    const DevContig& dc = contigs[blockIdx.y];
+    if (!dc.prep_m4) return;
+#pragma unroll 1
+    for (uint32_t r = 0; r < (uint32_t)PG_VREP; ++r) prep_m4_unit(dc, tab, blockIdx.x * (uint32_t)PG_VREP + r);
+}
+
 __global__ __launch_bounds__(64) void k_emission_single(const DevContig* __restrict__ contigs, DevTable tab,
                                                         uint32_t v, double* out_m, int* out_e) {
     __shared__ double s_m[64 * 3];
@@ -5357,11 +5547,14 @@ static void launch_sweep(const DevContig* d_contigs, uint32_t n_contigs, uint32_
 }
 extern "C" {
 
-void pgk_launch_prep(const DevContig* d_contigs, uint32_t n_contigs, uint32_t max_v, DevTable tab, hipStream_t s) {
-    dim3 grid((max_v + 4 * PG_VREP - 1) / (4 * PG_VREP), n_contigs);
-    hipLaunchKernelGGL(k_prep, grid, dim3(256), 0, s, d_contigs, tab);
+// max_w = the longest walk of k_prep over the chains (a chain's list of objects, or all its variants), max_m4 = the longest list of k_prep_m4
+void pgk_launch_prep(const DevContig* d_contigs, uint32_t n_contigs, uint32_t max_v, uint32_t max_w, uint32_t max_m4, DevTable tab, hipStream_t s) {
+    dim3 grid((max_w + 4 * PG_VREP - 1) / (4 * PG_VREP), n_contigs);
+    if (max_w) hipLaunchKernelGGL(k_prep, grid, dim3(256), 0, s, d_contigs, tab);
     dim3 grid16((max_v + 16 * PG_VREP - 1) / (16 * PG_VREP), n_contigs);
     hipLaunchKernelGGL(k_prep_bi, grid16, dim3(256), 0, s, d_contigs, tab);  // (chains of biallelic objects; each kernel skips the other's)
+    dim3 gridm((max_m4 + 16 * PG_VREP - 1) / (16 * PG_VREP), n_contigs);
+    if (max_m4) hipLaunchKernelGGL(k_prep_m4, gridm, dim3(256), 0, s, d_contigs, tab);
 }
 void pgk_launch_compact(const DevContig* d_contigs, uint32_t n_contigs, hipStream_t s) {
     hipLaunchKernelGGL(k_compact, dim3(n_contigs), dim3(1024), 0, s, d_contigs);

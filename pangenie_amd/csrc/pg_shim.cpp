@@ -33,7 +33,7 @@
 #include "pg_device.h"
 
 extern "C" {
-void pgk_launch_prep(const DevContig*, uint32_t, uint32_t, DevTable, hipStream_t);
+void pgk_launch_prep(const DevContig*, uint32_t, uint32_t, uint32_t, uint32_t, DevTable, hipStream_t);
 void pgk_launch_compact(const DevContig*, uint32_t, hipStream_t);
 void pgk_launch_records(const DevContig*, uint32_t, uint32_t, hipStream_t);
 void pgk_launch_bins(const DevContig*, uint32_t, uint32_t, uint32_t, hipStream_t);
@@ -217,6 +217,8 @@ struct IndexHost {   // one index contig
     bool leanx = false; // HP = 128 / 64 and every object has at most PG_AMAX alleles (not `lean`): the store-only phases run on k_sweep_leanx
     bool small = false; // every object biallelic and H = HP = 16: the store-only phases run on k_sweep_small16
     bool smallx = false; // H = HP = 16 with multiallelic objects (the 15 + 1 sampled paths): k_sweep_small16x (pg_small16x.h)
+    std::vector<uint32_t> list_m4, list_w;   // prep_fast == 2: the objects of k_prep_m4 (3 .. PG_AMAX alleles, <= 64 k-mers) / of k_prep (neither that nor k_prep_bi's)
+    size_t o_list_m4 = 0, o_list_w = 0;
     std::vector<uint32_t> auxidx;    // [V] aux slot offset / 16 of every variant with more than two alleles (smallx), PG_WIDE_NONE otherwise
     uint64_t aux_bytes = 0;
     size_t o_auxidx = 0;
@@ -383,6 +385,7 @@ struct pg_job {
     std::vector<int32_t> tab_e;
     DevTable tab;
     uint32_t hp_mask = 0, max_v = 0;
+    uint32_t max_prep_w = 0, max_prep_m4 = 0;   // grid extents of k_prep (lists or all variants) and k_prep_m4
     uint32_t bins_which = 0;   // bit 0: chains whose bins k_bins forms, bit 1: chains on k_sweep_lean2 (k_bins_lean2), bit 2: k_bins_thin
     uint32_t vit_bits = 0;     // run_phasing: 1 / 2 / 4 = chains with 16 / 32 / 64 padded paths
     hipEvent_t ev_vit[2];
@@ -563,6 +566,8 @@ int upload_inputs(pg_job* job, const pg_contig_batch* batches, const std::vector
             UP(x.o_goff, x.goff.data(), ((size_t)x.V + 1) * 8, bi);
             if (x.wide_bytes) UP(x.o_widx, x.widx.data(), (size_t)x.V * 4, bi);
             if (x.aux_bytes) UP(x.o_auxidx, x.auxidx.data(), (size_t)x.V * 4, bi);
+            UP(x.o_list_m4, x.list_m4.data(), x.list_m4.size() * 4, bi);
+            UP(x.o_list_w, x.list_w.data(), x.list_w.size() * 4, bi);
         }
         UP(job->o_tab_m, job->tab_m.data(), job->tab_m.size() * sizeof(double), bi);
         UP(job->o_tab_e, job->tab_e.data(), job->tab_e.size() * sizeof(int32_t), bi);
@@ -785,6 +790,15 @@ int job_build(int device, uint32_t n_index, const pg_contig_batch* batches, cons
             // 15 + 1 sampled paths have a fifth of their objects multiallelic); PG_KERNELS=prepwave: k_prep for everything (cross-check)
             const bool ok = x.H <= 64u && x.V > 0 && !kc.prepwave;
             x.prep_fast = !ok ? 0u : ((two_alleles && maxK <= 32u) ? 1u : (2u * n_bi >= x.V ? 2u : 0u));
+            if (x.prep_fast == 2u) {   // who prepares what: k_prep_bi scans the chain for its own, the others walk lists
+                for (uint32_t v = 0; v < x.V; ++v) {
+                    const uint64_t A = b.allele_off[v + 1] - b.allele_off[v];
+                    const uint32_t Kv = b.kmer_off[v + 1] - b.kmer_off[v];
+                    if (A == 2 && Kv <= 32u) continue;
+                    if (A >= 3 && A <= PG_AMAX && Kv <= 64u) x.list_m4.push_back(v);
+                    else x.list_w.push_back(v);
+                }
+            }
         }
         x.n_lik = x.goff[x.V];
         x.pair_n = (uint32_t)(maxA < PG_AMAX ? maxA : PG_AMAX);
@@ -949,6 +963,8 @@ int job_build(int device, uint32_t n_index, const pg_contig_batch* batches, cons
         x.o_goff = take(((size_t)x.V + 1) * 8);
         x.o_widx = take(x.wide_bytes ? (size_t)x.V * 4 : 0);
         x.o_auxidx = take(x.aux_bytes ? (size_t)x.V * 4 : 0);
+        x.o_list_m4 = take(x.list_m4.size() * 4);
+        x.o_list_w = take(x.list_w.size() * 4);
     }
     job->sample_lo = align_up(off);   // the per-sample arrays of all chains, one contiguous run (pg_job::sample_lo)
     for (uint32_t c = 0; c < n_chains; ++c) {
@@ -1059,6 +1075,12 @@ int job_build(int device, uint32_t n_index, const pg_contig_batch* batches, cons
         d.aux = A + p.aux; d.aux_idx = (d.smallx == 2u && x.aux_bytes) ? (const uint32_t*)(A + x.o_auxidx) : nullptr;
         d.live = (!job->chunked && x.HP == 32u && !kc.fullcols) ? std::min<uint32_t>(x.HP, (x.H + 3u) & ~3u) : x.HP;
         d.prep_fast = x.prep_fast;
+        if (x.prep_fast == 2u) {   // (a non-null list pointer = "walk the list", also when it is empty)
+            d.prep_m4 = (const uint32_t*)(A + x.o_list_m4); d.n_prep_m4 = (uint32_t)x.list_m4.size();
+            d.prep_w = (const uint32_t*)(A + x.o_list_w); d.n_prep_w = (uint32_t)x.list_w.size();
+            job->max_prep_m4 = std::max(job->max_prep_m4, d.n_prep_m4);
+            job->max_prep_w = std::max(job->max_prep_w, d.n_prep_w);
+        } else if (x.prep_fast == 0u) job->max_prep_w = std::max(job->max_prep_w, x.V);
         if (params->run_phasing) {
             d.vit_tq = (double*)(A + p.vtq); d.vit_back = (uint16_t*)(A + p.vback); d.vit_best = (uint32_t*)(A + p.vbest);
             d.hap1 = (uint16_t*)(A + p.hap1); d.hap2 = (uint16_t*)(A + p.hap2);
@@ -1336,7 +1358,7 @@ extern "C" int pg_job_run(pg_job* job, void* stream_, char* err, size_t errlen) 
     HIP_TRY(hipMemsetAsync(job->zero_base, 0, job->zero_bytes, s));
     if (job->max_v > 0 && job->params.run_genotyping) {
         HIP_TRY(hipEventRecord(job->ev[0], s));
-        pgk_launch_prep(job->d_contigs, n, job->max_v, job->tab, s);
+        pgk_launch_prep(job->d_contigs, n, job->max_v, job->max_prep_w, job->max_prep_m4, job->tab, s);
         HIP_TRY(hipGetLastError());
         HIP_TRY(hipEventRecord(job->ev[1], s));
         pgk_launch_compact(job->d_contigs, n, s);
@@ -1383,7 +1405,7 @@ extern "C" int pg_job_run(pg_job* job, void* stream_, char* err, size_t errlen) 
         }
     } else if (job->max_v > 0) {
         // run_genotyping == false: the ColumnIndexer part and the column records (what the Viterbi reads)
-        pgk_launch_prep(job->d_contigs, n, job->max_v, job->tab, s);
+        pgk_launch_prep(job->d_contigs, n, job->max_v, job->max_prep_w, job->max_prep_m4, job->tab, s);
         pgk_launch_compact(job->d_contigs, n, s);
         HIP_TRY(hipGetLastError());
     }
