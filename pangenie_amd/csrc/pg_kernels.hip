@@ -5177,8 +5177,10 @@ __global__ __launch_bounds__(256) void k_bins_lean2(const DevContig* __restrict_
 #define PG_POST_PLACEMENT_LDS (152 * 1024)
 // the bins of column c from its two stored columns A = alpha', B = beta' (full columns, row-pair layout) by one wave;
 // s_bins = the wave's row of narrow bins
+#define PG_WIDE_LDS_N 16   // wide columns with at most this many local alleles gather their raw bins in LDS (136 doubles per wave)
+#define PG_WIDE_LDS_BINS (PG_WIDE_LDS_N * (PG_WIDE_LDS_N + 1) / 2)
 DEVI void post_ab(const DevContig& dc, uint32_t C, uint32_t c, const double* A, const double* B, uint32_t lane,
-                  double (&s_bins_row)[PG_AMAX * (PG_AMAX + 1) / 2]);
+                  double (&s_bins_row)[PG_AMAX * (PG_AMAX + 1) / 2], double* s_wide = nullptr);
 // one column (index idx inside the chunk: forward role first) by one wave
 DEVI void post_column(const DevContig& dc, uint32_t chunk, uint32_t idx, uint32_t wave, uint32_t lane,
                       double (&s_bins)[PG_POST_WAVES][PG_AMAX * (PG_AMAX + 1) / 2]) {
@@ -5208,8 +5210,11 @@ DEVI void post_column(const DevContig& dc, uint32_t chunk, uint32_t idx, uint32_
     }
     post_ab(dc, C, c, A, B, lane, s_bins[wave]);
 }
+// s_wide (optional): PG_WIDE_LDS_BINS doubles of LDS of this wave's own — the raw bins of a wide column with at most
+// PG_WIDE_LDS_N local alleles are added up there instead of in `lik` (a dependent global read-modify-write per (row allele,
+// column allele) pair by one lane: ~45 of them in series cost a 16-path wide column more than everything else together)
 DEVI void post_ab(const DevContig& dc, uint32_t C, uint32_t c, const double* A, const double* B, uint32_t lane,
-                  double (&s_bins_row)[PG_AMAX * (PG_AMAX + 1) / 2]) {
+                  double (&s_bins_row)[PG_AMAX * (PG_AMAX + 1) / 2], double* s_wide) {
     const uint32_t HP = dc.HP;
     const bool direct = compact_records_only(dc, C);  // (no column-order copy of the records: the variant's own)
     const unsigned char* rec = direct ? dc.vrec + (size_t)dc.col_variant[c] * dc.RB : dc.colrec + (size_t)c * dc.RB;
@@ -5244,6 +5249,11 @@ DEVI void post_ab(const DevContig& dc, uint32_t C, uint32_t c, const double* A, 
     if (widec) {
         went = dc.wide + (size_t)(*(const uint32_t*)(rec + PG_REC_WIDE_IDX)) * 16u;
         wslots = (const uint16_t*)(went + PG_WIDE_OFF_SLOT(WS));
+    }
+    const bool in_lds = widec && s_wide != nullptr && nl <= (uint32_t)PG_WIDE_LDS_N;
+    if (in_lds) {
+        for (uint32_t q = lane; q < nl * (nl + 1u) / 2u; q += 64u) s_wide[q] = 0.0;
+        wave_sync_lds();
     }
     for (uint32_t abase = 0; abase < nl; abase += PG_AMAX)
     for (uint32_t ps = 0; ps < npass; ++ps) {
@@ -5315,9 +5325,12 @@ DEVI void post_ab(const DevContig& dc, uint32_t C, uint32_t c, const double* A, 
                         const double tot = wave_sum(b == cb ? acc[a] : 0.0);
                         if (lane == 0 && tot != 0.0) {
                             const uint32_t lo2 = ra < cb ? ra : cb, hi2 = ra < cb ? cb : ra;
-                            const uint32_t sa = wslots[lo2], sb = wslots[hi2];
-                            const uint64_t gi = dc.geno_off[v] + (uint64_t)sa * Av - (uint64_t)sa * (sa - 1) / 2 + (sb - sa);
-                            dc.lik[gi] += tot;  // raw sum; finished below
+                            if (in_lds) s_wide[tri_n(lo2, hi2, nl)] += tot;   // (la <= lb: the order decode_pair enumerates)
+                            else {
+                                const uint32_t sa = wslots[lo2], sb = wslots[hi2];
+                                const uint64_t gi = dc.geno_off[v] + (uint64_t)sa * Av - (uint64_t)sa * (sa - 1) / 2 + (sb - sa);
+                                dc.lik[gi] += tot;  // raw sum; finished below
+                            }
                         }
                     }
                 }
@@ -5343,8 +5356,8 @@ DEVI void post_ab(const DevContig& dc, uint32_t C, uint32_t c, const double* A, 
     } else {
         // wide column: the raw sums of its bins sit in lik (lane 0 added them up above); finish every
         // local pair la <= lb, one per lane
-        __threadfence();
-        wave_sync();
+        if (in_lds) wave_sync_lds();
+        else { __threadfence(); wave_sync(); }
         const double* Pm = (const double*)(went + PG_WIDE_OFF_PM(WS));
         const int* Pe = (const int*)(went + PG_WIDE_OFF_PE(WS));
         const uint32_t npairs = nl * (nl + 1u) / 2u;
@@ -5355,8 +5368,9 @@ DEVI void post_ab(const DevContig& dc, uint32_t C, uint32_t c, const double* A, 
             const uint64_t gi = dc.geno_off[v] + (uint64_t)sa * Av - (uint64_t)sa * (sa - 1) / 2 + (sb - sa);
             const double pm = fb ? 0.5 : Pm[la * WS + lb];
             const int pe = fb ? 1 : Pe[la * WS + lb];
-            store_bin(dc.lik, dc.lik_exp, gi, dc.lik[gi] * scale, pm, pe, xexp);
+            store_bin(dc.lik, dc.lik_exp, gi, (in_lds ? s_wide[q] : dc.lik[gi]) * scale, pm, pe, xexp);
         }
+        if (in_lds) wave_sync_lds();   // (the wave's row is reused by its next wide column)
     }
 }
 
@@ -5458,6 +5472,7 @@ __global__ __launch_bounds__(256) void k_bins_x(const DevContig* __restrict__ co
 
 __global__ __launch_bounds__(256) void k_bins_wide(const DevContig* __restrict__ contigs) {
     __shared__ double s_bins[4][PG_AMAX * (PG_AMAX + 1) / 2];
+    __shared__ double s_wide[4][PG_WIDE_LDS_BINS];
     const DevContig& dc = contigs[blockIdx.y];
     const uint32_t C = *dc.n_cols;
     if (!bins_x(dc, C) || !dc.wide_idx) return;   // (no object of this chain's index has more than PG_AMAX alleles)
@@ -5482,8 +5497,8 @@ __global__ __launch_bounds__(256) void k_bins_wide(const DevContig* __restrict__
         const double* mine = (const double*)(dc.aux + (size_t)ax * 16u);   // what this column's phase-2 role stored
         const double* stored = dc.fwd + (size_t)c * colsz;                 // its partner, from phase 1
         // c >= mid: the forward role ran phase 2 (alpha' = its column, beta' = the stored one); below: the backward role
-        if (c >= C / 2) post_ab(dc, C, c, mine, stored, lane, s_bins[wave]);
-        else post_ab(dc, C, c, stored, mine, lane, s_bins[wave]);
+        if (c >= C / 2) post_ab(dc, C, c, mine, stored, lane, s_bins[wave], s_wide[wave]);
+        else post_ab(dc, C, c, stored, mine, lane, s_bins[wave], s_wide[wave]);
         wave_sync_lds();
     }
 }

@@ -51,7 +51,7 @@ if sq:
     lines.append("")
     lines.append("SQ counters per launch (rocprofv3 --pmc, four separate passes):")
     for k, d in sq.items():
-        if "k_sweep" in k or "k_post" in k or "ks_" in k:
+        if any(t in k for t in ("k_sweep", "k_post", "ks_", "k_bins", "k_prep", "k_vit", "k_records")):
             lines.append("  " + k[:70])
             lines.append("    " + "  ".join("%s=%.4g" % (c, v) for c, v in sorted(d.items())))
 lines.append("")
