@@ -785,8 +785,10 @@ __global__ __launch_bounds__(256) void k_prep_bi(const DevContig* __restrict__ c
 // ------------------------------------------------------------------------------------------
 DEVI uint32_t row16_ballot(bool p, uint32_t grp) { return (uint32_t)((__ballot(p) >> (16u * grp)) & 0xFFFFull); }
 DEVI void prep_m4_unit(const DevContig& dc, const DevTable& tab, uint32_t unit) {
-    __shared__ double s_m[4][4][64 * 3];
-    __shared__ int s_e[4][4][64 * 3];
+    // (row strides padded: at 192 doubles / ints the four rows of a wave fell on the same LDS banks — every factor read a
+    //  four-way conflict, 40 % of the kernel's busy cycles)
+    __shared__ double s_m[4][4][64 * 3 + 4];
+    __shared__ int s_e[4][4][64 * 3 + 8];
     __shared__ unsigned char s_rec[4][4][448] __attribute__((aligned(16)));   // [wave][object of the wave][RB <= 448: H <= 64]
     const uint32_t wv = threadIdx.x >> 6, lane = threadIdx.x & 63u, grp = lane >> 4, l = lane & 15u;
     const uint32_t base = unit * 16u + wv * 4u;
@@ -5389,8 +5391,8 @@ __global__ __launch_bounds__(64 * PG_POST_WAVES) void k_post(const DevContig* __
 // ------------------------------------------------------------------------------------------
 //  k_bins_x / k_bins_wide : the bins of chains whose phase 2 ran on k_sweep_small16x (DevContig::smallx == 2).
 //  k_bins_x — one THREAD per column: a column with at most two local alleles has its four class sums in part[c][4]
-//  (DevContig::cls4's layout); one with three to five has the sixteen lanes' row-allele accumulators in its aux slot
-//  ([lane j][6 doubles]; the column allele of lane j is the allele of path j); the rare column whose bins are re-formed
+//  (DevContig::cls4's layout); one with three to five has its bins, finished inside the sweep, in its aux slot (fifteen
+//  doubles in tri_local order); the rare column whose bins are re-formed
 //  from the stored backward column (forward fall-back, see k_bins) is walked by its thread alone.  Same factors,
 //  exponents and fall-back rule as bins_unit.  WIDE columns are left to k_bins_wide — one WAVE per wide column: the
 //  column this role's phase 2 put into the aux slot times the stored partner column, as k_post does it (post_ab).
@@ -5431,26 +5433,13 @@ __global__ __launch_bounds__(256) void k_bins_x(const DevContig* __restrict__ co
         acc[tri_local(0, 0)] = 0.0 + p4[0];
         if (nl > 1u) { acc[tri_local(0, 1)] = (0.0 + p4[1]) + p4[2]; acc[tri_local(1, 1)] = 0.0 + p4[3]; }
     } else {
-        // sixteen lanes x {acc0 .. acc4, 0}: eight lanes' entries (24 16-byte loads) in flight at a time
+        // the column's bins arrive finished (tri_local order), 120 bytes in its aux slot
         const v2f64* e = (const v2f64*)(dc.aux + (size_t)(*(const uint32_t*)(rec + PG_REC_AUX)) * 16u);
-        const uint4 aw = ((const uint4*)al)[0];
-        const uint32_t alw[4] = {aw.x, aw.y, aw.z, aw.w};
-        static_for<0, 2>([&](auto hb) __attribute__((always_inline)) {
-            constexpr int j0 = decltype(hb)::value * 8;
-            v2f64 pv[8][3];
+        v2f64 pv[8];
 #pragma unroll
-            for (int k = 0; k < 8; ++k) { pv[k][0] = e[3 * (j0 + k)]; pv[k][1] = e[3 * (j0 + k) + 1]; pv[k][2] = e[3 * (j0 + k) + 2]; }
+        for (int k = 0; k < 8; ++k) pv[k] = e[k];
 #pragma unroll
-            for (int k = 0; k < 8; ++k) {
-                const uint32_t b = (alw[(j0 + k) >> 2] >> (8 * ((j0 + k) & 3))) & 0xFFu;
-                if (b < nl) {
-                    add(0, b, pv[k][0].x); add(1, b, pv[k][0].y);
-                    add(2, b, pv[k][1].x);
-                    if (nl > 3u) add(3, b, pv[k][1].y);
-                    if (nl > 4u) add(4, b, pv[k][2].x);
-                }
-            }
-        });
+        for (int k = 0; k < 8; ++k) { acc[2 * k] = pv[k].x; if (2 * k + 1 < PG_NBINS) acc[2 * k + 1] = pv[k].y; }
     }
     const double scale = 1.0 / ((fb ? 1.0 : dc.fscale[c]) * dc.bscale[c]);
     int xexp = -((fb ? 0 : PG_BIAS_F) + PG_BIAS_B);

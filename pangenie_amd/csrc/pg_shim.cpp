@@ -827,14 +827,14 @@ int job_build(int device, uint32_t n_index, const pg_contig_batch* batches, cons
         // per object (narrow columns from the record's table, wide ones from the side table: per COLUMN)
         x.smallx = lean_ok && x.HP == 16 && x.H == 16 && maxA > 2 && x.V > 0;
         if (x.smallx) {
-            // aux slots: a variant with 3 .. PG_AMAX alleles may leave phase 2 as sixteen lanes' accumulators (HP x 48 bytes),
-            // one with more as a whole column (a wide column) — or as accumulators, if its paths carry at most PG_AMAX of them
+            // aux slots: a variant with 3 .. PG_AMAX alleles leaves phase 2 as its (up to) fifteen bins (128 bytes), one with
+            // more as a whole column (a wide column) — or as bins, if its paths carry at most PG_AMAX of them
             x.auxidx.assign(x.V, PG_WIDE_NONE);
             uint64_t ao = 0;
             for (uint32_t v = 0; v < x.V; ++v) {
                 const uint64_t A = b.allele_off[v + 1] - b.allele_off[v];
                 if (A <= 2) continue;
-                const uint64_t small_slot = (uint64_t)x.HP * 48u, col_slot = (uint64_t)x.HP * x.HP * 8u;
+                const uint64_t small_slot = 128u /* fifteen bins */, col_slot = (uint64_t)x.HP * x.HP * 8u;
                 x.auxidx[v] = (uint32_t)(ao / 16);
                 ao += A > PG_AMAX ? (col_slot > small_slot ? col_slot : small_slot) : small_slot;
             }

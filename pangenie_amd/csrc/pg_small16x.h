@@ -19,8 +19,8 @@
 //   * phase 2: P' beta' is added by ROW allele into five accumulators with exact 0 / 1 weights that are 16-byte LDS reads
 //     from a constant one-hot table addressed by the same row byte (ten issue slots per state, no compare, no select).
 //     Columns with at most two local alleles leave the sweep as the four class sums of DevContig::cls4's layout; columns
-//     with three to five write the sixteen lanes' accumulators (768 bytes) into the column's aux slot and k_bins_x splits
-//     them by column allele.
+//     with three to five as their (up to) fifteen genotype bins, formed inside the row through an LDS transpose, in the
+//     column's 128-byte aux slot (k_bins_x finishes both kinds).
 //   * WIDE columns (more than PG_AMAX alleles on the sixteen paths) cost that COLUMN, not the job: their emissions are
 //     gathered from the side table (a wave-uniform branch, 16 loads per lane of the rows concerned), and in phase 2 the
 //     column itself goes to its aux slot — k_bins_wide forms its bins from the two stored columns the way k_post does.
@@ -44,6 +44,7 @@
 typedef uint32_t v4u32 __attribute__((ext_vector_type(4)));   // native vector type (address-space qualifiable)
 struct SmallXShared {
     double onehot[PG_ESTRIDE][PG_ESTRIDE];                 // row 0: zeros; row a + 1: 1.0 at a (a < PG_AMAX) — the row-allele weights
+    double red[4][PG_ESTRIDE][16];                         // phase 2: a multiallelic column's accumulators [half-chain][row allele][lane]; row PG_AMAX: zeros
     unsigned char rec[4][2][PG_XSLOT_BYTES] __attribute__((aligned(16)));   // [half-chain of the wave][column parity]
 };
 struct XPieces { v2f64 p0, p1; };
@@ -119,30 +120,48 @@ DEVI void smallx_init_shared(SmallXShared& sh, uint32_t lane) {
     // of the wave that carry no half-chain read zero offsets, not whatever the LDS held (8 slots x 384 bytes = 192 pieces)
 #pragma unroll
     for (uint32_t q = 0; q < 3u; ++q) *(v2f64*)(&sh.rec[0][0][0] + (lane + 64u * q) * 16u) = v2f64{0.0, 0.0};
+    sh.red[lane >> 4][PG_AMAX][lane & 15u] = 0.0;
     wave_sync_lds();
 }
 
 // phase 2, one column of one half-chain: the posterior sums leave the sweep (see the header)
 //   acc[a] = sum over the rows with allele a of P'(k, j) beta'(k, j), this lane's column j
-DEVI void smallx_posterior_out(const SmallXCtx& cx, const XCol& col, bool act, int64_t t, uint32_t j, const double (&acc)[PG_AMAX], const double (&colv)[16]) {
+// Columns with at most two local alleles: four class sums (row allele x column allele) by masked sums over the row's lanes.
+// Columns with three to five: the sixteen lanes' accumulators are transposed through LDS and lane p of the row adds up
+// genotype bin p = {a, b} (tri_local order: the accumulators a of the lanes whose column carries b, and b of those that
+// carry a) — 120 bytes leave for the column's aux slot where 768 bytes of accumulators did (a wave-uniform branch: in a
+// cohort the four rows of a wave are samples of one contig, the same columns are multiallelic in all of them).
+DEVI void smallx_posterior_out(const SmallXCtx& cx, SmallXShared& sh, const XCol& col, bool act, int64_t t, uint32_t j, uint32_t row,
+                               const double (&acc)[PG_AMAX], const double (&colv)[16]) {
     const uint32_t nl = col.nlf & 0xFFu;
     const bool wide = (col.nlf & PG_XREC_FLAG_WIDE) != 0u;
     const bool b1 = col.rawj == 1u;
     const double s00 = row16_sum(b1 ? 0.0 : acc[0]), s01 = row16_sum(b1 ? acc[0] : 0.0);
     const double s10 = row16_sum(b1 ? 0.0 : acc[1]), s11 = row16_sum(b1 ? acc[1] : 0.0);
-    if (act && !wide) {
-        if (nl <= 2u) {
-            if (j == 0) {
-                gdouble2* o = (gdouble2*)cx.part + (size_t)t * 2u;
-                o[0] = v2f64{s00, s01};
-                o[1] = v2f64{s10, s11};
-            }
-        } else {
-            gdouble2* o = (gdouble2*)(cx.aux + (size_t)col.aux * 16u) + 3u * j;
-            o[0] = v2f64{acc[0], acc[1]};
-            o[1] = v2f64{acc[2], acc[3]};
-            o[2] = v2f64{acc[4], 0.0};
+    if (act && !wide && nl <= 2u && j == 0) {
+        gdouble2* o = (gdouble2*)cx.part + (size_t)t * 2u;
+        o[0] = v2f64{s00, s01};
+        o[1] = v2f64{s10, s11};
+    }
+    const bool multi = act && !wide && nl > 2u;
+    if (__any(multi)) {
+        const uint32_t red = (uint32_t)(uintptr_t)(LAS unsigned char*)&sh.red[row][0][0];
+#pragma unroll
+        for (int a = 0; a < PG_AMAX; ++a) *(LAS double*)(uintptr_t)(red + (uint32_t)a * 128u + 8u * j) = acc[a];
+        // this lane's bin p = j: {pa, pb}, pa <= pb (tri_local: rows of 5, 4, 3, 2, 1 entries)
+        const uint32_t pa = (j >= 5u ? 1u : 0u) + (j >= 9u ? 1u : 0u) + (j >= 12u ? 1u : 0u) + (j >= 14u ? 1u : 0u);
+        const uint32_t pb = j - (pa * (uint32_t)PG_AMAX - pa * (pa - 1u) / 2u) + pa;
+        const uint32_t offa = red + pa * 128u, offb = red + pb * 128u, offz = red + (uint32_t)PG_AMAX * 128u;
+        const v4u32 rw = *(LAS const v4u32*)(uintptr_t)(col.slot + PG_XSLOT_RAW);
+        const uint32_t raw[4] = {rw.x, rw.y, rw.z, rw.w};
+        double sum = 0.0;
+#pragma unroll
+        for (int l = 0; l < 16; ++l) {
+            const uint32_t al = (raw[l >> 2] >> (8 * (l & 3))) & 0xFFu;   // column allele of lane l
+            const uint32_t src = al == pb ? offa : (al == pa ? offb : offz);
+            sum += *(LAS const double*)(uintptr_t)(src + 8u * (uint32_t)l);
         }
+        if (multi && j < (uint32_t)(PG_AMAX * (PG_AMAX + 1) / 2)) *((gdouble*)(cx.aux + (size_t)col.aux * 16u) + j) = sum;
     }
     if (act && wide) {   // the column itself (row-pair layout, like a stored column): k_bins_wide multiplies it with its partner
         gdouble2* o = (gdouble2*)(cx.aux + (size_t)col.aux * 16u) + j;
@@ -321,7 +340,7 @@ DEVI void small16x_forward(const DevContig* contigs, const uint32_t* ids, uint32
             }
         }
         if constexpr (PHASE == 2) {
-            smallx_posterior_out(cx, col, act, t, j, acc, pp);
+            smallx_posterior_out(cx, sh, col, act, t, j, row, acc, pp);
             load_partner(t + 3, vp);
         }
         if (act) {   // the column's scale mantissa: sixteen columns collected in the row's lanes, one store per sixteen
@@ -503,7 +522,7 @@ DEVI void small16x_backward(const DevContig* contigs, const uint32_t* ids, uint3
             }
         }
         if constexpr (PHASE == 2) {
-            smallx_posterior_out(cx, col, act, t, j, acc, pp);
+            smallx_posterior_out(cx, sh, col, act, t, j, row, acc, pp);
             load_partner(t - 3, vp);
         }
         Sy = Snew;
