@@ -145,9 +145,10 @@ struct DevContig {
     // prep_fast == 2: the objects with 3 .. PG_AMAX alleles and <= 64 k-mers (k_prep_m4: four per wave) and every other object
     // that is not k_prep_bi's (k_prep: one per wave), as lists of variant ids per index contig — null: k_prep walks all variants
     uint32_t  n_prep_m4, n_prep_w;
-    uint32_t  pad2;
+    uint32_t  n_prep_b;        // ... and k_prep_bi's own objects (two alleles, <= 32 k-mers)
     const uint32_t* prep_m4;
     const uint32_t* prep_w;
+    const uint32_t* prep_b;
     uint32_t  lean;            // 1: the store-only phases of this chain run on k_sweep_lean
     // 1 or 2 (lean chains of FUSED jobs; 2: phase 2 on k_sweep_lean2, 1: on the general kernel's triangle ring): phase 1 stores only the upper triangle of its (symmetric) columns, COMPACT at the
     // start of the column's slot (1152 16-byte units: row pair q, lanes 8 (q >> 2) .. 63, see tri_unit_of); elements

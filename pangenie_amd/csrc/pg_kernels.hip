@@ -609,9 +609,13 @@ DEVI int row_last_i32(int v) { return __builtin_amdgcn_update_dpp(v, v, 0x15F, 0
 
 DEVI void prep_bi_unit(const DevContig& dc, const DevTable& tab, uint32_t unit) {
     const uint32_t lane = threadIdx.x & 63u, grp = lane >> 4, l = lane & 15u;
-    const uint32_t v = unit * 16u + (threadIdx.x >> 6) * 4u + grp;
-    if (unit * 16u + (threadIdx.x >> 6) * 4u >= dc.V) return;  // the whole wave is beyond the contig
-    bool live = v < dc.V;   // (a row beyond the contig idles along: the ballots below are wave-wide)
+    // mixed chains (DevContig::prep_fast == 2) hand this kernel the LIST of its objects (prep_b): no rows idling along on
+    // the objects of the other kernels
+    const uint32_t nobj = dc.prep_b ? dc.n_prep_b : dc.V;
+    const uint32_t pos = unit * 16u + (threadIdx.x >> 6) * 4u + grp;
+    if (unit * 16u + (threadIdx.x >> 6) * 4u >= nobj) return;  // the whole wave is beyond the contig
+    bool live = pos < nobj;   // (a row beyond the contig idles along: the ballots below are wave-wide)
+    const uint32_t v = dc.prep_b ? dc.prep_b[live ? pos : nobj - 1u] : pos;
     const uint32_t vv = live ? v : dc.V - 1u;
     const uint32_t H = dc.H, HP = dc.HP;
     const uint32_t a0 = dc.allele_off[vv];  // two alleles
@@ -5398,43 +5402,54 @@ __global__ __launch_bounds__(64 * PG_POST_WAVES) void k_post(const DevContig* __
 //  column this role's phase 2 put into the aux slot times the stored partner column, as k_post does it (post_ab).
 // ------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_bins_x(const DevContig* __restrict__ contigs) {
-    __shared__ double s_acc[256][PG_NBINS + 2];   // (17 doubles: an odd row stride spreads the threads' rows over the banks)
+    // (the bins of a column live in registers, every index static: with a private LDS row per thread — k_bins_thin's way —
+    //  four blocks fit a CU, and this kernel is a chain of dependent loads: it needs the waves)
     const DevContig& dc = contigs[blockIdx.y];
     const uint32_t C = *dc.n_cols;
     if (!bins_x(dc, C)) return;
     if (blockIdx.x * 256u >= C) return;
     const uint32_t c = blockIdx.x * 256u + threadIdx.x;
     if (c >= C) return;
-    const unsigned char* rec = dc.vrec + (size_t)dc.col_variant[c] * dc.RB;
-    if (rec[PG_REC_FLAGS] & PG_REC_FLAG_WIDE) return;   // k_bins_wide
-    const uint32_t v = *(const uint32_t*)(rec + PG_REC_VARIANT);
-    const uint32_t nl = rec[PG_REC_NLOCAL];
-    const uint32_t H = dc.H, HP = dc.HP;
-    const unsigned char* al = rec + PG_REC_ALLELES;
-    double* acc = s_acc[threadIdx.x];
-#pragma unroll
-    for (int i = 0; i < PG_NBINS; ++i) acc[i] = 0.0;
-    auto add = [&](uint32_t a, uint32_t b, double val) { acc[tri_local(a < b ? a : b, a < b ? b : a)] += val; };
+    const uint32_t cv = dc.col_variant[c], cvn = c + 1 < C ? dc.col_variant[c + 1] : cv;
+    const unsigned char* rec = dc.vrec + (size_t)cv * dc.RB;
+    const uint4 hd = *(const uint4*)(rec + PG_REC_VARIANT);   // variant, exponent, nlocal | flags << 8, wide entry
+    if ((hd.z >> 8) & PG_REC_FLAG_WIDE) return;               // k_bins_wide
+    const uint32_t v = hd.x;
+    const uint32_t nl = hd.z & 0xFFu;
+    const uint4 lsw = *(const uint4*)(rec + PG_REC_LOCAL_SLOT);   // local allele -> allele slot (five u16), then the aux slot
+    const int32_t xnext = c + 1 < C ? *(const int32_t*)(dc.vrec + (size_t)cvn * dc.RB + PG_REC_EXP) : 0;
     const bool fb = dc.fwd_fallback[c] != 0;
     const bool reform = fb && c >= C / 2;
+    double acc[PG_NBINS];
+#pragma unroll
+    for (int i = 0; i < PG_NBINS; ++i) acc[i] = 0.0;
     if (reform) {
-        // (see bins_unit) alpha_hat * fsum = 1 / H^2 for every state, times the stored backward column
+        // (see bins_unit) alpha_hat * fsum = 1 / H^2 for every state, times the stored backward column.  Rare: the bin of a
+        // state is picked by fifteen selects
+        const uint32_t H = dc.H, HP = dc.HP;
+        const unsigned char* al = rec + PG_REC_ALLELES;
         const double unif = 1.0 / ((double)H * (double)H);
         const double* col = dc.fwd + (size_t)c * dc.col_stride;
         for (uint32_t i = 0; i < H; ++i) {
             const uint32_t a = al[i];
             for (uint32_t jj = 0; jj < H; ++jj) {
                 const uint32_t b = al[jj];
-                if (a < nl && b < nl) add(a, b, col[((size_t)(i >> 1) * HP + jj) * 2 + (i & 1u)] * unif);
+                if (a < nl && b < nl) {
+                    const uint32_t idx = tri_local(a < b ? a : b, a < b ? b : a);
+                    const double val = col[((size_t)(i >> 1) * HP + jj) * 2 + (i & 1u)] * unif;
+#pragma unroll
+                    for (int q = 0; q < PG_NBINS; ++q) acc[q] += idx == (uint32_t)q ? val : 0.0;
+                }
             }
         }
     } else if (nl <= 2u) {
-        const double* p4 = dc.part + (size_t)c * 4u;
-        acc[tri_local(0, 0)] = 0.0 + p4[0];
-        if (nl > 1u) { acc[tri_local(0, 1)] = (0.0 + p4[1]) + p4[2]; acc[tri_local(1, 1)] = 0.0 + p4[3]; }
+        const v2f64* p4 = (const v2f64*)(dc.part + (size_t)c * 4u);
+        const v2f64 p01 = p4[0], p23 = p4[1];
+        acc[0] = 0.0 + p01.x;                                                        // tri_local(0, 0)
+        if (nl > 1u) { acc[1] = (0.0 + p01.y) + p23.x; acc[PG_AMAX] = 0.0 + p23.y; }   // tri_local(0, 1), tri_local(1, 1)
     } else {
         // the column's bins arrive finished (tri_local order), 120 bytes in its aux slot
-        const v2f64* e = (const v2f64*)(dc.aux + (size_t)(*(const uint32_t*)(rec + PG_REC_AUX)) * 16u);
+        const v2f64* e = (const v2f64*)(dc.aux + (size_t)lsw.w * 16u);
         v2f64 pv[8];
 #pragma unroll
         for (int k = 0; k < 8; ++k) pv[k] = e[k];
@@ -5442,21 +5457,26 @@ __global__ __launch_bounds__(256) void k_bins_x(const DevContig* __restrict__ co
         for (int k = 0; k < 8; ++k) { acc[2 * k] = pv[k].x; if (2 * k + 1 < PG_NBINS) acc[2 * k + 1] = pv[k].y; }
     }
     const double scale = 1.0 / ((fb ? 1.0 : dc.fscale[c]) * dc.bscale[c]);
-    int xexp = -((fb ? 0 : PG_BIAS_F) + PG_BIAS_B);
-    if (c + 1 < C) xexp += *(const int32_t*)(dc.vrec + (size_t)dc.col_variant[c + 1] * dc.RB + PG_REC_EXP);
-    const uint16_t* ls = (const uint16_t*)(rec + PG_REC_LOCAL_SLOT);
+    const int xexp = -((fb ? 0 : PG_BIAS_F) + PG_BIAS_B) + xnext;
     const uint32_t a0 = dc.allele_off[v], A = dc.allele_off[v + 1] - a0;
+    const uint64_t g0 = dc.geno_off[v];
     const uint32_t pn = dc.pair_n, NP = (pn * (pn + 1) / 2 + 1u) & ~1u;
     const unsigned char* vp = dc.vpair + (size_t)v * (NP * 12u);
-    for (uint32_t la = 0; la < nl; ++la)
-        for (uint32_t lb = la; lb < nl; ++lb) {
-            const uint32_t sa = ls[la], sb = ls[lb];
-            const uint64_t idx = dc.geno_off[v] + (uint64_t)sa * A - (uint64_t)sa * (sa - 1) / 2 + (sb - sa);
-            const uint32_t pi = tri_n(la, lb, pn);
-            const double pm = fb ? 0.5 : ((const double*)vp)[pi];
-            const int pe = fb ? 1 : ((const int*)(vp + (size_t)NP * 8u))[pi];
-            store_bin(dc.lik, dc.lik_exp, idx, acc[tri_local(la, lb)] * scale, pm, pe, xexp);
-        }
+    const uint32_t lsv[PG_AMAX] = {lsw.x & 0xFFFFu, lsw.x >> 16, lsw.y & 0xFFFFu, lsw.y >> 16, lsw.z & 0xFFFFu};
+    static_for<0, PG_AMAX>([&](auto lac) __attribute__((always_inline)) {
+        constexpr int la = decltype(lac)::value;
+        static_for<la, PG_AMAX>([&](auto lbc) __attribute__((always_inline)) {
+            constexpr int lb = decltype(lbc)::value;
+            if ((uint32_t)lb < nl) {
+                const uint32_t sa = lsv[la], sb = lsv[lb];
+                const uint64_t idx = g0 + (uint64_t)sa * A - (uint64_t)sa * (sa - 1) / 2 + (sb - sa);
+                const uint32_t pi = tri_n((uint32_t)la, (uint32_t)lb, pn);
+                const double pm = fb ? 0.5 : ((const double*)vp)[pi];
+                const int pe = fb ? 1 : ((const int*)(vp + (size_t)NP * 8u))[pi];
+                store_bin(dc.lik, dc.lik_exp, idx, acc[la * PG_AMAX - la * (la - 1) / 2 + (lb - la)] * scale, pm, pe, xexp);
+            }
+        });
+    });
 }
 
 __global__ __launch_bounds__(256) void k_bins_wide(const DevContig* __restrict__ contigs) {

@@ -217,6 +217,8 @@ struct IndexHost {   // one index contig
     bool leanx = false; // HP = 128 / 64 and every object has at most PG_AMAX alleles (not `lean`): the store-only phases run on k_sweep_leanx
     bool small = false; // every object biallelic and H = HP = 16: the store-only phases run on k_sweep_small16
     bool smallx = false; // H = HP = 16 with multiallelic objects (the 15 + 1 sampled paths): k_sweep_small16x (pg_small16x.h)
+    std::vector<uint32_t> list_b;            // ... and k_prep_bi's own
+    size_t o_list_b = 0;
     std::vector<uint32_t> list_m4, list_w;   // prep_fast == 2: the objects of k_prep_m4 (3 .. PG_AMAX alleles, <= 64 k-mers) / of k_prep (neither that nor k_prep_bi's)
     size_t o_list_m4 = 0, o_list_w = 0;
     std::vector<uint32_t> auxidx;    // [V] aux slot offset / 16 of every variant with more than two alleles (smallx), PG_WIDE_NONE otherwise
@@ -568,6 +570,7 @@ int upload_inputs(pg_job* job, const pg_contig_batch* batches, const std::vector
             if (x.aux_bytes) UP(x.o_auxidx, x.auxidx.data(), (size_t)x.V * 4, bi);
             UP(x.o_list_m4, x.list_m4.data(), x.list_m4.size() * 4, bi);
             UP(x.o_list_w, x.list_w.data(), x.list_w.size() * 4, bi);
+            UP(x.o_list_b, x.list_b.data(), x.list_b.size() * 4, bi);
         }
         UP(job->o_tab_m, job->tab_m.data(), job->tab_m.size() * sizeof(double), bi);
         UP(job->o_tab_e, job->tab_e.data(), job->tab_e.size() * sizeof(int32_t), bi);
@@ -794,7 +797,7 @@ int job_build(int device, uint32_t n_index, const pg_contig_batch* batches, cons
                 for (uint32_t v = 0; v < x.V; ++v) {
                     const uint64_t A = b.allele_off[v + 1] - b.allele_off[v];
                     const uint32_t Kv = b.kmer_off[v + 1] - b.kmer_off[v];
-                    if (A == 2 && Kv <= 32u) continue;
+                    if (A == 2 && Kv <= 32u) { x.list_b.push_back(v); continue; }
                     if (A >= 3 && A <= PG_AMAX && Kv <= 64u) x.list_m4.push_back(v);
                     else x.list_w.push_back(v);
                 }
@@ -965,6 +968,7 @@ int job_build(int device, uint32_t n_index, const pg_contig_batch* batches, cons
         x.o_auxidx = take(x.aux_bytes ? (size_t)x.V * 4 : 0);
         x.o_list_m4 = take(x.list_m4.size() * 4);
         x.o_list_w = take(x.list_w.size() * 4);
+        x.o_list_b = take(x.list_b.size() * 4);
     }
     job->sample_lo = align_up(off);   // the per-sample arrays of all chains, one contiguous run (pg_job::sample_lo)
     for (uint32_t c = 0; c < n_chains; ++c) {
@@ -1078,6 +1082,7 @@ int job_build(int device, uint32_t n_index, const pg_contig_batch* batches, cons
         if (x.prep_fast == 2u) {   // (a non-null list pointer = "walk the list", also when it is empty)
             d.prep_m4 = (const uint32_t*)(A + x.o_list_m4); d.n_prep_m4 = (uint32_t)x.list_m4.size();
             d.prep_w = (const uint32_t*)(A + x.o_list_w); d.n_prep_w = (uint32_t)x.list_w.size();
+            d.prep_b = (const uint32_t*)(A + x.o_list_b); d.n_prep_b = (uint32_t)x.list_b.size();
             job->max_prep_m4 = std::max(job->max_prep_m4, d.n_prep_m4);
             job->max_prep_w = std::max(job->max_prep_w, d.n_prep_w);
         } else if (x.prep_fast == 0u) job->max_prep_w = std::max(job->max_prep_w, x.V);
