@@ -169,12 +169,12 @@ struct DevContig {
     // k_bins_lean2 turns them into bins — instead of per-thread partials reduced by k_bins
     uint32_t  cls4;
     // 1 / 2: HP = H = 16 and NOT every object biallelic: the store-only phases (1) / both phases (2: fused jobs) run on
-    // k_sweep_small16x (pg_small16x.h): 320-byte column records in `frec`, class sums of columns with at most two local
-    // alleles in `part` ([C][4]), the accumulators of columns with three to five and the phase-2 column of WIDE columns in
+    // k_sweep_small16x (pg_small16x.h): 192-byte column records in `frec`, class sums of columns with at most two local
+    // alleles in `part` ([C][4]), the fifteen bins of columns with three to five and the phase-2 column of WIDE columns in
     // the variant's `aux` slot (k_bins_x, k_bins_wide)
     uint32_t  smallx;
     uint32_t  pad1;
-    unsigned char* aux;        // per chain: slots of the variants with more than two alleles (768 B) / more than PG_AMAX (max(768, 8 HP^2) B)
+    unsigned char* aux;        // per chain: slots of the variants with more than two alleles (128 B) / more than PG_AMAX (8 HP^2 B)
     const uint32_t* aux_idx;   // [V] per index contig: byte offset / 16 of the variant's slot, PG_WIDE_NONE if it has two alleles
     // rows and lanes of a stored column that carry data: H rounded up to a multiple of 4 (fused jobs at HP = 32, where
     // 17 paths — the 15 + 1 behind haplotype sampling — would otherwise move 32 x 32 states per column for 17 x 17 real ones), else HP.

@@ -1107,35 +1107,45 @@ DEVI void records_unit(const DevContig& dc, uint32_t unit) {
         dst[p] = val;
     }
     if (dc.smallx) {
-        // the 320-byte records of k_sweep_small16x (pg_small16x.h): pieces 0..14 = rows 0..4 of the 6 x 6 table, 15 = header,
-        // 16-17 = constants, 18 = table-row offset (a + 1) * 48 of every path's allele (0: phantom, and every path of a wide
-        // column), 19 = the raw local alleles; the wave's n records are n * 20 pieces, contiguous on the destination side
-        f64x2* xd = (f64x2*)((unsigned char*)dc.frec + (size_t)cbase * 320u);
-        for (uint32_t p = lane; p < n * 20u; p += 64u) {
-            const uint32_t q = p / 20u, w = p - q * 20u;
+        // the 192-byte records of k_sweep_small16x (pg_small16x.h): pieces 0..7 = the fifteen entries E(a, b), a <= b, of the 6 x 6
+        // table in tri_local order (a WIDE column: piece 0 = its sixteen raw local alleles, the rest zero), 8 = header {nlocal |
+        // flags << 8, wide entry, aux slot, 0}, 9-10 = constants, 11 = table-row offset (a + 1) * 48 of every path's allele
+        // (0: phantom, and every path of a wide column); the wave's n records are n * 12 pieces, contiguous on the destination side
+        f64x2* xd = (f64x2*)((unsigned char*)dc.frec + (size_t)cbase * 192u);
+        for (uint32_t p = lane; p < n * 12u; p += 64u) {
+            const uint32_t q = p / 12u, w = p - q * 12u;
             const unsigned char* src = dc.vrec + (size_t)s_v[wave][q] * dc.RB;
-            f64x2 val;
-            if (w < 15u) val = ((const f64x2*)(src + PG_REC_E))[w];
-            else if (w == 16u) val = f64x2{s_c[wave][q][0], s_c[wave][q][1]};
-            else if (w == 17u) val = f64x2{s_c[wave][q][2], s_c[wave][q][3]};
+            const uint32_t nlf = (uint32_t)src[PG_REC_NLOCAL] | ((uint32_t)src[PG_REC_FLAGS] << 8);
+            const bool widec = (nlf & 0x200u) != 0u;
+            f64x2 val = f64x2{0.0, 0.0};
+            if (w < 8u) {
+                if (widec) { if (w == 0u) val = *(const f64x2*)(src + PG_REC_ALLELES); }
+                else {
+                    auto entry = [&](uint32_t e) {   // table entry e in tri_local order (15: padding)
+                        if (e >= 15u) return 0.0;
+                        const uint32_t a = (e >= 5u ? 1u : 0u) + (e >= 9u ? 1u : 0u) + (e >= 12u ? 1u : 0u) + (e >= 14u ? 1u : 0u);
+                        const uint32_t b = e - (a * (uint32_t)PG_AMAX - a * (a - 1u) / 2u) + a;
+                        return ((const double*)(src + PG_REC_E))[a * PG_ESTRIDE + b];
+                    };
+                    val = f64x2{entry(2u * w), entry(2u * w + 1u)};
+                }
+            } else if (w == 9u) val = f64x2{s_c[wave][q][0], s_c[wave][q][1]};
+            else if (w == 10u) val = f64x2{s_c[wave][q][2], s_c[wave][q][3]};
             else {
-                const uint32_t nlf = (uint32_t)src[PG_REC_NLOCAL] | ((uint32_t)src[PG_REC_FLAGS] << 8);
                 uint4 u;
-                if (w == 15u) u = uint4{*(const uint32_t*)(src + PG_REC_VARIANT), nlf, *(const uint32_t*)(src + PG_REC_WIDE_IDX), *(const uint32_t*)(src + PG_REC_AUX)};
+                if (w == 8u) u = uint4{nlf, *(const uint32_t*)(src + PG_REC_WIDE_IDX), *(const uint32_t*)(src + PG_REC_AUX), 0u};
                 else {
                     u = *(const uint4*)(src + PG_REC_ALLELES);
-                    if (w == 18u) {
-                        auto f = [&](uint32_t x) {   // four allele bytes -> four row offsets
-                            uint32_t r = 0;
+                    auto f = [&](uint32_t x) {   // four allele bytes -> four row offsets
+                        uint32_t r = 0;
 #pragma unroll
-                            for (int b = 0; b < 4; ++b) {
-                                const uint32_t a = (x >> (8 * b)) & 0xFFu;
-                                r |= ((a < (uint32_t)PG_AMAX && !(nlf & 0x200u)) ? (a + 1u) * (uint32_t)(PG_ESTRIDE * 8) : 0u) << (8 * b);
-                            }
-                            return r;
-                        };
-                        u = uint4{f(u.x), f(u.y), f(u.z), f(u.w)};
-                    }
+                        for (int b = 0; b < 4; ++b) {
+                            const uint32_t a = (x >> (8 * b)) & 0xFFu;
+                            r |= ((a < (uint32_t)PG_AMAX && !widec) ? (a + 1u) * (uint32_t)(PG_ESTRIDE * 8) : 0u) << (8 * b);
+                        }
+                        return r;
+                    };
+                    u = uint4{f(u.x), f(u.y), f(u.z), f(u.w)};
                 }
                 val = *(const f64x2*)&u;
             }

@@ -1006,7 +1006,7 @@ int job_build(int device, uint32_t n_index, const pg_contig_batch* batches, cons
         p.wide = take(x.wide_bytes);
         p.vpair = take((size_t)x.V * pg_pair_bytes(x.pair_n));
         p.xbuf = take((x.HP >= 256 || (force_generic && x.HP >= 64)) ? (size_t)2 * x.HP * x.HP * sizeof(double) : 0);
-        p.frec = take((x.lean || x.small) ? (size_t)x.V * 64 : (x.smallx ? (size_t)x.V * 320 : 0));
+        p.frec = take((x.lean || x.small) ? (size_t)x.V * 64 : (x.smallx ? (size_t)x.V * 192 : 0));
         if (x.lean) job->hp_mask |= 64u;
         if (x.leanx) job->hp_mask |= x.HP == 128 ? 512u : 1024u;
         p.fscale = take((size_t)x.V * sizeof(double));

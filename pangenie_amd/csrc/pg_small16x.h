@@ -7,12 +7,13 @@
 // recursion is k_sweep_small16's (in-lane column sums, u_i by v_fmac_f64_dpp row_newbcast, total by four rotate-and-add
 // steps).  What differs is everything that depends on the alleles — ONE path for every column, eligibility is per COLUMN,
 // not per chain or job ("what's missing" 1-2):
-//   * records: 320 bytes per column (k_records, DevContig::smallx): the five rows of the column's 6 x 6 emission table, a
-//     16-byte header (variant, local alleles, flags, wide entry, aux slot), the transition constants, the table-row offset
-//     (a + 1) * 48 of every path's allele, the raw local allele of every path.  Lane j fetches piece j and piece 16 + (j & 3)
+//   * records: 192 bytes per column (k_records, DevContig::smallx): the fifteen entries E(a, b), a <= b, of the column's
+//     (symmetric) emission table, a 16-byte header (local alleles, flags, wide entry, aux slot), the transition constants,
+//     the table-row offset (a + 1) * 48 of every path's allele.  Lane j fetches entry j (8 bytes) and piece 8 + (j & 3)
 //     three columns ahead (two global loads per lane and column where the biallelic kernel issues four) and parks them in
-//     the half-chain's LDS slot one step before the column is due; constants, header and row offsets come back as broadcast
-//     LDS reads a step ahead of use.
+//     the half-chain's LDS slot one step before the column is due — the entry at [a][b] and [b][a] of the slot's 6 x 6 table;
+//     constants, header and row offsets come back as broadcast LDS reads a step ahead of use.  (Round 5's first version
+//     carried the five table rows and the raw alleles: 320 bytes, an eighth of the sweep's traffic.)
 //   * emission of a state = E[a_k][a_j] = one v_add_u32_sdwa (the row's byte + the lane's table column) + one ds_read_b64
 //     (two issue slots; the biallelic select takes three), fetched during the step before it is used.  Row offset 0 = a row
 //     of zeros in front of the table: phantom alleles and the columns below.
@@ -27,19 +28,17 @@
 // Same stored columns, scales, fall-back rules and resume conventions as every other sweep kernel.
 #pragma once
 
-#define PG_XREC_BYTES 320u          // per column: pieces 0..14 = table rows 0..4, 15 = header, 16-17 = constants, 18 = row offsets, 19 = raw alleles
-#define PG_XREC_HDR 240u
-#define PG_XREC_CONSTS 256u
-#define PG_XREC_ROWOFF 288u
-#define PG_XREC_RAW 304u
-#define PG_XREC_FLAG_WIDE 0x200u    // header dword 1: nlocal | flags << 8 (PG_REC_FLAG_* << 8)
-// LDS slot of one record: a row of zeros, then the pieces
-#define PG_XSLOT_TABLE 48u          // pieces 0..15 at 48 + 16 p: table rows at (a + 1) * 48, header at 288
+#define PG_XREC_BYTES 192u          // per column: 15 table entries (tri_local order; a WIDE column: its sixteen raw alleles) + 8 bytes, then
+#define PG_XREC_HDR 128u            //   header {nlocal | flags << 8, wide entry / 16, aux slot / 16, 0},
+#define PG_XREC_CONSTS 144u         //   {c0, c1}, {c2, kappa},
+#define PG_XREC_ROWOFF 176u         //   the table-row offsets of the sixteen paths' alleles
+#define PG_XREC_FLAG_WIDE 0x200u    // header dword 0: nlocal | flags << 8 (PG_REC_FLAG_* << 8)
+// LDS slot of one record: a row of zeros, the 6 x 6 table (rows at (a + 1) * 48), then the four 16-byte pieces
+#define PG_XSLOT_TABLE 48u
 #define PG_XSLOT_HDR 288u
 #define PG_XSLOT_CONSTS 304u
 #define PG_XSLOT_ROWOFF 336u
-#define PG_XSLOT_RAW 352u
-#define PG_XSLOT_BYTES 384u
+#define PG_XSLOT_BYTES 352u
 
 typedef uint32_t v4u32 __attribute__((ext_vector_type(4)));   // native vector type (address-space qualifiable)
 struct SmallXShared {
@@ -47,14 +46,19 @@ struct SmallXShared {
     double red[4][PG_ESTRIDE][16];                         // phase 2: a multiallelic column's accumulators [half-chain][row allele][lane]; row PG_AMAX: zeros
     unsigned char rec[4][2][PG_XSLOT_BYTES] __attribute__((aligned(16)));   // [half-chain of the wave][column parity]
 };
-struct XPieces { v2f64 p0, p1; };
+struct XPieces { double p0; v2f64 p1; };
+// table entry p (tri_local order: rows of 5, 4, 3, 2, 1 entries) = E(a, b), a <= b
+DEVI void x_pair_of(uint32_t p, uint32_t& a, uint32_t& b) {
+    a = (p >= 5u ? 1u : 0u) + (p >= 9u ? 1u : 0u) + (p >= 12u ? 1u : 0u) + (p >= 14u ? 1u : 0u);
+    b = p - (a * (uint32_t)PG_AMAX - a * (a - 1u) / 2u) + a;
+}
 struct XConsts { double c0, c1, c2, kappa; };
 struct XCol {            // what a step needs of a column's record, read from LDS a step ahead
     uint32_t ro[4];      // row offsets of the sixteen paths' alleles (bytes)
     uint32_t ecol;       // LDS address of the lane's table column: slot + 8 * min(a_j, 5)
     uint32_t nlf;        // nlocal | flags << 8
     uint32_t widx, aux;  // wide entry offset / 16, aux slot offset / 16
-    uint32_t rawj;       // the lane's own local allele
+    uint32_t roj;        // the lane's own row offset: (its allele + 1) * 48, 0 = phantom / wide column
     uint32_t slot;       // LDS address of the record's slot
 };
 
@@ -62,13 +66,17 @@ DEVI XPieces load_xrec(gcdouble* xrec, int64_t c, int64_t C, uint32_t j) {   // 
     c = c < 0 ? 0 : (c >= C ? C - 1 : c);
     const GAS char* b = (const GAS char*)xrec + (size_t)c * PG_XREC_BYTES;
     XPieces r;
-    r.p0 = *(const GAS v2f64*)(b + 16u * j);
-    r.p1 = *(const GAS v2f64*)(b + PG_XREC_CONSTS + 16u * (j & 3u));
+    r.p0 = *(const GAS double*)(b + 8u * j);
+    r.p1 = *(const GAS v2f64*)(b + PG_XREC_HDR + 16u * (j & 3u));
     return r;
 }
-DEVI void park_xrec(uint32_t slot, uint32_t j, const XPieces& r) {
-    *(LAS v2f64*)(uintptr_t)(slot + PG_XSLOT_TABLE + 16u * j) = r.p0;
-    if (j < 4u) *(LAS v2f64*)(uintptr_t)(slot + PG_XSLOT_CONSTS + 16u * j) = r.p1;
+// tab_ab / tab_ba: where this lane's table entry goes inside a slot — [a][b] and [b][a] (lane 15: none)
+DEVI void park_xrec(uint32_t slot, uint32_t j, uint32_t tab_ab, uint32_t tab_ba, const XPieces& r) {
+    if (j < 15u) {
+        *(LAS double*)(uintptr_t)(slot + tab_ab) = r.p0;
+        *(LAS double*)(uintptr_t)(slot + tab_ba) = r.p0;   // (a == b: the same place again)
+    }
+    if (j < 4u) *(LAS v2f64*)(uintptr_t)(slot + PG_XSLOT_HDR + 16u * j) = r.p1;
 }
 DEVI XConsts read_xconsts(uint32_t slot) {
     const v2f64 a = *(LAS const v2f64*)(uintptr_t)(slot + PG_XSLOT_CONSTS), b = *(LAS const v2f64*)(uintptr_t)(slot + PG_XSLOT_CONSTS + 16u);
@@ -78,20 +86,23 @@ DEVI XCol read_xcol(uint32_t slot, uint32_t j) {
     XCol c;
     const v4u32 ro = *(LAS const v4u32*)(uintptr_t)(slot + PG_XSLOT_ROWOFF);
     const v4u32 hd = *(LAS const v4u32*)(uintptr_t)(slot + PG_XSLOT_HDR);
-    const uint32_t raw = *(LAS const unsigned char*)(uintptr_t)(slot + PG_XSLOT_RAW + j);
+    const uint32_t roj = *(LAS const unsigned char*)(uintptr_t)(slot + PG_XSLOT_ROWOFF + j);
     c.ro[0] = ro.x; c.ro[1] = ro.y; c.ro[2] = ro.z; c.ro[3] = ro.w;
-    c.nlf = hd.y; c.widx = hd.z; c.aux = hd.w;
-    c.rawj = raw;
-    c.ecol = slot + 8u * (raw < (uint32_t)PG_AMAX ? raw : (uint32_t)PG_AMAX);
+    c.nlf = hd.x; c.widx = hd.y; c.aux = hd.z;
+    c.roj = roj;
+    // the lane's table column: 8 * its allele = roj / 6 - 8 ((roj * 171) >> 10 is roj / 6 for the six values roj takes); phantom: column 5
+    c.ecol = slot + (roj ? ((roj * 171u) >> 10) - 8u : 8u * (uint32_t)PG_AMAX);
     c.slot = slot;
     return c;
 }
 template <int K>
 DEVI double x_emission(const XCol& c) { return *(LAS const double*)(uintptr_t)add_byte<(K & 3)>(c.ro[K >> 2], c.ecol); }
 
-// the emissions of a WIDE column's rows from the side table: E[a_k][a_j], S = nlocal + 1 doubles per row (pg_device.h)
-DEVI void x_wide_emissions(const XCol& c, const unsigned char* wide, bool mine, double (&ee)[16]) {
-    const v4u32 rw = *(LAS const v4u32*)(uintptr_t)(c.slot + PG_XSLOT_RAW);
+// the emissions of a WIDE column's rows from the side table: E[a_k][a_j], S = nlocal + 1 doubles per row (pg_device.h);
+// the sixteen raw local alleles of such a column travel where the (unused) table entries 0 and 1 do: slot bytes 48 .. 63
+DEVI void x_wide_emissions(const XCol& c, const unsigned char* wide, bool mine, uint32_t j, double (&ee)[16]) {
+    const v4u32 rw = *(LAS const v4u32*)(uintptr_t)(c.slot + PG_XSLOT_TABLE);
+    const uint32_t rawj = *(LAS const unsigned char*)(uintptr_t)(c.slot + PG_XSLOT_TABLE + j);
     const uint32_t raw[4] = {rw.x, rw.y, rw.z, rw.w};
     if (mine) {
         const uint32_t S = (c.nlf & 0xFFu) + 1u;
@@ -99,7 +110,7 @@ DEVI void x_wide_emissions(const XCol& c, const unsigned char* wide, bool mine, 
 #pragma unroll
         for (int k = 0; k < 16; ++k) {
             const uint32_t ak = (raw[k >> 2] >> (8 * (k & 3))) & 0xFFu;
-            ee[k] = Ew[(size_t)ak * S + c.rawj];
+            ee[k] = Ew[(size_t)ak * S + rawj];
         }
     }
 }
@@ -117,9 +128,10 @@ DEVI void smallx_init_shared(SmallXShared& sh, uint32_t lane) {
         sh.onehot[r][a] = (r > 0u && a == r - 1u && a < (uint32_t)PG_AMAX) ? 1.0 : 0.0;
     }
     // every record slot starts as zeros: the row of zeros in front of each table stays (nothing parks there), and the rows
-    // of the wave that carry no half-chain read zero offsets, not whatever the LDS held (8 slots x 384 bytes = 192 pieces)
+    // of the wave that carry no half-chain read zero offsets, not whatever the LDS held (8 slots x 352 bytes = 176 pieces);
+    // column 5 of every table row stays zero too (the entries parked cover [a][b], a, b < 5)
 #pragma unroll
-    for (uint32_t q = 0; q < 3u; ++q) *(v2f64*)(&sh.rec[0][0][0] + (lane + 64u * q) * 16u) = v2f64{0.0, 0.0};
+    for (uint32_t q = 0; q < 3u; ++q) if (lane + 64u * q < 8u * PG_XSLOT_BYTES / 16u) *(v2f64*)(&sh.rec[0][0][0] + (lane + 64u * q) * 16u) = v2f64{0.0, 0.0};
     sh.red[lane >> 4][PG_AMAX][lane & 15u] = 0.0;
     wave_sync_lds();
 }
@@ -135,7 +147,7 @@ DEVI void smallx_posterior_out(const SmallXCtx& cx, SmallXShared& sh, const XCol
                                const double (&acc)[PG_AMAX], const double (&colv)[16]) {
     const uint32_t nl = col.nlf & 0xFFu;
     const bool wide = (col.nlf & PG_XREC_FLAG_WIDE) != 0u;
-    const bool b1 = col.rawj == 1u;
+    const bool b1 = col.roj == 2u * (uint32_t)(PG_ESTRIDE * 8);   // the lane's column carries local allele 1
     const double s00 = row16_sum(b1 ? 0.0 : acc[0]), s01 = row16_sum(b1 ? acc[0] : 0.0);
     const double s10 = row16_sum(b1 ? 0.0 : acc[1]), s11 = row16_sum(b1 ? acc[1] : 0.0);
     if (act && !wide && nl <= 2u && j == 0) {
@@ -149,16 +161,15 @@ DEVI void smallx_posterior_out(const SmallXCtx& cx, SmallXShared& sh, const XCol
 #pragma unroll
         for (int a = 0; a < PG_AMAX; ++a) *(LAS double*)(uintptr_t)(red + (uint32_t)a * 128u + 8u * j) = acc[a];
         // this lane's bin p = j: {pa, pb}, pa <= pb (tri_local: rows of 5, 4, 3, 2, 1 entries)
-        const uint32_t pa = (j >= 5u ? 1u : 0u) + (j >= 9u ? 1u : 0u) + (j >= 12u ? 1u : 0u) + (j >= 14u ? 1u : 0u);
-        const uint32_t pb = j - (pa * (uint32_t)PG_AMAX - pa * (pa - 1u) / 2u) + pa;
+        uint32_t pa, pb;
+        x_pair_of(j, pa, pb);
         const uint32_t offa = red + pa * 128u, offb = red + pb * 128u, offz = red + (uint32_t)PG_AMAX * 128u;
-        const v4u32 rw = *(LAS const v4u32*)(uintptr_t)(col.slot + PG_XSLOT_RAW);
-        const uint32_t raw[4] = {rw.x, rw.y, rw.z, rw.w};
+        const uint32_t roa = (pa + 1u) * (uint32_t)(PG_ESTRIDE * 8), rob = (pb + 1u) * (uint32_t)(PG_ESTRIDE * 8);
         double sum = 0.0;
 #pragma unroll
         for (int l = 0; l < 16; ++l) {
-            const uint32_t al = (raw[l >> 2] >> (8 * (l & 3))) & 0xFFu;   // column allele of lane l
-            const uint32_t src = al == pb ? offa : (al == pa ? offb : offz);
+            const uint32_t al = (col.ro[l >> 2] >> (8 * (l & 3))) & 0xFFu;   // row offset of the column allele of lane l
+            const uint32_t src = al == rob ? offa : (al == roa ? offb : offz);
             sum += *(LAS const double*)(uintptr_t)(src + 8u * (uint32_t)l);
         }
         if (multi && j < (uint32_t)(PG_AMAX * (PG_AMAX + 1) / 2)) *((gdouble*)(cx.aux + (size_t)col.aux * 16u) + j) = sum;
@@ -212,11 +223,18 @@ DEVI void small16x_forward(const DevContig* contigs, const uint32_t* ids, uint32
     const uint32_t slot0 = (uint32_t)(uintptr_t)(LAS unsigned char*)&sh.rec[row][0][0];
     const uint32_t onehot = (uint32_t)(uintptr_t)(LAS unsigned char*)&sh.onehot[0][0];
     auto slot_of = [&](int64_t c) { return slot0 + ((uint32_t)c & 1u) * PG_XSLOT_BYTES; };
+    uint32_t tab_ab, tab_ba;
+    {
+        uint32_t pa, pb;
+        x_pair_of(j < 15u ? j : 14u, pa, pb);
+        tab_ab = PG_XSLOT_TABLE + pa * (uint32_t)(PG_ESTRIDE * 8) + pb * 8u;
+        tab_ba = PG_XSLOT_TABLE + pb * (uint32_t)(PG_ESTRIDE * 8) + pa * 8u;
+    }
     auto emissions = [&](const XCol& col, double (&ee)[R]) __attribute__((always_inline)) {
         static_for<0, R>([&](auto kc) __attribute__((always_inline)) { constexpr int k = decltype(kc)::value; ee[k] = x_emission<k>(col); });
         const bool wide = cx.live && (col.nlf & PG_XREC_FLAG_WIDE) != 0u;
         if (__any(wide)) {   // (uniform) some row's column is wide: its sixteen emissions from the side table
-            x_wide_emissions(col, cx.wide, wide, ee);
+            x_wide_emissions(col, cx.wide, wide, j, ee);
             __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0)
         }
     };
@@ -249,8 +267,8 @@ DEVI void small16x_forward(const DevContig* contigs, const uint32_t* ids, uint32
 #pragma unroll
     for (int k = 0; k < R; ++k) x[k] = 0.0;
     XCol prevcol{};
-    if (cx.live) park_xrec(slot_of((int64_t)first - 1), j, load_xrec(cx.xrec, (int64_t)first - 1, cx.C, j));
-    if (cx.live) park_xrec(slot_of((int64_t)first), j, load_xrec(cx.xrec, (int64_t)first, cx.C, j));
+    if (cx.live) park_xrec(slot_of((int64_t)first - 1), j, tab_ab, tab_ba, load_xrec(cx.xrec, (int64_t)first - 1, cx.C, j));
+    if (cx.live) park_xrec(slot_of((int64_t)first), j, tab_ab, tab_ba, load_xrec(cx.xrec, (int64_t)first, cx.C, j));
     {
         const XCol c0 = read_xcol(slot_of((int64_t)first - 1), j);
         double e0[R];
@@ -286,7 +304,7 @@ DEVI void small16x_forward(const DevContig* contigs, const uint32_t* ids, uint32
     auto step = [&](int n, XPieces& slot_rec, double (&vp)[PHASE == 2 ? R : 1]) __attribute__((always_inline)) {
         const int64_t t = (int64_t)first + n;
         const bool act = cx.live && t < cx.hi;
-        park_xrec(slot_of(t + 1), j, slot_rec);
+        park_xrec(slot_of(t + 1), j, tab_ab, tab_ba, slot_rec);
         if (cx.live) slot_rec = load_xrec(cx.xrec, t + 4, cx.C, j);
         double Cj = 0.0;
         static_for<0, R>([&](auto kc) __attribute__((always_inline)) { constexpr int k = decltype(kc)::value; x[k] = ee[k] * pp[k]; Cj += x[k]; });
@@ -335,7 +353,7 @@ DEVI void small16x_forward(const DevContig* contigs, const uint32_t* ids, uint32
         {
             const bool wide = act && (col.nlf & PG_XREC_FLAG_WIDE) != 0u;
             if (__any(wide)) {
-                x_wide_emissions(col, cx.wide, wide, ee);
+                x_wide_emissions(col, cx.wide, wide, j, ee);
                 __builtin_amdgcn_s_waitcnt(0x0F70);
             }
         }
@@ -419,18 +437,25 @@ DEVI void small16x_backward(const DevContig* contigs, const uint32_t* ids, uint3
     const uint32_t slot0 = (uint32_t)(uintptr_t)(LAS unsigned char*)&sh.rec[row][0][0];
     const uint32_t onehot = (uint32_t)(uintptr_t)(LAS unsigned char*)&sh.onehot[0][0];
     auto slot_of = [&](int64_t c) { return slot0 + ((uint32_t)c & 1u) * PG_XSLOT_BYTES; };
+    uint32_t tab_ab, tab_ba;
+    {
+        uint32_t pa, pb;
+        x_pair_of(j < 15u ? j : 14u, pa, pb);
+        tab_ab = PG_XSLOT_TABLE + pa * (uint32_t)(PG_ESTRIDE * 8) + pb * 8u;
+        tab_ba = PG_XSLOT_TABLE + pb * (uint32_t)(PG_ESTRIDE * 8) + pa * 8u;
+    }
     auto emissions = [&](const XCol& col, bool on, double (&e)[R]) __attribute__((always_inline)) {
         static_for<0, R>([&](auto kc) __attribute__((always_inline)) { constexpr int k = decltype(kc)::value; e[k] = x_emission<k>(col); });
         const bool wide = on && (col.nlf & PG_XREC_FLAG_WIDE) != 0u;
         if (__any(wide)) {
-            x_wide_emissions(col, cx.wide, wide, e);
+            x_wide_emissions(col, cx.wide, wide, j, e);
             __builtin_amdgcn_s_waitcnt(0x0F70);
         }
     };
     // records: column t0 + 1 (its emission enters the first step, its constants are those of the gap t0 -> t0 + 1) and
     // column t0 (alleles / table of the first step's own column)
-    if (cx.live) park_xrec(slot_of(t0 + 1), j, load_xrec(cx.xrec, t0 + 1, cx.C, j));
-    if (cx.live) park_xrec(slot_of(t0), j, load_xrec(cx.xrec, t0, cx.C, j));
+    if (cx.live) park_xrec(slot_of(t0 + 1), j, tab_ab, tab_ba, load_xrec(cx.xrec, t0 + 1, cx.C, j));
+    if (cx.live) park_xrec(slot_of(t0), j, tab_ab, tab_ba, load_xrec(cx.xrec, t0, cx.C, j));
     {
         const XCol c1 = read_xcol(slot_of(t0 + 1), j);
         double e1[R];
@@ -479,7 +504,7 @@ DEVI void small16x_backward(const DevContig* contigs, const uint32_t* ids, uint3
     auto step = [&](int n, XPieces& slot_rec, double (&vp)[PHASE == 2 ? R : 1]) __attribute__((always_inline)) {
         const int64_t t = t0 - n;
         const bool act = cx.live && t >= cx.lo;
-        park_xrec(slot_of(t - 1), j, slot_rec);
+        park_xrec(slot_of(t - 1), j, tab_ab, tab_ba, slot_rec);
         if (cx.live) slot_rec = load_xrec(cx.xrec, t - 4, cx.C, j);
         int es = exponent_of(Sy) - PG_BIAS_B;
         es = es < -900 ? -900 : es;
@@ -517,7 +542,7 @@ DEVI void small16x_backward(const DevContig* contigs, const uint32_t* ids, uint3
         {
             const bool wide = act && (col.nlf & PG_XREC_FLAG_WIDE) != 0u;
             if (__any(wide)) {
-                x_wide_emissions(col, cx.wide, wide, ee);
+                x_wide_emissions(col, cx.wide, wide, j, ee);
                 __builtin_amdgcn_s_waitcnt(0x0F70);
             }
         }
