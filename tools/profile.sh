@@ -4,7 +4,8 @@
 #   pass 2: --pmc FETCH_SIZE  (own pass)     -> HBM read  KiB per launch (doubled: the gfx950 correction, MI355X_MICROARCH.md)
 #   pass 3: --pmc WRITE_SIZE  (own pass)     -> HBM write KiB per launch
 #   SQ=1  : four more --pmc passes of SQ counters (issue / wait picture of the sweeps)
-#   UNITS=1: five more passes — TA busy / stalls, VMEM FIFO stalls (which unit bounds a sweep)
+#   UNITS=1: three more passes — TA busy / stalls, VMEM FIFO stalls (which unit bounds a sweep).  SLOW: the TA_* counters
+#            serialise the dispatches — ten minutes per workload on the cohorts; budget for it
 # usage: [SQ=1] [UNITS=1] tools/profile.sh <workload> <tag>
 #   <workload> = a main workload of bench.py (genome24_h64, chr22_h64, ...), `cohort_h64`, any key of bench.py's COHORTS_MORE
 #                (cohort_h16, cohort_h16m, cohort_h16w, cohort_h64m, cohort_h128, cohort_h17), `sampler` or `viterbi`
@@ -43,6 +44,9 @@ fi
 # keep the merge-back small: kernel trace rows are not needed, only stats + counters
 rm -f $OUT/*/*kernel_trace.csv $OUT/*/*agent_info.csv
 python tools/summarize_profile.py $OUT $R/gpurun_out/profiles/${TAG}_$W $W > /dev/null 2>&1
+# ... and the raw counter rows are in the summary now (a TA_* pass writes one row per instance and dispatch: hundreds of MB,
+# and gpurun refuses to copy back more than 64 MiB — round 5 lost a 22-minute capture that way)
+rm -rf $OUT/pmc_* $OUT/kt/*_domain_stats.csv
 cp $OUT/kt/kt_kernel_stats.csv $R/gpurun_out/profiles/${TAG}_${W}_kernel_stats.csv 2>/dev/null
 grep '^{' $OUT/kt.log | tail -1 > $R/gpurun_out/profiles/${TAG}_${W}_bench_under_rocprof.json 2>/dev/null
 head -40 $R/gpurun_out/profiles/${TAG}_${W}_summary.txt
