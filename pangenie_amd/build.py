@@ -11,7 +11,7 @@ ROOT = Path(__file__).resolve().parent.parent
 CSRC = ROOT / "pangenie_amd" / "csrc"
 HIP_LIB = CSRC / "libpangenie_hmm.so"
 HIP_SOURCES = [CSRC / "pg_kernels.hip", CSRC / "pg_shim.cpp", CSRC / "pg_gather.cpp", CSRC / "pg_sampler.hip", CSRC / "pg_viterbi.hip"]
-HIP_DEPS = HIP_SOURCES + [CSRC / "pg_device.h", CSRC / "pg_devmath.h", CSRC / "pg_experiments.h", ROOT / "include" / "pangenie_hmm.h", ROOT / "include" / "pangenie_sampler.h"]
+HIP_DEPS = HIP_SOURCES + [CSRC / "pg_device.h", CSRC / "pg_devmath.h", CSRC / "pg_small16x.h", CSRC / "pg_experiments.h", ROOT / "include" / "pangenie_hmm.h", ROOT / "include" / "pangenie_sampler.h"]
 
 
 def _stale(target: Path, deps) -> bool:

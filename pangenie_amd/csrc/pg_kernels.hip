@@ -4211,6 +4211,10 @@ struct SmallCtx {      // per lane: the half-chain of its DPP row
 template <int PHASE>
 DEVI void small16_forward(const DevContig* contigs, const uint32_t* ids, uint32_t n_ids, uint32_t chunk, double* dump) {
     constexpr int HP = 16, R = 16;
+    // records in flight: five in the store-only phases — a wave's loads and stores share one in-order counter, so waiting for
+    // a record caps the stores the wave may have in flight at the number issued since (pg_small16x.h; profiles/r05_small16x_ablation.txt);
+    // five: with six the kernel needs more than 256 registers, one wave per SIMD instead of two
+    constexpr int D = PHASE == 2 ? 3 : 5;
     const uint32_t lane = threadIdx.x & 63u, j = lane & 15u;
     const uint32_t slot = blockIdx.x * 4u + (lane >> 4);
     const size_t colsz = (size_t)HP * HP;
@@ -4308,7 +4312,7 @@ DEVI void small16_forward(const DevContig* contigs, const uint32_t* ids, uint32_
         const int64_t t = (int64_t)first + n;
         const bool act = cx.live && t < cx.hi;
         const FRec cur = slot_rec;                                   // (its fields move on; the variable takes the far record)
-        if (cx.live) slot_rec = load_frec(cx.frec, t + 3, cx.C);
+        if (cx.live) slot_rec = load_frec(cx.frec, t + D, cx.C);
         double Cj = 0.0;
         static_for<0, R>([&](auto kc) __attribute__((always_inline)) { constexpr int k = decltype(kc)::value; x[k] = ee[k] * pp[k]; Cj += x[k]; });
         double S = row16_sum(Cj);
@@ -4369,20 +4373,15 @@ DEVI void small16_forward(const DevContig* contigs, const uint32_t* ids, uint32_
             if (((uint32_t)t & 15u) == 15u || t + 1 == cx.hi) { if (j <= ((uint32_t)t & 15u) && (int64_t)((t & ~15ll) + j) >= (int64_t)first) cx.sc_a[(t & ~15ll) + j] = buf; }
         }
     };
-    FRec ra = cx.live ? load_frec(cx.frec, (int64_t)first, cx.C) : FRec{};
-    FRec rb_ = cx.live ? load_frec(cx.frec, (int64_t)first + 1, cx.C) : FRec{};
-    FRec rc_ = cx.live ? load_frec(cx.frec, (int64_t)first + 2, cx.C) : FRec{};
-    double va[PHASE == 2 ? R : 1], vb[PHASE == 2 ? R : 1], vc[PHASE == 2 ? R : 1];
-    if constexpr (PHASE == 2) { load_partner((int64_t)first, va); load_partner((int64_t)first + 1, vb); load_partner((int64_t)first + 2, vc); }
+    FRec rr[D];
+    static_for<0, D>([&](auto ic) __attribute__((always_inline)) { constexpr int i = decltype(ic)::value; rr[i] = cx.live ? load_frec(cx.frec, (int64_t)first + i, cx.C) : FRec{}; });
+    double vv[3][PHASE == 2 ? R : 1];
+    if constexpr (PHASE == 2) { load_partner((int64_t)first, vv[0]); load_partner((int64_t)first + 1, vv[1]); load_partner((int64_t)first + 2, vv[2]); }
     __builtin_amdgcn_s_waitcnt(0x0F70);   // (no load of the prologue in flight inside the loop: see lean_forward)
     int n = 0;
-    for (; n + 2 < n_steps; n += 3) {
-        step(n, ra, va);
-        step(n + 1, rb_, vb);
-        step(n + 2, rc_, vc);
-    }
-    if (n < n_steps) { step(n, ra, va); ++n; }
-    if (n < n_steps) { step(n, rb_, vb); ++n; }
+    for (; n + D - 1 < n_steps; n += D)
+        static_for<0, D>([&](auto ic) __attribute__((always_inline)) { constexpr int i = decltype(ic)::value; step(n + i, rr[i], vv[i % 3]); });
+    static_for<0, D - 1>([&](auto ic) __attribute__((always_inline)) { constexpr int i = decltype(ic)::value; if (n < n_steps) { step(n, rr[i], vv[i % 3]); ++n; } });
     {   // the last column of the rows that ran to the wave's last step may itself have summed to zero
         double Cj = 0.0;
 #pragma unroll
@@ -4395,6 +4394,7 @@ DEVI void small16_forward(const DevContig* contigs, const uint32_t* ids, uint32_
 template <int PHASE>
 DEVI void small16_backward(const DevContig* contigs, const uint32_t* ids, uint32_t n_ids, uint32_t chunk, double* dump) {
     constexpr int HP = 16, R = 16;
+    constexpr int D = PHASE == 2 ? 3 : 5;   // (see small16_forward)
     const uint32_t lane = threadIdx.x & 63u, j = lane & 15u;
     const uint32_t slot = blockIdx.x * 4u + (lane >> 4);
     const size_t colsz = (size_t)HP * HP;
@@ -4484,7 +4484,7 @@ DEVI void small16_backward(const DevContig* contigs, const uint32_t* ids, uint32
         const int64_t t = t0 - n;
         const bool act = cx.live && t >= cx.lo;
         const FRec cur = cur_rec;
-        if (cx.live) cur_rec = load_frec(cx.frec, t - 2, cx.C);
+        if (cx.live) cur_rec = load_frec(cx.frec, t + 1 - D, cx.C);
         int es = exponent_of(Sy) - PG_BIAS_B;
         es = es < -900 ? -900 : es;
         const double m = ldexp(Sy, -es - PG_BIAS_B);
@@ -4542,20 +4542,15 @@ DEVI void small16_backward(const DevContig* contigs, const uint32_t* ids, uint32
             }
         }
     };
-    FRec ra = cx.live ? load_frec(cx.frec, t0 + 1, cx.C) : FRec{};
-    FRec rb_ = cx.live ? load_frec(cx.frec, t0, cx.C) : FRec{};
-    FRec rc_ = cx.live ? load_frec(cx.frec, t0 - 1, cx.C) : FRec{};
-    double va[PHASE == 2 ? R : 1], vb[PHASE == 2 ? R : 1], vc[PHASE == 2 ? R : 1];
-    if constexpr (PHASE == 2) { load_partner(t0, va); load_partner(t0 - 1, vb); load_partner(t0 - 2, vc); }
+    FRec rr[D];   // rr[i] = record t0 + 1 - i: step n takes its constants from rr[n % D] (record t + 1), its emission from the next one (record t)
+    static_for<0, D>([&](auto ic) __attribute__((always_inline)) { constexpr int i = decltype(ic)::value; rr[i] = cx.live ? load_frec(cx.frec, t0 + 1 - i, cx.C) : FRec{}; });
+    double vv[3][PHASE == 2 ? R : 1];
+    if constexpr (PHASE == 2) { load_partner(t0, vv[0]); load_partner(t0 - 1, vv[1]); load_partner(t0 - 2, vv[2]); }
     __builtin_amdgcn_s_waitcnt(0x0F70);
     int n = 0;
-    for (; n + 2 < n_steps; n += 3) {
-        step(n, ra, rb_, va);
-        step(n + 1, rb_, rc_, vb);
-        step(n + 2, rc_, ra, vc);
-    }
-    if (n < n_steps) { step(n, ra, rb_, va); ++n; }
-    if (n < n_steps) { step(n, rb_, rc_, vb); ++n; }
+    for (; n + D - 1 < n_steps; n += D)
+        static_for<0, D>([&](auto ic) __attribute__((always_inline)) { constexpr int i = decltype(ic)::value; step(n + i, rr[i], rr[(i + 1) % D], vv[i % 3]); });
+    static_for<0, D - 1>([&](auto ic) __attribute__((always_inline)) { constexpr int i = decltype(ic)::value; if (n < n_steps) { step(n, rr[i], rr[(i + 1) % D], vv[i % 3]); ++n; } });
 }
 
 template <int PHASE>

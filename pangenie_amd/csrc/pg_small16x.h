@@ -184,6 +184,11 @@ DEVI void smallx_posterior_out(const SmallXCtx& cx, SmallXShared& sh, const XCol
 template <int PHASE>
 DEVI void small16x_forward(const DevContig* contigs, const uint32_t* ids, uint32_t n_ids, uint32_t chunk, double* dump, SmallXShared& sh) {
     constexpr int HP = 16, R = 16;
+    // Records in flight (steps between a record's loads and its parking).  The store-only phases keep SIX: a wave's loads and
+    // stores share one in-order counter, so waiting for a record caps the stores the wave may have in flight at the number
+    // issued since — at three steps (24 operations) that cap cost the store-bound phase 1 a third of its time
+    // (profiles/r05_small16x_ablation.txt: 14.6 ms, 9.9 without the wait).  Phase 2 waits for its partner columns anyway.
+    constexpr int D = PHASE == 2 ? 3 : 6;
     const uint32_t lane = threadIdx.x & 63u, j = lane & 15u, row = lane >> 4;
     const uint32_t slot_id = blockIdx.x * 4u + row;
     const size_t colsz = (size_t)HP * HP;
@@ -299,13 +304,13 @@ DEVI void small16x_forward(const DevContig* contigs, const uint32_t* ids, uint32
 #pragma unroll
     for (int k = 0; k < R; ++k) { ee[k] = 1.0; pp[k] = x[k]; }
     // One column step of the (up to) four half-chains.  `slot_rec` holds the pieces of column t + 1 (parked now, read back at
-    // the end of the step) and then takes those of column t + 4.  Rows whose half-chain is done (or absent) compute on
+    // the end of the step) and then takes those of column t + 1 + D.  Rows whose half-chain is done (or absent) compute on
     // whatever their registers hold and store nothing.
     auto step = [&](int n, XPieces& slot_rec, double (&vp)[PHASE == 2 ? R : 1]) __attribute__((always_inline)) {
         const int64_t t = (int64_t)first + n;
         const bool act = cx.live && t < cx.hi;
-        park_xrec(slot_of(t + 1), j, tab_ab, tab_ba, slot_rec);
-        if (cx.live) slot_rec = load_xrec(cx.xrec, t + 4, cx.C, j);
+        if (!(kXExp & 2u)) park_xrec(slot_of(t + 1), j, tab_ab, tab_ba, slot_rec);
+        if (cx.live && !(kXExp & 4u)) slot_rec = load_xrec(cx.xrec, t + 1 + D, cx.C, j);
         double Cj = 0.0;
         static_for<0, R>([&](auto kc) __attribute__((always_inline)) { constexpr int k = decltype(kc)::value; x[k] = ee[k] * pp[k]; Cj += x[k]; });
         double S = row16_sum(Cj);
@@ -333,20 +338,22 @@ DEVI void small16x_forward(const DevContig* contigs, const uint32_t* ids, uint32
         static_for<0, R>([&](auto kc) __attribute__((always_inline)) {
             constexpr int k = decltype(kc)::value;
             const double pk = fmac_row_bcast<k>(fma(c0s, x[k], ujs), ucol, sc);   // P'_t(k, j) 2^-es = c0 x + u_j + u_k
-            ee[k] = x_emission<k>(col);
+            ee[k] = (kXExp & 1u) ? 1.0 : x_emission<k>(col);
             pp[k] = pk;
             if constexpr (PHASE == 2) {
                 // posterior: P'_t beta'_t added by row allele — the weights are the one-hot row of the row's allele (exact 0 / 1)
                 const double pr = vp[k] * pk;
+                if constexpr (!(kXExp & 16u)) {
                 const uint32_t wa = add_byte<(k & 3)>(col.ro[k >> 2], onehot);
                 const v2f64 w01 = *(LAS const v2f64*)(uintptr_t)wa, w23 = *(LAS const v2f64*)(uintptr_t)(wa + 16u);
                 const double w4 = *(LAS const double*)(uintptr_t)(wa + 32u);
                 acc[0] = fma(pr, w01.x, acc[0]); acc[1] = fma(pr, w01.y, acc[1]);
                 acc[2] = fma(pr, w23.x, acc[2]); acc[3] = fma(pr, w23.y, acc[3]);
                 acc[4] = fma(pr, w4, acc[4]);
+                } else acc[0] += pr;
                 if constexpr ((k & 3) == 3) __builtin_amdgcn_sched_barrier(0);   // (the weight reads of at most four states in flight: hoisted together they took 160 registers)
             } else {
-                if constexpr (k & 1) dst[(size_t)(k >> 1) * HP] = v2f64{pprev, pk};
+                if constexpr (k & 1) { if (!(kXExp & 8u)) dst[(size_t)(k >> 1) * HP] = v2f64{pprev, pk}; else asm volatile("" :: "v"(pprev), "v"(pk)); }
                 else pprev = pk;
             }
         });
@@ -358,31 +365,29 @@ DEVI void small16x_forward(const DevContig* contigs, const uint32_t* ids, uint32
             }
         }
         if constexpr (PHASE == 2) {
-            smallx_posterior_out(cx, sh, col, act, t, j, row, acc, pp);
-            load_partner(t + 3, vp);
+            if (!(kXExp & 32u)) smallx_posterior_out(cx, sh, col, act, t, j, row, acc, pp);
+            else if (act && j == 0 && acc[0] + acc[1] + acc[2] + acc[3] + acc[4] == 1.2345) cx.part[t] = 0.0;
+            if (!(kXExp & 64u)) load_partner(t + 3, vp);
         }
         if (act) {   // the column's scale mantissa: sixteen columns collected in the row's lanes, one store per sixteen
             if (j == ((uint32_t)t & 15u)) buf = m;
             if (((uint32_t)t & 15u) == 15u || t + 1 == cx.hi) { if (j <= ((uint32_t)t & 15u) && (int64_t)((t & ~15ll) + j) >= (int64_t)first) cx.sc_a[(t & ~15ll) + j] = buf; }
         }
         prevcol = col;
-        cur = read_xconsts(slot_of(t + 1));
-        col = read_xcol(slot_of(t + 1), j);
+        if (!(kXExp & 2u)) {
+            cur = read_xconsts(slot_of(t + 1));
+            col = read_xcol(slot_of(t + 1), j);
+        }
     };
-    XPieces ra = cx.live ? load_xrec(cx.xrec, (int64_t)first + 1, cx.C, j) : XPieces{};
-    XPieces rb_ = cx.live ? load_xrec(cx.xrec, (int64_t)first + 2, cx.C, j) : XPieces{};
-    XPieces rc_ = cx.live ? load_xrec(cx.xrec, (int64_t)first + 3, cx.C, j) : XPieces{};
-    double va[PHASE == 2 ? R : 1], vb[PHASE == 2 ? R : 1], vc[PHASE == 2 ? R : 1];
-    if constexpr (PHASE == 2) { load_partner((int64_t)first, va); load_partner((int64_t)first + 1, vb); load_partner((int64_t)first + 2, vc); }
+    XPieces rr[D];
+    static_for<0, D>([&](auto ic) __attribute__((always_inline)) { constexpr int i = decltype(ic)::value; rr[i] = cx.live ? load_xrec(cx.xrec, (int64_t)first + 1 + i, cx.C, j) : XPieces{}; });
+    double vv[3][PHASE == 2 ? R : 1];
+    if constexpr (PHASE == 2) { load_partner((int64_t)first, vv[0]); load_partner((int64_t)first + 1, vv[1]); load_partner((int64_t)first + 2, vv[2]); }
     __builtin_amdgcn_s_waitcnt(0x0F70);   // (no load of the prologue in flight inside the loop: see lean_forward)
     int n = 0;
-    for (; n + 2 < n_steps; n += 3) {
-        step(n, ra, va);
-        step(n + 1, rb_, vb);
-        step(n + 2, rc_, vc);
-    }
-    if (n < n_steps) { step(n, ra, va); ++n; }
-    if (n < n_steps) { step(n, rb_, vb); ++n; }
+    for (; n + D - 1 < n_steps; n += D)
+        static_for<0, D>([&](auto ic) __attribute__((always_inline)) { constexpr int i = decltype(ic)::value; step(n + i, rr[i], vv[i % 3]); });
+    static_for<0, D - 1>([&](auto ic) __attribute__((always_inline)) { constexpr int i = decltype(ic)::value; if (n < n_steps) { step(n, rr[i], vv[i % 3]); ++n; } });
     {   // the last column of the rows that ran to the wave's last step may itself have summed to zero
         double Cj = 0.0;
 #pragma unroll
@@ -395,6 +400,11 @@ DEVI void small16x_forward(const DevContig* contigs, const uint32_t* ids, uint32
 template <int PHASE>
 DEVI void small16x_backward(const DevContig* contigs, const uint32_t* ids, uint32_t n_ids, uint32_t chunk, double* dump, SmallXShared& sh) {
     constexpr int HP = 16, R = 16;
+    // Records in flight (steps between a record's loads and its parking).  The store-only phases keep SIX: a wave's loads and
+    // stores share one in-order counter, so waiting for a record caps the stores the wave may have in flight at the number
+    // issued since — at three steps (24 operations) that cap cost the store-bound phase 1 a third of its time
+    // (profiles/r05_small16x_ablation.txt: 14.6 ms, 9.9 without the wait).  Phase 2 waits for its partner columns anyway.
+    constexpr int D = PHASE == 2 ? 3 : 6;
     const uint32_t lane = threadIdx.x & 63u, j = lane & 15u, row = lane >> 4;
     const uint32_t slot_id = blockIdx.x * 4u + row;
     const size_t colsz = (size_t)HP * HP;
@@ -500,12 +510,12 @@ DEVI void small16x_backward(const DevContig* contigs, const uint32_t* ids, uint3
         for (int k = 0; k < R; k += 2) { const v2f64 t = src[(size_t)(k >> 1) * HP]; v[k] = t.x; v[k + 1] = t.y; }
     };
     // step n: column t = t0 - n.  `cur` = constants of record t + 1, `col` = record t; `slot_rec` holds the pieces of record
-    // t - 1 (parked now into the slot record t + 1 leaves) and then takes those of record t - 4.
+    // t - 1 (parked now into the slot record t + 1 leaves) and then takes those of record t - 1 - D.
     auto step = [&](int n, XPieces& slot_rec, double (&vp)[PHASE == 2 ? R : 1]) __attribute__((always_inline)) {
         const int64_t t = t0 - n;
         const bool act = cx.live && t >= cx.lo;
-        park_xrec(slot_of(t - 1), j, tab_ab, tab_ba, slot_rec);
-        if (cx.live) slot_rec = load_xrec(cx.xrec, t - 4, cx.C, j);
+        if (!(kXExp & 2u)) park_xrec(slot_of(t - 1), j, tab_ab, tab_ba, slot_rec);
+        if (cx.live && !(kXExp & 4u)) slot_rec = load_xrec(cx.xrec, t - 1 - D, cx.C, j);
         int es = exponent_of(Sy) - PG_BIAS_B;
         es = es < -900 ? -900 : es;
         const double m = ldexp(Sy, -es - PG_BIAS_B);
@@ -523,19 +533,21 @@ DEVI void small16x_backward(const DevContig* contigs, const uint32_t* ids, uint3
         static_for<0, R>([&](auto kc) __attribute__((always_inline)) {
             constexpr int k = decltype(kc)::value;
             const double yk = fmac_row_bcast<k>(fma(k0, w[k], uj), ucol, one);  // beta'_t = k0 w + u_j + u_k
-            ee[k] = x_emission<k>(col);
+            ee[k] = (kXExp & 1u) ? 1.0 : x_emission<k>(col);
             pp[k] = yk;
             if constexpr (PHASE == 2) {   // (see small16x_forward)
                 const double pr = vp[k] * yk;
+                if constexpr (!(kXExp & 16u)) {
                 const uint32_t wa = add_byte<(k & 3)>(col.ro[k >> 2], onehot);
                 const v2f64 w01 = *(LAS const v2f64*)(uintptr_t)wa, w23 = *(LAS const v2f64*)(uintptr_t)(wa + 16u);
                 const double w4 = *(LAS const double*)(uintptr_t)(wa + 32u);
                 acc[0] = fma(pr, w01.x, acc[0]); acc[1] = fma(pr, w01.y, acc[1]);
                 acc[2] = fma(pr, w23.x, acc[2]); acc[3] = fma(pr, w23.y, acc[3]);
                 acc[4] = fma(pr, w4, acc[4]);
+                } else acc[0] += pr;
                 if constexpr ((k & 3) == 3) __builtin_amdgcn_sched_barrier(0);   // (the weight reads of at most four states in flight: hoisted together they took 160 registers)
             } else {
-                if constexpr (k & 1) dst[(size_t)(k >> 1) * HP] = v2f64{yprev, yk};
+                if constexpr (k & 1) { if (!(kXExp & 8u)) dst[(size_t)(k >> 1) * HP] = v2f64{yprev, yk}; else asm volatile("" :: "v"(yprev), "v"(yk)); }
                 else yprev = yk;
             }
         });
@@ -547,8 +559,9 @@ DEVI void small16x_backward(const DevContig* contigs, const uint32_t* ids, uint3
             }
         }
         if constexpr (PHASE == 2) {
-            smallx_posterior_out(cx, sh, col, act, t, j, row, acc, pp);
-            load_partner(t - 3, vp);
+            if (!(kXExp & 32u)) smallx_posterior_out(cx, sh, col, act, t, j, row, acc, pp);
+            else if (act && j == 0 && acc[0] + acc[1] + acc[2] + acc[3] + acc[4] == 1.2345) cx.part[t] = 0.0;
+            if (!(kXExp & 64u)) load_partner(t - 3, vp);
         }
         Sy = Snew;
         if (act && !(Snew > 0.0)) {
@@ -565,23 +578,20 @@ DEVI void small16x_backward(const DevContig* contigs, const uint32_t* ids, uint3
                 if (j >= q && c <= t0) { cx.sc_a[c] = bufA; cx.sc_b[c] = bufB; }
             }
         }
-        cur = read_xconsts(slot_of(t));        // constants of the gap t - 1 -> t (record t: still in its slot)
-        col = read_xcol(slot_of(t - 1), j);    // record t - 1, parked at the top of this step
+        if (!(kXExp & 2u)) {
+            cur = read_xconsts(slot_of(t));        // constants of the gap t - 1 -> t (record t: still in its slot)
+            col = read_xcol(slot_of(t - 1), j);    // record t - 1, parked at the top of this step
+        }
     };
-    XPieces ra = cx.live ? load_xrec(cx.xrec, t0 - 1, cx.C, j) : XPieces{};
-    XPieces rb_ = cx.live ? load_xrec(cx.xrec, t0 - 2, cx.C, j) : XPieces{};
-    XPieces rc_ = cx.live ? load_xrec(cx.xrec, t0 - 3, cx.C, j) : XPieces{};
-    double va[PHASE == 2 ? R : 1], vb[PHASE == 2 ? R : 1], vc[PHASE == 2 ? R : 1];
-    if constexpr (PHASE == 2) { load_partner(t0, va); load_partner(t0 - 1, vb); load_partner(t0 - 2, vc); }
+    XPieces rr[D];
+    static_for<0, D>([&](auto ic) __attribute__((always_inline)) { constexpr int i = decltype(ic)::value; rr[i] = cx.live ? load_xrec(cx.xrec, t0 - 1 - i, cx.C, j) : XPieces{}; });
+    double vv[3][PHASE == 2 ? R : 1];
+    if constexpr (PHASE == 2) { load_partner(t0, vv[0]); load_partner(t0 - 1, vv[1]); load_partner(t0 - 2, vv[2]); }
     __builtin_amdgcn_s_waitcnt(0x0F70);
     int n = 0;
-    for (; n + 2 < n_steps; n += 3) {
-        step(n, ra, va);
-        step(n + 1, rb_, vb);
-        step(n + 2, rc_, vc);
-    }
-    if (n < n_steps) { step(n, ra, va); ++n; }
-    if (n < n_steps) { step(n, rb_, vb); ++n; }
+    for (; n + D - 1 < n_steps; n += D)
+        static_for<0, D>([&](auto ic) __attribute__((always_inline)) { constexpr int i = decltype(ic)::value; step(n + i, rr[i], vv[i % 3]); });
+    static_for<0, D - 1>([&](auto ic) __attribute__((always_inline)) { constexpr int i = decltype(ic)::value; if (n < n_steps) { step(n, rr[i], vv[i % 3]); ++n; } });
 }
 
 template <int PHASE>
