@@ -9,11 +9,14 @@
 // not per chain or job ("what's missing" 1-2):
 //   * records: 192 bytes per column (k_records, DevContig::smallx): the fifteen entries E(a, b), a <= b, of the column's
 //     (symmetric) emission table, a 16-byte header (local alleles, flags, wide entry, aux slot), the transition constants,
-//     the table-row offset (a + 1) * 48 of every path's allele.  Lane j fetches entry j (8 bytes) and piece 8 + (j & 3)
-//     three columns ahead (two global loads per lane and column where the biallelic kernel issues four) and parks them in
-//     the half-chain's LDS slot one step before the column is due — the entry at [a][b] and [b][a] of the slot's 6 x 6 table;
-//     constants, header and row offsets come back as broadcast LDS reads a step ahead of use.  (Round 5's first version
-//     carried the five table rows and the raw alleles: 320 bytes, an eighth of the sweep's traffic.)
+//     the table-row offset (a + 1) * 48 of every path's allele.  Records reach the wave in BLOCKS of eight (phase 2: six)
+//     columns: the sixteen lanes of a row fetch their half-chain's 1.5 KB with six 16-byte loads once per block, a whole
+//     block ahead, and park them in an LDS staging ring; every step expands the next column's fifteen entries into the
+//     half-chain's 6 x 6 table slot (entry j at [a][b] and [b][a]) and reads its constants, header and row offsets straight
+//     from the staging ring, a step ahead of use.  (A record fetched per step — two loads per lane and column, three to six
+//     columns ahead — cost the store-bound phase 1 a third of its time, whatever the distance: 14.6 ms against 10.0 with
+//     the loads compiled out, profiles/r05_small16x_ablation*.txt — a trickle of small reads into a memory system that is
+//     streaming writes.  Round 5's first version also carried five table rows and the raw alleles: 320 bytes.)
 //   * emission of a state = E[a_k][a_j] = one v_add_u32_sdwa (the row's byte + the lane's table column) + one ds_read_b64
 //     (two issue slots; the biallelic select takes three), fetched during the step before it is used.  Row offset 0 = a row
 //     of zeros in front of the table: phantom alleles and the columns below.
@@ -33,20 +36,18 @@
 #define PG_XREC_CONSTS 144u         //   {c0, c1}, {c2, kappa},
 #define PG_XREC_ROWOFF 176u         //   the table-row offsets of the sixteen paths' alleles
 #define PG_XREC_FLAG_WIDE 0x200u    // header dword 0: nlocal | flags << 8 (PG_REC_FLAG_* << 8)
-// LDS slot of one record: a row of zeros, the 6 x 6 table (rows at (a + 1) * 48), then the four 16-byte pieces
+// LDS table slot of one column: a row of zeros, then the 6 x 6 table (rows at (a + 1) * 48; a wide column: its raw alleles at 48)
 #define PG_XSLOT_TABLE 48u
-#define PG_XSLOT_HDR 288u
-#define PG_XSLOT_CONSTS 304u
-#define PG_XSLOT_ROWOFF 336u
-#define PG_XSLOT_BYTES 352u
+#define PG_XSLOT_BYTES 336u
+#define PG_XBLOCK_MAX 8             // columns per record block (store-only phases: 8, phase 2: 6 — twice its partner-column rotation)
 
 typedef uint32_t v4u32 __attribute__((ext_vector_type(4)));   // native vector type (address-space qualifiable)
 struct SmallXShared {
     double onehot[PG_ESTRIDE][PG_ESTRIDE];                 // row 0: zeros; row a + 1: 1.0 at a (a < PG_AMAX) — the row-allele weights
     double red[4][PG_ESTRIDE][16];                         // phase 2: a multiallelic column's accumulators [half-chain][row allele][lane]; row PG_AMAX: zeros
-    unsigned char rec[4][2][PG_XSLOT_BYTES] __attribute__((aligned(16)));   // [half-chain of the wave][column parity]
+    unsigned char rec[4][2][PG_XSLOT_BYTES] __attribute__((aligned(16)));   // [half-chain of the wave][column parity]: table slots
+    unsigned char stg[4][2][PG_XBLOCK_MAX * PG_XREC_BYTES] __attribute__((aligned(16)));   // [half-chain][block parity]: record blocks as they lie in memory
 };
-struct XPieces { double p0; v2f64 p1; };
 // table entry p (tri_local order: rows of 5, 4, 3, 2, 1 entries) = E(a, b), a <= b
 DEVI void x_pair_of(uint32_t p, uint32_t& a, uint32_t& b) {
     a = (p >= 5u ? 1u : 0u) + (p >= 9u ? 1u : 0u) + (p >= 12u ? 1u : 0u) + (p >= 14u ? 1u : 0u);
@@ -59,34 +60,55 @@ struct XCol {            // what a step needs of a column's record, read from LD
     uint32_t nlf;        // nlocal | flags << 8
     uint32_t widx, aux;  // wide entry offset / 16, aux slot offset / 16
     uint32_t roj;        // the lane's own row offset: (its allele + 1) * 48, 0 = phantom / wide column
-    uint32_t slot;       // LDS address of the record's slot
+    uint32_t slot;       // LDS address of the column's table slot
 };
 
-DEVI XPieces load_xrec(gcdouble* xrec, int64_t c, int64_t C, uint32_t j) {   // (clamped: records past the end are never used)
-    c = c < 0 ? 0 : (c >= C ? C - 1 : c);
-    const GAS char* b = (const GAS char*)xrec + (size_t)c * PG_XREC_BYTES;
-    XPieces r;
-    r.p0 = *(const GAS double*)(b + 8u * j);
-    r.p1 = *(const GAS v2f64*)(b + PG_XREC_HDR + 16u * (j & 3u));
-    return r;
-}
-// tab_ab / tab_ba: where this lane's table entry goes inside a slot — [a][b] and [b][a] (lane 15: none)
-DEVI void park_xrec(uint32_t slot, uint32_t j, uint32_t tab_ab, uint32_t tab_ba, const XPieces& r) {
-    if (j < 15u) {
-        *(LAS double*)(uintptr_t)(slot + tab_ab) = r.p0;
-        *(LAS double*)(uintptr_t)(slot + tab_ba) = r.p0;   // (a == b: the same place again)
+// A block of BL records = BL * 12 pieces of 16 bytes, contiguous in memory (columns c0 .. c0 + BL - 1 of the half-chain's record
+// array, clamped to the array: a block may reach past either end — what is fetched there is never used): lane j of the row
+// takes the pieces j, j + 16, ... — NQ loads per lane and block.
+template <int BL>
+struct XBlock {
+    static constexpr int NP = BL * 12, NQ = (NP + 15) / 16;
+    v2f64 v[NQ];
+};
+template <int BL>
+DEVI void x_block_load(XBlock<BL>& b, gcdouble* xrec, int64_t c0, int64_t C, uint32_t j) {
+#pragma unroll
+    for (int q = 0; q < XBlock<BL>::NQ; ++q) {
+        const uint32_t g = j + 16u * (uint32_t)q;
+        if (XBlock<BL>::NP % 16 == 0 || g < (uint32_t)XBlock<BL>::NP) {
+            int64_t c = c0 + (int64_t)(g / 12u);
+            c = c < 0 ? 0 : (c >= C ? C - 1 : c);
+            b.v[q] = *(const GAS v2f64*)((const GAS char*)xrec + (size_t)c * PG_XREC_BYTES + 16u * (g % 12u));
+        }
     }
-    if (j < 4u) *(LAS v2f64*)(uintptr_t)(slot + PG_XSLOT_HDR + 16u * j) = r.p1;
 }
-DEVI XConsts read_xconsts(uint32_t slot) {
-    const v2f64 a = *(LAS const v2f64*)(uintptr_t)(slot + PG_XSLOT_CONSTS), b = *(LAS const v2f64*)(uintptr_t)(slot + PG_XSLOT_CONSTS + 16u);
+template <int BL>
+DEVI void x_block_park(const XBlock<BL>& b, uint32_t stg, uint32_t j) {   // stg: LDS address of the block's staging area
+#pragma unroll
+    for (int q = 0; q < XBlock<BL>::NQ; ++q) {
+        const uint32_t g = j + 16u * (uint32_t)q;
+        if (XBlock<BL>::NP % 16 == 0 || g < (uint32_t)XBlock<BL>::NP) *(LAS v2f64*)(uintptr_t)(stg + 16u * g) = b.v[q];
+    }
+}
+// the fifteen table entries of the staged record at `src` -> the 6 x 6 table of `slot`: entry j at [a][b] and [b][a] (lane 15:
+// none).  A wide column's entries 0 and 1 are its sixteen raw alleles: they land at slot + 48 .. 63, where x_wide_emissions reads them.
+DEVI void x_expand(uint32_t src, uint32_t slot, uint32_t j, uint32_t tab_ab, uint32_t tab_ba) {
+    if (j < 15u) {
+        const double e = *(LAS const double*)(uintptr_t)(src + 8u * j);
+        *(LAS double*)(uintptr_t)(slot + tab_ab) = e;
+        *(LAS double*)(uintptr_t)(slot + tab_ba) = e;   // (a == b: the same place again)
+    }
+}
+DEVI XConsts read_xconsts(uint32_t src) {   // src: LDS address of the staged record
+    const v2f64 a = *(LAS const v2f64*)(uintptr_t)(src + PG_XREC_CONSTS), b = *(LAS const v2f64*)(uintptr_t)(src + PG_XREC_CONSTS + 16u);
     return XConsts{a.x, a.y, b.x, b.y};
 }
-DEVI XCol read_xcol(uint32_t slot, uint32_t j) {
+DEVI XCol read_xcol(uint32_t src, uint32_t slot, uint32_t j) {   // src: the staged record, slot: the table slot its entries went to
     XCol c;
-    const v4u32 ro = *(LAS const v4u32*)(uintptr_t)(slot + PG_XSLOT_ROWOFF);
-    const v4u32 hd = *(LAS const v4u32*)(uintptr_t)(slot + PG_XSLOT_HDR);
-    const uint32_t roj = *(LAS const unsigned char*)(uintptr_t)(slot + PG_XSLOT_ROWOFF + j);
+    const v4u32 ro = *(LAS const v4u32*)(uintptr_t)(src + PG_XREC_ROWOFF);
+    const v4u32 hd = *(LAS const v4u32*)(uintptr_t)(src + PG_XREC_HDR);
+    const uint32_t roj = *(LAS const unsigned char*)(uintptr_t)(src + PG_XREC_ROWOFF + j);
     c.ro[0] = ro.x; c.ro[1] = ro.y; c.ro[2] = ro.z; c.ro[3] = ro.w;
     c.nlf = hd.x; c.widx = hd.y; c.aux = hd.z;
     c.roj = roj;
@@ -127,11 +149,10 @@ DEVI void smallx_init_shared(SmallXShared& sh, uint32_t lane) {
         const uint32_t r = lane / (uint32_t)PG_ESTRIDE, a = lane % (uint32_t)PG_ESTRIDE;
         sh.onehot[r][a] = (r > 0u && a == r - 1u && a < (uint32_t)PG_AMAX) ? 1.0 : 0.0;
     }
-    // every record slot starts as zeros: the row of zeros in front of each table stays (nothing parks there), and the rows
-    // of the wave that carry no half-chain read zero offsets, not whatever the LDS held (8 slots x 352 bytes = 176 pieces);
-    // column 5 of every table row stays zero too (the entries parked cover [a][b], a, b < 5)
-#pragma unroll
-    for (uint32_t q = 0; q < 3u; ++q) if (lane + 64u * q < 8u * PG_XSLOT_BYTES / 16u) *(v2f64*)(&sh.rec[0][0][0] + (lane + 64u * q) * 16u) = v2f64{0.0, 0.0};
+    // every table slot and the staging ring start as zeros: the row of zeros in front of each table and column 5 of its rows
+    // stay (the entries expanded cover [a][b], a, b < 5), and the rows of the wave that carry no half-chain read zero offsets,
+    // not whatever the LDS held
+    for (uint32_t q = lane; q < (uint32_t)(sizeof(sh.rec) + sizeof(sh.stg)) / 16u; q += 64u) *(v2f64*)(&sh.rec[0][0][0] + q * 16u) = v2f64{0.0, 0.0};
     sh.red[lane >> 4][PG_AMAX][lane & 15u] = 0.0;
     wave_sync_lds();
 }
@@ -181,14 +202,65 @@ DEVI void smallx_posterior_out(const SmallXCtx& cx, SmallXShared& sh, const XCol
     }
 }
 
+// The record pipeline of one role.  Records are numbered in the order the role meets them: rel 0 is the column whose emission
+// enters the first step (forward: first - 1, backward: t0 + 1), rel r the column r steps further (DIR = +1: first - 1 + r,
+// DIR = -1: t0 + 1 - r).  Block b = rel BL b .. BL b + BL - 1, a contiguous run of the half-chain's record array whichever the
+// direction; the staging ring keeps a block as it lies in memory, so rel r sits at position r % BL (forward) or BL - 1 - r % BL
+// (backward) of block r / BL.  Step n (uniform over the wave: every row counts from its own first column) needs rel n + 2 at
+// its end; the loop is unrolled by BL, so the phase of a step inside its block is static:
+//   (n + 2) % BL == BL - 1 : the block after this one — fetched at phase 0, BL - 1 steps ago — is parked;
+//   (n + 2) % BL == 0      : a new block is in use (parked a step ago); the loads of the next one are issued.
+template <int BL, int DIR>
+struct XPipe {
+    uint32_t stg0;      // LDS address of the row's staging ring
+    uint32_t slot0;     // ... of its two table slots
+    uint32_t tab_ab, tab_ba;
+    uint32_t j;
+    gcdouble* xrec;
+    int64_t origin, C;  // column of rel 0
+    bool live;
+    XBlock<BL> blk;
+    DEVI uint32_t staged(uint32_t rel) const {   // LDS address of the staged record rel (rel uniform)
+        const uint32_t b = rel / (uint32_t)BL, i = rel % (uint32_t)BL;
+        return stg0 + (b & 1u) * (uint32_t)(PG_XBLOCK_MAX * PG_XREC_BYTES) + (DIR > 0 ? i : (uint32_t)BL - 1u - i) * PG_XREC_BYTES;
+    }
+    DEVI uint32_t slot_of(uint32_t rel) const { return slot0 + (rel & 1u) * PG_XSLOT_BYTES; }
+    DEVI int64_t block_first_column(uint32_t b) const {   // lowest column of block b
+        return DIR > 0 ? origin + (int64_t)b * BL : origin - (int64_t)b * BL - (BL - 1);
+    }
+    DEVI void fetch(uint32_t b) { if (live && !(kXExp & 4u)) x_block_load<BL>(blk, xrec, block_first_column(b), C, j); }
+    DEVI void park(uint32_t b) const { x_block_park<BL>(blk, stg0 + (b & 1u) * (uint32_t)(PG_XBLOCK_MAX * PG_XREC_BYTES), j); }
+    DEVI void expand(uint32_t rel) const { x_expand(staged(rel), slot_of(rel), j, tab_ab, tab_ba); }
+    DEVI XConsts consts(uint32_t rel) const { return read_xconsts(staged(rel)); }
+    DEVI XCol column(uint32_t rel) const { return read_xcol(staged(rel), slot_of(rel), j); }
+    // what step n does for the pipeline, at its end (I = n % BL, static)
+    template <int I>
+    DEVI void advance(uint32_t n) {
+        constexpr int P = (I + 2) % BL;
+        if constexpr (P == BL - 1) park((n + 2u) / (uint32_t)BL + 1u);
+        if constexpr (P == 0) fetch((n + 2u) / (uint32_t)BL + 1u);
+    }
+    DEVI void init(SmallXShared& sh, uint32_t row, uint32_t lane_j, gcdouble* recs, int64_t origin_col, int64_t n_cols, bool on) {
+        j = lane_j; xrec = recs; origin = origin_col; C = n_cols; live = on;
+        stg0 = (uint32_t)(uintptr_t)(LAS unsigned char*)&sh.stg[row][0][0];
+        slot0 = (uint32_t)(uintptr_t)(LAS unsigned char*)&sh.rec[row][0][0];
+        uint32_t pa, pb;
+        x_pair_of(j < 15u ? j : 14u, pa, pb);
+        tab_ab = PG_XSLOT_TABLE + pa * (uint32_t)(PG_ESTRIDE * 8) + pb * 8u;
+        tab_ba = PG_XSLOT_TABLE + pb * (uint32_t)(PG_ESTRIDE * 8) + pa * 8u;
+#pragma unroll
+        for (int q = 0; q < XBlock<BL>::NQ; ++q) blk.v[q] = v2f64{0.0, 0.0};
+        // block 0 now, block 1 on its way (parked by step BL - 3)
+        if (live) x_block_load<BL>(blk, xrec, block_first_column(0), C, j);
+        park(0);
+        if (live) x_block_load<BL>(blk, xrec, block_first_column(1), C, j);
+    }
+};
+
 template <int PHASE>
 DEVI void small16x_forward(const DevContig* contigs, const uint32_t* ids, uint32_t n_ids, uint32_t chunk, double* dump, SmallXShared& sh) {
     constexpr int HP = 16, R = 16;
-    // Records in flight (steps between a record's loads and its parking).  The store-only phases keep SIX: a wave's loads and
-    // stores share one in-order counter, so waiting for a record caps the stores the wave may have in flight at the number
-    // issued since — at three steps (24 operations) that cap cost the store-bound phase 1 a third of its time
-    // (profiles/r05_small16x_ablation.txt: 14.6 ms, 9.9 without the wait).  Phase 2 waits for its partner columns anyway.
-    constexpr int D = PHASE == 2 ? 3 : 6;
+    constexpr int BL = PHASE == 2 ? 6 : 8;   // columns per record block (phase 2: a multiple of its partner-column rotation of three)
     const uint32_t lane = threadIdx.x & 63u, j = lane & 15u, row = lane >> 4;
     const uint32_t slot_id = blockIdx.x * 4u + row;
     const size_t colsz = (size_t)HP * HP;
@@ -225,16 +297,9 @@ DEVI void small16x_forward(const DevContig* contigs, const uint32_t* ids, uint32
     const int n_steps = __builtin_amdgcn_readfirstlane(wave_max_i32(cx.live ? (int)(cx.hi - (int64_t)first) : 0));   // (uniform) the longest of the four
     if (__builtin_amdgcn_readfirstlane(wave_max_i32(cx.live ? 1 : 0)) == 0) return;
     smallx_init_shared(sh, lane);
-    const uint32_t slot0 = (uint32_t)(uintptr_t)(LAS unsigned char*)&sh.rec[row][0][0];
     const uint32_t onehot = (uint32_t)(uintptr_t)(LAS unsigned char*)&sh.onehot[0][0];
-    auto slot_of = [&](int64_t c) { return slot0 + ((uint32_t)c & 1u) * PG_XSLOT_BYTES; };
-    uint32_t tab_ab, tab_ba;
-    {
-        uint32_t pa, pb;
-        x_pair_of(j < 15u ? j : 14u, pa, pb);
-        tab_ab = PG_XSLOT_TABLE + pa * (uint32_t)(PG_ESTRIDE * 8) + pb * 8u;
-        tab_ba = PG_XSLOT_TABLE + pb * (uint32_t)(PG_ESTRIDE * 8) + pa * 8u;
-    }
+    XPipe<BL, +1> pipe;
+    pipe.init(sh, row, j, cx.xrec, (int64_t)first - 1, cx.C, cx.live);   // rel r = column first - 1 + r
     auto emissions = [&](const XCol& col, double (&ee)[R]) __attribute__((always_inline)) {
         static_for<0, R>([&](auto kc) __attribute__((always_inline)) { constexpr int k = decltype(kc)::value; ee[k] = x_emission<k>(col); });
         const bool wide = cx.live && (col.nlf & PG_XREC_FLAG_WIDE) != 0u;
@@ -272,10 +337,10 @@ DEVI void small16x_forward(const DevContig* contigs, const uint32_t* ids, uint32
 #pragma unroll
     for (int k = 0; k < R; ++k) x[k] = 0.0;
     XCol prevcol{};
-    if (cx.live) park_xrec(slot_of((int64_t)first - 1), j, tab_ab, tab_ba, load_xrec(cx.xrec, (int64_t)first - 1, cx.C, j));
-    if (cx.live) park_xrec(slot_of((int64_t)first), j, tab_ab, tab_ba, load_xrec(cx.xrec, (int64_t)first, cx.C, j));
+    pipe.expand(0);
+    pipe.expand(1);
     {
-        const XCol c0 = read_xcol(slot_of((int64_t)first - 1), j);
+        const XCol c0 = pipe.column(0);
         double e0[R];
         emissions(c0, e0);
         prevcol = c0;
@@ -298,19 +363,18 @@ DEVI void small16x_forward(const DevContig* contigs, const uint32_t* ids, uint32
             }
         }
     }
-    XConsts cur = read_xconsts(slot_of((int64_t)first));   // column `first`: constants of the gap first-1 -> first
-    XCol col = read_xcol(slot_of((int64_t)first), j);      // ... its alleles, header, table
+    XConsts cur = pipe.consts(1);   // column `first`: constants of the gap first-1 -> first
+    XCol col = pipe.column(1);      // ... its alleles, header, table
     double ee[R], pp[R];   // x = ee pp (formed at the start of the next step, see lean_forward)
 #pragma unroll
     for (int k = 0; k < R; ++k) { ee[k] = 1.0; pp[k] = x[k]; }
-    // One column step of the (up to) four half-chains.  `slot_rec` holds the pieces of column t + 1 (parked now, read back at
-    // the end of the step) and then takes those of column t + 1 + D.  Rows whose half-chain is done (or absent) compute on
-    // whatever their registers hold and store nothing.
-    auto step = [&](int n, XPieces& slot_rec, double (&vp)[PHASE == 2 ? R : 1]) __attribute__((always_inline)) {
+    // One column step of the (up to) four half-chains: column t = first + n = rel n + 1; at its end the next column's record
+    // (rel n + 2) is expanded and read.  Rows whose half-chain is done (or absent) compute on whatever their registers hold
+    // and store nothing.
+    auto step = [&](int n, auto ic, double (&vp)[PHASE == 2 ? R : 1]) __attribute__((always_inline)) {
+        constexpr int I = decltype(ic)::value;   // n % BL
         const int64_t t = (int64_t)first + n;
         const bool act = cx.live && t < cx.hi;
-        if (!(kXExp & 2u)) park_xrec(slot_of(t + 1), j, tab_ab, tab_ba, slot_rec);
-        if (cx.live && !(kXExp & 4u)) slot_rec = load_xrec(cx.xrec, t + 1 + D, cx.C, j);
         double Cj = 0.0;
         static_for<0, R>([&](auto kc) __attribute__((always_inline)) { constexpr int k = decltype(kc)::value; x[k] = ee[k] * pp[k]; Cj += x[k]; });
         double S = row16_sum(Cj);
@@ -344,12 +408,12 @@ DEVI void small16x_forward(const DevContig* contigs, const uint32_t* ids, uint32
                 // posterior: P'_t beta'_t added by row allele — the weights are the one-hot row of the row's allele (exact 0 / 1)
                 const double pr = vp[k] * pk;
                 if constexpr (!(kXExp & 16u)) {
-                const uint32_t wa = add_byte<(k & 3)>(col.ro[k >> 2], onehot);
-                const v2f64 w01 = *(LAS const v2f64*)(uintptr_t)wa, w23 = *(LAS const v2f64*)(uintptr_t)(wa + 16u);
-                const double w4 = *(LAS const double*)(uintptr_t)(wa + 32u);
-                acc[0] = fma(pr, w01.x, acc[0]); acc[1] = fma(pr, w01.y, acc[1]);
-                acc[2] = fma(pr, w23.x, acc[2]); acc[3] = fma(pr, w23.y, acc[3]);
-                acc[4] = fma(pr, w4, acc[4]);
+                    const uint32_t wa = add_byte<(k & 3)>(col.ro[k >> 2], onehot);
+                    const v2f64 w01 = *(LAS const v2f64*)(uintptr_t)wa, w23 = *(LAS const v2f64*)(uintptr_t)(wa + 16u);
+                    const double w4 = *(LAS const double*)(uintptr_t)(wa + 32u);
+                    acc[0] = fma(pr, w01.x, acc[0]); acc[1] = fma(pr, w01.y, acc[1]);
+                    acc[2] = fma(pr, w23.x, acc[2]); acc[3] = fma(pr, w23.y, acc[3]);
+                    acc[4] = fma(pr, w4, acc[4]);
                 } else acc[0] += pr;
                 if constexpr ((k & 3) == 3) __builtin_amdgcn_sched_barrier(0);   // (the weight reads of at most four states in flight: hoisted together they took 160 registers)
             } else {
@@ -375,19 +439,18 @@ DEVI void small16x_forward(const DevContig* contigs, const uint32_t* ids, uint32
         }
         prevcol = col;
         if (!(kXExp & 2u)) {
-            cur = read_xconsts(slot_of(t + 1));
-            col = read_xcol(slot_of(t + 1), j);
+            pipe.template advance<I>((uint32_t)n);
+            pipe.expand((uint32_t)n + 2u);
+            cur = pipe.consts((uint32_t)n + 2u);
+            col = pipe.column((uint32_t)n + 2u);
         }
     };
-    XPieces rr[D];
-    static_for<0, D>([&](auto ic) __attribute__((always_inline)) { constexpr int i = decltype(ic)::value; rr[i] = cx.live ? load_xrec(cx.xrec, (int64_t)first + 1 + i, cx.C, j) : XPieces{}; });
     double vv[3][PHASE == 2 ? R : 1];
     if constexpr (PHASE == 2) { load_partner((int64_t)first, vv[0]); load_partner((int64_t)first + 1, vv[1]); load_partner((int64_t)first + 2, vv[2]); }
-    __builtin_amdgcn_s_waitcnt(0x0F70);   // (no load of the prologue in flight inside the loop: see lean_forward)
     int n = 0;
-    for (; n + D - 1 < n_steps; n += D)
-        static_for<0, D>([&](auto ic) __attribute__((always_inline)) { constexpr int i = decltype(ic)::value; step(n + i, rr[i], vv[i % 3]); });
-    static_for<0, D - 1>([&](auto ic) __attribute__((always_inline)) { constexpr int i = decltype(ic)::value; if (n < n_steps) { step(n, rr[i], vv[i % 3]); ++n; } });
+    for (; n + BL - 1 < n_steps; n += BL)
+        static_for<0, BL>([&](auto ic) __attribute__((always_inline)) { constexpr int i = decltype(ic)::value; step(n + i, ic, vv[i % 3]); });
+    static_for<0, BL - 1>([&](auto ic) __attribute__((always_inline)) { constexpr int i = decltype(ic)::value; if (n < n_steps) { step(n, ic, vv[i % 3]); ++n; } });
     {   // the last column of the rows that ran to the wave's last step may itself have summed to zero
         double Cj = 0.0;
 #pragma unroll
@@ -400,11 +463,7 @@ DEVI void small16x_forward(const DevContig* contigs, const uint32_t* ids, uint32
 template <int PHASE>
 DEVI void small16x_backward(const DevContig* contigs, const uint32_t* ids, uint32_t n_ids, uint32_t chunk, double* dump, SmallXShared& sh) {
     constexpr int HP = 16, R = 16;
-    // Records in flight (steps between a record's loads and its parking).  The store-only phases keep SIX: a wave's loads and
-    // stores share one in-order counter, so waiting for a record caps the stores the wave may have in flight at the number
-    // issued since — at three steps (24 operations) that cap cost the store-bound phase 1 a third of its time
-    // (profiles/r05_small16x_ablation.txt: 14.6 ms, 9.9 without the wait).  Phase 2 waits for its partner columns anyway.
-    constexpr int D = PHASE == 2 ? 3 : 6;
+    constexpr int BL = PHASE == 2 ? 6 : 8;   // (see small16x_forward)
     const uint32_t lane = threadIdx.x & 63u, j = lane & 15u, row = lane >> 4;
     const uint32_t slot_id = blockIdx.x * 4u + row;
     const size_t colsz = (size_t)HP * HP;
@@ -444,16 +503,9 @@ DEVI void small16x_backward(const DevContig* contigs, const uint32_t* ids, uint3
     const int n_steps = __builtin_amdgcn_readfirstlane(wave_max_i32(cx.live ? (int)(t0 - cx.lo + 1) : 0));
     if (__builtin_amdgcn_readfirstlane(wave_max_i32(cx.live ? 1 : 0)) == 0) return;
     smallx_init_shared(sh, lane);
-    const uint32_t slot0 = (uint32_t)(uintptr_t)(LAS unsigned char*)&sh.rec[row][0][0];
     const uint32_t onehot = (uint32_t)(uintptr_t)(LAS unsigned char*)&sh.onehot[0][0];
-    auto slot_of = [&](int64_t c) { return slot0 + ((uint32_t)c & 1u) * PG_XSLOT_BYTES; };
-    uint32_t tab_ab, tab_ba;
-    {
-        uint32_t pa, pb;
-        x_pair_of(j < 15u ? j : 14u, pa, pb);
-        tab_ab = PG_XSLOT_TABLE + pa * (uint32_t)(PG_ESTRIDE * 8) + pb * 8u;
-        tab_ba = PG_XSLOT_TABLE + pb * (uint32_t)(PG_ESTRIDE * 8) + pa * 8u;
-    }
+    XPipe<BL, -1> pipe;
+    pipe.init(sh, row, j, cx.xrec, t0 + 1, cx.C, cx.live);   // rel r = column t0 + 1 - r
     auto emissions = [&](const XCol& col, bool on, double (&e)[R]) __attribute__((always_inline)) {
         static_for<0, R>([&](auto kc) __attribute__((always_inline)) { constexpr int k = decltype(kc)::value; e[k] = x_emission<k>(col); });
         const bool wide = on && (col.nlf & PG_XREC_FLAG_WIDE) != 0u;
@@ -462,12 +514,12 @@ DEVI void small16x_backward(const DevContig* contigs, const uint32_t* ids, uint3
             __builtin_amdgcn_s_waitcnt(0x0F70);
         }
     };
-    // records: column t0 + 1 (its emission enters the first step, its constants are those of the gap t0 -> t0 + 1) and
-    // column t0 (alleles / table of the first step's own column)
-    if (cx.live) park_xrec(slot_of(t0 + 1), j, tab_ab, tab_ba, load_xrec(cx.xrec, t0 + 1, cx.C, j));
-    if (cx.live) park_xrec(slot_of(t0), j, tab_ab, tab_ba, load_xrec(cx.xrec, t0, cx.C, j));
+    // records: rel 0 = column t0 + 1 (its emission enters the first step, its constants are those of the gap t0 -> t0 + 1),
+    // rel 1 = column t0 (alleles / table of the first step's own column)
+    pipe.expand(0);
+    pipe.expand(1);
     {
-        const XCol c1 = read_xcol(slot_of(t0 + 1), j);
+        const XCol c1 = pipe.column(0);
         double e1[R];
         emissions(c1, cx.live, e1);
         if (cx.live) {
@@ -497,8 +549,8 @@ DEVI void small16x_backward(const DevContig* contigs, const uint32_t* ids, uint3
             for (int k = 0; k < R; ++k) { ee[k] = e1[k]; pp[k] = y[k]; }
         }
     }
-    XConsts cur = read_xconsts(slot_of(t0 + 1));   // constants of the gap t0 -> t0 + 1
-    XCol col = read_xcol(slot_of(t0), j);          // column t0: its alleles, header, table
+    XConsts cur = pipe.consts(0);   // constants of the gap t0 -> t0 + 1 (record t0 + 1)
+    XCol col = pipe.column(1);      // column t0: its alleles, header, table
     double one = 1.0, bufA = 0.0, bufB = 0.0;
     asm volatile("" : "+v"(one));
     // phase 2: the partner column P'_t of this lane's column, fetched three steps ahead (clamped: see small16x_forward)
@@ -509,13 +561,12 @@ DEVI void small16x_backward(const DevContig* contigs, const uint32_t* ids, uint3
 #pragma unroll
         for (int k = 0; k < R; k += 2) { const v2f64 t = src[(size_t)(k >> 1) * HP]; v[k] = t.x; v[k + 1] = t.y; }
     };
-    // step n: column t = t0 - n.  `cur` = constants of record t + 1, `col` = record t; `slot_rec` holds the pieces of record
-    // t - 1 (parked now into the slot record t + 1 leaves) and then takes those of record t - 1 - D.
-    auto step = [&](int n, XPieces& slot_rec, double (&vp)[PHASE == 2 ? R : 1]) __attribute__((always_inline)) {
+    // step n: column t = t0 - n = rel n + 1.  `cur` = constants of record t + 1 (rel n), `col` = record t; at the end of the step
+    // the constants of record t (rel n + 1: the gap t - 1 -> t) and record t - 1 (rel n + 2) are read.
+    auto step = [&](int n, auto ic, double (&vp)[PHASE == 2 ? R : 1]) __attribute__((always_inline)) {
+        constexpr int I = decltype(ic)::value;   // n % BL
         const int64_t t = t0 - n;
         const bool act = cx.live && t >= cx.lo;
-        if (!(kXExp & 2u)) park_xrec(slot_of(t - 1), j, tab_ab, tab_ba, slot_rec);
-        if (cx.live && !(kXExp & 4u)) slot_rec = load_xrec(cx.xrec, t - 1 - D, cx.C, j);
         int es = exponent_of(Sy) - PG_BIAS_B;
         es = es < -900 ? -900 : es;
         const double m = ldexp(Sy, -es - PG_BIAS_B);
@@ -538,14 +589,14 @@ DEVI void small16x_backward(const DevContig* contigs, const uint32_t* ids, uint3
             if constexpr (PHASE == 2) {   // (see small16x_forward)
                 const double pr = vp[k] * yk;
                 if constexpr (!(kXExp & 16u)) {
-                const uint32_t wa = add_byte<(k & 3)>(col.ro[k >> 2], onehot);
-                const v2f64 w01 = *(LAS const v2f64*)(uintptr_t)wa, w23 = *(LAS const v2f64*)(uintptr_t)(wa + 16u);
-                const double w4 = *(LAS const double*)(uintptr_t)(wa + 32u);
-                acc[0] = fma(pr, w01.x, acc[0]); acc[1] = fma(pr, w01.y, acc[1]);
-                acc[2] = fma(pr, w23.x, acc[2]); acc[3] = fma(pr, w23.y, acc[3]);
-                acc[4] = fma(pr, w4, acc[4]);
+                    const uint32_t wa = add_byte<(k & 3)>(col.ro[k >> 2], onehot);
+                    const v2f64 w01 = *(LAS const v2f64*)(uintptr_t)wa, w23 = *(LAS const v2f64*)(uintptr_t)(wa + 16u);
+                    const double w4 = *(LAS const double*)(uintptr_t)(wa + 32u);
+                    acc[0] = fma(pr, w01.x, acc[0]); acc[1] = fma(pr, w01.y, acc[1]);
+                    acc[2] = fma(pr, w23.x, acc[2]); acc[3] = fma(pr, w23.y, acc[3]);
+                    acc[4] = fma(pr, w4, acc[4]);
                 } else acc[0] += pr;
-                if constexpr ((k & 3) == 3) __builtin_amdgcn_sched_barrier(0);   // (the weight reads of at most four states in flight: hoisted together they took 160 registers)
+                if constexpr ((k & 3) == 3) __builtin_amdgcn_sched_barrier(0);
             } else {
                 if constexpr (k & 1) { if (!(kXExp & 8u)) dst[(size_t)(k >> 1) * HP] = v2f64{yprev, yk}; else asm volatile("" :: "v"(yprev), "v"(yk)); }
                 else yprev = yk;
@@ -579,19 +630,18 @@ DEVI void small16x_backward(const DevContig* contigs, const uint32_t* ids, uint3
             }
         }
         if (!(kXExp & 2u)) {
-            cur = read_xconsts(slot_of(t));        // constants of the gap t - 1 -> t (record t: still in its slot)
-            col = read_xcol(slot_of(t - 1), j);    // record t - 1, parked at the top of this step
+            pipe.template advance<I>((uint32_t)n);
+            pipe.expand((uint32_t)n + 2u);
+            cur = pipe.consts((uint32_t)n + 1u);   // record t: the gap t - 1 -> t
+            col = pipe.column((uint32_t)n + 2u);   // record t - 1
         }
     };
-    XPieces rr[D];
-    static_for<0, D>([&](auto ic) __attribute__((always_inline)) { constexpr int i = decltype(ic)::value; rr[i] = cx.live ? load_xrec(cx.xrec, t0 - 1 - i, cx.C, j) : XPieces{}; });
     double vv[3][PHASE == 2 ? R : 1];
     if constexpr (PHASE == 2) { load_partner(t0, vv[0]); load_partner(t0 - 1, vv[1]); load_partner(t0 - 2, vv[2]); }
-    __builtin_amdgcn_s_waitcnt(0x0F70);
     int n = 0;
-    for (; n + D - 1 < n_steps; n += D)
-        static_for<0, D>([&](auto ic) __attribute__((always_inline)) { constexpr int i = decltype(ic)::value; step(n + i, rr[i], vv[i % 3]); });
-    static_for<0, D - 1>([&](auto ic) __attribute__((always_inline)) { constexpr int i = decltype(ic)::value; if (n < n_steps) { step(n, rr[i], vv[i % 3]); ++n; } });
+    for (; n + BL - 1 < n_steps; n += BL)
+        static_for<0, BL>([&](auto ic) __attribute__((always_inline)) { constexpr int i = decltype(ic)::value; step(n + i, ic, vv[i % 3]); });
+    static_for<0, BL - 1>([&](auto ic) __attribute__((always_inline)) { constexpr int i = decltype(ic)::value; if (n < n_steps) { step(n, ic, vv[i % 3]); ++n; } });
 }
 
 template <int PHASE>
