@@ -129,7 +129,7 @@ def _sweep_phase(name: str):
     k_sweep<HP, R, VBUF, KEEPW, PHASE>, k_sweep_lean[_tri]<PHASE, R>, k_sweep_leanx<PHASE, HP>, k_sweep_small16[x]<PHASE>,
     k_sweep_generic<PHASE>."""
     import re
-    if name.startswith("void k_sweep_lean2<") or name.startswith("k_sweep_small16_p2("):  # phase 2 of triangle chains / of all-biallelic 16-path chains
+    if name.startswith("void k_sweep_lean2<"):  # phase 2 of triangle chains
         return 2
     m = re.match(r"void k_sweep_lean<(\d), ", name) or re.match(r"void k_sweep_lean_tri<(\d), ", name) or \
         re.match(r"void k_sweep_leanx<(\d), ", name) or re.match(r"void k_sweep_small16x?<(\d)>", name) or \

@@ -4214,9 +4214,7 @@ DEVI void small16_forward(const DevContig* contigs, const uint32_t* ids, uint32_
     // records in flight: five in the store-only phases — a wave's loads and stores share one in-order counter, so waiting for
     // a record caps the stores the wave may have in flight at the number issued since (pg_small16x.h; profiles/r05_small16x_ablation.txt);
     // five: with six the kernel needs more than 256 registers, one wave per SIMD instead of two
-    // phase 2: two records and two partner columns in flight — 230 registers, TWO waves per SIMD (at three deep the kernel
-    // took 282 and every SIMD ran its waves one after the other: the phase is bound by what one wave per SIMD can issue)
-    constexpr int D = PHASE == 2 ? 2 : 5, NV = PHASE == 2 ? 2 : 1;
+    constexpr int D = PHASE == 2 ? 3 : 5;
     const uint32_t lane = threadIdx.x & 63u, j = lane & 15u;
     const uint32_t slot = blockIdx.x * 4u + (lane >> 4);
     const size_t colsz = (size_t)HP * HP;
@@ -4368,7 +4366,7 @@ DEVI void small16_forward(const DevContig* contigs, const uint32_t* ids, uint32_
                 o[0] = v2f64{s00, s01};
                 o[1] = v2f64{s10, s11};
             }
-            load_partner(t + NV, vp);
+            load_partner(t + 3, vp);
         }
         if (act) {   // the column's scale mantissa: sixteen columns collected in the row's lanes, one store per sixteen
             if (j == ((uint32_t)t & 15u)) buf = m;
@@ -4377,13 +4375,13 @@ DEVI void small16_forward(const DevContig* contigs, const uint32_t* ids, uint32_
     };
     FRec rr[D];
     static_for<0, D>([&](auto ic) __attribute__((always_inline)) { constexpr int i = decltype(ic)::value; rr[i] = cx.live ? load_frec(cx.frec, (int64_t)first + i, cx.C) : FRec{}; });
-    double vv[NV][PHASE == 2 ? R : 1];
-    if constexpr (PHASE == 2) { load_partner((int64_t)first, vv[0]); load_partner((int64_t)first + 1, vv[1]); }
+    double vv[3][PHASE == 2 ? R : 1];
+    if constexpr (PHASE == 2) { load_partner((int64_t)first, vv[0]); load_partner((int64_t)first + 1, vv[1]); load_partner((int64_t)first + 2, vv[2]); }
     __builtin_amdgcn_s_waitcnt(0x0F70);   // (no load of the prologue in flight inside the loop: see lean_forward)
     int n = 0;
     for (; n + D - 1 < n_steps; n += D)
-        static_for<0, D>([&](auto ic) __attribute__((always_inline)) { constexpr int i = decltype(ic)::value; step(n + i, rr[i], vv[i % NV]); });
-    static_for<0, D - 1>([&](auto ic) __attribute__((always_inline)) { constexpr int i = decltype(ic)::value; if (n < n_steps) { step(n, rr[i], vv[i % NV]); ++n; } });
+        static_for<0, D>([&](auto ic) __attribute__((always_inline)) { constexpr int i = decltype(ic)::value; step(n + i, rr[i], vv[i % 3]); });
+    static_for<0, D - 1>([&](auto ic) __attribute__((always_inline)) { constexpr int i = decltype(ic)::value; if (n < n_steps) { step(n, rr[i], vv[i % 3]); ++n; } });
     {   // the last column of the rows that ran to the wave's last step may itself have summed to zero
         double Cj = 0.0;
 #pragma unroll
@@ -4396,7 +4394,7 @@ DEVI void small16_forward(const DevContig* contigs, const uint32_t* ids, uint32_
 template <int PHASE>
 DEVI void small16_backward(const DevContig* contigs, const uint32_t* ids, uint32_t n_ids, uint32_t chunk, double* dump) {
     constexpr int HP = 16, R = 16;
-    constexpr int D = PHASE == 2 ? 2 : 5, NV = PHASE == 2 ? 2 : 1;   // (see small16_forward)
+    constexpr int D = PHASE == 2 ? 3 : 5;   // (see small16_forward)
     const uint32_t lane = threadIdx.x & 63u, j = lane & 15u;
     const uint32_t slot = blockIdx.x * 4u + (lane >> 4);
     const size_t colsz = (size_t)HP * HP;
@@ -4526,7 +4524,7 @@ DEVI void small16_backward(const DevContig* contigs, const uint32_t* ids, uint32
                 o[0] = v2f64{s00, s01};
                 o[1] = v2f64{s10, s11};
             }
-            load_partner(t - NV, vp);
+            load_partner(t - 3, vp);
         }
         Sy = Snew;
         if (act && !(Snew > 0.0)) {
@@ -4546,13 +4544,13 @@ DEVI void small16_backward(const DevContig* contigs, const uint32_t* ids, uint32
     };
     FRec rr[D];   // rr[i] = record t0 + 1 - i: step n takes its constants from rr[n % D] (record t + 1), its emission from the next one (record t)
     static_for<0, D>([&](auto ic) __attribute__((always_inline)) { constexpr int i = decltype(ic)::value; rr[i] = cx.live ? load_frec(cx.frec, t0 + 1 - i, cx.C) : FRec{}; });
-    double vv[NV][PHASE == 2 ? R : 1];
-    if constexpr (PHASE == 2) { load_partner(t0, vv[0]); load_partner(t0 - 1, vv[1]); }
+    double vv[3][PHASE == 2 ? R : 1];
+    if constexpr (PHASE == 2) { load_partner(t0, vv[0]); load_partner(t0 - 1, vv[1]); load_partner(t0 - 2, vv[2]); }
     __builtin_amdgcn_s_waitcnt(0x0F70);
     int n = 0;
     for (; n + D - 1 < n_steps; n += D)
-        static_for<0, D>([&](auto ic) __attribute__((always_inline)) { constexpr int i = decltype(ic)::value; step(n + i, rr[i], rr[(i + 1) % D], vv[i % NV]); });
-    static_for<0, D - 1>([&](auto ic) __attribute__((always_inline)) { constexpr int i = decltype(ic)::value; if (n < n_steps) { step(n, rr[i], rr[(i + 1) % D], vv[i % NV]); ++n; } });
+        static_for<0, D>([&](auto ic) __attribute__((always_inline)) { constexpr int i = decltype(ic)::value; step(n + i, rr[i], rr[(i + 1) % D], vv[i % 3]); });
+    static_for<0, D - 1>([&](auto ic) __attribute__((always_inline)) { constexpr int i = decltype(ic)::value; if (n < n_steps) { step(n, rr[i], rr[(i + 1) % D], vv[i % 3]); ++n; } });
 }
 
 template <int PHASE>
@@ -4560,12 +4558,6 @@ __global__ __launch_bounds__(64) void k_sweep_small16(const DevContig* __restric
                                                       double* dump) {
     if (blockIdx.y == 0) small16_forward<PHASE>(contigs, ids, n_ids, chunk, dump);
     else small16_backward<PHASE>(contigs, ids, n_ids, chunk, dump);
-}
-// phase 2 of the same kernel, held to 256 registers: two waves per SIMD
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2)))
-void k_sweep_small16_p2(const DevContig* __restrict__ contigs, const uint32_t* __restrict__ ids, uint32_t n_ids, uint32_t chunk, double* dump) {
-    if (blockIdx.y == 0) small16_forward<2>(contigs, ids, n_ids, chunk, dump);
-    else small16_backward<2>(contigs, ids, n_ids, chunk, dump);
 }
 #include "pg_small16x.h"   // k_sweep_small16x: the same step with table emissions — 16-path chains with multiallelic objects, wide columns per column
 
@@ -5624,7 +5616,7 @@ void pgk_launch_sweep_small(const DevContig* d_contigs, const uint32_t* d_ids, u
     if (n_ids == 0) return;
     const dim3 grid((n_ids + 3u) / 4u, 2);
     if (phase == 1) hipLaunchKernelGGL(k_sweep_small16<1>, grid, dim3(64), 0, s, d_contigs, d_ids, n_ids, chunk, d_dump);
-    else if (phase == 2) hipLaunchKernelGGL(k_sweep_small16_p2, grid, dim3(64), 0, s, d_contigs, d_ids, n_ids, chunk, d_dump);
+    else if (phase == 2) hipLaunchKernelGGL(k_sweep_small16<2>, grid, dim3(64), 0, s, d_contigs, d_ids, n_ids, chunk, d_dump);
     else hipLaunchKernelGGL(k_sweep_small16<3>, grid, dim3(64), 0, s, d_contigs, d_ids, n_ids, chunk, d_dump);
 }
 // ... and of the H = 16 chains with multiallelic objects (DevContig::smallx): k_sweep_small16x
