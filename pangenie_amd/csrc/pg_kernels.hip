@@ -859,9 +859,9 @@ DEVI void prep_m4_unit(const DevContig& dc, const DevTable& tab, uint32_t unit) 
     const uint32_t k0 = dc.kmer_off[v], K = dc.kmer_off[v + 1] - k0, cov = dc.cov[v];
     double* lm = s_m[wv][grp];
     int* le = s_e[wv][grp];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const uint32_t k = 16u * (uint32_t)i + l;
+    const uint32_t rounds = ((uint32_t)__builtin_amdgcn_readfirstlane(wave_max_i32((int)K)) + 15u) / 16u;   // (uniform: the wave's largest object)
+    for (uint32_t i = 0; i < rounds; ++i) {
+        const uint32_t k = 16u * i + l;
         if (k < K) {
             double m[3]; int e[3];
             cn_lookup(tab, cov, dc.kmer_count[k0 + k], m, e);
@@ -887,8 +887,11 @@ DEVI void prep_m4_unit(const DevContig& dc, const DevTable& tab, uint32_t unit) 
     double pm = 1.0;
     int pe = 0;
     if (active) {
-        for (uint32_t k = 0; k < K; ++k) {
-            const uint32_t c = kmer_on(off1, mask1, k) + kmer_on(off2, mask2, k);
+        // (k-mer k lies on an allele <=> bit k - off of its mask, 0 <= k - off < 32: as a 64-bit word, K <= 64 — two shifts and an
+        //  add per k-mer where kmer_on took a dozen instructions)
+        unsigned long long M1 = off1 < 64u ? (unsigned long long)mask1 << off1 : 0ull, M2 = off2 < 64u ? (unsigned long long)mask2 << off2 : 0ull;
+        for (uint32_t k = 0; k < K; ++k, M1 >>= 1, M2 >>= 1) {
+            const uint32_t c = (uint32_t)(M1 & 1ull) + (uint32_t)(M2 & 1ull);
             double fm; int fe;
             if (u1 && u2) mix3(lm + k * 3, le + k * 3, 1.0 / 3.0, fm, fe);
             else if (u1 || u2) {
