@@ -66,6 +66,14 @@ static inline uint64_t pg_wide_entry_bytes(uint32_t n_local) {
 #define PG_WIDE_OFF_PE(S) ((size_t)(S) * (S) * 16)
 #define PG_WIDE_OFF_SLOT(S) ((size_t)(S) * (S) * 20)
 
+// Chunked mode: the store-only chunk sweeps of phase 2 write into PG_SCRATCH_BUFS rotating scratch buffers (two roles each),
+// k_post reads a finished one from a second stream.  Three (round 5; two before): with two, sweep i + 2 had to wait for the
+// posteriors of chunk i, and while all chains of a genome are still running k_post takes longer than a sweep (3.0 against
+// 2.7 ms on genome24_h64) — 6 ms of idle gaps between the 50 chunk sweeps (profiles/r05_genome24_timeline.txt); with three the
+// early deficit is worked off once the short chains have ended.
+#define PG_SCRATCH_BUFS 3u
+#define PG_SCR_BUF(c) ((c) % PG_SCRATCH_BUFS)
+
 // Column biases: stored forward columns (before the emission multiply) sum to about
 // 2^PG_BIAS_F, stored backward columns to about 2^PG_BIAS_B times their emission-weighted mass.
 #define PG_BIAS_F 400
@@ -127,7 +135,7 @@ struct DevContig {
     double*   bsum;          // [V] sum of the stored backward column (hand-over between the phases)
     uint8_t*  fwd_fallback;  // [V] column c fell back to the uniform forward column (fsum := 1, no emission scale)
     // chunked mode (few chains, see pg_shim.cpp): phase 2 is run in chunks of chunk_cols columns per
-    // half-chain that only STORE their columns into this scratch ([2 buffers][2 roles][chunk_cols][HP*HP],
+    // half-chain that only STORE their columns into this scratch ([PG_SCRATCH_BUFS buffers][2 roles][chunk_cols][HP*HP],
     // forward role first); k_post forms the posteriors of a finished chunk on the idle CUs.
     double*   scratch;
     uint32_t  chunk_cols;

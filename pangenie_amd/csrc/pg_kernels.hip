@@ -1829,8 +1829,8 @@ DEVI void forward_body(const DevContig& dc, ChainShared<HP, R>& sh, uint32_t C, 
     gcdouble* resume = (gcdouble*)(fwd + (size_t)(lo > 0 ? lo - 1 : 0) * colsz);
     if constexpr (PHASE == 3) {
         gdouble* scr = (gdouble*)dc.scratch;
-        wr = scr + (size_t)((chunk & 1u) * 2u) * K * colsz - (size_t)lo * colsz;
-        if (chunk > 0) resume = (gcdouble*)(scr + ((size_t)(((chunk - 1u) & 1u) * 2u) * K + (K - 1u)) * colsz);
+        wr = scr + (size_t)(PG_SCR_BUF(chunk) * 2u) * K * colsz - (size_t)lo * colsz;
+        if (chunk > 0) resume = (gcdouble*)(scr + ((size_t)(PG_SCR_BUF(chunk - 1u) * 2u) * K + (K - 1u)) * colsz);
     }
     auto store_col = [&](uint32_t c, const double (&x)[R]) {
         if (kExp & 1u) return;
@@ -2259,8 +2259,8 @@ DEVI void backward_body(const DevContig& dc, ChainShared<HP, R>& sh, uint32_t C,
     gcdouble* resume = (gcdouble*)(cols + (size_t)(top + 1 < (int64_t)C ? top + 1 : top) * colsz);
     if constexpr (PHASE == 3) {
         gdouble* scr = (gdouble*)dc.scratch;
-        wr = scr + (size_t)((chunk & 1u) * 2u + 1u) * (size_t)K * colsz - (size_t)bot * colsz;
-        if (chunk > 0) resume = (gcdouble*)(scr + (size_t)(((chunk - 1u) & 1u) * 2u + 1u) * (size_t)K * colsz);  // its slot 0
+        wr = scr + (size_t)(PG_SCR_BUF(chunk) * 2u + 1u) * (size_t)K * colsz - (size_t)bot * colsz;
+        if (chunk > 0) resume = (gcdouble*)(scr + (size_t)(PG_SCR_BUF(chunk - 1u) * 2u + 1u) * (size_t)K * colsz);  // its slot 0
     }
     auto load_col = [&](int64_t c, double (&v)[R]) {
         if (c < 0) return;
@@ -2867,8 +2867,8 @@ DEVI void lean_forward(const DevContig& dc, LeanShared<R>& sh, uint32_t C, uint3
     gcdouble* resume = (gcdouble*)(fwd + (size_t)(lo > 0 ? lo - 1 : 0) * colsz);
     if constexpr (PHASE == 3) {
         gdouble* scr = (gdouble*)dc.scratch;
-        wr = scr + (size_t)((chunk & 1u) * 2u) * K * colsz - (size_t)lo * colsz;
-        if (chunk > 0) resume = (gcdouble*)(scr + ((size_t)(((chunk - 1u) & 1u) * 2u) * K + (K - 1u)) * colsz);
+        wr = scr + (size_t)(PG_SCR_BUF(chunk) * 2u) * K * colsz - (size_t)lo * colsz;
+        if (chunk > 0) resume = (gcdouble*)(scr + ((size_t)(PG_SCR_BUF(chunk - 1u) * 2u) * K + (K - 1u)) * colsz);
     }
     const size_t toff = (size_t)(i0 >> 1) * HP + lane;  // this thread's first row pair inside a column (in 16-byte units)
     auto emis = [&](const FRec& r, double& eA, double& eB) {  // e(i, j) = row bit ? eB : eA for this lane's column allele
@@ -3088,8 +3088,8 @@ DEVI void lean_backward(const DevContig& dc, LeanShared<R>& sh, uint32_t C, uint
     gcdouble* resume = (gcdouble*)(cols + (size_t)(top + 1 < (int64_t)C ? top + 1 : top) * colsz);
     if constexpr (PHASE == 3) {
         gdouble* scr = (gdouble*)dc.scratch;
-        wr = scr + (size_t)((chunk & 1u) * 2u + 1u) * (size_t)K * colsz - (size_t)bot * colsz;
-        if (chunk > 0) resume = (gcdouble*)(scr + (size_t)(((chunk - 1u) & 1u) * 2u + 1u) * (size_t)K * colsz);
+        wr = scr + (size_t)(PG_SCR_BUF(chunk) * 2u + 1u) * (size_t)K * colsz - (size_t)bot * colsz;
+        if (chunk > 0) resume = (gcdouble*)(scr + (size_t)(PG_SCR_BUF(chunk - 1u) * 2u + 1u) * (size_t)K * colsz);
     }
     const size_t toff = (size_t)(i0 >> 1) * HP + lane;
     auto emis = [&](const FRec& r, double& eA, double& eB) {
@@ -3817,8 +3817,8 @@ DEVI void leanx_forward(const DevContig& dc, LxShared<HP>& sh, uint32_t C, uint3
     gcdouble* resume = (gcdouble*)(fwd + (size_t)(lo > 0 ? lo - 1 : 0) * colsz);
     if constexpr (PHASE == 3) {
         gdouble* scr = (gdouble*)dc.scratch;
-        wr = scr + (size_t)((chunk & 1u) * 2u) * K * colsz - (size_t)lo * colsz;
-        if (chunk > 0) resume = (gcdouble*)(scr + ((size_t)(((chunk - 1u) & 1u) * 2u) * K + (K - 1u)) * colsz);
+        wr = scr + (size_t)(PG_SCR_BUF(chunk) * 2u) * K * colsz - (size_t)lo * colsz;
+        if (chunk > 0) resume = (gcdouble*)(scr + ((size_t)(PG_SCR_BUF(chunk - 1u) * 2u) * K + (K - 1u)) * colsz);
     }
     const size_t toff = (size_t)(i0 >> 1) * HP + j;  // this thread's first row pair inside a column (in 16-byte units)
     // the stores of a step: R/8 per-thread pointers (four row pairs each, reached by immediates), advanced by one column
@@ -4002,8 +4002,8 @@ DEVI void leanx_backward(const DevContig& dc, LxShared<HP>& sh, uint32_t C, uint
     gcdouble* resume = (gcdouble*)(cols + (size_t)(top + 1 < (int64_t)C ? top + 1 : top) * colsz);
     if constexpr (PHASE == 3) {
         gdouble* scr = (gdouble*)dc.scratch;
-        wr = scr + (size_t)((chunk & 1u) * 2u + 1u) * (size_t)K * colsz - (size_t)bot * colsz;
-        if (chunk > 0) resume = (gcdouble*)(scr + (size_t)(((chunk - 1u) & 1u) * 2u + 1u) * (size_t)K * colsz);
+        wr = scr + (size_t)(PG_SCR_BUF(chunk) * 2u + 1u) * (size_t)K * colsz - (size_t)bot * colsz;
+        if (chunk > 0) resume = (gcdouble*)(scr + (size_t)(PG_SCR_BUF(chunk - 1u) * 2u + 1u) * (size_t)K * colsz);
     }
     const size_t toff = (size_t)(i0 >> 1) * HP + j;
     GAS char* sp[R / 8];   // (see leanx_forward; filled in below, once `wr` is known)
@@ -4245,8 +4245,8 @@ DEVI void small16_forward(const DevContig* contigs, const uint32_t* ids, uint32_
             cx.resume = (gcdouble*)(fwd + (size_t)(lo > 0 ? lo - 1 : 0) * colsz);
             if constexpr (PHASE == 3) {
                 gdouble* scr = (gdouble*)dc.scratch;
-                cx.wr = scr + (size_t)((chunk & 1u) * 2u) * K * colsz - (size_t)lo * colsz;
-                if (chunk > 0) cx.resume = (gcdouble*)(scr + ((size_t)(((chunk - 1u) & 1u) * 2u) * K + (K - 1u)) * colsz);
+                cx.wr = scr + (size_t)(PG_SCR_BUF(chunk) * 2u) * K * colsz - (size_t)lo * colsz;
+                if (chunk > 0) cx.resume = (gcdouble*)(scr + ((size_t)(PG_SCR_BUF(chunk - 1u) * 2u) * K + (K - 1u)) * colsz);
             }
             first = lo == 0 ? 1u : lo;
         }
@@ -4428,8 +4428,8 @@ DEVI void small16_backward(const DevContig* contigs, const uint32_t* ids, uint32
             cx.resume = (gcdouble*)(cols + (size_t)(top + 1 < C ? top + 1 : top) * colsz);
             if constexpr (PHASE == 3) {
                 gdouble* scr = (gdouble*)dc.scratch;
-                cx.wr = scr + (size_t)((chunk & 1u) * 2u + 1u) * (size_t)K * colsz - (size_t)bot * colsz;
-                if (chunk > 0) cx.resume = (gcdouble*)(scr + (size_t)(((chunk - 1u) & 1u) * 2u + 1u) * (size_t)K * colsz);
+                cx.wr = scr + (size_t)(PG_SCR_BUF(chunk) * 2u + 1u) * (size_t)K * colsz - (size_t)bot * colsz;
+                if (chunk > 0) cx.resume = (gcdouble*)(scr + (size_t)(PG_SCR_BUF(chunk - 1u) * 2u + 1u) * (size_t)K * colsz);
             }
             t0 = PHASE == 1 ? top - 1 : top;
         }
@@ -4652,8 +4652,8 @@ DEVI void gen_forward(const DevContig& dc, GenShared& sh, uint32_t C, uint32_t c
     double* wr = fwd;
     const double* resume = fwd + (size_t)(lo > 0 ? lo - 1 : 0) * colsz;
     if constexpr (PHASE == 3) {
-        wr = dc.scratch + (size_t)((chunk & 1u) * 2u) * K * colsz - (size_t)lo * colsz;
-        if (chunk > 0) resume = dc.scratch + ((size_t)(((chunk - 1u) & 1u) * 2u) * K + (K - 1u)) * colsz;
+        wr = dc.scratch + (size_t)(PG_SCR_BUF(chunk) * 2u) * K * colsz - (size_t)lo * colsz;
+        if (chunk > 0) resume = dc.scratch + ((size_t)(PG_SCR_BUF(chunk - 1u) * 2u) * K + (K - 1u)) * colsz;
     }
     v2f64* xb = (v2f64*)dc.xbuf;  // forward role: first half of xbuf
     auto real = [&](uint32_t i) { return (i < H && p.j < H); };
@@ -4764,8 +4764,8 @@ DEVI void gen_backward(const DevContig& dc, GenShared& sh, uint32_t C, uint32_t 
     double* wr = cols;
     const double* resume = cols + (size_t)(top + 1 < (int64_t)C ? top + 1 : top) * colsz;
     if constexpr (PHASE == 3) {
-        wr = dc.scratch + (size_t)((chunk & 1u) * 2u + 1u) * (size_t)K * colsz - (size_t)bot * colsz;
-        if (chunk > 0) resume = dc.scratch + (size_t)(((chunk - 1u) & 1u) * 2u + 1u) * (size_t)K * colsz;
+        wr = dc.scratch + (size_t)(PG_SCR_BUF(chunk) * 2u + 1u) * (size_t)K * colsz - (size_t)bot * colsz;
+        if (chunk > 0) resume = dc.scratch + (size_t)(PG_SCR_BUF(chunk - 1u) * 2u + 1u) * (size_t)K * colsz;
     }
     v2f64* wb = (v2f64*)(dc.xbuf + colsz);  // backward role: second half of xbuf
     auto real = [&](uint32_t i) { return (i < H && p.j < H); };
@@ -5203,7 +5203,7 @@ DEVI void post_column(const DevContig& dc, uint32_t chunk, uint32_t idx, uint32_
     if (C == 0 || idx >= 2u * K) return;
     const uint32_t mid = C / 2;
     const size_t colsz = (size_t)HP * HP;
-    const double* scr = dc.scratch + (size_t)((chunk & 1u) * 2u) * K * colsz;
+    const double* scr = dc.scratch + (size_t)(PG_SCR_BUF(chunk) * 2u) * K * colsz;
     uint32_t c;
     const double *A, *B;  // alpha', beta'
     if (idx < K) {        // forward role: columns mid + chunk*K ...

@@ -408,7 +408,7 @@ struct pg_job {
     bool chunked = false;
     uint32_t chunk_cols = 0, n_chunks = 0;
     hipStream_t stream2 = nullptr;
-    hipEvent_t ev_sweep[2], ev_post[2];
+    hipEvent_t ev_sweep[PG_SCRATCH_BUFS], ev_post[PG_SCRATCH_BUFS];
     bool events2 = false;
     // Per-sample inputs (read k-mer counts, local coverage) of all chains lie in ONE contiguous run of the arena,
     // [sample_lo, sample_lo + sample_bytes): a cohort's next batch of samples is packed by host threads into a pinned
@@ -445,7 +445,7 @@ extern "C" void pg_job_destroy(pg_job* job) {
         for (auto& e : job->ev_vit) hipEventDestroy(e);
     }
     if (job->events2)
-        for (int q = 0; q < 2; ++q) { hipEventDestroy(job->ev_sweep[q]); hipEventDestroy(job->ev_post[q]); }
+        for (int q = 0; q < (int)PG_SCRATCH_BUFS; ++q) { hipEventDestroy(job->ev_sweep[q]); hipEventDestroy(job->ev_post[q]); }
     if (job->arena) {
         if (job->cache_arena) g_pool.put(job->device, job->arena, job->arena_bytes);
         else hipFree(job->arena);
@@ -879,8 +879,8 @@ int job_build(int device, uint32_t n_index, const pg_contig_batch* batches, cons
 
     // ---- sweep mode ------------------------------------------------------------------------
     {
-        size_t per_col = 0;  // scratch bytes per chunk column over all chains (2 buffers x 2 roles)
-        for (const ChainSpec& sp : specs) { const IndexHost& x = job->index[sp.index]; per_col += (size_t)4 * x.HP * x.HP * sizeof(double); }
+        size_t per_col = 0;  // scratch bytes per chunk column over all chains (PG_SCRATCH_BUFS buffers x 2 roles)
+        for (const ChainSpec& sp : specs) { const IndexHost& x = job->index[sp.index]; per_col += (size_t)2 * PG_SCRATCH_BUFS * x.HP * x.HP * sizeof(double); }
         // wide columns and HP >= 256 have their posteriors formed by k_post only: such jobs always run chunked
         bool want = n_chains * 2u < 128u;  // fewer workgroups than half the CUs
         // merged one-shot calls (cache_arena): always the mode — and with it the kernels — every one of them runs alone, so
@@ -902,7 +902,7 @@ int job_build(int device, uint32_t n_index, const pg_contig_batch* batches, cons
         }
         if (job->chunked) {
             size_t k = 4096;
-            const size_t budget = (size_t)12 << 30;
+            const size_t budget = (size_t)18 << 30;   // (three buffers: 4096 columns for the 24 chains of a whole genome at 64 paths)
             if (per_col * k > budget) k = budget / per_col;
             if (const char* e = getenv("PG_CHUNK_COLS")) { const long v = strtol(e, nullptr, 0); if (v > 0) k = (size_t)v; }
             const size_t half = (size_t)max_v / 2 + 1;
@@ -911,7 +911,7 @@ int job_build(int device, uint32_t n_index, const pg_contig_batch* batches, cons
             job->chunk_cols = (uint32_t)k;
             job->n_chunks = (uint32_t)((half + k - 1) / k);
             if ((he = hipStreamCreateWithFlags(&job->stream2, hipStreamNonBlocking)) != hipSuccess) return fail(PG_ERR_DEVICE, "hipStreamCreate", he);
-            for (int q = 0; q < 2; ++q) {
+            for (int q = 0; q < (int)PG_SCRATCH_BUFS; ++q) {
                 if ((he = hipEventCreateWithFlags(&job->ev_sweep[q], hipEventDisableTiming)) != hipSuccess) return fail(PG_ERR_DEVICE, "hipEventCreate", he);
                 if ((he = hipEventCreateWithFlags(&job->ev_post[q], hipEventDisableTiming)) != hipSuccess) return fail(PG_ERR_DEVICE, "hipEventCreate", he);
             }
@@ -1002,7 +1002,7 @@ int job_build(int device, uint32_t n_index, const pg_contig_batch* batches, cons
         p.vtq = take(params->run_phasing ? (size_t)x.V * 8 * sizeof(double) : 0);
         p.vback = take(params->run_phasing ? (size_t)x.V * x.H * x.HP * sizeof(uint16_t) : 0);
         if (params->run_phasing) job->vit_bits |= x.HP == 16 ? 1u : (x.HP == 32 ? 2u : 4u);
-        p.scratch = take(job->chunked ? (size_t)4 * job->chunk_cols * x.HP * x.HP * sizeof(double) : 0);
+        p.scratch = take(job->chunked ? (size_t)2 * PG_SCRATCH_BUFS * job->chunk_cols * x.HP * x.HP * sizeof(double) : 0);
         p.wide = take(x.wide_bytes);
         p.vpair = take((size_t)x.V * pg_pair_bytes(x.pair_n));
         p.xbuf = take((x.HP >= 256 || (force_generic && x.HP >= 64)) ? (size_t)2 * x.HP * x.HP * sizeof(double) : 0);
@@ -1387,12 +1387,12 @@ extern "C" int pg_job_run(pg_job* job, void* stream_, char* err, size_t errlen) 
             HIP_TRY(hipGetLastError());
             HIP_TRY(hipEventRecord(job->ev[6], s));
         } else {
-            // chunk i: store-only sweep on s -> ev_sweep -> k_post on stream2 -> ev_post; the sweep of
-            // chunk i+2 reuses scratch buffer i&1 and therefore waits for the posteriors of chunk i
+            // chunk i: store-only sweep on s -> ev_sweep -> k_post on stream2 -> ev_post; the sweep of chunk
+            // i + PG_SCRATCH_BUFS reuses scratch buffer i % PG_SCRATCH_BUFS and therefore waits for the posteriors of chunk i
             hipStream_t s2 = job->stream2;
             for (uint32_t i = 0; i < job->n_chunks; ++i) {
-                const int b = (int)(i & 1u);
-                if (i >= 2) HIP_TRY(hipStreamWaitEvent(s, job->ev_post[b], 0));
+                const int b = (int)PG_SCR_BUF(i);
+                if (i >= PG_SCRATCH_BUFS) HIP_TRY(hipStreamWaitEvent(s, job->ev_post[b], 0));
                 pgk_launch_sweep_chunk(job->d_contigs, n, job->hp_mask, i, s);
                 pgk_launch_sweep_small(job->d_contigs, job->d_small, job->n_small, 3, i, job->d_dump, s);
                 pgk_launch_sweep_smallx(job->d_contigs, job->d_smallx, job->n_smallx, 3, i, job->d_dump, s);
@@ -1403,8 +1403,7 @@ extern "C" int pg_job_run(pg_job* job, void* stream_, char* err, size_t errlen) 
                 HIP_TRY(hipGetLastError());
                 HIP_TRY(hipEventRecord(job->ev_post[b], s2));
             }
-            HIP_TRY(hipStreamWaitEvent(s, job->ev_post[0], 0));
-            if (job->n_chunks > 1) HIP_TRY(hipStreamWaitEvent(s, job->ev_post[1], 0));
+            for (uint32_t q = 0; q < PG_SCRATCH_BUFS && q < job->n_chunks; ++q) HIP_TRY(hipStreamWaitEvent(s, job->ev_post[q], 0));
             HIP_TRY(hipEventRecord(job->ev[5], s));  // "k_sweep_phase2" = all chunks incl. their posteriors
             HIP_TRY(hipEventRecord(job->ev[6], s));  // (no k_bins in this mode)
         }

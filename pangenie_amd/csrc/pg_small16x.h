@@ -288,8 +288,8 @@ DEVI void small16x_forward(const DevContig* contigs, const uint32_t* ids, uint32
             cx.resume = (gcdouble*)(fwd + (size_t)(lo > 0 ? lo - 1 : 0) * colsz);
             if constexpr (PHASE == 3) {
                 gdouble* scr = (gdouble*)dc.scratch;
-                cx.wr = scr + (size_t)((chunk & 1u) * 2u) * K * colsz - (size_t)lo * colsz;
-                if (chunk > 0) cx.resume = (gcdouble*)(scr + ((size_t)(((chunk - 1u) & 1u) * 2u) * K + (K - 1u)) * colsz);
+                cx.wr = scr + (size_t)(PG_SCR_BUF(chunk) * 2u) * K * colsz - (size_t)lo * colsz;
+                if (chunk > 0) cx.resume = (gcdouble*)(scr + ((size_t)(PG_SCR_BUF(chunk - 1u) * 2u) * K + (K - 1u)) * colsz);
             }
             first = lo == 0 ? 1u : lo;
         }
@@ -494,8 +494,8 @@ DEVI void small16x_backward(const DevContig* contigs, const uint32_t* ids, uint3
             cx.resume = (gcdouble*)(cols + (size_t)(top + 1 < C ? top + 1 : top) * colsz);
             if constexpr (PHASE == 3) {
                 gdouble* scr = (gdouble*)dc.scratch;
-                cx.wr = scr + (size_t)((chunk & 1u) * 2u + 1u) * (size_t)K * colsz - (size_t)bot * colsz;
-                if (chunk > 0) cx.resume = (gcdouble*)(scr + (size_t)(((chunk - 1u) & 1u) * 2u + 1u) * (size_t)K * colsz);
+                cx.wr = scr + (size_t)(PG_SCR_BUF(chunk) * 2u + 1u) * (size_t)K * colsz - (size_t)bot * colsz;
+                if (chunk > 0) cx.resume = (gcdouble*)(scr + (size_t)(PG_SCR_BUF(chunk - 1u) * 2u + 1u) * (size_t)K * colsz);
             }
             t0 = PHASE == 1 ? top - 1 : top;
         }
