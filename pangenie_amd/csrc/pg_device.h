@@ -185,7 +185,7 @@ struct DevContig {
     unsigned char* aux;        // per chain: slots of the variants with more than two alleles (128 B) / more than PG_AMAX (8 HP^2 B)
     const uint32_t* aux_idx;   // [V] per index contig: byte offset / 16 of the variant's slot, PG_WIDE_NONE if it has two alleles
     // rows and lanes of a stored column that carry data: H rounded up to a multiple of 4 (fused jobs at HP = 32, where
-    // 17 paths — the 15 + 1 behind haplotype sampling — would otherwise move 32 x 32 states per column for 17 x 17 real ones), else HP.
+    // 17 paths — a user-chosen panel size of 16 + the reference path; the DEFAULT, 15 + 1 = 16 paths, runs on k_sweep_small16[x] — would otherwise move 32 x 32 states per column for 17 x 17 real ones), else HP.
     // Phase 1 stores only rows and lanes below `live` (whole 64-byte sectors), the loader of phase 2 fetches only those,
     // and the rest of the LDS ring is zeroed once.  Nothing else reads the columns of a fused job.
     uint32_t  live;

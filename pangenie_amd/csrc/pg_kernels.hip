@@ -2588,7 +2588,7 @@ DEVI void backward_body(const DevContig& dc, ChainShared<HP, R>& sh, uint32_t C,
 
 // grid = (n_contigs, 2): blockIdx.y = 0 forward half-chain, 1 backward half-chain
 template <int HP, int R, int VBUF, bool KEEPW, int PHASE>
-// HP = 32 (17 .. 32 paths: the 15 + 1 paths behind haplotype sampling): 8 rows per lane = two compute waves (+ the loader in
+// HP = 32 (17 .. 32 paths: user-chosen panel sizes — the default of haplotype sampling, 15 + 1 = 16 paths, is k_sweep_small16[x]'s): 8 rows per lane = two compute waves (+ the loader in
 // phase 2 only: sweep_has_loader) per half-chain, held to 128 registers (a few spills) so that a SIMD takes four waves.  With 16 rows per lane (one compute
 // wave of 209 - 240 registers) a CU ran four half-chains at a time and two thirds of a 1024-chain cohort's time was
 // waiting: 72 -> 59 ms per step on `cohort_h17` (PG_HP32_ROWS=16 PG_HP32_WAVES=1 builds the old configuration).

@@ -21,6 +21,8 @@ KERNELS = {
     "_Z12k_sweep_leanILi1ELi16ELb0EEvPK9DevContigj": (100, False),        # the lone-chain lean step
     "_Z15k_sweep_small16ILi1EEvPK9DevContigPKjjjPd": (100, False),        # four half-chains per wave, phase 1
     "_Z15k_sweep_small16ILi2EEvPK9DevContigPKjjjPd": (100, False),        # ... phase 2
+    "_Z16k_sweep_small16xILi1EEvPK9DevContigPKjjjPd": (100, False),       # the same step with table emissions (16 paths, multiallelic objects), phase 1
+    "_Z16k_sweep_small16xILi2EEvPK9DevContigPKjjjPd": (100, False),       # ... phase 2 (256 + AGPRs: register moves, no scratch)
 }
 
 
@@ -85,6 +87,9 @@ OCCUPANCY = {
     "_Z15k_sweep_small16ILi1EEvPK9DevContigPKjjjPd": 2,
     "_Z15k_sweep_small16ILi2EEvPK9DevContigPKjjjPd": 1,       # three partner-column buffers: one wave per SIMD, 2048 waves per launch
     "_Z12k_bins_lean2PK9DevContig": 8,
+    "_Z16k_sweep_small16xILi1EEvPK9DevContigPKjjjPd": 2,      # 18 KB of LDS per wave: eight workgroups per CU
+    "_Z16k_sweep_small16xILi3EEvPK9DevContigPKjjjPd": 2,
+    "_Z8k_bins_xPK9DevContig": 5,                             # the bins of a column in registers, no LDS row per thread
 }
 
 

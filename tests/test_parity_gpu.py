@@ -429,7 +429,7 @@ def test_class_sums_in_the_single_wave_sweeps_vs_oracle_and_partials(H, orc, mon
 
 @pytest.mark.parametrize("H", [17, 20, 21, 24, 25, 29, 32])
 def test_short_columns_of_fused_jobs_vs_oracle_and_full_columns(H, orc, monkeypatch):
-    """Fused jobs at 17 ... 32 paths (HP = 32; 17 = the 15 + 1 paths behind haplotype sampling): phase 1 stores, and the loader of
+    """Fused jobs at 17 ... 32 paths (HP = 32; 17 = a user-chosen panel size of 16 + the reference path — the default is 15 + 1 = 16): phase 1 stores, and the loader of
     phase 2 fetches, only the first DevContig::live = H rounded up to 4 rows and lanes of a column (the rest of the LDS ring is
     zeroed once); the posterior partials of a wave's two halves are added in registers and only real paths' entries are
     written / read.  Regularised and unregularised table (fall-back columns re-formed from the stored backward column, which

@@ -1,7 +1,9 @@
 """Randomised parity soak (GPU box): many seeded panels of mixed shape, both sweep modes, small chunk
 sizes, narrow and wide columns, regularised and unregularised tables — HIP path vs the oracle.
 usage: python tools/soak_parity.py [n_panels] [seed0]   (80 panels: about two minutes)
-SOAK_TRI=1: only all-biallelic H = 64 panels in fused mode (triangle storage, k_sweep_lean2), from 1 variant up."""
+SOAK_TRI=1: only all-biallelic H = 64 panels in fused mode (triangle storage, k_sweep_lean2), from 1 variant up.
+SOAK_X=1: only 16-path panels on k_sweep_small16[x] (PG_KERNELS=small[,nosmall2]): multiallelic and wide objects (6-12 alleles of
+which the sixteen paths carry up to nine), both sweep modes."""
 import os, sys, time
 sys.path.insert(0, os.getcwd())
 import numpy as np
@@ -27,6 +29,11 @@ for it in range(n):
         H, wide = 64, False
         V = int(rng.choice([1, 2, 3, 4, 5, 7, 64, 65, 129, int(rng.integers(6, 900))]))
         kw.update(multiallelic_frac=0.0)
+    if os.environ.get("SOAK_X") == "1":
+        H, wide = 16, False
+        V = int(rng.choice([2, 3, 4, 5, 7, 9, 15, 16, 17, 64, 65, 129, int(rng.integers(6, 900)), int(rng.integers(6, 900))]))
+        kw.update(multiallelic_frac=float(rng.choice([0.0, 0.2, 0.45, 1.0])), wide_frac=float(rng.choice([0.0, 0.0, 0.03, 0.3])) if V > 1 else 0.0)
+        kw.pop("max_alleles", None); kw.pop("local_alts", None)
     b = synthetic_panel(V, H, K, seed=int(rng.integers(1 << 30)), **kw)
     reg = float(rng.choice([0.01, 0.01, 0.0, 0.001]))
     if reg == 0.0:
@@ -41,9 +48,11 @@ for it in range(n):
     if os.environ.get("SOAK_TRI") == "1":
         mode = "fused"
     os.environ["PG_SWEEP_MODE"] = mode
-    kern = str(rng.choice(["", "", "", "general", "generic", "leanpipe", "prepwave", "small", "small,nosmall2", "fullcols", "nocls4"]))
+    kern = str(rng.choice(["", "", "", "general", "generic", "prepwave", "small", "small,nosmall2", "fullcols", "nocls4"]))
     if os.environ.get("SOAK_TRI") == "1":
         kern = ""
+    if os.environ.get("SOAK_X") == "1":
+        kern = str(rng.choice(["small", "small", "small", "small,nosmall2", "small,prepwave"]))
     if kern:
         os.environ["PG_KERNELS"] = kern
     else:
