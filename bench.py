@@ -79,6 +79,11 @@ COHORTS_MORE = {
     # a user-chosen panel size (`-x 16` + the reference path = 17 ... 31 paths; NOT the default, which is 15 + 1 = 16): pads to 32
     "cohort_h17": dict(samples=128, contigs=8, V=8_000, H=17, K=20, multi=0.2, distinct=16),    # 1024 chains, 8.2 M variants, 67 GB of columns
 }
+# The same production shape as it arrives when every sample brings its OWN sampled panel (HaplotypeSampler picks the 15 paths per
+# sample: src/haplotypesampler.cpp:110-294): chains = samples x contigs, each with an index of its own (pg_job_new, no shared
+# index) — the four half-chains of a wave then differ in which columns are multiallelic / wide (the wave-uniform branches of
+# k_sweep_small16x are taken more often than in a cohort over one index).  64 distinct panels, each used by 64 chains.
+PANEL_JOB = dict(chains=4096, distinct=64, V=8_000, H=16, K=20, multi=0.2, wide=0.02)
 # GRCh38 chromosome lengths (Mb) 1..22, X, Y: proportions of the 24 synthetic contigs
 CONTIG_MB = [248, 242, 198, 190, 181, 171, 159, 145, 138, 134, 135, 133, 114, 107, 102, 90, 83, 80, 59, 64, 47, 51, 156, 57]
 
@@ -233,7 +238,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-cohort", action="store_true", help="skip the cohort sub-measurement")
     ap.add_argument("--cohort-only", action="store_true", help="profiling: only the cohort measurement")
-    ap.add_argument("--cohort-key", default="cohort", choices=["cohort"] + sorted(COHORTS_MORE), help="with --cohort-only: which cohort (profiling)")
+    ap.add_argument("--cohort-key", default="cohort", choices=["cohort", "panels_h16"] + sorted(COHORTS_MORE), help="with --cohort-only: which cohort (profiling)")
     ap.add_argument("--no-sampler", action="store_true", help="skip the HaplotypeSampler sub-measurement")
     ap.add_argument("--no-viterbi", action="store_true", help="skip the Viterbi phasing sub-measurement")
     ap.add_argument("--no-dropin", action="store_true", help="skip the threaded one-shot (drop-in) sub-measurement")
@@ -540,6 +545,38 @@ def main():
         hmm._lib.load_hip().pg_hmm_release_cache()
         return res
 
+    def panel_job_measure(c):
+        """chains with an index of their own each (what per-sample haplotype sampling produces), one resident job"""
+        Hc = c["H"]
+        distinct = [synthetic_panel(c["V"], Hc, c["K"], seed=9000 + 17 * i + 1000 * rank, multiallelic_frac=c["multi"], wide_frac=c["wide"]) for i in range(c["distinct"])]
+        # consecutive chains (the four rows of a wave) get different panels
+        pj_batches = [distinct[(i * 7 + i // c["distinct"]) % c["distinct"]] for i in range(c["chains"])]
+        pjob = hmm.Job(pj_batches, table, params, device=local_rank)
+        csteps = max(2, min(args.steps, 3))
+        pjob.run()
+        pk = {}
+        fence()
+        t0 = time.perf_counter()
+        for _ in range(csteps):
+            pjob.run()
+            for k, v in pjob.kernel_ms().items():
+                pk[k] = pk.get(k, 0.0) + v
+        fence()
+        pdt = max_over_ranks(time.perf_counter() - t0)
+        pk = {k: v / csteps for k, v in pk.items()}
+        res = None
+        if rank == 0:
+            proof, pncol, (pmode, _) = roofline_of(pjob.fetch_all(), pj_batches, pk, Hc, None, job_info_of(pjob))
+            pv = c["chains"] * c["V"]
+            res = {"workload": f"{c['chains']} chains of {c['V']} variants, {Hc} paths (15 sampled + the reference path), {int(100 * c['multi'])} % multiallelic, "
+                               f"{int(100 * c['wide'])} % of the objects with 6-12 alleles — every chain with an index of its OWN ({c['distinct']} distinct panels, "
+                               "neighbouring chains differ): pg_job_new, no shared index",
+                   "value": pv * world * csteps / pdt, "unit": "variants/s", "scaling": "weak", "steps": csteps, "ms_per_step": pdt / csteps * 1e3,
+                   "chains_per_gpu": c["chains"], "sweep_mode": pmode, "kept_columns": pncol, "roofline": proof, "kernel_ms": pk, "device_bytes": pjob.device_bytes()}
+        pjob.close()
+        hmm._lib.load_hip().pg_hmm_release_cache()
+        return res
+
     def cohort_strong_measure(key, like):
         """The cohort as a STRONG-scaling line (where north_star's >= 6x 1 -> 8 GPUs can land): a FIXED set
         of samples — COHORTS_MORE[key]'s, whatever N — sharded by sample over the ranks, every rank one resident cohort job
@@ -641,7 +678,12 @@ def main():
         return res
 
     if not args.no_cohort:
-        if args.cohort_only and args.cohort_key != "cohort":   # profiling: one of the other cohorts alone
+        if args.cohort_only and args.cohort_key == "panels_h16":
+            r = panel_job_measure(PANEL_JOB)
+            if rank == 0:
+                out["panels_h16"] = r
+                out.update({"value": r["value"], "ms_per_step": r["ms_per_step"], "scaling": "weak", "config": {"workload": "panels_h16 only: " + r["workload"]}, "roofline": r["roofline"]})
+        elif args.cohort_only and args.cohort_key != "cohort":   # profiling: one of the other cohorts alone
             spec = COHORTS_MORE[args.cohort_key]
             r = cohort_measure(spec, spec["samples"], args.cohort_key, args.cohort_key if world == 1 else None)
             if rank == 0:
@@ -662,6 +704,9 @@ def main():
                     r = cohort_measure(spec, spec["samples"], key, key if world == 1 else None)
                     if rank == 0:
                         out[key] = r
+                r = panel_job_measure(PANEL_JOB)
+                if rank == 0:
+                    out["panels_h16"] = r
                 # the strong-scaling cohort: the default production shape, a fixed set of samples sharded over the ranks
                 r = cohort_strong_measure("cohort_h16m", out.get("cohort_h16m") if rank == 0 else None)
                 if rank == 0 and r:

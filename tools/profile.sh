@@ -20,7 +20,7 @@ cd /tmp && export TMPDIR=/tmp
 cd $R
 case $W in
   cohort_h64) CMD="python bench.py --steps 3 --warmup 1 --cohort-only --no-cpu-baseline --no-sampler" ;;
-  cohort_*)   CMD="python bench.py --steps 3 --warmup 1 --cohort-only --cohort-key $W --no-cpu-baseline --no-sampler" ;;
+  cohort_*|panels_h16)   CMD="python bench.py --steps 3 --warmup 1 --cohort-only --cohort-key $W --no-cpu-baseline --no-sampler" ;;
   sampler)    CMD="python tools/bench_sampler.py --variants 40000 --paths 215 --size 15 --contigs 8 --cpu-variants 2000" ;;
   viterbi)    CMD="python tools/bench_viterbi.py" ;;
   *)          CMD="python bench.py --steps 3 --warmup 1 --workload $W --no-cpu-baseline --no-cohort --no-sampler --no-viterbi --no-dropin" ;;
