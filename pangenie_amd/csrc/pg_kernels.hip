@@ -859,8 +859,11 @@ DEVI void prep_m4_unit(const DevContig& dc, const DevTable& tab, uint32_t unit) 
     const uint32_t k0 = dc.kmer_off[v], K = dc.kmer_off[v + 1] - k0, cov = dc.cov[v];
     double* lm = s_m[wv][grp];
     int* le = s_e[wv][grp];
-    const uint32_t rounds = ((uint32_t)__builtin_amdgcn_readfirstlane(wave_max_i32((int)K)) + 15u) / 16u;   // (uniform: the wave's largest object)
-    for (uint32_t i = 0; i < rounds; ++i) {
+    // (as many rounds as the wave's largest object needs.  A BALLOT, not a shuffle butterfly: rows of the wave have left — objects
+    //  that are no column — and a butterfly through their lanes loses the other rows' values: round 5's first version staged
+    //  nothing for an object whose wave began with such a row)
+    for (uint32_t i = 0; i < 4u; ++i) {
+        if (!__any(16u * i < K)) break;
         const uint32_t k = 16u * i + l;
         if (k < K) {
             double m[3]; int e[3];
