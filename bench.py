@@ -484,14 +484,18 @@ def main():
             pool.append((list(kcs), list(covs)))
         samples = [pool[s % distinct] for s in range(S)]
         cjob = hmm.Job.cohort(index, samples, table, params, device=local_rank)
-        csteps, cwarm = max(2, min(args.steps, 3)), 1
+        # (three warm-up steps: the first steps on a freshly allocated 100+ GB arena — right after the previous cohort's was
+        #  freed — have been seen to run their store phase 60 % slower than every later one: `step_ms` shows each timed step)
+        csteps, cwarm = max(2, min(args.steps, 5)), 3
         for _ in range(cwarm):
             cjob.run()
-        ckms = {}
+        ckms, step_ms = {}, []
         fence()
         t0 = time.perf_counter()
         for _ in range(csteps):
+            t1 = time.perf_counter()
             cjob.run()
+            step_ms.append((time.perf_counter() - t1) * 1e3)
             for k, v in cjob.kernel_ms().items():
                 ckms[k] = ckms.get(k, 0.0) + v
         fence()
@@ -531,7 +535,8 @@ def main():
                             (f", {int(100 * c['wide'])} % of the objects with 6-12 alleles (wide columns)" if c.get("wide") else "") + f" per GPU: "
                             f"{S * NC} chains over ONE shared index (pg_cohort_new)" +
                             (f"; {distinct} distinct count sets, reused in turn" if distinct < S else ""),
-                "value": cv * world * csteps / cdt, "unit": "variants/s", "scaling": "weak", "steps": csteps, "ms_per_step": cdt / csteps * 1e3,
+                "value": cv * world * csteps / cdt, "unit": "variants/s", "scaling": "weak", "steps": csteps, "warmup": cwarm, "ms_per_step": cdt / csteps * 1e3,
+                "step_ms": [round(x, 2) for x in step_ms],
                 "chains_per_gpu": S * NC, "sweep_mode": cmode, "kept_columns": cncol,
                 "value_with_sample_upload": cv * world / cdt_up,   # every step with the NEXT batch's counts uploaded beside it
                 "sample_upload": {"pipelined_ms_per_step": cdt_up * 1e3, "waited_for_upload_ms_per_step": wait_s / csteps * 1e3,
@@ -552,8 +557,9 @@ def main():
         # consecutive chains (the four rows of a wave) get different panels
         pj_batches = [distinct[(i * 7 + i // c["distinct"]) % c["distinct"]] for i in range(c["chains"])]
         pjob = hmm.Job(pj_batches, table, params, device=local_rank)
-        csteps = max(2, min(args.steps, 3))
-        pjob.run()
+        csteps = max(2, min(args.steps, 5))
+        for _ in range(3):
+            pjob.run()
         pk = {}
         fence()
         t0 = time.perf_counter()
