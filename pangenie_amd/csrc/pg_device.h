@@ -182,6 +182,10 @@ struct DevContig {
     // the variant's `aux` slot (k_bins_x, k_bins_wide)
     uint32_t  smallx;
     uint32_t  pad1;
+    // the WIDE columns of the chain (smallx == 2, index with objects of more than PG_AMAX alleles): k_records appends every wide
+    // column it meets, k_bins_wide walks the list — one wave per entry instead of a scan of all columns for the rare one
+    uint32_t* wcols;           // [wide candidates of the index contig]
+    uint32_t* n_wcols;         // (zeroed at the start of every run)
     unsigned char* aux;        // per chain: slots of the variants with more than two alleles (128 B) / more than PG_AMAX (8 HP^2 B)
     const uint32_t* aux_idx;   // [V] per index contig: byte offset / 16 of the variant's slot, PG_WIDE_NONE if it has two alleles
     // rows and lanes of a stored column that carry data: H rounded up to a multiple of 4 (fused jobs at HP = 32, where

@@ -1096,6 +1096,8 @@ DEVI void records_unit(const DevContig& dc, uint32_t unit) {
         }
         s_c[wave][lane][0] = c0; s_c[wave][lane][1] = c1; s_c[wave][lane][2] = c2; s_c[wave][lane][3] = kappa;
         s_v[wave][lane] = v;
+        // a wide column of a chain whose bins k_bins_wide forms: onto the chain's list (any order: every column is its own work item)
+        if (c < C && dc.wcols && (dc.vrec[(size_t)v * dc.RB + PG_REC_FLAGS] & PG_REC_FLAG_WIDE)) dc.wcols[atomicAdd(dc.n_wcols, 1u)] = c;
     }
     wave_sync_lds();
     // the copy: the wave's n records are n * RB/16 16-byte pieces, contiguous on the destination side (1 KB per wave
@@ -5495,32 +5497,20 @@ __global__ __launch_bounds__(256) void k_bins_wide(const DevContig* __restrict__
     __shared__ double s_wide[4][PG_WIDE_LDS_BINS];
     const DevContig& dc = contigs[blockIdx.y];
     const uint32_t C = *dc.n_cols;
-    if (!bins_x(dc, C) || !dc.wide_idx) return;   // (no object of this chain's index has more than PG_AMAX alleles)
+    if (!bins_x(dc, C) || !dc.wcols) return;   // (no object of this chain's index has more than PG_AMAX alleles)
     const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
-    const uint32_t cbase = (blockIdx.x * 4u + wave) * 64u;
-    if (cbase >= C) return;
-    // the wave's 64 columns: which of them are wide (rare), then one after the other by the whole wave
-    bool wide = false;
-    uint32_t aux = 0;
-    if (cbase + lane < C) {
-        const unsigned char* rec = dc.vrec + (size_t)dc.col_variant[cbase + lane] * dc.RB;
-        wide = (rec[PG_REC_FLAGS] & PG_REC_FLAG_WIDE) != 0;
-        aux = *(const uint32_t*)(rec + PG_REC_AUX);
-    }
-    unsigned long long todo = __ballot(wide);
+    // one wave per entry of the chain's list of wide columns (k_records made it)
+    const uint32_t id = blockIdx.x * 4u + wave;
+    if (id >= *dc.n_wcols) return;
+    const uint32_t c = (uint32_t)__builtin_amdgcn_readfirstlane((int)dc.wcols[id]);
+    const unsigned char* rec = dc.vrec + (size_t)dc.col_variant[c] * dc.RB;
+    const uint32_t ax = (uint32_t)__builtin_amdgcn_readfirstlane((int)*(const uint32_t*)(rec + PG_REC_AUX));
     const size_t colsz = (size_t)dc.HP * dc.HP;
-    while (todo) {
-        const int i = __builtin_ctzll(todo);
-        todo &= todo - 1ull;
-        const uint32_t c = cbase + (uint32_t)i;
-        const uint32_t ax = (uint32_t)__builtin_amdgcn_readlane((int)aux, i);
-        const double* mine = (const double*)(dc.aux + (size_t)ax * 16u);   // what this column's phase-2 role stored
-        const double* stored = dc.fwd + (size_t)c * colsz;                 // its partner, from phase 1
-        // c >= mid: the forward role ran phase 2 (alpha' = its column, beta' = the stored one); below: the backward role
-        if (c >= C / 2) post_ab(dc, C, c, mine, stored, lane, s_bins[wave], s_wide[wave]);
-        else post_ab(dc, C, c, stored, mine, lane, s_bins[wave], s_wide[wave]);
-        wave_sync_lds();
-    }
+    const double* mine = (const double*)(dc.aux + (size_t)ax * 16u);   // what this column's phase-2 role stored
+    const double* stored = dc.fwd + (size_t)c * colsz;                 // its partner, from phase 1
+    // c >= mid: the forward role ran phase 2 (alpha' = its column, beta' = the stored one); below: the backward role
+    if (c >= C / 2) post_ab(dc, C, c, mine, stored, lane, s_bins[wave], s_wide[wave]);
+    else post_ab(dc, C, c, stored, mine, lane, s_bins[wave], s_wide[wave]);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -5599,7 +5589,7 @@ void pgk_launch_records(const DevContig* d_contigs, uint32_t n_contigs, uint32_t
     hipLaunchKernelGGL(k_records, grid, dim3(256), 0, s, d_contigs);
 }
 // which: bit 0 = the job has chains whose bins k_bins forms, bit 1 = chains on k_sweep_lean2 (k_bins_lean2), bit 2 = chains of k_bins_thin
-void pgk_launch_bins(const DevContig* d_contigs, uint32_t n_contigs, uint32_t max_v, uint32_t which, hipStream_t s) {
+void pgk_launch_bins(const DevContig* d_contigs, uint32_t n_contigs, uint32_t max_v, uint32_t which, uint32_t max_wide, hipStream_t s) {
     // (a chain on k_sweep_lean2 that ends up with a single column is k_bins' too: one block per chain covers that)
     dim3 grid((which & 1u) ? (max_v + 3) / 4 : 1u, n_contigs);
     hipLaunchKernelGGL(k_bins, grid, dim3(256), 0, s, d_contigs);
@@ -5607,7 +5597,8 @@ void pgk_launch_bins(const DevContig* d_contigs, uint32_t n_contigs, uint32_t ma
     if (which & 2u) hipLaunchKernelGGL(k_bins_lean2, grid256, dim3(256), 0, s, d_contigs);  // (each kernel skips the other's columns)
     if (which & 4u) hipLaunchKernelGGL(k_bins_thin, grid256, dim3(256), 0, s, d_contigs);
     if (which & 8u) hipLaunchKernelGGL(k_bins_x, grid256, dim3(256), 0, s, d_contigs);      // bit 3: chains on k_sweep_small16x<2>
-    if (which & 16u) hipLaunchKernelGGL(k_bins_wide, grid256, dim3(256), 0, s, d_contigs);  // bit 4: ... with objects of more than PG_AMAX alleles
+    if ((which & 16u) && max_wide)   // bit 4: ... with objects of more than PG_AMAX alleles: one wave per listed wide column
+        hipLaunchKernelGGL(k_bins_wide, dim3((max_wide + 3u) / 4u, n_contigs), dim3(256), 0, s, d_contigs);
 }
 void pgk_launch_sweep(const DevContig* d_contigs, uint32_t n_contigs, uint32_t hp_mask, int phase, hipStream_t s) {
     if (phase == 1) launch_sweep<1>(d_contigs, n_contigs, hp_mask, 0, s);

@@ -36,7 +36,7 @@ extern "C" {
 void pgk_launch_prep(const DevContig*, uint32_t, uint32_t, uint32_t, uint32_t, DevTable, hipStream_t);
 void pgk_launch_compact(const DevContig*, uint32_t, hipStream_t);
 void pgk_launch_records(const DevContig*, uint32_t, uint32_t, hipStream_t);
-void pgk_launch_bins(const DevContig*, uint32_t, uint32_t, uint32_t, hipStream_t);
+void pgk_launch_bins(const DevContig*, uint32_t, uint32_t, uint32_t, uint32_t, hipStream_t);
 void pgk_launch_sweep(const DevContig*, uint32_t, uint32_t, int, hipStream_t);
 void pgk_launch_sweep_chunk(const DevContig*, uint32_t, uint32_t, uint32_t, hipStream_t);
 void pgk_launch_post(const DevContig*, uint32_t, uint32_t, uint32_t, hipStream_t);
@@ -223,6 +223,7 @@ struct IndexHost {   // one index contig
     size_t o_list_m4 = 0, o_list_w = 0;
     std::vector<uint32_t> auxidx;    // [V] aux slot offset / 16 of every variant with more than two alleles (smallx), PG_WIDE_NONE otherwise
     uint64_t aux_bytes = 0;
+    uint32_t n_wide_cand = 0;        // variants with more than PG_AMAX alleles (each may be a wide column)
     size_t o_auxidx = 0;
     uint32_t prep_fast = 0;  // 1: every object has exactly two alleles and <= 32 k-mers, H <= 64: k_prep_bi; 2: at least half of them (k_prep the rest)
     uint32_t sumK = 0, sumA = 0;
@@ -387,6 +388,7 @@ struct pg_job {
     std::vector<int32_t> tab_e;
     DevTable tab;
     uint32_t hp_mask = 0, max_v = 0;
+    uint32_t max_wide = 0;   // grid extent of k_bins_wide: the longest list of wide-column candidates
     uint32_t max_prep_w = 0, max_prep_m4 = 0;   // grid extents of k_prep (lists or all variants) and k_prep_m4
     uint32_t bins_which = 0;   // bit 0: chains whose bins k_bins forms, bit 1: chains on k_sweep_lean2 (k_bins_lean2), bit 2: k_bins_thin
     uint32_t vit_bits = 0;     // run_phasing: 1 / 2 / 4 = chains with 16 / 32 / 64 padded paths
@@ -839,6 +841,7 @@ int job_build(int device, uint32_t n_index, const pg_contig_batch* batches, cons
                 if (A <= 2) continue;
                 const uint64_t small_slot = 128u /* fifteen bins */, col_slot = (uint64_t)x.HP * x.HP * 8u;
                 x.auxidx[v] = (uint32_t)(ao / 16);
+                if (A > PG_AMAX) x.n_wide_cand += 1;
                 ao += A > PG_AMAX ? (col_slot > small_slot ? col_slot : small_slot) : small_slot;
             }
             if (ao / 16 >= 0xFFFFFFF0ull) x.smallx = false;   // (the general kernel then)
@@ -923,7 +926,7 @@ int job_build(int device, uint32_t n_index, const pg_contig_batch* batches, cons
     job->chains.resize(n_chains);
     size_t off = 0;
     auto take = [&](size_t bytes, size_t al = 256) { off = align_up(off, al); size_t o = off; off += (bytes ? bytes : 8); return o; };
-    struct Plan { size_t aux, frec, scratch, wide, vpair, xbuf, prof, fback, fscale, bscale, bsum, vrec, cvar, colrec, fwd, part, kept, apres,
+    struct Plan { size_t wcols, aux, frec, scratch, wide, vpair, xbuf, prof, fback, fscale, bscale, bsum, vrec, cvar, colrec, fwd, part, kept, apres,
                   vtq, vback, vbest, hap1, hap2; };
     std::vector<Plan> plan(n_chains);
     const size_t o_contigs = take(sizeof(DevContig) * n_chains);
@@ -943,6 +946,7 @@ int job_build(int device, uint32_t n_index, const pg_contig_batch* batches, cons
         plan[c].fback = take(x.V);
         plan[c].prof = take(64 * sizeof(unsigned long long));
         plan[c].apres = take(x.sumA);
+        plan[c].wcols = take(4);   // (the count of the chain's wide-column list: zeroed with the rest of this block; the list itself below)
         const bool vit = params->run_phasing != 0;
         plan[c].vbest = take(vit ? 4 : 0);
         plan[c].hap1 = take(vit ? (size_t)x.V * 2 : 0);
@@ -978,6 +982,7 @@ int job_build(int device, uint32_t n_index, const pg_contig_batch* batches, cons
     }
     job->sample_bytes = align_up(off) - job->sample_lo;
     std::vector<char> tri_of_chain(n_chains, 0);
+    std::vector<size_t> plan_wlist(n_chains, 0);
     for (uint32_t c = 0; c < n_chains; ++c) {
         ChainHost& ch = job->chains[c];
         const IndexHost& x = job->index[ch.index];
@@ -998,6 +1003,8 @@ int job_build(int device, uint32_t n_index, const pg_contig_batch* batches, cons
         p.part = take(job->chunked || !geno ? 0 : (x2 ? (size_t)x.V * 32u + (size_t)x.part_slots * part_entries(x) * sizeof(double)
                                                       : (size_t)x.V * x.part_slots * part_entries(x) * sizeof(double)));
         p.aux = take(x2 && geno ? x.aux_bytes : 0);
+        const size_t o_wlist = take(x2 && geno && x.wide_bytes ? (size_t)x.n_wide_cand * 4 : 0);
+        plan_wlist[c] = o_wlist;
         // Viterbi: transition probabilities and one 2-byte backpointer per state and column
         p.vtq = take(params->run_phasing ? (size_t)x.V * 8 * sizeof(double) : 0);
         p.vback = take(params->run_phasing ? (size_t)x.V * x.H * x.HP * sizeof(uint16_t) : 0);
@@ -1077,6 +1084,10 @@ int job_build(int device, uint32_t n_index, const pg_contig_batch* batches, cons
         d.frec = (double*)(A + p.frec); d.lean = x.lean ? 1u : 0u; d.small = x.small ? ((!job->chunked && x.cls4 && !kc.nosmall2) ? 2u : 1u) : 0u; d.leanx = x.leanx ? 1u : 0u; d.cls4 = x.cls4 ? 1u : 0u;
         d.smallx = x.smallx ? ((!job->chunked && !kc.nosmall2) ? 2u : 1u) : 0u;
         d.aux = A + p.aux; d.aux_idx = (d.smallx == 2u && x.aux_bytes) ? (const uint32_t*)(A + x.o_auxidx) : nullptr;
+        if (d.smallx == 2u && x.wide_bytes && x.n_wide_cand) {
+            d.wcols = (uint32_t*)(A + plan_wlist[c]); d.n_wcols = (uint32_t*)(A + p.wcols);
+            job->max_wide = std::max(job->max_wide, x.n_wide_cand);
+        }
         d.live = (!job->chunked && x.HP == 32u && !kc.fullcols) ? std::min<uint32_t>(x.HP, (x.H + 3u) & ~3u) : x.HP;
         d.prep_fast = x.prep_fast;
         if (x.prep_fast == 2u) {   // (a non-null list pointer = "walk the list", also when it is empty)
@@ -1383,7 +1394,7 @@ extern "C" int pg_job_run(pg_job* job, void* stream_, char* err, size_t errlen) 
             if (job->smallx_phase2) pgk_launch_sweep_smallx(job->d_contigs, job->d_smallx, job->n_smallx, 2, 0, job->d_dump, s);
             HIP_TRY(hipGetLastError());
             HIP_TRY(hipEventRecord(job->ev[5], s));
-            pgk_launch_bins(job->d_contigs, n, job->max_v, job->bins_which, s);
+            pgk_launch_bins(job->d_contigs, n, job->max_v, job->bins_which, job->max_wide, s);
             HIP_TRY(hipGetLastError());
             HIP_TRY(hipEventRecord(job->ev[6], s));
         } else {
