@@ -572,7 +572,7 @@ def main():
         pk = {k: v / csteps for k, v in pk.items()}
         res = None
         if rank == 0:
-            proof, pncol, (pmode, _) = roofline_of(pjob.fetch_all(), pj_batches, pk, Hc, None, job_info_of(pjob))
+            proof, pncol, (pmode, _) = roofline_of(pjob.fetch_all(), pj_batches, pk, Hc, "panels_h16" if world == 1 else None, job_info_of(pjob))
             pv = c["chains"] * c["V"]
             res = {"workload": f"{c['chains']} chains of {c['V']} variants, {Hc} paths (15 sampled + the reference path), {int(100 * c['multi'])} % multiallelic, "
                                f"{int(100 * c['wide'])} % of the objects with 6-12 alleles — every chain with an index of its OWN ({c['distinct']} distinct panels, "
