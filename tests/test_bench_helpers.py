@@ -48,3 +48,39 @@ def test_profiled_traffic_matches_the_algorithmic_bytes_of_the_committed_bench_l
     # the lookup itself: phase 1 of the 128-path chain is k_sweep_leanx's writes
     t1, src = b.profiled_traffic("chr22_h128", 1)
     assert src == "r03_chr22_h128_summary.json" and 7.5e9 < t1 < 8.5e9
+
+
+def test_round5_kernel_names_and_profiles():
+    """The kernels of round 5 are classified (k_sweep_small16x: phases 1-3; the bins / prep kernels: no sweep phase), and the
+    committed round-5 summaries give the traffic of the new cohort lines within 20 % of their algorithmic bytes."""
+    b = _bench()
+    assert b._sweep_phase("void k_sweep_small16x<2>(DevContig const*, unsigned int const*, unsigned int, unsigned int, double*)") == 2
+    assert b._sweep_phase("void k_sweep_small16x<1>(DevContig const*, unsigned int const*, unsigned int, unsigned int, double*)") == 1
+    assert b._sweep_phase("void k_sweep_small16x<3>(DevContig const*, unsigned int const*, unsigned int, unsigned int, double*)") == 3
+    for n in ("k_bins_x(DevContig const*)", "k_bins_wide(DevContig const*)", "k_prep_m4(DevContig const*, DevTable)"):
+        assert b._sweep_phase(n) is None
+    d = json.loads((ROOT / "profiles" / "r05_bench_default.json").read_text())
+    for key in ("cohort_h16m", "cohort_h16w"):
+        r = d[key]["roofline"]
+        assert d[key]["sweep_mode"] == "fused" and r["kernel"] == "k_sweep_phase2"
+        assert r["traffic_source"].startswith("r05_") and 0.95 <= r["traffic"] / r["algorithmic_bytes_per_launch"] <= 1.15
+        assert r["frac"] >= 0.55
+    assert d["cohort_h16m"]["value"] >= 0.8 * d["cohort_h16"]["value"] and d["cohort_h16w"]["value"] >= 0.7 * d["cohort_h16"]["value"]
+
+
+def test_wide_objects_of_the_generator_leave_the_other_draws_alone():
+    """synthetic_panel(wide_frac=...) draws its wide objects from a generator of its own: positions, coverage and the alleles of
+    every other object are those of the panel without them (the bench lines with and without wide objects differ in those only)."""
+    import numpy as np
+    import sys
+    sys.path.insert(0, str(ROOT))
+    from pangenie_amd.panel import synthetic_panel
+    a = synthetic_panel(1500, 16, 20, seed=5, multiallelic_frac=0.2)
+    w = synthetic_panel(1500, 16, 20, seed=5, multiallelic_frac=0.2, wide_frac=0.05)
+    Aa, Aw = np.diff(a.allele_off.astype(int)), np.diff(w.allele_off.astype(int))
+    wide = Aw > 5
+    assert 30 < int(wide.sum()) < 130 and (Aa[~wide] == Aw[~wide]).all()
+    assert (a.variant_pos == w.variant_pos).all() and (a.coverage == w.coverage).all()
+    pa, pw = a.path_allele.reshape(1500, 16), w.path_allele.reshape(1500, 16)
+    assert (pa[~wide] == pw[~wide]).all()
+    assert max(len(set(r)) for r in pw[wide]) > 5   # (wide COLUMNS: more than five alleles on the sixteen paths)
