@@ -758,11 +758,20 @@ DEVI void prep_bi_unit(const DevContig& dc, const DevTable& tab, uint32_t unit) 
         ((unsigned long long*)(rec + PG_REC_BITS1))[1] = 0ull;
     }
     wave_sync_lds();
-    {   // copy-out: the variant's 16 lanes move RB / 16 pieces of 16 bytes, consecutive lanes consecutive pieces
+    {   // copy-out: only the 16-byte pieces of the record that are not zero by construction — header (bytes 32 .. 63), row bits
+        // (64 .. 79), E'00 E'01 (80 .. 95), E'10 E'11 (128 .. 143), the path alleles (PG_REC_ALLELES ...): 6 of 24 pieces at 16
+        // paths, ONE store per object.  The rest of the record is zero since the job was built (pg_shim.cpp zeroes the variant
+        // records once) and no kernel ever writes anything else there for THIS object (the kernel that prepares an object is a
+        // function of the index alone).  The kernel waits for its memory 70 % of its cycles (profiles/r05_cohort_h16m_summary.txt,
+        // round 4: 27 GB written per launch for 12.6 GB of records).
         typedef double f64x2 __attribute__((ext_vector_type(2)));
         const f64x2* src = (const f64x2*)rec;
         f64x2* dst = (f64x2*)(dc.vrec + (size_t)v * dc.RB);
-        for (uint32_t p = l; p < dc.RB / 16u; p += 16u) dst[p] = src[p];
+        const uint32_t n_al = HP / 16u;   // pieces of path alleles
+        if (l < 5u + n_al) {
+            const uint32_t p = l == 0u ? 2u : l == 1u ? 3u : l == 2u ? 4u : l == 3u ? 5u : l == 4u ? 8u : (uint32_t)(PG_REC_ALLELES / 16) + (l - 5u);
+            dst[p] = src[p];
+        }
     }
     wave_sync_lds();   // (the slot is rewritten by the wave's next unit)
 }

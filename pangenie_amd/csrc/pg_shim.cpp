@@ -983,11 +983,17 @@ int job_build(int device, uint32_t n_index, const pg_contig_batch* batches, cons
     job->sample_bytes = align_up(off) - job->sample_lo;
     std::vector<char> tri_of_chain(n_chains, 0);
     std::vector<size_t> plan_wlist(n_chains, 0);
+    // The variant records of all chains in ONE run of the arena, zeroed once when the job is built: k_prep_bi writes only the
+    // pieces of a biallelic object's record that are not zero by construction (header, row bits, four table entries, the path
+    // alleles: 96 of 384 bytes at 16 paths — it is a kernel that waits for its memory 70 % of the time); what it leaves out — the
+    // rest of the 6 x 6 table, the padding — has to BE zero for every reader of the full record.
+    const size_t vrec_lo = align_up(off);
+    for (uint32_t c = 0; c < n_chains; ++c) { const IndexHost& x = job->index[job->chains[c].index]; plan[c].vrec = take((size_t)x.V * x.RB); }
+    const size_t vrec_hi = off;
     for (uint32_t c = 0; c < n_chains; ++c) {
         ChainHost& ch = job->chains[c];
         const IndexHost& x = job->index[ch.index];
         Plan& p = plan[c];
-        p.vrec = take((size_t)x.V * x.RB);
         p.cvar = take((size_t)x.V * 4);
         p.colrec = take((size_t)x.V * x.RB);
         // fused jobs: lean chains store / read their columns as compact upper triangles (18 KB instead of 32 KB per
@@ -1042,6 +1048,7 @@ int job_build(int device, uint32_t n_index, const pg_contig_batch* batches, cons
             return PG_ERR_NOMEM;
         }
     }
+    if ((he = hipMemsetAsync(job->arena + vrec_lo, 0, vrec_hi - vrec_lo, job->stream)) != hipSuccess) return fail(PG_ERR_DEVICE, "hipMemset (variant records)", he);
     job->host_s[0] = now_s() - t_alloc;
     lap("arena plan + allocation");
     unsigned char* A = job->arena;
