@@ -193,7 +193,11 @@ uint64_t pg_job_device_bytes(const pg_job* job);
 /* How pg_job_run schedules the second half of every half-chain: 0 = fused (posterior partials formed
  * inside the sweep, one launch; chosen when many chains fill the chip), 1 = chunked (store-only sweep
  * chunks of *chunk_cols columns, posteriors of each finished chunk on the idle CUs; chosen for few
- * chains).  Override with the environment variables PG_SWEEP_MODE=fused|chunked, PG_CHUNK_COLS=n. */
+ * chains).  Override with the environment variables PG_SWEEP_MODE=fused|chunked, PG_CHUNK_COLS=n.
+ * A column with more than five distinct alleles on the selected paths ("wide") is genotyped inside a fused job when its
+ * chain has 16 paths (the sampled panels of production: the column costs that column); a chain of any other width with an
+ * object of more than five alleles makes its job chunked, whatever is asked for.  A 16-path chain whose ONLY column is wide
+ * is refused in a fused job (PG_ERR_UNSUPPORTED from pg_job_run), never genotyped wrongly. */
 int  pg_job_sweep_mode(const pg_job* job, uint32_t* chunk_cols);
 /* Number of chains of the job whose columns are kept as upper triangles (fused mode, every object biallelic,
  * H = 64: the columns are symmetric, so phase 1 writes and phase 2 reads only the stored half — half of the
