@@ -49,7 +49,7 @@
 #define PG_REC_AUX 60         // u32: byte offset / 16 of the variant's slot inside DevContig::aux (PG_WIDE_NONE: none); the last two of the eight local-slot entries
 
 // Wide entries (columns with PG_AMAX < n_local <= PG_WIDE_MAX distinct alleles on the selected paths;
-// chunked sweep mode only): the emission table no longer fits the column record, so it lives in a
+// chunked sweep mode — or, round 5, a fused job's 16-path chain on k_sweep_small16x): the emission table no longer fits the column record, so it lives in a
 // side buffer.  With S = n_local + 1 (row/column n_local is zero: phantom paths) an entry holds
 //   double  E [S][S]   emission products scaled by 2^-X (symmetric), read by the recursion
 //   double  Pm[S][S]   mantissa in [0.5,1) (or 0) of the unscaled product of the local pair

@@ -348,8 +348,8 @@ DEVI void prep_unit(const DevContig& dc, const DevTable& tab, uint32_t unit) {
     if (lane == 0) dc.kept[v] = kept ? 1 : 0;
     if (!kept) return;
     // more than PG_AMAX alleles on the selected paths: a WIDE column, its tables go to the side
-    // buffer (chunked sweep mode only; pg_shim.cpp reserves an entry for every variant that could
-    // be wide and forces that mode)
+    // buffer (pg_shim.cpp reserves an entry for every variant that could be wide; such a column is genotyped by k_post in
+    // chunked mode — which the shim forces for every chain but k_sweep_small16x's — or by k_sweep_small16x + k_bins_wide)
     const bool wide = n_local > PG_AMAX;
     const uint32_t woff = wide && dc.wide_idx ? dc.wide_idx[v] : PG_WIDE_NONE;
     if (wide && (woff == PG_WIDE_NONE || n_local > PG_WIDE_MAX)) {

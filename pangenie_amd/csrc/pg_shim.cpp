@@ -884,7 +884,7 @@ int job_build(int device, uint32_t n_index, const pg_contig_batch* batches, cons
     {
         size_t per_col = 0;  // scratch bytes per chunk column over all chains (PG_SCRATCH_BUFS buffers x 2 roles)
         for (const ChainSpec& sp : specs) { const IndexHost& x = job->index[sp.index]; per_col += (size_t)2 * PG_SCRATCH_BUFS * x.HP * x.HP * sizeof(double); }
-        // wide columns and HP >= 256 have their posteriors formed by k_post only: such jobs always run chunked
+        // wide columns of chains that are not k_sweep_small16x's (wide_candidates, above) and HP >= 256 have their posteriors formed by k_post only: such jobs always run chunked
         bool want = n_chains * 2u < 128u;  // fewer workgroups than half the CUs
         // merged one-shot calls (cache_arena): always the mode — and with it the kernels — every one of them runs alone, so
         // that a caller's result does not depend on who else happened to be in flight (bit for bit, by construction)
