@@ -77,8 +77,8 @@ struct LeanTimeline {
 
 // k_sweep_small16x (pg_small16x.h): 1 no emission reads (e := 1), 2 no parking / no next-record reads (the first record's
 // constants and alleles for every column), 4 no record loads, 8 no column stores (phases 1, 3), 16 no row-allele accumulation
-// (phase 2), 32 no class sums / bins / aux stores (phase 2), 64 no partner-column loads (phase 2), 128 constants parked instead of the
-// loaded record (no wait for the load), 256 no next-record LDS reads, 512 no parking
+// (phase 2), 32 no class sums / bins / aux stores (phase 2), 64 no partner-column loads (phase 2).  (The masks 128 / 256 / 512 named in
+// profiles/r05_small16x_ablation*.txt belonged to the per-step record loads those measurements replaced by blocks; they are gone.)
 #ifndef PG_X_EXP
 #define PG_X_EXP 0
 #endif
