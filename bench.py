@@ -468,6 +468,9 @@ def main():
                 out["cpu_baseline"] = cpu_baseline(batches, H, args.cpu_sample or auto)
         if job:
             job.close()
+        if abi:   # the main workload's communicator and rank 0's gathered block: not needed by the cohort lines
+            abi.close()
+            abi = None
         del batches
         hmm._lib.load_hip().pg_hmm_release_cache()
 
@@ -714,7 +717,11 @@ def main():
                 if rank == 0:
                     out["panels_h16"] = r
                 # the strong-scaling cohort: the default production shape, a fixed set of samples sharded over the ranks
-                r = cohort_strong_measure("cohort_h16m", out.get("cohort_h16m") if rank == 0 else None)
+                try:
+                    r = cohort_strong_measure("cohort_h16m", out.get("cohort_h16m") if rank == 0 else None)
+                except Exception as e:  # noqa: BLE001 — a sub-measurement must not take the main line with it
+                    print(f"[rank {rank}] cohort_strong failed: {e!r}", file=sys.stderr)
+                    r = {"error": repr(e)}
                 if rank == 0 and r:
                     out["cohort_strong"] = r
 
