@@ -90,13 +90,16 @@ CASES = [
     (18, 9, 64, dict(multiallelic_frac=0.8, max_alleles=12, local_alts=8), (1.26, False, 1e-5)),        # wide columns
     (14, 12, 96, dict(multiallelic_frac=1.0, max_alleles=24, local_alts=11, undefined_frac=0.1), (446.287102628, False, 0.25)),
     (16, 3, 96, dict(multiallelic_frac=0.7, max_alleles=32), (0.001, False, 1e-5)),                       # many alleles, few on paths
+    # the default production shape (15 sampled paths + the reference path) as the round-5 parity tests and bench lines build it:
+    # a fifth .. half of the objects with 3-5 alleles, some bubbles of 6-12 alleles of which the paths carry up to nine
+    (12, 16, 40, dict(multiallelic_frac=0.45, wide_frac=0.25), (1.26, False, 1e-5)),
 ]
 
 
 @pytest.mark.parametrize("V,H,K,kw,par", CASES)
 def test_oracle_matches_dense_matrix_restatement(V, H, K, kw, par):
     b = synthetic_panel(V, H, K, seed=900 + V + H, **kw)
-    if kw.get("local_alts", 0) > 5:  # these cases are meant to contain wide columns
+    if kw.get("local_alts", 0) > 5 or kw.get("wide_frac", 0) > 0:  # these cases are meant to contain wide columns
         assert max(len(set(r)) for r in b.path_allele.reshape(V, H)) > 5
     for reg in (0.01, 0.0):
         if reg == 0.0:
