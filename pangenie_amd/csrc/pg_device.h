@@ -98,6 +98,60 @@ struct DevTable {
     double reg;           // regularization constant (on-the-fly path)
     const double* mant;   // [cov-cov_min][count][3]
     const int32_t* expo;  // [cov-cov_min][count][3]
+    // the same entries as ONE 32-byte piece each, {m0, m1, m2, int16 e0, e1, e2, 0}: two 16-byte loads per k-mer where the
+    // split arrays take six (the sample-level kernels of the split path, pg_split.h; every exponent of the table lies in
+    // [PG_LD_MIN_EXP, 1], so int16 holds it)
+    const unsigned char* packed;   // [cov-cov_min][count][32]
+};
+
+// ------------------------------------------------------------------------------------------------------------------
+//  The split path (round 6): what depends on the INDEX alone is formed once, when the index is uploaded, and shared by
+//  every chain (sample) over that index contig; a run of the job forms only what depends on the sample's read counts.
+//  reference: the index is sample-independent, update_readcount / set_coverage are the per-sample part
+//  (src/commands.cpp:118-138); the column list hangs on path alleles and undefined flags (src/columnindexer.cpp:8-33), the
+//  transition probabilities on positions (src/transitionprobabilitycomputer.cpp:8-19), the emissions on the counts
+//  (src/emissionprobabilitycomputer.cpp:9-53).
+//
+//  For EVERY chain (all kernels): kept[V], allele_present[sumA], col_variant[C], n_cols, col_of[V] are per index contig
+//  (k_index_scan + k_compact at upload; no k_compact in a run).
+//  For the 16-path chains of fused jobs (DevContig::split; k_sweep_small16 / k_sweep_small16x both phases), per COLUMN:
+//    ix_pd [C][32]  what the sample-level emission kernel needs of a column: {variant, first k-mer, K | flags << 8,
+//                   k-mer bits of allele slot 0, of slot 1 (biallelic objects), 0, 0, 0}
+//    ix_rec[C][64]  what the sweeps need besides the emissions.  split == 1 (every object biallelic): {c0, c1, c2, kappa,
+//                   row bits, 0, 0, 0} — copied into the 64-byte record of k_sweep_small16 by the emission kernel;
+//                   split == 2: bytes 128 .. 191 of k_sweep_small16x's record (header, constants, row offsets), read
+//                   by the sweep as a second stream
+//    ix_bin[C][32]  what the bins kernels need: {first bin of the variant, variant, aux slot, A (u16), nlocal, flags,
+//                   allele slot of local allele 0 .. 4 (u16), paths carrying local allele 0 .. 4 (u8), 0}
+//  and per chain, in COLUMN order, written by the emission kernels k_prep_s_* every run:
+//    split == 1: frec[C][64]  {c0, c1, c2, kappa, E'00, E'01, E'11, row bits | flags << 16 | X << 32}
+//    split == 2: frec[C][128] the fifteen table entries (tri_local order; a wide column: its sixteen raw local alleles in
+//                the first sixteen bytes) then {int32 X, uint32 flags}
+//    cprec[C][192] only for columns flagged PG_SREC_FLAG_PRECISE: the unscaled products as (mantissa[16], exponent[16]).
+//  The bins kernels recover a pair's (mantissa, exponent) from the scaled entry and X — E' = m 2^(e - X) exactly unless
+//  that is subnormal: a column with such an entry (a present pair 2^-1021 below the column's largest) is flagged and its
+//  products go to cprec as well.  No vrec / colrec / vpair for such chains.
+#define PG_IXPD_BYTES 32u
+#define PG_IXREC_BYTES 64u
+#define PG_IXBIN_BYTES 32u
+#define PG_SREC1_BYTES 64u
+#define PG_SREC2_BYTES 128u
+#define PG_CPREC_BYTES 192u
+#define PG_COL_NONE 0xFFFFFFFFu
+#define PG_IXPD_U0 0x100u        // kf: K | these
+#define PG_IXPD_U1 0x200u
+#define PG_IXPD_HAS0 0x400u
+#define PG_IXPD_HAS1 0x800u
+#define PG_SREC_FLAG_ALLZERO 1u  // (= PG_REC_FLAG_ALLZERO)
+#define PG_SREC_FLAG_WIDE 2u     // (= PG_REC_FLAG_WIDE)
+#define PG_SREC_FLAG_PRECISE 4u
+struct IxBin {
+    uint32_t g0, v, aux;
+    uint16_t A;
+    uint8_t nl, flags;
+    uint16_t ls[5];
+    uint8_t cnt[5];
+    uint8_t pad;
 };
 
 struct DevContig {
@@ -181,7 +235,14 @@ struct DevContig {
     // alleles in `part` ([C][4]), the fifteen bins of columns with three to five and the phase-2 column of WIDE columns in
     // the variant's `aux` slot (k_bins_x, k_bins_wide)
     uint32_t  smallx;
-    uint32_t  pad1;
+    // 1 / 2 (small == 2 / smallx == 2 chains of fused jobs without run_phasing): the split path, see above
+    uint32_t  split;
+    const uint32_t* col_of;    // [V] per index contig: column of a kept variant, PG_COL_NONE otherwise
+    const unsigned char* ix_pd;
+    const unsigned char* ix_rec;
+    const unsigned char* ix_bin;
+    unsigned char* cprec;      // [V][192] per chain (touched for flagged columns only)
+    uint32_t* ix_err;          // per index contig: error bits of k_index_scan (PG_DEVERR_*)
     // the WIDE columns of the chain (smallx == 2, index with objects of more than PG_AMAX alleles): k_records appends every wide
     // column it meets, k_bins_wide walks the list — one wave per entry instead of a scan of all columns for the rare one
     uint32_t* wcols;           // [wide candidates of the index contig]

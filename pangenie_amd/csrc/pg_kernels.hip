@@ -37,6 +37,7 @@
 #include "pg_devmath.h"
 
 #define DEVI __device__ __forceinline__
+typedef double v2f64 __attribute__((ext_vector_type(2)));  // native vector type (address-space qualifiable)
 #include "pg_experiments.h"   // masks of the timing experiments: all zero in the product build
 
 // ------------------------------------------------------------------------------------------
@@ -281,6 +282,7 @@ DEVI int slot_of(const DevContig& dc, uint32_t a0, uint32_t A, uint16_t a) {
 #define PG_VREP 8   // units (what one block of the one-variant-per-wave grid did) a block of k_prep / k_prep_bi walks: fewer, longer blocks
                     // (measured on 4096 chains of 8000 variants: 15.1 -> 13.2 ms; k_records and k_bins lose with the same change)
 #endif
+template <bool SPLIT>
 DEVI void prep_unit(const DevContig& dc, const DevTable& tab, uint32_t unit) {
     constexpr int NLP = PG_AMAX * (PG_AMAX + 1) / 2;  // local pairs of a narrow column
     __shared__ double s_m[4][64 * 3];
@@ -303,9 +305,17 @@ DEVI void prep_unit(const DevContig& dc, const DevTable& tab, uint32_t unit) {
 
     const uint32_t a0 = dc.allele_off[v], A = dc.allele_off[v + 1] - a0;
     const uint32_t H = dc.H, HP = dc.HP;
-    if (dc.prep_fast == 2u && A == 2u && dc.kmer_off[v + 1] - dc.kmer_off[v] <= 32u) return;   // k_prep_bi's object
+    // the split path (pg_split.h): the list is the kernel's own, kept columns are the index's; the record goes to the
+    // column's sample record instead of vrec
+    uint32_t col = PG_COL_NONE;
+    if constexpr (SPLIT) {
+        col = dc.col_of[v];
+        if (col == PG_COL_NONE) return;
+    } else {
+        if (dc.prep_fast == 2u && A == 2u && dc.kmer_off[v + 1] - dc.kmer_off[v] <= 32u) return;   // k_prep_bi's object
+    }
     if (A > PG_MAX_ALLELES_PER_VARIANT || A == 0) {
-        if (lane == 0) { atomicOr(dc.err, PG_DEVERR_TOO_MANY_ALLELES); dc.kept[v] = 0; }
+        if (lane == 0 && !SPLIT) { atomicOr(dc.err, PG_DEVERR_TOO_MANY_ALLELES); dc.kept[v] = 0; }
         return;
     }
     // ---- ColumnIndexer rule: kept iff a selected path carries a defined non-ref allele
@@ -336,16 +346,18 @@ DEVI void prep_unit(const DevContig& dc, const DevTable& tab, uint32_t unit) {
         }
     }
     wave_sync_lds();
-    const bool kept = __any(nonref) != 0;
+    const bool kept = SPLIT || __any(nonref) != 0;
     if (__any(bad) != 0) {
-        if (lane == 0) { atomicOr(dc.err, PG_DEVERR_ALLELE_NOT_FOUND); dc.kept[v] = 0; }
+        if (lane == 0 && !SPLIT) { atomicOr(dc.err, PG_DEVERR_ALLELE_NOT_FOUND); dc.kept[v] = 0; }
         return;
     }
     uint32_t n_local = 0;
 #pragma unroll
     for (int q = 0; q < 8; ++q) n_local += __popc(pres[q]);
-    for (uint32_t q = lane; q < A; q += 64) dc.allele_present[a0 + q] = slot_present(pres, q) ? 1 : 0;
-    if (lane == 0) dc.kept[v] = kept ? 1 : 0;
+    if constexpr (!SPLIT) {
+        for (uint32_t q = lane; q < A; q += 64) dc.allele_present[a0 + q] = slot_present(pres, q) ? 1 : 0;
+        if (lane == 0) dc.kept[v] = kept ? 1 : 0;
+    }
     if (!kept) return;
     // more than PG_AMAX alleles on the selected paths: a WIDE column, its tables go to the side
     // buffer (pg_shim.cpp reserves an entry for every variant that could be wide; such a column is genotyped by k_post in
@@ -357,7 +369,8 @@ DEVI void prep_unit(const DevContig& dc, const DevTable& tab, uint32_t unit) {
         return;
     }
 
-    unsigned char* rec = dc.vrec + (size_t)v * dc.RB;
+    unsigned char* rec = SPLIT ? nullptr : dc.vrec + (size_t)v * dc.RB;
+    unsigned char* srec = SPLIT ? (unsigned char*)dc.frec + (size_t)col * (dc.split == 1u ? PG_SREC1_BYTES : PG_SREC2_BYTES) : nullptr;
     // local (dense) allele index of every selected path; phantom paths of the padding get 255
     const uint32_t pspan = HP < 128u ? 128u : HP;
     for (uint32_t p0 = 0; p0 < pspan; p0 += 64) {
@@ -367,9 +380,17 @@ DEVI void prep_unit(const DevContig& dc, const DevTable& tab, uint32_t unit) {
             const int s = slot_lookup(dc.path_allele[(size_t)v * H + p]);
             val = (unsigned char)local_index(pres, (uint32_t)s);
         }
+        if constexpr (SPLIT) {
+            // a WIDE column's record carries its sixteen raw local alleles in its first sixteen bytes, the rest is zero (pg_small16x.h)
+            if (n_local > PG_AMAX && p0 == 0) {
+                if (lane < 16u) srec[lane] = val;
+                if (lane >= 2u && lane < 15u) ((double*)srec)[lane] = 0.0;
+            }
+        } else {
         if (p < HP) rec[PG_REC_ALLELES + p] = val;
         const unsigned long long b1 = __ballot(val == 1);
         if (lane == 0 && p0 < 128u) ((unsigned long long*)(rec + PG_REC_BITS1))[p0 >> 6] = b1;
+        }
     }
 
     // ---- emission products over ALL allele pairs of the object (a1<=a2; table is symmetric),
@@ -416,6 +437,16 @@ DEVI void prep_unit(const DevContig& dc, const DevTable& tab, uint32_t unit) {
                     Pe[la * S + lb] = ev; Pe[lb * S + la] = ev;
                 }
             }
+        }
+        if constexpr (SPLIT) {
+            if (lane == 0) {
+                uint32_t l = 0;
+                for (uint32_t sl = 0; sl < A; ++sl)
+                    if (slot_present(pres, sl)) slots[l++] = (uint16_t)sl;
+                const uint32_t fl = (any_nz ? 0u : PG_SREC_FLAG_ALLZERO) | PG_SREC_FLAG_WIDE;
+                ((unsigned long long*)srec)[15] = (unsigned long long)(uint32_t)Xw | ((unsigned long long)fl << 32);
+            }
+            return;
         }
         if (lane < PG_ETAB) ((double*)(rec + PG_REC_E))[lane] = 0.0;
         if (lane < 4) ((double*)rec)[lane] = 0.0;
@@ -539,6 +570,34 @@ DEVI void prep_unit(const DevContig& dc, const DevTable& tab, uint32_t unit) {
     int X = wave_max_i32((mine && pm > 0.0) ? pe : -(1 << 30));
     if (X == -(1 << 30) || all_zeros) X = 0;
 
+    if constexpr (SPLIT) {
+        // lane = local pair in tri_local order (above): its scaled entry, X and the flags straight into the column's sample record
+        const double val = !mine ? 0.0 : (all_zeros ? 1.0 : ((pm > 0.0) ? ldexp(pm, pe - X) : pm));
+        const bool precise = __any(mine && !all_zeros && pm > 0.0 && pe - X < -1021) != 0;
+        const uint32_t fl = (all_zeros ? PG_SREC_FLAG_ALLZERO : 0u) | (precise ? PG_SREC_FLAG_PRECISE : 0u);
+        if (dc.split == 1u) {
+            // (a biallelic object with more than 32 k-mers in an all-biallelic chain: k_sweep_small16's 64-byte record)
+            const double E00 = readlane_f64(val, 0), E01 = readlane_f64(val, 1), E11 = readlane_f64(val, PG_AMAX);
+            if (lane == 0) {
+                const v2f64* ir = (const v2f64*)(dc.ix_rec + (size_t)col * PG_IXREC_BYTES);
+                const unsigned long long bits = (unsigned long long)__double_as_longlong(ir[2].x);
+                const unsigned long long packed = (bits & 0xFFFFull) | ((unsigned long long)fl << 16) | ((unsigned long long)(uint32_t)X << 32);
+                v2f64* dst = (v2f64*)srec;
+                dst[0] = ir[0]; dst[1] = ir[1];
+                dst[2] = v2f64{E00, E01};
+                dst[3] = v2f64{E11, __longlong_as_double((long long)packed)};
+            }
+        } else if (lane < 16u) {
+            double out = val;
+            if (lane == 15u) out = __longlong_as_double((long long)((unsigned long long)(uint32_t)X | ((unsigned long long)fl << 32)));
+            ((double*)srec)[lane] = out;
+        }
+        if (precise && lane < 16u) {
+            ((double*)(dc.cprec + (size_t)col * PG_CPREC_BYTES))[lane] = !mine ? 0.0 : (all_zeros ? 0.5 : pm);
+            ((int*)(dc.cprec + (size_t)col * PG_CPREC_BYTES + 128u))[lane] = !mine ? 0 : (all_zeros ? 1 : pe);
+        }
+        return;
+    }
     if (lane < PG_ETAB) s_E[wave][lane] = 0.0;
     wave_sync_lds();
     if (mine) {
@@ -574,11 +633,21 @@ DEVI void prep_unit(const DevContig& dc, const DevTable& tab, uint32_t unit) {
 }
 __global__ __launch_bounds__(256) void k_prep(const DevContig* __restrict__ contigs, DevTable tab) {
     const DevContig& dc = contigs[blockIdx.y];
-    if (dc.prep_fast == 1u) return;  // k_prep_bi's chain (2: its two-allele objects only, see prep_unit)
+    if (dc.prep_fast == 1u || dc.split) return;  // k_prep_bi's chain (2: its two-allele objects only, see prep_unit); the split path's
 #pragma unroll 1
     for (uint32_t r = 0; r < (uint32_t)PG_VREP; ++r) {
-        prep_unit(dc, tab, blockIdx.x * (uint32_t)PG_VREP + r);
+        prep_unit<false>(dc, tab, blockIdx.x * (uint32_t)PG_VREP + r);
         wave_sync_lds();   // (a wave's LDS slices are its own: the next unit's writes stay behind this unit's reads)
+    }
+}
+// ... of the split path (pg_split.h): the objects of a split chain that are neither k_prep_s_bi's nor k_prep_s_m4's (the list prep_w)
+__global__ __launch_bounds__(256) void k_prep_s_w(const DevContig* __restrict__ contigs, DevTable tab) {
+    const DevContig& dc = contigs[blockIdx.y];
+    if (!dc.split || !dc.prep_w) return;
+#pragma unroll 1
+    for (uint32_t r = 0; r < (uint32_t)PG_VREP; ++r) {
+        prep_unit<true>(dc, tab, blockIdx.x * (uint32_t)PG_VREP + r);
+        wave_sync_lds();
     }
 }
 
@@ -777,7 +846,7 @@ DEVI void prep_bi_unit(const DevContig& dc, const DevTable& tab, uint32_t unit) 
 }
 __global__ __launch_bounds__(256) void k_prep_bi(const DevContig* __restrict__ contigs, DevTable tab) {
     const DevContig& dc = contigs[blockIdx.y];
-    if (!dc.prep_fast) return;
+    if (!dc.prep_fast || dc.split) return;
 #pragma unroll 1
     for (uint32_t r = 0; r < (uint32_t)PG_VREP; ++r) prep_bi_unit(dc, tab, blockIdx.x * (uint32_t)PG_VREP + r);
 }
@@ -797,6 +866,7 @@ __global__ __launch_bounds__(256) void k_prep_bi(const DevContig* __restrict__ c
 //  order of the multiplications differs.  reference src/emissionprobabilitycomputer.cpp:9-53, src/columnindexer.cpp:24-31
 // ------------------------------------------------------------------------------------------
 DEVI uint32_t row16_ballot(bool p, uint32_t grp) { return (uint32_t)((__ballot(p) >> (16u * grp)) & 0xFFFFull); }
+template <bool SPLIT>
 DEVI void prep_m4_unit(const DevContig& dc, const DevTable& tab, uint32_t unit) {
     // (row strides padded: at 192 doubles / ints the four rows of a wave fell on the same LDS banks — every factor read a
     //  four-way conflict, 40 % of the kernel's busy cycles)
@@ -822,6 +892,16 @@ DEVI void prep_m4_unit(const DevContig& dc, const DevTable& tab, uint32_t unit) 
     int slot[4];
     uint32_t mine = 0;   // slots this lane's paths carry
     bool bad = false, nonref = false;
+    uint32_t pres = 0;
+    uint32_t col = PG_COL_NONE;   // (SPLIT) the object's column
+    if constexpr (SPLIT) {
+        // the split path (pg_split.h): kept columns and present alleles are the INDEX's — nothing to scan
+        col = live ? dc.col_of[v] : PG_COL_NONE;
+        live = live && col != PG_COL_NONE;
+#pragma unroll
+        for (int q = 0; q < PG_AMAX; ++q) if ((uint32_t)q < A && dc.allele_present[a0 + q]) pres |= 1u << q;
+        if (!live) return;
+    } else {
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const uint32_t p = 16u * (uint32_t)i + l;
@@ -841,7 +921,6 @@ DEVI void prep_m4_unit(const DevContig& dc, const DevTable& tab, uint32_t unit) 
         }
     }
     const bool any_bad = row16_ballot(bad, grp) != 0u, kept = row16_ballot(nonref, grp) != 0u;
-    uint32_t pres = 0;
 #pragma unroll
     for (int q = 0; q < PG_AMAX; ++q) pres |= (row16_ballot((mine >> q) & 1u, grp) != 0u ? 1u : 0u) << q;
     if (!live) return;
@@ -852,10 +931,12 @@ DEVI void prep_m4_unit(const DevContig& dc, const DevTable& tab, uint32_t unit) 
     if (l < A) dc.allele_present[a0 + l] = (pres >> l) & 1u;
     if (l == 0) dc.kept[v] = kept ? 1 : 0;
     if (!kept) return;
+    }
     const uint32_t n_local = __popc(pres);
     auto local_of = [&](uint32_t sl) { return (uint32_t)__popc(pres & ((1u << sl) - 1u)); };
     unsigned char* rec = s_rec[wv][grp];
     unsigned long long ones = 0;   // bit p: selected path p carries LOCAL allele 1
+    if constexpr (!SPLIT) {
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const uint32_t p = 16u * (uint32_t)i + l;
@@ -864,6 +945,7 @@ DEVI void prep_m4_unit(const DevContig& dc, const DevTable& tab, uint32_t unit) 
         ones |= (unsigned long long)row16_ballot(loc == 1u, grp) << (16u * (uint32_t)i);
     }
     for (uint32_t pad = PG_REC_ALLELES + HP + l; pad < dc.RB; pad += 16u) rec[pad] = 0;   // (the record's tail up to RB)
+    }
     // ---- the copy-number factors of the object's k-mers -> LDS (lane l: k-mers l, 16 + l, 32 + l, 48 + l)
     const uint32_t k0 = dc.kmer_off[v], K = dc.kmer_off[v + 1] - k0, cov = dc.cov[v];
     double* lm = s_m[wv][grp];
@@ -881,8 +963,10 @@ DEVI void prep_m4_unit(const DevContig& dc, const DevTable& tab, uint32_t unit) 
             for (int c = 0; c < 3; ++c) { lm[k * 3 + c] = m[c]; le[k * 3 + c] = e[c]; }
         }
     }
+    if constexpr (!SPLIT) {
     if (l < 4u) ((double*)rec)[l] = 0.0;  // transition constants are filled by k_records
     for (uint32_t t = l; t < (uint32_t)PG_ETAB; t += 16u) ((double*)(rec + PG_REC_E))[t] = 0.0;
+    }
     wave_sync_lds();
     // ---- the product of allele pair l over the k-mers
     const uint32_t P = A * (A + 1u) / 2u;
@@ -929,6 +1013,35 @@ DEVI void prep_m4_unit(const DevContig& dc, const DevTable& tab, uint32_t unit) 
         o = __builtin_amdgcn_update_dpp(X, X, 0x121, 0xF, 0xF, false); X = o > X ? o : X;   // row_ror:1
     }
     if (X == -(1 << 30) || all_zeros) X = 0;
+    if constexpr (SPLIT) {
+        // the column's sample record (pg_device.h): the fifteen scaled entries in tri_local order, then {X, flags} — put together
+        // in the row's LDS slice (entry of local pair (la, lb) at tri_local(la, lb)), stored by the row's sixteen lanes as
+        // 128 contiguous bytes; a column with a present pair below fp64's normal range under X also keeps its
+        // (mantissa, exponent) products in cprec
+        double* ent = (double*)rec;   // [16] entries, then [16] mantissas, [16] exponents (as ints)
+        ent[l] = 0.0; ent[16 + l] = 0.0; ((int*)(ent + 32))[l] = 0;
+        const bool lowp = both && !all_zeros && pm > 0.0 && pe - X < -1021;
+        const bool precise = row16_ballot(lowp, grp) != 0u;
+        wave_sync_lds();
+        if (both) {
+            const uint32_t la = local_of(s1), lb = local_of(s2);   // s1 <= s2  =>  la <= lb
+            const uint32_t ti = tri_local(la, lb);
+            ent[ti] = all_zeros ? 1.0 : ((pm > 0.0) ? ldexp(pm, pe - X) : pm);
+            ent[16 + ti] = all_zeros ? 0.5 : pm;
+            ((int*)(ent + 32))[ti] = all_zeros ? 1 : pe;
+        }
+        wave_sync_lds();
+        const uint32_t flags = (all_zeros ? PG_SREC_FLAG_ALLZERO : 0u) | (precise ? PG_SREC_FLAG_PRECISE : 0u);
+        double out = ent[l];
+        if (l == 15u) out = __longlong_as_double((long long)((unsigned long long)(uint32_t)X | ((unsigned long long)flags << 32)));
+        ((double*)((unsigned char*)dc.frec + (size_t)col * PG_SREC2_BYTES))[l] = out;
+        if (precise) {
+            ((double*)(dc.cprec + (size_t)col * PG_CPREC_BYTES))[l] = ent[16 + l];
+            ((int*)(dc.cprec + (size_t)col * PG_CPREC_BYTES + 128u))[l] = ((int*)(ent + 32))[l];
+        }
+        wave_sync_lds();   // (the slots are rewritten by the wave's next unit)
+        return;
+    }
     if (both) {
         const uint32_t la = local_of(s1), lb = local_of(s2);   // s1 <= s2  =>  la <= lb
         double val;
@@ -973,9 +1086,16 @@ DEVI void prep_m4_unit(const DevContig& dc, const DevTable& tab, uint32_t unit) 
 }
 __global__ __launch_bounds__(256) void k_prep_m4(const DevContig* __restrict__ contigs, DevTable tab) {
     const DevContig& dc = contigs[blockIdx.y];
-    if (!dc.prep_m4) return;
+    if (!dc.prep_m4 || dc.split) return;
 #pragma unroll 1
-    for (uint32_t r = 0; r < (uint32_t)PG_VREP; ++r) prep_m4_unit(dc, tab, blockIdx.x * (uint32_t)PG_VREP + r);
+    for (uint32_t r = 0; r < (uint32_t)PG_VREP; ++r) prep_m4_unit<false>(dc, tab, blockIdx.x * (uint32_t)PG_VREP + r);
+}
+// ... of the split path: the same products of the chain's 3 .. PG_AMAX-allele objects, into the column's sample record (pg_split.h)
+__global__ __launch_bounds__(256) void k_prep_s_m4(const DevContig* __restrict__ contigs, DevTable tab) {
+    const DevContig& dc = contigs[blockIdx.y];
+    if (!dc.prep_m4 || dc.split != 2u) return;
+#pragma unroll 1
+    for (uint32_t r = 0; r < (uint32_t)PG_VREP; ++r) prep_m4_unit<true>(dc, tab, blockIdx.x * (uint32_t)PG_VREP + r);
 }
 
 __global__ __launch_bounds__(64) void k_emission_single(const DevContig* __restrict__ contigs, DevTable tab,
@@ -1021,8 +1141,11 @@ __global__ __launch_bounds__(1024) void k_compact(const DevContig* __restrict__ 
         __syncthreads();
     }
     uint32_t pos = s_cnt[tid] - cnt;
-    for (uint32_t v = lo; v < hi; ++v)
+    uint32_t* col_of = const_cast<uint32_t*>(dc.col_of);
+    for (uint32_t v = lo; v < hi; ++v) {
+        if (col_of) col_of[v] = dc.kept[v] ? pos : PG_COL_NONE;
         if (dc.kept[v]) dc.col_variant[pos++] = v;
+    }
     if (tid == 1023) *dc.n_cols = s_cnt[1023];
 }
 
@@ -1066,6 +1189,7 @@ DEVI bool compact_records_only(const DevContig& dc, uint32_t C) {
 DEVI void records_unit(const DevContig& dc, uint32_t unit) {
     const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const uint32_t C = *dc.n_cols;
+    if (dc.split) return;   // the split path (pg_split.h): its records are written in column order by the emission kernels
     if (compact_records_only(dc, C) && !dc.smallx) {
         const uint32_t c = unit * 256u + threadIdx.x;
         if (c >= C) return;
@@ -2618,6 +2742,7 @@ __global__ __launch_bounds__((ChainCfg<HP, R, sweep_has_loader<HP, PHASE>()>::TT
     extern __shared__ __attribute__((aligned(16))) unsigned char dyn_ring[];  // phase 2: kRingSlots column slots
     const DevContig& dc = contigs[blockIdx.x];
     if (dc.HP != (uint32_t)HP) return;
+    if (dc.split) return;   // the split path: k_sweep_small16[x] both phases; a chain left with one column needs no sweep (k_bins_s)
     if (PHASE != 2 && (dc.lean || dc.small || dc.smallx || dc.leanx)) return;  // store-only phases of all-biallelic H = 64 / H = 16 chains: k_sweep_lean / k_sweep_small16[x]
     // (written by k_compact: a vector load as far as the compiler knows — make the trip count, and
     // with it every column index, ring slot and address derived from it, wave-uniform again)
@@ -4906,14 +5031,15 @@ DEVI void store_bin(double* lik, int32_t* lik_exp, uint64_t idx, double sum, dou
 // chains of up to 32 paths (at most 64 partial entries per column and slot pair): one THREAD per column (k_bins_thin) —
 // a wave per column spent ~460 vector instructions on each (eight 64-lane sums, the index arithmetic and a division, all
 // wave-wide for one column), 7 ms for the 8.2 M columns of `cohort_h17`
-DEVI bool bins_x(const DevContig& dc, uint32_t C) { return dc.smallx == 2u && C >= 2u; }   // k_bins_x / k_bins_wide (chains on k_sweep_small16x<2>)
-DEVI bool bins_thin(const DevContig& dc) { return dc.T <= 64u && dc.HP <= 32u && !dc.cls4 && dc.chunk_cols == 0u && !bins_x(dc, *dc.n_cols); }
+DEVI bool bins_x(const DevContig& dc, uint32_t C) { return dc.smallx == 2u && C >= 2u && !dc.split; }   // k_bins_x / k_bins_wide (chains on k_sweep_small16x<2>)
+DEVI bool bins_thin(const DevContig& dc) { return dc.T <= 64u && dc.HP <= 32u && !dc.cls4 && dc.chunk_cols == 0u && !bins_x(dc, *dc.n_cols) && !dc.split; }
 
 DEVI void bins_unit(const DevContig& dc, uint32_t unit, double (&s_bins)[4][PG_AMAX * (PG_AMAX + 1) / 2]) {
     const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const uint32_t c = unit * 4 + wave;
     const uint32_t C = *dc.n_cols;
     if (c >= C) return;
+    if (dc.split) return;                                // the split path: k_bins_s / k_bins_wide_s (pg_split.h)
     if ((dc.tri == 2u && C >= 2u) || dc.cls4) return;  // chains whose class sums arrive finished (k_sweep_lean2, DevContig::cls4): k_bins_lean2
     if (bins_x(dc, C)) return;                           // chains on k_sweep_small16x<2>: k_bins_x, k_bins_wide
     if (bins_thin(dc)) return;                           // few partial entries per column: k_bins_thin
@@ -5132,7 +5258,7 @@ __global__ __launch_bounds__(256) void k_bins_lean2(const DevContig* __restrict_
     const DevContig& dc = contigs[blockIdx.y];
     const uint32_t C = *dc.n_cols;
     const bool cls = dc.cls4 != 0u;   // class sums from the general kernel's single-wave configurations: full columns, no halving
-    if (!((dc.tri == 2u && C >= 2u) || cls)) return;
+    if (!((dc.tri == 2u && C >= 2u) || cls) || dc.split) return;
     const uint32_t c = blockIdx.x * 256u + threadIdx.x;
     if (c >= C) return;
     const bool fb = dc.fwd_fallback[c] != 0;
@@ -5245,10 +5371,14 @@ DEVI void post_ab(const DevContig& dc, uint32_t C, uint32_t c, const double* A, 
                   double (&s_bins_row)[PG_AMAX * (PG_AMAX + 1) / 2], double* s_wide) {
     const uint32_t HP = dc.HP;
     const bool direct = compact_records_only(dc, C);  // (no column-order copy of the records: the variant's own)
-    const unsigned char* rec = direct ? dc.vrec + (size_t)dc.col_variant[c] * dc.RB : dc.colrec + (size_t)c * dc.RB;
-    const uint32_t v = *(const uint32_t*)(rec + PG_REC_VARIANT);
-    const uint32_t nl = rec[PG_REC_NLOCAL];
-    const unsigned char* al = rec + PG_REC_ALLELES;
+    // (split chains, pg_split.h: only their WIDE columns come here — variant and allele count from the index's bins record, the
+    //  sixteen raw local alleles from the head of the column's sample record, the wide entry from the index's record)
+    const bool sp = dc.split != 0u;
+    const unsigned char* rec = sp ? nullptr : (direct ? dc.vrec + (size_t)dc.col_variant[c] * dc.RB : dc.colrec + (size_t)c * dc.RB);
+    const IxBin* ixb = sp ? (const IxBin*)(dc.ix_bin + (size_t)c * PG_IXBIN_BYTES) : nullptr;
+    const uint32_t v = sp ? ixb->v : *(const uint32_t*)(rec + PG_REC_VARIANT);
+    const uint32_t nl = sp ? ixb->nl : rec[PG_REC_NLOCAL];
+    const unsigned char* al = sp ? (const unsigned char*)dc.frec + (size_t)c * PG_SREC2_BYTES : rec + PG_REC_ALLELES;
     if (lane < PG_AMAX * (PG_AMAX + 1) / 2) s_bins_row[lane] = 0.0;
     wave_sync_lds();   // (LDS only: the header loads above stay in flight under the first column loads below)
 
@@ -5266,7 +5396,8 @@ DEVI void post_ab(const DevContig& dc, uint32_t C, uint32_t c, const double* A, 
     const double scale = 1.0 / ((fb ? 1.0 : dc.fscale[c]) * dc.bscale[c]);
     int xexp = -((fb ? 0 : PG_BIAS_F) + PG_BIAS_B);
     if (c + 1 < C)
-        xexp += *(const int32_t*)((direct ? dc.vrec + (size_t)dc.col_variant[c + 1] * dc.RB : dc.colrec + (size_t)(c + 1) * dc.RB) + PG_REC_EXP);
+        xexp += sp ? *(const int32_t*)((const unsigned char*)dc.frec + (size_t)(c + 1) * PG_SREC2_BYTES + 120u)
+                   : *(const int32_t*)((direct ? dc.vrec + (size_t)dc.col_variant[c + 1] * dc.RB : dc.colrec + (size_t)(c + 1) * dc.RB) + PG_REC_EXP);
     // Wide columns (more than PG_AMAX alleles on the selected paths) take one sweep over the two
     // columns per block of PG_AMAX row alleles and add their bins straight into lik (zeroed at the
     // start of the run; this wave is the only writer of the variant's bins).
@@ -5275,7 +5406,7 @@ DEVI void post_ab(const DevContig& dc, uint32_t C, uint32_t c, const double* A, 
     const unsigned char* went = nullptr;
     const uint32_t WS = nl + 1u;  // row stride of a wide entry's tables
     if (widec) {
-        went = dc.wide + (size_t)(*(const uint32_t*)(rec + PG_REC_WIDE_IDX)) * 16u;
+        went = dc.wide + (size_t)(sp ? *(const uint32_t*)(dc.ix_rec + (size_t)c * PG_IXREC_BYTES + 4u) : *(const uint32_t*)(rec + PG_REC_WIDE_IDX)) * 16u;
         wslots = (const uint16_t*)(went + PG_WIDE_OFF_SLOT(WS));
     }
     const bool in_lds = widec && s_wide != nullptr && nl <= (uint32_t)PG_WIDE_LDS_N;
@@ -5522,6 +5653,8 @@ __global__ __launch_bounds__(256) void k_bins_wide(const DevContig* __restrict__
     else post_ab(dc, C, c, stored, mine, lane, s_bins[wave], s_wide[wave]);
 }
 
+#include "pg_split.h"   // the split path: index-level kernels, sample-level emissions and bins of the 16-path chains of fused jobs
+
 // ------------------------------------------------------------------------------------------
 //  host-callable launchers (defined here so that the shim needs no kernel templates)
 // ------------------------------------------------------------------------------------------
@@ -5593,6 +5726,21 @@ void pgk_launch_prep(const DevContig* d_contigs, uint32_t n_contigs, uint32_t ma
 void pgk_launch_compact(const DevContig* d_contigs, uint32_t n_contigs, hipStream_t s) {
     hipLaunchKernelGGL(k_compact, dim3(n_contigs), dim3(1024), 0, s, d_contigs);
 }
+// The index-level work of a job (pg_split.h), once per uploaded index: d_reps = one chain descriptor per index contig.
+// ColumnIndexer flags -> column list -> (split chains) the per-column index records.
+void pgk_launch_index(const DevContig* d_reps, uint32_t n_index, uint32_t max_v, int any_split, hipStream_t s) {
+    if (max_v == 0 || n_index == 0) return;
+    hipLaunchKernelGGL(k_index_scan, dim3((max_v + 3u) / 4u, n_index), dim3(256), 0, s, d_reps);
+    hipLaunchKernelGGL(k_compact, dim3(n_index), dim3(1024), 0, s, d_reps);
+    if (any_split) hipLaunchKernelGGL(k_index_cols, dim3((max_v + 3u) / 4u, n_index), dim3(256), 0, s, d_reps);
+}
+// The sample-level emission kernels of split chains: max_b / max_m4 / max_w = the longest walks of k_prep_s_bi (a chain's list of
+// biallelic objects, or all its variants), k_prep_s_m4 and k_prep_s_w over the chains
+void pgk_launch_prep_split(const DevContig* d_contigs, uint32_t n_contigs, uint32_t max_b, uint32_t max_m4, uint32_t max_w, DevTable tab, hipStream_t s) {
+    if (max_b) hipLaunchKernelGGL(k_prep_s_bi, dim3((max_b + 255u) / 256u, n_contigs), dim3(256), 0, s, d_contigs, tab);
+    if (max_m4) hipLaunchKernelGGL(k_prep_s_m4, dim3((max_m4 + 16 * PG_VREP - 1) / (16 * PG_VREP), n_contigs), dim3(256), 0, s, d_contigs, tab);
+    if (max_w) hipLaunchKernelGGL(k_prep_s_w, dim3((max_w + 4 * PG_VREP - 1) / (4 * PG_VREP), n_contigs), dim3(256), 0, s, d_contigs, tab);
+}
 void pgk_launch_records(const DevContig* d_contigs, uint32_t n_contigs, uint32_t max_v, hipStream_t s) {
     dim3 grid((max_v + 255) / 256, n_contigs);   // 256 columns per block either way (a thread or a quarter of a wave's 64 each)
     hipLaunchKernelGGL(k_records, grid, dim3(256), 0, s, d_contigs);
@@ -5608,6 +5756,9 @@ void pgk_launch_bins(const DevContig* d_contigs, uint32_t n_contigs, uint32_t ma
     if (which & 8u) hipLaunchKernelGGL(k_bins_x, grid256, dim3(256), 0, s, d_contigs);      // bit 3: chains on k_sweep_small16x<2>
     if ((which & 16u) && max_wide)   // bit 4: ... with objects of more than PG_AMAX alleles: one wave per listed wide column
         hipLaunchKernelGGL(k_bins_wide, dim3((max_wide + 3u) / 4u, n_contigs), dim3(256), 0, s, d_contigs);
+    if (which & 32u) hipLaunchKernelGGL(k_bins_s, grid256, dim3(256), 0, s, d_contigs);     // bit 5: split chains (pg_split.h)
+    if ((which & 64u) && max_wide)   // bit 6: ... with wide columns
+        hipLaunchKernelGGL(k_bins_wide_s, dim3((max_wide + 3u) / 4u, n_contigs), dim3(256), 0, s, d_contigs);
 }
 void pgk_launch_sweep(const DevContig* d_contigs, uint32_t n_contigs, uint32_t hp_mask, int phase, hipStream_t s) {
     if (phase == 1) launch_sweep<1>(d_contigs, n_contigs, hp_mask, 0, s);

@@ -35,6 +35,8 @@
 extern "C" {
 void pgk_launch_prep(const DevContig*, uint32_t, uint32_t, uint32_t, uint32_t, DevTable, hipStream_t);
 void pgk_launch_compact(const DevContig*, uint32_t, hipStream_t);
+void pgk_launch_index(const DevContig*, uint32_t, uint32_t, int, hipStream_t);
+void pgk_launch_prep_split(const DevContig*, uint32_t, uint32_t, uint32_t, uint32_t, DevTable, hipStream_t);
 void pgk_launch_records(const DevContig*, uint32_t, uint32_t, hipStream_t);
 void pgk_launch_bins(const DevContig*, uint32_t, uint32_t, uint32_t, uint32_t, hipStream_t);
 void pgk_launch_sweep(const DevContig*, uint32_t, uint32_t, int, hipStream_t);
@@ -128,7 +130,7 @@ bool in_table(const pg_table* t, uint16_t cov, uint16_t count) {
 // (mantissa, exponent) view of the dense table, layout [cov][count][3].  Every job gets its OWN device
 // copy inside its arena: a later pg_table_modify / pg_table_destroy cannot pull it away from under a
 // resident job.
-void table_snapshot(pg_table* t, std::vector<double>& m, std::vector<int32_t>& e, DevTable* meta) {
+void table_snapshot(pg_table* t, std::vector<double>& m, std::vector<int32_t>& e, std::vector<unsigned char>& packed, DevTable* meta) {
     std::lock_guard<std::mutex> lock(t->mu);
     const uint32_t ncov = t->cov_max > t->cov_min ? t->cov_max - t->cov_min : 0;
     meta->cov_min = t->cov_min; meta->cov_max = t->cov_max; meta->count_max = t->count_max; meta->pad = 0;
@@ -145,6 +147,16 @@ void table_snapshot(pg_table* t, std::vector<double>& m, std::vector<int32_t>& e
                 m[((size_t)c * t->count_max + k) * 3 + i] = (double)mant;
                 e[((size_t)c * t->count_max + k) * 3 + i] = ex;
             }
+    // the same entries as 32-byte pieces {m0, m1, m2, int16 e0, e1, e2, 0} (DevTable::packed)
+    packed.assign(n ? n / 3 * 32 : 32, 0);
+    for (size_t q = 0; q < n / 3; ++q) {
+        memcpy(&packed[q * 32], &m[q * 3], 24);
+        for (int i = 0; i < 3; ++i) {
+            const int32_t ex = e[q * 3 + i];
+            const int16_t e16 = (int16_t)(ex < -32768 ? -32768 : (ex > 32767 ? 32767 : ex));   // (|exponent| <= 16445: long double's range)
+            memcpy(&packed[q * 32 + 24 + 2 * i], &e16, 2);
+        }
+    }
 }
 
 }  // namespace
@@ -226,6 +238,12 @@ struct IndexHost {   // one index contig
     uint32_t n_wide_cand = 0;        // variants with more than PG_AMAX alleles (each may be a wide column)
     size_t o_auxidx = 0;
     uint32_t prep_fast = 0;  // 1: every object has exactly two alleles and <= 32 k-mers, H <= 64: k_prep_bi; 2: at least half of them (k_prep the rest)
+    // The split path (pg_device.h, pg_split.h): 1 / 2 = the chains over this index contig are small / smallx chains whose
+    // per-variant work is split into what the index alone decides (formed once per upload) and what the sample's counts decide
+    uint32_t split = 0;
+    bool all_sb = false;     // every object is k_prep_s_bi's (two alleles, <= 32 k-mers): no lists
+    // index-level device arrays (every chain over this contig points at them)
+    size_t o_kept = 0, o_apres = 0, o_colv = 0, o_colof = 0, o_ixpd = 0, o_ixrec = 0, o_ixbin = 0, o_ixwl = 0, o_ixnw = 0;
     uint32_t sumK = 0, sumA = 0;
     uint64_t n_lik = 0, wide_bytes = 0;
     std::vector<uint16_t> n_kmers;   // [V] K of every variant
@@ -378,7 +396,18 @@ struct pg_job {
     bool smallx_phase2 = false;
     bool small_phase2 = false;    // some of them (fused jobs, class sums: DevContig::small == 2) also run their phase 2 on k_sweep_small16
     double* d_dump = nullptr;
-    uint32_t* d_ncols = nullptr;  // [n_chains]
+    uint32_t* d_ncols = nullptr;  // [n_index] kept columns of every index contig (k_compact, when the index is uploaded)
+    uint32_t* d_ixerr = nullptr;  // [n_index] error bits of the index-level kernels
+    DevContig* d_reps = nullptr;  // [n_index] one chain descriptor per index contig: what the index-level kernels walk
+    unsigned char* ix_base = nullptr;   // the index-derived arrays of all contigs, one run of the arena (zeroed before every index pass)
+    size_t ix_bytes = 0;
+    unsigned char* srec_base = nullptr; // the sample records of all split chains, one run (zeroed with every index pass: k_prep_s_bi leaves the zero pieces out)
+    size_t srec_bytes = 0;
+    bool any_split = false;
+    uint32_t max_sb = 0, max_sm4 = 0, max_sw = 0;   // grid extents of the split path's emission kernels
+    bool any_legacy_prep = false;
+    std::vector<unsigned char> tab_p;
+    size_t o_tab_p = 0;
     uint32_t* d_err = nullptr;    // [n_chains]
     double* d_lik = nullptr;      // packed, chain after chain
     int32_t* d_likexp = nullptr;
@@ -576,6 +605,7 @@ int upload_inputs(pg_job* job, const pg_contig_batch* batches, const std::vector
         }
         UP(job->o_tab_m, job->tab_m.data(), job->tab_m.size() * sizeof(double), bi);
         UP(job->o_tab_e, job->tab_e.data(), job->tab_e.size() * sizeof(int32_t), bi);
+        UP(job->o_tab_p, job->tab_p.data(), job->tab_p.size(), bi);
     }
     if (job->cohort) {   // (host arrays by contract: packed into pinned staging, a few large copies)
         std::vector<std::vector<uint16_t>> cov(job->chains.size());
@@ -629,6 +659,17 @@ int upload_inputs(pg_job* job, const pg_contig_batch* batches, const std::vector
         }
     }
     HIP_TRY(hipStreamSynchronize(s));
+    if (with_index) {
+        // The index pass (pg_split.h): what the index alone decides — kept columns, present alleles, the column list; for split
+        // chains the per-column index records — is formed NOW, once, for every chain over the index (reference: ColumnIndexer and
+        // TransitionProbabilityComputer read positions and path alleles only, src/columnindexer.cpp:8-33,
+        // src/transitionprobabilitycomputer.cpp:8-19).  A run of the job forms only what hangs on the sample's counts.
+        HIP_TRY(hipMemsetAsync(job->ix_base, 0, job->ix_bytes, s));
+        if (job->srec_bytes) HIP_TRY(hipMemsetAsync(job->srec_base, 0, job->srec_bytes, s));
+        pgk_launch_index(job->d_reps, (uint32_t)job->index.size(), job->max_v, job->any_split ? 1 : 0, s);
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipStreamSynchronize(s));
+    }
     job->up_bytes[0] = bi; job->up_bytes[1] = bs;
     job->host_s[1] = now_s() - t0;
     return PG_OK;
@@ -644,8 +685,10 @@ int upload_inputs(pg_job* job, const pg_contig_batch* batches, const std::vector
 //                       partials instead of class sums | k_prep for every object
 //   fullcols            fused jobs at HP = 32 store and fetch whole 32 x 32 columns (DevContig::live = HP)
 //   nosmall2            phase 2 of the 16-path chains of fused jobs on the general kernel (k_sweep_small16 for phase 1 only)
+//   nosplit             the 16-path chains of fused jobs prepare every variant per sample (k_prep*, k_records, k_bins_lean2 / _x) instead of
+//                       taking the split path (pg_split.h)
 struct KernelChoice {
-    bool general = false, generic = false, nolean2 = false, notri = false, nocls4 = false, prepwave = false, fullcols = false, nosmall2 = false;
+    bool general = false, generic = false, nolean2 = false, notri = false, nocls4 = false, prepwave = false, fullcols = false, nosmall2 = false, nosplit = false;
     int leanx = -1, small = -1;   // -1: by the job, 0 / 1: forced
     std::string unknown;          // a token this list does not know
 };
@@ -661,6 +704,7 @@ KernelChoice kernel_choice() {
         else if (tok == "nolean2") k.nolean2 = true; else if (tok == "notri") k.notri = true;
         else if (tok == "nocls4") k.nocls4 = true; else if (tok == "prepwave") k.prepwave = true;
         else if (tok == "fullcols") k.fullcols = true; else if (tok == "nosmall2") k.nosmall2 = true;
+        else if (tok == "nosplit") k.nosplit = true;
         else if (!tok.empty()) k.unknown = tok;   // (a typo would quietly test the default path against itself: job creation fails)
         tok.clear();
     };
@@ -752,7 +796,7 @@ int job_build(int device, uint32_t n_index, const pg_contig_batch* batches, cons
     for (auto& e : job->ev_vit)
         if ((he = hipEventCreate(&e)) != hipSuccess) return fail(PG_ERR_DEVICE, "hipEventCreate", he);
     job->events = true;
-    table_snapshot(const_cast<pg_table*>(table), job->tab_m, job->tab_e, &job->tab);
+    table_snapshot(const_cast<pg_table*>(table), job->tab_m, job->tab_e, job->tab_p, &job->tab);
 
     lap("streams, events, table");
     // ---- index contigs -------------------------------------------------------------------
@@ -795,7 +839,9 @@ int job_build(int device, uint32_t n_index, const pg_contig_batch* batches, cons
             // 15 + 1 sampled paths have a fifth of their objects multiallelic); PG_KERNELS=prepwave: k_prep for everything (cross-check)
             const bool ok = x.H <= 64u && x.V > 0 && !kc.prepwave;
             x.prep_fast = !ok ? 0u : ((two_alleles && maxK <= 32u) ? 1u : (2u * n_bi >= x.V ? 2u : 0u));
-            if (x.prep_fast == 2u) {   // who prepares what: k_prep_bi scans the chain for its own, the others walk lists
+            x.all_sb = two_alleles && maxK <= 32u;
+            // (the same lists serve the split path's emission kernels — 16-path chains, whatever the share of biallelic objects)
+            if (x.prep_fast == 2u || (lean_ok && x.HP == 16u && x.H == 16u && !x.all_sb)) {   // who prepares what: k_prep_bi scans the chain for its own, the others walk lists
                 for (uint32_t v = 0; v < x.V; ++v) {
                     const uint64_t A = b.allele_off[v + 1] - b.allele_off[v];
                     const uint32_t Kv = b.kmer_off[v + 1] - b.kmer_off[v];
@@ -922,30 +968,37 @@ int job_build(int device, uint32_t n_index, const pg_contig_batch* batches, cons
         }
     }
 
+    // ---- the split path: which index contigs' chains take it (pg_device.h) ---------------------------
+    for (auto& x : job->index) {
+        const bool s1 = x.small && !job->chunked && x.cls4 && !kc.nosmall2;   // (DevContig::small == 2 below)
+        const bool s2 = x.smallx && !job->chunked && !kc.nosmall2;            // (DevContig::smallx == 2)
+        const bool ok = !kc.nosplit && !params->run_phasing && params->run_genotyping && x.n_lik < 0xFFFFFFF0ull && x.V > 0;
+        x.split = !ok ? 0u : (s1 ? 1u : (s2 ? 2u : 0u));
+        if (x.split) job->any_split = true;
+    }
+
     // ---- plan the arena -----------------------------------------------------------------------
     job->chains.resize(n_chains);
     size_t off = 0;
     auto take = [&](size_t bytes, size_t al = 256) { off = align_up(off, al); size_t o = off; off += (bytes ? bytes : 8); return o; };
-    struct Plan { size_t wcols, aux, frec, scratch, wide, vpair, xbuf, prof, fback, fscale, bscale, bsum, vrec, cvar, colrec, fwd, part, kept, apres,
+    struct Plan { size_t wcols, aux, frec, scratch, wide, vpair, xbuf, prof, fback, fscale, bscale, bsum, vrec, colrec, fwd, part, cprec,
                   vtq, vback, vbest, hap1, hap2; };
     std::vector<Plan> plan(n_chains);
     const size_t o_contigs = take(sizeof(DevContig) * n_chains);
+    const size_t o_reps = take(sizeof(DevContig) * n_index);
     const size_t o_small = take(sizeof(uint32_t) * n_chains);   // chain ids of the H = 16 chains (k_sweep_small16)
     const size_t o_dump = take(64 * 8 * 16 + 8 * 16 * 16 * 16);  // scrap column for the stores of its rows that are done
     // zeroed-every-run block: n_cols, err, per chain kept / fallback flags / profile counters / allele_present,
     // then the packed lik and lik_exp regions (chain after chain, no gaps: one range each for a gather)
     const size_t zero_lo = align_up(off);
-    const size_t o_ncols = take(sizeof(uint32_t) * n_chains);
     const size_t o_err = take(sizeof(uint32_t) * n_chains);
     uint64_t lik_total = 0;
     for (uint32_t c = 0; c < n_chains; ++c) {
         ChainHost& ch = job->chains[c];
         ch.index = specs[c].index;
         const IndexHost& x = job->index[ch.index];
-        plan[c].kept = take(x.V);
         plan[c].fback = take(x.V);
         plan[c].prof = take(64 * sizeof(unsigned long long));
-        plan[c].apres = take(x.sumA);
         plan[c].wcols = take(4);   // (the count of the chain's wide-column list: zeroed with the rest of this block; the list itself below)
         const bool vit = params->run_phasing != 0;
         plan[c].vbest = take(vit ? 4 : 0);
@@ -960,6 +1013,24 @@ int job_build(int device, uint32_t n_index, const pg_contig_batch* batches, cons
     const size_t zero_hi = off;
     job->o_tab_m = take(job->tab_m.size() * sizeof(double));
     job->o_tab_e = take(job->tab_e.size() * sizeof(int32_t));
+    job->o_tab_p = take(job->tab_p.size());
+    // what the index alone decides, formed by the index-level kernels whenever an index is uploaded (pg_split.h): one run of the
+    // arena, zeroed before every such pass — column flags, present alleles, the column list and its inverse for every index
+    // contig; for split contigs the per-column records and the list of wide columns
+    const size_t ix_lo = align_up(off);
+    const size_t o_ncols = take(sizeof(uint32_t) * n_index);
+    const size_t o_ixerr = take(sizeof(uint32_t) * n_index);
+    for (uint32_t i = 0; i < n_index; ++i) {
+        IndexHost& x = job->index[i];
+        x.o_kept = take(x.V); x.o_apres = take(x.sumA);
+        x.o_colv = take((size_t)x.V * 4); x.o_colof = take((size_t)x.V * 4);
+        x.o_ixpd = take(x.split ? (size_t)x.V * PG_IXPD_BYTES : 0);
+        x.o_ixrec = take(x.split ? (size_t)x.V * PG_IXREC_BYTES : 0);
+        x.o_ixbin = take(x.split ? (size_t)x.V * PG_IXBIN_BYTES : 0);
+        x.o_ixwl = take(x.split == 2u && x.wide_bytes ? (size_t)x.n_wide_cand * 4 : 0);
+        x.o_ixnw = take(4);
+    }
+    const size_t ix_hi = off > ix_lo ? off : ix_lo;
     for (uint32_t i = 0; i < n_index; ++i) {
         IndexHost& x = job->index[i];
         x.o_pos = take((size_t)x.V * 8);
@@ -988,14 +1059,22 @@ int job_build(int device, uint32_t n_index, const pg_contig_batch* batches, cons
     // alleles: 96 of 384 bytes at 16 paths — it is a kernel that waits for its memory 70 % of the time); what it leaves out — the
     // rest of the 6 x 6 table, the padding — has to BE zero for every reader of the full record.
     const size_t vrec_lo = align_up(off);
-    for (uint32_t c = 0; c < n_chains; ++c) { const IndexHost& x = job->index[job->chains[c].index]; plan[c].vrec = take((size_t)x.V * x.RB); }
+    for (uint32_t c = 0; c < n_chains; ++c) { const IndexHost& x = job->index[job->chains[c].index]; plan[c].vrec = take(x.split ? 0 : (size_t)x.V * x.RB); }
     const size_t vrec_hi = off;
+    // ... and the sample records of the split chains in another: zeroed with every index pass (k_prep_s_bi stores only the pieces
+    // of a biallelic column's 128-byte record that are not zero by construction; which columns those are hangs on the index alone)
+    const size_t srec_lo = align_up(off);
+    for (uint32_t c = 0; c < n_chains; ++c) {
+        const IndexHost& x = job->index[job->chains[c].index];
+        if (x.split) plan[c].frec = take((size_t)x.V * (x.split == 1u ? PG_SREC1_BYTES : PG_SREC2_BYTES));
+    }
+    const size_t srec_hi = off > srec_lo ? off : srec_lo;   // (no split chain: an empty run)
     for (uint32_t c = 0; c < n_chains; ++c) {
         ChainHost& ch = job->chains[c];
         const IndexHost& x = job->index[ch.index];
         Plan& p = plan[c];
-        p.cvar = take((size_t)x.V * 4);
-        p.colrec = take((size_t)x.V * x.RB);
+        p.colrec = take(x.split ? 0 : (size_t)x.V * x.RB);
+        p.cprec = take(x.split ? (size_t)x.V * PG_CPREC_BYTES : 0);
         // fused jobs: lean chains store / read their columns as compact upper triangles (18 KB instead of 32 KB per
         // column: half the sweep's HBM bytes and of the arena); PG_KERNELS=notri keeps full columns (cross-check)
         const bool tri = x.lean && !job->chunked && !kc.notri;
@@ -1009,7 +1088,7 @@ int job_build(int device, uint32_t n_index, const pg_contig_batch* batches, cons
         p.part = take(job->chunked || !geno ? 0 : (x2 ? (size_t)x.V * 32u + (size_t)x.part_slots * part_entries(x) * sizeof(double)
                                                       : (size_t)x.V * x.part_slots * part_entries(x) * sizeof(double)));
         p.aux = take(x2 && geno ? x.aux_bytes : 0);
-        const size_t o_wlist = take(x2 && geno && x.wide_bytes ? (size_t)x.n_wide_cand * 4 : 0);
+        const size_t o_wlist = take(x2 && geno && x.wide_bytes && !x.split ? (size_t)x.n_wide_cand * 4 : 0);
         plan_wlist[c] = o_wlist;
         // Viterbi: transition probabilities and one 2-byte backpointer per state and column
         p.vtq = take(params->run_phasing ? (size_t)x.V * 8 * sizeof(double) : 0);
@@ -1017,9 +1096,9 @@ int job_build(int device, uint32_t n_index, const pg_contig_batch* batches, cons
         if (params->run_phasing) job->vit_bits |= x.HP == 16 ? 1u : (x.HP == 32 ? 2u : 4u);
         p.scratch = take(job->chunked ? (size_t)2 * PG_SCRATCH_BUFS * job->chunk_cols * x.HP * x.HP * sizeof(double) : 0);
         p.wide = take(x.wide_bytes);
-        p.vpair = take((size_t)x.V * pg_pair_bytes(x.pair_n));
+        p.vpair = take(x.split ? 0 : (size_t)x.V * pg_pair_bytes(x.pair_n));
         p.xbuf = take((x.HP >= 256 || (force_generic && x.HP >= 64)) ? (size_t)2 * x.HP * x.HP * sizeof(double) : 0);
-        p.frec = take((x.lean || x.small) ? (size_t)x.V * 64 : (x.smallx ? (size_t)x.V * 192 : 0));
+        if (!x.split) p.frec = take((x.lean || x.small) ? (size_t)x.V * 64 : (x.smallx ? (size_t)x.V * 192 : 0));
         if (x.lean) job->hp_mask |= 64u;
         if (x.leanx) job->hp_mask |= x.HP == 128 ? 512u : 1024u;
         p.fscale = take((size_t)x.V * sizeof(double));
@@ -1027,7 +1106,7 @@ int job_build(int device, uint32_t n_index, const pg_contig_batch* batches, cons
         p.bsum = take((size_t)x.V * sizeof(double));
         if (x.HP >= 256) job->hp_mask |= 16u;
         else if (force_generic && x.HP >= 64) job->hp_mask |= 32u;
-        else job->hp_mask |= x.HP == 16 ? 1u : x.HP == 32 ? 2u : x.HP == 64 ? 4u : 8u;
+        else if (!x.split) job->hp_mask |= x.HP == 16 ? 1u : x.HP == 32 ? 2u : x.HP == 64 ? 4u : 8u;   // (split chains never run on the general kernel)
     }
     if (job->hp_mask & 32u) job->hp_mask |= 16u;  // one generic launch covers both
     job->arena_bytes = align_up(off);
@@ -1053,6 +1132,10 @@ int job_build(int device, uint32_t n_index, const pg_contig_batch* batches, cons
     lap("arena plan + allocation");
     unsigned char* A = job->arena;
     job->d_contigs = (DevContig*)(A + o_contigs);
+    job->d_reps = (DevContig*)(A + o_reps);
+    job->d_ixerr = (uint32_t*)(A + o_ixerr);
+    job->ix_base = A + ix_lo; job->ix_bytes = ix_hi - ix_lo;
+    job->srec_base = A + srec_lo; job->srec_bytes = srec_hi - srec_lo;
     job->d_ncols = (uint32_t*)(A + o_ncols);
     job->d_err = (uint32_t*)(A + o_err);
     job->d_lik = (double*)(A + o_lik);
@@ -1061,6 +1144,7 @@ int job_build(int device, uint32_t n_index, const pg_contig_batch* batches, cons
     job->zero_bytes = zero_hi - zero_lo;
     job->tab.mant = (const double*)(A + job->o_tab_m);
     job->tab.expo = (const int32_t*)(A + job->o_tab_e);
+    job->tab.packed = A + job->o_tab_p;
 
     // ---- chain descriptors ----------------------------------------------------------------------
     std::vector<DevContig> hd(n_chains);
@@ -1080,8 +1164,13 @@ int job_build(int device, uint32_t n_index, const pg_contig_batch* batches, cons
         d.allele_flags = (const uint8_t*)(A + x.o_aflag); d.allele_koff = (const uint16_t*)(A + x.o_akoff);
         d.allele_kmask = (const uint32_t*)(A + x.o_akmask); d.path_allele = (const uint16_t*)(A + x.o_pa);
         d.geno_off = (const uint64_t*)(A + x.o_goff);
-        d.vrec = A + p.vrec; d.kept = A + p.kept; d.allele_present = A + p.apres;
-        d.n_cols = job->d_ncols + c; d.col_variant = (uint32_t*)(A + p.cvar); d.colrec = A + p.colrec;
+        d.vrec = A + p.vrec; d.kept = A + x.o_kept; d.allele_present = A + x.o_apres;
+        d.n_cols = job->d_ncols + ch.index; d.col_variant = (uint32_t*)(A + x.o_colv); d.colrec = A + p.colrec;
+        d.col_of = (const uint32_t*)(A + x.o_colof); d.ix_err = job->d_ixerr + ch.index;
+        d.split = x.split;
+        if (x.split) {
+            d.ix_pd = A + x.o_ixpd; d.ix_rec = A + x.o_ixrec; d.ix_bin = A + x.o_ixbin; d.cprec = A + p.cprec;
+        }
         d.fwd = (double*)(A + p.fwd); d.part = (double*)(A + p.part); d.fwd_fallback = A + p.fback; d.prof = (unsigned long long*)(A + p.prof);
         d.fscale = (double*)(A + p.fscale); d.bscale = (double*)(A + p.bscale); d.bsum = (double*)(A + p.bsum); d.err = job->d_err + c;
         d.lik = job->d_lik + ch.lik_first; d.lik_exp = job->d_likexp + ch.lik_first;
@@ -1092,11 +1181,25 @@ int job_build(int device, uint32_t n_index, const pg_contig_batch* batches, cons
         d.smallx = x.smallx ? ((!job->chunked && !kc.nosmall2) ? 2u : 1u) : 0u;
         d.aux = A + p.aux; d.aux_idx = (d.smallx == 2u && x.aux_bytes) ? (const uint32_t*)(A + x.o_auxidx) : nullptr;
         if (d.smallx == 2u && x.wide_bytes && x.n_wide_cand) {
-            d.wcols = (uint32_t*)(A + plan_wlist[c]); d.n_wcols = (uint32_t*)(A + p.wcols);
+            // (split chains: the wide columns hang on the index alone — one list per index contig, made by k_index_cols)
+            if (x.split) { d.wcols = (uint32_t*)(A + x.o_ixwl); d.n_wcols = (uint32_t*)(A + x.o_ixnw); }
+            else { d.wcols = (uint32_t*)(A + plan_wlist[c]); d.n_wcols = (uint32_t*)(A + p.wcols); }
             job->max_wide = std::max(job->max_wide, x.n_wide_cand);
         }
         d.live = (!job->chunked && x.HP == 32u && !kc.fullcols) ? std::min<uint32_t>(x.HP, (x.H + 3u) & ~3u) : x.HP;
         d.prep_fast = x.prep_fast;
+        if (x.split) {
+            // the split path's emission kernels: lists unless every object is k_prep_s_bi's
+            if (!x.all_sb) {
+                d.prep_m4 = (const uint32_t*)(A + x.o_list_m4); d.n_prep_m4 = (uint32_t)x.list_m4.size();
+                d.prep_w = (const uint32_t*)(A + x.o_list_w); d.n_prep_w = (uint32_t)x.list_w.size();
+                d.prep_b = (const uint32_t*)(A + x.o_list_b); d.n_prep_b = (uint32_t)x.list_b.size();
+            }
+            job->max_sb = std::max(job->max_sb, x.all_sb ? x.V : d.n_prep_b);
+            job->max_sm4 = std::max(job->max_sm4, d.n_prep_m4);
+            job->max_sw = std::max(job->max_sw, d.n_prep_w);
+        } else {
+        job->any_legacy_prep = true;
         if (x.prep_fast == 2u) {   // (a non-null list pointer = "walk the list", also when it is empty)
             d.prep_m4 = (const uint32_t*)(A + x.o_list_m4); d.n_prep_m4 = (uint32_t)x.list_m4.size();
             d.prep_w = (const uint32_t*)(A + x.o_list_w); d.n_prep_w = (uint32_t)x.list_w.size();
@@ -1104,6 +1207,7 @@ int job_build(int device, uint32_t n_index, const pg_contig_batch* batches, cons
             job->max_prep_m4 = std::max(job->max_prep_m4, d.n_prep_m4);
             job->max_prep_w = std::max(job->max_prep_w, d.n_prep_w);
         } else if (x.prep_fast == 0u) job->max_prep_w = std::max(job->max_prep_w, x.V);
+        }
         if (params->run_phasing) {
             d.vit_tq = (double*)(A + p.vtq); d.vit_back = (uint16_t*)(A + p.vback); d.vit_best = (uint32_t*)(A + p.vbest);
             d.hap1 = (uint16_t*)(A + p.hap1); d.hap2 = (uint16_t*)(A + p.hap2);
@@ -1113,8 +1217,11 @@ int job_build(int device, uint32_t n_index, const pg_contig_batch* batches, cons
         if (d.tri) job->hp_mask |= 128u;
         if (d.tri == 2u) job->hp_mask |= 256u;
         // (k_bins_thin: what bins_thin() in pg_kernels.hip says — at most 64 partial entries per column, fused job)
+        if (x.split) job->bins_which |= 32u | ((x.split == 2u && x.wide_bytes) ? 64u : 0u);   // k_bins_s, k_bins_wide_s
+        else {
         job->bins_which |= (d.tri == 2u || d.cls4) ? 2u : ((d.T <= 64u && d.HP <= 32u && !job->chunked) ? 4u : 1u);
         if (d.smallx == 2u) job->bins_which |= 8u | (x.wide_bytes ? 16u : 0u);   // k_bins_x, k_bins_wide (a chain left with one column: k_bins_thin, above)
+        }
         ch.d = d;
     }
     {
@@ -1141,6 +1248,15 @@ int job_build(int device, uint32_t n_index, const pg_contig_batch* batches, cons
     }
     job->h_contigs = hd;
     job->cur_samples = A + job->sample_lo;
+    {   // one descriptor per index contig for the index-level kernels (any chain over it: they touch index-level fields only)
+        std::vector<DevContig> reps(n_index);
+        for (auto& r : reps) memset(&r, 0, sizeof(r));
+        std::vector<char> have(n_index, 0);
+        for (uint32_t c = 0; c < n_chains; ++c) { const uint32_t i = job->chains[c].index; if (!have[i]) { have[i] = 1; reps[i] = hd[c]; } }
+        if ((he = hipMemcpyAsync(job->d_reps, reps.data(), sizeof(DevContig) * n_index, hipMemcpyHostToDevice, job->stream)) != hipSuccess ||
+            (he = hipStreamSynchronize(job->stream)) != hipSuccess)
+            return fail(PG_ERR_DEVICE, "hipMemcpy index descriptors", he);
+    }
     if ((he = hipMemcpyAsync(job->d_contigs, hd.data(), sizeof(DevContig) * n_chains, hipMemcpyHostToDevice, job->stream)) != hipSuccess ||
         (he = hipStreamSynchronize(job->stream)) != hipSuccess)
         return fail(PG_ERR_DEVICE, "hipMemcpy contigs", he);
@@ -1381,13 +1497,13 @@ extern "C" int pg_job_run(pg_job* job, void* stream_, char* err, size_t errlen) 
     HIP_TRY(hipMemsetAsync(job->zero_base, 0, job->zero_bytes, s));
     if (job->max_v > 0 && job->params.run_genotyping) {
         HIP_TRY(hipEventRecord(job->ev[0], s));
-        pgk_launch_prep(job->d_contigs, n, job->max_v, job->max_prep_w, job->max_prep_m4, job->tab, s);
+        if (job->any_legacy_prep) pgk_launch_prep(job->d_contigs, n, job->max_v, job->max_prep_w, job->max_prep_m4, job->tab, s);
+        if (job->any_split) pgk_launch_prep_split(job->d_contigs, n, job->max_sb, job->max_sm4, job->max_sw, job->tab, s);
         HIP_TRY(hipGetLastError());
         HIP_TRY(hipEventRecord(job->ev[1], s));
-        pgk_launch_compact(job->d_contigs, n, s);
-        HIP_TRY(hipGetLastError());
+        // (no k_compact: the column list is the index's, made when it was uploaded — the class stays in the timing table, at zero)
         HIP_TRY(hipEventRecord(job->ev[2], s));
-        pgk_launch_records(job->d_contigs, n, job->max_v, s);
+        if (job->any_legacy_prep) pgk_launch_records(job->d_contigs, n, job->max_v, s);
         HIP_TRY(hipGetLastError());
         HIP_TRY(hipEventRecord(job->ev[3], s));
         pgk_launch_sweep(job->d_contigs, n, job->hp_mask, 1, s);
@@ -1426,9 +1542,8 @@ extern "C" int pg_job_run(pg_job* job, void* stream_, char* err, size_t errlen) 
             HIP_TRY(hipEventRecord(job->ev[6], s));  // (no k_bins in this mode)
         }
     } else if (job->max_v > 0) {
-        // run_genotyping == false: the ColumnIndexer part and the column records (what the Viterbi reads)
+        // run_genotyping == false: the variant records (what the Viterbi reads; the column list is the index's)
         pgk_launch_prep(job->d_contigs, n, job->max_v, job->max_prep_w, job->max_prep_m4, job->tab, s);
-        pgk_launch_compact(job->d_contigs, n, s);
         HIP_TRY(hipGetLastError());
     }
     if (job->max_v > 0 && job->params.run_phasing) {
@@ -1460,8 +1575,14 @@ extern "C" int pg_job_run(pg_job* job, void* stream_, char* err, size_t errlen) 
         job->vit_ms = ms;
     }
     std::vector<uint32_t> ncols(n), errs(n);
-    HIP_TRY(hipMemcpy(ncols.data(), job->d_ncols, sizeof(uint32_t) * n, hipMemcpyDeviceToHost));
-    HIP_TRY(hipMemcpy(errs.data(), job->d_err, sizeof(uint32_t) * n, hipMemcpyDeviceToHost));
+    {   // (column counts and the index-level kernels' error bits are per index contig)
+        const size_t ni = job->index.size();
+        std::vector<uint32_t> nc_ix(ni), err_ix(ni);
+        HIP_TRY(hipMemcpy(nc_ix.data(), job->d_ncols, sizeof(uint32_t) * ni, hipMemcpyDeviceToHost));
+        HIP_TRY(hipMemcpy(err_ix.data(), job->d_ixerr, sizeof(uint32_t) * ni, hipMemcpyDeviceToHost));
+        HIP_TRY(hipMemcpy(errs.data(), job->d_err, sizeof(uint32_t) * n, hipMemcpyDeviceToHost));
+        for (uint32_t i = 0; i < n; ++i) { ncols[i] = nc_ix[job->chains[i].index]; errs[i] |= err_ix[job->chains[i].index]; }
+    }
     job->ran = true;
     job->host_s[2] = now_s() - t_run;
     for (uint32_t i = 0; i < n; ++i) {

@@ -71,24 +71,46 @@ struct XBlock {
     static constexpr int NP = BL * 12, NQ = (NP + 15) / 16;
     v2f64 v[NQ];
 };
+// Split chains (DevContig::split == 2, pg_split.h) keep a column's record as TWO streams — the sample's 128 bytes (the fifteen
+// entries, X, flags: written every run) and the index's 64 (header, constants, row offsets: written once, shared by every sample
+// over the index contig): piece g of a block is then piece g % 8 of sample record g / 8 for g < 8 BL, and piece (g - 8 BL) % 4 of
+// index record (g - 8 BL) / 4 behind — parked where the same bytes of the one-stream record would lie, so that nothing
+// downstream of the staging ring knows.
 template <int BL>
-DEVI void x_block_load(XBlock<BL>& b, gcdouble* xrec, int64_t c0, int64_t C, uint32_t j) {
+DEVI void x_piece(bool two, uint32_t g, uint32_t& q, uint32_t& mem_off, uint32_t& lds_off, bool& from_index) {
+    if (!two) { q = g / 12u; const uint32_t w = g - q * 12u; mem_off = 16u * w; lds_off = q * PG_XREC_BYTES + 16u * w; from_index = false; return; }
+    if (g < (uint32_t)BL * 8u) { q = g >> 3; const uint32_t w = g & 7u; mem_off = 16u * w; lds_off = q * PG_XREC_BYTES + 16u * w; from_index = false; }
+    else { const uint32_t gg = g - (uint32_t)BL * 8u; q = gg >> 2; const uint32_t w = gg & 3u; mem_off = 16u * w; lds_off = q * PG_XREC_BYTES + PG_XREC_HDR + 16u * w; from_index = true; }
+}
+template <int BL>
+DEVI void x_block_load(XBlock<BL>& b, gcdouble* xrec, gcdouble* irec, int64_t c0, int64_t C, uint32_t j) {
+    const bool two = irec != nullptr;
 #pragma unroll
     for (int q = 0; q < XBlock<BL>::NQ; ++q) {
         const uint32_t g = j + 16u * (uint32_t)q;
         if (XBlock<BL>::NP % 16 == 0 || g < (uint32_t)XBlock<BL>::NP) {
-            int64_t c = c0 + (int64_t)(g / 12u);
+            uint32_t cq, mo, lo;
+            bool fi;
+            x_piece<BL>(two, g, cq, mo, lo, fi);
+            int64_t c = c0 + (int64_t)cq;
             c = c < 0 ? 0 : (c >= C ? C - 1 : c);
-            b.v[q] = *(const GAS v2f64*)((const GAS char*)xrec + (size_t)c * PG_XREC_BYTES + 16u * (g % 12u));
+            const GAS char* base = fi ? (const GAS char*)irec + (size_t)c * PG_IXREC_BYTES
+                                      : (const GAS char*)xrec + (size_t)c * (two ? PG_SREC2_BYTES : PG_XREC_BYTES);
+            b.v[q] = *(const GAS v2f64*)(base + mo);
         }
     }
 }
 template <int BL>
-DEVI void x_block_park(const XBlock<BL>& b, uint32_t stg, uint32_t j) {   // stg: LDS address of the block's staging area
+DEVI void x_block_park(const XBlock<BL>& b, uint32_t stg, uint32_t j, bool two) {   // stg: LDS address of the block's staging area
 #pragma unroll
     for (int q = 0; q < XBlock<BL>::NQ; ++q) {
         const uint32_t g = j + 16u * (uint32_t)q;
-        if (XBlock<BL>::NP % 16 == 0 || g < (uint32_t)XBlock<BL>::NP) *(LAS v2f64*)(uintptr_t)(stg + 16u * g) = b.v[q];
+        if (XBlock<BL>::NP % 16 == 0 || g < (uint32_t)XBlock<BL>::NP) {
+            uint32_t cq, mo, lo;
+            bool fi;
+            x_piece<BL>(two, g, cq, mo, lo, fi);
+            *(LAS v2f64*)(uintptr_t)(stg + lo) = b.v[q];
+        }
     }
 }
 // the fifteen table entries of the staged record at `src` -> the 6 x 6 table of `slot`: entry j at [a][b] and [b][a] (lane 15:
@@ -139,7 +161,7 @@ DEVI void x_wide_emissions(const XCol& c, const unsigned char* wide, bool mine, 
 
 struct SmallXCtx {     // per lane: the half-chain of its DPP row
     bool live;
-    gcdouble* xrec; gdouble* wr; gcdouble* resume; gdouble* sc_a; gdouble* sc_b; gu8* fallback;
+    gcdouble* xrec; gcdouble* irec; gdouble* wr; gcdouble* resume; gdouble* sc_a; gdouble* sc_b; gu8* fallback;
     gcdouble* partner; gdouble* part; GAS char* aux; const unsigned char* wide;
     int64_t C, lo, hi;
 };
@@ -217,6 +239,7 @@ struct XPipe {
     uint32_t tab_ab, tab_ba;
     uint32_t j;
     gcdouble* xrec;
+    gcdouble* irec;     // split chains: the index's stream of the records (see x_piece); null: one stream
     int64_t origin, C;  // column of rel 0
     bool live;
     XBlock<BL> blk;
@@ -228,8 +251,8 @@ struct XPipe {
     DEVI int64_t block_first_column(uint32_t b) const {   // lowest column of block b
         return DIR > 0 ? origin + (int64_t)b * BL : origin - (int64_t)b * BL - (BL - 1);
     }
-    DEVI void fetch(uint32_t b) { if (live && !(kXExp & 4u)) x_block_load<BL>(blk, xrec, block_first_column(b), C, j); }
-    DEVI void park(uint32_t b) const { x_block_park<BL>(blk, stg0 + (b & 1u) * (uint32_t)(PG_XBLOCK_MAX * PG_XREC_BYTES), j); }
+    DEVI void fetch(uint32_t b) { if (live && !(kXExp & 4u)) x_block_load<BL>(blk, xrec, irec, block_first_column(b), C, j); }
+    DEVI void park(uint32_t b) const { x_block_park<BL>(blk, stg0 + (b & 1u) * (uint32_t)(PG_XBLOCK_MAX * PG_XREC_BYTES), j, irec != nullptr); }
     DEVI void expand(uint32_t rel) const { x_expand(staged(rel), slot_of(rel), j, tab_ab, tab_ba); }
     DEVI XConsts consts(uint32_t rel) const { return read_xconsts(staged(rel)); }
     DEVI XCol column(uint32_t rel) const { return read_xcol(staged(rel), slot_of(rel), j); }
@@ -240,8 +263,8 @@ struct XPipe {
         if constexpr (P == BL - 1) park((n + 2u) / (uint32_t)BL + 1u);
         if constexpr (P == 0) fetch((n + 2u) / (uint32_t)BL + 1u);
     }
-    DEVI void init(SmallXShared& sh, uint32_t row, uint32_t lane_j, gcdouble* recs, int64_t origin_col, int64_t n_cols, bool on) {
-        j = lane_j; xrec = recs; origin = origin_col; C = n_cols; live = on;
+    DEVI void init(SmallXShared& sh, uint32_t row, uint32_t lane_j, gcdouble* recs, gcdouble* irecs, int64_t origin_col, int64_t n_cols, bool on) {
+        j = lane_j; xrec = recs; irec = irecs; origin = origin_col; C = n_cols; live = on;
         stg0 = (uint32_t)(uintptr_t)(LAS unsigned char*)&sh.stg[row][0][0];
         slot0 = (uint32_t)(uintptr_t)(LAS unsigned char*)&sh.rec[row][0][0];
         uint32_t pa, pb;
@@ -251,9 +274,9 @@ struct XPipe {
 #pragma unroll
         for (int q = 0; q < XBlock<BL>::NQ; ++q) blk.v[q] = v2f64{0.0, 0.0};
         // block 0 now, block 1 on its way (parked by step BL - 3)
-        if (live) x_block_load<BL>(blk, xrec, block_first_column(0), C, j);
+        if (live) x_block_load<BL>(blk, xrec, irec, block_first_column(0), C, j);
         park(0);
-        if (live) x_block_load<BL>(blk, xrec, block_first_column(1), C, j);
+        if (live) x_block_load<BL>(blk, xrec, irec, block_first_column(1), C, j);
     }
 };
 
@@ -282,7 +305,7 @@ DEVI void small16x_forward(const DevContig* contigs, const uint32_t* ids, uint32
         ok = ok && lo < hi;
         if (ok) {
             cx.live = true; cx.C = C; cx.lo = lo; cx.hi = hi;
-            cx.xrec = (gcdouble*)dc.frec; cx.sc_a = (gdouble*)dc.fscale; cx.fallback = (gu8*)dc.fwd_fallback;
+            cx.xrec = (gcdouble*)dc.frec; cx.irec = dc.split == 2u ? (gcdouble*)dc.ix_rec : nullptr; cx.sc_a = (gdouble*)dc.fscale; cx.fallback = (gu8*)dc.fwd_fallback;
             gdouble* fwd = (gdouble*)dc.fwd;
             cx.wr = fwd; cx.partner = (gcdouble*)fwd; cx.part = (gdouble*)dc.part; cx.aux = (GAS char*)dc.aux; cx.wide = dc.wide;
             cx.resume = (gcdouble*)(fwd + (size_t)(lo > 0 ? lo - 1 : 0) * colsz);
@@ -299,7 +322,7 @@ DEVI void small16x_forward(const DevContig* contigs, const uint32_t* ids, uint32
     smallx_init_shared(sh, lane);
     const uint32_t onehot = (uint32_t)(uintptr_t)(LAS unsigned char*)&sh.onehot[0][0];
     XPipe<BL, +1> pipe;
-    pipe.init(sh, row, j, cx.xrec, (int64_t)first - 1, cx.C, cx.live);   // rel r = column first - 1 + r
+    pipe.init(sh, row, j, cx.xrec, cx.irec, (int64_t)first - 1, cx.C, cx.live);   // rel r = column first - 1 + r
     auto emissions = [&](const XCol& col, double (&ee)[R]) __attribute__((always_inline)) {
         static_for<0, R>([&](auto kc) __attribute__((always_inline)) { constexpr int k = decltype(kc)::value; ee[k] = x_emission<k>(col); });
         const bool wide = cx.live && (col.nlf & PG_XREC_FLAG_WIDE) != 0u;
@@ -488,7 +511,7 @@ DEVI void small16x_backward(const DevContig* contigs, const uint32_t* ids, uint3
         ok = ok && top >= bot;
         if (ok) {
             cx.live = true; cx.C = C; cx.lo = bot; cx.hi = top;
-            cx.xrec = (gcdouble*)dc.frec; cx.sc_a = (gdouble*)dc.bscale; cx.sc_b = (gdouble*)dc.bsum;
+            cx.xrec = (gcdouble*)dc.frec; cx.irec = dc.split == 2u ? (gcdouble*)dc.ix_rec : nullptr; cx.sc_a = (gdouble*)dc.bscale; cx.sc_b = (gdouble*)dc.bsum;
             gdouble* cols = (gdouble*)dc.fwd;
             cx.wr = cols; cx.partner = (gcdouble*)cols; cx.part = (gdouble*)dc.part; cx.aux = (GAS char*)dc.aux; cx.wide = dc.wide;
             cx.resume = (gcdouble*)(cols + (size_t)(top + 1 < C ? top + 1 : top) * colsz);
@@ -505,7 +528,7 @@ DEVI void small16x_backward(const DevContig* contigs, const uint32_t* ids, uint3
     smallx_init_shared(sh, lane);
     const uint32_t onehot = (uint32_t)(uintptr_t)(LAS unsigned char*)&sh.onehot[0][0];
     XPipe<BL, -1> pipe;
-    pipe.init(sh, row, j, cx.xrec, t0 + 1, cx.C, cx.live);   // rel r = column t0 + 1 - r
+    pipe.init(sh, row, j, cx.xrec, cx.irec, t0 + 1, cx.C, cx.live);   // rel r = column t0 + 1 - r
     auto emissions = [&](const XCol& col, bool on, double (&e)[R]) __attribute__((always_inline)) {
         static_for<0, R>([&](auto kc) __attribute__((always_inline)) { constexpr int k = decltype(kc)::value; e[k] = x_emission<k>(col); });
         const bool wide = on && (col.nlf & PG_XREC_FLAG_WIDE) != 0u;

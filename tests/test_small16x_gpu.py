@@ -111,17 +111,22 @@ def test_small16x_wide_columns_cost_the_column_not_the_job(mode, reg, orc, monke
         _agree(r, g, 1e-10)
 
 
-def test_small16x_single_wide_column_chain_is_refused_in_a_fused_job_not_miscomputed(orc, monkeypatch):
-    """A chain whose ONLY column is wide runs phase 2 on the general kernel (one column: no step for k_sweep_small16x), which has
-    no wide path inside a fused job: PG_ERR_UNSUPPORTED, never a wrong bin; chunked, the same chain matches the oracle."""
+def test_small16x_single_wide_column_chain(orc, monkeypatch):
+    """A chain whose ONLY column is wide.  Round 6: on the split path (the default for such chains, pg_split.h) a single column
+    needs no sweep and k_bins_wide_s forms its bins — fused or chunked, the chain matches the oracle.  With the per-sample
+    preparation (PG_KERNELS=nosplit) phase 2 of a one-column chain runs on the general kernel, which has no wide path inside a
+    fused job: PG_ERR_UNSUPPORTED, never a wrong bin."""
     b = synthetic_panel(1, 16, 20, seed=77, wide_at=(0,), wide_alleles=(12, 12))
     assert len(set(b.path_allele.tolist())) > 5
     args = default_table_args()
     t, p = hmm.ProbabilityTable(*args), hmm.make_params(1.26, False, 1e-5)
+    ref = orc.genotype_contig(b, orc.OracleTable(*args), orc.make_params(1.26, False, 1e-5))
     monkeypatch.setenv("PG_KERNELS", "small")
     monkeypatch.setenv("PG_SWEEP_MODE", "chunked")
-    assert_parity(b, hmm.genotype_contig(b, t, p), orc.genotype_contig(b, orc.OracleTable(*args), orc.make_params(1.26, False, 1e-5)))
+    assert_parity(b, hmm.genotype_contig(b, t, p), ref)
     monkeypatch.setenv("PG_SWEEP_MODE", "fused")
+    assert_parity(b, hmm.genotype_contig(b, t, p), ref)
+    monkeypatch.setenv("PG_KERNELS", "small,nosplit")
     with pytest.raises(hmm.PanGenieError):
         hmm.genotype_contig(b, t, p)
 
