@@ -166,6 +166,46 @@ def profiled_traffic(workload, kernel_phase):
     return (total / passes if total > 0 else None), cands[-1].name
 
 
+# Seams of the device platform: what a test replaces to drive main()'s N > 1 control flow on CPU ranks (gloo) with the job
+# and the gather stubbed (tests/test_bench_world2.py) — the product run never touches them.
+BACKEND = "nccl"
+
+
+def _cuda_ok():
+    import torch
+    return torch.cuda.is_available()
+
+
+def _cuda_set(local_rank):
+    import torch
+    torch.cuda.set_device(local_rank)
+
+
+def _sync():
+    import torch
+    torch.cuda.synchronize()
+
+
+def _make_device(local_rank):
+    import torch
+    return torch.device("cuda", local_rank)
+
+
+def _device_view(ptr, n, typestr, dev):
+    """zero-copy torch view of a device range owned by the job"""
+    import torch
+    return torch.as_tensor(_DevArray(ptr, n, typestr), device=dev)
+
+
+def _make_abi_gather(rank, world, local_rank):
+    from pangenie_amd.dist import AbiGather
+    return AbiGather(rank, world, local_rank)
+
+
+def _release_cache():
+    hmm._lib.load_hip().pg_hmm_release_cache()
+
+
 class _DevArray:
     """Zero-copy torch view of a device range owned by the job (CUDA array interface)."""
 
@@ -179,14 +219,36 @@ def job_info_of(job):
             "device_bytes": job.device_bytes(), "upload_bytes": job.upload_bytes()}
 
 
-def roofline_of(results, batches, kms, H, workload_name, info):
-    """Roofline of the dominant sweep launch: algorithmic bytes per launch / hipEvent time.
-    results: the fetched ContigResult of every chain (kept flags); info: job_info_of(job)."""
-    ncol, bytes_total = 0, 0
+def step_table(kms, ms_per_step, p1_bytes, col_read_bytes, in_bytes, out_bytes):
+    """The WHOLE step against the roofline (roofline.achieved = sum_v B_v / wall): every kernel class of the
+    step with its hipEvent time, its share of the step and the algorithmic bytes SURVEY's B(H, K, A) charges to it — the
+    forward columns written once (phase 1) and read once (phase 2), the per-variant inputs 4K + 2H + 3A + 16 (the emission
+    kernels) and outputs 8G + 8 (the bins; in the chunked mode k_post forms them inside the phase-2 class).  `step_frac` =
+    all of them over the step's wall time: never above the best kernel's `frac`."""
+    alg = {"k_prep": in_bytes, "k_compact": 0.0, "k_records": 0.0, "k_sweep_phase1": p1_bytes, "k_sweep_phase2": col_read_bytes, "k_bins": out_bytes}
+    total_ms = sum(kms.values()) or 1e-9
+    rows = []
+    for k in ("k_prep", "k_compact", "k_records", "k_sweep_phase1", "k_sweep_phase2", "k_bins"):
+        ms = kms.get(k, 0.0)
+        gbs = alg[k] / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
+        rows.append({"kernel": k, "ms": ms, "share": ms / total_ms, "algorithmic_bytes": alg[k], "GBs": gbs, "frac": gbs / HBM_PEAK_GBS})
+    bytes_step = p1_bytes + col_read_bytes + in_bytes + out_bytes
+    step_gbs = bytes_step / (ms_per_step * 1e-3) / 1e9 if ms_per_step > 0 else 0.0
+    return {"step_achieved": step_gbs, "step_frac": step_gbs / HBM_PEAK_GBS, "step_algorithmic_bytes": bytes_step,
+            "step_ms": ms_per_step, "kernel_table": rows}
+
+
+def roofline_of(results, batches, kms, H, workload_name, info, ms_per_step=None):
+    """Roofline of the dominant sweep launch: algorithmic bytes per launch / hipEvent time — and of the whole
+    step (step_table).  results: the fetched ContigResult of every chain (kept flags); info: job_info_of(job);
+    ms_per_step: wall time of a step (default: the sum of the kernel classes)."""
+    ncol, bytes_total, out_bytes = 0, 0, 0
     for r, bt in zip(results, batches):
         kp = r.kept
         ncol += int(kp.sum())
         bytes_total += algorithmic_bytes(bt, kp)
+        A = np.diff(bt.allele_off.astype(np.int64))
+        out_bytes += int((8 * (A * (A + 1) // 2) + 8).sum())
     # sweep phase 1 writes every kept column once (8*H^2 B), phase 2 reads it once; the
     # per-variant inputs/outputs (4K+2H+3A+16+8G+8 B) are charged to phase 2.
     p1_bytes = 8.0 * H * H * ncol
@@ -219,9 +281,12 @@ def roofline_of(results, batches, kms, H, workload_name, info):
                  "full_formulation_GBs": full_bytes / (dom_ms * 1e-3) / 1e9 if dom_ms > 0 else 0.0,
                  "note": "columns are symmetric and stored as upper triangles (18 KB of 32 KB per column): algorithmic bytes and "
                          "PMC traffic are those of the triangle formulation"}
+    col_bytes = (1152 * 16.0 if extra else 8.0 * H * H) * ncol        # one column pass in this formulation's storage
+    in_bytes = float(bytes_total) - 2.0 * col_bytes - out_bytes        # 4K + 2H + 3A + 16 per variant
+    whole = step_table(kms, ms_per_step if ms_per_step else sum(kms.values()), col_bytes, col_bytes, in_bytes, float(out_bytes))
     return {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
-            "algorithmic_bytes_per_launch": dom_bytes, "avg_launch_ms": dom_ms, **extra,
+            "algorithmic_bytes_per_launch": dom_bytes, "avg_launch_ms": dom_ms, **extra, **whole,
             "sweep_GBs": (bytes_total / (sweep_ms * 1e-3) / 1e9) if sweep_ms > 0 else 0.0,
             "phase2_ms": kms.get("k_sweep_phase2", 0.0),
             "phase2_traffic": (profiled_traffic(workload_name, 2)[0] if workload_name else None)}, ncol, (mode, chunk_cols)
@@ -251,21 +316,21 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus and world > 1:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
-    if not torch.cuda.is_available():
+    if not _cuda_ok():
         raise SystemExit("bench.py needs a GPU (no CPU fallback)")
-    torch.cuda.set_device(local_rank)
+    _cuda_set(local_rank)
     dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world)
-    dev = torch.device("cuda", local_rank)
+        dist.init_process_group(BACKEND, rank=rank, world_size=world)
+    dev = _make_device(local_rank)
 
     def fence():
-        torch.cuda.synchronize()
+        _sync()
         if world > 1:
             dist.barrier()
-        torch.cuda.synchronize()
+        _sync()
 
     def max_over_ranks(x):
         if world == 1:
@@ -311,8 +376,8 @@ def main():
             n_lik = [int(x) for x in t]
             # zero-copy views of the job's packed result ranges, cut per chain for the exchange
             if job:
-                lik_t = torch.as_tensor(_DevArray(d_lik, n_tot, "<f8"), device=dev)
-                exp_t = torch.as_tensor(_DevArray(d_exp, n_tot, "<i4"), device=dev)
+                lik_t = _device_view(d_lik, n_tot, "<f8", dev)
+                exp_t = _device_view(d_exp, n_tot, "<i4", dev)
                 off = 0
                 for i in mine:
                     local[i] = (lik_t[off:off + n_lik[i]], exp_t[off:off + n_lik[i]])
@@ -324,9 +389,8 @@ def main():
         per_rank = [int(sum(n_lik[i] for i in chains)) for chains in plan]
         abi, gather_kind = None, "none (one GPU)"
         if world > 1 or os.environ.get("PG_BENCH_FORCE_GATHER"):
-            from pangenie_amd.dist import AbiGather
             try:
-                abi = AbiGather(rank, world, local_rank)
+                abi = _make_abi_gather(rank, world, local_rank)
                 abi.gather(job, per_rank)
                 ok = 1.0
             except Exception as e:  # noqa: BLE001
@@ -336,6 +400,8 @@ def main():
                 tt = torch.tensor([ok], dtype=torch.float64, device=dev)
                 dist.all_reduce(tt, op=dist.ReduceOp.MIN)
                 if float(tt.item()) < 1.0:
+                    if abi:
+                        abi.close()
                     abi = None
             gather_kind = "pg_hmm_gather (C ABI: grouped ncclSend / ncclRecv)" if abi else "torch.distributed batch_isend_irecv"
 
@@ -352,7 +418,7 @@ def main():
                 gather_posteriors(local, n_lik, plan, dst=0, unpack=False, device=dev)
             if timed:
                 if world > 1:
-                    torch.cuda.synchronize()
+                    _sync()
                 rank_ms["run"] += (t_b - t_a) * 1e3
                 rank_ms["gather"] += (time.perf_counter() - t_b) * 1e3
 
@@ -441,10 +507,15 @@ def main():
                       "note": "steady state: device arenas come from the library's pool (first round excluded)"}
 
         if rank == 0:
-            roof, ncol, (mode, chunk_cols) = roofline_of(results, batches, kms, H, args.workload if (V == w["V"] and world == 1) else None, job_info)
+            roof, ncol, (mode, chunk_cols) = roofline_of(results, batches, kms, H, args.workload if (V == w["V"] and world == 1) else None, job_info,
+                                                         ms_per_step=dt / args.steps * 1e3)
             out.update({
                 "value": V_total * args.steps / dt, "ms_per_step": dt / args.steps * 1e3,
-                "scaling": "strong",   # BASELINE configs[3] as written: the total work is fixed, the chains are sharded over the ranks
+                # BASELINE configs[3] as written: the total work is fixed, the chains are sharded over the ranks (one GPU: nothing to scale)
+                "scaling": "strong" if world > 1 else "single",
+                # the call-inclusive rate SURVEY.md §8(d) names (host buffers in, host results out, H2D and D2H inside): `value` stays
+                # the resident rate the bench contract prescribes (inputs in HBM when the timed region starts)
+                "value_call_inclusive": V_total / dt_e2e,
                 "value_end_to_end": V_total / dt_e2e,
                 "end_to_end": {"ms": dt_e2e * 1e3, "h2d_ms": hs2["upload_s"] * 1e3, "run_ms": hs2["run_s"] * 1e3, "d2h_ms": hs2["fetch_s"] * 1e3,
                                "h2d_bytes": sum(job_info["upload_bytes"].values()),
@@ -472,7 +543,7 @@ def main():
             abi.close()
             abi = None
         del batches
-        hmm._lib.load_hip().pg_hmm_release_cache()
+        _release_cache()
 
     # ------------------------------------------------------------------ cohort sub-measurements
     def cohort_measure(c, S, key, profile_name):
@@ -529,7 +600,7 @@ def main():
         res = None
         if rank == 0:
             cb = cjob.batches
-            croof, cncol, (cmode, _) = roofline_of(cjob.fetch_all(), cb, ckms, Hc, profile_name, job_info_of(cjob))
+            croof, cncol, (cmode, _) = roofline_of(cjob.fetch_all(), cb, ckms, Hc, profile_name, job_info_of(cjob), ms_per_step=cdt / csteps * 1e3)
             cv = S * NC * c["V"]
             ub = cjob.upload_bytes()
             res = {
@@ -550,7 +621,7 @@ def main():
                 "roofline": croof, "kernel_ms": ckms, "device_bytes": cjob.device_bytes(),
             }
         cjob.close()
-        hmm._lib.load_hip().pg_hmm_release_cache()
+        _release_cache()
         return res
 
     def panel_job_measure(c):
@@ -575,7 +646,8 @@ def main():
         pk = {k: v / csteps for k, v in pk.items()}
         res = None
         if rank == 0:
-            proof, pncol, (pmode, _) = roofline_of(pjob.fetch_all(), pj_batches, pk, Hc, "panels_h16" if world == 1 else None, job_info_of(pjob))
+            proof, pncol, (pmode, _) = roofline_of(pjob.fetch_all(), pj_batches, pk, Hc, "panels_h16" if world == 1 else None, job_info_of(pjob),
+                                                   ms_per_step=pdt / csteps * 1e3)
             pv = c["chains"] * c["V"]
             res = {"workload": f"{c['chains']} chains of {c['V']} variants, {Hc} paths (15 sampled + the reference path), {int(100 * c['multi'])} % multiallelic, "
                                f"{int(100 * c['wide'])} % of the objects with 6-12 alleles — every chain with an index of its OWN ({c['distinct']} distinct panels, "
@@ -583,7 +655,7 @@ def main():
                    "value": pv * world * csteps / pdt, "unit": "variants/s", "scaling": "weak", "steps": csteps, "ms_per_step": pdt / csteps * 1e3,
                    "chains_per_gpu": c["chains"], "sweep_mode": pmode, "kept_columns": pncol, "roofline": proof, "kernel_ms": pk, "device_bytes": pjob.device_bytes()}
         pjob.close()
-        hmm._lib.load_hip().pg_hmm_release_cache()
+        _release_cache()
         return res
 
     def cohort_strong_measure(key, like):
@@ -601,21 +673,35 @@ def main():
                     "per_rank": [{"rank": 0, "samples": S_total, "chains": S_total * NC, "run_ms_per_step": like["ms_per_step"], "gather_ms_per_step": 0.0}],
                     "note": f"N = 1: the `{key}` measurement of this line (same job)"}
         S_mine = S_total // world + (1 if rank < S_total % world else 0)
+        S_first = rank * (S_total // world) + min(rank, S_total % world)   # this rank's samples: global ids S_first .. S_first + S_mine - 1
         index = [synthetic_panel(c["V"], Hc, c["K"], seed=777 + i, multiallelic_frac=c.get("multi", 0.0), wide_frac=c.get("wide", 0.0)) for i in range(NC)]
-        distinct = min(max(S_mine, 1), c.get("distinct", S_total))
-        pool = []
-        for sidx in range(distinct):
-            kcs, covs = zip(*[synthetic_sample_counts(ix, seed=100_000 * (rank + 1) + 100 * sidx + i) for i, ix in enumerate(index)])
-            pool.append((list(kcs), list(covs)))
-        cjob = hmm.Job.cohort(index, [pool[i % distinct] for i in range(S_mine)], table, params, device=local_rank) if S_mine else None
+        # the count set of a sample hangs on its GLOBAL id alone (set gid % distinct, seeded without the rank): the same samples
+        # at every N, whichever rank holds them
+        distinct = min(S_total, c.get("distinct", S_total))
+        pool = {}
+        for gid in range(S_first, S_first + S_mine):
+            k = gid % distinct
+            if k not in pool:
+                kcs, covs = zip(*[synthetic_sample_counts(ix, seed=100_000 + 100 * k + i) for i, ix in enumerate(index)])
+                pool[k] = (list(kcs), list(covs))
+        cjob, build_err = None, None
+        try:
+            cjob = hmm.Job.cohort(index, [pool[gid % distinct] for gid in range(S_first, S_first + S_mine)], table, params, device=local_rank) if S_mine else None
+        except Exception as e:  # noqa: BLE001 — agreed on below: no rank walks into a collective the others never reach
+            build_err = e
+        t_ok = torch.tensor([0.0 if build_err else 1.0], dtype=torch.float64, device=dev)
+        dist.all_reduce(t_ok, op=dist.ReduceOp.MIN)
+        if float(t_ok.item()) < 1.0:
+            if cjob:
+                cjob.close()
+            raise RuntimeError(f"cohort_strong: the job could not be built on every rank (this rank: {build_err!r})")
         n_mine = cjob.packed_results()[2] if cjob else 0
         tt = torch.zeros(world, dtype=torch.int64, device=dev)
         tt[rank] = n_mine
         dist.all_reduce(tt)
         per_rank_lik = [int(x) for x in tt]
-        from pangenie_amd.dist import AbiGather
         try:
-            abi = AbiGather(rank, world, local_rank)
+            abi = _make_abi_gather(rank, world, local_rank)
             abi.gather(cjob, per_rank_lik)
             ok = 1.0
         except Exception as e:  # noqa: BLE001
@@ -624,13 +710,15 @@ def main():
         t_ok = torch.tensor([ok], dtype=torch.float64, device=dev)
         dist.all_reduce(t_ok, op=dist.ReduceOp.MIN)
         if float(t_ok.item()) < 1.0:
+            if abi:
+                abi.close()
             abi = None
         lik_t = exp_t = recv = None
         if abi is None:   # the same exchange through torch: every rank's two packed ranges to rank 0
             if cjob:
                 d_lik, d_exp, n_tot = cjob.packed_results()
-                lik_t = torch.as_tensor(_DevArray(d_lik, n_tot, "<f8"), device=dev)
-                exp_t = torch.as_tensor(_DevArray(d_exp, n_tot, "<i4"), device=dev)
+                lik_t = _device_view(d_lik, n_tot, "<f8", dev)
+                exp_t = _device_view(d_exp, n_tot, "<i4", dev)
             if rank == 0:
                 recv = {r: (torch.empty(per_rank_lik[r], dtype=torch.float64, device=dev), torch.empty(per_rank_lik[r], dtype=torch.int32, device=dev))
                         for r in range(1, world) if per_rank_lik[r]}
@@ -662,7 +750,7 @@ def main():
                 cjob.run()
             t_b = time.perf_counter()
             exchange()
-            torch.cuda.synchronize()
+            _sync()
             ms["run"] += (t_b - t_a) * 1e3
             ms["gather"] += (time.perf_counter() - t_b) * 1e3
         fence()
@@ -683,7 +771,7 @@ def main():
             abi.close()
         if cjob:
             cjob.close()
-        hmm._lib.load_hip().pg_hmm_release_cache()
+        _release_cache()
         return res
 
     if not args.no_cohort:
