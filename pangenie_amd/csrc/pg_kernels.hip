@@ -1590,6 +1590,36 @@ DEVI void dma_column_tri(const gdouble* cols, size_t stride, int64_t c, int64_t 
         __builtin_amdgcn_global_load_lds((const GAS void*)(g + n * 1024u), (LAS void*)(l + n * 1024u), 16, 0, 0);
 }
 // this thread's eight units of a column: LDS byte offsets inside a slot; units below the diagonal read the zero unit
+// Triangle STORE of one row pair (rows i0 + 2q, i0 + 2q + 1 of column j; i0 a multiple of 16) without per-pair registers — the
+// general kernel has none to spare (k_sweep_lean_tri keeps factors and units in registers).  With d = j - i0: the pair's elements
+// take the factor 0 below the diagonal, 1/2 on it, 1 above; the pair is not stored at all when its unit lies in a 128-byte line
+// left of the stored part (j < 8 (row pair / 4)); its place in the compact column is base[g] + (q & 3) (64 - 8 g), g = row pair / 4.
+struct TriStore {
+    int d;                 // j - i0
+    uint32_t base0, base1; // unit of row pair i0 / 2 (q = 0) and i0 / 2 + 4 (q = 4) for this lane
+    uint32_t g0;           // (i0 / 2) / 4, wave-uniform
+};
+DEVI TriStore tri_store_setup(uint32_t i0, uint32_t j) {
+    TriStore t;
+    t.d = (int)j - (int)i0;
+    t.g0 = i0 >> 3;
+    const uint32_t g0 = t.g0, g1 = g0 + 1u;
+    t.base0 = 256u * g0 - 16u * g0 * (g0 - 1u) + (j - 8u * g0);
+    t.base1 = 256u * g1 - 16u * g1 * (g1 - 1u) + (j - 8u * g1);
+    return t;
+}
+DEVI void tri_store_pair(const TriStore& t, gdouble2* col, int Q /* a constant once the caller's loop is unrolled */, double a, double b) {
+    const int lo = Q < 4 ? 0 : 8;   // (r0 & ~7) - i0
+    int d = t.d;
+    uint32_t base = Q < 4 ? t.base0 : t.base1;
+    asm volatile("" : "+v"(d), "+v"(base));   // (formed HERE, every time: hoisted out of the column loop the sixteen factors and eight units are forty registers)
+    if (d < lo) return;               // the unit's line is not stored
+    const double fa = d < 2 * Q ? 0.0 : (d == 2 * Q ? 0.5 : 1.0);
+    const double fb = d <= 2 * Q ? 0.0 : (d == 2 * Q + 1 ? 0.5 : 1.0);
+    const uint32_t g = t.g0 + (Q < 4 ? 0u : 1u);
+    const uint32_t unit = base + (uint32_t)(Q & 3) * (64u - 8u * g);
+    col[unit] = v2f64{a * fa, b * fb};
+}
 template <int R>
 DEVI void tri_read_setup(uint32_t i0, uint32_t j, uint32_t (&loff)[R / 2], uint32_t& valid) {
     valid = 0;
@@ -1812,7 +1842,7 @@ DEVI void posterior(ChainShared<HP, R>& sh, gdouble* part_out, uint32_t part_slo
 // ------------------------------------------------------------------------------------------
 // PHASE 1: columns [0, mid), stored.  PHASE 2 (fused): columns [mid, C), posterior partials inline.
 // PHASE 3 (chunked): columns [mid + chunk*K, +K), stored into the chunk scratch (posteriors by k_post).
-template <int HP, int R, int PHASE>
+template <int HP, int R, int PHASE, bool TST = false>
 DEVI void forward_body(const DevContig& dc, ChainShared<HP, R>& sh, uint32_t C, unsigned char* ring, uint32_t chunk) {
     using Cfg = ChainCfg<HP, R, sweep_has_loader<HP, PHASE>()>;
     constexpr bool RING = Cfg::LOADER && PHASE == 2;  // partner columns via the LDS ring
@@ -1835,6 +1865,9 @@ DEVI void forward_body(const DevContig& dc, ChainShared<HP, R>& sh, uint32_t C, 
     gdouble* part_out = (gdouble*)dc.part;
     const uint32_t part_slots = dc.cls4 ? 0u : dc.part_slots;   // (0: the four class sums of a column instead of per-thread partials, see posterior)
     const bool tri = PHASE == 2 && HP == 64 && __builtin_amdgcn_readfirstlane((int)dc.tri) != 0;  // stored columns are upper triangles
+    // ... and phase 1 of such a chain that is not a lean chain (64 paths with multiallelic objects, round 6) STORES them: see tri_store_setup
+    constexpr bool tri_st = TST;   // (a compile-time variant: as a run-time branch inside the unrolled steps it cost phase 1 ninety spilled registers)
+    static_assert(!TST || (PHASE == 1 && HP == 64), "triangle stores: phase 1 at 64 paths");
 
     auto rec_load = [&](uint32_t c) -> unsigned long long {
         if (p.lane < (uint32_t)Cfg::WORDS && c < C) return colrec[(size_t)c * Cfg::WORDS + p.lane];
@@ -1946,7 +1979,7 @@ DEVI void forward_body(const DevContig& dc, ChainShared<HP, R>& sh, uint32_t C, 
     gdouble* fwd = (gdouble*)dc.fwd;
     gdouble* fscale = (gdouble*)dc.fscale;
     gu8* fallback = (gu8*)dc.fwd_fallback;
-    const size_t colsz = tri ? (size_t)dc.col_stride : (size_t)HP * HP;
+    const size_t colsz = (tri || tri_st) ? (size_t)dc.col_stride : (size_t)HP * HP;
     const uint32_t dbg = dc.debug;
     // short columns (ChainCfg::SHORT): this thread stores / resumes from its rows k < kl only
     const uint32_t live = Cfg::SHORT ? (uint32_t)__builtin_amdgcn_readfirstlane((int)dc.live) : (uint32_t)HP;
@@ -1970,8 +2003,18 @@ DEVI void forward_body(const DevContig& dc, ChainShared<HP, R>& sh, uint32_t C, 
         wr = scr + (size_t)(PG_SCR_BUF(chunk) * 2u) * K * colsz - (size_t)lo * colsz;
         if (chunk > 0) resume = (gcdouble*)(scr + ((size_t)(PG_SCR_BUF(chunk - 1u) * 2u) * K + (K - 1u)) * colsz);
     }
+    // Triangle stores (DevContig::tri, phase 1 at HP = 64): only the upper triangle is stored, the diagonal halved, the element
+    // below the diagonal inside a straddling 16-byte unit as 0 — the layout k_sweep_lean_tri writes and the triangle ring /
+    // load_col_tri of phase 2 read (a column is symmetric whatever the allele count of its object).  Fixed per thread.
+    TriStore tst{};
+    if constexpr (TST) tst = tri_store_setup(p.i0, p.j);
     auto store_col = [&](uint32_t c, const double (&x)[R]) {
         if (kExp & 1u) return;
+        if constexpr (TST) {
+            gdouble2* col = (gdouble2*)(wr + (size_t)c * colsz);
+            static_for<0, R / 2>([&](auto qc) __attribute__((always_inline)) { constexpr int q = decltype(qc)::value; tri_store_pair(tst, col, q, x[2 * q], x[2 * q + 1]); });
+            return;
+        }
         gdouble2* dst = (gdouble2*)(wr + (size_t)c * colsz) + (size_t)(p.i0 >> 1) * HP + p.j;
 #pragma unroll
         for (int k = 0; k < R; k += 2)
@@ -1980,9 +2023,10 @@ DEVI void forward_body(const DevContig& dc, ChainShared<HP, R>& sh, uint32_t C, 
     // store of one row pair, issued from inside the recursion loop: eight back-to-back 16-byte
     // stores per wave queue behind each other in the texture-address unit (store-issue bound);
     // spread between the arithmetic of the following rows they cost their issue slots only
-    auto store_pair = [&](uint32_t c, int k, double a, double b) {
+    auto store_pair = [&](uint32_t c, int k, double a, double b) __attribute__((always_inline)) {
         if (kExp & 1u) return;
         if (Cfg::SHORT && !(k < kl)) return;
+        if constexpr (TST) { tri_store_pair(tst, (gdouble2*)(wr + (size_t)c * colsz), k >> 1, a, b); return; }
         gdouble2* dst = (gdouble2*)(wr + (size_t)c * colsz) + (size_t)(p.i0 >> 1) * HP + p.j;
         dst[(size_t)(k >> 1) * HP] = v2f64{a, b};
     };
@@ -2251,7 +2295,7 @@ DEVI void forward_body(const DevContig& dc, ChainShared<HP, R>& sh, uint32_t C, 
 //  VBUF  = number of forward-column register buffers (prefetch distance in columns)
 //  KEEPW = keep w = beta_hat*e in registers across the column-sum exchange (else recompute it)
 // ------------------------------------------------------------------------------------------
-template <int HP, int R, int VBUF, bool KEEPW, int PHASE>
+template <int HP, int R, int VBUF, bool KEEPW, int PHASE, bool TST = false>
 DEVI void backward_body(const DevContig& dc, ChainShared<HP, R>& sh, uint32_t C, unsigned char* ring, uint32_t chunk) {
     using Cfg = ChainCfg<HP, R, sweep_has_loader<HP, PHASE>()>;
     constexpr bool RING = Cfg::LOADER && PHASE == 2;  // partner columns via the LDS ring
@@ -2278,6 +2322,7 @@ DEVI void backward_body(const DevContig& dc, ChainShared<HP, R>& sh, uint32_t C,
     // all-ones column) and t0 = top in phase 2 (resumed behind column mid)
     const int64_t t0 = PHASE == 1 ? top - 1 : top;
     const bool tri = PHASE == 2 && HP == 64 && __builtin_amdgcn_readfirstlane((int)dc.tri) != 0;  // stored columns are upper triangles
+    constexpr bool tri_st = TST;   // (see forward_body)
 
     auto rec_load = [&](int64_t c) -> unsigned long long {
         if (p.lane < (uint32_t)Cfg::WORDS && c >= 0 && c < (int64_t)C) return colrec[(size_t)c * Cfg::WORDS + p.lane];
@@ -2377,7 +2422,7 @@ DEVI void backward_body(const DevContig& dc, ChainShared<HP, R>& sh, uint32_t C,
     gdouble* cols = (gdouble*)dc.fwd;
     gdouble* bscale = (gdouble*)dc.bscale;
     gdouble* bsum = (gdouble*)dc.bsum;
-    const size_t colsz = tri ? (size_t)dc.col_stride : (size_t)HP * HP;
+    const size_t colsz = (tri || tri_st) ? (size_t)dc.col_stride : (size_t)HP * HP;
     // short columns (ChainCfg::SHORT, see forward_body): this thread stores / resumes from its rows k < kl only
     const uint32_t live = Cfg::SHORT ? (uint32_t)__builtin_amdgcn_readfirstlane((int)dc.live) : (uint32_t)HP;
     const int kl = Cfg::SHORT ? (p.j < live ? (int)live - (int)p.i0 : 0) : R;
@@ -2418,15 +2463,23 @@ DEVI void backward_body(const DevContig& dc, ChainShared<HP, R>& sh, uint32_t C,
             v[k] = a == b ? 2.0 * val : val;
         }
     };
+    TriStore tst{};   // triangle stores: see forward_body
+    if constexpr (TST) tst = tri_store_setup(p.i0, p.j);
     auto store_col = [&](int64_t c, const double (&y)[R]) {
+        if constexpr (TST) {
+            gdouble2* col = (gdouble2*)(wr + (size_t)c * colsz);
+            static_for<0, R / 2>([&](auto qc) __attribute__((always_inline)) { constexpr int q = decltype(qc)::value; tri_store_pair(tst, col, q, y[2 * q], y[2 * q + 1]); });
+            return;
+        }
         gdouble2* dst = (gdouble2*)(wr + (size_t)c * colsz) + (size_t)(p.i0 >> 1) * HP + p.j;
 #pragma unroll
         for (int k = 0; k < R; k += 2)
             if (!Cfg::SHORT || k < kl) dst[(size_t)(k >> 1) * HP] = v2f64{y[k], y[k + 1]};
     };
-    auto store_pair = [&](int64_t c, int k, double a, double b) {  // see forward_body
+    auto store_pair = [&](int64_t c, int k, double a, double b) __attribute__((always_inline)) {  // see forward_body
         if (kExp & 1u) return;
         if (Cfg::SHORT && !(k < kl)) return;
+        if constexpr (TST) { tri_store_pair(tst, (gdouble2*)(wr + (size_t)c * colsz), k >> 1, a, b); return; }
         gdouble2* dst = (gdouble2*)(wr + (size_t)c * colsz) + (size_t)(p.i0 >> 1) * HP + p.j;
         dst[(size_t)(k >> 1) * HP] = v2f64{a, b};
     };
@@ -2755,8 +2808,21 @@ __global__ __launch_bounds__((ChainCfg<HP, R, sweep_has_loader<HP, PHASE>()>::TT
         // behind the P0 barrier of the bodies
         if (threadIdx.x == 0) *(v2f64*)(dyn_ring + (uint32_t)kTriSlots * kTriSlotB) = v2f64{0.0, 0.0};
     }
+    if (PHASE == 1 && HP == 64 && dc.tri) return;   // phase 1 of 64-path triangle chains with multiallelic objects: k_sweep_tri1
     if (blockIdx.y == 0) forward_body<HP, R, PHASE>(dc, sh, C, dyn_ring, chunk);
     else backward_body<HP, R, VBUF, KEEPW, PHASE>(dc, sh, C, dyn_ring, chunk);
+}
+// phase 1 of the 64-path chains of fused jobs that store their columns as upper triangles and are not lean chains (objects with
+// 3 .. PG_AMAX alleles, round 6): the general kernel with triangle stores — k_sweep_lean_tri's layout, read by phase 2 through the
+// general kernel's triangle ring (DevContig::tri == 1)
+__global__ __launch_bounds__((ChainCfg<64, 16, sweep_has_loader<64, 1>()>::TT), 1) void k_sweep_tri1(const DevContig* __restrict__ contigs) {
+    __shared__ ChainShared<64, 16> sh;
+    const DevContig& dc = contigs[blockIdx.x];
+    if (dc.HP != 64u || dc.split || dc.lean || dc.leanx || !dc.tri) return;   // (leanx == 2: k_sweep_leanx_tri)
+    const uint32_t C = (uint32_t)__builtin_amdgcn_readfirstlane((int)*dc.n_cols);
+    if (C == 0) return;
+    if (blockIdx.y == 0) forward_body<64, 16, 1, true>(dc, sh, C, nullptr, 0);
+    else backward_body<64, 16, 1, true, 1, true>(dc, sh, C, nullptr, 0);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -3920,8 +3986,33 @@ DEVI double lx_emission(uint32_t ecol, const LxAlleles<LxCfg<HP>::R>& a) {
     return *(LAS const double*)(uintptr_t)add_byte<(K & 3)>(a.rows[K >> 2], ecol);
 }
 
-template <int PHASE, int HP>
+// TRI (phase 1 at 64 paths, round 6): the column is stored as its upper triangle — k_sweep_lean_tri's layout (diagonal halved,
+// zeros below it inside a stored line, nothing in the lines left of it) — for fused jobs whose 64-path chains carry
+// multiallelic objects (DevContig::tri == 1): phase 2 reads it through the general kernel's triangle ring.
+template <int R>
+struct LxTri {
+    double fa[R / 2], fb[R / 2];   // factor of the pair's two elements
+    uint32_t off[R / 2];           // byte offset of the pair's unit inside the compact column
+    uint32_t skip;                 // bit q: the unit's line is not stored
+    DEVI void setup(uint32_t i0, uint32_t j) {
+        skip = 0;
+#pragma unroll
+        for (int q = 0; q < R / 2; ++q) {
+            const uint32_t r0 = i0 + 2u * (uint32_t)q;
+            fa[q] = j < r0 ? 0.0 : (j == r0 ? 0.5 : 1.0);
+            fb[q] = j <= r0 ? 0.0 : (j == r0 + 1u ? 0.5 : 1.0);
+            const bool off_q = j < (r0 & ~7u);
+            skip |= (off_q ? 1u : 0u) << q;
+            off[q] = off_q ? 0u : tri_unit_of(r0 >> 1, j) * 16u;
+        }
+    }
+    DEVI void put(GAS char* col, int q, double a, double b) const {
+        if (!((skip >> q) & 1u)) *(gdouble2*)(col + off[q]) = v2f64{a * fa[q], b * fb[q]};
+    }
+};
+template <int PHASE, int HP, bool TRI = false>
 DEVI void leanx_forward(const DevContig& dc, LxShared<HP>& sh, uint32_t C, uint32_t chunk) {
+    static_assert(!TRI || (PHASE == 1 && HP == 64), "triangle stores: phase 1 at 64 paths");
     using Cfg = LxCfg<HP>;
     constexpr int R = Cfg::R, NS = Cfg::NS, BLK = Cfg::BLK, PPT = Cfg::PPT;
     const uint32_t mid = C / 2, K = dc.chunk_cols;
@@ -3938,7 +4029,7 @@ DEVI void leanx_forward(const DevContig& dc, LxShared<HP>& sh, uint32_t C, uint3
     const uint32_t wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const uint32_t rg = wave / (uint32_t)Cfg::NCH, i0 = rg * R, j = (wave % (uint32_t)Cfg::NCH) * 64u + lane;
     const uint32_t H = dc.H;
-    const size_t colsz = (size_t)HP * HP;
+    const size_t colsz = TRI ? (size_t)dc.col_stride : (size_t)HP * HP;
     const double unif = 1.0 / ((double)H * (double)H);
     LxRecs<HP> recs{(const GAS char*)dc.colrec, (int64_t)first - 1, (int64_t)C, +1, tid};
     v2f64 piece[PPT];
@@ -3965,7 +4056,15 @@ DEVI void leanx_forward(const DevContig& dc, LxShared<HP>& sh, uint32_t C, uint3
     GAS char* sp[R / 8];
 #pragma unroll
     for (int g = 0; g < R / 8; ++g) sp[g] = (GAS char*)(wr + (size_t)first * colsz) + toff * 16u + (size_t)(4 * g + 2) * (size_t)(HP * 16);
+    LxTri<TRI ? R : 2> ltri;
+    if constexpr (TRI) ltri.setup(i0, j);
     auto store_col = [&](uint32_t c, const double (&v)[R]) {
+        if constexpr (TRI) {
+            GAS char* col = (GAS char*)(wr + (size_t)c * colsz);
+#pragma unroll
+            for (int k = 0; k < R; k += 2) ltri.put(col, k >> 1, v[k], v[k + 1]);
+            return;
+        }
         gdouble2* dst = (gdouble2*)(wr + (size_t)c * colsz) + toff;
 #pragma unroll
         for (int k = 0; k < R; k += 2) dst[(size_t)(k >> 1) * HP] = v2f64{v[k], v[k + 1]};
@@ -4077,7 +4176,8 @@ DEVI void leanx_forward(const DevContig& dc, LxShared<HP>& sh, uint32_t C, uint3
             pin_here(x[k]);
             if (!(kLxExp & 2)) e[k] = lx_emission<HP, k>(ecoln, anx);   // e_{t+1}(i0 + k, j): the LDS reads of the next step ride under this step's arithmetic
             if constexpr (k & 1) {
-                if (!(kLxExp & 1)) *(gdouble2*)(sp[k >> 3] + (((k >> 1) & 3) - 2) * (HP * 16)) = v2f64{pprev, pk};
+                if constexpr (TRI) ltri.put((GAS char*)(wr + (size_t)t * colsz), k >> 1, pprev, pk);
+                else if (!(kLxExp & 1)) *(gdouble2*)(sp[k >> 3] + (((k >> 1) & 3) - 2) * (HP * 16)) = v2f64{pprev, pk};
                 __builtin_amdgcn_sched_barrier(0);
             }
             else pprev = pk;
@@ -4105,8 +4205,9 @@ DEVI void leanx_forward(const DevContig& dc, LxShared<HP>& sh, uint32_t C, uint3
     }
 }
 
-template <int PHASE, int HP>
+template <int PHASE, int HP, bool TRI = false>
 DEVI void leanx_backward(const DevContig& dc, LxShared<HP>& sh, uint32_t C, uint32_t chunk) {
+    static_assert(!TRI || (PHASE == 1 && HP == 64), "triangle stores: phase 1 at 64 paths");
     using Cfg = LxCfg<HP>;
     constexpr int R = Cfg::R, NS = Cfg::NS, BLK = Cfg::BLK, PPT = Cfg::PPT;
     const int64_t mid = C / 2, K = dc.chunk_cols;
@@ -4123,7 +4224,7 @@ DEVI void leanx_backward(const DevContig& dc, LxShared<HP>& sh, uint32_t C, uint
     const uint32_t wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const uint32_t rg = wave / (uint32_t)Cfg::NCH, i0 = rg * R, j = (wave % (uint32_t)Cfg::NCH) * 64u + lane;
     const uint32_t H = dc.H;
-    const size_t colsz = (size_t)HP * HP;
+    const size_t colsz = TRI ? (size_t)dc.col_stride : (size_t)HP * HP;
     const double unif = 1.0 / ((double)H * (double)H);
     LxRecs<HP> recs{(const GAS char*)dc.colrec, t0 + 1, (int64_t)C, -1, tid};   // rel r = column t0 + 1 - r
     v2f64 piece[PPT];
@@ -4146,7 +4247,15 @@ DEVI void leanx_backward(const DevContig& dc, LxShared<HP>& sh, uint32_t C, uint
     }
     const size_t toff = (size_t)(i0 >> 1) * HP + j;
     GAS char* sp[R / 8];   // (see leanx_forward; filled in below, once `wr` is known)
+    LxTri<TRI ? R : 2> ltri;   // (see leanx_forward)
+    if constexpr (TRI) ltri.setup(i0, j);
     auto store_col = [&](int64_t c, const double (&v)[R]) {
+        if constexpr (TRI) {
+            GAS char* col = (GAS char*)(wr + (size_t)c * colsz);
+#pragma unroll
+            for (int k = 0; k < R; k += 2) ltri.put(col, k >> 1, v[k], v[k + 1]);
+            return;
+        }
         gdouble2* dst = (gdouble2*)(wr + (size_t)c * colsz) + toff;
 #pragma unroll
         for (int k = 0; k < R; k += 2) dst[(size_t)(k >> 1) * HP] = v2f64{v[k], v[k + 1]};
@@ -4249,7 +4358,8 @@ DEVI void leanx_backward(const DevContig& dc, LxShared<HP>& sh, uint32_t C, uint
             pin_here(w[k]);
             if (!(kLxExp & 2)) e[k] = lx_emission<HP, k>(ecoln, anx);   // e_{t-1}(i0 + k, j) for the next step
             if constexpr (k & 1) {
-                if (!(kLxExp & 1)) *(gdouble2*)(sp[k >> 3] + (((k >> 1) & 3) - 2) * (HP * 16)) = v2f64{yprev, yk};
+                if constexpr (TRI) ltri.put((GAS char*)(wr + (size_t)t * colsz), k >> 1, yprev, yk);
+                else if (!(kLxExp & 1)) *(gdouble2*)(sp[k >> 3] + (((k >> 1) & 3) - 2) * (HP * 16)) = v2f64{yprev, yk};
                 __builtin_amdgcn_sched_barrier(0);
             }
             else yprev = yk;
@@ -4284,11 +4394,22 @@ DEVI void leanx_backward(const DevContig& dc, LxShared<HP>& sh, uint32_t C, uint
     if (wave == 2 && bsm.valid) bsm.flush(bsum, lane, (uint64_t)bot);
 }
 
+// phase 1 of the 64-path chains of fused jobs with multiallelic objects (DevContig::tri == 1, leanx == 2): the lean-x step with
+// triangle stores (phase 2: the general kernel's triangle ring)
+__global__ __launch_bounds__((LxCfg<64>::T)) void k_sweep_leanx_tri(const DevContig* __restrict__ contigs) {
+    __shared__ LxShared<64> sh;
+    const DevContig& dc = contigs[blockIdx.x];
+    if (dc.leanx != 2u || dc.HP != 64u || !dc.tri) return;
+    const uint32_t C = (uint32_t)__builtin_amdgcn_readfirstlane((int)*dc.n_cols);
+    if (C == 0) return;
+    if (blockIdx.y == 0) leanx_forward<1, 64, true>(dc, sh, C, 0);
+    else leanx_backward<1, 64, true>(dc, sh, C, 0);
+}
 template <int PHASE, int HP>
 __global__ __launch_bounds__((LxCfg<HP>::T)) void k_sweep_leanx(const DevContig* __restrict__ contigs, uint32_t chunk) {
     __shared__ LxShared<HP> sh;
     const DevContig& dc = contigs[blockIdx.x];
-    if (!dc.leanx || dc.HP != (uint32_t)HP) return;
+    if (dc.leanx != 1u || dc.HP != (uint32_t)HP) return;
     const uint32_t C = (uint32_t)__builtin_amdgcn_readfirstlane((int)*dc.n_cols);
     if (C == 0) return;
     const unsigned long long t_begin = kChainProf ? __builtin_amdgcn_s_memtime() : 0ull;
@@ -5692,6 +5813,12 @@ static void launch_sweep(const DevContig* d_contigs, uint32_t n_contigs, uint32_
 #endif
     if (hp_mask & 2u) launch_one<32, PG_HP32_ROWS, 1, true, PHASE>(d_contigs, n_contigs, chunk, s);
     if (hp_mask & 4u) launch_one<64, 16, 1, true, PHASE>(d_contigs, n_contigs, chunk, s);
+    if constexpr (PHASE == 1) {
+        if (hp_mask & 2048u)   // bit 11: 64-path triangle chains that are not lean chains, phase 1 on the general kernel (PG_KERNELS=noleanx)
+            hipLaunchKernelGGL(k_sweep_tri1, dim3(n_contigs, 2), dim3(ChainCfg<64, 16, sweep_has_loader<64, 1>()>::TT), 0, s, d_contigs);
+        if (hp_mask & 4096u)   // bit 12: ... on the lean-x step (DevContig::leanx == 2)
+            hipLaunchKernelGGL(k_sweep_leanx_tri, dim3(n_contigs, 2), dim3(LxCfg<64>::T), 0, s, d_contigs);
+    }
     if (hp_mask & 8u) launch_one<128, 32, 1, false, PHASE>(d_contigs, n_contigs, chunk, s);
     if constexpr (PHASE == 2) {
         if (hp_mask & 256u) hipLaunchKernelGGL((k_sweep_lean2<16>), dim3(n_contigs, 2), dim3(256), 0, s, d_contigs);  // bit 8: chains with tri == 2

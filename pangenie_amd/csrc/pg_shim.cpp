@@ -1077,7 +1077,10 @@ int job_build(int device, uint32_t n_index, const pg_contig_batch* batches, cons
         p.cprec = take(x.split ? (size_t)x.V * PG_CPREC_BYTES : 0);
         // fused jobs: lean chains store / read their columns as compact upper triangles (18 KB instead of 32 KB per
         // column: half the sweep's HBM bytes and of the arena); PG_KERNELS=notri keeps full columns (cross-check)
-        const bool tri = x.lean && !job->chunked && !kc.notri;
+        // (round 6: and the 64-path chains with multiallelic objects — every column narrow — whose phase 1 runs on the general
+        //  kernel: it stores the same triangles, phase 2 reads them through its triangle ring: DevContig::tri == 1)
+        const bool tri_multi = !x.lean && !x.leanx && x.HP == 64 && x.H == 64 && !x.wide_bytes && x.pair_n > 2 && !force_generic && !kc.general;
+        const bool tri = (x.lean || tri_multi) && !job->chunked && !kc.notri;
         tri_of_chain[c] = tri;
         const bool geno = params->run_genotyping != 0;  // (a phasing-only job has no sweep: no columns, no partials)
         p.fwd = take(geno ? (size_t)x.V * (tri ? 2304u : (size_t)x.HP * x.HP) * sizeof(double) : 0);
@@ -1212,9 +1215,15 @@ int job_build(int device, uint32_t n_index, const pg_contig_batch* batches, cons
             d.vit_tq = (double*)(A + p.vtq); d.vit_back = (uint16_t*)(A + p.vback); d.vit_best = (uint32_t*)(A + p.vbest);
             d.hap1 = (uint16_t*)(A + p.hap1); d.hap2 = (uint16_t*)(A + p.hap2);
         }
-        d.tri = tri_of_chain[c] ? (kc.nolean2 ? 1u : 2u) : 0u;   // (PG_KERNELS=nolean2: phase 2 of triangle chains on the general kernel's triangle ring)
+        d.tri = tri_of_chain[c] ? ((kc.nolean2 || !x.lean) ? 1u : 2u) : 0u;   // (PG_KERNELS=nolean2, and chains with multiallelic objects: phase 2 of triangle chains on the general kernel's triangle ring)
         d.col_stride = d.tri ? 2304u : x.HP * x.HP;
         if (d.tri) job->hp_mask |= 128u;
+        if (d.tri && !x.lean) {
+            // phase 1 of such chains: the lean-x step with triangle stores (DevContig::leanx == 2; it needs the column-order records
+            // of the general kernel, which phase 2 reads too) — PG_KERNELS=noleanx: the general kernel with triangle stores
+            if (kc.leanx != 0) { d.leanx = 2u; job->hp_mask |= 4096u; }
+            else job->hp_mask |= 2048u;
+        }
         if (d.tri == 2u) job->hp_mask |= 256u;
         // (k_bins_thin: what bins_thin() in pg_kernels.hip says — at most 64 partial entries per column, fused job)
         if (x.split) job->bins_which |= 32u | ((x.split == 2u && x.wide_bytes) ? 64u : 0u);   // k_bins_s, k_bins_wide_s

@@ -204,3 +204,39 @@ def test_split_entries_below_the_normal_range_keep_their_precise_products(orc, m
         assert lik.size and float(np.log2(lik.max()) - np.log2(lik.min())) > 1100   # (the test does reach below the normal range)
         assert_parity(b, got, ref)
         assert_parity(b, old_path, ref)
+
+
+@pytest.mark.parametrize("phase1", ["leanx_tri", "tri1"])
+@pytest.mark.parametrize("V", [330, 331, 1, 2])
+def test_triangle_storage_of_64_path_chains_with_multiallelic_objects(V, phase1, orc, monkeypatch):
+    """Round 6 (first step): a 64-path chain with 3-5-allele objects in a fused job stores its (symmetric)
+    columns as upper triangles too — the general kernel's phase 1 writes k_sweep_lean_tri's layout, its phase 2 reads it through
+    the triangle ring — instead of leaving triangle storage the moment one object is not biallelic.  Unregularised table as
+    well (fall-backs in both halves, re-formed bins); PG_KERNELS=notri (full columns) must agree to fp64 rounding."""
+    monkeypatch.setenv("PG_SWEEP_MODE", "fused")
+    for seed, reg, multi in ((515, 0.0, 0.3), (516, 0.01, 0.2), (517, 0.0, 1.0)):
+        args = (6, 108, 54, reg)
+        b = synthetic_panel(V, 64, 20, seed=seed, multiallelic_frac=multi, undefined_frac=0.03)
+        if reg == 0.0 and V > 3:
+            b.kmer_count[::3] = 0
+            b.kmer_count[1::17] = 60000
+        t, p = hmm.ProbabilityTable(*args), hmm.make_params(1.26, False, 1e-5)
+        # phase 1 on the lean-x step with triangle stores (k_sweep_leanx_tri, the default) or on the general kernel with them (k_sweep_tri1)
+        if phase1 == "tri1":
+            monkeypatch.setenv("PG_KERNELS", "noleanx")
+        else:
+            monkeypatch.delenv("PG_KERNELS", raising=False)
+        job = hmm.Job([b, synthetic_panel(100, 64, 20, seed=seed + 50)], t, p)   # (a lean chain in the same job: k_sweep_lean_tri / _lean2)
+        assert job.sweep_mode()[0] == "fused"
+        if int(np.diff(b.allele_off.astype(np.int64)).max()) > 2:
+            assert job.triangle_chains() == 2
+        job.run()
+        tri = job.fetch(0)
+        job.close()
+        monkeypatch.setenv("PG_KERNELS", "notri")
+        full = hmm.genotype_contig(b, t, p)
+        monkeypatch.delenv("PG_KERNELS", raising=False)
+        ref = orc.genotype_contig(b, orc.OracleTable(*args), orc.make_params(1.26, False, 1e-5))
+        assert_parity(b, tri, ref)
+        assert_parity(b, full, ref)
+        _agree(tri, full, 1e-11)
