@@ -216,7 +216,7 @@ class _DevArray:
 def job_info_of(job):
     mode, chunk_cols = job.sweep_mode()
     return {"mode": mode, "chunk_cols": chunk_cols, "tri_chains": job.triangle_chains(), "n_chains": job.n_chains,
-            "device_bytes": job.device_bytes(), "upload_bytes": job.upload_bytes()}
+            "device_bytes": job.device_bytes(), "upload_bytes": job.upload_bytes(), "index_ms": job.index_ms(), "plan": job.plan()}
 
 
 def step_table(kms, ms_per_step, p1_bytes, col_read_bytes, in_bytes, out_bytes):
@@ -527,7 +527,7 @@ def main():
                            "chains_on_rank0": len(mine), "kept_columns_rank0": ncol, "workgroups_per_chain": 2,
                            "parallelism": f"contig-sharded x{world}", "sweep_mode": "%s (chunk_cols=%d)" % (mode, chunk_cols),
                            "gather": gather_kind},
-                "per_rank": rows,
+                "per_rank": rows, "index_pass_ms": job_info.get("index_ms"), "plan": job_info.get("plan"),
                 "roofline": roof, "kernel_ms": kms, "device_bytes": job_info["device_bytes"],
                 "alloc_s": hs["alloc_s"], "upload_s": hs["upload_s"],
             })
@@ -618,6 +618,9 @@ def main():
                                   "note": "pipelined = pg_job_upload_begin(next batch); pg_job_run(this batch); pg_job_upload_end: pinned staging, "
                                           "<= chains/64 H2D copies, second set of per-sample arrays on the device"},
                 "h2d_bytes_per_sample_variant": ub["samples"] / float(cv),
+                # what the index alone decides (column list, path alleles, transition constants) is formed once per uploaded index,
+                # outside the step: its hipEvent time, and the kernels the library chose for this job
+                "index_pass_ms": cjob.index_ms(), "plan": cjob.plan(),
                 "roofline": croof, "kernel_ms": ckms, "device_bytes": cjob.device_bytes(),
             }
         cjob.close()
@@ -653,7 +656,10 @@ def main():
                                f"{int(100 * c['wide'])} % of the objects with 6-12 alleles — every chain with an index of its OWN ({c['distinct']} distinct panels, "
                                "neighbouring chains differ): pg_job_new, no shared index",
                    "value": pv * world * csteps / pdt, "unit": "variants/s", "scaling": "weak", "steps": csteps, "ms_per_step": pdt / csteps * 1e3,
-                   "chains_per_gpu": c["chains"], "sweep_mode": pmode, "kept_columns": pncol, "roofline": proof, "kernel_ms": pk, "device_bytes": pjob.device_bytes()}
+                   "chains_per_gpu": c["chains"], "sweep_mode": pmode, "kept_columns": pncol, "roofline": proof, "kernel_ms": pk, "device_bytes": pjob.device_bytes(),
+                   # every chain of this job has an index of its OWN (a sampled panel per sample): the index pass — once per uploaded
+                   # index — recurs with every batch of samples here, so the rate with it inside the step is the one that counts
+                   "index_pass_ms": pjob.index_ms(), "value_incl_index_pass": pv * world / (pdt / csteps + 1e-3 * pjob.index_ms()), "plan": pjob.plan()}
         pjob.close()
         _release_cache()
         return res

@@ -196,13 +196,25 @@ uint64_t pg_job_device_bytes(const pg_job* job);
  * chains).  Override with the environment variables PG_SWEEP_MODE=fused|chunked, PG_CHUNK_COLS=n.
  * A column with more than five distinct alleles on the selected paths ("wide") is genotyped inside a fused job when its
  * chain has 16 paths (the sampled panels of production: the column costs that column); a chain of any other width with an
- * object of more than five alleles makes its job chunked, whatever is asked for.  A 16-path chain whose ONLY column is wide
- * is refused in a fused job (PG_ERR_UNSUPPORTED from pg_job_run), never genotyped wrongly. */
+ * object of more than five alleles makes its job chunked, whatever is asked for.  (Round 5 refused a 16-path chain whose ONLY
+ * column is wide in a fused job; since round 6 such a chain needs no sweep and is genotyped — only with PG_KERNELS=nosplit or
+ * run_phasing, where the per-sample preparation of round 5 runs, pg_job_run still answers PG_ERR_UNSUPPORTED for it.) */
 int  pg_job_sweep_mode(const pg_job* job, uint32_t* chunk_cols);
-/* Number of chains of the job whose columns are kept as upper triangles (fused mode, every object biallelic,
- * H = 64: the columns are symmetric, so phase 1 writes and phase 2 reads only the stored half — half of the
+/* Number of chains of the job whose columns are kept as upper triangles (fused mode, H = 64, every object with at most five
+ * alleles: the columns are symmetric, so phase 1 writes and phase 2 reads only the stored half — half of the
  * 16 H^2 bytes per variant of the full formulation; PG_KERNELS=notri turns it off).  For traffic accounting. */
 uint32_t pg_job_triangle_chains(const pg_job* job);
+/* The index pass (round 6): what the INDEX alone decides — the ColumnIndexer flags and the column list of every contig
+ * (reference src/columnindexer.cpp:8-33); for the 16-path chains of fused jobs also every column's path -> local allele map,
+ * transition constants (src/transitionprobabilitycomputer.cpp:8-19) and bin addresses — is formed ONCE per uploaded index,
+ * inside pg_job_new / pg_cohort_new / pg_job_upload(batches != NULL), and shared by every chain (sample) over that index contig
+ * (src/commands.cpp:118-138: one index, per-sample counts).  pg_job_run forms only what hangs on the sample's counts.
+ * Elapsed milliseconds of the LAST index pass (hipEvents); it is NOT part of pg_job_kernel_ms. */
+double pg_job_index_ms(const pg_job* job);
+/* Which kernels run for which chains of this job, as text (one line per group of chains with the same plan: count, paths,
+ * sweep mode, the kernels of the preparation / phase 1 / phase 2 / bins).  Writes at most `len` bytes incl. the terminator,
+ * returns the length the full text needs.  For logs and DESIGN.md's table; the library takes every decision itself. */
+size_t pg_job_plan(const pg_job* job, char* out, size_t len);
 /* Elapsed milliseconds of the Viterbi kernels (run_phasing) of the LAST pg_job_run, hipEvents on the launch stream. */
 double pg_job_viterbi_ms(const pg_job* job);
 void pg_job_destroy(pg_job* job);

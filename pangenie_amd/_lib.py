@@ -141,6 +141,10 @@ def _bind_hip(lib):
     lib.pg_job_device_results.argtypes = [C.c_void_p, C.c_uint32, C.POINTER(C.c_void_p),
                                           u64p, C.POINTER(C.c_void_p), u64p]
     lib.pg_job_device_results.restype = C.c_int
+    lib.pg_job_index_ms.argtypes = [C.c_void_p]
+    lib.pg_job_index_ms.restype = C.c_double
+    lib.pg_job_plan.argtypes = [C.c_void_p, C.c_char_p, C.c_size_t]
+    lib.pg_job_plan.restype = C.c_size_t
     lib.pg_job_kernel_ms.argtypes = [C.c_void_p, f64p]
     lib.pg_job_kernel_ms.restype = C.c_int
     lib.pg_job_kernel_name.argtypes = [C.c_int]
@@ -222,7 +226,7 @@ HIP_ABI_SYMBOLS = [
     "pg_hmm_geno_offsets", "pg_table_create", "pg_table_create_default", "pg_table_modify",
     "pg_table_get", "pg_table_destroy", "pg_hmm_device_count", "pg_hmm_version",
     "pg_hmm_genotype_contig", "pg_job_create", "pg_job_run", "pg_job_fetch",
-    "pg_job_device_results", "pg_job_profile_counters", "pg_job_kernel_ms", "pg_job_kernel_name", "pg_job_device_bytes", "pg_job_sweep_mode",
+    "pg_job_device_results", "pg_job_profile_counters", "pg_job_kernel_ms", "pg_job_index_ms", "pg_job_plan", "pg_job_kernel_name", "pg_job_device_bytes", "pg_job_sweep_mode",
     "pg_job_destroy", "pg_emission_table", "pg_transition_probs",
     "pg_job_new", "pg_cohort_new", "pg_job_n_chains", "pg_job_upload", "pg_job_upload_begin", "pg_job_upload_end", "pg_job_host_seconds", "pg_job_upload_bytes",
     "pg_job_packed_results", "pg_hmm_release_cache", "pg_job_triangle_chains", "pg_job_viterbi_ms",

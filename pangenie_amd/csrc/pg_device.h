@@ -47,6 +47,11 @@
 #define PG_REC_FLAG_WIDE 2    // more than PG_AMAX alleles on the selected paths: table in DevContig::wide
 #define PG_REC_WIDE_IDX 44    // u32: byte offset / 16 of the variant's wide entry inside DevContig::wide
 #define PG_REC_AUX 60         // u32: byte offset / 16 of the variant's slot inside DevContig::aux (PG_WIDE_NONE: none); the last two of the eight local-slot entries
+// INVARIANT of vrec: the records of a job are zeroed ONCE, when the job is built (pg_shim.cpp), and k_prep_bi stores only
+// the 16-byte pieces of a biallelic object's record that are not zero by construction (header, row bits, four table entries,
+// path alleles).  That is sound because the kernel that prepares an object is a function of the index shape alone (alleles and
+// k-mers per variant, which pg_job_upload holds fixed) and no kernel writes anything else into a record: a new writer into
+// vrec has to keep both, or store whole records.  The split path (below) has no vrec at all.
 
 // Wide entries (columns with PG_AMAX < n_local <= PG_WIDE_MAX distinct alleles on the selected paths;
 // chunked sweep mode — or, round 5, a fused job's 16-path chain on k_sweep_small16x): the emission table no longer fits the column record, so it lives in a

@@ -821,6 +821,7 @@ DEVI void prep_bi_unit(const DevContig& dc, const DevTable& tab, uint32_t unit) 
         rec[PG_REC_FLAGS] = all_zeros ? PG_REC_FLAG_ALLZERO : 0;
         rec[PG_REC_FLAGS + 1] = 0; rec[PG_REC_FLAGS + 2] = 0;
         *(uint32_t*)(rec + PG_REC_WIDE_IDX) = PG_WIDE_NONE;
+        *(uint32_t*)(rec + PG_REC_AUX) = PG_WIDE_NONE;   // (a biallelic object has no aux slot: what pg_device.h says a reader finds; behind the slot entries 6, 7 above)
     }
     if (l == 9u) {
         ((unsigned long long*)(rec + PG_REC_BITS1))[0] = has0 ? ones : 0ull;  // bit p: path p carries LOCAL allele 1

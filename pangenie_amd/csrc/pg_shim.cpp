@@ -406,6 +406,9 @@ struct pg_job {
     bool any_split = false;
     uint32_t max_sb = 0, max_sm4 = 0, max_sw = 0;   // grid extents of the split path's emission kernels
     bool any_legacy_prep = false;
+    hipEvent_t ev_ix[2];
+    double index_ms = 0.0;
+    std::string plan_text;
     std::vector<unsigned char> tab_p;
     size_t o_tab_p = 0;
     uint32_t* d_err = nullptr;    // [n_chains]
@@ -474,6 +477,7 @@ extern "C" void pg_job_destroy(pg_job* job) {
     if (job->events) {
         for (auto& e : job->ev) hipEventDestroy(e);
         for (auto& e : job->ev_vit) hipEventDestroy(e);
+        for (auto& e : job->ev_ix) hipEventDestroy(e);
     }
     if (job->events2)
         for (int q = 0; q < (int)PG_SCRATCH_BUFS; ++q) { hipEventDestroy(job->ev_sweep[q]); hipEventDestroy(job->ev_post[q]); }
@@ -664,11 +668,16 @@ int upload_inputs(pg_job* job, const pg_contig_batch* batches, const std::vector
         // chains the per-column index records — is formed NOW, once, for every chain over the index (reference: ColumnIndexer and
         // TransitionProbabilityComputer read positions and path alleles only, src/columnindexer.cpp:8-33,
         // src/transitionprobabilitycomputer.cpp:8-19).  A run of the job forms only what hangs on the sample's counts.
+        HIP_TRY(hipEventRecord(job->ev_ix[0], s));
         HIP_TRY(hipMemsetAsync(job->ix_base, 0, job->ix_bytes, s));
         if (job->srec_bytes) HIP_TRY(hipMemsetAsync(job->srec_base, 0, job->srec_bytes, s));
         pgk_launch_index(job->d_reps, (uint32_t)job->index.size(), job->max_v, job->any_split ? 1 : 0, s);
         HIP_TRY(hipGetLastError());
+        HIP_TRY(hipEventRecord(job->ev_ix[1], s));
         HIP_TRY(hipStreamSynchronize(s));
+        float ims = 0.f;
+        HIP_TRY(hipEventElapsedTime(&ims, job->ev_ix[0], job->ev_ix[1]));
+        job->index_ms = ims;
     }
     job->up_bytes[0] = bi; job->up_bytes[1] = bs;
     job->host_s[1] = now_s() - t0;
@@ -730,9 +739,10 @@ void parallel_contigs(uint32_t n, const pg_contig_batch* batches, F&& f) {
     for (auto& t : th) t.join();
 }
 
+// (chunk_cap: 0, or the most chunk columns this attempt may plan for — the retry of a chunked job whose arena did not fit)
 int job_build(int device, uint32_t n_index, const pg_contig_batch* batches, const std::vector<ChainSpec>& specs,
               uint32_t n_samples, bool cohort, const pg_table* table, const pg_hmm_params* params, bool cache_arena,
-              pg_job** out, char* err, size_t errlen) {
+              pg_job** out, char* err, size_t errlen, size_t chunk_cap = 0) {
     *out = nullptr;
     if (!batches || !table || !params || n_index == 0 || specs.empty()) { set_err(err, errlen, "null argument"); return PG_ERR_INVALID; }
 #ifdef PG_HOST_TIMING   // (measurement builds: where the host time of a job's construction goes)
@@ -794,6 +804,8 @@ int job_build(int device, uint32_t n_index, const pg_contig_batch* batches, cons
     for (auto& e : job->ev)
         if ((he = hipEventCreate(&e)) != hipSuccess) return fail(PG_ERR_DEVICE, "hipEventCreate", he);
     for (auto& e : job->ev_vit)
+        if ((he = hipEventCreate(&e)) != hipSuccess) return fail(PG_ERR_DEVICE, "hipEventCreate", he);
+    for (auto& e : job->ev_ix)
         if ((he = hipEventCreate(&e)) != hipSuccess) return fail(PG_ERR_DEVICE, "hipEventCreate", he);
     job->events = true;
     table_snapshot(const_cast<pg_table*>(table), job->tab_m, job->tab_e, job->tab_p, &job->tab);
@@ -954,6 +966,7 @@ int job_build(int device, uint32_t n_index, const pg_contig_batch* batches, cons
             const size_t budget = (size_t)18 << 30;   // (three buffers: 4096 columns for the 24 chains of a whole genome at 64 paths)
             if (per_col * k > budget) k = budget / per_col;
             if (const char* e = getenv("PG_CHUNK_COLS")) { const long v = strtol(e, nullptr, 0); if (v > 0) k = (size_t)v; }
+            if (chunk_cap && k > chunk_cap) k = chunk_cap;
             const size_t half = (size_t)max_v / 2 + 1;
             if (k > half) k = half;
             if (k < 1) k = 1;
@@ -1125,6 +1138,15 @@ int job_build(int device, uint32_t n_index, const pg_contig_batch* batches, cons
         }
         if (he != hipSuccess) {
             job->arena = nullptr;
+            (void)hipGetLastError();
+            // A chunked job's scratch (PG_SCRATCH_BUFS buffers of chunk_cols columns per half-chain: up to 18 GB) is a choice, not
+            // a need: before giving up, plan again with half the chunk columns (the fixed budget could fail a job
+            // that fitted with smaller chunks — on a smaller device, or next to other resident jobs)
+            if (job->chunked && job->chunk_cols > 64u) {
+                const size_t next_cap = job->chunk_cols / 2u;
+                pg_job_destroy(job);
+                return job_build(device, n_index, batches, specs, n_samples, cohort, table, params, cache_arena, out, err, errlen, next_cap);
+            }
             set_err(err, errlen, "hipMalloc(%zu bytes) failed: %s", job->arena_bytes, hipGetErrorString(he));
             pg_job_destroy(job);
             return PG_ERR_NOMEM;
@@ -1254,6 +1276,49 @@ int job_build(int device, uint32_t n_index, const pg_contig_batch* batches, cons
         if (!small_ids.empty() && (he = hipMemcpyAsync(job->d_small, small_ids.data(), sizeof(uint32_t) * small_ids.size(), hipMemcpyHostToDevice, job->stream)) != hipSuccess)
             return fail(PG_ERR_DEVICE, "hipMemcpy small ids", he);
         if (!small_ids.empty() && (he = hipStreamSynchronize(job->stream)) != hipSuccess) return fail(PG_ERR_DEVICE, "hipMemcpy small ids", he);
+    }
+    {   // the plan as text (pg_job_plan): one line per group of chains with the same kernels
+        struct Group { std::string text; uint32_t count = 0; };
+        std::vector<Group> groups;
+        for (uint32_t c = 0; c < n_chains; ++c) {
+            const DevContig& d = hd[c];
+            const IndexHost& x = job->index[job->chains[c].index];
+            if (x.V == 0) continue;
+            const bool multi = x.pair_n > 2, wide = x.wide_bytes != 0;
+            std::string prep, p1, p2, bins;
+            const char* gen = d.HP >= 256 || force_generic ? "k_sweep_generic" : (d.HP == 16 ? "k_sweep<16,4>" : d.HP == 32 ? "k_sweep<32,8>" : d.HP == 64 ? "k_sweep<64,16>" : "k_sweep<128,32>");
+            if (d.split) {
+                prep = std::string("index pass once (k_index_scan, k_compact, k_index_cols); per run k_prep_s_bi") + (x.all_sb ? "" : " + k_prep_s_m4 + k_prep_s_w");
+                p1 = d.split == 1u ? "k_sweep_small16<1>" : "k_sweep_small16x<1>";
+                p2 = d.split == 1u ? "k_sweep_small16<2>" : "k_sweep_small16x<2>";
+                bins = std::string("k_bins_s") + (wide ? " + k_bins_wide_s" : "");
+            } else {
+                prep = "index pass once (k_index_scan, k_compact); per run ";
+                prep += x.prep_fast == 1u ? "k_prep_bi" : (x.prep_fast == 2u ? "k_prep_bi + k_prep_m4 + k_prep" : "k_prep");
+                prep += " + k_records";
+                p1 = d.lean ? (d.tri ? "k_sweep_lean_tri<1>" : "k_sweep_lean<1>") : d.leanx == 2u ? "k_sweep_leanx_tri" : d.leanx ? "k_sweep_leanx<1>"
+                     : d.small ? "k_sweep_small16<1>" : d.smallx ? "k_sweep_small16x<1>" : (d.tri ? "k_sweep_tri1" : std::string(gen) + "<1>");
+                if (job->chunked) {
+                    p2 = d.lean ? "k_sweep_lean<3>" : d.leanx ? "k_sweep_leanx<3>" : d.small ? "k_sweep_small16<3>" : d.smallx ? "k_sweep_small16x<3>" : std::string(gen) + "<3>";
+                    p2 += " chunks + k_post";
+                    bins = "(k_post)";
+                } else {
+                    p2 = d.tri == 2u ? "k_sweep_lean2" : d.small == 2u ? "k_sweep_small16<2>" : d.smallx == 2u ? "k_sweep_small16x<2>"
+                         : std::string(gen) + (d.tri ? "<2> (triangle ring)" : "<2>");
+                    bins = (d.tri == 2u || d.cls4) ? "k_bins_lean2" : d.smallx == 2u ? (wide ? "k_bins_x + k_bins_wide" : "k_bins_x")
+                           : (d.T <= 64u && d.HP <= 32u) ? "k_bins_thin" : "k_bins";
+                }
+            }
+            char head[160];
+            snprintf(head, sizeof(head), "%u path(s) (padded %u), %s%s%s columns: ", d.H, d.HP, multi ? "multiallelic" : "biallelic", wide ? " + wide" : "",
+                     d.tri ? ", triangle" : "");
+            std::string text = std::string(head) + "prep = " + prep + "; phase 1 = " + p1 + "; phase 2 = " + p2 + "; bins = " + bins;
+            bool found = false;
+            for (auto& g : groups) if (g.text == text) { g.count += 1; found = true; break; }
+            if (!found) groups.push_back({text, 1});
+        }
+        job->plan_text = std::string(job->chunked ? "chunked" : "fused") + " job, " + std::to_string(n_chains) + " chain(s)" + (params->run_phasing ? ", run_phasing (k_viterbi)" : "") + "\n";
+        for (const auto& g : groups) job->plan_text += "  " + std::to_string(g.count) + " x " + g.text + "\n";
     }
     job->h_contigs = hd;
     job->cur_samples = A + job->sample_lo;
@@ -1772,6 +1837,13 @@ extern "C" int pg_job_sweep_mode(const pg_job* job, uint32_t* chunk_cols) {
 
 extern "C" double pg_job_viterbi_ms(const pg_job* job) { return job ? job->vit_ms : 0.0; }
 
+extern "C" double pg_job_index_ms(const pg_job* job) { return job ? job->index_ms : 0.0; }
+extern "C" size_t pg_job_plan(const pg_job* job, char* out, size_t len) {
+    if (!job) return 0;
+    const std::string& t = job->plan_text;
+    if (out && len) { const size_t n = t.size() < len - 1 ? t.size() : len - 1; memcpy(out, t.data(), n); out[n] = 0; }
+    return t.size() + 1;
+}
 extern "C" uint32_t pg_job_triangle_chains(const pg_job* job) {
     if (!job) return 0;
     uint32_t n = 0;

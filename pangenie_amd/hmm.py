@@ -379,6 +379,17 @@ class Job:
                                         C.byref(d_exp), C.byref(n_var))
         return d_lik.value, n_lik.value, d_exp.value, n_var.value
 
+    def index_ms(self) -> float:
+        """pg_job_index_ms: hipEvent time of the last index pass (what the index alone decides, formed once per uploaded index)"""
+        return float(self._lib.pg_job_index_ms(self.h))
+
+    def plan(self) -> str:
+        """pg_job_plan: which kernels run for which chains of this job"""
+        n = int(self._lib.pg_job_plan(self.h, None, 0))
+        buf = C.create_string_buffer(n)
+        self._lib.pg_job_plan(self.h, buf, n)
+        return buf.value.decode(errors="replace")
+
     def kernel_ms(self) -> dict:
         ms = (C.c_double * PG_N_KERNEL_CLASSES)()
         self._lib.pg_job_kernel_ms(self.h, ms)

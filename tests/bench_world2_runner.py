@@ -89,6 +89,12 @@ class MockJob:
     def device_bytes(self):
         return 1
 
+    def index_ms(self):
+        return 0.5
+
+    def plan(self):
+        return "mock"
+
     def close(self):
         pass
 
