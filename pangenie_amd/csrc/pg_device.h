@@ -248,6 +248,9 @@ struct DevContig {
     const unsigned char* ix_bin;
     unsigned char* cprec;      // [V][192] per chain (touched for flagged columns only)
     uint32_t* ix_err;          // per index contig: error bits of k_index_scan (PG_DEVERR_*)
+    const uint32_t* ix_big;    // per index contig: its variants with more than 32 alleles (the wave-per-object index kernels' list)
+    uint32_t n_ix_big;
+    uint32_t pad2;
     // the WIDE columns of the chain (smallx == 2, index with objects of more than PG_AMAX alleles): k_records appends every wide
     // column it meets, k_bins_wide walks the list — one wave per entry instead of a scan of all columns for the rare one
     uint32_t* wcols;           // [wide candidates of the index contig]

@@ -5856,11 +5856,16 @@ void pgk_launch_compact(const DevContig* d_contigs, uint32_t n_contigs, hipStrea
 }
 // The index-level work of a job (pg_split.h), once per uploaded index: d_reps = one chain descriptor per index contig.
 // ColumnIndexer flags -> column list -> (split chains) the per-column index records.
-void pgk_launch_index(const DevContig* d_reps, uint32_t n_index, uint32_t max_v, int any_split, hipStream_t s) {
+void pgk_launch_index(const DevContig* d_reps, uint32_t n_index, uint32_t max_v, uint32_t max_big, int any_split, hipStream_t s) {
     if (max_v == 0 || n_index == 0) return;
-    hipLaunchKernelGGL(k_index_scan, dim3((max_v + 3u) / 4u, n_index), dim3(256), 0, s, d_reps);
+    // one thread per variant / column; the (rare) objects with more than 32 alleles from their list, one wave each
+    hipLaunchKernelGGL(k_index_scan_t, dim3((max_v + 255u) / 256u, n_index), dim3(256), 0, s, d_reps);
+    if (max_big) hipLaunchKernelGGL(k_index_scan, dim3((max_big + 3u) / 4u, n_index), dim3(256), 0, s, d_reps);
     hipLaunchKernelGGL(k_compact, dim3(n_index), dim3(1024), 0, s, d_reps);
-    if (any_split) hipLaunchKernelGGL(k_index_cols, dim3((max_v + 3u) / 4u, n_index), dim3(256), 0, s, d_reps);
+    if (any_split) {
+        hipLaunchKernelGGL(k_index_cols_t, dim3((max_v + 255u) / 256u, n_index), dim3(256), 0, s, d_reps);
+        if (max_big) hipLaunchKernelGGL(k_index_cols, dim3((max_big + 3u) / 4u, n_index), dim3(256), 0, s, d_reps);
+    }
 }
 // The sample-level emission kernels of split chains: max_b / max_m4 / max_w = the longest walks of k_prep_s_bi (a chain's list of
 // biallelic objects, or all its variants), k_prep_s_m4 and k_prep_s_w over the chains

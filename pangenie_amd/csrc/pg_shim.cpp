@@ -35,7 +35,7 @@
 extern "C" {
 void pgk_launch_prep(const DevContig*, uint32_t, uint32_t, uint32_t, uint32_t, DevTable, hipStream_t);
 void pgk_launch_compact(const DevContig*, uint32_t, hipStream_t);
-void pgk_launch_index(const DevContig*, uint32_t, uint32_t, int, hipStream_t);
+void pgk_launch_index(const DevContig*, uint32_t, uint32_t, uint32_t, int, hipStream_t);
 void pgk_launch_prep_split(const DevContig*, uint32_t, uint32_t, uint32_t, uint32_t, DevTable, hipStream_t);
 void pgk_launch_records(const DevContig*, uint32_t, uint32_t, hipStream_t);
 void pgk_launch_bins(const DevContig*, uint32_t, uint32_t, uint32_t, uint32_t, hipStream_t);
@@ -242,6 +242,8 @@ struct IndexHost {   // one index contig
     // per-variant work is split into what the index alone decides (formed once per upload) and what the sample's counts decide
     uint32_t split = 0;
     bool all_sb = false;     // every object is k_prep_s_bi's (two alleles, <= 32 k-mers): no lists
+    std::vector<uint32_t> list_big;   // variants with more than 32 alleles: the wave-per-object index kernels' list (the others: one thread each)
+    size_t o_list_big = 0;
     // index-level device arrays (every chain over this contig points at them)
     size_t o_kept = 0, o_apres = 0, o_colv = 0, o_colof = 0, o_ixpd = 0, o_ixrec = 0, o_ixbin = 0, o_ixwl = 0, o_ixnw = 0;
     uint32_t sumK = 0, sumA = 0;
@@ -606,6 +608,7 @@ int upload_inputs(pg_job* job, const pg_contig_batch* batches, const std::vector
             UP(x.o_list_m4, x.list_m4.data(), x.list_m4.size() * 4, bi);
             UP(x.o_list_w, x.list_w.data(), x.list_w.size() * 4, bi);
             UP(x.o_list_b, x.list_b.data(), x.list_b.size() * 4, bi);
+            UP(x.o_list_big, x.list_big.data(), x.list_big.size() * 4, bi);
         }
         UP(job->o_tab_m, job->tab_m.data(), job->tab_m.size() * sizeof(double), bi);
         UP(job->o_tab_e, job->tab_e.data(), job->tab_e.size() * sizeof(int32_t), bi);
@@ -671,7 +674,9 @@ int upload_inputs(pg_job* job, const pg_contig_batch* batches, const std::vector
         HIP_TRY(hipEventRecord(job->ev_ix[0], s));
         HIP_TRY(hipMemsetAsync(job->ix_base, 0, job->ix_bytes, s));
         if (job->srec_bytes) HIP_TRY(hipMemsetAsync(job->srec_base, 0, job->srec_bytes, s));
-        pgk_launch_index(job->d_reps, (uint32_t)job->index.size(), job->max_v, job->any_split ? 1 : 0, s);
+        uint32_t max_big = 0;
+        for (const IndexHost& x : job->index) max_big = std::max<uint32_t>(max_big, (uint32_t)x.list_big.size());
+        pgk_launch_index(job->d_reps, (uint32_t)job->index.size(), job->max_v, max_big, job->any_split ? 1 : 0, s);
         HIP_TRY(hipGetLastError());
         HIP_TRY(hipEventRecord(job->ev_ix[1], s));
         HIP_TRY(hipStreamSynchronize(s));
@@ -840,6 +845,7 @@ int job_build(int device, uint32_t n_index, const pg_contig_batch* batches, cons
             const uint64_t A = b.allele_off[v + 1] - b.allele_off[v];
             x.goff[v + 1] = x.goff[v] + A * (A + 1) / 2;
             if (A > maxA) maxA = A;
+            if (A > 32u) x.list_big.push_back(v);
             if (A != 2) two_alleles = false;
             x.n_kmers[v] = (uint16_t)(b.kmer_off[v + 1] - b.kmer_off[v]);
             if (b.kmer_off[v + 1] - b.kmer_off[v] > maxK) maxK = b.kmer_off[v + 1] - b.kmer_off[v];
@@ -1057,6 +1063,7 @@ int job_build(int device, uint32_t n_index, const pg_contig_batch* batches, cons
         x.o_list_m4 = take(x.list_m4.size() * 4);
         x.o_list_w = take(x.list_w.size() * 4);
         x.o_list_b = take(x.list_b.size() * 4);
+        x.o_list_big = take(x.list_big.size() * 4);
     }
     job->sample_lo = align_up(off);   // the per-sample arrays of all chains, one contiguous run (pg_job::sample_lo)
     for (uint32_t c = 0; c < n_chains; ++c) {
@@ -1192,6 +1199,7 @@ int job_build(int device, uint32_t n_index, const pg_contig_batch* batches, cons
         d.vrec = A + p.vrec; d.kept = A + x.o_kept; d.allele_present = A + x.o_apres;
         d.n_cols = job->d_ncols + ch.index; d.col_variant = (uint32_t*)(A + x.o_colv); d.colrec = A + p.colrec;
         d.col_of = (const uint32_t*)(A + x.o_colof); d.ix_err = job->d_ixerr + ch.index;
+        d.ix_big = (const uint32_t*)(A + x.o_list_big); d.n_ix_big = (uint32_t)x.list_big.size();
         d.split = x.split;
         if (x.split) {
             d.ix_pd = A + x.o_ixpd; d.ix_rec = A + x.o_ixrec; d.ix_bin = A + x.o_ixbin; d.cprec = A + p.cprec;

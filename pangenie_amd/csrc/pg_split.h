@@ -19,13 +19,18 @@
 // ------------------------------------------------------------------------------------------
 //  k_index_scan : one wave per variant
 // ------------------------------------------------------------------------------------------
+// (objects with more than PG_IX_THREAD_AMAX alleles only — the list ix_big of the index contig; every other object is
+//  k_index_scan_t's, one THREAD per variant: a wave per variant spent 46 ms on the 32.8 M objects of 4096 sixteen-path panels)
+#define PG_IX_THREAD_AMAX 32u
 __global__ __launch_bounds__(256) void k_index_scan(const DevContig* __restrict__ reps) {
     __shared__ uint32_t s_pres[4][8];
     __shared__ uint16_t s_aid[4][64];
     __shared__ uint8_t s_afl[4][64];
     const DevContig& dc = reps[blockIdx.y];
     const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const uint32_t v = blockIdx.x * 4u + wave;
+    const uint32_t bi = blockIdx.x * 4u + wave;
+    if (bi >= dc.n_ix_big) return;
+    const uint32_t v = dc.ix_big[bi];
     if (v >= dc.V) return;
     const uint32_t a0 = dc.allele_off[v], A = dc.allele_off[v + 1] - a0, H = dc.H;
     if (A > PG_MAX_ALLELES_PER_VARIANT || A == 0) {
@@ -76,9 +81,11 @@ __global__ __launch_bounds__(256) void k_index_cols(const DevContig* __restrict_
     const DevContig& dc = reps[blockIdx.y];
     if (!dc.split) return;
     const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const uint32_t C = *dc.n_cols;
-    const uint32_t c = blockIdx.x * 4u + wave;
-    if (c >= C) return;
+    const uint32_t bi = blockIdx.x * 4u + wave;   // (the index contig's objects with more than PG_IX_THREAD_AMAX alleles: see k_index_scan)
+    if (bi >= dc.n_ix_big) return;
+    const uint32_t vb = dc.ix_big[bi];
+    const uint32_t c = dc.col_of[vb];
+    if (c == PG_COL_NONE) return;
     const uint32_t v = dc.col_variant[c];
     const uint32_t a0 = dc.allele_off[v], A = dc.allele_off[v + 1] - a0, H = dc.H;
     uint32_t* pres = s_pres[wave];
@@ -163,6 +170,124 @@ __global__ __launch_bounds__(256) void k_index_cols(const DevContig* __restrict_
         *(IxBin*)(const_cast<unsigned char*>(dc.ix_bin) + (size_t)c * PG_IXBIN_BYTES) = b;
         if (wide && dc.wcols) dc.wcols[atomicAdd(dc.n_wcols, 1u)] = c;
     }
+}
+
+// ------------------------------------------------------------------------------------------
+//  k_index_scan_t / k_index_cols_t : the same, one THREAD per variant / column, for objects with at most PG_IX_THREAD_AMAX
+//  alleles (the presence bitmap is one register) — all but the largest bubbles
+// ------------------------------------------------------------------------------------------
+DEVI int ix_slot_of(const uint16_t* aid, uint32_t A, uint16_t a) {   // the LAST matching slot, as slot_of
+    int s = -1;
+    for (uint32_t q = 0; q < A; ++q) if (aid[q] == a) s = (int)q;
+    return s;
+}
+__global__ __launch_bounds__(256) void k_index_scan_t(const DevContig* __restrict__ reps) {
+    const DevContig& dc = reps[blockIdx.y];
+    const uint32_t v = blockIdx.x * 256u + threadIdx.x;
+    if (v >= dc.V) return;
+    const uint32_t a0 = dc.allele_off[v], A = dc.allele_off[v + 1] - a0, H = dc.H;
+    if (A > PG_IX_THREAD_AMAX || A == 0) return;   // k_index_scan (A == 0 cannot be: check_batch)
+    const uint16_t* aid = dc.allele_id + a0;
+    const uint8_t* afl = dc.allele_flags + a0;
+    const uint16_t* pa = dc.path_allele + (size_t)v * H;
+    uint32_t pres = 0;
+    bool nonref = false, bad = false;
+    if (A == 2u) {
+        const uint16_t id0 = aid[0], id1 = aid[1];
+        const bool u0 = afl[0] & 1, u1 = afl[1] & 1;
+        for (uint32_t p = 0; p < H; ++p) {
+            const uint16_t a = pa[p];
+            const bool s1 = a == id1, s0 = !s1 && a == id0;
+            bad = bad || !(s1 || s0);
+            pres |= s1 ? 2u : (s0 ? 1u : 0u);
+            nonref = nonref || ((s1 || s0) && a != 0 && !(s1 ? u1 : u0));
+        }
+    } else {
+        for (uint32_t p = 0; p < H; ++p) {
+            const uint16_t a = pa[p];
+            const int sl = ix_slot_of(aid, A, a);
+            if (sl < 0) bad = true;
+            else { pres |= 1u << sl; if (a != 0 && !(afl[sl] & 1)) nonref = true; }
+        }
+    }
+    if (bad) { atomicOr(dc.ix_err, PG_DEVERR_ALLELE_NOT_FOUND); dc.kept[v] = 0; return; }
+    for (uint32_t q = 0; q < A; ++q) dc.allele_present[a0 + q] = (pres >> q) & 1u;
+    dc.kept[v] = nonref ? 1 : 0;
+    if (nonref && (uint32_t)__popc(pres) > (uint32_t)PG_AMAX && (!dc.wide_idx || dc.wide_idx[v] == PG_WIDE_NONE)) atomicOr(dc.ix_err, PG_DEVERR_TOO_MANY_LOCAL);
+}
+
+__global__ __launch_bounds__(256) void k_index_cols_t(const DevContig* __restrict__ reps) {
+    const DevContig& dc = reps[blockIdx.y];
+    if (!dc.split) return;
+    const uint32_t C = *dc.n_cols;
+    const uint32_t c = blockIdx.x * 256u + threadIdx.x;
+    if (c >= C) return;
+    const uint32_t v = dc.col_variant[c];
+    const uint32_t a0 = dc.allele_off[v], A = dc.allele_off[v + 1] - a0;   // (H = HP = 16: split chains)
+    if (A > PG_IX_THREAD_AMAX) return;   // k_index_cols
+    const uint16_t* aid = dc.allele_id + a0;
+    uint32_t pres = 0;
+    for (uint32_t q = 0; q < A; ++q) if (dc.allele_present[a0 + q]) pres |= 1u << q;
+    const uint32_t n_local = (uint32_t)__popc(pres);
+    const bool wide = n_local > (uint32_t)PG_AMAX;
+    const uint4 pw0 = *(const uint4*)(dc.path_allele + (size_t)v * 16u), pw1 = *(const uint4*)(dc.path_allele + (size_t)v * 16u + 8u);
+    const uint32_t pwords[8] = {pw0.x, pw0.y, pw0.z, pw0.w, pw1.x, pw1.y, pw1.z, pw1.w};
+    uint32_t bits1 = 0, row[4] = {0, 0, 0, 0}, cnt[PG_AMAX] = {0, 0, 0, 0, 0};
+#pragma unroll
+    for (int pth = 0; pth < 16; ++pth) {
+        const uint16_t a = (uint16_t)(pwords[pth >> 1] >> (16 * (pth & 1)));
+        uint32_t loc = PG_PHANTOM;
+        if (A == 2u) loc = a == aid[1] ? ((pres & 1u) ? 1u : 0u) : 0u;   // (slot 1 is local 1 if slot 0 is present too; the scan has vouched for every allele)
+        else {
+            const int sl = ix_slot_of(aid, A, a);
+            if (sl >= 0) loc = (uint32_t)__popc(pres & ((1u << sl) - 1u));
+        }
+        bits1 |= (loc == 1u ? 1u : 0u) << pth;
+#pragma unroll
+        for (int l = 0; l < PG_AMAX; ++l) cnt[l] += loc == (uint32_t)l ? 1u : 0u;
+        const uint32_t ro = (!wide && loc < (uint32_t)PG_AMAX) ? (loc + 1u) * (uint32_t)(PG_ESTRIDE * 8) : 0u;
+        row[pth >> 2] |= ro << (8 * (pth & 3));
+    }
+    double c0 = 0.0, c1 = 0.0, c2 = 0.0, kappa = 0.0;
+    if (c > 0) {
+        const double d = (double)(dc.pos[v] - dc.pos[dc.col_variant[c - 1]]) * dc.dist_scale;
+        transition_consts(d, dc.H, dc.uniform, c0, c1, c2, kappa);
+    }
+    const uint32_t widx = wide && dc.wide_idx ? dc.wide_idx[v] : PG_WIDE_NONE;
+    const uint32_t aux = dc.aux_idx ? dc.aux_idx[v] : PG_WIDE_NONE;
+    const uint32_t nlf = (n_local & 0xFFu) | (wide ? (uint32_t)PG_REC_FLAG_WIDE << 8 : 0u);
+    v2f64* rec = (v2f64*)(const_cast<unsigned char*>(dc.ix_rec) + (size_t)c * PG_IXREC_BYTES);
+    if (dc.split == 1u) {
+        rec[0] = v2f64{c0, c1}; rec[1] = v2f64{c2, kappa};
+        rec[2] = v2f64{__longlong_as_double((long long)(unsigned long long)bits1), 0.0}; rec[3] = v2f64{0.0, 0.0};
+    } else {
+        const uint4 h = uint4{nlf, widx, aux, 0u}, r4 = uint4{row[0], row[1], row[2], row[3]};
+        rec[0] = *(const v2f64*)&h; rec[1] = v2f64{c0, c1}; rec[2] = v2f64{c2, kappa}; rec[3] = *(const v2f64*)&r4;
+    }
+    const uint32_t k0 = dc.kmer_off[v], K = dc.kmer_off[v + 1] - k0;
+    uint32_t kf = K > 0xFFu ? 0xFFu : K, on0 = 0, on1 = 0;
+    if (A == 2u) {
+        const uint32_t off0 = dc.allele_koff[a0], off1 = dc.allele_koff[a0 + 1];
+        on0 = off0 < 32u ? dc.allele_kmask[a0] << off0 : 0u;
+        on1 = off1 < 32u ? dc.allele_kmask[a0 + 1] << off1 : 0u;
+        if (dc.allele_flags[a0] & 1) kf |= PG_IXPD_U0;
+        if (dc.allele_flags[a0 + 1] & 1) kf |= PG_IXPD_U1;
+        if (pres & 1u) kf |= PG_IXPD_HAS0;
+        if (pres & 2u) kf |= PG_IXPD_HAS1;
+    }
+    uint4* pd = (uint4*)(const_cast<unsigned char*>(dc.ix_pd) + (size_t)c * PG_IXPD_BYTES);
+    pd[0] = uint4{v, k0, kf, on0}; pd[1] = uint4{on1, 0u, 0u, 0u};
+    IxBin b;
+    b.g0 = (uint32_t)dc.geno_off[v]; b.v = v; b.aux = aux; b.A = (uint16_t)A; b.nl = (uint8_t)n_local;
+    b.flags = wide ? (uint8_t)PG_SREC_FLAG_WIDE : 0; b.pad = 0;
+    uint32_t l = 0;
+    for (uint32_t sl = 0; sl < A && l < (uint32_t)PG_AMAX; ++sl)
+        if ((pres >> sl) & 1u) b.ls[l++] = (uint16_t)sl;
+    for (; l < (uint32_t)PG_AMAX; ++l) b.ls[l] = 0;
+#pragma unroll
+    for (int q = 0; q < PG_AMAX; ++q) b.cnt[q] = (uint8_t)cnt[q];
+    *(IxBin*)(const_cast<unsigned char*>(dc.ix_bin) + (size_t)c * PG_IXBIN_BYTES) = b;
+    if (wide && dc.wcols) dc.wcols[atomicAdd(dc.n_wcols, 1u)] = c;
 }
 
 // ------------------------------------------------------------------------------------------
