@@ -78,6 +78,10 @@ static inline uint64_t pg_wide_entry_bytes(uint32_t n_local) {
 // early deficit is worked off once the short chains have ended.
 #define PG_SCRATCH_BUFS 3u
 #define PG_SCR_BUF(c) ((c) % PG_SCRATCH_BUFS)
+#define PG_SYNC_NEXT 16u
+#define PG_SYNC_DONE 17u
+#define PG_SYNC_READY 32u   // chunks with both roles stored, republished by k_post_loop's watcher wave (what its other waves poll)
+#define PG_SYNC_WORDS 48u   // DevContig::sync: three 64-byte lines per chain
 
 // Column biases: stored forward columns (before the emission multiply) sum to about
 // 2^PG_BIAS_F, stored backward columns to about 2^PG_BIAS_B times their emission-weighted mass.
@@ -95,6 +99,7 @@ static inline uint32_t pg_rec_bytes(uint32_t hp) { return (PG_REC_ALLELES + hp +
 #define PG_DEVERR_ALLELE_NOT_FOUND 1u
 #define PG_DEVERR_TOO_MANY_ALLELES 2u
 #define PG_DEVERR_TOO_MANY_LOCAL 4u
+#define PG_DEVERR_SYNC_TIMEOUT 16u // a persistent phase-2 kernel (k_sweep_lean<4> / k_post_loop) gave up waiting for its partner's chunk flag
 #define PG_DEVERR_WIDE_FUSED 8u   // a wide column reached a fused bins kernel that has no path for it (a single-column chain of k_sweep_small16x's job)
 
 struct DevTable {
@@ -197,6 +202,13 @@ struct DevContig {
     // half-chain that only STORE their columns into this scratch ([PG_SCRATCH_BUFS buffers][2 roles][chunk_cols][HP*HP],
     // forward role first); k_post forms the posteriors of a finished chunk on the idle CUs.
     double*   scratch;
+    // persistent chunked phase 2 (all chains lean, few of them — pg_shim.cpp `persist`): ONE launch of k_sweep_lean<4> walks
+    // every chunk of a half-chain and ONE launch of k_post_loop every chunk's posteriors; the two hand chunks over through
+    // these words (zeroed at the start of every run; agent-scope release / acquire):
+    //   sync[0] / sync[1]      = chunks the forward / backward role has finished storing (written by the sweep; a 64-byte line of their own),
+    //   sync[PG_SYNC_NEXT]     = the next column slot to hand out (k_post_loop's work queue: chunk after chunk, 2 chunk_cols slots each),
+    //   sync[PG_SYNC_DONE + b] = column slots of scratch buffer b whose posteriors are done, over all its chunks so far (k_post_loop)
+    uint32_t* sync;            // [PG_SYNC_WORDS]
     uint32_t  chunk_cols;
     uint32_t  col_stride;      // doubles between consecutive columns of `fwd`: HP*HP, or 2304 (the 18 KB of a compact triangle) when tri
     uint8_t*  wide;            // wide entries (see above)

@@ -29,6 +29,21 @@ static constexpr bool kLeanDppSum = true;
 static constexpr bool kLeanDppSum = false;
 #endif
 
+// -DPG_POST_GENERIC: k_post / k_post_loop form the columns of lean chains with the general post_ab instead of post_lean64 (results
+// identical; the A/B build of round 6's k_post measurement)
+#ifdef PG_POST_GENERIC
+static constexpr bool kPostGeneric = true;
+#else
+static constexpr bool kPostGeneric = false;
+#endif
+
+// persistent phase 2 (k_sweep_lean<4> + k_post_loop), timing experiments — results WRONG: 1 k_post_loop hands the buffers back
+// without forming posteriors, 2 the sweep does not wait for its scratch buffer
+#ifndef PG_PERSIST_EXP
+#define PG_PERSIST_EXP 0
+#endif
+static constexpr unsigned kPersistExp = PG_PERSIST_EXP;
+
 // lean-x step (k_sweep_leanx): 1 no column stores, 2 no emission fetches
 #ifndef PG_LX_EXP
 #define PG_LX_EXP 0

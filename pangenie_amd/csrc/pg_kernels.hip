@@ -3041,6 +3041,47 @@ DEVI double lean_colsum(const LeanShared<R>& sh, uint32_t pb, uint32_t lane) {
 
 
 
+// ------------------------------------------------------------------------------------------
+//  Chunk hand-over of the PERSISTENT chunked phase 2 (PHASE 4 of k_sweep_lean, k_post_loop; DevContig::sync).  The sweep of a
+//  half-chain stores chunk after chunk into the rotating scratch buffers without leaving the CU; k_post_loop's blocks (on the CUs
+//  the chains leave idle) form the posteriors of a chunk as soon as both roles have published it, and hand the buffer back.
+//  Stores -> agent-scope release fence by every wave (the XCD's L2 is written back) -> workgroup barrier -> the flag; the
+//  reader's acquire invalidates its own XCD's L2.  Every wait is bounded (wall clock): a partner that never arrives — a kernel
+//  that was not co-resident — raises PG_DEVERR_SYNC_TIMEOUT instead of hanging the device.
+// ------------------------------------------------------------------------------------------
+#define PG_SYNC_TIMEOUT_TICKS 1000000000ull   // 10 s of the 100 MHz constant clock
+#ifndef PG_POLL_SLEEPS
+#define PG_POLL_SLEEPS 2   // s_sleep 127 (~3.4 us) between two polls of a chunk flag
+#endif
+// (The poll is a RELAXED load every ~7 us — an acquire per poll would invalidate the XCD's L2 every time, and 192 blocks polling
+//  every half microsecond cost the chains beside them 15 % (profiles/r06_persist.txt); the acquire follows the successful poll.)
+DEVI bool chunk_spin(uint32_t* flag, uint32_t want, uint32_t* err) {   // one thread
+    bool ok = __hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= want;
+    if (!ok) {
+        const unsigned long long t0 = wall_clock64();
+        for (uint32_t it = 0;; ++it) {
+#pragma unroll
+            for (int z = 0; z < PG_POLL_SLEEPS; ++z) __builtin_amdgcn_s_sleep(127);
+            if (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= want) { ok = true; break; }
+            if ((it & 63u) == 63u) {
+                if (__hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & PG_DEVERR_SYNC_TIMEOUT) break;   // (the partner gave up)
+                if (wall_clock64() - t0 > PG_SYNC_TIMEOUT_TICKS) { atomicOr(err, PG_DEVERR_SYNC_TIMEOUT); break; }
+            }
+        }
+    }
+    if (ok) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    return ok;
+}
+DEVI void chunk_publish(uint32_t* flag, uint32_t value) {   // the whole workgroup
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    __syncthreads();
+    if (threadIdx.x == 0) __hip_atomic_store(flag, value, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+}
+DEVI void chunk_wait_buffer(uint32_t* flag, uint32_t want, uint32_t* err) {   // the whole workgroup (nothing is READ behind it: the buffer is only written)
+    if (threadIdx.x == 0 && !(kPersistExp & 2u)) (void)chunk_spin(flag, want, err);
+    __syncthreads();
+}
+
 template <int PHASE, int R, bool TRI>
 DEVI void lean_forward(const DevContig& dc, LeanShared<R>& sh, uint32_t C, uint32_t chunk) {
     constexpr int HP = 64;
@@ -3076,6 +3117,8 @@ DEVI void lean_forward(const DevContig& dc, LeanShared<R>& sh, uint32_t C, uint3
         wr = scr + (size_t)(PG_SCR_BUF(chunk) * 2u) * K * colsz - (size_t)lo * colsz;
         if (chunk > 0) resume = (gcdouble*)(scr + ((size_t)(PG_SCR_BUF(chunk - 1u) * 2u) * K + (K - 1u)) * colsz);
     }
+    // PHASE 4: the whole second half in ONE launch, chunk after chunk into the scratch buffers (`chunk` = k_post_loop's blocks per chain)
+    if constexpr (PHASE == 4) wr = (gdouble*)dc.scratch - (size_t)lo * colsz;
     const size_t toff = (size_t)(i0 >> 1) * HP + lane;  // this thread's first row pair inside a column (in 16-byte units)
     auto emis = [&](const FRec& r, double& eA, double& eB) {  // e(i, j) = row bit ? eB : eA for this lane's column allele
         const bool aj = (r.bits1 >> lane) & 1ull;
@@ -3139,12 +3182,16 @@ DEVI void lean_forward(const DevContig& dc, LeanShared<R>& sh, uint32_t C, uint3
             gcdouble2* src = (gcdouble2*)resume + toff;
 #pragma unroll
             for (int k = 0; k < R; k += 2) { const v2f64 t = src[(size_t)(k >> 1) * HP]; x[k] = t.x; x[k + 1] = t.y; }
+            // (the partial sum exactly as the step forms it — part = fma(e, P', part), row after row — so that a column resumed from
+            //  memory and one carried in registers (PHASE 4) hand the same bits to the next step: the result does not depend on
+            //  where the chunk boundaries fall)
             if (!fallback[lo - 1]) {
 #pragma unroll
-                for (int k = 0; k < R; ++k) x[k] *= sel_by_bit(rb, k, eA, eB);
-            }
+                for (int k = 0; k < R; ++k) { const double e = sel_by_bit(rb, k, eA, eB); part = fma(e, x[k], part); x[k] *= e; }
+            } else {
 #pragma unroll
-            for (int k = 0; k < R; ++k) part += x[k];
+                for (int k = 0; k < R; ++k) part += x[k];
+            }
         }
         sh.psum[(first - 1) & 1u][wave][lane] = part;
     }
@@ -3248,6 +3295,34 @@ DEVI void lean_forward(const DevContig& dc, LeanShared<R>& sh, uint32_t C, uint3
     __builtin_amdgcn_s_waitcnt(0x0F70);
     lds_barrier();
     uint32_t t = first;
+    if constexpr (PHASE == 4) {
+        // chunk q = columns [mid + q K, mid + (q + 1) K) into scratch buffer q % PG_SCRATCH_BUFS; the state stays in registers
+        // (K is even — the host sees to it — so the two record variables are back in their roles at every chunk boundary)
+        const uint32_t post_groups = 2u * (uint32_t)K;   // k_post_loop's work items per chunk: one per column slot
+        gdouble* scr = (gdouble*)dc.scratch;
+        uint32_t q = 0, cend = hi - lo > K ? lo + K : hi;
+        for (;;) {
+            for (; t + 1 < cend; t += 2) {
+                step(t, ra, rb2);
+                step(t + 1, rb2, ra);
+            }
+            if (t < cend) { step(t, ra, rb2); ++t; }   // (the last chunk only)
+            // what a chunk launch of PHASE 3 does when it ends: the scalars still parked, the zero test of the chunk's last column
+            if (wave == 0 && fsc.valid) fsc.flush(fscale, lane, cend - 1);
+            {
+                const double Cj = lean_colsum<R>(sh, (cend - 1) & 1u, lane);
+                if (!(wave_total_mfma(Cj) > 0.0)) flag_uniform(cend - 1);
+            }
+            chunk_publish(dc.sync + 0, q + 1u);
+            if (cend >= hi) break;
+            ++q;
+            lo = cend;
+            cend = hi - lo > K ? lo + K : hi;
+            wr = scr + (size_t)(PG_SCR_BUF(q) * 2u) * K * colsz - (size_t)lo * colsz;
+            if (q >= PG_SCRATCH_BUFS) chunk_wait_buffer(dc.sync + PG_SYNC_DONE + PG_SCR_BUF(q), (q / PG_SCRATCH_BUFS) * post_groups, dc.err);
+        }
+        return;
+    }
     for (; t + 1 < hi; t += 2) {
         step(t, ra, rb2);
         step(t + 1, rb2, ra);
@@ -3296,6 +3371,11 @@ DEVI void lean_backward(const DevContig& dc, LeanShared<R>& sh, uint32_t C, uint
         gdouble* scr = (gdouble*)dc.scratch;
         wr = scr + (size_t)(PG_SCR_BUF(chunk) * 2u + 1u) * (size_t)K * colsz - (size_t)bot * colsz;
         if (chunk > 0) resume = (gcdouble*)(scr + (size_t)(PG_SCR_BUF(chunk - 1u) * 2u + 1u) * (size_t)K * colsz);
+    }
+    int64_t cbot = bot;   // PHASE 4 (see lean_forward): the lowest column of the chunk being stored
+    if constexpr (PHASE == 4) {
+        cbot = top - K + 1 > 0 ? top - K + 1 : 0;
+        wr = (gdouble*)dc.scratch + (size_t)K * colsz - (size_t)cbot * colsz;
     }
     const size_t toff = (size_t)(i0 >> 1) * HP + lane;
     auto emis = [&](const FRec& r, double& eA, double& eB) {
@@ -3358,7 +3438,7 @@ DEVI void lean_backward(const DevContig& dc, LeanShared<R>& sh, uint32_t C, uint
         const uint32_t rb = (uint32_t)__builtin_amdgcn_readfirstlane((int)((uint32_t)(cur.bits1 >> i0) & RMASK));
         double part = 0.0;
 #pragma unroll
-        for (int k = 0; k < R; ++k) { w[k] = y[k] * sel_by_bit(rb, k, eA, eB); part += w[k]; }
+        for (int k = 0; k < R; ++k) { const double e = sel_by_bit(rb, k, eA, eB); part = fma(e, y[k], part); w[k] = y[k] * e; }   // (as the step: see lean_forward)
         sh.psum[(uint32_t)t0 & 1u][wave][lane] = part;
     }
     double ec[R];   // (see lean_forward)
@@ -3462,6 +3542,28 @@ DEVI void lean_backward(const DevContig& dc, LeanShared<R>& sh, uint32_t C, uint
     FRec rb2;
     int64_t t = t0;
     __builtin_amdgcn_s_waitcnt(0x0F70);   // (see lean_forward: no load of the prologue is still in flight inside the loop)
+    if constexpr (PHASE == 4) {
+        const uint32_t post_groups = 2u * (uint32_t)K;   // k_post_loop's work items per chunk: one per column slot
+        gdouble* scr = (gdouble*)dc.scratch;
+        uint32_t q = 0;
+        for (;;) {
+            for (; t - 1 >= cbot; t -= 2) {
+                step(t, cur, rb2);
+                step(t - 1, rb2, cur);
+            }
+            if (t >= cbot) { step(t, cur, rb2); --t; }   // (the last chunk only: K is even)
+            if (wave == 1 && bsc.valid) bsc.flush(bscale, lane, (uint64_t)cbot);
+            if (wave == 2 && bsm.valid) bsm.flush(bsum, lane, (uint64_t)cbot);
+            chunk_publish(dc.sync + 1, q + 1u);
+            if (cbot == 0) break;
+            ++q;
+            const int64_t ntop = cbot - 1;
+            cbot = ntop - K + 1 > 0 ? ntop - K + 1 : 0;
+            wr = scr + (size_t)(PG_SCR_BUF(q) * 2u + 1u) * (size_t)K * colsz - (size_t)cbot * colsz;
+            if (q >= PG_SCRATCH_BUFS) chunk_wait_buffer(dc.sync + PG_SYNC_DONE + PG_SCR_BUF(q), (q / PG_SCRATCH_BUFS) * post_groups, dc.err);
+        }
+        return;
+    }
     for (; t - 1 >= bot; t -= 2) {
         step(t, cur, rb2);
         step(t - 1, rb2, cur);
@@ -5458,6 +5560,102 @@ __global__ __launch_bounds__(256) void k_bins_lean2(const DevContig* __restrict_
 DEVI void post_ab(const DevContig& dc, uint32_t C, uint32_t c, const double* A, const double* B, uint32_t lane,
                   double (&s_bins_row)[PG_AMAX * (PG_AMAX + 1) / 2], double* s_wide = nullptr);
 // one column (index idx inside the chunk: forward role first) by one wave
+// The same column for LEAN chains (64 paths, at most two local alleles, the variant's record read in place — every chain of the
+// whole-genome job).  post_ab spends a column as eight rounds of {issue eight 1 KB loads, wait, add up}: 34–46 us per column
+// and wave, 1.5 TB/s on 192 CUs, and the chunk sweeps beside it wait for its scratch buffers (round 6: k_post bounds phase 2
+// of genome24_h64, not the chains).  Here the loads are double-buffered — the next four row pairs are in flight while the four
+// before them are added up —, the row alleles come from the column's compact record (no load behind the variant id) and
+// everything the bins need at the end (variant id, record, slots, offsets, pair factors) is fetched before the first column
+// load is waited for.  Same products, same order of additions, same bins as post_ab.
+DEVI void post_lean64(const DevContig& dc, uint32_t C, uint32_t c, const double* A, const double* B, uint32_t lane,
+                      double (&s_bins_row)[PG_AMAX * (PG_AMAX + 1) / 2]) {
+    constexpr uint32_t HP = 64;
+    // (the lane number behind an opaque move: a lane's 64 triangle weights and 32 load offsets are the same for every column, and
+    //  the compiler otherwise keeps them across k_post's column loop — hundreds of registers, all spilled)
+    uint32_t ln = lane;
+    asm volatile("" : "+v"(ln));
+    const GAS char* A2 = (const GAS char*)A;   // (uniform: the wave's column)
+    const GAS char* B2 = (const GAS char*)B;
+    v2f64 av[2][4], bv[2][4];
+    // upper triangle only (see post_ab): a lane below the diagonal of row pair ip re-reads its own diagonal unit — in cache, weight 0 —
+    // instead of being masked off (a masked load is a branch of its own to this compiler, with a full wait behind it)
+    const uint32_t ipmax = ln >> 1;
+    auto fetch = [&](auto btc) __attribute__((always_inline)) {
+        constexpr int bt = decltype(btc)::value, buf = bt & 1;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const uint32_t ip = (uint32_t)(4 * bt + u), ipc = ip < ipmax ? ip : ipmax;
+            const uint32_t off = (ipc * HP + ln) * 16u;
+            av[buf][u] = *(gcdouble2*)(A2 + off); bv[buf][u] = *(gcdouble2*)(B2 + off);
+        }
+    };
+    fetch(std::integral_constant<int, 0>{});
+    const unsigned long long bits = (unsigned long long)__double_as_longlong(dc.frec[(size_t)c * 8u + 7u]);   // bit p: path p carries local allele 1
+    const uint32_t cv = dc.col_variant[c];
+    const uint32_t cvn = dc.col_variant[c + 1 < C ? c + 1 : c];
+    const bool fb = dc.fwd_fallback[c] != 0;
+    const double fscl = dc.fscale[c], bscl = dc.bscale[c];
+    fetch(std::integral_constant<int, 1>{});
+    if (lane < PG_AMAX * (PG_AMAX + 1) / 2) s_bins_row[lane] = 0.0;
+    const unsigned char* rec = dc.vrec + (size_t)cv * dc.RB;
+    const uint32_t nl = rec[PG_REC_NLOCAL];
+    const uint16_t* ls = (const uint16_t*)(rec + PG_REC_LOCAL_SLOT);
+    const uint32_t la = nl ? lane / nl : 0u, lb = nl ? lane % nl : 0u;
+    const bool binlane = lane < nl * nl && la <= lb;   // the lane that finishes bin (la, lb)
+    const uint32_t sa = binlane ? ls[la] : 0u, sb = binlane ? ls[lb] : 0u;
+    const uint32_t Av = dc.allele_off[cv + 1] - dc.allele_off[cv];
+    const uint64_t g0 = dc.geno_off[cv];
+    const uint32_t pn = dc.pair_n, NP = (pn * (pn + 1) / 2 + 1u) & ~1u;
+    const unsigned char* vp = dc.vpair + (size_t)cv * (NP * 12u);
+    const uint32_t pi = binlane ? tri_n(la, lb, pn) : 0u;
+    const double pm0 = ((const double*)vp)[pi];
+    const int pe0 = ((const int*)(vp + (size_t)NP * 8u))[pi];
+    const int nexp = *(const int32_t*)(dc.vrec + (size_t)cvn * dc.RB + PG_REC_EXP);
+    __builtin_amdgcn_sched_barrier(0);
+    const uint32_t blo = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)bits), bhi = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(bits >> 32));
+    double acc0 = 0.0, acc1 = 0.0;
+    static_for<0, 8>([&](auto btc) __attribute__((always_inline)) {
+        constexpr int bt = decltype(btc)::value, buf = bt & 1;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const uint32_t ip = (uint32_t)(4 * bt + u);
+            const double w0 = ln > 2u * ip ? 2.0 : (ln == 2u * ip ? 1.0 : 0.0);
+            const double w1 = ln > 2u * ip + 1u ? 2.0 : (ln == 2u * ip + 1u ? 1.0 : 0.0);
+            const double p0 = av[buf][u].x * bv[buf][u].x * w0, p1 = av[buf][u].y * bv[buf][u].y * w1;
+            const uint32_t word = ip < 16u ? blo : bhi;
+            const bool r0 = (word >> ((2u * ip) & 31u)) & 1u, r1 = (word >> ((2u * ip + 1u) & 31u)) & 1u;   // (uniform) row alleles
+            acc0 = fma(p0, r0 ? 0.0 : 1.0, acc0); acc1 = fma(p0, r0 ? 1.0 : 0.0, acc1);
+            acc0 = fma(p1, r1 ? 0.0 : 1.0, acc0); acc1 = fma(p1, r1 ? 1.0 : 0.0, acc1);
+        }
+        asm volatile("" : "+v"(acc0), "+v"(acc1));   // (the sums are formed HERE: left alone, the additions of all eight rounds end up behind the last one, their products spilled)
+        __builtin_amdgcn_sched_barrier(0);   // (the scheduler otherwise hoists all 64 loads to the top: 600 spilled registers)
+        if constexpr (bt + 2 < 8) fetch(std::integral_constant<int, bt + 2>{});   // (into the buffer just added up)
+        __builtin_amdgcn_sched_barrier(0);
+    });
+    wave_sync_lds();   // (the zeros of s_bins_row)
+    const uint32_t b = (uint32_t)((bits >> lane) & 1ull);
+#pragma unroll
+    for (int a = 0; a < 2; ++a) {
+        if ((uint32_t)a < nl) {
+#pragma unroll
+            for (int bb = 0; bb < 2; ++bb) {
+                if ((uint32_t)bb < nl) {
+                    const double tot = wave_sum(b == (uint32_t)bb ? (a ? acc1 : acc0) : 0.0);
+                    if (lane == 0) s_bins_row[tri_local(a < bb ? a : bb, a < bb ? bb : a)] += tot;
+                }
+            }
+        }
+    }
+    wave_sync_lds();
+    if (binlane) {
+        const double scale = 1.0 / ((fb ? 1.0 : fscl) * bscl);
+        int xexp = -((fb ? 0 : PG_BIAS_F) + PG_BIAS_B);
+        if (c + 1 < C) xexp += nexp;
+        const uint64_t gi = g0 + (uint64_t)sa * Av - (uint64_t)sa * (sa - 1) / 2 + (sb - sa);
+        store_bin(dc.lik, dc.lik_exp, gi, s_bins_row[tri_local(la, lb)] * scale, fb ? 0.5 : pm0, fb ? 1 : pe0, xexp);
+    }
+}
+
 DEVI void post_column(const DevContig& dc, uint32_t chunk, uint32_t idx, uint32_t wave, uint32_t lane,
                       double (&s_bins)[PG_POST_WAVES][PG_AMAX * (PG_AMAX + 1) / 2]) {
     const uint32_t C = *dc.n_cols;
@@ -5484,7 +5682,8 @@ DEVI void post_column(const DevContig& dc, uint32_t chunk, uint32_t idx, uint32_
         B = scr + (size_t)K * colsz + (size_t)(idx - K) * colsz;
         A = dc.fwd + (size_t)c * colsz;
     }
-    post_ab(dc, C, c, A, B, lane, s_bins[wave]);
+    if (dc.lean == 1u && dc.tri == 0u && !kPostGeneric) post_lean64(dc, C, c, A, B, lane, s_bins[wave]);
+    else post_ab(dc, C, c, A, B, lane, s_bins[wave]);
 }
 // s_wide (optional): PG_WIDE_LDS_BINS doubles of LDS of this wave's own — the raw bins of a wide column with at most
 // PG_WIDE_LDS_N local alleles are added up there instead of in `lik` (a dependent global read-modify-write per (row allele,
@@ -5662,8 +5861,121 @@ __global__ __launch_bounds__(64 * PG_POST_WAVES) void k_post(const DevContig* __
     // grid-stride over the columns of the chunk: the launcher may cap the number of blocks per chain so that
     // this kernel trickles along next to the chains instead of bursting
     for (uint32_t idx = blockIdx.x * PG_POST_WAVES + wave; idx < 2u * dc.chunk_cols; idx += gridDim.x * PG_POST_WAVES) {
-        post_column(dc, chunk, idx, wave, lane, s_bins);
+        post_column(dc, chunk, (uint32_t)__builtin_amdgcn_readfirstlane((int)idx), wave, lane, s_bins);
         wave_sync_lds();   // (the wave's s_bins row is reused by its next column; its global stores need no wait)
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+//  k_post_loop : k_post for the PERSISTENT chunked phase 2 (see chunk_spin above) — ONE launch; a block walks the chunks of its
+//  chain in order: waits until both roles of k_sweep_lean<4> have published the chunk, forms its share of the posteriors, hands
+//  the scratch buffer back.  Same grid shape and placement LDS as k_post (the blocks sit on the CUs the chains leave idle, for
+//  the whole phase).
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(64 * PG_POST_WAVES) void k_post_loop(const DevContig* __restrict__ contigs) {
+    __shared__ double s_bins[PG_POST_WAVES][PG_AMAX * (PG_AMAX + 1) / 2];
+    const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const uint32_t n = gridDim.y;   // chains of the job (<= 64: pg_shim.cpp)
+    // Work items = columns (2 K slots per chunk, forward role first), handed out in order through the chain's
+    // sync[PG_SYNC_NEXT], one per WAVE and turn: a wave takes what it can do — a block that never gets a CU takes nothing, and
+    // nobody waits for it.  (A column of chunk q + PG_SCRATCH_BUFS is only handed out once every column of chunk q has been
+    // TAKEN, by a running wave; the sweep publishes that chunk when they are all done.)  No block-wide barrier: the waves run on
+    // their own.  A wave starts on the chain of its block; when that chain has handed out its last column the wave moves to
+    // one of the chains that still have columns to come, drawn with the weight of what is left — the chains of a genome end
+    // one after the other, the longest is the job's wall time, and the waves of the ended ones are its reserve.
+    // (Measured dead end, profiles/r06_persist.txt: every wave looking at every chain before every column — three relaxed
+    //  agent-scope loads per chain — 645 ms instead of 129: a line that thousands of waves poll serves ~45 M accesses a second,
+    //  and the sweep's own flag traffic queues behind them.  Hence: no look before the take, polls only while a taken column is
+    //  not yet published, the flags the sweep writes on a line of their own.)
+    const uint32_t twoK = 2u * contigs[0].chunk_cols;
+    uint32_t home = blockIdx.y;
+    if (blockIdx.x == 0 && wave == 0) {
+        // The chain's WATCHER: the one wave that reads the flags the sweep writes; it republishes "chunks with both roles
+        // stored" on a line of its own (sync[PG_SYNC_READY]), and that is what every other wave polls.  (Thousands of waves
+        // polling the sweep's own line made the sweep's publishing store queue behind them: 138 ms instead of 129.)
+        const DevContig& dc = contigs[home];
+        const uint32_t C = (dc.lean == 1u && dc.tri == 0u) ? *dc.n_cols : 0u;
+        if (!C) return;
+        const uint32_t K = dc.chunk_cols, mid = C / 2;
+        const uint32_t nf = (C - mid + K - 1u) / K, nb = (mid + K - 1u) / K, nq = nf > nb ? nf : nb;
+        if (lane != 0) return;
+        uint32_t told = 0;
+        const unsigned long long t0 = wall_clock64();
+        unsigned long long t_last = t0;
+        while (told < nq) {
+            const uint32_t fpub = __hip_atomic_load(dc.sync + 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const uint32_t bpub = __hip_atomic_load(dc.sync + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const uint32_t fe = fpub >= nf ? nq : fpub, be = bpub >= nb ? nq : bpub;
+            const uint32_t ready = fe < be ? fe : be;
+            if (ready > told) {
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+                __hip_atomic_store(dc.sync + PG_SYNC_READY, ready, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+                told = ready;
+                t_last = wall_clock64();
+            } else {
+                if (wall_clock64() - t_last > PG_SYNC_TIMEOUT_TICKS) { atomicOr(dc.err, PG_DEVERR_SYNC_TIMEOUT); return; }
+                if (__hip_atomic_load(dc.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & PG_DEVERR_SYNC_TIMEOUT) return;
+                __builtin_amdgcn_s_sleep(64);
+            }
+        }
+        return;
+    }
+    for (;;) {
+        const DevContig& dc = contigs[home];
+        const uint32_t C = (dc.lean == 1u && dc.tri == 0u) ? *dc.n_cols : 0u;   // (what k_sweep_lean<4, 16, false> takes)
+        if (C) {
+            const uint32_t K = dc.chunk_cols, mid = C / 2;
+            const uint32_t nf = (C - mid + K - 1u) / K, nb = (mid + K - 1u) / K;   // chunks of the forward / backward role
+            const uint32_t nq = nf > nb ? nf : nb;
+            auto take = [&]() -> uint32_t {
+                uint32_t it = 0;
+                if (lane == 0) it = __hip_atomic_fetch_add(dc.sync + PG_SYNC_NEXT, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                return it;   // (lane 0's value; made uniform where it is used)
+            };
+            uint32_t q_ready = 0;   // chunks of this chain the wave knows to be published
+            uint32_t item = take();
+            for (;;) {
+                item = (uint32_t)__builtin_amdgcn_readfirstlane((int)item);
+                const uint32_t q = item / twoK, idx = item % twoK;
+                if (q >= nq) break;
+                const uint32_t nxt = take();   // (the next column's number is on its way while this one is worked on)
+                if (q >= q_ready) {
+                    uint32_t ok = 1u;
+                    if (lane == 0) ok = chunk_spin(dc.sync + PG_SYNC_READY, q + 1u, dc.err) ? 1u : 0u;   // (the watcher's line)
+                    if (!__builtin_amdgcn_readfirstlane((int)ok)) return;   // (PG_DEVERR_SYNC_TIMEOUT is up: pg_job_run fails the job)
+                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+                    q_ready = q + 1u;
+                }
+                if (!(kPersistExp & 1u)) { post_column(dc, q, idx, wave, lane, s_bins); wave_sync_lds(); }
+                // (what the wave read of the buffer has arrived — it was used —: the slot may be overwritten)
+                if (lane == 0) __hip_atomic_fetch_add(dc.sync + PG_SYNC_DONE + PG_SCR_BUF(q), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                item = nxt;
+            }
+        }
+        // the chain has handed out its last column: on to another one (lane c looks at chain c)
+        uint32_t left = 0;
+        if (lane < n) {
+            const DevContig& d = contigs[lane];
+            const uint32_t Cc = (d.lean == 1u && d.tri == 0u) ? *d.n_cols : 0u;
+            if (Cc) {
+                const uint32_t K = d.chunk_cols, mid = Cc / 2;
+                const uint32_t nf = (Cc - mid + K - 1u) / K, nb = (mid + K - 1u) / K;
+                const uint32_t total = (nf > nb ? nf : nb) * twoK;
+                const uint32_t next = __hip_atomic_load(d.sync + PG_SYNC_NEXT, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                left = next < total ? (total - next + 1023u) >> 10 : 0u;   // (in units of 1024 columns: the sum below stays in 32 bits)
+            }
+        }
+        uint32_t incl = left;   // inclusive prefix sum over the lanes
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) { const uint32_t v = (uint32_t)__shfl_up((int)incl, o); if (lane >= (uint32_t)o) incl += v; }
+        const uint32_t total_left = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+        if (total_left == 0u) return;
+        // a draw in [0, total_left) that differs from wave to wave
+        uint32_t r = (blockIdx.y * gridDim.x + blockIdx.x) * PG_POST_WAVES + wave;
+        r = (r * 2654435761u) ^ (home * 40503u);
+        r = (uint32_t)(((unsigned long long)r * total_left) >> 32);
+        const unsigned long long hit = __ballot(left > 0u && r < incl);
+        home = (uint32_t)__builtin_ctzll(hit);   // the first chain whose running sum passes the draw
     }
 }
 
@@ -5917,31 +6229,64 @@ void pgk_launch_sweep_smallx(const DevContig* d_contigs, const uint32_t* d_ids, 
     else if (phase == 2) hipLaunchKernelGGL(k_sweep_small16x<2>, grid, dim3(64), 0, s, d_contigs, d_ids, n_ids, chunk, d_dump);
     else hipLaunchKernelGGL(k_sweep_small16x<3>, grid, dim3(64), 0, s, d_contigs, d_ids, n_ids, chunk, d_dump);
 }
+// Blocks per chain of k_post / k_post_loop: they fill the CUs the chains leave idle and no more.  A block in excess would
+// sit in the queue and take the CU of a chain workgroup the moment a chunk sweep ends — the next chunk's
+// workgroup (which cannot share a CU with it, by LDS size) then waits for it: measured on the 24-contig
+// genome, 8 blocks per chain (= (256 - 48) / 24) 144 ms for phase 2, 6 blocks 164 ms, 10 blocks 173 ms,
+// uncapped 172 ms.  *cus_out (optional): the device's CU count.
+uint32_t pgk_post_blocks(uint32_t n_contigs, uint32_t chunk_cols, uint32_t* cus_out) {
+    static int cus[PG_MAX_DEVICES];
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= PG_MAX_DEVICES) dev = 0;
+    if (cus[dev] == 0) {
+        hipDeviceProp_t prop;
+        cus[dev] = (hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0) ? prop.multiProcessorCount : 256;
+    }
+    if (cus_out) *cus_out = (uint32_t)cus[dev];
+    const int idle = cus[dev] - 2 * (int)n_contigs;
+    const uint32_t cap = idle > (int)n_contigs ? (uint32_t)(idle / (int)n_contigs) : 1u;
+    uint32_t bx = (2u * chunk_cols + PG_POST_WAVES - 1u) / PG_POST_WAVES;
+    if (bx > cap) bx = cap;
+    return bx ? bx : 1u;
+}
 void pgk_launch_post(const DevContig* d_contigs, uint32_t n_contigs, uint32_t chunk_cols, uint32_t chunk, hipStream_t s) {
     static bool attr_done[PG_MAX_DEVICES];
     if (lds_attr_pending(attr_done))
         (void)hipFuncSetAttribute((const void*)k_post, hipFuncAttributeMaxDynamicSharedMemorySize, PG_POST_PLACEMENT_LDS);
-    // Blocks per chain: k_post blocks fill the CUs the chains leave idle and no more.  A block in excess would
-    // sit in the queue and take the CU of a chain workgroup the moment a chunk sweep ends — the next chunk's
-    // workgroup (which cannot share a CU with it, by LDS size) then waits for it: measured on the 24-contig
-    // genome, 8 blocks per chain (= (256 - 48) / 24) 144 ms for phase 2, 6 blocks 164 ms, 10 blocks 173 ms,
-    // uncapped 172 ms.
-    uint32_t cap = 0;
-    if (!cap) {
-        static int cus[PG_MAX_DEVICES];
-        int dev = 0;
-        if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= PG_MAX_DEVICES) dev = 0;
-        if (cus[dev] == 0) {
-            hipDeviceProp_t prop;
-            cus[dev] = (hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0) ? prop.multiProcessorCount : 256;
-        }
-        const int idle = cus[dev] - 2 * (int)n_contigs;
-        cap = idle > (int)n_contigs ? (uint32_t)(idle / (int)n_contigs) : 1u;
-    }
-    uint32_t bx = (2u * chunk_cols + PG_POST_WAVES - 1u) / PG_POST_WAVES;
-    if (bx > cap) bx = cap;
-    dim3 grid(bx, n_contigs);
+    dim3 grid(pgk_post_blocks(n_contigs, chunk_cols, nullptr), n_contigs);
     hipLaunchKernelGGL(k_post, grid, dim3(64 * PG_POST_WAVES), PG_POST_PLACEMENT_LDS, s, d_contigs, chunk);
+}
+// Do kernels on two streams really run side by side?  HIP maps streams onto a handful of hardware queues; two streams that share
+// one run their kernels one after the other, and the persistent phase 2 (whose kernels wait for each other) would stall until its
+// timeouts.  Role 0 (first stream) raises w[0] and waits — at most 20 ms — for w[1], which role 1 (second stream) raises: w[2] = 1
+// if it arrived.  Asked once per (stream, stream2) pair (pg_shim.cpp: streams_concurrent).
+__global__ void k_stream_handshake(uint32_t* w, uint32_t role) {
+    if (threadIdx.x != 0) return;
+    if (role == 1u) { __hip_atomic_store(w + 1, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT); return; }
+    __hip_atomic_store(w + 0, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+    const unsigned long long t0 = wall_clock64();
+    uint32_t ok = 0;
+    for (;;) {
+        if (__hip_atomic_load(w + 1, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT)) { ok = 1; break; }
+        if (wall_clock64() - t0 > 2000000ull) break;   // 20 ms of the 100 MHz clock
+        __builtin_amdgcn_s_sleep(20);
+    }
+    w[2] = ok;
+}
+void pgk_launch_stream_handshake(uint32_t* d_words, hipStream_t s, hipStream_t s2) {
+    hipLaunchKernelGGL(k_stream_handshake, dim3(1), dim3(64), 0, s, d_words, 0u);
+    hipLaunchKernelGGL(k_stream_handshake, dim3(1), dim3(64), 0, s2, d_words, 1u);
+}
+// The persistent chunked phase 2 of all-lean jobs (DevContig::sync): the second half of every half-chain in ONE launch of
+// k_sweep_lean<4> on `s`, every chunk's posteriors in ONE launch of k_post_loop on `s2`.  The caller has checked that both grids
+// fit the device with room to spare (2 n_contigs + n_contigs * post_blocks workgroups, one per CU): k_post_loop waits for the sweep's
+// workgroups, which must all be running; the sweep waits for columns that running k_post_loop waves have taken.
+void pgk_launch_phase2_persistent(const DevContig* d_contigs, uint32_t n_contigs, uint32_t post_blocks, hipStream_t s, hipStream_t s2) {
+    static bool attr_done[PG_MAX_DEVICES];
+    if (lds_attr_pending(attr_done))
+        (void)hipFuncSetAttribute((const void*)k_post_loop, hipFuncAttributeMaxDynamicSharedMemorySize, PG_POST_PLACEMENT_LDS);
+    hipLaunchKernelGGL((k_sweep_lean<4, 16, false>), dim3(n_contigs, 2), dim3(256), 0, s, d_contigs, post_blocks);
+    hipLaunchKernelGGL(k_post_loop, dim3(post_blocks, n_contigs), dim3(64 * PG_POST_WAVES), PG_POST_PLACEMENT_LDS, s2, d_contigs);
 }
 void pgk_launch_emission_single(const DevContig* d_contig, DevTable tab, uint32_t v, double* out_m, int* out_e,
                                 hipStream_t s) {

@@ -42,6 +42,9 @@ void pgk_launch_bins(const DevContig*, uint32_t, uint32_t, uint32_t, uint32_t, h
 void pgk_launch_sweep(const DevContig*, uint32_t, uint32_t, int, hipStream_t);
 void pgk_launch_sweep_chunk(const DevContig*, uint32_t, uint32_t, uint32_t, hipStream_t);
 void pgk_launch_post(const DevContig*, uint32_t, uint32_t, uint32_t, hipStream_t);
+uint32_t pgk_post_blocks(uint32_t, uint32_t, uint32_t*);
+void pgk_launch_phase2_persistent(const DevContig*, uint32_t, uint32_t, hipStream_t, hipStream_t);
+void pgk_launch_stream_handshake(uint32_t*, hipStream_t, hipStream_t);
 void pgk_launch_sweep_small(const DevContig*, const uint32_t*, uint32_t, int, uint32_t, double*, hipStream_t);
 void pgk_launch_sweep_smallx(const DevContig*, const uint32_t*, uint32_t, int, uint32_t, double*, hipStream_t);
 void pgk_launch_emission_single(const DevContig*, DevTable, uint32_t, double*, int*, hipStream_t);
@@ -443,6 +446,14 @@ struct pg_job {
     // chunk on the idle CUs from a second stream.
     bool chunked = false;
     uint32_t chunk_cols = 0, n_chunks = 0;
+    // chunked jobs whose chains are ALL lean chains, few enough that every workgroup of k_sweep_lean<4> and k_post_loop has a CU
+    // of its own: phase 2 is ONE launch of each, chunks handed over through DevContig::sync (PG_KERNELS=nopersist: a launch per chunk)
+    bool persist = false;
+    uint32_t post_blocks = 0;
+    hipStream_t persist_checked = nullptr;   // the stream whose kernels are known to run beside stream2's (streams_concurrent)
+    bool persist_checked_any = false;
+    uint32_t* d_handshake = nullptr;
+    uint32_t persist_runs = 0, persist_fallbacks = 0;
     hipStream_t stream2 = nullptr;
     hipEvent_t ev_sweep[PG_SCRATCH_BUFS], ev_post[PG_SCRATCH_BUFS];
     bool events2 = false;
@@ -699,10 +710,14 @@ int upload_inputs(pg_job* job, const pg_contig_batch* batches, const std::vector
 //                       partials instead of class sums | k_prep for every object
 //   fullcols            fused jobs at HP = 32 store and fetch whole 32 x 32 columns (DevContig::live = HP)
 //   nosmall2            phase 2 of the 16-path chains of fused jobs on the general kernel (k_sweep_small16 for phase 1 only)
+//   persist             chunked jobs whose chains are all lean chains run phase 2 as the persistent pair k_sweep_lean<4> + k_post_loop
+//                       (one launch each, chunks handed over on the device) instead of one launch per chunk (k_sweep_lean<3> + k_post).
+//                       Opt-in: measured at par or behind on the whole-genome job (profiles/r06_persist.txt).  nopersist: the default, spelled out
 //   nosplit             the 16-path chains of fused jobs prepare every variant per sample (k_prep*, k_records, k_bins_lean2 / _x) instead of
 //                       taking the split path (pg_split.h)
 struct KernelChoice {
     bool general = false, generic = false, nolean2 = false, notri = false, nocls4 = false, prepwave = false, fullcols = false, nosmall2 = false, nosplit = false;
+    bool persist = false;
     int leanx = -1, small = -1;   // -1: by the job, 0 / 1: forced
     std::string unknown;          // a token this list does not know
 };
@@ -719,6 +734,7 @@ KernelChoice kernel_choice() {
         else if (tok == "nocls4") k.nocls4 = true; else if (tok == "prepwave") k.prepwave = true;
         else if (tok == "fullcols") k.fullcols = true; else if (tok == "nosmall2") k.nosmall2 = true;
         else if (tok == "nosplit") k.nosplit = true;
+        else if (tok == "persist") k.persist = true; else if (tok == "nopersist") k.persist = false;
         else if (!tok.empty()) k.unknown = tok;   // (a typo would quietly test the default path against itself: job creation fails)
         tok.clear();
     };
@@ -942,7 +958,13 @@ int job_build(int device, uint32_t n_index, const pg_contig_batch* batches, cons
     // take it inside a fused phase 2 — k_sweep_small16x (its column goes to the aux slot, k_bins_wide forms the bins); a
     // chain of any other kernel with such an object still makes the job chunked (k_post is their only wide path)
     wide_candidates = false;
-    for (const IndexHost& x : job->index) if (x.wide_bytes && !(x.smallx && !kc.nosmall2)) wide_candidates = true;
+    for (const IndexHost& x : job->index) {
+        // (a k_sweep_small16x chain left with ONE column that is wide has its bins formed by k_bins_wide_s — the split path; jobs
+        //  that cannot take the split path — run_phasing, 2^32 bins — go chunked as before round 5 instead of failing such a chain
+        //  with PG_DEVERR_WIDE_FUSED at run time.  PG_KERNELS=nosplit keeps the fused job: a cross-check switch.)
+        const bool split_possible = kc.nosplit || (!params->run_phasing && params->run_genotyping && x.n_lik < 0xFFFFFFF0ull);
+        if (x.wide_bytes && !(x.smallx && !kc.nosmall2 && split_possible)) wide_candidates = true;
+    }
 
     // ---- sweep mode ------------------------------------------------------------------------
     {
@@ -984,6 +1006,23 @@ int job_build(int device, uint32_t n_index, const pg_contig_batch* batches, cons
                 if ((he = hipEventCreateWithFlags(&job->ev_post[q], hipEventDisableTiming)) != hipSuccess) return fail(PG_ERR_DEVICE, "hipEventCreate", he);
             }
             job->events2 = true;
+            // the persistent phase 2: every chain a lean chain (or empty), an even chunk (the lean step runs two columns per loop
+            // iteration) unless a chunk is the whole half, and a CU for every workgroup of the two kernels that wait for each other
+            bool all_lean = kc.persist, any_lean = false;
+            for (const ChainSpec& sp : specs) { const IndexHost& x = job->index[sp.index]; if (x.V && !x.lean) all_lean = false; if (x.lean) any_lean = true; }
+            if (all_lean && any_lean && ((job->chunk_cols & 1u) == 0u || job->n_chunks == 1u)) {
+                uint32_t cus = 0;
+                uint32_t pb = pgk_post_blocks((uint32_t)n_chains, job->chunk_cols, &cus);
+                // (the sweep's workgroups MUST all be running — a k_post_loop block that is not merely takes no work —: eight CUs are
+                //  left free beside the two grids, whatever else may hold a CU)
+                const uint32_t margin = 8u;
+                if (n_chains <= 64u && cus > 2u * n_chains + margin) {   // (k_post_loop looks at all chains with one lane each)
+                    const uint32_t room = (cus - 2u * n_chains - margin) / n_chains;
+                    if (pb > room) pb = room;
+                    if (const char* e = getenv("PG_POST_BLOCKS")) { const long v = strtol(e, nullptr, 0); if (v >= 1 && (uint32_t)v < pb) pb = (uint32_t)v; }   // (experiments: fewer)
+                    if (pb >= 1u) { job->persist = true; job->post_blocks = pb; }
+                }
+            }
         }
     }
 
@@ -1000,13 +1039,14 @@ int job_build(int device, uint32_t n_index, const pg_contig_batch* batches, cons
     job->chains.resize(n_chains);
     size_t off = 0;
     auto take = [&](size_t bytes, size_t al = 256) { off = align_up(off, al); size_t o = off; off += (bytes ? bytes : 8); return o; };
-    struct Plan { size_t wcols, aux, frec, scratch, wide, vpair, xbuf, prof, fback, fscale, bscale, bsum, vrec, colrec, fwd, part, cprec,
+    struct Plan { size_t sync, wcols, aux, frec, scratch, wide, vpair, xbuf, prof, fback, fscale, bscale, bsum, vrec, colrec, fwd, part, cprec,
                   vtq, vback, vbest, hap1, hap2; };
     std::vector<Plan> plan(n_chains);
     const size_t o_contigs = take(sizeof(DevContig) * n_chains);
     const size_t o_reps = take(sizeof(DevContig) * n_index);
     const size_t o_small = take(sizeof(uint32_t) * n_chains);   // chain ids of the H = 16 chains (k_sweep_small16)
     const size_t o_dump = take(64 * 8 * 16 + 8 * 16 * 16 * 16);  // scrap column for the stores of its rows that are done
+    const size_t o_handshake = take(64);   // k_stream_handshake's words
     // zeroed-every-run block: n_cols, err, per chain kept / fallback flags / profile counters / allele_present,
     // then the packed lik and lik_exp regions (chain after chain, no gaps: one range each for a gather)
     const size_t zero_lo = align_up(off);
@@ -1019,6 +1059,7 @@ int job_build(int device, uint32_t n_index, const pg_contig_batch* batches, cons
         plan[c].fback = take(x.V);
         plan[c].prof = take(64 * sizeof(unsigned long long));
         plan[c].wcols = take(4);   // (the count of the chain's wide-column list: zeroed with the rest of this block; the list itself below)
+        plan[c].sync = take(job->chunked ? PG_SYNC_WORDS * sizeof(uint32_t) : 0);   // (chunk hand-over words of the persistent phase 2)
         const bool vit = params->run_phasing != 0;
         plan[c].vbest = take(vit ? 4 : 0);
         plan[c].hap1 = take(vit ? (size_t)x.V * 2 : 0);
@@ -1129,7 +1170,11 @@ int job_build(int device, uint32_t n_index, const pg_contig_batch* batches, cons
         p.bsum = take((size_t)x.V * sizeof(double));
         if (x.HP >= 256) job->hp_mask |= 16u;
         else if (force_generic && x.HP >= 64) job->hp_mask |= 32u;
-        else if (!x.split) job->hp_mask |= x.HP == 16 ? 1u : x.HP == 32 ? 2u : x.HP == 64 ? 4u : 8u;   // (split chains never run on the general kernel)
+        // (split chains never run on the general kernel; nor do, in a chunked job — no phase 2 —, the chains whose store-only phases
+        //  have a kernel of their own: the general kernel's launch returned at once for them, fifty empty launches on the
+        //  whole-genome job's phase 2)
+        else if (!x.split && !(job->chunked && (x.lean || x.small || x.smallx || x.leanx)))
+            job->hp_mask |= x.HP == 16 ? 1u : x.HP == 32 ? 2u : x.HP == 64 ? 4u : 8u;
     }
     if (job->hp_mask & 32u) job->hp_mask |= 16u;  // one generic launch covers both
     job->arena_bytes = align_up(off);
@@ -1207,7 +1252,7 @@ int job_build(int device, uint32_t n_index, const pg_contig_batch* batches, cons
         d.fwd = (double*)(A + p.fwd); d.part = (double*)(A + p.part); d.fwd_fallback = A + p.fback; d.prof = (unsigned long long*)(A + p.prof);
         d.fscale = (double*)(A + p.fscale); d.bscale = (double*)(A + p.bscale); d.bsum = (double*)(A + p.bsum); d.err = job->d_err + c;
         d.lik = job->d_lik + ch.lik_first; d.lik_exp = job->d_likexp + ch.lik_first;
-        d.scratch = (double*)(A + p.scratch); d.chunk_cols = job->chunk_cols;
+        d.scratch = (double*)(A + p.scratch); d.chunk_cols = job->chunk_cols; d.sync = (uint32_t*)(A + p.sync);
         d.wide = A + p.wide; d.wide_idx = x.wide_bytes ? (const uint32_t*)(A + x.o_widx) : nullptr;
         d.vpair = A + p.vpair; d.xbuf = (double*)(A + p.xbuf);
         d.frec = (double*)(A + p.frec); d.lean = x.lean ? 1u : 0u; d.small = x.small ? ((!job->chunked && x.cls4 && !kc.nosmall2) ? 2u : 1u) : 0u; d.leanx = x.leanx ? 1u : 0u; d.cls4 = x.cls4 ? 1u : 0u;
@@ -1280,6 +1325,7 @@ int job_build(int device, uint32_t n_index, const pg_contig_batch* batches, cons
         job->d_small = (uint32_t*)(A + o_small);
         job->d_smallx = job->d_small + job->n_small;
         job->d_dump = (double*)(A + o_dump);
+        job->d_handshake = (uint32_t*)(A + o_handshake);
         small_ids.insert(small_ids.end(), x_ids.begin(), x_ids.end());
         if (!small_ids.empty() && (he = hipMemcpyAsync(job->d_small, small_ids.data(), sizeof(uint32_t) * small_ids.size(), hipMemcpyHostToDevice, job->stream)) != hipSuccess)
             return fail(PG_ERR_DEVICE, "hipMemcpy small ids", he);
@@ -1306,7 +1352,10 @@ int job_build(int device, uint32_t n_index, const pg_contig_batch* batches, cons
                 prep += " + k_records";
                 p1 = d.lean ? (d.tri ? "k_sweep_lean_tri<1>" : "k_sweep_lean<1>") : d.leanx == 2u ? "k_sweep_leanx_tri" : d.leanx ? "k_sweep_leanx<1>"
                      : d.small ? "k_sweep_small16<1>" : d.smallx ? "k_sweep_small16x<1>" : (d.tri ? "k_sweep_tri1" : std::string(gen) + "<1>");
-                if (job->chunked) {
+                if (job->chunked && job->persist) {
+                    p2 = "k_sweep_lean<4> (one launch, all chunks) + k_post_loop";
+                    bins = "(k_post_loop)";
+                } else if (job->chunked) {
                     p2 = d.lean ? "k_sweep_lean<3>" : d.leanx ? "k_sweep_leanx<3>" : d.small ? "k_sweep_small16<3>" : d.smallx ? "k_sweep_small16x<3>" : std::string(gen) + "<3>";
                     p2 += " chunks + k_post";
                     bins = "(k_post)";
@@ -1569,6 +1618,30 @@ int viterbi_transitions(pg_job* job, hipStream_t s, char* err, size_t errlen) {
 }
 }  // namespace
 
+namespace {
+// The persistent phase 2 needs the kernels of `s` and of the job's second stream to run SIDE BY SIDE (they wait for each other).
+// Streams are mapped onto a few hardware queues, and two streams on one queue run one after the other: ask the device once per
+// stream (k_stream_handshake); a second stream that shares the queue is replaced by a new one, a few times.  False: this run
+// takes a launch per chunk.
+bool streams_concurrent(pg_job* job, hipStream_t s) {
+    if (job->persist_checked_any && job->persist_checked == s) return true;
+    for (int attempt = 0; attempt < 6; ++attempt) {
+        uint32_t w[4] = {0, 0, 0, 0};
+        if (hipMemcpyAsync(job->d_handshake, w, sizeof(w), hipMemcpyHostToDevice, s) != hipSuccess || hipStreamSynchronize(s) != hipSuccess) break;
+        pgk_launch_stream_handshake(job->d_handshake, s, job->stream2);
+        if (hipGetLastError() != hipSuccess || hipStreamSynchronize(s) != hipSuccess || hipStreamSynchronize(job->stream2) != hipSuccess) break;
+        if (hipMemcpy(w, job->d_handshake, sizeof(w), hipMemcpyDeviceToHost) != hipSuccess) break;
+        if (w[2] == 1u) { job->persist_checked = s; job->persist_checked_any = true; return true; }
+        hipStream_t fresh = nullptr;   // (created BEFORE the old one is destroyed: the runtime hands a new stream the least used queue)
+        if (hipStreamCreateWithFlags(&fresh, hipStreamNonBlocking) != hipSuccess) break;
+        (void)hipStreamDestroy(job->stream2);
+        job->stream2 = fresh;
+    }
+    (void)hipGetLastError();
+    return false;
+}
+}  // namespace
+
 extern "C" int pg_job_run(pg_job* job, void* stream_, char* err, size_t errlen) {
     if (!job) { set_err(err, errlen, "null job"); return PG_ERR_INVALID; }
     const double t_run = now_s();
@@ -1576,6 +1649,8 @@ extern "C" int pg_job_run(pg_job* job, void* stream_, char* err, size_t errlen) 
     hipStream_t s = stream_ ? (hipStream_t)stream_ : job->stream;
     const uint32_t n = (uint32_t)job->chains.size();
     job->host_s[3] = 0.0;
+    const bool persist_now = job->persist && job->max_v > 0 && job->params.run_genotyping && streams_concurrent(job, s);   // (may replace stream2)
+    if (job->persist && job->max_v > 0 && job->params.run_genotyping) { if (persist_now) job->persist_runs += 1; else job->persist_fallbacks += 1; }
     HIP_TRY(hipMemsetAsync(job->zero_base, 0, job->zero_bytes, s));
     if (job->max_v > 0 && job->params.run_genotyping) {
         HIP_TRY(hipEventRecord(job->ev[0], s));
@@ -1606,6 +1681,15 @@ extern "C" int pg_job_run(pg_job* job, void* stream_, char* err, size_t errlen) 
             // chunk i: store-only sweep on s -> ev_sweep -> k_post on stream2 -> ev_post; the sweep of chunk
             // i + PG_SCRATCH_BUFS reuses scratch buffer i % PG_SCRATCH_BUFS and therefore waits for the posteriors of chunk i
             hipStream_t s2 = job->stream2;
+            if (persist_now) {
+                // one launch each: the chunks are handed over on the device (DevContig::sync, zeroed above); k_post_loop must not
+                // start (and wait) before phase 1 has ended
+                HIP_TRY(hipStreamWaitEvent(s2, job->ev[4], 0));
+                pgk_launch_phase2_persistent(job->d_contigs, n, job->post_blocks, s, s2);
+                HIP_TRY(hipGetLastError());
+                HIP_TRY(hipEventRecord(job->ev_post[0], s2));
+                HIP_TRY(hipStreamWaitEvent(s, job->ev_post[0], 0));
+            } else
             for (uint32_t i = 0; i < job->n_chunks; ++i) {
                 const int b = (int)PG_SCR_BUF(i);
                 if (i >= PG_SCRATCH_BUFS) HIP_TRY(hipStreamWaitEvent(s, job->ev_post[b], 0));
@@ -1619,7 +1703,7 @@ extern "C" int pg_job_run(pg_job* job, void* stream_, char* err, size_t errlen) 
                 HIP_TRY(hipGetLastError());
                 HIP_TRY(hipEventRecord(job->ev_post[b], s2));
             }
-            for (uint32_t q = 0; q < PG_SCRATCH_BUFS && q < job->n_chunks; ++q) HIP_TRY(hipStreamWaitEvent(s, job->ev_post[q], 0));
+            if (!persist_now) for (uint32_t q = 0; q < PG_SCRATCH_BUFS && q < job->n_chunks; ++q) HIP_TRY(hipStreamWaitEvent(s, job->ev_post[q], 0));
             HIP_TRY(hipEventRecord(job->ev[5], s));  // "k_sweep_phase2" = all chunks incl. their posteriors
             HIP_TRY(hipEventRecord(job->ev[6], s));  // (no k_bins in this mode)
         }
@@ -1676,6 +1760,10 @@ extern "C" int pg_job_run(pg_job* job, void* stream_, char* err, size_t errlen) 
         if (errs[i] & PG_DEVERR_TOO_MANY_ALLELES) {
             set_err(err, errlen, "chain %u: a variant has more than %d alleles (device limit)", i, PG_MAX_ALLELES_PER_VARIANT);
             return PG_ERR_UNSUPPORTED;
+        }
+        if (errs[i] & PG_DEVERR_SYNC_TIMEOUT) {
+            set_err(err, errlen, "chain %u: the persistent phase-2 kernels lost each other (a chunk flag did not arrive within 10 s); without PG_KERNELS=persist phase 2 takes a launch per chunk", i);
+            return PG_ERR_DEVICE;
         }
         if (errs[i] & PG_DEVERR_WIDE_FUSED) {
             set_err(err, errlen, "chain %u: its only column carries more than %d alleles on the selected paths, which a fused job cannot genotype (PG_SWEEP_MODE=chunked)", i, PG_AMAX);
@@ -1848,7 +1936,12 @@ extern "C" double pg_job_viterbi_ms(const pg_job* job) { return job ? job->vit_m
 extern "C" double pg_job_index_ms(const pg_job* job) { return job ? job->index_ms : 0.0; }
 extern "C" size_t pg_job_plan(const pg_job* job, char* out, size_t len) {
     if (!job) return 0;
-    const std::string& t = job->plan_text;
+    std::string t = job->plan_text;
+    if (job->persist) {   // (what the runs so far really did: a run whose streams share a hardware queue takes a launch per chunk)
+        char line[160];
+        snprintf(line, sizeof(line), "  persistent phase 2: %u run(s), %u more fell back to a launch per chunk\n", job->persist_runs, job->persist_fallbacks);
+        t += line;
+    }
     if (out && len) { const size_t n = t.size() < len - 1 ? t.size() : len - 1; memcpy(out, t.data(), n); out[n] = 0; }
     return t.size() + 1;
 }

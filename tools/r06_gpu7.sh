@@ -1,0 +1,16 @@
+set -x
+timeout 900 python -m pytest tests/test_persist_gpu.py -x -q 2>&1 | tail -15 > gpurun_out/r06_tests7.txt
+cat gpurun_out/r06_tests7.txt
+timeout 900 python -m pytest tests/test_parity_gpu.py -x -q -k "lean or chunk or config3 or full_size" 2>&1 | tail -8 >> gpurun_out/r06_tests7.txt
+tail -8 gpurun_out/r06_tests7.txt
+run() { timeout 600 python bench.py --steps 5 --warmup 2 --no-cohort --no-sampler --no-viterbi --no-dropin --no-cpu-baseline 2>gpurun_out/r06_p7_$1.err | python -c "
+import json,sys
+d=json.loads(sys.stdin.read().strip().splitlines()[-1])
+print('$1', '%.2f M/s'%(d['value']/1e6), 'ms/step %.2f'%d['ms_per_step'], {a:round(b,2) for a,b in d['kernel_ms'].items()}, d.get('device_bytes'))
+" >> gpurun_out/r06_persist7.txt; }
+rm -f gpurun_out/r06_persist7.txt
+run persist_4096
+PG_CHUNK_COLS=1024 run persist_1024
+PG_CHUNK_COLS=512 run persist_512
+PG_KERNELS=nopersist run nopersist_4096
+cat gpurun_out/r06_persist7.txt
