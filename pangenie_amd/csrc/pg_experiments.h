@@ -44,6 +44,16 @@ static constexpr bool kPostGeneric = false;
 #endif
 static constexpr unsigned kPersistExp = PG_PERSIST_EXP;
 
+// -DPG_LEAN_PRETOTAL=1 (round 6's structural attempt on the lean step, measured and NOT adopted — profiles/r06_lean_chain.txt): every
+// wave adds up its own partial sums IN FRONT of the barrier (six DPP levels) and the column's total S is three additions of four
+// broadcast LDS reads behind it, instead of two dependent fp64 MFMAs behind the exchange.  Correct (the lean suites pass), slower:
+// phase 1 of genome24_h64 125.8 ms against 121.5 — the MFMAs' latency was already covered by the work pinned into their shadows,
+// the eighteen DPP instructions in front of the barrier are not covered by anything.
+#ifndef PG_LEAN_PRETOTAL
+#define PG_LEAN_PRETOTAL 0
+#endif
+static constexpr bool kLeanPreTotal = PG_LEAN_PRETOTAL != 0;
+
 // lean-x step (k_sweep_leanx): 1 no column stores, 2 no emission fetches
 #ifndef PG_LX_EXP
 #define PG_LX_EXP 0

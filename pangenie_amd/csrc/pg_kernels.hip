@@ -2848,6 +2848,7 @@ template <int R>
 struct LeanShared {
     static constexpr int NW = 64 / R;  // waves = row groups
     double psum[2][NW][64];
+    double ptot[2][NW] __attribute__((aligned(32)));   // the waves' totals of their partial sums (kLeanPreTotal: lean_put_sums)
     double u[NW][64] __attribute__((aligned(16)));
     double rec[2][PG_LEAN_BLOCK][8] __attribute__((aligned(16)));  // two blocks of compact records
     double scal[2][64];   // per-column scalars on their way out (ColScalars)
@@ -3082,6 +3083,31 @@ DEVI void chunk_wait_buffer(uint32_t* flag, uint32_t want, uint32_t* err) {   //
     __syncthreads();
 }
 
+// A wave parks its 64 partial column sums — and (kLeanPreTotal, round 6) their TOTAL over the wave, formed in front of the step's
+// barrier by six DPP levels (the sum ends in lane 63, which stores it): behind the barrier the column's total S is then three
+// additions of four broadcast LDS reads, next to the column sums — instead of two dependent fp64 MFMAs behind them
+// (profiles/r06_lean_chain.txt: the exchange -> column sums -> MFMA -> MFMA -> exponent chain was 756 of a column's 1384 cycles).
+template <int R>
+DEVI void lean_put_sums(LeanShared<R>& sh, uint32_t pb, uint32_t wave, uint32_t lane, double part) {
+    sh.psum[pb][wave][lane] = part;
+    if constexpr (kLeanPreTotal) {
+        double v = part;
+        v += dpp_f64<0x111, 0xF, true>(v);   // row_shr:1
+        v += dpp_f64<0x112, 0xF, true>(v);   // row_shr:2
+        v += dpp_f64<0x114, 0xF, true>(v);   // row_shr:4
+        v += dpp_f64<0x118, 0xF, true>(v);   // row_shr:8
+        v += dpp_f64<0x142, 0xA, false>(v);  // row_bcast:15 -> rows 1,3
+        v += dpp_f64<0x143, 0xC, false>(v);  // row_bcast:31 -> rows 2,3
+        if (lane == 63u) sh.ptot[pb][wave] = v;
+    }
+}
+template <int R>
+DEVI double lean_total(const LeanShared<R>& sh, uint32_t pb) {   // (kLeanPreTotal) the column's total: every lane reads the waves' totals
+    static_assert(R == 16, "four waves");
+    const v2f64 a = *(const v2f64*)&sh.ptot[pb][0], b = *(const v2f64*)&sh.ptot[pb][2];
+    return (a.x + a.y) + (b.x + b.y);
+}
+
 template <int PHASE, int R, bool TRI>
 DEVI void lean_forward(const DevContig& dc, LeanShared<R>& sh, uint32_t C, uint32_t chunk) {
     constexpr int HP = 64;
@@ -3193,7 +3219,7 @@ DEVI void lean_forward(const DevContig& dc, LeanShared<R>& sh, uint32_t C, uint3
                 for (int k = 0; k < R; ++k) part += x[k];
             }
         }
-        sh.psum[(first - 1) & 1u][wave][lane] = part;
+        lean_put_sums<R>(sh, (first - 1) & 1u, wave, lane, part);
     }
     // Emissions of a column are fetched by row pairs (lean_pairs) DURING the previous step: a pair's next emissions are
     // read right after its two states used the current ones, so the LDS reads ride under the following pairs' arithmetic.
@@ -3228,10 +3254,11 @@ DEVI void lean_forward(const DevContig& dc, LeanShared<R>& sh, uint32_t C, uint3
         double pc[64 / R], pr[64 / R];
 #pragma unroll
         for (int q = 0; q < 64 / R; ++q) { pc[q] = sh.psum[pb][q][lane]; pr[q] = sh.psum[pb][q][i0 + (lane & 15u)]; }
+        const double Spre = kLeanPreTotal ? lean_total<R>(sh, pb) : 0.0;   // (issued with the other LDS reads)
         const double Cj = (pc[0] + pc[1]) + (pc[2] + pc[3]);
         tl.template mark<1>(Cj);                      // the column sums are back from LDS
         const v4f64 zz = {0.0, 0.0, 0.0, 0.0};
-        const v4f64 ma = kLeanDppSum ? zz : __builtin_amdgcn_mfma_f64_16x16x4f64(Cj, 1.0, zz, 0, 0, 0);
+        const v4f64 ma = (kLeanDppSum || kLeanPreTotal) ? zz : __builtin_amdgcn_mfma_f64_16x16x4f64(Cj, 1.0, zz, 0, 0, 0);
         lean_fence();
         const double ucol = cur.c1 * Cj;
         const double urep = dpp_source(cur.c1 * ((pr[0] + pr[1]) + (pr[2] + pr[3])));
@@ -3239,10 +3266,10 @@ DEVI void lean_forward(const DevContig& dc, LeanShared<R>& sh, uint32_t C, uint3
         const double msum = (ma[0] + ma[1]) + (ma[2] + ma[3]);
         tl.template mark<2>(msum);                    // first MFMA + three adds
         lean_fence();
-        const v4f64 mb = kLeanDppSum ? zz : __builtin_amdgcn_mfma_f64_16x16x4f64(msum, 1.0, zz, 0, 0, 0);
-        asm volatile("" :: "v"(mb));   // (the whole result stays allocated: a temporary in one of its registers would wait out the MFMA)
+        const v4f64 mb = (kLeanDppSum || kLeanPreTotal) ? zz : __builtin_amdgcn_mfma_f64_16x16x4f64(msum, 1.0, zz, 0, 0, 0);
+        if constexpr (!kLeanPreTotal) asm volatile("" :: "v"(mb));   // (the whole result stays allocated: a temporary in one of its registers would wait out the MFMA)
         lean_fence();
-        double S = (kLeanExp & 4) ? 64.0 * Cj : (kLeanDppSum ? wave_sum(Cj) : mb[0]);
+        double S = (kLeanExp & 4) ? 64.0 * Cj : (kLeanPreTotal ? Spre : (kLeanDppSum ? wave_sum(Cj) : mb[0]));
         tl.template mark<3>(S);                       // second MFMA: the total
         double uj = fma(cur.c2, S, ucol);
         double c0 = cur.c0;
@@ -3279,7 +3306,7 @@ DEVI void lean_forward(const DevContig& dc, LeanShared<R>& sh, uint32_t C, uint3
             } else pprev = pk;
         });
         tl.template mark<6>(part);                    // the other seven row pairs: states, stores, next emissions
-        sh.psum[t & 1u][wave][lane] = part;
+        lean_put_sums<R>(sh, t & 1u, wave, lane, part);
         if (wave == 0) {  // (scalar branch)
             fsc.put(lane, t, m);
             if ((t & 63u) == 63u) fsc.flush(fscale, lane, t);
@@ -3439,7 +3466,7 @@ DEVI void lean_backward(const DevContig& dc, LeanShared<R>& sh, uint32_t C, uint
         double part = 0.0;
 #pragma unroll
         for (int k = 0; k < R; ++k) { const double e = sel_by_bit(rb, k, eA, eB); part = fma(e, y[k], part); w[k] = y[k] * e; }   // (as the step: see lean_forward)
-        sh.psum[(uint32_t)t0 & 1u][wave][lane] = part;
+        lean_put_sums<R>(sh, (uint32_t)t0 & 1u, wave, lane, part);
     }
     double ec[R];   // (see lean_forward)
     {
@@ -3476,6 +3503,7 @@ DEVI void lean_backward(const DevContig& dc, LeanShared<R>& sh, uint32_t C, uint
         double pc[64 / R], pr[64 / R];  // (see lean_forward)
 #pragma unroll
         for (int q = 0; q < 64 / R; ++q) { pc[q] = sh.psum[pb][q][lane]; pr[q] = sh.psum[pb][q][i0 + (lane & 15u)]; }
+        const double Spre = kLeanPreTotal ? lean_total<R>(sh, pb) : 0.0;
         // the records of the next step are read HERE, behind the barrier and behind the column sums (in front of the barrier
         // the wave would wait out their LDS latency: the barrier's release waits for every outstanding LDS operation)
         lean_fence();
@@ -3486,7 +3514,7 @@ DEVI void lean_backward(const DevContig& dc, LeanShared<R>& sh, uint32_t C, uint
         const double Cj = (pc[0] + pc[1]) + (pc[2] + pc[3]);
         tl.template mark<3>(Cj);                      // the column sums are back from LDS (the next records read behind them)
         const v4f64 zz = {0.0, 0.0, 0.0, 0.0};
-        const v4f64 ma = kLeanDppSum ? zz : __builtin_amdgcn_mfma_f64_16x16x4f64(Cj, 1.0, zz, 0, 0, 0);
+        const v4f64 ma = (kLeanDppSum || kLeanPreTotal) ? zz : __builtin_amdgcn_mfma_f64_16x16x4f64(Cj, 1.0, zz, 0, 0, 0);
         lean_fence();
         const double ucol = k1 * Cj;
         const double urep = dpp_source(k1 * ((pr[0] + pr[1]) + (pr[2] + pr[3])));  // u_i of row i0 + (lane & 15)
@@ -3494,10 +3522,10 @@ DEVI void lean_backward(const DevContig& dc, LeanShared<R>& sh, uint32_t C, uint
         const double msum = (ma[0] + ma[1]) + (ma[2] + ma[3]);
         tl.template mark<4>(msum);                    // first MFMA + three adds
         lean_fence();
-        const v4f64 mb = kLeanDppSum ? zz : __builtin_amdgcn_mfma_f64_16x16x4f64(msum, 1.0, zz, 0, 0, 0);
-        asm volatile("" :: "v"(mb));
+        const v4f64 mb = (kLeanDppSum || kLeanPreTotal) ? zz : __builtin_amdgcn_mfma_f64_16x16x4f64(msum, 1.0, zz, 0, 0, 0);
+        if constexpr (!kLeanPreTotal) asm volatile("" :: "v"(mb));
         lean_fence();
-        const double Sw = (kLeanExp & 4) ? 64.0 * Cj : (kLeanDppSum ? wave_sum(Cj) : mb[0]);
+        const double Sw = (kLeanExp & 4) ? 64.0 * Cj : (kLeanPreTotal ? Spre : (kLeanDppSum ? wave_sum(Cj) : mb[0]));
         tl.template mark<5>(Sw);                      // second MFMA: the total
         const double uj = fma(k2, Sw, ucol);
         const double Snew = kap * Sw;  // = sum(beta'_t)
@@ -3530,7 +3558,7 @@ DEVI void lean_backward(const DevContig& dc, LeanShared<R>& sh, uint32_t C, uint
             Sy = 1.0;
         }
         tl.template mark<7>(part);                    // the other seven row pairs: states, stores, next emissions
-        sh.psum[(uint32_t)(t - 1) & 1u][wave][lane] = part;
+        lean_put_sums<R>(sh, (uint32_t)(t - 1) & 1u, wave, lane, part);
         if (wave == 2) { asm volatile("" ::: "memory"); bsm.put(lane, (uint64_t)t, Snew); }   // (a branch, not predication: three of the four waves skip it)
         if (((uint64_t)t & 63u) == 0u) {
             if (wave == 1) bsc.flush(bscale, lane, (uint64_t)t);
