@@ -949,9 +949,20 @@ int job_build(int device, uint32_t n_index, const pg_contig_batch* batches, cons
     {
         // k_sweep_small16 packs four H = 16 half-chains into a wave: a throughput kernel.  A single chain is faster on the
         // general kernel (four states per lane instead of sixteen: 375 vs 470 ns per column); PG_KERNELS=small / nosmall forces.
-        size_t n_small_chains = 0;
-        for (const ChainSpec& sp : specs) n_small_chains += (job->index[sp.index].small || job->index[sp.index].smallx) ? 1 : 0;
-        const bool use = kc.small >= 0 ? kc.small == 1 : n_small_chains >= 512;
+        // Where the whole STEP crosses over (round 6, tools/exp_small_crossover.py, profiles/r06_small_crossover.txt: 8 contigs x
+        // 8000 variants per sample, fused; with the small kernels comes the split path, 0.6 against 2.5 ms of per-variant work at
+        // 512 chains) — step ms, small kernels / general kernel:
+        //   chains        64           128          256          512           1024
+        //   biallelic     5.99 / 5.39  6.13 / 5.82  6.33 / 7.35  6.98 / 9.28   9.16 / 14.01
+        //   a fifth 3-5   8.15 / 5.32  8.39 / 6.15  8.71 / 8.33  9.30 / 12.01  11.81 / 19.48
+        // -> from 256 chains on when every such chain is biallelic, from 320 when some have multiallelic objects (512 for both
+        //    until round 6: a 256-chain biallelic cohort ran 14 % below what it could).
+        size_t n_small_chains = 0, n_x_chains = 0;
+        for (const ChainSpec& sp : specs) {
+            n_small_chains += (job->index[sp.index].small || job->index[sp.index].smallx) ? 1 : 0;
+            n_x_chains += job->index[sp.index].smallx ? 1 : 0;
+        }
+        const bool use = kc.small >= 0 ? kc.small == 1 : n_small_chains >= (n_x_chains ? 320u : 256u);
         if (!use) for (auto& x : job->index) { x.small = false; x.smallx = false; x.aux_bytes = 0; }
     }
     // A WIDE column (more than PG_AMAX alleles on the selected paths) costs that column, not the job, on the kernels that
