@@ -54,6 +54,19 @@ static constexpr unsigned kPersistExp = PG_PERSIST_EXP;
 #endif
 static constexpr bool kLeanPreTotal = PG_LEAN_PRETOTAL != 0;
 
+// -DPG_NT_STORES: the lean sweeps' column stores as non-temporal stores; -DPG_NT_POST: k_post's column loads (post_lean64) as
+// non-temporal loads (round 6 A/B builds)
+#ifdef PG_NT_STORES
+static constexpr bool kNtStores = true;
+#else
+static constexpr bool kNtStores = false;
+#endif
+#ifdef PG_NT_POST
+static constexpr bool kNtPost = true;
+#else
+static constexpr bool kNtPost = false;
+#endif
+
 // lean-x step (k_sweep_leanx): 1 no column stores, 2 no emission fetches
 #ifndef PG_LX_EXP
 #define PG_LX_EXP 0

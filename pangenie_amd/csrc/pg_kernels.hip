@@ -3087,6 +3087,11 @@ DEVI void chunk_wait_buffer(uint32_t* flag, uint32_t want, uint32_t* err) {   //
 // barrier by six DPP levels (the sum ends in lane 63, which stores it): behind the barrier the column's total S is then three
 // additions of four broadcast LDS reads, next to the column sums — instead of two dependent fp64 MFMAs behind them
 // (profiles/r06_lean_chain.txt: the exchange -> column sums -> MFMA -> MFMA -> exponent chain was 756 of a column's 1384 cycles).
+// a column store of the lean sweeps (-DPG_NT_STORES: as a non-temporal store — the columns are streamed out and never read by this kernel)
+DEVI void lean_store(gdouble2* p, v2f64 v) {
+    if constexpr (kNtStores) __builtin_nontemporal_store(v, p);
+    else *p = v;
+}
 template <int R>
 DEVI void lean_put_sums(LeanShared<R>& sh, uint32_t pb, uint32_t wave, uint32_t lane, double part) {
     sh.psum[pb][wave][lane] = part;
@@ -3169,9 +3174,9 @@ DEVI void lean_forward(const DevContig& dc, LeanShared<R>& sh, uint32_t C, uint3
     }
     auto put_pair = [&](gdouble2* dst, int q, double a, double b) __attribute__((always_inline)) {
         if constexpr (TRI) {
-            if (!((tskip >> q) & 1u)) (dst - toff)[tunit[q]] = v2f64{a * tfa[q], b * tfb[q]};
+            if (!((tskip >> q) & 1u)) lean_store((dst - toff) + tunit[q], v2f64{a * tfa[q], b * tfb[q]});
         } else {
-            dst[(size_t)q * HP] = v2f64{a, b};
+            lean_store(dst + (size_t)q * HP, v2f64{a, b});
         }
     };
     auto store_col = [&](uint32_t c, const double (&v)[R]) {
@@ -3425,9 +3430,9 @@ DEVI void lean_backward(const DevContig& dc, LeanShared<R>& sh, uint32_t C, uint
     }
     auto put_pair = [&](gdouble2* dst, int q, double a, double b) __attribute__((always_inline)) {
         if constexpr (TRI) {
-            if (!((tskip >> q) & 1u)) (dst - toff)[tunit[q]] = v2f64{a * tfa[q], b * tfb[q]};
+            if (!((tskip >> q) & 1u)) lean_store((dst - toff) + tunit[q], v2f64{a * tfa[q], b * tfb[q]});
         } else {
-            dst[(size_t)q * HP] = v2f64{a, b};
+            lean_store(dst + (size_t)q * HP, v2f64{a, b});
         }
     };
     auto store_col = [&](int64_t c, const double (&v)[R]) {
@@ -5614,7 +5619,8 @@ DEVI void post_lean64(const DevContig& dc, uint32_t C, uint32_t c, const double*
         for (int u = 0; u < 4; ++u) {
             const uint32_t ip = (uint32_t)(4 * bt + u), ipc = ip < ipmax ? ip : ipmax;
             const uint32_t off = (ipc * HP + ln) * 16u;
-            av[buf][u] = *(gcdouble2*)(A2 + off); bv[buf][u] = *(gcdouble2*)(B2 + off);
+            if constexpr (kNtPost) { av[buf][u] = __builtin_nontemporal_load((gcdouble2*)(A2 + off)); bv[buf][u] = __builtin_nontemporal_load((gcdouble2*)(B2 + off)); }
+            else { av[buf][u] = *(gcdouble2*)(A2 + off); bv[buf][u] = *(gcdouble2*)(B2 + off); }
         }
     };
     fetch(std::integral_constant<int, 0>{});

@@ -156,3 +156,31 @@ def test_small16x_cohort_rows_of_a_wave_share_their_contig(mode, orc, monkeypatc
             b = ix.with_counts(samples[s][0][i], samples[s][1][i])
             ref = orc.genotype_contig(b, orc.OracleTable(*args), orc.make_params(1.26, False, 1e-5))
             assert_parity(b, got[s * 3 + i], ref)
+
+
+def test_default_kernel_choice_by_chain_count(orc, monkeypatch):
+    """No PG_KERNELS override: the planner's own choice (pg_shim.cpp: the small kernels — and with them the split path — from 256
+    sixteen-path chains on, from 320 when some have multiallelic objects; the general kernel below; measured crossover,
+    profiles/r06_small_crossover.txt).  Both sides of each threshold are built, the plans say which kernels they got, and a few
+    chains of each job are held to the oracle."""
+    monkeypatch.delenv("PG_KERNELS", raising=False)
+    monkeypatch.delenv("PG_SWEEP_MODE", raising=False)
+    args = default_table_args()
+    t, p = hmm.ProbabilityTable(*args), hmm.make_params(1.26, False, 1e-5)
+    for multi, below, above, kernel in ((0.0, 31, 32, "k_sweep_small16<2>"), (0.25, 39, 40, "k_sweep_small16x<2>")):
+        index = [synthetic_panel(v, 16, 20, seed=1500 + i, multiallelic_frac=multi) for i, v in enumerate((70, 41, 96, 33, 64, 57, 80, 49))]   # (no wide objects: below the threshold they would make the job chunked)
+        for S in (below, above):   # 8 S chains
+            samples = []
+            for s in range(S):
+                kcs, covs = zip(*[synthetic_sample_counts(ix, seed=7000 + 10 * (s % 5) + i) for i, ix in enumerate(index)])
+                samples.append((list(kcs), list(covs)))
+            job = hmm.Job.cohort(index, samples, t, p)
+            plan = job.plan()
+            assert job.sweep_mode()[0] == "fused", plan
+            assert (kernel in plan) == (S == above), plan
+            assert ("index pass once (k_index_scan, k_compact, k_index_cols)" in plan) == (S == above), plan   # the split path comes with them
+            job.run()
+            for s, i in ((0, 0), (S - 1, 7), (3, 2)):
+                b = index[i].with_counts(samples[s][0][i], samples[s][1][i])
+                assert_parity(b, job.fetch(s * 8 + i), orc.genotype_contig(b, orc.OracleTable(*args), orc.make_params(1.26, False, 1e-5)))
+            job.close()
