@@ -158,31 +158,68 @@ void save_unique_kmers_map(const UniqueKmersMap& m, const std::string& path) {
 }
 
 // ------------------------------------------------------------------ Results (`-w`: <out>_genotyping.cereal)
+// vector<GenotypingResult> as cereal writes it: what HMM::serialize archives (reference src/hmm.hpp:49-52) and what every
+// chromosome of the Results archive holds
+static void read_genotyping_results(Reader& r, std::vector<GenotypingResult>& vec) {
+    const uint64_t nv = r.count(16);
+    vec.resize((size_t)nv);
+    for (uint64_t v = 0; v < nv; ++v) {
+        GenotypingResult& g = vec[(size_t)v];
+        const uint64_t nl = r.count(20);
+        for (uint64_t l = 0; l < nl; ++l) {
+            const unsigned short a1 = r.take<uint16_t>(), a2 = r.take<uint16_t>();
+            if (16 > r.n - r.o) throw std::runtime_error("Results archive: truncated");
+            long double lik = 0.0L;
+            std::memcpy(&lik, r.p + r.o, 10);  // the 80-bit value; 6 bytes of padding follow
+            r.o += 16;
+            g.add_to_likelihood(a1, a2, lik);
+        }
+        g.add_first_haplotype_allele(r.take<uint16_t>());
+        g.add_second_haplotype_allele(r.take<uint16_t>());
+        g.set_coverage(r.take<uint16_t>());
+        g.set_unique_kmers(r.take<uint16_t>());
+    }
+}
+static void write_genotyping_results(Writer& w, const std::vector<GenotypingResult>& vec) {
+    static_assert(sizeof(long double) == 16, "x86-64 long double");
+    w.put<uint64_t>(vec.size());
+    for (const GenotypingResult& g : vec) {
+        const auto& m = g.get_stored_likelihoods();
+        w.put<uint64_t>(m.size());
+        for (const auto& e : m) {
+            w.put<uint16_t>(e.first.first);
+            w.put<uint16_t>(e.first.second);
+            unsigned char b[16] = {0};
+            std::memcpy(b, &e.second, 10);
+            w.out.insert(w.out.end(), b, b + 16);
+        }
+        w.put<uint16_t>(g.get_haplotype().first);
+        w.put<uint16_t>(g.get_haplotype().second);
+        w.put<uint16_t>(g.coverage());
+        w.put<uint16_t>(g.nr_unique_kmers());
+    }
+}
+
+std::vector<unsigned char> HMM::serialize() const {
+    Writer w;
+    write_genotyping_results(w, genotyping_result_);
+    return w.out;
+}
+HMM HMM::deserialize(const std::vector<unsigned char>& bytes) {
+    Reader r{bytes.data(), bytes.size()};
+    HMM h;
+    read_genotyping_results(r, h.genotyping_result_);
+    if (r.o != r.n) throw std::runtime_error("HMM archive: trailing bytes");
+    return h;
+}
+
 Results parse_results(const std::vector<unsigned char>& bytes) {
     Reader r{bytes.data(), bytes.size()};
     Results out;
     const uint64_t nc = r.count(16);
     for (uint64_t c = 0; c < nc; ++c) {
         const std::string name = r.str();
-        const uint64_t nv = r.count(16);
-        std::vector<GenotypingResult>& vec = out.result[name];
-        vec.resize((size_t)nv);
-        for (uint64_t v = 0; v < nv; ++v) {
-            GenotypingResult& g = vec[(size_t)v];
-            const uint64_t nl = r.count(20);
-            for (uint64_t l = 0; l < nl; ++l) {
-                const unsigned short a1 = r.take<uint16_t>(), a2 = r.take<uint16_t>();
-                if (16 > r.n - r.o) throw std::runtime_error("Results archive: truncated");
-                long double lik = 0.0L;
-                std::memcpy(&lik, r.p + r.o, 10);  // the 80-bit value; 6 bytes of padding follow
-                r.o += 16;
-                g.add_to_likelihood(a1, a2, lik);
-            }
-            g.add_first_haplotype_allele(r.take<uint16_t>());
-            g.add_second_haplotype_allele(r.take<uint16_t>());
-            g.set_coverage(r.take<uint16_t>());
-            g.set_unique_kmers(r.take<uint16_t>());
-        }
+        read_genotyping_results(r, out.result[name]);
     }
     out.runtimes = read_str_double(r);
     if (r.o != r.n) throw std::runtime_error("Results archive: trailing bytes");
@@ -190,27 +227,11 @@ Results parse_results(const std::vector<unsigned char>& bytes) {
 }
 
 std::vector<unsigned char> serialize_results(const Results& res) {
-    static_assert(sizeof(long double) == 16, "x86-64 long double");
     Writer w;
     w.put<uint64_t>(res.result.size());
     for (const auto& kv : res.result) {
         w.str(kv.first);
-        w.put<uint64_t>(kv.second.size());
-        for (const GenotypingResult& g : kv.second) {
-            const auto& m = g.get_stored_likelihoods();
-            w.put<uint64_t>(m.size());
-            for (const auto& e : m) {
-                w.put<uint16_t>(e.first.first);
-                w.put<uint16_t>(e.first.second);
-                unsigned char b[16] = {0};
-                std::memcpy(b, &e.second, 10);
-                w.out.insert(w.out.end(), b, b + 16);
-            }
-            w.put<uint16_t>(g.get_haplotype().first);
-            w.put<uint16_t>(g.get_haplotype().second);
-            w.put<uint16_t>(g.coverage());
-            w.put<uint16_t>(g.nr_unique_kmers());
-        }
+        write_genotyping_results(w, kv.second);
     }
     w.put<uint64_t>(res.runtimes.size());
     for (const auto& kv : res.runtimes) { w.str(kv.first); w.put<double>(kv.second); }

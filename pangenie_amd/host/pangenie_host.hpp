@@ -283,6 +283,12 @@ public:
     void normalize();
     std::vector<GenotypingResult> get_genotyping_result() const { return genotyping_result_; }
     std::vector<GenotypingResult> move_genotyping_result() { return std::move(genotyping_result_); }
+    /** reference src/hmm.hpp:49-52 — `archive(genotyping_result)`: what a cereal binary archive holds of an HMM, the vector of its
+     *  GenotypingResults (u64 count, then per element the layout host/cereal_io.hpp gives for the `-w` Results archive, whose
+     *  per-chromosome vectors are these same bytes).  deserialize() is the loading direction of the same template; it needs no
+     *  device.  Defined in host/cereal_io.cpp. */
+    std::vector<unsigned char> serialize() const;
+    static HMM deserialize(const std::vector<unsigned char>& bytes);
     /** device the calling thread's HMMs run on (default 0) */
     static void set_device(int device);
     static int device_count();

@@ -1150,6 +1150,30 @@ static void archive_cpu_tests() {
         try { std::vector<unsigned char> cut(bytes.begin(), bytes.end() - 3); parse_results(cut); } catch (const std::runtime_error&) { threw = true; }
         CHECK(threw);
     });
+    run("HMM::serialize (reference src/hmm.hpp:49-52: archive(genotyping_result)) = one chromosome's vector of the Results archive", [] {
+        const Results r = sample_results();
+        const std::vector<GenotypingResult>& chr1 = r.result.at("chr1");
+        // the Results archive of {"chr1": v}: u64 1, u64 4 "chr1", <the vector>, u64 0 runtimes — the vector's bytes are the HMM's
+        Results one;
+        one.result["chr1"] = chr1;
+        const std::vector<unsigned char> whole = serialize_results(one);
+        const std::vector<unsigned char> vec(whole.begin() + 8 + 8 + 4, whole.end() - 8);
+        HMM h = HMM::deserialize(vec);   // (no device needed)
+        CHECK(h.serialize() == vec);
+        const std::vector<GenotypingResult> got = h.get_genotyping_result();
+        CHECK(got.size() == chr1.size());
+        for (size_t i = 0; i < got.size() && i < chr1.size(); ++i) {
+            CHECK(got[i].get_stored_likelihoods() == chr1[i].get_stored_likelihoods());
+            CHECK(got[i].get_haplotype() == chr1[i].get_haplotype() && got[i].coverage() == chr1[i].coverage() && got[i].nr_unique_kmers() == chr1[i].nr_unique_kmers());
+        }
+        CHECK(HMM().serialize() == std::vector<unsigned char>(8, 0));   // an HMM that genotyped nothing: an empty vector
+        bool threw = false;
+        try { std::vector<unsigned char> cut(vec.begin(), vec.end() - 1); (void)HMM::deserialize(cut); } catch (const std::runtime_error&) { threw = true; }
+        CHECK(threw);
+        threw = false;
+        try { std::vector<unsigned char> more = vec; more.push_back(0); (void)HMM::deserialize(more); } catch (const std::runtime_error&) { threw = true; }
+        CHECK(threw);
+    });
     run("cereal binary archive: the reference's own fixtures parse and re-serialise byte for byte", [] {
         for (const char* name : {"region_UniqueKmersList.cereal", "region2_UniqueKmersList.cereal"}) {
             const std::string path = g_golden_dir + "/" + name;
