@@ -378,6 +378,26 @@ struct ArenaPool {
     }
 } g_pool;
 
+// Pinned staging buffers of the pipelined first run (upload_inputs: group B's copies).  Copies that are to run BESIDE a kernel
+// must be on a stream that does not share its hardware queue with the kernel's (measured, profiles/r06_persist.txt: pageable
+// copies on streams made for the purpose, and the same out of pinned memory, returned when group A's phase 1 ended, 122 - 135 ms
+// later; on the job's second stream — the one the stream handshake vouches for — 17 ms), and a host thread can only feed such
+// a stream asynchronously out of pinned memory.  So group B's host threads stage their sources through these themselves:
+// 16 MB pieces, two per thread, kept for the life of the process.
+struct PinnedPool {
+    static constexpr size_t kBytes = (size_t)16 << 20;
+    std::mutex mu;
+    std::vector<unsigned char*> free_list;
+    unsigned char* get() {
+        { std::lock_guard<std::mutex> l(mu); if (!free_list.empty()) { unsigned char* p = free_list.back(); free_list.pop_back(); return p; } }
+        void* p = nullptr;
+        if (hipHostMalloc(&p, kBytes, hipHostMallocDefault) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+        return (unsigned char*)p;
+    }
+    void put(unsigned char* p) { if (p) { std::lock_guard<std::mutex> l(mu); free_list.push_back(p); } }
+    void clear() { std::lock_guard<std::mutex> l(mu); for (unsigned char* p : free_list) hipHostFree(p); free_list.clear(); }
+} g_pinned;
+
 }  // namespace
 
 struct pg_job {
@@ -450,6 +470,19 @@ struct pg_job {
     // of its own: phase 2 is ONE launch of each, chunks handed over through DevContig::sync (PG_KERNELS=nopersist: a launch per chunk)
     bool persist = false;
     uint32_t post_blocks = 0;
+    // The pipelined first run of a one-shot job (job_build with cache_arena: upload and run inside ONE call, the host arrays stay
+    // valid): the inputs of the LONG chains (group A: the job's wall time) are uploaded first and their preparation + phase 1
+    // start while the other chains' inputs (group B, most of the bytes) are still crossing PCIe; B's index pass, preparation and
+    // phase 1 then run on the second stream beside A's.  24 chromosomes x 64 paths: 27 ms of H2D in front of a 252 ms run.
+    bool pipeline = false, late_pending = false;
+    uint32_t nA = 0;
+    std::vector<uint32_t> grp_order;          // chains (= index contigs: 1:1 in such jobs), group A first
+    DevContig* d_contigs_g = nullptr;         // the chain descriptors in that order
+    DevContig* d_reps_g = nullptr;            // the index descriptors in that order
+    std::vector<std::thread> late_threads;    // group B's copies
+    std::vector<int> late_rc;
+    hipEvent_t ev_late[2];
+    bool ev_late_made = false;
     hipStream_t persist_checked = nullptr;   // the stream whose kernels are known to run beside stream2's (streams_concurrent)
     bool persist_checked_any = false;
     uint32_t* d_handshake = nullptr;
@@ -481,6 +514,8 @@ extern "C" void pg_job_destroy(pg_job* job) {
     if (!job) return;
     hipSetDevice(job->device);
     if (job->uploader.joinable()) job->uploader.join();
+    for (auto& t : job->late_threads) if (t.joinable()) t.join();
+    if (job->ev_late_made) { hipEventDestroy(job->ev_late[0]); hipEventDestroy(job->ev_late[1]); }
     if (job->copy_stream) { hipStreamSynchronize(job->copy_stream); hipStreamDestroy(job->copy_stream); }
     if (job->staging) hipHostFree(job->staging);
     if (job->alt_samples) hipFree(job->alt_samples);
@@ -507,6 +542,7 @@ extern "C" void pg_hmm_release_cache(void) {
     int cur = -1;
     const bool have = hipGetDevice(&cur) == hipSuccess;
     g_pool.clear();
+    g_pinned.clear();
     if (have) hipSetDevice(cur);
 }
 
@@ -579,6 +615,7 @@ int sample_upload(pg_job* job, const std::vector<ChainSpec>& specs, unsigned cha
     return PG_OK;
 }
 
+bool streams_concurrent(pg_job* job, hipStream_t s);   // (below, in front of pg_job_run)
 // H2D of the inputs into a planned job.  Copies are queued on the job's stream; pageable sources are
 // staged by the runtime, so every call returns when its source has been read.
 int upload_inputs(pg_job* job, const pg_contig_batch* batches, const std::vector<ChainSpec>& specs, bool with_index,
@@ -591,11 +628,17 @@ int upload_inputs(pg_job* job, const pg_contig_batch* batches, const std::vector
     // arrays, 1.06 GB) is then issued from several host threads on streams of their own — the runtime stages a pageable
     // source through its bounce buffers on the calling thread, one copy after the other: 24 ms on one thread
     struct Copy { void* dst; const void* src; size_t bytes; };
-    std::vector<Copy> copies;
+    std::vector<Copy> copies, late_copies;   // late: group B of a pipelined first run (pg_job::pipeline) — issued here, waited for in pg_job_run
+    // (the pipelined first run needs the job's two streams to run side by side: asked once, here, where nothing is in flight)
+    if (with_index && job->pipeline && !streams_concurrent(job, s)) job->pipeline = false;
+    const bool pipe = with_index && job->pipeline;
+    std::vector<char> late(job->chains.size(), 0);
+    if (pipe) for (size_t k = job->nA; k < job->grp_order.size(); ++k) late[job->grp_order[k]] = 1;
+    bool cur_late = false;
 #define UP(off, src, bytes, acc)                                                                              \
     do {                                                                                                      \
         if ((bytes) > 0) {                                                                                    \
-            copies.push_back({(void*)(A + (off)), (const void*)(src), (size_t)(bytes)});  /* (host or device source) */ \
+            (cur_late ? late_copies : copies).push_back({(void*)(A + (off)), (const void*)(src), (size_t)(bytes)});  /* (host or device source) */ \
             acc += (uint64_t)(bytes);                                                                         \
         }                                                                                                     \
     } while (0)
@@ -604,6 +647,7 @@ int upload_inputs(pg_job* job, const pg_contig_batch* batches, const std::vector
             const pg_contig_batch& b = batches[i];
             IndexHost& x = job->index[i];
             if (x.V == 0) continue;
+            cur_late = pipe && late[i];   // (pipelined jobs: chain i over index contig i)
             UP(x.o_pos, b.variant_pos, (size_t)x.V * 8, bi);
             if (job->params.run_phasing) { x.pos.assign(b.variant_pos, b.variant_pos + x.V); job->vit_tq_ready = false; }
             UP(x.o_koff, b.kmer_off, ((size_t)x.V + 1) * 4, bi);
@@ -621,6 +665,7 @@ int upload_inputs(pg_job* job, const pg_contig_batch* batches, const std::vector
             UP(x.o_list_b, x.list_b.data(), x.list_b.size() * 4, bi);
             UP(x.o_list_big, x.list_big.data(), x.list_big.size() * 4, bi);
         }
+        cur_late = false;
         UP(job->o_tab_m, job->tab_m.data(), job->tab_m.size() * sizeof(double), bi);
         UP(job->o_tab_e, job->tab_e.data(), job->tab_e.size() * sizeof(int32_t), bi);
         UP(job->o_tab_p, job->tab_p.data(), job->tab_p.size(), bi);
@@ -636,44 +681,97 @@ int upload_inputs(pg_job* job, const pg_contig_batch* batches, const std::vector
             ChainHost& ch = job->chains[c];
             const IndexHost& x = job->index[ch.index];
             if (x.V == 0) continue;
+            cur_late = pipe && late[c];
             UP(ch.o_cov + rebase, specs[c].coverage, (size_t)x.V * 2, bs);
             UP(ch.o_kcnt + rebase, specs[c].kmer_count, (size_t)x.sumK * 2, bs);
             ch.coverage.assign(specs[c].coverage, specs[c].coverage + x.V);
         }
     }
 #undef UP
+    // `list` split over up to four host threads (largest first onto the least loaded), each on a stream of its own; a thread
+    // returns when its copies have been read AND have arrived
+    auto shares_of = [](const std::vector<Copy>& list, unsigned nt) {
+        std::vector<std::vector<Copy>> share(nt);
+        std::vector<size_t> load(nt, 0), order(list.size());
+        for (size_t i = 0; i < order.size(); ++i) order[i] = i;
+        std::sort(order.begin(), order.end(), [&](size_t x, size_t y) { return list[x].bytes > list[y].bytes; });
+        for (size_t i : order) {
+            unsigned best = 0;
+            for (unsigned t = 1; t < nt; ++t) if (load[t] < load[best]) best = t;
+            share[best].push_back(list[i]); load[best] += list[i].bytes;
+        }
+        return share;
+    };
+    const int device = job->device;
+    auto copy_worker = [device](std::vector<Copy> mine, int* rc) {   // (by value: group B's threads outlive this call)
+        hipStream_t st = nullptr;
+        hipError_t e = hipSetDevice(device);
+        if (e == hipSuccess) e = hipStreamCreateWithFlags(&st, hipStreamNonBlocking);
+        for (const Copy& c : mine) { if (e != hipSuccess) break; e = hipMemcpyAsync(c.dst, c.src, c.bytes, hipMemcpyDefault, st); }
+        if (e == hipSuccess) e = hipStreamSynchronize(st);
+        if (st) hipStreamDestroy(st);
+        *rc = (int)e;
+    };
     {
         size_t total = 0;
         for (const Copy& c : copies) total += c.bytes;
-        unsigned nt = (total >= ((size_t)64 << 20) && copies.size() >= 8) ? 4u : 1u;
+        for (const Copy& c : late_copies) total += c.bytes;
+        const unsigned nt = (total >= ((size_t)64 << 20) && copies.size() + late_copies.size() >= 8) ? 4u : 1u;
         if (nt > 1) {
-            std::vector<std::vector<size_t>> share(nt);   // largest first onto the least loaded thread
-            std::vector<size_t> load(nt, 0), order(copies.size());
-            for (size_t i = 0; i < order.size(); ++i) order[i] = i;
-            std::sort(order.begin(), order.end(), [&](size_t x, size_t y) { return copies[x].bytes > copies[y].bytes; });
-            for (size_t i : order) {
-                unsigned best = 0;
-                for (unsigned t = 1; t < nt; ++t) if (load[t] < load[best]) best = t;
-                share[best].push_back(i); load[best] += copies[i].bytes;
-            }
+            std::vector<std::vector<Copy>> share = shares_of(copies, nt);
             std::vector<int> rcs(nt, (int)hipSuccess);
-            auto work = [&](unsigned t) {
-                hipStream_t st = nullptr;
-                hipError_t e = hipSetDevice(job->device);
-                if (e == hipSuccess) e = hipStreamCreateWithFlags(&st, hipStreamNonBlocking);
-                for (size_t i : share[t]) { if (e != hipSuccess) break; e = hipMemcpyAsync(copies[i].dst, copies[i].src, copies[i].bytes, hipMemcpyDefault, st); }
-                if (e == hipSuccess) e = hipStreamSynchronize(st);
-                if (st) hipStreamDestroy(st);
-                rcs[t] = (int)e;
-            };
             std::vector<std::thread> th;
-            for (unsigned t = 1; t < nt; ++t) th.emplace_back(work, t);
-            work(0);
+            for (unsigned t = 1; t < nt; ++t) th.emplace_back(copy_worker, share[t], &rcs[t]);
+            copy_worker(share[0], &rcs[0]);
             for (auto& t : th) t.join();
             for (unsigned t = 0; t < nt; ++t)
                 if (rcs[t] != (int)hipSuccess) { set_err(err, errlen, "input upload: %s", hipGetErrorString((hipError_t)rcs[t])); return PG_ERR_DEVICE; }
         } else {
             for (const Copy& c : copies) HIP_TRY(hipMemcpyAsync(c.dst, c.src, c.bytes, hipMemcpyDefault, s));
+        }
+        if (pipe) {
+            // group B: on its way from here on; pg_job_run joins the threads when group A's kernels are running.  Staged through
+            // pinned pieces by the thread itself (g_pinned: a pageable copy would wait for group A's kernels to end); a source
+            // that is device memory is copied as it is.
+            // All of them on the job's SECOND stream — the one stream known to run beside `s` (streams_concurrent): a stream made here
+            // may share its hardware queue with `s`, and its copies then wait for group A's phase 1 to end (measured: 130 ms).
+            hipStream_t st2 = job->stream2;
+            auto staged_worker = [device, st2](std::vector<Copy> mine, int* rc) {
+                hipStream_t st = st2;
+                hipEvent_t ev[2] = {nullptr, nullptr};
+                unsigned char* buf[2] = {g_pinned.get(), g_pinned.get()};
+                hipError_t e = hipSetDevice(device);
+                for (int k = 0; k < 2 && e == hipSuccess; ++k) e = hipEventCreateWithFlags(&ev[k], hipEventDisableTiming);
+                if (e == hipSuccess && (!buf[0] || !buf[1])) e = hipErrorOutOfMemory;
+                size_t piece = 0;
+                for (const Copy& c : mine) {
+                    if (e != hipSuccess) break;
+                    hipPointerAttribute_t at;
+                    const bool on_device = hipPointerGetAttributes(&at, c.src) == hipSuccess && at.type == hipMemoryTypeDevice;
+                    if (!on_device) (void)hipGetLastError();
+                    if (on_device) { e = hipMemcpyAsync(c.dst, c.src, c.bytes, hipMemcpyDeviceToDevice, st); continue; }
+                    for (size_t off = 0; off < c.bytes && e == hipSuccess; off += PinnedPool::kBytes, ++piece) {
+                        const size_t nby = std::min(PinnedPool::kBytes, c.bytes - off);
+                        const int k = (int)(piece & 1u);
+                        if (piece >= 2) e = hipEventSynchronize(ev[k]);   // (the piece two back has left this buffer)
+                        if (e != hipSuccess) break;
+                        memcpy(buf[k], (const unsigned char*)c.src + off, nby);
+                        e = hipMemcpyAsync((unsigned char*)c.dst + off, buf[k], nby, hipMemcpyHostToDevice, st);
+                        if (e == hipSuccess) e = hipEventRecord(ev[k], st);
+                    }
+                }
+                // (the last pieces have left the pinned buffers before they go back to the pool; the stream itself is not waited for:
+                //  group B's kernels are queued behind these copies, on the same stream)
+                for (int k = 0; k < 2; ++k) if (ev[k] && piece > (size_t)k) { const hipError_t e2 = hipEventSynchronize(ev[k]); if (e == hipSuccess) e = e2; }
+                for (int k = 0; k < 2; ++k) { if (ev[k]) hipEventDestroy(ev[k]); g_pinned.put(buf[k]); }
+                *rc = (int)e;
+            };
+            const unsigned ntb = late_copies.size() >= 8 ? 4u : 1u;
+            std::vector<std::vector<Copy>> share = shares_of(late_copies, ntb);
+            job->late_rc.assign(ntb, (int)hipSuccess);
+            job->late_threads.clear();
+            for (unsigned t = 0; t < ntb; ++t) job->late_threads.emplace_back(staged_worker, share[t], &job->late_rc[t]);
+            job->late_pending = true;
         }
     }
     HIP_TRY(hipStreamSynchronize(s));
@@ -687,7 +785,8 @@ int upload_inputs(pg_job* job, const pg_contig_batch* batches, const std::vector
         if (job->srec_bytes) HIP_TRY(hipMemsetAsync(job->srec_base, 0, job->srec_bytes, s));
         uint32_t max_big = 0;
         for (const IndexHost& x : job->index) max_big = std::max<uint32_t>(max_big, (uint32_t)x.list_big.size());
-        pgk_launch_index(job->d_reps, (uint32_t)job->index.size(), job->max_v, max_big, job->any_split ? 1 : 0, s);
+        if (pipe) pgk_launch_index(job->d_reps_g, job->nA, job->max_v, max_big, 0, s);   // (group B's: pg_job_run, when its inputs have arrived)
+        else pgk_launch_index(job->d_reps, (uint32_t)job->index.size(), job->max_v, max_big, job->any_split ? 1 : 0, s);
         HIP_TRY(hipGetLastError());
         HIP_TRY(hipEventRecord(job->ev_ix[1], s));
         HIP_TRY(hipStreamSynchronize(s));
@@ -1055,6 +1154,7 @@ int job_build(int device, uint32_t n_index, const pg_contig_batch* batches, cons
     std::vector<Plan> plan(n_chains);
     const size_t o_contigs = take(sizeof(DevContig) * n_chains);
     const size_t o_reps = take(sizeof(DevContig) * n_index);
+    const size_t o_contigs_g = take(sizeof(DevContig) * n_chains), o_reps_g = take(sizeof(DevContig) * n_index);   // (the pipelined first run: group order)
     const size_t o_small = take(sizeof(uint32_t) * n_chains);   // chain ids of the H = 16 chains (k_sweep_small16)
     const size_t o_dump = take(64 * 8 * 16 + 8 * 16 * 16 * 16);  // scrap column for the stores of its rows that are done
     const size_t o_handshake = take(64);   // k_stream_handshake's words
@@ -1221,6 +1321,7 @@ int job_build(int device, uint32_t n_index, const pg_contig_batch* batches, cons
     unsigned char* A = job->arena;
     job->d_contigs = (DevContig*)(A + o_contigs);
     job->d_reps = (DevContig*)(A + o_reps);
+    job->d_contigs_g = (DevContig*)(A + o_contigs_g); job->d_reps_g = (DevContig*)(A + o_reps_g);
     job->d_ixerr = (uint32_t*)(A + o_ixerr);
     job->ix_base = A + ix_lo; job->ix_bytes = ix_hi - ix_lo;
     job->srec_base = A + srec_lo; job->srec_bytes = srec_hi - srec_lo;
@@ -1403,6 +1504,45 @@ int job_build(int device, uint32_t n_index, const pg_contig_batch* batches, cons
         (he = hipStreamSynchronize(job->stream)) != hipSuccess)
         return fail(PG_ERR_DEVICE, "hipMemcpy contigs", he);
     lap("descriptors");
+    {
+        // The pipelined first run (pg_job::pipeline): a one-shot job — upload and run inside one call — of few chains (chunked: bound
+        // by its longest chain, not by throughput), every chain over an index contig of its own, on kernels that take a sub-range
+        // of the descriptor array (no chain-id lists, no split path), with enough bytes to upload that hiding them matters.
+        // Group A = the chains with at least 0.78 of the longest one's variants (they decide the wall time; the others, starting
+        // later by their upload — ~10 % of a run at 40 GB/s —, still end phase 1 first), unless that is most of the bytes anyway.
+        bool ok = cache_arena && job->chunked && !cohort && n_index == n_chains && n_chains >= 2 && !job->any_split &&
+                  params->run_genotyping && !params->run_phasing && getenv("PG_NO_PIPELINE") == nullptr;
+        for (uint32_t c = 0; ok && c < n_chains; ++c) ok = job->chains[c].index == c && !job->index[c].small && !job->index[c].smallx;
+        if (ok) {
+            uint64_t vmax = 0, wA = 0, wAll = 0;
+            for (const IndexHost& x : job->index) vmax = std::max<uint64_t>(vmax, x.V);
+            std::vector<uint32_t> a, b;
+            for (uint32_t c = 0; c < n_chains; ++c) {
+                const IndexHost& x = job->index[c];
+                const uint64_t w = (uint64_t)x.V * x.H * 2u + (uint64_t)x.sumK * 2u + (uint64_t)x.V * 24u;
+                wAll += w;
+                if ((double)x.V >= 0.78 * (double)vmax) { a.push_back(c); wA += w; } else b.push_back(c);
+            }
+            uint64_t min_bytes = (uint64_t)128 << 20;   // (PG_PIPELINE_MIN_MB: tests put small jobs through the pipelined run)
+            if (const char* e = getenv("PG_PIPELINE_MIN_MB")) min_bytes = (uint64_t)strtoul(e, nullptr, 0) << 20;
+            if (!b.empty() && wAll >= min_bytes && (double)wA <= 0.6 * (double)wAll) {
+                job->grp_order = a;
+                job->grp_order.insert(job->grp_order.end(), b.begin(), b.end());
+                job->nA = (uint32_t)a.size();
+                std::vector<DevContig> g(n_chains);
+                for (uint32_t k = 0; k < n_chains; ++k) g[k] = hd[job->grp_order[k]];
+                // (chain c over index c: the chain's descriptor serves as its index contig's)
+                if ((he = hipMemcpyAsync(job->d_contigs_g, g.data(), sizeof(DevContig) * n_chains, hipMemcpyHostToDevice, job->stream)) != hipSuccess ||
+                    (he = hipMemcpyAsync(job->d_reps_g, g.data(), sizeof(DevContig) * n_chains, hipMemcpyHostToDevice, job->stream)) != hipSuccess ||
+                    (he = hipStreamSynchronize(job->stream)) != hipSuccess)
+                    return fail(PG_ERR_DEVICE, "hipMemcpy group descriptors", he);
+                if (hipEventCreateWithFlags(&job->ev_late[0], hipEventDisableTiming) == hipSuccess && hipEventCreateWithFlags(&job->ev_late[1], hipEventDisableTiming) == hipSuccess) {
+                    job->ev_late_made = true;
+                    job->pipeline = true;
+                }
+            }
+        }
+    }
     const int rc = upload_inputs(job, batches, specs, true, err, errlen);
     if (rc != PG_OK) { pg_job_destroy(job); return rc; }
     lap("upload of the inputs");
@@ -1665,6 +1805,52 @@ extern "C" int pg_job_run(pg_job* job, void* stream_, char* err, size_t errlen) 
     HIP_TRY(hipMemsetAsync(job->zero_base, 0, job->zero_bytes, s));
     if (job->max_v > 0 && job->params.run_genotyping) {
         HIP_TRY(hipEventRecord(job->ev[0], s));
+        if (job->late_pending && s == job->stream) {
+            // The pipelined first run (pg_job::pipeline): group A's preparation and phase 1 start NOW, on `s`; the host then waits for
+            // group B's inputs (they have been crossing PCIe since job_build) and puts B's index pass, preparation and phase 1 on the
+            // second stream, beside A's.  Phase 2 (below) starts when both are done.  (The timing classes: B's preparation counts
+            // into the phase-1 class.)
+            const uint32_t nA = job->nA, nB = n - nA;
+            HIP_TRY(hipEventRecord(job->ev_late[0], s));   // (behind the zeroing of the per-run block)
+            pgk_launch_prep(job->d_contigs_g, nA, job->max_v, job->max_prep_w, job->max_prep_m4, job->tab, s);
+            HIP_TRY(hipGetLastError());
+            HIP_TRY(hipEventRecord(job->ev[1], s));
+            HIP_TRY(hipEventRecord(job->ev[2], s));
+            pgk_launch_records(job->d_contigs_g, nA, job->max_v, s);
+            HIP_TRY(hipGetLastError());
+            HIP_TRY(hipEventRecord(job->ev[3], s));
+            pgk_launch_sweep(job->d_contigs_g, nA, job->hp_mask, 1, s);
+            HIP_TRY(hipGetLastError());
+            for (auto& t : job->late_threads) if (t.joinable()) t.join();   // (their copies are ISSUED — 17 ms on the whole genome —, on stream2)
+            job->late_threads.clear();
+            job->late_pending = false;
+            for (int rcb : job->late_rc)
+                if (rcb != (int)hipSuccess) { set_err(err, errlen, "input upload: %s", hipGetErrorString((hipError_t)rcb)); return PG_ERR_DEVICE; }
+            hipStream_t sb = job->stream2;
+            HIP_TRY(hipStreamWaitEvent(sb, job->ev_late[0], 0));
+            uint32_t max_big = 0;
+            for (const IndexHost& x : job->index) max_big = std::max<uint32_t>(max_big, (uint32_t)x.list_big.size());
+            pgk_launch_index(job->d_reps_g + nA, nB, job->max_v, max_big, 0, sb);
+            pgk_launch_prep(job->d_contigs_g + nA, nB, job->max_v, job->max_prep_w, job->max_prep_m4, job->tab, sb);
+            pgk_launch_records(job->d_contigs_g + nA, nB, job->max_v, sb);
+            pgk_launch_sweep(job->d_contigs_g + nA, nB, job->hp_mask, 1, sb);
+            HIP_TRY(hipGetLastError());
+            HIP_TRY(hipEventRecord(job->ev_late[1], sb));
+            HIP_TRY(hipStreamWaitEvent(s, job->ev_late[1], 0));
+            HIP_TRY(hipEventRecord(job->ev[4], s));
+        } else {
+        if (job->late_pending) {
+            // (a caller's own stream: no pipelining — group B's inputs are waited for, its index pass made up, then the run as ever)
+            for (auto& t : job->late_threads) if (t.joinable()) t.join();
+            job->late_threads.clear();
+            job->late_pending = false;
+            for (int rcb : job->late_rc)
+                if (rcb != (int)hipSuccess) { set_err(err, errlen, "input upload: %s", hipGetErrorString((hipError_t)rcb)); return PG_ERR_DEVICE; }
+            uint32_t max_big = 0;
+            for (const IndexHost& x : job->index) max_big = std::max<uint32_t>(max_big, (uint32_t)x.list_big.size());
+            pgk_launch_index(job->d_reps_g + job->nA, n - job->nA, job->max_v, max_big, 0, s);
+            HIP_TRY(hipGetLastError());
+        }
         if (job->any_legacy_prep) pgk_launch_prep(job->d_contigs, n, job->max_v, job->max_prep_w, job->max_prep_m4, job->tab, s);
         if (job->any_split) pgk_launch_prep_split(job->d_contigs, n, job->max_sb, job->max_sm4, job->max_sw, job->tab, s);
         HIP_TRY(hipGetLastError());
@@ -1679,6 +1865,7 @@ extern "C" int pg_job_run(pg_job* job, void* stream_, char* err, size_t errlen) 
         pgk_launch_sweep_smallx(job->d_contigs, job->d_smallx, job->n_smallx, 1, 0, job->d_dump, s);
         HIP_TRY(hipGetLastError());
         HIP_TRY(hipEventRecord(job->ev[4], s));
+        }
         if (!job->chunked) {
             pgk_launch_sweep(job->d_contigs, n, job->hp_mask, 2, s);
             if (job->small_phase2) pgk_launch_sweep_small(job->d_contigs, job->d_small, job->n_small, 2, 0, job->d_dump, s);

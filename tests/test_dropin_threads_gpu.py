@@ -146,3 +146,30 @@ def test_an_announced_call_that_never_arrives_costs_the_wait_bound_once(orc):
           % (len(batches), t_all * 1e3, t_half * 1e3, t_late * 1e3))
     assert t_late < t_all + 0.6      # bounded: the 250 ms wait once, not per caller
     assert t_half < t_all + 0.2      # un-announced callers cost nothing extra
+
+
+def test_merged_one_shot_job_pipelines_its_upload_behind_the_long_chains(orc, monkeypatch):
+    """Round 6: a merged one-shot job (upload and run inside one call) uploads the inputs of its LONG chains first, starts their
+    preparation and phase 1, and lets the other chains' inputs cross PCIe meanwhile; their index pass, preparation and phase 1
+    then run on the job's second stream (pg_shim.cpp: pg_job::pipeline).  PG_PIPELINE_MIN_MB=0 puts these small contigs through
+    it (by default only jobs with >= 128 MB of inputs take it); the callers get the bits they get with PG_NO_PIPELINE=1 and
+    alone, and match the oracle."""
+    args = default_table_args()
+    table, otable = hmm.ProbabilityTable(*args), orc.OracleTable(*args)
+    prm = hmm.make_params(1.26, False, 1e-5)
+    # two long chains (group A), five shorter ones (group B), one of them with multiallelic objects (k_sweep_leanx beside k_sweep_lean)
+    batches = [synthetic_panel(v, 64, 20, seed=2100 + i, multiallelic_frac=0.2 if i == 4 else 0.0) for i, v in enumerate((1000, 980, 500, 400, 300, 450, 350))]
+    monkeypatch.setenv("PG_PIPELINE_MIN_MB", "0")
+    piped = hmm.genotype_contigs_threaded(batches, table, prm)
+    again = hmm.genotype_contigs_threaded(batches, table, prm)
+    monkeypatch.setenv("PG_NO_PIPELINE", "1")
+    plain = hmm.genotype_contigs_threaded(batches, table, prm)
+    monkeypatch.delenv("PG_NO_PIPELINE")
+    monkeypatch.delenv("PG_PIPELINE_MIN_MB")
+    for b, r, r2, q in zip(batches, piped, again, plain):
+        assert not isinstance(r, Exception), r
+        assert not isinstance(r2, Exception) and not isinstance(q, Exception)
+        assert np.array_equal(r.lik, q.lik) and np.array_equal(r.lik_exp, q.lik_exp) and r.n_columns == q.n_columns
+        assert np.array_equal(r.lik, r2.lik) and np.array_equal(r.lik_exp, r2.lik_exp)
+        assert np.array_equal(r.kept, q.kept)
+        assert_parity(b, r, orc.genotype_contig(b, otable, prm if False else orc.make_params(1.26, False, 1e-5)))
