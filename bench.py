@@ -462,8 +462,7 @@ def main():
             fence()
             t0 = time.perf_counter()
             if job:
-                job.upload()
-                job.run()
+                job.upload_run()   # (pg_job_upload + pg_job_run in one call: the short chains' inputs cross PCIe behind the long chains' phase 1)
                 job.fetch_all(results)
             if abi:
                 abi.gather(job, per_rank)

@@ -262,6 +262,11 @@ int  pg_cohort_new(int device, uint32_t n_contigs, const pg_contig_batch* index,
  * NULL to keep the resident index and upload the counts only). */
 int  pg_job_upload(pg_job* job, const pg_contig_batch* batches, const pg_sample_counts* samples,
                    char* err, size_t errlen);
+/* pg_job_upload followed by pg_job_run (on the job's own stream) in ONE call — the arrays stay valid until it returns, so a job of a
+ * few long chains (a whole genome's chromosomes) uploads the inputs of its longest chains first, starts their preparation and phase 1
+ * and lets the other chains' inputs cross PCIe meanwhile (round 6; the one-shot pg_hmm_genotype_contig does the same inside).  Same
+ * results as the two calls, bit for bit.  pg_job_host_seconds: [1] then counts only what the caller waited for in front of the run. */
+int  pg_job_upload_run(pg_job* job, const pg_contig_batch* batches, const pg_sample_counts* samples, char* err, size_t errlen);
 /* The same for a cohort job WITHOUT stalling the device: pg_job_upload_begin starts copying the next batch of samples
  * (reference: one PanGenie run per sample re-reads its counts, src/commands.cpp:118-138) into the job's second set of
  * per-sample arrays — host threads pack the counts into a pinned staging buffer, a few large H2D copies on a copy stream of

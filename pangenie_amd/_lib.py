@@ -171,6 +171,8 @@ def _bind_hip(lib):
     lib.pg_job_n_chains.restype = C.c_uint32
     lib.pg_job_upload.argtypes = [C.c_void_p, C.POINTER(PgContigBatch), C.POINTER(PgSampleCounts), C.c_char_p, C.c_size_t]
     lib.pg_job_upload.restype = C.c_int
+    lib.pg_job_upload_run.argtypes = [C.c_void_p, C.POINTER(PgContigBatch), C.POINTER(PgSampleCounts), C.c_char_p, C.c_size_t]
+    lib.pg_job_upload_run.restype = C.c_int
     lib.pg_job_upload_begin.argtypes = [C.c_void_p, C.POINTER(PgSampleCounts), C.c_char_p, C.c_size_t]
     lib.pg_job_upload_begin.restype = C.c_int
     lib.pg_job_upload_end.argtypes = [C.c_void_p, C.c_char_p, C.c_size_t]
@@ -228,7 +230,7 @@ HIP_ABI_SYMBOLS = [
     "pg_hmm_genotype_contig", "pg_job_create", "pg_job_run", "pg_job_fetch",
     "pg_job_device_results", "pg_job_profile_counters", "pg_job_kernel_ms", "pg_job_index_ms", "pg_job_plan", "pg_job_kernel_name", "pg_job_device_bytes", "pg_job_sweep_mode",
     "pg_job_destroy", "pg_emission_table", "pg_transition_probs",
-    "pg_job_new", "pg_cohort_new", "pg_job_n_chains", "pg_job_upload", "pg_job_upload_begin", "pg_job_upload_end", "pg_job_host_seconds", "pg_job_upload_bytes",
+    "pg_job_new", "pg_cohort_new", "pg_job_n_chains", "pg_job_upload", "pg_job_upload_run", "pg_job_upload_begin", "pg_job_upload_end", "pg_job_host_seconds", "pg_job_upload_bytes",
     "pg_job_packed_results", "pg_hmm_release_cache", "pg_job_triangle_chains", "pg_job_viterbi_ms",
     "pg_comm_unique_id", "pg_comm_init", "pg_comm_init_all", "pg_comm_rank", "pg_comm_world", "pg_comm_destroy",
     "pg_hmm_gather", "pg_hmm_gather_all", "pg_hmm_gather_to_host",

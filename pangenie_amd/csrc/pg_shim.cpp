@@ -474,7 +474,7 @@ struct pg_job {
     // valid): the inputs of the LONG chains (group A: the job's wall time) are uploaded first and their preparation + phase 1
     // start while the other chains' inputs (group B, most of the bytes) are still crossing PCIe; B's index pass, preparation and
     // phase 1 then run on the second stream beside A's.  24 chromosomes x 64 paths: 27 ms of H2D in front of a 252 ms run.
-    bool pipeline = false, late_pending = false;
+    bool pipeline = false, pipeline_capable = false, late_pending = false;
     uint32_t nA = 0;
     std::vector<uint32_t> grp_order;          // chains (= index contigs: 1:1 in such jobs), group A first
     DevContig* d_contigs_g = nullptr;         // the chain descriptors in that order
@@ -632,6 +632,7 @@ int upload_inputs(pg_job* job, const pg_contig_batch* batches, const std::vector
     // (the pipelined first run needs the job's two streams to run side by side: asked once, here, where nothing is in flight)
     if (with_index && job->pipeline && !streams_concurrent(job, s)) job->pipeline = false;
     const bool pipe = with_index && job->pipeline;
+    job->pipeline = false;   // (one upload: asked for again by whoever uploads and runs inside one call)
     std::vector<char> late(job->chains.size(), 0);
     if (pipe) for (size_t k = job->nA; k < job->grp_order.size(); ++k) late[job->grp_order[k]] = 1;
     bool cur_late = false;
@@ -1510,7 +1511,7 @@ int job_build(int device, uint32_t n_index, const pg_contig_batch* batches, cons
         // of the descriptor array (no chain-id lists, no split path), with enough bytes to upload that hiding them matters.
         // Group A = the chains with at least 0.78 of the longest one's variants (they decide the wall time; the others, starting
         // later by their upload — ~10 % of a run at 40 GB/s —, still end phase 1 first), unless that is most of the bytes anyway.
-        bool ok = cache_arena && job->chunked && !cohort && n_index == n_chains && n_chains >= 2 && !job->any_split &&
+        bool ok = job->chunked && !cohort && n_index == n_chains && n_chains >= 2 && !job->any_split &&
                   params->run_genotyping && !params->run_phasing && getenv("PG_NO_PIPELINE") == nullptr;
         for (uint32_t c = 0; ok && c < n_chains; ++c) ok = job->chains[c].index == c && !job->index[c].small && !job->index[c].smallx;
         if (ok) {
@@ -1538,7 +1539,8 @@ int job_build(int device, uint32_t n_index, const pg_contig_batch* batches, cons
                     return fail(PG_ERR_DEVICE, "hipMemcpy group descriptors", he);
                 if (hipEventCreateWithFlags(&job->ev_late[0], hipEventDisableTiming) == hipSuccess && hipEventCreateWithFlags(&job->ev_late[1], hipEventDisableTiming) == hipSuccess) {
                     job->ev_late_made = true;
-                    job->pipeline = true;
+                    job->pipeline_capable = true;
+                    job->pipeline = cache_arena;   // (a resident job's first upload returns to a caller who may free the arrays: pg_job_upload_run asks for it)
                 }
             }
         }
@@ -1582,6 +1584,17 @@ extern "C" int pg_cohort_new(int device, uint32_t n_contigs, const pg_contig_bat
             specs[(size_t)s * n_contigs + c] = {c, samples[s].kmer_count[c], samples[s].coverage[c]};
     }
     return job_build(device, n_contigs, index, specs, n_samples, true, table, params, false, out, err, errlen);
+}
+
+extern "C" int pg_job_upload_run(pg_job* job, const pg_contig_batch* batches, const pg_sample_counts* samples, char* err, size_t errlen) {
+    if (!job) { set_err(err, errlen, "null job"); return PG_ERR_INVALID; }
+    // upload + run inside ONE call: the host arrays stay valid throughout, so the upload of the shorter chains may hide behind
+    // the long chains' phase 1 (pg_job::pipeline) where the job is capable of it; otherwise exactly pg_job_upload, pg_job_run
+    job->pipeline = job->pipeline_capable && batches != nullptr && getenv("PG_NO_PIPELINE") == nullptr;
+    int rc = pg_job_upload(job, batches, samples, err, errlen);
+    job->pipeline = false;
+    if (rc == PG_OK) rc = pg_job_run(job, nullptr, err, errlen);
+    return rc;
 }
 
 extern "C" int pg_job_upload(pg_job* job, const pg_contig_batch* batches, const pg_sample_counts* samples, char* err, size_t errlen) {

@@ -297,6 +297,16 @@ class Job:
         if rc:
             raise PanGenieError(rc, err.value.decode(errors="replace"))
 
+    def upload_run(self) -> None:
+        """pg_job_upload_run: re-upload every input and run, in one call (the upload of the shorter chains hides behind the long
+        chains' phase 1 where the job can do that); a plain (non-cohort) job."""
+        if self._samples is not None:
+            raise PanGenieError(-2, "upload_run: a cohort job uploads samples with upload() / upload_begin()")
+        err = C.create_string_buffer(_ERRLEN)
+        rc = self._lib.pg_job_upload_run(self.h, self._arr, None, err, _ERRLEN)
+        if rc:
+            raise PanGenieError(rc, err.value.decode(errors="replace"))
+
     def upload_begin(self, samples=None) -> None:
         """pg_job_upload_begin: start copying the next batch of samples of a cohort job into the job's second set of
         per-sample arrays while the current batch is genotyped (run()); upload_end() makes it the current one.  Fetch

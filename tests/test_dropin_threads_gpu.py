@@ -173,3 +173,27 @@ def test_merged_one_shot_job_pipelines_its_upload_behind_the_long_chains(orc, mo
         assert np.array_equal(r.lik, r2.lik) and np.array_equal(r.lik_exp, r2.lik_exp)
         assert np.array_equal(r.kept, q.kept)
         assert_parity(b, r, orc.genotype_contig(b, otable, prm if False else orc.make_params(1.26, False, 1e-5)))
+
+
+def test_upload_run_in_one_call_equals_upload_then_run(orc, monkeypatch):
+    """pg_job_upload_run on a resident job: the same bits as pg_job_upload + pg_job_run, pipelined (PG_PIPELINE_MIN_MB=0 lets
+    these small contigs take the pipelined path) or not, twice in a row."""
+    args = default_table_args()
+    table = hmm.ProbabilityTable(*args)
+    prm = hmm.make_params(1.26, False, 1e-5)
+    batches = [synthetic_panel(v, 64, 20, seed=2300 + i) for i, v in enumerate((900, 890, 300, 420, 333, 10, 505))]
+    monkeypatch.setenv("PG_PIPELINE_MIN_MB", "0")
+    job = hmm.Job(batches, table, prm)
+    assert job.sweep_mode()[0] == "chunked"
+    job.run()
+    first = job.fetch_all()
+    for _ in range(2):
+        job.upload_run()
+        piped = job.fetch_all()
+        for a, b in zip(first, piped):
+            assert np.array_equal(a.lik, b.lik) and np.array_equal(a.lik_exp, b.lik_exp) and a.n_columns == b.n_columns
+    job.upload()
+    job.run()
+    for a, b in zip(first, job.fetch_all()):
+        assert np.array_equal(a.lik, b.lik) and np.array_equal(a.lik_exp, b.lik_exp)
+    job.close()
