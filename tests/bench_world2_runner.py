@@ -68,6 +68,9 @@ class MockJob:
 
     upload_begin = upload
 
+    def upload_run(self):
+        self.run()
+
     def upload_end(self):
         pass
 
