@@ -76,7 +76,9 @@ static inline uint64_t pg_wide_entry_bytes(uint32_t n_local) {
 // posteriors of chunk i, and while all chains of a genome are still running k_post takes longer than a sweep (3.0 against
 // 2.7 ms on genome24_h64) — 6 ms of idle gaps between the 50 chunk sweeps (profiles/r05_genome24_timeline.txt); with three the
 // early deficit is worked off once the short chains have ended.
+#ifndef PG_SCRATCH_BUFS
 #define PG_SCRATCH_BUFS 3u
+#endif
 #define PG_SCR_BUF(c) ((c) % PG_SCRATCH_BUFS)
 #define PG_SYNC_NEXT 16u
 #define PG_SYNC_DONE 17u

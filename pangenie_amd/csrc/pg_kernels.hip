@@ -5888,13 +5888,35 @@ DEVI void post_ab(const DevContig& dc, uint32_t C, uint32_t c, const double* A, 
     }
 }
 
-__global__ __launch_bounds__(64 * PG_POST_WAVES) void k_post(const DevContig* __restrict__ contigs, uint32_t chunk) {
+__global__ __launch_bounds__(64 * PG_POST_WAVES) void k_post(const DevContig* __restrict__ contigs, uint32_t chunk, uint32_t n_contigs) {
     __shared__ double s_bins[PG_POST_WAVES][PG_AMAX * (PG_AMAX + 1) / 2];
-    const DevContig& dc = contigs[blockIdx.y];
     const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    // grid-stride over the columns of the chunk: the launcher may cap the number of blocks per chain so that
-    // this kernel trickles along next to the chains instead of bursting
-    for (uint32_t idx = blockIdx.x * PG_POST_WAVES + wave; idx < 2u * dc.chunk_cols; idx += gridDim.x * PG_POST_WAVES) {
+    // Grid = (blocks, 1): as many blocks as the chains leave CUs idle (the launcher), shared out over the chains that HAVE
+    // columns in this chunk — the chains of a genome end one after the other, and with a fixed share per chain (8 of the
+    // 208 idle CUs each, until round 6) the long chains' k_post ran at the sweep's own rate to the end (7 instead of 8 blocks
+    // per chain: phase 2 136 instead of 128 ms) while the blocks of chains that had ended left at once.  Lane c looks at chain
+    // c (at most 64 chains: more of them run fused, or this kernel with the y dimension as before).
+    uint32_t ci = blockIdx.y, sub = blockIdx.x, share = gridDim.x;
+    if (n_contigs) {
+        bool active = false;
+        if (lane < n_contigs) {
+            const DevContig& d = contigs[lane];
+            const uint32_t C = *d.n_cols, K = d.chunk_cols, mid = C / 2;
+            // (forward role: columns mid + chunk K ...; backward role: mid - 1 - chunk K downwards — post_column)
+            active = C > 0 && ((unsigned long long)mid + (unsigned long long)chunk * K < C || (unsigned long long)chunk * K < mid);
+        }
+        const unsigned long long am = __ballot(active);
+        const uint32_t na = (uint32_t)__popcll(am);
+        if (na == 0u) return;
+        const uint32_t rank = blockIdx.x % na;
+        sub = blockIdx.x / na;
+        share = gridDim.x / na + (rank < gridDim.x % na ? 1u : 0u);
+        unsigned long long m = am;   // the rank-th active chain (the first ones — the long chromosomes of a genome — get the odd blocks)
+        for (uint32_t r = 0; r < rank; ++r) m &= m - 1ull;
+        ci = (uint32_t)__builtin_ctzll(m);
+    }
+    const DevContig& dc = contigs[ci];
+    for (uint32_t idx = sub * PG_POST_WAVES + wave; idx < 2u * dc.chunk_cols; idx += share * PG_POST_WAVES) {
         post_column(dc, chunk, (uint32_t)__builtin_amdgcn_readfirstlane((int)idx), wave, lane, s_bins);
         wave_sync_lds();   // (the wave's s_bins row is reused by its next column; its global stores need no wait)
     }
@@ -6281,14 +6303,26 @@ uint32_t pgk_post_blocks(uint32_t n_contigs, uint32_t chunk_cols, uint32_t* cus_
     const uint32_t cap = idle > (int)n_contigs ? (uint32_t)(idle / (int)n_contigs) : 1u;
     uint32_t bx = (2u * chunk_cols + PG_POST_WAVES - 1u) / PG_POST_WAVES;
     if (bx > cap) bx = cap;
+    if (const char* e = getenv("PG_POST_BLOCKS")) { const long v = strtol(e, nullptr, 0); if (v >= 1 && (uint32_t)v < bx) bx = (uint32_t)v; }   // (experiments: fewer)
     return bx ? bx : 1u;
 }
 void pgk_launch_post(const DevContig* d_contigs, uint32_t n_contigs, uint32_t chunk_cols, uint32_t chunk, hipStream_t s) {
     static bool attr_done[PG_MAX_DEVICES];
     if (lds_attr_pending(attr_done))
         (void)hipFuncSetAttribute((const void*)k_post, hipFuncAttributeMaxDynamicSharedMemorySize, PG_POST_PLACEMENT_LDS);
-    dim3 grid(pgk_post_blocks(n_contigs, chunk_cols, nullptr), n_contigs);
-    hipLaunchKernelGGL(k_post, grid, dim3(64 * PG_POST_WAVES), PG_POST_PLACEMENT_LDS, s, d_contigs, chunk);
+    // (blocks = the CUs the chains leave idle, shared out inside the kernel over the chains that have columns in this chunk)
+    const uint32_t per_chain = pgk_post_blocks(n_contigs, chunk_cols, nullptr);
+    if (n_contigs <= 64u && getenv("PG_POST_FIXED") == nullptr) {
+        uint32_t cus = 0;
+        (void)pgk_post_blocks(n_contigs, chunk_cols, &cus);
+        uint32_t total = cus > 2u * n_contigs + n_contigs ? cus - 2u * n_contigs : n_contigs;
+        if (const char* e = getenv("PG_POST_BLOCKS")) { const long v = strtol(e, nullptr, 0); if (v >= 1) total = std::min<uint32_t>(total, (uint32_t)v * n_contigs); }
+        const uint32_t most = ((2u * chunk_cols + PG_POST_WAVES - 1u) / PG_POST_WAVES) * n_contigs;
+        if (total > most) total = most;
+        hipLaunchKernelGGL(k_post, dim3(total, 1), dim3(64 * PG_POST_WAVES), PG_POST_PLACEMENT_LDS, s, d_contigs, chunk, n_contigs);
+    } else {
+        hipLaunchKernelGGL(k_post, dim3(per_chain, n_contigs), dim3(64 * PG_POST_WAVES), PG_POST_PLACEMENT_LDS, s, d_contigs, chunk, 0u);
+    }
 }
 // Do kernels on two streams really run side by side?  HIP maps streams onto a handful of hardware queues; two streams that share
 // one run their kernels one after the other, and the persistent phase 2 (whose kernels wait for each other) would stall until its
