@@ -1101,8 +1101,12 @@ int job_build(int device, uint32_t n_index, const pg_contig_batch* batches, cons
             if (kc.leanx != 1) for (auto& x : job->index) x.leanx = false;
         }
         if (job->chunked) {
-            size_t k = 4096;
-            const size_t budget = (size_t)18 << 30;   // (three buffers: 4096 columns for the 24 chains of a whole genome at 64 paths)
+            // 8192 columns per chunk (round 6; 4096 before): 25 chunk rounds instead of 50 on the whole genome.  With k_post no longer
+            // the bound (post_lean64, the idle CUs shared out over the chains still running) what a chunk round costs beyond its columns
+            // is its launches and resume prologues, and how much THAT is varies from box to box: 4096 / 6144 / 8192 / 12288 columns:
+            // 128.7 / 128.5 / 126.9 / - ms of phase 2 on one box, 133.8 / 127.8 / 127.9 / 127.5 on another (profiles/r06_persist.txt 8).
+            size_t k = 8192;
+            const size_t budget = (size_t)39 << 30;   // (three buffers: 8192 columns for the 24 chains of a whole genome at 64 paths)
             if (per_col * k > budget) k = budget / per_col;
             if (const char* e = getenv("PG_CHUNK_COLS")) { const long v = strtol(e, nullptr, 0); if (v > 0) k = (size_t)v; }
             if (chunk_cap && k > chunk_cap) k = chunk_cap;
