@@ -18,6 +18,9 @@ OUT=$R/gpurun_out/${TAG}_$W
 mkdir -p $OUT $R/gpurun_out/profiles
 cd /tmp && export TMPDIR=/tmp
 cd $R
+# (the bench's end-to-end rounds run pg_job_upload_run, which splits phase 1 into two launches — the long chains' and the others' —:
+#  the per-kernel AVERAGES of a profile would then mix whole and partial launches; profiled runs take the sequential path)
+export PG_NO_PIPELINE=1
 case $W in
   cohort_h64) CMD="python bench.py --steps 3 --warmup 1 --cohort-only --no-cpu-baseline --no-sampler" ;;
   cohort_*|panels_h16)   CMD="python bench.py --steps 3 --warmup 1 --cohort-only --cohort-key $W --no-cpu-baseline --no-sampler" ;;
