@@ -3,7 +3,8 @@ sizes, narrow and wide columns, regularised and unregularised tables — HIP pat
 usage: python tools/soak_parity.py [n_panels] [seed0]   (80 panels: about two minutes)
 SOAK_TRI=1: only all-biallelic H = 64 panels in fused mode (triangle storage, k_sweep_lean2), from 1 variant up.
 SOAK_X=1: only 16-path panels on k_sweep_small16[x] (PG_KERNELS=small[,nosmall2]): multiallelic and wide objects (6-12 alleles of
-which the sixteen paths carry up to nine), both sweep modes."""
+which the sixteen paths carry up to nine), both sweep modes.
+SOAK_PERSIST=1: only all-biallelic H = 64 panels in chunked mode on the persistent phase-2 pair (PG_KERNELS=persist), even chunk sizes."""
 import os, sys, time
 sys.path.insert(0, os.getcwd())
 import numpy as np
@@ -28,6 +29,10 @@ for it in range(n):
     if os.environ.get("SOAK_TRI") == "1":
         H, wide = 64, False
         V = int(rng.choice([1, 2, 3, 4, 5, 7, 64, 65, 129, int(rng.integers(6, 900))]))
+        kw.update(multiallelic_frac=0.0)
+    if os.environ.get("SOAK_PERSIST") == "1":
+        H, wide = 64, False
+        V = int(rng.choice([1, 2, 3, 5, 64, 65, 129, 257, int(rng.integers(6, 900)), int(rng.integers(6, 900))]))
         kw.update(multiallelic_frac=0.0)
     if os.environ.get("SOAK_X") == "1":
         H, wide = 16, False
@@ -58,6 +63,10 @@ for it in range(n):
     else:
         os.environ.pop("PG_KERNELS", None)
     os.environ["PG_CHUNK_COLS"] = str(int(rng.choice([1, 3, 16, 64, 4096])))
+    if os.environ.get("SOAK_PERSIST") == "1":
+        os.environ["PG_SWEEP_MODE"] = mode = "chunked"
+        os.environ["PG_KERNELS"] = kern = "persist"
+        os.environ["PG_CHUNK_COLS"] = str(int(rng.choice([2, 16, 64, 4096])))
     res = hmm.genotype_contig(b, hmm.ProbabilityTable(*args), hmm.make_params(recomb, uniform, N))
     ref = orc.genotype_contig(b, orc.OracleTable(*args), orc.make_params(recomb, uniform, N))
     try:
