@@ -237,6 +237,10 @@ struct DevContig {
     // take the posterior sums over the stored half alone and k_bins doubles them: half the HBM bytes written by
     // phase 1 and read by phase 2
     uint32_t  tri;
+    // 1 (tri == 1 and the chain is not a lean chain: 64 paths, multiallelic objects, fused job): phase 2 on k_sweep_leanx2 — the
+    // posterior partials leave added up over the four waves, T = 64 entries per column and slot pair (PG_KERNELS=noleanx2: the
+    // general kernel's triangle ring, T = 256)
+    uint32_t  leanx2;
     // 1: every object of the chain is biallelic and H = HP = 16: the store-only phases run on k_sweep_small16 (four
     // half-chains per wave); the chain keeps its compact records (frec) next to the full ones
     // 2 (fused jobs, with cls4): phase 2 runs there too — partner columns prefetched into registers three steps ahead, the four

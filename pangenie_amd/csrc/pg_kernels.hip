@@ -2798,6 +2798,7 @@ __global__ __launch_bounds__((ChainCfg<HP, R, sweep_has_loader<HP, PHASE>()>::TT
     if (dc.HP != (uint32_t)HP) return;
     if (dc.split) return;   // the split path: k_sweep_small16[x] both phases; a chain left with one column needs no sweep (k_bins_s)
     if (PHASE != 2 && (dc.lean || dc.small || dc.smallx || dc.leanx)) return;  // store-only phases of all-biallelic H = 64 / H = 16 chains: k_sweep_lean / k_sweep_small16[x]
+    if (PHASE == 2 && dc.leanx2) return;   // 64-path triangle chains with multiallelic objects: k_sweep_leanx2
     // (written by k_compact: a vector load as far as the compiler knows — make the trip count, and
     // with it every column index, ring slot and address derived from it, wave-uniform again)
     const uint32_t C = (uint32_t)__builtin_amdgcn_readfirstlane((int)*dc.n_cols);
@@ -4530,6 +4531,381 @@ DEVI void leanx_backward(const DevContig& dc, LxShared<HP>& sh, uint32_t C, uint
     if (wave == 2 && bsm.valid) bsm.flush(bsum, lane, (uint64_t)bot);
 }
 
+// ------------------------------------------------------------------------------------------
+//  k_sweep_leanx2 (round 6): PHASE 2 of the 64-path triangle chains of fused jobs WITH multiallelic objects (DevContig::leanx2) —
+//  k_sweep_lean2's design (no loader waves, no LDS ring: every thread fetches its own units of the compact partner column two
+//  columns ahead into registers, three buffers rotating through a three-step loop body; the four waves' posterior partials
+//  added up through LDS on the step's barrier before they leave) on the lean-x step (emissions from the column's 6 x 6 table in
+//  LDS, records in blocks of sixteen).  The products P' beta' are added by ROW allele with exact 0 / 1 multipliers that are
+//  scalar operands (a row's allele is the same in every lane): two accumulators for a column with at most two local alleles
+//  (four columns in five), five otherwise — a uniform branch around the state loop.  Out: 64 entries per column and slot pair
+//  (DevContig::T = 64), what k_bins reads — 3 KB of a multiallelic column instead of the 12 KB of per-thread partials the general
+//  kernel's triangle ring wrote (21 GB per step on cohort_h64m, read back by k_bins).
+//  Until round 6 these chains ran phase 2 on the general kernel: one workgroup per CU (the ring takes the LDS), 0.45 of the HBM peak.
+// ------------------------------------------------------------------------------------------
+#define PG_LX2_PAIRS ((PG_AMAX + 1) / 2)
+#ifndef PG_LX2_TWO
+#define PG_LX2_TWO 1   // columns with at most two local alleles add into two accumulators (0: five for every column)
+#endif
+#ifndef PG_LX2_EW
+#define PG_LX2_EW 4   // emissions of a column in flight (LDS reads issued this many states ahead of their use)
+#endif
+struct LxShared2 {
+    LxShared<64> a;
+    v2f64 pp[2][4][PG_LX2_PAIRS][64];   // posterior partials {row allele 2q, 2q + 1} per wave and lane, by column parity
+};
+// (behind the barrier that follows the step of column c) wave q: slot pair q of column c, the four waves' partials added, 64 entries out
+DEVI void lx2_flush(const LxShared2& sh, uint32_t pb, gdouble* part, uint32_t part_slots, size_t c, uint32_t nl, uint32_t wave, uint32_t lane) {
+    if (wave >= (uint32_t)PG_LX2_PAIRS || 2u * wave >= nl) return;
+    v2f64 t = sh.pp[pb][0][wave][lane];
+#pragma unroll
+    for (int w = 1; w < 4; ++w) { const v2f64 o = sh.pp[pb][w][wave][lane]; t.x += o.x; t.y += o.y; }
+    ((gdouble2*)part)[(c * (size_t)(part_slots >> 1) + wave) * 64u + lane] = t;
+}
+// what a step needs of its OWN column beyond the emissions: the sixteen row offsets of the wave's rows (a * 48, uniform), the
+// lane's table column, the number of local alleles — read from the LDS record a step ahead and carried
+struct Lx2Col { uint32_t rows[4]; uint32_t ecol; uint32_t nl; };
+DEVI Lx2Col lx2_col(const LxShared<64>& sh, uint32_t rel, uint32_t lane, uint32_t i0) {
+    const LxAlleles<16> a = lx_alleles<64>(sh, rel, lane, i0);
+    Lx2Col c;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) c.rows[q] = a.rows[q];
+    c.ecol = lx_ecol<64>(sh, rel, a.col8);
+    c.nl = lx_rec<64>(sh, rel)[PG_REC_NLOCAL];
+    return c;
+}
+template <int K>
+DEVI double lx2_emission(const Lx2Col& c) { return *(LAS const double*)(uintptr_t)add_byte<(K & 3)>(c.rows[K >> 2], c.ecol); }
+// one state's product into the accumulators of its row's allele (ro = the row's table-row offset a * 48; 5 * 48 = a phantom path: none)
+template <int NA>
+DEVI void lx2_add(double (&acc)[2 * PG_LX2_PAIRS], double pr, uint32_t ro /*uniform*/) {
+#pragma unroll
+    for (int a = 0; a < NA; ++a) acc[a] = fma(pr, ro == (uint32_t)(a * PG_ESTRIDE * 8) ? 1.0 : 0.0, acc[a]);
+}
+
+DEVI void leanx2_forward(const DevContig& dc, LxShared2& sh2, uint32_t C) {
+    constexpr int R = 16, BLK = LxCfg<64>::BLK, PPT = LxCfg<64>::PPT;
+    LxShared<64>& sh = sh2.a;
+    const uint32_t mid = C / 2, lo = mid, hi = C, first = lo == 0 ? 1u : lo;   // (C == 1: lo = 0, the one column is the prologue's)
+    const uint32_t tid = threadIdx.x, lane = tid & 63u;
+    const uint32_t wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const uint32_t i0 = wave * R, H = dc.H;
+    const size_t colsz = dc.col_stride;   // compact triangles
+    const double unif = 1.0 / ((double)H * (double)H);
+    LxRecs<64> recs{(const GAS char*)dc.colrec, (int64_t)first - 1, (int64_t)C, +1, tid};
+    v2f64 piece[PPT];
+#pragma unroll
+    for (int p = 0; p < PPT; ++p) recs.park(sh, 0, p, recs.fetch(0, p));
+#pragma unroll
+    for (int p = 0; p < PPT; ++p) piece[p] = recs.fetch(1, p);
+    lds_barrier();
+    lx_transform<64>(sh, 0, tid);
+    lds_barrier();
+    gcdouble* cols = (gcdouble*)dc.fwd;
+    gdouble* fscale = (gdouble*)dc.fscale;
+    gu8* fallback = (gu8*)dc.fwd_fallback;
+    gdouble* part = (gdouble*)dc.part;
+    const uint32_t part_slots = dc.part_slots;
+    LeanTri<R> tri;
+    tri.setup(i0, lane);
+    double b0[R], b1[R], b2[R];   // partner columns beta'_t, two ahead of their use
+#pragma unroll
+    for (int k = 0; k < R; ++k) { b0[k] = 0.0; b1[k] = 0.0; b2[k] = 0.0; }
+    tri.load(cols + (size_t)lo * colsz, b0);
+    if (lo + 1 < C) tri.load(cols + (size_t)(lo + 1) * colsz, b1);
+
+    ColScalars fsc{&sh.scal[0][0]};
+    double x[R];
+    uint32_t pnl = 0;   // local alleles of the column whose partials are pending
+    if (lo == 0) {
+        // C == 1: column 0 IS the chain: v_0 = e_0 2^BIAS_F, its partner the backward role's beta'_0 (phase 1); no step follows
+        const Lx2Col c0 = lx2_col(sh, 0, lane, i0);
+        const double P0 = ldexp(1.0, PG_BIAS_F);
+        double acc[2 * PG_LX2_PAIRS];
+#pragma unroll
+        for (int a = 0; a < 2 * PG_LX2_PAIRS; ++a) acc[a] = 0.0;
+        uint32_t rw[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) rw[q] = (uint32_t)__builtin_amdgcn_readfirstlane((int)c0.rows[q]);
+        double part0 = 0.0;
+        static_for<0, R>([&](auto kc) __attribute__((always_inline)) {
+            constexpr int k = decltype(kc)::value;
+            part0 += lx2_emission<k>(c0) * P0;
+            lx2_add<PG_AMAX>(acc, P0 * b0[k], (rw[k >> 2] >> (8 * (k & 3))) & 0xFFu);
+        });
+        sh.psum[0][wave][lane] = part0;
+#pragma unroll
+        for (int q = 0; q < PG_LX2_PAIRS; ++q) sh2.pp[0][wave][q][lane] = v2f64{acc[2 * q], acc[2 * q + 1]};
+        if (tid == 0) fscale[0] = 1.0;
+        lds_barrier();
+        lx2_flush(sh2, 0, part, part_slots, 0, (uint32_t)__builtin_amdgcn_readfirstlane((int)c0.nl), wave, lane);
+        const double Cj = (sh.psum[0][0][lane] + sh.psum[0][1][lane]) + (sh.psum[0][2][lane] + sh.psum[0][3][lane]);
+        if (!(wave_total_mfma(Cj) > 0.0) && tid == 0) fallback[0] = 1;
+        return;
+    }
+    {
+        const Lx2Col cp = lx2_col(sh, 0, lane, i0);   // column lo - 1: its emission makes x of the stored P'
+        lean_load_mirrored<R>(cols + (size_t)(lo - 1) * colsz, i0, lane, x);   // P'_{lo-1}, stored by phase 1 of this role
+        const bool was_uniform = fallback[lo - 1] != 0;
+        double part0 = 0.0;
+        static_for<0, R>([&](auto kc) __attribute__((always_inline)) {
+            constexpr int k = decltype(kc)::value;
+            if (!was_uniform) x[k] *= lx2_emission<k>(cp);
+            part0 += x[k];
+        });
+        sh.psum[(first - 1) & 1u][wave][lane] = part0;
+    }
+    LxConsts cur = lx_consts<64>(sh, 1);      // column `first`: constants of the gap first-1 -> first
+    Lx2Col col = lx2_col(sh, 1, lane, i0);    // ... its alleles, table column, allele count
+    // One column step (lean2_forward's, with table emissions): `ba` = the partner column beta'_t, `bc` takes beta'_{t+2}
+    auto step = [&](uint32_t t, const double (&ba)[R], double (&bc)[R]) __attribute__((always_inline)) {
+        const uint32_t n = t - first;   // column t is the record with rel = n + 1
+        if (((n + 4u) % (uint32_t)BLK) == 0u) {
+            const uint32_t blk = (n + 4u) / (uint32_t)BLK;
+#pragma unroll
+            for (int p = 0; p < PPT; ++p) { recs.park(sh, blk, p, piece[p]); piece[p] = recs.fetch(blk + 1u, p); }
+        } else if (((n + 3u) % (uint32_t)BLK) == 0u) {
+            lx_transform<64>(sh, (n + 3u) / (uint32_t)BLK, tid);   // the block parked a step ago (a barrier lies between)
+        }
+        if (t + 2 < C) tri.load(cols + (size_t)(t + 2) * colsz, bc);   // two columns ahead (bc was last read a step ago)
+        if (t > first) lx2_flush(sh2, (t - 1) & 1u, part, part_slots, (size_t)(t - 1), pnl, wave, lane);
+        const uint32_t pb = (t - 1) & 1u;
+        const double Cj = (sh.psum[pb][0][lane] + sh.psum[pb][1][lane]) + (sh.psum[pb][2][lane] + sh.psum[pb][3][lane]);
+        const uint32_t ri = i0 + (lane & 15u);
+        const double Cr = (sh.psum[pb][0][ri] + sh.psum[pb][1][ri]) + (sh.psum[pb][2][ri] + sh.psum[pb][3][ri]);
+        const double ucol = cur.c1 * Cj;
+        const double urep = dpp_source(cur.c1 * Cr);   // u_i of row i0 + (lane & 15): the DPP source
+        const LxConsts cnx = lx_consts<64>(sh, n + 2u);
+        const Lx2Col coln = lx2_col(sh, n + 2u, lane, i0);   // the next column's, a step ahead
+        const v4f64 zz = {0.0, 0.0, 0.0, 0.0};
+        const v4f64 ma = __builtin_amdgcn_mfma_f64_16x16x4f64(Cj, 1.0, zz, 0, 0, 0);
+        double S = __builtin_amdgcn_mfma_f64_16x16x4f64((ma[0] + ma[1]) + (ma[2] + ma[3]), 1.0, zz, 0, 0, 0)[0];
+        double uj = fma(cur.c2, S, ucol);
+        double c0 = cur.c0;
+        if (__builtin_expect(!(S > 0.0), 0)) {
+            // column t-1 summed to zero: the uniform column takes its place (hmm.cpp:253-267); its own partials were formed from
+            // the all-zero column — k_bins re-forms those bins from the flag
+            if (tid == 0) fallback[t - 1] = 1;
+            const double Cu = (double)H * unif;
+            S = 1.0;
+            uj = fma(cur.c0, unif, fma(cur.c2, 1.0, 2.0 * cur.c1 * Cu));
+            c0 = 0.0;
+        }
+        int es = exponent_of(S) - PG_BIAS_F;
+        es = es < -900 ? -900 : es;
+        const double m = ldexp(S, -es - PG_BIAS_F);
+        const double sc = ldexp(1.0, -es), c0s = ldexp(c0, -es), ujs = ldexp(uj, -es);
+        uint32_t rw[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) rw[q] = (uint32_t)__builtin_amdgcn_readfirstlane((int)col.rows[q]);
+        const uint32_t nl = (uint32_t)__builtin_amdgcn_readfirstlane((int)col.nl);
+        double part0 = 0.0, acc[2 * PG_LX2_PAIRS];
+#pragma unroll
+        for (int a = 0; a < 2 * PG_LX2_PAIRS; ++a) acc[a] = 0.0;
+        auto states = [&](auto na_c) __attribute__((always_inline)) {
+            constexpr int NA = decltype(na_c)::value;
+            double ew[PG_LX2_EW];   // emissions of the column, a few states ahead of their use
+            static_for<0, PG_LX2_EW>([&](auto kc) __attribute__((always_inline)) { constexpr int k = decltype(kc)::value; ew[k] = lx2_emission<k>(col); });
+            static_for<0, R>([&](auto kc) __attribute__((always_inline)) {
+                constexpr int k = decltype(kc)::value;
+                const double e = ew[k % PG_LX2_EW];
+                if constexpr (k + PG_LX2_EW < R) ew[k % PG_LX2_EW] = lx2_emission<k + PG_LX2_EW>(col);
+                const double pk = fmac_row_bcast<k>(fma(c0s, x[k], ujs), urep, sc);   // P'_t = c0 x + u_j + u_i
+                x[k] = pk * e;
+                part0 += x[k];
+                lx2_add<NA>(acc, pk * ba[k], (rw[k >> 2] >> (8 * (k & 3))) & 0xFFu);   // P'_t beta'_t (0 below the stored half)
+                if constexpr ((k & 3) == 3) __builtin_amdgcn_sched_barrier(0);
+            });
+        };
+        if (PG_LX2_TWO && nl <= 2u) states(std::integral_constant<int, 2>{});
+        else states(std::integral_constant<int, PG_AMAX>{});
+        sh.psum[t & 1u][wave][lane] = part0;
+#pragma unroll
+        for (int q = 0; q < PG_LX2_PAIRS; ++q)
+            if ((uint32_t)(2 * q) < nl) sh2.pp[t & 1u][wave][q][lane] = v2f64{acc[2 * q], acc[2 * q + 1]};
+        if (wave == 0) {
+            fsc.put(lane, t, m);
+            if ((t & 63u) == 63u) fsc.flush(fscale, lane, t);
+        }
+        pnl = nl; cur = cnx; col = coln;
+        lds_barrier();
+    };
+    __builtin_amdgcn_s_waitcnt(0x0F70);   // (see lean_forward)
+    lds_barrier();
+    {
+        uint32_t t = first;
+        for (; t + 2 < hi; t += 3) {
+            step(t, b0, b2);
+            step(t + 1, b1, b0);
+            step(t + 2, b2, b1);
+        }
+        if (t < hi) step(t, b0, b2);
+        if (t + 1 < hi) step(t + 1, b1, b0);
+    }
+    lx2_flush(sh2, (hi - 1) & 1u, part, part_slots, (size_t)(hi - 1), pnl, wave, lane);
+    if (wave == 0 && fsc.valid) fsc.flush(fscale, lane, hi - 1);
+    {   // the last column may itself have summed to zero
+        const uint32_t pb = (hi - 1) & 1u;
+        const double Cj = (sh.psum[pb][0][lane] + sh.psum[pb][1][lane]) + (sh.psum[pb][2][lane] + sh.psum[pb][3][lane]);
+        if (!(wave_total_mfma(Cj) > 0.0) && tid == 0) fallback[hi - 1] = 1;
+    }
+}
+
+DEVI void leanx2_backward(const DevContig& dc, LxShared2& sh2, uint32_t C) {
+    constexpr int R = 16, BLK = LxCfg<64>::BLK, PPT = LxCfg<64>::PPT;
+    LxShared<64>& sh = sh2.a;
+    const int64_t mid = C / 2, top = mid - 1, bot = 0, t0 = top;
+    if (top < 0) return;   // (C == 1: the forward role has the one column)
+    const uint32_t tid = threadIdx.x, lane = tid & 63u;
+    const uint32_t wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const uint32_t i0 = wave * R, H = dc.H;
+    const size_t colsz = dc.col_stride;
+    const double unif = 1.0 / ((double)H * (double)H);
+    LxRecs<64> recs{(const GAS char*)dc.colrec, t0 + 1, (int64_t)C, -1, tid};   // rel r = column t0 + 1 - r
+    v2f64 piece[PPT];
+#pragma unroll
+    for (int p = 0; p < PPT; ++p) recs.park(sh, 0, p, recs.fetch(0, p));
+#pragma unroll
+    for (int p = 0; p < PPT; ++p) piece[p] = recs.fetch(1, p);
+    lds_barrier();
+    lx_transform<64>(sh, 0, tid);
+    lds_barrier();
+    gcdouble* cols = (gcdouble*)dc.fwd;
+    gdouble* bscale = (gdouble*)dc.bscale;
+    gcdouble* bsum = (gcdouble*)dc.bsum;
+    gdouble* part = (gdouble*)dc.part;
+    const uint32_t part_slots = dc.part_slots;
+    LeanTri<R> tri;
+    tri.setup(i0, lane);
+    double b0[R], b1[R], b2[R];   // partner columns P'_t (forward, stored by phase 1), two ahead of their use
+#pragma unroll
+    for (int k = 0; k < R; ++k) { b0[k] = 0.0; b1[k] = 0.0; b2[k] = 0.0; }
+    tri.load(cols + (size_t)t0 * colsz, b0);
+    if (t0 - 1 >= 0) tri.load(cols + (size_t)(t0 - 1) * colsz, b1);
+
+    ColScalars bsc{&sh.scal[0][0]};
+    double w[R], Sy;
+    {
+        double y[R];
+        lean_load_mirrored<R>(cols + (size_t)(top + 1) * colsz, i0, lane, y);   // beta'_{mid}, stored by phase 1 of this role
+        Sy = bsum[top + 1];
+        if (!(Sy > 0.0)) {   // resuming behind an all-zero column: uniform (hmm.cpp:374-380)
+#pragma unroll
+            for (int k = 0; k < R; ++k) y[k] = (lane < H && i0 + (uint32_t)k < H) ? unif : 0.0;
+            Sy = 1.0;
+        }
+        const Lx2Col c1 = lx2_col(sh, 0, lane, i0);   // column t0 + 1: its emission goes into the first w
+        double part0 = 0.0;
+        static_for<0, R>([&](auto kc) __attribute__((always_inline)) {
+            constexpr int k = decltype(kc)::value;
+            w[k] = y[k] * lx2_emission<k>(c1);
+            part0 += w[k];
+        });
+        sh.psum[(uint32_t)t0 & 1u][wave][lane] = part0;
+    }
+    LxConsts cur = lx_consts<64>(sh, 0);      // constants of the gap t0 -> t0 + 1
+    Lx2Col col = lx2_col(sh, 1, lane, i0);    // column t0: alleles, table column, allele count
+    uint32_t pnl = 0;
+    double one = 1.0;   // (in a register: the DPP form of v_fmac_f64 takes no constant)
+    asm volatile("" : "+v"(one));
+    auto step = [&](int64_t t, const double (&ba)[R], double (&bc)[R]) __attribute__((always_inline)) {
+        const uint32_t n = (uint32_t)(t0 - t);   // column t is the record with rel = n + 1
+        if (((n + 4u) % (uint32_t)BLK) == 0u) {
+            const uint32_t blk = (n + 4u) / (uint32_t)BLK;
+#pragma unroll
+            for (int p = 0; p < PPT; ++p) { recs.park(sh, blk, p, piece[p]); piece[p] = recs.fetch(blk + 1u, p); }
+        } else if (((n + 3u) % (uint32_t)BLK) == 0u) {
+            lx_transform<64>(sh, (n + 3u) / (uint32_t)BLK, tid);
+        }
+        if (t - 2 >= 0) tri.load(cols + (size_t)(t - 2) * colsz, bc);
+        int es = exponent_of(Sy) - PG_BIAS_B;
+        es = es < -900 ? -900 : es;
+        const double m = ldexp(Sy, -es - PG_BIAS_B);
+        if (wave == 0) bsc.put(lane, (uint64_t)t, m);
+        const double k0 = ldexp(cur.c0, -es), k1 = ldexp(cur.c1, -es), k2 = ldexp(cur.c2, -es), kap = ldexp(cur.kappa, -es);
+        lds_barrier();
+        const LxConsts cnx = lx_consts<64>(sh, n + 1u);        // next step: the gap t-1 -> t = record t
+        const Lx2Col coln = lx2_col(sh, n + 2u, lane, i0);     // ... and column t-1
+        if (t < t0) lx2_flush(sh2, (uint32_t)(t + 1) & 1u, part, part_slots, (size_t)(t + 1), pnl, wave, lane);
+        const uint32_t pb = (uint32_t)t & 1u;
+        const double Cj = (sh.psum[pb][0][lane] + sh.psum[pb][1][lane]) + (sh.psum[pb][2][lane] + sh.psum[pb][3][lane]);
+        const uint32_t ri = i0 + (lane & 15u);
+        const double Cr = (sh.psum[pb][0][ri] + sh.psum[pb][1][ri]) + (sh.psum[pb][2][ri] + sh.psum[pb][3][ri]);
+        const double ucol = k1 * Cj;
+        const double urep = dpp_source(k1 * Cr);
+        const v4f64 zz = {0.0, 0.0, 0.0, 0.0};
+        const v4f64 ma = __builtin_amdgcn_mfma_f64_16x16x4f64(Cj, 1.0, zz, 0, 0, 0);
+        const double Sw = __builtin_amdgcn_mfma_f64_16x16x4f64((ma[0] + ma[1]) + (ma[2] + ma[3]), 1.0, zz, 0, 0, 0)[0];
+        const double uj = fma(k2, Sw, ucol);
+        const double Snew = kap * Sw;   // = sum(beta'_t)
+        uint32_t rw[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) rw[q] = (uint32_t)__builtin_amdgcn_readfirstlane((int)col.rows[q]);
+        const uint32_t nl = (uint32_t)__builtin_amdgcn_readfirstlane((int)col.nl);
+        double part0 = 0.0, acc[2 * PG_LX2_PAIRS];
+#pragma unroll
+        for (int a = 0; a < 2 * PG_LX2_PAIRS; ++a) acc[a] = 0.0;
+        if (__builtin_expect(!(Snew > 0.0), 0)) {
+            // beta~_t is all zero: its own posteriors are 0, the next step starts from the uniform column (phantom paths: emission 0)
+            static_for<0, R>([&](auto kc) __attribute__((always_inline)) {
+                constexpr int k = decltype(kc)::value;
+                w[k] = unif * lx2_emission<k>(col);
+                part0 += w[k];
+            });
+        } else {
+            auto states = [&](auto na_c) __attribute__((always_inline)) {
+                constexpr int NA = decltype(na_c)::value;
+                double ew[PG_LX2_EW];
+                static_for<0, PG_LX2_EW>([&](auto kc) __attribute__((always_inline)) { constexpr int k = decltype(kc)::value; ew[k] = lx2_emission<k>(col); });
+                static_for<0, R>([&](auto kc) __attribute__((always_inline)) {
+                    constexpr int k = decltype(kc)::value;
+                    const double e = ew[k % PG_LX2_EW];
+                    if constexpr (k + PG_LX2_EW < R) ew[k % PG_LX2_EW] = lx2_emission<k + PG_LX2_EW>(col);
+                    const double yk = fmac_row_bcast<k>(fma(k0, w[k], uj), urep, one);   // beta'_t = k0 w + u_j + u_i
+                    w[k] = yk * e;
+                    part0 += w[k];
+                    lx2_add<NA>(acc, ba[k] * yk, (rw[k >> 2] >> (8 * (k & 3))) & 0xFFu);   // P'_t beta'_t
+                    if constexpr ((k & 3) == 3) __builtin_amdgcn_sched_barrier(0);
+                });
+            };
+            if (PG_LX2_TWO && nl <= 2u) states(std::integral_constant<int, 2>{});
+            else states(std::integral_constant<int, PG_AMAX>{});
+        }
+        sh.psum[(uint32_t)(t - 1) & 1u][wave][lane] = part0;
+#pragma unroll
+        for (int q = 0; q < PG_LX2_PAIRS; ++q)
+            if ((uint32_t)(2 * q) < nl) sh2.pp[(uint32_t)t & 1u][wave][q][lane] = v2f64{acc[2 * q], acc[2 * q + 1]};
+        if (wave == 0 && ((uint64_t)t & 63u) == 0u) bsc.flush(bscale, lane, (uint64_t)t);
+        Sy = Snew > 0.0 ? Snew : 1.0;
+        pnl = nl; cur = cnx; col = coln;
+    };
+    __builtin_amdgcn_s_waitcnt(0x0F70);
+    {
+        int64_t t = t0;
+        for (; t - 2 >= bot; t -= 3) {
+            step(t, b0, b2);
+            step(t - 1, b1, b0);
+            step(t - 2, b2, b1);
+        }
+        if (t >= bot) step(t, b0, b2);
+        if (t - 1 >= bot) step(t - 1, b1, b0);
+    }
+    lds_barrier();
+    lx2_flush(sh2, (uint32_t)bot & 1u, part, part_slots, (size_t)bot, pnl, wave, lane);
+    if (wave == 0 && bsc.valid) bsc.flush(bscale, lane, (uint64_t)bot);
+}
+
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2)))   // two workgroups per CU: <= 256 registers per lane
+void k_sweep_leanx2(const DevContig* __restrict__ contigs) {
+    __shared__ LxShared2 sh;
+    const DevContig& dc = contigs[blockIdx.x];
+    if (!dc.leanx2 || dc.HP != 64u || dc.tri != 1u) return;
+    const uint32_t C = (uint32_t)__builtin_amdgcn_readfirstlane((int)*dc.n_cols);
+    if (C == 0) return;
+    if (blockIdx.y == 0) leanx2_forward(dc, sh, C);
+    else leanx2_backward(dc, sh, C);
+}
+
 // phase 1 of the 64-path chains of fused jobs with multiallelic objects (DevContig::tri == 1, leanx == 2): the lean-x step with
 // triangle stores (phase 2: the general kernel's triangle ring)
 __global__ __launch_bounds__((LxCfg<64>::T)) void k_sweep_leanx_tri(const DevContig* __restrict__ contigs) {
@@ -5300,6 +5676,7 @@ DEVI void bins_unit(const DevContig& dc, uint32_t unit, double (&s_bins)[4][PG_A
     if ((dc.tri == 2u && C >= 2u) || dc.cls4) return;  // chains whose class sums arrive finished (k_sweep_lean2, DevContig::cls4): k_bins_lean2
     if (bins_x(dc, C)) return;                           // chains on k_sweep_small16x<2>: k_bins_x, k_bins_wide
     if (bins_thin(dc)) return;                           // few partial entries per column: k_bins_thin
+    if (dc.leanx2) return;                               // chains on k_sweep_leanx2 (64 entries per column and slot pair): k_bins_q
     // (chains with compact records only have no column-order copy of the records: the variant's own record)
     const bool direct = compact_records_only(dc, C);
     const unsigned char* rec = direct ? dc.vrec + (size_t)dc.col_variant[c] * dc.RB : dc.colrec + (size_t)c * dc.RB;
@@ -5401,6 +5778,109 @@ DEVI void bins_unit(const DevContig& dc, uint32_t unit, double (&s_bins)[4][PG_A
         }
     }
 }
+// ------------------------------------------------------------------------------------------
+//  k_bins_q (round 6) : the bins of chains on k_sweep_leanx2 — 64 partial entries per column and slot pair, already added up over
+//  the sweep's four waves.  FOUR columns per wave, a DPP row of 16 lanes each (a lane takes four of the 64 entries; the sums over
+//  the row are four DPP steps): a wave per column (k_bins) spent its time on the chain of dependent loads in front of and behind
+//  1 - 3 KB of partials and on 64-lane sums — 3.95 ms for the 4.1 M columns of cohort_h64m.  Same factors, exponents, fall-back
+//  rule (bins re-formed from the stored backward column) and triangle doubling as bins_unit.
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_bins_q(const DevContig* __restrict__ contigs) {
+    constexpr int NB = PG_AMAX * (PG_AMAX + 1) / 2;
+    __shared__ double s_bins[16][NB + 1];
+    const DevContig& dc = contigs[blockIdx.y];
+    if (!dc.leanx2 || dc.split) return;
+    const uint32_t C = *dc.n_cols;
+    if (blockIdx.x * 16u >= C) return;
+    const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u, g = lane >> 4, l = lane & 15u;
+    const uint32_t cc = blockIdx.x * 16u + wave * 4u + g;
+    const bool valid = cc < C;
+    const uint32_t c = valid ? cc : C - 1u;   // (rows past the last column run along on its data — DPP steps and LDS syncs are the wave's — and store nothing)
+    double* sb = s_bins[wave * 4u + g];
+    const unsigned char* rec = dc.colrec + (size_t)c * dc.RB;   // (triangle chains that are not lean chains keep column-order records)
+    const uint32_t v = *(const uint32_t*)(rec + PG_REC_VARIANT);
+    const uint32_t nl = rec[PG_REC_NLOCAL];
+    const unsigned char* al = rec + PG_REC_ALLELES;
+    uint32_t bl[4];   // column alleles of this lane's four entries (entry t belongs to column allele al[t])
+#pragma unroll
+    for (int i = 0; i < 4; ++i) bl[i] = al[l + 16u * (uint32_t)i];
+    const bool fb = dc.fwd_fallback[c] != 0;
+    const bool reform = fb && c >= C / 2;
+    if (l < (uint32_t)NB) sb[l] = 0.0;
+    wave_sync_lds();
+    if (__any(reform)) {
+        // (bins_unit) the forward column fell back to uniform after this column's partials had been formed from the all-zero
+        // column: the bins are those of the uniform column times the stored backward column (upper triangle, diagonal halved)
+        const uint32_t H = dc.H;
+        const double unif = 1.0 / ((double)H * (double)H);
+        const double* col = dc.fwd + (size_t)c * dc.col_stride;
+        const uint32_t nlw = (uint32_t)__builtin_amdgcn_readfirstlane(wave_max_i32(reform ? (int)nl : 0));
+        for (uint32_t a = 0; a < nlw; ++a)
+            for (uint32_t b = 0; b < nlw; ++b) {
+                double sacc = 0.0;
+                if (reform && a < nl && b < nl)
+                    for (uint32_t st = l; st < H * H; st += 16u) {
+                        const uint32_t i = st / H, jj = st % H;
+                        if (al[i] == a && al[jj] == b) {
+                            const uint32_t lo3 = i < jj ? i : jj, hi3 = i < jj ? jj : i;
+                            const double val = col[(size_t)tri_unit_of(lo3 >> 1, hi3) * 2 + (lo3 & 1u)];
+                            sacc += lo3 == hi3 ? 2.0 * val : val;
+                        }
+                    }
+                const double tot = row16_sum(sacc) * unif;
+                if (l == 0 && reform && a < nl && b < nl) sb[tri_local(a < b ? a : b, a < b ? b : a)] += tot;
+            }
+    }
+    {
+        const uint32_t nq = reform ? 0u : (nl + 1u) >> 1;
+        const uint32_t nqw = (uint32_t)__builtin_amdgcn_readfirstlane(wave_max_i32((int)nq));
+        const uint32_t nlw = (uint32_t)__builtin_amdgcn_readfirstlane(wave_max_i32(reform ? 0 : (int)nl));
+        const v2f64* base = (const v2f64*)dc.part + (size_t)c * (dc.part_slots >> 1) * 64u + l;
+        for (uint32_t q = 0; q < nqw; ++q) {
+            const bool mine = q < nq;
+            v2f64 pv[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) { pv[i] = v2f64{0.0, 0.0}; if (mine) pv[i] = base[(size_t)q * 64u + 16u * (uint32_t)i]; }
+            const uint32_t ra0 = 2u * q, ra1 = 2u * q + 1u;
+#pragma unroll
+            for (int bb = 0; bb < PG_AMAX; ++bb) {
+                if ((uint32_t)bb < nlw) {   // (uniform)
+                    double a0s = 0.0, a1s = 0.0;
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) { a0s += bl[i] == (uint32_t)bb ? pv[i].x : 0.0; a1s += bl[i] == (uint32_t)bb ? pv[i].y : 0.0; }
+                    const double t0 = row16_sum(a0s), t1 = row16_sum(a1s);
+                    if (l == 0 && mine && (uint32_t)bb < nl) {
+                        const uint32_t cb = (uint32_t)bb;
+                        sb[tri_local(ra0 < cb ? ra0 : cb, ra0 < cb ? cb : ra0)] += t0;
+                        if (ra1 < nl) sb[tri_local(ra1 < cb ? ra1 : cb, ra1 < cb ? cb : ra1)] += t1;
+                    }
+                }
+            }
+        }
+    }
+    wave_sync_lds();
+    if (!valid) return;
+    const uint32_t a0 = dc.allele_off[v], A = dc.allele_off[v + 1] - a0;
+    const uint16_t* ls = (const uint16_t*)(rec + PG_REC_LOCAL_SLOT);
+    const double scale = 1.0 / ((fb ? 1.0 : dc.fscale[c]) * dc.bscale[c]);
+    int xexp = -((fb ? 0 : PG_BIAS_F) + PG_BIAS_B);
+    if (c + 1 < C) xexp += *(const int32_t*)(dc.colrec + (size_t)(c + 1) * dc.RB + PG_REC_EXP);
+    if (!reform) xexp += 1;   // triangle storage: the partials are sums over the stored half = half of the bin
+    const uint32_t pn = dc.pair_n, NP = (pn * (pn + 1) / 2 + 1u) & ~1u;
+    const unsigned char* vp = dc.vpair + (size_t)v * (NP * 12u);
+    for (uint32_t pidx = l; pidx < nl * nl; pidx += 16u) {
+        const uint32_t la = pidx / nl, lb = pidx % nl;
+        if (la <= lb) {
+            const uint32_t sa = ls[la], sbb = ls[lb];
+            const uint64_t idx = dc.geno_off[v] + (uint64_t)sa * A - (uint64_t)sa * (sa - 1) / 2 + (sbb - sa);
+            const uint32_t pi = tri_n(la, lb, pn);
+            const double pm = fb ? 0.5 : ((const double*)vp)[pi];
+            const int pe = fb ? 1 : ((const int*)(vp + (size_t)NP * 8u))[pi];
+            store_bin(dc.lik, dc.lik_exp, idx, sb[tri_local(la, lb)] * scale, pm, pe, xexp);
+        }
+    }
+}
+
 __global__ __launch_bounds__(256) void k_bins(const DevContig* __restrict__ contigs) {
     __shared__ double s_bins[4][PG_AMAX * (PG_AMAX + 1) / 2];
     const DevContig& dc = contigs[blockIdx.y];
@@ -6191,6 +6671,7 @@ static void launch_sweep(const DevContig* d_contigs, uint32_t n_contigs, uint32_
     if (hp_mask & 8u) launch_one<128, 32, 1, false, PHASE>(d_contigs, n_contigs, chunk, s);
     if constexpr (PHASE == 2) {
         if (hp_mask & 256u) hipLaunchKernelGGL((k_sweep_lean2<16>), dim3(n_contigs, 2), dim3(256), 0, s, d_contigs);  // bit 8: chains with tri == 2
+        if (hp_mask & 8192u) hipLaunchKernelGGL(k_sweep_leanx2, dim3(n_contigs, 2), dim3(256), 0, s, d_contigs);      // bit 13: DevContig::leanx2
     }
     if constexpr (PHASE != 2) {
         if (hp_mask & 64u) {  // bit 6: the job has lean chains (all-biallelic, H = HP = 64)
@@ -6260,6 +6741,7 @@ void pgk_launch_bins(const DevContig* d_contigs, uint32_t n_contigs, uint32_t ma
     if (which & 32u) hipLaunchKernelGGL(k_bins_s, grid256, dim3(256), 0, s, d_contigs);     // bit 5: split chains (pg_split.h)
     if ((which & 64u) && max_wide)   // bit 6: ... with wide columns
         hipLaunchKernelGGL(k_bins_wide_s, dim3((max_wide + 3u) / 4u, n_contigs), dim3(256), 0, s, d_contigs);
+    if (which & 128u) hipLaunchKernelGGL(k_bins_q, dim3((max_v + 15u) / 16u, n_contigs), dim3(256), 0, s, d_contigs);   // bit 7: chains on k_sweep_leanx2
 }
 void pgk_launch_sweep(const DevContig* d_contigs, uint32_t n_contigs, uint32_t hp_mask, int phase, hipStream_t s) {
     if (phase == 1) launch_sweep<1>(d_contigs, n_contigs, hp_mask, 0, s);

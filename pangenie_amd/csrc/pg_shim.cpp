@@ -810,6 +810,8 @@ int upload_inputs(pg_job* job, const pg_contig_batch* batches, const std::vector
 //                       partials instead of class sums | k_prep for every object
 //   fullcols            fused jobs at HP = 32 store and fetch whole 32 x 32 columns (DevContig::live = HP)
 //   nosmall2            phase 2 of the 16-path chains of fused jobs on the general kernel (k_sweep_small16 for phase 1 only)
+//   noleanx2            phase 2 of the 64-path triangle chains with multiallelic objects on the general kernel's triangle ring (per-thread
+//                       partials) instead of k_sweep_leanx2 — cross-check
 //   persist             chunked jobs whose chains are all lean chains run phase 2 as the persistent pair k_sweep_lean<4> + k_post_loop
 //                       (one launch each, chunks handed over on the device) instead of one launch per chunk (k_sweep_lean<3> + k_post).
 //                       Opt-in: measured at par or behind on the whole-genome job (profiles/r06_persist.txt).  nopersist: the default, spelled out
@@ -817,7 +819,7 @@ int upload_inputs(pg_job* job, const pg_contig_batch* batches, const std::vector
 //                       taking the split path (pg_split.h)
 struct KernelChoice {
     bool general = false, generic = false, nolean2 = false, notri = false, nocls4 = false, prepwave = false, fullcols = false, nosmall2 = false, nosplit = false;
-    bool persist = false;
+    bool persist = false, noleanx2 = false;
     int leanx = -1, small = -1;   // -1: by the job, 0 / 1: forced
     std::string unknown;          // a token this list does not know
 };
@@ -834,6 +836,7 @@ KernelChoice kernel_choice() {
         else if (tok == "nocls4") k.nocls4 = true; else if (tok == "prepwave") k.prepwave = true;
         else if (tok == "fullcols") k.fullcols = true; else if (tok == "nosmall2") k.nosmall2 = true;
         else if (tok == "nosplit") k.nosplit = true;
+        else if (tok == "noleanx2") k.noleanx2 = true;
         else if (tok == "persist") k.persist = true; else if (tok == "nopersist") k.persist = false;
         else if (!tok.empty()) k.unknown = tok;   // (a typo would quietly test the default path against itself: job creation fails)
         tok.clear();
@@ -1409,6 +1412,9 @@ int job_build(int device, uint32_t n_index, const pg_contig_batch* batches, cons
         }
         d.tri = tri_of_chain[c] ? ((kc.nolean2 || !x.lean) ? 1u : 2u) : 0u;   // (PG_KERNELS=nolean2, and chains with multiallelic objects: phase 2 of triangle chains on the general kernel's triangle ring)
         d.col_stride = d.tri ? 2304u : x.HP * x.HP;
+        if (d.tri == 1u && !x.lean && x.HP == 64u && !kc.noleanx2 && !params->run_phasing) {   // phase 2 on k_sweep_leanx2
+            d.leanx2 = 1u; d.T = 64u; job->hp_mask |= 8192u;
+        }
         if (d.tri) job->hp_mask |= 128u;
         if (d.tri && !x.lean) {
             // phase 1 of such chains: the lean-x step with triangle stores (DevContig::leanx == 2; it needs the column-order records
@@ -1420,7 +1426,7 @@ int job_build(int device, uint32_t n_index, const pg_contig_batch* batches, cons
         // (k_bins_thin: what bins_thin() in pg_kernels.hip says — at most 64 partial entries per column, fused job)
         if (x.split) job->bins_which |= 32u | ((x.split == 2u && x.wide_bytes) ? 64u : 0u);   // k_bins_s, k_bins_wide_s
         else {
-        job->bins_which |= (d.tri == 2u || d.cls4) ? 2u : ((d.T <= 64u && d.HP <= 32u && !job->chunked) ? 4u : 1u);
+        job->bins_which |= d.leanx2 ? 128u : (d.tri == 2u || d.cls4) ? 2u : ((d.T <= 64u && d.HP <= 32u && !job->chunked) ? 4u : 1u);   // (bit 7: k_bins_q)
         if (d.smallx == 2u) job->bins_which |= 8u | (x.wide_bytes ? 16u : 0u);   // k_bins_x, k_bins_wide (a chain left with one column: k_bins_thin, above)
         }
         ch.d = d;
@@ -1477,9 +1483,9 @@ int job_build(int device, uint32_t n_index, const pg_contig_batch* batches, cons
                     p2 += " chunks + k_post";
                     bins = "(k_post)";
                 } else {
-                    p2 = d.tri == 2u ? "k_sweep_lean2" : d.small == 2u ? "k_sweep_small16<2>" : d.smallx == 2u ? "k_sweep_small16x<2>"
+                    p2 = d.leanx2 ? "k_sweep_leanx2" : d.tri == 2u ? "k_sweep_lean2" : d.small == 2u ? "k_sweep_small16<2>" : d.smallx == 2u ? "k_sweep_small16x<2>"
                          : std::string(gen) + (d.tri ? "<2> (triangle ring)" : "<2>");
-                    bins = (d.tri == 2u || d.cls4) ? "k_bins_lean2" : d.smallx == 2u ? (wide ? "k_bins_x + k_bins_wide" : "k_bins_x")
+                    bins = d.leanx2 ? "k_bins_q" : (d.tri == 2u || d.cls4) ? "k_bins_lean2" : d.smallx == 2u ? (wide ? "k_bins_x + k_bins_wide" : "k_bins_x")
                            : (d.T <= 64u && d.HP <= 32u) ? "k_bins_thin" : "k_bins";
                 }
             }

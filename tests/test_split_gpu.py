@@ -209,9 +209,10 @@ def test_split_entries_below_the_normal_range_keep_their_precise_products(orc, m
 @pytest.mark.parametrize("phase1", ["leanx_tri", "tri1"])
 @pytest.mark.parametrize("V", [330, 331, 1, 2])
 def test_triangle_storage_of_64_path_chains_with_multiallelic_objects(V, phase1, orc, monkeypatch):
-    """Round 6 (first step): a 64-path chain with 3-5-allele objects in a fused job stores its (symmetric)
-    columns as upper triangles too — the general kernel's phase 1 writes k_sweep_lean_tri's layout, its phase 2 reads it through
-    the triangle ring — instead of leaving triangle storage the moment one object is not biallelic.  Unregularised table as
+    """Round 6: a 64-path chain with 3-5-allele objects in a fused job stores its (symmetric) columns as upper
+    triangles too — phase 1 writes k_sweep_lean_tri's layout (k_sweep_leanx_tri, or the general kernel: "tri1"), phase 2 reads it on
+    k_sweep_leanx2 (the lean-2 design with table emissions; partials added up over the waves, k_bins_q) or, PG_KERNELS=noleanx2,
+    through the general kernel's triangle ring — instead of leaving triangle storage the moment one object is not biallelic.  Unregularised table as
     well (fall-backs in both halves, re-formed bins); PG_KERNELS=notri (full columns) must agree to fp64 rounding."""
     monkeypatch.setenv("PG_SWEEP_MODE", "fused")
     for seed, reg, multi in ((515, 0.0, 0.3), (516, 0.01, 0.2), (517, 0.0, 1.0)):
@@ -230,13 +231,23 @@ def test_triangle_storage_of_64_path_chains_with_multiallelic_objects(V, phase1,
         assert job.sweep_mode()[0] == "fused"
         if int(np.diff(b.allele_off.astype(np.int64)).max()) > 2:
             assert job.triangle_chains() == 2
+        assert ("k_sweep_leanx2" in job.plan() and "k_bins_q" in job.plan()) == (int(np.diff(b.allele_off.astype(np.int64)).max()) > 2), job.plan()
         job.run()
         tri = job.fetch(0)
+        job.close()
+        # phase 2 on the general kernel's triangle ring + k_bins (PG_KERNELS=noleanx2: round 6's first step) instead of k_sweep_leanx2 + k_bins_q
+        monkeypatch.setenv("PG_KERNELS", "noleanx2" + (",noleanx" if phase1 == "tri1" else ""))
+        job = hmm.Job([b, synthetic_panel(100, 64, 20, seed=seed + 50)], t, p)
+        assert "k_sweep_leanx2" not in job.plan(), job.plan()
+        job.run()
+        ring = job.fetch(0)
         job.close()
         monkeypatch.setenv("PG_KERNELS", "notri")
         full = hmm.genotype_contig(b, t, p)
         monkeypatch.delenv("PG_KERNELS", raising=False)
         ref = orc.genotype_contig(b, orc.OracleTable(*args), orc.make_params(1.26, False, 1e-5))
         assert_parity(b, tri, ref)
+        assert_parity(b, ring, ref)
         assert_parity(b, full, ref)
         _agree(tri, full, 1e-11)
+        _agree(tri, ring, 1e-11)
