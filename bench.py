@@ -134,8 +134,10 @@ def _sweep_phase(name: str):
     k_sweep<HP, R, VBUF, KEEPW, PHASE>, k_sweep_lean[_tri]<PHASE, R>, k_sweep_leanx<PHASE, HP>, k_sweep_small16[x]<PHASE>,
     k_sweep_generic<PHASE>."""
     import re
-    if name.startswith("void k_sweep_lean2<"):  # phase 2 of triangle chains
+    if name.startswith("void k_sweep_lean2<") or name.startswith("k_sweep_leanx2("):  # phase 2 of triangle chains (biallelic / with multiallelic objects)
         return 2
+    if name.startswith("k_sweep_leanx_tri(") or name.startswith("k_sweep_tri1("):      # their phase 1 (not templates: no "void", no <PHASE>)
+        return 1
     m = re.match(r"void k_sweep_lean<(\d), ", name) or re.match(r"void k_sweep_lean_tri<(\d), ", name) or \
         re.match(r"void k_sweep_leanx<(\d), ", name) or re.match(r"void k_sweep_small16x?<(\d)>", name) or \
         re.match(r"void k_sweep_generic<(\d)>", name) or re.match(r"void k_sweep<\d+, \d+, \d+, \w+, (\d)>", name)

@@ -4553,7 +4553,30 @@ DEVI void leanx_backward(const DevContig& dc, LxShared<HP>& sh, uint32_t C, uint
 struct LxShared2 {
     LxShared<64> a;
     v2f64 pp[2][4][PG_LX2_PAIRS][64];   // posterior partials {row allele 2q, 2q + 1} per wave and lane, by column parity
+    // the row-allele weights: row a (at the byte offset a * 48 — a row's table-row offset IS its address here) has 1.0 at a; row
+    // PG_AMAX (a phantom path) is zeros.  A state's weights are one SDWA add + one to three broadcast LDS reads (k_sweep_small16x's
+    // scheme) instead of a compare and a select per allele on the scalar unit (PG_LX2_ONEHOT=0)
+    double onehot[PG_ESTRIDE][PG_ESTRIDE] __attribute__((aligned(16)));
 };
+#ifndef PG_LX2_ONEHOT
+#define PG_LX2_ONEHOT 1
+#endif
+DEVI void lx2_init_onehot(LxShared2& sh, uint32_t tid) {
+    if (tid < (uint32_t)(PG_ESTRIDE * PG_ESTRIDE)) sh.onehot[tid / (uint32_t)PG_ESTRIDE][tid % (uint32_t)PG_ESTRIDE] = (tid / (uint32_t)PG_ESTRIDE == tid % (uint32_t)PG_ESTRIDE && tid / (uint32_t)PG_ESTRIDE < (uint32_t)PG_AMAX) ? 1.0 : 0.0;
+}
+// the same through the one-hot rows: K = the state's row inside the wave, rows = the wave's sixteen row offsets, oh = LDS address of the table
+template <int NA, int K>
+DEVI void lx2_add_oh(double (&acc)[2 * PG_LX2_PAIRS], double pr, const uint32_t (&rows)[4], uint32_t oh) {
+    const uint32_t wa = add_byte<(K & 3)>(rows[K >> 2], oh);
+    const v2f64 w01 = *(LAS const v2f64*)(uintptr_t)wa;
+    acc[0] = fma(pr, w01.x, acc[0]); acc[1] = fma(pr, w01.y, acc[1]);
+    if constexpr (NA > 2) {
+        const v2f64 w23 = *(LAS const v2f64*)(uintptr_t)(wa + 16u);
+        const double w4 = *(LAS const double*)(uintptr_t)(wa + 32u);
+        acc[2] = fma(pr, w23.x, acc[2]); acc[3] = fma(pr, w23.y, acc[3]);
+        acc[4] = fma(pr, w4, acc[4]);
+    }
+}
 // (behind the barrier that follows the step of column c) wave q: slot pair q of column c, the four waves' partials added, 64 entries out
 DEVI void lx2_flush(const LxShared2& sh, uint32_t pb, gdouble* part, uint32_t part_slots, size_t c, uint32_t nl, uint32_t wave, uint32_t lane) {
     if (wave >= (uint32_t)PG_LX2_PAIRS || 2u * wave >= nl) return;
@@ -4583,7 +4606,7 @@ DEVI void lx2_add(double (&acc)[2 * PG_LX2_PAIRS], double pr, uint32_t ro /*unif
     for (int a = 0; a < NA; ++a) acc[a] = fma(pr, ro == (uint32_t)(a * PG_ESTRIDE * 8) ? 1.0 : 0.0, acc[a]);
 }
 
-DEVI void leanx2_forward(const DevContig& dc, LxShared2& sh2, uint32_t C) {
+DEVI void leanx2_forward(const DevContig& dc, LxShared2& sh2, uint32_t C, uint32_t oh /* LDS address of sh2.onehot */) {
     constexpr int R = 16, BLK = LxCfg<64>::BLK, PPT = LxCfg<64>::PPT;
     LxShared<64>& sh = sh2.a;
     const uint32_t mid = C / 2, lo = mid, hi = C, first = lo == 0 ? 1u : lo;   // (C == 1: lo = 0, the one column is the prologue's)
@@ -4598,6 +4621,7 @@ DEVI void leanx2_forward(const DevContig& dc, LxShared2& sh2, uint32_t C) {
     for (int p = 0; p < PPT; ++p) recs.park(sh, 0, p, recs.fetch(0, p));
 #pragma unroll
     for (int p = 0; p < PPT; ++p) piece[p] = recs.fetch(1, p);
+    lx2_init_onehot(sh2, tid);
     lds_barrier();
     lx_transform<64>(sh, 0, tid);
     lds_barrier();
@@ -4675,8 +4699,6 @@ DEVI void leanx2_forward(const DevContig& dc, LxShared2& sh2, uint32_t C) {
         const double Cr = (sh.psum[pb][0][ri] + sh.psum[pb][1][ri]) + (sh.psum[pb][2][ri] + sh.psum[pb][3][ri]);
         const double ucol = cur.c1 * Cj;
         const double urep = dpp_source(cur.c1 * Cr);   // u_i of row i0 + (lane & 15): the DPP source
-        const LxConsts cnx = lx_consts<64>(sh, n + 2u);
-        const Lx2Col coln = lx2_col(sh, n + 2u, lane, i0);   // the next column's, a step ahead
         const v4f64 zz = {0.0, 0.0, 0.0, 0.0};
         const v4f64 ma = __builtin_amdgcn_mfma_f64_16x16x4f64(Cj, 1.0, zz, 0, 0, 0);
         double S = __builtin_amdgcn_mfma_f64_16x16x4f64((ma[0] + ma[1]) + (ma[2] + ma[3]), 1.0, zz, 0, 0, 0)[0];
@@ -4713,7 +4735,8 @@ DEVI void leanx2_forward(const DevContig& dc, LxShared2& sh2, uint32_t C) {
                 const double pk = fmac_row_bcast<k>(fma(c0s, x[k], ujs), urep, sc);   // P'_t = c0 x + u_j + u_i
                 x[k] = pk * e;
                 part0 += x[k];
-                lx2_add<NA>(acc, pk * ba[k], (rw[k >> 2] >> (8 * (k & 3))) & 0xFFu);   // P'_t beta'_t (0 below the stored half)
+                if constexpr (PG_LX2_ONEHOT) lx2_add_oh<NA, k>(acc, pk * ba[k], col.rows, oh);   // P'_t beta'_t (0 below the stored half)
+                else lx2_add<NA>(acc, pk * ba[k], (rw[k >> 2] >> (8 * (k & 3))) & 0xFFu);
                 if constexpr ((k & 3) == 3) __builtin_amdgcn_sched_barrier(0);
             });
         };
@@ -4727,7 +4750,9 @@ DEVI void leanx2_forward(const DevContig& dc, LxShared2& sh2, uint32_t C) {
             fsc.put(lane, t, m);
             if ((t & 63u) == 63u) fsc.flush(fscale, lane, t);
         }
-        pnl = nl; cur = cnx; col = coln;
+        pnl = nl;
+        cur = lx_consts<64>(sh, n + 2u);          // the next column's constants, alleles, table column: read HERE, behind the state
+        col = lx2_col(sh, n + 2u, lane, i0);      // loop (not a step ahead in front of it: fourteen registers less across the loop)
         lds_barrier();
     };
     __builtin_amdgcn_s_waitcnt(0x0F70);   // (see lean_forward)
@@ -4751,7 +4776,7 @@ DEVI void leanx2_forward(const DevContig& dc, LxShared2& sh2, uint32_t C) {
     }
 }
 
-DEVI void leanx2_backward(const DevContig& dc, LxShared2& sh2, uint32_t C) {
+DEVI void leanx2_backward(const DevContig& dc, LxShared2& sh2, uint32_t C, uint32_t oh) {
     constexpr int R = 16, BLK = LxCfg<64>::BLK, PPT = LxCfg<64>::PPT;
     LxShared<64>& sh = sh2.a;
     const int64_t mid = C / 2, top = mid - 1, bot = 0, t0 = top;
@@ -4767,6 +4792,7 @@ DEVI void leanx2_backward(const DevContig& dc, LxShared2& sh2, uint32_t C) {
     for (int p = 0; p < PPT; ++p) recs.park(sh, 0, p, recs.fetch(0, p));
 #pragma unroll
     for (int p = 0; p < PPT; ++p) piece[p] = recs.fetch(1, p);
+    lx2_init_onehot(sh2, tid);
     lds_barrier();
     lx_transform<64>(sh, 0, tid);
     lds_barrier();
@@ -4824,8 +4850,6 @@ DEVI void leanx2_backward(const DevContig& dc, LxShared2& sh2, uint32_t C) {
         if (wave == 0) bsc.put(lane, (uint64_t)t, m);
         const double k0 = ldexp(cur.c0, -es), k1 = ldexp(cur.c1, -es), k2 = ldexp(cur.c2, -es), kap = ldexp(cur.kappa, -es);
         lds_barrier();
-        const LxConsts cnx = lx_consts<64>(sh, n + 1u);        // next step: the gap t-1 -> t = record t
-        const Lx2Col coln = lx2_col(sh, n + 2u, lane, i0);     // ... and column t-1
         if (t < t0) lx2_flush(sh2, (uint32_t)(t + 1) & 1u, part, part_slots, (size_t)(t + 1), pnl, wave, lane);
         const uint32_t pb = (uint32_t)t & 1u;
         const double Cj = (sh.psum[pb][0][lane] + sh.psum[pb][1][lane]) + (sh.psum[pb][2][lane] + sh.psum[pb][3][lane]);
@@ -4864,7 +4888,8 @@ DEVI void leanx2_backward(const DevContig& dc, LxShared2& sh2, uint32_t C) {
                     const double yk = fmac_row_bcast<k>(fma(k0, w[k], uj), urep, one);   // beta'_t = k0 w + u_j + u_i
                     w[k] = yk * e;
                     part0 += w[k];
-                    lx2_add<NA>(acc, ba[k] * yk, (rw[k >> 2] >> (8 * (k & 3))) & 0xFFu);   // P'_t beta'_t
+                    if constexpr (PG_LX2_ONEHOT) lx2_add_oh<NA, k>(acc, ba[k] * yk, col.rows, oh);   // P'_t beta'_t
+                    else lx2_add<NA>(acc, ba[k] * yk, (rw[k >> 2] >> (8 * (k & 3))) & 0xFFu);
                     if constexpr ((k & 3) == 3) __builtin_amdgcn_sched_barrier(0);
                 });
             };
@@ -4877,7 +4902,9 @@ DEVI void leanx2_backward(const DevContig& dc, LxShared2& sh2, uint32_t C) {
             if ((uint32_t)(2 * q) < nl) sh2.pp[(uint32_t)t & 1u][wave][q][lane] = v2f64{acc[2 * q], acc[2 * q + 1]};
         if (wave == 0 && ((uint64_t)t & 63u) == 0u) bsc.flush(bscale, lane, (uint64_t)t);
         Sy = Snew > 0.0 ? Snew : 1.0;
-        pnl = nl; cur = cnx; col = coln;
+        pnl = nl;
+        cur = lx_consts<64>(sh, n + 1u);          // next step: the gap t-1 -> t = record t
+        col = lx2_col(sh, n + 2u, lane, i0);      // ... and column t-1 (behind the state loop: see leanx2_forward)
     };
     __builtin_amdgcn_s_waitcnt(0x0F70);
     {
@@ -4902,8 +4929,11 @@ void k_sweep_leanx2(const DevContig* __restrict__ contigs) {
     if (!dc.leanx2 || dc.HP != 64u || dc.tri != 1u) return;
     const uint32_t C = (uint32_t)__builtin_amdgcn_readfirstlane((int)*dc.n_cols);
     if (C == 0) return;
-    if (blockIdx.y == 0) leanx2_forward(dc, sh, C);
-    else leanx2_backward(dc, sh, C);
+    // (LDS address of the one-hot table, taken relative to the record blocks': the direct cast of &sh.onehot trips this compiler's
+    //  machine verifier — "V_CMP_NE_U32 0, $src_shared_base: operand has incorrect register class")
+    const uint32_t oh = (uint32_t)(uintptr_t)(LAS const unsigned char*)((const unsigned char*)&sh.a.rec[0][0][0]) + (uint32_t)(offsetof(LxShared2, onehot) - offsetof(LxShared2, a) - offsetof(LxShared<64>, rec));
+    if (blockIdx.y == 0) leanx2_forward(dc, sh, C, oh);
+    else leanx2_backward(dc, sh, C, oh);
 }
 
 // phase 1 of the 64-path chains of fused jobs with multiallelic objects (DevContig::tri == 1, leanx == 2): the lean-x step with

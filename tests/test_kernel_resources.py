@@ -18,6 +18,7 @@ KERNELS = {
     "_Z7k_sweepILi128ELi32ELi1ELb0ELi2EEvPK9DevContigj": (200, True),    # general kernel, 128 paths, fused phase 2 (rare paths may spill)
     "_Z7k_sweepILi64ELi16ELi1ELb1ELi2EEvPK9DevContigj": (200, False),    # general kernel, 64 paths, phase 2
     "_Z13k_sweep_lean2ILi16EEvPK9DevContig": (200, True),                 # triangle chains, phase 2
+    "_Z14k_sweep_leanx2PK9DevContig": (300, True),                        # ... with multiallelic objects (round 6): the state loops (both allele-count variants) carry no scratch
     "_Z12k_sweep_leanILi1ELi16ELb0EEvPK9DevContigj": (100, False),        # the lone-chain lean step
     "_Z15k_sweep_small16ILi1EEvPK9DevContigPKjjjPd": (100, False),        # four half-chains per wave, phase 1
     "_Z15k_sweep_small16ILi2EEvPK9DevContigPKjjjPd": (100, False),        # ... phase 2
@@ -84,6 +85,7 @@ OCCUPANCY = {
     "_Z7k_sweepILi128ELi32ELi1ELb0ELi2EEvPK9DevContigj": 2,   # eight waves per workgroup: two per SIMD
     "_Z16k_sweep_lean_triILi1ELi16EEvPK9DevContigj": 2,       # two workgroups per CU
     "_Z13k_sweep_lean2ILi16EEvPK9DevContig": 2,
+    "_Z14k_sweep_leanx2PK9DevContig": 2,                      # two workgroups per CU
     "_Z15k_sweep_small16ILi1EEvPK9DevContigPKjjjPd": 2,
     "_Z15k_sweep_small16ILi2EEvPK9DevContigPKjjjPd": 1,       # three partner-column buffers: one wave per SIMD, 2048 waves per launch
     "_Z12k_bins_lean2PK9DevContig": 8,
