@@ -4555,11 +4555,12 @@ struct LxShared2 {
     v2f64 pp[2][4][PG_LX2_PAIRS][64];   // posterior partials {row allele 2q, 2q + 1} per wave and lane, by column parity
     // the row-allele weights: row a (at the byte offset a * 48 — a row's table-row offset IS its address here) has 1.0 at a; row
     // PG_AMAX (a phantom path) is zeros.  A state's weights are one SDWA add + one to three broadcast LDS reads (k_sweep_small16x's
-    // scheme) instead of a compare and a select per allele on the scalar unit (PG_LX2_ONEHOT=0)
+    // scheme) instead of a compare and a select per allele on the scalar unit — the A/B build -DPG_LX2_ONEHOT=1; the product takes the
+    // scalar selects
     double onehot[PG_ESTRIDE][PG_ESTRIDE] __attribute__((aligned(16)));
 };
 #ifndef PG_LX2_ONEHOT
-#define PG_LX2_ONEHOT 1
+#define PG_LX2_ONEHOT 0   // (measured on cohort_h64m, tools/r06_runs/gpu44.sh: phase 2 17.0 ms with the scalar selects, 17.7 with the one-hot reads)
 #endif
 DEVI void lx2_init_onehot(LxShared2& sh, uint32_t tid) {
     if (tid < (uint32_t)(PG_ESTRIDE * PG_ESTRIDE)) sh.onehot[tid / (uint32_t)PG_ESTRIDE][tid % (uint32_t)PG_ESTRIDE] = (tid / (uint32_t)PG_ESTRIDE == tid % (uint32_t)PG_ESTRIDE && tid / (uint32_t)PG_ESTRIDE < (uint32_t)PG_AMAX) ? 1.0 : 0.0;
