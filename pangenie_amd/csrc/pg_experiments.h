@@ -121,3 +121,50 @@ struct LeanTimeline {
 #define PG_X_EXP 0
 #endif
 static constexpr unsigned kXExp = PG_X_EXP;
+
+// -DPG_VIT_TIMELINE builds only (tools/exp_viterbi_timeline.py, profiles/r06_viterbi.txt): s_memtime stamps at the segment
+// boundaries of one column step of k_viterbi's wave 0, each issued behind a use of the value that ends the segment; sums per
+// segment over the launch go to DevContig::prof[0 .. 11], [15] = steps.  -DPG_VIT_EXP=mask: timing experiments (results WRONG):
+// 1 rows: no lo pass, 2 rows: no index pass, 4 column as a whole: no lo pass, 8 no back-pointer stores, 16 no emission fetches.
+#ifdef PG_VIT_TIMELINE
+static constexpr bool kVitTimeline = true;
+#else
+static constexpr bool kVitTimeline = false;
+#endif
+#ifndef PG_VIT_EXP
+#define PG_VIT_EXP 0
+#endif
+static constexpr unsigned kVitExp = PG_VIT_EXP;
+struct VitTimeline {
+    unsigned long long t[13], acc[13];
+    DEVI void init() { if constexpr (kVitTimeline) { for (int i = 0; i < 13; ++i) { t[i] = 0; acc[i] = 0; } } }
+    template <int I>
+    DEVI void mark(double dep) {
+        if constexpr (kVitTimeline) {
+            __builtin_amdgcn_sched_barrier(0);
+            asm volatile("" :: "v"(dep));
+            t[I] = __builtin_amdgcn_s_memtime();
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+    template <int I>
+    DEVI void mark_u(unsigned dep) {
+        if constexpr (kVitTimeline) {
+            __builtin_amdgcn_sched_barrier(0);
+            asm volatile("" :: "v"(dep));
+            t[I] = __builtin_amdgcn_s_memtime();
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+    template <int N>
+    DEVI void fold() {
+        if constexpr (kVitTimeline) {
+#pragma unroll
+            for (int i = 0; i < N; ++i) acc[i] += t[i + 1] - t[i];
+            acc[12] += 1;
+        }
+    }
+    DEVI void write(unsigned long long* o) const {
+        if constexpr (kVitTimeline) { for (int i = 0; i < 12; ++i) o[i] = acc[i]; o[15] = acc[12]; }
+    }
+};

@@ -39,6 +39,7 @@
 #include "pg_devmath.h"
 
 #define DEVI __device__ __forceinline__
+#include "pg_experiments.h"
 #define GAS __attribute__((address_space(1)))
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));  // (HIP's uint4 has no address-space-qualified copy)
 
@@ -184,22 +185,34 @@ __global__ __launch_bounds__((VitCfg<K>::T)) void k_viterbi(const DevContig* __r
     GAS uint16_t* back = (GAS uint16_t*)dc.vit_back;
 
     // ---- block staging: the records of columns [BC b, BC b + BC) are loaded into registers while block b - 1 is
-    //      being worked on, and written to LDS one column before the block starts
+    //      being worked on, and written to LDS one column before the block starts.  A record is found through the column's
+    //      variant (col_variant): those indices are fetched ONE BLOCK EARLIER still (round 6: the step used to wait for
+    //      UPT dependent pairs of loads, index then record, one pair after the other, at every block boundary).
     u32x4 pre[UPT];
     u32x4 pretq = {0u, 0u, 0u, 0u};
+    uint32_t pvar[UPT];  // variants of the columns this thread's units of the next block to issue belong to
 #pragma unroll
-    for (int u = 0; u < UPT; ++u) pre[u] = pretq;
-    auto issue = [&](uint32_t blk) {
+    for (int u = 0; u < UPT; ++u) { pre[u] = pretq; pvar[u] = 0u; }
+    auto issue_variants = [&](uint32_t blk) {
+#pragma unroll
+        for (int u = 0; u < UPT; ++u) {
+            const uint32_t unit = tid + (uint32_t)u * T;
+            const uint32_t col = blk * BC + unit / (RB / 16);
+            if (unit < (uint32_t)UNITS && col < C) pvar[u] = colv[col];
+        }
+    };
+    auto issue = [&](uint32_t blk) {  // (pvar holds block blk's variants)
 #pragma unroll
         for (int u = 0; u < UPT; ++u) {
             const uint32_t unit = tid + (uint32_t)u * T;
             const uint32_t col = blk * BC + unit / (RB / 16), off = unit % (RB / 16);
-            if (unit < (uint32_t)UNITS && col < C) pre[u] = *(const GAS u32x4*)(vrec + (size_t)colv[col] * RB + off * 16u);
+            if (unit < (uint32_t)UNITS && col < C) pre[u] = *(const GAS u32x4*)(vrec + (size_t)pvar[u] * RB + off * 16u);
         }
         if (tid < BC * 4u) {  // BC columns x 64 bytes
             const uint32_t col = blk * BC + (tid >> 2);
             if (col < C) pretq = *(const GAS u32x4*)(tqg + (size_t)col * 8 + (tid & 3u) * 2u);
         }
+        issue_variants(blk + 1u);
     };
     auto commit = [&](uint32_t blk) {
 #pragma unroll
@@ -258,6 +271,7 @@ __global__ __launch_bounds__((VitCfg<K>::T)) void k_viterbi(const DevContig* __r
             for (int k = 0; k < K; ++k) asm volatile("" : "+v"(e[r][k]));
     };
 
+    issue_variants(0);
     issue(0);
     commit(0);
     __syncthreads();
@@ -281,7 +295,10 @@ __global__ __launch_bounds__((VitCfg<K>::T)) void k_viterbi(const DevContig* __r
             if (w.flags & PG_REC_FLAG_WIDE) fetch_e_wide(a, w, e);
         }
     }
+    VitTimeline tl;
+    tl.init();
     for (uint32_t c = 1; c <= C; ++c) {
+        tl.template mark<0>(cur[0][0].hi);
         const uint32_t cn = c + 1u;  // the column whose emissions are fetched during this step
         if ((cn & (BC - 1u)) == 0u && cn < C) {
             commit(cn >> BSH);
@@ -310,11 +327,16 @@ __global__ __launch_bounds__((VitCfg<K>::T)) void k_viterbi(const DevContig* __r
                 lk = t ? (uint32_t)k : lk;
             }
             m[r].hi = row16_max<true>(lm.hi);   // (an all-phantom row gives 0 instead of -1: never read)
-            m[r].lo = row16_max<false>(lm.hi == m[r].hi ? lm.lo : kNone);
-            ml[r] = row16_max_u32(((lm.hi == m[r].hi) & (lm.lo == m[r].lo)) ? col0 + lk : 0u);
+            if (r == R - 1) tl.template mark<1>(m[r].hi);
+            m[r].lo = (kVitExp & 1u) ? lm.lo : row16_max<false>(lm.hi == m[r].hi ? lm.lo : kNone);
+            if (r == R - 1) tl.template mark<2>(m[r].lo);
+            ml[r] = (kVitExp & 2u) ? col0 + lk : row16_max_u32(((lm.hi == m[r].hi) & (lm.lo == m[r].lo)) ? col0 + lk : 0u);
+            if (r == R - 1) tl.template mark_u<3>(ml[r]);
             if (((lane & 15u) == 0u) & (row[r] < H)) { sh.rmh[par][row[r]] = m[r].hi; sh.rml[par][row[r]] = m[r].lo; sh.rl[par][row[r]] = ml[r]; }
         }
+        tl.template mark_u<4>(ml[R - 1]);
         __syncthreads();
+        tl.template mark_u<5>(ml[R - 1]);
         dd colm[K];      // column j of a symmetric matrix = row j
         uint32_t coll[K];  // ... its last maximum sits in row rl[j]
 #pragma unroll
@@ -328,10 +350,19 @@ __global__ __launch_bounds__((VitCfg<K>::T)) void k_viterbi(const DevContig* __r
         const uint32_t xl = sh.rl[par][pl];
         double en[R][K];
         WideInfo wn;
-        fetch_e(cn, an, en, wn);  // (second round of the emission prefetch, in the shadow of the reads above)
+        if (!(kVitExp & 16u)) fetch_e(cn, an, en, wn);  // (second round of the emission prefetch, in the shadow of the reads above)
+        else {
+#pragma unroll
+            for (int r = 0; r < R; ++r)
+#pragma unroll
+                for (int k = 0; k < K; ++k) en[r][k] = e[r][k];
+            wn.flags = 0; wn.nlocal = 0; wn.widx = 0;
+        }
+        tl.template mark<6>(x.hi);
         dd gmax;
         gmax.hi = wave_max<true>(x.hi);
-        gmax.lo = wave_max<false>(x.hi == gmax.hi ? x.lo : kNone);
+        tl.template mark<7>(gmax.hi);
+        gmax.lo = (kVitExp & 4u) ? x.lo : wave_max<false>(x.hi == gmax.hi ? x.lo : kNone);
         const uint32_t ga = last_bit64(__ballot((x.hi == gmax.hi) & (x.lo == gmax.lo)));  // last row that holds the column's maximum
         uint32_t gidx = ga * H + (uint32_t)__builtin_amdgcn_readlane((int)xl, (int)__builtin_amdgcn_readfirstlane((int)ga));
         if (!(gmax.hi > 0.0)) {
@@ -346,6 +377,7 @@ __global__ __launch_bounds__((VitCfg<K>::T)) void k_viterbi(const DevContig* __r
             for (int k = 0; k < K; ++k) { colm[k] = {col0 + k < H ? 1.0 : -1.0, 0.0}; coll[k] = H - 1u; }
             gmax = {1.0, 0.0}; gidx = n - 1u;
         }
+        tl.template mark_u<8>(gidx);
         if (c == C) {  // best state of the last column: the last maximum (reference src/hmm.cpp:131-141)
             if (tid == 0) *dc.vit_best = gidx;
             break;
@@ -358,6 +390,7 @@ __global__ __launch_bounds__((VitCfg<K>::T)) void k_viterbi(const DevContig* __r
 #pragma unroll
         for (int k = 0; k < K; ++k) cc[k] = {dd_mul(colm[k], t1), coll[k] * H + col0 + k};
         GAS uint16_t* bk = back + (size_t)c * H * HP;
+        tl.template mark<9>(cc[K - 1].v.hi);
 #pragma unroll
         for (int r = 0; r < R; ++r) {
             const Cand rg = better({dd_mul(m[r], t1), row[r] * H + ml[r]}, g);  // row or anywhere: the same for the whole row
@@ -373,7 +406,7 @@ __global__ __launch_bounds__((VitCfg<K>::T)) void k_viterbi(const DevContig* __r
                 cur[r][k] = {real[r][k] ? nv.hi * scale : -1.0, real[r][k] ? nv.lo * scale : 0.0};
             }
             // K backpointers of one row, neighbouring second paths: one aligned store (row stride HP)
-            if (row[r] < H && col0 < H) {
+            if (row[r] < H && col0 < H && !(kVitExp & 8u)) {
                 GAS uint16_t* o = bk + row[r] * HP + col0;
                 if (K == 1) o[0] = (uint16_t)idx[0];
                 else if (K == 2) *(GAS uint32_t*)o = idx[0] | (idx[K > 1 ? 1 : 0] << 16);
@@ -384,12 +417,16 @@ __global__ __launch_bounds__((VitCfg<K>::T)) void k_viterbi(const DevContig* __r
                 }
             }
         }
+        tl.template mark<10>(cur[R - 1][K - 1].hi);
         if ((wn.flags & PG_REC_FLAG_WIDE) && cn < C) fetch_e_wide(an, wn, en);
 #pragma unroll
         for (int r = 0; r < R; ++r)
 #pragma unroll
             for (int k = 0; k < K; ++k) e[r][k] = en[r][k];
+        tl.template mark<11>(e[R - 1][K - 1]);
+        tl.template fold<11>();
     }
+    if (kVitTimeline && tid == 0) tl.write(dc.prof);
 }
 
 // ------------------------------------------------------------------------------------------

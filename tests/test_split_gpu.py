@@ -251,3 +251,43 @@ def test_triangle_storage_of_64_path_chains_with_multiallelic_objects(V, phase1,
         assert_parity(b, full, ref)
         _agree(tri, full, 1e-11)
         _agree(tri, ring, 1e-11)
+
+
+def test_leanx2_cohort_chains_of_awkward_lengths(orc, monkeypatch):
+    """k_sweep_leanx2 / k_bins_q behind the cohort boundary (pg_cohort_new: SURVEY §8(f)-1): three samples over an index of 64-path
+    contigs with 3-5-allele objects whose column counts sit on and beside the kernel's blocks — records in blocks of sixteen, bins
+    sixteen columns per workgroup and four per wave, a three-step rotation of the partner buffers — incl. chains of one, two and
+    three columns.  Every (sample, contig) chain against the oracle on that sample's counts, and against the general kernel's
+    triangle ring (PG_KERNELS=noleanx2) to fp64 rounding; a second run of the resident job gives the same bits."""
+    from pangenie_amd.panel import synthetic_sample_counts
+    monkeypatch.setenv("PG_SWEEP_MODE", "fused")
+    args = default_table_args()
+    t, p = hmm.ProbabilityTable(*args), hmm.make_params(1.26, False, 1e-5)
+    lengths = (1, 2, 3, 4, 15, 16, 17, 31, 32, 33, 47, 48, 49, 63, 64, 65, 95, 96, 97, 129, 257)
+    index = [synthetic_panel(V, 64, 20, seed=7000 + V, multiallelic_frac=0.6, undefined_frac=0.02) for V in lengths]
+    samples = []
+    for s in range(3):
+        kcs, covs = zip(*[synthetic_sample_counts(ix, seed=7100 + 100 * s + c) for c, ix in enumerate(index)])
+        samples.append((list(kcs), list(covs)))
+    job = hmm.Job.cohort(index, samples, t, p)
+    assert job.sweep_mode()[0] == "fused"
+    assert "k_sweep_leanx2" in job.plan() and "k_bins_q" in job.plan(), job.plan()
+    job.run()
+    first = job.fetch_all()
+    job.run()
+    again = job.fetch_all()
+    job.close()
+    monkeypatch.setenv("PG_KERNELS", "noleanx2")
+    job = hmm.Job.cohort(index, samples, t, p)
+    assert "k_sweep_leanx2" not in job.plan(), job.plan()
+    job.run()
+    ring = job.fetch_all()
+    job.close()
+    monkeypatch.delenv("PG_KERNELS", raising=False)
+    for s in range(3):
+        for c, ix in enumerate(index):
+            i = s * len(index) + c
+            assert np.array_equal(first[i].lik, again[i].lik) and np.array_equal(first[i].lik_exp, again[i].lik_exp)
+            b = ix.with_counts(samples[s][0][c], samples[s][1][c])
+            assert_parity(b, first[i], orc.genotype_contig(b, orc.OracleTable(*args), orc.make_params(1.26, False, 1e-5)))
+            _agree(first[i], ring[i], 1e-11)
