@@ -136,10 +136,19 @@ DEVI Cand better(Cand a, Cand b) {
 //  A row of the state matrix (first path fixed) lies in one DPP row of 16 lanes, K neighbouring second paths per lane;
 //  a wave holds 4 rows, the workgroup 16 (K = 1) or 32 rows per pass, R passes cover the matrix.
 // ------------------------------------------------------------------------------------------
+#ifndef PG_VIT_NW
+#define PG_VIT_NW 8
+#endif
+#ifndef PG_VIT_FASTG
+#define PG_VIT_FASTG 1
+#endif
+#ifndef PG_VIT_FASTR
+#define PG_VIT_FASTR 1
+#endif
 template <int K>
 struct VitCfg {
     static constexpr int HP = 16 * K;
-    static constexpr int NW = K == 1 ? 4 : 8;           // waves
+    static constexpr int NW = K == 1 ? 4 : PG_VIT_NW;   // waves
     static constexpr int T = 64 * NW;
     static constexpr int RPP = NW * 4;                  // rows per pass of the workgroup
     static constexpr int R = HP / RPP;                  // passes: 1 / 1 / 2
@@ -315,6 +324,7 @@ __global__ __launch_bounds__((VitCfg<K>::T)) void k_viterbi(const DevContig* __r
         // ---- maxima of the previous column: inside the lane, inside the row of 16 lanes, the rest through LDS
         dd m[R];
         uint32_t ml[R];
+        bool rowfast[R];  // (wave-uniform)
 #pragma unroll
         for (int r = 0; r < R; ++r) {
             dd lm = cur[r][0];
@@ -328,11 +338,30 @@ __global__ __launch_bounds__((VitCfg<K>::T)) void k_viterbi(const DevContig* __r
             }
             m[r].hi = row16_max<true>(lm.hi);   // (an all-phantom row gives 0 instead of -1: never read)
             if (r == R - 1) tl.template mark<1>(m[r].hi);
-            m[r].lo = (kVitExp & 1u) ? lm.lo : row16_max<false>(lm.hi == m[r].hi ? lm.lo : kNone);
-            if (r == R - 1) tl.template mark<2>(m[r].lo);
-            ml[r] = (kVitExp & 2u) ? col0 + lk : row16_max_u32(((lm.hi == m[r].hi) & (lm.lo == m[r].lo)) ? col0 + lk : 0u);
-            if (r == R - 1) tl.template mark_u<3>(ml[r]);
-            if (((lane & 15u) == 0u) & (row[r] < H)) { sh.rmh[par][row[r]] = m[r].hi; sh.rml[par][row[r]] = m[r].lo; sh.rl[par][row[r]] = ml[r]; }
+            // The maximum of a row is (hi, lo, last index) in lexicographic order.  Round 6: when no row of the wave has two lanes
+            // that hold the largest hi — a ballot and three bit operations per lane — the one lane that holds it IS the row's
+            // maximum: it writes its (hi, lo, index) to the exchange itself, and the row's other lanes read lo and index back with
+            // the column maxima behind the barrier.  Otherwise (ties at a row's maximum: exact duplicates among the second paths):
+            // two more DPP passes, over lo among the holders of hi and over the index among the holders of (hi, lo).
+            bool fast = false;
+            const bool holder = lm.hi == m[r].hi;
+            if (PG_VIT_FASTR && !(kVitExp & 3u)) {
+                const unsigned long long hb = __ballot(holder);
+                const uint32_t rowbits = (uint32_t)(hb >> (lane & 48u)) & 0xFFFFu;
+                fast = __ballot((rowbits & (rowbits - 1u)) != 0u) == 0ull;
+            }
+            if (fast) {
+                if (holder & (row[r] < H)) { sh.rmh[par][row[r]] = lm.hi; sh.rml[par][row[r]] = lm.lo; sh.rl[par][row[r]] = col0 + lk; }
+                rowfast[r] = true;
+                if (r == R - 1) { tl.template mark<2>(lm.lo); tl.template mark_u<3>(lk); }
+            } else {
+                m[r].lo = (kVitExp & 1u) ? lm.lo : row16_max<false>(holder ? lm.lo : kNone);
+                if (r == R - 1) tl.template mark<2>(m[r].lo);
+                ml[r] = (kVitExp & 2u) ? col0 + lk : row16_max_u32((holder & (lm.lo == m[r].lo)) ? col0 + lk : 0u);
+                if (r == R - 1) tl.template mark_u<3>(ml[r]);
+                if (((lane & 15u) == 0u) & (row[r] < H)) { sh.rmh[par][row[r]] = m[r].hi; sh.rml[par][row[r]] = m[r].lo; sh.rl[par][row[r]] = ml[r]; }
+                rowfast[r] = false;
+            }
         }
         tl.template mark_u<4>(ml[R - 1]);
         __syncthreads();
@@ -348,6 +377,13 @@ __global__ __launch_bounds__((VitCfg<K>::T)) void k_viterbi(const DevContig* __r
         const uint32_t pl = lane < H ? lane : 0u;
         const dd x = {lane < H ? sh.rmh[par][pl] : -1.0, sh.rml[par][pl]};
         const uint32_t xl = sh.rl[par][pl];
+#pragma unroll
+        for (int r = 0; r < R; ++r)
+            if (rowfast[r]) {  // (rows outside the matrix: values never used)
+                const uint32_t rr = row[r] < H ? row[r] : 0u;
+                m[r].lo = sh.rml[par][rr];
+                ml[r] = sh.rl[par][rr];
+            }
         double en[R][K];
         WideInfo wn;
         if (!(kVitExp & 16u)) fetch_e(cn, an, en, wn);  // (second round of the emission prefetch, in the shadow of the reads above)
@@ -362,8 +398,20 @@ __global__ __launch_bounds__((VitCfg<K>::T)) void k_viterbi(const DevContig* __r
         dd gmax;
         gmax.hi = wave_max<true>(x.hi);
         tl.template mark<7>(gmax.hi);
-        gmax.lo = (kVitExp & 4u) ? x.lo : wave_max<false>(x.hi == gmax.hi ? x.lo : kNone);
-        const uint32_t ga = last_bit64(__ballot((x.hi == gmax.hi) & (x.lo == gmax.lo)));  // last row that holds the column's maximum
+        // (hi, lo) of the column's maximum and the last row that holds it.  The matrix is symmetric, so at least two rows hold the
+        // largest hi (unless it sits on the diagonal) — with the SAME lo.  Round 6: if every row that holds the largest hi has
+        // the lo of the last one of them — one ballot, two lane reads, one compare —, that row is the answer; otherwise a second
+        // reduction pass over lo among the holders.
+        const unsigned long long gh = __ballot(x.hi == gmax.hi);
+        const uint32_t glast = (uint32_t)__builtin_amdgcn_readfirstlane((int)last_bit64(gh));
+        gmax.lo = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(x.lo), (int)glast), __builtin_amdgcn_readlane(__double2loint(x.lo), (int)glast));
+        uint32_t ga = glast;
+        if (!PG_VIT_FASTG || (kVitExp & 4u) == 0u) {
+            if (!PG_VIT_FASTG || (__ballot((x.hi == gmax.hi) & (x.lo != gmax.lo)) != 0ull)) {
+                gmax.lo = wave_max<false>(x.hi == gmax.hi ? x.lo : kNone);
+                ga = last_bit64(__ballot((x.hi == gmax.hi) & (x.lo == gmax.lo)));  // last row that holds the column's maximum
+            }
+        }
         uint32_t gidx = ga * H + (uint32_t)__builtin_amdgcn_readlane((int)xl, (int)__builtin_amdgcn_readfirstlane((int)ga));
         if (!(gmax.hi > 0.0)) {
             // the previous column was all 0: the reference sets it to the constant 1/n (src/hmm.cpp:484-491)

@@ -41,9 +41,11 @@ def main():
     lib = R / "pangenie_amd/csrc/libpangenie_hmm.so"
     keep = Path("/tmp/lib_keep.so")
     shutil.copy(lib, keep)
-    variants = [("product", None), ("timeline", ["PG_VIT_TIMELINE"])] + [("exp %d" % m, ["PG_VIT_EXP=%d" % m]) for m in (1, 3, 7, 8, 16, 31)]
+    variants = [("product", None), ("no fast paths", ["PG_VIT_FASTG=0", "PG_VIT_FASTR=0"]), ("rows fast only", ["PG_VIT_FASTG=0"]),
+                ("column fast only", ["PG_VIT_FASTR=0"]), ("4 waves", ["PG_VIT_NW=4"]), ("timeline", ["PG_VIT_TIMELINE"]),
+                ("timeline, 4 waves", ["PG_VIT_TIMELINE", "PG_VIT_NW=4"])] + [("exp %d" % m, ["PG_VIT_EXP=%d" % m]) for m in (8, 16)]
     if len(sys.argv) > 1:
-        variants = [v for v in variants if v[0].split()[0] in sys.argv[1:] or v[0] in sys.argv[1:]]
+        variants = [v for v in variants if v[0] in sys.argv[1:]]
     try:
         for name, defs in variants:
             if defs is not None:
@@ -57,7 +59,7 @@ def main():
                 if not line.startswith("{"):
                     continue
                 d = json.loads(line)
-                print("%-10s H = %2d: %7.1f ns per column" % (name, d["H"], d["ns_per_column"]), flush=True)
+                print("%-18s H = %2d: %7.1f ns per column" % (name, d["H"], d["ns_per_column"]), flush=True)
                 if d["steps"]:
                     tot = sum(d["seg"])
                     for s, v in zip(SEG, d["seg"]):
