@@ -143,7 +143,7 @@ DEVI Cand better(Cand a, Cand b) {
 #define PG_VIT_FASTG 1
 #endif
 #ifndef PG_VIT_FASTR
-#define PG_VIT_FASTR 1
+#define PG_VIT_FASTR 0
 #endif
 template <int K>
 struct VitCfg {
