@@ -4,7 +4,9 @@ usage: python tools/soak_parity.py [n_panels] [seed0]   (80 panels: about two mi
 SOAK_TRI=1: only all-biallelic H = 64 panels in fused mode (triangle storage, k_sweep_lean2), from 1 variant up.
 SOAK_X=1: only 16-path panels on k_sweep_small16[x] (PG_KERNELS=small[,nosmall2]): multiallelic and wide objects (6-12 alleles of
 which the sixteen paths carry up to nine), both sweep modes.
-SOAK_PERSIST=1: only all-biallelic H = 64 panels in chunked mode on the persistent phase-2 pair (PG_KERNELS=persist), even chunk sizes."""
+SOAK_PERSIST=1: only all-biallelic H = 64 panels in chunked mode on the persistent phase-2 pair (PG_KERNELS=persist), even chunk sizes.
+SOAK_LX2=1: only H = 64 panels with 3-5-allele objects in fused mode (triangle storage, phase 2 on k_sweep_leanx2 + k_bins_q; phase 1
+on k_sweep_leanx_tri or, PG_KERNELS=noleanx, the general kernel with triangle stores), from 1 variant up; the job's plan is checked."""
 import os, sys, time
 sys.path.insert(0, os.getcwd())
 import numpy as np
@@ -34,6 +36,10 @@ for it in range(n):
         H, wide = 64, False
         V = int(rng.choice([1, 2, 3, 5, 64, 65, 129, 257, int(rng.integers(6, 900)), int(rng.integers(6, 900))]))
         kw.update(multiallelic_frac=0.0)
+    if os.environ.get("SOAK_LX2") == "1":
+        H, wide = 64, False
+        V = int(rng.choice([1, 2, 3, 4, 5, 7, 15, 16, 17, 33, 48, 64, 65, 129, int(rng.integers(6, 900)), int(rng.integers(6, 900))]))
+        kw.update(multiallelic_frac=float(rng.choice([0.05, 0.2, 0.6, 1.0])))
     if os.environ.get("SOAK_X") == "1":
         H, wide = 16, False
         V = int(rng.choice([2, 3, 4, 5, 7, 9, 15, 16, 17, 64, 65, 129, int(rng.integers(6, 900)), int(rng.integers(6, 900))]))
@@ -56,6 +62,9 @@ for it in range(n):
     kern = str(rng.choice(["", "", "", "general", "generic", "prepwave", "small", "small,nosmall2", "fullcols", "nocls4"]))
     if os.environ.get("SOAK_TRI") == "1":
         kern = ""
+    if os.environ.get("SOAK_LX2") == "1":
+        os.environ["PG_SWEEP_MODE"] = mode = "fused"
+        kern = str(rng.choice(["", "", "noleanx"]))
     if os.environ.get("SOAK_X") == "1":
         kern = str(rng.choice(["small", "small", "small", "small,nosmall2", "small,prepwave"]))
     if kern:
@@ -67,7 +76,15 @@ for it in range(n):
         os.environ["PG_SWEEP_MODE"] = mode = "chunked"
         os.environ["PG_KERNELS"] = kern = "persist"
         os.environ["PG_CHUNK_COLS"] = str(int(rng.choice([2, 16, 64, 4096])))
-    res = hmm.genotype_contig(b, hmm.ProbabilityTable(*args), hmm.make_params(recomb, uniform, N))
+    if os.environ.get("SOAK_LX2") == "1":
+        job = hmm.Job([b], hmm.ProbabilityTable(*args), hmm.make_params(recomb, uniform, N))
+        if int(np.diff(b.allele_off.astype(np.int64)).max()) > 2:
+            assert "k_sweep_leanx2" in job.plan() and "k_bins_q" in job.plan(), job.plan()
+        job.run()
+        res = job.fetch(0)
+        job.close()
+    else:
+        res = hmm.genotype_contig(b, hmm.ProbabilityTable(*args), hmm.make_params(recomb, uniform, N))
     ref = orc.genotype_contig(b, orc.OracleTable(*args), orc.make_params(recomb, uniform, N))
     try:
         assert_parity(b, res, ref)
