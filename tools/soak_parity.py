@@ -40,6 +40,7 @@ for it in range(n):
         H, wide = 64, False
         V = int(rng.choice([1, 2, 3, 4, 5, 7, 15, 16, 17, 33, 48, 64, 65, 129, int(rng.integers(6, 900)), int(rng.integers(6, 900))]))
         kw.update(multiallelic_frac=float(rng.choice([0.05, 0.2, 0.6, 1.0])))
+        kw.pop("max_alleles", None); kw.pop("local_alts", None)
     if os.environ.get("SOAK_X") == "1":
         H, wide = 16, False
         V = int(rng.choice([2, 3, 4, 5, 7, 9, 15, 16, 17, 64, 65, 129, int(rng.integers(6, 900)), int(rng.integers(6, 900))]))
