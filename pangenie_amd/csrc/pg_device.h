@@ -241,6 +241,12 @@ struct DevContig {
     // posterior partials leave added up over the four waves, T = 64 entries per column and slot pair (PG_KERNELS=noleanx2: the
     // general kernel's triangle ring, T = 256)
     uint32_t  leanx2;
+    // 1 (round 6, 64-path chains of FUSED jobs on the general kernel whose objects include wide ones — more than PG_AMAX alleles on the
+    // selected paths): a wide column costs that column, not the job — its phase-2 role stores its own column P' / beta' in the
+    // variant's aux slot (8 HP^2 bytes, PG_REC_AUX) instead of forming posterior partials, and k_bins_wide forms the bins from
+    // that column and the stored partner (post_ab: what k_post does for every column of a chunked job).  PG_KERNELS=nowidef:
+    // such a job runs chunked, as before.
+    uint32_t  widef;
     // 1: every object of the chain is biallelic and H = HP = 16: the store-only phases run on k_sweep_small16 (four
     // half-chains per wave); the chain keeps its compact records (frec) next to the full ones
     // 2 (fused jobs, with cls4): phase 2 runs there too — partner columns prefetched into registers three steps ahead, the four

@@ -2031,6 +2031,20 @@ DEVI void forward_body(const DevContig& dc, ChainShared<HP, R>& sh, uint32_t C, 
         gdouble2* dst = (gdouble2*)(wr + (size_t)c * colsz) + (size_t)(p.i0 >> 1) * HP + p.j;
         dst[(size_t)(k >> 1) * HP] = v2f64{a, b};
     };
+    // DevContig::widef (phase 2 of 64-path chains of fused jobs): is the column of record `rec` a wide one with an aux slot?
+    const bool widef = PHASE == 2 && HP == 64 && __builtin_amdgcn_readfirstlane((int)dc.widef) != 0;
+    auto widef_col = [&](const unsigned char* rec, const RecInfo& ri) -> bool {
+        if constexpr (PHASE == 2 && HP == 64)
+            return __builtin_amdgcn_readfirstlane((int)(widef && ri.em.wide != nullptr && *(const uint32_t*)(rec + PG_REC_AUX) != PG_WIDE_NONE)) != 0;
+        else return false;
+    };
+    auto aux_of = [&](const unsigned char* rec) -> uint32_t { return (uint32_t)__builtin_amdgcn_readfirstlane((int)*(const uint32_t*)(rec + PG_REC_AUX)); };
+    uint32_t prev_ax = PG_WIDE_NONE;   // aux slot of the column the last step formed, if that was a wide one (flag_uniform)
+    auto store_aux = [&](uint32_t ax, const double (&v)[R]) {   // the column in the stored columns' row-pair layout
+        gdouble2* dst = (gdouble2*)(GAS unsigned char*)(dc.aux + (size_t)ax * 16u) + (size_t)(p.i0 >> 1) * HP + p.j;
+#pragma unroll
+        for (int k = 0; k < R; k += 2) dst[(size_t)(k >> 1) * HP] = v2f64{v[k], v[k + 1]};
+    };
     auto load_col = [&](uint32_t c, double (&v)[R]) {
         if (c >= C) return;
         gcdouble2* src = (gcdouble2*)(c + 1 == lo ? resume : (gcdouble*)(fwd + (size_t)c * colsz)) + (size_t)(p.i0 >> 1) * HP + p.j;
@@ -2091,9 +2105,12 @@ DEVI void forward_body(const DevContig& dc, ChainShared<HP, R>& sh, uint32_t C, 
             if constexpr (RING) {
                 double bt[R];
                 ring_get(0, bt);
+                if (widef_col(sh.rec[0], prev)) { prev_ax = aux_of(sh.rec[0]); store_aux(prev_ax, pz); }   // (DevContig::widef: see the step)
+                else {
 #pragma unroll
-                for (int k = 0; k < R; ++k) bt[k] *= P0;
-                posterior<HP, R>(sh, part_out, part_slots, prev, 0, p, bt);
+                    for (int k = 0; k < R; ++k) bt[k] *= P0;
+                    posterior<HP, R>(sh, part_out, part_slots, prev, 0, p, bt);
+                }
             } else {
 #pragma unroll
                 for (int k = 0; k < R; ++k) vA[k] *= P0;
@@ -2134,6 +2151,15 @@ DEVI void forward_body(const DevContig& dc, ChainShared<HP, R>& sh, uint32_t C, 
 #pragma unroll
             for (int k = 0; k < R; ++k) xu[k] = (p.j < H && p.i0 + k < H) ? unif : 0.0;
             store_col(cprev, xu);
+        }
+        if constexpr (PHASE == 2 && HP == 64) {
+            // (DevContig::widef: a wide column's slot holds the column itself — the uniform column then, as a chunk's scratch would)
+            if (prev_ax != PG_WIDE_NONE && cprev >= lo) {
+                double xu[R];
+#pragma unroll
+                for (int k = 0; k < R; ++k) xu[k] = (p.j < H && p.i0 + k < H) ? unif : 0.0;
+                store_aux(prev_ax, xu);
+            }
         }
         if (p.tid == 0) fallback[cprev] = 1;
     };
@@ -2193,6 +2219,16 @@ DEVI void forward_body(const DevContig& dc, ChainShared<HP, R>& sh, uint32_t C, 
         __builtin_amdgcn_sched_barrier(0);
         double bt[RING ? R : 1];
         if constexpr (RING) ring_get(t, bt);
+        // DevContig::widef, a WIDE column (uniform): no partials — the column P'_t itself goes to the variant's aux slot, k_bins_wide
+        // forms the bins from it and the stored partner.  The states below multiply bt by P': with bt = 1 they leave P' there, exactly.
+        const bool auxcol = RING && widef_col(rec, cur);
+        const uint32_t ax_t = auxcol ? aux_of(rec) : PG_WIDE_NONE;
+        if constexpr (RING) {
+            if (auxcol) {
+#pragma unroll
+                for (int k = 0; k < R; ++k) bt[k] = 1.0;
+            }
+        }
         const RecInfo nxt = decode_record<Cfg::UNI>(sh.rec[(t + 1) & 7u], p.j, p.i0, full, dc.wide);
         __builtin_amdgcn_sched_barrier(0);
         double part = 0.0;
@@ -2260,7 +2296,8 @@ DEVI void forward_body(const DevContig& dc, ChainShared<HP, R>& sh, uint32_t C, 
             // posterior of the column just formed (optimistic: if the column turns out to sum to
             // zero, the next step flags it and k_bins re-forms its bins from the uniform column)
             if constexpr (RING) {
-                posterior<HP, R>(sh, part_out, part_slots, cur, t, p, bt);
+                if (auxcol) store_aux(ax_t, bt);
+                else posterior<HP, R>(sh, part_out, part_slots, cur, t, p, bt);
             } else {
                 // register prefetch of the next beta' column: a whole step ahead of its use and
                 // AFTER the last read of the old one, so no vmcnt wait lands inside the recursion
@@ -2274,6 +2311,7 @@ DEVI void forward_body(const DevContig& dc, ChainShared<HP, R>& sh, uint32_t C, 
         }
         prev = cur;
         cur = nxt;
+        if constexpr (PHASE == 2 && HP == 64) prev_ax = ax_t;
         lds_barrier();  // B_t
     };
     const unsigned long long t_begin = prof ? __builtin_amdgcn_s_memtime() : 0;
@@ -2455,6 +2493,19 @@ DEVI void backward_body(const DevContig& dc, ChainShared<HP, R>& sh, uint32_t C,
             if (!Cfg::SHORT || k < kl) t = src[(size_t)(k >> 1) * HP];
             v[k] = t.x; v[k + 1] = t.y;
         }
+    };
+    // DevContig::widef: see forward_body
+    const bool widef = PHASE == 2 && HP == 64 && __builtin_amdgcn_readfirstlane((int)dc.widef) != 0;
+    auto widef_col = [&](const unsigned char* rec, const RecInfo& ri) -> bool {
+        if constexpr (PHASE == 2 && HP == 64)
+            return __builtin_amdgcn_readfirstlane((int)(widef && ri.em.wide != nullptr && *(const uint32_t*)(rec + PG_REC_AUX) != PG_WIDE_NONE)) != 0;
+        else return false;
+    };
+    auto store_aux = [&](const unsigned char* rec, const double (&v)[R]) {
+        const uint32_t ax = (uint32_t)__builtin_amdgcn_readfirstlane((int)*(const uint32_t*)(rec + PG_REC_AUX));
+        gdouble2* dst = (gdouble2*)(GAS unsigned char*)(dc.aux + (size_t)ax * 16u) + (size_t)(p.i0 >> 1) * HP + p.j;
+#pragma unroll
+        for (int k = 0; k < R; k += 2) dst[(size_t)(k >> 1) * HP] = v2f64{v[k], v[k + 1]};
     };
     auto load_col_tri = [&](gcdouble* col, double (&v)[R]) {  // see forward_body
 #pragma unroll
@@ -2753,6 +2804,7 @@ DEVI void backward_body(const DevContig& dc, ChainShared<HP, R>& sh, uint32_t C,
             }
             write_colsums<HP, R>(sh, (uint32_t)(t - 1) & 1u, p, part);
             if constexpr (STORE) { if (Cfg::NW == 1 || p.tid == 0) bsum[t] = Snew; }
+            else if (widef_col(rec0, nxt)) store_aux(rec0, y);   // (DevContig::widef, a wide column: beta'_t to its aux slot — see forward_body)
             else {
 #pragma unroll
                 for (int k = 0; k < R; ++k) vt[k] *= y[k];  // P'_t * beta'_t
@@ -5713,6 +5765,7 @@ DEVI void bins_unit(const DevContig& dc, uint32_t unit, double (&s_bins)[4][PG_A
     const unsigned char* rec = direct ? dc.vrec + (size_t)dc.col_variant[c] * dc.RB : dc.colrec + (size_t)c * dc.RB;
     const uint32_t v = *(const uint32_t*)(rec + PG_REC_VARIANT);
     const uint32_t nl = rec[PG_REC_NLOCAL];
+    if (dc.widef && nl > (uint32_t)PG_AMAX) return;      // a wide column of a DevContig::widef chain: k_bins_wide (its column is in the aux slot)
     const uint32_t T = dc.T, HP = dc.HP;
     const unsigned char* al = rec + PG_REC_ALLELES;
     if (lane < PG_AMAX * (PG_AMAX + 1) / 2) s_bins[wave][lane] = 0.0;
@@ -6638,7 +6691,7 @@ __global__ __launch_bounds__(256) void k_bins_wide(const DevContig* __restrict__
     __shared__ double s_wide[4][PG_WIDE_LDS_BINS];
     const DevContig& dc = contigs[blockIdx.y];
     const uint32_t C = *dc.n_cols;
-    if (!bins_x(dc, C) || !dc.wcols) return;   // (no object of this chain's index has more than PG_AMAX alleles)
+    if (!(bins_x(dc, C) || dc.widef) || !dc.wcols) return;   // (no object of this chain's index has more than PG_AMAX alleles)
     const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
     // one wave per entry of the chain's list of wide columns (k_records made it)
     const uint32_t id = blockIdx.x * 4u + wave;

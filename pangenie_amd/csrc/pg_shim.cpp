@@ -239,6 +239,7 @@ struct IndexHost {   // one index contig
     std::vector<uint32_t> auxidx;    // [V] aux slot offset / 16 of every variant with more than two alleles (smallx), PG_WIDE_NONE otherwise
     uint64_t aux_bytes = 0;
     uint32_t n_wide_cand = 0;        // variants with more than PG_AMAX alleles (each may be a wide column)
+    bool widef_cand = false, widef = false;   // 64-path chains on the general kernel with such variants: in a fused job a wide column costs that column (DevContig::widef)
     size_t o_auxidx = 0;
     uint32_t prep_fast = 0;  // 1: every object has exactly two alleles and <= 32 k-mers, H <= 64: k_prep_bi; 2: at least half of them (k_prep the rest)
     // The split path (pg_device.h, pg_split.h): 1 / 2 = the chains over this index contig are small / smallx chains whose
@@ -812,6 +813,8 @@ int upload_inputs(pg_job* job, const pg_contig_batch* batches, const std::vector
 //   nosmall2            phase 2 of the 16-path chains of fused jobs on the general kernel (k_sweep_small16 for phase 1 only)
 //   noleanx2            phase 2 of the 64-path triangle chains with multiallelic objects on the general kernel's triangle ring (per-thread
 //                       partials) instead of k_sweep_leanx2 — cross-check
+//   nowidef             a job with wide columns on 64-path chains of the general kernel runs chunked (as until round 6) instead of fused with
+//                       those columns through their aux slots + k_bins_wide (DevContig::widef) — cross-check
 //   persist             chunked jobs whose chains are all lean chains run phase 2 as the persistent pair k_sweep_lean<4> + k_post_loop
 //                       (one launch each, chunks handed over on the device) instead of one launch per chunk (k_sweep_lean<3> + k_post).
 //                       Opt-in: measured at par or behind on the whole-genome job (profiles/r06_persist.txt).  nopersist: the default, spelled out
@@ -819,7 +822,7 @@ int upload_inputs(pg_job* job, const pg_contig_batch* batches, const std::vector
 //                       taking the split path (pg_split.h)
 struct KernelChoice {
     bool general = false, generic = false, nolean2 = false, notri = false, nocls4 = false, prepwave = false, fullcols = false, nosmall2 = false, nosplit = false;
-    bool persist = false, noleanx2 = false;
+    bool persist = false, noleanx2 = false, nowidef = false;
     int leanx = -1, small = -1;   // -1: by the job, 0 / 1: forced
     std::string unknown;          // a token this list does not know
 };
@@ -837,6 +840,7 @@ KernelChoice kernel_choice() {
         else if (tok == "fullcols") k.fullcols = true; else if (tok == "nosmall2") k.nosmall2 = true;
         else if (tok == "nosplit") k.nosplit = true;
         else if (tok == "noleanx2") k.noleanx2 = true;
+        else if (tok == "nowidef") k.nowidef = true;
         else if (tok == "persist") k.persist = true; else if (tok == "nopersist") k.persist = false;
         else if (!tok.empty()) k.unknown = tok;   // (a typo would quietly test the default path against itself: job creation fails)
         tok.clear();
@@ -1039,6 +1043,20 @@ int job_build(int device, uint32_t n_index, const pg_contig_batch* batches, cons
             // PG_KERNELS=noleanx: the general kernel (cross-check)
             x.leanx = lean_ok && (x.HP == 128 || x.HP == 64) && !x.lean && maxA >= 1 && maxA <= PG_AMAX && x.V > 0 && kc.leanx != 0;
         }
+        if (x.HP == 64 && maxA > PG_AMAX && x.V > 0 && !kc.nowidef && !force_generic && params->run_genotyping && !params->run_phasing) {
+            // DevContig::widef: an aux slot of one column (8 HP^2 bytes) for every variant that may turn into a wide column
+            x.auxidx.assign(x.V, PG_WIDE_NONE);
+            uint64_t ao = 0;
+            for (uint32_t v = 0; v < x.V; ++v) {
+                const uint64_t A = b.allele_off[v + 1] - b.allele_off[v];
+                if (A <= PG_AMAX) continue;
+                x.auxidx[v] = (uint32_t)(ao / 16);
+                x.n_wide_cand += 1;
+                ao += (uint64_t)x.HP * x.HP * 8u;
+            }
+            if (ao / 16 < 0xFFFFFFF0ull) { x.aux_bytes = ao; x.widef_cand = true; }
+            else { x.auxidx.clear(); x.n_wide_cand = 0; }
+        }
     });
     for (uint32_t i = 0; i < n_index; ++i) {
         const IndexHost& x = job->index[i];
@@ -1066,7 +1084,7 @@ int job_build(int device, uint32_t n_index, const pg_contig_batch* batches, cons
             n_x_chains += job->index[sp.index].smallx ? 1 : 0;
         }
         const bool use = kc.small >= 0 ? kc.small == 1 : n_small_chains >= (n_x_chains ? 320u : 256u);
-        if (!use) for (auto& x : job->index) { x.small = false; x.smallx = false; x.aux_bytes = 0; }
+        if (!use) for (auto& x : job->index) { x.small = false; x.smallx = false; if (!x.widef_cand) x.aux_bytes = 0; }
     }
     // A WIDE column (more than PG_AMAX alleles on the selected paths) costs that column, not the job, on the kernels that
     // take it inside a fused phase 2 — k_sweep_small16x (its column goes to the aux slot, k_bins_wide forms the bins); a
@@ -1077,7 +1095,7 @@ int job_build(int device, uint32_t n_index, const pg_contig_batch* batches, cons
         //  that cannot take the split path — run_phasing, 2^32 bins — go chunked as before round 5 instead of failing such a chain
         //  with PG_DEVERR_WIDE_FUSED at run time.  PG_KERNELS=nosplit keeps the fused job: a cross-check switch.)
         const bool split_possible = kc.nosplit || (!params->run_phasing && params->run_genotyping && x.n_lik < 0xFFFFFFF0ull);
-        if (x.wide_bytes && !(x.smallx && !kc.nosmall2 && split_possible)) wide_candidates = true;
+        if (x.wide_bytes && !(x.smallx && !kc.nosmall2 && split_possible) && !x.widef_cand) wide_candidates = true;
     }
 
     // ---- sweep mode ------------------------------------------------------------------------
@@ -1099,7 +1117,8 @@ int job_build(int device, uint32_t n_index, const pg_contig_batch* batches, cons
         // with hundreds of chains is bound by HBM writes, where the general kernel measured faster (7.8 vs 8.9 ms on 128 chains
         // of 128 paths).  PG_KERNELS=leanx forces it there too.
         if (job->chunked) for (auto& x : job->index) { x.cls4 = false; x.aux_bytes = 0; }   // (chunked jobs form their posteriors in k_post)
-        if (kc.nosmall2) for (auto& x : job->index) x.aux_bytes = 0;
+        if (kc.nosmall2) for (auto& x : job->index) if (!x.widef_cand) x.aux_bytes = 0;
+        for (auto& x : job->index) x.widef = x.widef_cand && !job->chunked && x.aux_bytes != 0;
         if (!job->chunked) {
             if (kc.leanx != 1) for (auto& x : job->index) x.leanx = false;
         }
@@ -1270,8 +1289,8 @@ int job_build(int device, uint32_t n_index, const pg_contig_batch* batches, cons
         const bool x2 = x.smallx && !job->chunked && !kc.nosmall2;
         p.part = take(job->chunked || !geno ? 0 : (x2 ? (size_t)x.V * 32u + (size_t)x.part_slots * part_entries(x) * sizeof(double)
                                                       : (size_t)x.V * x.part_slots * part_entries(x) * sizeof(double)));
-        p.aux = take(x2 && geno ? x.aux_bytes : 0);
-        const size_t o_wlist = take(x2 && geno && x.wide_bytes && !x.split ? (size_t)x.n_wide_cand * 4 : 0);
+        p.aux = take((x2 || x.widef) && geno ? x.aux_bytes : 0);
+        const size_t o_wlist = take((x2 || x.widef) && geno && x.wide_bytes && !x.split ? (size_t)x.n_wide_cand * 4 : 0);
         plan_wlist[c] = o_wlist;
         // Viterbi: transition probabilities and one 2-byte backpointer per state and column
         p.vtq = take(params->run_phasing ? (size_t)x.V * 8 * sizeof(double) : 0);
@@ -1377,8 +1396,9 @@ int job_build(int device, uint32_t n_index, const pg_contig_batch* batches, cons
         d.vpair = A + p.vpair; d.xbuf = (double*)(A + p.xbuf);
         d.frec = (double*)(A + p.frec); d.lean = x.lean ? 1u : 0u; d.small = x.small ? ((!job->chunked && x.cls4 && !kc.nosmall2) ? 2u : 1u) : 0u; d.leanx = x.leanx ? 1u : 0u; d.cls4 = x.cls4 ? 1u : 0u;
         d.smallx = x.smallx ? ((!job->chunked && !kc.nosmall2) ? 2u : 1u) : 0u;
-        d.aux = A + p.aux; d.aux_idx = (d.smallx == 2u && x.aux_bytes) ? (const uint32_t*)(A + x.o_auxidx) : nullptr;
-        if (d.smallx == 2u && x.wide_bytes && x.n_wide_cand) {
+        d.widef = x.widef ? 1u : 0u;
+        d.aux = A + p.aux; d.aux_idx = ((d.smallx == 2u || x.widef) && x.aux_bytes) ? (const uint32_t*)(A + x.o_auxidx) : nullptr;
+        if ((d.smallx == 2u || x.widef) && x.wide_bytes && x.n_wide_cand) {
             // (split chains: the wide columns hang on the index alone — one list per index contig, made by k_index_cols)
             if (x.split) { d.wcols = (uint32_t*)(A + x.o_ixwl); d.n_wcols = (uint32_t*)(A + x.o_ixnw); }
             else { d.wcols = (uint32_t*)(A + plan_wlist[c]); d.n_wcols = (uint32_t*)(A + p.wcols); }
@@ -1428,6 +1448,7 @@ int job_build(int device, uint32_t n_index, const pg_contig_batch* batches, cons
         else {
         job->bins_which |= d.leanx2 ? 128u : (d.tri == 2u || d.cls4) ? 2u : ((d.T <= 64u && d.HP <= 32u && !job->chunked) ? 4u : 1u);   // (bit 7: k_bins_q)
         if (d.smallx == 2u) job->bins_which |= 8u | (x.wide_bytes ? 16u : 0u);   // k_bins_x, k_bins_wide (a chain left with one column: k_bins_thin, above)
+        if (x.widef && x.n_wide_cand) job->bins_which |= 16u;   // k_bins_wide for the wide columns of DevContig::widef chains
         }
         ch.d = d;
     }
@@ -1487,6 +1508,7 @@ int job_build(int device, uint32_t n_index, const pg_contig_batch* batches, cons
                          : std::string(gen) + (d.tri ? "<2> (triangle ring)" : "<2>");
                     bins = d.leanx2 ? "k_bins_q" : (d.tri == 2u || d.cls4) ? "k_bins_lean2" : d.smallx == 2u ? (wide ? "k_bins_x + k_bins_wide" : "k_bins_x")
                            : (d.T <= 64u && d.HP <= 32u) ? "k_bins_thin" : "k_bins";
+                    if (d.widef) { p2 += " (wide columns to their aux slots)"; bins += " + k_bins_wide"; }
                 }
             }
             char head[160];
