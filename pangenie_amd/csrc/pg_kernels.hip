@@ -6155,7 +6155,7 @@ __global__ __launch_bounds__(256) void k_bins_lean2(const DevContig* __restrict_
 #define PG_WIDE_LDS_N 16   // wide columns with at most this many local alleles gather their raw bins in LDS (136 doubles per wave)
 #define PG_WIDE_LDS_BINS (PG_WIDE_LDS_N * (PG_WIDE_LDS_N + 1) / 2)
 DEVI void post_ab(const DevContig& dc, uint32_t C, uint32_t c, const double* A, const double* B, uint32_t lane,
-                  double (&s_bins_row)[PG_AMAX * (PG_AMAX + 1) / 2], double* s_wide = nullptr);
+                  double (&s_bins_row)[PG_AMAX * (PG_AMAX + 1) / 2], double* s_wide = nullptr, uint32_t tri_ab = 0u);
 // one column (index idx inside the chunk: forward role first) by one wave
 // The same column for LEAN chains (64 paths, at most two local alleles, the variant's record read in place — every chain of the
 // whole-genome job).  post_ab spends a column as eight rounds of {issue eight 1 KB loads, wait, add up}: 34–46 us per column
@@ -6286,8 +6286,10 @@ DEVI void post_column(const DevContig& dc, uint32_t chunk, uint32_t idx, uint32_
 // s_wide (optional): PG_WIDE_LDS_BINS doubles of LDS of this wave's own — the raw bins of a wide column with at most
 // PG_WIDE_LDS_N local alleles are added up there instead of in `lik` (a dependent global read-modify-write per (row allele,
 // column allele) pair by one lane: ~45 of them in series cost a 16-path wide column more than everything else together)
+// tri_ab (64 paths): bit 0 / bit 1 = A / B is a column stored as its upper triangle (DevContig::tri: units of tri_unit_of, the
+// diagonal halved) — the partner of a wide column of a triangle chain (k_bins_wide); this function reads the upper triangle only anyway
 DEVI void post_ab(const DevContig& dc, uint32_t C, uint32_t c, const double* A, const double* B, uint32_t lane,
-                  double (&s_bins_row)[PG_AMAX * (PG_AMAX + 1) / 2], double* s_wide) {
+                  double (&s_bins_row)[PG_AMAX * (PG_AMAX + 1) / 2], double* s_wide, uint32_t tri_ab) {
     const uint32_t HP = dc.HP;
     const bool direct = compact_records_only(dc, C);  // (no column-order copy of the records: the variant's own)
     // (split chains, pg_split.h: only their WIDE columns come here — variant and allele count from the index's bins record, the
@@ -6355,7 +6357,14 @@ DEVI void post_ab(const DevContig& dc, uint32_t C, uint32_t c, const double* A, 
                 av[u] = v2f64{0.0, 0.0}; bv[u] = v2f64{0.0, 0.0};
                 if (ip < HP / 2 && j >= 2u * ip) {
                     const size_t e = (size_t)ip * HP + j;
-                    av[u] = A2[e]; bv[u] = B2[e];
+                    if (tri_ab == 0u) { av[u] = A2[e]; bv[u] = B2[e]; }
+                    else {
+                        const size_t et = tri_unit_of(ip, j);
+                        av[u] = A2[(tri_ab & 1u) ? et : e]; bv[u] = B2[(tri_ab & 2u) ? et : e];
+                        const double d0 = j == 2u * ip ? 2.0 : 1.0, d1 = j == 2u * ip + 1u ? 2.0 : 1.0;   // (the stored diagonal is halved)
+                        if (tri_ab & 1u) { av[u].x *= d0; av[u].y *= d1; }
+                        if (tri_ab & 2u) { bv[u].x *= d0; bv[u].y *= d1; }
+                    }
                 }
             }
 #pragma unroll
@@ -6701,10 +6710,11 @@ __global__ __launch_bounds__(256) void k_bins_wide(const DevContig* __restrict__
     const uint32_t ax = (uint32_t)__builtin_amdgcn_readfirstlane((int)*(const uint32_t*)(rec + PG_REC_AUX));
     const size_t colsz = (size_t)dc.HP * dc.HP;
     const double* mine = (const double*)(dc.aux + (size_t)ax * 16u);   // what this column's phase-2 role stored
-    const double* stored = dc.fwd + (size_t)c * colsz;                 // its partner, from phase 1
+    const double* stored = dc.fwd + (size_t)c * (dc.tri ? (size_t)dc.col_stride : colsz);   // its partner, from phase 1 (DevContig::widef chains with triangle storage: a triangle)
+    const uint32_t st = dc.tri ? 1u : 0u;
     // c >= mid: the forward role ran phase 2 (alpha' = its column, beta' = the stored one); below: the backward role
-    if (c >= C / 2) post_ab(dc, C, c, mine, stored, lane, s_bins[wave], s_wide[wave]);
-    else post_ab(dc, C, c, stored, mine, lane, s_bins[wave], s_wide[wave]);
+    if (c >= C / 2) post_ab(dc, C, c, mine, stored, lane, s_bins[wave], s_wide[wave], st << 1);
+    else post_ab(dc, C, c, stored, mine, lane, s_bins[wave], s_wide[wave], st);
 }
 
 #include "pg_split.h"   // the split path: index-level kernels, sample-level emissions and bins of the 16-path chains of fused jobs

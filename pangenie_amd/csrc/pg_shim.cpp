@@ -1278,7 +1278,8 @@ int job_build(int device, uint32_t n_index, const pg_contig_batch* batches, cons
         // column: half the sweep's HBM bytes and of the arena); PG_KERNELS=notri keeps full columns (cross-check)
         // (round 6: and the 64-path chains with multiallelic objects — every column narrow — whose phase 1 runs on the general
         //  kernel: it stores the same triangles, phase 2 reads them through its triangle ring: DevContig::tri == 1)
-        const bool tri_multi = !x.lean && !x.leanx && x.HP == 64 && x.H == 64 && !x.wide_bytes && x.pair_n > 2 && !force_generic && !kc.general;
+        // (DevContig::widef chains too: their wide columns leave phase 2 through aux slots, k_bins_wide reads the stored triangle)
+        const bool tri_multi = !x.lean && !x.leanx && x.HP == 64 && x.H == 64 && (!x.wide_bytes || x.widef) && x.pair_n > 2 && !force_generic && !kc.general;
         const bool tri = (x.lean || tri_multi) && !job->chunked && !kc.notri;
         tri_of_chain[c] = tri;
         const bool geno = params->run_genotyping != 0;  // (a phasing-only job has no sweep: no columns, no partials)
@@ -1432,14 +1433,14 @@ int job_build(int device, uint32_t n_index, const pg_contig_batch* batches, cons
         }
         d.tri = tri_of_chain[c] ? ((kc.nolean2 || !x.lean) ? 1u : 2u) : 0u;   // (PG_KERNELS=nolean2, and chains with multiallelic objects: phase 2 of triangle chains on the general kernel's triangle ring)
         d.col_stride = d.tri ? 2304u : x.HP * x.HP;
-        if (d.tri == 1u && !x.lean && x.HP == 64u && !kc.noleanx2 && !params->run_phasing) {   // phase 2 on k_sweep_leanx2
+        if (d.tri == 1u && !x.lean && x.HP == 64u && !kc.noleanx2 && !params->run_phasing && !x.widef) {   // phase 2 on k_sweep_leanx2 (no wide columns there)
             d.leanx2 = 1u; d.T = 64u; job->hp_mask |= 8192u;
         }
         if (d.tri) job->hp_mask |= 128u;
         if (d.tri && !x.lean) {
             // phase 1 of such chains: the lean-x step with triangle stores (DevContig::leanx == 2; it needs the column-order records
             // of the general kernel, which phase 2 reads too) — PG_KERNELS=noleanx: the general kernel with triangle stores
-            if (kc.leanx != 0) { d.leanx = 2u; job->hp_mask |= 4096u; }
+            if (kc.leanx != 0 && !x.widef) { d.leanx = 2u; job->hp_mask |= 4096u; }   // (wide columns: the general kernel's emissions)
             else job->hp_mask |= 2048u;
         }
         if (d.tri == 2u) job->hp_mask |= 256u;
