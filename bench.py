@@ -139,7 +139,7 @@ def _sweep_phase(name: str):
     import re
     if name.startswith("void k_sweep_lean2<") or name.startswith("k_sweep_leanx2("):  # phase 2 of triangle chains (biallelic / with multiallelic objects)
         return 2
-    if name.startswith("k_sweep_leanx_tri(") or name.startswith("k_sweep_tri1("):      # their phase 1 (not templates: no "void", no <PHASE>)
+    if name.startswith("k_sweep_leanx_tri(") or name.startswith("k_sweep_leanx_triw(") or name.startswith("k_sweep_tri1("):      # their phase 1 (not templates: no "void", no <PHASE>)
         return 1
     m = re.match(r"void k_sweep_lean<(\d), ", name) or re.match(r"void k_sweep_lean_tri<(\d), ", name) or \
         re.match(r"void k_sweep_leanx<(\d), ", name) or re.match(r"void k_sweep_small16x?<(\d)>", name) or \

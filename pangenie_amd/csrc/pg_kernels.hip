@@ -4199,7 +4199,7 @@ struct LxTri {
         if (!((skip >> q) & 1u)) *(gdouble2*)(col + off[q]) = v2f64{a * fa[q], b * fb[q]};
     }
 };
-template <int PHASE, int HP, bool TRI = false>
+template <int PHASE, int HP, bool TRI = false, bool WIDE = false>
 DEVI void leanx_forward(const DevContig& dc, LxShared<HP>& sh, uint32_t C, uint32_t chunk) {
     static_assert(!TRI || (PHASE == 1 && HP == 64), "triangle stores: phase 1 at 64 paths");
     using Cfg = LxCfg<HP>;
@@ -4272,11 +4272,35 @@ DEVI void leanx_forward(const DevContig& dc, LxShared<HP>& sh, uint32_t C, uint3
     };
     using I0 = std::integral_constant<int, 0>; using IH = std::integral_constant<int, R / 2>; using IR = std::integral_constant<int, R>;
 
+    // DevContig::widef (phase 1 of triangle chains whose objects include wide ones, round 6): the emissions of a WIDE column do not
+    // come from the record's 6 x 6 table (the LDS record's allele bytes are clamped table-row offsets) but from the column's side
+    // table, indexed by the raw local alleles of the column-order record in memory — a rare column pays two dependent loads
+    // (a kernel of its own, k_sweep_leanx_triw: with the branch in it the step of the chains WITHOUT wide columns ran 7 % slower)
+    auto wide_fix = [&](uint32_t rel, int64_t c, double (&ev)[R]) __attribute__((always_inline)) {
+        if constexpr (TRI && WIDE) {
+            if (c < 0 || c >= (int64_t)C) return;
+            const unsigned char* lrec = lx_rec<HP>(sh, rel);
+            const uint32_t nl = (uint32_t)__builtin_amdgcn_readfirstlane((int)lrec[PG_REC_NLOCAL]);
+            if (nl <= (uint32_t)PG_AMAX) return;
+            const uint32_t woff = (uint32_t)__builtin_amdgcn_readfirstlane((int)*(const uint32_t*)(lrec + PG_REC_WIDE_IDX));
+            const GAS double* Ew = (const GAS double*)(const GAS unsigned char*)(dc.wide + (size_t)woff * 16u);
+            const GAS unsigned char* al = (const GAS unsigned char*)dc.colrec + (size_t)c * Cfg::RB + PG_REC_ALLELES;
+            uint32_t aj = al[j];
+            aj = aj > nl ? nl : aj;
+#pragma unroll
+            for (int k = 0; k < R; ++k) {
+                uint32_t ai = al[i0 + (uint32_t)k];
+                ai = ai > nl ? nl : ai;
+                ev[k] = Ew[ai * (nl + 1u) + aj];
+            }
+        }
+    };
     ColScalars fsc{&sh.scal[0][0]};
     double x[R], e[R];
     {
         const LxAlleles<R> a0 = lx_alleles<HP>(sh, 0, j, i0);
         gather(I0{}, IR{}, lx_ecol<HP>(sh, 0, a0.col8), a0, e);
+        wide_fix(0, (int64_t)first - 1, e);
         double part = 0.0;
         if (lo == 0) {
             const double P0 = ldexp(1.0, PG_BIAS_F);
@@ -4302,6 +4326,7 @@ DEVI void leanx_forward(const DevContig& dc, LxShared<HP>& sh, uint32_t C, uint3
     {
         const LxAlleles<R> a1 = lx_alleles<HP>(sh, 1, j, i0);   // and its emissions (every step fetches those of the next)
         gather(I0{}, IR{}, lx_ecol<HP>(sh, 1, a1.col8), a1, e);
+        wide_fix(1, (int64_t)first, e);
     }
     double one = 1.0;
     asm volatile("" : "+v"(one));
@@ -4371,6 +4396,7 @@ DEVI void leanx_forward(const DevContig& dc, LxShared<HP>& sh, uint32_t C, uint3
             }
             else pprev = pk;
         });
+        wide_fix(n + 2u, (int64_t)t + 1, e);
         sh.psum[t & 1u][rg][j] = part;
         if (wave == 0) {  // (scalar branch)
             fsc.put(lane, t, m);
@@ -4394,7 +4420,7 @@ DEVI void leanx_forward(const DevContig& dc, LxShared<HP>& sh, uint32_t C, uint3
     }
 }
 
-template <int PHASE, int HP, bool TRI = false>
+template <int PHASE, int HP, bool TRI = false, bool WIDE = false>
 DEVI void leanx_backward(const DevContig& dc, LxShared<HP>& sh, uint32_t C, uint32_t chunk) {
     static_assert(!TRI || (PHASE == 1 && HP == 64), "triangle stores: phase 1 at 64 paths");
     using Cfg = LxCfg<HP>;
@@ -4454,6 +4480,29 @@ DEVI void leanx_backward(const DevContig& dc, LxShared<HP>& sh, uint32_t C, uint
     };
     using I0 = std::integral_constant<int, 0>; using IH = std::integral_constant<int, R / 2>; using IR = std::integral_constant<int, R>;
 
+    // DevContig::widef (phase 1 of triangle chains whose objects include wide ones, round 6): the emissions of a WIDE column do not
+    // come from the record's 6 x 6 table (the LDS record's allele bytes are clamped table-row offsets) but from the column's side
+    // table, indexed by the raw local alleles of the column-order record in memory — a rare column pays two dependent loads
+    // (a kernel of its own, k_sweep_leanx_triw: with the branch in it the step of the chains WITHOUT wide columns ran 7 % slower)
+    auto wide_fix = [&](uint32_t rel, int64_t c, double (&ev)[R]) __attribute__((always_inline)) {
+        if constexpr (TRI && WIDE) {
+            if (c < 0 || c >= (int64_t)C) return;
+            const unsigned char* lrec = lx_rec<HP>(sh, rel);
+            const uint32_t nl = (uint32_t)__builtin_amdgcn_readfirstlane((int)lrec[PG_REC_NLOCAL]);
+            if (nl <= (uint32_t)PG_AMAX) return;
+            const uint32_t woff = (uint32_t)__builtin_amdgcn_readfirstlane((int)*(const uint32_t*)(lrec + PG_REC_WIDE_IDX));
+            const GAS double* Ew = (const GAS double*)(const GAS unsigned char*)(dc.wide + (size_t)woff * 16u);
+            const GAS unsigned char* al = (const GAS unsigned char*)dc.colrec + (size_t)c * Cfg::RB + PG_REC_ALLELES;
+            uint32_t aj = al[j];
+            aj = aj > nl ? nl : aj;
+#pragma unroll
+            for (int k = 0; k < R; ++k) {
+                uint32_t ai = al[i0 + (uint32_t)k];
+                ai = ai > nl ? nl : ai;
+                ev[k] = Ew[ai * (nl + 1u) + aj];
+            }
+        }
+    };
     ColScalars bsc{&sh.scal[0][0]}, bsm{&sh.scal[1][0]};
     double w[R], e[R], Sy;
     {
@@ -4479,6 +4528,7 @@ DEVI void leanx_backward(const DevContig& dc, LxShared<HP>& sh, uint32_t C, uint
         }
         const LxAlleles<R> a0 = lx_alleles<HP>(sh, 0, j, i0);   // column t0+1: its emission goes into the first w
         gather(I0{}, IR{}, lx_ecol<HP>(sh, 0, a0.col8), a0, e);
+        wide_fix(0, t0 + 1, e);
         double part = 0.0;
 #pragma unroll
         for (int k = 0; k < R; ++k) { w[k] = y[k] * e[k]; part += w[k]; }
@@ -4488,6 +4538,7 @@ DEVI void leanx_backward(const DevContig& dc, LxShared<HP>& sh, uint32_t C, uint
     {
         const LxAlleles<R> a1 = lx_alleles<HP>(sh, 1, j, i0);   // emissions of column t0 (the first step's w); every step fetches the next
         gather(I0{}, IR{}, lx_ecol<HP>(sh, 1, a1.col8), a1, e);
+        wide_fix(1, t0, e);
     }
     double one = 1.0;   // (in a register for the whole sweep: the DPP form of v_fmac_f64 takes no constant)
     asm volatile("" : "+v"(one));
@@ -4560,11 +4611,13 @@ DEVI void leanx_backward(const DevContig& dc, LxShared<HP>& sh, uint32_t C, uint
             const LxAlleles<R> at = lx_alleles<HP>(sh, n + 1u, j, i0);
             double et[R];
             gather(I0{}, IR{}, lx_ecol<HP>(sh, n + 1u, at.col8), at, et);
+            wide_fix(n + 1u, t, et);
             part = 0.0;
 #pragma unroll
             for (int k = 0; k < R; ++k) { w[k] = unif * et[k]; part += w[k]; }
             Sy = 1.0;
         }
+        wide_fix(n + 2u, t - 1, e);
         sh.psum[(uint32_t)(t - 1) & 1u][rg][j] = part;
         if (wave == 2) { asm volatile("" ::: "memory"); bsm.put(lane, (uint64_t)t, Snew); }
         if (((uint64_t)t & 63u) == 0u) {
@@ -4994,11 +5047,21 @@ void k_sweep_leanx2(const DevContig* __restrict__ contigs) {
 __global__ __launch_bounds__((LxCfg<64>::T)) void k_sweep_leanx_tri(const DevContig* __restrict__ contigs) {
     __shared__ LxShared<64> sh;
     const DevContig& dc = contigs[blockIdx.x];
-    if (dc.leanx != 2u || dc.HP != 64u || !dc.tri) return;
+    if (dc.leanx != 2u || dc.HP != 64u || !dc.tri || dc.widef) return;
     const uint32_t C = (uint32_t)__builtin_amdgcn_readfirstlane((int)*dc.n_cols);
     if (C == 0) return;
     if (blockIdx.y == 0) leanx_forward<1, 64, true>(dc, sh, C, 0);
     else leanx_backward<1, 64, true>(dc, sh, C, 0);
+}
+// ... of such chains whose objects include WIDE ones (DevContig::widef): a wide column's emissions from its side table (wide_fix)
+__global__ __launch_bounds__((LxCfg<64>::T)) void k_sweep_leanx_triw(const DevContig* __restrict__ contigs) {
+    __shared__ LxShared<64> sh;
+    const DevContig& dc = contigs[blockIdx.x];
+    if (dc.leanx != 2u || dc.HP != 64u || !dc.tri || !dc.widef) return;
+    const uint32_t C = (uint32_t)__builtin_amdgcn_readfirstlane((int)*dc.n_cols);
+    if (C == 0) return;
+    if (blockIdx.y == 0) leanx_forward<1, 64, true, true>(dc, sh, C, 0);
+    else leanx_backward<1, 64, true, true>(dc, sh, C, 0);
 }
 template <int PHASE, int HP>
 __global__ __launch_bounds__((LxCfg<HP>::T)) void k_sweep_leanx(const DevContig* __restrict__ contigs, uint32_t chunk) {
@@ -6761,6 +6824,8 @@ static void launch_sweep(const DevContig* d_contigs, uint32_t n_contigs, uint32_
             hipLaunchKernelGGL(k_sweep_tri1, dim3(n_contigs, 2), dim3(ChainCfg<64, 16, sweep_has_loader<64, 1>()>::TT), 0, s, d_contigs);
         if (hp_mask & 4096u)   // bit 12: ... on the lean-x step (DevContig::leanx == 2)
             hipLaunchKernelGGL(k_sweep_leanx_tri, dim3(n_contigs, 2), dim3(LxCfg<64>::T), 0, s, d_contigs);
+        if (hp_mask & 16384u)  // bit 14: ... of chains with wide columns (DevContig::widef)
+            hipLaunchKernelGGL(k_sweep_leanx_triw, dim3(n_contigs, 2), dim3(LxCfg<64>::T), 0, s, d_contigs);
     }
     if (hp_mask & 8u) launch_one<128, 32, 1, false, PHASE>(d_contigs, n_contigs, chunk, s);
     if constexpr (PHASE == 2) {

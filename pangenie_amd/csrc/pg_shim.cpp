@@ -1440,7 +1440,7 @@ int job_build(int device, uint32_t n_index, const pg_contig_batch* batches, cons
         if (d.tri && !x.lean) {
             // phase 1 of such chains: the lean-x step with triangle stores (DevContig::leanx == 2; it needs the column-order records
             // of the general kernel, which phase 2 reads too) — PG_KERNELS=noleanx: the general kernel with triangle stores
-            if (kc.leanx != 0 && !x.widef) { d.leanx = 2u; job->hp_mask |= 4096u; }   // (wide columns: the general kernel's emissions)
+            if (kc.leanx != 0) { d.leanx = 2u; job->hp_mask |= x.widef ? 16384u : 4096u; }   // (DevContig::widef chains: k_sweep_leanx_triw — leanx_forward / _backward's wide_fix)
             else job->hp_mask |= 2048u;
         }
         if (d.tri == 2u) job->hp_mask |= 256u;
@@ -1495,7 +1495,7 @@ int job_build(int device, uint32_t n_index, const pg_contig_batch* batches, cons
                 prep = "index pass once (k_index_scan, k_compact); per run ";
                 prep += x.prep_fast == 1u ? "k_prep_bi" : (x.prep_fast == 2u ? "k_prep_bi + k_prep_m4 + k_prep" : "k_prep");
                 prep += " + k_records";
-                p1 = d.lean ? (d.tri ? "k_sweep_lean_tri<1>" : "k_sweep_lean<1>") : d.leanx == 2u ? "k_sweep_leanx_tri" : d.leanx ? "k_sweep_leanx<1>"
+                p1 = d.lean ? (d.tri ? "k_sweep_lean_tri<1>" : "k_sweep_lean<1>") : d.leanx == 2u ? (d.widef ? "k_sweep_leanx_triw" : "k_sweep_leanx_tri") : d.leanx ? "k_sweep_leanx<1>"
                      : d.small ? "k_sweep_small16<1>" : d.smallx ? "k_sweep_small16x<1>" : (d.tri ? "k_sweep_tri1" : std::string(gen) + "<1>");
                 if (job->chunked && job->persist) {
                     p2 = "k_sweep_lean<4> (one launch, all chunks) + k_post_loop";
