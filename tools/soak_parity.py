@@ -6,7 +6,9 @@ SOAK_X=1: only 16-path panels on k_sweep_small16[x] (PG_KERNELS=small[,nosmall2]
 which the sixteen paths carry up to nine), both sweep modes.
 SOAK_PERSIST=1: only all-biallelic H = 64 panels in chunked mode on the persistent phase-2 pair (PG_KERNELS=persist), even chunk sizes.
 SOAK_LX2=1: only H = 64 panels with 3-5-allele objects in fused mode (triangle storage, phase 2 on k_sweep_leanx2 + k_bins_q; phase 1
-on k_sweep_leanx_tri or, PG_KERNELS=noleanx, the general kernel with triangle stores), from 1 variant up; the job's plan is checked."""
+on k_sweep_leanx_tri or, PG_KERNELS=noleanx, the general kernel with triangle stores), from 1 variant up; the job's plan is checked.
+SOAK_WIDEF=1: only 41 ... 64-path panels with objects of 6 ... 69 alleles (wide columns) in fused mode (DevContig::widef: the job must stay
+fused; phase 1 on k_sweep_leanx_triw / k_sweep_tri1 / the general kernel, phase 2 through aux slots + k_bins_wide), from 1 variant up."""
 import os, sys, time
 sys.path.insert(0, os.getcwd())
 import numpy as np
@@ -41,6 +43,10 @@ for it in range(n):
         V = int(rng.choice([1, 2, 3, 4, 5, 7, 15, 16, 17, 33, 48, 64, 65, 129, int(rng.integers(6, 900)), int(rng.integers(6, 900))]))
         kw.update(multiallelic_frac=float(rng.choice([0.05, 0.2, 0.6, 1.0])))
         kw.pop("max_alleles", None); kw.pop("local_alts", None)
+    if os.environ.get("SOAK_WIDEF") == "1":
+        H, wide, K = int(rng.choice([64, 64, 64, 41, 50, 63])), True, 40
+        V = int(rng.choice([1, 2, 3, 4, 5, 7, 15, 16, 17, 33, 64, 65, 129, int(rng.integers(6, 900)), int(rng.integers(6, 900))]))
+        kw.update(max_alleles=int(rng.integers(6, 70)), local_alts=int(rng.integers(5, 60)), multiallelic_frac=float(rng.choice([0.2, 0.6, 1.0])))
     if os.environ.get("SOAK_X") == "1":
         H, wide = 16, False
         V = int(rng.choice([2, 3, 4, 5, 7, 9, 15, 16, 17, 64, 65, 129, int(rng.integers(6, 900)), int(rng.integers(6, 900))]))
@@ -66,6 +72,9 @@ for it in range(n):
     if os.environ.get("SOAK_LX2") == "1":
         os.environ["PG_SWEEP_MODE"] = mode = "fused"
         kern = str(rng.choice(["", "", "noleanx"]))
+    if os.environ.get("SOAK_WIDEF") == "1":
+        os.environ["PG_SWEEP_MODE"] = mode = "fused"
+        kern = str(rng.choice(["", "", "", "noleanx", "general", "prepwave", "notri"]))
     if os.environ.get("SOAK_X") == "1":
         kern = str(rng.choice(["small", "small", "small", "small,nosmall2", "small,prepwave"]))
     if kern:
@@ -77,9 +86,13 @@ for it in range(n):
         os.environ["PG_SWEEP_MODE"] = mode = "chunked"
         os.environ["PG_KERNELS"] = kern = "persist"
         os.environ["PG_CHUNK_COLS"] = str(int(rng.choice([2, 16, 64, 4096])))
-    if os.environ.get("SOAK_LX2") == "1":
+    if os.environ.get("SOAK_LX2") == "1" or os.environ.get("SOAK_WIDEF") == "1":
         job = hmm.Job([b], hmm.ProbabilityTable(*args), hmm.make_params(recomb, uniform, N))
-        if int(np.diff(b.allele_off.astype(np.int64)).max()) > 2:
+        if os.environ.get("SOAK_WIDEF") == "1":
+            assert job.sweep_mode()[0] == "fused", job.plan()
+            n_wide_f = sum(len(set(r)) > 5 for r in b.path_allele.reshape(b.n_variants, b.n_paths))
+            globals()["wide_cols_seen"] = globals().get("wide_cols_seen", 0) + n_wide_f
+        elif int(np.diff(b.allele_off.astype(np.int64)).max()) > 2:
             assert "k_sweep_leanx2" in job.plan() and "k_bins_q" in job.plan(), job.plan()
         job.run()
         res = job.fetch(0)
@@ -97,4 +110,4 @@ for it in range(n):
     if rm > 1e-8:
         print("note", it, f"{rm:.2e}", dict(H=H, V=V, K=K, reg=reg, recomb=recomb, uniform=uniform, N=N, mode=mode, wide=wide))
     worst = max(worst, rm)
-print(f"soak OK: {n} panels, worst relative error {worst:.3e}, {time.time() - t0:.0f} s")
+print(f"soak OK: {n} panels, worst relative error {worst:.3e}, {time.time() - t0:.0f} s" + (f", {globals().get('wide_cols_seen', 0)} wide columns" if os.environ.get("SOAK_WIDEF") == "1" else ""))
