@@ -28,7 +28,7 @@ def test_every_sweep_kernel_of_the_committed_profiles_has_a_phase():
     assert any("k_sweep_leanx<1" in n for n in seen) and any("k_sweep_lean2<" in n for n in seen)
     assert any("k_sweep_small16<1" in n for n in seen) and any("k_sweep_lean_tri<1" in n for n in seen)
     assert b._sweep_phase("k_post(DevContig const*, unsigned int)") is None
-    assert b._sweep_phase("k_sweep_leanx2(DevContig const*)") == 2 and b._sweep_phase("k_sweep_leanx_tri(DevContig const*)") == 1
+    assert b._sweep_phase("k_sweep_leanx2(DevContig const*)") == 2 and b._sweep_phase("k_sweep_leanx_tri(DevContig const*)") == 1 and b._sweep_phase("k_sweep_leanx_triw(DevContig const*)") == 1
     assert b._sweep_phase("void k_sweep<128, 32, 1, false, 3>(DevContig const*, unsigned int)") == 3
 
 

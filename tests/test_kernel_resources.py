@@ -20,6 +20,8 @@ KERNELS = {
     "_Z13k_sweep_lean2ILi16EEvPK9DevContig": (200, True),                 # triangle chains, phase 2
     "_Z14k_sweep_leanx2PK9DevContig": (300, True),                        # ... with multiallelic objects (round 6): the state loops (both allele-count variants) carry no scratch
     "_Z12k_sweep_leanILi1ELi16ELb0EEvPK9DevContigj": (100, False),        # the lone-chain lean step
+    "_Z17k_sweep_leanx_triPK9DevContig": (100, True),                     # phase 1 of 64-path triangle chains with multiallelic objects (the lean-x step)
+    "_Z18k_sweep_leanx_triwPK9DevContig": (100, True),                    # ... with wide columns (round 6: wide_fix — the rare branch may spill, the state loop must not)
     "_Z15k_sweep_small16ILi1EEvPK9DevContigPKjjjPd": (100, False),        # four half-chains per wave, phase 1
     "_Z15k_sweep_small16ILi2EEvPK9DevContigPKjjjPd": (100, False),        # ... phase 2
     "_Z16k_sweep_small16xILi1EEvPK9DevContigPKjjjPd": (100, False),       # the same step with table emissions (16 paths, multiallelic objects), phase 1
